@@ -1,0 +1,514 @@
+"""CPU restatement of the reference forward path (TEST INFRASTRUCTURE ONLY).
+
+Each function is an explicit-formula restatement of a
+reference module; citations are `file:line` relative to /root/reference/.
+All functions are pure: they take a `state_dict`-like mapping `sd` (key ->
+tensor, the reference's own key names) and float tensors,
+compute in the dtype of `x` (float32 or float64) on the CPU and mutate nothing.
+
+Not a product path: see oracle/__init__.py.
+"""
+import math
+
+import torch
+
+LN_EPS = 1e-5  # nn.LayerNorm / nn.GroupNorm / nn.BatchNorm2d default eps
+
+
+# --------------------------------------------------------------------------
+# primitives
+# --------------------------------------------------------------------------
+def _p(sd, key, like):
+    """Fetch a parameter as a CPU tensor of `like`'s dtype."""
+    t = sd[key]
+    if not torch.is_tensor(t):
+        t = torch.as_tensor(t)
+    return t.detach().to(device="cpu", dtype=like.dtype)
+
+
+def gelu(z):
+    """Exact erf GELU, `nn.GELU()` / `F.gelu` defaults (mlp_mixer.py:21, g_mlp.py:35)."""
+    return 0.5 * z * (1.0 + torch.erf(z * (1.0 / math.sqrt(2.0))))
+
+
+def layer_norm(x, gamma, beta, eps=LN_EPS):
+    """LayerNorm over the last axis, biased variance (mlp_mixer.py:10,13)."""
+    mu = x.mean(dim=-1, keepdim=True)
+    xc = x - mu
+    var = (xc * xc).mean(dim=-1, keepdim=True)
+    return xc * torch.rsqrt(var + eps) * gamma + beta
+
+
+def group_norm1(x, gamma, beta, eps=LN_EPS):
+    """GroupNorm(1, C) on NCHW: per-sample stats over (C,H,W), per-channel affine
+    (as_mlp.py:343-344)."""
+    n = x.shape[0]
+    flat = x.reshape(n, -1)
+    mu = flat.mean(dim=1).view(n, 1, 1, 1)
+    xc = x - mu
+    var = (xc * xc).reshape(n, -1).mean(dim=1).view(n, 1, 1, 1)
+    return xc * torch.rsqrt(var + eps) * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
+
+
+def batch_norm_eval(x, sd, prefix):
+    """BatchNorm2d in eval mode on NCHW (conv_mixer.py:20,27,31)."""
+    g = _p(sd, prefix + ".weight", x).view(1, -1, 1, 1)
+    b = _p(sd, prefix + ".bias", x).view(1, -1, 1, 1)
+    m = _p(sd, prefix + ".running_mean", x).view(1, -1, 1, 1)
+    v = _p(sd, prefix + ".running_var", x).view(1, -1, 1, 1)
+    return (x - m) * torch.rsqrt(v + LN_EPS) * g + b
+
+
+def _pair(v):
+    return (v, v) if not isinstance(v, (tuple, list)) else tuple(v)
+
+
+def patch_embed(x, w, b, padding=0):
+    """Conv2d(k = stride = patch) as a patch-gather GEMM; returns channel-last
+    (B, Hp, Wp, Cout).  mlp_mixer.py:58-60,68-71 (padding=0) and
+    conv_mixer.py:18 (padding = patch//2)."""
+    cout, cin, ph, pw = w.shape
+    if padding:
+        x = torch.nn.functional.pad(x, (padding, padding, padding, padding))
+    bsz, _, hh, ww = x.shape
+    hp, wp = (hh - ph) // ph + 1, (ww - pw) // pw + 1
+    x = x[:, :, : hp * ph, : wp * pw]
+    # k index = ci*ph*pw + i*pw + j, matching w.reshape(cout, -1)
+    pat = x.reshape(bsz, cin, hp, ph, wp, pw).permute(0, 2, 4, 1, 3, 5).reshape(bsz, hp, wp, cin * ph * pw)
+    out = pat @ w.reshape(cout, -1).t()
+    if b is not None:
+        out = out + b
+    return out
+
+
+def linear(x, w, b=None):
+    """nn.Linear: y = x W^T + b with W (out,in)."""
+    y = x @ w.t()
+    return y if b is None else y + b
+
+
+def token_linear(x, w, b):
+    """Conv1d(k=1) over the token axis of (B,S,C): y[b,t,c] = sum_s W[t,s] x[b,s,c] + b[t]
+    (mlp_mixer.py:34,37; g_mlp.py:14,20; res_mlp.py:46,54)."""
+    w2 = w.reshape(w.shape[0], w.shape[1])
+    return torch.einsum("ts,bsc->btc", w2, x) + b.view(1, -1, 1)
+
+
+def conv1x1(x, w, b=None):
+    """1x1 Conv2d on NCHW (as_mlp.py:11,13,41-44; conv_mixer.py:29)."""
+    w2 = w.reshape(w.shape[0], w.shape[1])
+    y = torch.einsum("oc,nchw->nohw", w2, x)
+    return y if b is None else y + b.view(1, -1, 1, 1)
+
+
+# --------------------------------------------------------------------------
+# MLP-Mixer  (mlp_mixer.py:6-76)
+# --------------------------------------------------------------------------
+def mixer_block(sd, x, pre):
+    """One Mixer block on (B,S,C) (mlp_mixer.py:36-39; Appendix E)."""
+    g, b = _p(sd, pre + "0.norm.weight", x), _p(sd, pre + "0.norm.bias", x)
+    xh = layer_norm(x, g, b)
+    h = gelu(token_linear(xh, _p(sd, pre + "0.fn.net.0.weight", x), _p(sd, pre + "0.fn.net.0.bias", x)))
+    x = x + token_linear(h, _p(sd, pre + "0.fn.net.3.weight", x), _p(sd, pre + "0.fn.net.3.bias", x))
+    g, b = _p(sd, pre + "1.norm.weight", x), _p(sd, pre + "1.norm.bias", x)
+    xh = layer_norm(x, g, b)
+    h = gelu(linear(xh, _p(sd, pre + "1.fn.net.0.weight", x), _p(sd, pre + "1.fn.net.0.bias", x)))
+    x = x + linear(h, _p(sd, pre + "1.fn.net.3.weight", x), _p(sd, pre + "1.fn.net.3.bias", x))
+    return x
+
+
+def _depth(sd, fmt):
+    i = 0
+    while (fmt % i) in sd:
+        i += 1
+    return i
+
+
+def mixer_forward(sd, x, hooks=None):
+    """MLPMixerForImageClassification.forward (mlp_mixer.py:67-76)."""
+    x = x.detach().cpu()
+    t = patch_embed(x, _p(sd, "patcher.0.weight", x), _p(sd, "patcher.0.bias", x))
+    bsz, hp, wp, c = t.shape
+    t = t.reshape(bsz, hp * wp, c)
+    for i in range(_depth(sd, "model.%d.0.norm.weight")):
+        t = mixer_block(sd, t, "model.%d." % i)
+        if hooks is not None:
+            hooks("model.%d" % i, t)
+    t = layer_norm(t, _p(sd, "active.weight", x), _p(sd, "active.bias", x))
+    t = t.mean(dim=1)
+    return linear(t, _p(sd, "mlp_head.0.weight", x), _p(sd, "mlp_head.0.bias", x))
+
+
+# --------------------------------------------------------------------------
+# gMLP  (g_mlp.py:10-81)
+# --------------------------------------------------------------------------
+def gmlp_block(sd, x, pre):
+    """gMLPBlock.forward with SpatialGatingUnit (g_mlp.py:17-22, 32-39)."""
+    xh = layer_norm(x, _p(sd, pre + "norm.weight", x), _p(sd, pre + "norm.bias", x))
+    h = gelu(linear(xh, _p(sd, pre + "channel_proj1.weight", x), _p(sd, pre + "channel_proj1.bias", x)))
+    f = h.shape[-1] // 2
+    u, v = h[..., :f], h[..., f:]
+    v = layer_norm(v, _p(sd, pre + "sgu.norm.weight", x), _p(sd, pre + "sgu.norm.bias", x))
+    v = token_linear(v, _p(sd, pre + "sgu.spatial_proj.weight", x), _p(sd, pre + "sgu.spatial_proj.bias", x))
+    y = linear(u * v, _p(sd, pre + "channel_proj2.weight", x), _p(sd, pre + "channel_proj2.bias", x))
+    return y + x
+
+
+def gmlp_forward(sd, x, hooks=None):
+    """gMLPForImageClassification.forward (g_mlp.py:73-81); no final norm."""
+    x = x.detach().cpu()
+    t = patch_embed(x, _p(sd, "patcher.0.weight", x), _p(sd, "patcher.0.bias", x))
+    bsz, hp, wp, c = t.shape
+    t = t.reshape(bsz, hp * wp, c)
+    for i in range(_depth(sd, "model.%d.norm.weight")):
+        t = gmlp_block(sd, t, "model.%d." % i)
+        if hooks is not None:
+            hooks("model.%d" % i, t)
+    t = t.mean(dim=1)
+    return linear(t, _p(sd, "mlp_head.0.weight", x), _p(sd, "mlp_head.0.bias", x))
+
+
+# --------------------------------------------------------------------------
+# ResMLP  (res_mlp.py:11-99)
+# --------------------------------------------------------------------------
+def resmlp_block(sd, x, pre):
+    """MLPblock.forward: the residual is taken on the affine'd tensor (res_mlp.py:52-57)."""
+    x1 = x * _p(sd, pre + "pre_affine.alpha", x) + _p(sd, pre + "pre_affine.beta", x)
+    x2 = x1 + _p(sd, pre + "gamma_1", x) * token_linear(
+        x1, _p(sd, pre + "token_mix.weight", x), _p(sd, pre + "token_mix.bias", x))
+    x3 = x2 * _p(sd, pre + "post_affine.alpha", x) + _p(sd, pre + "post_affine.beta", x)
+    h = gelu(linear(x3, _p(sd, pre + "ff.net.0.weight", x), _p(sd, pre + "ff.net.0.bias", x)))
+    y = linear(h, _p(sd, pre + "ff.net.3.weight", x), _p(sd, pre + "ff.net.3.bias", x))
+    return x3 + _p(sd, pre + "gamma_2", x) * y
+
+
+def resmlp_forward(sd, x, hooks=None):
+    """ResMLPForImageClassification.forward (res_mlp.py:91-99); `affine.*` is unused (:86)."""
+    x = x.detach().cpu()
+    t = patch_embed(x, _p(sd, "patcher.0.weight", x), _p(sd, "patcher.0.bias", x))
+    bsz, hp, wp, c = t.shape
+    t = t.reshape(bsz, hp * wp, c)
+    for i in range(_depth(sd, "model.%d.gamma_1")):
+        t = resmlp_block(sd, t, "model.%d." % i)
+        if hooks is not None:
+            hooks("model.%d" % i, t)
+    t = t.mean(dim=1)
+    return linear(t, _p(sd, "mlp_head.0.weight", x), _p(sd, "mlp_head.0.bias", x))
+
+
+# --------------------------------------------------------------------------
+# split attention (vip.py:37-57 == s2_mlp_v2.py:31-51)
+# --------------------------------------------------------------------------
+def split_attention(x1, x2, x3, m1, m2):
+    """SplitAttention.forward on three (B,H,W,C) tensors; mlp1/mlp2 are bias-free.
+    hat_a flat index = k*C + c (vip.py:52)."""
+    bsz, hh, ww, c = x1.shape
+    a = (x1 + x2 + x3).reshape(bsz, -1, c).sum(dim=1)            # (B,C)  vip.py:50
+    hat = linear(gelu(linear(a, m1)), m2).reshape(bsz, 3, c)     # vip.py:51-52
+    bar = torch.softmax(hat, dim=1)                              # vip.py:53
+    return (bar[:, 0].view(bsz, 1, 1, c) * x1 + bar[:, 1].view(bsz, 1, 1, c) * x2
+            + bar[:, 2].view(bsz, 1, 1, c) * x3)
+
+
+# --------------------------------------------------------------------------
+# ViP  (vip.py:59-171)
+# --------------------------------------------------------------------------
+def vip_permute_h(x, s):
+    """Rearrange('b h w (c s) -> b w c (h s)') (vip.py:69):
+    y[b,w,g,h*s+j] = x[b,h,w,g*s+j]."""
+    b, h, w, c = x.shape
+    g = c // s
+    return x.reshape(b, h, w, g, s).permute(0, 2, 3, 1, 4).reshape(b, w, g, h * s)
+
+
+def vip_unpermute_h(y, s):
+    """Rearrange('b w c (h s) -> b h w (c s)') (vip.py:71)."""
+    b, w, g, hs = y.shape
+    h = hs // s
+    return y.reshape(b, w, g, h, s).permute(0, 3, 1, 2, 4).reshape(b, h, w, g * s)
+
+
+def vip_permute_w(x, s):
+    """Rearrange('b h w (c s) -> b h c (w s)') (vip.py:74):
+    y[b,h,g,w*s+j] = x[b,h,w,g*s+j]."""
+    b, h, w, c = x.shape
+    g = c // s
+    return x.reshape(b, h, w, g, s).permute(0, 1, 3, 2, 4).reshape(b, h, g, w * s)
+
+
+def vip_unpermute_w(y, s):
+    """Rearrange('b h c (w s) -> b h w (c s)') (vip.py:76)."""
+    b, h, g, ws = y.shape
+    w = ws // s
+    return y.reshape(b, h, g, w, s).permute(0, 1, 3, 2, 4).reshape(b, h, w, g * s)
+
+
+def vip_block(sd, x, pre, segments, weighted):
+    """One (Weighted)Permutator block on (B,H,W,C) (vip.py:65-90 / 100-125)."""
+    p0 = pre + "0.fn.0."
+    xh = layer_norm(x, _p(sd, pre + "0.norm.weight", x), _p(sd, pre + "0.norm.bias", x))
+    zh = linear(vip_permute_h(xh, segments), _p(sd, p0 + "fns.0.1.weight", x), _p(sd, p0 + "fns.0.1.bias", x))
+    x_h = vip_unpermute_h(zh, segments)
+    zw = linear(vip_permute_w(xh, segments), _p(sd, p0 + "fns.1.1.weight", x), _p(sd, p0 + "fns.1.1.bias", x))
+    x_w = vip_unpermute_w(zw, segments)
+    x_c = linear(xh, _p(sd, p0 + "fns.2.weight", x), _p(sd, p0 + "fns.2.bias", x))
+    if weighted:
+        m = split_attention(x_h, x_w, x_c, _p(sd, p0 + "split_attention.mlp1.weight", x),
+                            _p(sd, p0 + "split_attention.mlp2.weight", x))
+    else:
+        m = x_h + x_w + x_c                                       # ParallelSum vip.py:16-22
+    x = x + linear(m, _p(sd, pre + "0.fn.1.weight", x), _p(sd, pre + "0.fn.1.bias", x))
+    xh = layer_norm(x, _p(sd, pre + "1.norm.weight", x), _p(sd, pre + "1.norm.bias", x))
+    h = gelu(linear(xh, _p(sd, pre + "1.fn.0.weight", x), _p(sd, pre + "1.fn.0.bias", x)))
+    return x + linear(h, _p(sd, pre + "1.fn.3.weight", x), _p(sd, pre + "1.fn.3.bias", x))
+
+
+def vip_forward(sd, x, segments, hooks=None):
+    """ViP.forward (vip.py:166-171); head = LN -> mean(h,w) -> Linear (vip.py:160-164)."""
+    x = x.detach().cpu()
+    weighted = "blocks.model.0.0.fn.0.split_attention.mlp1.weight" in sd
+    t = patch_embed(x, _p(sd, "patcher.0.weight", x), _p(sd, "patcher.0.bias", x))   # (B,H,W,C)
+    for i in range(_depth(sd, "blocks.model.%d.0.norm.weight")):
+        t = vip_block(sd, t, "blocks.model.%d." % i, segments, weighted)
+        if hooks is not None:
+            hooks("blocks.model.%d" % i, t)
+    t = layer_norm(t, _p(sd, "mlp_head.0.weight", x), _p(sd, "mlp_head.0.bias", x))
+    t = t.mean(dim=(1, 2))
+    return linear(t, _p(sd, "mlp_head.2.weight", x), _p(sd, "mlp_head.2.bias", x))
+
+
+# --------------------------------------------------------------------------
+# S2-MLP shifts  (s2_mlp_v2.py:15-29; s2_mlp_v1.py:19-25)
+# --------------------------------------------------------------------------
+def _shift_axis(x, axis, direction, mode):
+    """Shift one channel group of a (b, d1, d2, c') tensor by one along `axis`.
+
+    direction=+1 is the reference's `x[:,1:] = x[:,:n-1]`, -1 its `x[:,:n-1] = x[:,1:]`.
+    The reference assigns IN PLACE on overlapping views.  mode:
+      'shift'              -- the intended semantics (paper Algorithm 1, Jittor twin):
+                              +1: y[i] = x[i-1] (y[0] = x[0]);  -1: y[i] = x[i+1] (y[n-1] = x[n-1]).
+      'reference_inplace'  -- what the PyTorch reference deterministically computes with
+                              one CPU thread: +1 groups smear,
+                              y[i] = x[0] for all i;  -1 groups equal the clean shift.
+    """
+    n = x.shape[axis]
+    idx = torch.arange(n)
+    if direction < 0:
+        src = torch.clamp(idx + 1, max=n - 1)
+    elif mode == "shift":
+        src = torch.clamp(idx - 1, min=0)
+    elif mode == "reference_inplace":
+        src = torch.zeros_like(idx)
+    else:
+        raise ValueError("unknown S2 shift mode %r" % (mode,))
+    return x.index_select(axis, src)
+
+
+def _s2_groups(c):
+    """Channel group boundaries exactly as the slices of s2_mlp_v2.py:17-20."""
+    return [(0, c // 4), (c // 4, c // 2), (c // 2, c * 3 // 4), (3 * c // 4, c)]
+
+
+def spatial_shift1(x, mode="reference_inplace"):
+    """s2_mlp_v2.py:15-21 / s2_mlp_v1.py:19-25 (out of place): groups -> (dim1,+1),(dim1,-1),(dim2,+1),(dim2,-1)."""
+    c = x.shape[-1]
+    plan = [(1, +1), (1, -1), (2, +1), (2, -1)]
+    out = x.clone()
+    for (lo, hi), (axis, d) in zip(_s2_groups(c), plan):
+        if hi > lo:
+            out[..., lo:hi] = _shift_axis(x[..., lo:hi], axis, d, mode)
+    return out
+
+
+def spatial_shift2(x, mode="reference_inplace"):
+    """s2_mlp_v2.py:23-29: groups -> (dim2,+1),(dim2,-1),(dim1,+1),(dim1,-1)."""
+    c = x.shape[-1]
+    plan = [(2, +1), (2, -1), (1, +1), (1, -1)]
+    out = x.clone()
+    for (lo, hi), (axis, d) in zip(_s2_groups(c), plan):
+        if hi > lo:
+            out[..., lo:hi] = _shift_axis(x[..., lo:hi], axis, d, mode)
+    return out
+
+
+# --------------------------------------------------------------------------
+# S2-MLPv2  (s2_mlp_v2.py:53-132)
+# --------------------------------------------------------------------------
+def s2v2_block(sd, x, pre, mode):
+    """One S2Block layer on (B,H,W,C): S2Attention + MLP (s2_mlp_v2.py:60-69, 76-85)."""
+    c = x.shape[-1]
+    p0 = pre + "0.fn."
+    xh = layer_norm(x, _p(sd, pre + "0.norm.weight", x), _p(sd, pre + "0.norm.bias", x))
+    t = linear(xh, _p(sd, p0 + "mlp1.weight", x), _p(sd, p0 + "mlp1.bias", x))          # (B,H,W,3C)
+    x1 = spatial_shift1(t[..., :c], mode)
+    x2 = spatial_shift2(t[..., c:2 * c], mode)
+    x3 = t[..., 2 * c:]
+    a = split_attention(x1, x2, x3, _p(sd, p0 + "split_attention.mlp1.weight", x),
+                        _p(sd, p0 + "split_attention.mlp2.weight", x))
+    x = x + linear(a, _p(sd, p0 + "mlp2.weight", x), _p(sd, p0 + "mlp2.bias", x))
+    xh = layer_norm(x, _p(sd, pre + "1.norm.weight", x), _p(sd, pre + "1.norm.bias", x))
+    h = gelu(linear(xh, _p(sd, pre + "1.fn.0.weight", x), _p(sd, pre + "1.fn.0.bias", x)))
+    return x + linear(h, _p(sd, pre + "1.fn.3.weight", x), _p(sd, pre + "1.fn.3.bias", x))
+
+
+def _s2_stages(sd, x, block_fn, hooks):
+    t = x                                                       # NCHW into each stage conv
+    s = 0
+    while ("stages.%d.0.weight" % s) in sd:
+        t = patch_embed(t, _p(sd, "stages.%d.0.weight" % s, x), _p(sd, "stages.%d.0.bias" % s, x))  # -> NHWC
+        for i in range(_depth(sd, "stages.%d" % s + ".1.model.%d.0.norm.weight")):
+            t = block_fn(t, "stages.%d.1.model.%d." % (s, i))
+            if hooks is not None:
+                hooks("stages.%d.1.model.%d" % (s, i), t)
+        t = t.permute(0, 3, 1, 2)                               # back to NCHW (s2_mlp_v2.py:91)
+        s += 1
+    t = t.mean(dim=(2, 3))                                      # Reduce('b c h w -> b c','mean') :125
+    return linear(t, _p(sd, "mlp_head.1.weight", x), _p(sd, "mlp_head.1.bias", x))
+
+
+def s2mlpv2_forward(sd, x, mode="reference_inplace", hooks=None):
+    """S2MLPv2.forward (s2_mlp_v2.py:129-132); no final LayerNorm."""
+    x = x.detach().cpu()
+    return _s2_stages(sd, x, lambda t, pre: s2v2_block(sd, t, pre, mode), hooks)
+
+
+# --------------------------------------------------------------------------
+# S2-MLPv1  (s2_mlp_v1.py:15-93)
+# --------------------------------------------------------------------------
+def s2v1_block(sd, x, pre, mode):
+    """Linear -> GELU -> Spatial_Shift -> Linear, then MLP (s2_mlp_v1.py:33-46)."""
+    xh = layer_norm(x, _p(sd, pre + "0.norm.weight", x), _p(sd, pre + "0.norm.bias", x))
+    t = gelu(linear(xh, _p(sd, pre + "0.fn.0.weight", x), _p(sd, pre + "0.fn.0.bias", x)))
+    t = spatial_shift1(t, mode)
+    x = x + linear(t, _p(sd, pre + "0.fn.3.weight", x), _p(sd, pre + "0.fn.3.bias", x))
+    xh = layer_norm(x, _p(sd, pre + "1.norm.weight", x), _p(sd, pre + "1.norm.bias", x))
+    h = gelu(linear(xh, _p(sd, pre + "1.fn.0.weight", x), _p(sd, pre + "1.fn.0.bias", x)))
+    return x + linear(h, _p(sd, pre + "1.fn.3.weight", x), _p(sd, pre + "1.fn.3.bias", x))
+
+
+def s2mlpv1_forward(sd, x, mode="reference_inplace", hooks=None):
+    """S2MLPv1.forward (s2_mlp_v1.py:90-93)."""
+    x = x.detach().cpu()
+    return _s2_stages(sd, x, lambda t, pre: s2v1_block(sd, t, pre, mode), hooks)
+
+
+# --------------------------------------------------------------------------
+# AS-MLP  (as_mlp.py; utils/shift_cuda.py)
+# --------------------------------------------------------------------------
+def axial_shift_nchw(x, kernel_size, dim):
+    """The `Shift` op's forward kernel formula (shift_cuda.py:44-72, group :119):
+    group = ceil(C/k); g = c // group; s = k//2 - g;
+    out[n,c,h,w] = in[n,c,h+s,w] (dim 2) or in[n,c,h,w+s] (dim 3), zero out of range.
+    kernel_size == 1 is the identity (shift_cuda.py:188-189)."""
+    assert dim in (2, 3)
+    assert kernel_size % 2 == 1
+    if kernel_size == 1:
+        return x
+    n, c, h, w = x.shape
+    group = int(math.ceil(c / kernel_size))
+    out = torch.zeros_like(x)
+    for g in range((c + group - 1) // group):
+        lo, hi = g * group, min(c, (g + 1) * group)
+        s = kernel_size // 2 - g
+        length = h if dim == 2 else w
+        # destination index i reads source i+s, valid when 0 <= i+s < length
+        d0, d1 = max(0, -s), min(length, length - s)
+        if d1 <= d0:
+            continue
+        if dim == 2:
+            out[:, lo:hi, d0:d1, :] = x[:, lo:hi, d0 + s:d1 + s, :]
+        else:
+            out[:, lo:hi, :, d0:d1] = x[:, lo:hi, :, d0 + s:d1 + s]
+    return out
+
+
+def asmlp_axial_shift(sd, x, pre, shift_size):
+    """AxialShift.forward (as_mlp.py:55-95)."""
+    t = conv1x1(x, _p(sd, pre + "conv1.weight", x), _opt(sd, pre + "conv1.bias", x))
+    t = gelu(group_norm1(t, _p(sd, pre + "norm1.weight", x), _p(sd, pre + "norm1.bias", x)))
+    lr = axial_shift_nchw(t, shift_size, 3)                      # shift_dim3 :81
+    td = axial_shift_nchw(t, shift_size, 2)                      # shift_dim2 :82
+    lr = gelu(conv1x1(lr, _p(sd, pre + "conv2_1.weight", x), _opt(sd, pre + "conv2_1.bias", x)))
+    td = gelu(conv1x1(td, _p(sd, pre + "conv2_2.weight", x), _opt(sd, pre + "conv2_2.bias", x)))
+    t = group_norm1(lr + td, _p(sd, pre + "norm2.weight", x), _p(sd, pre + "norm2.bias", x))
+    return conv1x1(t, _p(sd, pre + "conv3.weight", x), _opt(sd, pre + "conv3.bias", x))
+
+
+def _opt(sd, key, like):
+    return _p(sd, key, like) if key in sd else None
+
+
+def asmlp_block(sd, x, pre, shift_size):
+    """AxialShiftedBlock.forward in eval mode: DropPath is the identity (as_mlp.py:149-162)."""
+    t = group_norm1(x, _p(sd, pre + "norm1.weight", x), _p(sd, pre + "norm1.bias", x))
+    x = x + asmlp_axial_shift(sd, t, pre + "axial_shift.", shift_size)
+    t = group_norm1(x, _p(sd, pre + "norm2.weight", x), _p(sd, pre + "norm2.bias", x))
+    h = gelu(conv1x1(t, _p(sd, pre + "mlp.fc1.weight", x), _p(sd, pre + "mlp.fc1.bias", x)))
+    return x + conv1x1(h, _p(sd, pre + "mlp.fc2.weight", x), _p(sd, pre + "mlp.fc2.bias", x))
+
+
+def asmlp_patch_merging(sd, x, pre):
+    """PatchMerging.forward (as_mlp.py:197-216): order (0,0),(1,0),(0,1),(1,1) on (h,w) parity."""
+    x0 = x[:, :, 0::2, 0::2]
+    x1 = x[:, :, 1::2, 0::2]
+    x2 = x[:, :, 0::2, 1::2]
+    x3 = x[:, :, 1::2, 1::2]
+    t = torch.cat([x0, x1, x2, x3], dim=1)
+    t = group_norm1(t, _p(sd, pre + "norm.weight", x), _p(sd, pre + "norm.bias", x))
+    return conv1x1(t, _p(sd, pre + "reduction.weight", x), None)
+
+
+def asmlp_forward(sd, x, shift_size=5, hooks=None):
+    """AS_MLP.forward (as_mlp.py:428-443), eval mode, NCHW throughout."""
+    x = x.detach().cpu()
+    t = patch_embed(x, _p(sd, "patch_embed.proj.weight", x), _p(sd, "patch_embed.proj.bias", x))
+    t = t.permute(0, 3, 1, 2)
+    if "patch_embed.norm.weight" in sd:
+        t = group_norm1(t, _p(sd, "patch_embed.norm.weight", x), _p(sd, "patch_embed.norm.bias", x))
+    layer = 0
+    while ("layers.%d.blocks.0.norm1.weight" % layer) in sd:
+        for i in range(_depth(sd, "layers.%d" % layer + ".blocks.%d.norm1.weight")):
+            t = asmlp_block(sd, t, "layers.%d.blocks.%d." % (layer, i), shift_size)
+            if hooks is not None:
+                hooks("layers.%d.blocks.%d" % (layer, i), t)
+        if ("layers.%d.downsample.reduction.weight" % layer) in sd:
+            t = asmlp_patch_merging(sd, t, "layers.%d.downsample." % layer)
+        layer += 1
+    t = group_norm1(t, _p(sd, "norm.weight", x), _p(sd, "norm.bias", x))
+    t = t.mean(dim=(2, 3))
+    return linear(t, _p(sd, "head.weight", x), _p(sd, "head.bias", x))
+
+
+# --------------------------------------------------------------------------
+# ConvMixer  (conv_mixer.py:13-45)
+# --------------------------------------------------------------------------
+def depthwise_conv_same(x, w, b):
+    """Depthwise k x k conv, padding='same' (odd k -> (k-1)/2 each side) (conv_mixer.py:25):
+    out[n,c,y,x] = b[c] + sum_{dy,dx} w[c,0,dy,dx] * in[n,c,y+dy-p,x+dx-p]."""
+    k = w.shape[-1]
+    p = (k - 1) // 2
+    n, c, h, ww = x.shape
+    xp = torch.nn.functional.pad(x, (p, k - 1 - p, p, k - 1 - p))
+    out = torch.zeros_like(x)
+    for dy in range(k):
+        for dx in range(k):
+            out += w[:, 0, dy, dx].view(1, c, 1, 1) * xp[:, :, dy:dy + h, dx:dx + ww]
+    return out + b.view(1, c, 1, 1)
+
+
+def convmixer_forward(sd, x, hooks=None):
+    """ConvMixer.forward in eval mode: GELU *then* BN (conv_mixer.py:17-21, 23-32, 35-45)."""
+    x = x.detach().cpu()
+    w = _p(sd, "embedding.0.weight", x)
+    t = patch_embed(x, w, _p(sd, "embedding.0.bias", x), padding=w.shape[-1] // 2).permute(0, 3, 1, 2)
+    t = batch_norm_eval(gelu(t), sd, "embedding.2")
+    for i in range(_depth(sd, "blocks.%d.0.fn.0.weight")):
+        pre = "blocks.%d." % i
+        d = depthwise_conv_same(t, _p(sd, pre + "0.fn.0.weight", x), _p(sd, pre + "0.fn.0.bias", x))
+        t = t + batch_norm_eval(gelu(d), sd, pre + "0.fn.2")     # Residual :5-11
+        t = conv1x1(t, _p(sd, pre + "1.weight", x), _p(sd, pre + "1.bias", x))
+        t = batch_norm_eval(gelu(t), sd, pre + "3")
+        if hooks is not None:
+            hooks("blocks.%d" % i, t)
+    t = t.mean(dim=(2, 3))
+    return linear(t, _p(sd, "classifier.2.weight", x), _p(sd, "classifier.2.bias", x))

@@ -1,0 +1,393 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by running THE REFERENCE ITSELF.
+
+Runs ONLY in the authoring container (needs /root/reference); never on the GPU box.
+The reference is imported read-only through the shim of SURVEY.md section 8c:
+  * bare `models_pytorch` package object (its __init__ needs cupy/timm/torchvision),
+  * stub `cupy` (only `_util.memoize` is touched at import time, shift_cuda.py:23),
+  * stub `timm.models.layers` (DropPath = identity in eval, to_2tuple, trunc_normal_),
+  * `Shift.forward` re-pointed at the reference's own `torch_shift` (shift_cuda.py:195-205)
+    because `_shift_cuda` raises NotImplementedError on CPU (shift_cuda.py:170-173).
+Nothing from the reference's source text is written to the repo: fixtures hold inputs,
+weights (tiny configs only) and the reference's outputs.
+
+Usage:  python tests/golden/make_golden.py [--only tiny|real|ops|manifest] [--check]
+"""
+import argparse
+import importlib
+import inspect
+import json
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+import oracle  # noqa: E402
+from oracle.portable_init import portable_input, portable_state_dict  # noqa: E402
+
+
+# ---------------------------------------------------------------- reference shim
+def load_reference():
+    pkg = types.ModuleType("models_pytorch")
+    pkg.__path__ = [os.path.join(REF, "models_pytorch")]
+    sys.modules["models_pytorch"] = pkg
+    cupy = types.ModuleType("cupy")
+    cupy._util = types.SimpleNamespace(memoize=lambda **kw: (lambda f: f))
+    cupy.ndarray = type("ndarray", (), {})          # einops probes `cupy.ndarray` if cupy is in sys.modules
+    sys.modules["cupy"] = cupy
+    timm = types.ModuleType("timm")
+    tm = types.ModuleType("timm.models")
+    tl = types.ModuleType("timm.models.layers")
+
+    class DropPath(torch.nn.Module):
+        def __init__(self, p=0.0):
+            super().__init__()
+            self.p = p
+
+        def forward(self, x):
+            assert not self.training
+            return x
+
+    tl.DropPath = DropPath
+    tl.to_2tuple = lambda v: v if isinstance(v, (tuple, list)) else (v, v)
+    tl.trunc_normal_ = torch.nn.init.trunc_normal_
+    sys.modules["timm"], sys.modules["timm.models"], sys.modules["timm.models.layers"] = timm, tm, tl
+    mods = {}
+    for name in ("mlp_mixer", "g_mlp", "res_mlp", "vip", "s2_mlp_v1", "s2_mlp_v2", "conv_mixer", "as_mlp"):
+        mods[name] = importlib.import_module("models_pytorch." + name)
+    sc = importlib.import_module("models_pytorch.utils.shift_cuda")
+    sc.Shift.forward = lambda self, x: x if self.kernel_size == 1 else sc.torch_shift(x, self.kernel_size, self.dim)
+    mods["shift_cuda"] = sc
+    return mods
+
+
+def np_sd(model):
+    return {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+
+
+def load_portable(model, seed):
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = portable_state_dict(shapes, seed=seed)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return sd
+
+
+def randomize_norm_stats(model, seed):
+    """Tiny configs use torch default init; make norm affines / BN stats / ResMLP scales non-trivial."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in list(model.named_parameters()) + list(model.named_buffers()):
+            leaf = name.rsplit(".", 1)[-1]
+            if leaf == "running_mean":
+                p.copy_(torch.empty_like(p).uniform_(-0.2, 0.2, generator=g))
+            elif leaf == "running_var":
+                p.copy_(torch.empty_like(p).uniform_(0.5, 1.5, generator=g))
+            elif leaf in ("gamma_1", "gamma_2"):
+                p.copy_(torch.empty_like(p).uniform_(0.05, 0.3, generator=g))
+            elif leaf in ("alpha",) or (leaf == "weight" and p.dim() == 1):
+                p.copy_(torch.empty_like(p).uniform_(0.8, 1.2, generator=g))
+            elif leaf in ("beta",) or (leaf == "bias" and name.rsplit(".", 2)[-2] in ("norm", "norm1", "norm2", "active")):
+                p.copy_(torch.empty_like(p).uniform_(-0.2, 0.2, generator=g))
+
+
+# ---------------------------------------------------------------- block pins
+def sample_pin(t):
+    """Strided sample + fp64 checksums of an activation (reference layout)."""
+    f = t.detach().double().reshape(-1)
+    return np.concatenate([[f.sum().item(), f.abs().sum().item()], f[::17][:4096].numpy()])
+
+
+def hook_pins(model, paths):
+    pins, handles = {}, []
+    for path in paths:
+        mod = model
+        for part in path.split("."):
+            mod = mod[int(part)] if part.isdigit() else getattr(mod, part)
+        handles.append(mod.register_forward_hook(lambda m, i, o, path=path: pins.__setitem__(path, sample_pin(o))))
+    return pins, handles
+
+
+# ---------------------------------------------------------------- configs
+def tiny_configs(ref):
+    mm, gm, rm, vp = ref["mlp_mixer"], ref["g_mlp"], ref["res_mlp"], ref["vip"]
+    s1, s2, cm, am = ref["s2_mlp_v1"], ref["s2_mlp_v2"], ref["conv_mixer"], ref["as_mlp"]
+    return {
+        "mixer": dict(ctor=mm.MLPMixerForImageClassification, kw=dict(d_model=32, depth=2, patch_size=8, image_size=32, num_classes=10), hw=(32, 32),
+                      pins=["model.0.0", "model.0.1", "model.1"], oracle=lambda sd, x, kw: oracle.mixer_forward(sd, x)),
+        "mixer_nonsquare": dict(ctor=mm.MLPMixerForImageClassification, kw=dict(d_model=32, depth=2, patch_size=(8, 4), image_size=32, num_classes=10), hw=(32, 32),
+                                pins=["model.1"], oracle=lambda sd, x, kw: oracle.mixer_forward(sd, x)),
+        "gmlp": dict(ctor=gm.gMLPForImageClassification, kw=dict(image_size=32, patch_size=8, d_model=32, d_ffn=64, depth=2, num_classes=10), hw=(32, 32),
+                     pins=["model.0", "model.1"], oracle=lambda sd, x, kw: oracle.gmlp_forward(sd, x)),
+        "resmlp": dict(ctor=rm.ResMLPForImageClassification, kw=dict(image_size=32, patch_size=8, d_model=32, depth=2, num_classes=10), hw=(32, 32),
+                       pins=["model.0", "model.1"], oracle=lambda sd, x, kw: oracle.resmlp_forward(sd, x)),
+        "vip_weighted": dict(ctor=vp.ViP, kw=dict(image_size=32, patch_size=8, d_model=32, depth=2, segments=8, num_classes=10, weighted=True), hw=(32, 32),
+                             pins=["blocks.model.0.0", "blocks.model.1"], oracle=lambda sd, x, kw: oracle.vip_forward(sd, x, kw["segments"])),
+        "vip_unweighted": dict(ctor=vp.ViP, kw=dict(image_size=32, patch_size=8, d_model=32, depth=2, segments=8, num_classes=10, weighted=False), hw=(32, 32),
+                               pins=["blocks.model.1"], oracle=lambda sd, x, kw: oracle.vip_forward(sd, x, kw["segments"])),
+        "vip_rect": dict(ctor=vp.ViP, kw=dict(image_size=(32, 48), patch_size=8, d_model=24, depth=1, segments=6, num_classes=10, expansion_factor=3), hw=(32, 48),
+                         pins=["blocks.model.0"], oracle=lambda sd, x, kw: oracle.vip_forward(sd, x, kw["segments"])),
+        "s2mlpv2": dict(ctor=s2.S2MLPv2, kw=dict(image_size=32, patch_size=[4, 2], d_model=[16, 32], depth=[1, 2], expansion_factor=[3, 3], num_classes=10), hw=(32, 32),
+                        pins=["stages.0.1.model.0", "stages.1.1.model.1"], one_thread=True,
+                        oracle=lambda sd, x, kw: oracle.s2mlpv2_forward(sd, x, mode="reference_inplace")),
+        "s2mlpv1": dict(ctor=s1.S2MLPv1, kw=dict(image_size=32, patch_size=[8], d_model=[32], depth=[2], expansion_factor=[4], num_classes=10), hw=(32, 32),
+                        pins=["stages.0.1.model.1"], one_thread=True,
+                        oracle=lambda sd, x, kw: oracle.s2mlpv1_forward(sd, x, mode="reference_inplace")),
+        "asmlp": dict(ctor=am.AS_MLP, kw=dict(img_size=64, patch_size=4, embed_dim=16, depths=[1, 1, 2, 1], shift_size=5, num_classes=10), hw=(64, 64),
+                      pins=["layers.0.blocks.0", "layers.2.blocks.1", "layers.2.blocks.1.axial_shift"],
+                      oracle=lambda sd, x, kw: oracle.asmlp_forward(sd, x, shift_size=kw["shift_size"])),
+        "asmlp_shift3": dict(ctor=am.AS_MLP, kw=dict(img_size=32, patch_size=4, embed_dim=10, depths=[1, 1], shift_size=3, num_classes=10), hw=(32, 32),
+                             pins=["layers.1.blocks.0"], oracle=lambda sd, x, kw: oracle.asmlp_forward(sd, x, shift_size=kw["shift_size"])),
+        "convmixer": dict(ctor=cm.ConvMixer, kw=dict(dim=32, depth=2, kernel_size=5, patch_size=4, n_classes=10), hw=(32, 32),
+                          pins=["blocks.0.0", "blocks.1.3"], oracle=lambda sd, x, kw: oracle.convmixer_forward(sd, x)),
+    }
+
+
+def real_configs(ref):
+    mm, gm, rm, vp = ref["mlp_mixer"], ref["g_mlp"], ref["res_mlp"], ref["vip"]
+    s2, cm, am = ref["s2_mlp_v2"], ref["conv_mixer"], ref["as_mlp"]
+    return {
+        # BASELINE.json configs[0]: Mixer-S/16, 224^2, bs=8, fp32 on CPU
+        "mixer_s16": dict(ctor=mm.MLPMixerForImageClassification, kw=dict(d_model=512, depth=8, patch_size=16, image_size=224), bs=8,
+                          oracle=lambda sd, x, kw: oracle.mixer_forward(sd, x)),
+        # configs[1]: Mixer-B/16
+        "mixer_b16": dict(ctor=mm.MLPMixerForImageClassification, kw=dict(d_model=768, depth=12, patch_size=16, image_size=224), bs=4,
+                          oracle=lambda sd, x, kw: oracle.mixer_forward(sd, x)),
+        # configs[2]
+        "gmlp_s": dict(ctor=gm.gMLPForImageClassification, kw=dict(image_size=224), bs=2, oracle=lambda sd, x, kw: oracle.gmlp_forward(sd, x)),
+        "resmlp_24": dict(ctor=rm.ResMLPForImageClassification, kw=dict(depth=24), bs=2, oracle=lambda sd, x, kw: oracle.resmlp_forward(sd, x)),
+        # configs[3]
+        "vip_s7": dict(ctor=vp.ViP, kw=dict(image_size=224, patch_size=7, d_model=384, depth=18, segments=12, expansion_factor=3), bs=1,
+                       oracle=lambda sd, x, kw: oracle.vip_forward(sd, x, kw["segments"])),
+        "s2mlpv2": dict(ctor=s2.S2MLPv2, kw=dict(), bs=2, one_thread=True,
+                        oracle=lambda sd, x, kw: oracle.s2mlpv2_forward(sd, x, mode="reference_inplace")),
+        "asmlp_t": dict(ctor=am.AS_MLP, kw=dict(), bs=2, oracle=lambda sd, x, kw: oracle.asmlp_forward(sd, x, shift_size=5)),
+        # configs[4]
+        "convmixer_1536_20": dict(ctor=cm.ConvMixer, kw=dict(dim=1536, depth=20), bs=1, oracle=lambda sd, x, kw: oracle.convmixer_forward(sd, x)),
+        "mixer_l16": dict(ctor=mm.MLPMixerForImageClassification, kw=dict(d_model=1024, depth=24, patch_size=16, image_size=224), bs=1,
+                          oracle=lambda sd, x, kw: oracle.mixer_forward(sd, x)),
+    }
+
+
+def _jsonable(kw):
+    return json.dumps({k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()})
+
+
+def run_ref(model, x, one_thread):
+    nt = torch.get_num_threads()
+    if one_thread:
+        torch.set_num_threads(1)
+    try:
+        with torch.no_grad():
+            return model(x.clone())
+    finally:
+        torch.set_num_threads(nt)
+
+
+def report(tag, ref_out, sd, x, cfg):
+    o32 = cfg["oracle"](sd, x, cfg["kw"])
+    o64 = cfg["oracle"]({k: v.double() if v.is_floating_point() else v for k, v in sd.items()}, x.double(), cfg["kw"])
+    d32 = (o32 - ref_out).abs().max().item()
+    d64 = (o64 - ref_out.double()).abs().max().item()
+    print("  %-20s ref-vs-oracle max|d|: fp32 %.3e  fp64-oracle %.3e   max|ref| %.3f" % (tag, d32, d64, ref_out.abs().max().item()), flush=True)
+    return d32, d64
+
+
+def make_tiny(ref):
+    for name, cfg in tiny_configs(ref).items():
+        torch.manual_seed(0)
+        model = cfg["ctor"](**cfg["kw"]).eval()
+        randomize_norm_stats(model, 1)
+        x = torch.randn(2, 3, *cfg["hw"])
+        pins, handles = hook_pins(model, cfg["pins"])
+        out = run_ref(model, x, cfg.get("one_thread", False))
+        for h in handles:
+            h.remove()
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        d32, _ = report("tiny/" + name, out, sd, x, cfg)
+        assert d32 < 2e-5, (name, d32)
+        blob = {"input": x.numpy(), "logits": out.numpy(), "kwargs": np.array(_jsonable(cfg["kw"]))}
+        for k, v in sd.items():
+            blob["sd/" + k] = v.numpy()
+        for k, v in pins.items():
+            blob["pin/" + k] = v
+        np.savez_compressed(os.path.join(HERE, "tiny_%s.npz" % name), **blob)
+    # S2-MLPv2 with the INTENDED clean shift (paper Algorithm 1 / Jittor twin): the reference
+    # model with its two shift functions replaced by out-of-place versions.
+    s2 = ref["s2_mlp_v2"]
+    cfg = tiny_configs(ref)["s2mlpv2"]
+    orig = (s2.spatial_shift1, s2.spatial_shift2)
+
+    def clean1(x):
+        src = x.clone()
+        b, w, h, c = x.size()
+        x[:, 1:, :, :c // 4] = src[:, :w - 1, :, :c // 4]
+        x[:, :w - 1, :, c // 4:c // 2] = src[:, 1:, :, c // 4:c // 2]
+        x[:, :, 1:, c // 2:c * 3 // 4] = src[:, :, :h - 1, c // 2:c * 3 // 4]
+        x[:, :, :h - 1, 3 * c // 4:] = src[:, :, 1:, 3 * c // 4:]
+        return x
+
+    def clean2(x):
+        src = x.clone()
+        b, w, h, c = x.size()
+        x[:, :, 1:, :c // 4] = src[:, :, :h - 1, :c // 4]
+        x[:, :, :h - 1, c // 4:c // 2] = src[:, :, 1:, c // 4:c // 2]
+        x[:, 1:, :, c // 2:c * 3 // 4] = src[:, :w - 1, :, c // 2:c * 3 // 4]
+        x[:, :w - 1, :, 3 * c // 4:] = src[:, 1:, :, 3 * c // 4:]
+        return x
+
+    s2.spatial_shift1, s2.spatial_shift2 = clean1, clean2
+    try:
+        torch.manual_seed(0)
+        model = cfg["ctor"](**cfg["kw"]).eval()
+        randomize_norm_stats(model, 1)
+        x = torch.randn(2, 3, 32, 32)
+        out = run_ref(model, x, False)
+    finally:
+        s2.spatial_shift1, s2.spatial_shift2 = orig
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    o = oracle.s2mlpv2_forward(sd, x, mode="shift")
+    print("  tiny/s2mlpv2_cleanshift  max|d| %.3e" % (o - out).abs().max().item())
+    assert (o - out).abs().max().item() < 2e-5
+    blob = {"input": x.numpy(), "logits": out.numpy(), "kwargs": np.array(_jsonable(cfg["kw"]))}
+    for k, v in sd.items():
+        blob["sd/" + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "tiny_s2mlpv2_cleanshift.npz"), **blob)
+
+
+def make_real(ref, only=None):
+    for name, cfg in real_configs(ref).items():
+        if only and name not in only:
+            continue
+        torch.manual_seed(0)
+        model = cfg["ctor"](**cfg["kw"]).eval()
+        sd_np = load_portable(model, seed=0)
+        x = torch.from_numpy(portable_input((cfg["bs"], 3, 224, 224), seed=0))
+        out = run_ref(model, x, cfg.get("one_thread", False))
+        sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+        d32, d64 = report("real/" + name, out, sd, x, cfg)
+        nparam = sum(p.numel() for p in model.parameters())
+        np.savez_compressed(os.path.join(HERE, "real_%s.npz" % name), logits=out.numpy(), kwargs=np.array(_jsonable(cfg["kw"])),
+                            bs=np.array(cfg["bs"]), seed=np.array(0), n_params=np.array(nparam),
+                            oracle_fp32_maxdiff=np.array(d32), oracle_fp64_maxdiff=np.array(d64))
+        del model, sd, sd_np
+
+
+def make_ops(ref):
+    sc, s2, vp = ref["shift_cuda"], ref["s2_mlp_v2"], ref["vip"]
+    from einops import rearrange
+    blob = {}
+    torch.manual_seed(0)
+    # AS-MLP Shift (reference torch_shift == the CUDA kernel's formula)
+    for i, (shape, k) in enumerate([((2, 96, 7, 7), 5), ((2, 10, 4, 5), 3), ((2, 8, 5, 6), 5), ((1, 7, 9, 4), 7), ((2, 10, 4, 5), 5)]):
+        x = torch.randn(*shape)
+        for dim in (2, 3):
+            y = sc.torch_shift(x, k, dim)
+            o = oracle.axial_shift_nchw(x, k, dim)
+            assert torch.equal(o, y), ("axial shift mismatch", shape, k, dim)
+            blob["shift%d/x" % i] = x.numpy()
+            blob["shift%d/k" % i] = np.array(k)
+            blob["shift%d/dim%d" % (i, dim)] = y.numpy()
+    # S2 spatial shifts: reference in-place behaviour with ONE thread
+    nt = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        for i, shape in enumerate([(2, 5, 7, 10), (2, 8, 8, 32), (1, 32, 32, 192), (2, 3, 2, 7)]):
+            x = torch.randn(*shape)
+            y1 = s2.spatial_shift1(x.clone())
+            y2 = s2.spatial_shift2(x.clone())
+            for fn, y, tag in ((oracle.spatial_shift1, y1, "s1"), (oracle.spatial_shift2, y2, "s2")):
+                o = fn(x, mode="reference_inplace")
+                assert torch.equal(o, y), ("S2 in-place (1 thread) mismatch", shape, tag, (o - y).abs().max())
+            blob["s2shift%d/x" % i] = x.numpy()
+            blob["s2shift%d/ref1" % i] = y1.numpy()
+            blob["s2shift%d/ref2" % i] = y2.numpy()
+            # sliced (non-contiguous) view as used inside S2Attention (s2_mlp_v2.py:63-64)
+            big = torch.randn(shape[0], shape[1], shape[2], 3 * shape[3])
+            c = shape[3]
+            yb = big.clone()
+            s2.spatial_shift1(yb[:, :, :, :c])
+            s2.spatial_shift2(yb[:, :, :, c:2 * c])
+            ob = big.clone()
+            ob[..., :c] = oracle.spatial_shift1(big[..., :c], mode="reference_inplace")
+            ob[..., c:2 * c] = oracle.spatial_shift2(big[..., c:2 * c], mode="reference_inplace")
+            assert torch.equal(ob, yb), ("S2 in-place sliced mismatch", shape)
+    finally:
+        torch.set_num_threads(nt)
+    # ViP rearranges (einops patterns of vip.py:69,71,74,76)
+    x = torch.randn(2, 3, 4, 30)
+    yh = rearrange(x, "b h w (c s) -> b w c (h s)", s=6)
+    yw = rearrange(x, "b h w (c s) -> b h c (w s)", s=6)
+    assert torch.equal(oracle.vip_permute_h(x, 6), yh) and torch.equal(oracle.vip_permute_w(x, 6), yw)
+    from oracle.functional import vip_unpermute_h, vip_unpermute_w
+    assert torch.equal(vip_unpermute_h(yh, 6), rearrange(yh, "b w c (h s) -> b h w (c s)", s=6))
+    assert torch.equal(vip_unpermute_w(yw, 6), rearrange(yw, "b h c (w s) -> b h w (c s)", s=6))
+    blob["vip/x"], blob["vip/h"], blob["vip/w"] = x.numpy(), yh.numpy(), yw.numpy()
+    # SplitAttention
+    sa = vp.SplitAttention(channel=8, k=3).eval()
+    xa = torch.randn(2, 3, 4, 4, 8)
+    with torch.no_grad():
+        ya = sa(xa)
+    oa = oracle.split_attention(xa[:, 0], xa[:, 1], xa[:, 2], sa.mlp1.weight.detach(), sa.mlp2.weight.detach())
+    assert (oa - ya).abs().max().item() < 1e-6
+    blob["sa/x"], blob["sa/m1"], blob["sa/m2"], blob["sa/y"] = xa.numpy(), sa.mlp1.weight.detach().numpy(), sa.mlp2.weight.detach().numpy(), ya.numpy()
+    np.savez_compressed(os.path.join(HERE, "ops.npz"), **blob)
+    print("  ops pins written (%d arrays)" % len(blob))
+
+
+def make_manifest(ref):
+    """Drop-in manifests: constructor signatures + state_dict key->shape for every hot-path model."""
+    man = {"signatures": {}, "state_dicts": {}}
+    ctors = {
+        "MLPMixerForImageClassification": ref["mlp_mixer"].MLPMixerForImageClassification,
+        "gMLPForImageClassification": ref["g_mlp"].gMLPForImageClassification,
+        "ResMLPForImageClassification": ref["res_mlp"].ResMLPForImageClassification,
+        "ViP": ref["vip"].ViP, "S2MLPv2": ref["s2_mlp_v2"].S2MLPv2, "S2MLPv1": ref["s2_mlp_v1"].S2MLPv1,
+        "S2MLPv1_deep": ref["s2_mlp_v1"].S2MLPv1_deep, "S2MLPv1_wide": ref["s2_mlp_v1"].S2MLPv1_wide,
+        "ConvMixer": ref["conv_mixer"].ConvMixer, "AS_MLP": ref["as_mlp"].AS_MLP, "Shift": ref["shift_cuda"].Shift,
+        "MLPMixer": ref["mlp_mixer"].MLPMixer, "gMLP": ref["g_mlp"].gMLP, "ResMLP": ref["res_mlp"].ResMLP,
+        "WeightedPermutator": ref["vip"].WeightedPermutator, "Permutator": ref["vip"].Permutator,
+        "S2Block": ref["s2_mlp_v2"].S2Block,
+    }
+    for name, c in ctors.items():
+        sig = inspect.signature(c)
+        man["signatures"][name] = [[p.name, repr(p.default) if p.default is not inspect._empty else None, str(p.kind)]
+                                   for p in sig.parameters.values() if p.name != "norm_layer"]
+    for name, cfg in list(real_configs(ref).items()) + [("tiny_" + k, v) for k, v in tiny_configs(ref).items()]:
+        model = cfg["ctor"](**cfg["kw"])
+        man["state_dicts"][name] = {"kwargs": json.loads(_jsonable(cfg["kw"])), "ctor": cfg["ctor"].__name__,
+                                    "n_params": sum(p.numel() for p in model.parameters()),
+                                    "keys": [[k, list(v.shape)] for k, v in model.state_dict().items()]}
+        del model
+    with open(os.path.join(HERE, "manifest.json"), "w") as f:
+        json.dump(man, f, separators=(",", ":"))
+    print("  manifest written")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--real", default=None, help="comma list of real configs")
+    args = ap.parse_args()
+    assert os.path.isdir(REF), "the reference is only available in the authoring container"
+    ref = load_reference()
+    if args.only in (None, "ops"):
+        make_ops(ref)
+    if args.only in (None, "tiny"):
+        make_tiny(ref)
+    if args.only in (None, "manifest"):
+        make_manifest(ref)
+    if args.only in (None, "real"):
+        make_real(ref, args.real.split(",") if args.real else None)
+
+
+if __name__ == "__main__":
+    main()
