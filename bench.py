@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Headline benchmark: forward images/s of Mixer-B/16, 224^2, 256 images per GPU, bf16 MFMA path.
+
+  python bench.py --gpus N --steps K --warmup W          (N=1: plain python;  N>1: launched by
+  python -m torch.distributed.run --nproc-per-node N ... one rank per GPU, RCCL over xGMI)
+
+A "step" is one forward pass of the hot path over one resident synthetic batch (BASELINE.json
+configs[1]): patch embed -> 12 x (token-mixing MLP, channel MLP) -> LN/mean/head, plus -- for
+N > 1 -- the single all-gather of the (256, 1000) logits that data-parallel inference needs
+(SURVEY.md 8e).  Inputs are already in HBM when the timed region starts.  Protocol of the
+reference's compare.py:149-158: warm-up, device sync, K timed forwards, device sync.
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline     -- the dominant kernel (channel-MLP GEMM, 79 % of the flops): algorithmic
+                  2*M*N*K per launch / HIP-event time of those launches inside the timed region,
+                  against the gfx950 dense bf16 MFMA peak (2.5 PFLOP/s);
+  cpu_baseline -- the CPU oracle (oracle/, a port of the reference forward) timed on this host
+                  on a bounded sample (Mixer-B/16, fp32, bs=8), N=1 only.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MODELS = {
+    # name: (ctor name, kwargs, GFLOP per image)
+    "mixer_b16": ("MLPMixerForImageClassification", dict(d_model=768, depth=12, patch_size=16, image_size=224), 28.094),
+    "mixer_s16": ("MLPMixerForImageClassification", dict(d_model=512, depth=8, patch_size=16, image_size=224), 9.249),
+    "mixer_l16": ("MLPMixerForImageClassification", dict(d_model=1024, depth=24, patch_size=16, image_size=224), 94.336),
+    "gmlp_s": ("gMLPForImageClassification", dict(image_size=224), 17.491),
+    "resmlp_24": ("ResMLPForImageClassification", dict(depth=24), 11.923),
+    "vip_s7": ("ViP", dict(image_size=224, patch_size=7, d_model=384, depth=18, segments=12, expansion_factor=3), 54.496),
+    "s2mlpv2": ("S2MLPv2", dict(), 13.817),
+    "asmlp_t": ("AS_MLP", dict(), 8.701),
+    "convmixer_1536_20": ("ConvMixer", dict(dim=1536, depth=20), 102.198),
+}
+PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16/f16 MFMA (MI355X_MICROARCH.md); f32 MFMA 157.3
+DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
+
+
+def run_cpu_baseline(model_name, kwargs, ctor_name, pkg):
+    import oracle
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_oracle_golden import run_oracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    model = getattr(pkg.models_pytorch, ctor_name)(**kwargs).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    bs = 8
+    x = torch.rand(bs, 3, 224, 224)
+    fam = {"MLPMixerForImageClassification": "mixer", "gMLPForImageClassification": "gmlp",
+           "ResMLPForImageClassification": "resmlp", "ViP": "vip", "S2MLPv2": "s2mlpv2", "AS_MLP": "asmlp",
+           "ConvMixer": "convmixer"}[ctor_name]
+    run_oracle(fam, sd, x, kwargs)                                  # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        run_oracle(fam, sd, x, kwargs)
+        n += 1
+        if time.perf_counter() - t0 > 10.0 or n >= 10:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(bs * n / dt, 2), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%s fp32 bs=%d, %d forwards of the oracle/ restatement in %.1f s, %d torch threads"
+                      % (model_name, bs, n, dt, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="mixer_b16", choices=sorted(MODELS))
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=sorted(DT))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--algo", default="", help="tag=algo[,tag=algo] GEMM tile overrides (tuning)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                             "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import __graft_entry__ as ge
+    ge.build()
+    pkg = importlib.import_module("jittor-mlp_amd")
+    E = pkg.engine
+    for item in filter(None, args.algo.split(",")):
+        tag, algo = item.split("=")
+        E.GEMM_ALGO[tag] = int(algo)
+
+    ctor_name, kwargs, gflop_img = MODELS[args.model]
+    cd = DT[args.dtype]
+    torch.manual_seed(0)                                             # same random-init weights on every rank (replicated)
+    model = getattr(pkg.models_pytorch, ctor_name)(**kwargs).eval().to(dev)
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    x = torch.rand((args.batch, 3, 224, 224), generator=g).to(dev).to(cd)   # uniform[0,1) like compare.py:23; resident in HBM
+    parallel = importlib.import_module("jittor-mlp_amd.parallel")
+    runner = parallel.DataParallelForward(model, world)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = runner(x)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        timer = None
+        if not args.no_kernel_timing:
+            timer = E.KernelTimer()
+            E.TIMER = timer
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = runner(x)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        E.TIMER = None
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert out.shape == (args.batch * world, 1000) and bool(torch.isfinite(out.float()).all())
+
+    if rank == 0:
+        global_batch = args.batch * world
+        ms = elapsed / args.steps * 1e3
+        line = {
+            "metric": "images/sec fwd, 224^2 bs=256/GPU, Mixer-B/16" if args.model == "mixer_b16" else "images/sec fwd " + args.model,
+            "value": round(global_batch * args.steps / elapsed, 1), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "%s forward, 224x224, %d images/GPU x %d GPU, random-init weights, uniform[0,1) input resident in HBM"
+                                   % (args.model, args.batch, world),
+                       "global_batch": global_batch, "parallelism": "dp%d" % world,
+                       "collective": "all_gather(logits)" if world > 1 else "none"},
+            "model_tflops": round(gflop_img * global_batch * args.steps / elapsed / 1e3, 1),
+        }
+        if timer is not None and timer.events:
+            summ = timer.summary()
+            dom = [t for t in ("channel_fc1", "channel_fc2") if t in summ]
+            if dom:
+                flops = sum(summ[t]["flops_per_launch"] * summ[t]["launches"] for t in dom)
+                secs = sum(summ[t]["avg_ms"] * summ[t]["launches"] for t in dom) * 1e-3
+                n_launch = sum(summ[t]["launches"] for t in dom)
+                peak = PEAK_BF16_TFLOPS if args.dtype != "fp32" else 157.3
+                ach = flops / secs / 1e12
+                line["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel (channel-MLP fc1+fc2)", "achieved": round(ach, 1),
+                                    "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                                    "flops_per_launch": flops / n_launch, "avg_launch_ms": round(secs / n_launch * 1e3, 4),
+                                    "launches_timed": n_launch}
+            line["kernels"] = {t: {"avg_ms": round(v["avg_ms"], 4), "tflops": round(v["flops_per_launch"] / v["avg_ms"] / 1e9, 1),
+                                   "launches": v["launches"]} for t, v in summ.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = run_cpu_baseline(args.model, kwargs, ctor_name, pkg)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,245 @@
+/*
+ * mlpk.h -- C ABI of the MI355X (gfx950) native kernels for the vision-MLP forward path.
+ *
+ * Drop-in boundary.  The reference has exactly one native-op seam on the
+ * PyTorch side: `models_pytorch/utils/shift_cuda.py:106-129` -- a Python autograd.Function that
+ * launches a raw-pointer kernel on torch's current stream, with the output allocated by the
+ * caller (`input.new(...)`, :112).  Every entry point here follows that contract:
+ *
+ *   - plain pointers and sizes only (no torch types); the CALLER owns all memory, the library
+ *     allocates nothing and keeps no state between calls;
+ *   - all tensors are dense device buffers; "ld*" are row strides in ELEMENTS;
+ *   - `dtype` selects the storage/MFMA operand type of activations and weights
+ *     (MLPK_F32 / MLPK_F16 / MLPK_BF16); accumulation, statistics, GELU and every
+ *     per-channel vector (bias, scale, shift, gamma, beta, mean, rstd) are float32;
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream), launches are
+ *     asynchronous;
+ *   - return value: 0 = launched, negative = MLPK_E* argument error (nothing launched),
+ *     positive = hipError_t from the launch.
+ *
+ * Reference interfaces replaced (file:line relative to the reference repository):
+ *   mlpk_gemm_nt        nn.Linear / Conv1d(k=1) / Conv2d(1x1) + the elementwise ops the reference
+ *                       runs after them (GELU, residual add, BatchNorm-eval affine, SGU gate):
+ *                       mlp_mixer.py:16-27,6-13; g_mlp.py:17-22,32-39; res_mlp.py:52-57;
+ *                       vip.py:65-90; s2_mlp_v2.py:60-69,76-85; as_mlp.py:8-24,55-95; conv_mixer.py:29-31
+ *   mlpk_patchify       the im2col half of nn.Conv2d(k=stride=patch): mlp_mixer.py:58-60,68-71;
+ *                       conv_mixer.py:18; s2_mlp_v2.py:119; as_mlp.py:319,330; PatchMerging as_mlp.py:207-211
+ *   mlpk_row_stats      statistics of nn.LayerNorm (mlp_mixer.py:10) and nn.GroupNorm(1,C) (as_mlp.py:343-344)
+ *   mlpk_norm_apply     the normalise+affine half of LayerNorm/GroupNorm/Aff (res_mlp.py:17-19), fused with
+ *                       GELU (as_mlp.py:64-66) and with the layout change the next GEMM needs:
+ *                       token-major transpose (Conv1d over tokens) or the ViP rearranges (vip.py:69,74)
+ *   mlpk_vip_unpermute  einops Rearrange back (vip.py:71,76)
+ *   mlpk_pool_mean      x.mean(dim=1) / Reduce('b h w c -> b c') / AdaptiveAvgPool2d, optionally through
+ *                       the final LayerNorm: mlp_mixer.py:73-74; vip.py:160-163; s2_mlp_v2.py:125; as_mlp.py:435-437
+ *   mlpk_shift_nchw     Shift / _shift.forward / shift_forward_kernel: utils/shift_cuda.py:44-72,106-129,177-192
+ *   mlpk_shift_nhwc     the same remap on the channel-last layout used internally for AS-MLP
+ *   mlpk_split_sum      the reduction of SplitAttention (vip.py:49-50; s2_mlp_v2.py:43-44), with the
+ *                       S2 spatial shifts (s2_mlp_v2.py:15-29) applied on load
+ *   mlpk_split_softmax  softmax over the k=3 branches (vip.py:52-53)
+ *   mlpk_split_apply    attention * x_all summed over k (vip.py:54-56), shifts applied on load
+ *   mlpk_s2_shift       Spatial_Shift (s2_mlp_v1.py:19-25), out of place
+ *   mlpk_dwconv_nhwc    depthwise Conv2d(k, groups=dim, padding="same") + GELU + BatchNorm(eval) + residual:
+ *                       conv_mixer.py:5-11,24-28
+ */
+#ifndef MLPK_H
+#define MLPK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- dtypes --------------------------------------------------------------------------- */
+#define MLPK_F32 0
+#define MLPK_F16 1
+#define MLPK_BF16 2
+
+/* ---- error codes (negative) ----------------------------------------------------------- */
+#define MLPK_OK 0
+#define MLPK_EDTYPE (-1)   /* unknown dtype */
+#define MLPK_ESHAPE (-2)   /* size/stride violates a documented constraint */
+#define MLPK_EALIGN (-3)   /* pointer or leading dimension not 16-byte aligned where required */
+#define MLPK_ENULL (-4)    /* required pointer is NULL */
+#define MLPK_EMODE (-5)    /* unknown mode/flag value */
+
+/* ABI version; bumped on any signature change. */
+int mlpk_abi_version(void);
+/* Human-readable message for a return code (static storage). */
+const char* mlpk_strerror(int code);
+
+/* ---- GEMM with fused epilogue ----------------------------------------------------------
+ * acc[m,n] = sum_k A[m*lda + k] * B[n*ldb + k]           (A: MxK, B: NxK, both K-contiguous)
+ * v = acc + bias[n]                     (bias may be NULL)
+ * v = gelu(v)   if act == MLPK_ACT_GELU (exact erf form)
+ * v = v * cscale[n] + cshift[n]         (either may be NULL)
+ * v = v * rscale[m % rperiod]           (rscale may be NULL)
+ * v = v + R[...]  (res_mode ADD)  |  v = v * R[...]  (res_mode MUL)
+ * C[...] = (dtype) v
+ * Addressing of C (and R with ldr):
+ *   out_mode ROWMAJOR : C[m*ldc + n]
+ *   out_mode TOKEN_T  : rows are (image b, channel c) pairs, m = b*t_rows + c, and columns are
+ *                       tokens n; element goes to C[(b*t_tokens + n)*ldc + c]  (the per-image
+ *                       transpose that turns the token-mixing Conv1d into this NT GEMM).
+ * Constraints: K % (16/sizeof(dtype) * 2) == 0 is NOT required; K, lda, ldb must be multiples of
+ * 16/sizeof(dtype) elements (16-byte chunks); A, B 16-byte aligned.  TOKEN_T needs t_rows % 4 == 0.
+ * R may alias C.  `algo` 0 = automatic tile choice.
+ */
+#define MLPK_ACT_NONE 0
+#define MLPK_ACT_GELU 1
+#define MLPK_RES_NONE 0
+#define MLPK_RES_ADD 1
+#define MLPK_RES_MUL 2
+#define MLPK_OUT_ROWMAJOR 0
+#define MLPK_OUT_TOKEN_T 1
+
+typedef struct mlpk_gemm_desc {
+    int32_t dtype;
+    int32_t M, N, K;
+    int32_t lda, ldb, ldc, ldr;
+    const void* A;
+    const void* B;
+    void* C;
+    const void* R;        /* residual / gate source, same dtype as C, or NULL */
+    const float* bias;    /* [N] or NULL */
+    const float* cscale;  /* [N] or NULL */
+    const float* cshift;  /* [N] or NULL */
+    const float* rscale;  /* [rperiod] or NULL */
+    int32_t rperiod;
+    int32_t act;
+    int32_t res_mode;
+    int32_t out_mode;
+    int32_t t_rows;       /* TOKEN_T: rows (channels) per image */
+    int32_t t_tokens;     /* TOKEN_T: tokens per image (row count of one image in C) */
+    int32_t algo;         /* 0 auto; otherwise a tile-config id, see mlpk_gemm_algo_count */
+    int32_t reserved;
+} mlpk_gemm_desc;
+
+int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream);
+/* number of tile configurations (valid algo ids are 1..count) and dynamic LDS bytes of one */
+int mlpk_gemm_algo_count(void);
+int mlpk_gemm_algo_info(int algo, int* bm, int* bn, int* threads, int* lds_bytes);
+
+/* ---- patch gather (im2col of a kernel==stride convolution) -----------------------------
+ * out[(b*Hp + hp)*Wp + wp][k], row stride ldo (>= K, pad columns [K, ldo) are zero-filled).
+ * src_layout NCHW : src is (B,Cin,H,W) of src_dtype; k = ci*ph*pw + i*pw + j (conv weight flattening)
+ * src_layout NHWC : src is (B,H,W,Cin) of src_dtype with pixel stride lds_px elements;
+ *                   k = (i*pw + j)*Cin + ci  (the host permutes the weight once)
+ * Pixel (hp*ph + i - pad, wp*pw + j - pad); outside the image -> 0.  Hp = (H + 2*pad - ph)/ph + 1.
+ * order 0: patch offsets enumerate i (rows) outer, j inner.
+ * order 1 (NHWC only): PatchMerging order of as_mlp.py:207-211 -- (i,j) in (0,0),(1,0),(0,1),(1,1).
+ */
+#define MLPK_LAYOUT_NCHW 0
+#define MLPK_LAYOUT_NHWC 1
+int mlpk_patchify(int src_dtype, int dst_dtype, int src_layout, const void* src, void* out,
+                  int B, int Cin, int H, int W, int ph, int pw, int pad, int src_px_stride,
+                  int ldo, int order, void* stream);
+
+/* ---- row statistics ---------------------------------------------------------------------
+ * For each of `rows` rows of `len` contiguous elements (row r starts at x + r*ldx):
+ * mean[r], rstd[r] = 1/sqrt(biased_var + eps).  Two-pass (mean, then centred squares), fp32.
+ * LayerNorm: rows = B*S, len = C.  GroupNorm(1,C): rows = B, len = C*H*W.
+ */
+int mlpk_row_stats(int dtype, const void* x, int64_t rows, int64_t len, int64_t ldx,
+                   float eps, float* mean, float* rstd, void* stream);
+
+/* ---- normalise / affine / activation + layout change -------------------------------------
+ * y = (x[r,c] - mean[sr]) * rstd[sr] * gamma[c] + beta[c]      (mean/rstd NULL -> plain affine;
+ * gamma/beta NULL -> 1/0);  y = gelu(y) if act;  sr = r / stat_group (stat_group = 1 for
+ * LayerNorm; = H*W for GroupNorm(1,C) on channel-last data where one stat covers a whole sample).
+ * x: rows x C, row stride ldx.  Outputs (any subset, NULL to skip):
+ *   out_rm : row-major rows x C, stride ld_rm
+ *   out_tt : token-transposed (B, C, ld_tt) with out_tt[(b*C + c)*ld_tt + s], r = b*S + s;
+ *            columns [S, ld_tt) are zero-filled (they are the K padding of the token GEMM)
+ *   out_ph / out_pw : the ViP rearranges (vip.py:69 / :74) of x viewed as (B,H,W,C=G*seg):
+ *            out_ph[((b*W + w)*G + g)*ld_p + h*seg + j] = y[b,h,w,g*seg + j]
+ *            out_pw[((b*H + h)*G + g)*ld_p + w*seg + j] = y[b,h,w,g*seg + j]; pad columns zero-filled
+ */
+typedef struct mlpk_norm_desc {
+    int32_t dtype;
+    int32_t act;
+    int64_t rows;
+    int32_t C;
+    int32_t ldx;
+    int32_t stat_group;
+    int32_t S;            /* tokens per image (out_tt) */
+    int32_t H, W, seg;    /* ViP geometry (out_ph/out_pw) */
+    int32_t ld_rm, ld_tt, ld_p;
+    const void* x;
+    const float* mean;
+    const float* rstd;
+    const float* gamma;
+    const float* beta;
+    void* out_rm;
+    void* out_tt;
+    void* out_ph;
+    void* out_pw;
+} mlpk_norm_desc;
+int mlpk_norm_apply(const mlpk_norm_desc* d, void* stream);
+
+/* ViP inverse rearranges (vip.py:71 / :76): z is the GEMM output in the permuted layout.
+ * which = 0: out[b,h,w,g*seg+q] = z[((b*W + w)*G + g)*ldz + h*seg + q]
+ * which = 1: out[b,h,w,g*seg+q] = z[((b*H + h)*G + g)*ldz + w*seg + q]        (out row stride C) */
+int mlpk_vip_unpermute(int dtype, int which, const void* z, void* out, int B, int H, int W, int C,
+                       int seg, int ldz, void* stream);
+
+/* ---- mean over tokens --------------------------------------------------------------------
+ * out[b,c] = mean_s y[b,s,c], y = x or the LayerNorm of x (mean/rstd per row given, gamma/beta
+ * per channel); x is (B,S,C) with row stride ldx.  stat_group as in mlpk_norm_apply.
+ * out dtype = dtype, row stride ldo.
+ */
+int mlpk_pool_mean(int dtype, const void* x, int B, int S, int C, int ldx, const float* mean,
+                   const float* rstd, int stat_group, const float* gamma, const float* beta,
+                   void* out, int ldo, void* stream);
+
+/* ---- AS-MLP axial shift (the reference's one native op) -----------------------------------
+ * group = ceil(C / kernel_size); s = kernel_size/2 - c/group;
+ * NCHW: out[n,c,h,w] = in[n,c,h+s,w] (dim 2) | in[n,c,h,w+s] (dim 3), zero outside.
+ * NHWC: same on (N,H,W,C).  kernel_size must be odd and >= 3, dim in {2,3}.
+ */
+int mlpk_shift_nchw(int dtype, const void* in, void* out, int N, int C, int H, int W,
+                    int kernel_size, int dim, void* stream);
+int mlpk_shift_nhwc(int dtype, const void* in, void* out, int N, int H, int W, int C,
+                    int kernel_size, int dim, void* stream);
+
+/* ---- split attention (ViP / S2-MLPv2) -----------------------------------------------------
+ * Three branch tensors x_k (B,H,W,C), k=0..2, each with its own pixel stride ld_k (so they may be
+ * column slices of one (B,H,W,3C) buffer).  shift_mode selects a gather applied to branches 0/1
+ * while loading (s2_mlp_v2.py:15-29); branch 2 is never shifted:
+ *   MLPK_SHIFT_NONE      ViP
+ *   MLPK_SHIFT_S2        branch0 = spatial_shift1, branch1 = spatial_shift2, clean 1-pixel shift
+ *   MLPK_SHIFT_S2_REF    same, with the reference's deterministic in-place ("smear") behaviour
+ * split_sum:    a[b,c] = sum_{k,h,w} x_k[b,h,w,c]                     (fp32, a pre-zeroed by callee)
+ * split_softmax: bar[b,k,c] = softmax_k(hat[b, k*C + c])             (fp32 in/out)
+ * split_apply:  out[b,h,w,c] = sum_k bar[b,k,c] * x_k[b,h,w,c]       (out pixel stride ldo)
+ */
+#define MLPK_SHIFT_NONE 0
+#define MLPK_SHIFT_S2 1
+#define MLPK_SHIFT_S2_REF 2
+int mlpk_split_sum(int dtype, const void* x0, const void* x1, const void* x2, int ld0, int ld1,
+                   int ld2, int B, int H, int W, int C, int shift_mode, float* a, void* stream);
+int mlpk_split_softmax(const float* hat, float* bar, int B, int C, void* stream);
+int mlpk_split_apply(int dtype, const void* x0, const void* x1, const void* x2, int ld0, int ld1,
+                     int ld2, int B, int H, int W, int C, int shift_mode, const float* bar,
+                     void* out, int ldo, void* stream);
+/* S2-MLPv1 Spatial_Shift on (B,H,W,C), out of place, same shift_mode values (NONE = copy). */
+int mlpk_s2_shift(int dtype, const void* in, void* out, int B, int H, int W, int C, int ldi,
+                  int ldo, int shift_mode, void* stream);
+
+/* ---- ConvMixer depthwise half --------------------------------------------------------------
+ * x, out: (B,H,W,C) channel-last.  w: float32 [k*k][C] (tap-major), bias/bn_scale/bn_shift float32 [C].
+ * out = x + (gelu(dwconv_same(x) + bias) * bn_scale + bn_shift)        (conv_mixer.py:24-28, 5-11)
+ */
+int mlpk_dwconv_nhwc(int dtype, const void* x, void* out, int B, int H, int W, int C, int k,
+                     const float* w, const float* bias, const float* bn_scale,
+                     const float* bn_shift, void* stream);
+
+/* ---- small utilities ------------------------------------------------------------------------ */
+/* dst[i] = (dst_dtype) src[i], n elements */
+int mlpk_convert(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLPK_H */

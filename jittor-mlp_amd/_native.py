@@ -1,0 +1,88 @@
+"""ctypes binding of libmlpk.so (include/mlpk.h).  No CPU fallback: if the HIP library is
+missing or a call fails, this raises -- the product path never silently degrades."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmlpk.so")
+
+F32, F16, BF16 = 0, 1, 2
+ACT_NONE, ACT_GELU = 0, 1
+RES_NONE, RES_ADD, RES_MUL = 0, 1, 2
+OUT_ROWMAJOR, OUT_TOKEN_T = 0, 1
+LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
+SHIFT_NONE, SHIFT_S2, SHIFT_S2_REF = 0, 1, 2
+
+c_void_p, c_int, c_i64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+
+
+class GemmDesc(ctypes.Structure):
+    _fields_ = [("dtype", ctypes.c_int32), ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32),
+                ("lda", ctypes.c_int32), ("ldb", ctypes.c_int32), ("ldc", ctypes.c_int32), ("ldr", ctypes.c_int32),
+                ("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("R", c_void_p),
+                ("bias", c_void_p), ("cscale", c_void_p), ("cshift", c_void_p), ("rscale", c_void_p),
+                ("rperiod", ctypes.c_int32), ("act", ctypes.c_int32), ("res_mode", ctypes.c_int32),
+                ("out_mode", ctypes.c_int32), ("t_rows", ctypes.c_int32), ("t_tokens", ctypes.c_int32),
+                ("algo", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class NormDesc(ctypes.Structure):
+    _fields_ = [("dtype", ctypes.c_int32), ("act", ctypes.c_int32), ("rows", ctypes.c_int64), ("C", ctypes.c_int32),
+                ("ldx", ctypes.c_int32), ("stat_group", ctypes.c_int32), ("S", ctypes.c_int32),
+                ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("seg", ctypes.c_int32),
+                ("ld_rm", ctypes.c_int32), ("ld_tt", ctypes.c_int32), ("ld_p", ctypes.c_int32),
+                ("x", c_void_p), ("mean", c_void_p), ("rstd", c_void_p), ("gamma", c_void_p), ("beta", c_void_p),
+                ("out_rm", c_void_p), ("out_tt", c_void_p), ("out_ph", c_void_p), ("out_pw", c_void_p)]
+
+
+# name -> (restype, argtypes); every symbol include/mlpk.h declares
+PROTOTYPES = {
+    "mlpk_abi_version": (c_int, []),
+    "mlpk_strerror": (ctypes.c_char_p, [c_int]),
+    "mlpk_gemm_nt": (c_int, [ctypes.POINTER(GemmDesc), c_void_p]),
+    "mlpk_gemm_algo_count": (c_int, []),
+    "mlpk_gemm_algo_info": (c_int, [c_int] + [ctypes.POINTER(c_int)] * 4),
+    "mlpk_patchify": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
+    "mlpk_row_stats": (c_int, [c_int, c_void_p, c_i64, c_i64, c_i64, c_float, c_void_p, c_void_p, c_void_p]),
+    "mlpk_norm_apply": (c_int, [ctypes.POINTER(NormDesc), c_void_p]),
+    "mlpk_vip_unpermute": (c_int, [c_int, c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "mlpk_pool_mean": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                               c_void_p, c_void_p, c_int, c_void_p]),
+    "mlpk_shift_nchw": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "mlpk_shift_nhwc": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "mlpk_split_sum": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p, c_void_p]),
+    "mlpk_split_softmax": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "mlpk_split_apply": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p, c_void_p, c_int, c_void_p]),
+    "mlpk_s2_shift": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    "mlpk_dwconv_nhwc": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p] * 4 + [c_void_p]),
+    "mlpk_convert": (c_int, [c_int, c_int, c_void_p, c_void_p, c_i64, c_void_p]),
+}
+
+_lib = None
+
+
+class MlpkError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libmlpk.so once.  Raises MlpkError (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MlpkError("HIP kernel library %s is missing: run `python __graft_entry__.py build` "
+                            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)          # AttributeError if a declared symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        if handle.mlpk_abi_version() != 1:
+            raise MlpkError("libmlpk.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().mlpk_strerror(rc)
+        raise MlpkError("%s failed (%d): %s" % (what or "mlpk call", rc, msg.decode() if msg else "?"))

@@ -1,0 +1,130 @@
+// Patch gather: the im2col half of a kernel == stride convolution (patch embedding, S2 stage
+// embedding, AS-MLP PatchMerging).  The other half is mlpk_gemm_nt.  No im2col buffer beyond
+// the GEMM's own A operand is ever materialised, and the dtype conversion of the input image
+// (fp32 NCHW -> bf16/f16 tokens) happens here, in the same pass.
+#include "mlpk_common.h"
+
+namespace mlpk {
+
+struct PatchArgs {
+    const void* src;
+    void* out;
+    int B, Cin, H, W, ph, pw, pad, px_stride, ldo, order, layout;
+    int Hp, Wp, K;
+    int64_t rows;
+};
+
+template <typename TS, typename TD>
+__global__ void __launch_bounds__(256) patchify_kernel(const PatchArgs p) {
+    const TS* __restrict__ src = reinterpret_cast<const TS*>(p.src);
+    TD* __restrict__ out = reinterpret_cast<TD*>(p.out);
+    const int chunks = p.ldo / 8;
+    const int64_t total = p.rows * chunks;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t row = idx / chunks;
+        const int k0 = (int)(idx - row * chunks) * 8;
+        const int wp = (int)(row % p.Wp);
+        const int hp = (int)((row / p.Wp) % p.Hp);
+        const int b = (int)(row / ((int64_t)p.Wp * p.Hp));
+        TD e[8];
+        if (p.layout == MLPK_LAYOUT_NHWC && (p.Cin & 7) == 0 && k0 < p.K) {
+            // 8 consecutive k share the patch offset (i,j): one contiguous 8-channel run
+            const int q = k0 / p.Cin;
+            const int ci = k0 - q * p.Cin;
+            const int i = p.order == 1 ? (q & 1) : q / p.pw;
+            const int j = p.order == 1 ? (q >> 1) : q - (q / p.pw) * p.pw;
+            const int y = hp * p.ph + i - p.pad, x = wp * p.pw + j - p.pad;
+            if (y >= 0 && y < p.H && x >= 0 && x < p.W) {
+                const TS* s = src + (((int64_t)b * p.H + y) * p.W + x) * p.px_stride + ci;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) e[t] = from_f32<TD>(to_f32(s[t]));
+            } else {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) e[t] = from_f32<TD>(0.f);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int k = k0 + t;
+                float v = 0.f;
+                if (k < p.K) {
+                    int ci, i, j;
+                    if (p.layout == MLPK_LAYOUT_NCHW) {
+                        ci = k / (p.ph * p.pw);
+                        const int rem = k - ci * (p.ph * p.pw);
+                        i = rem / p.pw;
+                        j = rem - i * p.pw;
+                    } else {
+                        const int q = k / p.Cin;
+                        ci = k - q * p.Cin;
+                        i = p.order == 1 ? (q & 1) : q / p.pw;
+                        j = p.order == 1 ? (q >> 1) : q - (q / p.pw) * p.pw;
+                    }
+                    const int y = hp * p.ph + i - p.pad, x = wp * p.pw + j - p.pad;
+                    if (y >= 0 && y < p.H && x >= 0 && x < p.W) {
+                        const int64_t si = p.layout == MLPK_LAYOUT_NCHW
+                                               ? (((int64_t)b * p.Cin + ci) * p.H + y) * p.W + x
+                                               : (((int64_t)b * p.H + y) * p.W + x) * p.px_stride + ci;
+                        v = to_f32(src[si]);
+                    }
+                }
+                e[t] = from_f32<TD>(v);
+            }
+        }
+        TD* o = out + row * p.ldo + k0;
+        if constexpr (sizeof(TD) == 2) {
+            u32x4 t;
+            __builtin_memcpy(&t, e, 16);
+            *reinterpret_cast<u32x4*>(o) = t;
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) o[t] = e[t];
+        }
+    }
+}
+
+template <typename TS> static int patchify_from(int dst, const PatchArgs& a, unsigned grid, hipStream_t s) {
+    switch (dst) {
+        case MLPK_F32: hipLaunchKernelGGL((patchify_kernel<TS, float>), dim3(grid), dim3(256), 0, s, a); break;
+        case MLPK_F16: hipLaunchKernelGGL((patchify_kernel<TS, f16_t>), dim3(grid), dim3(256), 0, s, a); break;
+        case MLPK_BF16: hipLaunchKernelGGL((patchify_kernel<TS, bf16_t>), dim3(grid), dim3(256), 0, s, a); break;
+        default: return MLPK_EDTYPE;
+    }
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace mlpk
+
+using namespace mlpk;
+
+extern "C" int mlpk_patchify(int src_dtype, int dst_dtype, int src_layout, const void* src, void* out, int B, int Cin,
+                             int H, int W, int ph, int pw, int pad, int src_px_stride, int ldo, int order,
+                             void* stream) {
+    if (!src || !out) return MLPK_ENULL;
+    if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || ph <= 0 || pw <= 0 || pad < 0) return MLPK_ESHAPE;
+    if (src_layout != MLPK_LAYOUT_NCHW && src_layout != MLPK_LAYOUT_NHWC) return MLPK_EMODE;
+    if (order != 0 && order != 1) return MLPK_EMODE;
+    if (order == 1 && (src_layout != MLPK_LAYOUT_NHWC || ph != 2 || pw != 2)) return MLPK_EMODE;
+    PatchArgs a;
+    a.src = src; a.out = out; a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.ph = ph; a.pw = pw; a.pad = pad;
+    a.px_stride = src_layout == MLPK_LAYOUT_NHWC ? src_px_stride : 0;
+    a.ldo = ldo; a.order = order; a.layout = src_layout;
+    a.Hp = (H + 2 * pad - ph) / ph + 1;
+    a.Wp = (W + 2 * pad - pw) / pw + 1;
+    a.K = Cin * ph * pw;
+    if (a.Hp <= 0 || a.Wp <= 0) return MLPK_ESHAPE;
+    if (ldo % 8 || ldo < a.K) return MLPK_ESHAPE;
+    if (src_layout == MLPK_LAYOUT_NHWC && src_px_stride < Cin) return MLPK_ESHAPE;
+    if ((uintptr_t)out & 15) return MLPK_EALIGN;
+    a.rows = (int64_t)B * a.Hp * a.Wp;
+    const int64_t total = a.rows * (ldo / 8);
+    const unsigned grid = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (src_dtype) {
+        case MLPK_F32: return patchify_from<float>(dst_dtype, a, grid, s);
+        case MLPK_F16: return patchify_from<f16_t>(dst_dtype, a, grid, s);
+        case MLPK_BF16: return patchify_from<bf16_t>(dst_dtype, a, grid, s);
+        default: return MLPK_EDTYPE;
+    }
+}

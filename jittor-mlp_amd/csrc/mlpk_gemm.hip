@@ -1,0 +1,415 @@
+// NT GEMM on MFMA with a fused epilogue -- the kernel every dense contraction of the path maps to.
+//
+//   acc[m,n] = sum_k A[m,k] * B[n,k]     A: M x K, B: N x K, both K-contiguous (nn.Linear layout)
+//
+// Design (gfx950 / CDNA4):
+//   * workgroup tile BM x BN, K consumed in 128-byte slabs per row (64 bf16/f16 or 32 f32);
+//     WM x WN wavefronts of 64 lanes, each owning a (BM/WM) x (BN/WN) sub-tile made of 16x16 MFMA
+//     blocks (v_mfma_f32_16x16x32_{bf16,f16}; exact-f32 v_mfma_f32_16x16x4_f32 for float);
+//   * LDS rows are 128 B = 8 x 16-byte chunks, chunk index XOR-swizzled with (row & 7) so the
+//     ds_read_b128 fragment reads (16 rows x one chunk column per lane group) are conflict-free;
+//   * global -> VGPR -> LDS staging, double-buffered, ONE barrier per K-slab: loads for slab t+1
+//     are issued before the MFMAs of slab t and written to the other buffer after them;
+//   * the accumulator is produced "transposed" (MFMA operands swapped) for row-major outputs so each
+//     lane owns 4 consecutive n of one row -> 8/16-byte epilogue stores; for the token-mixing
+//     (per-image transposed) output the natural orientation gives 4 consecutive channels instead;
+//   * bias / exact GELU / per-column scale+shift (BatchNorm-eval, ResMLP gamma) / per-row scale /
+//     residual-add or gate-multiply are applied on the fp32 accumulator before the single store;
+//   * XCD-aware tile order: each of the 8 XCDs walks a contiguous range of tiles (n fastest) so the
+//     A panel and the weight panels are re-used out of that XCD's private L2.
+#include "mlpk_common.h"
+
+namespace mlpk {
+
+struct GemmArgs {
+    const void* A;
+    const void* B;
+    void* C;
+    const void* R;
+    const float* bias;
+    const float* cscale;
+    const float* cshift;
+    const float* rscale;
+    int M, N, K;
+    int lda, ldb, ldc, ldr;
+    int rperiod, act, res_mode;
+    int t_rows, t_tokens;
+    int vec_c, vec_r;   // vector (4-element) store / residual-load allowed
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                       __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<f16_t> {
+    static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a),
+                                                      __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    // one 16-byte chunk = 4 consecutive k per lane group; four K=4 steps, each taking element e of
+    // every lane's chunk (any k <-> (lane group, e) bijection is valid as long as A and B agree).
+    static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.y), __builtin_bit_cast(float, b.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.z), __builtin_bit_cast(float, b.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), c, 0, 0, 0);
+        return c;
+    }
+};
+
+// ---- 4-element vector access in the storage dtype ---------------------------------------------
+template <typename T> __device__ __forceinline__ void load4(const T* p, bool vec, float (&v)[4]) {
+    if (vec) {
+        if constexpr (sizeof(T) == 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+            const u32x2 t = *reinterpret_cast<const u32x2*>(p);
+            T e[4];
+            __builtin_memcpy(e, &t, 8);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = to_f32(e[r]);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = to_f32(p[r]);
+    }
+}
+
+template <typename T> __device__ __forceinline__ void store4(T* p, bool vec, const float (&v)[4]) {
+    if (vec) {
+        if constexpr (sizeof(T) == 4) {
+            f32x4 t = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(p) = t;
+        } else {
+            T e[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) e[r] = from_f32<T>(v[r]);
+            u32x2 t;
+            __builtin_memcpy(&t, e, 8);
+            *reinterpret_cast<u32x2*>(p) = t;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r] = from_f32<T>(v[r]);
+    }
+}
+
+template <typename T, int BM, int BN, int WM, int WN, bool TRANS>
+__global__ void __launch_bounds__(WM* WN * 64) gemm_nt_kernel(const GemmArgs p) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int FM = TM / 16, FN = TN / 16;
+    constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
+    constexpr int BK = 8 * EPC;                // elements per 128-byte K-slab
+    constexpr int RPP = NT / 8;                // rows staged per pass (8 chunks per row)
+    constexpr int A_IT = BM / RPP, B_IT = BN / RPP;
+    constexpr int BUF = (BM + BN) * 128;
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
+    static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile must be made of 16x16 blocks");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (wg / tiles_n) * BM;
+    const int n0 = (wg % tiles_n) * BN;
+
+    const T* __restrict__ A = reinterpret_cast<const T*>(p.A);
+    const T* __restrict__ B = reinterpret_cast<const T*>(p.B);
+
+    // ---- staging geometry: thread -> (row r0 + i*RPP, chunk kc) ----
+    const int kc = tid & 7;
+    const int r0 = tid >> 3;
+    const int st_off = (r0 * 128) + ((kc ^ (r0 & 7)) << 4);   // (row & 7) is the same for every pass (RPP % 8 == 0)
+    u32x4 ra[A_IT], rb[B_IT];
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+    const int nk = (p.K + BK - 1) / BK;
+
+#define MLPK_GLOAD(kt)                                                                           \
+    {                                                                                            \
+        const int k__ = (kt)*BK + kc * EPC;                                                      \
+        const bool kok__ = k__ < p.K;                                                            \
+        _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                       \
+            const int gm = m0 + r0 + i * RPP;                                                    \
+            ra[i] = (kok__ && gm < p.M)                                                          \
+                        ? *reinterpret_cast<const u32x4*>(A + (size_t)gm * p.lda + k__)          \
+                        : zero4;                                                                 \
+        }                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < B_IT; ++i) {                                       \
+            const int gn = n0 + r0 + i * RPP;                                                    \
+            rb[i] = (kok__ && gn < p.N)                                                          \
+                        ? *reinterpret_cast<const u32x4*>(B + (size_t)gn * p.ldb + k__)          \
+                        : zero4;                                                                 \
+        }                                                                                        \
+    }
+#define MLPK_SSTORE(buf)                                                                         \
+    {                                                                                            \
+        char* base__ = smem + (buf)*BUF + st_off;                                                \
+        _Pragma("unroll") for (int i = 0; i < A_IT; ++i)                                         \
+            *reinterpret_cast<u32x4*>(base__ + i * (RPP * 128)) = ra[i];                         \
+        _Pragma("unroll") for (int i = 0; i < B_IT; ++i)                                         \
+            *reinterpret_cast<u32x4*>(base__ + BM * 128 + i * (RPP * 128)) = rb[i];              \
+    }
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets: row = (wave sub-tile) + 16*block + (lane & 15); (row & 7) == (lane & 7)
+    const int frow = lane & 15;
+    const int fg = lane >> 4;
+    const int sw = lane & 7;
+    const int a_rd = (wm * TM + frow) * 128;
+    const int b_rd = BM * 128 + (wn * TN + frow) * 128;
+    const int c_off0 = ((fg ^ sw)) << 4;        // K sub-step 0: chunk = fg
+    const int c_off1 = ((fg ^ sw) ^ 4) << 4;    // K sub-step 1: chunk = 4 + fg
+
+    MLPK_GLOAD(0);
+    MLPK_SSTORE(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = (kt + 1) < nk;
+        if (more) MLPK_GLOAD(kt + 1);
+        const char* buf = smem + (kt & 1) * BUF;
+        const int krem = p.K - kt * BK;            // wave-uniform: skip the all-zero half of a ragged last slab
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if (kk == 1 && krem <= BK / 2) break;
+            const int co = kk ? c_off1 : c_off0;
+            u32x4 af[FM], bf[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const u32x4*>(buf + a_rd + i * 2048 + co);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) bf[j] = *reinterpret_cast<const u32x4*>(buf + b_rd + j * 2048 + co);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = TRANS ? Mma<T>::run(af[i], bf[j], acc[i][j]) : Mma<T>::run(bf[j], af[i], acc[i][j]);
+        }
+        if (more) MLPK_SSTORE((kt + 1) & 1);
+        __syncthreads();
+    }
+#undef MLPK_GLOAD
+#undef MLPK_SSTORE
+
+    // ------------------------------- epilogue -------------------------------
+    T* __restrict__ C = reinterpret_cast<T*>(p.C);
+    const T* R = reinterpret_cast<const T*>(p.R);
+    const bool gelu = p.act == MLPK_ACT_GELU;
+
+    if constexpr (!TRANS) {
+        // lane owns row m = .. + (lane & 15) and 4 consecutive columns n = .. + 4*(lane >> 4) + r
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = m0 + wm * TM + i * 16 + frow;
+            if (m >= p.M) continue;
+            const float rs = p.rscale ? p.rscale[m % p.rperiod] : 1.0f;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int nb = n0 + wn * TN + j * 16 + 4 * fg;
+                if (nb >= p.N) continue;
+                const bool full = nb + 3 < p.N;
+                float v[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = (nb + r < p.N) ? nb + r : p.N - 1;
+                    float t = v[r];
+                    if (p.bias) t += p.bias[n];
+                    if (gelu) t = gelu_f(t);
+                    if (p.cscale) t *= p.cscale[n];
+                    if (p.cshift) t += p.cshift[n];
+                    v[r] = t * rs;
+                }
+                const size_t co = (size_t)m * p.ldc + nb;
+                if (full) {
+                    if (p.res_mode != MLPK_RES_NONE) {
+                        float rv[4];
+                        load4<T>(R + (size_t)m * p.ldr + nb, p.vec_r != 0, rv);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = (p.res_mode == MLPK_RES_ADD) ? v[r] + rv[r] : v[r] * rv[r];
+                    }
+                    store4<T>(C + co, p.vec_c != 0, v);
+                } else {
+                    for (int r = 0; r < 4 && nb + r < p.N; ++r) {
+                        float t = v[r];
+                        if (p.res_mode != MLPK_RES_NONE) {
+                            const float rv = to_f32(R[(size_t)m * p.ldr + nb + r]);
+                            t = (p.res_mode == MLPK_RES_ADD) ? t + rv : t * rv;
+                        }
+                        C[co + r] = from_f32<T>(t);
+                    }
+                }
+            }
+        }
+    } else {
+        // token-transposed output: lane owns token n = .. + (lane & 15) and 4 consecutive rows
+        // m = .. + 4*(lane >> 4) + r, i.e. 4 consecutive channels of one image (t_rows % 4 == 0).
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = n0 + wn * TN + j * 16 + frow;
+            if (n >= p.N) continue;
+            const float bn = p.bias ? p.bias[n] : 0.0f;
+            const float cs = p.cscale ? p.cscale[n] : 1.0f;
+            const float ch = p.cshift ? p.cshift[n] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int mb = m0 + wm * TM + i * 16 + 4 * fg;
+                if (mb >= p.M) continue;     // M % 4 == 0 for TOKEN_T, so the 4 rows are all valid
+                const int img = mb / p.t_rows;
+                const int c = mb - img * p.t_rows;
+                float v[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = v[r] + bn;
+                    if (gelu) t = gelu_f(t);
+                    t = t * cs + ch;
+                    if (p.rscale) t *= p.rscale[(c + r) % p.rperiod];
+                    v[r] = t;
+                }
+                const size_t row = (size_t)img * p.t_tokens + n;
+                if (p.res_mode != MLPK_RES_NONE) {
+                    float rv[4];
+                    load4<T>(R + row * p.ldr + c, p.vec_r != 0, rv);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (p.res_mode == MLPK_RES_ADD) ? v[r] + rv[r] : v[r] * rv[r];
+                }
+                store4<T>(C + row * p.ldc + c, p.vec_c != 0, v);
+            }
+        }
+    }
+}
+
+// ------------------------------- host-side dispatch -------------------------------
+struct TileCfg { int bm, bn, wm, wn; };
+static const TileCfg kTiles[] = {
+    {256, 256, 2, 4},   // algo 1: 8 waves, 128 KiB LDS, 1 workgroup / CU
+    {256, 128, 4, 2},   // algo 2: 8 waves,  96 KiB
+    {128, 256, 2, 4},   // algo 3: 8 waves,  96 KiB
+    {128, 128, 2, 2},   // algo 4: 4 waves,  64 KiB, 2 workgroups / CU
+    {64, 64, 2, 2},     // algo 5: 4 waves,  32 KiB, small problems
+};
+static const int kNumTiles = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
+
+template <typename T, int BM, int BN, int WM, int WN>
+static int launch_cfg(const GemmArgs& a, bool trans, hipStream_t stream) {
+    const int lds = 2 * (BM + BN) * 128;
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    hipError_t e;
+    if (trans) {
+        auto k = gemm_nt_kernel<T, BM, BN, WM, WN, true>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(k, dim3(tiles), dim3(WM * WN * 64), lds, stream, a);
+    } else {
+        auto k = gemm_nt_kernel<T, BM, BN, WM, WN, false>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(k, dim3(tiles), dim3(WM * WN * 64), lds, stream, a);
+    }
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T> static int launch_algo(int algo, const GemmArgs& a, bool trans, hipStream_t s) {
+    switch (algo) {
+        case 1: return launch_cfg<T, 256, 256, 2, 4>(a, trans, s);
+        case 2: return launch_cfg<T, 256, 128, 4, 2>(a, trans, s);
+        case 3: return launch_cfg<T, 128, 256, 2, 4>(a, trans, s);
+        case 4: return launch_cfg<T, 128, 128, 2, 2>(a, trans, s);
+        case 5: return launch_cfg<T, 64, 64, 2, 2>(a, trans, s);
+        default: return MLPK_EMODE;
+    }
+}
+
+// Pick the tile that minimises (padded MFMA work) x (wave-quantisation of the grid over 256 CUs).
+static int auto_algo(int M, int N) {
+    double best = 1e300;
+    int best_algo = 4;
+    for (int i = 0; i < kNumTiles; ++i) {
+        const TileCfg& t = kTiles[i];
+        const double tm = (double)((M + t.bm - 1) / t.bm), tn = (double)((N + t.bn - 1) / t.bn);
+        const double tiles = tm * tn;
+        const int wg_per_cu = (t.bm + t.bn) * 256 <= 80 * 1024 ? 2 : 1;
+        const double slots = 256.0 * wg_per_cu;
+        const double rounds = __builtin_ceil(tiles / slots);
+        // time ~ rounds * work per tile / per-CU rate; smaller tiles run at a lower MFMA efficiency
+        const double eff = (t.bm * t.bn >= 256 * 256) ? 1.0 : (t.bm * t.bn >= 256 * 128) ? 0.92 : (t.bm * t.bn >= 128 * 128) ? 0.80 : 0.45;
+        const double cost = rounds * (double)t.bm * t.bn / wg_per_cu / eff;
+        if (cost < best) { best = cost; best_algo = i + 1; }
+    }
+    return best_algo;
+}
+
+}  // namespace mlpk
+
+using namespace mlpk;
+
+extern "C" int mlpk_gemm_algo_count(void) { return kNumTiles; }
+
+extern "C" int mlpk_gemm_algo_info(int algo, int* bm, int* bn, int* threads, int* lds_bytes) {
+    if (algo < 1 || algo > kNumTiles) return MLPK_EMODE;
+    const TileCfg& t = kTiles[algo - 1];
+    if (bm) *bm = t.bm;
+    if (bn) *bn = t.bn;
+    if (threads) *threads = t.wm * t.wn * 64;
+    if (lds_bytes) *lds_bytes = 2 * (t.bm + t.bn) * 128;
+    return 0;
+}
+
+extern "C" int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream) {
+    if (!d) return MLPK_ENULL;
+    if (!d->A || !d->B || !d->C) return MLPK_ENULL;
+    if (d->dtype != MLPK_F32 && d->dtype != MLPK_F16 && d->dtype != MLPK_BF16) return MLPK_EDTYPE;
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0) return MLPK_ESHAPE;
+    const int es = d->dtype == MLPK_F32 ? 4 : 2;
+    const int epc = 16 / es;
+    if (d->K % epc || d->lda % epc || d->ldb % epc || d->lda < d->K || d->ldb < d->K) return MLPK_ESHAPE;
+    if (((uintptr_t)d->A & 15) || ((uintptr_t)d->B & 15)) return MLPK_EALIGN;
+    if (d->act != MLPK_ACT_NONE && d->act != MLPK_ACT_GELU) return MLPK_EMODE;
+    if (d->res_mode < MLPK_RES_NONE || d->res_mode > MLPK_RES_MUL) return MLPK_EMODE;
+    if (d->res_mode != MLPK_RES_NONE && !d->R) return MLPK_ENULL;
+    if (d->out_mode != MLPK_OUT_ROWMAJOR && d->out_mode != MLPK_OUT_TOKEN_T) return MLPK_EMODE;
+    if (d->rscale && d->rperiod <= 0) return MLPK_ESHAPE;
+    const bool trans = d->out_mode == MLPK_OUT_TOKEN_T;
+    if (trans) {
+        if (d->t_rows <= 0 || d->t_tokens <= 0 || d->t_rows % 4 || d->M % d->t_rows || d->N > d->t_tokens) return MLPK_ESHAPE;
+        if (d->ldc < d->t_rows) return MLPK_ESHAPE;
+    } else if (d->ldc < d->N) {
+        return MLPK_ESHAPE;
+    }
+    GemmArgs a;
+    a.A = d->A; a.B = d->B; a.C = d->C; a.R = d->R;
+    a.bias = d->bias; a.cscale = d->cscale; a.cshift = d->cshift; a.rscale = d->rscale;
+    a.M = d->M; a.N = d->N; a.K = d->K;
+    a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc; a.ldr = d->ldr;
+    a.rperiod = d->rperiod > 0 ? d->rperiod : 1;
+    a.act = d->act; a.res_mode = d->res_mode;
+    a.t_rows = d->t_rows; a.t_tokens = d->t_tokens;
+    const int vb = 4 * es;   // bytes of a 4-element vector
+    a.vec_c = (d->ldc % 4 == 0) && (((uintptr_t)d->C % vb) == 0);
+    a.vec_r = d->R ? ((d->ldr % 4 == 0) && (((uintptr_t)d->R % vb) == 0)) : 0;
+    int algo = d->algo;
+    if (algo == 0) algo = auto_algo(d->M, d->N);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (d->dtype) {
+        case MLPK_F32: return launch_algo<float>(algo, a, trans, s);
+        case MLPK_F16: return launch_algo<f16_t>(algo, a, trans, s);
+        default: return launch_algo<bf16_t>(algo, a, trans, s);
+    }
+}

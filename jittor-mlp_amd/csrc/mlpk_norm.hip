@@ -1,0 +1,478 @@
+// Row statistics, normalise+affine(+GELU) with the layout change the next GEMM needs, ViP
+// (un)permutes and token mean-pooling.  All of these are HBM-bound: 16-byte vector accesses,
+// rows staged through LDS whenever the output order differs from the input order so that both
+// the global reads and the global writes stay fully coalesced.
+#include "mlpk_common.h"
+
+namespace mlpk {
+
+// ---- 8-element vector access (16 B for bf16/f16, 2 x 16 B for f32) ----------------------------
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]) {
+    if constexpr (sizeof(T) == 4) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(p)[0];
+        const f32x4 b = reinterpret_cast<const f32x4*>(p)[1];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+        const u32x4 t = *reinterpret_cast<const u32x4*>(p);
+        T e[8];
+        __builtin_memcpy(e, &t, 16);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = to_f32(e[i]);
+    }
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]) {
+    if constexpr (sizeof(T) == 4) {
+        reinterpret_cast<f32x4*>(p)[0] = f32x4{v[0], v[1], v[2], v[3]};
+        reinterpret_cast<f32x4*>(p)[1] = f32x4{v[4], v[5], v[6], v[7]};
+    } else {
+        T e[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e[i] = from_f32<T>(v[i]);
+        u32x4 t;
+        __builtin_memcpy(&t, e, 16);
+        *reinterpret_cast<u32x4*>(p) = t;
+    }
+}
+
+// ================================ row statistics ================================
+// TPR threads per row (64 = one wave per row, 256 = one workgroup per row).  Two passes over the
+// row (the second one is served by L1/L2): mean, then centred sum of squares -- no E[x^2]-mu^2
+// cancellation, which matters for the fp32 1e-5 parity gate.
+template <typename T, int TPR>
+__global__ void __launch_bounds__(256) row_stats_kernel(const T* __restrict__ x, int64_t rows, int64_t len,
+                                                        int64_t ldx, float eps, float* __restrict__ mean,
+                                                        float* __restrict__ rstd, int vec) {
+    __shared__ float red[8];
+    const int tid = threadIdx.x;
+    const int sub = TPR == 64 ? (tid >> 6) : 0;
+    const int t = TPR == 64 ? (tid & 63) : tid;
+    const int64_t row = (int64_t)blockIdx.x * (256 / TPR) + sub;
+    if (TPR == 64 && row >= rows) return;   // whole wave exits together
+    const T* xr = x + row * ldx;
+
+    auto block_sum = [&](float v) -> float {
+        v = wave_sum(v);
+        if constexpr (TPR == 256) {
+            __syncthreads();
+            if ((tid & 63) == 0) red[tid >> 6] = v;
+            __syncthreads();
+            v = red[0] + red[1] + red[2] + red[3];
+        }
+        return v;
+    };
+
+    float s = 0.f;
+    if (vec) {
+        for (int64_t i = (int64_t)t * 8; i < len; i += TPR * 8) {
+            float v[8];
+            load8<T>(xr + i, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[e];
+        }
+    } else {
+        for (int64_t i = t; i < len; i += TPR) s += to_f32(xr[i]);
+    }
+    const float mu = block_sum(s) / (float)len;
+    float q = 0.f;
+    if (vec) {
+        for (int64_t i = (int64_t)t * 8; i < len; i += TPR * 8) {
+            float v[8];
+            load8<T>(xr + i, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[e] - mu; q += d * d; }
+        }
+    } else {
+        for (int64_t i = t; i < len; i += TPR) { const float d = to_f32(xr[i]) - mu; q += d * d; }
+    }
+    const float var = block_sum(q) / (float)len;
+    if (t == 0) {
+        mean[row] = mu;
+        rstd[row] = 1.0f / __builtin_sqrtf(var + eps);
+    }
+}
+
+// ================================ norm apply: row-major / token-transposed ================================
+// Tile = 64 rows (tokens of ONE image) x 64 channels, 256 threads, each thread 2 x (8 channels).
+struct NormArgs {
+    const void* x;
+    const float* mean;
+    const float* rstd;
+    const float* gamma;
+    const float* beta;
+    void* out_rm;
+    void* out_tt;
+    int64_t rows;
+    int C, ldx, stat_group, S, ld_rm, ld_tt, act;
+    int s_tiles;   // tiles along the token axis per image
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) norm_apply_tile_kernel(const NormArgs p) {
+    constexpr int PITCH = 64 + 8;                 // elements; keeps 16-byte alignment of every row
+    __shared__ __attribute__((aligned(16))) T tile[64 * PITCH];
+    const int tid = threadIdx.x;
+    const int img = blockIdx.x / p.s_tiles;
+    const int s0 = (blockIdx.x % p.s_tiles) * 64;
+    const int c0 = blockIdx.y * 64;
+    const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+    T* out_rm = reinterpret_cast<T*>(p.out_rm);
+    T* out_tt = reinterpret_cast<T*>(p.out_tt);
+    const int cl = (tid & 7) * 8;                 // channel offset within the tile
+    const int c = c0 + cl;
+    const bool c_ok = c < p.C;                    // C % 8 == 0, so a chunk is all-in or all-out
+    float g[8], b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        g[e] = (c_ok && p.gamma) ? p.gamma[c + e] : 1.0f;
+        b[e] = (c_ok && p.beta) ? p.beta[c + e] : 0.0f;
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int sl = (tid >> 3) + it * 32;
+        const int s = s0 + sl;
+        float v[8];
+        if (s < p.S && c_ok) {
+            const int64_t r = (int64_t)img * p.S + s;
+            load8<T>(x + r * p.ldx + c, v);
+            float mu = 0.f, rs = 1.f;
+            if (p.mean) {
+                const int64_t sr = r / p.stat_group;
+                mu = p.mean[sr];
+                rs = p.rstd[sr];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = (v[e] - mu) * rs * g[e] + b[e];
+                if (p.act == MLPK_ACT_GELU) t = gelu_f(t);
+                v[e] = t;
+            }
+            if (out_rm) store8<T>(out_rm + r * p.ld_rm + c, v);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;   // token padding columns of out_tt are zeros
+        }
+        if (out_tt) store8<T>(&tile[sl * PITCH + cl], v);
+    }
+    if (!out_tt) return;
+    __syncthreads();
+    // transposed write: thread -> (channel cc, 8 consecutive tokens)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = tid + it * 256;           // 0..511 = 64 channels x 8 token chunks
+        const int cc = idx >> 3;
+        const int sc = (idx & 7) * 8;
+        if (c0 + cc >= p.C) continue;
+        if (s0 + sc >= p.ld_tt) continue;         // ld_tt % 8 == 0
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = to_f32(tile[(sc + e) * PITCH + cc]);
+        store8<T>(out_tt + ((int64_t)img * p.C + c0 + cc) * p.ld_tt + s0 + sc, v);
+    }
+}
+
+// ================================ norm apply: ViP rearranges ================================
+// One workgroup per (image, fixed w) [which = 0, all h] or (image, fixed h) [which = 1, all w]:
+// the L x C slab (L = H or W) is staged in LDS in pixel order and written back in (g, l, j)
+// order -- both sides are contiguous runs in global memory.
+struct VipArgs {
+    const void* x;      // (B,H,W,C) pixel stride ldx
+    const float* mean;
+    const float* rstd;
+    const float* gamma;
+    const float* beta;
+    void* out;
+    int B, H, W, C, seg, ldx, ld_p, which, act;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) vip_permute_kernel(const VipArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* slab = reinterpret_cast<T*>(smem_raw);          // [L][C]
+    const int tid = threadIdx.x;
+    const int L = p.which == 0 ? p.H : p.W;            // length of the mixed axis
+    const int O = p.which == 0 ? p.W : p.H;            // the fixed axis
+    const int img = blockIdx.x / O;
+    const int o = blockIdx.x % O;
+    const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+    const int cv = p.C / 8;
+    for (int idx = tid; idx < L * cv; idx += 256) {
+        const int l = idx / cv;
+        const int c = (idx % cv) * 8;
+        const int h = p.which == 0 ? l : o;
+        const int w = p.which == 0 ? o : l;
+        const int64_t r = ((int64_t)img * p.H + h) * p.W + w;
+        float v[8];
+        load8<T>(x + r * p.ldx + c, v);
+        float mu = 0.f, rs = 1.f;
+        if (p.mean) { mu = p.mean[r]; rs = p.rstd[r]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float t = (v[e] - mu) * rs * (p.gamma ? p.gamma[c + e] : 1.0f) + (p.beta ? p.beta[c + e] : 0.0f);
+            if (p.act == MLPK_ACT_GELU) t = gelu_f(t);
+            v[e] = t;
+        }
+        store8<T>(slab + l * p.C + c, v);
+    }
+    __syncthreads();
+    const int G = p.C / p.seg;
+    T* out = reinterpret_cast<T*>(p.out) + ((int64_t)img * O + o) * G * p.ld_p;
+    const int total = G * p.ld_p;
+    for (int idx = tid; idx < total; idx += 256) {
+        const int g = idx / p.ld_p;
+        const int col = idx - g * p.ld_p;
+        T val = from_f32<T>(0.f);
+        if (col < L * p.seg) {
+            const int l = col / p.seg;
+            const int j = col - l * p.seg;
+            val = slab[l * p.C + g * p.seg + j];
+        }
+        out[idx] = val;
+    }
+}
+
+// inverse rearrange of the GEMM output z back to (B,H,W,C)
+template <typename T>
+__global__ void __launch_bounds__(256) vip_unpermute_kernel(const T* __restrict__ z, T* __restrict__ out, int B, int H,
+                                                            int W, int C, int seg, int ldz, int which) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* slab = reinterpret_cast<T*>(smem_raw);          // [G][L*seg] compact
+    const int tid = threadIdx.x;
+    const int L = which == 0 ? H : W;
+    const int O = which == 0 ? W : H;
+    const int img = blockIdx.x / O;
+    const int o = blockIdx.x % O;
+    const int G = C / seg;
+    const int rowlen = L * seg;
+    const T* zin = z + ((int64_t)img * O + o) * G * ldz;
+    for (int idx = tid; idx < G * rowlen; idx += 256) {
+        const int g = idx / rowlen;
+        const int col = idx - g * rowlen;
+        slab[idx] = zin[(int64_t)g * ldz + col];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < L * C; idx += 256) {
+        const int l = idx / C;
+        const int c = idx - l * C;
+        const int g = c / seg;
+        const int q = c - g * seg;
+        const int h = which == 0 ? l : o;
+        const int w = which == 0 ? o : l;
+        out[(((int64_t)img * H + h) * W + w) * C + c] = slab[g * rowlen + l * seg + q];
+    }
+}
+
+// ================================ mean over tokens ================================
+// workgroup = (image, 64 channels): 32 token rows in flight x 8 lanes x 8 channels.
+template <typename T>
+__global__ void __launch_bounds__(256) pool_mean_kernel(const T* __restrict__ x, int B, int S, int C, int ldx,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        int stat_group, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, T* __restrict__ out, int ldo) {
+    __shared__ float red[32][64 + 1];
+    const int tid = threadIdx.x;
+    const int img = blockIdx.x;
+    const int cl = (tid & 7) * 8;
+    const int c = blockIdx.y * 64 + cl;
+    const int sl = tid >> 3;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (c < C) {
+        for (int s = sl; s < S; s += 32) {
+            const int64_t r = (int64_t)img * S + s;
+            float v[8];
+            load8<T>(x + r * ldx + c, v);
+            float mu = 0.f, rs = 1.f;
+            if (mean) { const int64_t sr = r / stat_group; mu = mean[sr]; rs = rstd[sr]; }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (v[e] - mu) * rs;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[sl][cl + e] = acc[e];
+    __syncthreads();
+    if (tid < 64) {
+        const int cc = blockIdx.y * 64 + tid;
+        if (cc < C) {
+            float s = 0.f;
+#pragma unroll 8
+            for (int i = 0; i < 32; ++i) s += red[i][tid];
+            float y = s / (float)S;
+            if (gamma) y *= gamma[cc];
+            if (beta) y += beta[cc];
+            out[(int64_t)img * ldo + cc] = from_f32<T>(y);
+        }
+    }
+}
+
+template <typename TS, typename TD>
+__global__ void __launch_bounds__(256) convert_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        dst[i] = from_f32<TD>(to_f32(src[i]));
+}
+
+}  // namespace mlpk
+
+using namespace mlpk;
+
+#define DISPATCH_DTYPE(dt, ...)                                              \
+    switch (dt) {                                                            \
+        case MLPK_F32: { typedef float T; __VA_ARGS__; break; }              \
+        case MLPK_F16: { typedef f16_t T; __VA_ARGS__; break; }              \
+        case MLPK_BF16: { typedef bf16_t T; __VA_ARGS__; break; }            \
+        default: return MLPK_EDTYPE;                                         \
+    }
+
+static inline int esize(int dt) { return dt == MLPK_F32 ? 4 : 2; }
+
+extern "C" int mlpk_row_stats(int dtype, const void* x, int64_t rows, int64_t len, int64_t ldx, float eps,
+                              float* mean, float* rstd, void* stream) {
+    if (!x || !mean || !rstd) return MLPK_ENULL;
+    if (rows <= 0 || len <= 0 || ldx < len) return MLPK_ESHAPE;
+    if (dtype < 0 || dtype > 2) return MLPK_EDTYPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int vec = (len % 8 == 0) && (ldx % 8 == 0) && (((uintptr_t)x & 15) == 0);
+    if (len <= 4096) {
+        const unsigned grid = (unsigned)((rows + 3) / 4);
+        DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((row_stats_kernel<T, 64>), dim3(grid), dim3(256), 0, s,
+                                                 (const T*)x, rows, len, ldx, eps, mean, rstd, vec));
+    } else {
+        DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((row_stats_kernel<T, 256>), dim3((unsigned)rows), dim3(256), 0, s,
+                                                 (const T*)x, rows, len, ldx, eps, mean, rstd, vec));
+    }
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mlpk_norm_apply(const mlpk_norm_desc* d, void* stream) {
+    if (!d || !d->x) return MLPK_ENULL;
+    if (d->dtype < 0 || d->dtype > 2) return MLPK_EDTYPE;
+    if (d->rows <= 0 || d->C <= 0 || d->C % 8 || d->ldx % 8 || d->ldx < d->C) return MLPK_ESHAPE;
+    if ((d->mean == nullptr) != (d->rstd == nullptr)) return MLPK_ENULL;
+    if (d->act != MLPK_ACT_NONE && d->act != MLPK_ACT_GELU) return MLPK_EMODE;
+    if ((uintptr_t)d->x & 15) return MLPK_EALIGN;
+    const int sg = d->stat_group > 0 ? d->stat_group : 1;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (d->out_rm || d->out_tt) {
+        NormArgs a;
+        a.x = d->x; a.mean = d->mean; a.rstd = d->rstd; a.gamma = d->gamma; a.beta = d->beta;
+        a.out_rm = d->out_rm; a.out_tt = d->out_tt; a.rows = d->rows; a.C = d->C; a.ldx = d->ldx;
+        a.stat_group = sg; a.act = d->act; a.ld_rm = d->ld_rm; a.ld_tt = d->ld_tt;
+        if (d->out_rm && (d->ld_rm % 8 || d->ld_rm < d->C || ((uintptr_t)d->out_rm & 15))) return MLPK_ESHAPE;
+        int S = d->S, nimg;
+        if (d->out_tt) {
+            if (S <= 0 || d->rows % S || d->ld_tt % 8 || d->ld_tt < S || ((uintptr_t)d->out_tt & 15)) return MLPK_ESHAPE;
+            nimg = (int)(d->rows / S);
+            a.s_tiles = (d->ld_tt + 63) / 64;
+        } else {
+            // no transposed output: treat all rows as one "image" so tiles simply walk the rows
+            if (d->rows > 0x7fffffffLL) return MLPK_ESHAPE;
+            S = (int)d->rows;
+            nimg = 1;
+            a.s_tiles = (S + 63) / 64;
+        }
+        a.S = S;
+        const dim3 grid((unsigned)(nimg * a.s_tiles), (unsigned)((d->C + 63) / 64));
+        DISPATCH_DTYPE(d->dtype, hipLaunchKernelGGL((norm_apply_tile_kernel<T>), grid, dim3(256), 0, s, a));
+        MLPK_LAUNCH_CHECK();
+    }
+    for (int which = 0; which < 2; ++which) {
+        void* out = which == 0 ? d->out_ph : d->out_pw;
+        if (!out) continue;
+        if (d->H <= 0 || d->W <= 0 || d->seg <= 0 || d->C % d->seg) return MLPK_ESHAPE;
+        if (d->rows % ((int64_t)d->H * d->W)) return MLPK_ESHAPE;
+        const int L = which == 0 ? d->H : d->W;
+        if (d->ld_p < L * d->seg) return MLPK_ESHAPE;
+        if (sg != 1) return MLPK_EMODE;
+        VipArgs a;
+        a.x = d->x; a.mean = d->mean; a.rstd = d->rstd; a.gamma = d->gamma; a.beta = d->beta; a.out = out;
+        a.B = (int)(d->rows / ((int64_t)d->H * d->W)); a.H = d->H; a.W = d->W; a.C = d->C; a.seg = d->seg;
+        a.ldx = d->ldx; a.ld_p = d->ld_p; a.which = which; a.act = d->act;
+        const size_t lds = (size_t)L * d->C * esize(d->dtype);
+        if (lds > 160 * 1024) return MLPK_ESHAPE;
+        const unsigned grid = (unsigned)(a.B * (which == 0 ? d->W : d->H));
+        DISPATCH_DTYPE(d->dtype, {
+            auto k = vip_permute_kernel<T>;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, a);
+        });
+        MLPK_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int mlpk_vip_unpermute(int dtype, int which, const void* z, void* out, int B, int H, int W, int C,
+                                  int seg, int ldz, void* stream) {
+    if (!z || !out) return MLPK_ENULL;
+    if (which != 0 && which != 1) return MLPK_EMODE;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || seg <= 0 || C % seg) return MLPK_ESHAPE;
+    const int L = which == 0 ? H : W;
+    if (ldz < L * seg) return MLPK_ESHAPE;
+    const size_t lds = (size_t)L * C * esize(dtype);
+    if (lds > 160 * 1024) return MLPK_ESHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const unsigned grid = (unsigned)(B * (which == 0 ? W : H));
+    DISPATCH_DTYPE(dtype, {
+        auto k = vip_unpermute_kernel<T>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, (const T*)z, (T*)out, B, H, W, C, seg, ldz, which);
+    });
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mlpk_pool_mean(int dtype, const void* x, int B, int S, int C, int ldx, const float* mean,
+                              const float* rstd, int stat_group, const float* gamma, const float* beta,
+                              void* out, int ldo, void* stream) {
+    if (!x || !out) return MLPK_ENULL;
+    if (B <= 0 || S <= 0 || C <= 0 || C % 8 || ldx % 8 || ldx < C || ldo < C) return MLPK_ESHAPE;
+    if ((mean == nullptr) != (rstd == nullptr)) return MLPK_ENULL;
+    if ((uintptr_t)x & 15) return MLPK_EALIGN;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)B, (unsigned)((C + 63) / 64));
+    const int sg = stat_group > 0 ? stat_group : 1;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pool_mean_kernel<T>), grid, dim3(256), 0, s, (const T*)x, B, S, C, ldx,
+                                             mean, rstd, sg, gamma, beta, (T*)out, ldo));
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename TS> static int convert_from(int dst_dtype, const void* src, void* dst, int64_t n, hipStream_t s) {
+    const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    switch (dst_dtype) {
+        case MLPK_F32: hipLaunchKernelGGL((convert_kernel<TS, float>), dim3(grid), dim3(256), 0, s, (const TS*)src, (float*)dst, n); break;
+        case MLPK_F16: hipLaunchKernelGGL((convert_kernel<TS, f16_t>), dim3(grid), dim3(256), 0, s, (const TS*)src, (f16_t*)dst, n); break;
+        case MLPK_BF16: hipLaunchKernelGGL((convert_kernel<TS, bf16_t>), dim3(grid), dim3(256), 0, s, (const TS*)src, (bf16_t*)dst, n); break;
+        default: return MLPK_EDTYPE;
+    }
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mlpk_convert(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream) {
+    if (!src || !dst) return MLPK_ENULL;
+    if (n <= 0) return MLPK_ESHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (src_dtype) {
+        case MLPK_F32: return convert_from<float>(dst_dtype, src, dst, n, s);
+        case MLPK_F16: return convert_from<f16_t>(dst_dtype, src, dst, n, s);
+        case MLPK_BF16: return convert_from<bf16_t>(dst_dtype, src, dst, n, s);
+        default: return MLPK_EDTYPE;
+    }
+}
+
+extern "C" int mlpk_abi_version(void) { return 1; }
+
+extern "C" const char* mlpk_strerror(int code) {
+    switch (code) {
+        case MLPK_OK: return "ok";
+        case MLPK_EDTYPE: return "mlpk: unknown dtype";
+        case MLPK_ESHAPE: return "mlpk: size/stride violates a documented constraint";
+        case MLPK_EALIGN: return "mlpk: pointer not 16-byte aligned";
+        case MLPK_ENULL: return "mlpk: required pointer is NULL";
+        case MLPK_EMODE: return "mlpk: unknown mode/flag";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "mlpk: unknown error";
+    }
+}

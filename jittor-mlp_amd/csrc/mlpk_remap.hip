@@ -1,0 +1,364 @@
+// Index remaps and the reductions around them: AS-MLP axial shift (the reference's one native
+// op), S2-MLP spatial shifts, split attention (ViP / S2-MLPv2) and the ConvMixer depthwise half.
+// All channel-last kernels put the 64 lanes of a wave on 64 consecutive channels, so every
+// global access is a contiguous 128/256-byte run whatever the spatial gather does; none of the
+// shifts is ever materialised as a tensor except where the reference's API returns one.
+#include "mlpk_common.h"
+
+namespace mlpk {
+
+// ================================ AS-MLP axial shift ================================
+// shift_cuda.py:44-72: group = ceil(C/k), g = c / group, s = k/2 - g, zero fill.
+template <typename T>
+__global__ void __launch_bounds__(256) shift_nchw_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int C,
+                                                         int H, int W, int ksz, int dim) {
+    const int64_t total = (int64_t)N * C * H * W;
+    const int group = (C + ksz - 1) / ksz;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int w = (int)(idx % W);
+        const int h = (int)((idx / W) % H);
+        const int c = (int)((idx / ((int64_t)W * H)) % C);
+        const int s = ksz / 2 - c / group;
+        T v = from_f32<T>(0.f);
+        if (dim == 2) {
+            if (h + s >= 0 && h + s < H) v = in[idx + (int64_t)s * W];
+        } else {
+            if (w + s >= 0 && w + s < W) v = in[idx + s];
+        }
+        out[idx] = v;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) shift_nhwc_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H,
+                                                         int W, int C, int ksz, int dim) {
+    const int64_t total = (int64_t)N * H * W * C;
+    const int group = (C + ksz - 1) / ksz;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        const int w = (int)((idx / C) % W);
+        const int h = (int)((idx / ((int64_t)C * W)) % H);
+        const int s = ksz / 2 - c / group;
+        T v = from_f32<T>(0.f);
+        if (dim == 2) {
+            if (h + s >= 0 && h + s < H) v = in[idx + (int64_t)s * W * C];
+        } else {
+            if (w + s >= 0 && w + s < W) v = in[idx + (int64_t)s * C];
+        }
+        out[idx] = v;
+    }
+}
+
+// ================================ S2 spatial shifts ================================
+// Tensor (B, D1, D2, C).  Channel quarters as the slices of s2_mlp_v2.py:17-20.
+// which = 1: spatial_shift1 -> (d1,+1),(d1,-1),(d2,+1),(d2,-1); which = 2: spatial_shift2 ->
+// (d2,+1),(d2,-1),(d1,+1),(d1,-1).  "+1": y[i] = x[i-1] (border keeps x[0]); the reference's
+// in-place assignment makes that y[i] = x[0] for all i (MLPK_SHIFT_S2_REF).  "-1": y[i] = x[min(i+1,n-1)].
+__device__ __forceinline__ void s2_source(int which, int mode, int c, int C, int i1, int i2, int D1, int D2, int& j1,
+                                          int& j2) {
+    j1 = i1;
+    j2 = i2;
+    if (mode == MLPK_SHIFT_NONE || which == 0) return;
+    int q;
+    if (c < C / 4) q = 0;
+    else if (c < C / 2) q = 1;
+    else if (c < C * 3 / 4) q = 2;
+    else q = 3;
+    const bool plus = (q & 1) == 0;
+    const bool axis1 = which == 1 ? (q < 2) : (q >= 2);
+    if (axis1) {
+        if (plus) j1 = mode == MLPK_SHIFT_S2_REF ? 0 : (i1 > 0 ? i1 - 1 : 0);
+        else j1 = i1 + 1 < D1 ? i1 + 1 : D1 - 1;
+    } else {
+        if (plus) j2 = mode == MLPK_SHIFT_S2_REF ? 0 : (i2 > 0 ? i2 - 1 : 0);
+        else j2 = i2 + 1 < D2 ? i2 + 1 : D2 - 1;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) s2_shift_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int D1,
+                                                       int D2, int C, int ldi, int ldo, int mode) {
+    const int64_t total = (int64_t)B * D1 * D2 * C;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        const int64_t px = idx / C;
+        const int i2 = (int)(px % D2);
+        const int i1 = (int)((px / D2) % D1);
+        const int64_t b = px / ((int64_t)D1 * D2);
+        int j1, j2;
+        s2_source(1, mode, c, C, i1, i2, D1, D2, j1, j2);
+        out[px * ldo + c] = in[((b * D1 + j1) * D2 + j2) * ldi + c];
+    }
+}
+
+// ================================ split attention ================================
+struct SplitArgs {
+    const void* x0;
+    const void* x1;
+    const void* x2;
+    int ld0, ld1, ld2;
+    int B, D1, D2, C, mode;
+};
+
+// a[b,c] = sum over the three branches and all pixels; workgroup = (image, 64 channels),
+// 4 pixel phases x 64 channel lanes, fp32 accumulation.
+template <typename T>
+__global__ void __launch_bounds__(256) split_sum_kernel(const SplitArgs p, float* __restrict__ a) {
+    __shared__ float red[4][64];
+    const int tid = threadIdx.x;
+    const int cl = tid & 63;
+    const int ph = tid >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    const int b = blockIdx.x;
+    const T* x0 = reinterpret_cast<const T*>(p.x0);
+    const T* x1 = reinterpret_cast<const T*>(p.x1);
+    const T* x2 = reinterpret_cast<const T*>(p.x2);
+    float s = 0.f;
+    if (c < p.C) {
+        const int npx = p.D1 * p.D2;
+        for (int px = ph; px < npx; px += 4) {
+            const int i1 = px / p.D2, i2 = px - i1 * p.D2;
+            int j1, j2;
+            s2_source(1, p.mode, c, p.C, i1, i2, p.D1, p.D2, j1, j2);
+            s += to_f32(x0[(((int64_t)b * p.D1 + j1) * p.D2 + j2) * p.ld0 + c]);
+            s2_source(2, p.mode, c, p.C, i1, i2, p.D1, p.D2, j1, j2);
+            s += to_f32(x1[(((int64_t)b * p.D1 + j1) * p.D2 + j2) * p.ld1 + c]);
+            s += to_f32(x2[(((int64_t)b * p.D1 + i1) * p.D2 + i2) * p.ld2 + c]);
+        }
+    }
+    red[ph][cl] = s;
+    __syncthreads();
+    if (tid < 64 && c < p.C) a[(int64_t)b * p.C + c] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+__global__ void __launch_bounds__(256) split_softmax_kernel(const float* __restrict__ hat, float* __restrict__ bar,
+                                                            int B, int C) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * C) return;
+    const int b = idx / C, c = idx - b * C;
+    const float* h = hat + (int64_t)b * 3 * C;
+    const float h0 = h[c], h1 = h[C + c], h2 = h[2 * C + c];
+    const float m = fmaxf(h0, fmaxf(h1, h2));
+    const float e0 = __expf(h0 - m), e1 = __expf(h1 - m), e2 = __expf(h2 - m);
+    const float inv = 1.0f / (e0 + e1 + e2);
+    float* o = bar + (int64_t)b * 3 * C;
+    o[c] = e0 * inv;
+    o[C + c] = e1 * inv;
+    o[2 * C + c] = e2 * inv;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) split_apply_kernel(const SplitArgs p, const float* __restrict__ bar,
+                                                          T* __restrict__ out, int ldo) {
+    const T* x0 = reinterpret_cast<const T*>(p.x0);
+    const T* x1 = reinterpret_cast<const T*>(p.x1);
+    const T* x2 = reinterpret_cast<const T*>(p.x2);
+    const int64_t total = (int64_t)p.B * p.D1 * p.D2 * p.C;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c = (int)(idx % p.C);
+        const int64_t px = idx / p.C;
+        const int i2 = (int)(px % p.D2);
+        const int i1 = (int)((px / p.D2) % p.D1);
+        const int64_t b = px / ((int64_t)p.D1 * p.D2);
+        const float* w = bar + b * 3 * p.C;
+        int j1, j2;
+        s2_source(1, p.mode, c, p.C, i1, i2, p.D1, p.D2, j1, j2);
+        float v = w[c] * to_f32(x0[((b * p.D1 + j1) * p.D2 + j2) * p.ld0 + c]);
+        s2_source(2, p.mode, c, p.C, i1, i2, p.D1, p.D2, j1, j2);
+        v += w[p.C + c] * to_f32(x1[((b * p.D1 + j1) * p.D2 + j2) * p.ld1 + c]);
+        v += w[2 * p.C + c] * to_f32(x2[px * p.ld2 + c]);
+        out[px * ldo + c] = from_f32<T>(v);
+    }
+}
+
+// ================================ ConvMixer depthwise half ================================
+// thread = (image, row y, strip of 8 outputs along x, channel c); the k*k taps of channel c and a
+// sliding (8 + k - 1)-wide input window live in registers, lanes run along c (coalesced).
+template <typename T, int KS>
+__global__ void __launch_bounds__(256) dwconv_nhwc_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int H,
+                                                          int W, int C, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, const float* __restrict__ bns,
+                                                          const float* __restrict__ bnh) {
+    constexpr int P = (KS - 1) / 2;
+    constexpr int STRIP = 8;
+    const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+    const int strips = (W + STRIP - 1) / STRIP;
+    const int64_t job = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);    // (b, y, strip)
+    const int64_t njobs = (int64_t)B * H * strips;
+    if (c >= C || job >= njobs) return;
+    const int st = (int)(job % strips);
+    const int y = (int)((job / strips) % H);
+    const int64_t b = job / ((int64_t)strips * H);
+    const int x0 = st * STRIP;
+    float wt[KS * KS];
+#pragma unroll
+    for (int t = 0; t < KS * KS; ++t) wt[t] = w[(int64_t)t * C + c];
+    float acc[STRIP];
+    const float bs = bias ? bias[c] : 0.f;
+#pragma unroll
+    for (int o = 0; o < STRIP; ++o) acc[o] = bs;
+#pragma unroll
+    for (int dy = 0; dy < KS; ++dy) {
+        const int yy = y + dy - P;
+        if (yy < 0 || yy >= H) continue;
+        float win[STRIP + KS - 1];
+#pragma unroll
+        for (int t = 0; t < STRIP + KS - 1; ++t) {
+            const int xx = x0 + t - P;
+            win[t] = (xx >= 0 && xx < W) ? to_f32(x[(((b * H + yy) * W) + xx) * C + c]) : 0.f;
+        }
+#pragma unroll
+        for (int dx = 0; dx < KS; ++dx)
+#pragma unroll
+            for (int o = 0; o < STRIP; ++o) acc[o] = __builtin_fmaf(wt[dy * KS + dx], win[o + dx], acc[o]);
+    }
+    const float sc = bns ? bns[c] : 1.f, sh = bnh ? bnh[c] : 0.f;
+#pragma unroll
+    for (int o = 0; o < STRIP; ++o) {
+        const int xx = x0 + o;
+        if (xx >= W) break;
+        const int64_t i = (((b * H + y) * W) + xx) * C + c;
+        out[i] = from_f32<T>(to_f32(x[i]) + gelu_f(acc[o]) * sc + sh);
+    }
+}
+
+}  // namespace mlpk
+
+using namespace mlpk;
+
+#define DISPATCH_DTYPE(dt, ...)                                              \
+    switch (dt) {                                                            \
+        case MLPK_F32: { typedef float T; __VA_ARGS__; break; }              \
+        case MLPK_F16: { typedef f16_t T; __VA_ARGS__; break; }              \
+        case MLPK_BF16: { typedef bf16_t T; __VA_ARGS__; break; }            \
+        default: return MLPK_EDTYPE;                                         \
+    }
+
+static inline unsigned grid_for(int64_t total) {
+    const int64_t g = (total + 255) / 256;
+    return (unsigned)(g < 32768 ? g : 32768);
+}
+
+static int shift_check(int ksz, int dim) {
+    // shift_cuda.py:167-168 / 184-185: odd kernel >= 3, dim in {2,3}
+    if (ksz < 3 || (ksz & 1) == 0) return MLPK_ESHAPE;
+    if (dim != 2 && dim != 3) return MLPK_EMODE;
+    return 0;
+}
+
+extern "C" int mlpk_shift_nchw(int dtype, const void* in, void* out, int N, int C, int H, int W, int kernel_size,
+                               int dim, void* stream) {
+    if (!in || !out) return MLPK_ENULL;
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return MLPK_ESHAPE;
+    if (int e = shift_check(kernel_size, dim)) return e;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t total = (int64_t)N * C * H * W;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((shift_nchw_kernel<T>), dim3(grid_for(total)), dim3(256), 0, s,
+                                             (const T*)in, (T*)out, N, C, H, W, kernel_size, dim));
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mlpk_shift_nhwc(int dtype, const void* in, void* out, int N, int H, int W, int C, int kernel_size,
+                               int dim, void* stream) {
+    if (!in || !out) return MLPK_ENULL;
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return MLPK_ESHAPE;
+    if (int e = shift_check(kernel_size, dim)) return e;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t total = (int64_t)N * C * H * W;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((shift_nhwc_kernel<T>), dim3(grid_for(total)), dim3(256), 0, s,
+                                             (const T*)in, (T*)out, N, H, W, C, kernel_size, dim));
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+static int split_check(const void* x0, const void* x1, const void* x2, int ld0, int ld1, int ld2, int B, int H, int W,
+                       int C, int mode) {
+    if (!x0 || !x1 || !x2) return MLPK_ENULL;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || ld0 < C || ld1 < C || ld2 < C) return MLPK_ESHAPE;
+    if (mode < MLPK_SHIFT_NONE || mode > MLPK_SHIFT_S2_REF) return MLPK_EMODE;
+    return 0;
+}
+
+extern "C" int mlpk_split_sum(int dtype, const void* x0, const void* x1, const void* x2, int ld0, int ld1, int ld2,
+                              int B, int H, int W, int C, int shift_mode, float* a, void* stream) {
+    if (int e = split_check(x0, x1, x2, ld0, ld1, ld2, B, H, W, C, shift_mode)) return e;
+    if (!a) return MLPK_ENULL;
+    SplitArgs p{x0, x1, x2, ld0, ld1, ld2, B, H, W, C, shift_mode};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)B, (unsigned)((C + 63) / 64));
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((split_sum_kernel<T>), grid, dim3(256), 0, s, p, a));
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mlpk_split_softmax(const float* hat, float* bar, int B, int C, void* stream) {
+    if (!hat || !bar) return MLPK_ENULL;
+    if (B <= 0 || C <= 0) return MLPK_ESHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(split_softmax_kernel, dim3((unsigned)((B * C + 255) / 256)), dim3(256), 0, s, hat, bar, B, C);
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mlpk_split_apply(int dtype, const void* x0, const void* x1, const void* x2, int ld0, int ld1, int ld2,
+                                int B, int H, int W, int C, int shift_mode, const float* bar, void* out, int ldo,
+                                void* stream) {
+    if (int e = split_check(x0, x1, x2, ld0, ld1, ld2, B, H, W, C, shift_mode)) return e;
+    if (!bar || !out) return MLPK_ENULL;
+    if (ldo < C) return MLPK_ESHAPE;
+    SplitArgs p{x0, x1, x2, ld0, ld1, ld2, B, H, W, C, shift_mode};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t total = (int64_t)B * H * W * C;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((split_apply_kernel<T>), dim3(grid_for(total)), dim3(256), 0, s, p, bar,
+                                             (T*)out, ldo));
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mlpk_s2_shift(int dtype, const void* in, void* out, int B, int H, int W, int C, int ldi, int ldo,
+                             int shift_mode, void* stream) {
+    if (!in || !out) return MLPK_ENULL;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || ldi < C || ldo < C) return MLPK_ESHAPE;
+    if (shift_mode < MLPK_SHIFT_NONE || shift_mode > MLPK_SHIFT_S2_REF) return MLPK_EMODE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t total = (int64_t)B * H * W * C;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((s2_shift_kernel<T>), dim3(grid_for(total)), dim3(256), 0, s, (const T*)in,
+                                             (T*)out, B, H, W, C, ldi, ldo, shift_mode));
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+static int dwconv_launch(int k, const void* x, void* out, int B, int H, int W, int C, const float* w, const float* bias,
+                         const float* bns, const float* bnh, hipStream_t s) {
+    const int strips = (W + 7) / 8;
+    const int64_t njobs = (int64_t)B * H * strips;
+    const dim3 grid((unsigned)((njobs + 3) / 4), (unsigned)((C + 63) / 64));
+#define DW_CASE(KS)                                                                                                   \
+    case KS:                                                                                                          \
+        hipLaunchKernelGGL((dwconv_nhwc_kernel<T, KS>), grid, dim3(256), 0, s, (const T*)x, (T*)out, B, H, W, C, w, bias, \
+                           bns, bnh);                                                                                 \
+        break;
+    switch (k) {
+        DW_CASE(3) DW_CASE(5) DW_CASE(7) DW_CASE(9)
+        default: return MLPK_ESHAPE;
+    }
+#undef DW_CASE
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mlpk_dwconv_nhwc(int dtype, const void* x, void* out, int B, int H, int W, int C, int k, const float* w,
+                                const float* bias, const float* bn_scale, const float* bn_shift, void* stream) {
+    if (!x || !out || !w) return MLPK_ENULL;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return MLPK_ESHAPE;
+    if ((int64_t)B * H * ((W + 7) / 8) / 4 + 1 > 0x7fffffffLL) return MLPK_ESHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case MLPK_F32: return dwconv_launch<float>(k, x, out, B, H, W, C, w, bias, bn_scale, bn_shift, s);
+        case MLPK_F16: return dwconv_launch<f16_t>(k, x, out, B, H, W, C, w, bias, bn_scale, bn_shift, s);
+        case MLPK_BF16: return dwconv_launch<bf16_t>(k, x, out, B, H, W, C, w, bias, bn_scale, bn_shift, s);
+        default: return MLPK_EDTYPE;
+    }
+}

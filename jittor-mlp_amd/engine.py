@@ -1,0 +1,245 @@
+"""Host-side plumbing between torch tensors and the C-ABI kernels (include/mlpk.h).
+
+torch is used for device memory (caching allocator), streams and nothing else: every
+function here hands raw device pointers + sizes to libmlpk.so on torch's current stream,
+exactly like the reference's only native op does (utils/shift_cuda.py:112,122-125).
+There is deliberately no CPU implementation: a non-GPU tensor raises NotImplementedError,
+the same error type the reference's Shift raises on CPU (shift_cuda.py:170-173).
+"""
+import ctypes
+
+import torch
+
+from . import _native as N
+
+DT = {torch.float32: N.F32, torch.float16: N.F16, torch.bfloat16: N.BF16}
+
+
+def dtype_code(dtype):
+    try:
+        return DT[dtype]
+    except KeyError:
+        raise TypeError("unsupported dtype %s (float32, float16, bfloat16 only)" % (dtype,))
+
+
+def require_gpu(x, what="forward"):
+    if not x.is_cuda:
+        raise NotImplementedError("%s: the MI355X path needs a GPU tensor (no CPU implementation; "
+                                  "the CPU oracle lives in oracle/ and is test-only)" % what)
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+# ------------------------------------------------------------------ weight packing
+def pack_matrix(w, dtype, device, kpad=8):
+    """(N, K) weight -> contiguous (N, round_up(K, kpad)) in the compute dtype, zero padded."""
+    w = w.detach().reshape(w.shape[0], -1)
+    n, k = w.shape
+    kp = round_up(k, kpad)
+    out = torch.zeros((n, kp), dtype=dtype, device=device)
+    out[:, :k] = w.to(device=device, dtype=dtype)
+    return out
+
+
+def f32(v, device):
+    """Per-channel vectors always travel as float32."""
+    if v is None:
+        return None
+    return v.detach().to(device=device, dtype=torch.float32).reshape(-1).contiguous()
+
+
+# ------------------------------------------------------------------ kernel wrappers
+class KernelTimer:
+    """Optional HIP-event timing of tagged GEMM launches on the launch stream (bench.py's roofline
+    leg).  Disabled (None) in normal use: zero overhead on the product path."""
+
+    def __init__(self):
+        self.events = {}          # tag -> list of (start, end, flops)
+
+    def summary(self):
+        out = {}
+        for tag, evs in self.events.items():
+            ms = [s.elapsed_time(e) for s, e, _ in evs]
+            out[tag] = {"launches": len(evs), "avg_ms": sum(ms) / len(ms), "flops_per_launch": evs[0][2]}
+        return out
+
+
+TIMER = None
+GEMM_ALGO = {}                    # tag -> forced tile config (tuning/bench hook); default auto
+
+
+def gemm(A, B, C, M, Nn, K, *, lda=None, ldb=None, ldc=None, bias=None, act=N.ACT_NONE, cscale=None, cshift=None,
+         rscale=None, rperiod=0, R=None, ldr=None, res=N.RES_NONE, out_mode=N.OUT_ROWMAJOR, t_rows=0, t_tokens=0,
+         algo=0, tag=None):
+    if tag is not None and algo == 0:
+        algo = GEMM_ALGO.get(tag, 0)
+    timed = TIMER is not None and tag is not None
+    if timed:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    d = N.GemmDesc()
+    d.dtype = dtype_code(A.dtype)
+    d.M, d.N, d.K = M, Nn, K
+    d.lda = lda if lda is not None else A.stride(0)
+    d.ldb = ldb if ldb is not None else B.stride(0)
+    d.ldc = ldc if ldc is not None else C.stride(-2)
+    d.ldr = (ldr if ldr is not None else (R.stride(-2) if R is not None else 0))
+    d.A, d.B, d.C, d.R = ptr(A), ptr(B), ptr(C), ptr(R)
+    d.bias, d.cscale, d.cshift, d.rscale = ptr(bias), ptr(cscale), ptr(cshift), ptr(rscale)
+    d.rperiod, d.act, d.res_mode, d.out_mode = rperiod, act, res, out_mode
+    d.t_rows, d.t_tokens, d.algo = t_rows, t_tokens, algo
+    N.check(N.lib().mlpk_gemm_nt(ctypes.byref(d), stream()), "mlpk_gemm_nt")
+    if timed:
+        ev1.record()
+        TIMER.events.setdefault(tag, []).append((ev0, ev1, 2.0 * M * Nn * K))
+
+
+def patchify(src, out, B, Cin, H, W, ph, pw, pad, ldo, layout=N.LAYOUT_NCHW, px_stride=0, order=0):
+    N.check(N.lib().mlpk_patchify(dtype_code(src.dtype), dtype_code(out.dtype), layout, ptr(src), ptr(out), B, Cin, H, W,
+                                  ph, pw, pad, px_stride, ldo, order, stream()), "mlpk_patchify")
+
+
+def row_stats(x, rows, length, ldx, mean, rstd, eps=1e-5):
+    N.check(N.lib().mlpk_row_stats(dtype_code(x.dtype), ptr(x), rows, length, ldx, eps, ptr(mean), ptr(rstd), stream()),
+            "mlpk_row_stats")
+
+
+def norm_apply(x, rows, C, ldx, *, mean=None, rstd=None, gamma=None, beta=None, act=N.ACT_NONE, stat_group=1,
+               out_rm=None, ld_rm=0, out_tt=None, S=0, ld_tt=0, out_ph=None, out_pw=None, H=0, W=0, seg=0, ld_p=0):
+    d = N.NormDesc()
+    d.dtype, d.act, d.rows, d.C, d.ldx, d.stat_group = dtype_code(x.dtype), act, rows, C, ldx, stat_group
+    d.S, d.H, d.W, d.seg = S, H, W, seg
+    d.ld_rm, d.ld_tt, d.ld_p = ld_rm, ld_tt, ld_p
+    d.x, d.mean, d.rstd, d.gamma, d.beta = ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta)
+    d.out_rm, d.out_tt, d.out_ph, d.out_pw = ptr(out_rm), ptr(out_tt), ptr(out_ph), ptr(out_pw)
+    N.check(N.lib().mlpk_norm_apply(ctypes.byref(d), stream()), "mlpk_norm_apply")
+
+
+def vip_unpermute(which, z, out, B, H, W, C, seg, ldz):
+    N.check(N.lib().mlpk_vip_unpermute(dtype_code(z.dtype), which, ptr(z), ptr(out), B, H, W, C, seg, ldz, stream()),
+            "mlpk_vip_unpermute")
+
+
+def pool_mean(x, B, S, C, ldx, out, ldo, *, mean=None, rstd=None, stat_group=1, gamma=None, beta=None):
+    N.check(N.lib().mlpk_pool_mean(dtype_code(x.dtype), ptr(x), B, S, C, ldx, ptr(mean), ptr(rstd), stat_group,
+                                   ptr(gamma), ptr(beta), ptr(out), ldo, stream()), "mlpk_pool_mean")
+
+
+def shift_nchw(x, out, kernel_size, dim):
+    n, c, h, w = x.shape
+    N.check(N.lib().mlpk_shift_nchw(dtype_code(x.dtype), ptr(x), ptr(out), n, c, h, w, kernel_size, dim, stream()),
+            "mlpk_shift_nchw")
+
+
+def shift_nhwc(x, out, n, h, w, c, kernel_size, dim):
+    N.check(N.lib().mlpk_shift_nhwc(dtype_code(x.dtype), ptr(x), ptr(out), n, h, w, c, kernel_size, dim, stream()),
+            "mlpk_shift_nhwc")
+
+
+def split_sum(x0, x1, x2, ld0, ld1, ld2, B, H, W, C, mode, a):
+    N.check(N.lib().mlpk_split_sum(dtype_code(x0.dtype), ptr(x0), ptr(x1), ptr(x2), ld0, ld1, ld2, B, H, W, C, mode,
+                                   ptr(a), stream()), "mlpk_split_sum")
+
+
+def split_softmax(hat, bar, B, C):
+    N.check(N.lib().mlpk_split_softmax(ptr(hat), ptr(bar), B, C, stream()), "mlpk_split_softmax")
+
+
+def split_apply(x0, x1, x2, ld0, ld1, ld2, B, H, W, C, mode, bar, out, ldo):
+    N.check(N.lib().mlpk_split_apply(dtype_code(x0.dtype), ptr(x0), ptr(x1), ptr(x2), ld0, ld1, ld2, B, H, W, C, mode,
+                                     ptr(bar), ptr(out), ldo, stream()), "mlpk_split_apply")
+
+
+def s2_shift(x, out, B, H, W, C, ldi, ldo, mode):
+    N.check(N.lib().mlpk_s2_shift(dtype_code(x.dtype), ptr(x), ptr(out), B, H, W, C, ldi, ldo, mode, stream()),
+            "mlpk_s2_shift")
+
+
+def dwconv_nhwc(x, out, B, H, W, C, k, w, bias, bn_scale, bn_shift):
+    N.check(N.lib().mlpk_dwconv_nhwc(dtype_code(x.dtype), ptr(x), ptr(out), B, H, W, C, k, ptr(w), ptr(bias),
+                                     ptr(bn_scale), ptr(bn_shift), stream()), "mlpk_dwconv_nhwc")
+
+
+def convert(src, dst, n):
+    N.check(N.lib().mlpk_convert(dtype_code(src.dtype), dtype_code(dst.dtype), ptr(src), ptr(dst), n, stream()),
+            "mlpk_convert")
+
+
+# ------------------------------------------------------------------ per-model caches
+class Workspace:
+    """Named device buffers for one (batch, dtype, device) shape of a model.  torch owns the
+    memory; buffers are zero-initialised once (GEMM K-padding columns rely on that) and never
+    re-purposed for another role."""
+
+    def __init__(self, device, dtype):
+        self.device, self.dtype = device, dtype
+        self.t = {}
+
+    def get(self, name, shape, dtype=None):
+        t = self.t.get(name)
+        if t is None:
+            t = torch.zeros(shape, dtype=dtype or self.dtype, device=self.device)
+            self.t[name] = t
+        return t
+
+
+class EngineModule(torch.nn.Module):
+    """Base of the drop-in models: caches packed weights per (dtype, device) and workspaces per
+    (batch, dtype, device); caches are dropped whenever parameters change identity/version."""
+
+    def __init__(self):
+        super().__init__()
+        self.__dict__["_packs"] = {}
+        self.__dict__["_spaces"] = {}
+        self.__dict__["_compute_dtype"] = None
+
+    def set_compute_dtype(self, dtype):
+        """Run the MFMA path in `dtype` regardless of the input dtype (input is converted while
+        the patches are gathered; logits come back in the input dtype)."""
+        self.__dict__["_compute_dtype"] = dtype
+        return self
+
+    def _param_stamp(self):
+        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+    def _get_pack(self, dtype, device):
+        key = (dtype, str(device))
+        stamp = self._param_stamp()
+        hit = self._packs.get(key)
+        if hit is None or hit[0] != stamp:
+            with torch.no_grad():
+                hit = (stamp, self._pack(dtype, device))
+            self._packs[key] = hit
+        return hit[1]
+
+    def _get_space(self, batch, dtype, device):
+        key = (batch, dtype, str(device))
+        ws = self._spaces.get(key)
+        if ws is None:
+            if len(self._spaces) >= 4:          # bound resident workspaces (288 GB is big, not infinite)
+                self._spaces.pop(next(iter(self._spaces)))
+            ws = Workspace(device, dtype)
+            self._spaces[key] = ws
+        return ws
+
+    def _resolve(self, x):
+        require_gpu(x, type(self).__name__ + ".forward")
+        if x.dim() != 4:
+            raise ValueError("expected a (B, C, H, W) tensor")
+        cd = self._compute_dtype or x.dtype
+        dtype_code(cd)
+        dtype_code(x.dtype)
+        return cd
+
+    def _pack(self, dtype, device):  # pragma: no cover - abstract
+        raise NotImplementedError

@@ -1,0 +1,67 @@
+"""Building blocks shared by the drop-in models: each helper issues the HIP kernels for one
+reference sub-module on channel-last activations held in a Workspace."""
+import torch
+from torch import nn
+
+from .. import _native as N
+from .. import engine as E
+
+
+class Holder(nn.Module):
+    """A parameter container.  The per-block compute runs in the fused HIP kernels issued by the
+    owning model's forward(), so calling a holder on its own is not supported."""
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("%s only holds parameters; call the enclosing model" % type(self).__name__)
+
+
+def embed_patches(ws, name, x, w_packed, bias, cdtype, patch, pad=0, out=None):
+    """Conv2d(k = stride = patch) on an NCHW input -> channel-last tokens (B*Hp*Wp, Cout).
+    mlp_mixer.py:58-60,68-71; conv_mixer.py:18."""
+    B, cin, H, W = x.shape
+    ph, pw = patch
+    hp, wp = (H + 2 * pad - ph) // ph + 1, (W + 2 * pad - pw) // pw + 1
+    kp = w_packed.shape[1]
+    cout = w_packed.shape[0]
+    rows = B * hp * wp
+    patches = ws.get(name + ".patches", (rows, kp))
+    E.patchify(x, patches, B, cin, H, W, ph, pw, pad, kp)
+    if out is None:
+        out = ws.get(name + ".tokens", (rows, cout))
+    E.gemm(patches, w_packed, out, rows, cout, kp, bias=bias)
+    return out, hp, wp
+
+
+def layernorm_stats(ws, x, rows, C, tag="ln"):
+    mean = ws.get(tag + ".mean", (rows,), torch.float32)
+    rstd = ws.get(tag + ".rstd", (rows,), torch.float32)
+    E.row_stats(x, rows, C, x.stride(0), mean, rstd)
+    return mean, rstd
+
+
+def channel_mlp(ws, x, rows, C, pk, prefix, hidden, *, norm=True, cscale2=None, res_src=None, tag="cm"):
+    """x <- x + fc2(gelu(fc1(LN(x))))   (mlp_mixer.py:38; vip.py:82-88; s2_mlp_v2.py:78-84).
+    LN -> row-major normalised copy; fc1 epilogue = bias + exact GELU; fc2 epilogue = bias + residual."""
+    if norm:
+        mean, rstd = layernorm_stats(ws, x, rows, C)
+        xn = ws.get(tag + ".xn", (rows, C))
+        E.norm_apply(x, rows, C, x.stride(0), mean=mean, rstd=rstd, gamma=pk[prefix + "ln.g"], beta=pk[prefix + "ln.b"],
+                     out_rm=xn, ld_rm=C)
+    else:
+        xn = x
+    h = ws.get(tag + ".h", (rows, hidden))
+    E.gemm(xn, pk[prefix + "fc1.w"], h, rows, hidden, C, bias=pk[prefix + "fc1.b"], act=N.ACT_GELU, tag="channel_fc1")
+    E.gemm(h, pk[prefix + "fc2.w"], x, rows, C, hidden, bias=pk[prefix + "fc2.b"], cscale=cscale2,
+           R=res_src if res_src is not None else x, res=N.RES_ADD, tag="channel_fc2")
+    return x
+
+
+def head_linear(ws, pooled, B, C, w, b, num_classes, out_dtype):
+    logits = ws.get("logits", (B, num_classes))
+    E.gemm(pooled, w, logits, B, num_classes, C, bias=b)
+    out = logits
+    if out.dtype != out_dtype:
+        out = torch.empty((B, num_classes), dtype=out_dtype, device=logits.device)
+        E.convert(logits, out, B * num_classes)
+        return out
+    return logits.clone()

@@ -1,0 +1,138 @@
+"""gMLP, drop-in for the reference's models_pytorch/g_mlp.py.
+
+Block (g_mlp.py:17-22, 32-39):  h = gelu(LN(x) P1^T + p1)  (width 2F);  u, v = halves of h;
+  v' = Wsp . LN_F(v) + bsp   (contraction over tokens);   x <- x + (u * v') P2^T + p2.
+Kernels: LN -> row-major copy; proj1 GEMM (bias+GELU epilogue) writes h once; the LayerNorm of the
+v half is written token-transposed (reads the half in place through its row stride, no chunk()
+copy); the spatial GEMM's epilogue adds the per-token bias, multiplies by u (read in place from h)
+and stores through the per-image transpose; proj2 GEMM adds bias + residual.
+"""
+import torch
+from torch import nn
+
+from .. import _native as N
+from .. import engine as E
+from .common import Holder, embed_patches, head_linear, layernorm_stats
+from .utils.tools import check_sizes, pair
+
+
+class SpatialGatingUnit(Holder):
+    """g_mlp.py:10-22; spatial_proj bias initialised to 1.0 (:15), weight default-initialised."""
+
+    def __init__(self, d_ffn, seq_len):
+        super().__init__()
+        self.norm = nn.LayerNorm(d_ffn)
+        self.spatial_proj = nn.Conv1d(seq_len, seq_len, kernel_size=1)
+        nn.init.constant_(self.spatial_proj.bias, 1.0)
+
+
+class gMLPBlock(Holder):
+    """g_mlp.py:24-39; channel_proj1 is 2*d_ffn wide (:28)."""
+
+    def __init__(self, d_model, d_ffn, seq_len):
+        super().__init__()
+        self.norm = nn.LayerNorm(d_model)
+        self.channel_proj1 = nn.Linear(d_model, d_ffn * 2)
+        self.channel_proj2 = nn.Linear(d_ffn, d_model)
+        self.sgu = SpatialGatingUnit(d_ffn, seq_len)
+
+
+class gMLP(E.EngineModule):
+    """Backbone on tokens (g_mlp.py:41-49)."""
+
+    def __init__(self, d_model=256, d_ffn=1536, seq_len=256, depth=30):
+        super().__init__()
+        self.model = nn.Sequential(*[gMLPBlock(d_model, d_ffn, seq_len) for _ in range(depth)])
+        self._dims = (seq_len, d_model, d_ffn, depth)
+
+    def _pack_blocks(self, pk, dtype, device):
+        for i, blk in enumerate(self.model):
+            p = "b%d." % i
+            pk[p + "ln.g"], pk[p + "ln.b"] = E.f32(blk.norm.weight, device), E.f32(blk.norm.bias, device)
+            pk[p + "p1.w"] = E.pack_matrix(blk.channel_proj1.weight, dtype, device)
+            pk[p + "p1.b"] = E.f32(blk.channel_proj1.bias, device)
+            pk[p + "p2.w"] = E.pack_matrix(blk.channel_proj2.weight, dtype, device)
+            pk[p + "p2.b"] = E.f32(blk.channel_proj2.bias, device)
+            pk[p + "sgu.g"], pk[p + "sgu.b"] = E.f32(blk.sgu.norm.weight, device), E.f32(blk.sgu.norm.bias, device)
+            pk[p + "sp.w"] = E.pack_matrix(blk.sgu.spatial_proj.weight, dtype, device)      # (S, S_pad)
+            pk[p + "sp.b"] = E.f32(blk.sgu.spatial_proj.bias, device)
+
+    def _pack(self, dtype, device):
+        pk = {}
+        self._pack_blocks(pk, dtype, device)
+        return pk
+
+    def _run_blocks(self, ws, pk, x, B):
+        S, C, F, depth = self._dims
+        rows = B * S
+        sp = E.round_up(S, 8)
+        for i in range(depth):
+            p = "b%d." % i
+            mean, rstd = layernorm_stats(ws, x, rows, C)
+            xn = ws.get("xn", (rows, C))
+            E.norm_apply(x, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "ln.g"], beta=pk[p + "ln.b"], out_rm=xn, ld_rm=C)
+            h = ws.get("h", (rows, 2 * F))
+            E.gemm(xn, pk[p + "p1.w"], h, rows, 2 * F, C, bias=pk[p + "p1.b"], act=N.ACT_GELU)
+            v = h[:, F:]                                        # second half, row stride 2F (g_mlp.py:18)
+            vmean = ws.get("v.mean", (rows,), torch.float32)
+            vrstd = ws.get("v.rstd", (rows,), torch.float32)
+            E.row_stats(v, rows, F, 2 * F, vmean, vrstd)
+            vt = ws.get("vt", (B * F, sp))
+            E.norm_apply(v, rows, F, 2 * F, mean=vmean, rstd=vrstd, gamma=pk[p + "sgu.g"], beta=pk[p + "sgu.b"],
+                         out_tt=vt, S=S, ld_tt=sp)
+            g = ws.get("gate", (rows, F))
+            # out[b,t,f] = u[b,t,f] * (sum_s Wsp[t,s] v^[b,s,f] + bsp[t]);  u = h[:, :F] read in place
+            E.gemm(vt, pk[p + "sp.w"], g, B * F, S, sp, ldc=F, bias=pk[p + "sp.b"], R=h, ldr=2 * F, res=N.RES_MUL,
+                   out_mode=N.OUT_TOKEN_T, t_rows=F, t_tokens=S)
+            E.gemm(g, pk[p + "p2.w"], x, rows, C, F, bias=pk[p + "p2.b"], R=x, res=N.RES_ADD)
+        return x
+
+    def forward(self, x):
+        E.require_gpu(x, "gMLP.forward")
+        S, C, _, _ = self._dims
+        if x.dim() != 3 or x.shape[1] != S or x.shape[2] != C:
+            raise ValueError("expected tokens of shape (B, %d, %d)" % (S, C))
+        B = x.shape[0]
+        pk = self._get_pack(x.dtype, x.device)
+        ws = self._get_space(B, x.dtype, x.device)
+        buf = ws.get("x", (B * S, C))
+        buf.copy_(x.reshape(B * S, C))
+        self._run_blocks(ws, pk, buf, B)
+        return buf.reshape(B, S, C).clone()
+
+
+class gMLPForImageClassification(gMLP):
+    """Same signature and defaults as the reference (g_mlp.py:52-62); note image_size defaults to 256."""
+
+    def __init__(self, image_size=256, patch_size=16, in_channels=3, num_classes=1000, d_model=256, d_ffn=1536, depth=30):
+        num_patches = check_sizes(image_size, patch_size)
+        super().__init__(d_model, d_ffn, num_patches, depth)
+        self.patcher = nn.Sequential(nn.Conv2d(in_channels, d_model, kernel_size=patch_size, stride=patch_size))
+        self.mlp_head = nn.Sequential(nn.Linear(d_model, num_classes))
+        self._patch = pair(patch_size)
+        self._num_classes = num_classes
+
+    def _pack(self, dtype, device):
+        pk = {}
+        self._pack_blocks(pk, dtype, device)
+        pk["embed.w"] = E.pack_matrix(self.patcher[0].weight, dtype, device)
+        pk["embed.b"] = E.f32(self.patcher[0].bias, device)
+        pk["head.w"] = E.pack_matrix(self.mlp_head[0].weight, dtype, device)
+        pk["head.b"] = E.f32(self.mlp_head[0].bias, device)
+        return pk
+
+    def forward(self, x):
+        cd = self._resolve(x)
+        S, C, _, _ = self._dims
+        B = x.shape[0]
+        pk = self._get_pack(cd, x.device)
+        ws = self._get_space(B, cd, x.device)
+        x = x.contiguous()
+        tokens, hp, wp = embed_patches(ws, "embed", x, pk["embed.w"], pk["embed.b"], cd, self._patch,
+                                       out=ws.get("x", (B * S, C)))
+        if hp * wp != S:
+            raise ValueError("input size gives %d patches, the model was built for %d" % (hp * wp, S))
+        self._run_blocks(ws, pk, tokens, B)
+        pooled = ws.get("pooled", (B, C))
+        E.pool_mean(tokens, B, S, C, C, pooled, C)               # no final norm (g_mlp.py:79)
+        return head_linear(ws, pooled, B, C, pk["head.w"], pk["head.b"], self._num_classes, x.dtype)

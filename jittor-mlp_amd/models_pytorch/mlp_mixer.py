@@ -1,0 +1,153 @@
+"""MLP-Mixer, drop-in for the reference's models_pytorch/mlp_mixer.py (same constructors, same
+state_dict keys), with forward() running on hand-written gfx950 kernels.
+
+Per block (reference mlp_mixer.py:36-39, formulas SURVEY.md Appendix E):
+  token mixing   x <- x + W2 . gelu(W1 . LN(x) + b1) + b2     contraction over tokens (Conv1d k=1)
+  channel mixing x <- x + gelu(LN(x) W3^T + b3) W4^T + b4     contraction over channels (Linear)
+Mapping to kernels:
+  * LN statistics: mlpk_row_stats; the normalised copy is written TOKEN-TRANSPOSED (B, C, S_pad)
+    by mlpk_norm_apply so the token contraction becomes the same K-contiguous NT GEMM as the
+    channel one: rows = (image, channel) pairs, K = tokens;
+  * token fc1: GEMM (B*C, S) x (4S, S)^T, epilogue bias+GELU -> hidden (B*C, 4S);
+  * token fc2: GEMM (B*C, 4S) x (S, 4S)^T, epilogue bias + residual, stored through the per-image
+    transpose straight back into x (B, S, C) -- no einops/permute copy ever exists;
+  * channel fc1/fc2: GEMM with bias+GELU / bias+residual epilogues;
+  * head: LN folded into the token mean (mlpk_pool_mean) then one small GEMM.
+"""
+from functools import partial
+
+import torch
+from torch import nn
+
+from .. import _native as N
+from .. import engine as E
+from .common import Holder, channel_mlp, embed_patches, head_linear, layernorm_stats
+from .utils.tools import check_sizes, pair
+
+
+class PreNormResidual(Holder):
+    """fn(LayerNorm(x)) + x  (mlp_mixer.py:6-13): holds `fn` and `norm`."""
+
+    def __init__(self, dim, fn):
+        super().__init__()
+        self.fn = fn
+        self.norm = nn.LayerNorm(dim)
+
+
+class FeedForward(Holder):
+    """dense -> GELU -> Dropout -> dense -> Dropout (mlp_mixer.py:16-27); parameters at net.0 / net.3."""
+
+    def __init__(self, dim, hidden_dim, dropout=0., dense=nn.Linear):
+        super().__init__()
+        self.net = nn.Sequential(dense(dim, hidden_dim), nn.GELU(), nn.Dropout(dropout),
+                                 dense(hidden_dim, dim), nn.Dropout(dropout))
+
+
+class MLPMixer(E.EngineModule):
+    """Backbone on tokens (B, S, C) (mlp_mixer.py:30-43)."""
+
+    def __init__(self, num_patches, d_model, depth, expansion_factor=4, dropout=0.):
+        super().__init__()
+        chan_first, chan_last = partial(nn.Conv1d, kernel_size=1), nn.Linear
+        self.model = nn.Sequential(*[
+            nn.Sequential(
+                PreNormResidual(d_model, FeedForward(num_patches, num_patches * expansion_factor, dropout, chan_first)),
+                PreNormResidual(d_model, FeedForward(d_model, d_model * expansion_factor, dropout, chan_last)))
+            for _ in range(depth)])
+        self._dims = (num_patches, d_model, depth, expansion_factor)
+
+    # ---- weight packing: compute-dtype matrices (K zero-padded to 16 B), fp32 vectors ----
+    def _pack_blocks(self, pk, dtype, device):
+        for i, blk in enumerate(self.model):
+            tok, ch = blk[0], blk[1]
+            p = "b%d." % i
+            pk[p + "tok.ln.g"], pk[p + "tok.ln.b"] = E.f32(tok.norm.weight, device), E.f32(tok.norm.bias, device)
+            pk[p + "tok.fc1.w"] = E.pack_matrix(tok.fn.net[0].weight, dtype, device)     # (4S, S_pad)
+            pk[p + "tok.fc1.b"] = E.f32(tok.fn.net[0].bias, device)
+            pk[p + "tok.fc2.w"] = E.pack_matrix(tok.fn.net[3].weight, dtype, device)     # (S, 4S_pad)
+            pk[p + "tok.fc2.b"] = E.f32(tok.fn.net[3].bias, device)
+            pk[p + "ch.ln.g"], pk[p + "ch.ln.b"] = E.f32(ch.norm.weight, device), E.f32(ch.norm.bias, device)
+            pk[p + "ch.fc1.w"] = E.pack_matrix(ch.fn.net[0].weight, dtype, device)
+            pk[p + "ch.fc1.b"] = E.f32(ch.fn.net[0].bias, device)
+            pk[p + "ch.fc2.w"] = E.pack_matrix(ch.fn.net[3].weight, dtype, device)
+            pk[p + "ch.fc2.b"] = E.f32(ch.fn.net[3].bias, device)
+
+    def _pack(self, dtype, device):
+        pk = {}
+        self._pack_blocks(pk, dtype, device)
+        return pk
+
+    def _run_blocks(self, ws, pk, x, B):
+        """x: (B*S, C) channel-last tokens, updated in place."""
+        S, C, depth, ef = self._dims
+        rows = B * S
+        sp = E.round_up(S, 8)
+        th = S * ef
+        thp = E.round_up(th, 8)
+        for i in range(depth):
+            p = "b%d." % i
+            mean, rstd = layernorm_stats(ws, x, rows, C)
+            xt = ws.get("tok.xt", (B * C, sp))                 # LN(x) transposed per image, zero K-padding
+            E.norm_apply(x, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "tok.ln.g"], beta=pk[p + "tok.ln.b"],
+                         out_tt=xt, S=S, ld_tt=sp)
+            ht = ws.get("tok.h", (B * C, thp))
+            E.gemm(xt, pk[p + "tok.fc1.w"], ht, B * C, th, sp, bias=pk[p + "tok.fc1.b"], act=N.ACT_GELU, tag="token_fc1")
+            E.gemm(ht, pk[p + "tok.fc2.w"], x, B * C, S, thp, ldc=C, bias=pk[p + "tok.fc2.b"], R=x, ldr=C,
+                   res=N.RES_ADD, out_mode=N.OUT_TOKEN_T, t_rows=C, t_tokens=S, tag="token_fc2")
+            channel_mlp(ws, x, rows, C, pk, p + "ch.", C * ef)
+        return x
+
+    def forward(self, x):
+        """tokens (B, S, C) -> (B, S, C), as the reference backbone (mlp_mixer.py:42-43)."""
+        E.require_gpu(x, "MLPMixer.forward")
+        S, C, _, _ = self._dims
+        if x.dim() != 3 or x.shape[1] != S or x.shape[2] != C:
+            raise ValueError("expected tokens of shape (B, %d, %d)" % (S, C))
+        B = x.shape[0]
+        pk = self._get_pack(x.dtype, x.device)
+        ws = self._get_space(B, x.dtype, x.device)
+        buf = ws.get("x", (B * S, C))
+        buf.copy_(x.reshape(B * S, C))
+        self._run_blocks(ws, pk, buf, B)
+        return buf.reshape(B, S, C).clone()
+
+
+class MLPMixerForImageClassification(MLPMixer):
+    """Same signature and defaults as the reference (mlp_mixer.py:45-54)."""
+
+    def __init__(self, in_channels=3, d_model=512, num_classes=1000, patch_size=16, image_size=224, depth=12,
+                 expansion_factor=4):
+        num_patches = check_sizes(image_size, patch_size)
+        super().__init__(num_patches, d_model, depth, expansion_factor)
+        self.patcher = nn.Sequential(nn.Conv2d(in_channels, d_model, kernel_size=patch_size, stride=patch_size))
+        self.active = nn.LayerNorm(d_model)
+        self.mlp_head = nn.Sequential(nn.Linear(d_model, num_classes))
+        self._patch = pair(patch_size)
+        self._num_classes = num_classes
+
+    def _pack(self, dtype, device):
+        pk = {}
+        self._pack_blocks(pk, dtype, device)
+        pk["embed.w"] = E.pack_matrix(self.patcher[0].weight, dtype, device)
+        pk["embed.b"] = E.f32(self.patcher[0].bias, device)
+        pk["active.g"], pk["active.b"] = E.f32(self.active.weight, device), E.f32(self.active.bias, device)
+        pk["head.w"] = E.pack_matrix(self.mlp_head[0].weight, dtype, device)
+        pk["head.b"] = E.f32(self.mlp_head[0].bias, device)
+        return pk
+
+    def forward(self, x):
+        cd = self._resolve(x)
+        S, C, _, _ = self._dims
+        B = x.shape[0]
+        pk = self._get_pack(cd, x.device)
+        ws = self._get_space(B, cd, x.device)
+        x = x.contiguous()
+        tokens, hp, wp = embed_patches(ws, "embed", x, pk["embed.w"], pk["embed.b"], cd, self._patch,
+                                       out=ws.get("x", (B * S, C)))
+        if hp * wp != S:
+            raise ValueError("input size gives %d patches, the model was built for %d" % (hp * wp, S))
+        self._run_blocks(ws, pk, tokens, B)
+        mean, rstd = layernorm_stats(ws, tokens, B * S, C)
+        pooled = ws.get("pooled", (B, C))
+        E.pool_mean(tokens, B, S, C, C, pooled, C, mean=mean, rstd=rstd, gamma=pk["active.g"], beta=pk["active.b"])
+        return head_linear(ws, pooled, B, C, pk["head.w"], pk["head.b"], self._num_classes, x.dtype)

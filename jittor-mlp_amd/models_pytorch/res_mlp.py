@@ -1,0 +1,151 @@
+"""ResMLP, drop-in for the reference's models_pytorch/res_mlp.py.
+
+Block (res_mlp.py:52-57; the residual is taken on the AFFINE'd tensor, unlike the paper):
+  x1 = a*x + b;  x2 = x1 + g1 * (Wt . x1 + bt);  x3 = a'*x2 + b';  x <- x3 + g2 * FF(x3)
+Kernels: one affine pass writes x1 row-major AND token-transposed; the token GEMM's epilogue applies
+bias, the per-channel gamma_1 (a per-ROW scale in the transposed problem) and the residual while
+storing through the transpose; a second affine pass; FF as two GEMMs whose second epilogue applies
+gamma_2 and the residual.
+"""
+import torch
+from torch import nn
+
+from .. import _native as N
+from .. import engine as E
+from .common import Holder, embed_patches, head_linear
+from .utils.tools import check_sizes, pair
+
+
+class Aff(Holder):
+    """x * alpha + beta with (1,1,dim) parameters (res_mlp.py:11-19)."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.alpha = nn.Parameter(torch.ones([1, 1, dim]))
+        self.beta = nn.Parameter(torch.zeros([1, 1, dim]))
+
+
+class FeedForward(Holder):
+    def __init__(self, dim, hidden_dim, dropout=0.):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(dim, hidden_dim), nn.GELU(), nn.Dropout(dropout),
+                                 nn.Linear(hidden_dim, dim), nn.Dropout(dropout))
+
+
+class MLPblock(Holder):
+    """res_mlp.py:34-57; layer-scale init by depth (:38-43)."""
+
+    def __init__(self, num_patch, dim, mlp_dim, dropout=0., depth=18):
+        super().__init__()
+        if depth <= 18:
+            init_values = 0.1
+        elif depth <= 24:
+            init_values = 1e-5
+        else:
+            init_values = 1e-6
+        self.pre_affine = Aff(dim)
+        self.token_mix = nn.Conv1d(num_patch, num_patch, kernel_size=1)
+        self.ff = FeedForward(dim, mlp_dim, dropout)
+        self.post_affine = Aff(dim)
+        self.gamma_1 = nn.Parameter(init_values * torch.ones((dim)), requires_grad=True)
+        self.gamma_2 = nn.Parameter(init_values * torch.ones((dim)), requires_grad=True)
+
+
+class ResMLP(E.EngineModule):
+    def __init__(self, num_patch, d_model, depth, expansion_factor):
+        super().__init__()
+        self.model = nn.Sequential(*[MLPblock(num_patch, d_model, d_model * expansion_factor, depth=depth)
+                                     for _ in range(depth)])
+        self._dims = (num_patch, d_model, depth, expansion_factor)
+
+    def _pack_blocks(self, pk, dtype, device):
+        for i, blk in enumerate(self.model):
+            p = "b%d." % i
+            pk[p + "pre.a"], pk[p + "pre.b"] = E.f32(blk.pre_affine.alpha, device), E.f32(blk.pre_affine.beta, device)
+            pk[p + "post.a"], pk[p + "post.b"] = E.f32(blk.post_affine.alpha, device), E.f32(blk.post_affine.beta, device)
+            pk[p + "g1"], pk[p + "g2"] = E.f32(blk.gamma_1, device), E.f32(blk.gamma_2, device)
+            pk[p + "tok.w"] = E.pack_matrix(blk.token_mix.weight, dtype, device)            # (S, S_pad)
+            pk[p + "tok.b"] = E.f32(blk.token_mix.bias, device)
+            pk[p + "fc1.w"] = E.pack_matrix(blk.ff.net[0].weight, dtype, device)
+            pk[p + "fc1.b"] = E.f32(blk.ff.net[0].bias, device)
+            pk[p + "fc2.w"] = E.pack_matrix(blk.ff.net[3].weight, dtype, device)
+            pk[p + "fc2.b"] = E.f32(blk.ff.net[3].bias, device)
+
+    def _pack(self, dtype, device):
+        pk = {}
+        self._pack_blocks(pk, dtype, device)
+        return pk
+
+    def _run_blocks(self, ws, pk, x, B):
+        S, C, depth, ef = self._dims
+        rows = B * S
+        sp = E.round_up(S, 8)
+        hidden = C * ef
+        for i in range(depth):
+            p = "b%d." % i
+            xt = ws.get("xt", (B * C, sp))
+            # x1 = alpha*x + beta, in place, plus its token-transposed copy for the token GEMM
+            E.norm_apply(x, rows, C, C, gamma=pk[p + "pre.a"], beta=pk[p + "pre.b"], out_rm=x, ld_rm=C, out_tt=xt, S=S, ld_tt=sp)
+            # x2 = x1 + gamma_1[c] * (sum_s Wt[t,s] x1[b,s,c] + bt[t])
+            E.gemm(xt, pk[p + "tok.w"], x, B * C, S, sp, ldc=C, bias=pk[p + "tok.b"], rscale=pk[p + "g1"], rperiod=C,
+                   R=x, ldr=C, res=N.RES_ADD, out_mode=N.OUT_TOKEN_T, t_rows=C, t_tokens=S)
+            # x3 = alpha'*x2 + beta'
+            E.norm_apply(x, rows, C, C, gamma=pk[p + "post.a"], beta=pk[p + "post.b"], out_rm=x, ld_rm=C)
+            h = ws.get("h", (rows, hidden))
+            E.gemm(x, pk[p + "fc1.w"], h, rows, hidden, C, bias=pk[p + "fc1.b"], act=N.ACT_GELU)
+            # x = x3 + gamma_2 * (h F2^T + f2)
+            E.gemm(h, pk[p + "fc2.w"], x, rows, C, hidden, bias=pk[p + "fc2.b"], cscale=pk[p + "g2"], R=x, res=N.RES_ADD)
+        return x
+
+    def forward(self, x):
+        E.require_gpu(x, "ResMLP.forward")
+        S, C, _, _ = self._dims
+        if x.dim() != 3 or x.shape[1] != S or x.shape[2] != C:
+            raise ValueError("expected tokens of shape (B, %d, %d)" % (S, C))
+        B = x.shape[0]
+        pk = self._get_pack(x.dtype, x.device)
+        ws = self._get_space(B, x.dtype, x.device)
+        buf = ws.get("x", (B * S, C))
+        buf.copy_(x.reshape(B * S, C))
+        self._run_blocks(ws, pk, buf, B)
+        return buf.reshape(B, S, C).clone()
+
+
+class ResMLPForImageClassification(ResMLP):
+    """Same signature and defaults as the reference (res_mlp.py:69-78).  `affine` exists in the
+    state_dict but takes no part in forward (res_mlp.py:86, 91-99)."""
+
+    def __init__(self, in_channels=3, d_model=384, num_classes=1000, patch_size=16, image_size=224, depth=12,
+                 expansion_factor=4):
+        num_patches = check_sizes(image_size, patch_size)
+        super().__init__(num_patches, d_model, depth, expansion_factor)
+        self.patcher = nn.Sequential(nn.Conv2d(in_channels, d_model, kernel_size=patch_size, stride=patch_size))
+        self.affine = Aff(d_model)
+        self.mlp_head = nn.Sequential(nn.Linear(d_model, num_classes))
+        self._patch = pair(patch_size)
+        self._num_classes = num_classes
+
+    def _pack(self, dtype, device):
+        pk = {}
+        self._pack_blocks(pk, dtype, device)
+        pk["embed.w"] = E.pack_matrix(self.patcher[0].weight, dtype, device)
+        pk["embed.b"] = E.f32(self.patcher[0].bias, device)
+        pk["head.w"] = E.pack_matrix(self.mlp_head[0].weight, dtype, device)
+        pk["head.b"] = E.f32(self.mlp_head[0].bias, device)
+        return pk
+
+    def forward(self, x):
+        cd = self._resolve(x)
+        S, C, _, _ = self._dims
+        B = x.shape[0]
+        pk = self._get_pack(cd, x.device)
+        ws = self._get_space(B, cd, x.device)
+        x = x.contiguous()
+        tokens, hp, wp = embed_patches(ws, "embed", x, pk["embed.w"], pk["embed.b"], cd, self._patch,
+                                       out=ws.get("x", (B * S, C)))
+        if hp * wp != S:
+            raise ValueError("input size gives %d patches, the model was built for %d" % (hp * wp, S))
+        self._run_blocks(ws, pk, tokens, B)
+        pooled = ws.get("pooled", (B, C))
+        E.pool_mean(tokens, B, S, C, C, pooled, C)
+        return head_linear(ws, pooled, B, C, pk["head.w"], pk["head.b"], self._num_classes, x.dtype)

@@ -1,0 +1,354 @@
+"""-m gpu: every C-ABI kernel against a float64 CPU restatement of its header contract
+(include/mlpk.h) on seeded inputs, including ragged tails and the edge cases the reference's
+ops have (zero-fill borders, non-divisible channel groups, K padding)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import load_pkg
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.float16, torch.bfloat16]
+EPS = {torch.float32: 2e-6, torch.float16: 1e-3, torch.bfloat16: 8e-3}
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(shape, dtype, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+def gemm_ref(A, B, M, N, K, bias=None, act=0, cscale=None, cshift=None, rscale=None, rperiod=1, R=None, res=0,
+             out_mode=0, t_rows=0, t_tokens=0, ldc=None):
+    """float64 restatement of the mlpk_gemm_nt contract; returns the dense expected C tensor(s)."""
+    acc = A[:M, :K].double() @ B[:N, :K].double().t()
+    v = acc
+    if bias is not None:
+        v = v + bias.double()[None, :N]
+    if act:
+        v = oracle.gelu(v)
+    if cscale is not None:
+        v = v * cscale.double()[None, :N]
+    if cshift is not None:
+        v = v + cshift.double()[None, :N]
+    if rscale is not None:
+        idx = torch.arange(M) % rperiod
+        v = v * rscale.double()[idx][:, None]
+    if out_mode == 0:
+        if res:
+            r = R[:M, :N].double()
+            v = v + r if res == 1 else v * r
+        return v
+    nimg = M // t_rows
+    v = v.reshape(nimg, t_rows, N).permute(0, 2, 1)             # (img, token n, channel c)
+    if res:
+        r = R.reshape(nimg, t_tokens, -1)[:, :N, :t_rows].double()
+        v = v + r if res == 1 else v * r
+    return v
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("algo", [0, 1, 2, 3, 4, 5])
+def test_gemm_rowmajor_epilogues(dtype, algo):
+    pkg = load_pkg()
+    E, N = pkg.engine, pkg._native
+    cases = [  # M, N, K, flags
+        (300, 200, 72, dict(bias=True)),
+        (257, 129, 200, dict(bias=True, act=1)),
+        (512, 256, 64, dict(bias=True, res=1)),
+        (130, 70, 136, dict(bias=True, act=1, cscale=True, cshift=True)),
+        (96, 1000, 64, dict(bias=True, cscale=True, res=1)),
+        (64, 10, 32, dict(bias=True)),                        # ldc = 10: scalar-store path
+    ]
+    for ci, (M, Nn, K, fl) in enumerate(cases):
+        A = rnd((M, K), dtype, 10 + ci).to(dev())
+        B = rnd((Nn, K), dtype, 20 + ci, 1.0 / math.sqrt(K)).to(dev())
+        bias = rnd((Nn,), torch.float32, 30 + ci).to(dev()) if fl.get("bias") else None
+        cs = (rnd((Nn,), torch.float32, 40 + ci) * 0.2 + 1).to(dev()) if fl.get("cscale") else None
+        ch = rnd((Nn,), torch.float32, 50 + ci).to(dev()) if fl.get("cshift") else None
+        R = rnd((M, Nn), dtype, 60 + ci).to(dev()) if fl.get("res") else None
+        C = torch.full((M, Nn), float("nan"), dtype=dtype, device=dev())
+        E.gemm(A, B, C, M, Nn, K, bias=bias, act=fl.get("act", 0), cscale=cs, cshift=ch, R=R, res=fl.get("res", 0), algo=algo)
+        torch.cuda.synchronize()
+        ref = gemm_ref(A.cpu(), B.cpu(), M, Nn, K, bias=None if bias is None else bias.cpu(), act=fl.get("act", 0),
+                       cscale=None if cs is None else cs.cpu(), cshift=None if ch is None else ch.cpu(),
+                       R=None if R is None else R.cpu(), res=fl.get("res", 0))
+        got = C.cpu().double()
+        assert torch.isfinite(got).all(), (ci, "non-finite output")
+        err = (got - ref).abs().max().item()
+        tol = EPS[dtype] * max(1.0, ref.abs().max().item()) * 4
+        assert err < tol, (str(dtype), algo, ci, err, tol)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("algo", [0, 1, 4, 5])
+def test_gemm_token_transposed(dtype, algo):
+    """OUT_TOKEN_T: the token-mixing form (Mixer fc2 residual, ResMLP gamma_1 row scale, gMLP gate)."""
+    pkg = load_pkg()
+    E, N = pkg.engine, pkg._native
+    for ci, (nimg, t_rows, S, K, res, rscale, ldr_extra) in enumerate([
+            (3, 64, 49, 56, 1, False, 0), (2, 40, 196, 200, 1, True, 0), (2, 128, 16, 16, 2, False, 128), (5, 8, 20, 24, 0, False, 0)]):
+        M = nimg * t_rows
+        A = rnd((M, K), dtype, 100 + ci).to(dev())
+        B = rnd((S, K), dtype, 110 + ci, 1.0 / math.sqrt(K)).to(dev())
+        bias = rnd((S,), torch.float32, 120 + ci).to(dev())
+        rs = (rnd((t_rows,), torch.float32, 130 + ci) * 0.3 + 1).to(dev()) if rscale else None
+        ldr = t_rows + ldr_extra
+        R = rnd((nimg * S, ldr), dtype, 140 + ci).to(dev()) if res else None
+        C = torch.full((nimg * S, t_rows), float("nan"), dtype=dtype, device=dev())
+        E.gemm(A, B, C, M, S, K, ldc=t_rows, bias=bias, rscale=rs, rperiod=t_rows if rscale else 0, R=R, ldr=ldr if res else None,
+               res=res, out_mode=N.OUT_TOKEN_T, t_rows=t_rows, t_tokens=S, algo=algo)
+        torch.cuda.synchronize()
+        ref = gemm_ref(A.cpu(), B.cpu(), M, S, K, bias=bias.cpu(), rscale=None if rs is None else rs.cpu(), rperiod=t_rows,
+                       R=None if R is None else R.cpu(), res=res, out_mode=1, t_rows=t_rows, t_tokens=S)
+        got = C.cpu().double().reshape(nimg, S, t_rows)
+        assert torch.isfinite(got).all()
+        err = (got - ref).abs().max().item()
+        tol = EPS[dtype] * max(1.0, ref.abs().max().item()) * 4
+        assert err < tol, (str(dtype), algo, ci, err, tol)
+
+
+def test_gemm_inplace_residual_and_identity():
+    """A = I with an ASYMMETRIC B catches a transposed accumulator layout; R aliasing C is allowed."""
+    pkg = load_pkg()
+    E = pkg.engine
+    for dtype in DTYPES:
+        n = 96
+        A = torch.eye(n, dtype=dtype, device=dev())
+        B = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 7 - 3).to(dtype).to(dev())
+        C = torch.ones((n, n), dtype=dtype, device=dev())
+        E.gemm(A, B, C, n, n, n, R=C, res=1)
+        torch.cuda.synchronize()
+        assert torch.equal(C.cpu().float(), B.cpu().float().t() + 1.0)
+
+
+def test_gemm_argument_errors():
+    pkg = load_pkg()
+    E, N = pkg.engine, pkg._native
+    A = torch.zeros((16, 12), dtype=torch.bfloat16, device=dev())
+    with pytest.raises(N.MlpkError):
+        E.gemm(A, A, A, 16, 16, 12)                             # K not a multiple of 8 elements
+    with pytest.raises(TypeError):
+        E.gemm(A.to(torch.float64), A, A, 16, 16, 8)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_row_stats_and_norm_apply(dtype):
+    pkg = load_pkg()
+    E, N = pkg.engine, pkg._native
+    B_, S, C = 3, 50, 72
+    rows = B_ * S
+    x = (rnd((rows, C), torch.float32, 1) * 2 + 0.5).to(dtype).to(dev())
+    mean = torch.empty(rows, device=dev())
+    rstd = torch.empty(rows, device=dev())
+    E.row_stats(x, rows, C, C, mean, rstd)
+    xd = x.cpu().double()
+    mu = xd.mean(1)
+    var = ((xd - mu[:, None]) ** 2).mean(1)
+    assert (mean.cpu().double() - mu).abs().max() < 1e-5
+    assert (rstd.cpu().double() - 1 / torch.sqrt(var + 1e-5)).abs().max() < 1e-4
+    g = (rnd((C,), torch.float32, 2) * 0.2 + 1).to(dev())
+    b = rnd((C,), torch.float32, 3).to(dev())
+    sp = 56
+    out_rm = torch.full((rows, C), float("nan"), dtype=dtype, device=dev())
+    out_tt = torch.full((B_ * C, sp), float("nan"), dtype=dtype, device=dev())
+    E.norm_apply(x, rows, C, C, mean=mean, rstd=rstd, gamma=g, beta=b, out_rm=out_rm, ld_rm=C, out_tt=out_tt, S=S, ld_tt=sp)
+    torch.cuda.synchronize()
+    ref = oracle.layer_norm(xd, g.cpu().double(), b.cpu().double())
+    tol = EPS[dtype] * 8
+    assert (out_rm.cpu().double() - ref).abs().max() < tol
+    tt = out_tt.cpu().double().reshape(B_, C, sp)
+    assert (tt[:, :, :S] - ref.reshape(B_, S, C).permute(0, 2, 1)).abs().max() < tol
+    assert (tt[:, :, S:] == 0).all()                          # K padding of the token GEMM
+    # GELU + long-row (GroupNorm-like) statistics: one stat per sample covering S rows
+    gm = torch.empty(B_, device=dev())
+    gr = torch.empty(B_, device=dev())
+    E.row_stats(x, B_, S * C, S * C, gm, gr)
+    out = torch.empty_like(x)
+    E.norm_apply(x, rows, C, C, mean=gm, rstd=gr, gamma=g, beta=b, act=N.ACT_GELU, stat_group=S, out_rm=out, ld_rm=C)
+    torch.cuda.synchronize()
+    xs = xd.reshape(B_, S * C)
+    m2 = xs.mean(1)
+    v2 = ((xs - m2[:, None]) ** 2).mean(1)
+    ref2 = oracle.gelu(((xs - m2[:, None]) / torch.sqrt(v2 + 1e-5)[:, None]).reshape(rows, C) * g.cpu().double() + b.cpu().double())
+    assert (out.cpu().double() - ref2).abs().max() < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_vip_permutes(dtype):
+    pkg = load_pkg()
+    E = pkg.engine
+    B_, H, W, C, seg = 2, 4, 6, 24, 6
+    x = rnd((B_, H, W, C), dtype, 5).to(dev())
+    G = C // seg
+    ldh, ldw = E.round_up(H * seg, 8), E.round_up(W * seg, 8)
+    ph = torch.full((B_ * W * G, ldh), float("nan"), dtype=dtype, device=dev())
+    pw = torch.full((B_ * H * G, ldw), float("nan"), dtype=dtype, device=dev())
+    E.norm_apply(x, B_ * H * W, C, C, out_ph=ph, H=H, W=W, seg=seg, ld_p=ldh)
+    E.norm_apply(x, B_ * H * W, C, C, out_pw=pw, H=H, W=W, seg=seg, ld_p=ldw)
+    torch.cuda.synchronize()
+    xh = oracle.vip_permute_h(x.cpu().float(), seg).reshape(-1, H * seg)
+    xw = oracle.vip_permute_w(x.cpu().float(), seg).reshape(-1, W * seg)
+    assert torch.equal(ph.cpu().float()[:, :H * seg], xh) and (ph.cpu().float()[:, H * seg:] == 0).all()
+    assert torch.equal(pw.cpu().float()[:, :W * seg], xw) and (pw.cpu().float()[:, W * seg:] == 0).all()
+    back_h = torch.empty_like(x)
+    back_w = torch.empty_like(x)
+    E.vip_unpermute(0, ph, back_h, B_, H, W, C, seg, ldh)
+    E.vip_unpermute(1, pw, back_w, B_, H, W, C, seg, ldw)
+    torch.cuda.synchronize()
+    assert torch.equal(back_h.cpu(), x.cpu()) and torch.equal(back_w.cpu(), x.cpu())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pool_mean(dtype):
+    pkg = load_pkg()
+    E = pkg.engine
+    B_, S, C = 3, 37, 72
+    x = rnd((B_ * S, C), dtype, 7).to(dev())
+    out = torch.empty((B_, C), dtype=dtype, device=dev())
+    E.pool_mean(x, B_, S, C, C, out, C)
+    torch.cuda.synchronize()
+    ref = x.cpu().double().reshape(B_, S, C).mean(1)
+    assert (out.cpu().double() - ref).abs().max() < EPS[dtype] * 4
+    mean = torch.empty(B_ * S, device=dev())
+    rstd = torch.empty(B_ * S, device=dev())
+    E.row_stats(x, B_ * S, C, C, mean, rstd)
+    g = (rnd((C,), torch.float32, 8) * 0.2 + 1).to(dev())
+    b = rnd((C,), torch.float32, 9).to(dev())
+    E.pool_mean(x, B_, S, C, C, out, C, mean=mean, rstd=rstd, gamma=g, beta=b)
+    torch.cuda.synchronize()
+    ref = oracle.layer_norm(x.cpu().double(), g.cpu().double(), b.cpu().double()).reshape(B_, S, C).mean(1)
+    assert (out.cpu().double() - ref).abs().max() < EPS[dtype] * 4
+
+
+@pytest.mark.parametrize("src_dtype", [torch.float32, torch.bfloat16])
+def test_patchify(src_dtype):
+    pkg = load_pkg()
+    E, N = pkg.engine, pkg._native
+    for (B_, cin, H, W, ph, pw, pad) in [(2, 3, 32, 32, 8, 8, 0), (2, 3, 32, 24, 8, 4, 0), (1, 3, 28, 28, 7, 7, 3), (2, 3, 16, 16, 4, 4, 0)]:
+        x = rnd((B_, cin, H, W), src_dtype, 11).to(dev())
+        hp, wp = (H + 2 * pad - ph) // ph + 1, (W + 2 * pad - pw) // pw + 1
+        K = cin * ph * pw
+        kp = E.round_up(K, 8)
+        out = torch.full((B_ * hp * wp, kp), float("nan"), dtype=torch.float32, device=dev())
+        E.patchify(x, out, B_, cin, H, W, ph, pw, pad, kp)
+        torch.cuda.synchronize()
+        w_eye = torch.eye(K).reshape(K, cin, ph, pw)
+        ref = oracle.patch_embed(x.cpu().float(), w_eye, None, padding=pad).reshape(-1, K)
+        assert torch.equal(out.cpu()[:, :K], ref)
+        assert (out.cpu()[:, K:] == 0).all()
+    # channel-last source (S2 stage-2 embedding) and the PatchMerging order (as_mlp.py:207-211)
+    B_, H, W, cin = 2, 8, 8, 16
+    x = rnd((B_, H, W, cin), torch.float32, 12).to(dev())
+    out = torch.empty((B_ * 16, 4 * cin), dtype=torch.float32, device=dev())
+    E.patchify(x, out, B_, cin, H, W, 2, 2, 0, 4 * cin, layout=N.LAYOUT_NHWC, px_stride=cin, order=0)
+    torch.cuda.synchronize()
+    xc = x.cpu()
+    ref = xc.reshape(B_, 4, 2, 4, 2, cin).permute(0, 1, 3, 2, 4, 5).reshape(B_ * 16, 4 * cin)   # k = (i*2+j)*cin + ci
+    assert torch.equal(out.cpu(), ref)
+    E.patchify(x, out, B_, cin, H, W, 2, 2, 0, 4 * cin, layout=N.LAYOUT_NHWC, px_stride=cin, order=1)
+    torch.cuda.synchronize()
+    nchw = xc.permute(0, 3, 1, 2)
+    merged = torch.cat([nchw[:, :, 0::2, 0::2], nchw[:, :, 1::2, 0::2], nchw[:, :, 0::2, 1::2], nchw[:, :, 1::2, 1::2]], 1)
+    assert torch.equal(out.cpu(), merged.permute(0, 2, 3, 1).reshape(B_ * 16, 4 * cin))
+
+
+def test_axial_shift_against_golden(golden_dir):
+    """The reference's one native op: bit-exact against the pinned outputs of its own torch_shift."""
+    pkg = load_pkg()
+    E = pkg.engine
+    z = np.load(golden_dir + "/ops.npz")
+    i = 0
+    while "shift%d/x" % i in z.files:
+        x = torch.from_numpy(z["shift%d/x" % i]).to(dev())
+        k = int(z["shift%d/k" % i])
+        for dim in (2, 3):
+            out = torch.full_like(x, float("nan"))
+            E.shift_nchw(x, out, k, dim)
+            torch.cuda.synchronize()
+            assert torch.equal(out.cpu(), torch.from_numpy(z["shift%d/dim%d" % (i, dim)]))
+            n, c, h, w = x.shape
+            xl = x.permute(0, 2, 3, 1).contiguous()
+            ol = torch.full_like(xl, float("nan"))
+            E.shift_nhwc(xl, ol, n, h, w, c, k, dim)
+            torch.cuda.synchronize()
+            assert torch.equal(ol.permute(0, 3, 1, 2).cpu(), torch.from_numpy(z["shift%d/dim%d" % (i, dim)]))
+        i += 1
+    for dt in (torch.float16, torch.bfloat16):
+        x = rnd((2, 10, 5, 6), dt, 3).to(dev())
+        out = torch.empty_like(x)
+        E.shift_nchw(x, out, 3, 3)
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu().float(), oracle.axial_shift_nchw(x.cpu().float(), 3, 3))
+    with pytest.raises(pkg._native.MlpkError):
+        E.shift_nchw(x, out, 4, 2)                              # even kernel (shift_cuda.py:167)
+    with pytest.raises(pkg._native.MlpkError):
+        E.shift_nchw(x, out, 3, 1)                              # bad dim (shift_cuda.py:168)
+
+
+def test_s2_shift_and_split_attention(golden_dir):
+    pkg = load_pkg()
+    E, N = pkg.engine, pkg._native
+    z = np.load(golden_dir + "/ops.npz")
+    i = 0
+    while "s2shift%d/x" % i in z.files:
+        x = torch.from_numpy(z["s2shift%d/x" % i]).to(dev())
+        b, d1, d2, c = x.shape
+        out = torch.full_like(x, float("nan"))
+        E.s2_shift(x, out, b, d1, d2, c, c, c, N.SHIFT_S2_REF)
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), torch.from_numpy(z["s2shift%d/ref1" % i]))
+        E.s2_shift(x, out, b, d1, d2, c, c, c, N.SHIFT_S2)
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), oracle.spatial_shift1(x.cpu(), mode="shift"))
+        i += 1
+    for mode, omode in ((N.SHIFT_NONE, None), (N.SHIFT_S2, "shift"), (N.SHIFT_S2_REF, "reference_inplace")):
+        for dtype in DTYPES:
+            B_, H, W, C = 2, 5, 6, 24
+            t = rnd((B_, H, W, 3 * C), dtype, 21).to(dev())
+            x0, x1, x2 = t[..., :C], t[..., C:2 * C], t[..., 2 * C:]
+            a = torch.empty((B_, C), device=dev())
+            E.split_sum(x0, x1, x2, 3 * C, 3 * C, 3 * C, B_, H, W, C, mode, a)
+            tc = t.cpu().double()
+            r0, r1, r2 = tc[..., :C], tc[..., C:2 * C], tc[..., 2 * C:]
+            if omode:
+                r0, r1 = oracle.spatial_shift1(r0, omode), oracle.spatial_shift2(r1, omode)
+            torch.cuda.synchronize()
+            assert (a.cpu().double() - (r0 + r1 + r2).sum((1, 2))).abs().max() < 1e-3 * (1 if dtype == torch.float32 else 30)
+            hat = rnd((B_, 3 * C), torch.float32, 22).to(dev())
+            bar = torch.empty((B_, 3 * C), device=dev())
+            E.split_softmax(hat, bar, B_, C)
+            out = torch.empty((B_, H, W, C), dtype=dtype, device=dev())
+            E.split_apply(x0, x1, x2, 3 * C, 3 * C, 3 * C, B_, H, W, C, mode, bar, out, C)
+            torch.cuda.synchronize()
+            sm = torch.softmax(hat.cpu().double().reshape(B_, 3, C), 1)
+            assert (bar.cpu().double().reshape(B_, 3, C) - sm).abs().max() < 1e-6
+            ref = sm[:, 0, None, None] * r0 + sm[:, 1, None, None] * r1 + sm[:, 2, None, None] * r2
+            assert (out.cpu().double() - ref).abs().max() < EPS[dtype] * 8
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_dwconv(dtype):
+    pkg = load_pkg()
+    E = pkg.engine
+    for (B_, H, W, C, k) in [(2, 8, 8, 32, 5), (1, 32, 32, 64, 9), (2, 7, 9, 16, 3)]:
+        x = rnd((B_, H, W, C), dtype, 31).to(dev())
+        w = rnd((C, 1, k, k), torch.float32, 32, 1.0 / k)
+        bias = rnd((C,), torch.float32, 33)
+        bns = rnd((C,), torch.float32, 34) * 0.2 + 1
+        bnh = rnd((C,), torch.float32, 35)
+        wt = w.reshape(C, k * k).t().contiguous().to(dev())        # tap-major [k*k][C]
+        out = torch.empty_like(x)
+        E.dwconv_nhwc(x, out, B_, H, W, C, k, wt, bias.to(dev()), bns.to(dev()), bnh.to(dev()))
+        torch.cuda.synchronize()
+        xn = x.cpu().double().permute(0, 3, 1, 2)
+        d = oracle.functional.depthwise_conv_same(xn, w.double(), bias.double())
+        ref = xn + oracle.gelu(d) * bns.double().view(1, C, 1, 1) + bnh.double().view(1, C, 1, 1)
+        assert (out.cpu().double().permute(0, 3, 1, 2) - ref).abs().max() < EPS[dtype] * 8

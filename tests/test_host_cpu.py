@@ -1,0 +1,123 @@
+"""CPU-side checks (no GPU): the C-ABI library builds, loads and exports every symbol that
+include/mlpk.h declares; the drop-in constructors match the reference's signatures and
+state_dict layouts (manifest generated from the reference); argument validation keeps the
+reference's error types; the product package never imports the oracle."""
+import ctypes
+import inspect
+import json
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT, load_pkg
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    ge.build()
+    pkg = load_pkg()
+    lib = pkg._native.lib()
+    with open(os.path.join(ROOT, "include", "mlpk.h")) as f:
+        header = f.read()
+    declared = set(re.findall(r"\b(mlpk_[a-z0-9_]+)\s*\(", header))
+    declared -= {"mlpk_gemm_desc", "mlpk_norm_desc"}
+    assert len(declared) >= 18
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libmlpk.so does not export %s" % name
+        assert name in pkg._native.PROTOTYPES, "no ctypes prototype for %s" % name
+    assert lib.mlpk_abi_version() == 1
+    assert lib.mlpk_gemm_algo_count() >= 4
+    bm, bn, th, lds = (ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int())
+    assert lib.mlpk_gemm_algo_info(1, bm, bn, th, lds) == 0
+    assert lds.value <= 160 * 1024 and th.value % 64 == 0
+    assert lib.mlpk_gemm_algo_info(99, bm, bn, th, lds) < 0
+
+
+def test_argument_validation_without_gpu():
+    """Argument errors are detected before any launch, so they can be checked without a device."""
+    pkg = load_pkg()
+    N = pkg._native
+    lib = N.lib()
+    d = N.GemmDesc()
+    assert lib.mlpk_gemm_nt(ctypes.byref(d), None) == -4            # NULL operands
+    d.A = d.B = d.C = 4096
+    d.dtype = 7
+    assert lib.mlpk_gemm_nt(ctypes.byref(d), None) == -1            # dtype
+    d.dtype, d.M, d.N, d.K, d.lda, d.ldb, d.ldc = N.BF16, 16, 16, 12, 12, 12, 16
+    assert lib.mlpk_gemm_nt(ctypes.byref(d), None) == -2            # K not a multiple of a 16-byte chunk
+    assert lib.mlpk_shift_nchw(N.F32, 4096, 4096, 1, 4, 4, 4, 4, 2, None) == -2   # even kernel_size
+    assert lib.mlpk_shift_nchw(N.F32, 4096, 4096, 1, 4, 4, 4, 3, 1, None) == -5   # dim not in {2,3}
+    assert b"stride" in lib.mlpk_strerror(-2)
+
+
+def test_constructor_signatures_match_reference():
+    pkg = load_pkg()
+    with open(os.path.join(GOLDEN, "manifest.json")) as f:
+        man = json.load(f)
+    mods = pkg.models_pytorch
+    checked = 0
+    for name, ref_sig in man["signatures"].items():
+        if not hasattr(mods, name):
+            continue
+        sig = inspect.signature(getattr(mods, name))
+        mine = [[p.name, repr(p.default) if p.default is not inspect._empty else None, str(p.kind)]
+                for p in sig.parameters.values() if p.name != "norm_layer"]
+        assert mine == ref_sig, (name, mine, ref_sig)
+        checked += 1
+    assert checked >= 3
+
+
+def test_state_dict_layouts_match_reference():
+    pkg = load_pkg()
+    with open(os.path.join(GOLDEN, "manifest.json")) as f:
+        man = json.load(f)["state_dicts"]
+    mods = pkg.models_pytorch
+    checked = 0
+    for name, m in man.items():
+        if not hasattr(mods, m["ctor"]):
+            continue
+        if m["n_params"] > 80e6:
+            continue                                               # Mixer-L: covered by the GPU test
+        kw = dict(m["kwargs"])
+        for k in ("patch_size", "image_size"):
+            if isinstance(kw.get(k), list) and not m["ctor"].startswith("S2"):
+                kw[k] = tuple(kw[k])
+        model = getattr(mods, m["ctor"])(**kw)
+        mine = [[k, list(v.shape)] for k, v in model.state_dict().items()]
+        assert mine == m["keys"], name
+        assert sum(p.numel() for p in model.parameters()) == m["n_params"]
+        checked += 1
+    assert checked >= 6
+
+
+def test_reference_error_types():
+    pkg = load_pkg()
+    with pytest.raises(AssertionError):
+        pkg.MLPMixerForImageClassification(image_size=224, patch_size=15)     # tools.py:11
+    m = pkg.MLPMixerForImageClassification(d_model=32, depth=1, patch_size=8, image_size=32, num_classes=10)
+    with pytest.raises(NotImplementedError):                                   # shift_cuda.py:173 precedent
+        m(torch.zeros(1, 3, 32, 32))
+    from importlib import import_module
+    tools = import_module("jittor-mlp_amd.models_pytorch.utils.tools")
+    assert tools.pair(3) == (3, 3) and tools.pair((2, 5)) == (2, 5) and tools.pair([2, 5]) == ([2, 5], [2, 5])
+    assert tools.check_sizes(224, 16) == 196 and tools.check_sizes((32, 48), (8, 4)) == 48
+
+
+def test_product_never_imports_oracle():
+    """A product path routed through the oracle would void every parity claim."""
+    out = subprocess.run([sys.executable, "-c",
+                          "import sys, importlib; sys.path.insert(0, %r); importlib.import_module('jittor-mlp_amd'); "
+                          "print(any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules))" % ROOT],
+                         capture_output=True, text=True, check=True)
+    assert out.stdout.strip() == "False"
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "jittor-mlp_amd")):
+        for fn in files:
+            if fn.endswith(".py"):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), fn
