@@ -50,7 +50,9 @@ def run_cpu_baseline(model_name, kwargs, ctor_name, pkg):
     import oracle
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_oracle_golden import run_oracle
-    cores = os.cpu_count() or 1
+    # one torch thread per physical core, capped: oversubscribing a 2-socket EPYC (256 logical CPUs)
+    # makes MKL/OpenMP collapse (measured 0.14 img/s at 256 threads)
+    cores = max(1, min(64, (os.cpu_count() or 2) // 2))
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     model = getattr(pkg.models_pytorch, ctor_name)(**kwargs).eval()

@@ -35,6 +35,7 @@ struct GemmArgs {
     int rperiod, act, res_mode;
     int t_rows, t_tokens;
     int vec_c, vec_r;   // vector (4-element) store / residual-load allowed
+    int dbg;            // tuning ablations (desc.reserved): 1 = no main loop, 2 = no stores, 4 = no epilogue
 };
 
 template <typename T> struct Mma;
@@ -54,10 +55,13 @@ template <> struct Mma<float> {
     // one 16-byte chunk = 4 consecutive k per lane group; four K=4 steps, each taking element e of
     // every lane's chunk (any k <-> (lane group, e) bijection is valid as long as A and B agree).
     static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.y), __builtin_bit_cast(float, b.y), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.z), __builtin_bit_cast(float, b.z), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), c, 0, 0, 0);
+        // NB: __builtin_bit_cast(float, a.y) on an ext-vector ELEMENT miscompiles with hipcc 7.2 (every
+        // element reads .x); go through memcpy of the whole vector instead.
+        float af[4], bf[4];
+        __builtin_memcpy(af, &a, 16);
+        __builtin_memcpy(bf, &b, 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], c, 0, 0, 0);
         return c;
     }
 };
@@ -100,7 +104,12 @@ template <typename T> __device__ __forceinline__ void store4(T* p, bool vec, con
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool TRANS>
+// GLDS = false: global -> VGPR -> LDS staging (handles every shape: predicated, zero-filled tails).
+// GLDS = true : global_load_lds_dwordx4 straight into LDS (no staging VGPRs, no ds_write pass).  The
+//               LDS image is lane-linear (wave base + lane*16), so the XOR swizzle is applied to the
+//               per-lane SOURCE address; out-of-range rows are clamped (their results are never
+//               stored) and K must be a multiple of half a slab (the ragged half is skipped).
+template <typename T, int BM, int BN, int WM, int WN, bool TRANS, bool GLDS>
 __global__ void __launch_bounds__(WM* WN * 64) gemm_nt_kernel(const GemmArgs p) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM, TN = BN / WN;
@@ -135,7 +144,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_nt_kernel(const GemmArgs p) 
     u32x4 ra[A_IT], rb[B_IT];
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
-    const int nk = (p.K + BK - 1) / BK;
+    const int nk = (p.dbg & 1) ? 0 : (p.K + BK - 1) / BK;
 
 #define MLPK_GLOAD(kt)                                                                           \
     {                                                                                            \
@@ -178,42 +187,188 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_nt_kernel(const GemmArgs p) 
     const int c_off0 = ((fg ^ sw)) << 4;        // K sub-step 0: chunk = fg
     const int c_off1 = ((fg ^ sw) ^ 4) << 4;    // K sub-step 1: chunk = 4 + fg
 
-    MLPK_GLOAD(0);
-    MLPK_SSTORE(0);
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = (kt + 1) < nk;
-        if (more) MLPK_GLOAD(kt + 1);
-        const char* buf = smem + (kt & 1) * BUF;
-        const int krem = p.K - kt * BK;            // wave-uniform: skip the all-zero half of a ragged last slab
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            if (kk == 1 && krem <= BK / 2) break;
-            const int co = kk ? c_off1 : c_off0;
-            u32x4 af[FM], bf[FN];
-#pragma unroll
-            for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const u32x4*>(buf + a_rd + i * 2048 + co);
-#pragma unroll
-            for (int j = 0; j < FN; ++j) bf[j] = *reinterpret_cast<const u32x4*>(buf + b_rd + j * 2048 + co);
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] = TRANS ? Mma<T>::run(af[i], bf[j], acc[i][j]) : Mma<T>::run(bf[j], af[i], acc[i][j]);
-        }
-        if (more) MLPK_SSTORE((kt + 1) & 1);
-        __syncthreads();
+#define MLPK_COMPUTE(kt)                                                                         \
+    {                                                                                            \
+        const char* buf = smem + ((kt)&1) * BUF;                                                 \
+        const int krem = p.K - (kt)*BK; /* wave-uniform: skip the ragged half of the last slab */ \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                       \
+            if (kk == 1 && krem <= BK / 2) break;                                                \
+            const int co = kk ? c_off1 : c_off0;                                                 \
+            u32x4 af[FM], bf[FN];                                                                \
+            _Pragma("unroll") for (int i = 0; i < FM; ++i)                                       \
+                af[i] = *reinterpret_cast<const u32x4*>(buf + a_rd + i * 2048 + co);             \
+            _Pragma("unroll") for (int j = 0; j < FN; ++j)                                       \
+                bf[j] = *reinterpret_cast<const u32x4*>(buf + b_rd + j * 2048 + co);             \
+            _Pragma("unroll") for (int i = 0; i < FM; ++i)                                       \
+                _Pragma("unroll") for (int j = 0; j < FN; ++j) acc[i][j] =                       \
+                    TRANS ? Mma<T>::run(af[i], bf[j], acc[i][j]) : Mma<T>::run(bf[j], af[i], acc[i][j]); \
+        }                                                                                        \
     }
+
+    if constexpr (!GLDS) {
+        MLPK_GLOAD(0);
+        MLPK_SSTORE(0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool more = (kt + 1) < nk;
+            if (more) MLPK_GLOAD(kt + 1);
+            MLPK_COMPUTE(kt);
+            if (more) MLPK_SSTORE((kt + 1) & 1);
+            __syncthreads();
+        }
+    } else {
+        constexpr int NW = WM * WN;
+        constexpr int A_G = BM / 8 / NW, B_G = BN / 8 / NW;   // 1-KiB (8 rows x 128 B) pieces per wave
+        static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split into 8-row pieces per wave");
+        const int lrow = lane >> 3;
+        const int lchunk = (lane & 7) ^ lrow;               // logical chunk this lane fetches (source-side swizzle)
+        const T* srcA[A_G];
+        const T* srcB[B_G];
+#pragma unroll
+        for (int g = 0; g < A_G; ++g) {
+            int gm = m0 + (wave * A_G + g) * 8 + lrow;
+            gm = gm < p.M ? gm : p.M - 1;
+            srcA[g] = A + (size_t)gm * p.lda;
+        }
+#pragma unroll
+        for (int g = 0; g < B_G; ++g) {
+            int gn = n0 + (wave * B_G + g) * 8 + lrow;
+            gn = gn < p.N ? gn : p.N - 1;
+            srcB[g] = B + (size_t)gn * p.ldb;
+        }
+        typedef __attribute__((address_space(3))) void* lds_ptr_t;
+        typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+#define MLPK_STAGE(kt)                                                                           \
+    {                                                                                            \
+        int k__ = (kt)*BK + lchunk * EPC;                                                        \
+        k__ = k__ < p.K ? k__ : p.K - EPC;                                                       \
+        char* dst__ = smem + ((kt)&1) * BUF + wave * (A_G * 1024);                               \
+        _Pragma("unroll") for (int g = 0; g < A_G; ++g)                                          \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(srcA[g] + k__), (lds_ptr_t)(dst__ + g * 1024), 16, 0, 0); \
+        char* dstb__ = smem + ((kt)&1) * BUF + BM * 128 + wave * (B_G * 1024);                   \
+        _Pragma("unroll") for (int g = 0; g < B_G; ++g)                                          \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(srcB[g] + k__), (lds_ptr_t)(dstb__ + g * 1024), 16, 0, 0); \
+    }
+        MLPK_STAGE(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            if ((kt + 1) < nk) MLPK_STAGE(kt + 1);
+            MLPK_COMPUTE(kt);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+#undef MLPK_STAGE
+    }
+#undef MLPK_COMPUTE
 #undef MLPK_GLOAD
 #undef MLPK_SSTORE
 
     // ------------------------------- epilogue -------------------------------
+    if (p.dbg & 4) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) sacc += acc[i][j].x + acc[i][j].y + acc[i][j].z + acc[i][j].w;
+        if (sacc == 123.456f) reinterpret_cast<float*>(p.C)[0] = sacc;
+        return;
+    }
     T* __restrict__ C = reinterpret_cast<T*>(p.C);
     const T* R = reinterpret_cast<const T*>(p.R);
     const bool gelu = p.act == MLPK_ACT_GELU;
 
-    if constexpr (!TRANS) {
+    if constexpr (!TRANS && sizeof(T) == 2) {
+        // ---- 2-byte row-major output: stage the finished tile through LDS (the pipeline buffers are
+        // free now) so that global traffic is full 16-byte-per-lane, whole-row coalesced: the MFMA
+        // accumulator layout only gives 8 bytes per lane in 32-byte runs, which measured 1.9 TB/s.
+        // Phase 1: bias / GELU / column scale+shift / row scale on the fp32 accumulator, round to T,
+        //          ds_write_b64 into a [BM][BN] tile whose 16-byte chunks are XOR-swizzled by row.
+        // Phase 2: every thread moves 16-byte chunks LDS -> (optional residual add|mul) -> global.
+        constexpr int CPR = BN / 8;                      // 16-byte chunks per tile row
+        constexpr int XM = (CPR >= 16 ? 16 : CPR) - 1;   // swizzle mask
+        T* tile = reinterpret_cast<T*>(smem);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int nl = wn * TN + j * 16 + 4 * fg;    // column of this lane's 4-vector inside the tile
+            float bz[4], cs[4], ch[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int n = n0 + nl + r;
+                n = n < p.N ? n : p.N - 1;
+                bz[r] = p.bias ? p.bias[n] : 0.f;
+                cs[r] = p.cscale ? p.cscale[n] : 1.f;
+                ch[r] = p.cshift ? p.cshift[n] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int rl = wm * TM + i * 16 + frow;
+                float rs = 1.f;
+                if (p.rscale) {
+                    int m = m0 + rl;
+                    m = m < p.M ? m : p.M - 1;
+                    rs = p.rscale[m % p.rperiod];
+                }
+                float v[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
+                T e[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = v[r] + bz[r];
+                    if (gelu) t = gelu_f(t);
+                    e[r] = from_f32<T>((t * cs[r] + ch[r]) * rs);
+                }
+                u32x2 pk;
+                __builtin_memcpy(&pk, e, 8);
+                const int c16 = nl >> 3;
+                char* dst = reinterpret_cast<char*>(tile) + rl * (BN * 2) + (((c16 ^ (rl & XM)) << 4) | ((nl & 4) << 1));
+                *reinterpret_cast<u32x2*>(dst) = pk;
+            }
+        }
+        __syncthreads();
+        constexpr int RPASS = NT / CPR;                  // rows moved per pass
+        const int c16 = tid % CPR;
+        const int rsub = tid / CPR;
+        const int gn = n0 + c16 * 8;
+        const bool vec_ok = p.vec_c == 2 && (p.res_mode == MLPK_RES_NONE || p.vec_r == 2);
+        if (gn < p.N) {
+#pragma unroll 4
+            for (int rp = 0; rp < BM / RPASS; ++rp) {
+                const int rl = rp * RPASS + rsub;
+                const int gm = m0 + rl;
+                if (gm >= p.M) break;
+                const u32x4 raw = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(tile) + rl * (BN * 2) +
+                                                                  ((c16 ^ (rl & XM)) << 4));
+                T* cp = C + (size_t)gm * p.ldc + gn;
+                if (vec_ok && gn + 8 <= p.N) {
+                    u32x4 outv = raw;
+                    if (p.res_mode != MLPK_RES_NONE) {
+                        const u32x4 rr = *reinterpret_cast<const u32x4*>(R + (size_t)gm * p.ldr + gn);
+                        T a8[8], r8[8];
+                        __builtin_memcpy(a8, &raw, 16);
+                        __builtin_memcpy(r8, &rr, 16);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float a = to_f32(a8[e]), b = to_f32(r8[e]);
+                            a8[e] = from_f32<T>(p.res_mode == MLPK_RES_ADD ? a + b : a * b);
+                        }
+                        __builtin_memcpy(&outv, a8, 16);
+                    }
+                    if (!(p.dbg & 2) || outv.x == 0x12345678u) *reinterpret_cast<u32x4*>(cp) = outv;
+                } else {
+                    T a8[8];
+                    __builtin_memcpy(a8, &raw, 16);
+                    for (int e = 0; e < 8 && gn + e < p.N; ++e) {
+                        float a = to_f32(a8[e]);
+                        if (p.res_mode != MLPK_RES_NONE) {
+                            const float b = to_f32(R[(size_t)gm * p.ldr + gn + e]);
+                            a = p.res_mode == MLPK_RES_ADD ? a + b : a * b;
+                        }
+                        cp[e] = from_f32<T>(a);
+                    }
+                }
+            }
+        }
+    } else if constexpr (!TRANS) {
         // lane owns row m = .. + (lane & 15) and 4 consecutive columns n = .. + 4*(lane >> 4) + r
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
@@ -244,7 +399,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_nt_kernel(const GemmArgs p) 
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = (p.res_mode == MLPK_RES_ADD) ? v[r] + rv[r] : v[r] * rv[r];
                     }
-                    store4<T>(C + co, p.vec_c != 0, v);
+                    if (!(p.dbg & 2) || v[0] == 123.456f) store4<T>(C + co, p.vec_c != 0, v);
                 } else {
                     for (int r = 0; r < 4 && nb + r < p.N; ++r) {
                         float t = v[r];
@@ -296,28 +451,33 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_nt_kernel(const GemmArgs p) 
 }
 
 // ------------------------------- host-side dispatch -------------------------------
-struct TileCfg { int bm, bn, wm, wn; };
+struct TileCfg { int bm, bn, wm, wn, glds; };
 static const TileCfg kTiles[] = {
-    {256, 256, 2, 4},   // algo 1: 8 waves, 128 KiB LDS, 1 workgroup / CU
-    {256, 128, 4, 2},   // algo 2: 8 waves,  96 KiB
-    {128, 256, 2, 4},   // algo 3: 8 waves,  96 KiB
-    {128, 128, 2, 2},   // algo 4: 4 waves,  64 KiB, 2 workgroups / CU
-    {64, 64, 2, 2},     // algo 5: 4 waves,  32 KiB, small problems
+    {256, 256, 2, 4, 0},   // algo 1: 8 waves, 128 KiB LDS, 1 workgroup / CU, register staging
+    {256, 128, 4, 2, 0},   // algo 2: 8 waves,  96 KiB
+    {128, 256, 2, 4, 0},   // algo 3: 8 waves,  96 KiB
+    {128, 128, 2, 2, 0},   // algo 4: 4 waves,  64 KiB, 2 workgroups / CU
+    {64, 64, 2, 2, 0},     // algo 5: 4 waves,  32 KiB, small / ragged problems
+    {256, 256, 2, 4, 1},   // algo 6..9: the same tiles with direct-to-LDS loads (K % half-slab == 0)
+    {256, 128, 4, 2, 1},
+    {128, 256, 2, 4, 1},
+    {128, 128, 2, 2, 1},
+    {64, 64, 2, 2, 1},     // algo 10
 };
 static const int kNumTiles = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, bool GLDS>
 static int launch_cfg(const GemmArgs& a, bool trans, hipStream_t stream) {
     const int lds = 2 * (BM + BN) * 128;
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     hipError_t e;
     if (trans) {
-        auto k = gemm_nt_kernel<T, BM, BN, WM, WN, true>;
+        auto k = gemm_nt_kernel<T, BM, BN, WM, WN, true, GLDS>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(k, dim3(tiles), dim3(WM * WN * 64), lds, stream, a);
     } else {
-        auto k = gemm_nt_kernel<T, BM, BN, WM, WN, false>;
+        auto k = gemm_nt_kernel<T, BM, BN, WM, WN, false, GLDS>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(k, dim3(tiles), dim3(WM * WN * 64), lds, stream, a);
@@ -328,29 +488,34 @@ static int launch_cfg(const GemmArgs& a, bool trans, hipStream_t stream) {
 
 template <typename T> static int launch_algo(int algo, const GemmArgs& a, bool trans, hipStream_t s) {
     switch (algo) {
-        case 1: return launch_cfg<T, 256, 256, 2, 4>(a, trans, s);
-        case 2: return launch_cfg<T, 256, 128, 4, 2>(a, trans, s);
-        case 3: return launch_cfg<T, 128, 256, 2, 4>(a, trans, s);
-        case 4: return launch_cfg<T, 128, 128, 2, 2>(a, trans, s);
-        case 5: return launch_cfg<T, 64, 64, 2, 2>(a, trans, s);
+        case 1: return launch_cfg<T, 256, 256, 2, 4, false>(a, trans, s);
+        case 2: return launch_cfg<T, 256, 128, 4, 2, false>(a, trans, s);
+        case 3: return launch_cfg<T, 128, 256, 2, 4, false>(a, trans, s);
+        case 4: return launch_cfg<T, 128, 128, 2, 2, false>(a, trans, s);
+        case 5: return launch_cfg<T, 64, 64, 2, 2, false>(a, trans, s);
+        case 6: return launch_cfg<T, 256, 256, 2, 4, true>(a, trans, s);
+        case 7: return launch_cfg<T, 256, 128, 4, 2, true>(a, trans, s);
+        case 8: return launch_cfg<T, 128, 256, 2, 4, true>(a, trans, s);
+        case 9: return launch_cfg<T, 128, 128, 2, 2, true>(a, trans, s);
+        case 10: return launch_cfg<T, 64, 64, 2, 2, true>(a, trans, s);
         default: return MLPK_EMODE;
     }
 }
 
-// Pick the tile that minimises (padded MFMA work) x (wave-quantisation of the grid over 256 CUs).
-static int auto_algo(int M, int N) {
+// Pick the tile that minimises (padded MFMA work / tile efficiency) x (a soft tail penalty for grids that
+// do not fill the 256 CUs many times over).  Efficiencies are measured on MI355X (profiles/).
+static int auto_algo(int M, int N, bool glds_ok) {
     double best = 1e300;
     int best_algo = 4;
     for (int i = 0; i < kNumTiles; ++i) {
         const TileCfg& t = kTiles[i];
-        const double tm = (double)((M + t.bm - 1) / t.bm), tn = (double)((N + t.bn - 1) / t.bn);
-        const double tiles = tm * tn;
+        if (t.glds != (glds_ok ? 1 : 0)) continue;
+        const double tiles = (double)((M + t.bm - 1) / t.bm) * (double)((N + t.bn - 1) / t.bn);
         const int wg_per_cu = (t.bm + t.bn) * 256 <= 80 * 1024 ? 2 : 1;
         const double slots = 256.0 * wg_per_cu;
-        const double rounds = __builtin_ceil(tiles / slots);
-        // time ~ rounds * work per tile / per-CU rate; smaller tiles run at a lower MFMA efficiency
-        const double eff = (t.bm * t.bn >= 256 * 256) ? 1.0 : (t.bm * t.bn >= 256 * 128) ? 0.92 : (t.bm * t.bn >= 128 * 128) ? 0.80 : 0.45;
-        const double cost = rounds * (double)t.bm * t.bn / wg_per_cu / eff;
+        const int area = t.bm * t.bn;
+        const double eff = area >= 256 * 256 ? 1.0 : area >= 256 * 128 ? 0.92 : area >= 128 * 128 ? 0.82 : 0.5;
+        const double cost = tiles * area / eff * (1.0 + 0.5 * slots / tiles);
         if (cost < best) { best = cost; best_algo = i + 1; }
     }
     return best_algo;
@@ -401,11 +566,17 @@ extern "C" int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream) {
     a.rperiod = d->rperiod > 0 ? d->rperiod : 1;
     a.act = d->act; a.res_mode = d->res_mode;
     a.t_rows = d->t_rows; a.t_tokens = d->t_tokens;
+    a.dbg = d->reserved;
     const int vb = 4 * es;   // bytes of a 4-element vector
     a.vec_c = (d->ldc % 4 == 0) && (((uintptr_t)d->C % vb) == 0);
     a.vec_r = d->R ? ((d->ldr % 4 == 0) && (((uintptr_t)d->R % vb) == 0)) : 0;
+    if (a.vec_c && d->ldc % 8 == 0 && ((uintptr_t)d->C % 16) == 0) a.vec_c = 2;     // 8-element (16-byte) vectors
+    if (a.vec_r && d->ldr % 8 == 0 && ((uintptr_t)d->R % 16) == 0) a.vec_r = 2;
     int algo = d->algo;
-    if (algo == 0) algo = auto_algo(d->M, d->N);
+    const bool glds_ok = d->K % (4 * epc) == 0;      // K a multiple of half a 128-byte slab
+    if (algo == 0) algo = auto_algo(d->M, d->N, glds_ok);
+    if (algo < 1 || algo > kNumTiles) return MLPK_EMODE;
+    if (kTiles[algo - 1].glds && !glds_ok) return MLPK_ESHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (d->dtype) {
         case MLPK_F32: return launch_algo<float>(algo, a, trans, s);

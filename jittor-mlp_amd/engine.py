@@ -80,7 +80,7 @@ GEMM_ALGO = {}                    # tag -> forced tile config (tuning/bench hook
 
 def gemm(A, B, C, M, Nn, K, *, lda=None, ldb=None, ldc=None, bias=None, act=N.ACT_NONE, cscale=None, cshift=None,
          rscale=None, rperiod=0, R=None, ldr=None, res=N.RES_NONE, out_mode=N.OUT_ROWMAJOR, t_rows=0, t_tokens=0,
-         algo=0, tag=None):
+         algo=0, tag=None, dbg=0):
     if tag is not None and algo == 0:
         algo = GEMM_ALGO.get(tag, 0)
     timed = TIMER is not None and tag is not None
@@ -98,6 +98,7 @@ def gemm(A, B, C, M, Nn, K, *, lda=None, ldb=None, ldc=None, bias=None, act=N.AC
     d.bias, d.cscale, d.cshift, d.rscale = ptr(bias), ptr(cscale), ptr(cshift), ptr(rscale)
     d.rperiod, d.act, d.res_mode, d.out_mode = rperiod, act, res, out_mode
     d.t_rows, d.t_tokens, d.algo = t_rows, t_tokens, algo
+    d.reserved = dbg
     N.check(N.lib().mlpk_gemm_nt(ctypes.byref(d), stream()), "mlpk_gemm_nt")
     if timed:
         ev1.record()

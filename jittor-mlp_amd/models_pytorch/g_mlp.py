@@ -54,7 +54,7 @@ class gMLP(E.EngineModule):
             pk[p + "p2.w"] = E.pack_matrix(blk.channel_proj2.weight, dtype, device)
             pk[p + "p2.b"] = E.f32(blk.channel_proj2.bias, device)
             pk[p + "sgu.g"], pk[p + "sgu.b"] = E.f32(blk.sgu.norm.weight, device), E.f32(blk.sgu.norm.bias, device)
-            pk[p + "sp.w"] = E.pack_matrix(blk.sgu.spatial_proj.weight, dtype, device)      # (S, S_pad)
+            pk[p + "sp.w"] = E.pack_matrix(blk.sgu.spatial_proj.weight, dtype, device, kpad=32)      # (S, S_pad)
             pk[p + "sp.b"] = E.f32(blk.sgu.spatial_proj.bias, device)
 
     def _pack(self, dtype, device):
@@ -65,7 +65,7 @@ class gMLP(E.EngineModule):
     def _run_blocks(self, ws, pk, x, B):
         S, C, F, depth = self._dims
         rows = B * S
-        sp = E.round_up(S, 8)
+        sp = E.round_up(S, 32)        # token K padding: whole half-slabs -> direct-to-LDS GEMM tiles
         for i in range(depth):
             p = "b%d." % i
             mean, rstd = layernorm_stats(ws, x, rows, C)

@@ -62,9 +62,9 @@ class MLPMixer(E.EngineModule):
             tok, ch = blk[0], blk[1]
             p = "b%d." % i
             pk[p + "tok.ln.g"], pk[p + "tok.ln.b"] = E.f32(tok.norm.weight, device), E.f32(tok.norm.bias, device)
-            pk[p + "tok.fc1.w"] = E.pack_matrix(tok.fn.net[0].weight, dtype, device)     # (4S, S_pad)
+            pk[p + "tok.fc1.w"] = E.pack_matrix(tok.fn.net[0].weight, dtype, device, kpad=32)     # (4S, S_pad)
             pk[p + "tok.fc1.b"] = E.f32(tok.fn.net[0].bias, device)
-            pk[p + "tok.fc2.w"] = E.pack_matrix(tok.fn.net[3].weight, dtype, device)     # (S, 4S_pad)
+            pk[p + "tok.fc2.w"] = E.pack_matrix(tok.fn.net[3].weight, dtype, device, kpad=32)     # (S, 4S_pad)
             pk[p + "tok.fc2.b"] = E.f32(tok.fn.net[3].bias, device)
             pk[p + "ch.ln.g"], pk[p + "ch.ln.b"] = E.f32(ch.norm.weight, device), E.f32(ch.norm.bias, device)
             pk[p + "ch.fc1.w"] = E.pack_matrix(ch.fn.net[0].weight, dtype, device)
@@ -81,9 +81,9 @@ class MLPMixer(E.EngineModule):
         """x: (B*S, C) channel-last tokens, updated in place."""
         S, C, depth, ef = self._dims
         rows = B * S
-        sp = E.round_up(S, 8)
+        sp = E.round_up(S, 32)        # token K padding: whole half-slabs -> direct-to-LDS GEMM tiles
         th = S * ef
-        thp = E.round_up(th, 8)
+        thp = E.round_up(th, 32)
         for i in range(depth):
             p = "b%d." % i
             mean, rstd = layernorm_stats(ws, x, rows, C)

@@ -64,7 +64,7 @@ class ResMLP(E.EngineModule):
             pk[p + "pre.a"], pk[p + "pre.b"] = E.f32(blk.pre_affine.alpha, device), E.f32(blk.pre_affine.beta, device)
             pk[p + "post.a"], pk[p + "post.b"] = E.f32(blk.post_affine.alpha, device), E.f32(blk.post_affine.beta, device)
             pk[p + "g1"], pk[p + "g2"] = E.f32(blk.gamma_1, device), E.f32(blk.gamma_2, device)
-            pk[p + "tok.w"] = E.pack_matrix(blk.token_mix.weight, dtype, device)            # (S, S_pad)
+            pk[p + "tok.w"] = E.pack_matrix(blk.token_mix.weight, dtype, device, kpad=32)            # (S, S_pad)
             pk[p + "tok.b"] = E.f32(blk.token_mix.bias, device)
             pk[p + "fc1.w"] = E.pack_matrix(blk.ff.net[0].weight, dtype, device)
             pk[p + "fc1.b"] = E.f32(blk.ff.net[0].bias, device)
@@ -79,7 +79,7 @@ class ResMLP(E.EngineModule):
     def _run_blocks(self, ws, pk, x, B):
         S, C, depth, ef = self._dims
         rows = B * S
-        sp = E.round_up(S, 8)
+        sp = E.round_up(S, 32)        # token K padding: whole half-slabs -> direct-to-LDS GEMM tiles
         hidden = C * ef
         for i in range(depth):
             p = "b%d." % i

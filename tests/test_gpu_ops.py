@@ -352,3 +352,41 @@ def test_dwconv(dtype):
         d = oracle.functional.depthwise_conv_same(xn, w.double(), bias.double())
         ref = xn + oracle.gelu(d) * bns.double().view(1, C, 1, 1) + bnh.double().view(1, C, 1, 1)
         assert (out.cpu().double().permute(0, 3, 1, 2) - ref).abs().max() < EPS[dtype] * 8
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("algo", [6, 7, 8, 9])
+def test_gemm_direct_to_lds_tiles(dtype, algo):
+    """global_load_lds staging: ragged M/N (clamped source rows), K = whole and half slabs, both outputs."""
+    pkg = load_pkg()
+    E, N = pkg.engine, pkg._native
+    es = 4 if dtype == torch.float32 else 8
+    for ci, (M, Nn, kmul, trans) in enumerate([(300, 200, 12, False), (513, 129, 4, False), (256, 256, 20, False),
+                                               (3 * 64, 49, 8, True), (2 * 200, 196, 28, True)]):
+        K = kmul * es * 2                                      # multiples of half a 128-byte slab
+        A = rnd((M, K), dtype, 200 + ci).to(dev())
+        B = rnd((Nn, K), dtype, 210 + ci, 1.0 / math.sqrt(K)).to(dev())
+        bias = rnd((Nn,), torch.float32, 220 + ci).to(dev())
+        if not trans:
+            R = rnd((M, Nn), dtype, 230 + ci).to(dev())
+            C = torch.full((M, Nn), float("nan"), dtype=dtype, device=dev())
+            E.gemm(A, B, C, M, Nn, K, bias=bias, act=1, R=R, res=1, algo=algo)
+            ref = gemm_ref(A.cpu(), B.cpu(), M, Nn, K, bias=bias.cpu(), act=1, R=R.cpu(), res=1)
+            got = C.cpu().double()
+        else:
+            t_rows = 64 if ci == 3 else 200
+            nimg = M // t_rows
+            R = rnd((nimg * Nn, t_rows), dtype, 230 + ci).to(dev())
+            C = torch.full((nimg * Nn, t_rows), float("nan"), dtype=dtype, device=dev())
+            E.gemm(A, B, C, M, Nn, K, ldc=t_rows, bias=bias, R=R, ldr=t_rows, res=1, out_mode=N.OUT_TOKEN_T, t_rows=t_rows,
+                   t_tokens=Nn, algo=algo)
+            ref = gemm_ref(A.cpu(), B.cpu(), M, Nn, K, bias=bias.cpu(), R=R.cpu(), res=1, out_mode=1, t_rows=t_rows, t_tokens=Nn)
+            got = C.cpu().double().reshape(nimg, Nn, t_rows)
+        torch.cuda.synchronize()
+        assert torch.isfinite(got).all(), (ci, "non-finite")
+        err = (got - ref).abs().max().item()
+        tol = EPS[dtype] * max(1.0, ref.abs().max().item()) * 4
+        assert err < tol, (str(dtype), algo, ci, err, tol)
+    with pytest.raises(N.MlpkError):                          # K not a multiple of half a slab -> refused, not wrong
+        A = torch.zeros((64, es * 3), dtype=dtype, device=dev())
+        E.gemm(A, A, torch.zeros((64, 64), dtype=dtype, device=dev()), 64, 64, es * 3, algo=algo)

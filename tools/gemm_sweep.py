@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""GPU tuning aid: time every GEMM tile configuration on the Mixer-B/16 bs=256 shapes (HIP events,
+random bf16 operands) and print TFLOP/s.  usage: python tools/gemm_sweep.py [dtype] [algos]"""
+import importlib
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("jittor-mlp_amd")
+E, N = pkg.engine, pkg._native
+dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[sys.argv[1] if len(sys.argv) > 1 else "bf16"]
+algos = [int(a) for a in sys.argv[2].split(",")] if len(sys.argv) > 2 else list(range(1, N.lib().mlpk_gemm_algo_count() + 1))
+dev = "cuda:0"
+SHAPES = [  # name, M, N, K, token_t(t_rows, t_tokens) or None, gelu
+    ("channel_fc1", 50176, 3072, 768, None, True),
+    ("channel_fc2", 50176, 768, 3072, None, False),
+    ("token_fc1", 196608, 784, 200, None, True),
+    ("token_fc2", 196608, 196, 784, (768, 196), False),
+    ("gmlp_proj1", 50176, 3072, 256, None, True),
+    ("vip_branch", 262144, 384, 384, None, False),
+]
+for name, M, Nn, K, tt, gelu in SHAPES:
+    A = (torch.rand((M, K), device=dev) * 2 - 1).to(dt)
+    B = ((torch.rand((Nn, K), device=dev) * 2 - 1) / K ** 0.5).to(dt)
+    bias = torch.rand(Nn, device=dev)
+    if tt:
+        C = torch.zeros((M // tt[0] * tt[1], tt[0]), dtype=dt, device=dev)
+        kw = dict(ldc=tt[0], R=C, ldr=tt[0], res=N.RES_ADD, out_mode=N.OUT_TOKEN_T, t_rows=tt[0], t_tokens=tt[1])
+    else:
+        C = torch.zeros((M, Nn), dtype=dt, device=dev)
+        kw = dict(R=C, res=N.RES_ADD) if not gelu else {}
+    for algo in algos:
+        try:
+            for _ in range(2):
+                E.gemm(A, B, C, M, Nn, K, bias=bias, act=N.ACT_GELU if gelu else 0, algo=algo, **kw)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 10
+            e0.record()
+            for _ in range(reps):
+                E.gemm(A, B, C, M, Nn, K, bias=bias, act=N.ACT_GELU if gelu else 0, algo=algo, **kw)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            print("%-12s M=%6d N=%4d K=%4d algo=%d  %8.3f ms  %7.1f TFLOP/s" % (name, M, Nn, K, algo, ms, 2.0 * M * Nn * K / ms / 1e9), flush=True)
+        except Exception as ex:  # noqa
+            print(name, algo, "ERR", str(ex)[:80])
+    del A, B, C
