@@ -186,11 +186,13 @@ class Workspace:
         self.device, self.dtype = device, dtype
         self.t = {}
 
-    def get(self, name, shape, dtype=None):
+    def get(self, name, shape, dtype=None, fill=0.0):
         t = self.t.get(name)
         if t is None:
-            t = torch.zeros(shape, dtype=dtype or self.dtype, device=self.device)
+            t = torch.full(shape, fill, dtype=dtype or self.dtype, device=self.device)
             self.t[name] = t
+        elif tuple(t.shape) != tuple(shape):
+            raise RuntimeError("workspace buffer %r re-requested with a different shape" % name)
         return t
 
 

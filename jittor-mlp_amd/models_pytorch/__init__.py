@@ -5,5 +5,18 @@ resolve here."""
 from .g_mlp import gMLPForImageClassification  # noqa: F401
 from .res_mlp import ResMLPForImageClassification  # noqa: F401
 from .mlp_mixer import MLPMixerForImageClassification  # noqa: F401
+from .vip import ViP  # noqa: F401
+from .s2_mlp_v1 import S2MLPv1, S2MLPv1_deep, S2MLPv1_wide  # noqa: F401
+from .s2_mlp_v2 import S2MLPv2  # noqa: F401
+from .conv_mixer import ConvMixer  # noqa: F401
+from .as_mlp import AS_MLP  # noqa: F401
+from .utils import Shift  # noqa: F401
+# secondary classes the reference lets users import from the sub-modules
+from .mlp_mixer import MLPMixer  # noqa: F401
+from .g_mlp import gMLP  # noqa: F401
+from .res_mlp import ResMLP  # noqa: F401
+from .vip import WeightedPermutator, Permutator  # noqa: F401
+from .s2_mlp_v2 import S2Block  # noqa: F401
 
-__all__ = ["gMLPForImageClassification", "ResMLPForImageClassification", "MLPMixerForImageClassification"]
+__all__ = ["gMLPForImageClassification", "ResMLPForImageClassification", "MLPMixerForImageClassification", "ViP",
+           "S2MLPv1", "S2MLPv1_deep", "S2MLPv1_wide", "S2MLPv2", "ConvMixer", "AS_MLP", "Shift"]

@@ -1,0 +1,281 @@
+"""AS-MLP, drop-in for the reference's models_pytorch/as_mlp.py (eval-mode forward).
+
+The reference keeps NCHW and runs every "linear" as a 1x1 Conv2d; only the input image layout and
+the logits are contractual, so activations live channel-last here and every 1x1 conv is the same
+K-contiguous NT GEMM as the rest of the package.  Per block (as_mlp.py:149-162, 55-95):
+  x <- x + conv3(GN(gelu(conv2_1(shift_W(t))) + gelu(conv2_2(shift_H(t))))),  t = gelu(GN(conv1(GN(x))))
+  x <- x + fc2(gelu(fc1(GN(x))))
+GroupNorm(1, C) (as_mlp.py:343-344) = one (mean, rstd) per SAMPLE over (C,H,W): mlpk_row_stats on the
+sample viewed as one long row, applied (with GELU where the reference has it) by mlpk_norm_apply.
+The axial shift (utils/shift_cuda.py:44-72) runs as mlpk_shift_nhwc; conv2_2's epilogue does
+GELU and adds conv2_1's GELU output, conv3's and fc2's epilogues add the residual.
+DropPath is the identity in eval mode (as_mlp.py:144,159-160); `use_checkpoint` is accepted and ignored.
+"""
+import torch
+from torch import nn
+
+from .. import _native as N
+from .. import engine as E
+from .common import Holder, head_linear
+from .utils.shift import Shift
+
+
+def to_2tuple(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+
+
+class Mlp(Holder):
+    """as_mlp.py:8-24."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Conv2d(in_features, hidden_features, 1, 1)
+        self.act = act_layer()
+        self.fc2 = nn.Conv2d(hidden_features, out_features, 1, 1)
+        self.drop = nn.Dropout(drop)
+
+
+class AxialShift(Holder):
+    """as_mlp.py:27-53."""
+
+    def __init__(self, dim, shift_size, as_bias=True, proj_drop=0.):
+        super().__init__()
+        self.dim = dim
+        self.shift_size = shift_size
+        self.pad = shift_size // 2
+        self.conv1 = nn.Conv2d(dim, dim, 1, 1, 0, groups=1, bias=as_bias)
+        self.conv2_1 = nn.Conv2d(dim, dim, 1, 1, 0, groups=1, bias=as_bias)
+        self.conv2_2 = nn.Conv2d(dim, dim, 1, 1, 0, groups=1, bias=as_bias)
+        self.conv3 = nn.Conv2d(dim, dim, 1, 1, 0, groups=1, bias=as_bias)
+        self.actn = nn.GELU()
+        self.norm1 = MyNorm(dim)
+        self.norm2 = MyNorm(dim)
+        self.shift_dim2 = Shift(self.shift_size, 2)
+        self.shift_dim3 = Shift(self.shift_size, 3)
+
+    def extra_repr(self):
+        return f'dim={self.dim}, shift_size={self.shift_size}'
+
+
+class AxialShiftedBlock(Holder):
+    """as_mlp.py:118-147."""
+
+    def __init__(self, dim, input_resolution, shift_size=7, mlp_ratio=4., as_bias=True, drop=0., drop_path=0.,
+                 act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.dim = dim
+        self.input_resolution = input_resolution
+        self.shift_size = shift_size
+        self.mlp_ratio = mlp_ratio
+        self.norm1 = norm_layer(dim)
+        self.axial_shift = AxialShift(dim, shift_size=shift_size, as_bias=as_bias, proj_drop=drop)
+        self.drop_path = nn.Identity()                 # DropPath(p) is the identity in eval mode
+        self.drop_path_rate = drop_path
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+
+
+class PatchMerging(Holder):
+    """as_mlp.py:182-195."""
+
+    def __init__(self, input_resolution, dim, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.input_resolution = input_resolution
+        self.dim = dim
+        self.reduction = nn.Conv2d(4 * dim, 2 * dim, 1, 1, bias=False)
+        self.norm = norm_layer(4 * dim)
+
+
+class BasicLayer(Holder):
+    """as_mlp.py:228-272."""
+
+    def __init__(self, dim, input_resolution, depth, shift_size, mlp_ratio=4., as_bias=True, drop=0., drop_path=0.,
+                 norm_layer=nn.LayerNorm, downsample=None, use_checkpoint=False):
+        super().__init__()
+        self.dim = dim
+        self.input_resolution = input_resolution
+        self.depth = depth
+        self.use_checkpoint = use_checkpoint
+        self.blocks = nn.ModuleList([
+            AxialShiftedBlock(dim=dim, input_resolution=input_resolution, shift_size=shift_size, mlp_ratio=mlp_ratio,
+                              as_bias=as_bias, drop=drop, drop_path=drop_path[i] if isinstance(drop_path, list) else drop_path,
+                              norm_layer=norm_layer) for i in range(depth)])
+        self.downsample = downsample(input_resolution, dim=dim, norm_layer=norm_layer) if downsample is not None else None
+
+
+class PatchEmbed(Holder):
+    """as_mlp.py:296-321."""
+
+    def __init__(self, img_size=224, patch_size=4, in_chans=3, embed_dim=96, norm_layer=None):
+        super().__init__()
+        img_size = to_2tuple(img_size)
+        patch_size = to_2tuple(patch_size)
+        self.img_size = img_size
+        self.patch_size = patch_size
+        self.patches_resolution = [img_size[0] // patch_size[0], img_size[1] // patch_size[1]]
+        self.num_patches = self.patches_resolution[0] * self.patches_resolution[1]
+        self.in_chans = in_chans
+        self.embed_dim = embed_dim
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+        self.norm = norm_layer(embed_dim) if norm_layer is not None else None
+
+
+def MyNorm(dim):
+    """GroupNorm with ONE group (as_mlp.py:343-344)."""
+    return nn.GroupNorm(1, dim)
+
+
+def _gn_params(norm, device):
+    if not (isinstance(norm, nn.GroupNorm) and norm.num_groups == 1):
+        raise NotImplementedError("the MI355X path implements the reference's MyNorm = GroupNorm(1, C) only")
+    return E.f32(norm.weight, device), E.f32(norm.bias, device)
+
+
+class AS_MLP(E.EngineModule):
+    """Same signature and defaults as the reference (as_mlp.py:368-373)."""
+
+    def __init__(self, img_size=224, patch_size=4, in_chans=3, num_classes=1000, embed_dim=96, depths=[2, 2, 6, 2],
+                 shift_size=5, mlp_ratio=4., as_bias=True, drop_rate=0., drop_path_rate=0.1, norm_layer=MyNorm,
+                 patch_norm=True, use_checkpoint=False, **kwargs):
+        super().__init__()
+        self.num_classes = num_classes
+        self.num_layers = len(depths)
+        self.embed_dim = embed_dim
+        self.patch_norm = patch_norm
+        self.num_features = int(embed_dim * 2 ** (self.num_layers - 1))
+        self.mlp_ratio = mlp_ratio
+        self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim,
+                                      norm_layer=norm_layer if self.patch_norm else None)
+        patches_resolution = self.patch_embed.patches_resolution
+        self.patches_resolution = patches_resolution
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(depths))]
+        self.layers = nn.ModuleList()
+        for i_layer in range(self.num_layers):
+            self.layers.append(BasicLayer(
+                dim=int(embed_dim * 2 ** i_layer),
+                input_resolution=(patches_resolution[0] // (2 ** i_layer), patches_resolution[1] // (2 ** i_layer)),
+                depth=depths[i_layer], shift_size=shift_size, mlp_ratio=self.mlp_ratio, as_bias=as_bias, drop=drop_rate,
+                drop_path=dpr[sum(depths[:i_layer]):sum(depths[:i_layer + 1])], norm_layer=norm_layer,
+                downsample=PatchMerging if (i_layer < self.num_layers - 1) else None, use_checkpoint=use_checkpoint))
+        self.norm = norm_layer(self.num_features)
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
+        self.apply(self._init_weights)
+        self._shift = shift_size
+
+    def _init_weights(self, m):
+        # as_mlp.py:419-426: only nn.Linear (= the head) gets the truncated normal
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def _pack(self, dtype, device):
+        pk = {}
+        pe = self.patch_embed
+        pk["embed.w"] = E.pack_matrix(pe.proj.weight, dtype, device)
+        pk["embed.b"] = E.f32(pe.proj.bias, device)
+        if pe.norm is not None:
+            pk["embed.g"], pk["embed.be"] = _gn_params(pe.norm, device)
+
+        def conv(prefix, c):
+            pk[prefix + ".w"] = E.pack_matrix(c.weight, dtype, device)
+            pk[prefix + ".b"] = E.f32(c.bias, device) if c.bias is not None else None
+
+        for li, layer in enumerate(self.layers):
+            for bi, blk in enumerate(layer.blocks):
+                p = "l%d.b%d." % (li, bi)
+                pk[p + "n1.g"], pk[p + "n1.b"] = _gn_params(blk.norm1, device)
+                pk[p + "n2.g"], pk[p + "n2.b"] = _gn_params(blk.norm2, device)
+                a = blk.axial_shift
+                conv(p + "c1", a.conv1), conv(p + "c21", a.conv2_1), conv(p + "c22", a.conv2_2), conv(p + "c3", a.conv3)
+                pk[p + "an1.g"], pk[p + "an1.b"] = _gn_params(a.norm1, device)
+                pk[p + "an2.g"], pk[p + "an2.b"] = _gn_params(a.norm2, device)
+                conv(p + "fc1", blk.mlp.fc1), conv(p + "fc2", blk.mlp.fc2)
+            if layer.downsample is not None:
+                p = "l%d.down." % li
+                pk[p + "g"], pk[p + "b"] = _gn_params(layer.downsample.norm, device)
+                pk[p + "w"] = E.pack_matrix(layer.downsample.reduction.weight, dtype, device)
+        pk["norm.g"], pk["norm.b"] = _gn_params(self.norm, device)
+        if isinstance(self.head, nn.Linear):
+            pk["head.w"] = E.pack_matrix(self.head.weight, dtype, device)
+            pk["head.b"] = E.f32(self.head.bias, device)
+        return pk
+
+    @staticmethod
+    def _gn(ws, tag, x, B, HW, C, g, b, out, act=N.ACT_NONE):
+        """GroupNorm(1,C) of channel-last x (B*HW, C) -> out (may alias x), optional GELU."""
+        mean = ws.get(tag + ".mean", (B,), torch.float32)
+        rstd = ws.get(tag + ".rstd", (B,), torch.float32)
+        E.row_stats(x, B, HW * C, HW * C, mean, rstd)
+        E.norm_apply(x, B * HW, C, C, mean=mean, rstd=rstd, gamma=g, beta=b, act=act, stat_group=HW, out_rm=out, ld_rm=C)
+        return out
+
+    def forward(self, x):
+        cd = self._resolve(x)
+        pe = self.patch_embed
+        B, _, H_in, W_in = x.shape
+        # FIXME-free restatement of as_mlp.py:328: the input size must match the constructor's
+        assert H_in == pe.img_size[0] and W_in == pe.img_size[1], \
+            f"Input image size ({H_in}*{W_in}) doesn't match model ({pe.img_size[0]}*{pe.img_size[1]})."
+        pk = self._get_pack(cd, x.device)
+        ws = self._get_space(B, cd, x.device)
+        x = x.contiguous()
+        ph, pw = pe.patch_size
+        H, W = H_in // ph, W_in // pw
+        C = self.embed_dim
+        kp = pk["embed.w"].shape[1]
+        patches = ws.get("embed.patches", (B * H * W, kp))
+        E.patchify(x, patches, B, pe.in_chans, H_in, W_in, ph, pw, 0, kp)
+        cur = ws.get("l0.x", (B * H * W, C))
+        E.gemm(patches, pk["embed.w"], cur, B * H * W, C, kp, bias=pk["embed.b"])
+        if pe.norm is not None:
+            self._gn(ws, "gn0", cur, B, H * W, C, pk["embed.g"], pk["embed.be"], cur)
+        for li, layer in enumerate(self.layers):
+            rows, HW = B * H * W, H * W
+            t0 = ws.get("l%d.t0" % li, (rows, C))
+            t1 = ws.get("l%d.t1" % li, (rows, C))
+            t2 = ws.get("l%d.t2" % li, (rows, C))
+            hid = int(C * self.mlp_ratio)
+            hbuf = ws.get("l%d.h" % li, (rows, hid))
+            tag = "l%d.gn" % li
+            for bi in range(len(layer.blocks)):
+                p = "l%d.b%d." % (li, bi)
+                self._gn(ws, tag, cur, B, HW, C, pk[p + "n1.g"], pk[p + "n1.b"], t0)                 # norm1(x)
+                E.gemm(t0, pk[p + "c1.w"], t1, rows, C, C, bias=pk[p + "c1.b"], tag="as_conv")       # conv1
+                self._gn(ws, tag, t1, B, HW, C, pk[p + "an1.g"], pk[p + "an1.b"], t1, act=N.ACT_GELU)  # GN -> GELU
+                E.shift_nhwc(t1, t0, B, H, W, C, self._shift, 3)                                     # shift along W
+                E.gemm(t0, pk[p + "c21.w"], t2, rows, C, C, bias=pk[p + "c21.b"], act=N.ACT_GELU, tag="as_conv")
+                E.shift_nhwc(t1, t0, B, H, W, C, self._shift, 2)                                     # shift along H
+                E.gemm(t0, pk[p + "c22.w"], t2, rows, C, C, bias=pk[p + "c22.b"], act=N.ACT_GELU, R=t2, res=N.RES_ADD,
+                       tag="as_conv")                                                                # gelu(.) + x_lr
+                self._gn(ws, tag, t2, B, HW, C, pk[p + "an2.g"], pk[p + "an2.b"], t2)
+                E.gemm(t2, pk[p + "c3.w"], cur, rows, C, C, bias=pk[p + "c3.b"], R=cur, res=N.RES_ADD, tag="as_conv")
+                self._gn(ws, tag, cur, B, HW, C, pk[p + "n2.g"], pk[p + "n2.b"], t0)                 # norm2(x)
+                E.gemm(t0, pk[p + "fc1.w"], hbuf, rows, hid, C, bias=pk[p + "fc1.b"], act=N.ACT_GELU, tag="as_fc1")
+                E.gemm(hbuf, pk[p + "fc2.w"], cur, rows, C, hid, bias=pk[p + "fc2.b"], R=cur, res=N.RES_ADD, tag="as_fc2")
+            if layer.downsample is not None:
+                assert H % 2 == 0 and W % 2 == 0, f"x size ({H}*{W}) are not even."                   # as_mlp.py:203
+                p = "l%d.down." % li
+                H2, W2 = H // 2, W // 2
+                merged = ws.get("l%d.merged" % li, (B * H2 * W2, 4 * C))
+                E.patchify(cur, merged, B, C, H, W, 2, 2, 0, 4 * C, layout=N.LAYOUT_NHWC, px_stride=C, order=1)
+                self._gn(ws, "l%d.gnm" % li, merged, B, H2 * W2, 4 * C, pk[p + "g"], pk[p + "b"], merged)
+                nxt = ws.get("l%d.x" % (li + 1), (B * H2 * W2, 2 * C))
+                E.gemm(merged, pk[p + "w"], nxt, B * H2 * W2, 2 * C, 4 * C, tag="as_merge")
+                cur, H, W, C = nxt, H2, W2, 2 * C
+        mean = ws.get("final.mean", (B,), torch.float32)
+        rstd = ws.get("final.rstd", (B,), torch.float32)
+        E.row_stats(cur, B, H * W * C, H * W * C, mean, rstd)
+        pooled = ws.get("pooled", (B, C))
+        E.pool_mean(cur, B, H * W, C, C, pooled, C, mean=mean, rstd=rstd, stat_group=H * W, gamma=pk["norm.g"], beta=pk["norm.b"])
+        if not isinstance(self.head, nn.Linear):
+            out = pooled.clone()
+            return out if out.dtype == x.dtype else out.to(x.dtype)
+        return head_linear(ws, pooled, B, C, pk["head.w"], pk["head.b"], self.num_classes, x.dtype)

@@ -43,7 +43,7 @@ def channel_mlp(ws, x, rows, C, pk, prefix, hidden, *, norm=True, cscale2=None, 
     """x <- x + fc2(gelu(fc1(LN(x))))   (mlp_mixer.py:38; vip.py:82-88; s2_mlp_v2.py:78-84).
     LN -> row-major normalised copy; fc1 epilogue = bias + exact GELU; fc2 epilogue = bias + residual."""
     if norm:
-        mean, rstd = layernorm_stats(ws, x, rows, C)
+        mean, rstd = layernorm_stats(ws, x, rows, C, tag=tag + ".ln")
         xn = ws.get(tag + ".xn", (rows, C))
         E.norm_apply(x, rows, C, x.stride(0), mean=mean, rstd=rstd, gamma=pk[prefix + "ln.g"], beta=pk[prefix + "ln.b"],
                      out_rm=xn, ld_rm=C)
@@ -65,3 +65,37 @@ def head_linear(ws, pooled, B, C, w, b, num_classes, out_dtype):
         E.convert(logits, out, B * num_classes)
         return out
     return logits.clone()
+
+
+def stage_embed(ws, name, src, B, cin, H, W, w_packed, bias, patch, channel_last):
+    """Conv2d(k = stride = patch) at a stage boundary -> channel-last tokens (B*Hp*Wp, Cout).
+    `src` is the NCHW input image (channel_last=False) or the previous stage's channel-last
+    activation (B*H*W, cin) (channel_last=True; the weight was packed in (i, j, ci) order).
+    s2_mlp_v2.py:119; s2_mlp_v1.py:82."""
+    ph, pw = patch
+    hp, wp = H // ph, W // pw
+    kp, cout = w_packed.shape[1], w_packed.shape[0]
+    rows = B * hp * wp
+    patches = ws.get(name + ".patches", (rows, kp))
+    if channel_last:
+        E.patchify(src, patches, B, cin, H, W, ph, pw, 0, kp, layout=N.LAYOUT_NHWC, px_stride=src.stride(0))
+    else:
+        E.patchify(src, patches, B, cin, H, W, ph, pw, 0, kp)
+    out = ws.get(name + ".x", (rows, cout))
+    E.gemm(patches, w_packed, out, rows, cout, kp, bias=bias)
+    return out, hp, wp
+
+
+def split_attention_weights(ws, x0, x1, x2, ld0, ld1, ld2, B, H, W, C, mode, m1, m2, tag="sa"):
+    """bar[b,k,c] of SplitAttention (vip.py:47-53 == s2_mlp_v2.py:41-47): whole-image reduction of the
+    three branches (S2 shifts applied on load), then the two bias-free Linears + GELU in fp32 (tiny:
+    B rows) and the softmax over the k = 3 branches.  Returns a (B, 3C) float32 tensor."""
+    a = ws.get(tag + ".a", (B, C), torch.float32)
+    E.split_sum(x0, x1, x2, ld0, ld1, ld2, B, H, W, C, mode, a)
+    t = ws.get(tag + ".t", (B, C), torch.float32)
+    E.gemm(a, m1, t, B, C, C, act=N.ACT_GELU)
+    hat = ws.get(tag + ".hat", (B, 3 * C), torch.float32)
+    E.gemm(t, m2, hat, B, 3 * C, C)
+    bar = ws.get(tag + ".bar", (B, 3 * C), torch.float32)
+    E.split_softmax(hat, bar, B, C)
+    return bar

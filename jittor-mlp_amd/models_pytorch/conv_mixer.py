@@ -1,0 +1,90 @@
+"""ConvMixer, drop-in for the reference's models_pytorch/conv_mixer.py (eval-mode forward:
+BatchNorm uses its running statistics, as in the reference's own harness, compare.py:141).
+
+Layer (conv_mixer.py:23-32): x <- x + BN(gelu(dwconv_kxk_same(x) + b));  x <- BN(gelu(W_pw x + b)).
+GELU comes BEFORE BatchNorm, so BN cannot be folded into the conv weights; it is applied as a
+per-channel scale/shift after GELU inside the producing kernel's epilogue.  Activations are
+channel-last: the depthwise half is one stencil kernel (residual, GELU and BN fused), the
+pointwise half is the NT GEMM with bias + GELU + scale/shift epilogue; the stem conv
+(7x7, stride 7, padding 3) is the patch gather + the same GEMM epilogue.
+"""
+import torch
+from torch import nn
+
+from .. import _native as N
+from .. import engine as E
+from .common import Holder, head_linear
+
+
+class Residual(Holder):
+    """fn(x) + x (conv_mixer.py:5-11)."""
+
+    def __init__(self, fn):
+        super().__init__()
+        self.fn = fn
+
+
+def _bn_affine(bn, device):
+    scale = (bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps))
+    shift = bn.bias.detach().double() - bn.running_mean.detach().double() * scale
+    return E.f32(scale.float(), device), E.f32(shift.float(), device)
+
+
+class ConvMixer(E.EngineModule):
+    """Same signature and defaults as the reference (conv_mixer.py:14)."""
+
+    def __init__(self, dim, depth, kernel_size=9, patch_size=7, n_classes=1000):
+        super().__init__()
+        self.embedding = nn.Sequential(
+            nn.Conv2d(3, dim, kernel_size=patch_size, stride=patch_size, padding=patch_size // 2), nn.GELU(), nn.BatchNorm2d(dim))
+        self.blocks = nn.Sequential(*[nn.Sequential(
+            Residual(nn.Sequential(nn.Conv2d(dim, dim, kernel_size, groups=dim, padding="same"), nn.GELU(), nn.BatchNorm2d(dim))),
+            nn.Conv2d(dim, dim, kernel_size=1), nn.GELU(), nn.BatchNorm2d(dim)) for i in range(depth)])
+        self.classifier = nn.Sequential(nn.AdaptiveAvgPool2d((1, 1)), nn.Flatten(), nn.Linear(dim, n_classes))
+        self._cfg = (dim, depth, kernel_size, patch_size, n_classes)
+
+    def _pack(self, dtype, device):
+        dim, depth, k, patch, _ = self._cfg
+        if k not in (3, 5, 7, 9):
+            raise NotImplementedError("depthwise kernel sizes 3/5/7/9 are built; got %d" % k)
+        pk = {}
+        pk["embed.w"] = E.pack_matrix(self.embedding[0].weight, dtype, device)
+        pk["embed.b"] = E.f32(self.embedding[0].bias, device)
+        pk["embed.s"], pk["embed.h"] = _bn_affine(self.embedding[2], device)
+        for i, blk in enumerate(self.blocks):
+            p = "b%d." % i
+            dw, bn_a = blk[0].fn[0], blk[0].fn[2]
+            pk[p + "dw.w"] = dw.weight.detach().reshape(dim, k * k).t().contiguous().to(device=device, dtype=torch.float32)
+            pk[p + "dw.b"] = E.f32(dw.bias, device)
+            pk[p + "dw.s"], pk[p + "dw.h"] = _bn_affine(bn_a, device)
+            pk[p + "pw.w"] = E.pack_matrix(blk[1].weight, dtype, device)
+            pk[p + "pw.b"] = E.f32(blk[1].bias, device)
+            pk[p + "pw.s"], pk[p + "pw.h"] = _bn_affine(blk[3], device)
+        pk["head.w"] = E.pack_matrix(self.classifier[2].weight, dtype, device)
+        pk["head.b"] = E.f32(self.classifier[2].bias, device)
+        return pk
+
+    def forward(self, x):
+        cd = self._resolve(x)
+        dim, depth, k, patch, n_classes = self._cfg
+        B, cin, H_in, W_in = x.shape
+        pk = self._get_pack(cd, x.device)
+        ws = self._get_space(B, cd, x.device)
+        x = x.contiguous()
+        pad = patch // 2
+        H, W = (H_in + 2 * pad - patch) // patch + 1, (W_in + 2 * pad - patch) // patch + 1
+        rows = B * H * W
+        kp = pk["embed.w"].shape[1]
+        patches = ws.get("embed.patches", (rows, kp))
+        E.patchify(x, patches, B, cin, H_in, W_in, patch, patch, pad, kp)
+        cur = ws.get("x", (rows, dim))
+        tmp = ws.get("y", (rows, dim))
+        E.gemm(patches, pk["embed.w"], cur, rows, dim, kp, bias=pk["embed.b"], act=N.ACT_GELU, cscale=pk["embed.s"], cshift=pk["embed.h"])
+        for i in range(depth):
+            p = "b%d." % i
+            E.dwconv_nhwc(cur, tmp, B, H, W, dim, k, pk[p + "dw.w"], pk[p + "dw.b"], pk[p + "dw.s"], pk[p + "dw.h"])
+            E.gemm(tmp, pk[p + "pw.w"], cur, rows, dim, dim, bias=pk[p + "pw.b"], act=N.ACT_GELU, cscale=pk[p + "pw.s"],
+                   cshift=pk[p + "pw.h"], tag="convmixer_pw")
+        pooled = ws.get("pooled", (B, dim))
+        E.pool_mean(cur, B, H * W, dim, dim, pooled, dim)
+        return head_linear(ws, pooled, B, dim, pk["head.w"], pk["head.b"], n_classes, x.dtype)

@@ -1,0 +1,145 @@
+"""S2-MLPv1, drop-in for the reference's models_pytorch/s2_mlp_v1.py.
+
+Block (s2_mlp_v1.py:33-46): x <- x + Linear(Spatial_Shift(gelu(Linear(LN(x))))); x <- x + MLP(LN(x)).
+Spatial_Shift (s2_mlp_v1.py:19-25) is spatial_shift1 of v2 applied to the full C-wide tensor; see
+s2_mlp_v2.py in this package for the two `shift_mode` semantics.
+"""
+from torch import nn
+
+from .. import _native as N
+from .. import engine as E
+from .common import Holder, channel_mlp, head_linear, layernorm_stats, stage_embed
+from .s2_mlp_v2 import SHIFT_MODES
+from .utils.tools import pair
+
+
+class PreNormResidual(Holder):
+    def __init__(self, dim, fn):
+        super().__init__()
+        self.fn = fn
+        self.norm = nn.LayerNorm(dim)
+
+
+class Spatial_Shift(Holder):
+    """Parameter-free (s2_mlp_v1.py:15-25); applied as a gather by mlpk_s2_shift."""
+
+
+class S2Block(E.EngineModule):
+    def __init__(self, d_model, depth, expansion_factor=4, dropout=0.):
+        super().__init__()
+        self.model = nn.Sequential(*[nn.Sequential(
+            PreNormResidual(d_model, nn.Sequential(nn.Linear(d_model, d_model), nn.GELU(), Spatial_Shift(), nn.Linear(d_model, d_model))),
+            PreNormResidual(d_model, nn.Sequential(nn.Linear(d_model, d_model * expansion_factor), nn.GELU(), nn.Dropout(dropout),
+                                                   nn.Linear(d_model * expansion_factor, d_model), nn.Dropout(dropout))))
+            for _ in range(depth)])
+        self._dims = (d_model, depth, expansion_factor)
+
+    def _pack_blocks(self, pk, dtype, device, prefix):
+        for i, blk in enumerate(self.model):
+            p = prefix + "b%d." % i
+            sm = blk[0]
+            pk[p + "ln.g"], pk[p + "ln.b"] = E.f32(sm.norm.weight, device), E.f32(sm.norm.bias, device)
+            pk[p + "l0.w"] = E.pack_matrix(sm.fn[0].weight, dtype, device)
+            pk[p + "l0.b"] = E.f32(sm.fn[0].bias, device)
+            pk[p + "l3.w"] = E.pack_matrix(sm.fn[3].weight, dtype, device)
+            pk[p + "l3.b"] = E.f32(sm.fn[3].bias, device)
+            mlp = blk[1]
+            pk[p + "mlp.ln.g"], pk[p + "mlp.ln.b"] = E.f32(mlp.norm.weight, device), E.f32(mlp.norm.bias, device)
+            pk[p + "mlp.fc1.w"] = E.pack_matrix(mlp.fn[0].weight, dtype, device)
+            pk[p + "mlp.fc1.b"] = E.f32(mlp.fn[0].bias, device)
+            pk[p + "mlp.fc2.w"] = E.pack_matrix(mlp.fn[3].weight, dtype, device)
+            pk[p + "mlp.fc2.b"] = E.f32(mlp.fn[3].bias, device)
+
+    def _run_blocks(self, ws, pk, x, B, H, W, prefix, mode):
+        C, depth, ef = self._dims
+        rows = B * H * W
+        for i in range(depth):
+            p = prefix + "b%d." % i
+            mean, rstd = layernorm_stats(ws, x, rows, C, tag=prefix + "ln")
+            xn = ws.get(prefix + "xn", (rows, C))
+            E.norm_apply(x, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "ln.g"], beta=pk[p + "ln.b"], out_rm=xn, ld_rm=C)
+            t = ws.get(prefix + "t", (rows, C))
+            E.gemm(xn, pk[p + "l0.w"], t, rows, C, C, bias=pk[p + "l0.b"], act=N.ACT_GELU, tag="s2v1_l0")
+            ts = ws.get(prefix + "ts", (rows, C))
+            E.s2_shift(t, ts, B, H, W, C, C, C, mode)
+            E.gemm(ts, pk[p + "l3.w"], x, rows, C, C, bias=pk[p + "l3.b"], R=x, res=N.RES_ADD, tag="s2v1_l3")
+            channel_mlp(ws, x, rows, C, pk, p + "mlp.", C * ef, tag=prefix + "cm")
+        return x
+
+    def forward(self, x):
+        raise NotImplementedError("S2Block holds one stage; call the enclosing S2MLPv1")
+
+
+class S2MLPv1(E.EngineModule):
+    """Same signature, defaults and assertions as the reference (s2_mlp_v1.py:55-88)."""
+
+    def __init__(self, image_size=224, patch_size=[7, 2], in_channels=3, num_classes=1000, d_model=[192, 384], depth=[4, 14],
+                 expansion_factor=[3, 3]):
+        image_size = pair(image_size)
+        oldps = [1, 1]
+        for ps in patch_size:
+            ps = pair(ps)
+            assert (image_size[0] % (ps[0] * oldps[0])) == 0, 'image must be divisible by patch size'
+            assert (image_size[1] % (ps[1] * oldps[1])) == 0, 'image must be divisible by patch size'
+            oldps[0] = oldps[0] * ps[0]
+            oldps[1] = oldps[1] * ps[1]
+        assert (len(patch_size) == len(depth) == len(d_model) == len(expansion_factor)), \
+            'patch_size/depth/d_model/expansion_factor must be a list'
+        super().__init__()
+        self.stage = len(patch_size)
+        self.stages = nn.Sequential(*[nn.Sequential(
+            nn.Conv2d(in_channels if i == 0 else d_model[i - 1], d_model[i], kernel_size=patch_size[i], stride=patch_size[i]),
+            S2Block(d_model[i], depth[i], expansion_factor[i], dropout=0.)) for i in range(self.stage)])
+        self.mlp_head = nn.Sequential(Holder(), nn.Linear(d_model[-1], num_classes))
+        self._patches = [pair(p) for p in patch_size]
+        self._d_model = list(d_model)
+        self._num_classes = num_classes
+        self.shift_mode = "reference_inplace"
+
+    def set_shift_mode(self, mode):
+        if mode not in SHIFT_MODES:
+            raise ValueError("shift_mode must be one of %s" % sorted(SHIFT_MODES))
+        self.shift_mode = mode
+        return self
+
+    def _pack(self, dtype, device):
+        pk = {}
+        for s in range(self.stage):
+            conv, blk = self.stages[s][0], self.stages[s][1]
+            w = conv.weight
+            if s > 0:
+                w = w.permute(0, 2, 3, 1)
+            pk["s%d.embed.w" % s] = E.pack_matrix(w.reshape(w.shape[0], -1), dtype, device)
+            pk["s%d.embed.b" % s] = E.f32(conv.bias, device)
+            blk._pack_blocks(pk, dtype, device, "s%d." % s)
+        pk["head.w"] = E.pack_matrix(self.mlp_head[1].weight, dtype, device)
+        pk["head.b"] = E.f32(self.mlp_head[1].bias, device)
+        return pk
+
+    def forward(self, x):
+        cd = self._resolve(x)
+        B = x.shape[0]
+        pk = self._get_pack(cd, x.device)
+        ws = self._get_space(B, cd, x.device)
+        mode = SHIFT_MODES[self.shift_mode]
+        cur, H, W, C = x.contiguous(), x.shape[2], x.shape[3], x.shape[1]
+        for s in range(self.stage):
+            cur, H, W = stage_embed(ws, "s%d" % s, cur, B, C, H, W, pk["s%d.embed.w" % s], pk["s%d.embed.b" % s],
+                                    self._patches[s], channel_last=s > 0)
+            C = self._d_model[s]
+            self.stages[s][1]._run_blocks(ws, pk, cur, B, H, W, "s%d." % s, mode)
+        pooled = ws.get("pooled", (B, C))
+        E.pool_mean(cur, B, H * W, C, C, pooled, C)
+        return head_linear(ws, pooled, B, C, pk["head.w"], pk["head.b"], self._num_classes, x.dtype)
+
+
+def S2MLPv1_deep(num_classes: int = 1000, **kwargs):
+    """s2_mlp_v1.py:95-103."""
+    return S2MLPv1(image_size=224, patch_size=[16], d_model=[384], depth=[36], num_classes=num_classes,
+                   expansion_factor=[4], **kwargs)
+
+
+def S2MLPv1_wide(num_classes: int = 1000, **kwargs):
+    """s2_mlp_v1.py:105-113."""
+    return S2MLPv1(image_size=224, patch_size=[16], d_model=[768], depth=[12], num_classes=num_classes,
+                   expansion_factor=[4], **kwargs)

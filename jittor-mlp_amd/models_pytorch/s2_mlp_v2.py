@@ -1,0 +1,175 @@
+"""S2-MLPv2, drop-in for the reference's models_pytorch/s2_mlp_v2.py.
+
+S2Attention on channel-last (B,H,W,C) (s2_mlp_v2.py:60-69): t = LN(x) A1^T + a1 (3C wide);
+x1 = spatial_shift1(t[..., :C]), x2 = spatial_shift2(t[..., C:2C]), x3 = t[..., 2C:];
+split attention over (x1,x2,x3); x <- x + (.) A2^T + a2; then the channel MLP.
+
+The two shifts are never materialised: the reduction and the weighted-sum kernels gather the
+shifted pixel while loading (mlpk_split_sum / mlpk_split_apply).
+
+Shift semantics.  The reference assigns overlapping slices IN PLACE
+(s2_mlp_v2.py:17-20,25-28); with one CPU thread that deterministically "smears" the two "+1"
+channel groups (y[i] = x[0]), with several threads it is a data race.  `shift_mode`:
+  "reference_inplace" (default) -- the reference's deterministic single-thread result, which is
+                                    what the golden logits pin;
+  "shift"                        -- the intended one-pixel shift (paper Algorithm 1, Jittor twin).
+Both are out-of-place and deterministic here.
+"""
+import torch
+from torch import nn
+
+from .. import _native as N
+from .. import engine as E
+from .common import Holder, channel_mlp, head_linear, layernorm_stats, split_attention_weights, stage_embed
+from .utils.tools import pair
+
+SHIFT_MODES = {"reference_inplace": N.SHIFT_S2_REF, "shift": N.SHIFT_S2}
+
+
+class PreNormResidual(Holder):
+    def __init__(self, dim, fn):
+        super().__init__()
+        self.fn = fn
+        self.norm = nn.LayerNorm(dim)
+
+
+class SplitAttention(Holder):
+    """s2_mlp_v2.py:31-51 (bias-free mlp1/mlp2)."""
+
+    def __init__(self, channel=512, k=3):
+        super().__init__()
+        self.channel = channel
+        self.k = k
+        self.mlp1 = nn.Linear(channel, channel, bias=False)
+        self.gelu = nn.GELU()
+        self.mlp2 = nn.Linear(channel, channel * k, bias=False)
+        self.softmax = nn.Softmax(1)
+
+
+class S2Attention(Holder):
+    """s2_mlp_v2.py:53-69."""
+
+    def __init__(self, channels=512):
+        super().__init__()
+        self.mlp1 = nn.Linear(channels, channels * 3)
+        self.mlp2 = nn.Linear(channels, channels)
+        self.split_attention = SplitAttention(channels)
+
+
+class S2Block(E.EngineModule):
+    """depth x [PreNormResidual(S2Attention), PreNormResidual(MLP)] (s2_mlp_v2.py:71-92)."""
+
+    def __init__(self, d_model, depth, expansion_factor=4, dropout=0.):
+        super().__init__()
+        self.model = nn.Sequential(*[nn.Sequential(
+            PreNormResidual(d_model, S2Attention(d_model)),
+            PreNormResidual(d_model, nn.Sequential(nn.Linear(d_model, d_model * expansion_factor), nn.GELU(), nn.Dropout(dropout),
+                                                   nn.Linear(d_model * expansion_factor, d_model), nn.Dropout(dropout))))
+            for _ in range(depth)])
+        self._dims = (d_model, depth, expansion_factor)
+
+    def _pack_blocks(self, pk, dtype, device, prefix):
+        for i, blk in enumerate(self.model):
+            p = prefix + "b%d." % i
+            att = blk[0].fn
+            pk[p + "ln.g"], pk[p + "ln.b"] = E.f32(blk[0].norm.weight, device), E.f32(blk[0].norm.bias, device)
+            pk[p + "a1.w"] = E.pack_matrix(att.mlp1.weight, dtype, device)
+            pk[p + "a1.b"] = E.f32(att.mlp1.bias, device)
+            pk[p + "a2.w"] = E.pack_matrix(att.mlp2.weight, dtype, device)
+            pk[p + "a2.b"] = E.f32(att.mlp2.bias, device)
+            pk[p + "sa.m1"] = E.pack_matrix(att.split_attention.mlp1.weight, torch.float32, device)
+            pk[p + "sa.m2"] = E.pack_matrix(att.split_attention.mlp2.weight, torch.float32, device)
+            mlp = blk[1]
+            pk[p + "mlp.ln.g"], pk[p + "mlp.ln.b"] = E.f32(mlp.norm.weight, device), E.f32(mlp.norm.bias, device)
+            pk[p + "mlp.fc1.w"] = E.pack_matrix(mlp.fn[0].weight, dtype, device)
+            pk[p + "mlp.fc1.b"] = E.f32(mlp.fn[0].bias, device)
+            pk[p + "mlp.fc2.w"] = E.pack_matrix(mlp.fn[3].weight, dtype, device)
+            pk[p + "mlp.fc2.b"] = E.f32(mlp.fn[3].bias, device)
+
+    def _run_blocks(self, ws, pk, x, B, H, W, prefix, mode):
+        C, depth, ef = self._dims
+        rows = B * H * W
+        for i in range(depth):
+            p = prefix + "b%d." % i
+            mean, rstd = layernorm_stats(ws, x, rows, C, tag=prefix + "ln")
+            xn = ws.get(prefix + "xn", (rows, C))
+            E.norm_apply(x, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "ln.g"], beta=pk[p + "ln.b"], out_rm=xn, ld_rm=C)
+            t = ws.get(prefix + "t", (rows, 3 * C))
+            E.gemm(xn, pk[p + "a1.w"], t, rows, 3 * C, C, bias=pk[p + "a1.b"], tag="s2_mlp1")
+            x0, x1, x2 = t[:, :C], t[:, C:2 * C], t[:, 2 * C:]
+            bar = split_attention_weights(ws, x0, x1, x2, 3 * C, 3 * C, 3 * C, B, H, W, C, mode, pk[p + "sa.m1"], pk[p + "sa.m2"],
+                                          tag=prefix + "sa")
+            m = ws.get(prefix + "m", (rows, C))
+            E.split_apply(x0, x1, x2, 3 * C, 3 * C, 3 * C, B, H, W, C, mode, bar, m, C)
+            E.gemm(m, pk[p + "a2.w"], x, rows, C, C, bias=pk[p + "a2.b"], R=x, res=N.RES_ADD, tag="s2_mlp2")
+            channel_mlp(ws, x, rows, C, pk, p + "mlp.", C * ef, tag=prefix + "cm")
+        return x
+
+    def forward(self, x):
+        raise NotImplementedError("S2Block holds one stage; call the enclosing S2MLPv2")
+
+
+class S2MLPv2(E.EngineModule):
+    """Same signature, defaults and assertions as the reference (s2_mlp_v2.py:94-127)."""
+
+    def __init__(self, image_size=224, patch_size=[7, 2], in_channels=3, num_classes=1000, d_model=[192, 384], depth=[4, 14],
+                 expansion_factor=[3, 3]):
+        image_size = pair(image_size)
+        oldps = [1, 1]
+        for ps in patch_size:
+            ps = pair(ps)
+            assert (image_size[0] % (ps[0] * oldps[0])) == 0, 'image must be divisible by patch size'
+            assert (image_size[1] % (ps[1] * oldps[1])) == 0, 'image must be divisible by patch size'
+            oldps[0] = oldps[0] * ps[0]
+            oldps[1] = oldps[1] * ps[1]
+        assert (len(patch_size) == len(depth) == len(d_model) == len(expansion_factor)), \
+            'patch_size/depth/d_model/expansion_factor must be a list'
+        super().__init__()
+        self.stage = len(patch_size)
+        self.stages = nn.Sequential(*[nn.Sequential(
+            nn.Conv2d(in_channels if i == 0 else d_model[i - 1], d_model[i], kernel_size=patch_size[i], stride=patch_size[i]),
+            S2Block(d_model[i], depth[i], expansion_factor[i], dropout=0.)) for i in range(self.stage)])
+        self.mlp_head = nn.Sequential(Holder(), nn.Linear(d_model[-1], num_classes))
+        self._patches = [pair(p) for p in patch_size]
+        self._d_model = list(d_model)
+        self._num_classes = num_classes
+        self.shift_mode = "reference_inplace"
+
+    def set_shift_mode(self, mode):
+        if mode not in SHIFT_MODES:
+            raise ValueError("shift_mode must be one of %s" % sorted(SHIFT_MODES))
+        self.shift_mode = mode
+        return self
+
+    def _pack(self, dtype, device):
+        pk = {}
+        for s in range(self.stage):
+            conv, blk = self.stages[s][0], self.stages[s][1]
+            w = conv.weight
+            if s > 0:                                              # channel-last source: k = (i*pw + j)*Cin + ci
+                w = w.permute(0, 2, 3, 1)
+            pk["s%d.embed.w" % s] = E.pack_matrix(w.reshape(w.shape[0], -1), dtype, device)
+            pk["s%d.embed.b" % s] = E.f32(conv.bias, device)
+            blk._pack_blocks(pk, dtype, device, "s%d." % s)
+        pk["head.w"] = E.pack_matrix(self.mlp_head[1].weight, dtype, device)
+        pk["head.b"] = E.f32(self.mlp_head[1].bias, device)
+        return pk
+
+    def _block_runner(self, s):
+        return self.stages[s][1]._run_blocks
+
+    def forward(self, x):
+        cd = self._resolve(x)
+        B = x.shape[0]
+        pk = self._get_pack(cd, x.device)
+        ws = self._get_space(B, cd, x.device)
+        mode = SHIFT_MODES[self.shift_mode]
+        cur, H, W, C = x.contiguous(), x.shape[2], x.shape[3], x.shape[1]
+        for s in range(self.stage):
+            cur, H, W = stage_embed(ws, "s%d" % s, cur, B, C, H, W, pk["s%d.embed.w" % s], pk["s%d.embed.b" % s],
+                                    self._patches[s], channel_last=s > 0)
+            C = self._d_model[s]
+            self._block_runner(s)(ws, pk, cur, B, H, W, "s%d." % s, mode)
+        pooled = ws.get("pooled", (B, C))
+        E.pool_mean(cur, B, H * W, C, C, pooled, C)                 # Reduce('b c h w -> b c', 'mean'), no final norm
+        return head_linear(ws, pooled, B, C, pk["head.w"], pk["head.b"], self._num_classes, x.dtype)

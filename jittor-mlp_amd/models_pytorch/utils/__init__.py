@@ -1,1 +1,2 @@
 from .tools import pair, check_sizes  # noqa: F401
+from .shift import Shift  # noqa: F401

@@ -1,0 +1,238 @@
+"""Vision Permutator, drop-in for the reference's models_pytorch/vip.py.
+
+Block on channel-last (B,H,W,C), C = G*s with s = `segments` (vip.py:65-90):
+  x^ = LN(x);  xH = Linear_{H*s} over the (h, j) index of x^[b,h,w,g*s+j]  (vip.py:68-72)
+               xW = the same over (w, j)                                   (vip.py:73-77)
+               xC = Linear_C(x^)                                           (vip.py:78)
+  m = split-attention weighted sum of (xH, xW, xC)  (vip.py:24-57)  |  plain sum (vip.py:16-22)
+  x <- x + Linear_C(m);   x <- x + MLP(LN(x))
+Kernels: one normalise pass writes x^ row-major plus BOTH rearranged copies (each a contiguous
+slab staged through LDS, so the einops copies of the reference become coalesced index remaps);
+three NT GEMMs; the inverse rearranges; split attention as reduce -> two tiny fp32 GEMMs ->
+softmax -> weighted apply; projection GEMM with the residual in its epilogue.
+"""
+import torch
+from torch import nn
+
+from .. import _native as N
+from .. import engine as E
+from .common import Holder, channel_mlp, embed_patches, head_linear, layernorm_stats, split_attention_weights
+from .utils.tools import pair
+
+
+class PreNormResidual(Holder):
+    def __init__(self, dim, fn):
+        super().__init__()
+        self.fn = fn
+        self.norm = nn.LayerNorm(dim)
+
+
+class ParallelSum(Holder):
+    """Sum of branches (vip.py:16-22)."""
+
+    def __init__(self, *fns):
+        super().__init__()
+        self.fns = nn.ModuleList(fns)
+
+
+class ParallelWeightedSum(Holder):
+    """Split-attention weighted sum of three branches (vip.py:24-35)."""
+
+    def __init__(self, sa, *fns):
+        super().__init__()
+        self.fns = nn.ModuleList(fns)
+        self.split_attention = sa
+
+
+class SplitAttention(Holder):
+    """Bias-free mlp1 (C->C), GELU, mlp2 (C->kC), softmax over k (vip.py:37-57)."""
+
+    def __init__(self, channel=512, k=3):
+        super().__init__()
+        self.channel = channel
+        self.k = k
+        self.mlp1 = nn.Linear(channel, channel, bias=False)
+        self.gelu = nn.GELU()
+        self.mlp2 = nn.Linear(channel, channel * k, bias=False)
+        self.softmax = nn.Softmax(1)
+
+
+class _Rearrange(Holder):
+    """Parameter-free placeholder keeping the reference's Sequential indices (the Linear sits at .1)."""
+
+    def __init__(self, pattern):
+        super().__init__()
+        self.pattern = pattern
+
+
+def _branches(height, width, d_model, segments):
+    return (nn.Sequential(_Rearrange('b h w (c s) -> b w c (h s)'), nn.Linear(height * segments, height * segments),
+                          _Rearrange('b w c (h s) -> b h w (c s)')),
+            nn.Sequential(_Rearrange('b h w (c s) -> b h c (w s)'), nn.Linear(width * segments, width * segments),
+                          _Rearrange('b h c (w s) -> b h w (c s)')),
+            nn.Linear(d_model, d_model))
+
+
+def _mlp(d_model, expansion_factor, dropout):
+    return nn.Sequential(nn.Linear(d_model, d_model * expansion_factor), nn.GELU(), nn.Dropout(dropout),
+                         nn.Linear(d_model * expansion_factor, d_model), nn.Dropout(dropout))
+
+
+class _PermutatorBase(E.EngineModule):
+    weighted = True
+
+    def __init__(self, height, width, d_model, depth, segments, expansion_factor=4, dropout=0.):
+        super().__init__()
+        blocks = []
+        for _ in range(depth):
+            if self.weighted:
+                mix = ParallelWeightedSum(SplitAttention(d_model, k=3), *_branches(height, width, d_model, segments))
+            else:
+                mix = ParallelSum(*_branches(height, width, d_model, segments))
+            blocks.append(nn.Sequential(
+                PreNormResidual(d_model, nn.Sequential(mix, nn.Linear(d_model, d_model))),
+                PreNormResidual(d_model, _mlp(d_model, expansion_factor, dropout))))
+        self.model = nn.Sequential(*blocks)
+        self._dims = (height, width, d_model, depth, segments, expansion_factor)
+
+    def _pack_blocks(self, pk, dtype, device, prefix=""):
+        for i, blk in enumerate(self.model):
+            p = prefix + "b%d." % i
+            mix, proj = blk[0].fn[0], blk[0].fn[1]
+            pk[p + "ln.g"], pk[p + "ln.b"] = E.f32(blk[0].norm.weight, device), E.f32(blk[0].norm.bias, device)
+            pk[p + "h.w"] = E.pack_matrix(mix.fns[0][1].weight, dtype, device, kpad=32)
+            pk[p + "h.b"] = E.f32(mix.fns[0][1].bias, device)
+            pk[p + "w.w"] = E.pack_matrix(mix.fns[1][1].weight, dtype, device, kpad=32)
+            pk[p + "w.b"] = E.f32(mix.fns[1][1].bias, device)
+            pk[p + "c.w"] = E.pack_matrix(mix.fns[2].weight, dtype, device)
+            pk[p + "c.b"] = E.f32(mix.fns[2].bias, device)
+            if self.weighted:
+                pk[p + "sa.m1"] = E.pack_matrix(mix.split_attention.mlp1.weight, torch.float32, device)
+                pk[p + "sa.m2"] = E.pack_matrix(mix.split_attention.mlp2.weight, torch.float32, device)
+            pk[p + "proj.w"] = E.pack_matrix(proj.weight, dtype, device)
+            pk[p + "proj.b"] = E.f32(proj.bias, device)
+            mlp = blk[1]
+            pk[p + "mlp.ln.g"], pk[p + "mlp.ln.b"] = E.f32(mlp.norm.weight, device), E.f32(mlp.norm.bias, device)
+            pk[p + "mlp.fc1.w"] = E.pack_matrix(mlp.fn[0].weight, dtype, device)
+            pk[p + "mlp.fc1.b"] = E.f32(mlp.fn[0].bias, device)
+            pk[p + "mlp.fc2.w"] = E.pack_matrix(mlp.fn[3].weight, dtype, device)
+            pk[p + "mlp.fc2.b"] = E.f32(mlp.fn[3].bias, device)
+
+    def _pack(self, dtype, device):
+        pk = {}
+        self._pack_blocks(pk, dtype, device)
+        return pk
+
+    def _run_blocks(self, ws, pk, x, B, prefix=""):
+        H, W, C, depth, seg, ef = self._dims
+        rows = B * H * W
+        G = C // seg
+        hs, wsz = H * seg, W * seg
+        ldh, ldw = E.round_up(hs, 32), E.round_up(wsz, 32)
+        for i in range(depth):
+            p = prefix + "b%d." % i
+            mean, rstd = layernorm_stats(ws, x, rows, C)
+            xn = ws.get("vip.xn", (rows, C))
+            ph = ws.get("vip.ph", (B * W * G, ldh))
+            pw = ws.get("vip.pw", (B * H * G, ldw))
+            E.norm_apply(x, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "ln.g"], beta=pk[p + "ln.b"], out_rm=xn, ld_rm=C,
+                         out_ph=ph, H=H, W=W, seg=seg, ld_p=ldh)
+            E.norm_apply(x, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "ln.g"], beta=pk[p + "ln.b"],
+                         out_pw=pw, H=H, W=W, seg=seg, ld_p=ldw)
+            ldzh, ldzw = E.round_up(hs, 8), E.round_up(wsz, 8)
+            zh = ws.get("vip.zh", (B * W * G, ldzh))
+            zw = ws.get("vip.zw", (B * H * G, ldzw))
+            E.gemm(ph, pk[p + "h.w"], zh, B * W * G, hs, ldh, bias=pk[p + "h.b"], tag="vip_h")
+            E.gemm(pw, pk[p + "w.w"], zw, B * H * G, wsz, ldw, bias=pk[p + "w.b"], tag="vip_w")
+            xh = ws.get("vip.xh", (rows, C))
+            xw = ws.get("vip.xw", (rows, C))
+            xc = ws.get("vip.xc", (rows, C))
+            E.vip_unpermute(0, zh, xh, B, H, W, C, seg, ldzh)
+            E.vip_unpermute(1, zw, xw, B, H, W, C, seg, ldzw)
+            E.gemm(xn, pk[p + "c.w"], xc, rows, C, C, bias=pk[p + "c.b"], tag="vip_c")
+            if self.weighted:
+                bar = split_attention_weights(ws, xh, xw, xc, C, C, C, B, H, W, C, N.SHIFT_NONE, pk[p + "sa.m1"], pk[p + "sa.m2"])
+            else:
+                bar = ws.get("vip.ones", (B, 3 * C), torch.float32, fill=1.0)     # plain sum (vip.py:16-22)
+            m = ws.get("vip.m", (rows, C))
+            E.split_apply(xh, xw, xc, C, C, C, B, H, W, C, N.SHIFT_NONE, bar, m, C)
+            E.gemm(m, pk[p + "proj.w"], x, rows, C, C, bias=pk[p + "proj.b"], R=x, res=N.RES_ADD, tag="vip_proj")
+            channel_mlp(ws, x, rows, C, pk, p + "mlp.", C * ef)
+        return x
+
+    def forward(self, x):
+        """(B,H,W,C) -> (B,H,W,C), as the reference backbones (vip.py:92-93, 127-128)."""
+        E.require_gpu(x, type(self).__name__ + ".forward")
+        H, W, C = self._dims[:3]
+        if x.dim() != 4 or tuple(x.shape[1:]) != (H, W, C):
+            raise ValueError("expected (B, %d, %d, %d)" % (H, W, C))
+        B = x.shape[0]
+        pk = self._get_pack(x.dtype, x.device)
+        ws = self._get_space(B, x.dtype, x.device)
+        buf = ws.get("x", (B * H * W, C))
+        buf.copy_(x.reshape(B * H * W, C))
+        self._run_blocks(ws, pk, buf, B)
+        return buf.reshape(B, H, W, C).clone()
+
+
+class WeightedPermutator(_PermutatorBase):
+    """vip.py:59-93."""
+    weighted = True
+
+
+class Permutator(_PermutatorBase):
+    """vip.py:95-128."""
+    weighted = False
+
+
+class ViP(E.EngineModule):
+    """Same signature, defaults and assertions as the reference (vip.py:130-148).  Note that the
+    all-default call fails its own divisibility assert (256 % 14), exactly like the reference."""
+
+    def __init__(self, image_size=224, patch_size=16, in_channels=3, num_classes=1000, d_model=256, depth=30, segments=14,
+                 expansion_factor=4, weighted=True):
+        image_size = pair(image_size)
+        patch_size = pair(patch_size)
+        assert (image_size[0] % patch_size[0]) == 0, 'image must be divisible by patch size'
+        assert (image_size[1] % patch_size[1]) == 0, 'image must be divisible by patch size'
+        assert (d_model % segments) == 0, 'dimension must be divisible by the number of segments'
+        height = image_size[0] // patch_size[0]
+        width = image_size[1] // patch_size[1]
+        super().__init__()
+        self.patcher = nn.Sequential(nn.Conv2d(in_channels, d_model, kernel_size=patch_size, stride=patch_size))
+        cls = WeightedPermutator if weighted else Permutator
+        self.blocks = cls(height, width, d_model, depth, segments, expansion_factor, dropout=0.)
+        self.mlp_head = nn.Sequential(nn.LayerNorm(d_model), _Rearrange('b h w c -> b c (mean)'), nn.Linear(d_model, num_classes))
+        self._patch = patch_size
+        self._num_classes = num_classes
+        self._hw = (height, width)
+        self._C = d_model
+
+    def _pack(self, dtype, device):
+        pk = {}
+        self.blocks._pack_blocks(pk, dtype, device)
+        pk["embed.w"] = E.pack_matrix(self.patcher[0].weight, dtype, device)
+        pk["embed.b"] = E.f32(self.patcher[0].bias, device)
+        pk["head.ln.g"], pk["head.ln.b"] = E.f32(self.mlp_head[0].weight, device), E.f32(self.mlp_head[0].bias, device)
+        pk["head.w"] = E.pack_matrix(self.mlp_head[2].weight, dtype, device)
+        pk["head.b"] = E.f32(self.mlp_head[2].bias, device)
+        return pk
+
+    def forward(self, x):
+        cd = self._resolve(x)
+        H, W = self._hw
+        C = self._C
+        B = x.shape[0]
+        pk = self._get_pack(cd, x.device)
+        ws = self._get_space(B, cd, x.device)
+        x = x.contiguous()
+        tokens, hp, wp = embed_patches(ws, "embed", x, pk["embed.w"], pk["embed.b"], cd, self._patch,
+                                       out=ws.get("x", (B * H * W, C)))
+        if (hp, wp) != (H, W):
+            raise ValueError("input size gives a %dx%d grid, the model was built for %dx%d" % (hp, wp, H, W))
+        self.blocks._run_blocks(ws, pk, tokens, B)
+        rows = B * H * W
+        mean, rstd = layernorm_stats(ws, tokens, rows, C)
+        pooled = ws.get("pooled", (B, C))
+        E.pool_mean(tokens, B, H * W, C, C, pooled, C, mean=mean, rstd=rstd, gamma=pk["head.ln.g"], beta=pk["head.ln.b"])
+        return head_linear(ws, pooled, B, C, pk["head.w"], pk["head.b"], self._num_classes, x.dtype)
