@@ -104,6 +104,235 @@ template <typename T> __device__ __forceinline__ void store4(T* p, bool vec, con
     }
 }
 
+// Shared epilogue: consumes the fp32 accumulator blocks of one workgroup tile (see the kernels for
+// the accumulator orientation) and writes C.  `smem` is the workgroup's LDS, free for staging once
+// every wave has passed the barrier that ends the main loop.
+template <typename T, int BM, int BN, int WM, int WN, bool TRANS>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem,
+                                              const int m0, const int n0) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int FM = TM / 16, FN = TN / 16;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int frow = lane & 15;
+    const int fg = lane >> 4;
+    if (p.dbg & 4) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) sacc += acc[i][j].x + acc[i][j].y + acc[i][j].z + acc[i][j].w;
+        if (sacc == 123.456f) reinterpret_cast<float*>(p.C)[0] = sacc;
+        return;
+    }
+    T* __restrict__ C = reinterpret_cast<T*>(p.C);
+    const T* R = reinterpret_cast<const T*>(p.R);
+    const bool gelu = p.act == MLPK_ACT_GELU;
+
+    if constexpr (!TRANS && sizeof(T) == 2) {
+        // ---- 2-byte row-major output: stage the finished tile through LDS (the pipeline buffers are
+        // free now) so that global traffic is full 16-byte-per-lane, whole-row coalesced: the MFMA
+        // accumulator layout only gives 8 bytes per lane in 32-byte runs, which measured 1.9 TB/s.
+        // Phase 1: bias / GELU / column scale+shift / row scale on the fp32 accumulator, round to T,
+        //          ds_write_b64 into a [BM][BN] tile whose 16-byte chunks are XOR-swizzled by row.
+        // Phase 2: every thread moves 16-byte chunks LDS -> (optional residual add|mul) -> global.
+        constexpr int CPR = BN / 8;                      // 16-byte chunks per tile row
+        constexpr int XM = (CPR >= 16 ? 16 : CPR) - 1;   // swizzle mask
+        T* tile = reinterpret_cast<T*>(smem);
+        // phase-2 geometry, and the residual chunks of the first passes put in flight NOW so that their
+        // latency hides under the phase-1 VALU work
+        constexpr int RPASS = NT / CPR;                  // rows moved per pass
+        constexpr int NP = BM / RPASS;                   // passes
+        constexpr int PB0 = NP < 8 ? NP : 8;
+        const int c16 = tid % CPR;
+        const int rsub = tid / CPR;
+        const int gn = n0 + c16 * 8;
+        const bool has_res = p.res_mode != MLPK_RES_NONE;
+        const bool fast = p.vec_c == 2 && (!has_res || p.vec_r == 2) && gn + 8 <= p.N;
+        u32x4 rr0[PB0];
+        if (fast && has_res) {
+#pragma unroll
+            for (int q = 0; q < PB0; ++q) {
+                const int gm = m0 + q * RPASS + rsub;
+                rr0[q] = gm < p.M ? *reinterpret_cast<const u32x4*>(R + (size_t)gm * p.ldr + gn) : u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int nl = wn * TN + j * 16 + 4 * fg;    // column of this lane's 4-vector inside the tile
+            float bz[4], cs[4], ch[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int n = n0 + nl + r;
+                n = n < p.N ? n : p.N - 1;
+                bz[r] = p.bias ? p.bias[n] : 0.f;
+                cs[r] = p.cscale ? p.cscale[n] : 1.f;
+                ch[r] = p.cshift ? p.cshift[n] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int rl = wm * TM + i * 16 + frow;
+                float rs = 1.f;
+                if (p.rscale) {
+                    int m = m0 + rl;
+                    m = m < p.M ? m : p.M - 1;
+                    rs = p.rscale[m % p.rperiod];
+                }
+                float v[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
+                T e[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = v[r] + bz[r];
+                    if (gelu) t = gelu_f(t);
+                    e[r] = from_f32<T>((t * cs[r] + ch[r]) * rs);
+                }
+                u32x2 pk;
+                __builtin_memcpy(&pk, e, 8);
+                const int c16 = nl >> 3;
+                char* dst = reinterpret_cast<char*>(tile) + rl * (BN * 2) + (((c16 ^ (rl & XM)) << 4) | ((nl & 4) << 1));
+                *reinterpret_cast<u32x2*>(dst) = pk;
+            }
+        }
+        __syncthreads();
+        if (fast) {
+            // residual chunks of the remaining groups go in flight first, then each pass is LDS read ->
+            // combine -> one 16-byte store; rows past M are skipped.
+            u32x4 rr[NP];
+#pragma unroll
+            for (int q = 0; q < PB0; ++q) rr[q] = rr0[q];
+            if (has_res) {
+#pragma unroll
+                for (int q = PB0; q < NP; ++q) {
+                    const int gm = m0 + q * RPASS + rsub;
+                    rr[q] = gm < p.M ? *reinterpret_cast<const u32x4*>(R + (size_t)gm * p.ldr + gn) : u32x4{0u, 0u, 0u, 0u};
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const int rl = q * RPASS + rsub;
+                const int gm = m0 + rl;
+                const u32x4 raw = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(tile) + rl * (BN * 2) +
+                                                                  ((c16 ^ (rl & XM)) << 4));
+                u32x4 outv = raw;
+                if (has_res) {
+                    T a8[8], r8[8];
+                    __builtin_memcpy(a8, &raw, 16);
+                    __builtin_memcpy(r8, &rr[q], 16);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float a = to_f32(a8[e]), b = to_f32(r8[e]);
+                        a8[e] = from_f32<T>(p.res_mode == MLPK_RES_ADD ? a + b : a * b);
+                    }
+                    __builtin_memcpy(&outv, a8, 16);
+                }
+                if (gm < p.M && (!(p.dbg & 2) || outv.x == 0x12345678u))
+                    *reinterpret_cast<u32x4*>(C + (size_t)gm * p.ldc + gn) = outv;
+            }
+        } else if (gn < p.N) {
+            for (int rp = 0; rp < NP; ++rp) {
+                const int rl = rp * RPASS + rsub;
+                const int gm = m0 + rl;
+                if (gm >= p.M) break;
+                const u32x4 raw = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(tile) + rl * (BN * 2) +
+                                                                  ((c16 ^ (rl & XM)) << 4));
+                T* cp = C + (size_t)gm * p.ldc + gn;
+                T a8[8];
+                __builtin_memcpy(a8, &raw, 16);
+                for (int e = 0; e < 8 && gn + e < p.N; ++e) {
+                    float a = to_f32(a8[e]);
+                    if (has_res) {
+                        const float b = to_f32(R[(size_t)gm * p.ldr + gn + e]);
+                        a = p.res_mode == MLPK_RES_ADD ? a + b : a * b;
+                    }
+                    cp[e] = from_f32<T>(a);
+                }
+            }
+        }
+    } else if constexpr (!TRANS) {
+        // lane owns row m = .. + (lane & 15) and 4 consecutive columns n = .. + 4*(lane >> 4) + r
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = m0 + wm * TM + i * 16 + frow;
+            if (m >= p.M) continue;
+            const float rs = p.rscale ? p.rscale[m % p.rperiod] : 1.0f;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int nb = n0 + wn * TN + j * 16 + 4 * fg;
+                if (nb >= p.N) continue;
+                const bool full = nb + 3 < p.N;
+                float v[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = (nb + r < p.N) ? nb + r : p.N - 1;
+                    float t = v[r];
+                    if (p.bias) t += p.bias[n];
+                    if (gelu) t = gelu_f(t);
+                    if (p.cscale) t *= p.cscale[n];
+                    if (p.cshift) t += p.cshift[n];
+                    v[r] = t * rs;
+                }
+                const size_t co = (size_t)m * p.ldc + nb;
+                if (full) {
+                    if (p.res_mode != MLPK_RES_NONE) {
+                        float rv[4];
+                        load4<T>(R + (size_t)m * p.ldr + nb, p.vec_r != 0, rv);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = (p.res_mode == MLPK_RES_ADD) ? v[r] + rv[r] : v[r] * rv[r];
+                    }
+                    if (!(p.dbg & 2) || v[0] == 123.456f) store4<T>(C + co, p.vec_c != 0, v);
+                } else {
+                    for (int r = 0; r < 4 && nb + r < p.N; ++r) {
+                        float t = v[r];
+                        if (p.res_mode != MLPK_RES_NONE) {
+                            const float rv = to_f32(R[(size_t)m * p.ldr + nb + r]);
+                            t = (p.res_mode == MLPK_RES_ADD) ? t + rv : t * rv;
+                        }
+                        C[co + r] = from_f32<T>(t);
+                    }
+                }
+            }
+        }
+    } else {
+        // token-transposed output: lane owns token n = .. + (lane & 15) and 4 consecutive rows
+        // m = .. + 4*(lane >> 4) + r, i.e. 4 consecutive channels of one image (t_rows % 4 == 0).
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = n0 + wn * TN + j * 16 + frow;
+            if (n >= p.N) continue;
+            const float bn = p.bias ? p.bias[n] : 0.0f;
+            const float cs = p.cscale ? p.cscale[n] : 1.0f;
+            const float ch = p.cshift ? p.cshift[n] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int mb = m0 + wm * TM + i * 16 + 4 * fg;
+                if (mb >= p.M) continue;     // M % 4 == 0 for TOKEN_T, so the 4 rows are all valid
+                const int img = mb / p.t_rows;
+                const int c = mb - img * p.t_rows;
+                float v[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = v[r] + bn;
+                    if (gelu) t = gelu_f(t);
+                    t = t * cs + ch;
+                    if (p.rscale) t *= p.rscale[(c + r) % p.rperiod];
+                    v[r] = t;
+                }
+                const size_t row = (size_t)img * p.t_tokens + n;
+                if (p.res_mode != MLPK_RES_NONE) {
+                    float rv[4];
+                    load4<T>(R + row * p.ldr + c, p.vec_r != 0, rv);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (p.res_mode == MLPK_RES_ADD) ? v[r] + rv[r] : v[r] * rv[r];
+                }
+                store4<T>(C + row * p.ldc + c, p.vec_c != 0, v);
+            }
+        }
+    }
+}
+
 // GLDS = false: global -> VGPR -> LDS staging (handles every shape: predicated, zero-filled tails).
 // GLDS = true : global_load_lds_dwordx4 straight into LDS (no staging VGPRs, no ds_write pass).  The
 //               LDS image is lane-linear (wave base + lane*16), so the XOR swizzle is applied to the
@@ -264,190 +493,111 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_nt_kernel(const GemmArgs p) 
 #undef MLPK_GLOAD
 #undef MLPK_SSTORE
 
-    // ------------------------------- epilogue -------------------------------
-    if (p.dbg & 4) {
-        float sacc = 0.f;
+    gemm_epilogue<T, BM, BN, WM, WN, TRANS>(p, acc, smem, m0, n0);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// "s3" pipeline: 4 wavefronts per workgroup (one per SIMD), 64-byte LDS rows (K slabs of 32 bf16/f16 or
+// 16 f32), THREE LDS stages filled by global_load_lds two slabs ahead, ONE raw s_barrier per slab and
+// counted vmcnt waits (the loads of the next slab stay in flight across the barrier).  72 KiB of LDS
+// and <= 256 VGPRs per wave let TWO independent workgroups share a CU: each SIMD then holds one wave
+// of each, so one workgroup's MFMAs cover the other's LDS reads / barrier waits, and one workgroup's
+// epilogue (VALU GELU + stores) overlaps the other's main loop -- the two costs the lockstep
+// 8-wave / 1-workgroup-per-CU kernel above cannot hide (measured: 46 % MFMA busy in its main loop).
+// 64-byte rows: chunk c of row r is stored at chunk c ^ ((r & 8) >> 2), conflict-free for ds_read_b128.
+template <typename T, int BM, int BN, int WM, int WN, bool TRANS>
+__global__ void __launch_bounds__(WM* WN * 64, 2) gemm_nt_s3_kernel(const GemmArgs p) {
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int FM = TM / 16, FN = TN / 16;
+    constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr int BK = 4 * EPC;                           // elements per 64-byte slab
+    constexpr int STAGE_B = (BM + BN) * 64;
+    constexpr int A_G = BM / 16 / NW, B_G = BN / 16 / NW;  // 1-KiB pieces (16 rows x 64 B) per wave per slab
+    constexpr int PIECES = A_G + B_G;
+    static_assert(BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "tile rows must split into 16-row pieces per wave");
+    static_assert(3 * STAGE_B >= BM * BN * 2 || sizeof(T) != 2 || TRANS, "LDS too small for the staged epilogue");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (wg / tiles_n) * BM;
+    const int n0 = (wg % tiles_n) * BN;
+    const T* __restrict__ A = reinterpret_cast<const T*>(p.A);
+    const T* __restrict__ B = reinterpret_cast<const T*>(p.B);
+
+    // staging: lane -> (row lrow of the 16-row piece, physical chunk lane & 3); source-side swizzle
+    const int lrow = lane >> 2;
+    const int lchunk = (lane & 3) ^ ((lrow & 8) >> 2);
+    const T* srcA[A_G];
+    const T* srcB[B_G];
+#pragma unroll
+    for (int g = 0; g < A_G; ++g) {
+        int gm = m0 + (wave * A_G + g) * 16 + lrow;
+        gm = gm < p.M ? gm : p.M - 1;
+        srcA[g] = A + (size_t)gm * p.lda + lchunk * EPC;
+    }
+#pragma unroll
+    for (int g = 0; g < B_G; ++g) {
+        int gn = n0 + (wave * B_G + g) * 16 + lrow;
+        gn = gn < p.N ? gn : p.N - 1;
+        srcB[g] = B + (size_t)gn * p.ldb + lchunk * EPC;
+    }
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+    const int nk = (p.dbg & 1) ? 0 : p.K / BK;
+
+#define S3_STAGE(kt)                                                                                   \
+    {                                                                                                  \
+        char* dst__ = smem + ((kt) % 3) * STAGE_B + wave * (A_G * 1024);                                \
+        _Pragma("unroll") for (int g = 0; g < A_G; ++g)                                                \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(srcA[g] + (size_t)(kt)*BK), (lds_ptr_t)(dst__ + g * 1024), 16, 0, 0); \
+        char* dstb__ = smem + ((kt) % 3) * STAGE_B + BM * 64 + wave * (B_G * 1024);                     \
+        _Pragma("unroll") for (int g = 0; g < B_G; ++g)                                                \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(srcB[g] + (size_t)(kt)*BK), (lds_ptr_t)(dstb__ + g * 1024), 16, 0, 0); \
+    }
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15;
+    const int fg = lane >> 4;
+    const int co = (fg ^ ((frow & 8) >> 2)) << 4;
+    const int a_rd = (wm * TM + frow) * 64 + co;
+    const int b_rd = BM * 64 + (wn * TN + frow) * 64 + co;
+
+    if (nk > 0) S3_STAGE(0);
+    if (nk > 1) S3_STAGE(1);
+    for (int kt = 0; kt < nk; ++kt) {
+        // own pieces of slab kt have landed (slab kt+1, if issued, may still be in flight) ...
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ... and after the barrier everybody's have; every wave is also past its reads of slab kt-1,
+        // whose stage is the one refilled next.
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) S3_STAGE(kt + 2);
+        const char* buf = smem + (kt % 3) * STAGE_B;
+        u32x4 af[FM], bf[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const u32x4*>(buf + a_rd + i * 1024);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bf[j] = *reinterpret_cast<const u32x4*>(buf + b_rd + j * 1024);
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int j = 0; j < FN; ++j) sacc += acc[i][j].x + acc[i][j].y + acc[i][j].z + acc[i][j].w;
-        if (sacc == 123.456f) reinterpret_cast<float*>(p.C)[0] = sacc;
-        return;
+            for (int j = 0; j < FN; ++j)
+                acc[i][j] = TRANS ? Mma<T>::run(af[i], bf[j], acc[i][j]) : Mma<T>::run(bf[j], af[i], acc[i][j]);
     }
-    T* __restrict__ C = reinterpret_cast<T*>(p.C);
-    const T* R = reinterpret_cast<const T*>(p.R);
-    const bool gelu = p.act == MLPK_ACT_GELU;
-
-    if constexpr (!TRANS && sizeof(T) == 2) {
-        // ---- 2-byte row-major output: stage the finished tile through LDS (the pipeline buffers are
-        // free now) so that global traffic is full 16-byte-per-lane, whole-row coalesced: the MFMA
-        // accumulator layout only gives 8 bytes per lane in 32-byte runs, which measured 1.9 TB/s.
-        // Phase 1: bias / GELU / column scale+shift / row scale on the fp32 accumulator, round to T,
-        //          ds_write_b64 into a [BM][BN] tile whose 16-byte chunks are XOR-swizzled by row.
-        // Phase 2: every thread moves 16-byte chunks LDS -> (optional residual add|mul) -> global.
-        constexpr int CPR = BN / 8;                      // 16-byte chunks per tile row
-        constexpr int XM = (CPR >= 16 ? 16 : CPR) - 1;   // swizzle mask
-        T* tile = reinterpret_cast<T*>(smem);
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int nl = wn * TN + j * 16 + 4 * fg;    // column of this lane's 4-vector inside the tile
-            float bz[4], cs[4], ch[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int n = n0 + nl + r;
-                n = n < p.N ? n : p.N - 1;
-                bz[r] = p.bias ? p.bias[n] : 0.f;
-                cs[r] = p.cscale ? p.cscale[n] : 1.f;
-                ch[r] = p.cshift ? p.cshift[n] : 0.f;
-            }
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int rl = wm * TM + i * 16 + frow;
-                float rs = 1.f;
-                if (p.rscale) {
-                    int m = m0 + rl;
-                    m = m < p.M ? m : p.M - 1;
-                    rs = p.rscale[m % p.rperiod];
-                }
-                float v[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
-                T e[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float t = v[r] + bz[r];
-                    if (gelu) t = gelu_f(t);
-                    e[r] = from_f32<T>((t * cs[r] + ch[r]) * rs);
-                }
-                u32x2 pk;
-                __builtin_memcpy(&pk, e, 8);
-                const int c16 = nl >> 3;
-                char* dst = reinterpret_cast<char*>(tile) + rl * (BN * 2) + (((c16 ^ (rl & XM)) << 4) | ((nl & 4) << 1));
-                *reinterpret_cast<u32x2*>(dst) = pk;
-            }
-        }
-        __syncthreads();
-        constexpr int RPASS = NT / CPR;                  // rows moved per pass
-        const int c16 = tid % CPR;
-        const int rsub = tid / CPR;
-        const int gn = n0 + c16 * 8;
-        const bool vec_ok = p.vec_c == 2 && (p.res_mode == MLPK_RES_NONE || p.vec_r == 2);
-        if (gn < p.N) {
-#pragma unroll 4
-            for (int rp = 0; rp < BM / RPASS; ++rp) {
-                const int rl = rp * RPASS + rsub;
-                const int gm = m0 + rl;
-                if (gm >= p.M) break;
-                const u32x4 raw = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(tile) + rl * (BN * 2) +
-                                                                  ((c16 ^ (rl & XM)) << 4));
-                T* cp = C + (size_t)gm * p.ldc + gn;
-                if (vec_ok && gn + 8 <= p.N) {
-                    u32x4 outv = raw;
-                    if (p.res_mode != MLPK_RES_NONE) {
-                        const u32x4 rr = *reinterpret_cast<const u32x4*>(R + (size_t)gm * p.ldr + gn);
-                        T a8[8], r8[8];
-                        __builtin_memcpy(a8, &raw, 16);
-                        __builtin_memcpy(r8, &rr, 16);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float a = to_f32(a8[e]), b = to_f32(r8[e]);
-                            a8[e] = from_f32<T>(p.res_mode == MLPK_RES_ADD ? a + b : a * b);
-                        }
-                        __builtin_memcpy(&outv, a8, 16);
-                    }
-                    if (!(p.dbg & 2) || outv.x == 0x12345678u) *reinterpret_cast<u32x4*>(cp) = outv;
-                } else {
-                    T a8[8];
-                    __builtin_memcpy(a8, &raw, 16);
-                    for (int e = 0; e < 8 && gn + e < p.N; ++e) {
-                        float a = to_f32(a8[e]);
-                        if (p.res_mode != MLPK_RES_NONE) {
-                            const float b = to_f32(R[(size_t)gm * p.ldr + gn + e]);
-                            a = p.res_mode == MLPK_RES_ADD ? a + b : a * b;
-                        }
-                        cp[e] = from_f32<T>(a);
-                    }
-                }
-            }
-        }
-    } else if constexpr (!TRANS) {
-        // lane owns row m = .. + (lane & 15) and 4 consecutive columns n = .. + 4*(lane >> 4) + r
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            const int m = m0 + wm * TM + i * 16 + frow;
-            if (m >= p.M) continue;
-            const float rs = p.rscale ? p.rscale[m % p.rperiod] : 1.0f;
-#pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                const int nb = n0 + wn * TN + j * 16 + 4 * fg;
-                if (nb >= p.N) continue;
-                const bool full = nb + 3 < p.N;
-                float v[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int n = (nb + r < p.N) ? nb + r : p.N - 1;
-                    float t = v[r];
-                    if (p.bias) t += p.bias[n];
-                    if (gelu) t = gelu_f(t);
-                    if (p.cscale) t *= p.cscale[n];
-                    if (p.cshift) t += p.cshift[n];
-                    v[r] = t * rs;
-                }
-                const size_t co = (size_t)m * p.ldc + nb;
-                if (full) {
-                    if (p.res_mode != MLPK_RES_NONE) {
-                        float rv[4];
-                        load4<T>(R + (size_t)m * p.ldr + nb, p.vec_r != 0, rv);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = (p.res_mode == MLPK_RES_ADD) ? v[r] + rv[r] : v[r] * rv[r];
-                    }
-                    if (!(p.dbg & 2) || v[0] == 123.456f) store4<T>(C + co, p.vec_c != 0, v);
-                } else {
-                    for (int r = 0; r < 4 && nb + r < p.N; ++r) {
-                        float t = v[r];
-                        if (p.res_mode != MLPK_RES_NONE) {
-                            const float rv = to_f32(R[(size_t)m * p.ldr + nb + r]);
-                            t = (p.res_mode == MLPK_RES_ADD) ? t + rv : t * rv;
-                        }
-                        C[co + r] = from_f32<T>(t);
-                    }
-                }
-            }
-        }
-    } else {
-        // token-transposed output: lane owns token n = .. + (lane & 15) and 4 consecutive rows
-        // m = .. + 4*(lane >> 4) + r, i.e. 4 consecutive channels of one image (t_rows % 4 == 0).
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int n = n0 + wn * TN + j * 16 + frow;
-            if (n >= p.N) continue;
-            const float bn = p.bias ? p.bias[n] : 0.0f;
-            const float cs = p.cscale ? p.cscale[n] : 1.0f;
-            const float ch = p.cshift ? p.cshift[n] : 0.0f;
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int mb = m0 + wm * TM + i * 16 + 4 * fg;
-                if (mb >= p.M) continue;     // M % 4 == 0 for TOKEN_T, so the 4 rows are all valid
-                const int img = mb / p.t_rows;
-                const int c = mb - img * p.t_rows;
-                float v[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float t = v[r] + bn;
-                    if (gelu) t = gelu_f(t);
-                    t = t * cs + ch;
-                    if (p.rscale) t *= p.rscale[(c + r) % p.rperiod];
-                    v[r] = t;
-                }
-                const size_t row = (size_t)img * p.t_tokens + n;
-                if (p.res_mode != MLPK_RES_NONE) {
-                    float rv[4];
-                    load4<T>(R + row * p.ldr + c, p.vec_r != 0, rv);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = (p.res_mode == MLPK_RES_ADD) ? v[r] + rv[r] : v[r] * rv[r];
-                }
-                store4<T>(C + row * p.ldc + c, p.vec_c != 0, v);
-            }
-        }
-    }
+#undef S3_STAGE
+    __syncthreads();
+    gemm_epilogue<T, BM, BN, WM, WN, TRANS>(p, acc, smem, m0, n0);
 }
 
 // ------------------------------- host-side dispatch -------------------------------
@@ -463,6 +613,9 @@ static const TileCfg kTiles[] = {
     {128, 256, 2, 4, 1},
     {128, 128, 2, 2, 1},
     {64, 64, 2, 2, 1},     // algo 10
+    {256, 128, 2, 2, 2},   // algo 11..13: "s3" pipeline (4 waves, 3 LDS stages of 64-byte rows, 2 workgroups / CU)
+    {128, 128, 2, 2, 2},
+    {128, 256, 2, 2, 2},
 };
 static const int kNumTiles = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
 
@@ -486,6 +639,26 @@ static int launch_cfg(const GemmArgs& a, bool trans, hipStream_t stream) {
     return 0;
 }
 
+template <typename T, int BM, int BN, int WM, int WN>
+static int launch_s3(const GemmArgs& a, bool trans, hipStream_t stream) {
+    const int lds = 3 * (BM + BN) * 64;
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    hipError_t e;
+    if (trans) {
+        auto k = gemm_nt_s3_kernel<T, BM, BN, WM, WN, true>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(k, dim3(tiles), dim3(WM * WN * 64), lds, stream, a);
+    } else {
+        auto k = gemm_nt_s3_kernel<T, BM, BN, WM, WN, false>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(k, dim3(tiles), dim3(WM * WN * 64), lds, stream, a);
+    }
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
 template <typename T> static int launch_algo(int algo, const GemmArgs& a, bool trans, hipStream_t s) {
     switch (algo) {
         case 1: return launch_cfg<T, 256, 256, 2, 4, false>(a, trans, s);
@@ -498,23 +671,31 @@ template <typename T> static int launch_algo(int algo, const GemmArgs& a, bool t
         case 8: return launch_cfg<T, 128, 256, 2, 4, true>(a, trans, s);
         case 9: return launch_cfg<T, 128, 128, 2, 2, true>(a, trans, s);
         case 10: return launch_cfg<T, 64, 64, 2, 2, true>(a, trans, s);
+        case 11: return launch_s3<T, 256, 128, 2, 2>(a, trans, s);
+        case 12: return launch_s3<T, 128, 128, 2, 2>(a, trans, s);
+        case 13: return launch_s3<T, 128, 256, 2, 2>(a, trans, s);
         default: return MLPK_EMODE;
     }
 }
 
 // Pick the tile that minimises (padded MFMA work / tile efficiency) x (a soft tail penalty for grids that
-// do not fill the 256 CUs many times over).  Efficiencies are measured on MI355X (profiles/).
+// do not fill the CUs many times over).  Efficiencies follow the MI355X sweeps in profiles/: with K a
+// multiple of 32 elements the 2-workgroup-per-CU "s3" tiles win on every shape of the path (their
+// epilogue overlaps the other workgroup's main loop); ragged K falls back to the register-staged tiles.
 static int auto_algo(int M, int N, bool glds_ok) {
     double best = 1e300;
     int best_algo = 4;
     for (int i = 0; i < kNumTiles; ++i) {
         const TileCfg& t = kTiles[i];
-        if (t.glds != (glds_ok ? 1 : 0)) continue;
-        const double tiles = (double)((M + t.bm - 1) / t.bm) * (double)((N + t.bn - 1) / t.bn);
-        const int wg_per_cu = (t.bm + t.bn) * 256 <= 80 * 1024 ? 2 : 1;
-        const double slots = 256.0 * wg_per_cu;
         const int area = t.bm * t.bn;
-        const double eff = area >= 256 * 256 ? 1.0 : area >= 256 * 128 ? 0.92 : area >= 128 * 128 ? 0.82 : 0.5;
+        if (glds_ok) {
+            if (!(t.glds == 2 || (t.glds == 1 && area <= 64 * 64))) continue;
+        } else if (t.glds != 0) {
+            continue;
+        }
+        const double tiles = (double)((M + t.bm - 1) / t.bm) * (double)((N + t.bn - 1) / t.bn);
+        const double slots = area >= 256 * 256 ? 256.0 : area >= 128 * 128 ? 512.0 : 1024.0;
+        const double eff = area >= 256 * 128 ? 1.0 : area >= 128 * 128 ? 0.9 : 0.45;
         const double cost = tiles * area / eff * (1.0 + 0.5 * slots / tiles);
         if (cost < best) { best = cost; best_algo = i + 1; }
     }
@@ -533,7 +714,7 @@ extern "C" int mlpk_gemm_algo_info(int algo, int* bm, int* bn, int* threads, int
     if (bm) *bm = t.bm;
     if (bn) *bn = t.bn;
     if (threads) *threads = t.wm * t.wn * 64;
-    if (lds_bytes) *lds_bytes = 2 * (t.bm + t.bn) * 128;
+    if (lds_bytes) *lds_bytes = t.glds == 2 ? 3 * (t.bm + t.bn) * 64 : 2 * (t.bm + t.bn) * 128;
     return 0;
 }
 

@@ -355,7 +355,7 @@ def test_dwconv(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("algo", [6, 7, 8, 9])
+@pytest.mark.parametrize("algo", [6, 7, 8, 9, 10, 11, 12, 13])
 def test_gemm_direct_to_lds_tiles(dtype, algo):
     """global_load_lds staging: ragged M/N (clamped source rows), K = whole and half slabs, both outputs."""
     pkg = load_pkg()

@@ -18,9 +18,21 @@ fi
 if has bench; then
   timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -1 $OUT/bench.json
 fi
+if has models; then
+  : > $OUT/bench_models.jsonl
+  for m in mixer_s16 mixer_l16 gmlp_s resmlp_24 vip_s7 s2mlpv2 asmlp_t convmixer_1536_20; do
+    timeout 600 python bench.py --model $m --steps 5 --warmup 2 --no-cpu-baseline >> $OUT/bench_models.jsonl 2>> $OUT/bench_models.err
+  done
+  python - <<'PY'
+import json
+for l in open("gpurun_out/bench_models.jsonl"):
+    d = json.loads(l)
+    print("%-60s %10.1f img/s %8.2f ms  %7.1f model-TF/s" % (d["metric"], d["value"], d["ms_per_step"], d["model_tflops"]))
+PY
+fi
 if has prof; then
   rm -rf $OUT/prof
-  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof" -o mixer_b16 -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err" )
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o mixer_b16 -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err" )
   echo "prof rc=$?"
   find $OUT/prof -name "*kernel_stats*" | head -3
   f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
