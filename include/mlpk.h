@@ -71,7 +71,10 @@ const char* mlpk_strerror(int code);
 
 /* ---- GEMM with fused epilogue ----------------------------------------------------------
  * acc[m,n] = sum_k A[m*lda + k] * B[n*ldb + k]           (A: MxK, B: NxK, both K-contiguous)
- * v = acc + bias[n]                     (bias may be NULL)
+ * v = (acc - ln_mean[m]*ln_csum[n]) * ln_rstd[m]   (all three NULL -> v = acc).  This folds a LayerNorm
+ *     of the A rows into the GEMM: with W' = W*diag(gamma) as B, ln_csum[n] = sum_k W'[n,k] and the
+ *     LayerNorm's beta folded into `bias`, A can be the UN-normalised activation (ROWMAJOR output only).
+ * v = v + bias[n]                       (bias may be NULL)
  * v = gelu(v)   if act == MLPK_ACT_GELU (exact erf form)
  * v = v * cscale[n] + cshift[n]         (either may be NULL)
  * v = v * rscale[m % rperiod]           (rscale may be NULL)
@@ -106,6 +109,9 @@ typedef struct mlpk_gemm_desc {
     const float* cscale;  /* [N] or NULL */
     const float* cshift;  /* [N] or NULL */
     const float* rscale;  /* [rperiod] or NULL */
+    const float* ln_mean; /* [M] or NULL: folded LayerNorm row means */
+    const float* ln_rstd; /* [M] or NULL */
+    const float* ln_csum; /* [N] or NULL: row sums of B */
     int32_t rperiod;
     int32_t act;
     int32_t res_mode;

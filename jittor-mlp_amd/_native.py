@@ -21,6 +21,7 @@ class GemmDesc(ctypes.Structure):
                 ("lda", ctypes.c_int32), ("ldb", ctypes.c_int32), ("ldc", ctypes.c_int32), ("ldr", ctypes.c_int32),
                 ("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("R", c_void_p),
                 ("bias", c_void_p), ("cscale", c_void_p), ("cshift", c_void_p), ("rscale", c_void_p),
+                ("ln_mean", c_void_p), ("ln_rstd", c_void_p), ("ln_csum", c_void_p),
                 ("rperiod", ctypes.c_int32), ("act", ctypes.c_int32), ("res_mode", ctypes.c_int32),
                 ("out_mode", ctypes.c_int32), ("t_rows", ctypes.c_int32), ("t_tokens", ctypes.c_int32),
                 ("algo", ctypes.c_int32), ("reserved", ctypes.c_int32)]
@@ -76,7 +77,7 @@ def lib():
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(handle, name)          # AttributeError if a declared symbol is not exported
             fn.restype, fn.argtypes = res, args
-        if handle.mlpk_abi_version() != 1:
+        if handle.mlpk_abi_version() != 2:
             raise MlpkError("libmlpk.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -30,6 +30,9 @@ struct GemmArgs {
     const float* cscale;
     const float* cshift;
     const float* rscale;
+    const float* ln_mean;   // folded LayerNorm: v = (acc - ln_mean[m]*ln_csum[n]) * ln_rstd[m]
+    const float* ln_rstd;
+    const float* ln_csum;
     int M, N, K;
     int lda, ldb, ldc, ldr;
     int rperiod, act, res_mode;
@@ -37,6 +40,22 @@ struct GemmArgs {
     int vec_c, vec_r;   // vector (4-element) store / residual-load allowed
     int dbg;            // tuning ablations (desc.reserved): 1 = no main loop, 2 = no stores, 4 = no epilogue
 };
+
+// tuning aid (dbg & 8): wave 0 / lane 0 of each workgroup logs s_memtime stamps into the buffer passed in R
+#define MLPK_STAMP(slot)                                                                          \
+    if ((p.dbg & 8) && threadIdx.x == 0 && (slot) < 64)                                            \
+        reinterpret_cast<unsigned long long*>(const_cast<void*>(p.R))[(size_t)blockIdx.x * 64 + (slot)] = __builtin_readcyclecounter();
+
+// One 1-KiB LDS-DMA piece: 64 lanes x 16 bytes, per-lane global source, LDS destination = M0 base + lane*16.
+// Inline asm on purpose: hipcc tracks the builtin form as an LDS store and drains vmcnt(0) in front of any
+// later ds_read it cannot disambiguate, which serialises the pipeline; here the counted waits are ours.
+__device__ __forceinline__ void glds_piece(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -163,29 +182,31 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
             const int nl = wn * TN + j * 16 + 4 * fg;    // column of this lane's 4-vector inside the tile
-            float bz[4], cs[4], ch[4];
+            float bz[4], cs[4], ch[4], lc[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int n = n0 + nl + r;
                 n = n < p.N ? n : p.N - 1;
                 bz[r] = p.bias ? p.bias[n] : 0.f;
+                lc[r] = p.ln_mean ? p.ln_csum[n] : 0.f;
                 cs[r] = p.cscale ? p.cscale[n] : 1.f;
                 ch[r] = p.cshift ? p.cshift[n] : 0.f;
             }
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 const int rl = wm * TM + i * 16 + frow;
-                float rs = 1.f;
-                if (p.rscale) {
+                float rs = 1.f, lmu = 0.f, lrs = 1.f;
+                if (p.rscale || p.ln_mean) {
                     int m = m0 + rl;
                     m = m < p.M ? m : p.M - 1;
-                    rs = p.rscale[m % p.rperiod];
+                    if (p.rscale) rs = p.rscale[m % p.rperiod];
+                    if (p.ln_mean) { lmu = p.ln_mean[m]; lrs = p.ln_rstd[m]; }
                 }
                 float v[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
                 T e[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float t = v[r] + bz[r];
+                    float t = (v[r] - lmu * lc[r]) * lrs + bz[r];
                     if (gelu) t = gelu_f(t);
                     e[r] = from_f32<T>((t * cs[r] + ch[r]) * rs);
                 }
@@ -258,6 +279,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
             const int m = m0 + wm * TM + i * 16 + frow;
             if (m >= p.M) continue;
             const float rs = p.rscale ? p.rscale[m % p.rperiod] : 1.0f;
+            const float lmu = p.ln_mean ? p.ln_mean[m] : 0.f, lrs = p.ln_mean ? p.ln_rstd[m] : 1.f;
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
                 const int nb = n0 + wn * TN + j * 16 + 4 * fg;
@@ -268,6 +290,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
                 for (int r = 0; r < 4; ++r) {
                     const int n = (nb + r < p.N) ? nb + r : p.N - 1;
                     float t = v[r];
+                    if (p.ln_mean) t = (t - lmu * p.ln_csum[n]) * lrs;
                     if (p.bias) t += p.bias[n];
                     if (gelu) t = gelu_f(t);
                     if (p.cscale) t *= p.cscale[n];
@@ -478,17 +501,25 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_nt_kernel(const GemmArgs p) 
         _Pragma("unroll") for (int g = 0; g < B_G; ++g)                                          \
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(srcB[g] + k__), (lds_ptr_t)(dstb__ + g * 1024), 16, 0, 0); \
     }
+        MLPK_STAMP(0);
         MLPK_STAGE(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        MLPK_STAMP(1);
         for (int kt = 0; kt < nk; ++kt) {
             if ((kt + 1) < nk) MLPK_STAGE(kt + 1);
+            MLPK_STAMP(2 + 4 * kt);
             MLPK_COMPUTE(kt);
+            MLPK_STAMP(3 + 4 * kt);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            MLPK_STAMP(4 + 4 * kt);
             __syncthreads();
+            MLPK_STAMP(5 + 4 * kt);
         }
 #undef MLPK_STAGE
     }
+    MLPK_STAMP(60);
+    if (p.dbg & 8) return;
 #undef MLPK_COMPUTE
 #undef MLPK_GLOAD
 #undef MLPK_SSTORE
@@ -551,14 +582,18 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) gemm_nt_s3_kernel(const GemmAr
     typedef const __attribute__((address_space(1))) void* glb_ptr_t;
     const int nk = (p.dbg & 1) ? 0 : p.K / BK;
 
+    const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)smem;
+    const unsigned dst_a = __builtin_amdgcn_readfirstlane(lds_base + wave * (A_G * 1024));
+    const unsigned dst_b = __builtin_amdgcn_readfirstlane(lds_base + BM * 64 + wave * (B_G * 1024));
+#define S3_PIECE(kt, q)                                                                                \
+    {                                                                                                  \
+        const unsigned st__ = ((kt) % 3) * STAGE_B;                                                     \
+        if ((q) < A_G) glds_piece(srcA[(q) < A_G ? (q) : 0] + (size_t)(kt)*BK, dst_a + st__ + (q)*1024); \
+        else glds_piece(srcB[(q) >= A_G ? (q)-A_G : 0] + (size_t)(kt)*BK, dst_b + st__ + ((q)-A_G) * 1024); \
+    }
 #define S3_STAGE(kt)                                                                                   \
     {                                                                                                  \
-        char* dst__ = smem + ((kt) % 3) * STAGE_B + wave * (A_G * 1024);                                \
-        _Pragma("unroll") for (int g = 0; g < A_G; ++g)                                                \
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(srcA[g] + (size_t)(kt)*BK), (lds_ptr_t)(dst__ + g * 1024), 16, 0, 0); \
-        char* dstb__ = smem + ((kt) % 3) * STAGE_B + BM * 64 + wave * (B_G * 1024);                     \
-        _Pragma("unroll") for (int g = 0; g < B_G; ++g)                                                \
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(srcB[g] + (size_t)(kt)*BK), (lds_ptr_t)(dstb__ + g * 1024), 16, 0, 0); \
+        _Pragma("unroll") for (int q = 0; q < PIECES; ++q) S3_PIECE(kt, q);                            \
     }
 
     f32x4 acc[FM][FN];
@@ -573,30 +608,48 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) gemm_nt_s3_kernel(const GemmAr
     const int a_rd = (wm * TM + frow) * 64 + co;
     const int b_rd = BM * 64 + (wn * TN + frow) * 64 + co;
 
+    MLPK_STAMP(0);
     if (nk > 0) S3_STAGE(0);
     if (nk > 1) S3_STAGE(1);
+    MLPK_STAMP(1);
     for (int kt = 0; kt < nk; ++kt) {
+        MLPK_STAMP(2 + 2 * kt);
         // own pieces of slab kt have landed (slab kt+1, if issued, may still be in flight) ...
         if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // ... and after the barrier everybody's have; every wave is also past its reads of slab kt-1,
         // whose stage is the one refilled next.
         __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) S3_STAGE(kt + 2);
+        MLPK_STAMP(3 + 2 * kt);
         const char* buf = smem + (kt % 3) * STAGE_B;
         u32x4 af[FM], bf[FN];
 #pragma unroll
-        for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const u32x4*>(buf + a_rd + i * 1024);
-#pragma unroll
         for (int j = 0; j < FN; ++j) bf[j] = *reinterpret_cast<const u32x4*>(buf + b_rd + j * 1024);
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
+        for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const u32x4*>(buf + a_rd + i * 1024);
+        // the fragment reads are issued first (they cannot sink below the asm pieces: "memory" clobber) ...
+        // ... then the 1-KiB LDS-DMA pieces of slab kt+2 go out ONE AT A TIME between groups of MFMAs.
+        // Issued back to back (all waves at once, right after the barrier) they saturate the CU's
+        // texture-address path and every wave sits in VMEM issue for ~95 cycles per piece with the matrix
+        // pipe idle (s_memtime stamps: ~760 of ~3660 cycles per 64-wide K step of the 8-wave kernel).
+        constexpr int NB = FM * FN;                  // MFMA blocks per slab
+        constexpr int GAP = NB / PIECES;             // MFMAs between two pieces
+        const bool do_stage = kt + 2 < nk;           // wave-uniform
 #pragma unroll
-            for (int j = 0; j < FN; ++j)
-                acc[i][j] = TRANS ? Mma<T>::run(af[i], bf[j], acc[i][j]) : Mma<T>::run(bf[j], af[i], acc[i][j]);
+        for (int blk = 0; blk < NB; ++blk) {
+            const int i = blk / FN, j = blk % FN;
+            if (blk % GAP == 0 && blk / GAP < PIECES) {
+                if (do_stage) S3_PIECE(kt + 2, blk / GAP);
+            }
+            acc[i][j] = TRANS ? Mma<T>::run(af[i], bf[j], acc[i][j]) : Mma<T>::run(bf[j], af[i], acc[i][j]);
+        }
     }
+#undef S3_PIECE
 #undef S3_STAGE
+    MLPK_STAMP(60);
     __syncthreads();
+    MLPK_STAMP(61);
+    if (p.dbg & 8) return;
     gemm_epilogue<T, BM, BN, WM, WN, TRANS>(p, acc, smem, m0, n0);
 }
 
@@ -733,6 +786,8 @@ extern "C" int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream) {
     if (d->out_mode != MLPK_OUT_ROWMAJOR && d->out_mode != MLPK_OUT_TOKEN_T) return MLPK_EMODE;
     if (d->rscale && d->rperiod <= 0) return MLPK_ESHAPE;
     const bool trans = d->out_mode == MLPK_OUT_TOKEN_T;
+    if ((d->ln_mean != nullptr) != (d->ln_rstd != nullptr) || (d->ln_mean != nullptr) != (d->ln_csum != nullptr)) return MLPK_ENULL;
+    if (d->ln_mean && trans) return MLPK_EMODE;     // the fold is per GEMM row; token-transposed GEMMs normalise along K
     if (trans) {
         if (d->t_rows <= 0 || d->t_tokens <= 0 || d->t_rows % 4 || d->M % d->t_rows || d->N > d->t_tokens) return MLPK_ESHAPE;
         if (d->ldc < d->t_rows) return MLPK_ESHAPE;
@@ -742,6 +797,7 @@ extern "C" int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream) {
     GemmArgs a;
     a.A = d->A; a.B = d->B; a.C = d->C; a.R = d->R;
     a.bias = d->bias; a.cscale = d->cscale; a.cshift = d->cshift; a.rscale = d->rscale;
+    a.ln_mean = d->ln_mean; a.ln_rstd = d->ln_rstd; a.ln_csum = d->ln_csum;
     a.M = d->M; a.N = d->N; a.K = d->K;
     a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc; a.ldr = d->ldr;
     a.rperiod = d->rperiod > 0 ? d->rperiod : 1;

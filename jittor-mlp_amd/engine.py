@@ -51,6 +51,21 @@ def pack_matrix(w, dtype, device, kpad=8):
     return out
 
 
+def pack_ln_folded(w, b, gamma, beta, dtype, device, kpad=8):
+    """Fold LayerNorm(gamma, beta) into the Linear(w, b) that consumes it:
+    LN(x) W^T + b = rstd * (x W'^T - mu * csum) + b',  W' = W diag(gamma), csum[n] = sum_k W'[n,k]
+    (taken over the ROUNDED packed values, so it cancels exactly what the MFMA accumulates),
+    b' = b + W beta.  Returns (W' packed, b' fp32, csum fp32)."""
+    w32 = w.detach().to(device=device, dtype=torch.float32).reshape(w.shape[0], -1)
+    wf = w32 * gamma.detach().to(device=device, dtype=torch.float32).reshape(1, -1)
+    packed = pack_matrix(wf, dtype, device, kpad)
+    csum = packed.to(torch.float32).sum(dim=1).contiguous()
+    bias = w32 @ beta.detach().to(device=device, dtype=torch.float32).reshape(-1)
+    if b is not None:
+        bias = bias + b.detach().to(device=device, dtype=torch.float32).reshape(-1)
+    return packed, bias.contiguous(), csum
+
+
 def f32(v, device):
     """Per-channel vectors always travel as float32."""
     if v is None:
@@ -80,7 +95,7 @@ GEMM_ALGO = {}                    # tag -> forced tile config (tuning/bench hook
 
 def gemm(A, B, C, M, Nn, K, *, lda=None, ldb=None, ldc=None, bias=None, act=N.ACT_NONE, cscale=None, cshift=None,
          rscale=None, rperiod=0, R=None, ldr=None, res=N.RES_NONE, out_mode=N.OUT_ROWMAJOR, t_rows=0, t_tokens=0,
-         algo=0, tag=None, dbg=0):
+         algo=0, tag=None, dbg=0, ln=None):
     if tag is not None and algo == 0:
         algo = GEMM_ALGO.get(tag, 0)
     timed = TIMER is not None and tag is not None
@@ -96,6 +111,8 @@ def gemm(A, B, C, M, Nn, K, *, lda=None, ldb=None, ldc=None, bias=None, act=N.AC
     d.ldr = (ldr if ldr is not None else (R.stride(-2) if R is not None else 0))
     d.A, d.B, d.C, d.R = ptr(A), ptr(B), ptr(C), ptr(R)
     d.bias, d.cscale, d.cshift, d.rscale = ptr(bias), ptr(cscale), ptr(cshift), ptr(rscale)
+    if ln is not None:                                   # (mean[M], rstd[M], csum[N]) of a folded LayerNorm
+        d.ln_mean, d.ln_rstd, d.ln_csum = ptr(ln[0]), ptr(ln[1]), ptr(ln[2])
     d.rperiod, d.act, d.res_mode, d.out_mode = rperiod, act, res, out_mode
     d.t_rows, d.t_tokens, d.algo = t_rows, t_tokens, algo
     d.reserved = dbg

@@ -32,6 +32,14 @@ def embed_patches(ws, name, x, w_packed, bias, cdtype, patch, pad=0, out=None):
     return out, hp, wp
 
 
+def pack_channel_mlp(pk, prefix, norm, fc1, fc2, dtype, device):
+    """Pack LN -> fc1 -> GELU -> fc2 with the LayerNorm folded into fc1 (engine.pack_ln_folded)."""
+    pk[prefix + "fc1.w"], pk[prefix + "fc1.b"], pk[prefix + "fc1.csum"] = E.pack_ln_folded(
+        fc1.weight, fc1.bias, norm.weight, norm.bias, dtype, device)
+    pk[prefix + "fc2.w"] = E.pack_matrix(fc2.weight, dtype, device)
+    pk[prefix + "fc2.b"] = E.f32(fc2.bias, device)
+
+
 def layernorm_stats(ws, x, rows, C, tag="ln"):
     mean = ws.get(tag + ".mean", (rows,), torch.float32)
     rstd = ws.get(tag + ".rstd", (rows,), torch.float32)
@@ -42,7 +50,14 @@ def layernorm_stats(ws, x, rows, C, tag="ln"):
 def channel_mlp(ws, x, rows, C, pk, prefix, hidden, *, norm=True, cscale2=None, res_src=None, tag="cm"):
     """x <- x + fc2(gelu(fc1(LN(x))))   (mlp_mixer.py:38; vip.py:82-88; s2_mlp_v2.py:78-84).
     LN -> row-major normalised copy; fc1 epilogue = bias + exact GELU; fc2 epilogue = bias + residual."""
-    if norm:
+    ln = None
+    if norm and (prefix + "fc1.csum") in pk:
+        # LayerNorm folded into fc1 (gamma in the weights, beta in the bias, mean/rstd applied on the
+        # accumulator): x itself is the GEMM operand, only the row statistics are computed
+        mean, rstd = layernorm_stats(ws, x, rows, C, tag=tag + ".ln")
+        ln = (mean, rstd, pk[prefix + "fc1.csum"])
+        xn = x
+    elif norm:
         mean, rstd = layernorm_stats(ws, x, rows, C, tag=tag + ".ln")
         xn = ws.get(tag + ".xn", (rows, C))
         E.norm_apply(x, rows, C, x.stride(0), mean=mean, rstd=rstd, gamma=pk[prefix + "ln.g"], beta=pk[prefix + "ln.b"],
@@ -50,7 +65,7 @@ def channel_mlp(ws, x, rows, C, pk, prefix, hidden, *, norm=True, cscale2=None, 
     else:
         xn = x
     h = ws.get(tag + ".h", (rows, hidden))
-    E.gemm(xn, pk[prefix + "fc1.w"], h, rows, hidden, C, bias=pk[prefix + "fc1.b"], act=N.ACT_GELU, tag="channel_fc1")
+    E.gemm(xn, pk[prefix + "fc1.w"], h, rows, hidden, C, bias=pk[prefix + "fc1.b"], act=N.ACT_GELU, ln=ln, tag="channel_fc1")
     E.gemm(h, pk[prefix + "fc2.w"], x, rows, C, hidden, bias=pk[prefix + "fc2.b"], cscale=cscale2,
            R=res_src if res_src is not None else x, res=N.RES_ADD, tag="channel_fc2")
     return x

@@ -48,9 +48,9 @@ class gMLP(E.EngineModule):
     def _pack_blocks(self, pk, dtype, device):
         for i, blk in enumerate(self.model):
             p = "b%d." % i
-            pk[p + "ln.g"], pk[p + "ln.b"] = E.f32(blk.norm.weight, device), E.f32(blk.norm.bias, device)
-            pk[p + "p1.w"] = E.pack_matrix(blk.channel_proj1.weight, dtype, device)
-            pk[p + "p1.b"] = E.f32(blk.channel_proj1.bias, device)
+            # block LayerNorm folded into channel_proj1 (gamma -> weights, beta -> bias, stats in the epilogue)
+            pk[p + "p1.w"], pk[p + "p1.b"], pk[p + "p1.csum"] = E.pack_ln_folded(
+                blk.channel_proj1.weight, blk.channel_proj1.bias, blk.norm.weight, blk.norm.bias, dtype, device)
             pk[p + "p2.w"] = E.pack_matrix(blk.channel_proj2.weight, dtype, device)
             pk[p + "p2.b"] = E.f32(blk.channel_proj2.bias, device)
             pk[p + "sgu.g"], pk[p + "sgu.b"] = E.f32(blk.sgu.norm.weight, device), E.f32(blk.sgu.norm.bias, device)
@@ -69,10 +69,9 @@ class gMLP(E.EngineModule):
         for i in range(depth):
             p = "b%d." % i
             mean, rstd = layernorm_stats(ws, x, rows, C)
-            xn = ws.get("xn", (rows, C))
-            E.norm_apply(x, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "ln.g"], beta=pk[p + "ln.b"], out_rm=xn, ld_rm=C)
             h = ws.get("h", (rows, 2 * F))
-            E.gemm(xn, pk[p + "p1.w"], h, rows, 2 * F, C, bias=pk[p + "p1.b"], act=N.ACT_GELU)
+            E.gemm(x, pk[p + "p1.w"], h, rows, 2 * F, C, bias=pk[p + "p1.b"], act=N.ACT_GELU, ln=(mean, rstd, pk[p + "p1.csum"]),
+                   tag="gmlp_proj1")
             v = h[:, F:]                                        # second half, row stride 2F (g_mlp.py:18)
             vmean = ws.get("v.mean", (rows,), torch.float32)
             vrstd = ws.get("v.rstd", (rows,), torch.float32)

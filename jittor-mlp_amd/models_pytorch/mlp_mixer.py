@@ -21,7 +21,7 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Holder, channel_mlp, embed_patches, head_linear, layernorm_stats
+from .common import Holder, channel_mlp, embed_patches, head_linear, layernorm_stats, pack_channel_mlp
 from .utils.tools import check_sizes, pair
 
 
@@ -66,11 +66,7 @@ class MLPMixer(E.EngineModule):
             pk[p + "tok.fc1.b"] = E.f32(tok.fn.net[0].bias, device)
             pk[p + "tok.fc2.w"] = E.pack_matrix(tok.fn.net[3].weight, dtype, device, kpad=32)     # (S, 4S_pad)
             pk[p + "tok.fc2.b"] = E.f32(tok.fn.net[3].bias, device)
-            pk[p + "ch.ln.g"], pk[p + "ch.ln.b"] = E.f32(ch.norm.weight, device), E.f32(ch.norm.bias, device)
-            pk[p + "ch.fc1.w"] = E.pack_matrix(ch.fn.net[0].weight, dtype, device)
-            pk[p + "ch.fc1.b"] = E.f32(ch.fn.net[0].bias, device)
-            pk[p + "ch.fc2.w"] = E.pack_matrix(ch.fn.net[3].weight, dtype, device)
-            pk[p + "ch.fc2.b"] = E.f32(ch.fn.net[3].bias, device)
+            pack_channel_mlp(pk, p + "ch.", ch.norm, ch.fn.net[0], ch.fn.net[3], dtype, device)
 
     def _pack(self, dtype, device):
         pk = {}

@@ -8,7 +8,7 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Holder, channel_mlp, head_linear, layernorm_stats, stage_embed
+from .common import Holder, channel_mlp, head_linear, layernorm_stats, stage_embed, pack_channel_mlp
 from .s2_mlp_v2 import SHIFT_MODES
 from .utils.tools import pair
 
@@ -38,17 +38,12 @@ class S2Block(E.EngineModule):
         for i, blk in enumerate(self.model):
             p = prefix + "b%d." % i
             sm = blk[0]
-            pk[p + "ln.g"], pk[p + "ln.b"] = E.f32(sm.norm.weight, device), E.f32(sm.norm.bias, device)
-            pk[p + "l0.w"] = E.pack_matrix(sm.fn[0].weight, dtype, device)
-            pk[p + "l0.b"] = E.f32(sm.fn[0].bias, device)
+            pk[p + "l0.w"], pk[p + "l0.b"], pk[p + "l0.csum"] = E.pack_ln_folded(
+                sm.fn[0].weight, sm.fn[0].bias, sm.norm.weight, sm.norm.bias, dtype, device)
             pk[p + "l3.w"] = E.pack_matrix(sm.fn[3].weight, dtype, device)
             pk[p + "l3.b"] = E.f32(sm.fn[3].bias, device)
             mlp = blk[1]
-            pk[p + "mlp.ln.g"], pk[p + "mlp.ln.b"] = E.f32(mlp.norm.weight, device), E.f32(mlp.norm.bias, device)
-            pk[p + "mlp.fc1.w"] = E.pack_matrix(mlp.fn[0].weight, dtype, device)
-            pk[p + "mlp.fc1.b"] = E.f32(mlp.fn[0].bias, device)
-            pk[p + "mlp.fc2.w"] = E.pack_matrix(mlp.fn[3].weight, dtype, device)
-            pk[p + "mlp.fc2.b"] = E.f32(mlp.fn[3].bias, device)
+            pack_channel_mlp(pk, p + "mlp.", mlp.norm, mlp.fn[0], mlp.fn[3], dtype, device)
 
     def _run_blocks(self, ws, pk, x, B, H, W, prefix, mode):
         C, depth, ef = self._dims
@@ -56,10 +51,9 @@ class S2Block(E.EngineModule):
         for i in range(depth):
             p = prefix + "b%d." % i
             mean, rstd = layernorm_stats(ws, x, rows, C, tag=prefix + "ln")
-            xn = ws.get(prefix + "xn", (rows, C))
-            E.norm_apply(x, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "ln.g"], beta=pk[p + "ln.b"], out_rm=xn, ld_rm=C)
             t = ws.get(prefix + "t", (rows, C))
-            E.gemm(xn, pk[p + "l0.w"], t, rows, C, C, bias=pk[p + "l0.b"], act=N.ACT_GELU, tag="s2v1_l0")
+            E.gemm(x, pk[p + "l0.w"], t, rows, C, C, bias=pk[p + "l0.b"], act=N.ACT_GELU, ln=(mean, rstd, pk[p + "l0.csum"]),
+                   tag="s2v1_l0")
             ts = ws.get(prefix + "ts", (rows, C))
             E.s2_shift(t, ts, B, H, W, C, C, C, mode)
             E.gemm(ts, pk[p + "l3.w"], x, rows, C, C, bias=pk[p + "l3.b"], R=x, res=N.RES_ADD, tag="s2v1_l3")

@@ -20,7 +20,7 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Holder, channel_mlp, head_linear, layernorm_stats, split_attention_weights, stage_embed
+from .common import Holder, channel_mlp, head_linear, layernorm_stats, split_attention_weights, stage_embed, pack_channel_mlp
 from .utils.tools import pair
 
 SHIFT_MODES = {"reference_inplace": N.SHIFT_S2_REF, "shift": N.SHIFT_S2}
@@ -72,19 +72,14 @@ class S2Block(E.EngineModule):
         for i, blk in enumerate(self.model):
             p = prefix + "b%d." % i
             att = blk[0].fn
-            pk[p + "ln.g"], pk[p + "ln.b"] = E.f32(blk[0].norm.weight, device), E.f32(blk[0].norm.bias, device)
-            pk[p + "a1.w"] = E.pack_matrix(att.mlp1.weight, dtype, device)
-            pk[p + "a1.b"] = E.f32(att.mlp1.bias, device)
+            pk[p + "a1.w"], pk[p + "a1.b"], pk[p + "a1.csum"] = E.pack_ln_folded(
+                att.mlp1.weight, att.mlp1.bias, blk[0].norm.weight, blk[0].norm.bias, dtype, device)
             pk[p + "a2.w"] = E.pack_matrix(att.mlp2.weight, dtype, device)
             pk[p + "a2.b"] = E.f32(att.mlp2.bias, device)
             pk[p + "sa.m1"] = E.pack_matrix(att.split_attention.mlp1.weight, torch.float32, device)
             pk[p + "sa.m2"] = E.pack_matrix(att.split_attention.mlp2.weight, torch.float32, device)
             mlp = blk[1]
-            pk[p + "mlp.ln.g"], pk[p + "mlp.ln.b"] = E.f32(mlp.norm.weight, device), E.f32(mlp.norm.bias, device)
-            pk[p + "mlp.fc1.w"] = E.pack_matrix(mlp.fn[0].weight, dtype, device)
-            pk[p + "mlp.fc1.b"] = E.f32(mlp.fn[0].bias, device)
-            pk[p + "mlp.fc2.w"] = E.pack_matrix(mlp.fn[3].weight, dtype, device)
-            pk[p + "mlp.fc2.b"] = E.f32(mlp.fn[3].bias, device)
+            pack_channel_mlp(pk, p + "mlp.", mlp.norm, mlp.fn[0], mlp.fn[3], dtype, device)
 
     def _run_blocks(self, ws, pk, x, B, H, W, prefix, mode):
         C, depth, ef = self._dims
@@ -92,10 +87,8 @@ class S2Block(E.EngineModule):
         for i in range(depth):
             p = prefix + "b%d." % i
             mean, rstd = layernorm_stats(ws, x, rows, C, tag=prefix + "ln")
-            xn = ws.get(prefix + "xn", (rows, C))
-            E.norm_apply(x, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "ln.g"], beta=pk[p + "ln.b"], out_rm=xn, ld_rm=C)
             t = ws.get(prefix + "t", (rows, 3 * C))
-            E.gemm(xn, pk[p + "a1.w"], t, rows, 3 * C, C, bias=pk[p + "a1.b"], tag="s2_mlp1")
+            E.gemm(x, pk[p + "a1.w"], t, rows, 3 * C, C, bias=pk[p + "a1.b"], ln=(mean, rstd, pk[p + "a1.csum"]), tag="s2_mlp1")
             x0, x1, x2 = t[:, :C], t[:, C:2 * C], t[:, 2 * C:]
             bar = split_attention_weights(ws, x0, x1, x2, 3 * C, 3 * C, 3 * C, B, H, W, C, mode, pk[p + "sa.m1"], pk[p + "sa.m2"],
                                           tag=prefix + "sa")

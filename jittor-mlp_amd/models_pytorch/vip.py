@@ -16,7 +16,7 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Holder, channel_mlp, embed_patches, head_linear, layernorm_stats, split_attention_weights
+from .common import Holder, channel_mlp, embed_patches, head_linear, layernorm_stats, split_attention_weights, pack_channel_mlp
 from .utils.tools import pair
 
 
@@ -112,11 +112,7 @@ class _PermutatorBase(E.EngineModule):
             pk[p + "proj.w"] = E.pack_matrix(proj.weight, dtype, device)
             pk[p + "proj.b"] = E.f32(proj.bias, device)
             mlp = blk[1]
-            pk[p + "mlp.ln.g"], pk[p + "mlp.ln.b"] = E.f32(mlp.norm.weight, device), E.f32(mlp.norm.bias, device)
-            pk[p + "mlp.fc1.w"] = E.pack_matrix(mlp.fn[0].weight, dtype, device)
-            pk[p + "mlp.fc1.b"] = E.f32(mlp.fn[0].bias, device)
-            pk[p + "mlp.fc2.w"] = E.pack_matrix(mlp.fn[3].weight, dtype, device)
-            pk[p + "mlp.fc2.b"] = E.f32(mlp.fn[3].bias, device)
+            pack_channel_mlp(pk, p + "mlp.", mlp.norm, mlp.fn[0], mlp.fn[3], dtype, device)
 
     def _pack(self, dtype, device):
         pk = {}

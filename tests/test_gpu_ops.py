@@ -390,3 +390,27 @@ def test_gemm_direct_to_lds_tiles(dtype, algo):
     with pytest.raises(N.MlpkError):                          # K not a multiple of half a slab -> refused, not wrong
         A = torch.zeros((64, es * 3), dtype=dtype, device=dev())
         E.gemm(A, A, torch.zeros((64, 64), dtype=dtype, device=dev()), 64, 64, es * 3, algo=algo)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_folded_layernorm(dtype):
+    """LayerNorm folded into the consuming GEMM (ln_mean/ln_rstd/ln_csum) == LN then Linear."""
+    pkg = load_pkg()
+    E = pkg.engine
+    M, C, Nn = 300, 96, 200
+    x = (rnd((M, C), torch.float32, 301) * 1.5 + 0.7).to(dtype).to(dev())
+    w = rnd((Nn, C), torch.float32, 302, 1.0 / math.sqrt(C))
+    b = rnd((Nn,), torch.float32, 303)
+    g = rnd((C,), torch.float32, 304) * 0.2 + 1
+    be = rnd((C,), torch.float32, 305) * 0.3
+    wp, bp, cs = E.pack_ln_folded(w, b, g, be, dtype, dev())
+    mean = torch.empty(M, device=dev())
+    rstd = torch.empty(M, device=dev())
+    E.row_stats(x, M, C, C, mean, rstd)
+    for algo in (0, 5, 12):
+        out = torch.full((M, Nn), float("nan"), dtype=dtype, device=dev())
+        E.gemm(x, wp, out, M, Nn, C, bias=bp, act=1, ln=(mean, rstd, cs), algo=algo)
+        torch.cuda.synchronize()
+        ref = oracle.gelu(oracle.layer_norm(x.cpu().double(), g.double(), be.double()) @ w.double().t() + b.double())
+        err = (out.cpu().double() - ref).abs().max().item()
+        assert err < EPS[dtype] * 8 * max(1.0, ref.abs().max().item()), (str(dtype), algo, err)
