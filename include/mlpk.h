@@ -22,6 +22,8 @@
  *                       runs after them (GELU, residual add, BatchNorm-eval affine, SGU gate):
  *                       mlp_mixer.py:16-27,6-13; g_mlp.py:17-22,32-39; res_mlp.py:52-57;
  *                       vip.py:65-90; s2_mlp_v2.py:60-69,76-85; as_mlp.py:8-24,55-95; conv_mixer.py:29-31
+ *   mlpk_token_mlp      both Conv1d(k=1) of the Mixer token-mixing FeedForward + GELU + residual in ONE kernel
+ *                       (mlp_mixer.py:16-27,34,37), hidden activations never leave the CU
  *   mlpk_patchify       the im2col half of nn.Conv2d(k=stride=patch): mlp_mixer.py:58-60,68-71;
  *                       conv_mixer.py:18; s2_mlp_v2.py:119; as_mlp.py:319,330; PatchMerging as_mlp.py:207-211
  *   mlpk_row_stats      statistics of nn.LayerNorm (mlp_mixer.py:10) and nn.GroupNorm(1,C) (as_mlp.py:343-344)
@@ -126,6 +128,20 @@ int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream);
 /* number of tile configurations (valid algo ids are 1..count) and dynamic LDS bytes of one */
 int mlpk_gemm_algo_count(void);
 int mlpk_gemm_algo_info(int algo, int* bm, int* bn, int* threads, int* lds_bytes);
+
+/* ---- fused token-mixing MLP (MLP-Mixer) ------------------------------------------------------
+ * x[b,s,c] += sum_t W2[s,t] * gelu(sum_s' W1[t,s'] * xt[b*C + c, s'] + b1[t]) + b2[s]      (mlp_mixer.py:16-27,34,37)
+ * with the hidden kept on chip (never written to HBM).  16-bit dtypes only.
+ *   xt : (M = B*C, ldxt) token-transposed LayerNorm output (mlpk_norm_apply out_tt), ldxt = K of the first
+ *        product: a multiple of 32, <= 224, columns >= S zero;
+ *   w1 : (nchunks*CH, ldw1 = 256) rows >= 4S and columns >= S zero, CH = mlpk_token_mlp_chunk() = 32;
+ *   b1 : (nchunks*CH) zero-padded;  nchunks*CH <= 1024;
+ *   w2 : (S, ldw2), ldw2 >= nchunks*CH, columns >= 4S zero;  b2: (S);  S <= 208;
+ *   x  : (B*S, ldx) residual stream updated in place, t_rows = C channels per image (M % t_rows == 0).
+ */
+int mlpk_token_mlp_chunk(void);
+int mlpk_token_mlp(int dtype, const void* xt, int ldxt, int M, int S, const void* w1, int ldw1, const float* b1,
+                   const void* w2, int ldw2, const float* b2, int nchunks, void* x, int ldx, int t_rows, void* stream);
 
 /* ---- patch gather (im2col of a kernel==stride convolution) -----------------------------
  * out[(b*Hp + hp)*Wp + wp][k], row stride ldo (>= K, pad columns [K, ldo) are zero-filled).

@@ -122,6 +122,32 @@ def gemm(A, B, C, M, Nn, K, *, lda=None, ldb=None, ldc=None, bias=None, act=N.AC
         TIMER.events.setdefault(tag, []).append((ev0, ev1, 2.0 * M * Nn * K))
 
 
+def token_mlp(xt, ldxt, M, S, w1, b1, w2, b2, nchunks, x, ldx, t_rows):
+    N.check(N.lib().mlpk_token_mlp(dtype_code(xt.dtype), ptr(xt), ldxt, M, S, ptr(w1), w1.stride(0), ptr(b1), ptr(w2),
+                                   w2.stride(0), ptr(b2), nchunks, ptr(x), ldx, t_rows, stream()), "mlpk_token_mlp")
+
+
+def token_mlp_supported(dtype, S, sp, hidden=0):
+    return dtype in (torch.float16, torch.bfloat16) and S <= 208 and sp <= 224 and sp % 32 == 0 and hidden <= 1024
+
+
+def pack_token_mlp(w1, b1, w2, b2, dtype, device, sp):
+    """Weights of the fused token-mixing kernel: W1 rows / b1 / W2 columns zero-padded to whole hidden groups
+    of mlpk_token_mlp_chunk() = 32, W1's K axis zero-padded to 256 (8 LDS planes per group)."""
+    ch = N.lib().mlpk_token_mlp_chunk()
+    w1 = w1.detach().reshape(w1.shape[0], -1)
+    w2 = w2.detach().reshape(w2.shape[0], -1)
+    T, S = w1.shape
+    nch = (T + ch - 1) // ch
+    w1p = torch.zeros((nch * ch, 256), dtype=dtype, device=device)
+    w1p[:T, :S] = w1.to(device=device, dtype=dtype)
+    b1p = torch.zeros((nch * ch,), dtype=torch.float32, device=device)
+    b1p[:T] = b1.detach().to(device=device, dtype=torch.float32)
+    w2p = torch.zeros((S, nch * ch), dtype=dtype, device=device)
+    w2p[:, :T] = w2.to(device=device, dtype=dtype)
+    return w1p, b1p, w2p, f32(b2, device), nch
+
+
 def patchify(src, out, B, Cin, H, W, ph, pw, pad, ldo, layout=N.LAYOUT_NCHW, px_stride=0, order=0):
     N.check(N.lib().mlpk_patchify(dtype_code(src.dtype), dtype_code(out.dtype), layout, ptr(src), ptr(out), B, Cin, H, W,
                                   ph, pw, pad, px_stride, ldo, order, stream()), "mlpk_patchify")

@@ -14,6 +14,7 @@ Mapping to kernels:
   * channel fc1/fc2: GEMM with bias+GELU / bias+residual epilogues;
   * head: LN folded into the token mean (mlpk_pool_mean) then one small GEMM.
 """
+import os
 from functools import partial
 
 import torch
@@ -55,6 +56,7 @@ class MLPMixer(E.EngineModule):
                 PreNormResidual(d_model, FeedForward(d_model, d_model * expansion_factor, dropout, chan_last)))
             for _ in range(depth)])
         self._dims = (num_patches, d_model, depth, expansion_factor)
+        self.__dict__["fused_token_mlp"] = os.environ.get("MLPK_NO_FUSED_TOKEN", "0") != "1"
 
     # ---- weight packing: compute-dtype matrices (K zero-padded to 16 B), fp32 vectors ----
     def _pack_blocks(self, pk, dtype, device):
@@ -66,6 +68,10 @@ class MLPMixer(E.EngineModule):
             pk[p + "tok.fc1.b"] = E.f32(tok.fn.net[0].bias, device)
             pk[p + "tok.fc2.w"] = E.pack_matrix(tok.fn.net[3].weight, dtype, device, kpad=32)     # (S, 4S_pad)
             pk[p + "tok.fc2.b"] = E.f32(tok.fn.net[3].bias, device)
+            S = tok.fn.net[0].weight.shape[1]
+            if self.fused_token_mlp and E.token_mlp_supported(dtype, S, E.round_up(S, 32), tok.fn.net[0].weight.shape[0]):
+                pk[p + "tok.fused"] = E.pack_token_mlp(tok.fn.net[0].weight, tok.fn.net[0].bias, tok.fn.net[3].weight,
+                                                       tok.fn.net[3].bias, dtype, device, E.round_up(S, 32))
             pack_channel_mlp(pk, p + "ch.", ch.norm, ch.fn.net[0], ch.fn.net[3], dtype, device)
 
     def _pack(self, dtype, device):
@@ -86,6 +92,13 @@ class MLPMixer(E.EngineModule):
             xt = ws.get("tok.xt", (B * C, sp))                 # LN(x) transposed per image, zero K-padding
             E.norm_apply(x, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "tok.ln.g"], beta=pk[p + "tok.ln.b"],
                          out_tt=xt, S=S, ld_tt=sp)
+            fused = pk.get(p + "tok.fused")
+            if fused is not None:
+                # both token-mixing products + GELU + residual in one kernel; the hidden stays in LDS
+                w1f, b1f, w2f, b2f, nch = fused
+                E.token_mlp(xt, sp, B * C, S, w1f, b1f, w2f, b2f, nch, x, C, C)
+                channel_mlp(ws, x, rows, C, pk, p + "ch.", C * ef)
+                continue
             ht = ws.get("tok.h", (B * C, thp))
             E.gemm(xt, pk[p + "tok.fc1.w"], ht, B * C, th, sp, bias=pk[p + "tok.fc1.b"], act=N.ACT_GELU, tag="token_fc1")
             E.gemm(ht, pk[p + "tok.fc2.w"], x, B * C, S, thp, ldc=C, bias=pk[p + "tok.fc2.b"], R=x, ldr=C,

@@ -414,3 +414,33 @@ def test_gemm_folded_layernorm(dtype):
         ref = oracle.gelu(oracle.layer_norm(x.cpu().double(), g.double(), be.double()) @ w.double().t() + b.double())
         err = (out.cpu().double() - ref).abs().max().item()
         assert err < EPS[dtype] * 8 * max(1.0, ref.abs().max().item()), (str(dtype), algo, err)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_fused_token_mlp(dtype):
+    """mlpk_token_mlp == the two token-mixing GEMMs + GELU + residual (mlp_mixer.py:16-27 with Conv1d k=1),
+    incl. ragged tokens (S not a multiple of 16/32), several hidden chunks, rows spanning several images."""
+    pkg = load_pkg()
+    E = pkg.engine
+    for ci, (B_, C, S, T) in enumerate([(2, 32, 16, 64), (3, 40, 49, 196), (2, 128, 196, 784), (5, 8, 20, 40), (1, 32, 32, 32), (2, 64, 208, 1024)]):
+        sp = E.round_up(S, 32)
+        xn = rnd((B_, S, C), dtype, 400 + ci)                                 # LN output (token-major)
+        x = rnd((B_ * S, C), dtype, 410 + ci).to(dev())                       # residual stream
+        w1 = rnd((T, S), torch.float32, 420 + ci, 1.0 / math.sqrt(S))
+        b1 = rnd((T,), torch.float32, 430 + ci)
+        w2 = rnd((S, T), torch.float32, 440 + ci, 1.0 / math.sqrt(T))
+        b2 = rnd((S,), torch.float32, 450 + ci)
+        xt = torch.zeros((B_ * C, sp), dtype=dtype, device=dev())
+        xt[:, :S] = xn.permute(0, 2, 1).reshape(B_ * C, S).to(dev())
+        w1p, b1p, w2p, b2p, nch = E.pack_token_mlp(w1, b1, w2, b2, dtype, dev(), sp)
+        x0 = x.clone()
+        E.token_mlp(xt, sp, B_ * C, S, w1p, b1p, w2p, b2p, nch, x, C, C)
+        torch.cuda.synchronize()
+        w1r, w2r = w1.to(dtype).double(), w2.to(dtype).double()
+        h = oracle.gelu(torch.einsum("ts,bsc->btc", w1r, xn.double()) + b1.double().view(1, -1, 1))
+        h = h.to(dtype).double()                                              # the kernel rounds H to the storage dtype
+        ref = x0.cpu().double().reshape(B_, S, C) + torch.einsum("st,btc->bsc", w2r, h) + b2.double().view(1, -1, 1)
+        got = x.cpu().double().reshape(B_, S, C)
+        assert torch.isfinite(got).all()
+        err = (got - ref).abs().max().item()
+        assert err < EPS[dtype] * 6 * max(1.0, ref.abs().max().item()), (str(dtype), ci, err)

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Tuning aid: time the fused token-MLP kernel at Mixer-B/16 bs=256 (and the unfused pair for comparison)."""
+import importlib, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("jittor-mlp_amd")
+E, N = pkg.engine, pkg._native
+B_, C, S, T = 256, 768, 196, 784
+dt = torch.bfloat16
+sp = 224
+xt = torch.zeros((B_ * C, sp), dtype=dt, device="cuda"); xt[:, :S] = torch.randn((B_ * C, S), device="cuda").to(dt)
+x = torch.randn((B_ * S, C), device="cuda").to(dt)
+w1p, b1p, w2p, b2p, nch = E.pack_token_mlp(torch.randn(T, S) / 14, torch.randn(T), torch.randn(S, T) / 28, torch.randn(S), dt, "cuda", sp)
+for it in range(3):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        E.token_mlp(xt, sp, B_ * C, S, w1p, b1p, w2p, b2p, nch, x, C, C)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    print("fused token mlp: %.4f ms  (%.1f TFLOP/s algorithmic)" % (ms, 2 * 2.0 * B_ * C * S * T / ms / 1e9))
+import ctypes
+import numpy as np
+fn = ctypes.CDLL(N.LIB_PATH).mlpk_token_mlp_debug
+fn.argtypes = [ctypes.c_void_p]
+nwg = B_ * C // 128
+dbg = torch.zeros((nwg, 256), dtype=torch.int64, device="cuda")
+fn(dbg.data_ptr())
+E.token_mlp(xt, sp, B_ * C, S, w1p, b1p, w2p, b2p, nch, x, C, C)
+torch.cuda.synchronize()
+fn(None)
+t = dbg.cpu().numpy()
+for wg in (0, 700, nwg - 1):
+    r = t[wg]
+    out = []
+    for it in range(2, 12):
+        a = r[5 * it:5 * it + 5]
+        nxt = r[5 * (it + 1)]
+        out.append("[vm %d bar %d fc1 %d gelu %d fc2 %d]" % (a[1] - a[0], a[2] - a[1], a[3] - a[2], a[4] - a[3], nxt - a[4]))
+    print("wg", wg, "total", r[5 * 26] - r[0], " ".join(out))
