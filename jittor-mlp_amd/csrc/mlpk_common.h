@@ -62,6 +62,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 }  // namespace mlpk
 
+int mlpk_dwconv_direct(int dtype, const void* x, void* out, int B, int H, int W, int C, int k, const float* w,
+                       const float* bias, const float* bn_scale, const float* bn_shift, void* stream);
+
 #define MLPK_LAUNCH_CHECK()                            \
     do {                                               \
         hipError_t e__ = hipGetLastError();            \

@@ -1,0 +1,171 @@
+// ConvMixer depthwise half, LDS-tiled:  out = x + BN(gelu(dwconv_kxk_same(x) + b))   (conv_mixer.py:5-11, 24-28)
+// on channel-last activations.  81 taps per output at k = 9 make this VALU-bound, not HBM-bound, once every
+// input element is fetched once -- so the design is about feeding the vector ALUs:
+//   * workgroup = one image x CT channels x the whole H x W plane (+ halo), staged in LDS TRANSPOSED to
+//     [channel][row][col] so that a lane can read 16 consecutive columns of its channel with two 16-byte reads;
+//     the channel plane pitch is an odd number of 16-byte slots -> conflict-free for lanes on different channels;
+//   * thread = one channel (its k*k taps stay in registers for the whole tile) and strips of 8 outputs along x:
+//     per tap row 2 LDS reads feed 8*k FMAs (sliding window in registers);
+//   * the residual comes from the same LDS tile; bias, exact GELU, BatchNorm(eval) scale/shift fused in the store.
+// Global traffic = x read once + out written once (the stencil re-reads stay in LDS).
+#include "mlpk_common.h"
+
+namespace mlpk {
+
+template <typename T> struct DwCfg;
+template <> struct DwCfg<float> { static constexpr int CT = 16; };
+template <> struct DwCfg<f16_t> { static constexpr int CT = 32; };
+template <> struct DwCfg<bf16_t> { static constexpr int CT = 32; };
+
+template <typename T, int KS>
+__global__ void __launch_bounds__(256) dwconv_lds_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int H, int W,
+                                                         int C, const float* __restrict__ w, const float* __restrict__ bias,
+                                                         const float* __restrict__ bns, const float* __restrict__ bnh,
+                                                         int pitch, int plane) {
+    constexpr int CT = DwCfg<T>::CT;
+    constexpr int P = (KS - 1) / 2;
+    constexpr int STRIP = 8;
+    constexpr int EPV = 16 / (int)sizeof(T);           // elements per 16-byte vector
+    constexpr int WIN = STRIP + KS - 1;                // input window of a strip (<= 16 elements)
+    constexpr int NV = (WIN + EPV - 1) / EPV;          // 16-byte reads per window row
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* tile = reinterpret_cast<T*>(smem_raw);          // [CT][H + 2P][pitch], plane stride `plane` elements
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const int c0 = blockIdx.y * CT;
+    const int HP = H + 2 * P;
+
+    // ---- zero the tile (halo + padding), then scatter the image in: 16-byte global reads along channels ----
+    {
+        const int nvec = CT * plane / EPV;
+        u32x4* t4 = reinterpret_cast<u32x4*>(tile);
+        for (int i = tid; i < nvec; i += 256) t4[i] = u32x4{0u, 0u, 0u, 0u};
+    }
+    __syncthreads();
+    {
+        constexpr int CV = CT / EPV;                    // channel vectors per pixel
+        const int total = H * W * CV;
+        for (int i = tid; i < total; i += 256) {
+            const int cv = i % CV;
+            const int px = i / CV;
+            const int xx = px % W, yy = px / W;
+            const int c = c0 + cv * EPV;
+            if (c < C) {                                // C % EPV == 0 is checked by the launcher
+                const u32x4 raw = *reinterpret_cast<const u32x4*>(x + (((size_t)b * H + yy) * W + xx) * C + c);
+                T e[EPV];
+                __builtin_memcpy(e, &raw, 16);
+                T* dst = tile + (cv * EPV) * plane + (yy + P) * pitch + (xx + P);
+#pragma unroll
+                for (int k = 0; k < EPV; ++k) dst[k * plane] = e[k];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- compute: thread -> channel cl = tid % CT, tasks (row, strip) = tid / CT + k * (256 / CT) ----
+    const int cl = tid % CT;
+    const int c = c0 + cl;
+    if (c >= C) return;
+    float wt[KS * KS];
+#pragma unroll
+    for (int t = 0; t < KS * KS; ++t) wt[t] = w[(size_t)t * C + c];
+    const float bs = bias ? bias[c] : 0.f;
+    const float sc = bns ? bns[c] : 1.f, sh = bnh ? bnh[c] : 0.f;
+    const int strips = (W + STRIP - 1) / STRIP;
+    const int ntask = H * strips;
+    const T* cplane = tile + cl * plane;
+    for (int task = tid / CT; task < ntask; task += 256 / CT) {
+        const int st = task % strips, y = task / strips;
+        const int x0 = st * STRIP;
+        float acc[STRIP];
+#pragma unroll
+        for (int o = 0; o < STRIP; ++o) acc[o] = bs;
+        float centre[STRIP];
+#pragma unroll
+        for (int dy = 0; dy < KS; ++dy) {
+            // window row: padded columns x0 .. x0 + WIN - 1 of padded row y + dy (16-byte aligned: pitch % EPV == 0)
+            const T* row = cplane + (y + dy) * pitch + x0;
+            float win[NV * EPV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const u32x4 raw = *reinterpret_cast<const u32x4*>(row + v * EPV);
+                T e[EPV];
+                __builtin_memcpy(e, &raw, 16);
+#pragma unroll
+                for (int k = 0; k < EPV; ++k) win[v * EPV + k] = to_f32(e[k]);
+            }
+            if (dy == P) {
+#pragma unroll
+                for (int o = 0; o < STRIP; ++o) centre[o] = win[o + P];
+            }
+#pragma unroll
+            for (int dx = 0; dx < KS; ++dx)
+#pragma unroll
+                for (int o = 0; o < STRIP; ++o) acc[o] = __builtin_fmaf(wt[dy * KS + dx], win[o + dx], acc[o]);
+        }
+#pragma unroll
+        for (int o = 0; o < STRIP; ++o) {
+            const int xx = x0 + o;
+            if (xx < W) out[(((size_t)b * H + y) * W + xx) * C + c] = from_f32<T>(centre[o] + gelu_f(acc[o]) * sc + sh);
+        }
+    }
+}
+
+template <typename T>
+static int dwconv_lds_launch(int k, const void* x, void* out, int B, int H, int W, int C, const float* w, const float* bias,
+                             const float* bns, const float* bnh, hipStream_t s) {
+    constexpr int CT = DwCfg<T>::CT;
+    constexpr int EPV = 16 / (int)sizeof(T);
+    const int P = (k - 1) / 2;
+    // row pitch: W + 2P columns, plus room for the last strip's 16-element window, rounded to whole vectors
+    const int strips = (W + 7) / 8;
+    int pitch = (strips - 1) * 8 + ((8 + k - 1 + EPV - 1) / EPV) * EPV;
+    if (pitch < W + 2 * P) pitch = W + 2 * P;
+    pitch = (pitch + EPV - 1) / EPV * EPV;
+    int plane = (H + 2 * P) * pitch;                    // elements; make it an ODD number of 16-byte slots
+    plane = (plane + EPV - 1) / EPV * EPV;
+    if (((plane / EPV) & 1) == 0) plane += EPV;
+    const size_t lds = (size_t)CT * plane * sizeof(T);
+    if (lds > 160 * 1024) return 1;                     // caller falls back
+    const dim3 grid((unsigned)B, (unsigned)((C + CT - 1) / CT));
+#define DW_CASE(KS)                                                                                                    \
+    case KS: {                                                                                                         \
+        auto kern = dwconv_lds_kernel<T, KS>;                                                                          \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return (int)e;                                                                            \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)x, (T*)out, B, H, W, C, w, bias, bns, bnh, pitch, plane); \
+        break;                                                                                                         \
+    }
+    switch (k) {
+        DW_CASE(3) DW_CASE(5) DW_CASE(7) DW_CASE(9)
+        default: return MLPK_ESHAPE;
+    }
+#undef DW_CASE
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace mlpk
+
+using namespace mlpk;
+
+extern "C" int mlpk_dwconv_nhwc(int dtype, const void* x, void* out, int B, int H, int W, int C, int k, const float* w,
+                                const float* bias, const float* bn_scale, const float* bn_shift, void* stream) {
+    if (!x || !out || !w) return MLPK_ENULL;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return MLPK_ESHAPE;
+    if (x == out) return MLPK_ESHAPE;                    // a stencil cannot run in place
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int es = dtype == MLPK_F32 ? 4 : 2;
+    const bool fast_ok = (C % (16 / es) == 0) && (((uintptr_t)x & 15) == 0) && B <= 0x7fffffff;
+    if (fast_ok) {
+        int rc;
+        switch (dtype) {
+            case MLPK_F32: rc = dwconv_lds_launch<float>(k, x, out, B, H, W, C, w, bias, bn_scale, bn_shift, s); break;
+            case MLPK_F16: rc = dwconv_lds_launch<f16_t>(k, x, out, B, H, W, C, w, bias, bn_scale, bn_shift, s); break;
+            case MLPK_BF16: rc = dwconv_lds_launch<bf16_t>(k, x, out, B, H, W, C, w, bias, bn_scale, bn_shift, s); break;
+            default: return MLPK_EDTYPE;
+        }
+        if (rc != 1) return rc;                          // 1 = tile does not fit the LDS: use the generic kernel
+    }
+    return mlpk_dwconv_direct(dtype, x, out, B, H, W, C, k, w, bias, bn_scale, bn_shift, stream);
+}

@@ -349,8 +349,9 @@ static int dwconv_launch(int k, const void* x, void* out, int B, int H, int W, i
     return 0;
 }
 
-extern "C" int mlpk_dwconv_nhwc(int dtype, const void* x, void* out, int B, int H, int W, int C, int k, const float* w,
-                                const float* bias, const float* bn_scale, const float* bn_shift, void* stream) {
+// generic fallback (any H, W, C); the LDS-tiled kernel in mlpk_dwconv.hip is the fast path
+int mlpk_dwconv_direct(int dtype, const void* x, void* out, int B, int H, int W, int C, int k, const float* w,
+                       const float* bias, const float* bn_scale, const float* bn_shift, void* stream) {
     if (!x || !out || !w) return MLPK_ENULL;
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return MLPK_ESHAPE;
     if ((int64_t)B * H * ((W + 7) / 8) / 4 + 1 > 0x7fffffffLL) return MLPK_ESHAPE;
