@@ -35,28 +35,30 @@ template <typename T> __device__ __forceinline__ void store8(T* p, const float (
 }
 
 // ================================ row statistics ================================
-// TPR threads per row (64 = one wave per row, 256 = one workgroup per row).  Two passes over the
+// TPR threads per row (64 = one wave per row, 1024 = one 16-wave workgroup per row for GroupNorm-sized rows).  Two passes over the
 // row (the second one is served by L1/L2): mean, then centred sum of squares -- no E[x^2]-mu^2
 // cancellation, which matters for the fp32 1e-5 parity gate.
 template <typename T, int TPR>
-__global__ void __launch_bounds__(256) row_stats_kernel(const T* __restrict__ x, int64_t rows, int64_t len,
+__global__ void __launch_bounds__(TPR == 64 ? 256 : TPR) row_stats_kernel(const T* __restrict__ x, int64_t rows, int64_t len,
                                                         int64_t ldx, float eps, float* __restrict__ mean,
                                                         float* __restrict__ rstd, int vec) {
-    __shared__ float red[8];
+    __shared__ float red[16];
     const int tid = threadIdx.x;
     const int sub = TPR == 64 ? (tid >> 6) : 0;
     const int t = TPR == 64 ? (tid & 63) : tid;
-    const int64_t row = (int64_t)blockIdx.x * (256 / TPR) + sub;
+    const int64_t row = (int64_t)blockIdx.x * (TPR == 64 ? 4 : 1) + sub;
     if (TPR == 64 && row >= rows) return;   // whole wave exits together
     const T* xr = x + row * ldx;
 
     auto block_sum = [&](float v) -> float {
         v = wave_sum(v);
-        if constexpr (TPR == 256) {
+        if constexpr (TPR != 64) {
             __syncthreads();
             if ((tid & 63) == 0) red[tid >> 6] = v;
             __syncthreads();
-            v = red[0] + red[1] + red[2] + red[3];
+            v = 0.f;
+#pragma unroll
+            for (int i = 0; i < TPR / 64; ++i) v += red[i];
         }
         return v;
     };
@@ -217,6 +219,33 @@ __global__ void __launch_bounds__(256) vip_permute_kernel(const VipArgs p) {
     const int G = p.C / p.seg;
     T* out = reinterpret_cast<T*>(p.out) + ((int64_t)img * O + o) * G * p.ld_p;
     const int total = G * p.ld_p;
+    if ((p.ld_p & 7) == 0 && ((uintptr_t)out & 15) == 0) {
+        // 8 consecutive output elements per thread: one division pair per vector, then the (l, j) cursor is
+        // advanced incrementally; LDS is read element-wise (cheap), global memory is written 16 bytes per lane
+        for (int v8 = tid; v8 < total / 8; v8 += 256) {
+            const int idx = v8 * 8;
+            const int g = idx / p.ld_p;
+            int col = idx - g * p.ld_p;
+            int l = col / p.seg;
+            int j = col - l * p.seg;
+            const T* src = slab + g * p.seg;
+            T e[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                e[k] = l < L ? src[l * p.C + j] : from_f32<T>(0.f);
+                if (++j == p.seg) { j = 0; ++l; }
+            }
+            if constexpr (sizeof(T) == 2) {
+                u32x4 t;
+                __builtin_memcpy(&t, e, 16);
+                *reinterpret_cast<u32x4*>(out + idx) = t;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) out[idx + k] = e[k];
+            }
+        }
+        return;
+    }
     for (int idx = tid; idx < total; idx += 256) {
         const int g = idx / p.ld_p;
         const int col = idx - g * p.ld_p;
@@ -244,12 +273,43 @@ __global__ void __launch_bounds__(256) vip_unpermute_kernel(const T* __restrict_
     const int G = C / seg;
     const int rowlen = L * seg;
     const T* zin = z + ((int64_t)img * O + o) * G * ldz;
-    for (int idx = tid; idx < G * rowlen; idx += 256) {
-        const int g = idx / rowlen;
-        const int col = idx - g * rowlen;
-        slab[idx] = zin[(int64_t)g * ldz + col];
+    if ((rowlen & 7) == 0 && (ldz & 7) == 0 && sizeof(T) == 2 && ((uintptr_t)zin & 15) == 0) {
+        const int rv = rowlen / 8;
+        for (int v8 = tid; v8 < G * rv; v8 += 256) {
+            const int g = v8 / rv;
+            const int col = (v8 - g * rv) * 8;
+            *reinterpret_cast<u32x4*>(slab + g * rowlen + col) = *reinterpret_cast<const u32x4*>(zin + (int64_t)g * ldz + col);
+        }
+    } else {
+        for (int idx = tid; idx < G * rowlen; idx += 256) {
+            const int g = idx / rowlen;
+            const int col = idx - g * rowlen;
+            slab[idx] = zin[(int64_t)g * ldz + col];
+        }
     }
     __syncthreads();
+    if ((C & 7) == 0 && sizeof(T) == 2 && ((uintptr_t)out & 15) == 0) {
+        // 8 consecutive channels per thread -> one 16-byte store; (g, q) cursor advanced incrementally
+        const int cv = C / 8;
+        for (int v8 = tid; v8 < L * cv; v8 += 256) {
+            const int l = v8 / cv;
+            const int c = (v8 - l * cv) * 8;
+            int g = c / seg;
+            int q = c - g * seg;
+            T e[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                e[k] = slab[g * rowlen + l * seg + q];
+                if (++q == seg) { q = 0; ++g; }
+            }
+            const int h = which == 0 ? l : o;
+            const int w = which == 0 ? o : l;
+            u32x4 t;
+            __builtin_memcpy(&t, e, 16);
+            *reinterpret_cast<u32x4*>(out + (((int64_t)img * H + h) * W + w) * C + c) = t;
+        }
+        return;
+    }
     for (int idx = tid; idx < L * C; idx += 256) {
         const int l = idx / C;
         const int c = idx - l * C;
@@ -337,7 +397,7 @@ extern "C" int mlpk_row_stats(int dtype, const void* x, int64_t rows, int64_t le
         DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((row_stats_kernel<T, 64>), dim3(grid), dim3(256), 0, s,
                                                  (const T*)x, rows, len, ldx, eps, mean, rstd, vec));
     } else {
-        DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((row_stats_kernel<T, 256>), dim3((unsigned)rows), dim3(256), 0, s,
+        DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((row_stats_kernel<T, 1024>), dim3((unsigned)rows), dim3(1024), 0, s,
                                                  (const T*)x, rows, len, ldx, eps, mean, rstd, vec));
     }
     MLPK_LAUNCH_CHECK();

@@ -171,6 +171,109 @@ __global__ void __launch_bounds__(256) split_apply_kernel(const SplitArgs p, con
     }
 }
 
+
+// ---- 16-byte (8-channel) versions, used when every channel quarter is a multiple of 8 so that one
+// vector never straddles two shift groups: thread = 8 consecutive channels of one pixel ----
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&v)[8]) {
+    const u32x4 t = *reinterpret_cast<const u32x4*>(p);
+    T e[8];
+    __builtin_memcpy(e, &t, 16);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = to_f32(e[i]);
+}
+template <typename T> __device__ __forceinline__ void st8(T* p, const float (&v)[8]) {
+    T e[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e[i] = from_f32<T>(v[i]);
+    u32x4 t;
+    __builtin_memcpy(&t, e, 16);
+    *reinterpret_cast<u32x4*>(p) = t;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) split_sum_vec_kernel(const SplitArgs p, float* __restrict__ a) {
+    __shared__ float red[32][64 + 1];
+    const int tid = threadIdx.x;
+    const int cl = (tid & 7) * 8;
+    const int ph = tid >> 3;                       // 32 pixel phases
+    const int c = blockIdx.y * 64 + cl;
+    const int b = blockIdx.x;
+    const T* x0 = reinterpret_cast<const T*>(p.x0);
+    const T* x1 = reinterpret_cast<const T*>(p.x1);
+    const T* x2 = reinterpret_cast<const T*>(p.x2);
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    if (c < p.C) {
+        const int npx = p.D1 * p.D2;
+        for (int px = ph; px < npx; px += 32) {
+            const int i1 = px / p.D2, i2 = px - i1 * p.D2;
+            int j1, j2;
+            float v[8];
+            s2_source(1, p.mode, c, p.C, i1, i2, p.D1, p.D2, j1, j2);
+            ld8<T>(x0 + (((int64_t)b * p.D1 + j1) * p.D2 + j2) * p.ld0 + c, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += v[e];
+            s2_source(2, p.mode, c, p.C, i1, i2, p.D1, p.D2, j1, j2);
+            ld8<T>(x1 + (((int64_t)b * p.D1 + j1) * p.D2 + j2) * p.ld1 + c, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += v[e];
+            ld8<T>(x2 + (((int64_t)b * p.D1 + i1) * p.D2 + i2) * p.ld2 + c, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[ph][cl + e] = s[e];
+    __syncthreads();
+    if (tid < 64) {
+        const int cc = blockIdx.y * 64 + tid;
+        if (cc < p.C) {
+            float t = 0.f;
+#pragma unroll 8
+            for (int i = 0; i < 32; ++i) t += red[i][tid];
+            a[(int64_t)b * p.C + cc] = t;
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) split_apply_vec_kernel(const SplitArgs p, const float* __restrict__ bar,
+                                                              T* __restrict__ out, int ldo) {
+    const T* x0 = reinterpret_cast<const T*>(p.x0);
+    const T* x1 = reinterpret_cast<const T*>(p.x1);
+    const T* x2 = reinterpret_cast<const T*>(p.x2);
+    const int cv = p.C / 8;
+    const int64_t total = (int64_t)p.B * p.D1 * p.D2 * cv;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c = (int)(idx % cv) * 8;
+        const int64_t px = idx / cv;
+        const int i2 = (int)(px % p.D2);
+        const int i1 = (int)((px / p.D2) % p.D1);
+        const int64_t b = px / ((int64_t)p.D1 * p.D2);
+        const float* w = bar + b * 3 * p.C + c;
+        float w0[8], w1[8], w2[8], v0[8], v1[8], v2[8], o[8];
+#pragma unroll
+        for (int e = 0; e < 8; e += 4) {
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(w + e);
+            const f32x4 t1 = *reinterpret_cast<const f32x4*>(w + p.C + e);
+            const f32x4 t2 = *reinterpret_cast<const f32x4*>(w + 2 * p.C + e);
+            w0[e] = t0.x; w0[e + 1] = t0.y; w0[e + 2] = t0.z; w0[e + 3] = t0.w;
+            w1[e] = t1.x; w1[e + 1] = t1.y; w1[e + 2] = t1.z; w1[e + 3] = t1.w;
+            w2[e] = t2.x; w2[e + 1] = t2.y; w2[e + 2] = t2.z; w2[e + 3] = t2.w;
+        }
+        int j1, j2;
+        s2_source(1, p.mode, c, p.C, i1, i2, p.D1, p.D2, j1, j2);
+        ld8<T>(x0 + ((b * p.D1 + j1) * p.D2 + j2) * p.ld0 + c, v0);
+        s2_source(2, p.mode, c, p.C, i1, i2, p.D1, p.D2, j1, j2);
+        ld8<T>(x1 + ((b * p.D1 + j1) * p.D2 + j2) * p.ld1 + c, v1);
+        ld8<T>(x2 + px * p.ld2 + c, v2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = w0[e] * v0[e] + w1[e] * v1[e] + w2[e] * v2[e];
+        st8<T>(out + px * ldo + c, o);
+    }
+}
+
 // ================================ ConvMixer depthwise half ================================
 // thread = (image, row y, strip of 8 outputs along x, channel c); the k*k taps of channel c and a
 // sliding (8 + k - 1)-wide input window live in registers, lanes run along c (coalesced).
@@ -272,6 +375,15 @@ extern "C" int mlpk_shift_nhwc(int dtype, const void* in, void* out, int N, int 
     return 0;
 }
 
+// 8-channel vectors are usable when no vector straddles two S2 shift groups (quarters of C) and all
+// three branch pointers / strides keep 16-byte alignment (16-bit dtypes; fp32 keeps the scalar kernels)
+static bool split_vec_ok(const void* x0, const void* x1, const void* x2, int ld0, int ld1, int ld2, int C, int mode) {
+    if (C % 8 || ld0 % 8 || ld1 % 8 || ld2 % 8) return false;
+    if (((uintptr_t)x0 | (uintptr_t)x1 | (uintptr_t)x2) & 15) return false;
+    if (mode != MLPK_SHIFT_NONE && C % 32) return false;
+    return true;
+}
+
 static int split_check(const void* x0, const void* x1, const void* x2, int ld0, int ld1, int ld2, int B, int H, int W,
                        int C, int mode) {
     if (!x0 || !x1 || !x2) return MLPK_ENULL;
@@ -287,7 +399,11 @@ extern "C" int mlpk_split_sum(int dtype, const void* x0, const void* x1, const v
     SplitArgs p{x0, x1, x2, ld0, ld1, ld2, B, H, W, C, shift_mode};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)B, (unsigned)((C + 63) / 64));
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((split_sum_kernel<T>), grid, dim3(256), 0, s, p, a));
+    if (dtype != MLPK_F32 && split_vec_ok(x0, x1, x2, ld0, ld1, ld2, C, shift_mode)) {
+        DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((split_sum_vec_kernel<T>), grid, dim3(256), 0, s, p, a));
+    } else {
+        DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((split_sum_kernel<T>), grid, dim3(256), 0, s, p, a));
+    }
     MLPK_LAUNCH_CHECK();
     return 0;
 }
@@ -310,8 +426,14 @@ extern "C" int mlpk_split_apply(int dtype, const void* x0, const void* x1, const
     SplitArgs p{x0, x1, x2, ld0, ld1, ld2, B, H, W, C, shift_mode};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int64_t total = (int64_t)B * H * W * C;
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((split_apply_kernel<T>), dim3(grid_for(total)), dim3(256), 0, s, p, bar,
-                                             (T*)out, ldo));
+    if (dtype != MLPK_F32 && split_vec_ok(x0, x1, x2, ld0, ld1, ld2, C, shift_mode) && ldo % 8 == 0 && ((uintptr_t)out & 15) == 0 &&
+        ((uintptr_t)bar & 15) == 0) {
+        DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((split_apply_vec_kernel<T>), dim3(grid_for(total / 8)), dim3(256), 0, s, p,
+                                                 bar, (T*)out, ldo));
+    } else {
+        DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((split_apply_kernel<T>), dim3(grid_for(total)), dim3(256), 0, s, p, bar,
+                                                 (T*)out, ldo));
+    }
     MLPK_LAUNCH_CHECK();
     return 0;
 }
