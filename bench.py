@@ -169,8 +169,15 @@ def main():
                 n_launch = sum(summ[t]["launches"] for t in dom)
                 peak = PEAK_BF16_TFLOPS if args.dtype != "fp32" else 157.3
                 ach = flops / secs / 1e12
-                line["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel (channel-MLP fc1+fc2)", "achieved": round(ach, 1),
-                                    "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                # HBM-side bytes per launch of this kernel from the PMC counters (FETCH_SIZE x2 gfx950 correction +
+                # WRITE_SIZE), measured offline on the same command: profiles/r01_pmc_bench_mixer_b16.txt
+                traffic = None
+                tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
+                if args.model == "mixer_b16" and args.batch == 256 and args.dtype == "bf16" and os.path.exists(tfile):
+                    with open(tfile) as f:
+                        traffic = json.load(f).get("channel_mlp_gemm_bytes_per_launch")
+                line["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_s3_kernel (channel-MLP fc1+fc2)", "achieved": round(ach, 1),
+                                    "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                                     "flops_per_launch": flops / n_launch, "avg_launch_ms": round(secs / n_launch * 1e3, 4),
                                     "launches_timed": n_launch}
             line["kernels"] = {t: {"avg_ms": round(v["avg_ms"], 4), "tflops": round(v["flops_per_launch"] / v["avg_ms"] / 1e9, 1),

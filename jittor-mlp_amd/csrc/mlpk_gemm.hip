@@ -38,6 +38,7 @@ struct GemmArgs {
     int rperiod, act, res_mode;
     int t_rows, t_tokens;
     int vec_c, vec_r;   // vector (4-element) store / residual-load allowed
+    int dbg_delay;      // de-phase sleep, units of 8128 cycles
     int dbg;            // tuning ablations (desc.reserved): 1 = no main loop, 2 = no stores, 4 = no epilogue
 };
 
@@ -56,6 +57,8 @@ __device__ __forceinline__ void glds_piece(const void* gsrc, unsigned lds_dst) {
                  : "v"(gsrc), "s"(lds_dst)
                  : "memory");
 }
+
+__device__ unsigned g_cu_ticket[2048];
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -608,6 +611,22 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) gemm_nt_s3_kernel(const GemmAr
     const int a_rd = (wm * TM + frow) * 64 + co;
     const int b_rd = BM * 64 + (wn * TN + frow) * 64 + co;
 
+    // ---- de-phase the two workgroups that share a CU (tuning flag dbg & 16) ----
+    // Both start together and would run main loop / epilogue in lockstep, leaving the matrix pipe idle
+    // during both epilogues.  The second arriver on a CU (per-CU ticket, first launch round only) sleeps
+    // for about one epilogue, so that from then on one workgroup's VALU/store phase overlaps the other's MFMAs.
+    if ((p.dbg & 16) && blockIdx.x < 512) {
+        if (tid == 0) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);     // HW_REG_HW_ID[15:0]
+            const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);    // HW_REG_XCC_ID[3:0]
+            const unsigned key = ((xcc & 7) << 8) | ((hw >> 8) & 0xff);                   // cu / sh / se bits
+            const unsigned ticket = atomicAdd(&g_cu_ticket[key], 1u);
+            if (ticket & 1) {
+                for (int i = 0; i < p.dbg_delay; ++i) __builtin_amdgcn_s_sleep(127);
+            }
+        }
+        __syncthreads();
+    }
     MLPK_STAMP(0);
     if (nk > 0) S3_STAGE(0);
     if (nk > 1) S3_STAGE(1);
@@ -803,7 +822,8 @@ extern "C" int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream) {
     a.rperiod = d->rperiod > 0 ? d->rperiod : 1;
     a.act = d->act; a.res_mode = d->res_mode;
     a.t_rows = d->t_rows; a.t_tokens = d->t_tokens;
-    a.dbg = d->reserved;
+    a.dbg = d->reserved & 0xff;
+    a.dbg_delay = (d->reserved >> 8) & 0xff;
     const int vb = 4 * es;   // bytes of a 4-element vector
     a.vec_c = (d->ldc % 4 == 0) && (((uintptr_t)d->C % vb) == 0);
     a.vec_r = d->R ? ((d->ldr % 4 == 0) && (((uintptr_t)d->R % vb) == 0)) : 0;

@@ -200,7 +200,8 @@ __global__ void __launch_bounds__(256, 1) token_mlp_kernel(const TokenMlpArgs p)
             for (int j = 0; j < 2; ++j) aw[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < TM_KMAX; ++kk) {
-            if (kk < 4) { TM_ISSUE_W1(t + 3, kk); }
+            // (no LDS-DMA issue in this region: the asm statements would fence the instruction scheduler and
+            //  expose every GELU dependency chain; all 8 pieces go out between the fc2 MFMAs below)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 aw[i][0] = Mma2<T>::run(bw[kk][0], xa[i][kk], aw[i][0]);
@@ -225,7 +226,8 @@ __global__ void __launch_bounds__(256, 1) token_mlp_kernel(const TokenMlpArgs p)
         // ---- (C) fc2(t-2): natural operands -> lane = token frow of block j, 4 consecutive rows 4*fg + r ----
 #pragma unroll
         for (int j = 0; j < TM_FN2; ++j) {
-            if ((j % 3) == 0 && j / 3 < 4) { TM_ISSUE_W2(t + 1, j / 3); }
+            if (j < 4) { TM_ISSUE_W1(t + 3, j); }
+            else if (j < 8) { TM_ISSUE_W2(t + 1, j - 4); }
 #pragma unroll
             for (int i = 0; i < 2; ++i) acc2[i][j] = Mma2<T>::run(af[i], bf2[j], acc2[i][j]);
         }
