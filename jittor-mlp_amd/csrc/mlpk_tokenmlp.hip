@@ -73,7 +73,10 @@ constexpr int TM_B1 = TM_HS + 4 * 2 * 2048;
 constexpr int TM_B1_FLOATS = 1024;                     // hidden (padded) <= 1024
 constexpr int TM_LDS = TM_B1 + TM_B1_FLOATS * 4;
 
-template <typename T>
+// ABL: tuning ablations, only 0 is instantiated (1 = identity instead of GELU, 2/3 = skip fc2/fc1 MFMAs, 4 = no LDS-DMA,
+// 5 = no LDS operand reads, 6 = 5 + no barrier).  Measured on MI355X (profiles/r01_token_mlp_ablation.txt): each removes
+// only 4-13 % -- no single phase dominates the 0.29 ms.
+template <typename T, int ABL>
 __global__ void __launch_bounds__(256, 1) token_mlp_kernel(const TokenMlpArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -167,9 +170,10 @@ __global__ void __launch_bounds__(256, 1) token_mlp_kernel(const TokenMlpArgs p)
         f32x4 aw[2][2];
         // pieces of the two previous iterations may still be in flight; older ones (W1(t), W2(t-2)) have landed
         TM_STAMP(5 * t);
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if constexpr (ABL == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         TM_STAMP(5 * t + 1);
-        __builtin_amdgcn_s_barrier();
+        if constexpr (ABL != 6) __builtin_amdgcn_s_barrier();
         TM_STAMP(5 * t + 2);
         const char* r1 = smem + TM_R1 + (t & 3) * TM_STAGE;
         const char* r2 = smem + TM_R2 + ((t - 2) & 3) * TM_STAGE;
@@ -178,13 +182,19 @@ __global__ void __launch_bounds__(256, 1) token_mlp_kernel(const TokenMlpArgs p)
         u32x4 bw[TM_KMAX][2], af[2], bf2[TM_FN2];
 #pragma unroll
         for (int kk = 0; kk < TM_KMAX; ++kk) {
-            bw[kk][0] = *reinterpret_cast<const u32x4*>(r1 + kk * 2048 + f_rd);
-            bw[kk][1] = *reinterpret_cast<const u32x4*>(r1 + kk * 2048 + f_rd + 1024);
+            if constexpr (ABL == 5 || ABL == 6) { bw[kk][0] = xa[0][kk]; bw[kk][1] = xa[1][kk]; }
+            else {
+                bw[kk][0] = *reinterpret_cast<const u32x4*>(r1 + kk * 2048 + f_rd);
+                bw[kk][1] = *reinterpret_cast<const u32x4*>(r1 + kk * 2048 + f_rd + 1024);
+            }
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const u32x4*>(hr + i * 1024 + f_rd);
 #pragma unroll
-        for (int j = 0; j < TM_FN2; ++j) bf2[j] = *reinterpret_cast<const u32x4*>(r2 + j * 1024 + f_rd);
+        for (int j = 0; j < TM_FN2; ++j) {
+            if constexpr (ABL == 5 || ABL == 6) bf2[j] = xa[j & 1][j % TM_KMAX];
+            else bf2[j] = *reinterpret_cast<const u32x4*>(r2 + j * 1024 + f_rd);
+        }
         if (t < 2) { af[0] = u32x4{0u, 0u, 0u, 0u}; af[1] = u32x4{0u, 0u, 0u, 0u}; }   // fc2(t-2) does not exist yet
         // bias of the group whose GELU runs now (t-1, clamped: the first / last iterations produce unused H)
         const int gb = t - 1 < 0 ? 0 : (t - 1 < G ? t - 1 : G - 1);
@@ -204,8 +214,12 @@ __global__ void __launch_bounds__(256, 1) token_mlp_kernel(const TokenMlpArgs p)
             //  expose every GELU dependency chain; all 8 pieces go out between the fc2 MFMAs below)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                aw[i][0] = Mma2<T>::run(bw[kk][0], xa[i][kk], aw[i][0]);
-                aw[i][1] = Mma2<T>::run(bw[kk][1], xa[i][kk], aw[i][1]);
+                if constexpr (ABL == 3) {
+                    if (kk == 0) { aw[i][0] = Mma2<T>::run(bw[kk][0], xa[i][kk], aw[i][0]); aw[i][1] = Mma2<T>::run(bw[kk][1], xa[i][kk], aw[i][1]); }
+                } else {
+                    aw[i][0] = Mma2<T>::run(bw[kk][0], xa[i][kk], aw[i][0]);
+                    aw[i][1] = Mma2<T>::run(bw[kk][1], xa[i][kk], aw[i][1]);
+                }
             }
             if (kk < 4) {
                 // block (i, j) = (kk >> 1, kk & 1) of gelu(t-1): bias, exact-erf GELU, round, store in A-operand order
@@ -213,10 +227,15 @@ __global__ void __launch_bounds__(256, 1) token_mlp_kernel(const TokenMlpArgs p)
                 const int row = i * 16 + frow;
                 const int lc = j * 2 + (fg >> 1);
                 T e[4];
-                e[0] = from_f32<T>(gelu_f(ar[i][j].x + bb[j].x));
-                e[1] = from_f32<T>(gelu_f(ar[i][j].y + bb[j].y));
-                e[2] = from_f32<T>(gelu_f(ar[i][j].z + bb[j].z));
-                e[3] = from_f32<T>(gelu_f(ar[i][j].w + bb[j].w));
+                if constexpr (ABL == 1) {
+                    e[0] = from_f32<T>(ar[i][j].x + bb[j].x); e[1] = from_f32<T>(ar[i][j].y + bb[j].y);
+                    e[2] = from_f32<T>(ar[i][j].z + bb[j].z); e[3] = from_f32<T>(ar[i][j].w + bb[j].w);
+                } else {
+                    e[0] = from_f32<T>(gelu_f(ar[i][j].x + bb[j].x));
+                    e[1] = from_f32<T>(gelu_f(ar[i][j].y + bb[j].y));
+                    e[2] = from_f32<T>(gelu_f(ar[i][j].z + bb[j].z));
+                    e[3] = from_f32<T>(gelu_f(ar[i][j].w + bb[j].w));
+                }
                 u32x2 pk;
                 __builtin_memcpy(&pk, e, 8);
                 *reinterpret_cast<u32x2*>(hw + row * 64 + ((lc ^ ((row & 8) >> 2)) << 4) + ((fg & 1) << 3)) = pk;
@@ -226,10 +245,16 @@ __global__ void __launch_bounds__(256, 1) token_mlp_kernel(const TokenMlpArgs p)
         // ---- (C) fc2(t-2): natural operands -> lane = token frow of block j, 4 consecutive rows 4*fg + r ----
 #pragma unroll
         for (int j = 0; j < TM_FN2; ++j) {
-            if (j < 4) { TM_ISSUE_W1(t + 3, j); }
-            else if (j < 8) { TM_ISSUE_W2(t + 1, j - 4); }
+            if constexpr (ABL != 4) {
+                if (j < 4) { TM_ISSUE_W1(t + 3, j); }
+                else if (j < 8) { TM_ISSUE_W2(t + 1, j - 4); }
+            }
+            if constexpr (ABL == 2) {
+                if (j == 0) acc2[0][j] = Mma2<T>::run(af[0], bf2[j], acc2[0][j]);
+            } else {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) acc2[i][j] = Mma2<T>::run(af[i], bf2[j], acc2[i][j]);
+                for (int i = 0; i < 2; ++i) acc2[i][j] = Mma2<T>::run(af[i], bf2[j], acc2[i][j]);
+            }
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -297,12 +322,12 @@ extern "C" int mlpk_token_mlp(int dtype, const void* xt, int ldxt, int M, int S,
     const unsigned grid = (unsigned)((M + TM_BM - 1) / TM_BM);
     hipError_t e;
     if (dtype == MLPK_BF16) {
-        auto k = token_mlp_kernel<bf16_t>;
+        auto k = token_mlp_kernel<bf16_t, 0>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, TM_LDS);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(k, dim3(grid), dim3(256), TM_LDS, s, a);
     } else {
-        auto k = token_mlp_kernel<f16_t>;
+        auto k = token_mlp_kernel<f16_t, 0>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, TM_LDS);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(k, dim3(grid), dim3(256), TM_LDS, s, a);
