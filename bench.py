@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--algo", default="", help="tag=algo[,tag=algo] GEMM tile overrides (tuning)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm; gloo only for "
+                    "exercising the multi-process path on a single-GPU box together with --share-device)")
+    ap.add_argument("--share-device", action="store_true", help="testing only: every rank uses cuda:0")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -97,12 +100,17 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
                              "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ..." % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     import __graft_entry__ as ge
     ge.build()
@@ -150,7 +158,7 @@ def main():
         global_batch = args.batch * world
         ms = elapsed / args.steps * 1e3
         line = {
-            "metric": "images/sec fwd, 224^2 bs=256/GPU, Mixer-B/16" if args.model == "mixer_b16" else "images/sec fwd " + args.model,
+            "metric": ("images/sec fwd, 224^2 bs=%d/GPU, Mixer-B/16" % args.batch) if args.model == "mixer_b16" else "images/sec fwd " + args.model,
             "value": round(global_batch * args.steps / elapsed, 1), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
