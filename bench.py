@@ -184,7 +184,7 @@ def main():
                 if args.model == "mixer_b16" and args.batch == 256 and args.dtype == "bf16" and os.path.exists(tfile):
                     with open(tfile) as f:
                         traffic = json.load(f).get("channel_mlp_gemm_bytes_per_launch")
-                line["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_s3_kernel (channel-MLP fc1+fc2)", "achieved": round(ach, 1),
+                line["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_p8_kernel (channel-MLP fc1+fc2)", "achieved": round(ach, 1),
                                     "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                                     "flops_per_launch": flops / n_launch, "avg_launch_ms": round(secs / n_launch * 1e3, 4),
                                     "launches_timed": n_launch}

@@ -8,6 +8,7 @@
 namespace mlpk {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -42,6 +43,53 @@ __device__ __forceinline__ float erf_fast(float x) {
 
 __device__ __forceinline__ float gelu_f(float x) {
     return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f));
+}
+
+// GELU for 16-bit outputs: erf by Abramowitz & Stegun 7.1.28, erf(z) = 1 - (1 + a1 z + .. + a6 z^6)^-16
+// (|err| <= 3e-7), with the 1/sqrt(2) folded into the coefficients: ONE quarter-rate instruction (rcp) per
+// element instead of two (rcp + exp), everything else pairs into v_pk_fma/mul_f32.  |GELU error| <= 7.1e-7
+// (measured over [-12, 12]), far below half an ulp of f16/bf16; float outputs keep gelu_f.
+//   gelu(x) = x/2 + |x|/2 * erf(|x|/sqrt 2) = (x/2 + |x|/2) - |x|/2 * D^-16
+__device__ __forceinline__ f32x2 gelu_pk(f32x2 x) {
+    const f32x2 ax = __builtin_elementwise_abs(x);
+    f32x2 d = __builtin_elementwise_fma(ax, f32x2{5.38297490e-6f, 5.38297490e-6f}, f32x2{4.88906371e-5f, 4.88906371e-5f});
+    d = __builtin_elementwise_fma(d, ax, f32x2{3.80035744e-5f, 3.80035744e-5f});
+    d = __builtin_elementwise_fma(d, ax, f32x2{3.27762635e-3f, 3.27762635e-3f});
+    d = __builtin_elementwise_fma(d, ax, f32x2{2.11410057e-2f, 2.11410057e-2f});
+    d = __builtin_elementwise_fma(d, ax, f32x2{4.98673469e-2f, 4.98673469e-2f});
+    d = __builtin_elementwise_fma(d, ax, f32x2{1.0f, 1.0f});
+    d = d * d;
+    d = d * d;
+    d = d * d;
+    d = d * d;
+    const f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    const f32x2 h = x * 0.5f;
+    const f32x2 ah = ax * 0.5f;
+    return __builtin_elementwise_fma(-ah, r, h + ah);
+}
+
+// scalar form of gelu_pk (the same operation sequence, hence bit-identical results)
+__device__ __forceinline__ float gelu16_f(float x) {
+    const float ax = __builtin_fabsf(x);
+    float d = __builtin_fmaf(ax, 5.38297490e-6f, 4.88906371e-5f);
+    d = __builtin_fmaf(d, ax, 3.80035744e-5f);
+    d = __builtin_fmaf(d, ax, 3.27762635e-3f);
+    d = __builtin_fmaf(d, ax, 2.11410057e-2f);
+    d = __builtin_fmaf(d, ax, 4.98673469e-2f);
+    d = __builtin_fmaf(d, ax, 1.0f);
+    d = d * d;
+    d = d * d;
+    d = d * d;
+    d = d * d;
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float h = x * 0.5f;
+    const float ah = ax * 0.5f;
+    return __builtin_fmaf(-ah, r, h + ah);
+}
+
+template <typename T> __device__ __forceinline__ float gelu_t(float x) {
+    if constexpr (sizeof(T) == 2) return gelu16_f(x);
+    else return gelu_f(x);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

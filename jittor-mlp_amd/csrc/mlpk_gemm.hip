@@ -61,19 +61,34 @@ __device__ __forceinline__ void glds_piece(const void* gsrc, unsigned lds_dst) {
 __device__ unsigned g_cu_ticket[2048];
 
 template <typename T> struct Mma;
+// `pinned` = the same instruction as volatile inline asm: it keeps its place between the barriers / waits /
+// LDS-DMA pieces of a hand-scheduled loop (hipcc otherwise floats the side-effect-free builtin across them).
 template <> struct Mma<bf16_t> {
+    static __device__ __forceinline__ void pinned(u32x4 a, u32x4 b, f32x4& c) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    }
     static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
                                                        __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
 };
 template <> struct Mma<f16_t> {
+    static __device__ __forceinline__ void pinned(u32x4 a, u32x4 b, f32x4& c) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    }
     static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a),
                                                       __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     }
 };
 template <> struct Mma<float> {
+    static __device__ __forceinline__ void pinned(u32x4 a, u32x4 b, f32x4& c) {
+        float af[4], bf[4];
+        __builtin_memcpy(af, &a, 16);
+        __builtin_memcpy(bf, &b, 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c) : "v"(af[e]), "v"(bf[e]));
+    }
     // one 16-byte chunk = 4 consecutive k per lane group; four K=4 steps, each taking element e of
     // every lane's chunk (any k <-> (lane group, e) bijection is valid as long as A and B agree).
     static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
@@ -129,18 +144,28 @@ template <typename T> __device__ __forceinline__ void store4(T* p, bool vec, con
 // Shared epilogue: consumes the fp32 accumulator blocks of one workgroup tile (see the kernels for
 // the accumulator orientation) and writes C.  `smem` is the workgroup's LDS, free for staging once
 // every wave has passed the barrier that ends the main loop.
-template <typename T, int BM, int BN, int WM, int WN, bool TRANS>
+// SPLIT = false: a wave owns one contiguous TM x TN sub-tile.  SPLIT = true (the "p8" kernel): it owns the
+// 2 x 2 quadrants (TM/2) x (TN/2) at (half_m * BM/2 + wm * TM/2, half_n * BN/2 + wn * TN/2).
+template <typename T, int BM, int BN, int WM, int WN, bool TRANS, bool SPLIT = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem,
-                                              const int m0, const int n0) {
+                                              const int m0, const int n0, const int tid) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 16, FN = TN / 16;
-    const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int frow = lane & 15;
     const int fg = lane >> 4;
+    // first row / column (inside the workgroup tile) of accumulator block row i / block column j
+    auto rbase = [&](int i) {
+        if constexpr (SPLIT) return (i / (FM / 2)) * (BM / 2) + wm * (TM / 2) + (i % (FM / 2)) * 16;
+        else return wm * TM + i * 16;
+    };
+    auto cbase = [&](int j) {
+        if constexpr (SPLIT) return (j / (FN / 2)) * (BN / 2) + wn * (TN / 2) + (j % (FN / 2)) * 16;
+        else return wn * TN + j * 16;
+    };
     if (p.dbg & 4) {
         float sacc = 0.f;
 #pragma unroll
@@ -184,7 +209,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
         }
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-            const int nl = wn * TN + j * 16 + 4 * fg;    // column of this lane's 4-vector inside the tile
+            const int nl = cbase(j) + 4 * fg;            // column of this lane's 4-vector inside the tile
             float bz[4], cs[4], ch[4], lc[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -197,7 +222,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
             }
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
-                const int rl = wm * TM + i * 16 + frow;
+                const int rl = rbase(i) + frow;
                 float rs = 1.f, lmu = 0.f, lrs = 1.f;
                 if (p.rscale || p.ln_mean) {
                     int m = m0 + rl;
@@ -210,7 +235,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float t = (v[r] - lmu * lc[r]) * lrs + bz[r];
-                    if (gelu) t = gelu_f(t);
+                    if (gelu) t = gelu_t<T>(t);
                     e[r] = from_f32<T>((t * cs[r] + ch[r]) * rs);
                 }
                 u32x2 pk;
@@ -279,13 +304,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
         // lane owns row m = .. + (lane & 15) and 4 consecutive columns n = .. + 4*(lane >> 4) + r
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-            const int m = m0 + wm * TM + i * 16 + frow;
+            const int m = m0 + rbase(i) + frow;
             if (m >= p.M) continue;
             const float rs = p.rscale ? p.rscale[m % p.rperiod] : 1.0f;
             const float lmu = p.ln_mean ? p.ln_mean[m] : 0.f, lrs = p.ln_mean ? p.ln_rstd[m] : 1.f;
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                const int nb = n0 + wn * TN + j * 16 + 4 * fg;
+                const int nb = n0 + cbase(j) + 4 * fg;
                 if (nb >= p.N) continue;
                 const bool full = nb + 3 < p.N;
                 float v[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
@@ -295,7 +320,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
                     float t = v[r];
                     if (p.ln_mean) t = (t - lmu * p.ln_csum[n]) * lrs;
                     if (p.bias) t += p.bias[n];
-                    if (gelu) t = gelu_f(t);
+                    if (gelu) t = gelu_t<T>(t);
                     if (p.cscale) t *= p.cscale[n];
                     if (p.cshift) t += p.cshift[n];
                     v[r] = t * rs;
@@ -326,14 +351,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
         // m = .. + 4*(lane >> 4) + r, i.e. 4 consecutive channels of one image (t_rows % 4 == 0).
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-            const int n = n0 + wn * TN + j * 16 + frow;
+            const int n = n0 + cbase(j) + frow;
             if (n >= p.N) continue;
             const float bn = p.bias ? p.bias[n] : 0.0f;
             const float cs = p.cscale ? p.cscale[n] : 1.0f;
             const float ch = p.cshift ? p.cshift[n] : 0.0f;
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
-                const int mb = m0 + wm * TM + i * 16 + 4 * fg;
+                const int mb = m0 + rbase(i) + 4 * fg;
                 if (mb >= p.M) continue;     // M % 4 == 0 for TOKEN_T, so the 4 rows are all valid
                 const int img = mb / p.t_rows;
                 const int c = mb - img * p.t_rows;
@@ -341,7 +366,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float t = v[r] + bn;
-                    if (gelu) t = gelu_f(t);
+                    if (gelu) t = gelu_t<T>(t);
                     t = t * cs + ch;
                     if (p.rscale) t *= p.rscale[(c + r) % p.rperiod];
                     v[r] = t;
@@ -527,7 +552,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_nt_kernel(const GemmArgs p) 
 #undef MLPK_GLOAD
 #undef MLPK_SSTORE
 
-    gemm_epilogue<T, BM, BN, WM, WN, TRANS>(p, acc, smem, m0, n0);
+    gemm_epilogue<T, BM, BN, WM, WN, TRANS>(p, acc, smem, m0, n0, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -669,7 +694,397 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) gemm_nt_s3_kernel(const GemmAr
     __syncthreads();
     MLPK_STAMP(61);
     if (p.dbg & 8) return;
-    gemm_epilogue<T, BM, BN, WM, WN, TRANS>(p, acc, smem, m0, n0);
+    gemm_epilogue<T, BM, BN, WM, WN, TRANS>(p, acc, smem, m0, n0, threadIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// "p8" pipeline: ONE 256 x 256 tile per CU, 8 wavefronts (2 per SIMD) in two groups of four that run half a
+// phase apart ("ping-pong"): while one group issues its 16 MFMAs of a phase, the other issues the LDS
+// fragment reads and the LDS-DMA pieces of its own phase, so every SIMD always has one wave on the matrix
+// pipe and one on the memory pipes.  K is consumed in 128-byte slabs (64 bf16/f16, 32 f32); LDS holds two
+// slab buffers of four 16-KiB HALF-TILES each (A rows 0-127, A rows 128-255, B rows 0-127, B rows 128-255;
+// 128-byte rows, 16-byte chunk c of row r at chunk c ^ (r & 7)).  A wave owns the 2 x 2 output quadrants
+// (64 x 32 each) at (hm * 128 + g * 64, hn * 128 + wn * 32): quadrant operands A0/A1 come from the two A
+// half-tiles and B0/B1 from the two B half-tiles, so each half-tile is dead early in the slab and can be
+// refilled for slab t + 2 while slab t is still being multiplied.  One slab = four phases:
+//
+//   phase  LDS reads (this wave)        LDS-DMA issued (2 x 1 KiB per wave)   MFMAs (16)
+//   0      B0 (4), A0 (8); lgkmcnt(8)   A-hi of slab t+1                      A0 x B0
+//   1      B1 (4)                       B-lo of slab t+2                      A0 x B1
+//   2      A1 (8)                       A-lo of slab t+2                      A1 x B1
+//   3      -                            B-hi of slab t+2; vmcnt(6)            A1 x B0
+//
+// Every phase is  [reads + DMA issue] s_barrier [MFMAs] s_barrier ; the second group executes one extra
+// barrier up front (and the first group one at the end), which is what puts the groups half a phase apart.
+// Hazards, with the groups staggered by one barrier (epochs between consecutive barriers: group 0 loads in
+// epoch 2p and multiplies in 2p+1, group 1 loads in 2p+1 and multiplies in 2p+2):
+//   * RAW: a half-tile is read in the phase AFTER the one whose counted vmcnt retired its DMAs (phase 3's
+//     vmcnt(6) leaves only the three half-tiles of slab t+2 issued in phases 1-3 in flight, so all of slab
+//     t+1 has landed, and is first read in the next phase 0);
+//   * WAR: a half-tile is refilled no sooner than two phases after its last ds_read -- or one phase after,
+//     when an lgkmcnt before that phase's first barrier retired the read (phase 0's lgkmcnt(8) retires the
+//     four B0 reads, which are issued first): B-lo last read in phase 0 / refilled in 1, A-lo 0 / 2,
+//     B-hi 1 / 3, A-hi 2 / next phase 0.
+// The last two slabs are peeled (MODE 1 / 2) because their DMA counts differ.
+template <typename T, int MODE>
+struct P8 {
+    // all LDS offsets are relative to the slab buffer `rb` (generic pointer into LDS)
+    template <bool TRANS>
+    static __device__ __forceinline__ void mma16(f32x4 (&acc)[8][4], const u32x4 (&a)[4][2], const u32x4 (&b)[2][2],
+                                                 const int i0, const int j0) {
+        asm volatile("s_setprio 1");
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (TRANS) Mma<T>::pinned(a[i][s], b[j][s], acc[i0 + i][j0 + j]);
+                    else Mma<T>::pinned(b[j][s], a[i][s], acc[i0 + i][j0 + j]);
+                }
+        asm volatile("s_setprio 0");
+    }
+};
+
+#define P8_BARRIER()                                  \
+    do {                                              \
+        asm volatile("s_barrier" ::: "memory");       \
+        __builtin_amdgcn_sched_barrier(0);            \
+    } while (0)
+
+__device__ __forceinline__ void glds_piece_s(unsigned voff, const void* sbase, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+
+// Fast epilogue of the p8 kernel for 2-byte row-major outputs on whole tiles: bias [+ folded LayerNorm]
+// [+ GELU] [+ per-column scale/shift] [+ residual], the tile staged through 64 KiB of LDS in two 128-row halves so that the other 64 KiB
+// slab buffer can already receive the next tile's first slab.  Column parameters are fetched as 16-byte
+// vectors up front, the element math is branch-free and written on float pairs (v_pk_* issue).
+template <typename T, bool GELU, bool LN, bool AFF>
+__device__ __forceinline__ void p8_store_tile(const GemmArgs& p, f32x4 (&acc)[8][4], char* stg, const int m0, const int n0,
+                                              const int tid, unsigned long long (&prof)[8]) {
+#ifdef MLPK_P8_PROF   // fine-grained epilogue stamps cost registers: tuning builds only (-DMLPK_P8_PROF)
+    const bool stamp = (p.dbg & 8) != 0;
+    unsigned long long tprev = stamp ? __builtin_readcyclecounter() : 0;
+#define P8_PROF(k)                                                           \
+    if (stamp) {                                                             \
+        const unsigned long long n__ = __builtin_readcyclecounter();          \
+        prof[k] += n__ - tprev;                                               \
+        tprev = n__;                                                          \
+    }
+#else
+#define P8_PROF(k)
+#endif
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int grp = wave >> 2, wn = wave & 3;
+    const int frow = lane & 15;
+    const int fg = lane >> 4;
+    T* __restrict__ C = reinterpret_cast<T*>(p.C);
+    const T* R = reinterpret_cast<const T*>(p.R);
+    const bool has_res = p.res_mode != MLPK_RES_NONE;
+    const bool res_add = p.res_mode == MLPK_RES_ADD;
+    f32x4 bz[4], lc[4], cs[4], ch[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + (j >> 1) * 128 + wn * 32 + (j & 1) * 16 + 4 * fg;
+        bz[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (LN) lc[j] = *reinterpret_cast<const f32x4*>(p.ln_csum + n);
+        if (AFF) {
+            cs[j] = p.cscale ? *reinterpret_cast<const f32x4*>(p.cscale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+            ch[j] = p.cshift ? *reinterpret_cast<const f32x4*>(p.cshift + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const int c16 = tid & 31;
+    const int rsub = tid >> 5;
+    const int gn = n0 + c16 * 8;
+#pragma unroll
+    for (int hm = 0; hm < 2; ++hm) {
+        u32x4 rr[8];
+        if (has_res) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                rr[q] = *reinterpret_cast<const u32x4*>(R + (size_t)(m0 + hm * 128 + q * 16 + rsub) * p.ldr + gn);
+        }
+        float lmu[4], lrs[4];
+        if (LN) {
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+                const int m = m0 + hm * 128 + grp * 64 + i4 * 16 + frow;
+                lmu[i4] = p.ln_mean[m];
+                lrs[i4] = p.ln_rstd[m];
+            }
+        }
+        // phase 1: element math on the fp32 accumulator, round, ds_write_b64 into the swizzled staging tile
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+            const int sr = grp * 64 + i4 * 16 + frow;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int nl = (j >> 1) * 128 + wn * 32 + (j & 1) * 16 + 4 * fg;
+                const f32x4 a = acc[hm * 4 + i4][j];
+                f32x2 lo = {a.x, a.y}, hi = {a.z, a.w};
+                const f32x2 blo = {bz[j].x, bz[j].y}, bhi = {bz[j].z, bz[j].w};
+                if (LN) {
+                    const f32x2 nm = {-lmu[i4], -lmu[i4]}, rs = {lrs[i4], lrs[i4]};
+                    lo = __builtin_elementwise_fma(__builtin_elementwise_fma(nm, f32x2{lc[j].x, lc[j].y}, lo), rs, blo);
+                    hi = __builtin_elementwise_fma(__builtin_elementwise_fma(nm, f32x2{lc[j].z, lc[j].w}, hi), rs, bhi);
+                } else {
+                    lo = lo + blo;
+                    hi = hi + bhi;
+                }
+                if (GELU) {
+                    lo = gelu_pk(lo);
+                    hi = gelu_pk(hi);
+                }
+                if (AFF) {
+                    lo = __builtin_elementwise_fma(lo, f32x2{cs[j].x, cs[j].y}, f32x2{ch[j].x, ch[j].y});
+                    hi = __builtin_elementwise_fma(hi, f32x2{cs[j].z, cs[j].w}, f32x2{ch[j].z, ch[j].w});
+                }
+                T e[4] = {from_f32<T>(lo.x), from_f32<T>(lo.y), from_f32<T>(hi.x), from_f32<T>(hi.y)};
+                u32x2 pk;
+                __builtin_memcpy(&pk, e, 8);
+                *reinterpret_cast<u32x2*>(stg + sr * 512 + ((((nl >> 3) ^ (sr & 15)) << 4) | ((nl & 4) << 1))) = pk;
+            }
+        }
+        P8_PROF(hm * 4 + 0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        P8_PROF(hm * 4 + 1);
+        // phase 2: 16-byte chunks LDS -> (residual) -> global, whole 512-byte rows per 32 lanes
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int row = q * 16 + rsub;
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(stg + row * 512 + ((c16 ^ (row & 15)) << 4));
+            u32x4 outv = raw;
+            if (has_res) {
+                T a8[8], r8[8];
+                __builtin_memcpy(a8, &raw, 16);
+                __builtin_memcpy(r8, &rr[q], 16);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float x = to_f32(a8[e]), y = to_f32(r8[e]);
+                    a8[e] = from_f32<T>(res_add ? x + y : x * y);
+                }
+                __builtin_memcpy(&outv, a8, 16);
+            }
+            if (!(p.dbg & 2) || outv.x == 0x12345678u)
+                *reinterpret_cast<u32x4*>(C + (size_t)(m0 + hm * 128 + row) * p.ldc + gn) = outv;
+        }
+        P8_PROF(hm * 4 + 2);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        P8_PROF(hm * 4 + 3);
+    }
+#undef P8_PROF
+}
+
+template <typename T, bool TRANS>
+__global__ void __launch_bounds__(512, 1) gemm_nt_p8_kernel(const GemmArgs p) {
+    constexpr int BM = 256, BN = 256;
+    constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr int BK = 8 * EPC;                            // elements per 128-byte slab row
+    constexpr int HALF_B = 128 * 128;                      // bytes of one half-tile
+    constexpr int BUF_B = 4 * HALF_B;                      // A-lo, A-hi, B-lo, B-hi
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wn = wave & 3;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_total = ((p.M + BM - 1) / BM) * tiles_n;
+
+    // ---- per-tile state: tile origin, operand bases, per-lane source offsets of the 8 staging pieces ----
+    // staging: wave w fills rows 16w .. 16w+15 of every half-tile, two 1-KiB pieces of 8 rows; lane ->
+    // (row lane >> 3, physical chunk lane & 7), source chunk (lane & 7) ^ (row & 7)
+    int m0 = 0, n0 = 0;
+    const char* baseA = nullptr;
+    const char* baseB = nullptr;
+    unsigned voff[4][2];
+    auto setup = [&](const int v) {
+        const int wg = xcd_remap(v, tiles_total);
+        m0 = (wg / tiles_n) * BM;
+        n0 = (wg % tiles_n) * BN;
+        baseA = reinterpret_cast<const char*>(p.A) + (size_t)m0 * p.lda * sizeof(T);
+        baseB = reinterpret_cast<const char*>(p.B) + (size_t)n0 * p.ldb * sizeof(T);
+        const int lr = lane >> 3;
+        const int sc = (lane & 7) ^ lr;
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int hr = (h & 1) * 128 + wave * 16 + q * 8 + lr;       // row inside the 256-row tile
+                if (h < 2) {
+                    const int r = m0 + hr < p.M ? hr : p.M - 1 - m0;
+                    voff[h][q] = (unsigned)(r * p.lda + sc * EPC) * (unsigned)sizeof(T);
+                } else {
+                    const int r = n0 + hr < p.N ? hr : p.N - 1 - n0;
+                    voff[h][q] = (unsigned)(r * p.ldb + sc * EPC) * (unsigned)sizeof(T);
+                }
+            }
+    };
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const unsigned lds_w = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)smem + wave * 2048);
+    // half ids: 0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi
+    auto stage = [&](const int t, const int h) {
+        const unsigned dst = lds_w + (unsigned)((t & 1) * BUF_B + h * HALF_B);
+        const char* gb = (h < 2 ? baseA : baseB) + (size_t)t * (BK * sizeof(T));
+        glds_piece_s(voff[h][0], gb, dst);
+        glds_piece_s(voff[h][1], gb, dst + 1024);
+    };
+
+    const int frow = lane & 15;
+    const int fg = lane >> 4;
+    const int c0 = ((fg ^ (frow & 7)) << 4);               // chunk of k-substep 0; substep 1 is c0 ^ 64
+    const int a_rd = (grp * 64 + frow) * 128 + c0;          // + half * HALF_B + i * 2048
+    const int b_rd = 2 * HALF_B + (wn * 32 + frow) * 128 + c0;
+    const int nk = p.K / BK;                                // >= 2 (host checked)
+
+    // tuning aid (dbg & 8): per-workgroup sums of [wait for first slabs | main loop | epilogue] in shader clocks
+    unsigned long long tw = 0, tl = 0, te = 0, ts = 0;
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool stamp = (p.dbg & 8) != 0;
+    const void* stamp_buf = p.R;
+
+    // the epilogue class is a launch-wide property; whole-tile-ness is per tile
+    bool fast_ok = false;
+    if constexpr (sizeof(T) == 2 && !TRANS) {
+        fast_ok = p.vec_c == 2 && (p.res_mode == MLPK_RES_NONE || stamp || p.vec_r == 2) && !p.rscale && !(p.dbg & 4) &&
+                  ((reinterpret_cast<uintptr_t>(p.bias) | reinterpret_cast<uintptr_t>(p.ln_csum) | reinterpret_cast<uintptr_t>(p.cscale) |
+                    reinterpret_cast<uintptr_t>(p.cshift)) & 15) == 0;
+    }
+
+    // ---- first tile: slab 0 complete before the loop, three half-tiles of slab 1 in flight ----
+    int v = blockIdx.x;
+    setup(v);
+    stage(0, 2); stage(0, 0); stage(0, 3); stage(0, 1);
+    stage(1, 2); stage(1, 0); stage(1, 3);
+
+    for (;;) {
+        if (stamp) ts = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        P8_BARRIER();
+        if (grp == 1) P8_BARRIER();
+        if (stamp) { const unsigned long long n = __builtin_readcyclecounter(); tw += n - ts; ts = n; }
+
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x4 a0[4][2], a1[4][2], b0[2][2], b1[2][2];
+#define P8_READ_A(dst, h)                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
+        dst[i][0] = *reinterpret_cast<const u32x4*>(rb + (a_rd + (h) * HALF_B + i * 2048));                         \
+        dst[i][1] = *reinterpret_cast<const u32x4*>(rb + ((a_rd + (h) * HALF_B + i * 2048) ^ 64));                  \
+    }
+#define P8_READ_B(dst, h)                                                                                         \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                \
+        dst[j][0] = *reinterpret_cast<const u32x4*>(rb + (b_rd + (h) * HALF_B + j * 2048));                         \
+        dst[j][1] = *reinterpret_cast<const u32x4*>(rb + ((b_rd + (h) * HALF_B + j * 2048) ^ 64));                  \
+    }
+#define P8_SLAB(MODE, t)                                                                                          \
+    {                                                                                                             \
+        const char* rb = smem + ((t) & 1) * BUF_B;                                                                 \
+        /* phase 0 */                                                                                             \
+        P8_READ_B(b0, 0);                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        P8_READ_A(a0, 0);                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        if (MODE <= 1) stage((t) + 1, 1);                                                                          \
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                                         \
+        P8_BARRIER();                                                                                              \
+        P8<T, MODE>::template mma16<TRANS>(acc, a0, b0, 0, 0);                                                      \
+        P8_BARRIER();                                                                                              \
+        /* phase 1 */                                                                                             \
+        P8_READ_B(b1, 1);                                                                                          \
+        if (MODE == 0) stage((t) + 2, 2);                                                                          \
+        P8_BARRIER();                                                                                              \
+        P8<T, MODE>::template mma16<TRANS>(acc, a0, b1, 0, 2);                                                      \
+        P8_BARRIER();                                                                                              \
+        /* phase 2 */                                                                                             \
+        P8_READ_A(a1, 1);                                                                                          \
+        if (MODE == 0) stage((t) + 2, 0);                                                                          \
+        P8_BARRIER();                                                                                              \
+        P8<T, MODE>::template mma16<TRANS>(acc, a1, b1, 4, 2);                                                      \
+        P8_BARRIER();                                                                                              \
+        /* phase 3 */                                                                                             \
+        if (MODE == 0) {                                                                                           \
+            stage((t) + 2, 3);                                                                                     \
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                       \
+        } else if (MODE == 1) {                                                                                    \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
+        }                                                                                                          \
+        P8_BARRIER();                                                                                              \
+        P8<T, MODE>::template mma16<TRANS>(acc, a1, b0, 4, 0);                                                      \
+        P8_BARRIER();                                                                                              \
+    }
+#pragma unroll 1
+        for (int t = 0; t < nk - 2; ++t) P8_SLAB(0, t);
+        P8_SLAB(1, nk - 2);
+        P8_SLAB(2, nk - 1);
+#undef P8_SLAB
+#undef P8_READ_A
+#undef P8_READ_B
+        // the asm MFMAs are invisible to the hazard recogniser: cover the XDL-write -> VALU-read window by hand
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        if (grp == 0) P8_BARRIER();
+        // every wave is past all its LDS reads of this tile; the groups are aligned again
+        if (stamp) { const unsigned long long n = __builtin_readcyclecounter(); tl += n - ts; ts = n; }
+
+        const int cm0 = m0, cn0 = n0;
+        v += gridDim.x;
+        const bool more = v < tiles_total;                 // workgroup-uniform
+        GemmArgs q = p;
+        if (stamp) { q.R = nullptr; q.res_mode = MLPK_RES_NONE; }
+        const bool fast = fast_ok && cm0 + BM <= p.M && cn0 + BN <= p.N;
+        // opaque copy of the thread id: keeps the epilogue's address arithmetic inside this iteration (hoisted
+        // out of the persistent loop it would sit in VGPRs through the main loop and spill)
+        int etid = tid;
+        asm volatile("" : "+v"(etid));
+        if (fast) {
+            // next tile's slab 0 streams into buffer 0 while this tile leaves through buffer 1
+            if (more) {
+                setup(v);
+                stage(0, 2); stage(0, 0); stage(0, 3); stage(0, 1);
+            }
+            if constexpr (sizeof(T) == 2 && !TRANS) {
+                char* stg = smem + BUF_B;
+                const int cls = (p.act == MLPK_ACT_GELU ? 1 : 0) | (p.ln_mean ? 2 : 0) | ((p.cscale || p.cshift) ? 4 : 0);
+                switch (cls) {
+                    case 0: p8_store_tile<T, false, false, false>(q, acc, stg, cm0, cn0, etid, prof); break;
+                    case 1: p8_store_tile<T, true, false, false>(q, acc, stg, cm0, cn0, etid, prof); break;
+                    case 2: p8_store_tile<T, false, true, false>(q, acc, stg, cm0, cn0, etid, prof); break;
+                    case 3: p8_store_tile<T, true, true, false>(q, acc, stg, cm0, cn0, etid, prof); break;
+                    case 4: p8_store_tile<T, false, false, true>(q, acc, stg, cm0, cn0, etid, prof); break;
+                    case 5: p8_store_tile<T, true, false, true>(q, acc, stg, cm0, cn0, etid, prof); break;
+                    case 6: p8_store_tile<T, false, true, true>(q, acc, stg, cm0, cn0, etid, prof); break;
+                    default: p8_store_tile<T, true, true, true>(q, acc, stg, cm0, cn0, etid, prof); break;
+                }
+            }
+            if (more) { stage(1, 2); stage(1, 0); stage(1, 3); }
+        } else {
+            __syncthreads();
+            gemm_epilogue<T, BM, BN, 2, 4, TRANS, true>(q, acc, smem, cm0, cn0, etid);
+            __syncthreads();
+            if (more) {
+                setup(v);
+                stage(0, 2); stage(0, 0); stage(0, 3); stage(0, 1);
+                stage(1, 2); stage(1, 0); stage(1, 3);
+            }
+        }
+        if (stamp) { const unsigned long long n = __builtin_readcyclecounter(); te += n - ts; ts = n; }
+        if (!more) break;
+    }
+    if (stamp && tid == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<void*>(stamp_buf)) + (size_t)blockIdx.x * 64;
+        o[0] = tw; o[1] = tl; o[2] = te;
+        o[3] = (tiles_total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;       // tiles of this workgroup
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[4 + k] = prof[k];
+    }
 }
 
 // ------------------------------- host-side dispatch -------------------------------
@@ -688,6 +1103,7 @@ static const TileCfg kTiles[] = {
     {256, 128, 2, 2, 2},   // algo 11..13: "s3" pipeline (4 waves, 3 LDS stages of 64-byte rows, 2 workgroups / CU)
     {128, 128, 2, 2, 2},
     {128, 256, 2, 2, 2},
+    {256, 256, 2, 4, 3},   // algo 14: "p8" ping-pong pipeline (8 waves, 128 KiB LDS, 1 workgroup / CU; K % slab == 0, K >= 2 slabs)
 };
 static const int kNumTiles = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
 
@@ -731,6 +1147,37 @@ static int launch_s3(const GemmArgs& a, bool trans, hipStream_t stream) {
     return 0;
 }
 
+// one persistent workgroup per compute unit (a multiple of 8 keeps the XCD-contiguous tile walk)
+static int p8_grid_cap() {
+    static int cap = 0;
+    if (!cap) {
+        int dev = 0, cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu < 8) cu = 256;
+        cap = cu & ~7;
+    }
+    return cap;
+}
+
+template <typename T> static int launch_p8(const GemmArgs& a, bool trans, hipStream_t stream) {
+    const int lds = 2 * 4 * 128 * 128;
+    const int total = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+    const int tiles = total < p8_grid_cap() ? total : p8_grid_cap();     // persistent: one workgroup per CU
+    hipError_t e;
+    if (trans) {
+        auto k = gemm_nt_p8_kernel<T, true>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(k, dim3(tiles), dim3(512), lds, stream, a);
+    } else {
+        auto k = gemm_nt_p8_kernel<T, false>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(k, dim3(tiles), dim3(512), lds, stream, a);
+    }
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
 template <typename T> static int launch_algo(int algo, const GemmArgs& a, bool trans, hipStream_t s) {
     switch (algo) {
         case 1: return launch_cfg<T, 256, 256, 2, 4, false>(a, trans, s);
@@ -746,6 +1193,7 @@ template <typename T> static int launch_algo(int algo, const GemmArgs& a, bool t
         case 11: return launch_s3<T, 256, 128, 2, 2>(a, trans, s);
         case 12: return launch_s3<T, 128, 128, 2, 2>(a, trans, s);
         case 13: return launch_s3<T, 128, 256, 2, 2>(a, trans, s);
+        case 14: return launch_p8<T>(a, trans, s);
         default: return MLPK_EMODE;
     }
 }
@@ -754,12 +1202,26 @@ template <typename T> static int launch_algo(int algo, const GemmArgs& a, bool t
 // do not fill the CUs many times over).  Efficiencies follow the MI355X sweeps in profiles/: with K a
 // multiple of 32 elements the 2-workgroup-per-CU "s3" tiles win on every shape of the path (their
 // epilogue overlaps the other workgroup's main loop); ragged K falls back to the register-staged tiles.
-static int auto_algo(int M, int N, bool glds_ok) {
+static int auto_algo(int M, int N, int K, int epc, bool glds_ok, bool p8_ok) {
     double best = 1e300;
     int best_algo = 4;
     for (int i = 0; i < kNumTiles; ++i) {
         const TileCfg& t = kTiles[i];
         const int area = t.bm * t.bn;
+        if (t.glds == 3) {
+            // persistent 256 x 256 ping-pong tile: whole launch rounds of one tile per CU; its per-tile fixed cost
+            // (first slabs + epilogue, not overlapped with another workgroup) weighs more the shorter K is.
+            // Calibrated on the MI355X sweeps: 0.76-0.82 x the best s3 time at K = 768 / 3072, break-even at K = 256.
+            if (!p8_ok || K % (8 * epc) || K < 16 * epc) continue;
+            const double tiles = (double)((M + 255) / 256) * (double)((N + 255) / 256);
+            const double cap = (double)p8_grid_cap();
+            const double rounds = (double)(long long)((tiles + cap - 1) / cap);
+            const double kb = (double)K / epc * 16.0;          // bytes of K per row
+            const double eff = 1.45 * kb / (kb + 192.0);
+            const double cost = (tiles < cap ? tiles : rounds * cap) * area / eff * (tiles < cap ? cap / tiles : 1.0);
+            if (cost < best) { best = cost; best_algo = i + 1; }
+            continue;
+        }
         if (glds_ok) {
             if (!(t.glds == 2 || (t.glds == 1 && area <= 64 * 64))) continue;
         } else if (t.glds != 0) {
@@ -787,7 +1249,7 @@ extern "C" int mlpk_gemm_algo_info(int algo, int* bm, int* bn, int* threads, int
     if (bm) *bm = t.bm;
     if (bn) *bn = t.bn;
     if (threads) *threads = t.wm * t.wn * 64;
-    if (lds_bytes) *lds_bytes = t.glds == 2 ? 3 * (t.bm + t.bn) * 64 : 2 * (t.bm + t.bn) * 128;
+    if (lds_bytes) *lds_bytes = t.glds == 2 ? 3 * (t.bm + t.bn) * 64 : 2 * (t.bm + t.bn) * 128;   // (p8: 2 x 64 KiB too)
     return 0;
 }
 
@@ -832,9 +1294,12 @@ extern "C" int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream) {
     if (a.vec_r && d->ldr % 8 == 0 && ((uintptr_t)d->R % 16) == 0) a.vec_r = 2;
     int algo = d->algo;
     const bool glds_ok = d->K % (4 * epc) == 0;      // K a multiple of half a 128-byte slab
-    if (algo == 0) algo = auto_algo(d->M, d->N, glds_ok);
+    // the persistent tile is auto-selected where its overlapped epilogue applies (16-bit row-major, no row scale)
+    const bool p8_ok = es == 2 && !trans && !d->rscale && a.vec_c == 2 && (!d->R || a.vec_r == 2);
+    if (algo == 0) algo = auto_algo(d->M, d->N, d->K, epc, glds_ok, p8_ok);
     if (algo < 1 || algo > kNumTiles) return MLPK_EMODE;
     if (kTiles[algo - 1].glds && !glds_ok) return MLPK_ESHAPE;
+    if (kTiles[algo - 1].glds == 3 && (d->K % (8 * epc) != 0 || d->K < 16 * epc)) return MLPK_ESHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (d->dtype) {
         case MLPK_F32: return launch_algo<float>(algo, a, trans, s);

@@ -355,6 +355,62 @@ def test_dwconv(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_p8_pingpong_tile(dtype):
+    """algo 14 (256 x 256 ping-pong pipeline): ragged M/N, 2 .. 12 K slabs (peeled tail slabs), both outputs."""
+    pkg = load_pkg()
+    E, N = pkg.engine, pkg._native
+    slab = 32 if dtype == torch.float32 else 64
+    for ci, (M, Nn, nslab, trans) in enumerate([(300, 200, 2, False), (513, 129, 3, False), (256, 256, 5, False), (1000, 700, 12, False),
+                                                (3 * 64, 49, 4, True), (2 * 200, 196, 7, True)]):
+        K = nslab * slab
+        A = rnd((M, K), dtype, 300 + ci).to(dev())
+        B = rnd((Nn, K), dtype, 310 + ci, 1.0 / math.sqrt(K)).to(dev())
+        bias = rnd((Nn,), torch.float32, 320 + ci).to(dev())
+        if not trans:
+            R = rnd((M, Nn), dtype, 330 + ci).to(dev())
+            C = torch.full((M, Nn), float("nan"), dtype=dtype, device=dev())
+            E.gemm(A, B, C, M, Nn, K, bias=bias, act=1, R=R, res=1, algo=14)
+            ref = gemm_ref(A.cpu(), B.cpu(), M, Nn, K, bias=bias.cpu(), act=1, R=R.cpu(), res=1)
+            got = C.cpu().double()
+        else:
+            t_rows = 64 if ci == 4 else 200
+            nimg = M // t_rows
+            R = rnd((nimg * Nn, t_rows), dtype, 330 + ci).to(dev())
+            C = torch.full((nimg * Nn, t_rows), float("nan"), dtype=dtype, device=dev())
+            E.gemm(A, B, C, M, Nn, K, ldc=t_rows, bias=bias, R=R, ldr=t_rows, res=1, out_mode=N.OUT_TOKEN_T, t_rows=t_rows,
+                   t_tokens=Nn, algo=14)
+            ref = gemm_ref(A.cpu(), B.cpu(), M, Nn, K, bias=bias.cpu(), R=R.cpu(), res=1, out_mode=1, t_rows=t_rows, t_tokens=Nn)
+            got = C.cpu().double().reshape(nimg, Nn, t_rows)
+        torch.cuda.synchronize()
+        assert torch.isfinite(got).all(), (ci, "non-finite")
+        err = (got - ref).abs().max().item()
+        tol = EPS[dtype] * max(1.0, ref.abs().max().item()) * 4
+        assert err < tol, (str(dtype), ci, err, tol)
+    for K in (slab, slab * 2 + slab // 2):                      # one slab / a ragged slab -> refused, not wrong
+        with pytest.raises(N.MlpkError):
+            A = torch.zeros((64, K), dtype=dtype, device=dev())
+            E.gemm(A, A, torch.zeros((64, 64), dtype=dtype, device=dev()), 64, 64, K, algo=14)
+
+
+def test_gemm_p8_race_screen_bit_equal_to_s3():
+    """The hand-scheduled LDS-DMA / barrier pipeline of algo 14 against the independent s3 tile (algo 13) on the
+    channel-MLP shapes: both accumulate k in the same order, so every run must be BIT-equal."""
+    pkg = load_pkg()
+    E, N = pkg.engine, pkg._native
+    for (M, Nn, K) in ((50176 // 4, 3072, 768), (50176 // 4, 768, 3072)):
+        A = rnd((M, K), torch.bfloat16, 400).to(dev())
+        B = rnd((Nn, K), torch.bfloat16, 401, 1.0 / math.sqrt(K)).to(dev())
+        bias = rnd((Nn,), torch.float32, 402).to(dev())
+        ref = torch.empty((M, Nn), dtype=torch.bfloat16, device=dev())
+        E.gemm(A, B, ref, M, Nn, K, bias=bias, act=1, algo=13)
+        for run in range(6):
+            C = torch.full((M, Nn), float("nan"), dtype=torch.bfloat16, device=dev())
+            E.gemm(A, B, C, M, Nn, K, bias=bias, act=1, algo=14)
+            torch.cuda.synchronize()
+            assert torch.equal(C.view(torch.int16), ref.view(torch.int16)), (M, Nn, K, run, (C.float() - ref.float()).abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("algo", [6, 7, 8, 9, 10, 11, 12, 13])
 def test_gemm_direct_to_lds_tiles(dtype, algo):
     """global_load_lds staging: ragged M/N (clamped source rows), K = whole and half slabs, both outputs."""

@@ -21,6 +21,16 @@ SHAPES = [  # name, M, N, K, token_t(t_rows, t_tokens) or None, gelu
     ("token_fc2", 196608, 196, 784, (768, 196), False),
     ("gmlp_proj1", 50176, 3072, 256, None, True),
     ("vip_branch", 262144, 384, 384, None, False),
+    ("mixer_l_fc1", 50176, 4096, 1024, None, True),
+    ("mixer_l_fc2", 50176, 1024, 4096, None, False),
+    ("mixer_s_fc1", 50176, 2048, 512, None, True),
+    ("mixer_s_fc2", 50176, 512, 2048, None, False),
+    ("resmlp_fc1", 50176, 1536, 384, None, True),
+    ("resmlp_fc2", 50176, 384, 1536, None, False),
+    ("convmixer_pw", 262144, 1536, 1536, None, True),
+    ("s2_mlp1", 262144, 576, 192, None, False),
+    ("s2_fc1", 65536, 1152, 384, None, True),
+    ("gmlp_proj2", 50176, 256, 1536, None, False),
 ]
 for name, M, Nn, K, tt, gelu in SHAPES:
     A = (torch.rand((M, K), device=dev) * 2 - 1).to(dt)
