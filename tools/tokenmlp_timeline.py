@@ -24,18 +24,12 @@ import ctypes
 import numpy as np
 fn = ctypes.CDLL(N.LIB_PATH).mlpk_token_mlp_debug
 fn.argtypes = [ctypes.c_void_p]
-nwg = B_ * C // 128
-dbg = torch.zeros((nwg, 256), dtype=torch.int64, device="cuda")
+grid = 256
+dbg = torch.zeros((grid, 4), dtype=torch.int64, device="cuda")
 fn(dbg.data_ptr())
 E.token_mlp(xt, sp, B_ * C, S, w1p, b1p, w2p, b2p, nch, x, C, C)
 torch.cuda.synchronize()
 fn(None)
-t = dbg.cpu().numpy()
-for wg in (0, 700, nwg - 1):
-    r = t[wg]
-    out = []
-    for it in range(2, 12):
-        a = r[5 * it:5 * it + 5]
-        nxt = r[5 * (it + 1)]
-        out.append("[vm %d bar %d fc1 %d gelu %d fc2 %d]" % (a[1] - a[0], a[2] - a[1], a[3] - a[2], a[4] - a[3], nxt - a[4]))
-    print("wg", wg, "total", r[5 * 26] - r[0], " ".join(out))
+t = dbg.cpu().numpy().astype(np.float64)
+per = t[:, :2] / t[:, 2:3]
+print("per tile (shader clocks, matrix wave 0): main loop mean %.0f (%.0f per iteration), epilogue mean %.0f" % (per[:, 0].mean(), per[:, 0].mean() / (nch + 2), per[:, 1].mean()))
