@@ -18,6 +18,7 @@
 //   * XCD-aware tile order: each of the 8 XCDs walks a contiguous range of tiles (n fastest) so the
 //     A panel and the weight panels are re-used out of that XCD's private L2.
 #include "mlpk_common.h"
+#include <stdlib.h>
 
 namespace mlpk {
 
@@ -1211,13 +1212,14 @@ static int auto_algo(int M, int N, int K, int epc, bool glds_ok, bool p8_ok) {
         if (t.glds == 3) {
             // persistent 256 x 256 ping-pong tile: whole launch rounds of one tile per CU; its per-tile fixed cost
             // (first slabs + epilogue, not overlapped with another workgroup) weighs more the shorter K is.
-            // Calibrated on the MI355X sweeps: 0.76-0.82 x the best s3 time at K = 768 / 3072, break-even at K = 256.
+            // Calibrated on the MI355X sweeps and model benches: 0.76-0.82 x the best s3 time at K = 768 / 3072,
+            // break-even around K = 384, behind below that.
             if (!p8_ok || K % (8 * epc) || K < 16 * epc) continue;
             const double tiles = (double)((M + 255) / 256) * (double)((N + 255) / 256);
             const double cap = (double)p8_grid_cap();
             const double rounds = (double)(long long)((tiles + cap - 1) / cap);
             const double kb = (double)K / epc * 16.0;          // bytes of K per row
-            const double eff = 1.45 * kb / (kb + 192.0);
+            const double eff = 1.5 * kb / (kb + 384.0);
             const double cost = (tiles < cap ? tiles : rounds * cap) * area / eff * (tiles < cap ? cap / tiles : 1.0);
             if (cost < best) { best = cost; best_algo = i + 1; }
             continue;
@@ -1295,7 +1297,8 @@ extern "C" int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream) {
     int algo = d->algo;
     const bool glds_ok = d->K % (4 * epc) == 0;      // K a multiple of half a 128-byte slab
     // the persistent tile is auto-selected where its overlapped epilogue applies (16-bit row-major, no row scale)
-    const bool p8_ok = es == 2 && !trans && !d->rscale && a.vec_c == 2 && (!d->R || a.vec_r == 2);
+    static const bool no_p8 = getenv("MLPK_GEMM_NO_P8") != nullptr;      // tuning hook: A/B the tile choice in one run
+    const bool p8_ok = !no_p8 && es == 2 && !trans && !d->rscale && a.vec_c == 2 && (!d->R || a.vec_r == 2);
     if (algo == 0) algo = auto_algo(d->M, d->N, d->K, epc, glds_ok, p8_ok);
     if (algo < 1 || algo > kNumTiles) return MLPK_EMODE;
     if (kTiles[algo - 1].glds && !glds_ok) return MLPK_ESHAPE;

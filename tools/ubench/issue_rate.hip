@@ -1,0 +1,95 @@
+// Tuning aid: instruction issue cost per wave on gfx950 with 1 or 2 waves per SIMD (256 / 512 threads, one
+// workgroup per CU).  Build + run: hipcc --offload-arch=gfx950 -O3 issue_rate.hip -o /tmp/issue_rate && /tmp/issue_rate
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define REP 64
+template <int MODE>
+__global__ void __launch_bounds__(512) k(float* out, unsigned long long* cyc, int iters) {
+    extern __shared__ char smem[];
+    f32x2 a[8];
+    for (int i = 0; i < 8; ++i) a[i] = f32x2{(float)threadIdx.x + i, 1.0f};
+    float s[8];
+    for (int i = 0; i < 8; ++i) s[i] = threadIdx.x * 0.5f + i;
+    f32x4 acc[4] = {};
+    bf16x8 fa = {}, fb = {};
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < REP / 8; ++r) {
+            if (MODE == 0) {   // packed fp32 fma, 8 independent chains
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
+            } else if (MODE == 1) {   // scalar fp32 fma
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(s[i]) : "v"(s[(i + 1) & 7]));
+            } else if (MODE == 2) {   // v_rcp
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_rcp_f32 %0, %0" : "+v"(s[i]));
+            } else if (MODE == 3) {   // salu
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("s_add_u32 s20, s20, 1" ::: "s20");
+            } else if (MODE == 4) {   // mfma 16x16x32
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i & 3]) : "v"(fa), "v"(fb));
+            } else if (MODE == 5) {   // 1 mfma + 3 pk_fma interleaved
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i & 3]) : "v"(fa), "v"(fb));
+                    asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(a[3 * i]) : "v"(a[7]));
+                    asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(a[3 * i + 1]) : "v"(a[7]));
+                    asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(a[3 * i + 2]) : "v"(a[7]));
+                }
+            } else if (MODE == 6) {   // role split: waves 0-3 mfma only, waves 4-7 pk_fma only
+                if ((threadIdx.x >> 8) == 0) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i & 3]) : "v"(fa), "v"(fb));
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
+                }
+            } else if (MODE == 7) {   // ds_read_b128, conflict-free lane-linear
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { f32x4 v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"((unsigned)(threadIdx.x & 63) * 16u), "n"(0)); acc[i & 3] += v; }
+            }
+        }
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    float r = 0;
+    for (int i = 0; i < 8; ++i) r += a[i].x + a[i].y + s[i];
+    for (int i = 0; i < 4; ++i) r += acc[i].x;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
+}
+template <int MODE> void run(const char* name, int threads) {
+    float* out; unsigned long long* cyc;
+    hipMalloc(&out, 256 * 512 * 4); hipMalloc(&cyc, 256 * 8 * 8);
+    hipMemset(cyc, 0, 256 * 8 * 8);
+    const int iters = 200;
+    hipFuncSetAttribute((const void*)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    k<MODE><<<256, threads, 100 * 1024>>>(out, cyc, iters);
+    hipDeviceSynchronize();
+    unsigned long long h[256 * 8];
+    hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+    double s0 = 0, s1 = 0; int n0 = 0, n1 = 0;
+    for (int b = 0; b < 256; ++b) for (int w = 0; w < threads / 64; ++w) { if (w < 4) { s0 += h[b * 8 + w]; ++n0; } else { s1 += h[b * 8 + w]; ++n1; } }
+    printf("%-34s %3d thr: waves0-3 %6.2f clk/instr", name, threads, s0 / n0 / (iters * REP));
+    if (n1) printf("   waves4-7 %6.2f clk/instr", s1 / n1 / (iters * REP));
+    printf("\n");
+    hipFree(out); hipFree(cyc);
+}
+int main() {
+    for (int thr : {256, 512}) {
+        run<0>("v_pk_fma_f32 (8 chains)", thr);
+        run<1>("v_fma_f32 (8 chains)", thr);
+        run<2>("v_rcp_f32", thr);
+        run<3>("s_add_u32", thr);
+        run<4>("v_mfma_16x16x32_bf16", thr);
+        run<5>("1 mfma + 3 pk_fma", thr);
+        run<7>("ds_read_b128 + 4 v_add", thr);
+    }
+    run<6>("split: w0-3 mfma | w4-7 pk_fma", 512);
+    return 0;
+}
