@@ -47,77 +47,71 @@ __device__ __forceinline__ float gelu_f(float x) {
 
 // GELU for 16-bit outputs: erf by Abramowitz & Stegun 7.1.28, erf(z) = 1 - (1 + a1 z + .. + a6 z^6)^-16
 // (|err| <= 3e-7), with the 1/sqrt(2) folded into the coefficients: ONE quarter-rate instruction (rcp) per
-// element instead of two (rcp + exp), everything else pairs into v_pk_fma/mul_f32.  |GELU error| <= 7.1e-7
-// (measured over [-12, 12]), far below half an ulp of f16/bf16; float outputs keep gelu_f.
-//   gelu(x) = x/2 + |x|/2 * erf(|x|/sqrt 2) = (x/2 + |x|/2) - |x|/2 * D^-16
-__device__ __forceinline__ f32x2 gelu_pk(f32x2 x) {
-    const f32x2 ax = __builtin_elementwise_abs(x);
-    f32x2 d = __builtin_elementwise_fma(ax, f32x2{5.38297490e-6f, 5.38297490e-6f}, f32x2{4.88906371e-5f, 4.88906371e-5f});
-    d = __builtin_elementwise_fma(d, ax, f32x2{3.80035744e-5f, 3.80035744e-5f});
-    d = __builtin_elementwise_fma(d, ax, f32x2{3.27762635e-3f, 3.27762635e-3f});
-    d = __builtin_elementwise_fma(d, ax, f32x2{2.11410057e-2f, 2.11410057e-2f});
-    d = __builtin_elementwise_fma(d, ax, f32x2{4.98673469e-2f, 4.98673469e-2f});
-    d = __builtin_elementwise_fma(d, ax, f32x2{1.0f, 1.0f});
-    d = d * d;
-    d = d * d;
-    d = d * d;
-    d = d * d;
-    const f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-    const f32x2 h = x * 0.5f;
-    const f32x2 ah = ax * 0.5f;
-    return __builtin_elementwise_fma(-ah, r, h + ah);
-}
+// element instead of two (rcp + exp), everything else pairs into v_pk_* ops.  The polynomial is additionally scaled
+// by 2^(1/16), so that its 16th power carries the factor 2 and the reciprocal comes out already halved:
+//   gelu(x) = x/2 + |x|/2 * erf(|x|/sqrt 2) = max(x, 0) - |x| * D'(|x|)^-16,    D' = 2^(1/16) * D
+// 17 VALU instructions per PAIR of elements.  |GELU error| <= 7.1e-7 (measured over [-12, 12]), far below half an
+// ulp of f16/bf16; float outputs keep gelu_f.
+#define MLPK_GELU_C0 1.0442737340927124f
+#define MLPK_GELU_C1 0.052075162529945374f
+#define MLPK_GELU_C2 0.02207699790596962f
+#define MLPK_GELU_C3 0.003422739217057824f
+#define MLPK_GELU_C4 3.9686136005911976e-05f
+#define MLPK_GELU_C5 5.105520904180594e-05f
+#define MLPK_GELU_C6 5.62129980608006e-06f
 
-// gelu_pk on N independent pairs with the N dependency chains interleaved step by step: a single wave running
-// ONE chain is latency-bound (each v_pk op waits ~2 issue slots for its predecessor, measured ~2.3x slower);
-// N = 4 keeps the VALU issuing every cycle.  Same operations per element, hence the same bits as gelu_pk.
+// gelu on N independent pairs with the N dependency chains interleaved step by step: a single wave running ONE
+// chain is latency-bound (each v_pk op waits for its predecessor); N = 4 keeps the VALU issuing back to back.
 template <int N> __device__ __forceinline__ void gelu_pk_n(f32x2 (&x)[N]) {
-    f32x2 ax[N], d[N], r[N];
+    f32x2 ax[N], d[N];
 #pragma unroll
     for (int c = 0; c < N; ++c) ax[c] = __builtin_elementwise_abs(x[c]);
 #pragma unroll
-    for (int c = 0; c < N; ++c) d[c] = __builtin_elementwise_fma(ax[c], f32x2{5.38297490e-6f, 5.38297490e-6f}, f32x2{4.88906371e-5f, 4.88906371e-5f});
+    for (int c = 0; c < N; ++c) d[c] = __builtin_elementwise_fma(ax[c], f32x2{MLPK_GELU_C6, MLPK_GELU_C6}, f32x2{MLPK_GELU_C5, MLPK_GELU_C5});
 #pragma unroll
-    for (int c = 0; c < N; ++c) d[c] = __builtin_elementwise_fma(d[c], ax[c], f32x2{3.80035744e-5f, 3.80035744e-5f});
+    for (int c = 0; c < N; ++c) d[c] = __builtin_elementwise_fma(d[c], ax[c], f32x2{MLPK_GELU_C4, MLPK_GELU_C4});
 #pragma unroll
-    for (int c = 0; c < N; ++c) d[c] = __builtin_elementwise_fma(d[c], ax[c], f32x2{3.27762635e-3f, 3.27762635e-3f});
+    for (int c = 0; c < N; ++c) d[c] = __builtin_elementwise_fma(d[c], ax[c], f32x2{MLPK_GELU_C3, MLPK_GELU_C3});
 #pragma unroll
-    for (int c = 0; c < N; ++c) d[c] = __builtin_elementwise_fma(d[c], ax[c], f32x2{2.11410057e-2f, 2.11410057e-2f});
+    for (int c = 0; c < N; ++c) d[c] = __builtin_elementwise_fma(d[c], ax[c], f32x2{MLPK_GELU_C2, MLPK_GELU_C2});
 #pragma unroll
-    for (int c = 0; c < N; ++c) d[c] = __builtin_elementwise_fma(d[c], ax[c], f32x2{4.98673469e-2f, 4.98673469e-2f});
+    for (int c = 0; c < N; ++c) d[c] = __builtin_elementwise_fma(d[c], ax[c], f32x2{MLPK_GELU_C1, MLPK_GELU_C1});
 #pragma unroll
-    for (int c = 0; c < N; ++c) d[c] = __builtin_elementwise_fma(d[c], ax[c], f32x2{1.0f, 1.0f});
+    for (int c = 0; c < N; ++c) d[c] = __builtin_elementwise_fma(d[c], ax[c], f32x2{MLPK_GELU_C0, MLPK_GELU_C0});
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int c = 0; c < N; ++c) d[c] = d[c] * d[c];
 #pragma unroll
-    for (int c = 0; c < N; ++c) r[c] = f32x2{__builtin_amdgcn_rcpf(d[c].x), __builtin_amdgcn_rcpf(d[c].y)};
+    for (int c = 0; c < N; ++c) d[c] = f32x2{__builtin_amdgcn_rcpf(d[c].x), __builtin_amdgcn_rcpf(d[c].y)};
 #pragma unroll
     for (int c = 0; c < N; ++c) {
-        const f32x2 h = x[c] * 0.5f;
-        const f32x2 ah = ax[c] * 0.5f;
-        x[c] = __builtin_elementwise_fma(-ah, r[c], h + ah);
+        const f32x2 relu = __builtin_elementwise_fma(x[c], f32x2{0.5f, 0.5f}, ax[c] * 0.5f);     // max(x, 0) = x/2 + |x|/2
+        x[c] = __builtin_elementwise_fma(-ax[c], d[c], relu);
     }
 }
 
-// scalar form of gelu_pk (the same operation sequence, hence bit-identical results)
+__device__ __forceinline__ f32x2 gelu_pk(f32x2 x) {
+    f32x2 v[1] = {x};
+    gelu_pk_n<1>(v);
+    return v[0];
+}
+
+// scalar form of gelu_pk (the same operation sequence, hence the same results)
 __device__ __forceinline__ float gelu16_f(float x) {
     const float ax = __builtin_fabsf(x);
-    float d = __builtin_fmaf(ax, 5.38297490e-6f, 4.88906371e-5f);
-    d = __builtin_fmaf(d, ax, 3.80035744e-5f);
-    d = __builtin_fmaf(d, ax, 3.27762635e-3f);
-    d = __builtin_fmaf(d, ax, 2.11410057e-2f);
-    d = __builtin_fmaf(d, ax, 4.98673469e-2f);
-    d = __builtin_fmaf(d, ax, 1.0f);
+    float d = __builtin_fmaf(ax, MLPK_GELU_C6, MLPK_GELU_C5);
+    d = __builtin_fmaf(d, ax, MLPK_GELU_C4);
+    d = __builtin_fmaf(d, ax, MLPK_GELU_C3);
+    d = __builtin_fmaf(d, ax, MLPK_GELU_C2);
+    d = __builtin_fmaf(d, ax, MLPK_GELU_C1);
+    d = __builtin_fmaf(d, ax, MLPK_GELU_C0);
     d = d * d;
     d = d * d;
     d = d * d;
     d = d * d;
     const float r = __builtin_amdgcn_rcpf(d);
-    const float h = x * 0.5f;
-    const float ah = ax * 0.5f;
-    return __builtin_fmaf(-ah, r, h + ah);
+    return __builtin_fmaf(-ax, r, __builtin_fmaf(x, 0.5f, ax * 0.5f));
 }
 
 template <typename T> __device__ __forceinline__ float gelu_t(float x) {

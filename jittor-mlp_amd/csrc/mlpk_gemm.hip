@@ -872,8 +872,11 @@ __device__ __forceinline__ void p8_store_tile(const GemmArgs& p, f32x4 (&acc)[8]
                 }
                 __builtin_memcpy(&outv, a8, 16);
             }
-            if (!(p.dbg & 2) || outv.x == 0x12345678u)
-                *reinterpret_cast<u32x4*>(C + (size_t)(m0 + hm * 128 + row) * p.ldc + gn) = outv;
+            if (!(p.dbg & 2) || outv.x == 0x12345678u) {
+                u32x4* dst = reinterpret_cast<u32x4*>(C + (size_t)(m0 + hm * 128 + row) * p.ldc + gn);
+                if (p.dbg & 32) __builtin_nontemporal_store(outv, dst);
+                else *dst = outv;
+            }
         }
         P8_PROF(hm * 4 + 2);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");

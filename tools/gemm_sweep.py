@@ -13,6 +13,8 @@ pkg = importlib.import_module("jittor-mlp_amd")
 E, N = pkg.engine, pkg._native
 dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[sys.argv[1] if len(sys.argv) > 1 else "bf16"]
 algos = [int(a) for a in sys.argv[2].split(",")] if len(sys.argv) > 2 else list(range(1, N.lib().mlpk_gemm_algo_count() + 1))
+dbgs = [int(a) for a in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0]
+only = sys.argv[4].split(",") if len(sys.argv) > 4 else None
 dev = "cuda:0"
 SHAPES = [  # name, M, N, K, token_t(t_rows, t_tokens) or None, gelu
     ("channel_fc1", 50176, 3072, 768, None, True),
@@ -33,6 +35,8 @@ SHAPES = [  # name, M, N, K, token_t(t_rows, t_tokens) or None, gelu
     ("gmlp_proj2", 50176, 256, 1536, None, False),
 ]
 for name, M, Nn, K, tt, gelu in SHAPES:
+    if only and name not in only:
+        continue
     A = (torch.rand((M, K), device=dev) * 2 - 1).to(dt)
     B = ((torch.rand((Nn, K), device=dev) * 2 - 1) / K ** 0.5).to(dt)
     bias = torch.rand(Nn, device=dev)
@@ -42,7 +46,8 @@ for name, M, Nn, K, tt, gelu in SHAPES:
     else:
         C = torch.zeros((M, Nn), dtype=dt, device=dev)
         kw = dict(R=C, res=N.RES_ADD) if not gelu else {}
-    for algo in algos:
+    for algo, dbgv in [(a, d) for a in algos for d in dbgs]:
+        kw["dbg"] = dbgv
         try:
             for _ in range(2):
                 E.gemm(A, B, C, M, Nn, K, bias=bias, act=N.ACT_GELU if gelu else 0, algo=algo, **kw)
@@ -55,7 +60,7 @@ for name, M, Nn, K, tt, gelu in SHAPES:
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / reps
-            print("%-12s M=%6d N=%4d K=%4d algo=%d  %8.3f ms  %7.1f TFLOP/s" % (name, M, Nn, K, algo, ms, 2.0 * M * Nn * K / ms / 1e9), flush=True)
+            print("%-12s M=%6d N=%4d K=%4d algo=%d dbg=%d  %8.3f ms  %7.1f TFLOP/s" % (name, M, Nn, K, algo, dbgv, ms, 2.0 * M * Nn * K / ms / 1e9), flush=True)
         except Exception as ex:  # noqa
             print(name, algo, "ERR", str(ex)[:80])
     del A, B, C
