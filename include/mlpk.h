@@ -122,9 +122,17 @@ typedef struct mlpk_gemm_desc {
     int32_t t_tokens;     /* TOKEN_T: tokens per image (row count of one image in C) */
     int32_t algo;         /* 0 auto; otherwise a tile-config id, see mlpk_gemm_algo_count */
     int32_t reserved;
+    /* Optional scratch (16-byte aligned, >= mlpk_gemm_workspace_bytes(), ZERO-FILLED once when allocated; the library
+       leaves its first 4 KiB zero after every launch).  With it the persistent tile shares the tiles of a partial last
+       round between several workgroups (split-K); without it (NULL / 0) every tile is computed by one workgroup.
+       One workspace must not be used by two launches that can run concurrently (different streams). */
+    void* workspace;
+    int64_t workspace_bytes;
 } mlpk_gemm_desc;
 
 int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream);
+/* size of the optional workspace for the current device */
+long long mlpk_gemm_workspace_bytes(void);
 /* number of tile configurations (valid algo ids are 1..count) and dynamic LDS bytes of one */
 int mlpk_gemm_algo_count(void);
 int mlpk_gemm_algo_info(int algo, int* bm, int* bn, int* threads, int* lds_bytes);

@@ -24,7 +24,8 @@ class GemmDesc(ctypes.Structure):
                 ("ln_mean", c_void_p), ("ln_rstd", c_void_p), ("ln_csum", c_void_p),
                 ("rperiod", ctypes.c_int32), ("act", ctypes.c_int32), ("res_mode", ctypes.c_int32),
                 ("out_mode", ctypes.c_int32), ("t_rows", ctypes.c_int32), ("t_tokens", ctypes.c_int32),
-                ("algo", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("algo", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("workspace", c_void_p), ("workspace_bytes", ctypes.c_int64)]
 
 
 class NormDesc(ctypes.Structure):
@@ -41,6 +42,7 @@ PROTOTYPES = {
     "mlpk_abi_version": (c_int, []),
     "mlpk_strerror": (ctypes.c_char_p, [c_int]),
     "mlpk_gemm_nt": (c_int, [ctypes.POINTER(GemmDesc), c_void_p]),
+    "mlpk_gemm_workspace_bytes": (ctypes.c_longlong, []),
     "mlpk_gemm_algo_count": (c_int, []),
     "mlpk_gemm_algo_info": (c_int, [c_int] + [ctypes.POINTER(c_int)] * 4),
     "mlpk_token_mlp_chunk": (c_int, []),
@@ -80,7 +82,7 @@ def lib():
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(handle, name)          # AttributeError if a declared symbol is not exported
             fn.restype, fn.argtypes = res, args
-        if handle.mlpk_abi_version() != 2:
+        if handle.mlpk_abi_version() != 3:
             raise MlpkError("libmlpk.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -39,6 +39,10 @@ struct GemmArgs {
     int rperiod, act, res_mode;
     int t_rows, t_tokens;
     int vec_c, vec_r;   // vector (4-element) store / residual-load allowed
+    // p8 split-K tail (see gemm_nt_p8_kernel): tiles >= tail_start are shared by tail_S workgroups each
+    float* ws_part;     // partial accumulators, 65536 floats per (tail tile, part > 0)
+    unsigned* ws_cnt;   // one arrival counter per tail tile (zero before and after every launch)
+    int tail_start, tail_S;
     int dbg_delay;      // de-phase sleep, units of 8128 cycles
     int dbg;            // tuning ablations (desc.reserved): 1 = no main loop, 2 = no stores, 4 = no epilogue
 };
@@ -907,12 +911,12 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_p8_kernel(const GemmArgs p) {
     const char* baseA = nullptr;
     const char* baseB = nullptr;
     unsigned voff[4][2];
-    auto setup = [&](const int v) {
+    auto setup = [&](const int v, const int slab0) {
         const int wg = xcd_remap(v, tiles_total);
         m0 = (wg / tiles_n) * BM;
         n0 = (wg % tiles_n) * BN;
-        baseA = reinterpret_cast<const char*>(p.A) + (size_t)m0 * p.lda * sizeof(T);
-        baseB = reinterpret_cast<const char*>(p.B) + (size_t)n0 * p.ldb * sizeof(T);
+        baseA = reinterpret_cast<const char*>(p.A) + ((size_t)m0 * p.lda + (size_t)slab0 * BK) * sizeof(T);
+        baseB = reinterpret_cast<const char*>(p.B) + ((size_t)n0 * p.ldb + (size_t)slab0 * BK) * sizeof(T);
         const int lr = lane >> 3;
         const int sc = (lane & 7) ^ lr;
 #pragma unroll
@@ -944,7 +948,23 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_p8_kernel(const GemmArgs p) {
     const int c0 = ((fg ^ (frow & 7)) << 4);               // chunk of k-substep 0; substep 1 is c0 ^ 64
     const int a_rd = (grp * 64 + frow) * 128 + c0;          // + half * HALF_B + i * 2048
     const int b_rd = 2 * HALF_B + (wn * 32 + frow) * 128 + c0;
-    const int nk = p.K / BK;                                // >= 2 (host checked)
+    const int nk_full = p.K / BK;                           // >= 2 (host checked)
+    // ---- work items of this workgroup: whole tiles v = blockIdx, + grid, ... below tail_start; then, when the tile
+    // count leaves a partial last round, ONE K-slice of a tail tile: the T_tail = total - tail_start leftover tiles are
+    // each shared by tail_S workgroups (split-K), parts 1.. hand their fp32 partial accumulators to part 0 through the
+    // workspace (release / acquire on a per-tile counter), part 0 adds them and runs the epilogue.  The partial
+    // round then costs about 1/tail_S of a main loop instead of a whole tile time on a fraction of the CUs.
+    const int n_whole = p.tail_S > 1 ? p.tail_start : tiles_total;
+    // the tail_S parts of a tail tile are workgroups of ONE XCD (blockIdx % 8, consecutive local indices): they run at
+    // the same clocks and reach the hand-over together (partners spread over XCDs kept part 0 waiting ~60k cycles)
+    const int xl = (int)blockIdx.x >> 3;                   // index inside the XCD
+    const int tail_grp = p.tail_S > 1 ? xl / p.tail_S : 0;
+    const int tail_part = p.tail_S > 1 ? xl % p.tail_S : 0;
+    const int tail_tile = tail_grp * 8 + ((int)blockIdx.x & 7);
+    const bool has_tail = p.tail_S > 1 && tail_grp < ((int)gridDim.x >> 3) / p.tail_S && p.tail_start + tail_tile < tiles_total;
+    const int tail_slab0 = (int)(((long long)nk_full * tail_part) / (p.tail_S > 1 ? p.tail_S : 1));
+    const int tail_nk = (int)(((long long)nk_full * (tail_part + 1)) / (p.tail_S > 1 ? p.tail_S : 1)) - tail_slab0;
+    int nk = nk_full;
 
     // tuning aid (dbg & 8): per-workgroup sums of [wait for first slabs | main loop | epilogue] in shader clocks
     unsigned long long tw = 0, tl = 0, te = 0, ts = 0;
@@ -961,8 +981,20 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_p8_kernel(const GemmArgs p) {
     }
 
     // ---- first tile: slab 0 complete before the loop, three half-tiles of slab 1 in flight ----
+    // The tail slice comes FIRST: its hand-over needs the partners' partial accumulators to be written back to memory,
+    // and at the end of the launch that write-back queues behind ~70 MB of freshly stored output (measured: part 0
+    // waited ~60k cycles); at the start of the launch the memory system is idle.
     int v = blockIdx.x;
-    setup(v);
+    bool in_tail = false;
+    if (has_tail) {
+        in_tail = true;
+        v = p.tail_start + tail_tile;
+        nk = tail_nk;
+        setup(v, tail_slab0);
+    } else {
+        if (v >= n_whole) return;
+        setup(v, 0);
+    }
     stage(0, 2); stage(0, 0); stage(0, 3); stage(0, 1);
     stage(1, 2); stage(1, 0); stage(1, 3);
 
@@ -1039,10 +1071,79 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_p8_kernel(const GemmArgs p) {
         if (stamp) { const unsigned long long n = __builtin_readcyclecounter(); tl += n - ts; ts = n; }
 
         const int cm0 = m0, cn0 = n0;
-        v += gridDim.x;
-        const bool more = v < tiles_total;                 // workgroup-uniform
+        const bool cur_tail = in_tail;
+        // next work item (workgroup-uniform): after the tail slice the whole tiles blockIdx, + grid, ...
+        bool more;
+        const int next_slab0 = 0;
+        if (in_tail) {
+            in_tail = false;
+            v = blockIdx.x;
+            more = v < n_whole;
+        } else {
+            v += gridDim.x;
+            more = v < n_whole;
+        }
+        const int next_nk = in_tail ? tail_nk : nk_full;
         GemmArgs q = p;
         if (stamp) { q.R = nullptr; q.res_mode = MLPK_RES_NONE; }
+        if (cur_tail) {
+            // ---- split-K hand-over (accumulator layout kept: [block][thread] float4, coalesced) ----
+            // L2s of different XCDs are not coherent with each other and the agent-scope fences that bridge them act on a
+            // WHOLE L2 (write back / invalidate), which is full of other tiles' operands and output.  Measured variants:
+            // every thread fencing + acquire-invalidate on the reader: launch 30-40 % slower; write-through (sc1) payload
+            // stores: ~55k cycles to retire 256 KiB per part.  Kept: plain payload stores, ONE release (L2 write-back)
+            // per writing workgroup on the flag atomic, and cache-bypassing (sc1) payload loads on the reader, so no L2
+            // is ever invalidated.
+            float* part = p.ws_part + ((size_t)tail_tile * (p.tail_S - 1)) * 65536;
+            if (tail_part > 0) {
+                float* dst = part + (size_t)(tail_part - 1) * 65536 + tid * 4;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        *reinterpret_cast<f32x4*>(dst + (i * 4 + j) * 2048) = acc[i][j];
+                __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): this wave's stores have reached the L2
+                __syncthreads();
+                if (tid == 0) __hip_atomic_fetch_add(p.ws_cnt + tail_tile, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                // no output from this part: on to its whole tiles (nothing was prefetched for them yet)
+                if (!more) break;
+                __syncthreads();
+                setup(v, 0);
+                stage(0, 2); stage(0, 0); stage(0, 3); stage(0, 1);
+                stage(1, 2); stage(1, 0); stage(1, 3);
+                nk = nk_full;
+                continue;
+            }
+            unsigned long long th0 = stamp ? __builtin_readcyclecounter() : 0;
+            if (tid == 0) {
+                // polled with a read-modify-write: it is performed at the coherence point, whereas a plain agent-scope
+                // load was seen to return this XCD's stale copy for ~60k cycles after the partners' increments
+                while (__hip_atomic_fetch_add(p.ws_cnt + tail_tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(p.tail_S - 1))
+                    __builtin_amdgcn_s_sleep(4);
+                __hip_atomic_store(p.ws_cnt + tail_tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
+            }
+            __syncthreads();
+            if (stamp) { const unsigned long long n = __builtin_readcyclecounter(); prof[0] += n - th0; th0 = n; }
+            for (int s2 = 0; s2 < p.tail_S - 1; ++s2) {
+                const float* src = part + (size_t)s2 * 65536 + tid * 4;
+                // 16 cache-bypassing loads in flight per round trip (the operand registers are free by now)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f32x4 t4[16];
+#pragma unroll
+                    for (int q2 = 0; q2 < 16; ++q2)
+                        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(t4[q2]) : "v"(src + (h * 16 + q2) * 2048) : "memory");
+                    asm volatile("s_waitcnt vmcnt(0)"
+                                 : "+v"(t4[0]), "+v"(t4[1]), "+v"(t4[2]), "+v"(t4[3]), "+v"(t4[4]), "+v"(t4[5]), "+v"(t4[6]), "+v"(t4[7]),
+                                   "+v"(t4[8]), "+v"(t4[9]), "+v"(t4[10]), "+v"(t4[11]), "+v"(t4[12]), "+v"(t4[13]), "+v"(t4[14]), "+v"(t4[15])
+                                 :
+                                 : "memory");
+#pragma unroll
+                    for (int q2 = 0; q2 < 16; ++q2) acc[(h * 16 + q2) >> 2][(h * 16 + q2) & 3] += t4[q2];
+                }
+            }
+            if (stamp) { const unsigned long long n = __builtin_readcyclecounter(); prof[1] += n - th0; }
+        }
         const bool fast = fast_ok && cm0 + BM <= p.M && cn0 + BN <= p.N;
         // opaque copy of the thread id: keeps the epilogue's address arithmetic inside this iteration (hoisted
         // out of the persistent loop it would sit in VGPRs through the main loop and spill)
@@ -1051,7 +1152,7 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_p8_kernel(const GemmArgs p) {
         if (fast) {
             // next tile's slab 0 streams into buffer 0 while this tile leaves through buffer 1
             if (more) {
-                setup(v);
+                setup(v, next_slab0);
                 stage(0, 2); stage(0, 0); stage(0, 3); stage(0, 1);
             }
             if constexpr (sizeof(T) == 2 && !TRANS) {
@@ -1074,13 +1175,14 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_p8_kernel(const GemmArgs p) {
             gemm_epilogue<T, BM, BN, 2, 4, TRANS, true>(q, acc, smem, cm0, cn0, etid);
             __syncthreads();
             if (more) {
-                setup(v);
+                setup(v, next_slab0);
                 stage(0, 2); stage(0, 0); stage(0, 3); stage(0, 1);
                 stage(1, 2); stage(1, 0); stage(1, 3);
             }
         }
         if (stamp) { const unsigned long long n = __builtin_readcyclecounter(); te += n - ts; ts = n; }
         if (!more) break;
+        nk = next_nk;
     }
     if (stamp && tid == 0) {
         unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<void*>(stamp_buf)) + (size_t)blockIdx.x * 64;
@@ -1162,10 +1264,37 @@ static int p8_grid_cap() {
     return cap;
 }
 
-template <typename T> static int launch_p8(const GemmArgs& a, bool trans, hipStream_t stream) {
+// Split-K plan of the partial last round: S workgroups per leftover tile (0 = no split).  Needs >= 2 slabs per part and a
+// workspace of mlpk_gemm_workspace_bytes().
+static int p8_tail_split(int total, int nk, int* tail_start) {
+    const int G = p8_grid_cap();
+    const int rem = total % G;
+    *tail_start = total - rem;
+    if (total <= G || rem == 0) return 0;
+    // every part must keep >= 8 slabs: below that the hand-over (2 x 256 KiB per extra part, through memory) and the
+    // un-split epilogue cost more than the main-loop time the split saves (measured on K = 768: slower)
+    int S = (G / 8) / ((rem + 7) / 8);                 // parts of a tile sit in one XCD: 8 x floor((G/8)/S) >= rem
+    if (S > nk / 8) S = nk / 8;
+    if (S > 8) S = 8;
+    return S >= 2 ? S : 0;
+}
+
+template <typename T> static int launch_p8(const GemmArgs& a0, bool trans, hipStream_t stream, void* ws, long long ws_bytes) {
+    GemmArgs a = a0;
     const int lds = 2 * 4 * 128 * 128;
     const int total = ((a.M + 255) / 256) * ((a.N + 255) / 256);
     const int tiles = total < p8_grid_cap() ? total : p8_grid_cap();     // persistent: one workgroup per CU
+    a.tail_S = 0; a.tail_start = total; a.ws_part = nullptr; a.ws_cnt = nullptr;
+    {
+        int ts = 0;
+        const int S = p8_tail_split(total, a.K / (128 / (int)sizeof(T)), &ts);
+        const long long need = S ? 4096 + (long long)(total - ts) * (S - 1) * 65536 * 4 : 0;
+        if (S && ws && ws_bytes >= need && !(a.dbg & 64)) {
+            a.tail_S = S; a.tail_start = ts;
+            a.ws_cnt = reinterpret_cast<unsigned*>(ws);
+            a.ws_part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + 4096);
+        }
+    }
     hipError_t e;
     if (trans) {
         auto k = gemm_nt_p8_kernel<T, true>;
@@ -1182,7 +1311,7 @@ template <typename T> static int launch_p8(const GemmArgs& a, bool trans, hipStr
     return 0;
 }
 
-template <typename T> static int launch_algo(int algo, const GemmArgs& a, bool trans, hipStream_t s) {
+template <typename T> static int launch_algo(int algo, const GemmArgs& a, bool trans, hipStream_t s, void* ws, long long ws_bytes) {
     switch (algo) {
         case 1: return launch_cfg<T, 256, 256, 2, 4, false>(a, trans, s);
         case 2: return launch_cfg<T, 256, 128, 4, 2, false>(a, trans, s);
@@ -1197,7 +1326,7 @@ template <typename T> static int launch_algo(int algo, const GemmArgs& a, bool t
         case 11: return launch_s3<T, 256, 128, 2, 2>(a, trans, s);
         case 12: return launch_s3<T, 128, 128, 2, 2>(a, trans, s);
         case 13: return launch_s3<T, 128, 256, 2, 2>(a, trans, s);
-        case 14: return launch_p8<T>(a, trans, s);
+        case 14: return launch_p8<T>(a, trans, s, ws, ws_bytes);
         default: return MLPK_EMODE;
     }
 }
@@ -1258,6 +1387,11 @@ extern "C" int mlpk_gemm_algo_info(int algo, int* bm, int* bn, int* threads, int
     return 0;
 }
 
+extern "C" long long mlpk_gemm_workspace_bytes(void) {
+    // counters (4 KiB) + at most (workgroups - 1) partial 256 x 256 fp32 accumulators
+    return 4096 + (long long)(p8_grid_cap() - 1) * 65536 * 4;
+}
+
 extern "C" int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream) {
     if (!d) return MLPK_ENULL;
     if (!d->A || !d->B || !d->C) return MLPK_ENULL;
@@ -1266,7 +1400,8 @@ extern "C" int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream) {
     const int es = d->dtype == MLPK_F32 ? 4 : 2;
     const int epc = 16 / es;
     if (d->K % epc || d->lda % epc || d->ldb % epc || d->lda < d->K || d->ldb < d->K) return MLPK_ESHAPE;
-    if (((uintptr_t)d->A & 15) || ((uintptr_t)d->B & 15)) return MLPK_EALIGN;
+    if (((uintptr_t)d->A & 15) || ((uintptr_t)d->B & 15) || ((uintptr_t)d->workspace & 15)) return MLPK_EALIGN;
+    if (d->workspace_bytes < 0 || (d->workspace_bytes > 0 && !d->workspace)) return MLPK_ENULL;
     if (d->act != MLPK_ACT_NONE && d->act != MLPK_ACT_GELU) return MLPK_EMODE;
     if (d->res_mode < MLPK_RES_NONE || d->res_mode > MLPK_RES_MUL) return MLPK_EMODE;
     if (d->res_mode != MLPK_RES_NONE && !d->R) return MLPK_ENULL;
@@ -1308,8 +1443,8 @@ extern "C" int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream) {
     if (kTiles[algo - 1].glds == 3 && (d->K % (8 * epc) != 0 || d->K < 16 * epc)) return MLPK_ESHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (d->dtype) {
-        case MLPK_F32: return launch_algo<float>(algo, a, trans, s);
-        case MLPK_F16: return launch_algo<f16_t>(algo, a, trans, s);
-        default: return launch_algo<bf16_t>(algo, a, trans, s);
+        case MLPK_F32: return launch_algo<float>(algo, a, trans, s, d->workspace, d->workspace_bytes);
+        case MLPK_F16: return launch_algo<f16_t>(algo, a, trans, s, d->workspace, d->workspace_bytes);
+        default: return launch_algo<bf16_t>(algo, a, trans, s, d->workspace, d->workspace_bytes);
     }
 }

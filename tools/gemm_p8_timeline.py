@@ -24,12 +24,10 @@ for _ in range(3):
     E.gemm(A, B, C, M, Nn, K, bias=bias, act=gelu, algo=14, R=dbg, res=0, dbg=8 | extra)
 torch.cuda.synchronize()
 t = dbg.cpu().numpy().astype(np.float64)
-per = t[:, :3] / t[:, 3:4]
-print("%s gelu=%d dbg+%d tiles %d, per-tile shader clocks (mean over workgroups of per-workgroup means)" % (which, gelu, extra, ntiles))
-for k, name in enumerate(("first-slab wait", "main loop", "epilogue")):
-    v = per[:, k]
-    print("  %-15s mean %8.1f  min %8.1f  max %8.1f" % (name, v.mean(), v.min(), v.max()))
-names = ["1a math+ds_write", "1a barrier", "2a lds->global", "2a barrier", "1b math+ds_write", "1b barrier", "2b lds->global", "2b barrier"]
-for k in range(8):
-    v = t[:, 4 + k] / t[:, 3]
-    print("    epilogue %-18s mean %8.1f" % (names[k], v.mean()))
+tot = t[:, :3].sum(axis=1)
+print("%s gelu=%d dbg+%d tiles %d: per-workgroup totals (shader clocks): wait %.0f  main %.0f  epilogue(+hand-over) %.0f  sum mean %.0f max %.0f" % (
+    which, gelu, extra, ntiles, t[:, 0].mean(), t[:, 1].mean(), t[:, 2].mean(), tot.mean(), tot.max()))
+if which == "fc2" and not (extra & 64):
+    w = np.arange(grid)
+    for name, m in (("part 0", ((w >> 3) < 30) & ((w >> 3) % 3 == 0)), ("part 1-2", ((w >> 3) < 30) & ((w >> 3) % 3 != 0)), ("no tail slice", (w >> 3) >= 30)):
+        print("  %-14s n=%3d  wait %.0f  main %.0f  epi+hand-over %.0f  total %.0f   [poll %.0f, partial reads %.0f]" % (name, m.sum(), t[m, 0].mean(), t[m, 1].mean(), t[m, 2].mean(), tot[m].mean(), t[m, 4].mean(), t[m, 5].mean()))
