@@ -17,8 +17,12 @@ template <> struct DwCfg<float> { static constexpr int CT = 16; };
 template <> struct DwCfg<f16_t> { static constexpr int CT = 32; };
 template <> struct DwCfg<bf16_t> { static constexpr int CT = 32; };
 
+// 512 threads: the tile's LDS footprint allows one workgroup per CU, and a SIMD holding a single wave issues a VALU
+// instruction only every ~5.5 cycles against ~2.7 with two (tools/ubench/issue_rate.hip) -- 8 waves, not 4.
+constexpr int DW_NT = 512;
+
 template <typename T, int KS>
-__global__ void __launch_bounds__(256) dwconv_lds_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int H, int W,
+__global__ void __launch_bounds__(DW_NT) dwconv_lds_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int H, int W,
                                                          int C, const float* __restrict__ w, const float* __restrict__ bias,
                                                          const float* __restrict__ bns, const float* __restrict__ bnh,
                                                          int pitch, int plane) {
@@ -39,13 +43,13 @@ __global__ void __launch_bounds__(256) dwconv_lds_kernel(const T* __restrict__ x
     {
         const int nvec = CT * plane / EPV;
         u32x4* t4 = reinterpret_cast<u32x4*>(tile);
-        for (int i = tid; i < nvec; i += 256) t4[i] = u32x4{0u, 0u, 0u, 0u};
+        for (int i = tid; i < nvec; i += DW_NT) t4[i] = u32x4{0u, 0u, 0u, 0u};
     }
     __syncthreads();
     {
         constexpr int CV = CT / EPV;                    // channel vectors per pixel
         const int total = H * W * CV;
-        for (int i = tid; i < total; i += 256) {
+        for (int i = tid; i < total; i += DW_NT) {
             const int cv = i % CV;
             const int px = i / CV;
             const int xx = px % W, yy = px / W;
@@ -62,30 +66,37 @@ __global__ void __launch_bounds__(256) dwconv_lds_kernel(const T* __restrict__ x
     }
     __syncthreads();
 
-    // ---- compute: thread -> channel cl = tid % CT, tasks (row, strip) = tid / CT + k * (256 / CT) ----
+    // ---- compute: thread -> channel cl = tid % CT, tasks (row, strip) = tid / CT + k * (DW_NT / CT) ----
     const int cl = tid % CT;
     const int c = c0 + cl;
     if (c >= C) return;
-    float wt[KS * KS];
+    // taps as register PAIRS (tap 2q, tap 2q+1): v_pk_fma_f32 broadcasts either half to both of its lanes through
+    // op_sel, so no tap is duplicated (81 duplicated pairs do not fit next to the window at two waves per SIMD)
+    constexpr int NT2 = (KS * KS + 1) / 2;
+    f32x2 wt2[NT2];
 #pragma unroll
-    for (int t = 0; t < KS * KS; ++t) wt[t] = w[(size_t)t * C + c];
+    for (int q = 0; q < NT2; ++q) {
+        wt2[q].x = w[(size_t)(2 * q) * C + c];
+        wt2[q].y = 2 * q + 1 < KS * KS ? w[(size_t)(2 * q + 1) * C + c] : 0.f;
+    }
     const float bs = bias ? bias[c] : 0.f;
     const float sc = bns ? bns[c] : 1.f, sh = bnh ? bnh[c] : 0.f;
     const int strips = (W + STRIP - 1) / STRIP;
     const int ntask = H * strips;
     const T* cplane = tile + cl * plane;
-    for (int task = tid / CT; task < ntask; task += 256 / CT) {
+    for (int task = tid / CT; task < ntask; task += DW_NT / CT) {
         const int st = task % strips, y = task / strips;
         const int x0 = st * STRIP;
-        float acc[STRIP];
+        // outputs as pairs (o, o+1); the window in two views, pairs starting at even and at odd columns
+        f32x2 acc2[STRIP / 2];
 #pragma unroll
-        for (int o = 0; o < STRIP; ++o) acc[o] = bs;
+        for (int o = 0; o < STRIP / 2; ++o) acc2[o] = f32x2{bs, bs};
         float centre[STRIP];
 #pragma unroll
         for (int dy = 0; dy < KS; ++dy) {
             // window row: padded columns x0 .. x0 + WIN - 1 of padded row y + dy (16-byte aligned: pitch % EPV == 0)
             const T* row = cplane + (y + dy) * pitch + x0;
-            float win[NV * EPV];
+            float win[NV * EPV + 1];
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const u32x4 raw = *reinterpret_cast<const u32x4*>(row + v * EPV);
@@ -94,19 +105,41 @@ __global__ void __launch_bounds__(256) dwconv_lds_kernel(const T* __restrict__ x
 #pragma unroll
                 for (int k = 0; k < EPV; ++k) win[v * EPV + k] = to_f32(e[k]);
             }
+            win[NV * EPV] = 0.f;
             if (dy == P) {
 #pragma unroll
                 for (int o = 0; o < STRIP; ++o) centre[o] = win[o + P];
             }
 #pragma unroll
-            for (int dx = 0; dx < KS; ++dx)
+            for (int dx = 0; dx < KS; ++dx) {
+                const int tap = dy * KS + dx;
 #pragma unroll
-                for (int o = 0; o < STRIP; ++o) acc[o] = __builtin_fmaf(wt[dy * KS + dx], win[o + dx], acc[o]);
+                for (int o = 0; o < STRIP / 2; ++o) {
+                    const f32x2 xin = {win[2 * o + dx], win[2 * o + dx + 1]};
+                    if (tap & 1) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc2[o]) : "v"(xin), "v"(wt2[tap >> 1]));
+                    else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc2[o]) : "v"(xin), "v"(wt2[tap >> 1]));
+                }
+            }
+        }
+        float acc[STRIP];
+#pragma unroll
+        for (int o = 0; o < STRIP / 2; ++o) { acc[2 * o] = acc2[o].x; acc[2 * o + 1] = acc2[o].y; }
+        if constexpr (sizeof(T) == 2) {
+            // 16-bit storage: the packed rcp-only GELU on four interleaved pairs (17 instructions per pair)
+            f32x2 g[STRIP / 2];
+#pragma unroll
+            for (int o = 0; o < STRIP / 2; ++o) g[o] = f32x2{acc[2 * o], acc[2 * o + 1]};
+            gelu_pk_n<STRIP / 2>(g);
+#pragma unroll
+            for (int o = 0; o < STRIP / 2; ++o) { acc[2 * o] = g[o].x; acc[2 * o + 1] = g[o].y; }
+        } else {
+#pragma unroll
+            for (int o = 0; o < STRIP; ++o) acc[o] = gelu_f(acc[o]);
         }
 #pragma unroll
         for (int o = 0; o < STRIP; ++o) {
             const int xx = x0 + o;
-            if (xx < W) out[(((size_t)b * H + y) * W + xx) * C + c] = from_f32<T>(centre[o] + gelu_f(acc[o]) * sc + sh);
+            if (xx < W) out[(((size_t)b * H + y) * W + xx) * C + c] = from_f32<T>(centre[o] + acc[o] * sc + sh);
         }
     }
 }
@@ -133,7 +166,7 @@ static int dwconv_lds_launch(int k, const void* x, void* out, int B, int H, int 
         auto kern = dwconv_lds_kernel<T, KS>;                                                                          \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return (int)e;                                                                            \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)x, (T*)out, B, H, W, C, w, bias, bns, bnh, pitch, plane); \
+        hipLaunchKernelGGL(kern, grid, dim3(DW_NT), lds, s, (const T*)x, (T*)out, B, H, W, C, w, bias, bns, bnh, pitch, plane); \
         break;                                                                                                         \
     }
     switch (k) {
