@@ -259,6 +259,87 @@ __global__ void __launch_bounds__(256) vip_permute_kernel(const VipArgs p) {
     }
 }
 
+// Fast path (seg % 4 == 0, C % 8 == 0, ld_p % 8 == 0): the slab is staged in LDS already in OUTPUT order
+// ([g][l][j], one padded row per group g), so the write-back is pure 16-byte LDS reads -> 16-byte global stores and the
+// read side is one 16-byte global load per 8 channels, split into two 4-channel pieces (a piece never straddles a
+// group because seg % 4 == 0).  gamma / beta sit in LDS; rows are padded by 32 bytes so that the pieces of neighbouring
+// groups fall on different banks.
+template <typename T>
+__global__ void __launch_bounds__(256) vip_permute_fast_kernel(const VipArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x;
+    const int L = p.which == 0 ? p.H : p.W;            // length of the mixed axis
+    const int O = p.which == 0 ? p.W : p.H;            // the fixed axis
+    const int img = blockIdx.x / O;
+    const int o = blockIdx.x % O;
+    const int G = p.C / p.seg;
+    const int rowb = p.ld_p * (int)sizeof(T) + 32;     // LDS bytes per group row
+    char* const slab = smem_raw;                       // [G][rowb]
+    float* const gb = reinterpret_cast<float*>(smem_raw + (size_t)G * rowb);   // gamma[C], beta[C]
+    const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+    for (int i = tid; i < p.C; i += 256) {
+        gb[i] = p.gamma ? p.gamma[i] : 1.0f;
+        gb[p.C + i] = p.beta ? p.beta[i] : 0.0f;
+    }
+    // zero the pad columns [L*seg, ld_p) of every group row
+    const int padn = p.ld_p - L * p.seg;
+    if (padn > 0) {
+        for (int i = tid; i < G * padn; i += 256) {
+            const int g = i / padn, k = i - g * padn;
+            *reinterpret_cast<T*>(slab + (size_t)g * rowb + (size_t)(L * p.seg + k) * sizeof(T)) = from_f32<T>(0.f);
+        }
+    }
+    __syncthreads();
+    const int cv = p.C / 8;
+    for (int idx = tid; idx < L * cv; idx += 256) {
+        const int l = idx / cv;
+        const int c = (idx - l * cv) * 8;
+        const int h = p.which == 0 ? l : o;
+        const int w = p.which == 0 ? o : l;
+        const int64_t r = ((int64_t)img * p.H + h) * p.W + w;
+        float v[8];
+        load8<T>(x + r * p.ldx + c, v);
+        float mu = 0.f, rs = 1.f;
+        if (p.mean) { mu = p.mean[r]; rs = p.rstd[r]; }
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gb + c), g1 = *reinterpret_cast<const f32x4*>(gb + c + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(gb + p.C + c), b1 = *reinterpret_cast<const f32x4*>(gb + p.C + c + 4);
+        const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        T e[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float t = (v[k] - mu) * rs * gm[k] + bt[k];
+            if (p.act == MLPK_ACT_GELU) t = gelu_t<T>(t);
+            e[k] = from_f32<T>(t);
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int cc = c + half * 4;
+            const int g = cc / p.seg;
+            const int j = cc - g * p.seg;
+            char* dst = slab + (size_t)g * rowb + (size_t)(l * p.seg + j) * sizeof(T);
+            if constexpr (sizeof(T) == 2) {
+                u32x2 t;
+                __builtin_memcpy(&t, e + half * 4, 8);
+                *reinterpret_cast<u32x2*>(dst) = t;
+            } else {
+                u32x4 t;
+                __builtin_memcpy(&t, e + half * 4, 16);
+                *reinterpret_cast<u32x4*>(dst) = t;
+            }
+        }
+    }
+    __syncthreads();
+    T* out = reinterpret_cast<T*>(p.out) + ((int64_t)img * O + o) * G * p.ld_p;
+    constexpr int EPV = 16 / (int)sizeof(T);
+    const int vpr = p.ld_p / EPV;                       // 16-byte vectors per group row
+    for (int i = tid; i < G * vpr; i += 256) {
+        const int g = i / vpr, k = i - g * vpr;
+        const u32x4 t = *reinterpret_cast<const u32x4*>(slab + (size_t)g * rowb + (size_t)k * 16);
+        *reinterpret_cast<u32x4*>(out + (size_t)g * p.ld_p + k * EPV) = t;
+    }
+}
+
 // inverse rearrange of the GEMM output z back to (B,H,W,C)
 template <typename T>
 __global__ void __launch_bounds__(256) vip_unpermute_kernel(const T* __restrict__ z, T* __restrict__ out, int B, int H,
@@ -448,9 +529,23 @@ extern "C" int mlpk_norm_apply(const mlpk_norm_desc* d, void* stream) {
         a.x = d->x; a.mean = d->mean; a.rstd = d->rstd; a.gamma = d->gamma; a.beta = d->beta; a.out = out;
         a.B = (int)(d->rows / ((int64_t)d->H * d->W)); a.H = d->H; a.W = d->W; a.C = d->C; a.seg = d->seg;
         a.ldx = d->ldx; a.ld_p = d->ld_p; a.which = which; a.act = d->act;
+        const unsigned grid = (unsigned)(a.B * (which == 0 ? d->W : d->H));
+        const int es_ = esize(d->dtype);
+        const size_t lds_fast = (size_t)(d->C / d->seg) * ((size_t)d->ld_p * es_ + 32) + (size_t)2 * d->C * 4;
+        const bool fast = d->seg % 4 == 0 && d->C % 8 == 0 && d->ld_p % 8 == 0 && (d->ld_p * es_) % 16 == 0 &&
+                          ((uintptr_t)out & 15) == 0 && lds_fast <= 160 * 1024;
+        if (fast) {
+            DISPATCH_DTYPE(d->dtype, {
+                auto k = vip_permute_fast_kernel<T>;
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast);
+                if (e != hipSuccess) return (int)e;
+                hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds_fast, s, a);
+            });
+            MLPK_LAUNCH_CHECK();
+            continue;
+        }
         const size_t lds = (size_t)L * d->C * esize(d->dtype);
         if (lds > 160 * 1024) return MLPK_ESHAPE;
-        const unsigned grid = (unsigned)(a.B * (which == 0 ? d->W : d->H));
         DISPATCH_DTYPE(d->dtype, {
             auto k = vip_permute_kernel<T>;
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
