@@ -36,8 +36,8 @@ template <typename T> __device__ __forceinline__ void store8(T* p, const float (
 
 // ================================ row statistics ================================
 // TPR threads per row (64 = one wave per row, 1024 = one 16-wave workgroup per row for GroupNorm-sized rows).  Two passes over the
-// row (the second one is served by L1/L2): mean, then centred sum of squares -- no E[x^2]-mu^2
-// cancellation, which matters for the fp32 1e-5 parity gate.
+// row: mean, then centred sum of squares -- no E[x^2]-mu^2 cancellation, which matters for the fp32 1e-5 parity
+// gate.  Rows of up to 2048 elements are held in registers between the passes; longer ones are re-read (L1/L2).
 template <typename T, int TPR>
 __global__ void __launch_bounds__(TPR == 64 ? 256 : TPR) row_stats_kernel(const T* __restrict__ x, int64_t rows, int64_t len,
                                                         int64_t ldx, float eps, float* __restrict__ mean,
@@ -63,6 +63,38 @@ __global__ void __launch_bounds__(TPR == 64 ? 256 : TPR) row_stats_kernel(const 
         return v;
     };
 
+    if constexpr (TPR == 64) {
+        // rows of up to 2048 elements stay in registers between the two passes: ONE trip to memory per element
+        if (vec && len <= 4 * 64 * 8) {
+            float v[4][8];
+            float s1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t i = (int64_t)t * 8 + k * 512;
+                if (i < len) {
+                    load8<T>(xr + i, v[k]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s1 += v[k][e];
+                }
+            }
+            const float mu1 = wave_sum(s1) / (float)len;
+            float q1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t i = (int64_t)t * 8 + k * 512;
+                if (i < len) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float d = v[k][e] - mu1; q1 += d * d; }
+                }
+            }
+            const float var1 = wave_sum(q1) / (float)len;
+            if (t == 0) {
+                mean[row] = mu1;
+                rstd[row] = 1.0f / __builtin_sqrtf(var1 + eps);
+            }
+            return;
+        }
+    }
     float s = 0.f;
     if (vec) {
         for (int64_t i = (int64_t)t * 8; i < len; i += TPR * 8) {
