@@ -146,6 +146,8 @@ template <typename T> __device__ __forceinline__ void store4(T* p, bool vec, con
     }
 }
 
+template <bool B> struct BoolK { static constexpr bool value = B; };
+
 // Shared epilogue: consumes the fp32 accumulator blocks of one workgroup tile (see the kernels for
 // the accumulator orientation) and writes C.  `smem` is the workgroup's LDS, free for staging once
 // every wave has passed the barrier that ends the main loop.
@@ -212,44 +214,66 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
                 rr0[q] = gm < p.M ? *reinterpret_cast<const u32x4*>(R + (size_t)gm * p.ldr + gn) : u32x4{0u, 0u, 0u, 0u};
             }
         }
+        // row parameters once per accumulator block row (not once per block): row scale, folded-LayerNorm mean / rstd
+        float rs_[FM], lmu_[FM], lrs_[FM];
 #pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int nl = cbase(j) + 4 * fg;            // column of this lane's 4-vector inside the tile
-            float bz[4], cs[4], ch[4], lc[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int n = n0 + nl + r;
-                n = n < p.N ? n : p.N - 1;
-                bz[r] = p.bias ? p.bias[n] : 0.f;
-                lc[r] = p.ln_mean ? p.ln_csum[n] : 0.f;
-                cs[r] = p.cscale ? p.cscale[n] : 1.f;
-                ch[r] = p.cshift ? p.cshift[n] : 0.f;
-            }
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int rl = rbase(i) + frow;
-                float rs = 1.f, lmu = 0.f, lrs = 1.f;
-                if (p.rscale || p.ln_mean) {
-                    int m = m0 + rl;
-                    m = m < p.M ? m : p.M - 1;
-                    if (p.rscale) rs = p.rscale[m % p.rperiod];
-                    if (p.ln_mean) { lmu = p.ln_mean[m]; lrs = p.ln_rstd[m]; }
-                }
-                float v[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
-                T e[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float t = (v[r] - lmu * lc[r]) * lrs + bz[r];
-                    if (gelu) t = gelu_t<T>(t);
-                    e[r] = from_f32<T>((t * cs[r] + ch[r]) * rs);
-                }
-                u32x2 pk;
-                __builtin_memcpy(&pk, e, 8);
-                const int c16 = nl >> 3;
-                char* dst = reinterpret_cast<char*>(tile) + rl * (BN * 2) + (((c16 ^ (rl & XM)) << 4) | ((nl & 4) << 1));
-                *reinterpret_cast<u32x2*>(dst) = pk;
+        for (int i = 0; i < FM; ++i) {
+            rs_[i] = 1.f; lmu_[i] = 0.f; lrs_[i] = 1.f;
+            if (p.rscale || p.ln_mean) {
+                int m = m0 + rbase(i) + frow;
+                m = m < p.M ? m : p.M - 1;
+                if (p.rscale) rs_[i] = p.rscale[m % p.rperiod];
+                if (p.ln_mean) { lmu_[i] = p.ln_mean[m]; lrs_[i] = p.ln_rstd[m]; }
             }
         }
+        // the element loop is instantiated with and without the activation (a per-element uniform branch around the
+        // GELU code costs more than the GELU's arithmetic); GELU runs on float pairs (v_pk_*)
+        auto phase1 = [&](auto gelu_c) {
+            constexpr bool GELU = decltype(gelu_c)::value;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int nl = cbase(j) + 4 * fg;            // column of this lane's 4-vector inside the tile
+                float bz[4], cs[4], ch[4], lc[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int n = n0 + nl + r;
+                    n = n < p.N ? n : p.N - 1;
+                    bz[r] = p.bias ? p.bias[n] : 0.f;
+                    lc[r] = p.ln_mean ? p.ln_csum[n] : 0.f;
+                    cs[r] = p.cscale ? p.cscale[n] : 1.f;
+                    ch[r] = p.cshift ? p.cshift[n] : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const int rl = rbase(i) + frow;
+                    const float rs = rs_[i], lmu = lmu_[i], lrs = lrs_[i];
+                    float v[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
+                    float t[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t[r] = (v[r] - lmu * lc[r]) * lrs + bz[r];
+                    if constexpr (GELU) {
+                        if constexpr (sizeof(T) == 2) {
+                            f32x2 g2[2] = {f32x2{t[0], t[1]}, f32x2{t[2], t[3]}};
+                            gelu_pk_n<2>(g2);
+                            t[0] = g2[0].x; t[1] = g2[0].y; t[2] = g2[1].x; t[3] = g2[1].y;
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) t[r] = gelu_f(t[r]);
+                        }
+                    }
+                    T e[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) e[r] = from_f32<T>((t[r] * cs[r] + ch[r]) * rs);
+                    u32x2 pk;
+                    __builtin_memcpy(&pk, e, 8);
+                    const int c16w = nl >> 3;
+                    char* dst = reinterpret_cast<char*>(tile) + rl * (BN * 2) + (((c16w ^ (rl & XM)) << 4) | ((nl & 4) << 1));
+                    *reinterpret_cast<u32x2*>(dst) = pk;
+                }
+            }
+        };
+        if (gelu) phase1(BoolK<true>{});
+        else phase1(BoolK<false>{});
         __syncthreads();
         if (fast) {
             // residual chunks of the remaining groups go in flight first, then each pass is LDS read ->
@@ -1351,7 +1375,11 @@ static int auto_algo(int M, int N, int K, int epc, bool glds_ok, bool p8_ok) {
             const double cap = (double)p8_grid_cap();
             const double rounds = (double)(long long)((tiles + cap - 1) / cap);
             const double kb = (double)K / epc * 16.0;          // bytes of K per row
-            const double eff = 1.5 * kb / (kb + 384.0);
+            double eff = 1.5 * kb / (kb + 384.0);
+            // ragged tiles leave the overlapped fast epilogue (whole 256 x 256 tiles only) and pad their MFMA work:
+            // N = 384, K = 1536 measured 0.113 ms against 0.087 ms for the 256 x 128 s3 tile
+            if (N % 256) eff *= 0.65;
+            if (M % 256) eff *= 0.95;
             const double cost = (tiles < cap ? tiles : rounds * cap) * area / eff * (tiles < cap ? cap / tiles : 1.0);
             if (cost < best) { best = cost; best_algo = i + 1; }
             continue;
