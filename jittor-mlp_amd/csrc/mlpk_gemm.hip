@@ -378,6 +378,72 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
     } else {
         // token-transposed output: lane owns token n = .. + (lane & 15) and 4 consecutive rows
         // m = .. + 4*(lane >> 4) + r, i.e. 4 consecutive channels of one image (t_rows % 4 == 0).
+        if constexpr (sizeof(T) == 2) {
+            // Whole tile inside one image: stage the finished values through LDS as [token][channel] so that global
+            // traffic (store, and the residual / gate operand) is 16 bytes per lane in whole BM-channel runs per token;
+            // the accumulator layout itself only gives 8-byte pieces in 32-byte runs.
+            const bool has_res = p.res_mode != MLPK_RES_NONE;
+            if (p.t_rows % BM == 0 && m0 + BM <= p.M && p.vec_c == 2 && (!has_res || p.vec_r == 2) && !(p.dbg & 2)) {
+                constexpr int CPT = BM / 8;                      // 16-byte chunks per token row
+                constexpr int XT = (CPT >= 16 ? 16 : CPT) - 1;
+                constexpr int TPP = NT / CPT;                    // tokens moved per pass
+                char* tile = smem;
+                const int img = m0 / p.t_rows;
+                const int c0 = m0 - img * p.t_rows;
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int nl = cbase(j) + frow;
+                    int n = n0 + nl;
+                    n = n < p.N ? n : p.N - 1;
+                    const float bn = p.bias ? p.bias[n] : 0.0f;
+                    const float cs = p.cscale ? p.cscale[n] : 1.0f;
+                    const float ch = p.cshift ? p.cshift[n] : 0.0f;
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) {
+                        const int ml = rbase(i) + 4 * fg;
+                        float v[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
+                        T e[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float t = v[r] + bn;
+                            if (gelu) t = gelu_t<T>(t);
+                            t = t * cs + ch;
+                            if (p.rscale) t *= p.rscale[(c0 + ml + r) % p.rperiod];
+                            e[r] = from_f32<T>(t);
+                        }
+                        u32x2 pk;
+                        __builtin_memcpy(&pk, e, 8);
+                        *reinterpret_cast<u32x2*>(tile + nl * (BM * 2) + ((((ml >> 3) ^ (nl & XT)) << 4) | ((ml & 4) << 1))) = pk;
+                    }
+                }
+                __syncthreads();
+                const int cc = tid % CPT;
+                const int tsub = tid / CPT;
+#pragma unroll 4
+                for (int ps = 0; ps < BN / TPP; ++ps) {
+                    const int nl = ps * TPP + tsub;
+                    const int n = n0 + nl;
+                    if (n >= p.N) continue;
+                    const u32x4 raw = *reinterpret_cast<const u32x4*>(tile + nl * (BM * 2) + ((cc ^ (nl & XT)) << 4));
+                    const size_t row = (size_t)img * p.t_tokens + n;
+                    u32x4 outv = raw;
+                    if (has_res) {
+                        const u32x4 rr = *reinterpret_cast<const u32x4*>(R + row * p.ldr + c0 + cc * 8);
+                        T a8[8], r8[8];
+                        __builtin_memcpy(a8, &raw, 16);
+                        __builtin_memcpy(r8, &rr, 16);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float a = to_f32(a8[e]), b = to_f32(r8[e]);
+                            a8[e] = from_f32<T>(p.res_mode == MLPK_RES_ADD ? a + b : a * b);
+                        }
+                        __builtin_memcpy(&outv, a8, 16);
+                    }
+                    *reinterpret_cast<u32x4*>(C + row * p.ldc + c0 + cc * 8) = outv;
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
             const int n = n0 + cbase(j) + frow;
@@ -604,7 +670,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) gemm_nt_s3_kernel(const GemmAr
     constexpr int A_G = BM / 16 / NW, B_G = BN / 16 / NW;  // 1-KiB pieces (16 rows x 64 B) per wave per slab
     constexpr int PIECES = A_G + B_G;
     static_assert(BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "tile rows must split into 16-row pieces per wave");
-    static_assert(3 * STAGE_B >= BM * BN * 2 || sizeof(T) != 2 || TRANS, "LDS too small for the staged epilogue");
+    static_assert(3 * STAGE_B >= BM * BN * 2 || sizeof(T) != 2, "LDS too small for the staged epilogue");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
