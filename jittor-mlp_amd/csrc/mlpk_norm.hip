@@ -144,6 +144,11 @@ template <typename T>
 __global__ void __launch_bounds__(256) norm_apply_tile_kernel(const NormArgs p) {
     constexpr int PITCH = 64 + 8;                 // elements; keeps 16-byte alignment of every row
     __shared__ __attribute__((aligned(16))) T tile[64 * PITCH];
+    // 16-bit types stage the transposed copy as [channel pair][token] 32-bit words, row pitch 66 words: the four
+    // 4-byte writes of a thread and the 8-byte reads of the transposed side are both bank-conflict free (the
+    // element-wise [token][channel] reads used for float measured 9.4M conflict cycles per launch)
+    constexpr int WP = 66;
+    uint32_t* tw = reinterpret_cast<uint32_t*>(tile);   // 32 pairs x 66 words = 8448 B <= sizeof(tile)
     const int tid = threadIdx.x;
     const int img = blockIdx.x / p.s_tiles;
     const int s0 = (blockIdx.x % p.s_tiles) * 64;
@@ -156,9 +161,24 @@ __global__ void __launch_bounds__(256) norm_apply_tile_kernel(const NormArgs p) 
     const bool c_ok = c < p.C;                    // C % 8 == 0, so a chunk is all-in or all-out
     float g[8], b[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        g[e] = (c_ok && p.gamma) ? p.gamma[c + e] : 1.0f;
-        b[e] = (c_ok && p.beta) ? p.beta[c + e] : 0.0f;
+    for (int e = 0; e < 8; ++e) { g[e] = 1.0f; b[e] = 0.0f; }
+    if (c_ok && p.gamma) {                           // two 16-byte loads each (torch allocations are 16-byte aligned, c % 8 == 0)
+        if ((reinterpret_cast<uintptr_t>(p.gamma) & 15) == 0) {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gamma + c), g1 = *reinterpret_cast<const f32x4*>(p.gamma + c + 4);
+            g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] = p.gamma[c + e];
+        }
+    }
+    if (c_ok && p.beta) {
+        if ((reinterpret_cast<uintptr_t>(p.beta) & 15) == 0) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.beta + c), b1 = *reinterpret_cast<const f32x4*>(p.beta + c + 4);
+            b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) b[e] = p.beta[c + e];
+        }
     }
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -185,10 +205,47 @@ __global__ void __launch_bounds__(256) norm_apply_tile_kernel(const NormArgs p) 
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = 0.f;   // token padding columns of out_tt are zeros
         }
-        if (out_tt) store8<T>(&tile[sl * PITCH + cl], v);
+        if (out_tt) {
+            if constexpr (sizeof(T) == 2) {
+                T e[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) e[k] = from_f32<T>(v[k]);
+                uint32_t w4[4];
+                __builtin_memcpy(w4, e, 16);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tw[((tid & 7) * 4 + k) * WP + sl] = w4[k];
+            } else {
+                store8<T>(&tile[sl * PITCH + cl], v);
+            }
+        }
     }
     if (!out_tt) return;
     __syncthreads();
+    if constexpr (sizeof(T) == 2) {
+        // transposed write: thread -> (channel pair tid >> 3, 8 consecutive tokens (tid & 7) * 8): four 8-byte LDS
+        // reads, the low / high halves of the 8 words are the 8 tokens of the even / odd channel
+        const int pr = tid >> 3;
+        const int sc = (tid & 7) * 8;
+        const int cch = c0 + pr * 2;
+        if (cch < p.C && s0 + sc < p.ld_tt) {
+            uint32_t w8[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u32x2 t2 = *reinterpret_cast<const u32x2*>(tw + pr * WP + sc + 2 * k);
+                w8[2 * k] = t2.x;
+                w8[2 * k + 1] = t2.y;
+            }
+            u32x4 lo, hi;
+            lo.x = __builtin_amdgcn_perm(w8[1], w8[0], 0x05040100u); hi.x = __builtin_amdgcn_perm(w8[1], w8[0], 0x07060302u);
+            lo.y = __builtin_amdgcn_perm(w8[3], w8[2], 0x05040100u); hi.y = __builtin_amdgcn_perm(w8[3], w8[2], 0x07060302u);
+            lo.z = __builtin_amdgcn_perm(w8[5], w8[4], 0x05040100u); hi.z = __builtin_amdgcn_perm(w8[5], w8[4], 0x07060302u);
+            lo.w = __builtin_amdgcn_perm(w8[7], w8[6], 0x05040100u); hi.w = __builtin_amdgcn_perm(w8[7], w8[6], 0x07060302u);
+            T* dst = out_tt + ((int64_t)img * p.C + cch) * p.ld_tt + s0 + sc;
+            *reinterpret_cast<u32x4*>(dst) = lo;
+            *reinterpret_cast<u32x4*>(dst + p.ld_tt) = hi;      // C % 8 == 0: the odd channel exists whenever the even one does
+        }
+        return;
+    }
     // transposed write: thread -> (channel cc, 8 consecutive tokens)
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
