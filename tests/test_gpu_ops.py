@@ -392,6 +392,72 @@ def test_gemm_p8_pingpong_tile(dtype):
             E.gemm(A, A, torch.zeros((64, 64), dtype=dtype, device=dev()), 64, 64, K, algo=14)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_gemm_p8_fast_epilogue_classes(dtype):
+    """The eight classes of the persistent tile's overlapped epilogue (GELU x folded LayerNorm x column scale/shift), with
+    and without a residual, on whole 256 x 256 tiles over several persistent rounds (tiles > CUs), against gemm_ref."""
+    pkg = load_pkg()
+    E = pkg.engine
+    M, Nn, K = 256 * 70, 256 * 4, 192                       # 280 tiles: two rounds on 256 CUs, ragged last round
+    A = rnd((M, K), dtype, 500).to(dev())
+    B = rnd((Nn, K), dtype, 501, 1.0 / math.sqrt(K)).to(dev())
+    bias = rnd((Nn,), torch.float32, 502).to(dev())
+    cs = (rnd((Nn,), torch.float32, 503) * 0.2 + 1).to(dev())
+    ch = rnd((Nn,), torch.float32, 504).to(dev())
+    R = rnd((M, Nn), dtype, 505).to(dev())
+    mean = rnd((M,), torch.float32, 506, 0.1).to(dev())
+    rstd = (rnd((M,), torch.float32, 507, 0.1) + 1.0).to(dev())
+    csum = B.float().sum(dim=1).contiguous()
+    for cls in range(8):
+        for res in (0, 1):
+            act = cls & 1
+            ln = (mean, rstd, csum) if cls & 2 else None
+            kw = dict(cscale=cs, cshift=ch) if cls & 4 else {}
+            C = torch.full((M, Nn), float("nan"), dtype=dtype, device=dev())
+            E.gemm(A, B, C, M, Nn, K, bias=bias, act=act, R=R if res else None, res=res, ln=ln, algo=14, **kw)
+            torch.cuda.synchronize()
+            acc = A.cpu().double() @ B.cpu().double().T
+            if ln is not None:
+                acc = (acc - mean.cpu().double()[:, None] * csum.cpu().double()[None, :]) * rstd.cpu().double()[:, None]
+            v = acc + bias.cpu().double()[None, :]
+            if act:
+                v = oracle.gelu(v)
+            if cls & 4:
+                v = v * cs.cpu().double()[None, :] + ch.cpu().double()[None, :]
+            if res:
+                v = v + R.cpu().double()
+            got = C.cpu().double()
+            assert torch.isfinite(got).all(), (str(dtype), cls, res)
+            err = (got - v).abs().max().item()
+            tol = EPS[dtype] * max(1.0, v.abs().max().item()) * 4
+            assert err < tol, (str(dtype), cls, res, err, tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("algo", [4, 12, 13, 14])
+def test_gemm_token_transposed_staged(dtype, algo):
+    """Token-transposed outputs whose tiles lie inside one image take the LDS-staged store path (16-byte stores and
+    gate / residual loads in whole channel runs): gate-multiply (gMLP SGU) and residual-add (ResMLP) forms."""
+    pkg = load_pkg()
+    E, N = pkg.engine, pkg._native
+    for ci, (nimg, t_rows, Nn, K, res) in enumerate([(3, 512, 196, 256, 2), (2, 768, 200, 128, 1), (2, 256, 49, 128, 1)]):
+        M = nimg * t_rows
+        A = rnd((M, K), dtype, 600 + ci).to(dev())
+        B = rnd((Nn, K), dtype, 610 + ci, 1.0 / math.sqrt(K)).to(dev())
+        bias = rnd((Nn,), torch.float32, 620 + ci).to(dev())
+        R = rnd((nimg * Nn, t_rows), dtype, 630 + ci).to(dev())
+        C = torch.full((nimg * Nn, t_rows), float("nan"), dtype=dtype, device=dev())
+        E.gemm(A, B, C, M, Nn, K, ldc=t_rows, bias=bias, R=R, ldr=t_rows, res=res, out_mode=N.OUT_TOKEN_T, t_rows=t_rows,
+               t_tokens=Nn, algo=algo)
+        torch.cuda.synchronize()
+        ref = gemm_ref(A.cpu(), B.cpu(), M, Nn, K, bias=bias.cpu(), R=R.cpu(), res=res, out_mode=1, t_rows=t_rows, t_tokens=Nn)
+        got = C.cpu().double().reshape(nimg, Nn, t_rows)
+        assert torch.isfinite(got).all(), (ci, "non-finite")
+        err = (got - ref).abs().max().item()
+        tol = EPS[dtype] * max(1.0, ref.abs().max().item()) * 6     # the staged path rounds before the residual / gate
+        assert err < tol, (str(dtype), algo, ci, err, tol)
+
+
 def test_gemm_p8_race_screen_bit_equal_to_s3():
     """The hand-scheduled LDS-DMA / barrier pipeline of algo 14 against the independent s3 tile (algo 13) on the
     channel-MLP shapes: both accumulate k in the same order, so every run must be BIT-equal."""
