@@ -1379,7 +1379,7 @@ template <typename T> static int launch_p8(const GemmArgs& a0, bool trans, hipSt
         int ts = 0;
         const int S = p8_tail_split(total, a.K / (128 / (int)sizeof(T)), &ts);
         const long long need = S ? 4096 + (long long)(total - ts) * (S - 1) * 65536 * 4 : 0;
-        if (S && ws && ws_bytes >= need && !(a.dbg & 64)) {
+        if (S && ws && ws_bytes >= need && (a.dbg & 128)) {      // opt-in (reserved & 128): see include/mlpk.h
             a.tail_S = S; a.tail_start = ts;
             a.ws_cnt = reinterpret_cast<unsigned*>(ws);
             a.ws_part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + 4096);

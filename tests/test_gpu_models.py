@@ -151,8 +151,10 @@ def test_batch_256_rows_match_small_batch():
     with torch.no_grad():
         big = model(x)
         small = model(x[100:104].contiguous())
+        last = model(x[252:256].contiguous())      # the last images sit in the partial last round of the persistent GEMM
     torch.cuda.synchronize()
     assert torch.equal(big[100:104], small)
+    assert torch.equal(big[252:256], last)
     # and against the CPU oracle on those four images
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
     ref = oracle.mixer_forward(sd, x[100:104].float().cpu())

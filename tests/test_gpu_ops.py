@@ -471,15 +471,15 @@ def test_gemm_p8_race_screen_bit_equal_to_s3():
         E.gemm(A, B, ref, M, Nn, K, bias=bias, act=1, algo=13)
         for run in range(6):
             C = torch.full((M, Nn), float("nan"), dtype=torch.bfloat16, device=dev())
-            E.gemm(A, B, C, M, Nn, K, bias=bias, act=1, algo=14, dbg=64)      # 64: no split-K of the last round
+            E.gemm(A, B, C, M, Nn, K, bias=bias, act=1, algo=14)
             torch.cuda.synchronize()
             assert torch.equal(C.view(torch.int16), ref.view(torch.int16)), (M, Nn, K, run, (C.float() - ref.float()).abs().max().item())
-        # with the partial last round split along K (the default) the tail tiles sum their K-slices in another order:
+        # with the partial last round split along K (opt-in, reserved & 128) the tail tiles sum their K-slices in another order:
         # equal to the one-workgroup result within an ulp of the storage type, and identical from run to run
         first = None
         for run in range(4):
             C = torch.full((M, Nn), float("nan"), dtype=torch.bfloat16, device=dev())
-            E.gemm(A, B, C, M, Nn, K, bias=bias, act=1, algo=14)
+            E.gemm(A, B, C, M, Nn, K, bias=bias, act=1, algo=14, dbg=128)
             torch.cuda.synchronize()
             d = (C.float() - ref.float()).abs()
             assert torch.isfinite(C.float()).all() and (d <= 2 ** -7 * ref.float().abs().clamp(min=2 ** -6)).all(), (M, Nn, K, run, d.max().item())
