@@ -919,31 +919,42 @@ __device__ __forceinline__ void p8_store_tile(const GemmArgs& p, f32x4 (&acc)[8]
         for (int i4 = 0; i4 < 4; ++i4) {
             const int sr = grp * 64 + i4 * 16 + frow;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int nl = (j >> 1) * 128 + wn * 32 + (j & 1) * 16 + 4 * fg;
-                const f32x4 a = acc[hm * 4 + i4][j];
-                f32x2 lo = {a.x, a.y}, hi = {a.z, a.w};
-                const f32x2 blo = {bz[j].x, bz[j].y}, bhi = {bz[j].z, bz[j].w};
-                if (LN) {
-                    const f32x2 nm = {-lmu[i4], -lmu[i4]}, rs = {lrs[i4], lrs[i4]};
-                    lo = __builtin_elementwise_fma(__builtin_elementwise_fma(nm, f32x2{lc[j].x, lc[j].y}, lo), rs, blo);
-                    hi = __builtin_elementwise_fma(__builtin_elementwise_fma(nm, f32x2{lc[j].z, lc[j].w}, hi), rs, bhi);
-                } else {
-                    lo = lo + blo;
-                    hi = hi + bhi;
+            for (int jp = 0; jp < 2; ++jp) {
+                // two accumulator blocks = four float pairs at a time: their GELU chains are interleaved step by step
+                // (gelu_pk_n<4>); one chain at a time leaves the wave waiting on its own previous instruction
+                f32x2 v[4];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = jp * 2 + jj;
+                    const f32x4 a = acc[hm * 4 + i4][j];
+                    f32x2 lo = {a.x, a.y}, hi = {a.z, a.w};
+                    const f32x2 blo = {bz[j].x, bz[j].y}, bhi = {bz[j].z, bz[j].w};
+                    if (LN) {
+                        const f32x2 nm = {-lmu[i4], -lmu[i4]}, rs = {lrs[i4], lrs[i4]};
+                        lo = __builtin_elementwise_fma(__builtin_elementwise_fma(nm, f32x2{lc[j].x, lc[j].y}, lo), rs, blo);
+                        hi = __builtin_elementwise_fma(__builtin_elementwise_fma(nm, f32x2{lc[j].z, lc[j].w}, hi), rs, bhi);
+                    } else {
+                        lo = lo + blo;
+                        hi = hi + bhi;
+                    }
+                    v[2 * jj] = lo;
+                    v[2 * jj + 1] = hi;
                 }
-                if (GELU) {
-                    lo = gelu_pk(lo);
-                    hi = gelu_pk(hi);
+                if (GELU) gelu_pk_n<4>(v);
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = jp * 2 + jj;
+                    const int nl = (j >> 1) * 128 + wn * 32 + (j & 1) * 16 + 4 * fg;
+                    f32x2 lo = v[2 * jj], hi = v[2 * jj + 1];
+                    if (AFF) {
+                        lo = __builtin_elementwise_fma(lo, f32x2{cs[j].x, cs[j].y}, f32x2{ch[j].x, ch[j].y});
+                        hi = __builtin_elementwise_fma(hi, f32x2{cs[j].z, cs[j].w}, f32x2{ch[j].z, ch[j].w});
+                    }
+                    T e[4] = {from_f32<T>(lo.x), from_f32<T>(lo.y), from_f32<T>(hi.x), from_f32<T>(hi.y)};
+                    u32x2 pk;
+                    __builtin_memcpy(&pk, e, 8);
+                    *reinterpret_cast<u32x2*>(stg + sr * 512 + ((((nl >> 3) ^ (sr & 15)) << 4) | ((nl & 4) << 1))) = pk;
                 }
-                if (AFF) {
-                    lo = __builtin_elementwise_fma(lo, f32x2{cs[j].x, cs[j].y}, f32x2{ch[j].x, ch[j].y});
-                    hi = __builtin_elementwise_fma(hi, f32x2{cs[j].z, cs[j].w}, f32x2{ch[j].z, ch[j].w});
-                }
-                T e[4] = {from_f32<T>(lo.x), from_f32<T>(lo.y), from_f32<T>(hi.x), from_f32<T>(hi.y)};
-                u32x2 pk;
-                __builtin_memcpy(&pk, e, 8);
-                *reinterpret_cast<u32x2*>(stg + sr * 512 + ((((nl >> 3) ^ (sr & 15)) << 4) | ((nl & 4) << 1))) = pk;
             }
         }
         P8_PROF(hm * 4 + 0);
