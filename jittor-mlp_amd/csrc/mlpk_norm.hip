@@ -37,7 +37,8 @@ template <typename T> __device__ __forceinline__ void store8(T* p, const float (
 // ================================ row statistics ================================
 // TPR threads per row (64 = one wave per row, 1024 = one 16-wave workgroup per row for GroupNorm-sized rows).  Two passes over the
 // row: mean, then centred sum of squares -- no E[x^2]-mu^2 cancellation, which matters for the fp32 1e-5 parity
-// gate.  Rows of up to 2048 elements are held in registers between the passes; longer ones are re-read (L1/L2).
+// gate.  Rows of up to 2048 elements are held in registers between the passes; rows up to 4096 are re-read (L1/L2);
+// longer ones (one workgroup per row) are read once with pivoted sums, see below.
 template <typename T, int TPR>
 __global__ void __launch_bounds__(TPR == 64 ? 256 : TPR) row_stats_kernel(const T* __restrict__ x, int64_t rows, int64_t len,
                                                         int64_t ldx, float eps, float* __restrict__ mean,
@@ -95,9 +96,61 @@ __global__ void __launch_bounds__(TPR == 64 ? 256 : TPR) row_stats_kernel(const 
             return;
         }
     }
+    if constexpr (TPR != 64) {
+        // Long rows (GroupNorm over C*H*W: 0.6 MB per row, 154 MB per call) are HBM-bound and do not fit the L2, so they are
+        // read ONCE: sums of d = x - K and d^2 around a pivot K = x[row][0] (var = (q - s^2/n)/n cancels only as far as the
+        // pivot is from the mean, i.e. by ~1 + (mean-K)^2/var ulps), four independent 16-byte loads in flight per thread.
+        if (vec) {
+            const float K = to_f32(xr[0]);
+            float s1 = 0.f, q1 = 0.f;
+            int64_t i = (int64_t)t * 8;
+            for (; i + 3 * (int64_t)TPR * 8 < len; i += 4 * (int64_t)TPR * 8) {
+                float v0[8], v1[8], v2[8], v3[8];
+                load8<T>(xr + i, v0);
+                load8<T>(xr + i + (int64_t)TPR * 8, v1);
+                load8<T>(xr + i + 2 * (int64_t)TPR * 8, v2);
+                load8<T>(xr + i + 3 * (int64_t)TPR * 8, v3);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d0 = v0[e] - K, d1 = v1[e] - K, d2 = v2[e] - K, d3 = v3[e] - K;
+                    s1 += (d0 + d1) + (d2 + d3);
+                    q1 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                }
+            }
+            for (; i < len; i += TPR * 8) {
+                float v[8];
+                load8<T>(xr + i, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[e] - K; s1 += d; q1 += d * d; }
+            }
+            const float S1 = block_sum(s1);
+            const float Q1 = block_sum(q1);
+            const float n = (float)len;
+            const float dm = S1 / n;
+            float var1 = (Q1 - S1 * dm) / n;
+            var1 = var1 > 0.f ? var1 : 0.f;
+            if (t == 0) {
+                mean[row] = K + dm;
+                rstd[row] = 1.0f / __builtin_sqrtf(var1 + eps);
+            }
+            return;
+        }
+    }
     float s = 0.f;
     if (vec) {
-        for (int64_t i = (int64_t)t * 8; i < len; i += TPR * 8) {
+        // four independent 16-byte loads in flight per thread: one workgroup per (long) row means one workgroup per
+        // CU, and with a single load per thread the row streams at memory LATENCY (measured 2 TB/s on GroupNorm rows)
+        int64_t i = (int64_t)t * 8;
+        for (; i + 3 * (int64_t)TPR * 8 < len; i += 4 * (int64_t)TPR * 8) {
+            float v0[8], v1[8], v2[8], v3[8];
+            load8<T>(xr + i, v0);
+            load8<T>(xr + i + (int64_t)TPR * 8, v1);
+            load8<T>(xr + i + 2 * (int64_t)TPR * 8, v2);
+            load8<T>(xr + i + 3 * (int64_t)TPR * 8, v3);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += (v0[e] + v1[e]) + (v2[e] + v3[e]);
+        }
+        for (; i < len; i += TPR * 8) {
             float v[8];
             load8<T>(xr + i, v);
 #pragma unroll
@@ -109,7 +162,20 @@ __global__ void __launch_bounds__(TPR == 64 ? 256 : TPR) row_stats_kernel(const 
     const float mu = block_sum(s) / (float)len;
     float q = 0.f;
     if (vec) {
-        for (int64_t i = (int64_t)t * 8; i < len; i += TPR * 8) {
+        int64_t i = (int64_t)t * 8;
+        for (; i + 3 * (int64_t)TPR * 8 < len; i += 4 * (int64_t)TPR * 8) {
+            float v0[8], v1[8], v2[8], v3[8];
+            load8<T>(xr + i, v0);
+            load8<T>(xr + i + (int64_t)TPR * 8, v1);
+            load8<T>(xr + i + 2 * (int64_t)TPR * 8, v2);
+            load8<T>(xr + i + 3 * (int64_t)TPR * 8, v3);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d0 = v0[e] - mu, d1 = v1[e] - mu, d2 = v2[e] - mu, d3 = v3[e] - mu;
+                q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+        }
+        for (; i < len; i += TPR * 8) {
             float v[8];
             load8<T>(xr + i, v);
 #pragma unroll

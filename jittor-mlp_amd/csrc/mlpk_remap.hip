@@ -49,6 +49,42 @@ __global__ void __launch_bounds__(256) shift_nhwc_kernel(const T* __restrict__ i
     }
 }
 
+// 16-bit types, C % 8 == 0: one thread moves 8 channels (16 bytes).  A vector that straddles two shift groups is
+// assembled from the two source positions; 32-bit index arithmetic (one division pair per 16 bytes, not per element).
+template <typename T>
+__global__ void __launch_bounds__(256) shift_nhwc_vec_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H,
+                                                             int W, int C, int ksz, int dim) {
+    const int CV = C / 8;
+    const unsigned total = (unsigned)N * H * W * CV;
+    const int group = (C + ksz - 1) / ksz;
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const unsigned px = idx / CV;                       // pixel (n, h, w)
+        const int c = (int)(idx - px * CV) * 8;
+        const int w = (int)(px % W);
+        const int h = (int)((px / W) % H);
+        const int g0 = c / group, g1 = (c + 7) / group;
+        const int pos = dim == 2 ? h : w, lim = dim == 2 ? H : W;
+        const int step = dim == 2 ? W * C : C;
+        const T* src = in + (size_t)px * C + c;
+        const int s0 = ksz / 2 - g0;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (pos + s0 >= 0 && pos + s0 < lim) v = *reinterpret_cast<const u32x4*>(src + (ptrdiff_t)s0 * step);
+        if (g1 != g0) {
+            const int s1 = ksz / 2 - g1;
+            u32x4 v1 = {0u, 0u, 0u, 0u};
+            if (pos + s1 >= 0 && pos + s1 < lim) v1 = *reinterpret_cast<const u32x4*>(src + (ptrdiff_t)s1 * step);
+            T a[8], b[8];
+            __builtin_memcpy(a, &v, 16);
+            __builtin_memcpy(b, &v1, 16);
+            const int first1 = g1 * group - c;              // first element of the vector that belongs to group g1
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = e >= first1 ? b[e] : a[e];
+            __builtin_memcpy(&v, a, 16);
+        }
+        *reinterpret_cast<u32x4*>(out + (size_t)px * C + c) = v;
+    }
+}
+
 // ================================ S2 spatial shifts ================================
 // Tensor (B, D1, D2, C).  Channel quarters as the slices of s2_mlp_v2.py:17-20.
 // which = 1: spatial_shift1 -> (d1,+1),(d1,-1),(d2,+1),(d2,-1); which = 2: spatial_shift2 ->
@@ -369,8 +405,15 @@ extern "C" int mlpk_shift_nhwc(int dtype, const void* in, void* out, int N, int 
     if (int e = shift_check(kernel_size, dim)) return e;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int64_t total = (int64_t)N * C * H * W;
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((shift_nhwc_kernel<T>), dim3(grid_for(total)), dim3(256), 0, s,
-                                             (const T*)in, (T*)out, N, H, W, C, kernel_size, dim));
+    const int group = (C + kernel_size - 1) / kernel_size;
+    if (dtype != MLPK_F32 && C % 8 == 0 && group >= 8 && total / 8 < 0x7fffffffLL && (((uintptr_t)in | (uintptr_t)out) & 15) == 0) {
+        // (group >= 8: an 8-channel vector touches at most two shift groups)
+        DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((shift_nhwc_vec_kernel<T>), dim3(grid_for(total / 8)), dim3(256), 0, s,
+                                                 (const T*)in, (T*)out, N, H, W, C, kernel_size, dim));
+    } else {
+        DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((shift_nhwc_kernel<T>), dim3(grid_for(total)), dim3(256), 0, s,
+                                                 (const T*)in, (T*)out, N, H, W, C, kernel_size, dim));
+    }
     MLPK_LAUNCH_CHECK();
     return 0;
 }

@@ -33,6 +33,10 @@ SHAPES = [  # name, M, N, K, token_t(t_rows, t_tokens) or None, gelu
     ("s2_mlp1", 262144, 576, 192, None, False),
     ("s2_fc1", 65536, 1152, 384, None, True),
     ("gmlp_proj2", 50176, 256, 1536, None, False),
+    ("vip_fc1", 262144, 1152, 384, None, True),
+    ("vip_fc2", 262144, 384, 1152, None, False),
+    ("s2_mlp2", 262144, 192, 192, None, False),
+    ("s2_fc2", 65536, 384, 1152, None, False),
 ]
 for name, M, Nn, K, tt, gelu in SHAPES:
     if only and name not in only:
