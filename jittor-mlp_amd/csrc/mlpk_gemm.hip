@@ -1470,7 +1470,11 @@ static int auto_algo(int M, int N, int K, int epc, bool glds_ok, bool p8_ok) {
         const double slots = area >= 256 * 256 ? 256.0 : area >= 128 * 128 ? 512.0 : 1024.0;
         // 128 x 256 (wave tile 64 x 128) measured 2-8 % ahead of 256 x 128 on the channel-MLP shapes
         const double eff = area >= 256 * 128 ? (t.bn > t.bm ? 1.0 : 0.97) : area >= 128 * 128 ? 0.9 : 0.45;
-        const double cost = tiles * area / eff * (1.0 + 0.5 * slots / tiles);
+        // (tiles + 256): a soft tail for grids that do not fill the CUs many times over; the same constant for every
+        // tile size, so that a problem of a few tiles (the M = batch GEMMs of SplitAttention) is costed by the time of
+        // ONE tile, area / eff, and gets the small tile (128 x 128 fp32 tiles took 38 us for 75 MFLOP)
+        (void)slots;
+        const double cost = area / eff * (tiles + 256.0);
         if (cost < best) { best = cost; best_algo = i + 1; }
     }
     return best_algo;
