@@ -119,10 +119,18 @@ template <typename T> __device__ __forceinline__ float gelu_t(float x) {
     else return gelu_f(x);
 }
 
+// Sum over the 64 lanes of a wave, result in every lane.  DPP row operations (6 VALU instructions + one readlane)
+// instead of six __shfl_xor, which compile to ds_bpermute_b32 round trips through the LDS crossbar.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    // within each row of 16 lanes: xor 1, xor 2 (quad_perm), then half-mirror / mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    // every lane of a row now holds the row's sum: add rows 0+1 and 2+3, then the two halves
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, true));   // row_bcast15 -> rows 1, 3
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, true));   // row_bcast31 -> rows 2, 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // Bijective XCD-aware block remap (8 XCDs, block b runs on XCD b % 8): gives every XCD a
