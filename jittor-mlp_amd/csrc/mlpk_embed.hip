@@ -42,6 +42,25 @@ __global__ void __launch_bounds__(256) patchify_kernel(const PatchArgs p) {
 #pragma unroll
                 for (int t = 0; t < 8; ++t) e[t] = from_f32<TD>(0.f);
             }
+        } else if (p.layout == MLPK_LAYOUT_NCHW && (p.pw & 7) == 0 && p.pad == 0 && (p.W & 7) == 0 && k0 < p.K &&
+                   (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+            // 8 consecutive k = 8 consecutive pixels of one image row of one channel: 16-byte loads
+            const int ci = k0 / (p.ph * p.pw);
+            const int rem = k0 - ci * (p.ph * p.pw);
+            const int i = rem / p.pw;
+            const int j = rem - i * p.pw;
+            const TS* s = src + (((int64_t)b * p.Cin + ci) * p.H + (hp * p.ph + i)) * p.W + wp * p.pw + j;
+            if constexpr (sizeof(TS) == 4) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(s), a1 = *reinterpret_cast<const f32x4*>(s + 4);
+                e[0] = from_f32<TD>(a0.x); e[1] = from_f32<TD>(a0.y); e[2] = from_f32<TD>(a0.z); e[3] = from_f32<TD>(a0.w);
+                e[4] = from_f32<TD>(a1.x); e[5] = from_f32<TD>(a1.y); e[6] = from_f32<TD>(a1.z); e[7] = from_f32<TD>(a1.w);
+            } else {
+                const u32x4 raw = *reinterpret_cast<const u32x4*>(s);
+                TS t8[8];
+                __builtin_memcpy(t8, &raw, 16);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) e[t] = from_f32<TD>(to_f32(t8[t]));
+            }
         } else {
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
