@@ -5,6 +5,7 @@
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define REP 64
 template <int MODE>
 __global__ void __launch_bounds__(512) k(float* out, unsigned long long* cyc, int iters) {
@@ -14,6 +15,8 @@ __global__ void __launch_bounds__(512) k(float* out, unsigned long long* cyc, in
     float s[8];
     for (int i = 0; i < 8; ++i) s[i] = threadIdx.x * 0.5f + i;
     f32x4 acc[4] = {};
+    f32x4 acc16[16] = {};
+    f32x16 big[4] = {};
     bf16x8 fa = {}, fb = {};
     unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
@@ -50,6 +53,64 @@ __global__ void __launch_bounds__(512) k(float* out, unsigned long long* cyc, in
 #pragma unroll
                     for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
                 }
+            } else if (MODE == 8) {   // mfma 16x16x32, 16 independent accumulators (the p8 phase)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc16[(r & 1) * 8 + i]) : "v"(fa), "v"(fb));
+            } else if (MODE == 9) {   // mfma 32x32x16, 4 independent accumulators
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(big[i & 3]) : "v"(fa), "v"(fb));
+            } else if (MODE == 10 || MODE == 11) {   // ping-pong mimic: waves 0-3 mfma, waves 4-7 ds_read_b128
+                if ((threadIdx.x >> 8) == 0) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        if (MODE == 10) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc16[(r & 1) * 8 + i]) : "v"(fa), "v"(fb));
+                        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(big[i & 3]) : "v"(fa), "v"(fb));
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { f32x4 v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"((unsigned)(threadIdx.x & 63) * 16u), "n"(0)); asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); asm volatile("" :: "v"(v)); }
+                }
+            } else if (MODE == 12 || MODE == 13 || MODE == 14) {   // as 10, accumulators in AGPRs (12), reads into AGPRs (13), both (14)
+                if ((threadIdx.x >> 8) == 0) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        if (MODE == 13) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc16[(r & 1) * 8 + i]) : "v"(fa), "v"(fb));
+                        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc16[(r & 1) * 8 + i]) : "v"(fa), "v"(fb));
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        f32x4 v;
+                        if (MODE == 12) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"((unsigned)(threadIdx.x & 63) * 16u), "n"(0));
+                        else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(v) : "v"((unsigned)(threadIdx.x & 63) * 16u), "n"(0));
+                        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                        if (MODE == 12) asm volatile("" :: "v"(v)); else asm volatile("" :: "a"(v));
+                    }
+                }
+            } else if (MODE == 15) {   // as 10 with ds_read_b64 (half the bytes per instruction)
+                if ((threadIdx.x >> 8) == 0) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc16[(r & 1) * 8 + i]) : "v"(fa), "v"(fb));
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { f32x2 v; asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"((unsigned)(threadIdx.x & 63) * 8u), "n"(0)); asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); asm volatile("" :: "v"(v)); }
+                }
+            } else if (MODE >= 16 && MODE <= 20) {   // MFMA wave | other wave: 16 setprio+ds_read, 17 reads without waits, 18 s_nop, 19 salu, 20 s_sleep
+                if ((threadIdx.x >> 8) == 0) {
+                    if (MODE == 16) asm volatile("s_setprio 3");
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc16[(r & 1) * 8 + i]) : "v"(fa), "v"(fb));
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        if (MODE == 16) { f32x4 v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"((unsigned)(threadIdx.x & 63) * 16u), "n"(0)); asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); asm volatile("" :: "v"(v)); }
+                        if (MODE == 17) { f32x4 v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"((unsigned)(threadIdx.x & 63) * 16u), "n"(0)); asm volatile("" :: "v"(v)); }
+                        if (MODE == 18) asm volatile("s_nop 7");
+                        if (MODE == 19) asm volatile("s_add_u32 s20, s20, 1" ::: "s20");
+                        if (MODE == 20) asm volatile("s_sleep 2");
+                    }
+                    if (MODE == 17) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
             } else if (MODE == 7) {   // ds_read_b128, conflict-free lane-linear
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { f32x4 v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"((unsigned)(threadIdx.x & 63) * 16u), "n"(0)); acc[i & 3] += v; }
@@ -59,7 +120,8 @@ __global__ void __launch_bounds__(512) k(float* out, unsigned long long* cyc, in
     unsigned long long t1 = __builtin_readcyclecounter();
     float r = 0;
     for (int i = 0; i < 8; ++i) r += a[i].x + a[i].y + s[i];
-    for (int i = 0; i < 4; ++i) r += acc[i].x;
+    for (int i = 0; i < 4; ++i) r += acc[i].x + big[i][0];
+    for (int i = 0; i < 16; ++i) r += acc16[i].x;
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
 }
@@ -89,7 +151,20 @@ int main() {
         run<4>("v_mfma_16x16x32_bf16", thr);
         run<5>("1 mfma + 3 pk_fma", thr);
         run<7>("ds_read_b128 + 4 v_add", thr);
+        run<8>("v_mfma_16x16x32_bf16 (16 accs)", thr);
+        run<9>("v_mfma_32x32x16_bf16 (4 accs)", thr);
     }
+    run<10>("split: w0-3 mfma16 | w4-7 ds_read", 512);
+    run<11>("split: w0-3 mfma32 | w4-7 ds_read", 512);
+    run<12>("split: mfma16 acc=AGPR | ds_read", 512);
+    run<13>("split: mfma16 | ds_read -> AGPR", 512);
+    run<14>("split: mfma16 acc=AGPR | ds_read->AGPR", 512);
+    run<15>("split: mfma16 | ds_read_b64", 512);
+    run<16>("split: mfma16 prio3 | ds_read", 512);
+    run<17>("split: mfma16 | ds_read x8, 1 wait", 512);
+    run<18>("split: mfma16 | s_nop 7", 512);
+    run<19>("split: mfma16 | s_add_u32", 512);
+    run<20>("split: mfma16 | s_sleep 2", 512);
     run<6>("split: w0-3 mfma | w4-7 pk_fma", 512);
     return 0;
 }
