@@ -111,6 +111,26 @@ __global__ void __launch_bounds__(512) k(float* out, unsigned long long* cyc, in
                     }
                     if (MODE == 17) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
+            } else if (MODE == 21 || MODE == 22 || MODE == 23) {   // 32x32x16 with 1 / 2 / 3 accumulators in rotation (dependent chains)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(big[MODE == 21 ? 0 : MODE == 22 ? (i & 1) : (i % 3)]) : "v"(fa), "v"(fb));
+            } else if (MODE == 24 || MODE == 25) {   // 16x16x32 with 1 / 2 accumulators
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc16[MODE == 24 ? 0 : (i & 1)]) : "v"(fa), "v"(fb));
+            } else if (MODE >= 30 && MODE <= 36) {   // ds_read_b128 address patterns of the p8 tile (128-byte rows, chunk ^ (row & 7))
+                const unsigned l = threadIdx.x & 63;
+                unsigned addr;
+                if (MODE == 30) { const unsigned row = l & 15; addr = row * 128 + (((l >> 4) ^ (row & 7)) << 4); }          // 16x16x32 operand
+                else if (MODE == 31) { const unsigned row = l & 31; addr = row * 128 + (((l >> 5) ^ (row & 7)) << 4); }     // 32x32x16 operand
+                else if (MODE == 32) { const unsigned row = l & 31; addr = row * 128 + ((((l >> 5) ^ (row & 7)) ^ ((row >> 3) & 1) * 2) << 4); }   // + row bit 3 into chunk bit 1
+                else if (MODE == 33) { const unsigned row = l & 31; addr = row * 128 + ((((l >> 5) ^ (row & 7)) ^ ((row >> 3) & 3) * 2) << 4); }                 // + row bits 3,4 into chunk bits 1,2
+                else if (MODE == 34) { const unsigned row = l & 31; addr = row * 128 + ((((l >> 5) ^ (row & 7)) ^ ((row >> 4) & 1)) << 4); }     // + row bit 4 into chunk bit 0
+                else if (MODE == 35) { const unsigned row = l & 31; addr = row * 128 + ((((l >> 5) ^ (row & 7)) ^ ((row >> 3) & 1)) << 4); }     // + row bit 3 into chunk bit 0
+                else { const unsigned row = l & 31; addr = row * 128 + ((((l >> 5) ^ (row & 7)) ^ ((row >> 3) & 1) ^ (((row >> 4) & 1) << 1)) << 4); }   // bit3->c0, bit4->c1
+                addr += (threadIdx.x >> 6) * 4096;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { f32x4 v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(0)); asm volatile("" :: "v"(v)); }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             } else if (MODE == 7) {   // ds_read_b128, conflict-free lane-linear
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { f32x4 v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"((unsigned)(threadIdx.x & 63) * 16u), "n"(0)); acc[i & 3] += v; }
@@ -151,8 +171,20 @@ int main() {
         run<4>("v_mfma_16x16x32_bf16", thr);
         run<5>("1 mfma + 3 pk_fma", thr);
         run<7>("ds_read_b128 + 4 v_add", thr);
+        run<30>("ds_read_b128 p8 16x16 operand", thr);
+        run<31>("ds_read_b128 p8 32x32 operand", thr);
+        run<32>("ds_read_b128 32x32 + row bit3", thr);
+        run<33>("ds_read_b128 32x32 + row bits34", thr);
+        run<34>("ds_read_b128 32x32 row bit4->c0", thr);
+        run<35>("ds_read_b128 32x32 row bit3->c0", thr);
+        run<36>("ds_read_b128 32x32 b3->c0 b4->c1", thr);
         run<8>("v_mfma_16x16x32_bf16 (16 accs)", thr);
         run<9>("v_mfma_32x32x16_bf16 (4 accs)", thr);
+        run<21>("v_mfma_32x32x16_bf16 (1 acc)", thr);
+        run<22>("v_mfma_32x32x16_bf16 (2 accs)", thr);
+        run<23>("v_mfma_32x32x16_bf16 (3 accs)", thr);
+        run<24>("v_mfma_16x16x32_bf16 (1 acc)", thr);
+        run<25>("v_mfma_16x16x32_bf16 (2 accs)", thr);
     }
     run<10>("split: w0-3 mfma16 | w4-7 ds_read", 512);
     run<11>("split: w0-3 mfma32 | w4-7 ds_read", 512);
