@@ -794,32 +794,32 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) gemm_nt_s3_kernel(const GemmAr
 
 // ---------------------------------------------------------------------------------------------------
 // "p8" pipeline: ONE 256 x 256 tile per CU, 8 wavefronts (2 per SIMD) in two groups of four that run half a
-// phase apart ("ping-pong"): while one group issues its 16 MFMAs of a phase, the other issues the LDS
-// fragment reads and the LDS-DMA pieces of its own phase, so every SIMD always has one wave on the matrix
+// window apart ("ping-pong"): while one group issues the 32 MFMAs of a window, the other issues the LDS
+// fragment reads and the LDS-DMA pieces of its own window, so every SIMD always has one wave on the matrix
 // pipe and one on the memory pipes.  K is consumed in 128-byte slabs (64 bf16/f16, 32 f32); LDS holds two
 // slab buffers of four 16-KiB HALF-TILES each (A rows 0-127, A rows 128-255, B rows 0-127, B rows 128-255;
 // 128-byte rows, 16-byte chunk c of row r at chunk c ^ (r & 7)).  A wave owns the 2 x 2 output quadrants
 // (64 x 32 each) at (hm * 128 + g * 64, hn * 128 + wn * 32): quadrant operands A0/A1 come from the two A
-// half-tiles and B0/B1 from the two B half-tiles, so each half-tile is dead early in the slab and can be
-// refilled for slab t + 2 while slab t is still being multiplied.  One slab = four phases:
+// half-tiles and B0/B1 from the two B half-tiles, so three half-tiles are dead after the first window of a slab
+// and are refilled for slab t + 2 while slab t is still being multiplied.  One slab = two windows:
 //
-//   phase  LDS reads (this wave)        LDS-DMA issued (2 x 1 KiB per wave)   MFMAs (16)
-//   0      B0 (4), A0 (8); lgkmcnt(8)   A-hi of slab t+1                      A0 x B0
-//   1      B1 (4)                       B-lo of slab t+2                      A0 x B1
-//   2      A1 (8)                       A-lo of slab t+2                      A1 x B1
-//   3      -                            B-hi of slab t+2; vmcnt(6)            A1 x B0
+//   window  LDS reads (this wave)   LDS-DMA issued (2 x 1 KiB per wave and half-tile)   wait before the barrier   MFMAs (32)
+//   X       B0 (4), B1 (4), A0 (8)  A-hi of slab t+1                                    vmcnt(8) lgkmcnt(0)       A0 x B0, A0 x B1
+//   Y       A1 (8)                  B-lo, A-lo, B-hi of slab t+2                        vmcnt(8) lgkmcnt(0)       A1 x B1, A1 x B0
 //
-// Every phase is  [reads + DMA issue] s_barrier [MFMAs] s_barrier ; the second group executes one extra
-// barrier up front (and the first group one at the end), which is what puts the groups half a phase apart.
+// Every window is  [reads + DMA issue + waits] s_barrier [MFMAs] s_barrier ; the second group executes one extra
+// barrier up front (and the first group one at the end), which is what puts the groups half a window apart.
+// (Four windows of 16 MFMAs per slab, as first built, spent ~50 of every ~306 cycles on the barrier pair.)
 // Hazards, with the groups staggered by one barrier (epochs between consecutive barriers: group 0 loads in
 // epoch 2p and multiplies in 2p+1, group 1 loads in 2p+1 and multiplies in 2p+2):
-//   * RAW: a half-tile is read in the phase AFTER the one whose counted vmcnt retired its DMAs (phase 3's
-//     vmcnt(6) leaves only the three half-tiles of slab t+2 issued in phases 1-3 in flight, so all of slab
-//     t+1 has landed, and is first read in the next phase 0);
-//   * WAR: a half-tile is refilled no sooner than two phases after its last ds_read -- or one phase after,
-//     when an lgkmcnt before that phase's first barrier retired the read (phase 0's lgkmcnt(8) retires the
-//     four B0 reads, which are issued first): B-lo last read in phase 0 / refilled in 1, A-lo 0 / 2,
-//     B-hi 1 / 3, A-hi 2 / next phase 0.
+//   * RAW: a half-tile is read in the window AFTER the one whose counted vmcnt retired its DMAs, i.e. at least
+//     one epoch after BOTH groups' waits: Y's vmcnt(8) leaves A-hi(t+1) and the three half-tiles of slab t+2 in
+//     flight, so B-lo / A-lo / B-hi of slab t+1 have landed before the next X reads them; X's vmcnt(8) leaves
+//     those same three of slab t+1 (t+2 in steady state: the DMAs issued one slab ago) and the A-hi just issued,
+//     so A-hi of slab t has landed before Y reads it;
+//   * WAR: a half-tile is refilled one window after its last ds_read, and every read window ends with lgkmcnt(0)
+//     before its barrier: B-lo / A-lo / B-hi are last read in X (epochs e, e+1 for the two groups) and refilled in
+//     Y (epochs e+2, e+3); A-hi is last read in Y and refilled in the next X.
 // The last two slabs are peeled (MODE 1 / 2) because their DMA counts differ.
 template <typename T, int MODE>
 struct P8 {
@@ -1125,36 +1125,37 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_p8_kernel(const GemmArgs p) {
 #define P8_SLAB(MODE, t)                                                                                          \
     {                                                                                                             \
         const char* rb = smem + ((t) & 1) * BUF_B;                                                                 \
-        /* phase 0 */                                                                                             \
+        /* window X: operands of A0 x B0, A0 x B1 */                                                              \
         P8_READ_B(b0, 0);                                                                                          \
+        P8_READ_B(b1, 1);                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                         \
         P8_READ_A(a0, 0);                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                         \
-        if (MODE <= 1) stage((t) + 1, 1);                                                                          \
-        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                                         \
-        P8_BARRIER();                                                                                              \
-        P8<T, MODE>::template mma16<TRANS>(acc, a0, b0, 0, 0);                                                      \
-        P8_BARRIER();                                                                                              \
-        /* phase 1 */                                                                                             \
-        P8_READ_B(b1, 1);                                                                                          \
-        if (MODE == 0) stage((t) + 2, 2);                                                                          \
-        P8_BARRIER();                                                                                              \
-        P8<T, MODE>::template mma16<TRANS>(acc, a0, b1, 0, 2);                                                      \
-        P8_BARRIER();                                                                                              \
-        /* phase 2 */                                                                                             \
-        P8_READ_A(a1, 1);                                                                                          \
-        if (MODE == 0) stage((t) + 2, 0);                                                                          \
-        P8_BARRIER();                                                                                              \
-        P8<T, MODE>::template mma16<TRANS>(acc, a1, b1, 4, 2);                                                      \
-        P8_BARRIER();                                                                                              \
-        /* phase 3 */                                                                                             \
-        if (MODE == 0) {                                                                                           \
-            stage((t) + 2, 3);                                                                                     \
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                       \
-        } else if (MODE == 1) {                                                                                    \
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
+        if (MODE <= 1) {                                                                                           \
+            stage((t) + 1, 1);                                                                                     \
+            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                                            \
+        } else {                                                                                                   \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                            \
         }                                                                                                          \
         P8_BARRIER();                                                                                              \
+        P8<T, MODE>::template mma16<TRANS>(acc, a0, b0, 0, 0);                                                      \
+        P8<T, MODE>::template mma16<TRANS>(acc, a0, b1, 0, 2);                                                      \
+        P8_BARRIER();                                                                                              \
+        /* window Y: operand of A1 x B1, A1 x B0 */                                                               \
+        P8_READ_A(a1, 1);                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        if (MODE == 0) {                                                                                           \
+            stage((t) + 2, 2);                                                                                     \
+            stage((t) + 2, 0);                                                                                     \
+            stage((t) + 2, 3);                                                                                     \
+            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                                            \
+        } else if (MODE == 1) {                                                                                    \
+            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");                                            \
+        } else {                                                                                                   \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+        }                                                                                                          \
+        P8_BARRIER();                                                                                              \
+        P8<T, MODE>::template mma16<TRANS>(acc, a1, b1, 4, 2);                                                      \
         P8<T, MODE>::template mma16<TRANS>(acc, a1, b0, 4, 0);                                                      \
         P8_BARRIER();                                                                                              \
     }
