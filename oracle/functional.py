@@ -512,3 +512,52 @@ def convmixer_forward(sd, x, hooks=None):
             hooks("blocks.%d" % i, t)
     t = t.mean(dim=(2, 3))
     return linear(t, _p(sd, "classifier.2.weight", x), _p(sd, "classifier.2.bias", x))
+
+
+# --------------------------------------------------------------------------
+# Sparse-MLP  (sparse_mlp.py:17-167)  -- SURVEY.md 8(f) rank 2
+# --------------------------------------------------------------------------
+def sparsemlp_block(sd, x, pre):
+    """One entry of sMLPStage.model on NCHW x (sparse_mlp.py:84-104):
+    x + dwconv3x3(BN(x)); x + fuse(cat[proj_h(BN x), proj_w(BN x), BN x]); x + FF(LN(x)) channel-last."""
+    t = batch_norm_eval(x, sd, pre + "0.norm")
+    x = x + depthwise_conv_same(t, _p(sd, pre + "0.fn.0.weight", x), _p(sd, pre + "0.fn.0.bias", x))      # :85-87, padding=1
+    t = batch_norm_eval(x, sd, pre + "1.norm")
+    # sMLPBlock.forward (:68-74): proj_h mixes along H (via the (0,1,3,2) permutes), proj_w along W
+    xh = torch.einsum("gh,nchw->ncgw", _p(sd, pre + "1.fn.0.proj_h.weight", x), t) + _p(sd, pre + "1.fn.0.proj_h.bias", x).view(1, 1, -1, 1)
+    xw = torch.einsum("gw,nchw->nchg", _p(sd, pre + "1.fn.0.proj_w.weight", x), t) + _p(sd, pre + "1.fn.0.proj_w.bias", x).view(1, 1, 1, -1)
+    x = x + conv1x1(torch.cat([xh, xw, t], dim=1), _p(sd, pre + "1.fn.0.fuse.weight", x), _p(sd, pre + "1.fn.0.fuse.bias", x))
+    tl = x.permute(0, 2, 3, 1)                                                                          # :93
+    n = layer_norm(tl, _p(sd, pre + "3.norm.weight", x), _p(sd, pre + "3.norm.bias", x))
+    h = gelu(linear(n, _p(sd, pre + "3.fn.0.weight", x), _p(sd, pre + "3.fn.0.bias", x)))
+    tl = tl + linear(h, _p(sd, pre + "3.fn.3.weight", x), _p(sd, pre + "3.fn.3.bias", x))
+    return tl.permute(0, 3, 1, 2)                                                                       # :101
+
+
+def sparsemlp_patch_merging(sd, x, pre):
+    """PatchMerging.forward on channel-last x (sparse_mlp.py:34-52): (h,w) parities (0,0),(1,0),(0,1),(1,1) on C,
+    LayerNorm(4C), bias-free Linear(4C, 2C)."""
+    t = torch.cat([x[:, 0::2, 0::2, :], x[:, 1::2, 0::2, :], x[:, 0::2, 1::2, :], x[:, 1::2, 1::2, :]], dim=-1)
+    t = layer_norm(t, _p(sd, pre + "norm.weight", x), _p(sd, pre + "norm.bias", x))
+    return linear(t, _p(sd, pre + "reduction.weight", x), None)
+
+
+def sparsemlp_forward(sd, x, hooks=None):
+    """SparseMLP.forward (sparse_mlp.py:159-166) in eval mode."""
+    x = x.detach().cpu()
+    t = patch_embed(x, _p(sd, "patcher.0.weight", x), _p(sd, "patcher.0.bias", x))                      # :124
+    if "patcher.1.1.weight" in sd:                                                                      # patcher_norm (:126-130)
+        t = layer_norm(t, _p(sd, "patcher.1.1.weight", x), _p(sd, "patcher.1.1.bias", x))
+    t = t.permute(0, 3, 1, 2)
+    layer = 0
+    while ("layers.%d.model.0.0.fn.0.weight" % layer) in sd:
+        for i in range(_depth(sd, "layers.%d" % layer + ".model.%d.0.fn.0.weight")):
+            t = sparsemlp_block(sd, t, "layers.%d.model.%d." % (layer, i))
+            if hooks is not None:
+                hooks("layers.%d.model.%d" % (layer, i), t)
+        if ("layers.%d.model.0.0.fn.0.weight" % (layer + 1)) in sd:                                      # pooling = not the last stage (:138)
+            t = sparsemlp_patch_merging(sd, t.permute(0, 2, 3, 1), "layers.%d.patch_merge.1." % layer).permute(0, 3, 1, 2)
+        layer += 1
+    t = layer_norm(t.permute(0, 2, 3, 1), _p(sd, "mlp_head.1.weight", x), _p(sd, "mlp_head.1.bias", x))  # :152-157
+    t = t.mean(dim=(1, 2))
+    return linear(t, _p(sd, "mlp_head.3.weight", x), _p(sd, "mlp_head.3.bias", x))

@@ -62,7 +62,7 @@ def load_reference():
     tl.trunc_normal_ = torch.nn.init.trunc_normal_
     sys.modules["timm"], sys.modules["timm.models"], sys.modules["timm.models.layers"] = timm, tm, tl
     mods = {}
-    for name in ("mlp_mixer", "g_mlp", "res_mlp", "vip", "s2_mlp_v1", "s2_mlp_v2", "conv_mixer", "as_mlp"):
+    for name in ("mlp_mixer", "g_mlp", "res_mlp", "vip", "s2_mlp_v1", "s2_mlp_v2", "conv_mixer", "as_mlp", "sparse_mlp"):
         mods[name] = importlib.import_module("models_pytorch." + name)
     sc = importlib.import_module("models_pytorch.utils.shift_cuda")
     sc.Shift.forward = lambda self, x: x if self.kernel_size == 1 else sc.torch_shift(x, self.kernel_size, self.dim)
@@ -148,6 +148,12 @@ def tiny_configs(ref):
                              pins=["layers.1.blocks.0"], oracle=lambda sd, x, kw: oracle.asmlp_forward(sd, x, shift_size=kw["shift_size"])),
         "convmixer": dict(ctor=cm.ConvMixer, kw=dict(dim=32, depth=2, kernel_size=5, patch_size=4, n_classes=10), hw=(32, 32),
                           pins=["blocks.0.0", "blocks.1.3"], oracle=lambda sd, x, kw: oracle.convmixer_forward(sd, x)),
+        # SURVEY.md 8(f) rank 2
+        "sparsemlp": dict(ctor=ref["sparse_mlp"].SparseMLP, kw=dict(image_size=64, patch_size=4, d_model=16, depth=[1, 2, 1], expansion_factor=2, num_classes=10),
+                          hw=(64, 64), pins=["layers.0.model.0", "layers.1.model.1"], oracle=lambda sd, x, kw: oracle.sparsemlp_forward(sd, x)),
+        "sparsemlp_norm": dict(ctor=ref["sparse_mlp"].SparseMLP, kw=dict(image_size=(32, 48), patch_size=4, d_model=8, depth=[1, 1], expansion_factor=3, num_classes=10,
+                                                                         patcher_norm=True),
+                               hw=(32, 48), pins=["layers.1.model.0"], oracle=lambda sd, x, kw: oracle.sparsemlp_forward(sd, x)),
     }
 
 
@@ -174,6 +180,8 @@ def real_configs(ref):
         "convmixer_1536_20": dict(ctor=cm.ConvMixer, kw=dict(dim=1536, depth=20), bs=1, oracle=lambda sd, x, kw: oracle.convmixer_forward(sd, x)),
         "mixer_l16": dict(ctor=mm.MLPMixerForImageClassification, kw=dict(d_model=1024, depth=24, patch_size=16, image_size=224), bs=1,
                           oracle=lambda sd, x, kw: oracle.mixer_forward(sd, x)),
+        # the reference's default Sparse-MLP (d_model 96, depth [2,10,24,2])
+        "sparsemlp_t": dict(ctor=ref["sparse_mlp"].SparseMLP, kw=dict(), bs=2, oracle=lambda sd, x, kw: oracle.sparsemlp_forward(sd, x)),
     }
 
 
@@ -201,8 +209,10 @@ def report(tag, ref_out, sd, x, cfg):
     return d32, d64
 
 
-def make_tiny(ref):
+def make_tiny(ref, names=None):
     for name, cfg in tiny_configs(ref).items():
+        if names and name not in names:
+            continue
         torch.manual_seed(0)
         model = cfg["ctor"](**cfg["kw"]).eval()
         randomize_norm_stats(model, 1)
@@ -220,6 +230,8 @@ def make_tiny(ref):
         for k, v in pins.items():
             blob["pin/" + k] = v
         np.savez_compressed(os.path.join(HERE, "tiny_%s.npz" % name), **blob)
+    if names and "s2mlpv2_cleanshift" not in names:
+        return
     # S2-MLPv2 with the INTENDED clean shift (paper Algorithm 1 / Jittor twin): the reference
     # model with its two shift functions replaced by out-of-place versions.
     s2 = ref["s2_mlp_v2"]
@@ -355,7 +367,7 @@ def make_manifest(ref):
         "ConvMixer": ref["conv_mixer"].ConvMixer, "AS_MLP": ref["as_mlp"].AS_MLP, "Shift": ref["shift_cuda"].Shift,
         "MLPMixer": ref["mlp_mixer"].MLPMixer, "gMLP": ref["g_mlp"].gMLP, "ResMLP": ref["res_mlp"].ResMLP,
         "WeightedPermutator": ref["vip"].WeightedPermutator, "Permutator": ref["vip"].Permutator,
-        "S2Block": ref["s2_mlp_v2"].S2Block,
+        "S2Block": ref["s2_mlp_v2"].S2Block, "SparseMLP": ref["sparse_mlp"].SparseMLP,
     }
     for name, c in ctors.items():
         sig = inspect.signature(c)
@@ -376,13 +388,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     ap.add_argument("--real", default=None, help="comma list of real configs")
+    ap.add_argument("--tiny", default=None, help="comma list of tiny configs (default: all)")
     args = ap.parse_args()
     assert os.path.isdir(REF), "the reference is only available in the authoring container"
     ref = load_reference()
     if args.only in (None, "ops"):
         make_ops(ref)
     if args.only in (None, "tiny"):
-        make_tiny(ref)
+        make_tiny(ref, args.tiny.split(",") if args.tiny else None)
     if args.only in (None, "manifest"):
         make_manifest(ref)
     if args.only in (None, "real"):
