@@ -267,6 +267,15 @@ int mlpk_dwconv_nhwc(int dtype, const void* x, void* out, int B, int H, int W, i
                      const float* w, const float* bias, const float* bn_scale,
                      const float* bn_shift, void* stream);
 
+/* ---- Sparse-MLP depthwise step ------------------------------------------------
+ * x, out: (B,H,W,C) channel-last, C a multiple of the 16-byte vector.  w: float32 [k*k][C] (tap-major), k odd.
+ * out = x + dwconv_same(pre_scale[c] * x + pre_shift[c]) + bias[c], zero padding applied after the affine
+ * (BatchNorm2d(eval) -> Conv2d(C, C, 3, padding=1, groups=C) inside a PreNormResidual: sparse_mlp.py:9-15, 84-87).
+ */
+int mlpk_dwconv_affine_nhwc(int dtype, const void* x, void* out, int B, int H, int W, int C, int k,
+                            const float* w, const float* bias, const float* pre_scale,
+                            const float* pre_shift, void* stream);
+
 /* ---- small utilities ------------------------------------------------------------------------ */
 /* dst[i] = (dst_dtype) src[i], n elements */
 int mlpk_convert(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);

@@ -178,9 +178,87 @@ static int dwconv_lds_launch(int k, const void* x, void* out, int B, int H, int 
     return 0;
 }
 
+// Sparse-MLP depthwise step (sparse_mlp.py:84-87): out = x + dwconv_same(pre_scale * x + pre_shift) + bias, zero padding
+// applied AFTER the per-channel affine (BatchNorm in eval mode in front of the convolution: a padded tap contributes
+// nothing, so the shift cannot be folded into the bias near the border).  Channel-last, one thread per pixel and
+// 16-byte channel vector, k*k neighbour vectors from L1/L2; HBM-bound (read + write of x once).
+template <typename T>
+__global__ void __launch_bounds__(256) dwconv_affine_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int H, int W, int C,
+                                                            int k, const float* __restrict__ w, const float* __restrict__ bias,
+                                                            const float* __restrict__ ps, const float* __restrict__ ph) {
+    constexpr int EPV = 16 / (int)sizeof(T);
+    const int cv = C / EPV;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)B * H * W * cv;
+    if (idx >= total) return;
+    const int c0 = (int)(idx % cv) * EPV;
+    const long long pix = idx / cv;
+    const int xw = (int)(pix % W);
+    const int yh = (int)((pix / W) % H);
+    const long long b = pix / ((long long)W * H);
+    const int P = (k - 1) / 2;
+    float a[EPV], sh[EPV], acc[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+        a[e] = ps ? ps[c0 + e] : 1.f;
+        sh[e] = ph ? ph[c0 + e] : 0.f;
+        acc[e] = bias ? bias[c0 + e] : 0.f;
+    }
+    T ctr[EPV];
+    for (int dy = 0; dy < k; ++dy) {
+        const int yy = yh + dy - P;
+        if (yy < 0 || yy >= H) continue;
+        for (int dx = 0; dx < k; ++dx) {
+            const int xx = xw + dx - P;
+            if (xx < 0 || xx >= W) continue;
+            T v[EPV];
+            *reinterpret_cast<u32x4*>(v) = *reinterpret_cast<const u32x4*>(x + ((b * H + yy) * W + xx) * C + c0);
+            if (dy == P && dx == P) {
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) ctr[e] = v[e];
+            }
+            const float* wt = w + (size_t)(dy * k + dx) * C + c0;
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) acc[e] = fmaf(wt[e], fmaf(a[e], to_f32(v[e]), sh[e]), acc[e]);
+        }
+    }
+    T o[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) o[e] = from_f32<T>(to_f32(ctr[e]) + acc[e]);
+    *reinterpret_cast<u32x4*>(out + pix * C + c0) = *reinterpret_cast<const u32x4*>(o);
+}
+
 }  // namespace mlpk
 
 using namespace mlpk;
+
+extern "C" int mlpk_dwconv_affine_nhwc(int dtype, const void* x, void* out, int B, int H, int W, int C, int k, const float* w,
+                                       const float* bias, const float* pre_scale, const float* pre_shift, void* stream) {
+    if (!x || !out || !w) return MLPK_ENULL;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || k < 1 || !(k & 1)) return MLPK_ESHAPE;
+    if (x == out) return MLPK_ESHAPE;                    // a stencil cannot run in place
+    if (dtype != MLPK_F32 && dtype != MLPK_F16 && dtype != MLPK_BF16) return MLPK_EDTYPE;
+    const int epv = dtype == MLPK_F32 ? 4 : 8;
+    if (C % epv) return MLPK_ESHAPE;
+    if (((uintptr_t)x & 15) || ((uintptr_t)out & 15)) return MLPK_EALIGN;
+    const long long total = (long long)B * H * W * (C / epv);
+    if ((total + 255) / 256 > 0x7fffffffLL) return MLPK_ESHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    switch (dtype) {
+        case MLPK_F32:
+            hipLaunchKernelGGL(dwconv_affine_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (float*)out, B, H, W, C, k, w, bias, pre_scale, pre_shift);
+            break;
+        case MLPK_F16:
+            hipLaunchKernelGGL(dwconv_affine_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)x, (f16_t*)out, B, H, W, C, k, w, bias, pre_scale, pre_shift);
+            break;
+        default:
+            hipLaunchKernelGGL(dwconv_affine_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)out, B, H, W, C, k, w, bias, pre_scale, pre_shift);
+            break;
+    }
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int mlpk_dwconv_nhwc(int dtype, const void* x, void* out, int B, int H, int W, int C, int k, const float* w,
                                 const float* bias, const float* bn_scale, const float* bn_shift, void* stream) {

@@ -230,6 +230,11 @@ def dwconv_nhwc(x, out, B, H, W, C, k, w, bias, bn_scale, bn_shift):
                                      ptr(bn_scale), ptr(bn_shift), stream()), "mlpk_dwconv_nhwc")
 
 
+def dwconv_affine_nhwc(x, out, B, H, W, C, k, w, bias, pre_scale, pre_shift):
+    N.check(N.lib().mlpk_dwconv_affine_nhwc(dtype_code(x.dtype), ptr(x), ptr(out), B, H, W, C, k, ptr(w), ptr(bias),
+                                            ptr(pre_scale), ptr(pre_shift), stream()), "mlpk_dwconv_affine_nhwc")
+
+
 def convert(src, dst, n):
     N.check(N.lib().mlpk_convert(dtype_code(src.dtype), dtype_code(dst.dtype), ptr(src), ptr(dst), n, stream()),
             "mlpk_convert")

@@ -1,0 +1,194 @@
+"""Sparse-MLP, drop-in for the reference's models_pytorch/sparse_mlp.py (eval-mode forward:
+BatchNorm uses its running statistics).
+
+One entry of sMLPStage.model (sparse_mlp.py:84-104), on channel-last activations (B*H*W, C):
+  * x <- x + dwconv3x3(BN(x)) + b                 one stencil kernel (mlpk_dwconv_affine_nhwc): the BatchNorm affine
+                                                  is applied to the taps, padding stays zero, residual = the raw x;
+  * x <- x + fuse(cat[proj_h(x^), proj_w(x^), x^]),  x^ = BN(x)  (sMLPBlock, :61-74):
+      - one mlpk_norm_apply writes x^ row-major into the right half of a (rows, 2C) buffer AND its per-(b,h) token
+        transpose ((B*H)*C, W); a second one writes the per-image transpose over H ((B)*(W*C), H) -- the two axial
+        mixes are then the same K-contiguous NT GEMM as every other token mix on this path, stored straight back
+        channel-last through the per-image transposed epilogue (no permute copy):
+          x_w[(b,h), w', c] = sum_w Ww[w', w] x^[(b,h), w, c] + bw[w']      tokens = W, channels = C
+          x_h[b, h', (w,c)] = sum_h Wh[h', h] x^[b, h, (w,c)] + bh[h']      tokens = H, channels = W*C
+      - the 1x1 fuse conv over the concatenation is two accumulating GEMMs (K = C on x_h, K = 2C on [x_w | x^]),
+        bias and the residual in the epilogues;
+  * x <- x + FF(LN(x))                            LayerNorm folded into fc1 (common.channel_mlp).
+PatchMerging (:17-52) = 2x2 space-to-depth gather + LayerNorm(4C) folded into the bias-free reduction GEMM.
+Head (:151-157) = LayerNorm folded into the token mean, then one small GEMM.
+"""
+import torch
+from torch import nn
+
+from .. import _native as N
+from .. import engine as E
+from .common import Holder, channel_mlp, embed_patches, head_linear, layernorm_stats, pack_channel_mlp
+from .conv_mixer import _bn_affine
+from .utils import pair
+
+
+class PreNormResidual(Holder):
+    """fn(norm(x)) + x (sparse_mlp.py:8-15)."""
+
+    def __init__(self, dim, fn, norm=nn.LayerNorm):
+        super().__init__()
+        self.fn = fn
+        self.norm = norm(dim)
+
+
+class PatchMerging(Holder):
+    """sparse_mlp.py:17-31."""
+
+    def __init__(self, input_resolution, dim, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.input_resolution = input_resolution
+        self.dim = dim
+        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+        self.norm = norm_layer(4 * dim)
+
+
+class sMLPBlock(Holder):
+    """sparse_mlp.py:61-66."""
+
+    def __init__(self, h=224, w=224, d_model=3):
+        super().__init__()
+        self.proj_h = nn.Linear(h, h)
+        self.proj_w = nn.Linear(w, w)
+        self.fuse = nn.Conv2d(3 * d_model, d_model, kernel_size=1)
+
+
+class sMLPStage(Holder):
+    """sparse_mlp.py:76-104.  `patch_merge` exists in every stage (also where pooling is False), like the reference's,
+    so that the state_dict keys match."""
+
+    def __init__(self, height, width, d_model, depth, expansion_factor=2, dropout=0., pooling=False):
+        super().__init__()
+        self.pooling = pooling
+        self.patch_merge = nn.Sequential(nn.Identity(), PatchMerging((height, width), d_model), nn.Identity())
+        self.model = nn.Sequential(*[nn.Sequential(
+            PreNormResidual(d_model, nn.Sequential(nn.Conv2d(d_model, d_model, kernel_size=3, padding=1, groups=d_model)),
+                            norm=nn.BatchNorm2d),
+            PreNormResidual(d_model, nn.Sequential(sMLPBlock(height, width, d_model)), norm=nn.BatchNorm2d),
+            nn.Identity(),
+            PreNormResidual(d_model, nn.Sequential(nn.Linear(d_model, d_model * expansion_factor), nn.GELU(), nn.Dropout(dropout),
+                                                   nn.Linear(d_model * expansion_factor, d_model), nn.Dropout(dropout)),
+                            norm=nn.LayerNorm),
+            nn.Identity()) for _ in range(depth)])
+        self.geom = (height, width, d_model, depth, expansion_factor)
+
+
+class SparseMLP(E.EngineModule):
+    """Same signature and defaults as the reference (sparse_mlp.py:106-117)."""
+
+    def __init__(self, image_size=224, patch_size=4, in_channels=3, num_classes=1000, d_model=96, depth=[2, 10, 24, 2],
+                 expansion_factor=2, patcher_norm=False):
+        image_size = pair(image_size)
+        patch_size = pair(patch_size)
+        assert (image_size[0] % patch_size[0]) == 0, 'image must be divisible by patch size'
+        assert (image_size[1] % patch_size[1]) == 0, 'image must be divisible by patch size'
+        height = image_size[0] // patch_size[0]
+        width = image_size[1] // patch_size[1]
+        super().__init__()
+        self.patcher = nn.Sequential(
+            nn.Conv2d(in_channels, d_model, kernel_size=patch_size, stride=patch_size),
+            nn.Identity() if (not patcher_norm) else nn.Sequential(nn.Identity(), nn.LayerNorm(d_model), nn.Identity()))
+        self.layers = nn.ModuleList()
+        for i_layer in range(len(depth)):
+            self.layers.append(sMLPStage(height // (2 ** i_layer), width // (2 ** i_layer), d_model, depth[i_layer],
+                                         expansion_factor=expansion_factor, pooling=((i_layer + 1) < len(depth))))
+            if (i_layer + 1) < len(depth):
+                d_model = d_model * 2
+        self.mlp_head = nn.Sequential(nn.Identity(), nn.LayerNorm(d_model), nn.Identity(), nn.Linear(d_model, num_classes))
+        self._cfg = (image_size, patch_size, in_channels, num_classes, patcher_norm)
+
+    def _pack(self, dtype, device):
+        pk = {}
+        pk["embed.w"] = E.pack_matrix(self.patcher[0].weight, dtype, device)
+        pk["embed.b"] = E.f32(self.patcher[0].bias, device)
+        if self._cfg[4]:
+            pk["embed.g"], pk["embed.be"] = E.f32(self.patcher[1][1].weight, device), E.f32(self.patcher[1][1].bias, device)
+        for li, stage in enumerate(self.layers):
+            H, W, C, depth, ef = stage.geom
+            for bi, blk in enumerate(stage.model):
+                p = "l%d.b%d." % (li, bi)
+                dw = blk[0].fn[0]
+                pk[p + "dw.w"] = dw.weight.detach().reshape(C, 9).t().contiguous().to(device=device, dtype=torch.float32)
+                pk[p + "dw.b"] = E.f32(dw.bias, device)
+                pk[p + "dw.s"], pk[p + "dw.h"] = _bn_affine(blk[0].norm, device)
+                sm = blk[1].fn[0]
+                s, h = _bn_affine(blk[1].norm, device)
+                pk[p + "bn.s"], pk[p + "bn.h"] = s, h
+                pk[p + "bn.sw"], pk[p + "bn.hw"] = s.repeat(W).contiguous(), h.repeat(W).contiguous()   # per (w, c) "channel"
+                pk[p + "ph.w"], pk[p + "ph.b"] = E.pack_matrix(sm.proj_h.weight, dtype, device), E.f32(sm.proj_h.bias, device)
+                pk[p + "pw.w"], pk[p + "pw.b"] = E.pack_matrix(sm.proj_w.weight, dtype, device), E.f32(sm.proj_w.bias, device)
+                wf = sm.fuse.weight.detach().reshape(C, 3 * C)
+                pk[p + "fu.wh"] = E.pack_matrix(wf[:, :C], dtype, device)
+                pk[p + "fu.wr"] = E.pack_matrix(wf[:, C:], dtype, device)                                # [x_w | x^] columns
+                pk[p + "fu.b"] = E.f32(sm.fuse.bias, device)
+                ff = blk[3]
+                pack_channel_mlp(pk, p + "ff.", ff.norm, ff.fn[0], ff.fn[3], dtype, device)
+            if stage.pooling:
+                pm = stage.patch_merge[1]
+                p = "l%d.merge." % li
+                pk[p + "w"], pk[p + "b"], pk[p + "csum"] = E.pack_ln_folded(pm.reduction.weight, None, pm.norm.weight, pm.norm.bias,
+                                                                             dtype, device)
+        pk["head.g"], pk["head.be"] = E.f32(self.mlp_head[1].weight, device), E.f32(self.mlp_head[1].bias, device)
+        pk["head.w"] = E.pack_matrix(self.mlp_head[3].weight, dtype, device)
+        pk["head.b"] = E.f32(self.mlp_head[3].bias, device)
+        return pk
+
+    def forward(self, x):
+        cd = self._resolve(x)
+        image_size, patch, cin, num_classes, patcher_norm = self._cfg
+        B = x.shape[0]
+        pk = self._get_pack(cd, x.device)
+        ws = self._get_space(B, cd, x.device)
+        x = x.contiguous()
+        C0 = self.layers[0].geom[2]
+        cur, H, W = embed_patches(ws, "embed", x, pk["embed.w"], pk["embed.b"], cd, patch, out=ws.get("l0.x", (B * self.layers[0].geom[0] * self.layers[0].geom[1], C0)))
+        if (H, W) != self.layers[0].geom[:2]:
+            raise ValueError("input size gives a %dx%d grid, the model was built for %dx%d" % ((H, W) + self.layers[0].geom[:2]))
+        if patcher_norm:
+            mean, rstd = layernorm_stats(ws, cur, B * H * W, C0, tag="embed.ln")
+            E.norm_apply(cur, B * H * W, C0, C0, mean=mean, rstd=rstd, gamma=pk["embed.g"], beta=pk["embed.be"], out_rm=cur, ld_rm=C0)
+        for li, stage in enumerate(self.layers):
+            H, W, C, depth, ef = stage.geom
+            rows = B * H * W
+            hp, wp = E.round_up(H, 8), E.round_up(W, 8)
+            tmp = ws.get("l%d.tmp" % li, (rows, C))
+            xh = ws.get("l%d.xh" % li, (rows, C))
+            cat = ws.get("l%d.cat" % li, (rows, 2 * C))                  # [x_w | x^]
+            xt_w = ws.get("l%d.xtw" % li, (B * H * C, wp))
+            xt_h = ws.get("l%d.xth" % li, (B * W * C, hp))
+            for bi in range(depth):
+                p = "l%d.b%d." % (li, bi)
+                # x + dwconv3x3(BN(x)) + b    (ping-pong cur <-> tmp: a stencil cannot run in place)
+                E.dwconv_affine_nhwc(cur, tmp, B, H, W, C, 3, pk[p + "dw.w"], pk[p + "dw.b"], pk[p + "dw.s"], pk[p + "dw.h"])
+                cur, tmp = tmp, cur
+                # x^ = BN(x): row-major into cat[:, C:], transposed over W per (b, h); transposed over H per image
+                E.norm_apply(cur, rows, C, C, gamma=pk[p + "bn.s"], beta=pk[p + "bn.h"], out_rm=cat[:, C:], ld_rm=2 * C,
+                             out_tt=xt_w, S=W, ld_tt=wp)
+                E.norm_apply(cur, B * H, W * C, W * C, gamma=pk[p + "bn.sw"], beta=pk[p + "bn.hw"], out_tt=xt_h, S=H, ld_tt=hp)
+                E.gemm(xt_w, pk[p + "pw.w"], cat, B * H * C, W, wp, ldc=2 * C, bias=pk[p + "pw.b"], out_mode=N.OUT_TOKEN_T,
+                       t_rows=C, t_tokens=W, tag="smlp_w")
+                E.gemm(xt_h, pk[p + "ph.w"], xh, B * W * C, H, hp, ldc=W * C, bias=pk[p + "ph.b"], out_mode=N.OUT_TOKEN_T,
+                       t_rows=W * C, t_tokens=H, tag="smlp_h")
+                E.gemm(xh, pk[p + "fu.wh"], cur, rows, C, C, bias=pk[p + "fu.b"], R=cur, res=N.RES_ADD, tag="smlp_fuse")
+                E.gemm(cat, pk[p + "fu.wr"], cur, rows, C, 2 * C, R=cur, res=N.RES_ADD, tag="smlp_fuse")
+                channel_mlp(ws, cur, rows, C, pk, p + "ff.", C * ef, tag="l%d.cm" % li)
+            if stage.pooling:
+                assert H % 2 == 0 and W % 2 == 0, f"x size ({H}*{W}) are not even."                      # sparse_mlp.py:38
+                p = "l%d.merge." % li
+                H2, W2 = H // 2, W // 2
+                merged = ws.get("l%d.merged" % li, (B * H2 * W2, 4 * C))
+                E.patchify(cur, merged, B, C, H, W, 2, 2, 0, 4 * C, layout=N.LAYOUT_NHWC, px_stride=C, order=1)
+                mean, rstd = layernorm_stats(ws, merged, B * H2 * W2, 4 * C, tag="l%d.merge.ln" % li)
+                nxt = ws.get("l%d.x" % (li + 1), (B * H2 * W2, 2 * C))
+                E.gemm(merged, pk[p + "w"], nxt, B * H2 * W2, 2 * C, 4 * C, bias=pk[p + "b"], ln=(mean, rstd, pk[p + "csum"]),
+                       tag="smlp_merge")
+                cur = nxt
+        H, W, C = self.layers[-1].geom[:3]
+        mean, rstd = layernorm_stats(ws, cur, B * H * W, C, tag="head.ln")
+        pooled = ws.get("pooled", (B, C))
+        E.pool_mean(cur, B, H * W, C, C, pooled, C, mean=mean, rstd=rstd, gamma=pk["head.g"], beta=pk["head.be"])
+        return head_linear(ws, pooled, B, C, pk["head.w"], pk["head.b"], num_classes, x.dtype)

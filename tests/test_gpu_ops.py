@@ -579,3 +579,25 @@ def test_fused_token_mlp(dtype):
         assert torch.isfinite(got).all()
         err = (got - ref).abs().max().item()
         assert err < EPS[dtype] * 6 * max(1.0, ref.abs().max().item()), (str(dtype), ci, err)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_dwconv_affine_nhwc(dtype):
+    """Sparse-MLP depthwise step: x + dwconv_same(scale * x + shift) + bias with zero padding AFTER the affine
+    (sparse_mlp.py:84-87), against torch's BatchNorm-affine -> conv2d(groups=C, padding=k//2) in fp32."""
+    pkg = load_pkg()
+    E = pkg.engine
+    for ci, (B, H, W, C, k) in enumerate(((2, 8, 12, 16, 3), (3, 7, 5, 24, 3), (1, 4, 4, 8, 5), (2, 1, 1, 8, 3))):
+        x = rnd((B, H, W, C), dtype, 900 + ci).to(dev())
+        w = rnd((C, 1, k, k), torch.float32, 910 + ci, 0.5)
+        bias = rnd((C,), torch.float32, 920 + ci)
+        sc = rnd((C,), torch.float32, 930 + ci) + 1.5
+        sh = rnd((C,), torch.float32, 940 + ci)
+        xf = x.float().cpu().permute(0, 3, 1, 2)
+        ref = xf + torch.nn.functional.conv2d(xf * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1), w, bias, padding=k // 2, groups=C)
+        out = torch.full((B, H, W, C), float("nan"), dtype=dtype, device=dev())
+        E.dwconv_affine_nhwc(x, out, B, H, W, C, k, w.reshape(C, k * k).t().contiguous().to(dev()), bias.to(dev()), sc.to(dev()), sh.to(dev()))
+        torch.cuda.synchronize()
+        err = (out.float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
+        tol = 2e-5 if dtype == torch.float32 else (4e-3 if dtype == torch.float16 else 3e-2)
+        assert err < tol * max(1.0, ref.abs().max().item()), (str(dtype), ci, err)
