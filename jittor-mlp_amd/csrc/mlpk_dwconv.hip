@@ -197,12 +197,16 @@ __global__ void __launch_bounds__(256) dwconv_affine_kernel(const T* __restrict_
     const int yh = (int)((pix / W) % H);
     const long long b = pix / ((long long)W * H);
     const int P = (k - 1) / 2;
+    // per-channel parameters as 16-byte vectors (EPV scalar loads per tap made the texture-address unit the bottleneck)
     float a[EPV], sh[EPV], acc[EPV];
 #pragma unroll
-    for (int e = 0; e < EPV; ++e) {
-        a[e] = ps ? ps[c0 + e] : 1.f;
-        sh[e] = ph ? ph[c0 + e] : 0.f;
-        acc[e] = bias ? bias[c0 + e] : 0.f;
+    for (int e = 0; e < EPV; e += 4) {
+        const f32x4 av = ps ? *reinterpret_cast<const f32x4*>(ps + c0 + e) : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 sv = ph ? *reinterpret_cast<const f32x4*>(ph + c0 + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + c0 + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+        a[e] = av.x; a[e + 1] = av.y; a[e + 2] = av.z; a[e + 3] = av.w;
+        sh[e] = sv.x; sh[e + 1] = sv.y; sh[e + 2] = sv.z; sh[e + 3] = sv.w;
+        acc[e] = bv.x; acc[e + 1] = bv.y; acc[e + 2] = bv.z; acc[e + 3] = bv.w;
     }
     T ctr[EPV];
     for (int dy = 0; dy < k; ++dy) {
@@ -219,7 +223,13 @@ __global__ void __launch_bounds__(256) dwconv_affine_kernel(const T* __restrict_
             }
             const float* wt = w + (size_t)(dy * k + dx) * C + c0;
 #pragma unroll
-            for (int e = 0; e < EPV; ++e) acc[e] = fmaf(wt[e], fmaf(a[e], to_f32(v[e]), sh[e]), acc[e]);
+            for (int e = 0; e < EPV; e += 4) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wt + e);
+                acc[e] = fmaf(wv.x, fmaf(a[e], to_f32(v[e]), sh[e]), acc[e]);
+                acc[e + 1] = fmaf(wv.y, fmaf(a[e + 1], to_f32(v[e + 1]), sh[e + 1]), acc[e + 1]);
+                acc[e + 2] = fmaf(wv.z, fmaf(a[e + 2], to_f32(v[e + 2]), sh[e + 2]), acc[e + 2]);
+                acc[e + 3] = fmaf(wv.w, fmaf(a[e + 3], to_f32(v[e + 3]), sh[e + 3]), acc[e + 3]);
+            }
         }
     }
     T o[EPV];
@@ -240,7 +250,9 @@ extern "C" int mlpk_dwconv_affine_nhwc(int dtype, const void* x, void* out, int 
     if (dtype != MLPK_F32 && dtype != MLPK_F16 && dtype != MLPK_BF16) return MLPK_EDTYPE;
     const int epv = dtype == MLPK_F32 ? 4 : 8;
     if (C % epv) return MLPK_ESHAPE;
-    if (((uintptr_t)x & 15) || ((uintptr_t)out & 15)) return MLPK_EALIGN;
+    if (((uintptr_t)x & 15) || ((uintptr_t)out & 15) || ((uintptr_t)w & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)pre_scale & 15) ||
+        ((uintptr_t)pre_shift & 15))
+        return MLPK_EALIGN;
     const long long total = (long long)B * H * W * (C / epv);
     if ((total + 255) / 256 > 0x7fffffffLL) return MLPK_ESHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
