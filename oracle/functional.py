@@ -561,3 +561,88 @@ def sparsemlp_forward(sd, x, hooks=None):
     t = layer_norm(t.permute(0, 2, 3, 1), _p(sd, "mlp_head.1.weight", x), _p(sd, "mlp_head.1.bias", x))  # :152-157
     t = t.mean(dim=(1, 2))
     return linear(t, _p(sd, "mlp_head.3.weight", x), _p(sd, "mlp_head.3.bias", x))
+
+
+# --------------------------------------------------------------------------
+# Hire-MLP  (hire_mlp.py:8-229)  -- SURVEY.md 8(f) rank 2
+# --------------------------------------------------------------------------
+def conv2d_im2col(x, w, b, stride, padding):
+    """Conv2d on NCHW with square kernel k, stride s, zero padding p, as an explicit window gather + matmul
+    (hire_mlp.py:21 patcher k=7 s=patch p=3; :161 patch_merge k=3 s=2 p=1).  Returns channel-last (B, Ho, Wo, Cout)."""
+    cout, cin, kh, kw = w.shape
+    xp = torch.nn.functional.pad(x, (padding, padding, padding, padding))
+    bsz, _, hh, ww = xp.shape
+    ho, wo = (hh - kh) // stride + 1, (ww - kw) // stride + 1
+    cols = []
+    for i in range(kh):
+        for j in range(kw):
+            cols.append(xp[:, :, i:i + (ho - 1) * stride + 1:stride, j:j + (wo - 1) * stride + 1:stride])       # (B, Cin, Ho, Wo)
+    pat = torch.stack(cols, dim=2).permute(0, 3, 4, 1, 2).reshape(bsz, ho, wo, cin * kh * kw)                  # k = ci*kh*kw + i*kw + j
+    out = pat @ w.reshape(cout, -1).t()
+    return out if b is None else out + b
+
+
+def _circular_pad_hw(x, pad_h, pad_w):
+    """F.pad(x, (0, pad_w, 0, pad_h), 'circular') on NCHW (hire_mlp.py:133): the appended rows / columns repeat the first ones."""
+    if pad_w:
+        x = torch.cat([x, x[:, :, :, :pad_w]], dim=3)
+    if pad_h:
+        x = torch.cat([x, x[:, :, :pad_h, :]], dim=2)
+    return x
+
+
+def hiremlp_block(sd, x, pre, h, w, step, cross):
+    """HireMLPBlock.forward on channel-last x = LayerNorm output (hire_mlp.py:127-152), padding_type 'circular'.
+    NB the pad is h - H % h (w - W % w): a whole extra region when the size already divides (:131-133)."""
+    t = x.permute(0, 3, 1, 2)
+    bsz, c, hh, ww = t.shape
+    t = _circular_pad_hw(t, h - hh % h, w - ww % w)
+    hp, wp = t.shape[2], t.shape[3]
+    th = torch.roll(t, step, 2) if cross else t                                                   # CrossRegion dim 2 (:44-51, 109)
+    tw = torch.roll(t, step, 3) if cross else t
+    gh, gw = hp // h, wp // w
+    # InnerRegionH 'b c (h group) w -> b (c h) group w' (:68-70); InnerRegionW 'b c h (w group) -> b (c w) h group' (:57-59)
+    xh = th.reshape(bsz, c, h, gh, wp).reshape(bsz, c * h, gh, wp)
+    xw = tw.reshape(bsz, c, hp, w, gw).permute(0, 1, 3, 2, 4).reshape(bsz, c * w, hp, gw)
+
+    def ff(z, p):                                                                                 # FeedForward (:33-42)
+        z = gelu(conv1x1(z, _p(sd, p + "net.0.weight", x), _p(sd, p + "net.0.bias", x)))
+        return conv1x1(z, _p(sd, p + "net.2.weight", x), _p(sd, p + "net.2.bias", x))
+
+    xh = ff(xh, pre + "proj_h.")
+    xw = ff(xw, pre + "proj_w.")
+    xc = conv1x1(t, _p(sd, pre + "proj_c.weight", x), _p(sd, pre + "proj_c.bias", x))
+    xh = xh.reshape(bsz, c, h, gh, wp).reshape(bsz, c, hp, wp)                                    # restore (:90-92)
+    xw = xw.reshape(bsz, c, w, hp, gw).permute(0, 1, 3, 2, 4).reshape(bsz, c, hp, wp)             # restore (:79-81)
+    if cross:
+        xh = torch.roll(xh, -step, 2)
+        xw = torch.roll(xw, -step, 3)
+    out = (xc + xh + xw)[:, :, :hh, :ww]
+    return out.permute(0, 2, 3, 1)
+
+
+def hiremlp_forward(sd, x, h, w, cross_region_step, cross_region_interval=2, patch_size=4, hooks=None):
+    """HireMLP.forward (hire_mlp.py:222-228) in eval mode; h, w, cross_region_step are the per-stage lists of the constructor."""
+    x = x.detach().cpu()
+    t = conv2d_im2col(x, _p(sd, "patcher.reduction.0.weight", x), _p(sd, "patcher.reduction.0.bias", x), patch_size, 3)     # :203
+    if "patcher.reduction.1.1.weight" in sd:
+        t = layer_norm(t, _p(sd, "patcher.reduction.1.1.weight", x), _p(sd, "patcher.reduction.1.1.bias", x))
+    layer = 0
+    while ("layers.%d.model.0.0.norm.weight" % layer) in sd:
+        for i in range(_depth(sd, "layers.%d" % layer + ".model.%d.0.norm.weight")):
+            pre = "layers.%d.model.%d." % (layer, i)
+            cross = ((i + 1) % cross_region_interval == 0)                                       # cross_region_id = i_depth + 1 (:168, 104)
+            n = layer_norm(t, _p(sd, pre + "0.norm.weight", x), _p(sd, pre + "0.norm.bias", x))
+            t = t + hiremlp_block(sd, n, pre + "0.fn.0.", h[layer], w[layer], cross_region_step[layer], cross)
+            n = layer_norm(t, _p(sd, pre + "1.norm.weight", x), _p(sd, pre + "1.norm.bias", x))
+            hdn = gelu(linear(n, _p(sd, pre + "1.fn.0.weight", x), _p(sd, pre + "1.fn.0.bias", x)))
+            t = t + linear(hdn, _p(sd, pre + "1.fn.3.weight", x), _p(sd, pre + "1.fn.3.bias", x))
+            if hooks is not None:
+                hooks("layers.%d.model.%d" % (layer, i), t)
+        if ("layers.%d.model.0.0.norm.weight" % (layer + 1)) in sd:                               # pooling (:213)
+            pm = "layers.%d.patch_merge.1.reduction.0." % layer
+            t = conv2d_im2col(t.permute(0, 3, 1, 2), _p(sd, pm + "weight", x), _p(sd, pm + "bias", x), 2, 1)
+        layer += 1
+    t = layer_norm(t, _p(sd, "mlp_head.0.weight", x), _p(sd, "mlp_head.0.bias", x))
+    t = t.mean(dim=(1, 2))
+    return linear(t, _p(sd, "mlp_head.2.weight", x), _p(sd, "mlp_head.2.bias", x))

@@ -62,7 +62,7 @@ def load_reference():
     tl.trunc_normal_ = torch.nn.init.trunc_normal_
     sys.modules["timm"], sys.modules["timm.models"], sys.modules["timm.models.layers"] = timm, tm, tl
     mods = {}
-    for name in ("mlp_mixer", "g_mlp", "res_mlp", "vip", "s2_mlp_v1", "s2_mlp_v2", "conv_mixer", "as_mlp", "sparse_mlp"):
+    for name in ("mlp_mixer", "g_mlp", "res_mlp", "vip", "s2_mlp_v1", "s2_mlp_v2", "conv_mixer", "as_mlp", "sparse_mlp", "hire_mlp"):
         mods[name] = importlib.import_module("models_pytorch." + name)
     sc = importlib.import_module("models_pytorch.utils.shift_cuda")
     sc.Shift.forward = lambda self, x: x if self.kernel_size == 1 else sc.torch_shift(x, self.kernel_size, self.dim)
@@ -154,6 +154,14 @@ def tiny_configs(ref):
         "sparsemlp_norm": dict(ctor=ref["sparse_mlp"].SparseMLP, kw=dict(image_size=(32, 48), patch_size=4, d_model=8, depth=[1, 1], expansion_factor=3, num_classes=10,
                                                                          patcher_norm=True),
                                hw=(32, 48), pins=["layers.1.model.0"], oracle=lambda sd, x, kw: oracle.sparsemlp_forward(sd, x)),
+        "hiremlp": dict(ctor=ref["hire_mlp"].HireMLP, kw=dict(patch_size=4, d_model=[16, 32], h=[4, 3], w=[4, 3], cross_region_step=[2, 1], cross_region_interval=2,
+                                                              depth=[2, 2], expansion_factor=2, num_classes=10),
+                        hw=(64, 64), pins=["layers.0.model.1", "layers.1.model.0"],
+                        oracle=lambda sd, x, kw: oracle.hiremlp_forward(sd, x, kw["h"], kw["w"], kw["cross_region_step"], kw["cross_region_interval"], kw["patch_size"])),
+        "hiremlp_rect": dict(ctor=ref["hire_mlp"].HireMLP, kw=dict(patch_size=4, d_model=[8, 16], h=[3, 2], w=[2, 3], cross_region_step=[1, 2], cross_region_interval=1,
+                                                                   depth=[1, 2], expansion_factor=3, num_classes=10, patcher_norm=True),
+                             hw=(32, 48), pins=["layers.1.model.1"],
+                             oracle=lambda sd, x, kw: oracle.hiremlp_forward(sd, x, kw["h"], kw["w"], kw["cross_region_step"], kw["cross_region_interval"], kw["patch_size"])),
     }
 
 
@@ -182,6 +190,9 @@ def real_configs(ref):
                           oracle=lambda sd, x, kw: oracle.mixer_forward(sd, x)),
         # the reference's default Sparse-MLP (d_model 96, depth [2,10,24,2])
         "sparsemlp_t": dict(ctor=ref["sparse_mlp"].SparseMLP, kw=dict(), bs=2, oracle=lambda sd, x, kw: oracle.sparsemlp_forward(sd, x)),
+        # the reference's default Hire-MLP (d_model [64,128,320,512], depth [4,6,24,3])
+        "hiremlp_s": dict(ctor=ref["hire_mlp"].HireMLP, kw=dict(), bs=2,
+                          oracle=lambda sd, x, kw: oracle.hiremlp_forward(sd, x, [4, 3, 3, 2], [4, 3, 3, 2], [2, 2, 1, 1], 2, 4)),
     }
 
 
@@ -367,7 +378,7 @@ def make_manifest(ref):
         "ConvMixer": ref["conv_mixer"].ConvMixer, "AS_MLP": ref["as_mlp"].AS_MLP, "Shift": ref["shift_cuda"].Shift,
         "MLPMixer": ref["mlp_mixer"].MLPMixer, "gMLP": ref["g_mlp"].gMLP, "ResMLP": ref["res_mlp"].ResMLP,
         "WeightedPermutator": ref["vip"].WeightedPermutator, "Permutator": ref["vip"].Permutator,
-        "S2Block": ref["s2_mlp_v2"].S2Block, "SparseMLP": ref["sparse_mlp"].SparseMLP,
+        "S2Block": ref["s2_mlp_v2"].S2Block, "SparseMLP": ref["sparse_mlp"].SparseMLP, "HireMLP": ref["hire_mlp"].HireMLP,
     }
     for name, c in ctors.items():
         sig = inspect.signature(c)
