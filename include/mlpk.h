@@ -276,6 +276,30 @@ int mlpk_dwconv_affine_nhwc(int dtype, const void* x, void* out, int B, int H, i
                             const float* w, const float* bias, const float* pre_scale,
                             const float* pre_shift, void* stream);
 
+/* ---- general window gather (Hire-MLP's overlapping convolutions) ----------------
+ * mlpk_patchify with a stride of its own: window kh x kw, stride (stride_h, stride_w), zero padding `pad`;
+ * out rows (b, ho, wo), Ho = (H + 2 pad - kh) / stride_h + 1; column order as mlpk_patchify (order 0):
+ * NCHW source ci*kh*kw + i*kw + j, NHWC source (i*kw + j)*Cin + ci.  hire_mlp.py:21 (7x7 s4 p3), :161 (3x3 s2 p1).
+ */
+int mlpk_im2col(int src_dtype, int dst_dtype, int src_layout, const void* src, void* out, int B, int Cin,
+                int H, int W, int kh, int kw, int stride_h, int stride_w, int pad, int src_px_stride,
+                int ldo, void* stream);
+
+/* ---- Hire-MLP region remaps (hire_mlp.py:44-152) -------------------------------------------------
+ * xn: (B,H,W,C) channel-last LayerNorm output.  Hp = H + (h - H % h), Wp = W + (w - W % w) (circular padding, a whole extra
+ * region when the size divides: hire_mlp.py:131-133), gh = Hp / h, gw = Wp / w, step = the cross-region roll (0 = none).
+ * gather : a_h[((b*gh + g)*W + x)*ld_h + hh*C + c] = xn[b, P_H((hh*gh + g - step) mod Hp), x, c]     rows = B*gh*W, K = h*C
+ *          a_w[((b*H + y)*gw + g)*ld_w + ww*C + c] = xn[b, y, P_W((ww*gw + g - step) mod Wp), c]     rows = B*H*gw, K = w*C
+ *          with P_N(q) = q < N ? q : q - N.  The K order is (region row, channel): the 1x1-conv weights of proj_h / proj_w
+ *          are permuted from the reference's (channel, region row) order when they are packed.
+ * combine: x[b,y,x',c] += y_h[((b*gh + qh % gh)*W + x')*ld_h + (qh / gh)*C + c] + y_w[((b*H + y)*gw + qw % gw)*ld_w + (qw / gw)*C + c],
+ *          qh = (y + step) mod Hp, qw = (x' + step) mod Wp          (restore + roll back + crop, :144-150)
+ */
+int mlpk_hire_gather(int dtype, const void* xn, void* a_h, void* a_w, int B, int H, int W, int C, int h, int w,
+                     int step, int ld_h, int ld_w, void* stream);
+int mlpk_hire_combine(int dtype, void* x, const void* y_h, const void* y_w, int B, int H, int W, int C, int h, int w,
+                      int step, int ld_h, int ld_w, void* stream);
+
 /* ---- small utilities ------------------------------------------------------------------------ */
 /* dst[i] = (dst_dtype) src[i], n elements */
 int mlpk_convert(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);

@@ -9,7 +9,7 @@ namespace mlpk {
 struct PatchArgs {
     const void* src;
     void* out;
-    int B, Cin, H, W, ph, pw, pad, px_stride, ldo, order, layout;
+    int B, Cin, H, W, ph, pw, sh, sw, pad, px_stride, ldo, order, layout;      // ph x pw window, sh x sw stride
     int Hp, Wp, K;
     int64_t rows;
 };
@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(256) patchify_kernel(const PatchArgs p) {
             const int ci = k0 - q * p.Cin;
             const int i = p.order == 1 ? (q & 1) : q / p.pw;
             const int j = p.order == 1 ? (q >> 1) : q - (q / p.pw) * p.pw;
-            const int y = hp * p.ph + i - p.pad, x = wp * p.pw + j - p.pad;
+            const int y = hp * p.sh + i - p.pad, x = wp * p.sw + j - p.pad;
             if (y >= 0 && y < p.H && x >= 0 && x < p.W) {
                 const TS* s = src + (((int64_t)b * p.H + y) * p.W + x) * p.px_stride + ci;
 #pragma unroll
@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256) patchify_kernel(const PatchArgs p) {
 #pragma unroll
                 for (int t = 0; t < 8; ++t) e[t] = from_f32<TD>(0.f);
             }
-        } else if (p.layout == MLPK_LAYOUT_NCHW && (p.pw & 7) == 0 && p.pad == 0 && (p.W & 7) == 0 && k0 < p.K &&
+        } else if (p.layout == MLPK_LAYOUT_NCHW && (p.pw & 7) == 0 && p.sw == p.pw && p.sh == p.ph && p.pad == 0 && (p.W & 7) == 0 && k0 < p.K &&
                    (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
             // 8 consecutive k = 8 consecutive pixels of one image row of one channel: 16-byte loads
             const int ci = k0 / (p.ph * p.pw);
@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256) patchify_kernel(const PatchArgs p) {
                         i = p.order == 1 ? (q & 1) : q / p.pw;
                         j = p.order == 1 ? (q >> 1) : q - (q / p.pw) * p.pw;
                     }
-                    const int y = hp * p.ph + i - p.pad, x = wp * p.pw + j - p.pad;
+                    const int y = hp * p.sh + i - p.pad, x = wp * p.sw + j - p.pad;
                     if (y >= 0 && y < p.H && x >= 0 && x < p.W) {
                         const int64_t si = p.layout == MLPK_LAYOUT_NCHW
                                                ? (((int64_t)b * p.Cin + ci) * p.H + y) * p.W + x
@@ -117,20 +117,20 @@ template <typename TS> static int patchify_from(int dst, const PatchArgs& a, uns
 
 using namespace mlpk;
 
-extern "C" int mlpk_patchify(int src_dtype, int dst_dtype, int src_layout, const void* src, void* out, int B, int Cin,
-                             int H, int W, int ph, int pw, int pad, int src_px_stride, int ldo, int order,
-                             void* stream) {
+static int im2col_impl(int src_dtype, int dst_dtype, int src_layout, const void* src, void* out, int B, int Cin, int H, int W,
+                       int ph, int pw, int sh, int sw, int pad, int src_px_stride, int ldo, int order, void* stream) {
     if (!src || !out) return MLPK_ENULL;
-    if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || ph <= 0 || pw <= 0 || pad < 0) return MLPK_ESHAPE;
+    if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || ph <= 0 || pw <= 0 || sh <= 0 || sw <= 0 || pad < 0) return MLPK_ESHAPE;
     if (src_layout != MLPK_LAYOUT_NCHW && src_layout != MLPK_LAYOUT_NHWC) return MLPK_EMODE;
     if (order != 0 && order != 1) return MLPK_EMODE;
     if (order == 1 && (src_layout != MLPK_LAYOUT_NHWC || ph != 2 || pw != 2)) return MLPK_EMODE;
     PatchArgs a;
-    a.src = src; a.out = out; a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.ph = ph; a.pw = pw; a.pad = pad;
+    a.src = src; a.out = out; a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.ph = ph; a.pw = pw; a.sh = sh; a.sw = sw; a.pad = pad;
     a.px_stride = src_layout == MLPK_LAYOUT_NHWC ? src_px_stride : 0;
     a.ldo = ldo; a.order = order; a.layout = src_layout;
-    a.Hp = (H + 2 * pad - ph) / ph + 1;
-    a.Wp = (W + 2 * pad - pw) / pw + 1;
+    if (H + 2 * pad < ph || W + 2 * pad < pw) return MLPK_ESHAPE;
+    a.Hp = (H + 2 * pad - ph) / sh + 1;
+    a.Wp = (W + 2 * pad - pw) / sw + 1;
     a.K = Cin * ph * pw;
     if (a.Hp <= 0 || a.Wp <= 0) return MLPK_ESHAPE;
     if (ldo % 8 || ldo < a.K) return MLPK_ESHAPE;
@@ -146,4 +146,16 @@ extern "C" int mlpk_patchify(int src_dtype, int dst_dtype, int src_layout, const
         case MLPK_BF16: return patchify_from<bf16_t>(dst_dtype, a, grid, s);
         default: return MLPK_EDTYPE;
     }
+}
+
+extern "C" int mlpk_patchify(int src_dtype, int dst_dtype, int src_layout, const void* src, void* out, int B, int Cin,
+                             int H, int W, int ph, int pw, int pad, int src_px_stride, int ldo, int order,
+                             void* stream) {
+    return im2col_impl(src_dtype, dst_dtype, src_layout, src, out, B, Cin, H, W, ph, pw, ph, pw, pad, src_px_stride, ldo, order, stream);
+}
+
+extern "C" int mlpk_im2col(int src_dtype, int dst_dtype, int src_layout, const void* src, void* out, int B, int Cin,
+                           int H, int W, int kh, int kw, int stride_h, int stride_w, int pad, int src_px_stride, int ldo,
+                           void* stream) {
+    return im2col_impl(src_dtype, dst_dtype, src_layout, src, out, B, Cin, H, W, kh, kw, stride_h, stride_w, pad, src_px_stride, ldo, 0, stream);
 }

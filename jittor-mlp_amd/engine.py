@@ -235,6 +235,21 @@ def dwconv_affine_nhwc(x, out, B, H, W, C, k, w, bias, pre_scale, pre_shift):
                                             ptr(pre_scale), ptr(pre_shift), stream()), "mlpk_dwconv_affine_nhwc")
 
 
+def im2col(src, out, B, Cin, H, W, kh, kw, sh, sw, pad, ldo, layout=N.LAYOUT_NCHW, px_stride=0):
+    N.check(N.lib().mlpk_im2col(dtype_code(src.dtype), dtype_code(out.dtype), layout, ptr(src), ptr(out), B, Cin, H, W,
+                                kh, kw, sh, sw, pad, px_stride, ldo, stream()), "mlpk_im2col")
+
+
+def hire_gather(xn, a_h, a_w, B, H, W, C, h, w, step, ld_h, ld_w):
+    N.check(N.lib().mlpk_hire_gather(dtype_code(xn.dtype), ptr(xn), ptr(a_h), ptr(a_w), B, H, W, C, h, w, step, ld_h, ld_w,
+                                     stream()), "mlpk_hire_gather")
+
+
+def hire_combine(x, y_h, y_w, B, H, W, C, h, w, step, ld_h, ld_w):
+    N.check(N.lib().mlpk_hire_combine(dtype_code(x.dtype), ptr(x), ptr(y_h), ptr(y_w), B, H, W, C, h, w, step, ld_h, ld_w,
+                                      stream()), "mlpk_hire_combine")
+
+
 def convert(src, dst, n):
     N.check(N.lib().mlpk_convert(dtype_code(src.dtype), dtype_code(dst.dtype), ptr(src), ptr(dst), n, stream()),
             "mlpk_convert")

@@ -1,0 +1,211 @@
+"""Hire-MLP, drop-in for the reference's models_pytorch/hire_mlp.py, padding_type 'circular'
+(the reference default; the other torch padding modes are not built).
+
+HireMLPBlock (hire_mlp.py:96-152) on the channel-last LayerNorm output xn (B*H*W, C):
+  * the circular pad to whole regions (:131-133 -- a whole extra region when the size already divides), the cross-region
+    roll (:44-51) and the einops fold of the h (w) rows (columns) one region-count apart into the channel axis (:53-93) are
+    index arithmetic inside mlpk_hire_gather, which writes the operand rows of the two branch MLPs directly:
+        A_h rows (b, g, x), K = (region row hh, channel c);   A_w rows (b, y, g), K = (region column ww, channel c)
+    (the 1x1-conv weights are permuted from the reference's (c, hh) order once, when packed);
+  * proj_h / proj_w (FeedForward: 1x1 conv -> GELU -> 1x1 conv, hidden C/2) are two NT GEMMs each, GELU in the epilogue;
+  * proj_c is a GEMM on xn with the block's residual in its epilogue; mlpk_hire_combine adds both branch results back through
+    the inverse index map (restore, roll back, crop) -- nothing padded, rolled or permuted is ever materialised.
+The patcher (7x7 stride-4 pad-3 conv, :203) and the stage transitions (3x3 stride-2 pad-1 conv, :161) are window gathers
+(mlpk_im2col) + GEMM; the channel MLP folds its LayerNorm into fc1; the head folds its LayerNorm into the token mean.
+"""
+import torch
+from torch import nn
+
+from .. import _native as N
+from .. import engine as E
+from .common import Holder, channel_mlp, head_linear, layernorm_stats, pack_channel_mlp
+from .utils import pair
+
+
+class PreNormResidual(Holder):
+    """fn(norm(x)) + x (hire_mlp.py:8-15)."""
+
+    def __init__(self, dim, fn, norm=nn.LayerNorm):
+        super().__init__()
+        self.fn = fn
+        self.norm = norm(dim)
+
+
+class PatchEmbedding(Holder):
+    """hire_mlp.py:17-31."""
+
+    def __init__(self, dim_in, dim_out, kernel_size, stride, padding, norm_layer=False):
+        super().__init__()
+        self.reduction = nn.Sequential(
+            nn.Conv2d(dim_in, dim_out, kernel_size=kernel_size, stride=stride, padding=padding),
+            nn.Identity() if (not norm_layer) else nn.Sequential(nn.Identity(), nn.LayerNorm(dim_out), nn.Identity()))
+
+
+class FeedForward(Holder):
+    """hire_mlp.py:33-42."""
+
+    def __init__(self, dim_in, hidden_dim, dim_out):
+        super().__init__()
+        self.net = nn.Sequential(nn.Conv2d(dim_in, hidden_dim, kernel_size=1), nn.GELU(), nn.Conv2d(hidden_dim, dim_out, kernel_size=1))
+
+
+class HireMLPBlock(Holder):
+    """hire_mlp.py:96-125 (the rearrange / roll sub-modules hold no parameters and are index arithmetic here)."""
+
+    def __init__(self, h, w, d_model, cross_region_step=1, cross_region_id=0, cross_region_interval=2, padding_type='circular'):
+        super().__init__()
+        assert (padding_type in ['constant', 'reflect', 'replicate', 'circular'])
+        if padding_type != 'circular':
+            raise NotImplementedError("padding_type %r: only the reference default 'circular' is built" % padding_type)
+        self.padding_type = padding_type
+        self.w = w
+        self.h = h
+        self.cross_region = (cross_region_id % cross_region_interval == 0)
+        self.step = cross_region_step if self.cross_region else 0
+        self.proj_h = FeedForward(h * d_model, d_model // 2, h * d_model)
+        self.proj_w = FeedForward(w * d_model, d_model // 2, w * d_model)
+        self.proj_c = nn.Conv2d(d_model, d_model, kernel_size=1)
+
+
+class HireMLPStage(Holder):
+    """hire_mlp.py:154-187; `patch_merge` exists in every stage, like the reference's."""
+
+    def __init__(self, h, w, d_model_in, d_model_out, depth, cross_region_step, cross_region_interval, expansion_factor=2,
+                 dropout=0., pooling=False, padding_type='circular'):
+        super().__init__()
+        self.pooling = pooling
+        self.patch_merge = nn.Sequential(nn.Identity(),
+                                         PatchEmbedding(d_model_in, d_model_out, kernel_size=3, stride=2, padding=1, norm_layer=False),
+                                         nn.Identity())
+        self.model = nn.Sequential(*[nn.Sequential(
+            PreNormResidual(d_model_in, nn.Sequential(HireMLPBlock(h, w, d_model_in, cross_region_step=cross_region_step,
+                                                                   cross_region_id=i_depth + 1, cross_region_interval=cross_region_interval,
+                                                                   padding_type=padding_type)), norm=nn.LayerNorm),
+            PreNormResidual(d_model_in, nn.Sequential(nn.Linear(d_model_in, d_model_in * expansion_factor), nn.GELU(), nn.Dropout(dropout),
+                                                      nn.Linear(d_model_in * expansion_factor, d_model_in), nn.Dropout(dropout)),
+                            norm=nn.LayerNorm)) for i_depth in range(depth)])
+        self.geom = (h, w, d_model_in, d_model_out, depth, expansion_factor)
+
+
+def _perm_in(wt, c, r):
+    """1x1-conv weight (out, c*r [,1,1]) with input index c_i * r + rr  ->  (out, r*c) with index rr * c + c_i."""
+    o = wt.shape[0]
+    return wt.detach().reshape(o, c, r).permute(0, 2, 1).reshape(o, r * c)
+
+
+def _perm_out(wt, b, c, r):
+    """1x1-conv weight (c*r, in [,1,1]) / bias (c*r) with output index c_o * r + rr  ->  rows rr * c + c_o."""
+    i = wt.shape[1]
+    return (wt.detach().reshape(c, r, i).permute(1, 0, 2).reshape(r * c, i), b.detach().reshape(c, r).t().reshape(r * c))
+
+
+class HireMLP(E.EngineModule):
+    """Same signature and defaults as the reference (hire_mlp.py:188-201)."""
+
+    def __init__(self, patch_size=4, in_channels=3, num_classes=1000, d_model=[64, 128, 320, 512], h=[4, 3, 3, 2], w=[4, 3, 3, 2],
+                 cross_region_step=[2, 2, 1, 1], cross_region_interval=2, depth=[4, 6, 24, 3], expansion_factor=2,
+                 patcher_norm=False, padding_type='circular'):
+        patch_size = pair(patch_size)
+        super().__init__()
+        self.patcher = PatchEmbedding(dim_in=in_channels, dim_out=d_model[0], kernel_size=7, stride=patch_size, padding=3,
+                                      norm_layer=patcher_norm)
+        self.layers = nn.ModuleList()
+        for i_layer in range(len(depth)):
+            self.layers.append(HireMLPStage(
+                h[i_layer], w[i_layer], d_model[i_layer],
+                d_model_out=d_model[i_layer + 1] if (i_layer + 1 < len(depth)) else d_model[-1], depth=depth[i_layer],
+                cross_region_step=cross_region_step[i_layer], cross_region_interval=cross_region_interval,
+                expansion_factor=expansion_factor, pooling=((i_layer + 1) < len(depth)), padding_type=padding_type))
+        self.mlp_head = nn.Sequential(nn.LayerNorm(d_model[-1]), nn.Identity(), nn.Linear(d_model[-1], num_classes))
+        self._cfg = (patch_size, in_channels, num_classes, patcher_norm)
+
+    def _pack(self, dtype, device):
+        pk = {}
+        conv = self.patcher.reduction[0]
+        pk["embed.w"] = E.pack_matrix(conv.weight, dtype, device)                           # (ci, i, j) order == the NCHW window gather
+        pk["embed.b"] = E.f32(conv.bias, device)
+        if self._cfg[3]:
+            ln = self.patcher.reduction[1][1]
+            pk["embed.g"], pk["embed.be"] = E.f32(ln.weight, device), E.f32(ln.bias, device)
+        for li, stage in enumerate(self.layers):
+            h, w, C, Cout, depth, ef = stage.geom
+            for bi, blk in enumerate(stage.model):
+                p = "l%d.b%d." % (li, bi)
+                hb = blk[0].fn[0]
+                pk[p + "ln.g"], pk[p + "ln.b"] = E.f32(blk[0].norm.weight, device), E.f32(blk[0].norm.bias, device)
+                for tag, ff, r in (("h", hb.proj_h, h), ("w", hb.proj_w, w)):
+                    pk[p + tag + "1.w"] = E.pack_matrix(_perm_in(ff.net[0].weight, C, r), dtype, device)
+                    pk[p + tag + "1.b"] = E.f32(ff.net[0].bias, device)
+                    w2, b2 = _perm_out(ff.net[2].weight, ff.net[2].bias, C, r)
+                    pk[p + tag + "2.w"] = E.pack_matrix(w2, dtype, device)
+                    pk[p + tag + "2.b"] = E.f32(b2, device)
+                pk[p + "c.w"] = E.pack_matrix(hb.proj_c.weight, dtype, device)
+                pk[p + "c.b"] = E.f32(hb.proj_c.bias, device)
+                ff = blk[1]
+                pack_channel_mlp(pk, p + "ff.", ff.norm, ff.fn[0], ff.fn[3], dtype, device)
+            if stage.pooling:
+                mc = stage.patch_merge[1].reduction[0]
+                # channel-last window gather: K order (i, j, ci)
+                pk["l%d.merge.w" % li] = E.pack_matrix(mc.weight.detach().permute(0, 2, 3, 1).reshape(Cout, 9 * C), dtype, device)
+                pk["l%d.merge.b" % li] = E.f32(mc.bias, device)
+        pk["head.g"], pk["head.be"] = E.f32(self.mlp_head[0].weight, device), E.f32(self.mlp_head[0].bias, device)
+        pk["head.w"] = E.pack_matrix(self.mlp_head[2].weight, dtype, device)
+        pk["head.b"] = E.f32(self.mlp_head[2].bias, device)
+        return pk
+
+    def forward(self, x):
+        cd = self._resolve(x)
+        patch, cin, num_classes, patcher_norm = self._cfg
+        B, _, H_in, W_in = x.shape
+        pk = self._get_pack(cd, x.device)
+        ws = self._get_space(B, cd, x.device)
+        x = x.contiguous()
+        C = self.layers[0].geom[2]
+        H, W = (H_in + 6 - 7) // patch[0] + 1, (W_in + 6 - 7) // patch[1] + 1
+        kp = pk["embed.w"].shape[1]
+        patches = ws.get("embed.patches", (B * H * W, kp))
+        E.im2col(x, patches, B, cin, H_in, W_in, 7, 7, patch[0], patch[1], 3, kp)
+        cur = ws.get("l0.x", (B * H * W, C))
+        E.gemm(patches, pk["embed.w"], cur, B * H * W, C, kp, bias=pk["embed.b"])
+        if patcher_norm:
+            mean, rstd = layernorm_stats(ws, cur, B * H * W, C, tag="embed.ln")
+            E.norm_apply(cur, B * H * W, C, C, mean=mean, rstd=rstd, gamma=pk["embed.g"], beta=pk["embed.be"], out_rm=cur, ld_rm=C)
+        for li, stage in enumerate(self.layers):
+            h, w, C, Cout, depth, ef = stage.geom
+            rows = B * H * W
+            Hp, Wp = H + (h - H % h), W + (w - W % w)                                         # hire_mlp.py:131-133
+            gh, gw = Hp // h, Wp // w
+            rows_h, rows_w = B * gh * W, B * H * gw
+            hid = C // 2
+            hidp = E.round_up(hid, 8)
+            xn = ws.get("l%d.xn" % li, (rows, C))
+            a_h = ws.get("l%d.ah" % li, (rows_h, h * C))
+            a_w = ws.get("l%d.aw" % li, (rows_w, w * C))
+            t_h = ws.get("l%d.th" % li, (rows_h, hidp))
+            t_w = ws.get("l%d.tw" % li, (rows_w, hidp))
+            for bi, blk in enumerate(stage.model):
+                p = "l%d.b%d." % (li, bi)
+                step = blk[0].fn[0].step
+                mean, rstd = layernorm_stats(ws, cur, rows, C, tag="l%d.ln" % li)
+                E.norm_apply(cur, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "ln.g"], beta=pk[p + "ln.b"], out_rm=xn, ld_rm=C)
+                E.hire_gather(xn, a_h, a_w, B, H, W, C, h, w, step, h * C, w * C)
+                E.gemm(a_h, pk[p + "h1.w"], t_h, rows_h, hid, h * C, bias=pk[p + "h1.b"], act=N.ACT_GELU, tag="hire_fc1")
+                E.gemm(t_h, pk[p + "h2.w"], a_h, rows_h, h * C, hidp, bias=pk[p + "h2.b"], tag="hire_fc2")    # y_h overwrites a_h
+                E.gemm(a_w, pk[p + "w1.w"], t_w, rows_w, hid, w * C, bias=pk[p + "w1.b"], act=N.ACT_GELU, tag="hire_fc1")
+                E.gemm(t_w, pk[p + "w2.w"], a_w, rows_w, w * C, hidp, bias=pk[p + "w2.b"], tag="hire_fc2")
+                E.gemm(xn, pk[p + "c.w"], cur, rows, C, C, bias=pk[p + "c.b"], R=cur, res=N.RES_ADD, tag="hire_c")   # x + proj_c(xn)
+                E.hire_combine(cur, a_h, a_w, B, H, W, C, h, w, step, h * C, w * C)
+                channel_mlp(ws, cur, rows, C, pk, p + "ff.", C * ef, tag="l%d.cm" % li)
+            if stage.pooling:
+                H2, W2 = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+                kp = pk["l%d.merge.w" % li].shape[1]
+                cols = ws.get("l%d.cols" % li, (B * H2 * W2, kp))
+                E.im2col(cur, cols, B, C, H, W, 3, 3, 2, 2, 1, kp, layout=N.LAYOUT_NHWC, px_stride=C)
+                nxt = ws.get("l%d.x" % (li + 1), (B * H2 * W2, Cout))
+                E.gemm(cols, pk["l%d.merge.w" % li], nxt, B * H2 * W2, Cout, kp, bias=pk["l%d.merge.b" % li], tag="hire_merge")
+                cur, H, W = nxt, H2, W2
+        C = self.layers[-1].geom[2]
+        mean, rstd = layernorm_stats(ws, cur, B * H * W, C, tag="head.ln")
+        pooled = ws.get("pooled", (B, C))
+        E.pool_mean(cur, B, H * W, C, C, pooled, C, mean=mean, rstd=rstd, gamma=pk["head.g"], beta=pk["head.be"])
+        return head_linear(ws, pooled, B, C, pk["head.w"], pk["head.b"], num_classes, x.dtype)

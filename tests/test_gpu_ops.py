@@ -601,3 +601,70 @@ def test_dwconv_affine_nhwc(dtype):
         err = (out.float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
         tol = 2e-5 if dtype == torch.float32 else (4e-3 if dtype == torch.float16 else 3e-2)
         assert err < tol * max(1.0, ref.abs().max().item()), (str(dtype), ci, err)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_im2col_strided(dtype):
+    """mlpk_im2col: overlapping windows (kernel != stride) with zero padding, both source layouts, against
+    torch.nn.functional.unfold (hire_mlp.py:21 7x7 s4 p3 on NCHW; :161 3x3 s2 p1 on channel-last)."""
+    pkg = load_pkg()
+    E, N = pkg.engine, pkg._native
+    for ci, (B, C, H, W, k, s_, p, layout) in enumerate(((2, 3, 20, 28, 7, 4, 3, 0), (2, 8, 9, 7, 3, 2, 1, 1), (1, 16, 8, 8, 3, 2, 1, 1),
+                                                         (1, 3, 16, 16, 5, 3, 2, 0))):
+        x = rnd((B, C, H, W), dtype, 1000 + ci)
+        Ho, Wo = (H + 2 * p - k) // s_ + 1, (W + 2 * p - k) // s_ + 1
+        cols = torch.nn.functional.unfold(x.float(), k, padding=p, stride=s_)                    # (B, C*k*k, Ho*Wo), k index ci*k*k + i*k + j
+        ref = cols.transpose(1, 2).reshape(B * Ho * Wo, C, k * k)
+        K = C * k * k
+        kp = (K + 7) // 8 * 8
+        out = torch.full((B * Ho * Wo, kp), float("nan"), dtype=dtype, device=dev())
+        if layout == 0:
+            E.im2col(x.to(dev()), out, B, C, H, W, k, k, s_, s_, p, kp)
+            want = ref.reshape(B * Ho * Wo, K)
+        else:
+            xl = x.permute(0, 2, 3, 1).contiguous().to(dev())
+            E.im2col(xl, out, B, C, H, W, k, k, s_, s_, p, kp, layout=N.LAYOUT_NHWC, px_stride=C)
+            want = ref.permute(0, 2, 1).reshape(B * Ho * Wo, K)                                    # (i*k + j)*C + ci
+        torch.cuda.synchronize()
+        got = out.float().cpu()
+        assert torch.equal(got[:, :K], want.to(dtype).float()), (str(dtype), ci)
+        assert (got[:, K:] == 0).all()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_hire_gather_combine(dtype):
+    """Hire-MLP region remaps against the reference formulation (circular pad -> roll -> einops fold, hire_mlp.py:127-150)
+    written with torch ops: gather builds the branch operands, combine is the inverse map (+ crop) added onto x.  Bit-exact moves."""
+    pkg = load_pkg()
+    E = pkg.engine
+    for ci, (B, H, W, C, h, w, step) in enumerate(((2, 8, 12, 16, 3, 2, 1), (1, 16, 16, 8, 4, 4, 2), (2, 4, 6, 8, 2, 3, 0), (1, 7, 5, 8, 3, 2, 2))):
+        xn = rnd((B, H, W, C), dtype, 1100 + ci)
+        Hp, Wp = H + (h - H % h), W + (w - W % w)
+        gh, gw = Hp // h, Wp // w
+        t = xn.permute(0, 3, 1, 2)
+        t = torch.cat([t, t[:, :, :, :Wp - W]], dim=3)
+        t = torch.cat([t, t[:, :, :Hp - H, :]], dim=2)
+        th, tw = torch.roll(t, step, 2), torch.roll(t, step, 3)
+        # 'b c (h group) w -> b (c h) group w' read back as rows (b, group, w) x columns (hh, c); only the columns < W are needed
+        ref_h = th.reshape(B, C, h, gh, Wp)[..., :W].permute(0, 3, 4, 2, 1).reshape(B * gh * W, h * C)
+        ref_w = tw.reshape(B, C, Hp, w, gw)[:, :, :H].permute(0, 2, 4, 3, 1).reshape(B * H * gw, w * C)
+        a_h = torch.full((B * gh * W, h * C), float("nan"), dtype=dtype, device=dev())
+        a_w = torch.full((B * H * gw, w * C), float("nan"), dtype=dtype, device=dev())
+        E.hire_gather(xn.to(dev()), a_h, a_w, B, H, W, C, h, w, step, h * C, w * C)
+        torch.cuda.synchronize()
+        assert torch.equal(a_h.cpu(), ref_h) and torch.equal(a_w.cpu(), ref_w), (str(dtype), ci)
+        # combine: the inverse maps applied to arbitrary branch outputs
+        y_h = rnd((B * gh * W, h * C), dtype, 1110 + ci)
+        y_w = rnd((B * H * gw, w * C), dtype, 1120 + ci)
+        full_h = torch.zeros((B, C, Hp, Wp), dtype=torch.float32)
+        full_h[..., :W] = y_h.float().reshape(B, gh, W, h, C).permute(0, 4, 3, 1, 2).reshape(B, C, Hp, W)
+        full_w = torch.zeros((B, C, Hp, Wp), dtype=torch.float32)
+        full_w[:, :, :H] = y_w.float().reshape(B, H, gw, w, C).permute(0, 4, 1, 3, 2).reshape(B, C, H, Wp)
+        back = (torch.roll(full_h, -step, 2) + torch.roll(full_w, -step, 3))[:, :, :H, :W].permute(0, 2, 3, 1)
+        x0 = rnd((B, H, W, C), dtype, 1130 + ci)
+        want = (x0.float() + back).to(dtype)
+        xg = x0.clone().to(dev())
+        E.hire_combine(xg, y_h.to(dev()), y_w.to(dev()), B, H, W, C, h, w, step, h * C, w * C)
+        torch.cuda.synchronize()
+        err = (xg.float().cpu() - want.float()).abs().max().item()
+        assert err <= (1e-6 if dtype == torch.float32 else 2e-2), (str(dtype), ci, err)
