@@ -646,3 +646,60 @@ def hiremlp_forward(sd, x, h, w, cross_region_step, cross_region_interval=2, pat
     t = layer_norm(t, _p(sd, "mlp_head.0.weight", x), _p(sd, "mlp_head.0.bias", x))
     t = t.mean(dim=(1, 2))
     return linear(t, _p(sd, "mlp_head.2.weight", x), _p(sd, "mlp_head.2.bias", x))
+
+
+# --------------------------------------------------------------------------
+# MS-MLP  (ms_mlp.py:11-359)  -- SURVEY.md 8(f) rank 3
+# --------------------------------------------------------------------------
+MS_EPS = 1e-6          # ms_mlp.py:279: its own LayerNorm class defaults to eps = 1e-6
+
+
+def msmlp_block(sd, x, pre, shift_dist, mix_size):
+    """MixShiftBlock.forward on NCHW x in eval mode (ms_mlp.py:48-78): channel chunks (torch.chunk sizes) rolled by their
+    relative distance along W / along H, each mixed by its own k x k depthwise conv (zero padding k//2), the two sums added,
+    LayerNorm(eps 1e-6) -> Linear -> GELU -> Linear -> layer scale gamma, residual onto the block input."""
+    n, c, hh, ww = x.shape
+    groups = len(shift_dist)
+    sizes = [t.shape[0] for t in torch.chunk(torch.zeros(c), groups)]                   # :33
+    lr, td, c0 = [], [], 0
+    for i, cs in enumerate(sizes):
+        xc = x[:, c0:c0 + cs]
+        wl, bl = _p(sd, pre + "dwconv_lr.%d.weight" % i, x), _p(sd, pre + "dwconv_lr.%d.bias" % i, x)
+        wt, bt = _p(sd, pre + "dwconv_td.%d.weight" % i, x), _p(sd, pre + "dwconv_td.%d.bias" % i, x)
+        assert wl.shape[-1] == mix_size[i]
+        lr.append(depthwise_conv_same(torch.roll(xc, shift_dist[i], 3), wl, bl))         # :56, :61
+        td.append(depthwise_conv_same(torch.roll(xc, shift_dist[i], 2), wt, bt))         # :57, :62
+        c0 += cs
+    t = (torch.cat(lr, 1) + torch.cat(td, 1)).permute(0, 2, 3, 1)
+    t = layer_norm(t, _p(sd, pre + "norm.weight", x), _p(sd, pre + "norm.bias", x), eps=MS_EPS)
+    t = linear(gelu(linear(t, _p(sd, pre + "pwconv1.weight", x), _p(sd, pre + "pwconv1.bias", x))),
+               _p(sd, pre + "pwconv2.weight", x), _p(sd, pre + "pwconv2.bias", x))
+    if (pre + "gamma") in sd:
+        t = t * _p(sd, pre + "gamma", x)
+    return x + t.permute(0, 3, 1, 2)
+
+
+def msmlp_forward(sd, x, shift_dist=(-2, -1, 0, 1, 2), mix_size=((1, 1, 3, 5, 7), (1, 1, 3, 5, 5), (1, 1, 3, 3, 3), (1, 1, 1, 1, 3)), hooks=None):
+    """MS_MLP.forward (ms_mlp.py:341-359), eval mode: patch embed + LN, stages of MixShiftBlocks with a 2x2-conv + LN
+    downsample (a PatchEmbed, :178-180), global average pool, LayerNorm AFTER the pool (:352-354), head."""
+    x = x.detach().cpu()
+    t = patch_embed(x, _p(sd, "patch_embed.proj.weight", x), _p(sd, "patch_embed.proj.bias", x))
+    if "patch_embed.norm.weight" in sd:
+        t = layer_norm(t, _p(sd, "patch_embed.norm.weight", x), _p(sd, "patch_embed.norm.bias", x), eps=MS_EPS)
+    t = t.permute(0, 3, 1, 2)
+    layer = 0
+    while ("layers.%d.blocks.0.norm.weight" % layer) in sd:
+        for i in range(_depth(sd, "layers.%d" % layer + ".blocks.%d.norm.weight")):
+            t = msmlp_block(sd, t, "layers.%d.blocks.%d." % (layer, i), shift_dist, mix_size[layer])
+            if hooks is not None:
+                hooks("layers.%d.blocks.%d" % (layer, i), t)
+        pre = "layers.%d.downsample." % layer
+        if (pre + "proj.weight") in sd:
+            t = patch_embed(t, _p(sd, pre + "proj.weight", x), _p(sd, pre + "proj.bias", x))
+            if (pre + "norm.weight") in sd:
+                t = layer_norm(t, _p(sd, pre + "norm.weight", x), _p(sd, pre + "norm.bias", x), eps=MS_EPS)
+            t = t.permute(0, 3, 1, 2)
+        layer += 1
+    t = t.mean(dim=(2, 3))
+    t = layer_norm(t, _p(sd, "norm.weight", x), _p(sd, "norm.bias", x), eps=MS_EPS)
+    return linear(t, _p(sd, "head.weight", x), _p(sd, "head.bias", x))

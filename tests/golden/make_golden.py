@@ -62,7 +62,7 @@ def load_reference():
     tl.trunc_normal_ = torch.nn.init.trunc_normal_
     sys.modules["timm"], sys.modules["timm.models"], sys.modules["timm.models.layers"] = timm, tm, tl
     mods = {}
-    for name in ("mlp_mixer", "g_mlp", "res_mlp", "vip", "s2_mlp_v1", "s2_mlp_v2", "conv_mixer", "as_mlp", "sparse_mlp", "hire_mlp"):
+    for name in ("mlp_mixer", "g_mlp", "res_mlp", "vip", "s2_mlp_v1", "s2_mlp_v2", "conv_mixer", "as_mlp", "sparse_mlp", "hire_mlp", "ms_mlp"):
         mods[name] = importlib.import_module("models_pytorch." + name)
     sc = importlib.import_module("models_pytorch.utils.shift_cuda")
     sc.Shift.forward = lambda self, x: x if self.kernel_size == 1 else sc.torch_shift(x, self.kernel_size, self.dim)
@@ -162,6 +162,15 @@ def tiny_configs(ref):
                                                                    depth=[1, 2], expansion_factor=3, num_classes=10, patcher_norm=True),
                              hw=(32, 48), pins=["layers.1.model.1"],
                              oracle=lambda sd, x, kw: oracle.hiremlp_forward(sd, x, kw["h"], kw["w"], kw["cross_region_step"], kw["cross_region_interval"], kw["patch_size"])),
+        # SURVEY.md 8(f) rank 3
+        "msmlp": dict(ctor=ref["ms_mlp"].MS_MLP, kw=dict(img_size=64, patch_size=4, embed_dim=24, depths=[1, 2, 1], shift_size=5, shift_dist=[-2, -1, 0, 1, 2],
+                                                         mix_size=[[1, 1, 3, 5, 7], [1, 1, 3, 5, 5], [1, 1, 1, 3, 3]], num_classes=10),
+                      hw=(64, 64), pins=["layers.0.blocks.0", "layers.1.blocks.1"], gamma=0.3,
+                      oracle=lambda sd, x, kw: oracle.msmlp_forward(sd, x, kw["shift_dist"], kw["mix_size"])),
+        "msmlp_s3": dict(ctor=ref["ms_mlp"].MS_MLP, kw=dict(img_size=32, patch_size=4, embed_dim=16, depths=[2, 1], shift_size=3, shift_dist=[-1, 0, 3],
+                                                            mix_size=[[3, 1, 5], [1, 3, 3]], mlp_ratio=2., num_classes=10, patch_norm=False),
+                         hw=(32, 32), pins=["layers.0.blocks.1"], gamma=0.5,
+                         oracle=lambda sd, x, kw: oracle.msmlp_forward(sd, x, kw["shift_dist"], kw["mix_size"])),
     }
 
 
@@ -193,6 +202,8 @@ def real_configs(ref):
         # the reference's default Hire-MLP (d_model [64,128,320,512], depth [4,6,24,3])
         "hiremlp_s": dict(ctor=ref["hire_mlp"].HireMLP, kw=dict(), bs=2,
                           oracle=lambda sd, x, kw: oracle.hiremlp_forward(sd, x, [4, 3, 3, 2], [4, 3, 3, 2], [2, 2, 1, 1], 2, 4)),
+        # the reference's default MS-MLP (embed 96, depths [2,2,6,2])
+        "msmlp_t": dict(ctor=ref["ms_mlp"].MS_MLP, kw=dict(), bs=2, oracle=lambda sd, x, kw: oracle.msmlp_forward(sd, x)),
     }
 
 
@@ -227,6 +238,11 @@ def make_tiny(ref, names=None):
         torch.manual_seed(0)
         model = cfg["ctor"](**cfg["kw"]).eval()
         randomize_norm_stats(model, 1)
+        if "gamma" in cfg:          # layer-scale parameters start at 1e-6 (ms_mlp.py:43): make the blocks visible in the logits
+            with torch.no_grad():
+                for n_, p_ in model.named_parameters():
+                    if n_.endswith(".gamma"):
+                        p_.copy_(cfg["gamma"] * (1.0 + 0.5 * torch.rand_like(p_)))
         x = torch.randn(2, 3, *cfg["hw"])
         pins, handles = hook_pins(model, cfg["pins"])
         out = run_ref(model, x, cfg.get("one_thread", False))
@@ -378,7 +394,7 @@ def make_manifest(ref):
         "ConvMixer": ref["conv_mixer"].ConvMixer, "AS_MLP": ref["as_mlp"].AS_MLP, "Shift": ref["shift_cuda"].Shift,
         "MLPMixer": ref["mlp_mixer"].MLPMixer, "gMLP": ref["g_mlp"].gMLP, "ResMLP": ref["res_mlp"].ResMLP,
         "WeightedPermutator": ref["vip"].WeightedPermutator, "Permutator": ref["vip"].Permutator,
-        "S2Block": ref["s2_mlp_v2"].S2Block, "SparseMLP": ref["sparse_mlp"].SparseMLP, "HireMLP": ref["hire_mlp"].HireMLP,
+        "S2Block": ref["s2_mlp_v2"].S2Block, "SparseMLP": ref["sparse_mlp"].SparseMLP, "HireMLP": ref["hire_mlp"].HireMLP, "MS_MLP": ref["ms_mlp"].MS_MLP,
     }
     for name, c in ctors.items():
         sig = inspect.signature(c)
