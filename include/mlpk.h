@@ -300,6 +300,17 @@ int mlpk_hire_gather(int dtype, const void* xn, void* a_h, void* a_w, int B, int
 int mlpk_hire_combine(int dtype, void* x, const void* y_h, const void* y_w, int B, int H, int W, int C, int h, int w,
                       int step, int ld_h, int ld_w, void* stream);
 
+/* ---- MS-MLP mix-shift (ms_mlp.py:48-66) -------------------------------------------
+ * x, out: (B,H,W,C) channel-last.  The C channels form `groups` <= 8 chunks of ceil(C/groups) channels (torch.chunk); chunk g is
+ * rolled by shift[g] along W (left/right branch) and along H (top/down branch) and each rolled copy goes through its own
+ * ksize[g] x ksize[g] depthwise convolution (odd, zero padding ksize/2); out = branch_lr + branch_td (biases included).
+ * w_lr / w_td: float32 [kmax*kmax][C], channel c's taps in rows dy*k + dx with k = its chunk's ksize; b_lr / b_td: float32 [C].
+ * The host pointers `shift`, `ksize` are read at launch time (they travel as kernel arguments).
+ */
+int mlpk_mixshift_nhwc(int dtype, const void* x, void* out, int B, int H, int W, int C, int groups, const int* shift,
+                       const int* ksize, const float* w_lr, const float* b_lr, const float* w_td, const float* b_td,
+                       void* stream);
+
 /* ---- small utilities ------------------------------------------------------------------------ */
 /* dst[i] = (dst_dtype) src[i], n elements */
 int mlpk_convert(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);

@@ -151,3 +151,190 @@ extern "C" int mlpk_hire_combine(int dtype, void* x, const void* y_h, const void
     MLPK_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- MS-MLP mix-shift (ms_mlp.py:48-66) -------------------------------------------------
+// out[b,y,x,c] = b_lr[c] + sum_{dy,dx} w_lr[c][dy][dx] * R_w(y+dy-p, x+dx-p)  +  b_td[c] + sum w_td[c][dy][dx] * R_h(y+dy-p, x+dx-p)
+// with k = ksize[g(c)], p = k/2, zero outside [0,H)x[0,W), R_w(y,x) = in[b, y, (x - s) mod W, c] (the chunk rolled along W),
+// R_h(y,x) = in[b, (y - s) mod H, x, c], s = shift[g(c)], g(c) = c / chunk0 (torch.chunk: ceil(C / groups) channels per chunk).
+// One thread per (pixel, channel): consecutive threads = consecutive channels (coalesced); chunks need not be whole vectors.
+namespace mlpk {
+
+struct MixShiftArgs {
+    const void* x;
+    void* out;
+    const float* w_lr;   // [kmax*kmax][C] tap-major (row dy*k + dx of the chunk's own k), unused taps absent
+    const float* w_td;
+    const float* b_lr;   // [C]
+    const float* b_td;
+    int B, H, W, C, groups, chunk0;
+    int shift[8], ksize[8];
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) mixshift_kernel(const MixShiftArgs p) {
+    const T* __restrict__ in = reinterpret_cast<const T*>(p.x);
+    T* __restrict__ out = reinterpret_cast<T*>(p.out);
+    const int64_t total = (int64_t)p.B * p.H * p.W * p.C;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c = (int)(idx % p.C);
+        int64_t r = idx / p.C;
+        const int x = (int)(r % p.W); r /= p.W;
+        const int y = (int)(r % p.H);
+        const int64_t b = r / p.H;
+        const int g = c / p.chunk0;
+        const int k = p.ksize[g], s = p.shift[g], P = k >> 1;
+        float acc = p.b_lr[c] + p.b_td[c];
+        const T* img = in + b * p.H * p.W * p.C + c;
+        for (int dy = 0; dy < k; ++dy) {
+            const int yy = y + dy - P;
+            if (yy < 0 || yy >= p.H) continue;
+            int ys = (yy - s) % p.H;
+            if (ys < 0) ys += p.H;
+            for (int dx = 0; dx < k; ++dx) {
+                const int xx = x + dx - P;
+                if (xx < 0 || xx >= p.W) continue;
+                int xs = (xx - s) % p.W;
+                if (xs < 0) xs += p.W;
+                const int t = dy * k + dx;
+                acc = fmaf(p.w_lr[(size_t)t * p.C + c], to_f32(img[((int64_t)yy * p.W + xs) * p.C]), acc);
+                acc = fmaf(p.w_td[(size_t)t * p.C + c], to_f32(img[((int64_t)ys * p.W + xx) * p.C]), acc);
+            }
+        }
+        out[idx] = from_f32<T>(acc);
+    }
+}
+
+// 16-byte channel vectors: a vector whose channels share one chunk (same shift, same kernel size) moves as whole vectors
+// -- per tap two 16-byte data loads and the weight vectors -- instead of one 2-byte load per channel and tap; a vector
+// that straddles a chunk boundary (chunks of 20 channels: every fifth one) falls back to the per-channel arithmetic.
+// Measured on MS-MLP-T (bs 256, bf16): 950 us per call per-channel -> 805 us; still texture-address bound (every input vector is
+// fetched once per tap and branch, and a wave runs the longest kernel of its lanes).  A variant with 4-pixel output strips
+// and the kernel size as a template parameter (each loaded vector reused for 4 outputs) spilled its window registers
+// and ran at 2650 us; the real fix is the LDS-tiled stencil of mlpk_dwconv.hip with a rolled tile load -- next.
+template <typename T>
+__global__ void __launch_bounds__(256) mixshift_vec_kernel(const MixShiftArgs p) {
+    constexpr int EPV = 16 / (int)sizeof(T);
+    const T* __restrict__ in = reinterpret_cast<const T*>(p.x);
+    T* __restrict__ out = reinterpret_cast<T*>(p.out);
+    const int cv = p.C / EPV;
+    const int64_t total = (int64_t)p.B * p.H * p.W * cv;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c0 = (int)(idx % cv) * EPV;
+        int64_t r = idx / cv;
+        const int x = (int)(r % p.W); r /= p.W;
+        const int y = (int)(r % p.H);
+        const int64_t b = r / p.H;
+        const T* img = in + b * p.H * p.W * p.C;
+        float acc[EPV];
+        const int g0 = c0 / p.chunk0;
+        if (g0 == (c0 + EPV - 1) / p.chunk0) {
+            const int k = p.ksize[g0], P = k >> 1;
+            // roll distances reduced once (two divisions per thread, none per tap): 0 <= sh < H, 0 <= sw < W
+            int sh = p.shift[g0] % p.H, sw = p.shift[g0] % p.W;
+            if (sh < 0) sh += p.H;
+            if (sw < 0) sw += p.W;
+#pragma unroll
+            for (int e = 0; e < EPV; e += 4) {
+                const f32x4 bl = *reinterpret_cast<const f32x4*>(p.b_lr + c0 + e), bt = *reinterpret_cast<const f32x4*>(p.b_td + c0 + e);
+                acc[e] = bl.x + bt.x; acc[e + 1] = bl.y + bt.y; acc[e + 2] = bl.z + bt.z; acc[e + 3] = bl.w + bt.w;
+            }
+            for (int dy = 0; dy < k; ++dy) {
+                const int yy = y + dy - P;
+                if (yy < 0 || yy >= p.H) continue;
+                int ys = yy - sh;
+                if (ys < 0) ys += p.H;
+                for (int dx = 0; dx < k; ++dx) {
+                    const int xx = x + dx - P;
+                    if (xx < 0 || xx >= p.W) continue;
+                    int xs = xx - sw;
+                    if (xs < 0) xs += p.W;
+                    const int t = dy * k + dx;
+                    T vl[EPV], vt[EPV];
+                    *reinterpret_cast<u32x4*>(vl) = *reinterpret_cast<const u32x4*>(img + ((int64_t)yy * p.W + xs) * p.C + c0);
+                    *reinterpret_cast<u32x4*>(vt) = *reinterpret_cast<const u32x4*>(img + ((int64_t)ys * p.W + xx) * p.C + c0);
+                    const float* wl = p.w_lr + (size_t)t * p.C + c0;
+                    const float* wt = p.w_td + (size_t)t * p.C + c0;
+#pragma unroll
+                    for (int e = 0; e < EPV; e += 4) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(wl + e), d = *reinterpret_cast<const f32x4*>(wt + e);
+                        acc[e] = fmaf(d.x, to_f32(vt[e]), fmaf(a.x, to_f32(vl[e]), acc[e]));
+                        acc[e + 1] = fmaf(d.y, to_f32(vt[e + 1]), fmaf(a.y, to_f32(vl[e + 1]), acc[e + 1]));
+                        acc[e + 2] = fmaf(d.z, to_f32(vt[e + 2]), fmaf(a.z, to_f32(vl[e + 2]), acc[e + 2]));
+                        acc[e + 3] = fmaf(d.w, to_f32(vt[e + 3]), fmaf(a.w, to_f32(vl[e + 3]), acc[e + 3]));
+                    }
+                }
+            }
+        } else {
+            for (int e = 0; e < EPV; ++e) {
+                const int c = c0 + e;
+                const int g = c / p.chunk0;
+                const int k = p.ksize[g], s = p.shift[g], P = k >> 1;
+                float a = p.b_lr[c] + p.b_td[c];
+                for (int dy = 0; dy < k; ++dy) {
+                    const int yy = y + dy - P;
+                    if (yy < 0 || yy >= p.H) continue;
+                    int ys = (yy - s) % p.H;
+                    if (ys < 0) ys += p.H;
+                    for (int dx = 0; dx < k; ++dx) {
+                        const int xx = x + dx - P;
+                        if (xx < 0 || xx >= p.W) continue;
+                        int xs = (xx - s) % p.W;
+                        if (xs < 0) xs += p.W;
+                        const int t = dy * k + dx;
+                        a = fmaf(p.w_lr[(size_t)t * p.C + c], to_f32(img[((int64_t)yy * p.W + xs) * p.C + c]), a);
+                        a = fmaf(p.w_td[(size_t)t * p.C + c], to_f32(img[((int64_t)ys * p.W + xx) * p.C + c]), a);
+                    }
+                }
+                acc[e] = a;
+            }
+        }
+        T o[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) o[e] = from_f32<T>(acc[e]);
+        *reinterpret_cast<u32x4*>(out + ((b * p.H + y) * p.W + x) * p.C + c0) = *reinterpret_cast<const u32x4*>(o);
+    }
+}
+
+}  // namespace mlpk
+
+extern "C" int mlpk_mixshift_nhwc(int dtype, const void* x, void* out, int B, int H, int W, int C, int groups, const int* shift,
+                                  const int* ksize, const float* w_lr, const float* b_lr, const float* w_td, const float* b_td,
+                                  void* stream) {
+    if (!x || !out || !shift || !ksize || !w_lr || !b_lr || !w_td || !b_td) return MLPK_ENULL;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || groups <= 0 || groups > 8 || groups > C) return MLPK_ESHAPE;
+    if (x == out) return MLPK_ESHAPE;
+    if (dtype != MLPK_F32 && dtype != MLPK_F16 && dtype != MLPK_BF16) return MLPK_EDTYPE;
+    MixShiftArgs a;
+    a.x = x; a.out = out; a.w_lr = w_lr; a.w_td = w_td; a.b_lr = b_lr; a.b_td = b_td;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.groups = groups;
+    a.chunk0 = (C + groups - 1) / groups;                       // torch.chunk
+    if ((C + a.chunk0 - 1) / a.chunk0 != groups) return MLPK_ESHAPE;     // torch.chunk would return fewer chunks
+    for (int g = 0; g < 8; ++g) {
+        a.shift[g] = g < groups ? shift[g] : 0;
+        a.ksize[g] = g < groups ? ksize[g] : 1;
+        if (a.ksize[g] < 1 || !(a.ksize[g] & 1) || a.ksize[g] > 15) return MLPK_ESHAPE;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int epv = dtype == MLPK_F32 ? 4 : 8;
+    const bool aligned = !(((uintptr_t)x | (uintptr_t)out | (uintptr_t)w_lr | (uintptr_t)w_td | (uintptr_t)b_lr | (uintptr_t)b_td) & 15);
+    if (C % epv == 0 && aligned) {
+        const long long tv = (long long)B * H * W * (C / epv);
+        const unsigned gv = (unsigned)((tv + 255) / 256 < 262144 ? (tv + 255) / 256 : 262144);
+        switch (dtype) {
+            case MLPK_F32: hipLaunchKernelGGL(mlpk::mixshift_vec_kernel<float>, dim3(gv), dim3(256), 0, s, a); break;
+            case MLPK_F16: hipLaunchKernelGGL(mlpk::mixshift_vec_kernel<mlpk::f16_t>, dim3(gv), dim3(256), 0, s, a); break;
+            default: hipLaunchKernelGGL(mlpk::mixshift_vec_kernel<mlpk::bf16_t>, dim3(gv), dim3(256), 0, s, a); break;
+        }
+        MLPK_LAUNCH_CHECK();
+        return 0;
+    }
+    const long long total = (long long)B * H * W * C;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 262144 ? (total + 255) / 256 : 262144);
+    switch (dtype) {
+        case MLPK_F32: hipLaunchKernelGGL(mlpk::mixshift_kernel<float>, dim3(grid), dim3(256), 0, s, a); break;
+        case MLPK_F16: hipLaunchKernelGGL(mlpk::mixshift_kernel<mlpk::f16_t>, dim3(grid), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL(mlpk::mixshift_kernel<mlpk::bf16_t>, dim3(grid), dim3(256), 0, s, a); break;
+    }
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}

@@ -250,6 +250,13 @@ def hire_combine(x, y_h, y_w, B, H, W, C, h, w, step, ld_h, ld_w):
                                       stream()), "mlpk_hire_combine")
 
 
+def mixshift_nhwc(x, out, B, H, W, C, shift, ksize, w_lr, b_lr, w_td, b_td):
+    g = len(shift)
+    arr = ctypes.c_int * g
+    N.check(N.lib().mlpk_mixshift_nhwc(dtype_code(x.dtype), ptr(x), ptr(out), B, H, W, C, g, arr(*shift), arr(*ksize), ptr(w_lr), ptr(b_lr),
+                                       ptr(w_td), ptr(b_td), stream()), "mlpk_mixshift_nhwc")
+
+
 def convert(src, dst, n):
     N.check(N.lib().mlpk_convert(dtype_code(src.dtype), dtype_code(dst.dtype), ptr(src), ptr(dst), n, stream()),
             "mlpk_convert")

@@ -40,25 +40,25 @@ def pack_channel_mlp(pk, prefix, norm, fc1, fc2, dtype, device):
     pk[prefix + "fc2.b"] = E.f32(fc2.bias, device)
 
 
-def layernorm_stats(ws, x, rows, C, tag="ln"):
+def layernorm_stats(ws, x, rows, C, tag="ln", eps=1e-5):
     mean = ws.get(tag + ".mean", (rows,), torch.float32)
     rstd = ws.get(tag + ".rstd", (rows,), torch.float32)
-    E.row_stats(x, rows, C, x.stride(0), mean, rstd)
+    E.row_stats(x, rows, C, x.stride(0), mean, rstd, eps=eps)
     return mean, rstd
 
 
-def channel_mlp(ws, x, rows, C, pk, prefix, hidden, *, norm=True, cscale2=None, res_src=None, tag="cm"):
+def channel_mlp(ws, x, rows, C, pk, prefix, hidden, *, norm=True, cscale2=None, res_src=None, tag="cm", eps=1e-5):
     """x <- x + fc2(gelu(fc1(LN(x))))   (mlp_mixer.py:38; vip.py:82-88; s2_mlp_v2.py:78-84).
     LN -> row-major normalised copy; fc1 epilogue = bias + exact GELU; fc2 epilogue = bias + residual."""
     ln = None
     if norm and (prefix + "fc1.csum") in pk:
         # LayerNorm folded into fc1 (gamma in the weights, beta in the bias, mean/rstd applied on the
         # accumulator): x itself is the GEMM operand, only the row statistics are computed
-        mean, rstd = layernorm_stats(ws, x, rows, C, tag=tag + ".ln")
+        mean, rstd = layernorm_stats(ws, x, rows, C, tag=tag + ".ln", eps=eps)
         ln = (mean, rstd, pk[prefix + "fc1.csum"])
         xn = x
     elif norm:
-        mean, rstd = layernorm_stats(ws, x, rows, C, tag=tag + ".ln")
+        mean, rstd = layernorm_stats(ws, x, rows, C, tag=tag + ".ln", eps=eps)
         xn = ws.get(tag + ".xn", (rows, C))
         E.norm_apply(x, rows, C, x.stride(0), mean=mean, rstd=rstd, gamma=pk[prefix + "ln.g"], beta=pk[prefix + "ln.b"],
                      out_rm=xn, ld_rm=C)

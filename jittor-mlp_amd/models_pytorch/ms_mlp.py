@@ -1,0 +1,233 @@
+"""MS-MLP, drop-in for the reference's models_pytorch/ms_mlp.py (eval mode: DropPath is the identity).
+
+MixShiftBlock (ms_mlp.py:11-78) on channel-last activations (B*H*W, C):
+  * the channel chunks' rolls along W / H (:56-57), their depthwise k x k convolutions with per-chunk kernel sizes (:60-62),
+    the concatenations and the sum of the two branches (:64-67) are ONE stencil kernel (mlpk_mixshift_nhwc): the roll is
+    a modular source index, the chunk decides shift and kernel size per channel -- no chunk / roll / cat copy exists;
+  * LayerNorm(eps 1e-6) folded into pwconv1 (GEMM, GELU epilogue); pwconv2 GEMM with the layer scale gamma as a per-column
+    scale and the block's residual (the block INPUT, not the mixed map) in its epilogue.
+Patch embedding and the stage transitions (PatchEmbed with patch_size 2, :178-180) = patch gather + GEMM + LayerNorm;
+head = token mean, then LayerNorm on the pooled vector (:352-354), then the classifier GEMM.
+"""
+import torch
+from torch import nn
+
+from .. import _native as N
+from .. import engine as E
+from .common import Holder, channel_mlp, embed_patches, head_linear, layernorm_stats, pack_channel_mlp
+
+MS_EPS = 1e-6
+
+
+def to_2tuple(v):
+    return v if isinstance(v, (tuple, list)) else (v, v)
+
+
+class LayerNorm(Holder):
+    """The reference's own LayerNorm class (ms_mlp.py:273-298): eps 1e-6, parameters `weight`, `bias`."""
+
+    def __init__(self, normalized_shape, eps=1e-6, data_format="channels_last"):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(normalized_shape))
+        self.bias = nn.Parameter(torch.zeros(normalized_shape))
+        self.eps = eps
+        self.data_format = data_format
+        if self.data_format not in ["channels_last", "channels_first"]:
+            raise NotImplementedError
+        self.normalized_shape = (normalized_shape, )
+
+
+class MixShiftBlock(Holder):
+    """ms_mlp.py:24-46."""
+
+    def __init__(self, dim, input_resolution, shift_size, shift_dist, mix_size, layer_scale_init_value=1e-6, mlp_ratio=4, drop=0.,
+                 drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.dim = dim
+        self.input_resolution = input_resolution
+        self.mlp_ratio = mlp_ratio
+        self.shift_size = shift_size
+        self.shift_dist = shift_dist
+        self.chunk_size = [i.shape[0] for i in torch.chunk(torch.zeros(dim), self.shift_size)]
+        self.kernel_size = [(ms, ms // 2) for ms in mix_size]
+        self.dwconv_lr = nn.ModuleList([nn.Conv2d(cd, cd, kernel_size=ks[0], padding=ks[1], groups=cd)
+                                        for cd, ks in zip(self.chunk_size, self.kernel_size)])
+        self.dwconv_td = nn.ModuleList([nn.Conv2d(cd, cd, kernel_size=ks[0], padding=ks[1], groups=cd)
+                                        for cd, ks in zip(self.chunk_size, self.kernel_size)])
+        self.norm = LayerNorm(dim, eps=1e-6)
+        self.pwconv1 = nn.Linear(dim, int(mlp_ratio * dim))
+        self.act = nn.GELU()
+        self.pwconv2 = nn.Linear(int(mlp_ratio * dim), dim)
+        self.gamma = nn.Parameter(layer_scale_init_value * torch.ones((dim)), requires_grad=True) if layer_scale_init_value > 0 else None
+        self.drop_path = nn.Identity()
+
+
+class PatchEmbed(Holder):
+    """ms_mlp.py:229-253 (also the stage transition, with patch_size 2)."""
+
+    def __init__(self, img_size=224, patch_size=4, in_chans=3, embed_dim=96, norm_layer=None):
+        super().__init__()
+        img_size = to_2tuple(img_size)
+        patch_size = to_2tuple(patch_size)
+        patches_resolution = [img_size[0] // patch_size[0], img_size[1] // patch_size[1]]
+        self.img_size = img_size
+        self.patch_size = patch_size
+        self.patches_resolution = patches_resolution
+        self.num_patches = patches_resolution[0] * patches_resolution[1]
+        self.in_chans = in_chans
+        self.embed_dim = embed_dim
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+        self.norm = norm_layer(embed_dim) if norm_layer is not None else None
+
+
+class BasicLayer(Holder):
+    """ms_mlp.py:151-181."""
+
+    def __init__(self, dim, input_resolution, depth, shift_size, shift_dist, mix_size, mlp_ratio=4., drop=0., drop_path=0.,
+                 norm_layer=nn.LayerNorm, downsample=None, use_checkpoint=False):
+        super().__init__()
+        self.dim = dim
+        self.input_resolution = input_resolution
+        self.depth = depth
+        self.use_checkpoint = use_checkpoint
+        self.blocks = nn.ModuleList([
+            MixShiftBlock(dim=dim, input_resolution=input_resolution, shift_size=shift_size, shift_dist=shift_dist, mix_size=mix_size,
+                          mlp_ratio=mlp_ratio, drop=drop, drop_path=drop_path[i] if isinstance(drop_path, list) else drop_path,
+                          norm_layer=norm_layer) for i in range(depth)])
+        if downsample is not None:
+            self.downsample = downsample(img_size=input_resolution, patch_size=2, in_chans=dim, embed_dim=2 * dim, norm_layer=norm_layer)
+        else:
+            self.downsample = None
+
+
+class MS_MLP(E.EngineModule):
+    """Same signature and defaults as the reference (ms_mlp.py:300-306)."""
+
+    def __init__(self, img_size=224, patch_size=4, in_chans=3, num_classes=1000, embed_dim=96, depths=[2, 2, 6, 2], shift_size=5,
+                 shift_dist=[-2, -1, 0, 1, 2], mix_size=[[1, 1, 3, 5, 7], [1, 1, 3, 5, 5], [1, 1, 3, 3, 3], [1, 1, 1, 1, 3]], mlp_ratio=4.,
+                 drop_rate=0., drop_path_rate=0.1, norm_layer=LayerNorm, patch_norm=True, use_checkpoint=False, **kwargs):
+        super().__init__()
+        self.num_classes = num_classes
+        self.num_layers = len(depths)
+        self.embed_dim = embed_dim
+        self.patch_norm = patch_norm
+        self.num_features = int(embed_dim * 2 ** (self.num_layers - 1))
+        self.mlp_ratio = mlp_ratio
+        self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim,
+                                      norm_layer=norm_layer if self.patch_norm else None)
+        patches_resolution = self.patch_embed.patches_resolution
+        self.patches_resolution = patches_resolution
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(depths))]
+        self.layers = nn.ModuleList()
+        for i_layer in range(self.num_layers):
+            self.layers.append(BasicLayer(
+                dim=int(embed_dim * 2 ** i_layer),
+                input_resolution=(patches_resolution[0] // (2 ** i_layer), patches_resolution[1] // (2 ** i_layer)),
+                depth=depths[i_layer], shift_size=shift_size, shift_dist=shift_dist, mix_size=mix_size[i_layer], mlp_ratio=self.mlp_ratio,
+                drop=drop_rate, drop_path=dpr[sum(depths[:i_layer]):sum(depths[:i_layer + 1])], norm_layer=norm_layer,
+                downsample=PatchEmbed if (i_layer < self.num_layers - 1) else None, use_checkpoint=use_checkpoint))
+        self.norm = norm_layer(self.num_features)
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m):
+        # ms_mlp.py:332-339
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def _pack(self, dtype, device):
+        pk = {}
+        pe = self.patch_embed
+        pk["embed.w"] = E.pack_matrix(pe.proj.weight, dtype, device)
+        pk["embed.b"] = E.f32(pe.proj.bias, device)
+        if pe.norm is not None:
+            pk["embed.g"], pk["embed.be"] = E.f32(pe.norm.weight, device), E.f32(pe.norm.bias, device)
+        for li, layer in enumerate(self.layers):
+            C = layer.dim
+            for bi, blk in enumerate(layer.blocks):
+                p = "l%d.b%d." % (li, bi)
+                kmax = max(k for k, _ in blk.kernel_size)
+                for tag, convs in (("lr", blk.dwconv_lr), ("td", blk.dwconv_td)):
+                    wt = torch.zeros((kmax * kmax, C), dtype=torch.float32)
+                    bs = torch.zeros((C,), dtype=torch.float32)
+                    c0 = 0
+                    for conv, cs, (k, _) in zip(convs, blk.chunk_size, blk.kernel_size):
+                        wt[:k * k, c0:c0 + cs] = conv.weight.detach().float().reshape(cs, k * k).t().cpu()
+                        bs[c0:c0 + cs] = conv.bias.detach().float().cpu()
+                        c0 += cs
+                    pk[p + tag + ".w"], pk[p + tag + ".b"] = wt.to(device).contiguous(), bs.to(device)
+                pk[p + "ff.fc1.w"], pk[p + "ff.fc1.b"], pk[p + "ff.fc1.csum"] = E.pack_ln_folded(
+                    blk.pwconv1.weight, blk.pwconv1.bias, blk.norm.weight, blk.norm.bias, dtype, device)
+                pk[p + "ff.fc2.w"] = E.pack_matrix(blk.pwconv2.weight, dtype, device)
+                pk[p + "ff.fc2.b"] = E.f32(blk.pwconv2.bias, device)
+                pk[p + "gamma"] = E.f32(blk.gamma, device) if blk.gamma is not None else None
+            if layer.downsample is not None:
+                d = layer.downsample
+                p = "l%d.down." % li
+                # channel-last 2x2 patch gather: K order (i, j, ci)
+                pk[p + "w"] = E.pack_matrix(d.proj.weight.detach().permute(0, 2, 3, 1).reshape(d.embed_dim, -1), dtype, device)
+                pk[p + "b"] = E.f32(d.proj.bias, device)
+                if d.norm is not None:
+                    pk[p + "g"], pk[p + "be"] = E.f32(d.norm.weight, device), E.f32(d.norm.bias, device)
+        pk["norm.g"], pk["norm.b"] = E.f32(self.norm.weight, device), E.f32(self.norm.bias, device)
+        if isinstance(self.head, nn.Linear):
+            pk["head.w"] = E.pack_matrix(self.head.weight, dtype, device)
+            pk["head.b"] = E.f32(self.head.bias, device)
+        return pk
+
+    def forward(self, x):
+        cd = self._resolve(x)
+        pe = self.patch_embed
+        B, _, H_in, W_in = x.shape
+        assert H_in == pe.img_size[0] and W_in == pe.img_size[1], \
+            f"Input image size ({H_in}*{W_in}) doesn't match model ({pe.img_size[0]}*{pe.img_size[1]})."          # ms_mlp.py:256-257
+        pk = self._get_pack(cd, x.device)
+        ws = self._get_space(B, cd, x.device)
+        x = x.contiguous()
+        C = self.embed_dim
+        cur, H, W = embed_patches(ws, "embed", x, pk["embed.w"], pk["embed.b"], cd, tuple(pe.patch_size),
+                                  out=ws.get("l0.x", (B * pe.patches_resolution[0] * pe.patches_resolution[1], C)))
+        if pe.norm is not None:
+            mean, rstd = layernorm_stats(ws, cur, B * H * W, C, tag="embed.ln", eps=MS_EPS)
+            E.norm_apply(cur, B * H * W, C, C, mean=mean, rstd=rstd, gamma=pk["embed.g"], beta=pk["embed.be"], out_rm=cur, ld_rm=C)
+        for li, layer in enumerate(self.layers):
+            rows = B * H * W
+            hid = int(self.mlp_ratio * C)
+            mix = ws.get("l%d.mix" % li, (rows, C))
+            for bi, blk in enumerate(layer.blocks):
+                p = "l%d.b%d." % (li, bi)
+                E.mixshift_nhwc(cur, mix, B, H, W, C, list(blk.shift_dist), [k for k, _ in blk.kernel_size], pk[p + "lr.w"], pk[p + "lr.b"],
+                                pk[p + "td.w"], pk[p + "td.b"])
+                # mix <- cur + gamma * pwconv2(gelu(pwconv1(LN(mix))));  then the roles of the two buffers swap
+                channel_mlp(ws, mix, rows, C, pk, p + "ff.", hid, cscale2=pk[p + "gamma"], res_src=cur, tag="l%d.cm" % li, eps=MS_EPS)
+                cur, mix = mix, cur
+            if layer.downsample is not None:
+                d = layer.downsample
+                p = "l%d.down." % li
+                assert H == d.img_size[0] and W == d.img_size[1], \
+                    f"Input image size ({H}*{W}) doesn't match model ({d.img_size[0]}*{d.img_size[1]})."
+                H2, W2, C2 = H // 2, W // 2, d.embed_dim
+                kp = pk[p + "w"].shape[1]
+                cols = ws.get("l%d.cols" % li, (B * H2 * W2, kp))
+                E.patchify(cur, cols, B, C, H, W, 2, 2, 0, kp, layout=N.LAYOUT_NHWC, px_stride=C)
+                nxt = ws.get("l%d.x" % (li + 1), (B * H2 * W2, C2))
+                E.gemm(cols, pk[p + "w"], nxt, B * H2 * W2, C2, kp, bias=pk[p + "b"], tag="ms_down")
+                if d.norm is not None:
+                    mean, rstd = layernorm_stats(ws, nxt, B * H2 * W2, C2, tag="l%d.down.ln" % li, eps=MS_EPS)
+                    E.norm_apply(nxt, B * H2 * W2, C2, C2, mean=mean, rstd=rstd, gamma=pk[p + "g"], beta=pk[p + "be"], out_rm=nxt, ld_rm=C2)
+                cur, H, W, C = nxt, H2, W2, C2
+        pooled = ws.get("pooled", (B, C))
+        E.pool_mean(cur, B, H * W, C, C, pooled, C)
+        mean, rstd = layernorm_stats(ws, pooled, B, C, tag="head.ln", eps=MS_EPS)                                   # LayerNorm after the pool
+        E.norm_apply(pooled, B, C, C, mean=mean, rstd=rstd, gamma=pk["norm.g"], beta=pk["norm.b"], out_rm=pooled, ld_rm=C)
+        if not isinstance(self.head, nn.Linear):
+            out = pooled.clone()
+            return out if out.dtype == x.dtype else out.to(x.dtype)
+        return head_linear(ws, pooled, B, C, pk["head.w"], pk["head.b"], self.num_classes, x.dtype)

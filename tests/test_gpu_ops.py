@@ -668,3 +668,35 @@ def test_hire_gather_combine(dtype):
         torch.cuda.synchronize()
         err = (xg.float().cpu() - want.float()).abs().max().item()
         assert err <= (1e-6 if dtype == torch.float32 else 2e-2), (str(dtype), ci, err)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_mixshift_nhwc(dtype):
+    """MS-MLP mix-shift (ms_mlp.py:52-67): per-chunk roll along W / H, per-chunk depthwise k x k conv with zero padding, the two
+    branches added -- against torch.chunk / torch.roll / conv2d in fp32; chunk sizes that are not whole vectors included."""
+    pkg = load_pkg()
+    E = pkg.engine
+    for ci, (B, H, W, C, shift, ks) in enumerate(((2, 8, 10, 24, [-2, -1, 0, 1, 2], [1, 1, 3, 5, 7]), (1, 6, 5, 16, [-1, 0, 3], [3, 1, 5]),
+                                                  (2, 4, 4, 8, [7], [3]), (1, 7, 9, 12, [2, -3], [5, 3]))):
+        x = rnd((B, H, W, C), dtype, 1200 + ci)
+        xf = x.float().permute(0, 3, 1, 2)
+        chunks = torch.chunk(xf, len(shift), 1)
+        kmax = max(ks)
+        w_lr = torch.zeros((kmax * kmax, C)); w_td = torch.zeros((kmax * kmax, C)); b_lr = torch.zeros(C); b_td = torch.zeros(C)
+        lr, td, c0 = [], [], 0
+        for gi, (xc, s_, k) in enumerate(zip(chunks, shift, ks)):
+            cs = xc.shape[1]
+            wl, wt = rnd((cs, 1, k, k), torch.float32, 1210 + 10 * ci + gi, 0.5), rnd((cs, 1, k, k), torch.float32, 1250 + 10 * ci + gi, 0.5)
+            bl, bt = rnd((cs,), torch.float32, 1290 + 10 * ci + gi), rnd((cs,), torch.float32, 1330 + 10 * ci + gi)
+            lr.append(torch.nn.functional.conv2d(torch.roll(xc, s_, 3), wl, bl, padding=k // 2, groups=cs))
+            td.append(torch.nn.functional.conv2d(torch.roll(xc, s_, 2), wt, bt, padding=k // 2, groups=cs))
+            w_lr[:k * k, c0:c0 + cs] = wl.reshape(cs, k * k).t(); w_td[:k * k, c0:c0 + cs] = wt.reshape(cs, k * k).t()
+            b_lr[c0:c0 + cs] = bl; b_td[c0:c0 + cs] = bt
+            c0 += cs
+        ref = (torch.cat(lr, 1) + torch.cat(td, 1)).permute(0, 2, 3, 1)
+        out = torch.full((B, H, W, C), float("nan"), dtype=dtype, device=dev())
+        E.mixshift_nhwc(x.to(dev()), out, B, H, W, C, shift, ks, w_lr.to(dev()), b_lr.to(dev()), w_td.to(dev()), b_td.to(dev()))
+        torch.cuda.synchronize()
+        err = (out.float().cpu() - ref).abs().max().item()
+        tol = 2e-5 if dtype == torch.float32 else (4e-3 if dtype == torch.float16 else 3e-2)
+        assert err < tol * max(1.0, ref.abs().max().item()), (str(dtype), ci, err)
