@@ -703,3 +703,60 @@ def msmlp_forward(sd, x, shift_dist=(-2, -1, 0, 1, 2), mix_size=((1, 1, 3, 5, 7)
     t = t.mean(dim=(2, 3))
     t = layer_norm(t, _p(sd, "norm.weight", x), _p(sd, "norm.bias", x), eps=MS_EPS)
     return linear(t, _p(sd, "head.weight", x), _p(sd, "head.bias", x))
+
+
+# --------------------------------------------------------------------------
+# Swin-MLP  (swin_mlp.py:12-460)  -- SURVEY.md 8(f) rank 3
+# --------------------------------------------------------------------------
+def swinmlp_block(sd, x, pre, hh, ww, num_heads, window_size, shift_size):
+    """SwinMLPBlock.forward on x (B, H*W, C) in eval mode (swin_mlp.py:113-157): LayerNorm, zero-pad by
+    (ws - shift, shift) on the left/top and right/bottom when shifted (:101-102, 122-124), ws x ws windows, per head a
+    (ws^2 x ws^2) token mix with bias -- the grouped Conv1d of :105-108 -- window merge, crop, residual; then the channel MLP."""
+    bsz, _, c = x.shape
+    ws = window_size
+    if min(hh, ww) <= ws:                                                                       # :94-97
+        shift_size, ws = 0, min(hh, ww)
+    t = layer_norm(x, _p(sd, pre + "norm1.weight", x), _p(sd, pre + "norm1.bias", x)).reshape(bsz, hh, ww, c)
+    if shift_size > 0:
+        pl, pr, pt, pb = ws - shift_size, shift_size, ws - shift_size, shift_size
+        t = torch.nn.functional.pad(t, (0, 0, pl, pr, pt, pb))
+    hp, wp = t.shape[1], t.shape[2]
+    win = t.reshape(bsz, hp // ws, ws, wp // ws, ws, c).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, num_heads, c // num_heads)
+    wgt = _p(sd, pre + "spatial_mlp.weight", x).reshape(num_heads, ws * ws, ws * ws)            # Conv1d(groups = heads): [h][t_out][t_in]
+    bia = _p(sd, pre + "spatial_mlp.bias", x).reshape(num_heads, ws * ws)
+    mixed = torch.einsum("hts,nshd->nthd", wgt, win) + bia.t().reshape(1, ws * ws, num_heads, 1)
+    t = mixed.reshape(bsz, hp // ws, wp // ws, ws, ws, c).permute(0, 1, 3, 2, 4, 5).reshape(bsz, hp, wp, c)
+    if shift_size > 0:
+        t = t[:, pt:hp - pb, pl:wp - pr, :]
+    x = x + t.reshape(bsz, hh * ww, c)
+    n = layer_norm(x, _p(sd, pre + "norm2.weight", x), _p(sd, pre + "norm2.bias", x))
+    hdn = gelu(linear(n, _p(sd, pre + "mlp.fc1.weight", x), _p(sd, pre + "mlp.fc1.bias", x)))
+    return x + linear(hdn, _p(sd, pre + "mlp.fc2.weight", x), _p(sd, pre + "mlp.fc2.bias", x))
+
+
+def swinmlp_forward(sd, x, num_heads=(3, 6, 12, 24), window_size=7, hooks=None):
+    """SwinMLP.forward (swin_mlp.py:433-446) in eval mode (ape = False)."""
+    x = x.detach().cpu()
+    t = patch_embed(x, _p(sd, "patch_embed.proj.weight", x), _p(sd, "patch_embed.proj.bias", x))
+    bsz, hh, ww, c = t.shape
+    t = t.reshape(bsz, hh * ww, c)
+    if "patch_embed.norm.weight" in sd:
+        t = layer_norm(t, _p(sd, "patch_embed.norm.weight", x), _p(sd, "patch_embed.norm.bias", x))
+    layer = 0
+    while ("layers.%d.blocks.0.norm1.weight" % layer) in sd:
+        for i in range(_depth(sd, "layers.%d" % layer + ".blocks.%d.norm1.weight")):
+            t = swinmlp_block(sd, t, "layers.%d.blocks.%d." % (layer, i), hh, ww, num_heads[layer], window_size,
+                              0 if i % 2 == 0 else window_size // 2)                            # :246
+            if hooks is not None:
+                hooks("layers.%d.blocks.%d" % (layer, i), t)
+        pre = "layers.%d.downsample." % layer
+        if (pre + "reduction.weight") in sd:                                                    # PatchMerging (:193-212)
+            c = t.shape[-1]
+            g = t.reshape(bsz, hh, ww, c)
+            g = torch.cat([g[:, 0::2, 0::2, :], g[:, 1::2, 0::2, :], g[:, 0::2, 1::2, :], g[:, 1::2, 1::2, :]], dim=-1)
+            hh, ww = hh // 2, ww // 2
+            g = layer_norm(g.reshape(bsz, hh * ww, 4 * c), _p(sd, pre + "norm.weight", x), _p(sd, pre + "norm.bias", x))
+            t = linear(g, _p(sd, pre + "reduction.weight", x), None)
+        layer += 1
+    t = layer_norm(t, _p(sd, "norm.weight", x), _p(sd, "norm.bias", x)).mean(dim=1)
+    return linear(t, _p(sd, "head.weight", x), _p(sd, "head.bias", x))

@@ -62,7 +62,7 @@ def load_reference():
     tl.trunc_normal_ = torch.nn.init.trunc_normal_
     sys.modules["timm"], sys.modules["timm.models"], sys.modules["timm.models.layers"] = timm, tm, tl
     mods = {}
-    for name in ("mlp_mixer", "g_mlp", "res_mlp", "vip", "s2_mlp_v1", "s2_mlp_v2", "conv_mixer", "as_mlp", "sparse_mlp", "hire_mlp", "ms_mlp"):
+    for name in ("mlp_mixer", "g_mlp", "res_mlp", "vip", "s2_mlp_v1", "s2_mlp_v2", "conv_mixer", "as_mlp", "sparse_mlp", "hire_mlp", "ms_mlp", "swin_mlp"):
         mods[name] = importlib.import_module("models_pytorch." + name)
     sc = importlib.import_module("models_pytorch.utils.shift_cuda")
     sc.Shift.forward = lambda self, x: x if self.kernel_size == 1 else sc.torch_shift(x, self.kernel_size, self.dim)
@@ -171,6 +171,14 @@ def tiny_configs(ref):
                                                             mix_size=[[3, 1, 5], [1, 3, 3]], mlp_ratio=2., num_classes=10, patch_norm=False),
                          hw=(32, 32), pins=["layers.0.blocks.1"], gamma=0.5,
                          oracle=lambda sd, x, kw: oracle.msmlp_forward(sd, x, kw["shift_dist"], kw["mix_size"])),
+        "swinmlp": dict(ctor=ref["swin_mlp"].SwinMLP, kw=dict(img_size=64, patch_size=4, embed_dim=16, depths=[2, 2], num_heads=[2, 4], window_size=4, num_classes=10),
+                        hw=(64, 64), pins=["layers.0.blocks.1", "layers.1.blocks.0"],
+                        oracle=lambda sd, x, kw: oracle.swinmlp_forward(sd, x, kw["num_heads"], kw["window_size"])),
+        # window larger than the last stage's map (no partition, :94-97), mlp_ratio 2, no patch norm
+        "swinmlp_small": dict(ctor=ref["swin_mlp"].SwinMLP, kw=dict(img_size=48, patch_size=4, embed_dim=8, depths=[2, 1], num_heads=[1, 2], window_size=6, mlp_ratio=2.,
+                                                                     num_classes=10, patch_norm=False),
+                              hw=(48, 48), pins=["layers.0.blocks.1"],
+                              oracle=lambda sd, x, kw: oracle.swinmlp_forward(sd, x, kw["num_heads"], kw["window_size"])),
     }
 
 
@@ -204,6 +212,8 @@ def real_configs(ref):
                           oracle=lambda sd, x, kw: oracle.hiremlp_forward(sd, x, [4, 3, 3, 2], [4, 3, 3, 2], [2, 2, 1, 1], 2, 4)),
         # the reference's default MS-MLP (embed 96, depths [2,2,6,2])
         "msmlp_t": dict(ctor=ref["ms_mlp"].MS_MLP, kw=dict(), bs=2, oracle=lambda sd, x, kw: oracle.msmlp_forward(sd, x)),
+        # the reference's default Swin-MLP (embed 96, depths [2,2,6,2], heads [3,6,12,24], window 7)
+        "swinmlp_t": dict(ctor=ref["swin_mlp"].SwinMLP, kw=dict(), bs=2, oracle=lambda sd, x, kw: oracle.swinmlp_forward(sd, x)),
     }
 
 
@@ -394,7 +404,7 @@ def make_manifest(ref):
         "ConvMixer": ref["conv_mixer"].ConvMixer, "AS_MLP": ref["as_mlp"].AS_MLP, "Shift": ref["shift_cuda"].Shift,
         "MLPMixer": ref["mlp_mixer"].MLPMixer, "gMLP": ref["g_mlp"].gMLP, "ResMLP": ref["res_mlp"].ResMLP,
         "WeightedPermutator": ref["vip"].WeightedPermutator, "Permutator": ref["vip"].Permutator,
-        "S2Block": ref["s2_mlp_v2"].S2Block, "SparseMLP": ref["sparse_mlp"].SparseMLP, "HireMLP": ref["hire_mlp"].HireMLP, "MS_MLP": ref["ms_mlp"].MS_MLP,
+        "S2Block": ref["s2_mlp_v2"].S2Block, "SparseMLP": ref["sparse_mlp"].SparseMLP, "HireMLP": ref["hire_mlp"].HireMLP, "MS_MLP": ref["ms_mlp"].MS_MLP, "SwinMLP": ref["swin_mlp"].SwinMLP,
     }
     for name, c in ctors.items():
         sig = inspect.signature(c)
