@@ -44,6 +44,7 @@ MODELS = {
     "sparsemlp_t": ("SparseMLP", dict(), 16.231),      # SURVEY.md 8(f) rank 2; 2*MAC of its GEMMs/convs counted by hand
     "hiremlp_s": ("HireMLP", dict(), 9.742),           # SURVEY.md 8(f) rank 2; counted by hand (padded region rows included)
     "msmlp_t": ("MS_MLP", dict(), 5.990),              # SURVEY.md 8(f) rank 3; counted by hand
+    "swinmlp_t": ("SwinMLP", dict(), 6.110),           # SURVEY.md 8(f) rank 3; counted by hand (useful flops of the per-head window mixes)
 }
 PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16/f16 MFMA (MI355X_MICROARCH.md); f32 MFMA 157.3
 DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
@@ -64,7 +65,7 @@ def run_cpu_baseline(model_name, kwargs, ctor_name, pkg):
     x = torch.rand(bs, 3, 224, 224)
     fam = {"MLPMixerForImageClassification": "mixer", "gMLPForImageClassification": "gmlp",
            "ResMLPForImageClassification": "resmlp", "ViP": "vip", "S2MLPv2": "s2mlpv2", "AS_MLP": "asmlp",
-           "ConvMixer": "convmixer", "SparseMLP": "sparsemlp", "HireMLP": "hiremlp", "MS_MLP": "msmlp"}[ctor_name]
+           "ConvMixer": "convmixer", "SparseMLP": "sparsemlp", "HireMLP": "hiremlp", "MS_MLP": "msmlp", "SwinMLP": "swinmlp"}[ctor_name]
     run_oracle(fam, sd, x, kwargs)                                  # warm-up
     t0 = time.perf_counter()
     n = 0

@@ -311,6 +311,17 @@ int mlpk_mixshift_nhwc(int dtype, const void* x, void* out, int B, int H, int W,
                        const int* ksize, const float* w_lr, const float* b_lr, const float* w_td, const float* b_td,
                        void* stream);
 
+/* ---- Swin-MLP window partition / merge (swin_mlp.py:29-60, 122-151) ---------------
+ * The (B,H,W,C) map is zero-padded to Hp x Wp (pad_t rows on top, pad_l columns on the left, the rest at the bottom / right;
+ * Hp, Wp multiples of ws) and cut into ws x ws windows; `windows` holds rows ((b, wy, wx), (iy, ix)) of C channels.
+ * gather     : windows <- padded map (zeros in the padding)
+ * scatter_add: x[b,y,x',:] += windows[row of padded position (y + pad_t, x' + pad_l)]      (merge, crop, residual)
+ */
+int mlpk_window_gather(int dtype, const void* x, void* windows, int B, int H, int W, int C, int ws, int pad_t, int pad_l,
+                       int Hp, int Wp, void* stream);
+int mlpk_window_scatter_add(int dtype, void* x, const void* windows, int B, int H, int W, int C, int ws, int pad_t,
+                            int pad_l, int Hp, int Wp, void* stream);
+
 /* ---- small utilities ------------------------------------------------------------------------ */
 /* dst[i] = (dst_dtype) src[i], n elements */
 int mlpk_convert(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);

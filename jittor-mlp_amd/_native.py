@@ -66,6 +66,8 @@ PROTOTYPES = {
     "mlpk_hire_gather": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     "mlpk_hire_combine": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     "mlpk_mixshift_nhwc": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 5 + [ctypes.POINTER(c_int), ctypes.POINTER(c_int)] + [c_void_p] * 4 + [c_void_p]),
+    "mlpk_window_gather": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
+    "mlpk_window_scatter_add": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     "mlpk_convert": (c_int, [c_int, c_int, c_void_p, c_void_p, c_i64, c_void_p]),
 }
 

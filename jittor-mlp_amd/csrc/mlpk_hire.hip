@@ -338,3 +338,93 @@ extern "C" int mlpk_mixshift_nhwc(int dtype, const void* x, void* out, int B, in
     MLPK_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- Swin-MLP window partition / merge (swin_mlp.py:29-60, 122-151) -----------------------
+// gather : rows ((b, wy, wx), (iy, ix)) of the ws x ws windows of the zero-padded map (pad_t rows on top, pad_l columns on
+//          the left; the bottom/right padding is whatever completes Hp x Wp), 16-byte channel vectors
+// scatter: x[b, y, x', :] += yw[window row of padded position (y + pad_t, x' + pad_l)]   (merge + crop + residual)
+namespace mlpk {
+
+struct WinArgs {
+    void* x;             // (B, H, W, C): source of the gather / destination of the scatter-add
+    void* w;             // (B * nWy * nWx * ws * ws, C)
+    int B, H, W, C, ws, pad_t, pad_l, nWy, nWx;
+};
+
+template <typename T, bool SCATTER>
+__global__ void __launch_bounds__(256) window_kernel(const WinArgs p) {
+    constexpr int EPV = 16 / (int)sizeof(T);
+    T* __restrict__ xm = reinterpret_cast<T*>(p.x);
+    T* __restrict__ wn = reinterpret_cast<T*>(p.w);
+    const int cv = p.C / EPV;
+    if constexpr (!SCATTER) {
+        const int64_t total = (int64_t)p.B * p.nWy * p.nWx * p.ws * p.ws * cv;
+        for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+            const int c0 = (int)(idx % cv) * EPV;
+            int64_t r = idx / cv;
+            const int64_t row = r;
+            const int ix = (int)(r % p.ws); r /= p.ws;
+            const int iy = (int)(r % p.ws); r /= p.ws;
+            const int wx = (int)(r % p.nWx); r /= p.nWx;
+            const int wy = (int)(r % p.nWy);
+            const int64_t b = r / p.nWy;
+            const int y = wy * p.ws + iy - p.pad_t, x = wx * p.ws + ix - p.pad_l;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (y >= 0 && y < p.H && x >= 0 && x < p.W) v = *reinterpret_cast<const u32x4*>(xm + ((b * p.H + y) * p.W + x) * p.C + c0);
+            *reinterpret_cast<u32x4*>(wn + row * p.C + c0) = v;
+        }
+    } else {
+        const int64_t total = (int64_t)p.B * p.H * p.W * cv;
+        for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+            const int c0 = (int)(idx % cv) * EPV;
+            int64_t r = idx / cv;
+            const int x = (int)(r % p.W); r /= p.W;
+            const int y = (int)(r % p.H);
+            const int64_t b = r / p.H;
+            const int py = y + p.pad_t, px = x + p.pad_l;
+            const int64_t row = (((b * p.nWy + py / p.ws) * p.nWx + px / p.ws) * p.ws + py % p.ws) * p.ws + px % p.ws;
+            T a[EPV], u[EPV];
+            T* po = xm + ((b * p.H + y) * p.W + x) * p.C + c0;
+            *reinterpret_cast<u32x4*>(a) = *reinterpret_cast<const u32x4*>(po);
+            *reinterpret_cast<u32x4*>(u) = *reinterpret_cast<const u32x4*>(wn + row * p.C + c0);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) a[e] = from_f32<T>(to_f32(a[e]) + to_f32(u[e]));
+            *reinterpret_cast<u32x4*>(po) = *reinterpret_cast<const u32x4*>(a);
+        }
+    }
+}
+
+template <bool SCATTER>
+static int window_launch(int dtype, void* x, void* w, int B, int H, int W, int C, int ws, int pad_t, int pad_l, int Hp, int Wp, void* stream) {
+    if (!x || !w) return MLPK_ENULL;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || ws <= 0 || pad_t < 0 || pad_l < 0) return MLPK_ESHAPE;
+    if (Hp < H + pad_t || Wp < W + pad_l || Hp % ws || Wp % ws) return MLPK_ESHAPE;
+    if (dtype != MLPK_F32 && dtype != MLPK_F16 && dtype != MLPK_BF16) return MLPK_EDTYPE;
+    const int epv = dtype == MLPK_F32 ? 4 : 8;
+    if (C % epv) return MLPK_ESHAPE;
+    if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return MLPK_EALIGN;
+    WinArgs a;
+    a.x = x; a.w = w; a.B = B; a.H = H; a.W = W; a.C = C; a.ws = ws; a.pad_t = pad_t; a.pad_l = pad_l; a.nWy = Hp / ws; a.nWx = Wp / ws;
+    const long long total = SCATTER ? (long long)B * H * W * (C / epv) : (long long)B * Hp * Wp * (C / epv);
+    const unsigned grid = (unsigned)((total + 255) / 256 < 262144 ? (total + 255) / 256 : 262144);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case MLPK_F32: hipLaunchKernelGGL((window_kernel<float, SCATTER>), dim3(grid), dim3(256), 0, s, a); break;
+        case MLPK_F16: hipLaunchKernelGGL((window_kernel<f16_t, SCATTER>), dim3(grid), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((window_kernel<bf16_t, SCATTER>), dim3(grid), dim3(256), 0, s, a); break;
+    }
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace mlpk
+
+extern "C" int mlpk_window_gather(int dtype, const void* x, void* windows, int B, int H, int W, int C, int ws, int pad_t, int pad_l,
+                                  int Hp, int Wp, void* stream) {
+    return mlpk::window_launch<false>(dtype, const_cast<void*>(x), windows, B, H, W, C, ws, pad_t, pad_l, Hp, Wp, stream);
+}
+
+extern "C" int mlpk_window_scatter_add(int dtype, void* x, const void* windows, int B, int H, int W, int C, int ws, int pad_t,
+                                       int pad_l, int Hp, int Wp, void* stream) {
+    return mlpk::window_launch<true>(dtype, x, const_cast<void*>(windows), B, H, W, C, ws, pad_t, pad_l, Hp, Wp, stream);
+}

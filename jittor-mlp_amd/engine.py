@@ -257,6 +257,16 @@ def mixshift_nhwc(x, out, B, H, W, C, shift, ksize, w_lr, b_lr, w_td, b_td):
                                        ptr(w_td), ptr(b_td), stream()), "mlpk_mixshift_nhwc")
 
 
+def window_gather(x, windows, B, H, W, C, ws, pad_t, pad_l, Hp, Wp):
+    N.check(N.lib().mlpk_window_gather(dtype_code(x.dtype), ptr(x), ptr(windows), B, H, W, C, ws, pad_t, pad_l, Hp, Wp, stream()),
+            "mlpk_window_gather")
+
+
+def window_scatter_add(x, windows, B, H, W, C, ws, pad_t, pad_l, Hp, Wp):
+    N.check(N.lib().mlpk_window_scatter_add(dtype_code(x.dtype), ptr(x), ptr(windows), B, H, W, C, ws, pad_t, pad_l, Hp, Wp, stream()),
+            "mlpk_window_scatter_add")
+
+
 def convert(src, dst, n):
     N.check(N.lib().mlpk_convert(dtype_code(src.dtype), dtype_code(dst.dtype), ptr(src), ptr(dst), n, stream()),
             "mlpk_convert")

@@ -13,6 +13,7 @@ from .as_mlp import AS_MLP  # noqa: F401
 from .sparse_mlp import SparseMLP  # noqa: F401  
 from .hire_mlp import HireMLP  # noqa: F401  
 from .ms_mlp import MS_MLP  # noqa: F401  
+from .swin_mlp import SwinMLP  # noqa: F401  
 from .utils import Shift  # noqa: F401
 # secondary classes the reference lets users import from the sub-modules
 from .mlp_mixer import MLPMixer  # noqa: F401
@@ -22,4 +23,4 @@ from .vip import WeightedPermutator, Permutator  # noqa: F401
 from .s2_mlp_v2 import S2Block  # noqa: F401
 
 __all__ = ["gMLPForImageClassification", "ResMLPForImageClassification", "MLPMixerForImageClassification", "ViP",
-           "S2MLPv1", "S2MLPv1_deep", "S2MLPv1_wide", "S2MLPv2", "ConvMixer", "AS_MLP", "SparseMLP", "HireMLP", "MS_MLP", "Shift"]
+           "S2MLPv1", "S2MLPv1_deep", "S2MLPv1_wide", "S2MLPv2", "ConvMixer", "AS_MLP", "SparseMLP", "HireMLP", "MS_MLP", "SwinMLP", "Shift"]

@@ -1,0 +1,248 @@
+"""Swin-MLP, drop-in for the reference's models_pytorch/swin_mlp.py (eval mode: DropPath is the identity;
+`ape=True` is not built).
+
+SwinMLPBlock (swin_mlp.py:63-157) on channel-last tokens (B*H*W, C):
+  * LayerNorm -> mlpk_window_gather: zero padding of the shifted blocks (:101-102, 122-124) and the window partition (:29-42)
+    as one index map, rows ((b, wy, wx), token) of C channels;
+  * the multi-head spatial MLP -- a grouped Conv1d over the ws^2 window positions, one (ws^2 x ws^2) matrix per head
+    (:105-108) -- is ONE token GEMM per block: the window rows are viewed as (window, (token, head)) x (C / heads)
+    channels, transposed per window by mlpk_norm_apply, and multiplied by the block-diagonal (token, head) x (token, head)
+    matrix built once from the Conv1d weight; the transposed epilogue stores the result back window-major.  (The dense
+    block-diagonal form spends heads x the useful flops on a part that is < 2 % of the model's.)
+  * mlpk_window_scatter_add: window merge (:45-60), crop of the padding (:148-149) and the residual in one pass;
+  * the channel MLP folds its LayerNorm into fc1.
+PatchMerging (:178-212) = 2x2 gather + LayerNorm(4C) folded into the bias-free reduction; head = LayerNorm folded into the
+token mean, then the classifier GEMM.
+"""
+import torch
+from torch import nn
+
+from .. import _native as N
+from .. import engine as E
+from .common import Holder, channel_mlp, embed_patches, head_linear, layernorm_stats, pack_channel_mlp
+
+
+def to_2tuple(v):
+    return v if isinstance(v, (tuple, list)) else (v, v)
+
+
+class Mlp(Holder):
+    """swin_mlp.py:12-26."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+
+
+class SwinMLPBlock(Holder):
+    """swin_mlp.py:79-111."""
+
+    def __init__(self, dim, input_resolution, num_heads, window_size=7, shift_size=0, mlp_ratio=4., drop=0., drop_path=0.,
+                 act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.dim = dim
+        self.input_resolution = input_resolution
+        self.num_heads = num_heads
+        self.window_size = window_size
+        self.shift_size = shift_size
+        self.mlp_ratio = mlp_ratio
+        if min(self.input_resolution) <= self.window_size:
+            self.shift_size = 0
+            self.window_size = min(self.input_resolution)
+        assert 0 <= self.shift_size < self.window_size, "shift_size must in 0-window_size"
+        self.padding = [self.window_size - self.shift_size, self.shift_size,
+                        self.window_size - self.shift_size, self.shift_size]  # P_l,P_r,P_t,P_b
+        self.norm1 = norm_layer(dim)
+        self.spatial_mlp = nn.Conv1d(self.num_heads * self.window_size ** 2, self.num_heads * self.window_size ** 2, kernel_size=1,
+                                     groups=self.num_heads)
+        self.drop_path = nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+
+
+class PatchMerging(Holder):
+    """swin_mlp.py:178-191."""
+
+    def __init__(self, input_resolution, dim, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.input_resolution = input_resolution
+        self.dim = dim
+        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+        self.norm = norm_layer(4 * dim)
+
+
+class BasicLayer(Holder):
+    """swin_mlp.py:231-256."""
+
+    def __init__(self, dim, input_resolution, depth, num_heads, window_size, mlp_ratio=4., drop=0., drop_path=0., norm_layer=nn.LayerNorm,
+                 downsample=None, use_checkpoint=False):
+        super().__init__()
+        self.dim = dim
+        self.input_resolution = input_resolution
+        self.depth = depth
+        self.use_checkpoint = use_checkpoint
+        self.blocks = nn.ModuleList([
+            SwinMLPBlock(dim=dim, input_resolution=input_resolution, num_heads=num_heads, window_size=window_size,
+                         shift_size=0 if (i % 2 == 0) else window_size // 2, mlp_ratio=mlp_ratio, drop=drop,
+                         drop_path=drop_path[i] if isinstance(drop_path, list) else drop_path, norm_layer=norm_layer) for i in range(depth)])
+        self.downsample = downsample(input_resolution, dim=dim, norm_layer=norm_layer) if downsample is not None else None
+
+
+class PatchEmbed(Holder):
+    """swin_mlp.py:296-322."""
+
+    def __init__(self, img_size=224, patch_size=4, in_chans=3, embed_dim=96, norm_layer=None):
+        super().__init__()
+        img_size = to_2tuple(img_size)
+        patch_size = to_2tuple(patch_size)
+        patches_resolution = [img_size[0] // patch_size[0], img_size[1] // patch_size[1]]
+        self.img_size = img_size
+        self.patch_size = patch_size
+        self.patches_resolution = patches_resolution
+        self.num_patches = patches_resolution[0] * patches_resolution[1]
+        self.in_chans = in_chans
+        self.embed_dim = embed_dim
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+        self.norm = norm_layer(embed_dim) if norm_layer is not None else None
+
+
+class SwinMLP(E.EngineModule):
+    """Same signature and defaults as the reference (swin_mlp.py:374-379)."""
+
+    def __init__(self, img_size=224, patch_size=4, in_chans=3, num_classes=1000, embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24],
+                 window_size=7, mlp_ratio=4., drop_rate=0., drop_path_rate=0.1, norm_layer=nn.LayerNorm, ape=False, patch_norm=True,
+                 use_checkpoint=False, **kwargs):
+        super().__init__()
+        self.num_classes = num_classes
+        self.num_layers = len(depths)
+        self.embed_dim = embed_dim
+        self.ape = ape
+        self.patch_norm = patch_norm
+        self.num_features = int(embed_dim * 2 ** (self.num_layers - 1))
+        self.mlp_ratio = mlp_ratio
+        self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim,
+                                      norm_layer=norm_layer if self.patch_norm else None)
+        num_patches = self.patch_embed.num_patches
+        patches_resolution = self.patch_embed.patches_resolution
+        self.patches_resolution = patches_resolution
+        if self.ape:
+            self.absolute_pos_embed = nn.Parameter(torch.zeros(1, num_patches, embed_dim))
+            nn.init.trunc_normal_(self.absolute_pos_embed, std=.02)
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(depths))]
+        self.layers = nn.ModuleList()
+        for i_layer in range(self.num_layers):
+            self.layers.append(BasicLayer(
+                dim=int(embed_dim * 2 ** i_layer),
+                input_resolution=(patches_resolution[0] // (2 ** i_layer), patches_resolution[1] // (2 ** i_layer)),
+                depth=depths[i_layer], num_heads=num_heads[i_layer], window_size=window_size, mlp_ratio=self.mlp_ratio, drop=drop_rate,
+                drop_path=dpr[sum(depths[:i_layer]):sum(depths[:i_layer + 1])], norm_layer=norm_layer,
+                downsample=PatchMerging if (i_layer < self.num_layers - 1) else None, use_checkpoint=use_checkpoint))
+        self.norm = norm_layer(self.num_features)
+        self.avgpool = nn.AdaptiveAvgPool1d(1)
+        self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m):
+        # swin_mlp.py:419-426
+        if isinstance(m, (nn.Linear, nn.Conv1d)):
+            nn.init.trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def _pack(self, dtype, device):
+        pk = {}
+        pe = self.patch_embed
+        pk["embed.w"] = E.pack_matrix(pe.proj.weight, dtype, device)
+        pk["embed.b"] = E.f32(pe.proj.bias, device)
+        if pe.norm is not None:
+            pk["embed.g"], pk["embed.be"] = E.f32(pe.norm.weight, device), E.f32(pe.norm.bias, device)
+        for li, layer in enumerate(self.layers):
+            for bi, blk in enumerate(layer.blocks):
+                p = "l%d.b%d." % (li, bi)
+                nh, t = blk.num_heads, blk.window_size ** 2
+                pk[p + "n1.g"], pk[p + "n1.b"] = E.f32(blk.norm1.weight, device), E.f32(blk.norm1.bias, device)
+                # grouped Conv1d weight (heads*t, t, 1): [h][t_out][t_in]  ->  block-diagonal over (token, head) x (token, head)
+                w = blk.spatial_mlp.weight.detach().float().reshape(nh, t, t).cpu()
+                bd = torch.zeros((t, nh, t, nh), dtype=torch.float32)
+                for h in range(nh):
+                    bd[:, h, :, h] = w[h]
+                pk[p + "sp.w"] = E.pack_matrix(bd.reshape(t * nh, t * nh), dtype, device)
+                pk[p + "sp.b"] = E.f32(blk.spatial_mlp.bias.detach().reshape(nh, t).t().reshape(-1), device)      # index t_out * heads + h
+                pack_channel_mlp(pk, p + "ff.", blk.norm2, blk.mlp.fc1, blk.mlp.fc2, dtype, device)
+            if layer.downsample is not None:
+                pm = layer.downsample
+                p = "l%d.merge." % li
+                pk[p + "w"], pk[p + "b"], pk[p + "csum"] = E.pack_ln_folded(pm.reduction.weight, None, pm.norm.weight, pm.norm.bias, dtype, device)
+        pk["norm.g"], pk["norm.b"] = E.f32(self.norm.weight, device), E.f32(self.norm.bias, device)
+        if isinstance(self.head, nn.Linear):
+            pk["head.w"] = E.pack_matrix(self.head.weight, dtype, device)
+            pk["head.b"] = E.f32(self.head.bias, device)
+        return pk
+
+    def forward(self, x):
+        if self.ape:
+            raise NotImplementedError("ape=True (absolute position embedding) is not built")
+        cd = self._resolve(x)
+        pe = self.patch_embed
+        B, _, H_in, W_in = x.shape
+        assert H_in == pe.img_size[0] and W_in == pe.img_size[1], \
+            f"Input image size ({H_in}*{W_in}) doesn't match model ({pe.img_size[0]}*{pe.img_size[1]})."          # swin_mlp.py:327-328
+        pk = self._get_pack(cd, x.device)
+        ws_ = self._get_space(B, cd, x.device)
+        x = x.contiguous()
+        C = self.embed_dim
+        cur, H, W = embed_patches(ws_, "embed", x, pk["embed.w"], pk["embed.b"], cd, tuple(pe.patch_size),
+                                  out=ws_.get("l0.x", (B * pe.patches_resolution[0] * pe.patches_resolution[1], C)))
+        if pe.norm is not None:
+            mean, rstd = layernorm_stats(ws_, cur, B * H * W, C, tag="embed.ln")
+            E.norm_apply(cur, B * H * W, C, C, mean=mean, rstd=rstd, gamma=pk["embed.g"], beta=pk["embed.be"], out_rm=cur, ld_rm=C)
+        for li, layer in enumerate(self.layers):
+            rows = B * H * W
+            xn = ws_.get("l%d.xn" % li, (rows, C))
+            for bi, blk in enumerate(layer.blocks):
+                p = "l%d.b%d." % (li, bi)
+                ws, nh = blk.window_size, blk.num_heads
+                d = C // nh
+                pad_l, pad_r, pad_t, pad_b = blk.padding if blk.shift_size > 0 else (0, 0, 0, 0)
+                Hp, Wp = H + pad_t + pad_b, W + pad_l + pad_r
+                nwin = B * (Hp // ws) * (Wp // ws)
+                tk = ws * ws * nh                                     # "tokens" of the per-window GEMM: (window position, head)
+                kp = E.round_up(tk, 8)
+                tag = "l%d.s%d." % (li, 1 if blk.shift_size > 0 else 0)
+                xw = ws_.get(tag + "xw", (nwin * ws * ws, C))
+                xt = ws_.get(tag + "xt", (nwin * d, kp))
+                mean, rstd = layernorm_stats(ws_, cur, rows, C, tag="l%d.ln" % li)
+                E.norm_apply(cur, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "n1.g"], beta=pk[p + "n1.b"], out_rm=xn, ld_rm=C)
+                E.window_gather(xn, xw, B, H, W, C, ws, pad_t, pad_l, Hp, Wp)
+                # rows (window, token, head) x d channels  ->  per window transposed: ((window, channel), (token, head))
+                E.norm_apply(xw, nwin * tk, d, d, out_tt=xt, S=tk, ld_tt=kp)
+                E.gemm(xt, pk[p + "sp.w"], xw, nwin * d, tk, kp, ldc=d, bias=pk[p + "sp.b"], out_mode=N.OUT_TOKEN_T, t_rows=d, t_tokens=tk,
+                       tag="swin_spatial")
+                E.window_scatter_add(cur, xw, B, H, W, C, ws, pad_t, pad_l, Hp, Wp)
+                channel_mlp(ws_, cur, rows, C, pk, p + "ff.", int(C * self.mlp_ratio), tag="l%d.cm" % li)
+            if layer.downsample is not None:
+                assert H % 2 == 0 and W % 2 == 0, f"x size ({H}*{W}) are not even."                                 # swin_mlp.py:201
+                p = "l%d.merge." % li
+                H2, W2 = H // 2, W // 2
+                merged = ws_.get("l%d.merged" % li, (B * H2 * W2, 4 * C))
+                E.patchify(cur, merged, B, C, H, W, 2, 2, 0, 4 * C, layout=N.LAYOUT_NHWC, px_stride=C, order=1)
+                mean, rstd = layernorm_stats(ws_, merged, B * H2 * W2, 4 * C, tag="l%d.merge.ln" % li)
+                nxt = ws_.get("l%d.x" % (li + 1), (B * H2 * W2, 2 * C))
+                E.gemm(merged, pk[p + "w"], nxt, B * H2 * W2, 2 * C, 4 * C, bias=pk[p + "b"], ln=(mean, rstd, pk[p + "csum"]), tag="swin_merge")
+                cur, H, W, C = nxt, H2, W2, 2 * C
+        mean, rstd = layernorm_stats(ws_, cur, B * H * W, C, tag="head.ln")
+        pooled = ws_.get("pooled", (B, C))
+        E.pool_mean(cur, B, H * W, C, C, pooled, C, mean=mean, rstd=rstd, gamma=pk["norm.g"], beta=pk["norm.b"])
+        if not isinstance(self.head, nn.Linear):
+            out = pooled.clone()
+            return out if out.dtype == x.dtype else out.to(x.dtype)
+        return head_linear(ws_, pooled, B, C, pk["head.w"], pk["head.b"], self.num_classes, x.dtype)

@@ -36,7 +36,7 @@ def tol_for(dtype, ref, real=False):
 def ctor_for(pkg, name):
     table = {"mixer": "MLPMixerForImageClassification", "gmlp": "gMLPForImageClassification",
              "resmlp": "ResMLPForImageClassification", "vip": "ViP", "s2mlpv2": "S2MLPv2", "s2mlpv1": "S2MLPv1",
-             "asmlp": "AS_MLP", "convmixer": "ConvMixer", "sparsemlp": "SparseMLP", "hiremlp": "HireMLP", "msmlp": "MS_MLP"}
+             "asmlp": "AS_MLP", "convmixer": "ConvMixer", "sparsemlp": "SparseMLP", "hiremlp": "HireMLP", "msmlp": "MS_MLP", "swinmlp": "SwinMLP"}
     for k, v in table.items():
         if name.startswith(k):
             mod = pkg.models_pytorch
@@ -61,7 +61,7 @@ def build_from_tiny(pkg, name):
 
 
 TINY_TOKEN = ["mixer", "mixer_nonsquare", "gmlp", "resmlp", "vip_weighted", "vip_unweighted", "vip_rect", "s2mlpv2",
-              "s2mlpv2_cleanshift", "s2mlpv1", "asmlp", "convmixer", "sparsemlp", "sparsemlp_norm", "hiremlp", "hiremlp_rect", "msmlp", "msmlp_s3"]
+              "s2mlpv2_cleanshift", "s2mlpv1", "asmlp", "convmixer", "sparsemlp", "sparsemlp_norm", "hiremlp", "hiremlp_rect", "msmlp", "msmlp_s3", "swinmlp", "swinmlp_small"]
 
 
 @pytest.mark.parametrize("name", TINY_TOKEN)
@@ -93,7 +93,7 @@ def test_tiny_fp32_input_bf16_compute(name):
 
 
 REAL = [("mixer_s16", 8), ("mixer_b16", 4), ("gmlp_s", 2), ("resmlp_24", 2), ("vip_s7", 1), ("s2mlpv2", 2), ("asmlp_t", 2),
-        ("convmixer_1536_20", 1), ("mixer_l16", 1), ("sparsemlp_t", 2), ("hiremlp_s", 2), ("msmlp_t", 2)]
+        ("convmixer_1536_20", 1), ("mixer_l16", 1), ("sparsemlp_t", 2), ("hiremlp_s", 2), ("msmlp_t", 2), ("swinmlp_t", 2)]
 
 
 @pytest.mark.parametrize("name,bs", REAL)

@@ -700,3 +700,29 @@ def test_mixshift_nhwc(dtype):
         err = (out.float().cpu() - ref).abs().max().item()
         tol = 2e-5 if dtype == torch.float32 else (4e-3 if dtype == torch.float16 else 3e-2)
         assert err < tol * max(1.0, ref.abs().max().item()), (str(dtype), ci, err)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_window_gather_scatter(dtype):
+    """Swin-MLP window partition with the shifted blocks' zero padding and the inverse merge + crop + residual
+    (swin_mlp.py:29-60, 122-151) against F.pad / view / permute.  Bit-exact moves."""
+    pkg = load_pkg()
+    E = pkg.engine
+    for ci, (B, H, W, C, ws, shift) in enumerate(((2, 8, 8, 16, 4, 2), (1, 14, 14, 8, 7, 3), (2, 6, 6, 8, 6, 0), (1, 8, 12, 8, 4, 1))):
+        x = rnd((B, H, W, C), dtype, 1400 + ci)
+        pl, pr, pt, pb = (ws - shift, shift, ws - shift, shift) if shift > 0 else (0, 0, 0, 0)
+        xp = torch.nn.functional.pad(x, (0, 0, pl, pr, pt, pb))
+        Hp, Wp = xp.shape[1], xp.shape[2]
+        ref = xp.view(B, Hp // ws, ws, Wp // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, C)
+        win = torch.full((B * Hp * Wp, C), float("nan"), dtype=dtype, device=dev())
+        E.window_gather(x.to(dev()), win, B, H, W, C, ws, pt, pl, Hp, Wp)
+        torch.cuda.synchronize()
+        assert torch.equal(win.cpu(), ref), (str(dtype), ci)
+        yw = rnd((B * Hp * Wp, C), dtype, 1410 + ci)
+        back = yw.float().view(B, Hp // ws, Wp // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, C)[:, pt:pt + H, pl:pl + W, :]
+        x0 = rnd((B, H, W, C), dtype, 1420 + ci)
+        want = (x0.float() + back).to(dtype)
+        xg = x0.clone().to(dev())
+        E.window_scatter_add(xg, yw.to(dev()), B, H, W, C, ws, pt, pl, Hp, Wp)
+        torch.cuda.synchronize()
+        assert torch.equal(xg.cpu(), want), (str(dtype), ci)

@@ -20,7 +20,7 @@ if has bench; then
 fi
 if has models; then
   : > $OUT/bench_models.jsonl
-  for m in mixer_s16 mixer_l16 gmlp_s resmlp_24 vip_s7 s2mlpv2 asmlp_t convmixer_1536_20 sparsemlp_t hiremlp_s msmlp_t; do
+  for m in mixer_s16 mixer_l16 gmlp_s resmlp_24 vip_s7 s2mlpv2 asmlp_t convmixer_1536_20 sparsemlp_t hiremlp_s msmlp_t swinmlp_t; do
     timeout 600 python bench.py --model $m --steps 5 --warmup 2 --no-cpu-baseline >> $OUT/bench_models.jsonl 2>> $OUT/bench_models.err
   done
   python - <<'PY'
