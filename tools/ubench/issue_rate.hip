@@ -131,6 +131,19 @@ __global__ void __launch_bounds__(512) k(float* out, unsigned long long* cyc, in
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { f32x4 v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(0)); asm volatile("" :: "v"(v)); }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else if (MODE >= 40 && MODE <= 45) {   // ds_read_b128 on 64-byte rows (16x16x32 operand: row = lane & 15, chunk = lane >> 4), swizzles
+                const unsigned l = threadIdx.x & 63, row = l & 15, ch = l >> 4;
+                unsigned sw;
+                if (MODE == 40) sw = 0;                                   // no swizzle
+                else if (MODE == 41) sw = (row & 8) >> 2;                  // token_mlp today: row bit 3 -> chunk bit 1
+                else if (MODE == 42) sw = (row >> 2) & 3;                  // row bits 2,3 -> chunk bits 0,1
+                else if (MODE == 43) sw = (row >> 1) & 3;                  // row bits 1,2
+                else if (MODE == 44) sw = ((row >> 2) & 1) | ((row >> 3) << 1);   // same as 42
+                else sw = ((row >> 2) & 1) ^ (((row >> 3) & 1) << 1) ^ ((row >> 2) & 2);
+                unsigned addr = row * 64 + ((ch ^ sw) << 4) + (threadIdx.x >> 6) * 4096;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { f32x4 v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(0)); asm volatile("" :: "v"(v)); }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             } else if (MODE == 7) {   // ds_read_b128, conflict-free lane-linear
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { f32x4 v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"((unsigned)(threadIdx.x & 63) * 16u), "n"(0)); acc[i & 3] += v; }
@@ -178,6 +191,10 @@ int main() {
         run<34>("ds_read_b128 32x32 row bit4->c0", thr);
         run<35>("ds_read_b128 32x32 row bit3->c0", thr);
         run<36>("ds_read_b128 32x32 b3->c0 b4->c1", thr);
+        run<40>("ds_read_b128 64B rows, no swizzle", thr);
+        run<41>("ds_read_b128 64B rows, bit3->c1 (token)", thr);
+        run<42>("ds_read_b128 64B rows, bits23->c01", thr);
+        run<43>("ds_read_b128 64B rows, bits12->c01", thr);
         run<8>("v_mfma_16x16x32_bf16 (16 accs)", thr);
         run<9>("v_mfma_32x32x16_bf16 (4 accs)", thr);
         run<21>("v_mfma_32x32x16_bf16 (1 acc)", thr);
