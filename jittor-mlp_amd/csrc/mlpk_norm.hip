@@ -39,6 +39,36 @@ template <typename T> __device__ __forceinline__ void store8(T* p, const float (
 // row: mean, then centred sum of squares -- no E[x^2]-mu^2 cancellation, which matters for the fp32 1e-5 parity
 // gate.  Rows of up to 2048 elements are held in registers between the passes; rows up to 4096 are re-read (L1/L2);
 // longer ones (one workgroup per row) are read once with pivoted sums, see below.
+// Short rows (<= 128 elements: the 64..128-channel LayerNorms of the staged models): 16 lanes per row, 16 rows per
+// workgroup -- with a whole wave per row 3/4 or more of the lanes had nothing to load (96 channels = 12 lanes).
+template <typename T>
+__global__ void __launch_bounds__(256) row_stats_short_kernel(const T* __restrict__ x, int64_t rows, int64_t len, int64_t ldx, float eps,
+                                                              float* __restrict__ mean, float* __restrict__ rstd) {
+    const int tid = threadIdx.x;
+    const int t = tid & 15;
+    const int64_t row = (int64_t)blockIdx.x * 16 + (tid >> 4);
+    const bool live = row < rows;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    const bool has = live && (int64_t)t * 8 < len;
+    if (has) load8<T>(x + row * ldx + t * 8, v);
+    float s1 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1 += v[e];
+    const float mu = row16_sum(s1) / (float)len;
+    float q1 = 0.f;
+    if (has) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[e] - mu; q1 += d * d; }
+    }
+    const float var = row16_sum(q1) / (float)len;
+    if (live && t == 0) {
+        mean[row] = mu;
+        rstd[row] = 1.0f / __builtin_sqrtf(var + eps);
+    }
+}
+
 template <typename T, int TPR>
 __global__ void __launch_bounds__(TPR == 64 ? 256 : TPR) row_stats_kernel(const T* __restrict__ x, int64_t rows, int64_t len,
                                                         int64_t ldx, float eps, float* __restrict__ mean,
@@ -628,7 +658,11 @@ extern "C" int mlpk_row_stats(int dtype, const void* x, int64_t rows, int64_t le
     if (dtype < 0 || dtype > 2) return MLPK_EDTYPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int vec = (len % 8 == 0) && (ldx % 8 == 0) && (((uintptr_t)x & 15) == 0);
-    if (len <= 4096) {
+    if (vec && len <= 128) {
+        const unsigned grid = (unsigned)((rows + 15) / 16);
+        DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((row_stats_short_kernel<T>), dim3(grid), dim3(256), 0, s, (const T*)x, rows, len, ldx, eps,
+                                                 mean, rstd));
+    } else if (len <= 4096) {
         const unsigned grid = (unsigned)((rows + 3) / 4);
         DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((row_stats_kernel<T, 64>), dim3(grid), dim3(256), 0, s,
                                                  (const T*)x, rows, len, ldx, eps, mean, rstd, vec));

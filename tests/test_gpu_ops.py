@@ -726,3 +726,22 @@ def test_window_gather_scatter(dtype):
         E.window_scatter_add(xg, yw.to(dev()), B, H, W, C, ws, pt, pl, Hp, Wp)
         torch.cuda.synchronize()
         assert torch.equal(xg.cpu(), want), (str(dtype), ci)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_row_stats_short_rows(dtype):
+    """Rows of <= 128 elements take the 16-lanes-per-row kernel: lengths 8..128, row counts that are not multiples of 16,
+    a row stride larger than the row; fp64 statistics as the reference."""
+    pkg = load_pkg()
+    E = pkg.engine
+    for ci, (rows, C, ld) in enumerate(((1, 8, 8), (37, 96, 96), (16, 128, 128), (50, 64, 192), (3, 24, 40))):
+        x = (rnd((rows, ld), torch.float32, 1500 + ci) * 3 + 0.7).to(dtype).to(dev())
+        mean = torch.full((rows,), float("nan"), device=dev())
+        rstd = torch.full((rows,), float("nan"), device=dev())
+        E.row_stats(x, rows, C, ld, mean, rstd, eps=1e-6)
+        torch.cuda.synchronize()
+        xd = x.cpu().double()[:, :C]
+        mu = xd.mean(1)
+        var = ((xd - mu[:, None]) ** 2).mean(1)
+        assert (mean.cpu().double() - mu).abs().max() < 1e-5, (str(dtype), ci)
+        assert ((rstd.cpu().double() - 1 / torch.sqrt(var + 1e-6)).abs() * torch.sqrt(var + 1e-6)).max() < 1e-5, (str(dtype), ci)
