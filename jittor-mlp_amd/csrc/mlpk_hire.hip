@@ -210,7 +210,8 @@ __global__ void __launch_bounds__(256) mixshift_kernel(const MixShiftArgs p) {
 // Measured on MS-MLP-T (bs 256, bf16): 950 us per call per-channel -> 805 us; still texture-address bound (every input vector is
 // fetched once per tap and branch, and a wave runs the longest kernel of its lanes).  A variant with 4-pixel output strips
 // and the kernel size as a template parameter (each loaded vector reused for 4 outputs) spilled its window registers
-// and ran at 2650 us; the real fix is the LDS-tiled stencil of mlpk_dwconv.hip with a rolled tile load -- next.
+// and ran at 2650 us; the LDS-tiled mixshift_band_kernel below is what the models use, this one is the fallback for the
+// shapes it does not cover (kernel sizes other than 1/3/5/7, maps wider than 56 columns).
 template <typename T>
 __global__ void __launch_bounds__(256) mixshift_vec_kernel(const MixShiftArgs p) {
     constexpr int EPV = 16 / (int)sizeof(T);
@@ -295,6 +296,179 @@ __global__ void __launch_bounds__(256) mixshift_vec_kernel(const MixShiftArgs p)
     }
 }
 
+// LDS-tiled form (the design of mlpk_dwconv.hip): workgroup = one image x a band of 8 output rows x 32 channels of ONE chunk
+// (uniform kernel size KS and shift), both branches.  Per branch the band (+ halo) is staged TRANSPOSED in LDS as
+// [channel][row][column] with the roll folded into the source index and zeros outside the map; a thread is one channel
+// and walks strips of 8 outputs, its taps in registers as pairs feeding v_pk_fma_f32.  The partial sums of the first
+// branch stay in registers while the second branch's band replaces the first in LDS.  Every input element is fetched
+// from global (R + KS - 1) / R times per branch instead of KS * KS times.
+constexpr int MS_CT = 32, MS_R = 8, MS_NT = 256, MS_TMAX = 7;
+
+template <typename T, int KS>
+__global__ void __launch_bounds__(MS_NT) mixshift_band_kernel(const MixShiftArgs p, const int cb, const int cn, const int sh, const int sw,
+                                                              const int pitch, const int plane) {
+    constexpr int P = KS / 2;
+    constexpr int STRIP = 8;
+    constexpr int EPV = 16 / (int)sizeof(T);
+    constexpr int WIN = STRIP + KS - 1;
+    constexpr int NV = (WIN + EPV - 1) / EPV;
+    constexpr int GROUPS = MS_NT / MS_CT;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* tile = reinterpret_cast<T*>(smem_raw);              // [MS_CT][MS_R + 2P][pitch], plane stride `plane` elements
+    const T* __restrict__ in = reinterpret_cast<const T*>(p.x);
+    T* __restrict__ out = reinterpret_cast<T*>(p.out);
+    const int tid = threadIdx.x;
+    const int nbands = (p.H + MS_R - 1) / MS_R;
+    const int b = blockIdx.x / nbands;
+    const int y0 = (blockIdx.x - b * nbands) * MS_R;
+    const int c0 = cb + blockIdx.y * MS_CT;
+    const int nch = min(MS_CT, cb + cn - c0);              // channels of this tile
+    const int rows_t = MS_R + 2 * P;
+    const int cols_t = p.W + 2 * P;
+    const T* img = in + (size_t)b * p.H * p.W * p.C;
+
+    const int cl = tid % MS_CT;
+    const int c = c0 + cl;
+    const bool live = cl < nch;
+    const int strips = (p.W + STRIP - 1) / STRIP;
+    const int ntask = MS_R * strips;
+    const T* cplane = tile + cl * plane;
+    f32x2 acc2[MS_TMAX][STRIP / 2];
+    {
+        const float bs = live ? p.b_lr[c] + p.b_td[c] : 0.f;
+#pragma unroll
+        for (int k = 0; k < MS_TMAX; ++k)
+#pragma unroll
+            for (int o = 0; o < STRIP / 2; ++o) acc2[k][o] = f32x2{bs, bs};
+    }
+#pragma unroll 1
+    for (int branch = 0; branch < 2; ++branch) {
+        __syncthreads();                                   // the previous branch's reads of the tile are done
+        // ---- stage: element (channel ch, tile row r, tile column q) <- rolled source or zero; consecutive threads = channels ----
+        {
+            const int total = rows_t * cols_t * MS_CT;
+            for (int i = tid; i < total; i += MS_NT) {
+                const int ch = i % MS_CT;
+                const int px = i / MS_CT;
+                const int q = px % cols_t, r = px / cols_t;
+                const int yy = y0 + r - P, xx = q - P;
+                T v = from_f32<T>(0.f);
+                if (ch < nch && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) {
+                    int ys = yy, xs = xx;
+                    if (branch == 0) { xs -= sw; if (xs < 0) xs += p.W; }
+                    else { ys -= sh; if (ys < 0) ys += p.H; }
+                    v = img[((size_t)ys * p.W + xs) * p.C + c0 + ch];
+                }
+                tile[ch * plane + r * pitch + q] = v;
+            }
+            // the window reads run up to NV * EPV columns past a strip's start: zero the slack columns of every row
+            const int slack = pitch - cols_t;
+            if (slack > 0) {
+                const int tot2 = rows_t * slack * MS_CT;
+                for (int i = tid; i < tot2; i += MS_NT) {
+                    const int ch = i % MS_CT;
+                    const int px = i / MS_CT;
+                    tile[ch * plane + (px / slack) * pitch + cols_t + px % slack] = from_f32<T>(0.f);
+                }
+            }
+        }
+        __syncthreads();
+        if (live) {
+            const float* wsrc = branch == 0 ? p.w_lr : p.w_td;
+            constexpr int NT2 = (KS * KS + 1) / 2;
+            f32x2 wt2[NT2];
+#pragma unroll
+            for (int q = 0; q < NT2; ++q) {
+                wt2[q].x = wsrc[(size_t)(2 * q) * p.C + c];
+                wt2[q].y = 2 * q + 1 < KS * KS ? wsrc[(size_t)(2 * q + 1) * p.C + c] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < MS_TMAX; ++k) {
+                const int task = tid / MS_CT + k * GROUPS;
+                if (task >= ntask) break;
+                const int st = task % strips, ly = task / strips;
+                const int x0 = st * STRIP;
+#pragma unroll
+                for (int dy = 0; dy < KS; ++dy) {
+                    const T* row = cplane + (ly + dy) * pitch + x0;
+                    float win[NV * EPV + 1];
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        const u32x4 raw = *reinterpret_cast<const u32x4*>(row + v * EPV);
+                        T e[EPV];
+                        __builtin_memcpy(e, &raw, 16);
+#pragma unroll
+                        for (int kk = 0; kk < EPV; ++kk) win[v * EPV + kk] = to_f32(e[kk]);
+                    }
+                    win[NV * EPV] = 0.f;
+#pragma unroll
+                    for (int dx = 0; dx < KS; ++dx) {
+                        const int tap = dy * KS + dx;
+#pragma unroll
+                        for (int o = 0; o < STRIP / 2; ++o) {
+                            const f32x2 xin = {win[2 * o + dx], win[2 * o + dx + 1]};
+                            if (tap & 1) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc2[k][o]) : "v"(xin), "v"(wt2[tap >> 1]));
+                            else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc2[k][o]) : "v"(xin), "v"(wt2[tap >> 1]));
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int k = 0; k < MS_TMAX; ++k) {
+        const int task = tid / MS_CT + k * GROUPS;
+        if (task >= ntask) break;
+        const int st = task % strips, ly = task / strips;
+        const int y = y0 + ly;
+        if (y >= p.H) continue;
+#pragma unroll
+        for (int o = 0; o < STRIP; ++o) {
+            const int xx = st * STRIP + o;
+            if (xx < p.W) out[(((size_t)b * p.H + y) * p.W + xx) * p.C + c] = from_f32<T>((o & 1) ? acc2[k][o >> 1].y : acc2[k][o >> 1].x);
+        }
+    }
+}
+
+template <typename T>
+static int mixshift_band_launch(const MixShiftArgs& a, hipStream_t s) {
+    constexpr int EPV = 16 / (int)sizeof(T);
+    const int strips = (a.W + 7) / 8;
+    if (strips > MS_TMAX) return 1;
+    for (int g = 0; g < a.groups; ++g)
+        if (a.ksize[g] != 1 && a.ksize[g] != 3 && a.ksize[g] != 5 && a.ksize[g] != 7) return 1;
+    const int nbands = (a.H + MS_R - 1) / MS_R;
+    for (int g = 0; g < a.groups; ++g) {
+        const int k = a.ksize[g], P = k / 2;
+        const int cb = g * a.chunk0;
+        const int cn = (cb + a.chunk0 <= a.C ? a.chunk0 : a.C - cb);
+        int pitch = (strips - 1) * 8 + ((8 + k - 1 + EPV - 1) / EPV) * EPV;
+        if (pitch < a.W + 2 * P) pitch = a.W + 2 * P;
+        pitch = (pitch + EPV - 1) / EPV * EPV;
+        int plane = (MS_R + 2 * P) * pitch;
+        plane = (plane + EPV - 1) / EPV * EPV;
+        if (((plane / EPV) & 1) == 0) plane += EPV;            // odd number of 16-byte slots per channel plane: conflict-free across channels
+        const size_t lds = (size_t)MS_CT * plane * sizeof(T);
+        if (lds > 150 * 1024) return 1;
+        int sh = a.shift[g] % a.H, sw = a.shift[g] % a.W;
+        if (sh < 0) sh += a.H;
+        if (sw < 0) sw += a.W;
+        const dim3 grid((unsigned)(a.B * nbands), (unsigned)((cn + MS_CT - 1) / MS_CT));
+#define MS_CASE(KS)                                                                                                         \
+    case KS: {                                                                                                              \
+        auto kern = mixshift_band_kernel<T, KS>;                                                                            \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return (int)e;                                                                                 \
+        hipLaunchKernelGGL(kern, grid, dim3(MS_NT), lds, s, a, cb, cn, sh, sw, pitch, plane);                                \
+        break;                                                                                                              \
+    }
+        switch (k) { MS_CASE(1) MS_CASE(3) MS_CASE(5) MS_CASE(7) default: return 1; }
+#undef MS_CASE
+    }
+    return 0;
+}
+
 }  // namespace mlpk
 
 extern "C" int mlpk_mixshift_nhwc(int dtype, const void* x, void* out, int B, int H, int W, int C, int groups, const int* shift,
@@ -315,6 +489,20 @@ extern "C" int mlpk_mixshift_nhwc(int dtype, const void* x, void* out, int B, in
         if (a.ksize[g] < 1 || !(a.ksize[g] & 1) || a.ksize[g] > 15) return MLPK_ESHAPE;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    static const bool no_band = getenv("MLPK_MIXSHIFT_NO_BAND") != nullptr;      // tuning hook
+    if (!no_band && B <= 0x7fffff) {
+        int rc;
+        switch (dtype) {
+            case MLPK_F32: rc = mlpk::mixshift_band_launch<float>(a, s); break;
+            case MLPK_F16: rc = mlpk::mixshift_band_launch<mlpk::f16_t>(a, s); break;
+            default: rc = mlpk::mixshift_band_launch<mlpk::bf16_t>(a, s); break;
+        }
+        if (rc != 1) {                                      // 1 = shape outside the tiled kernel: gather kernels below
+            if (rc) return rc;
+            MLPK_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     const int epv = dtype == MLPK_F32 ? 4 : 8;
     const bool aligned = !(((uintptr_t)x | (uintptr_t)out | (uintptr_t)w_lr | (uintptr_t)w_td | (uintptr_t)b_lr | (uintptr_t)b_td) & 15);
     if (C % epv == 0 && aligned) {
