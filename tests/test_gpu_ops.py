@@ -677,7 +677,9 @@ def test_mixshift_nhwc(dtype):
     pkg = load_pkg()
     E = pkg.engine
     for ci, (B, H, W, C, shift, ks) in enumerate(((2, 8, 10, 24, [-2, -1, 0, 1, 2], [1, 1, 3, 5, 7]), (1, 6, 5, 16, [-1, 0, 3], [3, 1, 5]),
-                                                  (2, 4, 4, 8, [7], [3]), (1, 7, 9, 12, [2, -3], [5, 3]))):
+                                                  (2, 4, 4, 8, [7], [3]), (1, 7, 9, 12, [2, -3], [5, 3]),
+                                                  # outside the LDS-tiled kernel (kernel size 9; a map wider than 56): the gather kernels
+                                                  (1, 6, 6, 16, [1, -1], [9, 3]), (1, 4, 64, 8, [2], [3]), (1, 5, 6, 12, [1, 2], [9, 1]))):
         x = rnd((B, H, W, C), dtype, 1200 + ci)
         xf = x.float().permute(0, 3, 1, 2)
         chunks = torch.chunk(xf, len(shift), 1)
