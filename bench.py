@@ -51,7 +51,7 @@ DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
 
 
 def run_cpu_baseline(model_name, kwargs, ctor_name, pkg):
-    import oracle
+    import oracle  # noqa: F401  (the CPU baseline IS the oracle package: fail here, loudly, if it is missing)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_oracle_golden import run_oracle
     # one torch thread per physical core, capped: oversubscribing a 2-socket EPYC (256 logical CPUs)

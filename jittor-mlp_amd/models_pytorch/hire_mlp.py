@@ -13,7 +13,6 @@ HireMLPBlock (hire_mlp.py:96-152) on the channel-last LayerNorm output xn (B*H*W
 The patcher (7x7 stride-4 pad-3 conv, :203) and the stage transitions (3x3 stride-2 pad-1 conv, :161) are window gathers
 (mlpk_im2col) + GEMM; the channel MLP folds its LayerNorm into fc1; the head folds its LayerNorm into the token mean.
 """
-import torch
 from torch import nn
 
 from .. import _native as N

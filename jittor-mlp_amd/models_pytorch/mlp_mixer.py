@@ -17,7 +17,6 @@ Mapping to kernels:
 import os
 from functools import partial
 
-import torch
 from torch import nn
 
 from .. import _native as N

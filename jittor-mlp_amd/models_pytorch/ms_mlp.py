@@ -14,7 +14,7 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Holder, channel_mlp, embed_patches, head_linear, layernorm_stats, pack_channel_mlp
+from .common import Holder, channel_mlp, embed_patches, head_linear, layernorm_stats
 
 MS_EPS = 1e-6
 

@@ -17,7 +17,7 @@ import torch
 import oracle
 from conftest import load_pkg
 from oracle.portable_init import portable_input, portable_state_dict
-from test_oracle_golden import run_oracle
+from test_oracle_golden import run_oracle  # noqa: F401  (re-exported for ad-hoc debugging sessions)
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")

@@ -2,7 +2,6 @@
 the gathered logits of a sharded run equal a single run on the concatenated batch, row for row
 (SURVEY.md section 4 tier 6).  The per-rank forward is the CPU oracle here (the HIP forward needs a
 GPU); the collective code path (jittor-mlp_amd/parallel.py) is exactly the one bench.py uses."""
-import json
 import os
 import socket
 import sys
