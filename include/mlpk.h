@@ -152,6 +152,10 @@ int mlpk_gemm_algo_info(int algo, int* bm, int* bn, int* threads, int* lds_bytes
 int mlpk_token_mlp_chunk(void);
 int mlpk_token_mlp(int dtype, const void* xt, int ldxt, int M, int S, const void* w1, int ldw1, const float* b1,
                    const void* w2, int ldw2, const float* b2, int nchunks, void* x, int ldx, int t_rows, void* stream);
+/* Tuning hook (tools/tokenmlp_timeline.py), not part of the forward path: when `buf` is non-NULL, later mlpk_token_mlp
+ * launches log per-workgroup s_memtime stamps into it (64 x uint64 per workgroup); NULL switches the logging off.
+ * The only library-held state, and off by default. */
+void mlpk_token_mlp_debug(void* buf);
 
 /* ---- patch gather (im2col of a kernel==stride convolution) -----------------------------
  * out[(b*Hp + hp)*Wp + wp][k], row stride ldo (>= K, pad columns [K, ldo) are zero-filled).

@@ -48,6 +48,7 @@ PROTOTYPES = {
     "mlpk_token_mlp_chunk": (c_int, []),
     "mlpk_token_mlp": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                c_int, c_void_p, c_int, c_int, c_void_p]),
+    "mlpk_token_mlp_debug": (None, [c_void_p]),
     "mlpk_patchify": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "mlpk_row_stats": (c_int, [c_int, c_void_p, c_i64, c_i64, c_i64, c_float, c_void_p, c_void_p, c_void_p]),
     "mlpk_norm_apply": (c_int, [ctypes.POINTER(NormDesc), c_void_p]),

@@ -144,6 +144,10 @@ __global__ void __launch_bounds__(DW_NT) dwconv_lds_kernel(const T* __restrict__
     }
 }
 
+// "the staged plane does not fit the LDS": distinct from every hipError_t (>= 0) and MLPK_E* (-1 .. -5) value, so a real
+// HIP error can never be mistaken for it and swallowed by the fallback
+static constexpr int DW_NOFIT = -1000;
+
 template <typename T>
 static int dwconv_lds_launch(int k, const void* x, void* out, int B, int H, int W, int C, const float* w, const float* bias,
                              const float* bns, const float* bnh, hipStream_t s) {
@@ -159,7 +163,7 @@ static int dwconv_lds_launch(int k, const void* x, void* out, int B, int H, int 
     plane = (plane + EPV - 1) / EPV * EPV;
     if (((plane / EPV) & 1) == 0) plane += EPV;
     const size_t lds = (size_t)CT * plane * sizeof(T);
-    if (lds > 160 * 1024) return 1;                     // caller falls back
+    if (lds > 160 * 1024) return DW_NOFIT;              // caller falls back (a value no hipError_t / MLPK_E* takes)
     const dim3 grid((unsigned)B, (unsigned)((C + CT - 1) / CT));
 #define DW_CASE(KS)                                                                                                    \
     case KS: {                                                                                                         \
@@ -288,7 +292,7 @@ extern "C" int mlpk_dwconv_nhwc(int dtype, const void* x, void* out, int B, int 
             case MLPK_BF16: rc = dwconv_lds_launch<bf16_t>(k, x, out, B, H, W, C, w, bias, bn_scale, bn_shift, s); break;
             default: return MLPK_EDTYPE;
         }
-        if (rc != 1) return rc;                          // 1 = tile does not fit the LDS: use the generic kernel
+        if (rc != DW_NOFIT) return rc;                   // tile does not fit the LDS: use the generic kernel
     }
     return mlpk_dwconv_direct(dtype, x, out, B, H, W, C, k, w, bias, bn_scale, bn_shift, stream);
 }

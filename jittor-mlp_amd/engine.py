@@ -29,7 +29,16 @@ def require_gpu(x, what="forward"):
 
 
 def stream():
+    """torch's current stream of the CURRENT device.  Every entry point that takes tensors runs under
+    `on_device(x)` (EngineModule.__call__, Shift), which makes x's device current for the duration of the
+    call, so launches, the stream and the device-attribute queries inside libmlpk.so all refer to the device
+    the pointers live on -- also when the caller's current device is another GPU."""
     return torch.cuda.current_stream().cuda_stream
+
+
+def on_device(x):
+    """Context manager: x's device current (hipSetDevice + torch's per-device current stream)."""
+    return torch.cuda.device(x.device)
 
 
 def ptr(t):
@@ -288,7 +297,10 @@ class Workspace:
             t = torch.full(shape, fill, dtype=dtype or self.dtype, device=self.device)
             self.t[name] = t
         elif tuple(t.shape) != tuple(shape):
-            raise RuntimeError("workspace buffer %r re-requested with a different shape" % name)
+            # the same role at another size (a model without a fixed image size called at a second resolution with
+            # a workspace key that did not separate them): a fresh zero-initialised buffer, never a reinterpretation
+            t = torch.full(shape, fill, dtype=dtype or self.dtype, device=self.device)
+            self.t[name] = t
         return t
 
 
@@ -301,6 +313,16 @@ class EngineModule(torch.nn.Module):
         self.__dict__["_packs"] = {}
         self.__dict__["_spaces"] = {}
         self.__dict__["_compute_dtype"] = None
+        self.__dict__["_in_shape"] = None
+        self.__dict__["_warned_train"] = False
+
+    def __call__(self, *args, **kwargs):
+        # run the whole forward with the input's device current: launches go to THAT device's stream
+        x = args[0] if args else None
+        if torch.is_tensor(x) and x.is_cuda:
+            with on_device(x):
+                return super().__call__(*args, **kwargs)
+        return super().__call__(*args, **kwargs)
 
     def set_compute_dtype(self, dtype):
         """Run the MFMA path in `dtype` regardless of the input dtype (input is converted while
@@ -322,7 +344,8 @@ class EngineModule(torch.nn.Module):
         return hit[1]
 
     def _get_space(self, batch, dtype, device):
-        key = (batch, dtype, str(device))
+        # keyed by the input's spatial shape too: ConvMixer / Hire-MLP / ... take any resolution, like the reference
+        key = (batch, self._in_shape, dtype, str(device))
         ws = self._spaces.get(key)
         if ws is None:
             if len(self._spaces) >= 4:          # bound resident workspaces (288 GB is big, not infinite)
@@ -335,6 +358,13 @@ class EngineModule(torch.nn.Module):
         require_gpu(x, type(self).__name__ + ".forward")
         if x.dim() != 4:
             raise ValueError("expected a (B, C, H, W) tensor")
+        self.__dict__["_in_shape"] = tuple(x.shape[1:])
+        if self.training and not self._warned_train:
+            import warnings
+            warnings.warn("%s is inference-only: forward() ignores train mode (Dropout / DropPath are identity, BatchNorm uses "
+                          "its running statistics) and the outputs carry no grad_fn; call .eval()" % type(self).__name__,
+                          stacklevel=3)
+            self.__dict__["_warned_train"] = True
         cd = self._compute_dtype or x.dtype
         dtype_code(cd)
         dtype_code(x.dtype)

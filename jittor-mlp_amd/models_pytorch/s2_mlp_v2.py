@@ -81,10 +81,10 @@ class S2Block(E.EngineModule):
             mlp = blk[1]
             pack_channel_mlp(pk, p + "mlp.", mlp.norm, mlp.fn[0], mlp.fn[3], dtype, device)
 
-    def _run_blocks(self, ws, pk, x, B, H, W, prefix, mode):
+    def _run_blocks(self, ws, pk, x, B, H, W, prefix, mode, only=None):
         C, depth, ef = self._dims
         rows = B * H * W
-        for i in range(depth):
+        for i in (range(depth) if only is None else only):
             p = prefix + "b%d." % i
             mean, rstd = layernorm_stats(ws, x, rows, C, tag=prefix + "ln")
             t = ws.get(prefix + "t", (rows, 3 * C))
@@ -150,6 +150,23 @@ class S2MLPv2(E.EngineModule):
 
     def _block_runner(self, s):
         return self.stages[s][1]._run_blocks
+
+    def forward_block(self, stage, index, x):
+        """One block `stages[stage][1].model[index]` on a channel-last activation (B, H, W, C) -> (B, H, W, C): what
+        calling that sub-module does in the reference (s2_mlp_v2.py:86-92).  Used for teacher-forced parity checks."""
+        E.require_gpu(x, "S2MLPv2.forward_block")
+        B, H, W, C = x.shape
+        if C != self._d_model[stage]:
+            raise ValueError("stage %d works on %d channels" % (stage, self._d_model[stage]))
+        cd = self._compute_dtype or x.dtype
+        with E.on_device(x):
+            pk = self._get_pack(cd, x.device)
+            self.__dict__["_in_shape"] = ("block", H, W)
+            ws = self._get_space(B, cd, x.device)
+            buf = ws.get("blk%d.x" % stage, (B * H * W, C))
+            buf.copy_(x.reshape(B * H * W, C))
+            self._block_runner(stage)(ws, pk, buf, B, H, W, "s%d." % stage, SHIFT_MODES[self.shift_mode], only=[index])
+            return buf.reshape(B, H, W, C).to(x.dtype).clone()
 
     def forward(self, x):
         cd = self._resolve(x)

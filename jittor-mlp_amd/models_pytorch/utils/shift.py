@@ -17,7 +17,8 @@ def _shift_gpu(input, shift, dim):
     assert input.dim() == 4
     x = input.contiguous()
     out = torch.empty_like(x)
-    E.shift_nchw(x, out, shift, dim)
+    with E.on_device(x):
+        E.shift_nchw(x, out, shift, dim)
     return out
 
 

@@ -11,7 +11,7 @@ The reference is imported read-only through the shim of SURVEY.md section 8c:
 Nothing from the reference's source text is written to the repo: fixtures hold inputs,
 weights (tiny configs only) and the reference's outputs.
 
-Usage:  python tests/golden/make_golden.py [--only tiny|real|ops|manifest] [--check]
+Usage:  python tests/golden/make_golden.py [--only tiny|real|ops|manifest|s2lowp] [--check]
 """
 import argparse
 import importlib
@@ -392,6 +392,69 @@ def make_ops(ref):
     print("  ops pins written (%d arrays)" % len(blob))
 
 
+def make_s2_lowp(ref):
+    """S2-MLPv2 at BASELINE depth (configs[3]) in 16 bit -- the floors the GPU tests gate against:
+      real_s2mlpv2_lowp.npz    the REFERENCE's own fp16 / bf16 forward (CPU, 1 thread, portable weights, bs=2): logits and
+                               max|d| against its fp32 logits.  The 18-block network amplifies round-off ~100x (the
+                               in-place "smear" shift + SplitAttention sums over all pixels), so a 16-bit run of the
+                               reference itself is 0.4 / 0.7 away from its fp32 logits: that, not 1e-3, is the floor.
+      real_s2mlpv2_blocks.npz  teacher forcing: full input and output (fp32, reference layout (B,H,W,C)) of blocks
+                               0, 3 of stage 1 and 0, 7, 13 of stage 2 at bs=1, plus the reference's own 16-bit error
+                               on each of those blocks fed the SAME input -- per-block parity has no conditioning excuse.
+    s2_mlp_v2.py:15-92."""
+    s2 = ref["s2_mlp_v2"]
+    nt = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        def fresh():
+            torch.manual_seed(0)
+            m = s2.S2MLPv2().eval()
+            load_portable(m, seed=0)
+            return m
+        x = torch.from_numpy(portable_input((2, 3, 224, 224), seed=0))
+        with torch.no_grad():
+            o32 = fresh()(x.clone())
+        z = np.load(os.path.join(HERE, "real_s2mlpv2.npz"))
+        assert np.array_equal(o32.numpy(), z["logits"]), "fp32 logits differ from the committed fixture"
+        blob = {"logits_fp32": o32.numpy()}
+        for tag, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+            with torch.no_grad():
+                o = fresh().to(dt)(x.clone().to(dt)).float()
+            blob["logits_" + tag] = o.numpy()
+            blob["err_" + tag] = np.array((o - o32).abs().max().item())
+            print("  s2mlpv2 reference %s vs its fp32: max|d| %.4f (max|ref| %.3f)" % (tag, blob["err_" + tag], o32.abs().max().item()), flush=True)
+        np.savez_compressed(os.path.join(HERE, "real_s2mlpv2_lowp.npz"), **blob)
+
+        # ---- teacher-forced blocks, bs = 1
+        model = fresh()
+        picks = [(0, 0), (0, 3), (1, 0), (1, 7), (1, 13)]
+        cap, handles = {}, []
+        for s, i in picks:
+            mod = model.stages[s][1].model[i]
+            handles.append(mod.register_forward_hook(
+                lambda m, inp, out, key="s%d.b%d" % (s, i): cap.__setitem__(key, (inp[0].detach().clone(), out.detach().clone()))))
+        with torch.no_grad():
+            model(x[:1].clone())
+        for h in handles:
+            h.remove()
+        blob = {}
+        for s, i in picks:
+            key = "s%d.b%d" % (s, i)
+            xin, yout = cap[key]
+            blob[key + "/in"], blob[key + "/out"] = xin.numpy(), yout.numpy()
+            for tag, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+                blk = fresh().stages[s][1].model[i].to(dt)
+                with torch.no_grad():
+                    y = blk(xin.clone().to(dt)).float()
+                rel = ((y - yout).abs().max() / yout.abs().max()).item()
+                blob[key + "/ref_relerr_" + tag] = np.array(rel)
+                print("  block %-7s shape %s max|out| %.3f  reference %s rel err %.3e (2^%.1f)"
+                      % (key, tuple(xin.shape), yout.abs().max().item(), tag, rel, np.log2(rel)), flush=True)
+        np.savez_compressed(os.path.join(HERE, "real_s2mlpv2_blocks.npz"), **blob)
+    finally:
+        torch.set_num_threads(nt)
+
+
 def make_manifest(ref):
     """Drop-in manifests: constructor signatures + state_dict key->shape for every hot-path model."""
     man = {"signatures": {}, "state_dicts": {}}
@@ -437,6 +500,8 @@ def main():
         make_manifest(ref)
     if args.only in (None, "real"):
         make_real(ref, args.real.split(",") if args.real else None)
+    if args.only in (None, "s2lowp"):
+        make_s2_lowp(ref)
 
 
 if __name__ == "__main__":

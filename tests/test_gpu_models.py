@@ -3,9 +3,11 @@
       real-shape fixtures with portable weights), and
   (2) the CPU oracle on the same seeded inputs.
 Tolerances (north star: 1e-5 fp32 / 1e-3 fp16; SURVEY Appendix C for bf16):
-  fp32  abs 1e-5 on tiny configs, 2e-5 at real depth (fp32 MFMA sums in a different order than MKL);
-  fp16  abs 1e-3;
-  bf16  abs 1.5e-2 * max(1, max|ref|)   (the reference's own bf16 run misses 1e-3, Appendix C).
+  fp32  abs 1e-5 (tiny and real depth);
+  fp16  abs 1e-3 * max(1, max|ref|);
+  bf16  abs 5e-3 * max(1, max|ref|) at real depth (the reference's own bf16 run is 2.7-4.7e-3 away
+        from its fp32 logits, so 1e-3 is not attainable by any bf16 implementation), with the per-model exceptions of
+        BF16_REAL_EXCEPTIONS; 1.5e-2 on the tiny configs (random norm statistics, logits of magnitude ~1).
 """
 import json
 import os
@@ -24,12 +26,29 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 DEV = "cuda:0"
 
 
-def tol_for(dtype, ref, real=False):
+# bf16 at real depth: the gate is 5e-3 * max(1, max|ref|) (Mixer-S/B/L 2.3-2.8e-3, ResMLP 3.9e-3, Swin-MLP 3.8e-3,
+# ConvMixer 6e-4 measured; the reference's OWN bf16 forward is 2.7e-3 on Mixer-B and 4.7e-3 on gMLP-S).
+# Exceptions, each = measured value on MI355X (round 1 logs) + ~20 % head-room, all for the same reason: these networks add
+# 2 x depth bf16-rounded updates to a bf16 residual stream -- exactly like the reference run in bf16 -- and are 30-38
+# blocks deep or carry a residual of magnitude 4-8 (half-ulp 2^-7 .. 2^-6 per add) where a 12-block Mixer does not.
+BF16_REAL_EXCEPTIONS = {
+    "gmlp_s": 6.0e-3,       # measured 4.8e-3 (30 blocks; the reference's own bf16 run: 4.7e-3)
+    "vip_s7": 8.0e-3,       # measured 6.2e-3 (18 blocks x 3 branch GEMMs + 2 MLP GEMMs, logits only 0.44)
+    "asmlp_t": 8.0e-3,      # measured 7.7e-3 on max|ref| 1.17 (6.6e-3 relative); GroupNorm over whole samples
+    "sparsemlp_t": 9.0e-3,  # measured 7.4e-3 (38 blocks)
+    "hiremlp_s": 9.0e-3,    # measured 7.6e-3 (37 blocks)
+    "msmlp_t": 1.0e-2,      # measured 1.53e-2 on max|ref| 1.90 (8.0e-3 relative): LayerNorm AFTER the pool rescales the error
+}
+
+
+def tol_for(dtype, ref, real=False, name=None):
     m = max(1.0, float(ref.abs().max()))
     if dtype == torch.float32:
-        return 2e-5 if real else 1e-5
+        return 1e-5
     if dtype == torch.float16:
         return 1e-3 * m
+    if real:
+        return BF16_REAL_EXCEPTIONS.get(name, 5e-3) * m
     return 1.5e-2 * m
 
 
@@ -117,14 +136,9 @@ def test_real_golden_fp32_and_fp16(name, bs):
         torch.cuda.synchronize()
         err = (out.float().cpu() - ref).abs().max().item()
         print("real %-10s %-8s max|d| = %.3e  (max|ref| %.3f)" % (name, str(dtype)[6:], err, ref.abs().max()))
-        tol = tol_for(dtype, ref, real=True)
+        tol = tol_for(dtype, ref, real=True, name=name)
         if name == "s2mlpv2":
-            # the reference's in-place shift semantics amplify round-off ~1.6x per block on these weights
-            # (fp32 reference vs fp64 oracle already differ by 8.8e-4, tests/test_oracle_golden.py): the
-            # fp32 gate is conditioning-bound and the 16-bit runs are checked in the clean mode below.
-            if dtype != torch.float32:
-                continue
-            tol = 5e-3
+            tol = s2_real_gate(dtype)
         assert err < tol, (name, str(dtype), err)
     if name == "s2mlpv2":
         model.set_shift_mode("shift")
@@ -134,11 +148,59 @@ def test_real_golden_fp32_and_fp16(name, bs):
                 out = model(x.to(DEV).to(dtype))
             err = (out.float().cpu() - ref2).abs().max().item()
             print("real %-10s %-8s clean-shift mode vs oracle max|d| = %.3e (max|ref| %.3f)" % (name, str(dtype)[6:], err, ref2.abs().max()))
-            # SplitAttention sums (not averages) 3*H*W pixels before its softmax, so this 18-block network
-            # amplifies round-off ~100x more than the other families (fp32: 4e-5 here vs 5e-7 elsewhere);
-            # the 16-bit gates are scaled by that measured factor and bf16 is only required to stay finite.
-            gate = {torch.float32: 2e-4, torch.float16: 1e-1, torch.bfloat16: float("inf")}[dtype]
+            # SplitAttention sums (not averages) 3*H*W pixels before its softmax, so this 18-block network amplifies
+            # round-off ~100x more than the other families (fp32: 4e-5 here vs 5e-7 elsewhere).  There is no reference run
+            # of this mode in 16 bit (the reference has no clean shift), so the 16-bit gates here are the same multiples of
+            # the fp32 one that the reference's own runs show in its own mode (fp16 0.386 / fp32-vs-fp64 8.8e-4 = 440x,
+            # bf16 1100x), times the factor 2 used everywhere else.
+            gate = {torch.float32: 2e-4, torch.float16: 2e-4 * 440 * 2, torch.bfloat16: 2e-4 * 1100 * 2}[dtype]
             assert bool(torch.isfinite(out).all()) and err < gate, (name, str(dtype), err)
+
+
+def s2_real_gate(dtype):
+    """S2-MLPv2 at config depth (BASELINE configs[3]), reference_inplace mode.  The network is ill-conditioned (the in-place
+    'smear' shift + SplitAttention's sum over all pixels amplify round-off ~1.6x per block): the reference's OWN fp32 logits
+    differ from the fp64 oracle by 8.8e-4 (real_s2mlpv2.npz: oracle_fp64_maxdiff), and the reference's OWN 16-bit forwards
+    are 0.386 (fp16) / 0.967 (bf16) away from its fp32 logits (real_s2mlpv2_lowp.npz, generated by running the reference
+    in those dtypes, make_golden.py --only s2lowp).  Gates: fp32 = 5x the reference's fp32-vs-fp64 distance; 16 bit = 2x
+    the reference's own 16-bit distance.  The conditioning-free check is test_s2mlpv2_teacher_forced_blocks below."""
+    if dtype == torch.float32:
+        return 5e-3
+    z = np.load(os.path.join(GOLDEN, "real_s2mlpv2_lowp.npz"))
+    return 2.0 * float(z["err_fp16" if dtype == torch.float16 else "err_bf16"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_s2mlpv2_teacher_forced_blocks(dtype):
+    """Per-block parity at the real shapes (C = 192 @ 32x32, C = 384 @ 16x16) with no error amplification: feed the
+    reference's own block INPUT (fp32 golden, bs = 1) to the HIP block and compare with the reference's block OUTPUT.
+    Gates, relative to max|out|: fp32 1e-5; fp16 2^-10; bf16 2^-7 -- rounding level, and at or below what the reference
+    itself achieves on the same block in that dtype (stored next to the tensors: fp16 7e-4..1.1e-3, bf16 5.7e-3..1.1e-2).
+    s2_mlp_v2.py:53-92."""
+    pkg = load_pkg()
+    z = np.load(os.path.join(GOLDEN, "real_s2mlpv2_blocks.npz"))
+    with open(os.path.join(GOLDEN, "manifest.json")) as f:
+        man = json.load(f)["state_dicts"]["s2mlpv2"]
+    model = ctor_for(pkg, "s2mlpv2")(**man["kwargs"]).eval()
+    shapes = {k: tuple(s) for k, s in man["keys"]}
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in portable_state_dict(shapes, seed=0).items()}, strict=True)
+    model = model.to(DEV)
+    gate = {torch.float32: 1e-5, torch.float16: 2.0 ** -10, torch.bfloat16: 2.0 ** -7}[dtype]
+    keys = sorted({k.split("/")[0] for k in z.files})
+    assert len(keys) == 5
+    for key in keys:
+        s, i = int(key[1]), int(key.split(".b")[1])
+        xin, yout = torch.from_numpy(z[key + "/in"]), torch.from_numpy(z[key + "/out"])
+        with torch.no_grad():
+            y = model.forward_block(s, i, xin.to(DEV).to(dtype))
+        torch.cuda.synchronize()
+        assert y.shape == yout.shape and y.dtype == dtype
+        rel = ((y.float().cpu() - yout).abs().max() / yout.abs().max()).item()
+        ref_rel = float(z[key + "/ref_relerr_" + ("bf16" if dtype == torch.bfloat16 else "fp16")]) if dtype != torch.float32 else 0.0
+        print("block %-7s %-8s rel err %.3e (2^%.1f)   reference's own: %.3e" % (key, str(dtype)[6:], rel, np.log2(max(rel, 1e-30)), ref_rel))
+        assert rel < gate, (key, str(dtype), rel)
+        if dtype != torch.float32:
+            assert rel < 1.25 * ref_rel, (key, str(dtype), rel, ref_rel)
 
 
 def test_batch_256_rows_match_small_batch():

@@ -1,0 +1,109 @@
+"""-m gpu: the N > 1 path on hardware -- HIP forward + the logits all-gather in the same processes.
+
+A gpurun box has ONE MI355X, so both ranks share cuda:0 (RCCL refuses two ranks on one device, hence gloo for the
+two-rank case: the collective then stages through the host, but everything around it -- sharding, the HIP forward
+on each rank's stream, the stream-ordered hand-over into torch.distributed, rank order of the gathered rows -- is
+the code bench.py runs on the 8-GPU node).  The RCCL side is covered by a world-size-1 process group on the GPU:
+ncclAllGather on the RCCL stream, ordered against the compute stream by the events parallel.py documents.
+SURVEY.md 8e."""
+import importlib
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _model_and_input(pkg, world, per_rank):
+    torch.manual_seed(0)                                  # identical replicated weights on every rank
+    model = pkg.MLPMixerForImageClassification(d_model=256, depth=3, patch_size=16, image_size=224, num_classes=1000).eval().to("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand((world * per_rank, 3, 224, 224), generator=g).to("cuda:0").to(torch.bfloat16)
+    return model, x
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pkg = importlib.import_module("jittor-mlp_amd")
+        parallel = importlib.import_module("jittor-mlp_amd.parallel")
+        model, x = _model_and_input(pkg, world, 32)
+        runner = parallel.DataParallelForward(model, world)
+        with torch.no_grad():
+            out = runner(parallel.shard_batch(x, rank, world))
+            out_b = runner(parallel.shard_batch(x, rank, world))          # a second forward must not disturb the first result
+            single = model(x)                                             # one rank on the concatenated batch
+        torch.cuda.synchronize()
+        ok = (out.shape == single.shape and bool(torch.equal(out, single)) and bool(torch.equal(out, out_b))
+              and out.data_ptr() != out_b.data_ptr())
+        q.put((rank, ok, float((out.float() - single.float()).abs().max())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_hip_forward_plus_all_gather_bit_equal():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in results) == list(range(world))
+    assert all(r[1] for r in results), results
+
+
+def _rccl_worker(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        pkg = importlib.import_module("jittor-mlp_amd")
+        parallel = importlib.import_module("jittor-mlp_amd.parallel")
+        model, x = _model_and_input(pkg, 1, 32)
+        runner = parallel.DataParallelForward(model, 1, force_collective=True)
+        with torch.no_grad():
+            plain = model(x)
+            outs = [runner(x) for _ in range(3)]           # back to back: gather i is ordered between forward i and i+1
+        torch.cuda.synchronize()
+        q.put(all(bool(torch.equal(o, plain)) for o in outs))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_all_gather_is_ordered_on_the_compute_stream():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    ok = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0 and ok

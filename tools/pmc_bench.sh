@@ -32,4 +32,20 @@ with open(out + "/summary.txt", "w") as fo:
             continue
         fo.write("%-40s %-30s launches=%d mean=%.5g\n" % (short, c, n, s / n))
 print(open(out + "/summary.txt").read())
+# traffic of the dominant kernel for bench.py's roofline.traffic, stamped with the source it was measured on
+import hashlib, json
+root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+dom = [k for k in agg if "gemm_nt_p8" in k[0] or "gemm_nt_q" in k[0]]
+names = sorted({k[0] for k in dom})
+if names:
+    kn = max(names, key=lambda n_: agg.get((n_, "FETCH_SIZE"), [0, 0.0])[0])
+    f_n, f_s = agg[(kn, "FETCH_SIZE")]
+    w_n, w_s = agg[(kn, "WRITE_SIZE")]
+    head = open(os.path.join(root, "tools", ".git_head")).read().strip() if os.path.exists(os.path.join(root, "tools", ".git_head")) else "?"
+    tj = {"channel_mlp_gemm_bytes_per_launch": (2.0 * f_s / f_n + w_s / w_n) * 1024.0,
+          "fetch_kib_per_launch_as_reported": f_s / f_n, "write_kib_per_launch": w_s / w_n, "kernel": kn, "launches": f_n,
+          "git": head, "gemm_source_sha256": hashlib.sha256(open(os.path.join(root, "jittor-mlp_amd/csrc/mlpk_gemm.hip"), "rb").read()).hexdigest(),
+          "note": "mean over the launches of that kernel in bench.py --steps 3 --warmup 1 (channel-MLP fc1 + fc2 and the few other GEMMs that pick the same tile); (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md)"}
+    json.dump(tj, open(out + "/traffic.json", "w"))
+    print(json.dumps(tj))
 PY
