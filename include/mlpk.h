@@ -121,19 +121,17 @@ typedef struct mlpk_gemm_desc {
     int32_t t_rows;       /* TOKEN_T: rows (channels) per image */
     int32_t t_tokens;     /* TOKEN_T: tokens per image (row count of one image in C) */
     int32_t algo;         /* 0 auto; otherwise a tile-config id, see mlpk_gemm_algo_count */
-    int32_t reserved;
-    /* Optional scratch (16-byte aligned, >= mlpk_gemm_workspace_bytes(), ZERO-FILLED once when allocated; the library
-       leaves its first 4 KiB zero after every launch).  With it AND bit 128 of `reserved` set, the persistent tile
-       shares the tiles of a partial last round between several workgroups (split-K): 3-7 % faster on K >= 3072 shapes,
-       but the rows of those tiles then sum their K-slices in a different order, so a row's bits depend on the launch's
-       tile count (i.e. on the batch it is computed in).  Off by default: every tile is computed by one workgroup and
-       results do not depend on the batch.  One workspace must not be shared by launches that can run concurrently. */
+    int32_t reserved;     /* 0.  Tuning bits of the persistent tile (A/B runs only; results are bit-identical with every
+                             combination): 16 = 256-row tiles only (no mixed tile heights), 64 = LDS-staged epilogue,
+                             128 = a single column group */
+    /* Unused since ABI 5 (mlpk_gemm_workspace_bytes() == 0): every tile is computed by one workgroup, in one K order,
+       so results never depend on the batch a row is computed in.  Kept so that descriptors stay layout-compatible. */
     void* workspace;
     int64_t workspace_bytes;
 } mlpk_gemm_desc;
 
 int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream);
-/* size of the optional workspace for the current device */
+/* 0 (no kernel needs scratch) */
 long long mlpk_gemm_workspace_bytes(void);
 /* number of tile configurations (valid algo ids are 1..count) and dynamic LDS bytes of one */
 int mlpk_gemm_algo_count(void);

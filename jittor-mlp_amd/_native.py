@@ -90,7 +90,7 @@ def lib():
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(handle, name)          # AttributeError if a declared symbol is not exported
             fn.restype, fn.argtypes = res, args
-        if handle.mlpk_abi_version() != 4:
+        if handle.mlpk_abi_version() != 5:
             raise MlpkError("libmlpk.so ABI version mismatch")
         _lib = handle
     return _lib

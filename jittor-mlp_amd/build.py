@@ -52,7 +52,9 @@ def build(force=False, verbose=False):
 
     def compile_one(src):
         obj = os.path.join(OBJ, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        # -save-temps=obj keeps the gfx950 assembly next to the object: tools/isa_lint.py (tests/test_host_cpu.py) checks
+        # the hand-scheduled loops in what hipcc actually generated
+        cmd = [hipcc] + FLAGS + ["-save-temps=obj", "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))

@@ -18,6 +18,7 @@
 //   * XCD-aware tile order: each of the 8 XCDs walks a contiguous range of tiles (n fastest) so the
 //     A panel and the weight panels are re-used out of that XCD's private L2.
 #include "mlpk_common.h"
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace mlpk {
@@ -39,10 +40,9 @@ struct GemmArgs {
     int rperiod, act, res_mode;
     int t_rows, t_tokens;
     int vec_c, vec_r;   // vector (4-element) store / residual-load allowed
-    // p8 split-K tail (see gemm_nt_p8_kernel): tiles >= tail_start are shared by tail_S workgroups each
-    float* ws_part;     // partial accumulators, 65536 floats per (tail tile, part > 0)
-    unsigned* ws_cnt;   // one arrival counter per tail tile (zero before and after every launch)
-    int tail_start, tail_S;
+    // p8 launch (see gemm_nt_p8_kernel): row panels [m_base, m_base + panels * tile height), column groups
+    int m_base, panels, cgroups;
+    void* prof_buf;     // MLPK_P8_PROF builds: per-workgroup cycle sums (reserved & 8)
     int dbg_delay;      // de-phase sleep, units of 8128 cycles
     int dbg;            // tuning ablations (desc.reserved): 1 = no main loop, 2 = no stores, 4 = no epilogue
 };
@@ -821,21 +821,19 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) gemm_nt_s3_kernel(const GemmAr
 //     before its barrier: B-lo / A-lo / B-hi are last read in X (epochs e, e+1 for the two groups) and refilled in
 //     Y (epochs e+2, e+3); A-hi is last read in Y and refilled in the next X.
 // The last two slabs are peeled (MODE 1 / 2) because their DMA counts differ.
-template <typename T, int MODE>
+template <typename T, int NI>
 struct P8 {
-    // all LDS offsets are relative to the slab buffer `rb` (generic pointer into LDS)
-    template <bool TRANS>
-    static __device__ __forceinline__ void mma16(f32x4 (&acc)[8][4], const u32x4 (&a)[4][2], const u32x4 (&b)[2][2],
+    // NI x 2 blocks x 2 K-substeps = 4 NI MFMAs (NI = 4: the 16 of a quadrant pair)
+    static __device__ __forceinline__ void mma16(f32x4 (&acc)[2 * NI][4], const u32x4 (&a)[NI][2], const u32x4 (&b)[2][2],
                                                  const int i0, const int j0) {
         asm volatile("s_setprio 1");
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    if (TRANS) Mma<T>::pinned(a[i][s], b[j][s], acc[i0 + i][j0 + j]);
-                    else Mma<T>::pinned(b[j][s], a[i][s], acc[i0 + i][j0 + j]);
+                    Mma<T>::pinned(b[j][s], a[i][s], acc[i0 + i][j0 + j]);     // operands swapped: a lane owns 4 consecutive columns
                 }
         asm volatile("s_setprio 0");
     }
@@ -990,11 +988,146 @@ __device__ __forceinline__ void p8_store_tile(const GemmArgs& p, f32x4 (&acc)[8]
 #undef P8_PROF
 }
 
-template <typename T, bool TRANS>
+// Direct epilogue of the p8 kernel (2-byte row-major outputs, whole tiles): NO LDS round trip and NO barrier.
+// The accumulator gives a lane 4 consecutive columns (8 bytes) of one row per 16 x 16 block; the two blocks of a
+// quadrant row that sit side by side (32 columns) are exchanged between lane rows with v_permlane16_swap_b32 (gfx950:
+// odd 16-lane rows of the first operand <-> even rows of the second), after which every lane holds 8 consecutive
+// columns = one 16-byte store, and a store instruction covers 16 rows x 64 contiguous bytes.  Each wave runs its own
+// stream  [bias / folded LN / GELU / affine on four float pairs -> round -> 2 swaps -> (residual) -> store]  sixteen
+// times, with nothing to wait for but its own residual loads: the waves of a workgroup drift apart, so one wave's VALU
+// work overlaps another's store issue (the LDS-staged form alternated all-VALU and all-store phases between barriers:
+// 20-23k cycles per fc1 tile of which ~10k GELU and ~8k store issue, strictly one after the other).
+template <typename T, bool GELU, bool LN, bool AFF, int NI>
+__device__ __forceinline__ void p8_store_direct(const GemmArgs& p, f32x4 (&acc)[2 * NI][4], const int m0, const int n0, const int tid) {
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int grp = wave >> 2, wn = wave & 3;
+    const int frow = lane & 15;
+    const int fg = lane >> 4;
+    T* __restrict__ C = reinterpret_cast<T*>(p.C);
+    const T* R = reinterpret_cast<const T*>(p.R);
+    const bool has_res = p.res_mode != MLPK_RES_NONE;
+    const bool res_add = p.res_mode == MLPK_RES_ADD;
+    f32x4 bz[4], lc[4], cs[4], ch[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + (j >> 1) * 128 + wn * 32 + (j & 1) * 16 + 4 * fg;
+        bz[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (LN) lc[j] = *reinterpret_cast<const f32x4*>(p.ln_csum + n);
+        if (AFF) {
+            cs[j] = p.cscale ? *reinterpret_cast<const f32x4*>(p.cscale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+            ch[j] = p.cshift ? *reinterpret_cast<const f32x4*>(p.cshift + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    // after the swap: even lane rows hold columns 4*fg .. 4*fg+7 of the left block, odd ones 16 + 4*(fg-1) .. +7 (right block)
+    const int ccol = (fg & 1) ? 16 + 4 * (fg - 1) : 4 * fg;
+#pragma unroll
+    for (int hm = 0; hm < 2; ++hm) {
+        // residual chunks of this half (8 per lane) in flight before its math
+        u32x4 rr[NI][2];
+        if (has_res) {
+#pragma unroll
+            for (int i4 = 0; i4 < NI; ++i4)
+#pragma unroll
+                for (int hn = 0; hn < 2; ++hn)
+                    rr[i4][hn] = *reinterpret_cast<const u32x4*>(R + (size_t)(m0 + hm * (NI * 32) + grp * (NI * 16) + i4 * 16 + frow) * p.ldr + n0 + hn * 128 + wn * 32 + ccol);
+        }
+        float lmu[NI], lrs[NI];
+        if (LN) {
+#pragma unroll
+            for (int i4 = 0; i4 < NI; ++i4) {
+                const int m = m0 + hm * (NI * 32) + grp * (NI * 16) + i4 * 16 + frow;
+                lmu[i4] = p.ln_mean[m];
+                lrs[i4] = p.ln_rstd[m];
+            }
+        }
+#pragma unroll
+        for (int i4 = 0; i4 < NI; ++i4) {
+            const size_t grow = (size_t)(m0 + hm * (NI * 32) + grp * (NI * 16) + i4 * 16 + frow);
+#pragma unroll
+            for (int hn = 0; hn < 2; ++hn) {
+                f32x2 v[4];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = hn * 2 + jj;
+                    const f32x4 a = acc[hm * NI + i4][j];
+                    f32x2 lo = {a.x, a.y}, hi = {a.z, a.w};
+                    const f32x2 blo = {bz[j].x, bz[j].y}, bhi = {bz[j].z, bz[j].w};
+                    if (LN) {
+                        const f32x2 nm = {-lmu[i4], -lmu[i4]}, rs = {lrs[i4], lrs[i4]};
+                        lo = __builtin_elementwise_fma(__builtin_elementwise_fma(nm, f32x2{lc[j].x, lc[j].y}, lo), rs, blo);
+                        hi = __builtin_elementwise_fma(__builtin_elementwise_fma(nm, f32x2{lc[j].z, lc[j].w}, hi), rs, bhi);
+                    } else {
+                        lo = lo + blo;
+                        hi = hi + bhi;
+                    }
+                    v[2 * jj] = lo;
+                    v[2 * jj + 1] = hi;
+                }
+                if (GELU) gelu_pk_n<4>(v);
+                unsigned w[4];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = hn * 2 + jj;
+                    f32x2 lo = v[2 * jj], hi = v[2 * jj + 1];
+                    if (AFF) {
+                        lo = __builtin_elementwise_fma(lo, f32x2{cs[j].x, cs[j].y}, f32x2{ch[j].x, ch[j].y});
+                        hi = __builtin_elementwise_fma(hi, f32x2{cs[j].z, cs[j].w}, f32x2{ch[j].z, ch[j].w});
+                    }
+                    T e[4] = {from_f32<T>(lo.x), from_f32<T>(lo.y), from_f32<T>(hi.x), from_f32<T>(hi.y)};
+                    __builtin_memcpy(&w[2 * jj], e, 8);
+                }
+                // w[0..1] = this lane's 4 columns of the left block, w[2..3] = of the right block
+                const auto s0 = __builtin_amdgcn_permlane16_swap(w[0], w[2], false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(w[1], w[3], false, false);
+                u32x4 outv = {s0[0], s1[0], s0[1], s1[1]};
+                if (has_res) {
+                    T a8[8], r8[8];
+                    __builtin_memcpy(a8, &outv, 16);
+                    __builtin_memcpy(r8, &rr[i4][hn], 16);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float x = to_f32(a8[e]), y = to_f32(r8[e]);
+                        a8[e] = from_f32<T>(res_add ? x + y : x * y);
+                    }
+                    __builtin_memcpy(&outv, a8, 16);
+                }
+                if (!(p.dbg & 2) || outv.x == 0x12345678u)
+                    *reinterpret_cast<u32x4*>(C + grow * p.ldc + n0 + hn * 128 + wn * 32 + ccol) = outv;
+            }
+        }
+    }
+}
+
+// Template parameters of the persistent kernel:
+//   NI   16-row blocks per wave and half-tile: the tile is NI * 64 rows x 256 columns (NI = 4: the 256 x 256 tile described
+//        above).  Shorter tiles use the SAME LDS image (128-row half-tiles, wave w stages rows 16w..16w+15 of each) and the
+//        same windows with NI instead of 4 block rows per wave, so the two wave groups stay balanced for every NI; logical
+//        tile row  h * 32NI + g * 16NI + i * 16 + r  sits at LDS row  h * 128 + g * 64 + i * 16 + r  (half h, group g,
+//        block i < NI); the slots of blocks i >= NI are staged from the first rows of the tile and never multiplied.  A launch
+//        covers the row panels of ONE height; the host mixes heights so that every launch is a whole number of rounds of one
+//        tile per CU (p8_plan): Mixer-B fc2 = 588 tiles of 256 rows = 2.3 -> 3 rounds becomes 1 round of 256-row + 2 rounds of
+//        192-row tiles (2.5 tile times), with the K order of every output element -- hence every result bit -- unchanged.
+//   EPI  epilogue: 1 = direct (registers -> global, p8_store_direct), 0 = staged through LDS (p8_store_tile, NI = 4 only;
+//        kept for A/B runs via reserved & 64).
+// The kernel takes WHOLE tiles only (the host guarantees M % 64 == 0 with the panel heights adding up to M exactly,
+// N % 256 == 0, K a multiple of the slab, 16-byte aligned rows and parameter vectors, no per-row scale): nothing is clamped
+// or predicated, and the per-lane source offset of an LDS-DMA piece is ONE register per operand for the whole launch (lane ->
+// row lane >> 3, chunk (lane & 7) ^ row of an 8-row piece); where a piece lies inside the tile is a scalar offset.
+// Tile order: the launch's tiles are (panel, column tile) pairs.  The 8 XCDs are split into `cgroups` groups that each own a
+// contiguous range of column tiles (so that a group's weight panels, cg * 256 * K elements, stay resident in the 4 MiB L2s of
+// its XCDs instead of all N x K weights being re-fetched by every XCD every round), and a group's tiles are dealt to its XCDs
+// in contiguous runs, column fastest: the column tiles of one row panel run on one XCD at the same time and share the panel.
+// Register budget (256 per wave at two waves per SIMD): 32 NI accumulators + 24 NI operand fragments + ~20; hipcc must not
+// spill inside the K loop -- a spill reload is a VMEM operation whose compiler-inserted wait drains the hand-counted LDS-DMA
+// queue every slab; tools/isa_lint.py (run by tests/test_host_cpu.py) checks the generated loop for exactly that.
+template <typename T, int EPI, int NI>
 __global__ void __launch_bounds__(512, 1) gemm_nt_p8_kernel(const GemmArgs p) {
-    constexpr int BM = 256, BN = 256;
-    constexpr int EPC = 16 / (int)sizeof(T);
-    constexpr int BK = 8 * EPC;                            // elements per 128-byte slab row
+    static_assert(NI >= 1 && NI <= 4 && (EPI == 1 || NI == 4), "tile height / epilogue combination");
+    static_assert(sizeof(T) == 2, "16-bit operands");
+    constexpr int BM = NI * 64, BN = 256;
+    constexpr int EPC = 8;                                 // elements per 16-byte chunk
+    constexpr int BK = 64;                                 // elements per 128-byte slab row
     constexpr int HALF_B = 128 * 128;                      // bytes of one half-tile
     constexpr int BUF_B = 4 * HALF_B;                      // A-lo, A-hi, B-lo, B-hi
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1002,118 +1135,120 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_p8_kernel(const GemmArgs p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wn = wave & 3;
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int tiles_total = ((p.M + BM - 1) / BM) * tiles_n;
 
-    // ---- per-tile state: tile origin, operand bases, per-lane source offsets of the 8 staging pieces ----
-    // staging: wave w fills rows 16w .. 16w+15 of every half-tile, two 1-KiB pieces of 8 rows; lane ->
-    // (row lane >> 3, physical chunk lane & 7), source chunk (lane & 7) ^ (row & 7)
+    // ---- work list: XCD xcd = blockIdx & 7 belongs to column group xcd / X and is member xj of it; it walks the tiles
+    // u = xj * Q + l, l = blockIdx >> 3, + gridDim >> 3, ... of its group's U = panels * cg tiles ----
+    const int tiles_n = p.N / BN;
+    const int X = 8 / p.cgroups;
+    const int cg = tiles_n / p.cgroups;
+    const int U = p.panels * cg;
+    const int Q = (U + X - 1) / X;
+    const int xcd = (int)blockIdx.x & 7;
+    const int cgrp = xcd / X;
+    const int xj = xcd - cgrp * X;
+    const int lstep = (int)gridDim.x >> 3;
+    int lend = U - xj * Q;
+    lend = __builtin_amdgcn_readfirstlane(lend < Q ? lend : Q);       // (integer divisions run on the VALU: pin the results to SGPRs)
+    const int u0 = __builtin_amdgcn_readfirstlane(xj * Q);
+    const int cg_s = __builtin_amdgcn_readfirstlane(cg);
+    const int ncol0 = __builtin_amdgcn_readfirstlane(cgrp * cg);
+    int l = (int)blockIdx.x >> 3;
+    if (l >= lend) return;
+
+    // ---- staging geometry: wave w fills rows 16w .. 16w+15 of every half-tile, two 1-KiB pieces of 8 rows ----
+    const unsigned laneA = (unsigned)((lane >> 3) * p.lda + (((lane & 7) ^ (lane >> 3)) * EPC)) * 2u;
+    const unsigned laneB = (unsigned)((lane >> 3) * p.ldb + (((lane & 7) ^ (lane >> 3)) * EPC)) * 2u;
+    unsigned offA[2][2], offB[2][2];                       // scalar byte offsets of this wave's pieces inside a tile's panels
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            // LDS row h * 128 + wave * 16 + q * 8 + r  =  half h, group wave >> 2, block wave & 3
+            const int rowA = (wave & 3) < NI ? h * (NI * 32) + (wave >> 2) * (NI * 16) + (wave & 3) * 16 + q * 8 : q * 8;
+            offA[h][q] = __builtin_amdgcn_readfirstlane((unsigned)(rowA * p.lda) * 2u);
+            offB[h][q] = __builtin_amdgcn_readfirstlane((unsigned)((h * 128 + wave * 16 + q * 8) * p.ldb) * 2u);
+        }
+    // wave-uniform by construction, but a 64-bit product computed on the VALU lands in VGPRs and the "s" constraint of
+    // the LDS-DMA asm then fails to assemble: pin both halves to SGPRs
+    auto uniform64 = [](const size_t x) {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x), hi = __builtin_amdgcn_readfirstlane((unsigned)(x >> 32));
+        return ((size_t)hi << 32) | lo;
+    };
     int m0 = 0, n0 = 0;
-    const char* baseA = nullptr;
-    const char* baseB = nullptr;
-    unsigned voff[4][2];
-    auto setup = [&](const int v, const int slab0) {
-        const int wg = xcd_remap(v, tiles_total);
-        m0 = (wg / tiles_n) * BM;
-        n0 = (wg % tiles_n) * BN;
-        baseA = reinterpret_cast<const char*>(p.A) + ((size_t)m0 * p.lda + (size_t)slab0 * BK) * sizeof(T);
-        baseB = reinterpret_cast<const char*>(p.B) + ((size_t)n0 * p.ldb + (size_t)slab0 * BK) * sizeof(T);
-        const int lr = lane >> 3;
-        const int sc = (lane & 7) ^ lr;
-#pragma unroll
-        for (int h = 0; h < 4; ++h)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int hr = (h & 1) * 128 + wave * 16 + q * 8 + lr;       // row inside the 256-row tile
-                if (h < 2) {
-                    const int r = m0 + hr < p.M ? hr : p.M - 1 - m0;
-                    voff[h][q] = (unsigned)(r * p.lda + sc * EPC) * (unsigned)sizeof(T);
-                } else {
-                    const int r = n0 + hr < p.N ? hr : p.N - 1 - n0;
-                    voff[h][q] = (unsigned)(r * p.ldb + sc * EPC) * (unsigned)sizeof(T);
-                }
-            }
+    const char* tileA = nullptr;
+    const char* tileB = nullptr;
+    auto setup = [&](const int li) {
+        const int u = u0 + li;
+        const int panel = __builtin_amdgcn_readfirstlane(u / cg_s);
+        m0 = p.m_base + panel * BM;
+        n0 = (ncol0 + (u - panel * cg_s)) * BN;
+        tileA = reinterpret_cast<const char*>(p.A) + uniform64((size_t)m0 * p.lda * 2u);
+        tileB = reinterpret_cast<const char*>(p.B) + uniform64((size_t)n0 * p.ldb * 2u);
     };
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     const unsigned lds_w = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)smem + wave * 2048);
     // half ids: 0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi
     auto stage = [&](const int t, const int h) {
-        const unsigned dst = lds_w + (unsigned)((t & 1) * BUF_B + h * HALF_B);
-        const char* gb = (h < 2 ? baseA : baseB) + (size_t)t * (BK * sizeof(T));
-        glds_piece_s(voff[h][0], gb, dst);
-        glds_piece_s(voff[h][1], gb, dst + 1024);
+        // the slab counter may live in a VGPR under SGPR pressure: pin what the asm takes as scalars
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_w + (unsigned)((t & 1) * BUF_B + h * HALF_B));
+        const unsigned tb = __builtin_amdgcn_readfirstlane((unsigned)(t * (BK * 2)));
+        if (h < 2) {
+            glds_piece_s(laneA, tileA + tb + offA[h][0], dst);
+            glds_piece_s(laneA, tileA + tb + offA[h][1], dst + 1024);
+        } else {
+            glds_piece_s(laneB, tileB + tb + offB[h - 2][0], dst);
+            glds_piece_s(laneB, tileB + tb + offB[h - 2][1], dst + 1024);
+        }
     };
 
-    const int frow = lane & 15;
-    const int fg = lane >> 4;
-    const int c0 = ((fg ^ (frow & 7)) << 4);               // chunk of k-substep 0; substep 1 is c0 ^ 64
-    const int a_rd = (grp * 64 + frow) * 128 + c0;          // + half * HALF_B + i * 2048
-    const int b_rd = 2 * HALF_B + (wn * 32 + frow) * 128 + c0;
-    const int nk_full = p.K / BK;                           // >= 2 (host checked)
-    // ---- work items of this workgroup: whole tiles v = blockIdx, + grid, ... below tail_start; then, when the tile
-    // count leaves a partial last round, ONE K-slice of a tail tile: the T_tail = total - tail_start leftover tiles are
-    // each shared by tail_S workgroups (split-K), parts 1.. hand their fp32 partial accumulators to part 0 through the
-    // workspace (release / acquire on a per-tile counter), part 0 adds them and runs the epilogue.  The partial
-    // round then costs about 1/tail_S of a main loop instead of a whole tile time on a fraction of the CUs.
-    const int n_whole = p.tail_S > 1 ? p.tail_start : tiles_total;
-    // the tail_S parts of a tail tile are workgroups of ONE XCD (blockIdx % 8, consecutive local indices): they run at
-    // the same clocks and reach the hand-over together (partners spread over XCDs kept part 0 waiting ~60k cycles)
-    const int xl = (int)blockIdx.x >> 3;                   // index inside the XCD
-    const int tail_grp = p.tail_S > 1 ? xl / p.tail_S : 0;
-    const int tail_part = p.tail_S > 1 ? xl % p.tail_S : 0;
-    const int tail_tile = tail_grp * 8 + ((int)blockIdx.x & 7);
-    const bool has_tail = p.tail_S > 1 && tail_grp < ((int)gridDim.x >> 3) / p.tail_S && p.tail_start + tail_tile < tiles_total;
-    const int tail_slab0 = (int)(((long long)nk_full * tail_part) / (p.tail_S > 1 ? p.tail_S : 1));
-    const int tail_nk = (int)(((long long)nk_full * (tail_part + 1)) / (p.tail_S > 1 ? p.tail_S : 1)) - tail_slab0;
-    int nk = nk_full;
+    const int nk = __builtin_amdgcn_readfirstlane(p.K / BK);   // >= 2 (host checked)
 
-    // tuning aid (dbg & 8): per-workgroup sums of [wait for first slabs | main loop | epilogue] in shader clocks
+#ifdef MLPK_P8_PROF   // tuning builds only (tools/gemm_p8_timeline.py): per-workgroup sums of [first slabs | main loop | epilogue]
     unsigned long long tw = 0, tl = 0, te = 0, ts = 0;
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool stamp = (p.dbg & 8) != 0;
-    const void* stamp_buf = p.R;
-
-    // the epilogue class is a launch-wide property; whole-tile-ness is per tile
-    bool fast_ok = false;
-    if constexpr (sizeof(T) == 2 && !TRANS) {
-        fast_ok = p.vec_c == 2 && (p.res_mode == MLPK_RES_NONE || stamp || p.vec_r == 2) && !p.rscale && !(p.dbg & 4) &&
-                  ((reinterpret_cast<uintptr_t>(p.bias) | reinterpret_cast<uintptr_t>(p.ln_csum) | reinterpret_cast<uintptr_t>(p.cscale) |
-                    reinterpret_cast<uintptr_t>(p.cshift)) & 15) == 0;
+    int ntiles = 0;
+#define P8_STAMP(acc_)                                                       \
+    {                                                                        \
+        const unsigned long long n__ = __builtin_readcyclecounter();          \
+        acc_ += n__ - ts;                                                     \
+        ts = n__;                                                             \
     }
+#else
+    unsigned long long prof[8];
+#define P8_STAMP(acc_)
+#endif
 
     // ---- first tile: slab 0 complete before the loop, three half-tiles of slab 1 in flight ----
-    // The tail slice comes FIRST: its hand-over needs the partners' partial accumulators to be written back to memory,
-    // and at the end of the launch that write-back queues behind ~70 MB of freshly stored output (measured: part 0
-    // waited ~60k cycles); at the start of the launch the memory system is idle.
-    int v = blockIdx.x;
-    bool in_tail = false;
-    if (has_tail) {
-        in_tail = true;
-        v = p.tail_start + tail_tile;
-        nk = tail_nk;
-        setup(v, tail_slab0);
-    } else {
-        if (v >= n_whole) return;
-        setup(v, 0);
-    }
+    setup(l);
     stage(0, 2); stage(0, 0); stage(0, 3); stage(0, 1);
     stage(1, 2); stage(1, 0); stage(1, 3);
 
     for (;;) {
-        if (stamp) ts = __builtin_readcyclecounter();
+#ifdef MLPK_P8_PROF
+        ts = __builtin_readcyclecounter();
+#endif
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         P8_BARRIER();
         if (grp == 1) P8_BARRIER();
-        if (stamp) { const unsigned long long n = __builtin_readcyclecounter(); tw += n - ts; ts = n; }
+        P8_STAMP(tw);
 
-        f32x4 acc[8][4];
+        // fragment read offsets, recomputed per tile from an opaque copy of the lane id: as launch-wide constants they
+        // would be live across the register-hungry epilogue, and hipcc then spills them and reloads them INSIDE the K loop
+        int kl = lane;
+        asm volatile("" : "+v"(kl));
+        const int frow = kl & 15;
+        const int c0 = (((kl >> 4) ^ (frow & 7)) << 4);        // chunk of k-substep 0; substep 1 is c0 ^ 64
+        const int a_rd = (grp * 64 + frow) * 128 + c0;          // + half * HALF_B + i * 2048
+        const int b_rd = 2 * HALF_B + (wn * 32 + frow) * 128 + c0;
+
+        f32x4 acc[2 * NI][4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 2 * NI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        u32x4 a0[4][2], a1[4][2], b0[2][2], b1[2][2];
+        u32x4 a0[NI][2], a1[NI][2], b0[2][2], b1[2][2];
 #define P8_READ_A(dst, h)                                                                                         \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                                               \
         dst[i][0] = *reinterpret_cast<const u32x4*>(rb + (a_rd + (h) * HALF_B + i * 2048));                         \
         dst[i][1] = *reinterpret_cast<const u32x4*>(rb + ((a_rd + (h) * HALF_B + i * 2048) ^ 64));                  \
     }
@@ -1138,8 +1273,8 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_p8_kernel(const GemmArgs p) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                            \
         }                                                                                                          \
         P8_BARRIER();                                                                                              \
-        P8<T, MODE>::template mma16<TRANS>(acc, a0, b0, 0, 0);                                                      \
-        P8<T, MODE>::template mma16<TRANS>(acc, a0, b1, 0, 2);                                                      \
+        P8<T, NI>::mma16(acc, a0, b0, 0, 0);                                                                        \
+        P8<T, NI>::mma16(acc, a0, b1, 0, 2);                                                                        \
         P8_BARRIER();                                                                                              \
         /* window Y: operand of A1 x B1, A1 x B0 */                                                               \
         P8_READ_A(a1, 1);                                                                                          \
@@ -1155,8 +1290,8 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_p8_kernel(const GemmArgs p) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
         }                                                                                                          \
         P8_BARRIER();                                                                                              \
-        P8<T, MODE>::template mma16<TRANS>(acc, a1, b1, 4, 2);                                                      \
-        P8<T, MODE>::template mma16<TRANS>(acc, a1, b0, 4, 0);                                                      \
+        P8<T, NI>::mma16(acc, a1, b1, NI, 2);                                                                       \
+        P8<T, NI>::mma16(acc, a1, b0, NI, 0);                                                                       \
         P8_BARRIER();                                                                                              \
     }
 #pragma unroll 1
@@ -1170,129 +1305,67 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_p8_kernel(const GemmArgs p) {
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
         if (grp == 0) P8_BARRIER();
         // every wave is past all its LDS reads of this tile; the groups are aligned again
-        if (stamp) { const unsigned long long n = __builtin_readcyclecounter(); tl += n - ts; ts = n; }
+        P8_STAMP(tl);
 
         const int cm0 = m0, cn0 = n0;
-        const bool cur_tail = in_tail;
-        // next work item (workgroup-uniform): after the tail slice the whole tiles blockIdx, + grid, ...
-        bool more;
-        const int next_slab0 = 0;
-        if (in_tail) {
-            in_tail = false;
-            v = blockIdx.x;
-            more = v < n_whole;
-        } else {
-            v += gridDim.x;
-            more = v < n_whole;
-        }
-        const int next_nk = in_tail ? tail_nk : nk_full;
-        GemmArgs q = p;
-        if (stamp) { q.R = nullptr; q.res_mode = MLPK_RES_NONE; }
-        if (cur_tail) {
-            // ---- split-K hand-over (accumulator layout kept: [block][thread] float4, coalesced) ----
-            // L2s of different XCDs are not coherent with each other and the agent-scope fences that bridge them act on a
-            // WHOLE L2 (write back / invalidate), which is full of other tiles' operands and output.  Measured variants:
-            // every thread fencing + acquire-invalidate on the reader: launch 30-40 % slower; write-through (sc1) payload
-            // stores: ~55k cycles to retire 256 KiB per part.  Kept: plain payload stores, ONE release (L2 write-back)
-            // per writing workgroup on the flag atomic, and cache-bypassing (sc1) payload loads on the reader, so no L2
-            // is ever invalidated.
-            float* part = p.ws_part + ((size_t)tail_tile * (p.tail_S - 1)) * 65536;
-            if (tail_part > 0) {
-                float* dst = part + (size_t)(tail_part - 1) * 65536 + tid * 4;
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        *reinterpret_cast<f32x4*>(dst + (i * 4 + j) * 2048) = acc[i][j];
-                __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): this wave's stores have reached the L2
-                __syncthreads();
-                if (tid == 0) __hip_atomic_fetch_add(p.ws_cnt + tail_tile, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                // no output from this part: on to its whole tiles (nothing was prefetched for them yet)
-                if (!more) break;
-                __syncthreads();
-                setup(v, 0);
-                stage(0, 2); stage(0, 0); stage(0, 3); stage(0, 1);
-                stage(1, 2); stage(1, 0); stage(1, 3);
-                nk = nk_full;
-                continue;
-            }
-            unsigned long long th0 = stamp ? __builtin_readcyclecounter() : 0;
-            if (tid == 0) {
-                // polled with a read-modify-write: it is performed at the coherence point, whereas a plain agent-scope
-                // load was seen to return this XCD's stale copy for ~60k cycles after the partners' increments
-                while (__hip_atomic_fetch_add(p.ws_cnt + tail_tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(p.tail_S - 1))
-                    __builtin_amdgcn_s_sleep(4);
-                __hip_atomic_store(p.ws_cnt + tail_tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
-            }
-            __syncthreads();
-            if (stamp) { const unsigned long long n = __builtin_readcyclecounter(); prof[0] += n - th0; th0 = n; }
-            for (int s2 = 0; s2 < p.tail_S - 1; ++s2) {
-                const float* src = part + (size_t)s2 * 65536 + tid * 4;
-                // 16 cache-bypassing loads in flight per round trip (the operand registers are free by now)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    f32x4 t4[16];
-#pragma unroll
-                    for (int q2 = 0; q2 < 16; ++q2)
-                        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(t4[q2]) : "v"(src + (h * 16 + q2) * 2048) : "memory");
-                    asm volatile("s_waitcnt vmcnt(0)"
-                                 : "+v"(t4[0]), "+v"(t4[1]), "+v"(t4[2]), "+v"(t4[3]), "+v"(t4[4]), "+v"(t4[5]), "+v"(t4[6]), "+v"(t4[7]),
-                                   "+v"(t4[8]), "+v"(t4[9]), "+v"(t4[10]), "+v"(t4[11]), "+v"(t4[12]), "+v"(t4[13]), "+v"(t4[14]), "+v"(t4[15])
-                                 :
-                                 : "memory");
-#pragma unroll
-                    for (int q2 = 0; q2 < 16; ++q2) acc[(h * 16 + q2) >> 2][(h * 16 + q2) & 3] += t4[q2];
-                }
-            }
-            if (stamp) { const unsigned long long n = __builtin_readcyclecounter(); prof[1] += n - th0; }
-        }
-        const bool fast = fast_ok && cm0 + BM <= p.M && cn0 + BN <= p.N;
+        l += lstep;
+        const bool more = l < lend;                         // workgroup-uniform
         // opaque copy of the thread id: keeps the epilogue's address arithmetic inside this iteration (hoisted
         // out of the persistent loop it would sit in VGPRs through the main loop and spill)
         int etid = tid;
         asm volatile("" : "+v"(etid));
-        if (fast) {
-            // next tile's slab 0 streams into buffer 0 while this tile leaves through buffer 1
-            if (more) {
-                setup(v, next_slab0);
-                stage(0, 2); stage(0, 0); stage(0, 3); stage(0, 1);
+        // next tile's slab 0 streams into buffer 0 while this tile leaves (EPI 0: through the other buffer)
+        if (more) {
+            setup(l);
+            stage(0, 2); stage(0, 0); stage(0, 3); stage(0, 1);
+        }
+        const int cls = (p.act == MLPK_ACT_GELU ? 1 : 0) | (p.ln_mean ? 2 : 0) | ((p.cscale || p.cshift) ? 4 : 0);
+        if constexpr (EPI == 1) {
+            switch (cls) {
+                case 0: p8_store_direct<T, false, false, false, NI>(p, acc, cm0, cn0, etid); break;
+                case 1: p8_store_direct<T, true, false, false, NI>(p, acc, cm0, cn0, etid); break;
+                case 2: p8_store_direct<T, false, true, false, NI>(p, acc, cm0, cn0, etid); break;
+                case 3: p8_store_direct<T, true, true, false, NI>(p, acc, cm0, cn0, etid); break;
+                case 4: p8_store_direct<T, false, false, true, NI>(p, acc, cm0, cn0, etid); break;
+                case 5: p8_store_direct<T, true, false, true, NI>(p, acc, cm0, cn0, etid); break;
+                case 6: p8_store_direct<T, false, true, true, NI>(p, acc, cm0, cn0, etid); break;
+                default: p8_store_direct<T, true, true, true, NI>(p, acc, cm0, cn0, etid); break;
             }
-            if constexpr (sizeof(T) == 2 && !TRANS) {
-                char* stg = smem + BUF_B;
-                const int cls = (p.act == MLPK_ACT_GELU ? 1 : 0) | (p.ln_mean ? 2 : 0) | ((p.cscale || p.cshift) ? 4 : 0);
-                switch (cls) {
-                    case 0: p8_store_tile<T, false, false, false>(q, acc, stg, cm0, cn0, etid, prof); break;
-                    case 1: p8_store_tile<T, true, false, false>(q, acc, stg, cm0, cn0, etid, prof); break;
-                    case 2: p8_store_tile<T, false, true, false>(q, acc, stg, cm0, cn0, etid, prof); break;
-                    case 3: p8_store_tile<T, true, true, false>(q, acc, stg, cm0, cn0, etid, prof); break;
-                    case 4: p8_store_tile<T, false, false, true>(q, acc, stg, cm0, cn0, etid, prof); break;
-                    case 5: p8_store_tile<T, true, false, true>(q, acc, stg, cm0, cn0, etid, prof); break;
-                    case 6: p8_store_tile<T, false, true, true>(q, acc, stg, cm0, cn0, etid, prof); break;
-                    default: p8_store_tile<T, true, true, true>(q, acc, stg, cm0, cn0, etid, prof); break;
-                }
-            }
-            if (more) { stage(1, 2); stage(1, 0); stage(1, 3); }
         } else {
-            __syncthreads();
-            gemm_epilogue<T, BM, BN, 2, 4, TRANS, true>(q, acc, smem, cm0, cn0, etid);
-            __syncthreads();
-            if (more) {
-                setup(v, next_slab0);
-                stage(0, 2); stage(0, 0); stage(0, 3); stage(0, 1);
-                stage(1, 2); stage(1, 0); stage(1, 3);
+            char* stg = smem + BUF_B;
+            switch (cls) {
+                case 0: p8_store_tile<T, false, false, false>(p, acc, stg, cm0, cn0, etid, prof); break;
+                case 1: p8_store_tile<T, true, false, false>(p, acc, stg, cm0, cn0, etid, prof); break;
+                case 2: p8_store_tile<T, false, true, false>(p, acc, stg, cm0, cn0, etid, prof); break;
+                case 3: p8_store_tile<T, true, true, false>(p, acc, stg, cm0, cn0, etid, prof); break;
+                case 4: p8_store_tile<T, false, false, true>(p, acc, stg, cm0, cn0, etid, prof); break;
+                case 5: p8_store_tile<T, true, false, true>(p, acc, stg, cm0, cn0, etid, prof); break;
+                case 6: p8_store_tile<T, false, true, true>(p, acc, stg, cm0, cn0, etid, prof); break;
+                default: p8_store_tile<T, true, true, true>(p, acc, stg, cm0, cn0, etid, prof); break;
             }
         }
-        if (stamp) { const unsigned long long n = __builtin_readcyclecounter(); te += n - ts; ts = n; }
+        // A wait hipcc can SEE (the asm ones are opaque to it): every load of the epilogue has landed.  Without it the
+        // compiler carries "a VMEM load into these registers may be pending" around the persistent loop into the K loop and
+        // protects the first fragment reads of every slab with s_waitcnt vmcnt(0..4) -- which drains the LDS-DMA prefetch
+        // queue it knows nothing about (tools/isa_lint.py).  Here it costs nothing extra: the loop-top vmcnt(6) waits
+        // for the same stores anyway, and only slab 1's pieces are issued behind it.
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        if (more) { stage(1, 2); stage(1, 0); stage(1, 3); }
+#ifdef MLPK_P8_PROF
+        P8_STAMP(te);
+        ++ntiles;
+#endif
         if (!more) break;
-        nk = next_nk;
     }
-    if (stamp && tid == 0) {
-        unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<void*>(stamp_buf)) + (size_t)blockIdx.x * 64;
-        o[0] = tw; o[1] = tl; o[2] = te;
-        o[3] = (tiles_total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;       // tiles of this workgroup
+#ifdef MLPK_P8_PROF
+    if ((p.dbg & 8) && tid == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.prof_buf) + (size_t)blockIdx.x * 64;
+        o[0] = tw; o[1] = tl; o[2] = te; o[3] = (unsigned long long)ntiles;
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[4 + k] = prof[k];
     }
+#endif
+#undef P8_STAMP
 }
 
 // ------------------------------- host-side dispatch -------------------------------
@@ -1355,7 +1428,7 @@ static int launch_s3(const GemmArgs& a, bool trans, hipStream_t stream) {
     return 0;
 }
 
-// one persistent workgroup per compute unit (a multiple of 8 keeps the XCD-contiguous tile walk)
+// one persistent workgroup per compute unit (a multiple of 8: whole XCDs)
 static int p8_grid_cap() {
     static int cap = 0;
     if (!cap) {
@@ -1366,51 +1439,135 @@ static int p8_grid_cap() {
     return cap;
 }
 
-// Split-K plan of the partial last round: S workgroups per leftover tile (0 = no split).  Needs >= 2 slabs per part and a
-// workspace of mlpk_gemm_workspace_bytes().
-static int p8_tail_split(int total, int nk, int* tail_start) {
-    const int G = p8_grid_cap();
-    const int rem = total % G;
-    *tail_start = total - rem;
-    if (total <= G || rem == 0) return 0;
-    // every part must keep >= 8 slabs: below that the hand-over (2 x 256 KiB per extra part, through memory) and the
-    // un-split epilogue cost more than the main-loop time the split saves (measured on K = 768: slower)
-    int S = (G / 8) / ((rem + 7) / 8);                 // parts of a tile sit in one XCD: 8 x floor((G/8)/S) >= rem
-    if (S > nk / 8) S = nk / 8;
-    if (S > 8) S = 8;
-    return S >= 2 ? S : 0;
-}
-
-template <typename T> static int launch_p8(const GemmArgs& a0, bool trans, hipStream_t stream, void* ws, long long ws_bytes) {
-    GemmArgs a = a0;
-    const int lds = 2 * 4 * 128 * 128;
-    const int total = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-    const int tiles = total < p8_grid_cap() ? total : p8_grid_cap();     // persistent: one workgroup per CU
-    a.tail_S = 0; a.tail_start = total; a.ws_part = nullptr; a.ws_cnt = nullptr;
-    {
-        int ts = 0;
-        const int S = p8_tail_split(total, a.K / (128 / (int)sizeof(T)), &ts);
-        const long long need = S ? 4096 + (long long)(total - ts) * (S - 1) * 65536 * 4 : 0;
-        if (S && ws && ws_bytes >= need && (a.dbg & 128)) {      // opt-in (reserved & 128): see include/mlpk.h
-            a.tail_S = S; a.tail_start = ts;
-            a.ws_cnt = reinterpret_cast<unsigned*>(ws);
-            a.ws_part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + 4096);
+// Height plan of a persistent launch sequence.  A problem of tiles_m x tiles_n tiles of 256 rows leaves the last round of one
+// tile per CU partly empty (Mixer-B fc2: 588 tiles on 256 CUs = 2.3 -> 3 rounds).  Instead, the M = 64 m rows are cut into
+// panels of 256, 192, 128 or 64 rows (NI = 4 .. 1) that add up to M exactly, and every height gets its own launch of r_h whole
+// rounds; cost model per round: w_h = (365 + 512 NI) / 2413 of a 256-row round (fixed per-slab cost of the barriers and the
+// B operand + MFMA time), plus a fixed cost per extra launch.  Exhaustive search over (r4, r3, r2, r1).
+struct P8Plan { int n; int ni[4]; int panels[4]; };
+static const double* p8_weights() {
+    // time of one round of NI * 64-row tiles relative to a 256-row round; MLPK_P8_W="w1,w2,w3" overrides (calibration runs)
+    static double w[5] = {0.0, 0.37, 0.58, 0.79, 1.0};
+    static bool init = false;
+    if (!init) {
+        init = true;
+        if (const char* e = getenv("MLPK_P8_W")) {
+            double a, b, c;
+            if (sscanf(e, "%lf,%lf,%lf", &a, &b, &c) == 3) { w[1] = a; w[2] = b; w[3] = c; }
         }
     }
-    hipError_t e;
-    if (trans) {
-        auto k = gemm_nt_p8_kernel<T, true>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(k, dim3(tiles), dim3(512), lds, stream, a);
-    } else {
-        auto k = gemm_nt_p8_kernel<T, false>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(k, dim3(tiles), dim3(512), lds, stream, a);
+    return w;
+}
+
+static P8Plan p8_plan(int M, int tiles_n, int nk, int G, bool mixed, double* cost_out = nullptr) {
+    const double* w = p8_weights();
+    const int m = M / 64;
+    const double launch_pen = 6000.0 / (nk * 2413.0 + 8000.0);
+    auto rounds = [&](long long panels) { return (int)((panels * tiles_n + G - 1) / G); };
+    // default: 256-row panels, and one short panel for the M % 256 rows
+    P8Plan best;
+    best.n = 0;
+    if (m / 4) { best.ni[best.n] = 4; best.panels[best.n] = m / 4; ++best.n; }
+    if (m % 4) { best.ni[best.n] = m % 4; best.panels[best.n] = 1; ++best.n; }
+    double best_cost = rounds(m / 4) + (m % 4 ? w[m % 4] * rounds(1) : 0.0) + (best.n - 1) * launch_pen;
+    if (cost_out) *cost_out = best_cost;
+    if (!mixed) return best;
+    static const int force_ni = getenv("MLPK_P8_FORCE_NI") ? atoi(getenv("MLPK_P8_FORCE_NI")) : 0;     // calibration runs: one height
+    if (force_ni >= 1 && force_ni <= 4 && m % force_ni == 0) {
+        best.n = 1; best.ni[0] = force_ni; best.panels[0] = m / force_ni;
+        return best;
     }
-    MLPK_LAUNCH_CHECK();
-    return 0;
+    const int rmax = rounds(m / 4) + 1;
+    auto cap = [&](int r) { return (int)((long long)r * G / tiles_n); };      // panels that fit r rounds
+    for (int r4 = 0; r4 <= rmax; ++r4)
+        for (int r3 = 0; r3 * 3 <= (rmax + 1 - r4) * 4; ++r3)
+            for (int r2 = 0; r2 <= 2; ++r2)
+                for (int r1 = 0; r1 <= 1; ++r1) {
+                    const int r[5] = {0, r1, r2, r3, r4};
+                    // greedy exact cover, tallest first
+                    int left = m, take[5] = {0, 0, 0, 0, 0}, launches = 0;
+                    double cost = 0.0;
+                    for (int h = 4; h >= 1; --h) {
+                        if (!r[h]) continue;
+                        const int c = cap(r[h]);
+                        take[h] = left / h < c ? left / h : c;
+                        left -= take[h] * h;
+                        if (take[h]) { cost += rounds(take[h]) * w[h]; ++launches; }
+                    }
+                    if (left != 0 || launches == 0) continue;
+                    cost += (launches - 1) * launch_pen;
+                    if (cost < best_cost - 1e-9) {
+                        best_cost = cost;
+                        best.n = 0;
+                        for (int h = 4; h >= 1; --h)
+                            if (take[h]) { best.ni[best.n] = h; best.panels[best.n] = take[h]; ++best.n; }
+                    }
+                }
+    if (cost_out) *cost_out = best_cost;
+    return best;
+}
+
+// column groups: the smallest power of two G | tiles_n, G <= 8, whose group of tiles_n / G weight panels fits ~2.5 MiB of
+// an XCD's 4 MiB L2 -- when all the weights do not (else 1: no panel is ever re-fetched anyway)
+static int p8_cgroups(int tiles_n, int K, int es) {
+    const double panel = 256.0 * K * es;
+    if (panel * tiles_n <= 3.0 * 1048576.0) return 1;
+    for (int g = 2; g <= 8; g *= 2)
+        if (tiles_n % g == 0 && panel * (tiles_n / g) <= 2.5 * 1048576.0) return g;
+    for (int g = 8; g >= 2; g /= 2)
+        if (tiles_n % g == 0) return g;
+    return 1;
+}
+
+// what the persistent tile accepts (everything else goes to the other pipelines): 16-bit row-major output in whole tiles
+static bool p8_eligible(const GemmArgs& a, int es, bool trans) {
+    if (es != 2 || trans || a.rscale || a.vec_c != 2 || (a.res_mode != MLPK_RES_NONE && a.vec_r != 2)) return false;
+    if (a.M % 64 || a.N % 256 || a.K % 64 || a.K < 128) return false;
+    const uintptr_t par = reinterpret_cast<uintptr_t>(a.bias) | reinterpret_cast<uintptr_t>(a.ln_csum) | reinterpret_cast<uintptr_t>(a.cscale) |
+                          reinterpret_cast<uintptr_t>(a.cshift);
+    return (par & 15) == 0;
+}
+
+template <typename T> static int launch_p8(const GemmArgs& a0, bool trans, hipStream_t stream) {
+    if constexpr (sizeof(T) != 2) {
+        return MLPK_EDTYPE;                  // the persistent tile is a 16-bit kernel (fp32 uses the exact-f32 MFMA tiles)
+    } else {
+        GemmArgs a = a0;
+        if (!p8_eligible(a, 2, trans)) return MLPK_ESHAPE;
+        const int lds = 2 * 4 * 128 * 128;
+        const int tiles_n = a.N / 256;
+        const int cap = p8_grid_cap();
+        a.cgroups = (a.dbg & 128) ? 1 : p8_cgroups(tiles_n, a.K, 2);           // reserved & 128: one column group (A/B runs)
+        const bool staged = (a.dbg & 64) != 0;                                 // reserved & 64: LDS-staged epilogue (A/B runs)
+        const P8Plan plan = p8_plan(a.M, tiles_n, a.K / 64, cap, !staged && !(a.dbg & 16));   // reserved & 16: 256-row tiles only
+        int m_base = 0;
+        for (int s = 0; s < plan.n; ++s) {
+            const int ni = plan.ni[s];
+            a.m_base = m_base;
+            a.panels = plan.panels[s];
+            m_base += a.panels * ni * 64;
+            const int X = 8 / a.cgroups;
+            const int U = a.panels * (tiles_n / a.cgroups);
+            const int Q = (U + X - 1) / X;
+            const int grid = 8 * (Q < cap / 8 ? Q : cap / 8);
+            hipError_t e = hipSuccess;
+#define P8_LAUNCH(EP, NIv)                                                                                              \
+    {                                                                                                                   \
+        auto k = gemm_nt_p8_kernel<T, EP, NIv>;                                                                         \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);     \
+        if (e != hipSuccess) return (int)e;                                                                             \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, stream, a);                                                   \
+    }
+            if (staged) P8_LAUNCH(0, 4)
+            else if (ni == 4) P8_LAUNCH(1, 4)
+            else if (ni == 3) P8_LAUNCH(1, 3)
+            else if (ni == 2) P8_LAUNCH(1, 2)
+            else P8_LAUNCH(1, 1)
+#undef P8_LAUNCH
+            MLPK_LAUNCH_CHECK();
+        }
+        return 0;
+    }
 }
 
 template <typename T> static int launch_algo(int algo, const GemmArgs& a, bool trans, hipStream_t s, void* ws, long long ws_bytes) {
@@ -1428,7 +1585,7 @@ template <typename T> static int launch_algo(int algo, const GemmArgs& a, bool t
         case 11: return launch_s3<T, 256, 128, 2, 2>(a, trans, s);
         case 12: return launch_s3<T, 128, 128, 2, 2>(a, trans, s);
         case 13: return launch_s3<T, 128, 256, 2, 2>(a, trans, s);
-        case 14: return launch_p8<T>(a, trans, s, ws, ws_bytes);
+        case 14: return launch_p8<T>(a, trans, s);
         default: return MLPK_EMODE;
     }
 }
@@ -1444,21 +1601,17 @@ static int auto_algo(int M, int N, int K, int epc, bool glds_ok, bool p8_ok) {
         const TileCfg& t = kTiles[i];
         const int area = t.bm * t.bn;
         if (t.glds == 3) {
-            // persistent 256 x 256 ping-pong tile: whole launch rounds of one tile per CU; its per-tile fixed cost
-            // (first slabs + epilogue, not overlapped with another workgroup) weighs more the shorter K is.
-            // Calibrated on the MI355X sweeps and model benches: 0.76-0.82 x the best s3 time at K = 768 / 3072,
-            // break-even around K = 384, behind below that.
-            if (!p8_ok || K % (8 * epc) || K < 16 * epc) continue;
-            const double tiles = (double)((M + 255) / 256) * (double)((N + 255) / 256);
+            // persistent ping-pong tile: whole launch rounds of one tile per CU, tile heights mixed to fill them (p8_plan);
+            // its per-tile fixed cost (first slabs + epilogue, not overlapped with another workgroup) weighs more the
+            // shorter K is.  Calibrated on the MI355X sweeps and model benches: 0.76-0.82 x the best s3 time at
+            // K = 768 / 3072, break-even around K = 384, behind below that.
+            if (!p8_ok) continue;
             const double cap = (double)p8_grid_cap();
-            const double rounds = (double)(long long)((tiles + cap - 1) / cap);
+            double rounds = 0.0;
+            p8_plan(M, N / 256, K / 64, (int)cap, true, &rounds);
             const double kb = (double)K / epc * 16.0;          // bytes of K per row
-            double eff = 1.5 * kb / (kb + 384.0);
-            // ragged tiles leave the overlapped fast epilogue (whole 256 x 256 tiles only) and pad their MFMA work:
-            // N = 384, K = 1536 measured 0.113 ms against 0.087 ms for the 256 x 128 s3 tile
-            if (N % 256) eff *= 0.65;
-            if (M % 256) eff *= 0.95;
-            const double cost = (tiles < cap ? tiles : rounds * cap) * area / eff * (tiles < cap ? cap / tiles : 1.0);
+            const double eff = 1.5 * kb / (kb + 384.0);
+            const double cost = rounds * cap * area / eff;
             if (cost < best) { best = cost; best_algo = i + 1; }
             continue;
         }
@@ -1498,8 +1651,9 @@ extern "C" int mlpk_gemm_algo_info(int algo, int* bm, int* bn, int* threads, int
 }
 
 extern "C" long long mlpk_gemm_workspace_bytes(void) {
-    // counters (4 KiB) + at most (workgroups - 1) partial 256 x 256 fp32 accumulators
-    return 4096 + (long long)(p8_grid_cap() - 1) * 65536 * 4;
+    // no kernel needs scratch any more (the split-K hand-over of a partial last round was replaced by mixed tile heights);
+    // the descriptor's workspace fields stay in the ABI and are ignored
+    return 0;
 }
 
 extern "C" int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream) {
@@ -1537,6 +1691,7 @@ extern "C" int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream) {
     a.t_rows = d->t_rows; a.t_tokens = d->t_tokens;
     a.dbg = d->reserved & 0xff;
     a.dbg_delay = (d->reserved >> 8) & 0xff;
+    a.m_base = 0; a.panels = 0; a.cgroups = 1; a.prof_buf = d->workspace;
     const int vb = 4 * es;   // bytes of a 4-element vector
     a.vec_c = (d->ldc % 4 == 0) && (((uintptr_t)d->C % vb) == 0);
     a.vec_r = d->R ? ((d->ldr % 4 == 0) && (((uintptr_t)d->R % vb) == 0)) : 0;
@@ -1546,11 +1701,10 @@ extern "C" int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream) {
     const bool glds_ok = d->K % (4 * epc) == 0;      // K a multiple of half a 128-byte slab
     // the persistent tile is auto-selected where its overlapped epilogue applies (16-bit row-major, no row scale)
     static const bool no_p8 = getenv("MLPK_GEMM_NO_P8") != nullptr;      // tuning hook: A/B the tile choice in one run
-    const bool p8_ok = !no_p8 && es == 2 && !trans && !d->rscale && a.vec_c == 2 && (!d->R || a.vec_r == 2);
+    const bool p8_ok = !no_p8 && p8_eligible(a, es, trans);
     if (algo == 0) algo = auto_algo(d->M, d->N, d->K, epc, glds_ok, p8_ok);
     if (algo < 1 || algo > kNumTiles) return MLPK_EMODE;
     if (kTiles[algo - 1].glds && !glds_ok) return MLPK_ESHAPE;
-    if (kTiles[algo - 1].glds == 3 && (d->K % (8 * epc) != 0 || d->K < 16 * epc)) return MLPK_ESHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (d->dtype) {
         case MLPK_F32: return launch_algo<float>(algo, a, trans, s, d->workspace, d->workspace_bytes);

@@ -807,7 +807,7 @@ extern "C" int mlpk_convert(int src_dtype, int dst_dtype, const void* src, void*
     }
 }
 
-extern "C" int mlpk_abi_version(void) { return 4; }
+extern "C" int mlpk_abi_version(void) { return 5; }
 
 extern "C" const char* mlpk_strerror(int code) {
     switch (code) {

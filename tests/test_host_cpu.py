@@ -31,7 +31,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libmlpk.so does not export %s" % name
         assert name in pkg._native.PROTOTYPES, "no ctypes prototype for %s" % name
-    assert lib.mlpk_abi_version() == 4
+    assert lib.mlpk_abi_version() == 5
     assert lib.mlpk_gemm_algo_count() >= 4
     bm, bn, th, lds = (ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int())
     assert lib.mlpk_gemm_algo_info(1, bm, bn, th, lds) == 0
@@ -121,3 +121,19 @@ def test_product_never_imports_oracle():
             if fn.endswith(".py"):
                 src = open(os.path.join(dirpath, fn)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), fn
+
+
+def test_hand_scheduled_gemm_loops_have_no_compiler_vmem_waits():
+    """tools/isa_lint.py on the assembly of the build: the K loop of every instantiation of the persistent GEMM tile must
+    contain no spill traffic and no s_waitcnt on vmcnt other than the hand-counted ones -- either would drain the LDS-DMA
+    prefetch queue every slab (a pure performance bug no numerical test can see)."""
+    import importlib.util
+    pkg = load_pkg()
+    builder = __import__("importlib").import_module("jittor-mlp_amd.build")
+    builder.build()
+    asm = os.path.join(builder.OBJ, "mlpk_gemm-hip-amdgcn-amd-amdhsa-gfx950.s")
+    assert os.path.exists(asm), "the build keeps the device assembly (-save-temps=obj)"
+    spec = importlib.util.spec_from_file_location("isa_lint", os.path.join(ROOT, "tools", "isa_lint.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    assert lint.lint(asm) == 0
