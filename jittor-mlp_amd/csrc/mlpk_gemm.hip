@@ -997,8 +997,51 @@ __device__ __forceinline__ void p8_store_tile(const GemmArgs& p, f32x4 (&acc)[8]
 // times, with nothing to wait for but its own residual loads: the waves of a workgroup drift apart, so one wave's VALU
 // work overlaps another's store issue (the LDS-staged form alternated all-VALU and all-store phases between barriers:
 // 20-23k cycles per fc1 tile of which ~10k GELU and ~8k store issue, strictly one after the other).
-template <typename T, bool GELU, bool LN, bool AFF, int NI>
-__device__ __forceinline__ void p8_store_direct(const GemmArgs& p, f32x4 (&acc)[2 * NI][4], const int m0, const int n0, const int tid) {
+// What the direct epilogue needs before it can touch its first accumulator -- the LayerNorm statistics of the tile's rows and
+// the bias / folded-LayerNorm vectors of its columns, 4 x 256 floats -- is brought into LDS behind the two slab buffers by
+// p8_par_prefetch: TWO 256-byte LDS-DMA pieces per wave, issued a whole tile ahead (for the first tile before its first
+// operand piece, for every later tile during the previous tile's epilogue, in front of that tile's slab-0 pieces), into one of
+// two 4-KiB buffers that alternate from tile to tile.  Being OLDER than every operand piece of their tile they are retired
+// by the loop-top wait with no count of their own, after a whole epilogue in flight.  Fetched with ordinary loads at the top
+// of the epilogue these few scattered 64-byte reads were fully exposed (~2k cycles, once per half tile, behind the other
+// CUs' store bursts: the folded LayerNorm cost fc1 22 us = 8 %, almost all of it waiting); issued in the second-to-last K
+// slab the same wait merely moved into the last slab's vmcnt(0).  (Registers instead of LDS do not fit: 192 live + 48.)
+// LDS image: [0, 1 KiB) ln_mean of logical tile rows 0..255, [1, 2) ln_rstd, [2, 3) bias of tile columns 0..255, [3, 4) ln_csum.
+#define P8_PAR_OFF (2 * 4 * 128 * 128)
+#define P8_LDS_BYTES (P8_PAR_OFF + 2 * 4096)
+
+__device__ __forceinline__ void glds_dword_s(unsigned voff, const void* sbase, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+
+template <int BM>
+__device__ __forceinline__ void p8_par_prefetch(const GemmArgs& p, const int m0, const int n0, const int wave, const int lane,
+                                                const unsigned lds_par) {
+    const int seg = wave & 3;                                  // 64 of the 256 entries
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_par + (unsigned)(seg * 256 + (wave >> 2) * 2048));
+    // absent vectors (no LayerNorm / no bias) are "fetched" from the A operand: every wave issues exactly two pieces, which
+    // is what the counted waits assume; the epilogue never reads what it does not use
+    const char* dummy = reinterpret_cast<const char*>(p.A);
+    if (wave < 4) {
+        int r = seg * 64 + lane;
+        r = r < BM ? r : BM - 1;                               // short tiles: stay inside this tile's rows
+        const unsigned vo = (unsigned)r * 4u;
+        glds_dword_s(vo, p.ln_mean ? reinterpret_cast<const char*>(p.ln_mean + m0) : dummy, dst);
+        glds_dword_s(vo, p.ln_mean ? reinterpret_cast<const char*>(p.ln_rstd + m0) : dummy, dst + 1024);
+    } else {
+        const unsigned vo = (unsigned)(seg * 64 + lane) * 4u;
+        glds_dword_s(vo, p.bias ? reinterpret_cast<const char*>(p.bias + n0) : dummy, dst);
+        glds_dword_s(vo, p.ln_mean ? reinterpret_cast<const char*>(p.ln_csum + n0) : dummy, dst + 1024);
+    }
+}
+
+template <typename T, bool GELU, bool LN, bool AFF, bool RES, int NI>
+__device__ __forceinline__ void p8_store_direct(const GemmArgs& p, f32x4 (&acc)[2 * NI][4], const char* par_lds, const int m0, const int n0,
+                                                const int tid) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int grp = wave >> 2, wn = wave & 3;
@@ -1006,41 +1049,47 @@ __device__ __forceinline__ void p8_store_direct(const GemmArgs& p, f32x4 (&acc)[
     const int fg = lane >> 4;
     T* __restrict__ C = reinterpret_cast<T*>(p.C);
     const T* R = reinterpret_cast<const T*>(p.R);
-    const bool has_res = p.res_mode != MLPK_RES_NONE;
+    constexpr bool has_res = RES;     // a template parameter: the 64 registers of the residual chunks must not weigh on the GELU classes
     const bool res_add = p.res_mode == MLPK_RES_ADD;
     f32x4 bz[4], lc[4], cs[4], ch[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int n = n0 + (j >> 1) * 128 + wn * 32 + (j & 1) * 16 + 4 * fg;
-        bz[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-        if (LN) lc[j] = *reinterpret_cast<const f32x4*>(p.ln_csum + n);
+        const int nl = (j >> 1) * 128 + wn * 32 + (j & 1) * 16 + 4 * fg;              // column inside the tile
+        bz[j] = p.bias ? *reinterpret_cast<const f32x4*>(par_lds + 2048 + nl * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (LN) lc[j] = *reinterpret_cast<const f32x4*>(par_lds + 3072 + nl * 4);
         if (AFF) {
-            cs[j] = p.cscale ? *reinterpret_cast<const f32x4*>(p.cscale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
-            ch[j] = p.cshift ? *reinterpret_cast<const f32x4*>(p.cshift + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            cs[j] = p.cscale ? *reinterpret_cast<const f32x4*>(p.cscale + n0 + nl) : f32x4{1.f, 1.f, 1.f, 1.f};
+            ch[j] = p.cshift ? *reinterpret_cast<const f32x4*>(p.cshift + n0 + nl) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
     // after the swap: even lane rows hold columns 4*fg .. 4*fg+7 of the left block, odd ones 16 + 4*(fg-1) .. +7 (right block)
     const int ccol = (fg & 1) ? 16 + 4 * (fg - 1) : 4 * fg;
+    // residual chunks of BOTH halves in flight before any math: the load latency (and the burst of every CU reading its
+    // residual tile at once) is paid once per tile, the second half arrives under the first half's math
+    u32x4 rr[RES ? 2 : 1][RES ? NI : 1][2];
+    if constexpr (has_res) {
 #pragma unroll
-    for (int hm = 0; hm < 2; ++hm) {
-        // residual chunks of this half (8 per lane) in flight before its math
-        u32x4 rr[NI][2];
-        if (has_res) {
+        for (int hm = 0; hm < 2; ++hm)
 #pragma unroll
             for (int i4 = 0; i4 < NI; ++i4)
 #pragma unroll
                 for (int hn = 0; hn < 2; ++hn)
-                    rr[i4][hn] = *reinterpret_cast<const u32x4*>(R + (size_t)(m0 + hm * (NI * 32) + grp * (NI * 16) + i4 * 16 + frow) * p.ldr + n0 + hn * 128 + wn * 32 + ccol);
-        }
-        float lmu[NI], lrs[NI];
-        if (LN) {
+                    rr[hm][i4][hn] = *reinterpret_cast<const u32x4*>(R + (size_t)(m0 + hm * (NI * 32) + grp * (NI * 16) + i4 * 16 + frow) * p.ldr +
+                                                                     n0 + hn * 128 + wn * 32 + ccol);
+    }
+    float lmu[2][NI], lrs[2][NI];
+    if (LN) {
+#pragma unroll
+        for (int hm = 0; hm < 2; ++hm)
 #pragma unroll
             for (int i4 = 0; i4 < NI; ++i4) {
-                const int m = m0 + hm * (NI * 32) + grp * (NI * 16) + i4 * 16 + frow;
-                lmu[i4] = p.ln_mean[m];
-                lrs[i4] = p.ln_rstd[m];
+                const int rl = hm * (NI * 32) + grp * (NI * 16) + i4 * 16 + frow;           // logical tile row
+                lmu[hm][i4] = *reinterpret_cast<const float*>(par_lds + rl * 4);
+                lrs[hm][i4] = *reinterpret_cast<const float*>(par_lds + 1024 + rl * 4);
             }
-        }
+    }
+#pragma unroll
+    for (int hm = 0; hm < 2; ++hm) {
 #pragma unroll
         for (int i4 = 0; i4 < NI; ++i4) {
             const size_t grow = (size_t)(m0 + hm * (NI * 32) + grp * (NI * 16) + i4 * 16 + frow);
@@ -1054,7 +1103,7 @@ __device__ __forceinline__ void p8_store_direct(const GemmArgs& p, f32x4 (&acc)[
                     f32x2 lo = {a.x, a.y}, hi = {a.z, a.w};
                     const f32x2 blo = {bz[j].x, bz[j].y}, bhi = {bz[j].z, bz[j].w};
                     if (LN) {
-                        const f32x2 nm = {-lmu[i4], -lmu[i4]}, rs = {lrs[i4], lrs[i4]};
+                        const f32x2 nm = {-lmu[hm][i4], -lmu[hm][i4]}, rs = {lrs[hm][i4], lrs[hm][i4]};
                         lo = __builtin_elementwise_fma(__builtin_elementwise_fma(nm, f32x2{lc[j].x, lc[j].y}, lo), rs, blo);
                         hi = __builtin_elementwise_fma(__builtin_elementwise_fma(nm, f32x2{lc[j].z, lc[j].w}, hi), rs, bhi);
                     } else {
@@ -1074,21 +1123,21 @@ __device__ __forceinline__ void p8_store_direct(const GemmArgs& p, f32x4 (&acc)[
                         lo = __builtin_elementwise_fma(lo, f32x2{cs[j].x, cs[j].y}, f32x2{ch[j].x, ch[j].y});
                         hi = __builtin_elementwise_fma(hi, f32x2{cs[j].z, cs[j].w}, f32x2{ch[j].z, ch[j].w});
                     }
-                    T e[4] = {from_f32<T>(lo.x), from_f32<T>(lo.y), from_f32<T>(hi.x), from_f32<T>(hi.y)};
-                    __builtin_memcpy(&w[2 * jj], e, 8);
+                    T el[4] = {from_f32<T>(lo.x), from_f32<T>(lo.y), from_f32<T>(hi.x), from_f32<T>(hi.y)};
+                    __builtin_memcpy(&w[2 * jj], el, 8);
                 }
                 // w[0..1] = this lane's 4 columns of the left block, w[2..3] = of the right block
                 const auto s0 = __builtin_amdgcn_permlane16_swap(w[0], w[2], false, false);
                 const auto s1 = __builtin_amdgcn_permlane16_swap(w[1], w[3], false, false);
                 u32x4 outv = {s0[0], s1[0], s0[1], s1[1]};
-                if (has_res) {
+                if constexpr (has_res) {
                     T a8[8], r8[8];
                     __builtin_memcpy(a8, &outv, 16);
-                    __builtin_memcpy(r8, &rr[i4][hn], 16);
+                    __builtin_memcpy(r8, &rr[hm][i4][hn], 16);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float x = to_f32(a8[e]), y = to_f32(r8[e]);
-                        a8[e] = from_f32<T>(res_add ? x + y : x * y);
+                    for (int k = 0; k < 8; ++k) {
+                        const float x = to_f32(a8[k]), y = to_f32(r8[k]);
+                        a8[k] = from_f32<T>(res_add ? x + y : x * y);
                     }
                     __builtin_memcpy(&outv, a8, 16);
                 }
@@ -1187,6 +1236,7 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_p8_kernel(const GemmArgs p) {
     };
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     const unsigned lds_w = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)smem + wave * 2048);
+    const unsigned lds_par = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)smem + P8_PAR_OFF);
     // half ids: 0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi
     auto stage = [&](const int t, const int h) {
         // the slab counter may live in a VGPR under SGPR pressure: pin what the asm takes as scalars
@@ -1220,6 +1270,8 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_p8_kernel(const GemmArgs p) {
 
     // ---- first tile: slab 0 complete before the loop, three half-tiles of slab 1 in flight ----
     setup(l);
+    int par_sel = 0;                                        // parameter buffer of the CURRENT tile
+    if constexpr (EPI == 1) p8_par_prefetch<BM>(p, m0, n0, wave, lane, lds_par);
     stage(0, 2); stage(0, 0); stage(0, 3); stage(0, 1);
     stage(1, 2); stage(1, 0); stage(1, 3);
 
@@ -1315,21 +1367,30 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_p8_kernel(const GemmArgs p) {
         int etid = tid;
         asm volatile("" : "+v"(etid));
         // next tile's slab 0 streams into buffer 0 while this tile leaves (EPI 0: through the other buffer)
+        const char* par = smem + P8_PAR_OFF + par_sel * 4096;
         if (more) {
             setup(l);
+            par_sel ^= 1;
+            if constexpr (EPI == 1) p8_par_prefetch<BM>(p, m0, n0, wave, etid & 63, lds_par + (unsigned)(par_sel * 4096));
             stage(0, 2); stage(0, 0); stage(0, 3); stage(0, 1);
         }
         const int cls = (p.act == MLPK_ACT_GELU ? 1 : 0) | (p.ln_mean ? 2 : 0) | ((p.cscale || p.cshift) ? 4 : 0);
         if constexpr (EPI == 1) {
-            switch (cls) {
-                case 0: p8_store_direct<T, false, false, false, NI>(p, acc, cm0, cn0, etid); break;
-                case 1: p8_store_direct<T, true, false, false, NI>(p, acc, cm0, cn0, etid); break;
-                case 2: p8_store_direct<T, false, true, false, NI>(p, acc, cm0, cn0, etid); break;
-                case 3: p8_store_direct<T, true, true, false, NI>(p, acc, cm0, cn0, etid); break;
-                case 4: p8_store_direct<T, false, false, true, NI>(p, acc, cm0, cn0, etid); break;
-                case 5: p8_store_direct<T, true, false, true, NI>(p, acc, cm0, cn0, etid); break;
-                case 6: p8_store_direct<T, false, true, true, NI>(p, acc, cm0, cn0, etid); break;
-                default: p8_store_direct<T, true, true, true, NI>(p, acc, cm0, cn0, etid); break;
+            // (the host sends residual + GELU / residual + LayerNorm combinations to the staged kernel)
+            if (p.res_mode != MLPK_RES_NONE) {
+                if (cls & 4) p8_store_direct<T, false, false, true, true, NI>(p, acc, par, cm0, cn0, etid);
+                else p8_store_direct<T, false, false, false, true, NI>(p, acc, par, cm0, cn0, etid);
+            } else {
+                switch (cls) {
+                    case 0: p8_store_direct<T, false, false, false, false, NI>(p, acc, par, cm0, cn0, etid); break;
+                    case 1: p8_store_direct<T, true, false, false, false, NI>(p, acc, par, cm0, cn0, etid); break;
+                    case 2: p8_store_direct<T, false, true, false, false, NI>(p, acc, par, cm0, cn0, etid); break;
+                    case 3: p8_store_direct<T, true, true, false, false, NI>(p, acc, par, cm0, cn0, etid); break;
+                    case 4: p8_store_direct<T, false, false, true, false, NI>(p, acc, par, cm0, cn0, etid); break;
+                    case 5: p8_store_direct<T, true, false, true, false, NI>(p, acc, par, cm0, cn0, etid); break;
+                    case 6: p8_store_direct<T, false, true, true, false, NI>(p, acc, par, cm0, cn0, etid); break;
+                    default: p8_store_direct<T, true, true, true, false, NI>(p, acc, par, cm0, cn0, etid); break;
+                }
             }
         } else {
             char* stg = smem + BUF_B;
@@ -1534,11 +1595,13 @@ template <typename T> static int launch_p8(const GemmArgs& a0, bool trans, hipSt
     } else {
         GemmArgs a = a0;
         if (!p8_eligible(a, 2, trans)) return MLPK_ESHAPE;
-        const int lds = 2 * 4 * 128 * 128;
+        const int lds = P8_LDS_BYTES;
         const int tiles_n = a.N / 256;
         const int cap = p8_grid_cap();
         a.cgroups = (a.dbg & 128) ? 1 : p8_cgroups(tiles_n, a.K, 2);           // reserved & 128: one column group (A/B runs)
-        const bool staged = (a.dbg & 64) != 0;                                 // reserved & 64: LDS-staged epilogue (A/B runs)
+        // reserved & 64: LDS-staged epilogue (A/B runs); it also serves the rare residual + GELU / residual + LayerNorm
+        // combinations, which the direct epilogue does not instantiate
+        const bool staged = (a.dbg & 64) != 0 || (a.res_mode != MLPK_RES_NONE && (a.act == MLPK_ACT_GELU || a.ln_mean));
         const P8Plan plan = p8_plan(a.M, tiles_n, a.K / 64, cap, !staged && !(a.dbg & 16));   // reserved & 16: 256-row tiles only
         int m_base = 0;
         for (int s = 0; s < plan.n; ++s) {
@@ -1646,7 +1709,7 @@ extern "C" int mlpk_gemm_algo_info(int algo, int* bm, int* bn, int* threads, int
     if (bm) *bm = t.bm;
     if (bn) *bn = t.bn;
     if (threads) *threads = t.wm * t.wn * 64;
-    if (lds_bytes) *lds_bytes = t.glds == 2 ? 3 * (t.bm + t.bn) * 64 : 2 * (t.bm + t.bn) * 128;   // (p8: 2 x 64 KiB too)
+    if (lds_bytes) *lds_bytes = t.glds == 3 ? P8_LDS_BYTES : t.glds == 2 ? 3 * (t.bm + t.bn) * 64 : 2 * (t.bm + t.bn) * 128;
     return 0;
 }
 

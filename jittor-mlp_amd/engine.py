@@ -7,6 +7,7 @@ There is deliberately no CPU implementation: a non-GPU tensor raises NotImplemen
 the same error type the reference's Shift raises on CPU (shift_cuda.py:170-173).
 """
 import ctypes
+import os
 
 import torch
 
@@ -145,6 +146,26 @@ def gemm(A, B, C, M, Nn, K, *, lda=None, ldb=None, ldc=None, bias=None, act=N.AC
     if timed:
         ev1.record()
         TIMER.events.setdefault(tag, []).append((ev0, ev1, 2.0 * M * Nn * K))
+
+
+CHANNEL_CHUNKS = int(os.environ.get("MLPK_CHANNEL_CHUNKS", "0"))      # 0 = by size (below); tuning override
+
+
+def channel_chunks(rows, hidden_row_bytes):
+    """Number of row chunks of a channel MLP: the smallest power of two whose hidden slice fits ~160 MB (the 256 MiB
+    Infinity Cache minus what else streams through it), with whole 64-row groups per chunk."""
+    if CHANNEL_CHUNKS > 0:
+        n = CHANNEL_CHUNKS
+    else:
+        n = 1
+        while n < 8 and rows * hidden_row_bytes / n > CHUNK_BYTES:
+            n *= 2
+    while n > 1 and (rows % n or (rows // n) % 64):
+        n //= 2
+    return max(1, n)
+
+
+CHUNK_BYTES = float(os.environ.get("MLPK_CHUNK_MB", "1e9")) * 1e6      # default off (one chunk) until measured
 
 
 def token_mlp(xt, ldxt, M, S, w1, b1, w2, b2, nchunks, x, ldx, t_rows):
