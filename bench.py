@@ -45,7 +45,8 @@ MODELS = {
     "sparsemlp_t": ("SparseMLP", dict(), 16.231),      # SURVEY.md 8(f) rank 2; 2*MAC of its GEMMs/convs counted by hand
     "hiremlp_s": ("HireMLP", dict(), 9.742),           # SURVEY.md 8(f) rank 2; counted by hand (padded region rows included)
     "msmlp_t": ("MS_MLP", dict(), 5.990),              # SURVEY.md 8(f) rank 3; counted by hand
-    "swinmlp_t": ("SwinMLP", dict(), 6.110),           # SURVEY.md 8(f) rank 3; counted by hand (useful flops of the per-head window mixes)
+    "swinmlp_t": ("SwinMLP", dict(), 6.110),
+    "cyclemlp_b1": ("CycleMLP_B1", dict(), 4.2),       # SURVEY.md 8(f) rank 3; 2 x the 2.1 GMACs the CycleMLP paper quotes for B1           # SURVEY.md 8(f) rank 3; counted by hand (useful flops of the per-head window mixes)
 }
 PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16/f16 MFMA (MI355X_MICROARCH.md); f32 MFMA 157.3
 DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}

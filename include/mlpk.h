@@ -35,6 +35,9 @@
  *                       the final LayerNorm: mlp_mixer.py:73-74; vip.py:160-163; s2_mlp_v2.py:125; as_mlp.py:435-437
  *   mlpk_shift_nchw     Shift / _shift.forward / shift_forward_kernel: utils/shift_cuda.py:44-72,106-129,177-192
  *   mlpk_shift_nhwc     the same remap on the channel-last layout used internally for AS-MLP
+ *   mlpk_norm_shift_nhwc  AxialShift's GroupNorm + GELU + both shifts as one index-remapping pass (as_mlp.py:64-66,84-95)
+ *   mlpk_cycle_shift    the sampling half of CycleFC (cycle_mlp.py:104-131: deform_conv2d with a 1 x 1 kernel and fixed integer
+ *                       offsets = a per-channel cyclic pixel shift with zero fill); the 1 x 1 convolution is mlpk_gemm_nt
  *   mlpk_split_sum      the reduction of SplitAttention (vip.py:49-50; s2_mlp_v2.py:43-44), with the
  *                       S2 spatial shifts (s2_mlp_v2.py:15-29) applied on load
  *   mlpk_split_softmax  softmax over the k=3 branches (vip.py:52-53)
@@ -111,8 +114,8 @@ typedef struct mlpk_gemm_desc {
     const float* cscale;  /* [N] or NULL */
     const float* cshift;  /* [N] or NULL */
     const float* rscale;  /* [rperiod] or NULL */
-    const float* ln_mean; /* [M] or NULL: folded LayerNorm row means */
-    const float* ln_rstd; /* [M] or NULL */
+    const float* ln_mean; /* [ceil(M / ln_group)] or NULL: folded LayerNorm / GroupNorm(1,C) means */
+    const float* ln_rstd; /* [ceil(M / ln_group)] or NULL */
     const float* ln_csum; /* [N] or NULL: row sums of B */
     int32_t rperiod;
     int32_t act;
@@ -121,6 +124,8 @@ typedef struct mlpk_gemm_desc {
     int32_t t_rows;       /* TOKEN_T: rows (channels) per image */
     int32_t t_tokens;     /* TOKEN_T: tokens per image (row count of one image in C) */
     int32_t algo;         /* 0 auto; otherwise a tile-config id, see mlpk_gemm_algo_count */
+    int32_t ln_group;     /* rows that share one folded statistic: 0 / 1 = LayerNorm (one per row); H*W = GroupNorm(1, C) on channel-last
+                             rows (one per sample, as_mlp.py:343-344) */
     int32_t reserved;     /* 0.  Tuning bits of the persistent tile (A/B runs only; results are bit-identical with every
                              combination): 16 = 256-row tiles only (no mixed tile heights), 64 = LDS-staged epilogue,
                              128 = a single column group */
@@ -237,6 +242,21 @@ int mlpk_shift_nchw(int dtype, const void* in, void* out, int N, int C, int H, i
 int mlpk_shift_nhwc(int dtype, const void* in, void* out, int N, int H, int W, int C,
                     int kernel_size, int dim, void* stream);
 
+/* AS-MLP: t = act(GroupNorm(1,C)(in)) read through BOTH axial shifts in one pass, t itself never stored (as_mlp.py:64-66,84-95):
+ *   out_w[n,h,w,c] = t[n,h,w+s,c],  out_h[n,h,w,c] = t[n,h+s,w,c],  t = act((in - mean[n]) * rstd[n] * gamma[c] + beta[c]),
+ * s as in mlpk_shift_nhwc, zero outside the map.  16-bit dtypes, C % 8 == 0, ceil(C / kernel_size) >= 8. */
+int mlpk_norm_shift_nhwc(int dtype, const void* in, void* out_w, void* out_h, int N, int H, int W, int C, int kernel_size,
+                         const float* mean, const float* rstd, const float* gamma, const float* beta, int act, void* stream);
+
+/* ---- CycleFC sampling (CycleMLP) ---------------------------------------------------------------
+ * in: (B,H,W,C) channel-last with pixel stride ldi.  d(c) = (c + k/2) % k - k/2  (gen_offset, cycle_mlp.py:104-120):
+ *   out_h[b,y,x,c] = in[b, y, x + d(c), c]     the operand of `sfc_h` = CycleFC(kernel (1,k))
+ *   out_w[b,y,x,c] = in[b, y + d(c), x, c]     the operand of `sfc_w` = CycleFC(kernel (k,1))
+ * zero where the source pixel lies outside the map; either output may be NULL; pixel stride ldo; k odd.
+ */
+int mlpk_cycle_shift(int dtype, const void* in, void* out_h, void* out_w, int B, int H, int W, int C, int k,
+                     int ldi, int ldo, void* stream);
+
 /* ---- split attention (ViP / S2-MLPv2) -----------------------------------------------------
  * Three branch tensors x_k (B,H,W,C), k=0..2, each with its own pixel stride ld_k (so they may be
  * column slices of one (B,H,W,3C) buffer).  shift_mode selects a gather applied to branches 0/1
@@ -244,7 +264,8 @@ int mlpk_shift_nhwc(int dtype, const void* in, void* out, int N, int H, int W, i
  *   MLPK_SHIFT_NONE      ViP
  *   MLPK_SHIFT_S2        branch0 = spatial_shift1, branch1 = spatial_shift2, clean 1-pixel shift
  *   MLPK_SHIFT_S2_REF    same, with the reference's deterministic in-place ("smear") behaviour
- * split_sum:    a[b,c] = sum_{k,h,w} x_k[b,h,w,c]                     (fp32, a pre-zeroed by callee)
+ * split_sum:    a[b,c] = scale * sum_{k,h,w} x_k[b,h,w,c]             (fp32; scale = 1 for the SplitAttention of ViP / S2-MLPv2,
+ *                                                                     1 / (H W) for CycleMLP's mean, cycle_mlp.py:169)
  * split_softmax: bar[b,k,c] = softmax_k(hat[b, k*C + c])             (fp32 in/out)
  * split_apply:  out[b,h,w,c] = sum_k bar[b,k,c] * x_k[b,h,w,c]       (out pixel stride ldo)
  */
@@ -252,7 +273,7 @@ int mlpk_shift_nhwc(int dtype, const void* in, void* out, int N, int H, int W, i
 #define MLPK_SHIFT_S2 1
 #define MLPK_SHIFT_S2_REF 2
 int mlpk_split_sum(int dtype, const void* x0, const void* x1, const void* x2, int ld0, int ld1,
-                   int ld2, int B, int H, int W, int C, int shift_mode, float* a, void* stream);
+                   int ld2, int B, int H, int W, int C, int shift_mode, float scale, float* a, void* stream);
 int mlpk_split_softmax(const float* hat, float* bar, int B, int C, void* stream);
 int mlpk_split_apply(int dtype, const void* x0, const void* x1, const void* x2, int ld0, int ld1,
                      int ld2, int B, int H, int W, int C, int shift_mode, const float* bar,

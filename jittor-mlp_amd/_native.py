@@ -24,7 +24,7 @@ class GemmDesc(ctypes.Structure):
                 ("ln_mean", c_void_p), ("ln_rstd", c_void_p), ("ln_csum", c_void_p),
                 ("rperiod", ctypes.c_int32), ("act", ctypes.c_int32), ("res_mode", ctypes.c_int32),
                 ("out_mode", ctypes.c_int32), ("t_rows", ctypes.c_int32), ("t_tokens", ctypes.c_int32),
-                ("algo", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("algo", ctypes.c_int32), ("ln_group", ctypes.c_int32), ("reserved", ctypes.c_int32),
                 ("workspace", c_void_p), ("workspace_bytes", ctypes.c_int64)]
 
 
@@ -57,7 +57,9 @@ PROTOTYPES = {
                                c_void_p, c_void_p, c_int, c_void_p]),
     "mlpk_shift_nchw": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "mlpk_shift_nhwc": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
-    "mlpk_split_sum": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p, c_void_p]),
+    "mlpk_norm_shift_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p] * 4 + [c_int, c_void_p]),
+    "mlpk_cycle_shift": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    "mlpk_split_sum": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_float, c_void_p, c_void_p]),
     "mlpk_split_softmax": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "mlpk_split_apply": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p, c_void_p, c_int, c_void_p]),
     "mlpk_s2_shift": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),

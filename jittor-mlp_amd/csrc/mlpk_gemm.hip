@@ -32,9 +32,10 @@ struct GemmArgs {
     const float* cscale;
     const float* cshift;
     const float* rscale;
-    const float* ln_mean;   // folded LayerNorm: v = (acc - ln_mean[m]*ln_csum[n]) * ln_rstd[m]
+    const float* ln_mean;   // folded LayerNorm / GroupNorm(1,C): v = (acc - ln_mean[m / ln_group]*ln_csum[n]) * ln_rstd[m / ln_group]
     const float* ln_rstd;
     const float* ln_csum;
+    int ln_group;           // rows that share one statistic (1: LayerNorm; H*W: GroupNorm(1,C) on channel-last rows)
     int M, N, K;
     int lda, ldb, ldc, ldr;
     int rperiod, act, res_mode;
@@ -223,7 +224,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
                 int m = m0 + rbase(i) + frow;
                 m = m < p.M ? m : p.M - 1;
                 if (p.rscale) rs_[i] = p.rscale[m % p.rperiod];
-                if (p.ln_mean) { lmu_[i] = p.ln_mean[m]; lrs_[i] = p.ln_rstd[m]; }
+                if (p.ln_mean) { lmu_[i] = p.ln_mean[m / p.ln_group]; lrs_[i] = p.ln_rstd[m / p.ln_group]; }
             }
         }
         // the element loop is instantiated with and without the activation (a per-element uniform branch around the
@@ -336,7 +337,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
             const int m = m0 + rbase(i) + frow;
             if (m >= p.M) continue;
             const float rs = p.rscale ? p.rscale[m % p.rperiod] : 1.0f;
-            const float lmu = p.ln_mean ? p.ln_mean[m] : 0.f, lrs = p.ln_mean ? p.ln_rstd[m] : 1.f;
+            const float lmu = p.ln_mean ? p.ln_mean[m / p.ln_group] : 0.f, lrs = p.ln_mean ? p.ln_rstd[m / p.ln_group] : 1.f;
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
                 const int nb = n0 + cbase(j) + 4 * fg;
@@ -908,8 +909,8 @@ __device__ __forceinline__ void p8_store_tile(const GemmArgs& p, f32x4 (&acc)[8]
 #pragma unroll
             for (int i4 = 0; i4 < 4; ++i4) {
                 const int m = m0 + hm * 128 + grp * 64 + i4 * 16 + frow;
-                lmu[i4] = p.ln_mean[m];
-                lrs[i4] = p.ln_rstd[m];
+                lmu[i4] = p.ln_mean[m / p.ln_group];
+                lrs[i4] = p.ln_rstd[m / p.ln_group];
             }
         }
         // phase 1: element math on the fp32 accumulator, round, ds_write_b64 into the swizzled staging tile
@@ -1029,9 +1030,9 @@ __device__ __forceinline__ void p8_par_prefetch(const GemmArgs& p, const int m0,
     if (wave < 4) {
         int r = seg * 64 + lane;
         r = r < BM ? r : BM - 1;                               // short tiles: stay inside this tile's rows
-        const unsigned vo = (unsigned)r * 4u;
-        glds_dword_s(vo, p.ln_mean ? reinterpret_cast<const char*>(p.ln_mean + m0) : dummy, dst);
-        glds_dword_s(vo, p.ln_mean ? reinterpret_cast<const char*>(p.ln_rstd + m0) : dummy, dst + 1024);
+        const unsigned vo = (unsigned)((m0 + r) / p.ln_group) * 4u;          // (ln_group = 1 when there is no LayerNorm)
+        glds_dword_s(p.ln_mean ? vo : (unsigned)r * 4u, p.ln_mean ? reinterpret_cast<const char*>(p.ln_mean) : dummy, dst);
+        glds_dword_s(p.ln_mean ? vo : (unsigned)r * 4u, p.ln_mean ? reinterpret_cast<const char*>(p.ln_rstd) : dummy, dst + 1024);
     } else {
         const unsigned vo = (unsigned)(seg * 64 + lane) * 4u;
         glds_dword_s(vo, p.bias ? reinterpret_cast<const char*>(p.bias + n0) : dummy, dst);
@@ -1584,6 +1585,8 @@ static int p8_cgroups(int tiles_n, int K, int es) {
 static bool p8_eligible(const GemmArgs& a, int es, bool trans) {
     if (es != 2 || trans || a.rscale || a.vec_c != 2 || (a.res_mode != MLPK_RES_NONE && a.vec_r != 2)) return false;
     if (a.M % 64 || a.N % 256 || a.K % 64 || a.K < 128) return false;
+    // residual + GELU / residual + LayerNorm go through the LDS-staged epilogue, which exists for 256-row tiles only
+    if (a.res_mode != MLPK_RES_NONE && (a.act == MLPK_ACT_GELU || a.ln_mean) && a.M % 256) return false;
     const uintptr_t par = reinterpret_cast<uintptr_t>(a.bias) | reinterpret_cast<uintptr_t>(a.ln_csum) | reinterpret_cast<uintptr_t>(a.cscale) |
                           reinterpret_cast<uintptr_t>(a.cshift);
     return (par & 15) == 0;
@@ -1602,6 +1605,7 @@ template <typename T> static int launch_p8(const GemmArgs& a0, bool trans, hipSt
         // reserved & 64: LDS-staged epilogue (A/B runs); it also serves the rare residual + GELU / residual + LayerNorm
         // combinations, which the direct epilogue does not instantiate
         const bool staged = (a.dbg & 64) != 0 || (a.res_mode != MLPK_RES_NONE && (a.act == MLPK_ACT_GELU || a.ln_mean));
+        if (staged && a.M % 256) return MLPK_ESHAPE;                            // the staged epilogue is built for 256-row tiles only
         const P8Plan plan = p8_plan(a.M, tiles_n, a.K / 64, cap, !staged && !(a.dbg & 16));   // reserved & 16: 256-row tiles only
         int m_base = 0;
         for (int s = 0; s < plan.n; ++s) {
@@ -1747,6 +1751,7 @@ extern "C" int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream) {
     a.A = d->A; a.B = d->B; a.C = d->C; a.R = d->R;
     a.bias = d->bias; a.cscale = d->cscale; a.cshift = d->cshift; a.rscale = d->rscale;
     a.ln_mean = d->ln_mean; a.ln_rstd = d->ln_rstd; a.ln_csum = d->ln_csum;
+    a.ln_group = d->ln_group > 0 ? d->ln_group : 1;
     a.M = d->M; a.N = d->N; a.K = d->K;
     a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc; a.ldr = d->ldr;
     a.rperiod = d->rperiod > 0 ? d->rperiod : 1;

@@ -85,6 +85,83 @@ __global__ void __launch_bounds__(256) shift_nhwc_vec_kernel(const T* __restrict
     }
 }
 
+// ================================ CycleFC sampling (CycleMLP) ================================
+// cycle_mlp.py:104-131: torchvision's deform_conv2d with a 1 x 1 kernel and the fixed integer offsets of gen_offset --
+// input channel c is read one cycle step away, d(c) = (c + k/2) % k - k/2, along W (kernel (1,k), `sfc_h`) or along H
+// (kernel (k,1), `sfc_w`), zero outside the map (bilinear sampling at an integer point outside [0, size) is 0).  Both
+// gathered copies of the channel-last activation are produced in one pass (the 1 x 1 convolutions that follow are GEMMs).
+template <typename T>
+__global__ void __launch_bounds__(256) cycle_shift_kernel(const T* __restrict__ in, T* __restrict__ out_h, T* __restrict__ out_w, int B,
+                                                          int H, int W, int C, int kw, int kh, int ldi, int ldo) {
+    const int64_t total = (int64_t)B * H * W * C;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        const int64_t px = idx / C;
+        const int x = (int)(px % W);
+        const int y = (int)((px / W) % H);
+        if (out_h) {
+            const int d = (c + kw / 2) % kw - kw / 2;
+            out_h[px * ldo + c] = (x + d >= 0 && x + d < W) ? in[(px + d) * ldi + c] : from_f32<T>(0.f);
+        }
+        if (out_w) {
+            const int d = (c + kh / 2) % kh - kh / 2;
+            out_w[px * ldo + c] = (y + d >= 0 && y + d < H) ? in[(px + (int64_t)d * W) * ldi + c] : from_f32<T>(0.f);
+        }
+    }
+}
+
+// 16-bit types, C % 8 == 0: one thread produces 8 channels (16 bytes) of both outputs from the <= k neighbouring pixels'
+// vectors at the same channel offset (all but the centre one are L1 / L2 hits: the neighbours' threads read them too).
+template <typename T, int K>
+__global__ void __launch_bounds__(256) cycle_shift_vec_kernel(const T* __restrict__ in, T* __restrict__ out_h, T* __restrict__ out_w, int B,
+                                                              int H, int W, int C, int ldi, int ldo) {
+    const int CV = C / 8;
+    const unsigned total = (unsigned)B * H * W * CV;
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const unsigned px = idx / CV;
+        const int c = (int)(idx - px * CV) * 8;
+        const int x = (int)(px % W);
+        const int y = (int)((px / W) % H);
+        const T* src = in + (size_t)px * ldi + c;
+        T oh[8], ow[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) oh[e] = ow[e] = from_f32<T>(0.f);
+#pragma unroll
+        for (int d = -(K / 2); d <= K / 2; ++d) {
+            // elements of this vector whose cycle step is d: (c + e + K/2) % K == d + K/2
+            const int first = ((d + K / 2 - (c + K / 2) % K) % K + K) % K;
+            if (first < 8) {
+                if (out_h && x + d >= 0 && x + d < W) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(src + (ptrdiff_t)d * ldi);
+                    T a[8];
+                    __builtin_memcpy(a, &v, 16);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (e >= first && (e - first) % K == 0) oh[e] = a[e];
+                }
+                if (out_w && y + d >= 0 && y + d < H) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(src + (ptrdiff_t)d * W * ldi);
+                    T a[8];
+                    __builtin_memcpy(a, &v, 16);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (e >= first && (e - first) % K == 0) ow[e] = a[e];
+                }
+            }
+        }
+        if (out_h) {
+            u32x4 v;
+            __builtin_memcpy(&v, oh, 16);
+            *reinterpret_cast<u32x4*>(out_h + (size_t)px * ldo + c) = v;
+        }
+        if (out_w) {
+            u32x4 v;
+            __builtin_memcpy(&v, ow, 16);
+            *reinterpret_cast<u32x4*>(out_w + (size_t)px * ldo + c) = v;
+        }
+    }
+}
+
 // ================================ S2 spatial shifts ================================
 // Tensor (B, D1, D2, C).  Channel quarters as the slices of s2_mlp_v2.py:17-20.
 // which = 1: spatial_shift1 -> (d1,+1),(d1,-1),(d2,+1),(d2,-1); which = 2: spatial_shift2 ->
@@ -139,7 +216,7 @@ struct SplitArgs {
 // a[b,c] = sum over the three branches and all pixels; workgroup = (image, 64 channels),
 // 4 pixel phases x 64 channel lanes, fp32 accumulation.
 template <typename T>
-__global__ void __launch_bounds__(256) split_sum_kernel(const SplitArgs p, float* __restrict__ a) {
+__global__ void __launch_bounds__(256) split_sum_kernel(const SplitArgs p, float* __restrict__ a, const float scale) {
     __shared__ float red[4][64];
     const int tid = threadIdx.x;
     const int cl = tid & 63;
@@ -164,7 +241,7 @@ __global__ void __launch_bounds__(256) split_sum_kernel(const SplitArgs p, float
     }
     red[ph][cl] = s;
     __syncthreads();
-    if (tid < 64 && c < p.C) a[(int64_t)b * p.C + c] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    if (tid < 64 && c < p.C) a[(int64_t)b * p.C + c] = (red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]) * scale;
 }
 
 __global__ void __launch_bounds__(256) split_softmax_kernel(const float* __restrict__ hat, float* __restrict__ bar,
@@ -227,7 +304,7 @@ template <typename T> __device__ __forceinline__ void st8(T* p, const float (&v)
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) split_sum_vec_kernel(const SplitArgs p, float* __restrict__ a) {
+__global__ void __launch_bounds__(256) split_sum_vec_kernel(const SplitArgs p, float* __restrict__ a, const float scale) {
     __shared__ float red[32][64 + 1];
     const int tid = threadIdx.x;
     const int cl = (tid & 7) * 8;
@@ -268,7 +345,7 @@ __global__ void __launch_bounds__(256) split_sum_vec_kernel(const SplitArgs p, f
             float t = 0.f;
 #pragma unroll 8
             for (int i = 0; i < 32; ++i) t += red[i][tid];
-            a[(int64_t)b * p.C + cc] = t;
+            a[(int64_t)b * p.C + cc] = t * scale;
         }
     }
 }
@@ -307,6 +384,64 @@ __global__ void __launch_bounds__(256) split_apply_vec_kernel(const SplitArgs p,
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = w0[e] * v0[e] + w1[e] * v1[e] + w2[e] * v2[e];
         st8<T>(out + px * ldo + c, o);
+    }
+}
+
+// ================================ AS-MLP: GroupNorm + GELU + both axial shifts in one pass ================================
+// as_mlp.py:64-66,84-95: t = gelu(GroupNorm(1,C)(conv1(x))) is only ever read through the two axial shifts (conv2_1 takes the
+// W-shifted, conv2_2 the H-shifted copy), so t itself is never stored: this kernel reads the conv1 output u once per output
+// and writes  out_w[n,h,w,c] = t[n,h,w+s,c],  out_h[n,h,w,c] = t[n,h+s,w,c]  (s = k/2 - c / ceil(C/k), zero outside the map,
+// utils/shift_cuda.py:49-69) with  t = act((u - mean[n]) * rstd[n] * gamma[c] + beta[c])  computed on the fly.  One thread
+// = 8 channels (16 bytes) of both outputs; a vector that straddles two shift groups is assembled from two source pixels.
+template <typename T>
+__global__ void __launch_bounds__(256) norm_shift_vec_kernel(const T* __restrict__ in, T* __restrict__ out_w, T* __restrict__ out_h, int N, int H,
+                                                             int W, int C, int ksz, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int act) {
+    const int CV = C / 8;
+    const unsigned total = (unsigned)N * H * W * CV;
+    const int group = (C + ksz - 1) / ksz;
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const unsigned px = idx / CV;                       // pixel (n, h, w)
+        const int c = (int)(idx - px * CV) * 8;
+        const int w = (int)(px % W);
+        const int h = (int)((px / W) % H);
+        const int n = (int)(px / ((unsigned)W * H));
+        const float mu = mean[n], rs = rstd[n];
+        float sc[8], sh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float g = gamma ? gamma[c + e] : 1.f;
+            sc[e] = rs * g;
+            sh[e] = (beta ? beta[c + e] : 0.f) - mu * rs * g;
+        }
+        const int g0 = c / group, g1 = (c + 7) / group;
+        const int first1 = g1 * group - c;                  // first element of the vector that belongs to group g1 (if g1 != g0)
+        const T* src = in + (size_t)px * C + c;
+#pragma unroll
+        for (int dim = 3; dim >= 2; --dim) {
+            const int pos = dim == 2 ? h : w, lim = dim == 2 ? H : W;
+            const int step = dim == 2 ? W * C : C;
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                if (part == 1 && g1 == g0) break;
+                const int s = ksz / 2 - (part ? g1 : g0);
+                if (pos + s < 0 || pos + s >= lim) continue;
+                float v[8];
+                ld8<T>(src + (ptrdiff_t)s * step, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float t = v[e] * sc[e] + sh[e];
+                    if (act == MLPK_ACT_GELU) t = gelu_t<T>(t);
+                    const bool mine = g1 == g0 || (part ? e >= first1 : e < first1);
+                    o[e] = mine ? t : o[e];
+                }
+            }
+            st8<T>((dim == 3 ? out_w : out_h) + (size_t)px * C + c, o);
+        }
     }
 }
 
@@ -418,6 +553,58 @@ extern "C" int mlpk_shift_nhwc(int dtype, const void* in, void* out, int N, int 
     return 0;
 }
 
+extern "C" int mlpk_norm_shift_nhwc(int dtype, const void* in, void* out_w, void* out_h, int N, int H, int W, int C, int kernel_size,
+                                    const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                                    void* stream) {
+    if (!in || !out_w || !out_h || !mean || !rstd) return MLPK_ENULL;
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return MLPK_ESHAPE;
+    if (kernel_size < 3 || !(kernel_size & 1)) return MLPK_ESHAPE;
+    if (act != MLPK_ACT_NONE && act != MLPK_ACT_GELU) return MLPK_EMODE;
+    if (dtype != MLPK_F16 && dtype != MLPK_BF16) return MLPK_EDTYPE;     // 16-bit channel-last activations (fp32 keeps the unfused path)
+    const int64_t total = (int64_t)N * C * H * W;
+    const int group = (C + kernel_size - 1) / kernel_size;
+    if (C % 8 || group < 8 || total / 8 >= 0x7fffffffLL) return MLPK_ESHAPE;    // (group >= 8: a vector touches at most two shift groups)
+    if (((uintptr_t)in | (uintptr_t)out_w | (uintptr_t)out_h) & 15) return MLPK_EALIGN;
+    if (in == out_w || in == out_h) return MLPK_ESHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MLPK_BF16) {
+        hipLaunchKernelGGL((norm_shift_vec_kernel<bf16_t>), dim3(grid_for(total / 8)), dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out_w,
+                           (bf16_t*)out_h, N, H, W, C, kernel_size, mean, rstd, gamma, beta, act);
+    } else {
+        hipLaunchKernelGGL((norm_shift_vec_kernel<f16_t>), dim3(grid_for(total / 8)), dim3(256), 0, s, (const f16_t*)in, (f16_t*)out_w,
+                           (f16_t*)out_h, N, H, W, C, kernel_size, mean, rstd, gamma, beta, act);
+    }
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mlpk_cycle_shift(int dtype, const void* in, void* out_h, void* out_w, int B, int H, int W, int C, int k, int ldi,
+                                int ldo, void* stream) {
+    if (!in || (!out_h && !out_w)) return MLPK_ENULL;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || ldi < C || ldo < C) return MLPK_ESHAPE;
+    if (k < 1 || !(k & 1)) return MLPK_ESHAPE;
+    if (in == out_h || in == out_w) return MLPK_ESHAPE;         // a gather cannot run in place
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t total = (int64_t)B * H * W * C;
+    const bool vec = dtype != MLPK_F32 && C % 8 == 0 && ldi % 8 == 0 && ldo % 8 == 0 && total / 8 < 0x7fffffffLL && (k == 3 || k == 5 || k == 7) &&
+                     (((uintptr_t)in | (uintptr_t)out_h | (uintptr_t)out_w) & 15) == 0;
+    if (vec) {
+        const dim3 grid(grid_for(total / 8));
+        if (k == 3) {
+            DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((cycle_shift_vec_kernel<T, 3>), grid, dim3(256), 0, s, (const T*)in, (T*)out_h, (T*)out_w, B, H, W, C, ldi, ldo));
+        } else if (k == 5) {
+            DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((cycle_shift_vec_kernel<T, 5>), grid, dim3(256), 0, s, (const T*)in, (T*)out_h, (T*)out_w, B, H, W, C, ldi, ldo));
+        } else {
+            DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((cycle_shift_vec_kernel<T, 7>), grid, dim3(256), 0, s, (const T*)in, (T*)out_h, (T*)out_w, B, H, W, C, ldi, ldo));
+        }
+    } else {
+        DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((cycle_shift_kernel<T>), dim3(grid_for(total)), dim3(256), 0, s, (const T*)in, (T*)out_h,
+                                                 (T*)out_w, B, H, W, C, k, k, ldi, ldo));
+    }
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
 // 8-channel vectors are usable when no vector straddles two S2 shift groups (quarters of C) and all
 // three branch pointers / strides keep 16-byte alignment (16-bit dtypes; fp32 keeps the scalar kernels)
 static bool split_vec_ok(const void* x0, const void* x1, const void* x2, int ld0, int ld1, int ld2, int C, int mode) {
@@ -436,16 +623,16 @@ static int split_check(const void* x0, const void* x1, const void* x2, int ld0, 
 }
 
 extern "C" int mlpk_split_sum(int dtype, const void* x0, const void* x1, const void* x2, int ld0, int ld1, int ld2,
-                              int B, int H, int W, int C, int shift_mode, float* a, void* stream) {
+                              int B, int H, int W, int C, int shift_mode, float scale, float* a, void* stream) {
     if (int e = split_check(x0, x1, x2, ld0, ld1, ld2, B, H, W, C, shift_mode)) return e;
     if (!a) return MLPK_ENULL;
     SplitArgs p{x0, x1, x2, ld0, ld1, ld2, B, H, W, C, shift_mode};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)B, (unsigned)((C + 63) / 64));
     if (dtype != MLPK_F32 && split_vec_ok(x0, x1, x2, ld0, ld1, ld2, C, shift_mode)) {
-        DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((split_sum_vec_kernel<T>), grid, dim3(256), 0, s, p, a));
+        DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((split_sum_vec_kernel<T>), grid, dim3(256), 0, s, p, a, scale));
     } else {
-        DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((split_sum_kernel<T>), grid, dim3(256), 0, s, p, a));
+        DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((split_sum_kernel<T>), grid, dim3(256), 0, s, p, a, scale));
     }
     MLPK_LAUNCH_CHECK();
     return 0;

@@ -119,7 +119,7 @@ def gemm_workspace(device):
 
 def gemm(A, B, C, M, Nn, K, *, lda=None, ldb=None, ldc=None, bias=None, act=N.ACT_NONE, cscale=None, cshift=None,
          rscale=None, rperiod=0, R=None, ldr=None, res=N.RES_NONE, out_mode=N.OUT_ROWMAJOR, t_rows=0, t_tokens=0,
-         algo=0, tag=None, dbg=0, ln=None):
+         algo=0, tag=None, dbg=0, ln=None, ln_group=1):
     if tag is not None and algo == 0:
         algo = GEMM_ALGO.get(tag, 0)
     timed = TIMER is not None and tag is not None
@@ -137,6 +137,7 @@ def gemm(A, B, C, M, Nn, K, *, lda=None, ldb=None, ldc=None, bias=None, act=N.AC
     d.bias, d.cscale, d.cshift, d.rscale = ptr(bias), ptr(cscale), ptr(cshift), ptr(rscale)
     if ln is not None:                                   # (mean[M], rstd[M], csum[N]) of a folded LayerNorm
         d.ln_mean, d.ln_rstd, d.ln_csum = ptr(ln[0]), ptr(ln[1]), ptr(ln[2])
+        d.ln_group = ln_group
     d.rperiod, d.act, d.res_mode, d.out_mode = rperiod, act, res, out_mode
     d.t_rows, d.t_tokens, d.algo = t_rows, t_tokens, algo
     d.reserved = dbg
@@ -236,9 +237,19 @@ def shift_nhwc(x, out, n, h, w, c, kernel_size, dim):
             "mlpk_shift_nhwc")
 
 
-def split_sum(x0, x1, x2, ld0, ld1, ld2, B, H, W, C, mode, a):
+def norm_shift_nhwc(x, out_w, out_h, n, h, w, c, kernel_size, mean, rstd, gamma, beta, act):
+    N.check(N.lib().mlpk_norm_shift_nhwc(dtype_code(x.dtype), ptr(x), ptr(out_w), ptr(out_h), n, h, w, c, kernel_size, ptr(mean), ptr(rstd),
+                                         ptr(gamma), ptr(beta), act, stream()), "mlpk_norm_shift_nhwc")
+
+
+def cycle_shift(x, out_h, out_w, B, H, W, C, k, ldi, ldo):
+    N.check(N.lib().mlpk_cycle_shift(dtype_code(x.dtype), ptr(x), ptr(out_h), ptr(out_w), B, H, W, C, k, ldi, ldo, stream()),
+            "mlpk_cycle_shift")
+
+
+def split_sum(x0, x1, x2, ld0, ld1, ld2, B, H, W, C, mode, a, scale=1.0):
     N.check(N.lib().mlpk_split_sum(dtype_code(x0.dtype), ptr(x0), ptr(x1), ptr(x2), ld0, ld1, ld2, B, H, W, C, mode,
-                                   ptr(a), stream()), "mlpk_split_sum")
+                                   scale, ptr(a), stream()), "mlpk_split_sum")
 
 
 def split_softmax(hat, bar, B, C):

@@ -184,9 +184,15 @@ class AS_MLP(E.EngineModule):
         if pe.norm is not None:
             pk["embed.g"], pk["embed.be"] = _gn_params(pe.norm, device)
 
-        def conv(prefix, c):
-            pk[prefix + ".w"] = E.pack_matrix(c.weight, dtype, device)
-            pk[prefix + ".b"] = E.f32(c.bias, device) if c.bias is not None else None
+        def conv(prefix, c, norm=None):
+            """1x1 conv as a GEMM weight; `norm` = the GroupNorm(1,C) in front of it, folded in (gamma into the weights,
+            beta into the bias, the per-sample mean / rstd applied on the accumulator, ln_group = H*W)."""
+            if norm is None:
+                pk[prefix + ".w"] = E.pack_matrix(c.weight, dtype, device)
+                pk[prefix + ".b"] = E.f32(c.bias, device) if c.bias is not None else None
+            else:
+                g, b = _gn_params(norm, device)
+                pk[prefix + ".w"], pk[prefix + ".b"], pk[prefix + ".csum"] = E.pack_ln_folded(c.weight, c.bias, g, b, dtype, device)
 
         for li, layer in enumerate(self.layers):
             for bi, blk in enumerate(layer.blocks):
@@ -198,10 +204,13 @@ class AS_MLP(E.EngineModule):
                 pk[p + "an1.g"], pk[p + "an1.b"] = _gn_params(a.norm1, device)
                 pk[p + "an2.g"], pk[p + "an2.b"] = _gn_params(a.norm2, device)
                 conv(p + "fc1", blk.mlp.fc1), conv(p + "fc2", blk.mlp.fc2)
+                # the same three convolutions with the GroupNorm in front of them folded in (16-bit fast path)
+                conv(p + "c1f", a.conv1, blk.norm1), conv(p + "c3f", a.conv3, a.norm2), conv(p + "fc1f", blk.mlp.fc1, blk.norm2)
             if layer.downsample is not None:
                 p = "l%d.down." % li
                 pk[p + "g"], pk[p + "b"] = _gn_params(layer.downsample.norm, device)
                 pk[p + "w"] = E.pack_matrix(layer.downsample.reduction.weight, dtype, device)
+                conv(p + "f", layer.downsample.reduction, layer.downsample.norm)
         pk["norm.g"], pk["norm.b"] = _gn_params(self.norm, device)
         if isinstance(self.head, nn.Linear):
             pk["head.w"] = E.pack_matrix(self.head.weight, dtype, device)
@@ -245,8 +254,37 @@ class AS_MLP(E.EngineModule):
             hid = int(C * self.mlp_ratio)
             hbuf = ws.get("l%d.h" % li, (rows, hid))
             tag = "l%d.gn" % li
+            # 16-bit fast path: a GroupNorm(1,C) in front of a 1x1 conv is folded into that GEMM (per-sample statistics on the
+            # accumulator, ln_group = H*W rows per statistic), and AxialShift's GroupNorm -> GELU -> two shifts is ONE
+            # index-remapping pass that writes both shifted operands directly (t itself is never stored): per block 5
+            # statistics passes, 1 normalise+shift pass and 6 GEMMs instead of 5 + 5 + 2 + 6 kernels.  fp32 and shapes the
+            # remap kernel does not take (channel groups narrower than 8) keep the unfused sequence.
+            fused = cd != torch.float32 and C % 8 == 0 and (C + self._shift - 1) // self._shift >= 8
+            mean = ws.get(tag + ".mean", (B,), torch.float32)
+            rstd = ws.get(tag + ".rstd", (B,), torch.float32)
+
+            def stats(t, width):
+                E.row_stats(t, B, HW * width, HW * width, mean, rstd)
+
             for bi in range(len(layer.blocks)):
                 p = "l%d.b%d." % (li, bi)
+                if fused:
+                    stats(cur, C)
+                    E.gemm(cur, pk[p + "c1f.w"], t1, rows, C, C, bias=pk[p + "c1f.b"], ln=(mean, rstd, pk[p + "c1f.csum"]), ln_group=HW,
+                           tag="as_conv")                                                            # conv1(norm1(x))
+                    stats(t1, C)
+                    E.norm_shift_nhwc(t1, t0, t2, B, H, W, C, self._shift, mean, rstd, pk[p + "an1.g"], pk[p + "an1.b"], N.ACT_GELU)
+                    E.gemm(t0, pk[p + "c21.w"], t1, rows, C, C, bias=pk[p + "c21.b"], act=N.ACT_GELU, tag="as_conv")      # x_lr (W shift)
+                    E.gemm(t2, pk[p + "c22.w"], t1, rows, C, C, bias=pk[p + "c22.b"], act=N.ACT_GELU, R=t1, res=N.RES_ADD,
+                           tag="as_conv")                                                            # gelu(.) + x_lr (H shift)
+                    stats(t1, C)
+                    E.gemm(t1, pk[p + "c3f.w"], cur, rows, C, C, bias=pk[p + "c3f.b"], ln=(mean, rstd, pk[p + "c3f.csum"]), ln_group=HW,
+                           R=cur, res=N.RES_ADD, tag="as_conv")                                      # x + conv3(norm2(.))
+                    stats(cur, C)
+                    E.gemm(cur, pk[p + "fc1f.w"], hbuf, rows, hid, C, bias=pk[p + "fc1f.b"], act=N.ACT_GELU,
+                           ln=(mean, rstd, pk[p + "fc1f.csum"]), ln_group=HW, tag="as_fc1")
+                    E.gemm(hbuf, pk[p + "fc2.w"], cur, rows, C, hid, bias=pk[p + "fc2.b"], R=cur, res=N.RES_ADD, tag="as_fc2")
+                    continue
                 self._gn(ws, tag, cur, B, HW, C, pk[p + "n1.g"], pk[p + "n1.b"], t0)                 # norm1(x)
                 E.gemm(t0, pk[p + "c1.w"], t1, rows, C, C, bias=pk[p + "c1.b"], tag="as_conv")       # conv1
                 self._gn(ws, tag, t1, B, HW, C, pk[p + "an1.g"], pk[p + "an1.b"], t1, act=N.ACT_GELU)  # GN -> GELU
@@ -266,9 +304,16 @@ class AS_MLP(E.EngineModule):
                 H2, W2 = H // 2, W // 2
                 merged = ws.get("l%d.merged" % li, (B * H2 * W2, 4 * C))
                 E.patchify(cur, merged, B, C, H, W, 2, 2, 0, 4 * C, layout=N.LAYOUT_NHWC, px_stride=C, order=1)
-                self._gn(ws, "l%d.gnm" % li, merged, B, H2 * W2, 4 * C, pk[p + "g"], pk[p + "b"], merged)
                 nxt = ws.get("l%d.x" % (li + 1), (B * H2 * W2, 2 * C))
-                E.gemm(merged, pk[p + "w"], nxt, B * H2 * W2, 2 * C, 4 * C, tag="as_merge")
+                if cd != torch.float32:
+                    mm = ws.get("l%d.gnm.mean" % li, (B,), torch.float32)
+                    mr = ws.get("l%d.gnm.rstd" % li, (B,), torch.float32)
+                    E.row_stats(merged, B, H2 * W2 * 4 * C, H2 * W2 * 4 * C, mm, mr)
+                    E.gemm(merged, pk[p + "f.w"], nxt, B * H2 * W2, 2 * C, 4 * C, bias=pk[p + "f.b"], ln=(mm, mr, pk[p + "f.csum"]),
+                           ln_group=H2 * W2, tag="as_merge")
+                else:
+                    self._gn(ws, "l%d.gnm" % li, merged, B, H2 * W2, 4 * C, pk[p + "g"], pk[p + "b"], merged)
+                    E.gemm(merged, pk[p + "w"], nxt, B * H2 * W2, 2 * C, 4 * C, tag="as_merge")
                 cur, H, W, C = nxt, H2, W2, 2 * C
         mean = ws.get("final.mean", (B,), torch.float32)
         rstd = ws.get("final.rstd", (B,), torch.float32)

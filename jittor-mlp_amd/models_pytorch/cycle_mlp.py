@@ -1,0 +1,317 @@
+"""CycleMLP, drop-in for the reference's models_pytorch/cycle_mlp.py: same classes, constructor
+signatures, state_dict keys (CycleFC's `offset` buffer included) and CycleMLP_B1..B5 factories, classification head.
+
+CycleFC (cycle_mlp.py:54-131) hands torchvision's deform_conv2d a 1 x 1 kernel and a FIXED integer offset per input channel
+(gen_offset, :104-120): channel c is sampled d(c) = (c + k/2) % k - k/2 pixels away along W (`sfc_h`, kernel (1,3)) or along H
+(`sfc_w`, kernel (3,1)); bilinear sampling at an integer point is the pixel itself, or 0 outside the map.  So the operator is a
+per-channel cyclic pixel shift with zero fill followed by a 1 x 1 convolution: mlpk_cycle_shift writes both gathered copies
+of LN(x) in one pass, the convolutions are NT GEMMs.  (torchvision is absent from this image: the sampling rule is restated
+from its published algorithm, oracle/functional.py, "parity unpinned" against torchvision itself.)
+
+CycleMLP block (:147-175) on channel-last rows (B*H*W, C):
+  h, w, c   = three GEMMs on shift_W(xn), shift_H(xn), xn
+  a         = mean over pixels of (h + w + c)        mlpk_split_sum with scale 1 / (H W)
+  reweight  = Mlp(C -> C/4 -> 3C), fp32, B rows; its output index is c*3 + k (reshape(B, C, 3), :170): fc2's rows are
+              permuted to k*C + c once when packed, so the softmax / weighted sum kernels of ViP / S2-MLPv2 apply as they are
+  x        += proj(h a0 + w a1 + c a2)               mlpk_split_apply, GEMM with the residual in its epilogue
+then the channel MLP with its LayerNorm folded into fc1.  PatchEmbedOverlapping (7x7 stride 4 pad 2, :261) and Downsample
+(3x3 stride 2 pad 1, :220-231) are window gathers (mlpk_im2col) + GEMM; the final LayerNorm is folded into the token mean.
+"""
+import math
+
+import torch
+from torch import nn
+from torch.nn import init
+
+from .. import _native as N
+from .. import engine as E
+from .common import Holder, channel_mlp, head_linear, layernorm_stats, pack_channel_mlp
+from .utils import pair
+
+
+class Mlp(Holder):
+    """cycle_mlp.py:35-51."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+
+
+class CycleFC(Holder):
+    """cycle_mlp.py:54-145: parameters and the registered `offset` buffer; same argument checks."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True):
+        super().__init__()
+        if in_channels % groups != 0:
+            raise ValueError('in_channels must be divisible by groups')
+        if out_channels % groups != 0:
+            raise ValueError('out_channels must be divisible by groups')
+        if stride != 1:
+            raise ValueError('stride must be 1')
+        if padding != 0:
+            raise ValueError('padding must be 0')
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = kernel_size
+        self.stride = pair(stride)
+        self.padding = pair(padding)
+        self.dilation = pair(dilation)
+        self.groups = groups
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels // groups, 1, 1))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.register_buffer('offset', self.gen_offset())
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in, _ = init._calculate_fan_in_and_fan_out(self.weight)
+            bound = 1 / math.sqrt(fan_in)
+            init.uniform_(self.bias, -bound, bound)
+
+    def gen_offset(self):
+        """(1, 2 * in_channels, 1, 1): (dy, dx) per input channel (cycle_mlp.py:104-120)."""
+        offset = torch.empty(1, self.in_channels * 2, 1, 1)
+        start_idx = (self.kernel_size[0] * self.kernel_size[1]) // 2
+        assert self.kernel_size[0] == 1 or self.kernel_size[1] == 1, self.kernel_size
+        for i in range(self.in_channels):
+            if self.kernel_size[0] == 1:
+                offset[0, 2 * i + 0, 0, 0] = 0
+                offset[0, 2 * i + 1, 0, 0] = (i + start_idx) % self.kernel_size[1] - (self.kernel_size[1] // 2)
+            else:
+                offset[0, 2 * i + 0, 0, 0] = (i + start_idx) % self.kernel_size[0] - (self.kernel_size[0] // 2)
+                offset[0, 2 * i + 1, 0, 0] = 0
+        return offset
+
+    def extra_repr(self):
+        return '%d, %d, kernel_size=%s' % (self.in_channels, self.out_channels, (self.kernel_size,))
+
+
+class CycleMLP(Holder):
+    """cycle_mlp.py:147-158."""
+
+    def __init__(self, dim, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        self.mlp_c = nn.Linear(dim, dim, bias=qkv_bias)
+        self.sfc_h = CycleFC(dim, dim, (1, 3), 1, 0)
+        self.sfc_w = CycleFC(dim, dim, (3, 1), 1, 0)
+        self.reweight = Mlp(dim, dim // 4, dim * 3)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+
+
+class CycleBlock(Holder):
+    """cycle_mlp.py:178-197 (DropPath is the identity on the forward path built here)."""
+
+    def __init__(self, dim, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0., drop_path=0., act_layer=nn.GELU,
+                 norm_layer=nn.LayerNorm, skip_lam=1.0, mlp_fn=CycleMLP):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = mlp_fn(dim, qkv_bias=qkv_bias, qk_scale=None, attn_drop=attn_drop)
+        self.drop_path = nn.Identity()
+        self.norm2 = norm_layer(dim)
+        mlp_hidden_dim = int(dim * mlp_ratio)
+        self.mlp = Mlp(in_features=dim, hidden_features=mlp_hidden_dim, act_layer=act_layer)
+        self.skip_lam = skip_lam
+
+
+class PatchEmbedOverlapping(Holder):
+    """cycle_mlp.py:200-217."""
+
+    def __init__(self, patch_size=16, stride=16, padding=0, in_chans=3, embed_dim=768, norm_layer=None, groups=1):
+        super().__init__()
+        patch_size, stride, padding = pair(patch_size), pair(stride), pair(padding)
+        self.patch_size = patch_size
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=stride, padding=padding, groups=groups)
+        self.norm = norm_layer(embed_dim) if norm_layer else nn.Identity()
+
+
+class Downsample(Holder):
+    """cycle_mlp.py:220-231."""
+
+    def __init__(self, in_embed_dim, out_embed_dim, patch_size):
+        super().__init__()
+        assert patch_size == 2, patch_size
+        self.proj = nn.Conv2d(in_embed_dim, out_embed_dim, kernel_size=(3, 3), stride=(2, 2), padding=1)
+
+
+def basic_blocks(dim, index, layers, mlp_ratio=3., qkv_bias=False, qk_scale=None, attn_drop=0., drop_path_rate=0., skip_lam=1.0,
+                 mlp_fn=CycleMLP, **kwargs):
+    """cycle_mlp.py:234-245."""
+    blocks = []
+    for block_idx in range(layers[index]):
+        block_dpr = drop_path_rate * (block_idx + sum(layers[:index])) / (sum(layers) - 1)
+        blocks.append(CycleBlock(dim, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, drop_path=block_dpr,
+                                 skip_lam=skip_lam, mlp_fn=mlp_fn))
+    return nn.Sequential(*blocks)
+
+
+class CycleNet(E.EngineModule):
+    """Same signature as the reference (cycle_mlp.py:248-256).  fork_feat (dense-prediction feature pyramid) is not on the
+    classification path and is not built."""
+
+    def __init__(self, layers, img_size=224, patch_size=4, in_chans=3, num_classes=1000, embed_dims=None, transitions=None,
+                 segment_dim=None, mlp_ratios=None, skip_lam=1.0, qkv_bias=False, qk_scale=None, drop_rate=0., attn_drop_rate=0.,
+                 drop_path_rate=0., norm_layer=nn.LayerNorm, mlp_fn=CycleMLP, fork_feat=False):
+        super().__init__()
+        if fork_feat:
+            raise NotImplementedError("fork_feat=True (feature pyramid outputs) is not built; classification head only")
+        self.num_classes = num_classes
+        self.fork_feat = fork_feat
+        self.patch_embed = PatchEmbedOverlapping(patch_size=7, stride=4, padding=2, in_chans=3, embed_dim=embed_dims[0])
+        network = []
+        for i in range(len(layers)):
+            network.append(basic_blocks(embed_dims[i], i, layers, mlp_ratio=mlp_ratios[i], qkv_bias=qkv_bias, qk_scale=qk_scale,
+                                        attn_drop=attn_drop_rate, drop_path_rate=drop_path_rate, norm_layer=norm_layer,
+                                        skip_lam=skip_lam, mlp_fn=mlp_fn))
+            if i >= len(layers) - 1:
+                break
+            if transitions[i] or embed_dims[i] != embed_dims[i + 1]:
+                network.append(Downsample(embed_dims[i], embed_dims[i + 1], 2 if transitions[i] else 1))
+        self.network = nn.ModuleList(network)
+        self.norm = norm_layer(embed_dims[-1])
+        self.head = nn.Linear(embed_dims[-1], num_classes) if num_classes > 0 else nn.Identity()
+        self.apply(self.cls_init_weights)
+
+    def cls_init_weights(self, m):
+        """cycle_mlp.py:296-306."""
+        if isinstance(m, nn.Linear):
+            init.trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+        elif isinstance(m, CycleFC):
+            init.trunc_normal_(m.weight, std=.02)
+            nn.init.constant_(m.bias, 0)
+
+    def get_classifier(self):
+        return self.head
+
+    # ------------------------------------------------------------------ packing
+    def _pack(self, dtype, device):
+        pk = {}
+        conv = self.patch_embed.proj
+        pk["embed.w"] = E.pack_matrix(conv.weight, dtype, device)
+        pk["embed.b"] = E.f32(conv.bias, device)
+        for si, stage in enumerate(self.network):
+            if isinstance(stage, Downsample):
+                w = stage.proj.weight
+                pk["n%d.w" % si] = E.pack_matrix(w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1), dtype, device)   # (i, j, ci)
+                pk["n%d.b" % si] = E.f32(stage.proj.bias, device)
+                continue
+            for bi, blk in enumerate(stage):
+                p = "n%d.b%d." % (si, bi)
+                att = blk.attn
+                C = att.proj.weight.shape[0]
+                lam = 1.0 / float(blk.skip_lam)
+                pk[p + "ln.g"], pk[p + "ln.b"] = E.f32(blk.norm1.weight, device), E.f32(blk.norm1.bias, device)
+                pk[p + "h.w"] = E.pack_matrix(att.sfc_h.weight, dtype, device)
+                pk[p + "h.b"] = E.f32(att.sfc_h.bias, device)
+                pk[p + "w.w"] = E.pack_matrix(att.sfc_w.weight, dtype, device)
+                pk[p + "w.b"] = E.f32(att.sfc_w.bias, device)
+                pk[p + "c.w"] = E.pack_matrix(att.mlp_c.weight, dtype, device)
+                pk[p + "c.b"] = E.f32(att.mlp_c.bias, device)
+                pk[p + "r1.w"] = E.pack_matrix(att.reweight.fc1.weight, torch.float32, device)
+                pk[p + "r1.b"] = E.f32(att.reweight.fc1.bias, device)
+                w2 = att.reweight.fc2.weight.detach()                                               # rows c*3 + k -> k*C + c
+                pk[p + "r2.w"] = E.pack_matrix(w2.reshape(C, 3, -1).permute(1, 0, 2).reshape(3 * C, -1), torch.float32, device)
+                pk[p + "r2.b"] = E.f32(att.reweight.fc2.bias.detach().reshape(C, 3).t().reshape(-1), device)
+                pk[p + "p.w"] = E.pack_matrix(att.proj.weight.detach() * lam, dtype, device)
+                pk[p + "p.b"] = E.f32(att.proj.bias.detach() * lam, device)
+                pack_channel_mlp(pk, p + "ff.", blk.norm2, blk.mlp.fc1, blk.mlp.fc2, dtype, device)
+                if lam != 1.0:
+                    pk[p + "ff.fc2.w"] = E.pack_matrix(blk.mlp.fc2.weight.detach() * lam, dtype, device)
+                    pk[p + "ff.fc2.b"] = E.f32(blk.mlp.fc2.bias.detach() * lam, device)
+        pk["head.g"], pk["head.be"] = E.f32(self.norm.weight, device), E.f32(self.norm.bias, device)
+        if isinstance(self.head, nn.Linear):
+            pk["head.w"] = E.pack_matrix(self.head.weight, dtype, device)
+            pk["head.b"] = E.f32(self.head.bias, device)
+        return pk
+
+    # ------------------------------------------------------------------ forward
+    def _block(self, ws, pk, p, cur, B, H, W, C, hidden, tag):
+        rows = B * H * W
+        mean, rstd = layernorm_stats(ws, cur, rows, C, tag=tag + ".ln")
+        xn = ws.get(tag + ".xn", (rows, C))
+        E.norm_apply(cur, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "ln.g"], beta=pk[p + "ln.b"], out_rm=xn, ld_rm=C)
+        sh, sw = ws.get(tag + ".sh", (rows, C)), ws.get(tag + ".sw", (rows, C))
+        E.cycle_shift(xn, sh, sw, B, H, W, C, 3, C, C)
+        th, tw, tc = ws.get(tag + ".th", (rows, C)), ws.get(tag + ".tw", (rows, C)), ws.get(tag + ".tc", (rows, C))
+        E.gemm(sh, pk[p + "h.w"], th, rows, C, C, bias=pk[p + "h.b"], tag="cycle_fc")
+        E.gemm(sw, pk[p + "w.w"], tw, rows, C, C, bias=pk[p + "w.b"], tag="cycle_fc")
+        E.gemm(xn, pk[p + "c.w"], tc, rows, C, C, bias=pk[p + "c.b"], tag="cycle_c")
+        # reweight: mean over pixels -> Mlp -> softmax over the three branches (fp32, B rows)
+        a = ws.get(tag + ".a", (B, C), torch.float32)
+        E.split_sum(th, tw, tc, C, C, C, B, H, W, C, N.SHIFT_NONE, a, scale=1.0 / (H * W))
+        hid = pk[p + "r1.w"].shape[0]
+        hp = pk[p + "r2.w"].shape[1]                                   # hidden padded to whole 16-byte chunks (zero columns)
+        t = ws.get(tag + ".t", (B, hp), torch.float32)
+        E.gemm(a, pk[p + "r1.w"], t, B, hid, C, ldc=hp, bias=pk[p + "r1.b"], act=N.ACT_GELU)
+        hat = ws.get(tag + ".hat", (B, 3 * C), torch.float32)
+        E.gemm(t, pk[p + "r2.w"], hat, B, 3 * C, hp, bias=pk[p + "r2.b"])
+        bar = ws.get(tag + ".bar", (B, 3 * C), torch.float32)
+        E.split_softmax(hat, bar, B, C)
+        m = ws.get(tag + ".m", (rows, C))
+        E.split_apply(th, tw, tc, C, C, C, B, H, W, C, N.SHIFT_NONE, bar, m, C)
+        E.gemm(m, pk[p + "p.w"], cur, rows, C, C, bias=pk[p + "p.b"], R=cur, res=N.RES_ADD, tag="cycle_proj")
+        channel_mlp(ws, cur, rows, C, pk, p + "ff.", hidden, tag=tag + ".cm")
+
+    def forward(self, x):
+        cd = self._resolve(x)
+        B, cin, H_in, W_in = x.shape
+        pk = self._get_pack(cd, x.device)
+        ws = self._get_space(B, cd, x.device)
+        x = x.contiguous()
+        C = pk["embed.w"].shape[0]
+        H, W = (H_in + 4 - 7) // 4 + 1, (W_in + 4 - 7) // 4 + 1
+        kp = pk["embed.w"].shape[1]
+        patches = ws.get("embed.patches", (B * H * W, kp))
+        E.im2col(x, patches, B, cin, H_in, W_in, 7, 7, 4, 4, 2, kp)
+        cur = ws.get("n0.x", (B * H * W, C))
+        E.gemm(patches, pk["embed.w"], cur, B * H * W, C, kp, bias=pk["embed.b"])
+        for si, stage in enumerate(self.network):
+            if isinstance(stage, Downsample):
+                Cout = pk["n%d.w" % si].shape[0]
+                H2, W2 = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+                kp = pk["n%d.w" % si].shape[1]
+                cols = ws.get("n%d.cols" % si, (B * H2 * W2, kp))
+                E.im2col(cur, cols, B, C, H, W, 3, 3, 2, 2, 1, kp, layout=N.LAYOUT_NHWC, px_stride=C)
+                nxt = ws.get("n%d.x" % (si + 1), (B * H2 * W2, Cout))
+                E.gemm(cols, pk["n%d.w" % si], nxt, B * H2 * W2, Cout, kp, bias=pk["n%d.b" % si], tag="cycle_down")
+                cur, H, W, C = nxt, H2, W2, Cout
+                continue
+            for bi, blk in enumerate(stage):
+                self._block(ws, pk, "n%d.b%d." % (si, bi), cur, B, H, W, C, blk.mlp.fc1.weight.shape[0], "n%d" % si)
+        mean, rstd = layernorm_stats(ws, cur, B * H * W, C, tag="head.ln")
+        pooled = ws.get("pooled", (B, C))
+        E.pool_mean(cur, B, H * W, C, C, pooled, C, mean=mean, rstd=rstd, gamma=pk["head.g"], beta=pk["head.be"])
+        if not isinstance(self.head, nn.Linear):
+            out = torch.empty((B, C), dtype=x.dtype, device=x.device)
+            E.convert(pooled, out, B * C)
+            return out
+        return head_linear(ws, pooled, B, C, pk["head.w"], pk["head.b"], self.num_classes, x.dtype)
+
+
+def _factory(layers, mlp_ratios, embed_dims):
+    def make(pretrained=False, **kwargs):
+        return CycleNet(layers, embed_dims=embed_dims, patch_size=7, transitions=[True, True, True, True], mlp_ratios=mlp_ratios,
+                        mlp_fn=CycleMLP, **kwargs)
+    return make
+
+
+# cycle_mlp.py:352-410
+CycleMLP_B1 = _factory([2, 2, 4, 2], [4, 4, 4, 4], [64, 128, 320, 512])
+CycleMLP_B2 = _factory([2, 3, 10, 3], [4, 4, 4, 4], [64, 128, 320, 512])
+CycleMLP_B3 = _factory([3, 4, 18, 3], [8, 8, 4, 4], [64, 128, 320, 512])
+CycleMLP_B4 = _factory([3, 8, 27, 3], [8, 8, 4, 4], [64, 128, 320, 512])
+CycleMLP_B5 = _factory([3, 4, 24, 3], [4, 4, 4, 4], [96, 192, 384, 768])

@@ -760,3 +760,120 @@ def swinmlp_forward(sd, x, num_heads=(3, 6, 12, 24), window_size=7, hooks=None):
         layer += 1
     t = layer_norm(t, _p(sd, "norm.weight", x), _p(sd, "norm.bias", x)).mean(dim=1)
     return linear(t, _p(sd, "head.weight", x), _p(sd, "head.bias", x))
+
+
+# --------------------------------------------------------------------------
+# CycleMLP  (cycle_mlp.py:54-350)  -- SURVEY.md 8(f) rank 3
+# --------------------------------------------------------------------------
+# cycle_mlp.py:14 takes `deform_conv2d` from torchvision.ops.deform_conv, a dependency that is ABSENT from this image
+# and not pinned by the reference (no requirements file; README.md:182 names only the import).  Its published algorithm
+# (torchvision/csrc/ops/cpu/deform_conv2d_kernel.cpp, deformable_im2col + bilinear_interpolate; docs of
+# torchvision.ops.deform_conv2d): with weight (Cout, Cin/groups, kh, kw), offset (B, 2 * G_off * kh * kw, Ho, Wo) holding
+# (dy, dx) pairs per offset group and kernel point, out[b,o,y,x] = bias[o] + sum_{c,i,j} W[o,c,i,j] *
+# bilinear(in[b,c], y*s - p + i*d + dy, x*s - p + j*d + dx), where bilinear() is zero for a sample point at or beyond
+# one pixel outside the map (h <= -1 or h >= H, likewise w) and takes each of the four corners only when it lies inside.
+# `deform_conv2d_pointwise_loop` below restates exactly that for the only case CycleFC uses (1 x 1 kernel, stride 1, no
+# padding, one offset group per input channel) with an explicit per-element loop; `cycle_fc` is the vectorised form for
+# CycleFC's integer offsets (a per-channel shifted gather with zero fill followed by a 1 x 1 convolution), and
+# tests/test_oracle_golden.py checks the two against each other.  CycleFC is therefore "parity unpinned" against
+# torchvision itself; everything around it is pinned by running the reference's own module code (make_golden.py).
+def _bilinear_zero(img, h, w):
+    """torchvision's bilinear_interpolate on one (H, W) plane at a real-valued point."""
+    hh, ww = img.shape
+    if h <= -1 or h >= hh or w <= -1 or w >= ww:
+        return img.new_zeros(())
+    h_low, w_low = int(math.floor(h)), int(math.floor(w))
+    h_high, w_high = h_low + 1, w_low + 1
+    lh, lw = h - h_low, w - w_low
+    hhg, hw = 1 - lh, 1 - lw
+    v1 = img[h_low, w_low] if (h_low >= 0 and w_low >= 0) else 0.0
+    v2 = img[h_low, w_high] if (h_low >= 0 and w_high <= ww - 1) else 0.0
+    v3 = img[h_high, w_low] if (h_high <= hh - 1 and w_low >= 0) else 0.0
+    v4 = img[h_high, w_high] if (h_high <= hh - 1 and w_high <= ww - 1) else 0.0
+    return hhg * hw * v1 + hhg * lw * v2 + lh * hw * v3 + lh * lw * v4
+
+
+def deform_conv2d_pointwise_loop(inp, offset, weight, bias=None):
+    """deform_conv2d for a 1 x 1 kernel, stride 1, padding 0, dilation 1, groups 1 and one offset group per input channel
+    (offset: (B or 1, 2*Cin, H or 1, W or 1), (dy, dx) interleaved), as an explicit loop over every output element
+    (small inputs only).  cycle_mlp.py:126-131."""
+    bsz, cin, hh, ww = inp.shape
+    cout = weight.shape[0]
+    off = offset.expand(bsz, 2 * cin, hh, ww)
+    wmat = weight.reshape(cout, cin)
+    cols = inp.new_zeros((bsz, cin, hh, ww))
+    for b in range(bsz):
+        for c in range(cin):
+            for y in range(hh):
+                for x in range(ww):
+                    dy, dx = float(off[b, 2 * c, y, x]), float(off[b, 2 * c + 1, y, x])
+                    cols[b, c, y, x] = _bilinear_zero(inp[b, c], y + dy, x + dx)
+    out = torch.einsum("oc,bchw->bohw", wmat, cols)
+    if bias is not None:
+        out = out + bias.view(1, -1, 1, 1)
+    return out
+
+
+def cycle_offsets(channels, kernel_size):
+    """CycleFC.gen_offset (cycle_mlp.py:104-120): per input channel i the integer (dy, dx)."""
+    kh, kw = kernel_size
+    assert kh == 1 or kw == 1
+    start = (kh * kw) // 2
+    dy = [0 if kh == 1 else (i + start) % kh - kh // 2 for i in range(channels)]
+    dx = [(i + start) % kw - kw // 2 if kh == 1 else 0 for i in range(channels)]
+    return dy, dx
+
+
+def cycle_fc(x, weight, bias, kernel_size):
+    """CycleFC.forward on NCHW x (cycle_mlp.py:122-131): channel i is read at (y + dy_i, x + dx_i), zero outside the map,
+    then a 1 x 1 convolution."""
+    bsz, cin, hh, ww = x.shape
+    dy, dx = cycle_offsets(cin, kernel_size)
+    g = torch.zeros_like(x)
+    for i in range(cin):
+        ys0, ys1 = max(0, -dy[i]), min(hh, hh - dy[i])
+        xs0, xs1 = max(0, -dx[i]), min(ww, ww - dx[i])
+        if ys1 > ys0 and xs1 > xs0:
+            g[:, i, ys0:ys1, xs0:xs1] = x[:, i, ys0 + dy[i]:ys1 + dy[i], xs0 + dx[i]:xs1 + dx[i]]
+    return conv1x1(g, weight.reshape(weight.shape[0], cin), bias)
+
+
+def cyclemlp_attn(sd, x, pre):
+    """CycleMLP.forward on channel-last x (B,H,W,C) (cycle_mlp.py:160-175)."""
+    bsz, hh, ww, c = x.shape
+    xc = x.permute(0, 3, 1, 2)
+    h = cycle_fc(xc, _p(sd, pre + "sfc_h.weight", x), _p(sd, pre + "sfc_h.bias", x), (1, 3)).permute(0, 2, 3, 1)
+    w = cycle_fc(xc, _p(sd, pre + "sfc_w.weight", x), _p(sd, pre + "sfc_w.bias", x), (3, 1)).permute(0, 2, 3, 1)
+    cc = linear(x, _p(sd, pre + "mlp_c.weight", x), _opt(sd, pre + "mlp_c.bias", x))
+    a = (h + w + cc).mean(dim=(1, 2))                                                              # (B, C)
+    a = linear(gelu(linear(a, _p(sd, pre + "reweight.fc1.weight", x), _p(sd, pre + "reweight.fc1.bias", x))),
+               _p(sd, pre + "reweight.fc2.weight", x), _p(sd, pre + "reweight.fc2.bias", x))       # (B, 3C), index c*3 + k
+    a = torch.softmax(a.reshape(bsz, c, 3), dim=2)                                                 # softmax over k (:170)
+    t = h * a[:, :, 0].view(bsz, 1, 1, c) + w * a[:, :, 1].view(bsz, 1, 1, c) + cc * a[:, :, 2].view(bsz, 1, 1, c)
+    return linear(t, _p(sd, pre + "proj.weight", x), _p(sd, pre + "proj.bias", x))
+
+
+def cyclemlp_forward(sd, x, hooks=None):
+    """CycleNet.forward (cycle_mlp.py:322-350) in eval mode, classification head (fork_feat False), skip_lam 1."""
+    x = x.detach().cpu()
+    t = conv2d_im2col(x, _p(sd, "patch_embed.proj.weight", x), _p(sd, "patch_embed.proj.bias", x), 4, 2)   # 7x7 s4 p2 (:261)
+    idx = 0
+    while True:
+        if ("network.%d.0.norm1.weight" % idx) in sd:                                             # a stage of CycleBlocks
+            for i in range(_depth(sd, "network.%d" % idx + ".%d.norm1.weight")):
+                pre = "network.%d.%d." % (idx, i)
+                n = layer_norm(t, _p(sd, pre + "norm1.weight", x), _p(sd, pre + "norm1.bias", x))
+                t = t + cyclemlp_attn(sd, n, pre + "attn.")
+                n = layer_norm(t, _p(sd, pre + "norm2.weight", x), _p(sd, pre + "norm2.bias", x))
+                hdn = gelu(linear(n, _p(sd, pre + "mlp.fc1.weight", x), _p(sd, pre + "mlp.fc1.bias", x)))
+                t = t + linear(hdn, _p(sd, pre + "mlp.fc2.weight", x), _p(sd, pre + "mlp.fc2.bias", x))
+                if hooks is not None:
+                    hooks("network.%d.%d" % (idx, i), t)
+        elif ("network.%d.proj.weight" % idx) in sd:                                              # Downsample 3x3 s2 p1 (:220-231)
+            t = conv2d_im2col(t.permute(0, 3, 1, 2), _p(sd, "network.%d.proj.weight" % idx, x), _p(sd, "network.%d.proj.bias" % idx, x), 2, 1)
+        else:
+            break
+        idx += 1
+    t = layer_norm(t, _p(sd, "norm.weight", x), _p(sd, "norm.bias", x))
+    t = t.reshape(t.shape[0], -1, t.shape[-1]).mean(dim=1)
+    return linear(t, _p(sd, "head.weight", x), _p(sd, "head.bias", x))

@@ -68,6 +68,11 @@ def portable_state_dict(shapes, seed=0):
         stem = key[: -len(leaf) - 1] if "." in key else ""
         if leaf == "num_batches_tracked":
             out[key] = np.zeros(shape, dtype=np.int64)
+        elif leaf == "offset" and stem.rsplit(".", 1)[-1] in ("sfc_h", "sfc_w"):
+            # CycleFC's registered buffer (cycle_mlp.py:95, 104-120) is structure, not a weight: its fixed integer pattern
+            from .functional import cycle_offsets
+            dy, dx = cycle_offsets(shape[1] // 2, (1, 3) if stem.endswith("sfc_h") else (3, 1))
+            out[key] = np.array([v for pr in zip(dy, dx) for v in pr], dtype=np.float32).reshape(shape)
         elif leaf == "running_mean":
             out[key] = portable_tensor(key, shape, -0.1, 0.1, seed)
         elif leaf == "running_var":

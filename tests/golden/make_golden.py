@@ -35,6 +35,35 @@ import oracle  # noqa: E402
 from oracle.portable_init import portable_input, portable_state_dict  # noqa: E402
 
 
+# ---------------------------------------------------------------- torchvision stand-in (absent dependency)
+def deform_conv2d_vec(input, offset, weight, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1), mask=None):
+    """torchvision.ops.deform_conv2d restated (published algorithm: deformable_im2col + bilinear_interpolate with zero
+    padding) for 1 x 1 kernels, stride 1, no padding, groups 1 -- all cycle_mlp.py:126-131 uses -- with REAL-valued
+    offsets, vectorised.  offset: (B, 2 * G, H, W), (dy, dx) per offset group; G must divide Cin."""
+    assert tuple(stride) == (1, 1) and tuple(padding) == (0, 0) and mask is None and weight.shape[2:] == (1, 1)
+    bsz, cin, hh, ww = input.shape
+    g = offset.shape[1] // 2
+    cpg = cin // g
+    dy = offset[:, 0::2].repeat_interleave(cpg, dim=1).expand(bsz, cin, hh, ww)
+    dx = offset[:, 1::2].repeat_interleave(cpg, dim=1).expand(bsz, cin, hh, ww)
+    ys = torch.arange(hh, dtype=input.dtype).view(1, 1, hh, 1) + dy
+    xs = torch.arange(ww, dtype=input.dtype).view(1, 1, 1, ww) + dx
+    inside = (ys > -1) & (ys < hh) & (xs > -1) & (xs < ww)
+    y0, x0 = torch.floor(ys), torch.floor(xs)
+    ly, lx = ys - y0, xs - x0
+    flat = input.reshape(bsz, cin, hh * ww)
+
+    def corner(yi, xi, wgt):
+        ok = inside & (yi >= 0) & (yi <= hh - 1) & (xi >= 0) & (xi <= ww - 1)
+        idx = (yi.clamp(0, hh - 1) * ww + xi.clamp(0, ww - 1)).long().reshape(bsz, cin, hh * ww)
+        v = torch.gather(flat, 2, idx).reshape(bsz, cin, hh, ww)
+        return torch.where(ok, v * wgt, torch.zeros_like(v))
+
+    cols = corner(y0, x0, (1 - ly) * (1 - lx)) + corner(y0, x0 + 1, (1 - ly) * lx) + corner(y0 + 1, x0, ly * (1 - lx)) + corner(y0 + 1, x0 + 1, ly * lx)
+    out = torch.einsum("oc,bchw->bohw", weight.reshape(weight.shape[0], cin), cols)
+    return out if bias is None else out + bias.view(1, -1, 1, 1)
+
+
 # ---------------------------------------------------------------- reference shim
 def load_reference():
     pkg = types.ModuleType("models_pytorch")
@@ -61,8 +90,23 @@ def load_reference():
     tl.to_2tuple = lambda v: v if isinstance(v, (tuple, list)) else (v, v)
     tl.trunc_normal_ = torch.nn.init.trunc_normal_
     sys.modules["timm"], sys.modules["timm.models"], sys.modules["timm.models.layers"] = timm, tm, tl
+    # cycle_mlp.py additionally touches timm.data (two constants), timm.models.registry (a decorator),
+    # timm.models.layers.helpers (to_2tuple) and torchvision.ops.deform_conv.deform_conv2d.  torchvision is ABSENT here
+    # and unpinned by the reference; its deform_conv2d is restated from the published algorithm (deform_conv2d_vec
+    # below, checked against the explicit per-element loop of oracle.deform_conv2d_pointwise_loop on fractional offsets),
+    # so the CycleMLP fixtures pin the reference's MODULE code around it, not torchvision itself.
+    td = types.ModuleType("timm.data")
+    td.IMAGENET_DEFAULT_MEAN, td.IMAGENET_DEFAULT_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    tr = types.ModuleType("timm.models.registry")
+    tr.register_model = lambda f: f
+    th = types.ModuleType("timm.models.layers.helpers")
+    th.to_2tuple = tl.to_2tuple
+    sys.modules["timm.data"], sys.modules["timm.models.registry"], sys.modules["timm.models.layers.helpers"] = td, tr, th
+    tv, tvo, tvd = types.ModuleType("torchvision"), types.ModuleType("torchvision.ops"), types.ModuleType("torchvision.ops.deform_conv")
+    tvd.deform_conv2d = deform_conv2d_vec
+    sys.modules["torchvision"], sys.modules["torchvision.ops"], sys.modules["torchvision.ops.deform_conv"] = tv, tvo, tvd
     mods = {}
-    for name in ("mlp_mixer", "g_mlp", "res_mlp", "vip", "s2_mlp_v1", "s2_mlp_v2", "conv_mixer", "as_mlp", "sparse_mlp", "hire_mlp", "ms_mlp", "swin_mlp"):
+    for name in ("mlp_mixer", "g_mlp", "res_mlp", "vip", "s2_mlp_v1", "s2_mlp_v2", "conv_mixer", "as_mlp", "sparse_mlp", "hire_mlp", "ms_mlp", "swin_mlp", "cycle_mlp"):
         mods[name] = importlib.import_module("models_pytorch." + name)
     sc = importlib.import_module("models_pytorch.utils.shift_cuda")
     sc.Shift.forward = lambda self, x: x if self.kernel_size == 1 else sc.torch_shift(x, self.kernel_size, self.dim)
@@ -174,6 +218,14 @@ def tiny_configs(ref):
         "swinmlp": dict(ctor=ref["swin_mlp"].SwinMLP, kw=dict(img_size=64, patch_size=4, embed_dim=16, depths=[2, 2], num_heads=[2, 4], window_size=4, num_classes=10),
                         hw=(64, 64), pins=["layers.0.blocks.1", "layers.1.blocks.0"],
                         oracle=lambda sd, x, kw: oracle.swinmlp_forward(sd, x, kw["num_heads"], kw["window_size"])),
+        # CycleMLP (cycle_mlp.py): CycleNet has no size defaults -- tiny configurations in the style of its CycleMLP_B* factories
+        "cyclemlp": dict(ctor=ref["cycle_mlp"].CycleNet, kw=dict(layers=[1, 2], embed_dims=[16, 32], transitions=[True, True], mlp_ratios=[2, 4],
+                                                                  mlp_fn=None, num_classes=10),
+                         hw=(64, 64), pins=["network.0.0", "network.2.1"], oracle=lambda sd, x, kw: oracle.cyclemlp_forward(sd, x)),
+        # odd map sizes (48 x 80 -> 12 x 20 -> 6 x 10 -> 3 x 5), qkv_bias, channel widths that are no multiple of 3
+        "cyclemlp_rect": dict(ctor=ref["cycle_mlp"].CycleNet, kw=dict(layers=[1, 1, 1], embed_dims=[8, 16, 40], transitions=[True, True, True],
+                                                                       mlp_ratios=[4, 2, 2], mlp_fn=None, qkv_bias=True, num_classes=10),
+                              hw=(48, 80), pins=["network.4.0"], oracle=lambda sd, x, kw: oracle.cyclemlp_forward(sd, x)),
         # window larger than the last stage's map (no partition, :94-97), mlp_ratio 2, no patch norm
         "swinmlp_small": dict(ctor=ref["swin_mlp"].SwinMLP, kw=dict(img_size=48, patch_size=4, embed_dim=8, depths=[2, 1], num_heads=[1, 2], window_size=6, mlp_ratio=2.,
                                                                      num_classes=10, patch_norm=False),
@@ -214,11 +266,20 @@ def real_configs(ref):
         "msmlp_t": dict(ctor=ref["ms_mlp"].MS_MLP, kw=dict(), bs=2, oracle=lambda sd, x, kw: oracle.msmlp_forward(sd, x)),
         # the reference's default Swin-MLP (embed 96, depths [2,2,6,2], heads [3,6,12,24], window 7)
         "swinmlp_t": dict(ctor=ref["swin_mlp"].SwinMLP, kw=dict(), bs=2, oracle=lambda sd, x, kw: oracle.swinmlp_forward(sd, x)),
+        # CycleMLP-B1 (cycle_mlp.py:352-361): layers [2,2,4,2], dims [64,128,320,512], mlp_ratio 4
+        "cyclemlp_b1": dict(ctor=ref["cycle_mlp"].CycleMLP_B1, kw=dict(), bs=2, oracle=lambda sd, x, kw: oracle.cyclemlp_forward(sd, x)),
     }
 
 
 def _jsonable(kw):
-    return json.dumps({k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()})
+    return json.dumps({k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items() if k != "mlp_fn"})
+
+
+def ctor_kw(ref, kw):
+    """`mlp_fn=None` in a config stands for the reference's CycleMLP class (not JSON-serialisable)."""
+    if "mlp_fn" in kw:
+        kw = dict(kw, mlp_fn=ref["cycle_mlp"].CycleMLP)
+    return kw
 
 
 def run_ref(model, x, one_thread):
@@ -246,7 +307,7 @@ def make_tiny(ref, names=None):
         if names and name not in names:
             continue
         torch.manual_seed(0)
-        model = cfg["ctor"](**cfg["kw"]).eval()
+        model = cfg["ctor"](**ctor_kw(ref, cfg["kw"])).eval()
         randomize_norm_stats(model, 1)
         if "gamma" in cfg:          # layer-scale parameters start at 1e-6 (ms_mlp.py:43): make the blocks visible in the logits
             with torch.no_grad():
@@ -467,14 +528,15 @@ def make_manifest(ref):
         "ConvMixer": ref["conv_mixer"].ConvMixer, "AS_MLP": ref["as_mlp"].AS_MLP, "Shift": ref["shift_cuda"].Shift,
         "MLPMixer": ref["mlp_mixer"].MLPMixer, "gMLP": ref["g_mlp"].gMLP, "ResMLP": ref["res_mlp"].ResMLP,
         "WeightedPermutator": ref["vip"].WeightedPermutator, "Permutator": ref["vip"].Permutator,
-        "S2Block": ref["s2_mlp_v2"].S2Block, "SparseMLP": ref["sparse_mlp"].SparseMLP, "HireMLP": ref["hire_mlp"].HireMLP, "MS_MLP": ref["ms_mlp"].MS_MLP, "SwinMLP": ref["swin_mlp"].SwinMLP,
+        "S2Block": ref["s2_mlp_v2"].S2Block, "CycleNet": ref["cycle_mlp"].CycleNet, "CycleFC": ref["cycle_mlp"].CycleFC, "CycleMLP": ref["cycle_mlp"].CycleMLP,
+        "CycleBlock": ref["cycle_mlp"].CycleBlock, "SparseMLP": ref["sparse_mlp"].SparseMLP, "HireMLP": ref["hire_mlp"].HireMLP, "MS_MLP": ref["ms_mlp"].MS_MLP, "SwinMLP": ref["swin_mlp"].SwinMLP,
     }
     for name, c in ctors.items():
         sig = inspect.signature(c)
         man["signatures"][name] = [[p.name, repr(p.default) if p.default is not inspect._empty else None, str(p.kind)]
-                                   for p in sig.parameters.values() if p.name != "norm_layer"]
+                                   for p in sig.parameters.values() if p.name not in ("norm_layer", "mlp_fn")]
     for name, cfg in list(real_configs(ref).items()) + [("tiny_" + k, v) for k, v in tiny_configs(ref).items()]:
-        model = cfg["ctor"](**cfg["kw"])
+        model = cfg["ctor"](**ctor_kw(ref, cfg["kw"]))
         man["state_dicts"][name] = {"kwargs": json.loads(_jsonable(cfg["kw"])), "ctor": cfg["ctor"].__name__,
                                     "n_params": sum(p.numel() for p in model.parameters()),
                                     "keys": [[k, list(v.shape)] for k, v in model.state_dict().items()]}

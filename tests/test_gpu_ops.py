@@ -368,16 +368,35 @@ def test_gemm_p8_pingpong_tile(dtype):
         B = rnd((Nn, K), dtype, 310 + ci, 1.0 / math.sqrt(K)).to(dev())
         bias = rnd((Nn,), torch.float32, 320 + ci).to(dev())
         R = rnd((M, Nn), dtype, 330 + ci).to(dev())
-        ref = gemm_ref(A.cpu(), B.cpu(), M, Nn, K, bias=bias.cpu(), act=1, R=R.cpu(), res=1)
+        # GELU + residual is served by the LDS-staged epilogue (256-row tiles): other heights are exercised without the residual
+        res = M % 256 == 0
+        ref = gemm_ref(A.cpu(), B.cpu(), M, Nn, K, bias=bias.cpu(), act=1, R=R.cpu() if res else None, res=1 if res else 0)
         for dbg in (0, 16, 64, 128):           # mixed heights | 256-row tiles + one short panel | staged epilogue | one column group
+            if dbg == 64 and M % 256:
+                with pytest.raises(N.MlpkError):
+                    E.gemm(A, B, torch.empty((M, Nn), dtype=dtype, device=dev()), M, Nn, K, bias=bias, act=1, algo=14, dbg=dbg)
+                continue
             C = torch.full((M, Nn), float("nan"), dtype=dtype, device=dev())
-            E.gemm(A, B, C, M, Nn, K, bias=bias, act=1, R=R, res=1, algo=14, dbg=dbg)
+            E.gemm(A, B, C, M, Nn, K, bias=bias, act=1, R=R if res else None, res=1 if res else 0, algo=14, dbg=dbg)
             torch.cuda.synchronize()
             got = C.cpu().double()
             assert torch.isfinite(got).all(), (ci, dbg, "non-finite")
             err = (got - ref).abs().max().item()
             tol = EPS[dtype] * max(1.0, ref.abs().max().item()) * 4
             assert err < tol, (str(dtype), ci, dbg, err, tol)
+    # bias + residual without activation = the direct epilogue's residual form (channel fc2), every tile height
+    for ci, (M, Nn, nslab) in enumerate([(64, 256, 2), (192, 512, 3), (320, 256, 4), (256 * 9 + 128, 768, 6)]):
+        K = nslab * 64
+        A = rnd((M, K), dtype, 340 + ci).to(dev())
+        B = rnd((Nn, K), dtype, 350 + ci, 1.0 / math.sqrt(K)).to(dev())
+        bias = rnd((Nn,), torch.float32, 360 + ci).to(dev())
+        R = rnd((M, Nn), dtype, 370 + ci).to(dev())
+        C = torch.full((M, Nn), float("nan"), dtype=dtype, device=dev())
+        E.gemm(A, B, C, M, Nn, K, bias=bias, R=R, res=1, algo=14)
+        torch.cuda.synchronize()
+        ref = gemm_ref(A.cpu(), B.cpu(), M, Nn, K, bias=bias.cpu(), R=R.cpu(), res=1)
+        err = (C.cpu().double() - ref).abs().max().item()
+        assert err < EPS[dtype] * max(1.0, ref.abs().max().item()) * 4, (str(dtype), "res", ci, err)
     z = lambda *sh: torch.zeros(sh, dtype=dtype, device=dev())
     for (M, Nn, K) in ((64, 256, 64), (64, 256, 160), (100, 256, 128), (64, 200, 128)):      # one slab / ragged slab / ragged M / ragged N
         with pytest.raises(N.MlpkError):
@@ -737,3 +756,28 @@ def test_row_stats_short_rows(dtype):
         var = ((xd - mu[:, None]) ** 2).mean(1)
         assert (mean.cpu().double() - mu).abs().max() < 1e-5, (str(dtype), ci)
         assert ((rstd.cpu().double() - 1 / torch.sqrt(var + 1e-6)).abs() * torch.sqrt(var + 1e-6)).max() < 1e-5, (str(dtype), ci)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_cycle_shift_bit_exact(dtype):
+    """mlpk_cycle_shift = the sampling half of CycleFC (cycle_mlp.py:104-131): a pure gather, bit-exact against the oracle's
+    per-channel shifted copy (itself checked against the explicit deform_conv2d loop); vector and scalar kernels, k = 3 / 5 / 7,
+    channel counts that are no multiple of the cycle, maps narrower than the cycle."""
+    pkg = load_pkg()
+    E = pkg.engine
+    for ci, (B, H, W, C, k) in enumerate(((2, 5, 7, 16, 3), (1, 14, 14, 64, 3), (2, 3, 4, 40, 5), (1, 2, 9, 24, 7), (2, 6, 5, 10, 3), (1, 1, 1, 8, 3))):
+        x = rnd((B, H, W, C), dtype, 1500 + ci)
+        xg = x.to(dev())
+        oh = torch.full((B, H, W, C), float("nan"), dtype=dtype, device=dev())
+        ow = torch.full((B, H, W, C), float("nan"), dtype=dtype, device=dev())
+        E.cycle_shift(xg, oh, ow, B, H, W, C, k, C, C)
+        torch.cuda.synchronize()
+        xc = x.permute(0, 3, 1, 2)
+        eye = torch.eye(C, dtype=x.dtype).reshape(C, C, 1, 1)
+        ref_h = oracle.cycle_fc(xc.float(), eye.float(), None, (1, k)).permute(0, 2, 3, 1)
+        ref_w = oracle.cycle_fc(xc.float(), eye.float(), None, (k, 1)).permute(0, 2, 3, 1)
+        assert torch.equal(oh.float().cpu(), ref_h), (str(dtype), ci)
+        assert torch.equal(ow.float().cpu(), ref_w), (str(dtype), ci)
+        only = torch.full((B, H, W, C), float("nan"), dtype=dtype, device=dev())
+        E.cycle_shift(xg, None, only, B, H, W, C, k, C, C)                      # one output only
+        assert torch.equal(only.float().cpu(), ref_w)

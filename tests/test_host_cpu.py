@@ -67,7 +67,7 @@ def test_constructor_signatures_match_reference():
             continue
         sig = inspect.signature(getattr(mods, name))
         mine = [[p.name, repr(p.default) if p.default is not inspect._empty else None, str(p.kind)]
-                for p in sig.parameters.values() if p.name != "norm_layer"]
+                for p in sig.parameters.values() if p.name not in ("norm_layer", "mlp_fn")]      # class-valued defaults: other module paths
         assert mine == ref_sig, (name, mine, ref_sig)
         checked += 1
     assert checked >= 3
