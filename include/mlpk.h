@@ -42,6 +42,7 @@
  *                       S2 spatial shifts (s2_mlp_v2.py:15-29) applied on load
  *   mlpk_split_softmax  softmax over the k=3 branches (vip.py:52-53)
  *   mlpk_split_apply    attention * x_all summed over k (vip.py:54-56), shifts applied on load
+ *   mlpk_vip_split_sum / _apply   the same two steps with the inverse ViP rearranges (vip.py:71,76) as load addresses
  *   mlpk_s2_shift       Spatial_Shift (s2_mlp_v1.py:19-25), out of place
  *   mlpk_dwconv_nhwc    depthwise Conv2d(k, groups=dim, padding="same") + GELU + BatchNorm(eval) + residual:
  *                       conv_mixer.py:5-11,24-28
@@ -278,6 +279,14 @@ int mlpk_split_softmax(const float* hat, float* bar, int B, int C, void* stream)
 int mlpk_split_apply(int dtype, const void* x0, const void* x1, const void* x2, int ld0, int ld1,
                      int ld2, int B, int H, int W, int C, int shift_mode, const float* bar,
                      void* out, int ldo, void* stream);
+/* ViP: the same reduction / weighted sum reading the H- and W-branch GEMM outputs WHERE THEY LIE (the layout of
+ * mlpk_vip_unpermute's input), so the inverse rearranges of vip.py:71,76 are never materialised:
+ *   xH[b,h,w,g*seg+q] = zh[((b*W + w)*G + g)*ldh + h*seg + q],  xW[b,h,w,g*seg+q] = zw[((b*H + h)*G + g)*ldw + w*seg + q],
+ *   xc row-major (B*H*W, ldc).  16-bit dtypes, C % 8 == 0, seg % 4 == 0, ldh % 4 == ldw % 4 == 0. */
+int mlpk_vip_split_sum(int dtype, const void* zh, const void* zw, const void* xc, int ldh, int ldw, int ldc, int B, int H,
+                       int W, int C, int seg, float scale, float* a, void* stream);
+int mlpk_vip_split_apply(int dtype, const void* zh, const void* zw, const void* xc, int ldh, int ldw, int ldc, int B, int H,
+                         int W, int C, int seg, const float* bar, void* out, int ldo, void* stream);
 /* S2-MLPv1 Spatial_Shift on (B,H,W,C), out of place, same shift_mode values (NONE = copy). */
 int mlpk_s2_shift(int dtype, const void* in, void* out, int B, int H, int W, int C, int ldi,
                   int ldo, int shift_mode, void* stream);

@@ -62,6 +62,8 @@ PROTOTYPES = {
     "mlpk_split_sum": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_float, c_void_p, c_void_p]),
     "mlpk_split_softmax": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "mlpk_split_apply": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p, c_void_p, c_int, c_void_p]),
+    "mlpk_vip_split_sum": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_float, c_void_p, c_void_p]),
+    "mlpk_vip_split_apply": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p, c_void_p, c_int, c_void_p]),
     "mlpk_s2_shift": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "mlpk_dwconv_nhwc": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p] * 4 + [c_void_p]),
     "mlpk_dwconv_affine_nhwc": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p] * 4 + [c_void_p]),

@@ -9,6 +9,7 @@
 //   * the residual comes from the same LDS tile; bias, exact GELU, BatchNorm(eval) scale/shift fused in the store.
 // Global traffic = x read once + out written once (the stencil re-reads stay in LDS).
 #include "mlpk_common.h"
+#include <stdlib.h>
 
 namespace mlpk {
 
@@ -276,6 +277,238 @@ extern "C" int mlpk_dwconv_affine_nhwc(int dtype, const void* x, void* out, int 
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Depthwise k x k convolution on the MATRIX pipe (16-bit dtypes, maps of up to 32 x 32 pixels: every ConvMixer of the
+// reference at 224^2 with patch >= 7).  For one channel and one tap row i the stencil is a banded-Toeplitz product: with the
+// input plane stored with a 4-pixel zero halo, a 16 x 16 block of outputs at (16 ty, 16 tx) is
+//     out[16ty + m][16tx + n] += sum_{kk < 32}  plane[16ty + m + i - P + 4][16tx + kk] * Tb_i[kk][n],    Tb_i[kk][n] = w[i][kk - 4 - n + P]
+// (zero outside 0 <= kk - 4 - n + P < k), i.e. v_mfma_f32_16x16x32 with A = 16 rows x 32 consecutive plane columns and a B
+// operand that depends on the tap row ONLY -- not on the block -- so one channel needs k fragments (4 registers each) and
+// 4 k MFMAs per 32 x 32 plane instead of k^2 = 81 VALU FMAs per output: 3.2x the arithmetic at 16x the rate, which takes the
+// kernel off the VALU wall (1.66 ms per ConvMixer-1536/20 layer, 39 TFLOP/s fp32) towards the HBM time of its 1.6 GB.
+// The taps are rounded to the activation dtype (they are MFMA operands); products and sums are fp32.
+//   * workgroup = 8 CPW channels (CPW = 4 for k <= 5: 64 contiguous bytes of every channel-last pixel; 3 for k = 7, 9: 48 bytes --
+//     what 256 registers hold) x a range of images; wave w owns channels CPW w .. and keeps their CPW k tap fragments in
+//     registers for the whole range;
+//   * LDS = 8 CPW planes (+ one all-zero plane for the fragment lanes that only meet zero taps) of [40 rows][40 columns] (80-byte rows: 16 consecutive rows fall on distinct banks for the 16-byte
+//     fragment reads), zeroed once; a plane is input AND output: when a channel's MFMAs are done its wave applies bias,
+//     exact GELU, BatchNorm scale / shift and the residual (the plane's own centre value) and writes the result in place;
+//   * between two images every thread stores its 4 pixel-pair chunks (8 channels x 2 pixels, two 16-byte stores) and puts the
+//     next image's chunks (prefetched into registers during the MFMA phase) into the SAME dwords -- no double buffer, two
+//     barriers per image.
+constexpr int DWM_PITCH = 80;
+constexpr int DWM_PLANE = 40 * DWM_PITCH;
+
+template <typename T> struct Mfma16;
+template <> struct Mfma16<bf16_t> {
+    static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mfma16<f16_t> {
+    static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+
+template <typename T, int KS, int CPW>
+__global__ void __launch_bounds__(512) dwconv_mfma_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int H, int W, int C,
+                                                          const float* __restrict__ w, const float* __restrict__ bias,
+                                                          const float* __restrict__ bns, const float* __restrict__ bnh, int img_per_wg) {
+    constexpr int P = KS / 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    constexpr int CG = 8 * CPW;                                     // channels per workgroup
+    const int c0 = blockIdx.x * CG;
+    const int b0 = blockIdx.y * img_per_wg;
+    const int b1 = b0 + img_per_wg < B ? b0 + img_per_wg : B;
+    if (b0 >= B) return;
+
+    for (int i = tid * 16; i < (CG + 1) * DWM_PLANE; i += 512 * 16) *reinterpret_cast<u32x4*>(smem + i) = u32x4{0u, 0u, 0u, 0u};
+
+    // ---- tap fragments: B operand of 16x16x32 = lane (n = lane & 15, kk = (lane >> 4) * 8 + e) ----
+    const int n = lane & 15;
+    const int kq = lane >> 4;
+    u32x4 tf[CPW][KS];
+    float bz[CPW], sc[CPW], sh[CPW];                                // wave-uniform: kept in SGPRs
+#pragma unroll
+    for (int j = 0; j < CPW; ++j) {
+        const int c = c0 + wave * CPW + j;
+        const bool live = c < C;
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            T e[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                // (unconditional loads from a clamped address + a select: no branch per tap)
+                const int d = kq * 8 + q - 4 - n + P;
+                const int dc = d < 0 ? 0 : (d >= KS ? KS - 1 : d);
+                const float tap = w[(size_t)(i * KS + dc) * C + (live ? c : C - 1)];
+                e[q] = from_f32<T>((live && d >= 0 && d < KS) ? tap : 0.f);
+            }
+            __builtin_memcpy(&tf[j][i], e, 16);
+        }
+        bz[j] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (live && bias) ? bias[c] : 0.f)));
+        sc[j] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (live && bns) ? bns[c] : 1.f)));
+        sh[j] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (live && bnh) ? bnh[c] : 0.f)));
+    }
+
+    // ---- staging slots of this thread: slot = tid + 512 q, q < CPW -> (pixel pair slot / CPW, 8-channel chunk slot % CPW):
+    // consecutive lanes move the consecutive chunks of one pixel pair ----
+    auto slot_of = [&](const int q, int& cq, int& yy, int& xx) {
+        const int slot = tid + 512 * q;
+        const int pp = slot / CPW;                                  // pixel pair 0 .. 511
+        cq = slot - pp * CPW;
+        yy = pp >> 4;
+        xx = (pp & 15) * 2;
+    };
+    u32x4 r0[CPW], r1[CPW];
+#pragma unroll
+    for (int q = 0; q < CPW; ++q) r0[q] = r1[q] = u32x4{0u, 0u, 0u, 0u};
+    auto gload = [&](const int b) {
+#pragma unroll
+        for (int q = 0; q < CPW; ++q) {
+            int cq, yy, xx;
+            slot_of(q, cq, yy, xx);
+            const bool cok = c0 + 8 * cq < C;                       // (C % 8 == 0: a chunk is whole or absent)
+            const T* src = x + (((size_t)b * H + yy) * W + xx) * C + c0 + 8 * cq;
+            if (cok && yy < H && xx < W) r0[q] = *reinterpret_cast<const u32x4*>(src);
+            if (cok && yy < H && xx + 1 < W) r1[q] = *reinterpret_cast<const u32x4*>(src + C);
+        }
+    };
+    auto lds_put = [&]() {
+#pragma unroll
+        for (int q = 0; q < CPW; ++q) {
+            int cq, yy, xx;
+            slot_of(q, cq, yy, xx);
+            if (!(c0 + 8 * cq < C && yy < H && xx < W)) continue;
+            char* dst = smem + (8 * cq) * DWM_PLANE + (yy + 4) * DWM_PITCH + (xx + 4) * 2;
+            const unsigned a[4] = {r0[q].x, r0[q].y, r0[q].z, r0[q].w}, bb[4] = {r1[q].x, r1[q].y, r1[q].z, r1[q].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // channels 2j, 2j+1 of both pixels: (px0.lo | px1.lo << 16), (px0.hi | px1.hi << 16)
+                *reinterpret_cast<unsigned*>(dst + (2 * j) * DWM_PLANE) = __builtin_amdgcn_perm(bb[j], a[j], 0x05040100);
+                *reinterpret_cast<unsigned*>(dst + (2 * j + 1) * DWM_PLANE) = __builtin_amdgcn_perm(bb[j], a[j], 0x07060302);
+            }
+        }
+    };
+    // fragment reads: lane = (row m = lane & 15, 8 columns at kq * 8); the last column group (kk >= 24) only meets zero taps and
+    // would run past the plane row for the right-hand blocks: it reads the zero halo row 0 instead
+    const int a_rd = kq < 3 ? (n + 4 - P) * DWM_PITCH + kq * 16 : 0;
+    const char* const zplane = smem + CG * DWM_PLANE;               // one more plane that is never written: all zeros
+
+    gload(b0);
+    __syncthreads();                                                // planes zeroed
+    lds_put();
+    for (int b = b0; b < b1; ++b) {
+        if (b + 1 < b1) gload(b + 1);
+        __syncthreads();                                            // image b is in the planes
+#pragma unroll
+        for (int j = 0; j < CPW; ++j) {
+            char* const plane = smem + (wave * CPW + j) * DWM_PLANE;
+            const char* const ab = (kq < 3 ? plane : zplane) + a_rd;
+            f32x4 res[2][2];
+            // the upper and the lower 16 rows one after the other (8 accumulators + two pairs of fragments live at a time)
+#pragma unroll
+            for (int ty = 0; ty < 2; ++ty) {
+                const char* const at = ab + ty * (16 * DWM_PITCH);
+                f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+                // one tap row ahead: the fragment reads of row i + 1 are in flight under the MFMAs of row i (pinned: left to
+                // itself hipcc hoists all the reads of a channel in front of its MFMAs and spills)
+                u32x4 av[2][2];
+                av[0][0] = *reinterpret_cast<const u32x4*>(at);
+                av[0][1] = *reinterpret_cast<const u32x4*>(at + 32);
+#pragma unroll
+                for (int i = 0; i < KS; ++i) {
+                    if (i + 1 < KS) {
+                        av[(i + 1) & 1][0] = *reinterpret_cast<const u32x4*>(at + (i + 1) * DWM_PITCH);
+                        av[(i + 1) & 1][1] = *reinterpret_cast<const u32x4*>(at + (i + 1) * DWM_PITCH + 32);
+                    }
+                    acc[0] = Mfma16<T>::run(av[i & 1][0], tf[j][i], acc[0]);
+                    acc[1] = Mfma16<T>::run(av[i & 1][1], tf[j][i], acc[1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // epilogue: acc[tx][r] = out[y = 16 ty + 4 kq + r][x = 16 tx + n]; results go back into the plane.  (The rows this
+                // half writes, 16 ty .. 16 ty + 15, are read again by the OTHER half's fragments only through tap rows that
+                // reach across the boundary -- so both halves' MFMAs must be done before any result is written: see below.)
+#pragma unroll
+                for (int tx = 0; tx < 2; ++tx) res[ty][tx] = acc[tx];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 a4 = res[t >> 1][t & 1];
+                float ctr[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int y = 16 * (t >> 1) + 4 * kq + r, xx = 16 * (t & 1) + n;
+                    ctr[r] = to_f32(*reinterpret_cast<const T*>(plane + (y + 4) * DWM_PITCH + (xx + 4) * 2));
+                }
+                f32x2 v[2] = {f32x2{a4.x + bz[j], a4.y + bz[j]}, f32x2{a4.z + bz[j], a4.w + bz[j]}};
+                gelu_pk_n<2>(v);
+                const float g[4] = {v[0].x, v[0].y, v[1].x, v[1].y};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int y = 16 * (t >> 1) + 4 * kq + r, xx = 16 * (t & 1) + n;
+                    if (y < H && xx < W)                            // never write outside the map: the halo must stay zero
+                        *reinterpret_cast<T*>(plane + (y + 4) * DWM_PITCH + (xx + 4) * 2) = from_f32<T>(ctr[r] + g[r] * sc[j] + sh[j]);
+                }
+            }
+        }
+        __syncthreads();                                            // results of image b are in the planes
+        // ---- results out (two 16-byte stores per slot), next image in (same dwords) ----
+#pragma unroll
+        for (int q = 0; q < CPW; ++q) {
+            int cq, yy, xx;
+            slot_of(q, cq, yy, xx);
+            if (!(c0 + 8 * cq < C && yy < H && xx < W)) continue;
+            const char* src = smem + (8 * cq) * DWM_PLANE + (yy + 4) * DWM_PITCH + (xx + 4) * 2;
+            unsigned d[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] = *reinterpret_cast<const unsigned*>(src + j * DWM_PLANE);
+            u32x4 o0, o1;
+            o0.x = __builtin_amdgcn_perm(d[1], d[0], 0x05040100); o1.x = __builtin_amdgcn_perm(d[1], d[0], 0x07060302);
+            o0.y = __builtin_amdgcn_perm(d[3], d[2], 0x05040100); o1.y = __builtin_amdgcn_perm(d[3], d[2], 0x07060302);
+            o0.z = __builtin_amdgcn_perm(d[5], d[4], 0x05040100); o1.z = __builtin_amdgcn_perm(d[5], d[4], 0x07060302);
+            o0.w = __builtin_amdgcn_perm(d[7], d[6], 0x05040100); o1.w = __builtin_amdgcn_perm(d[7], d[6], 0x07060302);
+            T* dstg = out + (((size_t)b * H + yy) * W + xx) * C + c0 + 8 * cq;
+            *reinterpret_cast<u32x4*>(dstg) = o0;
+            if (xx + 1 < W) *reinterpret_cast<u32x4*>(dstg + C) = o1;
+        }
+        if (b + 1 < b1) lds_put();
+    }
+}
+
+template <typename T>
+static int dwconv_mfma_launch(int k, const void* x, void* out, int B, int H, int W, int C, const float* w, const float* bias,
+                              const float* bns, const float* bnh, hipStream_t s) {
+    const int cpw = k <= 5 ? 4 : 3;                     // channels per wave: what the register file holds next to the tap fragments
+    const int cg = 8 * cpw;
+    // images per workgroup: enough to amortise the fragment build (about one image's worth of work), few enough to fill the chip
+    const int groups = (C + cg - 1) / cg;
+    int per = 32;
+    while (per > 4 && (long long)groups * ((B + per - 1) / per) < 512) per /= 2;
+    const dim3 grid((unsigned)groups, (unsigned)((B + per - 1) / per));
+    const int lds = (cg + 1) * DWM_PLANE;
+    hipError_t e = hipSuccess;
+#define DWM_CASE(KS, CPW)                                                                                              \
+    case KS: {                                                                                                         \
+        auto kern = dwconv_mfma_kernel<T, KS, CPW>;                                                                    \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        if (e != hipSuccess) return (int)e;                                                                            \
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, (const T*)x, (T*)out, B, H, W, C, w, bias, bns, bnh, per);    \
+        break;                                                                                                         \
+    }
+    switch (k) {
+        DWM_CASE(3, 4) DWM_CASE(5, 4) DWM_CASE(7, 3) DWM_CASE(9, 3)
+        default: return DW_NOFIT;
+    }
+#undef DWM_CASE
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int mlpk_dwconv_nhwc(int dtype, const void* x, void* out, int B, int H, int W, int C, int k, const float* w,
                                 const float* bias, const float* bn_scale, const float* bn_shift, void* stream) {
     if (!x || !out || !w) return MLPK_ENULL;
@@ -284,6 +517,13 @@ extern "C" int mlpk_dwconv_nhwc(int dtype, const void* x, void* out, int B, int 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int es = dtype == MLPK_F32 ? 4 : 2;
     const bool fast_ok = (C % (16 / es) == 0) && (((uintptr_t)x & 15) == 0) && B <= 0x7fffffff;
+    // matrix-pipe form: 16-bit dtypes, maps of up to 32 x 32, whole 8-channel groups (MLPK_DWCONV_NO_MFMA: tuning hook for A/B runs)
+    static const bool no_mfma = getenv("MLPK_DWCONV_NO_MFMA") != nullptr;
+    if (fast_ok && !no_mfma && es == 2 && H <= 32 && W <= 32 && C % 8 == 0 && (((uintptr_t)out & 15) == 0)) {
+        const int rc = dtype == MLPK_F16 ? dwconv_mfma_launch<f16_t>(k, x, out, B, H, W, C, w, bias, bn_scale, bn_shift, s)
+                                         : dwconv_mfma_launch<bf16_t>(k, x, out, B, H, W, C, w, bias, bn_scale, bn_shift, s);
+        if (rc != DW_NOFIT) return rc;
+    }
     if (fast_ok) {
         int rc;
         switch (dtype) {

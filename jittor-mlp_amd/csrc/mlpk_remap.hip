@@ -387,6 +387,118 @@ __global__ void __launch_bounds__(256) split_apply_vec_kernel(const SplitArgs p,
     }
 }
 
+// ================================ ViP: split attention straight on the permuted branch outputs ================================
+// vip.py:69-76: the H- and W-branch Linears run on rearranged rows, so their outputs come out as
+//   zh[((b*W + w)*G + g)*ldh + h*seg + q] = xH[b,h,w,g*seg + q]      zw[((b*H + h)*G + g)*ldw + w*seg + q] = xW[b,h,w,g*seg + q]
+// and the reference rearranges them back ('b w c (h s) -> b h w (c s)') before SplitAttention.  Here the inverse rearrange is the
+// ADDRESS of the load: the reduction and the weighted sum of SplitAttention read both tensors where they lie (with seg % 4 == 0
+// a lane's 8 channels are two 8-byte pieces of a permuted row), so neither xH nor xW is ever written in (B,H,W,C) order.
+template <typename T>
+__device__ __forceinline__ void vip_ld8(const T* __restrict__ z, const int ldz, const int64_t row0, const int G, const int seg, const int pos,
+                                        const int c, float (&v)[8]) {
+    // row0 = (b*W + w) * G (H branch, pos = h) or (b*H + h) * G (W branch, pos = w); channels c .. c+7, c % 8 == 0
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        const int cc = c + 4 * part;
+        const int g = cc / seg;
+        const int q = cc - g * seg;                                   // multiple of 4: the 4 channels stay inside group g
+        const u32x2 t = *reinterpret_cast<const u32x2*>(z + (row0 + g) * ldz + pos * seg + q);
+        T e[4];
+        __builtin_memcpy(e, &t, 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[4 * part + i] = to_f32(e[i]);
+    }
+}
+
+struct VipSplitArgs {
+    const void* zh;
+    const void* zw;
+    const void* xc;
+    int ldh, ldw, ldc;
+    int B, H, W, C, seg;
+};
+
+// a[b,c] = scale * sum over pixels of (xH + xW + xC)[b,h,w,c]; workgroup = (image, 64 channels), 32 pixel phases x 8 lanes x 8 channels
+template <typename T>
+__global__ void __launch_bounds__(256) vip_split_sum_kernel(const VipSplitArgs p, float* __restrict__ a, const float scale) {
+    __shared__ float red[32][64 + 1];
+    const int tid = threadIdx.x;
+    const int cl = (tid & 7) * 8;
+    const int ph = tid >> 3;
+    const int c = blockIdx.y * 64 + cl;
+    const int b = blockIdx.x;
+    const int G = p.C / p.seg;
+    const T* zh = reinterpret_cast<const T*>(p.zh);
+    const T* zw = reinterpret_cast<const T*>(p.zw);
+    const T* xc = reinterpret_cast<const T*>(p.xc);
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    if (c < p.C) {
+        const int npx = p.H * p.W;
+        for (int px = ph; px < npx; px += 32) {
+            const int h = px / p.W, w = px - h * p.W;
+            float v[8];
+            vip_ld8<T>(zh, p.ldh, ((int64_t)b * p.W + w) * G, G, p.seg, h, c, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += v[e];
+            vip_ld8<T>(zw, p.ldw, ((int64_t)b * p.H + h) * G, G, p.seg, w, c, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += v[e];
+            ld8<T>(xc + ((int64_t)b * npx + px) * p.ldc + c, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[ph][cl + e] = s[e];
+    __syncthreads();
+    if (tid < 64) {
+        const int cc = blockIdx.y * 64 + tid;
+        if (cc < p.C) {
+            float t = 0.f;
+#pragma unroll 8
+            for (int i = 0; i < 32; ++i) t += red[i][tid];
+            a[(int64_t)b * p.C + cc] = t * scale;
+        }
+    }
+}
+
+// out[b,h,w,c] = bar[b,0,c] xH + bar[b,1,c] xW + bar[b,2,c] xC
+template <typename T>
+__global__ void __launch_bounds__(256) vip_split_apply_kernel(const VipSplitArgs p, const float* __restrict__ bar, T* __restrict__ out, int ldo) {
+    const T* zh = reinterpret_cast<const T*>(p.zh);
+    const T* zw = reinterpret_cast<const T*>(p.zw);
+    const T* xc = reinterpret_cast<const T*>(p.xc);
+    const int cv = p.C / 8;
+    const int G = p.C / p.seg;
+    const int64_t total = (int64_t)p.B * p.H * p.W * cv;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c = (int)(idx % cv) * 8;
+        const int64_t px = idx / cv;
+        const int w = (int)(px % p.W);
+        const int h = (int)((px / p.W) % p.H);
+        const int64_t b = px / ((int64_t)p.H * p.W);
+        const float* wt = bar + b * 3 * p.C + c;
+        float w0[8], w1[8], w2[8], v0[8], v1[8], v2[8], o[8];
+#pragma unroll
+        for (int e = 0; e < 8; e += 4) {
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(wt + e);
+            const f32x4 t1 = *reinterpret_cast<const f32x4*>(wt + p.C + e);
+            const f32x4 t2 = *reinterpret_cast<const f32x4*>(wt + 2 * p.C + e);
+            w0[e] = t0.x; w0[e + 1] = t0.y; w0[e + 2] = t0.z; w0[e + 3] = t0.w;
+            w1[e] = t1.x; w1[e + 1] = t1.y; w1[e + 2] = t1.z; w1[e + 3] = t1.w;
+            w2[e] = t2.x; w2[e + 1] = t2.y; w2[e + 2] = t2.z; w2[e + 3] = t2.w;
+        }
+        vip_ld8<T>(zh, p.ldh, (b * p.W + w) * G, G, p.seg, h, c, v0);
+        vip_ld8<T>(zw, p.ldw, (b * p.H + h) * G, G, p.seg, w, c, v1);
+        ld8<T>(xc + px * p.ldc + c, v2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = w0[e] * v0[e] + w1[e] * v1[e] + w2[e] * v2[e];
+        st8<T>(out + px * ldo + c, o);
+    }
+}
+
 // ================================ AS-MLP: GroupNorm + GELU + both axial shifts in one pass ================================
 // as_mlp.py:64-66,84-95: t = gelu(GroupNorm(1,C)(conv1(x))) is only ever read through the two axial shifts (conv2_1 takes the
 // W-shifted, conv2_2 the H-shifted copy), so t itself is never stored: this kernel reads the conv1 output u once per output
@@ -664,6 +776,45 @@ extern "C" int mlpk_split_apply(int dtype, const void* x0, const void* x1, const
         DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((split_apply_kernel<T>), dim3(grid_for(total)), dim3(256), 0, s, p, bar,
                                                  (T*)out, ldo));
     }
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+static int vip_split_check(int dtype, const void* zh, const void* zw, const void* xc, int ldh, int ldw, int ldc, int B, int H, int W, int C,
+                           int seg) {
+    if (!zh || !zw || !xc) return MLPK_ENULL;
+    if (dtype != MLPK_F16 && dtype != MLPK_BF16) return MLPK_EDTYPE;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || seg <= 0 || C % seg) return MLPK_ESHAPE;
+    // 8-byte pieces: 4 channels never straddle a segment, every piece is 8-byte aligned
+    if (C % 8 || seg % 4 || ldh % 4 || ldw % 4 || ldc % 8 || ldh < H * seg || ldw < W * seg || ldc < C) return MLPK_ESHAPE;
+    if (((uintptr_t)zh | (uintptr_t)zw) & 7 || ((uintptr_t)xc & 15)) return MLPK_EALIGN;
+    return 0;
+}
+
+extern "C" int mlpk_vip_split_sum(int dtype, const void* zh, const void* zw, const void* xc, int ldh, int ldw, int ldc, int B, int H, int W,
+                                  int C, int seg, float scale, float* a, void* stream) {
+    if (int e = vip_split_check(dtype, zh, zw, xc, ldh, ldw, ldc, B, H, W, C, seg)) return e;
+    if (!a) return MLPK_ENULL;
+    VipSplitArgs p{zh, zw, xc, ldh, ldw, ldc, B, H, W, C, seg};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)B, (unsigned)((C + 63) / 64));
+    if (dtype == MLPK_BF16) hipLaunchKernelGGL((vip_split_sum_kernel<bf16_t>), grid, dim3(256), 0, s, p, a, scale);
+    else hipLaunchKernelGGL((vip_split_sum_kernel<f16_t>), grid, dim3(256), 0, s, p, a, scale);
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mlpk_vip_split_apply(int dtype, const void* zh, const void* zw, const void* xc, int ldh, int ldw, int ldc, int B, int H, int W,
+                                    int C, int seg, const float* bar, void* out, int ldo, void* stream) {
+    if (int e = vip_split_check(dtype, zh, zw, xc, ldh, ldw, ldc, B, H, W, C, seg)) return e;
+    if (!bar || !out) return MLPK_ENULL;
+    if (ldo < C || ldo % 8) return MLPK_ESHAPE;
+    if (((uintptr_t)out | (uintptr_t)bar) & 15) return MLPK_EALIGN;
+    VipSplitArgs p{zh, zw, xc, ldh, ldw, ldc, B, H, W, C, seg};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t total = (int64_t)B * H * W * C;
+    if (dtype == MLPK_BF16) hipLaunchKernelGGL((vip_split_apply_kernel<bf16_t>), dim3(grid_for(total / 8)), dim3(256), 0, s, p, bar, (bf16_t*)out, ldo);
+    else hipLaunchKernelGGL((vip_split_apply_kernel<f16_t>), dim3(grid_for(total / 8)), dim3(256), 0, s, p, bar, (f16_t*)out, ldo);
     MLPK_LAUNCH_CHECK();
     return 0;
 }

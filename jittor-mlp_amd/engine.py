@@ -261,6 +261,16 @@ def split_apply(x0, x1, x2, ld0, ld1, ld2, B, H, W, C, mode, bar, out, ldo):
                                      ptr(bar), ptr(out), ldo, stream()), "mlpk_split_apply")
 
 
+def vip_split_sum(zh, zw, xc, ldh, ldw, ldc, B, H, W, C, seg, a, scale=1.0):
+    N.check(N.lib().mlpk_vip_split_sum(dtype_code(zh.dtype), ptr(zh), ptr(zw), ptr(xc), ldh, ldw, ldc, B, H, W, C, seg, scale, ptr(a),
+                                       stream()), "mlpk_vip_split_sum")
+
+
+def vip_split_apply(zh, zw, xc, ldh, ldw, ldc, B, H, W, C, seg, bar, out, ldo):
+    N.check(N.lib().mlpk_vip_split_apply(dtype_code(zh.dtype), ptr(zh), ptr(zw), ptr(xc), ldh, ldw, ldc, B, H, W, C, seg, ptr(bar),
+                                         ptr(out), ldo, stream()), "mlpk_vip_split_apply")
+
+
 def s2_shift(x, out, B, H, W, C, ldi, ldo, mode):
     N.check(N.lib().mlpk_s2_shift(dtype_code(x.dtype), ptr(x), ptr(out), B, H, W, C, ldi, ldo, mode, stream()),
             "mlpk_s2_shift")

@@ -140,18 +140,34 @@ class _PermutatorBase(E.EngineModule):
             zw = ws.get("vip.zw", (B * H * G, ldzw))
             E.gemm(ph, pk[p + "h.w"], zh, B * W * G, hs, ldh, bias=pk[p + "h.b"], tag="vip_h")
             E.gemm(pw, pk[p + "w.w"], zw, B * H * G, wsz, ldw, bias=pk[p + "w.b"], tag="vip_w")
-            xh = ws.get("vip.xh", (rows, C))
-            xw = ws.get("vip.xw", (rows, C))
             xc = ws.get("vip.xc", (rows, C))
-            E.vip_unpermute(0, zh, xh, B, H, W, C, seg, ldzh)
-            E.vip_unpermute(1, zw, xw, B, H, W, C, seg, ldzw)
             E.gemm(xn, pk[p + "c.w"], xc, rows, C, C, bias=pk[p + "c.b"], tag="vip_c")
-            if self.weighted:
-                bar = split_attention_weights(ws, xh, xw, xc, C, C, C, B, H, W, C, N.SHIFT_NONE, pk[p + "sa.m1"], pk[p + "sa.m2"])
-            else:
-                bar = ws.get("vip.ones", (B, 3 * C), torch.float32, fill=1.0)     # plain sum (vip.py:16-22)
             m = ws.get("vip.m", (rows, C))
-            E.split_apply(xh, xw, xc, C, C, C, B, H, W, C, N.SHIFT_NONE, bar, m, C)
+            if x.dtype != torch.float32 and seg % 4 == 0 and C % 8 == 0:
+                # the inverse rearranges (vip.py:71,76) are load addresses of the split-attention kernels: xH / xW are never
+                # written back in (B,H,W,C) order (two full-tensor passes per block fewer)
+                if self.weighted:
+                    a = ws.get("sa.a", (B, C), torch.float32)
+                    E.vip_split_sum(zh, zw, xc, ldzh, ldzw, C, B, H, W, C, seg, a)
+                    t = ws.get("sa.t", (B, C), torch.float32)
+                    E.gemm(a, pk[p + "sa.m1"], t, B, C, C, act=N.ACT_GELU)
+                    hat = ws.get("sa.hat", (B, 3 * C), torch.float32)
+                    E.gemm(t, pk[p + "sa.m2"], hat, B, 3 * C, C)
+                    bar = ws.get("sa.bar", (B, 3 * C), torch.float32)
+                    E.split_softmax(hat, bar, B, C)
+                else:
+                    bar = ws.get("vip.ones", (B, 3 * C), torch.float32, fill=1.0)     # plain sum (vip.py:16-22)
+                E.vip_split_apply(zh, zw, xc, ldzh, ldzw, C, B, H, W, C, seg, bar, m, C)
+            else:
+                xh = ws.get("vip.xh", (rows, C))
+                xw = ws.get("vip.xw", (rows, C))
+                E.vip_unpermute(0, zh, xh, B, H, W, C, seg, ldzh)
+                E.vip_unpermute(1, zw, xw, B, H, W, C, seg, ldzw)
+                if self.weighted:
+                    bar = split_attention_weights(ws, xh, xw, xc, C, C, C, B, H, W, C, N.SHIFT_NONE, pk[p + "sa.m1"], pk[p + "sa.m2"])
+                else:
+                    bar = ws.get("vip.ones", (B, 3 * C), torch.float32, fill=1.0)     # plain sum (vip.py:16-22)
+                E.split_apply(xh, xw, xc, C, C, C, B, H, W, C, N.SHIFT_NONE, bar, m, C)
             E.gemm(m, pk[p + "proj.w"], x, rows, C, C, bias=pk[p + "proj.b"], R=x, res=N.RES_ADD, tag="vip_proj")
             channel_mlp(ws, x, rows, C, pk, p + "mlp.", C * ef)
         return x

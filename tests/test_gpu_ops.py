@@ -781,3 +781,36 @@ def test_cycle_shift_bit_exact(dtype):
         only = torch.full((B, H, W, C), float("nan"), dtype=dtype, device=dev())
         E.cycle_shift(xg, None, only, B, H, W, C, k, C, C)                      # one output only
         assert torch.equal(only.float().cpu(), ref_w)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_vip_split_attention_on_permuted_layout(dtype):
+    """mlpk_vip_split_sum / _apply read the H- and W-branch GEMM outputs where they lie (inverse rearranges of vip.py:71,76 as load
+    addresses): BIT-equal to unpermute + the plain split kernels, and the unpermute itself is pinned to the reference's einops
+    patterns by test_vip_permutes."""
+    pkg = load_pkg()
+    E, N = pkg.engine, pkg._native
+    for ci, (B, H, W, C, seg) in enumerate(((2, 4, 6, 32, 8), (1, 32, 32, 384, 12), (3, 5, 3, 64, 4), (2, 8, 8, 48, 24))):
+        G = C // seg
+        ldh, ldw = (H * seg + 7) // 8 * 8, (W * seg + 7) // 8 * 8
+        zh = rnd((B * W * G, ldh), dtype, 1600 + ci).to(dev())
+        zw = rnd((B * H * G, ldw), dtype, 1610 + ci).to(dev())
+        xc = rnd((B * H * W, C), dtype, 1620 + ci).to(dev())
+        bar = torch.softmax(rnd((B, 3, C), torch.float32, 1630 + ci), dim=1).reshape(B, 3 * C).contiguous().to(dev())
+        xh = torch.empty((B * H * W, C), dtype=dtype, device=dev())
+        xw = torch.empty((B * H * W, C), dtype=dtype, device=dev())
+        E.vip_unpermute(0, zh, xh, B, H, W, C, seg, ldh)
+        E.vip_unpermute(1, zw, xw, B, H, W, C, seg, ldw)
+        a_ref = torch.empty((B, C), dtype=torch.float32, device=dev())
+        a = torch.full((B, C), float("nan"), dtype=torch.float32, device=dev())
+        E.split_sum(xh, xw, xc, C, C, C, B, H, W, C, N.SHIFT_NONE, a_ref)
+        E.vip_split_sum(zh, zw, xc, ldh, ldw, C, B, H, W, C, seg, a)
+        m_ref = torch.empty((B * H * W, C), dtype=dtype, device=dev())
+        m = torch.full((B * H * W, C), float("nan"), dtype=dtype, device=dev())
+        E.split_apply(xh, xw, xc, C, C, C, B, H, W, C, N.SHIFT_NONE, bar, m_ref, C)
+        E.vip_split_apply(zh, zw, xc, ldh, ldw, C, B, H, W, C, seg, bar, m, C)
+        torch.cuda.synchronize()
+        assert torch.equal(a, a_ref), (str(dtype), ci)
+        assert torch.equal(m.view(torch.int16), m_ref.view(torch.int16)), (str(dtype), ci)
+    with pytest.raises(N.MlpkError):                                            # seg % 4 != 0 is refused (the host keeps the unfused path)
+        E.vip_split_sum(zh, zw, xc, ldh, ldw, C, 1, 2, 2, 12, 6, a)
