@@ -287,9 +287,8 @@ extern "C" int mlpk_dwconv_affine_nhwc(int dtype, const void* x, void* out, int 
 // 4 k MFMAs per 32 x 32 plane instead of k^2 = 81 VALU FMAs per output: 3.2x the arithmetic at 16x the rate, which takes the
 // kernel off the VALU wall (1.66 ms per ConvMixer-1536/20 layer, 39 TFLOP/s fp32) towards the HBM time of its 1.6 GB.
 // The taps are rounded to the activation dtype (they are MFMA operands); products and sums are fp32.
-//   * workgroup = 8 CPW channels (CPW = 4 for k <= 5: 64 contiguous bytes of every channel-last pixel; 3 for k = 7, 9: 48 bytes --
-//     what 256 registers hold) x a range of images; wave w owns channels CPW w .. and keeps their CPW k tap fragments in
-//     registers for the whole range;
+//   * workgroup = 8 waves x CPW channels (CPW = 4 for k <= 5: 64 contiguous bytes of every channel-last pixel; 3 for k = 7, 9) x a
+//     range of images; a wave keeps the CPW k tap fragments of its channels in registers for the whole range;
 //   * LDS = 8 CPW planes (+ one all-zero plane for the fragment lanes that only meet zero taps) of [40 rows][40 columns] (80-byte rows: 16 consecutive rows fall on distinct banks for the 16-byte
 //     fragment reads), zeroed once; a plane is input AND output: when a channel's MFMAs are done its wave applies bias,
 //     exact GELU, BatchNorm scale / shift and the residual (the plane's own centre value) and writes the result in place;
@@ -311,8 +310,8 @@ template <> struct Mfma16<f16_t> {
     }
 };
 
-template <typename T, int KS, int CPW>
-__global__ void __launch_bounds__(512) dwconv_mfma_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int H, int W, int C,
+template <typename T, int KS, int CPW, int NW>
+__global__ void __launch_bounds__(NW * 64) dwconv_mfma_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int H, int W, int C,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
                                                           const float* __restrict__ bns, const float* __restrict__ bnh, int img_per_wg) {
     constexpr int P = KS / 2;
@@ -320,13 +319,17 @@ __global__ void __launch_bounds__(512) dwconv_mfma_kernel(const T* __restrict__ 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    constexpr int CG = 8 * CPW;                                     // channels per workgroup
+    constexpr int CG = NW * CPW;                                    // channels per workgroup (a multiple of 8)
+    constexpr int NT = NW * 64;
+    constexpr int CH8 = CG / 8;                                     // 16-byte chunks per pixel
+    constexpr int NSLOT = 512 * CH8 / NT;                           // (pixel pair, chunk) slots per thread
+    static_assert(CG % 8 == 0 && (512 * CH8) % NT == 0, "workgroup geometry");
     const int c0 = blockIdx.x * CG;
     const int b0 = blockIdx.y * img_per_wg;
     const int b1 = b0 + img_per_wg < B ? b0 + img_per_wg : B;
     if (b0 >= B) return;
 
-    for (int i = tid * 16; i < (CG + 1) * DWM_PLANE; i += 512 * 16) *reinterpret_cast<u32x4*>(smem + i) = u32x4{0u, 0u, 0u, 0u};
+    for (int i = tid * 16; i < (CG + 1) * DWM_PLANE; i += NT * 16) *reinterpret_cast<u32x4*>(smem + i) = u32x4{0u, 0u, 0u, 0u};
 
     // ---- tap fragments: B operand of 16x16x32 = lane (n = lane & 15, kk = (lane >> 4) * 8 + e) ----
     const int n = lane & 15;
@@ -355,21 +358,21 @@ __global__ void __launch_bounds__(512) dwconv_mfma_kernel(const T* __restrict__ 
         sh[j] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (live && bnh) ? bnh[c] : 0.f)));
     }
 
-    // ---- staging slots of this thread: slot = tid + 512 q, q < CPW -> (pixel pair slot / CPW, 8-channel chunk slot % CPW):
+    // ---- staging slots of this thread: slot = tid + NT q, q < NSLOT -> (pixel pair slot / CH8, 8-channel chunk slot % CH8):
     // consecutive lanes move the consecutive chunks of one pixel pair ----
     auto slot_of = [&](const int q, int& cq, int& yy, int& xx) {
-        const int slot = tid + 512 * q;
-        const int pp = slot / CPW;                                  // pixel pair 0 .. 511
-        cq = slot - pp * CPW;
+        const int slot = tid + NT * q;
+        const int pp = slot / CH8;                                  // pixel pair 0 .. 511
+        cq = slot - pp * CH8;
         yy = pp >> 4;
         xx = (pp & 15) * 2;
     };
-    u32x4 r0[CPW], r1[CPW];
+    u32x4 r0[NSLOT], r1[NSLOT];
 #pragma unroll
-    for (int q = 0; q < CPW; ++q) r0[q] = r1[q] = u32x4{0u, 0u, 0u, 0u};
+    for (int q = 0; q < NSLOT; ++q) r0[q] = r1[q] = u32x4{0u, 0u, 0u, 0u};
     auto gload = [&](const int b) {
 #pragma unroll
-        for (int q = 0; q < CPW; ++q) {
+        for (int q = 0; q < NSLOT; ++q) {
             int cq, yy, xx;
             slot_of(q, cq, yy, xx);
             const bool cok = c0 + 8 * cq < C;                       // (C % 8 == 0: a chunk is whole or absent)
@@ -380,7 +383,7 @@ __global__ void __launch_bounds__(512) dwconv_mfma_kernel(const T* __restrict__ 
     };
     auto lds_put = [&]() {
 #pragma unroll
-        for (int q = 0; q < CPW; ++q) {
+        for (int q = 0; q < NSLOT; ++q) {
             int cq, yy, xx;
             slot_of(q, cq, yy, xx);
             if (!(c0 + 8 * cq < C && yy < H && xx < W)) continue;
@@ -459,7 +462,7 @@ __global__ void __launch_bounds__(512) dwconv_mfma_kernel(const T* __restrict__ 
         __syncthreads();                                            // results of image b are in the planes
         // ---- results out (two 16-byte stores per slot), next image in (same dwords) ----
 #pragma unroll
-        for (int q = 0; q < CPW; ++q) {
+        for (int q = 0; q < NSLOT; ++q) {
             int cq, yy, xx;
             slot_of(q, cq, yy, xx);
             if (!(c0 + 8 * cq < C && yy < H && xx < W)) continue;
@@ -483,25 +486,29 @@ __global__ void __launch_bounds__(512) dwconv_mfma_kernel(const T* __restrict__ 
 template <typename T>
 static int dwconv_mfma_launch(int k, const void* x, void* out, int B, int H, int W, int C, const float* w, const float* bias,
                               const float* bns, const float* bnh, hipStream_t s) {
-    const int cpw = k <= 5 ? 4 : 3;                     // channels per wave: what the register file holds next to the tap fragments
+    // Channels per workgroup: k <= 5: 8 waves x 4 channels = 32 (64 contiguous bytes of every pixel); k = 7, 9: 8 waves x 3 = 24
+    // (what 256 registers hold next to 4 k registers of tap fragments per channel).  Measured on ConvMixer-1536/20 (k = 9, per
+    // layer): 8 x 3: 0.96 ms; 4 waves x 8 channels with the whole 512-register file per wave (sector-aligned 64-byte pieces, but
+    // one wave per SIMD): 1.33 ms; 8 waves x 1 channel (16-byte pieces): 1.41 ms; the VALU stencil it replaces: 1.66 ms.
+    const int cpw = k <= 5 ? 4 : 3;
     const int cg = 8 * cpw;
-    // images per workgroup: enough to amortise the fragment build (about one image's worth of work), few enough to fill the chip
     const int groups = (C + cg - 1) / cg;
+    // images per workgroup: enough to amortise the fragment build (about one image's worth of work), few enough to fill the chip
     int per = 32;
     while (per > 4 && (long long)groups * ((B + per - 1) / per) < 512) per /= 2;
     const dim3 grid((unsigned)groups, (unsigned)((B + per - 1) / per));
     const int lds = (cg + 1) * DWM_PLANE;
     hipError_t e = hipSuccess;
-#define DWM_CASE(KS, CPW)                                                                                              \
+#define DWM_CASE(KS, CPW, NW)                                                                                          \
     case KS: {                                                                                                         \
-        auto kern = dwconv_mfma_kernel<T, KS, CPW>;                                                                    \
+        auto kern = dwconv_mfma_kernel<T, KS, CPW, NW>;                                                                \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
         if (e != hipSuccess) return (int)e;                                                                            \
-        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, (const T*)x, (T*)out, B, H, W, C, w, bias, bns, bnh, per);    \
+        hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, (const T*)x, (T*)out, B, H, W, C, w, bias, bns, bnh, per); \
         break;                                                                                                         \
     }
     switch (k) {
-        DWM_CASE(3, 4) DWM_CASE(5, 4) DWM_CASE(7, 3) DWM_CASE(9, 3)
+        DWM_CASE(3, 4, 8) DWM_CASE(5, 4, 8) DWM_CASE(7, 3, 8) DWM_CASE(9, 3, 8)
         default: return DW_NOFIT;
     }
 #undef DWM_CASE
