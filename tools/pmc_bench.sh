@@ -32,20 +32,28 @@ with open(out + "/summary.txt", "w") as fo:
             continue
         fo.write("%-40s %-30s launches=%d mean=%.5g\n" % (short, c, n, s / n))
 print(open(out + "/summary.txt").read())
-# traffic of the dominant kernel for bench.py's roofline.traffic, stamped with the source it was measured on
+# traffic of the dominant kernel for bench.py's roofline.traffic, stamped with the source it was measured on.
+# One mlpk_gemm_nt call of the persistent tile is up to three launches (one per tile height, p8_plan): the figure is per CALL =
+# all bytes of all gemm_nt_p8 launches / the calls that made them (4 forwards x (24 channel-MLP GEMMs + the patch embedding)).
 import hashlib, json
 root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
-dom = [k for k in agg if "gemm_nt_p8" in k[0] or "gemm_nt_q" in k[0]]
-names = sorted({k[0] for k in dom})
-if names:
-    kn = max(names, key=lambda n_: agg.get((n_, "FETCH_SIZE"), [0, 0.0])[0])
-    f_n, f_s = agg[(kn, "FETCH_SIZE")]
-    w_n, w_s = agg[(kn, "WRITE_SIZE")]
+full = collections.defaultdict(lambda: [0, 0.0])
+for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "gemm_nt_p8" in r["Kernel_Name"] and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+            k = (r["Kernel_Name"], r["Counter_Name"])
+            full[k][0] += 1
+            full[k][1] += float(r["Counter_Value"])
+if full:
+    calls = 4 * 25
+    fetch = sum(v[1] for k, v in full.items() if k[1] == "FETCH_SIZE")
+    write = sum(v[1] for k, v in full.items() if k[1] == "WRITE_SIZE")
     head = open(os.path.join(root, "tools", ".git_head")).read().strip() if os.path.exists(os.path.join(root, "tools", ".git_head")) else "?"
-    tj = {"channel_mlp_gemm_bytes_per_launch": (2.0 * f_s / f_n + w_s / w_n) * 1024.0,
-          "fetch_kib_per_launch_as_reported": f_s / f_n, "write_kib_per_launch": w_s / w_n, "kernel": kn, "launches": f_n,
-          "git": head, "gemm_source_sha256": hashlib.sha256(open(os.path.join(root, "jittor-mlp_amd/csrc/mlpk_gemm.hip"), "rb").read()).hexdigest(),
-          "note": "mean over the launches of that kernel in bench.py --steps 3 --warmup 1 (channel-MLP fc1 + fc2 and the few other GEMMs that pick the same tile); (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md)"}
+    tj = {"channel_mlp_gemm_bytes_per_launch": (2.0 * fetch + write) * 1024.0 / calls,
+          "per_instantiation_kib_per_launch": {k[0][-40:] + " " + k[1]: [v[0], v[1] / v[0]] for k, v in sorted(full.items())},
+          "gemm_calls": calls, "git": head,
+          "gemm_source_sha256": hashlib.sha256(open(os.path.join(root, "jittor-mlp_amd/csrc/mlpk_gemm.hip"), "rb").read()).hexdigest(),
+          "note": "bytes per mlpk_gemm_nt CALL of the persistent tile in bench.py --steps 3 --warmup 1: all launches of gemm_nt_p8_kernel (one per tile height) summed, (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md), divided by 4 forwards x 25 calls (24 channel-MLP GEMMs + the patch embedding, which has fc2's shape)"}
     json.dump(tj, open(out + "/traffic.json", "w"))
     print(json.dumps(tj))
 PY
