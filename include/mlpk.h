@@ -27,6 +27,7 @@
  *   mlpk_patchify       the im2col half of nn.Conv2d(k=stride=patch): mlp_mixer.py:58-60,68-71;
  *                       conv_mixer.py:18; s2_mlp_v2.py:119; as_mlp.py:319,330; PatchMerging as_mlp.py:207-211
  *   mlpk_row_stats      statistics of nn.LayerNorm (mlp_mixer.py:10) and nn.GroupNorm(1,C) (as_mlp.py:343-344)
+ *   mlpk_layernorm_transpose  statistics + affine + per-image transpose of the token-mixing LayerNorm (mlp_mixer.py:34) in one pass
  *   mlpk_norm_apply     the normalise+affine half of LayerNorm/GroupNorm/Aff (res_mlp.py:17-19), fused with
  *                       GELU (as_mlp.py:64-66) and with the layout change the next GEMM needs:
  *                       token-major transpose (Conv1d over tokens) or the ViP rearranges (vip.py:69,74)
@@ -155,7 +156,19 @@ int mlpk_gemm_algo_info(int algo, int* bm, int* bn, int* threads, int* lds_bytes
  */
 int mlpk_token_mlp_chunk(void);
 int mlpk_token_mlp(int dtype, const void* xt, int ldxt, int M, int S, const void* w1, int ldw1, const float* b1,
-                   const void* w2, int ldw2, const float* b2, int nchunks, void* x, int ldx, int t_rows, void* stream);
+                   const void* w2, int ldw2, const float* b2, int nchunks, void* x, int ldx, int t_rows, float* stats,
+                   int layout, void* stream);
+/* `layout` = what mlpk_token_mlp_layout(S, nchunks) returned when the weights were packed:
+ *   0  W2 in natural column order (128-row tiles, hidden handed between waves through LDS);
+ *   1  inside every group of 32 hidden columns, column slot 8 f + e (f = 0..3, e = 0..7) holds original column
+ *      (e < 4 ? 4 f + e : 16 + 4 f + e - 4): the order in which the first product's accumulators already are the second
+ *      product's operands, so the hidden never leaves the registers (256-row tiles; S <= 208). */
+int mlpk_token_mlp_layout(int S, int nchunks);
+/* `stats` (optional, t_rows % 128 == 0): the statistics of the LayerNorm that follows (mlp_mixer.py:38) come out of the epilogue:
+ * stats[((b*S + s)*(t_rows/128) + tile)*2 + {0,1}] = sum / sum of squares over the tile's 128 channels of the values written
+ * to x[b,s,:].  mlpk_stats_finalize reduces the partials of a row to mean / rstd (count = t_rows). */
+int mlpk_stats_finalize(const float* part, int64_t rows, int nparts, int64_t count, float eps, float* mean, float* rstd,
+                        void* stream);
 /* Tuning hook (tools/tokenmlp_timeline.py), not part of the forward path: when `buf` is non-NULL, later mlpk_token_mlp
  * launches log per-workgroup s_memtime stamps into it (64 x uint64 per workgroup); NULL switches the logging off.
  * The only library-held state, and off by default. */
@@ -217,6 +230,13 @@ typedef struct mlpk_norm_desc {
     void* out_pw;
 } mlpk_norm_desc;
 int mlpk_norm_apply(const mlpk_norm_desc* d, void* stream);
+
+/* Token-mixing LayerNorm of MLP-Mixer in one pass (mlp_mixer.py:34 with :6-13): statistics over C, affine, and the per-image
+ * transpose the token GEMMs read:  out_tt[(b*C + c)*ld_tt + s] = LayerNorm_C(x[b,s,:])[c], columns S..ld_tt-1 written as zeros.
+ * x is (nimg*S, C) with row stride ldx.  16-bit dtypes, C % 128 == 0, C <= 1024, ldx % 8 == 0, ld_tt % 8 == 0, 16-byte aligned
+ * pointers; other shapes: mlpk_row_stats + mlpk_norm_apply(out_tt). */
+int mlpk_layernorm_transpose(int dtype, const void* x, int64_t nimg, int S, int C, int ldx, const float* gamma, const float* beta,
+                             float eps, void* out_tt, int ld_tt, void* stream);
 
 /* ViP inverse rearranges (vip.py:71 / :76): z is the GEMM output in the permuted layout.
  * which = 0: out[b,h,w,g*seg+q] = z[((b*W + w)*G + g)*ldz + h*seg + q]

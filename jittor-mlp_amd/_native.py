@@ -4,7 +4,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmlpk.so")
+LIB_PATH = os.environ.get("MLPK_LIB_PATH") or os.path.join(_HERE, "lib", "libmlpk.so")    # (override: A/B builds of kernel variants, tools/build_variant.sh)
 
 F32, F16, BF16 = 0, 1, 2
 ACT_NONE, ACT_GELU = 0, 1
@@ -47,7 +47,10 @@ PROTOTYPES = {
     "mlpk_gemm_algo_info": (c_int, [c_int] + [ctypes.POINTER(c_int)] * 4),
     "mlpk_token_mlp_chunk": (c_int, []),
     "mlpk_token_mlp": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
-                               c_int, c_void_p, c_int, c_int, c_void_p]),
+                               c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "mlpk_token_mlp_layout": (c_int, [c_int, c_int]),
+    "mlpk_layernorm_transpose": (c_int, [c_int, c_void_p, c_i64, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p]),
+    "mlpk_stats_finalize": (c_int, [c_void_p, c_i64, c_int, c_i64, c_float, c_void_p, c_void_p, c_void_p]),
     "mlpk_token_mlp_debug": (None, [c_void_p]),
     "mlpk_patchify": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "mlpk_row_stats": (c_int, [c_int, c_void_p, c_i64, c_i64, c_i64, c_float, c_void_p, c_void_p, c_void_p]),

@@ -17,6 +17,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmlpk.so")
 SOURCES = ["mlpk_gemm.hip", "mlpk_norm.hip", "mlpk_embed.hip", "mlpk_remap.hip", "mlpk_tokenmlp.hip", "mlpk_dwconv.hip", "mlpk_hire.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
+FLAGS += os.environ.get("MLPK_EXTRA_FLAGS", "").split()      # tuning aid: A/B builds of a kernel variant (-DTM_...)
 
 
 def _hipcc():
@@ -44,7 +45,7 @@ def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 and link libmlpk.so.  Returns the library path."""
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
-    stamp = os.path.join(OBJ, "stamp.txt")
+    stamp = os.path.join(LIBDIR, "stamp.txt")      # next to the library: build/ (121 MB of -save-temps output) does not travel to the GPU box
     digest = _digest(_deps())
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
         return LIB

@@ -357,6 +357,111 @@ __global__ void __launch_bounds__(256) norm_apply_tile_kernel(const NormArgs p) 
     }
 }
 
+// ================================ token LayerNorm, statistics + apply + transpose in one pass ================================
+// The token-mixing PreNormResidual of MLP-Mixer (mlp_mixer.py:34 with :6-13): xt[b*C + c, s] = LayerNorm_C(x[b, s, :])[c].
+// One workgroup = 32 tokens of one image with ALL their channels: 16 lanes per token hold the row in registers (C / 128 16-byte
+// vectors each, coalesced), so mean and the centred sum of squares cost two DPP row reductions and no second read; the normalised
+// values go through LDS as [channel pair][token] words and leave as 16-byte stores of 8 consecutive tokens of one channel.
+// x is read once and xt written once: the separate statistics kernel (one more read of x per block) disappears.
+struct LnTtArgs {
+    const void* x;
+    const float* gamma;
+    const float* beta;
+    void* out;
+    int S, C, ldx, ld_tt, s_tiles;
+    float eps;
+};
+template <typename T>
+__global__ void __launch_bounds__(512) layernorm_transpose_kernel(const LnTtArgs p) {
+    static_assert(sizeof(T) == 2, "16-bit storage types");
+    constexpr int WP = 34;                                   // words per channel pair: 32 tokens + 2 (8-byte aligned rows)
+    extern __shared__ __attribute__((aligned(16))) uint32_t ltw[];      // (C / 2) x WP words
+    const int tid = threadIdx.x;
+    const int img = blockIdx.x / p.s_tiles;
+    const int s0 = (blockIdx.x % p.s_tiles) * 32;
+    const int sl = tid >> 4, l16 = tid & 15;
+    const int s = s0 + sl;
+    const int nv = p.C >> 7;                                 // vectors per lane (C % 128 == 0, <= 8)
+    const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+    const bool live = s < p.S;
+    u32x4 raw[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        raw[k] = u32x4{0u, 0u, 0u, 0u};
+        if (k < nv && live) raw[k] = *reinterpret_cast<const u32x4*>(x + ((int64_t)img * p.S + s) * p.ldx + (l16 + 16 * k) * 8);
+    }
+    float s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (k < nv) {
+            T e[8];
+            __builtin_memcpy(e, &raw[k], 16);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s1 += to_f32(e[i]);
+        }
+    }
+    const float inv = 1.0f / (float)p.C;
+    const float mu = row16_sum(s1) * inv;
+    float q1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (k < nv) {
+            T e[8];
+            __builtin_memcpy(e, &raw[k], 16);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float d = to_f32(e[i]) - mu;
+                q1 += d * d;
+            }
+        }
+    }
+    const float rs = 1.0f / __builtin_sqrtf(row16_sum(q1) * inv + p.eps);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (k < nv) {
+            const int c = (l16 + 16 * k) * 8;
+            T e[8];
+            __builtin_memcpy(e, &raw[k], 16);
+            if (live) {
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gamma + c), g1 = *reinterpret_cast<const f32x4*>(p.gamma + c + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.beta + c), b1 = *reinterpret_cast<const f32x4*>(p.beta + c + 4);
+                const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) e[i] = from_f32<T>((to_f32(e[i]) - mu) * rs * g[i] + b[i]);
+            }                                                // tokens past S: the zero K-padding of xt
+            uint32_t w4[4];
+            __builtin_memcpy(w4, e, 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ltw[((c >> 1) + i) * WP + sl] = w4[i];
+        }
+    }
+    __syncthreads();
+    // transposed side: item = (channel pair, 8 consecutive tokens); 4 items cover a pair's 32 tokens = 64 contiguous bytes per channel
+    T* out = reinterpret_cast<T*>(p.out);
+    const int items = (p.C >> 1) * 4;
+    for (int idx = tid; idx < items; idx += 512) {
+        const int pr = idx >> 2;
+        const int sc = (idx & 3) * 8;
+        if (s0 + sc >= p.ld_tt) continue;                    // ld_tt % 8 == 0
+        uint32_t w8[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const u32x2 t2 = *reinterpret_cast<const u32x2*>(ltw + pr * WP + sc + 2 * k);
+            w8[2 * k] = t2.x;
+            w8[2 * k + 1] = t2.y;
+        }
+        u32x4 lo, hi;
+        lo.x = __builtin_amdgcn_perm(w8[1], w8[0], 0x05040100u); hi.x = __builtin_amdgcn_perm(w8[1], w8[0], 0x07060302u);
+        lo.y = __builtin_amdgcn_perm(w8[3], w8[2], 0x05040100u); hi.y = __builtin_amdgcn_perm(w8[3], w8[2], 0x07060302u);
+        lo.z = __builtin_amdgcn_perm(w8[5], w8[4], 0x05040100u); hi.z = __builtin_amdgcn_perm(w8[5], w8[4], 0x07060302u);
+        lo.w = __builtin_amdgcn_perm(w8[7], w8[6], 0x05040100u); hi.w = __builtin_amdgcn_perm(w8[7], w8[6], 0x07060302u);
+        T* dst = out + ((int64_t)img * p.C + 2 * pr) * p.ld_tt + s0 + sc;
+        *reinterpret_cast<u32x4*>(dst) = lo;
+        *reinterpret_cast<u32x4*>(dst + p.ld_tt) = hi;
+    }
+}
+
 // ================================ norm apply: ViP rearranges ================================
 // One workgroup per (image, fixed w) [which = 0, all h] or (image, fixed h) [which = 1, all w]:
 // the L x C slab (L = H or W) is staged in LDS in pixel order and written back in (g, l, j)
@@ -649,6 +754,27 @@ using namespace mlpk;
         default: return MLPK_EDTYPE;                                         \
     }
 
+// mean / rstd of `rows` rows from `nparts` partial (sum, sum of squares) pairs per row, written by a producer's epilogue
+// (mlpk_token_mlp): mean = S1 / count, var = S2 / count - mean^2 (>= 0), rstd = 1 / sqrt(var + eps).  fp32 sums of values that
+// were rounded to 16 bits: the cancellation error of the E[x^2] - mean^2 form (~1e-7 (1 + mean^2 / var)) is far below the
+// storage rounding of the tensor being normalised.
+__global__ void __launch_bounds__(256) stats_finalize_kernel(const float* __restrict__ part, int64_t rows, int nparts, float inv_count, float eps,
+                                                             float* __restrict__ mean, float* __restrict__ rstd) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float* pp = part + r * nparts * 2;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < nparts; ++i) {
+        s1 += pp[2 * i];
+        s2 += pp[2 * i + 1];
+    }
+    const float mu = s1 * inv_count;
+    float var = s2 * inv_count - mu * mu;
+    var = var > 0.f ? var : 0.f;
+    mean[r] = mu;
+    rstd[r] = 1.0f / __builtin_sqrtf(var + eps);
+}
+
 static inline int esize(int dt) { return dt == MLPK_F32 ? 4 : 2; }
 
 extern "C" int mlpk_row_stats(int dtype, const void* x, int64_t rows, int64_t len, int64_t ldx, float eps,
@@ -670,6 +796,17 @@ extern "C" int mlpk_row_stats(int dtype, const void* x, int64_t rows, int64_t le
         DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((row_stats_kernel<T, 1024>), dim3((unsigned)rows), dim3(1024), 0, s,
                                                  (const T*)x, rows, len, ldx, eps, mean, rstd, vec));
     }
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mlpk_stats_finalize(const float* part, int64_t rows, int nparts, int64_t count, float eps, float* mean, float* rstd,
+                                   void* stream) {
+    if (!part || !mean || !rstd) return MLPK_ENULL;
+    if (rows <= 0 || nparts <= 0 || count <= 0) return MLPK_ESHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, part, rows, nparts, 1.0f / (float)count, eps,
+                       mean, rstd);
     MLPK_LAUNCH_CHECK();
     return 0;
 }
@@ -743,6 +880,33 @@ extern "C" int mlpk_norm_apply(const mlpk_norm_desc* d, void* stream) {
         });
         MLPK_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+extern "C" int mlpk_layernorm_transpose(int dtype, const void* x, int64_t nimg, int S, int C, int ldx, const float* gamma, const float* beta,
+                                        float eps, void* out_tt, int ld_tt, void* stream) {
+    if (!x || !gamma || !beta || !out_tt) return MLPK_ENULL;
+    if (dtype != MLPK_F16 && dtype != MLPK_BF16) return MLPK_EDTYPE;
+    if (nimg <= 0 || S <= 0 || C <= 0 || C % 128 || C > 1024 || ldx < C || ldx % 8 || ld_tt < S || ld_tt % 8) return MLPK_ESHAPE;
+    if (((uintptr_t)x | (uintptr_t)out_tt | (uintptr_t)gamma | (uintptr_t)beta) & 15) return MLPK_ESHAPE;
+    LnTtArgs a;
+    a.x = x; a.gamma = gamma; a.beta = beta; a.out = out_tt;
+    a.S = S; a.C = C; a.ldx = ldx; a.ld_tt = ld_tt; a.s_tiles = (ld_tt + 31) / 32; a.eps = eps;
+    if (nimg * a.s_tiles > 0x7fffffffLL) return MLPK_ESHAPE;
+    const size_t lds = (size_t)(C / 2) * 34 * 4;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MLPK_BF16) {
+        auto k = layernorm_transpose_kernel<bf16_t>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(k, dim3((unsigned)(nimg * a.s_tiles)), dim3(512), lds, s, a);
+    } else {
+        auto k = layernorm_transpose_kernel<f16_t>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(k, dim3((unsigned)(nimg * a.s_tiles)), dim3(512), lds, s, a);
+    }
+    MLPK_LAUNCH_CHECK();
     return 0;
 }
 

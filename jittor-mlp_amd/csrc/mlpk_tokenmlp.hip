@@ -22,10 +22,12 @@
 //     acc1 and H between the waves).  The weight streams are the same for every tile, so across tiles the
 //     rings simply keep turning (period G + 2 iterations).
 //   * Tile epilogue: acc2 + b2 staged through LDS as fp32 in 8 passes of 32 tokens; the reader side adds the
-//     residual (one rounding) with whole 256-byte token rows per 16 lanes, for both its load and its store;
-//     the next tile's X operands are requested before it.
-// LDS: 48 (W1 ring) + 48 (W2 ring) + 16 (H, double-buffered) + 32 (acc1 exchange / epilogue staging) + 4 (b1) = 148 KiB.
+//     residual (one rounding) with whole 256-byte token rows per 16 lanes, for both its load and its store.  The
+//     residual tile is requested during the last (drain) iteration and awaited once; the next tile's X operands are
+//     requested before the passes, which then issue nothing but stores.
+// LDS: 48 (W1 ring) + 48 (W2 ring) + 16 (H, double-buffered) + 32 (acc1 exchange / epilogue staging) + 4 (b1) + 0.9 (b2) = 149 KiB.
 #include "mlpk_common.h"
+#include <cstdlib>
 
 namespace mlpk {
 
@@ -38,6 +40,7 @@ struct TokenMlpArgs {
     void* x;            // (B*S, ldx) residual stream, updated in place
     int M, S, ks1, G;
     int ldxt, ldw2, ldx, t_rows;
+    float* stats;       // optional: per (token row, 128-channel tile) partial (sum, sum of squares) of the values written to x
     unsigned long long* dbg;   // tuning aid: per-workgroup [loop, epilogue] shader-clock sums (NULL in normal use)
 };
 
@@ -78,12 +81,21 @@ constexpr int TM_HS = 2 * TM_NST * TM_STAGE;           // 4 slices x 2 buffers x
 constexpr int TM_AX = TM_HS + 4 * 2 * 2048;            // 4 slices x 2 buffers x 4 KiB of fp32 acc1; epilogue: 2 x 8 KiB
 constexpr int TM_B1 = TM_AX + 4 * 2 * 4096;
 constexpr int TM_B1_FLOATS = 1024;                     // hidden (padded) <= 1024
-constexpr int TM_LDS = TM_B1 + TM_B1_FLOATS * 4;
+constexpr int TM_B2 = TM_B1 + TM_B1_FLOATS * 4;    // b2, zero-padded to 16 * (NB0 + NB1) tokens: a global load inside an epilogue
+                                                   // pass made hipcc wait vmcnt(0) there -- on the previous pass's stores and on the next tile's X
+constexpr int TM_LDS = TM_B2 + 16 * (TM_NB0 + TM_NB1) * 4;
 
 #define TM_BARRIER() asm volatile("s_barrier" ::: "memory")
 // (lgkmcnt(0): this wave's LDS writes of the previous iteration must have reached LDS before the barrier)
 #define TM_ITER_SYNC() do { asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory"); TM_BARRIER(); } while (0)
 
+// iteration flavours: RAMP (t < 2, run-time predicates), STEADY (branch-free), DRAIN (t >= G, t >= 2: no fc1 code at all,
+// which leaves the registers of its operands to the residual tile that is requested during the last iteration)
+#ifndef TM_ABL
+#define TM_ABL 0      // tuning aid (tools/build_variant.sh): 1 no in-loop LDS-DMA, 2 identity GELU, 4 no fc1 MFMAs, 8 no fc2 MFMAs -- wrong results, timing only
+#endif
+enum { TM_RAMP = 0, TM_STEADY = 1, TM_DRAIN = 2, TM_LAST = 3 };   // LAST = the DRAIN iteration that requests the residual tile
+template <int M> struct ModeC { static constexpr int value = M; };
 template <bool B> struct BoolC { static constexpr bool value = B; };
 
 // A wave issues at most one instruction per ~4 cycles, so the loop bodies below are written for instruction
@@ -110,6 +122,7 @@ __global__ void __launch_bounds__(512, 1) token_mlp_kernel(const TokenMlpArgs p)
     char* const hs = smem + TM_HS + slice * 4096;          // the slice's two 2-KiB H buffers
     char* const axs = smem + TM_AX + slice * 8192;         // the slice's two 4-KiB acc1 buffers (lane-linear)
     float* const b1s = reinterpret_cast<float*>(smem + TM_B1);
+    float* const b2s = reinterpret_cast<float*>(smem + TM_B2);
 
     // (All workgroups walk the hidden groups in the same order: rotating it per CU to spread the L2 accesses was
     //  measured neutral, and a fixed order keeps every row's result independent of the batch it is computed in.)
@@ -152,6 +165,9 @@ __global__ void __launch_bounds__(512, 1) token_mlp_kernel(const TokenMlpArgs p)
     auto issue = [&](const unsigned stoff, const int pi) {
         tm_glds(poff[pi], slice * 7 + pi < 14 ? pb1 : pb2, pdst[pi] + stoff);
     };
+    auto issue_loop = [&](const unsigned stoff, const int pi) {
+        if (!(TM_ABL & 1) || p.ldxt == 12345) issue(stoff, pi);
+    };
     if (role == 0) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -169,6 +185,7 @@ __global__ void __launch_bounds__(512, 1) token_mlp_kernel(const TokenMlpArgs p)
     const int f_rd = frow * 64 + co;                  // + block*1024 (+ plane*2048 in a W1 group)
 
     for (int i = tid; i < G * 32; i += 512) b1s[i] = p.b1[i];
+    if (tid < 16 * (TM_NB0 + TM_NB1)) b2s[tid] = tid < p.S ? p.b2[tid] : 0.f;
     __syncthreads();
 
     unsigned long long t_loop = 0, t_epi = 0, ts = 0;
@@ -179,9 +196,16 @@ __global__ void __launch_bounds__(512, 1) token_mlp_kernel(const TokenMlpArgs p)
     const int rt = tid >> 4, rc = tid & 15;
     char* const stg = smem + TM_AX;
     const int wc4 = slice * 8 + fg;                        // writer's 16-byte chunk (4 channels) for i = 0; + 4 for i = 1
+    // Statistics for the LayerNorm that follows (the channel-mixing PreNormResidual, mlp_mixer.py:38): the 16 lanes rc = 0..15 of a
+    // token hold the tile's 128 channels of it, AFTER rounding -- exactly what that LayerNorm will read -- so a DPP row reduction
+    // gives the tile's partial (sum, sum of squares) per token; mlpk_stats_finalize turns the t_rows / 128 partials of a row into
+    // mean / rstd.  One separate statistics pass over x per block (77 MB at Mixer-B/16, 256 images) disappears.
+    const int stile = p.stats ? (p.t_rows >> 7) : 0;                  // partial slots per token row (t_rows % 128 == 0, host checked)
     auto epilogue_reader = [&](const int j, const char* sb, const u32x4 res, const int rimg, const int rcc, const bool row_ok) {
         const int rn = (rt < 16 ? j : TM_NB0 + j) * 16 + (rt & 15);   // token this thread moves in pass j
-        if ((rt < 16 || j < TM_NB1) && rn < p.S && row_ok) {
+        const bool live = (rt < 16 || j < TM_NB1) && rn < p.S && row_ok;
+        float ssum = 0.f, ssq = 0.f;
+        if (live) {
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(sb + rt * 512 + (((2 * rc) ^ (rt & 15)) << 4));
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(sb + rt * 512 + (((2 * rc + 1) ^ (rt & 15)) << 4));
             T r8[8];
@@ -192,6 +216,23 @@ __global__ void __launch_bounds__(512, 1) token_mlp_kernel(const TokenMlpArgs p)
             u32x4 o;
             __builtin_memcpy(&o, e, 16);
             *reinterpret_cast<u32x4*>(x + ((size_t)rimg * p.S + rn) * p.ldx + rcc) = o;
+            if (p.stats) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float f = to_f32(e[k]);
+                    ssum += f;
+                    ssq += f * f;
+                }
+            }
+        }
+        if (p.stats) {                                                // (workgroup-uniform: every lane takes part in the DPP rows)
+            ssum = row16_sum(ssum);
+            ssq = row16_sum(ssq);
+            if (live && rc == 0) {
+                float* dst = p.stats + (((size_t)rimg * p.S + rn) * stile + (rcc >> 7)) * 2;
+                dst[0] = ssum;
+                dst[1] = ssq;
+            }
         }
     };
     auto residual_load = [&](const int j, const int rimg, const int rcc, const bool row_ok) {
@@ -199,6 +240,15 @@ __global__ void __launch_bounds__(512, 1) token_mlp_kernel(const TokenMlpArgs p)
         u32x4 r = {0u, 0u, 0u, 0u};
         if ((rt < 16 || j < TM_NB1) && rn < p.S && row_ok) r = *reinterpret_cast<const u32x4*>(x + ((size_t)rimg * p.S + rn) * p.ldx + rcc);
         return r;
+    };
+
+    auto request_residual = [&](const int tile, u32x4 (&res)[TM_NB0], int& rimg, int& rcc, bool& row_ok) {
+        const int mr = tile * TM_BM + rc * 8;
+        rimg = mr / p.t_rows;
+        rcc = mr - rimg * p.t_rows;
+        row_ok = mr < p.M;
+#pragma unroll
+        for (int j = 0; j < TM_NB0; ++j) res[j] = residual_load(j, rimg, rcc, row_ok);
     };
 
     if (role == 0) {
@@ -218,11 +268,15 @@ __global__ void __launch_bounds__(512, 1) token_mlp_kernel(const TokenMlpArgs p)
         load_x(blockIdx.x);
         unsigned st = 0;                                   // ring stage of the current iteration (global iteration mod 3)
         f32x4 acc2[2][TM_NB0];
-        auto iter = [&](auto steady_c, const int t) {
-            constexpr bool STEADY = decltype(steady_c)::value;
-            const bool fc1 = STEADY || t < G;
-            const bool fc2 = STEADY || t >= 2;
+        u32x4 res[TM_NB0];
+        int rimg = 0, rcc = 0;
+        bool row_ok = false;
+        auto iter = [&](auto mode_c, const int t, const int tile) {
+            constexpr int MODE = decltype(mode_c)::value;
+            const bool fc1 = MODE == TM_STEADY || (MODE == TM_RAMP && t < G);
+            const bool fc2 = MODE != TM_RAMP || t >= 2;
             TM_ITER_SYNC();
+            if constexpr (MODE == TM_LAST) request_residual(tile, res, rimg, rcc, row_ok);      // after this iteration's vmcnt(7)
             const char* r1 = smem + TM_R1 + st * TM_STAGE;
             const char* r2 = smem + TM_R2 + st * TM_STAGE;
             const unsigned stoff2 = (st == 0 ? 2 : st - 1) * TM_STAGE;   // stage (st + 2) mod 3
@@ -250,16 +304,20 @@ __global__ void __launch_bounds__(512, 1) token_mlp_kernel(const TokenMlpArgs p)
                     for (int j = 0; j < 2; ++j) a1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kk = 0; kk < TM_KMAX; ++kk) {
-                    issue(stoff2, kk);
+                    issue_loop(stoff2, kk);
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
+                        if constexpr (TM_ABL & 4) {
+                            a1[i][0] += __builtin_bit_cast(f32x4, bw[kk][0]) + __builtin_bit_cast(f32x4, xa[i][kk]);
+                            continue;
+                        }
                         a1[i][0] = Mma2<T>::run(bw[kk][0], xa[i][kk], a1[i][0]);
                         a1[i][1] = Mma2<T>::run(bw[kk][1], xa[i][kk], a1[i][1]);
                     }
                 }
             } else {
 #pragma unroll
-                for (int pi = 0; pi < 7; ++pi) issue(stoff2, pi);
+                for (int pi = 0; pi < 7; ++pi) issue_loop(stoff2, pi);
             }
             if (fc2) {
 #pragma unroll
@@ -276,6 +334,10 @@ __global__ void __launch_bounds__(512, 1) token_mlp_kernel(const TokenMlpArgs p)
                 // natural operands -> lane = token frow of block j, 4 consecutive rows 4*fg + r
 #pragma unroll
                 for (int j = 0; j < TM_NB0; ++j) {
+                    if constexpr (TM_ABL & 8) {
+                        acc2[0][j] += __builtin_bit_cast(f32x4, af0) + __builtin_bit_cast(f32x4, bf[j]);
+                        continue;
+                    }
                     acc2[0][j] = Mma2<T>::run(af0, bf[j], acc2[0][j]);
                     acc2[1][j] = Mma2<T>::run(af1, bf[j], acc2[1][j]);
                 }
@@ -293,28 +355,25 @@ __global__ void __launch_bounds__(512, 1) token_mlp_kernel(const TokenMlpArgs p)
 #pragma unroll
                 for (int j = 0; j < TM_NB0; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             int t = 0;
-            for (; t < 2; ++t) iter(BoolC<false>{}, t);
+            for (; t < 2; ++t) iter(ModeC<TM_RAMP>{}, t, tile);
 #pragma unroll 1
-            for (; t < G; ++t) iter(BoolC<true>{}, t);
-            for (; t < G + 2; ++t) iter(BoolC<false>{}, t);
+            for (; t < G; ++t) iter(ModeC<TM_STEADY>{}, t, tile);
+            if (t == G) { iter(ModeC<TM_DRAIN>{}, t, tile); ++t; }       // (G == 1: the ramp already ran iteration G)
+            iter(ModeC<TM_LAST>{}, t, tile);
             if (stamp) { const unsigned long long n = __builtin_readcyclecounter(); t_loop += n - ts; ts = n; }
             // ---- tile epilogue ----
-            const int m0 = tile * TM_BM;
-            const int mr = m0 + rc * 8;
-            const int rimg = mr / p.t_rows;
-            const int rcc = mr - rimg * p.t_rows;
-            const bool row_ok = mr < p.M;
-            u32x4 res[TM_NB0];
-#pragma unroll
-            for (int j = 0; j < TM_NB0; ++j) res[j] = residual_load(j, rimg, rcc, row_ok);
+            // The residual tile (requested one iteration ago) must have landed HERE, with a wait the compiler knows about:
+            // left to itself it waits vmcnt(0) in front of every pass's first use -- loads and stores share the counter and
+            // count as unordered once mixed -- which serialised the eight passes on each other's store round trips and on
+            // the next tile's X (8 x ~2k cycles per tile).  After this point the passes only issue stores.
+            __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0)
             if (tile + (int)gridDim.x < ntiles) load_x(tile + gridDim.x);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             TM_BARRIER();                                                   // every wave is done with the exchange buffers
 #pragma unroll
             for (int j = 0; j < TM_NB0; ++j) {
                 char* const sb = stg + (j & 1) * 16384;
-                const int n = j * 16 + frow;
-                const float bn = n < p.S ? p.b2[n] : 0.f;
+                const float bn = b2s[j * 16 + frow];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const f32x4 v = {acc2[i][j].x + bn, acc2[i][j].y + bn, acc2[i][j].z + bn, acc2[i][j].w + bn};
@@ -331,11 +390,15 @@ __global__ void __launch_bounds__(512, 1) token_mlp_kernel(const TokenMlpArgs p)
         unsigned st = 0;
         f32x4 acc2[2][TM_NB1];
         const bool blk14 = TM_NB0 + TM_NB1 - 1 < nblk;     // the 14th token block usually does not exist
-        auto iter = [&](auto steady_c, const int t) {
-            constexpr bool STEADY = decltype(steady_c)::value;
-            const bool gelu = STEADY || (t >= 1 && t <= G);
-            const bool fc2 = STEADY || t >= 2;
+        u32x4 res[TM_NB0];
+        int rimg = 0, rcc = 0;
+        bool row_ok = false;
+        auto iter = [&](auto mode_c, const int t, const int tile) {
+            constexpr int MODE = decltype(mode_c)::value;
+            const bool gelu = MODE == TM_STEADY || (t >= 1 && t <= G);
+            const bool fc2 = MODE != TM_RAMP || t >= 2;
             TM_ITER_SYNC();
+            if constexpr (MODE == TM_LAST) request_residual(tile, res, rimg, rcc, row_ok);
             const char* r2 = smem + TM_R2 + st * TM_STAGE;
             u32x4 af0, af1, bf[TM_NB1];
             if (fc2) {
@@ -365,7 +428,13 @@ __global__ void __launch_bounds__(512, 1) token_mlp_kernel(const TokenMlpArgs p)
                         v[2 * q] = f32x2{a[half * 2 + q].x + bb.x, a[half * 2 + q].y + bb.y};
                         v[2 * q + 1] = f32x2{a[half * 2 + q].z + bb.z, a[half * 2 + q].w + bb.w};
                     }
+#if TM_ABL & 2
+#elif defined(TM_GELU_SCALAR)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = f32x2{gelu16_f(v[c].x), gelu16_f(v[c].y)};
+#else
                     gelu_pk_n<4>(v);
+#endif
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         const int row = half * 16 + frow;
@@ -380,6 +449,10 @@ __global__ void __launch_bounds__(512, 1) token_mlp_kernel(const TokenMlpArgs p)
             if (fc2) {
 #pragma unroll
                 for (int j = 0; j < TM_NB1; ++j) {
+                    if constexpr (TM_ABL & 8) {
+                        acc2[0][j] += __builtin_bit_cast(f32x4, af0) + __builtin_bit_cast(f32x4, bf[j]);
+                        continue;
+                    }
                     if (j < TM_NB1 - 1 || blk14) {
                         acc2[0][j] = Mma2<T>::run(af0, bf[j], acc2[0][j]);
                         acc2[1][j] = Mma2<T>::run(af1, bf[j], acc2[1][j]);
@@ -394,27 +467,20 @@ __global__ void __launch_bounds__(512, 1) token_mlp_kernel(const TokenMlpArgs p)
 #pragma unroll
                 for (int j = 0; j < TM_NB1; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             int t = 0;
-            for (; t < 2; ++t) iter(BoolC<false>{}, t);
+            for (; t < 2; ++t) iter(ModeC<TM_RAMP>{}, t, tile);
 #pragma unroll 1
-            for (; t < G; ++t) iter(BoolC<true>{}, t);
-            for (; t < G + 2; ++t) iter(BoolC<false>{}, t);
+            for (; t < G; ++t) iter(ModeC<TM_STEADY>{}, t, tile);
+            if (t == G) { iter(ModeC<TM_DRAIN>{}, t, tile); ++t; }       // (G == 1: the ramp already ran iteration G)
+            iter(ModeC<TM_LAST>{}, t, tile);
             // ---- tile epilogue ----
-            const int m0 = tile * TM_BM;
-            const int mr = m0 + rc * 8;
-            const int rimg = mr / p.t_rows;
-            const int rcc = mr - rimg * p.t_rows;
-            const bool row_ok = mr < p.M;
-            u32x4 res[TM_NB0];
-#pragma unroll
-            for (int j = 0; j < TM_NB0; ++j) res[j] = residual_load(j, rimg, rcc, row_ok);
+            __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0): the residual tile has landed (see the matrix wave)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             TM_BARRIER();
 #pragma unroll
             for (int j = 0; j < TM_NB0; ++j) {
                 char* const sb = stg + (j & 1) * 16384;
                 if (j < TM_NB1) {
-                    const int n = (TM_NB0 + j) * 16 + frow;
-                    const float bn = n < p.S ? p.b2[n] : 0.f;
+                    const float bn = b2s[(TM_NB0 + j) * 16 + frow];
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         const f32x4 a = acc2[i][j < TM_NB1 ? j : 0];
@@ -428,6 +494,341 @@ __global__ void __launch_bounds__(512, 1) token_mlp_kernel(const TokenMlpArgs p)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no LDS-DMA may outlive the workgroup
+    if (stamp && tid == 0) {
+        p.dbg[(size_t)blockIdx.x * 4 + 0] = t_loop;
+        p.dbg[(size_t)blockIdx.x * 4 + 1] = t_epi;
+        p.dbg[(size_t)blockIdx.x * 4 + 2] = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    }
+}
+
+// ====================================================================================================================
+// Second form of the same operation: 256-row tiles, the hidden NEVER leaves the registers.
+//
+// The kernel above hands acc1 (fp32) and H (16 bit) between two specialised waves through LDS; its iteration is bound by
+// that chain of LDS round trips, LDS-DMA issue and the barrier that couples eight waves doing different things (removing
+// the MFMAs, the GELU or the DMA alone changes its time by 0-9 %, profiles/r02_token_mlp_ablation.txt).  Here every wave
+// owns 32 rows and runs fc1 -> GELU -> fc2 for them itself:
+//   * fc1 with swapped operands leaves lane (row frow, fg) holding hidden columns {4 fg + r} and {16 + 4 fg + r} of its row:
+//     after bias + GELU + rounding those eight values ARE one 16x16x32 A fragment, provided k slot 8 fg + e of the second
+//     product means hidden column (e < 4 ? 4 fg + e : 16 + 4 fg + e - 4).  The host packs W2 with that permutation inside
+//     every group of 32 hidden columns (layout 1, mlpk_token_mlp_layout), so nothing is exchanged at all.
+//   * 8 waves x 32 rows = 256-row tiles: a W1 group / W2 slab staged in LDS serves twice the rows, one barrier per
+//     iteration (the ring hand-over) is all the synchronisation, G iterations per tile instead of G + 2.
+//   * The two waves of a SIMD are skewed by half an iteration so that one is in its matrix phase while the other runs
+//     GELU: waves 0-3 run [fc1(t), gelu(t), fc2(t)], waves 4-7 run [gelu(t-1), fc2(t-1), fc1(t)] (acc1 stays in their
+//     registers across the barrier) and drain gelu/fc2(G-1) after the loop.  W2 slab t-1 is therefore still read during
+//     iteration t: the W2 ring has 4 stages, the W1 ring 3; both are filled two iterations ahead, 4 one-KiB pieces per
+//     wave per iteration (14 + 14 + 4 duplicates), constant `s_waitcnt vmcnt(4)`.
+//   * Epilogue: 13 passes of one token block x 256 channels of fp32 through LDS; reader = (token tid >> 5, 8 channels
+//     tid & 31): 512-byte runs of one token row per 32 lanes for the residual load and the store.
+// LDS: 48 (W1 ring) + 64 (W2 ring) + 32 (epilogue staging) + 4 (b1) + 0.9 (b2) = 149 KiB.
+#ifndef T2_BWD
+#define T2_BWD 3         // W1 fragment pairs read ahead of their MFMAs
+#endif
+#ifndef T2_BFD
+#define T2_BFD 4         // W2 fragments read ahead of their MFMAs
+#endif
+#ifndef T2_DIAG
+#define T2_DIAG 0
+#endif
+constexpr int T2_BM = 256;
+constexpr int T2_NB = 13;                              // token blocks of 16: S <= 208
+constexpr int T2_R1 = 0;
+constexpr int T2_R2 = 3 * TM_STAGE;
+constexpr int T2_STG = T2_R2 + 4 * TM_STAGE;
+constexpr int T2_B1 = T2_STG + 2 * 16384;
+constexpr int T2_B2 = T2_B1 + TM_B1_FLOATS * 4;
+constexpr int T2_LDS = T2_B2 + 16 * T2_NB * 4;
+#define T2_ITER_SYNC() do { asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); TM_BARRIER(); } while (0)
+
+template <typename T>
+__global__ void __launch_bounds__(512, 1) token_mlp_rr_kernel(const TokenMlpArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool lag = wave >= 4;                            // the half that runs gelu/fc2 one iteration late
+    const T* __restrict__ xt = reinterpret_cast<const T*>(p.xt);
+    const T* __restrict__ w1 = reinterpret_cast<const T*>(p.w1);
+    const T* __restrict__ w2 = reinterpret_cast<const T*>(p.w2);
+    T* __restrict__ x = reinterpret_cast<T*>(p.x);
+    const int G = p.G;
+    const int ks1 = p.ks1;
+    const int ntiles = (p.M + T2_BM - 1) / T2_BM;
+    const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)smem;
+    float* const b1s = reinterpret_cast<float*>(smem + T2_B1);
+    float* const b2s = reinterpret_cast<float*>(smem + T2_B2);
+
+    // ---- LDS-DMA pieces (geometry of the kernel above): wave w issues q = 4 w + pi; q < 14: W1 piece q (plane q >> 1, half
+    // q & 1), 14 <= q < 28: W2 piece q - 14 (rows 16 (q - 14) .., clamped to S - 1), q >= 28: W2 piece 13 again ----
+    // Every per-lane quantity the iterations use (piece offsets, fragment offsets, bias offsets) is re-derived inside the
+    // iteration from an opaque copy of the lane id: values that live across the loop get spilled around it, their reloads in
+    // the loop preheader leave "VMEM pending" at the loop header, and hipcc then waits vmcnt(3..0) in front of each LDS-DMA
+    // piece in EVERY iteration -- draining the prefetch ring (seen in the ISA: 3.9k cycles per iteration).
+    auto lane_now = [&]() {
+        unsigned l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return (int)l;
+    };
+    unsigned pdst[4];
+#pragma unroll
+    for (int pi = 0; pi < 4; ++pi) {
+        int q = wave * 4 + pi;
+        q = q < 28 ? q : 27;
+        pdst[pi] = __builtin_amdgcn_readfirstlane(q < 14 ? lds_base + T2_R1 + q * 1024 : lds_base + T2_R2 + (q - 14) * 1024);
+    }
+    auto piece_off = [&](const int pi, const int ln) {       // per-lane byte offset of piece pi from its group's base
+        int q = wave * 4 + pi;
+        q = q < 28 ? q : 27;
+        const int lrow = ln >> 2;
+        const int lchunk = (ln & 3) ^ ((lrow & 8) >> 2);
+        unsigned o;
+        if (q < 14) {
+            o = (unsigned)(((q & 1) * 16 + lrow) * 256 + (q >> 1) * 32 + lchunk * 8) * (unsigned)sizeof(T);
+        } else {
+            int r2 = (q - 14) * 16 + lrow;
+            r2 = r2 < p.S ? r2 : p.S - 1;
+            o = (unsigned)(r2 * p.ldw2 + lchunk * 8) * (unsigned)sizeof(T);
+        }
+        return o;
+    };
+    const T* pb1 = w1;
+    const T* pb2 = w2;
+    unsigned so1 = 0, so2 = 0;                             // ring stage byte offsets of the pieces being issued
+    auto piece_bases = [&](const int g) {                  // hidden group the pieces are for (already wrapped to 0..G-1)
+        pb1 = w1 + (size_t)g * (32 * 256);
+        pb2 = w2 + g * 32;
+    };
+    auto issue = [&](const int pi, const int ln) {
+        const bool is1 = wave * 4 + pi < 14;
+        tm_glds(piece_off(pi, ln), is1 ? pb1 : pb2, pdst[pi] + __builtin_amdgcn_readfirstlane(is1 ? so1 : so2));
+    };
+    // global iteration counter modulo the ring sizes; pieces of iteration gi live in W1 stage gi % 3, W2 stage gi % 4
+    unsigned s3 = 0, s4 = 0;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        piece_bases(it < G ? it : it - G);                 // (G == 1: iteration 1 is the next tile's group 0)
+        so1 = so2 = (unsigned)it * TM_STAGE;
+#pragma unroll
+        for (int pi = 0; pi < 4; ++pi) issue(pi, lane);
+    }
+    if (lag) __builtin_amdgcn_s_setprio(2);                // the younger half would lose every VALU arbitration
+
+    for (int i = tid; i < G * 32; i += 512) b1s[i] = p.b1[i];
+    if (tid < 16 * T2_NB) b2s[tid] = tid < p.S ? p.b2[tid] : 0.f;
+    __syncthreads();
+
+    unsigned long long t_loop = 0, t_epi = 0, ts = 0;
+    const bool stamp = !(T2_DIAG & 2) && p.dbg != nullptr;
+    char* const stg = smem + T2_STG;
+    const int stile = p.stats ? (p.t_rows >> 7) : 0;
+
+    u32x4 xa[2][TM_KMAX];
+    auto load_x = [&](const int tile, const int ln) {
+        const int frow = ln & 15, fg = ln >> 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int gm = tile * T2_BM + wave * 32 + i * 16 + frow;
+            gm = gm < p.M ? gm : p.M - 1;
+#pragma unroll
+            for (int kk = 0; kk < TM_KMAX; ++kk)
+                xa[i][kk] = *reinterpret_cast<const u32x4*>(xt + (size_t)gm * p.ldxt + (kk < ks1 ? kk : ks1 - 1) * 32 + fg * 8);
+        }
+    };
+
+    f32x4 acc2[2][T2_NB];
+    f32x4 a1[2][2];
+    auto frag_off = [&](const int ln) {                    // fragment chunk of a 64-byte LDS row: row ln & 15, swizzled chunk
+        const int fr = ln & 15;
+        return fr * 64 + (((ln >> 4) ^ ((fr & 8) >> 2)) << 4);
+    };
+    auto fc1 = [&](const unsigned st3, const int ln) {
+        const int f_rd = frag_off(ln);
+        const char* r1 = smem + T2_R1 + st3 * TM_STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) a1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // fragment reads two K-slabs ahead of their MFMAs, pinned there (left alone, hipcc hoists all 14 reads: 56 registers
+        // on top of the 184 that acc2 / X / acc1 / H hold, and spills)
+        u32x4 bw[T2_BWD + 1][2];
+#pragma unroll
+        for (int kk = 0; kk < T2_BWD; ++kk) {
+            bw[kk][0] = *reinterpret_cast<const u32x4*>(r1 + kk * 2048 + f_rd);
+            bw[kk][1] = *reinterpret_cast<const u32x4*>(r1 + kk * 2048 + f_rd + 1024);
+        }
+#pragma unroll
+        for (int kk = 0; kk < TM_KMAX; ++kk) {
+            if (kk + T2_BWD < TM_KMAX) {
+                bw[(kk + T2_BWD) % (T2_BWD + 1)][0] = *reinterpret_cast<const u32x4*>(r1 + (kk + T2_BWD) * 2048 + f_rd);
+                bw[(kk + T2_BWD) % (T2_BWD + 1)][1] = *reinterpret_cast<const u32x4*>(r1 + (kk + T2_BWD) * 2048 + f_rd + 1024);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a1[i][0] = Mma2<T>::run(bw[kk % (T2_BWD + 1)][0], xa[i][kk], a1[i][0]);
+                a1[i][1] = Mma2<T>::run(bw[kk % (T2_BWD + 1)][1], xa[i][kk], a1[i][1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    u32x4 hf[2];
+    auto gelu = [&](const int g, const int ln) {           // bias + exact-erf GELU + rounding: acc1 -> the two A fragments of fc2
+        const int fg = ln >> 4;
+        const f32x4 bb0 = *reinterpret_cast<const f32x4*>(b1s + g * 32 + 4 * fg);
+        const f32x4 bb1 = *reinterpret_cast<const f32x4*>(b1s + g * 32 + 16 + 4 * fg);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f32x2 v[4] = {f32x2{a1[i][0].x + bb0.x, a1[i][0].y + bb0.y}, f32x2{a1[i][0].z + bb0.z, a1[i][0].w + bb0.w},
+                          f32x2{a1[i][1].x + bb1.x, a1[i][1].y + bb1.y}, f32x2{a1[i][1].z + bb1.z, a1[i][1].w + bb1.w}};
+#if !(TM_ABL & 2)
+#ifdef T2_GELU_RCP
+            gelu_pk_n<4>(v);
+#else
+            gelu_poly_pk_n<4>(v);
+#endif
+#endif
+            T e[8] = {from_f32<T>(v[0].x), from_f32<T>(v[0].y), from_f32<T>(v[1].x), from_f32<T>(v[1].y),
+                      from_f32<T>(v[2].x), from_f32<T>(v[2].y), from_f32<T>(v[3].x), from_f32<T>(v[3].y)};
+            __builtin_memcpy(&hf[i], e, 16);
+        }
+    };
+    auto fc2 = [&](const unsigned st4, const int ln) {
+        const int f_rd = frag_off(ln);
+        const char* r2 = smem + T2_R2 + st4 * TM_STAGE;
+        u32x4 bf[T2_BFD + 1];
+#pragma unroll
+        for (int j = 0; j < T2_BFD; ++j) bf[j] = *reinterpret_cast<const u32x4*>(r2 + j * 1024 + f_rd);
+#pragma unroll
+        for (int j = 0; j < T2_NB; ++j) {
+            if (j + T2_BFD < T2_NB) bf[(j + T2_BFD) % (T2_BFD + 1)] = *reinterpret_cast<const u32x4*>(r2 + (j + T2_BFD) * 1024 + f_rd);
+            acc2[0][j] = Mma2<T>::run(hf[0], bf[j % (T2_BFD + 1)], acc2[0][j]);
+            acc2[1][j] = Mma2<T>::run(hf[1], bf[j % (T2_BFD + 1)], acc2[1][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    auto run = [&](auto lag_c) {
+        constexpr bool LAG = decltype(lag_c)::value;
+        load_x(blockIdx.x, lane_now());                    // (inside each half's own code: one live range per path)
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            if (stamp) ts = __builtin_readcyclecounter();
+            __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the X operands have landed, and the compiler knows it
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < T2_NB; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            auto iter = [&](auto first_c, const int t) {
+                constexpr bool FIRST = decltype(first_c)::value;
+                T2_ITER_SYNC();
+                // pieces of iteration t + 2 (the next tile's first groups at the end of this one: the weights are the same)
+                int g2 = t + 2;
+                g2 = g2 < G ? g2 : g2 - G;
+                g2 = g2 < G ? g2 : g2 - G;                    // (G == 1)
+                piece_bases(g2);
+                so1 = (s3 == 0 ? 2u : s3 - 1) * TM_STAGE;     // stage (gi + 2) % 3
+                so2 = ((s4 + 2) & 3) * TM_STAGE;              // stage (gi + 2) % 4
+                const int ln = lane_now();
+                issue(0, ln); issue(1, ln);
+                if constexpr (!LAG) {
+                    fc1(s3, ln);
+                    issue(2, ln); issue(3, ln);
+                    gelu(t, ln);
+                    fc2(s4, ln);
+                } else {
+                    if constexpr (!FIRST) {
+                        gelu(t - 1, ln);
+                        fc2((s4 + 3) & 3, ln);                // slab t - 1: stage (gi - 1) % 4
+                    }
+                    issue(2, ln); issue(3, ln);
+                    fc1(s3, ln);
+                }
+                s3 = s3 == 2 ? 0 : s3 + 1;
+                s4 = (s4 + 1) & 3;
+            };
+            iter(BoolC<true>{}, 0);
+#pragma unroll 1
+            for (int t = 1; t < G; ++t) iter(BoolC<false>{}, t);
+            if constexpr (LAG) {
+                const int ln = lane_now();
+                gelu(G - 1, ln);
+                fc2((s4 + 3) & 3, ln);
+            }
+            if (stamp) { const unsigned long long n = __builtin_readcyclecounter(); t_loop += n - ts; ts = n; }
+            // ---- tile epilogue ----
+            // (per-lane epilogue geometry from a fresh lane id as well: nothing lane-derived lives across the iterations)
+            const int le = lane_now();
+            const int frow = le & 15, fg = le >> 4;
+            const int rt = wave * 2 + (le >> 5), rc = le & 31;    // reader: token slot tid >> 5, 8-channel chunk tid & 31
+            const int mr = tile * T2_BM + rc * 8;
+            const int rimg = mr / p.t_rows;
+            const int rcc = mr - rimg * p.t_rows;
+            const bool row_ok = mr < p.M;
+            // token row j * 16 + rt of the image: one 32-bit per-lane offset for all passes + a uniform per-pass base (thirteen
+            // hoisted 64-bit addresses were spilled, and every reload in a pass is a vmcnt(0) on the previous pass's stores)
+            const unsigned voff = (unsigned)((((size_t)rimg * p.S + rt) * p.ldx + rcc) * sizeof(T));
+            const size_t pass_stride = (size_t)16 * p.ldx * sizeof(T);
+            u32x4 res[T2_NB];
+#pragma unroll
+            for (int j = 0; j < T2_NB; ++j) {
+                const int rn = j * 16 + rt;
+                res[j] = u32x4{0u, 0u, 0u, 0u};
+                if (rn < p.S && row_ok) res[j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(x) + j * pass_stride + voff);
+            }
+            // one wait for the whole residual tile; the passes issue nothing but stores (see above)
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+            for (int j = 0; j < T2_NB; ++j) {
+                // the next tile's X (56 registers) is requested once seven passes have released as many accumulators
+                // (unconditionally -- rows past M clamp to the last row: under a condition the OLD X stays live through all passes)
+                if (j == 7) load_x(tile + gridDim.x, le);
+                char* const sb = stg + (j & 1) * 16384;
+                const float bn = b2s[j * 16 + frow];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const f32x4 v = {acc2[i][j].x + bn, acc2[i][j].y + bn, acc2[i][j].z + bn, acc2[i][j].w + bn};
+                    *reinterpret_cast<f32x4*>(sb + frow * 1024 + (((wave * 8 + i * 4 + fg) ^ frow) << 4)) = v;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                const int rn = j * 16 + rt;
+                const bool live = rn < p.S && row_ok;
+                float ssum = 0.f, ssq = 0.f;
+                if (live) {
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(sb + rt * 1024 + (((2 * rc) ^ rt) << 4));
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(sb + rt * 1024 + (((2 * rc + 1) ^ rt) << 4));
+                    T r8[8];
+                    __builtin_memcpy(r8, &res[j], 16);
+                    T e[8] = {from_f32<T>(v0.x + to_f32(r8[0])), from_f32<T>(v0.y + to_f32(r8[1])), from_f32<T>(v0.z + to_f32(r8[2])),
+                              from_f32<T>(v0.w + to_f32(r8[3])), from_f32<T>(v1.x + to_f32(r8[4])), from_f32<T>(v1.y + to_f32(r8[5])),
+                              from_f32<T>(v1.z + to_f32(r8[6])), from_f32<T>(v1.w + to_f32(r8[7]))};
+                    u32x4 o;
+                    __builtin_memcpy(&o, e, 16);
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(x) + j * pass_stride + voff) = o;
+                    if (!(T2_DIAG & 1) && p.stats) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const float f = to_f32(e[k]);
+                            ssum += f;
+                            ssq += f * f;
+                        }
+                    }
+                }
+                if (!(T2_DIAG & 1) && p.stats) {                                 // (workgroup-uniform: every lane takes part in the DPP rows)
+                    ssum = row16_sum(ssum);
+                    ssq = row16_sum(ssq);
+                    if (live && (rc & 15) == 0) {
+                        float* dst = p.stats + (((size_t)rimg * p.S + rn) * stile + (rcc >> 7)) * 2;
+                        dst[0] = ssum;
+                        dst[1] = ssq;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (stamp) { const unsigned long long n = __builtin_readcyclecounter(); t_epi += n - ts; ts = n; }
+        }
+    };
+    if (!lag) run(BoolC<false>{}); else run(BoolC<true>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no LDS-DMA may outlive the workgroup
     if (stamp && tid == 0) {
         p.dbg[(size_t)blockIdx.x * 4 + 0] = t_loop;
@@ -456,24 +857,55 @@ extern "C" void mlpk_token_mlp_debug(void* buf) { g_tm_dbg = reinterpret_cast<un
 
 extern "C" int mlpk_token_mlp_chunk(void) { return 32; }
 
+// 1: W2 packed with the hidden columns of every group of 32 permuted (k slot 8 f + e <- column (e < 4 ? 4 f + e : 16 + 4 f + e - 4))
+// for the 256-row kernel that keeps the hidden in registers; 0: natural order (128-row kernel).
+extern "C" int mlpk_token_mlp_layout(int S, int nchunks) {
+    const char* e = getenv("MLPK_TOKEN_MLP_LAYOUT");
+    if (e && e[0] == '0') return 0;
+    return (S <= 16 * T2_NB && nchunks * 32 <= TM_B1_FLOATS) ? 1 : 0;
+}
+
 extern "C" int mlpk_token_mlp(int dtype, const void* xt, int ldxt, int M, int S, const void* w1, int ldw1, const float* b1,
                               const void* w2, int ldw2, const float* b2, int nchunks, void* x, int ldx, int t_rows,
-                              void* stream) {
+                              float* stats, int layout, void* stream) {
     if (!xt || !w1 || !w2 || !b1 || !b2 || !x) return MLPK_ENULL;
     if (dtype != MLPK_F16 && dtype != MLPK_BF16) return MLPK_EDTYPE;   // 16-bit storage only (fp32 uses the two-GEMM path)
     if (M <= 0 || S <= 0 || nchunks <= 0 || t_rows <= 0) return MLPK_ESHAPE;
+    if (layout != 0 && layout != 1) return MLPK_EMODE;
     if (S > 16 * (TM_NB0 + TM_NB1) || nchunks * 32 > TM_B1_FLOATS) return MLPK_ESHAPE;  // up to 224 tokens, 1024 hidden
     if (ldxt % 32 || ldxt > 32 * TM_KMAX || ldxt < S) return MLPK_ESHAPE;       // K of fc1 = ldxt: whole 64-byte slabs, <= 7
     if (ldw1 != 256 || ldw2 < nchunks * 32 || ldw2 % 8) return MLPK_ESHAPE;
     // a 16-byte chunk of the output = 8 consecutive rows (channels) of one image
     if (M % 8 || t_rows % 8 || M % t_rows || ldx % 8 || ldx < t_rows) return MLPK_ESHAPE;
+    if (stats && (t_rows % 128 || ((uintptr_t)stats & 7))) return MLPK_ESHAPE;     // statistics partials: whole 128-channel tiles per image
     if (((uintptr_t)xt & 15) || ((uintptr_t)w1 & 15) || ((uintptr_t)w2 & 15) || ((uintptr_t)x & 15)) return MLPK_EALIGN;
     TokenMlpArgs a;
     a.xt = xt; a.w1 = w1; a.w2 = w2; a.b1 = b1; a.b2 = b2; a.x = x;
     a.M = M; a.S = S; a.ks1 = ldxt / 32; a.G = nchunks;
     a.ldxt = ldxt; a.ldw2 = ldw2; a.ldx = ldx; a.t_rows = t_rows;
+    a.stats = stats;
     a.dbg = g_tm_dbg;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (layout == 1) {
+        if (S > 16 * T2_NB) return MLPK_ESHAPE;
+        if ((unsigned long long)(M / t_rows) * S * ldx * 2ull >= (1ull << 32)) return MLPK_ESHAPE;   // 32-bit per-lane offsets into x
+        const int tiles2 = (M + T2_BM - 1) / T2_BM;
+        const unsigned grid2 = (unsigned)(tiles2 < tm_grid_cap() ? tiles2 : tm_grid_cap());
+        hipError_t e2;
+        if (dtype == MLPK_BF16) {
+            auto k = token_mlp_rr_kernel<bf16_t>;
+            e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS);
+            if (e2 != hipSuccess) return (int)e2;
+            hipLaunchKernelGGL(k, dim3(grid2), dim3(512), T2_LDS, s, a);
+        } else {
+            auto k = token_mlp_rr_kernel<f16_t>;
+            e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS);
+            if (e2 != hipSuccess) return (int)e2;
+            hipLaunchKernelGGL(k, dim3(grid2), dim3(512), T2_LDS, s, a);
+        }
+        MLPK_LAUNCH_CHECK();
+        return 0;
+    }
     const int tiles = (M + TM_BM - 1) / TM_BM;
     const unsigned grid = (unsigned)(tiles < tm_grid_cap() ? tiles : tm_grid_cap());
     hipError_t e;

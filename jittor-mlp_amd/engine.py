@@ -169,16 +169,35 @@ def channel_chunks(rows, hidden_row_bytes):
 CHUNK_BYTES = float(os.environ.get("MLPK_CHUNK_MB", "1e9")) * 1e6      # default off (one chunk) until measured
 
 
-def token_mlp(xt, ldxt, M, S, w1, b1, w2, b2, nchunks, x, ldx, t_rows):
+def token_mlp(xt, ldxt, M, S, w1, b1, w2, b2, nchunks, x, ldx, t_rows, stats=None, layout=0):
     N.check(N.lib().mlpk_token_mlp(dtype_code(xt.dtype), ptr(xt), ldxt, M, S, ptr(w1), w1.stride(0), ptr(b1), ptr(w2),
-                                   w2.stride(0), ptr(b2), nchunks, ptr(x), ldx, t_rows, stream()), "mlpk_token_mlp")
+                                   w2.stride(0), ptr(b2), nchunks, ptr(x), ldx, t_rows, ptr(stats), layout, stream()), "mlpk_token_mlp")
+
+
+def layernorm_transpose_supported(dtype, C, ldx, ld_tt):
+    return dtype in (torch.float16, torch.bfloat16) and C % 128 == 0 and C <= 1024 and ldx % 8 == 0 and ld_tt % 8 == 0 \
+        and os.environ.get("MLPK_NO_FUSED_TOKEN_LN", "0") != "1"
+
+
+def layernorm_transpose(x, nimg, S, C, gamma, beta, out_tt, ld_tt, eps=1e-5):
+    N.check(N.lib().mlpk_layernorm_transpose(dtype_code(x.dtype), ptr(x), nimg, S, C, x.stride(0), ptr(gamma), ptr(beta), eps,
+                                             ptr(out_tt), ld_tt, stream()), "mlpk_layernorm_transpose")
+
+
+def epilogue_stats():
+    """MLPK_NO_EPILOGUE_STATS=1: separate statistics pass after the token kernel (A/B aid)."""
+    return os.environ.get("MLPK_NO_EPILOGUE_STATS", "0") != "1"
+
+
+def stats_finalize(part, rows, nparts, count, mean, rstd, eps=1e-5):
+    N.check(N.lib().mlpk_stats_finalize(ptr(part), rows, nparts, count, eps, ptr(mean), ptr(rstd), stream()), "mlpk_stats_finalize")
 
 
 def token_mlp_supported(dtype, S, sp, hidden=0):
     return dtype in (torch.float16, torch.bfloat16) and S <= 208 and sp <= 224 and sp % 32 == 0 and hidden <= 1024
 
 
-def pack_token_mlp(w1, b1, w2, b2, dtype, device, sp):
+def pack_token_mlp(w1, b1, w2, b2, dtype, device, sp, layout=None):
     """Weights of the fused token-mixing kernel: W1 rows / b1 / W2 columns zero-padded to whole hidden groups
     of mlpk_token_mlp_chunk() = 32, W1's K axis zero-padded to 256 (8 LDS planes per group)."""
     ch = N.lib().mlpk_token_mlp_chunk()
@@ -192,7 +211,15 @@ def pack_token_mlp(w1, b1, w2, b2, dtype, device, sp):
     b1p[:T] = b1.detach().to(device=device, dtype=torch.float32)
     w2p = torch.zeros((S, nch * ch), dtype=dtype, device=device)
     w2p[:, :T] = w2.to(device=device, dtype=dtype)
-    return w1p, b1p, w2p, f32(b2, device), nch
+    if layout is None:
+        layout = N.lib().mlpk_token_mlp_layout(S, nch)
+    if layout == 1:
+        # column slot 8 f + e of every 32-column group <- column (e < 4 ? 4 f + e : 16 + 4 f + e - 4)   (include/mlpk.h)
+        slot = torch.arange(32)
+        f, e = slot // 8, slot % 8
+        src = torch.where(e < 4, 4 * f + e, 16 + 4 * f + e - 4).to(device)
+        w2p = w2p.view(S, nch, 32)[:, :, src].reshape(S, nch * ch).contiguous()
+    return w1p, b1p, w2p, f32(b2, device), nch, layout
 
 
 def patchify(src, out, B, Cin, H, W, ph, pw, pad, ldo, layout=N.LAYOUT_NCHW, px_stride=0, order=0):

@@ -47,14 +47,15 @@ def layernorm_stats(ws, x, rows, C, tag="ln", eps=1e-5):
     return mean, rstd
 
 
-def channel_mlp(ws, x, rows, C, pk, prefix, hidden, *, norm=True, cscale2=None, res_src=None, tag="cm", eps=1e-5):
+def channel_mlp(ws, x, rows, C, pk, prefix, hidden, *, norm=True, cscale2=None, res_src=None, tag="cm", eps=1e-5, stats=None):
     """x <- x + fc2(gelu(fc1(LN(x))))   (mlp_mixer.py:38; vip.py:82-88; s2_mlp_v2.py:78-84).
-    LN -> row-major normalised copy; fc1 epilogue = bias + exact GELU; fc2 epilogue = bias + residual."""
+    LN -> row-major normalised copy; fc1 epilogue = bias + exact GELU; fc2 epilogue = bias + residual.
+    `stats` = (mean, rstd) of x's rows when the producer of x already delivered them (token_mlp's epilogue)."""
     ln = None
     if norm and (prefix + "fc1.csum") in pk:
         # LayerNorm folded into fc1 (gamma in the weights, beta in the bias, mean/rstd applied on the
         # accumulator): x itself is the GEMM operand, only the row statistics are computed
-        mean, rstd = layernorm_stats(ws, x, rows, C, tag=tag + ".ln", eps=eps)
+        mean, rstd = stats if stats is not None else layernorm_stats(ws, x, rows, C, tag=tag + ".ln", eps=eps)
         ln = (mean, rstd, pk[prefix + "fc1.csum"])
         xn = x
     elif norm:

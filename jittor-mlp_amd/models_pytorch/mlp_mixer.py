@@ -17,6 +17,7 @@ Mapping to kernels:
 import os
 from functools import partial
 
+import torch
 from torch import nn
 
 from .. import _native as N
@@ -87,16 +88,27 @@ class MLPMixer(E.EngineModule):
         thp = E.round_up(th, 32)
         for i in range(depth):
             p = "b%d." % i
-            mean, rstd = layernorm_stats(ws, x, rows, C)
             xt = ws.get("tok.xt", (B * C, sp))                 # LN(x) transposed per image, zero K-padding
-            E.norm_apply(x, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "tok.ln.g"], beta=pk[p + "tok.ln.b"],
-                         out_tt=xt, S=S, ld_tt=sp)
+            if E.layernorm_transpose_supported(x.dtype, C, C, sp):
+                E.layernorm_transpose(x, B, S, C, pk[p + "tok.ln.g"], pk[p + "tok.ln.b"], xt, sp)     # statistics + apply, one pass
+            else:
+                mean, rstd = layernorm_stats(ws, x, rows, C)
+                E.norm_apply(x, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "tok.ln.g"], beta=pk[p + "tok.ln.b"],
+                             out_tt=xt, S=S, ld_tt=sp)
             fused = pk.get(p + "tok.fused")
             if fused is not None:
                 # both token-mixing products + GELU + residual in one kernel; the hidden stays in LDS
-                w1f, b1f, w2f, b2f, nch = fused
-                E.token_mlp(xt, sp, B * C, S, w1f, b1f, w2f, b2f, nch, x, C, C)
-                channel_mlp(ws, x, rows, C, pk, p + "ch.", C * ef)
+                w1f, b1f, w2f, b2f, nch, lay = fused
+                stats = None
+                if C % 128 == 0 and (p + "ch.fc1.csum") in pk and E.epilogue_stats():
+                    # the statistics of the channel LayerNorm come out of the token kernel's epilogue (no pass over x)
+                    part = ws.get("tok.stats", (rows, C // 128, 2), torch.float32)
+                    E.token_mlp(xt, sp, B * C, S, w1f, b1f, w2f, b2f, nch, x, C, C, stats=part, layout=lay)
+                    stats = (ws.get("cm.ln.mean", (rows,), torch.float32), ws.get("cm.ln.rstd", (rows,), torch.float32))
+                    E.stats_finalize(part, rows, C // 128, C, stats[0], stats[1])
+                else:
+                    E.token_mlp(xt, sp, B * C, S, w1f, b1f, w2f, b2f, nch, x, C, C, layout=lay)
+                channel_mlp(ws, x, rows, C, pk, p + "ch.", C * ef, stats=stats)
                 continue
             ht = ws.get("tok.h", (B * C, thp))
             E.gemm(xt, pk[p + "tok.fc1.w"], ht, B * C, th, sp, bias=pk[p + "tok.fc1.b"], act=N.ACT_GELU, tag="token_fc1")

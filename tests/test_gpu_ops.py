@@ -560,13 +560,15 @@ def test_gemm_folded_layernorm(dtype):
         assert err < EPS[dtype] * 8 * max(1.0, ref.abs().max().item()), (str(dtype), algo, err)
 
 
+@pytest.mark.parametrize("layout", [0, 1])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_fused_token_mlp(dtype):
+def test_fused_token_mlp(dtype, layout):
     """mlpk_token_mlp == the two token-mixing GEMMs + GELU + residual (mlp_mixer.py:16-27 with Conv1d k=1),
-    incl. ragged tokens (S not a multiple of 16/32), several hidden chunks, rows spanning several images."""
+    incl. ragged tokens (S not a multiple of 16/32), several hidden chunks, rows spanning several images; both weight
+    layouts (0: 128-row tiles, hidden through LDS; 1: 256-row tiles, hidden in registers, W2 columns permuted)."""
     pkg = load_pkg()
     E = pkg.engine
-    for ci, (B_, C, S, T) in enumerate([(2, 32, 16, 64), (3, 40, 49, 196), (2, 128, 196, 784), (5, 8, 20, 40), (1, 32, 32, 32), (2, 64, 208, 1024)]):
+    for ci, (B_, C, S, T) in enumerate([(2, 32, 16, 64), (3, 40, 49, 196), (2, 128, 196, 784), (5, 8, 20, 40), (1, 32, 32, 32), (3, 256, 50, 96), (2, 64, 208, 1024)]):
         sp = E.round_up(S, 32)
         xn = rnd((B_, S, C), dtype, 400 + ci)                                 # LN output (token-major)
         x = rnd((B_ * S, C), dtype, 410 + ci).to(dev())                       # residual stream
@@ -576,9 +578,10 @@ def test_fused_token_mlp(dtype):
         b2 = rnd((S,), torch.float32, 450 + ci)
         xt = torch.zeros((B_ * C, sp), dtype=dtype, device=dev())
         xt[:, :S] = xn.permute(0, 2, 1).reshape(B_ * C, S).to(dev())
-        w1p, b1p, w2p, b2p, nch = E.pack_token_mlp(w1, b1, w2, b2, dtype, dev(), sp)
+        w1p, b1p, w2p, b2p, nch, lay = E.pack_token_mlp(w1, b1, w2, b2, dtype, dev(), sp, layout=layout)
+        assert lay == layout
         x0 = x.clone()
-        E.token_mlp(xt, sp, B_ * C, S, w1p, b1p, w2p, b2p, nch, x, C, C)
+        E.token_mlp(xt, sp, B_ * C, S, w1p, b1p, w2p, b2p, nch, x, C, C, layout=lay)
         torch.cuda.synchronize()
         w1r, w2r = w1.to(dtype).double(), w2.to(dtype).double()
         h = oracle.gelu(torch.einsum("ts,bsc->btc", w1r, xn.double()) + b1.double().view(1, -1, 1))
@@ -588,6 +591,55 @@ def test_fused_token_mlp(dtype):
         assert torch.isfinite(got).all()
         err = (got - ref).abs().max().item()
         assert err < EPS[dtype] * 6 * max(1.0, ref.abs().max().item()), (str(dtype), ci, err)
+        if C % 128 == 0:
+            # epilogue statistics: same x bit for bit, and mean / rstd of the rows of the ROUNDED x (what the next LayerNorm reads)
+            x2 = x0.clone()
+            part = torch.full((B_ * S, C // 128, 2), float("nan"), dtype=torch.float32, device=dev())
+            E.token_mlp(xt, sp, B_ * C, S, w1p, b1p, w2p, b2p, nch, x2, C, C, stats=part, layout=lay)
+            mean = torch.empty(B_ * S, dtype=torch.float32, device=dev())
+            rstd = torch.empty_like(mean)
+            E.stats_finalize(part, B_ * S, C // 128, C, mean, rstd, eps=1e-5)
+            torch.cuda.synchronize()
+            assert torch.equal(x2, x)
+            xd = x.cpu().double()
+            mu = xd.mean(1)
+            rs = 1.0 / torch.sqrt(xd.var(1, unbiased=False) + 1e-5)
+            assert (mean.cpu().double() - mu).abs().max().item() < 2e-6 * max(1.0, xd.abs().max().item())
+            assert ((rstd.cpu().double() - rs).abs() / rs).max().item() < 2e-5
+    with pytest.raises(RuntimeError):                                         # partial tiles per image: refused, not mis-summed
+        E.token_mlp(xt, sp, B_ * C, S, w1p, b1p, w2p, b2p, nch, x, C, C, stats=torch.zeros(B_ * S * 2, device=dev()), layout=lay)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_layernorm_transpose_one_pass(dtype):
+    """mlpk_layernorm_transpose == nn.LayerNorm over channels followed by the per-image transpose (mlp_mixer.py:34, :6-13),
+    zero K-padding columns, ragged last token tile; against the fp64 oracle and bit-compared with the two-kernel path's layout."""
+    pkg = load_pkg()
+    E = pkg.engine
+    for ci, (B_, S, C) in enumerate([(2, 196, 768), (3, 49, 128), (1, 33, 1024), (2, 64, 256), (5, 7, 512)]):
+        sp = E.round_up(S, 32)
+        x = (rnd((B_ * S, C), dtype, 1300 + ci) * 3 + 0.7).to(dtype).to(dev())
+        g = rnd((C,), torch.float32, 1310 + ci) + 1.2
+        be = rnd((C,), torch.float32, 1320 + ci)
+        xt = torch.full((B_ * C, sp), float("nan"), dtype=dtype, device=dev())
+        E.layernorm_transpose(x, B_, S, C, g.to(dev()), be.to(dev()), xt, sp)
+        torch.cuda.synchronize()
+        ref = oracle.layer_norm(x.cpu().double().reshape(B_, S, C), g.double(), be.double()).permute(0, 2, 1)   # (B, C, S)
+        got = xt.cpu().double().reshape(B_, C, sp)
+        assert torch.isfinite(got).all()
+        assert (got[:, :, S:] == 0).all()
+        err = (got[:, :, :S] - ref).abs().max().item()
+        assert err < EPS[dtype] * 1.01 * max(1.0, ref.abs().max().item()), (str(dtype), ci, err)
+        # the two-kernel path (row statistics, then normalise + transpose) rounds the same values
+        mean = torch.empty(B_ * S, dtype=torch.float32, device=dev())
+        rstd = torch.empty_like(mean)
+        E.row_stats(x, B_ * S, C, C, mean, rstd)
+        xt2 = torch.zeros((B_ * C, sp), dtype=dtype, device=dev())
+        E.norm_apply(x, B_ * S, C, C, mean=mean, rstd=rstd, gamma=g.to(dev()), beta=be.to(dev()), out_tt=xt2, S=S, ld_tt=sp)
+        torch.cuda.synchronize()
+        assert ((xt.float() - xt2.float()).abs() <= EPS[dtype] * 2 * xt2.float().abs().clamp(min=1.0)).all()
+    with pytest.raises(RuntimeError):
+        E.layernorm_transpose(x[:, :40], B_, S, 40, g.to(dev()), be.to(dev()), xt, sp)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

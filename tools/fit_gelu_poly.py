@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Fit the division-free GELU used by the fused token-mixing kernel (16-bit outputs):
+     gelu(x) = x * Phi(x),   Phi(x) ~= 0.5 + t * Q(t*t - 1),   t = clamp(x * sqrt(2) / A, -sqrt 2, sqrt 2)
+Q = polynomial of degree K-1 in u = t^2 - 1 in [-1, 1] (well conditioned in fp32), weighted minimax fit of the error of Phi.
+Prints the coefficients (highest first, Horner order) and the error of the fp32 evaluation over a dense grid."""
+import sys
+import numpy as np
+from numpy.polynomial import chebyshev as C, polynomial as P
+from scipy.special import erf
+
+A = float(sys.argv[1]) if len(sys.argv) > 1 else 4.5
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 11
+R2 = np.sqrt(2.0)
+
+
+def target(t):            # (Phi(x) - 0.5) / t with x = t * A / sqrt 2
+    x = t * A / R2
+    return np.where(t > 0, 0.5 * erf(x / R2) / np.maximum(t, 1e-300), A / R2 / np.sqrt(2 * np.pi))
+
+
+n = 6000
+t = (np.cos(np.pi * (np.arange(n) + 0.5) / n) * 0.5 + 0.5) * R2
+u = t * t - 1
+f = target(t)
+V = C.chebvander(u, K - 1)
+w = t.copy()
+for it in range(200):
+    c, *_ = np.linalg.lstsq(V * w[:, None], f * w, rcond=None)
+    e = np.abs((V @ c - f) * t)
+    w = w * (1 + 2 * e / e.max())
+    w /= w.max()
+mono = C.cheb2poly(c)                     # ascending powers of u
+coef = mono[::-1].astype(np.float32)      # Horner order, fp32
+
+
+def fma32(a, b, c_):
+    return (a.astype(np.float64) * b.astype(np.float64) + c_.astype(np.float64)).astype(np.float32)
+
+
+def gelu_poly32(x):
+    x = x.astype(np.float32)
+    tt = np.clip((x * np.float32(R2 / A)).astype(np.float32), np.float32(-R2), np.float32(R2))
+    uu = fma32(tt, tt, np.float32(-1.0) * np.ones_like(tt))
+    q = np.full_like(tt, coef[0])
+    for cc in coef[1:]:
+        q = fma32(q, uu, np.full_like(tt, cc))
+    ph = fma32(tt, q, np.full_like(tt, np.float32(0.5)))
+    return (x * ph).astype(np.float32), ph
+
+
+xs = np.concatenate([np.linspace(-12, 12, 2000001), np.linspace(-0.01, 0.01, 20001)])
+g, ph = gelu_poly32(xs)
+ref_phi = 0.5 * (1 + erf(xs / R2))
+ref = xs * ref_phi
+print("A = %.3f  K = %d   sum|coef| = %.2f" % (A, K, np.abs(mono).sum()))
+print("max |Phi err| = %.3e   max |gelu err| = %.3e (at x = %.3f)   max |gelu err| on |x| <= A: %.3e"
+      % (np.abs(ph - ref_phi).max(), np.abs(g - ref).max(), xs[np.abs(g - ref).argmax()], np.abs(g - ref)[np.abs(xs) <= A].max()))
+print("scale sqrt2/A = %.9g" % (R2 / A))
+print("coefficients (Horner order, u^%d first):" % (K - 1))
+print(", ".join("%.9gf" % v for v in coef))

@@ -26,42 +26,59 @@ def kernels(lines, pattern):
     return out
 
 
-def steady_loop(body):
-    """(start, end) of the innermost loop containing MFMAs: a conditional backward branch to a label."""
+def mfma_loops(body):
+    """Innermost loops containing >= 8 MFMAs: (start, end, n_mfma) of every conditional backward branch to a label whose
+    body holds no other such loop."""
     labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
-    best = None
+    loops = []
     for i, l in enumerate(body):
         m = re.match(r"\s+s_cbranch_\w+\s+(\.LBB\d+_\d+)", l)
         if m and m.group(1) in labels and labels[m.group(1)] < i:
             s = labels[m.group(1)]
             n = sum("v_mfma" in x for x in body[s:i])
-            if n >= 8 and (best is None or i - s < best[1] - best[0]):
-                best = (s, i, n)
-    return best
+            if n >= 8:
+                loops.append((s, i, n))
+    return [a for a in loops if not any(b is not a and a[0] <= b[0] and b[1] <= a[1] for b in loops)]
 
 
-def lint(path, pattern="gemm_nt_p8_kernel"):
+def steady_loop(body):
+    """the smallest of them (the persistent GEMM tile has one)"""
+    loops = mfma_loops(body)
+    return min(loops, key=lambda t: t[1] - t[0]) if loops else None
+
+
+def lint(path, pattern="gemm_nt_p8_kernel", hand_wait=r"s_waitcnt vmcnt\(8\) lgkmcnt\(0\)$", every_loop=False):
     lines = open(path).read().split("\n")
     bad = 0
     for name, a, b in kernels(lines, pattern):
         body = lines[a:b]
-        lp = steady_loop(body)
-        if lp is None:
+        found = mfma_loops(body) if every_loop else [steady_loop(body)]
+        if not found or found[0] is None:
             print("%s: no MFMA loop found" % name)
             bad += 1
             continue
-        s, e, n = lp
-        loop = [x.strip() for x in body[s:e + 1]]
-        spills = [x for x in loop if x.startswith(("scratch_", "buffer_load", "buffer_store"))]
-        waits = [x for x in loop if x.startswith("s_waitcnt") and "vmcnt" in x]
-        foreign = [x for x in waits if not re.match(r"s_waitcnt vmcnt\(8\) lgkmcnt\(0\)$", x)]
-        status = "ok" if not spills and not foreign else "BAD"
-        print("%-70s loop %4d instr, %3d mfma, %d glds, %d spill ops, vmcnt waits: %s  -> %s"
-              % (name[9:], len([x for x in loop if x and not x.startswith((";", "."))]), n,
-                 sum("global_load_lds" in x for x in loop), len(spills), sorted(set(waits)), status))
-        bad += status != "ok"
+        for s, e, n in found:
+            loop = [x.strip() for x in body[s:e + 1]]
+            spills = [x for x in loop if x.startswith(("scratch_", "buffer_load", "buffer_store"))]
+            waits = [x for x in loop if x.startswith("s_waitcnt") and "vmcnt" in x]
+            foreign = [x for x in waits if not re.match(hand_wait, x)]
+            status = "ok" if not spills and not foreign else "BAD"
+            print("%-70s loop %4d instr, %3d mfma, %d glds, %d spill ops, vmcnt waits: %s  -> %s"
+                  % (name[9:], len([x for x in loop if x and not x.startswith((";", "."))]), n,
+                     sum("global_load_lds" in x for x in loop), len(spills), sorted(set(waits)), status))
+            bad += status != "ok"
     return bad
 
 
+# the fused token-mixing kernels: one hand-counted wait per iteration each
+TOKEN_KERNELS = (("token_mlp_kernel", r"s_waitcnt vmcnt\(7\) lgkmcnt\(0\)$"), ("token_mlp_rr_kernel", r"s_waitcnt vmcnt\(4\) lgkmcnt\(0\)$"))
+
+
+def lint_token(path):
+    return sum(lint(path, pat, wait, every_loop=True) for pat, wait in TOKEN_KERNELS)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "token":
+        sys.exit(1 if lint_token(sys.argv[1]) else 0)
     sys.exit(1 if lint(sys.argv[1], *(sys.argv[2:3])) else 0)
