@@ -522,15 +522,16 @@ __global__ void __launch_bounds__(512, 1) token_mlp_kernel(const TokenMlpArgs p)
 //     wave per iteration (14 + 14 + 4 duplicates), constant `s_waitcnt vmcnt(4)`.
 //   * Epilogue: 13 passes of one token block x 256 channels of fp32 through LDS; reader = (token tid >> 5, 8 channels
 //     tid & 31): 512-byte runs of one token row per 32 lanes for the residual load and the store.
+//   * All 256 workgroups reach their epilogue together, so its 100 KB residual tile + 100 KB of stores + the 115 KB X tile of
+//     the next iteration arrive as one chip-wide burst (81 MB at ~8 TB/s = the measured 19k cycles per tile) while HBM idles
+//     during the 90k-cycle loops.  Touching those lines from inside the loop (LDS-DMA dword loads into a sink, all at once or
+//     one wave per iteration) moved the same wait into the loop's vmcnt and measured slower (0.207-0.218 vs 0.199 ms); left out.
 // LDS: 48 (W1 ring) + 64 (W2 ring) + 32 (epilogue staging) + 4 (b1) + 0.9 (b2) = 149 KiB.
 #ifndef T2_BWD
 #define T2_BWD 3         // W1 fragment pairs read ahead of their MFMAs
 #endif
 #ifndef T2_BFD
 #define T2_BFD 4         // W2 fragments read ahead of their MFMAs
-#endif
-#ifndef T2_DIAG
-#define T2_DIAG 0
 #endif
 constexpr int T2_BM = 256;
 constexpr int T2_NB = 13;                              // token blocks of 16: S <= 208
@@ -621,7 +622,7 @@ __global__ void __launch_bounds__(512, 1) token_mlp_rr_kernel(const TokenMlpArgs
     __syncthreads();
 
     unsigned long long t_loop = 0, t_epi = 0, ts = 0;
-    const bool stamp = !(T2_DIAG & 2) && p.dbg != nullptr;
+    const bool stamp = p.dbg != nullptr;
     char* const stg = smem + T2_STG;
     const int stile = p.stats ? (p.t_rows >> 7) : 0;
 
@@ -805,7 +806,7 @@ __global__ void __launch_bounds__(512, 1) token_mlp_rr_kernel(const TokenMlpArgs
                     u32x4 o;
                     __builtin_memcpy(&o, e, 16);
                     *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(x) + j * pass_stride + voff) = o;
-                    if (!(T2_DIAG & 1) && p.stats) {
+                    if (p.stats) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
                             const float f = to_f32(e[k]);
@@ -814,7 +815,7 @@ __global__ void __launch_bounds__(512, 1) token_mlp_rr_kernel(const TokenMlpArgs
                         }
                     }
                 }
-                if (!(T2_DIAG & 1) && p.stats) {                                 // (workgroup-uniform: every lane takes part in the DPP rows)
+                if (p.stats) {                                 // (workgroup-uniform: every lane takes part in the DPP rows)
                     ssum = row16_sum(ssum);
                     ssq = row16_sum(ssq);
                     if (live && (rc & 15) == 0) {
@@ -889,6 +890,7 @@ extern "C" int mlpk_token_mlp(int dtype, const void* xt, int ldxt, int M, int S,
     if (layout == 1) {
         if (S > 16 * T2_NB) return MLPK_ESHAPE;
         if ((unsigned long long)(M / t_rows) * S * ldx * 2ull >= (1ull << 32)) return MLPK_ESHAPE;   // 32-bit per-lane offsets into x
+        if ((unsigned long long)M * ldxt * 2ull >= (1ull << 32)) return MLPK_ESHAPE;                // ... and into xt (prefetch)
         const int tiles2 = (M + T2_BM - 1) / T2_BM;
         const unsigned grid2 = (unsigned)(tiles2 < tm_grid_cap() ? tiles2 : tm_grid_cap());
         hipError_t e2;
