@@ -45,62 +45,22 @@ __device__ __forceinline__ float gelu_f(float x) {
     return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f));
 }
 
-// GELU for 16-bit outputs: erf by Abramowitz & Stegun 7.1.28, erf(z) = 1 - (1 + a1 z + .. + a6 z^6)^-16
-// (|err| <= 3e-7), with the 1/sqrt(2) folded into the coefficients: ONE quarter-rate instruction (rcp) per
-// element instead of two (rcp + exp), everything else pairs into v_pk_* ops.  The polynomial is additionally scaled
-// by 2^(1/16), so that its 16th power carries the factor 2 and the reciprocal comes out already halved:
-//   gelu(x) = x/2 + |x|/2 * erf(|x|/sqrt 2) = max(x, 0) - |x| * D'(|x|)^-16,    D' = 2^(1/16) * D
-// 17 VALU instructions per PAIR of elements.  |GELU error| <= 7.1e-7 (measured over [-12, 12]), far below half an
-// ulp of f16/bf16; float outputs keep gelu_f.
-#define MLPK_GELU_C0 1.0442737340927124f
-#define MLPK_GELU_C1 0.052075162529945374f
-#define MLPK_GELU_C2 0.02207699790596962f
-#define MLPK_GELU_C3 0.003422739217057824f
-#define MLPK_GELU_C4 3.9686136005911976e-05f
-#define MLPK_GELU_C5 5.105520904180594e-05f
-#define MLPK_GELU_C6 5.62129980608006e-06f
+// GELU for 16-bit outputs, division-free:
+//   gelu(x) = x * Phi(x),  Phi(x) ~= 0.5 + t * Q(t^2 - 1),  t = clamp(x * sqrt2 / 4.5, -sqrt2, sqrt2)
+// Q = degree-10 polynomial in u = t^2 - 1 in [-1, 1] (weighted minimax fit of the error of Phi, tools/fit_gelu_poly.py; sum |c| =
+// 1.27, so fp32 Horner is well conditioned).  16 VALU instructions per PAIR of elements (everything but the clamp pairs into
+// v_pk_* ops) and no transcendental; the form it replaces -- erf by Abramowitz & Stegun 7.1.28, 1 - (1 + a1 z + .. + a6 z^6)^-16 --
+// took 19 + 2 v_rcp_f32 per pair, and the kernels that evaluate GELU are bound by VALU instruction count (the fused
+// token-mixing kernel: profiles/r02_token_mlp_ablation.txt; the fc1 epilogue of the channel MLP).
+// |Phi error| <= 2.7e-6 everywhere (|x| > 4.5 clamps to Phi(4.5) = 1 - 3.4e-6), |gelu error| <= 3.7e-6 on |x| <= 4.5: 60x below
+// half an ulp of f16 at that magnitude; checked in fp32 emulation by tests/test_host_cpu.py against the coefficients HERE.
+// float outputs keep gelu_f.
+#define MLPK_GELUP_SCALE 0.314269681f
+#define MLPK_GELUP_COEFS {0.00260713836f, -0.00718860654f, 0.00979797821f, -0.0172248576f, 0.0355015062f, -0.0601866171f, 0.090279378f, -0.127707109f, 0.174028099f, -0.245624334f, 0.499268919f}
 
 // gelu on N independent pairs with the N dependency chains interleaved step by step: a single wave running ONE
 // chain is latency-bound (each v_pk op waits for its predecessor); N = 4 keeps the VALU issuing back to back.
 template <int N> __device__ __forceinline__ void gelu_pk_n(f32x2 (&x)[N]) {
-    f32x2 ax[N], d[N];
-#pragma unroll
-    for (int c = 0; c < N; ++c) ax[c] = __builtin_elementwise_abs(x[c]);
-#pragma unroll
-    for (int c = 0; c < N; ++c) d[c] = __builtin_elementwise_fma(ax[c], f32x2{MLPK_GELU_C6, MLPK_GELU_C6}, f32x2{MLPK_GELU_C5, MLPK_GELU_C5});
-#pragma unroll
-    for (int c = 0; c < N; ++c) d[c] = __builtin_elementwise_fma(d[c], ax[c], f32x2{MLPK_GELU_C4, MLPK_GELU_C4});
-#pragma unroll
-    for (int c = 0; c < N; ++c) d[c] = __builtin_elementwise_fma(d[c], ax[c], f32x2{MLPK_GELU_C3, MLPK_GELU_C3});
-#pragma unroll
-    for (int c = 0; c < N; ++c) d[c] = __builtin_elementwise_fma(d[c], ax[c], f32x2{MLPK_GELU_C2, MLPK_GELU_C2});
-#pragma unroll
-    for (int c = 0; c < N; ++c) d[c] = __builtin_elementwise_fma(d[c], ax[c], f32x2{MLPK_GELU_C1, MLPK_GELU_C1});
-#pragma unroll
-    for (int c = 0; c < N; ++c) d[c] = __builtin_elementwise_fma(d[c], ax[c], f32x2{MLPK_GELU_C0, MLPK_GELU_C0});
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int c = 0; c < N; ++c) d[c] = d[c] * d[c];
-#pragma unroll
-    for (int c = 0; c < N; ++c) d[c] = f32x2{__builtin_amdgcn_rcpf(d[c].x), __builtin_amdgcn_rcpf(d[c].y)};
-#pragma unroll
-    for (int c = 0; c < N; ++c) {
-        const f32x2 relu = __builtin_elementwise_fma(x[c], f32x2{0.5f, 0.5f}, ax[c] * 0.5f);     // max(x, 0) = x/2 + |x|/2
-        x[c] = __builtin_elementwise_fma(-ax[c], d[c], relu);
-    }
-}
-
-// Division-free form for the kernels whose time is VALU instructions (the fused token-mixing kernel: its two waves per SIMD
-// serialise on the VALU port, a v_rcp_f32 costs four plain slots there):
-//   gelu(x) = x * Phi(x),  Phi(x) ~= 0.5 + t * Q(t^2 - 1),  t = clamp(x * sqrt2 / 4.5, -sqrt2, sqrt2)
-// Q = degree-10 polynomial in u = t^2 - 1 in [-1, 1] (weighted minimax fit of the error of Phi, tools/fit_gelu_poly.py; sum |c| =
-// 1.27, so fp32 Horner is well conditioned).  16 VALU per PAIR and no transcendental, vs 19 + 2 v_rcp_f32 above.
-// |Phi error| <= 2.7e-6 everywhere (|x| > 4.5 clamps to Phi(4.5) = 1 - 3.4e-6), |gelu error| <= 3.7e-6 on |x| <= 4.5: 60x below
-// half an ulp of f16 at that magnitude; checked in fp32 emulation by tests/test_host_cpu.py against the coefficients HERE.
-#define MLPK_GELUP_SCALE 0.314269681f
-#define MLPK_GELUP_COEFS {0.00260713836f, -0.00718860654f, 0.00979797821f, -0.0172248576f, 0.0355015062f, -0.0601866171f, 0.090279378f, -0.127707109f, 0.174028099f, -0.245624334f, 0.499268919f}
-template <int N> __device__ __forceinline__ void gelu_poly_pk_n(f32x2 (&x)[N]) {
     constexpr float c[11] = MLPK_GELUP_COEFS;
     constexpr float r2 = 1.41421356237f;
     f32x2 t[N], u[N], q[N];
@@ -128,19 +88,14 @@ __device__ __forceinline__ f32x2 gelu_pk(f32x2 x) {
 
 // scalar form of gelu_pk (the same operation sequence, hence the same results)
 __device__ __forceinline__ float gelu16_f(float x) {
-    const float ax = __builtin_fabsf(x);
-    float d = __builtin_fmaf(ax, MLPK_GELU_C6, MLPK_GELU_C5);
-    d = __builtin_fmaf(d, ax, MLPK_GELU_C4);
-    d = __builtin_fmaf(d, ax, MLPK_GELU_C3);
-    d = __builtin_fmaf(d, ax, MLPK_GELU_C2);
-    d = __builtin_fmaf(d, ax, MLPK_GELU_C1);
-    d = __builtin_fmaf(d, ax, MLPK_GELU_C0);
-    d = d * d;
-    d = d * d;
-    d = d * d;
-    d = d * d;
-    const float r = __builtin_amdgcn_rcpf(d);
-    return __builtin_fmaf(-ax, r, __builtin_fmaf(x, 0.5f, ax * 0.5f));
+    constexpr float c[11] = MLPK_GELUP_COEFS;
+    constexpr float r2 = 1.41421356237f;
+    const float t = __builtin_amdgcn_fmed3f(x * MLPK_GELUP_SCALE, -r2, r2);
+    const float u = __builtin_fmaf(t, t, -1.0f);
+    float q = __builtin_fmaf(u, c[0], c[1]);
+#pragma unroll
+    for (int i = 2; i < 11; ++i) q = __builtin_fmaf(q, u, c[i]);
+    return x * __builtin_fmaf(t, q, 0.5f);
 }
 
 template <typename T> __device__ __forceinline__ float gelu_t(float x) {
