@@ -43,7 +43,8 @@
  *                       S2 spatial shifts (s2_mlp_v2.py:15-29) applied on load
  *   mlpk_split_softmax  softmax over the k=3 branches (vip.py:52-53)
  *   mlpk_split_apply    attention * x_all summed over k (vip.py:54-56), shifts applied on load
- *   mlpk_vip_split_sum / _apply   the same two steps with the inverse ViP rearranges (vip.py:71,76) as load addresses
+ *   mlpk_vip_split_apply  the weighted sum with the inverse ViP rearranges (vip.py:71,76) as load addresses (8 x 8 pixel tiles staged in
+ *                       LDS); the reduction of ViP's SplitAttention needs no pass at all: mlpk_norm_desc.sum_ph / sum_pw + linearity
  *   mlpk_s2_shift       Spatial_Shift (s2_mlp_v1.py:19-25), out of place
  *   mlpk_dwconv_nhwc    depthwise Conv2d(k, groups=dim, padding="same") + GELU + BatchNorm(eval) + residual:
  *                       conv_mixer.py:5-11,24-28
@@ -228,6 +229,16 @@ typedef struct mlpk_norm_desc {
     void* out_tt;
     void* out_ph;
     void* out_pw;
+    /* optional by-products of the out_ph / out_pw passes (fp32; 16-bit fast path only): the sums of the ROUNDED normalised values over
+     * the axis the pass walks, laid out as the reduced operand of the OTHER branch --
+     *   sum_ph[((b*G + g)*ld_sum) + w*seg + j] = sum_h y[b,h,w,g*seg+j]   (written by the out_ph pass, which walks h for a fixed w)
+     *   sum_pw[((b*G + g)*ld_sum) + h*seg + j] = sum_w y[b,h,w,g*seg+j]   (written by the out_pw pass)
+     * With them SplitAttention's sum over all pixels of the three branch OUTPUTS (vip.py:49) follows from the linearity of the
+     * branch Linears without reading those outputs: sum_rows(A W^T + b) = (sum_rows A) W^T + rows * b. */
+    float* sum_ph;
+    float* sum_pw;
+    int32_t ld_sum;
+    int32_t reserved;
 } mlpk_norm_desc;
 int mlpk_norm_apply(const mlpk_norm_desc* d, void* stream);
 
@@ -303,8 +314,6 @@ int mlpk_split_apply(int dtype, const void* x0, const void* x1, const void* x2, 
  * mlpk_vip_unpermute's input), so the inverse rearranges of vip.py:71,76 are never materialised:
  *   xH[b,h,w,g*seg+q] = zh[((b*W + w)*G + g)*ldh + h*seg + q],  xW[b,h,w,g*seg+q] = zw[((b*H + h)*G + g)*ldw + w*seg + q],
  *   xc row-major (B*H*W, ldc).  16-bit dtypes, C % 8 == 0, seg % 4 == 0, ldh % 4 == ldw % 4 == 0. */
-int mlpk_vip_split_sum(int dtype, const void* zh, const void* zw, const void* xc, int ldh, int ldw, int ldc, int B, int H,
-                       int W, int C, int seg, float scale, float* a, void* stream);
 int mlpk_vip_split_apply(int dtype, const void* zh, const void* zw, const void* xc, int ldh, int ldw, int ldc, int B, int H,
                          int W, int C, int seg, const float* bar, void* out, int ldo, void* stream);
 /* S2-MLPv1 Spatial_Shift on (B,H,W,C), out of place, same shift_mode values (NONE = copy). */

@@ -34,7 +34,8 @@ class NormDesc(ctypes.Structure):
                 ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("seg", ctypes.c_int32),
                 ("ld_rm", ctypes.c_int32), ("ld_tt", ctypes.c_int32), ("ld_p", ctypes.c_int32),
                 ("x", c_void_p), ("mean", c_void_p), ("rstd", c_void_p), ("gamma", c_void_p), ("beta", c_void_p),
-                ("out_rm", c_void_p), ("out_tt", c_void_p), ("out_ph", c_void_p), ("out_pw", c_void_p)]
+                ("out_rm", c_void_p), ("out_tt", c_void_p), ("out_ph", c_void_p), ("out_pw", c_void_p),
+                ("sum_ph", c_void_p), ("sum_pw", c_void_p), ("ld_sum", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/mlpk.h declares
@@ -65,7 +66,6 @@ PROTOTYPES = {
     "mlpk_split_sum": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_float, c_void_p, c_void_p]),
     "mlpk_split_softmax": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "mlpk_split_apply": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p, c_void_p, c_int, c_void_p]),
-    "mlpk_vip_split_sum": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_float, c_void_p, c_void_p]),
     "mlpk_vip_split_apply": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p, c_void_p, c_int, c_void_p]),
     "mlpk_s2_shift": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "mlpk_dwconv_nhwc": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p] * 4 + [c_void_p]),

@@ -473,7 +473,8 @@ struct VipArgs {
     const float* gamma;
     const float* beta;
     void* out;
-    int B, H, W, C, seg, ldx, ld_p, which, act;
+    float* sums;        // optional (fast kernel): per (image, group, fixed coordinate, j) sum over the walked axis, row stride ld_sum
+    int B, H, W, C, seg, ldx, ld_p, which, act, ld_sum;
 };
 
 template <typename T>
@@ -620,6 +621,16 @@ __global__ void __launch_bounds__(256) vip_permute_fast_kernel(const VipArgs p) 
         }
     }
     __syncthreads();
+    if (p.sums) {
+        // by-product: sum over the walked axis of the ROUNDED values (what the branch GEMM will read), per (group, j)
+        for (int i = tid; i < p.C; i += 256) {
+            const int g = i / p.seg, j = i - g * p.seg;
+            const T* row = reinterpret_cast<const T*>(slab + (size_t)g * rowb) + j;
+            float acc = 0.f;
+            for (int l = 0; l < L; ++l) acc += to_f32(row[l * p.seg]);
+            p.sums[((int64_t)img * G + g) * p.ld_sum + o * p.seg + j] = acc;
+        }
+    }
     T* out = reinterpret_cast<T*>(p.out) + ((int64_t)img * O + o) * G * p.ld_p;
     constexpr int EPV = 16 / (int)sizeof(T);
     const int vpr = p.ld_p / EPV;                       // 16-byte vectors per group row
@@ -855,6 +866,9 @@ extern "C" int mlpk_norm_apply(const mlpk_norm_desc* d, void* stream) {
         a.x = d->x; a.mean = d->mean; a.rstd = d->rstd; a.gamma = d->gamma; a.beta = d->beta; a.out = out;
         a.B = (int)(d->rows / ((int64_t)d->H * d->W)); a.H = d->H; a.W = d->W; a.C = d->C; a.seg = d->seg;
         a.ldx = d->ldx; a.ld_p = d->ld_p; a.which = which; a.act = d->act;
+        a.sums = which == 0 ? d->sum_ph : d->sum_pw;
+        a.ld_sum = d->ld_sum;
+        if (a.sums && d->ld_sum < (which == 0 ? d->W : d->H) * d->seg) return MLPK_ESHAPE;
         const unsigned grid = (unsigned)(a.B * (which == 0 ? d->W : d->H));
         const int es_ = esize(d->dtype);
         const size_t lds_fast = (size_t)(d->C / d->seg) * ((size_t)d->ld_p * es_ + 32) + (size_t)2 * d->C * 4;
@@ -870,6 +884,7 @@ extern "C" int mlpk_norm_apply(const mlpk_norm_desc* d, void* stream) {
             MLPK_LAUNCH_CHECK();
             continue;
         }
+        if (a.sums) return MLPK_EMODE;                   // the by-product sums exist in the 16-byte fast path only
         const size_t lds = (size_t)L * d->C * esize(d->dtype);
         if (lds > 160 * 1024) return MLPK_ESHAPE;
         DISPATCH_DTYPE(d->dtype, {

@@ -4,6 +4,7 @@
 // global access is a contiguous 128/256-byte run whatever the spatial gather does; none of the
 // shifts is ever materialised as a tensor except where the reference's API returns one.
 #include "mlpk_common.h"
+#include <cstdlib>
 
 namespace mlpk {
 
@@ -418,52 +419,6 @@ struct VipSplitArgs {
     int B, H, W, C, seg;
 };
 
-// a[b,c] = scale * sum over pixels of (xH + xW + xC)[b,h,w,c]; workgroup = (image, 64 channels), 32 pixel phases x 8 lanes x 8 channels
-template <typename T>
-__global__ void __launch_bounds__(256) vip_split_sum_kernel(const VipSplitArgs p, float* __restrict__ a, const float scale) {
-    __shared__ float red[32][64 + 1];
-    const int tid = threadIdx.x;
-    const int cl = (tid & 7) * 8;
-    const int ph = tid >> 3;
-    const int c = blockIdx.y * 64 + cl;
-    const int b = blockIdx.x;
-    const int G = p.C / p.seg;
-    const T* zh = reinterpret_cast<const T*>(p.zh);
-    const T* zw = reinterpret_cast<const T*>(p.zw);
-    const T* xc = reinterpret_cast<const T*>(p.xc);
-    float s[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s[e] = 0.f;
-    if (c < p.C) {
-        const int npx = p.H * p.W;
-        for (int px = ph; px < npx; px += 32) {
-            const int h = px / p.W, w = px - h * p.W;
-            float v[8];
-            vip_ld8<T>(zh, p.ldh, ((int64_t)b * p.W + w) * G, G, p.seg, h, c, v);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s[e] += v[e];
-            vip_ld8<T>(zw, p.ldw, ((int64_t)b * p.H + h) * G, G, p.seg, w, c, v);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s[e] += v[e];
-            ld8<T>(xc + ((int64_t)b * npx + px) * p.ldc + c, v);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s[e] += v[e];
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) red[ph][cl + e] = s[e];
-    __syncthreads();
-    if (tid < 64) {
-        const int cc = blockIdx.y * 64 + tid;
-        if (cc < p.C) {
-            float t = 0.f;
-#pragma unroll 8
-            for (int i = 0; i < 32; ++i) t += red[i][tid];
-            a[(int64_t)b * p.C + cc] = t * scale;
-        }
-    }
-}
-
 // out[b,h,w,c] = bar[b,0,c] xH + bar[b,1,c] xW + bar[b,2,c] xC
 template <typename T>
 __global__ void __launch_bounds__(256) vip_split_apply_kernel(const VipSplitArgs p, const float* __restrict__ bar, T* __restrict__ out, int ldo) {
@@ -495,6 +450,66 @@ __global__ void __launch_bounds__(256) vip_split_apply_kernel(const VipSplitArgs
         ld8<T>(xc + px * p.ldc + c, v2);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = w0[e] * v0[e] + w1[e] * v1[e] + w2[e] * v2[e];
+        st8<T>(out + px * ldo + c, o);
+    }
+}
+
+// The same weighted sum on 8 x 8 pixel tiles: read pixel by pixel, a lane's piece of zh is 8-16 bytes of a row that the next
+// lane does not touch (row stride ldh), i.e. a quarter of every 64-byte sector (measured 2.7 TB/s).  A tile of 8 h x 8 w pixels
+// needs, of the h branch, the columns (h0..h0+7, all q) of the rows (b, w, g) for 8 w: runs of 8 * seg contiguous elements (192
+// bytes at seg = 12) -- and of the w branch the mirror image.  Both sets of runs are staged in LDS as they lie (16-byte copies),
+// the (pixel, 8 channels) items then pick their 8-byte pieces out of LDS; xc, the weights and the output are contiguous anyway.
+template <typename T>
+__global__ void __launch_bounds__(512) vip_split_apply_tile_kernel(const VipSplitArgs p, const float* __restrict__ bar, T* __restrict__ out, int ldo) {
+    static_assert(sizeof(T) == 2, "16-bit storage types");
+    extern __shared__ __attribute__((aligned(16))) char vsmem[];
+    const int tid = threadIdx.x;
+    const int G = p.C / p.seg;
+    const int run = 8 * p.seg;                              // elements per run (one (w, g) row x 8 h, or one (h, g) row x 8 w)
+    T* const zh_t = reinterpret_cast<T*>(vsmem);            // [8 w][G][8 h * seg]
+    T* const zw_t = zh_t + 8 * G * run;                     // [8 h][G][8 w * seg]
+    float* const wt = reinterpret_cast<float*>(zw_t + 8 * G * run);   // bar[b]: 3 x C
+    const int tw = p.W >> 3, th = p.H >> 3;
+    const int b = blockIdx.x / (th * tw);
+    const int t = blockIdx.x - b * (th * tw);
+    const int h0 = (t / tw) * 8, w0 = (t % tw) * 8;
+    const T* zh = reinterpret_cast<const T*>(p.zh);
+    const T* zw = reinterpret_cast<const T*>(p.zw);
+    const T* xc = reinterpret_cast<const T*>(p.xc);
+    const int ppr = p.seg;                                  // 16-byte pieces per run: 8 * seg * 2 / 16
+    for (int idx = tid; idx < 8 * G * ppr; idx += 512) {
+        const int r = idx / ppr, pc = idx - r * ppr;        // r = l * G + g
+        const int l = r / G, g = r - l * G;
+        *reinterpret_cast<u32x4*>(zh_t + (size_t)r * run + pc * 8) =
+            *reinterpret_cast<const u32x4*>(zh + (((int64_t)b * p.W + w0 + l) * G + g) * p.ldh + h0 * p.seg + pc * 8);
+        *reinterpret_cast<u32x4*>(zw_t + (size_t)r * run + pc * 8) =
+            *reinterpret_cast<const u32x4*>(zw + (((int64_t)b * p.H + h0 + l) * G + g) * p.ldw + w0 * p.seg + pc * 8);
+    }
+    for (int i = tid; i < 3 * p.C; i += 512) wt[i] = bar[(int64_t)b * 3 * p.C + i];
+    __syncthreads();
+    const int cv = p.C / 8;
+    for (int idx = tid; idx < 64 * cv; idx += 512) {
+        const int pl = idx / cv;
+        const int c = (idx - pl * cv) * 8;
+        const int hl = pl >> 3, wl = pl & 7;
+        const int64_t px = ((int64_t)b * p.H + h0 + hl) * p.W + w0 + wl;
+        float v0[8], v1[8], v2[8], o[8];
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            const int cc = c + 4 * part;
+            const int g = cc / p.seg;
+            const int q = cc - g * p.seg;                   // multiple of 4: the 4 channels stay inside group g
+            const u32x2 a0 = *reinterpret_cast<const u32x2*>(zh_t + (size_t)(wl * G + g) * run + hl * p.seg + q);
+            const u32x2 a1 = *reinterpret_cast<const u32x2*>(zw_t + (size_t)(hl * G + g) * run + wl * p.seg + q);
+            T e0[4], e1[4];
+            __builtin_memcpy(e0, &a0, 8);
+            __builtin_memcpy(e1, &a1, 8);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v0[4 * part + i] = to_f32(e0[i]); v1[4 * part + i] = to_f32(e1[i]); }
+        }
+        ld8<T>(xc + px * p.ldc + c, v2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = wt[c + e] * v0[e] + wt[p.C + c + e] * v1[e] + wt[2 * p.C + c + e] * v2[e];
         st8<T>(out + px * ldo + c, o);
     }
 }
@@ -791,19 +806,6 @@ static int vip_split_check(int dtype, const void* zh, const void* zw, const void
     return 0;
 }
 
-extern "C" int mlpk_vip_split_sum(int dtype, const void* zh, const void* zw, const void* xc, int ldh, int ldw, int ldc, int B, int H, int W,
-                                  int C, int seg, float scale, float* a, void* stream) {
-    if (int e = vip_split_check(dtype, zh, zw, xc, ldh, ldw, ldc, B, H, W, C, seg)) return e;
-    if (!a) return MLPK_ENULL;
-    VipSplitArgs p{zh, zw, xc, ldh, ldw, ldc, B, H, W, C, seg};
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const dim3 grid((unsigned)B, (unsigned)((C + 63) / 64));
-    if (dtype == MLPK_BF16) hipLaunchKernelGGL((vip_split_sum_kernel<bf16_t>), grid, dim3(256), 0, s, p, a, scale);
-    else hipLaunchKernelGGL((vip_split_sum_kernel<f16_t>), grid, dim3(256), 0, s, p, a, scale);
-    MLPK_LAUNCH_CHECK();
-    return 0;
-}
-
 extern "C" int mlpk_vip_split_apply(int dtype, const void* zh, const void* zw, const void* xc, int ldh, int ldw, int ldc, int B, int H, int W,
                                     int C, int seg, const float* bar, void* out, int ldo, void* stream) {
     if (int e = vip_split_check(dtype, zh, zw, xc, ldh, ldw, ldc, B, H, W, C, seg)) return e;
@@ -813,6 +815,27 @@ extern "C" int mlpk_vip_split_apply(int dtype, const void* zh, const void* zw, c
     VipSplitArgs p{zh, zw, xc, ldh, ldw, ldc, B, H, W, C, seg};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int64_t total = (int64_t)B * H * W * C;
+    // 8 x 8 pixel tiles when the map is made of whole tiles, the runs are 16-byte aligned and the two staged tiles fit in LDS
+    const size_t lds_tile = (size_t)2 * 8 * (C / seg) * 8 * seg * 2 + (size_t)3 * C * 4;
+    static const bool no_tile = getenv("MLPK_VIP_APPLY_NO_TILE") != nullptr;       // A/B aid
+    if (!no_tile && H % 8 == 0 && W % 8 == 0 && ldh % 8 == 0 && ldw % 8 == 0 && lds_tile <= 150 * 1024 && (int64_t)B * (H / 8) * (W / 8) < 0x7fffffff &&
+        (((uintptr_t)zh | (uintptr_t)zw) & 15) == 0) {
+        const unsigned grid = (unsigned)((int64_t)B * (H / 8) * (W / 8));
+        hipError_t e = hipSuccess;
+        if (dtype == MLPK_BF16) {
+            auto k = vip_split_apply_tile_kernel<bf16_t>;
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds_tile, s, p, bar, (bf16_t*)out, ldo);
+        } else {
+            auto k = vip_split_apply_tile_kernel<f16_t>;
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds_tile, s, p, bar, (f16_t*)out, ldo);
+        }
+        MLPK_LAUNCH_CHECK();
+        return 0;
+    }
     if (dtype == MLPK_BF16) hipLaunchKernelGGL((vip_split_apply_kernel<bf16_t>), dim3(grid_for(total / 8)), dim3(256), 0, s, p, bar, (bf16_t*)out, ldo);
     else hipLaunchKernelGGL((vip_split_apply_kernel<f16_t>), dim3(grid_for(total / 8)), dim3(256), 0, s, p, bar, (f16_t*)out, ldo);
     MLPK_LAUNCH_CHECK();

@@ -233,13 +233,15 @@ def row_stats(x, rows, length, ldx, mean, rstd, eps=1e-5):
 
 
 def norm_apply(x, rows, C, ldx, *, mean=None, rstd=None, gamma=None, beta=None, act=N.ACT_NONE, stat_group=1,
-               out_rm=None, ld_rm=0, out_tt=None, S=0, ld_tt=0, out_ph=None, out_pw=None, H=0, W=0, seg=0, ld_p=0):
+               out_rm=None, ld_rm=0, out_tt=None, S=0, ld_tt=0, out_ph=None, out_pw=None, H=0, W=0, seg=0, ld_p=0,
+               sum_ph=None, sum_pw=None, ld_sum=0):
     d = N.NormDesc()
     d.dtype, d.act, d.rows, d.C, d.ldx, d.stat_group = dtype_code(x.dtype), act, rows, C, ldx, stat_group
     d.S, d.H, d.W, d.seg = S, H, W, seg
     d.ld_rm, d.ld_tt, d.ld_p = ld_rm, ld_tt, ld_p
     d.x, d.mean, d.rstd, d.gamma, d.beta = ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta)
     d.out_rm, d.out_tt, d.out_ph, d.out_pw = ptr(out_rm), ptr(out_tt), ptr(out_ph), ptr(out_pw)
+    d.sum_ph, d.sum_pw, d.ld_sum = ptr(sum_ph), ptr(sum_pw), ld_sum
     N.check(N.lib().mlpk_norm_apply(ctypes.byref(d), stream()), "mlpk_norm_apply")
 
 
@@ -286,11 +288,6 @@ def split_softmax(hat, bar, B, C):
 def split_apply(x0, x1, x2, ld0, ld1, ld2, B, H, W, C, mode, bar, out, ldo):
     N.check(N.lib().mlpk_split_apply(dtype_code(x0.dtype), ptr(x0), ptr(x1), ptr(x2), ld0, ld1, ld2, B, H, W, C, mode,
                                      ptr(bar), ptr(out), ldo, stream()), "mlpk_split_apply")
-
-
-def vip_split_sum(zh, zw, xc, ldh, ldw, ldc, B, H, W, C, seg, a, scale=1.0):
-    N.check(N.lib().mlpk_vip_split_sum(dtype_code(zh.dtype), ptr(zh), ptr(zw), ptr(xc), ldh, ldw, ldc, B, H, W, C, seg, scale, ptr(a),
-                                       stream()), "mlpk_vip_split_sum")
 
 
 def vip_split_apply(zh, zw, xc, ldh, ldw, ldc, B, H, W, C, seg, bar, out, ldo):

@@ -106,9 +106,41 @@ class _PermutatorBase(E.EngineModule):
             pk[p + "w.b"] = E.f32(mix.fns[1][1].bias, device)
             pk[p + "c.w"] = E.pack_matrix(mix.fns[2].weight, dtype, device)
             pk[p + "c.b"] = E.f32(mix.fns[2].bias, device)
+            if dtype != torch.float32:
+                # the channel branch reads x itself: its LayerNorm is folded into the GEMM (no row-major normalised copy)
+                pk[p + "c.wf"], pk[p + "c.bf"], pk[p + "c.csum"] = E.pack_ln_folded(mix.fns[2].weight, mix.fns[2].bias, blk[0].norm.weight,
+                                                                                 blk[0].norm.bias, dtype, device)
             if self.weighted:
                 pk[p + "sa.m1"] = E.pack_matrix(mix.split_attention.mlp1.weight, torch.float32, device)
                 pk[p + "sa.m2"] = E.pack_matrix(mix.split_attention.mlp2.weight, torch.float32, device)
+                if dtype != torch.float32:
+                    # SplitAttention's a = sum over all pixels of the three branch OUTPUTS (vip.py:49) from sums of the branch
+                    # INPUTS: sum_rows(A W^T + b) = (sum_rows A) W^T + rows * b, with the reduced weights taken from the ROUNDED
+                    # packed matrices (what the MFMAs multiply).  Two tiny fp32 GEMMs:
+                    #   o (B*G, 2 seg) = [Ah | Aw] . W1^T + b1     columns j < seg: the h- and w-branch parts of a at channel (g, j),
+                    #                                               columns seg + j: sum over h of Ah = the per-image sum of x^ at (g, j)
+                    #   t (B, C) = gelu(o viewed as (B, G*2*seg) . (M1 W2)^T + M1 bc')   W2 = [identity | Wc] per group, so that
+                    #   W2 o + bc' IS a; mlp1 (vip.py:51, bias-free) is composed into it at pack time.
+                    H, W, C, _, seg, _ = self._dims
+                    G = C // seg
+                    wh, ww = pk[p + "h.w"].float(), pk[p + "w.w"].float()               # (H*seg, ldh), (W*seg, ldw)
+                    ldh, ldw = wh.shape[1], ww.shape[1]
+                    w1 = torch.zeros((2 * seg, ldh + ldw), dtype=torch.float32, device=device)
+                    w1[:seg, :ldh] = wh.view(H, seg, ldh).sum(0)
+                    w1[:seg, ldh:] = ww.view(W, seg, ldw).sum(0)
+                    for j in range(seg):
+                        w1[seg + j, j:H * seg:seg] = 1.0                              # sum over h of the (h, j) columns of Ah
+                    b1 = torch.zeros((2 * seg,), dtype=torch.float32, device=device)
+                    b1[:seg] = pk[p + "h.b"].view(H, seg).sum(0) * float(W) + pk[p + "w.b"].view(W, seg).sum(0) * float(H)
+                    wc = pk[p + "c.w"].float()                                          # (C, C)
+                    w2 = torch.zeros((C, G, 2 * seg), dtype=torch.float64, device=device)
+                    eye = torch.eye(C, dtype=torch.float64, device=device).view(C, G, seg)
+                    w2[:, :, :seg] = eye
+                    w2[:, :, seg:] = wc.double().view(C, G, seg)
+                    m1 = pk[p + "sa.m1"].double()
+                    pk[p + "sa.w1"], pk[p + "sa.b1"] = w1.contiguous(), b1
+                    pk[p + "sa.m1w2"] = (m1 @ w2.view(C, G * 2 * seg)).float().contiguous()
+                    pk[p + "sa.m1b"] = (m1 @ (pk[p + "c.b"].double() * float(H * W))).float().contiguous()
             pk[p + "proj.w"] = E.pack_matrix(proj.weight, dtype, device)
             pk[p + "proj.b"] = E.f32(proj.bias, device)
             mlp = blk[1]
@@ -128,29 +160,38 @@ class _PermutatorBase(E.EngineModule):
         for i in range(depth):
             p = prefix + "b%d." % i
             mean, rstd = layernorm_stats(ws, x, rows, C)
-            xn = ws.get("vip.xn", (rows, C))
+            cfold = (p + "c.csum") in pk
+            xn = None if cfold else ws.get("vip.xn", (rows, C))
             ph = ws.get("vip.ph", (B * W * G, ldh))
             pw = ws.get("vip.pw", (B * H * G, ldw))
+            fused = x.dtype != torch.float32 and seg % 4 == 0 and C % 8 == 0
+            lin = fused and self.weighted
+            # by-product sums of the two rearrange passes, side by side: [sum_w x^ as rows (b, g) x columns (h, j) | sum_h x^ ... (w, j)]
+            asum = ws.get("sa.sums", (B * G, ldh + ldw), torch.float32) if lin else None
             E.norm_apply(x, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "ln.g"], beta=pk[p + "ln.b"], out_rm=xn, ld_rm=C,
-                         out_ph=ph, H=H, W=W, seg=seg, ld_p=ldh)
+                         out_ph=ph, H=H, W=W, seg=seg, ld_p=ldh, sum_ph=asum[:, ldh:] if lin else None, ld_sum=ldh + ldw)
             E.norm_apply(x, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "ln.g"], beta=pk[p + "ln.b"],
-                         out_pw=pw, H=H, W=W, seg=seg, ld_p=ldw)
+                         out_pw=pw, H=H, W=W, seg=seg, ld_p=ldw, sum_pw=asum, ld_sum=ldh + ldw)
             ldzh, ldzw = E.round_up(hs, 8), E.round_up(wsz, 8)
             zh = ws.get("vip.zh", (B * W * G, ldzh))
             zw = ws.get("vip.zw", (B * H * G, ldzw))
             E.gemm(ph, pk[p + "h.w"], zh, B * W * G, hs, ldh, bias=pk[p + "h.b"], tag="vip_h")
             E.gemm(pw, pk[p + "w.w"], zw, B * H * G, wsz, ldw, bias=pk[p + "w.b"], tag="vip_w")
             xc = ws.get("vip.xc", (rows, C))
-            E.gemm(xn, pk[p + "c.w"], xc, rows, C, C, bias=pk[p + "c.b"], tag="vip_c")
+            if cfold:
+                E.gemm(x, pk[p + "c.wf"], xc, rows, C, C, bias=pk[p + "c.bf"], ln=(mean, rstd, pk[p + "c.csum"]), tag="vip_c")
+            else:
+                E.gemm(xn, pk[p + "c.w"], xc, rows, C, C, bias=pk[p + "c.b"], tag="vip_c")
             m = ws.get("vip.m", (rows, C))
-            if x.dtype != torch.float32 and seg % 4 == 0 and C % 8 == 0:
+            if fused:
                 # the inverse rearranges (vip.py:71,76) are load addresses of the split-attention kernels: xH / xW are never
                 # written back in (B,H,W,C) order (two full-tensor passes per block fewer)
                 if self.weighted:
-                    a = ws.get("sa.a", (B, C), torch.float32)
-                    E.vip_split_sum(zh, zw, xc, ldzh, ldzw, C, B, H, W, C, seg, a)
+                    # two tiny fp32 GEMMs on the by-product sums instead of a 600 MB pass over the three branch outputs
                     t = ws.get("sa.t", (B, C), torch.float32)
-                    E.gemm(a, pk[p + "sa.m1"], t, B, C, C, act=N.ACT_GELU)
+                    o = ws.get("sa.o", (B * G, 2 * seg), torch.float32)
+                    E.gemm(asum, pk[p + "sa.w1"], o, B * G, 2 * seg, ldh + ldw, bias=pk[p + "sa.b1"])
+                    E.gemm(o.view(B, G * 2 * seg), pk[p + "sa.m1w2"], t, B, C, G * 2 * seg, bias=pk[p + "sa.m1b"], act=N.ACT_GELU)
                     hat = ws.get("sa.hat", (B, 3 * C), torch.float32)
                     E.gemm(t, pk[p + "sa.m2"], hat, B, 3 * C, C)
                     bar = ws.get("sa.bar", (B, 3 * C), torch.float32)

@@ -42,12 +42,21 @@ BF16_REAL_EXCEPTIONS = {
 }
 
 
+FP16_REAL_EXCEPTIONS = {
+    # measured 1.10e-3 (9.2e-4 while SplitAttention's `a` was summed from the fp16-ROUNDED branch outputs; it now follows from
+    # fp32 sums of the branch inputs, 2.5e-4 instead of 4.5e-2 away from an fp64 evaluation of the same operands --
+    # tools/vip_a_check.py -- and the logits' distance to the fp32 reference, dominated by the fp16 storage rounding of
+    # 18 x 6 GEMM outputs on logits of magnitude 0.44, moved by 2e-4 with it)
+    "vip_s7": 1.3e-3,
+}
+
+
 def tol_for(dtype, ref, real=False, name=None):
     m = max(1.0, float(ref.abs().max()))
     if dtype == torch.float32:
         return 1e-5
     if dtype == torch.float16:
-        return 1e-3 * m
+        return (FP16_REAL_EXCEPTIONS.get(name, 1e-3) if real else 1e-3) * m
     if real:
         return BF16_REAL_EXCEPTIONS.get(name, 5e-3) * m
     return 1.5e-2 * m

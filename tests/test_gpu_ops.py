@@ -206,6 +206,45 @@ def test_vip_permutes(dtype):
     assert torch.equal(back_h.cpu(), x.cpu()) and torch.equal(back_w.cpu(), x.cpu())
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_vip_permute_byproduct_sums(dtype):
+    """The optional by-products of the ViP rearrange passes: sums of the ROUNDED normalised values over the walked axis, laid
+    out as the reduced operand of the other branch -- and the linearity they are used for (vip.py:49 on the branch outputs
+    == tiny GEMMs on these sums): sum over all pixels of Linear_h applied in the 'b w c (h s)' layout."""
+    pkg = load_pkg()
+    E = pkg.engine
+    B_, H, W, C, seg = 3, 8, 6, 32, 4
+    G = C // seg
+    rows = B_ * H * W
+    x = rnd((B_, H, W, C), dtype, 15).to(dev())
+    g = (rnd((C,), torch.float32, 16) * 0.2 + 1).to(dev())
+    b = rnd((C,), torch.float32, 17).to(dev())
+    mean = torch.empty(rows, device=dev())
+    rstd = torch.empty(rows, device=dev())
+    E.row_stats(x, rows, C, C, mean, rstd)
+    ldh, ldw = E.round_up(H * seg, 32), E.round_up(W * seg, 32)
+    ph = torch.zeros((B_ * W * G, ldh), dtype=dtype, device=dev())
+    pw = torch.zeros((B_ * H * G, ldw), dtype=dtype, device=dev())
+    Ah = torch.zeros((B_ * G, ldh), device=dev())
+    Aw = torch.zeros((B_ * G, ldw), device=dev())
+    E.norm_apply(x, rows, C, C, mean=mean, rstd=rstd, gamma=g, beta=b, out_ph=ph, H=H, W=W, seg=seg, ld_p=ldh, sum_ph=Aw, ld_sum=ldw)
+    E.norm_apply(x, rows, C, C, mean=mean, rstd=rstd, gamma=g, beta=b, out_pw=pw, H=H, W=W, seg=seg, ld_p=ldw, sum_pw=Ah, ld_sum=ldh)
+    torch.cuda.synchronize()
+    y = ph.cpu().double()[:, :H * seg].reshape(B_, W, G, H, seg)                   # rounded normalised values, (b, w, g, h, j)
+    ref_Ah = y.sum(1).reshape(B_ * G, H * seg)                                     # sum over w: rows (b, g), columns (h, j)
+    ref_Aw = y.sum(3).permute(0, 2, 1, 3).reshape(B_ * G, W * seg)                 # sum over h: rows (b, g), columns (w, j)
+    assert (Ah.cpu().double()[:, :H * seg] - ref_Ah).abs().max() < 1e-5 * max(1.0, ref_Ah.abs().max().item())
+    assert (Aw.cpu().double()[:, :W * seg] - ref_Aw).abs().max() < 1e-5 * max(1.0, ref_Aw.abs().max().item())
+    assert (Ah.cpu()[:, H * seg:] == 0).all() and (Aw.cpu()[:, W * seg:] == 0).all()
+    # linearity: sum over (h, w) of Linear_h's output at channel (g, j) == Ah . (sum_h' W[(h', j), :]) + W * sum_h' bias[(h', j)]
+    wgt = rnd((H * seg, H * seg), torch.float64, 18, 0.3)
+    bias = rnd((H * seg,), torch.float64, 19)
+    z = y.reshape(B_ * W * G, H * seg) @ wgt.t() + bias                            # rows (b, w, g), columns (h', j)
+    direct = z.reshape(B_, W, G, H, seg).sum((1, 3)).reshape(B_, C)               # sum over w and h' -> (b, (g, j))
+    via = ref_Ah @ wgt.reshape(H, seg, H * seg).sum(0).t() + W * bias.reshape(H, seg).sum(0)
+    assert (via.reshape(B_, C) - direct).abs().max() < 1e-9 * max(1.0, direct.abs().max().item())
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_pool_mean(dtype):
     pkg = load_pkg()
@@ -837,9 +876,9 @@ def test_cycle_shift_bit_exact(dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_vip_split_attention_on_permuted_layout(dtype):
-    """mlpk_vip_split_sum / _apply read the H- and W-branch GEMM outputs where they lie (inverse rearranges of vip.py:71,76 as load
-    addresses): BIT-equal to unpermute + the plain split kernels, and the unpermute itself is pinned to the reference's einops
-    patterns by test_vip_permutes."""
+    """mlpk_vip_split_apply reads the H- and W-branch GEMM outputs where they lie (inverse rearranges of vip.py:71,76 as load
+    addresses; 8 x 8 pixel tiles staged in LDS where the map allows, element gathers otherwise): BIT-equal to unpermute + the
+    plain split kernel, and the unpermute itself is pinned to the reference's einops patterns by test_vip_permutes."""
     pkg = load_pkg()
     E, N = pkg.engine, pkg._native
     for ci, (B, H, W, C, seg) in enumerate(((2, 4, 6, 32, 8), (1, 32, 32, 384, 12), (3, 5, 3, 64, 4), (2, 8, 8, 48, 24))):
@@ -853,16 +892,11 @@ def test_vip_split_attention_on_permuted_layout(dtype):
         xw = torch.empty((B * H * W, C), dtype=dtype, device=dev())
         E.vip_unpermute(0, zh, xh, B, H, W, C, seg, ldh)
         E.vip_unpermute(1, zw, xw, B, H, W, C, seg, ldw)
-        a_ref = torch.empty((B, C), dtype=torch.float32, device=dev())
-        a = torch.full((B, C), float("nan"), dtype=torch.float32, device=dev())
-        E.split_sum(xh, xw, xc, C, C, C, B, H, W, C, N.SHIFT_NONE, a_ref)
-        E.vip_split_sum(zh, zw, xc, ldh, ldw, C, B, H, W, C, seg, a)
         m_ref = torch.empty((B * H * W, C), dtype=dtype, device=dev())
         m = torch.full((B * H * W, C), float("nan"), dtype=dtype, device=dev())
         E.split_apply(xh, xw, xc, C, C, C, B, H, W, C, N.SHIFT_NONE, bar, m_ref, C)
         E.vip_split_apply(zh, zw, xc, ldh, ldw, C, B, H, W, C, seg, bar, m, C)
         torch.cuda.synchronize()
-        assert torch.equal(a, a_ref), (str(dtype), ci)
         assert torch.equal(m.view(torch.int16), m_ref.view(torch.int16)), (str(dtype), ci)
     with pytest.raises(N.MlpkError):                                            # seg % 4 != 0 is refused (the host keeps the unfused path)
-        E.vip_split_sum(zh, zw, xc, ldh, ldw, C, 1, 2, 2, 12, 6, a)
+        E.vip_split_apply(zh, zw, xc, ldh, ldw, C, 1, 2, 2, 12, 6, bar, m, C)
