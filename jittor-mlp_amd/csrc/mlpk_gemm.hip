@@ -1677,7 +1677,10 @@ static int auto_algo(int M, int N, int K, int epc, bool glds_ok, bool p8_ok) {
             double rounds = 0.0;
             p8_plan(M, N / 256, K / 64, (int)cap, true, &rounds);
             const double kb = (double)K / epc * 16.0;          // bytes of K per row
-            const double eff = 1.5 * kb / (kb + 384.0);
+            // (round 2: with the direct epilogue and the parameter prefetch the break-even against the s3 tiles moved from
+            //  K = 384 down to K = 192: measured 0.164 vs 0.192 ms at K = 256, 0.078 vs 0.078 at 192, 0.054 vs 0.049 at 128,
+            //  tools/gemm_sweep.py on the synthetic short-K shapes)
+            const double eff = 1.6 * kb / (kb + 260.0);
             const double cost = rounds * cap * area / eff;
             if (cost < best) { best = cost; best_algo = i + 1; }
             continue;
@@ -1690,7 +1693,9 @@ static int auto_algo(int M, int N, int K, int epc, bool glds_ok, bool p8_ok) {
         const double tiles = (double)((M + t.bm - 1) / t.bm) * (double)((N + t.bn - 1) / t.bn);
         const double slots = area >= 256 * 256 ? 256.0 : area >= 128 * 128 ? 512.0 : 1024.0;
         // 128 x 256 (wave tile 64 x 128) measured 2-8 % ahead of 256 x 128 on the channel-MLP shapes
-        const double eff = area >= 256 * 128 ? (t.bn > t.bm ? 1.0 : 0.97) : area >= 128 * 128 ? 0.9 : 0.45;
+        // ... for K > 512; at short K the 256 x 128 tile is the better of the two (K = 128 .. 320: 5-20 % ahead)
+        const double wide = K > 512 * (epc / 8.0) ? 1.0 : 0.92, tall = K > 512 * (epc / 8.0) ? 0.97 : 1.0;
+        const double eff = area >= 256 * 128 ? (t.bn > t.bm ? wide : tall) : area >= 128 * 128 ? 0.9 : 0.45;
         // (tiles + 256): a soft tail for grids that do not fill the CUs many times over; the same constant for every
         // tile size, so that a problem of a few tiles (the M = batch GEMMs of SplitAttention) is costed by the time of
         // ONE tile, area / eff, and gets the small tile (128 x 128 fp32 tiles took 38 us for 75 MFLOP)

@@ -37,6 +37,11 @@ SHAPES = [  # name, M, N, K, token_t(t_rows, t_tokens) or None, gelu
     ("vip_fc2", 262144, 384, 1152, None, False),
     ("s2_mlp2", 262144, 192, 192, None, False),
     ("s2_fc2", 65536, 384, 1152, None, False),
+    ("k128", 50176, 1024, 128, None, True),        # synthetic short-K shapes: calibration of the tile choice
+    ("k192", 50176, 1536, 192, None, True),
+    ("k128_big", 200704, 512, 128, None, False),
+    ("k256_small", 12544, 1024, 256, None, True),
+    ("k320", 50176, 1280, 320, None, True),
 ]
 for name, M, Nn, K, tt, gelu in SHAPES:
     if only and name not in only:
