@@ -244,7 +244,7 @@ int mlpk_norm_apply(const mlpk_norm_desc* d, void* stream);
 
 /* Token-mixing LayerNorm of MLP-Mixer in one pass (mlp_mixer.py:34 with :6-13): statistics over C, affine, and the per-image
  * transpose the token GEMMs read:  out_tt[(b*C + c)*ld_tt + s] = LayerNorm_C(x[b,s,:])[c], columns S..ld_tt-1 written as zeros.
- * x is (nimg*S, C) with row stride ldx.  16-bit dtypes, C % 128 == 0, C <= 1024, ldx % 8 == 0, ld_tt % 8 == 0, 16-byte aligned
+ * x is (nimg*S, C) with row stride ldx.  16-bit dtypes, C % 128 == 0, C <= 2048, ldx % 8 == 0, ld_tt % 8 == 0, 16-byte aligned
  * pointers; other shapes: mlpk_row_stats + mlpk_norm_apply(out_tt). */
 int mlpk_layernorm_transpose(int dtype, const void* x, int64_t nimg, int S, int C, int ldx, const float* gamma, const float* beta,
                              float eps, void* out_tt, int ld_tt, void* stream);

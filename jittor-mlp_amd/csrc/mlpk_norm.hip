@@ -371,7 +371,7 @@ struct LnTtArgs {
     int S, C, ldx, ld_tt, s_tiles;
     float eps;
 };
-template <typename T>
+template <typename T, int NVMAX>
 __global__ void __launch_bounds__(512) layernorm_transpose_kernel(const LnTtArgs p) {
     static_assert(sizeof(T) == 2, "16-bit storage types");
     constexpr int WP = 34;                                   // words per channel pair: 32 tokens + 2 (8-byte aligned rows)
@@ -381,18 +381,18 @@ __global__ void __launch_bounds__(512) layernorm_transpose_kernel(const LnTtArgs
     const int s0 = (blockIdx.x % p.s_tiles) * 32;
     const int sl = tid >> 4, l16 = tid & 15;
     const int s = s0 + sl;
-    const int nv = p.C >> 7;                                 // vectors per lane (C % 128 == 0, <= 8)
+    const int nv = p.C >> 7;                                 // vectors per lane (C % 128 == 0, <= NVMAX)
     const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
     const bool live = s < p.S;
-    u32x4 raw[8];
+    u32x4 raw[NVMAX];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < NVMAX; ++k) {
         raw[k] = u32x4{0u, 0u, 0u, 0u};
         if (k < nv && live) raw[k] = *reinterpret_cast<const u32x4*>(x + ((int64_t)img * p.S + s) * p.ldx + (l16 + 16 * k) * 8);
     }
     float s1 = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < NVMAX; ++k) {
         if (k < nv) {
             T e[8];
             __builtin_memcpy(e, &raw[k], 16);
@@ -404,7 +404,7 @@ __global__ void __launch_bounds__(512) layernorm_transpose_kernel(const LnTtArgs
     const float mu = row16_sum(s1) * inv;
     float q1 = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < NVMAX; ++k) {
         if (k < nv) {
             T e[8];
             __builtin_memcpy(e, &raw[k], 16);
@@ -417,7 +417,7 @@ __global__ void __launch_bounds__(512) layernorm_transpose_kernel(const LnTtArgs
     }
     const float rs = 1.0f / __builtin_sqrtf(row16_sum(q1) * inv + p.eps);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < NVMAX; ++k) {
         if (k < nv) {
             const int c = (l16 + 16 * k) * 8;
             T e[8];
@@ -902,7 +902,7 @@ extern "C" int mlpk_layernorm_transpose(int dtype, const void* x, int64_t nimg, 
                                         float eps, void* out_tt, int ld_tt, void* stream) {
     if (!x || !gamma || !beta || !out_tt) return MLPK_ENULL;
     if (dtype != MLPK_F16 && dtype != MLPK_BF16) return MLPK_EDTYPE;
-    if (nimg <= 0 || S <= 0 || C <= 0 || C % 128 || C > 1024 || ldx < C || ldx % 8 || ld_tt < S || ld_tt % 8) return MLPK_ESHAPE;
+    if (nimg <= 0 || S <= 0 || C <= 0 || C % 128 || C > 2048 || ldx < C || ldx % 8 || ld_tt < S || ld_tt % 8) return MLPK_ESHAPE;
     if (((uintptr_t)x | (uintptr_t)out_tt | (uintptr_t)gamma | (uintptr_t)beta) & 15) return MLPK_ESHAPE;
     LnTtArgs a;
     a.x = x; a.gamma = gamma; a.beta = beta; a.out = out_tt;
@@ -910,17 +910,19 @@ extern "C" int mlpk_layernorm_transpose(int dtype, const void* x, int64_t nimg, 
     if (nimg * a.s_tiles > 0x7fffffffLL) return MLPK_ESHAPE;
     const size_t lds = (size_t)(C / 2) * 34 * 4;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == MLPK_BF16) {
-        auto k = layernorm_transpose_kernel<bf16_t>;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(k, dim3((unsigned)(nimg * a.s_tiles)), dim3(512), lds, s, a);
-    } else {
-        auto k = layernorm_transpose_kernel<f16_t>;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(k, dim3((unsigned)(nimg * a.s_tiles)), dim3(512), lds, s, a);
+#define LNTT_LAUNCH(TT, NV)                                                                                              \
+    {                                                                                                                    \
+        auto k = layernorm_transpose_kernel<TT, NV>;                                                                     \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return (int)e;                                                                              \
+        hipLaunchKernelGGL(k, dim3((unsigned)(nimg * a.s_tiles)), dim3(512), lds, s, a);                                 \
     }
+    if (dtype == MLPK_BF16) {
+        if (C <= 1024) LNTT_LAUNCH(bf16_t, 8) else LNTT_LAUNCH(bf16_t, 16)
+    } else {
+        if (C <= 1024) LNTT_LAUNCH(f16_t, 8) else LNTT_LAUNCH(f16_t, 16)
+    }
+#undef LNTT_LAUNCH
     MLPK_LAUNCH_CHECK();
     return 0;
 }

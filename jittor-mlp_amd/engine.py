@@ -175,11 +175,12 @@ def token_mlp(xt, ldxt, M, S, w1, b1, w2, b2, nchunks, x, ldx, t_rows, stats=Non
 
 
 def layernorm_transpose_supported(dtype, C, ldx, ld_tt):
-    return dtype in (torch.float16, torch.bfloat16) and C % 128 == 0 and C <= 1024 and ldx % 8 == 0 and ld_tt % 8 == 0 \
+    return dtype in (torch.float16, torch.bfloat16) and C % 128 == 0 and C <= 2048 and ldx % 8 == 0 and ld_tt % 8 == 0 \
         and os.environ.get("MLPK_NO_FUSED_TOKEN_LN", "0") != "1"
 
 
 def layernorm_transpose(x, nimg, S, C, gamma, beta, out_tt, ld_tt, eps=1e-5):
+    """x: (nimg*S, >= C) with row stride x.stride(0) (a column slice of a wider tensor is fine)."""
     N.check(N.lib().mlpk_layernorm_transpose(dtype_code(x.dtype), ptr(x), nimg, S, C, x.stride(0), ptr(gamma), ptr(beta), eps,
                                              ptr(out_tt), ld_tt, stream()), "mlpk_layernorm_transpose")
 

@@ -73,12 +73,16 @@ class gMLP(E.EngineModule):
             E.gemm(x, pk[p + "p1.w"], h, rows, 2 * F, C, bias=pk[p + "p1.b"], act=N.ACT_GELU, ln=(mean, rstd, pk[p + "p1.csum"]),
                    tag="gmlp_proj1")
             v = h[:, F:]                                        # second half, row stride 2F (g_mlp.py:18)
-            vmean = ws.get("v.mean", (rows,), torch.float32)
-            vrstd = ws.get("v.rstd", (rows,), torch.float32)
-            E.row_stats(v, rows, F, 2 * F, vmean, vrstd)
             vt = ws.get("vt", (B * F, sp))
-            E.norm_apply(v, rows, F, 2 * F, mean=vmean, rstd=vrstd, gamma=pk[p + "sgu.g"], beta=pk[p + "sgu.b"],
-                         out_tt=vt, S=S, ld_tt=sp)
+            if E.layernorm_transpose_supported(v.dtype, F, 2 * F, sp):
+                # the SGU LayerNorm (g_mlp.py:19) in one pass: statistics + affine + per-image transpose
+                E.layernorm_transpose(v, B, S, F, pk[p + "sgu.g"], pk[p + "sgu.b"], vt, sp)
+            else:
+                vmean = ws.get("v.mean", (rows,), torch.float32)
+                vrstd = ws.get("v.rstd", (rows,), torch.float32)
+                E.row_stats(v, rows, F, 2 * F, vmean, vrstd)
+                E.norm_apply(v, rows, F, 2 * F, mean=vmean, rstd=vrstd, gamma=pk[p + "sgu.g"], beta=pk[p + "sgu.b"],
+                             out_tt=vt, S=S, ld_tt=sp)
             g = ws.get("gate", (rows, F))
             # out[b,t,f] = u[b,t,f] * (sum_s Wsp[t,s] v^[b,s,f] + bsp[t]);  u = h[:, :F] read in place
             E.gemm(vt, pk[p + "sp.w"], g, B * F, S, sp, ldc=F, bias=pk[p + "sp.b"], R=h, ldr=2 * F, res=N.RES_MUL,

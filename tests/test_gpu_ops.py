@@ -679,6 +679,20 @@ def test_layernorm_transpose_one_pass(dtype):
         assert ((xt.float() - xt2.float()).abs() <= EPS[dtype] * 2 * xt2.float().abs().clamp(min=1.0)).all()
     with pytest.raises(RuntimeError):
         E.layernorm_transpose(x[:, :40], B_, S, 40, g.to(dev()), be.to(dev()), xt, sp)
+    # wide rows (gMLP's SGU: 1536 channels, the second half of a 3072-wide tensor -> row stride 3072)
+    B_, S, C = 2, 50, 1536
+    sp = E.round_up(S, 32)
+    wide = (rnd((B_ * S, 2 * C), dtype, 1340) * 2 - 0.3).to(dtype).to(dev())
+    v = wide[:, C:]
+    g = rnd((C,), torch.float32, 1341) + 1.2
+    be = rnd((C,), torch.float32, 1342)
+    xt = torch.full((B_ * C, sp), float("nan"), dtype=dtype, device=dev())
+    E.layernorm_transpose(v, B_, S, C, g.to(dev()), be.to(dev()), xt, sp)
+    torch.cuda.synchronize()
+    ref = oracle.layer_norm(v.cpu().double().reshape(B_, S, C), g.double(), be.double()).permute(0, 2, 1)
+    got = xt.cpu().double().reshape(B_, C, sp)
+    assert (got[:, :, S:] == 0).all()
+    assert (got[:, :, :S] - ref).abs().max().item() < EPS[dtype] * 1.01 * max(1.0, ref.abs().max().item())
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
