@@ -153,6 +153,10 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if args.share_device:
         local_rank = 0
+        if args.backend == "nccl" and world > 1:
+            # RCCL refuses two ranks on one device ("Duplicate GPU detected"): the single-GPU exercise of the N > 1 path
+            # (HIP forward per rank + the logits gather) runs over gloo; the JSON line says so in config.collective
+            args.backend = "gloo"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -218,7 +222,7 @@ def main():
             "config": {"workload": "%s forward, 224x224, %d images/GPU x %d GPU, random-init weights, uniform[0,1) input resident in HBM"
                                    % (args.model, args.batch, world),
                        "global_batch": global_batch, "parallelism": "dp%d" % world,
-                       "collective": "all_gather(logits)" if world > 1 else "none"},
+                       "collective": ("all_gather(logits) over %s%s" % (args.backend, ", all ranks on cuda:0" if args.share_device else "")) if world > 1 else "none"},
             "model_tflops": round(gflop_img * global_batch * args.steps / elapsed / 1e3, 1),
         }
         if timer is not None and timer.events:
