@@ -24,6 +24,7 @@
  *                       vip.py:65-90; s2_mlp_v2.py:60-69,76-85; as_mlp.py:8-24,55-95; conv_mixer.py:29-31
  *   mlpk_token_mlp      both Conv1d(k=1) of the Mixer token-mixing FeedForward + GELU + residual in ONE kernel
  *                       (mlp_mixer.py:16-27,34,37), hidden activations never leave the CU
+ *   mlpk_token_gemm     one token-mixing product with the transposed epilogue: gMLP SGU (g_mlp.py:17-22), ResMLP cross-patch (res_mlp.py:52-55)
  *   mlpk_patchify       the im2col half of nn.Conv2d(k=stride=patch): mlp_mixer.py:58-60,68-71;
  *                       conv_mixer.py:18; s2_mlp_v2.py:119; as_mlp.py:319,330; PatchMerging as_mlp.py:207-211
  *   mlpk_row_stats      statistics of nn.LayerNorm (mlp_mixer.py:10) and nn.GroupNorm(1,C) (as_mlp.py:343-344)
@@ -165,6 +166,17 @@ int mlpk_token_mlp(int dtype, const void* xt, int ldxt, int M, int S, const void
  *      (e < 4 ? 4 f + e : 16 + 4 f + e - 4): the order in which the first product's accumulators already are the second
  *      product's operands, so the hidden never leaves the registers (256-row tiles; S <= 208). */
 int mlpk_token_mlp_layout(int S, int nchunks);
+
+/* ---- single token-mixing product with the per-image transpose in the epilogue -----------------------------------------------
+ * out[b,t,c] = R[b,t,c] (+ | *) rscale[c] * ( sum_s W[t,s] * xt[b*t_rows + c, s] + bias[t] )     (res_mode ADD | MUL; NONE: no R)
+ * gMLP's spatial gating unit (g_mlp.py:17-22: R = u, MUL) and ResMLP's cross-patch sublayer (res_mlp.py:52-55: R = x, ADD,
+ * rscale = gamma_1).  The same operation as mlpk_gemm_nt with MLPK_OUT_TOKEN_T, as a persistent kernel that keeps its rows of xt
+ * in registers.  16-bit dtypes; xt (M = B*t_rows, ldxt) with ldxt % 32 == 0, ldxt <= 224 (K); w (ngroups*32, 256): output-token
+ * rows padded to whole groups of 32 (ngroups <= 8), K zero-padded to 256; bias (ngroups*32) or NULL; rscale indexed by
+ * (row % rperiod) or NULL; out / R rows are (b, t) with strides ldo / ldr. */
+int mlpk_token_gemm(int dtype, const void* xt, int ldxt, int M, int S, const void* w, int ldw, const float* bias, int ngroups,
+                    const float* rscale, int rperiod, const void* R, int ldr, int res_mode, void* out, int ldo, int t_rows,
+                    void* stream);
 /* `stats` (optional, t_rows % 128 == 0): the statistics of the LayerNorm that follows (mlp_mixer.py:38) come out of the epilogue:
  * stats[((b*S + s)*(t_rows/128) + tile)*2 + {0,1}] = sum / sum of squares over the tile's 128 channels of the values written
  * to x[b,s,:].  mlpk_stats_finalize reduces the partials of a row to mean / rstd (count = t_rows). */

@@ -834,6 +834,186 @@ __global__ void __launch_bounds__(512, 1) token_mlp_rr_kernel(const TokenMlpArgs
     }
 }
 
+// ====================================================================================================================
+// Single token-mixing product with the per-image transpose in the epilogue (gMLP's spatial gating unit, g_mlp.py:17-22; ResMLP's
+// cross-patch sublayer, res_mlp.py:52-55):
+//     out[b,t,c] = R[b,t,c] (+ | *) rscale[c] * ( sum_s W[t,s] * xt[b*C + c, s] + bias[t] )
+// The general NT GEMM with the token-transposed epilogue runs this at 2-2.5x its memory floor (N = S = 196 is one and a half
+// 128-column tiles, K = 224 is three and a half slabs: 202 us for gMLP-S at 256 images against 80 us of traffic).  Here the
+// machinery of the kernels above is reused: persistent workgroups, 256-row tiles, every wave keeps its 32 x S_pad block of xt in
+// registers, W streams through a two-stage LDS ring in groups of 32 output tokens (one-KiB LDS-DMA pieces, 2 per wave and
+// iteration).  Iteration g: wait + barrier; request group g + 1 and the R values of group g - 1; the 28 MFMAs of group g (natural
+// operands: lane = token, 4 consecutive channels); group g - 1 leaves -- fp32 staging tile [32 tokens][256 channels] in LDS ->
+// (token, 8 channels) items, 16-byte R loads and stores in 512-byte runs; then group g's accumulators (+ bias) are staged in the
+// other buffer.  One barrier per iteration; loads and stores share the iterations evenly, so there is no chip-wide memory burst.
+// LDS: 32 (W ring) + 64 (staging) + 1 (bias) = 97 KiB.
+constexpr int T3_BM = 256;
+constexpr int T3_R1 = 0;                               // W ring: 2 stages x 16 KiB
+constexpr int T3_STG = 2 * TM_STAGE;                   // staging: 2 x 32 KiB
+constexpr int T3_B = T3_STG + 2 * 32768;
+constexpr int T3_LDS = T3_B + 256 * 4;
+
+struct TokenGemmArgs {
+    const void* xt;     // (M, ldxt) token-transposed operand, K-padded with zeros
+    const void* w;      // (G*32, 256): output-token rows and K zero-padded
+    const float* bias;  // (G*32) zero-padded, or NULL
+    const float* rscale;// per channel (index = row % rperiod), or NULL
+    const void* R;      // residual / gate, (B*S, ldr), or NULL
+    void* out;          // (B*S, ldo)
+    int M, S, ks1, G;
+    int ldxt, ldr, ldo, t_rows, rperiod, res_mode;
+};
+
+template <typename T, int RES>
+__global__ void __launch_bounds__(512, 1) token_gemm_kernel(const TokenGemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const T* __restrict__ xt = reinterpret_cast<const T*>(p.xt);
+    const T* __restrict__ w = reinterpret_cast<const T*>(p.w);
+    const T* __restrict__ Rp = reinterpret_cast<const T*>(p.R);
+    T* __restrict__ out = reinterpret_cast<T*>(p.out);
+    const int G = p.G;
+    const int ks1 = p.ks1;
+    const int ntiles = (p.M + T3_BM - 1) / T3_BM;
+    const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)smem;
+    float* const bs = reinterpret_cast<float*>(smem + T3_B);
+    for (int i = tid; i < 256; i += 512) bs[i] = (p.bias && i < G * 32) ? p.bias[i] : 0.f;
+
+    auto lane_now = [&]() {
+        unsigned l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return (int)l;
+    };
+    // W group = 8 planes (K-slabs) x [32 rows x 64 B], pieces pc = plane * 2 + half, planes 0-6 only: 14 pieces, wave w issues 2w, 2w + 1
+    // (waves 7: pieces 14, 15 -> duplicates of 13)
+    auto issue_w = [&](const int g, const unsigned stage, const int ln) {
+        const T* base = w + (size_t)g * (32 * 256);
+        const int lrow = ln >> 2;
+        const int lchunk = (ln & 3) ^ ((lrow & 8) >> 2);
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) {
+            int q = wave * 2 + pi;
+            q = q < 14 ? q : 13;
+            const unsigned off = (unsigned)(((q & 1) * 16 + lrow) * 256 + (q >> 1) * 32 + lchunk * 8) * (unsigned)sizeof(T);
+            tm_glds(off, base, __builtin_amdgcn_readfirstlane(lds_base + T3_R1 + stage * TM_STAGE + q * 1024));
+        }
+    };
+
+    u32x4 xa[2][TM_KMAX];
+    auto load_x = [&](const int tile, const int ln) {
+        const int frow = ln & 15, fg = ln >> 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int gm = tile * T3_BM + wave * 32 + i * 16 + frow;
+            gm = gm < p.M ? gm : p.M - 1;
+#pragma unroll
+            for (int kk = 0; kk < TM_KMAX; ++kk)
+                xa[i][kk] = *reinterpret_cast<const u32x4*>(xt + (size_t)gm * p.ldxt + (kk < ks1 ? kk : ks1 - 1) * 32 + fg * 8);
+        }
+    };
+    load_x(blockIdx.x, lane_now());
+    issue_w(0, 0, lane);                                   // group 0 of the first tile
+    __syncthreads();
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // reader geometry of this tile: item = (token slot tid >> 5 (+16), channels (tid & 31) * 8 .. + 7 of the tile's 256)
+        const int le = lane_now();
+        const int rt = wave * 2 + (le >> 5), rc = le & 31;
+        const int mr = tile * T3_BM + rc * 8;
+        const int rimg = mr / p.t_rows;
+        const int rcc = mr - rimg * p.t_rows;
+        const bool row_ok = mr < p.M;
+        float rsc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rsc[e] = 1.0f;
+        if (p.rscale && row_ok) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rsc[e] = p.rscale[(mr + e) % p.rperiod];
+        }
+        f32x4 acc[2][2];
+        u32x4 rv[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
+        auto request_r = [&](const int g) {                // R values of group g's reader items (used one iteration later)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int t = g * 32 + rt + 16 * k;
+                rv[k] = u32x4{0u, 0u, 0u, 0u};
+                if (RES != MLPK_RES_NONE && t < p.S && row_ok) rv[k] = *reinterpret_cast<const u32x4*>(Rp + ((size_t)rimg * p.S + t) * p.ldr + rcc);
+            }
+        };
+        // Order inside an iteration: (1) group g - 1 leaves (its R values were requested an iteration ago), (2) W group g + 1 and
+        // the R values of group g are requested, (3) the MFMAs of group g, (4) its accumulators are staged.  The single
+        // vmcnt(0) at the top then only meets operations that have had (almost) a whole iteration to complete -- the stores
+        // first of all (with the stores issued late in the iteration the same wait exposed their round trip).
+        for (int g = 0; g <= G; ++g) {
+            __builtin_amdgcn_s_waitcnt(0x0070);           // vmcnt(0) lgkmcnt(0) expcnt(7)
+            TM_BARRIER();
+            const int ln = lane_now();
+            const int frow = ln & 15, fg = ln >> 4;
+            if (g > 0) {
+                const char* sb = smem + T3_STG + ((g - 1) & 1) * 32768;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int slot = rt + 16 * k;
+                    const int t = (g - 1) * 32 + slot;
+                    if (t < p.S && row_ok) {
+                        const f32x4 v0 = *reinterpret_cast<const f32x4*>(sb + slot * 1024 + (((2 * rc) ^ (slot & 15)) << 4));
+                        const f32x4 v1 = *reinterpret_cast<const f32x4*>(sb + slot * 1024 + (((2 * rc + 1) ^ (slot & 15)) << 4));
+                        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                        T r8[8], e[8];
+                        __builtin_memcpy(r8, &rv[k], 16);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            float y = v[q] * rsc[q];
+                            if constexpr (RES == MLPK_RES_ADD) y += to_f32(r8[q]);
+                            else if constexpr (RES == MLPK_RES_MUL) y *= to_f32(r8[q]);
+                            e[q] = from_f32<T>(y);
+                        }
+                        u32x4 o;
+                        __builtin_memcpy(&o, e, 16);
+                        *reinterpret_cast<u32x4*>(out + ((size_t)rimg * p.S + t) * p.ldo + rcc) = o;
+                    }
+                }
+            }
+            if (g < G) {
+                // next W group: g + 1 of this tile, or group 0 again for the next tile (the weights are the same for every tile)
+                issue_w(g + 1 < G ? g + 1 : 0, (unsigned)((g + 1) & 1), ln);
+                request_r(g);
+                const char* r1 = smem + T3_R1 + (g & 1) * TM_STAGE;
+                const int f_rd = frow * 64 + ((fg ^ ((frow & 8) >> 2)) << 4);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < TM_KMAX; ++kk) {
+                    const u32x4 bw0 = *reinterpret_cast<const u32x4*>(r1 + kk * 2048 + f_rd);
+                    const u32x4 bw1 = *reinterpret_cast<const u32x4*>(r1 + kk * 2048 + f_rd + 1024);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        acc[i][0] = Mma2<T>::run(xa[i][kk], bw0, acc[i][0]);      // natural operands: lane = token frow, channels 4 fg + r
+                        acc[i][1] = Mma2<T>::run(xa[i][kk], bw1, acc[i][1]);
+                    }
+                }
+                if (g == G - 1) load_x(tile + gridDim.x, ln);                  // X is dead now: the next tile's (rows past M clamp)
+                char* const sw = smem + T3_STG + (g & 1) * 32768;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float bn = bs[g * 32 + j * 16 + frow];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const f32x4 v = {acc[i][j].x + bn, acc[i][j].y + bn, acc[i][j].z + bn, acc[i][j].w + bn};
+                        *reinterpret_cast<f32x4*>(sw + (j * 16 + frow) * 1024 + (((wave * 8 + i * 4 + fg) ^ frow) << 4)) = v;
+                    }
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no LDS-DMA may outlive the workgroup
+}
+
 static unsigned long long* g_tm_dbg = nullptr;
 
 static int tm_grid_cap() {
@@ -918,6 +1098,44 @@ extern "C" int mlpk_token_mlp(int dtype, const void* xt, int ldxt, int M, int S,
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(k, dim3(grid), dim3(512), TM_LDS, s, a);
     }
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mlpk_token_gemm(int dtype, const void* xt, int ldxt, int M, int S, const void* w, int ldw, const float* bias, int ngroups,
+                               const float* rscale, int rperiod, const void* R, int ldr, int res_mode, void* out, int ldo, int t_rows,
+                               void* stream) {
+    if (!xt || !w || !out) return MLPK_ENULL;
+    if (dtype != MLPK_F16 && dtype != MLPK_BF16) return MLPK_EDTYPE;
+    if (M <= 0 || S <= 0 || ngroups <= 0 || t_rows <= 0) return MLPK_ESHAPE;
+    if (res_mode < MLPK_RES_NONE || res_mode > MLPK_RES_MUL) return MLPK_EMODE;
+    if (res_mode != MLPK_RES_NONE && !R) return MLPK_ENULL;
+    if (rscale && rperiod <= 0) return MLPK_ESHAPE;
+    if (ngroups * 32 < S || ngroups > 8) return MLPK_ESHAPE;                      // output tokens: whole groups of 32, <= 256
+    if (ldxt % 32 || ldxt > 32 * TM_KMAX || ldxt < S) return MLPK_ESHAPE;           // K = ldxt: whole 64-byte slabs, <= 7
+    if (ldw != 256) return MLPK_ESHAPE;
+    if (M % 8 || t_rows % 8 || M % t_rows || ldo % 8 || ldo < t_rows || (R && (ldr % 8 || ldr < t_rows))) return MLPK_ESHAPE;
+    if (((uintptr_t)xt & 15) || ((uintptr_t)w & 15) || ((uintptr_t)out & 15) || ((uintptr_t)R & 15)) return MLPK_EALIGN;
+    TokenGemmArgs a;
+    a.xt = xt; a.w = w; a.bias = bias; a.rscale = rscale; a.R = R; a.out = out;
+    a.M = M; a.S = S; a.ks1 = ldxt / 32; a.G = ngroups;
+    a.ldxt = ldxt; a.ldr = ldr; a.ldo = ldo; a.t_rows = t_rows; a.rperiod = rperiod > 0 ? rperiod : 1; a.res_mode = res_mode;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int tiles = (M + T3_BM - 1) / T3_BM;
+    const unsigned grid = (unsigned)(tiles < tm_grid_cap() ? tiles : tm_grid_cap());
+#define TG_LAUNCH(TT, RR)                                                                                              \
+    {                                                                                                                   \
+        auto k = token_gemm_kernel<TT, RR>;                                                                             \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, T3_LDS); \
+        if (e != hipSuccess) return (int)e;                                                                             \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(512), T3_LDS, s, a);                                                     \
+    }
+    if (dtype == MLPK_BF16) {
+        if (res_mode == MLPK_RES_ADD) TG_LAUNCH(bf16_t, MLPK_RES_ADD) else if (res_mode == MLPK_RES_MUL) TG_LAUNCH(bf16_t, MLPK_RES_MUL) else TG_LAUNCH(bf16_t, MLPK_RES_NONE)
+    } else {
+        if (res_mode == MLPK_RES_ADD) TG_LAUNCH(f16_t, MLPK_RES_ADD) else if (res_mode == MLPK_RES_MUL) TG_LAUNCH(f16_t, MLPK_RES_MUL) else TG_LAUNCH(f16_t, MLPK_RES_NONE)
+    }
+#undef TG_LAUNCH
     MLPK_LAUNCH_CHECK();
     return 0;
 }

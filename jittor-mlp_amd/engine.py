@@ -198,6 +198,28 @@ def token_mlp_supported(dtype, S, sp, hidden=0):
     return dtype in (torch.float16, torch.bfloat16) and S <= 208 and sp <= 224 and sp % 32 == 0 and hidden <= 1024
 
 
+def token_gemm_supported(dtype, S, sp):
+    return dtype in (torch.float16, torch.bfloat16) and S <= 224 and sp <= 224 and sp % 32 == 0 and os.environ.get("MLPK_NO_TOKEN_GEMM", "0") != "1"
+
+
+def pack_token_gemm(w, b, dtype, device):
+    """(S_out, S_in) token-mixing weight -> (groups*32, 256) for mlpk_token_gemm, bias padded to groups*32."""
+    w = w.detach().reshape(w.shape[0], -1)
+    so, si = w.shape
+    ng = (so + 31) // 32
+    wp = torch.zeros((ng * 32, 256), dtype=dtype, device=device)
+    wp[:so, :si] = w.to(device=device, dtype=dtype)
+    bp = torch.zeros((ng * 32,), dtype=torch.float32, device=device)
+    if b is not None:
+        bp[:so] = b.detach().to(device=device, dtype=torch.float32).reshape(-1)
+    return wp, bp, ng
+
+
+def token_gemm(xt, ldxt, M, S, wp, bp, ng, out, ldo, t_rows, *, R=None, ldr=0, res=N.RES_NONE, rscale=None, rperiod=0):
+    N.check(N.lib().mlpk_token_gemm(dtype_code(xt.dtype), ptr(xt), ldxt, M, S, ptr(wp), wp.stride(0), ptr(bp), ng, ptr(rscale), rperiod,
+                                    ptr(R), ldr, res, ptr(out), ldo, t_rows, stream()), "mlpk_token_gemm")
+
+
 def pack_token_mlp(w1, b1, w2, b2, dtype, device, sp, layout=None):
     """Weights of the fused token-mixing kernel: W1 rows / b1 / W2 columns zero-padded to whole hidden groups
     of mlpk_token_mlp_chunk() = 32, W1's K axis zero-padded to 256 (8 LDS planes per group)."""

@@ -56,6 +56,9 @@ class gMLP(E.EngineModule):
             pk[p + "sgu.g"], pk[p + "sgu.b"] = E.f32(blk.sgu.norm.weight, device), E.f32(blk.sgu.norm.bias, device)
             pk[p + "sp.w"] = E.pack_matrix(blk.sgu.spatial_proj.weight, dtype, device, kpad=32)      # (S, S_pad)
             pk[p + "sp.b"] = E.f32(blk.sgu.spatial_proj.bias, device)
+            S = blk.sgu.spatial_proj.weight.shape[0]
+            if E.token_gemm_supported(dtype, S, E.round_up(S, 32)):
+                pk[p + "sp.tg"] = E.pack_token_gemm(blk.sgu.spatial_proj.weight, blk.sgu.spatial_proj.bias, dtype, device)
 
     def _pack(self, dtype, device):
         pk = {}
@@ -85,8 +88,12 @@ class gMLP(E.EngineModule):
                              out_tt=vt, S=S, ld_tt=sp)
             g = ws.get("gate", (rows, F))
             # out[b,t,f] = u[b,t,f] * (sum_s Wsp[t,s] v^[b,s,f] + bsp[t]);  u = h[:, :F] read in place
-            E.gemm(vt, pk[p + "sp.w"], g, B * F, S, sp, ldc=F, bias=pk[p + "sp.b"], R=h, ldr=2 * F, res=N.RES_MUL,
-                   out_mode=N.OUT_TOKEN_T, t_rows=F, t_tokens=S)
+            tg = pk.get(p + "sp.tg")
+            if tg is not None:
+                E.token_gemm(vt, sp, B * F, S, tg[0], tg[1], tg[2], g, F, F, R=h, ldr=2 * F, res=N.RES_MUL)
+            else:
+                E.gemm(vt, pk[p + "sp.w"], g, B * F, S, sp, ldc=F, bias=pk[p + "sp.b"], R=h, ldr=2 * F, res=N.RES_MUL,
+                       out_mode=N.OUT_TOKEN_T, t_rows=F, t_tokens=S)
             E.gemm(g, pk[p + "p2.w"], x, rows, C, F, bias=pk[p + "p2.b"], R=x, res=N.RES_ADD)
         return x
 

@@ -66,6 +66,9 @@ class ResMLP(E.EngineModule):
             pk[p + "g1"], pk[p + "g2"] = E.f32(blk.gamma_1, device), E.f32(blk.gamma_2, device)
             pk[p + "tok.w"] = E.pack_matrix(blk.token_mix.weight, dtype, device, kpad=32)            # (S, S_pad)
             pk[p + "tok.b"] = E.f32(blk.token_mix.bias, device)
+            S = blk.token_mix.weight.shape[0]
+            if E.token_gemm_supported(dtype, S, E.round_up(S, 32)):
+                pk[p + "tok.tg"] = E.pack_token_gemm(blk.token_mix.weight, blk.token_mix.bias, dtype, device)
             pk[p + "fc1.w"] = E.pack_matrix(blk.ff.net[0].weight, dtype, device)
             pk[p + "fc1.b"] = E.f32(blk.ff.net[0].bias, device)
             pk[p + "fc2.w"] = E.pack_matrix(blk.ff.net[3].weight, dtype, device)
@@ -87,8 +90,12 @@ class ResMLP(E.EngineModule):
             # x1 = alpha*x + beta, in place, plus its token-transposed copy for the token GEMM
             E.norm_apply(x, rows, C, C, gamma=pk[p + "pre.a"], beta=pk[p + "pre.b"], out_rm=x, ld_rm=C, out_tt=xt, S=S, ld_tt=sp)
             # x2 = x1 + gamma_1[c] * (sum_s Wt[t,s] x1[b,s,c] + bt[t])
-            E.gemm(xt, pk[p + "tok.w"], x, B * C, S, sp, ldc=C, bias=pk[p + "tok.b"], rscale=pk[p + "g1"], rperiod=C,
-                   R=x, ldr=C, res=N.RES_ADD, out_mode=N.OUT_TOKEN_T, t_rows=C, t_tokens=S)
+            tg = pk.get(p + "tok.tg")
+            if tg is not None:
+                E.token_gemm(xt, sp, B * C, S, tg[0], tg[1], tg[2], x, C, C, R=x, ldr=C, res=N.RES_ADD, rscale=pk[p + "g1"], rperiod=C)
+            else:
+                E.gemm(xt, pk[p + "tok.w"], x, B * C, S, sp, ldc=C, bias=pk[p + "tok.b"], rscale=pk[p + "g1"], rperiod=C,
+                       R=x, ldr=C, res=N.RES_ADD, out_mode=N.OUT_TOKEN_T, t_rows=C, t_tokens=S)
             # x3 = alpha'*x2 + beta'
             E.norm_apply(x, rows, C, C, gamma=pk[p + "post.a"], beta=pk[p + "post.b"], out_rm=x, ld_rm=C)
             h = ws.get("h", (rows, hidden))

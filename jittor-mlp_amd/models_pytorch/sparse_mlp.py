@@ -121,6 +121,10 @@ class SparseMLP(E.EngineModule):
                 pk[p + "bn.sw"], pk[p + "bn.hw"] = s.repeat(W).contiguous(), h.repeat(W).contiguous()   # per (w, c) "channel"
                 pk[p + "ph.w"], pk[p + "ph.b"] = E.pack_matrix(sm.proj_h.weight, dtype, device), E.f32(sm.proj_h.bias, device)
                 pk[p + "pw.w"], pk[p + "pw.b"] = E.pack_matrix(sm.proj_w.weight, dtype, device), E.f32(sm.proj_w.bias, device)
+                if E.token_gemm_supported(dtype, max(sm.proj_h.weight.shape[0], sm.proj_w.weight.shape[0]), 32):
+                    # the persistent single-product token kernel (gMLP / ResMLP) serves the two axial mixes as well
+                    pk[p + "ph.tg"] = E.pack_token_gemm(sm.proj_h.weight, sm.proj_h.bias, dtype, device)
+                    pk[p + "pw.tg"] = E.pack_token_gemm(sm.proj_w.weight, sm.proj_w.bias, dtype, device)
                 wf = sm.fuse.weight.detach().reshape(C, 3 * C)
                 pk[p + "fu.wh"] = E.pack_matrix(wf[:, :C], dtype, device)
                 pk[p + "fu.wr"] = E.pack_matrix(wf[:, C:], dtype, device)                                # [x_w | x^] columns
@@ -154,7 +158,8 @@ class SparseMLP(E.EngineModule):
         for li, stage in enumerate(self.layers):
             H, W, C, depth, ef = stage.geom
             rows = B * H * W
-            hp, wp = E.round_up(H, 8), E.round_up(W, 8)
+            tgk = ("l%d.b0.pw.tg" % li) in pk                            # token kernel: K padded to whole 64-byte slabs
+            hp, wp = E.round_up(H, 32 if tgk else 8), E.round_up(W, 32 if tgk else 8)
             tmp = ws.get("l%d.tmp" % li, (rows, C))
             xh = ws.get("l%d.xh" % li, (rows, C))
             cat = ws.get("l%d.cat" % li, (rows, 2 * C))                  # [x_w | x^]
@@ -169,10 +174,15 @@ class SparseMLP(E.EngineModule):
                 E.norm_apply(cur, rows, C, C, gamma=pk[p + "bn.s"], beta=pk[p + "bn.h"], out_rm=cat[:, C:], ld_rm=2 * C,
                              out_tt=xt_w, S=W, ld_tt=wp)
                 E.norm_apply(cur, B * H, W * C, W * C, gamma=pk[p + "bn.sw"], beta=pk[p + "bn.hw"], out_tt=xt_h, S=H, ld_tt=hp)
-                E.gemm(xt_w, pk[p + "pw.w"], cat, B * H * C, W, wp, ldc=2 * C, bias=pk[p + "pw.b"], out_mode=N.OUT_TOKEN_T,
-                       t_rows=C, t_tokens=W, tag="smlp_w")
-                E.gemm(xt_h, pk[p + "ph.w"], xh, B * W * C, H, hp, ldc=W * C, bias=pk[p + "ph.b"], out_mode=N.OUT_TOKEN_T,
-                       t_rows=W * C, t_tokens=H, tag="smlp_h")
+                if tgk:
+                    tw, th = pk[p + "pw.tg"], pk[p + "ph.tg"]
+                    E.token_gemm(xt_w, wp, B * H * C, W, tw[0], tw[1], tw[2], cat, 2 * C, C)
+                    E.token_gemm(xt_h, hp, B * W * C, H, th[0], th[1], th[2], xh, W * C, W * C)
+                else:
+                    E.gemm(xt_w, pk[p + "pw.w"], cat, B * H * C, W, wp, ldc=2 * C, bias=pk[p + "pw.b"], out_mode=N.OUT_TOKEN_T,
+                           t_rows=C, t_tokens=W, tag="smlp_w")
+                    E.gemm(xt_h, pk[p + "ph.w"], xh, B * W * C, H, hp, ldc=W * C, bias=pk[p + "ph.b"], out_mode=N.OUT_TOKEN_T,
+                           t_rows=W * C, t_tokens=H, tag="smlp_h")
                 E.gemm(xh, pk[p + "fu.wh"], cur, rows, C, C, bias=pk[p + "fu.b"], R=cur, res=N.RES_ADD, tag="smlp_fuse")
                 E.gemm(cat, pk[p + "fu.wr"], cur, rows, C, 2 * C, R=cur, res=N.RES_ADD, tag="smlp_fuse")
                 channel_mlp(ws, cur, rows, C, pk, p + "ff.", C * ef, tag="l%d.cm" % li)

@@ -695,6 +695,47 @@ def test_layernorm_transpose_one_pass(dtype):
     assert (got[:, :, :S] - ref).abs().max().item() < EPS[dtype] * 1.01 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_token_gemm(dtype):
+    """mlpk_token_gemm: out[b,t,c] = R[b,t,c] (+|*) rscale[c] * (sum_s W[t,s] xt[b*C+c, s] + bias[t]) -- gMLP's gate (g_mlp.py:17-22,
+    R = u inside a wider tensor, MUL) and ResMLP's cross-patch sublayer (res_mlp.py:52-55, in place, ADD, gamma_1) -- against fp64,
+    incl. ragged tokens, tiles spanning images, a partial last tile, and the same operation through mlpk_gemm_nt's transposed epilogue."""
+    pkg = load_pkg()
+    E, N = pkg.engine, pkg._native
+    for ci, (B_, C, S, mode) in enumerate([(2, 256, 196, "mul"), (3, 384, 196, "add"), (5, 40, 49, "add"), (1, 64, 32, "none"), (2, 1536, 50, "mul"), (4, 96, 224, "add")]):
+        sp = E.round_up(S, 32)
+        xn = rnd((B_, S, C), dtype, 2000 + ci)
+        xt = torch.zeros((B_ * C, sp), dtype=dtype, device=dev())
+        xt[:, :S] = xn.permute(0, 2, 1).reshape(B_ * C, S).to(dev())
+        w = rnd((S, S), torch.float32, 2010 + ci, 1.0 / math.sqrt(S))
+        bias = rnd((S,), torch.float32, 2020 + ci)
+        wp, bp, ng = E.pack_token_gemm(w, bias, dtype, dev())
+        wr = w.to(dtype).double()
+        core = torch.einsum("ts,bsc->btc", wr, xn.double()) + bias.double().view(1, -1, 1)
+        if mode == "mul":
+            wide = rnd((B_ * S, 2 * C), dtype, 2030 + ci).to(dev())              # R = first half of a wider tensor (row stride 2C)
+            out = torch.full((B_ * S, C), float("nan"), dtype=dtype, device=dev())
+            E.token_gemm(xt, sp, B_ * C, S, wp, bp, ng, out, C, C, R=wide, ldr=2 * C, res=N.RES_MUL)
+            ref = core * wide.cpu().double()[:, :C].reshape(B_, S, C)
+        elif mode == "add":
+            x = rnd((B_ * S, C), dtype, 2030 + ci).to(dev())
+            g1 = (rnd((C,), torch.float32, 2040 + ci) * 0.3 + 0.5).to(dev())
+            ref = x.cpu().double().reshape(B_, S, C) + core * g1.cpu().double().view(1, 1, -1)
+            out = x
+            E.token_gemm(xt, sp, B_ * C, S, wp, bp, ng, out, C, C, R=x, ldr=C, res=N.RES_ADD, rscale=g1, rperiod=C)   # in place
+        else:
+            out = torch.full((B_ * S, C), float("nan"), dtype=dtype, device=dev())
+            E.token_gemm(xt, sp, B_ * C, S, wp, bp, ng, out, C, C)
+            ref = core
+        torch.cuda.synchronize()
+        got = out.cpu().double().reshape(B_, S, C)
+        assert torch.isfinite(got).all(), (str(dtype), ci)
+        err = (got - ref).abs().max().item()
+        assert err < EPS[dtype] * 4 * max(1.0, ref.abs().max().item()), (str(dtype), ci, err)
+    with pytest.raises(RuntimeError):
+        E.token_gemm(xt, sp, B_ * C, 300, wp, bp, ng, out, C, C)                # more tokens than the packed groups hold
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_dwconv_affine_nhwc(dtype):
     """Sparse-MLP depthwise step: x + dwconv_same(scale * x + shift) + bias with zero padding AFTER the affine
