@@ -43,11 +43,12 @@ BF16_REAL_EXCEPTIONS = {
 
 
 FP16_REAL_EXCEPTIONS = {
-    # measured 1.10e-3 (9.2e-4 while SplitAttention's `a` was summed from the fp16-ROUNDED branch outputs; it now follows from
-    # fp32 sums of the branch inputs, 2.5e-4 instead of 4.5e-2 away from an fp64 evaluation of the same operands --
-    # tools/vip_a_check.py -- and the logits' distance to the fp32 reference, dominated by the fp16 storage rounding of
-    # 18 x 6 GEMM outputs on logits of magnitude 0.44, moved by 2e-4 with it)
-    "vip_s7": 1.3e-3,
+    # measured 1.03e-3 on logits of magnitude 0.44 after 18 blocks x 6 GEMMs with fp16 storage.  Same-box switches (round 2):
+    # SplitAttention's `a` from fp32 sums of the branch inputs (2.5e-4 from an fp64 evaluation of the same operands,
+    # tools/vip_a_check.py) 1.03e-3 | `a` summed from the fp16-ROUNDED branch outputs (4.5e-2 from fp64) 8.3e-4 | without the
+    # channel-branch LayerNorm fold 1.15e-3; bf16 moves the other way (5.9e-3 | 6.9e-3 | 6.4e-3): the max over 8000 logits
+    # fluctuates by +-20 % between equally valid roundings, and the more exact evaluation is kept.
+    "vip_s7": 1.2e-3,
 }
 
 
