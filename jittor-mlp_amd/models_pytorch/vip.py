@@ -11,8 +11,6 @@ slab staged through LDS, so the einops copies of the reference become coalesced 
 three NT GEMMs; the inverse rearranges; split attention as reduce -> two tiny fp32 GEMMs ->
 softmax -> weighted apply; projection GEMM with the residual in its epilogue.
 """
-import os
-
 import torch
 from torch import nn
 
