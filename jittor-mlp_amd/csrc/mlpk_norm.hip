@@ -371,24 +371,28 @@ struct LnTtArgs {
     int S, C, ldx, ld_tt, s_tiles;
     float eps;
 };
-template <typename T, int NVMAX>
-__global__ void __launch_bounds__(512) layernorm_transpose_kernel(const LnTtArgs p) {
+template <typename T, int NVMAX, int LPT>
+__global__ void __launch_bounds__(32 * LPT) layernorm_transpose_kernel(const LnTtArgs p) {
+    static_assert(LPT == 16 || LPT == 32, "lanes per token");
+    constexpr int THREADS = 32 * LPT;
     static_assert(sizeof(T) == 2, "16-bit storage types");
     constexpr int WP = 34;                                   // words per channel pair: 32 tokens + 2 (8-byte aligned rows)
     extern __shared__ __attribute__((aligned(16))) uint32_t ltw[];      // (C / 2) x WP words
     const int tid = threadIdx.x;
     const int img = blockIdx.x / p.s_tiles;
     const int s0 = (blockIdx.x % p.s_tiles) * 32;
-    const int sl = tid >> 4, l16 = tid & 15;
+    const int sl = tid / LPT, l16 = tid % LPT;               // token slot, lane within the token's row (wide rows: 32 lanes per
+                                                             // token, 1024 threads -- twice the waves in flight behind the one
+                                                             // workgroup per CU that the staging tile allows)
     const int s = s0 + sl;
-    const int nv = p.C >> 7;                                 // vectors per lane (C % 128 == 0, <= NVMAX)
+    const int nv = p.C / (LPT * 8);                          // vectors per lane (C % (LPT * 8) == 0, <= NVMAX)
     const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
     const bool live = s < p.S;
     u32x4 raw[NVMAX];
 #pragma unroll
     for (int k = 0; k < NVMAX; ++k) {
         raw[k] = u32x4{0u, 0u, 0u, 0u};
-        if (k < nv && live) raw[k] = *reinterpret_cast<const u32x4*>(x + ((int64_t)img * p.S + s) * p.ldx + (l16 + 16 * k) * 8);
+        if (k < nv && live) raw[k] = *reinterpret_cast<const u32x4*>(x + ((int64_t)img * p.S + s) * p.ldx + (l16 + LPT * k) * 8);
     }
     float s1 = 0.f;
 #pragma unroll
@@ -401,7 +405,12 @@ __global__ void __launch_bounds__(512) layernorm_transpose_kernel(const LnTtArgs
         }
     }
     const float inv = 1.0f / (float)p.C;
-    const float mu = row16_sum(s1) * inv;
+    auto row_sum = [&](float v) {
+        v = row16_sum(v);
+        if constexpr (LPT == 32) v += __shfl_xor(v, 16);
+        return v;
+    };
+    const float mu = row_sum(s1) * inv;
     float q1 = 0.f;
 #pragma unroll
     for (int k = 0; k < NVMAX; ++k) {
@@ -415,11 +424,11 @@ __global__ void __launch_bounds__(512) layernorm_transpose_kernel(const LnTtArgs
             }
         }
     }
-    const float rs = 1.0f / __builtin_sqrtf(row16_sum(q1) * inv + p.eps);
+    const float rs = 1.0f / __builtin_sqrtf(row_sum(q1) * inv + p.eps);
 #pragma unroll
     for (int k = 0; k < NVMAX; ++k) {
         if (k < nv) {
-            const int c = (l16 + 16 * k) * 8;
+            const int c = (l16 + LPT * k) * 8;
             T e[8];
             __builtin_memcpy(e, &raw[k], 16);
             if (live) {
@@ -440,7 +449,7 @@ __global__ void __launch_bounds__(512) layernorm_transpose_kernel(const LnTtArgs
     // transposed side: item = (channel pair, 8 consecutive tokens); 4 items cover a pair's 32 tokens = 64 contiguous bytes per channel
     T* out = reinterpret_cast<T*>(p.out);
     const int items = (p.C >> 1) * 4;
-    for (int idx = tid; idx < items; idx += 512) {
+    for (int idx = tid; idx < items; idx += THREADS) {
         const int pr = idx >> 2;
         const int sc = (idx & 3) * 8;
         if (s0 + sc >= p.ld_tt) continue;                    // ld_tt % 8 == 0
@@ -910,17 +919,18 @@ extern "C" int mlpk_layernorm_transpose(int dtype, const void* x, int64_t nimg, 
     if (nimg * a.s_tiles > 0x7fffffffLL) return MLPK_ESHAPE;
     const size_t lds = (size_t)(C / 2) * 34 * 4;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-#define LNTT_LAUNCH(TT, NV)                                                                                              \
+#define LNTT_LAUNCH(TT, NV, LP)                                                                                          \
     {                                                                                                                    \
-        auto k = layernorm_transpose_kernel<TT, NV>;                                                                     \
+        auto k = layernorm_transpose_kernel<TT, NV, LP>;                                                                 \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return (int)e;                                                                              \
-        hipLaunchKernelGGL(k, dim3((unsigned)(nimg * a.s_tiles)), dim3(512), lds, s, a);                                 \
+        hipLaunchKernelGGL(k, dim3((unsigned)(nimg * a.s_tiles)), dim3(32 * LP), lds, s, a);                             \
     }
+    const bool wide32 = C > 1024 && C % 256 == 0;           // 32 lanes per token
     if (dtype == MLPK_BF16) {
-        if (C <= 1024) LNTT_LAUNCH(bf16_t, 8) else LNTT_LAUNCH(bf16_t, 16)
+        if (C <= 1024) LNTT_LAUNCH(bf16_t, 8, 16) else if (wide32) LNTT_LAUNCH(bf16_t, 8, 32) else LNTT_LAUNCH(bf16_t, 16, 16)
     } else {
-        if (C <= 1024) LNTT_LAUNCH(f16_t, 8) else LNTT_LAUNCH(f16_t, 16)
+        if (C <= 1024) LNTT_LAUNCH(f16_t, 8, 16) else if (wide32) LNTT_LAUNCH(f16_t, 8, 32) else LNTT_LAUNCH(f16_t, 16, 16)
     }
 #undef LNTT_LAUNCH
     MLPK_LAUNCH_CHECK();

@@ -655,7 +655,7 @@ def test_layernorm_transpose_one_pass(dtype):
     zero K-padding columns, ragged last token tile; against the fp64 oracle and bit-compared with the two-kernel path's layout."""
     pkg = load_pkg()
     E = pkg.engine
-    for ci, (B_, S, C) in enumerate([(2, 196, 768), (3, 49, 128), (1, 33, 1024), (2, 64, 256), (5, 7, 512)]):
+    for ci, (B_, S, C) in enumerate([(2, 196, 768), (3, 49, 128), (1, 33, 1024), (2, 64, 256), (5, 7, 512), (2, 40, 1280), (1, 70, 2048)]):
         sp = E.round_up(S, 32)
         x = (rnd((B_ * S, C), dtype, 1300 + ci) * 3 + 0.7).to(dtype).to(dev())
         g = rnd((C,), torch.float32, 1310 + ci) + 1.2
