@@ -242,8 +242,8 @@ def main():
                                     # a "launch" here is one mlpk_gemm_nt CALL (236.8 GFLOP): the persistent tile covers M with up
                                     # to three tile heights, each its own kernel launch (NI = 4 / 3 / 1 at M = 50176), so a
                                     # rocprofv3 --stats summary lists them as separate rows; per call the row averages add up as
-                                    # sum(calls_i x avg_i) / number of calls (profiles/r02_mixer_b16_kernel_stats_v2.csv:
-                                    # (100 x 168.5 + 52 x 135.0 + 48 x 18.0) us / 100 calls = 247 us under the profiler)
+                                    # sum(calls_i x avg_i) / number of calls (profiles/r02_mixer_b16_kernel_stats_v4.csv:
+                                    # (100 x 164 + 52 x 133 + 48 x 18) us / 100 calls = 242 us under the profiler)
                                     "launch_means": "one mlpk_gemm_nt call = up to 3 kernel launches (tile heights)"}
             line["kernels"] = {t: {"avg_ms": round(v["avg_ms"], 4), "tflops": round(v["flops_per_launch"] / v["avg_ms"] / 1e9, 1),
                                    "launches": v["launches"]} for t, v in summ.items()}
