@@ -168,7 +168,16 @@ def main():
             dist.init_process_group(args.backend)
 
     import __graft_entry__ as ge
-    ge.build()
+    if world > 1:
+        # one rank compiles (a no-op when the in-tree library is current), the others wait: eight ranks racing on the same
+        # object files would corrupt a cold build
+        if rank == 0:
+            ge.build()
+        dist.barrier()
+        if rank != 0:
+            ge.build()
+    else:
+        ge.build()
     pkg = importlib.import_module("jittor-mlp_amd")
     E = pkg.engine
     for item in filter(None, args.algo.split(",")):
