@@ -2,7 +2,7 @@
 # final measurement run of the round: everything the judge reads, from one box
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
-OUT=$PWD/gpurun_out/r2z
+OUT=$PWD/gpurun_out/final
 mkdir -p $OUT
 python __graft_entry__.py build > $OUT/build.log 2>&1
 rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit|Max Clock" | head -6 > $OUT/rocminfo.txt; nproc >> $OUT/rocminfo.txt
@@ -18,7 +18,7 @@ bash tools/prof_model.sh mixer_b16 2>&1 | tail -12
 for m in mixer_s16 mixer_l16 gmlp_s resmlp_24 vip_s7 s2mlpv2 asmlp_t convmixer_1536_20 sparsemlp_t hiremlp_s msmlp_t swinmlp_t cyclemlp_b1; do timeout 300 python bench.py --model $m --steps 20 --warmup 5 --no-cpu-baseline >> $OUT/bench_models.jsonl 2>> $OUT/bench_models.err; done
 python - <<'PY'
 import json
-for l in open("gpurun_out/r2z/bench_models.jsonl"):
+for l in open("gpurun_out/final/bench_models.jsonl"):
     d = json.loads(l)
     print("%-40s %10.1f img/s %8.2f ms  %7.1f model-TF/s" % (d["metric"], d["value"], d["ms_per_step"], d["model_tflops"]))
 PY
