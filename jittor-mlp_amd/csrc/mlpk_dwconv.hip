@@ -429,11 +429,13 @@ __global__ void __launch_bounds__(NW * 64) dwconv_mfma_kernel(const T* __restric
                         av[(i + 1) & 1][0] = *reinterpret_cast<const u32x4*>(at + (i + 1) * DWM_PITCH);
                         av[(i + 1) & 1][1] = *reinterpret_cast<const u32x4*>(at + (i + 1) * DWM_PITCH + 32);
                     }
-                    acc[0] = Mfma16<T>::run(av[i & 1][0], tf[j][i], acc[0]);
-                    acc[1] = Mfma16<T>::run(av[i & 1][1], tf[j][i], acc[1]);
+                    // operands swapped (taps as A, plane rows as B): the accumulator then holds 4 consecutive x of ONE row per lane
+                    // -- 8 contiguous bytes of the plane -- instead of 4 rows of one column
+                    acc[0] = Mfma16<T>::run(tf[j][i], av[i & 1][0], acc[0]);
+                    acc[1] = Mfma16<T>::run(tf[j][i], av[i & 1][1], acc[1]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                // epilogue: acc[tx][r] = out[y = 16 ty + 4 kq + r][x = 16 tx + n]; results go back into the plane.  (The rows this
+                // epilogue: acc[tx][r] = out[y = 16 ty + n][x = 16 tx + 4 kq + r]; results go back into the plane.  (The rows this
                 // half writes, 16 ty .. 16 ty + 15, are read again by the OTHER half's fragments only through tap rows that
                 // reach across the boundary -- so both halves' MFMAs must be done before any result is written: see below.)
 #pragma unroll
@@ -442,20 +444,25 @@ __global__ void __launch_bounds__(NW * 64) dwconv_mfma_kernel(const T* __restric
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const f32x4 a4 = res[t >> 1][t & 1];
-                float ctr[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int y = 16 * (t >> 1) + 4 * kq + r, xx = 16 * (t & 1) + n;
-                    ctr[r] = to_f32(*reinterpret_cast<const T*>(plane + (y + 4) * DWM_PITCH + (xx + 4) * 2));
-                }
+                const int y = 16 * (t >> 1) + n, x0 = 16 * (t & 1) + 4 * kq;
+                char* const cell = plane + (y + 4) * DWM_PITCH + (x0 + 4) * 2;     // 8-byte aligned: 4 consecutive pixels of row y
+                const u32x2 cw = *reinterpret_cast<const u32x2*>(cell);
+                T c4[4];
+                __builtin_memcpy(c4, &cw, 8);
                 f32x2 v[2] = {f32x2{a4.x + bz[j], a4.y + bz[j]}, f32x2{a4.z + bz[j], a4.w + bz[j]}};
                 gelu_pk_n<2>(v);
                 const float g[4] = {v[0].x, v[0].y, v[1].x, v[1].y};
+                T o4[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int y = 16 * (t >> 1) + 4 * kq + r, xx = 16 * (t & 1) + n;
-                    if (y < H && xx < W)                            // never write outside the map: the halo must stay zero
-                        *reinterpret_cast<T*>(plane + (y + 4) * DWM_PITCH + (xx + 4) * 2) = from_f32<T>(ctr[r] + g[r] * sc[j] + sh[j]);
+                for (int r = 0; r < 4; ++r) o4[r] = from_f32<T>(to_f32(c4[r]) + g[r] * sc[j] + sh[j]);
+                if (y < H && x0 + 3 < W) {                          // never write outside the map: the halo must stay zero
+                    u32x2 ow;
+                    __builtin_memcpy(&ow, o4, 8);
+                    *reinterpret_cast<u32x2*>(cell) = ow;
+                } else if (y < H) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (x0 + r < W) *reinterpret_cast<T*>(cell + 2 * r) = o4[r];
                 }
             }
         }
