@@ -103,20 +103,6 @@ TIMER = None
 GEMM_ALGO = {}                    # tag -> forced tile config (tuning/bench hook); default auto
 
 
-_GEMM_WS = {}
-
-
-def gemm_workspace(device):
-    """Per-device scratch of the persistent GEMM tile (split-K hand-over of a partial last round): torch owns it,
-    zero-filled once; every launch on this process's single stream shares it (launches are stream-ordered)."""
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
-    ws = _GEMM_WS.get(key)
-    if ws is None:
-        ws = torch.zeros((int(N.lib().mlpk_gemm_workspace_bytes()),), dtype=torch.uint8, device=device)
-        _GEMM_WS[key] = ws
-    return ws
-
-
 def gemm(A, B, C, M, Nn, K, *, lda=None, ldb=None, ldc=None, bias=None, act=N.ACT_NONE, cscale=None, cshift=None,
          rscale=None, rperiod=0, R=None, ldr=None, res=N.RES_NONE, out_mode=N.OUT_ROWMAJOR, t_rows=0, t_tokens=0,
          algo=0, tag=None, dbg=0, ln=None, ln_group=1):
@@ -141,8 +127,7 @@ def gemm(A, B, C, M, Nn, K, *, lda=None, ldb=None, ldc=None, bias=None, act=N.AC
     d.rperiod, d.act, d.res_mode, d.out_mode = rperiod, act, res, out_mode
     d.t_rows, d.t_tokens, d.algo = t_rows, t_tokens, algo
     d.reserved = dbg
-    ws = gemm_workspace(A.device)
-    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    d.workspace, d.workspace_bytes = None, 0             # unused since ABI 5 (no kernel needs scratch)
     N.check(N.lib().mlpk_gemm_nt(ctypes.byref(d), stream()), "mlpk_gemm_nt")
     if timed:
         ev1.record()
