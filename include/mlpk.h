@@ -137,9 +137,23 @@ typedef struct mlpk_gemm_desc {
        so results never depend on the batch a row is computed in.  Kept so that descriptors stay layout-compatible. */
     void* workspace;
     int64_t workspace_bytes;
+    /* ABI 6.  By-product row statistics (optional; 16-bit row-major outputs with N % 8 == 0, 16-byte aligned rows of C and R):
+       the statistics pass of the LayerNorm that FOLLOWS this GEMM (vip.py:66,82; g_mlp.py:40; s2_mlp_v2.py:60,78: every one of
+       them reads a tensor a GEMM has just written) comes out of the store epilogue instead of a second pass over C:
+         row_part[(q * row_part_ld + m) * 2 + {0, 1}] = sum / sum of squares, over the q-th block of `width` columns, of the
+         values WRITTEN to C[m, :] (after rounding, after the residual), q < nparts = ceil(N / width)
+       -- planar, one plane of row_part_ld >= M pairs per column block.  width (128, or 32 from the persistent tile) follows from
+       the tile choice: mlpk_gemm_row_parts() answers nparts for a descriptor.  mlpk_stats_finalize_planar turns the pairs into
+       mean / rstd. */
+    float* row_part;
+    int32_t row_part_ld;
+    int32_t reserved2;    /* 0 */
 } mlpk_gemm_desc;
 
 int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream);
+/* pairs per row that mlpk_gemm_nt would write for this descriptor (row_part may still be NULL); an error code when the
+   descriptor cannot deliver statistics (fp32, token-transposed output, unaligned rows, an explicit algo with 64-column tiles) */
+int mlpk_gemm_row_parts(const mlpk_gemm_desc* d, int* nparts);
 /* 0 (no kernel needs scratch) */
 long long mlpk_gemm_workspace_bytes(void);
 /* number of tile configurations (valid algo ids are 1..count) and dynamic LDS bytes of one */
@@ -182,6 +196,11 @@ int mlpk_token_gemm(int dtype, const void* xt, int ldxt, int M, int S, const voi
  * to x[b,s,:].  mlpk_stats_finalize reduces the partials of a row to mean / rstd (count = t_rows). */
 int mlpk_stats_finalize(const float* part, int64_t rows, int nparts, int64_t count, float eps, float* mean, float* rstd,
                         void* stream);
+/* The same for the planar pairs of mlpk_gemm_nt's row_part: statistic r covers rows [r*group, (r+1)*group) of all `nplanes`
+ * planes, pair (q, m) at part[(q*plane_stride + m)*2]; count = elements per statistic (group * N).  group = 1: LayerNorm of the
+ * GEMM's rows; group = H*W: GroupNorm(1,C) per sample on channel-last rows (as_mlp.py:343-344). */
+int mlpk_stats_finalize_planar(const float* part, int64_t rows, int nplanes, int64_t plane_stride, int group, int64_t count, float eps,
+                               float* mean, float* rstd, void* stream);
 /* Tuning hook (tools/tokenmlp_timeline.py), not part of the forward path: when `buf` is non-NULL, later mlpk_token_mlp
  * launches log per-workgroup s_memtime stamps into it (64 x uint64 per workgroup); NULL switches the logging off.
  * The only library-held state, and off by default. */

@@ -25,7 +25,8 @@ class GemmDesc(ctypes.Structure):
                 ("rperiod", ctypes.c_int32), ("act", ctypes.c_int32), ("res_mode", ctypes.c_int32),
                 ("out_mode", ctypes.c_int32), ("t_rows", ctypes.c_int32), ("t_tokens", ctypes.c_int32),
                 ("algo", ctypes.c_int32), ("ln_group", ctypes.c_int32), ("reserved", ctypes.c_int32),
-                ("workspace", c_void_p), ("workspace_bytes", ctypes.c_int64)]
+                ("workspace", c_void_p), ("workspace_bytes", ctypes.c_int64),
+                ("row_part", c_void_p), ("row_part_ld", ctypes.c_int32), ("reserved2", ctypes.c_int32)]
 
 
 class NormDesc(ctypes.Structure):
@@ -43,6 +44,7 @@ PROTOTYPES = {
     "mlpk_abi_version": (c_int, []),
     "mlpk_strerror": (ctypes.c_char_p, [c_int]),
     "mlpk_gemm_nt": (c_int, [ctypes.POINTER(GemmDesc), c_void_p]),
+    "mlpk_gemm_row_parts": (c_int, [ctypes.POINTER(GemmDesc), ctypes.POINTER(c_int)]),
     "mlpk_gemm_workspace_bytes": (ctypes.c_longlong, []),
     "mlpk_gemm_algo_count": (c_int, []),
     "mlpk_gemm_algo_info": (c_int, [c_int] + [ctypes.POINTER(c_int)] * 4),
@@ -54,6 +56,7 @@ PROTOTYPES = {
                                 c_void_p, c_int, c_int, c_void_p]),
     "mlpk_layernorm_transpose": (c_int, [c_int, c_void_p, c_i64, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p]),
     "mlpk_stats_finalize": (c_int, [c_void_p, c_i64, c_int, c_i64, c_float, c_void_p, c_void_p, c_void_p]),
+    "mlpk_stats_finalize_planar": (c_int, [c_void_p, c_i64, c_int, c_i64, c_int, c_i64, c_float, c_void_p, c_void_p, c_void_p]),
     "mlpk_token_mlp_debug": (None, [c_void_p]),
     "mlpk_patchify": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "mlpk_row_stats": (c_int, [c_int, c_void_p, c_i64, c_i64, c_i64, c_float, c_void_p, c_void_p, c_void_p]),
@@ -99,7 +102,7 @@ def lib():
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(handle, name)          # AttributeError if a declared symbol is not exported
             fn.restype, fn.argtypes = res, args
-        if handle.mlpk_abi_version() != 5:
+        if handle.mlpk_abi_version() != 6:
             raise MlpkError("libmlpk.so ABI version mismatch")
         _lib = handle
     return _lib

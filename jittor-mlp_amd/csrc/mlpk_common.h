@@ -126,6 +126,30 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// (sum, sum of squares) of the eight 16-bit values of one 16-byte chunk, accumulated in fp32 by the packed dot products
+// (v_dot2c_f32_bf16 / v_dot2c_f32_f16: two products + the accumulator per instruction, 8 instructions per chunk where
+// convert + add + fma take 24)
+template <typename T> __device__ __forceinline__ void chunk_sums(const u32x4 v, float& s1, float& s2) {
+    static_assert(sizeof(T) == 2, "16-bit storage types");
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if constexpr (dtype_of<T>::value == MLPK_BF16) {
+            typedef __attribute__((ext_vector_type(2))) __bf16 pair_t;
+            const pair_t a = __builtin_bit_cast(pair_t, w[k]);
+            const pair_t one = {(__bf16)1.0f, (__bf16)1.0f};
+            s1 = __builtin_amdgcn_fdot2_f32_bf16(a, one, s1, false);
+            s2 = __builtin_amdgcn_fdot2_f32_bf16(a, a, s2, false);
+        } else {
+            typedef __attribute__((ext_vector_type(2))) _Float16 pair_t;
+            const pair_t a = __builtin_bit_cast(pair_t, w[k]);
+            const pair_t one = {(_Float16)1.0f, (_Float16)1.0f};
+            s1 = __builtin_amdgcn_fdot2(a, one, s1, false);
+            s2 = __builtin_amdgcn_fdot2(a, a, s2, false);
+        }
+    }
+}
+
 // Bijective XCD-aware block remap (8 XCDs, block b runs on XCD b % 8): gives every XCD a
 // contiguous range of logical tile ids so that neighbouring tiles share operand panels in
 // that XCD's private L2.

@@ -46,6 +46,13 @@ struct GemmArgs {
     void* prof_buf;     // MLPK_P8_PROF builds: per-workgroup cycle sums (reserved & 8)
     int dbg_delay;      // de-phase sleep, units of 8128 cycles
     int dbg;            // tuning ablations (desc.reserved): 1 = no main loop, 2 = no stores, 4 = no epilogue
+    // by-product row statistics of the stored values (16-bit row-major outputs): pair (q, m) = (sum, sum of squares) of row m over
+    // column block q; block width 128 (LDS-staged epilogue) or 32 (direct epilogue of the persistent tile).  PLANAR, one plane per
+    // column block: a tile's pairs are one contiguous run (256 rows x 8 bytes), written as whole cache lines -- interleaved per
+    // row ([m][q]) every pair was a lone 8-byte masked write next to pairs other workgroups write later (measured +27 us on a
+    // 130 us GEMM)
+    float* row_part;
+    int row_part_ld;    // plane stride in pairs (>= M)
 };
 
 // tuning aid (dbg & 8): wave 0 / lane 0 of each workgroup logs s_memtime stamps into the buffer passed in R
@@ -276,17 +283,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
         if (gelu) phase1(BoolK<true>{});
         else phase1(BoolK<false>{});
         __syncthreads();
-        if (fast) {
+        // STATS = true (GemmArgs::row_part; the host has checked what `fast` checks, except that a lane's chunk may lie past N):
+        // EVERY lane runs the passes, with its loads and stores predicated, because the DPP row reduction of the statistics
+        // must not read lanes that a branch has switched off (a DPP read of an EXEC-disabled lane does not return 0)
+        auto passes = [&](auto stats_c) {
+            constexpr bool STATS = decltype(stats_c)::value;
+            const bool live = !STATS || fast;
             // residual chunks of the remaining groups go in flight first, then each pass is LDS read ->
             // combine -> one 16-byte store; rows past M are skipped.
             u32x4 rr[NP];
 #pragma unroll
-            for (int q = 0; q < PB0; ++q) rr[q] = rr0[q];
+            for (int q = 0; q < PB0; ++q) rr[q] = (STATS && !(fast && has_res)) ? u32x4{0u, 0u, 0u, 0u} : rr0[q];
             if (has_res) {
 #pragma unroll
                 for (int q = PB0; q < NP; ++q) {
                     const int gm = m0 + q * RPASS + rsub;
-                    rr[q] = gm < p.M ? *reinterpret_cast<const u32x4*>(R + (size_t)gm * p.ldr + gn) : u32x4{0u, 0u, 0u, 0u};
+                    rr[q] = (gm < p.M && live) ? *reinterpret_cast<const u32x4*>(R + (size_t)gm * p.ldr + gn) : u32x4{0u, 0u, 0u, 0u};
                 }
             }
 #pragma unroll
@@ -307,9 +319,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
                     }
                     __builtin_memcpy(&outv, a8, 16);
                 }
-                if (gm < p.M && (!(p.dbg & 2) || outv.x == 0x12345678u))
+                if (gm < p.M && live && (!(p.dbg & 2) || outv.x == 0x12345678u))
                     *reinterpret_cast<u32x4*>(C + (size_t)gm * p.ldc + gn) = outv;
+                if constexpr (STATS && CPR >= 16) {
+                    // by-product statistics of the row's 128 columns that sit in these 16 lanes (one DPP row)
+                    float s1 = 0.f, s2 = 0.f;
+                    chunk_sums<T>(outv, s1, s2);
+                    s1 = row16_sum(live ? s1 : 0.f);
+                    s2 = row16_sum(live ? s2 : 0.f);
+                    if ((c16 & 15) == 0 && gm < p.M && live)
+                        *reinterpret_cast<f32x2*>(p.row_part + ((size_t)(gn >> 7) * p.row_part_ld + gm) * 2) = f32x2{s1, s2};
+                }
             }
+        };
+        if (p.row_part) {
+            passes(BoolK<true>{});
+        } else if (fast) {
+            passes(BoolK<false>{});
         } else if (gn < p.N) {
             for (int rp = 0; rp < NP; ++rp) {
                 const int rl = rp * RPASS + rsub;
@@ -1040,7 +1066,7 @@ __device__ __forceinline__ void p8_par_prefetch(const GemmArgs& p, const int m0,
     }
 }
 
-template <typename T, bool GELU, bool LN, bool AFF, bool RES, int NI>
+template <typename T, bool GELU, bool LN, bool AFF, bool RES, int NI, bool STATS = false>
 __device__ __forceinline__ void p8_store_direct(const GemmArgs& p, f32x4 (&acc)[2 * NI][4], const char* par_lds, const int m0, const int n0,
                                                 const int tid) {
     const int lane = tid & 63;
@@ -1144,6 +1170,24 @@ __device__ __forceinline__ void p8_store_direct(const GemmArgs& p, f32x4 (&acc)[
                 }
                 if (!(p.dbg & 2) || outv.x == 0x12345678u)
                     *reinterpret_cast<u32x4*>(C + grow * p.ldc + n0 + hn * 128 + wn * 32 + ccol) = outv;
+                if constexpr (STATS) {
+                    // by-product statistics of the stored values: this wave's 32 columns of row `grow` sit in the four lanes
+                    // frow, frow + 16, + 32, + 48; two swaps fold them (x + x of the neighbouring lane row, then of the other half)
+                    float s1 = 0.f, s2 = 0.f;
+                    chunk_sums<T>(outv, s1, s2);
+                    float sv[2] = {s1, s2};
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const unsigned u = __builtin_bit_cast(unsigned, sv[k]);
+                        const auto q = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+                        const float h = __builtin_bit_cast(float, (unsigned)q[0]) + __builtin_bit_cast(float, (unsigned)q[1]);
+                        const unsigned uh = __builtin_bit_cast(unsigned, h);
+                        const auto r = __builtin_amdgcn_permlane32_swap(uh, uh, false, false);
+                        sv[k] = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+                    }
+                    if (fg == 0)
+                        *reinterpret_cast<f32x2*>(p.row_part + ((size_t)((n0 + hn * 128 + wn * 32) >> 5) * p.row_part_ld + grow) * 2) = f32x2{sv[0], sv[1]};
+                }
             }
         }
     }
@@ -1159,7 +1203,7 @@ __device__ __forceinline__ void p8_store_direct(const GemmArgs& p, f32x4 (&acc)[
 //        tile per CU (p8_plan): Mixer-B fc2 = 588 tiles of 256 rows = 2.3 -> 3 rounds becomes 1 round of 256-row + 2 rounds of
 //        192-row tiles (2.5 tile times), with the K order of every output element -- hence every result bit -- unchanged.
 //   EPI  epilogue: 1 = direct (registers -> global, p8_store_direct), 0 = staged through LDS (p8_store_tile, NI = 4 only;
-//        kept for A/B runs via reserved & 64).
+//        kept for A/B runs via reserved & 64), 2 = direct, bias + residual, with the by-product row statistics (GemmArgs::row_part).
 // The kernel takes WHOLE tiles only (the host guarantees M % 64 == 0 with the panel heights adding up to M exactly,
 // N % 256 == 0, K a multiple of the slab, 16-byte aligned rows and parameter vectors, no per-row scale): nothing is clamped
 // or predicated, and the per-lane source offset of an LDS-DMA piece is ONE register per operand for the whole launch (lane ->
@@ -1173,7 +1217,7 @@ __device__ __forceinline__ void p8_store_direct(const GemmArgs& p, f32x4 (&acc)[
 // queue every slab; tools/isa_lint.py (run by tests/test_host_cpu.py) checks the generated loop for exactly that.
 template <typename T, int EPI, int NI>
 __global__ void __launch_bounds__(512, 1) gemm_nt_p8_kernel(const GemmArgs p) {
-    static_assert(NI >= 1 && NI <= 4 && (EPI == 1 || NI == 4), "tile height / epilogue combination");
+    static_assert(NI >= 1 && NI <= 4 && (EPI >= 1 || NI == 4), "tile height / epilogue combination");
     static_assert(sizeof(T) == 2, "16-bit operands");
     constexpr int BM = NI * 64, BN = 256;
     constexpr int EPC = 8;                                 // elements per 16-byte chunk
@@ -1272,7 +1316,7 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_p8_kernel(const GemmArgs p) {
     // ---- first tile: slab 0 complete before the loop, three half-tiles of slab 1 in flight ----
     setup(l);
     int par_sel = 0;                                        // parameter buffer of the CURRENT tile
-    if constexpr (EPI == 1) p8_par_prefetch<BM>(p, m0, n0, wave, lane, lds_par);
+    if constexpr (EPI >= 1) p8_par_prefetch<BM>(p, m0, n0, wave, lane, lds_par);
     stage(0, 2); stage(0, 0); stage(0, 3); stage(0, 1);
     stage(1, 2); stage(1, 0); stage(1, 3);
 
@@ -1372,11 +1416,15 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_p8_kernel(const GemmArgs p) {
         if (more) {
             setup(l);
             par_sel ^= 1;
-            if constexpr (EPI == 1) p8_par_prefetch<BM>(p, m0, n0, wave, etid & 63, lds_par + (unsigned)(par_sel * 4096));
+            if constexpr (EPI >= 1) p8_par_prefetch<BM>(p, m0, n0, wave, etid & 63, lds_par + (unsigned)(par_sel * 4096));
             stage(0, 2); stage(0, 0); stage(0, 3); stage(0, 1);
         }
         const int cls = (p.act == MLPK_ACT_GELU ? 1 : 0) | (p.ln_mean ? 2 : 0) | ((p.cscale || p.cshift) ? 4 : 0);
-        if constexpr (EPI == 1) {
+        if constexpr (EPI == 2) {
+            // bias + residual with the by-product row statistics (its own kernel: the register allocation of the other classes
+            // stays what it was tuned to be)
+            p8_store_direct<T, false, false, false, true, NI, true>(p, acc, par, cm0, cn0, etid);
+        } else if constexpr (EPI == 1) {
             // (the host sends residual + GELU / residual + LayerNorm combinations to the staged kernel)
             if (p.res_mode != MLPK_RES_NONE) {
                 if (cls & 4) p8_store_direct<T, false, false, true, true, NI>(p, acc, par, cm0, cn0, etid);
@@ -1626,6 +1674,10 @@ template <typename T> static int launch_p8(const GemmArgs& a0, bool trans, hipSt
         hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, stream, a);                                                   \
     }
             if (staged) P8_LAUNCH(0, 4)
+            else if (a.row_part && ni == 4) P8_LAUNCH(2, 4)
+            else if (a.row_part && ni == 3) P8_LAUNCH(2, 3)
+            else if (a.row_part && ni == 2) P8_LAUNCH(2, 2)
+            else if (a.row_part) P8_LAUNCH(2, 1)
             else if (ni == 4) P8_LAUNCH(1, 4)
             else if (ni == 3) P8_LAUNCH(1, 3)
             else if (ni == 2) P8_LAUNCH(1, 2)
@@ -1661,12 +1713,13 @@ template <typename T> static int launch_algo(int algo, const GemmArgs& a, bool t
 // do not fill the CUs many times over).  Efficiencies follow the MI355X sweeps in profiles/: with K a
 // multiple of 32 elements the 2-workgroup-per-CU "s3" tiles win on every shape of the path (their
 // epilogue overlaps the other workgroup's main loop); ragged K falls back to the register-staged tiles.
-static int auto_algo(int M, int N, int K, int epc, bool glds_ok, bool p8_ok) {
+static int auto_algo(int M, int N, int K, int epc, bool glds_ok, bool p8_ok, bool stats = false) {
     double best = 1e300;
     int best_algo = 4;
     for (int i = 0; i < kNumTiles; ++i) {
         const TileCfg& t = kTiles[i];
         const int area = t.bm * t.bn;
+        if (stats && t.bn < 128) continue;        // the by-product row statistics reduce over whole 16-lane rows = 128 columns
         if (t.glds == 3) {
             // persistent ping-pong tile: whole launch rounds of one tile per CU, tile heights mixed to fill them (p8_plan);
             // its per-tile fixed cost (first slabs + epilogue, not overlapped with another workgroup) weighs more the
@@ -1728,7 +1781,8 @@ extern "C" long long mlpk_gemm_workspace_bytes(void) {
     return 0;
 }
 
-extern "C" int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream) {
+// validation + tile choice shared by mlpk_gemm_nt and mlpk_gemm_row_parts
+static int gemm_prepare(const mlpk_gemm_desc* d, GemmArgs& a, int& algo, bool& trans) {
     if (!d) return MLPK_ENULL;
     if (!d->A || !d->B || !d->C) return MLPK_ENULL;
     if (d->dtype != MLPK_F32 && d->dtype != MLPK_F16 && d->dtype != MLPK_BF16) return MLPK_EDTYPE;
@@ -1743,7 +1797,7 @@ extern "C" int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream) {
     if (d->res_mode != MLPK_RES_NONE && !d->R) return MLPK_ENULL;
     if (d->out_mode != MLPK_OUT_ROWMAJOR && d->out_mode != MLPK_OUT_TOKEN_T) return MLPK_EMODE;
     if (d->rscale && d->rperiod <= 0) return MLPK_ESHAPE;
-    const bool trans = d->out_mode == MLPK_OUT_TOKEN_T;
+    trans = d->out_mode == MLPK_OUT_TOKEN_T;
     if ((d->ln_mean != nullptr) != (d->ln_rstd != nullptr) || (d->ln_mean != nullptr) != (d->ln_csum != nullptr)) return MLPK_ENULL;
     if (d->ln_mean && trans) return MLPK_EMODE;     // the fold is per GEMM row; token-transposed GEMMs normalise along K
     if (trans) {
@@ -1752,7 +1806,6 @@ extern "C" int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream) {
     } else if (d->ldc < d->N) {
         return MLPK_ESHAPE;
     }
-    GemmArgs a;
     a.A = d->A; a.B = d->B; a.C = d->C; a.R = d->R;
     a.bias = d->bias; a.cscale = d->cscale; a.cshift = d->cshift; a.rscale = d->rscale;
     a.ln_mean = d->ln_mean; a.ln_rstd = d->ln_rstd; a.ln_csum = d->ln_csum;
@@ -1765,19 +1818,59 @@ extern "C" int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream) {
     a.dbg = d->reserved & 0xff;
     a.dbg_delay = (d->reserved >> 8) & 0xff;
     a.m_base = 0; a.panels = 0; a.cgroups = 1; a.prof_buf = d->workspace;
+    a.row_part = d->row_part; a.row_part_ld = d->row_part_ld;
     const int vb = 4 * es;   // bytes of a 4-element vector
     a.vec_c = (d->ldc % 4 == 0) && (((uintptr_t)d->C % vb) == 0);
     a.vec_r = d->R ? ((d->ldr % 4 == 0) && (((uintptr_t)d->R % vb) == 0)) : 0;
     if (a.vec_c && d->ldc % 8 == 0 && ((uintptr_t)d->C % 16) == 0) a.vec_c = 2;     // 8-element (16-byte) vectors
     if (a.vec_r && d->ldr % 8 == 0 && ((uintptr_t)d->R % 16) == 0) a.vec_r = 2;
-    int algo = d->algo;
+    const bool stats = d->row_part != nullptr;
+    if (stats) {
+        // by-product statistics come out of the 16-byte-chunk store passes of the 16-bit row-major epilogues only
+        if (es != 2 || trans) return MLPK_EMODE;
+        if (d->N % 8 || a.vec_c != 2 || (d->res_mode != MLPK_RES_NONE && a.vec_r != 2)) return MLPK_ESHAPE;
+        if ((uintptr_t)d->row_part & 7) return MLPK_EALIGN;
+    }
+    algo = d->algo;
     const bool glds_ok = d->K % (4 * epc) == 0;      // K a multiple of half a 128-byte slab
     // the persistent tile is auto-selected where its overlapped epilogue applies (16-bit row-major, no row scale)
     static const bool no_p8 = getenv("MLPK_GEMM_NO_P8") != nullptr;      // tuning hook: A/B the tile choice in one run
-    const bool p8_ok = !no_p8 && p8_eligible(a, es, trans);
-    if (algo == 0) algo = auto_algo(d->M, d->N, d->K, epc, glds_ok, p8_ok);
+    bool p8_ok = !no_p8 && p8_eligible(a, es, trans);
+    // ... and with statistics, where the direct epilogue instantiates them: bias + residual (the GEMMs that produce a residual stream)
+    const bool p8_stats_ok = d->res_mode != MLPK_RES_NONE && d->act == MLPK_ACT_NONE && !d->ln_mean && !d->cscale && !d->cshift && !(a.dbg & 64);
+    if (stats && !p8_stats_ok) p8_ok = false;
+    if (algo == 0) algo = auto_algo(d->M, d->N, d->K, epc, glds_ok, p8_ok, stats);
     if (algo < 1 || algo > kNumTiles) return MLPK_EMODE;
     if (kTiles[algo - 1].glds && !glds_ok) return MLPK_ESHAPE;
+    if (stats) {
+        if (kTiles[algo - 1].bn < 128 || (kTiles[algo - 1].glds == 3 && !p8_stats_ok)) return MLPK_EMODE;
+        if (d->row_part_ld < d->M) return MLPK_ESHAPE;
+    }
+    return 0;
+}
+
+extern "C" int mlpk_gemm_row_parts(const mlpk_gemm_desc* d, int* nparts) {
+    if (!d || !nparts) return MLPK_ENULL;
+    mlpk_gemm_desc q = *d;
+    alignas(8) float dummy_pair[2];
+    if (!q.row_part) q.row_part = dummy_pair;     // a question about the tile choice, nothing is written
+    q.row_part_ld = 0x7fffffff;
+    GemmArgs a;
+    int algo = 0;
+    bool trans = false;
+    const int rc = gemm_prepare(&q, a, algo, trans);
+    if (rc) return rc;
+    const int width = kTiles[algo - 1].glds == 3 ? 32 : 128;
+    *nparts = (d->N + width - 1) / width;
+    return 0;
+}
+
+extern "C" int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream) {
+    GemmArgs a;
+    int algo = 0;
+    bool trans = false;
+    const int rc = gemm_prepare(d, a, algo, trans);
+    if (rc) return rc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (d->dtype) {
         case MLPK_F32: return launch_algo<float>(algo, a, trans, s, d->workspace, d->workspace_bytes);

@@ -795,6 +795,59 @@ __global__ void __launch_bounds__(256) stats_finalize_kernel(const float* __rest
     rstd[r] = 1.0f / __builtin_sqrtf(var + eps);
 }
 
+// planar pairs of a GEMM's by-product statistics (mlpk.h row_part): pair (q, m) at part[(q * plane_stride + m) * 2].
+// group = 1: one thread per row, the planes read coalesced.
+__global__ void __launch_bounds__(256) stats_finalize_planar_kernel(const float* __restrict__ part, int64_t rows, int nplanes, int64_t plane_stride,
+                                                                    float inv_count, float eps, float* __restrict__ mean, float* __restrict__ rstd) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const f32x2* pp = reinterpret_cast<const f32x2*>(part) + r;
+    float s1 = 0.f, s2 = 0.f;
+    for (int q = 0; q < nplanes; ++q) {
+        const f32x2 v = pp[(int64_t)q * plane_stride];
+        s1 += v.x;
+        s2 += v.y;
+    }
+    const float mu = s1 * inv_count;
+    float var = s2 * inv_count - mu * mu;
+    var = var > 0.f ? var : 0.f;
+    mean[r] = mu;
+    rstd[r] = 1.0f / __builtin_sqrtf(var + eps);
+}
+
+// group > 1 (per-sample GroupNorm(1,C) statistics from per-pixel-row pairs): one workgroup per statistic, fp64 for the combine
+// (the pairs are sums of <= 128 values each; what is left to lose is the E[x^2] - mean^2 cancellation of a whole sample)
+__global__ void __launch_bounds__(256) stats_finalize_group_kernel(const float* __restrict__ part, int nplanes, int64_t plane_stride, int group,
+                                                                   double inv_count, float eps, float* __restrict__ mean, float* __restrict__ rstd) {
+    __shared__ double red[2][4];
+    const int64_t r = blockIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int q = 0; q < nplanes; ++q) {
+        const f32x2* pp = reinterpret_cast<const f32x2*>(part) + (int64_t)q * plane_stride + r * group;
+        for (int i = threadIdx.x; i < group; i += 256) {
+            const f32x2 v = pp[i];
+            s1 += (double)v.x;
+            s2 += (double)v.y;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        s2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        const double mu = s1 * inv_count;
+        double var = s2 * inv_count - mu * mu;
+        var = var > 0.0 ? var : 0.0;
+        mean[r] = (float)mu;
+        rstd[r] = 1.0f / __builtin_sqrtf((float)var + eps);
+    }
+}
+
 static inline int esize(int dt) { return dt == MLPK_F32 ? 4 : 2; }
 
 extern "C" int mlpk_row_stats(int dtype, const void* x, int64_t rows, int64_t len, int64_t ldx, float eps,
@@ -827,6 +880,23 @@ extern "C" int mlpk_stats_finalize(const float* part, int64_t rows, int nparts, 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, part, rows, nparts, 1.0f / (float)count, eps,
                        mean, rstd);
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mlpk_stats_finalize_planar(const float* part, int64_t rows, int nplanes, int64_t plane_stride, int group, int64_t count, float eps,
+                                          float* mean, float* rstd, void* stream) {
+    if (!part || !mean || !rstd) return MLPK_ENULL;
+    if (rows <= 0 || nplanes <= 0 || group <= 0 || count <= 0 || plane_stride < rows * group) return MLPK_ESHAPE;
+    if ((uintptr_t)part & 7) return MLPK_EALIGN;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (group == 1) {
+        hipLaunchKernelGGL(stats_finalize_planar_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, part, rows, nplanes, plane_stride,
+                           1.0f / (float)count, eps, mean, rstd);
+    } else {
+        hipLaunchKernelGGL(stats_finalize_group_kernel, dim3((unsigned)rows), dim3(256), 0, s, part, nplanes, plane_stride, group,
+                           1.0 / (double)count, eps, mean, rstd);
+    }
     MLPK_LAUNCH_CHECK();
     return 0;
 }
@@ -998,7 +1068,7 @@ extern "C" int mlpk_convert(int src_dtype, int dst_dtype, const void* src, void*
     }
 }
 
-extern "C" int mlpk_abi_version(void) { return 5; }
+extern "C" int mlpk_abi_version(void) { return 6; }
 
 extern "C" const char* mlpk_strerror(int code) {
     switch (code) {

@@ -105,7 +105,10 @@ GEMM_ALGO = {}                    # tag -> forced tile config (tuning/bench hook
 
 def gemm(A, B, C, M, Nn, K, *, lda=None, ldb=None, ldc=None, bias=None, act=N.ACT_NONE, cscale=None, cshift=None,
          rscale=None, rperiod=0, R=None, ldr=None, res=N.RES_NONE, out_mode=N.OUT_ROWMAJOR, t_rows=0, t_tokens=0,
-         algo=0, tag=None, dbg=0, ln=None, ln_group=1):
+         algo=0, tag=None, dbg=0, ln=None, ln_group=1, part=None):
+    """C = epilogue(A . B^T).  `part` = (workspace, name): the epilogue also delivers the row statistics of what it stores
+    (mlpk.h: row_part) into a float32 buffer (nparts, M, 2) taken from the workspace; returns (buffer, nparts) for
+    stats_finalize_planar, or None when the descriptor cannot deliver them (fp32, unaligned rows) and the caller runs row_stats."""
     if tag is not None and algo == 0:
         algo = GEMM_ALGO.get(tag, 0)
     timed = TIMER is not None and tag is not None
@@ -128,10 +131,18 @@ def gemm(A, B, C, M, Nn, K, *, lda=None, ldb=None, ldc=None, bias=None, act=N.AC
     d.t_rows, d.t_tokens, d.algo = t_rows, t_tokens, algo
     d.reserved = dbg
     d.workspace, d.workspace_bytes = None, 0             # unused since ABI 5 (no kernel needs scratch)
+    out = None
+    if part is not None and epilogue_stats():
+        n = ctypes.c_int(0)
+        if N.lib().mlpk_gemm_row_parts(ctypes.byref(d), ctypes.byref(n)) == 0:
+            buf = part[0].get("%s.%d" % (part[1], n.value), (n.value, M, 2), torch.float32)     # (one buffer per plane count: no re-allocation)
+            d.row_part, d.row_part_ld = ptr(buf), M
+            out = (buf, n.value)
     N.check(N.lib().mlpk_gemm_nt(ctypes.byref(d), stream()), "mlpk_gemm_nt")
     if timed:
         ev1.record()
         TIMER.events.setdefault(tag, []).append((ev0, ev1, 2.0 * M * Nn * K))
+    return out
 
 
 CHANNEL_CHUNKS = int(os.environ.get("MLPK_CHANNEL_CHUNKS", "0"))      # 0 = by size (below); tuning override
@@ -177,6 +188,12 @@ def epilogue_stats():
 
 def stats_finalize(part, rows, nparts, count, mean, rstd, eps=1e-5):
     N.check(N.lib().mlpk_stats_finalize(ptr(part), rows, nparts, count, eps, ptr(mean), ptr(rstd), stream()), "mlpk_stats_finalize")
+
+
+def stats_finalize_planar(part, rows, count, mean, rstd, eps=1e-5, group=1):
+    """part = the (nplanes, M, 2) buffer engine.gemm(part=...) returned; statistic r covers GEMM rows [r*group, (r+1)*group)."""
+    N.check(N.lib().mlpk_stats_finalize_planar(ptr(part), rows, part.shape[0], part.shape[1], group, count, eps, ptr(mean), ptr(rstd), stream()),
+            "mlpk_stats_finalize_planar")
 
 
 def token_mlp_supported(dtype, S, sp, hidden=0):

@@ -47,10 +47,25 @@ def layernorm_stats(ws, x, rows, C, tag="ln", eps=1e-5):
     return mean, rstd
 
 
-def channel_mlp(ws, x, rows, C, pk, prefix, hidden, *, norm=True, cscale2=None, res_src=None, tag="cm", eps=1e-5, stats=None):
+def finalize_stats(ws, got, rows, count, tag="ln", eps=1e-5, group=1):
+    """(mean, rstd) of the LayerNorm (group = 1) or per-sample GroupNorm(1,C) (group = H*W rows per sample) that follows a GEMM,
+    from the by-product partials its epilogue delivered (`got` = what engine.gemm(part=...) returned); None stays None and the
+    caller runs the statistics pass."""
+    if got is None:
+        return None
+    part, n = got
+    mean = ws.get(tag + ".mean", (rows // group,), torch.float32)
+    rstd = ws.get(tag + ".rstd", (rows // group,), torch.float32)
+    E.stats_finalize_planar(part, rows // group, count * group, mean, rstd, eps=eps, group=group)
+    return mean, rstd
+
+
+def channel_mlp(ws, x, rows, C, pk, prefix, hidden, *, norm=True, cscale2=None, res_src=None, tag="cm", eps=1e-5, stats=None, part=None):
     """x <- x + fc2(gelu(fc1(LN(x))))   (mlp_mixer.py:38; vip.py:82-88; s2_mlp_v2.py:78-84).
     LN -> row-major normalised copy; fc1 epilogue = bias + exact GELU; fc2 epilogue = bias + residual.
-    `stats` = (mean, rstd) of x's rows when the producer of x already delivered them (token_mlp's epilogue)."""
+    `stats` = (mean, rstd) of x's rows when the producer of x already delivered them (token_mlp's epilogue, a GEMM's row_part).
+    `part` = (workspace, name): fc2's epilogue delivers the row statistics of the new x for the LayerNorm that follows; the
+    return value is then what finalize_stats takes (None when they could not be delivered) instead of x."""
     ln = None
     if norm and (prefix + "fc1.csum") in pk:
         # LayerNorm folded into fc1 (gamma in the weights, beta in the bias, mean/rstd applied on the
@@ -76,9 +91,9 @@ def channel_mlp(ws, x, rows, C, pk, prefix, hidden, *, norm=True, cscale2=None, 
         sl = slice(r0, r0 + step)
         lnc = None if ln is None else (ln[0][sl], ln[1][sl], ln[2])
         E.gemm(xn[sl], pk[prefix + "fc1.w"], h[sl], step, hidden, C, bias=pk[prefix + "fc1.b"], act=N.ACT_GELU, ln=lnc, tag="channel_fc1")
-        E.gemm(h[sl], pk[prefix + "fc2.w"], x[sl], step, C, hidden, bias=pk[prefix + "fc2.b"], cscale=cscale2,
-               R=res[sl], res=N.RES_ADD, tag="channel_fc2")
-    return x
+        got = E.gemm(h[sl], pk[prefix + "fc2.w"], x[sl], step, C, hidden, bias=pk[prefix + "fc2.b"], cscale=cscale2,
+                     R=res[sl], res=N.RES_ADD, tag="channel_fc2", part=part if nchunk == 1 else None)
+    return got if part is not None else x
 
 
 def head_linear(ws, pooled, B, C, w, b, num_classes, out_dtype):

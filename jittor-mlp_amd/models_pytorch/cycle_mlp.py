@@ -25,7 +25,7 @@ from torch.nn import init
 
 from .. import _native as N
 from .. import engine as E
-from .common import Holder, channel_mlp, head_linear, layernorm_stats, pack_channel_mlp
+from .common import Holder, channel_mlp, finalize_stats, head_linear, layernorm_stats, pack_channel_mlp
 from .utils import pair
 
 
@@ -239,9 +239,11 @@ class CycleNet(E.EngineModule):
         return pk
 
     # ------------------------------------------------------------------ forward
-    def _block(self, ws, pk, p, cur, B, H, W, C, hidden, tag):
+    def _block(self, ws, pk, p, cur, B, H, W, C, hidden, tag, stats=None):
+        """One CycleBlock in place.  `stats` = (mean, rstd) of cur's rows when the GEMM that wrote cur delivered them; returns the
+        statistics of the result the same way (or None): both LayerNorms read what a GEMM has just written (mlpk.h row_part)."""
         rows = B * H * W
-        mean, rstd = layernorm_stats(ws, cur, rows, C, tag=tag + ".ln")
+        mean, rstd = stats if stats is not None else layernorm_stats(ws, cur, rows, C, tag=tag + ".ln")
         xn = ws.get(tag + ".xn", (rows, C))
         E.norm_apply(cur, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "ln.g"], beta=pk[p + "ln.b"], out_rm=xn, ld_rm=C)
         sh, sw = ws.get(tag + ".sh", (rows, C)), ws.get(tag + ".sw", (rows, C))
@@ -263,8 +265,10 @@ class CycleNet(E.EngineModule):
         E.split_softmax(hat, bar, B, C)
         m = ws.get(tag + ".m", (rows, C))
         E.split_apply(th, tw, tc, C, C, C, B, H, W, C, N.SHIFT_NONE, bar, m, C)
-        E.gemm(m, pk[p + "p.w"], cur, rows, C, C, bias=pk[p + "p.b"], R=cur, res=N.RES_ADD, tag="cycle_proj")
-        channel_mlp(ws, cur, rows, C, pk, p + "ff.", hidden, tag=tag + ".cm")
+        got = E.gemm(m, pk[p + "p.w"], cur, rows, C, C, bias=pk[p + "p.b"], R=cur, res=N.RES_ADD, tag="cycle_proj", part=(ws, tag + ".p.part"))
+        got = channel_mlp(ws, cur, rows, C, pk, p + "ff.", hidden, tag=tag + ".cm", stats=finalize_stats(ws, got, rows, C, tag=tag + ".cm.ln"),
+                          part=(ws, tag + ".fc2.part"))
+        return finalize_stats(ws, got, rows, C, tag=tag + ".ln")
 
     def forward(self, x):
         cd = self._resolve(x)
@@ -278,7 +282,8 @@ class CycleNet(E.EngineModule):
         patches = ws.get("embed.patches", (B * H * W, kp))
         E.im2col(x, patches, B, cin, H_in, W_in, 7, 7, 4, 4, 2, kp)
         cur = ws.get("n0.x", (B * H * W, C))
-        E.gemm(patches, pk["embed.w"], cur, B * H * W, C, kp, bias=pk["embed.b"])
+        got = E.gemm(patches, pk["embed.w"], cur, B * H * W, C, kp, bias=pk["embed.b"], part=(ws, "embed.part"))
+        st = finalize_stats(ws, got, B * H * W, C, tag="n0.ln")
         for si, stage in enumerate(self.network):
             if isinstance(stage, Downsample):
                 Cout = pk["n%d.w" % si].shape[0]
@@ -287,12 +292,13 @@ class CycleNet(E.EngineModule):
                 cols = ws.get("n%d.cols" % si, (B * H2 * W2, kp))
                 E.im2col(cur, cols, B, C, H, W, 3, 3, 2, 2, 1, kp, layout=N.LAYOUT_NHWC, px_stride=C)
                 nxt = ws.get("n%d.x" % (si + 1), (B * H2 * W2, Cout))
-                E.gemm(cols, pk["n%d.w" % si], nxt, B * H2 * W2, Cout, kp, bias=pk["n%d.b" % si], tag="cycle_down")
+                got = E.gemm(cols, pk["n%d.w" % si], nxt, B * H2 * W2, Cout, kp, bias=pk["n%d.b" % si], tag="cycle_down", part=(ws, "n%d.down.part" % si))
+                st = finalize_stats(ws, got, B * H2 * W2, Cout, tag="n%d.ln" % (si + 1))
                 cur, H, W, C = nxt, H2, W2, Cout
                 continue
             for bi, blk in enumerate(stage):
-                self._block(ws, pk, "n%d.b%d." % (si, bi), cur, B, H, W, C, blk.mlp.fc1.weight.shape[0], "n%d" % si)
-        mean, rstd = layernorm_stats(ws, cur, B * H * W, C, tag="head.ln")
+                st = self._block(ws, pk, "n%d.b%d." % (si, bi), cur, B, H, W, C, blk.mlp.fc1.weight.shape[0], "n%d" % si, stats=st)
+        mean, rstd = st if st is not None else layernorm_stats(ws, cur, B * H * W, C, tag="head.ln")
         pooled = ws.get("pooled", (B, C))
         E.pool_mean(cur, B, H * W, C, C, pooled, C, mean=mean, rstd=rstd, gamma=pk["head.g"], beta=pk["head.be"])
         if not isinstance(self.head, nn.Linear):

@@ -12,7 +12,7 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Holder, embed_patches, head_linear, layernorm_stats
+from .common import Holder, embed_patches, finalize_stats, head_linear, layernorm_stats
 from .utils.tools import check_sizes, pair
 
 
@@ -69,9 +69,12 @@ class gMLP(E.EngineModule):
         S, C, F, depth = self._dims
         rows = B * S
         sp = E.round_up(S, 32)        # token K padding: whole half-slabs -> direct-to-LDS GEMM tiles
+        nxt = None
         for i in range(depth):
             p = "b%d." % i
-            mean, rstd = layernorm_stats(ws, x, rows, C)
+            # the block's LayerNorm (g_mlp.py:40) reads what the previous block's proj_out + residual GEMM wrote: its statistics
+            # come out of that epilogue (mlpk.h row_part)
+            mean, rstd = nxt if nxt is not None else layernorm_stats(ws, x, rows, C)
             h = ws.get("h", (rows, 2 * F))
             E.gemm(x, pk[p + "p1.w"], h, rows, 2 * F, C, bias=pk[p + "p1.b"], act=N.ACT_GELU, ln=(mean, rstd, pk[p + "p1.csum"]),
                    tag="gmlp_proj1")
@@ -94,7 +97,8 @@ class gMLP(E.EngineModule):
             else:
                 E.gemm(vt, pk[p + "sp.w"], g, B * F, S, sp, ldc=F, bias=pk[p + "sp.b"], R=h, ldr=2 * F, res=N.RES_MUL,
                        out_mode=N.OUT_TOKEN_T, t_rows=F, t_tokens=S)
-            E.gemm(g, pk[p + "p2.w"], x, rows, C, F, bias=pk[p + "p2.b"], R=x, res=N.RES_ADD)
+            got = E.gemm(g, pk[p + "p2.w"], x, rows, C, F, bias=pk[p + "p2.b"], R=x, res=N.RES_ADD, part=(ws, "p2.part") if i + 1 < depth else None)
+            nxt = finalize_stats(ws, got, rows, C)
         return x
 
     def forward(self, x):

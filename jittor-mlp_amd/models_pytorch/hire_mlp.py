@@ -17,7 +17,7 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Holder, channel_mlp, head_linear, layernorm_stats, pack_channel_mlp
+from .common import Holder, channel_mlp, finalize_stats, head_linear, layernorm_stats, pack_channel_mlp
 from .utils import pair
 
 
@@ -126,6 +126,7 @@ class HireMLP(E.EngineModule):
         if self._cfg[3]:
             ln = self.patcher.reduction[1][1]
             pk["embed.g"], pk["embed.be"] = E.f32(ln.weight, device), E.f32(ln.bias, device)
+        st = None            # (mean, rstd) of cur's rows when the GEMM that wrote cur delivered them (mlpk.h row_part)
         for li, stage in enumerate(self.layers):
             h, w, C, Cout, depth, ef = stage.geom
             for bi, blk in enumerate(stage.model):
@@ -169,6 +170,7 @@ class HireMLP(E.EngineModule):
         if patcher_norm:
             mean, rstd = layernorm_stats(ws, cur, B * H * W, C, tag="embed.ln")
             E.norm_apply(cur, B * H * W, C, C, mean=mean, rstd=rstd, gamma=pk["embed.g"], beta=pk["embed.be"], out_rm=cur, ld_rm=C)
+        st = None            # (mean, rstd) of cur's rows when the GEMM that wrote cur delivered them (mlpk.h row_part)
         for li, stage in enumerate(self.layers):
             h, w, C, Cout, depth, ef = stage.geom
             rows = B * H * W
@@ -185,7 +187,7 @@ class HireMLP(E.EngineModule):
             for bi, blk in enumerate(stage.model):
                 p = "l%d.b%d." % (li, bi)
                 step = blk[0].fn[0].step
-                mean, rstd = layernorm_stats(ws, cur, rows, C, tag="l%d.ln" % li)
+                mean, rstd = st if st is not None else layernorm_stats(ws, cur, rows, C, tag="l%d.ln" % li)
                 E.norm_apply(cur, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "ln.g"], beta=pk[p + "ln.b"], out_rm=xn, ld_rm=C)
                 E.hire_gather(xn, a_h, a_w, B, H, W, C, h, w, step, h * C, w * C)
                 E.gemm(a_h, pk[p + "h1.w"], t_h, rows_h, hid, h * C, bias=pk[p + "h1.b"], act=N.ACT_GELU, tag="hire_fc1")
@@ -194,17 +196,20 @@ class HireMLP(E.EngineModule):
                 E.gemm(t_w, pk[p + "w2.w"], a_w, rows_w, w * C, hidp, bias=pk[p + "w2.b"], tag="hire_fc2")
                 E.gemm(xn, pk[p + "c.w"], cur, rows, C, C, bias=pk[p + "c.b"], R=cur, res=N.RES_ADD, tag="hire_c")   # x + proj_c(xn)
                 E.hire_combine(cur, a_h, a_w, B, H, W, C, h, w, step, h * C, w * C)
-                channel_mlp(ws, cur, rows, C, pk, p + "ff.", C * ef, tag="l%d.cm" % li)
+                got = channel_mlp(ws, cur, rows, C, pk, p + "ff.", C * ef, tag="l%d.cm" % li, part=(ws, "l%d.fc2.part" % li))
+                st = finalize_stats(ws, got, rows, C, tag="l%d.ln" % li)
             if stage.pooling:
                 H2, W2 = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
                 kp = pk["l%d.merge.w" % li].shape[1]
                 cols = ws.get("l%d.cols" % li, (B * H2 * W2, kp))
                 E.im2col(cur, cols, B, C, H, W, 3, 3, 2, 2, 1, kp, layout=N.LAYOUT_NHWC, px_stride=C)
                 nxt = ws.get("l%d.x" % (li + 1), (B * H2 * W2, Cout))
-                E.gemm(cols, pk["l%d.merge.w" % li], nxt, B * H2 * W2, Cout, kp, bias=pk["l%d.merge.b" % li], tag="hire_merge")
+                got = E.gemm(cols, pk["l%d.merge.w" % li], nxt, B * H2 * W2, Cout, kp, bias=pk["l%d.merge.b" % li], tag="hire_merge",
+                             part=(ws, "l%d.merge.part" % li))
+                st = finalize_stats(ws, got, B * H2 * W2, Cout, tag="l%d.ln" % (li + 1))
                 cur, H, W = nxt, H2, W2
         C = self.layers[-1].geom[2]
-        mean, rstd = layernorm_stats(ws, cur, B * H * W, C, tag="head.ln")
+        mean, rstd = st if st is not None else layernorm_stats(ws, cur, B * H * W, C, tag="head.ln")
         pooled = ws.get("pooled", (B, C))
         E.pool_mean(cur, B, H * W, C, C, pooled, C, mean=mean, rstd=rstd, gamma=pk["head.g"], beta=pk["head.be"])
         return head_linear(ws, pooled, B, C, pk["head.w"], pk["head.b"], num_classes, x.dtype)

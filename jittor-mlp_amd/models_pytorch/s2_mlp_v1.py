@@ -8,7 +8,7 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Holder, channel_mlp, head_linear, layernorm_stats, stage_embed, pack_channel_mlp
+from .common import Holder, channel_mlp, finalize_stats, head_linear, layernorm_stats, stage_embed, pack_channel_mlp
 from .s2_mlp_v2 import SHIFT_MODES
 from .utils.tools import pair
 
@@ -48,16 +48,20 @@ class S2Block(E.EngineModule):
     def _run_blocks(self, ws, pk, x, B, H, W, prefix, mode):
         C, depth, ef = self._dims
         rows = B * H * W
+        nxt = None
         for i in range(depth):
             p = prefix + "b%d." % i
-            mean, rstd = layernorm_stats(ws, x, rows, C, tag=prefix + "ln")
+            # both LayerNorms of a block read what a GEMM + residual has just written: statistics from those epilogues (mlpk.h row_part)
+            mean, rstd = nxt if nxt is not None else layernorm_stats(ws, x, rows, C, tag=prefix + "ln")
             t = ws.get(prefix + "t", (rows, C))
             E.gemm(x, pk[p + "l0.w"], t, rows, C, C, bias=pk[p + "l0.b"], act=N.ACT_GELU, ln=(mean, rstd, pk[p + "l0.csum"]),
                    tag="s2v1_l0")
             ts = ws.get(prefix + "ts", (rows, C))
             E.s2_shift(t, ts, B, H, W, C, C, C, mode)
-            E.gemm(ts, pk[p + "l3.w"], x, rows, C, C, bias=pk[p + "l3.b"], R=x, res=N.RES_ADD, tag="s2v1_l3")
-            channel_mlp(ws, x, rows, C, pk, p + "mlp.", C * ef, tag=prefix + "cm")
+            got = E.gemm(ts, pk[p + "l3.w"], x, rows, C, C, bias=pk[p + "l3.b"], R=x, res=N.RES_ADD, tag="s2v1_l3", part=(ws, prefix + "l3.part"))
+            got = channel_mlp(ws, x, rows, C, pk, p + "mlp.", C * ef, tag=prefix + "cm", stats=finalize_stats(ws, got, rows, C, tag=prefix + "cm.ln"),
+                              part=(ws, prefix + "fc2.part"))
+            nxt = finalize_stats(ws, got, rows, C, tag=prefix + "ln")
         return x
 
     def forward(self, x):

@@ -20,7 +20,7 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Holder, channel_mlp, head_linear, layernorm_stats, split_attention_weights, stage_embed, pack_channel_mlp
+from .common import Holder, channel_mlp, finalize_stats, head_linear, layernorm_stats, split_attention_weights, stage_embed, pack_channel_mlp
 from .utils.tools import pair
 
 SHIFT_MODES = {"reference_inplace": N.SHIFT_S2_REF, "shift": N.SHIFT_S2}
@@ -84,9 +84,11 @@ class S2Block(E.EngineModule):
     def _run_blocks(self, ws, pk, x, B, H, W, prefix, mode, only=None):
         C, depth, ef = self._dims
         rows = B * H * W
+        nxt = None
         for i in (range(depth) if only is None else only):
             p = prefix + "b%d." % i
-            mean, rstd = layernorm_stats(ws, x, rows, C, tag=prefix + "ln")
+            # both LayerNorms of a block read what a GEMM + residual has just written: statistics from those epilogues (mlpk.h row_part)
+            mean, rstd = nxt if nxt is not None else layernorm_stats(ws, x, rows, C, tag=prefix + "ln")
             t = ws.get(prefix + "t", (rows, 3 * C))
             E.gemm(x, pk[p + "a1.w"], t, rows, 3 * C, C, bias=pk[p + "a1.b"], ln=(mean, rstd, pk[p + "a1.csum"]), tag="s2_mlp1")
             x0, x1, x2 = t[:, :C], t[:, C:2 * C], t[:, 2 * C:]
@@ -94,8 +96,10 @@ class S2Block(E.EngineModule):
                                           tag=prefix + "sa")
             m = ws.get(prefix + "m", (rows, C))
             E.split_apply(x0, x1, x2, 3 * C, 3 * C, 3 * C, B, H, W, C, mode, bar, m, C)
-            E.gemm(m, pk[p + "a2.w"], x, rows, C, C, bias=pk[p + "a2.b"], R=x, res=N.RES_ADD, tag="s2_mlp2")
-            channel_mlp(ws, x, rows, C, pk, p + "mlp.", C * ef, tag=prefix + "cm")
+            got = E.gemm(m, pk[p + "a2.w"], x, rows, C, C, bias=pk[p + "a2.b"], R=x, res=N.RES_ADD, tag="s2_mlp2", part=(ws, prefix + "a2.part"))
+            got = channel_mlp(ws, x, rows, C, pk, p + "mlp.", C * ef, tag=prefix + "cm", stats=finalize_stats(ws, got, rows, C, tag=prefix + "cm.ln"),
+                              part=(ws, prefix + "fc2.part"))
+            nxt = finalize_stats(ws, got, rows, C, tag=prefix + "ln")
         return x
 
     def forward(self, x):

@@ -22,7 +22,7 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Holder, channel_mlp, embed_patches, head_linear, layernorm_stats, pack_channel_mlp
+from .common import Holder, channel_mlp, finalize_stats, embed_patches, head_linear, layernorm_stats, pack_channel_mlp
 from .conv_mixer import _bn_affine
 from .utils import pair
 
@@ -184,8 +184,9 @@ class SparseMLP(E.EngineModule):
                     E.gemm(xt_h, pk[p + "ph.w"], xh, B * W * C, H, hp, ldc=W * C, bias=pk[p + "ph.b"], out_mode=N.OUT_TOKEN_T,
                            t_rows=W * C, t_tokens=H, tag="smlp_h")
                 E.gemm(xh, pk[p + "fu.wh"], cur, rows, C, C, bias=pk[p + "fu.b"], R=cur, res=N.RES_ADD, tag="smlp_fuse")
-                E.gemm(cat, pk[p + "fu.wr"], cur, rows, C, 2 * C, R=cur, res=N.RES_ADD, tag="smlp_fuse")
-                channel_mlp(ws, cur, rows, C, pk, p + "ff.", C * ef, tag="l%d.cm" % li)
+                # the LayerNorm of the channel MLP reads what this GEMM writes: its statistics come out of the epilogue (mlpk.h row_part)
+                got = E.gemm(cat, pk[p + "fu.wr"], cur, rows, C, 2 * C, R=cur, res=N.RES_ADD, tag="smlp_fuse", part=(ws, "l%d.fu.part" % li))
+                channel_mlp(ws, cur, rows, C, pk, p + "ff.", C * ef, tag="l%d.cm" % li, stats=finalize_stats(ws, got, rows, C, tag="l%d.cm.ln" % li))
             if stage.pooling:
                 assert H % 2 == 0 and W % 2 == 0, f"x size ({H}*{W}) are not even."                      # sparse_mlp.py:38
                 p = "l%d.merge." % li

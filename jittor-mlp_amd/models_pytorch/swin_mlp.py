@@ -19,7 +19,7 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Holder, channel_mlp, embed_patches, head_linear, layernorm_stats, pack_channel_mlp
+from .common import Holder, channel_mlp, finalize_stats, embed_patches, head_linear, layernorm_stats, pack_channel_mlp
 
 
 def to_2tuple(v):
@@ -205,6 +205,7 @@ class SwinMLP(E.EngineModule):
         if pe.norm is not None:
             mean, rstd = layernorm_stats(ws_, cur, B * H * W, C, tag="embed.ln")
             E.norm_apply(cur, B * H * W, C, C, mean=mean, rstd=rstd, gamma=pk["embed.g"], beta=pk["embed.be"], out_rm=cur, ld_rm=C)
+        st = None            # (mean, rstd) of cur's rows when the GEMM that wrote cur delivered them (mlpk.h row_part)
         for li, layer in enumerate(self.layers):
             rows = B * H * W
             xn = ws_.get("l%d.xn" % li, (rows, C))
@@ -220,7 +221,7 @@ class SwinMLP(E.EngineModule):
                 tag = "l%d.s%d." % (li, 1 if blk.shift_size > 0 else 0)
                 xw = ws_.get(tag + "xw", (nwin * ws * ws, C))
                 xt = ws_.get(tag + "xt", (nwin * d, kp))
-                mean, rstd = layernorm_stats(ws_, cur, rows, C, tag="l%d.ln" % li)
+                mean, rstd = st if st is not None else layernorm_stats(ws_, cur, rows, C, tag="l%d.ln" % li)
                 E.norm_apply(cur, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "n1.g"], beta=pk[p + "n1.b"], out_rm=xn, ld_rm=C)
                 E.window_gather(xn, xw, B, H, W, C, ws, pad_t, pad_l, Hp, Wp)
                 # rows (window, token, head) x d channels  ->  per window transposed: ((window, channel), (token, head))
@@ -228,7 +229,8 @@ class SwinMLP(E.EngineModule):
                 E.gemm(xt, pk[p + "sp.w"], xw, nwin * d, tk, kp, ldc=d, bias=pk[p + "sp.b"], out_mode=N.OUT_TOKEN_T, t_rows=d, t_tokens=tk,
                        tag="swin_spatial")
                 E.window_scatter_add(cur, xw, B, H, W, C, ws, pad_t, pad_l, Hp, Wp)
-                channel_mlp(ws_, cur, rows, C, pk, p + "ff.", int(C * self.mlp_ratio), tag="l%d.cm" % li)
+                got = channel_mlp(ws_, cur, rows, C, pk, p + "ff.", int(C * self.mlp_ratio), tag="l%d.cm" % li, part=(ws_, "l%d.fc2.part" % li))
+                st = finalize_stats(ws_, got, rows, C, tag="l%d.ln" % li)
             if layer.downsample is not None:
                 assert H % 2 == 0 and W % 2 == 0, f"x size ({H}*{W}) are not even."                                 # swin_mlp.py:201
                 p = "l%d.merge." % li
@@ -237,9 +239,11 @@ class SwinMLP(E.EngineModule):
                 E.patchify(cur, merged, B, C, H, W, 2, 2, 0, 4 * C, layout=N.LAYOUT_NHWC, px_stride=C, order=1)
                 mean, rstd = layernorm_stats(ws_, merged, B * H2 * W2, 4 * C, tag="l%d.merge.ln" % li)
                 nxt = ws_.get("l%d.x" % (li + 1), (B * H2 * W2, 2 * C))
-                E.gemm(merged, pk[p + "w"], nxt, B * H2 * W2, 2 * C, 4 * C, bias=pk[p + "b"], ln=(mean, rstd, pk[p + "csum"]), tag="swin_merge")
+                got = E.gemm(merged, pk[p + "w"], nxt, B * H2 * W2, 2 * C, 4 * C, bias=pk[p + "b"], ln=(mean, rstd, pk[p + "csum"]), tag="swin_merge",
+                             part=(ws_, "l%d.merge.part" % li))
+                st = finalize_stats(ws_, got, B * H2 * W2, 2 * C, tag="l%d.ln" % (li + 1))
                 cur, H, W, C = nxt, H2, W2, 2 * C
-        mean, rstd = layernorm_stats(ws_, cur, B * H * W, C, tag="head.ln")
+        mean, rstd = st if st is not None else layernorm_stats(ws_, cur, B * H * W, C, tag="head.ln")
         pooled = ws_.get("pooled", (B, C))
         E.pool_mean(cur, B, H * W, C, C, pooled, C, mean=mean, rstd=rstd, gamma=pk["norm.g"], beta=pk["norm.b"])
         if not isinstance(self.head, nn.Linear):

@@ -16,7 +16,7 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Holder, channel_mlp, embed_patches, head_linear, layernorm_stats, split_attention_weights, pack_channel_mlp
+from .common import Holder, channel_mlp, embed_patches, finalize_stats, head_linear, layernorm_stats, split_attention_weights, pack_channel_mlp
 from .utils.tools import pair
 
 
@@ -151,15 +151,19 @@ class _PermutatorBase(E.EngineModule):
         self._pack_blocks(pk, dtype, device)
         return pk
 
-    def _run_blocks(self, ws, pk, x, B, prefix=""):
+    def _run_blocks(self, ws, pk, x, B, prefix="", final_stats=False):
+        """final_stats: also return the (mean, rstd) of the rows of the result (for the LayerNorm of the head), or None."""
         H, W, C, depth, seg, ef = self._dims
         rows = B * H * W
         G = C // seg
         hs, wsz = H * seg, W * seg
         ldh, ldw = E.round_up(hs, 32), E.round_up(wsz, 32)
+        # both LayerNorms of a block read a tensor a GEMM has just written (proj + residual, fc2 + residual): their statistics
+        # come out of those epilogues (mlpk.h row_part) instead of two more passes over x per block
+        nxt = None
         for i in range(depth):
             p = prefix + "b%d." % i
-            mean, rstd = layernorm_stats(ws, x, rows, C)
+            mean, rstd = nxt if nxt is not None else layernorm_stats(ws, x, rows, C)
             cfold = (p + "c.csum") in pk
             xn = None if cfold else ws.get("vip.xn", (rows, C))
             ph = ws.get("vip.ph", (B * W * G, ldh))
@@ -209,9 +213,11 @@ class _PermutatorBase(E.EngineModule):
                 else:
                     bar = ws.get("vip.ones", (B, 3 * C), torch.float32, fill=1.0)     # plain sum (vip.py:16-22)
                 E.split_apply(xh, xw, xc, C, C, C, B, H, W, C, N.SHIFT_NONE, bar, m, C)
-            E.gemm(m, pk[p + "proj.w"], x, rows, C, C, bias=pk[p + "proj.b"], R=x, res=N.RES_ADD, tag="vip_proj")
-            channel_mlp(ws, x, rows, C, pk, p + "mlp.", C * ef)
-        return x
+            got = E.gemm(m, pk[p + "proj.w"], x, rows, C, C, bias=pk[p + "proj.b"], R=x, res=N.RES_ADD, tag="vip_proj", part=(ws, "vip.proj.part"))
+            got = channel_mlp(ws, x, rows, C, pk, p + "mlp.", C * ef, stats=finalize_stats(ws, got, rows, C, tag="cm.ln"),
+                              part=(ws, "vip.fc2.part"))
+            nxt = finalize_stats(ws, got, rows, C)
+        return (x, nxt) if final_stats else x
 
     def forward(self, x):
         """(B,H,W,C) -> (B,H,W,C), as the reference backbones (vip.py:92-93, 127-128)."""
@@ -283,9 +289,9 @@ class ViP(E.EngineModule):
                                        out=ws.get("x", (B * H * W, C)))
         if (hp, wp) != (H, W):
             raise ValueError("input size gives a %dx%d grid, the model was built for %dx%d" % (hp, wp, H, W))
-        self.blocks._run_blocks(ws, pk, tokens, B)
         rows = B * H * W
-        mean, rstd = layernorm_stats(ws, tokens, rows, C)
+        _, st = self.blocks._run_blocks(ws, pk, tokens, B, final_stats=True)
+        mean, rstd = st if st is not None else layernorm_stats(ws, tokens, rows, C)
         pooled = ws.get("pooled", (B, C))
         E.pool_mean(tokens, B, H * W, C, C, pooled, C, mean=mean, rstd=rstd, gamma=pk["head.ln.g"], beta=pk["head.ln.b"])
         return head_linear(ws, pooled, B, C, pk["head.w"], pk["head.b"], self._num_classes, x.dtype)

@@ -955,3 +955,95 @@ def test_vip_split_attention_on_permuted_layout(dtype):
         assert torch.equal(m.view(torch.int16), m_ref.view(torch.int16)), (str(dtype), ci)
     with pytest.raises(N.MlpkError):                                            # seg % 4 != 0 is refused (the host keeps the unfused path)
         E.vip_split_apply(zh, zw, xc, ldh, ldw, C, 1, 2, 2, 12, 6, bar, m, C)
+
+
+class _Space:
+    """the two-argument slice of engine.Workspace that engine.gemm(part=...) uses"""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, name, shape, dtype):
+        self.bufs[name] = torch.full(shape, float("nan"), dtype=dtype, device=dev())
+        return self.bufs[name]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("algo", [0, 1, 2, 3, 4, 7, 11, 12, 13, 14])
+def test_gemm_byproduct_row_statistics(dtype, algo):
+    """mlpk.h row_part: (sum, sum of squares) of the STORED values per row and column block, from every epilogue that
+    delivers them; C itself must not change by a bit, and mlpk_stats_finalize_planar must reproduce LayerNorm / per-sample
+    GroupNorm statistics of C (vip.py:66,82; as_mlp.py:90)."""
+    pkg = load_pkg()
+    E, N = pkg.engine, pkg._native
+    shapes = [(1000, 384, 96, True, 0), (512, 96, 64, False, 1), (777, 200, 128, True, 1), (1024, 512, 256, True, 0)]
+    if algo == 14:
+        shapes = [(1024, 512, 256, True, 0), (832, 256, 128, True, 0)]       # whole tiles, bias + residual
+    for (M, Nn, K, has_res, act) in shapes:
+        A = rnd((M, K), dtype, 500).to(dev())
+        B = rnd((Nn, K), dtype, 501, 1.0 / math.sqrt(K)).to(dev())
+        bias = (rnd((Nn,), torch.float32, 502) + 0.5).to(dev())
+        R = rnd((M, Nn), dtype, 503).to(dev()) if has_res else None
+        res = N.RES_ADD if has_res else N.RES_NONE
+        ref = torch.empty((M, Nn), dtype=dtype, device=dev())
+        E.gemm(A, B, ref, M, Nn, K, bias=bias, act=act, R=R, res=res, algo=algo)
+        C = torch.full((M, Nn), float("nan"), dtype=dtype, device=dev())
+        sp = _Space()
+        got = E.gemm(A, B, C, M, Nn, K, bias=bias, act=act, R=R, res=res, algo=algo, part=(sp, "p"))
+        assert got is not None, (M, Nn, K, algo)
+        part, nparts = got
+        torch.cuda.synchronize()
+        assert torch.equal(C.view(torch.int16), ref.view(torch.int16)), (M, Nn, K, algo)
+        width = 128 if nparts == -(-Nn // 128) else 32
+        assert nparts == -(-Nn // width) and (width == 32 or algo != 14)
+        c64 = C.double().cpu()
+        p64 = part.double().cpu()
+        assert not torch.isnan(p64).any()
+        for q in range(nparts):
+            blk = c64[:, q * width:min(Nn, (q + 1) * width)]
+            tol = 1e-5 * blk.abs().sum(1) + 1e-6
+            assert ((p64[q, :, 0] - blk.sum(1)).abs() <= tol).all(), (M, Nn, K, algo, q)
+            assert ((p64[q, :, 1] - (blk * blk).sum(1)).abs() <= 1e-5 * (blk * blk).sum(1) + 1e-6).all(), (M, Nn, K, algo, q)
+        # LayerNorm statistics of the rows
+        mean = torch.empty((M,), dtype=torch.float32, device=dev())
+        rstd = torch.empty((M,), dtype=torch.float32, device=dev())
+        assert tuple(part.shape) == (nparts, M, 2)
+        E.stats_finalize_planar(part, M, Nn, mean, rstd, eps=1e-5)
+        mu = c64.mean(1)
+        rs = 1.0 / torch.sqrt(c64.var(1, unbiased=False) + 1e-5)
+        assert (mean.double().cpu() - mu).abs().max().item() <= 1e-5
+        assert ((rstd.double().cpu() - rs).abs() / rs).max().item() <= 1e-4
+        # per-sample GroupNorm(1, C): groups of `hw` consecutive rows share one statistic
+        for hw in ([8] if M % 8 == 0 else []) + ([M // 4] if M % 4 == 0 else []):
+            Bn = M // hw
+            gm = torch.empty((Bn,), dtype=torch.float32, device=dev())
+            gr = torch.empty((Bn,), dtype=torch.float32, device=dev())
+            E.stats_finalize_planar(part, Bn, hw * Nn, gm, gr, eps=1e-5, group=hw)
+            g64 = c64.reshape(Bn, hw * Nn)
+            mu = g64.mean(1)
+            rs = 1.0 / torch.sqrt(g64.var(1, unbiased=False) + 1e-5)
+            assert (gm.double().cpu() - mu).abs().max().item() <= 1e-5, (hw, nparts)
+            assert ((gr.double().cpu() - rs).abs() / rs).max().item() <= 1e-4, (hw, nparts)
+
+
+def test_gemm_row_parts_refusals():
+    """what cannot deliver statistics says so (the caller then runs mlpk_row_stats): fp32, 64-column tiles, token-transposed
+    outputs, the persistent tile with an epilogue class it does not instantiate them for."""
+    import ctypes
+    pkg = load_pkg()
+    E, N = pkg.engine, pkg._native
+    sp = _Space()
+    A = rnd((256, 64), torch.float32, 1).to(dev())
+    B = rnd((128, 64), torch.float32, 2).to(dev())
+    C = torch.empty((256, 128), dtype=torch.float32, device=dev())
+    assert E.gemm(A, B, C, 256, 128, 64, part=(sp, "p")) is None and not sp.bufs
+    A, B, C = A.bfloat16(), B.bfloat16(), C.bfloat16()
+    assert E.gemm(A, B, C, 256, 128, 64, algo=5, part=(sp, "p")) is None
+    assert E.gemm(A, B, C, 256, 128, 64, part=(sp, "p")) is not None
+    d = N.GemmDesc()
+    d.dtype, d.M, d.N, d.K, d.lda, d.ldb, d.ldc = N.BF16, 256, 128, 64, 64, 64, 128
+    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), C.data_ptr()
+    d.row_part, d.row_part_ld = sp.bufs["p.1"].data_ptr(), 255      # a plane shorter than M
+    assert N.lib().mlpk_gemm_nt(ctypes.byref(d), None) != 0
+    d.row_part_ld, d.algo = 256, 14                                  # persistent tile without a residual: no statistics class
+    assert N.lib().mlpk_gemm_nt(ctypes.byref(d), None) != 0
