@@ -292,6 +292,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
             // residual chunks of the remaining groups go in flight first, then each pass is LDS read ->
             // combine -> one 16-byte store; rows past M are skipped.
             u32x4 rr[NP];
+            float ps1[STATS ? NP : 1], ps2[STATS ? NP : 1];
 #pragma unroll
             for (int q = 0; q < PB0; ++q) rr[q] = (STATS && !(fast && has_res)) ? u32x4{0u, 0u, 0u, 0u} : rr0[q];
             if (has_res) {
@@ -322,13 +323,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
                 if (gm < p.M && live && (!(p.dbg & 2) || outv.x == 0x12345678u))
                     *reinterpret_cast<u32x4*>(C + (size_t)gm * p.ldc + gn) = outv;
                 if constexpr (STATS && CPR >= 16) {
-                    // by-product statistics of the row's 128 columns that sit in these 16 lanes (one DPP row)
-                    float s1 = 0.f, s2 = 0.f;
-                    chunk_sums<T>(outv, s1, s2);
-                    s1 = row16_sum(live ? s1 : 0.f);
-                    s2 = row16_sum(live ? s2 : 0.f);
-                    if ((c16 & 15) == 0 && gm < p.M && live)
-                        *reinterpret_cast<f32x2*>(p.row_part + ((size_t)(gn >> 7) * p.row_part_ld + gm) * 2) = f32x2{s1, s2};
+                    ps1[q] = 0.f; ps2[q] = 0.f;
+                    chunk_sums<T>(outv, ps1[q], ps2[q]);
+                }
+            }
+            if constexpr (STATS && CPR >= 16) {
+                // by-product statistics: the row's 128 columns sit in 16 lanes (one DPP row).  All the passes' reductions in one
+                // block after the stores, so that their dependent DPP steps interleave instead of each waiting out its own latency
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    ps1[q] = row16_sum(live ? ps1[q] : 0.f);
+                    ps2[q] = row16_sum(live ? ps2[q] : 0.f);
+                }
+                if ((c16 & 15) == 0 && live) {
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) {
+                        const int gm = m0 + q * RPASS + rsub;
+                        if (gm < p.M) *reinterpret_cast<f32x2*>(p.row_part + ((size_t)(gn >> 7) * p.row_part_ld + gm) * 2) = f32x2{ps1[q], ps2[q]};
+                    }
                 }
             }
         };
