@@ -192,13 +192,13 @@ int mlpk_token_gemm(int dtype, const void* xt, int ldxt, int M, int S, const voi
                     const float* rscale, int rperiod, const void* R, int ldr, int res_mode, void* out, int ldo, int t_rows,
                     void* stream);
 /* `stats` (optional, t_rows % 128 == 0): the statistics of the LayerNorm that follows (mlp_mixer.py:38) come out of the epilogue:
- * stats[((b*S + s)*(t_rows/128) + tile)*2 + {0,1}] = sum / sum of squares over the tile's 128 channels of the values written
- * to x[b,s,:].  mlpk_stats_finalize reduces the partials of a row to mean / rstd (count = t_rows). */
-int mlpk_stats_finalize(const float* part, int64_t rows, int nparts, int64_t count, float eps, float* mean, float* rstd,
-                        void* stream);
-/* The same for the planar pairs of mlpk_gemm_nt's row_part: statistic r covers rows [r*group, (r+1)*group) of all `nplanes`
- * planes, pair (q, m) at part[(q*plane_stride + m)*2]; count = elements per statistic (group * N).  group = 1: LayerNorm of the
- * GEMM's rows; group = H*W: GroupNorm(1,C) per sample on channel-last rows (as_mlp.py:343-344). */
+ * stats[(tile*B*S + b*S + s)*2 + {0,1}] = sum / sum of squares over the tile's 128 channels of the values written to x[b,s,:]
+ * (planar: t_rows/128 planes of B*S pairs, B = M / t_rows).  mlpk_stats_finalize_planar(stats, B*S, t_rows/128, B*S, 1, t_rows, ..)
+ * reduces the partials of a row to mean / rstd. */
+/* mean / rstd from planar (sum, sum of squares) pairs -- mlpk_token_mlp's `stats`, mlpk_gemm_nt's row_part: statistic r covers
+ * rows [r*group, (r+1)*group) of all `nplanes` planes, pair (q, m) at part[(q*plane_stride + m)*2]; count = elements per
+ * statistic (group * row length).  group = 1: LayerNorm of the producer's rows; group = H*W: GroupNorm(1,C) per sample on
+ * channel-last rows (as_mlp.py:343-344).  rstd = 1 / sqrt(max(0, S2/count - mean^2) + eps). */
 int mlpk_stats_finalize_planar(const float* part, int64_t rows, int nplanes, int64_t plane_stride, int group, int64_t count, float eps,
                                float* mean, float* rstd, void* stream);
 /* Tuning hook (tools/tokenmlp_timeline.py), not part of the forward path: when `buf` is non-NULL, later mlpk_token_mlp

@@ -55,7 +55,6 @@ PROTOTYPES = {
     "mlpk_token_gemm": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
                                 c_void_p, c_int, c_int, c_void_p]),
     "mlpk_layernorm_transpose": (c_int, [c_int, c_void_p, c_i64, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p]),
-    "mlpk_stats_finalize": (c_int, [c_void_p, c_i64, c_int, c_i64, c_float, c_void_p, c_void_p, c_void_p]),
     "mlpk_stats_finalize_planar": (c_int, [c_void_p, c_i64, c_int, c_i64, c_int, c_i64, c_float, c_void_p, c_void_p, c_void_p]),
     "mlpk_token_mlp_debug": (None, [c_void_p]),
     "mlpk_patchify": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),

@@ -774,27 +774,10 @@ using namespace mlpk;
         default: return MLPK_EDTYPE;                                         \
     }
 
-// mean / rstd of `rows` rows from `nparts` partial (sum, sum of squares) pairs per row, written by a producer's epilogue
-// (mlpk_token_mlp): mean = S1 / count, var = S2 / count - mean^2 (>= 0), rstd = 1 / sqrt(var + eps).  fp32 sums of values that
-// were rounded to 16 bits: the cancellation error of the E[x^2] - mean^2 form (~1e-7 (1 + mean^2 / var)) is far below the
-// storage rounding of the tensor being normalised.
-__global__ void __launch_bounds__(256) stats_finalize_kernel(const float* __restrict__ part, int64_t rows, int nparts, float inv_count, float eps,
-                                                             float* __restrict__ mean, float* __restrict__ rstd) {
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= rows) return;
-    const float* pp = part + r * nparts * 2;
-    float s1 = 0.f, s2 = 0.f;
-    for (int i = 0; i < nparts; ++i) {
-        s1 += pp[2 * i];
-        s2 += pp[2 * i + 1];
-    }
-    const float mu = s1 * inv_count;
-    float var = s2 * inv_count - mu * mu;
-    var = var > 0.f ? var : 0.f;
-    mean[r] = mu;
-    rstd[r] = 1.0f / __builtin_sqrtf(var + eps);
-}
-
+// mean / rstd from partial (sum, sum of squares) pairs written by a producer's epilogue (mlpk_token_mlp, mlpk_gemm_nt):
+// mean = S1 / count, var = S2 / count - mean^2 (>= 0), rstd = 1 / sqrt(var + eps).  fp32 sums of values that were rounded to
+// 16 bits: the cancellation error of the E[x^2] - mean^2 form (~1e-7 (1 + mean^2 / var)) is far below the storage rounding of
+// the tensor being normalised.
 // planar pairs of a GEMM's by-product statistics (mlpk.h row_part): pair (q, m) at part[(q * plane_stride + m) * 2].
 // group = 1: one thread per row, the planes read coalesced.
 __global__ void __launch_bounds__(256) stats_finalize_planar_kernel(const float* __restrict__ part, int64_t rows, int nplanes, int64_t plane_stride,
@@ -869,17 +852,6 @@ extern "C" int mlpk_row_stats(int dtype, const void* x, int64_t rows, int64_t le
         DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((row_stats_kernel<T, 1024>), dim3((unsigned)rows), dim3(1024), 0, s,
                                                  (const T*)x, rows, len, ldx, eps, mean, rstd, vec));
     }
-    MLPK_LAUNCH_CHECK();
-    return 0;
-}
-
-extern "C" int mlpk_stats_finalize(const float* part, int64_t rows, int nparts, int64_t count, float eps, float* mean, float* rstd,
-                                   void* stream) {
-    if (!part || !mean || !rstd) return MLPK_ENULL;
-    if (rows <= 0 || nparts <= 0 || count <= 0) return MLPK_ESHAPE;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, part, rows, nparts, 1.0f / (float)count, eps,
-                       mean, rstd);
     MLPK_LAUNCH_CHECK();
     return 0;
 }

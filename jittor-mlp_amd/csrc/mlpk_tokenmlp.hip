@@ -40,7 +40,7 @@ struct TokenMlpArgs {
     void* x;            // (B*S, ldx) residual stream, updated in place
     int M, S, ks1, G;
     int ldxt, ldw2, ldx, t_rows;
-    float* stats;       // optional: per (token row, 128-channel tile) partial (sum, sum of squares) of the values written to x
+    float* stats;       // optional: per (128-channel tile, token row) partial (sum, sum of squares) of the values written to x, planar
     unsigned long long* dbg;   // tuning aid: per-workgroup [loop, epilogue] shader-clock sums (NULL in normal use)
 };
 
@@ -198,9 +198,11 @@ __global__ void __launch_bounds__(512, 1) token_mlp_kernel(const TokenMlpArgs p)
     const int wc4 = slice * 8 + fg;                        // writer's 16-byte chunk (4 channels) for i = 0; + 4 for i = 1
     // Statistics for the LayerNorm that follows (the channel-mixing PreNormResidual, mlp_mixer.py:38): the 16 lanes rc = 0..15 of a
     // token hold the tile's 128 channels of it, AFTER rounding -- exactly what that LayerNorm will read -- so a DPP row reduction
-    // gives the tile's partial (sum, sum of squares) per token; mlpk_stats_finalize turns the t_rows / 128 partials of a row into
+    // gives the tile's partial (sum, sum of squares) per token; mlpk_stats_finalize_planar turns the t_rows / 128 partials of a row into
     // mean / rstd.  One separate statistics pass over x per block (77 MB at Mixer-B/16, 256 images) disappears.
-    const int stile = p.stats ? (p.t_rows >> 7) : 0;                  // partial slots per token row (t_rows % 128 == 0, host checked)
+    // (PLANAR, one plane of B*S pairs per 128-channel tile: a workgroup's S pairs are one contiguous run; interleaved per token row
+    //  every pair was a lone 8-byte masked write between pairs that other workgroups write later.)
+    const size_t srows = (size_t)(p.M / p.t_rows) * p.S;             // plane stride in pairs (t_rows % 128 == 0, host checked)
     auto epilogue_reader = [&](const int j, const char* sb, const u32x4 res, const int rimg, const int rcc, const bool row_ok) {
         const int rn = (rt < 16 ? j : TM_NB0 + j) * 16 + (rt & 15);   // token this thread moves in pass j
         const bool live = (rt < 16 || j < TM_NB1) && rn < p.S && row_ok;
@@ -216,23 +218,13 @@ __global__ void __launch_bounds__(512, 1) token_mlp_kernel(const TokenMlpArgs p)
             u32x4 o;
             __builtin_memcpy(&o, e, 16);
             *reinterpret_cast<u32x4*>(x + ((size_t)rimg * p.S + rn) * p.ldx + rcc) = o;
-            if (p.stats) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const float f = to_f32(e[k]);
-                    ssum += f;
-                    ssq += f * f;
-                }
-            }
+            if (p.stats) chunk_sums<T>(o, ssum, ssq);
         }
         if (p.stats) {                                                // (workgroup-uniform: every lane takes part in the DPP rows)
             ssum = row16_sum(ssum);
             ssq = row16_sum(ssq);
-            if (live && rc == 0) {
-                float* dst = p.stats + (((size_t)rimg * p.S + rn) * stile + (rcc >> 7)) * 2;
-                dst[0] = ssum;
-                dst[1] = ssq;
-            }
+            if (live && rc == 0)
+                *reinterpret_cast<f32x2*>(p.stats + ((size_t)(rcc >> 7) * srows + (size_t)rimg * p.S + rn) * 2) = f32x2{ssum, ssq};
         }
     };
     auto residual_load = [&](const int j, const int rimg, const int rcc, const bool row_ok) {
@@ -624,7 +616,7 @@ __global__ void __launch_bounds__(512, 1) token_mlp_rr_kernel(const TokenMlpArgs
     unsigned long long t_loop = 0, t_epi = 0, ts = 0;
     const bool stamp = p.dbg != nullptr;
     char* const stg = smem + T2_STG;
-    const int stile = p.stats ? (p.t_rows >> 7) : 0;
+    const size_t srows = (size_t)(p.M / p.t_rows) * p.S;      // plane stride of the statistics pairs
 
     u32x4 xa[2][TM_KMAX];
     auto load_x = [&](const int tile, const int ln) {
@@ -802,23 +794,13 @@ __global__ void __launch_bounds__(512, 1) token_mlp_rr_kernel(const TokenMlpArgs
                     u32x4 o;
                     __builtin_memcpy(&o, e, 16);
                     *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(x) + j * pass_stride + voff) = o;
-                    if (p.stats) {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            const float f = to_f32(e[k]);
-                            ssum += f;
-                            ssq += f * f;
-                        }
-                    }
+                    if (p.stats) chunk_sums<T>(o, ssum, ssq);
                 }
                 if (p.stats) {                                 // (workgroup-uniform: every lane takes part in the DPP rows)
                     ssum = row16_sum(ssum);
                     ssq = row16_sum(ssq);
-                    if (live && (rc & 15) == 0) {
-                        float* dst = p.stats + (((size_t)rimg * p.S + rn) * stile + (rcc >> 7)) * 2;
-                        dst[0] = ssum;
-                        dst[1] = ssq;
-                    }
+                    if (live && (rc & 15) == 0)
+                        *reinterpret_cast<f32x2*>(p.stats + ((size_t)(rcc >> 7) * srows + (size_t)rimg * p.S + rn) * 2) = f32x2{ssum, ssq};
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

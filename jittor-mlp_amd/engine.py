@@ -186,10 +186,6 @@ def epilogue_stats():
     return os.environ.get("MLPK_NO_EPILOGUE_STATS", "0") != "1"
 
 
-def stats_finalize(part, rows, nparts, count, mean, rstd, eps=1e-5):
-    N.check(N.lib().mlpk_stats_finalize(ptr(part), rows, nparts, count, eps, ptr(mean), ptr(rstd), stream()), "mlpk_stats_finalize")
-
-
 def stats_finalize_planar(part, rows, count, mean, rstd, eps=1e-5, group=1):
     """part = the (nplanes, M, 2) buffer engine.gemm(part=...) returned; statistic r covers GEMM rows [r*group, (r+1)*group)."""
     N.check(N.lib().mlpk_stats_finalize_planar(ptr(part), rows, part.shape[0], part.shape[1], group, count, eps, ptr(mean), ptr(rstd), stream()),

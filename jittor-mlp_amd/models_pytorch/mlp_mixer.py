@@ -102,10 +102,10 @@ class MLPMixer(E.EngineModule):
                 stats = None
                 if C % 128 == 0 and (p + "ch.fc1.csum") in pk and E.epilogue_stats():
                     # the statistics of the channel LayerNorm come out of the token kernel's epilogue (no pass over x)
-                    part = ws.get("tok.stats", (rows, C // 128, 2), torch.float32)
+                    part = ws.get("tok.stats", (C // 128, rows, 2), torch.float32)
                     E.token_mlp(xt, sp, B * C, S, w1f, b1f, w2f, b2f, nch, x, C, C, stats=part, layout=lay)
                     stats = (ws.get("cm.ln.mean", (rows,), torch.float32), ws.get("cm.ln.rstd", (rows,), torch.float32))
-                    E.stats_finalize(part, rows, C // 128, C, stats[0], stats[1])
+                    E.stats_finalize_planar(part, rows, C, stats[0], stats[1])
                 else:
                     E.token_mlp(xt, sp, B * C, S, w1f, b1f, w2f, b2f, nch, x, C, C, layout=lay)
                 channel_mlp(ws, x, rows, C, pk, p + "ch.", C * ef, stats=stats)
