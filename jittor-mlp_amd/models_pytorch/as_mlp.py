@@ -11,13 +11,20 @@ The axial shift (utils/shift_cuda.py:44-72) runs as mlpk_shift_nhwc; conv2_2's e
 GELU and adds conv2_1's GELU output, conv3's and fc2's epilogues add the residual.
 DropPath is the identity in eval mode (as_mlp.py:144,159-160); `use_checkpoint` is accepted and ignored.
 """
+import os
+
 import torch
 from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Holder, head_linear
+from .common import Holder, finalize_stats, head_linear
 from .utils.shift import Shift
+
+# GroupNorm(1,C) statistics from the producing GEMMs' epilogues (mlpk.h row_part, per-sample groups).  Off by default: measured
+# SLOWER than the separate statistics pass on AS-MLP-T (the C = 96 / 192 GEMMs are short-K and epilogue-bound, and the statistics
+# pass over a whole sample runs at HBM speed); MLPK_ASMLP_EPILOGUE_STATS=1 switches it on (A/B runs, tests).
+EPILOGUE_STATS = os.environ.get("MLPK_ASMLP_EPILOGUE_STATS", "0") == "1"
 
 
 def to_2tuple(v):
@@ -246,6 +253,8 @@ class AS_MLP(E.EngineModule):
         E.gemm(patches, pk["embed.w"], cur, B * H * W, C, kp, bias=pk["embed.b"])
         if pe.norm is not None:
             self._gn(ws, "gn0", cur, B, H * W, C, pk["embed.g"], pk["embed.be"], cur)
+        have = False          # (mean, rstd) of the current layer already hold the per-sample statistics of `cur`
+        pending = None        # by-product partials of the PatchMerging GEMM that produced `cur`
         for li, layer in enumerate(self.layers):
             rows, HW = B * H * W, H * W
             t0 = ws.get("l%d.t0" % li, (rows, C))
@@ -262,29 +271,40 @@ class AS_MLP(E.EngineModule):
             fused = cd != torch.float32 and C % 8 == 0 and (C + self._shift - 1) // self._shift >= 8
             mean = ws.get(tag + ".mean", (B,), torch.float32)
             rstd = ws.get(tag + ".rstd", (B,), torch.float32)
+            have = finalize_stats(ws, pending, rows, C, tag=tag, group=HW) is not None
+            pending = None
 
-            def stats(t, width):
-                E.row_stats(t, B, HW * width, HW * width, mean, rstd)
+            def stats(t, width, got=None):
+                # per-sample statistics reduced from the per-row pairs of the GEMM that wrote t (mlpk.h row_part) when it delivered
+                # them (EPILOGUE_STATS), else a statistics pass over t
+                if finalize_stats(ws, got, rows, width, tag=tag, group=HW) is None:
+                    E.row_stats(t, B, HW * width, HW * width, mean, rstd)
 
+            part = (ws, "l%d.part" % li) if EPILOGUE_STATS else None
             for bi in range(len(layer.blocks)):
                 p = "l%d.b%d." % (li, bi)
                 if fused:
-                    stats(cur, C)
-                    E.gemm(cur, pk[p + "c1f.w"], t1, rows, C, C, bias=pk[p + "c1f.b"], ln=(mean, rstd, pk[p + "c1f.csum"]), ln_group=HW,
-                           tag="as_conv")                                                            # conv1(norm1(x))
-                    stats(t1, C)
+                    if not have:
+                        stats(cur, C)
+                    got = E.gemm(cur, pk[p + "c1f.w"], t1, rows, C, C, bias=pk[p + "c1f.b"], ln=(mean, rstd, pk[p + "c1f.csum"]), ln_group=HW,
+                                 tag="as_conv", part=part)                                           # conv1(norm1(x))
+                    stats(t1, C, got)
                     E.norm_shift_nhwc(t1, t0, t2, B, H, W, C, self._shift, mean, rstd, pk[p + "an1.g"], pk[p + "an1.b"], N.ACT_GELU)
                     E.gemm(t0, pk[p + "c21.w"], t1, rows, C, C, bias=pk[p + "c21.b"], act=N.ACT_GELU, tag="as_conv")      # x_lr (W shift)
-                    E.gemm(t2, pk[p + "c22.w"], t1, rows, C, C, bias=pk[p + "c22.b"], act=N.ACT_GELU, R=t1, res=N.RES_ADD,
-                           tag="as_conv")                                                            # gelu(.) + x_lr (H shift)
-                    stats(t1, C)
-                    E.gemm(t1, pk[p + "c3f.w"], cur, rows, C, C, bias=pk[p + "c3f.b"], ln=(mean, rstd, pk[p + "c3f.csum"]), ln_group=HW,
-                           R=cur, res=N.RES_ADD, tag="as_conv")                                      # x + conv3(norm2(.))
-                    stats(cur, C)
+                    got = E.gemm(t2, pk[p + "c22.w"], t1, rows, C, C, bias=pk[p + "c22.b"], act=N.ACT_GELU, R=t1, res=N.RES_ADD,
+                                 tag="as_conv", part=part)                                           # gelu(.) + x_lr (H shift)
+                    stats(t1, C, got)
+                    got = E.gemm(t1, pk[p + "c3f.w"], cur, rows, C, C, bias=pk[p + "c3f.b"], ln=(mean, rstd, pk[p + "c3f.csum"]), ln_group=HW,
+                                 R=cur, res=N.RES_ADD, tag="as_conv", part=part)                     # x + conv3(norm2(.))
+                    stats(cur, C, got)
                     E.gemm(cur, pk[p + "fc1f.w"], hbuf, rows, hid, C, bias=pk[p + "fc1f.b"], act=N.ACT_GELU,
                            ln=(mean, rstd, pk[p + "fc1f.csum"]), ln_group=HW, tag="as_fc1")
-                    E.gemm(hbuf, pk[p + "fc2.w"], cur, rows, C, hid, bias=pk[p + "fc2.b"], R=cur, res=N.RES_ADD, tag="as_fc2")
+                    got = E.gemm(hbuf, pk[p + "fc2.w"], cur, rows, C, hid, bias=pk[p + "fc2.b"], R=cur, res=N.RES_ADD, tag="as_fc2", part=part)
+                    # (mean, rstd) then describe `cur`: the next block's norm1, the PatchMerging norm (a permutation of the same
+                    # elements per sample, as_mlp.py:207-213) or the final norm start from them
+                    have = finalize_stats(ws, got, rows, C, tag=tag, group=HW) is not None
                     continue
+                have = False                                                                         # (each _gn below computes its own)
                 self._gn(ws, tag, cur, B, HW, C, pk[p + "n1.g"], pk[p + "n1.b"], t0)                 # norm1(x)
                 E.gemm(t0, pk[p + "c1.w"], t1, rows, C, C, bias=pk[p + "c1.b"], tag="as_conv")       # conv1
                 self._gn(ws, tag, t1, B, HW, C, pk[p + "an1.g"], pk[p + "an1.b"], t1, act=N.ACT_GELU)  # GN -> GELU
@@ -306,18 +326,24 @@ class AS_MLP(E.EngineModule):
                 E.patchify(cur, merged, B, C, H, W, 2, 2, 0, 4 * C, layout=N.LAYOUT_NHWC, px_stride=C, order=1)
                 nxt = ws.get("l%d.x" % (li + 1), (B * H2 * W2, 2 * C))
                 if cd != torch.float32:
-                    mm = ws.get("l%d.gnm.mean" % li, (B,), torch.float32)
-                    mr = ws.get("l%d.gnm.rstd" % li, (B,), torch.float32)
-                    E.row_stats(merged, B, H2 * W2 * 4 * C, H2 * W2 * 4 * C, mm, mr)
-                    E.gemm(merged, pk[p + "f.w"], nxt, B * H2 * W2, 2 * C, 4 * C, bias=pk[p + "f.b"], ln=(mm, mr, pk[p + "f.csum"]),
-                           ln_group=H2 * W2, tag="as_merge")
+                    if have:
+                        # GroupNorm(1, 4C) of the merged tensor (as_mlp.py:212) normalises over the same elements per sample as
+                        # a GroupNorm(1, C) of `cur` would: the statistics the last fc2 epilogue delivered are its statistics
+                        mm, mr = mean, rstd
+                    else:
+                        mm = ws.get("l%d.gnm.mean" % li, (B,), torch.float32)
+                        mr = ws.get("l%d.gnm.rstd" % li, (B,), torch.float32)
+                        E.row_stats(merged, B, H2 * W2 * 4 * C, H2 * W2 * 4 * C, mm, mr)
+                    pending = E.gemm(merged, pk[p + "f.w"], nxt, B * H2 * W2, 2 * C, 4 * C, bias=pk[p + "f.b"], ln=(mm, mr, pk[p + "f.csum"]),
+                                     ln_group=H2 * W2, tag="as_merge", part=(ws, "l%d.mpart" % li) if EPILOGUE_STATS else None)
                 else:
                     self._gn(ws, "l%d.gnm" % li, merged, B, H2 * W2, 4 * C, pk[p + "g"], pk[p + "b"], merged)
                     E.gemm(merged, pk[p + "w"], nxt, B * H2 * W2, 2 * C, 4 * C, tag="as_merge")
                 cur, H, W, C = nxt, H2, W2, 2 * C
-        mean = ws.get("final.mean", (B,), torch.float32)
-        rstd = ws.get("final.rstd", (B,), torch.float32)
-        E.row_stats(cur, B, H * W * C, H * W * C, mean, rstd)
+        if not have:
+            mean = ws.get("final.mean", (B,), torch.float32)
+            rstd = ws.get("final.rstd", (B,), torch.float32)
+            E.row_stats(cur, B, H * W * C, H * W * C, mean, rstd)
         pooled = ws.get("pooled", (B, C))
         E.pool_mean(cur, B, H * W, C, C, pooled, C, mean=mean, rstd=rstd, stat_group=H * W, gamma=pk["norm.g"], beta=pk["norm.b"])
         if not isinstance(self.head, nn.Linear):

@@ -13,12 +13,14 @@ mkdir -p profiles; cp $OUT/traffic.json profiles/r02_traffic.json
 echo "== bench (default)"; timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; python -c "
 import json; d=json.load(open('$OUT/bench.json')); print(d['value'], d['ms_per_step'], d['roofline'], d['cpu_baseline']['value'], d['cpu_baseline']['config1']['value'])"
 echo "== 2 ranks on one device"; timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --share-device --steps 20 --warmup 5 > $OUT/bench_2rank.json 2> $OUT/bench_2rank.err; tail -c 600 $OUT/bench_2rank.json
-bash tools/prof_model.sh mixer_b16 2>&1 | tail -12
+timeout 300 bash tools/prof_model.sh mixer_b16 < /dev/null 2>&1 | tail -12
 : > $OUT/bench_models.jsonl
-for m in mixer_s16 mixer_l16 gmlp_s resmlp_24 vip_s7 s2mlpv2 asmlp_t convmixer_1536_20 sparsemlp_t hiremlp_s msmlp_t swinmlp_t cyclemlp_b1; do timeout 300 python bench.py --model $m --steps 20 --warmup 5 --no-cpu-baseline >> $OUT/bench_models.jsonl 2>> $OUT/bench_models.err; done
+for m in mixer_s16 mixer_l16 gmlp_s resmlp_24 vip_s7 s2mlpv2 asmlp_t convmixer_1536_20 sparsemlp_t hiremlp_s msmlp_t swinmlp_t cyclemlp_b1; do timeout 200 python bench.py --model $m --steps 20 --warmup 5 --no-cpu-baseline < /dev/null >> $OUT/bench_models.jsonl 2>> $OUT/bench_models.err; done
 python - <<'PY'
 import json
 for l in open("gpurun_out/final/bench_models.jsonl"):
     d = json.loads(l)
     print("%-40s %10.1f img/s %8.2f ms  %7.1f model-TF/s" % (d["metric"], d["value"], d["ms_per_step"], d["model_tflops"]))
 PY
+for m in vip_s7 gmlp_s; do timeout 200 bash tools/prof_model.sh $m < /dev/null 2>&1 | tail -9; done
+echo "== epilogue statistics A/B"; timeout 400 bash tools/gpu_stats.sh < /dev/null > $OUT/epilogue_stats_ab.txt 2>&1; cat $OUT/epilogue_stats_ab.txt
