@@ -37,6 +37,54 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_SIDE = {}
+
+
+def side_stream(device):
+    """One extra stream per device for small, latency-bound kernel chains that are independent of the big kernels issued next
+    (ViP's SplitAttention MLP beside the branch GEMMs); None when MLPK_NO_SIDE_STREAM=1.  Fork / join are events on both sides:
+        ev = torch.cuda.Event(); ev.record(); with torch.cuda.stream(side): side.wait_event(ev); ...; done.record(side)
+        ...; torch.cuda.current_stream().wait_event(done)"""
+    if os.environ.get("MLPK_NO_SIDE_STREAM", "0") == "1":
+        return None
+    key = (device.type, device.index)
+    st = _SIDE.get(key)
+    if st is None:
+        st = _SIDE[key] = torch.cuda.Stream(device=device)
+    return st
+
+
+class SideChain:
+    """`with chain: <launches>` puts the launches on the device's side stream, ordered after everything issued so far on the
+    current stream (fork event); `chain.join()` makes the current stream wait for them.  What runs inside must touch only buffers
+    that nothing issued between the `with` block and join() touches.  With MLPK_NO_SIDE_STREAM=1 the launches simply stay on
+    the current stream."""
+
+    def __init__(self, ws, name, device):
+        self.side = side_stream(device)
+        self.main = torch.cuda.current_stream()
+        if self.side is not None:
+            self.fork_ev, self.join_ev = ws.get_event(name + ".fork"), ws.get_event(name + ".join")
+
+    def __enter__(self):
+        if self.side is not None:
+            self.fork_ev.record(self.main)
+            self.side.wait_event(self.fork_ev)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.side is not None:
+            self.join_ev.record(self.side)
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self):
+        if self.side is not None:
+            self.main.wait_event(self.join_ev)
+
+
 def on_device(x):
     """Context manager: x's device current (hipSetDevice + torch's per-device current stream)."""
     return torch.cuda.device(x.device)
@@ -389,6 +437,13 @@ class Workspace:
             t = torch.full(shape, fill, dtype=dtype or self.dtype, device=self.device)
             self.t[name] = t
         return t
+
+    def get_event(self, name):
+        """A named, reusable torch.cuda.Event (fork / join of a side stream)."""
+        ev = self.t.get(("event", name))
+        if ev is None:
+            ev = self.t[("event", name)] = torch.cuda.Event()
+        return ev
 
 
 class EngineModule(torch.nn.Module):

@@ -190,11 +190,16 @@ class HireMLP(E.EngineModule):
                 mean, rstd = st if st is not None else layernorm_stats(ws, cur, rows, C, tag="l%d.ln" % li)
                 E.norm_apply(cur, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "ln.g"], beta=pk[p + "ln.b"], out_rm=xn, ld_rm=C)
                 E.hire_gather(xn, a_h, a_w, B, H, W, C, h, w, step, h * C, w * C)
+                # the w-branch pair of GEMMs touches only a_w / t_w: it runs on a side stream beside the h-branch pair and proj_c
+                # (short GEMMs of 20-50 us each: two kernels in flight fill the tail of each other's last wave of tiles)
+                chain = E.SideChain(ws, "hire.w", cur.device)
+                with chain:
+                    E.gemm(a_w, pk[p + "w1.w"], t_w, rows_w, hid, w * C, bias=pk[p + "w1.b"], act=N.ACT_GELU, tag="hire_fc1")
+                    E.gemm(t_w, pk[p + "w2.w"], a_w, rows_w, w * C, hidp, bias=pk[p + "w2.b"], tag="hire_fc2")
                 E.gemm(a_h, pk[p + "h1.w"], t_h, rows_h, hid, h * C, bias=pk[p + "h1.b"], act=N.ACT_GELU, tag="hire_fc1")
                 E.gemm(t_h, pk[p + "h2.w"], a_h, rows_h, h * C, hidp, bias=pk[p + "h2.b"], tag="hire_fc2")    # y_h overwrites a_h
-                E.gemm(a_w, pk[p + "w1.w"], t_w, rows_w, hid, w * C, bias=pk[p + "w1.b"], act=N.ACT_GELU, tag="hire_fc1")
-                E.gemm(t_w, pk[p + "w2.w"], a_w, rows_w, w * C, hidp, bias=pk[p + "w2.b"], tag="hire_fc2")
                 E.gemm(xn, pk[p + "c.w"], cur, rows, C, C, bias=pk[p + "c.b"], R=cur, res=N.RES_ADD, tag="hire_c")   # x + proj_c(xn)
+                chain.join()
                 E.hire_combine(cur, a_h, a_w, B, H, W, C, h, w, step, h * C, w * C)
                 got = channel_mlp(ws, cur, rows, C, pk, p + "ff.", C * ef, tag="l%d.cm" % li, part=(ws, "l%d.fc2.part" % li))
                 st = finalize_stats(ws, got, rows, C, tag="l%d.ln" % li)

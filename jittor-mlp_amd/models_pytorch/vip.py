@@ -176,6 +176,22 @@ class _PermutatorBase(E.EngineModule):
                          out_ph=ph, H=H, W=W, seg=seg, ld_p=ldh, sum_ph=asum[:, ldh:] if lin else None, ld_sum=ldh + ldw)
             E.norm_apply(x, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "ln.g"], beta=pk[p + "ln.b"],
                          out_pw=pw, H=H, W=W, seg=seg, ld_p=ldw, sum_pw=asum, ld_sum=ldh + ldw)
+            bar = None
+            if lin:
+                # SplitAttention's weights from the by-product sums: two tiny fp32 GEMMs instead of a 600 MB pass over the three
+                # branch outputs, then mlp2 + softmax.  Four latency-bound kernels (~80 us in a row on a few CUs) that depend only
+                # on the rearrange passes above: they run on a side stream BESIDE the three branch GEMMs below and are joined in
+                # front of the weighted sum.
+                chain = E.SideChain(ws, "sa", x.device)
+                with chain:
+                    t = ws.get("sa.t", (B, C), torch.float32)
+                    o = ws.get("sa.o", (B * G, 2 * seg), torch.float32)
+                    E.gemm(asum, pk[p + "sa.w1"], o, B * G, 2 * seg, ldh + ldw, bias=pk[p + "sa.b1"])
+                    E.gemm(o.view(B, G * 2 * seg), pk[p + "sa.m1w2"], t, B, C, G * 2 * seg, bias=pk[p + "sa.m1b"], act=N.ACT_GELU)
+                    hat = ws.get("sa.hat", (B, 3 * C), torch.float32)
+                    E.gemm(t, pk[p + "sa.m2"], hat, B, 3 * C, C)
+                    bar = ws.get("sa.bar", (B, 3 * C), torch.float32)
+                    E.split_softmax(hat, bar, B, C)
             ldzh, ldzw = E.round_up(hs, 8), E.round_up(wsz, 8)
             zh = ws.get("vip.zh", (B * W * G, ldzh))
             zw = ws.get("vip.zw", (B * H * G, ldzw))
@@ -191,15 +207,7 @@ class _PermutatorBase(E.EngineModule):
                 # the inverse rearranges (vip.py:71,76) are load addresses of the split-attention kernels: xH / xW are never
                 # written back in (B,H,W,C) order (two full-tensor passes per block fewer)
                 if self.weighted:
-                    # two tiny fp32 GEMMs on the by-product sums instead of a 600 MB pass over the three branch outputs
-                    t = ws.get("sa.t", (B, C), torch.float32)
-                    o = ws.get("sa.o", (B * G, 2 * seg), torch.float32)
-                    E.gemm(asum, pk[p + "sa.w1"], o, B * G, 2 * seg, ldh + ldw, bias=pk[p + "sa.b1"])
-                    E.gemm(o.view(B, G * 2 * seg), pk[p + "sa.m1w2"], t, B, C, G * 2 * seg, bias=pk[p + "sa.m1b"], act=N.ACT_GELU)
-                    hat = ws.get("sa.hat", (B, 3 * C), torch.float32)
-                    E.gemm(t, pk[p + "sa.m2"], hat, B, 3 * C, C)
-                    bar = ws.get("sa.bar", (B, 3 * C), torch.float32)
-                    E.split_softmax(hat, bar, B, C)
+                    chain.join()
                 else:
                     bar = ws.get("vip.ones", (B, 3 * C), torch.float32, fill=1.0)     # plain sum (vip.py:16-22)
                 E.vip_split_apply(zh, zw, xc, ldzh, ldzw, C, B, H, W, C, seg, bar, m, C)
