@@ -56,6 +56,38 @@ def test_argument_validation_without_gpu():
     assert b"stride" in lib.mlpk_strerror(-2)
 
 
+def test_gemm_row_parts_plan_without_gpu():
+    """mlpk_gemm_row_parts is host logic (validation + the tile choice mlpk_gemm_nt would make): planes of the by-product row
+    statistics per shape, and the descriptors that cannot deliver them."""
+    pkg = load_pkg()
+    N = pkg._native
+    lib = N.lib()
+
+    def parts(dtype, M, Nn, K, res=False, act=0, out_mode=0, algo=0, ldc=None):
+        d = N.GemmDesc()
+        d.dtype, d.M, d.N, d.K, d.lda, d.ldb, d.ldc = dtype, M, Nn, K, K, K, ldc or Nn
+        d.A = d.B = d.C = 1 << 20
+        if res:
+            d.R, d.ldr, d.res_mode = 1 << 20, Nn, N.RES_ADD
+        d.act, d.out_mode, d.algo = act, out_mode, algo
+        if out_mode:
+            d.t_rows, d.t_tokens = 8, Nn
+        n = ctypes.c_int(-1)
+        return lib.mlpk_gemm_row_parts(ctypes.byref(d), ctypes.byref(n)), n.value
+
+    assert parts(N.BF16, 262144, 384, 384, res=True) == (0, 3)        # ViP proj: 128-column blocks of the LDS-staged epilogue
+    assert parts(N.F16, 1000, 96, 64) == (0, 1)                       # ragged rows, one partial block
+    assert parts(N.BF16, 50176, 256, 768, res=True) == (0, 8)         # gMLP proj_out on the persistent tile: 32-column blocks
+    assert parts(N.BF16, 50176, 256, 768, res=False) == (0, 2)        # ... without a residual it has no statistics class: other tiles
+    assert parts(N.BF16, 50176, 256, 768, res=True, algo=11) == (0, 2)
+    assert parts(N.F32, 1024, 384, 384)[0] != 0                       # fp32
+    assert parts(N.BF16, 1024, 196, 384, out_mode=N.OUT_TOKEN_T)[0] != 0
+    assert parts(N.BF16, 1024, 100, 64)[0] != 0                       # N not a multiple of 8
+    assert parts(N.BF16, 1024, 128, 64, algo=5)[0] != 0               # 64-column tiles
+    assert parts(N.BF16, 1024, 128, 64, ldc=132)[0] != 0              # rows of C not 16-byte aligned
+    assert lib.mlpk_stats_finalize_planar(None, 1, 1, 1, 1, 1, 1e-5, None, None, None) != 0
+
+
 def test_constructor_signatures_match_reference():
     pkg = load_pkg()
     with open(os.path.join(GOLDEN, "manifest.json")) as f:
