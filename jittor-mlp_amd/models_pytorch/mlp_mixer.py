@@ -22,26 +22,112 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Holder, channel_mlp, embed_patches, head_linear, layernorm_stats, pack_channel_mlp
+from .common import channel_mlp, embed_patches, head_linear, layernorm_stats, pack_channel_mlp
 from .utils.tools import check_sizes, pair
 
 
-class PreNormResidual(Holder):
-    """fn(LayerNorm(x)) + x  (mlp_mixer.py:6-13): holds `fn` and `norm`."""
+class _SubModule(E.EngineModule):
+    """Base of the Mixer sub-modules that the reference lets a caller run on their own (`model.model[i]`, `model.model[i][0]`,
+    `...fn`): their own packed weights and workspace, the same HIP kernels as the enclosing model's forward."""
+
+    def _begin(self, x, width):
+        E.require_gpu(x, type(self).__name__ + ".forward")
+        E.dtype_code(x.dtype)
+        if x.dim() < 2 or x.shape[-1] != width:
+            raise ValueError("expected a (..., %d) tensor" % width)
+        return self._get_pack(x.dtype, x.device)
+
+
+class FeedForward(_SubModule):
+    """dense -> GELU -> Dropout -> dense -> Dropout (mlp_mixer.py:16-27); parameters at net.0 / net.3.
+    dense = nn.Linear: acts on the last dimension.  dense = Conv1d(kernel_size=1): acts on dimension 1 of a (B, S, C) tensor
+    (the token-mixing MLP: the S tokens are the convolution's channels)."""
+
+    def __init__(self, dim, hidden_dim, dropout=0., dense=nn.Linear):
+        super().__init__()
+        self.net = nn.Sequential(dense(dim, hidden_dim), nn.GELU(), nn.Dropout(dropout),
+                                 dense(hidden_dim, dim), nn.Dropout(dropout))
+        self.__dict__["_token"] = not isinstance(self.net[0], nn.Linear)
+        self.__dict__["_dims"] = (dim, hidden_dim)
+
+    def _pack(self, dtype, device):
+        kpad = 32 if self._token else 8
+        return {"fc1.w": E.pack_matrix(self.net[0].weight, dtype, device, kpad=kpad), "fc1.b": E.f32(self.net[0].bias, device),
+                "fc2.w": E.pack_matrix(self.net[3].weight, dtype, device, kpad=kpad), "fc2.b": E.f32(self.net[3].bias, device)}
+
+    def _token_products(self, ws, pk, xt, B, S, C, out, R=None):
+        """out[b, t, c] (+= R) = sum_h W2[t, h] gelu(sum_s W1[h, s] xt[b*C + c, s] + b1[h]) + b2[t]; xt = (B*C, S_pad), zero padded."""
+        th = self._dims[1]
+        thp = pk["fc2.w"].shape[1]
+        ht = ws.get("ff.h", (B * C, thp))
+        E.gemm(xt, pk["fc1.w"], ht, B * C, th, xt.shape[1], bias=pk["fc1.b"], act=N.ACT_GELU)
+        E.gemm(ht, pk["fc2.w"], out, B * C, S, thp, ldc=C, bias=pk["fc2.b"], R=R, ldr=C if R is not None else None,
+               res=N.RES_ADD if R is not None else N.RES_NONE, out_mode=N.OUT_TOKEN_T, t_rows=C, t_tokens=S)
+
+    def forward(self, x):
+        dim, hidden = self._dims
+        if not self._token:
+            pk = self._begin(x, dim)
+            rows = x.numel() // dim
+            ws = self._get_space(rows, x.dtype, x.device)
+            xb = ws.get("ff.x", (rows, pk["fc1.w"].shape[1]))            # K zero-padded to whole 16-byte chunks
+            xb[:, :dim].copy_(x.reshape(rows, dim))
+            h = ws.get("ff.hid", (rows, pk["fc2.w"].shape[1]))
+            y = ws.get("ff.y", (rows, dim))
+            E.gemm(xb, pk["fc1.w"], h, rows, hidden, xb.shape[1], bias=pk["fc1.b"], act=N.ACT_GELU)
+            E.gemm(h, pk["fc2.w"], y, rows, dim, h.shape[1], bias=pk["fc2.b"])
+            return y.reshape(x.shape).clone()
+        if x.dim() != 3 or x.shape[1] != dim:
+            raise ValueError("expected a (B, %d, C) tensor" % dim)
+        B, S, C = x.shape
+        pk = self._begin(x, C)
+        ws = self._get_space(B * S * C, x.dtype, x.device)
+        xb = ws.get("ff.x", (B * S, C))
+        xb.copy_(x.reshape(B * S, C))
+        xt = ws.get("ff.xt", (B * C, pk["fc1.w"].shape[1]))
+        E.norm_apply(xb, B * S, C, C, out_tt=xt, S=S, ld_tt=xt.shape[1])    # plain per-image transpose
+        y = ws.get("ff.y", (B * S, C))
+        self._token_products(ws, pk, xt, B, S, C, y)
+        return y.reshape(B, S, C).clone()
+
+
+class PreNormResidual(_SubModule):
+    """fn(LayerNorm(x)) + x  (mlp_mixer.py:6-13): holds `fn` and `norm`; callable on (B, S, C) tokens like the reference's."""
 
     def __init__(self, dim, fn):
         super().__init__()
         self.fn = fn
         self.norm = nn.LayerNorm(dim)
 
+    def _pack(self, dtype, device):
+        pk = {}
+        if isinstance(self.fn, FeedForward) and not self.fn._token:
+            pack_channel_mlp(pk, "", self.norm, self.fn.net[0], self.fn.net[3], dtype, device)
+        else:
+            pk["ln.g"], pk["ln.b"] = E.f32(self.norm.weight, device), E.f32(self.norm.bias, device)
+        return pk
 
-class FeedForward(Holder):
-    """dense -> GELU -> Dropout -> dense -> Dropout (mlp_mixer.py:16-27); parameters at net.0 / net.3."""
-
-    def __init__(self, dim, hidden_dim, dropout=0., dense=nn.Linear):
-        super().__init__()
-        self.net = nn.Sequential(dense(dim, hidden_dim), nn.GELU(), nn.Dropout(dropout),
-                                 dense(hidden_dim, dim), nn.Dropout(dropout))
+    def forward(self, x):
+        if not isinstance(self.fn, FeedForward):
+            raise NotImplementedError("PreNormResidual runs on its own around a FeedForward only; call the enclosing model")
+        C = self.norm.normalized_shape[0]
+        pk = self._begin(x, C)
+        rows = x.numel() // C
+        ws = self._get_space(rows, x.dtype, x.device)
+        xb = ws.get("pn.x", (rows, C))
+        xb.copy_(x.reshape(rows, C))
+        if not self.fn._token:
+            channel_mlp(ws, xb, rows, C, pk, "", self.fn._dims[1], eps=self.norm.eps)
+            return xb.reshape(x.shape).clone()
+        if x.dim() != 3 or x.shape[1] != self.fn._dims[0]:
+            raise ValueError("expected a (B, %d, %d) tensor" % (self.fn._dims[0], C))
+        B, S, _ = x.shape
+        fpk = self.fn._get_pack(x.dtype, x.device)
+        mean, rstd = layernorm_stats(ws, xb, rows, C, eps=self.norm.eps)
+        xt = ws.get("pn.xt", (B * C, fpk["fc1.w"].shape[1]))
+        E.norm_apply(xb, rows, C, C, mean=mean, rstd=rstd, gamma=pk["ln.g"], beta=pk["ln.b"], out_tt=xt, S=S, ld_tt=xt.shape[1])
+        self.fn._token_products(ws, fpk, xt, B, S, C, xb, R=xb)
+        return xb.reshape(B, S, C).clone()
 
 
 class MLPMixer(E.EngineModule):

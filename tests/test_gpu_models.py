@@ -251,6 +251,54 @@ def test_backbone_forward_tokens():
     assert (out.cpu() - ref).abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_mixer_submodules_callable_like_the_reference(dtype):
+    """mlp_mixer.py:6-27,33-38: `model.model[i]` (a block), `[i][0]` / `[i][1]` (token / channel PreNormResidual) and their `.fn`
+    (FeedForward over Conv1d(k=1) / Linear) run on their own in the reference; here they do too, through the same HIP kernels, and
+    chaining the blocks by hand reproduces the backbone's forward."""
+    import torch.nn.functional as F
+    pkg = load_pkg()
+    mp = pkg.models_pytorch
+    S, C, depth, ef = 49, 64, 2, 2
+    torch.manual_seed(3)
+    bb = mp.MLPMixer(num_patches=S, d_model=C, depth=depth, expansion_factor=ef).eval()
+    for p in bb.parameters():
+        p.data.add_(0.05 * torch.randn_like(p))            # non-trivial LayerNorm gamma / beta, biases
+    x = torch.randn(3, S, C)
+    xd = x.to(dtype).double()
+
+    def ff_ref(ff, v, token):
+        w1, b1, w2, b2 = (t.detach().double() for t in (ff.net[0].weight, ff.net[0].bias, ff.net[3].weight, ff.net[3].bias))
+        if token:                                          # Conv1d(kernel_size=1) over dimension 1
+            w1, w2 = w1.squeeze(-1), w2.squeeze(-1)
+            h = oracle.gelu(torch.einsum("hs,bsc->bhc", w1, v) + b1.view(1, -1, 1))
+            return torch.einsum("sh,bhc->bsc", w2, h) + b2.view(1, -1, 1)
+        return F.linear(oracle.gelu(F.linear(v, w1, b1)), w2, b2)
+
+    def pn_ref(pn, v, token):
+        n = F.layer_norm(v, (C,), pn.norm.weight.detach().double(), pn.norm.bias.detach().double(), pn.norm.eps)
+        return ff_ref(pn.fn, n, token) + v
+
+    tol = 2e-5 if dtype == torch.float32 else 6e-2
+    blk = bb.model[0]
+    cases = [(blk[0].fn, ff_ref(blk[0].fn, xd, True)), (blk[1].fn, ff_ref(blk[1].fn, xd, False)),
+             (blk[0], pn_ref(blk[0], xd, True)), (blk[1], pn_ref(blk[1], xd, False)),
+             (blk, pn_ref(blk[1], pn_ref(blk[0], xd, True), False))]         # references from the CPU parameters, in float64
+    bb = bb.to(DEV)
+    xg = x.to(DEV).to(dtype)
+    for mod, ref in cases:
+        got = mod(xg)
+        assert got.dtype == dtype and got.shape == ref.shape
+        err = (got.double().cpu() - ref).abs().max().item()
+        assert err < tol * max(1.0, ref.abs().max().item()), (type(mod).__name__, str(dtype), err)
+    # the blocks chained by hand == the backbone (same kernels up to the fused token kernel's rounding of the hidden)
+    chained = bb.model(xg)
+    whole = bb(xg)
+    assert (chained.double() - whole.double()).abs().max().item() < tol * max(1.0, whole.abs().max().item())
+    with pytest.raises(NotImplementedError):
+        blk[0](x)                                          # CPU tensor: no fallback
+
+
 def test_cpu_input_raises():
     pkg = load_pkg()
     model = pkg.MLPMixerForImageClassification(d_model=32, depth=1, patch_size=8, image_size=32, num_classes=10)
