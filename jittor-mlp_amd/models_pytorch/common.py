@@ -15,6 +15,23 @@ class Holder(nn.Module):
         raise NotImplementedError("%s only holds parameters; call the enclosing model" % type(self).__name__)
 
 
+class Block(Holder):
+    """A parameter container that is one WHOLE block of a backbone (the unit the reference's nn.Sequential chains): callable on its
+    own like the reference's, through the owning backbone's packed weights and kernels (`backbone._run_single(index, x)`)."""
+
+    def forward(self, x):
+        owner = self.__dict__.get("_owner")
+        if owner is None:
+            return super().forward(x)
+        return owner[0]._run_single(owner[1], x)
+
+
+def adopt_blocks(backbone, blocks):
+    """Tell every block which backbone runs it (a plain reference kept out of the module tree: no extra state_dict keys)."""
+    for i, b in enumerate(blocks):
+        b.__dict__["_owner"] = (backbone, i)
+
+
 def embed_patches(ws, name, x, w_packed, bias, cdtype, patch, pad=0, out=None):
     """Conv2d(k = stride = patch) on an NCHW input -> channel-last tokens (B*Hp*Wp, Cout).
     mlp_mixer.py:58-60,68-71; conv_mixer.py:18."""

@@ -7,12 +7,14 @@ v half is written token-transposed (reads the half in place through its row stri
 copy); the spatial GEMM's epilogue adds the per-token bias, multiplies by u (read in place from h)
 and stores through the per-image transpose; proj2 GEMM adds bias + residual.
 """
+import contextlib
+
 import torch
 from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Holder, embed_patches, finalize_stats, head_linear, layernorm_stats
+from .common import Block, Holder, adopt_blocks, embed_patches, finalize_stats, head_linear, layernorm_stats
 from .utils.tools import check_sizes, pair
 
 
@@ -26,8 +28,8 @@ class SpatialGatingUnit(Holder):
         nn.init.constant_(self.spatial_proj.bias, 1.0)
 
 
-class gMLPBlock(Holder):
-    """g_mlp.py:24-39; channel_proj1 is 2*d_ffn wide (:28)."""
+class gMLPBlock(Block):
+    """g_mlp.py:24-39; channel_proj1 is 2*d_ffn wide (:28).  Callable on (B, S, C) tokens once it sits in a gMLP backbone."""
 
     def __init__(self, d_model, d_ffn, seq_len):
         super().__init__()
@@ -44,6 +46,7 @@ class gMLP(E.EngineModule):
         super().__init__()
         self.model = nn.Sequential(*[gMLPBlock(d_model, d_ffn, seq_len) for _ in range(depth)])
         self._dims = (seq_len, d_model, d_ffn, depth)
+        adopt_blocks(self, self.model)
 
     def _pack_blocks(self, pk, dtype, device):
         for i, blk in enumerate(self.model):
@@ -65,12 +68,12 @@ class gMLP(E.EngineModule):
         self._pack_blocks(pk, dtype, device)
         return pk
 
-    def _run_blocks(self, ws, pk, x, B):
+    def _run_blocks(self, ws, pk, x, B, only=None):
         S, C, F, depth = self._dims
         rows = B * S
         sp = E.round_up(S, 32)        # token K padding: whole half-slabs -> direct-to-LDS GEMM tiles
         nxt = None
-        for i in range(depth):
+        for i in (range(depth) if only is None else only):
             p = "b%d." % i
             # the block's LayerNorm (g_mlp.py:40) reads what the previous block's proj_out + residual GEMM wrote: its statistics
             # come out of that epilogue (mlpk.h row_part)
@@ -97,11 +100,11 @@ class gMLP(E.EngineModule):
             else:
                 E.gemm(vt, pk[p + "sp.w"], g, B * F, S, sp, ldc=F, bias=pk[p + "sp.b"], R=h, ldr=2 * F, res=N.RES_MUL,
                        out_mode=N.OUT_TOKEN_T, t_rows=F, t_tokens=S)
-            got = E.gemm(g, pk[p + "p2.w"], x, rows, C, F, bias=pk[p + "p2.b"], R=x, res=N.RES_ADD, part=(ws, "p2.part") if i + 1 < depth else None)
+            got = E.gemm(g, pk[p + "p2.w"], x, rows, C, F, bias=pk[p + "p2.b"], R=x, res=N.RES_ADD, part=(ws, "p2.part") if only is None and i + 1 < depth else None)
             nxt = finalize_stats(ws, got, rows, C)
         return x
 
-    def forward(self, x):
+    def forward(self, x, _only=None):
         E.require_gpu(x, "gMLP.forward")
         S, C, _, _ = self._dims
         if x.dim() != 3 or x.shape[1] != S or x.shape[2] != C:
@@ -111,8 +114,13 @@ class gMLP(E.EngineModule):
         ws = self._get_space(B, x.dtype, x.device)
         buf = ws.get("x", (B * S, C))
         buf.copy_(x.reshape(B * S, C))
-        self._run_blocks(ws, pk, buf, B)
+        self._run_blocks(ws, pk, buf, B, only=_only)
         return buf.reshape(B, S, C).clone()
+
+    def _run_single(self, i, x):
+        """block i alone, (B, S, C) -> (B, S, C): what `model.model[i](x)` computes in the reference (g_mlp.py:33-39)"""
+        with E.on_device(x) if x.is_cuda else contextlib.nullcontext():
+            return gMLP.forward(self, x, _only=[i])       # (the image-classification subclass overrides forward)
 
 
 class gMLPForImageClassification(gMLP):

@@ -7,12 +7,14 @@ bias, the per-channel gamma_1 (a per-ROW scale in the transposed problem) and th
 storing through the transpose; a second affine pass; FF as two GEMMs whose second epilogue applies
 gamma_2 and the residual.
 """
+import contextlib
+
 import torch
 from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Holder, embed_patches, head_linear
+from .common import Block, Holder, adopt_blocks, embed_patches, head_linear
 from .utils.tools import check_sizes, pair
 
 
@@ -32,8 +34,8 @@ class FeedForward(Holder):
                                  nn.Linear(hidden_dim, dim), nn.Dropout(dropout))
 
 
-class MLPblock(Holder):
-    """res_mlp.py:34-57; layer-scale init by depth (:38-43)."""
+class MLPblock(Block):
+    """res_mlp.py:34-57; layer-scale init by depth (:38-43).  Callable on (B, S, C) tokens once it sits in a ResMLP backbone."""
 
     def __init__(self, num_patch, dim, mlp_dim, dropout=0., depth=18):
         super().__init__()
@@ -57,6 +59,7 @@ class ResMLP(E.EngineModule):
         self.model = nn.Sequential(*[MLPblock(num_patch, d_model, d_model * expansion_factor, depth=depth)
                                      for _ in range(depth)])
         self._dims = (num_patch, d_model, depth, expansion_factor)
+        adopt_blocks(self, self.model)
 
     def _pack_blocks(self, pk, dtype, device):
         for i, blk in enumerate(self.model):
@@ -79,12 +82,12 @@ class ResMLP(E.EngineModule):
         self._pack_blocks(pk, dtype, device)
         return pk
 
-    def _run_blocks(self, ws, pk, x, B):
+    def _run_blocks(self, ws, pk, x, B, only=None):
         S, C, depth, ef = self._dims
         rows = B * S
         sp = E.round_up(S, 32)        # token K padding: whole half-slabs -> direct-to-LDS GEMM tiles
         hidden = C * ef
-        for i in range(depth):
+        for i in (range(depth) if only is None else only):
             p = "b%d." % i
             xt = ws.get("xt", (B * C, sp))
             # x1 = alpha*x + beta, in place, plus its token-transposed copy for the token GEMM
@@ -104,7 +107,7 @@ class ResMLP(E.EngineModule):
             E.gemm(h, pk[p + "fc2.w"], x, rows, C, hidden, bias=pk[p + "fc2.b"], cscale=pk[p + "g2"], R=x, res=N.RES_ADD)
         return x
 
-    def forward(self, x):
+    def forward(self, x, _only=None):
         E.require_gpu(x, "ResMLP.forward")
         S, C, _, _ = self._dims
         if x.dim() != 3 or x.shape[1] != S or x.shape[2] != C:
@@ -114,8 +117,13 @@ class ResMLP(E.EngineModule):
         ws = self._get_space(B, x.dtype, x.device)
         buf = ws.get("x", (B * S, C))
         buf.copy_(x.reshape(B * S, C))
-        self._run_blocks(ws, pk, buf, B)
+        self._run_blocks(ws, pk, buf, B, only=_only)
         return buf.reshape(B, S, C).clone()
+
+    def _run_single(self, i, x):
+        """block i alone, (B, S, C) -> (B, S, C): what `model.model[i](x)` computes in the reference (res_mlp.py:50-57)"""
+        with E.on_device(x) if x.is_cuda else contextlib.nullcontext():
+            return ResMLP.forward(self, x, _only=[i])       # (the image-classification subclass overrides forward)
 
 
 class ResMLPForImageClassification(ResMLP):

@@ -299,6 +299,37 @@ def test_mixer_submodules_callable_like_the_reference(dtype):
         blk[0](x)                                          # CPU tensor: no fallback
 
 
+def test_gmlp_resmlp_blocks_callable_like_the_reference():
+    """g_mlp.py:33-39, res_mlp.py:50-57: `model.model[i](x)` runs one block on (B, S, C) tokens in the reference; here the block
+    calls back into its backbone (same packed weights, same kernels) -- also inside the image-classification models -- and
+    chaining the blocks by hand reproduces the whole backbone."""
+    pkg = load_pkg()
+    mp = pkg.models_pytorch
+    torch.manual_seed(5)
+    cases = [(mp.gMLP(d_model=32, d_ffn=64, seq_len=16, depth=2), oracle.functional.gmlp_block, (16, 32)),
+             (mp.ResMLP(16, 32, 2, 2), oracle.functional.resmlp_block, (16, 32)),
+             (mp.gMLPForImageClassification(image_size=32, patch_size=8, d_model=32, d_ffn=64, depth=2, num_classes=10),
+              oracle.functional.gmlp_block, (16, 32))]
+    for model, block_ref, (S, C) in cases:
+        model = model.eval()
+        for p in model.parameters():
+            p.data.add_(0.05 * torch.randn_like(p))
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        t = torch.randn(3, S, C)
+        model = model.to(DEV)
+        cur = t.to(DEV)
+        ref = t.clone()
+        for i in range(2):
+            ref = block_ref(sd, ref, "model.%d." % i)
+            cur = model.model[i](cur)
+            assert (cur.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), (type(model).__name__, i)
+        if not type(model).__name__.endswith("Classification"):
+            assert (model(t.to(DEV)).cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    lone = mp.g_mlp.gMLPBlock(32, 64, 16)
+    with pytest.raises(NotImplementedError):
+        lone(torch.randn(1, 16, 32).to(DEV))                      # a block outside a backbone stays a parameter container
+
+
 def test_cpu_input_raises():
     pkg = load_pkg()
     model = pkg.MLPMixerForImageClassification(d_model=32, depth=1, patch_size=8, image_size=32, num_classes=10)
