@@ -151,7 +151,7 @@ typedef struct mlpk_gemm_desc {
 } mlpk_gemm_desc;
 
 int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream);
-/* pairs per row that mlpk_gemm_nt would write for this descriptor (row_part may still be NULL); an error code when the
+/* planes (pairs per row) that mlpk_gemm_nt would write for this descriptor (row_part may still be NULL); an error code when the
    descriptor cannot deliver statistics (fp32, token-transposed output, unaligned rows, an explicit algo with 64-column tiles) */
 int mlpk_gemm_row_parts(const mlpk_gemm_desc* d, int* nparts);
 /* 0 (no kernel needs scratch) */
@@ -191,7 +191,7 @@ int mlpk_token_mlp_layout(int S, int nchunks);
 int mlpk_token_gemm(int dtype, const void* xt, int ldxt, int M, int S, const void* w, int ldw, const float* bias, int ngroups,
                     const float* rscale, int rperiod, const void* R, int ldr, int res_mode, void* out, int ldo, int t_rows,
                     void* stream);
-/* `stats` (optional, t_rows % 128 == 0): the statistics of the LayerNorm that follows (mlp_mixer.py:38) come out of the epilogue:
+/* mlpk_token_mlp's `stats` (optional, t_rows % 128 == 0): the statistics of the LayerNorm that follows (mlp_mixer.py:38) come out of the epilogue:
  * stats[(tile*B*S + b*S + s)*2 + {0,1}] = sum / sum of squares over the tile's 128 channels of the values written to x[b,s,:]
  * (planar: t_rows/128 planes of B*S pairs, B = M / t_rows).  mlpk_stats_finalize_planar(stats, B*S, t_rows/128, B*S, 1, t_rows, ..)
  * reduces the partials of a row to mean / rstd. */
