@@ -25,7 +25,7 @@ from torch.nn import init
 
 from .. import _native as N
 from .. import engine as E
-from .common import Holder, channel_mlp, finalize_stats, head_linear, layernorm_stats, pack_channel_mlp
+from .common import Block, Holder, channel_mlp, finalize_stats, head_linear, layernorm_stats, pack_channel_mlp
 from .utils import pair
 
 
@@ -108,8 +108,9 @@ class CycleMLP(Holder):
         self.proj_drop = nn.Dropout(proj_drop)
 
 
-class CycleBlock(Holder):
-    """cycle_mlp.py:178-197 (DropPath is the identity on the forward path built here)."""
+class CycleBlock(Block):
+    """cycle_mlp.py:178-197 (DropPath is the identity on the forward path built here).  Callable on channel-last (B, H, W, C) like the
+    reference's once it sits in a CycleNet."""
 
     def __init__(self, dim, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0., drop_path=0., act_layer=nn.GELU,
                  norm_layer=nn.LayerNorm, skip_lam=1.0, mlp_fn=CycleMLP):
@@ -177,6 +178,10 @@ class CycleNet(E.EngineModule):
             if transitions[i] or embed_dims[i] != embed_dims[i + 1]:
                 network.append(Downsample(embed_dims[i], embed_dims[i + 1], 2 if transitions[i] else 1))
         self.network = nn.ModuleList(network)
+        for si, stage in enumerate(self.network):
+            if not isinstance(stage, Downsample):
+                for bi, blk in enumerate(stage):
+                    blk.__dict__["_owner"] = (self, (si, bi))      # lets `model.network[si][bi](x)` run (common.Block)
         self.norm = norm_layer(embed_dims[-1])
         self.head = nn.Linear(embed_dims[-1], num_classes) if num_classes > 0 else nn.Identity()
         self.apply(self.cls_init_weights)
@@ -269,6 +274,24 @@ class CycleNet(E.EngineModule):
         got = channel_mlp(ws, cur, rows, C, pk, p + "ff.", hidden, tag=tag + ".cm", stats=finalize_stats(ws, got, rows, C, tag=tag + ".cm.ln"),
                           part=(ws, tag + ".fc2.part"))
         return finalize_stats(ws, got, rows, C, tag=tag + ".ln")
+
+    def _run_single(self, key, x):
+        """CycleBlock (si, bi) alone on channel-last (B, H, W, C), as `model.network[si][bi](x)` in the reference (cycle_mlp.py:194-197)"""
+        si, bi = key
+        E.require_gpu(x, "CycleBlock.forward")
+        E.dtype_code(x.dtype)
+        blk = self.network[si][bi]
+        C = blk.norm1.normalized_shape[0]
+        if x.dim() != 4 or x.shape[-1] != C:
+            raise ValueError("expected a channel-last (B, H, W, %d) tensor" % C)
+        B, H, W, _ = x.shape
+        with E.on_device(x):
+            pk = self._get_pack(x.dtype, x.device)
+            ws = self._get_space(("block", B, H, W), x.dtype, x.device)
+            cur = ws.get("blk.x", (B * H * W, C))
+            cur.copy_(x.reshape(B * H * W, C))
+            self._block(ws, pk, "n%d.b%d." % (si, bi), cur, B, H, W, C, blk.mlp.fc1.weight.shape[0], "n%d" % si)
+            return cur.reshape(B, H, W, C).clone()
 
     def forward(self, x):
         cd = self._resolve(x)

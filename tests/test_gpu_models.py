@@ -330,6 +330,31 @@ def test_gmlp_resmlp_blocks_callable_like_the_reference():
         lone(torch.randn(1, 16, 32).to(DEV))                      # a block outside a backbone stays a parameter container
 
 
+def test_cycle_block_callable_like_the_reference():
+    """cycle_mlp.py:194-197: `model.network[si][bi](x)` on channel-last (B, H, W, C)."""
+    pkg = load_pkg()
+    mp = pkg.models_pytorch
+    Fo = oracle.functional
+    torch.manual_seed(7)
+    model = mp.CycleNet([1, 1], img_size=32, embed_dims=[16, 32], transitions=[True, True], mlp_ratios=[2, 2], num_classes=10,
+                        mlp_fn=mp.cycle_mlp.CycleMLP).eval()
+    for p in model.parameters():
+        p.data.add_(0.05 * torch.randn_like(p))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    for (si, C, H, W) in ((0, 16, 8, 6), (2, 32, 4, 5)):
+        t = torch.randn(2, H, W, C)
+        pre = "network.%d.0." % si
+        n = Fo.layer_norm(t, sd[pre + "norm1.weight"], sd[pre + "norm1.bias"])
+        ref = t + Fo.cyclemlp_attn(sd, n, pre + "attn.")
+        n = Fo.layer_norm(ref, sd[pre + "norm2.weight"], sd[pre + "norm2.bias"])
+        ref = ref + Fo.linear(Fo.gelu(Fo.linear(n, sd[pre + "mlp.fc1.weight"], sd[pre + "mlp.fc1.bias"])), sd[pre + "mlp.fc2.weight"],
+                              sd[pre + "mlp.fc2.bias"])
+        got = model.network[si][0](t.to(DEV))
+        assert got.shape == ref.shape
+        assert (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), si
+
+
 def test_cpu_input_raises():
     pkg = load_pkg()
     model = pkg.MLPMixerForImageClassification(d_model=32, depth=1, patch_size=8, image_size=32, num_classes=10)
