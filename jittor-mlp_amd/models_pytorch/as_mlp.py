@@ -18,7 +18,7 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Holder, finalize_stats, head_linear
+from .common import Block, Holder, finalize_stats, head_linear
 from .utils.shift import Shift
 
 # GroupNorm(1,C) statistics from the producing GEMMs' epilogues (mlpk.h row_part, per-sample groups).  Off by default: measured
@@ -66,7 +66,7 @@ class AxialShift(Holder):
         return f'dim={self.dim}, shift_size={self.shift_size}'
 
 
-class AxialShiftedBlock(Holder):
+class AxialShiftedBlock(Block):
     """as_mlp.py:118-147."""
 
     def __init__(self, dim, input_resolution, shift_size=7, mlp_ratio=4., as_bias=True, drop=0., drop_path=0.,
@@ -172,6 +172,9 @@ class AS_MLP(E.EngineModule):
         self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
         self.apply(self._init_weights)
         self._shift = shift_size
+        for li, layer in enumerate(self.layers):
+            for bi, blk in enumerate(layer.blocks):
+                blk.__dict__["_owner"] = (self, (li, bi))          # lets `model.layers[l].blocks[b](x)` run (common.Block)
 
     def _init_weights(self, m):
         # as_mlp.py:419-426: only nn.Linear (= the head) gets the truncated normal
@@ -233,29 +236,15 @@ class AS_MLP(E.EngineModule):
         E.norm_apply(x, B * HW, C, C, mean=mean, rstd=rstd, gamma=g, beta=b, act=act, stat_group=HW, out_rm=out, ld_rm=C)
         return out
 
-    def forward(self, x):
-        cd = self._resolve(x)
-        pe = self.patch_embed
-        B, _, H_in, W_in = x.shape
-        # FIXME-free restatement of as_mlp.py:328: the input size must match the constructor's
-        assert H_in == pe.img_size[0] and W_in == pe.img_size[1], \
-            f"Input image size ({H_in}*{W_in}) doesn't match model ({pe.img_size[0]}*{pe.img_size[1]})."
-        pk = self._get_pack(cd, x.device)
-        ws = self._get_space(B, cd, x.device)
-        x = x.contiguous()
-        ph, pw = pe.patch_size
-        H, W = H_in // ph, W_in // pw
-        C = self.embed_dim
-        kp = pk["embed.w"].shape[1]
-        patches = ws.get("embed.patches", (B * H * W, kp))
-        E.patchify(x, patches, B, pe.in_chans, H_in, W_in, ph, pw, 0, kp)
-        cur = ws.get("l0.x", (B * H * W, C))
-        E.gemm(patches, pk["embed.w"], cur, B * H * W, C, kp, bias=pk["embed.b"])
-        if pe.norm is not None:
-            self._gn(ws, "gn0", cur, B, H * W, C, pk["embed.g"], pk["embed.be"], cur)
+    def _run_layers(self, ws, pk, cur, B, H, W, C, cd, only=None):
+        """The stages on channel-last rows `cur` (B*H*W, C).  only = (layer, block): that one block alone, on a `cur` that already has
+        the layer's resolution and width (AxialShiftedBlock called on its own).  Returns (cur, H, W, C, have, mean, rstd)."""
+        mean = rstd = None
         have = False          # (mean, rstd) of the current layer already hold the per-sample statistics of `cur`
         pending = None        # by-product partials of the PatchMerging GEMM that produced `cur`
         for li, layer in enumerate(self.layers):
+            if only is not None and li != only[0]:
+                continue
             rows, HW = B * H * W, H * W
             t0 = ws.get("l%d.t0" % li, (rows, C))
             t1 = ws.get("l%d.t1" % li, (rows, C))
@@ -282,6 +271,8 @@ class AS_MLP(E.EngineModule):
 
             part = (ws, "l%d.part" % li) if EPILOGUE_STATS else None
             for bi in range(len(layer.blocks)):
+                if only is not None and bi != only[1]:
+                    continue
                 p = "l%d.b%d." % (li, bi)
                 if fused:
                     if not have:
@@ -318,7 +309,7 @@ class AS_MLP(E.EngineModule):
                 self._gn(ws, tag, cur, B, HW, C, pk[p + "n2.g"], pk[p + "n2.b"], t0)                 # norm2(x)
                 E.gemm(t0, pk[p + "fc1.w"], hbuf, rows, hid, C, bias=pk[p + "fc1.b"], act=N.ACT_GELU, tag="as_fc1")
                 E.gemm(hbuf, pk[p + "fc2.w"], cur, rows, C, hid, bias=pk[p + "fc2.b"], R=cur, res=N.RES_ADD, tag="as_fc2")
-            if layer.downsample is not None:
+            if layer.downsample is not None and only is None:
                 assert H % 2 == 0 and W % 2 == 0, f"x size ({H}*{W}) are not even."                   # as_mlp.py:203
                 p = "l%d.down." % li
                 H2, W2 = H // 2, W // 2
@@ -340,6 +331,47 @@ class AS_MLP(E.EngineModule):
                     self._gn(ws, "l%d.gnm" % li, merged, B, H2 * W2, 4 * C, pk[p + "g"], pk[p + "b"], merged)
                     E.gemm(merged, pk[p + "w"], nxt, B * H2 * W2, 2 * C, 4 * C, tag="as_merge")
                 cur, H, W, C = nxt, H2, W2, 2 * C
+        return cur, H, W, C, have, mean, rstd
+
+    def _run_single(self, key, x):
+        """AxialShiftedBlock (layer, block) alone on (B, C, H, W), as `model.layers[l].blocks[b](x)` in the reference (as_mlp.py:149-162)"""
+        li, bi = key
+        E.require_gpu(x, "AxialShiftedBlock.forward")
+        E.dtype_code(x.dtype)
+        blk = self.layers[li].blocks[bi]
+        C = blk.norm1.num_channels
+        if x.dim() != 4 or x.shape[1] != C:
+            raise ValueError("expected a (B, %d, H, W) tensor" % C)
+        B, _, H, W = x.shape
+        with E.on_device(x):
+            pk = self._get_pack(x.dtype, x.device)
+            ws = self._get_space(("block", B, H, W), x.dtype, x.device)
+            cur = ws.get("l%d.x" % li, (B * H * W, C))
+            cur.copy_(x.permute(0, 2, 3, 1).reshape(B * H * W, C))                     # channel-last rows, as the stages keep them
+            cur = self._run_layers(ws, pk, cur, B, H, W, C, x.dtype, only=(li, bi))[0]
+            return cur.reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
+
+    def forward(self, x):
+        cd = self._resolve(x)
+        pe = self.patch_embed
+        B, _, H_in, W_in = x.shape
+        # FIXME-free restatement of as_mlp.py:328: the input size must match the constructor's
+        assert H_in == pe.img_size[0] and W_in == pe.img_size[1], \
+            f"Input image size ({H_in}*{W_in}) doesn't match model ({pe.img_size[0]}*{pe.img_size[1]})."
+        pk = self._get_pack(cd, x.device)
+        ws = self._get_space(B, cd, x.device)
+        x = x.contiguous()
+        ph, pw = pe.patch_size
+        H, W = H_in // ph, W_in // pw
+        C = self.embed_dim
+        kp = pk["embed.w"].shape[1]
+        patches = ws.get("embed.patches", (B * H * W, kp))
+        E.patchify(x, patches, B, pe.in_chans, H_in, W_in, ph, pw, 0, kp)
+        cur = ws.get("l0.x", (B * H * W, C))
+        E.gemm(patches, pk["embed.w"], cur, B * H * W, C, kp, bias=pk["embed.b"])
+        if pe.norm is not None:
+            self._gn(ws, "gn0", cur, B, H * W, C, pk["embed.g"], pk["embed.be"], cur)
+        cur, H, W, C, have, mean, rstd = self._run_layers(ws, pk, cur, B, H, W, C, cd)
         if not have:
             mean = ws.get("final.mean", (B,), torch.float32)
             rstd = ws.get("final.rstd", (B,), torch.float32)

@@ -355,6 +355,26 @@ def test_cycle_block_callable_like_the_reference():
         assert (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), si
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_asmlp_block_callable_like_the_reference(dtype):
+    """as_mlp.py:149-162: `model.layers[l].blocks[b](x)` on (B, C, H, W); fp32 takes the unfused kernel sequence, bf16 the fused one."""
+    pkg = load_pkg()
+    mp = pkg.models_pytorch
+    torch.manual_seed(11)
+    model = mp.AS_MLP(img_size=32, patch_size=4, embed_dim=64, depths=[1, 2], shift_size=5, num_classes=10).eval()
+    for p in model.parameters():
+        p.data.add_(0.05 * torch.randn_like(p))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    tol = 2e-5 if dtype == torch.float32 else 6e-2
+    for (li, bi, C, H, W) in ((0, 0, 64, 8, 8), (1, 1, 128, 4, 4)):
+        t = torch.randn(2, C, H, W)
+        ref = oracle.functional.asmlp_block(sd, t.to(dtype).float(), "layers.%d.blocks.%d." % (li, bi), 5)
+        got = model.layers[li].blocks[bi](t.to(DEV).to(dtype))
+        assert got.shape == ref.shape and got.dtype == dtype
+        assert (got.float().cpu() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item()), (li, bi)
+
+
 def test_cpu_input_raises():
     pkg = load_pkg()
     model = pkg.MLPMixerForImageClassification(d_model=32, depth=1, patch_size=8, image_size=32, num_classes=10)
