@@ -14,7 +14,7 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Holder, channel_mlp, embed_patches, head_linear, layernorm_stats
+from .common import Block, Holder, channel_mlp, embed_patches, head_linear, layernorm_stats
 
 MS_EPS = 1e-6
 
@@ -37,8 +37,8 @@ class LayerNorm(Holder):
         self.normalized_shape = (normalized_shape, )
 
 
-class MixShiftBlock(Holder):
-    """ms_mlp.py:24-46."""
+class MixShiftBlock(Block):
+    """ms_mlp.py:24-46.  Callable on (B, C, H, W) like the reference's (ms_mlp.py:48-78) once it sits in an MS_MLP."""
 
     def __init__(self, dim, input_resolution, shift_size, shift_dist, mix_size, layer_scale_init_value=1e-6, mlp_ratio=4, drop=0.,
                  drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm):
@@ -130,6 +130,9 @@ class MS_MLP(E.EngineModule):
         self.norm = norm_layer(self.num_features)
         self.avgpool = nn.AdaptiveAvgPool2d(1)
         self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
+        for li, layer in enumerate(self.layers):
+            for bi, blk in enumerate(layer.blocks):
+                blk.__dict__["_owner"] = (self, (li, bi))          # lets `model.layers[l].blocks[b](x)` run (common.Block)
         self.apply(self._init_weights)
 
     def _init_weights(self, m):
@@ -181,6 +184,29 @@ class MS_MLP(E.EngineModule):
             pk["head.w"] = E.pack_matrix(self.head.weight, dtype, device)
             pk["head.b"] = E.f32(self.head.bias, device)
         return pk
+
+    def _run_single(self, key, x):
+        """MixShiftBlock (layer, block) alone on (B, C, H, W), as `model.layers[l].blocks[b](x)` in the reference (ms_mlp.py:48-78)"""
+        li, bi = key
+        E.require_gpu(x, "MixShiftBlock.forward")
+        E.dtype_code(x.dtype)
+        blk = self.layers[li].blocks[bi]
+        C = blk.dim
+        if x.dim() != 4 or x.shape[1] != C:
+            raise ValueError("expected a (B, %d, H, W) tensor" % C)
+        B, _, H, W = x.shape
+        rows = B * H * W
+        with E.on_device(x):
+            pk = self._get_pack(x.dtype, x.device)
+            ws = self._get_space(("block", B, H, W), x.dtype, x.device)
+            cur = ws.get("blk.x", (rows, C))
+            cur.copy_(x.permute(0, 2, 3, 1).reshape(rows, C))                          # channel-last rows, as the stages keep them
+            mix = ws.get("blk.mix", (rows, C))
+            p = "l%d.b%d." % (li, bi)
+            E.mixshift_nhwc(cur, mix, B, H, W, C, list(blk.shift_dist), [k for k, _ in blk.kernel_size], pk[p + "lr.w"], pk[p + "lr.b"],
+                            pk[p + "td.w"], pk[p + "td.b"])
+            channel_mlp(ws, mix, rows, C, pk, p + "ff.", int(self.mlp_ratio * C), cscale2=pk[p + "gamma"], res_src=cur, tag="blk.cm", eps=MS_EPS)
+            return mix.reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
 
     def forward(self, x):
         cd = self._resolve(x)

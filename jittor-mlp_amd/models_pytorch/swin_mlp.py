@@ -19,7 +19,7 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Holder, channel_mlp, finalize_stats, embed_patches, head_linear, layernorm_stats, pack_channel_mlp
+from .common import Block, Holder, channel_mlp, finalize_stats, embed_patches, head_linear, layernorm_stats, pack_channel_mlp
 
 
 def to_2tuple(v):
@@ -39,8 +39,8 @@ class Mlp(Holder):
         self.drop = nn.Dropout(drop)
 
 
-class SwinMLPBlock(Holder):
-    """swin_mlp.py:79-111."""
+class SwinMLPBlock(Block):
+    """swin_mlp.py:79-111.  Callable on (B, H*W, C) like the reference's (swin_mlp.py:113-157) once it sits in a SwinMLP."""
 
     def __init__(self, dim, input_resolution, num_heads, window_size=7, shift_size=0, mlp_ratio=4., drop=0., drop_path=0.,
                  act_layer=nn.GELU, norm_layer=nn.LayerNorm):
@@ -146,6 +146,9 @@ class SwinMLP(E.EngineModule):
         self.norm = norm_layer(self.num_features)
         self.avgpool = nn.AdaptiveAvgPool1d(1)
         self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
+        for li, layer in enumerate(self.layers):
+            for bi, blk in enumerate(layer.blocks):
+                blk.__dict__["_owner"] = (self, (li, bi))          # lets `model.layers[l].blocks[b](x)` run (common.Block)
         self.apply(self._init_weights)
 
     def _init_weights(self, m):
@@ -188,6 +191,53 @@ class SwinMLP(E.EngineModule):
             pk["head.b"] = E.f32(self.head.bias, device)
         return pk
 
+    def _block(self, ws_, pk, li, bi, blk, cur, B, H, W, C, st):
+        """One SwinMLPBlock in place on channel-last rows `cur` (B*H*W, C); st = (mean, rstd) of cur's rows when the GEMM that wrote
+        them delivered the statistics (else None); returns the statistics of the result the same way."""
+        rows = B * H * W
+        xn = ws_.get("l%d.xn" % li, (rows, C))
+        p = "l%d.b%d." % (li, bi)
+        ws, nh = blk.window_size, blk.num_heads
+        d = C // nh
+        pad_l, pad_r, pad_t, pad_b = blk.padding if blk.shift_size > 0 else (0, 0, 0, 0)
+        Hp, Wp = H + pad_t + pad_b, W + pad_l + pad_r
+        nwin = B * (Hp // ws) * (Wp // ws)
+        tk = ws * ws * nh                                     # "tokens" of the per-window GEMM: (window position, head)
+        kp = E.round_up(tk, 8)
+        tag = "l%d.s%d." % (li, 1 if blk.shift_size > 0 else 0)
+        xw = ws_.get(tag + "xw", (nwin * ws * ws, C))
+        xt = ws_.get(tag + "xt", (nwin * d, kp))
+        mean, rstd = st if st is not None else layernorm_stats(ws_, cur, rows, C, tag="l%d.ln" % li)
+        E.norm_apply(cur, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "n1.g"], beta=pk[p + "n1.b"], out_rm=xn, ld_rm=C)
+        E.window_gather(xn, xw, B, H, W, C, ws, pad_t, pad_l, Hp, Wp)
+        # rows (window, token, head) x d channels  ->  per window transposed: ((window, channel), (token, head))
+        E.norm_apply(xw, nwin * tk, d, d, out_tt=xt, S=tk, ld_tt=kp)
+        E.gemm(xt, pk[p + "sp.w"], xw, nwin * d, tk, kp, ldc=d, bias=pk[p + "sp.b"], out_mode=N.OUT_TOKEN_T, t_rows=d, t_tokens=tk,
+               tag="swin_spatial")
+        E.window_scatter_add(cur, xw, B, H, W, C, ws, pad_t, pad_l, Hp, Wp)
+        got = channel_mlp(ws_, cur, rows, C, pk, p + "ff.", int(C * self.mlp_ratio), tag="l%d.cm" % li, part=(ws_, "l%d.fc2.part" % li))
+        st = finalize_stats(ws_, got, rows, C, tag="l%d.ln" % li)
+        return st
+
+    def _run_single(self, key, x):
+        """SwinMLPBlock (layer, block) alone on (B, H*W, C), as `model.layers[l].blocks[b](x)` in the reference (swin_mlp.py:113-157)"""
+        li, bi = key
+        E.require_gpu(x, "SwinMLPBlock.forward")
+        E.dtype_code(x.dtype)
+        blk = self.layers[li].blocks[bi]
+        H, W = blk.input_resolution
+        C = blk.dim
+        if x.dim() != 3 or x.shape[1] != H * W or x.shape[2] != C:
+            raise ValueError("expected a (B, %d, %d) tensor" % (H * W, C))
+        B = x.shape[0]
+        with E.on_device(x):
+            pk = self._get_pack(x.dtype, x.device)
+            ws_ = self._get_space(("block", B, H, W), x.dtype, x.device)
+            cur = ws_.get("blk.x", (B * H * W, C))
+            cur.copy_(x.reshape(B * H * W, C))
+            self._block(ws_, pk, li, bi, blk, cur, B, H, W, C, None)
+            return cur.reshape(B, H * W, C).clone()
+
     def forward(self, x):
         if self.ape:
             raise NotImplementedError("ape=True (absolute position embedding) is not built")
@@ -210,27 +260,7 @@ class SwinMLP(E.EngineModule):
             rows = B * H * W
             xn = ws_.get("l%d.xn" % li, (rows, C))
             for bi, blk in enumerate(layer.blocks):
-                p = "l%d.b%d." % (li, bi)
-                ws, nh = blk.window_size, blk.num_heads
-                d = C // nh
-                pad_l, pad_r, pad_t, pad_b = blk.padding if blk.shift_size > 0 else (0, 0, 0, 0)
-                Hp, Wp = H + pad_t + pad_b, W + pad_l + pad_r
-                nwin = B * (Hp // ws) * (Wp // ws)
-                tk = ws * ws * nh                                     # "tokens" of the per-window GEMM: (window position, head)
-                kp = E.round_up(tk, 8)
-                tag = "l%d.s%d." % (li, 1 if blk.shift_size > 0 else 0)
-                xw = ws_.get(tag + "xw", (nwin * ws * ws, C))
-                xt = ws_.get(tag + "xt", (nwin * d, kp))
-                mean, rstd = st if st is not None else layernorm_stats(ws_, cur, rows, C, tag="l%d.ln" % li)
-                E.norm_apply(cur, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "n1.g"], beta=pk[p + "n1.b"], out_rm=xn, ld_rm=C)
-                E.window_gather(xn, xw, B, H, W, C, ws, pad_t, pad_l, Hp, Wp)
-                # rows (window, token, head) x d channels  ->  per window transposed: ((window, channel), (token, head))
-                E.norm_apply(xw, nwin * tk, d, d, out_tt=xt, S=tk, ld_tt=kp)
-                E.gemm(xt, pk[p + "sp.w"], xw, nwin * d, tk, kp, ldc=d, bias=pk[p + "sp.b"], out_mode=N.OUT_TOKEN_T, t_rows=d, t_tokens=tk,
-                       tag="swin_spatial")
-                E.window_scatter_add(cur, xw, B, H, W, C, ws, pad_t, pad_l, Hp, Wp)
-                got = channel_mlp(ws_, cur, rows, C, pk, p + "ff.", int(C * self.mlp_ratio), tag="l%d.cm" % li, part=(ws_, "l%d.fc2.part" % li))
-                st = finalize_stats(ws_, got, rows, C, tag="l%d.ln" % li)
+                st = self._block(ws_, pk, li, bi, blk, cur, B, H, W, C, st)
             if layer.downsample is not None:
                 assert H % 2 == 0 and W % 2 == 0, f"x size ({H}*{W}) are not even."                                 # swin_mlp.py:201
                 p = "l%d.merge." % li

@@ -375,6 +375,35 @@ def test_asmlp_block_callable_like_the_reference(dtype):
         assert (got.float().cpu() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item()), (li, bi)
 
 
+def test_swin_and_msmlp_blocks_callable_like_the_reference():
+    """swin_mlp.py:113-157 (`blocks[b](x)` on (B, H*W, C)), ms_mlp.py:48-78 (on (B, C, H, W))."""
+    pkg = load_pkg()
+    mp = pkg.models_pytorch
+    Fo = oracle.functional
+    torch.manual_seed(13)
+    swin = mp.SwinMLP(img_size=32, patch_size=4, embed_dim=32, depths=[2, 2], num_heads=[2, 4], window_size=4, num_classes=10).eval()
+    ms = mp.MS_MLP(img_size=32, patch_size=4, embed_dim=40, depths=[2, 1], shift_size=5, num_classes=10).eval()
+    for model in (swin, ms):
+        for p in model.parameters():
+            p.data.add_(0.05 * torch.randn_like(p))
+    sd = {k: v.detach().clone() for k, v in swin.state_dict().items()}
+    swin = swin.to(DEV)
+    for (li, bi, C, hw, nh) in ((0, 1, 32, 8, 2), (1, 0, 64, 4, 4)):                   # a shifted block, and a stage whose map == one window
+        blk = swin.layers[li].blocks[bi]
+        t = torch.randn(2, hw * hw, C)
+        ref = Fo.swinmlp_block(sd, t, "layers.%d.blocks.%d." % (li, bi), hw, hw, nh, 4, blk.shift_size if hw > 4 else 0)
+        got = blk(t.to(DEV))
+        assert (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), ("swin", li, bi)
+    sd = {k: v.detach().clone() for k, v in ms.state_dict().items()}
+    ms = ms.to(DEV)
+    for (li, bi, C, hw) in ((0, 1, 40, 8), (1, 0, 80, 4)):
+        blk = ms.layers[li].blocks[bi]
+        t = torch.randn(2, C, hw, hw)
+        ref = Fo.msmlp_block(sd, t, "layers.%d.blocks.%d." % (li, bi), tuple(blk.shift_dist), tuple(k for k, _ in blk.kernel_size))
+        got = blk(t.to(DEV))
+        assert (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), ("msmlp", li, bi)
+
+
 def test_cpu_input_raises():
     pkg = load_pkg()
     model = pkg.MLPMixerForImageClassification(d_model=32, depth=1, patch_size=8, image_size=32, num_classes=10)
