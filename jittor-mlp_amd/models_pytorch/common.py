@@ -26,6 +26,18 @@ class Block(Holder):
         return owner[0]._run_single(owner[1], x)
 
 
+class BlockSequential(nn.Sequential):
+    """The same for the families whose block is a plain nn.Sequential of inner modules in the reference (ViP, S2-MLP): the module
+    tree and the state_dict keys are those of nn.Sequential, and calling the block runs it through the owning model's kernels.
+    Outside a model it behaves like nn.Sequential (and its parameter-container children raise)."""
+
+    def forward(self, x):
+        owner = self.__dict__.get("_owner")
+        if owner is None:
+            return super().forward(x)
+        return owner[0]._run_single(owner[1], x)
+
+
 def adopt_blocks(backbone, blocks):
     """Tell every block which backbone runs it (a plain reference kept out of the module tree: no extra state_dict keys)."""
     for i, b in enumerate(blocks):

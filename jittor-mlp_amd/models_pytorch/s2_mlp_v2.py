@@ -20,7 +20,7 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Holder, channel_mlp, finalize_stats, head_linear, layernorm_stats, split_attention_weights, stage_embed, pack_channel_mlp
+from .common import BlockSequential, Holder, channel_mlp, finalize_stats, head_linear, layernorm_stats, split_attention_weights, stage_embed, pack_channel_mlp
 from .utils.tools import pair
 
 SHIFT_MODES = {"reference_inplace": N.SHIFT_S2_REF, "shift": N.SHIFT_S2}
@@ -61,7 +61,7 @@ class S2Block(E.EngineModule):
 
     def __init__(self, d_model, depth, expansion_factor=4, dropout=0.):
         super().__init__()
-        self.model = nn.Sequential(*[nn.Sequential(
+        self.model = nn.Sequential(*[BlockSequential(
             PreNormResidual(d_model, S2Attention(d_model)),
             PreNormResidual(d_model, nn.Sequential(nn.Linear(d_model, d_model * expansion_factor), nn.GELU(), nn.Dropout(dropout),
                                                    nn.Linear(d_model * expansion_factor, d_model), nn.Dropout(dropout))))
@@ -131,6 +131,9 @@ class S2MLPv2(E.EngineModule):
         self._d_model = list(d_model)
         self._num_classes = num_classes
         self.shift_mode = "reference_inplace"
+        for s in range(self.stage):
+            for i, blk in enumerate(self.stages[s][1].model):
+                blk.__dict__["_owner"] = (self, (s, i))            # lets `model.stages[s][1].model[i](x)` run (common.BlockSequential)
 
     def set_shift_mode(self, mode):
         if mode not in SHIFT_MODES:
@@ -154,6 +157,9 @@ class S2MLPv2(E.EngineModule):
 
     def _block_runner(self, s):
         return self.stages[s][1]._run_blocks
+
+    def _run_single(self, key, x):
+        return self.forward_block(key[0], key[1], x)
 
     def forward_block(self, stage, index, x):
         """One block `stages[stage][1].model[index]` on a channel-last activation (B, H, W, C) -> (B, H, W, C): what

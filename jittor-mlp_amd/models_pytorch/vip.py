@@ -16,7 +16,7 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Holder, channel_mlp, embed_patches, finalize_stats, head_linear, layernorm_stats, split_attention_weights, pack_channel_mlp
+from .common import BlockSequential, Holder, adopt_blocks, channel_mlp, embed_patches, finalize_stats, head_linear, layernorm_stats, split_attention_weights, pack_channel_mlp
 from .utils.tools import pair
 
 
@@ -89,11 +89,12 @@ class _PermutatorBase(E.EngineModule):
                 mix = ParallelWeightedSum(SplitAttention(d_model, k=3), *_branches(height, width, d_model, segments))
             else:
                 mix = ParallelSum(*_branches(height, width, d_model, segments))
-            blocks.append(nn.Sequential(
+            blocks.append(BlockSequential(
                 PreNormResidual(d_model, nn.Sequential(mix, nn.Linear(d_model, d_model))),
                 PreNormResidual(d_model, _mlp(d_model, expansion_factor, dropout))))
         self.model = nn.Sequential(*blocks)
         self._dims = (height, width, d_model, depth, segments, expansion_factor)
+        adopt_blocks(self, self.model)                             # lets `backbone.model[i](x)` run (common.BlockSequential)
 
     def _pack_blocks(self, pk, dtype, device, prefix=""):
         for i, blk in enumerate(self.model):
@@ -151,7 +152,7 @@ class _PermutatorBase(E.EngineModule):
         self._pack_blocks(pk, dtype, device)
         return pk
 
-    def _run_blocks(self, ws, pk, x, B, prefix="", final_stats=False):
+    def _run_blocks(self, ws, pk, x, B, prefix="", final_stats=False, only=None):
         """final_stats: also return the (mean, rstd) of the rows of the result (for the LayerNorm of the head), or None."""
         H, W, C, depth, seg, ef = self._dims
         rows = B * H * W
@@ -161,7 +162,7 @@ class _PermutatorBase(E.EngineModule):
         # both LayerNorms of a block read a tensor a GEMM has just written (proj + residual, fc2 + residual): their statistics
         # come out of those epilogues (mlpk.h row_part) instead of two more passes over x per block
         nxt = None
-        for i in range(depth):
+        for i in (range(depth) if only is None else only):
             p = prefix + "b%d." % i
             mean, rstd = nxt if nxt is not None else layernorm_stats(ws, x, rows, C)
             cfold = (p + "c.csum") in pk
@@ -227,7 +228,7 @@ class _PermutatorBase(E.EngineModule):
             nxt = finalize_stats(ws, got, rows, C)
         return (x, nxt) if final_stats else x
 
-    def forward(self, x):
+    def forward(self, x, _only=None):
         """(B,H,W,C) -> (B,H,W,C), as the reference backbones (vip.py:92-93, 127-128)."""
         E.require_gpu(x, type(self).__name__ + ".forward")
         H, W, C = self._dims[:3]
@@ -238,8 +239,12 @@ class _PermutatorBase(E.EngineModule):
         ws = self._get_space(B, x.dtype, x.device)
         buf = ws.get("x", (B * H * W, C))
         buf.copy_(x.reshape(B * H * W, C))
-        self._run_blocks(ws, pk, buf, B)
+        self._run_blocks(ws, pk, buf, B, only=_only)
         return buf.reshape(B, H, W, C).clone()
+
+    def _run_single(self, i, x):
+        """block i alone on (B, H, W, C): what `backbone.model[i](x)` computes in the reference (vip.py:85-93)"""
+        return self(x, _only=[i])
 
 
 class WeightedPermutator(_PermutatorBase):

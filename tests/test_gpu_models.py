@@ -404,6 +404,36 @@ def test_swin_and_msmlp_blocks_callable_like_the_reference():
         assert (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), ("msmlp", li, bi)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_vip_and_s2_blocks_callable_like_the_reference(dtype):
+    """vip.py:85-93 (`backbone.model[i](x)`), s2_mlp_v2.py:86-92 (`model.stages[s][1].model[i](x)`): blocks that are plain
+    nn.Sequential in the reference, on channel-last (B, H, W, C).  fp32 = unfused kernel sequences, bf16 = the fused ones."""
+    pkg = load_pkg()
+    mp = pkg.models_pytorch
+    Fo = oracle.functional
+    torch.manual_seed(17)
+    tol = 2e-5 if dtype == torch.float32 else 6e-2
+    vip = mp.WeightedPermutator(4, 6, 32, 2, 8, expansion_factor=2).eval()
+    s2 = mp.S2MLPv2(image_size=32, patch_size=[4, 2], d_model=[32, 64], depth=[2, 1], expansion_factor=[2, 2], num_classes=10).eval()
+    for model in (vip, s2):
+        for p in model.parameters():
+            p.data.add_(0.05 * torch.randn_like(p))
+    sd = {k: v.detach().clone() for k, v in vip.state_dict().items()}
+    vip = vip.to(DEV)
+    t = torch.randn(2, 4, 6, 32).to(dtype)
+    ref = Fo.vip_block(sd, t.float(), "model.1.", 8, True)
+    got = vip.model[1](t.to(DEV))
+    assert got.shape == ref.shape and got.dtype == dtype
+    assert (got.float().cpu() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
+    sd = {k: v.detach().clone() for k, v in s2.state_dict().items()}
+    s2 = s2.to(DEV)
+    for (st, i, C, hw) in ((0, 1, 32, 8), (1, 0, 64, 4)):
+        t = torch.randn(2, hw, hw, C).to(dtype)
+        ref = Fo.s2v2_block(sd, t.float(), "stages.%d.1.model.%d." % (st, i), "reference_inplace")
+        got = s2.stages[st][1].model[i](t.to(DEV))
+        assert (got.float().cpu() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item()), (st, i)
+
+
 def test_cpu_input_raises():
     pkg = load_pkg()
     model = pkg.MLPMixerForImageClassification(d_model=32, depth=1, patch_size=8, image_size=32, num_classes=10)
