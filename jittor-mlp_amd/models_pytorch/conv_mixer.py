@@ -13,7 +13,7 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Holder, head_linear
+from .common import BlockSequential, adopt_blocks, Holder, head_linear
 
 
 class Residual(Holder):
@@ -37,11 +37,12 @@ class ConvMixer(E.EngineModule):
         super().__init__()
         self.embedding = nn.Sequential(
             nn.Conv2d(3, dim, kernel_size=patch_size, stride=patch_size, padding=patch_size // 2), nn.GELU(), nn.BatchNorm2d(dim))
-        self.blocks = nn.Sequential(*[nn.Sequential(
+        self.blocks = nn.Sequential(*[BlockSequential(
             Residual(nn.Sequential(nn.Conv2d(dim, dim, kernel_size, groups=dim, padding="same"), nn.GELU(), nn.BatchNorm2d(dim))),
             nn.Conv2d(dim, dim, kernel_size=1), nn.GELU(), nn.BatchNorm2d(dim)) for i in range(depth)])
         self.classifier = nn.Sequential(nn.AdaptiveAvgPool2d((1, 1)), nn.Flatten(), nn.Linear(dim, n_classes))
         self._cfg = (dim, depth, kernel_size, patch_size, n_classes)
+        adopt_blocks(self, self.blocks)                            # lets `model.blocks[i](x)` run (common.BlockSequential)
 
     def _pack(self, dtype, device):
         dim, depth, k, patch, _ = self._cfg
@@ -63,6 +64,26 @@ class ConvMixer(E.EngineModule):
         pk["head.w"] = E.pack_matrix(self.classifier[2].weight, dtype, device)
         pk["head.b"] = E.f32(self.classifier[2].bias, device)
         return pk
+
+    def _run_single(self, i, x):
+        """block i alone on (B, dim, H, W), as `model.blocks[i](x)` in the reference (conv_mixer.py:23-32)"""
+        E.require_gpu(x, "ConvMixer block")
+        E.dtype_code(x.dtype)
+        dim, _, k, _, _ = self._cfg
+        if x.dim() != 4 or x.shape[1] != dim:
+            raise ValueError("expected a (B, %d, H, W) tensor" % dim)
+        B, _, H, W = x.shape
+        rows = B * H * W
+        with E.on_device(x):
+            pk = self._get_pack(x.dtype, x.device)
+            ws = self._get_space(("block", B, H, W), x.dtype, x.device)
+            cur = ws.get("blk.x", (rows, dim))
+            cur.copy_(x.permute(0, 2, 3, 1).reshape(rows, dim))                        # channel-last rows, as forward() keeps them
+            tmp = ws.get("blk.y", (rows, dim))
+            p = "b%d." % i
+            E.dwconv_nhwc(cur, tmp, B, H, W, dim, k, pk[p + "dw.w"], pk[p + "dw.b"], pk[p + "dw.s"], pk[p + "dw.h"])
+            E.gemm(tmp, pk[p + "pw.w"], cur, rows, dim, dim, bias=pk[p + "pw.b"], act=N.ACT_GELU, cscale=pk[p + "pw.s"], cshift=pk[p + "pw.h"])
+            return cur.reshape(B, H, W, dim).permute(0, 3, 1, 2).contiguous()
 
     def forward(self, x):
         cd = self._resolve(x)

@@ -8,7 +8,7 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Holder, channel_mlp, finalize_stats, head_linear, layernorm_stats, stage_embed, pack_channel_mlp
+from .common import BlockSequential, Holder, channel_mlp, finalize_stats, head_linear, layernorm_stats, stage_embed, pack_channel_mlp
 from .s2_mlp_v2 import SHIFT_MODES
 from .utils.tools import pair
 
@@ -27,7 +27,7 @@ class Spatial_Shift(Holder):
 class S2Block(E.EngineModule):
     def __init__(self, d_model, depth, expansion_factor=4, dropout=0.):
         super().__init__()
-        self.model = nn.Sequential(*[nn.Sequential(
+        self.model = nn.Sequential(*[BlockSequential(
             PreNormResidual(d_model, nn.Sequential(nn.Linear(d_model, d_model), nn.GELU(), Spatial_Shift(), nn.Linear(d_model, d_model))),
             PreNormResidual(d_model, nn.Sequential(nn.Linear(d_model, d_model * expansion_factor), nn.GELU(), nn.Dropout(dropout),
                                                    nn.Linear(d_model * expansion_factor, d_model), nn.Dropout(dropout))))
@@ -45,11 +45,11 @@ class S2Block(E.EngineModule):
             mlp = blk[1]
             pack_channel_mlp(pk, p + "mlp.", mlp.norm, mlp.fn[0], mlp.fn[3], dtype, device)
 
-    def _run_blocks(self, ws, pk, x, B, H, W, prefix, mode):
+    def _run_blocks(self, ws, pk, x, B, H, W, prefix, mode, only=None):
         C, depth, ef = self._dims
         rows = B * H * W
         nxt = None
-        for i in range(depth):
+        for i in (range(depth) if only is None else only):
             p = prefix + "b%d." % i
             # both LayerNorms of a block read what a GEMM + residual has just written: statistics from those epilogues (mlpk.h row_part)
             mean, rstd = nxt if nxt is not None else layernorm_stats(ws, x, rows, C, tag=prefix + "ln")
@@ -93,6 +93,25 @@ class S2MLPv1(E.EngineModule):
         self._d_model = list(d_model)
         self._num_classes = num_classes
         self.shift_mode = "reference_inplace"
+        for s in range(self.stage):
+            for i, blk in enumerate(self.stages[s][1].model):
+                blk.__dict__["_owner"] = (self, (s, i))            # lets `model.stages[s][1].model[i](x)` run (common.BlockSequential)
+
+    def _run_single(self, key, x):
+        """block `stages[s][1].model[i]` alone on channel-last (B, H, W, C), as calling it does in the reference (s2_mlp_v1.py:47-52)"""
+        stage, index = key
+        E.require_gpu(x, "S2MLPv1 block")
+        E.dtype_code(x.dtype)
+        B, H, W, C = x.shape
+        if C != self._d_model[stage]:
+            raise ValueError("stage %d works on %d channels" % (stage, self._d_model[stage]))
+        with E.on_device(x):
+            pk = self._get_pack(x.dtype, x.device)
+            ws = self._get_space(("block", B, H, W), x.dtype, x.device)
+            buf = ws.get("blk%d.x" % stage, (B * H * W, C))
+            buf.copy_(x.reshape(B * H * W, C))
+            self.stages[stage][1]._run_blocks(ws, pk, buf, B, H, W, "s%d." % stage, SHIFT_MODES[self.shift_mode], only=[index])
+            return buf.reshape(B, H, W, C).clone()
 
     def set_shift_mode(self, mode):
         if mode not in SHIFT_MODES:

@@ -434,6 +434,40 @@ def test_vip_and_s2_blocks_callable_like_the_reference(dtype):
         assert (got.float().cpu() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item()), (st, i)
 
 
+def test_s2v1_and_convmixer_blocks_callable_like_the_reference():
+    """s2_mlp_v1.py:47-52 (`model.stages[s][1].model[i](x)` on (B, H, W, C)), conv_mixer.py:23-32 (`model.blocks[i](x)` on (B, C, H, W))."""
+    pkg = load_pkg()
+    mp = pkg.models_pytorch
+    Fo = oracle.functional
+    torch.manual_seed(19)
+    s2 = mp.S2MLPv1(image_size=32, patch_size=[4, 2], d_model=[32, 64], depth=[2, 1], expansion_factor=[2, 2], num_classes=10).eval()
+    cm = mp.ConvMixer(32, 2, kernel_size=5, patch_size=4, n_classes=10).eval()
+    for model in (s2, cm):
+        for p in model.parameters():
+            p.data.add_(0.05 * torch.randn_like(p))
+    for m in cm.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+    sd = {k: v.detach().clone() for k, v in s2.state_dict().items()}
+    s2 = s2.to(DEV)
+    for (st, i, C, hw) in ((0, 1, 32, 8), (1, 0, 64, 4)):
+        t = torch.randn(2, hw, hw, C)
+        ref = Fo.s2v1_block(sd, t, "stages.%d.1.model.%d." % (st, i), "reference_inplace")
+        got = s2.stages[st][1].model[i](t.to(DEV))
+        assert (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), (st, i)
+    sd = {k: v.detach().clone() for k, v in cm.state_dict().items()}
+    cm = cm.to(DEV)
+    t = torch.randn(2, 32, 8, 8)
+    pre = "blocks.1."
+    d = Fo.depthwise_conv_same(t, sd[pre + "0.fn.0.weight"], sd[pre + "0.fn.0.bias"])
+    ref = t + Fo.batch_norm_eval(Fo.gelu(d), sd, pre + "0.fn.2")
+    ref = Fo.batch_norm_eval(Fo.gelu(Fo.conv1x1(ref, sd[pre + "1.weight"], sd[pre + "1.bias"])), sd, pre + "3")
+    got = cm.blocks[1](t.to(DEV))
+    assert got.shape == ref.shape
+    assert (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
 def test_cpu_input_raises():
     pkg = load_pkg()
     model = pkg.MLPMixerForImageClassification(d_model=32, depth=1, patch_size=8, image_size=32, num_classes=10)
