@@ -17,7 +17,7 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Holder, channel_mlp, finalize_stats, head_linear, layernorm_stats, pack_channel_mlp
+from .common import BlockSequential, Holder, channel_mlp, finalize_stats, head_linear, layernorm_stats, pack_channel_mlp
 from .utils import pair
 
 
@@ -76,7 +76,7 @@ class HireMLPStage(Holder):
         self.patch_merge = nn.Sequential(nn.Identity(),
                                          PatchEmbedding(d_model_in, d_model_out, kernel_size=3, stride=2, padding=1, norm_layer=False),
                                          nn.Identity())
-        self.model = nn.Sequential(*[nn.Sequential(
+        self.model = nn.Sequential(*[BlockSequential(
             PreNormResidual(d_model_in, nn.Sequential(HireMLPBlock(h, w, d_model_in, cross_region_step=cross_region_step,
                                                                    cross_region_id=i_depth + 1, cross_region_interval=cross_region_interval,
                                                                    padding_type=padding_type)), norm=nn.LayerNorm),
@@ -117,6 +117,9 @@ class HireMLP(E.EngineModule):
                 expansion_factor=expansion_factor, pooling=((i_layer + 1) < len(depth)), padding_type=padding_type))
         self.mlp_head = nn.Sequential(nn.LayerNorm(d_model[-1]), nn.Identity(), nn.Linear(d_model[-1], num_classes))
         self._cfg = (patch_size, in_channels, num_classes, patcher_norm)
+        for li, stage in enumerate(self.layers):
+            for bi, blk in enumerate(stage.model):
+                blk.__dict__["_owner"] = (self, (li, bi))          # lets `model.layers[l].model[b](x)` run (common.BlockSequential)
 
     def _pack(self, dtype, device):
         pk = {}
@@ -153,6 +156,60 @@ class HireMLP(E.EngineModule):
         pk["head.b"] = E.f32(self.mlp_head[2].bias, device)
         return pk
 
+    def _block(self, ws, pk, li, bi, stage, cur, B, H, W, st):
+        """Block `layers[li].model[bi]` in place on channel-last rows `cur` (B*H*W, C); st = (mean, rstd) of cur's rows when the GEMM that
+        wrote them delivered the statistics (else None); returns the statistics of the result the same way."""
+        h, w, C, Cout, depth, ef = stage.geom
+        rows = B * H * W
+        Hp, Wp = H + (h - H % h), W + (w - W % w)                                         # hire_mlp.py:131-133
+        gh, gw = Hp // h, Wp // w
+        rows_h, rows_w = B * gh * W, B * H * gw
+        hid = C // 2
+        hidp = E.round_up(hid, 8)
+        xn = ws.get("l%d.xn" % li, (rows, C))
+        a_h = ws.get("l%d.ah" % li, (rows_h, h * C))
+        a_w = ws.get("l%d.aw" % li, (rows_w, w * C))
+        t_h = ws.get("l%d.th" % li, (rows_h, hidp))
+        t_w = ws.get("l%d.tw" % li, (rows_w, hidp))
+        blk = stage.model[bi]
+        p = "l%d.b%d." % (li, bi)
+        step = blk[0].fn[0].step
+        mean, rstd = st if st is not None else layernorm_stats(ws, cur, rows, C, tag="l%d.ln" % li)
+        E.norm_apply(cur, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "ln.g"], beta=pk[p + "ln.b"], out_rm=xn, ld_rm=C)
+        E.hire_gather(xn, a_h, a_w, B, H, W, C, h, w, step, h * C, w * C)
+        # the w-branch pair of GEMMs touches only a_w / t_w: it runs on a side stream beside the h-branch pair and proj_c
+        # (short GEMMs of 20-50 us each: two kernels in flight fill the tail of each other's last wave of tiles)
+        chain = E.SideChain(ws, "hire.w", cur.device)
+        with chain:
+            E.gemm(a_w, pk[p + "w1.w"], t_w, rows_w, hid, w * C, bias=pk[p + "w1.b"], act=N.ACT_GELU, tag="hire_fc1")
+            E.gemm(t_w, pk[p + "w2.w"], a_w, rows_w, w * C, hidp, bias=pk[p + "w2.b"], tag="hire_fc2")
+        E.gemm(a_h, pk[p + "h1.w"], t_h, rows_h, hid, h * C, bias=pk[p + "h1.b"], act=N.ACT_GELU, tag="hire_fc1")
+        E.gemm(t_h, pk[p + "h2.w"], a_h, rows_h, h * C, hidp, bias=pk[p + "h2.b"], tag="hire_fc2")    # y_h overwrites a_h
+        E.gemm(xn, pk[p + "c.w"], cur, rows, C, C, bias=pk[p + "c.b"], R=cur, res=N.RES_ADD, tag="hire_c")   # x + proj_c(xn)
+        chain.join()
+        E.hire_combine(cur, a_h, a_w, B, H, W, C, h, w, step, h * C, w * C)
+        got = channel_mlp(ws, cur, rows, C, pk, p + "ff.", C * ef, tag="l%d.cm" % li, part=(ws, "l%d.fc2.part" % li))
+        st = finalize_stats(ws, got, rows, C, tag="l%d.ln" % li)
+        return st
+
+    def _run_single(self, key, x):
+        """block `layers[l].model[b]` alone on channel-last (B, H, W, C), as calling it does in the reference (hire_mlp.py:176-187)"""
+        li, bi = key
+        E.require_gpu(x, "HireMLP block")
+        E.dtype_code(x.dtype)
+        stage = self.layers[li]
+        C = stage.geom[2]
+        if x.dim() != 4 or x.shape[-1] != C:
+            raise ValueError("expected a channel-last (B, H, W, %d) tensor" % C)
+        B, H, W, _ = x.shape
+        with E.on_device(x):
+            pk = self._get_pack(x.dtype, x.device)
+            ws = self._get_space(("block", B, H, W), x.dtype, x.device)
+            cur = ws.get("blk.x", (B * H * W, C))
+            cur.copy_(x.reshape(B * H * W, C))
+            self._block(ws, pk, li, bi, stage, cur, B, H, W, None)
+            return cur.reshape(B, H, W, C).clone()
+
     def forward(self, x):
         cd = self._resolve(x)
         patch, cin, num_classes, patcher_norm = self._cfg
@@ -173,36 +230,8 @@ class HireMLP(E.EngineModule):
         st = None            # (mean, rstd) of cur's rows when the GEMM that wrote cur delivered them (mlpk.h row_part)
         for li, stage in enumerate(self.layers):
             h, w, C, Cout, depth, ef = stage.geom
-            rows = B * H * W
-            Hp, Wp = H + (h - H % h), W + (w - W % w)                                         # hire_mlp.py:131-133
-            gh, gw = Hp // h, Wp // w
-            rows_h, rows_w = B * gh * W, B * H * gw
-            hid = C // 2
-            hidp = E.round_up(hid, 8)
-            xn = ws.get("l%d.xn" % li, (rows, C))
-            a_h = ws.get("l%d.ah" % li, (rows_h, h * C))
-            a_w = ws.get("l%d.aw" % li, (rows_w, w * C))
-            t_h = ws.get("l%d.th" % li, (rows_h, hidp))
-            t_w = ws.get("l%d.tw" % li, (rows_w, hidp))
-            for bi, blk in enumerate(stage.model):
-                p = "l%d.b%d." % (li, bi)
-                step = blk[0].fn[0].step
-                mean, rstd = st if st is not None else layernorm_stats(ws, cur, rows, C, tag="l%d.ln" % li)
-                E.norm_apply(cur, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "ln.g"], beta=pk[p + "ln.b"], out_rm=xn, ld_rm=C)
-                E.hire_gather(xn, a_h, a_w, B, H, W, C, h, w, step, h * C, w * C)
-                # the w-branch pair of GEMMs touches only a_w / t_w: it runs on a side stream beside the h-branch pair and proj_c
-                # (short GEMMs of 20-50 us each: two kernels in flight fill the tail of each other's last wave of tiles)
-                chain = E.SideChain(ws, "hire.w", cur.device)
-                with chain:
-                    E.gemm(a_w, pk[p + "w1.w"], t_w, rows_w, hid, w * C, bias=pk[p + "w1.b"], act=N.ACT_GELU, tag="hire_fc1")
-                    E.gemm(t_w, pk[p + "w2.w"], a_w, rows_w, w * C, hidp, bias=pk[p + "w2.b"], tag="hire_fc2")
-                E.gemm(a_h, pk[p + "h1.w"], t_h, rows_h, hid, h * C, bias=pk[p + "h1.b"], act=N.ACT_GELU, tag="hire_fc1")
-                E.gemm(t_h, pk[p + "h2.w"], a_h, rows_h, h * C, hidp, bias=pk[p + "h2.b"], tag="hire_fc2")    # y_h overwrites a_h
-                E.gemm(xn, pk[p + "c.w"], cur, rows, C, C, bias=pk[p + "c.b"], R=cur, res=N.RES_ADD, tag="hire_c")   # x + proj_c(xn)
-                chain.join()
-                E.hire_combine(cur, a_h, a_w, B, H, W, C, h, w, step, h * C, w * C)
-                got = channel_mlp(ws, cur, rows, C, pk, p + "ff.", C * ef, tag="l%d.cm" % li, part=(ws, "l%d.fc2.part" % li))
-                st = finalize_stats(ws, got, rows, C, tag="l%d.ln" % li)
+            for bi in range(len(stage.model)):
+                st = self._block(ws, pk, li, bi, stage, cur, B, H, W, st)
             if stage.pooling:
                 H2, W2 = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
                 kp = pk["l%d.merge.w" % li].shape[1]

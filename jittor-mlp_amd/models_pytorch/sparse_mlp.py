@@ -22,7 +22,7 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Holder, channel_mlp, finalize_stats, embed_patches, head_linear, layernorm_stats, pack_channel_mlp
+from .common import BlockSequential, Holder, channel_mlp, finalize_stats, embed_patches, head_linear, layernorm_stats, pack_channel_mlp
 from .conv_mixer import _bn_affine
 from .utils import pair
 
@@ -65,7 +65,7 @@ class sMLPStage(Holder):
         super().__init__()
         self.pooling = pooling
         self.patch_merge = nn.Sequential(nn.Identity(), PatchMerging((height, width), d_model), nn.Identity())
-        self.model = nn.Sequential(*[nn.Sequential(
+        self.model = nn.Sequential(*[BlockSequential(
             PreNormResidual(d_model, nn.Sequential(nn.Conv2d(d_model, d_model, kernel_size=3, padding=1, groups=d_model)),
                             norm=nn.BatchNorm2d),
             PreNormResidual(d_model, nn.Sequential(sMLPBlock(height, width, d_model)), norm=nn.BatchNorm2d),
@@ -100,6 +100,9 @@ class SparseMLP(E.EngineModule):
                 d_model = d_model * 2
         self.mlp_head = nn.Sequential(nn.Identity(), nn.LayerNorm(d_model), nn.Identity(), nn.Linear(d_model, num_classes))
         self._cfg = (image_size, patch_size, in_channels, num_classes, patcher_norm)
+        for li, stage in enumerate(self.layers):
+            for bi, blk in enumerate(stage.model):
+                blk.__dict__["_owner"] = (self, (li, bi))          # lets `model.layers[l].model[b](x)` run (common.BlockSequential)
 
     def _pack(self, dtype, device):
         pk = {}
@@ -141,6 +144,59 @@ class SparseMLP(E.EngineModule):
         pk["head.b"] = E.f32(self.mlp_head[3].bias, device)
         return pk
 
+    def _block(self, ws, pk, li, bi, stage, cur, tmp, B):
+        """Block `layers[li].model[bi]` on channel-last rows `cur` (B*H*W, C) with `tmp` as the other half of the ping-pong pair (a stencil
+        cannot run in place); returns (result buffer, the other one)."""
+        H, W, C, depth, ef = stage.geom
+        rows = B * H * W
+        tgk = ("l%d.b0.pw.tg" % li) in pk                            # token kernel: K padded to whole 64-byte slabs
+        hp, wp = E.round_up(H, 32 if tgk else 8), E.round_up(W, 32 if tgk else 8)
+        xh = ws.get("l%d.xh" % li, (rows, C))
+        cat = ws.get("l%d.cat" % li, (rows, 2 * C))                  # [x_w | x^]
+        xt_w = ws.get("l%d.xtw" % li, (B * H * C, wp))
+        xt_h = ws.get("l%d.xth" % li, (B * W * C, hp))
+        p = "l%d.b%d." % (li, bi)
+        # x + dwconv3x3(BN(x)) + b    (ping-pong cur <-> tmp: a stencil cannot run in place)
+        E.dwconv_affine_nhwc(cur, tmp, B, H, W, C, 3, pk[p + "dw.w"], pk[p + "dw.b"], pk[p + "dw.s"], pk[p + "dw.h"])
+        cur, tmp = tmp, cur
+        # x^ = BN(x): row-major into cat[:, C:], transposed over W per (b, h); transposed over H per image
+        E.norm_apply(cur, rows, C, C, gamma=pk[p + "bn.s"], beta=pk[p + "bn.h"], out_rm=cat[:, C:], ld_rm=2 * C,
+                     out_tt=xt_w, S=W, ld_tt=wp)
+        E.norm_apply(cur, B * H, W * C, W * C, gamma=pk[p + "bn.sw"], beta=pk[p + "bn.hw"], out_tt=xt_h, S=H, ld_tt=hp)
+        if tgk:
+            tw, th = pk[p + "pw.tg"], pk[p + "ph.tg"]
+            E.token_gemm(xt_w, wp, B * H * C, W, tw[0], tw[1], tw[2], cat, 2 * C, C)
+            E.token_gemm(xt_h, hp, B * W * C, H, th[0], th[1], th[2], xh, W * C, W * C)
+        else:
+            E.gemm(xt_w, pk[p + "pw.w"], cat, B * H * C, W, wp, ldc=2 * C, bias=pk[p + "pw.b"], out_mode=N.OUT_TOKEN_T,
+                   t_rows=C, t_tokens=W, tag="smlp_w")
+            E.gemm(xt_h, pk[p + "ph.w"], xh, B * W * C, H, hp, ldc=W * C, bias=pk[p + "ph.b"], out_mode=N.OUT_TOKEN_T,
+                   t_rows=W * C, t_tokens=H, tag="smlp_h")
+        E.gemm(xh, pk[p + "fu.wh"], cur, rows, C, C, bias=pk[p + "fu.b"], R=cur, res=N.RES_ADD, tag="smlp_fuse")
+        # the LayerNorm of the channel MLP reads what this GEMM writes: its statistics come out of the epilogue (mlpk.h row_part)
+        got = E.gemm(cat, pk[p + "fu.wr"], cur, rows, C, 2 * C, R=cur, res=N.RES_ADD, tag="smlp_fuse", part=(ws, "l%d.fu.part" % li))
+        channel_mlp(ws, cur, rows, C, pk, p + "ff.", C * ef, tag="l%d.cm" % li, stats=finalize_stats(ws, got, rows, C, tag="l%d.cm.ln" % li))
+        return cur, tmp
+
+    def _run_single(self, key, x):
+        """block `layers[l].model[b]` alone on (B, C, H, W) with the stage's H x W, as calling it does in the reference (sparse_mlp.py:84-104)"""
+        li, bi = key
+        E.require_gpu(x, "SparseMLP block")
+        E.dtype_code(x.dtype)
+        stage = self.layers[li]
+        H, W, C = stage.geom[:3]
+        if x.dim() != 4 or tuple(x.shape[1:]) != (C, H, W):
+            raise ValueError("expected a (B, %d, %d, %d) tensor" % (C, H, W))
+        B = x.shape[0]
+        rows = B * H * W
+        with E.on_device(x):
+            pk = self._get_pack(x.dtype, x.device)
+            ws = self._get_space(("block", B, H, W), x.dtype, x.device)
+            cur = ws.get("blk.x", (rows, C))
+            cur.copy_(x.permute(0, 2, 3, 1).reshape(rows, C))                          # channel-last rows, as the stages keep them
+            cur, _ = self._block(ws, pk, li, bi, stage, cur, ws.get("blk.tmp", (rows, C)), B)
+            return cur.reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
+
     def forward(self, x):
         cd = self._resolve(x)
         image_size, patch, cin, num_classes, patcher_norm = self._cfg
@@ -158,35 +214,9 @@ class SparseMLP(E.EngineModule):
         for li, stage in enumerate(self.layers):
             H, W, C, depth, ef = stage.geom
             rows = B * H * W
-            tgk = ("l%d.b0.pw.tg" % li) in pk                            # token kernel: K padded to whole 64-byte slabs
-            hp, wp = E.round_up(H, 32 if tgk else 8), E.round_up(W, 32 if tgk else 8)
             tmp = ws.get("l%d.tmp" % li, (rows, C))
-            xh = ws.get("l%d.xh" % li, (rows, C))
-            cat = ws.get("l%d.cat" % li, (rows, 2 * C))                  # [x_w | x^]
-            xt_w = ws.get("l%d.xtw" % li, (B * H * C, wp))
-            xt_h = ws.get("l%d.xth" % li, (B * W * C, hp))
             for bi in range(depth):
-                p = "l%d.b%d." % (li, bi)
-                # x + dwconv3x3(BN(x)) + b    (ping-pong cur <-> tmp: a stencil cannot run in place)
-                E.dwconv_affine_nhwc(cur, tmp, B, H, W, C, 3, pk[p + "dw.w"], pk[p + "dw.b"], pk[p + "dw.s"], pk[p + "dw.h"])
-                cur, tmp = tmp, cur
-                # x^ = BN(x): row-major into cat[:, C:], transposed over W per (b, h); transposed over H per image
-                E.norm_apply(cur, rows, C, C, gamma=pk[p + "bn.s"], beta=pk[p + "bn.h"], out_rm=cat[:, C:], ld_rm=2 * C,
-                             out_tt=xt_w, S=W, ld_tt=wp)
-                E.norm_apply(cur, B * H, W * C, W * C, gamma=pk[p + "bn.sw"], beta=pk[p + "bn.hw"], out_tt=xt_h, S=H, ld_tt=hp)
-                if tgk:
-                    tw, th = pk[p + "pw.tg"], pk[p + "ph.tg"]
-                    E.token_gemm(xt_w, wp, B * H * C, W, tw[0], tw[1], tw[2], cat, 2 * C, C)
-                    E.token_gemm(xt_h, hp, B * W * C, H, th[0], th[1], th[2], xh, W * C, W * C)
-                else:
-                    E.gemm(xt_w, pk[p + "pw.w"], cat, B * H * C, W, wp, ldc=2 * C, bias=pk[p + "pw.b"], out_mode=N.OUT_TOKEN_T,
-                           t_rows=C, t_tokens=W, tag="smlp_w")
-                    E.gemm(xt_h, pk[p + "ph.w"], xh, B * W * C, H, hp, ldc=W * C, bias=pk[p + "ph.b"], out_mode=N.OUT_TOKEN_T,
-                           t_rows=W * C, t_tokens=H, tag="smlp_h")
-                E.gemm(xh, pk[p + "fu.wh"], cur, rows, C, C, bias=pk[p + "fu.b"], R=cur, res=N.RES_ADD, tag="smlp_fuse")
-                # the LayerNorm of the channel MLP reads what this GEMM writes: its statistics come out of the epilogue (mlpk.h row_part)
-                got = E.gemm(cat, pk[p + "fu.wr"], cur, rows, C, 2 * C, R=cur, res=N.RES_ADD, tag="smlp_fuse", part=(ws, "l%d.fu.part" % li))
-                channel_mlp(ws, cur, rows, C, pk, p + "ff.", C * ef, tag="l%d.cm" % li, stats=finalize_stats(ws, got, rows, C, tag="l%d.cm.ln" % li))
+                cur, tmp = self._block(ws, pk, li, bi, stage, cur, tmp, B)
             if stage.pooling:
                 assert H % 2 == 0 and W % 2 == 0, f"x size ({H}*{W}) are not even."                      # sparse_mlp.py:38
                 p = "l%d.merge." % li

@@ -468,6 +468,60 @@ def test_s2v1_and_convmixer_blocks_callable_like_the_reference():
     assert (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
+def test_hire_block_callable_like_the_reference():
+    """hire_mlp.py:176-187: `model.layers[l].model[b](x)` on channel-last (B, H, W, C); block 1 of a stage is the cross-region one."""
+    pkg = load_pkg()
+    mp = pkg.models_pytorch
+    Fo = oracle.functional
+    z = np.load(os.path.join(GOLDEN, "tiny_hiremlp.npz"))
+    kw = json.loads(str(z["kwargs"]))
+    torch.manual_seed(23)
+    model = mp.HireMLP(**kw).eval()
+    for p in model.parameters():
+        p.data.add_(0.05 * torch.randn_like(p))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    interval = kw.get("cross_region_interval", 2)
+    for li, stage in enumerate(model.layers):
+        h, w, C = stage.geom[:3]
+        for bi in range(len(stage.model)):
+            t = torch.randn(2, 7, 9, C)                               # neither side a multiple of the region size
+            pre = "layers.%d.model.%d." % (li, bi)
+            n = Fo.layer_norm(t, sd[pre + "0.norm.weight"], sd[pre + "0.norm.bias"])
+            ref = t + Fo.hiremlp_block(sd, n, pre + "0.fn.0.", h, w, stage.model[bi][0].fn[0].step or 1, (bi + 1) % interval == 0)
+            n = Fo.layer_norm(ref, sd[pre + "1.norm.weight"], sd[pre + "1.norm.bias"])
+            ref = ref + Fo.linear(Fo.gelu(Fo.linear(n, sd[pre + "1.fn.0.weight"], sd[pre + "1.fn.0.bias"])), sd[pre + "1.fn.3.weight"],
+                                  sd[pre + "1.fn.3.bias"])
+            got = stage.model[bi](t.to(DEV))
+            assert (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), (li, bi)
+
+
+def test_sparsemlp_block_callable_like_the_reference():
+    """sparse_mlp.py:84-104: `model.layers[l].model[b](x)` on (B, C, H, W) at the stage's resolution."""
+    pkg = load_pkg()
+    mp = pkg.models_pytorch
+    z = np.load(os.path.join(GOLDEN, "tiny_sparsemlp.npz"))
+    kw = json.loads(str(z["kwargs"]))
+    torch.manual_seed(29)
+    model = mp.SparseMLP(**kw).eval()
+    for p in model.parameters():
+        p.data.add_(0.05 * torch.randn_like(p))
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    for li, stage in enumerate(model.layers):
+        H, W, C = stage.geom[:3]
+        bi = len(stage.model) - 1
+        t = torch.randn(2, C, H, W)
+        ref = oracle.functional.sparsemlp_block(sd, t, "layers.%d.model.%d." % (li, bi))
+        got = stage.model[bi](t.to(DEV))
+        assert got.shape == ref.shape
+        assert (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), (li, bi)
+
+
 def test_cpu_input_raises():
     pkg = load_pkg()
     model = pkg.MLPMixerForImageClassification(d_model=32, depth=1, patch_size=8, image_size=32, num_classes=10)
