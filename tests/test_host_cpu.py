@@ -88,6 +88,31 @@ def test_gemm_row_parts_plan_without_gpu():
     assert lib.mlpk_stats_finalize_planar(None, 1, 1, 1, 1, 1, 1e-5, None, None, None) != 0
 
 
+def test_blocks_know_their_owner_and_have_no_cpu_path():
+    """Callable blocks (common.Block / BlockSequential): the owner reference lives outside the module tree (no extra state_dict keys,
+    no extra sub-modules), survives copy.deepcopy pointing at the COPY, and a CPU tensor raises instead of computing anything."""
+    import copy
+    import torch
+    pkg = load_pkg()
+    mp = pkg.models_pytorch
+    cases = [(mp.gMLP(d_model=16, d_ffn=32, seq_len=4, depth=2), lambda m: m.model[1], (1, 4, 16)),
+             (mp.WeightedPermutator(2, 2, 16, 2, 4), lambda m: m.model[1], (1, 2, 2, 16)),
+             (mp.ConvMixer(16, 2, kernel_size=3, patch_size=4, n_classes=5), lambda m: m.blocks[1], (1, 16, 4, 4)),
+             (mp.AS_MLP(img_size=16, patch_size=4, embed_dim=16, depths=[1, 1], num_classes=5), lambda m: m.layers[1].blocks[0], (1, 32, 2, 2))]
+    for model, pick, shape in cases:
+        blk = pick(model)
+        assert blk.__dict__["_owner"][0] is model
+        assert not any("_owner" in k for k in model.state_dict())
+        assert all(m is not model for m in blk.modules())                  # the owner is not a sub-module of its block
+        twin = copy.deepcopy(model)
+        assert pick(twin).__dict__["_owner"][0] is twin
+        with pytest.raises(NotImplementedError):
+            blk(torch.zeros(shape))
+    lone = mp.g_mlp.gMLPBlock(16, 32, 4)                                   # outside a backbone: a parameter container
+    with pytest.raises(NotImplementedError):
+        lone(torch.zeros(1, 4, 16))
+
+
 def test_constructor_signatures_match_reference():
     pkg = load_pkg()
     with open(os.path.join(GOLDEN, "manifest.json")) as f:
