@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmlpk.so")
-SOURCES = ["mlpk_gemm.hip", "mlpk_norm.hip", "mlpk_embed.hip", "mlpk_remap.hip", "mlpk_tokenmlp.hip", "mlpk_dwconv.hip", "mlpk_hire.hip"]
+SOURCES = ["mlpk_gemm.hip", "mlpk_gemm_q4.hip", "mlpk_norm.hip", "mlpk_embed.hip", "mlpk_remap.hip", "mlpk_tokenmlp.hip", "mlpk_dwconv.hip", "mlpk_hire.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
 FLAGS += os.environ.get("MLPK_EXTRA_FLAGS", "").split()      # tuning aid: A/B builds of a kernel variant (-DTM_...)
 
@@ -35,8 +35,25 @@ def _digest(paths):
     return h.hexdigest()
 
 
+GEN = os.path.join(CSRC, "gen")
+GEN_OUT = os.path.join(CSRC, "gen_out")
+
+
+def _generate():
+    """run the kernel generators (csrc/gen/*.py -> csrc/gen_out/*.inc, git-ignored: the generators are the source)"""
+    os.makedirs(GEN_OUT, exist_ok=True)
+    out = os.path.join(GEN_OUT, "q4_kernels.inc")
+    srcs = [os.path.join(GEN, f) for f in ("q4gen.py", "isa.py")]
+    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(x) for x in srcs):
+        return
+    r = subprocess.run([sys.executable, os.path.join(GEN, "q4gen.py"), out], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("q4gen failed:\n" + r.stderr[-4000:])
+
+
 def _deps():
     d = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    d += [os.path.join(GEN, f) for f in os.listdir(GEN) if f.endswith(".py")]
     d.append(os.path.join(os.path.dirname(HERE), "include", "mlpk.h"))
     return d
 
@@ -45,6 +62,7 @@ def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 and link libmlpk.so.  Returns the library path."""
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
+    _generate()
     stamp = os.path.join(LIBDIR, "stamp.txt")      # next to the library: build/ (121 MB of -save-temps output) does not travel to the GPU box
     digest = _digest(_deps())
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
@@ -55,7 +73,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(OBJ, src.replace(".hip", ".o"))
         # -save-temps=obj keeps the gfx950 assembly next to the object: tools/isa_lint.py (tests/test_host_cpu.py) checks
         # the hand-scheduled loops in what hipcc actually generated
-        cmd = [hipcc] + FLAGS + ["-save-temps=obj", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + ["-save-temps=obj", "-Wno-inline-asm", "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))

@@ -18,6 +18,7 @@
 //   * XCD-aware tile order: each of the 8 XCDs walks a contiguous range of tiles (n fastest) so the
 //     A panel and the weight panels are re-used out of that XCD's private L2.
 #include "mlpk_common.h"
+#include "mlpk_gemm_q4.h"
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -1507,6 +1508,8 @@ static const TileCfg kTiles[] = {
     {128, 128, 2, 2, 2},
     {128, 256, 2, 2, 2},
     {256, 256, 2, 4, 3},   // algo 14: "p8" ping-pong pipeline (8 waves, 128 KiB LDS, 1 workgroup / CU; K % slab == 0, K >= 2 slabs)
+    {256, 128, 2, 2, 4},   // algo 15: "q4" generated kernels (mlpk_gemm_q4.hip): 4 waves = one per SIMD, 144 KiB LDS, epilogue of tile
+                           //          T - 1 issued behind the MFMAs of tile T
 };
 static const int kNumTiles = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
 
@@ -1701,6 +1704,22 @@ template <typename T> static int launch_p8(const GemmArgs& a0, bool trans, hipSt
     }
 }
 
+// the call as the generated q4 kernels take it; false when they do not implement it (other tiles do)
+static bool q4_call_of(const GemmArgs& a, int dtype, bool trans, Q4Call& c) {
+    if (dtype == MLPK_F32 || trans || a.rscale || a.cscale || a.cshift || a.row_part) return false;
+    if (a.res_mode != MLPK_RES_NONE && a.res_mode != MLPK_RES_ADD) return false;
+    if (a.ln_mean && a.ln_group != 1) return false;
+    c.dtype = dtype;
+    c.M = a.M; c.N = a.N; c.K = a.K;
+    c.lda = a.lda; c.ldb = a.ldb; c.ldc = a.ldc; c.ldr = a.ldr;
+    c.A = a.A; c.B = a.B; c.C = a.C; c.R = a.res_mode != MLPK_RES_NONE ? a.R : nullptr;
+    c.bias = a.bias; c.ln_mean = a.ln_mean; c.ln_rstd = a.ln_rstd; c.ln_csum = a.ln_csum;
+    c.gelu = a.act == MLPK_ACT_GELU; c.ln = a.ln_mean != nullptr; c.res = a.res_mode != MLPK_RES_NONE;
+    c.one_group = (a.dbg & 128) != 0;
+    c.dbg = a.dbg & 5;
+    return q4_supported(c);
+}
+
 template <typename T> static int launch_algo(int algo, const GemmArgs& a, bool trans, hipStream_t s, void* ws, long long ws_bytes) {
     switch (algo) {
         case 1: return launch_cfg<T, 256, 256, 2, 4, false>(a, trans, s);
@@ -1717,6 +1736,11 @@ template <typename T> static int launch_algo(int algo, const GemmArgs& a, bool t
         case 12: return launch_s3<T, 128, 128, 2, 2>(a, trans, s);
         case 13: return launch_s3<T, 128, 256, 2, 2>(a, trans, s);
         case 14: return launch_p8<T>(a, trans, s);
+        case 15: {
+            Q4Call c;
+            if (!q4_call_of(a, dtype_of<T>::value, trans, c)) return MLPK_ESHAPE;
+            return q4_launch(c, s);
+        }
         default: return MLPK_EMODE;
     }
 }
@@ -1732,6 +1756,7 @@ static int auto_algo(int M, int N, int K, int epc, bool glds_ok, bool p8_ok, boo
         const TileCfg& t = kTiles[i];
         const int area = t.bm * t.bn;
         if (stats && t.bn < 128) continue;        // the by-product row statistics reduce over whole 16-lane rows = 128 columns
+        if (t.glds == 4) continue;                // the generated tile is chosen in gemm_prepare (q4_prefer), not by this cost model
         if (t.glds == 3) {
             // persistent ping-pong tile: whole launch rounds of one tile per CU, tile heights mixed to fill them (p8_plan);
             // its per-tile fixed cost (first slabs + epilogue, not overlapped with another workgroup) weighs more the
@@ -1783,7 +1808,7 @@ extern "C" int mlpk_gemm_algo_info(int algo, int* bm, int* bn, int* threads, int
     if (bm) *bm = t.bm;
     if (bn) *bn = t.bn;
     if (threads) *threads = t.wm * t.wn * 64;
-    if (lds_bytes) *lds_bytes = t.glds == 3 ? P8_LDS_BYTES : t.glds == 2 ? 3 * (t.bm + t.bn) * 64 : 2 * (t.bm + t.bn) * 128;
+    if (lds_bytes) *lds_bytes = t.glds == 4 ? Q4_LDS_BYTES : t.glds == 3 ? P8_LDS_BYTES : t.glds == 2 ? 3 * (t.bm + t.bn) * 64 : 2 * (t.bm + t.bn) * 128;
     return 0;
 }
 
@@ -1851,9 +1876,19 @@ static int gemm_prepare(const mlpk_gemm_desc* d, GemmArgs& a, int& algo, bool& t
     // ... and with statistics, where the direct epilogue instantiates them: bias + residual (the GEMMs that produce a residual stream)
     const bool p8_stats_ok = d->res_mode != MLPK_RES_NONE && d->act == MLPK_ACT_NONE && !d->ln_mean && !d->cscale && !d->cshift && !(a.dbg & 64);
     if (stats && !p8_stats_ok) p8_ok = false;
+    if (algo == 0) {
+        // round 3: the generated one-wave-per-SIMD tile where it applies (MLPK_GEMM_Q4=0 switches it off for A/B runs)
+        static const int q4_mode = getenv("MLPK_GEMM_Q4") ? atoi(getenv("MLPK_GEMM_Q4")) : 0;
+        Q4Call qc;
+        if (q4_mode && !stats && q4_call_of(a, d->dtype, trans, qc)) algo = 15;
+    }
     if (algo == 0) algo = auto_algo(d->M, d->N, d->K, epc, glds_ok, p8_ok, stats);
     if (algo < 1 || algo > kNumTiles) return MLPK_EMODE;
     if (kTiles[algo - 1].glds && !glds_ok) return MLPK_ESHAPE;
+    if (kTiles[algo - 1].glds == 4) {
+        Q4Call qc;
+        if (stats || !q4_call_of(a, d->dtype, trans, qc)) return MLPK_ESHAPE;
+    }
     if (stats) {
         if (kTiles[algo - 1].bn < 128 || (kTiles[algo - 1].glds == 3 && !p8_stats_ok)) return MLPK_EMODE;
         if (d->row_part_ld < d->M) return MLPK_ESHAPE;

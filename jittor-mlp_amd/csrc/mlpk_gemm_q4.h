@@ -1,0 +1,29 @@
+// Host interface of the generated "q4" GEMM kernels (mlpk_gemm_q4.hip); called from the tile dispatch of mlpk_gemm.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mlpk {
+
+#define Q4_LDS_BYTES (3 * 49152)
+
+struct Q4Call {
+    int dtype;                 // MLPK_BF16 / MLPK_F16
+    int M, N, K;
+    int lda, ldb, ldc, ldr;
+    const void* A;
+    const void* B;
+    void* C;
+    const void* R;             // residual (res): C = round(round(acc + bias) + R)
+    const float* bias;         // [N], required
+    const float* ln_mean;      // folded LayerNorm (ln): v = (acc - mean[m] * csum[n]) * rstd[m] + bias[n]
+    const float* ln_rstd;
+    const float* ln_csum;
+    int gelu, ln, res;
+    int one_group;             // tuning: a single column group
+    int dbg;                   // tuning ablations: 1 = no LDS-DMA, 4 = no epilogue fillers (results are wrong by construction)
+};
+
+bool q4_supported(const Q4Call& c);
+int q4_launch(const Q4Call& c, hipStream_t stream);
+
+}  // namespace mlpk
