@@ -505,6 +505,20 @@ class Emu:
                 w.spend.discard(r)
         w.lgkm.append(done)
 
+    def x_s_memtime(self, w, i):
+        d = i.args[0]
+        regs = [d.idx, d.idx + 1]
+        val = w.nissued * 4
+        for r in regs:
+            w.spend.add(r)
+
+        def done():
+            w.s[regs[0]] = val & 0xFFFFFFFF
+            w.s[regs[1]] = val >> 32
+            for r in regs:
+                w.spend.discard(r)
+        w.lgkm.append(done)
+
     def x_s_load_dword(self, w, i):
         self._s_load(w, i, 1)
 
@@ -820,6 +834,11 @@ def lint(asm, mfma_gap=16, verbose=False):
     for k, i in enumerate(asm.ins):
         if i.op == "label":
             continue
+        for o in i.args:
+            if isinstance(o, Neg):
+                o = o.r
+            if isinstance(o, Reg) and o.n >= 2 and o.kind in ("v", "a", "s") and o.idx % 2:
+                problems.append((k, "register tuple %s is not 64-bit aligned" % o.text()))
         d, u = defs_uses(i)
         is_mfma = i.op.startswith("v_mfma")
         is_valu = i.op.startswith("v_") and not is_mfma

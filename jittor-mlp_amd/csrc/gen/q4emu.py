@@ -85,6 +85,9 @@ def run_case(gen, M, N, K, grid, cgroups=1, seed=0, dma_mode="late", order=None,
     ints = dict(lda=K, ldb=K, ldc=N, ldr=N, **pl)
     for name, val in ints.items():
         struct.pack_into("<I", ka, q4gen.KA[name], val)
+    prof = np.zeros(grid * 2, np.uint32)
+    aProf = mem.add(prof)
+    struct.pack_into("<Q", ka, q4gen.KA["prof"], aProf)
     karg = mem.add(np.frombuffer(bytes(ka), np.uint8))
     Cbuf = mem.get(aC)
     nins = 0
@@ -92,6 +95,8 @@ def run_case(gen, M, N, K, grid, cgroups=1, seed=0, dma_mode="late", order=None,
         e = Q4Emu(gen, mem, karg, bid, dma_mode=dma_mode, order=order)
         waves = e.run()
         nins += sum(w.nissued for w in waves)
+    if verbose:
+        print("prof:", mem.get(aProf).view(np.uint32).reshape(grid, 2).tolist())
     out = from16(Cbuf.view(np.uint16).reshape(M, N), dt).astype(np.float64)
     # reference
     acc = from16(A, dt).astype(np.float64) @ from16(B, dt).astype(np.float64).T

@@ -38,7 +38,7 @@ LDS_BYTES = 3 * STAGE_B
 
 # kernarg layout (bytes) -- mirrored by struct Q4Args in mlpk_gemm_q4.hip
 KA = dict(A=0, B=8, C=16, R=24, bias=32, ln_mean=40, ln_rstd=48, ln_csum=56,
-          lda=64, ldb=68, ldc=72, ldr=76, nk=80, cg=84, cg_magic=88, U=92, Q=96, log2X=100, m_base=104, grid=108)
+          lda=64, ldb=68, ldc=72, ldr=76, nk=80, cg=84, cg_magic=88, U=92, Q=96, log2X=100, m_base=104, grid=108, prof=112)
 
 
 class Alloc:
@@ -56,10 +56,13 @@ class Alloc:
 
 
 class Q4:
-    def __init__(self, dtype="bf16", gelu=False, ln=False, res=False, nkf=4, fillers_on=True, dma_on=True, name=None):
+    def __init__(self, dtype="bf16", gelu=False, ln=False, res=False, nkf=4, dbg=0, name=None):
         assert nkf >= 2
         self.dtype, self.gelu, self.ln, self.res, self.nkf = dtype, gelu, ln, res, nkf
-        self.fillers_on, self.dma_on = fillers_on, dma_on
+        # tuning ablations (results are wrong by construction): 1 no LDS-DMA, 2 no stores, 4 no epilogue fillers, 8 no fragment reads,
+        # 16 minimal iteration tail (no stage rotation)
+        self.dbg = dbg
+        self.fillers_on, self.dma_on, self.stores_on, self.reads_on, self.tail_on = not (dbg & 4), not (dbg & 1), not (dbg & 2), not (dbg & 8), not (dbg & 16)
         self.name = name or "q4_%s%s%s%s_f%d" % (dtype, "_gelu" if gelu else "", "_ln" if ln else "", "_res" if res else "", nkf)
         self.a = Asm()
         self.mfma = "v_mfma_f32_32x32x16_bf16" if dtype == "bf16" else "v_mfma_f32_32x32x16_f16"
@@ -92,6 +95,7 @@ class Q4:
         self.s_eC, self.s_eR = s("eC", 2, 2), s("eR", 2, 2)
         self.s_eBias, self.s_eCsum, self.s_eMu, self.s_eRstd = s("eBias", 2, 2), s("eCsum", 2, 2), s("eMu", 2, 2), s("eRstd", 2, 2)
         self.s_r2 = s("r2")
+        self.s_prof0, self.s_prof1, self.s_profp, self.s_ntiles = s("prof0", 2, 2), s("prof1", 2, 2), s("profp", 2, 2), s("ntiles")
         self.s_t = [s("t%d" % i) for i in range(6)]
         self.s_t64 = s("t64", 2, 2)
         # vector registers
@@ -118,6 +122,7 @@ class Q4:
         self.v_quad = [v("quad%d" % k, 4, 4) for k in range(2)]
         self.v_res = [[[v("res%d_%d_%d" % (i, j, h), 4, 4) for h in range(2)] for j in range(2)] for i in range(4)] if self.res else None
         self.v_tmp = [v("tmp%d" % i) for i in range(8)]
+        self.v_pair = v("pair", 2, 2)
         self.nv, self.ns = v.next, s.next
 
     def acc(self, set_, b):
@@ -317,7 +322,8 @@ class Q4:
                             E("v_add_f32", tm[0], tm[0], tm[2])
                             E("v_add_f32", tm[1], tm[1], tm[3])
                             E(self.cvt, quad[k], tm[0], tm[1])
-                    E("global_store_dwordx4", self.voffC[i], quad, self.s_eC, offset=(j * 32 + (g >> 1) * 16) * 2)
+                    if self.stores_on:
+                        E("global_store_dwordx4", self.voffC[i], quad, self.s_eC, offset=(j * 32 + (g >> 1) * 16) * 2)
         return ops
 
     # ------------------------------------------------------------------ one iteration of the K loop
@@ -333,6 +339,8 @@ class Q4:
 
         def need(frag, idx_of):
             # wait until read number idx is complete: allow (issued - idx - 1) younger reads outstanding
+            if not self.reads_on:
+                return
             n = nread - idx_of[frag] - 1
             a("s_waitcnt", lgkmcnt=n)
         dma_slots = {(0, 1): ("A", 0), (0, 3): ("A", 1), (0, 6): ("A", 2), (0, 7): ("A", 3),
@@ -367,7 +375,7 @@ class Q4:
                         a("global_load_lds_dwordx4", self.voffA[pc], self.s_dA)
                     else:
                         a("global_load_lds_dwordx4", self.voffB[pc], self.s_dB)
-                if qm < 6:
+                if qm < 6 and self.reads_on:
                     kind, idx = read_order[qm]
                     if kind == "A":
                         a("ds_read_b128", self.FA[rbuf][idx], self.v_curA[s], offset=idx * 4096)
@@ -397,6 +405,10 @@ class Q4:
     def iter_tail(self, vm_allow):
         """advance the DMA stream and the LDS stages, then wait + barrier"""
         a, t = self.a, self.s_t
+        if not self.tail_on:
+            a("s_waitcnt", vmcnt=vm_allow, lgkmcnt=0)
+            a("s_barrier")
+            return
         if self.dma_on:
             self.add64(self.s_dA, self.s_dA, 128)
             self.add64(self.s_dB, self.s_dB, 128)
@@ -432,6 +444,7 @@ class Q4:
         a("s_load_dwordx16", S(4, 16), self.s_karg, 0)
         a("s_load_dwordx8", S(20, 8), self.s_karg, 64)
         a("s_load_dwordx4", S(28, 4), self.s_karg, 96)
+        a("s_load_dwordx2", self.s_profp, self.s_karg, KA["prof"])
         # ---- lane constants (independent of the arguments)
         vt = self.v_tmp
         lane, l31, h, l3, l7, x = vt[0], vt[1], vt[2], vt[3], vt[4], vt[5]
@@ -449,6 +462,7 @@ class Q4:
         a("s_mov_b32", self.s_r2, F(SQRT2))
         a("v_mov_b32", self.v_c0, F(GELU_COEFS[0]))
         a("s_waitcnt", lgkmcnt=0)
+        a("s_memtime", self.s_prof0)
         # wave position: wm = wave >> 1, wn = wave & 1
         wm, wn = t[3], t[4]
         a("s_lshr_b32", wm, self.s_wave, 1)
@@ -508,6 +522,7 @@ class Q4:
         a("s_sub_u32", t[3], k["U"], self.s_u0)                      # may wrap when u0 > U: compared as signed below
         a("s_cmp_lt_i32", t[3], k["Q"])
         a("s_cselect_b32", self.s_lend, t[3], k["Q"])
+        a("s_mov_b32", self.s_ntiles, 0)
         a("s_lshr_b32", self.s_lnext, self.s_bid, 3)                 # l of the first tile
         a("s_cmp_lt_i32", self.s_lnext, self.s_lend)
         a("s_cbranch_scc0", L_end)
@@ -520,6 +535,7 @@ class Q4:
         a("s_add_u32", t[3], t[3], self.s_lstep)
         a("s_cmp_lt_u32", t[3], self.s_lend)
         a("s_cbranch_scc1", L_cnt)
+        a("s_mov_b32", self.s_ntiles, self.s_left)
         # ---- first tile: coordinates, DMA bases; the next tile's
         self.coords(self.s_lnext, self.s_cm0, self.s_cn0)
         self.dma_base(self.s_dA, self.s_dB, self.s_cm0, self.s_cn0)
@@ -615,12 +631,28 @@ class Q4:
         a("s_branch", L_block[0])
         a.label(L_end)
         a("s_waitcnt", vmcnt=0, lgkmcnt=0)
+        # tuning: prof != 0 -> wave 0 of every workgroup stores (cycles of the whole kernel body, tiles)
+        L_np = a.newlabel("NOPROF")
+        a("s_memtime", self.s_prof1)
+        a("s_cmp_eq_u32", self.s_profp[0], 0)
+        a("s_cbranch_scc1", L_np)
+        a("s_cmp_lg_u32", self.s_wave, 0)
+        a("s_cbranch_scc1", L_np)
+        a("s_waitcnt", lgkmcnt=0)
+        a("s_sub_u32", self.s_prof1[0], self.s_prof1[0], self.s_prof0[0])
+        a("s_lshl_b32", self.s_t[0], self.s_bid, 3)
+        a("v_mov_b32", self.v_tmp[0], self.s_t[0])
+        a("v_mov_b32", self.v_pair[0], self.s_prof1[0])
+        a("v_mov_b32", self.v_pair[1], self.s_ntiles)
+        a("global_store_dwordx2", self.v_tmp[0], self.v_pair, self.s_profp)
+        a("s_waitcnt", vmcnt=0)
+        a.label(L_np)
 
 
 # ------------------------------------------------------------------ emission
 # variant table: (class name, gelu, ln, res, unrolled iterations)
 CLASSES = {"p": (False, False, False), "l": (False, True, False), "g": (True, False, False), "gl": (True, True, False), "r": (False, False, True)}
-NKF = {"p": (3, 4), "l": (3, 4, 6), "g": (4, 6, 12), "gl": (4, 6, 12), "r": (4, 6)}
+NKF = {"p": (3, 4), "l": (3, 4, 6), "g": (3, 4, 6, 12), "gl": (3, 4, 6, 12), "r": (3, 4, 6)}
 DTYPES = ("bf16", "f16")
 
 
@@ -629,11 +661,11 @@ def variants():
         for cls, (gelu, ln, res) in CLASSES.items():
             for nkf in NKF[cls]:
                 yield "q4_%s_%s_f%d" % (dt, cls, nkf), dict(dtype=dt, gelu=gelu, ln=ln, res=res, nkf=nkf)
-    # tuning ablations (wrong results by construction; desc.reserved bits 1 = no LDS-DMA, 4 = no epilogue fillers)
+    # tuning ablations (wrong results by construction; bits in Q4.__init__)
     for cls, nkf in (("gl", 12), ("r", 6)):
         gelu, ln, res = CLASSES[cls]
-        for x in (1, 4, 5):
-            yield "q4_bf16_%s_f%d_x%d" % (cls, nkf, x), dict(dtype="bf16", gelu=gelu, ln=ln, res=res, nkf=nkf, dma_on=not (x & 1), fillers_on=not (x & 4))
+        for x in (1, 2, 4, 5, 13, 21, 29):
+            yield "q4_bf16_%s_f%d_x%d" % (cls, nkf, x), dict(dtype="bf16", gelu=gelu, ln=ln, res=res, nkf=nkf, dbg=x)
 
 
 def kernel_text(name, gen):
@@ -659,7 +691,7 @@ def emit(path):
     out.append("namespace mlpk {\nstruct Q4Variant { const char* name; const void* fn; int dtype, gelu, ln, res, nkf, dbg; };\n"
                "static const Q4Variant kQ4Variants[] = {\n")
     for name, kw in table:
-        dbg = (0 if kw.get("dma_on", True) else 1) | (0 if kw.get("fillers_on", True) else 4)
+        dbg = kw.get("dbg", 0)
         out.append("    {\"%s\", reinterpret_cast<const void*>(&%s), %s, %d, %d, %d, %d, %d},\n" %
                    (name, name, "MLPK_BF16" if kw["dtype"] == "bf16" else "MLPK_F16", kw["gelu"], kw["ln"], kw["res"], kw["nkf"], dbg))
     out.append("};\n}  // namespace mlpk\n")

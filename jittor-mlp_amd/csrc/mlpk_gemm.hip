@@ -1716,7 +1716,8 @@ static bool q4_call_of(const GemmArgs& a, int dtype, bool trans, Q4Call& c) {
     c.bias = a.bias; c.ln_mean = a.ln_mean; c.ln_rstd = a.ln_rstd; c.ln_csum = a.ln_csum;
     c.gelu = a.act == MLPK_ACT_GELU; c.ln = a.ln_mean != nullptr; c.res = a.res_mode != MLPK_RES_NONE;
     c.one_group = (a.dbg & 128) != 0;
-    c.dbg = a.dbg & 5;
+    c.dbg = a.dbg & 31;
+    c.prof = (a.dbg & 32) ? a.prof_buf : nullptr;      // reserved & 32: cycle counts into desc.workspace
     return q4_supported(c);
 }
 

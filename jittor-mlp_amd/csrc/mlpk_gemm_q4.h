@@ -20,6 +20,7 @@ struct Q4Call {
     const float* ln_csum;
     int gelu, ln, res;
     int one_group;             // tuning: a single column group
+    void* prof;                // tuning: (cycles, tiles) of every workgroup, 8 bytes each, or null
     int dbg;                   // tuning ablations: 1 = no LDS-DMA, 4 = no epilogue fillers (results are wrong by construction)
 };
 

@@ -21,7 +21,8 @@ struct Q4Args {
     int lda, ldb, ldc, ldr;
     int nk, cg, cg_magic, U;
     int Q, log2X, m_base, grid;
-    int pad[4];
+    void* prof;          // tuning: per-workgroup (cycles, tiles) pairs, or null
+    int pad[2];
 };
 static_assert(sizeof(Q4Args) == 128, "kernarg layout");
 }  // namespace mlpk
@@ -102,7 +103,8 @@ int q4_launch(const Q4Call& c, hipStream_t stream) {
     int lg = 0;
     while ((1 << lg) < X) ++lg;
     a.log2X = lg; a.m_base = 0; a.grid = grid;
-    a.pad[0] = a.pad[1] = a.pad[2] = a.pad[3] = 0;
+    a.prof = c.prof;
+    a.pad[0] = a.pad[1] = 0;
     hipError_t e = hipFuncSetAttribute(v->fn, hipFuncAttributeMaxDynamicSharedMemorySize, Q4_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     void* params[] = {&a};

@@ -153,7 +153,7 @@ GEMM_ALGO = {}                    # tag -> forced tile config (tuning/bench hook
 
 def gemm(A, B, C, M, Nn, K, *, lda=None, ldb=None, ldc=None, bias=None, act=N.ACT_NONE, cscale=None, cshift=None,
          rscale=None, rperiod=0, R=None, ldr=None, res=N.RES_NONE, out_mode=N.OUT_ROWMAJOR, t_rows=0, t_tokens=0,
-         algo=0, tag=None, dbg=0, ln=None, ln_group=1, part=None):
+         algo=0, tag=None, dbg=0, ln=None, ln_group=1, part=None, prof=None):
     """C = epilogue(A . B^T).  `part` = (workspace, name): the epilogue also delivers the row statistics of what it stores
     (mlpk.h: row_part) into a float32 buffer (nparts, M, 2) taken from the workspace; returns (buffer, nparts) for
     stats_finalize_planar, or None when the descriptor cannot deliver them (fp32, unaligned rows) and the caller runs row_stats."""
@@ -179,6 +179,8 @@ def gemm(A, B, C, M, Nn, K, *, lda=None, ldb=None, ldc=None, bias=None, act=N.AC
     d.t_rows, d.t_tokens, d.algo = t_rows, t_tokens, algo
     d.reserved = dbg
     d.workspace, d.workspace_bytes = None, 0             # unused since ABI 5 (no kernel needs scratch)
+    if prof is not None:                                 # tuning builds: per-workgroup cycle counters (reserved & 32 with algo 15)
+        d.workspace, d.workspace_bytes = ptr(prof), prof.numel() * prof.element_size()
     out = None
     if part is not None and epilogue_stats():
         n = ctypes.c_int(0)

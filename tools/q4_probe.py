@@ -142,7 +142,38 @@ def times():
     bench("square 8192", 8192, 8192, 8192, [("p8", (0, 0, 0, 14, 0, 0)), ("q4 plain f4", (0, 0, 0, 15, 0, 4))], reps=4)
 
 
+def prof():
+    """cycles per tile / per MFMA from the in-kernel counters (clock independent)"""
+    for title, (M, Nn, K), variants in (
+            ("channel fc1", (50176, 3072, 768), [("full f12", (1, 1, 0, 0, 12)), ("full f6", (1, 1, 0, 0, 6)), ("no stores", (1, 1, 0, 2, 12)), ("no fillers", (1, 1, 0, 4, 12)),
+                                                ("no dma", (1, 1, 0, 1, 12)), ("no dma no fillers", (1, 1, 0, 5, 12)), ("+ no reads", (1, 1, 0, 13, 12)),
+                                                ("no dma/fillers, min tail", (1, 1, 0, 21, 12)), ("mfma + barrier only", (1, 1, 0, 29, 12))]),
+            ("channel fc2", (50176, 768, 3072), [("full f6", (0, 0, 1, 0, 6)), ("no stores", (0, 0, 1, 2, 6)), ("no fillers", (0, 0, 1, 4, 6)), ("no dma", (0, 0, 1, 1, 6)),
+                                                ("no dma no fillers", (0, 0, 1, 5, 6)), ("+ no reads", (0, 0, 1, 13, 6)), ("no dma/fillers, min tail", (0, 0, 1, 21, 6)),
+                                                ("mfma + barrier only", (0, 0, 1, 29, 6))])):
+        A, B, bias, R, ln3 = operands(M, Nn, K, torch.bfloat16)
+        C = torch.zeros((M, Nn), dtype=torch.bfloat16, device=dev)
+        print("== %s M=%d N=%d K=%d: cycles per 256x128 tile (incl. the draining block), per MFMA (4 x 8 x K/16 per wave and tile)" % (title, M, Nn, K))
+        for name, (gelu, ln, res, dbg, nkf) in variants:
+            buf = torch.zeros(256 * 2, dtype=torch.int32, device=dev)
+            os.environ["MLPK_Q4_NKF"] = str(nkf)
+            kw = dict(R=R, res=N.RES_ADD) if res else {}
+            if ln:
+                kw["ln"] = ln3
+            for _ in range(2):
+                E.gemm(A, B, C, M, Nn, K, bias=bias, act=N.ACT_GELU if gelu else 0, algo=15, dbg=dbg | 32, prof=buf, **kw)
+            torch.cuda.synchronize()
+            h = buf.cpu().view(256, 2).double()
+            cyc, nt = h[:, 0], h[:, 1]
+            per_tile = (cyc / nt.clamp(min=1)).mean().item()
+            print("   %-28s tiles/WG %4.1f  cycles/tile %8.0f  cycles/MFMA %6.2f   (max WG cycles %d)" % (name, nt.mean().item(), per_tile, per_tile / (8 * K / 16), int(cyc.max().item())), flush=True)
+    os.environ.pop("MLPK_Q4_NKF", None)
+
+
 if __name__ == "__main__":
+    if what == "prof":
+        prof()
+        sys.exit(0)
     rc = 0
     if what in ("check", "all"):
         rc = check()

@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Micro-benchmark generator: what does an instruction cost when it is issued between the v_mfma_f32_32x32x16_bf16 of ONE wave
+per SIMD (the regime of the generated q4 GEMM)?  Emits a .hip file with one kernel per pattern (the body is one asm block, as in
+csrc/gen/q4gen.py) and a main() that launches each on every CU and prints shader cycles per MFMA.
+
+usage: python tools/ubench/q4_slots.py /tmp/q4_slots.hip && hipcc --offload-arch=gfx950 -O2 /tmp/q4_slots.hip -o q4_slots.bin && ./q4_slots.bin
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "jittor-mlp_amd", "csrc", "gen"))
+from isa import A, F, S, V, Asm  # noqa: E402
+
+ITERS = 64          # loop iterations of 32 MFMAs
+
+
+def kernel(name, pattern, per_iter=None, setup=None):
+    """pattern(a, q): instructions after MFMA q (0..31) of an iteration; per_iter(a): at the end of an iteration"""
+    a = Asm()
+    # s[0:1] = kernarg, s2 = block id, v0 = thread id.  kernarg: out (8), src (8)
+    a("s_load_dwordx4", S(4, 4), S(0, 2), 0)
+    a("v_and_b32", V(1), 63, V(0))
+    a("v_lshlrev_b32", V(2), 4, V(1))                 # lane * 16: LDS read address / DMA source offset
+    a("v_lshrrev_b32", V(3), 6, V(0))
+    a("s_nop", 0)
+    a("v_readfirstlane_b32", S(10), V(3))             # wave
+    a("s_waitcnt", lgkmcnt=0)
+    a("s_lshl_b32", S(11), S(10), 14)                 # this wave's 16 KiB of LDS
+    a("v_add_u32", V(2), S(11), V(2))
+    a("s_mov_b32", S(12), 0)
+    for r in range(4, 64):
+        a("v_mov_b32", V(r), 0)
+    a("v_mov_b32", V(64), F(1.0))
+    a("v_mov_b32", V(65), F(0.5))
+    for r in range(128):
+        a("v_accvgpr_write_b32", A(r), 0)
+    if setup:
+        setup(a)
+    a("s_mov_b32", S(13), ITERS)
+    a("s_barrier")
+    a("s_memtime", S(14, 2))
+    a("s_waitcnt", lgkmcnt=0)
+    L = a.newlabel("LOOP")
+    a.label(L)
+    for q in range(32):
+        a("v_mfma_f32_32x32x16_bf16", A(16 * (q & 7), 16), V(4, 4), V(8, 4), A(16 * (q & 7), 16))
+        pattern(a, q)
+    if per_iter:
+        per_iter(a)
+    a("s_sub_u32", S(13), S(13), 1)
+    a("s_cmp_lg_u32", S(13), 0)
+    a("s_cbranch_scc1", L)
+    a("s_memtime", S(16, 2))
+    a("s_waitcnt", vmcnt=0, lgkmcnt=0)
+    a("s_sub_u32", S(14), S(16), S(14))
+    a("s_subb_u32", S(15), S(17), S(15))
+    # out[(bid * 4 + wave)] = cycles (low 32 bits)
+    a("s_lshl_b32", S(18), S(2), 2)
+    a("s_add_u32", S(18), S(18), S(10))
+    a("s_lshl_b32", S(18), S(18), 2)
+    a("v_mov_b32", V(70), S(18))
+    a("v_mov_b32", V(71), S(14))
+    a("global_store_dword", V(70), V(71), S(4, 2))
+    a("s_waitcnt", vmcnt=0)
+    clob = ['"v%d"' % i for i in range(128)] + ['"a%d"' % i for i in range(256)] + ['"s%d"' % i for i in range(40) if i != 32] + ['"vcc"', '"memory"']
+    body = ['"s_mov_b64 s[0:1], %0\\n\\t"', '"s_mov_b32 s2, %1\\n\\t"', '"v_mov_b32 v0, %2\\n\\t"', a.c_string()]
+    return ("extern \"C\" __global__ void __launch_bounds__(256, 1) %s(void* out, const void* src) {\n    asm volatile(\n%s\n        :\n"
+            "        : \"s\"(__builtin_amdgcn_kernarg_segment_ptr()), \"s\"(blockIdx.x), \"v\"(threadIdx.x)\n        : %s);\n}\n"
+            % (name, "\n".join(body), ", ".join(clob)))
+
+
+def fma(a, n, base=0):
+    for k in range(n):
+        r = 72 + ((base + k) % 16)
+        a("v_fma_f32", V(r), V(r), V(64), V(65))
+
+
+def fmaak(a, n, base=0):
+    for k in range(n):
+        r = 72 + ((base + k) % 16)
+        a("v_fmaak_f32", V(r), V(r), V(64), F(0.123))
+
+
+def ds_read(a, k):
+    a("ds_read_b128", V(12 + 4 * (k % 6), 4), V(2), offset=(k % 8) * 1024)
+
+
+def dma(a, k, nop=True):
+    a("s_add_u32", "m0", S(11), (k % 12) * 1024)
+    if nop:
+        a("s_nop", 0)
+    a("global_load_lds_dwordx4", V(2), S(6, 2))
+
+
+PAT = []
+
+
+def P(name, pattern, per_iter=None):
+    PAT.append((name, pattern, per_iter))
+
+
+READS68 = lambda q: (q & 7) < 6            # 6 reads per 8 MFMAs, as the GEMM
+P("mfma_only", lambda a, q: None)
+for n in (2, 4, 5, 6, 8):
+    P("fma%d" % n, lambda a, q, n=n: fma(a, n, q * n))
+P("fmaak4", lambda a, q: fmaak(a, 4, q * 4))
+P("fmaak6", lambda a, q: fmaak(a, 6, q * 6))
+P("accread4", lambda a, q: [a("v_accvgpr_read_b32", V(72 + k), A(128 + (q * 4 + k) % 128)) for k in range(4)] and None)
+P("salu4", lambda a, q: [a("s_add_u32", S(20 + k), S(20 + k), 1) for k in range(4)] and None)
+P("salu8", lambda a, q: [a("s_add_u32", S(20 + k % 4), S(20 + k % 4), 1) for k in range(8)] and None)
+P("dsread_every", lambda a, q: ds_read(a, q))
+P("dsread_6of8", lambda a, q: ds_read(a, q) if READS68(q) else None)
+P("dsread_6of8_wait", lambda a, q: (ds_read(a, q) if READS68(q) else None, a("s_waitcnt", lgkmcnt=3) if (q & 1) == 0 else None) and None)
+P("dsread_6of8_fma3", lambda a, q: (ds_read(a, q) if READS68(q) else None, fma(a, 3, q * 3)) and None)
+P("dsread_4of8", lambda a, q: ds_read(a, q) if (q & 1) == 0 else None)
+P("dsread_b64_6of8", lambda a, q: a("ds_read_b64", V(12 + 4 * (q % 6), 2), V(2), offset=(q % 8) * 1024) if READS68(q) else None)
+P("dsread2x_b64", lambda a, q: [a("ds_read_b64", V(12 + 2 * ((2 * q + k) % 12), 2), V(2), offset=((2 * q + k) % 16) * 512) for k in range(2)] and None if READS68(q) else None)
+P("dma_12of32", lambda a, q: dma(a, q) if q % 8 in (1, 3, 6) else None, lambda a: a("s_waitcnt", vmcnt=12))
+P("dma_12of32_nonop", lambda a, q: dma(a, q, False) if q % 8 in (1, 3, 6) else None, lambda a: a("s_waitcnt", vmcnt=12))
+P("dma_6of32", lambda a, q: dma(a, q) if q % 16 in (1, 6, 11) else None, lambda a: a("s_waitcnt", vmcnt=12))
+P("dma_12_reads", lambda a, q: (dma(a, q) if q % 8 in (1, 3, 6) else None, ds_read(a, q) if READS68(q) else None) and None, lambda a: a("s_waitcnt", vmcnt=12))
+P("dma_12_reads_fma3", lambda a, q: (dma(a, q) if q % 8 in (1, 3, 6) else None, ds_read(a, q) if READS68(q) else None, fma(a, 3, 3 * q)) and None,
+  lambda a: a("s_waitcnt", vmcnt=12))
+P("barrier_per_iter", lambda a, q: None, lambda a: a("s_barrier"))
+P("reads_barrier", lambda a, q: ds_read(a, q) if READS68(q) else None, lambda a: (a("s_waitcnt", lgkmcnt=0), a("s_barrier")) and None)
+P("reads_salu30_barrier", lambda a, q: ds_read(a, q) if READS68(q) else None,
+  lambda a: ([a("s_add_u32", S(20 + k % 4), S(20 + k % 4), 1) for k in range(30)], a("s_waitcnt", lgkmcnt=0), a("s_barrier")) and None)
+P("store_1of16", lambda a, q: a("global_store_dwordx4", V(2), V(72, 4), S(6, 2), offset=2048) if q % 16 == 5 else None, lambda a: a("s_waitcnt", vmcnt=8))
+P("cvt_perm", lambda a, q: (a("v_cvt_pk_bf16_f32", V(80 + q % 4), V(72), V(73)), a("s_nop", 1), a("v_permlane32_swap_b32", V(80 + q % 4), V(84 + q % 4))) and None)
+P("waitcnt4", lambda a, q: [a("s_waitcnt", lgkmcnt=15) for k in range(4)] and None)
+P("nop4", lambda a, q: [a("s_nop", 0) for k in range(4)] and None)
+
+
+def main(path):
+    out = ["#include <hip/hip_runtime.h>\n#include <stdio.h>\n#include <vector>\n"]
+    for name, pat, per in PAT:
+        out.append(kernel("ub_" + name, pat, per))
+    out.append("struct K { const char* name; const void* fn; };\nstatic const K ks[] = {\n")
+    for name, _, _ in PAT:
+        out.append("    {\"%s\", (const void*)&ub_%s},\n" % (name, name))
+    out.append("};\n")
+    out.append("""int main() {
+    setvbuf(stdout, 0, _IONBF, 0);
+    unsigned* out; char* src;
+    hipMalloc(&out, 256 * 4 * 4);
+    hipMalloc(&src, 1 << 20);
+    hipMemset(src, 0, 1 << 20);
+    std::vector<unsigned> h(1024);
+    for (const K& k : ks) {
+        hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        void* args[] = {&out, &src};
+        for (int rep = 0; rep < 2; ++rep) hipLaunchKernel(k.fn, dim3(256), dim3(256), args, 65536, 0);
+        if (hipDeviceSynchronize() != hipSuccess) { printf("%%s: launch failed\\n", k.name); return 1; }
+        hipMemcpy(h.data(), out, 4096, hipMemcpyDeviceToHost);
+        double s = 0; unsigned mx = 0, mn = ~0u;
+        for (unsigned v : h) { s += v; mx = v > mx ? v : mx; mn = v < mn ? v : mn; }
+        const double per = %d.0 * 32;
+        printf("%%-24s cycles per MFMA: mean %%7.2f  min %%7.2f  max %%7.2f\\n", k.name, s / 1024 / per, mn / per, mx / per);
+    }
+    return 0;
+}
+""" % ITERS)
+    with open(path, "w") as f:
+        f.write("".join(out))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
