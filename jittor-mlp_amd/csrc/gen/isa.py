@@ -218,6 +218,7 @@ class Wave:
         self.a = np.zeros((256, 64), np.uint32)
         self.s = np.zeros(128, np.uint64)          # 32-bit values (kept in 64-bit cells to dodge overflow warnings)
         self.m0 = 0
+        self.exec = np.ones(64, bool)
         self.scc = 0
         self.pc = 0
         self.done = False
@@ -367,6 +368,10 @@ class Emu:
 
     def x_s_mov_b64(self, w, i):
         d, s = i.args
+        if d == "exec":
+            val = 0xFFFFFFFFFFFFFFFF if s == -1 else self.rds64(w, s)
+            w.exec = np.array([(val >> k) & 1 for k in range(64)], bool)
+            return
         self.wrs(w, d[0], self.rds(w, s[0]))
         self.wrs(w, d[1], self.rds(w, s[1]))
 
@@ -621,6 +626,35 @@ class Emu:
         with np.errstate(all="ignore"):
             self.wrv(w, i.args[0], self.u(self.f(self.rd(w, i.args[1])) - self.f(self.rd(w, i.args[2]))))
 
+    def x_v_add_f32_dpp(self, w, i):
+        """dst = dpp(src0) + src1; quad_perm / row_half_mirror with full row and bank masks (every lane enabled)"""
+        assert w.exec.all()
+        a, b = self.rd(w, i.args[1]), self.rd(w, i.args[2])
+        lane = np.arange(64)
+        if "quad_perm" in i.mods:
+            perm = [int(x) for x in i.mods["quad_perm"].strip("[]").split(",")]
+            src = (lane & ~3) | np.array(perm)[lane & 3]
+        elif i.mods.get("row_half_mirror"):
+            src = (lane & ~7) | (7 - (lane & 7))
+        else:
+            raise NotImplementedError(i.mods)
+        with np.errstate(all="ignore"):
+            self.wrv(w, i.args[0], self.u(self.f(a[src]) + self.f(b)))
+
+    def _dot2c(self, w, i, dec):
+        d, a, b = i.args
+        av, bv, dv = self.rd(w, a), self.rd(w, b), self.rd(w, d)
+        with np.errstate(all="ignore"):
+            r = (self.f(dv).astype(np.float64) + dec(av & 0xFFFF).astype(np.float64) * dec(bv & 0xFFFF).astype(np.float64)
+                 + dec(av >> 16).astype(np.float64) * dec(bv >> 16).astype(np.float64)).astype(np.float32)
+        self.wrv(w, d, self.u(r))
+
+    def x_v_dot2c_f32_bf16(self, w, i):
+        self._dot2c(w, i, lambda u: _bf16_to_f32(u.astype(np.uint16)))
+
+    def x_v_dot2c_f32_f16(self, w, i):
+        self._dot2c(w, i, lambda u: u.astype(np.uint16).view(np.float16).astype(np.float32))
+
     def x_v_med3_f32(self, w, i):
         a, b, c = (self.f(self.rd(w, x)) for x in i.args[1:4])
         with np.errstate(all="ignore"):
@@ -722,6 +756,25 @@ class Emu:
     def x_ds_read_b32(self, w, i):
         self._ds_read(w, i, 4)
 
+    def _ds_write(self, w, i, nbytes):
+        a, d = i.args
+        addr = self.rd(w, a).astype(np.int64) + i.mods.get("offset", 0)
+        if addr.max() + nbytes > len(self.lds):
+            raise RuntimeError("LDS write out of range: %d" % addr.max())
+        n = nbytes // 4
+        bank = w.v if d.kind == "v" else w.a
+        data = np.stack([bank[d.idx + k] for k in range(n)], axis=1).copy()
+        if np.any(data == POISON):
+            raise RuntimeError("ds_write of a register that still holds poison (pc %d)" % w.pc)
+        self.lds[addr[:, None] + np.arange(nbytes)[None, :]] = data.view(np.uint8).reshape(64, nbytes)
+        w.lgkm.append(lambda: None)
+
+    def x_ds_write_b64(self, w, i):
+        self._ds_write(w, i, 8)
+
+    def x_ds_write_b128(self, w, i):
+        self._ds_write(w, i, 16)
+
     # ---- global
     def _gaddr(self, w, i, voff, sbase):
         off = i.mods.get("offset", 0)
@@ -774,9 +827,9 @@ class Emu:
         addr = self._gaddr(w, i, voff, sbase)
         bank = w.v if d.kind == "v" else w.a
         data = np.stack([bank[d.idx + k] for k in range(n)], axis=1).copy()           # [64, n]
-        if np.any(data == POISON):
+        if np.any(data[w.exec] == POISON):
             raise RuntimeError("store of a register that still holds poison (pc %d)" % w.pc)
-        self.mem.scatter(addr, data.view(np.uint8).reshape(64, 4 * n))
+        self.mem.scatter(addr[w.exec], data.view(np.uint8).reshape(64, 4 * n)[w.exec])
         w.vm.append(("store", None))
 
     def x_global_store_dwordx4(self, w, i):
@@ -800,7 +853,7 @@ def _regs_of(o):
     return set()
 
 
-_NO_DST = ("s_waitcnt", "s_barrier", "s_nop", "s_branch", "s_cbranch_scc0", "s_cbranch_scc1", "s_endpgm", "s_setprio", "label",
+_NO_DST = ("ds_write_b64", "ds_write_b128", "s_waitcnt", "s_barrier", "s_nop", "s_branch", "s_cbranch_scc0", "s_cbranch_scc1", "s_endpgm", "s_setprio", "label",
            "global_load_lds_dwordx4", "global_store_dwordx4", "global_store_dwordx2", "global_store_dword",
            "s_cmp_eq_u32", "s_cmp_lg_u32", "s_cmp_lt_u32", "s_cmp_le_u32", "s_cmp_gt_u32", "s_cmp_ge_u32", "s_cmp_lt_i32", "s_cmp_gt_i32")
 
@@ -817,7 +870,7 @@ def defs_uses(i):
     u = set()
     for a in i.args[1:]:
         u |= _regs_of(a)
-    if i.op in ("v_fmac_f32",):
+    if i.op in ("v_fmac_f32", "v_dot2c_f32_bf16", "v_dot2c_f32_f16"):
         u |= d
     if i.op == "v_permlane32_swap_b32":
         d |= _regs_of(i.args[1])
@@ -853,6 +906,8 @@ def lint(asm, mfma_gap=16, verbose=False):
                 problems.append((k, "MFMA operand written by an MFMA %d states before" % dist))
             if r == ("m0", 0) and i.op == "global_load_lds_dwordx4" and dist < 1:
                 problems.append((k, "LDS-DMA straight after the m0 write"))
+            if i.op.endswith("_dpp") and kind == "valu" and dist < 2 and r in _regs_of(i.args[1]):
+                problems.append((k, "DPP source %s%d written by a VALU instruction %d states before (< 2)" % (r[0], r[1], dist)))
             if i.op == "v_permlane32_swap_b32" and kind == "valu" and dist < 2:
                 problems.append((k, "v_permlane32_swap %d states after a VALU write of %s%d (< 2)" % (dist, r[0], r[1])))
             if kind == "valu_sgpr" and (i.op.startswith("global_") or i.op.startswith("s_load")) and dist < 5:

@@ -79,12 +79,16 @@ def run_case(gen, M, N, K, grid, cgroups=1, seed=0, dma_mode="late", order=None,
     aA, aB, aC, aR = mem.add(A), mem.add(B), mem.add(C), mem.add(R)
     aBias, aMean, aRstd, aCsum = mem.add(bias), mem.add(mean), mem.add(rstd), mem.add(csum)
     pl = plan(M, N, K, grid, cgroups)
-    ka = bytearray(128)
+    ka = bytearray(144)
     for name, val in (("A", aA), ("B", aB), ("C", aC), ("R", aR), ("bias", aBias), ("ln_mean", aMean), ("ln_rstd", aRstd), ("ln_csum", aCsum)):
         struct.pack_into("<Q", ka, q4gen.KA[name], val)
     ints = dict(lda=K, ldb=K, ldc=N, ldr=N, **pl)
     for name, val in ints.items():
         struct.pack_into("<I", ka, q4gen.KA[name], val)
+    part = np.full((N // 64, M, 2), np.nan, np.float32)
+    aPart = mem.add(part)
+    struct.pack_into("<Q", ka, q4gen.KA["row_part"], aPart)
+    struct.pack_into("<I", ka, q4gen.KA["row_part_ld"], M)
     prof = np.zeros(grid * 2, np.uint32)
     aProf = mem.add(prof)
     struct.pack_into("<Q", ka, q4gen.KA["prof"], aProf)
@@ -122,7 +126,16 @@ def run_case(gen, M, N, K, grid, cgroups=1, seed=0, dma_mode="late", order=None,
             rows = sorted(set(idx[:, 0] // 32))
             cols = sorted(set(idx[:, 1] // 32))
             print("  bad row blocks of 32:", rows[:40], " col blocks:", cols[:40])
-    return bool(written.all() and not bad.any())
+    ok = bool(written.all() and not bad.any())
+    if getattr(gen, "stats", False):
+        got = mem.get(aPart).view(np.float32).reshape(N // 64, M, 2).astype(np.float64)
+        outq = out.reshape(M, N // 64, 64)
+        want = np.stack([outq.sum(axis=2).T, (outq * outq).sum(axis=2).T], axis=2)
+        perr = np.abs(got - want).max() if np.isfinite(got).all() else float("nan")
+        if not (perr < 1e-3):
+            print("row statistics: max error %s" % perr)
+            ok = False
+    return ok
 
 
 if __name__ == "__main__":

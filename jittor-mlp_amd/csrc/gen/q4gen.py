@@ -27,18 +27,22 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from isa import A, F, S, V, Asm, Neg, Reg  # noqa: E402
 
-GELU_SCALE = 0.314269681
-GELU_COEFS = [0.00260713836, -0.00718860654, 0.00979797821, -0.0172248576, 0.0355015062, -0.0601866171, 0.090279378, -0.127707109,
-              0.174028099, -0.245624334, 0.499268919]
+# the 16-bit GELU polynomials of mlpk_common.h (MLPK_GELUP_*): scale and Horner coefficients by storage type
+GELU = {"f16": (0.314269681, [0.00260713836, -0.00718860654, 0.00979797821, -0.0172248576, 0.0355015062, -0.0601866171, 0.090279378,
+                              -0.127707109, 0.174028099, -0.245624334, 0.499268919]),
+        "bf16": (0.353553391, [-0.00937665813, 0.0246067308, -0.0355258957, 0.059637472, -0.103835642, 0.158927634, -0.238559365,
+                               0.497641712])}
 SQRT2 = 1.41421356237
 
 STAGE_B = 49152          # one LDS stage: A 256 x 128 B, then B 128 x 128 B
 B_OFF = 32768
-LDS_BYTES = 3 * STAGE_B
+OUT_OFF = 3 * STAGE_B     # 4 x 4 KiB: one staging tile per wave for the stores
+LDS_BYTES = OUT_OFF + 16384
 
 # kernarg layout (bytes) -- mirrored by struct Q4Args in mlpk_gemm_q4.hip
 KA = dict(A=0, B=8, C=16, R=24, bias=32, ln_mean=40, ln_rstd=48, ln_csum=56,
-          lda=64, ldb=68, ldc=72, ldr=76, nk=80, cg=84, cg_magic=88, U=92, Q=96, log2X=100, m_base=104, grid=108, prof=112)
+          lda=64, ldb=68, ldc=72, ldr=76, nk=80, cg=84, cg_magic=88, U=92, Q=96, log2X=100, m_base=104, grid=108, prof=112,
+          row_part=120, row_part_ld=128)
 
 
 class Alloc:
@@ -56,11 +60,12 @@ class Alloc:
 
 
 class Q4:
-    def __init__(self, dtype="bf16", gelu=False, ln=False, res=False, nkf=4, dbg=0, name=None):
+    def __init__(self, dtype="bf16", gelu=False, ln=False, res=False, stats=False, nkf=4, dbg=0, name=None):
         assert nkf >= 2
-        self.dtype, self.gelu, self.ln, self.res, self.nkf = dtype, gelu, ln, res, nkf
+        self.dtype, self.gelu, self.ln, self.res, self.stats, self.nkf = dtype, gelu, ln, res, stats, nkf
         # tuning ablations (results are wrong by construction): 1 no LDS-DMA, 2 no stores, 4 no epilogue fillers, 8 no fragment reads,
-        # 16 minimal iteration tail (no stage rotation)
+        # 16 minimal iteration tail (no stage rotation), 64 every tile stored over tile (0, 0); variants under test: A/B switches: 256 the four
+        # stores of a block row back to back (default: spread over the next block row), 512 ordinary instead of non-temporal stores
         self.dbg = dbg
         self.fillers_on, self.dma_on, self.stores_on, self.reads_on, self.tail_on = not (dbg & 4), not (dbg & 1), not (dbg & 2), not (dbg & 8), not (dbg & 16)
         self.name = name or "q4_%s%s%s%s_f%d" % (dtype, "_gelu" if gelu else "", "_ln" if ln else "", "_res" if res else "", nkf)
@@ -81,7 +86,6 @@ class Q4:
         self.s_lnext = s("lnext")              # l of the tile whose coordinates were computed last
         self.s_left = s("left")                # blocks still to run (tiles after the first + the draining one)
         self.s_roll = s("roll")                # rolled iterations of the current block
-        self.s_cnt = s("cnt")
         # tile coordinates: p = the tile being drained, c = the tile being multiplied, n = the next one (DMA target after c)
         self.s_pm0, self.s_pn0, self.s_cm0, self.s_cn0, self.s_nm0, self.s_nn0 = (s(x) for x in ["pm0", "pn0", "cm0", "cn0", "nm0", "nn0"])
         # DMA stream
@@ -92,12 +96,19 @@ class Q4:
         self.s_wrA, self.s_wrB = s("wrA"), s("wrB")        # + this wave's share
         self.s_wvA, self.s_wvB = s("wvA"), s("wvB")        # wave * 8192, 32768 + wave * 4096
         # epilogue bases of tile p
-        self.s_eC, self.s_eR = s("eC", 2, 2), s("eR", 2, 2)
-        self.s_eBias, self.s_eCsum, self.s_eMu, self.s_eRstd = s("eBias", 2, 2), s("eCsum", 2, 2), s("eMu", 2, 2), s("eRstd", 2, 2)
+        self.s_eC = s("eC", 2, 2)
+        self.s_eR = s("eR", 2, 2) if self.res else None
+        self.s_rowC = s("rowC")                                # bytes of 32 rows of C / R
+        self.s_rowR = s("rowR") if self.res else None
+        self.s_eBias = s("eBias", 2, 2)
+        self.s_eCsum, self.s_eMu, self.s_eRstd = (s("eCsum", 2, 2), s("eMu", 2, 2), s("eRstd", 2, 2)) if self.ln else (None, None, None)
+        if self.stats:
+            self.s_part, self.s_partld = s("part", 2, 2), s("partld")
+            self.s_eP = s("eP", 2, 2)
+            self.s_mask8 = s("mask8", 2, 2)
         self.s_r2 = s("r2")
         self.s_prof0, self.s_prof1, self.s_profp, self.s_ntiles = s("prof0", 2, 2), s("prof1", 2, 2), s("profp", 2, 2), s("ntiles")
         self.s_t = [s("t%d" % i) for i in range(6)]
-        self.s_t64 = s("t64", 2, 2)
         # vector registers
         self.FA = [[v("FA%d_%d" % (b, i), 4, 4) for i in range(4)] for b in range(2)]
         self.FB = [[v("FB%d_%d" % (b, j), 4, 4) for j in range(2)] for b in range(2)]
@@ -107,20 +118,28 @@ class Q4:
         self.v_rdB0 = [v("rdB0_%d" % k) for k in range(4)]
         self.voffA = [v("voffA%d" % k) for k in range(8)]
         self.voffB = [v("voffB%d" % k) for k in range(4)]
-        self.voffC = [v("voffC%d" % i) for i in range(4)]
-        self.voffR = [v("voffR%d" % i) for i in range(4)]
+        self.voffC = [v("voffC%d" % i) for i in range(4)]      # store offsets of the 4 row groups of 8 rows of a block row
+        self.voffR = [v("voffR%d" % i) for i in range(4)] if self.res else None
         self.voffCol, self.voffRow = v("voffCol"), v("voffRow")
         self.v_bias = [[v("bias%d_%d" % (j, g), 4, 4) for g in range(4)] for j in range(2)]
         self.v_csum = [[v("csum%d_%d" % (j, g), 4, 4) for g in range(4)] for j in range(2)] if self.ln else None
         self.v_mu = [v("mu%d" % i) for i in range(4)] if self.ln else None
         self.v_rstd = [v("rstd%d" % i) for i in range(4)] if self.ln else None
-        self.v_c0 = v("c0")
+        self.v_c0 = v("c0") if self.gelu else None
         self.v_x = [[v("x%d_%d" % (b, r)) for r in range(4)] for b in range(2)]
-        self.v_t = [[v("t%d_%d" % (b, r)) for r in range(4)] for b in range(2)]
-        self.v_u = [[v("u%d_%d" % (b, r)) for r in range(4)] for b in range(2)]
-        self.v_q = [[v("q%d_%d" % (b, r)) for r in range(4)] for b in range(2)]
-        self.v_quad = [v("quad%d" % k, 4, 4) for k in range(2)]
-        self.v_res = [[[v("res%d_%d_%d" % (i, j, h), 4, 4) for h in range(2)] for j in range(2)] for i in range(4)] if self.res else None
+        ge = self.gelu
+        self.v_t = [[v("t%d_%d" % (b, r)) for r in range(4)] for b in range(2)] if ge else [None, None]
+        self.v_u = [[v("u%d_%d" % (b, r)) for r in range(4)] for b in range(2)] if ge else [None, None]
+        self.v_q = [[v("q%d_%d" % (b, r)) for r in range(4)] for b in range(2)] if ge else [None, None]
+        self.v_pk = [v("pk%d" % k, 2, 2) for k in range(2)]
+        self.v_stw = [v("stw%d" % c) for c in range(8)]        # LDS staging: write address of 16-byte chunk c of this lane's row
+        self.v_strd = v("strd")                                # ... and the read address (row lane >> 3, chunk lane & 7)
+        self.v_out = [v("out%d" % k, 4, 4) for k in range(4)]
+        self.v_res = [[v("res%d_%d" % (i, k), 4, 4) for k in range(4)] for i in range(2)] if self.res else None    # block rows i, i + 2
+        if self.stats:
+            self.v_sp = v("sp", 2, 2)                          # (sum, sum of squares) of a lane's 8 stored values, then of its row
+            self.v_ones = v("ones")
+            self.voffP = [v("voffP%d" % k) for k in range(4)]
         self.v_tmp = [v("tmp%d" % i) for i in range(8)]
         self.v_pair = v("pair", 2, 2)
         self.nv, self.ns = v.next, s.next
@@ -129,6 +148,25 @@ class Q4:
         return A(128 * set_ + 16 * b, 16)
 
     # ------------------------------------------------------------------ helpers
+    SCC_READERS = ("s_addc_u32", "s_subb_u32", "s_cselect_b32", "s_cbranch_scc0", "s_cbranch_scc1")
+
+    def capture(self, fn):
+        """run fn (which emits plain instructions), take the instructions back out of the listing and return them as filler
+        closures -- an instruction that READS SCC stays glued to its predecessors (fillers from different lists are interleaved
+        gap by gap, and nearly every SALU instruction writes SCC)"""
+        a = self.a
+        n0 = len(a.ins)
+        fn()
+        ins = a.ins[n0:]
+        del a.ins[n0:]
+        groups = []
+        for x in ins:
+            if x.op in self.SCC_READERS and groups:
+                groups[-1].append(x)
+            else:
+                groups.append([x])
+        return [(lambda g=g: a.ins.extend(g)) for g in groups]
+
     def add64(self, dst, src, lo, hi=None):
         """dst(64) = src(64) + (hi:lo); hi None = 0"""
         a = self.a
@@ -163,67 +201,76 @@ class Q4:
             self.add64(d, ptr, t[0], t[1])
 
     def epi_bases_ops(self):
-        """SALU ops (a list of closures, one instruction each) that set the epilogue bases from (pm0, pn0)"""
+        """SALU fillers that set the epilogue bases from (pm0, pn0)"""
         a, t = self.a, self.s_t
-        ops = []
 
-        def E(*x, **kw):
-            ops.append(lambda: a(*x, **kw))
-        for dst, ptr, ld, on in ((self.s_eC, self.p["C"], self.k["ldc"], True), (self.s_eR, self.p["R"], self.k["ldr"], self.res)):
-            if not on:
-                continue
-            # (pm0 * ld + pn0) * 2
-            E("s_mul_i32", t[0], self.s_pm0, ld)
-            E("s_mul_hi_u32", t[1], self.s_pm0, ld)
-            E("s_add_u32", t[0], t[0], self.s_pn0)
-            E("s_addc_u32", t[1], t[1], 0)
-            E("s_lshl_b32", t[1], t[1], 1)
-            E("s_lshr_b32", t[2], t[0], 31)
-            E("s_or_b32", t[1], t[1], t[2])
-            E("s_lshl_b32", t[0], t[0], 1)
-            E("s_add_u32", dst[0], ptr[0], t[0])
-            E("s_addc_u32", dst[1], ptr[1], t[1])
-        E("s_lshl_b32", t[0], self.s_pn0, 2)
-        E("s_add_u32", self.s_eBias[0], self.p["bias"][0], t[0])
-        E("s_addc_u32", self.s_eBias[1], self.p["bias"][1], 0)
-        if self.ln:
-            E("s_add_u32", self.s_eCsum[0], self.p["ln_csum"][0], t[0])
-            E("s_addc_u32", self.s_eCsum[1], self.p["ln_csum"][1], 0)
-            E("s_lshl_b32", t[0], self.s_pm0, 2)
-            E("s_add_u32", self.s_eMu[0], self.p["ln_mean"][0], t[0])
-            E("s_addc_u32", self.s_eMu[1], self.p["ln_mean"][1], 0)
-            E("s_add_u32", self.s_eRstd[0], self.p["ln_rstd"][0], t[0])
-            E("s_addc_u32", self.s_eRstd[1], self.p["ln_rstd"][1], 0)
-        return ops
+        def emit():
+            E = a
+            for dst, ptr, ld, on in ((self.s_eC, self.p["C"], self.k["ldc"], True), (self.s_eR, self.p["R"], self.k["ldr"], self.res)):
+                if not on:
+                    continue
+                # (pm0 * ld + pn0) * 2
+                E("s_mul_i32", t[0], self.s_pm0, ld)
+                E("s_mul_hi_u32", t[1], self.s_pm0, ld)
+                E("s_add_u32", t[0], t[0], self.s_pn0)
+                E("s_addc_u32", t[1], t[1], 0)
+                E("s_lshl_b32", t[1], t[1], 1)
+                E("s_lshr_b32", t[2], t[0], 31)
+                E("s_or_b32", t[1], t[1], t[2])
+                E("s_lshl_b32", t[0], t[0], 1)
+                E("s_add_u32", dst[0], ptr[0], t[0])
+                E("s_addc_u32", dst[1], ptr[1], t[1])
+            if self.stats:
+                # plane (pn0 / 64 + wn), row pm0: ((pn0 >> 6) + wn) * ld + pm0 pairs of 8 bytes
+                E("s_lshr_b32", t[0], self.s_pn0, 6)
+                E("s_and_b32", t[1], self.s_wave, 1)
+                E("s_add_u32", t[0], t[0], t[1])
+                E("s_mul_hi_u32", t[1], t[0], self.s_partld)
+                E("s_mul_i32", t[0], t[0], self.s_partld)
+                E("s_add_u32", t[0], t[0], self.s_pm0)
+                E("s_addc_u32", t[1], t[1], 0)
+                E("s_lshl_b32", t[1], t[1], 3)
+                E("s_lshr_b32", t[2], t[0], 29)
+                E("s_or_b32", t[1], t[1], t[2])
+                E("s_lshl_b32", t[0], t[0], 3)
+                E("s_add_u32", self.s_eP[0], self.s_part[0], t[0])
+                E("s_addc_u32", self.s_eP[1], self.s_part[1], t[1])
+            E("s_lshl_b32", t[0], self.s_pn0, 2)
+            E("s_add_u32", self.s_eBias[0], self.p["bias"][0], t[0])
+            E("s_addc_u32", self.s_eBias[1], self.p["bias"][1], 0)
+            if self.ln:
+                E("s_add_u32", self.s_eCsum[0], self.p["ln_csum"][0], t[0])
+                E("s_addc_u32", self.s_eCsum[1], self.p["ln_csum"][1], 0)
+                E("s_lshl_b32", t[0], self.s_pm0, 2)
+                E("s_add_u32", self.s_eMu[0], self.p["ln_mean"][0], t[0])
+                E("s_addc_u32", self.s_eMu[1], self.p["ln_mean"][1], 0)
+                E("s_add_u32", self.s_eRstd[0], self.p["ln_rstd"][0], t[0])
+                E("s_addc_u32", self.s_eRstd[1], self.p["ln_rstd"][1], 0)
+        return self.capture(emit)
 
     def block_start_ops(self):
-        """shift the tile coordinates, compute the next tile's and its DMA bases, the epilogue bases of the drained tile"""
-        a = self.a
-        ops = []
+        """shift the tile coordinates, the epilogue bases and parameter loads of the drained tile, the next tile's coordinates and
+        DMA bases, the number of rolled iterations"""
+        a, t = self.a, self.s_t
 
-        def E(*x, **kw):
-            ops.append(lambda: a(*x, **kw))
-        E("s_mov_b32", self.s_pm0, self.s_cm0)
-        E("s_mov_b32", self.s_pn0, self.s_cn0)
-        E("s_mov_b32", self.s_cm0, self.s_nm0)
-        E("s_mov_b32", self.s_cn0, self.s_nn0)
-        ops += self.epi_bases_ops()
+        def shift():
+            a("s_mov_b32", self.s_pm0, 0 if (self.dbg & 64) else self.s_cm0)       # (64: every tile is stored over tile (0, 0))
+            a("s_mov_b32", self.s_pn0, 0 if (self.dbg & 64) else self.s_cn0)
+            a("s_mov_b32", self.s_cm0, self.s_nm0)
+            a("s_mov_b32", self.s_cn0, self.s_nn0)
+
+        def nxt():
+            a("s_add_u32", self.s_lnext, self.s_lnext, self.s_lstep)
+            self.coords(self.s_lnext, self.s_nm0, self.s_nn0)
+            self.dma_base(self.s_dAn, self.s_dBn, self.s_nm0, self.s_nn0)
+            # rolled iterations of this block: nk - nkf, or 0 for the draining block (no block left after it)
+            a("s_sub_u32", t[0], self.k["nk"], self.nkf)
+            a("s_cmp_lg_u32", self.s_left, 0)
+            a("s_cselect_b32", self.s_roll, t[0], 0)
+        ops = self.capture(shift) + self.epi_bases_ops()
         if self.fillers_on:
             ops += self.param_load_ops()
-        E("s_add_u32", self.s_lnext, self.s_lnext, self.s_lstep)
-        n0 = len(a.ins)
-        self.coords(self.s_lnext, self.s_nm0, self.s_nn0)
-        self.dma_base(self.s_dAn, self.s_dBn, self.s_nm0, self.s_nn0)
-        captured = a.ins[n0:]
-        del a.ins[n0:]
-        for ins in captured:
-            ops.append(lambda ins=ins: a.ins.append(ins))
-        # rolled iterations of this block: nk - nkf, or 0 for the draining block (no block left after it)
-        t = self.s_t
-        E("s_sub_u32", t[0], self.k["nk"], self.nkf)
-        E("s_cmp_lg_u32", self.s_left, 0)
-        E("s_cselect_b32", self.s_roll, t[0], 0)
-        return ops
+        return ops + self.capture(nxt)
 
     def param_load_ops(self):
         """the column / row parameters (and the residual tile) of the drained tile, as loads"""
@@ -234,18 +281,37 @@ class Q4:
             ops.append(lambda: a(*x, **kw))
         for j in range(2):
             for g in range(4):
-                E("global_load_dwordx4", self.v_bias[j][g], self.voffCol, self.s_eBias, offset=(j * 32 + g * 8) * 4)
+                ops.append(lambda j=j, g=g: self.vload("global_load_dwordx4", self.v_bias[j][g], self.voffCol, self.s_eBias, offset=(j * 32 + g * 8) * 4))
                 if self.ln:
-                    E("global_load_dwordx4", self.v_csum[j][g], self.voffCol, self.s_eCsum, offset=(j * 32 + g * 8) * 4)
+                    ops.append(lambda j=j, g=g: self.vload("global_load_dwordx4", self.v_csum[j][g], self.voffCol, self.s_eCsum, offset=(j * 32 + g * 8) * 4))
         if self.ln:
             for i in range(4):
-                E("global_load_dword", self.v_mu[i], self.voffRow, self.s_eMu, offset=i * 128)
-                E("global_load_dword", self.v_rstd[i], self.voffRow, self.s_eRstd, offset=i * 128)
+                ops.append(lambda i=i: self.vload("global_load_dword", self.v_mu[i], self.voffRow, self.s_eMu, offset=i * 128))
+                ops.append(lambda i=i: self.vload("global_load_dword", self.v_rstd[i], self.voffRow, self.s_eRstd, offset=i * 128))
         if self.res:
-            for i in range(4):
-                for j in range(2):
-                    for h in range(2):
-                        E("global_load_dwordx4", self.v_res[i][j][h], self.voffR[i], self.s_eR, offset=(j * 32 + h * 16) * 2)
+            for i in range(2):
+                ops += self.res_load_ops(i)
+        return ops
+
+    def vload(self, op, *args, **kw):
+        """emit a VGPR load and number it (vmcnt bookkeeping: loads and LDS-DMA complete in order)"""
+        self.a(op, *args, **kw)
+        self.vm_loads += 1
+        return self.vm_loads - 1
+
+    def wait_vload(self, idx):
+        n = self.vm_loads - idx - 1
+        self.a("s_waitcnt", vmcnt=min(n, 63))
+
+    def res_load_ops(self, i):
+        """residual tile of block row i, in the layout of the stores: lane = (row lane >> 3 of row group k, 16-byte chunk
+        lane & 7); s_eR walks the block rows.  Registers are shared by block rows i and i + 2."""
+        ops = []
+        rec = [None] * 4
+        self._res_loads[i] = rec
+        for k in range(4):
+            ops.append(lambda k=k: rec.__setitem__(k, self.vload("global_load_dwordx4", self.v_res[i & 1][k], self.voffR[k], self.s_eR)))
+        ops += self.capture(lambda: self.add64(self.s_eR, self.s_eR, self.s_rowR))
         return ops
 
     def n_param_loads(self):
@@ -253,16 +319,16 @@ class Q4:
 
     def gelu_ops(self, E, x, t, u, q):
         """x[r] <- gelu(x[r]) for the 4 chains abreast (the operation sequence of gelu16_f in mlpk_common.h)"""
-        c = GELU_COEFS
+        scale, c = GELU[self.dtype]
         for r in range(4):
-            E("v_mul_f32", t[r], F(GELU_SCALE), x[r])
+            E("v_mul_f32", t[r], F(scale), x[r])
         for r in range(4):
             E("v_med3_f32", t[r], t[r], Neg(self.s_r2), self.s_r2)
         for r in range(4):
             E("v_fma_f32", u[r], t[r], t[r], F(-1.0))
         for r in range(4):
             E("v_fmaak_f32", q[r], u[r], self.v_c0, F(c[1]))
-        for k in range(2, 11):
+        for k in range(2, len(c)):
             for r in range(4):
                 E("v_fmaak_f32", q[r], q[r], u[r], F(c[k]))
         for r in range(4):
@@ -270,98 +336,181 @@ class Q4:
         for r in range(4):
             E("v_mul_f32", x[r], x[r], t[r])
 
+    def ds(self, op, *args, **kw):
+        """emit an LDS instruction and count it (lgkmcnt bookkeeping: LDS operations of a wave complete in order)"""
+        self.a(op, *args, **kw)
+        self.lgkm_issued += 1
+        return self.lgkm_issued - 1
+
+    def wait_lds(self, idx):
+        """wait until LDS operation number idx has completed"""
+        n = self.lgkm_issued - idx - 1
+        self.a("s_waitcnt", lgkmcnt=min(n, 15))
+
     def epilogue_ops(self, set_):
-        """the drain of accumulator set `set_` as a flat list of one-instruction closures"""
+        """The drain of accumulator set `set_` as a flat list of one-instruction closures.  Per block row (32 rows x 64 columns of the
+        wave): the 8 groups of 4 columns go acc -> fp32 math -> packed 16-bit pair -> ds_write_b64 into the wave's 4 KiB staging tile
+        ([row][128 B], 16-byte chunk c of row r at chunk c ^ (r & 7)); then the tile is read back as rows (lane = row lane >> 3 of a
+        group of 8 rows, chunk lane & 7), so that every global store instruction writes 8 whole 128-byte lines.  (Stored straight from
+        the accumulator layout -- every lane its own row, 32 rows x 32 bytes per instruction -- a store took ~590 cycles to issue:
+        profiles/r03_q4_cycles_v1.txt.)  The stores of block row i are issued two groups into block row i + 1."""
         a = self.a
         ops = []
 
         def E(*x, **kw):
             ops.append(lambda: a(*x, **kw))
-        bank = 0
-        for b in range(8):
-            i, j = b >> 1, b & 1
-            for g in range(4):
-                x, t, u, q = self.v_x[bank], self.v_t[bank], self.v_u[bank], self.v_q[bank]
-                bank ^= 1
-                quad = self.v_quad[(b * 2 + (g >> 1)) & 1]
-                for r in range(4):
-                    E("v_accvgpr_read_b32", x[r], A(128 * set_ + 16 * b + 4 * g + r))
-                if self.ln:
-                    for r in range(4):
-                        E("v_fma_f32", x[r], Neg(self.v_mu[i]), self.v_csum[j][g][r], x[r])
-                    for r in range(4):
-                        E("v_fma_f32", x[r], x[r], self.v_rstd[i], self.v_bias[j][g][r])
+
+        def store_part(i, k):
+            """row group k of block row i: (residual add) + store; the first part waits for the staging reads"""
+            rd = self._st_reads[i]
+            if k == 0:
+                ops.append(lambda: self.wait_lds(rd[3]))
+                if self.res:
+                    ops.append(lambda: self.wait_vload(self._res_loads[i][3]))
+            o = self.v_out[k]
+            if self.res:
+                rr = self.v_res[i & 1][k]
+                tm = self.v_tmp
+                for c in range(4):
+                    if self.dtype == "bf16":
+                        E("v_lshlrev_b32", tm[0], 16, o[c])
+                        E("v_and_b32", tm[1], 0xFFFF0000, o[c])
+                        E("v_lshlrev_b32", tm[2], 16, rr[c])
+                        E("v_and_b32", tm[3], 0xFFFF0000, rr[c])
+                    else:
+                        E("v_lshrrev_b32", tm[1], 16, o[c])
+                        E("v_lshrrev_b32", tm[3], 16, rr[c])
+                        E("v_cvt_f32_f16", tm[0], o[c])
+                        E("v_cvt_f32_f16", tm[2], rr[c])
+                        E("v_cvt_f32_f16", tm[1], tm[1])
+                        E("v_cvt_f32_f16", tm[3], tm[3])
+                    E("v_add_f32", tm[0], tm[0], tm[2])
+                    E("v_add_f32", tm[1], tm[1], tm[3])
+                    E(self.cvt, o[c], tm[0], tm[1])
+            if self.stats:
+                sp, dot = self.v_sp, ("v_dot2c_f32_bf16" if self.dtype == "bf16" else "v_dot2c_f32_f16")
+                E("v_mov_b32", sp[0], 0)
+                E("v_mov_b32", sp[1], 0)
+                for c in range(4):
+                    E(dot, sp[0], o[c], self.v_ones)
+                    E(dot, sp[1], o[c], o[c])
+                for mod in (dict(quad_perm="[1,0,3,2]"), dict(quad_perm="[2,3,0,1]"), dict(row_half_mirror=True)):
+                    E("s_nop", 0)
+                    E("v_add_f32_dpp", sp[0], sp[0], sp[0], **mod, row_mask="0xf", bank_mask="0xf")
+                    E("v_add_f32_dpp", sp[1], sp[1], sp[1], **mod, row_mask="0xf", bank_mask="0xf")
+                # one pair per row: the lanes with (lane & 7) == 0
+                ops.append(lambda k=k, i=i: (a("s_mov_b64", "exec", self.s_mask8),
+                                             a("global_store_dwordx2", self.voffP[k], sp, self.s_eP, offset=i * 256),
+                                             a("s_mov_b64", "exec", -1)) and None)
+            if self.stores_on:
+                if not (self.dbg & 512):
+                    E("global_store_dwordx4", self.voffC[k], o, self.s_eC, nt=True)
                 else:
+                    E("global_store_dwordx4", self.voffC[k], o, self.s_eC)
+            if k == 3:
+                ops.extend(self.capture(lambda: self.add64(self.s_eC, self.s_eC, self.s_rowC)))
+                if self.res and i + 2 < 4:
+                    ops.extend(self.res_load_ops(i + 2))
+
+        def stores(i):
+            for k in range(4):
+                store_part(i, k)
+        self._st_reads = {}
+        bank = 0
+        for i in range(4):
+            for j in range(2):
+                for g in range(4):
+                    b = 2 * i + j
+                    x, t, u, q = self.v_x[bank], self.v_t[bank], self.v_u[bank], self.v_q[bank]
+                    pk = self.v_pk[bank]
+                    bank ^= 1
                     for r in range(4):
-                        E("v_add_f32", x[r], x[r], self.v_bias[j][g][r])
-                if self.gelu:
-                    self.gelu_ops(E, x, t, u, q)
-                E(self.cvt, quad[2 * (g & 1)], x[0], x[1])
-                E(self.cvt, quad[2 * (g & 1) + 1], x[2], x[3])
-                if g & 1:
-                    # groups g-1, g packed in quad: exchange halves so that every lane holds 8 consecutive columns
-                    E("s_nop", 1)          # 2 wait states between the v_cvt_pk that wrote quad[3] and the swaps
-                    E("v_permlane32_swap_b32", quad[0], quad[2])
-                    E("v_permlane32_swap_b32", quad[1], quad[3])
-                    if self.res:
-                        rr = self.v_res[i][j][g >> 1]
-                        tm = self.v_tmp
-                        for k in range(4):
-                            if self.dtype == "bf16":
-                                E("v_lshlrev_b32", tm[0], 16, quad[k])
-                                E("v_and_b32", tm[1], 0xFFFF0000, quad[k])
-                                E("v_lshlrev_b32", tm[2], 16, rr[k])
-                                E("v_and_b32", tm[3], 0xFFFF0000, rr[k])
-                            else:
-                                E("v_lshrrev_b32", tm[1], 16, quad[k])
-                                E("v_lshrrev_b32", tm[3], 16, rr[k])
-                                E("v_cvt_f32_f16", tm[0], quad[k])
-                                E("v_cvt_f32_f16", tm[2], rr[k])
-                                E("v_cvt_f32_f16", tm[1], tm[1])
-                                E("v_cvt_f32_f16", tm[3], tm[3])
-                            E("v_add_f32", tm[0], tm[0], tm[2])
-                            E("v_add_f32", tm[1], tm[1], tm[3])
-                            E(self.cvt, quad[k], tm[0], tm[1])
-                    if self.stores_on:
-                        E("global_store_dwordx4", self.voffC[i], quad, self.s_eC, offset=(j * 32 + (g >> 1) * 16) * 2)
+                        E("v_accvgpr_read_b32", x[r], A(128 * set_ + 16 * b + 4 * g + r))
+                    if self.ln:
+                        for r in range(4):
+                            E("v_fma_f32", x[r], Neg(self.v_mu[i]), self.v_csum[j][g][r], x[r])
+                        for r in range(4):
+                            E("v_fma_f32", x[r], x[r], self.v_rstd[i], self.v_bias[j][g][r])
+                    else:
+                        for r in range(4):
+                            E("v_add_f32", x[r], x[r], self.v_bias[j][g][r])
+                    if self.gelu:
+                        self.gelu_ops(E, x, t, u, q)
+                    E(self.cvt, pk[0], x[0], x[1])
+                    E(self.cvt, pk[1], x[2], x[3])
+                    ops.append(lambda c=4 * j + g, pk=pk: self.ds("ds_write_b64", self.v_stw[c], pk))
+                    if i > 0 and not (self.dbg & 256):
+                        if (4 * j + g) in (1, 3, 5, 7):
+                            store_part(i - 1, (4 * j + g) >> 1)
+                    elif i > 0 and j == 0 and g == 1:
+                        stores(i - 1)
+            rd = [None] * 4
+            self._st_reads[i] = rd
+            for k in range(4):
+                ops.append(lambda k=k, rd=rd: rd.__setitem__(k, self.ds("ds_read_b128", self.v_out[k], self.v_strd, offset=k * 1024)))
+        stores(3)
         return ops
 
     # ------------------------------------------------------------------ one iteration of the K loop
-    def iteration(self, set_first, set_main, zero_c, fill, extra_loads=0, head_ops=None):
-        """Four k-steps of 8 MFMAs with the loads of this iteration between them.
-        set_first / set_main: accumulator set of step 0 / steps 1..3; zero_c: step 1 starts the accumulators (C = 0);
-        fill(n): emit up to n filler instructions; extra_loads: VGPR loads among the fillers of this iteration (they count in
-        the vmcnt in front of the barrier)."""
-        a = self.a
-        nread = 0           # ds_reads issued so far in this iteration; 6 from the previous iteration are outstanding at entry
-        ready = {}          # fragment -> index of its read
-        prev = {("B", 0): -6, ("B", 1): -5, ("A", 0): -4, ("A", 1): -3, ("A", 2): -2, ("A", 3): -1}
+    def tail_ops(self):
+        """advance the DMA stream and the LDS stages (issued in the gaps of the last k-step: every piece of the iteration has been
+        issued by then, the fragment reads of the step use the old addresses until its sixth MFMA)"""
+        a, t = self.a, self.s_t
+        if not self.tail_on:
+            return [], []
 
-        def need(frag, idx_of):
-            # wait until read number idx is complete: allow (issued - idx - 1) younger reads outstanding
-            if not self.reads_on:
-                return
-            n = nread - idx_of[frag] - 1
-            a("s_waitcnt", lgkmcnt=n)
-        dma_slots = {(0, 1): ("A", 0), (0, 3): ("A", 1), (0, 6): ("A", 2), (0, 7): ("A", 3),
-                     (1, 1): ("A", 4), (1, 3): ("A", 5), (1, 6): ("A", 6), (1, 7): ("A", 7),
-                     (2, 6): ("B", 0), (2, 7): ("B", 1), (3, 6): ("B", 2), (3, 7): ("B", 3)}
+        def salu():
+            E = a
+            if self.dma_on:
+                self.add64(self.s_dA, self.s_dA, 128)
+                self.add64(self.s_dB, self.s_dB, 128)
+                E("s_sub_u32", self.s_dcnt, self.s_dcnt, 1)
+                E("s_cmp_eq_u32", self.s_dcnt, 0)
+                E("s_cselect_b32", self.s_dA[0], self.s_dAn[0], self.s_dA[0])
+                E("s_cselect_b32", self.s_dA[1], self.s_dAn[1], self.s_dA[1])
+                E("s_cselect_b32", self.s_dB[0], self.s_dBn[0], self.s_dB[0])
+                E("s_cselect_b32", self.s_dB[1], self.s_dBn[1], self.s_dB[1])
+                E("s_cselect_b32", self.s_dcnt, self.k["nk"], self.s_dcnt)
+            # stages: rd <- rd + 1, wr <- wr + 1 (mod 3)   (t[5] is the tail's own scratch register)
+            for r in (self.s_rd, self.s_wr):
+                E("s_add_u32", r, r, STAGE_B)
+                E("s_cmp_ge_u32", r, 3 * STAGE_B)
+                E("s_cselect_b32", t[5], 3 * STAGE_B, 0)
+                E("s_sub_u32", r, r, t[5])
+            E("s_add_u32", self.s_wrA, self.s_wr, self.s_wvA)
+            E("s_add_u32", self.s_wrB, self.s_wr, self.s_wvB)
+
+        def valu():
+            for k in range(4):
+                a("v_add_u32", self.v_curA[k], self.s_rd, self.v_rdA0[k])
+                a("v_add_u32", self.v_curB[k], self.s_rd, self.v_rdB0[k])
+        return self.capture(salu), self.capture(valu)
+
+    def iteration(self, set_first, set_main, zero_c, fill, head_ops=None):
+        """Four k-steps of 8 MFMAs with the loads of this iteration between them, then the wait and the barrier.
+        set_first / set_main: accumulator set of step 0 / steps 1..3; zero_c: step 1 starts the accumulators (C = 0);
+        fill(s, qm): emit the filler instructions of the gap behind MFMA qm of step s."""
+        a = self.a
+        ready = {}          # fragment -> number of its read
+        # 4 pieces behind MFMAs 1, 3, 6, 7 of steps 0, 1 (A) and 2 (B); step 3 carries the bookkeeping
+        dma_slots = {}
+        for s_, (kind, base) in enumerate((("A", 0), ("A", 4), ("B", 0))):
+            for n_, qm_ in enumerate((1, 3, 6, 7)):
+                dma_slots[(s_, qm_)] = (kind, base + n_)
         head = list(head_ops or [])
+        tail_s, tail_v = self.tail_ops()
         i_start = len(a.ins)
         for s in range(4):
             mbuf, rbuf = (s + 1) & 1, s & 1
-            cur = prev if s == 0 else ready
             acc_set = set_first if s == 0 else set_main
             read_order = [("B", 0), ("B", 1), ("A", 0), ("A", 1), ("A", 2), ("A", 3)]
             new_ready = {}
             for qm in range(8):
                 i, j = qm >> 1, qm & 1
-                if j == 0:
-                    # first use of A_i (and of both B fragments when i == 0)
-                    if i == 0:
-                        need(("A", 0), cur)       # B0, B1, A0 were read before A0
-                    else:
-                        need(("A", i), cur)
+                if j == 0 and s > 0 and self.reads_on:
+                    # first use of A_i (and of both B fragments when i == 0: they were read before A_0); the fragments of step 0
+                    # were waited for in front of the previous barrier
+                    self.wait_lds(ready[("A", i)])
                 d = self.acc(acc_set, 2 * i + j)
                 slot = dma_slots.get((s, qm))
                 if slot and self.dma_on:
@@ -372,17 +521,23 @@ class Q4:
                 if slot and self.dma_on:
                     kind, pc = slot
                     if kind == "A":
-                        a("global_load_lds_dwordx4", self.voffA[pc], self.s_dA)
+                        self.vload("global_load_lds_dwordx4", self.voffA[pc], self.s_dA)
                     else:
-                        a("global_load_lds_dwordx4", self.voffB[pc], self.s_dB)
+                        self.vload("global_load_lds_dwordx4", self.voffB[pc], self.s_dB)
                 if qm < 6 and self.reads_on:
                     kind, idx = read_order[qm]
                     if kind == "A":
-                        a("ds_read_b128", self.FA[rbuf][idx], self.v_curA[s], offset=idx * 4096)
+                        new_ready[(kind, idx)] = self.ds("ds_read_b128", self.FA[rbuf][idx], self.v_curA[s], offset=idx * 4096)
                     else:
-                        a("ds_read_b128", self.FB[rbuf][idx], self.v_curB[s], offset=idx * 4096)
-                    new_ready[(kind, idx)] = nread
-                    nread += 1
+                        new_ready[(kind, idx)] = self.ds("ds_read_b128", self.FB[rbuf][idx], self.v_curB[s], offset=idx * 4096)
+                if s == 3:
+                    for _ in range(3):
+                        if tail_s:
+                            tail_s.pop(0)()
+                    if qm >= 6:
+                        for _ in range(4):
+                            if tail_v:
+                                tail_v.pop(0)()
                 # fillers
                 if head:
                     for _ in range(4):
@@ -391,8 +546,9 @@ class Q4:
                 else:
                     fill(s, qm)
             ready = new_ready
-        while head:
-            head.pop(0)()
+        for rest in (head, tail_s, tail_v):
+            while rest:
+                rest.pop(0)()
         # vmcnt in front of the barrier: the pieces of the PREVIOUS iteration must have landed (<= 12 loads of this one may be
         # in flight: loads return in order, stores may not be counted on), and so must every VGPR load issued in this one
         kinds = [("load" if x.op.startswith("global_load_dword") else "dma") for x in a.ins[i_start:]
@@ -400,43 +556,16 @@ class Q4:
         allow = len(kinds)
         if "load" in kinds:
             allow = len(kinds) - 1 - max(k for k, x in enumerate(kinds) if x == "load")
-        return min(allow, 12 if self.dma_on else 0)
-
-    def iter_tail(self, vm_allow):
-        """advance the DMA stream and the LDS stages, then wait + barrier"""
-        a, t = self.a, self.s_t
-        if not self.tail_on:
-            a("s_waitcnt", vmcnt=vm_allow, lgkmcnt=0)
-            a("s_barrier")
-            return
-        if self.dma_on:
-            self.add64(self.s_dA, self.s_dA, 128)
-            self.add64(self.s_dB, self.s_dB, 128)
-            a("s_sub_u32", self.s_dcnt, self.s_dcnt, 1)
-            a("s_cmp_eq_u32", self.s_dcnt, 0)
-            a("s_cselect_b32", self.s_dA[0], self.s_dAn[0], self.s_dA[0])
-            a("s_cselect_b32", self.s_dA[1], self.s_dAn[1], self.s_dA[1])
-            a("s_cselect_b32", self.s_dB[0], self.s_dBn[0], self.s_dB[0])
-            a("s_cselect_b32", self.s_dB[1], self.s_dBn[1], self.s_dB[1])
-            a("s_cselect_b32", self.s_dcnt, self.k["nk"], self.s_dcnt)
-        # stages: rd <- rd + 1, wr <- wr + 1 (mod 3)
-        for r in (self.s_rd, self.s_wr):
-            a("s_add_u32", r, r, STAGE_B)
-            a("s_cmp_ge_u32", r, 3 * STAGE_B)
-            a("s_cselect_b32", t[0], 3 * STAGE_B, 0)
-            a("s_sub_u32", r, r, t[0])
-        a("s_add_u32", self.s_wrA, self.s_wr, self.s_wvA)
-        a("s_add_u32", self.s_wrB, self.s_wr, self.s_wvB)
-        for k in range(4):
-            a("v_add_u32", self.v_curA[k], self.s_rd, self.v_rdA0[k])
-            a("v_add_u32", self.v_curB[k], self.s_rd, self.v_rdB0[k])
-        a("s_waitcnt", vmcnt=vm_allow, lgkmcnt=0)
+        a("s_waitcnt", vmcnt=min(allow, 12 if self.dma_on else 0), lgkmcnt=0)
         a("s_barrier")
 
     # ------------------------------------------------------------------ the kernel
     def build(self):
         a = self.a
         self.regs()
+        self.lgkm_issued = 0
+        self.vm_loads = 0
+        self._res_loads = {}
         t = self.s_t
         k, p = self.k, self.p
         L_end = a.newlabel("END")
@@ -445,6 +574,9 @@ class Q4:
         a("s_load_dwordx8", S(20, 8), self.s_karg, 64)
         a("s_load_dwordx4", S(28, 4), self.s_karg, 96)
         a("s_load_dwordx2", self.s_profp, self.s_karg, KA["prof"])
+        if self.stats:
+            a("s_load_dwordx2", self.s_part, self.s_karg, KA["row_part"])
+            a("s_load_dword", self.s_partld, self.s_karg, KA["row_part_ld"])
         # ---- lane constants (independent of the arguments)
         vt = self.v_tmp
         lane, l31, h, l3, l7, x = vt[0], vt[1], vt[2], vt[3], vt[4], vt[5]
@@ -460,7 +592,8 @@ class Q4:
         a("v_xor_b32", x, x, l7)                   # read swizzle (lane & 7) ^ ((lane >> 4) & 1)
         a("v_xor_b32", x, x, h)                    # ^ k-half of the lane
         a("s_mov_b32", self.s_r2, F(SQRT2))
-        a("v_mov_b32", self.v_c0, F(GELU_COEFS[0]))
+        if self.gelu:
+            a("v_mov_b32", self.v_c0, F(GELU[self.dtype][1][0]))
         a("s_waitcnt", lgkmcnt=0)
         a("s_memtime", self.s_prof0)
         # wave position: wm = wave >> 1, wn = wave & 1
@@ -496,20 +629,48 @@ class Q4:
                 a("v_lshlrev_b32", arr[pc], 1, vt[7])
         # epilogue offsets
         a("s_lshl_b32", t[0], wm, 7)
-        a("v_add_u32", vt[6], t[0], l31)                            # row inside the tile (block row 0)
+        a("v_add_u32", vt[6], t[0], l31)                            # row inside the tile (block row 0), accumulator layout
         a("v_lshlrev_b32", self.voffRow, 2, vt[6])
-        a("s_lshl_b32", t[0], wn, 6)
-        a("v_lshl_add_u32", vt[7], h, 3, t[0])                      # wn * 64 + h * 8
+        a("s_lshl_b32", t[1], wn, 6)
+        a("v_lshl_add_u32", vt[7], h, 2, t[1])                      # wn * 64 + h * 4
+        a("v_lshlrev_b32", self.voffCol, 2, vt[7])
+        # stores / residual loads: row wm * 128 + (lane >> 3) + 8 k of block row 0, columns wn * 64 + (lane & 7) * 8
+        a("v_add_u32", vt[6], t[0], l3)
+        a("v_lshl_add_u32", vt[7], l7, 3, t[1])
         for arr, ld, on in ((self.voffC, k["ldc"], True), (self.voffR, k["ldr"], self.res)):
             if not on:
                 continue
-            for i in range(4):
-                a("v_add_u32", lane, 32 * i, vt[6])
+            for kk in range(4):
+                a("v_add_u32", lane, 8 * kk, vt[6])
                 a("v_mul_lo_u32", lane, lane, ld)
                 a("v_add_u32", lane, lane, vt[7])
-                a("v_lshlrev_b32", arr[i], 1, lane)
-        a("v_lshl_add_u32", vt[7], h, 2, t[0])                      # wn * 64 + h * 4
-        a("v_lshlrev_b32", self.voffCol, 2, vt[7])
+                a("v_lshlrev_b32", arr[kk], 1, lane)
+        a("s_lshl_b32", self.s_rowC, k["ldc"], 6)
+        if self.res:
+            a("s_lshl_b32", self.s_rowR, k["ldr"], 6)
+        if self.stats:
+            # pair offsets: row wm * 128 + 8 k + (lane >> 3) of block row 0, 8 bytes per row
+            a("s_lshl_b32", t[0], wm, 7)
+            a("v_add_u32", vt[6], t[0], l3)
+            for kk in range(4):
+                a("v_add_u32", lane, 8 * kk, vt[6])
+                a("v_lshlrev_b32", self.voffP[kk], 3, lane)
+            a("v_mov_b32", self.v_ones, 0x3F803F80 if self.dtype == "bf16" else 0x3C003C00)
+            a("s_mov_b32", self.s_mask8[0], 0x01010101)
+            a("s_mov_b32", self.s_mask8[1], 0x01010101)
+        # LDS staging tile of this wave: OUT_OFF + wave * 4096; write: row l31, chunk c ^ (l31 & 7), half h; read: row l3, chunk l7 ^ l3
+        a("s_lshl_b32", t[0], self.s_wave, 12)
+        a("s_add_u32", t[0], t[0], OUT_OFF)
+        a("v_lshlrev_b32", vt[6], 7, l31)
+        a("v_add_u32", vt[6], t[0], vt[6])
+        a("v_lshl_add_u32", vt[6], h, 3, vt[6])
+        for c in range(8):
+            a("v_xor_b32", lane, c, l7)
+            a("v_lshl_add_u32", self.v_stw[c], lane, 4, vt[6])
+        a("v_lshlrev_b32", vt[6], 7, l3)
+        a("v_add_u32", vt[6], t[0], vt[6])
+        a("v_xor_b32", lane, l7, l3)
+        a("v_lshl_add_u32", self.v_strd, lane, 4, vt[6])
         # ---- work list (gemm_nt_p8_kernel's): XCD = bid & 7 -> column group, member; tiles u0 + l, l = bid >> 3, += grid >> 3
         xcd, cgrp, xj = t[0], t[1], t[2]
         a("s_and_b32", xcd, self.s_bid, 7)
@@ -603,9 +764,9 @@ class Q4:
                     state["done"] += 1
             for u in range(self.nkf):
                 if u == 0:
-                    self.iter_tail(self.iteration(1 - P, P, True, lambda s, qm: None, head_ops=head))
+                    self.iteration(1 - P, P, True, lambda s, qm: None, head_ops=head)
                 else:
-                    self.iter_tail(self.iteration(P, P, False, fill))
+                    self.iteration(P, P, False, fill)
             while state["done"] < len(ops):
                 ops[state["done"]]()
                 state["done"] += 1
@@ -614,7 +775,7 @@ class Q4:
             a("s_cmp_eq_u32", self.s_roll, 0)
             a("s_cbranch_scc1", L_rdone[P])
             a.label(L_roll[P])
-            self.iter_tail(self.iteration(P, P, False, lambda s, qm: None))
+            self.iteration(P, P, False, lambda s, qm: None)
             a("s_sub_u32", self.s_roll, self.s_roll, 1)
             a("s_cmp_lg_u32", self.s_roll, 0)
             a("s_cbranch_scc1", L_roll[P])
@@ -651,20 +812,22 @@ class Q4:
 
 # ------------------------------------------------------------------ emission
 # variant table: (class name, gelu, ln, res, unrolled iterations)
-CLASSES = {"p": (False, False, False), "l": (False, True, False), "g": (True, False, False), "gl": (True, True, False), "r": (False, False, True)}
-NKF = {"p": (3, 4), "l": (3, 4, 6), "g": (3, 4, 6, 12), "gl": (3, 4, 6, 12), "r": (3, 4, 6)}
+# (gelu, ln, res, stats)
+CLASSES = {"p": (False, False, False, False), "l": (False, True, False, False), "g": (True, False, False, False), "gl": (True, True, False, False),
+           "r": (False, False, True, False), "rs": (False, False, True, True)}
+NKF = {c: (3, 4, 6, 12) for c in CLASSES}
 DTYPES = ("bf16", "f16")
 
 
 def variants():
     for dt in DTYPES:
-        for cls, (gelu, ln, res) in CLASSES.items():
+        for cls, (gelu, ln, res, stats) in CLASSES.items():
             for nkf in NKF[cls]:
-                yield "q4_%s_%s_f%d" % (dt, cls, nkf), dict(dtype=dt, gelu=gelu, ln=ln, res=res, nkf=nkf)
+                yield "q4_%s_%s_f%d" % (dt, cls, nkf), dict(dtype=dt, gelu=gelu, ln=ln, res=res, stats=stats, nkf=nkf)
     # tuning ablations (wrong results by construction; bits in Q4.__init__)
-    for cls, nkf in (("gl", 12), ("r", 6)):
-        gelu, ln, res = CLASSES[cls]
-        for x in (1, 2, 4, 5, 13, 21, 29):
+    for cls, nkf in (("gl", 12), ("r", 12)):
+        gelu, ln, res, _ = CLASSES[cls]
+        for x in (1, 2, 3, 4, 5, 13, 21, 29, 64, 65, 256, 512, 768):
             yield "q4_bf16_%s_f%d_x%d" % (cls, nkf, x), dict(dtype="bf16", gelu=gelu, ln=ln, res=res, nkf=nkf, dbg=x)
 
 
@@ -688,12 +851,12 @@ def emit(path):
             raise RuntimeError("%s: %d hazard lint findings, first: %s" % (name, len(pr), pr[0]))
         out.append(kernel_text(name, g))
         table.append((name, kw))
-    out.append("namespace mlpk {\nstruct Q4Variant { const char* name; const void* fn; int dtype, gelu, ln, res, nkf, dbg; };\n"
+    out.append("namespace mlpk {\nstruct Q4Variant { const char* name; const void* fn; int dtype, gelu, ln, res, stats, nkf, dbg; };\n"
                "static const Q4Variant kQ4Variants[] = {\n")
     for name, kw in table:
         dbg = kw.get("dbg", 0)
-        out.append("    {\"%s\", reinterpret_cast<const void*>(&%s), %s, %d, %d, %d, %d, %d},\n" %
-                   (name, name, "MLPK_BF16" if kw["dtype"] == "bf16" else "MLPK_F16", kw["gelu"], kw["ln"], kw["res"], kw["nkf"], dbg))
+        out.append("    {\"%s\", reinterpret_cast<const void*>(&%s), %s, %d, %d, %d, %d, %d, %d},\n" %
+                   (name, name, "MLPK_BF16" if kw["dtype"] == "bf16" else "MLPK_F16", kw["gelu"], kw["ln"], kw["res"], kw.get("stats", False), kw["nkf"], dbg))
     out.append("};\n}  // namespace mlpk\n")
     text = "".join(out)
     if not os.path.exists(path) or open(path).read() != text:

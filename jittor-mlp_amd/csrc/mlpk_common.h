@@ -55,17 +55,23 @@ __device__ __forceinline__ float gelu_f(float x) {
 // |Phi error| <= 2.7e-6 everywhere (|x| > 4.5 clamps to Phi(4.5) = 1 - 3.4e-6), |gelu error| <= 3.7e-6 on |x| <= 4.5: 60x below
 // half an ulp of f16 at that magnitude; checked in fp32 emulation by tests/test_host_cpu.py against the coefficients HERE.
 // float outputs keep gelu_f.
+// Two grades (tools/fit_gelu_poly.py A K), by storage type of the result:
+//   f16 : A = 4.5, 11 coefficients -- |Phi error| <= 2.7e-6, |gelu error| <= 3.7e-6 on |x| <= 4.5 (60x below half an ulp of f16)
+//   bf16: A = 4.0,  8 coefficients -- |Phi error| <= 5.3e-5, |gelu error| <= 8.5e-5 on |x| <= 4 (half an ulp of bf16 is 2^-9 relative:
+//         the polynomial error stays below the rounding of every result above 0.04 in magnitude); three fewer fma per element in the
+//         kernels whose epilogues are bound by VALU issue (round 3: the q4 GEMM's fillers, the token-mixing kernel).
 #define MLPK_GELUP_SCALE 0.314269681f
 #define MLPK_GELUP_COEFS {0.00260713836f, -0.00718860654f, 0.00979797821f, -0.0172248576f, 0.0355015062f, -0.0601866171f, 0.090279378f, -0.127707109f, 0.174028099f, -0.245624334f, 0.499268919f}
+#define MLPK_GELUP_SCALE_BF16 0.353553391f
+#define MLPK_GELUP_COEFS_BF16 {-0.00937665813f, 0.0246067308f, -0.0355258957f, 0.059637472f, -0.103835642f, 0.158927634f, -0.238559365f, 0.497641712f}
 
 // gelu on N independent pairs with the N dependency chains interleaved step by step: a single wave running ONE
 // chain is latency-bound (each v_pk op waits for its predecessor); N = 4 keeps the VALU issuing back to back.
-template <int N> __device__ __forceinline__ void gelu_pk_n(f32x2 (&x)[N]) {
-    constexpr float c[11] = MLPK_GELUP_COEFS;
+template <int N, int K> __device__ __forceinline__ void gelu_pk_impl(f32x2 (&x)[N], const float (&c)[K], const float scale) {
     constexpr float r2 = 1.41421356237f;
     f32x2 t[N], u[N], q[N];
 #pragma unroll
-    for (int k = 0; k < N; ++k) t[k] = x[k] * f32x2{MLPK_GELUP_SCALE, MLPK_GELUP_SCALE};
+    for (int k = 0; k < N; ++k) t[k] = x[k] * f32x2{scale, scale};
 #pragma unroll
     for (int k = 0; k < N; ++k) t[k] = f32x2{__builtin_amdgcn_fmed3f(t[k].x, -r2, r2), __builtin_amdgcn_fmed3f(t[k].y, -r2, r2)};
 #pragma unroll
@@ -73,33 +79,52 @@ template <int N> __device__ __forceinline__ void gelu_pk_n(f32x2 (&x)[N]) {
 #pragma unroll
     for (int k = 0; k < N; ++k) q[k] = __builtin_elementwise_fma(u[k], f32x2{c[0], c[0]}, f32x2{c[1], c[1]});
 #pragma unroll
-    for (int i = 2; i < 11; ++i)
+    for (int i = 2; i < K; ++i)
 #pragma unroll
         for (int k = 0; k < N; ++k) q[k] = __builtin_elementwise_fma(q[k], u[k], f32x2{c[i], c[i]});
 #pragma unroll
     for (int k = 0; k < N; ++k) x[k] = x[k] * __builtin_elementwise_fma(t[k], q[k], f32x2{0.5f, 0.5f});
 }
 
-__device__ __forceinline__ f32x2 gelu_pk(f32x2 x) {
+template <typename T, int N> __device__ __forceinline__ void gelu_pk_n(f32x2 (&x)[N]) {
+    if constexpr (dtype_of<T>::value == MLPK_BF16) {
+        constexpr float c[8] = MLPK_GELUP_COEFS_BF16;
+        gelu_pk_impl<N, 8>(x, c, MLPK_GELUP_SCALE_BF16);
+    } else {
+        constexpr float c[11] = MLPK_GELUP_COEFS;
+        gelu_pk_impl<N, 11>(x, c, MLPK_GELUP_SCALE);
+    }
+}
+
+template <typename T> __device__ __forceinline__ f32x2 gelu_pk(f32x2 x) {
     f32x2 v[1] = {x};
-    gelu_pk_n<1>(v);
+    gelu_pk_n<T, 1>(v);
     return v[0];
 }
 
 // scalar form of gelu_pk (the same operation sequence, hence the same results)
-__device__ __forceinline__ float gelu16_f(float x) {
-    constexpr float c[11] = MLPK_GELUP_COEFS;
+template <int K> __device__ __forceinline__ float gelu16_impl(float x, const float (&c)[K], const float scale) {
     constexpr float r2 = 1.41421356237f;
-    const float t = __builtin_amdgcn_fmed3f(x * MLPK_GELUP_SCALE, -r2, r2);
+    const float t = __builtin_amdgcn_fmed3f(x * scale, -r2, r2);
     const float u = __builtin_fmaf(t, t, -1.0f);
     float q = __builtin_fmaf(u, c[0], c[1]);
 #pragma unroll
-    for (int i = 2; i < 11; ++i) q = __builtin_fmaf(q, u, c[i]);
+    for (int i = 2; i < K; ++i) q = __builtin_fmaf(q, u, c[i]);
     return x * __builtin_fmaf(t, q, 0.5f);
 }
 
+template <typename T> __device__ __forceinline__ float gelu16_f(float x) {
+    if constexpr (dtype_of<T>::value == MLPK_BF16) {
+        constexpr float c[8] = MLPK_GELUP_COEFS_BF16;
+        return gelu16_impl<8>(x, c, MLPK_GELUP_SCALE_BF16);
+    } else {
+        constexpr float c[11] = MLPK_GELUP_COEFS;
+        return gelu16_impl<11>(x, c, MLPK_GELUP_SCALE);
+    }
+}
+
 template <typename T> __device__ __forceinline__ float gelu_t(float x) {
-    if constexpr (sizeof(T) == 2) return gelu16_f(x);
+    if constexpr (sizeof(T) == 2) return gelu16_f<T>(x);
     else return gelu_f(x);
 }
 

@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(DW_NT) dwconv_lds_kernel(const T* __restrict__
             f32x2 g[STRIP / 2];
 #pragma unroll
             for (int o = 0; o < STRIP / 2; ++o) g[o] = f32x2{acc[2 * o], acc[2 * o + 1]};
-            gelu_pk_n<STRIP / 2>(g);
+            gelu_pk_n<T, STRIP / 2>(g);
 #pragma unroll
             for (int o = 0; o < STRIP / 2; ++o) { acc[2 * o] = g[o].x; acc[2 * o + 1] = g[o].y; }
         } else {
@@ -450,7 +450,7 @@ __global__ void __launch_bounds__(NW * 64) dwconv_mfma_kernel(const T* __restric
                 T c4[4];
                 __builtin_memcpy(c4, &cw, 8);
                 f32x2 v[2] = {f32x2{a4.x + bz[j], a4.y + bz[j]}, f32x2{a4.z + bz[j], a4.w + bz[j]}};
-                gelu_pk_n<2>(v);
+                gelu_pk_n<T, 2>(v);
                 const float g[4] = {v[0].x, v[0].y, v[1].x, v[1].y};
                 T o4[4];
 #pragma unroll

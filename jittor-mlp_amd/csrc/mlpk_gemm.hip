@@ -46,6 +46,7 @@ struct GemmArgs {
     int m_base, panels, cgroups;
     void* prof_buf;     // MLPK_P8_PROF builds: per-workgroup cycle sums (reserved & 8)
     int dbg_delay;      // de-phase sleep, units of 8128 cycles
+    int dbg_q4;         // tuning bits of the generated q4 kernels (desc.reserved bits 16..23)
     int dbg;            // tuning ablations (desc.reserved): 1 = no main loop, 2 = no stores, 4 = no epilogue
     // by-product row statistics of the stored values (16-bit row-major outputs): pair (q, m) = (sum, sum of squares) of row m over
     // column block q; block width 128 (LDS-staged epilogue) or 32 (direct epilogue of the persistent tile).  PLANAR, one plane per
@@ -263,7 +264,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
                     if constexpr (GELU) {
                         if constexpr (sizeof(T) == 2) {
                             f32x2 g2[2] = {f32x2{t[0], t[1]}, f32x2{t[2], t[3]}};
-                            gelu_pk_n<2>(g2);
+                            gelu_pk_n<T, 2>(g2);
                             t[0] = g2[0].x; t[1] = g2[0].y; t[2] = g2[1].x; t[3] = g2[1].y;
                         } else {
 #pragma unroll
@@ -978,7 +979,7 @@ __device__ __forceinline__ void p8_store_tile(const GemmArgs& p, f32x4 (&acc)[8]
                     v[2 * jj] = lo;
                     v[2 * jj + 1] = hi;
                 }
-                if (GELU) gelu_pk_n<4>(v);
+                if (GELU) gelu_pk_n<T, 4>(v);
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
                     const int j = jp * 2 + jj;
@@ -1153,7 +1154,7 @@ __device__ __forceinline__ void p8_store_direct(const GemmArgs& p, f32x4 (&acc)[
                     v[2 * jj] = lo;
                     v[2 * jj + 1] = hi;
                 }
-                if (GELU) gelu_pk_n<4>(v);
+                if (GELU) gelu_pk_n<T, 4>(v);
                 unsigned w[4];
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
@@ -1706,7 +1707,7 @@ template <typename T> static int launch_p8(const GemmArgs& a0, bool trans, hipSt
 
 // the call as the generated q4 kernels take it; false when they do not implement it (other tiles do)
 static bool q4_call_of(const GemmArgs& a, int dtype, bool trans, Q4Call& c) {
-    if (dtype == MLPK_F32 || trans || a.rscale || a.cscale || a.cshift || a.row_part) return false;
+    if (dtype == MLPK_F32 || trans || a.rscale || a.cscale || a.cshift) return false;
     if (a.res_mode != MLPK_RES_NONE && a.res_mode != MLPK_RES_ADD) return false;
     if (a.ln_mean && a.ln_group != 1) return false;
     c.dtype = dtype;
@@ -1715,8 +1716,9 @@ static bool q4_call_of(const GemmArgs& a, int dtype, bool trans, Q4Call& c) {
     c.A = a.A; c.B = a.B; c.C = a.C; c.R = a.res_mode != MLPK_RES_NONE ? a.R : nullptr;
     c.bias = a.bias; c.ln_mean = a.ln_mean; c.ln_rstd = a.ln_rstd; c.ln_csum = a.ln_csum;
     c.gelu = a.act == MLPK_ACT_GELU; c.ln = a.ln_mean != nullptr; c.res = a.res_mode != MLPK_RES_NONE;
+    c.row_part = a.row_part; c.row_part_ld = a.row_part_ld;
     c.one_group = (a.dbg & 128) != 0;
-    c.dbg = a.dbg & 31;
+    c.dbg = (a.dbg & (31 | 64)) | (a.dbg_q4 << 8);
     c.prof = (a.dbg & 32) ? a.prof_buf : nullptr;      // reserved & 32: cycle counts into desc.workspace
     return q4_supported(c);
 }
@@ -1855,6 +1857,7 @@ static int gemm_prepare(const mlpk_gemm_desc* d, GemmArgs& a, int& algo, bool& t
     a.t_rows = d->t_rows; a.t_tokens = d->t_tokens;
     a.dbg = d->reserved & 0xff;
     a.dbg_delay = (d->reserved >> 8) & 0xff;
+    a.dbg_q4 = (d->reserved >> 16) & 0xff;
     a.m_base = 0; a.panels = 0; a.cgroups = 1; a.prof_buf = d->workspace;
     a.row_part = d->row_part; a.row_part_ld = d->row_part_ld;
     const int vb = 4 * es;   // bytes of a 4-element vector
@@ -1878,17 +1881,24 @@ static int gemm_prepare(const mlpk_gemm_desc* d, GemmArgs& a, int& algo, bool& t
     const bool p8_stats_ok = d->res_mode != MLPK_RES_NONE && d->act == MLPK_ACT_NONE && !d->ln_mean && !d->cscale && !d->cshift && !(a.dbg & 64);
     if (stats && !p8_stats_ok) p8_ok = false;
     if (algo == 0) {
-        // round 3: the generated one-wave-per-SIMD tile where it applies (MLPK_GEMM_Q4=0 switches it off for A/B runs)
-        static const int q4_mode = getenv("MLPK_GEMM_Q4") ? atoi(getenv("MLPK_GEMM_Q4")) : 0;
+        // round 3: the generated one-wave-per-SIMD tile where it is ahead (MLPK_GEMM_Q4=0 switches it off for A/B runs; 2 = wherever
+        // it applies).  Measured at M = 50176 (profiles/r03_q4_probe_v3.txt): ahead of the persistent 256 x 256 tile up to K = 1024
+        // (channel fc1 +7 %, Mixer-L fc1 +5 %, gMLP proj1 +5 %), behind it at K >= 3072 (its LDS-DMA runs two 48-KiB slabs ahead:
+        // HBM-latency bound on long-K streams); 20-28 % ahead of the s3 tile on the N = 384 / 1152 shapes the persistent tile cannot
+        // take.  Its pipeline spends one extra (draining) block per workgroup: only for grids of several tiles per CU.
+        static const int q4_mode = getenv("MLPK_GEMM_Q4") ? atoi(getenv("MLPK_GEMM_Q4")) : 1;
         Q4Call qc;
-        if (q4_mode && !stats && q4_call_of(a, d->dtype, trans, qc)) algo = 15;
+        if (q4_mode && q4_call_of(a, d->dtype, trans, qc)) {
+            const long long tiles = (long long)(d->M / 256) * (d->N / 128);
+            if (q4_mode >= 2 || (tiles >= 512 && (!p8_ok || d->K <= 1280))) algo = 15;
+        }
     }
     if (algo == 0) algo = auto_algo(d->M, d->N, d->K, epc, glds_ok, p8_ok, stats);
     if (algo < 1 || algo > kNumTiles) return MLPK_EMODE;
     if (kTiles[algo - 1].glds && !glds_ok) return MLPK_ESHAPE;
     if (kTiles[algo - 1].glds == 4) {
         Q4Call qc;
-        if (stats || !q4_call_of(a, d->dtype, trans, qc)) return MLPK_ESHAPE;
+        if (!q4_call_of(a, d->dtype, trans, qc)) return MLPK_ESHAPE;
     }
     if (stats) {
         if (kTiles[algo - 1].bn < 128 || (kTiles[algo - 1].glds == 3 && !p8_stats_ok)) return MLPK_EMODE;
@@ -1908,7 +1918,7 @@ extern "C" int mlpk_gemm_row_parts(const mlpk_gemm_desc* d, int* nparts) {
     bool trans = false;
     const int rc = gemm_prepare(&q, a, algo, trans);
     if (rc) return rc;
-    const int width = kTiles[algo - 1].glds == 3 ? 32 : 128;
+    const int width = kTiles[algo - 1].glds == 4 ? 64 : kTiles[algo - 1].glds == 3 ? 32 : 128;
     *nparts = (d->N + width - 1) / width;
     return 0;
 }

@@ -4,7 +4,7 @@
 
 namespace mlpk {
 
-#define Q4_LDS_BYTES (3 * 49152)
+#define Q4_LDS_BYTES (3 * 49152 + 16384)
 
 struct Q4Call {
     int dtype;                 // MLPK_BF16 / MLPK_F16
@@ -19,6 +19,8 @@ struct Q4Call {
     const float* ln_rstd;
     const float* ln_csum;
     int gelu, ln, res;
+    float* row_part;           // by-product (sum, sum of squares) of the stored rows per block of 64 columns (mlpk.h row_part), or null
+    int row_part_ld;
     int one_group;             // tuning: a single column group
     void* prof;                // tuning: (cycles, tiles) of every workgroup, 8 bytes each, or null
     int dbg;                   // tuning ablations: 1 = no LDS-DMA, 4 = no epilogue fillers (results are wrong by construction)

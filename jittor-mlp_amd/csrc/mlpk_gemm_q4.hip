@@ -22,9 +22,11 @@ struct Q4Args {
     int nk, cg, cg_magic, U;
     int Q, log2X, m_base, grid;
     void* prof;          // tuning: per-workgroup (cycles, tiles) pairs, or null
-    int pad[2];
+    float* row_part;     // by-product row statistics (classes with stats): planes of 64 columns
+    int row_part_ld;
+    int pad[3];
 };
-static_assert(sizeof(Q4Args) == 128, "kernarg layout");
+static_assert(sizeof(Q4Args) == 144, "kernarg layout");
 }  // namespace mlpk
 
 #include "gen_out/q4_kernels.inc"
@@ -57,6 +59,7 @@ bool q4_supported(const Q4Call& c) {
     if (c.M % 256 || c.N % 128 || c.K % 64 || c.K < 192) return false;
     if (!c.bias) return false;
     if (c.res && (c.gelu || c.ln)) return false;
+    if (c.row_part && (!c.res || c.row_part_ld < c.M || (reinterpret_cast<uintptr_t>(c.row_part) & 7))) return false;     // statistics: the bias + residual class
     if (c.lda % 8 || c.ldb % 8 || c.ldc % 8 || (c.res && c.ldr % 8)) return false;
     const uintptr_t al = reinterpret_cast<uintptr_t>(c.A) | reinterpret_cast<uintptr_t>(c.B) | reinterpret_cast<uintptr_t>(c.C) |
                          reinterpret_cast<uintptr_t>(c.R) | reinterpret_cast<uintptr_t>(c.bias) | reinterpret_cast<uintptr_t>(c.ln_csum);
@@ -70,7 +73,7 @@ static const Q4Variant* q4_pick(const Q4Call& c, int force_nkf) {
     const int nk = c.K / 64;
     const Q4Variant* best = nullptr;
     for (const Q4Variant& v : kQ4Variants) {
-        if (v.dtype != c.dtype || v.gelu != c.gelu || v.ln != c.ln || v.res != c.res || v.dbg != c.dbg) continue;
+        if (v.dtype != c.dtype || v.gelu != c.gelu || v.ln != c.ln || v.res != c.res || v.stats != (c.row_part != nullptr) || v.dbg != c.dbg) continue;
         if (v.nkf > nk) continue;
         if (force_nkf && v.nkf != force_nkf) continue;
         if (!best || v.nkf > best->nkf) best = &v;
@@ -104,7 +107,8 @@ int q4_launch(const Q4Call& c, hipStream_t stream) {
     while ((1 << lg) < X) ++lg;
     a.log2X = lg; a.m_base = 0; a.grid = grid;
     a.prof = c.prof;
-    a.pad[0] = a.pad[1] = 0;
+    a.row_part = c.row_part; a.row_part_ld = c.row_part_ld;
+    a.pad[0] = a.pad[1] = a.pad[2] = 0;
     hipError_t e = hipFuncSetAttribute(v->fn, hipFuncAttributeMaxDynamicSharedMemorySize, Q4_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     void* params[] = {&a};

@@ -423,9 +423,9 @@ __global__ void __launch_bounds__(512, 1) token_mlp_kernel(const TokenMlpArgs p)
 #if TM_ABL & 2
 #elif defined(TM_GELU_SCALAR)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = f32x2{gelu16_f(v[c].x), gelu16_f(v[c].y)};
+                    for (int c = 0; c < 4; ++c) v[c] = f32x2{gelu16_f<T>(v[c].x), gelu16_f<T>(v[c].y)};
 #else
-                    gelu_pk_n<4>(v);
+                    gelu_pk_n<T, 4>(v);
 #endif
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
@@ -676,7 +676,7 @@ __global__ void __launch_bounds__(512, 1) token_mlp_rr_kernel(const TokenMlpArgs
             f32x2 v[4] = {f32x2{a1[i][0].x + bb0.x, a1[i][0].y + bb0.y}, f32x2{a1[i][0].z + bb0.z, a1[i][0].w + bb0.w},
                           f32x2{a1[i][1].x + bb1.x, a1[i][1].y + bb1.y}, f32x2{a1[i][1].z + bb1.z, a1[i][1].w + bb1.w}};
 #if !(TM_ABL & 2)
-            gelu_pk_n<4>(v);
+            gelu_pk_n<T, 4>(v);
 #endif
             T e[8] = {from_f32<T>(v[0].x), from_f32<T>(v[0].y), from_f32<T>(v[1].x), from_f32<T>(v[1].y),
                       from_f32<T>(v[2].x), from_f32<T>(v[2].y), from_f32<T>(v[3].x), from_f32<T>(v[3].y)};

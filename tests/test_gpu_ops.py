@@ -969,7 +969,7 @@ class _Space:
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("algo", [0, 1, 2, 3, 4, 7, 11, 12, 13, 14])
+@pytest.mark.parametrize("algo", [0, 1, 2, 3, 4, 7, 11, 12, 13, 14, 15])
 def test_gemm_byproduct_row_statistics(dtype, algo):
     """mlpk.h row_part: (sum, sum of squares) of the STORED values per row and column block, from every epilogue that
     delivers them; C itself must not change by a bit, and mlpk_stats_finalize_planar must reproduce LayerNorm / per-sample
@@ -979,6 +979,8 @@ def test_gemm_byproduct_row_statistics(dtype, algo):
     shapes = [(1000, 384, 96, True, 0), (512, 96, 64, False, 1), (777, 200, 128, True, 1), (1024, 512, 256, True, 0)]
     if algo == 14:
         shapes = [(1024, 512, 256, True, 0), (832, 256, 128, True, 0)]       # whole tiles, bias + residual
+    if algo == 15:
+        shapes = [(1024, 512, 256, True, 0), (768, 384, 192, True, 0), (2048, 384, 1152, True, 0)]     # the generated tile: bias + residual
     for (M, Nn, K, has_res, act) in shapes:
         A = rnd((M, K), dtype, 500).to(dev())
         B = rnd((Nn, K), dtype, 501, 1.0 / math.sqrt(K)).to(dev())
@@ -994,7 +996,7 @@ def test_gemm_byproduct_row_statistics(dtype, algo):
         part, nparts = got
         torch.cuda.synchronize()
         assert torch.equal(C.view(torch.int16), ref.view(torch.int16)), (M, Nn, K, algo)
-        width = 128 if nparts == -(-Nn // 128) else 32
+        width = 64 if algo == 15 else 128 if nparts == -(-Nn // 128) else 32
         assert nparts == -(-Nn // width) and (width == 32 or algo != 14)
         c64 = C.double().cpu()
         p64 = part.double().cpu()

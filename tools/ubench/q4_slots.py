@@ -20,15 +20,29 @@ def kernel(name, pattern, per_iter=None, setup=None):
     a = Asm()
     # s[0:1] = kernarg, s2 = block id, v0 = thread id.  kernarg: out (8), src (8)
     a("s_load_dwordx4", S(4, 4), S(0, 2), 0)
+    a("s_load_dwordx2", S(8, 2), S(0, 2), 16)
     a("v_and_b32", V(1), 63, V(0))
     a("v_lshlrev_b32", V(2), 4, V(1))                 # lane * 16: LDS read address / DMA source offset
+    a("v_lshlrev_b32", V(67), 3, V(1))                # lane * 8
+    a("v_mul_u32_u24", V(90), 0x3039, V(0))           # LCG seed per thread
+    a("v_lshrrev_b32", V(68), 3, V(1))                # row lane >> 3 at a pitch of 6144 bytes, chunk lane & 7
+    a("v_mul_u32_u24", V(68), 6144, V(68))
+    a("v_and_b32", V(69), 7, V(1))
+    a("v_lshl_add_u32", V(68), V(69), 4, V(68))
     a("v_lshrrev_b32", V(3), 6, V(0))
     a("s_nop", 0)
     a("v_readfirstlane_b32", S(10), V(3))             # wave
     a("s_waitcnt", lgkmcnt=0)
     a("s_lshl_b32", S(11), S(10), 14)                 # this wave's 16 KiB of LDS
+    a("v_lshlrev_b32", V(66), 4, V(1))                # lane * 16
+    a("s_lshl_b32", S(19), S(2), 2)
+    a("s_add_u32", S(19), S(19), S(10))               # bid * 4 + wave
+    a("s_lshl_b32", S(19), S(19), 18)                 # 256 KiB of fresh destination per wave
+    a("s_add_u32", S(8), S(8), S(19))
+    a("s_addc_u32", S(9), S(9), 0)
     a("v_add_u32", V(2), S(11), V(2))
     a("s_mov_b32", S(12), 0)
+    a("s_mov_b32", S(26), 57344)
     for r in range(4, 64):
         a("v_mov_b32", V(r), 0)
     a("v_mov_b32", V(64), F(1.0))
@@ -67,7 +81,7 @@ def kernel(name, pattern, per_iter=None, setup=None):
     body = ['"s_mov_b64 s[0:1], %0\\n\\t"', '"s_mov_b32 s2, %1\\n\\t"', '"v_mov_b32 v0, %2\\n\\t"', a.c_string()]
     return ("extern \"C\" __global__ void __launch_bounds__(256, 1) %s(void* out, const void* src) {\n    asm volatile(\n%s\n        :\n"
             "        : \"s\"(__builtin_amdgcn_kernarg_segment_ptr()), \"s\"(blockIdx.x), \"v\"(threadIdx.x)\n        : %s);\n}\n"
-            % (name, "\n".join(body), ", ".join(clob)))
+            % (name, "\n".join(body), ", ".join(clob))).replace("(void* out, const void* src)", "(void* out, const void* src, void* dst)")
 
 
 def fma(a, n, base=0):
@@ -127,6 +141,70 @@ P("reads_barrier", lambda a, q: ds_read(a, q) if READS68(q) else None, lambda a:
 P("reads_salu30_barrier", lambda a, q: ds_read(a, q) if READS68(q) else None,
   lambda a: ([a("s_add_u32", S(20 + k % 4), S(20 + k % 4), 1) for k in range(30)], a("s_waitcnt", lgkmcnt=0), a("s_barrier")) and None)
 P("store_1of16", lambda a, q: a("global_store_dwordx4", V(2), V(72, 4), S(6, 2), offset=2048) if q % 16 == 5 else None, lambda a: a("s_waitcnt", vmcnt=8))
+def st_fresh(a, n, width=4, only_wave0=False, k=0):
+    """n stores of 16 (8) bytes per lane to lines never written before; s[8:9] advances"""
+    L = None
+    if only_wave0:
+        L = a.newlabel("SK")
+        a("s_cmp_lg_u32", S(10), 0)
+        a("s_cbranch_scc1", L)
+    for _ in range(n):
+        if width == 4:
+            a("global_store_dwordx4", V(66), V(72, 4), S(8, 2))
+            a("s_add_u32", S(8), S(8), 1024)
+        else:
+            a("global_store_dwordx2", V(67), V(72, 2), S(8, 2))
+            a("s_add_u32", S(8), S(8), 512)
+        a("s_addc_u32", S(9), S(9), 0)
+    if L:
+        a.label(L)
+
+
+P("st_fresh_2of32", lambda a, q: st_fresh(a, 1) if q % 16 == 5 else None, lambda a: a("s_waitcnt", vmcnt=8))
+P("st_fresh_2of32_wave0", lambda a, q: st_fresh(a, 1, only_wave0=True) if q % 16 == 5 else None, lambda a: a("s_waitcnt", vmcnt=8))
+P("st_fresh_4of32_x2", lambda a, q: st_fresh(a, 1, width=2) if q % 8 == 5 else None, lambda a: a("s_waitcnt", vmcnt=8))
+P("st_fresh_1of32", lambda a, q: st_fresh(a, 1) if q == 5 else None, lambda a: a("s_waitcnt", vmcnt=8))
+P("st_fresh_4of32", lambda a, q: st_fresh(a, 1) if q % 8 == 5 else None, lambda a: a("s_waitcnt", vmcnt=8))
+P("st_fresh_burst4", lambda a, q: st_fresh(a, 4) if q == 5 else None, lambda a: a("s_waitcnt", vmcnt=8))
+P("st_fresh_2of32_nowait", lambda a, q: st_fresh(a, 1) if q % 16 == 5 else None)
+def st_rows(a, n):
+    """n stores of 8 rows x 128 bytes at a row pitch of 6144 bytes (the GEMM's epilogue), fresh lines"""
+    for _ in range(n):
+        a("global_store_dwordx4", V(68), V(72, 4), S(8, 2))
+        a("s_add_u32", S(8), S(8), 128)
+        a("s_addc_u32", S(9), S(9), 0)
+
+
+P("st_rows_2of32", lambda a, q: st_rows(a, 1) if q % 16 == 5 else None, lambda a: a("s_waitcnt", vmcnt=8))
+P("st_rows_2of32_dma_reads", lambda a, q: (dma(a, q) if q % 8 in (1, 3, 6) else None, ds_read(a, q) if READS68(q) else None, st_rows(a, 1) if q % 16 == 5 else None) and None,
+  lambda a: a("s_waitcnt", vmcnt=12))
+P("st_fresh_2of32_dma_reads", lambda a, q: (dma(a, q) if q % 8 in (1, 3, 6) else None, ds_read(a, q) if READS68(q) else None, st_fresh(a, 1) if q % 16 == 5 else None) and None,
+  lambda a: a("s_waitcnt", vmcnt=12))
+P("st_rows_burst4_every2", lambda a, q: st_rows(a, 4) if q == 5 else None, lambda a: a("s_waitcnt", vmcnt=12))
+def gather(a, q, n=1, valu=0):
+    """n ds_read_b64 at pseudo-random 8-byte slots of an 8 KiB table (LDS offset 56 KiB) + valu dependent-free VALU"""
+    for k in range(n):
+        a("v_mul_u32_u24", V(90), 0x9E3B, V(90))                      # per-lane LCG
+        a("v_add_u32", V(90), 0x7F4A7, V(90))
+        a("v_bfe_u32", V(91), V(90), 8, 10)
+        a("v_lshl_add_u32", V(91), V(91), 3, S(26))
+        a("ds_read_b64", V(92 + 2 * ((q * n + k) % 4), 2), V(91))
+    fma(a, valu, q * valu)
+
+
+P("gather1", lambda a, q: gather(a, q, 1), lambda a: a("s_waitcnt", lgkmcnt=0))
+P("gather1_fma2", lambda a, q: gather(a, q, 1, 2), lambda a: a("s_waitcnt", lgkmcnt=0))
+P("gather1_reads_dma", lambda a, q: (dma(a, q) if q % 8 in (1, 3, 6) else None, ds_read(a, q) if READS68(q) else None, gather(a, q, 1)) and None,
+  lambda a: a("s_waitcnt", vmcnt=12, lgkmcnt=0))
+P("gather1_reads_dma_fma1", lambda a, q: (dma(a, q) if q % 8 in (1, 3, 6) else None, ds_read(a, q) if READS68(q) else None, gather(a, q, 1, 1)) and None,
+  lambda a: a("s_waitcnt", vmcnt=12, lgkmcnt=0))
+P("reads_dma_fma4", lambda a, q: (dma(a, q) if q % 8 in (1, 3, 6) else None, ds_read(a, q) if READS68(q) else None, fma(a, 4, 4 * q)) and None,
+  lambda a: a("s_waitcnt", vmcnt=12, lgkmcnt=0))
+P("reads_dma_fma5", lambda a, q: (dma(a, q) if q % 8 in (1, 3, 6) else None, ds_read(a, q) if READS68(q) else None, fma(a, 5, 5 * q)) and None,
+  lambda a: a("s_waitcnt", vmcnt=12, lgkmcnt=0))
+P("reads_dma_fma7", lambda a, q: (dma(a, q) if q % 8 in (1, 3, 6) else None, ds_read(a, q) if READS68(q) else None, fma(a, 7, 7 * q)) and None,
+  lambda a: a("s_waitcnt", vmcnt=12, lgkmcnt=0))
+P("st_only_nomfma_ref", lambda a, q: None)
 P("cvt_perm", lambda a, q: (a("v_cvt_pk_bf16_f32", V(80 + q % 4), V(72), V(73)), a("s_nop", 1), a("v_permlane32_swap_b32", V(80 + q % 4), V(84 + q % 4))) and None)
 P("waitcnt4", lambda a, q: [a("s_waitcnt", lgkmcnt=15) for k in range(4)] and None)
 P("nop4", lambda a, q: [a("s_nop", 0) for k in range(4)] and None)
@@ -142,14 +220,15 @@ def main(path):
     out.append("};\n")
     out.append("""int main() {
     setvbuf(stdout, 0, _IONBF, 0);
-    unsigned* out; char* src;
+    unsigned* out; char* src; char* dst;
+    hipMalloc(&dst, (size_t)1024 << 18);
     hipMalloc(&out, 256 * 4 * 4);
     hipMalloc(&src, 1 << 20);
     hipMemset(src, 0, 1 << 20);
     std::vector<unsigned> h(1024);
     for (const K& k : ks) {
         hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        void* args[] = {&out, &src};
+        void* args[] = {&out, &src, &dst};
         for (int rep = 0; rep < 2; ++rep) hipLaunchKernel(k.fn, dim3(256), dim3(256), args, 65536, 0);
         if (hipDeviceSynchronize() != hipSuccess) { printf("%%s: launch failed\\n", k.name); return 1; }
         hipMemcpy(h.data(), out, 4096, hipMemcpyDeviceToHost);
