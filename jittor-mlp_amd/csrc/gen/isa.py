@@ -906,8 +906,10 @@ def lint(asm, mfma_gap=16, verbose=False):
                 problems.append((k, "MFMA operand written by an MFMA %d states before" % dist))
             if r == ("m0", 0) and i.op == "global_load_lds_dwordx4" and dist < 1:
                 problems.append((k, "LDS-DMA straight after the m0 write"))
-            if i.op.endswith("_dpp") and kind == "valu" and dist < 2 and r in _regs_of(i.args[1]):
+            if i.op.endswith("_dpp") and kind in ("valu", "dot") and dist < 2 and r in _regs_of(i.args[1]):
                 problems.append((k, "DPP source %s%d written by a VALU instruction %d states before (< 2)" % (r[0], r[1], dist)))
+            if kind == "dot" and is_valu and not i.op.startswith("v_dot2c") and dist < 3:
+                problems.append((k, "%s reads the dot-product result %s%d %d states after it was written (< 3)" % (i.op, r[0], r[1], dist)))
             if i.op == "v_permlane32_swap_b32" and kind == "valu" and dist < 2:
                 problems.append((k, "v_permlane32_swap %d states after a VALU write of %s%d (< 2)" % (dist, r[0], r[1])))
             if kind == "valu_sgpr" and (i.op.startswith("global_") or i.op.startswith("s_load")) and dist < 5:
@@ -927,6 +929,8 @@ def lint(asm, mfma_gap=16, verbose=False):
                 last_def[r] = (pos, "mfma")
             elif i.op == "v_readfirstlane_b32":
                 last_def[r] = (pos, "valu_sgpr")
+            elif i.op.startswith("v_dot2c"):
+                last_def[r] = (pos, "dot")
             elif is_valu:
                 last_def[r] = (pos, "valu")
             else:

@@ -394,8 +394,9 @@ class Q4:
                 for c in range(4):
                     E(dot, sp[0], o[c], self.v_ones)
                     E(dot, sp[1], o[c], o[c])
-                for mod in (dict(quad_perm="[1,0,3,2]"), dict(quad_perm="[2,3,0,1]"), dict(row_half_mirror=True)):
-                    E("s_nop", 0)
+                for n_, mod in enumerate((dict(quad_perm="[1,0,3,2]"), dict(quad_perm="[2,3,0,1]"), dict(row_half_mirror=True))):
+                    # wait states: a VALU result is read through DPP after >= 2, a dot-product result by another opcode after >= 3
+                    E("s_nop", 1 if n_ == 0 else 0)
                     E("v_add_f32_dpp", sp[0], sp[0], sp[0], **mod, row_mask="0xf", bank_mask="0xf")
                     E("v_add_f32_dpp", sp[1], sp[1], sp[1], **mod, row_mask="0xf", bank_mask="0xf")
                 # one pair per row: the lanes with (lane & 7) == 0
