@@ -1882,15 +1882,23 @@ static int gemm_prepare(const mlpk_gemm_desc* d, GemmArgs& a, int& algo, bool& t
     if (stats && !p8_stats_ok) p8_ok = false;
     if (algo == 0) {
         // round 3: the generated one-wave-per-SIMD tile where it is ahead (MLPK_GEMM_Q4=0 switches it off for A/B runs; 2 = wherever
-        // it applies).  Measured at M = 50176 (profiles/r03_q4_probe_v3.txt): ahead of the persistent 256 x 256 tile up to K = 1024
-        // (channel fc1 +7 %, Mixer-L fc1 +5 %, gMLP proj1 +5 %), behind it at K >= 3072 (its LDS-DMA runs two 48-KiB slabs ahead:
-        // HBM-latency bound on long-K streams); 20-28 % ahead of the s3 tile on the N = 384 / 1152 shapes the persistent tile cannot
-        // take.  Its pipeline spends one extra (draining) block per workgroup: only for grids of several tiles per CU.
+        // it applies).  Rule from the per-shape A/B of every GEMM call of the bs=256 models (profiles/r03_gemm_shapes_q4_ab_v1.txt,
+        // r03_q4_probe_v3.txt):
+        //  * where the persistent 256 x 256 tile cannot run (N % 256 != 0: the N = 384 / 1152 / 640 / 128 shapes of ViP, S2-MLP, Swin-,
+        //    Hire-, CycleMLP, ResMLP) it replaces the s3 tile: 0.69-0.94 of its time on every measured shape;
+        //  * against the persistent tile it is ahead on the epilogue-heavy fc1 shapes (GELU, K = 768 / 1024, N >= 3072: 0.93-0.95) and
+        //    at N = 768 with short K (0.80-0.87: three column tiles fill the persistent tile's rounds badly), behind elsewhere (short K
+        //    with many column tiles 1.05-1.10; K >= 3072 1.10: its LDS-DMA runs two 48-KiB slabs ahead, HBM-latency bound on long K);
+        //  * its pipeline spends one extra (draining) block per workgroup: only grids of several tiles per CU.
         static const int q4_mode = getenv("MLPK_GEMM_Q4") ? atoi(getenv("MLPK_GEMM_Q4")) : 1;
         Q4Call qc;
         if (q4_mode && q4_call_of(a, d->dtype, trans, qc)) {
             const long long tiles = (long long)(d->M / 256) * (d->N / 128);
-            if (q4_mode >= 2 || (tiles >= 512 && (!p8_ok || d->K <= 1280))) algo = 15;
+            bool take = false;
+            if (!p8_ok) take = tiles >= 512;
+            else take = (d->act == MLPK_ACT_GELU && d->K >= 640 && d->K <= 1280 && d->N >= 3072 && tiles >= 2048) ||
+                        (d->N == 768 && d->K <= 512 && tiles >= 1024);
+            if (q4_mode >= 2 || take) algo = 15;
         }
     }
     if (algo == 0) algo = auto_algo(d->M, d->N, d->K, epc, glds_ok, p8_ok, stats);

@@ -159,6 +159,9 @@ def gemm(A, B, C, M, Nn, K, *, lda=None, ldb=None, ldc=None, bias=None, act=N.AC
     stats_finalize_planar, or None when the descriptor cannot deliver them (fp32, unaligned rows) and the caller runs row_stats."""
     if tag is not None and algo == 0:
         algo = GEMM_ALGO.get(tag, 0)
+    if GEMM_LOG is not None:                             # tuning: the distinct GEMM calls of a forward (tools/gemm_shapes.py)
+        GEMM_LOG.add((str(A.dtype), M, Nn, K, int(act), int(res), ln is not None, part is not None, cscale is not None or cshift is not None,
+                      rscale is not None, int(out_mode), bias is not None))
     timed = TIMER is not None and tag is not None
     if timed:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -195,6 +198,7 @@ def gemm(A, B, C, M, Nn, K, *, lda=None, ldb=None, ldc=None, bias=None, act=N.AC
     return out
 
 
+GEMM_LOG = None
 CHANNEL_CHUNKS = int(os.environ.get("MLPK_CHANNEL_CHUNKS", "0"))      # 0 = by size (below); tuning override
 
 
