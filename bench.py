@@ -45,8 +45,8 @@ MODELS = {
     "sparsemlp_t": ("SparseMLP", dict(), 16.231),      # SURVEY.md 8(f) rank 2; 2*MAC of its GEMMs/convs counted by hand
     "hiremlp_s": ("HireMLP", dict(), 9.742),           # SURVEY.md 8(f) rank 2; counted by hand (padded region rows included)
     "msmlp_t": ("MS_MLP", dict(), 5.990),              # SURVEY.md 8(f) rank 3; counted by hand
-    "swinmlp_t": ("SwinMLP", dict(), 6.110),
-    "cyclemlp_b1": ("CycleMLP_B1", dict(), 4.2),       # SURVEY.md 8(f) rank 3; 2 x the 2.1 GMACs the CycleMLP paper quotes for B1           # SURVEY.md 8(f) rank 3; counted by hand (useful flops of the per-head window mixes)
+    "swinmlp_t": ("SwinMLP", dict(), 6.110),           # SURVEY.md 8(f) rank 3; counted by hand (useful flops of the per-head window mixes)
+    "cyclemlp_b1": ("CycleMLP_B1", dict(), 4.2),       # SURVEY.md 8(f) rank 3; 2 x the 2.1 GMACs the CycleMLP paper quotes for B1
 }
 PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16/f16 MFMA (MI355X_MICROARCH.md); f32 MFMA 157.3
 DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
@@ -55,7 +55,7 @@ DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
 FAMILY = {"MLPMixerForImageClassification": "mixer", "gMLPForImageClassification": "gmlp",
           "ResMLPForImageClassification": "resmlp", "ViP": "vip", "S2MLPv2": "s2mlpv2", "AS_MLP": "asmlp",
           "ConvMixer": "convmixer", "SparseMLP": "sparsemlp", "HireMLP": "hiremlp", "MS_MLP": "msmlp", "SwinMLP": "swinmlp",
-          "CycleMLP": "cyclemlp"}
+          "CycleMLP": "cyclemlp", "CycleMLP_B1": "cyclemlp"}
 
 
 def _time_oracle(pkg, ctor_name, kwargs, bs, budget_s):
@@ -107,6 +107,20 @@ def run_cpu_baseline(model_name, kwargs, ctor_name, pkg):
     return out
 
 
+GEMM_SOURCES = ("jittor-mlp_amd/csrc/mlpk_gemm.hip", "jittor-mlp_amd/csrc/mlpk_gemm_q4.hip", "jittor-mlp_amd/csrc/gen/q4gen.py",
+                "jittor-mlp_amd/csrc/gen/isa.py", "jittor-mlp_amd/csrc/mlpk_common.h")
+
+
+def gemm_source_digest():
+    """sha256 over the sources of the channel-MLP GEMM kernels (hand-written tiles + the q4 generator)"""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in GEMM_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def measured_traffic(args):
     """HBM-side bytes per launch of the dominant kernel from the PMC passes of tools/pmc_bench.sh on this same
     command.  The JSON is stamped with the sha256 of the GEMM source it was measured on: a stale file (kernel
@@ -120,11 +134,49 @@ def measured_traffic(args):
         return None, None
     with open(files[-1]) as f:
         t = json.load(f)
-    with open(os.path.join(ROOT, "jittor-mlp_amd", "csrc", "mlpk_gemm.hip"), "rb") as f:
-        sha = hashlib.sha256(f.read()).hexdigest()
-    if t.get("gemm_source_sha256") != sha:
-        return None, "stale: %s was measured on another mlpk_gemm.hip" % os.path.basename(files[-1])
+    if t.get("gemm_source_sha256") != gemm_source_digest():
+        return None, "stale: %s was measured on other GEMM sources" % os.path.basename(files[-1])
     return t.get("channel_mlp_gemm_bytes_per_launch"), "%s (git %s)" % (os.path.basename(files[-1]), t.get("git", "?"))
+
+
+def cpu_stub(args, world, rank):
+    """The N-rank protocol of this file without a GPU: gloo, every rank "computes" deterministic logits for its shard, the
+    single all-gather, barrier-bracketed timing with the max over ranks, one JSON line from rank 0."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+    parallel = importlib.import_module("jittor-mlp_amd.parallel")
+
+    class Stub(torch.nn.Module):
+        def forward(self, x):
+            return x.flatten(1)[:, :1000].float() + float(rank)
+    runner = parallel.DataParallelForward(Stub(), world)
+    x = torch.zeros((args.batch, 3, 24, 24))
+    for _ in range(args.warmup):
+        out = runner(x)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = runner(x)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert out.shape == (args.batch * world, 1000)
+    # shard r of the gathered logits carries + r: the gather kept the rank order
+    assert all(abs(float(out[r * args.batch, 0] - out[0, 0]) - r) < 1e-6 for r in range(world))
+    if rank == 0:
+        print(json.dumps({"metric": "images/sec fwd (cpu stub)", "value": round(args.batch * world * args.steps / elapsed, 1), "unit": "images/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+                          "config": {"workload": "launcher self-test, no GPU", "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                                     "collective": "all_gather(logits) over gloo" if world > 1 else "none"}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -141,16 +193,29 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm; gloo only for "
                     "exercising the multi-process path on a single-GPU box together with --share-device)")
     ap.add_argument("--share-device", action="store_true", help="testing only: every rank uses cuda:0")
+    ap.add_argument("--cpu-stub", action="store_true", help="testing only (tests/test_parallel_gloo.py): no GPU, gloo, a stub forward "
+                    "-- exercises the launcher, the barrier / max-over-ranks timing and the logits gather")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                             "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # `python bench.py --gpus N` on its own: become the launcher (one rank per GPU, rendezvous on 127.0.0.1) -- the same
+            # command line the driver would have started through torch.distributed.run
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            sys.stdout.flush()
+            os.execv(sys.executable, cmd)
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if args.cpu_stub:
+        return cpu_stub(args, world, rank)
     if args.share_device:
         local_rank = 0
         if args.backend == "nccl" and world > 1:
@@ -244,20 +309,22 @@ def main():
                 peak = PEAK_BF16_TFLOPS if args.dtype != "fp32" else 157.3
                 ach = flops / secs / 1e12
                 traffic, traffic_src = measured_traffic(args)
-                line["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_p8_kernel (channel-MLP fc1+fc2)", "achieved": round(ach, 1),
+                line["roofline"] = {"bound": "mfma", "kernel": "channel-MLP fc1 (q4_bf16_gl_f12, generated) + fc2 (gemm_nt_p8_kernel)", "achieved": round(ach, 1),
                                     "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                                     "flops_per_launch": flops / n_launch, "avg_launch_ms": round(secs / n_launch * 1e3, 4),
                                     "launches_timed": n_launch, "traffic_source": traffic_src,
-                                    # a "launch" here is one mlpk_gemm_nt CALL (236.8 GFLOP): the persistent tile covers M with up
-                                    # to three tile heights, each its own kernel launch (NI = 4 / 3 / 1 at M = 50176), so a
-                                    # rocprofv3 --stats summary lists them as separate rows; per call the row averages add up as
-                                    # sum(calls_i x avg_i) / number of calls (profiles/r02_mixer_b16_kernel_stats_v4.csv:
-                                    # (100 x 164 + 52 x 133 + 48 x 18) us / 100 calls = 242 us under the profiler)
-                                    "launch_means": "one mlpk_gemm_nt call = up to 3 kernel launches (tile heights)"}
+                                    # a "launch" here is one mlpk_gemm_nt CALL (236.8 GFLOP).  fc1 is ONE launch of the generated q4
+                                    # kernel; fc2 runs the persistent 256 x 256 tile, which covers M with up to three tile heights,
+                                    # each its own kernel launch (NI = 4 / 3 at M = 50176): a rocprofv3 --stats summary lists
+                                    # them as separate rows, per call the row averages add up as sum(calls_i x avg_i) / calls
+                                    "launch_means": "one mlpk_gemm_nt call: fc1 = 1 launch (q4), fc2 = up to 3 launches (p8 tile heights)"}
             line["kernels"] = {t: {"avg_ms": round(v["avg_ms"], 4), "tflops": round(v["flops_per_launch"] / v["avg_ms"] / 1e9, 1),
                                    "launches": v["launches"]} for t, v in summ.items()}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = run_cpu_baseline(args.model, kwargs, ctor_name, pkg)
+            try:
+                line["cpu_baseline"] = run_cpu_baseline(args.model, kwargs, ctor_name, pkg)
+            except Exception as e:      # a baseline failure must not discard the measured GPU line
+                line["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

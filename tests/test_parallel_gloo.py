@@ -74,3 +74,23 @@ def test_shard_batch_contract():
         parallel.shard_batch(x, 0, 3)
     one = parallel.DataParallelForward(lambda t: t * 2, world=1)
     assert torch.equal(one(x), x * 2)
+
+
+def test_bench_launches_itself_for_n_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must become the launcher (one rank per GPU, rendezvous on 127.0.0.1)
+    and print ONE JSON line with n_gpus = 2: driven here without a GPU through the stub forward (--cpu-stub: gloo, the same barrier /
+    max-over-ranks timing and logits gather as the real path)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4", "--cpu-stub"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["global_batch"] == 8 and d["scaling"] == "weak"
+    # and the one-process form still runs on its own
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "4", "--cpu-stub"],
+                        capture_output=True, text=True, timeout=300, env=env)
+    assert r1.returncode == 0 and json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1

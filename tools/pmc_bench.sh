@@ -28,19 +28,20 @@ with open(out + "/summary.txt", "w") as fo:
     fo.write("# rocprofv3 --pmc <group> --kernel-trace (separate passes) on: python bench.py --steps 3 --warmup 1 (Mixer-B/16, bs=256, bf16)\n")
     fo.write("# per-launch means; FETCH_SIZE/WRITE_SIZE in KiB as reported (gfx950: wide coalesced reads are reported at HALF their bytes -> x2, MI355X_MICROARCH.md)\n")
     for (short, c), (n, s) in sorted(agg.items(), key=lambda kv: (kv[0][1], kv[0][0])):
-        if not any(t in short for t in ("gemm_nt", "token_mlp", "row_stats", "norm_apply", "layernorm_transpose", "stats_finalize")):
+        if not any(t in short for t in ("gemm_nt", "q4_", "token_mlp", "row_stats", "norm_apply", "layernorm_transpose", "stats_finalize")):
             continue
         fo.write("%-40s %-30s launches=%d mean=%.5g\n" % (short, c, n, s / n))
 print(open(out + "/summary.txt").read())
 # traffic of the dominant kernel for bench.py's roofline.traffic, stamped with the source it was measured on.
 # One mlpk_gemm_nt call of the persistent tile is up to three launches (one per tile height, p8_plan): the figure is per CALL =
 # all bytes of all gemm_nt_p8 launches / the calls that made them (4 forwards x (24 channel-MLP GEMMs + the patch embedding)).
-import hashlib, json
+import hashlib, json, sys
 root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sys.path.insert(0, root)
 full = collections.defaultdict(lambda: [0, 0.0])
 for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "gemm_nt_p8" in r["Kernel_Name"] and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+        if ("gemm_nt_p8" in r["Kernel_Name"] or r["Kernel_Name"].startswith("q4_")) and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
             k = (r["Kernel_Name"], r["Counter_Name"])
             full[k][0] += 1
             full[k][1] += float(r["Counter_Value"])
@@ -52,8 +53,8 @@ if full:
     tj = {"channel_mlp_gemm_bytes_per_launch": (2.0 * fetch + write) * 1024.0 / calls,
           "per_instantiation_kib_per_launch": {k[0][-40:] + " " + k[1]: [v[0], v[1] / v[0]] for k, v in sorted(full.items())},
           "gemm_calls": calls, "git": head,
-          "gemm_source_sha256": hashlib.sha256(open(os.path.join(root, "jittor-mlp_amd/csrc/mlpk_gemm.hip"), "rb").read()).hexdigest(),
-          "note": "bytes per mlpk_gemm_nt CALL of the persistent tile in bench.py --steps 3 --warmup 1: all launches of gemm_nt_p8_kernel (one per tile height) summed, (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md), divided by 4 forwards x 25 calls (24 channel-MLP GEMMs + the patch embedding, which has fc2's shape)"}
+          "gemm_source_sha256": __import__("bench").gemm_source_digest(),
+          "note": "bytes per mlpk_gemm_nt CALL of the channel-MLP GEMMs in bench.py --steps 3 --warmup 1: all launches of the generated q4 kernel (fc1) and of gemm_nt_p8_kernel (fc2 and the patch embedding; one launch per tile height) summed, (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md), divided by 4 forwards x 25 calls (24 channel-MLP GEMMs + the patch embedding, which has fc2's shape)"}
     json.dump(tj, open(out + "/traffic.json", "w"))
     print(json.dumps(tj))
 PY

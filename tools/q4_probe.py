@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 pkg = importlib.import_module("jittor-mlp_amd")
 E, N = pkg.engine, pkg._native
 dev = "cuda:0"
-what = sys.argv[1] if len(sys.argv) > 1 else "all"
+what = sys.argv[1] if len(sys.argv) > 1 and __name__ == "__main__" else "none"
 
 
 def operands(M, Nn, K, dt, seed=0):
