@@ -899,6 +899,12 @@ __global__ void __launch_bounds__(512, 1) token_gemm_kernel(const TokenGemmArgs 
     load_x(blockIdx.x, lane_now());
     issue_w(0, 0, lane);                                   // group 0 of the first tile
     __syncthreads();
+    // W ring stage of the group multiplied in the current iteration.  It must run ON across tiles: the last MFMA iteration of a
+    // tile prefetches group 0 of the next tile into the OTHER stage, and with an odd number of groups (S = 196 -> 7) that is stage 1
+    // -- indexing the ring by the group number read stage 0 (still the previous tile's last group) for the first 32 output tokens of
+    // every tile after a workgroup's first (round-3 finding of test_batch_256_rows_match_small_batch: gMLP-S at 256 images 5e-2 off;
+    // ResMLP's layer scale of 1e-4 hid the same fault)
+    unsigned wst = 0;
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         // reader geometry of this tile: item = (token slot tid >> 5 (+16), channels (tid & 31) * 8 .. + 7 of the tile's 256)
@@ -961,9 +967,10 @@ __global__ void __launch_bounds__(512, 1) token_gemm_kernel(const TokenGemmArgs 
             }
             if (g < G) {
                 // next W group: g + 1 of this tile, or group 0 again for the next tile (the weights are the same for every tile)
-                issue_w(g + 1 < G ? g + 1 : 0, (unsigned)((g + 1) & 1), ln);
+                issue_w(g + 1 < G ? g + 1 : 0, wst ^ 1u, ln);
                 request_r(g);
-                const char* r1 = smem + T3_R1 + (g & 1) * TM_STAGE;
+                const char* r1 = smem + T3_R1 + wst * TM_STAGE;
+                wst ^= 1u;
                 const int f_rd = frow * 64 + ((fg ^ ((frow & 8) >> 2)) << 4);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)

@@ -699,10 +699,14 @@ def test_layernorm_transpose_one_pass(dtype):
 def test_token_gemm(dtype):
     """mlpk_token_gemm: out[b,t,c] = R[b,t,c] (+|*) rscale[c] * (sum_s W[t,s] xt[b*C+c, s] + bias[t]) -- gMLP's gate (g_mlp.py:17-22,
     R = u inside a wider tensor, MUL) and ResMLP's cross-patch sublayer (res_mlp.py:52-55, in place, ADD, gamma_1) -- against fp64,
-    incl. ragged tokens, tiles spanning images, a partial last tile, and the same operation through mlpk_gemm_nt's transposed epilogue."""
+    incl. ragged tokens, tiles spanning images, a partial last tile, and the same operation through mlpk_gemm_nt's transposed epilogue.
+    The last two cases have more 256-row tiles than the chip has CUs: workgroups then walk SEVERAL tiles, and the weight ring must
+    run on across them -- with an odd number of 32-token groups (196 tokens -> 7) the round-2 kernel multiplied the first group of every
+    later tile by the wrong weights (found at bs = 256 by test_batch_256_rows_match_small_batch, invisible at the golden batch sizes)."""
     pkg = load_pkg()
     E, N = pkg.engine, pkg._native
-    for ci, (B_, C, S, mode) in enumerate([(2, 256, 196, "mul"), (3, 384, 196, "add"), (5, 40, 49, "add"), (1, 64, 32, "none"), (2, 1536, 50, "mul"), (4, 96, 224, "add")]):
+    for ci, (B_, C, S, mode) in enumerate([(2, 256, 196, "mul"), (3, 384, 196, "add"), (5, 40, 49, "add"), (1, 64, 32, "none"), (2, 1536, 50, "mul"), (4, 96, 224, "add"),
+                                           (90, 768, 196, "mul"), (150, 512, 100, "add")]):
         sp = E.round_up(S, 32)
         xn = rnd((B_, S, C), dtype, 2000 + ci)
         xt = torch.zeros((B_ * C, sp), dtype=dtype, device=dev())
