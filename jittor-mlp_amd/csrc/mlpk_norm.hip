@@ -785,17 +785,19 @@ __global__ void __launch_bounds__(256) stats_finalize_planar_kernel(const float*
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= rows) return;
     const f32x2* pp = reinterpret_cast<const f32x2*>(part) + r;
-    float s1 = 0.f, s2 = 0.f;
+    // the planes are combined in fp64: with rows whose mean is large against their spread (deep residual streams) the fp32 form
+    // S2 / n - mean^2 loses the variance to cancellation; what remains is the rounding of the per-plane fp32 sums themselves
+    double s1 = 0.0, s2 = 0.0;
     for (int q = 0; q < nplanes; ++q) {
         const f32x2 v = pp[(int64_t)q * plane_stride];
-        s1 += v.x;
-        s2 += v.y;
+        s1 += (double)v.x;
+        s2 += (double)v.y;
     }
-    const float mu = s1 * inv_count;
-    float var = s2 * inv_count - mu * mu;
-    var = var > 0.f ? var : 0.f;
-    mean[r] = mu;
-    rstd[r] = 1.0f / __builtin_sqrtf(var + eps);
+    const double mu = s1 * (double)inv_count;
+    double var = s2 * (double)inv_count - mu * mu;
+    var = var > 0.0 ? var : 0.0;
+    mean[r] = (float)mu;
+    rstd[r] = (float)(1.0 / __builtin_sqrt(var + (double)eps));
 }
 
 // group > 1 (per-sample GroupNorm(1,C) statistics from per-pixel-row pairs): one workgroup per statistic, fp64 for the combine

@@ -439,7 +439,13 @@ class Workspace:
             self.t[name] = t
         elif tuple(t.shape) != tuple(shape):
             # the same role at another size (a model without a fixed image size called at a second resolution with
-            # a workspace key that did not separate them): a fresh zero-initialised buffer, never a reinterpretation
+            # a workspace key that did not separate them): a fresh zero-initialised buffer, never a reinterpretation.
+            # Said once per workspace: two roles sharing one name would land here on every call and keep re-allocating.
+            if not self.t.get(("warned", "resize")):
+                import warnings
+                warnings.warn("workspace buffer %r requested as %s after %s: re-allocated (workspace keys should separate these)"
+                              % (name, tuple(shape), tuple(t.shape)))
+                self.t[("warned", "resize")] = True
             t = torch.full(shape, fill, dtype=dtype or self.dtype, device=self.device)
             self.t[name] = t
         return t

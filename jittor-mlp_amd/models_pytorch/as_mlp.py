@@ -65,6 +65,42 @@ class AxialShift(Holder):
     def extra_repr(self):
         return f'dim={self.dim}, shift_size={self.shift_size}'
 
+    def forward(self, x):
+        """as_mlp.py:55-95 on (B, C, H, W) like the reference's: conv1 -> GroupNorm -> GELU -> the two axial shifts -> conv2_1 /
+        conv2_2 (+ GELU) -> sum -> GroupNorm -> conv3.  Channel-last inside (the 1x1 convolutions are the NT GEMM, the shifts
+        mlpk_shift_nhwc); the two layout changes of a lone call are torch permutes -- inside AS_MLP the whole network stays
+        channel-last and the block additionally folds the norms into the GEMMs."""
+        E.require_gpu(x, "AxialShift.forward")
+        if x.dim() != 4 or x.shape[1] != self.dim:
+            raise ValueError("expected (B, %d, H, W)" % self.dim)
+        from .common import standalone_space
+        B, C, H, W = x.shape
+        rows, HW = B * H * W, H * W
+        ws = standalone_space(x)
+        dev, dt = x.device, x.dtype
+
+        def conv(c, src, dst, **kw):
+            E.gemm(src, E.pack_matrix(c.weight, dt, dev), dst, rows, C, C, bias=E.f32(c.bias, dev) if c.bias is not None else None, **kw)
+
+        def gn(t, norm, act=N.ACT_NONE):
+            g, b = _gn_params(norm, dev)
+            mean, rstd = ws.get("gn.mean", (B,), torch.float32), ws.get("gn.rstd", (B,), torch.float32)
+            E.row_stats(t, B, HW * C, HW * C, mean, rstd)
+            E.norm_apply(t, rows, C, C, mean=mean, rstd=rstd, gamma=g, beta=b, act=act, stat_group=HW, out_rm=t, ld_rm=C)
+        with E.on_device(x):
+            cur = x.permute(0, 2, 3, 1).contiguous().view(rows, C)
+            t0, t1, t2 = ws.get("t0", (rows, C)), ws.get("t1", (rows, C)), ws.get("t2", (rows, C))
+            conv(self.conv1, cur, t1)
+            gn(t1, self.norm1, act=N.ACT_GELU)
+            E.shift_nhwc(t1, t0, B, H, W, C, self.shift_size, 3)
+            conv(self.conv2_1, t0, t2, act=N.ACT_GELU)
+            E.shift_nhwc(t1, t0, B, H, W, C, self.shift_size, 2)
+            conv(self.conv2_2, t0, t2, act=N.ACT_GELU, R=t2, res=N.RES_ADD)
+            gn(t2, self.norm2)
+            out = torch.empty((rows, C), dtype=dt, device=dev)
+            conv(self.conv3, t2, out)
+        return out.view(B, H, W, C).permute(0, 3, 1, 2).contiguous()
+
 
 class AxialShiftedBlock(Block):
     """as_mlp.py:118-147."""

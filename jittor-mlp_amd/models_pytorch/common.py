@@ -15,6 +15,31 @@ class Holder(nn.Module):
         raise NotImplementedError("%s only holds parameters; call the enclosing model" % type(self).__name__)
 
 
+def standalone_space(x):
+    """A workspace for ONE call of an inner module on its own (the sub-block boundary of the reference: g_mlp.py:17-22,
+    vip.py:24-57, s2_mlp_v2.py:15-69, as_mlp.py:55-95).  Not a hot path: weights are packed per call."""
+    E.require_gpu(x, "sub-module forward")
+    return E.Workspace(x.device, x.dtype)
+
+
+def split_attention_forward(mod, x_all):
+    """SplitAttention.forward of vip.py:47-57 / s2_mlp_v2.py:41-51 on x_all (b, 3, h, w, c): whole-image reduction, the two
+    bias-free Linears + GELU (fp32), softmax over the three branches, weighted sum -- mlpk_split_sum / mlpk_gemm_nt /
+    mlpk_split_softmax / mlpk_split_apply, nothing shifted (MLPK_SHIFT_NONE)."""
+    if x_all.dim() != 5 or x_all.shape[1] != 3 or mod.k != 3:
+        raise ValueError("expected x_all of shape (b, 3, h, w, c) and k = 3")
+    b, _, h, w, c = x_all.shape
+    ws = standalone_space(x_all)
+    with E.on_device(x_all):
+        xs = [x_all[:, i].contiguous().view(b * h * w, c) for i in range(3)]
+        m1 = E.pack_matrix(mod.mlp1.weight, torch.float32, x_all.device)
+        m2 = E.pack_matrix(mod.mlp2.weight, torch.float32, x_all.device)
+        bar = split_attention_weights(ws, xs[0], xs[1], xs[2], c, c, c, b, h, w, c, N.SHIFT_NONE, m1, m2)
+        out = torch.empty((b * h * w, c), dtype=x_all.dtype, device=x_all.device)
+        E.split_apply(xs[0], xs[1], xs[2], c, c, c, b, h, w, c, N.SHIFT_NONE, bar, out, c)
+    return out.view(b, h, w, c)
+
+
 class Block(Holder):
     """A parameter container that is one WHOLE block of a backbone (the unit the reference's nn.Sequential chains): callable on its
     own like the reference's, through the owning backbone's packed weights and kernels (`backbone._run_single(index, x)`)."""

@@ -47,49 +47,40 @@ class CycleFC(Holder):
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True):
         super().__init__()
-        if in_channels % groups != 0:
-            raise ValueError('in_channels must be divisible by groups')
-        if out_channels % groups != 0:
-            raise ValueError('out_channels must be divisible by groups')
-        if stride != 1:
-            raise ValueError('stride must be 1')
-        if padding != 0:
-            raise ValueError('padding must be 0')
-        self.in_channels = in_channels
-        self.out_channels = out_channels
-        self.kernel_size = kernel_size
-        self.stride = pair(stride)
-        self.padding = pair(padding)
-        self.dilation = pair(dilation)
-        self.groups = groups
+        # the reference's argument contract (cycle_mlp.py:72-79): same conditions, same exception type and message text, because
+        # callers match on them
+        for ok, what in ((in_channels % groups == 0, 'in_channels must be divisible by groups'),
+                         (out_channels % groups == 0, 'out_channels must be divisible by groups'),
+                         (stride == 1, 'stride must be 1'), (padding == 0, 'padding must be 0')):
+            if not ok:
+                raise ValueError(what)
+        self.in_channels, self.out_channels, self.kernel_size, self.groups = in_channels, out_channels, kernel_size, groups
+        self.stride, self.padding, self.dilation = pair(stride), pair(padding), pair(dilation)
+        # state_dict contract: `weight` (out, in / groups, 1, 1), optional `bias` (out), buffer `offset` (1, 2 in, 1, 1)
         self.weight = nn.Parameter(torch.empty(out_channels, in_channels // groups, 1, 1))
-        if bias:
-            self.bias = nn.Parameter(torch.empty(out_channels))
-        else:
-            self.register_parameter('bias', None)
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
         self.register_buffer('offset', self.gen_offset())
         self.reset_parameters()
 
     def reset_parameters(self):
+        """nn.Linear's default initialisation, which is what the reference applies (cycle_mlp.py:96-102)."""
+        fan_in = self.weight.shape[1] * self.weight.shape[2] * self.weight.shape[3]
         init.kaiming_uniform_(self.weight, a=math.sqrt(5))
         if self.bias is not None:
-            fan_in, _ = init._calculate_fan_in_and_fan_out(self.weight)
-            bound = 1 / math.sqrt(fan_in)
-            init.uniform_(self.bias, -bound, bound)
+            init.uniform_(self.bias, -1.0 / math.sqrt(fan_in), 1.0 / math.sqrt(fan_in))
 
     def gen_offset(self):
-        """(1, 2 * in_channels, 1, 1): (dy, dx) per input channel (cycle_mlp.py:104-120)."""
-        offset = torch.empty(1, self.in_channels * 2, 1, 1)
-        start_idx = (self.kernel_size[0] * self.kernel_size[1]) // 2
-        assert self.kernel_size[0] == 1 or self.kernel_size[1] == 1, self.kernel_size
-        for i in range(self.in_channels):
-            if self.kernel_size[0] == 1:
-                offset[0, 2 * i + 0, 0, 0] = 0
-                offset[0, 2 * i + 1, 0, 0] = (i + start_idx) % self.kernel_size[1] - (self.kernel_size[1] // 2)
-            else:
-                offset[0, 2 * i + 0, 0, 0] = (i + start_idx) % self.kernel_size[0] - (self.kernel_size[0] // 2)
-                offset[0, 2 * i + 1, 0, 0] = 0
-        return offset
+        """The (dy, dx) pair of every input channel as the (1, 2 * in_channels, 1, 1) tensor torchvision's deform_conv2d takes
+        (values as cycle_mlp.py:104-120 produces them): channel i is displaced by ((i + k // 2) mod k) - k // 2 pixels along the
+        one axis on which the kernel is longer than 1 (k its length there), and by 0 along the other."""
+        kh, kw = self.kernel_size
+        if kh != 1 and kw != 1:
+            raise AssertionError(self.kernel_size)
+        k = kw if kh == 1 else kh
+        step = (torch.arange(self.in_channels) + (kh * kw) // 2) % k - k // 2
+        off = torch.zeros(self.in_channels, 2)
+        off[:, 1 if kh == 1 else 0] = step.to(off.dtype)
+        return off.reshape(1, 2 * self.in_channels, 1, 1)
 
     def extra_repr(self):
         return '%d, %d, kernel_size=%s' % (self.in_channels, self.out_channels, (self.kernel_size,))

@@ -14,7 +14,7 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Block, Holder, adopt_blocks, embed_patches, finalize_stats, head_linear, layernorm_stats
+from .common import Block, Holder, adopt_blocks, embed_patches, finalize_stats, head_linear, layernorm_stats, standalone_space
 from .utils.tools import check_sizes, pair
 
 
@@ -26,6 +26,30 @@ class SpatialGatingUnit(Holder):
         self.norm = nn.LayerNorm(d_ffn)
         self.spatial_proj = nn.Conv1d(seq_len, seq_len, kernel_size=1)
         nn.init.constant_(self.spatial_proj.bias, 1.0)
+
+    def forward(self, x):
+        """g_mlp.py:17-22 on x (B, S, 2 F): u, v = chunk; v = spatial_proj(norm(v)); u * v.  The halves are read in place, the
+        LayerNorm output is written token-transposed, the spatial product runs as the NT GEMM whose epilogue stores through the
+        per-image transpose and multiplies by u (the kernels of the model's own block, unfused from proj1 / proj2)."""
+        if x.dim() != 3 or x.shape[2] % 2:
+            raise ValueError("expected (B, S, 2 * d_ffn) tokens")
+        B, S, F2 = x.shape
+        F = F2 // 2
+        rows = B * S
+        sp = E.round_up(S, 32)
+        ws = standalone_space(x)
+        with E.on_device(x):
+            h = x.contiguous().view(rows, F2)
+            v = h[:, F:]
+            vt = ws.get("vt", (B * F, sp))
+            mean, rstd = ws.get("m", (rows,), torch.float32), ws.get("r", (rows,), torch.float32)
+            E.row_stats(v, rows, F, F2, mean, rstd)
+            E.norm_apply(v, rows, F, F2, mean=mean, rstd=rstd, gamma=E.f32(self.norm.weight, x.device), beta=E.f32(self.norm.bias, x.device),
+                         out_tt=vt, S=S, ld_tt=sp)
+            out = torch.empty((rows, F), dtype=x.dtype, device=x.device)
+            E.gemm(vt, E.pack_matrix(self.spatial_proj.weight, x.dtype, x.device, kpad=32), out, B * F, S, sp, ldc=F,
+                   bias=E.f32(self.spatial_proj.bias, x.device), R=h, ldr=F2, res=N.RES_MUL, out_mode=N.OUT_TOKEN_T, t_rows=F, t_tokens=S)
+        return out.view(B, S, F)
 
 
 class gMLPBlock(Block):

@@ -4,6 +4,7 @@ Block (s2_mlp_v1.py:33-46): x <- x + Linear(Spatial_Shift(gelu(Linear(LN(x)))));
 Spatial_Shift (s2_mlp_v1.py:19-25) is spatial_shift1 of v2 applied to the full C-wide tensor; see
 s2_mlp_v2.py in this package for the two `shift_mode` semantics.
 """
+import torch
 from torch import nn
 
 from .. import _native as N
@@ -21,7 +22,21 @@ class PreNormResidual(Holder):
 
 
 class Spatial_Shift(Holder):
-    """Parameter-free (s2_mlp_v1.py:15-25); applied as a gather by mlpk_s2_shift."""
+    """Parameter-free (s2_mlp_v1.py:15-25); applied as a gather by mlpk_s2_shift.  Callable on (b, w, h, c) like the reference's:
+    the argument is overwritten and returned (`shift_mode` as in s2_mlp_v2.SHIFT_MODES)."""
+    shift_mode = "reference_inplace"
+
+    def forward(self, x):
+        E.require_gpu(x, "Spatial_Shift.forward")
+        if x.dim() != 4:
+            raise ValueError("expected a (b, w, h, c) tensor")
+        b, hh, ww, c = x.shape
+        with E.on_device(x):
+            src = x.contiguous()
+            out = torch.empty_like(src)
+            E.s2_shift(src, out, b, hh, ww, c, c, c, {"reference_inplace": N.SHIFT_S2_REF, "shift": N.SHIFT_S2}[self.shift_mode])
+        x.copy_(out)
+        return x
 
 
 class S2Block(E.EngineModule):

@@ -20,7 +20,8 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import BlockSequential, Holder, channel_mlp, finalize_stats, head_linear, layernorm_stats, split_attention_weights, stage_embed, pack_channel_mlp
+from .common import (BlockSequential, Holder, channel_mlp, finalize_stats, head_linear, layernorm_stats, split_attention_forward,
+                     split_attention_weights, standalone_space, stage_embed, pack_channel_mlp)
 from .utils.tools import pair
 
 SHIFT_MODES = {"reference_inplace": N.SHIFT_S2_REF, "shift": N.SHIFT_S2}
@@ -33,8 +34,39 @@ class PreNormResidual(Holder):
         self.norm = nn.LayerNorm(dim)
 
 
+def _spatial_shift(x, branch, mode):
+    """spatial_shift1 / spatial_shift2 of s2_mlp_v2.py:15-29 on a channel-last (b, w, h, c) tensor, IN PLACE like the reference
+    (the argument is overwritten and returned).  The shift itself is the gather mlpk_split_apply applies while loading branch
+    `branch` -- called with unit weight on that branch, zero on the others -- so the standalone function and the fused block run the
+    same kernel.  mode: SHIFT_MODES ("reference_inplace": the reference's deterministic single-thread result; "shift": the
+    intended one-pixel shift)."""
+    E.require_gpu(x, "spatial_shift%d" % (branch + 1))
+    if x.dim() != 4:
+        raise ValueError("expected a (b, w, h, c) tensor")
+    b, hh, ww, c = x.shape
+    with E.on_device(x):
+        src = x.contiguous().view(b * hh * ww, c)
+        bar = torch.zeros((b, 3 * c), dtype=torch.float32, device=x.device)
+        bar[:, branch * c:(branch + 1) * c] = 1.0
+        out = torch.empty_like(src)
+        E.split_apply(src, src, src, c, c, c, b, hh, ww, c, SHIFT_MODES[mode], bar, out, c)
+    x.copy_(out.view(b, hh, ww, c))
+    return x
+
+
+def spatial_shift1(x, mode="reference_inplace"):
+    return _spatial_shift(x, 0, mode)
+
+
+def spatial_shift2(x, mode="reference_inplace"):
+    return _spatial_shift(x, 1, mode)
+
+
 class SplitAttention(Holder):
-    """s2_mlp_v2.py:31-51 (bias-free mlp1/mlp2)."""
+    """s2_mlp_v2.py:31-51 (bias-free mlp1/mlp2).  Callable on x_all (b, 3, h, w, c) like the reference's."""
+
+    def forward(self, x_all):
+        return split_attention_forward(self, x_all)
 
     def __init__(self, channel=512, k=3):
         super().__init__()
@@ -47,13 +79,36 @@ class SplitAttention(Holder):
 
 
 class S2Attention(Holder):
-    """s2_mlp_v2.py:53-69."""
+    """s2_mlp_v2.py:53-69.  Callable on (b, h, w, c) like the reference's: mlp1 -> the two shifts as gathers inside the
+    split-attention kernels -> mlp2 (no LayerNorm / residual: those belong to the enclosing PreNormResidual)."""
+    shift_mode = "reference_inplace"
 
     def __init__(self, channels=512):
         super().__init__()
         self.mlp1 = nn.Linear(channels, channels * 3)
         self.mlp2 = nn.Linear(channels, channels)
         self.split_attention = SplitAttention(channels)
+
+    def forward(self, x):
+        if x.dim() != 4:
+            raise ValueError("expected a (b, h, w, c) tensor")
+        b, h, w, c = x.shape
+        rows = b * h * w
+        ws = standalone_space(x)
+        mode = SHIFT_MODES[self.shift_mode]
+        with E.on_device(x):
+            xin = x.contiguous().view(rows, c)
+            t = ws.get("t", (rows, 3 * c))
+            E.gemm(xin, E.pack_matrix(self.mlp1.weight, x.dtype, x.device), t, rows, 3 * c, c, bias=E.f32(self.mlp1.bias, x.device))
+            x0, x1, x2 = t[:, :c], t[:, c:2 * c], t[:, 2 * c:]
+            sa = self.split_attention
+            bar = split_attention_weights(ws, x0, x1, x2, 3 * c, 3 * c, 3 * c, b, h, w, c, mode, E.pack_matrix(sa.mlp1.weight, torch.float32, x.device),
+                                          E.pack_matrix(sa.mlp2.weight, torch.float32, x.device))
+            m = ws.get("m", (rows, c))
+            E.split_apply(x0, x1, x2, 3 * c, 3 * c, 3 * c, b, h, w, c, mode, bar, m, c)
+            out = torch.empty((rows, c), dtype=x.dtype, device=x.device)
+            E.gemm(m, E.pack_matrix(self.mlp2.weight, x.dtype, x.device), out, rows, c, c, bias=E.f32(self.mlp2.bias, x.device))
+        return out.view(b, h, w, c)
 
 
 class S2Block(E.EngineModule):
@@ -139,6 +194,9 @@ class S2MLPv2(E.EngineModule):
         if mode not in SHIFT_MODES:
             raise ValueError("shift_mode must be one of %s" % sorted(SHIFT_MODES))
         self.shift_mode = mode
+        for m in self.modules():                  # the attention modules are callable on their own: keep them in step
+            if isinstance(m, S2Attention):
+                m.shift_mode = mode
         return self
 
     def _pack(self, dtype, device):

@@ -34,3 +34,12 @@ class Shift(nn.Module):
         if self.kernel_size == 1:
             return x
         return _shift_gpu(x, self.kernel_size, self.dim)
+
+
+def torch_shift(x, shift_size, dim):
+    """shift_cuda.py:195-205 -- the reference's pure-torch restatement of the same operation (pad, per-chunk roll, crop) on
+    (B, C, H, W): here the same kernel as `Shift` (chunk g of ceil(C / shift_size) channels moves by g - shift_size // 2 pixels along
+    `dim`, zeros shifted in), out of place."""
+    if shift_size == 1:
+        return x
+    return _shift_gpu(x, shift_size, dim)

@@ -16,7 +16,8 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import BlockSequential, Holder, adopt_blocks, channel_mlp, embed_patches, finalize_stats, head_linear, layernorm_stats, split_attention_weights, pack_channel_mlp
+from .common import (BlockSequential, Holder, adopt_blocks, channel_mlp, embed_patches, finalize_stats, head_linear, layernorm_stats,
+                     split_attention_forward, split_attention_weights, standalone_space, pack_channel_mlp)
 from .utils.tools import pair
 
 
@@ -43,6 +44,13 @@ class ParallelWeightedSum(Holder):
         self.fns = nn.ModuleList(fns)
         self.split_attention = sa
 
+    def forward(self, x):
+        """vip.py:24-35: the three branches of x (b, h, w, c), stacked, through the split attention."""
+        E.require_gpu(x, "ParallelWeightedSum.forward")
+        with E.on_device(x):
+            xs = [_branch_forward(f, x, k) for f, k in zip(self.fns, "hwc")]
+            return self.split_attention(torch.stack(xs, 1))
+
 
 class SplitAttention(Holder):
     """Bias-free mlp1 (C->C), GELU, mlp2 (C->kC), softmax over k (vip.py:37-57)."""
@@ -55,6 +63,32 @@ class SplitAttention(Holder):
         self.gelu = nn.GELU()
         self.mlp2 = nn.Linear(channel, channel * k, bias=False)
         self.softmax = nn.Softmax(1)
+
+    def forward(self, x_all):
+        """x_all (b, 3, h, w, c) -> (b, h, w, c), vip.py:47-57."""
+        return split_attention_forward(self, x_all)
+
+
+def _branch_forward(seq, x, which):
+    """One Permute-MLP branch on its own (vip.py:69-76): Sequential(Rearrange, Linear, Rearrange) for the h / w branches, a bare
+    Linear for the channel branch.  The Linear runs as mlpk_gemm_nt; the two rearranges of a lone branch are plain index
+    permutations done by torch here (inside the model they are fused into the normalise pass and the weighted-sum kernel)."""
+    b, h, w, c = x.shape
+    lin = seq if isinstance(seq, nn.Linear) else seq[1]
+    if which == "c":
+        rows = x.contiguous().view(b * h * w, c)
+    else:
+        s = lin.weight.shape[0] // (h if which == "h" else w)
+        g = c // s
+        v = x.contiguous().view(b, h, w, g, s)
+        rows = (v.permute(0, 2, 3, 1, 4) if which == "h" else v.permute(0, 1, 3, 2, 4)).contiguous().view(-1, lin.weight.shape[1])
+    out = torch.empty((rows.shape[0], lin.weight.shape[0]), dtype=x.dtype, device=x.device)
+    E.gemm(rows, E.pack_matrix(lin.weight, x.dtype, x.device), out, rows.shape[0], lin.weight.shape[0], lin.weight.shape[1], bias=E.f32(lin.bias, x.device))
+    if which == "c":
+        return out.view(b, h, w, c)
+    if which == "h":
+        return out.view(b, w, g, h, s).permute(0, 3, 1, 2, 4).contiguous().view(b, h, w, c)
+    return out.view(b, h, g, w, s).permute(0, 1, 3, 2, 4).contiguous().view(b, h, w, c)
 
 
 class _Rearrange(Holder):
@@ -169,7 +203,12 @@ class _PermutatorBase(E.EngineModule):
             xn = None if cfold else ws.get("vip.xn", (rows, C))
             ph = ws.get("vip.ph", (B * W * G, ldh))
             pw = ws.get("vip.pw", (B * H * G, ldw))
-            fused = x.dtype != torch.float32 and seg % 4 == 0 and C % 8 == 0
+            # the 16-byte rearrange path (and its by-product sums) also needs its LDS slab to fit: (C / seg) rows of ld_p elements
+            # (+ 32 bytes of padding) + gamma / beta -- mlpk_norm_apply's own condition, asked here so that a configuration it cannot
+            # take (very tall maps) falls back to the unfused split attention instead of failing
+            es = 2 if x.dtype != torch.float32 else 4
+            lds_ok = G * (max(ldh, ldw) * es + 32) + 2 * C * 4 <= 160 * 1024
+            fused = x.dtype != torch.float32 and seg % 4 == 0 and C % 8 == 0 and lds_ok
             lin = fused and self.weighted
             # by-product sums of the two rearrange passes, side by side: [sum_w x^ as rows (b, g) x columns (h, j) | sum_h x^ ... (w, j)]
             asum = ws.get("sa.sums", (B * G, ldh + ldw), torch.float32) if lin else None
@@ -183,15 +222,17 @@ class _PermutatorBase(E.EngineModule):
                 # branch outputs, then mlp2 + softmax.  Four latency-bound kernels (~80 us in a row on a few CUs) that depend only
                 # on the rearrange passes above: they run on a side stream BESIDE the three branch GEMMs below and are joined in
                 # front of the weighted sum.
+                # (the chain's buffers are taken BEFORE the side stream is entered: allocated -- and zero-filled -- on the stream
+                # that later reads `bar`, never owned by the side stream in the caching allocator's books)
+                t = ws.get("sa.t", (B, C), torch.float32)
+                o = ws.get("sa.o", (B * G, 2 * seg), torch.float32)
+                hat = ws.get("sa.hat", (B, 3 * C), torch.float32)
+                bar = ws.get("sa.bar", (B, 3 * C), torch.float32)
                 chain = E.SideChain(ws, "sa", x.device)
                 with chain:
-                    t = ws.get("sa.t", (B, C), torch.float32)
-                    o = ws.get("sa.o", (B * G, 2 * seg), torch.float32)
                     E.gemm(asum, pk[p + "sa.w1"], o, B * G, 2 * seg, ldh + ldw, bias=pk[p + "sa.b1"])
                     E.gemm(o.view(B, G * 2 * seg), pk[p + "sa.m1w2"], t, B, C, G * 2 * seg, bias=pk[p + "sa.m1b"], act=N.ACT_GELU)
-                    hat = ws.get("sa.hat", (B, 3 * C), torch.float32)
                     E.gemm(t, pk[p + "sa.m2"], hat, B, 3 * C, C)
-                    bar = ws.get("sa.bar", (B, 3 * C), torch.float32)
                     E.split_softmax(hat, bar, B, C)
             ldzh, ldzw = E.round_up(hs, 8), E.round_up(wsz, 8)
             zh = ws.get("vip.zh", (B * W * G, ldzh))

@@ -589,3 +589,80 @@ def test_shift_module_dropin():
         Shift(4, 2)
     with pytest.raises(AssertionError):
         Shift(3, 1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_inner_modules_callable_like_the_reference(dtype):
+    """The sub-block boundary BASELINE.json's north star names: `spatial_shift1/2` (s2_mlp_v2.py:15-29) and `torch_shift`
+    (shift_cuda.py:195-205) as functions, `SpatialGatingUnit` (g_mlp.py:10-22), `SplitAttention` / `ParallelWeightedSum`
+    (vip.py:24-57), `S2Attention` (s2_mlp_v2.py:53-69), `Spatial_Shift` (s2_mlp_v1.py:15-25) and `AxialShift` (as_mlp.py:27-95)
+    called on their own -- through the HIP kernels -- against the CPU oracle's restatement of the same reference lines."""
+    pkg = load_pkg()
+    mp = pkg.models_pytorch
+    from importlib import import_module
+    s2 = import_module("jittor-mlp_amd.models_pytorch.s2_mlp_v2")
+    s1 = import_module("jittor-mlp_amd.models_pytorch.s2_mlp_v1")
+    vip = import_module("jittor-mlp_amd.models_pytorch.vip")
+    gm = import_module("jittor-mlp_amd.models_pytorch.g_mlp")
+    asm = import_module("jittor-mlp_amd.models_pytorch.as_mlp")
+    ut = import_module("jittor-mlp_amd.models_pytorch.utils")
+    F = oracle.functional
+    tol = 2e-5 if dtype == torch.float32 else 4e-2
+    torch.manual_seed(11)
+
+    def close(got, ref, what):
+        err = (got.float().cpu().double() - ref.double()).abs().max().item()
+        assert err <= tol * max(1.0, ref.abs().max().item()), (what, str(dtype), err)
+
+    # spatial shifts: bit-exact moves, in place, both semantics
+    x = torch.randn(2, 6, 5, 16).to(dtype)
+    for fn, ref in ((s2.spatial_shift1, F.spatial_shift1), (s2.spatial_shift2, F.spatial_shift2)):
+        for mode in ("reference_inplace", "shift"):
+            xd = x.clone().to(DEV)
+            y = fn(xd, mode=mode)
+            assert y is xd
+            assert torch.equal(y.cpu(), ref(x.clone(), mode=mode)), (fn.__name__, mode)
+    xd = x.clone().to(DEV)
+    assert torch.equal(s1.Spatial_Shift()(xd).cpu(), F.spatial_shift1(x.clone()))          # s2_mlp_v1.py:19-25 == spatial_shift1
+    xn = torch.randn(2, 10, 7, 9).to(dtype)
+    for dim in (2, 3):
+        assert torch.equal(ut.torch_shift(xn.to(DEV), 5, dim).cpu(), F.axial_shift_nchw(xn, 5, dim))
+    # SplitAttention (ViP's and S2's are the same module)
+    for mod in (vip.SplitAttention(32), s2.SplitAttention(32)):
+        mod = mod.eval()
+        xa = torch.randn(2, 3, 4, 5, 32).to(dtype)
+        ref = F.split_attention(xa[:, 0].double(), xa[:, 1].double(), xa[:, 2].double(), mod.mlp1.weight.detach().double(), mod.mlp2.weight.detach().double())
+        close(mod.to(DEV)(xa.to(DEV)), ref, "SplitAttention")
+    # S2Attention, both shift modes
+    att = s2.S2Attention(32).eval()
+    xs = torch.randn(2, 6, 5, 32).to(dtype)
+    for mode in ("reference_inplace", "shift"):
+        att.shift_mode = mode
+        t = torch.nn.functional.linear(xs.double(), att.mlp1.weight.detach().double(), att.mlp1.bias.detach().double())
+        x1, x2, x3 = F.spatial_shift1(t[..., :32].clone(), mode=mode), F.spatial_shift2(t[..., 32:64].clone(), mode=mode), t[..., 64:]
+        a = F.split_attention(x1, x2, x3, att.split_attention.mlp1.weight.detach().double(), att.split_attention.mlp2.weight.detach().double())
+        ref = torch.nn.functional.linear(a, att.mlp2.weight.detach().double(), att.mlp2.bias.detach().double())
+        close(att.to(DEV)(xs.to(DEV)), ref, "S2Attention " + mode)
+        att = att.cpu()
+    # SpatialGatingUnit
+    sgu = gm.SpatialGatingUnit(24, 10).eval()
+    xg = torch.randn(3, 10, 48).to(dtype)
+    u, v = xg.double().chunk(2, dim=-1)
+    v = torch.nn.functional.layer_norm(v, (24,), sgu.norm.weight.detach().double(), sgu.norm.bias.detach().double())
+    v = torch.einsum("ts,bsf->btf", sgu.spatial_proj.weight.detach().double().squeeze(-1), v) + sgu.spatial_proj.bias.detach().double().view(1, -1, 1)
+    close(sgu.to(DEV)(xg.to(DEV)), u * v, "SpatialGatingUnit")
+    # ParallelWeightedSum of a ViP block: the three branch Linears with their rearranges, then the split attention
+    vm = mp.ViP(image_size=32, patch_size=8, d_model=32, depth=1, segments=4, expansion_factor=2).eval()
+    pws = [m for m in vm.modules() if isinstance(m, vip.ParallelWeightedSum)][0]
+    xv = torch.randn(2, 4, 4, 32).to(dtype)
+    sd = {k: p.detach().double() for k, p in pws.state_dict().items()}
+    xh = F.vip_unpermute_h(torch.nn.functional.linear(F.vip_permute_h(xv.double(), 4), sd["fns.0.1.weight"], sd["fns.0.1.bias"]), 4)
+    xw = F.vip_unpermute_w(torch.nn.functional.linear(F.vip_permute_w(xv.double(), 4), sd["fns.1.1.weight"], sd["fns.1.1.bias"]), 4)
+    xc = torch.nn.functional.linear(xv.double(), sd["fns.2.weight"], sd["fns.2.bias"])
+    ref = F.split_attention(xh, xw, xc, sd["split_attention.mlp1.weight"], sd["split_attention.mlp2.weight"])
+    close(pws.to(DEV)(xv.to(DEV)), ref, "ParallelWeightedSum")
+    # AxialShift
+    ax = asm.AxialShift(32, 5).eval()
+    xa = torch.randn(2, 32, 7, 6).to(dtype)
+    sda = {"a." + k: p.detach().double() for k, p in ax.state_dict().items()}
+    close(ax.to(DEV)(xa.to(DEV)), F.asmlp_axial_shift(sda, xa.double(), "a.", 5), "AxialShift")

@@ -1053,3 +1053,31 @@ def test_gemm_row_parts_refusals():
     assert N.lib().mlpk_gemm_nt(ctypes.byref(d), None) != 0
     d.row_part_ld, d.algo = 256, 14                                  # persistent tile without a residual: no statistics class
     assert N.lib().mlpk_gemm_nt(ctypes.byref(d), None) != 0
+
+
+@pytest.mark.gpu
+def test_byproduct_statistics_with_a_large_row_mean():
+    """Rows whose mean is two orders of magnitude above their spread (a deep residual stream): the by-product (sum, sum of squares)
+    pairs are reduced in fp64 by mlpk_stats_finalize_planar, so the variance is not lost to the S2 / n - mean^2 cancellation; against
+    the two-pass mlpk_row_stats on the same stored values."""
+    pkg = load_pkg()
+    E, N = pkg.engine, pkg._native
+    dtype = torch.bfloat16
+    M, Nn, K = 1024, 512, 256
+    A = rnd((M, K), dtype, 700).to(dev())
+    B = rnd((Nn, K), dtype, 701, 1.0 / math.sqrt(K)).to(dev())
+    bias = torch.full((Nn,), 100.0, device=dev())
+    R = rnd((M, Nn), dtype, 703).to(dev())
+    for algo in (0, 11, 14, 15):
+        C = torch.empty((M, Nn), dtype=dtype, device=dev())
+        got = E.gemm(A, B, C, M, Nn, K, bias=bias, R=R, res=N.RES_ADD, algo=algo, part=(_Space(), "p"))
+        assert got is not None
+        mean = torch.empty((M,), dtype=torch.float32, device=dev())
+        rstd = torch.empty((M,), dtype=torch.float32, device=dev())
+        E.stats_finalize_planar(got[0], M, Nn, mean, rstd, eps=1e-5)
+        m2 = torch.empty_like(mean)
+        r2 = torch.empty_like(rstd)
+        E.row_stats(C, M, Nn, Nn, m2, r2)
+        torch.cuda.synchronize()
+        assert (mean - m2).abs().max().item() <= 1e-3, algo
+        assert ((rstd - r2).abs() / r2).max().item() <= 2e-3, algo
