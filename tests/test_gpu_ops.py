@@ -1081,3 +1081,40 @@ def test_byproduct_statistics_with_a_large_row_mean():
         torch.cuda.synchronize()
         assert (mean - m2).abs().max().item() <= 1e-3, algo
         assert ((rstd - r2).abs() / r2).max().item() <= 2e-3, algo
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_gemm_q4_generated_tile(dtype):
+    """algo 15, the generated one-wave-per-SIMD kernels (csrc/gen/q4gen.py): every epilogue class (bias | + folded LayerNorm | + GELU |
+    + both | + residual) on shapes with several tiles per workgroup, rolled iterations, one and several column groups -- against
+    fp64, and BIT-EQUAL to the independent s3 tile (same K order, same epilogue operation sequence): the race screen of the
+    hand-counted LDS-DMA / barrier protocol (a wrong count shows as differing bits on some tiles)."""
+    pkg = load_pkg()
+    E, N = pkg.engine, pkg._native
+    for ci, (M, Nn, K) in enumerate([(256, 128, 192), (1024, 384, 384), (2048, 768, 768), (4096, 768, 3072), (16384, 3072, 768), (50176, 384, 384)]):
+        A = rnd((M, K), dtype, 900 + ci).to(dev())
+        B = rnd((Nn, K), dtype, 910 + ci, 1.0 / math.sqrt(K)).to(dev())
+        bias = (rnd((Nn,), torch.float32, 920 + ci) * 0.5).to(dev())
+        R = rnd((M, Nn), dtype, 930 + ci).to(dev())
+        ln3 = ((rnd((M,), torch.float32, 940 + ci) * 0.1).to(dev()), (rnd((M,), torch.float32, 950 + ci).abs() + 0.5).to(dev()), B.float().sum(dim=1).contiguous())
+        for gelu, ln, res in ((0, 0, 0), (0, 1, 0), (1, 0, 0), (1, 1, 0), (0, 0, 1)):
+            kw = dict(R=R, res=N.RES_ADD) if res else {}
+            if ln:
+                kw["ln"] = ln3
+            outs = []
+            for algo in (15, 11):
+                C = torch.full((M, Nn), float("nan"), dtype=dtype, device=dev())
+                E.gemm(A, B, C, M, Nn, K, bias=bias, act=N.ACT_GELU if gelu else 0, algo=algo, **kw)
+                outs.append(C)
+            torch.cuda.synchronize()
+            assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), (str(dtype), M, Nn, K, gelu, ln, res)
+            if M * Nn <= 2048 * 768:
+                acc = A.double() @ B.double().t()
+                v = (acc - ln3[0].double()[:, None] * ln3[2].double()[None, :]) * ln3[1].double()[:, None] + bias.double() if ln else acc + bias.double()
+                if gelu:
+                    v = torch.nn.functional.gelu(v)
+                if res:
+                    v = v.to(dtype).double() + R.double()
+                err = (outs[0].double() - v).abs().max().item()
+                assert err < EPS[dtype] * 4 * max(1.0, v.abs().max().item()), (str(dtype), M, Nn, K, gelu, ln, res, err)
