@@ -461,6 +461,17 @@ class Emu:
     def x_s_cmp_gt_i32(self, w, i):
         self._cmp(w, i, lambda a, b: a > b, True)
 
+    def x_s_cmp_ge_i32(self, w, i):
+        self._cmp(w, i, lambda a, b: a >= b, True)
+
+    def x_s_min_i32(self, w, i):
+        sg = lambda x: x - (1 << 32) if x & 0x80000000 else x
+        self.wrs(w, i.args[0], min(sg(self.rds(w, i.args[1])), sg(self.rds(w, i.args[2]))))
+
+    def x_s_max_i32(self, w, i):
+        sg = lambda x: x - (1 << 32) if x & 0x80000000 else x
+        self.wrs(w, i.args[0], max(sg(self.rds(w, i.args[1])), sg(self.rds(w, i.args[2]))))
+
     def x_s_cselect_b32(self, w, i):
         self.wrs(w, i.args[0], self.rds(w, i.args[1]) if w.scc else self.rds(w, i.args[2]))
 
@@ -570,6 +581,9 @@ class Emu:
     def x_v_xor_b32(self, w, i):
         self.wrv(w, i.args[0], self.rd(w, i.args[1]) ^ self.rd(w, i.args[2]))
 
+    def x_v_min_u32(self, w, i):
+        self.wrv(w, i.args[0], np.minimum(self.rd(w, i.args[1]), self.rd(w, i.args[2])))
+
     def x_v_lshl_add_u32(self, w, i):
         self.wrv(w, i.args[0], (self.rd(w, i.args[1]) << (self.rd(w, i.args[2]) & 31)) + self.rd(w, i.args[3]))
 
@@ -625,6 +639,31 @@ class Emu:
     def x_v_sub_f32(self, w, i):
         with np.errstate(all="ignore"):
             self.wrv(w, i.args[0], self.u(self.f(self.rd(w, i.args[1])) - self.f(self.rd(w, i.args[2]))))
+
+    # ---- packed fp32 (two lanes' worth of fp32 per instruction: 64-bit register pairs, element k of every operand)
+    def _rd2(self, w, o):
+        if isinstance(o, Reg):
+            assert o.n == 2 and o.idx % 2 == 0, o
+            return self.rd(w, o[0]), self.rd(w, o[1])
+        raise TypeError(o)
+
+    def x_v_pk_mul_f32(self, w, i):
+        a, b = self._rd2(w, i.args[1]), self._rd2(w, i.args[2])
+        with np.errstate(all="ignore"):
+            for k in range(2):
+                self.wrv(w, i.args[0][k], self.u(self.f(a[k]) * self.f(b[k])))
+
+    def x_v_pk_add_f32(self, w, i):
+        a, b = self._rd2(w, i.args[1]), self._rd2(w, i.args[2])
+        with np.errstate(all="ignore"):
+            for k in range(2):
+                self.wrv(w, i.args[0][k], self.u(self.f(a[k]) + self.f(b[k])))
+
+    def x_v_pk_fma_f32(self, w, i):
+        a, b, c = self._rd2(w, i.args[1]), self._rd2(w, i.args[2]), self._rd2(w, i.args[3])
+        res = [self.u(self._fma(a[k], b[k], c[k])) for k in range(2)]
+        for k in range(2):
+            self.wrv(w, i.args[0][k], res[k])
 
     def x_v_add_f32_dpp(self, w, i):
         """dst = dpp(src0) + src1; quad_perm / row_half_mirror with full row and bank masks (every lane enabled)"""
@@ -803,14 +842,17 @@ class Emu:
     def _gload(self, w, i, n):
         d, voff, sbase = i.args
         addr = self._gaddr(w, i, voff, sbase)
-        data = self.mem.gather(addr, 4 * n).copy().view(np.uint32)
+        ex = w.exec.copy()
+        data = np.zeros((64, n), np.uint32)
+        if ex.any():
+            data[ex] = self.mem.gather(addr[ex], 4 * n).copy().view(np.uint32)
         bank = w.v if d.kind == "v" else w.a
         for k in range(n):
-            bank[d.idx + k] = POISON
+            bank[d.idx + k][ex] = POISON
 
         def done():
             for k in range(n):
-                bank[d.idx + k] = data[:, k]
+                bank[d.idx + k][ex] = data[ex, k]
         w.vm.append(("load", done))
 
     def x_global_load_dword(self, w, i):
@@ -902,7 +944,9 @@ def lint(asm, mfma_gap=16, verbose=False):
             dist = pos - p - 1         # wait states in between
             if kind == "mfma" and not is_mfma and dist < mfma_gap:
                 problems.append((k, "%s reads %s%d %d states after the MFMA that writes it (< %d)" % (i.op, r[0], r[1], dist, mfma_gap)))
-            if kind == "mfma" and is_mfma and r[0] != "a" and dist < mfma_gap:
+            if kind == "mfma" and is_mfma and r[0] != "a" and dist < mfma_gap and not (
+                    isinstance(i.args[3], Reg) and i.args[3].kind == i.args[0].kind and i.args[3].idx == i.args[0].idx
+                    and r in _regs_of(i.args[3]) and r not in _regs_of(i.args[1]) and r not in _regs_of(i.args[2])):
                 problems.append((k, "MFMA operand written by an MFMA %d states before" % dist))
             if r == ("m0", 0) and i.op == "global_load_lds_dwordx4" and dist < 1:
                 problems.append((k, "LDS-DMA straight after the m0 write"))

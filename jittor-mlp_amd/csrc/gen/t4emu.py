@@ -1,0 +1,140 @@
+"""Run a generated t4 kernel (fused token-mixing MLP) on the numpy emulator of isa.py against an fp64 restatement."""
+import os
+import struct
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import isa  # noqa: E402
+import t4gen  # noqa: E402
+from q4emu import from16, gelu_ref, to16  # noqa: E402
+
+S_TOK, KPAD = 196, 224
+
+
+def w2_slot_source():
+    """k slot 16 kk + 8 h + e of a group of 32  <-  hidden 16 kk + 8 (e >> 2) + 4 h + (e & 3)   (layout 2, include/mlpk.h)"""
+    slot = np.arange(32)
+    kk, h, e = slot >> 4, (slot >> 3) & 1, slot & 7
+    return 16 * kk + 8 * (e >> 2) + 4 * h + (e & 3)
+
+
+def pack(w1, b1, w2, b2, dt):
+    """w1 (T, S), w2 (S, T) fp -> the layout-2 buffers of mlpk_token_mlp: W1 (G*32, 256), b1 (1024), W2 ((G+1)*224, 32), b2 (224)"""
+    T, S = w1.shape
+    G = (T + 31) // 32
+    w1p = np.zeros((G * 32, 256), np.uint16)
+    w1p[:T, :S] = to16(w1, dt)
+    b1p = np.zeros(1024, np.float32)
+    b1p[64:64 + T] = b1
+    w2z = np.zeros((S, G * 32), np.uint16)
+    w2z[:, :T] = to16(w2, dt)
+    w2p = np.zeros((G + 1, 224, 32), np.uint16)
+    src = w2_slot_source()
+    for g in range(G):
+        w2p[g, :S, :] = w2z[:, 32 * g + src]
+    b2p = np.zeros(224, np.float32)
+    b2p[:S] = b2
+    return w1p, b1p, w2p.reshape(-1, 32), b2p, G
+
+
+def plan(M, t_rows, G, grid, nimg):
+    tpi = t_rows // 256
+    nit = G + 2
+    lead = nit & 1
+    return dict(M=M, G=G, ldxt=KPAD, ldx=t_rows, ntiles=M // 256, tpi=tpi, tpi_magic=(((1 << 31) + tpi - 1) // tpi) & 0xFFFFFFFF,
+                grid=grid, stat_ld=nimg * S_TOK * 2, nit=nit + lead, lead=lead, S=S_TOK)
+
+
+class T4Emu(isa.Emu):
+    def __init__(self, gen, mem, karg_addr, bid, **kw):
+        asm = isa.Asm()
+        asm.ins = list(gen.a.ins)
+        super().__init__(asm, mem, lds_bytes=163840, nwaves=4, **kw)
+        self.karg_addr, self.bid = karg_addr, bid
+
+    def init(self, waves):
+        for w in waves:
+            w.s[0] = self.karg_addr & 0xFFFFFFFF
+            w.s[1] = self.karg_addr >> 32
+            w.s[2] = self.bid
+            w.v[0] = (np.arange(64) + 64 * w.wid).astype(np.uint32)
+            w.v[1:] = 0x7FC0BEEF
+            w.a[:] = 0x7FC0BEEF
+        self.lds[:] = 0xEE
+
+
+def run_case(gen, nimg=1, t_rows=512, T=80, grid=1, seed=0, dma_mode="late", order=None, verbose=False):
+    rng = np.random.default_rng(seed)
+    dt = gen.dtype
+    S = S_TOK
+    M = nimg * t_rows
+    xt = np.zeros((M, KPAD), np.uint16)
+    xt[:, :S] = to16(rng.uniform(-1, 1, (M, S)), dt)
+    w1 = rng.uniform(-1, 1, (T, S)) * 0.15
+    b1 = rng.uniform(-1, 1, T).astype(np.float32)
+    w2 = rng.uniform(-1, 1, (S, T)) * 0.2
+    b2 = rng.uniform(-1, 1, S).astype(np.float32)
+    x0 = to16(rng.uniform(-2, 2, (nimg * S, t_rows)), dt)
+    w1p, b1p, w2p, b2p, G = pack(w1, b1, w2, b2, dt)
+    mem = isa.Mem()
+    aXt, aW1, aW2, aB1, aB2 = mem.add(xt), mem.add(w1p), mem.add(w2p), mem.add(b1p), mem.add(b2p)
+    aX = mem.add(x0, writable=True)
+    nplanes = t_rows // 64
+    stats = np.full((nplanes, nimg * S, 2), np.nan, np.float32)
+    aSt = mem.add(stats, writable=True)
+    pl = plan(M, t_rows, G, grid, nimg)
+    ka = bytearray(t4gen.ARG_BYTES)
+    for name, val in (("xt", aXt), ("w1", aW1), ("w2", aW2), ("b1", aB1), ("b2", aB2), ("x", aX), ("stats", aSt), ("prof", 0)):
+        struct.pack_into("<Q", ka, t4gen.KA[name], val)
+    for name, val in pl.items():
+        struct.pack_into("<I", ka, t4gen.KA[name], val)
+    karg = mem.add(np.frombuffer(bytes(ka), np.uint8))
+    nins = 0
+    for bid in range(grid):
+        e = T4Emu(gen, mem, karg, bid, dma_mode=dma_mode, order=order)
+        waves = e.run()
+        nins += sum(w.nissued for w in waves)
+    out = from16(mem.get(aX).view(np.uint16).reshape(nimg * S, t_rows), dt).astype(np.float64)
+    # reference: rows of xt are (image, channel); x is (image, token, channel)
+    X = from16(xt[:, :S], dt).astype(np.float64)
+    W1 = from16(to16(w1, dt), dt).astype(np.float64)
+    W2 = from16(to16(w2, dt), dt).astype(np.float64)
+    hid = gelu_ref(X @ W1.T + b1[None, :].astype(np.float64))
+    hid = from16(to16(hid, dt), dt).astype(np.float64)
+    y = hid @ W2.T + b2[None, :].astype(np.float64)                       # (M, S)
+    y = y.reshape(nimg, t_rows, S).transpose(0, 2, 1).reshape(nimg * S, t_rows)
+    ref = from16(to16(y + from16(x0, dt).astype(np.float64), dt), dt).astype(np.float64)
+    err = np.abs(out - ref)
+    tol = (2.0 ** -7 if dt == "bf16" else 2.0 ** -10) * np.maximum(1.0, np.abs(ref)) * 1.5
+    bad = ~(err <= tol)
+    ok = not bad.any()
+    if verbose or bad.any():
+        print("case nimg=%d t_rows=%d T=%d (G=%d) grid=%d mode=%s: bad %d of %d, max err %.3g, instructions %d" %
+              (nimg, t_rows, T, G, grid, dma_mode, bad.sum(), bad.size, np.nanmax(err) if np.isfinite(err).any() else float("nan"), nins))
+        if bad.any():
+            idx = np.argwhere(bad)
+            print("  first bad (token row, channel):", idx[:8].tolist())
+            print("  bad token rows / 32:", sorted(set((idx[:, 0] % S) // 32))[:20], " channels / 32:", sorted(set(idx[:, 1] // 32))[:20],
+                  " images:", sorted(set(idx[:, 0] // S))[:8])
+    if gen.stats:
+        got = mem.get(aSt).view(np.float32).reshape(nplanes, nimg * S, 2).astype(np.float64)
+        oq = out.reshape(nimg * S, nplanes, 64)
+        want = np.stack([oq.sum(axis=2).T, (oq * oq).sum(axis=2).T], axis=2)
+        perr = np.abs(got - want).max() if np.isfinite(got).all() else float("nan")
+        if not (perr < 1e-3):
+            print("token-row statistics: max error %s (nan = rows never written)" % perr)
+            ok = False
+    return ok
+
+
+if __name__ == "__main__":
+    import time
+    t0 = time.time()
+    g = t4gen.T4(stats=True)
+    print("generated", len(g.a.ins), "instructions in %.1fs; vgprs %d sgprs %d" % (time.time() - t0, g.nv, g.ns))
+    print("lint problems:", len(isa.lint(g.a, verbose=True)))
+    t0 = time.time()
+    ok = run_case(g, nimg=1, t_rows=512, T=80, grid=1, verbose=True)
+    print("ok" if ok else "FAILED", "%.1fs" % (time.time() - t0))

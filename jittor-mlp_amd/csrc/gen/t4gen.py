@@ -1,0 +1,608 @@
+"""Generator of the "t4" fused token-mixing MLP (MLP-Mixer, mlp_mixer.py:16-27,34,37): one wave per SIMD, GELU as fillers.
+
+    x[b, s, c] += sum_t W2[s, t] * gelu(sum_s' W1[t, s'] * xt[b*C + c, s'] + b1[t]) + b2[s]
+
+Same operation and argument block as token_mlp_rr_kernel (mlpk_tokenmlp.hip); what changes is WHO overlaps with whom.  There, two
+waves share a SIMD and the GELU of one was meant to run beside the MFMAs of the other -- on gfx950 those times ADD
+(tools/ubench/issue_rate.hip).  Here a workgroup is 4 waves = one per SIMD with 512 registers; a wave owns 64 rows of xt (2 blocks of 32)
+for all 196 tokens and runs, in ONE instruction stream, three stages of a software pipeline over the groups of 32 hidden units:
+
+    iteration g:   MFMA  fc2(g-2)  28 x v_mfma_f32_32x32x16   D2[rb][tb] += h(g-2)[rb][kk] x W2frag(tb, kk)
+                   MFMA  fc1(g)    28 x                        D1[rb] = b1(g) + sum_ks W1frag(ks) x X[rb][ks]
+                   VALU  gelu(g-1) on the 32 fp32 values per lane that fc1(g-1) left, rounded into h(g-1): placed between the MFMAs
+
+with the first product computed "transposed" (hidden x rows), so that a lane's 16 accumulators of a block are -- after GELU and
+rounding -- exactly two A fragments of the second product once W2's columns are stored in that order inside every group of 32
+(layout 2 of mlpk_token_mlp_layout: k slot 16 kk + 8 h + e  <-  hidden 16 kk + 8 (e >> 2) + 4 h + (e & 3)).  The hidden never leaves
+the registers.  W1 / W2 groups stream through two 2-stage LDS rings by LDS-DMA one iteration ahead (one barrier per iteration);
+LDS rows are PADDED by 16 bytes (528 / 80-byte pitch) instead of XOR-swizzled: the 16 lanes of a ds_read_b128 group then fall on 16
+different bank quads and a k-step is an immediate offset of the one address register.
+Groups outside [0, G) (pipeline fill and drain) multiply by a zero W2 slab, so they add nothing.
+Epilogue per tile: accumulators + b2 staged as fp32 through LDS, read back as (token, 8 channels) items, residual added in fp32,
+one rounding, 16-byte stores of whole 128-byte lines; optional by-product (sum, sum of squares) per token over the wave's 64
+channels for the LayerNorm that follows (mlpk.h: stats).
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from isa import A, F, S, V, Asm, Neg, Reg  # noqa: E402
+from q4gen import GELU, SQRT2, Alloc  # noqa: E402
+
+KA = dict(xt=0, w1=8, w2=16, b1=24, b2=32, x=40, stats=48, prof=56,
+          M=64, G=68, ldxt=72, ldx=76, ntiles=80, tpi=84, tpi_magic=88, grid=92, stat_ld=96, nit=100, lead=104, S=108)
+ARG_BYTES = 112
+
+W1_PITCH, W1_PIECES = 528, 17            # 32 hidden rows x (512 B + 16): 16896 B
+W2_PITCH, W2_PIECES = 80, 18             # 224 tokens x (64 B + 16): 17920 B
+W1_STAGE, W2_STAGE = W1_PIECES * 1024, W2_PIECES * 1024
+W1_OFF, W2_OFF = 0, 2 * W1_STAGE
+B1_OFF = W2_OFF + 2 * W2_STAGE           # 1024 floats: entry j = bias of hidden j - 64 (two zero groups in front, zeros behind)
+STG_PITCH = 272                          # fp32 staging row: 64 channels + 16 B
+STG_WAVE = 32 * STG_PITCH
+STG_OFF = B1_OFF + 4096
+LDS_BYTES = STG_OFF + 4 * STG_WAVE
+W2_GROUP_BYTES = 224 * 64                # one hidden group of the packed W2: 224 token rows x 32 k slots
+W1_MAGIC, W2_MAGIC = 1986, 13108         # (o * magic) >> 20 == o // pitch for the multiples of 16 below one stage
+assert all((o * W1_MAGIC) >> 20 == o // W1_PITCH for o in range(0, W1_STAGE, 16))
+assert all((o * W2_MAGIC) >> 20 == o // W2_PITCH for o in range(0, W2_STAGE, 16))
+
+
+class T4:
+    NKS, NTB = 14, 7                       # K = 224 = 14 steps of 16; 196 tokens = 7 blocks of 32 (the last one holds 4)
+    NXA = 8                                # X fragments kept in the 32 AGPRs the accumulators leave over
+    DEPTH = 3                              # W fragments read ahead of their MFMAs (ring of 4 register quads)
+
+    def __init__(self, dtype="bf16", stats=False, dbg=0, name=None):
+        # tuning ablations (wrong results by construction): 1 no LDS-DMA, 2 no GELU fillers, 4 no epilogue stores
+        self.dtype, self.stats, self.dbg = dtype, stats, dbg
+        self.name = name or "t4_%s%s" % (dtype, "_st" if stats else "")
+        self.mfma = "v_mfma_f32_32x32x16_bf16" if dtype == "bf16" else "v_mfma_f32_32x32x16_f16"
+        self.cvt = "v_cvt_pk_bf16_f32" if dtype == "bf16" else "v_cvt_pk_f16_f32"
+        self.dot = "v_dot2c_f32_bf16" if dtype == "bf16" else "v_dot2c_f32_f16"
+        self.a = Asm()
+        self.build()
+
+    # ------------------------------------------------------------------ registers
+    def regs(self):
+        s = Alloc("s", 33, 100)
+        v = Alloc("v", 1, 256)
+        self.s_karg, self.s_bid, self.v_tid = S(0, 2), S(2), V(0)
+        self.p = {k: S(4 + 2 * i, 2) for i, k in enumerate(["xt", "w1", "w2", "b1", "b2", "x", "stats", "prof"])}
+        self.k = {k: S(20 + i) for i, k in enumerate(["M", "G", "ldxt", "ldx", "ntiles", "tpi", "tpi_magic", "grid", "stat_ld", "nit", "lead", "S"])}
+        self.s_wave, self.s_tile, self.s_next, self.s_has = s("wave"), s("tile"), s("next"), s("has")
+        self.s_g, self.s_cnt = s("g"), s("cnt")
+        self.s_wv1k, self.s_w2x = s("wv1k"), s("w2x")
+        self.s_w1src, self.s_w2src = s("w1src", 2, 2), s("w2src", 2, 2)
+        self.s_xb = [s("xb%d" % rb, 2, 2) for rb in range(2)]
+        self.s_ocur, self.s_lcur = s("ocur", 2, 2), s("lcur", 2, 2)      # store / residual-load cursors over the token rows of x
+        self.s_scur = s("scur", 2, 2) if self.stats else None
+        self.s_tok8 = s("tok8")
+        self.s_r2 = s("r2")
+        self.s_mask = s("mask", 2, 2)
+        self.s_t = [s("t%d" % i) for i in range(6)]
+        self.s_t64 = s("t64", 2, 2)
+        scale, c = GELU[self.dtype]
+        self.k_scale, self.k_m1, self.k_half = s("kscale", 2, 2), s("km1", 2, 2), s("khalf", 2, 2)
+        self.k_c = [None] + [s("kc%d" % i, 2, 2) for i in range(1, len(c))]
+        self.ns = s.next
+        # vector registers.  AGPRs: D2[rb][tb] at 16 (7 rb + tb); a[224:255] = the last NXA X fragments of row block 1
+        self.X = [[None] * self.NKS for _ in range(2)]
+        na = 0
+        for rb in range(2):
+            for ks in range(self.NKS):
+                if rb == 1 and ks >= self.NKS - self.NXA:
+                    self.X[rb][ks] = A(224 + 4 * na, 4)
+                    na += 1
+                else:
+                    self.X[rb][ks] = v("X%d_%d" % (rb, ks), 4, 2)
+        self.Wf = [v("Wf%d" % b, 4, 2) for b in range(4)]
+        self.b1 = v("b1", 16, 2)
+        self.xg = [[v("xg%d_%d" % (par, rb), 16, 2) for rb in range(2)] for par in range(2)]
+        self.h = [[[v("h%d_%d_%d" % (par, rb, kk), 4, 2) for kk in range(2)] for rb in range(2)] for par in range(2)]
+        self.tmp = [[v("g%s%d" % (n, ch), 2, 2) for n in "tuq"] for ch in range(2)]     # two chains of pairs abreast
+        self.v_c0 = v("c0", 2, 2)
+        self.v_w1rd, self.v_w2rd, self.v_b1rd, self.v_b1h = v("w1rd"), v("w2rd"), v("b1rd"), v("b1h")
+        self.v_w1off = [v("w1off%d" % i) for i in range(5)]
+        self.v_w2off = [v("w2off%d" % i) for i in range(5)]
+        self.v_xoff = v("xoff")
+        self.v_stw, self.v_strd, self.v_ooff, self.v_j4 = v("stw"), v("strd"), v("ooff"), v("j4")
+        self.v_soff = v("soff") if self.stats else None
+        self.nv = v.next
+        # the epilogue lives in registers that are dead by then
+        xg, h = self.xg, self.h
+        self.e_acc = [xg[0][0][4 * i:4 * i + 4] for i in range(4)]
+        self.e_in = [xg[0][1][4 * i:4 * i + 4] for i in range(4)] + [xg[1][0][4 * i:4 * i + 4] for i in range(4)]
+        hb = h[0][0][0].idx
+        self.e_res = [[xg[1][1][4 * i:4 * i + 4] for i in range(4)], [Reg("v", hb + 4 * i, 4) for i in range(4)]]
+        assert h[0][1][1].idx == hb + 12
+        self.e_b2 = [self.Wf[0][0], self.Wf[0][1], self.Wf[0][2], self.Wf[0][3], self.Wf[1][0], self.Wf[1][1], self.Wf[1][2]]
+        self.e_t = self.tmp[0][0]                      # pair: a residual dword as two fp32
+        self.e_sp = self.tmp[0][1]                     # pair: (sum, sum of squares)
+        self.e_ones = self.tmp[0][2][0]
+        self.e_x = [self.tmp[1][0][0], self.tmp[1][0][1], self.tmp[1][1][0], self.tmp[1][1][1]]
+
+    def D2(self, rb, tb):
+        return A(16 * (self.NTB * rb + tb), 16)
+
+    # ------------------------------------------------------------------ helpers
+    def ds(self, op, *args, **kw):
+        self.a(op, *args, **kw)
+        self.lgkm_issued += 1
+        return self.lgkm_issued - 1
+
+    def wait_lds(self, idx):
+        self.a("s_waitcnt", lgkmcnt=min(self.lgkm_issued - idx - 1, 15))
+
+    def vload(self, op, *args, **kw):
+        self.a(op, *args, **kw)
+        self.vm_loads += 1
+        return self.vm_loads - 1
+
+    def wait_vload(self, idx):
+        self.a("s_waitcnt", vmcnt=min(self.vm_loads - idx - 1, 63))
+
+    def add64(self, dst, src, lo, hi=None):
+        self.a("s_add_u32", dst[0], src[0], lo)
+        self.a("s_addc_u32", dst[1], src[1], hi if hi is not None else 0)
+
+    def mul64(self, dst, a_, b_, shift):
+        """dst(64) = (a * b) << shift, 32-bit unsigned factors"""
+        a, t = self.a, self.s_t
+        a("s_mul_hi_u32", dst[1], a_, b_)
+        a("s_mul_i32", dst[0], a_, b_)
+        if shift:
+            a("s_lshl_b32", dst[1], dst[1], shift)
+            a("s_lshr_b32", t[5], dst[0], 32 - shift)
+            a("s_or_b32", dst[1], dst[1], t[5])
+            a("s_lshl_b32", dst[0], dst[0], shift)
+
+    # ------------------------------------------------------------------ GELU of one group as fillers (packed fp32: 2 elements per op)
+    def gelu_ops(self, par_in, par_out):
+        """xg[par_in] (fc1 + b1 of a group, the accumulator layout) -> h[par_out][rb][kk] (A fragments of the second product).
+        The operation sequence of gelu16_f (mlpk_common.h) two elements per instruction, two such chains abreast."""
+        a = self.a
+        ops = []
+
+        def E(*x, **kw):
+            ops.append(lambda: a(*x, **kw))
+        scale, c = GELU[self.dtype]
+        for rb in range(2):
+            for grp in range(4):                      # accumulator registers 4 grp .. 4 grp + 3
+                xs = [self.xg[par_in][rb][4 * grp + 2 * ch:4 * grp + 2 * ch + 2] for ch in range(2)]
+                T = [self.tmp[ch][0] for ch in range(2)]
+                U = [self.tmp[ch][1] for ch in range(2)]
+                Q = [self.tmp[ch][2] for ch in range(2)]
+                for ch in range(2):
+                    E("v_pk_mul_f32", T[ch], xs[ch], self.k_scale)
+                for ch in range(2):
+                    for e in range(2):
+                        E("v_med3_f32", T[ch][e], T[ch][e], Neg(self.s_r2), self.s_r2)
+                for ch in range(2):
+                    E("v_pk_fma_f32", U[ch], T[ch], T[ch], self.k_m1)
+                for ch in range(2):
+                    E("v_pk_fma_f32", Q[ch], U[ch], self.v_c0, self.k_c[1])
+                for kx in range(2, len(c)):
+                    for ch in range(2):
+                        E("v_pk_fma_f32", Q[ch], Q[ch], U[ch], self.k_c[kx])
+                for ch in range(2):
+                    E("v_pk_fma_f32", T[ch], T[ch], Q[ch], self.k_half)
+                for ch in range(2):
+                    E("v_pk_mul_f32", xs[ch], xs[ch], T[ch])
+                # accumulator register 8 kk + e -> A fragment kk, packed pair e >> 1
+                kk, e0 = grp >> 1, 4 * (grp & 1)
+                hreg = self.h[par_out][rb][kk]
+                for ch in range(2):
+                    E(self.cvt, hreg[(e0 >> 1) + ch], xs[ch][0], xs[ch][1])
+        return ops
+
+    # ------------------------------------------------------------------ DMA sources of group index gn (in s_t[0]; may be out of range)
+    def dma_sources(self):
+        a, t, k, p = self.a, self.s_t, self.k, self.p
+        a("s_add_i32", t[1], k["G"], -1)
+        a("s_min_i32", t[3], t[0], t[1])
+        a("s_max_i32", t[3], t[3], 0)                         # any valid W1 group will do outside [0, G): its W2 slab is zero
+        a("s_lshl_b32", t[3], t[3], 14)                       # 32 rows x 512 B
+        self.add64(self.s_w1src, p["w1"], t[3])
+        a("s_add_i32", t[3], t[0], -2)                        # the second product runs two groups behind
+        a("s_cmp_lt_i32", t[3], 0)
+        a("s_cselect_b32", t[3], k["G"], t[3])                # group G of the packed W2 = zeros
+        a("s_mul_i32", t[3], t[3], W2_GROUP_BYTES)
+        self.add64(self.s_w2src, p["w2"], t[3])
+
+    def dma_piece(self, kind, i, stage):
+        """(m0 value as (sgpr, literal), offset register, source) of piece i of this wave"""
+        if kind == "w1":
+            if i < 4:
+                return self.s_wv1k, W1_OFF + stage * W1_STAGE + i * 4096, self.v_w1off[i], self.s_w1src
+            return None, W1_OFF + stage * W1_STAGE + 16384, self.v_w1off[4], self.s_w1src
+        if i < 4:
+            return self.s_wv1k, W2_OFF + stage * W2_STAGE + i * 4096, self.v_w2off[i], self.s_w2src
+        return self.s_w2x, W2_OFF + stage * W2_STAGE + 16384, self.v_w2off[4], self.s_w2src
+
+    def emit_m0(self, kind, i, stage):
+        sg, lit, _, _ = self.dma_piece(kind, i, stage)
+        if sg is None:
+            self.a("s_mov_b32", "m0", lit)
+        else:
+            self.a("s_add_u32", "m0", sg, lit)
+
+    def emit_dma(self, kind, i, stage):
+        _, _, voff, src = self.dma_piece(kind, i, stage)
+        self.a("global_load_lds_dwordx4", voff, src)
+
+    # ------------------------------------------------------------------ one pipeline iteration (static parity)
+    def iteration(self, par):
+        """fc2(g-2) from W2 stage par and h[par]; fc1(g) from W1 stage par into xg[par]; gelu(g-1): xg[1-par] -> h[1-par];
+        LDS-DMA of W1(g+1) / W2(g-1) into the stages 1-par."""
+        a, t, k = self.a, self.s_t, self.k
+        # group of the next iteration (wraps to the first iteration of the next tile)
+        a("s_add_i32", t[0], self.s_g, 1)
+        a("s_add_i32", t[1], k["G"], 2)
+        a("s_sub_u32", t[2], 0, k["lead"])
+        a("s_cmp_ge_i32", t[0], t[1])
+        a("s_cselect_b32", t[0], t[2], t[0])
+        self.dma_sources()
+        a("s_waitcnt", vmcnt=0, lgkmcnt=0)
+        a("s_barrier")
+        self.lgkm_issued = 0
+        fill = [] if (self.dbg & 2) else self.gelu_ops(1 - par, 1 - par)
+        dma = [] if (self.dbg & 1) else [(kind, i) for i in range(5) for kind in ("w1", "w2")]
+        state = {"done": 0, "gap": 0}
+        ngaps, total = 56, len(fill)
+
+        def gap():
+            state["gap"] += 1
+            target = (total * state["gap"] + ngaps - 1) // ngaps
+            while state["done"] < min(target, total):
+                fill[state["done"]]()
+                state["done"] += 1
+
+        def mfma(*margs):
+            if dma:
+                self.emit_m0(dma[0][0], dma[0][1], 1 - par)
+            a(self.mfma, *margs)
+            if dma:
+                kind, i = dma.pop(0)
+                self.emit_dma(kind, i, 1 - par)
+            gap()
+        # the 28 fragment reads of the iteration, in the order of their use
+        frs = [("w2", kk, tb) for kk in range(2) for tb in range(self.NTB)] + [("w1", ks, None) for ks in range(self.NKS)]
+
+        def read(n):
+            kind, x, tb = frs[n]
+            if kind == "w2":
+                return self.ds("ds_read_b128", self.Wf[n & 3], self.v_w2rd, offset=W2_OFF + par * W2_STAGE + tb * 32 * W2_PITCH + x * 32)
+            return self.ds("ds_read_b128", self.Wf[n & 3], self.v_w1rd, offset=W1_OFF + par * W1_STAGE + x * 32)
+        rd = {}
+        for n in range(self.DEPTH):
+            rd[n] = read(n)
+        for n, (kind, x, tb) in enumerate(frs):
+            if n + self.DEPTH < len(frs):
+                rd[n + self.DEPTH] = read(n + self.DEPTH)
+            if n == 6:                           # b1(g): the accumulator initialiser of fc1(g)
+                for qd in range(4):
+                    self.ds("ds_read_b128", self.b1[4 * qd:4 * qd + 4], self.v_b1rd, offset=B1_OFF + 32 * qd)
+            self.wait_lds(rd[n])
+            wf = self.Wf[n & 3]
+            for rb in range(2):
+                if kind == "w2":
+                    mfma(self.D2(rb, tb), self.h[par][rb][x], wf, self.D2(rb, tb))
+                else:
+                    mfma(self.xg[par][rb], wf, self.X[rb][x], self.b1 if x == 0 else self.xg[par][rb])
+        while state["done"] < total:
+            fill[state["done"]]()
+            state["done"] += 1
+        assert not dma
+        a("s_add_i32", self.s_g, self.s_g, 1)
+        a("v_add_u32", self.v_b1rd, 128, self.v_b1rd)
+
+    # ------------------------------------------------------------------ tile geometry
+    def tile_xbase(self, tile):
+        """s_xb[rb] = xt + ((tile * 256 + 64 wave + 32 rb) * ldxt) * 2"""
+        a, t, k = self.a, self.s_t, self.k
+        a("s_lshl_b32", t[0], tile, 8)
+        a("s_lshl_b32", t[1], self.s_wave, 6)
+        a("s_add_u32", t[0], t[0], t[1])
+        self.mul64(self.s_t64, t[0], k["ldxt"], 1)
+        self.add64(self.s_xb[0], self.p["xt"], self.s_t64[0], self.s_t64[1])
+        a("s_lshl_b32", t[0], k["ldxt"], 6)                   # 32 rows
+        self.add64(self.s_xb[1], self.s_xb[0], t[0])
+
+    def x_loads(self):
+        for rb in range(2):
+            for ks in range(self.NKS):
+                self.a("global_load_dwordx4", self.X[rb][ks], self.v_xoff, self.s_xb[rb], offset=32 * ks)
+
+    def tile_scalars(self):
+        """cursors of the tile's 64 channels of this wave: x + ((img * S) * ldx + c0) * 2 and the statistics plane"""
+        a, t, k, p = self.a, self.s_t, self.k, self.p
+        a("s_lshl_b32", t[0], self.s_tile, 1)
+        a("s_mul_hi_u32", t[1], t[0], k["tpi_magic"])         # img = tile / tpi
+        a("s_mul_i32", t[0], t[1], k["tpi"])
+        a("s_sub_u32", t[0], self.s_tile, t[0])
+        a("s_lshl_b32", t[0], t[0], 8)
+        a("s_lshl_b32", t[2], self.s_wave, 6)
+        a("s_add_u32", t[2], t[2], t[0])                      # c0 = first channel of the wave
+        a("s_mul_i32", t[3], t[1], k["S"])                    # first token row of the image
+        self.mul64(self.s_t64, t[3], k["ldx"], 1)
+        a("s_lshl_b32", t[0], t[2], 1)
+        self.add64(self.s_t64, self.s_t64, t[0])
+        self.add64(self.s_ocur, p["x"], self.s_t64[0], self.s_t64[1])
+        a("s_mov_b32", self.s_lcur[0], self.s_ocur[0])
+        a("s_mov_b32", self.s_lcur[1], self.s_ocur[1])
+        if self.stats:
+            a("s_lshr_b32", t[0], t[2], 6)                    # plane of 64 channels
+            self.mul64(self.s_t64, t[0], k["stat_ld"], 2)
+            a("s_lshl_b32", t[0], t[3], 3)                    # (sum, sum of squares) per token row
+            self.add64(self.s_t64, self.s_t64, t[0])
+            self.add64(self.s_scur, p["stats"], self.s_t64[0], self.s_t64[1])
+
+    # ------------------------------------------------------------------ tile epilogue
+    def res_loads(self, tb):
+        """residual of token block tb in the layout of the stores: round r = tokens 8 r + (lane >> 3), 8 channels lane & 7"""
+        a = self.a
+        rec = []
+        rounds = 4 if tb < self.NTB - 1 else 1
+        if rounds == 1:
+            a("s_mov_b64", "exec", self.s_mask)               # tokens 192..195: lanes 0..31 of round 0
+        for r in range(rounds):
+            rec.append(self.vload("global_load_dwordx4", self.e_res[tb & 1][r], self.v_ooff, self.s_lcur))
+            self.add64(self.s_lcur, self.s_lcur, self.s_tok8)
+        if rounds == 1:
+            a("s_mov_b64", "exec", -1)
+        return rec
+
+    def epilogue(self):
+        a, t = self.a, self.s_t
+        self.lgkm_issued = 0
+        self.vm_loads = 0
+        b2l = [self.vload("global_load_dword", self.e_b2[tb], self.v_j4, self.p["b2"], offset=128 * tb) for tb in range(self.NTB)]
+        res = {0: self.res_loads(0)}
+        if self.stats:
+            a("v_mov_b32", self.e_ones, 0x3F803F80 if self.dtype == "bf16" else 0x3C003C00)
+        for tb in range(self.NTB):
+            rounds = 4 if tb < self.NTB - 1 else 1
+            if tb == 0:
+                self.wait_vload(b2l[-1])
+            # accumulators + b2 -> fp32 staging [token][64 channels]
+            for rb in range(2):
+                for q in range(4):
+                    x = self.e_acc[q]
+                    for r in range(4):
+                        a("v_accvgpr_read_b32", x[r], A(16 * (self.NTB * rb + tb) + 4 * q + r))
+                    for r in range(4):
+                        a("v_add_f32", x[r], self.e_b2[tb], x[r])
+                    self.ds("ds_write_b128", self.v_stw, x, offset=128 * rb + 32 * q)
+            if tb + 1 < self.NTB:
+                res[tb + 1] = self.res_loads(tb + 1)
+            a("s_waitcnt", lgkmcnt=0)
+            rds = []
+            for r in range(rounds):
+                self.ds("ds_read_b128", self.e_in[2 * r], self.v_strd, offset=8 * r * STG_PITCH)
+                rds.append(self.ds("ds_read_b128", self.e_in[2 * r + 1], self.v_strd, offset=8 * r * STG_PITCH + 16))
+            for r in range(rounds):
+                self.wait_lds(rds[r])
+                self.wait_vload(res[tb][r])
+                rr = self.e_res[tb & 1][r]
+                for c in range(4):
+                    pin = self.e_in[2 * r + (c >> 1)][2 * (c & 1):2 * (c & 1) + 2]
+                    if self.dtype == "bf16":
+                        a("v_lshlrev_b32", self.e_t[0], 16, rr[c])
+                        a("v_and_b32", self.e_t[1], 0xFFFF0000, rr[c])
+                    else:
+                        a("v_lshrrev_b32", self.e_t[1], 16, rr[c])
+                        a("v_cvt_f32_f16", self.e_t[0], rr[c])
+                        a("v_cvt_f32_f16", self.e_t[1], self.e_t[1])
+                    a("v_pk_add_f32", pin, pin, self.e_t)
+                    a(self.cvt, rr[c], pin[0], pin[1])
+                if self.stats:
+                    sp = self.e_sp
+                    a("v_mov_b32", sp[0], 0)
+                    a("v_mov_b32", sp[1], 0)
+                    for c in range(4):
+                        a(self.dot, sp[0], rr[c], self.e_ones)
+                        a(self.dot, sp[1], rr[c], rr[c])
+                    for n_, mod in enumerate((dict(quad_perm="[1,0,3,2]"), dict(quad_perm="[2,3,0,1]"), dict(row_half_mirror=True))):
+                        a("s_nop", 1 if n_ == 0 else 0)
+                        a("v_add_f32_dpp", sp[0], sp[0], sp[0], **mod, row_mask="0xf", bank_mask="0xf")
+                        a("v_add_f32_dpp", sp[1], sp[1], sp[1], **mod, row_mask="0xf", bank_mask="0xf")
+                    a("s_mov_b32", self.s_t64[0], 0x01010101)
+                    a("s_mov_b32", self.s_t64[1], 0x01010101 if rounds == 4 else 0)
+                    a("s_mov_b64", "exec", self.s_t64)
+                    a("global_store_dwordx2", self.v_soff, sp, self.s_scur)
+                    a("s_mov_b64", "exec", -1)
+                    self.add64(self.s_scur, self.s_scur, 64)
+                if not (self.dbg & 4):
+                    if rounds == 1:
+                        a("s_mov_b64", "exec", self.s_mask)
+                    a("global_store_dwordx4", self.v_ooff, rr, self.s_ocur)
+                    if rounds == 1:
+                        a("s_mov_b64", "exec", -1)
+                self.add64(self.s_ocur, self.s_ocur, self.s_tok8)
+
+    # ------------------------------------------------------------------ the kernel
+    def build(self):
+        a = self.a
+        self.regs()
+        self.lgkm_issued = 0
+        self.vm_loads = 0
+        t, k, p = self.s_t, self.k, self.p
+        scale, c = GELU[self.dtype]
+        L_end, L_tile, L_iter, L_nonext = a.newlabel("END"), a.newlabel("TILE"), a.newlabel("ITER"), a.newlabel("NONEXT")
+        a("s_load_dwordx16", S(4, 16), self.s_karg, 0)
+        a("s_load_dwordx8", S(20, 8), self.s_karg, 64)
+        a("s_load_dwordx4", S(28, 4), self.s_karg, 96)
+        # ---- lane constants (prologue temporaries: the GELU scratch and one staging quad)
+        lane, j, h, l3, l7, x, y, z = (self.tmp[0][0][0], self.tmp[0][0][1], self.tmp[0][1][0], self.tmp[0][1][1], self.tmp[0][2][0],
+                                       self.tmp[0][2][1], self.tmp[1][0][0], self.tmp[1][0][1])
+        a("v_and_b32", lane, 63, self.v_tid)
+        a("v_lshrrev_b32", x, 6, self.v_tid)
+        a("s_nop", 0)
+        a("v_readfirstlane_b32", self.s_wave, x)
+        a("v_and_b32", j, 31, lane)
+        a("v_lshrrev_b32", h, 5, lane)
+        a("v_lshrrev_b32", l3, 3, lane)
+        a("v_and_b32", l7, 7, lane)
+        a("s_mov_b32", self.s_r2, F(SQRT2))
+        for pair, val in [(self.k_scale, scale), (self.k_m1, -1.0), (self.k_half, 0.5)] + [(self.k_c[i], c[i]) for i in range(1, len(c))]:
+            a("s_mov_b32", pair[0], F(val))
+            a("s_mov_b32", pair[1], F(val))
+        a("v_mov_b32", self.v_c0[0], F(c[0]))
+        a("v_mov_b32", self.v_c0[1], F(c[0]))
+        a("s_mov_b32", self.s_mask[0], -1)
+        a("s_mov_b32", self.s_mask[1], 0)
+        a("s_lshl_b32", self.s_wv1k, self.s_wave, 10)
+        a("s_and_b32", self.s_w2x, self.s_wave, 1)
+        a("s_lshl_b32", self.s_w2x, self.s_w2x, 10)
+        a("v_mul_u32_u24", x, W1_PITCH, j)
+        a("v_lshl_add_u32", self.v_w1rd, h, 4, x)
+        a("v_mul_u32_u24", x, W2_PITCH, j)
+        a("v_lshl_add_u32", self.v_w2rd, h, 4, x)
+        a("v_lshlrev_b32", self.v_b1h, 4, h)
+        a("v_lshlrev_b32", self.v_j4, 2, j)
+        # LDS-DMA source offsets: piece -> LDS offset o = piece * 1024 + lane * 16 -> (row, column) of the padded stage -> source byte
+        for i in range(5):
+            for kind, magic, pitch, colmax, rowmax, rshift, dst in (("w1", W1_MAGIC, W1_PITCH, 496, 31, 9, self.v_w1off[i]),
+                                                                    ("w2", W2_MAGIC, W2_PITCH, 48, 223, 6, self.v_w2off[i])):
+                sg, lit, _, _ = self.dma_piece(kind, i, 0)
+                lit -= W1_OFF if kind == "w1" else W2_OFF
+                if sg is None:
+                    a("s_mov_b32", t[0], lit)
+                else:
+                    a("s_add_u32", t[0], sg, lit)
+                a("v_lshl_add_u32", x, lane, 4, t[0])               # o
+                a("v_mul_u32_u24", y, magic, x)
+                a("v_lshrrev_b32", y, 20, y)                        # row = o / pitch
+                a("v_mul_u32_u24", z, pitch, y)
+                a("v_sub_u32", z, x, z)                             # column byte
+                a("v_min_u32", z, colmax, z)                        # the 16 padding bytes re-read the last chunk
+                a("v_min_u32", y, rowmax, y)
+                a("v_lshl_add_u32", dst, y, rshift, z)
+        a("s_waitcnt", lgkmcnt=0)
+        # ---- argument-dependent lane constants
+        a("v_mul_lo_u32", x, j, k["ldxt"])
+        a("v_lshlrev_b32", x, 1, x)
+        a("v_lshl_add_u32", self.v_xoff, h, 4, x)
+        a("s_mul_i32", t[0], self.s_wave, STG_WAVE)
+        a("s_add_u32", t[0], t[0], STG_OFF)
+        a("v_mul_u32_u24", x, STG_PITCH, j)
+        a("v_lshl_add_u32", x, h, 4, x)
+        a("v_add_u32", self.v_stw, t[0], x)
+        a("v_mul_u32_u24", x, STG_PITCH, l3)
+        a("v_lshl_add_u32", x, l7, 5, x)
+        a("v_add_u32", self.v_strd, t[0], x)
+        a("v_mul_lo_u32", x, l3, k["ldx"])
+        a("v_lshlrev_b32", x, 1, x)
+        a("v_lshl_add_u32", self.v_ooff, l7, 4, x)
+        if self.stats:
+            a("v_lshlrev_b32", self.v_soff, 3, l3)
+        a("s_lshl_b32", self.s_tok8, k["ldx"], 4)
+        # ---- the bias table: 4 KiB, 16 bytes per thread
+        a("v_lshlrev_b32", x, 4, self.v_tid)
+        a("global_load_dwordx4", self.e_acc[0], x, p["b1"])
+        a("s_mov_b32", self.s_tile, self.s_bid)
+        a("s_cmp_ge_u32", self.s_tile, k["ntiles"])
+        a("s_waitcnt", vmcnt=0)
+        a("ds_write_b128", x, self.e_acc[0], offset=B1_OFF)
+        a("s_cbranch_scc1", L_end)
+        # ---- the first stages and the first tile's X
+        a("s_sub_u32", t[0], 0, k["lead"])
+        self.dma_sources()
+        if not (self.dbg & 1):
+            for i in range(5):
+                for kind in ("w1", "w2"):
+                    self.emit_m0(kind, i, 0)
+                    a("s_nop", 0)
+                    self.emit_dma(kind, i, 0)
+        self.tile_xbase(self.s_tile)
+        self.x_loads()
+        a.label(L_tile)
+        self.tile_scalars()
+        for r in range(224):
+            a("v_accvgpr_write_b32", A(r), 0)
+        for par in range(2):
+            for rb in range(2):
+                for r in range(16):
+                    a("v_mov_b32", self.xg[par][rb][r], 0)
+                for kk in range(2):
+                    for r in range(4):
+                        a("v_mov_b32", self.h[par][rb][kk][r], 0)
+        a("s_sub_u32", t[0], 2, k["lead"])
+        a("s_lshl_b32", t[0], t[0], 7)
+        a("v_add_u32", self.v_b1rd, t[0], self.v_b1h)
+        a("s_sub_u32", self.s_g, 0, k["lead"])
+        a("s_lshr_b32", self.s_cnt, k["nit"], 1)
+        a.label(L_iter)
+        self.iteration(0)
+        self.iteration(1)
+        a("s_sub_u32", self.s_cnt, self.s_cnt, 1)
+        a("s_cmp_lg_u32", self.s_cnt, 0)
+        a("s_cbranch_scc1", L_iter)
+        # ---- next tile's X (the registers are dead from here on), then the epilogue
+        a("s_add_u32", self.s_next, self.s_tile, k["grid"])
+        a("s_cmp_lt_u32", self.s_next, k["ntiles"])
+        a("s_cselect_b32", self.s_has, 1, 0)
+        a("s_cbranch_scc0", L_nonext)
+        self.tile_xbase(self.s_next)
+        self.x_loads()
+        a.label(L_nonext)
+        self.epilogue()
+        a("s_mov_b32", self.s_tile, self.s_next)
+        a("s_cmp_lg_u32", self.s_has, 0)
+        a("s_cbranch_scc1", L_tile)
+        a.label(L_end)
+        a("s_waitcnt", vmcnt=0, lgkmcnt=0)
+        a("s_endpgm")
+
+
+def variants():
+    out = []
+    for dt in ("bf16", "f16"):
+        for st in (False, True):
+            out.append(dict(dtype=dt, stats=st))
+    for dbg in (1, 2, 4, 3):
+        out.append(dict(dtype="bf16", stats=True, dbg=dbg, name="t4_bf16_st_dbg%d" % dbg))
+    return out
+
+
+def kernel_text(gen):
+    clob = ['"v%d"' % i for i in range(256)] + ['"a%d"' % i for i in range(256)] + ['"s%d"' % i for i in range(100) if i != 32] + ['"vcc"', '"memory"']
+    body = ['"s_mov_b64 s[0:1], %0\\n\\t"', '"s_mov_b32 s2, %1\\n\\t"', '"v_mov_b32 v0, %2\\n\\t"', gen.a.c_string()]
+    return ("extern \"C\" __global__ void __launch_bounds__(256, 1) %s(const mlpk::T4Args args) {\n"
+            "    asm volatile(\n%s\n        :\n        : \"s\"(__builtin_amdgcn_kernarg_segment_ptr()), \"s\"(blockIdx.x), \"v\"(threadIdx.x)\n"
+            "        : %s);\n}\n" % (gen.name, "\n".join(body), ", ".join(clob)))
+
+
+def emit(path):
+    import isa
+    out = ["// GENERATED by csrc/gen/t4gen.py -- do not edit.  One asm block per kernel: every register is named by the generator.\n"]
+    table = []
+    for kw in variants():
+        g = T4(**kw)
+        pr = isa.lint(g.a)
+        if pr:
+            raise RuntimeError("%s: %d hazard lint findings, first: %s" % (g.name, len(pr), pr[0]))
+        out.append(kernel_text(g))
+        table.append((g.name, kw))
+    out.append("namespace mlpk {\nstruct T4Variant { const char* name; const void* fn; int dtype, stats, dbg; };\n"
+               "static const T4Variant kT4Variants[] = {\n")
+    for name, kw in table:
+        out.append("    {\"%s\", reinterpret_cast<const void*>(&%s), %s, %d, %d},\n" %
+                   (name, name, "MLPK_BF16" if kw["dtype"] == "bf16" else "MLPK_F16", kw["stats"], kw.get("dbg", 0)))
+    out.append("};\n}  // namespace mlpk\n")
+    text = "".join(out)
+    if not os.path.exists(path) or open(path).read() != text:
+        with open(path, "w") as f:
+            f.write(text)
+    return len(table)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        print("wrote %d kernels to %s" % (emit(sys.argv[1]), sys.argv[1]))
+    else:
+        import isa
+        g = T4(stats=True)
+        print("instructions:", len(g.a.ins), "vgprs:", g.nv, "sgprs:", g.ns)
+        isa.lint(g.a, verbose=True)
