@@ -178,8 +178,18 @@ int mlpk_token_mlp(int dtype, const void* xt, int ldxt, int M, int S, const void
  *   0  W2 in natural column order (128-row tiles, hidden handed between waves through LDS);
  *   1  inside every group of 32 hidden columns, column slot 8 f + e (f = 0..3, e = 0..7) holds original column
  *      (e < 4 ? 4 f + e : 16 + 4 f + e - 4): the order in which the first product's accumulators already are the second
- *      product's operands, so the hidden never leaves the registers (256-row tiles; S <= 208). */
+ *      product's operands, so the hidden never leaves the registers (256-row tiles; S <= 208);
+ *   2  (ABI 7) the generated one-wave-per-SIMD kernel (csrc/gen/t4gen.py): S == 196, ldxt == 224, t_rows % 256 == 0, nchunks <= 28.
+ *      w2 : ((nchunks + 1) * 224, ldw2 = 32) GROUP-MAJOR -- group g holds 224 token rows (rows >= S zero) of the 32 hidden units
+ *           of group g, k slot 16 kk + 8 h + e (kk, h = 0..1, e = 0..7) = hidden 16 kk + 8 (e >> 2) + 4 h + (e & 3); group nchunks
+ *           is all zeros (what the pipeline's fill iterations multiply by);
+ *      b1 : 1024 floats, entry 64 + t = bias of hidden unit t, zeros elsewhere;   b2 : 224 floats, zeros behind S;
+ *      MLPK_BF16 only: w1 and b1 carry a factor 1/4 and w2 a factor 4 (powers of two, applied to the ROUNDED weights: every
+ *      product is the unscaled one times a power of two) -- the kernel's GELU polynomial takes x / 4;
+ *      stats: planes of 64 channels (t_rows / 64 planes of B*S pairs) instead of 128.
+ * mlpk_token_mlp_layout_for additionally knows the channels per image and answers 2 when the generated kernel takes the shape. */
 int mlpk_token_mlp_layout(int S, int nchunks);
+int mlpk_token_mlp_layout_for(int dtype, int S, int nchunks, int t_rows);
 
 /* ---- single token-mixing product with the per-image transpose in the epilogue -----------------------------------------------
  * out[b,t,c] = R[b,t,c] (+ | *) rscale[c] * ( sum_s W[t,s] * xt[b*t_rows + c, s] + bias[t] )     (res_mode ADD | MUL; NONE: no R)

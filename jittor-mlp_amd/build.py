@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmlpk.so")
-SOURCES = ["mlpk_gemm.hip", "mlpk_gemm_q4.hip", "mlpk_norm.hip", "mlpk_embed.hip", "mlpk_remap.hip", "mlpk_tokenmlp.hip", "mlpk_dwconv.hip", "mlpk_hire.hip"]
+SOURCES = ["mlpk_gemm.hip", "mlpk_gemm_q4.hip", "mlpk_norm.hip", "mlpk_embed.hip", "mlpk_remap.hip", "mlpk_tokenmlp.hip", "mlpk_tokenmlp_t4.hip", "mlpk_dwconv.hip", "mlpk_hire.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
 FLAGS += os.environ.get("MLPK_EXTRA_FLAGS", "").split()      # tuning aid: A/B builds of a kernel variant (-DTM_...)
 
@@ -42,13 +42,14 @@ GEN_OUT = os.path.join(CSRC, "gen_out")
 def _generate():
     """run the kernel generators (csrc/gen/*.py -> csrc/gen_out/*.inc, git-ignored: the generators are the source)"""
     os.makedirs(GEN_OUT, exist_ok=True)
-    out = os.path.join(GEN_OUT, "q4_kernels.inc")
-    srcs = [os.path.join(GEN, f) for f in ("q4gen.py", "isa.py")]
-    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(x) for x in srcs):
-        return
-    r = subprocess.run([sys.executable, os.path.join(GEN, "q4gen.py"), out], capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("q4gen failed:\n" + r.stderr[-4000:])
+    for gen, inc in (("q4gen.py", "q4_kernels.inc"), ("t4gen.py", "t4_kernels.inc")):
+        out = os.path.join(GEN_OUT, inc)
+        srcs = [os.path.join(GEN, f) for f in (gen, "q4gen.py", "isa.py")]
+        if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(x) for x in srcs):
+            continue
+        r = subprocess.run([sys.executable, os.path.join(GEN, gen), out], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("%s failed:\n" % gen + r.stderr[-4000:])
 
 
 def _deps():

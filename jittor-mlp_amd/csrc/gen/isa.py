@@ -390,6 +390,11 @@ class Emu:
         w.scc = 1 if b > a else 0
         self.wrs(w, i.args[0], a - b)
 
+    def x_s_subb_u32(self, w, i):
+        r = self.rds(w, i.args[1]) - self.rds(w, i.args[2]) - w.scc
+        w.scc = 1 if r < 0 else 0
+        self.wrs(w, i.args[0], r)
+
     def x_s_add_i32(self, w, i):
         r = self.rds(w, i.args[1]) + self.rds(w, i.args[2])
         self.wrs(w, i.args[0], r)
@@ -934,6 +939,10 @@ def lint(asm, mfma_gap=16, verbose=False):
                 o = o.r
             if isinstance(o, Reg) and o.n >= 2 and o.kind in ("v", "a", "s") and o.idx % 2:
                 problems.append((k, "register tuple %s is not 64-bit aligned" % o.text()))
+        if i.op.startswith("ds_") and not 0 <= i.mods.get("offset", 0) < 65536:
+            problems.append((k, "DS offset %d does not fit 16 bits" % i.mods["offset"]))
+        if i.op.startswith("global_") and not -4096 <= i.mods.get("offset", 0) < 4096:
+            problems.append((k, "global offset %d does not fit 13 signed bits" % i.mods["offset"]))
         d, u = defs_uses(i)
         is_mfma = i.op.startswith("v_mfma")
         is_valu = i.op.startswith("v_") and not is_mfma

@@ -43,6 +43,11 @@ STG_WAVE = 32 * STG_PITCH
 STG_OFF = B1_OFF + 4096
 LDS_BYTES = STG_OFF + 4 * STG_WAVE
 W2_GROUP_BYTES = 224 * 64                # one hidden group of the packed W2: 224 token rows x 32 k slots
+# bf16: Phi(x) ~= 0.5 + t P(t^2), t = clamp(x / 4, -1, 1) (tools/fit_gelu_poly.py 4.0 K folded: the fit of MLPK_GELUP_*_BF16 in the
+# variable x / 4; |gelu error| < 9e-5 on |x| <= 4 and < 6e-5 |x| beyond for K = 8, 4.2e-4 / 1.1e-4 |x| for K = 7)
+GELU_FOLDED = {8: [-1.69735634, 8.16789436, -17.2002811, 21.1464729, -17.1737804, 9.89683151, -4.23522425, 1.59539008],
+               7: [1.88985848, -7.93517828, 14.2057104, -14.4012365, 9.33166599, -4.18485498, 1.59410763]}
+FOLD = 0.25                              # what the host multiplies W1 and b1 by for bf16 (and W2 by 1 / FOLD)
 W1_MAGIC, W2_MAGIC = 1986, 13108         # (o * magic) >> 20 == o // pitch for the multiples of 16 below one stage
 assert all((o * W1_MAGIC) >> 20 == o // W1_PITCH for o in range(0, W1_STAGE, 16))
 assert all((o * W2_MAGIC) >> 20 == o // W2_PITCH for o in range(0, W2_STAGE, 16))
@@ -54,12 +59,16 @@ class T4:
     DEPTH = 3                              # W fragments read ahead of their MFMAs (ring of 4 register quads)
 
     def __init__(self, dtype="bf16", stats=False, dbg=0, name=None):
-        # tuning ablations (wrong results by construction): 1 no LDS-DMA, 2 no GELU fillers, 4 no epilogue stores
+        # tuning ablations (wrong results by construction): 1 no LDS-DMA, 2 no GELU fillers, 4 no epilogue stores, 16 no residual loads,
+        # 32 no X loads; 8: the 7-coefficient polynomial
         self.dtype, self.stats, self.dbg = dtype, stats, dbg
         self.name = name or "t4_%s%s" % (dtype, "_st" if stats else "")
         self.mfma = "v_mfma_f32_32x32x16_bf16" if dtype == "bf16" else "v_mfma_f32_32x32x16_f16"
         self.cvt = "v_cvt_pk_bf16_f32" if dtype == "bf16" else "v_cvt_pk_f16_f32"
         self.dot = "v_dot2c_f32_bf16" if dtype == "bf16" else "v_dot2c_f32_f16"
+        # bf16: argument scale folded into the weights (see gelu_ops); dbg 8: the 7-coefficient polynomial (tuning)
+        self.folded = dtype == "bf16"
+        self.coefs = GELU_FOLDED[7 if (dbg & 8) else 8] if self.folded else GELU[dtype][1]
         self.a = Asm()
         self.build()
 
@@ -82,9 +91,7 @@ class T4:
         self.s_mask = s("mask", 2, 2)
         self.s_t = [s("t%d" % i) for i in range(6)]
         self.s_t64 = s("t64", 2, 2)
-        scale, c = GELU[self.dtype]
-        self.k_scale, self.k_m1, self.k_half = s("kscale", 2, 2), s("km1", 2, 2), s("khalf", 2, 2)
-        self.k_c = [None] + [s("kc%d" % i, 2, 2) for i in range(1, len(c))]
+        self.s_prof0 = s("prof0", 2, 2)
         self.ns = s.next
         # vector registers.  AGPRs: D2[rb][tb] at 16 (7 rb + tb); a[224:255] = the last NXA X fragments of row block 1
         self.X = [[None] * self.NKS for _ in range(2)]
@@ -100,14 +107,17 @@ class T4:
         self.b1 = v("b1", 16, 2)
         self.xg = [[v("xg%d_%d" % (par, rb), 16, 2) for rb in range(2)] for par in range(2)]
         self.h = [[[v("h%d_%d_%d" % (par, rb, kk), 4, 2) for kk in range(2)] for rb in range(2)] for par in range(2)]
-        self.tmp = [[v("g%s%d" % (n, ch), 2, 2) for n in "tuq"] for ch in range(2)]     # two chains of pairs abreast
-        self.v_c0 = v("c0", 2, 2)
-        self.v_w1rd, self.v_w2rd, self.v_b1rd, self.v_b1h = v("w1rd"), v("w2rd"), v("b1rd"), v("b1h")
+        self.tmp = [[v("g%s%d" % (n, ch), 2, 2) for n in "tuq"] for ch in range(2)]     # GELU scratch: 4 chains x (t, u, q)
+        flat = [r_[e] for grp_ in self.tmp for r_ in grp_ for e in range(2)]
+        self.tmp_t, self.tmp_u, self.tmp_q = flat[0:4], flat[4:8], flat[8:12]
+        self.v_c0 = v("c0")
+        self.v_w1rd, self.v_w2rd, self.v_b1rd = v("w1rd"), v("w2rd"), v("b1rd")
         self.v_w1off = [v("w1off%d" % i) for i in range(5)]
         self.v_w2off = [v("w2off%d" % i) for i in range(5)]
         self.v_xoff = v("xoff")
-        self.v_stw, self.v_strd, self.v_ooff, self.v_j4 = v("stw"), v("strd"), v("ooff"), v("j4")
+        self.v_stw, self.v_strd, self.v_ooff = v("stw"), v("strd"), v("ooff")
         self.v_soff = v("soff") if self.stats else None
+        self.v_b2 = [v("b2_%d" % tb) for tb in range(self.NTB)]        # b2 of token 32 tb + (lane & 31): what D2 starts from
         self.nv = v.next
         # the epilogue lives in registers that are dead by then
         xg, h = self.xg, self.h
@@ -116,7 +126,6 @@ class T4:
         hb = h[0][0][0].idx
         self.e_res = [[xg[1][1][4 * i:4 * i + 4] for i in range(4)], [Reg("v", hb + 4 * i, 4) for i in range(4)]]
         assert h[0][1][1].idx == hb + 12
-        self.e_b2 = [self.Wf[0][0], self.Wf[0][1], self.Wf[0][2], self.Wf[0][3], self.Wf[1][0], self.Wf[1][1], self.Wf[1][2]]
         self.e_t = self.tmp[0][0]                      # pair: a residual dword as two fp32
         self.e_sp = self.tmp[0][1]                     # pair: (sum, sum of squares)
         self.e_ones = self.tmp[0][2][0]
@@ -157,43 +166,51 @@ class T4:
             a("s_or_b32", dst[1], dst[1], t[5])
             a("s_lshl_b32", dst[0], dst[0], shift)
 
-    # ------------------------------------------------------------------ GELU of one group as fillers (packed fp32: 2 elements per op)
+    # ------------------------------------------------------------------ GELU of one group as fillers
     def gelu_ops(self, par_in, par_out):
         """xg[par_in] (fc1 + b1 of a group, the accumulator layout) -> h[par_out][rb][kk] (A fragments of the second product).
-        The operation sequence of gelu16_f (mlpk_common.h) two elements per instruction, two such chains abreast."""
+        Plain fp32 VALU operations, four independent chains abreast: v_pk_*_f32 would halve the count but does not overlap with
+        the matrix pipe (one v_pk_fma_f32 between two MFMAs costs 17 cycles, tools/ubench/q4_slots.py, profiles/r03_t4_issue_slots.txt).
+        bf16: the host folds the argument scale 1/4 into W1 and b1 (and 4 into W2 -- powers of two, exact), so the first product
+        delivers s = x / 4 and    h / 4 = s * (0.5 + t P(t^2)),  t = clamp(s, -1, 1)      10 (11) operations per element;
+        f16: the operation sequence of gelu16_f (mlpk_common.h), 15 per element."""
         a = self.a
         ops = []
 
         def E(*x, **kw):
             ops.append(lambda: a(*x, **kw))
-        scale, c = GELU[self.dtype]
+        T, U, Q = self.tmp_t, self.tmp_u, self.tmp_q
         for rb in range(2):
             for grp in range(4):                      # accumulator registers 4 grp .. 4 grp + 3
-                xs = [self.xg[par_in][rb][4 * grp + 2 * ch:4 * grp + 2 * ch + 2] for ch in range(2)]
-                T = [self.tmp[ch][0] for ch in range(2)]
-                U = [self.tmp[ch][1] for ch in range(2)]
-                Q = [self.tmp[ch][2] for ch in range(2)]
-                for ch in range(2):
-                    E("v_pk_mul_f32", T[ch], xs[ch], self.k_scale)
-                for ch in range(2):
-                    for e in range(2):
-                        E("v_med3_f32", T[ch][e], T[ch][e], Neg(self.s_r2), self.s_r2)
-                for ch in range(2):
-                    E("v_pk_fma_f32", U[ch], T[ch], T[ch], self.k_m1)
-                for ch in range(2):
-                    E("v_pk_fma_f32", Q[ch], U[ch], self.v_c0, self.k_c[1])
+                x = [self.xg[par_in][rb][4 * grp + r] for r in range(4)]
+                if self.folded:
+                    c = self.coefs
+                    for r in range(4):
+                        E("v_med3_f32", T[r], x[r], F(-1.0), F(1.0))
+                    for r in range(4):
+                        E("v_mul_f32", U[r], T[r], T[r])
+                else:
+                    scale, c = GELU[self.dtype]
+                    for r in range(4):
+                        E("v_mul_f32", T[r], F(scale), x[r])
+                    for r in range(4):
+                        E("v_med3_f32", T[r], T[r], Neg(self.s_r2), self.s_r2)
+                    for r in range(4):
+                        E("v_fma_f32", U[r], T[r], T[r], F(-1.0))
+                for r in range(4):
+                    E("v_fmaak_f32", Q[r], U[r], self.v_c0, F(c[1]))
                 for kx in range(2, len(c)):
-                    for ch in range(2):
-                        E("v_pk_fma_f32", Q[ch], Q[ch], U[ch], self.k_c[kx])
-                for ch in range(2):
-                    E("v_pk_fma_f32", T[ch], T[ch], Q[ch], self.k_half)
-                for ch in range(2):
-                    E("v_pk_mul_f32", xs[ch], xs[ch], T[ch])
+                    for r in range(4):
+                        E("v_fmaak_f32", Q[r], Q[r], U[r], F(c[kx]))
+                for r in range(4):
+                    E("v_fma_f32", T[r], T[r], Q[r], F(0.5))
+                for r in range(4):
+                    E("v_mul_f32", x[r], x[r], T[r])
                 # accumulator register 8 kk + e -> A fragment kk, packed pair e >> 1
                 kk, e0 = grp >> 1, 4 * (grp & 1)
                 hreg = self.h[par_out][rb][kk]
-                for ch in range(2):
-                    E(self.cvt, hreg[(e0 >> 1) + ch], xs[ch][0], xs[ch][1])
+                E(self.cvt, hreg[e0 >> 1], x[0], x[1])
+                E(self.cvt, hreg[(e0 >> 1) + 1], x[2], x[3])
         return ops
 
     # ------------------------------------------------------------------ DMA sources of group index gn (in s_t[0]; may be out of range)
@@ -272,7 +289,7 @@ class T4:
         def read(n):
             kind, x, tb = frs[n]
             if kind == "w2":
-                return self.ds("ds_read_b128", self.Wf[n & 3], self.v_w2rd, offset=W2_OFF + par * W2_STAGE + tb * 32 * W2_PITCH + x * 32)
+                return self.ds("ds_read_b128", self.Wf[n & 3], self.v_w2rd, offset=par * W2_STAGE + tb * 32 * W2_PITCH + x * 32)
             return self.ds("ds_read_b128", self.Wf[n & 3], self.v_w1rd, offset=W1_OFF + par * W1_STAGE + x * 32)
         rd = {}
         for n in range(self.DEPTH):
@@ -282,7 +299,7 @@ class T4:
                 rd[n + self.DEPTH] = read(n + self.DEPTH)
             if n == 6:                           # b1(g): the accumulator initialiser of fc1(g)
                 for qd in range(4):
-                    self.ds("ds_read_b128", self.b1[4 * qd:4 * qd + 4], self.v_b1rd, offset=B1_OFF + 32 * qd)
+                    self.ds("ds_read_b128", self.b1[4 * qd:4 * qd + 4], self.v_b1rd, offset=32 * qd)
             self.wait_lds(rd[n])
             wf = self.Wf[n & 3]
             for rb in range(2):
@@ -310,6 +327,8 @@ class T4:
         self.add64(self.s_xb[1], self.s_xb[0], t[0])
 
     def x_loads(self):
+        if self.dbg & 32:
+            return
         for rb in range(2):
             for ks in range(self.NKS):
                 self.a("global_load_dwordx4", self.X[rb][ks], self.v_xoff, self.s_xb[rb], offset=32 * ks)
@@ -347,6 +366,9 @@ class T4:
         if rounds == 1:
             a("s_mov_b64", "exec", self.s_mask)               # tokens 192..195: lanes 0..31 of round 0
         for r in range(rounds):
+            if self.dbg & 16:
+                rec.append(self.vm_loads - 1)
+                continue
             rec.append(self.vload("global_load_dwordx4", self.e_res[tb & 1][r], self.v_ooff, self.s_lcur))
             self.add64(self.s_lcur, self.s_lcur, self.s_tok8)
         if rounds == 1:
@@ -357,22 +379,17 @@ class T4:
         a, t = self.a, self.s_t
         self.lgkm_issued = 0
         self.vm_loads = 0
-        b2l = [self.vload("global_load_dword", self.e_b2[tb], self.v_j4, self.p["b2"], offset=128 * tb) for tb in range(self.NTB)]
         res = {0: self.res_loads(0)}
         if self.stats:
             a("v_mov_b32", self.e_ones, 0x3F803F80 if self.dtype == "bf16" else 0x3C003C00)
         for tb in range(self.NTB):
             rounds = 4 if tb < self.NTB - 1 else 1
-            if tb == 0:
-                self.wait_vload(b2l[-1])
-            # accumulators + b2 -> fp32 staging [token][64 channels]
+            # accumulators (started from b2) -> fp32 staging [token][64 channels]
             for rb in range(2):
                 for q in range(4):
                     x = self.e_acc[q]
                     for r in range(4):
                         a("v_accvgpr_read_b32", x[r], A(16 * (self.NTB * rb + tb) + 4 * q + r))
-                    for r in range(4):
-                        a("v_add_f32", x[r], self.e_b2[tb], x[r])
                     self.ds("ds_write_b128", self.v_stw, x, offset=128 * rb + 32 * q)
             if tb + 1 < self.NTB:
                 res[tb + 1] = self.res_loads(tb + 1)
@@ -428,7 +445,6 @@ class T4:
         self.lgkm_issued = 0
         self.vm_loads = 0
         t, k, p = self.s_t, self.k, self.p
-        scale, c = GELU[self.dtype]
         L_end, L_tile, L_iter, L_nonext = a.newlabel("END"), a.newlabel("TILE"), a.newlabel("ITER"), a.newlabel("NONEXT")
         a("s_load_dwordx16", S(4, 16), self.s_karg, 0)
         a("s_load_dwordx8", S(20, 8), self.s_karg, 64)
@@ -445,11 +461,7 @@ class T4:
         a("v_lshrrev_b32", l3, 3, lane)
         a("v_and_b32", l7, 7, lane)
         a("s_mov_b32", self.s_r2, F(SQRT2))
-        for pair, val in [(self.k_scale, scale), (self.k_m1, -1.0), (self.k_half, 0.5)] + [(self.k_c[i], c[i]) for i in range(1, len(c))]:
-            a("s_mov_b32", pair[0], F(val))
-            a("s_mov_b32", pair[1], F(val))
-        a("v_mov_b32", self.v_c0[0], F(c[0]))
-        a("v_mov_b32", self.v_c0[1], F(c[0]))
+        a("v_mov_b32", self.v_c0, F(self.coefs[0]))
         a("s_mov_b32", self.s_mask[0], -1)
         a("s_mov_b32", self.s_mask[1], 0)
         a("s_lshl_b32", self.s_wv1k, self.s_wave, 10)
@@ -459,8 +471,9 @@ class T4:
         a("v_lshl_add_u32", self.v_w1rd, h, 4, x)
         a("v_mul_u32_u24", x, W2_PITCH, j)
         a("v_lshl_add_u32", self.v_w2rd, h, 4, x)
-        a("v_lshlrev_b32", self.v_b1h, 4, h)
-        a("v_lshlrev_b32", self.v_j4, 2, j)
+        a("v_add_u32", self.v_w2rd, W2_OFF, self.v_w2rd)          # (DS offsets are 16 bits: the region bases live in the registers)
+        a("v_lshlrev_b32", self.v_b1rd, 4, h)
+        a("v_add_u32", self.v_b1rd, B1_OFF, self.v_b1rd)             # + 128 (group + 2) at the start of a tile, walks back at its end
         # LDS-DMA source offsets: piece -> LDS offset o = piece * 1024 + lane * 16 -> (row, column) of the padded stage -> source byte
         for i in range(5):
             for kind, magic, pitch, colmax, rowmax, rshift, dst in (("w1", W1_MAGIC, W1_PITCH, 496, 31, 9, self.v_w1off[i]),
@@ -480,6 +493,7 @@ class T4:
                 a("v_min_u32", y, rowmax, y)
                 a("v_lshl_add_u32", dst, y, rshift, z)
         a("s_waitcnt", lgkmcnt=0)
+        a("s_memtime", self.s_prof0)
         # ---- argument-dependent lane constants
         a("v_mul_lo_u32", x, j, k["ldxt"])
         a("v_lshlrev_b32", x, 1, x)
@@ -503,9 +517,13 @@ class T4:
         a("global_load_dwordx4", self.e_acc[0], x, p["b1"])
         a("s_mov_b32", self.s_tile, self.s_bid)
         a("s_cmp_ge_u32", self.s_tile, k["ntiles"])
+        a("v_add_u32", x, B1_OFF, x)
         a("s_waitcnt", vmcnt=0)
-        a("ds_write_b128", x, self.e_acc[0], offset=B1_OFF)
+        a("ds_write_b128", x, self.e_acc[0])
         a("s_cbranch_scc1", L_end)
+        a("v_lshlrev_b32", y, 2, j)
+        for tb in range(self.NTB):
+            a("global_load_dword", self.v_b2[tb], y, p["b2"], offset=128 * tb)
         # ---- the first stages and the first tile's X
         a("s_sub_u32", t[0], 0, k["lead"])
         self.dma_sources()
@@ -517,10 +535,16 @@ class T4:
                     self.emit_dma(kind, i, 0)
         self.tile_xbase(self.s_tile)
         self.x_loads()
+        a("s_sub_u32", t[0], 2, k["lead"])
+        a("s_lshl_b32", t[0], t[0], 7)
+        a("v_add_u32", self.v_b1rd, t[0], self.v_b1rd)              # bias row of the first iteration's group
+        a("s_waitcnt", vmcnt=0 if (self.dbg & 33) else 38)           # b2 (the loads before the 10 DMA pieces and 28 X quads)
         a.label(L_tile)
         self.tile_scalars()
-        for r in range(224):
-            a("v_accvgpr_write_b32", A(r), 0)
+        for rb in range(2):
+            for tb in range(self.NTB):
+                for r in range(16):
+                    a("v_accvgpr_write_b32", A(16 * (self.NTB * rb + tb) + r), self.v_b2[tb])
         for par in range(2):
             for rb in range(2):
                 for r in range(16):
@@ -528,9 +552,6 @@ class T4:
                 for kk in range(2):
                     for r in range(4):
                         a("v_mov_b32", self.h[par][rb][kk][r], 0)
-        a("s_sub_u32", t[0], 2, k["lead"])
-        a("s_lshl_b32", t[0], t[0], 7)
-        a("v_add_u32", self.v_b1rd, t[0], self.v_b1h)
         a("s_sub_u32", self.s_g, 0, k["lead"])
         a("s_lshr_b32", self.s_cnt, k["nit"], 1)
         a.label(L_iter)
@@ -539,6 +560,8 @@ class T4:
         a("s_sub_u32", self.s_cnt, self.s_cnt, 1)
         a("s_cmp_lg_u32", self.s_cnt, 0)
         a("s_cbranch_scc1", L_iter)
+        a("s_lshl_b32", t[0], k["nit"], 7)
+        a("v_sub_u32", self.v_b1rd, self.v_b1rd, t[0])              # back to the first iteration's bias row
         # ---- next tile's X (the registers are dead from here on), then the epilogue
         a("s_add_u32", self.s_next, self.s_tile, k["grid"])
         a("s_cmp_lt_u32", self.s_next, k["ntiles"])
@@ -552,6 +575,21 @@ class T4:
         a("s_cmp_lg_u32", self.s_has, 0)
         a("s_cbranch_scc1", L_tile)
         a.label(L_end)
+        # tuning: shader cycles of this workgroup -> prof[bid] (mlpk_token_mlp_debug), skipped when the pointer is null
+        L_noprof = a.newlabel("NOPROF")
+        a("s_memtime", self.s_t64)
+        a("s_or_b32", t[0], p["prof"][0], p["prof"][1])
+        a("s_cmp_eq_u32", t[0], 0)
+        a("s_cbranch_scc1", L_noprof)
+        a("s_waitcnt", lgkmcnt=0)
+        a("s_sub_u32", self.s_t64[0], self.s_t64[0], self.s_prof0[0])
+        a("s_subb_u32", self.s_t64[1], self.s_t64[1], self.s_prof0[1])
+        a("s_lshl_b32", t[0], self.s_bid, 3)
+        a("v_mov_b32", self.e_t[0], self.s_t64[0])
+        a("v_mov_b32", self.e_t[1], self.s_t64[1])
+        a("v_mov_b32", self.e_sp[0], t[0])
+        a("global_store_dwordx2", self.e_sp[0], self.e_t, p["prof"])
+        a.label(L_noprof)
         a("s_waitcnt", vmcnt=0, lgkmcnt=0)
         a("s_endpgm")
 
@@ -561,13 +599,14 @@ def variants():
     for dt in ("bf16", "f16"):
         for st in (False, True):
             out.append(dict(dtype=dt, stats=st))
-    for dbg in (1, 2, 4, 3):
+    for dbg in (1, 2, 4, 3, 8, 16, 32, 48, 52):
         out.append(dict(dtype="bf16", stats=True, dbg=dbg, name="t4_bf16_st_dbg%d" % dbg))
     return out
 
 
 def kernel_text(gen):
-    clob = ['"v%d"' % i for i in range(256)] + ['"a%d"' % i for i in range(256)] + ['"s%d"' % i for i in range(100) if i != 32] + ['"vcc"', '"memory"']
+    assert gen.nv <= 248, "the compiler needs a few VGPRs of its own (the thread id operand, WWM)"
+    clob = ['"v%d"' % i for i in range(gen.nv)] + ['"a%d"' % i for i in range(256)] + ['"s%d"' % i for i in range(gen.ns) if i != 32] + ['"vcc"', '"memory"']
     body = ['"s_mov_b64 s[0:1], %0\\n\\t"', '"s_mov_b32 s2, %1\\n\\t"', '"v_mov_b32 v0, %2\\n\\t"', gen.a.c_string()]
     return ("extern \"C\" __global__ void __launch_bounds__(256, 1) %s(const mlpk::T4Args args) {\n"
             "    asm volatile(\n%s\n        :\n        : \"s\"(__builtin_amdgcn_kernarg_segment_ptr()), \"s\"(blockIdx.x), \"v\"(threadIdx.x)\n"

@@ -27,6 +27,7 @@
 //     requested before the passes, which then issue nothing but stores.
 // LDS: 48 (W1 ring) + 48 (W2 ring) + 16 (H, double-buffered) + 32 (acc1 exchange / epilogue staging) + 4 (b1) + 0.9 (b2) = 149 KiB.
 #include "mlpk_common.h"
+#include "mlpk_tokenmlp_t4.h"
 #include <cstdlib>
 
 namespace mlpk {
@@ -1031,13 +1032,34 @@ extern "C" int mlpk_token_mlp_layout(int S, int nchunks) {
     return (S <= 16 * T2_NB && nchunks * 32 <= TM_B1_FLOATS) ? 1 : 0;
 }
 
+// 2 when the generated one-wave-per-SIMD kernel (mlpk_tokenmlp_t4.hip) takes the shape, else mlpk_token_mlp_layout's answer.
+extern "C" int mlpk_token_mlp_layout_for(int dtype, int S, int nchunks, int t_rows) {
+    const char* e = getenv("MLPK_TOKEN_MLP_LAYOUT");
+    if (e && (e[0] == '0' || e[0] == '1')) return mlpk_token_mlp_layout(S, nchunks);
+    if (t4_supported(dtype, S, nchunks, ((S + 31) / 32) * 32, t_rows, t_rows, t_rows)) return 2;
+    return mlpk_token_mlp_layout(S, nchunks);
+}
+
 extern "C" int mlpk_token_mlp(int dtype, const void* xt, int ldxt, int M, int S, const void* w1, int ldw1, const float* b1,
                               const void* w2, int ldw2, const float* b2, int nchunks, void* x, int ldx, int t_rows,
                               float* stats, int layout, void* stream) {
     if (!xt || !w1 || !w2 || !b1 || !b2 || !x) return MLPK_ENULL;
     if (dtype != MLPK_F16 && dtype != MLPK_BF16) return MLPK_EDTYPE;   // 16-bit storage only (fp32 uses the two-GEMM path)
     if (M <= 0 || S <= 0 || nchunks <= 0 || t_rows <= 0) return MLPK_ESHAPE;
-    if (layout != 0 && layout != 1) return MLPK_EMODE;
+    if (layout != 0 && layout != 1 && layout != 2) return MLPK_EMODE;
+    if (layout == 2) {
+        // generated kernel: W2 group-major ((nchunks + 1) * 224 rows of 32 k slots), b1 / b2 as padded tables (mlpk.h)
+        if (ldw1 != 256 || ldw2 != 32) return MLPK_ESHAPE;
+        if (!t4_supported(dtype, S, nchunks, ldxt, M, t_rows, ldx)) return MLPK_ESHAPE;
+        if (stats && ((uintptr_t)stats & 7)) return MLPK_ESHAPE;
+        if (((uintptr_t)xt & 15) || ((uintptr_t)w1 & 15) || ((uintptr_t)w2 & 15) || ((uintptr_t)x & 15) || ((uintptr_t)b1 & 15)) return MLPK_EALIGN;
+        T4Call c;
+        c.dtype = dtype; c.M = M; c.S = S; c.G = nchunks; c.ldxt = ldxt; c.ldx = ldx; c.t_rows = t_rows;
+        c.xt = xt; c.w1 = w1; c.w2 = w2; c.b1 = b1; c.b2 = b2; c.x = x; c.stats = stats; c.prof = g_tm_dbg;
+        const char* d = getenv("MLPK_T4_DBG");
+        c.dbg = d ? atoi(d) : 0;
+        return t4_launch(c, reinterpret_cast<hipStream_t>(stream));
+    }
     if (S > 16 * (TM_NB0 + TM_NB1) || nchunks * 32 > TM_B1_FLOATS) return MLPK_ESHAPE;  // up to 224 tokens, 1024 hidden
     if (ldxt % 32 || ldxt > 32 * TM_KMAX || ldxt < S) return MLPK_ESHAPE;       // K of fc1 = ldxt: whole 64-byte slabs, <= 7
     if (ldw1 != 256 || ldw2 < nchunks * 32 || ldw2 % 8) return MLPK_ESHAPE;

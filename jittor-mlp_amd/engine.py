@@ -272,9 +272,15 @@ def token_gemm(xt, ldxt, M, S, wp, bp, ng, out, ldo, t_rows, *, R=None, ldr=0, r
                                     ptr(R), ldr, res, ptr(out), ldo, t_rows, stream()), "mlpk_token_gemm")
 
 
-def pack_token_mlp(w1, b1, w2, b2, dtype, device, sp, layout=None):
+def token_mlp_stat_planes(C, layout):
+    """planes of mlpk_token_mlp's `stats` buffer: one per 128 channels, one per 64 for the generated kernel (layout 2)"""
+    return C // 64 if layout == 2 else C // 128
+
+
+def pack_token_mlp(w1, b1, w2, b2, dtype, device, sp, layout=None, t_rows=None):
     """Weights of the fused token-mixing kernel: W1 rows / b1 / W2 columns zero-padded to whole hidden groups
-    of mlpk_token_mlp_chunk() = 32, W1's K axis zero-padded to 256 (8 LDS planes per group)."""
+    of mlpk_token_mlp_chunk() = 32, W1's K axis zero-padded to 256 (8 LDS planes per group).  t_rows (channels per image) lets
+    the library pick the generated one-wave-per-SIMD kernel (layout 2) when the shape allows."""
     ch = N.lib().mlpk_token_mlp_chunk()
     w1 = w1.detach().reshape(w1.shape[0], -1)
     w2 = w2.detach().reshape(w2.shape[0], -1)
@@ -287,7 +293,24 @@ def pack_token_mlp(w1, b1, w2, b2, dtype, device, sp, layout=None):
     w2p = torch.zeros((S, nch * ch), dtype=dtype, device=device)
     w2p[:, :T] = w2.to(device=device, dtype=dtype)
     if layout is None:
-        layout = N.lib().mlpk_token_mlp_layout(S, nch)
+        layout = N.lib().mlpk_token_mlp_layout_for(dtype_code(dtype), S, nch, t_rows) if t_rows else N.lib().mlpk_token_mlp_layout(S, nch)
+    if layout == 2:
+        # include/mlpk.h: W2 group-major -- (nch + 1) groups x 224 token rows x 32 k slots, slot 16 kk + 8 h + e of a group <- hidden
+        # 16 kk + 8 (e >> 2) + 4 h + (e & 3); group nch and the token rows behind S are zeros; b1 / b2 as padded tables
+        slot = torch.arange(32)
+        kk, hh, e = slot // 16, (slot // 8) % 2, slot % 8
+        src = (16 * kk + 8 * (e // 4) + 4 * hh + (e % 4)).to(device)
+        w2g = torch.zeros((nch + 1, 224, 32), dtype=dtype, device=device)
+        w2g[:nch, :S] = w2p.view(S, nch, 32)[:, :, src].permute(1, 0, 2)
+        if dtype == torch.bfloat16:
+            # the kernel's GELU takes x / 4: W1 and b1 carry the 1/4, W2 the 4 (powers of two applied AFTER the rounding to bf16:
+            # every product and the rounded hidden are the unscaled ones times a power of two, so nothing changes bit-wise)
+            w1p, b1p, w2g = (w1p.float() * 0.25).to(dtype), b1p * 0.25, (w2g.float() * 4.0).to(dtype)
+        b1t = torch.zeros((1024,), dtype=torch.float32, device=device)
+        b1t[64:64 + nch * ch] = b1p
+        b2t = torch.zeros((224,), dtype=torch.float32, device=device)
+        b2t[:S] = f32(b2, device)
+        return w1p, b1t, w2g.view((nch + 1) * 224, 32), b2t, nch, layout
     if layout == 1:
         # column slot 8 f + e of every 32-column group <- column (e < 4 ? 4 f + e : 16 + 4 f + e - 4)   (include/mlpk.h)
         slot = torch.arange(32)

@@ -157,7 +157,8 @@ class MLPMixer(E.EngineModule):
             S = tok.fn.net[0].weight.shape[1]
             if self.fused_token_mlp and E.token_mlp_supported(dtype, S, E.round_up(S, 32), tok.fn.net[0].weight.shape[0]):
                 pk[p + "tok.fused"] = E.pack_token_mlp(tok.fn.net[0].weight, tok.fn.net[0].bias, tok.fn.net[3].weight,
-                                                       tok.fn.net[3].bias, dtype, device, E.round_up(S, 32))
+                                                       tok.fn.net[3].bias, dtype, device, E.round_up(S, 32),
+                                                       t_rows=tok.norm.weight.shape[0])
             pack_channel_mlp(pk, p + "ch.", ch.norm, ch.fn.net[0], ch.fn.net[3], dtype, device)
 
     def _pack(self, dtype, device):
@@ -188,7 +189,7 @@ class MLPMixer(E.EngineModule):
                 stats = None
                 if C % 128 == 0 and (p + "ch.fc1.csum") in pk and E.epilogue_stats():
                     # the statistics of the channel LayerNorm come out of the token kernel's epilogue (no pass over x)
-                    part = ws.get("tok.stats", (C // 128, rows, 2), torch.float32)
+                    part = ws.get("tok.stats", (E.token_mlp_stat_planes(C, lay), rows, 2), torch.float32)
                     E.token_mlp(xt, sp, B * C, S, w1f, b1f, w2f, b2f, nch, x, C, C, stats=part, layout=lay)
                     stats = (ws.get("cm.ln.mean", (rows,), torch.float32), ws.get("cm.ln.rstd", (rows,), torch.float32))
                     E.stats_finalize_planar(part, rows, C, stats[0], stats[1])

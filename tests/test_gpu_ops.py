@@ -650,6 +650,62 @@ def test_fused_token_mlp(dtype, layout):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_fused_token_mlp_generated_kernel(dtype):
+    """layout 2 of mlpk_token_mlp (the generated one-wave-per-SIMD kernel, csrc/gen/t4gen.py): against the fp64 restatement of
+    mlp_mixer.py:16-27, bit-equal to layout 1 in x (same operation sequence), statistics over 64-channel planes; several tiles
+    per workgroup (more tiles than CUs), odd and even group counts, a ragged hidden size; shapes it does not take are refused."""
+    pkg = load_pkg()
+    E, N = pkg.engine, pkg._native
+    S, sp = 196, 224
+    for ci, (B_, C, T) in enumerate([(1, 256, 784), (3, 512, 512), (2, 768, 100), (5, 256, 64), (300, 256, 96)]):
+        xn = rnd((B_, S, C), dtype, 900 + ci)
+        x = rnd((B_ * S, C), dtype, 910 + ci).to(dev())
+        w1 = rnd((T, S), torch.float32, 920 + ci, 1.0 / math.sqrt(S))
+        b1 = rnd((T,), torch.float32, 930 + ci)
+        w2 = rnd((S, T), torch.float32, 940 + ci, 1.0 / math.sqrt(T))
+        b2 = rnd((S,), torch.float32, 950 + ci)
+        xt = torch.zeros((B_ * C, sp), dtype=dtype, device=dev())
+        xt[:, :S] = xn.permute(0, 2, 1).reshape(B_ * C, S).to(dev())
+        w1p, b1p, w2p, b2p, nch, lay = E.pack_token_mlp(w1, b1, w2, b2, dtype, dev(), sp, t_rows=C)
+        assert lay == 2, "the generated kernel must take S = 196 with whole 256-channel tiles"
+        x0 = x.clone()
+        part = torch.full((E.token_mlp_stat_planes(C, lay), B_ * S, 2), float("nan"), dtype=torch.float32, device=dev())
+        E.token_mlp(xt, sp, B_ * C, S, w1p, b1p, w2p, b2p, nch, x, C, C, stats=part, layout=lay)
+        x_nostats = x0.clone()
+        E.token_mlp(xt, sp, B_ * C, S, w1p, b1p, w2p, b2p, nch, x_nostats, C, C, layout=lay)
+        p1 = E.pack_token_mlp(w1, b1, w2, b2, dtype, dev(), sp, layout=1)
+        x1 = x0.clone()
+        E.token_mlp(xt, sp, B_ * C, S, p1[0], p1[1], p1[2], p1[3], p1[4], x1, C, C, layout=1)
+        mean = torch.empty(B_ * S, dtype=torch.float32, device=dev())
+        rstd = torch.empty_like(mean)
+        E.stats_finalize_planar(part, B_ * S, C, mean, rstd, eps=1e-5)
+        torch.cuda.synchronize()
+        assert torch.equal(x, x_nostats) and not torch.isnan(part).any()
+        if B_ <= 8:
+            w1r, w2r = w1.to(dtype).double(), w2.to(dtype).double()
+            h = oracle.gelu(torch.einsum("ts,bsc->btc", w1r, xn.double()) + b1.double().view(1, -1, 1)).to(dtype).double()
+            ref = x0.cpu().double().reshape(B_, S, C) + torch.einsum("st,btc->bsc", w2r, h) + b2.double().view(1, -1, 1)
+            got = x.cpu().double().reshape(B_, S, C)
+            assert torch.isfinite(got).all()
+            err = (got - ref).abs().max().item()
+            assert err < EPS[dtype] * 6 * max(1.0, ref.abs().max().item()), (str(dtype), ci, err)
+        # the same operation sequence as the 256-row kernel: differences only where fp32 sums were formed in another order
+        d = (x.float() - x1.float()).abs()
+        assert d.max().item() <= EPS[dtype] * 2 * max(1.0, x1.float().abs().max().item()), (str(dtype), ci, d.max().item())
+        assert (d > 0).float().mean().item() < 0.02, (str(dtype), ci, (d > 0).float().mean().item())
+        xd = x.cpu().double()
+        mu = xd.mean(1)
+        rs = 1.0 / torch.sqrt(xd.var(1, unbiased=False) + 1e-5)
+        assert (mean.cpu().double() - mu).abs().max().item() < 2e-6 * max(1.0, xd.abs().max().item())
+        assert ((rstd.cpu().double() - rs).abs() / rs).max().item() < 2e-5
+    # not whole 256-channel tiles / another token count: refused, never mis-tiled
+    assert N.lib().mlpk_token_mlp_layout_for(E.dtype_code(dtype), 196, 25, 384) != 2
+    assert N.lib().mlpk_token_mlp_layout_for(E.dtype_code(dtype), 49, 7, 512) != 2
+    with pytest.raises(RuntimeError):
+        E.token_mlp(xt, sp, B_ * C, S, w1p, b1p, w2p, b2p, nch, x, C, C - 128, layout=2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_layernorm_transpose_one_pass(dtype):
     """mlpk_layernorm_transpose == nn.LayerNorm over channels followed by the per-image transpose (mlp_mixer.py:34, :6-13),
     zero K-padding columns, ragged last token tile; against the fp64 oracle and bit-compared with the two-kernel path's layout."""

@@ -1,0 +1,96 @@
+"""The generated fused token-mixing kernels (jittor-mlp_amd/csrc/gen/t4gen.py: both Conv1d(k=1) of the Mixer token FeedForward +
+GELU + residual, mlp_mixer.py:16-27,34,37) WITHOUT a GPU: the instruction list that becomes the asm block runs on the numpy
+emulator of csrc/gen/isa.py (four waves, LDS rings filled by LDS-DMA, MFMA 32x32x16, one counted wait + barrier per iteration,
+modelled adversarially) and is compared with an fp64 restatement, by-product statistics included.  Also the hazard lint over
+every shipped variant, mutations of the synchronisation the emulator must catch, and the accuracy of the folded GELU."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+GEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "jittor-mlp_amd", "csrc", "gen")
+sys.path.insert(0, GEN)
+import isa  # noqa: E402
+import t4emu  # noqa: E402
+import t4gen  # noqa: E402
+
+CASES = [
+    # kernel, images, channels per image, hidden size, grid, DMA landing model, wave order
+    (dict(stats=True), 2, 256, 128, 2, "late", None),                       # even group count (no lead iteration), one tile per image
+    (dict(stats=True), 2, 512, 100, 3, "early", [3, 2, 1, 0]),              # ragged hidden size, workgroups with one and two tiles
+    (dict(stats=False), 1, 768, 33, 1, "late", [2, 0, 3, 1]),               # three tiles in one workgroup, odd group count (lead iteration)
+    (dict(dtype="f16", stats=True), 1, 512, 80, 2, "late", None),
+]
+
+
+@pytest.mark.parametrize("kw,nimg,t_rows,T,grid,mode,order", CASES)
+def test_generated_kernel_matches_fp64_in_emulation(kw, nimg, t_rows, T, grid, mode, order):
+    g = t4gen.T4(**kw)
+    assert isa.lint(g.a) == []
+    assert t4emu.run_case(g, nimg=nimg, t_rows=t_rows, T=T, grid=grid, dma_mode=mode, order=order)
+
+
+def test_every_shipped_variant_passes_the_hazard_lint():
+    n = 0
+    for kw in t4gen.variants():
+        g = t4gen.T4(**kw)
+        assert isa.lint(g.a) == [], g.name
+        assert g.nv <= 248 and g.ns <= 100, g.name
+        n += 1
+    assert n >= 4
+
+
+def test_emulator_catches_protocol_faults():
+    def no_barrier(i):
+        if i.op == "s_barrier":
+            i.op, i.args = "s_nop", (0,)
+            return 1
+        return 0
+
+    def loose_vmcnt(i):            # the iteration barrier no longer waits for this wave's own LDS-DMA pieces
+        if i.op == "s_waitcnt" and i.mods.get("vmcnt") == 0 and i.mods.get("lgkmcnt") == 0:
+            i.mods["vmcnt"] = 10
+            return 1
+        return 0
+
+    def loose_lgkm(i):             # a weight fragment consumed one LDS read too early
+        if i.op == "s_waitcnt" and "vmcnt" not in i.mods and i.mods.get("lgkmcnt") == 3:
+            i.mods["lgkmcnt"] = 4
+            return 1
+        return 0
+    for mut in (no_barrier, loose_vmcnt, loose_lgkm):
+        g = t4gen.T4(stats=False)
+        assert sum(mut(i) for i in g.a.ins) > 0
+        caught = False
+        for mode, order in (("late", None), ("early", [3, 2, 1, 0]), ("late", [3, 1, 2, 0])):
+            try:
+                ok = t4emu.run_case(g, nimg=1, t_rows=512, T=100, grid=1, dma_mode=mode, order=order)
+            except RuntimeError:
+                ok = False
+            caught = caught or not ok
+        assert caught, mut.__name__
+
+
+def test_folded_gelu_coefficients():
+    """bf16 kernels take s = x / 4 from the first product (the host folds 1/4 into W1 and b1, 4 into W2): Phi(x) ~= 0.5 + t P(t^2),
+    t = clamp(s, -1, 1), evaluated as the kernel does (fp32 Horner).  Same grade as MLPK_GELUP_*_BF16 (tests/test_host_cpu.py):
+    below 9e-5 on |x| <= 4 and 6e-5 |x| beyond against the erf form (mlp_mixer.py:21 nn.GELU)."""
+    from scipy.special import erf
+
+    def fma(a, b, c):
+        return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+    c = [np.float32(v) for v in t4gen.GELU_FOLDED[8]]
+    x = np.concatenate([np.linspace(-12, 12, 400001), np.linspace(-1e-3, 1e-3, 2001)]).astype(np.float32)
+    s = (x * np.float32(t4gen.FOLD)).astype(np.float32)
+    t = np.clip(s, np.float32(-1), np.float32(1))
+    u = (t * t).astype(np.float32)
+    q = np.full_like(t, c[0])
+    for ck in c[1:]:
+        q = fma(q, u, np.full_like(t, ck))
+    got = (x * fma(t, q, np.full_like(t, 0.5))).astype(np.float32).astype(np.float64)
+    ref = x.astype(np.float64) * 0.5 * (1.0 + erf(x.astype(np.float64) / np.sqrt(2.0)))
+    err = np.abs(got - ref)
+    inside = np.abs(x) <= 4.0
+    assert err[inside].max() < 9e-5
+    assert (err[~inside] / np.abs(x[~inside])).max() < 6e-5

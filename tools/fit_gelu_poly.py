@@ -58,3 +58,30 @@ print("max |Phi err| = %.3e   max |gelu err| = %.3e (at x = %.3f)   max |gelu er
 print("scale sqrt2/A = %.9g" % (R2 / A))
 print("coefficients (Horner order, u^%d first):" % (K - 1))
 print(", ".join("%.9gf" % v for v in coef))
+
+if len(sys.argv) > 3 and sys.argv[3] == "folded":
+    # the same fit for a kernel whose first product already delivers s = x / A (A a power of two, folded into the weights):
+    # Phi(x) ~= 0.5 + s * P(s * s),  s = clamp(x / A, -1, 1):  t = sqrt2 s, u = 2 s^2 - 1  ->  P(w) = sqrt2 * Q(2 w - 1)
+    comp = np.zeros(K)
+    base = np.ones(1)
+    for k in range(K):
+        comp[:len(base)] += mono[k] * base
+        base = P.polymul(base, [-1.0, 2.0])
+    pw = (comp * R2)[::-1].astype(np.float32)          # Horner order in w = s^2
+
+    def gelu_folded32(x):
+        x = x.astype(np.float32)
+        s = (x * np.float32(1.0 / A)).astype(np.float32)
+        sc = np.clip(s, np.float32(-1), np.float32(1))
+        w_ = (sc * sc).astype(np.float32)
+        q = np.full_like(sc, pw[0])
+        for cc in pw[1:]:
+            q = fma32(q, w_, np.full_like(sc, cc))
+        ph = fma32(sc, q, np.full_like(sc, np.float32(0.5)))
+        return (x * ph).astype(np.float32), ph
+    g2, ph2 = gelu_folded32(xs)
+    print("folded form: max |Phi err| = %.3e   max |gelu err| on |x| <= A: %.3e   max rel beyond: %.3e   sum|coef| = %.1f"
+          % (np.abs(ph2 - ref_phi).max(), np.abs(g2 - ref)[np.abs(xs) <= A].max(),
+             (np.abs(g2 - ref)[np.abs(xs) > A] / np.abs(xs[np.abs(xs) > A])).max(), np.abs(pw).sum()))
+    print("coefficients (Horner order, w^%d first):" % (K - 1))
+    print(", ".join("%.9g" % v for v in pw))

@@ -15,7 +15,7 @@ from isa import A, F, S, V, Asm  # noqa: E402
 ITERS = 64          # loop iterations of 32 MFMAs
 
 
-def kernel(name, pattern, per_iter=None, setup=None):
+def kernel(name, pattern, per_iter=None, setup=None, vdst=False):
     """pattern(a, q): instructions after MFMA q (0..31) of an iteration; per_iter(a): at the end of an iteration"""
     a = Asm()
     # s[0:1] = kernarg, s2 = block id, v0 = thread id.  kernarg: out (8), src (8)
@@ -58,7 +58,10 @@ def kernel(name, pattern, per_iter=None, setup=None):
     L = a.newlabel("LOOP")
     a.label(L)
     for q in range(32):
-        a("v_mfma_f32_32x32x16_bf16", A(16 * (q & 7), 16), V(4, 4), V(8, 4), A(16 * (q & 7), 16))
+        if vdst:         # accumulators in VGPRs (two chains), B operand from AGPRs: the first product of the fused token MLP
+            a("v_mfma_f32_32x32x16_bf16", V(96 + 16 * (q & 1), 16), V(4, 4), A(128 + 4 * (q & 3), 4), V(96 + 16 * (q & 1), 16))
+        else:
+            a("v_mfma_f32_32x32x16_bf16", A(16 * (q & 7), 16), V(4, 4), V(8, 4), A(16 * (q & 7), 16))
         pattern(a, q)
     if per_iter:
         per_iter(a)
@@ -210,10 +213,56 @@ P("waitcnt4", lambda a, q: [a("s_waitcnt", lgkmcnt=15) for k in range(4)] and No
 P("nop4", lambda a, q: [a("s_nop", 0) for k in range(4)] and None)
 
 
+def pk(a, n, base=0, sgpr=False, chains=8):
+    for k in range(n):
+        r = 72 + 2 * ((base + k) % chains)
+        a("v_pk_fma_f32", V(r, 2), V(r, 2), V(64, 2), S(20, 2) if sgpr else V(64, 2))
+
+
+def med3(a, n, base=0):
+    for k in range(n):
+        r = 72 + ((base + k) % 16)
+        a("v_med3_f32", V(r), V(r), V(64), V(65))
+
+
+for n in (1, 2, 3, 4, 5):
+    P("pkfma%d" % n, lambda a, q, n=n: pk(a, n, q * n))
+P("pkfma3_sgpr", lambda a, q: pk(a, 3, q * 3, sgpr=True))
+P("pkfma3_2chains", lambda a, q: pk(a, 3, q * 3, chains=2))
+P("pkfma4_2chains", lambda a, q: pk(a, 4, q * 4, chains=2))
+P("fma4_2chains", lambda a, q: [a("v_fma_f32", V(72 + (4 * q + k) % 2), V(72 + (4 * q + k) % 2), V(64), V(65)) for k in range(4)] and None)
+P("pkmul3", lambda a, q: [a("v_pk_mul_f32", V(72 + 2 * ((3 * q + k) % 8), 2), V(72 + 2 * ((3 * q + k) % 8), 2), V(64, 2)) for k in range(3)] and None)
+P("t4gap", lambda a, q: (pk(a, 3, q * 3, sgpr=True, chains=2), med3(a, 1, q)) and None)
+P("t4gap_reads_dma", lambda a, q: (dma(a, q) if q % 8 in (1, 3, 6) else None, ds_read(a, q) if (q & 1) else None, pk(a, 3, q * 3, sgpr=True, chains=2), med3(a, 1, q)) and None,
+  lambda a: a("s_waitcnt", vmcnt=12, lgkmcnt=0))
+P("fma8_fullgelu", lambda a, q: fma(a, 7, q * 7))
+def t4mix(a, q, n, with_dma=True):
+    if with_dma and q % 8 in (1, 3, 6):
+        dma(a, q, nop=False)
+    if (q & 1) == 0:
+        ds_read(a, q)
+        a("s_waitcnt", lgkmcnt=3)
+    fmaak(a, n, q * n)
+
+
+for n in (3, 4, 5, 6, 7):
+    P("t4mix%d" % n, lambda a, q, n=n: t4mix(a, q, n), lambda a: (a("s_waitcnt", vmcnt=0, lgkmcnt=0), a("s_barrier")) and None)
+P("t4mix6_nodma", lambda a, q: t4mix(a, q, 6, False), lambda a: (a("s_waitcnt", vmcnt=0, lgkmcnt=0), a("s_barrier")) and None)
+P("t4mix6_nobar", lambda a, q: t4mix(a, q, 6), lambda a: a("s_waitcnt", vmcnt=12))
+VDST = set()
+for nm, pat in (("vdst_mfma_only", lambda a, q: None), ("vdst_fma4", lambda a, q: fma(a, 4, q * 4)), ("vdst_pkfma3", lambda a, q: pk(a, 3, q * 3)),
+                ("vdst_t4gap", lambda a, q: (pk(a, 3, q * 3, sgpr=True, chains=2), med3(a, 1, q)) and None)):
+    P(nm, pat)
+    VDST.add(nm)
+ONLY = os.environ.get("ONLY", "")
+if ONLY:
+    PAT[:] = [x for x in PAT if any(x[0].startswith(t) for t in ONLY.split(","))]
+
+
 def main(path):
     out = ["#include <hip/hip_runtime.h>\n#include <stdio.h>\n#include <vector>\n"]
     for name, pat, per in PAT:
-        out.append(kernel("ub_" + name, pat, per))
+        out.append(kernel("ub_" + name, pat, per, vdst=name in VDST))
     out.append("struct K { const char* name; const void* fn; };\nstatic const K ks[] = {\n")
     for name, _, _ in PAT:
         out.append("    {\"%s\", (const void*)&ub_%s},\n" % (name, name))
