@@ -41,7 +41,8 @@ B1_OFF = W2_OFF + 2 * W2_STAGE           # 1024 floats: entry j = bias of hidden
 STG_PITCH = 272                          # fp32 staging row: 64 channels + 16 B
 STG_WAVE = 32 * STG_PITCH
 STG_OFF = B1_OFF + 4096
-LDS_BYTES = STG_OFF + 4 * STG_WAVE
+STG_BUF = 4 * STG_WAVE                   # two staging buffers (token blocks alternate): block tb + 1 is written while tb is read back
+LDS_BYTES = STG_OFF + 2 * STG_BUF
 W2_GROUP_BYTES = 224 * 64                # one hidden group of the packed W2: 224 token rows x 32 k slots
 # bf16: Phi(x) ~= 0.5 + t P(t^2), t = clamp(x / 4, -1, 1) (tools/fit_gelu_poly.py 4.0 K folded: the fit of MLPK_GELUP_*_BF16 in the
 # variable x / 4; |gelu error| < 9e-5 on |x| <= 4 and < 6e-5 |x| beyond for K = 8, 4.2e-4 / 1.1e-4 |x| for K = 7)
@@ -54,7 +55,8 @@ assert all((o * W2_MAGIC) >> 20 == o // W2_PITCH for o in range(0, W2_STAGE, 16)
 
 
 class T4:
-    NKS, NTB = 14, 7                       # K = 224 = 14 steps of 16; 196 tokens = 7 blocks of 32 (the last one holds 4)
+    NKS, NTB = 13, 7                       # K: 196 tokens fit 13 steps of 16 (208; the 14th of xt's 224 columns is padding only);
+                                           # 196 tokens = 7 blocks of 32 for the second product (the last one holds 4)
     NXA = 8                                # X fragments kept in the 32 AGPRs the accumulators leave over
     DEPTH = 3                              # W fragments read ahead of their MFMAs (ring of 4 register quads)
 
@@ -266,7 +268,7 @@ class T4:
         fill = [] if (self.dbg & 2) else self.gelu_ops(1 - par, 1 - par)
         dma = [] if (self.dbg & 1) else [(kind, i) for i in range(5) for kind in ("w1", "w2")]
         state = {"done": 0, "gap": 0}
-        ngaps, total = 56, len(fill)
+        ngaps, total = 2 * (2 * self.NTB + self.NKS), len(fill)
 
         def gap():
             state["gap"] += 1
@@ -331,7 +333,7 @@ class T4:
             return
         for rb in range(2):
             for ks in range(self.NKS):
-                self.a("global_load_dwordx4", self.X[rb][ks], self.v_xoff, self.s_xb[rb], offset=32 * ks)
+                self.vload("global_load_dwordx4", self.X[rb][ks], self.v_xoff, self.s_xb[rb], offset=32 * ks)
 
     def tile_scalars(self):
         """cursors of the tile's 64 channels of this wave: x + ((img * S) * ldx + c0) * 2 and the statistics plane"""
@@ -375,29 +377,32 @@ class T4:
             a("s_mov_b64", "exec", -1)
         return rec
 
-    def epilogue(self):
+    def epilogue(self, res):
+        """res: the residual loads of token blocks 0 and 1 (issued behind the next tile's X: requesting them first only moved the
+        wait for X to block 2 and measured slower); block tb + 2 is requested when block tb has been stored"""
         a, t = self.a, self.s_t
-        self.lgkm_issued = 0
-        self.vm_loads = 0
-        res = {0: self.res_loads(0)}
         if self.stats:
             a("v_mov_b32", self.e_ones, 0x3F803F80 if self.dtype == "bf16" else 0x3C003C00)
-        for tb in range(self.NTB):
-            rounds = 4 if tb < self.NTB - 1 else 1
-            # accumulators (started from b2) -> fp32 staging [token][64 channels]
+        def stage(tb):
+            """accumulators (started from b2) of token block tb -> fp32 staging [token][64 channels]; returns the last write"""
+            last = None
             for rb in range(2):
                 for q in range(4):
                     x = self.e_acc[q]
                     for r in range(4):
                         a("v_accvgpr_read_b32", x[r], A(16 * (self.NTB * rb + tb) + 4 * q + r))
-                    self.ds("ds_write_b128", self.v_stw, x, offset=128 * rb + 32 * q)
+                    last = self.ds("ds_write_b128", self.v_stw, x, offset=(tb & 1) * STG_BUF + 128 * rb + 32 * q)
+            return last
+        staged = {0: stage(0)}
+        for tb in range(self.NTB):
+            rounds = 4 if tb < self.NTB - 1 else 1
             if tb + 1 < self.NTB:
-                res[tb + 1] = self.res_loads(tb + 1)
-            a("s_waitcnt", lgkmcnt=0)
+                staged[tb + 1] = stage(tb + 1)
+            self.wait_lds(staged[tb])
             rds = []
             for r in range(rounds):
-                self.ds("ds_read_b128", self.e_in[2 * r], self.v_strd, offset=8 * r * STG_PITCH)
-                rds.append(self.ds("ds_read_b128", self.e_in[2 * r + 1], self.v_strd, offset=8 * r * STG_PITCH + 16))
+                self.ds("ds_read_b128", self.e_in[2 * r], self.v_strd, offset=(tb & 1) * STG_BUF + 8 * r * STG_PITCH)
+                rds.append(self.ds("ds_read_b128", self.e_in[2 * r + 1], self.v_strd, offset=(tb & 1) * STG_BUF + 8 * r * STG_PITCH + 16))
             for r in range(rounds):
                 self.wait_lds(rds[r])
                 self.wait_vload(res[tb][r])
@@ -437,6 +442,8 @@ class T4:
                     if rounds == 1:
                         a("s_mov_b64", "exec", -1)
                 self.add64(self.s_ocur, self.s_ocur, self.s_tok8)
+            if tb + 2 < self.NTB:
+                res[tb + 2] = self.res_loads(tb + 2)
 
     # ------------------------------------------------------------------ the kernel
     def build(self):
@@ -538,7 +545,7 @@ class T4:
         a("s_sub_u32", t[0], 2, k["lead"])
         a("s_lshl_b32", t[0], t[0], 7)
         a("v_add_u32", self.v_b1rd, t[0], self.v_b1rd)              # bias row of the first iteration's group
-        a("s_waitcnt", vmcnt=0 if (self.dbg & 33) else 38)           # b2 (the loads before the 10 DMA pieces and 28 X quads)
+        a("s_waitcnt", vmcnt=0 if (self.dbg & 33) else 10 + 2 * self.NKS)   # b2 (the loads before the 10 DMA pieces and the X quads)
         a.label(L_tile)
         self.tile_scalars()
         for rb in range(2):
@@ -570,7 +577,12 @@ class T4:
         self.tile_xbase(self.s_next)
         self.x_loads()
         a.label(L_nonext)
-        self.epilogue()
+        self.lgkm_issued = 0
+        self.vm_loads = 0
+        a("s_nop", 7)                                                # the residual lands in registers the last MFMAs have just written
+        a("s_nop", 7)
+        res = {0: self.res_loads(0), 1: self.res_loads(1)}
+        self.epilogue(res)
         a("s_mov_b32", self.s_tile, self.s_next)
         a("s_cmp_lg_u32", self.s_has, 0)
         a("s_cbranch_scc1", L_tile)

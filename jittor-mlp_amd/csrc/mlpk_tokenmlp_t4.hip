@@ -28,7 +28,7 @@ static_assert(sizeof(T4Args) == 112, "kernarg layout");
 
 namespace mlpk {
 
-#define T4_LDS_BYTES 110592
+#define T4_LDS_BYTES 145408        // LDS_BYTES of t4gen.py
 
 static int t4_grid_cap() {
     static int cap = 0;
