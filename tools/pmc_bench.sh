@@ -28,7 +28,7 @@ with open(out + "/summary.txt", "w") as fo:
     fo.write("# rocprofv3 --pmc <group> --kernel-trace (separate passes) on: python bench.py --steps 3 --warmup 1 (Mixer-B/16, bs=256, bf16)\n")
     fo.write("# per-launch means; FETCH_SIZE/WRITE_SIZE in KiB as reported (gfx950: wide coalesced reads are reported at HALF their bytes -> x2, MI355X_MICROARCH.md)\n")
     for (short, c), (n, s) in sorted(agg.items(), key=lambda kv: (kv[0][1], kv[0][0])):
-        if not any(t in short for t in ("gemm_nt", "q4_", "token_mlp", "row_stats", "norm_apply", "layernorm_transpose", "stats_finalize")):
+        if not any(t in short for t in ("gemm_nt", "q4_", "t4_", "token_mlp", "row_stats", "norm_apply", "layernorm_transpose", "stats_finalize")):
             continue
         fo.write("%-40s %-30s launches=%d mean=%.5g\n" % (short, c, n, s / n))
 print(open(out + "/summary.txt").read())
