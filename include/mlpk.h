@@ -36,6 +36,7 @@
  *   mlpk_pool_mean      x.mean(dim=1) / Reduce('b h w c -> b c') / AdaptiveAvgPool2d, optionally through
  *                       the final LayerNorm: mlp_mixer.py:73-74; vip.py:160-163; s2_mlp_v2.py:125; as_mlp.py:435-437
  *   mlpk_shift_nchw     Shift / _shift.forward / shift_forward_kernel: utils/shift_cuda.py:44-72,106-129,177-192
+ *   mlpk_shift_nchw_backward   _shift.backward / shift_backward_grad_input_kernel: utils/shift_cuda.py:75-103,131-162
  *   mlpk_shift_nhwc     the same remap on the channel-last layout used internally for AS-MLP
  *   mlpk_norm_shift_nhwc  AxialShift's GroupNorm + GELU + both shifts as one index-remapping pass (as_mlp.py:64-66,84-95)
  *   mlpk_cycle_shift    the sampling half of CycleFC (cycle_mlp.py:104-131: deform_conv2d with a 1 x 1 kernel and fixed integer
@@ -314,6 +315,11 @@ int mlpk_shift_nchw(int dtype, const void* in, void* out, int N, int C, int H, i
                     int kernel_size, int dim, void* stream);
 int mlpk_shift_nhwc(int dtype, const void* in, void* out, int N, int H, int W, int C,
                     int kernel_size, int dim, void* stream);
+/* The op's backward (_shift.backward / shift_backward_grad_input_kernel: utils/shift_cuda.py:75-103,131-162):
+ * grad_in[n,c,h,w] = grad_out[n,c,h-s,w] (dim 2) | grad_out[n,c,h,w-s] (dim 3), zero outside -- the adjoint of the forward gather.
+ * Same argument checks as the forward; the caller allocates grad_in (shift_cuda.py:147). */
+int mlpk_shift_nchw_backward(int dtype, const void* grad_out, void* grad_in, int N, int C, int H, int W,
+                             int kernel_size, int dim, void* stream);
 
 /* AS-MLP: t = act(GroupNorm(1,C)(in)) read through BOTH axial shifts in one pass, t itself never stored (as_mlp.py:64-66,84-95):
  *   out_w[n,h,w,c] = t[n,h,w+s,c],  out_h[n,h,w,c] = t[n,h+s,w,c],  t = act((in - mean[n]) * rstd[n] * gamma[c] + beta[c]),

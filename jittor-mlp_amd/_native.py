@@ -65,6 +65,7 @@ PROTOTYPES = {
     "mlpk_pool_mean": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                c_void_p, c_void_p, c_int, c_void_p]),
     "mlpk_shift_nchw": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "mlpk_shift_nchw_backward": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "mlpk_shift_nhwc": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "mlpk_norm_shift_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p] * 4 + [c_int, c_void_p]),
     "mlpk_cycle_shift": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),

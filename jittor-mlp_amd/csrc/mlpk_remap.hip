@@ -10,16 +10,17 @@ namespace mlpk {
 
 // ================================ AS-MLP axial shift ================================
 // shift_cuda.py:44-72: group = ceil(C/k), g = c / group, s = k/2 - g, zero fill.
+// sign = +1: the forward gather; sign = -1: its adjoint, shift_backward_grad_input_kernel (shift_cuda.py:75-103: bottom_diff[h] = top_diff[h - s])
 template <typename T>
 __global__ void __launch_bounds__(256) shift_nchw_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int C,
-                                                         int H, int W, int ksz, int dim) {
+                                                         int H, int W, int ksz, int dim, int sign) {
     const int64_t total = (int64_t)N * C * H * W;
     const int group = (C + ksz - 1) / ksz;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         const int w = (int)(idx % W);
         const int h = (int)((idx / W) % H);
         const int c = (int)((idx / ((int64_t)W * H)) % C);
-        const int s = ksz / 2 - c / group;
+        const int s = sign * (ksz / 2 - c / group);
         T v = from_f32<T>(0.f);
         if (dim == 2) {
             if (h + s >= 0 && h + s < H) v = in[idx + (int64_t)s * W];
@@ -647,17 +648,27 @@ static int shift_check(int ksz, int dim) {
     return 0;
 }
 
-extern "C" int mlpk_shift_nchw(int dtype, const void* in, void* out, int N, int C, int H, int W, int kernel_size,
-                               int dim, void* stream) {
+static int shift_nchw_launch(int dtype, const void* in, void* out, int N, int C, int H, int W, int kernel_size, int dim, int sign,
+                             void* stream) {
     if (!in || !out) return MLPK_ENULL;
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return MLPK_ESHAPE;
     if (int e = shift_check(kernel_size, dim)) return e;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int64_t total = (int64_t)N * C * H * W;
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((shift_nchw_kernel<T>), dim3(grid_for(total)), dim3(256), 0, s,
-                                             (const T*)in, (T*)out, N, C, H, W, kernel_size, dim));
+                                             (const T*)in, (T*)out, N, C, H, W, kernel_size, dim, sign));
     MLPK_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int mlpk_shift_nchw(int dtype, const void* in, void* out, int N, int C, int H, int W, int kernel_size,
+                               int dim, void* stream) {
+    return shift_nchw_launch(dtype, in, out, N, C, H, W, kernel_size, dim, 1, stream);
+}
+
+extern "C" int mlpk_shift_nchw_backward(int dtype, const void* grad_out, void* grad_in, int N, int C, int H, int W, int kernel_size,
+                                        int dim, void* stream) {
+    return shift_nchw_launch(dtype, grad_out, grad_in, N, C, H, W, kernel_size, dim, -1, stream);
 }
 
 extern "C" int mlpk_shift_nhwc(int dtype, const void* in, void* out, int N, int H, int W, int C, int kernel_size,

@@ -359,6 +359,12 @@ def shift_nchw(x, out, kernel_size, dim):
             "mlpk_shift_nchw")
 
 
+def shift_nchw_backward(grad_out, grad_in, kernel_size, dim):
+    n, c, h, w = grad_out.shape
+    N.check(N.lib().mlpk_shift_nchw_backward(dtype_code(grad_out.dtype), ptr(grad_out), ptr(grad_in), n, c, h, w, kernel_size, dim, stream()),
+            "mlpk_shift_nchw_backward")
+
+
 def shift_nhwc(x, out, n, h, w, c, kernel_size, dim):
     N.check(N.lib().mlpk_shift_nhwc(dtype_code(x.dtype), ptr(x), ptr(out), n, h, w, c, kernel_size, dim, stream()),
             "mlpk_shift_nhwc")

@@ -1,11 +1,37 @@
 """`Shift`, drop-in for the reference's models_pytorch/utils/shift_cuda.py:177-192 -- its only
 native op.  Reference: a CUDA C string JIT-compiled through cupy per shape; here: one precompiled
-gfx950 kernel behind the C ABI (mlpk_shift_nchw), launched the same way (raw pointers, caller-
-allocated output, torch's current stream).  Forward only (the north star is the forward path)."""
+gfx950 kernel behind the C ABI (mlpk_shift_nchw / mlpk_shift_nchw_backward), launched the same way (raw pointers, caller-
+allocated output, torch's current stream).  Like the reference's `_shift` it is an autograd.Function with the op's own
+backward kernel (shift_cuda.py:75-103,131-162); the models' forward paths around it remain inference-only."""
 import torch
 from torch import nn
 
 from ... import engine as E
+
+
+class _shift(torch.autograd.Function):
+    """shift_cuda.py:106-162: forward = the gather kernel, backward = its adjoint kernel on grad_output; (grad_input, None, None)."""
+
+    @staticmethod
+    def forward(ctx, input, shift, dim):
+        assert input.dim() == 4 and input.is_cuda
+        x = input.contiguous()
+        out = torch.empty_like(x)                                  # caller-allocated, as input.new(...) at shift_cuda.py:112
+        with E.on_device(x):
+            E.shift_nchw(x, out, shift, dim)
+        ctx.shift, ctx.dim = shift, dim
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        assert grad_output.is_cuda
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        g = grad_output.contiguous()                               # shift_cuda.py:133-134
+        grad_input = torch.empty_like(g)
+        with E.on_device(g):
+            E.shift_nchw_backward(g, grad_input, ctx.shift, ctx.dim)
+        return grad_input, None, None
 
 
 def _shift_gpu(input, shift, dim):
@@ -15,11 +41,7 @@ def _shift_gpu(input, shift, dim):
     if not input.is_cuda:
         raise NotImplementedError
     assert input.dim() == 4
-    x = input.contiguous()
-    out = torch.empty_like(x)
-    with E.on_device(x):
-        E.shift_nchw(x, out, shift, dim)
-    return out
+    return _shift.apply(input, shift, dim)
 
 
 class Shift(nn.Module):

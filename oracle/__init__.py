@@ -22,7 +22,7 @@ from .functional import (  # noqa: F401
     mixer_forward, gmlp_forward, resmlp_forward, vip_forward,
     s2mlpv2_forward, s2mlpv1_forward, asmlp_forward, convmixer_forward, sparsemlp_forward, hiremlp_forward, msmlp_forward, swinmlp_forward, cyclemlp_forward,
     cycle_fc, cycle_offsets, deform_conv2d_pointwise_loop,
-    axial_shift_nchw, spatial_shift1, spatial_shift2, split_attention,
+    axial_shift_nchw, axial_shift_nchw_backward, spatial_shift1, spatial_shift2, split_attention,
     vip_permute_h, vip_permute_w,
 )
 from .portable_init import portable_tensor, portable_state_dict, portable_input  # noqa: F401

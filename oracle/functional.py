@@ -422,6 +422,32 @@ def axial_shift_nchw(x, kernel_size, dim):
     return out
 
 
+def axial_shift_nchw_backward(grad_out, kernel_size, dim):
+    """The `Shift` op's backward kernel formula (shift_cuda.py:75-103, launched from _shift.backward :131-162):
+    grad_in[n,c,h,w] = grad_out[n,c,h-s,w] (dim 2) or grad_out[n,c,h,w-s] (dim 3), zero out of range, with the forward's
+    group = ceil(C/k), g = c // group, s = k//2 - g -- the adjoint of the forward gather."""
+    assert dim in (2, 3)
+    assert kernel_size % 2 == 1
+    if kernel_size == 1:
+        return grad_out
+    n, c, h, w = grad_out.shape
+    group = int(math.ceil(c / kernel_size))
+    out = torch.zeros_like(grad_out)
+    for g in range((c + group - 1) // group):
+        lo, hi = g * group, min(c, (g + 1) * group)
+        s = kernel_size // 2 - g
+        length = h if dim == 2 else w
+        # destination index i reads source i - s, valid when 0 <= i - s < length
+        d0, d1 = max(0, s), min(length, length + s)
+        if d1 <= d0:
+            continue
+        if dim == 2:
+            out[:, lo:hi, d0:d1, :] = grad_out[:, lo:hi, d0 - s:d1 - s, :]
+        else:
+            out[:, lo:hi, :, d0:d1] = grad_out[:, lo:hi, :, d0 - s:d1 - s]
+    return out
+
+
 def asmlp_axial_shift(sd, x, pre, shift_size):
     """AxialShift.forward (as_mlp.py:55-95)."""
     t = conv1x1(x, _p(sd, pre + "conv1.weight", x), _opt(sd, pre + "conv1.bias", x))

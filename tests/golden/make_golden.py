@@ -406,6 +406,16 @@ def make_ops(ref):
             blob["shift%d/x" % i] = x.numpy()
             blob["shift%d/k" % i] = np.array(k)
             blob["shift%d/dim%d" % (i, dim)] = y.numpy()
+            # backward: autograd of the reference's torch_shift (the differentiable twin of its CUDA op, shift_cuda.py:195-205) against
+            # the restated backward kernel formula (shift_cuda.py:75-103); own generator: the forward fixtures above keep their values
+            gg = torch.Generator().manual_seed(1000 + 10 * i + dim)
+            go = torch.randn(*shape, generator=gg)
+            xr = x.clone().requires_grad_(True)
+            sc.torch_shift(xr, k, dim).backward(go)
+            ob = oracle.axial_shift_nchw_backward(go, k, dim)
+            assert torch.equal(ob, xr.grad), ("axial shift backward mismatch", shape, k, dim)
+            blob["shift%d/gout_dim%d" % (i, dim)] = go.numpy()
+            blob["shift%d/gin_dim%d" % (i, dim)] = xr.grad.numpy()
     # S2 spatial shifts: reference in-place behaviour with ONE thread
     nt = torch.get_num_threads()
     torch.set_num_threads(1)

@@ -2,6 +2,7 @@
 (include/mlpk.h) on seeded inputs, including ragged tails and the edge cases the reference's
 ops have (zero-fill borders, non-divisible channel groups, K padding)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -330,6 +331,41 @@ def test_axial_shift_against_golden(golden_dir):
         E.shift_nchw(x, out, 4, 2)                              # even kernel (shift_cuda.py:167)
     with pytest.raises(pkg._native.MlpkError):
         E.shift_nchw(x, out, 3, 1)                              # bad dim (shift_cuda.py:168)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_shift_backward_matches_reference_autograd(dtype):
+    """mlpk_shift_nchw_backward and the `Shift` module's autograd path (shift_cuda.py:75-103,131-162): bit-equal to the grads the
+    reference's autograd produced through its own torch_shift (tests/golden/ops.npz), for both axes, ragged channel groups,
+    non-contiguous grad_output; grads flow through the module like through the reference's `_shift.apply`."""
+    pkg = load_pkg()
+    E = pkg.engine
+    from importlib import import_module
+    ut = import_module("jittor-mlp_amd.models_pytorch.utils")
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ops.npz"))
+    i = 0
+    while "shift%d/x" % i in z.files:
+        k = int(z["shift%d/k" % i])
+        x = torch.from_numpy(z["shift%d/x" % i]).to(dtype)
+        for dim in (2, 3):
+            go = torch.from_numpy(z["shift%d/gout_dim%d" % (i, dim)]).to(dtype)
+            want = oracle.axial_shift_nchw_backward(go, k, dim)                       # (== the reference's grads in fp32, test_oracle_golden)
+            if dtype == torch.float32:
+                assert torch.equal(want, torch.from_numpy(z["shift%d/gin_dim%d" % (i, dim)]))
+            gi = torch.empty_like(go, device=dev())
+            E.shift_nchw_backward(go.to(dev()), gi, k, dim)
+            assert torch.equal(gi.cpu(), want)
+            xr = x.to(dev()).requires_grad_(True)
+            y = ut.Shift(k, dim)(xr)
+            assert y.requires_grad
+            y.backward(go.to(dev()).permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2))   # a non-contiguous grad_output
+            assert torch.equal(xr.grad.cpu(), want)
+        i += 1
+    assert i >= 4
+    x = torch.zeros(1, 4, 4, 4, dtype=dtype, device=dev())
+    with pytest.raises(RuntimeError):
+        E.shift_nchw_backward(x, torch.empty_like(x), 4, 2)
+
 
 
 def test_s2_shift_and_split_attention(golden_dir):
