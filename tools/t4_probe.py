@@ -19,7 +19,7 @@ w1, b1, w2, b2 = torch.randn(T, S) / 14, torch.randn(T), torch.randn(S, T) / 20,
 flops = 2.0 * B_ * C * S * T * 2
 for lay in (1, 2):
     for st in (False, True):
-        for dbg in ([0] if lay == 1 else [0, 1, 2, 4, 3, 8, 16, 32, 48, 52]):
+        for dbg in ([0] if lay == 1 else [int(v) for v in os.environ.get("DBGS", "0,1,2,4,3,8,16,32,48,52").split(",")]):
             os.environ["MLPK_T4_DBG"] = str(dbg)
             pk = E.pack_token_mlp(w1, b1, w2, b2, dt, "cuda", sp, layout=lay, t_rows=C)
             part = torch.empty(E.token_mlp_stat_planes(C, lay), B_ * S, 2, device="cuda") if st else None
