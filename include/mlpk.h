@@ -185,8 +185,6 @@ int mlpk_token_mlp(int dtype, const void* xt, int ldxt, int M, int S, const void
  *           of group g, k slot 16 kk + 8 h + e (kk, h = 0..1, e = 0..7) = hidden 16 kk + 8 (e >> 2) + 4 h + (e & 3); group nchunks
  *           is all zeros (what the pipeline's fill iterations multiply by);
  *      b1 : 1024 floats, entry 64 + t = bias of hidden unit t, zeros elsewhere;   b2 : 224 floats, zeros behind S;
- *      MLPK_BF16 only: w1 and b1 carry a factor 1/4 and w2 a factor 4 (powers of two, applied to the ROUNDED weights: every
- *      product is the unscaled one times a power of two) -- the kernel's GELU polynomial takes x / 4;
  *      stats: planes of 64 channels (t_rows / 64 planes of B*S pairs) instead of 128.
  * mlpk_token_mlp_layout_for additionally knows the channels per image and answers 2 when the generated kernel takes the shape. */
 int mlpk_token_mlp_layout(int S, int nchunks);

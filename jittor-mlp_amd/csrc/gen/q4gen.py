@@ -27,11 +27,13 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from isa import A, F, S, V, Asm, Neg, Reg  # noqa: E402
 
-# the 16-bit GELU polynomials of mlpk_common.h (MLPK_GELUP_*): scale and Horner coefficients by storage type
+# the 16-bit GELU polynomials of mlpk_common.h (MLPK_GELUP_*) by storage type.  f16: (scale, Horner coefficients) of the centred form
+# t = clamp(x * scale, -sqrt2, sqrt2), u = t * t - 1; bf16: (clamp, coefficients) of the raw form t = clamp(x, -clamp, clamp), u = t * t
 GELU = {"f16": (0.314269681, [0.00260713836, -0.00718860654, 0.00979797821, -0.0172248576, 0.0355015062, -0.0601866171, 0.090279378,
                               -0.127707109, 0.174028099, -0.245624334, 0.499268919]),
-        "bf16": (0.353553391, [-0.00937665813, 0.0246067308, -0.0355258957, 0.059637472, -0.103835642, 0.158927634, -0.238559365,
-                               0.497641712])}
+        "bf16": (4.0, [-1.58078628e-09, 1.21711111e-07, -4.10086659e-06, 8.06673925e-05, -0.00104820437, 0.00966487452, -0.0661753789,
+                       0.39884752])}
+GELU_RAW = {"f16": False, "bf16": True}
 SQRT2 = 1.41421356237
 
 STAGE_B = 49152          # one LDS stage: A 256 x 128 B, then B 128 x 128 B
@@ -320,12 +322,18 @@ class Q4:
     def gelu_ops(self, E, x, t, u, q):
         """x[r] <- gelu(x[r]) for the 4 chains abreast (the operation sequence of gelu16_f in mlpk_common.h)"""
         scale, c = GELU[self.dtype]
-        for r in range(4):
-            E("v_mul_f32", t[r], F(scale), x[r])
-        for r in range(4):
-            E("v_med3_f32", t[r], t[r], Neg(self.s_r2), self.s_r2)
-        for r in range(4):
-            E("v_fma_f32", u[r], t[r], t[r], F(-1.0))
+        if GELU_RAW[self.dtype]:
+            for r in range(4):
+                E("v_med3_f32", t[r], x[r], F(-scale), F(scale))
+            for r in range(4):
+                E("v_mul_f32", u[r], t[r], t[r])
+        else:
+            for r in range(4):
+                E("v_mul_f32", t[r], F(scale), x[r])
+            for r in range(4):
+                E("v_med3_f32", t[r], t[r], Neg(self.s_r2), self.s_r2)
+            for r in range(4):
+                E("v_fma_f32", u[r], t[r], t[r], F(-1.0))
         for r in range(4):
             E("v_fmaak_f32", q[r], u[r], self.v_c0, F(c[1]))
         for k in range(2, len(c)):

@@ -21,17 +21,16 @@ def w2_slot_source():
 
 
 def pack(w1, b1, w2, b2, dt):
-    """w1 (T, S), w2 (S, T) fp -> the layout-2 buffers of mlpk_token_mlp: W1 (G*32, 256), b1 (1024), W2 ((G+1)*224, 32), b2 (224);
-    bf16: W1 and b1 times 1/4, W2 times 4 AFTER rounding to the storage type (exact)"""
+    """w1 (T, S), w2 (S, T) fp -> the layout-2 buffers of mlpk_token_mlp: W1 (G*32, 256), b1 (1024), W2 ((G+1)*224, 32), b2 (224)
+    """
     T, S = w1.shape
     G = (T + 31) // 32
-    f1, f2 = (t4gen.FOLD, 1.0 / t4gen.FOLD) if dt == "bf16" else (1.0, 1.0)
     w1p = np.zeros((G * 32, 256), np.uint16)
-    w1p[:T, :S] = to16(from16(to16(w1, dt), dt) * np.float32(f1), dt)
+    w1p[:T, :S] = to16(w1, dt)
     b1p = np.zeros(1024, np.float32)
-    b1p[64:64 + T] = b1 * np.float32(f1)
+    b1p[64:64 + T] = b1
     w2z = np.zeros((S, G * 32), np.uint16)
-    w2z[:, :T] = to16(from16(to16(w2, dt), dt) * np.float32(f2), dt)
+    w2z[:, :T] = to16(w2, dt)
     w2p = np.zeros((G + 1, 224, 32), np.uint16)
     src = w2_slot_source()
     for g in range(G):

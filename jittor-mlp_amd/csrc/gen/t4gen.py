@@ -27,7 +27,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from isa import A, F, S, V, Asm, Neg, Reg  # noqa: E402
-from q4gen import GELU, SQRT2, Alloc  # noqa: E402
+from q4gen import GELU, GELU_RAW, SQRT2, Alloc  # noqa: E402
 
 KA = dict(xt=0, w1=8, w2=16, b1=24, b2=32, x=40, stats=48, prof=56,
           M=64, G=68, ldxt=72, ldx=76, ntiles=80, tpi=84, tpi_magic=88, grid=92, stat_ld=96, nit=100, lead=104, S=108)
@@ -44,11 +44,6 @@ STG_OFF = B1_OFF + 4096
 STG_BUF = 4 * STG_WAVE                   # two staging buffers (token blocks alternate): block tb + 1 is written while tb is read back
 LDS_BYTES = STG_OFF + 2 * STG_BUF
 W2_GROUP_BYTES = 224 * 64                # one hidden group of the packed W2: 224 token rows x 32 k slots
-# bf16: Phi(x) ~= 0.5 + t P(t^2), t = clamp(x / 4, -1, 1) (tools/fit_gelu_poly.py 4.0 K folded: the fit of MLPK_GELUP_*_BF16 in the
-# variable x / 4; |gelu error| < 9e-5 on |x| <= 4 and < 6e-5 |x| beyond for K = 8, 4.2e-4 / 1.1e-4 |x| for K = 7)
-GELU_FOLDED = {8: [-1.69735634, 8.16789436, -17.2002811, 21.1464729, -17.1737804, 9.89683151, -4.23522425, 1.59539008],
-               7: [1.88985848, -7.93517828, 14.2057104, -14.4012365, 9.33166599, -4.18485498, 1.59410763]}
-FOLD = 0.25                              # what the host multiplies W1 and b1 by for bf16 (and W2 by 1 / FOLD)
 W1_MAGIC, W2_MAGIC = 1986, 13108         # (o * magic) >> 20 == o // pitch for the multiples of 16 below one stage
 assert all((o * W1_MAGIC) >> 20 == o // W1_PITCH for o in range(0, W1_STAGE, 16))
 assert all((o * W2_MAGIC) >> 20 == o // W2_PITCH for o in range(0, W2_STAGE, 16))
@@ -62,15 +57,14 @@ class T4:
 
     def __init__(self, dtype="bf16", stats=False, dbg=0, name=None):
         # tuning ablations (wrong results by construction): 1 no LDS-DMA, 2 no GELU fillers, 4 no epilogue stores, 16 no residual loads,
-        # 32 no X loads; 8: the 7-coefficient polynomial
+        # 32 no X loads
         self.dtype, self.stats, self.dbg = dtype, stats, dbg
         self.name = name or "t4_%s%s" % (dtype, "_st" if stats else "")
         self.mfma = "v_mfma_f32_32x32x16_bf16" if dtype == "bf16" else "v_mfma_f32_32x32x16_f16"
         self.cvt = "v_cvt_pk_bf16_f32" if dtype == "bf16" else "v_cvt_pk_f16_f32"
         self.dot = "v_dot2c_f32_bf16" if dtype == "bf16" else "v_dot2c_f32_f16"
-        # bf16: argument scale folded into the weights (see gelu_ops); dbg 8: the 7-coefficient polynomial (tuning)
-        self.folded = dtype == "bf16"
-        self.coefs = GELU_FOLDED[7 if (dbg & 8) else 8] if self.folded else GELU[dtype][1]
+        self.raw = GELU_RAW[dtype]
+        self.coefs = GELU[dtype][1]
         self.a = Asm()
         self.build()
 
@@ -173,9 +167,7 @@ class T4:
         """xg[par_in] (fc1 + b1 of a group, the accumulator layout) -> h[par_out][rb][kk] (A fragments of the second product).
         Plain fp32 VALU operations, four independent chains abreast: v_pk_*_f32 would halve the count but does not overlap with
         the matrix pipe (one v_pk_fma_f32 between two MFMAs costs 17 cycles, tools/ubench/q4_slots.py, profiles/r03_t4_issue_slots.txt).
-        bf16: the host folds the argument scale 1/4 into W1 and b1 (and 4 into W2 -- powers of two, exact), so the first product
-        delivers s = x / 4 and    h / 4 = s * (0.5 + t P(t^2)),  t = clamp(s, -1, 1)      10 (11) operations per element;
-        f16: the operation sequence of gelu16_f (mlpk_common.h), 15 per element."""
+        The operation sequence of gelu16_f (mlpk_common.h): bf16 11 operations per element (raw form), f16 15 (centred form)."""
         a = self.a
         ops = []
 
@@ -185,14 +177,13 @@ class T4:
         for rb in range(2):
             for grp in range(4):                      # accumulator registers 4 grp .. 4 grp + 3
                 x = [self.xg[par_in][rb][4 * grp + r] for r in range(4)]
-                if self.folded:
-                    c = self.coefs
+                scale, c = GELU[self.dtype]
+                if self.raw:
                     for r in range(4):
-                        E("v_med3_f32", T[r], x[r], F(-1.0), F(1.0))
+                        E("v_med3_f32", T[r], x[r], F(-scale), F(scale))
                     for r in range(4):
                         E("v_mul_f32", U[r], T[r], T[r])
                 else:
-                    scale, c = GELU[self.dtype]
                     for r in range(4):
                         E("v_mul_f32", T[r], F(scale), x[r])
                     for r in range(4):
@@ -611,7 +602,7 @@ def variants():
     for dt in ("bf16", "f16"):
         for st in (False, True):
             out.append(dict(dtype=dt, stats=st))
-    for dbg in (1, 2, 4, 3, 8, 16, 32, 48, 52):
+    for dbg in (1, 2, 4, 3, 16, 32, 48, 52):
         out.append(dict(dtype="bf16", stats=True, dbg=dbg, name="t4_bf16_st_dbg%d" % dbg))
     return out
 

@@ -57,25 +57,37 @@ __device__ __forceinline__ float gelu_f(float x) {
 // float outputs keep gelu_f.
 // Two grades (tools/fit_gelu_poly.py A K), by storage type of the result:
 //   f16 : A = 4.5, 11 coefficients -- |Phi error| <= 2.7e-6, |gelu error| <= 3.7e-6 on |x| <= 4.5 (60x below half an ulp of f16)
-//   bf16: A = 4.0,  8 coefficients -- |Phi error| <= 5.3e-5, |gelu error| <= 8.5e-5 on |x| <= 4 (half an ulp of bf16 is 2^-9 relative:
+//   bf16: A = 4.0,  8 coefficients -- |Phi error| <= 5.3e-5, |gelu error| <= 9e-5 on |x| <= 4 (half an ulp of bf16 is 2^-9 relative:
 //         the polynomial error stays below the rounding of every result above 0.04 in magnitude); three fewer fma per element in the
-//         kernels whose epilogues are bound by VALU issue (round 3: the q4 GEMM's fillers, the token-mixing kernel).
+//         kernels whose epilogues are bound by VALU issue (round 3: the q4 GEMM's fillers, the token-mixing kernel).  At this grade the
+//         SAME fit is evaluated in the variable the kernels have at hand, without the scaling multiply in front of the clamp:
+//             Phi(x) ~= 0.5 + t * R(t * t),  t = clamp(x, -4, 4)          (tools/fit_gelu_poly.py 4.0 8 raw)
+//         -- R's coefficients sum to 81 in the variable (t/4)^2, i.e. ~5e-6 of fp32 cancellation, nothing against 9e-5; the f16
+//         grade (sum 500+) keeps the centred variable.  11 operations per element instead of 12.
 #define MLPK_GELUP_SCALE 0.314269681f
 #define MLPK_GELUP_COEFS {0.00260713836f, -0.00718860654f, 0.00979797821f, -0.0172248576f, 0.0355015062f, -0.0601866171f, 0.090279378f, -0.127707109f, 0.174028099f, -0.245624334f, 0.499268919f}
-#define MLPK_GELUP_SCALE_BF16 0.353553391f
-#define MLPK_GELUP_COEFS_BF16 {-0.00937665813f, 0.0246067308f, -0.0355258957f, 0.059637472f, -0.103835642f, 0.158927634f, -0.238559365f, 0.497641712f}
+#define MLPK_GELUP_CLAMP_BF16 4.0f
+#define MLPK_GELUP_COEFS_BF16 {-1.58078628e-09f, 1.21711111e-07f, -4.10086659e-06f, 8.06673925e-05f, -0.00104820437f, 0.00966487452f, -0.0661753789f, 0.39884752f}
 
 // gelu on N independent pairs with the N dependency chains interleaved step by step: a single wave running ONE
 // chain is latency-bound (each v_pk op waits for its predecessor); N = 4 keeps the VALU issuing back to back.
-template <int N, int K> __device__ __forceinline__ void gelu_pk_impl(f32x2 (&x)[N], const float (&c)[K], const float scale) {
+// RAW: the bf16 grade's form (t = clamp(x, -scale, scale), u = t * t); else t = clamp(x * scale, -sqrt2, sqrt2), u = t * t - 1
+template <int N, int K, bool RAW> __device__ __forceinline__ void gelu_pk_impl(f32x2 (&x)[N], const float (&c)[K], const float scale) {
     constexpr float r2 = 1.41421356237f;
     f32x2 t[N], u[N], q[N];
+    if constexpr (RAW) {
 #pragma unroll
-    for (int k = 0; k < N; ++k) t[k] = x[k] * f32x2{scale, scale};
+        for (int k = 0; k < N; ++k) t[k] = f32x2{__builtin_amdgcn_fmed3f(x[k].x, -scale, scale), __builtin_amdgcn_fmed3f(x[k].y, -scale, scale)};
 #pragma unroll
-    for (int k = 0; k < N; ++k) t[k] = f32x2{__builtin_amdgcn_fmed3f(t[k].x, -r2, r2), __builtin_amdgcn_fmed3f(t[k].y, -r2, r2)};
+        for (int k = 0; k < N; ++k) u[k] = t[k] * t[k];
+    } else {
 #pragma unroll
-    for (int k = 0; k < N; ++k) u[k] = __builtin_elementwise_fma(t[k], t[k], f32x2{-1.0f, -1.0f});
+        for (int k = 0; k < N; ++k) t[k] = x[k] * f32x2{scale, scale};
+#pragma unroll
+        for (int k = 0; k < N; ++k) t[k] = f32x2{__builtin_amdgcn_fmed3f(t[k].x, -r2, r2), __builtin_amdgcn_fmed3f(t[k].y, -r2, r2)};
+#pragma unroll
+        for (int k = 0; k < N; ++k) u[k] = __builtin_elementwise_fma(t[k], t[k], f32x2{-1.0f, -1.0f});
+    }
 #pragma unroll
     for (int k = 0; k < N; ++k) q[k] = __builtin_elementwise_fma(u[k], f32x2{c[0], c[0]}, f32x2{c[1], c[1]});
 #pragma unroll
@@ -89,10 +101,10 @@ template <int N, int K> __device__ __forceinline__ void gelu_pk_impl(f32x2 (&x)[
 template <typename T, int N> __device__ __forceinline__ void gelu_pk_n(f32x2 (&x)[N]) {
     if constexpr (dtype_of<T>::value == MLPK_BF16) {
         constexpr float c[8] = MLPK_GELUP_COEFS_BF16;
-        gelu_pk_impl<N, 8>(x, c, MLPK_GELUP_SCALE_BF16);
+        gelu_pk_impl<N, 8, true>(x, c, MLPK_GELUP_CLAMP_BF16);
     } else {
         constexpr float c[11] = MLPK_GELUP_COEFS;
-        gelu_pk_impl<N, 11>(x, c, MLPK_GELUP_SCALE);
+        gelu_pk_impl<N, 11, false>(x, c, MLPK_GELUP_SCALE);
     }
 }
 
@@ -103,10 +115,10 @@ template <typename T> __device__ __forceinline__ f32x2 gelu_pk(f32x2 x) {
 }
 
 // scalar form of gelu_pk (the same operation sequence, hence the same results)
-template <int K> __device__ __forceinline__ float gelu16_impl(float x, const float (&c)[K], const float scale) {
+template <int K, bool RAW> __device__ __forceinline__ float gelu16_impl(float x, const float (&c)[K], const float scale) {
     constexpr float r2 = 1.41421356237f;
-    const float t = __builtin_amdgcn_fmed3f(x * scale, -r2, r2);
-    const float u = __builtin_fmaf(t, t, -1.0f);
+    const float t = RAW ? __builtin_amdgcn_fmed3f(x, -scale, scale) : __builtin_amdgcn_fmed3f(x * scale, -r2, r2);
+    const float u = RAW ? t * t : __builtin_fmaf(t, t, -1.0f);
     float q = __builtin_fmaf(u, c[0], c[1]);
 #pragma unroll
     for (int i = 2; i < K; ++i) q = __builtin_fmaf(q, u, c[i]);
@@ -116,10 +128,10 @@ template <int K> __device__ __forceinline__ float gelu16_impl(float x, const flo
 template <typename T> __device__ __forceinline__ float gelu16_f(float x) {
     if constexpr (dtype_of<T>::value == MLPK_BF16) {
         constexpr float c[8] = MLPK_GELUP_COEFS_BF16;
-        return gelu16_impl<8>(x, c, MLPK_GELUP_SCALE_BF16);
+        return gelu16_impl<8, true>(x, c, MLPK_GELUP_CLAMP_BF16);
     } else {
         constexpr float c[11] = MLPK_GELUP_COEFS;
-        return gelu16_impl<11>(x, c, MLPK_GELUP_SCALE);
+        return gelu16_impl<11, false>(x, c, MLPK_GELUP_SCALE);
     }
 }
 

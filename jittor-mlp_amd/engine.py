@@ -302,10 +302,6 @@ def pack_token_mlp(w1, b1, w2, b2, dtype, device, sp, layout=None, t_rows=None):
         src = (16 * kk + 8 * (e // 4) + 4 * hh + (e % 4)).to(device)
         w2g = torch.zeros((nch + 1, 224, 32), dtype=dtype, device=device)
         w2g[:nch, :S] = w2p.view(S, nch, 32)[:, :, src].permute(1, 0, 2)
-        if dtype == torch.bfloat16:
-            # the kernel's GELU takes x / 4: W1 and b1 carry the 1/4, W2 the 4 (powers of two applied AFTER the rounding to bf16:
-            # every product and the rounded hidden are the unscaled ones times a power of two, so nothing changes bit-wise)
-            w1p, b1p, w2g = (w1p.float() * 0.25).to(dtype), b1p * 0.25, (w2g.float() * 4.0).to(dtype)
         b1t = torch.zeros((1024,), dtype=torch.float32, device=device)
         b1t[64:64 + nch * ch] = b1p
         b2t = torch.zeros((224,), dtype=torch.float32, device=device)

@@ -201,9 +201,10 @@ def test_hand_scheduled_gemm_loops_have_no_compiler_vmem_waits():
 def test_division_free_gelu_coefficients():
     """The polynomial GELUs of the 16-bit epilogues (csrc/mlpk_common.h, fitted by tools/fit_gelu_poly.py), evaluated here in
     emulated fp32 Horner arithmetic with the coefficients parsed from the header, against the exact erf form (mlp_mixer.py:21
-    nn.GELU): the f16 grade stays below 4e-6 on |x| <= 4.5 and below 4e-6 relative to |x| beyond; the bf16 grade (three fewer fma)
-    below 9e-5 on |x| <= 4 and 6e-5 relative beyond -- under half an ulp of bf16 (2^-9 relative) for every result above 0.04.
-    The generated q4 GEMM kernels (csrc/gen/q4gen.py) carry the same numbers."""
+    nn.GELU): the f16 grade stays below 4e-6 on |x| <= 4.5 and below 4e-6 relative to |x| beyond; the bf16 grade (three fewer fma,
+    and the raw form t = clamp(x, -4, 4), u = t * t: no scaling multiply) below 9e-5 on |x| <= 4 and 6e-5 relative beyond -- under
+    half an ulp of bf16 (2^-9 relative) for every result above 0.04.  The generated kernels (csrc/gen/q4gen.py, t4gen.py) carry the
+    same numbers and the same forms."""
     import numpy as np
     from scipy.special import erf
     src = open(os.path.join(ROOT, "jittor-mlp_amd", "csrc", "mlpk_common.h")).read()
@@ -213,15 +214,20 @@ def test_division_free_gelu_coefficients():
     def fma(a, b, c):
         return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
 
-    for suffix, ncoef, bound, inner, rel, gen_key in (("", 11, 4.5, 4e-6, 4e-6, "f16"), ("_BF16", 8, 4.0, 9e-5, 6e-5, "bf16")):
-        coefs = [np.float32(v) for v in re.search(r"#define MLPK_GELUP_COEFS%s \{([^}]*)\}" % suffix, src).group(1).replace("f", "").split(",")]
-        scale = np.float32(re.search(r"#define MLPK_GELUP_SCALE%s ([0-9.]+)f" % suffix, src).group(1))
+    for suffix, ncoef, bound, inner, rel, gen_key, raw in (("", 11, 4.5, 4e-6, 4e-6, "f16", False), ("_BF16", 8, 4.0, 9e-5, 6e-5, "bf16", True)):
+        coefs = [np.float32(v) for v in re.search(r"#define MLPK_GELUP_COEFS%s \{([^}]*)\}" % suffix, src).group(1).replace("f,", ",").rstrip("f").split(",")]
+        scale = np.float32(re.search(r"#define MLPK_GELUP_%s ([0-9.]+)f" % ("CLAMP_BF16" if raw else "SCALE"), src).group(1))
         assert len(coefs) == ncoef
         assert np.float32(q4gen.GELU[gen_key][0]) == scale and [np.float32(v) for v in q4gen.GELU[gen_key][1]] == coefs
+        assert q4gen.GELU_RAW[gen_key] == raw
         x = np.concatenate([np.linspace(-12, 12, 400001), np.linspace(-1e-3, 1e-3, 2001)]).astype(np.float32)
         r2 = np.float32(np.sqrt(2.0))
-        t = np.clip((x * scale).astype(np.float32), -r2, r2)
-        u = fma(t, t, np.full_like(t, -1.0))
+        if raw:
+            t = np.clip(x, -scale, scale)
+            u = (t * t).astype(np.float32)
+        else:
+            t = np.clip((x * scale).astype(np.float32), -r2, r2)
+            u = fma(t, t, np.full_like(t, -1.0))
         q = np.full_like(t, coefs[0])
         for c in coefs[1:]:
             q = fma(q, u, np.full_like(t, c))

@@ -2,11 +2,11 @@
 GELU + residual, mlp_mixer.py:16-27,34,37) WITHOUT a GPU: the instruction list that becomes the asm block runs on the numpy
 emulator of csrc/gen/isa.py (four waves, LDS rings filled by LDS-DMA, MFMA 32x32x16, one counted wait + barrier per iteration,
 modelled adversarially) and is compared with an fp64 restatement, by-product statistics included.  Also the hazard lint over
-every shipped variant, mutations of the synchronisation the emulator must catch, and the accuracy of the folded GELU."""
+every shipped variant and mutations of the synchronisation the emulator must catch.  (The GELU polynomial is q4gen.GELU =
+mlpk_common.h's: tests/test_host_cpu.py::test_division_free_gelu_coefficients.)"""
 import os
 import sys
 
-import numpy as np
 import pytest
 
 GEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "jittor-mlp_amd", "csrc", "gen")
@@ -70,27 +70,3 @@ def test_emulator_catches_protocol_faults():
                 ok = False
             caught = caught or not ok
         assert caught, mut.__name__
-
-
-def test_folded_gelu_coefficients():
-    """bf16 kernels take s = x / 4 from the first product (the host folds 1/4 into W1 and b1, 4 into W2): Phi(x) ~= 0.5 + t P(t^2),
-    t = clamp(s, -1, 1), evaluated as the kernel does (fp32 Horner).  Same grade as MLPK_GELUP_*_BF16 (tests/test_host_cpu.py):
-    below 9e-5 on |x| <= 4 and 6e-5 |x| beyond against the erf form (mlp_mixer.py:21 nn.GELU)."""
-    from scipy.special import erf
-
-    def fma(a, b, c):
-        return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
-    c = [np.float32(v) for v in t4gen.GELU_FOLDED[8]]
-    x = np.concatenate([np.linspace(-12, 12, 400001), np.linspace(-1e-3, 1e-3, 2001)]).astype(np.float32)
-    s = (x * np.float32(t4gen.FOLD)).astype(np.float32)
-    t = np.clip(s, np.float32(-1), np.float32(1))
-    u = (t * t).astype(np.float32)
-    q = np.full_like(t, c[0])
-    for ck in c[1:]:
-        q = fma(q, u, np.full_like(t, ck))
-    got = (x * fma(t, q, np.full_like(t, 0.5))).astype(np.float32).astype(np.float64)
-    ref = x.astype(np.float64) * 0.5 * (1.0 + erf(x.astype(np.float64) / np.sqrt(2.0)))
-    err = np.abs(got - ref)
-    inside = np.abs(x) <= 4.0
-    assert err[inside].max() < 9e-5
-    assert (err[~inside] / np.abs(x[~inside])).max() < 6e-5

@@ -85,3 +85,29 @@ if len(sys.argv) > 3 and sys.argv[3] == "folded":
              (np.abs(g2 - ref)[np.abs(xs) > A] / np.abs(xs[np.abs(xs) > A])).max(), np.abs(pw).sum()))
     print("coefficients (Horner order, w^%d first):" % (K - 1))
     print(", ".join("%.9g" % v for v in pw))
+
+if len(sys.argv) > 3 and sys.argv[3] == "raw":
+    # the same fit in the variable the kernels have at hand: Phi(x) ~= 0.5 + t * R(t * t), t = clamp(x, -A, A) -- no scaling multiply
+    # in front of the clamp: t = (A / sqrt2) t', u' = 2 (t / A)^2 - 1  ->  R(v) = (sqrt2 / A) Q(2 v / A^2 - 1)
+    comp = np.zeros(K)
+    base = np.ones(1)
+    for k in range(K):
+        comp[:len(base)] += mono[k] * base
+        base = P.polymul(base, [-1.0, 2.0 / (A * A)])
+    rv = (comp * R2 / A)[::-1].astype(np.float32)          # Horner order in v = t^2
+
+    def gelu_raw32(x):
+        x = x.astype(np.float32)
+        tt = np.clip(x, np.float32(-A), np.float32(A))
+        v_ = (tt * tt).astype(np.float32)
+        q = np.full_like(tt, rv[0])
+        for cc in rv[1:]:
+            q = fma32(q, v_, np.full_like(tt, cc))
+        ph = fma32(tt, q, np.full_like(tt, np.float32(0.5)))
+        return (x * ph).astype(np.float32), ph
+    g3, ph3 = gelu_raw32(xs)
+    print("raw form: max |Phi err| = %.3e   max |gelu err| on |x| <= A: %.3e   max rel beyond: %.3e"
+          % (np.abs(ph3 - ref_phi).max(), np.abs(g3 - ref)[np.abs(xs) <= A].max(),
+             (np.abs(g3 - ref)[np.abs(xs) > A] / np.abs(xs[np.abs(xs) > A])).max()))
+    print("coefficients (Horner order, v^%d first):" % (K - 1))
+    print(", ".join("%.9g" % v for v in rv))
