@@ -55,11 +55,15 @@ class T4:
     NXA = 8                                # X fragments kept in the 32 AGPRs the accumulators leave over
     DEPTH = 3                              # W fragments read ahead of their MFMAs (ring of 4 register quads)
 
-    def __init__(self, dtype="bf16", stats=False, dbg=0, name=None):
+    def __init__(self, dtype="bf16", stats=False, dbg=0, name=None, shape=0):
+        # shape: 0 = every iteration runs all three stages (pipeline fill / drain on dummy groups; any G); 1 / 2 = G odd (>= 3) / even
+        # (>= 2): the fill and drain iterations are emitted without the stages that have nothing to do, the next tile's X is
+        # requested two iterations before the tile ends
+        self.shape = shape
         # tuning ablations (wrong results by construction): 1 no LDS-DMA, 2 no GELU fillers, 4 no epilogue stores, 16 no residual loads,
         # 32 no X loads
         self.dtype, self.stats, self.dbg = dtype, stats, dbg
-        self.name = name or "t4_%s%s" % (dtype, "_st" if stats else "")
+        self.name = name or "t4_%s%s%s" % (dtype, "_st" if stats else "", ("", "_odd", "_even")[shape])
         self.mfma = "v_mfma_f32_32x32x16_bf16" if dtype == "bf16" else "v_mfma_f32_32x32x16_f16"
         self.cvt = "v_cvt_pk_bf16_f32" if dtype == "bf16" else "v_cvt_pk_f16_f32"
         self.dot = "v_dot2c_f32_bf16" if dtype == "bf16" else "v_dot2c_f32_f16"
@@ -242,10 +246,18 @@ class T4:
         self.a("global_load_lds_dwordx4", voff, src)
 
     # ------------------------------------------------------------------ one pipeline iteration (static parity)
-    def iteration(self, par):
+    def iteration(self, par, fc2=True, fc1=True, gelu=True, xload=False, vm_allow=0):
         """fc2(g-2) from W2 stage par and h[par]; fc1(g) from W1 stage par into xg[par]; gelu(g-1): xg[1-par] -> h[1-par];
-        LDS-DMA of W1(g+1) / W2(g-1) into the stages 1-par."""
+        LDS-DMA of W1(g+1) / W2(g-1) into the stages 1-par.  Stages can be left out (fill / drain of the pipeline); xload: the next
+        tile's X fragments are requested behind this iteration's DMA pieces (the registers are dead: no fc1 from here to the tile's
+        end); vm_allow: vector-memory operations that may stay in flight across the iteration's barrier (those X loads)."""
         a, t, k = self.a, self.s_t, self.k
+        if xload:
+            a("s_add_u32", self.s_next, self.s_tile, k["grid"])
+            a("s_cmp_lt_u32", self.s_next, k["ntiles"])
+            a("s_cselect_b32", self.s_has, 1, 0)
+            a("s_cselect_b32", t[4], self.s_next, self.s_tile)      # no next tile: this one again (the wait counts stay static)
+            self.tile_xbase(t[4])
         # group of the next iteration (wraps to the first iteration of the next tile)
         a("s_add_i32", t[0], self.s_g, 1)
         a("s_add_i32", t[1], k["G"], 2)
@@ -253,13 +265,33 @@ class T4:
         a("s_cmp_ge_i32", t[0], t[1])
         a("s_cselect_b32", t[0], t[2], t[0])
         self.dma_sources()
-        a("s_waitcnt", vmcnt=0, lgkmcnt=0)
+        a("s_waitcnt", vmcnt=vm_allow, lgkmcnt=0)
         a("s_barrier")
         self.lgkm_issued = 0
-        fill = [] if (self.dbg & 2) else self.gelu_ops(1 - par, 1 - par)
+        fill = [] if ((self.dbg & 2) or not gelu) else self.gelu_ops(1 - par, 1 - par)
         dma = [] if (self.dbg & 1) else [(kind, i) for i in range(5) for kind in ("w1", "w2")]
+        xl = []
+        if xload and not (self.dbg & 32):
+            xl = [(rb, ks) for rb in range(2) for ks in range(self.NKS)]
         state = {"done": 0, "gap": 0}
-        ngaps, total = 2 * (2 * self.NTB + self.NKS), len(fill)
+        frs = ([("w2", kk, tb) for kk in range(2) for tb in range(self.NTB)] if fc2 else []) + \
+              ([("w1", ks, None) for ks in range(self.NKS)] if fc1 else [])
+        ngaps, total = 2 * len(frs), len(fill)
+
+        def emit_xload():
+            rb, ks = xl.pop(0)
+            self.a("global_load_dwordx4", self.X[rb][ks], self.v_xoff, self.s_xb[rb], offset=32 * ks)
+        if not frs:
+            # nothing to multiply (the lead iteration of an odd group count): the DMA pieces alone
+            while dma:
+                kind, i = dma.pop(0)
+                self.emit_m0(kind, i, 1 - par)
+                a("s_nop", 0)
+                self.emit_dma(kind, i, 1 - par)
+            assert not fill and not xl
+            a("s_add_i32", self.s_g, self.s_g, 1)
+            a("v_add_u32", self.v_b1rd, 128, self.v_b1rd)
+            return
 
         def gap():
             state["gap"] += 1
@@ -275,24 +307,29 @@ class T4:
             if dma:
                 kind, i = dma.pop(0)
                 self.emit_dma(kind, i, 1 - par)
+            elif xl:
+                emit_xload()
             gap()
-        # the 28 fragment reads of the iteration, in the order of their use
-        frs = [("w2", kk, tb) for kk in range(2) for tb in range(self.NTB)] + [("w1", ks, None) for ks in range(self.NKS)]
 
         def read(n):
             kind, x, tb = frs[n]
             if kind == "w2":
                 return self.ds("ds_read_b128", self.Wf[n & 3], self.v_w2rd, offset=par * W2_STAGE + tb * 32 * W2_PITCH + x * 32)
             return self.ds("ds_read_b128", self.Wf[n & 3], self.v_w1rd, offset=W1_OFF + par * W1_STAGE + x * 32)
+
+        def b1_reads():                          # b1(g): the accumulator initialiser of fc1(g)
+            for qd in range(4):
+                self.ds("ds_read_b128", self.b1[4 * qd:4 * qd + 4], self.v_b1rd, offset=32 * qd)
+        if fc1 and not fc2:
+            b1_reads()                           # (LDS operations complete in order: the wait for fragment 0 covers them)
         rd = {}
         for n in range(self.DEPTH):
             rd[n] = read(n)
         for n, (kind, x, tb) in enumerate(frs):
             if n + self.DEPTH < len(frs):
                 rd[n + self.DEPTH] = read(n + self.DEPTH)
-            if n == 6:                           # b1(g): the accumulator initialiser of fc1(g)
-                for qd in range(4):
-                    self.ds("ds_read_b128", self.b1[4 * qd:4 * qd + 4], self.v_b1rd, offset=32 * qd)
+            if n == 6 and fc1 and fc2:
+                b1_reads()
             self.wait_lds(rd[n])
             wf = self.Wf[n & 3]
             for rb in range(2):
@@ -303,6 +340,8 @@ class T4:
         while state["done"] < total:
             fill[state["done"]]()
             state["done"] += 1
+        while xl:
+            emit_xload()
         assert not dma
         a("s_add_i32", self.s_g, self.s_g, 1)
         a("v_add_u32", self.v_b1rd, 128, self.v_b1rd)
@@ -551,23 +590,57 @@ class T4:
                     for r in range(4):
                         a("v_mov_b32", self.h[par][rb][kk][r], 0)
         a("s_sub_u32", self.s_g, 0, k["lead"])
-        a("s_lshr_b32", self.s_cnt, k["nit"], 1)
-        a.label(L_iter)
-        self.iteration(0)
-        self.iteration(1)
-        a("s_sub_u32", self.s_cnt, self.s_cnt, 1)
-        a("s_cmp_lg_u32", self.s_cnt, 0)
-        a("s_cbranch_scc1", L_iter)
+        nx = 0 if (self.dbg & 32) else 2 * self.NKS
+        if self.shape == 0:
+            a("s_lshr_b32", self.s_cnt, k["nit"], 1)
+            a.label(L_iter)
+            self.iteration(0)
+            self.iteration(1)
+            a("s_sub_u32", self.s_cnt, self.s_cnt, 1)
+            a("s_cmp_lg_u32", self.s_cnt, 0)
+            a("s_cbranch_scc1", L_iter)
+        else:
+            # fill: group g's first product has nothing in front of it; drain: the last two groups' second products alone
+            L_skip = a.newlabel("NOLOOP")
+            if self.shape == 1:                     # G odd: a lead iteration keeps the stage parity static (28 = 27 + 1 iterations for G = 25)
+                self.iteration(0, fc2=False, fc1=False, gelu=False)          # g = -1: the DMA pieces only
+                self.iteration(1, fc2=False, gelu=False)                     # g = 0
+                self.iteration(0, fc2=False)                                 # g = 1
+                first, second = 1, 0
+                a("s_sub_u32", self.s_cnt, k["G"], 3)
+            else:
+                self.iteration(0, fc2=False, gelu=False)                     # g = 0
+                self.iteration(1, fc2=False)                                 # g = 1
+                first, second = 0, 1
+                a("s_sub_u32", self.s_cnt, k["G"], 2)
+            a("s_lshr_b32", self.s_cnt, self.s_cnt, 1)
+            a("s_cmp_eq_u32", self.s_cnt, 0)
+            a("s_cbranch_scc1", L_skip)
+            a.label(L_iter)
+            self.iteration(first)
+            self.iteration(second)
+            a("s_sub_u32", self.s_cnt, self.s_cnt, 1)
+            a("s_cmp_lg_u32", self.s_cnt, 0)
+            a("s_cbranch_scc1", L_iter)
+            a.label(L_skip)
+            if self.shape == 1:
+                self.iteration(1)                                            # g = G - 1
+                self.iteration(0, fc1=False, xload=True)                     # g = G
+                self.iteration(1, fc1=False, gelu=False, vm_allow=nx)        # g = G + 1
+            else:
+                self.iteration(0, fc1=False, xload=True)
+                self.iteration(1, fc1=False, gelu=False, vm_allow=nx)
         a("s_lshl_b32", t[0], k["nit"], 7)
         a("v_sub_u32", self.v_b1rd, self.v_b1rd, t[0])              # back to the first iteration's bias row
         # ---- next tile's X (the registers are dead from here on), then the epilogue
-        a("s_add_u32", self.s_next, self.s_tile, k["grid"])
-        a("s_cmp_lt_u32", self.s_next, k["ntiles"])
-        a("s_cselect_b32", self.s_has, 1, 0)
-        a("s_cbranch_scc0", L_nonext)
-        self.tile_xbase(self.s_next)
-        self.x_loads()
-        a.label(L_nonext)
+        if self.shape == 0:
+            a("s_add_u32", self.s_next, self.s_tile, k["grid"])
+            a("s_cmp_lt_u32", self.s_next, k["ntiles"])
+            a("s_cselect_b32", self.s_has, 1, 0)
+            a("s_cbranch_scc0", L_nonext)
+            self.tile_xbase(self.s_next)
+            self.x_loads()
+            a.label(L_nonext)
         self.lgkm_issued = 0
         self.vm_loads = 0
         a("s_nop", 7)                                                # the residual lands in registers the last MFMAs have just written
@@ -601,7 +674,8 @@ def variants():
     out = []
     for dt in ("bf16", "f16"):
         for st in (False, True):
-            out.append(dict(dtype=dt, stats=st))
+            for shape in (0, 1, 2):
+                out.append(dict(dtype=dt, stats=st, shape=shape))
     for dbg in (1, 2, 4, 3, 16, 32, 48, 52):
         out.append(dict(dtype="bf16", stats=True, dbg=dbg, name="t4_bf16_st_dbg%d" % dbg))
     return out
@@ -627,11 +701,11 @@ def emit(path):
             raise RuntimeError("%s: %d hazard lint findings, first: %s" % (g.name, len(pr), pr[0]))
         out.append(kernel_text(g))
         table.append((g.name, kw))
-    out.append("namespace mlpk {\nstruct T4Variant { const char* name; const void* fn; int dtype, stats, dbg; };\n"
+    out.append("namespace mlpk {\nstruct T4Variant { const char* name; const void* fn; int dtype, stats, dbg, shape; };\n"
                "static const T4Variant kT4Variants[] = {\n")
     for name, kw in table:
-        out.append("    {\"%s\", reinterpret_cast<const void*>(&%s), %s, %d, %d},\n" %
-                   (name, name, "MLPK_BF16" if kw["dtype"] == "bf16" else "MLPK_F16", kw["stats"], kw.get("dbg", 0)))
+        out.append("    {\"%s\", reinterpret_cast<const void*>(&%s), %s, %d, %d, %d},\n" %
+                   (name, name, "MLPK_BF16" if kw["dtype"] == "bf16" else "MLPK_F16", kw["stats"], kw.get("dbg", 0), kw.get("shape", 0)))
     out.append("};\n}  // namespace mlpk\n")
     text = "".join(out)
     if not os.path.exists(path) or open(path).read() != text:

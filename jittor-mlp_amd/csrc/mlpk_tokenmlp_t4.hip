@@ -5,6 +5,7 @@
 // accumulation, gelu16_f's operation sequence, the hidden rounded once to the storage type, one rounding after the residual add.
 #include "mlpk_common.h"
 #include "mlpk_tokenmlp_t4.h"
+#include <cstdlib>
 
 namespace mlpk {
 // kernarg block read by the generated code (offsets: KA in t4gen.py)
@@ -51,9 +52,14 @@ bool t4_supported(int dtype, int S, int G, int ldxt, int M, int t_rows, int ldx)
 
 int t4_launch(const T4Call& c, hipStream_t stream) {
     if (!t4_supported(c.dtype, c.S, c.G, c.ldxt, c.M, c.t_rows, c.ldx)) return MLPK_ESHAPE;
+    // shape: the kernels whose pipeline fill / drain iterations carry only the stages that have work exist per parity of G
+    // (MLPK_T4_SHAPE=0 forces the generic one: A/B aid); the ablation variants are generic
+    int shape = (c.G & 1) ? (c.G >= 3 ? 1 : 0) : (c.G >= 2 ? 2 : 0);
+    const char* es = getenv("MLPK_T4_SHAPE");
+    if (c.dbg || (es && es[0] == '0')) shape = 0;
     const T4Variant* v = nullptr;
     for (const T4Variant& k : kT4Variants)
-        if (k.dtype == c.dtype && k.stats == (c.stats != nullptr) && k.dbg == c.dbg) { v = &k; break; }
+        if (k.dtype == c.dtype && k.stats == (c.stats != nullptr) && k.dbg == c.dbg && k.shape == shape) { v = &k; break; }
     if (!v) return MLPK_ESHAPE;
     T4Args a;
     a.xt = c.xt; a.w1 = c.w1; a.w2 = c.w2; a.b1 = c.b1; a.b2 = c.b2; a.x = c.x; a.stats = c.stats; a.prof = c.prof;

@@ -21,6 +21,11 @@ CASES = [
     (dict(stats=True), 2, 512, 100, 3, "early", [3, 2, 1, 0]),              # ragged hidden size, workgroups with one and two tiles
     (dict(stats=False), 1, 768, 33, 1, "late", [2, 0, 3, 1]),               # three tiles in one workgroup, odd group count (lead iteration)
     (dict(dtype="f16", stats=True), 1, 512, 80, 2, "late", None),
+    # the kernels without dummy stages in the pipeline's fill / drain iterations (per parity of the group count)
+    (dict(stats=True, shape=1), 3, 256, 160, 2, "late", None),              # G = 5
+    (dict(stats=True, shape=1), 1, 512, 80, 1, "early", [3, 2, 1, 0]),      # G = 3: no steady-state loop at all
+    (dict(stats=False, shape=2), 2, 256, 128, 2, "late", [2, 0, 3, 1]),     # G = 4
+    (dict(dtype="f16", stats=True, shape=2), 1, 768, 64, 1, "early", None), # G = 2
 ]
 
 
@@ -38,7 +43,7 @@ def test_every_shipped_variant_passes_the_hazard_lint():
         assert isa.lint(g.a) == [], g.name
         assert g.nv <= 248 and g.ns <= 100, g.name
         n += 1
-    assert n >= 4
+    assert n >= 12
 
 
 def test_emulator_catches_protocol_faults():
@@ -60,7 +65,7 @@ def test_emulator_catches_protocol_faults():
             return 1
         return 0
     for mut in (no_barrier, loose_vmcnt, loose_lgkm):
-        g = t4gen.T4(stats=False)
+        g = t4gen.T4(stats=False, shape=mut is not loose_vmcnt)
         assert sum(mut(i) for i in g.a.ins) > 0
         caught = False
         for mode, order in (("late", None), ("early", [3, 2, 1, 0]), ("late", [3, 1, 2, 0])):
