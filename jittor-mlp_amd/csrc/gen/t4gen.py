@@ -582,13 +582,15 @@ class T4:
             for tb in range(self.NTB):
                 for r in range(16):
                     a("v_accvgpr_write_b32", A(16 * (self.NTB * rb + tb) + r), self.v_b2[tb])
-        for par in range(2):
-            for rb in range(2):
-                for r in range(16):
-                    a("v_mov_b32", self.xg[par][rb][r], 0)
-                for kk in range(2):
-                    for r in range(4):
-                        a("v_mov_b32", self.h[par][rb][kk][r], 0)
+        if self.shape == 0:
+            # dummy groups run GELU on whatever these registers hold and multiply it by the zero W2 group: it has to be finite
+            for par in range(2):
+                for rb in range(2):
+                    for r in range(16):
+                        a("v_mov_b32", self.xg[par][rb][r], 0)
+                    for kk in range(2):
+                        for r in range(4):
+                            a("v_mov_b32", self.h[par][rb][kk][r], 0)
         a("s_sub_u32", self.s_g, 0, k["lead"])
         nx = 0 if (self.dbg & 32) else 2 * self.NKS
         if self.shape == 0:
