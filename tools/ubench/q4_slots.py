@@ -249,6 +249,27 @@ for n in (3, 4, 5, 6, 7):
     P("t4mix%d" % n, lambda a, q, n=n: t4mix(a, q, n), lambda a: (a("s_waitcnt", vmcnt=0, lgkmcnt=0), a("s_barrier")) and None)
 P("t4mix6_nodma", lambda a, q: t4mix(a, q, 6, False), lambda a: (a("s_waitcnt", vmcnt=0, lgkmcnt=0), a("s_barrier")) and None)
 P("t4mix6_nobar", lambda a, q: t4mix(a, q, 6), lambda a: a("s_waitcnt", vmcnt=12))
+def pkbatch(a, q, n, every, plain, mix=False):
+    """n packed fp32 operations behind every `every`-th MFMA, `plain` single fp32 operations behind all of them (mix: plus the
+    fragment reads / LDS-DMA pieces of the GEMM loop)"""
+    if mix:
+        if q % 8 in (1, 3, 6):
+            dma(a, q, nop=False)
+        if READS68(q):
+            ds_read(a, q)
+    if q % every == every - 1:
+        pk(a, n, q * n)
+    fmaak(a, plain, q * plain)
+
+
+for n, every, plain in ((8, 8, 0), (16, 8, 0), (16, 16, 0), (32, 16, 0), (16, 8, 2), (16, 8, 4), (32, 16, 4), (16, 8, 5), (8, 4, 4), (12, 8, 4), (24, 16, 4), (48, 32, 4)):
+    P("pkb%d_e%d_p%d" % (n, every, plain), lambda a, q, n=n, every=every, plain=plain: pkbatch(a, q, n, every, plain))
+for n, every, plain in ((16, 8, 2), (16, 8, 4), (32, 16, 4), (14, 8, 2), (28, 16, 2), (56, 32, 2)):
+    P("pkbmix%d_e%d_p%d" % (n, every, plain), lambda a, q, n=n, every=every, plain=plain: pkbatch(a, q, n, every, plain, True),
+      lambda a: (a("s_waitcnt", vmcnt=12, lgkmcnt=0), a("s_barrier")) and None)
+P("mix_p5", lambda a, q: pkbatch(a, q, 0, 8, 5, True), lambda a: (a("s_waitcnt", vmcnt=12, lgkmcnt=0), a("s_barrier")) and None)
+P("mix_p6", lambda a, q: pkbatch(a, q, 0, 8, 6, True), lambda a: (a("s_waitcnt", vmcnt=12, lgkmcnt=0), a("s_barrier")) and None)
+P("mix_p2", lambda a, q: pkbatch(a, q, 0, 8, 2, True), lambda a: (a("s_waitcnt", vmcnt=12, lgkmcnt=0), a("s_barrier")) and None)
 VDST = set()
 for nm, pat in (("vdst_mfma_only", lambda a, q: None), ("vdst_fma4", lambda a, q: fma(a, 4, q * 4)), ("vdst_pkfma3", lambda a, q: pk(a, 3, q * 3)),
                 ("vdst_t4gap", lambda a, q: (pk(a, 3, q * 3, sgpr=True, chains=2), med3(a, 1, q)) and None)):
