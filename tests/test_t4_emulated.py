@@ -75,3 +75,16 @@ def test_emulator_catches_protocol_faults():
                 ok = False
             caught = caught or not ok
         assert caught, mut.__name__
+
+
+def test_host_constants_match_the_generators():
+    """the host side launches with the LDS size and reads the argument block the generators laid out"""
+    import re
+    import q4gen
+    csrc = os.path.join(os.path.dirname(GEN))
+    t4 = open(os.path.join(csrc, "mlpk_tokenmlp_t4.hip")).read()
+    assert int(re.search(r"#define T4_LDS_BYTES (\d+)", t4).group(1)) == t4gen.LDS_BYTES <= 160 * 1024
+    assert int(re.search(r"static_assert\(sizeof\(T4Args\) == (\d+)", t4).group(1)) == t4gen.ARG_BYTES
+    q4h = open(os.path.join(csrc, "mlpk_gemm_q4.h")).read()
+    m = re.search(r"#define Q4_LDS_BYTES \((\d+) \* (\d+) \+ (\d+)\)", q4h)
+    assert int(m.group(1)) * int(m.group(2)) + int(m.group(3)) == q4gen.LDS_BYTES <= 160 * 1024
