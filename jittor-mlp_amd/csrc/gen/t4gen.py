@@ -8,7 +8,7 @@ waves share a SIMD and the GELU of one was meant to run beside the MFMAs of the 
 for all 196 tokens and runs, in ONE instruction stream, three stages of a software pipeline over the groups of 32 hidden units:
 
     iteration g:   MFMA  fc2(g-2)  28 x v_mfma_f32_32x32x16   D2[rb][tb] += h(g-2)[rb][kk] x W2frag(tb, kk)
-                   MFMA  fc1(g)    28 x                        D1[rb] = b1(g) + sum_ks W1frag(ks) x X[rb][ks]
+                   MFMA  fc1(g)    26 x                        xg[rb] = b1(g) + sum_ks W1frag(ks) x X[rb][ks]      (13 k-steps: 196 tokens fit 208)
                    VALU  gelu(g-1) on the 32 fp32 values per lane that fc1(g-1) left, rounded into h(g-1): placed between the MFMAs
 
 with the first product computed "transposed" (hidden x rows), so that a lane's 16 accumulators of a block are -- after GELU and
@@ -17,10 +17,12 @@ rounding -- exactly two A fragments of the second product once W2's columns are 
 the registers.  W1 / W2 groups stream through two 2-stage LDS rings by LDS-DMA one iteration ahead (one barrier per iteration);
 LDS rows are PADDED by 16 bytes (528 / 80-byte pitch) instead of XOR-swizzled: the 16 lanes of a ds_read_b128 group then fall on 16
 different bank quads and a k-step is an immediate offset of the one address register.
-Groups outside [0, G) (pipeline fill and drain) multiply by a zero W2 slab, so they add nothing.
-Epilogue per tile: accumulators + b2 staged as fp32 through LDS, read back as (token, 8 channels) items, residual added in fp32,
-one rounding, 16-byte stores of whole 128-byte lines; optional by-product (sum, sum of squares) per token over the wave's 64
-channels for the LayerNorm that follows (mlpk.h: stats).
+Pipeline fill and drain: shape 0 runs every iteration with all three stages -- groups outside [0, G) multiply by the zero W2 group
+of the packed tensor, so they add nothing -- and works for any G; shapes 1 / 2 (G odd / even, what the host launches) emit the first
+and last iterations of a tile with only the stages that have work, and request the next tile's X when the drain begins.
+Epilogue per tile: accumulators (started from b2) staged as fp32 through LDS (two buffers), read back as (token, 8 channels) items,
+residual added in fp32, one rounding, 16-byte stores of whole 128-byte lines; optional by-product (sum, sum of squares) per token
+over the wave's 64 channels for the LayerNorm that follows (mlpk.h: stats).
 """
 import os
 import sys
@@ -129,7 +131,6 @@ class T4:
         self.e_t = self.tmp[0][0]                      # pair: a residual dword as two fp32
         self.e_sp = self.tmp[0][1]                     # pair: (sum, sum of squares)
         self.e_ones = self.tmp[0][2][0]
-        self.e_x = [self.tmp[1][0][0], self.tmp[1][0][1], self.tmp[1][1][0], self.tmp[1][1][1]]
 
     def D2(self, rb, tb):
         return A(16 * (self.NTB * rb + tb), 16)
