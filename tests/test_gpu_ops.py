@@ -715,8 +715,17 @@ def test_fused_token_mlp_generated_kernel(dtype):
         mean = torch.empty(B_ * S, dtype=torch.float32, device=dev())
         rstd = torch.empty_like(mean)
         E.stats_finalize_planar(part, B_ * S, C, mean, rstd, eps=1e-5)
+        # the generic form of the kernel (every iteration with all three stages, dummy groups against the zero W2 group) computes
+        # the same sums in the same order as the shipped one (fill / drain iterations without the dummy stages): bit-equal
+        os.environ["MLPK_T4_SHAPE"] = "0"
+        try:
+            x_generic = x0.clone()
+            E.token_mlp(xt, sp, B_ * C, S, w1p, b1p, w2p, b2p, nch, x_generic, C, C, layout=lay)
+        finally:
+            del os.environ["MLPK_T4_SHAPE"]
         torch.cuda.synchronize()
         assert torch.equal(x, x_nostats) and not torch.isnan(part).any()
+        assert torch.equal(x, x_generic)
         if B_ <= 8:
             w1r, w2r = w1.to(dtype).double(), w2.to(dtype).double()
             h = oracle.gelu(torch.einsum("ts,bsc->btc", w1r, xn.double()) + b1.double().view(1, -1, 1)).to(dtype).double()
