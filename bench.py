@@ -309,7 +309,7 @@ def main():
                 peak = PEAK_BF16_TFLOPS if args.dtype != "fp32" else 157.3
                 ach = flops / secs / 1e12
                 traffic, traffic_src = measured_traffic(args)
-                line["roofline"] = {"bound": "mfma", "kernel": "channel-MLP fc1 (q4_bf16_gl_f12, generated) + fc2 (gemm_nt_p8_kernel)", "achieved": round(ach, 1),
+                line["roofline"] = {"bound": "mfma", "kernel": "channel-MLP fc1 (q4_bf16_gl_f12, generated) + fc2 (gemm_nt_p8_pair_kernel)", "achieved": round(ach, 1),
                                     "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                                     "flops_per_launch": flops / n_launch, "avg_launch_ms": round(secs / n_launch * 1e3, 4),
                                     "launches_timed": n_launch, "traffic_source": traffic_src,
@@ -317,7 +317,7 @@ def main():
                                     # kernel; fc2 runs the persistent 256 x 256 tile, which covers M with up to three tile heights,
                                     # each its own kernel launch (NI = 4 / 3 at M = 50176): a rocprofv3 --stats summary lists
                                     # them as separate rows, per call the row averages add up as sum(calls_i x avg_i) / calls
-                                    "launch_means": "one mlpk_gemm_nt call: fc1 = 1 launch (q4), fc2 = up to 3 launches (p8 tile heights)"}
+                                    "launch_means": "one mlpk_gemm_nt call = one launch: fc1 the generated q4 tile, fc2 the persistent tile with its 256- and 192-row panels in one launch"}
             line["kernels"] = {t: {"avg_ms": round(v["avg_ms"], 4), "tflops": round(v["flops_per_launch"] / v["avg_ms"] / 1e9, 1),
                                    "launches": v["launches"]} for t, v in summ.items()}
         if world == 1 and not args.no_cpu_baseline:

@@ -1229,8 +1229,10 @@ __device__ __forceinline__ void p8_store_direct(const GemmArgs& p, f32x4 (&acc)[
 // Register budget (256 per wave at two waves per SIMD): 32 NI accumulators + 24 NI operand fragments + ~20; hipcc must not
 // spill inside the K loop -- a spill reload is a VMEM operation whose compiler-inserted wait drains the hand-counted LDS-DMA
 // queue every slab; tools/isa_lint.py (run by tests/test_host_cpu.py) checks the generated loop for exactly that.
+// (the body is a force-inlined function so that ONE launch can run the panels of two tile heights one after the other:
+//  gemm_nt_p8_pair_kernel below)
 template <typename T, int EPI, int NI>
-__global__ void __launch_bounds__(512, 1) gemm_nt_p8_kernel(const GemmArgs p) {
+__device__ __forceinline__ void p8_body(const GemmArgs& p, char* const smem) {
     static_assert(NI >= 1 && NI <= 4 && (EPI >= 1 || NI == 4), "tile height / epilogue combination");
     static_assert(sizeof(T) == 2, "16-bit operands");
     constexpr int BM = NI * 64, BN = 256;
@@ -1238,7 +1240,6 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_p8_kernel(const GemmArgs p) {
     constexpr int BK = 64;                                 // elements per 128-byte slab row
     constexpr int HALF_B = 128 * 128;                      // bytes of one half-tile
     constexpr int BUF_B = 4 * HALF_B;                      // A-lo, A-hi, B-lo, B-hi
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1492,6 +1493,22 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_p8_kernel(const GemmArgs p) {
 #undef P8_STAMP
 }
 
+template <typename T, int EPI, int NI>
+__global__ void __launch_bounds__(512, 1) gemm_nt_p8_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    p8_body<T, EPI, NI>(p, smem);
+}
+
+// Two tile heights in ONE launch: a workgroup walks its tiles of the first height, then those of the second (the same tiles in
+// the same K order as two launches -- every result bit unchanged -- without the drain, launch gap and ramp between them).
+template <typename T, int EPI, int NIA, int NIB>
+__global__ void __launch_bounds__(512, 1) gemm_nt_p8_pair_kernel(const GemmArgs pa, const GemmArgs pb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    p8_body<T, EPI, NIA>(pa, smem);
+    __syncthreads();                                       // the LDS image of the last tile is dead only when every wave is done with it
+    p8_body<T, EPI, NIB>(pb, smem);
+}
+
 // ------------------------------- host-side dispatch -------------------------------
 struct TileCfg { int bm, bn, wm, wn, glds; };
 static const TileCfg kTiles[] = {
@@ -1672,16 +1689,44 @@ template <typename T> static int launch_p8(const GemmArgs& a0, bool trans, hipSt
         if (staged && a.M % 256) return MLPK_ESHAPE;                            // the staged epilogue is built for 256-row tiles only
         const P8Plan plan = p8_plan(a.M, tiles_n, a.K / 64, cap, !staged && !(a.dbg & 16));   // reserved & 16: 256-row tiles only
         int m_base = 0;
+        auto grid_of = [&](const int panels) {
+            const int X = 8 / a.cgroups;
+            const int U = panels * (tiles_n / a.cgroups);
+            const int Q = (U + X - 1) / X;
+            return 8 * (Q < cap / 8 ? Q : cap / 8);
+        };
+        const char* pe = getenv("MLPK_P8_PAIR");
+        const bool pair_on = !(pe && pe[0] == '0');                                                   // A/B aid
         for (int s = 0; s < plan.n; ++s) {
             const int ni = plan.ni[s];
             a.m_base = m_base;
             a.panels = plan.panels[s];
             m_base += a.panels * ni * 64;
-            const int X = 8 / a.cgroups;
-            const int U = a.panels * (tiles_n / a.cgroups);
-            const int Q = (U + X - 1) / X;
-            const int grid = 8 * (Q < cap / 8 ? Q : cap / 8);
             hipError_t e = hipSuccess;
+            // the 256- and 192-row panels of a plan (Mixer-B fc2: one round + two rounds) go out as one launch
+            if (pair_on && !staged && s + 1 < plan.n && ((ni == 4 && plan.ni[s + 1] == 3) || (ni == 3 && plan.ni[s + 1] == 4))) {
+                GemmArgs b = a;
+                b.m_base = m_base;
+                b.panels = plan.panels[s + 1];
+                m_base += b.panels * plan.ni[s + 1] * 64;
+                const GemmArgs& a4 = ni == 4 ? a : b;
+                const GemmArgs& a3 = ni == 4 ? b : a;
+                const int g4 = grid_of(a4.panels), g3 = grid_of(a3.panels);
+                const int gridp = g4 > g3 ? g4 : g3;
+#define P8_PAIR(EP)                                                                                                     \
+    {                                                                                                                   \
+        auto k = gemm_nt_p8_pair_kernel<T, EP, 4, 3>;                                                                   \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);     \
+        if (e != hipSuccess) return (int)e;                                                                             \
+        hipLaunchKernelGGL(k, dim3(gridp), dim3(512), lds, stream, a4, a3);                                             \
+    }
+                if (a.row_part) P8_PAIR(2) else P8_PAIR(1)
+#undef P8_PAIR
+                MLPK_LAUNCH_CHECK();
+                ++s;
+                continue;
+            }
+            const int grid = grid_of(a.panels);
 #define P8_LAUNCH(EP, NIv)                                                                                              \
     {                                                                                                                   \
         auto k = gemm_nt_p8_kernel<T, EP, NIv>;                                                                         \

@@ -685,6 +685,39 @@ def test_fused_token_mlp(dtype, layout):
         E.token_mlp(xt, sp, B_ * C, S, w1p, b1p, w2p, b2p, nch, x, C, C, stats=torch.zeros(B_ * S * 2, device=dev()), layout=lay)
 
 
+def test_gemm_two_tile_heights_in_one_launch():
+    """The persistent tile's mixed-height plan for Mixer-B/16 fc2 at 256 images (50176 x 768 x 3072: one round of 256-row + two
+    rounds of 192-row tiles) goes out as ONE launch (gemm_nt_p8_pair_kernel): same tiles, same K order -- bit-equal to the two
+    launches (MLPK_P8_PAIR=0), with and without the by-product statistics; the fp64 check of the shape's class is test_gemm_*'s."""
+    pkg = load_pkg()
+    E, N = pkg.engine, pkg._native
+    M, Nn, K = 50176, 768, 3072
+    dtype = torch.bfloat16
+    g = torch.Generator(device=dev()).manual_seed(5)
+    A = (torch.rand((M, K), device=dev(), generator=g) - 0.5).to(dtype)
+    B = ((torch.rand((Nn, K), device=dev(), generator=g) - 0.5) / 16).to(dtype)
+    R = (torch.rand((M, Nn), device=dev(), generator=g) - 0.5).to(dtype)
+    bias = torch.rand(Nn, device=dev(), generator=g)
+    outs = {}
+    for pair in ("1", "0"):
+        os.environ["MLPK_P8_PAIR"] = pair
+        try:
+            for stats in (False, True):
+                C = torch.zeros((M, Nn), dtype=dtype, device=dev())
+                ws = E.Workspace(dev(), dtype) if stats else None
+                got = E.gemm(A, B, C, M, Nn, K, bias=bias, R=R, res=N.RES_ADD, algo=14, part=(ws, "p") if stats else None)
+                torch.cuda.synchronize()
+                outs[(pair, stats)] = (C, got[0].clone() if stats and got is not None else None)
+        finally:
+            del os.environ["MLPK_P8_PAIR"]
+    for stats in (False, True):
+        assert torch.equal(outs[("1", stats)][0], outs[("0", stats)][0])
+    assert torch.equal(outs[("1", True)][0], outs[("1", False)][0])
+    assert outs[("1", True)][1] is not None and torch.equal(outs[("1", True)][1], outs[("0", True)][1])
+    ref = (A[:64].double() @ B.double().t() + bias.double() + R[:64].double())
+    assert (outs[("1", False)][0][:64].double() - ref).abs().max().item() < EPS[dtype] * 4 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_fused_token_mlp_generated_kernel(dtype):
     """layout 2 of mlpk_token_mlp (the generated one-wave-per-SIMD kernel, csrc/gen/t4gen.py): against the fp64 restatement of

@@ -194,6 +194,7 @@ def test_hand_scheduled_gemm_loops_have_no_compiler_vmem_waits():
     lint = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(lint)
     assert lint.lint(asm) == 0
+    assert lint.lint(asm, "gemm_nt_p8_pair_kernel", every_loop=True) == 0          # both heights' loops of the two-height launch
     # the fused token-mixing kernels: same rule for their iteration loops (one hand-counted vmcnt wait, no scratch)
     assert lint.lint_token(os.path.join(builder.OBJ, "mlpk_tokenmlp-hip-amdgcn-amd-amdhsa-gfx950.s")) == 0
 
