@@ -94,6 +94,8 @@ class T4:
         self.s_t = [s("t%d" % i) for i in range(6)]
         self.s_t64 = s("t64", 2, 2)
         self.s_prof0 = s("prof0", 2, 2)
+        self.s_prof1, self.s_epi = s("prof1", 2, 2), s("epi")          # tuning: cycles spent in the tile epilogues
+        self.s_ph = [s("ph%d" % i) for i in range(3)]                  # ... in the fill iterations, the steady loop, the drain iterations
         self.ns = s.next
         # vector registers.  AGPRs: D2[rb][tb] at 16 (7 rb + tb); a[224:255] = the last NXA X fragments of row block 1
         self.X = [[None] * self.NKS for _ in range(2)]
@@ -532,6 +534,9 @@ class T4:
                 a("v_lshl_add_u32", dst, y, rshift, z)
         a("s_waitcnt", lgkmcnt=0)
         a("s_memtime", self.s_prof0)
+        a("s_mov_b32", self.s_epi, 0)
+        for r_ in self.s_ph:
+            a("s_mov_b32", r_, 0)
         # ---- argument-dependent lane constants
         a("v_mul_lo_u32", x, j, k["ldxt"])
         a("v_lshlrev_b32", x, 1, x)
@@ -605,6 +610,16 @@ class T4:
         else:
             # fill: group g's first product has nothing in front of it; drain: the last two groups' second products alone
             L_skip = a.newlabel("NOLOOP")
+
+            def stamp(acc):
+                """acc += cycles since the last stamp"""
+                a("s_memtime", self.s_t64)
+                a("s_waitcnt", lgkmcnt=0)
+                a("s_sub_u32", t[0], self.s_t64[0], self.s_prof1[0])
+                a("s_add_u32", acc, acc, t[0])
+                a("s_mov_b32", self.s_prof1[0], self.s_t64[0])
+            a("s_memtime", self.s_prof1)
+            a("s_waitcnt", lgkmcnt=0)
             if self.shape == 1:                     # G odd: a lead iteration keeps the stage parity static (28 = 27 + 1 iterations for G = 25)
                 self.iteration(0, fc2=False, fc1=False, gelu=False)          # g = -1: the DMA pieces only
                 self.iteration(1, fc2=False, gelu=False)                     # g = 0
@@ -616,6 +631,7 @@ class T4:
                 self.iteration(1, fc2=False)                                 # g = 1
                 first, second = 0, 1
                 a("s_sub_u32", self.s_cnt, k["G"], 2)
+            stamp(self.s_ph[0])
             a("s_lshr_b32", self.s_cnt, self.s_cnt, 1)
             a("s_cmp_eq_u32", self.s_cnt, 0)
             a("s_cbranch_scc1", L_skip)
@@ -628,11 +644,14 @@ class T4:
             a.label(L_skip)
             if self.shape == 1:
                 self.iteration(1)                                            # g = G - 1
+                stamp(self.s_ph[1])
                 self.iteration(0, fc1=False, xload=True)                     # g = G
                 self.iteration(1, fc1=False, gelu=False, vm_allow=nx)        # g = G + 1
             else:
+                stamp(self.s_ph[1])
                 self.iteration(0, fc1=False, xload=True)
                 self.iteration(1, fc1=False, gelu=False, vm_allow=nx)
+            stamp(self.s_ph[2])
         a("s_lshl_b32", t[0], k["nit"], 7)
         a("v_sub_u32", self.v_b1rd, self.v_b1rd, t[0])              # back to the first iteration's bias row
         # ---- next tile's X (the registers are dead from here on), then the epilogue
@@ -646,10 +665,15 @@ class T4:
             a.label(L_nonext)
         self.lgkm_issued = 0
         self.vm_loads = 0
+        a("s_memtime", self.s_prof1)
         a("s_nop", 7)                                                # the residual lands in registers the last MFMAs have just written
         a("s_nop", 7)
         res = {0: self.res_loads(0), 1: self.res_loads(1)}
         self.epilogue(res)
+        a("s_memtime", self.s_t64)
+        a("s_waitcnt", lgkmcnt=0)
+        a("s_sub_u32", t[0], self.s_t64[0], self.s_prof1[0])
+        a("s_add_u32", self.s_epi, self.s_epi, t[0])
         a("s_mov_b32", self.s_tile, self.s_next)
         a("s_cmp_lg_u32", self.s_has, 0)
         a("s_cbranch_scc1", L_tile)
@@ -662,12 +686,18 @@ class T4:
         a("s_cbranch_scc1", L_noprof)
         a("s_waitcnt", lgkmcnt=0)
         a("s_sub_u32", self.s_t64[0], self.s_t64[0], self.s_prof0[0])
-        a("s_subb_u32", self.s_t64[1], self.s_t64[1], self.s_prof0[1])
-        a("s_lshl_b32", t[0], self.s_bid, 3)
-        a("v_mov_b32", self.e_t[0], self.s_t64[0])
-        a("v_mov_b32", self.e_t[1], self.s_t64[1])
+        a("s_lshl_b32", t[0], self.s_bid, 5)
         a("v_mov_b32", self.e_sp[0], t[0])
+        a("v_mov_b32", self.e_t[0], self.s_t64[0])                  # (cycles of the whole kernel body, cycles of its tile epilogues)
+        a("v_mov_b32", self.e_t[1], self.s_epi)
         a("global_store_dwordx2", self.e_sp[0], self.e_t, p["prof"])
+        a("s_nop", 1)
+        a("v_mov_b32", self.e_t[0], self.s_ph[0])                   # (fill iterations, steady loop)
+        a("v_mov_b32", self.e_t[1], self.s_ph[1])
+        a("global_store_dwordx2", self.e_sp[0], self.e_t, p["prof"], offset=8)
+        a("s_nop", 1)
+        a("v_mov_b32", self.e_t[0], self.s_ph[2])                   # (drain iterations)
+        a("global_store_dword", self.e_sp[0], self.e_t[0], p["prof"], offset=16)
         a.label(L_noprof)
         a("s_waitcnt", vmcnt=0, lgkmcnt=0)
         a("s_endpgm")

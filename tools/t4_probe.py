@@ -46,7 +46,10 @@ for lay in (1, 2):
                 E.token_mlp(xt, sp, B_ * C, S, pk[0], pk[1], pk[2], pk[3], pk[4], x, C, C, stats=part, layout=lay)
                 torch.cuda.synchronize()
                 fn(None)
-                cyc = prof[:256].float()
-                extra = "  ticks/WG mean %.0f max %.0f -> %.2f ticks/ns" % (cyc.mean().item(), cyc.max().item(), cyc.max().item() / (ms * 1e6))
+                rec = prof[:1024].view(torch.int32).view(256, 8).float()
+                cyc, epi = rec[:, 0], rec[:, 1]
+                extra = "  ticks/WG mean %.0f max %.0f (epilogues %.0f, fill %.0f, steady %.0f, drain %.0f) -> %.2f ticks/ns" % (
+                    cyc.mean().item(), cyc.max().item(), epi.mean().item(), rec[:, 2].mean().item(), rec[:, 3].mean().item(), rec[:, 4].mean().item(),
+                    cyc.max().item() / (ms * 1e6))
             print("layout %d stats %d dbg %d: %.1f us  %.0f TFLOP/s%s" % (lay, st, dbg, ms * 1e3, flops / ms / 1e9, extra), flush=True)
 os.environ["MLPK_T4_DBG"] = "0"
