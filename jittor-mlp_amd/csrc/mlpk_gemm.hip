@@ -1703,24 +1703,31 @@ template <typename T> static int launch_p8(const GemmArgs& a0, bool trans, hipSt
             a.panels = plan.panels[s];
             m_base += a.panels * ni * 64;
             hipError_t e = hipSuccess;
-            // the 256- and 192-row panels of a plan (Mixer-B fc2: one round + two rounds) go out as one launch
-            if (pair_on && !staged && s + 1 < plan.n && ((ni == 4 && plan.ni[s + 1] == 3) || (ni == 3 && plan.ni[s + 1] == 4))) {
+            // the 256-row panels of a plan and the shorter ones that follow them (Mixer-B fc2: one round + two rounds of 192-row tiles;
+            // gMLP proj1: nine rounds + a tail of 64-row tiles) go out as one launch
+            const int nj = s + 1 < plan.n ? plan.ni[s + 1] : 0;
+            if (pair_on && !staged && nj && ((ni == 4 && nj < 4) || (nj == 4 && ni < 4))) {
                 GemmArgs b = a;
                 b.m_base = m_base;
                 b.panels = plan.panels[s + 1];
-                m_base += b.panels * plan.ni[s + 1] * 64;
+                m_base += b.panels * nj * 64;
                 const GemmArgs& a4 = ni == 4 ? a : b;
-                const GemmArgs& a3 = ni == 4 ? b : a;
-                const int g4 = grid_of(a4.panels), g3 = grid_of(a3.panels);
-                const int gridp = g4 > g3 ? g4 : g3;
-#define P8_PAIR(EP)                                                                                                     \
+                const GemmArgs& ax = ni == 4 ? b : a;
+                const int nx = ni == 4 ? nj : ni;
+                const int g4 = grid_of(a4.panels), gx = grid_of(ax.panels);
+                const int gridp = g4 > gx ? g4 : gx;
+#define P8_PAIR(EP, NX)                                                                                                 \
     {                                                                                                                   \
-        auto k = gemm_nt_p8_pair_kernel<T, EP, 4, 3>;                                                                   \
+        auto k = gemm_nt_p8_pair_kernel<T, EP, 4, NX>;                                                                  \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);     \
         if (e != hipSuccess) return (int)e;                                                                             \
-        hipLaunchKernelGGL(k, dim3(gridp), dim3(512), lds, stream, a4, a3);                                             \
+        hipLaunchKernelGGL(k, dim3(gridp), dim3(512), lds, stream, a4, ax);                                             \
     }
-                if (a.row_part) P8_PAIR(2) else P8_PAIR(1)
+                if (a.row_part) {
+                    if (nx == 3) P8_PAIR(2, 3) else if (nx == 2) P8_PAIR(2, 2) else P8_PAIR(2, 1)
+                } else {
+                    if (nx == 3) P8_PAIR(1, 3) else if (nx == 2) P8_PAIR(1, 2) else P8_PAIR(1, 1)
+                }
 #undef P8_PAIR
                 MLPK_LAUNCH_CHECK();
                 ++s;

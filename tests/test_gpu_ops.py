@@ -688,7 +688,9 @@ def test_fused_token_mlp(dtype, layout):
 def test_gemm_two_tile_heights_in_one_launch():
     """The persistent tile's mixed-height plan for Mixer-B/16 fc2 at 256 images (50176 x 768 x 3072: one round of 256-row + two
     rounds of 192-row tiles) goes out as ONE launch (gemm_nt_p8_pair_kernel): same tiles, same K order -- bit-equal to the two
-    launches (MLPK_P8_PAIR=0), with and without the by-product statistics; the fp64 check of the shape's class is test_gemm_*'s."""
+    launches (MLPK_P8_PAIR=0), with and without the by-product statistics; the fp64 check of the shape's class is test_gemm_*'s.
+    (The other pairs -- 256-row panels + a 128- or 64-row tail -- are exercised by the bs=256 model tests, which are bit-compared
+    with small batches whose plans have no such pair.)"""
     pkg = load_pkg()
     E, N = pkg.engine, pkg._native
     M, Nn, K = 50176, 768, 3072
