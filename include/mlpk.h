@@ -22,6 +22,7 @@
  *                       runs after them (GELU, residual add, BatchNorm-eval affine, SGU gate):
  *                       mlp_mixer.py:16-27,6-13; g_mlp.py:17-22,32-39; res_mlp.py:52-57;
  *                       vip.py:65-90; s2_mlp_v2.py:60-69,76-85; as_mlp.py:8-24,55-95; conv_mixer.py:29-31
+ *   mlpk_token_mlp_ln   the token-mixing PreNormResidual (LayerNorm + both Conv1d(k=1) + GELU + residual) in ONE kernel: mlp_mixer.py:6-13,16-27,34
  *   mlpk_token_mlp      both Conv1d(k=1) of the Mixer token-mixing FeedForward + GELU + residual in ONE kernel
  *                       (mlp_mixer.py:16-27,34,37), hidden activations never leave the CU
  *   mlpk_token_gemm     one token-mixing product with the transposed epilogue: gMLP SGU (g_mlp.py:17-22), ResMLP cross-patch (res_mlp.py:52-55)
@@ -189,6 +190,15 @@ int mlpk_token_mlp(int dtype, const void* xt, int ldxt, int M, int S, const void
  * mlpk_token_mlp_layout_for additionally knows the channels per image and answers 2 when the generated kernel takes the shape. */
 int mlpk_token_mlp_layout(int S, int nchunks);
 int mlpk_token_mlp_layout_for(int dtype, int S, int nchunks, int t_rows);
+/* The whole token-mixing PreNormResidual in ONE kernel (ABI 7; mlp_mixer.py:34 with :6-13 and :16-27):
+ *   x[b,s,c] += sum_t W2[s,t] * gelu(sum_s' W1[t,s'] * LN_C(x[b,s',:])[c] + b1[t]) + b2[s]
+ * -- mlpk_layernorm_transpose + mlpk_token_mlp(layout 2) without the xt tensor between them: the generated kernel reads its rows of x
+ * (token-major 128-byte lines), normalises them with the given row statistics (ln_mean / ln_rstd over B*S rows: mlpk_row_stats, or a
+ * producer GEMM's row_part through mlpk_stats_finalize_planar) and gamma / beta (t_rows floats), and transposes through LDS into its
+ * operand registers.  Weights, b1, b2, stats exactly as for layout 2; the shapes of layout 2 with nchunks >= 2. */
+int mlpk_token_mlp_ln(int dtype, void* x, int ldx, int M, int S, const float* ln_mean, const float* ln_rstd, const float* gamma,
+                      const float* beta, const void* w1, int ldw1, const float* b1, const void* w2, int ldw2, const float* b2,
+                      int nchunks, int t_rows, float* stats, void* stream);
 
 /* ---- single token-mixing product with the per-image transpose in the epilogue -----------------------------------------------
  * out[b,t,c] = R[b,t,c] (+ | *) rscale[c] * ( sum_s W[t,s] * xt[b*t_rows + c, s] + bias[t] )     (res_mode ADD | MUL; NONE: no R)

@@ -51,6 +51,8 @@ PROTOTYPES = {
     "mlpk_token_mlp_chunk": (c_int, []),
     "mlpk_token_mlp": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "mlpk_token_mlp_ln": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                  c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "mlpk_token_mlp_layout": (c_int, [c_int, c_int]),
     "mlpk_token_mlp_layout_for": (c_int, [c_int, c_int, c_int, c_int]),
     "mlpk_token_gemm": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int,

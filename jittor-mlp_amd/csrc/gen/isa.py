@@ -813,6 +813,9 @@ class Emu:
         self.lds[addr[:, None] + np.arange(nbytes)[None, :]] = data.view(np.uint8).reshape(64, nbytes)
         w.lgkm.append(lambda: None)
 
+    def x_ds_write_b32(self, w, i):
+        self._ds_write(w, i, 4)
+
     def x_ds_write_b64(self, w, i):
         self._ds_write(w, i, 8)
 
@@ -900,7 +903,7 @@ def _regs_of(o):
     return set()
 
 
-_NO_DST = ("ds_write_b64", "ds_write_b128", "s_waitcnt", "s_barrier", "s_nop", "s_branch", "s_cbranch_scc0", "s_cbranch_scc1", "s_endpgm", "s_setprio", "label",
+_NO_DST = ("ds_write_b32", "ds_write_b64", "ds_write_b128", "s_waitcnt", "s_barrier", "s_nop", "s_branch", "s_cbranch_scc0", "s_cbranch_scc1", "s_endpgm", "s_setprio", "label",
            "global_load_lds_dwordx4", "global_store_dwordx4", "global_store_dwordx2", "global_store_dword",
            "s_cmp_eq_u32", "s_cmp_lg_u32", "s_cmp_lt_u32", "s_cmp_le_u32", "s_cmp_gt_u32", "s_cmp_ge_u32", "s_cmp_lt_i32", "s_cmp_gt_i32")
 

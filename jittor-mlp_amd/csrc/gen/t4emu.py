@@ -78,6 +78,16 @@ def run_case(gen, nimg=1, t_rows=512, T=80, grid=1, seed=0, dma_mode="late", ord
     w2 = rng.uniform(-1, 1, (S, T)) * 0.2
     b2 = rng.uniform(-1, 1, S).astype(np.float32)
     x0 = to16(rng.uniform(-2, 2, (nimg * S, t_rows)), dt)
+    ln = getattr(gen, "ln", False)
+    if ln:
+        # the kernel normalises x itself: xt = LayerNorm_C(x) transposed is what the reference formula is fed with
+        gamma = rng.uniform(0.5, 1.5, t_rows).astype(np.float32)
+        beta = rng.uniform(-0.5, 0.5, t_rows).astype(np.float32)
+        xf = from16(x0, dt).astype(np.float64)
+        mean = xf.mean(axis=1).astype(np.float32)
+        rstd = (1.0 / np.sqrt(xf.var(axis=1) + 1e-5)).astype(np.float32)
+        xn = ((xf - mean[:, None].astype(np.float64)) * rstd[:, None].astype(np.float64)) * gamma[None, :] + beta[None, :]
+        xt[:, :S] = to16(xn.reshape(nimg, S, t_rows).transpose(0, 2, 1).reshape(M, S), dt)
     w1p, b1p, w2p, b2p, G = pack(w1, b1, w2, b2, dt)
     mem = isa.Mem()
     aXt, aW1, aW2, aB1, aB2 = mem.add(xt), mem.add(w1p), mem.add(w2p), mem.add(b1p), mem.add(b2p)
@@ -91,6 +101,10 @@ def run_case(gen, nimg=1, t_rows=512, T=80, grid=1, seed=0, dma_mode="late", ord
         struct.pack_into("<Q", ka, t4gen.KA[name], val)
     for name, val in pl.items():
         struct.pack_into("<I", ka, t4gen.KA[name], val)
+    if ln:
+        for name, arr in (("ln_mean", mean), ("ln_rstd", rstd), ("gamma", gamma), ("beta", beta)):
+            struct.pack_into("<Q", ka, t4gen.KA[name], mem.add(arr))
+        struct.pack_into("<Q", ka, t4gen.KA["xt"], 0)
     karg = mem.add(np.frombuffer(bytes(ka), np.uint8))
     nins = 0
     for bid in range(grid):

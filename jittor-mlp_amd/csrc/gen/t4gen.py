@@ -32,8 +32,10 @@ from isa import A, F, S, V, Asm, Neg, Reg  # noqa: E402
 from q4gen import GELU, GELU_RAW, SQRT2, Alloc  # noqa: E402
 
 KA = dict(xt=0, w1=8, w2=16, b1=24, b2=32, x=40, stats=48, prof=56,
-          M=64, G=68, ldxt=72, ldx=76, ntiles=80, tpi=84, tpi_magic=88, grid=92, stat_ld=96, nit=100, lead=104, S=108)
-ARG_BYTES = 112
+          M=64, G=68, ldxt=72, ldx=76, ntiles=80, tpi=84, tpi_magic=88, grid=92, stat_ld=96, nit=100, lead=104, S=108,
+          ln_mean=112, ln_rstd=120, gamma=128, beta=136)
+ARG_BYTES = 144
+LN_WAVE = 2 * 8 * 272                    # LayerNorm loader: two buffers of 8 channel planes ([8 channels-of-8][8 token pairs] dwords + 16 B) per wave
 
 W1_PITCH, W1_PIECES = 528, 17            # 32 hidden rows x (512 B + 16): 16896 B
 W2_PITCH, W2_PIECES = 80, 18             # 224 tokens x (64 B + 16): 17920 B
@@ -57,7 +59,11 @@ class T4:
     NXA = 8                                # X fragments kept in the 32 AGPRs the accumulators leave over
     DEPTH = 3                              # W fragments read ahead of their MFMAs (ring of 4 register quads)
 
-    def __init__(self, dtype="bf16", stats=False, dbg=0, name=None, shape=0):
+    def __init__(self, dtype="bf16", stats=False, dbg=0, name=None, shape=0, ln=False):
+        # ln: the token LayerNorm + transpose is this kernel's X loader -- x itself is read (token-major rows, statistics given),
+        # normalised, transposed through LDS into the fragment registers; `xt` is not used (shaped kernels only)
+        assert not ln or shape
+        self.ln = ln
         # shape: 0 = every iteration runs all three stages (pipeline fill / drain on dummy groups; any G); 1 / 2 = G odd (>= 3) / even
         # (>= 2): the fill and drain iterations are emitted without the stages that have nothing to do, the next tile's X is
         # requested two iterations before the tile ends
@@ -65,7 +71,7 @@ class T4:
         # tuning ablations (wrong results by construction): 1 no LDS-DMA, 2 no GELU fillers, 4 no epilogue stores, 16 no residual loads,
         # 32 no X loads
         self.dtype, self.stats, self.dbg = dtype, stats, dbg
-        self.name = name or "t4_%s%s%s" % (dtype, "_st" if stats else "", ("", "_odd", "_even")[shape])
+        self.name = name or "t4_%s%s%s" % (dtype, "_st" if stats else "", ("", "_odd", "_even")[shape] + ("_ln" if ln else ""))
         self.mfma = "v_mfma_f32_32x32x16_bf16" if dtype == "bf16" else "v_mfma_f32_32x32x16_f16"
         self.cvt = "v_cvt_pk_bf16_f32" if dtype == "bf16" else "v_cvt_pk_f16_f32"
         self.dot = "v_dot2c_f32_bf16" if dtype == "bf16" else "v_dot2c_f32_f16"
@@ -96,6 +102,10 @@ class T4:
         self.s_prof0 = s("prof0", 2, 2)
         self.s_prof1, self.s_epi = s("prof1", 2, 2), s("epi")          # tuning: cycles spent in the tile epilogues
         self.s_ph = [s("ph%d" % i) for i in range(3)]                  # ... in the fill iterations, the steady loop, the drain iterations
+        if self.ln:
+            self.s_lnp = s("lnp", 8, 4)                                # ln_mean, ln_rstd, gamma, beta
+            self.s_lx, self.s_lmean, self.s_lrstd = s("lx", 2, 2), s("lmean", 2, 2), s("lrstd", 2, 2)
+            self.s_l16 = s("l16")                                      # bytes of 16 token rows of x
         self.ns = s.next
         # vector registers.  AGPRs: D2[rb][tb] at 16 (7 rb + tb); a[224:255] = the last NXA X fragments of row block 1
         self.X = [[None] * self.NKS for _ in range(2)]
@@ -368,6 +378,124 @@ class T4:
             for ks in range(self.NKS):
                 self.vload("global_load_dwordx4", self.X[rb][ks], self.v_xoff, self.s_xb[rb], offset=32 * ks)
 
+    def ln_loader(self, tile):
+        """X[rb][ks] of tile `tile` from x itself: LayerNorm_C(x[b, t, :]) of the wave's 64 channels, transposed (mlp_mixer.py:34 with
+        :6-13; the statistics of the rows come in as ln_mean / ln_rstd).  Per k-step of 16 tokens: a lane = (token pair lane >> 3,
+        8 channels lane & 7) loads two 16-byte pieces of full 128-byte lines, normalises 16 values, packs (token 2p, token 2p+1) pairs
+        per channel and writes them as [channel][token pair] words into a per-wave LDS tile (in-order LDS: no wait between the writes
+        and the two ds_read_b128 that pull the fragments of both row blocks out).  Runs with the pipeline idle: every pipeline register is
+        scratch.  Tokens behind S (the last k-step holds 4) keep whatever the registers held: W1's columns there are zero."""
+        a, t, k, p = self.a, self.s_t, self.k, self.p
+        bf = self.dtype == "bf16"
+        xg = self.xg
+        ldr = [[xg[0][0][0:4], xg[0][0][4:8], xg[0][0][8:10], xg[0][0][10:12]],          # two load buffers: x of tokens 2p / 2p+1 (quads), mean pair, rstd pair
+               [xg[0][1][0:4], xg[0][1][4:8], xg[0][1][8:10], xg[0][1][10:12]]]
+        gam, bet = [xg[1][0][e] for e in range(8)], [xg[1][0][8 + e] for e in range(8)]
+        fa, fb = [xg[1][1][e] for e in range(8)], [xg[1][1][8 + e] for e in range(8)]
+        hb = self.h[0][0][0].idx
+        pk = [Reg("v", hb + e) for e in range(8)]
+        lane, pp, c8, va0, va1, vst, vgb, vw = [Reg("v", hb + 8 + i) for i in range(8)]
+        vr = [Reg("v", hb + 16), Reg("v", hb + 17)]
+        x1, x2, mneg = Reg("v", hb + 18), Reg("v", hb + 19), [Reg("v", hb + 20), Reg("v", hb + 21)]
+        # ---- scalars of the tile
+        a("s_lshl_b32", t[0], tile, 1)
+        a("s_mul_hi_u32", t[1], t[0], k["tpi_magic"])         # img
+        a("s_mul_i32", t[0], t[1], k["tpi"])
+        a("s_sub_u32", t[0], tile, t[0])
+        a("s_lshl_b32", t[0], t[0], 8)
+        a("s_lshl_b32", t[2], self.s_wave, 6)
+        a("s_add_u32", t[2], t[2], t[0])                      # c0: first channel of the wave
+        a("s_mul_i32", t[3], t[1], k["S"])                    # first token row of the image
+        self.mul64(self.s_t64, t[3], k["ldx"], 1)
+        a("s_lshl_b32", t[0], t[2], 1)
+        self.add64(self.s_t64, self.s_t64, t[0])
+        self.add64(self.s_lx, p["x"], self.s_t64[0], self.s_t64[1])
+        a("s_lshl_b32", t[0], t[3], 2)
+        self.add64(self.s_lmean, self.s_lnp[0:2], t[0])
+        self.add64(self.s_lrstd, self.s_lnp[2:4], t[0])
+        a("s_lshl_b32", t[0], t[2], 2)
+        self.add64(self.s_t64, self.s_lnp[4:6], t[0])         # gamma + c0
+        a("s_lshl_b32", self.s_l16, k["ldx"], 5)
+        # ---- lane constants
+        a("v_and_b32", lane, 63, self.v_tid)
+        a("v_lshrrev_b32", pp, 3, lane)
+        a("v_and_b32", c8, 7, lane)
+        a("v_lshlrev_b32", vgb, 5, c8)
+        a("global_load_dwordx4", Reg("v", gam[0].idx, 4), vgb, self.s_t64)
+        a("global_load_dwordx4", Reg("v", gam[4].idx, 4), vgb, self.s_t64, offset=16)
+        self.add64(self.s_t64, self.s_lnp[6:8], t[0])         # beta + c0
+        a("v_mul_lo_u32", x1, pp, k["ldx"])
+        a("v_lshlrev_b32", x1, 2, x1)                         # 2 p rows, 2 bytes
+        a("v_lshl_add_u32", va0, c8, 4, x1)
+        a("s_lshl_b32", t[0], k["ldx"], 1)
+        a("v_add_u32", va1, t[0], va0)
+        a("v_lshlrev_b32", vst, 3, pp)
+        a("global_load_dwordx4", Reg("v", bet[0].idx, 4), vgb, self.s_t64)
+        a("global_load_dwordx4", Reg("v", bet[4].idx, 4), vgb, self.s_t64, offset=16)
+        a("s_mul_i32", t[0], self.s_wave, LN_WAVE)
+        a("s_add_u32", t[0], t[0], STG_OFF)
+        a("v_lshl_add_u32", x1, c8, 3, pp)                    # c8 * 8 + p
+        a("v_lshl_add_u32", vw, x1, 2, t[0])
+        a("v_and_b32", x1, 31, lane)                          # j
+        a("v_lshrrev_b32", x2, 5, lane)                       # h
+        for rb in range(2):
+            a("v_and_b32", vr[rb], 7, x1)                     # e = j & 7
+            a("v_mul_u32_u24", vr[rb], 272, vr[rb])
+            a("v_lshrrev_b32", mneg[0], 3, x1)                # j >> 3
+            a("v_add_u32", mneg[0], 4 * rb, mneg[0])          # c8' = 4 rb + (j >> 3)
+            a("v_lshl_add_u32", mneg[0], mneg[0], 1, x2)      # 2 c8' + h
+            a("v_lshl_add_u32", vr[rb], mneg[0], 4, vr[rb])   # + (c8' * 8 + 4 h) * 4
+            a("v_add_u32", vr[rb], t[0], vr[rb])
+        nks = self.NKS
+
+        def loads(ks):
+            buf = ldr[ks & 1]
+            last = ks == nks - 1
+            if last:
+                a("s_mov_b32", self.s_t64[0], 0xFFFF)         # tokens 192 .. 195: token pairs 0 and 1 = lanes 0 .. 15
+                a("s_mov_b32", self.s_t64[1], 0)
+                a("s_mov_b64", "exec", self.s_t64)
+            a("global_load_dwordx4", buf[0], va0, self.s_lx)
+            a("global_load_dwordx4", buf[1], va1, self.s_lx)
+            a("global_load_dwordx2", buf[2], vst, self.s_lmean)
+            a("global_load_dwordx2", buf[3], vst, self.s_lrstd)
+            if last:
+                a("s_mov_b64", "exec", -1)
+            else:
+                self.add64(self.s_lx, self.s_lx, self.s_l16)
+                self.add64(self.s_lmean, self.s_lmean, 64)
+                self.add64(self.s_lrstd, self.s_lrstd, 64)
+        loads(0)
+        for ks in range(nks):
+            if ks + 1 < nks:
+                loads(ks + 1)
+            a("s_waitcnt", vmcnt=4 if ks + 1 < nks else 0)
+            buf = ldr[ks & 1]
+            for tok, f in ((0, fa), (1, fb)):
+                q = buf[tok]
+                for d in range(4):
+                    if bf:
+                        a("v_lshlrev_b32", f[2 * d], 16, q[d])
+                        a("v_and_b32", f[2 * d + 1], 0xFFFF0000, q[d])
+                    else:
+                        a("v_lshrrev_b32", f[2 * d + 1], 16, q[d])
+                        a("v_cvt_f32_f16", f[2 * d], q[d])
+                        a("v_cvt_f32_f16", f[2 * d + 1], f[2 * d + 1])
+                a("v_mul_f32", mneg[tok], Neg(buf[2][tok]), buf[3][tok])        # -mean * rstd
+            for tok, f in ((0, fa), (1, fb)):
+                for e in range(8):
+                    a("v_fma_f32", f[e], f[e], buf[3][tok], mneg[tok])
+            for tok, f in ((0, fa), (1, fb)):
+                for e in range(8):
+                    a("v_fma_f32", f[e], f[e], gam[e], bet[e])
+            for e in range(8):
+                a(self.cvt, pk[e], fa[e], fb[e])
+            for e in range(8):
+                a("ds_write_b32", vw, pk[e], offset=(ks & 1) * 8 * 272 + e * 272)
+            for rb in range(2):
+                a("ds_read_b128", self.X[rb][ks], vr[rb], offset=(ks & 1) * 8 * 272)
+        a("s_waitcnt", lgkmcnt=0)
+
     def tile_scalars(self):
         """cursors of the tile's 64 channels of this wave: x + ((img * S) * ldx + c0) * 2 and the statistics plane"""
         a, t, k, p = self.a, self.s_t, self.k, self.p
@@ -489,6 +617,9 @@ class T4:
         a("s_load_dwordx16", S(4, 16), self.s_karg, 0)
         a("s_load_dwordx8", S(20, 8), self.s_karg, 64)
         a("s_load_dwordx4", S(28, 4), self.s_karg, 96)
+        if self.ln:
+            a("s_load_dwordx4", self.s_lnp[0:4], self.s_karg, KA["ln_mean"])
+            a("s_load_dwordx4", self.s_lnp[4:8], self.s_karg, KA["gamma"])
         # ---- lane constants (prologue temporaries: the GELU scratch and one staging quad)
         lane, j, h, l3, l7, x, y, z = (self.tmp[0][0][0], self.tmp[0][0][1], self.tmp[0][1][0], self.tmp[0][1][1], self.tmp[0][2][0],
                                        self.tmp[0][2][1], self.tmp[1][0][0], self.tmp[1][0][1])
@@ -576,12 +707,15 @@ class T4:
                     self.emit_m0(kind, i, 0)
                     a("s_nop", 0)
                     self.emit_dma(kind, i, 0)
-        self.tile_xbase(self.s_tile)
-        self.x_loads()
+        if self.ln:
+            self.ln_loader(self.s_tile)
+        else:
+            self.tile_xbase(self.s_tile)
+            self.x_loads()
         a("s_sub_u32", t[0], 2, k["lead"])
         a("s_lshl_b32", t[0], t[0], 7)
         a("v_add_u32", self.v_b1rd, t[0], self.v_b1rd)              # bias row of the first iteration's group
-        a("s_waitcnt", vmcnt=0 if (self.dbg & 33) else 10 + 2 * self.NKS)   # b2 (the loads before the 10 DMA pieces and the X quads)
+        a("s_waitcnt", vmcnt=0 if ((self.dbg & 33) or self.ln) else 10 + 2 * self.NKS)   # b2 (the loads before the 10 DMA pieces and the X quads)
         a.label(L_tile)
         self.tile_scalars()
         for rb in range(2):
@@ -598,7 +732,8 @@ class T4:
                         for r in range(4):
                             a("v_mov_b32", self.h[par][rb][kk][r], 0)
         a("s_sub_u32", self.s_g, 0, k["lead"])
-        nx = 0 if (self.dbg & 32) else 2 * self.NKS
+        nx = 0 if ((self.dbg & 32) or self.ln) else 2 * self.NKS
+        xl_on = not self.ln
         if self.shape == 0:
             a("s_lshr_b32", self.s_cnt, k["nit"], 1)
             a.label(L_iter)
@@ -645,16 +780,20 @@ class T4:
             if self.shape == 1:
                 self.iteration(1)                                            # g = G - 1
                 stamp(self.s_ph[1])
-                self.iteration(0, fc1=False, xload=True)                     # g = G
+                self.iteration(0, fc1=False, xload=xl_on)                    # g = G
                 self.iteration(1, fc1=False, gelu=False, vm_allow=nx)        # g = G + 1
             else:
                 stamp(self.s_ph[1])
-                self.iteration(0, fc1=False, xload=True)
+                self.iteration(0, fc1=False, xload=xl_on)
                 self.iteration(1, fc1=False, gelu=False, vm_allow=nx)
             stamp(self.s_ph[2])
         a("s_lshl_b32", t[0], k["nit"], 7)
         a("v_sub_u32", self.v_b1rd, self.v_b1rd, t[0])              # back to the first iteration's bias row
         # ---- next tile's X (the registers are dead from here on), then the epilogue
+        if self.ln:
+            a("s_add_u32", self.s_next, self.s_tile, k["grid"])
+            a("s_cmp_lt_u32", self.s_next, k["ntiles"])
+            a("s_cselect_b32", self.s_has, 1, 0)
         if self.shape == 0:
             a("s_add_u32", self.s_next, self.s_tile, k["grid"])
             a("s_cmp_lt_u32", self.s_next, k["ntiles"])
@@ -676,7 +815,12 @@ class T4:
         a("s_add_u32", self.s_epi, self.s_epi, t[0])
         a("s_mov_b32", self.s_tile, self.s_next)
         a("s_cmp_lg_u32", self.s_has, 0)
-        a("s_cbranch_scc1", L_tile)
+        if self.ln:
+            a("s_cbranch_scc0", L_end)
+            self.ln_loader(self.s_tile)                              # the next tile's operands: LayerNorm + transpose of its rows of x
+            a("s_branch", L_tile)
+        else:
+            a("s_cbranch_scc1", L_tile)
         a.label(L_end)
         # tuning: shader cycles of this workgroup -> prof[bid] (mlpk_token_mlp_debug), skipped when the pointer is null
         L_noprof = a.newlabel("NOPROF")
@@ -709,6 +853,8 @@ def variants():
         for st in (False, True):
             for shape in (0, 1, 2):
                 out.append(dict(dtype=dt, stats=st, shape=shape))
+            for shape in (1, 2):
+                out.append(dict(dtype=dt, stats=st, shape=shape, ln=True))
     for dbg in (1, 2, 4, 3, 16, 32, 48, 52):
         out.append(dict(dtype="bf16", stats=True, dbg=dbg, name="t4_bf16_st_dbg%d" % dbg))
     return out
@@ -734,11 +880,11 @@ def emit(path):
             raise RuntimeError("%s: %d hazard lint findings, first: %s" % (g.name, len(pr), pr[0]))
         out.append(kernel_text(g))
         table.append((g.name, kw))
-    out.append("namespace mlpk {\nstruct T4Variant { const char* name; const void* fn; int dtype, stats, dbg, shape; };\n"
+    out.append("namespace mlpk {\nstruct T4Variant { const char* name; const void* fn; int dtype, stats, dbg, shape, ln; };\n"
                "static const T4Variant kT4Variants[] = {\n")
     for name, kw in table:
-        out.append("    {\"%s\", reinterpret_cast<const void*>(&%s), %s, %d, %d, %d},\n" %
-                   (name, name, "MLPK_BF16" if kw["dtype"] == "bf16" else "MLPK_F16", kw["stats"], kw.get("dbg", 0), kw.get("shape", 0)))
+        out.append("    {\"%s\", reinterpret_cast<const void*>(&%s), %s, %d, %d, %d, %d},\n" %
+                   (name, name, "MLPK_BF16" if kw["dtype"] == "bf16" else "MLPK_F16", kw["stats"], kw.get("dbg", 0), kw.get("shape", 0), kw.get("ln", False)))
     out.append("};\n}  // namespace mlpk\n")
     text = "".join(out)
     if not os.path.exists(path) or open(path).read() != text:

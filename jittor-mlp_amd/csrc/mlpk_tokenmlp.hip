@@ -1056,6 +1056,7 @@ extern "C" int mlpk_token_mlp(int dtype, const void* xt, int ldxt, int M, int S,
         T4Call c;
         c.dtype = dtype; c.M = M; c.S = S; c.G = nchunks; c.ldxt = ldxt; c.ldx = ldx; c.t_rows = t_rows;
         c.xt = xt; c.w1 = w1; c.w2 = w2; c.b1 = b1; c.b2 = b2; c.x = x; c.stats = stats; c.prof = g_tm_dbg;
+        c.ln_mean = c.ln_rstd = c.gamma = c.beta = nullptr;
         const char* d = getenv("MLPK_T4_DBG");
         c.dbg = d ? atoi(d) : 0;
         return t4_launch(c, reinterpret_cast<hipStream_t>(stream));
@@ -1111,6 +1112,27 @@ extern "C" int mlpk_token_mlp(int dtype, const void* xt, int ldxt, int M, int S,
     }
     MLPK_LAUNCH_CHECK();
     return 0;
+}
+
+// The token-mixing PreNormResidual of MLP-Mixer in ONE kernel (mlp_mixer.py:34 with :6-13, :16-27): the LayerNorm + per-image transpose
+// is the generated kernel's operand loader (no xt tensor).  Weights packed for layout 2.
+extern "C" int mlpk_token_mlp_ln(int dtype, void* x, int ldx, int M, int S, const float* ln_mean, const float* ln_rstd, const float* gamma,
+                                 const float* beta, const void* w1, int ldw1, const float* b1, const void* w2, int ldw2, const float* b2,
+                                 int nchunks, int t_rows, float* stats, void* stream) {
+    if (!x || !ln_mean || !ln_rstd || !gamma || !beta || !w1 || !w2 || !b1 || !b2) return MLPK_ENULL;
+    if (dtype != MLPK_F16 && dtype != MLPK_BF16) return MLPK_EDTYPE;
+    if (ldw1 != 256 || ldw2 != 32 || nchunks < 2) return MLPK_ESHAPE;
+    if (!t4_supported(dtype, S, nchunks, 224, M, t_rows, ldx)) return MLPK_ESHAPE;
+    if (stats && ((uintptr_t)stats & 7)) return MLPK_ESHAPE;
+    if (((uintptr_t)w1 & 15) || ((uintptr_t)w2 & 15) || ((uintptr_t)x & 15) || ((uintptr_t)b1 & 15) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15) ||
+        ((uintptr_t)ln_mean & 7) || ((uintptr_t)ln_rstd & 7))
+        return MLPK_EALIGN;
+    T4Call c;
+    c.dtype = dtype; c.M = M; c.S = S; c.G = nchunks; c.ldxt = 224; c.ldx = ldx; c.t_rows = t_rows;
+    c.xt = nullptr; c.w1 = w1; c.w2 = w2; c.b1 = b1; c.b2 = b2; c.x = x; c.stats = stats; c.prof = g_tm_dbg;
+    c.ln_mean = ln_mean; c.ln_rstd = ln_rstd; c.gamma = gamma; c.beta = beta;
+    c.dbg = 0;
+    return t4_launch(c, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int mlpk_token_gemm(int dtype, const void* xt, int ldxt, int M, int S, const void* w, int ldw, const float* bias, int ngroups,

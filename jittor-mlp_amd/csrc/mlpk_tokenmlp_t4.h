@@ -15,6 +15,11 @@ struct T4Call {
     const float* b2;           // 224: zeros behind S
     void* x;                   // (B*S, ldx) residual stream, updated in place
     float* stats;              // planes of 64 channels x B*S x (sum, sum of squares), or null
+    // LayerNorm as the kernel's operand loader (mlpk_token_mlp_ln): xt unused, x normalised with these on the way in
+    const float* ln_mean;      // (B*S) statistics of the rows of x, or null: xt is read
+    const float* ln_rstd;
+    const float* gamma;        // (t_rows)
+    const float* beta;
     void* prof;                // tuning: shader cycles per workgroup (8 bytes each), or null
     int dbg;                   // tuning ablations (wrong results by construction)
 };

@@ -21,8 +21,12 @@ struct T4Args {
     int M, G, ldxt, ldx;
     int ntiles, tpi, tpi_magic, grid;
     int stat_ld, nit, lead, S;
+    const float* ln_mean;
+    const float* ln_rstd;
+    const float* gamma;
+    const float* beta;
 };
-static_assert(sizeof(T4Args) == 112, "kernarg layout");
+static_assert(sizeof(T4Args) == 144, "kernarg layout");
 }  // namespace mlpk
 
 #include "gen_out/t4_kernels.inc"
@@ -57,9 +61,11 @@ int t4_launch(const T4Call& c, hipStream_t stream) {
     int shape = (c.G & 1) ? (c.G >= 3 ? 1 : 0) : (c.G >= 2 ? 2 : 0);
     const char* es = getenv("MLPK_T4_SHAPE");
     if (c.dbg || (es && es[0] == '0')) shape = 0;
+    const int ln = c.ln_mean != nullptr;
+    if (ln && (!shape || !c.ln_rstd || !c.gamma || !c.beta)) return MLPK_ESHAPE;
     const T4Variant* v = nullptr;
     for (const T4Variant& k : kT4Variants)
-        if (k.dtype == c.dtype && k.stats == (c.stats != nullptr) && k.dbg == c.dbg && k.shape == shape) { v = &k; break; }
+        if (k.dtype == c.dtype && k.stats == (c.stats != nullptr) && k.dbg == c.dbg && k.shape == shape && k.ln == ln) { v = &k; break; }
     if (!v) return MLPK_ESHAPE;
     T4Args a;
     a.xt = c.xt; a.w1 = c.w1; a.w2 = c.w2; a.b1 = c.b1; a.b2 = c.b2; a.x = c.x; a.stats = c.stats; a.prof = c.prof;
@@ -72,6 +78,7 @@ int t4_launch(const T4Call& c, hipStream_t stream) {
     a.lead = (c.G + 2) & 1;                                     // iterations come in pairs (the LDS stage parity is static)
     a.nit = c.G + 2 + a.lead;
     a.S = c.S;
+    a.ln_mean = c.ln_mean; a.ln_rstd = c.ln_rstd; a.gamma = c.gamma; a.beta = c.beta;
     hipError_t e = hipFuncSetAttribute(v->fn, hipFuncAttributeMaxDynamicSharedMemorySize, T4_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     void* params[] = {&a};

@@ -224,6 +224,17 @@ def token_mlp(xt, ldxt, M, S, w1, b1, w2, b2, nchunks, x, ldx, t_rows, stats=Non
                                    w2.stride(0), ptr(b2), nchunks, ptr(x), ldx, t_rows, ptr(stats), layout, stream()), "mlpk_token_mlp")
 
 
+def token_mlp_ln(x, ldx, M, S, mean, rstd, gamma, beta, w1, b1, w2, b2, nchunks, t_rows, stats=None):
+    """LayerNorm + token-mixing MLP + residual in one kernel (weights packed for layout 2); x (B*S, ldx) is updated in place."""
+    N.check(N.lib().mlpk_token_mlp_ln(dtype_code(x.dtype), ptr(x), ldx, M, S, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(w1), w1.stride(0), ptr(b1),
+                                      ptr(w2), w2.stride(0), ptr(b2), nchunks, t_rows, ptr(stats), stream()), "mlpk_token_mlp_ln")
+
+
+def token_ln_fused():
+    """MLPK_TOKEN_LN_FUSED=0: LayerNorm + transpose as its own pass in front of the token kernel (A/B aid)."""
+    return os.environ.get("MLPK_TOKEN_LN_FUSED", "1") != "0"
+
+
 def layernorm_transpose_supported(dtype, C, ldx, ld_tt):
     return dtype in (torch.float16, torch.bfloat16) and C % 128 == 0 and C <= 2048 and ldx % 8 == 0 and ld_tt % 8 == 0 \
         and os.environ.get("MLPK_NO_FUSED_TOKEN_LN", "0") != "1"

@@ -22,7 +22,7 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import channel_mlp, embed_patches, head_linear, layernorm_stats, pack_channel_mlp
+from .common import channel_mlp, embed_patches, finalize_stats, head_linear, layernorm_stats, pack_channel_mlp
 from .utils.tools import check_sizes, pair
 
 
@@ -173,8 +173,24 @@ class MLPMixer(E.EngineModule):
         sp = E.round_up(S, 32)        # token K padding: whole half-slabs -> direct-to-LDS GEMM tiles
         th = S * ef
         thp = E.round_up(th, 32)
+        nxt = None                                             # statistics of x's rows out of the previous block's fc2 epilogue
         for i in range(depth):
             p = "b%d." % i
+            fused = pk.get(p + "tok.fused")
+            if (fused is not None and fused[5] == 2 and fused[4] >= 2 and E.token_ln_fused() and C % 128 == 0
+                    and (p + "ch.fc1.csum") in pk and E.epilogue_stats()):
+                # the whole token-mixing PreNormResidual in ONE kernel: the LayerNorm + transpose is the token kernel's operand loader
+                # (no xt tensor, x read once); its row statistics come out of the previous block's fc2 epilogue (first block: one pass)
+                w1f, b1f, w2f, b2f, nch, lay = fused
+                mean, rstd = nxt if nxt is not None else layernorm_stats(ws, x, rows, C, tag="tok.ln1")
+                part = ws.get("tok.stats", (E.token_mlp_stat_planes(C, lay), rows, 2), torch.float32)
+                E.token_mlp_ln(x, C, B * C, S, mean, rstd, pk[p + "tok.ln.g"], pk[p + "tok.ln.b"], w1f, b1f, w2f, b2f, nch, C, stats=part)
+                stats = (ws.get("cm.ln.mean", (rows,), torch.float32), ws.get("cm.ln.rstd", (rows,), torch.float32))
+                E.stats_finalize_planar(part, rows, C, stats[0], stats[1])
+                got = channel_mlp(ws, x, rows, C, pk, p + "ch.", C * ef, stats=stats, part=(ws, "tok.lnpart") if i + 1 < depth else None)
+                nxt = finalize_stats(ws, got, rows, C, tag="tok.ln1f") if i + 1 < depth else None
+                continue
+            nxt = None
             xt = ws.get("tok.xt", (B * C, sp))                 # LN(x) transposed per image, zero K-padding
             if E.layernorm_transpose_supported(x.dtype, C, C, sp):
                 E.layernorm_transpose(x, B, S, C, pk[p + "tok.ln.g"], pk[p + "tok.ln.b"], xt, sp)     # statistics + apply, one pass
@@ -182,7 +198,6 @@ class MLPMixer(E.EngineModule):
                 mean, rstd = layernorm_stats(ws, x, rows, C)
                 E.norm_apply(x, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "tok.ln.g"], beta=pk[p + "tok.ln.b"],
                              out_tt=xt, S=S, ld_tt=sp)
-            fused = pk.get(p + "tok.fused")
             if fused is not None:
                 # both token-mixing products + GELU + residual in one kernel; the hidden stays in LDS
                 w1f, b1f, w2f, b2f, nch, lay = fused

@@ -786,6 +786,61 @@ def test_fused_token_mlp_generated_kernel(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_token_mixing_prenorm_residual_in_one_kernel(dtype):
+    """mlpk_token_mlp_ln == x + FeedForward(LayerNorm(x) transposed) (mlp_mixer.py:6-13 with :16-27, :34): against the fp64 oracle with the
+    hidden and the normalised operand rounded where the kernel rounds them, and against the two-kernel path (mlpk_layernorm_transpose +
+    mlpk_token_mlp layout 2), from which it differs only by the rounding of the LayerNorm's fp32 expression; by-product statistics;
+    several tiles per workgroup, both parities of the group count."""
+    pkg = load_pkg()
+    E = pkg.engine
+    S, sp = 196, 224
+    for ci, (B_, C, T) in enumerate([(1, 256, 784), (3, 512, 512), (2, 768, 100), (300, 256, 96)]):
+        x = (rnd((B_ * S, C), dtype, 1500 + ci) * 2 + 0.3).to(dtype).to(dev())
+        g = rnd((C,), torch.float32, 1510 + ci) + 1.1
+        be = rnd((C,), torch.float32, 1520 + ci)
+        w1 = rnd((T, S), torch.float32, 1530 + ci, 1.0 / math.sqrt(S))
+        b1 = rnd((T,), torch.float32, 1540 + ci)
+        w2 = rnd((S, T), torch.float32, 1550 + ci, 1.0 / math.sqrt(T))
+        b2 = rnd((S,), torch.float32, 1560 + ci)
+        w1p, b1p, w2p, b2p, nch, lay = E.pack_token_mlp(w1, b1, w2, b2, dtype, dev(), sp, t_rows=C)
+        assert lay == 2
+        mean = torch.empty(B_ * S, dtype=torch.float32, device=dev())
+        rstd = torch.empty_like(mean)
+        E.row_stats(x, B_ * S, C, C, mean, rstd)
+        x0 = x.clone()
+        part = torch.full((E.token_mlp_stat_planes(C, lay), B_ * S, 2), float("nan"), dtype=torch.float32, device=dev())
+        E.token_mlp_ln(x, C, B_ * C, S, mean, rstd, g.to(dev()), be.to(dev()), w1p, b1p, w2p, b2p, nch, C, stats=part)
+        # the two-kernel path on the same input
+        xt = torch.zeros((B_ * C, sp), dtype=dtype, device=dev())
+        E.layernorm_transpose(x0, B_, S, C, g.to(dev()), be.to(dev()), xt, sp)
+        x2 = x0.clone()
+        E.token_mlp(xt, sp, B_ * C, S, w1p, b1p, w2p, b2p, nch, x2, C, C, layout=lay)
+        m2 = torch.empty_like(mean)
+        r2 = torch.empty_like(mean)
+        E.stats_finalize_planar(part, B_ * S, C, m2, r2, eps=1e-5)
+        torch.cuda.synchronize()
+        assert torch.isfinite(x.float()).all() and not torch.isnan(part).any()
+        d = (x.float() - x2.float()).abs()
+        assert d.max().item() <= EPS[dtype] * 4 * max(1.0, x2.float().abs().max().item()), (str(dtype), ci, d.max().item())
+        assert (d > 0).float().mean().item() < 0.05, (str(dtype), ci, (d > 0).float().mean().item())
+        if B_ <= 8:
+            xn = oracle.layer_norm(x0.cpu().double().reshape(B_, S, C), g.double(), be.double()).to(dtype).double()      # (B, S, C), rounded as the operand is
+            w1r, w2r = w1.to(dtype).double(), w2.to(dtype).double()
+            h = oracle.gelu(torch.einsum("ts,bsc->btc", w1r, xn) + b1.double().view(1, -1, 1)).to(dtype).double()
+            ref = x0.cpu().double().reshape(B_, S, C) + torch.einsum("st,btc->bsc", w2r, h) + b2.double().view(1, -1, 1)
+            err = (x.cpu().double().reshape(B_, S, C) - ref).abs().max().item()
+            assert err < EPS[dtype] * 6 * max(1.0, ref.abs().max().item()), (str(dtype), ci, err)
+        xd = x.cpu().double()
+        mu = xd.mean(1)
+        rs = 1.0 / torch.sqrt(xd.var(1, unbiased=False) + 1e-5)
+        assert (m2.cpu().double() - mu).abs().max().item() < 2e-6 * max(1.0, xd.abs().max().item())
+        assert ((r2.cpu().double() - rs).abs() / rs).max().item() < 2e-5
+    with pytest.raises(RuntimeError):                               # one hidden group: the kernel without fill / drain shaping has no LayerNorm loader
+        p1 = E.pack_token_mlp(w1[:32], b1[:32], w2[:, :32], b2, dtype, dev(), sp, t_rows=C)
+        E.token_mlp_ln(x, C, B_ * C, S, mean, rstd, g.to(dev()), be.to(dev()), p1[0], p1[1], p1[2], p1[3], p1[4], C)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_layernorm_transpose_one_pass(dtype):
     """mlpk_layernorm_transpose == nn.LayerNorm over channels followed by the per-image transpose (mlp_mixer.py:34, :6-13),
     zero K-padding columns, ragged last token tile; against the fp64 oracle and bit-compared with the two-kernel path's layout."""

@@ -26,6 +26,10 @@ CASES = [
     (dict(stats=True, shape=1), 1, 512, 80, 1, "early", [3, 2, 1, 0]),      # G = 3: no steady-state loop at all
     (dict(stats=False, shape=2), 2, 256, 128, 2, "late", [2, 0, 3, 1]),     # G = 4
     (dict(dtype="f16", stats=True, shape=2), 1, 768, 64, 1, "early", None), # G = 2
+    # the token LayerNorm + transpose as the kernel's operand loader (mlpk_token_mlp_ln: x itself is read, no xt)
+    (dict(stats=True, shape=1, ln=True), 3, 256, 160, 2, "late", None),
+    (dict(stats=False, shape=2, ln=True), 2, 512, 128, 3, "early", [2, 0, 3, 1]),
+    (dict(dtype="f16", stats=True, shape=1, ln=True), 1, 768, 96, 1, "late", [3, 2, 1, 0]),
 ]
 
 
@@ -43,7 +47,7 @@ def test_every_shipped_variant_passes_the_hazard_lint():
         assert isa.lint(g.a) == [], g.name
         assert g.nv <= 248 and g.ns <= 100, g.name
         n += 1
-    assert n >= 12
+    assert n >= 20
 
 
 def test_emulator_catches_protocol_faults():
