@@ -50,6 +50,7 @@ def _generate():
         r = subprocess.run([sys.executable, os.path.join(GEN, gen), out], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("%s failed:\n" % gen + r.stderr[-4000:])
+        os.utime(out)       # emit() leaves an unchanged .inc untouched: mark it current, or every later build() re-runs the generator
 
 
 def _deps():

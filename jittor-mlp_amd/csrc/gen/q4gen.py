@@ -62,15 +62,21 @@ class Alloc:
 
 
 class Q4:
-    def __init__(self, dtype="bf16", gelu=False, ln=False, res=False, stats=False, nkf=4, dbg=0, name=None):
+    def __init__(self, dtype="bf16", gelu=False, ln=False, res=False, stats=False, nkf=4, dbg=0, name=None, static=False):
         assert nkf >= 2
         self.dtype, self.gelu, self.ln, self.res, self.stats, self.nkf = dtype, gelu, ln, res, stats, nkf
+        # static (round 4): the kernel is built for ONE K = 64 * nkf with nkf % 3 == 0, so a tile always starts in LDS stage 0 and
+        # every stage / slab / tile-switch decision of the K loop is made HERE instead of by SALU instructions at run time: the loop's
+        # own overhead drops from 81 to 41 instructions per 32 MFMAs (no stage rotation, no DMA pointer arithmetic, one m0 write per
+        # FOUR LDS-DMA pieces -- the instruction's immediate offset moves both the global and the LDS address, tools/ubench/lds_dma_offset.hip)
+        self.static = static
+        assert not static or (nkf % 3 == 0 and nkf <= 32)
         # tuning ablations (results are wrong by construction): 1 no LDS-DMA, 2 no stores, 4 no epilogue fillers, 8 no fragment reads,
         # 16 minimal iteration tail (no stage rotation), 64 every tile stored over tile (0, 0); variants under test: A/B switches: 256 the four
         # stores of a block row back to back (default: spread over the next block row), 512 ordinary instead of non-temporal stores
         self.dbg = dbg
         self.fillers_on, self.dma_on, self.stores_on, self.reads_on, self.tail_on = not (dbg & 4), not (dbg & 1), not (dbg & 2), not (dbg & 8), not (dbg & 16)
-        self.name = name or "q4_%s%s%s%s_f%d" % (dtype, "_gelu" if gelu else "", "_ln" if ln else "", "_res" if res else "", nkf)
+        self.name = name or "q4_%s%s%s%s_%s%d" % (dtype, "_gelu" if gelu else "", "_ln" if ln else "", "_res" if res else "", "s" if static else "f", nkf)
         self.a = Asm()
         self.mfma = "v_mfma_f32_32x32x16_bf16" if dtype == "bf16" else "v_mfma_f32_32x32x16_f16"
         self.cvt = "v_cvt_pk_bf16_f32" if dtype == "bf16" else "v_cvt_pk_f16_f32"
@@ -114,8 +120,10 @@ class Q4:
         # vector registers
         self.FA = [[v("FA%d_%d" % (b, i), 4, 4) for i in range(4)] for b in range(2)]
         self.FB = [[v("FB%d_%d" % (b, j), 4, 4) for j in range(2)] for b in range(2)]
-        self.v_curA = [v("curA%d" % k) for k in range(4)]
-        self.v_curB = [v("curB%d" % k) for k in range(4)]
+        # fragment read addresses: dynamic kernels keep "current stage" copies; static ones a second base for stage 2 (a DS
+        # immediate offset has 16 bits: stages 0 and 1 are offsets of the first base)
+        self.v_curA = [v(("rdA2_%d" if self.static else "curA%d") % k) for k in range(4)]
+        self.v_curB = [v(("rdB2_%d" if self.static else "curB%d") % k) for k in range(4)]
         self.v_rdA0 = [v("rdA0_%d" % k) for k in range(4)]
         self.v_rdB0 = [v("rdB0_%d" % k) for k in range(4)]
         self.voffA = [v("voffA%d" % k) for k in range(8)]
@@ -256,6 +264,12 @@ class Q4:
         a, t = self.a, self.s_t
 
         def shift():
+            if self.static:
+                # the DMA stream moves on to this tile's panels (the previous block's last two iterations already requested its
+                # slabs 0 and 1 through dAn / dBn); these four lead the head so that they precede the iteration's first piece
+                for d_, n_ in ((self.s_dA, self.s_dAn), (self.s_dB, self.s_dBn)):
+                    a("s_mov_b32", d_[0], n_[0])
+                    a("s_mov_b32", d_[1], n_[1])
             a("s_mov_b32", self.s_pm0, 0 if (self.dbg & 64) else self.s_cm0)       # (64: every tile is stored over tile (0, 0))
             a("s_mov_b32", self.s_pn0, 0 if (self.dbg & 64) else self.s_cn0)
             a("s_mov_b32", self.s_cm0, self.s_nm0)
@@ -265,10 +279,11 @@ class Q4:
             a("s_add_u32", self.s_lnext, self.s_lnext, self.s_lstep)
             self.coords(self.s_lnext, self.s_nm0, self.s_nn0)
             self.dma_base(self.s_dAn, self.s_dBn, self.s_nm0, self.s_nn0)
-            # rolled iterations of this block: nk - nkf, or 0 for the draining block (no block left after it)
-            a("s_sub_u32", t[0], self.k["nk"], self.nkf)
-            a("s_cmp_lg_u32", self.s_left, 0)
-            a("s_cselect_b32", self.s_roll, t[0], 0)
+            if not self.static:
+                # rolled iterations of this block: nk - nkf, or 0 for the draining block (no block left after it)
+                a("s_sub_u32", t[0], self.k["nk"], self.nkf)
+                a("s_cmp_lg_u32", self.s_left, 0)
+                a("s_cselect_b32", self.s_roll, t[0], 0)
         ops = self.capture(shift) + self.epi_bases_ops()
         if self.fillers_on:
             ops += self.param_load_ops()
@@ -465,7 +480,7 @@ class Q4:
         """advance the DMA stream and the LDS stages (issued in the gaps of the last k-step: every piece of the iteration has been
         issued by then, the fragment reads of the step use the old addresses until its sixth MFMA)"""
         a, t = self.a, self.s_t
-        if not self.tail_on:
+        if not self.tail_on or self.static:
             return [], []
 
         def salu():
@@ -495,10 +510,30 @@ class Q4:
                 a("v_add_u32", self.v_curB[k], self.s_rd, self.v_rdB0[k])
         return self.capture(salu), self.capture(valu)
 
-    def iteration(self, set_first, set_main, zero_c, fill, head_ops=None):
+    def dma_piece(self, kind, pc, base, slab, stage):
+        """static kernels: LDS-DMA piece pc (A: 0..7, B: 0..3) of K slab `slab` (counted inside the tile whose panels `base` addresses)
+        into LDS stage `stage`.  Four pieces share one m0 value: the instruction's immediate offset
+            imm = (pc % 4) * 1024 + slab * 128 - 4096
+        is added to the LDS destination AND to the global address (measured, tools/ubench/lds_dma_offset.hip), so
+            m0   = wave share + stage * STAGE_B + (pc // 4) * 4096 + 4096 - slab * 128     (written once per group, by the caller)
+            voff = piece offset + 4096 - (pc % 4) * 1024                                     (set up once, build())
+        give LDS piece pc of the stage and global base + piece offset + slab * 128, with no pointer arithmetic per slab."""
+        imm = (pc % 4) * 1024 + slab * 128 - 4096
+        assert -4096 <= imm < 4096
+        voff = self.voffA[pc] if kind == "A" else self.voffB[pc]
+        return self.vload("global_load_lds_dwordx4", voff, base, offset=imm)
+
+    def dma_m0(self, kind, grp, slab, stage):
+        c = stage * STAGE_B + grp * 4096 + 4096 - slab * 128
+        assert c >= 0
+        self.a("s_add_u32", "m0", self.s_wvA if kind == "A" else self.s_wvB, c)
+
+    def iteration(self, set_first, set_main, zero_c, fill, head_ops=None, u=None):
         """Four k-steps of 8 MFMAs with the loads of this iteration between them, then the wait and the barrier.
         set_first / set_main: accumulator set of step 0 / steps 1..3; zero_c: step 1 starts the accumulators (C = 0);
-        fill(s, qm): emit the filler instructions of the gap behind MFMA qm of step s."""
+        fill(s, qm): emit the filler instructions of the gap behind MFMA qm of step s.
+        u (static kernels): the iteration's index inside its tile -- it reads slab u from stage u % 3 and requests slab u + 2 (of
+        this tile, or slab u + 2 - nk of the next one) into stage (u + 2) % 3."""
         a = self.a
         ready = {}          # fragment -> number of its read
         # 4 pieces behind MFMAs 1, 3, 6, 7 of steps 0, 1 (A) and 2 (B); step 3 carries the bookkeeping
@@ -506,6 +541,12 @@ class Q4:
         for s_, (kind, base) in enumerate((("A", 0), ("A", 4), ("B", 0))):
             for n_, qm_ in enumerate((1, 3, 6, 7)):
                 dma_slots[(s_, qm_)] = (kind, base + n_)
+        if self.static:
+            assert u is not None
+            nk = self.nkf
+            d_slab, d_next = (u + 2, False) if u + 2 < nk else (u + 2 - nk, True)
+            d_stage = (u + 2) % 3
+            r_stage = u % 3
         head = list(head_ops or [])
         tail_s, tail_v = self.tail_ops()
         i_start = len(a.ins)
@@ -524,21 +565,31 @@ class Q4:
                 slot = dma_slots.get((s, qm))
                 if slot and self.dma_on:
                     kind, pc = slot
-                    a("s_add_u32", "m0", self.s_wrA if kind == "A" else self.s_wrB, pc * 1024)
+                    if not self.static:
+                        a("s_add_u32", "m0", self.s_wrA if kind == "A" else self.s_wrB, pc * 1024)
+                    elif pc % 4 == 0:
+                        self.dma_m0(kind, pc // 4, d_slab, d_stage)
                 csrc = 0 if (zero_c and s == 1) else d
                 a(self.mfma, d, self.FB[mbuf][j], self.FA[mbuf][i], csrc)
                 if slot and self.dma_on:
                     kind, pc = slot
-                    if kind == "A":
+                    if self.static:
+                        base = ((self.s_dAn if d_next else self.s_dA) if kind == "A" else (self.s_dBn if d_next else self.s_dB))
+                        self.dma_piece(kind, pc, base, d_slab, d_stage)
+                    elif kind == "A":
                         self.vload("global_load_lds_dwordx4", self.voffA[pc], self.s_dA)
                     else:
                         self.vload("global_load_lds_dwordx4", self.voffB[pc], self.s_dB)
                 if qm < 6 and self.reads_on:
                     kind, idx = read_order[qm]
-                    if kind == "A":
-                        new_ready[(kind, idx)] = self.ds("ds_read_b128", self.FA[rbuf][idx], self.v_curA[s], offset=idx * 4096)
+                    if self.static:
+                        # stages 0 / 1: immediate offsets of the first base; stage 2: the second base
+                        regs = (self.v_rdA0, self.v_rdB0) if r_stage < 2 else (self.v_curA, self.v_curB)
+                        addr = (regs[0] if kind == "A" else regs[1])[s]
+                        off = idx * 4096 + (STAGE_B if r_stage == 1 else 0)
                     else:
-                        new_ready[(kind, idx)] = self.ds("ds_read_b128", self.FB[rbuf][idx], self.v_curB[s], offset=idx * 4096)
+                        addr, off = (self.v_curA[s] if kind == "A" else self.v_curB[s]), idx * 4096
+                    new_ready[(kind, idx)] = self.ds("ds_read_b128", (self.FA if kind == "A" else self.FB)[rbuf][idx], addr, offset=off)
                 if s == 3:
                     for _ in range(3):
                         if tail_s:
@@ -625,6 +676,9 @@ class Q4:
             a("v_lshlrev_b32", lane, 4, lane)
             a("v_add_u32", self.v_rdA0[ks], vt[6], lane)
             a("v_add_u32", self.v_rdB0[ks], vt[7], lane)
+            if self.static:
+                a("v_add_u32", self.v_curA[ks], 2 * STAGE_B, self.v_rdA0[ks])
+                a("v_add_u32", self.v_curB[ks], 2 * STAGE_B, self.v_rdB0[ks])
         # DMA source offsets: ((rows0 + 8 p + l3) * ld + ((l7 ^ l3 ^ ((p >> 1) & 1)) * 8)) * 2
         a("v_xor_b32", vt[6], l7, l3)
         for arr, npc, rows_shift, ld in ((self.voffA, 8, 6, k["lda"]), (self.voffB, 4, 5, k["ldb"])):
@@ -636,6 +690,8 @@ class Q4:
                 a("v_xor_b32", lane, (pc >> 1) & 1, vt[6])
                 a("v_lshl_add_u32", vt[7], lane, 3, vt[7])
                 a("v_lshlrev_b32", arr[pc], 1, vt[7])
+                if self.static:
+                    a("v_add_u32", arr[pc], 4096 - (pc % 4) * 1024, arr[pc])       # see dma_piece
         # epilogue offsets
         a("s_lshl_b32", t[0], wm, 7)
         a("v_add_u32", vt[6], t[0], l31)                            # row inside the tile (block row 0), accumulator layout
@@ -712,7 +768,8 @@ class Q4:
         a("s_add_u32", self.s_lnext, self.s_lnext, self.s_lstep)
         self.coords(self.s_lnext, self.s_nm0, self.s_nn0)
         self.dma_base(self.s_dAn, self.s_dBn, self.s_nm0, self.s_nn0)
-        a("s_mov_b32", self.s_dcnt, k["nk"])
+        if not self.static:
+            a("s_mov_b32", self.s_dcnt, k["nk"])
         # ---- accumulators of the first tile = 0, fragment buffer 1 = 0 (step 0 of the first iteration multiplies it)
         for r in range(128):
             a("v_accvgpr_write_b32", A(r), 0)
@@ -723,37 +780,56 @@ class Q4:
             for r in range(4):
                 a("v_mov_b32", self.FB[1][j][r], 0)
         # ---- prologue DMA: slabs 0 and 1 into stages 0 and 1
-        a("s_mov_b32", self.s_wr, 0)
-        for slab in range(2):
-            a("s_add_u32", self.s_wrA, self.s_wr, self.s_wvA)
-            a("s_add_u32", self.s_wrB, self.s_wr, self.s_wvB)
-            for pc in range(8):
-                a("s_add_u32", "m0", self.s_wrA, pc * 1024)
-                a("s_nop", 0)
-                a("global_load_lds_dwordx4", self.voffA[pc], self.s_dA)
-            for pc in range(4):
-                a("s_add_u32", "m0", self.s_wrB, pc * 1024)
-                a("s_nop", 0)
-                a("global_load_lds_dwordx4", self.voffB[pc], self.s_dB)
-            self.add64(self.s_dA, self.s_dA, 128)
-            self.add64(self.s_dB, self.s_dB, 128)
-            a("s_sub_u32", self.s_dcnt, self.s_dcnt, 1)
-            a("s_add_u32", self.s_wr, self.s_wr, STAGE_B)
-        # (nk >= 3: the stream cannot switch tiles inside the prologue)
-        a("s_mov_b32", self.s_rd, 0)
-        a("s_add_u32", self.s_wrA, self.s_wr, self.s_wvA)
-        a("s_add_u32", self.s_wrB, self.s_wr, self.s_wvB)
-        for kk in range(4):
-            a("v_mov_b32", self.v_curA[kk], self.v_rdA0[kk])
-            a("v_mov_b32", self.v_curB[kk], self.v_rdB0[kk])
-        a("s_mov_b32", self.s_roll, k["nk"])
-        a("s_waitcnt", vmcnt=12)
-        a("s_barrier")
-        # no ds_read is outstanding here, but the iteration's first waits are counted as if six were: harmless (they wait for less)
         L_roll = [a.newlabel("ROLL0"), a.newlabel("ROLL1")]
         L_block = [a.newlabel("BLK0"), a.newlabel("BLK1")]
         L_rtest = [a.newlabel("RT0"), a.newlabel("RT1")]
-        a("s_branch", L_rtest[0])
+        if self.static:
+            for slab in range(2):
+                for kind, npc in (("A", 8), ("B", 4)):
+                    for pc in range(npc):
+                        if pc % 4 == 0:
+                            self.dma_m0(kind, pc // 4, slab, slab)
+                            a("s_nop", 0)
+                        a("global_load_lds_dwordx4", (self.voffA if kind == "A" else self.voffB)[pc], self.s_dA if kind == "A" else self.s_dB,
+                          offset=(pc % 4) * 1024 + slab * 128 - 4096)
+            a("s_waitcnt", vmcnt=12)
+            a("s_barrier")
+            # the first tile: nk plain iterations into set 0 (nothing to drain yet); its last two request the second tile's slabs
+            for u in range(self.nkf):
+                self.iteration(0, 0, False, lambda s, qm: None, u=u)
+            a("s_cmp_eq_u32", self.s_left, 0)
+            a("s_cbranch_scc1", L_end)
+            a("s_sub_u32", self.s_left, self.s_left, 1)
+            a("s_branch", L_block[1])
+        else:
+            a("s_mov_b32", self.s_wr, 0)
+            for slab in range(2):
+                a("s_add_u32", self.s_wrA, self.s_wr, self.s_wvA)
+                a("s_add_u32", self.s_wrB, self.s_wr, self.s_wvB)
+                for pc in range(8):
+                    a("s_add_u32", "m0", self.s_wrA, pc * 1024)
+                    a("s_nop", 0)
+                    a("global_load_lds_dwordx4", self.voffA[pc], self.s_dA)
+                for pc in range(4):
+                    a("s_add_u32", "m0", self.s_wrB, pc * 1024)
+                    a("s_nop", 0)
+                    a("global_load_lds_dwordx4", self.voffB[pc], self.s_dB)
+                self.add64(self.s_dA, self.s_dA, 128)
+                self.add64(self.s_dB, self.s_dB, 128)
+                a("s_sub_u32", self.s_dcnt, self.s_dcnt, 1)
+                a("s_add_u32", self.s_wr, self.s_wr, STAGE_B)
+            # (nk >= 3: the stream cannot switch tiles inside the prologue)
+            a("s_mov_b32", self.s_rd, 0)
+            a("s_add_u32", self.s_wrA, self.s_wr, self.s_wvA)
+            a("s_add_u32", self.s_wrB, self.s_wr, self.s_wvB)
+            for kk in range(4):
+                a("v_mov_b32", self.v_curA[kk], self.v_rdA0[kk])
+                a("v_mov_b32", self.v_curB[kk], self.v_rdB0[kk])
+            a("s_mov_b32", self.s_roll, k["nk"])
+            a("s_waitcnt", vmcnt=12)
+            a("s_barrier")
+            # no ds_read is outstanding here, but the iteration's first waits are counted as if six were: harmless (they wait for less)
+            a("s_branch", L_rtest[0])
 
         def block(P):
             """tile multiplied into set P, set 1 - P drained"""
@@ -773,22 +849,23 @@ class Q4:
                     state["done"] += 1
             for u in range(self.nkf):
                 if u == 0:
-                    self.iteration(1 - P, P, True, lambda s, qm: None, head_ops=head)
+                    self.iteration(1 - P, P, True, lambda s, qm: None, head_ops=head, u=u)
                 else:
-                    self.iteration(P, P, False, fill)
+                    self.iteration(P, P, False, fill, u=u)
             while state["done"] < len(ops):
                 ops[state["done"]]()
                 state["done"] += 1
-            # --- rolled plain iterations
-            a.label(L_rtest[P])
-            a("s_cmp_eq_u32", self.s_roll, 0)
-            a("s_cbranch_scc1", L_rdone[P])
-            a.label(L_roll[P])
-            self.iteration(P, P, False, lambda s, qm: None)
-            a("s_sub_u32", self.s_roll, self.s_roll, 1)
-            a("s_cmp_lg_u32", self.s_roll, 0)
-            a("s_cbranch_scc1", L_roll[P])
-            a.label(L_rdone[P])
+            if not self.static:
+                # --- rolled plain iterations
+                a.label(L_rtest[P])
+                a("s_cmp_eq_u32", self.s_roll, 0)
+                a("s_cbranch_scc1", L_rdone[P])
+                a.label(L_roll[P])
+                self.iteration(P, P, False, lambda s, qm: None)
+                a("s_sub_u32", self.s_roll, self.s_roll, 1)
+                a("s_cmp_lg_u32", self.s_roll, 0)
+                a("s_cbranch_scc1", L_roll[P])
+                a.label(L_rdone[P])
             # --- next block?
             a("s_cmp_eq_u32", self.s_left, 0)
             a("s_cbranch_scc1", L_end)
@@ -825,6 +902,7 @@ class Q4:
 CLASSES = {"p": (False, False, False, False), "l": (False, True, False, False), "g": (True, False, False, False), "gl": (True, True, False, False),
            "r": (False, False, True, False), "rs": (False, False, True, True)}
 NKF = {c: (3, 4, 6, 12) for c in CLASSES}
+NK_STATIC = (6, 12, 18)          # K = 384 / 768 / 1152: the kernels built for one K (Q4.static)
 DTYPES = ("bf16", "f16")
 
 
@@ -833,6 +911,8 @@ def variants():
         for cls, (gelu, ln, res, stats) in CLASSES.items():
             for nkf in NKF[cls]:
                 yield "q4_%s_%s_f%d" % (dt, cls, nkf), dict(dtype=dt, gelu=gelu, ln=ln, res=res, stats=stats, nkf=nkf)
+            for nk in NK_STATIC:
+                yield "q4_%s_%s_s%d" % (dt, cls, nk), dict(dtype=dt, gelu=gelu, ln=ln, res=res, stats=stats, nkf=nk, static=True)
     # tuning ablations (wrong results by construction; bits in Q4.__init__)
     for cls, nkf in (("gl", 12), ("r", 12)):
         gelu, ln, res, _ = CLASSES[cls]
@@ -860,12 +940,13 @@ def emit(path):
             raise RuntimeError("%s: %d hazard lint findings, first: %s" % (name, len(pr), pr[0]))
         out.append(kernel_text(name, g))
         table.append((name, kw))
-    out.append("namespace mlpk {\nstruct Q4Variant { const char* name; const void* fn; int dtype, gelu, ln, res, stats, nkf, dbg; };\n"
+    out.append("namespace mlpk {\nstruct Q4Variant { const char* name; const void* fn; int dtype, gelu, ln, res, stats, nkf, dbg, is_static; };\n"
                "static const Q4Variant kQ4Variants[] = {\n")
     for name, kw in table:
         dbg = kw.get("dbg", 0)
-        out.append("    {\"%s\", reinterpret_cast<const void*>(&%s), %s, %d, %d, %d, %d, %d, %d},\n" %
-                   (name, name, "MLPK_BF16" if kw["dtype"] == "bf16" else "MLPK_F16", kw["gelu"], kw["ln"], kw["res"], kw.get("stats", False), kw["nkf"], dbg))
+        out.append("    {\"%s\", reinterpret_cast<const void*>(&%s), %s, %d, %d, %d, %d, %d, %d, %d},\n" %
+                   (name, name, "MLPK_BF16" if kw["dtype"] == "bf16" else "MLPK_F16", kw["gelu"], kw["ln"], kw["res"], kw.get("stats", False), kw["nkf"], dbg,
+                    kw.get("static", False)))
     out.append("};\n}  // namespace mlpk\n")
     text = "".join(out)
     if not os.path.exists(path) or open(path).read() != text:

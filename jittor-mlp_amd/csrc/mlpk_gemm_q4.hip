@@ -69,11 +69,19 @@ bool q4_supported(const Q4Call& c) {
     return true;
 }
 
+// the kernel for a call: the one built for exactly this K where there is one (round 4, Q4.static in q4gen.py: stage rotation, DMA
+// addressing and the tile switch resolved at generation time; MLPK_Q4_STATIC=0 switches them off for A/B runs), otherwise the
+// general kernel with the most unrolled (filler-carrying) iterations that K allows
 static const Q4Variant* q4_pick(const Q4Call& c, int force_nkf) {
+    static const bool use_static = !(getenv("MLPK_Q4_STATIC") && atoi(getenv("MLPK_Q4_STATIC")) == 0);
     const int nk = c.K / 64;
     const Q4Variant* best = nullptr;
     for (const Q4Variant& v : kQ4Variants) {
         if (v.dtype != c.dtype || v.gelu != c.gelu || v.ln != c.ln || v.res != c.res || v.stats != (c.row_part != nullptr) || v.dbg != c.dbg) continue;
+        if (v.is_static) {
+            if (use_static && !force_nkf && v.nkf == nk) return &v;
+            continue;
+        }
         if (v.nkf > nk) continue;
         if (force_nkf && v.nkf != force_nkf) continue;
         if (!best || v.nkf > best->nkf) best = &v;

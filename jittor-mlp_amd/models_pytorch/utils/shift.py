@@ -58,10 +58,28 @@ class Shift(nn.Module):
         return _shift_gpu(x, self.kernel_size, self.dim)
 
 
+def _shift_by_slices(x, shift_size, dim):
+    """chunk g of ceil(C / shift_size) channels moves by g - shift_size // 2 positions along `dim`, zeros shifted in: the same map as the
+    kernel, written with slice assignments (differentiable, any device, any shift size)"""
+    C, n = x.shape[1], x.shape[dim]
+    per = -(-C // shift_size)
+    out = torch.zeros_like(x)
+    for g, c0 in enumerate(range(0, C, per)):
+        s = g - shift_size // 2
+        if abs(s) >= n:
+            continue
+        src = x[:, c0:c0 + per].narrow(dim, max(0, -s), n - abs(s))
+        out[:, c0:c0 + per].narrow(dim, max(0, s), n - abs(s)).copy_(src)
+    return out
+
+
 def torch_shift(x, shift_size, dim):
-    """shift_cuda.py:195-205 -- the reference's pure-torch restatement of the same operation (pad, per-chunk roll, crop) on
-    (B, C, H, W): here the same kernel as `Shift` (chunk g of ceil(C / shift_size) channels moves by g - shift_size // 2 pixels along
-    `dim`, zeros shifted in), out of place."""
+    """shift_cuda.py:195-205 -- the reference's device-independent restatement of the operation (pad, per-chunk roll, crop) on
+    (B, C, H, W).  On a GPU tensor with a shift size the kernel takes (odd, >= 3) it IS the kernel (`Shift`'s autograd.Function);
+    CPU tensors and every other shift size run the same index map in torch slice operations, so it stays the cross-check the
+    reference uses it as."""
     if shift_size == 1:
         return x
-    return _shift_gpu(x, shift_size, dim)
+    if x.is_cuda and x.dim() == 4 and shift_size >= 3 and shift_size % 2 == 1:
+        return _shift_gpu(x, shift_size, dim)
+    return _shift_by_slices(x, shift_size, dim)

@@ -238,3 +238,32 @@ def test_division_free_gelu_coefficients():
         inside = np.abs(x) <= bound
         assert err[inside].max() < inner
         assert (err[~inside] / np.abs(x[~inside])).max() < rel
+
+
+def test_torch_shift_runs_on_cpu_and_matches_the_reference_pins():
+    """shift_cuda.py:195-205: the reference's `torch_shift` is its device-independent, differentiable restatement of the Shift op.  The
+    drop-in keeps that role: CPU tensors (and shift sizes the kernel does not take) run the same index map in torch slice operations;
+    outputs and grads are bit-equal to what the reference produced (tests/golden/ops.npz)."""
+    import numpy as np
+    pkg = load_pkg()
+    ut = pkg.models_pytorch.utils
+    z = np.load(os.path.join(GOLDEN, "ops.npz"))
+    i = 0
+    while "shift%d/x" % i in z.files:
+        x = torch.from_numpy(z["shift%d/x" % i]).requires_grad_(True)
+        k = int(z["shift%d/k" % i])
+        for dim in (2, 3):
+            y = ut.torch_shift(x, k, dim)
+            assert torch.equal(y.detach(), torch.from_numpy(z["shift%d/dim%d" % (i, dim)]))
+            if "shift%d/gout_dim%d" % (i, dim) in z.files:
+                g, = torch.autograd.grad(y, x, torch.from_numpy(z["shift%d/gout_dim%d" % (i, dim)]))
+                assert torch.equal(g, torch.from_numpy(z["shift%d/gin_dim%d" % (i, dim)]))
+        i += 1
+    assert i >= 4
+    x = torch.randn(2, 8, 5, 6)
+    assert ut.torch_shift(x, 1, 2) is x
+    y = ut.torch_shift(x, 4, 3)                     # an even size: chunks of 2 channels move by -2, -1, 0, +1 columns
+    assert torch.equal(y[:, 0:2, :, :4], x[:, 0:2, :, 2:]) and float(y[:, 0:2, :, 4:].abs().max()) == 0.0
+    assert torch.equal(y[:, 6:8, :, 1:], x[:, 6:8, :, :5]) and torch.equal(y[:, 4:6], x[:, 4:6])
+    with pytest.raises(NotImplementedError):        # the module itself is the native op: no CPU path (shift_cuda.py:170-173)
+        ut.Shift(3, 2)(x)

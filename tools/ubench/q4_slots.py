@@ -275,6 +275,69 @@ for nm, pat in (("vdst_mfma_only", lambda a, q: None), ("vdst_fma4", lambda a, q
                 ("vdst_t4gap", lambda a, q: (pk(a, 3, q * 3, sgpr=True, chains=2), med3(a, 1, q)) and None)):
     P(nm, pat)
     VDST.add(nm)
+
+# ---- round 4: what do transcendental / 16-bit packed instructions cost in the shadow of an MFMA, and LDS-DMA pieces that share
+# one m0 write through the instruction's immediate offset (tools/ubench/lds_dma_offset.hip shows where the offset goes)
+def trans(a, op, n, base=0):
+    for k in range(n):
+        r = 72 + ((base + k) % 16)
+        a(op, V(r), V(r))
+
+
+def pk16(a, op, n, base=0):
+    for k in range(n):
+        r = 72 + ((base + k) % 16)
+        if op == "v_pk_fma_f16":
+            a(op, V(r), V(r), V(64), V(65))
+        else:
+            a(op, V(r), V(r), V(64))
+
+
+def dma_off(a, q):
+    """three pieces behind MFMAs 1, 3, 6 of every 8 as in dma(), but m0 written once per FOUR pieces"""
+    k = (q // 8) * 3 + {1: 0, 3: 1, 6: 2}[q % 8]
+    if k % 4 == 0:
+        a("s_add_u32", "m0", S(11), (k // 4) * 4096)
+    a("global_load_lds_dwordx4", V(2), S(6, 2), offset=(k % 4) * 1024)
+
+
+for n in (1, 2, 4):
+    P("exp%d" % n, lambda a, q, n=n: trans(a, "v_exp_f32", n, q * n))
+    P("rcp%d" % n, lambda a, q, n=n: trans(a, "v_rcp_f32", n, q * n))
+P("exp1_fma4", lambda a, q: (trans(a, "v_exp_f32", 1, q), fma(a, 4, q * 4 + 4)) and None)
+P("exp1_fma5", lambda a, q: (trans(a, "v_exp_f32", 1, q), fma(a, 5, q * 5 + 4)) and None)
+P("exp1rcp1_fma3", lambda a, q: (trans(a, "v_exp_f32", 1, q), fma(a, 3, q * 3 + 4), trans(a, "v_rcp_f32", 1, q + 8)) and None)
+P("exp1rcp1_fma4", lambda a, q: (trans(a, "v_exp_f32", 1, q), fma(a, 4, q * 4 + 4), trans(a, "v_rcp_f32", 1, q + 8)) and None)
+P("alt_exp_rcp_fma4", lambda a, q: (trans(a, "v_exp_f32" if q & 1 else "v_rcp_f32", 1, q), fma(a, 4, q * 4 + 4)) and None)
+P("alt_exp_rcp_fma3", lambda a, q: (trans(a, "v_exp_f32" if q & 1 else "v_rcp_f32", 1, q), fma(a, 3, q * 3 + 4)) and None)
+for n in (2, 4, 5, 6):
+    P("pkfma16_%d" % n, lambda a, q, n=n: pk16(a, "v_pk_fma_f16", n, q * n))
+P("pkmul16_4", lambda a, q: pk16(a, "v_pk_mul_f16", 4, q * 4))
+P("dmaoff_12of32", lambda a, q: dma_off(a, q) if q % 8 in (1, 3, 6) else None, lambda a: a("s_waitcnt", vmcnt=12))
+P("dmaoff_12_reads_fma3", lambda a, q: (dma_off(a, q) if q % 8 in (1, 3, 6) else None, ds_read(a, q) if READS68(q) else None, fma(a, 3, 3 * q)) and None,
+  lambda a: a("s_waitcnt", vmcnt=12))
+
+
+def target(a, q, nf, off=True, transmix=True):
+    """the loop round 4 aims at: fragment reads, 12 DMA pieces (3 m0 writes), nf fillers per gap of which every fourth is transcendental"""
+    if q % 8 in (1, 3, 6):
+        (dma_off if off else (lambda a, q: dma(a, q, nop=False)))(a, q)
+    if READS68(q):
+        ds_read(a, q)
+    for k in range(nf):
+        n = q * nf + k
+        r = 72 + n % 16
+        if transmix and n % 4 == 3:
+            a("v_exp_f32" if n & 4 else "v_rcp_f32", V(r), V(r))
+        else:
+            a("v_fmaak_f32", V(r), V(r), V(64), F(0.123))
+
+
+for nf in (3, 4, 5):
+    P("target%d" % nf, lambda a, q, nf=nf: target(a, q, nf), lambda a: (a("s_waitcnt", vmcnt=12, lgkmcnt=0), a("s_barrier")) and None)
+P("target4_m0each", lambda a, q: target(a, q, 4, off=False), lambda a: (a("s_waitcnt", vmcnt=12, lgkmcnt=0), a("s_barrier")) and None)
+P("target4_plain", lambda a, q: target(a, q, 4, transmix=False), lambda a: (a("s_waitcnt", vmcnt=12, lgkmcnt=0), a("s_barrier")) and None)
+P("target5_plain", lambda a, q: target(a, q, 5, transmix=False), lambda a: (a("s_waitcnt", vmcnt=12, lgkmcnt=0), a("s_barrier")) and None)
 ONLY = os.environ.get("ONLY", "")
 if ONLY:
     PAT[:] = [x for x in PAT if any(x[0].startswith(t) for t in ONLY.split(","))]
