@@ -204,12 +204,9 @@ def main():
         if "WORLD_SIZE" not in os.environ and args.gpus > 1:
             # `python bench.py --gpus N` on its own: become the launcher (one rank per GPU, rendezvous on 127.0.0.1) -- the same
             # command line the driver would have started through torch.distributed.run
-            import socket
-            with socket.socket() as sk:
-                sk.bind(("127.0.0.1", 0))
-                port = sk.getsockname()[1]
-            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            # --standalone: torch.distributed.run picks and binds its own free rendezvous port (no bind-close-rebind race)
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                   os.path.abspath(__file__)] + sys.argv[1:]
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             sys.stdout.flush()
             os.execv(sys.executable, cmd)
@@ -309,15 +306,18 @@ def main():
                 peak = PEAK_BF16_TFLOPS if args.dtype != "fp32" else 157.3
                 ach = flops / secs / 1e12
                 traffic, traffic_src = measured_traffic(args)
-                line["roofline"] = {"bound": "mfma", "kernel": "channel-MLP fc1 (q4_bf16_gl_f12, generated) + fc2 (gemm_nt_p8_pair_kernel)", "achieved": round(ach, 1),
+                names = "; ".join("%s: %s" % (t, ", ".join(summ[t].get("kernels") or ["?"])) for t in dom)      # from the dispatch, not a constant
+                line["roofline"] = {"bound": "mfma", "kernel": names, "achieved": round(ach, 1),
                                     "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                                     "flops_per_launch": flops / n_launch, "avg_launch_ms": round(secs / n_launch * 1e3, 4),
                                     "launches_timed": n_launch, "traffic_source": traffic_src,
-                                    # a "launch" here is one mlpk_gemm_nt CALL (236.8 GFLOP).  fc1 is ONE launch of the generated q4
-                                    # kernel; fc2 runs the persistent 256 x 256 tile, which covers M with up to three tile heights,
-                                    # each its own kernel launch (NI = 4 / 3 at M = 50176): a rocprofv3 --stats summary lists
-                                    # them as separate rows, per call the row averages add up as sum(calls_i x avg_i) / calls
-                                    "launch_means": "one mlpk_gemm_nt call = one launch: fc1 the generated q4 tile, fc2 the persistent tile with its 256- and 192-row panels in one launch"}
+                                    # "traffic" is NOT measured in this run: it is the PMC result of tools/pmc_bench.sh on this command,
+                                    # read from profiles/ and dropped (null) when the GEMM sources changed since it was taken
+                                    "traffic_measured_in_run": False,
+                                    # a "launch" here is one mlpk_gemm_nt CALL (236.8 GFLOP at Mixer-B/16): the kernel names above are what
+                                    # the library's dispatch answered for the timed calls (mlpk_gemm_kernel_name); the persistent tile
+                                    # lists the tile heights of its plan ("rows 256+192": both in one launch of the pair kernel)
+                                    "launch_means": "one mlpk_gemm_nt call; kernel names as answered by the dispatch for the timed calls"}
             line["kernels"] = {t: {"avg_ms": round(v["avg_ms"], 4), "tflops": round(v["flops_per_launch"] / v["avg_ms"] / 1e9, 1),
                                    "launches": v["launches"]} for t, v in summ.items()}
         if world == 1 and not args.no_cpu_baseline:

@@ -142,11 +142,13 @@ typedef struct mlpk_gemm_desc {
     /* ABI 6.  By-product row statistics (optional; 16-bit row-major outputs with N % 8 == 0, 16-byte aligned rows of C and R):
        the statistics pass of the LayerNorm that FOLLOWS this GEMM (vip.py:66,82; g_mlp.py:40; s2_mlp_v2.py:60,78: every one of
        them reads a tensor a GEMM has just written) comes out of the store epilogue instead of a second pass over C:
-         row_part[(q * row_part_ld + m) * 2 + {0, 1}] = sum / sum of squares, over the q-th block of `width` columns, of the
-         values WRITTEN to C[m, :] (after rounding, after the residual), q < nparts = ceil(N / width)
-       -- planar, one plane of row_part_ld >= M pairs per column block.  width (128, or 32 from the persistent tile) follows from
-       the tile choice: mlpk_gemm_row_parts() answers nparts for a descriptor.  mlpk_stats_finalize_planar turns the pairs into
-       mean / rstd. */
+         row_part[(q * row_part_ld + m) * 2 + {0, 1}] = sum / sum of squares, over the q-th block of 32 columns, of the
+         values WRITTEN to C[m, :] (after rounding, after the residual), q < nparts = ceil(N / 32)
+       -- planar, one plane of row_part_ld >= M pairs per column block.  EVERY tile reduces a block in the same order (fp32): the 8
+       values of a 16-byte chunk by four two-term dot products in column order, then (c0 + c1) + (c2 + c3) over the block's four
+       chunks; mlpk_stats_finalize_planar adds the planes in ascending order in fp64.  So a row's mean / rstd do not depend on the
+       tile that stored it, i.e. not on the batch the row is computed in (SURVEY.md section 4 tier 6: a sharded forward equals the
+       single forward on the concatenated batch, row for row).  mlpk_gemm_row_parts() answers nparts for a descriptor. */
     float* row_part;
     int32_t row_part_ld;
     int32_t reserved2;    /* 0 */
@@ -156,6 +158,9 @@ int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream);
 /* planes (pairs per row) that mlpk_gemm_nt would write for this descriptor (row_part may still be NULL); an error code when the
    descriptor cannot deliver statistics (fp32, token-transposed output, unaligned rows, an explicit algo with 64-column tiles) */
 int mlpk_gemm_row_parts(const mlpk_gemm_desc* d, int* nparts);
+/* ABI 8.  Name of the kernel mlpk_gemm_nt would launch for this descriptor (tile family, generated variant, tile heights), for
+   measurement labels: bench.py's roofline.kernel is what the dispatch answers, not a constant.  Nothing is launched. */
+int mlpk_gemm_kernel_name(const mlpk_gemm_desc* d, char* buf, int len);
 /* 0 (no kernel needs scratch) */
 long long mlpk_gemm_workspace_bytes(void);
 /* number of tile configurations (valid algo ids are 1..count) and dynamic LDS bytes of one */

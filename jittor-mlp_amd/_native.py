@@ -48,6 +48,7 @@ PROTOTYPES = {
     "mlpk_gemm_workspace_bytes": (ctypes.c_longlong, []),
     "mlpk_gemm_algo_count": (c_int, []),
     "mlpk_gemm_algo_info": (c_int, [c_int] + [ctypes.POINTER(c_int)] * 4),
+    "mlpk_gemm_kernel_name": (c_int, [ctypes.POINTER(GemmDesc), ctypes.c_char_p, c_int]),
     "mlpk_token_mlp_chunk": (c_int, []),
     "mlpk_token_mlp": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
@@ -105,7 +106,7 @@ def lib():
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(handle, name)          # AttributeError if a declared symbol is not exported
             fn.restype, fn.argtypes = res, args
-        if handle.mlpk_abi_version() != 7:
+        if handle.mlpk_abi_version() != 8:
             raise MlpkError("libmlpk.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -59,6 +59,13 @@ class Neg:
         self.r = r
 
 
+class Abs:
+    """source modifier |x| (VOP3 float operands)"""
+
+    def __init__(self, r):
+        self.r = r
+
+
 class F:
     """float literal / inline constant"""
     INLINE = {0.0: "0", 0.5: "0.5", -0.5: "-0.5", 1.0: "1.0", -1.0: "-1.0", 2.0: "2.0", -2.0: "-2.0", 4.0: "4.0", -4.0: "-4.0"}
@@ -78,6 +85,8 @@ def _optext(o):
         return o.text()
     if isinstance(o, Neg):
         return "-" + _optext(o.r)
+    if isinstance(o, Abs):
+        return "|" + _optext(o.r) + "|"
     if isinstance(o, F):
         return o.text()
     if isinstance(o, bool):
@@ -258,6 +267,8 @@ class Emu:
             return np.full(64, o.bits(), np.uint32)
         if isinstance(o, Neg):
             return self.rd(w, o.r) ^ np.uint32(0x80000000)
+        if isinstance(o, Abs):
+            return self.rd(w, o.r) & np.uint32(0x7FFFFFFF)
         if isinstance(o, int):
             return np.full(64, o & 0xFFFFFFFF, np.uint32)
         if o == "m0":
@@ -641,6 +652,15 @@ class Emu:
         with np.errstate(all="ignore"):
             self.wrv(w, i.args[0], self.u(self.f(self.rd(w, i.args[1])) + self.f(self.rd(w, i.args[2]))))
 
+    # transcendentals: 1-ulp approximations in hardware, correctly rounded here (results are compared with a tolerance)
+    def x_v_exp_f32(self, w, i):
+        with np.errstate(all="ignore"):
+            self.wrv(w, i.args[0], self.u(np.exp2(self.f(self.rd(w, i.args[1])).astype(np.float64)).astype(np.float32)))
+
+    def x_v_rcp_f32(self, w, i):
+        with np.errstate(all="ignore"):
+            self.wrv(w, i.args[0], self.u((1.0 / self.f(self.rd(w, i.args[1])).astype(np.float64)).astype(np.float32)))
+
     def x_v_sub_f32(self, w, i):
         with np.errstate(all="ignore"):
             self.wrv(w, i.args[0], self.u(self.f(self.rd(w, i.args[1])) - self.f(self.rd(w, i.args[2]))))
@@ -895,7 +915,7 @@ class Emu:
 
 # ------------------------------------------------------------------ hazard lint
 def _regs_of(o):
-    if isinstance(o, Neg):
+    if isinstance(o, (Neg, Abs)):
         o = o.r
     if isinstance(o, Reg):
         return {(o.kind, o.idx + k) for k in range(o.n)}
@@ -929,6 +949,9 @@ def defs_uses(i):
     return d, u
 
 
+TRANS_OPS = ("v_exp_f32", "v_rcp_f32", "v_log_f32", "v_rsq_f32", "v_sqrt_f32", "v_sin_f32", "v_cos_f32")
+
+
 def lint(asm, mfma_gap=16, verbose=False):
     """Distances are counted in issued instructions along the LINEAR listing (s_nop N = N + 1), which is what the
     generator's straight-line bodies need; loop back-edges are covered by the padding the generator puts at loop heads."""
@@ -939,7 +962,7 @@ def lint(asm, mfma_gap=16, verbose=False):
         if i.op == "label":
             continue
         for o in i.args:
-            if isinstance(o, Neg):
+            if isinstance(o, (Neg, Abs)):
                 o = o.r
             if isinstance(o, Reg) and o.n >= 2 and o.kind in ("v", "a", "s") and o.idx % 2:
                 problems.append((k, "register tuple %s is not 64-bit aligned" % o.text()))
@@ -971,7 +994,10 @@ def lint(asm, mfma_gap=16, verbose=False):
                 problems.append((k, "v_permlane32_swap %d states after a VALU write of %s%d (< 2)" % (dist, r[0], r[1])))
             if kind == "valu_sgpr" and (i.op.startswith("global_") or i.op.startswith("s_load")) and dist < 5:
                 problems.append((k, "VMEM/SMEM reads s%d %d states after a VALU wrote it (< 5)" % (r[1], dist)))
-            if kind == "valu" and is_mfma and dist < 2:
+            if kind == "trans" and is_valu and i.op not in TRANS_OPS and dist < 1:
+                # gfx940+ trans forwarding hazard: a non-transcendental VALU instruction reads a transcendental's result >= 1 state later
+                problems.append((k, "%s reads the transcendental result %s%d straight after it was written" % (i.op, r[0], r[1])))
+            if kind in ("valu", "trans") and is_mfma and dist < 2:
                 problems.append((k, "MFMA reads %s%d %d states after a VALU write (< 2)" % (r[0], r[1], dist)))
         for r in d:
             if r in last_def:
@@ -988,6 +1014,8 @@ def lint(asm, mfma_gap=16, verbose=False):
                 last_def[r] = (pos, "valu_sgpr")
             elif i.op.startswith("v_dot2c"):
                 last_def[r] = (pos, "dot")
+            elif i.op in TRANS_OPS:
+                last_def[r] = (pos, "trans")
             elif is_valu:
                 last_def[r] = (pos, "valu")
             else:

@@ -85,7 +85,7 @@ def run_case(gen, M, N, K, grid, cgroups=1, seed=0, dma_mode="late", order=None,
     ints = dict(lda=K, ldb=K, ldc=N, ldr=N, **pl)
     for name, val in ints.items():
         struct.pack_into("<I", ka, q4gen.KA[name], val)
-    part = np.full((N // 64, M, 2), np.nan, np.float32)
+    part = np.full((N // 32, M, 2), np.nan, np.float32)
     aPart = mem.add(part)
     struct.pack_into("<Q", ka, q4gen.KA["row_part"], aPart)
     struct.pack_into("<I", ka, q4gen.KA["row_part_ld"], M)
@@ -128,8 +128,8 @@ def run_case(gen, M, N, K, grid, cgroups=1, seed=0, dma_mode="late", order=None,
             print("  bad row blocks of 32:", rows[:40], " col blocks:", cols[:40])
     ok = bool(written.all() and not bad.any())
     if getattr(gen, "stats", False):
-        got = mem.get(aPart).view(np.float32).reshape(N // 64, M, 2).astype(np.float64)
-        outq = out.reshape(M, N // 64, 64)
+        got = mem.get(aPart).view(np.float32).reshape(N // 32, M, 2).astype(np.float64)
+        outq = out.reshape(M, N // 32, 32)
         want = np.stack([outq.sum(axis=2).T, (outq * outq).sum(axis=2).T], axis=2)
         perr = np.abs(got - want).max() if np.isfinite(got).all() else float("nan")
         if not (perr < 1e-3):

@@ -25,7 +25,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from isa import A, F, S, V, Asm, Neg, Reg  # noqa: E402
+from isa import A, F, S, V, Abs, Asm, Neg, Reg  # noqa: E402
 
 # the 16-bit GELU polynomials of mlpk_common.h (MLPK_GELUP_*) by storage type.  f16: (scale, Horner coefficients) of the centred form
 # t = clamp(x * scale, -sqrt2, sqrt2), u = t * t - 1; bf16: (clamp, coefficients) of the raw form t = clamp(x, -clamp, clamp), u = t * t
@@ -34,6 +34,30 @@ GELU = {"f16": (0.314269681, [0.00260713836, -0.00718860654, 0.00979797821, -0.0
         "bf16": (4.0, [-1.58078628e-09, 1.21711111e-07, -4.10086659e-06, 8.06673925e-05, -0.00104820437, 0.00966487452, -0.0661753789,
                        0.39884752])}
 GELU_RAW = {"f16": False, "bf16": True}
+# round 4, bf16 grade: gelu(x) = x / (1 + 2^(x (k0 + k1 |x| + k2 x^2)))  (mlpk_common.h MLPK_GELUS_K*, tools/fit_gelu_sig.py): SEVEN
+# instructions per element instead of eleven (two of them transcendental: ~2 extra cycles each beside an MFMA, tools/ubench/q4_slots.py).
+# MLPK_GELU_BF16_POLY=1 at generation time (+ -DMLPK_GELU_BF16_POLY for the HIP sources) keeps the polynomial for A/B builds.
+GELU_SIG = {"bf16": (-2.28684449, -0.0305621661, -0.0905431807)}
+GELU_FORM = {"f16": "poly", "bf16": "poly" if os.environ.get("MLPK_GELU_BF16_POLY") == "1" else "sig"}
+
+
+def sig_gelu_ops(E, x, q, v_k2, s_k1, s_k0):
+    """x[r] <- gelu(x[r]) for four chains abreast, the operation sequence of gelu16_f<bf16> (mlpk_common.h); q: one scratch register
+    per chain.  (A transcendental's result is read >= 4 instructions after it was written: the gfx940 forwarding hazard needs 1.)"""
+    for r in range(4):
+        E("v_fma_f32", q[r], Abs(x[r]), v_k2, s_k1)
+    for r in range(4):
+        E("v_fma_f32", q[r], Abs(x[r]), q[r], s_k0)
+    for r in range(4):
+        E("v_mul_f32", q[r], x[r], q[r])
+    for r in range(4):
+        E("v_exp_f32", q[r], q[r])
+    for r in range(4):
+        E("v_add_f32", q[r], F(1.0), q[r])
+    for r in range(4):
+        E("v_rcp_f32", q[r], q[r])
+    for r in range(4):
+        E("v_mul_f32", x[r], x[r], q[r])
 SQRT2 = 1.41421356237
 
 STAGE_B = 49152          # one LDS stage: A 256 x 128 B, then B 128 x 128 B
@@ -115,6 +139,8 @@ class Q4:
             self.s_eP = s("eP", 2, 2)
             self.s_mask8 = s("mask8", 2, 2)
         self.s_r2 = s("r2")
+        self.sig = self.gelu and GELU_FORM[self.dtype] == "sig"
+        self.s_k0, self.s_k1 = (s("gk0"), s("gk1")) if self.sig else (None, None)
         self.s_prof0, self.s_prof1, self.s_profp, self.s_ntiles = s("prof0", 2, 2), s("prof1", 2, 2), s("profp", 2, 2), s("ntiles")
         self.s_t = [s("t%d" % i) for i in range(6)]
         # vector registers
@@ -231,9 +257,11 @@ class Q4:
                 E("s_add_u32", dst[0], ptr[0], t[0])
                 E("s_addc_u32", dst[1], ptr[1], t[1])
             if self.stats:
-                # plane (pn0 / 64 + wn), row pm0: ((pn0 >> 6) + wn) * ld + pm0 pairs of 8 bytes
-                E("s_lshr_b32", t[0], self.s_pn0, 6)
+                # plane (pn0 / 32 + 2 wn) (+ 1 for the lanes of the wave's second 32 columns: voffP), row pm0:
+                # ((pn0 >> 5) + 2 wn) * ld + pm0 pairs of 8 bytes
+                E("s_lshr_b32", t[0], self.s_pn0, 5)
                 E("s_and_b32", t[1], self.s_wave, 1)
+                E("s_lshl_b32", t[1], t[1], 1)
                 E("s_add_u32", t[0], t[0], t[1])
                 E("s_mul_hi_u32", t[1], t[0], self.s_partld)
                 E("s_mul_i32", t[0], t[0], self.s_partld)
@@ -336,6 +364,8 @@ class Q4:
 
     def gelu_ops(self, E, x, t, u, q):
         """x[r] <- gelu(x[r]) for the 4 chains abreast (the operation sequence of gelu16_f in mlpk_common.h)"""
+        if self.sig:
+            return sig_gelu_ops(E, x, q, self.v_c0, self.s_k1, self.s_k0)
         scale, c = GELU[self.dtype]
         if GELU_RAW[self.dtype]:
             for r in range(4):
@@ -417,12 +447,14 @@ class Q4:
                 for c in range(4):
                     E(dot, sp[0], o[c], self.v_ones)
                     E(dot, sp[1], o[c], o[c])
-                for n_, mod in enumerate((dict(quad_perm="[1,0,3,2]"), dict(quad_perm="[2,3,0,1]"), dict(row_half_mirror=True))):
+                # planes of 32 columns, reduced in ONE order by every tile of the library (mlpk.h row_part): a lane's chunk of 8 by four
+                # dot products, then (c0 + c1) + (c2 + c3) over the four lanes that hold 32 consecutive columns
+                for n_, mod in enumerate((dict(quad_perm="[1,0,3,2]"), dict(quad_perm="[2,3,0,1]"))):
                     # wait states: a VALU result is read through DPP after >= 2, a dot-product result by another opcode after >= 3
                     E("s_nop", 1 if n_ == 0 else 0)
                     E("v_add_f32_dpp", sp[0], sp[0], sp[0], **mod, row_mask="0xf", bank_mask="0xf")
                     E("v_add_f32_dpp", sp[1], sp[1], sp[1], **mod, row_mask="0xf", bank_mask="0xf")
-                # one pair per row: the lanes with (lane & 7) == 0
+                # two pairs per row: the lanes with (lane & 3) == 0
                 ops.append(lambda k=k, i=i: (a("s_mov_b64", "exec", self.s_mask8),
                                              a("global_store_dwordx2", self.voffP[k], sp, self.s_eP, offset=i * 256),
                                              a("s_mov_b64", "exec", -1)) and None)
@@ -557,10 +589,12 @@ class Q4:
             new_ready = {}
             for qm in range(8):
                 i, j = qm >> 1, qm & 1
-                if j == 0 and s > 0 and self.reads_on:
+                if j == 0 and s > 0 and self.reads_on and (not self.static or i in (0, 2)):
                     # first use of A_i (and of both B fragments when i == 0: they were read before A_0); the fragments of step 0
-                    # were waited for in front of the previous barrier
-                    self.wait_lds(ready[("A", i)])
+                    # were waited for in front of the previous barrier.  Static kernels wait twice per step instead of four times
+                    # (for A_1 in front of MFMA 0, for A_3 in front of MFMA 4: the reads were issued 5 / 3 MFMAs earlier) -- every
+                    # s_waitcnt is an issue slot of the one wave that feeds this SIMD
+                    self.wait_lds(ready[("A", i if not self.static else i + 1)])
                 d = self.acc(acc_set, 2 * i + j)
                 slot = dma_slots.get((s, qm))
                 if slot and self.dma_on:
@@ -652,7 +686,12 @@ class Q4:
         a("v_xor_b32", x, x, l7)                   # read swizzle (lane & 7) ^ ((lane >> 4) & 1)
         a("v_xor_b32", x, x, h)                    # ^ k-half of the lane
         a("s_mov_b32", self.s_r2, F(SQRT2))
-        if self.gelu:
+        if self.sig:
+            gk = GELU_SIG[self.dtype]
+            a("v_mov_b32", self.v_c0, F(gk[2]))
+            a("s_mov_b32", self.s_k1, F(gk[1]))
+            a("s_mov_b32", self.s_k0, F(gk[0]))
+        elif self.gelu:
             a("v_mov_b32", self.v_c0, F(GELU[self.dtype][1][0]))
         a("s_waitcnt", lgkmcnt=0)
         a("s_memtime", self.s_prof0)
@@ -714,15 +753,20 @@ class Q4:
         if self.res:
             a("s_lshl_b32", self.s_rowR, k["ldr"], 6)
         if self.stats:
-            # pair offsets: row wm * 128 + 8 k + (lane >> 3) of block row 0, 8 bytes per row
+            # pair offsets: row wm * 128 + 8 k + (lane >> 3) of block row 0, 8 bytes per row; the lanes of the wave's second 32
+            # columns (lane & 4) write the next plane
             a("s_lshl_b32", t[0], wm, 7)
             a("v_add_u32", vt[6], t[0], l3)
+            a("v_bfe_u32", vt[7], l7, 2, 1)
+            a("s_waitcnt", lgkmcnt=0)                                   # (s_partld: the s_load in front of the lane constants)
+            a("v_mul_lo_u32", vt[7], vt[7], self.s_partld)
             for kk in range(4):
                 a("v_add_u32", lane, 8 * kk, vt[6])
+                a("v_add_u32", lane, lane, vt[7])
                 a("v_lshlrev_b32", self.voffP[kk], 3, lane)
             a("v_mov_b32", self.v_ones, 0x3F803F80 if self.dtype == "bf16" else 0x3C003C00)
-            a("s_mov_b32", self.s_mask8[0], 0x01010101)
-            a("s_mov_b32", self.s_mask8[1], 0x01010101)
+            a("s_mov_b32", self.s_mask8[0], 0x11111111)
+            a("s_mov_b32", self.s_mask8[1], 0x11111111)
         # LDS staging tile of this wave: OUT_OFF + wave * 4096; write: row l31, chunk c ^ (l31 & 7), half h; read: row l3, chunk l7 ^ l3
         a("s_lshl_b32", t[0], self.s_wave, 12)
         a("s_add_u32", t[0], t[0], OUT_OFF)

@@ -29,7 +29,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from isa import A, F, S, V, Asm, Neg, Reg  # noqa: E402
-from q4gen import GELU, GELU_RAW, SQRT2, Alloc  # noqa: E402
+from q4gen import GELU, GELU_FORM, GELU_RAW, GELU_SIG, SQRT2, Alloc, sig_gelu_ops  # noqa: E402
 
 KA = dict(xt=0, w1=8, w2=16, b1=24, b2=32, x=40, stats=48, prof=56,
           M=64, G=68, ldxt=72, ldx=76, ntiles=80, tpi=84, tpi_magic=88, grid=92, stat_ld=96, nit=100, lead=104, S=108,
@@ -96,6 +96,8 @@ class T4:
         self.s_scur = s("scur", 2, 2) if self.stats else None
         self.s_tok8 = s("tok8")
         self.s_r2 = s("r2")
+        self.sig = GELU_FORM[self.dtype] == "sig"
+        self.s_k0, self.s_k1 = (s("gk0"), s("gk1")) if self.sig else (None, None)
         self.s_mask = s("mask", 2, 2)
         self.s_t = [s("t%d" % i) for i in range(6)]
         self.s_t64 = s("t64", 2, 2)
@@ -195,7 +197,9 @@ class T4:
             for grp in range(4):                      # accumulator registers 4 grp .. 4 grp + 3
                 x = [self.xg[par_in][rb][4 * grp + r] for r in range(4)]
                 scale, c = GELU[self.dtype]
-                if self.raw:
+                if self.sig:
+                    sig_gelu_ops(E, x, Q, self.v_c0, self.s_k1, self.s_k0)
+                elif self.raw:
                     for r in range(4):
                         E("v_med3_f32", T[r], x[r], F(-scale), F(scale))
                     for r in range(4):
@@ -207,15 +211,16 @@ class T4:
                         E("v_med3_f32", T[r], T[r], Neg(self.s_r2), self.s_r2)
                     for r in range(4):
                         E("v_fma_f32", U[r], T[r], T[r], F(-1.0))
-                for r in range(4):
-                    E("v_fmaak_f32", Q[r], U[r], self.v_c0, F(c[1]))
-                for kx in range(2, len(c)):
+                if not self.sig:
                     for r in range(4):
-                        E("v_fmaak_f32", Q[r], Q[r], U[r], F(c[kx]))
-                for r in range(4):
-                    E("v_fma_f32", T[r], T[r], Q[r], F(0.5))
-                for r in range(4):
-                    E("v_mul_f32", x[r], x[r], T[r])
+                        E("v_fmaak_f32", Q[r], U[r], self.v_c0, F(c[1]))
+                    for kx in range(2, len(c)):
+                        for r in range(4):
+                            E("v_fmaak_f32", Q[r], Q[r], U[r], F(c[kx]))
+                    for r in range(4):
+                        E("v_fma_f32", T[r], T[r], Q[r], F(0.5))
+                    for r in range(4):
+                        E("v_mul_f32", x[r], x[r], T[r])
                 # accumulator register 8 kk + e -> A fragment kk, packed pair e >> 1
                 kk, e0 = grp >> 1, 4 * (grp & 1)
                 hreg = self.h[par_out][rb][kk]
@@ -632,7 +637,12 @@ class T4:
         a("v_lshrrev_b32", l3, 3, lane)
         a("v_and_b32", l7, 7, lane)
         a("s_mov_b32", self.s_r2, F(SQRT2))
-        a("v_mov_b32", self.v_c0, F(self.coefs[0]))
+        if self.sig:
+            a("v_mov_b32", self.v_c0, F(GELU_SIG[self.dtype][2]))
+            a("s_mov_b32", self.s_k1, F(GELU_SIG[self.dtype][1]))
+            a("s_mov_b32", self.s_k0, F(GELU_SIG[self.dtype][0]))
+        else:
+            a("v_mov_b32", self.v_c0, F(self.coefs[0]))
         a("s_mov_b32", self.s_mask[0], -1)
         a("s_mov_b32", self.s_mask[1], 0)
         a("s_lshl_b32", self.s_wv1k, self.s_wave, 10)

@@ -68,6 +68,25 @@ __device__ __forceinline__ float gelu_f(float x) {
 #define MLPK_GELUP_COEFS {0.00260713836f, -0.00718860654f, 0.00979797821f, -0.0172248576f, 0.0355015062f, -0.0601866171f, 0.090279378f, -0.127707109f, 0.174028099f, -0.245624334f, 0.499268919f}
 #define MLPK_GELUP_CLAMP_BF16 4.0f
 #define MLPK_GELUP_COEFS_BF16 {-1.58078628e-09f, 1.21711111e-07f, -4.10086659e-06f, 8.06673925e-05f, -0.00104820437f, 0.00966487452f, -0.0661753789f, 0.39884752f}
+// Round 4 -- the bf16 grade every kernel now evaluates (the polynomial above stays behind -DMLPK_GELU_BF16_POLY for A/B builds):
+//         gelu(x) = x * Phi(x),   Phi(x) ~= 1 / (1 + 2^(x * (K0 + K1 |x| + K2 x^2)))          (tools/fit_gelu_sig.py)
+// a logistic with a cubic exponent, odd in x.  SEVEN instructions per element -- fma, fma (|x| is a source modifier), mul, v_exp_f32,
+// add, v_rcp_f32, mul -- against eleven: the epilogues that carry a GELU are bound by the number of instructions one wave can issue
+// behind its MFMAs (the q4 GEMM's fillers, the fused token-mixing kernel: 6.6 VALU operations per MFMA where 5 are free), and a
+// transcendental costs about two cycles more than a plain operation there (tools/ubench/q4_slots.py exp* / alt_* / target* rows).
+// |gelu error| <= 1.4e-4 for EVERY finite x (|Phi error| <= 3.7e-4 near 0 where gelu itself is small, <= 7e-5 beyond |x| = 2); the
+// exponent's leading coefficient has the sign of K0, so Phi -> 0 / 1 and gelu -> -0 / x in the tails without a clamp -- the clamped
+// polynomial's error grew like 5e-5 |x| beyond its interval (gelu(-1000) = -0.05).  Checked in emulated fp32 by tests/test_host_cpu.py.
+#define MLPK_GELUS_K0 -2.28684449f
+#define MLPK_GELUS_K1 -0.0305621661f
+#define MLPK_GELUS_K2 -0.0905431807f
+__device__ __forceinline__ float gelu_sig_f(float x) {
+    const float a = __builtin_fabsf(x);
+    float q = __builtin_fmaf(a, MLPK_GELUS_K2, MLPK_GELUS_K1);
+    q = __builtin_fmaf(a, q, MLPK_GELUS_K0);
+    const float e = __builtin_amdgcn_exp2f(x * q);
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
 
 // gelu on N independent pairs with the N dependency chains interleaved step by step: a single wave running ONE
 // chain is latency-bound (each v_pk op waits for its predecessor); N = 4 keeps the VALU issuing back to back.
@@ -99,6 +118,29 @@ template <int N, int K, bool RAW> __device__ __forceinline__ void gelu_pk_impl(f
 }
 
 template <typename T, int N> __device__ __forceinline__ void gelu_pk_n(f32x2 (&x)[N]) {
+#ifndef MLPK_GELU_BF16_POLY
+    if constexpr (dtype_of<T>::value == MLPK_BF16) {
+        // the N pairs step by step (the compiler is free to pair the fma / mul steps into v_pk_*: same bits either way)
+        f32x2 a[N], q[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) a[k] = f32x2{__builtin_fabsf(x[k].x), __builtin_fabsf(x[k].y)};
+#pragma unroll
+        for (int k = 0; k < N; ++k) q[k] = __builtin_elementwise_fma(a[k], f32x2{MLPK_GELUS_K2, MLPK_GELUS_K2}, f32x2{MLPK_GELUS_K1, MLPK_GELUS_K1});
+#pragma unroll
+        for (int k = 0; k < N; ++k) q[k] = __builtin_elementwise_fma(a[k], q[k], f32x2{MLPK_GELUS_K0, MLPK_GELUS_K0});
+#pragma unroll
+        for (int k = 0; k < N; ++k) q[k] = x[k] * q[k];
+#pragma unroll
+        for (int k = 0; k < N; ++k) q[k] = f32x2{__builtin_amdgcn_exp2f(q[k].x), __builtin_amdgcn_exp2f(q[k].y)};
+#pragma unroll
+        for (int k = 0; k < N; ++k) q[k] = q[k] + f32x2{1.0f, 1.0f};
+#pragma unroll
+        for (int k = 0; k < N; ++k) q[k] = f32x2{__builtin_amdgcn_rcpf(q[k].x), __builtin_amdgcn_rcpf(q[k].y)};
+#pragma unroll
+        for (int k = 0; k < N; ++k) x[k] = x[k] * q[k];
+        return;
+    }
+#endif
     if constexpr (dtype_of<T>::value == MLPK_BF16) {
         constexpr float c[8] = MLPK_GELUP_COEFS_BF16;
         gelu_pk_impl<N, 8, true>(x, c, MLPK_GELUP_CLAMP_BF16);
@@ -126,6 +168,9 @@ template <int K, bool RAW> __device__ __forceinline__ float gelu16_impl(float x,
 }
 
 template <typename T> __device__ __forceinline__ float gelu16_f(float x) {
+#ifndef MLPK_GELU_BF16_POLY
+    if constexpr (dtype_of<T>::value == MLPK_BF16) return gelu_sig_f(x);
+#endif
     if constexpr (dtype_of<T>::value == MLPK_BF16) {
         constexpr float c[8] = MLPK_GELUP_COEFS_BF16;
         return gelu16_impl<8, true>(x, c, MLPK_GELUP_CLAMP_BF16);
@@ -160,6 +205,15 @@ __device__ __forceinline__ float row16_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
+// Sum over each group of 4 consecutive lanes (the first two steps of row16_sum), result in every lane of the group: with one 16-byte
+// chunk (8 columns) per lane this is the 32-column partial of the by-product row statistics, (c0 + c1) + (c2 + c3) -- the ONE
+// reduction order every tile of the library uses (mlpk.h row_part), so a row's statistics do not depend on the tile that stored it.
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
     return v;
 }
 

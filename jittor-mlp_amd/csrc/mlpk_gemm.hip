@@ -251,7 +251,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
                     bz[r] = p.bias ? p.bias[n] : 0.f;
                     lc[r] = p.ln_mean ? p.ln_csum[n] : 0.f;
                     cs[r] = p.cscale ? p.cscale[n] : 1.f;
-                    ch[r] = p.cshift ? p.cshift[n] : 0.f;
+                    // (no shift = -0.0: t * 1 + (-0) keeps the sign of a zero t.  The logistic GELU returns x * 0 = -0 for x < -10.4,
+                    //  and the generated q4 kernels store that: with +0.0 here the two tiles would differ in the sign bit of a zero)
+                    ch[r] = p.cshift ? p.cshift[n] : -0.f;
                 }
 #pragma unroll
                 for (int i = 0; i < FM; ++i) {
@@ -330,18 +332,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
                 }
             }
             if constexpr (STATS && CPR >= 16) {
-                // by-product statistics: the row's 128 columns sit in 16 lanes (one DPP row).  All the passes' reductions in one
-                // block after the stores, so that their dependent DPP steps interleave instead of each waiting out its own latency
+                // by-product statistics: the row's 128 columns sit in 16 lanes (one DPP row), a plane's 32 columns in 4 consecutive
+                // lanes.  All the passes' reductions in one block after the stores, so that their dependent DPP steps interleave
+                // instead of each waiting out its own latency.  (Round 4: planes of 32 columns in the library-wide order -- quad_sum,
+                // mlpk_common.h -- instead of 128: a row's statistics no longer depend on the tile the batch size selects.)
 #pragma unroll
                 for (int q = 0; q < NP; ++q) {
-                    ps1[q] = row16_sum(live ? ps1[q] : 0.f);
-                    ps2[q] = row16_sum(live ? ps2[q] : 0.f);
+                    ps1[q] = quad_sum(live ? ps1[q] : 0.f);
+                    ps2[q] = quad_sum(live ? ps2[q] : 0.f);
                 }
-                if ((c16 & 15) == 0 && live) {
+                if ((c16 & 3) == 0 && live && gn < p.N) {
 #pragma unroll
                     for (int q = 0; q < NP; ++q) {
                         const int gm = m0 + q * RPASS + rsub;
-                        if (gm < p.M) *reinterpret_cast<f32x2*>(p.row_part + ((size_t)(gn >> 7) * p.row_part_ld + gm) * 2) = f32x2{ps1[q], ps2[q]};
+                        if (gm < p.M) *reinterpret_cast<f32x2*>(p.row_part + ((size_t)(gn >> 5) * p.row_part_ld + gm) * 2) = f32x2{ps1[q], ps2[q]};
                     }
                 }
             }
@@ -438,7 +442,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
                     n = n < p.N ? n : p.N - 1;
                     const float bn = p.bias ? p.bias[n] : 0.0f;
                     const float cs = p.cscale ? p.cscale[n] : 1.0f;
-                    const float ch = p.cshift ? p.cshift[n] : 0.0f;
+                    const float ch = p.cshift ? p.cshift[n] : -0.0f;     // (-0: keeps the sign of a zero, see the row-major epilogue)
 #pragma unroll
                     for (int i = 0; i < FM; ++i) {
                         const int ml = rbase(i) + 4 * fg;
@@ -491,7 +495,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
             if (n >= p.N) continue;
             const float bn = p.bias ? p.bias[n] : 0.0f;
             const float cs = p.cscale ? p.cscale[n] : 1.0f;
-            const float ch = p.cshift ? p.cshift[n] : 0.0f;
+            const float ch = p.cshift ? p.cshift[n] : -0.0f;
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 const int mb = m0 + rbase(i) + 4 * fg;
@@ -1186,17 +1190,19 @@ __device__ __forceinline__ void p8_store_direct(const GemmArgs& p, f32x4 (&acc)[
                     *reinterpret_cast<u32x4*>(C + grow * p.ldc + n0 + hn * 128 + wn * 32 + ccol) = outv;
                 if constexpr (STATS) {
                     // by-product statistics of the stored values: this wave's 32 columns of row `grow` sit in the four lanes
-                    // frow, frow + 16, + 32, + 48; two swaps fold them (x + x of the neighbouring lane row, then of the other half)
+                    // frow, frow + 16, + 32, + 48, which hold the chunks 0, 2, 1, 3 of 8 columns (ccol).  Two swaps fold them in the
+                    // library-wide order (c0 + c1) + (c2 + c3) (mlpk.h row_part): first the other half of the wave (lane ^ 32:
+                    // chunks 0 + 1 and 2 + 3), then the neighbouring lane row (lane ^ 16)
                     float s1 = 0.f, s2 = 0.f;
                     chunk_sums<T>(outv, s1, s2);
                     float sv[2] = {s1, s2};
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
                         const unsigned u = __builtin_bit_cast(unsigned, sv[k]);
-                        const auto q = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+                        const auto q = __builtin_amdgcn_permlane32_swap(u, u, false, false);
                         const float h = __builtin_bit_cast(float, (unsigned)q[0]) + __builtin_bit_cast(float, (unsigned)q[1]);
                         const unsigned uh = __builtin_bit_cast(unsigned, h);
-                        const auto r = __builtin_amdgcn_permlane32_swap(uh, uh, false, false);
+                        const auto r = __builtin_amdgcn_permlane16_swap(uh, uh, false, false);
                         sv[k] = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
                     }
                     if (fg == 0)
@@ -1944,7 +1950,9 @@ static int gemm_prepare(const mlpk_gemm_desc* d, GemmArgs& a, int& algo, bool& t
         //  * its pipeline spends one extra (draining) block per workgroup: only grids of several tiles per CU.
         static const int q4_mode = getenv("MLPK_GEMM_Q4") ? atoi(getenv("MLPK_GEMM_Q4")) : 1;
         Q4Call qc;
-        if (q4_mode && q4_call_of(a, d->dtype, trans, qc)) {
+        // (... and only when a generated kernel exists for the call's class AND its tuning bits: reserved bits meant for the persistent
+        //  tile, or a forced MLPK_Q4_NKF, must fall through to the other tiles instead of failing the call)
+        if (q4_mode && q4_call_of(a, d->dtype, trans, qc) && q4_variant_name(qc)) {
             const long long tiles = (long long)(d->M / 256) * (d->N / 128);
             bool take = false;
             if (!p8_ok) take = tiles >= 512;
@@ -1967,6 +1975,34 @@ static int gemm_prepare(const mlpk_gemm_desc* d, GemmArgs& a, int& algo, bool& t
     return 0;
 }
 
+extern "C" int mlpk_gemm_kernel_name(const mlpk_gemm_desc* d, char* buf, int len) {
+    if (!d || !buf || len <= 0) return MLPK_ENULL;
+    GemmArgs a;
+    int algo = 0;
+    bool trans = false;
+    const int rc = gemm_prepare(d, a, algo, trans);
+    if (rc) return rc;
+    const TileCfg& t = kTiles[algo - 1];
+    if (t.glds == 4) {
+        Q4Call qc;
+        const char* nm = q4_call_of(a, d->dtype, trans, qc) ? q4_variant_name(qc) : nullptr;
+        snprintf(buf, (size_t)len, "%s", nm ? nm : "q4 (no variant)");
+    } else if (t.glds == 3) {
+        // the persistent tile: which template runs follows from the plan of tile heights (launch_p8)
+        const bool staged = (a.dbg & 64) != 0 || (a.res_mode != MLPK_RES_NONE && (a.act == MLPK_ACT_GELU || a.ln_mean));
+        const P8Plan plan = p8_plan(a.M, a.N / 256, a.K / 64, p8_grid_cap(), !staged && !(a.dbg & 16));
+        const char* pe = getenv("MLPK_P8_PAIR");
+        const bool pair_on = !(pe && pe[0] == '0');
+        const bool pair = pair_on && !staged && plan.n >= 2 && ((plan.ni[0] == 4 && plan.ni[1] < 4) || (plan.ni[1] == 4 && plan.ni[0] < 4));
+        char hs[32] = "";
+        for (int s = 0, o = 0; s < plan.n && o < 28; ++s) o += snprintf(hs + o, sizeof(hs) - (size_t)o, "%s%d", s ? "+" : "", plan.ni[s] * 64);
+        snprintf(buf, (size_t)len, "%s<EPI=%d> rows %s", pair ? "gemm_nt_p8_pair_kernel" : "gemm_nt_p8_kernel", staged ? 0 : a.row_part ? 2 : 1, hs);
+    } else {
+        snprintf(buf, (size_t)len, "%s %dx%d", t.glds == 2 ? "gemm_nt_s3_kernel" : t.glds == 1 ? "gemm_nt_glds_kernel" : "gemm_nt_kernel", t.bm, t.bn);
+    }
+    return 0;
+}
+
 extern "C" int mlpk_gemm_row_parts(const mlpk_gemm_desc* d, int* nparts) {
     if (!d || !nparts) return MLPK_ENULL;
     mlpk_gemm_desc q = *d;
@@ -1978,8 +2014,8 @@ extern "C" int mlpk_gemm_row_parts(const mlpk_gemm_desc* d, int* nparts) {
     bool trans = false;
     const int rc = gemm_prepare(&q, a, algo, trans);
     if (rc) return rc;
-    const int width = kTiles[algo - 1].glds == 4 ? 64 : kTiles[algo - 1].glds == 3 ? 32 : 128;
-    *nparts = (d->N + width - 1) / width;
+    // (round 4: every tile writes planes of 32 columns, reduced in one order -- the answer no longer depends on the tile)
+    *nparts = (d->N + 31) / 32;
     return 0;
 }
 

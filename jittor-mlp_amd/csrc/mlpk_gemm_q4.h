@@ -27,6 +27,8 @@ struct Q4Call {
 };
 
 bool q4_supported(const Q4Call& c);
+// name of the generated kernel q4_launch would run for this call (nullptr: no variant for this class / its tuning bits)
+const char* q4_variant_name(const Q4Call& c);
 int q4_launch(const Q4Call& c, hipStream_t stream);
 
 }  // namespace mlpk

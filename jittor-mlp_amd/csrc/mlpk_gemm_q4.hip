@@ -89,11 +89,22 @@ static const Q4Variant* q4_pick(const Q4Call& c, int force_nkf) {
     return best;
 }
 
-int q4_launch(const Q4Call& c, hipStream_t stream) {
-    if (!q4_supported(c)) return MLPK_ESHAPE;
+static const Q4Variant* q4_variant(const Q4Call& c) {
     const int force_nkf = getenv("MLPK_Q4_NKF") ? atoi(getenv("MLPK_Q4_NKF")) : 0;       // tuning: unrolled (filler) iterations
     const Q4Variant* v = q4_pick(c, force_nkf);
     if (!v && force_nkf) v = q4_pick(c, 0);
+    return v;
+}
+
+const char* q4_variant_name(const Q4Call& c) {
+    if (!q4_supported(c)) return nullptr;
+    const Q4Variant* v = q4_variant(c);
+    return v ? v->name : nullptr;
+}
+
+int q4_launch(const Q4Call& c, hipStream_t stream) {
+    if (!q4_supported(c)) return MLPK_ESHAPE;
+    const Q4Variant* v = q4_variant(c);
     if (!v) return MLPK_ESHAPE;
     const int tiles_n = c.N / 128;
     const int cgroups = c.one_group ? 1 : q4_cgroups(tiles_n, c.K);

@@ -1042,7 +1042,7 @@ extern "C" int mlpk_convert(int src_dtype, int dst_dtype, const void* src, void*
     }
 }
 
-extern "C" int mlpk_abi_version(void) { return 7; }
+extern "C" int mlpk_abi_version(void) { return 8; }
 
 extern "C" const char* mlpk_strerror(int code) {
     switch (code) {

@@ -138,12 +138,13 @@ class KernelTimer:
 
     def __init__(self):
         self.events = {}          # tag -> list of (start, end, flops)
+        self.kernels = {}         # tag -> names of the kernels the dispatch chose for the timed calls (mlpk_gemm_kernel_name)
 
     def summary(self):
         out = {}
         for tag, evs in self.events.items():
             ms = [s.elapsed_time(e) for s, e, _ in evs]
-            out[tag] = {"launches": len(evs), "avg_ms": sum(ms) / len(ms), "flops_per_launch": evs[0][2]}
+            out[tag] = {"launches": len(evs), "avg_ms": sum(ms) / len(ms), "flops_per_launch": evs[0][2], "kernels": sorted(self.kernels.get(tag, ()))}
         return out
 
 
@@ -195,6 +196,10 @@ def gemm(A, B, C, M, Nn, K, *, lda=None, ldb=None, ldc=None, bias=None, act=N.AC
     if timed:
         ev1.record()
         TIMER.events.setdefault(tag, []).append((ev0, ev1, 2.0 * M * Nn * K))
+        if len(TIMER.kernels.setdefault(tag, set())) < 4:        # what actually ran, as the dispatch names it (a host-side query)
+            nm = ctypes.create_string_buffer(96)
+            if N.lib().mlpk_gemm_kernel_name(ctypes.byref(d), nm, 96) == 0:
+                TIMER.kernels[tag].add(nm.value.decode())
     return out
 
 
@@ -232,7 +237,8 @@ def token_mlp_ln(x, ldx, M, S, mean, rstd, gamma, beta, w1, b1, w2, b2, nchunks,
 
 def token_ln_fused():
     """MLPK_TOKEN_LN_FUSED=0: LayerNorm + transpose as its own pass in front of the token kernel (A/B aid)."""
-    return os.environ.get("MLPK_TOKEN_LN_FUSED", "1") != "0"
+    # (MLPK_T4_SHAPE=0 forces the generic token kernel, which has no LayerNorm loader: the unfused path then, not an error)
+    return os.environ.get("MLPK_TOKEN_LN_FUSED", "1") != "0" and os.environ.get("MLPK_T4_SHAPE", "") != "0"
 
 
 def layernorm_transpose_supported(dtype, C, ldx, ld_tt):

@@ -381,7 +381,7 @@ class AS_MLP(E.EngineModule):
         B, _, H, W = x.shape
         with E.on_device(x):
             pk = self._get_pack(x.dtype, x.device)
-            ws = self._get_space(("block", B, H, W), x.dtype, x.device)
+            ws = self._get_space(("block", B, H, W, C), x.dtype, x.device)     # (C: blocks of different stages can meet at one map size)
             cur = ws.get("l%d.x" % li, (B * H * W, C))
             cur.copy_(x.permute(0, 2, 3, 1).reshape(B * H * W, C))                     # channel-last rows, as the stages keep them
             cur = self._run_layers(ws, pk, cur, B, H, W, C, x.dtype, only=(li, bi))[0]

@@ -76,7 +76,7 @@ class ConvMixer(E.EngineModule):
         rows = B * H * W
         with E.on_device(x):
             pk = self._get_pack(x.dtype, x.device)
-            ws = self._get_space(("block", B, H, W), x.dtype, x.device)
+            ws = self._get_space(("block", B, H, W, dim), x.dtype, x.device)
             cur = ws.get("blk.x", (rows, dim))
             cur.copy_(x.permute(0, 2, 3, 1).reshape(rows, dim))                        # channel-last rows, as forward() keeps them
             tmp = ws.get("blk.y", (rows, dim))

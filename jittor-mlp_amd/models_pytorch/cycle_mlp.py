@@ -278,7 +278,7 @@ class CycleNet(E.EngineModule):
         B, H, W, _ = x.shape
         with E.on_device(x):
             pk = self._get_pack(x.dtype, x.device)
-            ws = self._get_space(("block", B, H, W), x.dtype, x.device)
+            ws = self._get_space(("block", B, H, W, C), x.dtype, x.device)     # (C: blocks of different stages can meet at one map size)
             cur = ws.get("blk.x", (B * H * W, C))
             cur.copy_(x.reshape(B * H * W, C))
             self._block(ws, pk, "n%d.b%d." % (si, bi), cur, B, H, W, C, blk.mlp.fc1.weight.shape[0], "n%d" % si)

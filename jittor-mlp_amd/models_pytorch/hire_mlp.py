@@ -204,7 +204,7 @@ class HireMLP(E.EngineModule):
         B, H, W, _ = x.shape
         with E.on_device(x):
             pk = self._get_pack(x.dtype, x.device)
-            ws = self._get_space(("block", B, H, W), x.dtype, x.device)
+            ws = self._get_space(("block", B, H, W, C), x.dtype, x.device)     # (C: blocks of different stages can meet at one map size)
             cur = ws.get("blk.x", (B * H * W, C))
             cur.copy_(x.reshape(B * H * W, C))
             self._block(ws, pk, li, bi, stage, cur, B, H, W, None)

@@ -122,7 +122,7 @@ class S2MLPv1(E.EngineModule):
             raise ValueError("stage %d works on %d channels" % (stage, self._d_model[stage]))
         with E.on_device(x):
             pk = self._get_pack(x.dtype, x.device)
-            ws = self._get_space(("block", B, H, W), x.dtype, x.device)
+            ws = self._get_space(("block", B, H, W, C), x.dtype, x.device)     # (C: blocks of different stages can meet at one map size)
             buf = ws.get("blk%d.x" % stage, (B * H * W, C))
             buf.copy_(x.reshape(B * H * W, C))
             self.stages[stage][1]._run_blocks(ws, pk, buf, B, H, W, "s%d." % stage, SHIFT_MODES[self.shift_mode], only=[index])

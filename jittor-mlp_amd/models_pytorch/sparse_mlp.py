@@ -191,7 +191,7 @@ class SparseMLP(E.EngineModule):
         rows = B * H * W
         with E.on_device(x):
             pk = self._get_pack(x.dtype, x.device)
-            ws = self._get_space(("block", B, H, W), x.dtype, x.device)
+            ws = self._get_space(("block", B, H, W, C), x.dtype, x.device)     # (C: blocks of different stages can meet at one map size)
             cur = ws.get("blk.x", (rows, C))
             cur.copy_(x.permute(0, 2, 3, 1).reshape(rows, C))                          # channel-last rows, as the stages keep them
             cur, _ = self._block(ws, pk, li, bi, stage, cur, ws.get("blk.tmp", (rows, C)), B)

@@ -232,7 +232,7 @@ class SwinMLP(E.EngineModule):
         B = x.shape[0]
         with E.on_device(x):
             pk = self._get_pack(x.dtype, x.device)
-            ws_ = self._get_space(("block", B, H, W), x.dtype, x.device)
+            ws_ = self._get_space(("block", B, H, W, C), x.dtype, x.device)     # (C: blocks of different stages can meet at one map size)
             cur = ws_.get("blk.x", (B * H * W, C))
             cur.copy_(x.reshape(B * H * W, C))
             self._block(ws_, pk, li, bi, blk, cur, B, H, W, C, None)

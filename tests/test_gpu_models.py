@@ -232,10 +232,10 @@ BS256 = [
 ]
 
 
-# no by-product statistics on their paths (or the same grouping at every batch size): batch-independent to the bit.  (The Mixers left
-# this set when their token LayerNorm moved into the token kernel: its row statistics now come out of the previous block's fc2
-# epilogue, summed over 32-, 64- or 128-column planes depending on the tile the batch size selects.)
-BIT_EQUAL = {"resmlp_24", "asmlp_t", "convmixer_1536_20"}
+# batch-independent to the bit.  Round 4: every tile of the library reduces its by-product LayerNorm statistics over planes of 32 columns in
+# ONE order (include/mlpk.h row_part), so the models whose LayerNorms read those statistics -- the Mixers since their token LayerNorm moved
+# into the token kernel -- are back in this set (round 3: sums over 32 / 64 / 128 columns "depending on the tile the batch size selects").
+BIT_EQUAL = {"resmlp_24", "asmlp_t", "convmixer_1536_20", "mixer_b16", "mixer_l16"}
 
 
 @pytest.mark.parametrize("name,ctor,kw,k,family", BS256)
@@ -247,9 +247,9 @@ def test_batch_256_rows_match_small_batch(name, ctor, kw, k, family):
     (eval mode), so rows [100, 100 + k) and the LAST k rows (the partial last round of the persistent kernels) of the
     bs = 256 forward must reproduce the same images run as a batch of k, and BOTH must meet the usual gate against the CPU oracle.
     Every tile computes a row's dot products in the same K order, so the rows are bit-equal (asserted for the models listed in
-    BIT_EQUAL) unless a LayerNorm statistic was summed in another grouping (by-product sums over 32 / 64 / 128 columns, per tile
-    choice): one flipped rounding then propagates through the depth like any other 16-bit rounding, and the two evaluations end up
-    one noise level apart -- asserted: within the gate of each other, reported: the actual difference.
+    BIT_EQUAL) unless something on the model's path still depends on the batch (a kernel choice with another summation order): one
+    flipped rounding then propagates through the depth like any other 16-bit rounding, and the two evaluations end up one noise
+    level apart -- asserted: within the gate of each other, reported: the actual difference.
     (Round 3: this test found mlpk_token_gemm multiplying the first token group of every tile after a workgroup's first by the
     wrong weights -- gMLP-S 5e-2 off at 256 images, correct at every golden batch size.)"""
     pkg = load_pkg()

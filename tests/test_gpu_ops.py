@@ -1191,8 +1191,8 @@ def test_gemm_byproduct_row_statistics(dtype, algo):
         part, nparts = got
         torch.cuda.synchronize()
         assert torch.equal(C.view(torch.int16), ref.view(torch.int16)), (M, Nn, K, algo)
-        width = 64 if algo == 15 else 128 if nparts == -(-Nn // 128) else 32
-        assert nparts == -(-Nn // width) and (width == 32 or algo != 14)
+        width = 32                     # every tile writes planes of 32 columns (round 4: one reduction order library-wide, mlpk.h row_part)
+        assert nparts == -(-Nn // width)
         c64 = C.double().cpu()
         p64 = part.double().cpu()
         assert not torch.isnan(p64).any()
@@ -1240,7 +1240,7 @@ def test_gemm_row_parts_refusals():
     d = N.GemmDesc()
     d.dtype, d.M, d.N, d.K, d.lda, d.ldb, d.ldc = N.BF16, 256, 128, 64, 64, 64, 128
     d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), C.data_ptr()
-    d.row_part, d.row_part_ld = sp.bufs["p.1"].data_ptr(), 255      # a plane shorter than M
+    d.row_part, d.row_part_ld = sp.bufs["p.4"].data_ptr(), 255      # (N = 128: four planes of 32 columns) a plane shorter than M
     assert N.lib().mlpk_gemm_nt(ctypes.byref(d), None) != 0
     d.row_part_ld, d.algo = 256, 14                                  # persistent tile without a residual: no statistics class
     assert N.lib().mlpk_gemm_nt(ctypes.byref(d), None) != 0
@@ -1309,3 +1309,37 @@ def test_gemm_q4_generated_tile(dtype):
                     v = v.to(dtype).double() + R.double()
                 err = (outs[0].double() - v).abs().max().item()
                 assert err < EPS[dtype] * 4 * max(1.0, v.abs().max().item()), (str(dtype), M, Nn, K, gelu, ln, res, err)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_byproduct_statistics_do_not_depend_on_the_tile(dtype):
+    """Round 4 (SURVEY.md section 4 tier 6: a sharded forward == the single forward on the concatenated batch, row for row): which tile
+    stores a row follows from the batch size, so the by-product LayerNorm statistics must not depend on the tile.  Every tile family
+    reduces planes of 32 columns in ONE order (mlpk.h row_part): the planes of the register-staged, direct-to-LDS, s3, persistent and
+    generated tiles are BIT-equal on the same product, and so are the finalized mean / rstd."""
+    pkg = load_pkg()
+    E, N = pkg.engine, pkg._native
+    for (M, Nn, K) in ((1024, 512, 256), (768, 768, 384), (2048, 256, 1152)):
+        A = rnd((M, K), dtype, 520).to(dev())
+        B = rnd((Nn, K), dtype, 521, 1.0 / math.sqrt(K)).to(dev())
+        bias = (rnd((Nn,), torch.float32, 522) + 0.5).to(dev())
+        R = (rnd((M, Nn), dtype, 523) * 3.0 + 1.0).to(dev())
+        ref = None
+        for algo in (13, 1, 3, 7, 11, 12, 14, 15, 0):
+            C = torch.full((M, Nn), float("nan"), dtype=dtype, device=dev())
+            sp = _Space()
+            got = E.gemm(A, B, C, M, Nn, K, bias=bias, R=R, res=N.RES_ADD, algo=algo, part=(sp, "p"))
+            assert got is not None, (M, Nn, K, algo)
+            part, nparts = got
+            mean = torch.empty((M,), dtype=torch.float32, device=dev())
+            rstd = torch.empty((M,), dtype=torch.float32, device=dev())
+            E.stats_finalize_planar(part, M, Nn, mean, rstd, eps=1e-5)
+            torch.cuda.synchronize()
+            assert nparts == Nn // 32
+            cur = (C.clone(), part.clone(), mean, rstd)
+            if ref is None:
+                ref = cur
+                continue
+            assert torch.equal(cur[0].view(torch.int16), ref[0].view(torch.int16)), (M, Nn, K, algo)
+            assert torch.equal(cur[1].view(torch.int32), ref[1].view(torch.int32)), (M, Nn, K, algo, int((cur[1] != ref[1]).sum()))
+            assert torch.equal(cur[2], ref[2]) and torch.equal(cur[3], ref[3]), (M, Nn, K, algo)

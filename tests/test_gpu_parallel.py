@@ -29,7 +29,9 @@ def _free_port():
 
 def _model_and_input(pkg, world, per_rank):
     torch.manual_seed(0)                                  # identical replicated weights on every rank
-    model = pkg.MLPMixerForImageClassification(d_model=256, depth=3, patch_size=16, image_size=224, num_classes=1000).eval().to("cuda:0")
+    # the benchmarked architecture itself (BASELINE configs[1], Mixer-B/16): fused token kernel with the LayerNorm loader, q4 / persistent
+    # GEMM tiles with by-product statistics -- the sharded forward must equal the single forward on the concatenated batch BIT FOR BIT
+    model = pkg.MLPMixerForImageClassification(d_model=768, depth=12, patch_size=16, image_size=224, num_classes=1000).eval().to("cuda:0")
     g = torch.Generator().manual_seed(11)
     x = torch.rand((world * per_rank, 3, 224, 224), generator=g).to("cuda:0").to(torch.bfloat16)
     return model, x
