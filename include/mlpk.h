@@ -26,6 +26,7 @@
  *   mlpk_token_mlp      both Conv1d(k=1) of the Mixer token-mixing FeedForward + GELU + residual in ONE kernel
  *                       (mlp_mixer.py:16-27,34,37), hidden activations never leave the CU
  *   mlpk_token_gemm     one token-mixing product with the transposed epilogue: gMLP SGU (g_mlp.py:17-22), ResMLP cross-patch (res_mlp.py:52-55)
+ *   mlpk_token_gemm_ln  the same with the LayerNorm / Aff in front of it (g_mlp.py:19; res_mlp.py:17-19,53) as the kernel's operand loader
  *   mlpk_patchify       the im2col half of nn.Conv2d(k=stride=patch): mlp_mixer.py:58-60,68-71;
  *                       conv_mixer.py:18; s2_mlp_v2.py:119; as_mlp.py:319,330; PatchMerging as_mlp.py:207-211
  *   mlpk_row_stats      statistics of nn.LayerNorm (mlp_mixer.py:10) and nn.GroupNorm(1,C) (as_mlp.py:343-344)
@@ -215,6 +216,17 @@ int mlpk_token_mlp_ln(int dtype, void* x, int ldx, int M, int S, const float* ln
 int mlpk_token_gemm(int dtype, const void* xt, int ldxt, int M, int S, const void* w, int ldw, const float* bias, int ngroups,
                     const float* rscale, int rperiod, const void* R, int ldr, int res_mode, void* out, int ldo, int t_rows,
                     void* stream);
+/* ABI 8.  The same product with its operand built on the fly: xt[b*t_rows + c, s] = (x[b*S + s, c] - mean[b*S + s]) * rstd[b*S + s] *
+ * gamma[c] + beta[c] (rounded to the storage type once) -- the LayerNorm of gMLP's spatial gating unit (g_mlp.py:19) or, with mean /
+ * rstd NULL (0 / 1), ResMLP's Aff (res_mlp.py:17-19) -- read straight from the token-major x (B*S rows of stride ldx; the pointer
+ * addresses channel 0 of the t_rows channels, so a column slice of a wider tensor is fine) and transposed through LDS inside the
+ * kernel: no xt tensor, no normalise-and-transpose pass.  t_rows % 32 == 0, S <= 224; everything else as mlpk_token_gemm.
+ * With res_mode ADD, no statistics and R == x the residual is the affine output itself, R = round(gamma x + beta) rebuilt in the kernel
+ * (res_mlp.py:53-55 adds the cross-patch product onto the POST-affine tensor); out may be x (every element is read by the workgroup that
+ * writes it, before it is written). */
+int mlpk_token_gemm_ln(int dtype, const void* x, int ldx, int M, int S, const float* ln_mean, const float* ln_rstd, const float* gamma,
+                       const float* beta, const void* w, int ldw, const float* bias, int ngroups, const float* rscale, int rperiod,
+                       const void* R, int ldr, int res_mode, void* out, int ldo, int t_rows, void* stream);
 /* mlpk_token_mlp's `stats` (optional, t_rows % 128 == 0): the statistics of the LayerNorm that follows (mlp_mixer.py:38) come out of the epilogue:
  * stats[(tile*B*S + b*S + s)*2 + {0,1}] = sum / sum of squares over the tile's 128 channels of the values written to x[b,s,:]
  * (planar: t_rows/128 planes of B*S pairs, B = M / t_rows).  mlpk_stats_finalize_planar(stats, B*S, t_rows/128, B*S, 1, t_rows, ..)

@@ -375,7 +375,14 @@ class Emu:
 
     # ---- SALU
     def x_s_mov_b32(self, w, i):
-        self.wrs(w, i.args[0], self.rds(w, i.args[1]))
+        d = i.args[0]
+        if d in ("exec_lo", "exec_hi"):
+            val = self.rds(w, i.args[1])
+            lo = 0 if d == "exec_lo" else 32
+            for k in range(32):
+                w.exec[lo + k] = bool((val >> k) & 1)
+            return
+        self.wrs(w, d, self.rds(w, i.args[1]))
 
     def x_s_mov_b64(self, w, i):
         d, s = i.args

@@ -108,7 +108,9 @@ class Q4:
 
     # ------------------------------------------------------------------ registers
     def regs(self):
-        s = Alloc("s", 33, 96)          # (s32 is the ABI stack pointer: hipcc warns when an asm block clobbers it)
+        s = Alloc("s", 33, 96)          # (s32 is the ABI stack pointer: hipcc warns when an asm block clobbers it; s96..s101 stay free for the
+                                        #  asm block's scalar inputs and the wrapper's own needs -- with fewer "inline assembly requires more
+                                        #  registers than available"; s102.. are flat_scratch / xnack / vcc)
         v = Alloc("v", 1, 248)
         self.s_karg, self.s_bid, self.v_tid = S(0, 2), S(2), V(0)
         self.p = {k: S(4 + 2 * i, 2) for i, k in enumerate(["A", "B", "C", "R", "bias", "ln_mean", "ln_rstd", "ln_csum"])}
@@ -137,11 +139,11 @@ class Q4:
         if self.stats:
             self.s_part, self.s_partld = s("part", 2, 2), s("partld")
             self.s_eP = s("eP", 2, 2)
-            self.s_mask8 = s("mask8", 2, 2)
-        self.s_r2 = s("r2")
         self.sig = self.gelu and GELU_FORM[self.dtype] == "sig"
+        self.s_r2 = s("r2") if (self.gelu and not self.sig and not GELU_RAW[self.dtype]) else None      # sqrt 2: the centred polynomial's clamp
         self.s_k0, self.s_k1 = (s("gk0"), s("gk1")) if self.sig else (None, None)
-        self.s_prof0, self.s_prof1, self.s_profp, self.s_ntiles = s("prof0", 2, 2), s("prof1", 2, 2), s("profp", 2, 2), s("ntiles")
+        # (prof1 = the end stamp, taken after the last block: it lives in the next-tile DMA base, which is dead by then)
+        self.s_prof0, self.s_prof1, self.s_profp, self.s_ntiles = s("prof0", 2, 2), self.s_dAn, s("profp", 2, 2), s("ntiles")
         self.s_t = [s("t%d" % i) for i in range(6)]
         # vector registers
         self.FA = [[v("FA%d_%d" % (b, i), 4, 4) for i in range(4)] for b in range(2)]
@@ -455,7 +457,7 @@ class Q4:
                     E("v_add_f32_dpp", sp[0], sp[0], sp[0], **mod, row_mask="0xf", bank_mask="0xf")
                     E("v_add_f32_dpp", sp[1], sp[1], sp[1], **mod, row_mask="0xf", bank_mask="0xf")
                 # two pairs per row: the lanes with (lane & 3) == 0
-                ops.append(lambda k=k, i=i: (a("s_mov_b64", "exec", self.s_mask8),
+                ops.append(lambda k=k, i=i: (a("s_mov_b32", "exec_lo", 0x11111111), a("s_mov_b32", "exec_hi", 0x11111111),
                                              a("global_store_dwordx2", self.voffP[k], sp, self.s_eP, offset=i * 256),
                                              a("s_mov_b64", "exec", -1)) and None)
             if self.stores_on:
@@ -685,7 +687,8 @@ class Q4:
         a("v_bfe_u32", x, lane, 4, 1)
         a("v_xor_b32", x, x, l7)                   # read swizzle (lane & 7) ^ ((lane >> 4) & 1)
         a("v_xor_b32", x, x, h)                    # ^ k-half of the lane
-        a("s_mov_b32", self.s_r2, F(SQRT2))
+        if self.s_r2 is not None:
+            a("s_mov_b32", self.s_r2, F(SQRT2))
         if self.sig:
             gk = GELU_SIG[self.dtype]
             a("v_mov_b32", self.v_c0, F(gk[2]))
@@ -765,8 +768,6 @@ class Q4:
                 a("v_add_u32", lane, lane, vt[7])
                 a("v_lshlrev_b32", self.voffP[kk], 3, lane)
             a("v_mov_b32", self.v_ones, 0x3F803F80 if self.dtype == "bf16" else 0x3C003C00)
-            a("s_mov_b32", self.s_mask8[0], 0x11111111)
-            a("s_mov_b32", self.s_mask8[1], 0x11111111)
         # LDS staging tile of this wave: OUT_OFF + wave * 4096; write: row l31, chunk c ^ (l31 & 7), half h; read: row l3, chunk l7 ^ l3
         a("s_lshl_b32", t[0], self.s_wave, 12)
         a("s_add_u32", t[0], t[0], OUT_OFF)
@@ -944,7 +945,10 @@ class Q4:
 # variant table: (class name, gelu, ln, res, unrolled iterations)
 # (gelu, ln, res, stats)
 CLASSES = {"p": (False, False, False, False), "l": (False, True, False, False), "g": (True, False, False, False), "gl": (True, True, False, False),
-           "r": (False, False, True, False), "rs": (False, False, True, True)}
+           "r": (False, False, True, False), "rs": (False, False, True, True),
+           # round 4: GELU + folded LayerNorm WITH the by-product statistics of what it stores -- the v half of gMLP's channel_proj1, whose
+           # LayerNorm (g_mlp.py:19) is then the spatial product's operand loader (mlpk_token_gemm_ln) without a statistics pass
+           "gls": (True, True, False, True)}
 NKF = {c: (3, 4, 6, 12) for c in CLASSES}
 NK_STATIC = (6, 12, 18)          # K = 384 / 768 / 1152: the kernels built for one K (Q4.static)
 DTYPES = ("bf16", "f16")

@@ -19,6 +19,7 @@
 //     A panel and the weight panels are re-used out of that XCD's private L2.
 #include "mlpk_common.h"
 #include "mlpk_gemm_q4.h"
+#include "mlpk_gemm_skinny.h"
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -1534,6 +1535,7 @@ static const TileCfg kTiles[] = {
     {256, 256, 2, 4, 3},   // algo 14: "p8" ping-pong pipeline (8 waves, 128 KiB LDS, 1 workgroup / CU; K % slab == 0, K >= 2 slabs)
     {256, 128, 2, 2, 4},   // algo 15: "q4" generated kernels (mlpk_gemm_q4.hip): 4 waves = one per SIMD, 144 KiB LDS, epilogue of tile
                            //          T - 1 issued behind the MFMAs of tile T
+    {8, 64, 4, 1, 5},      // algo 16: skinny fp32 kernel (mlpk_gemm_skinny.hip): no MFMA, the whole chip on a product of a few hundred MFLOP
 };
 static const int kNumTiles = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
 
@@ -1763,6 +1765,15 @@ template <typename T> static int launch_p8(const GemmArgs& a0, bool trans, hipSt
     }
 }
 
+// the call as the skinny fp32 kernel takes it (bias, GELU, row-major, nothing else)
+static bool skinny_call_of(const GemmArgs& a, int dtype, bool trans, SkinnyCall& c) {
+    if (dtype != MLPK_F32 || trans || a.rscale || a.cscale || a.cshift || a.ln_mean || a.res_mode != MLPK_RES_NONE || a.row_part) return false;
+    c.M = a.M; c.N = a.N; c.K = a.K; c.lda = a.lda; c.ldb = a.ldb; c.ldc = a.ldc;
+    c.A = reinterpret_cast<const float*>(a.A); c.B = reinterpret_cast<const float*>(a.B); c.C = reinterpret_cast<float*>(a.C);
+    c.bias = a.bias; c.gelu = a.act == MLPK_ACT_GELU;
+    return skinny_supported(c);
+}
+
 // the call as the generated q4 kernels take it; false when they do not implement it (other tiles do)
 static bool q4_call_of(const GemmArgs& a, int dtype, bool trans, Q4Call& c) {
     if (dtype == MLPK_F32 || trans || a.rscale || a.cscale || a.cshift) return false;
@@ -1802,6 +1813,11 @@ template <typename T> static int launch_algo(int algo, const GemmArgs& a, bool t
             if (!q4_call_of(a, dtype_of<T>::value, trans, c)) return MLPK_ESHAPE;
             return q4_launch(c, s);
         }
+        case 16: {
+            SkinnyCall c;
+            if (!skinny_call_of(a, dtype_of<T>::value, trans, c)) return MLPK_ESHAPE;
+            return skinny_launch(c, s);
+        }
         default: return MLPK_EMODE;
     }
 }
@@ -1817,7 +1833,7 @@ static int auto_algo(int M, int N, int K, int epc, bool glds_ok, bool p8_ok, boo
         const TileCfg& t = kTiles[i];
         const int area = t.bm * t.bn;
         if (stats && t.bn < 128) continue;        // the by-product row statistics reduce over whole 16-lane rows = 128 columns
-        if (t.glds == 4) continue;                // the generated tile is chosen in gemm_prepare (q4_prefer), not by this cost model
+        if (t.glds >= 4) continue;                // the generated tile / the skinny kernel are chosen in gemm_prepare, not by this cost model
         if (t.glds == 3) {
             // persistent ping-pong tile: whole launch rounds of one tile per CU, tile heights mixed to fill them (p8_plan);
             // its per-tile fixed cost (first slabs + epilogue, not overlapped with another workgroup) weighs more the
@@ -1869,7 +1885,7 @@ extern "C" int mlpk_gemm_algo_info(int algo, int* bm, int* bn, int* threads, int
     if (bm) *bm = t.bm;
     if (bn) *bn = t.bn;
     if (threads) *threads = t.wm * t.wn * 64;
-    if (lds_bytes) *lds_bytes = t.glds == 4 ? Q4_LDS_BYTES : t.glds == 3 ? P8_LDS_BYTES : t.glds == 2 ? 3 * (t.bm + t.bn) * 64 : 2 * (t.bm + t.bn) * 128;
+    if (lds_bytes) *lds_bytes = t.glds == 5 ? 6144 : t.glds == 4 ? Q4_LDS_BYTES : t.glds == 3 ? P8_LDS_BYTES : t.glds == 2 ? 3 * (t.bm + t.bn) * 64 : 2 * (t.bm + t.bn) * 128;
     return 0;
 }
 
@@ -1961,6 +1977,18 @@ static int gemm_prepare(const mlpk_gemm_desc* d, GemmArgs& a, int& algo, bool& t
             if (q4_mode >= 2 || take) algo = 15;
         }
     }
+    if (algo == 0 && d->dtype == MLPK_F32) {
+        // round 4: the small fp32 products of the SplitAttention / re-weighting MLPs (M = batch rows, K <= 1536) CAN run on the skinny
+        // kernel (algo 16) -- built because the MFMA tiles run them on <= 72 workgroups with a serial K loop (15-24 us each).  Measured
+        // (profiles/r04_skinny_ab.txt): S2-MLPv2 8.76 -> 8.74 ms, CycleMLP-B1 unchanged (these products are launch-latency bound either
+        // way), ViP-S7 30.1 -> 30.6 ms WORSE: its chain runs on a side stream beside a persistent GEMM, and a grid of 1024 small
+        // workgroups sits on every CU the persistent kernel's workgroups (all of a CU's LDS and registers each) are waiting for, where
+        // the 64 x 64 tile's 24-128 workgroups hold up only that many.  So it is opt-in (MLPK_GEMM_SKINNY=1), not the default.  The rule
+        // uses N and K only: which kernel computes a row must not depend on the batch
+        static const bool sk_on = getenv("MLPK_GEMM_SKINNY") && atoi(getenv("MLPK_GEMM_SKINNY")) == 1;
+        SkinnyCall sc;
+        if (sk_on && (long long)d->N * d->K <= (1ll << 21) && d->K <= 2048 && d->M <= 16384 && skinny_call_of(a, d->dtype, trans, sc)) algo = 16;
+    }
     if (algo == 0) algo = auto_algo(d->M, d->N, d->K, epc, glds_ok, p8_ok, stats);
     if (algo < 1 || algo > kNumTiles) return MLPK_EMODE;
     if (kTiles[algo - 1].glds && !glds_ok) return MLPK_ESHAPE;
@@ -1997,6 +2025,8 @@ extern "C" int mlpk_gemm_kernel_name(const mlpk_gemm_desc* d, char* buf, int len
         char hs[32] = "";
         for (int s = 0, o = 0; s < plan.n && o < 28; ++s) o += snprintf(hs + o, sizeof(hs) - (size_t)o, "%s%d", s ? "+" : "", plan.ni[s] * 64);
         snprintf(buf, (size_t)len, "%s<EPI=%d> rows %s", pair ? "gemm_nt_p8_pair_kernel" : "gemm_nt_p8_kernel", staged ? 0 : a.row_part ? 2 : 1, hs);
+    } else if (t.glds == 5) {
+        snprintf(buf, (size_t)len, "gemm_skinny_f32_kernel");
     } else {
         snprintf(buf, (size_t)len, "%s %dx%d", t.glds == 2 ? "gemm_nt_s3_kernel" : t.glds == 1 ? "gemm_nt_glds_kernel" : "gemm_nt_kernel", t.bm, t.bn);
     }

@@ -59,7 +59,8 @@ bool q4_supported(const Q4Call& c) {
     if (c.M % 256 || c.N % 128 || c.K % 64 || c.K < 192) return false;
     if (!c.bias) return false;
     if (c.res && (c.gelu || c.ln)) return false;
-    if (c.row_part && (!c.res || c.row_part_ld < c.M || (reinterpret_cast<uintptr_t>(c.row_part) & 7))) return false;     // statistics: the bias + residual class
+    // statistics: the bias + residual class, and GELU + folded LayerNorm (q4_variant_name says whether a kernel exists)
+    if (c.row_part && (!(c.res || (c.gelu && c.ln)) || c.row_part_ld < c.M || (reinterpret_cast<uintptr_t>(c.row_part) & 7))) return false;
     if (c.lda % 8 || c.ldb % 8 || c.ldc % 8 || (c.res && c.ldr % 8)) return false;
     const uintptr_t al = reinterpret_cast<uintptr_t>(c.A) | reinterpret_cast<uintptr_t>(c.B) | reinterpret_cast<uintptr_t>(c.C) |
                          reinterpret_cast<uintptr_t>(c.R) | reinterpret_cast<uintptr_t>(c.bias) | reinterpret_cast<uintptr_t>(c.ln_csum);

@@ -835,6 +835,15 @@ constexpr int T3_R1 = 0;                               // W ring: 2 stages x 16 
 constexpr int T3_STG = 2 * TM_STAGE;                   // staging: 2 x 32 KiB
 constexpr int T3_B = T3_STG + 2 * 32768;
 constexpr int T3_LDS = T3_B + 256 * 4;
+// Round 4 -- the LayerNorm / affine in front of the product as this kernel's OPERAND LOADER (LNL = 1; mlpk_token_gemm_ln): instead of
+// a pass that writes LN(x) token-transposed (gMLP's SGU: mlpk_layernorm_transpose, 72 us and 308 MB per layer at 256 images, 17 % of
+// the model; ResMLP's Aff: the transposed half of mlpk_norm_apply) and this kernel reading it back, every wave reads ITS 32 channels
+// of the token-major rows of x itself (64-byte pieces of full lines), normalises them in fp32 -- (x rstd - mean rstd) gamma + beta,
+// the token kernel's expression (csrc/gen/t4gen.py) -- rounds once, and transposes through a per-wave LDS tile
+// [32 channels][16 token pairs] (80-byte pitch) into the A fragments it keeps in registers for the whole tile.
+constexpr int T3_XT = T3_LDS;                          // 8 waves x 32 channels x 80 B
+constexpr int T3_XT_PITCH = 80;
+constexpr int T3_LDS_LN = T3_XT + 8 * 32 * T3_XT_PITCH;
 
 struct TokenGemmArgs {
     const void* xt;     // (M, ldxt) token-transposed operand, K-padded with zeros
@@ -845,9 +854,16 @@ struct TokenGemmArgs {
     void* out;          // (B*S, ldo)
     int M, S, ks1, G;
     int ldxt, ldr, ldo, t_rows, rperiod, res_mode;
+    // LNL: the operand is LN(x) / Aff(x) of the token-major x (B*S, ldx), channels [0, t_rows) of the rows the pointer addresses
+    const void* x;
+    const float* ln_mean;   // per token row (B*S), or NULL (affine only: mean 0, rstd 1)
+    const float* ln_rstd;
+    const float* gamma;     // per channel (t_rows)
+    const float* beta;
+    int ldx;
 };
 
-template <typename T, int RES>
+template <typename T, int RES, int LNL = 0>
 __global__ void __launch_bounds__(512, 1) token_gemm_kernel(const TokenGemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -888,13 +904,76 @@ __global__ void __launch_bounds__(512, 1) token_gemm_kernel(const TokenGemmArgs 
     u32x4 xa[2][TM_KMAX];
     auto load_x = [&](const int tile, const int ln) {
         const int frow = ln & 15, fg = ln >> 4;
+        if constexpr (LNL) {
+            // this wave's 32 rows of the transposed operand = channels c0 .. c0 + 31 of image b (32 | t_rows: one image per wave)
+            int m0w = tile * T3_BM + wave * 32;
+            m0w = m0w < p.M ? m0w : p.M - 32;
+            const int b = m0w / p.t_rows;
+            const int c0 = m0w - b * p.t_rows;
+            const int pr = ln >> 2, q = ln & 3;                 // token pair of the k-step, octet of channels
+            const T* xr = reinterpret_cast<const T*>(p.x) + (size_t)b * p.S * p.ldx + c0 + q * 8;
+            float ga[8], be[8];
+            {
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gamma + c0 + q * 8), g1 = *reinterpret_cast<const f32x4*>(p.gamma + c0 + q * 8 + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.beta + c0 + q * 8), b1 = *reinterpret_cast<const f32x4*>(p.beta + c0 + q * 8 + 4);
+                ga[0] = g0.x; ga[1] = g0.y; ga[2] = g0.z; ga[3] = g0.w; ga[4] = g1.x; ga[5] = g1.y; ga[6] = g1.z; ga[7] = g1.w;
+                be[0] = b0.x; be[1] = b0.y; be[2] = b0.z; be[3] = b0.w; be[4] = b1.x; be[5] = b1.y; be[6] = b1.z; be[7] = b1.w;
+            }
+            char* const xt_w = smem + T3_XT + wave * (32 * T3_XT_PITCH);
+            // loads one k-step ahead of the arithmetic
+            u32x4 raw[2][2];
+            float mu[2][2], rs[2][2];
+            auto request = [&](const int kk, const int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int gm = tile * T3_BM + wave * 32 + i * 16 + frow;
-            gm = gm < p.M ? gm : p.M - 1;
+                for (int h = 0; h < 2; ++h) {
+                    int sidx = kk * 32 + pr * 2 + h;
+                    sidx = sidx < p.S ? sidx : p.S - 1;           // (tokens past S: valid memory, zeroed below)
+                    raw[buf][h] = *reinterpret_cast<const u32x4*>(xr + (size_t)sidx * p.ldx);
+                    mu[buf][h] = p.ln_mean ? p.ln_mean[(size_t)b * p.S + sidx] : 0.f;
+                    rs[buf][h] = p.ln_mean ? p.ln_rstd[(size_t)b * p.S + sidx] : 1.f;
+                }
+            };
+            request(0, 0);
 #pragma unroll
-            for (int kk = 0; kk < TM_KMAX; ++kk)
-                xa[i][kk] = *reinterpret_cast<const u32x4*>(xt + (size_t)gm * p.ldxt + (kk < ks1 ? kk : ks1 - 1) * 32 + fg * 8);
+            for (int kk = 0; kk < TM_KMAX; ++kk) {
+                if (kk + 1 < TM_KMAX) request(kk + 1 < ks1 ? kk + 1 : ks1 - 1, (kk + 1) & 1);
+                const int buf = kk & 1;
+                float y[2][8];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    T e8[8];
+                    __builtin_memcpy(e8, &raw[buf][h], 16);
+                    const bool live = kk < ks1 && kk * 32 + pr * 2 + h < p.S;
+                    const float nm = -mu[buf][h] * rs[buf][h];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float v = __builtin_fmaf(__builtin_fmaf(to_f32(e8[e]), rs[buf][h], nm), ga[e], be[e]);
+                        y[h][e] = live ? v : 0.f;
+                    }
+                }
+                // word (channel 8 q + e, token pair pr) = (token 2 pr, token 2 pr + 1)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    T pk2[2] = {from_f32<T>(y[0][e]), from_f32<T>(y[1][e])};
+                    unsigned wv;
+                    __builtin_memcpy(&wv, pk2, 4);
+                    *reinterpret_cast<unsigned*>(xt_w + (q * 8 + e) * T3_XT_PITCH + pr * 4) = wv;
+                }
+                __builtin_amdgcn_wave_barrier();                // (scheduling only: the reads below stay behind the writes)
+                // (LDS executes a wave's operations in order: no wait between the writes and the reads, nor before the next k-step's writes)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) xa[i][kk] = *reinterpret_cast<const u32x4*>(xt_w + (i * 16 + frow) * T3_XT_PITCH + fg * 16);
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int gm = tile * T3_BM + wave * 32 + i * 16 + frow;
+                gm = gm < p.M ? gm : p.M - 1;
+#pragma unroll
+                for (int kk = 0; kk < TM_KMAX; ++kk)
+                    xa[i][kk] = *reinterpret_cast<const u32x4*>(xt + (size_t)gm * p.ldxt + (kk < ks1 ? kk : ks1 - 1) * 32 + fg * 8);
+            }
         }
     };
     load_x(blockIdx.x, lane_now());
@@ -922,6 +1001,13 @@ __global__ void __launch_bounds__(512, 1) token_gemm_kernel(const TokenGemmArgs 
 #pragma unroll
             for (int e = 0; e < 8; ++e) rsc[e] = p.rscale[(mr + e) % p.rperiod];
         }
+        // LNL == 2: the residual is the affine output itself, R = round(gamma x + beta) (res_mlp.py:53-55: x + gamma_1 token_mix(x) on the
+        // POST-affine tensor), rebuilt from x for the reader item's 8 channels -- no Aff pass, no x1 tensor
+        float rga[LNL == 2 ? 8 : 1], rbe[LNL == 2 ? 8 : 1];
+        if constexpr (LNL == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { rga[e] = row_ok ? p.gamma[rcc + e] : 0.f; rbe[e] = row_ok ? p.beta[rcc + e] : 0.f; }
+        }
         f32x4 acc[2][2];
         u32x4 rv[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
         auto request_r = [&](const int g) {                // R values of group g's reader items (used one iteration later)
@@ -929,7 +1015,11 @@ __global__ void __launch_bounds__(512, 1) token_gemm_kernel(const TokenGemmArgs 
             for (int k = 0; k < 2; ++k) {
                 const int t = g * 32 + rt + 16 * k;
                 rv[k] = u32x4{0u, 0u, 0u, 0u};
-                if (RES != MLPK_RES_NONE && t < p.S && row_ok) rv[k] = *reinterpret_cast<const u32x4*>(Rp + ((size_t)rimg * p.S + t) * p.ldr + rcc);
+                if constexpr (LNL == 2) {
+                    if (t < p.S && row_ok) rv[k] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.x) + ((size_t)rimg * p.S + t) * p.ldx + rcc);
+                } else {
+                    if (RES != MLPK_RES_NONE && t < p.S && row_ok) rv[k] = *reinterpret_cast<const u32x4*>(Rp + ((size_t)rimg * p.S + t) * p.ldr + rcc);
+                }
             }
         };
         // Order inside an iteration: (1) group g - 1 leaves (its R values were requested an iteration ago), (2) W group g + 1 and
@@ -956,7 +1046,8 @@ __global__ void __launch_bounds__(512, 1) token_gemm_kernel(const TokenGemmArgs 
 #pragma unroll
                         for (int q = 0; q < 8; ++q) {
                             float y = v[q] * rsc[q];
-                            if constexpr (RES == MLPK_RES_ADD) y += to_f32(r8[q]);
+                            if constexpr (LNL == 2) y += to_f32(from_f32<T>(__builtin_fmaf(to_f32(r8[q]), rga[q], rbe[q])));
+                            else if constexpr (RES == MLPK_RES_ADD) y += to_f32(r8[q]);
                             else if constexpr (RES == MLPK_RES_MUL) y *= to_f32(r8[q]);
                             e[q] = from_f32<T>(y);
                         }
@@ -1135,6 +1226,30 @@ extern "C" int mlpk_token_mlp_ln(int dtype, void* x, int ldx, int M, int S, cons
     return t4_launch(c, reinterpret_cast<hipStream_t>(stream));
 }
 
+static int token_gemm_launch(int dtype, TokenGemmArgs& a, int res_mode, int lnl, hipStream_t s) {
+    const int tiles = (a.M + T3_BM - 1) / T3_BM;
+    const unsigned grid = (unsigned)(tiles < tm_grid_cap() ? tiles : tm_grid_cap());
+#define TG_LAUNCH(TT, RR, LL)                                                                                          \
+    {                                                                                                                   \
+        auto k = token_gemm_kernel<TT, RR, LL>;                                                                         \
+        const int lds = LL ? T3_LDS_LN : T3_LDS;                                                                        \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        if (e != hipSuccess) return (int)e;                                                                             \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, a);                                                        \
+    }
+#define TG_RES(TT, LL)                                                                                                 \
+    if (res_mode == MLPK_RES_ADD) TG_LAUNCH(TT, MLPK_RES_ADD, LL) else if (res_mode == MLPK_RES_MUL) TG_LAUNCH(TT, MLPK_RES_MUL, LL) else TG_LAUNCH(TT, MLPK_RES_NONE, LL)
+    if (dtype == MLPK_BF16) {
+        if (lnl == 2) TG_LAUNCH(bf16_t, MLPK_RES_ADD, 2) else if (lnl) { TG_RES(bf16_t, 1) } else { TG_RES(bf16_t, 0) }
+    } else {
+        if (lnl == 2) TG_LAUNCH(f16_t, MLPK_RES_ADD, 2) else if (lnl) { TG_RES(f16_t, 1) } else { TG_RES(f16_t, 0) }
+    }
+#undef TG_RES
+#undef TG_LAUNCH
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int mlpk_token_gemm(int dtype, const void* xt, int ldxt, int M, int S, const void* w, int ldw, const float* bias, int ngroups,
                                const float* rscale, int rperiod, const void* R, int ldr, int res_mode, void* out, int ldo, int t_rows,
                                void* stream) {
@@ -1153,22 +1268,32 @@ extern "C" int mlpk_token_gemm(int dtype, const void* xt, int ldxt, int M, int S
     a.xt = xt; a.w = w; a.bias = bias; a.rscale = rscale; a.R = R; a.out = out;
     a.M = M; a.S = S; a.ks1 = ldxt / 32; a.G = ngroups;
     a.ldxt = ldxt; a.ldr = ldr; a.ldo = ldo; a.t_rows = t_rows; a.rperiod = rperiod > 0 ? rperiod : 1; a.res_mode = res_mode;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int tiles = (M + T3_BM - 1) / T3_BM;
-    const unsigned grid = (unsigned)(tiles < tm_grid_cap() ? tiles : tm_grid_cap());
-#define TG_LAUNCH(TT, RR)                                                                                              \
-    {                                                                                                                   \
-        auto k = token_gemm_kernel<TT, RR>;                                                                             \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, T3_LDS); \
-        if (e != hipSuccess) return (int)e;                                                                             \
-        hipLaunchKernelGGL(k, dim3(grid), dim3(512), T3_LDS, s, a);                                                     \
-    }
-    if (dtype == MLPK_BF16) {
-        if (res_mode == MLPK_RES_ADD) TG_LAUNCH(bf16_t, MLPK_RES_ADD) else if (res_mode == MLPK_RES_MUL) TG_LAUNCH(bf16_t, MLPK_RES_MUL) else TG_LAUNCH(bf16_t, MLPK_RES_NONE)
-    } else {
-        if (res_mode == MLPK_RES_ADD) TG_LAUNCH(f16_t, MLPK_RES_ADD) else if (res_mode == MLPK_RES_MUL) TG_LAUNCH(f16_t, MLPK_RES_MUL) else TG_LAUNCH(f16_t, MLPK_RES_NONE)
-    }
-#undef TG_LAUNCH
-    MLPK_LAUNCH_CHECK();
-    return 0;
+    a.x = nullptr; a.ln_mean = a.ln_rstd = a.gamma = a.beta = nullptr; a.ldx = 0;
+    return token_gemm_launch(dtype, a, res_mode, 0, reinterpret_cast<hipStream_t>(stream));
+}
+
+// mlpk_token_gemm with the LayerNorm / affine of its operand inside (mlpk.h): x token-major, no xt tensor
+extern "C" int mlpk_token_gemm_ln(int dtype, const void* x, int ldx, int M, int S, const float* ln_mean, const float* ln_rstd, const float* gamma,
+                                  const float* beta, const void* w, int ldw, const float* bias, int ngroups, const float* rscale, int rperiod,
+                                  const void* R, int ldr, int res_mode, void* out, int ldo, int t_rows, void* stream) {
+    if (!x || !w || !out || !gamma || !beta) return MLPK_ENULL;
+    if ((ln_mean != nullptr) != (ln_rstd != nullptr)) return MLPK_ENULL;
+    if (dtype != MLPK_F16 && dtype != MLPK_BF16) return MLPK_EDTYPE;
+    if (M <= 0 || S <= 0 || ngroups <= 0 || t_rows <= 0) return MLPK_ESHAPE;
+    if (res_mode < MLPK_RES_NONE || res_mode > MLPK_RES_MUL) return MLPK_EMODE;
+    // R == x with res_mode ADD: the residual is the affine output itself, rebuilt in the kernel (no statistics: ResMLP's Aff)
+    const bool raff = res_mode == MLPK_RES_ADD && R == x && !ln_mean;
+    if (res_mode != MLPK_RES_NONE && !R) return MLPK_ENULL;
+    if (rscale && rperiod <= 0) return MLPK_ESHAPE;
+    if (ngroups * 32 < S || ngroups > 8 || S > 32 * TM_KMAX) return MLPK_ESHAPE;
+    if (ldw != 256) return MLPK_ESHAPE;
+    // a wave owns 32 channels of ONE image; x rows in 16-byte pieces
+    if (t_rows % 32 || M % t_rows || ldx % 8 || ldx < t_rows || ldo % 8 || ldo < t_rows || (R && (ldr % 8 || ldr < t_rows))) return MLPK_ESHAPE;
+    if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)out & 15) || ((uintptr_t)R & 15) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15)) return MLPK_EALIGN;
+    TokenGemmArgs a;
+    a.xt = nullptr; a.w = w; a.bias = bias; a.rscale = rscale; a.R = R; a.out = out;
+    a.M = M; a.S = S; a.ks1 = (S + 31) / 32; a.G = ngroups;
+    a.ldxt = 0; a.ldr = ldr; a.ldo = ldo; a.t_rows = t_rows; a.rperiod = rperiod > 0 ? rperiod : 1; a.res_mode = res_mode;
+    a.x = x; a.ln_mean = ln_mean; a.ln_rstd = ln_rstd; a.gamma = gamma; a.beta = beta; a.ldx = ldx;
+    return token_gemm_launch(dtype, a, res_mode, raff ? 2 : 1, reinterpret_cast<hipStream_t>(stream));
 }

@@ -289,6 +289,19 @@ def token_gemm(xt, ldxt, M, S, wp, bp, ng, out, ldo, t_rows, *, R=None, ldr=0, r
                                     ptr(R), ldr, res, ptr(out), ldo, t_rows, stream()), "mlpk_token_gemm")
 
 
+def token_gemm_ln_supported(dtype, S, t_rows, ldx):
+    """mlpk_token_gemm_ln: the LayerNorm / Aff in front of a token-mixing product as the kernel's operand loader
+    (MLPK_TOKEN_GEMM_LN=0: the separate normalise-and-transpose pass, A/B aid)"""
+    return (token_gemm_supported(dtype, S, round_up(S, 32)) and t_rows % 32 == 0 and ldx % 8 == 0
+            and os.environ.get("MLPK_TOKEN_GEMM_LN", "1") != "0")
+
+
+def token_gemm_ln(x, ldx, M, S, mean, rstd, gamma, beta, wp, bp, ng, out, ldo, t_rows, *, R=None, ldr=0, res=N.RES_NONE, rscale=None, rperiod=0):
+    """x: token-major (B*S, >= t_rows) view (a column slice is fine: pass its stride as ldx); mean / rstd per token row or None."""
+    N.check(N.lib().mlpk_token_gemm_ln(dtype_code(x.dtype), ptr(x), ldx, M, S, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(wp), wp.stride(0),
+                                       ptr(bp), ng, ptr(rscale), rperiod, ptr(R), ldr, res, ptr(out), ldo, t_rows, stream()), "mlpk_token_gemm_ln")
+
+
 def token_mlp_stat_planes(C, layout):
     """planes of mlpk_token_mlp's `stats` buffer: one per 128 channels, one per 64 for the generated kernel (layout 2)"""
     return C // 64 if layout == 2 else C // 128

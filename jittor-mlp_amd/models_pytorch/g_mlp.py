@@ -8,6 +8,7 @@ copy); the spatial GEMM's epilogue adds the per-token bias, multiplies by u (rea
 and stores through the per-image transpose; proj2 GEMM adds bias + residual.
 """
 import contextlib
+import os
 
 import torch
 from torch import nn
@@ -63,6 +64,11 @@ class gMLPBlock(Block):
         self.sgu = SpatialGatingUnit(d_ffn, seq_len)
 
 
+# tuning: how channel_proj1 delivers the SGU LayerNorm's statistics -- "split" (u | v halves, the v half with by-product statistics),
+# "full" (one launch, statistics of all columns), "rowstats" (a statistics pass over the v half)
+P1_MODE = os.environ.get("MLPK_GMLP_P1", "split")
+
+
 class gMLP(E.EngineModule):
     """Backbone on tokens (g_mlp.py:41-49)."""
 
@@ -103,9 +109,41 @@ class gMLP(E.EngineModule):
             # come out of that epilogue (mlpk.h row_part)
             mean, rstd = nxt if nxt is not None else layernorm_stats(ws, x, rows, C)
             h = ws.get("h", (rows, 2 * F))
+            v = h[:, F:]                                        # second half, row stride 2F (g_mlp.py:18)
+            tg = pk.get(p + "sp.tg")
+            if tg is not None and E.token_gemm_ln_supported(v.dtype, S, F, 2 * F):
+                # round 4: the SGU LayerNorm (g_mlp.py:19) is the spatial product's operand loader: ONE kernel reads v, normalises,
+                # transposes through LDS, multiplies, gates with u and stores -- the token-transposed tensor and the normalise-and-
+                # transpose pass (17 % of gMLP-S at 256 images) are gone.  Its row statistics come out of channel_proj1's epilogue:
+                # the product is issued as its two halves (u | v, g_mlp.py:18), the v half with the by-product statistics of what it
+                # stores (mlpk.h row_part; a statistics pass over v when the tile cannot deliver them)
+                w1, b1, cs1 = pk[p + "p1.w"], pk[p + "p1.b"], pk[p + "p1.csum"]
+                vst = None
+                if P1_MODE == "split":
+                    E.gemm(x, w1[:F], h, rows, F, C, ldc=2 * F, bias=b1[:F], act=N.ACT_GELU, ln=(mean, rstd, cs1[:F]), tag="gmlp_proj1")
+                    got = E.gemm(x, w1[F:], v, rows, F, C, ldc=2 * F, bias=b1[F:], act=N.ACT_GELU, ln=(mean, rstd, cs1[F:]), tag="gmlp_proj1",
+                                 part=(ws, "p1.part"))
+                    vst = finalize_stats(ws, got, rows, F, tag="v")
+                elif P1_MODE == "full":
+                    # one launch with the statistics of all 2F columns; the planes of the v half are the second half of the buffer
+                    got = E.gemm(x, w1, h, rows, 2 * F, C, bias=b1, act=N.ACT_GELU, ln=(mean, rstd, cs1), tag="gmlp_proj1", part=(ws, "p1.part"))
+                    if got is not None:
+                        vst = finalize_stats(ws, (got[0][got[1] // 2:], got[1] // 2), rows, F, tag="v")
+                else:
+                    E.gemm(x, w1, h, rows, 2 * F, C, bias=b1, act=N.ACT_GELU, ln=(mean, rstd, cs1), tag="gmlp_proj1")
+                if vst is None:
+                    vst = (ws.get("v.mean", (rows,), torch.float32), ws.get("v.rstd", (rows,), torch.float32))
+                    E.row_stats(v, rows, F, 2 * F, vst[0], vst[1])
+                vmean, vrstd = vst
+                g = ws.get("gate", (rows, F))
+                E.token_gemm_ln(v, 2 * F, B * F, S, vmean, vrstd, pk[p + "sgu.g"], pk[p + "sgu.b"], tg[0], tg[1], tg[2], g, F, F,
+                                R=h, ldr=2 * F, res=N.RES_MUL)
+                got = E.gemm(g, pk[p + "p2.w"], x, rows, C, F, bias=pk[p + "p2.b"], R=x, res=N.RES_ADD,
+                             part=(ws, "p2.part") if only is None and i + 1 < depth else None)
+                nxt = finalize_stats(ws, got, rows, C)
+                continue
             E.gemm(x, pk[p + "p1.w"], h, rows, 2 * F, C, bias=pk[p + "p1.b"], act=N.ACT_GELU, ln=(mean, rstd, pk[p + "p1.csum"]),
                    tag="gmlp_proj1")
-            v = h[:, F:]                                        # second half, row stride 2F (g_mlp.py:18)
             vt = ws.get("vt", (B * F, sp))
             if E.layernorm_transpose_supported(v.dtype, F, 2 * F, sp):
                 # the SGU LayerNorm (g_mlp.py:19) in one pass: statistics + affine + per-image transpose

@@ -931,6 +931,122 @@ def test_token_gemm(dtype):
         E.token_gemm(xt, sp, B_ * C, 300, wp, bp, ng, out, C, C)                # more tokens than the packed groups hold
 
 
+def test_gemm_skinny_fp32_kernel():
+    """algo 16 (round 4): the small fp32 products of the SplitAttention / re-weighting MLPs (vip.py:42-53; s2_mlp_v2.py:36-47) on the
+    whole chip without MFMA -- lanes own output columns (or rows, when there are few columns), four waves split K.  Against fp64, and a
+    row's bits do not depend on how many rows the call has (the batch)."""
+    pkg = load_pkg()
+    E, N = pkg.engine, pkg._native
+    for ci, (M, Nn, K, act, has_bias) in enumerate([(256, 384, 768, 1, True), (256, 1152, 384, 0, False), (8192, 24, 768, 0, True), (7, 100, 64, 1, True),
+                                                    (64, 24, 768, 0, True), (300, 1000, 1536, 0, True), (2, 48, 16, 1, False)]):
+        A = rnd((M, K), torch.float32, 3000 + ci).to(dev())
+        B = rnd((Nn, K), torch.float32, 3010 + ci, 1.0 / math.sqrt(K)).to(dev())
+        bias = rnd((Nn,), torch.float32, 3020 + ci).to(dev()) if has_bias else None
+        ref = A.double().cpu() @ B.double().cpu().t()
+        if has_bias:
+            ref = ref + bias.double().cpu()
+        if act:
+            ref = torch.nn.functional.gelu(ref)
+        outs = {}
+        for algo in (16, 0, 5):
+            C = torch.full((M, Nn), float("nan"), dtype=torch.float32, device=dev())
+            E.gemm(A, B, C, M, Nn, K, bias=bias, act=act, algo=algo)
+            torch.cuda.synchronize()
+            err = (C.double().cpu() - ref).abs().max().item()
+            assert err < 2e-5 * max(1.0, ref.abs().max().item()), (ci, algo, err)
+            outs[algo] = C
+        if M >= 8:
+            k = M // 2
+            Ch = torch.full((k, Nn), float("nan"), dtype=torch.float32, device=dev())
+            E.gemm(A[:k].contiguous(), B, Ch, k, Nn, K, bias=bias, act=act, algo=16)
+            torch.cuda.synchronize()
+            assert torch.equal(Ch, outs[16][:k]), ci                       # same rows, half the batch: same bits
+    # opt-in (MLPK_GEMM_SKINNY=1): measured neutral on its own and worse beside a persistent GEMM (mlpk_gemm.hip, gemm_prepare)
+    assert ctypes_name(pkg, 256, 384, 768) != "gemm_skinny_f32_kernel"
+    with pytest.raises(RuntimeError):
+        E.gemm(A, B, C, M, Nn, K, algo=16, R=C, res=N.RES_ADD)               # no residual class
+
+
+def ctypes_name(pkg, M, Nn, K):
+    import ctypes
+    N = pkg._native
+    d = N.GemmDesc()
+    d.dtype, d.M, d.N, d.K, d.lda, d.ldb, d.ldc = N.F32, M, Nn, K, K, K, Nn
+    d.A = d.B = d.C = 1 << 20
+    buf = ctypes.create_string_buffer(96)
+    assert N.lib().mlpk_gemm_kernel_name(ctypes.byref(d), buf, 96) == 0
+    return buf.value.decode()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_token_gemm_with_the_layernorm_as_its_operand_loader(dtype):
+    """mlpk_token_gemm_ln (round 4): out[b,t,c] = R[b,t,c] (+|*) rscale[c] * (sum_s W[t,s] LN(x)[b,s,c] + bias[t]) with LN(x) built inside the
+    kernel from the token-major x -- gMLP's spatial gating unit (g_mlp.py:17-22: x = the v half of a wider tensor, LayerNorm over its
+    channels, gate u = the other half) and ResMLP's cross-patch sublayer (res_mlp.py:17-19,52-55: Aff, no statistics, residual = the
+    affine output).  Against fp64 on the SAME rounded operand, and against the two-kernel path it replaces (normalise + transpose pass,
+    then mlpk_token_gemm): the two differ only by the rounding of the LayerNorm expression.  Cases: ragged tokens (196 = 6.1 groups,
+    50, 224), tiles spanning images (384 channels), more tiles than CUs (workgroups walk several), a partial last tile."""
+    pkg = load_pkg()
+    E, N = pkg.engine, pkg._native
+    for ci, (B_, C, S, mode) in enumerate([(2, 256, 196, "sgu"), (3, 384, 196, "aff"), (5, 64, 49, "sgu"), (2, 1536, 50, "sgu"), (4, 96, 224, "aff"),
+                                           (90, 768, 196, "sgu"), (150, 384, 100, "aff")]):
+        rows = B_ * S
+        w = rnd((S, S), torch.float32, 2110 + ci, 1.0 / math.sqrt(S))
+        bias = rnd((S,), torch.float32, 2120 + ci)
+        wp, bp, ng = E.pack_token_gemm(w, bias, dtype, dev())
+        wr = w.to(dtype).double()
+        gamma = (rnd((C,), torch.float32, 2130 + ci) * 0.3 + 1.0).to(dev())
+        beta = (rnd((C,), torch.float32, 2140 + ci) * 0.2).to(dev())
+        if mode == "sgu":
+            wide = (rnd((rows, 2 * C), dtype, 2150 + ci) * 1.5 + 0.25).to(dev())   # h = (u | v), row stride 2C
+            v = wide[:, C:]
+            mean = torch.empty((rows,), dtype=torch.float32, device=dev())
+            rstd = torch.empty((rows,), dtype=torch.float32, device=dev())
+            E.row_stats(v, rows, C, 2 * C, mean, rstd)
+            out = torch.full((rows, C), float("nan"), dtype=dtype, device=dev())
+            E.token_gemm_ln(v, 2 * C, B_ * C, S, mean, rstd, gamma, beta, wp, bp, ng, out, C, C, R=wide, ldr=2 * C, res=N.RES_MUL)
+            torch.cuda.synchronize()
+            vn = ((v.double().cpu() - mean.double().cpu()[:, None]) * rstd.double().cpu()[:, None] * gamma.double().cpu() + beta.double().cpu())
+            vn = vn.to(dtype).double().reshape(B_, S, C)                            # the operand is rounded once
+            ref = (torch.einsum("ts,bsc->btc", wr, vn) + bias.double().view(1, -1, 1)) * wide.cpu().double()[:, :C].reshape(B_, S, C)
+            # the path it replaces
+            sp = E.round_up(S, 32)
+            vt = torch.zeros((B_ * C, sp), dtype=dtype, device=dev())
+            E.norm_apply(v, rows, C, 2 * C, mean=mean, rstd=rstd, gamma=gamma, beta=beta, out_tt=vt, S=S, ld_tt=sp)
+            two = torch.full((rows, C), float("nan"), dtype=dtype, device=dev())
+            E.token_gemm(vt, sp, B_ * C, S, wp, bp, ng, two, C, C, R=wide, ldr=2 * C, res=N.RES_MUL)
+        else:
+            x = rnd((rows, C), dtype, 2150 + ci).to(dev())
+            g1 = (rnd((C,), torch.float32, 2160 + ci) * 0.3 + 0.5).to(dev())
+            x1 = torch.empty_like(x)                                                  # Aff(x), the residual (res_mlp.py:53-55)
+            E.norm_apply(x, rows, C, C, gamma=gamma, beta=beta, out_rm=x1, ld_rm=C)
+            out = torch.full((rows, C), float("nan"), dtype=dtype, device=dev())
+            E.token_gemm_ln(x, C, B_ * C, S, None, None, gamma, beta, wp, bp, ng, out, C, C, R=x1, ldr=C, res=N.RES_ADD, rscale=g1, rperiod=C)
+            torch.cuda.synchronize()
+            xa = (x.double().cpu() * gamma.double().cpu() + beta.double().cpu()).to(dtype).double().reshape(B_, S, C)
+            ref = x1.cpu().double().reshape(B_, S, C) + (torch.einsum("ts,bsc->btc", wr, xa) + bias.double().view(1, -1, 1)) * g1.cpu().double().view(1, 1, -1)
+            sp = E.round_up(S, 32)
+            xt = torch.zeros((B_ * C, sp), dtype=dtype, device=dev())
+            E.norm_apply(x, rows, C, C, gamma=gamma, beta=beta, out_tt=xt, S=S, ld_tt=sp)
+            two = torch.full((rows, C), float("nan"), dtype=dtype, device=dev())
+            E.token_gemm(xt, sp, B_ * C, S, wp, bp, ng, two, C, C, R=x1, ldr=C, res=N.RES_ADD, rscale=g1, rperiod=C)
+            # ... and with the residual rebuilt from x itself (R == x), in place: bit-equal to the run with the stored Aff output
+            xin = x.clone()
+            E.token_gemm_ln(xin, C, B_ * C, S, None, None, gamma, beta, wp, bp, ng, xin, C, C, R=xin, ldr=C, res=N.RES_ADD, rscale=g1, rperiod=C)
+            torch.cuda.synchronize()
+            assert torch.equal(xin.view(torch.int16), out.view(torch.int16)), (str(dtype), ci, "in place, residual rebuilt")
+        torch.cuda.synchronize()
+        got = out.cpu().double().reshape(B_, S, C)
+        assert torch.isfinite(got).all(), (str(dtype), ci)
+        scale = max(1.0, ref.abs().max().item())
+        err = (got - ref).abs().max().item()
+        assert err < EPS[dtype] * 4 * scale, (str(dtype), ci, mode, err)
+        d2 = (got - two.cpu().double().reshape(B_, S, C)).abs().max().item()
+        assert d2 < EPS[dtype] * 4 * scale, (str(dtype), ci, mode, d2)
+    with pytest.raises(RuntimeError):
+        E.token_gemm_ln(x, C, B_ * C, S, None, None, gamma, beta, wp, bp, ng, out, C, 40)      # t_rows must be whole groups of 32 channels
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_dwconv_affine_nhwc(dtype):
     """Sparse-MLP depthwise step: x + dwconv_same(scale * x + shift) + bias with zero padding AFTER the affine
