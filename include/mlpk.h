@@ -41,6 +41,8 @@
  *   mlpk_shift_nchw_backward   _shift.backward / shift_backward_grad_input_kernel: utils/shift_cuda.py:75-103,131-162
  *   mlpk_shift_nhwc     the same remap on the channel-last layout used internally for AS-MLP
  *   mlpk_norm_shift_nhwc  AxialShift's GroupNorm + GELU + both shifts as one index-remapping pass (as_mlp.py:64-66,84-95)
+ *   mlpk_as_conv2       AxialShift's core in ONE kernel: GroupNorm + GELU, both axial shifts, conv2_1 and conv2_2 with their GELUs and the sum
+ *                       (as_mlp.py:64-66,84-93; utils/shift_cuda.py:49-69): the shifts are LDS read addresses of the MFMA operands
  *   mlpk_cycle_shift    the sampling half of CycleFC (cycle_mlp.py:104-131: deform_conv2d with a 1 x 1 kernel and fixed integer
  *                       offsets = a per-channel cyclic pixel shift with zero fill); the 1 x 1 convolution is mlpk_gemm_nt
  *   mlpk_split_sum      the reduction of SplitAttention (vip.py:49-50; s2_mlp_v2.py:43-44), with the
@@ -352,6 +354,16 @@ int mlpk_shift_nchw_backward(int dtype, const void* grad_out, void* grad_in, int
 int mlpk_norm_shift_nhwc(int dtype, const void* in, void* out_w, void* out_h, int N, int H, int W, int C, int kernel_size,
                          const float* mean, const float* rstd, const float* gamma, const float* beta, int act, void* stream);
 
+/* ABI 8.  y = gelu(conv2_1(shift_W(u)) + b1) + gelu(conv2_2(shift_H(u)) + b2),  u = gelu((t - mean[b]) * rstd[b] * gamma[c] + beta[c])
+ * (as_mlp.py:64-66,84-93) on channel-last t, y (B*H*W, C) in one kernel: a workgroup stages a band of image rows of u (with its zero
+ * halo) in LDS and applies the per-channel-group pixel offsets  s(c) = k/2 - c / ceil(C/k)  (utils/shift_cuda.py:49-69) as LDS read
+ * addresses of the matrix-core operands; mlpk_norm_shift_nhwc's two shifted copies and the two GEMM launches that read them are gone.
+ * Results are bit-equal to that three-kernel sequence.  16-bit dtypes, kernel_size 5, C = 96 or 192 (AS-MLP-T / -S / -B stages 1-2;
+ * mlpk_as_conv2_supported answers for a shape), w1 / w2 (C, ldw) = the Conv2d(C, C, 1) weights (out, in), y != t. */
+int mlpk_as_conv2_supported(int dtype, int H, int W, int C, int kernel_size);
+int mlpk_as_conv2(int dtype, const void* t, void* y, int B, int H, int W, int C, int kernel_size, const float* mean, const float* rstd,
+                  const float* gamma, const float* beta, const void* w1, const float* b1, const void* w2, const float* b2, int ldw,
+                  void* stream);
 /* ---- CycleFC sampling (CycleMLP) ---------------------------------------------------------------
  * in: (B,H,W,C) channel-last with pixel stride ldi.  d(c) = (c + k/2) % k - k/2  (gen_offset, cycle_mlp.py:104-120):
  *   out_h[b,y,x,c] = in[b, y, x + d(c), c]     the operand of `sfc_h` = CycleFC(kernel (1,k))

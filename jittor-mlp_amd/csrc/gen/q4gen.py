@@ -950,7 +950,9 @@ CLASSES = {"p": (False, False, False, False), "l": (False, True, False, False), 
            # LayerNorm (g_mlp.py:19) is then the spatial product's operand loader (mlpk_token_gemm_ln) without a statistics pass
            "gls": (True, True, False, True)}
 NKF = {c: (3, 4, 6, 12) for c in CLASSES}
-NK_STATIC = (6, 12, 18)          # K = 384 / 768 / 1152: the kernels built for one K (Q4.static)
+# K = 192 / 384 / 576 / 768: the kernels built for one K (Q4.static).  Not 1152 (nk = 18): measured BEHIND the general f12 kernel on ViP's
+# fc2 (0.0624-0.0633 vs 0.0584-0.0586 ms, profiles/r04_q4_static_probe_v1.txt): 36 unrolled iterations no longer sit in the instruction cache
+NK_STATIC = (3, 6, 9, 12)
 DTYPES = ("bf16", "f16")
 
 

@@ -401,6 +401,18 @@ def norm_shift_nhwc(x, out_w, out_h, n, h, w, c, kernel_size, mean, rstd, gamma,
                                          ptr(gamma), ptr(beta), act, stream()), "mlpk_norm_shift_nhwc")
 
 
+def as_conv2_supported(dtype, H, W, C, kernel_size):
+    """mlpk_as_conv2 takes the shape (MLPK_ASMLP_FUSED_CONV2=0: the three-kernel sequence, A/B aid)"""
+    return (dtype in (torch.float16, torch.bfloat16) and os.environ.get("MLPK_ASMLP_FUSED_CONV2", "1") != "0"
+            and bool(N.lib().mlpk_as_conv2_supported(dtype_code(dtype), H, W, C, kernel_size)))
+
+
+def as_conv2(t, y, B, H, W, C, kernel_size, mean, rstd, gamma, beta, w1, b1, w2, b2):
+    """y = gelu(conv2_1(shift_W(u)) + b1) + gelu(conv2_2(shift_H(u)) + b2), u = gelu(GroupNorm affine of t): AxialShift's core in one kernel"""
+    N.check(N.lib().mlpk_as_conv2(dtype_code(t.dtype), ptr(t), ptr(y), B, H, W, C, kernel_size, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
+                                  ptr(w1), ptr(b1), ptr(w2), ptr(b2), w1.stride(0), stream()), "mlpk_as_conv2")
+
+
 def cycle_shift(x, out_h, out_w, B, H, W, C, k, ldi, ldo):
     N.check(N.lib().mlpk_cycle_shift(dtype_code(x.dtype), ptr(x), ptr(out_h), ptr(out_w), B, H, W, C, k, ldi, ldo, stream()),
             "mlpk_cycle_shift")

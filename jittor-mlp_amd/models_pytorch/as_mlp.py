@@ -18,7 +18,7 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Block, Holder, finalize_stats, head_linear
+from .common import Block, Holder, SubModule, finalize_stats, head_linear, two_layer_mlp
 from .utils.shift import Shift
 
 # GroupNorm(1,C) statistics from the producing GEMMs' epilogues (mlpk.h row_part, per-sample groups).  Off by default: measured
@@ -31,8 +31,9 @@ def to_2tuple(v):
     return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
 
 
-class Mlp(Holder):
-    """as_mlp.py:8-24."""
+class Mlp(SubModule):
+    """as_mlp.py:8-24: Conv2d(1x1) -> GELU -> Dropout -> Conv2d(1x1) -> Dropout on (B, C, H, W); callable on its own like the
+    reference's (channel-last inside: the 1 x 1 convolutions are the NT GEMM)."""
 
     def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
         super().__init__()
@@ -42,6 +43,26 @@ class Mlp(Holder):
         self.act = act_layer()
         self.fc2 = nn.Conv2d(hidden_features, out_features, 1, 1)
         self.drop = nn.Dropout(drop)
+
+    def _pack(self, dtype, device):
+        return {"fc1.w": E.pack_matrix(self.fc1.weight, dtype, device), "fc1.b": E.f32(self.fc1.bias, device),
+                "fc2.w": E.pack_matrix(self.fc2.weight, dtype, device), "fc2.b": E.f32(self.fc2.bias, device)}
+
+    def forward(self, x):
+        if not isinstance(self.act, nn.GELU):
+            raise NotImplementedError("Mlp runs on its own with the reference's default activation (GELU) only")
+        cin, hidden, cout = self.fc1.in_channels, self.fc1.out_channels, self.fc2.out_channels
+        if x.dim() != 4:
+            raise ValueError("expected a (B, C, H, W) tensor")
+        pk = self._begin(x, cin, axis=1)
+        B, _, H, W = x.shape
+        rows = B * H * W
+        with E.on_device(x):
+            ws = self._get_space(rows, x.dtype, x.device)
+            xb = ws.get("mlp.x", (rows, pk["fc1.w"].shape[1]))
+            xb[:, :cin].copy_(x.permute(0, 2, 3, 1).reshape(rows, cin))
+            y = two_layer_mlp(ws, pk, xb, rows, cin, hidden, cout)
+            return y.reshape(B, H, W, cout).permute(0, 3, 1, 2).contiguous()
 
 
 class AxialShift(Holder):
@@ -316,10 +337,19 @@ class AS_MLP(E.EngineModule):
                     got = E.gemm(cur, pk[p + "c1f.w"], t1, rows, C, C, bias=pk[p + "c1f.b"], ln=(mean, rstd, pk[p + "c1f.csum"]), ln_group=HW,
                                  tag="as_conv", part=part)                                           # conv1(norm1(x))
                     stats(t1, C, got)
-                    E.norm_shift_nhwc(t1, t0, t2, B, H, W, C, self._shift, mean, rstd, pk[p + "an1.g"], pk[p + "an1.b"], N.ACT_GELU)
-                    E.gemm(t0, pk[p + "c21.w"], t1, rows, C, C, bias=pk[p + "c21.b"], act=N.ACT_GELU, tag="as_conv")      # x_lr (W shift)
-                    got = E.gemm(t2, pk[p + "c22.w"], t1, rows, C, C, bias=pk[p + "c22.b"], act=N.ACT_GELU, R=t1, res=N.RES_ADD,
-                                 tag="as_conv", part=part)                                           # gelu(.) + x_lr (H shift)
+                    if pk.get(p + "c21.b") is not None and pk.get(p + "c22.b") is not None and E.as_conv2_supported(cd, H, W, C, self._shift):
+                        # round 4 (stages with C = 96 / 192): GroupNorm + GELU, both axial shifts, conv2_1, conv2_2, their GELUs and the sum
+                        # in ONE kernel -- the shifts are LDS read addresses of the matrix-core operands (mlpk_as_conv2); bit-equal to the
+                        # three kernels below, 2 tensor passes over HBM instead of 9
+                        E.as_conv2(t1, t0, B, H, W, C, self._shift, mean, rstd, pk[p + "an1.g"], pk[p + "an1.b"],
+                                   pk[p + "c21.w"], pk[p + "c21.b"], pk[p + "c22.w"], pk[p + "c22.b"])
+                        t0, t1 = t1, t0                                                              # the sum now lives in what was t0
+                        got = None
+                    else:
+                        E.norm_shift_nhwc(t1, t0, t2, B, H, W, C, self._shift, mean, rstd, pk[p + "an1.g"], pk[p + "an1.b"], N.ACT_GELU)
+                        E.gemm(t0, pk[p + "c21.w"], t1, rows, C, C, bias=pk[p + "c21.b"], act=N.ACT_GELU, tag="as_conv")      # x_lr (W shift)
+                        got = E.gemm(t2, pk[p + "c22.w"], t1, rows, C, C, bias=pk[p + "c22.b"], act=N.ACT_GELU, R=t1, res=N.RES_ADD,
+                                     tag="as_conv", part=part)                                       # gelu(.) + x_lr (H shift)
                     stats(t1, C, got)
                     got = E.gemm(t1, pk[p + "c3f.w"], cur, rows, C, C, bias=pk[p + "c3f.b"], ln=(mean, rstd, pk[p + "c3f.csum"]), ln_group=HW,
                                  R=cur, res=N.RES_ADD, tag="as_conv", part=part)                     # x + conv3(norm2(.))

@@ -15,6 +15,28 @@ class Holder(nn.Module):
         raise NotImplementedError("%s only holds parameters; call the enclosing model" % type(self).__name__)
 
 
+class SubModule(E.EngineModule):
+    """Base of the small inner modules the reference lets a caller run on their own (`Aff`, the families' `FeedForward` / `Mlp`): their
+    own packed weights and workspace, the same HIP kernels as the enclosing model's forward.  Inside a model they are parameter
+    containers: the model packs their parameters into its own fused sequence and never calls them."""
+
+    def _begin(self, x, width, axis=-1):
+        E.require_gpu(x, type(self).__name__ + ".forward")
+        E.dtype_code(x.dtype)
+        if x.dim() < 2 or x.shape[axis] != width:
+            raise ValueError("expected %d entries along dimension %d, got a tensor of shape %s" % (width, axis, tuple(x.shape)))
+        return self._get_pack(x.dtype, x.device)
+
+
+def two_layer_mlp(ws, pk, xb, rows, dim, hidden, out_dim):
+    """out = fc2(gelu(fc1(x))) on channel-last rows xb (rows, K-padded dim): two NT GEMMs, bias + exact GELU in the first epilogue"""
+    h = ws.get("mlp.hid", (rows, pk["fc2.w"].shape[1]))
+    y = ws.get("mlp.y", (rows, out_dim))
+    E.gemm(xb, pk["fc1.w"], h, rows, hidden, xb.shape[1], bias=pk["fc1.b"], act=N.ACT_GELU)
+    E.gemm(h, pk["fc2.w"], y, rows, out_dim, h.shape[1], bias=pk["fc2.b"])
+    return y
+
+
 def standalone_space(x):
     """A workspace for ONE call of an inner module on its own (the sub-block boundary of the reference: g_mlp.py:17-22,
     vip.py:24-57, s2_mlp_v2.py:15-69, as_mlp.py:55-95).  Not a hot path: weights are packed per call."""

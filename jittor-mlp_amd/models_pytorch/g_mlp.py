@@ -66,7 +66,7 @@ class gMLPBlock(Block):
 
 # tuning: how channel_proj1 delivers the SGU LayerNorm's statistics -- "split" (u | v halves, the v half with by-product statistics),
 # "full" (one launch, statistics of all columns), "rowstats" (a statistics pass over the v half)
-P1_MODE = os.environ.get("MLPK_GMLP_P1", "split")
+P1_MODE = os.environ.get("MLPK_GMLP_P1", "full")      # measured (profiles/r04_gmlp_p1_ab.txt): full 10.23 ms, rowstats 10.85, split 10.96-11.16
 
 
 class gMLP(E.EngineModule):

@@ -15,24 +15,55 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Block, Holder, adopt_blocks, embed_patches, head_linear
+from .common import Block, Holder, SubModule, adopt_blocks, embed_patches, head_linear, two_layer_mlp
 from .utils.tools import check_sizes, pair
 
 
-class Aff(Holder):
-    """x * alpha + beta with (1,1,dim) parameters (res_mlp.py:11-19)."""
+class Aff(SubModule):
+    """x * alpha + beta with (1,1,dim) parameters (res_mlp.py:11-19); callable on (..., dim) like the reference's."""
 
     def __init__(self, dim):
         super().__init__()
         self.alpha = nn.Parameter(torch.ones([1, 1, dim]))
         self.beta = nn.Parameter(torch.zeros([1, 1, dim]))
 
+    def _pack(self, dtype, device):
+        return {"a": E.f32(self.alpha.reshape(-1), device), "b": E.f32(self.beta.reshape(-1), device)}
 
-class FeedForward(Holder):
+    def forward(self, x):
+        dim = self.alpha.shape[-1]
+        pk = self._begin(x, dim)
+        rows = x.numel() // dim
+        with E.on_device(x):
+            ws = self._get_space(rows, x.dtype, x.device)
+            xb = ws.get("aff.x", (rows, dim))
+            xb.copy_(x.reshape(rows, dim))
+            y = ws.get("aff.y", (rows, dim))
+            E.norm_apply(xb, rows, dim, dim, gamma=pk["a"], beta=pk["b"], out_rm=y, ld_rm=dim)
+            return y.reshape(x.shape).clone()
+
+
+class FeedForward(SubModule):
+    """Linear -> GELU -> Dropout -> Linear -> Dropout on the last dimension (res_mlp.py:21-32); callable like the reference's."""
+
     def __init__(self, dim, hidden_dim, dropout=0.):
         super().__init__()
         self.net = nn.Sequential(nn.Linear(dim, hidden_dim), nn.GELU(), nn.Dropout(dropout),
                                  nn.Linear(hidden_dim, dim), nn.Dropout(dropout))
+
+    def _pack(self, dtype, device):
+        return {"fc1.w": E.pack_matrix(self.net[0].weight, dtype, device), "fc1.b": E.f32(self.net[0].bias, device),
+                "fc2.w": E.pack_matrix(self.net[3].weight, dtype, device), "fc2.b": E.f32(self.net[3].bias, device)}
+
+    def forward(self, x):
+        dim, hidden = self.net[0].in_features, self.net[0].out_features
+        pk = self._begin(x, dim)
+        rows = x.numel() // dim
+        with E.on_device(x):
+            ws = self._get_space(rows, x.dtype, x.device)
+            xb = ws.get("mlp.x", (rows, pk["fc1.w"].shape[1]))          # K zero-padded to whole 16-byte chunks
+            xb[:, :dim].copy_(x.reshape(rows, dim))
+            return two_layer_mlp(ws, pk, xb, rows, dim, hidden, dim).reshape(x.shape).clone()
 
 
 class MLPblock(Block):

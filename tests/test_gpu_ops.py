@@ -931,6 +931,54 @@ def test_token_gemm(dtype):
         E.token_gemm(xt, sp, B_ * C, 300, wp, bp, ng, out, C, C)                # more tokens than the packed groups hold
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_axial_shift_core_in_one_kernel(dtype):
+    """mlpk_as_conv2 (round 4; as_mlp.py:64-66,84-93, utils/shift_cuda.py:49-69): GroupNorm affine + GELU, the two axial shifts, conv2_1,
+    conv2_2, their GELUs and the sum in one kernel, the shifts applied as LDS read addresses of the MFMA operands -- BIT-EQUAL to the
+    three kernels it replaces (mlpk_norm_shift_nhwc writing both shifted copies, then two mlpk_gemm_nt), and within rounding of an
+    fp64 restatement through the oracle's shift.  Maps that are not multiples of anything (bands with a short tail, pixel blocks that
+    wrap rows), both widths the kernel is built for, several bands per image."""
+    pkg = load_pkg()
+    E, N = pkg.engine, pkg._native
+    for ci, (B, H, W, C) in enumerate([(2, 56, 56, 96), (3, 28, 28, 192), (2, 7, 9, 96), (1, 33, 5, 192), (5, 14, 14, 96), (2, 1, 1, 192)]):
+        rows = B * H * W
+        t = (rnd((rows, C), dtype, 4000 + ci) * 1.5 + 0.3).to(dev())
+        mean = (rnd((B,), torch.float32, 4010 + ci) * 0.2).to(dev())
+        rstd = (rnd((B,), torch.float32, 4020 + ci).abs() * 0.3 + 0.6).to(dev())
+        gamma = (rnd((C,), torch.float32, 4030 + ci) * 0.3 + 1.0).to(dev())
+        beta = (rnd((C,), torch.float32, 4040 + ci) * 0.2).to(dev())
+        w1 = rnd((C, C), dtype, 4050 + ci, 1.0 / math.sqrt(C)).to(dev())
+        w2 = rnd((C, C), dtype, 4060 + ci, 1.0 / math.sqrt(C)).to(dev())
+        b1 = rnd((C,), torch.float32, 4070 + ci).to(dev())
+        b2 = rnd((C,), torch.float32, 4080 + ci).to(dev())
+        assert E.as_conv2_supported(dtype, H, W, C, 5)
+        y = torch.full((rows, C), float("nan"), dtype=dtype, device=dev())
+        E.as_conv2(t, y, B, H, W, C, 5, mean, rstd, gamma, beta, w1, b1, w2, b2)
+        # the sequence it replaces
+        uw = torch.empty_like(t)
+        uh = torch.empty_like(t)
+        E.norm_shift_nhwc(t, uw, uh, B, H, W, C, 5, mean, rstd, gamma, beta, N.ACT_GELU)
+        ref = torch.empty_like(t)
+        E.gemm(uw, w1, ref, rows, C, C, bias=b1, act=N.ACT_GELU)
+        E.gemm(uh, w2, ref, rows, C, C, bias=b2, act=N.ACT_GELU, R=ref, res=N.RES_ADD)
+        torch.cuda.synchronize()
+        assert torch.isfinite(y.float()).all(), (str(dtype), ci)
+        nd = int((y.view(torch.int16) != ref.view(torch.int16)).sum())
+        assert nd == 0, (str(dtype), ci, (B, H, W, C), nd, (y.float() - ref.float()).abs().max().item())
+        # fp64 restatement on the rounded operand u (NCHW through the oracle's shift, shift_cuda.py:49-69)
+        u = torch.nn.functional.gelu((t.double().cpu().reshape(B, H * W, C) - mean.double().cpu().view(B, 1, 1)) * rstd.double().cpu().view(B, 1, 1)
+                                     * gamma.double().cpu() + beta.double().cpu()).to(dtype).double()
+        un = u.reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
+        sw = oracle.axial_shift_nchw(un, 5, 3).permute(0, 2, 3, 1).reshape(rows, C)
+        sh = oracle.axial_shift_nchw(un, 5, 2).permute(0, 2, 3, 1).reshape(rows, C)
+        want = torch.nn.functional.gelu(sw @ w1.double().cpu().t() + b1.double().cpu()) + torch.nn.functional.gelu(sh @ w2.double().cpu().t() + b2.double().cpu())
+        err = (y.double().cpu() - want).abs().max().item()
+        assert err < EPS[dtype] * 4 * max(1.0, want.abs().max().item()), (str(dtype), ci, err)
+    assert not E.as_conv2_supported(dtype, 14, 14, 384, 5) and not E.as_conv2_supported(torch.float32, 56, 56, 96, 5)
+    with pytest.raises(RuntimeError):
+        E.as_conv2(t, t, B, H, W, C, 5, mean, rstd, gamma, beta, w1, b1, w2, b2)       # in place: a band reads its neighbours' rows
+
+
 def test_gemm_skinny_fp32_kernel():
     """algo 16 (round 4): the small fp32 products of the SplitAttention / re-weighting MLPs (vip.py:42-53; s2_mlp_v2.py:36-47) on the
     whole chip without MFMA -- lanes own output columns (or rows, when there are few columns), four waves split K.  Against fp64, and a
