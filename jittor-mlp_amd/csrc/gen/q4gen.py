@@ -171,7 +171,7 @@ class Q4:
         self.v_q = [[v("q%d_%d" % (b, r)) for r in range(4)] for b in range(2)] if ge else [None, None]
         self.v_pk = [v("pk%d" % k, 2, 2) for k in range(2)]
         self.v_stw = [v("stw%d" % c) for c in range(8)]        # LDS staging: write address of 16-byte chunk c of this lane's row
-        self.v_strd = v("strd")                                # ... and the read address (row lane >> 3, chunk lane & 7)
+        self.v_strd = [v("strd%d" % k) for k in range(4)]      # ... and the read addresses (row (lane >> 3) + 8 k, chunk lane & 7)
         self.v_out = [v("out%d" % k, 4, 4) for k in range(4)]
         self.v_res = [[v("res%d_%d" % (i, k), 4, 4) for k in range(4)] for i in range(2)] if self.res else None    # block rows i, i + 2
         if self.stats:
@@ -505,7 +505,7 @@ class Q4:
             rd = [None] * 4
             self._st_reads[i] = rd
             for k in range(4):
-                ops.append(lambda k=k, rd=rd: rd.__setitem__(k, self.ds("ds_read_b128", self.v_out[k], self.v_strd, offset=k * 1024)))
+                ops.append(lambda k=k, rd=rd: rd.__setitem__(k, self.ds("ds_read_b128", self.v_out[k], self.v_strd[k])))
         stores(3)
         return ops
 
@@ -768,19 +768,29 @@ class Q4:
                 a("v_add_u32", lane, lane, vt[7])
                 a("v_lshlrev_b32", self.voffP[kk], 3, lane)
             a("v_mov_b32", self.v_ones, 0x3F803F80 if self.dtype == "bf16" else 0x3C003C00)
-        # LDS staging tile of this wave: OUT_OFF + wave * 4096; write: row l31, chunk c ^ (l31 & 7), half h; read: row l3, chunk l7 ^ l3
+        # LDS staging tile of this wave: OUT_OFF + wave * 4096, [32 rows][128 B]; chunk c of row r sits at chunk c ^ (r & 7) ^ (2 (r >> 3)).
+        # (Round 4: the second term.  Rows are 128 B = 32 banks apart, so a chunk position serves two bank groups (row parity) -- 16 slots
+        # for the 32 rows of a ds_write_b64; with c ^ (r & 7) alone rows r, r + 8, r + 16, r + 24 fell on ONE slot, a 4-way conflict where 2 is
+        # the natural rate: SQ_LDS_BANK_CONFLICT 2.4e6 per fc1 launch.  Padding the rows instead does not fit: LDS is full to the byte.)
+        # write: row l31, half h; read k: row l3 + 8 k, chunk l7
         a("s_lshl_b32", t[0], self.s_wave, 12)
         a("s_add_u32", t[0], t[0], OUT_OFF)
         a("v_lshlrev_b32", vt[6], 7, l31)
         a("v_add_u32", vt[6], t[0], vt[6])
         a("v_lshl_add_u32", vt[6], h, 3, vt[6])
+        a("v_bfe_u32", vt[7], l31, 3, 2)
+        a("v_lshlrev_b32", vt[7], 1, vt[7])
+        a("v_xor_b32", vt[7], vt[7], l7)                        # (l31 & 7) ^ (2 (l31 >> 3))
         for c in range(8):
-            a("v_xor_b32", lane, c, l7)
+            a("v_xor_b32", lane, c, vt[7])
             a("v_lshl_add_u32", self.v_stw[c], lane, 4, vt[6])
         a("v_lshlrev_b32", vt[6], 7, l3)
         a("v_add_u32", vt[6], t[0], vt[6])
-        a("v_xor_b32", lane, l7, l3)
-        a("v_lshl_add_u32", self.v_strd, lane, 4, vt[6])
+        a("v_xor_b32", vt[7], l7, l3)
+        for kk in range(4):
+            a("v_xor_b32", lane, 2 * kk, vt[7])
+            a("v_lshl_add_u32", self.v_strd[kk], lane, 4, vt[6])
+            a("v_add_u32", self.v_strd[kk], kk * 1024, self.v_strd[kk])
         # ---- work list (gemm_nt_p8_kernel's): XCD = bid & 7 -> column group, member; tiles u0 + l, l = bid >> 3, += grid >> 3
         xcd, cgrp, xj = t[0], t[1], t[2]
         a("s_and_b32", xcd, self.s_bid, 7)

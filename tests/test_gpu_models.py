@@ -28,21 +28,21 @@ DEV = "cuda:0"
 
 # bf16 at real depth: the gate is 5e-3 * max(1, max|ref|) (Mixer-S/B/L 2.3-2.8e-3, ResMLP 3.9e-3, Swin-MLP 3.8e-3,
 # ConvMixer 6e-4 measured; the reference's OWN bf16 forward is 2.7e-3 on Mixer-B and 4.7e-3 on gMLP-S).
-# Exceptions, each = measured value on MI355X (round 1 logs) + ~20 % head-room, all for the same reason: these networks add
-# 2 x depth bf16-rounded updates to a bf16 residual stream -- exactly like the reference run in bf16 -- and are 30-38
-# blocks deep or carry a residual of magnitude 4-8 (half-ulp 2^-7 .. 2^-6 per add) where a 12-block Mixer does not.
+# Deeper networks add 2 x depth bf16-rounded updates to a bf16 residual stream -- exactly like the reference run in bf16 -- and are 30-38
+# blocks deep or carry a residual of magnitude 4-8 (half-ulp 2^-7 .. 2^-6 per add) where a 12-block Mixer does not: their gates are
+# derived from the reference's own bf16 forward (REF_LOWP below); what is left here is a measured value + head-room.
 BF16_REAL_EXCEPTIONS = {
-    "vip_s7": 8.0e-3,       # measured 6.2e-3 (18 blocks x 3 branch GEMMs + 2 MLP GEMMs, logits only 0.44)
-    "cyclemlp_b1": 8.0e-3,  # measured 6.2e-3 (the same three-branch + reweight structure as ViP, 10 blocks)
-    "sparsemlp_t": 9.0e-3,  # measured 7.4e-3 (38 blocks)
-    "hiremlp_s": 9.0e-3,    # measured 7.6e-3 (37 blocks)
-    "msmlp_t": 1.0e-2,      # measured 1.53e-2 on max|ref| 1.90 (8.0e-3 relative): LayerNorm AFTER the pool rescales the error
+    # the one deep three-branch model whose reference cannot be run in 16 bit here (its torchvision stand-in builds the sampling grid in
+    # the input dtype): measured 6.2e-3 (the same three-branch + reweight structure as ViP, whose reference loses 9.3e-3 in bf16)
+    "cyclemlp_b1": 8.0e-3,
 }
 
 
 # Round 4: where the reference ITSELF was run in bf16 on the fixture's inputs (tests/golden/make_golden.py --only lowp -> real_lowp.json:
-# AS-MLP-T 9.7e-3 and gMLP-S 4.5e-3 away from its own fp32 logits), the gate is DERIVED -- 1.25 x the reference's own bf16 distance
-# (never below the 5e-3 rule) -- instead of a measured value plus head-room (round-3 review: AS-MLP-T passed 7.1e-3 against a tuned 8.0e-3).
+# AS-MLP-T 9.7e-3, gMLP-S 4.5e-3, ViP-S7 9.3e-3, Sparse-MLP 8.2e-3, Hire-MLP 6.3e-3, MS-MLP 2.0e-2 away from its own fp32 logits), the
+# gate is DERIVED -- 1.25 x the reference's own bf16 distance (never below the 5e-3 rule) -- instead of a measured value plus head-room
+# (round-3 review: AS-MLP-T passed 7.1e-3 against a tuned 8.0e-3).  Measured here against those gates: 7.3e-3 / 4.2e-3 / 8.7e-3 /
+# 6.8e-3 / 7.0e-3 / 1.7e-2 -- the kernels lose LESS than the reference's own bf16 forward on five of the six.
 with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "real_lowp.json")) as _f:
     REF_LOWP = json.load(_f)
 
@@ -242,7 +242,8 @@ BS256 = [
 # batch-independent to the bit.  Round 4: every tile of the library reduces its by-product LayerNorm statistics over planes of 32 columns in
 # ONE order (include/mlpk.h row_part), so the models whose LayerNorms read those statistics -- the Mixers since their token LayerNorm moved
 # into the token kernel -- are back in this set (round 3: sums over 32 / 64 / 128 columns "depending on the tile the batch size selects").
-BIT_EQUAL = {"resmlp_24", "asmlp_t", "convmixer_1536_20", "mixer_b16", "mixer_l16"}
+# (... and with them every other BASELINE configuration: gMLP-S, ViP-S7, S2-MLPv2 in both shift modes -- profiles/r04_bs256_parity.txt)
+BIT_EQUAL = {"resmlp_24", "asmlp_t", "convmixer_1536_20", "mixer_b16", "mixer_l16", "gmlp_s", "vip_s7", "s2mlpv2", "s2mlpv2_cleanshift"}
 
 
 @pytest.mark.parametrize("name,ctor,kw,k,family", BS256)
