@@ -45,6 +45,7 @@ struct GemmArgs {
     int vec_c, vec_r;   // vector (4-element) store / residual-load allowed
     // p8 launch (see gemm_nt_p8_kernel): row panels [m_base, m_base + panels * tile height), column groups
     int m_base, panels, cgroups;
+    int rev;            // p8: walk the row panels from the last to the first (tuning: MLPK_P8_REVERSE)
     void* prof_buf;     // MLPK_P8_PROF builds: per-workgroup cycle sums (reserved & 8)
     int dbg_delay;      // de-phase sleep, units of 8128 cycles
     int dbg_q4;         // tuning bits of the generated q4 kernels (desc.reserved bits 16..23)
@@ -1296,7 +1297,7 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, char* const smem) {
     auto setup = [&](const int li) {
         const int u = u0 + li;
         const int panel = __builtin_amdgcn_readfirstlane(u / cg_s);
-        m0 = p.m_base + panel * BM;
+        m0 = p.m_base + (p.rev ? p.panels - 1 - panel : panel) * BM;
         n0 = (ncol0 + (u - panel * cg_s)) * BN;
         tileA = reinterpret_cast<const char*>(p.A) + uniform64((size_t)m0 * p.lda * 2u);
         tileB = reinterpret_cast<const char*>(p.B) + uniform64((size_t)n0 * p.ldb * 2u);
@@ -1933,6 +1934,12 @@ static int gemm_prepare(const mlpk_gemm_desc* d, GemmArgs& a, int& algo, bool& t
     a.dbg_delay = (d->reserved >> 8) & 0xff;
     a.dbg_q4 = (d->reserved >> 16) & 0xff;
     a.m_base = 0; a.panels = 0; a.cgroups = 1; a.prof_buf = d->workspace;
+    {
+        // tuning (round 4): the persistent tile walks its row panels backwards when its A operand is larger than the Infinity Cache and was
+        // just written front to back by the previous kernel (channel-MLP fc2 reading the 308 MB hidden): the rows written last are read first
+        static const int rev_mode = getenv("MLPK_P8_REVERSE") ? atoi(getenv("MLPK_P8_REVERSE")) : 0;
+        a.rev = rev_mode == 2 || (rev_mode == 1 && (long long)d->M * d->K * es > (200ll << 20)) ? 1 : 0;
+    }
     a.row_part = d->row_part; a.row_part_ld = d->row_part_ld;
     const int vb = 4 * es;   // bytes of a 4-element vector
     a.vec_c = (d->ldc % 4 == 0) && (((uintptr_t)d->C % vb) == 0);
