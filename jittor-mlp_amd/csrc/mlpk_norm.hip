@@ -780,19 +780,43 @@ using namespace mlpk;
 // the tensor being normalised.
 // planar pairs of a GEMM's by-product statistics (mlpk.h row_part): pair (q, m) at part[(q * plane_stride + m) * 2].
 // group = 1: one thread per row, the planes read coalesced.
+template <int LPR>      // lanes per row: 1 (default) or 4 (MLPK_FINALIZE_LANES=4: A/B aid)
 __global__ void __launch_bounds__(256) stats_finalize_planar_kernel(const float* __restrict__ part, int64_t rows, int nplanes, int64_t plane_stride,
                                                                     float inv_count, float eps, float* __restrict__ mean, float* __restrict__ rstd) {
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= rows) return;
-    const f32x2* pp = reinterpret_cast<const f32x2*>(part) + r;
+    // LPR lanes per row, each adding a contiguous share of the planes (eight loads in flight), then (q0 + q1) + (q2 + q3).  Round 4 tried
+    // LPR = 4 against one thread per row (23 launches per Mixer forward, 59 per gMLP forward, 7-10 us each): measured NOT faster -- Mixer-B/16
+    // 7.600 vs 7.592 ms, gMLP-S 9.78 vs 9.67, ViP-S7 29.34 vs 29.32 (profiles/r04_finalize_lanes_ab.txt) -- the launches are bound by their
+    // launch latency, not by the chain of loads; one lane per row stays the default.
+    const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
+    const int sub = threadIdx.x % LPR;
+    const bool live = r < rows;
+    const f32x2* pp = reinterpret_cast<const f32x2*>(part) + (live ? r : rows - 1);
     // the planes are combined in fp64: with rows whose mean is large against their spread (deep residual streams) the fp32 form
     // S2 / n - mean^2 loses the variance to cancellation; what remains is the rounding of the per-plane fp32 sums themselves
+    const int per = (nplanes + LPR - 1) / LPR;
+    const int q0 = sub * per, q1 = q0 + per < nplanes ? q0 + per : nplanes;
     double s1 = 0.0, s2 = 0.0;
-    for (int q = 0; q < nplanes; ++q) {
+    int q = q0;
+    for (; q + 8 <= q1; q += 8) {
+        f32x2 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = pp[(int64_t)(q + k) * plane_stride];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s1 += (double)v[k].x; s2 += (double)v[k].y; }
+    }
+    for (; q < q1; ++q) {
         const f32x2 v = pp[(int64_t)q * plane_stride];
         s1 += (double)v.x;
         s2 += (double)v.y;
     }
+    // (q0 + q1) + (q2 + q3) over the four lanes of the row
+    if (LPR == 4) {
+        s1 += __shfl_xor(s1, 1);
+        s2 += __shfl_xor(s2, 1);
+        s1 += __shfl_xor(s1, 2);
+        s2 += __shfl_xor(s2, 2);
+    }
+    if (!live || sub) return;
     const double mu = s1 * (double)inv_count;
     double var = s2 * (double)inv_count - mu * mu;
     var = var > 0.0 ? var : 0.0;
@@ -865,8 +889,13 @@ extern "C" int mlpk_stats_finalize_planar(const float* part, int64_t rows, int n
     if ((uintptr_t)part & 7) return MLPK_EALIGN;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (group == 1) {
-        hipLaunchKernelGGL(stats_finalize_planar_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, part, rows, nplanes, plane_stride,
-                           1.0f / (float)count, eps, mean, rstd);
+        static const bool one_lane = !(getenv("MLPK_FINALIZE_LANES") && atoi(getenv("MLPK_FINALIZE_LANES")) == 4);
+        if (one_lane)
+            hipLaunchKernelGGL(stats_finalize_planar_kernel<1>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, part, rows, nplanes, plane_stride,
+                               1.0f / (float)count, eps, mean, rstd);
+        else
+            hipLaunchKernelGGL(stats_finalize_planar_kernel<4>, dim3((unsigned)((rows * 4 + 255) / 256)), dim3(256), 0, s, part, rows, nplanes, plane_stride,
+                               1.0f / (float)count, eps, mean, rstd);
     } else {
         hipLaunchKernelGGL(stats_finalize_group_kernel, dim3((unsigned)rows), dim3(256), 0, s, part, nplanes, plane_stride, group,
                            1.0 / (double)count, eps, mean, rstd);
