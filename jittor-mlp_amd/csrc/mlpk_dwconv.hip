@@ -10,6 +10,7 @@
 // Global traffic = x read once + out written once (the stencil re-reads stay in LDS).
 #include "mlpk_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace mlpk {
 
@@ -287,16 +288,45 @@ extern "C" int mlpk_dwconv_affine_nhwc(int dtype, const void* x, void* out, int 
 // 4 k MFMAs per 32 x 32 plane instead of k^2 = 81 VALU FMAs per output: 3.2x the arithmetic at 16x the rate, which takes the
 // kernel off the VALU wall (1.66 ms per ConvMixer-1536/20 layer, 39 TFLOP/s fp32) towards the HBM time of its 1.6 GB.
 // The taps are rounded to the activation dtype (they are MFMA operands); products and sums are fp32.
-//   * workgroup = 8 waves x CPW channels (CPW = 4 for k <= 5: 64 contiguous bytes of every channel-last pixel; 3 for k = 7, 9) x a
-//     range of images; a wave keeps the CPW k tap fragments of its channels in registers for the whole range;
-//   * LDS = 8 CPW planes (+ one all-zero plane for the fragment lanes that only meet zero taps) of [40 rows][40 columns] (80-byte rows: 16 consecutive rows fall on distinct banks for the 16-byte
-//     fragment reads), zeroed once; a plane is input AND output: when a channel's MFMAs are done its wave applies bias,
-//     exact GELU, BatchNorm scale / shift and the residual (the plane's own centre value) and writes the result in place;
+//   * workgroup = 8 waves x 4 channels x a range of images.  32 channels = 64 contiguous, 64-byte-ALIGNED bytes of every
+//     channel-last pixel: at 24 channels (48-byte pieces, what the register file holds at k = 9) the same data movement alone
+//     took 1.12 ms per ConvMixer-1536/20 layer against 0.40 ms at 32 (tools/gpu_dwconv_variants.sh, profiles/r04_dwconv_*):
+//     pieces that end inside a 64-byte sector reach HBM as partial writes;
+//   * a wave keeps the k tap fragments of CREG of its channels in registers for the whole range; those of the other 4 - CREG
+//     live in the LDS as a table of the 16 distinct lane patterns (+ one of zeros) per (channel, tap row) -- a fragment only
+//     depends on 8 (lane >> 4) - (lane & 15) -- and are read into registers channel by channel;
+//   * LDS = 32 planes (+ one all-zero plane for the fragment lanes that only meet zero taps) of [40 rows][40 columns] (80-byte rows)
+//     zeroed once; a plane is input AND output: when a channel's MFMAs are done its wave applies bias, GELU, BatchNorm
+//     scale / shift and the residual (the plane's own centre value) and writes the result in place;
+//   * a 16-byte fragment is read as TWO ds_read_b64, odd (lane >> 4) groups upper half first (the taps' fragments are stored in
+//     the same order): ds_read_b128 serves the lanes in groups of 16 that mix two (lane >> 4) values, whose 16-byte slots collide
+//     for any row pitch (2-way: SQ_LDS_BANK_CONFLICT was 48 % of the LDS cycles); ds_read_b64 serves 32 lanes per cycle from
+//     64 banks and the half swap puts the two (lane >> 4) values of a group on disjoint banks;
 //   * between two images every thread stores its 4 pixel-pair chunks (8 channels x 2 pixels, two 16-byte stores) and puts the
 //     next image's chunks (prefetched into registers during the MFMA phase) into the SAME dwords -- no double buffer, two
-//     barriers per image.
+//     barriers per image.  Every 8th plane starts 32 bytes later: the 4 chunks of a pixel pair (planes 8 apart) then fall
+//     on different banks in these 4-byte transposing accesses;
+//   * workgroups are dealt round-robin to the 8 XCDs, each with its own L2: the 8 workgroups of 8 NEIGHBOURING channel groups
+//     (4 whole 128-byte lines) go to ONE XCD at the same time, whose L2 then fetches a line once and writes whole lines back.
+#ifndef DWM_LOADS
+#define DWM_LOADS 3                                                 // experiment knobs of tools/gpu_dwconv_variants.sh
+#endif
+#ifndef DWM_CREG9
+#define DWM_CREG9 2
+#endif
+#ifndef DWM_CREG7
+#define DWM_CREG7 3
+#endif
+#ifndef DWM_XCD
+#define DWM_XCD 1
+#endif
+#ifndef DWM_SKIP
+#define DWM_SKIP 0                                                  // 1: no MFMA phase; 2: no global loads / stores; 4: no LDS transposes
+#endif
 constexpr int DWM_PITCH = 80;
 constexpr int DWM_PLANE = 40 * DWM_PITCH;
+constexpr int DWM_NPAT = 17;                                        // lane patterns of a tap fragment: 16 + all zeros
+__host__ __device__ constexpr int dwm_plane_off(int c) { return c * DWM_PLANE + (c >> 3) * 32; }
 
 template <typename T> struct Mfma16;
 template <> struct Mfma16<bf16_t> {
@@ -310,7 +340,27 @@ template <> struct Mfma16<f16_t> {
     }
 };
 
-template <typename T, int KS, int CPW, int NW>
+// A 16-byte fragment as two ds_read_b64 issued by hand (see the kernel's header): registers 0, 1 from `lo` + IMM, registers 2, 3
+// from `hi` + IMM, where lo / hi = the fragment's address + h0 / + 8 - h0.  The reads are asynchronous: the values may only be
+// used after a dwm_wait<N> that names them (N = LDS reads issued after theirs).  Inline assembly because hipcc pairs plain 8-byte
+// reads of two fragments into ds_read2_b64 (half the LDS rate) and then moves the halves between registers.
+struct DwmFrag { u32x2 lo, hi; };
+template <int IMM> static __device__ __forceinline__ void dwm_issue(DwmFrag& f, unsigned lo, unsigned hi) {
+    asm volatile("ds_read_b64 %0, %2 offset:%4\n\tds_read_b64 %1, %3 offset:%4" : "=&v"(f.lo), "=&v"(f.hi) : "v"(lo), "v"(hi), "i"(IMM));
+}
+template <int N> static __device__ __forceinline__ void dwm_wait(DwmFrag& a, DwmFrag& b) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi) : "i"(N));
+}
+static __device__ __forceinline__ void dwm_tie(DwmFrag& f) { asm volatile("" : "+v"(f.lo), "+v"(f.hi)); }   // "defined from here on"
+static __device__ __forceinline__ u32x4 dwm_val(const DwmFrag& f) { return u32x4{f.lo.x, f.lo.y, f.hi.x, f.hi.y}; }
+template <int I, int N, typename F> static __device__ __forceinline__ void dwm_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        dwm_for<I + 1, N>(f);
+    }
+}
+
+template <typename T, int KS, int CPW, int CREG, int NW, bool FULL>
 __global__ void __launch_bounds__(NW * 64) dwconv_mfma_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int H, int W, int C,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
                                                           const float* __restrict__ bns, const float* __restrict__ bnh, int img_per_wg) {
@@ -323,40 +373,93 @@ __global__ void __launch_bounds__(NW * 64) dwconv_mfma_kernel(const T* __restric
     constexpr int NT = NW * 64;
     constexpr int CH8 = CG / 8;                                     // 16-byte chunks per pixel
     constexpr int NSLOT = 512 * CH8 / NT;                           // (pixel pair, chunk) slots per thread
-    static_assert(CG % 8 == 0 && (512 * CH8) % NT == 0, "workgroup geometry");
-    const int c0 = blockIdx.x * CG;
-    const int b0 = blockIdx.y * img_per_wg;
+    constexpr int CLDS = CPW - CREG;                                // channels of a wave whose fragments live in the LDS
+    constexpr int PLANES_END = dwm_plane_off(CG) + DWM_PLANE;       // planes + the zero plane; the fragment tables follow
+    constexpr int TBL_WAVE = CLDS * KS * DWM_NPAT * 16;
+    static_assert(CG % 8 == 0 && (512 * CH8) % NT == 0 && CREG >= 0 && CREG <= CPW, "workgroup geometry");
+    static_assert(KS * KS * CG * 4 <= PLANES_END, "tap staging fits the planes");
+    int gx = blockIdx.x, gy = blockIdx.y;
+#if DWM_XCD
+    if (gridDim.x % 8 == 0 && (gridDim.x * gridDim.y) % 64 == 0) {     // (else the plain order: the deal below needs whole rounds)
+        const int id = blockIdx.x + gridDim.x * blockIdx.y;
+        const int xcd = id & 7, l = id >> 3;                        // l: this XCD's l-th workgroup
+        const int oct = (l >> 3) * 8 + xcd, octs = gridDim.x >> 3;  // octet = 8 neighbouring channel groups of one image range
+        gx = (oct % octs) * 8 + (l & 7);
+        gy = oct / octs;
+    }
+#endif
+    const int c0 = gx * CG;
+    const int b0 = gy * img_per_wg;
     const int b1 = b0 + img_per_wg < B ? b0 + img_per_wg : B;
     if (b0 >= B) return;
 
-    for (int i = tid * 16; i < (CG + 1) * DWM_PLANE; i += NT * 16) *reinterpret_cast<u32x4*>(smem + i) = u32x4{0u, 0u, 0u, 0u};
+    // ---- the workgroup's taps through the LDS first: [k * k][CG] floats, coalesced, before the planes are zeroed.  (Built from global
+    // memory directly, the 8 k CPW scalar loads of a lane came out of hipcc one at a time, an s_waitcnt vmcnt(0) between them.) ----
+    float* const wl = reinterpret_cast<float*>(smem);
+    for (int idx = tid; idx < KS * KS * CG; idx += NT) {
+        const int t = idx / CG, cc = idx - t * CG;
+        const bool live = c0 + cc < C;
+        const float tap = w[(size_t)t * C + (live ? c0 + cc : C - 1)];
+        wl[idx] = live ? tap : 0.f;
+    }
+    __syncthreads();
 
-    // ---- tap fragments: B operand of 16x16x32 = lane (n = lane & 15, kk = (lane >> 4) * 8 + e) ----
+    // ---- tap fragments: A operand of 16x16x32 = lane (n = lane & 15, kk = (lane >> 4) * 8 + e); element e of the fragment is
+    // tap d = E + e of the row with E = 8 kq - n + P - 4 (zero outside 0 <= d < k).  Odd kq: halves swapped (see dwm_read16). ----
     const int n = lane & 15;
     const int kq = lane >> 4;
-    u32x4 tf[CPW][KS];
+    const int h0 = (kq & 1) * 8;
+    const int eswap = (kq & 1) * 4;
+    u32x4 tf[CREG > 0 ? CREG : 1][KS];
     float bz[CPW], sc[CPW], sh[CPW];                                // wave-uniform: kept in SGPRs
 #pragma unroll
     for (int j = 0; j < CPW; ++j) {
         const int c = c0 + wave * CPW + j;
         const bool live = c < C;
+        if (j < CREG) {
 #pragma unroll
-        for (int i = 0; i < KS; ++i) {
-            T e[8];
+            for (int i = 0; i < KS; ++i) {
+                T e[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                // (unconditional loads from a clamped address + a select: no branch per tap)
-                const int d = kq * 8 + q - 4 - n + P;
-                const int dc = d < 0 ? 0 : (d >= KS ? KS - 1 : d);
-                const float tap = w[(size_t)(i * KS + dc) * C + (live ? c : C - 1)];
-                e[q] = from_f32<T>((live && d >= 0 && d < KS) ? tap : 0.f);
+                for (int q = 0; q < 8; ++q) {
+                    // (unconditional reads from a clamped address + a select: no branch per tap)
+                    const int d = kq * 8 + (q ^ eswap) - 4 - n + P;
+                    const int dc = d < 0 ? 0 : (d >= KS ? KS - 1 : d);
+                    const float tap = wl[(i * KS + dc) * CG + wave * CPW + j];
+                    e[q] = from_f32<T>((d >= 0 && d < KS) ? tap : 0.f);
+                }
+                __builtin_memcpy(&tf[j][i], e, 16);
             }
-            __builtin_memcpy(&tf[j][i], e, 16);
         }
-        bz[j] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (live && bias) ? bias[c] : 0.f)));
-        sc[j] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (live && bns) ? bns[c] : 1.f)));
-        sh[j] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (live && bnh) ? bnh[c] : 0.f)));
+        const int cl = live ? c : C - 1;
+        const float bzv = bias ? bias[cl] : 0.f, scv = bns ? bns[cl] : 1.f, shv = bnh ? bnh[cl] : 0.f;
+        bz[j] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, live ? bzv : 0.f)));
+        sc[j] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, live ? scv : 1.f)));
+        sh[j] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, live ? shv : 0.f)));
     }
+    // the table of this wave: [CLDS channels][k tap rows][17 patterns] x 16 bytes; pattern p < 16 holds taps d = p - 7 + e, e < 8
+    char* const tbl = smem + PLANES_END + wave * TBL_WAVE;
+    for (int idx = lane; idx < CLDS * KS * DWM_NPAT; idx += 64) {
+        const int ji = idx / DWM_NPAT, pat = idx - ji * DWM_NPAT;
+        const int jl = ji / KS, i = ji - jl * KS;
+        T e[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int d = pat - 7 + q;
+            const int dc = d < 0 ? 0 : (d >= KS ? KS - 1 : d);
+            const float tap = wl[(i * KS + dc) * CG + wave * CPW + CREG + jl];
+            e[q] = from_f32<T>((pat < 16 && d >= 0 && d < KS) ? tap : 0.f);
+        }
+        u32x4 v;
+        __builtin_memcpy(&v, e, 16);
+        *reinterpret_cast<u32x4*>(tbl + idx * 16) = v;
+    }
+    const int epat = 8 * kq - n + P - 4;                            // this lane's pattern: E in [-7, 8] -> E + 7, else the zeros
+    const unsigned tf_rd = (unsigned)(uintptr_t)(tbl + ((epat >= -7 && epat <= 8) ? epat + 7 : 16) * 16);
+    const unsigned tf_lo = tf_rd + h0, tf_hi = tf_rd + 8 - h0;
+    DwmFrag tfl[KS];                                                // the fragments of the channel at work when they are the table's
+    __syncthreads();                                                // every wave has its fragments: the taps' bytes become planes
+    for (int i = tid * 16; i < PLANES_END; i += NT * 16) *reinterpret_cast<u32x4*>(smem + i) = u32x4{0u, 0u, 0u, 0u};
 
     // ---- staging slots of this thread: slot = tid + NT q, q < NSLOT -> (pixel pair slot / CH8, 8-channel chunk slot % CH8):
     // consecutive lanes move the consecutive chunks of one pixel pair ----
@@ -370,24 +473,36 @@ __global__ void __launch_bounds__(NW * 64) dwconv_mfma_kernel(const T* __restric
     u32x4 r0[NSLOT], r1[NSLOT];
 #pragma unroll
     for (int q = 0; q < NSLOT; ++q) r0[q] = r1[q] = u32x4{0u, 0u, 0u, 0u};
+    // The loads are UNCONDITIONAL (an address clamped to the tensor's first bytes and a select): behind a branch each of them gets
+    // an s_waitcnt vmcnt(0) in front from hipcc, one memory latency after the other.  FULL (32 x 32 map, whole channel groups):
+    // no conditions at all.
+    auto gload_slot = [&](const int b, const int q) {
+        int cq, yy, xx;
+        slot_of(q, cq, yy, xx);
+        const T* src = x + (((size_t)b * H + yy) * W + xx) * C + c0 + 8 * cq;
+        if (FULL) {
+            r0[q] = *reinterpret_cast<const u32x4*>(src);
+            r1[q] = *reinterpret_cast<const u32x4*>(src + C);
+        } else {
+            const bool ok0 = c0 + 8 * cq < C && yy < H && xx < W;   // (C % 8 == 0: a chunk is whole or absent)
+            const bool ok1 = ok0 && xx + 1 < W;
+            const u32x4 a = *reinterpret_cast<const u32x4*>(ok0 ? src : x);
+            const u32x4 bb = *reinterpret_cast<const u32x4*>(ok1 ? src + C : x);
+            r0[q] = ok0 ? a : u32x4{0u, 0u, 0u, 0u};
+            r1[q] = ok1 ? bb : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
     auto gload = [&](const int b) {
 #pragma unroll
-        for (int q = 0; q < NSLOT; ++q) {
-            int cq, yy, xx;
-            slot_of(q, cq, yy, xx);
-            const bool cok = c0 + 8 * cq < C;                       // (C % 8 == 0: a chunk is whole or absent)
-            const T* src = x + (((size_t)b * H + yy) * W + xx) * C + c0 + 8 * cq;
-            if (cok && yy < H && xx < W) r0[q] = *reinterpret_cast<const u32x4*>(src);
-            if (cok && yy < H && xx + 1 < W) r1[q] = *reinterpret_cast<const u32x4*>(src + C);
-        }
+        for (int q = 0; q < NSLOT; ++q) gload_slot(b, q);
     };
     auto lds_put = [&]() {
 #pragma unroll
         for (int q = 0; q < NSLOT; ++q) {
             int cq, yy, xx;
             slot_of(q, cq, yy, xx);
-            if (!(c0 + 8 * cq < C && yy < H && xx < W)) continue;
-            char* dst = smem + (8 * cq) * DWM_PLANE + (yy + 4) * DWM_PITCH + (xx + 4) * 2;
+            if (!FULL && !(c0 + 8 * cq < C && yy < H && xx < W)) continue;
+            char* dst = smem + dwm_plane_off(8 * cq) + (yy + 4) * DWM_PITCH + (xx + 4) * 2;
             const unsigned a[4] = {r0[q].x, r0[q].y, r0[q].z, r0[q].w}, bb[4] = {r1[q].x, r1[q].y, r1[q].z, r1[q].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -398,49 +513,76 @@ __global__ void __launch_bounds__(NW * 64) dwconv_mfma_kernel(const T* __restric
         }
     };
     // fragment reads: lane = (row m = lane & 15, 8 columns at kq * 8); the last column group (kk >= 24) only meets zero taps and
-    // would run past the plane row for the right-hand blocks: it reads the zero halo row 0 instead
-    const int a_rd = kq < 3 ? (n + 4 - P) * DWM_PITCH + kq * 16 : 0;
-    const char* const zplane = smem + CG * DWM_PLANE;               // one more plane that is never written: all zeros
+    // would run past the plane row for the right-hand blocks: it reads the zero plane instead (at the 16-byte slot a kq = 2 lane
+    // would read: a bank none of its group's other lanes is on)
+    const int a_rd = (n + 4 - P) * DWM_PITCH + (kq < 3 ? kq : 2) * 16;
+    const char* const zplane = smem + dwm_plane_off(CG);            // one more plane that is never written: all zeros
 
     gload(b0);
     __syncthreads();                                                // planes zeroed
     lds_put();
     for (int b = b0; b < b1; ++b) {
-        if (b + 1 < b1) gload(b + 1);
+#if DWM_LOADS != 3
+        if (!(DWM_SKIP & 2) && b + 1 < b1) gload(b + 1);
+#endif
         __syncthreads();                                            // image b is in the planes
 #pragma unroll
-        for (int j = 0; j < CPW; ++j) {
-            char* const plane = smem + (wave * CPW + j) * DWM_PLANE;
-            const char* const ab = (kq < 3 ? plane : zplane) + a_rd;
-            f32x4 res[2][2];
-            // the upper and the lower 16 rows one after the other (8 accumulators + two pairs of fragments live at a time)
+        for (int j = 0; j < ((DWM_SKIP & 1) ? 0 : CPW); ++j) {
+#if DWM_LOADS == 3
+            if (b + 1 < b1) {
 #pragma unroll
-            for (int ty = 0; ty < 2; ++ty) {
-                const char* const at = ab + ty * (16 * DWM_PITCH);
-                f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-                // one tap row ahead: the fragment reads of row i + 1 are in flight under the MFMAs of row i (pinned: left to
-                // itself hipcc hoists all the reads of a channel in front of its MFMAs and spills)
-                u32x4 av[2][2];
-                av[0][0] = *reinterpret_cast<const u32x4*>(at);
-                av[0][1] = *reinterpret_cast<const u32x4*>(at + 32);
-#pragma unroll
-                for (int i = 0; i < KS; ++i) {
-                    if (i + 1 < KS) {
-                        av[(i + 1) & 1][0] = *reinterpret_cast<const u32x4*>(at + (i + 1) * DWM_PITCH);
-                        av[(i + 1) & 1][1] = *reinterpret_cast<const u32x4*>(at + (i + 1) * DWM_PITCH + 32);
-                    }
-                    // operands swapped (taps as A, plane rows as B): the accumulator then holds 4 consecutive x of ONE row per lane
-                    // -- 8 contiguous bytes of the plane -- instead of 4 rows of one column
-                    acc[0] = Mfma16<T>::run(tf[j][i], av[i & 1][0], acc[0]);
-                    acc[1] = Mfma16<T>::run(tf[j][i], av[i & 1][1], acc[1]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                // epilogue: acc[tx][r] = out[y = 16 ty + n][x = 16 tx + 4 kq + r]; results go back into the plane.  (The rows this
-                // half writes, 16 ty .. 16 ty + 15, are read again by the OTHER half's fragments only through tap rows that
-                // reach across the boundary -- so both halves' MFMAs must be done before any result is written: see below.)
-#pragma unroll
-                for (int tx = 0; tx < 2; ++tx) res[ty][tx] = acc[tx];
+                for (int q = j * NSLOT / CPW; q < (j + 1) * NSLOT / CPW; ++q) gload_slot(b + 1, q);
             }
+#endif
+            char* const plane = smem + dwm_plane_off(wave * CPW + j);
+            const unsigned ab = (unsigned)(uintptr_t)((kq < 3 ? plane : zplane) + a_rd);
+            const unsigned alo = ab + h0, ahi = ab + 8 - h0;
+            if (j >= CREG) {                                        // this channel's fragments were requested before the last epilogue
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                dwm_for<0, KS>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    dwm_tie(tfl[i]);
+                });
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (counted waits below: nothing else may be in flight)
+            }
+            // 2 k steps (the upper 16 rows' tap rows, then the lower 16 rows'), the plane rows of step s + 1 requested before the
+            // MFMAs of step s.  Operands swapped (taps as A, plane rows as B): the accumulator then holds 4 consecutive x of ONE
+            // row per lane -- 8 contiguous bytes of the plane -- instead of 4 rows of one column.
+            f32x4 res[2][2];
+            DwmFrag av[2][2];
+            dwm_issue<0>(av[0][0], alo, ahi);
+            dwm_issue<32>(av[0][1], alo, ahi);
+            dwm_for<0, 2 * KS>([&](auto sc) {
+                constexpr int st = decltype(sc)::value, ty = st / KS, i = st - ty * KS;
+                if constexpr (st + 1 < 2 * KS) {
+                    constexpr int ty1 = (st + 1) / KS, i1 = st + 1 - ty1 * KS, off = ty1 * (16 * DWM_PITCH) + i1 * DWM_PITCH;
+                    dwm_issue<off>(av[(st + 1) & 1][0], alo, ahi);
+                    dwm_issue<off + 32>(av[(st + 1) & 1][1], alo, ahi);
+                    dwm_wait<4>(av[st & 1][0], av[st & 1][1]);
+                } else {
+                    dwm_wait<0>(av[st & 1][0], av[st & 1][1]);
+                }
+                const u32x4 tfi = j < CREG ? tf[j < CREG ? j : 0][i] : dwm_val(tfl[i]);
+                if constexpr (i == 0) {
+                    res[ty][0] = Mfma16<T>::run(tfi, dwm_val(av[st & 1][0]), f32x4{0.f, 0.f, 0.f, 0.f});
+                    res[ty][1] = Mfma16<T>::run(tfi, dwm_val(av[st & 1][1]), f32x4{0.f, 0.f, 0.f, 0.f});
+                } else {
+                    res[ty][0] = Mfma16<T>::run(tfi, dwm_val(av[st & 1][0]), res[ty][0]);
+                    res[ty][1] = Mfma16<T>::run(tfi, dwm_val(av[st & 1][1]), res[ty][1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            // the next channel's fragments out of the table, under this channel's epilogue
+            if (j + 1 >= CREG && j + 1 < CPW) {
+                dwm_for<0, KS>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    dwm_issue<0>(tfl[i], tf_lo + ((j + 1 - CREG) * KS + i) * (DWM_NPAT * 16), tf_hi + ((j + 1 - CREG) * KS + i) * (DWM_NPAT * 16));
+                });
+            }
+            // epilogue: res[ty][tx][r] = out[y = 16 ty + n][x = 16 tx + 4 kq + r]; results go back into the plane.  (The rows one half
+            // writes are read by the OTHER half's fragments through the tap rows that reach across the boundary: both halves'
+            // MFMAs are done before any result is written.)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const f32x4 a4 = res[t >> 1][t & 1];
@@ -455,7 +597,7 @@ __global__ void __launch_bounds__(NW * 64) dwconv_mfma_kernel(const T* __restric
                 T o4[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o4[r] = from_f32<T>(to_f32(c4[r]) + g[r] * sc[j] + sh[j]);
-                if (y < H && x0 + 3 < W) {                          // never write outside the map: the halo must stay zero
+                if (FULL || (y < H && x0 + 3 < W)) {                // never write outside the map: the halo must stay zero
                     u32x2 ow;
                     __builtin_memcpy(&ow, o4, 8);
                     *reinterpret_cast<u32x2*>(cell) = ow;
@@ -469,11 +611,11 @@ __global__ void __launch_bounds__(NW * 64) dwconv_mfma_kernel(const T* __restric
         __syncthreads();                                            // results of image b are in the planes
         // ---- results out (two 16-byte stores per slot), next image in (same dwords) ----
 #pragma unroll
-        for (int q = 0; q < NSLOT; ++q) {
+        for (int q = 0; q < ((DWM_SKIP & 4) ? 0 : NSLOT); ++q) {
             int cq, yy, xx;
             slot_of(q, cq, yy, xx);
-            if (!(c0 + 8 * cq < C && yy < H && xx < W)) continue;
-            const char* src = smem + (8 * cq) * DWM_PLANE + (yy + 4) * DWM_PITCH + (xx + 4) * 2;
+            if (!FULL && !(c0 + 8 * cq < C && yy < H && xx < W)) continue;
+            const char* src = smem + dwm_plane_off(8 * cq) + (yy + 4) * DWM_PITCH + (xx + 4) * 2;
             unsigned d[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) d[j] = *reinterpret_cast<const unsigned*>(src + j * DWM_PLANE);
@@ -483,39 +625,51 @@ __global__ void __launch_bounds__(NW * 64) dwconv_mfma_kernel(const T* __restric
             o0.z = __builtin_amdgcn_perm(d[5], d[4], 0x05040100); o1.z = __builtin_amdgcn_perm(d[5], d[4], 0x07060302);
             o0.w = __builtin_amdgcn_perm(d[7], d[6], 0x05040100); o1.w = __builtin_amdgcn_perm(d[7], d[6], 0x07060302);
             T* dstg = out + (((size_t)b * H + yy) * W + xx) * C + c0 + 8 * cq;
-            *reinterpret_cast<u32x4*>(dstg) = o0;
-            if (xx + 1 < W) *reinterpret_cast<u32x4*>(dstg + C) = o1;
+#if DWM_SKIP & 2
+            if (o0.x == 0x12345678u && b == -1)
+#endif
+            {
+                *reinterpret_cast<u32x4*>(dstg) = o0;
+                if (FULL || xx + 1 < W) *reinterpret_cast<u32x4*>(dstg + C) = o1;
+            }
         }
-        if (b + 1 < b1) lds_put();
+        if (!(DWM_SKIP & 4) && b + 1 < b1) lds_put();
     }
 }
 
 template <typename T>
 static int dwconv_mfma_launch(int k, const void* x, void* out, int B, int H, int W, int C, const float* w, const float* bias,
                               const float* bns, const float* bnh, hipStream_t s) {
-    // Channels per workgroup: k <= 5: 8 waves x 4 channels = 32 (64 contiguous bytes of every pixel); k = 7, 9: 8 waves x 3 = 24
-    // (what 256 registers hold next to 4 k registers of tap fragments per channel).  Measured on ConvMixer-1536/20 (k = 9, per
-    // layer): 8 x 3: 0.96 ms; 4 waves x 8 channels with the whole 512-register file per wave (sector-aligned 64-byte pieces, but
-    // one wave per SIMD): 1.33 ms; 8 waves x 1 channel (16-byte pieces): 1.41 ms; the VALU stencil it replaces: 1.66 ms.
-    const int cpw = k <= 5 ? 4 : 3;
-    const int cg = 8 * cpw;
+    // 8 waves x 4 channels = 32 channels per workgroup (64 aligned bytes of every pixel); fragments of 2 (k = 9) or 3 (k = 7) of a
+    // wave's channels in registers, the others' in the LDS.  History on ConvMixer-1536/20 (k = 9, per layer): 8 x 3 channels, all
+    // fragments in registers (48-byte pieces): 0.88 ms; 4 waves x 8 channels with the whole 512-register file per wave: 1.33 ms;
+    // 8 waves x 1 channel (16-byte pieces): 1.41 ms; the VALU stencil it replaces: 1.66 ms.
+    constexpr int cpw = 4, cg = 8 * cpw;
+    const int creg = k <= 5 ? 4 : (k == 7 ? DWM_CREG7 : DWM_CREG9);
     const int groups = (C + cg - 1) / cg;
-    // images per workgroup: enough to amortise the fragment build (about one image's worth of work), few enough to fill the chip
-    int per = 32;
-    while (per > 4 && (long long)groups * ((B + per - 1) / per) < 512) per /= 2;
+    // images per workgroup: rounds of 256 workgroups x (images + about 2 images' worth of set-up: taps, fragments, zeroing) -- the
+    // fewest image-times wins (1536 channels, 256 images: 48 groups x 16 ranges of 16 = 3 whole rounds)
+    int per = 4;
+    long long best = -1;
+    for (int cand = 32; cand >= 4; cand /= 2) {
+        const long long wgs = (long long)groups * ((B + cand - 1) / cand);
+        const long long cost = ((wgs + 255) / 256) * (cand + 2);
+        if (best < 0 || cost < best) best = cost, per = cand;
+    }
     const dim3 grid((unsigned)groups, (unsigned)((B + per - 1) / per));
-    const int lds = (cg + 1) * DWM_PLANE;
+    const int lds = dwm_plane_off(cg) + DWM_PLANE + 8 * (cpw - creg) * k * DWM_NPAT * 16;
+    const bool full = H == 32 && W == 32 && C % cg == 0;
     hipError_t e = hipSuccess;
-#define DWM_CASE(KS, CPW, NW)                                                                                          \
+#define DWM_CASE(KS, CREG)                                                                                              \
     case KS: {                                                                                                         \
-        auto kern = dwconv_mfma_kernel<T, KS, CPW, NW>;                                                                \
+        auto kern = full ? dwconv_mfma_kernel<T, KS, cpw, CREG, 8, true> : dwconv_mfma_kernel<T, KS, cpw, CREG, 8, false>; \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
         if (e != hipSuccess) return (int)e;                                                                            \
-        hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, (const T*)x, (T*)out, B, H, W, C, w, bias, bns, bnh, per); \
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, (const T*)x, (T*)out, B, H, W, C, w, bias, bns, bnh, per);   \
         break;                                                                                                         \
     }
     switch (k) {
-        DWM_CASE(3, 4, 8) DWM_CASE(5, 4, 8) DWM_CASE(7, 3, 8) DWM_CASE(9, 3, 8)
+        DWM_CASE(3, 4) DWM_CASE(5, 4) DWM_CASE(7, DWM_CREG7) DWM_CASE(9, DWM_CREG9)
         default: return DW_NOFIT;
     }
 #undef DWM_CASE
