@@ -43,6 +43,7 @@
  *   mlpk_norm_shift_nhwc  AxialShift's GroupNorm + GELU + both shifts as one index-remapping pass (as_mlp.py:64-66,84-95)
  *   mlpk_as_conv2       AxialShift's core in ONE kernel: GroupNorm + GELU, both axial shifts, conv2_1 and conv2_2 with their GELUs and the sum
  *                       (as_mlp.py:64-66,84-93; utils/shift_cuda.py:49-69): the shifts are LDS read addresses of the MFMA operands
+ *   mlpk_channel_mlp    fc1 + GELU + fc2 + residual of a channel MLP on narrow (C <= 192) channel-last rows in ONE kernel (as_mlp.py:36-52)
  *   mlpk_cycle_shift    the sampling half of CycleFC (cycle_mlp.py:104-131: deform_conv2d with a 1 x 1 kernel and fixed integer
  *                       offsets = a per-channel cyclic pixel shift with zero fill); the 1 x 1 convolution is mlpk_gemm_nt
  *   mlpk_split_sum      the reduction of SplitAttention (vip.py:49-50; s2_mlp_v2.py:43-44), with the
@@ -364,6 +365,27 @@ int mlpk_as_conv2_supported(int dtype, int H, int W, int C, int kernel_size);
 int mlpk_as_conv2(int dtype, const void* t, void* y, int B, int H, int W, int C, int kernel_size, const float* mean, const float* rstd,
                   const float* gamma, const float* beta, const void* w1, const float* b1, const void* w2, const float* b2, int ldw,
                   void* stream);
+
+/* ---- fused channel MLP for narrow channel-last tensors (ABI 8, round 4) -------------------------------------------------------
+ * out[m, :] = R[m, :] + W2 . gelu( W1 . norm(x[m, :]) + b1 ) + b2      (as_mlp.py:36-52 with :343-344; the Mlp / FeedForward of every
+ * hierarchical family while its stage is at most 192 channels wide): both products, the GELU and the residual in ONE kernel, the
+ * hidden (M x 4C) never written.  16-bit dtypes, C % 32 == 0, 64 <= C <= 192, hidden = 32 nchunks <= 1024.
+ *   x (M, ldx), R (M, ldr) or NULL, out (M, ldo) -- out may be x and / or R (a workgroup reads its 256 rows before it writes them);
+ *   norm: ln_mean / ln_rstd NULL = none; else statistic m / ln_group of row m (LayerNorm: ln_group = 1; GroupNorm(1, C): H*W) applied
+ *     on the first accumulator as in mlpk_gemm_nt: v = (acc - mean * csum[h]) * rstd + b1[h] with gamma folded into w1, beta into b1,
+ *     csum[h] = the row sums of the rounded folded w1 (nchunks*32 floats, zero-padded);
+ *   w1 (nchunks*32, ldw1 = 256): hidden rows, K zero-padded to 256 (the W1 of mlpk_token_mlp); b1 (nchunks*32);
+ *   w2 (C, ldw2 >= nchunks*32), zero-padded, with
+ *     - the COLUMN order of mlpk_token_mlp's layout 1 inside every group of 32 hidden units: slot 8 f + e <- unit (e < 4 ? 4 f + e : 16 + 4 f + e - 4),
+ *     - the ROW order: inside every group of 32 output channels, row 16 h + 4 f + r (h < 2, f < 4, r < 4) <- channel 8 f + 4 h + r
+ *       (a lane's accumulators are then 8 consecutive channels of one row: 16-byte stores straight from the registers);
+ *   b2 (C) in natural channel order.
+ * Numerics: fp32 accumulation in K order starting from R + b2; GELU and roundings as in the GEMM epilogues (one rounding of the hidden
+ * to the storage type, one of the result). */
+int mlpk_channel_mlp_supported(int dtype, int C, int hidden);
+int mlpk_channel_mlp(int dtype, const void* x, int ldx, int M, int C, const float* ln_mean, const float* ln_rstd, int ln_group,
+                     const float* csum, const void* w1, int ldw1, const float* b1, const void* w2, int ldw2, const float* b2,
+                     int nchunks, const void* R, int ldr, void* out, int ldo, void* stream);
 /* ---- CycleFC sampling (CycleMLP) ---------------------------------------------------------------
  * in: (B,H,W,C) channel-last with pixel stride ldi.  d(c) = (c + k/2) % k - k/2  (gen_offset, cycle_mlp.py:104-120):
  *   out_h[b,y,x,c] = in[b, y, x + d(c), c]     the operand of `sfc_h` = CycleFC(kernel (1,k))

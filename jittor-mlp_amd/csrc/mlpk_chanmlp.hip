@@ -1,0 +1,387 @@
+// Fused channel MLP for NARROW channel-last tensors (the first stages of the hierarchical families: AS-MLP as_mlp.py:36-52 with
+// C = 96 / 192, Swin-MLP, MS-MLP, Hire-MLP, CycleMLP, Sparse-MLP with C = 64 .. 192):
+//
+//     out[m, :] = R[m, :] + W2 . gelu( W1 . norm(x[m, :]) + b1 ) + b2          x, out, R: (M, C) rows; hidden = 4 C (<= 1024)
+//
+// As two GEMMs this is memory-bound on the HIDDEN tensor: at AS-MLP-T's first stage (802816 rows x 96 channels, 256 images) fc1
+// writes and fc2 reads 617 MB for a 154 MB activation -- 259 + 219 us per block against 75 us for reading x and writing out once.
+// Here the hidden never leaves the registers.  The machinery is the token-mixing kernel's (token_mlp_rr_kernel, mlpk_tokenmlp.hip):
+//   * persistent workgroups of 8 waves walking 256-row tiles; a wave owns 32 rows, keeps their C channels in registers as MFMA
+//     operands and runs fc1 -> GELU -> fc2 for them itself over the groups of 32 hidden units;
+//   * fc1 with swapped operands (hidden x rows) leaves lane (row, fg) holding hidden units {4 fg + r} and {16 + 4 fg + r} of a group:
+//     after bias + GELU + rounding those eight values ARE one 16x16x32 operand fragment of fc2, provided W2's columns are stored in
+//     that order inside every group of 32 (layout 1 of mlpk_token_mlp_layout): nothing is exchanged between lanes or waves;
+//   * fc2 ALSO with swapped operands (output channels x rows): a lane's accumulators are then consecutive output channels of ONE
+//     row, and with W2's ROWS stored in the order [32 q + 8 fg + 4 (j & 1) + r  at  32 q + 16 (j & 1) + 4 fg + r] the two blocks
+//     j = 2q, 2q + 1 give a lane 8 consecutive channels: the epilogue is one 16-byte store per (row, 8 channels), 64 contiguous
+//     bytes per 4 lanes, straight from the accumulators -- no LDS staging, no barrier.  The accumulators START from R + b2;
+//   * the normalisation in front (LayerNorm, or GroupNorm(1, C) with one statistic per ln_group rows) is folded as in mlpk_gemm_nt:
+//     gamma in W1, beta in b1, v = (acc - mean * csum[h]) * rstd + b1[h] in the GELU stage;
+//   * the two waves of a SIMD are skewed by half an iteration (one in its matrix phase while the other runs GELU); W1 groups and
+//     W2 slabs stream through 3- and 4-stage LDS rings by LDS-DMA two iterations ahead, PPW one-KiB pieces per wave and iteration,
+//     one barrier per iteration.
+// LDS: 3 x (C / 16) KiB + 4 x (C / 16) KiB + 4 (b1) + 4 (csum) + 1 (b2) KiB = 93 KiB at C = 192.
+#include "mlpk_common.h"
+#include <cstdlib>
+
+namespace mlpk {
+
+struct ChanMlpArgs {
+    const void* x;          // (M, ldx) operand rows
+    const void* w1;         // (G*32, 256): hidden rows, K zero-padded to 256 (pack_token_mlp's W1)
+    const void* w2;         // (C, ldw2 >= G*32): rows and columns in the orders described above
+    const float* b1;        // (G*32)
+    const float* csum;      // (G*32) row sums of the folded W1, or NULL (no normalisation)
+    const float* b2;        // (C) in W2's row order
+    const float* ln_mean;   // statistic s = m / ln_group
+    const float* ln_rstd;
+    const void* R;          // (M, ldr) or NULL
+    void* out;              // (M, ldo)
+    int M, G, ldx, ldw2, ldr, ldo, ln_group;
+};
+
+static __device__ __forceinline__ void cm_glds(unsigned voff, const void* sbase, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+
+template <typename T> struct CmMma;
+template <> struct CmMma<bf16_t> {
+    static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct CmMma<f16_t> {
+    static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+template <bool B> struct CmBool { static constexpr bool value = B; };
+
+constexpr int CM_BM = 256;
+constexpr int CM_HID_MAX = 1024;
+
+template <int KS1, int NB> struct CmGeo {
+    static constexpr int N1 = 2 * KS1;                      // W1 pieces per group: plane kk, halves of 16 rows
+    static constexpr int P = N1 + NB;                       // + W2 pieces: 16 output channels each
+    static constexpr int PPW = (P + 7) / 8;                 // pieces per wave and iteration (the last ones issued twice)
+    static constexpr int ST1 = N1 * 1024, ST2 = NB * 1024;
+    static constexpr int R1 = 0, R2 = 3 * ST1;
+    static constexpr int B1 = R2 + 4 * ST2;
+    static constexpr int CS = B1 + CM_HID_MAX * 4;
+    static constexpr int B2 = CS + CM_HID_MAX * 4;
+    static constexpr int LDS = B2 + 16 * NB * 4;
+};
+
+template <typename T, int KS1, int NB>
+__global__ void __launch_bounds__(512, 1) chan_mlp_kernel(const ChanMlpArgs p) {
+    using Geo = CmGeo<KS1, NB>;
+    constexpr int PPW = Geo::PPW, N1 = Geo::N1, P = Geo::P;
+    constexpr int C = 16 * NB;
+    static_assert(NB == 2 * KS1, "C = 32 KS1 = 16 NB");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool lag = wave >= 4;                            // the half that runs gelu / fc2 one iteration late
+    const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+    const T* __restrict__ w1 = reinterpret_cast<const T*>(p.w1);
+    const T* __restrict__ w2 = reinterpret_cast<const T*>(p.w2);
+    const T* __restrict__ R = reinterpret_cast<const T*>(p.R);
+    T* __restrict__ out = reinterpret_cast<T*>(p.out);
+    const int G = p.G;
+    const int ntiles = (p.M + CM_BM - 1) / CM_BM;
+    const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)smem;
+    float* const b1s = reinterpret_cast<float*>(smem + Geo::B1);
+    float* const css = reinterpret_cast<float*>(smem + Geo::CS);
+    float* const b2s = reinterpret_cast<float*>(smem + Geo::B2);
+    const bool fold = p.ln_mean != nullptr;
+
+    // (every per-lane quantity the iterations use is re-derived from an opaque copy of the lane id: see token_mlp_rr_kernel)
+    auto lane_now = [&]() {
+        unsigned l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return (int)l;
+    };
+    // ---- LDS-DMA pieces: wave w issues q = PPW w + pi (clamped to P - 1); q < N1: W1 piece (plane q >> 1, rows 16 (q & 1) ..),
+    // else W2 piece q - N1 (output channels 16 (q - N1) ..) ----
+    unsigned pdst[PPW];
+#pragma unroll
+    for (int pi = 0; pi < PPW; ++pi) {
+        int q = wave * PPW + pi;
+        q = q < P ? q : P - 1;
+        pdst[pi] = __builtin_amdgcn_readfirstlane(q < N1 ? lds_base + Geo::R1 + q * 1024 : lds_base + Geo::R2 + (q - N1) * 1024);
+    }
+    auto piece_off = [&](const int pi, const int ln) {
+        int q = wave * PPW + pi;
+        q = q < P ? q : P - 1;
+        const int lrow = ln >> 2;
+        const int lchunk = (ln & 3) ^ ((lrow & 8) >> 2);
+        unsigned o;
+        if (q < N1) o = (unsigned)(((q & 1) * 16 + lrow) * 256 + (q >> 1) * 32 + lchunk * 8) * (unsigned)sizeof(T);
+        else o = (unsigned)(((q - N1) * 16 + lrow) * p.ldw2 + lchunk * 8) * (unsigned)sizeof(T);
+        return o;
+    };
+    const T* pb1 = w1;
+    const T* pb2 = w2;
+    unsigned so1 = 0, so2 = 0;
+    auto piece_bases = [&](const int g) {
+        pb1 = w1 + (size_t)g * (32 * 256);
+        pb2 = w2 + g * 32;
+    };
+    auto issue = [&](const int pi, const int ln) {
+        int q = wave * PPW + pi;
+        q = q < P ? q : P - 1;
+        const bool is1 = q < N1;
+        cm_glds(piece_off(pi, ln), is1 ? pb1 : pb2, pdst[pi] + __builtin_amdgcn_readfirstlane(is1 ? so1 : so2));
+    };
+    unsigned s3 = 0, s4 = 0;                               // iteration counter modulo the ring sizes (W1: 3 stages, W2: 4)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        piece_bases(it < G ? it : it - G);
+        so1 = (unsigned)it * Geo::ST1;
+        so2 = (unsigned)it * Geo::ST2;
+#pragma unroll
+        for (int pi = 0; pi < PPW; ++pi) issue(pi, lane);
+    }
+    if (lag) __builtin_amdgcn_s_setprio(2);
+
+    for (int i = tid; i < G * 32; i += 512) {
+        b1s[i] = p.b1[i];
+        css[i] = fold ? p.csum[i] : 0.f;
+    }
+    if (tid < C) b2s[tid] = p.b2[tid];
+    __syncthreads();
+
+    u32x4 xa[2][KS1], rr[2][KS1];
+    float lmu[2], lrs[2];
+    auto load_tile = [&](const int tile, const int ln) {     // operand rows, residual rows, row statistics of a tile
+        const int frow = ln & 15, fg = ln >> 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int gm = tile * CM_BM + wave * 32 + i * 16 + frow;
+            gm = gm < p.M ? gm : p.M - 1;
+#pragma unroll
+            for (int kk = 0; kk < KS1; ++kk) xa[i][kk] = *reinterpret_cast<const u32x4*>(x + (size_t)gm * p.ldx + kk * 32 + fg * 8);
+#pragma unroll
+            for (int kk = 0; kk < KS1; ++kk)
+                rr[i][kk] = R ? *reinterpret_cast<const u32x4*>(R + (size_t)gm * p.ldr + kk * 32 + fg * 8) : u32x4{0u, 0u, 0u, 0u};
+            lmu[i] = fold ? p.ln_mean[gm / p.ln_group] : 0.f;
+            lrs[i] = fold ? p.ln_rstd[gm / p.ln_group] : 1.f;
+        }
+    };
+
+    f32x4 acc2[2][NB];
+    f32x4 a1[2][2];
+    auto frag_off = [&](const int ln) {
+        const int fr = ln & 15;
+        return fr * 64 + (((ln >> 4) ^ ((fr & 8) >> 2)) << 4);
+    };
+    auto fc1 = [&](const unsigned st3, const int ln) {
+        const int f_rd = frag_off(ln);
+        const char* r1 = smem + Geo::R1 + st3 * Geo::ST1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) a1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int BWD = KS1 < 3 ? KS1 : 3;              // fragment pairs read ahead of their MFMAs, pinned there
+        u32x4 bw[BWD + 1][2];
+#pragma unroll
+        for (int kk = 0; kk < BWD; ++kk) {
+            bw[kk][0] = *reinterpret_cast<const u32x4*>(r1 + kk * 2048 + f_rd);
+            bw[kk][1] = *reinterpret_cast<const u32x4*>(r1 + kk * 2048 + f_rd + 1024);
+        }
+#pragma unroll
+        for (int kk = 0; kk < KS1; ++kk) {
+            if (kk + BWD < KS1) {
+                bw[(kk + BWD) % (BWD + 1)][0] = *reinterpret_cast<const u32x4*>(r1 + (kk + BWD) * 2048 + f_rd);
+                bw[(kk + BWD) % (BWD + 1)][1] = *reinterpret_cast<const u32x4*>(r1 + (kk + BWD) * 2048 + f_rd + 1024);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a1[i][0] = CmMma<T>::run(bw[kk % (BWD + 1)][0], xa[i][kk], a1[i][0]);
+                a1[i][1] = CmMma<T>::run(bw[kk % (BWD + 1)][1], xa[i][kk], a1[i][1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    u32x4 hf[2];
+    auto gelu = [&](const int g, const int ln) {           // (folded norm,) bias, GELU, rounding: acc1 -> the two operand fragments of fc2
+        const int fg = ln >> 4;
+        const f32x4 bb0 = *reinterpret_cast<const f32x4*>(b1s + g * 32 + 4 * fg);
+        const f32x4 bb1 = *reinterpret_cast<const f32x4*>(b1s + g * 32 + 16 + 4 * fg);
+        const f32x4 cs0 = *reinterpret_cast<const f32x4*>(css + g * 32 + 4 * fg);
+        const f32x4 cs1 = *reinterpret_cast<const f32x4*>(css + g * 32 + 16 + 4 * fg);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float mu = lmu[i], rs = lrs[i];
+            f32x2 v[4] = {f32x2{(a1[i][0].x - mu * cs0.x) * rs + bb0.x, (a1[i][0].y - mu * cs0.y) * rs + bb0.y},
+                          f32x2{(a1[i][0].z - mu * cs0.z) * rs + bb0.z, (a1[i][0].w - mu * cs0.w) * rs + bb0.w},
+                          f32x2{(a1[i][1].x - mu * cs1.x) * rs + bb1.x, (a1[i][1].y - mu * cs1.y) * rs + bb1.y},
+                          f32x2{(a1[i][1].z - mu * cs1.z) * rs + bb1.z, (a1[i][1].w - mu * cs1.w) * rs + bb1.w}};
+            gelu_pk_n<T, 4>(v);
+            T e[8] = {from_f32<T>(v[0].x), from_f32<T>(v[0].y), from_f32<T>(v[1].x), from_f32<T>(v[1].y),
+                      from_f32<T>(v[2].x), from_f32<T>(v[2].y), from_f32<T>(v[3].x), from_f32<T>(v[3].y)};
+            __builtin_memcpy(&hf[i], e, 16);
+        }
+    };
+    auto fc2 = [&](const unsigned st4, const int ln) {
+        const int f_rd = frag_off(ln);
+        const char* r2 = smem + Geo::R2 + st4 * Geo::ST2;
+        constexpr int BFD = NB < 4 ? NB : 4;                // W2 fragments read ahead of their MFMAs
+        u32x4 bf[BFD + 1];
+#pragma unroll
+        for (int j = 0; j < BFD; ++j) bf[j] = *reinterpret_cast<const u32x4*>(r2 + j * 1024 + f_rd);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (j + BFD < NB) bf[(j + BFD) % (BFD + 1)] = *reinterpret_cast<const u32x4*>(r2 + (j + BFD) * 1024 + f_rd);
+            // swapped: output channels x rows -- lane (row, fg) gets channels-in-W2-row-order 16 j + 4 fg + r of its row
+            acc2[0][j] = CmMma<T>::run(bf[j % (BFD + 1)], hf[0], acc2[0][j]);
+            acc2[1][j] = CmMma<T>::run(bf[j % (BFD + 1)], hf[1], acc2[1][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    auto run = [&](auto lag_c) {
+        constexpr bool LAG = decltype(lag_c)::value;
+        load_tile(blockIdx.x, lane_now());
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the tile's rows have landed, and the compiler knows it
+            {
+                // accumulators start from R + b2: lane (row, fg) holds channels 32 q + 8 fg + {0..3} in block 2q, + {4..7} in block 2q + 1
+                const int fg = lane_now() >> 4;
+#pragma unroll
+                for (int q = 0; q < KS1; ++q) {
+                    const f32x4 c0 = *reinterpret_cast<const f32x4*>(b2s + 32 * q + 8 * fg);
+                    const f32x4 c1 = *reinterpret_cast<const f32x4*>(b2s + 32 * q + 8 * fg + 4);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        T r8[8];
+                        __builtin_memcpy(r8, &rr[i][q], 16);
+                        acc2[i][2 * q] = f32x4{to_f32(r8[0]) + c0.x, to_f32(r8[1]) + c0.y, to_f32(r8[2]) + c0.z, to_f32(r8[3]) + c0.w};
+                        acc2[i][2 * q + 1] = f32x4{to_f32(r8[4]) + c1.x, to_f32(r8[5]) + c1.y, to_f32(r8[6]) + c1.z, to_f32(r8[7]) + c1.w};
+                    }
+                }
+            }
+            auto iter = [&](auto first_c, const int t) {
+                constexpr bool FIRST = decltype(first_c)::value;
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory");
+                asm volatile("s_barrier" ::: "memory");
+                int g2 = t + 2;                                // pieces of iteration t + 2 (the next tile's first groups at the end of this one)
+                g2 = g2 < G ? g2 : g2 - G;
+                g2 = g2 < G ? g2 : g2 - G;
+                piece_bases(g2);
+                so1 = (s3 == 0 ? 2u : s3 - 1) * Geo::ST1;     // stage (gi + 2) % 3
+                so2 = ((s4 + 2) & 3) * Geo::ST2;              // stage (gi + 2) % 4
+                const int ln = lane_now();
+                constexpr int PH = PPW / 2;
+#pragma unroll
+                for (int pi = 0; pi < PH; ++pi) issue(pi, ln);
+                if constexpr (!LAG) {
+                    fc1(s3, ln);
+#pragma unroll
+                    for (int pi = PH; pi < PPW; ++pi) issue(pi, ln);
+                    gelu(t, ln);
+                    fc2(s4, ln);
+                } else {
+                    if constexpr (!FIRST) {
+                        gelu(t - 1, ln);
+                        fc2((s4 + 3) & 3, ln);                // slab t - 1: stage (gi - 1) % 4
+                    }
+#pragma unroll
+                    for (int pi = PH; pi < PPW; ++pi) issue(pi, ln);
+                    fc1(s3, ln);
+                }
+                s3 = s3 == 2 ? 0 : s3 + 1;
+                s4 = (s4 + 1) & 3;
+            };
+            iter(CmBool<true>{}, 0);
+#pragma unroll 1
+            for (int t = 1; t < G; ++t) iter(CmBool<false>{}, t);
+            if constexpr (LAG) {
+                const int ln = lane_now();
+                gelu(G - 1, ln);
+                fc2((s4 + 3) & 3, ln);
+            }
+            // ---- tile epilogue: one rounding, 16-byte stores straight from the accumulators; then the next tile's rows ----
+            const int le = lane_now();
+            const int frow = le & 15, fg = le >> 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int gm = tile * CM_BM + wave * 32 + i * 16 + frow;
+#pragma unroll
+                for (int q = 0; q < KS1; ++q) {
+                    const f32x4 v0 = acc2[i][2 * q], v1 = acc2[i][2 * q + 1];
+                    T e[8] = {from_f32<T>(v0.x), from_f32<T>(v0.y), from_f32<T>(v0.z), from_f32<T>(v0.w),
+                              from_f32<T>(v1.x), from_f32<T>(v1.y), from_f32<T>(v1.z), from_f32<T>(v1.w)};
+                    u32x4 o;
+                    __builtin_memcpy(&o, e, 16);
+                    if (gm < p.M) *reinterpret_cast<u32x4*>(out + (size_t)gm * p.ldo + q * 32 + fg * 8) = o;
+                }
+            }
+            load_tile(tile + gridDim.x, le);                  // (unconditionally: rows past M clamp to the last row)
+        }
+    };
+    if (!lag) run(CmBool<false>{}); else run(CmBool<true>{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may outlive the workgroup
+}
+
+static int cm_grid_cap() {
+    static int cap = 0;
+    if (!cap) {
+        int dev = 0, cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu < 1) cu = 256;
+        cap = cu;
+    }
+    return cap;
+}
+
+template <typename T, int KS1>
+static int cm_launch(const ChanMlpArgs& a, hipStream_t s) {
+    using Geo = CmGeo<KS1, 2 * KS1>;
+    auto k = chan_mlp_kernel<T, KS1, 2 * KS1>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, Geo::LDS);
+    if (e != hipSuccess) return (int)e;
+    const int tiles = (a.M + CM_BM - 1) / CM_BM;
+    const unsigned grid = (unsigned)(tiles < cm_grid_cap() ? tiles : cm_grid_cap());
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), Geo::LDS, s, a);
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace mlpk
+
+using namespace mlpk;
+
+extern "C" int mlpk_channel_mlp_supported(int dtype, int C, int hidden) {
+    return (dtype == MLPK_F16 || dtype == MLPK_BF16) && C % 32 == 0 && C >= 64 && C <= 192 && hidden > 0 && hidden <= CM_HID_MAX;
+}
+
+extern "C" int mlpk_channel_mlp(int dtype, const void* x, int ldx, int M, int C, const float* ln_mean, const float* ln_rstd, int ln_group,
+                                const float* csum, const void* w1, int ldw1, const float* b1, const void* w2, int ldw2, const float* b2,
+                                int nchunks, const void* R, int ldr, void* out, int ldo, void* stream) {
+    if (!x || !w1 || !w2 || !b1 || !b2 || !out) return MLPK_ENULL;
+    if (dtype != MLPK_F16 && dtype != MLPK_BF16) return MLPK_EDTYPE;
+    if (M <= 0 || nchunks <= 0) return MLPK_ESHAPE;
+    if (!mlpk_channel_mlp_supported(dtype, C, nchunks * 32)) return MLPK_ESHAPE;
+    if ((ln_mean != nullptr) != (ln_rstd != nullptr) || (ln_mean != nullptr) != (csum != nullptr)) return MLPK_ENULL;
+    if (ln_mean && ln_group <= 0) return MLPK_ESHAPE;
+    if (ldw1 != 256 || ldw2 < nchunks * 32 || ldw2 % 8) return MLPK_ESHAPE;
+    if (ldx < C || ldo < C || ldx % 8 || ldo % 8 || (R && (ldr < C || ldr % 8))) return MLPK_ESHAPE;
+    if (((uintptr_t)x & 15) || ((uintptr_t)w1 & 15) || ((uintptr_t)w2 & 15) || ((uintptr_t)out & 15) || ((uintptr_t)R & 15)) return MLPK_EALIGN;
+    ChanMlpArgs a;
+    a.x = x; a.w1 = w1; a.w2 = w2; a.b1 = b1; a.csum = csum; a.b2 = b2; a.ln_mean = ln_mean; a.ln_rstd = ln_rstd; a.R = R; a.out = out;
+    a.M = M; a.G = nchunks; a.ldx = ldx; a.ldw2 = ldw2; a.ldr = ldr; a.ldo = ldo; a.ln_group = ln_mean ? ln_group : 1;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define CM_CASE(KS1) \
+    case KS1: return dtype == MLPK_BF16 ? cm_launch<bf16_t, KS1>(a, s) : cm_launch<f16_t, KS1>(a, s);
+    switch (C / 32) {
+        CM_CASE(2) CM_CASE(3) CM_CASE(4) CM_CASE(5) CM_CASE(6)
+        default: return MLPK_ESHAPE;
+    }
+#undef CM_CASE
+}

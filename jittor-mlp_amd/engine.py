@@ -346,6 +346,52 @@ def pack_token_mlp(w1, b1, w2, b2, dtype, device, sp, layout=None, t_rows=None):
     return w1p, b1p, w2p, f32(b2, device), nch, layout
 
 
+def channel_mlp_fused_supported(dtype, C, hidden):
+    """mlpk_channel_mlp: the whole channel MLP of a narrow stage in one kernel (MLPK_CHANNEL_MLP_FUSED=0: the two GEMMs, A/B aid)"""
+    return (dtype in (torch.float16, torch.bfloat16) and os.environ.get("MLPK_CHANNEL_MLP_FUSED", "1") != "0"
+            and bool(N.lib().mlpk_channel_mlp_supported(dtype_code(dtype), C, round_up(hidden, 32))))
+
+
+def pack_channel_mlp_fused(w1, b1, w2, b2, dtype, device, gamma=None, beta=None):
+    """Weights of mlpk_channel_mlp (include/mlpk.h): W1 (hidden, C) [x diag(gamma)] zero-padded to (nch*32, 256), b1 [+ W1 beta], the
+    row sums of the rounded folded W1 (None without a norm), W2 (C, hidden) with its columns in mlpk_token_mlp's layout-1 order
+    and its rows in the kernel's store order, b2.  Returns (w1p, b1p, csum, w2p, b2, nch)."""
+    w1 = w1.detach().to(device=device, dtype=torch.float32).reshape(w1.shape[0], -1)
+    w2 = w2.detach().to(device=device, dtype=torch.float32).reshape(w2.shape[0], -1)
+    T, C = w1.shape
+    nch = (T + 31) // 32
+    b1p = torch.zeros((nch * 32,), dtype=torch.float32, device=device)
+    if b1 is not None:
+        b1p[:T] = b1.detach().to(device=device, dtype=torch.float32).reshape(-1)
+    wf = w1
+    if gamma is not None:
+        wf = w1 * gamma.detach().to(device=device, dtype=torch.float32).reshape(1, -1)
+        b1p[:T] += w1 @ beta.detach().to(device=device, dtype=torch.float32).reshape(-1)
+    w1p = torch.zeros((nch * 32, 256), dtype=dtype, device=device)
+    w1p[:T, :C] = wf.to(dtype)
+    csum = w1p.to(torch.float32).sum(dim=1).contiguous() if gamma is not None else None
+    w2p = torch.zeros((C, nch * 32), dtype=dtype, device=device)
+    w2p[:, :T] = w2.to(dtype)
+    slot = torch.arange(32)
+    f, e = slot // 8, slot % 8
+    col = torch.where(e < 4, 4 * f + e, 16 + 4 * f + e - 4).to(device)          # hidden unit at k slot 8 f + e
+    h, f4, r = slot // 16, (slot // 4) % 4, slot % 4
+    row = (8 * f4 + 4 * h + r).to(device)                                        # output channel at row 16 h + 4 f + r
+    w2p = w2p.view(C // 32, 32, nch, 32)[:, row][:, :, :, col].reshape(C, nch * 32).contiguous()
+    b2p = torch.zeros((C,), dtype=torch.float32, device=device)
+    if b2 is not None:
+        b2p[:] = b2.detach().to(device=device, dtype=torch.float32).reshape(-1)
+    return w1p, b1p, csum, w2p, b2p, nch
+
+
+def channel_mlp_fused(x, rows, C, pack, out, *, R=None, ln=None, ln_group=1):
+    """out = R + fc2(gelu(fc1(norm(x)))) on channel-last rows; pack = pack_channel_mlp_fused(...); ln = (mean, rstd) or None"""
+    w1p, b1p, csum, w2p, b2p, nch = pack
+    N.check(N.lib().mlpk_channel_mlp(dtype_code(x.dtype), ptr(x), x.stride(0), rows, C, ptr(ln[0]) if ln else None, ptr(ln[1]) if ln else None,
+                                     ln_group, ptr(csum) if ln else None, ptr(w1p), w1p.stride(0), ptr(b1p), ptr(w2p), w2p.stride(0), ptr(b2p), nch,
+                                     ptr(R), R.stride(0) if R is not None else 0, ptr(out), out.stride(0), stream()), "mlpk_channel_mlp")
+
+
 def patchify(src, out, B, Cin, H, W, ph, pw, pad, ldo, layout=N.LAYOUT_NCHW, px_stride=0, order=0):
     N.check(N.lib().mlpk_patchify(dtype_code(src.dtype), dtype_code(out.dtype), layout, ptr(src), ptr(out), B, Cin, H, W,
                                   ph, pw, pad, px_stride, ldo, order, stream()), "mlpk_patchify")

@@ -1507,3 +1507,85 @@ def test_byproduct_statistics_do_not_depend_on_the_tile(dtype):
             assert torch.equal(cur[0].view(torch.int16), ref[0].view(torch.int16)), (M, Nn, K, algo)
             assert torch.equal(cur[1].view(torch.int32), ref[1].view(torch.int32)), (M, Nn, K, algo, int((cur[1] != ref[1]).sum()))
             assert torch.equal(cur[2], ref[2]) and torch.equal(cur[3], ref[3]), (M, Nn, K, algo)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_channel_mlp_of_a_narrow_stage_in_one_kernel(dtype):
+    """mlpk_channel_mlp (round 4): out = R + fc2(gelu(fc1(norm(x)))) on channel-last rows with C <= 192 -- both products, the GELU and
+    the residual in one kernel, the hidden never written (as_mlp.py:36-52 with the GroupNorm(1, C) of :343-344 folded; the FeedForward /
+    Mlp of every hierarchical family's narrow stages).  Against fp64 on the SAME rounded operands (hidden rounded once to the storage
+    type, as the two-GEMM path stores it), and against that two-GEMM path.  Cases: every supported width, a hidden that is not a
+    multiple of 32, ragged row counts (partial last tile, fewer tiles than workgroups, more tiles than CUs), LayerNorm (one statistic
+    per row) and GroupNorm (one per sample), no norm, no residual, residual from another tensor, in place."""
+    pkg = load_pkg()
+    E, N = pkg.engine, pkg._native
+    cases = [(64, 256, 1000, "ln", "x"), (96, 384, 256 * 9 + 40, "gn", "x"), (128, 512, 300, None, "x"), (160, 640, 2048, "ln", None),
+             (192, 768, 256 * 5, "gn", "other"), (96, 200, 777, "ln", "x"), (192, 576, 256 * 300 + 8, "gn", "x"), (64, 1024, 512, None, None)]
+    for ci, (C, hid, M, norm, res) in enumerate(cases):
+        assert E.channel_mlp_fused_supported(dtype, C, hid)
+        w1 = rnd((hid, C), torch.float32, 3100 + ci, 1.0 / math.sqrt(C))
+        b1 = rnd((hid,), torch.float32, 3110 + ci, 0.3)
+        w2 = rnd((C, hid), torch.float32, 3120 + ci, 1.0 / math.sqrt(hid))
+        b2 = rnd((C,), torch.float32, 3130 + ci, 0.3)
+        gamma = rnd((C,), torch.float32, 3140 + ci) * 0.3 + 1.0
+        beta = rnd((C,), torch.float32, 3150 + ci) * 0.2
+        x = (rnd((M, C), dtype, 3160 + ci) * 1.5 + 0.25).to(dev())
+        other = rnd((M, C), dtype, 3170 + ci).to(dev())
+        group = 1
+        ln = None
+        if norm:
+            group = 1 if norm == "ln" else 64
+            ns = (M + group - 1) // group
+            mean = torch.empty((ns,), dtype=torch.float32, device=dev())
+            rstd = torch.empty((ns,), dtype=torch.float32, device=dev())
+            if norm == "ln":
+                E.row_stats(x, M, C, C, mean, rstd)
+            else:
+                xs = x.float()
+                pad = ns * group - M
+                xp = torch.cat([xs, xs[-1:].expand(pad, C)]) if pad else xs      # (the last, partial sample: any finite statistic will do)
+                mean.copy_(xp.view(ns, -1).mean(1))
+                rstd.copy_(1.0 / torch.sqrt(xp.view(ns, -1).var(1, unbiased=False) + 1e-5))
+            ln = (mean, rstd)
+        pack = E.pack_channel_mlp_fused(w1, b1, w2, b2, dtype, dev(), gamma if norm else None, beta if norm else None)
+        R = x if res == "x" else (other if res == "other" else None)
+        out = torch.full((M, C), float("nan"), dtype=dtype, device=dev())
+        E.channel_mlp_fused(x, M, C, pack, out, R=R, ln=ln, ln_group=group)
+        torch.cuda.synchronize()
+        # fp64 on the rounded operands: the folded W1, the hidden rounded once
+        xd = x.cpu().double()
+        w1f = (w1 * gamma.view(1, -1) if norm else w1).to(dtype).double()
+        b1f = (b1 + w1 @ beta if norm else b1).double()
+        acc = xd @ w1f.t()
+        if norm:
+            idx = torch.arange(M) // group
+            mu, rs = mean.cpu().double()[idx], rstd.cpu().double()[idx]
+            acc = (acc - mu[:, None] * w1f.sum(1)[None, :]) * rs[:, None]
+        h = oracle.gelu(acc + b1f[None, :]).to(dtype).double()
+        ref = h @ w2.to(dtype).double().t() + b2.double()[None, :]
+        if R is not None:
+            ref = ref + R.cpu().double()
+        got = out.cpu().double()
+        assert torch.isfinite(got).all(), (str(dtype), ci)
+        scale = max(1.0, ref.abs().max().item())
+        err = (got - ref).abs().max().item()
+        assert err < EPS[dtype] * 4 * scale, (str(dtype), ci, C, hid, M, err)
+        # the two GEMMs it replaces (same folded weights)
+        if norm:
+            wq, bq, csum = E.pack_ln_folded(w1, b1, gamma, beta, dtype, dev())
+        else:
+            wq, bq, csum = E.pack_matrix(w1, dtype, dev()), b1.to(dev()), None
+        hb = torch.empty((M, E.round_up(hid, 8)), dtype=dtype, device=dev())
+        two = torch.empty((M, C), dtype=dtype, device=dev())
+        E.gemm(x, wq, hb, M, hid, C, bias=bq, act=N.ACT_GELU, ln=(mean, rstd, csum) if norm else None, ln_group=group)
+        E.gemm(hb, E.pack_matrix(w2, dtype, dev()), two, M, C, hid, bias=b2.to(dev()), R=R, res=N.RES_ADD if R is not None else N.RES_NONE)
+        torch.cuda.synchronize()
+        d2 = (got - two.cpu().double()).abs().max().item()
+        assert d2 < EPS[dtype] * 4 * scale, (str(dtype), ci, d2)
+        if res == "x":                                                            # in place: bit-equal to the run into a fresh tensor
+            xin = x.clone()
+            E.channel_mlp_fused(xin, M, C, pack, xin, R=xin, ln=ln, ln_group=group)
+            torch.cuda.synchronize()
+            assert torch.equal(xin.view(torch.int16), out.view(torch.int16)), (str(dtype), ci, "in place")
+    assert not E.channel_mlp_fused_supported(dtype, 224, 896) and not E.channel_mlp_fused_supported(dtype, 80, 320)
+    assert not E.channel_mlp_fused_supported(torch.float32, 96, 384) and not E.channel_mlp_fused_supported(dtype, 96, 2048)
