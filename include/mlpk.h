@@ -379,13 +379,16 @@ int mlpk_as_conv2(int dtype, const void* t, void* y, int B, int H, int W, int C,
  *     - the COLUMN order of mlpk_token_mlp's layout 1 inside every group of 32 hidden units: slot 8 f + e <- unit (e < 4 ? 4 f + e : 16 + 4 f + e - 4),
  *     - the ROW order: inside every group of 32 output channels, row 16 h + 4 f + r (h < 2, f < 4, r < 4) <- channel 8 f + 4 h + r
  *       (a lane's accumulators are then 8 consecutive channels of one row: 16-byte stores straight from the registers);
- *   b2 (C) in natural channel order.
+ *   b2 (C) in natural channel order;
+ *   row_part (optional): (sum, sum of squares) of the C values WRITTEN to row m (after the rounding) at row_part[2 m], [2 m + 1] -- one
+ *     plane of mlpk_stats_finalize_planar (nplanes = 1) for the LayerNorm / GroupNorm that follows; a row is summed inside one wave
+ *     in one fixed order, so the pair does not depend on the batch.
  * Numerics: fp32 accumulation in K order starting from R + b2; GELU and roundings as in the GEMM epilogues (one rounding of the hidden
  * to the storage type, one of the result). */
 int mlpk_channel_mlp_supported(int dtype, int C, int hidden);
 int mlpk_channel_mlp(int dtype, const void* x, int ldx, int M, int C, const float* ln_mean, const float* ln_rstd, int ln_group,
                      const float* csum, const void* w1, int ldw1, const float* b1, const void* w2, int ldw2, const float* b2,
-                     int nchunks, const void* R, int ldr, void* out, int ldo, void* stream);
+                     int nchunks, const void* R, int ldr, void* out, int ldo, float* row_part, void* stream);
 /* ---- CycleFC sampling (CycleMLP) ---------------------------------------------------------------
  * in: (B,H,W,C) channel-last with pixel stride ldi.  d(c) = (c + k/2) % k - k/2  (gen_offset, cycle_mlp.py:104-120):
  *   out_h[b,y,x,c] = in[b, y, x + d(c), c]     the operand of `sfc_h` = CycleFC(kernel (1,k))

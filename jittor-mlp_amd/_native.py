@@ -78,7 +78,7 @@ PROTOTYPES = {
     "mlpk_as_conv2_supported": (c_int, [c_int] * 5),
     "mlpk_channel_mlp_supported": (c_int, [c_int] * 3),
     "mlpk_channel_mlp": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
-                                 c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+                                 c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     # (dtype, t, y, B, H, W, C, kernel_size, mean, rstd, gamma, beta, w1, b1, w2, b2, ldw, stream)
     "mlpk_as_conv2": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p] * 8 + [c_int, c_void_p]),
     "mlpk_split_sum": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_float, c_void_p, c_void_p]),

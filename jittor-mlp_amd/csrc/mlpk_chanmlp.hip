@@ -37,6 +37,7 @@ struct ChanMlpArgs {
     const float* ln_rstd;
     const void* R;          // (M, ldr) or NULL
     void* out;              // (M, ldo)
+    float* row_part;        // optional by-product: (sum, sum of squares) of the C values written to row m at [2 m], [2 m + 1]
     int M, G, ldx, ldw2, ldr, ldo, ln_group;
 };
 
@@ -313,6 +314,7 @@ __global__ void __launch_bounds__(512, 1) chan_mlp_kernel(const ChanMlpArgs p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int gm = tile * CM_BM + wave * 32 + i * 16 + frow;
+                float ssum = 0.f, ssq = 0.f;
 #pragma unroll
                 for (int q = 0; q < KS1; ++q) {
                     const f32x4 v0 = acc2[i][2 * q], v1 = acc2[i][2 * q + 1];
@@ -321,6 +323,16 @@ __global__ void __launch_bounds__(512, 1) chan_mlp_kernel(const ChanMlpArgs p) {
                     u32x4 o;
                     __builtin_memcpy(&o, e, 16);
                     if (gm < p.M) *reinterpret_cast<u32x4*>(out + (size_t)gm * p.ldo + q * 32 + fg * 8) = o;
+                    if (p.row_part) chunk_sums<T>(o, ssum, ssq);
+                }
+                if (p.row_part) {
+                    // a row's C channels sit in the 4 lanes (row, fg = 0..3) of this wave: chunks q ascending inside a lane, then
+                    // (fg 0 + fg 1) + (fg 2 + fg 3) -- one fixed order whatever the batch or the grid
+                    ssum += __shfl_xor(ssum, 16);
+                    ssq += __shfl_xor(ssq, 16);
+                    ssum += __shfl_xor(ssum, 32);
+                    ssq += __shfl_xor(ssq, 32);
+                    if (fg == 0 && gm < p.M) *reinterpret_cast<f32x2*>(p.row_part + (size_t)gm * 2) = f32x2{ssum, ssq};
                 }
             }
             load_tile(tile + gridDim.x, le);                  // (unconditionally: rows past M clamp to the last row)
@@ -363,7 +375,7 @@ extern "C" int mlpk_channel_mlp_supported(int dtype, int C, int hidden) {
 
 extern "C" int mlpk_channel_mlp(int dtype, const void* x, int ldx, int M, int C, const float* ln_mean, const float* ln_rstd, int ln_group,
                                 const float* csum, const void* w1, int ldw1, const float* b1, const void* w2, int ldw2, const float* b2,
-                                int nchunks, const void* R, int ldr, void* out, int ldo, void* stream) {
+                                int nchunks, const void* R, int ldr, void* out, int ldo, float* row_part, void* stream) {
     if (!x || !w1 || !w2 || !b1 || !b2 || !out) return MLPK_ENULL;
     if (dtype != MLPK_F16 && dtype != MLPK_BF16) return MLPK_EDTYPE;
     if (M <= 0 || nchunks <= 0) return MLPK_ESHAPE;
@@ -372,9 +384,12 @@ extern "C" int mlpk_channel_mlp(int dtype, const void* x, int ldx, int M, int C,
     if (ln_mean && ln_group <= 0) return MLPK_ESHAPE;
     if (ldw1 != 256 || ldw2 < nchunks * 32 || ldw2 % 8) return MLPK_ESHAPE;
     if (ldx < C || ldo < C || ldx % 8 || ldo % 8 || (R && (ldr < C || ldr % 8))) return MLPK_ESHAPE;
-    if (((uintptr_t)x & 15) || ((uintptr_t)w1 & 15) || ((uintptr_t)w2 & 15) || ((uintptr_t)out & 15) || ((uintptr_t)R & 15)) return MLPK_EALIGN;
+    if (((uintptr_t)x & 15) || ((uintptr_t)w1 & 15) || ((uintptr_t)w2 & 15) || ((uintptr_t)out & 15) || ((uintptr_t)R & 15) ||
+        ((uintptr_t)row_part & 7))
+        return MLPK_EALIGN;
     ChanMlpArgs a;
     a.x = x; a.w1 = w1; a.w2 = w2; a.b1 = b1; a.csum = csum; a.b2 = b2; a.ln_mean = ln_mean; a.ln_rstd = ln_rstd; a.R = R; a.out = out;
+    a.row_part = row_part;
     a.M = M; a.G = nchunks; a.ldx = ldx; a.ldw2 = ldw2; a.ldr = ldr; a.ldo = ldo; a.ln_group = ln_mean ? ln_group : 1;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define CM_CASE(KS1) \

@@ -384,12 +384,18 @@ def pack_channel_mlp_fused(w1, b1, w2, b2, dtype, device, gamma=None, beta=None)
     return w1p, b1p, csum, w2p, b2p, nch
 
 
-def channel_mlp_fused(x, rows, C, pack, out, *, R=None, ln=None, ln_group=1):
-    """out = R + fc2(gelu(fc1(norm(x)))) on channel-last rows; pack = pack_channel_mlp_fused(...); ln = (mean, rstd) or None"""
+def channel_mlp_fused(x, rows, C, pack, out, *, R=None, ln=None, ln_group=1, part=None):
+    """out = R + fc2(gelu(fc1(norm(x)))) on channel-last rows; pack = pack_channel_mlp_fused(...); ln = (mean, rstd) or None.
+    part = (workspace, name): also deliver the row statistics of `out` -- returns (buffer (1, rows, 2), 1) as engine.gemm(part=...)
+    does, for finalize_stats / stats_finalize_planar; None otherwise."""
     w1p, b1p, csum, w2p, b2p, nch = pack
+    buf = None
+    if part is not None and epilogue_stats():
+        buf = part[0].get("%s.1" % part[1], (1, rows, 2), torch.float32)
     N.check(N.lib().mlpk_channel_mlp(dtype_code(x.dtype), ptr(x), x.stride(0), rows, C, ptr(ln[0]) if ln else None, ptr(ln[1]) if ln else None,
                                      ln_group, ptr(csum) if ln else None, ptr(w1p), w1p.stride(0), ptr(b1p), ptr(w2p), w2p.stride(0), ptr(b2p), nch,
-                                     ptr(R), R.stride(0) if R is not None else 0, ptr(out), out.stride(0), stream()), "mlpk_channel_mlp")
+                                     ptr(R), R.stride(0) if R is not None else 0, ptr(out), out.stride(0), ptr(buf), stream()), "mlpk_channel_mlp")
+    return (buf, 1) if buf is not None else None
 
 
 def patchify(src, out, B, Cin, H, W, ph, pw, pad, ldo, layout=N.LAYOUT_NCHW, px_stride=0, order=0):

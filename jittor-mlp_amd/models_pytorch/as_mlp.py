@@ -273,6 +273,11 @@ class AS_MLP(E.EngineModule):
                 conv(p + "fc1", blk.mlp.fc1), conv(p + "fc2", blk.mlp.fc2)
                 # the same three convolutions with the GroupNorm in front of them folded in (16-bit fast path)
                 conv(p + "c1f", a.conv1, blk.norm1), conv(p + "c3f", a.conv3, a.norm2), conv(p + "fc1f", blk.mlp.fc1, blk.norm2)
+                fc1, fc2 = blk.mlp.fc1, blk.mlp.fc2
+                if E.channel_mlp_fused_supported(dtype, fc1.in_channels, fc1.out_channels) and fc2.out_channels == fc1.in_channels:
+                    # narrow stages (C = 96, 192): norm2 + fc1 + GELU + fc2 + residual in one kernel (mlpk_channel_mlp)
+                    g, b = _gn_params(blk.norm2, device)
+                    pk[p + "mlpf"] = E.pack_channel_mlp_fused(fc1.weight, fc1.bias, fc2.weight, fc2.bias, dtype, device, g, b)
             if layer.downsample is not None:
                 p = "l%d.down." % li
                 pk[p + "g"], pk[p + "b"] = _gn_params(layer.downsample.norm, device)
@@ -354,9 +359,12 @@ class AS_MLP(E.EngineModule):
                     got = E.gemm(t1, pk[p + "c3f.w"], cur, rows, C, C, bias=pk[p + "c3f.b"], ln=(mean, rstd, pk[p + "c3f.csum"]), ln_group=HW,
                                  R=cur, res=N.RES_ADD, tag="as_conv", part=part)                     # x + conv3(norm2(.))
                     stats(cur, C, got)
-                    E.gemm(cur, pk[p + "fc1f.w"], hbuf, rows, hid, C, bias=pk[p + "fc1f.b"], act=N.ACT_GELU,
-                           ln=(mean, rstd, pk[p + "fc1f.csum"]), ln_group=HW, tag="as_fc1")
-                    got = E.gemm(hbuf, pk[p + "fc2.w"], cur, rows, C, hid, bias=pk[p + "fc2.b"], R=cur, res=N.RES_ADD, tag="as_fc2", part=part)
+                    if (p + "mlpf") in pk and E.channel_mlp_fused_supported(cd, C, hid):
+                        got = E.channel_mlp_fused(cur, rows, C, pk[p + "mlpf"], cur, R=cur, ln=(mean, rstd), ln_group=HW, part=part)
+                    else:
+                        E.gemm(cur, pk[p + "fc1f.w"], hbuf, rows, hid, C, bias=pk[p + "fc1f.b"], act=N.ACT_GELU,
+                               ln=(mean, rstd, pk[p + "fc1f.csum"]), ln_group=HW, tag="as_fc1")
+                        got = E.gemm(hbuf, pk[p + "fc2.w"], cur, rows, C, hid, bias=pk[p + "fc2.b"], R=cur, res=N.RES_ADD, tag="as_fc2", part=part)
                     # (mean, rstd) then describe `cur`: the next block's norm1, the PatchMerging norm (a permutation of the same
                     # elements per sample, as_mlp.py:207-213) or the final norm start from them
                     have = finalize_stats(ws, got, rows, C, tag=tag, group=HW) is not None

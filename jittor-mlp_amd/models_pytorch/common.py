@@ -114,6 +114,10 @@ def pack_channel_mlp(pk, prefix, norm, fc1, fc2, dtype, device):
         fc1.weight, fc1.bias, norm.weight, norm.bias, dtype, device)
     pk[prefix + "fc2.w"] = E.pack_matrix(fc2.weight, dtype, device)
     pk[prefix + "fc2.b"] = E.f32(fc2.bias, device)
+    w1 = fc1.weight.reshape(fc1.weight.shape[0], -1)
+    if E.channel_mlp_fused_supported(dtype, w1.shape[1], w1.shape[0]) and fc2.weight.reshape(fc2.weight.shape[0], -1).shape[0] == w1.shape[1]:
+        # narrow stage: the whole block in one kernel (mlpk_channel_mlp), the hidden never written
+        pk[prefix + "fused"] = E.pack_channel_mlp_fused(fc1.weight, fc1.bias, fc2.weight, fc2.bias, dtype, device, norm.weight, norm.bias)
 
 
 def layernorm_stats(ws, x, rows, C, tag="ln", eps=1e-5):
@@ -142,6 +146,10 @@ def channel_mlp(ws, x, rows, C, pk, prefix, hidden, *, norm=True, cscale2=None, 
     `stats` = (mean, rstd) of x's rows when the producer of x already delivered them (token_mlp's epilogue, a GEMM's row_part).
     `part` = (workspace, name): fc2's epilogue delivers the row statistics of the new x for the LayerNorm that follows; the
     return value is then what finalize_stats takes (None when they could not be delivered) instead of x."""
+    if norm and cscale2 is None and (prefix + "fused") in pk and E.channel_mlp_fused_supported(x.dtype, C, hidden):
+        mean, rstd = stats if stats is not None else layernorm_stats(ws, x, rows, C, tag=tag + ".ln", eps=eps)
+        got = E.channel_mlp_fused(x, rows, C, pk[prefix + "fused"], x, R=res_src if res_src is not None else x, ln=(mean, rstd), part=part)
+        return got if part is not None else x
     ln = None
     if norm and (prefix + "fc1.csum") in pk:
         # LayerNorm folded into fc1 (gamma in the weights, beta in the bias, mean/rstd applied on the

@@ -1550,8 +1550,15 @@ def test_channel_mlp_of_a_narrow_stage_in_one_kernel(dtype):
         pack = E.pack_channel_mlp_fused(w1, b1, w2, b2, dtype, dev(), gamma if norm else None, beta if norm else None)
         R = x if res == "x" else (other if res == "other" else None)
         out = torch.full((M, C), float("nan"), dtype=dtype, device=dev())
-        E.channel_mlp_fused(x, M, C, pack, out, R=R, ln=ln, ln_group=group)
+        ws = E.Workspace(dev(), dtype)
+        got_part = E.channel_mlp_fused(x, M, C, pack, out, R=R, ln=ln, ln_group=group, part=(ws, "cm.part"))
         torch.cuda.synchronize()
+        # the by-product: (sum, sum of squares) of the values written to each row, one plane
+        assert got_part is not None and got_part[1] == 1 and tuple(got_part[0].shape) == (1, M, 2)
+        od = out.cpu().double()
+        sums = got_part[0][0].cpu().double()
+        assert (sums[:, 0] - od.sum(1)).abs().max().item() < 1e-4 * max(1.0, od.abs().sum(1).max().item())
+        assert (sums[:, 1] - (od * od).sum(1)).abs().max().item() < 1e-4 * max(1.0, (od * od).sum(1).max().item())
         # fp64 on the rounded operands: the folded W1, the hidden rounded once
         xd = x.cpu().double()
         w1f = (w1 * gamma.view(1, -1) if norm else w1).to(dtype).double()
