@@ -352,10 +352,11 @@ def channel_mlp_fused_supported(dtype, C, hidden):
             and bool(N.lib().mlpk_channel_mlp_supported(dtype_code(dtype), C, round_up(hidden, 32))))
 
 
-def pack_channel_mlp_fused(w1, b1, w2, b2, dtype, device, gamma=None, beta=None):
+def pack_channel_mlp_fused(w1, b1, w2, b2, dtype, device, gamma=None, beta=None, cscale=None):
     """Weights of mlpk_channel_mlp (include/mlpk.h): W1 (hidden, C) [x diag(gamma)] zero-padded to (nch*32, 256), b1 [+ W1 beta], the
     row sums of the rounded folded W1 (None without a norm), W2 (C, hidden) with its columns in mlpk_token_mlp's layout-1 order
-    and its rows in the kernel's store order, b2.  Returns (w1p, b1p, csum, w2p, b2, nch)."""
+    and its rows in the kernel's store order, b2.  cscale (C): a per-output-channel scale of the second Linear (a layer scale),
+    folded into W2's rows and b2.  Returns (w1p, b1p, csum, w2p, b2, nch)."""
     w1 = w1.detach().to(device=device, dtype=torch.float32).reshape(w1.shape[0], -1)
     w2 = w2.detach().to(device=device, dtype=torch.float32).reshape(w2.shape[0], -1)
     T, C = w1.shape
@@ -370,6 +371,11 @@ def pack_channel_mlp_fused(w1, b1, w2, b2, dtype, device, gamma=None, beta=None)
     w1p = torch.zeros((nch * 32, 256), dtype=dtype, device=device)
     w1p[:T, :C] = wf.to(dtype)
     csum = w1p.to(torch.float32).sum(dim=1).contiguous() if gamma is not None else None
+    b2v = b2.detach().to(device=device, dtype=torch.float32).reshape(-1) if b2 is not None else torch.zeros((C,), dtype=torch.float32, device=device)
+    if cscale is not None:
+        cs = cscale.detach().to(device=device, dtype=torch.float32).reshape(-1)
+        w2 = w2 * cs.view(-1, 1)
+        b2v = b2v * cs
     w2p = torch.zeros((C, nch * 32), dtype=dtype, device=device)
     w2p[:, :T] = w2.to(dtype)
     slot = torch.arange(32)
@@ -378,10 +384,7 @@ def pack_channel_mlp_fused(w1, b1, w2, b2, dtype, device, gamma=None, beta=None)
     h, f4, r = slot // 16, (slot // 4) % 4, slot % 4
     row = (8 * f4 + 4 * h + r).to(device)                                        # output channel at row 16 h + 4 f + r
     w2p = w2p.view(C // 32, 32, nch, 32)[:, row][:, :, :, col].reshape(C, nch * 32).contiguous()
-    b2p = torch.zeros((C,), dtype=torch.float32, device=device)
-    if b2 is not None:
-        b2p[:] = b2.detach().to(device=device, dtype=torch.float32).reshape(-1)
-    return w1p, b1p, csum, w2p, b2p, nch
+    return w1p, b1p, csum, w2p, b2v.contiguous(), nch
 
 
 def channel_mlp_fused(x, rows, C, pack, out, *, R=None, ln=None, ln_group=1, part=None):

@@ -146,7 +146,7 @@ def channel_mlp(ws, x, rows, C, pk, prefix, hidden, *, norm=True, cscale2=None, 
     `stats` = (mean, rstd) of x's rows when the producer of x already delivered them (token_mlp's epilogue, a GEMM's row_part).
     `part` = (workspace, name): fc2's epilogue delivers the row statistics of the new x for the LayerNorm that follows; the
     return value is then what finalize_stats takes (None when they could not be delivered) instead of x."""
-    if norm and cscale2 is None and (prefix + "fused") in pk and E.channel_mlp_fused_supported(x.dtype, C, hidden):
+    if norm and (cscale2 is None or pk.get(prefix + "fused.scaled")) and (prefix + "fused") in pk and E.channel_mlp_fused_supported(x.dtype, C, hidden):
         mean, rstd = stats if stats is not None else layernorm_stats(ws, x, rows, C, tag=tag + ".ln", eps=eps)
         got = E.channel_mlp_fused(x, rows, C, pk[prefix + "fused"], x, R=res_src if res_src is not None else x, ln=(mean, rstd), part=part)
         return got if part is not None else x

@@ -171,6 +171,12 @@ class MS_MLP(E.EngineModule):
                 pk[p + "ff.fc2.w"] = E.pack_matrix(blk.pwconv2.weight, dtype, device)
                 pk[p + "ff.fc2.b"] = E.f32(blk.pwconv2.bias, device)
                 pk[p + "gamma"] = E.f32(blk.gamma, device) if blk.gamma is not None else None
+                w1 = blk.pwconv1.weight.reshape(blk.pwconv1.weight.shape[0], -1)
+                if E.channel_mlp_fused_supported(dtype, w1.shape[1], w1.shape[0]):
+                    # narrow stages: norm + pwconv1 + GELU + pwconv2 + layer scale + residual in one kernel (the scale folded into pwconv2)
+                    pk[p + "ff.fused"] = E.pack_channel_mlp_fused(blk.pwconv1.weight, blk.pwconv1.bias, blk.pwconv2.weight, blk.pwconv2.bias,
+                                                                 dtype, device, blk.norm.weight, blk.norm.bias, cscale=blk.gamma)
+                    pk[p + "ff.fused.scaled"] = True
             if layer.downsample is not None:
                 d = layer.downsample
                 p = "l%d.down." % li
