@@ -18,9 +18,9 @@
 //   * the normalisation in front (LayerNorm, or GroupNorm(1, C) with one statistic per ln_group rows) is folded as in mlpk_gemm_nt:
 //     gamma in W1, beta in b1, v = (acc - mean * csum[h]) * rstd + b1[h] in the GELU stage;
 //   * the two waves of a SIMD are skewed by half an iteration (one in its matrix phase while the other runs GELU); W1 groups and
-//     W2 slabs stream through 3- and 4-stage LDS rings by LDS-DMA two iterations ahead, PPW one-KiB pieces per wave and iteration,
+//     W2 slabs stream through (D + 1)- and (D + 2)-stage LDS rings by LDS-DMA D = 2 iterations ahead, PPW one-KiB pieces per wave and iteration,
 //     one barrier per iteration.
-// LDS: 3 x (C / 16) KiB + 4 x (C / 16) KiB + 4 (b1) + 4 (csum) + 1 (b2) KiB = 93 KiB at C = 192.
+// LDS (D = 2): 3 x (C / 16) KiB + 4 x (C / 16) KiB + 4 (b1) + 4 (csum) + 1 (b2) KiB = 93 KiB at C = 192.
 #include "mlpk_common.h"
 #include <cstdlib>
 
@@ -65,21 +65,23 @@ template <bool B> struct CmBool { static constexpr bool value = B; };
 constexpr int CM_BM = 256;
 constexpr int CM_HID_MAX = 1024;
 
-template <int KS1, int NB> struct CmGeo {
+// D = how many iterations ahead the weight pieces are requested (an iteration here is 3-6x shorter than the token kernel's: 24-48
+// MFMAs per wave; deeper rings were tried and change nothing, see cm_launch)
+template <int KS1, int NB, int D> struct CmGeo {
     static constexpr int N1 = 2 * KS1;                      // W1 pieces per group: plane kk, halves of 16 rows
     static constexpr int P = N1 + NB;                       // + W2 pieces: 16 output channels each
     static constexpr int PPW = (P + 7) / 8;                 // pieces per wave and iteration (the last ones issued twice)
     static constexpr int ST1 = N1 * 1024, ST2 = NB * 1024;
-    static constexpr int R1 = 0, R2 = 3 * ST1;
-    static constexpr int B1 = R2 + 4 * ST2;
+    static constexpr int R1 = 0, R2 = (D + 1) * ST1;        // W1 ring: D + 1 stages; W2 ring: D + 2 (the late half reads slab t - 1)
+    static constexpr int B1 = R2 + (D + 2) * ST2;
     static constexpr int CS = B1 + CM_HID_MAX * 4;
     static constexpr int B2 = CS + CM_HID_MAX * 4;
     static constexpr int LDS = B2 + 16 * NB * 4;
 };
 
-template <typename T, int KS1, int NB>
+template <typename T, int KS1, int NB, int D>
 __global__ void __launch_bounds__(512, 1) chan_mlp_kernel(const ChanMlpArgs p) {
-    using Geo = CmGeo<KS1, NB>;
+    using Geo = CmGeo<KS1, NB, D>;
     constexpr int PPW = Geo::PPW, N1 = Geo::N1, P = Geo::P;
     constexpr int C = 16 * NB;
     static_assert(NB == 2 * KS1, "C = 32 KS1 = 16 NB");
@@ -140,10 +142,14 @@ __global__ void __launch_bounds__(512, 1) chan_mlp_kernel(const ChanMlpArgs p) {
         const bool is1 = q < N1;
         cm_glds(piece_off(pi, ln), is1 ? pb1 : pb2, pdst[pi] + __builtin_amdgcn_readfirstlane(is1 ? so1 : so2));
     };
-    unsigned s3 = 0, s4 = 0;                               // iteration counter modulo the ring sizes (W1: 3 stages, W2: 4)
+    unsigned s3 = 0, s4 = 0;                               // iteration counter modulo the ring sizes (W1: D + 1 stages, W2: D + 2)
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        piece_bases(it < G ? it : it - G);
+    for (int it = 0; it < D; ++it) {
+        int g0 = it;
+        g0 = g0 < G ? g0 : g0 - G;
+        g0 = g0 < G ? g0 : g0 - G;
+        g0 = g0 < G ? g0 : g0 - G;                          // (G >= 2, D <= 6)
+        piece_bases(g0);
         so1 = (unsigned)it * Geo::ST1;
         so2 = (unsigned)it * Geo::ST2;
 #pragma unroll
@@ -270,14 +276,16 @@ __global__ void __launch_bounds__(512, 1) chan_mlp_kernel(const ChanMlpArgs p) {
             }
             auto iter = [&](auto first_c, const int t) {
                 constexpr bool FIRST = decltype(first_c)::value;
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((D - 1) * PPW) : "memory");
                 asm volatile("s_barrier" ::: "memory");
-                int g2 = t + 2;                                // pieces of iteration t + 2 (the next tile's first groups at the end of this one)
+                int g2 = t + D;                                // pieces of iteration t + D (the next tile's first groups at the end of this one)
+                g2 = g2 < G ? g2 : g2 - G;
+                g2 = g2 < G ? g2 : g2 - G;
                 g2 = g2 < G ? g2 : g2 - G;
                 g2 = g2 < G ? g2 : g2 - G;
                 piece_bases(g2);
-                so1 = (s3 == 0 ? 2u : s3 - 1) * Geo::ST1;     // stage (gi + 2) % 3
-                so2 = ((s4 + 2) & 3) * Geo::ST2;              // stage (gi + 2) % 4
+                so1 = (s3 == 0 ? (unsigned)D : s3 - 1) * Geo::ST1;                 // stage (gi + D) % (D + 1)
+                so2 = (s4 >= 2 ? s4 - 2 : s4 + D) * Geo::ST2;                      // stage (gi + D) % (D + 2)
                 const int ln = lane_now();
                 constexpr int PH = PPW / 2;
 #pragma unroll
@@ -291,14 +299,14 @@ __global__ void __launch_bounds__(512, 1) chan_mlp_kernel(const ChanMlpArgs p) {
                 } else {
                     if constexpr (!FIRST) {
                         gelu(t - 1, ln);
-                        fc2((s4 + 3) & 3, ln);                // slab t - 1: stage (gi - 1) % 4
+                        fc2(s4 == 0 ? D + 1 : s4 - 1, ln);    // slab t - 1: stage (gi - 1) % (D + 2)
                     }
 #pragma unroll
                     for (int pi = PH; pi < PPW; ++pi) issue(pi, ln);
                     fc1(s3, ln);
                 }
-                s3 = s3 == 2 ? 0 : s3 + 1;
-                s4 = (s4 + 1) & 3;
+                s3 = s3 == D ? 0 : s3 + 1;
+                s4 = s4 == D + 1 ? 0 : s4 + 1;
             };
             iter(CmBool<true>{}, 0);
 #pragma unroll 1
@@ -306,7 +314,7 @@ __global__ void __launch_bounds__(512, 1) chan_mlp_kernel(const ChanMlpArgs p) {
             if constexpr (LAG) {
                 const int ln = lane_now();
                 gelu(G - 1, ln);
-                fc2((s4 + 3) & 3, ln);
+                fc2(s4 == 0 ? D + 1 : s4 - 1, ln);
             }
             // ---- tile epilogue: one rounding, 16-byte stores straight from the accumulators; then the next tile's rows ----
             const int le = lane_now();
@@ -352,10 +360,10 @@ static int cm_grid_cap() {
     return cap;
 }
 
-template <typename T, int KS1>
-static int cm_launch(const ChanMlpArgs& a, hipStream_t s) {
-    using Geo = CmGeo<KS1, 2 * KS1>;
-    auto k = chan_mlp_kernel<T, KS1, 2 * KS1>;
+template <typename T, int KS1, int D>
+static int cm_launch_d(const ChanMlpArgs& a, hipStream_t s) {
+    using Geo = CmGeo<KS1, 2 * KS1, D>;
+    auto k = chan_mlp_kernel<T, KS1, 2 * KS1, D>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, Geo::LDS);
     if (e != hipSuccess) return (int)e;
     const int tiles = (a.M + CM_BM - 1) / CM_BM;
@@ -363,6 +371,19 @@ static int cm_launch(const ChanMlpArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), Geo::LDS, s, a);
     MLPK_LAUNCH_CHECK();
     return 0;
+}
+
+template <typename T, int KS1>
+static int cm_launch(const ChanMlpArgs& a, hipStream_t s) {
+    // MLPK_CM_DEPTH = 2 | 4 | 6: A/B aid (6 only while its rings fit the LDS).  Measured (profiles/r04_chanmlp_depth_ab.txt): no
+    // difference -- the kernel is bound by the GELU's VALU instructions (SQ_ACTIVE_INST_VALU 44 % of the time, MFMA busy 20 %), not by
+    // the weight stream -- so the shallow rings of the token kernel stay.
+    static const int want = getenv("MLPK_CM_DEPTH") ? atoi(getenv("MLPK_CM_DEPTH")) : 2;
+    if constexpr (CmGeo<KS1, 2 * KS1, 6>::LDS <= 160 * 1024) {
+        if (want >= 6) return cm_launch_d<T, KS1, 6>(a, s);
+    }
+    if (want >= 4) return cm_launch_d<T, KS1, 4>(a, s);
+    return cm_launch_d<T, KS1, 2>(a, s);
 }
 
 }  // namespace mlpk

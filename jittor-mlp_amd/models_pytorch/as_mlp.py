@@ -360,7 +360,10 @@ class AS_MLP(E.EngineModule):
                                  R=cur, res=N.RES_ADD, tag="as_conv", part=part)                     # x + conv3(norm2(.))
                     stats(cur, C, got)
                     if (p + "mlpf") in pk and E.channel_mlp_fused_supported(cd, C, hid):
-                        got = E.channel_mlp_fused(cur, rows, C, pk[p + "mlpf"], cur, R=cur, ln=(mean, rstd), ln_group=HW, part=part)
+                        # (its by-product statistics are one plane, summed inside a wave: always taken -- unlike the s3 tile's, whose
+                        # statistics epilogue costs more than the pass it saves, profiles/r04_epilogue_stats_ab.txt)
+                        got = E.channel_mlp_fused(cur, rows, C, pk[p + "mlpf"], cur, R=cur, ln=(mean, rstd), ln_group=HW,
+                                                  part=(ws, "l%d.mlppart" % li))
                     else:
                         E.gemm(cur, pk[p + "fc1f.w"], hbuf, rows, hid, C, bias=pk[p + "fc1f.b"], act=N.ACT_GELU,
                                ln=(mean, rstd, pk[p + "fc1f.csum"]), ln_group=HW, tag="as_fc1")
