@@ -344,22 +344,44 @@ __global__ void __launch_bounds__(MS_NT) mixshift_band_kernel(const MixShiftArgs
 #pragma unroll 1
     for (int branch = 0; branch < 2; ++branch) {
         __syncthreads();                                   // the previous branch's reads of the tile are done
-        // ---- stage: element (channel ch, tile row r, tile column q) <- rolled source or zero; consecutive threads = channels ----
+        // ---- stage: element (channel ch, tile row r, tile column q) <- rolled source or zero.  16-byte loads (8 channels of one
+        // pixel per thread, 4 consecutive threads = the 64 contiguous bytes of a pixel), UNCONDITIONAL: a position outside the map
+        // reads pixel 0 and stores zeros (behind `if (inside)` every load waits for the one before it -- one memory latency per
+        // element, which is what this kernel spent its time on: 0.5-0.9 TB/s, profiles/r04_traffic_models.txt) ----
         {
-            const int total = rows_t * cols_t * MS_CT;
-            for (int i = tid; i < total; i += MS_NT) {
-                const int ch = i % MS_CT;
-                const int px = i / MS_CT;
-                const int q = px % cols_t, r = px / cols_t;
-                const int yy = y0 + r - P, xx = q - P;
-                T v = from_f32<T>(0.f);
-                if (ch < nch && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) {
-                    int ys = yy, xs = xx;
+            constexpr int VPP = MS_CT / EPV;                   // vectors per pixel
+            const bool vec = sizeof(T) == 2 && (p.C % EPV) == 0 && (c0 % EPV) == 0 && (nch % EPV) == 0;
+            if (vec) {
+                const int total = rows_t * cols_t * VPP;
+                for (int i = tid; i < total; i += MS_NT) {
+                    const int vq = i % VPP;
+                    const int px = i / VPP;
+                    const int q = px % cols_t, r = px / cols_t;
+                    const int yy = y0 + r - P, xx = q - P;
+                    const bool inside = vq * EPV < nch && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+                    int ys = inside ? yy : 0, xs = inside ? xx : 0;
                     if (branch == 0) { xs -= sw; if (xs < 0) xs += p.W; }
                     else { ys -= sh; if (ys < 0) ys += p.H; }
-                    v = img[((size_t)ys * p.W + xs) * p.C + c0 + ch];
+                    const u32x4 raw = *reinterpret_cast<const u32x4*>(img + ((size_t)ys * p.W + xs) * p.C + c0 + (inside ? vq * EPV : 0));
+                    T e[EPV];
+                    __builtin_memcpy(e, &raw, 16);
+#pragma unroll
+                    for (int k = 0; k < EPV; ++k) tile[(vq * EPV + k) * plane + r * pitch + q] = inside ? e[k] : from_f32<T>(0.f);
                 }
-                tile[ch * plane + r * pitch + q] = v;
+            } else {
+                const int total = rows_t * cols_t * MS_CT;
+                for (int i = tid; i < total; i += MS_NT) {
+                    const int ch = i % MS_CT;
+                    const int px = i / MS_CT;
+                    const int q = px % cols_t, r = px / cols_t;
+                    const int yy = y0 + r - P, xx = q - P;
+                    const bool inside = ch < nch && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+                    int ys = inside ? yy : 0, xs = inside ? xx : 0;
+                    if (branch == 0) { xs -= sw; if (xs < 0) xs += p.W; }
+                    else { ys -= sh; if (ys < 0) ys += p.H; }
+                    const T v = img[((size_t)ys * p.W + xs) * p.C + c0 + (inside ? ch : 0)];
+                    tile[ch * plane + r * pitch + q] = inside ? v : from_f32<T>(0.f);
+                }
             }
             // the window reads run up to NV * EPV columns past a strip's start: zero the slack columns of every row
             const int slack = pitch - cols_t;

@@ -544,32 +544,31 @@ __global__ void __launch_bounds__(256) norm_shift_vec_kernel(const T* __restrict
             sh[e] = (beta ? beta[c + e] : 0.f) - mu * rs * g;
         }
         const int g0 = c / group, g1 = (c + 7) / group;
-        const int first1 = g1 * group - c;                  // first element of the vector that belongs to group g1 (if g1 != g0)
+        const int first1 = g1 != g0 ? g1 * group - c : 8;   // first element of the vector that belongs to group g1
         const T* src = in + (size_t)px * C + c;
+        // The four source vectors (two axes x the two groups a vector can straddle) are loaded UNCONDITIONALLY -- a source outside the
+        // map reads this pixel instead and is zeroed afterwards.  Behind `if (inside)` hipcc puts an s_waitcnt vmcnt(0) in front of
+        // every load: four memory latencies in a row per vector (the depthwise kernel's disease, profiles/r04_dwconv_variants.txt).
+        const int s0 = ksz / 2 - g0, s1 = ksz / 2 - g1;
+        const bool okw0 = (unsigned)(w + s0) < (unsigned)W, okw1 = (unsigned)(w + s1) < (unsigned)W;
+        const bool okh0 = (unsigned)(h + s0) < (unsigned)H, okh1 = (unsigned)(h + s1) < (unsigned)H;
+        float vw0[8], vw1[8], vh0[8], vh1[8];
+        ld8<T>(src + (okw0 ? (ptrdiff_t)s0 * C : 0), vw0);
+        ld8<T>(src + (okw1 ? (ptrdiff_t)s1 * C : 0), vw1);
+        ld8<T>(src + (okh0 ? (ptrdiff_t)s0 * W * C : 0), vh0);
+        ld8<T>(src + (okh1 ? (ptrdiff_t)s1 * W * C : 0), vh1);
+        float ow[8], oh[8];
 #pragma unroll
-        for (int dim = 3; dim >= 2; --dim) {
-            const int pos = dim == 2 ? h : w, lim = dim == 2 ? H : W;
-            const int step = dim == 2 ? W * C : C;
-            float o[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = 0.f;
-#pragma unroll
-            for (int part = 0; part < 2; ++part) {
-                if (part == 1 && g1 == g0) break;
-                const int s = ksz / 2 - (part ? g1 : g0);
-                if (pos + s < 0 || pos + s >= lim) continue;
-                float v[8];
-                ld8<T>(src + (ptrdiff_t)s * step, v);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float t = v[e] * sc[e] + sh[e];
-                    if (act == MLPK_ACT_GELU) t = gelu_t<T>(t);
-                    const bool mine = g1 == g0 || (part ? e >= first1 : e < first1);
-                    o[e] = mine ? t : o[e];
-                }
-            }
-            st8<T>((dim == 3 ? out_w : out_h) + (size_t)px * C + c, o);
+        for (int e = 0; e < 8; ++e) {
+            const bool lo = e < first1;                       // element of group g0
+            float tw = (lo ? vw0[e] : vw1[e]) * sc[e] + sh[e];
+            float th = (lo ? vh0[e] : vh1[e]) * sc[e] + sh[e];
+            if (act == MLPK_ACT_GELU) { tw = gelu_t<T>(tw); th = gelu_t<T>(th); }
+            ow[e] = (lo ? okw0 : okw1) ? tw : 0.f;
+            oh[e] = (lo ? okh0 : okh1) ? th : 0.f;
         }
+        st8<T>(out_w + (size_t)px * C + c, ow);
+        st8<T>(out_h + (size_t)px * C + c, oh);
     }
 }
 
