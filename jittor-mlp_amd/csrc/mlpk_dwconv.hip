@@ -320,6 +320,9 @@ extern "C" int mlpk_dwconv_affine_nhwc(int dtype, const void* x, void* out, int 
 #ifndef DWM_XCD
 #define DWM_XCD 1
 #endif
+#ifndef DWM_STAGES
+#define DWM_STAGES 2
+#endif
 #ifndef DWM_SKIP
 #define DWM_SKIP 0                                                  // 1: no MFMA phase; 2: no global loads / stores; 4: no LDS transposes
 #endif
@@ -550,26 +553,31 @@ __global__ void __launch_bounds__(NW * 64) dwconv_mfma_kernel(const T* __restric
             // MFMAs of step s.  Operands swapped (taps as A, plane rows as B): the accumulator then holds 4 consecutive x of ONE
             // row per lane -- 8 contiguous bytes of the plane -- instead of 4 rows of one column.
             f32x4 res[2][2];
-            DwmFrag av[2][2];
-            dwm_issue<0>(av[0][0], alo, ahi);
-            dwm_issue<32>(av[0][1], alo, ahi);
+            constexpr int NST = DWM_STAGES;                     // plane-row fragment pairs in flight: requested NST - 1 steps ahead
+            DwmFrag av[NST][2];
+            dwm_for<0, NST - 1>([&](auto pc) {
+                constexpr int s0 = decltype(pc)::value, ty0 = s0 / KS, i0 = s0 - ty0 * KS, off0 = ty0 * (16 * DWM_PITCH) + i0 * DWM_PITCH;
+                dwm_issue<off0>(av[s0][0], alo, ahi);
+                dwm_issue<off0 + 32>(av[s0][1], alo, ahi);
+            });
             dwm_for<0, 2 * KS>([&](auto sc) {
                 constexpr int st = decltype(sc)::value, ty = st / KS, i = st - ty * KS;
-                if constexpr (st + 1 < 2 * KS) {
-                    constexpr int ty1 = (st + 1) / KS, i1 = st + 1 - ty1 * KS, off = ty1 * (16 * DWM_PITCH) + i1 * DWM_PITCH;
-                    dwm_issue<off>(av[(st + 1) & 1][0], alo, ahi);
-                    dwm_issue<off + 32>(av[(st + 1) & 1][1], alo, ahi);
-                    dwm_wait<4>(av[st & 1][0], av[st & 1][1]);
-                } else {
-                    dwm_wait<0>(av[st & 1][0], av[st & 1][1]);
+                constexpr int ahead = st + NST - 1;
+                if constexpr (ahead < 2 * KS) {
+                    constexpr int ty1 = ahead / KS, i1 = ahead - ty1 * KS, off = ty1 * (16 * DWM_PITCH) + i1 * DWM_PITCH;
+                    dwm_issue<off>(av[ahead % NST][0], alo, ahi);
+                    dwm_issue<off + 32>(av[ahead % NST][1], alo, ahi);
                 }
+                // reads issued after this step's: 4 per step still ahead
+                constexpr int pending = (2 * KS - 1 - st < NST - 1 ? 2 * KS - 1 - st : NST - 1) * 4;
+                dwm_wait<pending>(av[st % NST][0], av[st % NST][1]);
                 const u32x4 tfi = j < CREG ? tf[j < CREG ? j : 0][i] : dwm_val(tfl[i]);
                 if constexpr (i == 0) {
-                    res[ty][0] = Mfma16<T>::run(tfi, dwm_val(av[st & 1][0]), f32x4{0.f, 0.f, 0.f, 0.f});
-                    res[ty][1] = Mfma16<T>::run(tfi, dwm_val(av[st & 1][1]), f32x4{0.f, 0.f, 0.f, 0.f});
+                    res[ty][0] = Mfma16<T>::run(tfi, dwm_val(av[st % NST][0]), f32x4{0.f, 0.f, 0.f, 0.f});
+                    res[ty][1] = Mfma16<T>::run(tfi, dwm_val(av[st % NST][1]), f32x4{0.f, 0.f, 0.f, 0.f});
                 } else {
-                    res[ty][0] = Mfma16<T>::run(tfi, dwm_val(av[st & 1][0]), res[ty][0]);
-                    res[ty][1] = Mfma16<T>::run(tfi, dwm_val(av[st & 1][1]), res[ty][1]);
+                    res[ty][0] = Mfma16<T>::run(tfi, dwm_val(av[st % NST][0]), res[ty][0]);
+                    res[ty][1] = Mfma16<T>::run(tfi, dwm_val(av[st % NST][1]), res[ty][1]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
