@@ -553,6 +553,7 @@ __global__ void __launch_bounds__(NW * 64) dwconv_mfma_kernel(const T* __restric
             // MFMAs of step s.  Operands swapped (taps as A, plane rows as B): the accumulator then holds 4 consecutive x of ONE
             // row per lane -- 8 contiguous bytes of the plane -- instead of 4 rows of one column.
             f32x4 res[2][2];
+            const f32x4 binit = {bz[j], bz[j], bz[j], bz[j]};
             constexpr int NST = DWM_STAGES;                     // plane-row fragment pairs in flight: requested NST - 1 steps ahead
             DwmFrag av[NST][2];
             dwm_for<0, NST - 1>([&](auto pc) {
@@ -572,9 +573,9 @@ __global__ void __launch_bounds__(NW * 64) dwconv_mfma_kernel(const T* __restric
                 constexpr int pending = (2 * KS - 1 - st < NST - 1 ? 2 * KS - 1 - st : NST - 1) * 4;
                 dwm_wait<pending>(av[st % NST][0], av[st % NST][1]);
                 const u32x4 tfi = j < CREG ? tf[j < CREG ? j : 0][i] : dwm_val(tfl[i]);
-                if constexpr (i == 0) {
-                    res[ty][0] = Mfma16<T>::run(tfi, dwm_val(av[st % NST][0]), f32x4{0.f, 0.f, 0.f, 0.f});
-                    res[ty][1] = Mfma16<T>::run(tfi, dwm_val(av[st % NST][1]), f32x4{0.f, 0.f, 0.f, 0.f});
+                if constexpr (i == 0) {                        // the accumulators start from the bias (one splat per channel, not 16 adds)
+                    res[ty][0] = Mfma16<T>::run(tfi, dwm_val(av[st % NST][0]), binit);
+                    res[ty][1] = Mfma16<T>::run(tfi, dwm_val(av[st % NST][1]), binit);
                 } else {
                     res[ty][0] = Mfma16<T>::run(tfi, dwm_val(av[st % NST][0]), res[ty][0]);
                     res[ty][1] = Mfma16<T>::run(tfi, dwm_val(av[st % NST][1]), res[ty][1]);
@@ -599,7 +600,7 @@ __global__ void __launch_bounds__(NW * 64) dwconv_mfma_kernel(const T* __restric
                 const u32x2 cw = *reinterpret_cast<const u32x2*>(cell);
                 T c4[4];
                 __builtin_memcpy(c4, &cw, 8);
-                f32x2 v[2] = {f32x2{a4.x + bz[j], a4.y + bz[j]}, f32x2{a4.z + bz[j], a4.w + bz[j]}};
+                f32x2 v[2] = {f32x2{a4.x, a4.y}, f32x2{a4.z, a4.w}};
                 gelu_pk_n<T, 2>(v);
                 const float g[4] = {v[0].x, v[0].y, v[1].x, v[1].y};
                 T o4[4];
