@@ -572,6 +572,77 @@ __global__ void __launch_bounds__(256) norm_shift_vec_kernel(const T* __restrict
     }
 }
 
+// The same operation for maps that FIT THE LDS (AS-MLP stages 3 and 4: 14 x 14 x 384 and 7 x 7 x 768 16-bit values = 147 / 74 KiB): one
+// workgroup per image.  t = act(norm(u)) is evaluated ONCE per element into an LDS copy of the image (the gather form above evaluates
+// it for each of its two outputs, and spends as many instructions on dividing its flat index into (n, h, w, c)); both outputs are then
+// 16-byte reads of that copy at the shifted pixel -- zero outside the map, two reads where a vector straddles two shift groups.
+template <typename T>
+__global__ void __launch_bounds__(512) norm_shift_img_kernel(const T* __restrict__ in, T* __restrict__ out_w, T* __restrict__ out_h, int H, int W, int C,
+                                                             int ksz, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, int act) {
+    extern __shared__ __attribute__((aligned(16))) char smem_img[];
+    u32x4* const img = reinterpret_cast<u32x4*>(smem_img);
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int CV = C / 8, HW = H * W, NV = HW * CV;
+    const int group = (C + ksz - 1) / ksz;
+    const float mu = mean[n], rs = rstd[n];
+    const float inv_cv = 1.0f / (float)CV, inv_w = 1.0f / (float)W;
+    const T* src = in + (size_t)n * HW * C;
+    // (index arithmetic by float reciprocals: exact for these ranges -- NV < 2^17, the quotients are at least 0.5 / CV away from an integer)
+    for (int v = tid; v < NV; v += 512) {
+        const int px = (int)(((float)v + 0.5f) * inv_cv);
+        const int c = (v - px * CV) * 8;
+        float x[8], o[8];
+        ld8<T>(src + (size_t)v * 8, x);
+        // (the expressions of norm_shift_vec_kernel, term for term: the two forms -- and mlpk_as_conv2, which is bit-equal to that one --
+        // must round alike)
+        float sc[8], sh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float g = gamma ? gamma[c + e] : 1.f;
+            sc[e] = rs * g;
+            sh[e] = (beta ? beta[c + e] : 0.f) - mu * rs * g;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float t = x[e] * sc[e] + sh[e];
+            if (act == MLPK_ACT_GELU) t = gelu_t<T>(t);
+            o[e] = t;
+        }
+        T r[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = from_f32<T>(o[e]);
+        u32x4 pk;
+        __builtin_memcpy(&pk, r, 16);
+        img[v] = pk;
+    }
+    __syncthreads();
+    T* const dw = out_w + (size_t)n * HW * C;
+    T* const dh = out_h + (size_t)n * HW * C;
+    for (int v = tid; v < NV; v += 512) {
+        const int px = (int)(((float)v + 0.5f) * inv_cv);
+        const int cv = v - px * CV, c = cv * 8;
+        const int h = (int)(((float)px + 0.5f) * inv_w);
+        const int w = px - h * W;
+        const int ga = c / group, gb = (c + 7) / group;
+        const int first1 = gb != ga ? gb * group - c : 8;      // first element of the vector that belongs to group gb
+        const int s0 = ksz / 2 - ga, s1 = ksz / 2 - gb;
+        const bool okw0 = (unsigned)(w + s0) < (unsigned)W, okw1 = (unsigned)(w + s1) < (unsigned)W;
+        const bool okh0 = (unsigned)(h + s0) < (unsigned)H, okh1 = (unsigned)(h + s1) < (unsigned)H;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        // element e < first1 from the group-ga source, the others from the group-gb source: a 16-bit lane mask over the two vectors
+        const u32x4 a_w = okw0 ? img[v + s0 * CV] : z, b_w = okw1 ? img[v + s1 * CV] : z;
+        const u32x4 a_h = okh0 ? img[v + s0 * W * CV] : z, b_h = okh1 ? img[v + s1 * W * CV] : z;
+        unsigned m[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m[q] = (2 * q < first1 ? 0x0000ffffu : 0u) | (2 * q + 1 < first1 ? 0xffff0000u : 0u);
+        const u32x4 ow = {(a_w.x & m[0]) | (b_w.x & ~m[0]), (a_w.y & m[1]) | (b_w.y & ~m[1]), (a_w.z & m[2]) | (b_w.z & ~m[2]), (a_w.w & m[3]) | (b_w.w & ~m[3])};
+        const u32x4 oh = {(a_h.x & m[0]) | (b_h.x & ~m[0]), (a_h.y & m[1]) | (b_h.y & ~m[1]), (a_h.z & m[2]) | (b_h.z & ~m[2]), (a_h.w & m[3]) | (b_h.w & ~m[3])};
+        *reinterpret_cast<u32x4*>(dw + (size_t)v * 8) = ow;
+        *reinterpret_cast<u32x4*>(dh + (size_t)v * 8) = oh;
+    }
+}
+
 // ================================ ConvMixer depthwise half ================================
 // thread = (image, row y, strip of 8 outputs along x, channel c); the k*k taps of channel c and a
 // sliding (8 + k - 1)-wide input window live in registers, lanes run along c (coalesced).
@@ -704,6 +775,25 @@ extern "C" int mlpk_norm_shift_nhwc(int dtype, const void* in, void* out_w, void
     if (((uintptr_t)in | (uintptr_t)out_w | (uintptr_t)out_h) & 15) return MLPK_EALIGN;
     if (in == out_w || in == out_h) return MLPK_ESHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // maps that fit the LDS: one workgroup per image, the activation evaluated once per element (MLPK_NORM_SHIFT_IMG=0: the gather form, A/B aid)
+    const size_t img_bytes = (size_t)H * W * C * 2;
+    static const bool img_off = getenv("MLPK_NORM_SHIFT_IMG") && atoi(getenv("MLPK_NORM_SHIFT_IMG")) == 0;
+    if (!img_off && img_bytes <= 160 * 1024 && (size_t)H * W * (C / 8) < (1u << 17)) {
+        hipError_t e;
+        if (dtype == MLPK_BF16) {
+            auto k = norm_shift_img_kernel<bf16_t>;
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)img_bytes);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(k, dim3(N), dim3(512), img_bytes, s, (const bf16_t*)in, (bf16_t*)out_w, (bf16_t*)out_h, H, W, C, kernel_size, mean, rstd, gamma, beta, act);
+        } else {
+            auto k = norm_shift_img_kernel<f16_t>;
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)img_bytes);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(k, dim3(N), dim3(512), img_bytes, s, (const f16_t*)in, (f16_t*)out_w, (f16_t*)out_h, H, W, C, kernel_size, mean, rstd, gamma, beta, act);
+        }
+        MLPK_LAUNCH_CHECK();
+        return 0;
+    }
     if (dtype == MLPK_BF16) {
         hipLaunchKernelGGL((norm_shift_vec_kernel<bf16_t>), dim3(grid_for(total / 8)), dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out_w,
                            (bf16_t*)out_h, N, H, W, C, kernel_size, mean, rstd, gamma, beta, act);
