@@ -285,3 +285,41 @@ def test_torch_shift_runs_on_cpu_and_matches_the_reference_pins():
     assert torch.equal(y[:, 6:8, :, 1:], x[:, 6:8, :, :5]) and torch.equal(y[:, 4:6], x[:, 4:6])
     with pytest.raises(NotImplementedError):        # the module itself is the native op: no CPU path (shift_cuda.py:170-173)
         ut.Shift(3, 2)(x)
+
+
+def test_fused_channel_mlp_packing_orders(pkg):
+    """engine.pack_channel_mlp_fused (host side of mlpk_channel_mlp, include/mlpk.h): W1 folded with the norm's gamma and zero-padded to
+    (groups * 32, 256), b1 + W1 beta, csum = row sums of the ROUNDED folded W1, W2 with its columns in mlpk_token_mlp's layout-1 order
+    (slot 8 f + e <- hidden unit e < 4 ? 4 f + e : 16 + 4 f + e - 4) and its rows in the kernel's store order (row 16 h + 4 f + r <-
+    channel 8 f + 4 h + r inside every 32), an optional per-channel scale folded into W2's rows and b2 -- all on CPU tensors."""
+    E = pkg.engine
+    g = torch.Generator().manual_seed(7)
+    C, T = 96, 200                                          # hidden not a multiple of 32: 7 groups, 24 zero columns
+    w1, b1 = torch.randn((T, C), generator=g), torch.randn((T,), generator=g)
+    w2, b2 = torch.randn((C, T), generator=g), torch.randn((C,), generator=g)
+    gamma, beta, cs = torch.rand((C,), generator=g) + 0.5, torch.randn((C,), generator=g), torch.rand((C,), generator=g) + 0.5
+    dev = torch.device("cpu")
+    for dt in (torch.bfloat16, torch.float16):
+        w1p, b1p, csum, w2p, b2p, nch = E.pack_channel_mlp_fused(w1, b1, w2, b2, dt, dev, gamma, beta, cscale=cs)
+        assert nch == 7 and tuple(w1p.shape) == (224, 256) and tuple(w2p.shape) == (C, 224) and w1p.dtype == dt and w2p.dtype == dt
+        wf = (w1 * gamma.view(1, -1)).to(dt)
+        assert torch.equal(w1p[:T, :C], wf) and not w1p[T:].any() and not w1p[:, C:].any()
+        assert torch.allclose(b1p[:T], b1 + w1 @ beta, atol=1e-5) and not b1p[T:].any()
+        assert torch.equal(csum, w1p.float().sum(1))
+        assert torch.allclose(b2p, b2 * cs)
+        w2s = torch.zeros((C, 224), dtype=dt)
+        w2s[:, :T] = (w2 * cs.view(-1, 1)).to(dt)
+        for row in range(C):
+            q, rr = divmod(row, 32)
+            h, f, r = rr // 16, (rr // 4) % 4, rr % 4
+            src_row = 32 * q + 8 * f + 4 * h + r
+            for col in (0, 3, 4, 7, 8, 31, 32 + 13, 192 + 5, 223):
+                grp, sl = divmod(col, 32)
+                f2, e = sl // 8, sl % 8
+                src_col = 32 * grp + (4 * f2 + e if e < 4 else 16 + 4 * f2 + e - 4)
+                assert w2p[row, col] == w2s[src_row, src_col], (row, col)
+        # every row / column is used exactly once
+        assert torch.allclose(torch.sort(w2p.double().abs().sum(1))[0], torch.sort(w2s.double().abs().sum(1))[0], rtol=1e-12)
+    # no norm: no csum, weights unfolded
+    w1p, b1p, csum, w2p, b2p, nch = E.pack_channel_mlp_fused(w1, b1, w2, b2, torch.bfloat16, dev)
+    assert csum is None and torch.equal(w1p[:T, :C], w1.to(torch.bfloat16)) and torch.allclose(b1p[:T], b1) and torch.allclose(b2p, b2)
