@@ -28,6 +28,55 @@ class SubModule(E.EngineModule):
         return self._get_pack(x.dtype, x.device)
 
 
+class PreNormResidualMLP(SubModule):
+    """fn(LayerNorm(x)) + x  (vip.py:6-13, s2_mlp_v2.py:31-38, s2_mlp_v1.py, hire_mlp.py: the families' `PreNormResidual`).  Inside a model
+    it is a parameter container (`fn`, `norm`); on its own it is callable like the reference's
+      * around the channel MLP  nn.Sequential(Linear, GELU, Dropout, Linear, Dropout):  LayerNorm fold + fc1 + GELU + fc2 + residual through
+        the same kernels as the enclosing model's forward (mlpk_gemm_nt pair, or mlpk_channel_mlp for a narrow width);
+      * around a module that is itself callable on its own (S2Attention, ParallelWeightedSum, ...): LayerNorm through mlpk_row_stats +
+        mlpk_norm_apply, the module, then the residual add."""
+
+    def __init__(self, dim, fn):
+        super().__init__()
+        self.fn = fn
+        self.norm = nn.LayerNorm(dim)
+
+    def _mlp(self):
+        fn = self.fn
+        if isinstance(fn, nn.Sequential):
+            lin = [m for m in fn if isinstance(m, nn.Linear)]
+            rest = [m for m in fn if not isinstance(m, (nn.Linear, nn.GELU, nn.Dropout))]
+            if len(lin) == 2 and not rest and lin[0].out_features == lin[1].in_features and lin[1].out_features == lin[0].in_features:
+                return lin
+        return None
+
+    def _pack(self, dtype, device):
+        pk = {}
+        lin = self._mlp()
+        if lin is not None:
+            pack_channel_mlp(pk, "", self.norm, lin[0], lin[1], dtype, device)
+        else:
+            pk["ln.g"], pk["ln.b"] = E.f32(self.norm.weight, device), E.f32(self.norm.bias, device)
+        return pk
+
+    def forward(self, x):
+        C = self.norm.normalized_shape[0]
+        pk = self._begin(x, C)
+        rows = x.numel() // C
+        with E.on_device(x):
+            ws = self._get_space(rows, x.dtype, x.device)
+            xb = ws.get("pn.x", (rows, C))
+            xb.copy_(x.reshape(rows, C))
+            lin = self._mlp()
+            if lin is not None:
+                channel_mlp(ws, xb, rows, C, pk, "", lin[0].out_features, eps=self.norm.eps)
+                return xb.reshape(x.shape).clone()
+            mean, rstd = layernorm_stats(ws, xb, rows, C, eps=self.norm.eps)
+            xn = ws.get("pn.xn", (rows, C))
+            E.norm_apply(xb, rows, C, C, mean=mean, rstd=rstd, gamma=pk["ln.g"], beta=pk["ln.b"], out_rm=xn, ld_rm=C)
+            return self.fn(xn.reshape(x.shape)) + x
+
+
 def two_layer_mlp(ws, pk, xb, rows, dim, hidden, out_dim):
     """out = fc2(gelu(fc1(x))) on channel-last rows xb (rows, K-padded dim): two NT GEMMs, bias + exact GELU in the first epilogue"""
     h = ws.get("mlp.hid", (rows, pk["fc2.w"].shape[1]))

@@ -9,16 +9,13 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import BlockSequential, Holder, channel_mlp, finalize_stats, head_linear, layernorm_stats, stage_embed, pack_channel_mlp
+from .common import PreNormResidualMLP, BlockSequential, Holder, channel_mlp, finalize_stats, head_linear, layernorm_stats, stage_embed, pack_channel_mlp
 from .s2_mlp_v2 import SHIFT_MODES
 from .utils.tools import pair
 
 
-class PreNormResidual(Holder):
-    def __init__(self, dim, fn):
-        super().__init__()
-        self.fn = fn
-        self.norm = nn.LayerNorm(dim)
+class PreNormResidual(PreNormResidualMLP):
+    """fn(LayerNorm(x)) + x: a parameter container inside a model, callable on its own like the reference's (common.PreNormResidualMLP)."""
 
 
 class Spatial_Shift(Holder):

@@ -20,18 +20,15 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import (BlockSequential, Holder, channel_mlp, finalize_stats, head_linear, layernorm_stats, split_attention_forward,
+from .common import (PreNormResidualMLP, BlockSequential, Holder, channel_mlp, finalize_stats, head_linear, layernorm_stats, split_attention_forward,
                      split_attention_weights, standalone_space, stage_embed, pack_channel_mlp)
 from .utils.tools import pair
 
 SHIFT_MODES = {"reference_inplace": N.SHIFT_S2_REF, "shift": N.SHIFT_S2}
 
 
-class PreNormResidual(Holder):
-    def __init__(self, dim, fn):
-        super().__init__()
-        self.fn = fn
-        self.norm = nn.LayerNorm(dim)
+class PreNormResidual(PreNormResidualMLP):
+    """fn(LayerNorm(x)) + x: a parameter container inside a model, callable on its own like the reference's (common.PreNormResidualMLP)."""
 
 
 def _spatial_shift(x, branch, mode):

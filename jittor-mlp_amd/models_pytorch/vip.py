@@ -16,16 +16,13 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import (BlockSequential, Holder, adopt_blocks, channel_mlp, embed_patches, finalize_stats, head_linear, layernorm_stats,
+from .common import (PreNormResidualMLP, BlockSequential, Holder, adopt_blocks, channel_mlp, embed_patches, finalize_stats, head_linear, layernorm_stats,
                      split_attention_forward, split_attention_weights, standalone_space, pack_channel_mlp)
 from .utils.tools import pair
 
 
-class PreNormResidual(Holder):
-    def __init__(self, dim, fn):
-        super().__init__()
-        self.fn = fn
-        self.norm = nn.LayerNorm(dim)
+class PreNormResidual(PreNormResidualMLP):
+    """fn(LayerNorm(x)) + x: a parameter container inside a model, callable on its own like the reference's (common.PreNormResidualMLP)."""
 
 
 class ParallelSum(Holder):

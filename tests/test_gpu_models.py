@@ -9,6 +9,7 @@ Tolerances (north star: 1e-5 fp32 / 1e-3 fp16; SURVEY Appendix C for bf16):
         from its fp32 logits, so 1e-3 is not attainable by any bf16 implementation), with the per-model exceptions of
         BF16_REAL_EXCEPTIONS; 1.5e-2 on the tiny configs (random norm statistics, logits of magnitude ~1).
 """
+import copy
 import json
 import os
 
@@ -698,3 +699,24 @@ def test_inner_modules_callable_like_the_reference(dtype):
     close(got, want, "AS-MLP Mlp")
     with pytest.raises(NotImplementedError):
         mlp.cpu()(xa)                                                            # no CPU path, as everywhere
+    # round 4: PreNormResidual of ViP / S2-MLP v1 / v2 (vip.py:6-13, s2_mlp_v2.py:31-38) on its own -- around the channel MLP Sequential
+    # (two widths: the GEMM pair, and the one-kernel form of a narrow stage) and around a module that is callable itself (S2Attention)
+    nn = torch.nn
+    for mod_, width, hid in ((vip.PreNormResidual, 256, 512), (s2.PreNormResidual, 96, 384), (s1.PreNormResidual, 64, 200)):
+        pn = mod_(width, nn.Sequential(nn.Linear(width, hid), nn.GELU(), nn.Dropout(0.), nn.Linear(hid, width), nn.Dropout(0.))).eval()
+        with torch.no_grad():
+            pn.norm.weight.copy_(torch.randn(width) * 0.3 + 1.0)
+            pn.norm.bias.copy_(torch.randn(width) * 0.2)
+        xp = torch.randn(2, 5, 7, width).to(dtype)
+        pd = copy.deepcopy(pn).double()
+        want = (pd.fn(pd.norm(xp.double())) + xp.double()).detach()               # the held torch modules ARE the reference's lines
+        close(pn.to(DEV)(xp.to(DEV)), want, "%s around the channel MLP, width %d" % (mod_.__module__, width))
+    pa = s2.PreNormResidual(32, s2.S2Attention(32)).eval()
+    att2 = pa.fn
+    xs2 = torch.randn(2, 6, 5, 32).to(dtype)
+    ln = torch.nn.functional.layer_norm(xs2.double(), (32,), pa.norm.weight.detach().double(), pa.norm.bias.detach().double())
+    t = torch.nn.functional.linear(ln, att2.mlp1.weight.detach().double(), att2.mlp1.bias.detach().double())
+    x1, x2, x3 = F.spatial_shift1(t[..., :32].clone(), mode=att2.shift_mode), F.spatial_shift2(t[..., 32:64].clone(), mode=att2.shift_mode), t[..., 64:]
+    a = F.split_attention(x1, x2, x3, att2.split_attention.mlp1.weight.detach().double(), att2.split_attention.mlp2.weight.detach().double())
+    want = torch.nn.functional.linear(a, att2.mlp2.weight.detach().double(), att2.mlp2.bias.detach().double()) + xs2.double()
+    close(pa.to(DEV)(xs2.to(DEV)), want, "PreNormResidual around S2Attention")
