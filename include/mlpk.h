@@ -44,6 +44,7 @@
  *   mlpk_as_conv2       AxialShift's core in ONE kernel: GroupNorm + GELU, both axial shifts, conv2_1 and conv2_2 with their GELUs and the sum
  *                       (as_mlp.py:64-66,84-93; utils/shift_cuda.py:49-69): the shifts are LDS read addresses of the MFMA operands
  *   mlpk_channel_mlp    fc1 + GELU + fc2 + residual of a channel MLP on narrow (C <= 192) channel-last rows in ONE kernel (as_mlp.py:36-52)
+ *   mlpk_swin_spatial   LayerNorm + window partition + multi-head spatial MLP + merge + residual of a Swin-MLP block in ONE kernel (swin_mlp.py:97-151)
  *   mlpk_cycle_shift    the sampling half of CycleFC (cycle_mlp.py:104-131: deform_conv2d with a 1 x 1 kernel and fixed integer
  *                       offsets = a per-channel cyclic pixel shift with zero fill); the 1 x 1 convolution is mlpk_gemm_nt
  *   mlpk_split_sum      the reduction of SplitAttention (vip.py:49-50; s2_mlp_v2.py:43-44), with the
@@ -491,6 +492,19 @@ int mlpk_window_gather(int dtype, const void* x, void* windows, int B, int H, in
                        int Hp, int Wp, void* stream);
 int mlpk_window_scatter_add(int dtype, void* x, const void* windows, int B, int H, int W, int C, int ws, int pad_t,
                             int pad_l, int Hp, int Wp, void* stream);
+
+/* ---- Swin-MLP: the spatial-MLP half of a block in ONE kernel (ABI 8, round 4) ------------------------------------------------
+ * x[b,y,x',:] += crop(merge(spatial_mlp(partition(pad(LayerNorm(x))))))   (swin_mlp.py:97-151): LayerNorm with the given row statistics
+ * (mean / rstd over x's B*H*W rows) and gamma / beta, zero padding to (Hp, Wp) with pad_t rows above and pad_l columns left, windows of
+ * ws x ws positions, the grouped Conv1d over the ws^2 positions -- one (ws^2 x ws^2) matrix per head, head h = channels [32 h, 32 h + 32) --
+ * and the residual, in place.  16-bit dtypes, C == 32 * heads (heads <= 24), ws^2 <= 64.
+ *   w (heads, 64, 64): w[h][t_out][t_in] zero-padded (the Conv1d weight (heads * ws^2, ws^2, 1) reshaped); bias (heads, 64) zero-padded.
+ * The normalised window is rounded to the storage type once (MFMA operand), the product once, the sum with x once -- the roundings of the
+ * five-pass form it replaces (mlpk_norm_apply, mlpk_window_gather, transpose, mlpk_gemm_nt, mlpk_window_scatter_add). */
+int mlpk_swin_spatial_supported(int dtype, int C, int heads, int ws);
+int mlpk_swin_spatial(int dtype, void* x, int B, int H, int W, int C, int ws, int pad_t, int pad_l, int Hp, int Wp, int heads,
+                      const float* mean, const float* rstd, const float* gamma, const float* beta, const void* w, const float* bias,
+                      void* stream);
 
 /* ---- small utilities ------------------------------------------------------------------------ */
 /* dst[i] = (dst_dtype) src[i], n elements */

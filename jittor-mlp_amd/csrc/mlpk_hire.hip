@@ -491,7 +491,210 @@ static int mixshift_band_launch(const MixShiftArgs& a, hipStream_t s) {
     return 0;
 }
 
+// ================================ Swin-MLP: the whole spatial-MLP half of a block in one kernel ================================
+// swin_mlp.py:97-151: x <- x + merge(crop(spatial_mlp(partition(pad(LayerNorm(x)))))) where spatial_mlp is a grouped Conv1d over the ws^2
+// positions of a window, one (ws^2 x ws^2) matrix per head, a head = C / heads consecutive channels.  As separate passes this was
+// normalise, window gather, per-window transpose, a block-diagonal GEMM (heads x the useful flops, on the generic tile) and the
+// scatter-add: five trips over the tensor for 0.5 MFLOP per window.  Here a workgroup owns ONE window:
+//   * its ws^2 tokens are read once (16-byte loads from clamped addresses; a padded position is zeros, swin_mlp.py:101-102), normalised
+//     with the given row statistics and written TRANSPOSED into LDS as [channel][token] (the matrix cores want a lane's 8 k-values --
+//     tokens -- contiguous); the raw values stay in registers for the residual;
+//   * head h: out[t][c] = sum_s W_h[t][s] xn[s][c] + b_h[t] for its 32 channels -- v_mfma_f32_32x32x16 with W_h (zero-padded to 64 x 64,
+//     fragments straight from global: 8 KiB per head, cache-resident) as A and the LDS image as B: 8 MFMAs per head;
+//   * the results go back through the same LDS bytes as [token][channel], are added to the raw values and stored in place.
+// Requires C / heads == 32 (every Swin-MLP of the reference) and ws^2 <= 64.
+struct SwinArgs {
+    void* x;                 // (B, H, W, C) in place
+    const float* mean;       // LayerNorm statistics of x's rows
+    const float* rstd;
+    const float* gamma;
+    const float* beta;
+    const void* w;           // (heads, 64, 64) zero-padded [t_out][t_in]
+    const float* bias;       // (heads, 64)
+    int B, H, W, C, ws, pad_t, pad_l, nWy, nWx, heads;
+};
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <typename T> struct SwinMma;
+template <> struct SwinMma<bf16_t> {
+    static __device__ __forceinline__ f32x16 run(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct SwinMma<f16_t> {
+    static __device__ __forceinline__ f32x16 run(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+
+constexpr int SW_NT = 256;
+constexpr int SW_TPITCH = 64 * 2 + 16;                       // LDS row of the transposed image: 64 tokens + 16 bytes (bank spread)
+constexpr int SW_MAXI = 20;                                  // (token, 8-channel chunk) items per thread: ws^2 * C / 8 / 256 <= 20 (C <= 768 at ws = 7)
+
+template <typename T>
+__global__ void __launch_bounds__(SW_NT) swin_spatial_kernel(const SwinArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_sw[];
+    T* __restrict__ x = reinterpret_cast<T*>(p.x);
+    const T* __restrict__ wgt = reinterpret_cast<const T*>(p.w);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = p.C, CV = C / 8, ws = p.ws, T2 = ws * ws;
+    const int win = blockIdx.x;
+    const int wx = win % p.nWx, wy = (win / p.nWx) % p.nWy, b = win / (p.nWx * p.nWy);
+    const int nitem = T2 * CV;
+    const int opitch = 2 * C + 16;                           // LDS row of the result image [token][channel]
+    // zero the k-padding columns (tokens T2 .. 63) of every channel row
+    for (int i = tid; i < C * (64 - T2); i += SW_NT) {
+        const int ch = i / (64 - T2), t = T2 + i % (64 - T2);
+        *reinterpret_cast<T*>(smem_sw + ch * SW_TPITCH + t * 2) = from_f32<T>(0.f);
+    }
+    u32x4 raw[SW_MAXI];
+    const float inv_cv = 1.0f / (float)CV, inv_ws = 1.0f / (float)ws;
+#pragma unroll
+    for (int k = 0; k < SW_MAXI; ++k) {
+        const int it = tid + k * SW_NT;
+        raw[k] = u32x4{0u, 0u, 0u, 0u};
+        if (it < nitem) {
+            const int t = (int)(((float)it + 0.5f) * inv_cv), cq = it - t * CV;
+            const int ty = (int)(((float)t + 0.5f) * inv_ws), tx = t - ty * ws;
+            const int yy = wy * ws + ty - p.pad_t, xx = wx * ws + tx - p.pad_l;
+            const bool inside = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+            const size_t row = ((size_t)b * p.H + (inside ? yy : 0)) * p.W + (inside ? xx : 0);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(x + row * C + cq * 8);
+            raw[k] = v;
+            const float mu = p.mean[row], rs = p.rstd[row];
+            T e[8];
+            __builtin_memcpy(e, &v, 16);
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gamma + cq * 8), g1 = *reinterpret_cast<const f32x4*>(p.gamma + cq * 8 + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.beta + cq * 8), b1 = *reinterpret_cast<const f32x4*>(p.beta + cq * 8 + 4);
+            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float xn = (to_f32(e[q]) - mu) * rs * gg[q] + bb[q];
+                *reinterpret_cast<T*>(smem_sw + (cq * 8 + q) * SW_TPITCH + t * 2) = inside ? from_f32<T>(xn) : from_f32<T>(0.f);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- head by head: out (64 x 32) = W_h (64 x 64) . xn_h (64 tokens x 32 channels) ----
+    const int n = lane & 31, kh = lane >> 5;
+    f32x16 acc[2];
+    // every wave walks its heads (wave, wave + 4, ...); the results are written after a barrier that follows ALL MFMA reads of the image
+    const int nh_w = (p.heads - wave + SW_NT / 64 - 1) / (SW_NT / 64);      // heads of this wave: wave, wave + 4, ...
+    // results of up to 6 heads per wave (24 heads / 4 waves) are kept in registers as packed 16-bit values: 16 per lane and head
+    u32x4 res[6][2][2];
+#pragma unroll
+    for (int hi = 0; hi < 6; ++hi) {
+        if (hi < nh_w) {
+            const int h = wave + hi * (SW_NT / 64);
+            const T* wh = wgt + (size_t)h * 64 * 64;
+            acc[0] = acc[1] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const u32x4 bfrag = *reinterpret_cast<const u32x4*>(smem_sw + (h * 32 + n) * SW_TPITCH + (16 * ks + 8 * kh) * 2);
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    const u32x4 afrag = *reinterpret_cast<const u32x4*>(wh + (size_t)(32 * mb + n) * 64 + 16 * ks + 8 * kh);
+                    acc[mb] = SwinMma<T>::run(afrag, bfrag, acc[mb]);
+                }
+            }
+            // lane (channel n, kh): acc[mb][r] = out[token 32 mb + 8 (r / 4) + 4 kh + (r % 4)][channel 32 h + n]; + bias, round, pack
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                T e[16];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + h * 64 + 32 * mb + 8 * q4 + 4 * kh);
+                    e[4 * q4 + 0] = from_f32<T>(acc[mb][4 * q4 + 0] + bv.x);
+                    e[4 * q4 + 1] = from_f32<T>(acc[mb][4 * q4 + 1] + bv.y);
+                    e[4 * q4 + 2] = from_f32<T>(acc[mb][4 * q4 + 2] + bv.z);
+                    e[4 * q4 + 3] = from_f32<T>(acc[mb][4 * q4 + 3] + bv.w);
+                }
+                __builtin_memcpy(&res[hi][mb][0], e, 16);
+                __builtin_memcpy(&res[hi][mb][1], e + 8, 16);
+            }
+        }
+    }
+    __syncthreads();                                         // every wave is done reading the transposed image: its bytes become the result image
+#pragma unroll
+    for (int hi = 0; hi < 6; ++hi) {
+        if (hi < nh_w) {
+            const int h = wave + hi * (SW_NT / 64);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                T e[16];
+                __builtin_memcpy(e, &res[hi][mb][0], 16);
+                __builtin_memcpy(e + 8, &res[hi][mb][1], 16);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int t = 32 * mb + 8 * (r >> 2) + 4 * kh + (r & 3);
+                    if (t < T2) *reinterpret_cast<T*>(smem_sw + t * opitch + (h * 32 + n) * 2) = e[r];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- residual and store (the positions inside the map only: the crop of swin_mlp.py:148-149) ----
+#pragma unroll
+    for (int k = 0; k < SW_MAXI; ++k) {
+        const int it = tid + k * SW_NT;
+        if (it < nitem) {
+            const int t = (int)(((float)it + 0.5f) * inv_cv), cq = it - t * CV;
+            const int ty = (int)(((float)t + 0.5f) * inv_ws), tx = t - ty * ws;
+            const int yy = wy * ws + ty - p.pad_t, xx = wx * ws + tx - p.pad_l;
+            if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) {
+                const u32x4 yv = *reinterpret_cast<const u32x4*>(smem_sw + t * opitch + cq * 16);
+                T a[8], y8[8], o[8];
+                __builtin_memcpy(a, &raw[k], 16);
+                __builtin_memcpy(y8, &yv, 16);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) o[q] = from_f32<T>(to_f32(a[q]) + to_f32(y8[q]));
+                u32x4 ov;
+                __builtin_memcpy(&ov, o, 16);
+                *reinterpret_cast<u32x4*>(x + (((size_t)b * p.H + yy) * p.W + xx) * C + cq * 8) = ov;
+            }
+        }
+    }
+}
+
 }  // namespace mlpk
+
+extern "C" int mlpk_swin_spatial_supported(int dtype, int C, int heads, int ws) {
+    return (dtype == MLPK_F16 || dtype == MLPK_BF16) && heads > 0 && heads <= 24 && C == heads * 32 && ws >= 1 && ws * ws <= 64 &&
+           (ws * ws * (C / 8) + SW_NT - 1) / SW_NT <= SW_MAXI;
+}
+
+extern "C" int mlpk_swin_spatial(int dtype, void* x, int B, int H, int W, int C, int ws, int pad_t, int pad_l, int Hp, int Wp, int heads,
+                                 const float* mean, const float* rstd, const float* gamma, const float* beta, const void* w, const float* bias,
+                                 void* stream) {
+    if (!x || !mean || !rstd || !gamma || !beta || !w || !bias) return MLPK_ENULL;
+    if (B <= 0 || H <= 0 || W <= 0 || ws <= 0 || Hp % ws || Wp % ws || Hp < H + pad_t || Wp < W + pad_l || pad_t < 0 || pad_l < 0) return MLPK_ESHAPE;
+    if (!mlpk_swin_spatial_supported(dtype, C, heads, ws)) return MLPK_ESHAPE;
+    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)bias) & 15) return MLPK_EALIGN;
+    SwinArgs a;
+    a.x = x; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.w = w; a.bias = bias;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.ws = ws; a.pad_t = pad_t; a.pad_l = pad_l; a.nWy = Hp / ws; a.nWx = Wp / ws; a.heads = heads;
+    const long long nwin = (long long)B * a.nWy * a.nWx;
+    if (nwin > 0x7fffffffLL) return MLPK_ESHAPE;
+    const int t2 = ws * ws;
+    const int lds_t = C * SW_TPITCH, lds_o = t2 * (2 * C + 16);
+    const int lds = lds_t > lds_o ? lds_t : lds_o;
+    if (lds > 160 * 1024) return MLPK_ESHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipError_t e;
+    if (dtype == MLPK_BF16) {
+        auto k = swin_spatial_kernel<bf16_t>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(k, dim3((unsigned)nwin), dim3(SW_NT), lds, s, a);
+    } else {
+        auto k = swin_spatial_kernel<f16_t>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(k, dim3((unsigned)nwin), dim3(SW_NT), lds, s, a);
+    }
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int mlpk_mixshift_nhwc(int dtype, const void* x, void* out, int B, int H, int W, int C, int groups, const int* shift,
                                   const int* ksize, const float* w_lr, const float* b_lr, const float* w_td, const float* b_td,

@@ -346,6 +346,29 @@ def pack_token_mlp(w1, b1, w2, b2, dtype, device, sp, layout=None, t_rows=None):
     return w1p, b1p, w2p, f32(b2, device), nch, layout
 
 
+def swin_spatial_supported(dtype, C, heads, ws):
+    """mlpk_swin_spatial: the spatial-MLP half of a Swin-MLP block in one kernel (MLPK_SWIN_SPATIAL_FUSED=0: the five passes, A/B aid)"""
+    return (dtype in (torch.float16, torch.bfloat16) and os.environ.get("MLPK_SWIN_SPATIAL_FUSED", "1") != "0"
+            and bool(N.lib().mlpk_swin_spatial_supported(dtype_code(dtype), C, heads, ws)))
+
+
+def pack_swin_spatial(weight, bias, heads, ws, dtype, device):
+    """grouped Conv1d weight (heads * ws^2, ws^2, 1) / bias (heads * ws^2) -> (heads, 64, 64) [t_out][t_in] and (heads, 64), zero-padded"""
+    t = ws * ws
+    w = weight.detach().to(device=device, dtype=torch.float32).reshape(heads, t, t)
+    wp = torch.zeros((heads, 64, 64), dtype=dtype, device=device)
+    wp[:, :t, :t] = w.to(dtype)
+    bp = torch.zeros((heads, 64), dtype=torch.float32, device=device)
+    if bias is not None:
+        bp[:, :t] = bias.detach().to(device=device, dtype=torch.float32).reshape(heads, t)
+    return wp.contiguous(), bp.contiguous()
+
+
+def swin_spatial(x, B, H, W, C, ws, pad_t, pad_l, Hp, Wp, heads, mean, rstd, gamma, beta, wp, bp):
+    N.check(N.lib().mlpk_swin_spatial(dtype_code(x.dtype), ptr(x), B, H, W, C, ws, pad_t, pad_l, Hp, Wp, heads, ptr(mean), ptr(rstd), ptr(gamma),
+                                      ptr(beta), ptr(wp), ptr(bp), stream()), "mlpk_swin_spatial")
+
+
 def channel_mlp_fused_supported(dtype, C, hidden):
     """mlpk_channel_mlp: the whole channel MLP of a narrow stage in one kernel (MLPK_CHANNEL_MLP_FUSED=0: the two GEMMs, A/B aid)"""
     return (dtype in (torch.float16, torch.bfloat16) and os.environ.get("MLPK_CHANNEL_MLP_FUSED", "1") != "0"

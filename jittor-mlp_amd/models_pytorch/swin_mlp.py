@@ -180,6 +180,9 @@ class SwinMLP(E.EngineModule):
                     bd[:, h, :, h] = w[h]
                 pk[p + "sp.w"] = E.pack_matrix(bd.reshape(t * nh, t * nh), dtype, device)
                 pk[p + "sp.b"] = E.f32(blk.spatial_mlp.bias.detach().reshape(nh, t).t().reshape(-1), device)      # index t_out * heads + h
+                if E.swin_spatial_supported(dtype, blk.dim, nh, blk.window_size):
+                    # round 4: LayerNorm + partition + the grouped Conv1d + merge + residual in one kernel (mlpk_swin_spatial)
+                    pk[p + "sp.fw"], pk[p + "sp.fb"] = E.pack_swin_spatial(blk.spatial_mlp.weight, blk.spatial_mlp.bias, nh, blk.window_size, dtype, device)
                 pack_channel_mlp(pk, p + "ff.", blk.norm2, blk.mlp.fc1, blk.mlp.fc2, dtype, device)
             if layer.downsample is not None:
                 pm = layer.downsample
@@ -195,7 +198,6 @@ class SwinMLP(E.EngineModule):
         """One SwinMLPBlock in place on channel-last rows `cur` (B*H*W, C); st = (mean, rstd) of cur's rows when the GEMM that wrote
         them delivered the statistics (else None); returns the statistics of the result the same way."""
         rows = B * H * W
-        xn = ws_.get("l%d.xn" % li, (rows, C))
         p = "l%d.b%d." % (li, bi)
         ws, nh = blk.window_size, blk.num_heads
         d = C // nh
@@ -205,9 +207,14 @@ class SwinMLP(E.EngineModule):
         tk = ws * ws * nh                                     # "tokens" of the per-window GEMM: (window position, head)
         kp = E.round_up(tk, 8)
         tag = "l%d.s%d." % (li, 1 if blk.shift_size > 0 else 0)
+        mean, rstd = st if st is not None else layernorm_stats(ws_, cur, rows, C, tag="l%d.ln" % li)
+        if (p + "sp.fw") in pk and E.swin_spatial_supported(cur.dtype, C, nh, ws):
+            E.swin_spatial(cur, B, H, W, C, ws, pad_t, pad_l, Hp, Wp, nh, mean, rstd, pk[p + "n1.g"], pk[p + "n1.b"], pk[p + "sp.fw"], pk[p + "sp.fb"])
+            got = channel_mlp(ws_, cur, rows, C, pk, p + "ff.", int(C * self.mlp_ratio), tag="l%d.cm" % li, part=(ws_, "l%d.fc2.part" % li))
+            return finalize_stats(ws_, got, rows, C, tag="l%d.ln" % li)
+        xn = ws_.get("l%d.xn" % li, (rows, C))
         xw = ws_.get(tag + "xw", (nwin * ws * ws, C))
         xt = ws_.get(tag + "xt", (nwin * d, kp))
-        mean, rstd = st if st is not None else layernorm_stats(ws_, cur, rows, C, tag="l%d.ln" % li)
         E.norm_apply(cur, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "n1.g"], beta=pk[p + "n1.b"], out_rm=xn, ld_rm=C)
         E.window_gather(xn, xw, B, H, W, C, ws, pad_t, pad_l, Hp, Wp)
         # rows (window, token, head) x d channels  ->  per window transposed: ((window, channel), (token, head))

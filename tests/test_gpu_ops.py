@@ -1596,3 +1596,49 @@ def test_channel_mlp_of_a_narrow_stage_in_one_kernel(dtype):
             assert torch.equal(xin.view(torch.int16), out.view(torch.int16)), (str(dtype), ci, "in place")
     assert not E.channel_mlp_fused_supported(dtype, 224, 896) and not E.channel_mlp_fused_supported(dtype, 80, 320)
     assert not E.channel_mlp_fused_supported(torch.float32, 96, 384) and not E.channel_mlp_fused_supported(dtype, 96, 2048)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_swin_spatial_mlp_half_of_a_block_in_one_kernel(dtype):
+    """mlpk_swin_spatial (round 4): x += crop(merge(spatial_mlp(partition(pad(LayerNorm(x)))))) of swin_mlp.py:97-151 in one kernel --
+    against an fp64 restatement of those lines (zero padding AFTER the norm, window partition, grouped Conv1d over the window positions
+    with one matrix per head of 32 channels, merge, crop, residual) on the rounded operands.  Cases: plain and shifted windows (padding on
+    both axes), maps that are not a multiple of the window, 1 .. 24 heads, window sizes 7 and 4."""
+    pkg = load_pkg()
+    E = pkg.engine
+    for ci, (B, H, W, heads, ws, shift) in enumerate([(2, 14, 14, 3, 7, 0), (3, 14, 14, 3, 7, 3), (2, 7, 7, 24, 7, 0), (1, 28, 21, 6, 7, 3), (2, 8, 8, 1, 4, 2),
+                                                      (5, 56, 56, 3, 7, 3), (2, 14, 14, 12, 7, 3)]):
+        C, t = heads * 32, ws * ws
+        assert E.swin_spatial_supported(dtype, C, heads, ws)
+        x = (rnd((B * H * W, C), dtype, 4100 + ci) * 1.3 + 0.2).to(dev())
+        gamma = rnd((C,), torch.float32, 4110 + ci) * 0.3 + 1.0
+        beta = rnd((C,), torch.float32, 4120 + ci) * 0.2
+        wgt = rnd((heads * t, t, 1), torch.float32, 4130 + ci, 1.0 / math.sqrt(t))
+        bias = rnd((heads * t,), torch.float32, 4140 + ci, 0.3)
+        mean = torch.empty((B * H * W,), dtype=torch.float32, device=dev())
+        rstd = torch.empty((B * H * W,), dtype=torch.float32, device=dev())
+        E.row_stats(x, B * H * W, C, C, mean, rstd)
+        # swin_mlp.py:79-81: padding of a shifted block = [ws - shift, shift] on both axes (left / top first)
+        pad_l = pad_t = (ws - shift) if shift else 0
+        pad_r = pad_b = shift if shift else 0
+        Hp, Wp = H + pad_t + pad_b, W + pad_l + pad_r
+        Hp, Wp = -(-Hp // ws) * ws, -(-Wp // ws) * ws                                     # (maps that are not whole windows: more padding behind)
+        wp, bp = E.pack_swin_spatial(wgt, bias, heads, ws, dtype, dev())
+        got = x.clone()
+        E.swin_spatial(got, B, H, W, C, ws, pad_t, pad_l, Hp, Wp, heads, mean, rstd, gamma.to(dev()), beta.to(dev()), wp, bp)
+        torch.cuda.synchronize()
+        xd = x.cpu().double().reshape(B, H, W, C)
+        xn = ((xd - mean.cpu().double().reshape(B, H, W, 1)) * rstd.cpu().double().reshape(B, H, W, 1) * gamma.double() + beta.double()).to(dtype).double()
+        xp = torch.zeros((B, Hp, Wp, C), dtype=torch.float64)
+        xp[:, pad_t:pad_t + H, pad_l:pad_l + W] = xn
+        win = xp.reshape(B, Hp // ws, ws, Wp // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, t, heads, 32)      # (window, token, head, channel)
+        wd = wgt.to(dtype).double().reshape(heads, t, t)
+        y = torch.einsum("hts,wshc->wthc", wd, win) + bias.double().reshape(heads, t).t().reshape(1, t, heads, 1)
+        y = y.to(dtype).double().reshape(B, Hp // ws, Wp // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, C)
+        ref = xd + y[:, pad_t:pad_t + H, pad_l:pad_l + W]
+        g = got.cpu().double().reshape(B, H, W, C)
+        assert torch.isfinite(g).all(), (str(dtype), ci)
+        scale = max(1.0, ref.abs().max().item())
+        err = (g - ref).abs().max().item()
+        assert err < EPS[dtype] * 4 * scale, (str(dtype), ci, (B, H, W, heads, ws, shift), err)
+    assert not E.swin_spatial_supported(dtype, 96, 4, 7) and not E.swin_spatial_supported(dtype, 96, 3, 9) and not E.swin_spatial_supported(torch.float32, 96, 3, 7)
