@@ -44,6 +44,7 @@
  *   mlpk_as_conv2       AxialShift's core in ONE kernel: GroupNorm + GELU, both axial shifts, conv2_1 and conv2_2 with their GELUs and the sum
  *                       (as_mlp.py:64-66,84-93; utils/shift_cuda.py:49-69): the shifts are LDS read addresses of the MFMA operands
  *   mlpk_channel_mlp    fc1 + GELU + fc2 + residual of a channel MLP on narrow (C <= 192) channel-last rows in ONE kernel (as_mlp.py:36-52)
+ *   mlpk_linear_gelu    a short-K (<= 512) Linear + GELU with its rows resident in registers (g_mlp.py:28,35; the fc1 of the K = 384 channel MLPs)
  *   mlpk_swin_spatial   LayerNorm + window partition + multi-head spatial MLP + merge + residual of a Swin-MLP block in ONE kernel (swin_mlp.py:97-151)
  *   mlpk_cycle_shift    the sampling half of CycleFC (cycle_mlp.py:104-131: deform_conv2d with a 1 x 1 kernel and fixed integer
  *                       offsets = a per-channel cyclic pixel shift with zero fill); the 1 x 1 convolution is mlpk_gemm_nt
@@ -386,6 +387,18 @@ int mlpk_as_conv2(int dtype, const void* t, void* y, int B, int H, int W, int C,
  *     in one fixed order, so the pair does not depend on the batch.
  * Numerics: fp32 accumulation in K order starting from R + b2; GELU and roundings as in the GEMM epilogues (one rounding of the hidden
  * to the storage type, one of the result). */
+/* The FIRST product alone, same machinery (rows resident in registers, two waves per SIMD alternating between MFMAs and the GELU, no
+ * epilogue): out[m, n] = gelu( norm-fold(x[m, :] . w1[n, :]) + b1[n] ) for a short K -- gMLP's channel_proj1 (g_mlp.py:28,35), the fc1 of
+ * the K <= 512 channel MLPs (vip.py:82-88, res_mlp.py:21-32, s2_mlp_v2.py:78-84, as_mlp.py stage 3).  16-bit dtypes, M % 256 == 0,
+ * K in {128, 192, 256, 384, 512}, N = 32 nchunks <= 4096.
+ *   w1 (N, ldw1 >= K), zero-padded, ROWS of every group of 32 stored as [row 16 j + 4 f + r <- output column 8 f + 4 j + r] (j < 2, f < 4,
+ *   r < 4); b1 and csum (N floats each) in the same order; norm as for mlpk_channel_mlp (ln_mean NULL: none);
+ *   row_part (optional): by-product planes of 32 output columns in the canonical order of mlpk_gemm_desc.row_part -- pair of row m in
+ *   plane g at row_part[2 (g M + m)] -- so mlpk_stats_finalize_planar(row_part, M, N / 32, M, ...) (or any sub-range of planes) applies. */
+int mlpk_linear_gelu_supported(int dtype, int M, int K, int N);
+int mlpk_linear_gelu(int dtype, const void* x, int ldx, int M, int K, const float* ln_mean, const float* ln_rstd, int ln_group,
+                     const float* csum, const void* w1, int ldw1, const float* b1, int nchunks, void* out, int ldo, float* row_part,
+                     void* stream);
 int mlpk_channel_mlp_supported(int dtype, int C, int hidden);
 int mlpk_channel_mlp(int dtype, const void* x, int ldx, int M, int C, const float* ln_mean, const float* ln_rstd, int ln_group,
                      const float* csum, const void* w1, int ldw1, const float* b1, const void* w2, int ldw2, const float* b2,

@@ -77,6 +77,9 @@ PROTOTYPES = {
     "mlpk_cycle_shift": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "mlpk_as_conv2_supported": (c_int, [c_int] * 5),
     "mlpk_channel_mlp_supported": (c_int, [c_int] * 3),
+    "mlpk_linear_gelu_supported": (c_int, [c_int] * 4),
+    "mlpk_linear_gelu": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                                 c_void_p, c_void_p]),
     "mlpk_swin_spatial_supported": (c_int, [c_int] * 4),
     "mlpk_swin_spatial": (c_int, [c_int, c_void_p] + [c_int] * 10 + [c_void_p] * 7),
     "mlpk_channel_mlp": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,

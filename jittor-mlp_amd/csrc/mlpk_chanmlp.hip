@@ -38,7 +38,8 @@ struct ChanMlpArgs {
     const void* R;          // (M, ldr) or NULL
     void* out;              // (M, ldo)
     float* row_part;        // optional by-product: (sum, sum of squares) of the C values written to row m at [2 m], [2 m + 1]
-    int M, G, ldx, ldw2, ldr, ldo, ln_group;
+                            // (first product alone: planes of 32 columns, pair of row m in plane g at [2 (g M + m)])
+    int M, G, ldx, ldw1, ldw2, ldr, ldo, ln_group;
 };
 
 static __device__ __forceinline__ void cm_glds(unsigned voff, const void* sbase, unsigned lds_dst) {
@@ -63,28 +64,38 @@ template <> struct CmMma<f16_t> {
 template <bool B> struct CmBool { static constexpr bool value = B; };
 
 constexpr int CM_BM = 256;
-constexpr int CM_HID_MAX = 1024;
+constexpr int CM_HID_MAX = 1024;                          // both products
+constexpr int CM_N_MAX = 4096;                             // the first product alone
 
 // D = how many iterations ahead the weight pieces are requested (an iteration here is 3-6x shorter than the token kernel's: 24-48
 // MFMAs per wave; deeper rings were tried and change nothing, see cm_launch)
-template <int KS1, int NB, int D> struct CmGeo {
+template <int KS1, int NB, int D, bool FC2 = true> struct CmGeo {
+    static constexpr int HMAX = FC2 ? CM_HID_MAX : CM_N_MAX;
     static constexpr int N1 = 2 * KS1;                      // W1 pieces per group: plane kk, halves of 16 rows
-    static constexpr int P = N1 + NB;                       // + W2 pieces: 16 output channels each
+    static constexpr int P = N1 + (FC2 ? NB : 0);           // + W2 pieces: 16 output channels each
     static constexpr int PPW = (P + 7) / 8;                 // pieces per wave and iteration (the last ones issued twice)
-    static constexpr int ST1 = N1 * 1024, ST2 = NB * 1024;
+    static constexpr int ST1 = N1 * 1024, ST2 = FC2 ? NB * 1024 : 0;
     static constexpr int R1 = 0, R2 = (D + 1) * ST1;        // W1 ring: D + 1 stages; W2 ring: D + 2 (the late half reads slab t - 1)
     static constexpr int B1 = R2 + (D + 2) * ST2;
-    static constexpr int CS = B1 + CM_HID_MAX * 4;
-    static constexpr int B2 = CS + CM_HID_MAX * 4;
+    static constexpr int CS = B1 + HMAX * 4;
+    static constexpr int B2 = CS + HMAX * 4;
     static constexpr int LDS = B2 + 16 * NB * 4;
 };
 
-template <typename T, int KS1, int NB, int D>
+// FC2 = false: the FIRST product alone -- out[m, n] = gelu(norm-fold(x[m, :] . W1[n, :]) + b1[n]) for K = 32 KS1 <= 512 and any N = 32 G: the
+// short-K GELU GEMM with its rows resident (gMLP's channel_proj1, the fc1 of the K = 384 channel MLPs).  The one-wave-per-SIMD q4 tile
+// cannot hide a GELU epilogue behind 4-6 k-steps of MFMAs (gMLP proj1: 128 MFMAs against 2300 epilogue instructions per tile); here two
+// waves per SIMD alternate between MFMAs and GELU, and a lane's 8 rounded values -- with W1's ROWS stored as [hidden 8 f + 4 j + r at row
+// 16 j + 4 f + r] of every 32 -- are 8 consecutive output columns: one 16-byte store per (row, group), no epilogue at all.  STATS: the
+// by-product planes of 32 columns in the canonical order (a lane's chunk by chunk_sums, then (c0 + c1) + (c2 + c3) across the 4 lanes).
+template <typename T, int KS1, int NB, int D, bool FC2 = true, bool STATS = false>
 __global__ void __launch_bounds__(512, 1) chan_mlp_kernel(const ChanMlpArgs p) {
-    using Geo = CmGeo<KS1, NB, D>;
+    using Geo = CmGeo<KS1, NB, D, FC2>;
     constexpr int PPW = Geo::PPW, N1 = Geo::N1, P = Geo::P;
     constexpr int C = 16 * NB;
-    static_assert(NB == 2 * KS1, "C = 32 KS1 = 16 NB");
+    constexpr int NSTORE = FC2 ? 0 : (STATS ? 4 : 2);       // vector-memory stores a wave issues per iteration (first product alone)
+    static_assert(!FC2 || NB == 2 * KS1, "C = 32 KS1 = 16 NB");
+    static_assert(FC2 || D == 2, "the store-counting waits below are written for two iterations of look-ahead");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     const int tid = threadIdx.x;
@@ -125,7 +136,7 @@ __global__ void __launch_bounds__(512, 1) chan_mlp_kernel(const ChanMlpArgs p) {
         const int lrow = ln >> 2;
         const int lchunk = (ln & 3) ^ ((lrow & 8) >> 2);
         unsigned o;
-        if (q < N1) o = (unsigned)(((q & 1) * 16 + lrow) * 256 + (q >> 1) * 32 + lchunk * 8) * (unsigned)sizeof(T);
+        if (q < N1) o = (unsigned)(((q & 1) * 16 + lrow) * p.ldw1 + (q >> 1) * 32 + lchunk * 8) * (unsigned)sizeof(T);
         else o = (unsigned)(((q - N1) * 16 + lrow) * p.ldw2 + lchunk * 8) * (unsigned)sizeof(T);
         return o;
     };
@@ -133,7 +144,7 @@ __global__ void __launch_bounds__(512, 1) chan_mlp_kernel(const ChanMlpArgs p) {
     const T* pb2 = w2;
     unsigned so1 = 0, so2 = 0;
     auto piece_bases = [&](const int g) {
-        pb1 = w1 + (size_t)g * (32 * 256);
+        pb1 = w1 + (size_t)g * 32 * p.ldw1;
         pb2 = w2 + g * 32;
     };
     auto issue = [&](const int pi, const int ln) {
@@ -161,10 +172,10 @@ __global__ void __launch_bounds__(512, 1) chan_mlp_kernel(const ChanMlpArgs p) {
         b1s[i] = p.b1[i];
         css[i] = fold ? p.csum[i] : 0.f;
     }
-    if (tid < C) b2s[tid] = p.b2[tid];
+    if (FC2 && tid < C) b2s[tid] = p.b2[tid];
     __syncthreads();
 
-    u32x4 xa[2][KS1], rr[2][KS1];
+    u32x4 xa[2][KS1], rr[2][FC2 ? KS1 : 1];
     float lmu[2], lrs[2];
     auto load_tile = [&](const int tile, const int ln) {     // operand rows, residual rows, row statistics of a tile
         const int frow = ln & 15, fg = ln >> 4;
@@ -174,15 +185,17 @@ __global__ void __launch_bounds__(512, 1) chan_mlp_kernel(const ChanMlpArgs p) {
             gm = gm < p.M ? gm : p.M - 1;
 #pragma unroll
             for (int kk = 0; kk < KS1; ++kk) xa[i][kk] = *reinterpret_cast<const u32x4*>(x + (size_t)gm * p.ldx + kk * 32 + fg * 8);
+            if constexpr (FC2) {
 #pragma unroll
-            for (int kk = 0; kk < KS1; ++kk)
-                rr[i][kk] = R ? *reinterpret_cast<const u32x4*>(R + (size_t)gm * p.ldr + kk * 32 + fg * 8) : u32x4{0u, 0u, 0u, 0u};
+                for (int kk = 0; kk < KS1; ++kk)
+                    rr[i][kk] = R ? *reinterpret_cast<const u32x4*>(R + (size_t)gm * p.ldr + kk * 32 + fg * 8) : u32x4{0u, 0u, 0u, 0u};
+            }
             lmu[i] = fold ? p.ln_mean[gm / p.ln_group] : 0.f;
             lrs[i] = fold ? p.ln_rstd[gm / p.ln_group] : 1.f;
         }
     };
 
-    f32x4 acc2[2][NB];
+    f32x4 acc2[2][FC2 ? NB : 1];
     f32x4 a1[2][2];
     auto frag_off = [&](const int ln) {
         const int fr = ln & 15;
@@ -237,6 +250,7 @@ __global__ void __launch_bounds__(512, 1) chan_mlp_kernel(const ChanMlpArgs p) {
         }
     };
     auto fc2 = [&](const unsigned st4, const int ln) {
+      if constexpr (FC2) {
         const int f_rd = frag_off(ln);
         const char* r2 = smem + Geo::R2 + st4 * Geo::ST2;
         constexpr int BFD = NB < 4 ? NB : 4;                // W2 fragments read ahead of their MFMAs
@@ -251,6 +265,28 @@ __global__ void __launch_bounds__(512, 1) chan_mlp_kernel(const ChanMlpArgs p) {
             acc2[1][j] = CmMma<T>::run(bf[j % (BFD + 1)], hf[1], acc2[1][j]);
             __builtin_amdgcn_sched_barrier(0);
         }
+      }
+    };
+
+    // first product alone: the rounded hidden of group g IS the output -- 8 consecutive columns per lane
+    auto store_h = [&](const int g, const int tile, const int ln) {
+        const int frow = ln & 15, fg = ln >> 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const size_t gm = (size_t)tile * CM_BM + wave * 32 + i * 16 + frow;
+            *reinterpret_cast<u32x4*>(out + gm * p.ldo + g * 32 + fg * 8) = hf[i];
+            if constexpr (STATS) {
+                float ssum = 0.f, ssq = 0.f;
+                chunk_sums<T>(hf[i], ssum, ssq);
+                ssum += __shfl_xor(ssum, 16);
+                ssq += __shfl_xor(ssq, 16);
+                ssum += __shfl_xor(ssum, 32);
+                ssq += __shfl_xor(ssq, 32);
+                // (every lane stores: lanes fg != 0 to their own row's pair as well -- the same value four times, one store instruction
+                // with a fixed count for the vmcnt arithmetic)
+                *reinterpret_cast<f32x2*>(p.row_part + ((size_t)g * p.M + gm) * 2) = f32x2{ssum, ssq};
+            }
+        }
     };
 
     auto run = [&](auto lag_c) {
@@ -258,7 +294,7 @@ __global__ void __launch_bounds__(512, 1) chan_mlp_kernel(const ChanMlpArgs p) {
         load_tile(blockIdx.x, lane_now());
         for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
             __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the tile's rows have landed, and the compiler knows it
-            {
+            if constexpr (FC2) {
                 // accumulators start from R + b2: lane (row, fg) holds channels 32 q + 8 fg + {0..3} in block 2q, + {4..7} in block 2q + 1
                 const int fg = lane_now() >> 4;
 #pragma unroll
@@ -274,9 +310,12 @@ __global__ void __launch_bounds__(512, 1) chan_mlp_kernel(const ChanMlpArgs p) {
                     }
                 }
             }
-            auto iter = [&](auto first_c, const int t) {
+            auto iter = [&](auto first_c, auto second_c, const int t) {
                 constexpr bool FIRST = decltype(first_c)::value;
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((D - 1) * PPW) : "memory");
+                // what may still be in flight at this point: the pieces requested last iteration -- and, first product alone, the stores
+                // of last iteration (none in a tile's iteration 0 for the late half: the sync of iteration 1 does not count them)
+                constexpr int INFLIGHT = (D - 1) * PPW + (decltype(second_c)::value ? 0 : NSTORE);
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(INFLIGHT) : "memory");
                 asm volatile("s_barrier" ::: "memory");
                 int g2 = t + D;                                // pieces of iteration t + D (the next tile's first groups at the end of this one)
                 g2 = g2 < G ? g2 : g2 - G;
@@ -295,11 +334,12 @@ __global__ void __launch_bounds__(512, 1) chan_mlp_kernel(const ChanMlpArgs p) {
 #pragma unroll
                     for (int pi = PH; pi < PPW; ++pi) issue(pi, ln);
                     gelu(t, ln);
-                    fc2(s4, ln);
+                    if constexpr (FC2) fc2(s4, ln); else store_h(t, tile, ln);
                 } else {
                     if constexpr (!FIRST) {
                         gelu(t - 1, ln);
-                        fc2(s4 == 0 ? D + 1 : s4 - 1, ln);    // slab t - 1: stage (gi - 1) % (D + 2)
+                        if constexpr (FC2) fc2(s4 == 0 ? D + 1 : s4 - 1, ln);    // slab t - 1: stage (gi - 1) % (D + 2)
+                        else store_h(t - 1, tile, ln);
                     }
 #pragma unroll
                     for (int pi = PH; pi < PPW; ++pi) issue(pi, ln);
@@ -308,19 +348,20 @@ __global__ void __launch_bounds__(512, 1) chan_mlp_kernel(const ChanMlpArgs p) {
                 s3 = s3 == D ? 0 : s3 + 1;
                 s4 = s4 == D + 1 ? 0 : s4 + 1;
             };
-            iter(CmBool<true>{}, 0);
+            iter(CmBool<true>{}, CmBool<false>{}, 0);
+            if (G > 1) iter(CmBool<false>{}, CmBool<true>{}, 1);
 #pragma unroll 1
-            for (int t = 1; t < G; ++t) iter(CmBool<false>{}, t);
+            for (int t = 2; t < G; ++t) iter(CmBool<false>{}, CmBool<false>{}, t);
             if constexpr (LAG) {
                 const int ln = lane_now();
                 gelu(G - 1, ln);
-                fc2(s4 == 0 ? D + 1 : s4 - 1, ln);
+                if constexpr (FC2) fc2(s4 == 0 ? D + 1 : s4 - 1, ln); else store_h(G - 1, tile, ln);
             }
             // ---- tile epilogue: one rounding, 16-byte stores straight from the accumulators; then the next tile's rows ----
             const int le = lane_now();
             const int frow = le & 15, fg = le >> 4;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < (FC2 ? 2 : 0); ++i) {
                 const int gm = tile * CM_BM + wave * 32 + i * 16 + frow;
                 float ssum = 0.f, ssq = 0.f;
 #pragma unroll
@@ -386,9 +427,59 @@ static int cm_launch(const ChanMlpArgs& a, hipStream_t s) {
     return cm_launch_d<T, KS1, 2>(a, s);
 }
 
+template <typename T, int KS1>
+static int cm_launch_fc1(const ChanMlpArgs& a, hipStream_t s) {
+    using Geo = CmGeo<KS1, 2 * KS1, 2, false>;
+    hipError_t e;
+    const int tiles = a.M / CM_BM;
+    const unsigned grid = (unsigned)(tiles < cm_grid_cap() ? tiles : cm_grid_cap());
+    if (a.row_part) {
+        auto k = chan_mlp_kernel<T, KS1, 2 * KS1, 2, false, true>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, Geo::LDS);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(512), Geo::LDS, s, a);
+    } else {
+        auto k = chan_mlp_kernel<T, KS1, 2 * KS1, 2, false, false>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, Geo::LDS);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(512), Geo::LDS, s, a);
+    }
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace mlpk
 
 using namespace mlpk;
+
+extern "C" int mlpk_linear_gelu_supported(int dtype, int M, int K, int N) {
+    return (dtype == MLPK_F16 || dtype == MLPK_BF16) && M > 0 && M % CM_BM == 0 && (K == 128 || K == 192 || K == 256 || K == 384 || K == 512) && N > 0 &&
+           N % 32 == 0 && N <= CM_N_MAX;
+}
+
+extern "C" int mlpk_linear_gelu(int dtype, const void* x, int ldx, int M, int K, const float* ln_mean, const float* ln_rstd, int ln_group,
+                                const float* csum, const void* w1, int ldw1, const float* b1, int nchunks, void* out, int ldo, float* row_part,
+                                void* stream) {
+    if (!x || !w1 || !b1 || !out) return MLPK_ENULL;
+    if (dtype != MLPK_F16 && dtype != MLPK_BF16) return MLPK_EDTYPE;
+    if (nchunks <= 0 || !mlpk_linear_gelu_supported(dtype, M, K, nchunks * 32)) return MLPK_ESHAPE;
+    if ((ln_mean != nullptr) != (ln_rstd != nullptr) || (ln_mean != nullptr) != (csum != nullptr)) return MLPK_ENULL;
+    if (ln_mean && ln_group <= 0) return MLPK_ESHAPE;
+    if (ldw1 < K || ldw1 % 8 || ldx < K || ldx % 8 || ldo < nchunks * 32 || ldo % 8) return MLPK_ESHAPE;
+    if (((uintptr_t)x & 15) || ((uintptr_t)w1 & 15) || ((uintptr_t)out & 15) || ((uintptr_t)row_part & 7)) return MLPK_EALIGN;
+    ChanMlpArgs a;
+    a.x = x; a.w1 = w1; a.w2 = nullptr; a.b1 = b1; a.csum = csum; a.b2 = nullptr; a.ln_mean = ln_mean; a.ln_rstd = ln_rstd; a.R = nullptr; a.out = out;
+    a.row_part = row_part;
+    a.M = M; a.G = nchunks; a.ldx = ldx; a.ldw1 = ldw1; a.ldw2 = 0; a.ldr = 0; a.ldo = ldo; a.ln_group = ln_mean ? ln_group : 1;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define CM_CASE1(KS1) \
+    case KS1: return dtype == MLPK_BF16 ? cm_launch_fc1<bf16_t, KS1>(a, s) : cm_launch_fc1<f16_t, KS1>(a, s);
+    switch (K / 32) {
+        CM_CASE1(4) CM_CASE1(6) CM_CASE1(8) CM_CASE1(12) CM_CASE1(16)
+        default: return MLPK_ESHAPE;
+    }
+#undef CM_CASE1
+}
 
 extern "C" int mlpk_channel_mlp_supported(int dtype, int C, int hidden) {
     return (dtype == MLPK_F16 || dtype == MLPK_BF16) && C % 32 == 0 && C >= 64 && C <= 192 && hidden > 0 && hidden <= CM_HID_MAX;
@@ -411,7 +502,7 @@ extern "C" int mlpk_channel_mlp(int dtype, const void* x, int ldx, int M, int C,
     ChanMlpArgs a;
     a.x = x; a.w1 = w1; a.w2 = w2; a.b1 = b1; a.csum = csum; a.b2 = b2; a.ln_mean = ln_mean; a.ln_rstd = ln_rstd; a.R = R; a.out = out;
     a.row_part = row_part;
-    a.M = M; a.G = nchunks; a.ldx = ldx; a.ldw2 = ldw2; a.ldr = ldr; a.ldo = ldo; a.ln_group = ln_mean ? ln_group : 1;
+    a.M = M; a.G = nchunks; a.ldx = ldx; a.ldw1 = ldw1; a.ldw2 = ldw2; a.ldr = ldr; a.ldo = ldo; a.ln_group = ln_mean ? ln_group : 1;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define CM_CASE(KS1) \
     case KS1: return dtype == MLPK_BF16 ? cm_launch<bf16_t, KS1>(a, s) : cm_launch<f16_t, KS1>(a, s);

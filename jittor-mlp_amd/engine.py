@@ -346,6 +346,54 @@ def pack_token_mlp(w1, b1, w2, b2, dtype, device, sp, layout=None, t_rows=None):
     return w1p, b1p, w2p, f32(b2, device), nch, layout
 
 
+def linear_gelu_supported(dtype, M, K, Nn):
+    """mlpk_linear_gelu: a short-K Linear + GELU with its rows resident in registers.  OPT-IN (MLPK_LINEAR_GELU=1): measured slower than the
+    GEMM tiles with a GELU epilogue on every model shape (profiles/r04_linear_gelu_ab.txt: gMLP-S 11.33 vs 10.22 ms, ViP-S7 30.39 vs 30.17)."""
+    return (dtype in (torch.float16, torch.bfloat16) and os.environ.get("MLPK_LINEAR_GELU", "0") == "1"
+            and bool(N.lib().mlpk_linear_gelu_supported(dtype_code(dtype), M, K, round_up(Nn, 32))))
+
+
+def pack_linear_gelu(w, b, dtype, device, gamma=None, beta=None):
+    """Weights of mlpk_linear_gelu: W (N, K) [x diag(gamma)] with the rows of every group of 32 in the kernel's order (row 16 j + 4 f + r <-
+    output column 8 f + 4 j + r), K zero-padded to 256 / 512, N to whole groups; b [+ W beta] and the row sums of the rounded folded W in the
+    same order (csum None without a norm).  Returns (wp, bp, csum, nch)."""
+    w = w.detach().to(device=device, dtype=torch.float32).reshape(w.shape[0], -1)
+    Nn, K = w.shape
+    nch = (Nn + 31) // 32
+    kp = 256 if K <= 256 else 512
+    bp = torch.zeros((nch * 32,), dtype=torch.float32, device=device)
+    if b is not None:
+        bp[:Nn] = b.detach().to(device=device, dtype=torch.float32).reshape(-1)
+    wf = w
+    if gamma is not None:
+        wf = w * gamma.detach().to(device=device, dtype=torch.float32).reshape(1, -1)
+        bp[:Nn] += w @ beta.detach().to(device=device, dtype=torch.float32).reshape(-1)
+    wp = torch.zeros((nch * 32, kp), dtype=dtype, device=device)
+    wp[:Nn, :K] = wf.to(dtype)
+    csum = wp.to(torch.float32).sum(dim=1) if gamma is not None else None
+    slot = torch.arange(32)
+    j, f, r = slot // 16, (slot // 4) % 4, slot % 4
+    src = (8 * f + 4 * j + r).to(device)                                         # output column at row 16 j + 4 f + r
+    wp = wp.view(nch, 32, kp)[:, src].reshape(nch * 32, kp).contiguous()
+    bp = bp.view(nch, 32)[:, src].reshape(-1).contiguous()
+    if csum is not None:
+        csum = csum.view(nch, 32)[:, src].reshape(-1).contiguous()
+    return wp, bp, csum, nch
+
+
+def linear_gelu(x, rows, K, pack, out, *, ln=None, ln_group=1, part=None):
+    """out = gelu(norm(x) W^T + b); pack = pack_linear_gelu(...); ln = (mean, rstd) or None; part = (workspace, name): also deliver the row
+    statistics planes of `out` (32 columns each) -- returns (buffer (N / 32, rows, 2), N / 32) as engine.gemm(part=...) does."""
+    wp, bp, csum, nch = pack
+    buf = None
+    if part is not None and epilogue_stats():
+        buf = part[0].get("%s.%d" % (part[1], nch), (nch, rows, 2), torch.float32)
+    N.check(N.lib().mlpk_linear_gelu(dtype_code(x.dtype), ptr(x), x.stride(0), rows, K, ptr(ln[0]) if ln else None, ptr(ln[1]) if ln else None, ln_group,
+                                     ptr(csum) if ln else None, ptr(wp), wp.stride(0), ptr(bp), nch, ptr(out), out.stride(0), ptr(buf), stream()),
+            "mlpk_linear_gelu")
+    return (buf, nch) if buf is not None else None
+
+
 def swin_spatial_supported(dtype, C, heads, ws):
     """mlpk_swin_spatial: the spatial-MLP half of a Swin-MLP block in one kernel (MLPK_SWIN_SPATIAL_FUSED=0: the five passes, A/B aid)"""
     return (dtype in (torch.float16, torch.bfloat16) and os.environ.get("MLPK_SWIN_SPATIAL_FUSED", "1") != "0"

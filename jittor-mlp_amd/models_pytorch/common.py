@@ -164,6 +164,9 @@ def pack_channel_mlp(pk, prefix, norm, fc1, fc2, dtype, device):
     pk[prefix + "fc2.w"] = E.pack_matrix(fc2.weight, dtype, device)
     pk[prefix + "fc2.b"] = E.f32(fc2.bias, device)
     w1 = fc1.weight.reshape(fc1.weight.shape[0], -1)
+    if w1.shape[1] in (128, 192, 256, 384, 512) and w1.shape[0] % 32 == 0 and dtype in (torch.float16, torch.bfloat16):
+        # short K: fc1 + GELU with its rows resident in registers (mlpk_linear_gelu) instead of a GEMM tile with a GELU epilogue
+        pk[prefix + "fc1.rr"] = E.pack_linear_gelu(fc1.weight, fc1.bias, dtype, device, norm.weight, norm.bias)
     if E.channel_mlp_fused_supported(dtype, w1.shape[1], w1.shape[0]) and fc2.weight.reshape(fc2.weight.shape[0], -1).shape[0] == w1.shape[1]:
         # narrow stage: the whole block in one kernel (mlpk_channel_mlp), the hidden never written
         pk[prefix + "fused"] = E.pack_channel_mlp_fused(fc1.weight, fc1.bias, fc2.weight, fc2.bias, dtype, device, norm.weight, norm.bias)
@@ -223,7 +226,10 @@ def channel_mlp(ws, x, rows, C, pk, prefix, hidden, *, norm=True, cscale2=None, 
         r0 = c * step
         sl = slice(r0, r0 + step)
         lnc = None if ln is None else (ln[0][sl], ln[1][sl], ln[2])
-        E.gemm(xn[sl], pk[prefix + "fc1.w"], h[sl], step, hidden, C, bias=pk[prefix + "fc1.b"], act=N.ACT_GELU, ln=lnc, tag="channel_fc1")
+        if ln is not None and (prefix + "fc1.rr") in pk and E.linear_gelu_supported(x.dtype, step, C, hidden):
+            E.linear_gelu(xn[sl], step, C, pk[prefix + "fc1.rr"], h[sl], ln=(ln[0][sl], ln[1][sl]))
+        else:
+            E.gemm(xn[sl], pk[prefix + "fc1.w"], h[sl], step, hidden, C, bias=pk[prefix + "fc1.b"], act=N.ACT_GELU, ln=lnc, tag="channel_fc1")
         got = E.gemm(h[sl], pk[prefix + "fc2.w"], x[sl], step, C, hidden, bias=pk[prefix + "fc2.b"], cscale=cscale2,
                      R=res[sl], res=N.RES_ADD, tag="channel_fc2", part=part if nchunk == 1 else None)
     return got if part is not None else x

@@ -84,6 +84,10 @@ class gMLP(E.EngineModule):
             # block LayerNorm folded into channel_proj1 (gamma -> weights, beta -> bias, stats in the epilogue)
             pk[p + "p1.w"], pk[p + "p1.b"], pk[p + "p1.csum"] = E.pack_ln_folded(
                 blk.channel_proj1.weight, blk.channel_proj1.bias, blk.norm.weight, blk.norm.bias, dtype, device)
+            w1 = blk.channel_proj1.weight
+            if w1.shape[1] in (128, 192, 256, 384, 512) and w1.shape[0] % 32 == 0 and dtype in (torch.float16, torch.bfloat16):
+                # round 4: channel_proj1 + GELU with its rows resident in registers (mlpk_linear_gelu), statistics planes included
+                pk[p + "p1.rr"] = E.pack_linear_gelu(w1, blk.channel_proj1.bias, dtype, device, blk.norm.weight, blk.norm.bias)
             pk[p + "p2.w"] = E.pack_matrix(blk.channel_proj2.weight, dtype, device)
             pk[p + "p2.b"] = E.f32(blk.channel_proj2.bias, device)
             pk[p + "sgu.g"], pk[p + "sgu.b"] = E.f32(blk.sgu.norm.weight, device), E.f32(blk.sgu.norm.bias, device)
@@ -126,7 +130,10 @@ class gMLP(E.EngineModule):
                     vst = finalize_stats(ws, got, rows, F, tag="v")
                 elif P1_MODE == "full":
                     # one launch with the statistics of all 2F columns; the planes of the v half are the second half of the buffer
-                    got = E.gemm(x, w1, h, rows, 2 * F, C, bias=b1, act=N.ACT_GELU, ln=(mean, rstd, cs1), tag="gmlp_proj1", part=(ws, "p1.part"))
+                    if (p + "p1.rr") in pk and E.linear_gelu_supported(x.dtype, rows, C, 2 * F):
+                        got = E.linear_gelu(x, rows, C, pk[p + "p1.rr"], h, ln=(mean, rstd), part=(ws, "p1.part"))
+                    else:
+                        got = E.gemm(x, w1, h, rows, 2 * F, C, bias=b1, act=N.ACT_GELU, ln=(mean, rstd, cs1), tag="gmlp_proj1", part=(ws, "p1.part"))
                     if got is not None:
                         vst = finalize_stats(ws, (got[0][got[1] // 2:], got[1] // 2), rows, F, tag="v")
                 else:

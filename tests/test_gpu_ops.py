@@ -1642,3 +1642,73 @@ def test_swin_spatial_mlp_half_of_a_block_in_one_kernel(dtype):
         err = (g - ref).abs().max().item()
         assert err < EPS[dtype] * 4 * scale, (str(dtype), ci, (B, H, W, heads, ws, shift), err)
     assert not E.swin_spatial_supported(dtype, 96, 4, 7) and not E.swin_spatial_supported(dtype, 96, 3, 9) and not E.swin_spatial_supported(torch.float32, 96, 3, 7)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_short_k_linear_gelu_with_resident_rows(dtype):
+    """mlpk_linear_gelu (round 4): out = gelu(norm(x) W^T + b) for K <= 512 with the rows resident in registers and no epilogue -- gMLP's
+    channel_proj1 (g_mlp.py:28,35) and the fc1 of the K = 384 channel MLPs.  Against fp64 on the rounded operands, against mlpk_gemm_nt with
+    the same fold, and the by-product statistics planes (32 columns each, canonical order) against the sums of what was stored -- and
+    bit-equal to the planes mlpk_gemm_nt delivers for the same output where it delivers them."""
+    pkg = load_pkg()
+    E, N = pkg.engine, pkg._native
+    os.environ["MLPK_LINEAR_GELU"] = "1"                                         # (opt-in: the GEMM tiles are faster on the models' shapes)
+    for ci, (M, K, Nn, norm) in enumerate([(256, 256, 1536, "ln"), (512, 384, 1152, "ln"), (768, 128, 96, None), (256 * 5, 192, 768, "gn"), (256, 512, 2048, "ln"),
+                                            (256 * 270, 256, 512, "ln"), (1024, 384, 1536, None)]):
+        assert E.linear_gelu_supported(dtype, M, K, Nn)
+        w = rnd((Nn, K), torch.float32, 5100 + ci, 1.0 / math.sqrt(K))
+        b = rnd((Nn,), torch.float32, 5110 + ci, 0.3)
+        gamma = rnd((K,), torch.float32, 5120 + ci) * 0.3 + 1.0
+        beta = rnd((K,), torch.float32, 5130 + ci) * 0.2
+        x = (rnd((M, K), dtype, 5140 + ci) * 1.5 + 0.25).to(dev())
+        group, ln = 1, None
+        if norm:
+            group = 1 if norm == "ln" else 128
+            ns = M // group
+            mean = torch.empty((ns,), dtype=torch.float32, device=dev())
+            rstd = torch.empty((ns,), dtype=torch.float32, device=dev())
+            if norm == "ln":
+                E.row_stats(x, M, K, K, mean, rstd)
+            else:
+                xs = x.float().view(ns, -1)
+                mean.copy_(xs.mean(1))
+                rstd.copy_(1.0 / torch.sqrt(xs.var(1, unbiased=False) + 1e-5))
+            ln = (mean, rstd)
+        pack = E.pack_linear_gelu(w, b, dtype, dev(), gamma if norm else None, beta if norm else None)
+        out = torch.full((M, Nn), float("nan"), dtype=dtype, device=dev())
+        ws = E.Workspace(dev(), dtype)
+        got_part = E.linear_gelu(x, M, K, pack, out, ln=ln, ln_group=group, part=(ws, "lg.part"))
+        torch.cuda.synchronize()
+        wf = (w * gamma.view(1, -1) if norm else w).to(dtype).double()
+        bf = (b + w @ beta if norm else b).double()
+        acc = x.cpu().double() @ wf.t()
+        if norm:
+            idx = torch.arange(M) // group
+            acc = (acc - mean.cpu().double()[idx][:, None] * wf.sum(1)[None, :]) * rstd.cpu().double()[idx][:, None]
+        ref = oracle.gelu(acc + bf[None, :])
+        g = out.cpu().double()
+        assert torch.isfinite(g).all(), (str(dtype), ci)
+        scale = max(1.0, ref.abs().max().item())
+        err = (g - ref).abs().max().item()
+        assert err < EPS[dtype] * 4 * scale, (str(dtype), ci, (M, K, Nn), err)
+        # statistics planes: sums over each group of 32 stored columns
+        assert got_part is not None and got_part[1] == Nn // 32 and tuple(got_part[0].shape) == (Nn // 32, M, 2)
+        planes = got_part[0].cpu().double()
+        gs = g.view(M, Nn // 32, 32)
+        assert (planes[:, :, 0].t() - gs.sum(2)).abs().max().item() < 1e-4 * max(1.0, gs.abs().sum(2).max().item())
+        assert (planes[:, :, 1].t() - (gs * gs).sum(2)).abs().max().item() < 1e-4 * max(1.0, (gs * gs).sum(2).max().item())
+        # the GEMM tiles on the same fold
+        if norm:
+            wq, bq, csum = E.pack_ln_folded(w, b, gamma, beta, dtype, dev())
+        else:
+            wq, bq, csum = E.pack_matrix(w, dtype, dev()), b.to(dev()), None
+        two = torch.empty((M, Nn), dtype=dtype, device=dev())
+        gp = E.gemm(x, wq, two, M, Nn, K, bias=bq, act=N.ACT_GELU, ln=(mean, rstd, csum) if norm else None, ln_group=group, part=(ws, "gemm.part"))
+        torch.cuda.synchronize()
+        d2 = (g - two.cpu().double()).abs().max().item()
+        assert d2 < EPS[dtype] * 4 * scale, (str(dtype), ci, d2)
+        if gp is not None and torch.equal(out.view(torch.int16), two.view(torch.int16)):
+            assert gp[1] == got_part[1] and torch.equal(gp[0], got_part[0]), (str(dtype), ci, "planes of equal outputs differ")
+    assert not E.linear_gelu_supported(dtype, 250, 256, 512) and not E.linear_gelu_supported(dtype, 256, 320, 512) and not E.linear_gelu_supported(dtype, 256, 256, 8192)
+    del os.environ["MLPK_LINEAR_GELU"]
+    assert not E.linear_gelu_supported(dtype, 256, 256, 512)
