@@ -64,11 +64,11 @@ def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 and link libmlpk.so.  Returns the library path."""
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
-    _generate()
-    stamp = os.path.join(LIBDIR, "stamp.txt")      # next to the library: build/ (121 MB of -save-temps output) does not travel to the GPU box
-    digest = _digest(_deps())
+    stamp = os.path.join(LIBDIR, "stamp.txt")      # next to the library: build/ (386 MB of -save-temps output) does not travel to the GPU box
+    digest = _digest(_deps())                      # (sources and generators: not the generated .inc files, which do not travel either)
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
         return LIB
+    _generate()
     hipcc = _hipcc()
 
     def compile_one(src):
