@@ -531,7 +531,8 @@ constexpr int SW_NT = 256;
 constexpr int SW_TPITCH = 64 * 2 + 16;                       // LDS row of the transposed image: 64 tokens + 16 bytes (bank spread)
 constexpr int SW_MAXI = 20;                                  // (token, 8-channel chunk) items per thread: ws^2 * C / 8 / 256 <= 20 (C <= 768 at ws = 7)
 
-template <typename T>
+// MAXI = (token, chunk) items per thread, NHW = heads per wave: sized to the width (registers decide how many windows a CU holds at once)
+template <typename T, int MAXI, int NHW>
 __global__ void __launch_bounds__(SW_NT) swin_spatial_kernel(const SwinArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_sw[];
     T* __restrict__ x = reinterpret_cast<T*>(p.x);
@@ -547,10 +548,10 @@ __global__ void __launch_bounds__(SW_NT) swin_spatial_kernel(const SwinArgs p) {
         const int ch = i / (64 - T2), t = T2 + i % (64 - T2);
         *reinterpret_cast<T*>(smem_sw + ch * SW_TPITCH + t * 2) = from_f32<T>(0.f);
     }
-    u32x4 raw[SW_MAXI];
+    u32x4 raw[MAXI];
     const float inv_cv = 1.0f / (float)CV, inv_ws = 1.0f / (float)ws;
 #pragma unroll
-    for (int k = 0; k < SW_MAXI; ++k) {
+    for (int k = 0; k < MAXI; ++k) {
         const int it = tid + k * SW_NT;
         raw[k] = u32x4{0u, 0u, 0u, 0u};
         if (it < nitem) {
@@ -580,10 +581,10 @@ __global__ void __launch_bounds__(SW_NT) swin_spatial_kernel(const SwinArgs p) {
     f32x16 acc[2];
     // every wave walks its heads (wave, wave + 4, ...); the results are written after a barrier that follows ALL MFMA reads of the image
     const int nh_w = (p.heads - wave + SW_NT / 64 - 1) / (SW_NT / 64);      // heads of this wave: wave, wave + 4, ...
-    // results of up to 6 heads per wave (24 heads / 4 waves) are kept in registers as packed 16-bit values: 16 per lane and head
-    u32x4 res[6][2][2];
+    // results of up to NHW heads per wave (24 heads / 4 waves = 6) are kept in registers as packed 16-bit values: 16 per lane and head
+    u32x4 res[NHW][2][2];
 #pragma unroll
-    for (int hi = 0; hi < 6; ++hi) {
+    for (int hi = 0; hi < NHW; ++hi) {
         if (hi < nh_w) {
             const int h = wave + hi * (SW_NT / 64);
             const T* wh = wgt + (size_t)h * 64 * 64;
@@ -616,7 +617,7 @@ __global__ void __launch_bounds__(SW_NT) swin_spatial_kernel(const SwinArgs p) {
     }
     __syncthreads();                                         // every wave is done reading the transposed image: its bytes become the result image
 #pragma unroll
-    for (int hi = 0; hi < 6; ++hi) {
+    for (int hi = 0; hi < NHW; ++hi) {
         if (hi < nh_w) {
             const int h = wave + hi * (SW_NT / 64);
 #pragma unroll
@@ -635,7 +636,7 @@ __global__ void __launch_bounds__(SW_NT) swin_spatial_kernel(const SwinArgs p) {
     __syncthreads();
     // ---- residual and store (the positions inside the map only: the crop of swin_mlp.py:148-149) ----
 #pragma unroll
-    for (int k = 0; k < SW_MAXI; ++k) {
+    for (int k = 0; k < MAXI; ++k) {
         const int it = tid + k * SW_NT;
         if (it < nitem) {
             const int t = (int)(((float)it + 0.5f) * inv_cv), cq = it - t * CV;
@@ -680,18 +681,25 @@ extern "C" int mlpk_swin_spatial(int dtype, void* x, int B, int H, int W, int C,
     const int lds = lds_t > lds_o ? lds_t : lds_o;
     if (lds > 160 * 1024) return MLPK_ESHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipError_t e;
-    if (dtype == MLPK_BF16) {
-        auto k = swin_spatial_kernel<bf16_t>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(k, dim3((unsigned)nwin), dim3(SW_NT), lds, s, a);
-    } else {
-        auto k = swin_spatial_kernel<f16_t>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(k, dim3((unsigned)nwin), dim3(SW_NT), lds, s, a);
-    }
+    hipError_t e = hipSuccess;
+    const int items = (t2 * (C / 8) + SW_NT - 1) / SW_NT, hpw = (heads + 3) / 4;
+#define SW_LAUNCH(TT, MAXI, NHW)                                                                                           \
+    do {                                                                                                                   \
+        auto k = swin_spatial_kernel<TT, MAXI, NHW>;                                                                       \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);        \
+        if (e != hipSuccess) return (int)e;                                                                                \
+        hipLaunchKernelGGL(k, dim3((unsigned)nwin), dim3(SW_NT), lds, s, a);                                               \
+    } while (0)
+#define SW_PICK(TT)                                                                                                        \
+    do {                                                                                                                   \
+        if (items <= 3 && hpw <= 1) SW_LAUNCH(TT, 3, 1);                                                                   \
+        else if (items <= 5 && hpw <= 2) SW_LAUNCH(TT, 5, 2);                                                              \
+        else if (items <= 10 && hpw <= 3) SW_LAUNCH(TT, 10, 3);                                                            \
+        else SW_LAUNCH(TT, SW_MAXI, 6);                                                                                    \
+    } while (0)
+    if (dtype == MLPK_BF16) SW_PICK(bf16_t); else SW_PICK(f16_t);
+#undef SW_PICK
+#undef SW_LAUNCH
     MLPK_LAUNCH_CHECK();
     return 0;
 }
