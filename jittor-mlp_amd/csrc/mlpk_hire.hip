@@ -564,12 +564,16 @@ template <> struct SwinMma<f16_t> {
     }
 };
 
+#ifndef SW_RELOAD
+#define SW_RELOAD 0                                          // (measured: 4.53 vs 4.43 ms on Swin-MLP-T -- fewer registers, more windows per CU, no gain)
+#endif
 constexpr int SW_NT = 256;
 constexpr int SW_TPITCH = 64 * 2 + 16;                       // LDS row of the transposed image: 64 tokens + 16 bytes (bank spread)
 constexpr int SW_MAXI = 20;                                  // (token, 8-channel chunk) items per thread: ws^2 * C / 8 / 256 <= 20 (C <= 768 at ws = 7)
 
 // MAXI = (token, chunk) items per thread, NHW = heads per wave: sized to the width (registers decide how many windows a CU holds at once)
-template <typename T, int MAXI, int NHW>
+// (RELOAD: the raw values are read again for the residual -- cache hits -- instead of being held in registers across the products)
+template <typename T, int MAXI, int NHW, bool RELOAD>
 __global__ void __launch_bounds__(SW_NT) swin_spatial_kernel(const SwinArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_sw[];
     T* __restrict__ x = reinterpret_cast<T*>(p.x);
@@ -585,12 +589,12 @@ __global__ void __launch_bounds__(SW_NT) swin_spatial_kernel(const SwinArgs p) {
         const int ch = i / (64 - T2), t = T2 + i % (64 - T2);
         *reinterpret_cast<T*>(smem_sw + ch * SW_TPITCH + t * 2) = from_f32<T>(0.f);
     }
-    u32x4 raw[MAXI];
+    u32x4 raw[RELOAD ? 1 : MAXI];
     const float inv_cv = 1.0f / (float)CV, inv_ws = 1.0f / (float)ws;
 #pragma unroll
     for (int k = 0; k < MAXI; ++k) {
         const int it = tid + k * SW_NT;
-        raw[k] = u32x4{0u, 0u, 0u, 0u};
+        if (!RELOAD) raw[RELOAD ? 0 : k] = u32x4{0u, 0u, 0u, 0u};
         if (it < nitem) {
             const int t = (int)(((float)it + 0.5f) * inv_cv), cq = it - t * CV;
             const int ty = (int)(((float)t + 0.5f) * inv_ws), tx = t - ty * ws;
@@ -598,7 +602,7 @@ __global__ void __launch_bounds__(SW_NT) swin_spatial_kernel(const SwinArgs p) {
             const bool inside = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
             const size_t row = ((size_t)b * p.H + (inside ? yy : 0)) * p.W + (inside ? xx : 0);
             const u32x4 v = *reinterpret_cast<const u32x4*>(x + row * C + cq * 8);
-            raw[k] = v;
+            if (!RELOAD) raw[RELOAD ? 0 : k] = v;
             const float mu = p.mean[row], rs = p.rstd[row];
             T e[8];
             __builtin_memcpy(e, &v, 16);
@@ -682,7 +686,8 @@ __global__ void __launch_bounds__(SW_NT) swin_spatial_kernel(const SwinArgs p) {
             if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) {
                 const u32x4 yv = *reinterpret_cast<const u32x4*>(smem_sw + t * opitch + cq * 16);
                 T a[8], y8[8], o[8];
-                __builtin_memcpy(a, &raw[k], 16);
+                const u32x4 rv = RELOAD ? *reinterpret_cast<const u32x4*>(x + (((size_t)b * p.H + yy) * p.W + xx) * C + cq * 8) : raw[RELOAD ? 0 : k];
+                __builtin_memcpy(a, &rv, 16);
                 __builtin_memcpy(y8, &yv, 16);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) o[q] = from_f32<T>(to_f32(a[q]) + to_f32(y8[q]));
@@ -722,7 +727,7 @@ extern "C" int mlpk_swin_spatial(int dtype, void* x, int B, int H, int W, int C,
     const int items = (t2 * (C / 8) + SW_NT - 1) / SW_NT, hpw = (heads + 3) / 4;
 #define SW_LAUNCH(TT, MAXI, NHW)                                                                                           \
     do {                                                                                                                   \
-        auto k = swin_spatial_kernel<TT, MAXI, NHW>;                                                                       \
+        auto k = swin_spatial_kernel<TT, MAXI, NHW, (MAXI > 3) && SW_RELOAD>;                                                                       \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);        \
         if (e != hipSuccess) return (int)e;                                                                                \
         hipLaunchKernelGGL(k, dim3((unsigned)nwin), dim3(SW_NT), lds, s, a);                                               \
