@@ -244,6 +244,67 @@ __global__ void __launch_bounds__(256) dwconv_affine_kernel(const T* __restrict_
     *reinterpret_cast<u32x4*>(out + pix * C + c0) = *reinterpret_cast<const u32x4*>(o);
 }
 
+// The same for a compile-time k (3: Sparse-MLP): the k * k neighbour vectors and their taps are loaded UNCONDITIONALLY (a position outside
+// the map reads the centre pixel and contributes zero) -- behind `continue` each load waited for the one before it, 27 memory round
+// trips in a row per output vector (the depthwise kernel's finding, profiles/r04_dwconv_variants.txt).
+template <typename T, int KS>
+__global__ void __launch_bounds__(256) dwconv_affine_k_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int H, int W, int C,
+                                                              const float* __restrict__ w, const float* __restrict__ bias,
+                                                              const float* __restrict__ ps, const float* __restrict__ ph) {
+    constexpr int EPV = 16 / (int)sizeof(T);
+    constexpr int P = (KS - 1) / 2;
+    const int cv = C / EPV;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)B * H * W * cv;
+    if (idx >= total) return;
+    const int c0 = (int)(idx % cv) * EPV;
+    const long long pix = idx / cv;
+    const int xw = (int)(pix % W);
+    const int yh = (int)((pix / W) % H);
+    float a[EPV], sh[EPV], acc[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; e += 4) {
+        const f32x4 av = ps ? *reinterpret_cast<const f32x4*>(ps + c0 + e) : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 sv = ph ? *reinterpret_cast<const f32x4*>(ph + c0 + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + c0 + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+        a[e] = av.x; a[e + 1] = av.y; a[e + 2] = av.z; a[e + 3] = av.w;
+        sh[e] = sv.x; sh[e + 1] = sv.y; sh[e + 2] = sv.z; sh[e + 3] = sv.w;
+        acc[e] = bv.x; acc[e + 1] = bv.y; acc[e + 2] = bv.z; acc[e + 3] = bv.w;
+    }
+    const T* ctr_p = x + pix * C + c0;
+    u32x4 v[KS * KS];
+    bool ok[KS * KS];
+#pragma unroll
+    for (int dy = 0; dy < KS; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < KS; ++dx) {
+            const int yy = yh + dy - P, xx = xw + dx - P;
+            ok[dy * KS + dx] = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            v[dy * KS + dx] = *reinterpret_cast<const u32x4*>(ok[dy * KS + dx] ? ctr_p + ((ptrdiff_t)(dy - P) * W + (dx - P)) * C : ctr_p);
+        }
+#pragma unroll
+    for (int t = 0; t < KS * KS; ++t) {
+        T e8[EPV];
+        __builtin_memcpy(e8, &v[t], 16);
+        const float* wt = w + (size_t)t * C + c0;
+#pragma unroll
+        for (int e = 0; e < EPV; e += 4) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wt + e);
+            const float w4[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float tap = ok[t] ? fmaf(a[e + q], to_f32(e8[e + q]), sh[e + q]) : 0.f;
+                acc[e + q] = fmaf(w4[q], tap, acc[e + q]);
+            }
+        }
+    }
+    T c8[EPV], o[EPV];
+    __builtin_memcpy(c8, &v[P * KS + P], 16);
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) o[e] = from_f32<T>(to_f32(c8[e]) + acc[e]);
+    *reinterpret_cast<u32x4*>(out + pix * C + c0) = *reinterpret_cast<const u32x4*>(o);
+}
+
 }  // namespace mlpk
 
 using namespace mlpk;
@@ -263,6 +324,14 @@ extern "C" int mlpk_dwconv_affine_nhwc(int dtype, const void* x, void* out, int 
     if ((total + 255) / 256 > 0x7fffffffLL) return MLPK_ESHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)((total + 255) / 256));
+    if (k == 3 && dtype != MLPK_F32) {
+        if (dtype == MLPK_F16)
+            hipLaunchKernelGGL((dwconv_affine_k_kernel<f16_t, 3>), grid, dim3(256), 0, s, (const f16_t*)x, (f16_t*)out, B, H, W, C, w, bias, pre_scale, pre_shift);
+        else
+            hipLaunchKernelGGL((dwconv_affine_k_kernel<bf16_t, 3>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)out, B, H, W, C, w, bias, pre_scale, pre_shift);
+        MLPK_LAUNCH_CHECK();
+        return 0;
+    }
     switch (dtype) {
         case MLPK_F32:
             hipLaunchKernelGGL(dwconv_affine_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (float*)out, B, H, W, C, k, w, bias, pre_scale, pre_shift);
