@@ -323,3 +323,34 @@ def test_fused_channel_mlp_packing_orders(pkg):
     # no norm: no csum, weights unfolded
     w1p, b1p, csum, w2p, b2p, nch = E.pack_channel_mlp_fused(w1, b1, w2, b2, torch.bfloat16, dev)
     assert csum is None and torch.equal(w1p[:T, :C], w1.to(torch.bfloat16)) and torch.allclose(b1p[:T], b1) and torch.allclose(b2p, b2)
+
+
+def test_linear_gelu_and_swin_packing_orders(pkg):
+    """engine.pack_linear_gelu (mlpk_linear_gelu: rows of every 32 stored as [row 16 j + 4 f + r <- output column 8 f + 4 j + r], bias and
+    csum in the same order, K padded to 256 / 512) and engine.pack_swin_spatial (grouped Conv1d weight -> (heads, 64, 64) [t_out][t_in],
+    bias -> (heads, 64), zero-padded) on CPU tensors."""
+    E = pkg.engine
+    g = torch.Generator().manual_seed(9)
+    dev = torch.device("cpu")
+    Nn, K = 96, 384
+    w, b = torch.randn((Nn, K), generator=g), torch.randn((Nn,), generator=g)
+    gamma, beta = torch.rand((K,), generator=g) + 0.5, torch.randn((K,), generator=g)
+    wp, bp, csum, nch = E.pack_linear_gelu(w, b, torch.bfloat16, dev, gamma, beta)
+    assert nch == 3 and tuple(wp.shape) == (96, 512) and not wp[:, K:].any()
+    wf = (w * gamma.view(1, -1)).to(torch.bfloat16)
+    bf = b + w @ beta
+    for row in range(Nn):
+        grp, rr = divmod(row, 32)
+        j, f, r = rr // 16, (rr // 4) % 4, rr % 4
+        src = 32 * grp + 8 * f + 4 * j + r
+        assert torch.equal(wp[row, :K], wf[src]), row
+        assert abs(bp[row].item() - bf[src].item()) < 1e-5 and abs(csum[row].item() - wf[src].float().sum().item()) < 1e-3
+    wp2, _, cs2, _ = E.pack_linear_gelu(w[:, :200], b, torch.float16, dev)
+    assert tuple(wp2.shape) == (96, 256) and cs2 is None
+    heads, ws = 3, 7
+    t = ws * ws
+    cw, cb = torch.randn((heads * t, t, 1), generator=g), torch.randn((heads * t,), generator=g)
+    sw, sb = E.pack_swin_spatial(cw, cb, heads, ws, torch.bfloat16, dev)
+    assert tuple(sw.shape) == (heads, 64, 64) and tuple(sb.shape) == (heads, 64)
+    assert torch.equal(sw[:, :t, :t], cw.reshape(heads, t, t).to(torch.bfloat16)) and not sw[:, t:].any() and not sw[:, :, t:].any()
+    assert torch.equal(sb[:, :t], cb.reshape(heads, t)) and not sb[:, t:].any()
