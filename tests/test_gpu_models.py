@@ -237,6 +237,12 @@ BS256 = [
     ("asmlp_t", "AS_MLP", dict(), 2, "asmlp"),
     ("convmixer_1536_20", "ConvMixer", dict(dim=1536, depth=20), 2, "convmixer"),
     ("mixer_l16", "MLPMixerForImageClassification", dict(d_model=1024, depth=24, patch_size=16, image_size=224), 2, "mixer"),
+    # round 5: the SURVEY 8(f) models have bs=256-only kernel choices too (mlpk_channel_mlp, mlpk_swin_spatial, persistent tiles)
+    ("sparsemlp_t", "SparseMLP", dict(), 2, "sparsemlp"),
+    ("hiremlp_s", "HireMLP", dict(), 2, "hiremlp"),
+    ("msmlp_t", "MS_MLP", dict(), 2, "msmlp"),
+    ("swinmlp_t", "SwinMLP", dict(), 2, "swinmlp"),
+    ("cyclemlp_b1", "CycleMLP_B1", dict(), 2, "cyclemlp"),
 ]
 
 
@@ -244,7 +250,8 @@ BS256 = [
 # ONE order (include/mlpk.h row_part), so the models whose LayerNorms read those statistics -- the Mixers since their token LayerNorm moved
 # into the token kernel -- are back in this set (round 3: sums over 32 / 64 / 128 columns "depending on the tile the batch size selects").
 # (... and with them every other BASELINE configuration: gMLP-S, ViP-S7, S2-MLPv2 in both shift modes -- profiles/r04_bs256_parity.txt)
-BIT_EQUAL = {"resmlp_24", "asmlp_t", "convmixer_1536_20", "mixer_b16", "mixer_l16", "gmlp_s", "vip_s7", "s2mlpv2", "s2mlpv2_cleanshift"}
+BIT_EQUAL = {"resmlp_24", "asmlp_t", "convmixer_1536_20", "mixer_b16", "mixer_l16", "gmlp_s", "vip_s7", "s2mlpv2", "s2mlpv2_cleanshift",
+             "sparsemlp_t", "hiremlp_s", "msmlp_t", "swinmlp_t", "cyclemlp_b1"}
 
 
 @pytest.mark.parametrize("name,ctor,kw,k,family", BS256)
@@ -262,12 +269,20 @@ def test_batch_256_rows_match_small_batch(name, ctor, kw, k, family):
     (Round 3: this test found mlpk_token_gemm multiplying the first token group of every tile after a workgroup's first by the
     wrong weights -- gMLP-S 5e-2 off at 256 images, correct at every golden batch size.)"""
     pkg = load_pkg()
-    torch.manual_seed(0)
     model = getattr(pkg.models_pytorch, ctor)(**kw).eval()
     mode = "shift" if name.endswith("cleanshift") else "reference_inplace"
     if name.endswith("cleanshift"):
         model.set_shift_mode("shift")
-    sd = {kk: v.detach().float().clone() for kk, v in model.state_dict().items()}
+    # Round 5: weights from the portable generator (oracle/portable_init.py: LayerScale gamma 0.05-0.2, BatchNorm running statistics
+    # and every norm's affine non-trivial), NOT torch's default init -- with that, ResMLP's gamma = 1e-5 put every token / channel
+    # product 5 orders below bf16 resolution of the residual and ConvMixer's BatchNorm epilogue was the identity, so neither the oracle
+    # gate nor bit-equality could see a wrong bs=256-only tile (res_mlp.py:38-43, conv_mixer.py:24-31).
+    with open(os.path.join(GOLDEN, "manifest.json")) as f:
+        man = json.load(f)["state_dicts"][name.replace("_cleanshift", "")]
+    assert man["kwargs"] == kw
+    sd = {kk: torch.from_numpy(v) for kk, v in portable_state_dict({kk: tuple(sh) for kk, sh in man["keys"]}, seed=0).items()}
+    model.load_state_dict(sd, strict=True)
+    sd = {kk: v.float() for kk, v in sd.items()}
     model = model.to(DEV)
     x = torch.from_numpy(portable_input((256, 3, 224, 224), seed=3)).to(DEV).to(torch.bfloat16)
     with torch.no_grad():

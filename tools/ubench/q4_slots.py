@@ -338,6 +338,92 @@ for nf in (3, 4, 5):
 P("target4_m0each", lambda a, q: target(a, q, 4, off=False), lambda a: (a("s_waitcnt", vmcnt=12, lgkmcnt=0), a("s_barrier")) and None)
 P("target4_plain", lambda a, q: target(a, q, 4, transmix=False), lambda a: (a("s_waitcnt", vmcnt=12, lgkmcnt=0), a("s_barrier")) and None)
 P("target5_plain", lambda a, q: target(a, q, 5, transmix=False), lambda a: (a("s_waitcnt", vmcnt=12, lgkmcnt=0), a("s_barrier")) and None)
+
+# ---- round 5: the epilogue as an instruction STREAM at its real rate -- the logistic GELU in fp32 (7 per element, 2 of them transcendental)
+# against the packed-f16 polynomial (v_cvt_pk_f16_f32, v_pk_mul / v_pk_fma_f16, v_fma_mix_f32 back to fp32): what does the exchange buy?
+def stream_ops(kind):
+    """the instruction kinds of one group of FOUR elements, in issue order"""
+    R = lambda n: 72 + n % 16
+    ops = []
+    acc = [lambda a, k=k: a("v_accvgpr_read_b32", V(R(k)), A(128 + k)) for k in range(4)]
+    ln = [lambda a, k=k: a("v_fma_f32", V(R(k)), V(R(k)), V(64), V(65)) for k in range(8)]
+    cvtbf = [lambda a, k=k: a("v_cvt_pk_bf16_f32", V(88 + k), V(R(2 * k)), V(R(2 * k + 1))) for k in range(2)]
+    dsw = [lambda a: a("ds_write_b64", V(2), V(88, 2), offset=8192)]
+    f32 = lambda n: [lambda a, k=k: a("v_fma_f32", V(R(k)), V(R(k)), V(64), V(65)) for k in range(n)]
+    tr = lambda op: [lambda a, k=k: a(op, V(R(k + 8)), V(R(k + 8))) for k in range(4)]
+    pk = lambda n, op="v_pk_fma_f16": [lambda a, k=k: (a(op, V(R(k + 4)), V(R(k + 4)), V(64), V(65)) if op == "v_pk_fma_f16" else a(op, V(R(k + 4)), V(R(k + 4)), V(64))) for k in range(n)]
+    cvth = [lambda a, k=k: a("v_cvt_pk_f16_f32", V(R(k + 4)), V(R(2 * k)), V(R(2 * k + 1))) for k in range(2)]
+    mix = [lambda a, k=k: a("v_fma_mix_f32", V(R(k)), V(R(k)), V(R(4 + k // 2)), 0, op_sel="[0,%d,0]" % (k & 1), op_sel_hi="[0,1,0]") for k in range(4)]
+    sig = f32(4) + f32(4) + f32(4) + tr("v_exp_f32") + f32(4) + tr("v_rcp_f32") + f32(4)
+    h2 = lambda nh: cvth + pk(2, "v_pk_mul_f16") + pk(2) + pk(2 * nh) + pk(2)          # cvt, t, u, Horner, Phi
+    if kind == "q4_sig":
+        return acc + ln + sig + cvtbf + dsw
+    if kind == "q4_h2":            # 7 coefficients
+        return acc + ln + h2(6) + mix + cvtbf + dsw
+    if kind == "q4_h2n5":
+        return acc + ln + h2(4) + mix + cvtbf + dsw
+    if kind == "q4_h2_f16out":     # the hidden stored as f16: the product in packed f16, no conversion back
+        return acc + ln + h2(6) + pk(2, "v_pk_mul_f16") + dsw
+    if kind == "q4_none":
+        return acc + ln + cvtbf + dsw
+    if kind == "t4_sig":
+        return sig + cvtbf
+    if kind == "t4_h2":            # f16 hidden: x16 * Phi16 is the second product's operand
+        return h2(6) + pk(2, "v_pk_mul_f16")
+    if kind == "t4_h2_bf16":
+        return h2(6) + mix + cvtbf
+    raise KeyError(kind)
+
+
+class Stream:
+    def __init__(self, kind, per_iter):
+        self.ops, self.rate, self.pos = stream_ops(kind), per_iter / 32.0, 0
+
+    def __call__(self, a, q):
+        n = int((q + 1) * self.rate) - int(q * self.rate)
+        for _ in range(n):
+            self.ops[self.pos % len(self.ops)](a)
+            self.pos += 1
+
+
+def q4loop(kind):
+    """the q4 K loop of fc1 (K = 768: 32 groups of four elements drained over 12 iterations of 32 MFMAs) with the epilogue stream `kind`"""
+    st = Stream(kind, len(stream_ops(kind)) * 32 / 12.0)
+    def pat(a, q):
+        if q % 8 in (1, 3, 6):
+            dma_off(a, q)
+        if READS68(q):
+            ds_read(a, q)
+        st(a, q)
+    return pat
+
+
+for kind in ("q4_none", "q4_sig", "q4_h2", "q4_h2n5", "q4_h2_f16out"):
+    P("r5_" + kind, q4loop(kind), lambda a: (a("s_waitcnt", vmcnt=12, lgkmcnt=0), a("s_barrier")) and None)
+
+
+def t4loop(kind):
+    """the token kernel's group iteration: 54 MFMAs, 32 elements per lane -> 8 groups of four; here per 32 MFMAs"""
+    st = Stream(kind, len(stream_ops(kind)) * 8 * 32 / 54.0)
+    def pat(a, q):
+        if q % 8 in (1, 3, 6):
+            dma(a, q, nop=False)
+        if (q & 1) == 0:
+            ds_read(a, q)
+            a("s_waitcnt", lgkmcnt=3)
+        st(a, q)
+    return pat
+
+
+for kind in ("t4_sig", "t4_h2", "t4_h2_bf16"):
+    P("r5_" + kind, t4loop(kind), lambda a: (a("s_waitcnt", vmcnt=0, lgkmcnt=0), a("s_barrier")) and None)
+    VDSTN = kind
+P("mix4", lambda a, q: [a("v_fma_mix_f32", V(72 + (4 * q + k) % 16), V(72 + (4 * q + k) % 16), V(64), 0, op_sel="[0,%d,0]" % (k & 1), op_sel_hi="[0,1,0]") for k in range(4)] and None)
+P("mix5", lambda a, q: [a("v_fma_mix_f32", V(72 + (5 * q + k) % 16), V(72 + (5 * q + k) % 16), V(64), 0, op_sel="[0,%d,0]" % (k & 1), op_sel_hi="[0,1,0]") for k in range(5)] and None)
+P("cvth4", lambda a, q: [a("v_cvt_pk_f16_f32", V(72 + (4 * q + k) % 16), V(64), V(65)) for k in range(4)] and None)
+P("cvtbf4", lambda a, q: [a("v_cvt_pk_bf16_f32", V(72 + (4 * q + k) % 16), V(64), V(65)) for k in range(4)] and None)
+P("pkfma16_dep4", lambda a, q: [a("v_pk_fma_f16", V(72), V(72), V(64), V(65)) for k in range(4)] and None)       # ONE dependent chain
+P("fma_dep4", lambda a, q: [a("v_fma_f32", V(72), V(72), V(64), V(65)) for k in range(4)] and None)
 ONLY = os.environ.get("ONLY", "")
 if ONLY:
     PAT[:] = [x for x in PAT if any(x[0].startswith(t) for t in ONLY.split(","))]
