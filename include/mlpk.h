@@ -198,7 +198,10 @@ int mlpk_token_mlp(int dtype, const void* xt, int ldxt, int M, int S, const void
  *           is all zeros (what the pipeline's fill iterations multiply by);
  *      b1 : 1024 floats, entry 64 + t = bias of hidden unit t, zeros elsewhere;   b2 : 224 floats, zeros behind S;
  *      stats: planes of 64 channels (t_rows / 64 planes of B*S pairs) instead of 128.
- * mlpk_token_mlp_layout_for additionally knows the channels per image and answers 2 when the generated kernel takes the shape. */
+ *   3  (ABI 9, bf16 storage only) layout 2 with the HIDDEN KEPT IN f16: the kernel evaluates the GELU in packed f16 and hands the second product
+ *      f16 operands (11 mantissa bits instead of bf16's 8; values beyond +-65504 saturate there), so `w2` holds IEEE f16 values -- W2 rounded
+ *      to f16 by the packer -- in exactly the arrangement of layout 2.  x, xt, w1 and everything stored stay bf16.
+ * mlpk_token_mlp_layout_for additionally knows the channels per image and answers 3 (bf16) / 2 (f16) when the generated kernel takes the shape. */
 int mlpk_token_mlp_layout(int S, int nchunks);
 int mlpk_token_mlp_layout_for(int dtype, int S, int nchunks, int t_rows);
 /* The whole token-mixing PreNormResidual in ONE kernel (ABI 7; mlp_mixer.py:34 with :6-13 and :16-27):
@@ -206,10 +209,11 @@ int mlpk_token_mlp_layout_for(int dtype, int S, int nchunks, int t_rows);
  * -- mlpk_layernorm_transpose + mlpk_token_mlp(layout 2) without the xt tensor between them: the generated kernel reads its rows of x
  * (token-major 128-byte lines), normalises them with the given row statistics (ln_mean / ln_rstd over B*S rows: mlpk_row_stats, or a
  * producer GEMM's row_part through mlpk_stats_finalize_planar) and gamma / beta (t_rows floats), and transposes through LDS into its
- * operand registers.  Weights, b1, b2, stats exactly as for layout 2; the shapes of layout 2 with nchunks >= 2. */
+ * operand registers.  Weights, b1, b2, stats exactly as for layout 2 / 3 (`layout`, ABI 9: the answer of mlpk_token_mlp_layout_for the weights
+ * were packed with); the shapes of layout 2 with nchunks >= 2. */
 int mlpk_token_mlp_ln(int dtype, void* x, int ldx, int M, int S, const float* ln_mean, const float* ln_rstd, const float* gamma,
                       const float* beta, const void* w1, int ldw1, const float* b1, const void* w2, int ldw2, const float* b2,
-                      int nchunks, int t_rows, float* stats, void* stream);
+                      int nchunks, int t_rows, float* stats, int layout, void* stream);
 
 /* ---- single token-mixing product with the per-image transpose in the epilogue -----------------------------------------------
  * out[b,t,c] = R[b,t,c] (+ | *) rscale[c] * ( sum_s W[t,s] * xt[b*t_rows + c, s] + bias[t] )     (res_mode ADD | MUL; NONE: no R)

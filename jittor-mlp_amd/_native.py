@@ -53,7 +53,7 @@ PROTOTYPES = {
     "mlpk_token_mlp": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "mlpk_token_mlp_ln": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
-                                  c_void_p, c_int, c_int, c_void_p, c_void_p]),
+                                  c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "mlpk_token_mlp_layout": (c_int, [c_int, c_int]),
     "mlpk_token_mlp_layout_for": (c_int, [c_int, c_int, c_int, c_int]),
     "mlpk_token_gemm": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
@@ -120,7 +120,7 @@ def lib():
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(handle, name)          # AttributeError if a declared symbol is not exported
             fn.restype, fn.argtypes = res, args
-        if handle.mlpk_abi_version() != 8:
+        if handle.mlpk_abi_version() != 9:
             raise MlpkError("libmlpk.so ABI version mismatch")
         _lib = handle
     return _lib

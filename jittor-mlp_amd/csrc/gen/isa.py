@@ -80,7 +80,31 @@ class F:
         return self.INLINE.get(self.x, "0x%08x" % self.bits())
 
 
+class H:
+    """inline constant of a PACKED f16 instruction (VOP3P): the assembler puts the f16 value in the low half of the operand and zero in
+    the high half, so the instruction must name it with op_sel_hi 0 for that source to feed both lanes (tools/ubench/h2_semantics.hip)"""
+    INLINE = F.INLINE
+
+    def __init__(self, x):
+        self.x = float(x)
+        assert self.x in self.INLINE, "not an inline constant: %r" % x
+
+    def bits(self):
+        return int(np.float16(self.x).view(np.uint16))
+
+    def text(self):
+        return self.INLINE[self.x]
+
+
+def h2bits(x):
+    """the same f16 value in both halves of a 32-bit word (a packed constant held in a register)"""
+    b = int(np.float16(x).view(np.uint16))
+    return b | (b << 16)
+
+
 def _optext(o):
+    if isinstance(o, H):
+        return o.text()
     if isinstance(o, Reg):
         return o.text()
     if isinstance(o, Neg):
@@ -263,7 +287,7 @@ class Emu:
                 if o.idx in w.spend:
                     raise RuntimeError("read of s%d before its s_load was waited for (pc %d)" % (o.idx, w.pc))
                 return np.full(64, w.s[o.idx], np.uint32)
-        if isinstance(o, F):
+        if isinstance(o, (F, H)):
             return np.full(64, o.bits(), np.uint32)
         if isinstance(o, Neg):
             return self.rd(w, o.r) ^ np.uint32(0x80000000)
@@ -742,6 +766,74 @@ class Emu:
             lo = self.f(self.rd(w, i.args[1])).astype(np.float16).view(np.uint16).astype(np.uint32)
             hi = self.f(self.rd(w, i.args[2])).astype(np.float16).view(np.uint16).astype(np.uint32)
         self.wrv(w, i.args[0], lo | (hi << 16))
+
+    def x_v_cvt_pkrtz_f16_f32(self, w, i):
+        """round toward zero: never overflows to infinity (a finite input beyond the f16 range gives +-65504)"""
+        out = []
+        for k in (1, 2):
+            x = self.f(self.rd(w, i.args[k]))
+            with np.errstate(all="ignore"):
+                h = x.astype(np.float16)
+                hb = h.view(np.uint16).astype(np.uint32)
+                over = np.abs(h.astype(np.float32)) > np.abs(x)           # rounded away from zero (or to infinity): one step back
+                hb = np.where(over & np.isfinite(x), hb - 1, hb)
+            out.append(hb & 0xFFFF)
+        self.wrv(w, i.args[0], out[0] | (out[1] << 16))
+
+    # ---- packed f16 (VOP3P): lane 0 of source k = its half op_sel[k] (default low), lane 1 = its half op_sel_hi[k] (default high)
+    @staticmethod
+    def _sel(mods, key, default, n):
+        v = mods.get(key)
+        return [default] * n if v is None else [int(x) for x in str(v).strip("[]").split(",")]
+
+    def _pk16_src(self, w, i, nsrc):
+        lo_sel, hi_sel = self._sel(i.mods, "op_sel", 0, nsrc), self._sel(i.mods, "op_sel_hi", 1, nsrc)
+        lanes = ([], [])
+        for k in range(nsrc):
+            o = i.args[1 + k]
+            if isinstance(o, H):
+                assert hi_sel[k] == 0 and lo_sel[k] == 0, "an inline f16 constant sits in the LOW half only: op_sel_hi must be 0 for it"
+            v = self.rd(w, o)
+            for lane, sel in ((0, lo_sel[k]), (1, hi_sel[k])):
+                half = ((v >> 16) if sel else v) & 0xFFFF
+                lanes[lane].append(half.astype(np.uint16).view(np.float16).astype(np.float64))
+        return lanes
+
+    def _pk16_wr(self, w, i, res):
+        out = []
+        for r in res:
+            with np.errstate(all="ignore"):
+                h = r.astype(np.float16)
+            if i.mods.get("clamp"):
+                h = np.where(np.isnan(h), np.float16(0), np.clip(h, np.float16(0), np.float16(1))).astype(np.float16)
+            out.append(h.view(np.uint16).astype(np.uint32))
+        self.wrv(w, i.args[0], out[0] | (out[1] << 16))
+
+    def x_v_pk_mul_f16(self, w, i):
+        lanes = self._pk16_src(w, i, 2)
+        with np.errstate(all="ignore"):
+            self._pk16_wr(w, i, [l[0] * l[1] for l in lanes])
+
+    def x_v_pk_fma_f16(self, w, i):
+        lanes = self._pk16_src(w, i, 3)
+        with np.errstate(all="ignore"):
+            self._pk16_wr(w, i, [l[0] * l[1] + l[2] for l in lanes])       # (exact in fp64 up to astronomically rare ties, then ONE rounding)
+
+    def x_v_fma_mix_f32(self, w, i):
+        """fp32 fma whose source k is fp32 (op_sel_hi[k] = 0) or the f16 half op_sel[k] of its register (op_sel_hi[k] = 1)"""
+        sel, is16 = self._sel(i.mods, "op_sel", 0, 3), self._sel(i.mods, "op_sel_hi", 0, 3)
+        src = []
+        for k in range(3):
+            v = self.rd(w, i.args[1 + k])
+            if is16[k]:
+                src.append((((v >> 16) if sel[k] else v) & 0xFFFF).astype(np.uint16).view(np.float16).astype(np.float64))
+            else:
+                src.append(self.f(v).astype(np.float64))
+        with np.errstate(all="ignore"):
+            r = (src[0] * src[1] + src[2]).astype(np.float32)
+        if i.mods.get("clamp"):
+            r = np.where(np.isnan(r), np.float32(0), np.clip(r, 0, 1)).astype(np.float32)
+        self.wrv(w, i.args[0], self.u(r))
 
     def x_v_cvt_f32_f16(self, w, i):
         self.wrv(w, i.args[0], self.u((self.rd(w, i.args[1]) & 0xFFFF).astype(np.uint16).view(np.float16).astype(np.float32)))

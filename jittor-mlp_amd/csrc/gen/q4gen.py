@@ -25,7 +25,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from isa import A, F, S, V, Abs, Asm, Neg, Reg  # noqa: E402
+from isa import A, F, H, S, V, Abs, Asm, Neg, Reg, h2bits  # noqa: E402
 
 # the 16-bit GELU polynomials of mlpk_common.h (MLPK_GELUP_*) by storage type.  f16: (scale, Horner coefficients) of the centred form
 # t = clamp(x * scale, -sqrt2, sqrt2), u = t * t - 1; bf16: (clamp, coefficients) of the raw form t = clamp(x, -clamp, clamp), u = t * t
@@ -39,6 +39,37 @@ GELU_RAW = {"f16": False, "bf16": True}
 # MLPK_GELU_BF16_POLY=1 at generation time (+ -DMLPK_GELU_BF16_POLY for the HIP sources) keeps the polynomial for A/B builds.
 GELU_SIG = {"bf16": (-2.28684449, -0.0305621661, -0.0905431807)}
 GELU_FORM = {"f16": "poly", "bf16": "poly" if os.environ.get("MLPK_GELU_BF16_POLY") == "1" else "sig"}
+
+
+# round 5, the fused token-mixing kernel's bf16 grade ("h2", t4gen.py): Phi as a polynomial in PACKED f16 -- two elements per instruction and no
+# transcendental: h = rtz_f16(x); t = h * SCALE; u = t * t - 1; Phi = clamp01(0.5 + t * Q(u)), Q = 7 coefficients by Horner; gelu = h * Phi, which IS
+# the f16 operand of the second product (the hidden is kept in f16 there: 11 bits instead of bf16's 8).  11 instructions per PAIR against 15 (two of
+# them transcendental) -- profiles/r05_issue_slots_packed_gelu.txt: 43.7 -> 38.6 cycles per MFMA in the kernel's loop.  Every value is exact in f16
+# (tools/fit_gelu_h2.py: fitted on |x| <= 4 with the coefficients rounded one by one; the leading coefficient is positive, so beyond the interval the
+# polynomial runs off in the direction the clamp wants and no operand clamp is needed; rtz never produces an infinity, so h * Phi is never inf * 0).
+GELU_H2 = {"scale": 0.353515625,
+           "coefs": [0.01392364501953125, -0.046875, 0.07305908203125, -0.100830078125, 0.155029296875, -0.2386474609375, 0.497802734375]}
+
+
+def h2_gelu_ops(E, x, hdst, t, u, q, v_c0, s_scale, s_c):
+    """hdst[k] <- packed f16 (gelu(x[2k]), gelu(x[2k+1])) for the pairs k abreast; t, u, q: one scratch register per pair; v_c0 / s_scale / s_c[0:5]:
+    the packed constants (both halves) -- a VOP3P instruction reads at most one SGPR, so the first Horner step takes c0 from a VGPR."""
+    n = len(hdst)
+    for k in range(n):
+        E("v_cvt_pkrtz_f16_f32", hdst[k], x[2 * k], x[2 * k + 1])
+    for k in range(n):
+        E("v_pk_mul_f16", t[k], hdst[k], s_scale)
+    for k in range(n):
+        E("v_pk_fma_f16", u[k], t[k], t[k], H(-1.0), op_sel_hi="[1,1,0]")
+    for k in range(n):
+        E("v_pk_fma_f16", q[k], v_c0, u[k], s_c[0])
+    for j in range(1, 6):
+        for k in range(n):
+            E("v_pk_fma_f16", q[k], q[k], u[k], s_c[j])
+    for k in range(n):
+        E("v_pk_fma_f16", q[k], t[k], q[k], H(0.5), op_sel_hi="[1,1,0]", clamp=True)
+    for k in range(n):
+        E("v_pk_mul_f16", hdst[k], hdst[k], q[k])
 
 
 def sig_gelu_ops(E, x, q, v_k2, s_k1, s_k0):

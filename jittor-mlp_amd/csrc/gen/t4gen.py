@@ -28,8 +28,8 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from isa import A, F, S, V, Asm, Neg, Reg  # noqa: E402
-from q4gen import GELU, GELU_FORM, GELU_RAW, GELU_SIG, SQRT2, Alloc, sig_gelu_ops  # noqa: E402
+from isa import A, F, S, V, Asm, Neg, Reg, h2bits  # noqa: E402
+from q4gen import GELU, GELU_FORM, GELU_H2, GELU_RAW, GELU_SIG, SQRT2, Alloc, h2_gelu_ops, sig_gelu_ops  # noqa: E402
 
 KA = dict(xt=0, w1=8, w2=16, b1=24, b2=32, x=40, stats=48, prof=56,
           M=64, G=68, ldxt=72, ldx=76, ntiles=80, tpi=84, tpi_magic=88, grid=92, stat_ld=96, nit=100, lead=104, S=108,
@@ -59,7 +59,7 @@ class T4:
     NXA = 8                                # X fragments kept in the 32 AGPRs the accumulators leave over
     DEPTH = 3                              # W fragments read ahead of their MFMAs (ring of 4 register quads)
 
-    def __init__(self, dtype="bf16", stats=False, dbg=0, name=None, shape=0, ln=False):
+    def __init__(self, dtype="bf16", stats=False, dbg=0, name=None, shape=0, ln=False, h2=False):
         # ln: the token LayerNorm + transpose is this kernel's X loader -- x itself is read (token-major rows, statistics given),
         # normalised, transposed through LDS into the fragment registers; `xt` is not used (shaped kernels only)
         assert not ln or shape
@@ -71,8 +71,13 @@ class T4:
         # tuning ablations (wrong results by construction): 1 no LDS-DMA, 2 no GELU fillers, 4 no epilogue stores, 16 no residual loads,
         # 32 no X loads
         self.dtype, self.stats, self.dbg = dtype, stats, dbg
-        self.name = name or "t4_%s%s%s" % (dtype, "_st" if stats else "", ("", "_odd", "_even")[shape] + ("_ln" if ln else ""))
+        # h2 (round 5, bf16 storage only; mlpk.h layout 3): the GELU in packed f16 and the hidden KEPT in f16 -- W2 is packed as f16 and the second
+        # product runs on the f16 MFMA; x, W1, the first product and everything the kernel stores stay bf16
+        assert not h2 or dtype == "bf16"
+        self.h2 = h2
+        self.name = name or "t4_%s%s%s%s" % (dtype, "_h2" if h2 else "", "_st" if stats else "", ("", "_odd", "_even")[shape] + ("_ln" if ln else ""))
         self.mfma = "v_mfma_f32_32x32x16_bf16" if dtype == "bf16" else "v_mfma_f32_32x32x16_f16"
+        self.mfma2 = "v_mfma_f32_32x32x16_f16" if h2 else self.mfma          # the second product
         self.cvt = "v_cvt_pk_bf16_f32" if dtype == "bf16" else "v_cvt_pk_f16_f32"
         self.dot = "v_dot2c_f32_bf16" if dtype == "bf16" else "v_dot2c_f32_f16"
         self.raw = GELU_RAW[dtype]
@@ -96,8 +101,11 @@ class T4:
         self.s_scur = s("scur", 2, 2) if self.stats else None
         self.s_tok8 = s("tok8")
         self.s_r2 = s("r2")
-        self.sig = GELU_FORM[self.dtype] == "sig"
+        self.sig = GELU_FORM[self.dtype] == "sig" and not self.h2
         self.s_k0, self.s_k1 = (s("gk0"), s("gk1")) if self.sig else (None, None)
+        # packed-f16 constants: two in SGPRs (as many as the logistic form held -- the asm block may clobber no more scalar registers than
+        # that: "inline assembly requires more registers than available"), c0 .. c5 in VGPRs
+        self.s_hscale, self.s_hc6 = (s("hscale"), s("hc6")) if self.h2 else (None, None)
         self.s_mask = s("mask", 2, 2)
         self.s_t = [s("t%d" % i) for i in range(6)]
         self.s_t64 = s("t64", 2, 2)
@@ -127,6 +135,7 @@ class T4:
         flat = [r_[e] for grp_ in self.tmp for r_ in grp_ for e in range(2)]
         self.tmp_t, self.tmp_u, self.tmp_q = flat[0:4], flat[4:8], flat[8:12]
         self.v_c0 = v("c0")
+        self.v_hc = [v("hc%d" % j) for j in range(1, 6)] if self.h2 else None
         self.v_w1rd, self.v_w2rd, self.v_b1rd = v("w1rd"), v("w2rd"), v("b1rd")
         self.v_w1off = [v("w1off%d" % i) for i in range(5)]
         self.v_w2off = [v("w2off%d" % i) for i in range(5)]
@@ -197,6 +206,12 @@ class T4:
             for grp in range(4):                      # accumulator registers 4 grp .. 4 grp + 3
                 x = [self.xg[par_in][rb][4 * grp + r] for r in range(4)]
                 scale, c = GELU[self.dtype]
+                kk, e0 = grp >> 1, 4 * (grp & 1)
+                hreg = self.h[par_out][rb][kk]
+                if self.h2:
+                    # accumulator registers (4 grp + 2 k, 4 grp + 2 k + 1) -> the packed pair (e0 >> 1) + k of A fragment kk
+                    h2_gelu_ops(E, x, [hreg[(e0 >> 1) + k] for k in range(2)], T[0:2], U[0:2], Q[0:2], self.v_c0, self.s_hscale, self.v_hc + [self.s_hc6])
+                    continue
                 if self.sig:
                     sig_gelu_ops(E, x, Q, self.v_c0, self.s_k1, self.s_k0)
                 elif self.raw:
@@ -222,8 +237,6 @@ class T4:
                     for r in range(4):
                         E("v_mul_f32", x[r], x[r], T[r])
                 # accumulator register 8 kk + e -> A fragment kk, packed pair e >> 1
-                kk, e0 = grp >> 1, 4 * (grp & 1)
-                hreg = self.h[par_out][rb][kk]
                 E(self.cvt, hreg[e0 >> 1], x[0], x[1])
                 E(self.cvt, hreg[(e0 >> 1) + 1], x[2], x[3])
         return ops
@@ -318,10 +331,10 @@ class T4:
                 fill[state["done"]]()
                 state["done"] += 1
 
-        def mfma(*margs):
+        def mfma(*margs, op=None):
             if dma:
                 self.emit_m0(dma[0][0], dma[0][1], 1 - par)
-            a(self.mfma, *margs)
+            a(op or self.mfma, *margs)
             if dma:
                 kind, i = dma.pop(0)
                 self.emit_dma(kind, i, 1 - par)
@@ -352,7 +365,7 @@ class T4:
             wf = self.Wf[n & 3]
             for rb in range(2):
                 if kind == "w2":
-                    mfma(self.D2(rb, tb), self.h[par][rb][x], wf, self.D2(rb, tb))
+                    mfma(self.D2(rb, tb), self.h[par][rb][x], wf, self.D2(rb, tb), op=self.mfma2)
                 else:
                     mfma(self.xg[par][rb], wf, self.X[rb][x], self.b1 if x == 0 else self.xg[par][rb])
         while state["done"] < total:
@@ -637,7 +650,13 @@ class T4:
         a("v_lshrrev_b32", l3, 3, lane)
         a("v_and_b32", l7, 7, lane)
         a("s_mov_b32", self.s_r2, F(SQRT2))
-        if self.sig:
+        if self.h2:
+            a("v_mov_b32", self.v_c0, h2bits(GELU_H2["coefs"][0]))
+            a("s_mov_b32", self.s_hscale, h2bits(GELU_H2["scale"]))
+            for cj in range(5):
+                a("v_mov_b32", self.v_hc[cj], h2bits(GELU_H2["coefs"][cj + 1]))
+            a("s_mov_b32", self.s_hc6, h2bits(GELU_H2["coefs"][6]))
+        elif self.sig:
             a("v_mov_b32", self.v_c0, F(GELU_SIG[self.dtype][2]))
             a("s_mov_b32", self.s_k1, F(GELU_SIG[self.dtype][1]))
             a("s_mov_b32", self.s_k0, F(GELU_SIG[self.dtype][0]))
@@ -865,6 +884,11 @@ def variants():
                 out.append(dict(dtype=dt, stats=st, shape=shape))
             for shape in (1, 2):
                 out.append(dict(dtype=dt, stats=st, shape=shape, ln=True))
+    for st in (False, True):          # round 5: the bf16 kernels with the packed-f16 GELU and the f16 hidden (mlpk.h layout 3)
+        for shape in (0, 1, 2):
+            out.append(dict(dtype="bf16", stats=st, shape=shape, h2=True))
+        for shape in (1, 2):
+            out.append(dict(dtype="bf16", stats=st, shape=shape, ln=True, h2=True))
     for dbg in (1, 2, 4, 3, 16, 32, 48, 52):
         out.append(dict(dtype="bf16", stats=True, dbg=dbg, name="t4_bf16_st_dbg%d" % dbg))
     return out
@@ -890,11 +914,12 @@ def emit(path):
             raise RuntimeError("%s: %d hazard lint findings, first: %s" % (g.name, len(pr), pr[0]))
         out.append(kernel_text(g))
         table.append((g.name, kw))
-    out.append("namespace mlpk {\nstruct T4Variant { const char* name; const void* fn; int dtype, stats, dbg, shape, ln; };\n"
+    out.append("namespace mlpk {\nstruct T4Variant { const char* name; const void* fn; int dtype, stats, dbg, shape, ln, h2; };\n"
                "static const T4Variant kT4Variants[] = {\n")
     for name, kw in table:
-        out.append("    {\"%s\", reinterpret_cast<const void*>(&%s), %s, %d, %d, %d, %d},\n" %
-                   (name, name, "MLPK_BF16" if kw["dtype"] == "bf16" else "MLPK_F16", kw["stats"], kw.get("dbg", 0), kw.get("shape", 0), kw.get("ln", False)))
+        out.append("    {\"%s\", reinterpret_cast<const void*>(&%s), %s, %d, %d, %d, %d, %d},\n" %
+                   (name, name, "MLPK_BF16" if kw["dtype"] == "bf16" else "MLPK_F16", kw["stats"], kw.get("dbg", 0), kw.get("shape", 0), kw.get("ln", False),
+                    kw.get("h2", False)))
     out.append("};\n}  // namespace mlpk\n")
     text = "".join(out)
     if not os.path.exists(path) or open(path).read() != text:

@@ -1127,7 +1127,11 @@ extern "C" int mlpk_token_mlp_layout(int S, int nchunks) {
 extern "C" int mlpk_token_mlp_layout_for(int dtype, int S, int nchunks, int t_rows) {
     const char* e = getenv("MLPK_TOKEN_MLP_LAYOUT");
     if (e && (e[0] == '0' || e[0] == '1')) return mlpk_token_mlp_layout(S, nchunks);
-    if (t4_supported(dtype, S, nchunks, ((S + 31) / 32) * 32, t_rows, t_rows, t_rows)) return 2;
+    if (t4_supported(dtype, S, nchunks, ((S + 31) / 32) * 32, t_rows, t_rows, t_rows)) {
+        // 3 = layout 2 with the hidden kept in f16 (bf16 storage only; MLPK_T4_H2=0 keeps the all-bf16 kernels: A/B aid)
+        const char* h = getenv("MLPK_T4_H2");
+        return (dtype == MLPK_BF16 && !(h && h[0] == '0')) ? 3 : 2;
+    }
     return mlpk_token_mlp_layout(S, nchunks);
 }
 
@@ -1137,8 +1141,8 @@ extern "C" int mlpk_token_mlp(int dtype, const void* xt, int ldxt, int M, int S,
     if (!xt || !w1 || !w2 || !b1 || !b2 || !x) return MLPK_ENULL;
     if (dtype != MLPK_F16 && dtype != MLPK_BF16) return MLPK_EDTYPE;   // 16-bit storage only (fp32 uses the two-GEMM path)
     if (M <= 0 || S <= 0 || nchunks <= 0 || t_rows <= 0) return MLPK_ESHAPE;
-    if (layout != 0 && layout != 1 && layout != 2) return MLPK_EMODE;
-    if (layout == 2) {
+    if (layout < 0 || layout > 3 || (layout == 3 && dtype != MLPK_BF16)) return MLPK_EMODE;
+    if (layout == 2 || layout == 3) {
         // generated kernel: W2 group-major ((nchunks + 1) * 224 rows of 32 k slots), b1 / b2 as padded tables (mlpk.h)
         if (ldw1 != 256 || ldw2 != 32) return MLPK_ESHAPE;
         if (!t4_supported(dtype, S, nchunks, ldxt, M, t_rows, ldx)) return MLPK_ESHAPE;
@@ -1150,6 +1154,7 @@ extern "C" int mlpk_token_mlp(int dtype, const void* xt, int ldxt, int M, int S,
         c.ln_mean = c.ln_rstd = c.gamma = c.beta = nullptr;
         const char* d = getenv("MLPK_T4_DBG");
         c.dbg = d ? atoi(d) : 0;
+        c.h2 = layout == 3;
         return t4_launch(c, reinterpret_cast<hipStream_t>(stream));
     }
     if (S > 16 * (TM_NB0 + TM_NB1) || nchunks * 32 > TM_B1_FLOATS) return MLPK_ESHAPE;  // up to 224 tokens, 1024 hidden
@@ -1206,12 +1211,13 @@ extern "C" int mlpk_token_mlp(int dtype, const void* xt, int ldxt, int M, int S,
 }
 
 // The token-mixing PreNormResidual of MLP-Mixer in ONE kernel (mlp_mixer.py:34 with :6-13, :16-27): the LayerNorm + per-image transpose
-// is the generated kernel's operand loader (no xt tensor).  Weights packed for layout 2.
+// is the generated kernel's operand loader (no xt tensor).  Weights packed for layout 2 or 3 (`layout`: what mlpk_token_mlp_layout_for answered).
 extern "C" int mlpk_token_mlp_ln(int dtype, void* x, int ldx, int M, int S, const float* ln_mean, const float* ln_rstd, const float* gamma,
                                  const float* beta, const void* w1, int ldw1, const float* b1, const void* w2, int ldw2, const float* b2,
-                                 int nchunks, int t_rows, float* stats, void* stream) {
+                                 int nchunks, int t_rows, float* stats, int layout, void* stream) {
     if (!x || !ln_mean || !ln_rstd || !gamma || !beta || !w1 || !w2 || !b1 || !b2) return MLPK_ENULL;
     if (dtype != MLPK_F16 && dtype != MLPK_BF16) return MLPK_EDTYPE;
+    if ((layout != 2 && layout != 3) || (layout == 3 && dtype != MLPK_BF16)) return MLPK_EMODE;
     if (ldw1 != 256 || ldw2 != 32 || nchunks < 2) return MLPK_ESHAPE;
     if (!t4_supported(dtype, S, nchunks, 224, M, t_rows, ldx)) return MLPK_ESHAPE;
     if (stats && ((uintptr_t)stats & 7)) return MLPK_ESHAPE;
@@ -1223,6 +1229,7 @@ extern "C" int mlpk_token_mlp_ln(int dtype, void* x, int ldx, int M, int S, cons
     c.xt = nullptr; c.w1 = w1; c.w2 = w2; c.b1 = b1; c.b2 = b2; c.x = x; c.stats = stats; c.prof = g_tm_dbg;
     c.ln_mean = ln_mean; c.ln_rstd = ln_rstd; c.gamma = gamma; c.beta = beta;
     c.dbg = 0;
+    c.h2 = layout == 3;
     return t4_launch(c, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -10,7 +10,7 @@ struct T4Call {
     int ldxt, ldx, t_rows;
     const void* xt;            // (M, 224) token-transposed LayerNorm output, columns >= S zero
     const void* w1;            // (G*32, 256) zero-padded
-    const void* w2;            // ((G+1)*224, 32): group-major, k slots permuted (mlpk.h layout 2), group G and token rows >= S zero
+    const void* w2;            // ((G+1)*224, 32): group-major, k slots permuted (mlpk.h layout 2 / 3), group G and token rows >= S zero
     const float* b1;           // 1024: entry 64 + t = bias of hidden t, zeros elsewhere
     const float* b2;           // 224: zeros behind S
     void* x;                   // (B*S, ldx) residual stream, updated in place
@@ -22,6 +22,7 @@ struct T4Call {
     const float* beta;
     void* prof;                // tuning: shader cycles per workgroup (8 bytes each), or null
     int dbg;                   // tuning ablations (wrong results by construction)
+    int h2;                    // bf16 only (mlpk.h layout 3): GELU in packed f16, the hidden kept in f16, w2 holds f16 values
 };
 
 bool t4_supported(int dtype, int S, int G, int ldxt, int M, int t_rows, int ldx);

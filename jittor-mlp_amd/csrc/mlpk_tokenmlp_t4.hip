@@ -1,8 +1,10 @@
 // "t4" fused token-mixing MLP: 4 waves per workgroup = one per SIMD, a wave owns 64 rows of xt for all 196 tokens and runs both
-// products and the GELU between them in one instruction stream (the GELU of group g-1 as packed-fp32 fillers behind the MFMAs of
+// products and the GELU between them in one instruction stream (the GELU of group g-1 as fillers behind the MFMAs of
 // fc2(g-2) and fc1(g)); the hidden never leaves the registers.  The kernels are GENERATED (csrc/gen/t4gen.py -> t4_kernels.inc,
 // emulated on the CPU by csrc/gen/t4emu.py); this file is the host side.  Numerics contract of token_mlp_rr_kernel: fp32
 // accumulation, gelu16_f's operation sequence, the hidden rounded once to the storage type, one rounding after the residual add.
+// Round 5, bf16 storage ("h2" kernels, mlpk.h layout 3): the GELU runs in packed f16 (q4gen.GELU_H2) and the hidden STAYS f16 -- 11 bits instead of
+// bf16's 8 -- so W2 arrives as f16 values and the second product is the f16 MFMA; x, W1 and the first product are bf16 as before.
 #include "mlpk_common.h"
 #include "mlpk_tokenmlp_t4.h"
 #include <cstdlib>
@@ -62,10 +64,11 @@ int t4_launch(const T4Call& c, hipStream_t stream) {
     const char* es = getenv("MLPK_T4_SHAPE");
     if (c.dbg || (es && es[0] == '0')) shape = 0;
     const int ln = c.ln_mean != nullptr;
+    if (c.h2 && (c.dtype != MLPK_BF16 || c.dbg)) return MLPK_EMODE;
     if (ln && (!shape || !c.ln_rstd || !c.gamma || !c.beta)) return MLPK_ESHAPE;
     const T4Variant* v = nullptr;
     for (const T4Variant& k : kT4Variants)
-        if (k.dtype == c.dtype && k.stats == (c.stats != nullptr) && k.dbg == c.dbg && k.shape == shape && k.ln == ln) { v = &k; break; }
+        if (k.dtype == c.dtype && k.stats == (c.stats != nullptr) && k.dbg == c.dbg && k.shape == shape && k.ln == ln && k.h2 == c.h2) { v = &k; break; }
     if (!v) return MLPK_ESHAPE;
     T4Args a;
     a.xt = c.xt; a.w1 = c.w1; a.w2 = c.w2; a.b1 = c.b1; a.b2 = c.b2; a.x = c.x; a.stats = c.stats; a.prof = c.prof;

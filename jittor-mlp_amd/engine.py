@@ -229,10 +229,10 @@ def token_mlp(xt, ldxt, M, S, w1, b1, w2, b2, nchunks, x, ldx, t_rows, stats=Non
                                    w2.stride(0), ptr(b2), nchunks, ptr(x), ldx, t_rows, ptr(stats), layout, stream()), "mlpk_token_mlp")
 
 
-def token_mlp_ln(x, ldx, M, S, mean, rstd, gamma, beta, w1, b1, w2, b2, nchunks, t_rows, stats=None):
-    """LayerNorm + token-mixing MLP + residual in one kernel (weights packed for layout 2); x (B*S, ldx) is updated in place."""
+def token_mlp_ln(x, ldx, M, S, mean, rstd, gamma, beta, w1, b1, w2, b2, nchunks, t_rows, stats=None, layout=2):
+    """LayerNorm + token-mixing MLP + residual in one kernel (weights packed for layout 2 / 3); x (B*S, ldx) is updated in place."""
     N.check(N.lib().mlpk_token_mlp_ln(dtype_code(x.dtype), ptr(x), ldx, M, S, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(w1), w1.stride(0), ptr(b1),
-                                      ptr(w2), w2.stride(0), ptr(b2), nchunks, t_rows, ptr(stats), stream()), "mlpk_token_mlp_ln")
+                                      ptr(w2), w2.stride(0), ptr(b2), nchunks, t_rows, ptr(stats), layout, stream()), "mlpk_token_mlp_ln")
 
 
 def token_ln_fused():
@@ -304,7 +304,7 @@ def token_gemm_ln(x, ldx, M, S, mean, rstd, gamma, beta, wp, bp, ng, out, ldo, t
 
 def token_mlp_stat_planes(C, layout):
     """planes of mlpk_token_mlp's `stats` buffer: one per 128 channels, one per 64 for the generated kernel (layout 2)"""
-    return C // 64 if layout == 2 else C // 128
+    return C // 64 if layout in (2, 3) else C // 128
 
 
 def pack_token_mlp(w1, b1, w2, b2, dtype, device, sp, layout=None, t_rows=None):
@@ -324,13 +324,19 @@ def pack_token_mlp(w1, b1, w2, b2, dtype, device, sp, layout=None, t_rows=None):
     w2p[:, :T] = w2.to(device=device, dtype=dtype)
     if layout is None:
         layout = N.lib().mlpk_token_mlp_layout_for(dtype_code(dtype), S, nch, t_rows) if t_rows else N.lib().mlpk_token_mlp_layout(S, nch)
-    if layout == 2:
+    if layout in (2, 3):
         # include/mlpk.h: W2 group-major -- (nch + 1) groups x 224 token rows x 32 k slots, slot 16 kk + 8 h + e of a group <- hidden
         # 16 kk + 8 (e >> 2) + 4 h + (e & 3); group nch and the token rows behind S are zeros; b1 / b2 as padded tables
         slot = torch.arange(32)
         kk, hh, e = slot // 16, (slot // 8) % 2, slot % 8
         src = (16 * kk + 8 * (e // 4) + 4 * hh + (e % 4)).to(device)
-        w2g = torch.zeros((nch + 1, 224, 32), dtype=dtype, device=device)
+        # layout 3 (bf16 storage): the kernel keeps the hidden in f16 and multiplies it by f16 weights -- W2 rounded from fp32 to f16 HERE
+        w2dt = torch.float16 if layout == 3 else dtype
+        if layout == 3:
+            assert dtype == torch.bfloat16
+            w2p = torch.zeros((S, nch * ch), dtype=w2dt, device=device)
+            w2p[:, :T] = w2.to(device=device, dtype=w2dt)
+        w2g = torch.zeros((nch + 1, 224, 32), dtype=w2dt, device=device)
         w2g[:nch, :S] = w2p.view(S, nch, 32)[:, :, src].permute(1, 0, 2)
         b1t = torch.zeros((1024,), dtype=torch.float32, device=device)
         b1t[64:64 + nch * ch] = b1p

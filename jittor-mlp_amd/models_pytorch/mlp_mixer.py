@@ -177,14 +177,14 @@ class MLPMixer(E.EngineModule):
         for i in range(depth):
             p = "b%d." % i
             fused = pk.get(p + "tok.fused")
-            if (fused is not None and fused[5] == 2 and fused[4] >= 2 and E.token_ln_fused() and C % 128 == 0
+            if (fused is not None and fused[5] in (2, 3) and fused[4] >= 2 and E.token_ln_fused() and C % 128 == 0
                     and (p + "ch.fc1.csum") in pk and E.epilogue_stats()):
                 # the whole token-mixing PreNormResidual in ONE kernel: the LayerNorm + transpose is the token kernel's operand loader
                 # (no xt tensor, x read once); its row statistics come out of the previous block's fc2 epilogue (first block: one pass)
                 w1f, b1f, w2f, b2f, nch, lay = fused
                 mean, rstd = nxt if nxt is not None else layernorm_stats(ws, x, rows, C, tag="tok.ln1")
                 part = ws.get("tok.stats", (E.token_mlp_stat_planes(C, lay), rows, 2), torch.float32)
-                E.token_mlp_ln(x, C, B * C, S, mean, rstd, pk[p + "tok.ln.g"], pk[p + "tok.ln.b"], w1f, b1f, w2f, b2f, nch, C, stats=part)
+                E.token_mlp_ln(x, C, B * C, S, mean, rstd, pk[p + "tok.ln.g"], pk[p + "tok.ln.b"], w1f, b1f, w2f, b2f, nch, C, stats=part, layout=lay)
                 stats = (ws.get("cm.ln.mean", (rows,), torch.float32), ws.get("cm.ln.rstd", (rows,), torch.float32))
                 E.stats_finalize_planar(part, rows, C, stats[0], stats[1])
                 got = channel_mlp(ws, x, rows, C, pk, p + "ch.", C * ef, stats=stats, part=(ws, "tok.lnpart") if i + 1 < depth else None)

@@ -724,11 +724,14 @@ def test_gemm_two_tile_heights_in_one_launch():
 def test_fused_token_mlp_generated_kernel(dtype):
     """layout 2 of mlpk_token_mlp (the generated one-wave-per-SIMD kernel, csrc/gen/t4gen.py): against the fp64 restatement of
     mlp_mixer.py:16-27, bit-equal to layout 1 in x (same operation sequence), statistics over 64-channel planes; several tiles
-    per workgroup (more tiles than CUs), odd and even group counts, a ragged hidden size; shapes it does not take are refused."""
+    per workgroup (more tiles than CUs), odd and even group counts, a ragged hidden size; shapes it does not take are refused.
+    bf16 (round 5): the library answers layout 3 -- the same kernel with the GELU in packed f16 and the hidden KEPT in f16 (W2 packed as f16) --
+    held to the fp64 restatement with the hidden and W2 rounded to f16, at HALF the tolerance; the all-bf16 layout 2 stays selectable and is run too."""
     pkg = load_pkg()
     E, N = pkg.engine, pkg._native
     S, sp = 196, 224
-    for ci, (B_, C, T) in enumerate([(1, 256, 784), (3, 512, 512), (2, 768, 100), (5, 256, 64), (300, 256, 96)]):
+    cases = [(1, 256, 784), (3, 512, 512), (2, 768, 100), (5, 256, 64), (300, 256, 96)]
+    for ci, (B_, C, T, want) in enumerate([c + (None,) for c in cases] + ([c + (2,) for c in cases[:3]] if dtype == torch.bfloat16 else [])):
         xn = rnd((B_, S, C), dtype, 900 + ci)
         x = rnd((B_ * S, C), dtype, 910 + ci).to(dev())
         w1 = rnd((T, S), torch.float32, 920 + ci, 1.0 / math.sqrt(S))
@@ -737,8 +740,10 @@ def test_fused_token_mlp_generated_kernel(dtype):
         b2 = rnd((S,), torch.float32, 950 + ci)
         xt = torch.zeros((B_ * C, sp), dtype=dtype, device=dev())
         xt[:, :S] = xn.permute(0, 2, 1).reshape(B_ * C, S).to(dev())
-        w1p, b1p, w2p, b2p, nch, lay = E.pack_token_mlp(w1, b1, w2, b2, dtype, dev(), sp, t_rows=C)
-        assert lay == 2, "the generated kernel must take S = 196 with whole 256-channel tiles"
+        w1p, b1p, w2p, b2p, nch, lay = E.pack_token_mlp(w1, b1, w2, b2, dtype, dev(), sp, t_rows=C, layout=want)
+        assert lay == (want or (3 if dtype == torch.bfloat16 else 2)), "the generated kernel must take S = 196 with whole 256-channel tiles"
+        assert w2p.dtype == (torch.float16 if lay == 3 else dtype)
+        hdt = torch.float16 if lay == 3 else dtype                 # storage type of the hidden and of W2
         x0 = x.clone()
         part = torch.full((E.token_mlp_stat_planes(C, lay), B_ * S, 2), float("nan"), dtype=torch.float32, device=dev())
         E.token_mlp(xt, sp, B_ * C, S, w1p, b1p, w2p, b2p, nch, x, C, C, stats=part, layout=lay)
@@ -762,27 +767,35 @@ def test_fused_token_mlp_generated_kernel(dtype):
         assert torch.equal(x, x_nostats) and not torch.isnan(part).any()
         assert torch.equal(x, x_generic)
         if B_ <= 8:
-            w1r, w2r = w1.to(dtype).double(), w2.to(dtype).double()
-            h = oracle.gelu(torch.einsum("ts,bsc->btc", w1r, xn.double()) + b1.double().view(1, -1, 1)).to(dtype).double()
+            w1r, w2r = w1.to(dtype).double(), w2.to(hdt).double()
+            h = oracle.gelu(torch.einsum("ts,bsc->btc", w1r, xn.double()) + b1.double().view(1, -1, 1)).to(hdt).double()
             ref = x0.cpu().double().reshape(B_, S, C) + torch.einsum("st,btc->bsc", w2r, h) + b2.double().view(1, -1, 1)
             got = x.cpu().double().reshape(B_, S, C)
             assert torch.isfinite(got).all()
             err = (got - ref).abs().max().item()
-            assert err < EPS[dtype] * 6 * max(1.0, ref.abs().max().item()), (str(dtype), ci, err)
-        # the same operation sequence as the 256-row kernel: differences only where fp32 sums were formed in another order
+            print("t4 layout %d %s case %d: max err vs fp64 %.3e (max|ref| %.2f)" % (lay, str(dtype)[6:], ci, err, ref.abs().max().item()))
+            assert err < EPS[dtype] * (1.5 if lay == 3 else 6) * max(1.0, ref.abs().max().item()), (str(dtype), ci, lay, err)
         d = (x.float() - x1.float()).abs()
-        assert d.max().item() <= EPS[dtype] * 2 * max(1.0, x1.float().abs().max().item()), (str(dtype), ci, d.max().item())
-        assert (d > 0).float().mean().item() < 0.02, (str(dtype), ci, (d > 0).float().mean().item())
+        if lay == 3:
+            # against the all-bf16 256-row kernel: one noise level apart (its hidden and W2 carry 8 bits)
+            assert d.max().item() <= EPS[dtype] * 6 * max(1.0, x1.float().abs().max().item()), (str(dtype), ci, d.max().item())
+        else:
+            # the same operation sequence as the 256-row kernel: differences only where fp32 sums were formed in another order
+            assert d.max().item() <= EPS[dtype] * 2 * max(1.0, x1.float().abs().max().item()), (str(dtype), ci, d.max().item())
+            assert (d > 0).float().mean().item() < 0.02, (str(dtype), ci, (d > 0).float().mean().item())
         xd = x.cpu().double()
         mu = xd.mean(1)
         rs = 1.0 / torch.sqrt(xd.var(1, unbiased=False) + 1e-5)
         assert (mean.cpu().double() - mu).abs().max().item() < 2e-6 * max(1.0, xd.abs().max().item())
         assert ((rstd.cpu().double() - rs).abs() / rs).max().item() < 2e-5
     # not whole 256-channel tiles / another token count: refused, never mis-tiled
-    assert N.lib().mlpk_token_mlp_layout_for(E.dtype_code(dtype), 196, 25, 384) != 2
-    assert N.lib().mlpk_token_mlp_layout_for(E.dtype_code(dtype), 49, 7, 512) != 2
+    assert N.lib().mlpk_token_mlp_layout_for(E.dtype_code(dtype), 196, 25, 384) not in (2, 3)
+    assert N.lib().mlpk_token_mlp_layout_for(E.dtype_code(dtype), 49, 7, 512) not in (2, 3)
     with pytest.raises(RuntimeError):
-        E.token_mlp(xt, sp, B_ * C, S, w1p, b1p, w2p, b2p, nch, x, C, C - 128, layout=2)
+        E.token_mlp(xt, sp, B_ * C, S, w1p, b1p, w2p, b2p, nch, x, C, C - 128, layout=lay)
+    if dtype == torch.float16:
+        with pytest.raises(RuntimeError):                           # the f16-hidden form exists for bf16 storage only
+            E.token_mlp(xt, sp, B_ * C, S, w1p, b1p, w2p, b2p, nch, x, C, C, layout=3)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -803,13 +816,14 @@ def test_token_mixing_prenorm_residual_in_one_kernel(dtype):
         w2 = rnd((S, T), torch.float32, 1550 + ci, 1.0 / math.sqrt(T))
         b2 = rnd((S,), torch.float32, 1560 + ci)
         w1p, b1p, w2p, b2p, nch, lay = E.pack_token_mlp(w1, b1, w2, b2, dtype, dev(), sp, t_rows=C)
-        assert lay == 2
+        assert lay == (3 if dtype == torch.bfloat16 else 2)
+        hdt = torch.float16 if lay == 3 else dtype
         mean = torch.empty(B_ * S, dtype=torch.float32, device=dev())
         rstd = torch.empty_like(mean)
         E.row_stats(x, B_ * S, C, C, mean, rstd)
         x0 = x.clone()
         part = torch.full((E.token_mlp_stat_planes(C, lay), B_ * S, 2), float("nan"), dtype=torch.float32, device=dev())
-        E.token_mlp_ln(x, C, B_ * C, S, mean, rstd, g.to(dev()), be.to(dev()), w1p, b1p, w2p, b2p, nch, C, stats=part)
+        E.token_mlp_ln(x, C, B_ * C, S, mean, rstd, g.to(dev()), be.to(dev()), w1p, b1p, w2p, b2p, nch, C, stats=part, layout=lay)
         # the two-kernel path on the same input
         xt = torch.zeros((B_ * C, sp), dtype=dtype, device=dev())
         E.layernorm_transpose(x0, B_, S, C, g.to(dev()), be.to(dev()), xt, sp)
@@ -825,11 +839,12 @@ def test_token_mixing_prenorm_residual_in_one_kernel(dtype):
         assert (d > 0).float().mean().item() < 0.05, (str(dtype), ci, (d > 0).float().mean().item())
         if B_ <= 8:
             xn = oracle.layer_norm(x0.cpu().double().reshape(B_, S, C), g.double(), be.double()).to(dtype).double()      # (B, S, C), rounded as the operand is
-            w1r, w2r = w1.to(dtype).double(), w2.to(dtype).double()
-            h = oracle.gelu(torch.einsum("ts,bsc->btc", w1r, xn) + b1.double().view(1, -1, 1)).to(dtype).double()
+            w1r, w2r = w1.to(dtype).double(), w2.to(hdt).double()
+            h = oracle.gelu(torch.einsum("ts,bsc->btc", w1r, xn) + b1.double().view(1, -1, 1)).to(hdt).double()
             ref = x0.cpu().double().reshape(B_, S, C) + torch.einsum("st,btc->bsc", w2r, h) + b2.double().view(1, -1, 1)
             err = (x.cpu().double().reshape(B_, S, C) - ref).abs().max().item()
-            assert err < EPS[dtype] * 6 * max(1.0, ref.abs().max().item()), (str(dtype), ci, err)
+            print("t4 ln layout %d %s case %d: max err vs fp64 %.3e (max|ref| %.2f)" % (lay, str(dtype)[6:], ci, err, ref.abs().max().item()))
+            assert err < EPS[dtype] * (1.5 if lay == 3 else 6) * max(1.0, ref.abs().max().item()), (str(dtype), ci, err)
         xd = x.cpu().double()
         mu = xd.mean(1)
         rs = 1.0 / torch.sqrt(xd.var(1, unbiased=False) + 1e-5)
@@ -837,7 +852,7 @@ def test_token_mixing_prenorm_residual_in_one_kernel(dtype):
         assert ((r2.cpu().double() - rs).abs() / rs).max().item() < 2e-5
     with pytest.raises(RuntimeError):                               # one hidden group: the kernel without fill / drain shaping has no LayerNorm loader
         p1 = E.pack_token_mlp(w1[:32], b1[:32], w2[:, :32], b2, dtype, dev(), sp, t_rows=C)
-        E.token_mlp_ln(x, C, B_ * C, S, mean, rstd, g.to(dev()), be.to(dev()), p1[0], p1[1], p1[2], p1[3], p1[4], C)
+        E.token_mlp_ln(x, C, B_ * C, S, mean, rstd, g.to(dev()), be.to(dev()), p1[0], p1[1], p1[2], p1[3], p1[4], C, layout=p1[5])
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])

@@ -31,7 +31,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libmlpk.so does not export %s" % name
         assert name in pkg._native.PROTOTYPES, "no ctypes prototype for %s" % name
-    assert lib.mlpk_abi_version() == 8
+    assert lib.mlpk_abi_version() == 9
     assert lib.mlpk_gemm_algo_count() >= 4
     bm, bn, th, lds = (ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int())
     assert lib.mlpk_gemm_algo_info(1, bm, bn, th, lds) == 0
@@ -199,6 +199,34 @@ def test_hand_scheduled_gemm_loops_have_no_compiler_vmem_waits():
     assert lint.lint(asm, "gemm_nt_p8_pair_kernel", every_loop=True) == 0          # both heights' loops of the two-height launch
     # the fused token-mixing kernels: same rule for their iteration loops (one hand-counted vmcnt wait, no scratch)
     assert lint.lint_token(os.path.join(builder.OBJ, "mlpk_tokenmlp-hip-amdgcn-amd-amdhsa-gfx950.s")) == 0
+
+
+def test_packed_f16_gelu_of_the_token_kernel():
+    """Round 5: the fused token-mixing kernel's bf16 grade evaluates the GELU in PACKED f16 (q4gen.GELU_H2 / h2_gelu_ops; fit: tools/fit_gelu_h2.py)
+    and keeps the result in f16 as the second product's operand.  The restatement of that operation sequence (t4emu.h2_gelu_ref, the one
+    tests/test_t4_emulated.py holds the emulated kernel to) against the exact erf form (mlp_mixer.py:21 nn.GELU), over EVERY finite f16 input
+    and a dense fp32 grid -- the gate the round-4 review set: |err| <= 2^-9 |x| on |x| >= 0.25 (half an ulp of bf16, the type the hidden used to
+    be rounded to) and <= 2.5e-4 absolute below (the review's 2e-4 + the toward-zero conversion that keeps the tails finite); the tails are exact limits: x beyond the f16 range saturates at +-65504 instead of becoming
+    inf * 0; gelu(-big) = -0."""
+    import numpy as np
+    from scipy.special import erf
+    sys.path.insert(0, os.path.join(ROOT, "jittor-mlp_amd", "csrc", "gen"))
+    import q4gen
+    import t4emu
+    assert len(q4gen.GELU_H2["coefs"]) == 7 and q4gen.GELU_H2["coefs"][0] > 0          # odd count: the run-off direction the clamp relies on
+    for v in q4gen.GELU_H2["coefs"] + [q4gen.GELU_H2["scale"]]:
+        assert float(np.float16(v)) == v, "every constant must be exact in f16"
+    allh = np.arange(65536, dtype=np.uint16).view(np.float16)
+    x = np.concatenate([allh[np.isfinite(allh)].astype(np.float32), np.linspace(-12, 12, 400001).astype(np.float32)])
+    got = t4emu.h2_gelu_ref(x)
+    assert np.isfinite(got).all()
+    ref = x.astype(np.float64) * 0.5 * (1.0 + erf(x.astype(np.float64) / np.sqrt(2.0)))
+    err, ax = np.abs(got - ref), np.abs(x.astype(np.float64))
+    big = ax >= 0.25
+    assert (err[big] / ax[big]).max() <= 2.0 ** -9, (err[big] / ax[big]).max()
+    assert err[~big].max() <= 2.5e-4, err[~big].max()          # (2.3e-4: the toward-zero conversion of x costs up to one f16 spacing, 1.2e-4 there)
+    tails = t4emu.h2_gelu_ref(np.array([1e6, -1e6, 70000.0, -70000.0, 3e38, -3e38], np.float32))      # every FINITE fp32 input has a finite result
+    assert np.array_equal(np.abs(tails), [65504.0, 0.0, 65504.0, 0.0, 65504.0, 0.0]) and np.signbit(tails[[1, 3, 5]]).all()
 
 
 def test_division_free_gelu_coefficients():
