@@ -261,20 +261,28 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        # HIP events around the channel-MLP GEMM launches INSIDE the timed region, on every `every`-th step (all of them
-        # for short runs): 48 event pairs per timed step, not 48 x steps of them in a 100-step run
-        timer = None if args.no_kernel_timing else E.KernelTimer()
-        every = max(1, args.steps // 10)
+        E.TIMER = None
         t0 = time.perf_counter()
         for it in range(args.steps):
-            E.TIMER = timer if it % every == 0 else None
             out = runner(x)
-        E.TIMER = None
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         t1 = time.perf_counter()
-        E.TIMER = None
+        # Per-kernel durations for `roofline`: HIP events around the channel-MLP GEMM launches (on the stream they are launched on) in a
+        # SEPARATE short pass straight after the timed region -- same process, same resident batch, the chip at the same temperature --
+        # so that the headline loop carries no event records at all (round-4 review: 24 pairs per step sat inside it)
+        timer = None if args.no_kernel_timing else E.KernelTimer()
+        timing_steps = 0
+        if timer is not None:
+            timing_steps = max(2, min(args.steps, 6))
+            E.TIMER = timer
+            for it in range(timing_steps):
+                out = runner(x)
+            E.TIMER = None
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
     elapsed = t1 - t0
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -310,7 +318,8 @@ def main():
                 line["roofline"] = {"bound": "mfma", "kernel": names, "achieved": round(ach, 1),
                                     "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                                     "flops_per_launch": flops / n_launch, "avg_launch_ms": round(secs / n_launch * 1e3, 4),
-                                    "launches_timed": n_launch, "traffic_source": traffic_src,
+                                    "launches_timed": n_launch, "timed_in": "%d extra steps straight after the %d timed ones (no event records inside the headline loop)" % (timing_steps, args.steps),
+                                    "traffic_source": traffic_src,
                                     # "traffic" is NOT measured in this run: it is the PMC result of tools/pmc_bench.sh on this command,
                                     # read from profiles/ and dropped (null) when the GEMM sources changed since it was taken
                                     "traffic_measured_in_run": False,

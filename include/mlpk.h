@@ -111,6 +111,7 @@ const char* mlpk_strerror(int code);
 #define MLPK_RES_NONE 0
 #define MLPK_RES_ADD 1
 #define MLPK_RES_MUL 2
+#define MLPK_RES_ADD_AFFINE 3   /* mlpk_token_gemm_ln only (ABI 9): out = round(gamma x + beta) + rscale * (...): the residual is the affine output, rebuilt in the kernel */
 #define MLPK_OUT_ROWMAJOR 0
 #define MLPK_OUT_TOKEN_T 1
 
@@ -230,9 +231,10 @@ int mlpk_token_gemm(int dtype, const void* xt, int ldxt, int M, int S, const voi
  * rstd NULL (0 / 1), ResMLP's Aff (res_mlp.py:17-19) -- read straight from the token-major x (B*S rows of stride ldx; the pointer
  * addresses channel 0 of the t_rows channels, so a column slice of a wider tensor is fine) and transposed through LDS inside the
  * kernel: no xt tensor, no normalise-and-transpose pass.  t_rows % 32 == 0, S <= 224; everything else as mlpk_token_gemm.
- * With res_mode ADD, no statistics and R == x the residual is the affine output itself, R = round(gamma x + beta) rebuilt in the kernel
- * (res_mlp.py:53-55 adds the cross-patch product onto the POST-affine tensor); out may be x (every element is read by the workgroup that
- * writes it, before it is written). */
+ * res_mode MLPK_RES_ADD_AFFINE (ABI 9; no statistics, R NULL or == x): the residual is the affine output itself, round(gamma x + beta) rebuilt
+ * in the kernel (res_mlp.py:53-55 adds the cross-patch product onto the POST-affine tensor); out may be x (every element is read by the
+ * workgroup that writes it, before it is written).  Plain MLPK_RES_ADD adds R as stored and refuses R == x (MLPK_EMODE): until ABI 8 that
+ * aliasing silently selected the affine residual. */
 int mlpk_token_gemm_ln(int dtype, const void* x, int ldx, int M, int S, const float* ln_mean, const float* ln_rstd, const float* gamma,
                        const float* beta, const void* w, int ldw, const float* bias, int ngroups, const float* rscale, int rperiod,
                        const void* R, int ldr, int res_mode, void* out, int ldo, int t_rows, void* stream);

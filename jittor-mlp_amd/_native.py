@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("MLPK_LIB_PATH") or os.path.join(_HERE, "lib", "libmlp
 
 F32, F16, BF16 = 0, 1, 2
 ACT_NONE, ACT_GELU = 0, 1
-RES_NONE, RES_ADD, RES_MUL = 0, 1, 2
+RES_NONE, RES_ADD, RES_MUL, RES_ADD_AFFINE = 0, 1, 2, 3
 OUT_ROWMAJOR, OUT_TOKEN_T = 0, 1
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
 SHIFT_NONE, SHIFT_S2, SHIFT_S2_REF = 0, 1, 2

@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(NW * 64) dwconv_mfma_kernel(const T* __restric
     constexpr int CLDS = CPW - CREG;                                // channels of a wave whose fragments live in the LDS
     constexpr int PLANES_END = dwm_plane_off(CG) + DWM_PLANE;       // planes + the zero plane; the fragment tables follow
     constexpr int TBL_WAVE = CLDS * KS * DWM_NPAT * 16;
-    static_assert(CG % 8 == 0 && (512 * CH8) % NT == 0 && CREG >= 0 && CREG <= CPW, "workgroup geometry");
+    static_assert(CG % 8 == 0 && (512 * CH8) % NT == 0 && CREG >= 1 && CREG <= CPW, "workgroup geometry");
     static_assert(KS * KS * CG * 4 <= PLANES_END, "tap staging fits the planes");
     int gx = blockIdx.x, gy = blockIdx.y;
 #if DWM_XCD

@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(MS_NT) mixshift_band_kernel(const MixShiftArgs
         // element, which is what this kernel spent its time on: 0.5-0.9 TB/s, profiles/r04_traffic_models.txt) ----
         {
             constexpr int VPP = MS_CT / EPV;                   // vectors per pixel
-            const bool vec = sizeof(T) == 2 && (p.C % EPV) == 0 && (c0 % EPV) == 0 && (nch % EPV) == 0;
+            const bool vec = sizeof(T) == 2 && (p.C % EPV) == 0 && (c0 % EPV) == 0 && (nch % EPV) == 0 && (reinterpret_cast<uintptr_t>(p.x) & 15) == 0;
             if (vec) {
                 const int total = rows_t * cols_t * VPP;
                 for (int i = tid; i < total; i += MS_NT) {

@@ -1287,9 +1287,16 @@ extern "C" int mlpk_token_gemm_ln(int dtype, const void* x, int ldx, int M, int 
     if ((ln_mean != nullptr) != (ln_rstd != nullptr)) return MLPK_ENULL;
     if (dtype != MLPK_F16 && dtype != MLPK_BF16) return MLPK_EDTYPE;
     if (M <= 0 || S <= 0 || ngroups <= 0 || t_rows <= 0) return MLPK_ESHAPE;
-    if (res_mode < MLPK_RES_NONE || res_mode > MLPK_RES_MUL) return MLPK_EMODE;
-    // R == x with res_mode ADD: the residual is the affine output itself, rebuilt in the kernel (no statistics: ResMLP's Aff)
-    const bool raff = res_mode == MLPK_RES_ADD && R == x && !ln_mean;
+    if (res_mode < MLPK_RES_NONE || res_mode > MLPK_RES_ADD_AFFINE) return MLPK_EMODE;
+    // ADD_AFFINE: the residual is the affine output itself, rebuilt in the kernel from x (no statistics: ResMLP's Aff); an explicit mode
+    // since ABI 9 -- plain ADD with R aliasing x is refused instead of silently meaning this (advisor, round 4)
+    const bool raff = res_mode == MLPK_RES_ADD_AFFINE;
+    if (raff) {
+        if (ln_mean || (R && R != x)) return MLPK_EMODE;
+        R = x; ldr = ldx; res_mode = MLPK_RES_ADD;
+    } else if (res_mode == MLPK_RES_ADD && R == x) {
+        return MLPK_EMODE;
+    }
     if (res_mode != MLPK_RES_NONE && !R) return MLPK_ENULL;
     if (rscale && rperiod <= 0) return MLPK_ESHAPE;
     if (ngroups * 32 < S || ngroups > 8 || S > 32 * TM_KMAX) return MLPK_ESHAPE;

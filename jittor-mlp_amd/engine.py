@@ -352,10 +352,15 @@ def pack_token_mlp(w1, b1, w2, b2, dtype, device, sp, layout=None, t_rows=None):
     return w1p, b1p, w2p, f32(b2, device), nch, layout
 
 
+def linear_gelu_enabled():
+    """the opt-in switch of mlpk_linear_gelu; the models build its second copy of every fc1 weight only when it is on (advisor, round 4)"""
+    return os.environ.get("MLPK_LINEAR_GELU", "0") == "1"
+
+
 def linear_gelu_supported(dtype, M, K, Nn):
     """mlpk_linear_gelu: a short-K Linear + GELU with its rows resident in registers.  OPT-IN (MLPK_LINEAR_GELU=1): measured slower than the
     GEMM tiles with a GELU epilogue on every model shape (profiles/r04_linear_gelu_ab.txt: gMLP-S 11.33 vs 10.22 ms, ViP-S7 30.39 vs 30.17)."""
-    return (dtype in (torch.float16, torch.bfloat16) and os.environ.get("MLPK_LINEAR_GELU", "0") == "1"
+    return (dtype in (torch.float16, torch.bfloat16) and linear_gelu_enabled()
             and bool(N.lib().mlpk_linear_gelu_supported(dtype_code(dtype), M, K, round_up(Nn, 32))))
 
 

@@ -164,7 +164,7 @@ def pack_channel_mlp(pk, prefix, norm, fc1, fc2, dtype, device):
     pk[prefix + "fc2.w"] = E.pack_matrix(fc2.weight, dtype, device)
     pk[prefix + "fc2.b"] = E.f32(fc2.bias, device)
     w1 = fc1.weight.reshape(fc1.weight.shape[0], -1)
-    if w1.shape[1] in (128, 192, 256, 384, 512) and w1.shape[0] % 32 == 0 and dtype in (torch.float16, torch.bfloat16):
+    if E.linear_gelu_enabled() and w1.shape[1] in (128, 192, 256, 384, 512) and w1.shape[0] % 32 == 0 and dtype in (torch.float16, torch.bfloat16):
         # short K: fc1 + GELU with its rows resident in registers (mlpk_linear_gelu) instead of a GEMM tile with a GELU epilogue
         pk[prefix + "fc1.rr"] = E.pack_linear_gelu(fc1.weight, fc1.bias, dtype, device, norm.weight, norm.bias)
     if E.channel_mlp_fused_supported(dtype, w1.shape[1], w1.shape[0]) and fc2.weight.reshape(fc2.weight.shape[0], -1).shape[0] == w1.shape[1]:

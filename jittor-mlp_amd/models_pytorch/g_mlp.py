@@ -85,7 +85,7 @@ class gMLP(E.EngineModule):
             pk[p + "p1.w"], pk[p + "p1.b"], pk[p + "p1.csum"] = E.pack_ln_folded(
                 blk.channel_proj1.weight, blk.channel_proj1.bias, blk.norm.weight, blk.norm.bias, dtype, device)
             w1 = blk.channel_proj1.weight
-            if w1.shape[1] in (128, 192, 256, 384, 512) and w1.shape[0] % 32 == 0 and dtype in (torch.float16, torch.bfloat16):
+            if E.linear_gelu_enabled() and w1.shape[1] in (128, 192, 256, 384, 512) and w1.shape[0] % 32 == 0 and dtype in (torch.float16, torch.bfloat16):
                 # round 4: channel_proj1 + GELU with its rows resident in registers (mlpk_linear_gelu), statistics planes included
                 pk[p + "p1.rr"] = E.pack_linear_gelu(w1, blk.channel_proj1.bias, dtype, device, blk.norm.weight, blk.norm.bias)
             pk[p + "p2.w"] = E.pack_matrix(blk.channel_proj2.weight, dtype, device)

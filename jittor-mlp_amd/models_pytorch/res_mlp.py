@@ -135,7 +135,7 @@ class ResMLP(E.EngineModule):
                 # builds x1 = alpha x + beta for its operand (transposed through LDS) and for the residual items, and writes
                 # x2 = x1 + gamma_1 (Wt x1 + bt) over x: no Aff pass, no x1 tensor, no token-transposed copy
                 E.token_gemm_ln(x, C, B * C, S, None, None, pk[p + "pre.a"], pk[p + "pre.b"], tg[0], tg[1], tg[2], x, C, C,
-                                R=x, ldr=C, res=N.RES_ADD, rscale=pk[p + "g1"], rperiod=C)
+                                R=x, ldr=C, res=N.RES_ADD_AFFINE, rscale=pk[p + "g1"], rperiod=C)
                 E.norm_apply(x, rows, C, C, gamma=pk[p + "post.a"], beta=pk[p + "post.b"], out_rm=x, ld_rm=C)
                 h = ws.get("h", (rows, hidden))
                 E.gemm(x, pk[p + "fc1.w"], h, rows, hidden, C, bias=pk[p + "fc1.b"], act=N.ACT_GELU)

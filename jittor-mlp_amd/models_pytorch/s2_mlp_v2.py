@@ -154,8 +154,26 @@ class S2Block(E.EngineModule):
             nxt = finalize_stats(ws, got, rows, C, tag=prefix + "ln")
         return x
 
+    shift_mode = "reference_inplace"          # SHIFT_MODES; the enclosing model's set_shift_mode keeps it in step
+
+    def _pack(self, dtype, device):
+        pk = {}
+        self._pack_blocks(pk, dtype, device, "s.")
+        return pk
+
     def forward(self, x):
-        raise NotImplementedError("S2Block holds one stage; call the enclosing S2MLPv2")
+        """One stage on its own, as in the reference (s2_mlp_v2.py:86-92): (B, C, H, W) in, the depth blocks on the channel-last view, (B, C, H, W) out.
+        The two permutes are the module's boundary (a torch copy each way); inside a model the stage works on the resident channel-last rows."""
+        cd = self._resolve(x)
+        B, C, H, W = x.shape
+        if C != self._dims[0]:
+            raise ValueError("this stage works on %d channels" % self._dims[0])
+        pk = self._get_pack(cd, x.device)
+        ws = self._get_space(B, cd, x.device)
+        buf = ws.get("stage.x", (B * H * W, C))
+        buf.view(B, H, W, C).copy_(x.permute(0, 2, 3, 1))
+        self._run_blocks(ws, pk, buf, B, H, W, "s.", SHIFT_MODES[self.shift_mode])
+        return buf.view(B, H, W, C).permute(0, 3, 1, 2).to(x.dtype).clone()
 
 
 class S2MLPv2(E.EngineModule):
@@ -191,8 +209,8 @@ class S2MLPv2(E.EngineModule):
         if mode not in SHIFT_MODES:
             raise ValueError("shift_mode must be one of %s" % sorted(SHIFT_MODES))
         self.shift_mode = mode
-        for m in self.modules():                  # the attention modules are callable on their own: keep them in step
-            if isinstance(m, S2Attention):
+        for m in self.modules():                  # the attention modules and the stages are callable on their own: keep them in step
+            if isinstance(m, (S2Attention, S2Block)):
                 m.shift_mode = mode
         return self
 

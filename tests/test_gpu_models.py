@@ -48,6 +48,18 @@ with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "re
     REF_LOWP = json.load(_f)
 
 
+# Regression guard (advisor, round 4: "accuracy drift cannot hide under a looser gate").  The bf16 distance of every real-depth fixture as
+# MEASURED at the end of round 5 (profiles/r05_real_golden_lines.txt); a run may not exceed 1.3 x its entry, whatever the derived gate allows
+# (the max over 2000-8000 logits moves by +-20 % between equally valid roundings: same-box A/B of the two GELU forms below).  History of the
+# entries that moved: ViP-S7 6.2e-3 (rounds 1-3) -> 8.7e-3 (round 4) is the logistic bf16 GELU -- the SAME tree built with the polynomial
+# (-DMLPK_GELU_BF16_POLY) gives 5.6e-3 on the same box, while AS-MLP-T / Sparse-MLP move the other way (7.8e-3 vs 8.5e-3, 6.6e-3 vs 7.5e-3) and
+# gMLP-S / Hire / MS-MLP by +-10-15 % (profiles/r05_gelu_accuracy_ab.txt): a property of which roundings the maximum lands on, not a trend.
+BF16_RECORDED = {"mixer_s16": 2.34e-3, "mixer_b16": 2.33e-3, "gmlp_s": 4.67e-3, "resmlp_24": 3.33e-3, "vip_s7": 8.67e-3, "asmlp_t": 7.78e-3,
+                 "convmixer_1536_20": 8.3e-4, "mixer_l16": 2.14e-3, "sparsemlp_t": 6.64e-3, "hiremlp_s": 6.81e-3, "msmlp_t": 1.53e-2,
+                 "swinmlp_t": 4.30e-3, "cyclemlp_b1": 6.18e-3}
+REGRESSION_HEADROOM = 1.3
+
+
 FP16_REAL_EXCEPTIONS = {
     # measured 1.03e-3 on logits of magnitude 0.44 after 18 blocks x 6 GEMMs with fp16 storage.  Same-box switches (round 2):
     # SplitAttention's `a` from fp32 sums of the branch inputs (2.5e-4 from an fp64 evaluation of the same operands,
@@ -155,10 +167,13 @@ def test_real_golden_fp32_and_fp16(name, bs):
             out = model(x.to(DEV).to(dtype))
         torch.cuda.synchronize()
         err = (out.float().cpu() - ref).abs().max().item()
-        print("real %-10s %-8s max|d| = %.3e  (max|ref| %.3f)" % (name, str(dtype)[6:], err, ref.abs().max()))
+        rms = (out.float().cpu() - ref).pow(2).mean().sqrt().item()
+        print("real %-10s %-8s max|d| = %.3e  rms %.3e  (max|ref| %.3f)" % (name, str(dtype)[6:], err, rms, ref.abs().max()))
         tol = tol_for(dtype, ref, real=True, name=name)
         if name == "s2mlpv2":
             tol = s2_real_gate(dtype)
+        elif dtype == torch.bfloat16 and os.environ.get("MLPK_LIB_PATH") is None:
+            tol = min(tol, REGRESSION_HEADROOM * BF16_RECORDED[name])         # (an A/B build of another arithmetic keeps the plain gate)
         assert err < tol, (name, str(dtype), err)
     if name == "s2mlpv2":
         model.set_shift_mode("shift")
@@ -536,6 +551,49 @@ def test_s2v1_and_convmixer_blocks_callable_like_the_reference():
     got = cm.blocks[1](t.to(DEV))
     assert got.shape == ref.shape
     assert (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_s2_stage_callable_on_its_own_like_the_reference(dtype):
+    """s2_mlp_v2.py:71-92 / s2_mlp_v1.py:27-53: `S2Block(d_model, depth, expansion_factor)` is a module of its own in the reference -- (B, C, H, W)
+    in, permute, the depth blocks, permute back (SURVEY 8b lists it as a secondary constructor).  Built standalone AND taken out of a model
+    (`model.stages[s][1]`), in both shift semantics, against the oracle's blocks chained by hand."""
+    pkg = load_pkg()
+    mp = pkg.models_pytorch
+    Fo = oracle.functional
+    tol = 2e-5 if dtype == torch.float32 else 4e-2
+    for ver, mod, block_ref in ((2, mp.s2_mlp_v2, Fo.s2v2_block), (1, mp.s2_mlp_v1, Fo.s2v1_block)):
+        torch.manual_seed(31 + ver)
+        stage = mod.S2Block(32, 2, expansion_factor=3).eval()
+        for p in stage.parameters():
+            p.data.add_(0.05 * torch.randn_like(p))
+        sd = {k: v.detach().clone() for k, v in stage.state_dict().items()}
+        x = torch.randn(2, 32, 6, 5)
+        stage = stage.to(DEV)
+        for mode in ("reference_inplace", "shift"):
+            stage.shift_mode = mode
+            ref = x.to(dtype).float().permute(0, 2, 3, 1)
+            for i in range(2):
+                ref = block_ref(sd, ref, "model.%d." % i, mode)
+            ref = ref.permute(0, 3, 1, 2)
+            got = stage(x.to(DEV).to(dtype))
+            assert got.shape == ref.shape and got.dtype == dtype
+            err = (got.float().cpu() - ref).abs().max().item()
+            assert err < tol * max(1.0, ref.abs().max().item()), (ver, mode, str(dtype), err)
+        with pytest.raises(NotImplementedError):
+            stage(x)                                               # CPU tensor: no fallback
+    # a stage taken out of a model runs with the model's parameters and shift mode
+    torch.manual_seed(37)
+    model = mp.S2MLPv2(image_size=32, patch_size=[4, 2], d_model=[16, 32], depth=[1, 2], expansion_factor=[3, 3], num_classes=10).eval()
+    model.set_shift_mode("shift")
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    x = torch.randn(2, 32, 4, 4)
+    ref = x.permute(0, 2, 3, 1)
+    for i in range(2):
+        ref = Fo.s2v2_block(sd, ref, "stages.1.1.model.%d." % i, "shift")
+    got = model.stages[1][1](x.to(DEV))
+    assert (got.cpu() - ref.permute(0, 3, 1, 2)).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
 def test_hire_block_callable_like_the_reference():

@@ -1095,7 +1095,9 @@ def test_token_gemm_with_the_layernorm_as_its_operand_loader(dtype):
             E.token_gemm(xt, sp, B_ * C, S, wp, bp, ng, two, C, C, R=x1, ldr=C, res=N.RES_ADD, rscale=g1, rperiod=C)
             # ... and with the residual rebuilt from x itself (R == x), in place: bit-equal to the run with the stored Aff output
             xin = x.clone()
-            E.token_gemm_ln(xin, C, B_ * C, S, None, None, gamma, beta, wp, bp, ng, xin, C, C, R=xin, ldr=C, res=N.RES_ADD, rscale=g1, rperiod=C)
+            E.token_gemm_ln(xin, C, B_ * C, S, None, None, gamma, beta, wp, bp, ng, xin, C, C, R=xin, ldr=C, res=N.RES_ADD_AFFINE, rscale=g1, rperiod=C)
+            with pytest.raises(RuntimeError):              # plain ADD with R aliasing x no longer selects the affine residual silently
+                E.token_gemm_ln(xin, C, B_ * C, S, None, None, gamma, beta, wp, bp, ng, xin, C, C, R=xin, ldr=C, res=N.RES_ADD, rscale=g1, rperiod=C)
             torch.cuda.synchronize()
             assert torch.equal(xin.view(torch.int16), out.view(torch.int16)), (str(dtype), ci, "in place, residual rebuilt")
         torch.cuda.synchronize()

@@ -17,9 +17,9 @@ xt[:, :S] = torch.randn(B_ * C, S, device="cuda").to(dt)
 x = torch.randn(B_ * S, C, device="cuda").to(dt)
 w1, b1, w2, b2 = torch.randn(T, S) / 14, torch.randn(T), torch.randn(S, T) / 20, torch.randn(S)
 flops = 2.0 * B_ * C * S * T * 2
-for lay in (1, 2):
+for lay in (1, 2, 3):
     for st in (False, True):
-        for dbg in ([0] if lay == 1 else [int(v) for v in os.environ.get("DBGS", "0,1,2,4,3,8,16,32,48,52").split(",")]):
+        for dbg in ([0] if lay != 2 else [int(v) for v in os.environ.get("DBGS", "0,1,2,4,3,8,16,32,48,52").split(",")]):
             os.environ["MLPK_T4_DBG"] = str(dbg)
             pk = E.pack_token_mlp(w1, b1, w2, b2, dt, "cuda", sp, layout=lay, t_rows=C)
             part = torch.empty(E.token_mlp_stat_planes(C, lay), B_ * S, 2, device="cuda") if st else None
@@ -37,7 +37,7 @@ for lay in (1, 2):
             torch.cuda.synchronize()
             ms = ev[0].elapsed_time(ev[1]) / n
             extra = ""
-            if lay == 2:
+            if lay >= 2:
                 import ctypes
                 prof = torch.zeros(1024, dtype=torch.int64, device="cuda")
                 fn = ctypes.CDLL(pkg._native.LIB_PATH).mlpk_token_mlp_debug
