@@ -2,7 +2,7 @@
 
     C[m, n] = epi( sum_k A[m, k] * B[n, k] )      A: M x K, B: N x K, K-contiguous, 16-bit; C 16-bit row-major
 
-Why this shape: on gfx950 the VALU work of one wave does not overlap the MFMAs of ANOTHER wave of
+Why this shape (docs/DESIGN_LOG_r1-r4.md 3.1f): on gfx950 the VALU work of one wave does not overlap the MFMAs of ANOTHER wave of
 the same SIMD (tools/ubench/issue_rate.hip), but in ONE wave's own stream five plain VALU / LDS / SALU instructions issue for
 free behind every v_mfma_f32_32x32x16 (profiles/r02_mfma_valu_mix.txt).  The persistent 8-wave tile (gemm_nt_p8_kernel) ran its
 epilogue -- bias, folded LayerNorm, GELU, convert, store: as long as the 12 K-slabs of Mixer-B fc1 -- with the matrix pipe idle.

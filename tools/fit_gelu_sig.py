@@ -5,7 +5,7 @@
 
 SEVEN single-issue instructions per element -- two fma (|x| is a free source modifier), a multiply, v_exp_f32, an add, v_rcp_f32,
 a multiply -- against eleven for the clamped polynomial it replaces (0.5 + t R(t^2), 8 coefficients), in kernels whose epilogues are
-bound by the number of instructions ONE wave can issue behind its MFMAs.  The exponent polynomial is in |x|, not in
+bound by the number of instructions ONE wave can issue behind its MFMAs (docs/DESIGN_LOG_r1-r4.md 3.1f).  The exponent polynomial is in |x|, not in
 x^2: no squaring step, and its leading coefficient keeps the sign of k0, so the form has the right limits (Phi -> 0 / 1, gelu -> -0 / x)
 for every finite x -- no clamp.  Fit: minimax of the error of GELU itself, |x| * |Phi~ - Phi|, over x in [-14, 14], with the formula
 evaluated in emulated fp32 exactly as the kernels evaluate it.  Prints k (already multiplied by -log2 e) and the error table."""
