@@ -39,6 +39,8 @@
  *                       the final LayerNorm: mlp_mixer.py:73-74; vip.py:160-163; s2_mlp_v2.py:125; as_mlp.py:435-437
  *   mlpk_shift_nchw     Shift / _shift.forward / shift_forward_kernel: utils/shift_cuda.py:44-72,106-129,177-192
  *   mlpk_shift_nchw_backward   _shift.backward / shift_backward_grad_input_kernel: utils/shift_cuda.py:75-103,131-162
+ *   mlpk_gelu_elementwise, mlpk_layernorm_backward, mlpk_col_sum, mlpk_transpose_batched, mlpk_broadcast_rows
+ *                              the autograd of the Mixer path (train mode): mlp_mixer.py:6-27,34-38,62-75 (round 5)
  *   mlpk_shift_nhwc     the same remap on the channel-last layout used internally for AS-MLP
  *   mlpk_norm_shift_nhwc  AxialShift's GroupNorm + GELU + both shifts as one index-remapping pass (as_mlp.py:64-66,84-95)
  *   mlpk_as_conv2       AxialShift's core in ONE kernel: GroupNorm + GELU, both axial shifts, conv2_1 and conv2_2 with their GELUs and the sum
@@ -524,6 +526,30 @@ int mlpk_swin_spatial_supported(int dtype, int C, int heads, int ws);
 int mlpk_swin_spatial(int dtype, void* x, int B, int H, int W, int C, int ws, int pad_t, int pad_l, int Hp, int Wp, int heads,
                       const float* mean, const float* rstd, const float* gamma, const float* beta, const void* w, const float* bias,
                       void* stream);
+
+/* ---- backward of the path (ABI 9, round 5) --------------------------------------------------------------------
+ * What autograd through the GEMM epilogues needs beside mlpk_gemm_nt itself: for y = x W^T + b (+ r) the two products of the backward
+ * are mlpk_gemm_nt calls on transposed operands -- dX = gemm(dY, W^T), dW = gemm(dY^T, X^T) (K-contiguous copies from
+ * mlpk_transpose_batched) -- db = mlpk_col_sum(dY), dr = dY.  Reference: the autograd of nn.Linear / Conv1d(k=1), nn.GELU, nn.LayerNorm,
+ * the token mean and the rearranges of mlp_mixer.py:6-27,34-38,62-75; BatchNorm2d's batch statistics conv_mixer.py:20,28,31.
+ * All kernels: fp32 math, one rounding per stored value, deterministic summation orders (no atomics). */
+/* mode 0: out = gelu(a) (exact erf form: train-mode forward keeps the pre-activation);  mode 1: out = b * gelu'(a)   (row-major, rows x cols, stride ld) */
+int mlpk_gelu_elementwise(int dtype, int mode, const void* a, const void* b, void* out, int64_t rows, int cols, int64_t ld, void* stream);
+/* nn.LayerNorm backward over the last axis with the forward's row statistics: dx = rstd (g - mean(g) - x^ mean(g x^)), g = dy gamma;
+ * `part` receives mlpk_layernorm_backward_blocks(rows) x 2 x C floats: per row block the partial sums of (dy x^, dy); their column sums
+ * (mlpk_col_sum over the blocks) are dgamma / dbeta.  C <= 2048. */
+int mlpk_layernorm_backward_blocks(int64_t rows);
+int mlpk_layernorm_backward(int dtype, const void* x, int64_t ldx, const float* mean, const float* rstd, const float* gamma, const void* dy,
+                            int64_t lddy, void* dx, int64_t lddx, float* part, int64_t rows, int C, void* stream);
+/* out[c] = sum over rows of v[r, c] (square != 0: of v^2), fp32, v = x (sub NULL) or x - sub (same shape and stride): bias gradients, LayerNorm
+ * parameter gradients, BatchNorm batch sums (with `sub`: of what a kernel with a built-in residual -- mlpk_dwconv_nhwc -- added to its input) */
+int mlpk_col_sum(int dtype, const void* x, const void* sub, int64_t rows, int cols, int64_t ld, int square, float* out, void* stream);
+/* out[b, c, r] = in[b, r, c] (+ res[b, c, r]):  in (batch, R, ld_in), out (batch, Cc, ld_out), res like out or NULL.  The padding columns
+ * [R, ld_out) of out are not written (callers that use ld_out as a GEMM's K zero them once). */
+int mlpk_transpose_batched(int dtype, const void* in, int64_t ld_in, void* out, int64_t ld_out, const void* res, int64_t ld_res, int batch,
+                           int R, int Cc, void* stream);
+/* out[b, s, c] = scale * in[b, c]: backward of Reduce('b n c -> b c', 'mean') with scale = 1 / S */
+int mlpk_broadcast_rows(int dtype, const void* in, void* out, int B, int S, int C, float scale, void* stream);
 
 /* ---- small utilities ------------------------------------------------------------------------ */
 /* dst[i] = (dst_dtype) src[i], n elements */

@@ -85,7 +85,55 @@ class ConvMixer(E.EngineModule):
             E.gemm(tmp, pk[p + "pw.w"], cur, rows, dim, dim, bias=pk[p + "pw.b"], act=N.ACT_GELU, cscale=pk[p + "pw.s"], cshift=pk[p + "pw.h"])
             return cur.reshape(B, H, W, dim).permute(0, 3, 1, 2).contiguous()
 
+    def _forward_train(self, x):
+        """Train mode: BatchNorm2d normalises with the statistics of the BATCH and updates its running statistics
+        (conv_mixer.py:20,28,31).  Every BatchNorm layer is two passes of the inference kernel: first with the identity affine, whose
+        output gives the batch statistics (mlpk_col_sum; the depthwise kernel has its residual built in, so there the sums are taken of
+        out - x), then with the scale / shift those statistics give -- the same epilogue arithmetic as eval mode.  Forward only: the
+        result carries no grad_fn (the depthwise convolution's backward is not built)."""
+        from .. import autograd as AG
+        E.require_gpu(x, "ConvMixer.forward")
+        cd = self._compute_dtype or x.dtype
+        E.dtype_code(cd)
+        self.__dict__["_in_shape"] = ("train",) + tuple(x.shape[1:])
+        dim, depth, k, patch, n_classes = self._cfg
+        if k not in (3, 5, 7, 9):
+            raise NotImplementedError("depthwise kernel sizes 3/5/7/9 are built; got %d" % k)
+        B, cin, H_in, W_in = x.shape
+        dev = x.device
+        pad = patch // 2
+        H, W = (H_in + 2 * pad - patch) // patch + 1, (W_in + 2 * pad - patch) // patch + 1
+        rows = B * H * W
+        ones, zeros = torch.ones(dim, dtype=torch.float32, device=dev), torch.zeros(dim, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            ws = self._get_space(B, cd, dev)
+            w = E.pack_matrix(self.embedding[0].weight, cd, dev)
+            kp = w.shape[1]
+            patches = ws.get("embed.patches", (rows, kp))
+            E.patchify(x.contiguous(), patches, B, cin, H_in, W_in, patch, patch, pad, kp)
+            cur, tmp = ws.get("x", (rows, dim)), ws.get("y", (rows, dim))
+
+            def gemm_bn(a, conv, bn, out, kk):
+                wp, b = E.pack_matrix(conv.weight, cd, dev), E.f32(conv.bias, dev)
+                E.gemm(a, wp, out, rows, dim, kk, bias=b, act=N.ACT_GELU)
+                s, h = AG.batchnorm_train_affine(bn, *AG.batch_stats(out, rows, dim), rows)
+                E.gemm(a, wp, out, rows, dim, kk, bias=b, act=N.ACT_GELU, cscale=s, cshift=h)
+            gemm_bn(patches, self.embedding[0], self.embedding[2], cur, kp)
+            for blk in self.blocks:
+                dw, bn_a = blk[0].fn[0], blk[0].fn[2]
+                wd = dw.weight.detach().reshape(dim, k * k).t().contiguous().to(device=dev, dtype=torch.float32)
+                bd = E.f32(dw.bias, dev)
+                E.dwconv_nhwc(cur, tmp, B, H, W, dim, k, wd, bd, ones, zeros)                # tmp = cur + gelu(dwconv(cur) + b)
+                s, h = AG.batchnorm_train_affine(bn_a, *AG.batch_stats(tmp, rows, dim, sub=cur), rows)
+                E.dwconv_nhwc(cur, tmp, B, H, W, dim, k, wd, bd, s, h)
+                gemm_bn(tmp, blk[1], blk[3], cur, dim)
+            pooled = ws.get("pooled", (B, dim))
+            E.pool_mean(cur, B, H * W, dim, dim, pooled, dim)
+            return head_linear(ws, pooled, B, dim, E.pack_matrix(self.classifier[2].weight, cd, dev), E.f32(self.classifier[2].bias, dev), n_classes, x.dtype)
+
     def forward(self, x):
+        if self.training:
+            return self._forward_train(x)
         cd = self._resolve(x)
         dim, depth, k, patch, n_classes = self._cfg
         B, cin, H_in, W_in = x.shape

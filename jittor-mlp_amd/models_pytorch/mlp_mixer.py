@@ -257,7 +257,44 @@ class MLPMixerForImageClassification(MLPMixer):
         pk["head.b"] = E.f32(self.mlp_head[0].bias, device)
         return pk
 
+    def _forward_train(self, x):
+        """Train mode: the same mathematics as forward() with every step an autograd.Function of `..autograd` -- forward
+        and backward both through the C ABI -- so that `loss.backward()` fills the parameters' .grad like the reference's autograd does
+        (mlp_mixer.py:30-75; Dropout(p=0) is the identity there too).  Unfused on purpose: the pre-activations and the normalised tensors
+        are what the backward needs.  The gradient w.r.t. the input image is not produced (no consumer)."""
+        from .. import autograd as AG
+        E.require_gpu(x, "MLPMixerForImageClassification.forward")
+        if x.dim() != 4:
+            raise ValueError("expected a (B, C, H, W) tensor")
+        cd = self._compute_dtype or x.dtype
+        E.dtype_code(cd)
+        S, C, depth, _ = self._dims
+        B, cin, H, W = x.shape
+        ph, pw = self._patch
+        if (H // ph) * (W // pw) != S:
+            raise ValueError("input size gives %d patches, the model was built for %d" % ((H // ph) * (W // pw), S))
+        conv = self.patcher[0]
+        kp = E.round_up(cin * ph * pw, 4 if cd == torch.float32 else 8)
+        with E.on_device(x):
+            patches = torch.zeros((B * S, kp), dtype=cd, device=x.device)
+            E.patchify(x.contiguous(), patches, B, cin, H, W, ph, pw, 0, kp)
+        t = AG.Linear.apply(patches, conv.weight, conv.bias, None)                                   # (B*S, C)
+        for blk in self.model:
+            tok, ch = blk[0], blk[1]
+            n1 = AG.LayerNorm.apply(t, tok.norm.weight, tok.norm.bias, tok.norm.eps)
+            h = AG.Linear.apply(AG.TokensToRows.apply(n1, B, S), tok.fn.net[0].weight, tok.fn.net[0].bias, None)     # (B*C, 4S)
+            y = AG.Linear.apply(AG.Gelu.apply(h), tok.fn.net[3].weight, tok.fn.net[3].bias, None)                     # (B*C, S)
+            t = AG.RowsToTokensAdd.apply(y, t, B, S)
+            n2 = AG.LayerNorm.apply(t, ch.norm.weight, ch.norm.bias, ch.norm.eps)
+            h = AG.Linear.apply(n2, ch.fn.net[0].weight, ch.fn.net[0].bias, None)
+            t = AG.Linear.apply(AG.Gelu.apply(h), ch.fn.net[3].weight, ch.fn.net[3].bias, t)
+        nf = AG.LayerNorm.apply(t, self.active.weight, self.active.bias, self.active.eps)
+        logits = AG.Linear.apply(AG.TokenMean.apply(nf, B, S), self.mlp_head[0].weight, self.mlp_head[0].bias, None)
+        return logits if logits.dtype == x.dtype else logits.to(x.dtype)
+
     def forward(self, x):
+        if self.training and torch.is_grad_enabled():
+            return self._forward_train(x)
         cd = self._resolve(x)
         S, C, _, _ = self._dims
         B = x.shape[0]

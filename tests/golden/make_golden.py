@@ -11,7 +11,7 @@ The reference is imported read-only through the shim of SURVEY.md section 8c:
 Nothing from the reference's source text is written to the repo: fixtures hold inputs,
 weights (tiny configs only) and the reference's outputs.
 
-Usage:  python tests/golden/make_golden.py [--only tiny|real|ops|manifest|s2lowp|lowp] [--check]
+Usage:  python tests/golden/make_golden.py [--only tiny|real|ops|manifest|s2lowp|lowp|train] [--check]
 """
 import argparse
 import importlib
@@ -556,6 +556,58 @@ def make_s2_lowp(ref):
         torch.set_num_threads(nt)
 
 
+def make_train(ref):
+    """train_tiny.npz (round 5): what the REFERENCE's own autograd and train-mode BatchNorm produce.
+      mixer/...      MLPMixerForImageClassification (the tiny fixture's weights and input) in train(): logits, and the gradient of
+                     sum(logits * G) w.r.t. every parameter (G from the portable generator) -- mlp_mixer.py:30-75 through torch autograd;
+      mixer_mid/...  the same at d_model 64, depth 2, 16 patches of a 64x64 image, batch 4 (contraction axes that are not whole chunks);
+      convmixer/...  ConvMixer (the tiny fixture) in train(): logits from BATCH statistics and the running statistics after that one step
+                     (conv_mixer.py:17-31; momentum 0.1, unbiased variance)."""
+    out = {}
+    mm, cm = ref["mlp_mixer"], ref["conv_mixer"]
+    for tag, src, kw, hw, bs in (("mixer", "tiny_mixer.npz", None, None, None),
+                                 ("mixer_mid", None, dict(d_model=64, depth=2, patch_size=16, image_size=64, num_classes=12, expansion_factor=2), (64, 64), 4)):
+        if src:
+            z = np.load(os.path.join(HERE, src))
+            kw = json.loads(str(z["kwargs"]))
+            model = mm.MLPMixerForImageClassification(**kw)
+            model.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}, strict=True)
+            x = torch.from_numpy(z["input"])
+        else:
+            model = mm.MLPMixerForImageClassification(**kw)
+            load_portable(model, seed=11)
+            x = torch.from_numpy(portable_input((bs, 3) + hw, seed=12))
+            for k, v in model.state_dict().items():
+                out["%s/sd/%s" % (tag, k)] = v.detach().numpy().copy()
+            out[tag + "/input"] = x.numpy().copy()
+        model.train()
+        logits = model(x)
+        G = torch.from_numpy(portable_input(tuple(logits.shape), seed=13))
+        (logits * G).sum().backward()
+        out[tag + "/kwargs"] = np.array(_jsonable(kw))
+        out[tag + "/logits"] = logits.detach().numpy().copy()
+        out[tag + "/G"] = G.numpy().copy()
+        for k, p in model.named_parameters():
+            assert p.grad is not None, k
+            out["%s/grad/%s" % (tag, k)] = p.grad.numpy().copy()
+        print("train %-10s logits %s, %d parameter gradients, max |grad| %.3e" % (tag, tuple(logits.shape), len(list(model.parameters())),
+                                                                                 max(float(p.grad.abs().max()) for p in model.parameters())))
+    z = np.load(os.path.join(HERE, "tiny_convmixer.npz"))
+    kw = json.loads(str(z["kwargs"]))
+    model = cm.ConvMixer(**kw)
+    model.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}, strict=True)
+    model.train()
+    with torch.no_grad():
+        logits = model(torch.from_numpy(z["input"]))
+    out["convmixer/kwargs"] = np.array(_jsonable(kw))
+    out["convmixer/logits"] = logits.numpy().copy()
+    for k, v in model.state_dict().items():
+        if "running_" in k or "num_batches" in k:
+            out["convmixer/after/" + k] = v.numpy().copy()
+    print("train convmixer logits", tuple(logits.shape), "max |logit| %.3f" % float(logits.abs().max()))
+    np.savez_compressed(os.path.join(HERE, "train_tiny.npz"), **out)
+
+
 def make_manifest(ref):
     """Drop-in manifests: constructor signatures + state_dict key->shape for every hot-path model."""
     man = {"signatures": {}, "state_dicts": {}}
@@ -606,6 +658,8 @@ def main():
         make_s2_lowp(ref)
     if args.only in (None, "lowp"):
         make_real_lowp(ref)
+    if args.only in (None, "train"):
+        make_train(ref)
 
 
 if __name__ == "__main__":
