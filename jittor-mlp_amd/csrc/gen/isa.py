@@ -1096,7 +1096,10 @@ def lint(asm, mfma_gap=16, verbose=False):
             if kind == "trans" and is_valu and i.op not in TRANS_OPS and dist < 1:
                 # gfx940+ trans forwarding hazard: a non-transcendental VALU instruction reads a transcendental's result >= 1 state later
                 problems.append((k, "%s reads the transcendental result %s%d straight after it was written" % (i.op, r[0], r[1])))
-            if kind in ("valu", "trans") and is_mfma and dist < 2:
+            if kind == "pk16" and is_valu and dist < 1:
+                # gfx940+ destination-forwarding hazard of the 16-bit packed (VOP3P) results: hipcc pads a dependent v_pk_fma_f16 with s_nop 0
+                problems.append((k, "%s reads the packed-f16 result %s%d straight after it was written" % (i.op, r[0], r[1])))
+            if kind in ("valu", "trans", "pk16") and is_mfma and dist < 2:
                 problems.append((k, "MFMA reads %s%d %d states after a VALU write (< 2)" % (r[0], r[1], dist)))
         for r in d:
             if r in last_def:
@@ -1115,6 +1118,8 @@ def lint(asm, mfma_gap=16, verbose=False):
                 last_def[r] = (pos, "dot")
             elif i.op in TRANS_OPS:
                 last_def[r] = (pos, "trans")
+            elif i.op in ("v_pk_fma_f16", "v_pk_mul_f16", "v_pk_add_f16", "v_pk_max_f16", "v_pk_min_f16", "v_cvt_pk_f16_f32", "v_cvt_pkrtz_f16_f32"):
+                last_def[r] = (pos, "pk16")
             elif is_valu:
                 last_def[r] = (pos, "valu")
             else:

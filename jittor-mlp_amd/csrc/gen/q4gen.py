@@ -38,7 +38,9 @@ GELU_RAW = {"f16": False, "bf16": True}
 # instructions per element instead of eleven (two of them transcendental: ~2 extra cycles each beside an MFMA, tools/ubench/q4_slots.py).
 # MLPK_GELU_BF16_POLY=1 at generation time (+ -DMLPK_GELU_BF16_POLY for the HIP sources) keeps the polynomial for A/B builds.
 GELU_SIG = {"bf16": (-2.28684449, -0.0305621661, -0.0905431807)}
-GELU_FORM = {"f16": "poly", "bf16": "poly" if os.environ.get("MLPK_GELU_BF16_POLY") == "1" else "sig"}
+# round 5: the default bf16 form is "h2b" -- Phi in packed f16 (GELU_H2 below), the product in fp32 on the unrounded x (mlpk_common.h gelu_h2b_f);
+# MLPK_GELU_BF16_SIG=1 / MLPK_GELU_BF16_POLY=1 at generation time (+ the -D of the same name for the HIP sources) keep the older forms for A/B builds
+GELU_FORM = {"f16": "poly", "bf16": "poly" if os.environ.get("MLPK_GELU_BF16_POLY") == "1" else ("sig" if os.environ.get("MLPK_GELU_BF16_SIG") == "1" else "h2b")}
 
 
 # round 5, the fused token-mixing kernel's bf16 grade ("h2", t4gen.py): Phi as a polynomial in PACKED f16 -- two elements per instruction and no
@@ -70,6 +72,30 @@ def h2_gelu_ops(E, x, hdst, t, u, q, v_c0, s_scale, s_c):
         E("v_pk_fma_f16", q[k], t[k], q[k], H(0.5), op_sel_hi="[1,1,0]", clamp=True)
     for k in range(n):
         E("v_pk_mul_f16", hdst[k], hdst[k], q[k])
+
+
+def h2b_gelu_ops(E, x, hp, t, u, q, v_c, s_scale, s_c6, v_nz):
+    """x[r] <- gelu(x[r]) in fp32 for four chains = two pairs abreast, the operation sequence of gelu_h2b_f (mlpk_common.h): Phi of the
+    nearest-even f16 of x in packed f16, the product on the unrounded fp32 x.  hp, t, u, q: two scratch registers each; v_c: c0 .. c5 as
+    packed constants in VGPRs, s_scale / s_c6 in SGPRs (a VOP3P instruction reads at most one SGPR); v_nz holds -0.0: the product is an fma
+    and x * 0 = -0 for x < 0 must stay -0 (a +0 addend would turn it into +0; the HIP kernels multiply, and the tiles are held bit-equal)."""
+    for k in range(2):
+        E("v_cvt_pk_f16_f32", hp[k], x[2 * k], x[2 * k + 1])
+    for k in range(2):
+        E("v_pk_mul_f16", t[k], hp[k], s_scale)
+    for k in range(2):
+        E("v_pk_fma_f16", u[k], t[k], t[k], H(-1.0), op_sel_hi="[1,1,0]")
+    for k in range(2):
+        E("v_pk_fma_f16", q[k], v_c[0], u[k], v_c[1])
+    for j in range(2, 6):
+        for k in range(2):
+            E("v_pk_fma_f16", q[k], q[k], u[k], v_c[j])
+    for k in range(2):
+        E("v_pk_fma_f16", q[k], q[k], u[k], s_c6)
+    for k in range(2):
+        E("v_pk_fma_f16", q[k], t[k], q[k], H(0.5), op_sel_hi="[1,1,0]", clamp=True)
+    for r in range(4):
+        E("v_fma_mix_f32", x[r], x[r], q[r >> 1], v_nz, op_sel="[0,%d,0]" % (r & 1), op_sel_hi="[0,1,0]")
 
 
 def sig_gelu_ops(E, x, q, v_k2, s_k1, s_k0):
@@ -171,8 +197,9 @@ class Q4:
             self.s_part, self.s_partld = s("part", 2, 2), s("partld")
             self.s_eP = s("eP", 2, 2)
         self.sig = self.gelu and GELU_FORM[self.dtype] == "sig"
-        self.s_r2 = s("r2") if (self.gelu and not self.sig and not GELU_RAW[self.dtype]) else None      # sqrt 2: the centred polynomial's clamp
-        self.s_k0, self.s_k1 = (s("gk0"), s("gk1")) if self.sig else (None, None)
+        self.h2b = self.gelu and GELU_FORM[self.dtype] == "h2b"
+        self.s_r2 = s("r2") if (self.gelu and not self.sig and not self.h2b and not GELU_RAW[self.dtype]) else None      # sqrt 2: the centred polynomial's clamp
+        self.s_k0, self.s_k1 = (s("gk0"), s("gk1")) if (self.sig or self.h2b) else (None, None)      # (h2b: the packed scale and c6)
         # (prof1 = the end stamp, taken after the last block: it lives in the next-tile DMA base, which is dead by then)
         self.s_prof0, self.s_prof1, self.s_profp, self.s_ntiles = s("prof0", 2, 2), self.s_dAn, s("profp", 2, 2), s("ntiles")
         self.s_t = [s("t%d" % i) for i in range(6)]
@@ -197,9 +224,13 @@ class Q4:
         self.v_c0 = v("c0") if self.gelu else None
         self.v_x = [[v("x%d_%d" % (b, r)) for r in range(4)] for b in range(2)]
         ge = self.gelu
-        self.v_t = [[v("t%d_%d" % (b, r)) for r in range(4)] for b in range(2)] if ge else [None, None]
-        self.v_u = [[v("u%d_%d" % (b, r)) for r in range(4)] for b in range(2)] if ge else [None, None]
-        self.v_q = [[v("q%d_%d" % (b, r)) for r in range(4)] for b in range(2)] if ge else [None, None]
+        ns_ = 2 if self.h2b else 4                     # scratch registers per chain set (h2b works on PAIRS: half as many, + the packed f16 of x)
+        self.v_t = [[v("t%d_%d" % (b, r)) for r in range(ns_)] for b in range(2)] if ge else [None, None]
+        self.v_u = [[v("u%d_%d" % (b, r)) for r in range(ns_)] for b in range(2)] if ge else [None, None]
+        self.v_q = [[v("q%d_%d" % (b, r)) for r in range(ns_)] for b in range(2)] if ge else [None, None]
+        self.v_hp = [[v("hp%d_%d" % (b, r)) for r in range(2)] for b in range(2)] if self.h2b else [None, None]
+        self.v_hc = [v("hc%d" % j) for j in range(1, 6)] if self.h2b else None      # c1 .. c5 (c0 is v_c0)
+        self.v_nz = v("negzero") if self.h2b else None
         self.v_pk = [v("pk%d" % k, 2, 2) for k in range(2)]
         self.v_stw = [v("stw%d" % c) for c in range(8)]        # LDS staging: write address of 16-byte chunk c of this lane's row
         self.v_strd = [v("strd%d" % k) for k in range(4)]      # ... and the read addresses (row (lane >> 3) + 8 k, chunk lane & 7)
@@ -399,6 +430,8 @@ class Q4:
         """x[r] <- gelu(x[r]) for the 4 chains abreast (the operation sequence of gelu16_f in mlpk_common.h)"""
         if self.sig:
             return sig_gelu_ops(E, x, q, self.v_c0, self.s_k1, self.s_k0)
+        if self.h2b:
+            return h2b_gelu_ops(E, x, self._hp, t, u, q, [self.v_c0] + self.v_hc, self.s_k0, self.s_k1, self.v_nz)
         scale, c = GELU[self.dtype]
         if GELU_RAW[self.dtype]:
             for r in range(4):
@@ -511,6 +544,7 @@ class Q4:
                 for g in range(4):
                     b = 2 * i + j
                     x, t, u, q = self.v_x[bank], self.v_t[bank], self.v_u[bank], self.v_q[bank]
+                    self._hp = self.v_hp[bank]
                     pk = self.v_pk[bank]
                     bank ^= 1
                     for r in range(4):
@@ -725,6 +759,13 @@ class Q4:
             a("v_mov_b32", self.v_c0, F(gk[2]))
             a("s_mov_b32", self.s_k1, F(gk[1]))
             a("s_mov_b32", self.s_k0, F(gk[0]))
+        elif self.h2b:
+            a("v_mov_b32", self.v_c0, h2bits(GELU_H2["coefs"][0]))
+            for cj in range(5):
+                a("v_mov_b32", self.v_hc[cj], h2bits(GELU_H2["coefs"][cj + 1]))
+            a("s_mov_b32", self.s_k0, h2bits(GELU_H2["scale"]))
+            a("s_mov_b32", self.s_k1, h2bits(GELU_H2["coefs"][6]))
+            a("v_mov_b32", self.v_nz, 0x80000000)
         elif self.gelu:
             a("v_mov_b32", self.v_c0, F(GELU[self.dtype][1][0]))
         a("s_waitcnt", lgkmcnt=0)

@@ -29,7 +29,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from isa import A, F, S, V, Asm, Neg, Reg, h2bits  # noqa: E402
-from q4gen import GELU, GELU_FORM, GELU_H2, GELU_RAW, GELU_SIG, SQRT2, Alloc, h2_gelu_ops, sig_gelu_ops  # noqa: E402
+from q4gen import GELU, GELU_FORM, GELU_H2, GELU_RAW, GELU_SIG, SQRT2, Alloc, h2_gelu_ops, h2b_gelu_ops, sig_gelu_ops  # noqa: E402
 
 KA = dict(xt=0, w1=8, w2=16, b1=24, b2=32, x=40, stats=48, prof=56,
           M=64, G=68, ldxt=72, ldx=76, ntiles=80, tpi=84, tpi_magic=88, grid=92, stat_ld=96, nit=100, lead=104, S=108,
@@ -102,7 +102,8 @@ class T4:
         self.s_tok8 = s("tok8")
         self.s_r2 = s("r2")
         self.sig = GELU_FORM[self.dtype] == "sig" and not self.h2
-        self.s_k0, self.s_k1 = (s("gk0"), s("gk1")) if self.sig else (None, None)
+        self.h2b = GELU_FORM[self.dtype] == "h2b" and not self.h2         # (layout 2 of a bf16 model: the library-wide bf16 GELU, the hidden bf16)
+        self.s_k0, self.s_k1 = (s("gk0"), s("gk1")) if (self.sig or self.h2b) else (None, None)
         # packed-f16 constants: two in SGPRs (as many as the logistic form held -- the asm block may clobber no more scalar registers than
         # that: "inline assembly requires more registers than available"), c0 .. c5 in VGPRs
         self.s_hscale, self.s_hc6 = (s("hscale"), s("hc6")) if self.h2 else (None, None)
@@ -135,7 +136,9 @@ class T4:
         flat = [r_[e] for grp_ in self.tmp for r_ in grp_ for e in range(2)]
         self.tmp_t, self.tmp_u, self.tmp_q = flat[0:4], flat[4:8], flat[8:12]
         self.v_c0 = v("c0")
-        self.v_hc = [v("hc%d" % j) for j in range(1, 6)] if self.h2 else None
+        self.v_hc = [v("hc%d" % j) for j in range(1, 6)] if (self.h2 or self.h2b) else None
+        self.v_hp = [v("hp%d" % j) for j in range(2)] if self.h2b else None
+        self.v_nz = v("negzero") if self.h2b else None
         self.v_w1rd, self.v_w2rd, self.v_b1rd = v("w1rd"), v("w2rd"), v("b1rd")
         self.v_w1off = [v("w1off%d" % i) for i in range(5)]
         self.v_w2off = [v("w2off%d" % i) for i in range(5)]
@@ -214,6 +217,8 @@ class T4:
                     continue
                 if self.sig:
                     sig_gelu_ops(E, x, Q, self.v_c0, self.s_k1, self.s_k0)
+                elif self.h2b:
+                    h2b_gelu_ops(E, x, self.v_hp, T[0:2], U[0:2], Q[0:2], [self.v_c0] + self.v_hc, self.s_k0, self.s_k1, self.v_nz)
                 elif self.raw:
                     for r in range(4):
                         E("v_med3_f32", T[r], x[r], F(-scale), F(scale))
@@ -226,7 +231,7 @@ class T4:
                         E("v_med3_f32", T[r], T[r], Neg(self.s_r2), self.s_r2)
                     for r in range(4):
                         E("v_fma_f32", U[r], T[r], T[r], F(-1.0))
-                if not self.sig:
+                if not self.sig and not self.h2b:
                     for r in range(4):
                         E("v_fmaak_f32", Q[r], U[r], self.v_c0, F(c[1]))
                     for kx in range(2, len(c)):
@@ -656,6 +661,13 @@ class T4:
             for cj in range(5):
                 a("v_mov_b32", self.v_hc[cj], h2bits(GELU_H2["coefs"][cj + 1]))
             a("s_mov_b32", self.s_hc6, h2bits(GELU_H2["coefs"][6]))
+        elif self.h2b:
+            a("v_mov_b32", self.v_c0, h2bits(GELU_H2["coefs"][0]))
+            for cj in range(5):
+                a("v_mov_b32", self.v_hc[cj], h2bits(GELU_H2["coefs"][cj + 1]))
+            a("s_mov_b32", self.s_k0, h2bits(GELU_H2["scale"]))
+            a("s_mov_b32", self.s_k1, h2bits(GELU_H2["coefs"][6]))
+            a("v_mov_b32", self.v_nz, 0x80000000)
         elif self.sig:
             a("v_mov_b32", self.v_c0, F(GELU_SIG[self.dtype][2]))
             a("s_mov_b32", self.s_k1, F(GELU_SIG[self.dtype][1]))

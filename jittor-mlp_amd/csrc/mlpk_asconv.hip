@@ -113,8 +113,12 @@ __global__ void __launch_bounds__(512, 1) as_conv2_kernel(const AsConvArgs p) {
                     if (in[k]) {
                         T v8[8], e8[8];
                         __builtin_memcpy(v8, &raw[k], 16);
+                        f32x2 g2[4];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) e8[e] = from_f32<T>(gelu16_f<T>(__builtin_fmaf(to_f32(v8[e]), sc[e], sh[e])));
+                        for (int e = 0; e < 4; ++e) g2[e] = f32x2{__builtin_fmaf(to_f32(v8[2 * e]), sc[2 * e], sh[2 * e]), __builtin_fmaf(to_f32(v8[2 * e + 1]), sc[2 * e + 1], sh[2 * e + 1])};
+                        gelu_pk_n<T, 4>(g2);                 // (four pairs abreast: the same bits as gelu16_f per element)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { e8[2 * e] = from_f32<T>(g2[e].x); e8[2 * e + 1] = from_f32<T>(g2[e].y); }
                         __builtin_memcpy(&o, e8, 16);
                     }
                     *reinterpret_cast<u32x4*>(smem + (size_t)pp * PITCH + oct * 16) = o;
@@ -189,9 +193,12 @@ __global__ void __launch_bounds__(512, 1) as_conv2_kernel(const AsConvArgs p) {
             for (int g = 0; g < 4; ++g) {
                 const f32x4 bz = *reinterpret_cast<const f32x4*>(bias + nc * 32 + 8 * g + 4 * hh);
                 const float bb[4] = {bz.x, bz.y, bz.z, bz.w};
+                f32x2 g2[2] = {f32x2{acc[4 * g] + bb[0], acc[4 * g + 1] + bb[1]}, f32x2{acc[4 * g + 2] + bb[2], acc[4 * g + 3] + bb[3]}};
+                gelu_pk_n<T, 2>(g2);
+                const float gv[4] = {g2[0].x, g2[0].y, g2[1].x, g2[1].y};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v = to_f32(from_f32<T>(gelu16_f<T>(acc[4 * g + r] + bb[r])));
+                    const float v = to_f32(from_f32<T>(gv[r]));
                     yv[4 * g + r] = conv == 0 ? v : to_f32(from_f32<T>(v + yv[4 * g + r]));
                 }
             }

@@ -68,7 +68,7 @@ __device__ __forceinline__ float gelu_f(float x) {
 #define MLPK_GELUP_COEFS {0.00260713836f, -0.00718860654f, 0.00979797821f, -0.0172248576f, 0.0355015062f, -0.0601866171f, 0.090279378f, -0.127707109f, 0.174028099f, -0.245624334f, 0.499268919f}
 #define MLPK_GELUP_CLAMP_BF16 4.0f
 #define MLPK_GELUP_COEFS_BF16 {-1.58078628e-09f, 1.21711111e-07f, -4.10086659e-06f, 8.06673925e-05f, -0.00104820437f, 0.00966487452f, -0.0661753789f, 0.39884752f}
-// Round 4 -- the bf16 grade every kernel now evaluates (the polynomial above stays behind -DMLPK_GELU_BF16_POLY for A/B builds):
+// Round 4 -- the logistic bf16 grade (round 5: behind -DMLPK_GELU_BF16_SIG; the polynomial above behind -DMLPK_GELU_BF16_POLY; default: "h2b" below):
 //         gelu(x) = x * Phi(x),   Phi(x) ~= 1 / (1 + 2^(x * (K0 + K1 |x| + K2 x^2)))          (tools/fit_gelu_sig.py)
 // a logistic with a cubic exponent, odd in x.  SEVEN instructions per element -- fma, fma (|x| is a source modifier), mul, v_exp_f32,
 // add, v_rcp_f32, mul -- against eleven: the epilogues that carry a GELU are bound by the number of instructions one wave can issue
@@ -86,6 +86,67 @@ __device__ __forceinline__ float gelu_sig_f(float x) {
     q = __builtin_fmaf(a, q, MLPK_GELUS_K0);
     const float e = __builtin_amdgcn_exp2f(x * q);
     return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// Round 5 -- the bf16 grade every kernel evaluates now ("h2b"; -DMLPK_GELU_BF16_SIG keeps the logistic form above, -DMLPK_GELU_BF16_POLY the
+// polynomial, for A/B builds):  gelu(x) = x * Phi(h),  h = f16(x) (nearest-even),  Phi in PACKED f16 -- two elements per instruction:
+//         t = h * S;  u = t * t - 1;  Phi = clamp01(0.5 + t * Q(u)),  Q = 7 coefficients by Horner            (tools/fit_gelu_h2.py)
+// -- and the product in fp32 on the unrounded x (v_fma_mix_f32 reads the f16 half as an fp32 source).  Per PAIR: 1 convert + 9 packed + 2
+// mixed = 12 plain instructions, none transcendental, against 14 of which four are quarter-rate (v_exp_f32 / v_rcp_f32): in the epilogues that
+// are bound by VALU time (gMLP's channel_proj1, the narrow channel MLPs) a transcendental costs four plain issue cycles, in the q4 GEMM's
+// filler stream two (profiles/r05_issue_slots_packed_gelu.txt: the fc1 loop 39.45 -> 37.71 cycles per MFMA).  No operand clamp: the fit's
+// leading coefficient is positive, so beyond |x| = 4 the polynomial runs off in the direction the result clamp wants (h = +-inf included:
+// every intermediate is +-inf of the right sign, never inf - inf), and x itself stays fp32, so gelu(-1e6) = -1e6 * 0 = -0.
+// |gelu error| <= 9e-4 |x| on |x| >= 0.25 (half an ulp of bf16 is 2e-3 |x|), <= 1.7e-4 below; rms 1.2e-4 .. 3.5e-4 for x ~ N(0, 0.5 .. 2): +1 .. 3 %
+// on the rms error of the bf16-rounded result (tests/test_host_cpu.py evaluates it over every f16 input, tools/fit_gelu_h2.py prints the table).
+#define MLPK_GELUH_SCALE 0.353515625f
+#define MLPK_GELUH_COEFS {0.01392364501953125f, -0.046875f, 0.07305908203125f, -0.100830078125f, 0.155029296875f, -0.2386474609375f, 0.497802734375f}
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ h2_t gelu_h2_phi(const h2_t h) {
+    constexpr float c[7] = MLPK_GELUH_COEFS;
+    const h2_t t = h * h2_t{(_Float16)MLPK_GELUH_SCALE, (_Float16)MLPK_GELUH_SCALE};
+    const h2_t u = __builtin_elementwise_fma(t, t, h2_t{(_Float16)-1.0f, (_Float16)-1.0f});
+    h2_t q = __builtin_elementwise_fma(h2_t{(_Float16)c[0], (_Float16)c[0]}, u, h2_t{(_Float16)c[1], (_Float16)c[1]});
+#pragma unroll
+    for (int i = 2; i < 7; ++i) q = __builtin_elementwise_fma(q, u, h2_t{(_Float16)c[i], (_Float16)c[i]});
+    const h2_t p = __builtin_elementwise_fma(t, q, h2_t{(_Float16)0.5f, (_Float16)0.5f});
+    return __builtin_elementwise_min(__builtin_elementwise_max(p, h2_t{(_Float16)0.0f, (_Float16)0.0f}), h2_t{(_Float16)1.0f, (_Float16)1.0f});
+}
+__device__ __forceinline__ float gelu_h2b_f(float x) {         // the scalar form: the same f16 operations on one lane, hence the same bits
+    const h2_t p = gelu_h2_phi(h2_t{(_Float16)x, (_Float16)x});
+    return x * (float)p.x;
+}
+// The same Phi for N >= 2 pairs with the instruction ORDER fixed: one step of all N chains, then the next step.  A packed-f16 (VOP3P) result
+// needs one wait state before the VALU instruction that reads it (gfx940+ destination forwarding); hipcc's own schedule of gelu_h2_phi ran one
+// chain at a time and padded EVERY step with s_nop 0 -- 21 issue slots per pair, slower than the logistic form it replaces (AS-MLP-T -3 %
+// same-box, profiles/r05_gelu_h2b_ab.txt).  Step-major order puts N - 1 independent instructions between dependent ones: no padding at all.
+// asm volatile statements keep their order; everything else (the MFMAs and loads around an epilogue) still schedules freely between them.
+template <int N> __device__ __forceinline__ void gelu_h2_phi_n(unsigned (&h)[N]) {          // h: packed f16 pairs in, Phi out
+    static_assert(N >= 2, "two chains at least: the interleave IS the hazard distance");
+    constexpr float c[7] = MLPK_GELUH_COEFS;
+    auto pk = [](float v) { const unsigned short b = __builtin_bit_cast(unsigned short, (_Float16)v); return (unsigned)b | ((unsigned)b << 16); };
+    const unsigned kS = pk(MLPK_GELUH_SCALE), c0 = pk(c[0]), k1 = pk(c[1]), k2 = pk(c[2]), k3 = pk(c[3]), k4 = pk(c[4]), k5 = pk(c[5]), k6 = pk(c[6]);
+    unsigned t[N], u[N], q[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(t[k]) : "v"(h[k]), "s"(kS));
+#pragma unroll
+    for (int k = 0; k < N; ++k) asm volatile("v_pk_fma_f16 %0, %1, %1, -1.0 op_sel_hi:[1,1,0]" : "=v"(u[k]) : "v"(t[k]));
+#pragma unroll
+    for (int k = 0; k < N; ++k) asm volatile("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(q[k]) : "v"(c0), "v"(u[k]), "s"(k1));
+#pragma unroll
+    for (int k = 0; k < N; ++k) asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(q[k]) : "v"(u[k]), "s"(k2));
+#pragma unroll
+    for (int k = 0; k < N; ++k) asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(q[k]) : "v"(u[k]), "s"(k3));
+#pragma unroll
+    for (int k = 0; k < N; ++k) asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(q[k]) : "v"(u[k]), "s"(k4));
+#pragma unroll
+    for (int k = 0; k < N; ++k) asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(q[k]) : "v"(u[k]), "s"(k5));
+#pragma unroll
+    for (int k = 0; k < N; ++k) asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(q[k]) : "v"(u[k]), "s"(k6));
+#pragma unroll
+    for (int k = 0; k < N - 1; ++k) asm volatile("v_pk_fma_f16 %0, %1, %2, 0.5 op_sel_hi:[1,1,0] clamp" : "=v"(h[k]) : "v"(t[k]), "v"(q[k]));
+    // (the compiler does not know that the last statement writes a packed result: the wait state in front of whatever reads it is spelled out)
+    asm volatile("v_pk_fma_f16 %0, %1, %2, 0.5 op_sel_hi:[1,1,0] clamp\n\ts_nop 0" : "=v"(h[N - 1]) : "v"(t[N - 1]), "v"(q[N - 1]));
 }
 
 // gelu on N independent pairs with the N dependency chains interleaved step by step: a single wave running ONE
@@ -118,6 +179,25 @@ template <int N, int K, bool RAW> __device__ __forceinline__ void gelu_pk_impl(f
 }
 
 template <typename T, int N> __device__ __forceinline__ void gelu_pk_n(f32x2 (&x)[N]) {
+#if !defined(MLPK_GELU_BF16_POLY) && !defined(MLPK_GELU_BF16_SIG)
+    if constexpr (dtype_of<T>::value == MLPK_BF16) {
+        if constexpr (N >= 2) {
+            unsigned h[N];
+#pragma unroll
+            for (int k = 0; k < N; ++k) h[k] = __builtin_bit_cast(unsigned, h2_t{(_Float16)x[k].x, (_Float16)x[k].y});
+            gelu_h2_phi_n<N>(h);
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const h2_t p = __builtin_bit_cast(h2_t, h[k]);
+                x[k] = f32x2{x[k].x * (float)p.x, x[k].y * (float)p.y};
+            }
+        } else {
+            const h2_t p = gelu_h2_phi(h2_t{(_Float16)x[0].x, (_Float16)x[0].y});
+            x[0] = f32x2{x[0].x * (float)p.x, x[0].y * (float)p.y};
+        }
+        return;
+    }
+#endif
 #ifndef MLPK_GELU_BF16_POLY
     if constexpr (dtype_of<T>::value == MLPK_BF16) {
         // the N pairs step by step (the compiler is free to pair the fma / mul steps into v_pk_*: same bits either way)
@@ -168,6 +248,9 @@ template <int K, bool RAW> __device__ __forceinline__ float gelu16_impl(float x,
 }
 
 template <typename T> __device__ __forceinline__ float gelu16_f(float x) {
+#if !defined(MLPK_GELU_BF16_POLY) && !defined(MLPK_GELU_BF16_SIG)
+    if constexpr (dtype_of<T>::value == MLPK_BF16) return gelu_h2b_f(x);
+#endif
 #ifndef MLPK_GELU_BF16_POLY
     if constexpr (dtype_of<T>::value == MLPK_BF16) return gelu_sig_f(x);
 #endif

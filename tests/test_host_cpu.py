@@ -268,7 +268,7 @@ def test_division_free_gelu_coefficients():
     assert (err[~inside] / np.abs(x[~inside])).max() < 4e-6
     # ---- bf16: the logistic form, all the way out (the polynomial's tail)
     k = [np.float32(re.search(r"#define MLPK_GELUS_K%d (-?[0-9.e-]+)f" % i, src).group(1)) for i in range(3)]
-    assert [np.float32(v) for v in q4gen.GELU_SIG["bf16"]] == k and q4gen.GELU_FORM["bf16"] == "sig"
+    assert [np.float32(v) for v in q4gen.GELU_SIG["bf16"]] == k and q4gen.GELU_FORM["bf16"] == "h2b"       # (the logistic form: A/B builds only, round 5)
 
     def gelu_sig(x):
         a = np.abs(x)
@@ -284,6 +284,33 @@ def test_division_free_gelu_coefficients():
     far = np.abs(xs) >= 8
     assert err[far].max() < 1e-12                                       # x (or -0) to the last bit beyond |x| = 8
     assert float(gelu_sig(np.float32([-1000.0]))[0]) == 0.0 and float(gelu_sig(np.float32([50.0]))[0]) == 50.0
+    # ---- bf16, round 5 ("h2b", the default): Phi of the nearest-even f16 of x in packed f16, the product in fp32 on the unrounded x
+    hc = [float(v) for v in re.search(r"#define MLPK_GELUH_COEFS \{([^}]*)\}", src).group(1).replace("f,", ",").rstrip("f").split(",")]
+    hs = float(re.search(r"#define MLPK_GELUH_SCALE ([0-9.]+)f", src).group(1))
+    assert hc == q4gen.GELU_H2["coefs"] and hs == q4gen.GELU_H2["scale"]
+
+    def f16(v):
+        with np.errstate(over="ignore", invalid="ignore"):
+            return np.asarray(v, np.float64).astype(np.float16).astype(np.float64)
+
+    def gelu_h2b(x):
+        with np.errstate(over="ignore", invalid="ignore"):
+            h = x.astype(np.float16).astype(np.float64)
+            t = f16(h * hs)
+            u = f16(t * t - 1.0)
+            q = f16(hc[0] * u + hc[1])
+            for c in hc[2:]:
+                q = f16(q * u + c)
+            p = f16(t * q + 0.5)
+            p = np.where(np.isnan(p), 0.0, np.clip(p, 0.0, 1.0))
+            return (x * p.astype(np.float32)).astype(np.float32)
+    g = gelu_h2b(xs).astype(np.float64)
+    assert np.isfinite(g).all()
+    err, ax = np.abs(g - exact(xs)), np.abs(xs.astype(np.float64))
+    assert (err[ax >= 0.25] / ax[ax >= 0.25]).max() <= 2.0 ** -10          # half of half an ulp of bf16, everywhere incl. the tails
+    assert err[ax < 0.25].max() <= 2e-4
+    assert err[ax >= 8].max() < 1e-12                                      # x (or -0) to the last bit beyond |x| = 8
+    assert float(gelu_h2b(np.float32([-1e30]))[0]) == 0.0 and np.signbit(gelu_h2b(np.float32([-1e30]))[0]) and float(gelu_h2b(np.float32([1e30]))[0]) == np.float32(1e30)
 
 
 def test_torch_shift_runs_on_cpu_and_matches_the_reference_pins():

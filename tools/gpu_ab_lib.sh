@@ -4,7 +4,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 tag=$1; shift
 MODELS="${@:-mixer_b16}"
 for m in $MODELS; do
-  for rep in 1 2 3; do
+  for rep in $(seq 1 ${REPS:-3}); do
     for v in new $tag; do
       unset MLPK_LIB_PATH
       [ $v = new ] || export MLPK_LIB_PATH=$PWD/jittor-mlp_amd/lib/variants/libmlpk_$tag.so
