@@ -49,14 +49,15 @@ with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "re
 
 
 # Regression guard (advisor, round 4: "accuracy drift cannot hide under a looser gate").  The bf16 distance of every real-depth fixture as
-# MEASURED at the end of round 5 (profiles/r05_real_golden_lines.txt); a run may not exceed 1.3 x its entry, whatever the derived gate allows
-# (the max over 2000-8000 logits moves by +-20 % between equally valid roundings: same-box A/B of the two GELU forms below).  History of the
-# entries that moved: ViP-S7 6.2e-3 (rounds 1-3) -> 8.7e-3 (round 4) is the logistic bf16 GELU -- the SAME tree built with the polynomial
-# (-DMLPK_GELU_BF16_POLY) gives 5.6e-3 on the same box, while AS-MLP-T / Sparse-MLP move the other way (7.8e-3 vs 8.5e-3, 6.6e-3 vs 7.5e-3) and
-# gMLP-S / Hire / MS-MLP by +-10-15 % (profiles/r05_gelu_accuracy_ab.txt): a property of which roundings the maximum lands on, not a trend.
-BF16_RECORDED = {"mixer_s16": 2.34e-3, "mixer_b16": 2.33e-3, "gmlp_s": 4.67e-3, "resmlp_24": 3.33e-3, "vip_s7": 8.67e-3, "asmlp_t": 7.78e-3,
-                 "convmixer_1536_20": 8.3e-4, "mixer_l16": 2.14e-3, "sparsemlp_t": 6.64e-3, "hiremlp_s": 6.81e-3, "msmlp_t": 1.53e-2,
-                 "swinmlp_t": 4.30e-3, "cyclemlp_b1": 6.18e-3}
+# MEASURED at the end of round 5 (profiles/r05_real_golden_lines.txt, the shipped packed-f16 GELU); a run may not exceed 1.3 x its entry,
+# whatever the derived gate allows (the max over 2000-8000 logits moves by +-20 % between equally valid roundings).  History of the entries
+# that moved: ViP-S7 6.2e-3 (rounds 1-3) -> 8.7e-3 (round 4) was the logistic bf16 GELU -- the SAME tree built with the polynomial
+# (-DMLPK_GELU_BF16_POLY) gave 5.6e-3 on the same box, while AS-MLP-T / Sparse-MLP moved the other way (7.8e-3 vs 8.5e-3, 6.6e-3 vs 7.5e-3) and
+# gMLP-S / Hire / MS-MLP by +-10-15 % (profiles/r05_gelu_accuracy_ab.txt): a property of which roundings the maximum lands on, not a trend;
+# with round 5's form ViP-S7 is 7.0e-3, gMLP-S 4.3e-3, ResMLP-24 3.9e-3 (was 3.3e-3), the Mixers 2.3 - 2.6e-3.
+BF16_RECORDED = {"mixer_s16": 2.34e-3, "mixer_b16": 2.51e-3, "gmlp_s": 4.27e-3, "resmlp_24": 3.91e-3, "vip_s7": 6.98e-3, "asmlp_t": 7.28e-3,
+                 "convmixer_1536_20": 8.3e-4, "mixer_l16": 2.56e-3, "sparsemlp_t": 7.44e-3, "hiremlp_s": 6.78e-3, "msmlp_t": 1.53e-2,
+                 "swinmlp_t": 3.76e-3, "cyclemlp_b1": 5.20e-3}
 REGRESSION_HEADROOM = 1.3
 
 

@@ -10,7 +10,7 @@ echo "== smoke"; timeout 300 python __graft_entry__.py smoke 2>&1 | tail -1
 echo "== full gpu suite"; timeout 1500 python -m pytest tests -q -m gpu > $OUT/pytest_gpu.log 2>&1; tail -2 $OUT/pytest_gpu.log
 echo "== bs=256 parity (printed distances)"; timeout 900 python -m pytest tests/test_gpu_models.py -q -m gpu -s -k "batch_256" > $OUT/bs256_parity.txt 2>&1; tail -3 $OUT/bs256_parity.txt
 echo "== pmc"; bash tools/pmc_bench.sh > $OUT/pmc.log 2>&1; tail -2 $OUT/pmc.log; cp gpurun_out/pmc/summary.txt $OUT/pmc_summary.txt; cp gpurun_out/pmc/traffic.json $OUT/traffic.json
-mkdir -p profiles; cp $OUT/traffic.json profiles/r04_traffic.json
+mkdir -p profiles; cp $OUT/traffic.json profiles/${ROUND:-r05}_traffic.json
 echo "== bench (default)"; timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; python -c "
 import json; d=json.load(open('$OUT/bench.json')); print(d['value'], d['ms_per_step'], d['roofline'], d['cpu_baseline']['value'], d['cpu_baseline']['config1']['value'])"
 echo "== 2 ranks on one device"; timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --share-device --steps 20 --warmup 5 > $OUT/bench_2rank.json 2> $OUT/bench_2rank.err; tail -c 600 $OUT/bench_2rank.json
