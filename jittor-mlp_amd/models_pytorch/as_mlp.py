@@ -141,8 +141,9 @@ class AxialShiftedBlock(Block):
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
 
 
-class PatchMerging(Holder):
-    """as_mlp.py:182-195."""
+class PatchMerging(Block):
+    """as_mlp.py:182-216.  Inside an AS_MLP it runs on its own like the reference's -- (B, C, H, W) -> (B, 2C, H/2, W/2) -- through the
+    model's packed weights and kernels (2 x 2 gather + GroupNorm folded into the bias-free reduction GEMM); round 5."""
 
     def __init__(self, input_resolution, dim, norm_layer=nn.LayerNorm):
         super().__init__()
@@ -152,8 +153,8 @@ class PatchMerging(Holder):
         self.norm = norm_layer(4 * dim)
 
 
-class BasicLayer(Holder):
-    """as_mlp.py:228-272."""
+class BasicLayer(Block):
+    """as_mlp.py:228-272.  Inside an AS_MLP a stage runs on its own like the reference's (its blocks, then its PatchMerging); round 5."""
 
     def __init__(self, dim, input_resolution, depth, shift_size, mlp_ratio=4., as_bias=True, drop=0., drop_path=0.,
                  norm_layer=nn.LayerNorm, downsample=None, use_checkpoint=False):
@@ -169,8 +170,8 @@ class BasicLayer(Holder):
         self.downsample = downsample(input_resolution, dim=dim, norm_layer=norm_layer) if downsample is not None else None
 
 
-class PatchEmbed(Holder):
-    """as_mlp.py:296-321."""
+class PatchEmbed(Block):
+    """as_mlp.py:296-333.  Inside an AS_MLP it runs on its own like the reference's: (B, 3, H, W) -> (B, embed_dim, H/4, W/4); round 5."""
 
     def __init__(self, img_size=224, patch_size=4, in_chans=3, embed_dim=96, norm_layer=None):
         super().__init__()
@@ -232,6 +233,10 @@ class AS_MLP(E.EngineModule):
         for li, layer in enumerate(self.layers):
             for bi, blk in enumerate(layer.blocks):
                 blk.__dict__["_owner"] = (self, (li, bi))          # lets `model.layers[l].blocks[b](x)` run (common.Block)
+            layer.__dict__["_owner"] = (self, (li, "layer"))       # ... `model.layers[l](x)`: the blocks, then the PatchMerging
+            if layer.downsample is not None:
+                layer.downsample.__dict__["_owner"] = (self, (li, "down"))
+        self.patch_embed.__dict__["_owner"] = (self, ("embed", None))
 
     def _init_weights(self, m):
         # as_mlp.py:419-426: only nn.Linear (= the head) gets the truncated normal
@@ -333,7 +338,7 @@ class AS_MLP(E.EngineModule):
 
             part = (ws, "l%d.part" % li) if EPILOGUE_STATS else None
             for bi in range(len(layer.blocks)):
-                if only is not None and bi != only[1]:
+                if only is not None and only[1] != "layer" and bi != only[1]:
                     continue
                 p = "l%d.b%d." % (li, bi)
                 if fused:
@@ -386,7 +391,7 @@ class AS_MLP(E.EngineModule):
                 self._gn(ws, tag, cur, B, HW, C, pk[p + "n2.g"], pk[p + "n2.b"], t0)                 # norm2(x)
                 E.gemm(t0, pk[p + "fc1.w"], hbuf, rows, hid, C, bias=pk[p + "fc1.b"], act=N.ACT_GELU, tag="as_fc1")
                 E.gemm(hbuf, pk[p + "fc2.w"], cur, rows, C, hid, bias=pk[p + "fc2.b"], R=cur, res=N.RES_ADD, tag="as_fc2")
-            if layer.downsample is not None and only is None:
+            if layer.downsample is not None and (only is None or only[1] in ("layer", "down")):
                 assert H % 2 == 0 and W % 2 == 0, f"x size ({H}*{W}) are not even."                   # as_mlp.py:203
                 p = "l%d.down." % li
                 H2, W2 = H // 2, W // 2
@@ -410,13 +415,37 @@ class AS_MLP(E.EngineModule):
                 cur, H, W, C = nxt, H2, W2, 2 * C
         return cur, H, W, C, have, mean, rstd
 
+    def _embed(self, ws, pk, x, B, H_in, W_in):
+        pe = self.patch_embed
+        ph, pw = pe.patch_size
+        H, W = H_in // ph, W_in // pw
+        C = self.embed_dim
+        kp = pk["embed.w"].shape[1]
+        patches = ws.get("embed.patches", (B * H * W, kp))
+        E.patchify(x, patches, B, pe.in_chans, H_in, W_in, ph, pw, 0, kp)
+        cur = ws.get("l0.x", (B * H * W, C))
+        E.gemm(patches, pk["embed.w"], cur, B * H * W, C, kp, bias=pk["embed.b"])
+        if pe.norm is not None:
+            self._gn(ws, "gn0", cur, B, H * W, C, pk["embed.g"], pk["embed.be"], cur)
+        return cur, H, W, C
+
     def _run_single(self, key, x):
-        """AxialShiftedBlock (layer, block) alone on (B, C, H, W), as `model.layers[l].blocks[b](x)` in the reference (as_mlp.py:149-162)"""
+        """An inner module alone on (B, C, H, W), as calling it does in the reference: `model.layers[l].blocks[b](x)` (as_mlp.py:149-162),
+        `model.layers[l](x)` (a stage: :258-266), `model.layers[l].downsample(x)` (:197-216), `model.patch_embed(x)` (:323-333)"""
         li, bi = key
-        E.require_gpu(x, "AxialShiftedBlock.forward")
+        E.require_gpu(x, "AS_MLP inner module")
         E.dtype_code(x.dtype)
-        blk = self.layers[li].blocks[bi]
-        C = blk.norm1.num_channels
+        if li == "embed":
+            pe = self.patch_embed
+            B, _, H_in, W_in = x.shape
+            assert H_in == pe.img_size[0] and W_in == pe.img_size[1], \
+                f"Input image size ({H_in}*{W_in}) doesn't match model ({pe.img_size[0]}*{pe.img_size[1]})."
+            with E.on_device(x):
+                pk = self._get_pack(x.dtype, x.device)
+                ws = self._get_space(("embed", B, H_in, W_in), x.dtype, x.device)
+                cur, H, W, C = self._embed(ws, pk, x.contiguous(), B, H_in, W_in)
+                return cur.reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
+        C = self.layers[li].dim
         if x.dim() != 4 or x.shape[1] != C:
             raise ValueError("expected a (B, %d, H, W) tensor" % C)
         B, _, H, W = x.shape
@@ -425,7 +454,7 @@ class AS_MLP(E.EngineModule):
             ws = self._get_space(("block", B, H, W, C), x.dtype, x.device)     # (C: blocks of different stages can meet at one map size)
             cur = ws.get("l%d.x" % li, (B * H * W, C))
             cur.copy_(x.permute(0, 2, 3, 1).reshape(B * H * W, C))                     # channel-last rows, as the stages keep them
-            cur = self._run_layers(ws, pk, cur, B, H, W, C, x.dtype, only=(li, bi))[0]
+            cur, H, W, C = self._run_layers(ws, pk, cur, B, H, W, C, x.dtype, only=(li, bi))[:4]
             return cur.reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
 
     def forward(self, x):
@@ -437,17 +466,7 @@ class AS_MLP(E.EngineModule):
             f"Input image size ({H_in}*{W_in}) doesn't match model ({pe.img_size[0]}*{pe.img_size[1]})."
         pk = self._get_pack(cd, x.device)
         ws = self._get_space(B, cd, x.device)
-        x = x.contiguous()
-        ph, pw = pe.patch_size
-        H, W = H_in // ph, W_in // pw
-        C = self.embed_dim
-        kp = pk["embed.w"].shape[1]
-        patches = ws.get("embed.patches", (B * H * W, kp))
-        E.patchify(x, patches, B, pe.in_chans, H_in, W_in, ph, pw, 0, kp)
-        cur = ws.get("l0.x", (B * H * W, C))
-        E.gemm(patches, pk["embed.w"], cur, B * H * W, C, kp, bias=pk["embed.b"])
-        if pe.norm is not None:
-            self._gn(ws, "gn0", cur, B, H * W, C, pk["embed.g"], pk["embed.be"], cur)
+        cur, H, W, C = self._embed(ws, pk, x.contiguous(), B, H_in, W_in)
         cur, H, W, C, have, mean, rstd = self._run_layers(ws, pk, cur, B, H, W, C, cd)
         if not have:
             mean = ws.get("final.mean", (B,), torch.float32)

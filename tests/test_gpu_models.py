@@ -459,6 +459,30 @@ def test_asmlp_block_callable_like_the_reference(dtype):
         got = model.layers[li].blocks[bi](t.to(DEV).to(dtype))
         assert got.shape == ref.shape and got.dtype == dtype
         assert (got.float().cpu() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item()), (li, bi)
+    # round 5: the stage-level modules run on their own too -- PatchEmbed (as_mlp.py:323-333), PatchMerging (:197-216), BasicLayer (:258-266)
+    Fo = oracle.functional
+    img = torch.randn(2, 3, 32, 32)
+    ref = Fo.patch_embed(img.to(dtype).float(), sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"]).permute(0, 3, 1, 2)
+    ref = Fo.group_norm1(ref, sd["patch_embed.norm.weight"], sd["patch_embed.norm.bias"])
+    got = model.patch_embed(img.to(DEV).to(dtype))
+    assert got.shape == ref.shape == (2, 64, 8, 8)
+    assert (got.float().cpu() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
+    t = torch.randn(2, 64, 8, 8)
+    ref = Fo.asmlp_patch_merging(sd, t.to(dtype).float(), "layers.0.downsample.")
+    got = model.layers[0].downsample(t.to(DEV).to(dtype))
+    assert got.shape == ref.shape == (2, 128, 4, 4)
+    assert (got.float().cpu() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
+    ref = Fo.asmlp_patch_merging(sd, Fo.asmlp_block(sd, t.to(dtype).float(), "layers.0.blocks.0.", 5), "layers.0.downsample.")
+    got = model.layers[0](t.to(DEV).to(dtype))                                 # stage 0: one block, then the merging
+    assert got.shape == ref.shape and (got.float().cpu() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
+    t = torch.randn(2, 128, 4, 4)
+    ref = t.to(dtype).float()
+    for bi in range(2):
+        ref = Fo.asmlp_block(sd, ref, "layers.1.blocks.%d." % bi, 5)
+    got = model.layers[1](t.to(DEV).to(dtype))                                 # the last stage has no downsample
+    assert got.shape == ref.shape and (got.float().cpu() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
+    with pytest.raises(NotImplementedError):
+        mp.as_mlp.PatchMerging((8, 8), 64, norm_layer=mp.as_mlp.MyNorm)(t.to(DEV))     # outside a model: a parameter container
 
 
 def test_swin_and_msmlp_blocks_callable_like_the_reference():
