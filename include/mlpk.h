@@ -454,6 +454,9 @@ int mlpk_s2_shift(int dtype, const void* in, void* out, int B, int H, int W, int
 /* ---- ConvMixer depthwise half --------------------------------------------------------------
  * x, out: (B,H,W,C) channel-last.  w: float32 [k*k][C] (tap-major), bias/bn_scale/bn_shift float32 [C].
  * out = x + (gelu(dwconv_same(x) + bias) * bn_scale + bn_shift)        (conv_mixer.py:24-28, 5-11)
+ * k odd, <= 13: 3 / 5 / 7 / 9 have the LDS-tiled and (16-bit, maps <= 32 x 32) matrix-core forms, the others the generic kernel.  An EVEN
+ * kernel size of Conv2d(padding="same") pads (k - 1) / 2 before and k / 2 after: the caller passes it as the odd size k + 1 with a zero tap
+ * row and column in front (models_pytorch/conv_mixer.py does).
  */
 int mlpk_dwconv_nhwc(int dtype, const void* x, void* out, int B, int H, int W, int C, int k,
                      const float* w, const float* bias, const float* bn_scale,

@@ -177,7 +177,7 @@ static int dwconv_lds_launch(int k, const void* x, void* out, int B, int H, int 
     }
     switch (k) {
         DW_CASE(3) DW_CASE(5) DW_CASE(7) DW_CASE(9)
-        default: return MLPK_ESHAPE;
+        default: return DW_NOFIT;                        // other sizes: the generic kernel (odd k <= 13, round 5)
     }
 #undef DW_CASE
     MLPK_LAUNCH_CHECK();

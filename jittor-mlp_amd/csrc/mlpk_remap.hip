@@ -967,7 +967,7 @@ static int dwconv_launch(int k, const void* x, void* out, int B, int H, int W, i
                            bns, bnh);                                                                                 \
         break;
     switch (k) {
-        DW_CASE(3) DW_CASE(5) DW_CASE(7) DW_CASE(9)
+        DW_CASE(1) DW_CASE(3) DW_CASE(5) DW_CASE(7) DW_CASE(9) DW_CASE(11) DW_CASE(13)
         default: return MLPK_ESHAPE;
     }
 #undef DW_CASE

@@ -24,6 +24,28 @@ class Residual(Holder):
         self.fn = fn
 
 
+def _check_k(k):
+    if not 1 <= k <= 13 and not (k % 2 == 0 and k <= 12):
+        raise NotImplementedError("depthwise kernel sizes 1 .. 13 are built; got %d" % k)
+
+
+def _keff(k):
+    """the odd size the kernels run: Conv2d(padding="same") pads (k - 1) // 2 before and k // 2 after, so an even k is the odd k + 1 with
+    a zero tap row and column in FRONT (conv_mixer.py:26 takes any kernel_size; round 5: 1 .. 13, odd or even)"""
+    return k if k % 2 else k + 1
+
+
+def _dw_taps(weight, dim, k, device):
+    """(dim, 1, k, k) depthwise weight -> tap-major float32 [keff * keff][dim] (include/mlpk.h mlpk_dwconv_nhwc)"""
+    w = weight.detach().to(device=device, dtype=torch.float32).reshape(dim, k, k)
+    ke = _keff(k)
+    if ke != k:
+        wz = torch.zeros((dim, ke, ke), dtype=torch.float32, device=device)
+        wz[:, 1:, 1:] = w
+        w = wz
+    return w.reshape(dim, ke * ke).t().contiguous()
+
+
 def _bn_affine(bn, device):
     scale = (bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps))
     shift = bn.bias.detach().double() - bn.running_mean.detach().double() * scale
@@ -46,8 +68,7 @@ class ConvMixer(E.EngineModule):
 
     def _pack(self, dtype, device):
         dim, depth, k, patch, _ = self._cfg
-        if k not in (3, 5, 7, 9):
-            raise NotImplementedError("depthwise kernel sizes 3/5/7/9 are built; got %d" % k)
+        _check_k(k)
         pk = {}
         pk["embed.w"] = E.pack_matrix(self.embedding[0].weight, dtype, device)
         pk["embed.b"] = E.f32(self.embedding[0].bias, device)
@@ -55,7 +76,7 @@ class ConvMixer(E.EngineModule):
         for i, blk in enumerate(self.blocks):
             p = "b%d." % i
             dw, bn_a = blk[0].fn[0], blk[0].fn[2]
-            pk[p + "dw.w"] = dw.weight.detach().reshape(dim, k * k).t().contiguous().to(device=device, dtype=torch.float32)
+            pk[p + "dw.w"] = _dw_taps(dw.weight, dim, k, device)
             pk[p + "dw.b"] = E.f32(dw.bias, device)
             pk[p + "dw.s"], pk[p + "dw.h"] = _bn_affine(bn_a, device)
             pk[p + "pw.w"] = E.pack_matrix(blk[1].weight, dtype, device)
@@ -81,7 +102,7 @@ class ConvMixer(E.EngineModule):
             cur.copy_(x.permute(0, 2, 3, 1).reshape(rows, dim))                        # channel-last rows, as forward() keeps them
             tmp = ws.get("blk.y", (rows, dim))
             p = "b%d." % i
-            E.dwconv_nhwc(cur, tmp, B, H, W, dim, k, pk[p + "dw.w"], pk[p + "dw.b"], pk[p + "dw.s"], pk[p + "dw.h"])
+            E.dwconv_nhwc(cur, tmp, B, H, W, dim, _keff(k), pk[p + "dw.w"], pk[p + "dw.b"], pk[p + "dw.s"], pk[p + "dw.h"])
             E.gemm(tmp, pk[p + "pw.w"], cur, rows, dim, dim, bias=pk[p + "pw.b"], act=N.ACT_GELU, cscale=pk[p + "pw.s"], cshift=pk[p + "pw.h"])
             return cur.reshape(B, H, W, dim).permute(0, 3, 1, 2).contiguous()
 
@@ -97,8 +118,7 @@ class ConvMixer(E.EngineModule):
         E.dtype_code(cd)
         self.__dict__["_in_shape"] = ("train",) + tuple(x.shape[1:])
         dim, depth, k, patch, n_classes = self._cfg
-        if k not in (3, 5, 7, 9):
-            raise NotImplementedError("depthwise kernel sizes 3/5/7/9 are built; got %d" % k)
+        _check_k(k)
         B, cin, H_in, W_in = x.shape
         dev = x.device
         pad = patch // 2
@@ -121,11 +141,11 @@ class ConvMixer(E.EngineModule):
             gemm_bn(patches, self.embedding[0], self.embedding[2], cur, kp)
             for blk in self.blocks:
                 dw, bn_a = blk[0].fn[0], blk[0].fn[2]
-                wd = dw.weight.detach().reshape(dim, k * k).t().contiguous().to(device=dev, dtype=torch.float32)
+                wd = _dw_taps(dw.weight, dim, k, dev)
                 bd = E.f32(dw.bias, dev)
-                E.dwconv_nhwc(cur, tmp, B, H, W, dim, k, wd, bd, ones, zeros)                # tmp = cur + gelu(dwconv(cur) + b)
+                E.dwconv_nhwc(cur, tmp, B, H, W, dim, _keff(k), wd, bd, ones, zeros)                # tmp = cur + gelu(dwconv(cur) + b)
                 s, h = AG.batchnorm_train_affine(bn_a, *AG.batch_stats(tmp, rows, dim, sub=cur), rows)
-                E.dwconv_nhwc(cur, tmp, B, H, W, dim, k, wd, bd, s, h)
+                E.dwconv_nhwc(cur, tmp, B, H, W, dim, _keff(k), wd, bd, s, h)
                 gemm_bn(tmp, blk[1], blk[3], cur, dim)
             pooled = ws.get("pooled", (B, dim))
             E.pool_mean(cur, B, H * W, dim, dim, pooled, dim)
@@ -151,7 +171,7 @@ class ConvMixer(E.EngineModule):
         E.gemm(patches, pk["embed.w"], cur, rows, dim, kp, bias=pk["embed.b"], act=N.ACT_GELU, cscale=pk["embed.s"], cshift=pk["embed.h"])
         for i in range(depth):
             p = "b%d." % i
-            E.dwconv_nhwc(cur, tmp, B, H, W, dim, k, pk[p + "dw.w"], pk[p + "dw.b"], pk[p + "dw.s"], pk[p + "dw.h"])
+            E.dwconv_nhwc(cur, tmp, B, H, W, dim, _keff(k), pk[p + "dw.w"], pk[p + "dw.b"], pk[p + "dw.s"], pk[p + "dw.h"])
             E.gemm(tmp, pk[p + "pw.w"], cur, rows, dim, dim, bias=pk[p + "pw.b"], act=N.ACT_GELU, cscale=pk[p + "pw.s"],
                    cshift=pk[p + "pw.h"], tag="convmixer_pw")
         pooled = ws.get("pooled", (B, dim))

@@ -192,6 +192,11 @@ def tiny_configs(ref):
                              pins=["layers.1.blocks.0"], oracle=lambda sd, x, kw: oracle.asmlp_forward(sd, x, shift_size=kw["shift_size"])),
         "convmixer": dict(ctor=cm.ConvMixer, kw=dict(dim=32, depth=2, kernel_size=5, patch_size=4, n_classes=10), hw=(32, 32),
                           pins=["blocks.0.0", "blocks.1.3"], oracle=lambda sd, x, kw: oracle.convmixer_forward(sd, x)),
+        # round 5: kernel sizes beyond 3/5/7/9 -- an EVEN one (padding="same" pads 1 before, 2 after) and 11 (conv_mixer.py:14,25 take any)
+        "convmixer_k4": dict(ctor=cm.ConvMixer, kw=dict(dim=16, depth=1, kernel_size=4, patch_size=4, n_classes=10), hw=(32, 32),
+                             pins=["blocks.0.0"], oracle=lambda sd, x, kw: oracle.convmixer_forward(sd, x)),
+        "convmixer_k11": dict(ctor=cm.ConvMixer, kw=dict(dim=16, depth=1, kernel_size=11, patch_size=4, n_classes=10), hw=(32, 32),
+                              pins=["blocks.0.0"], oracle=lambda sd, x, kw: oracle.convmixer_forward(sd, x)),
         # SURVEY.md 8(f) rank 2
         "sparsemlp": dict(ctor=ref["sparse_mlp"].SparseMLP, kw=dict(image_size=64, patch_size=4, d_model=16, depth=[1, 2, 1], expansion_factor=2, num_classes=10),
                           hw=(64, 64), pins=["layers.0.model.0", "layers.1.model.1"], oracle=lambda sd, x, kw: oracle.sparsemlp_forward(sd, x)),

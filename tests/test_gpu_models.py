@@ -113,7 +113,7 @@ def build_from_tiny(pkg, name):
 
 
 TINY_TOKEN = ["mixer", "mixer_nonsquare", "gmlp", "resmlp", "vip_weighted", "vip_unweighted", "vip_rect", "s2mlpv2",
-              "s2mlpv2_cleanshift", "s2mlpv1", "asmlp", "convmixer", "sparsemlp", "sparsemlp_norm", "hiremlp", "hiremlp_rect", "msmlp", "msmlp_s3", "swinmlp", "swinmlp_small", "cyclemlp", "cyclemlp_rect"]
+              "s2mlpv2_cleanshift", "s2mlpv1", "asmlp", "convmixer", "convmixer_k4", "convmixer_k11", "sparsemlp", "sparsemlp_norm", "hiremlp", "hiremlp_rect", "msmlp", "msmlp_s3", "swinmlp", "swinmlp_small", "cyclemlp", "cyclemlp_rect"]
 
 
 @pytest.mark.parametrize("name", TINY_TOKEN)
