@@ -56,6 +56,7 @@
  *   mlpk_split_apply    attention * x_all summed over k (vip.py:54-56), shifts applied on load
  *   mlpk_vip_split_apply  the weighted sum with the inverse ViP rearranges (vip.py:71,76) as load addresses (8 x 8 pixel tiles staged in
  *                       LDS); the reduction of ViP's SplitAttention needs no pass at all: mlpk_norm_desc.sum_ph / sum_pw + linearity
+ *   mlpk_vip_branch     LayerNorm + rearrange + Linear of ViP's h / w branch in ONE kernel, the rearrange as LDS staging order (vip.py:66-76)
  *   mlpk_s2_shift       Spatial_Shift (s2_mlp_v1.py:19-25), out of place
  *   mlpk_dwconv_nhwc    depthwise Conv2d(k, groups=dim, padding="same") + GELU + BatchNorm(eval) + residual:
  *                       conv_mixer.py:5-11,24-28
@@ -447,6 +448,18 @@ int mlpk_split_apply(int dtype, const void* x0, const void* x1, const void* x2, 
  *   xc row-major (B*H*W, ldc).  16-bit dtypes, C % 8 == 0, seg % 4 == 0, ldh % 4 == ldw % 4 == 0. */
 int mlpk_vip_split_apply(int dtype, const void* zh, const void* zw, const void* xc, int ldh, int ldw, int ldc, int B, int H,
                          int W, int C, int seg, const float* bar, void* out, int ldo, void* stream);
+/* ABI 9 (round 5).  One branch of ViP's WeightedPermuteMLP in ONE kernel -- LayerNorm + einops rearrange + Linear (vip.py:66-76):
+ *   out[((b*O + o)*G + g)*ldz + n] = bias[n] + sum_{l,j} w[n*ldw + l*seg + j] * LN(x)[b, pixel(o, l), g*seg + j]
+ * which = 0: the h branch (o = w, l = h: 'b h w (c s) -> b w c (h s)'), 1: the w branch (o = h, l = w); G = C / seg, N = K = L*seg.
+ * The rearranged operand is staged in LDS in operand order and multiplied where it lies: no rearranged tensor in HBM (what
+ * mlpk_norm_apply(out_ph / out_pw) + mlpk_gemm_nt moved: 2 x the activation per branch), bit-equal to that pair.  mean / rstd: the
+ * LayerNorm statistics per pixel; sums (optional): sums[(b*G + g)*ld_sum + o*seg + j] = sum over l of the rounded LN(x) -- the by-product
+ * SplitAttention's linearity trick reads (mlpk_norm_desc.sum_ph / sum_pw).  16-bit dtypes; C / seg == 32, seg % 4 == 0, K in {128, 256, 384}
+ * (mlpk_vip_branch_supported). */
+int mlpk_vip_branch_supported(int dtype, int H, int W, int C, int seg, int which);
+int mlpk_vip_branch(int dtype, const void* x, int ldx, int B, int H, int W, int C, int seg, int which, const float* mean, const float* rstd,
+                    const float* gamma, const float* beta, const void* w, int ldw, const float* bias, void* out, int ldz, float* sums, int ld_sum,
+                    void* stream);
 /* S2-MLPv1 Spatial_Shift on (B,H,W,C), out of place, same shift_mode values (NONE = copy). */
 int mlpk_s2_shift(int dtype, const void* in, void* out, int B, int H, int W, int C, int ldi,
                   int ldo, int shift_mode, void* stream);

@@ -71,6 +71,9 @@ PROTOTYPES = {
     "mlpk_pool_mean": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                c_void_p, c_void_p, c_int, c_void_p]),
     "mlpk_shift_nchw": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "mlpk_vip_branch_supported": (c_int, [c_int] * 6),
+    "mlpk_vip_branch": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "mlpk_shift_nchw_backward": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "mlpk_gelu_elementwise": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_void_p]),
     "mlpk_layernorm_backward_blocks": (c_int, [c_i64]),

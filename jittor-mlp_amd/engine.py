@@ -511,6 +511,18 @@ def vip_unpermute(which, z, out, B, H, W, C, seg, ldz):
             "mlpk_vip_unpermute")
 
 
+def vip_branch_supported(dtype, H, W, C, seg):
+    """mlpk_vip_branch for BOTH branches of a ViP block (MLPK_VIP_BRANCH=0: the two-kernel path, A/B aid)"""
+    return (dtype in (torch.float16, torch.bfloat16) and os.environ.get("MLPK_VIP_BRANCH", "1") != "0"
+            and bool(N.lib().mlpk_vip_branch_supported(dtype_code(dtype), H, W, C, seg, 0))
+            and bool(N.lib().mlpk_vip_branch_supported(dtype_code(dtype), H, W, C, seg, 1)))
+
+
+def vip_branch(which, x, ldx, B, H, W, C, seg, mean, rstd, gamma, beta, w, bias, out, ldz, sums=None, ld_sum=0):
+    N.check(N.lib().mlpk_vip_branch(dtype_code(x.dtype), ptr(x), ldx, B, H, W, C, seg, which, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(w), w.stride(0),
+                                    ptr(bias), ptr(out), ldz, ptr(sums), ld_sum, stream()), "mlpk_vip_branch")
+
+
 def pool_mean(x, B, S, C, ldx, out, ldo, *, mean=None, rstd=None, stat_group=1, gamma=None, beta=None):
     N.check(N.lib().mlpk_pool_mean(dtype_code(x.dtype), ptr(x), B, S, C, ldx, ptr(mean), ptr(rstd), stat_group,
                                    ptr(gamma), ptr(beta), ptr(out), ldo, stream()), "mlpk_pool_mean")

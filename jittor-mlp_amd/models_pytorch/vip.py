@@ -11,6 +11,7 @@ slab staged through LDS, so the einops copies of the reference become coalesced 
 three NT GEMMs; the inverse rearranges; split attention as reduce -> two tiny fp32 GEMMs ->
 softmax -> weighted apply; projection GEMM with the residual in its epilogue.
 """
+import contextlib
 import torch
 from torch import nn
 
@@ -198,8 +199,6 @@ class _PermutatorBase(E.EngineModule):
             mean, rstd = nxt if nxt is not None else layernorm_stats(ws, x, rows, C)
             cfold = (p + "c.csum") in pk
             xn = None if cfold else ws.get("vip.xn", (rows, C))
-            ph = ws.get("vip.ph", (B * W * G, ldh))
-            pw = ws.get("vip.pw", (B * H * G, ldw))
             # the 16-byte rearrange path (and its by-product sums) also needs its LDS slab to fit: (C / seg) rows of ld_p elements
             # (+ 32 bytes of padding) + gamma / beta -- mlpk_norm_apply's own condition, asked here so that a configuration it cannot
             # take (very tall maps) falls back to the unfused split attention instead of failing
@@ -209,11 +208,28 @@ class _PermutatorBase(E.EngineModule):
             lin = fused and self.weighted
             # by-product sums of the two rearrange passes, side by side: [sum_w x^ as rows (b, g) x columns (h, j) | sum_h x^ ... (w, j)]
             asum = ws.get("sa.sums", (B * G, ldh + ldw), torch.float32) if lin else None
-            E.norm_apply(x, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "ln.g"], beta=pk[p + "ln.b"], out_rm=xn, ld_rm=C,
-                         out_ph=ph, H=H, W=W, seg=seg, ld_p=ldh, sum_ph=asum[:, ldh:] if lin else None, ld_sum=ldh + ldw)
-            E.norm_apply(x, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "ln.g"], beta=pk[p + "ln.b"],
-                         out_pw=pw, H=H, W=W, seg=seg, ld_p=ldw, sum_pw=asum, ld_sum=ldh + ldw)
-            bar = None
+            ldzh, ldzw = E.round_up(hs, 8), E.round_up(wsz, 8)
+            zh = ws.get("vip.zh", (B * W * G, ldzh))
+            zw = ws.get("vip.zw", (B * H * G, ldzw))
+            # round 5: LayerNorm + rearrange + the branch Linear in ONE kernel per branch (mlpk_vip_branch): the rearranged operand is
+            # staged in LDS in operand order and multiplied where it lies -- `ph` / `pw` (2 x 201 MB written and read back per block at
+            # ViP-S7 / 256 images) do not exist; bit-equal to the two-kernel path below, which stays for the shapes the kernel does not take
+            branch = fused and E.vip_branch_supported(x.dtype, H, W, C, seg)
+            if branch:
+                E.vip_branch(0, x, C, B, H, W, C, seg, mean, rstd, pk[p + "ln.g"], pk[p + "ln.b"], pk[p + "h.w"], pk[p + "h.b"], zh, ldzh,
+                             sums=asum[:, ldh:] if lin else None, ld_sum=ldh + ldw)
+                E.vip_branch(1, x, C, B, H, W, C, seg, mean, rstd, pk[p + "ln.g"], pk[p + "ln.b"], pk[p + "w.w"], pk[p + "w.b"], zw, ldzw,
+                             sums=asum if lin else None, ld_sum=ldh + ldw)
+                if xn is not None:
+                    E.norm_apply(x, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "ln.g"], beta=pk[p + "ln.b"], out_rm=xn, ld_rm=C)
+            else:
+                ph = ws.get("vip.ph", (B * W * G, ldh))
+                pw = ws.get("vip.pw", (B * H * G, ldw))
+                E.norm_apply(x, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "ln.g"], beta=pk[p + "ln.b"], out_rm=xn, ld_rm=C,
+                             out_ph=ph, H=H, W=W, seg=seg, ld_p=ldh, sum_ph=asum[:, ldh:] if lin else None, ld_sum=ldh + ldw)
+                E.norm_apply(x, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "ln.g"], beta=pk[p + "ln.b"],
+                             out_pw=pw, H=H, W=W, seg=seg, ld_p=ldw, sum_pw=asum, ld_sum=ldh + ldw)
+            bar, inline = None, False
             if lin:
                 # SplitAttention's weights from the by-product sums: two tiny fp32 GEMMs instead of a 600 MB pass over the three
                 # branch outputs, then mlp2 + softmax.  Four latency-bound kernels (~80 us in a row on a few CUs) that depend only
@@ -225,17 +241,21 @@ class _PermutatorBase(E.EngineModule):
                 o = ws.get("sa.o", (B * G, 2 * seg), torch.float32)
                 hat = ws.get("sa.hat", (B, 3 * C), torch.float32)
                 bar = ws.get("sa.bar", (B, 3 * C), torch.float32)
-                chain = E.SideChain(ws, "sa", x.device)
+                # round 5: with the one-kernel branches the sums exist only after BOTH branch kernels, and what is left beside the chain is one
+                # GEMM -- shorter than the chain of three 64 x 64-tile products (25 - 75 us each on a few CUs): it runs IN LINE on the skinny
+                # fp32 kernel (algo 16: ~25 us per product on the whole chip) instead; same-box: 28.5 ms with the side stream, 27.5 - 27.9
+                # in line, 28.8 - 29.6 for the two-kernel branches (profiles/r05_vip_branch_ab.txt)
+                inline = branch and B * G <= 16384 and (ldh + ldw) % 16 == 0 and (G * 2 * seg) % 16 == 0 and C % 16 == 0     # what algo 16 takes
+                sk = dict(algo=16) if inline else {}
+                chain = contextlib.nullcontext() if inline else E.SideChain(ws, "sa", x.device)
                 with chain:
-                    E.gemm(asum, pk[p + "sa.w1"], o, B * G, 2 * seg, ldh + ldw, bias=pk[p + "sa.b1"])
-                    E.gemm(o.view(B, G * 2 * seg), pk[p + "sa.m1w2"], t, B, C, G * 2 * seg, bias=pk[p + "sa.m1b"], act=N.ACT_GELU)
-                    E.gemm(t, pk[p + "sa.m2"], hat, B, 3 * C, C)
+                    E.gemm(asum, pk[p + "sa.w1"], o, B * G, 2 * seg, ldh + ldw, bias=pk[p + "sa.b1"], **sk)
+                    E.gemm(o.view(B, G * 2 * seg), pk[p + "sa.m1w2"], t, B, C, G * 2 * seg, bias=pk[p + "sa.m1b"], act=N.ACT_GELU, **sk)
+                    E.gemm(t, pk[p + "sa.m2"], hat, B, 3 * C, C, **sk)
                     E.split_softmax(hat, bar, B, C)
-            ldzh, ldzw = E.round_up(hs, 8), E.round_up(wsz, 8)
-            zh = ws.get("vip.zh", (B * W * G, ldzh))
-            zw = ws.get("vip.zw", (B * H * G, ldzw))
-            E.gemm(ph, pk[p + "h.w"], zh, B * W * G, hs, ldh, bias=pk[p + "h.b"], tag="vip_h")
-            E.gemm(pw, pk[p + "w.w"], zw, B * H * G, wsz, ldw, bias=pk[p + "w.b"], tag="vip_w")
+            if not branch:
+                E.gemm(ph, pk[p + "h.w"], zh, B * W * G, hs, ldh, bias=pk[p + "h.b"], tag="vip_h")
+                E.gemm(pw, pk[p + "w.w"], zw, B * H * G, wsz, ldw, bias=pk[p + "w.b"], tag="vip_w")
             xc = ws.get("vip.xc", (rows, C))
             if cfold:
                 E.gemm(x, pk[p + "c.wf"], xc, rows, C, C, bias=pk[p + "c.bf"], ln=(mean, rstd, pk[p + "c.csum"]), tag="vip_c")
@@ -246,7 +266,8 @@ class _PermutatorBase(E.EngineModule):
                 # the inverse rearranges (vip.py:71,76) are load addresses of the split-attention kernels: xH / xW are never
                 # written back in (B,H,W,C) order (two full-tensor passes per block fewer)
                 if self.weighted:
-                    chain.join()
+                    if not inline:
+                        chain.join()
                 else:
                     bar = ws.get("vip.ones", (B, 3 * C), torch.float32, fill=1.0)     # plain sum (vip.py:16-22)
                 E.vip_split_apply(zh, zw, xc, ldzh, ldzw, C, B, H, W, C, seg, bar, m, C)

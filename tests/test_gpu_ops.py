@@ -1729,3 +1729,51 @@ def test_short_k_linear_gelu_with_resident_rows(dtype):
     assert not E.linear_gelu_supported(dtype, 250, 256, 512) and not E.linear_gelu_supported(dtype, 256, 320, 512) and not E.linear_gelu_supported(dtype, 256, 256, 8192)
     del os.environ["MLPK_LINEAR_GELU"]
     assert not E.linear_gelu_supported(dtype, 256, 256, 512)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_vip_branch_in_one_kernel_is_bit_equal_to_rearrange_plus_gemm(dtype):
+    """mlpk_vip_branch (round 5): LayerNorm + einops rearrange + the branch Linear of ViP's WeightedPermuteMLP (vip.py:66-76) in ONE kernel,
+    the rearrange as the LDS staging order.  BIT-EQUAL -- outputs and the by-product sums -- to the two-kernel path it replaces
+    (mlpk_norm_apply writing the rearranged operand + mlpk_gemm_nt), which the einops pins of ops.npz and the model goldens hold to the
+    reference; ViP-S7's geometry (32 x 32 pixels, 384 channels in 32 groups of 12) with a ragged number of slabs per workgroup, and a
+    rectangular map with K = 128 / 256."""
+    pkg = load_pkg()
+    E = pkg.engine
+    for ci, (B_, H, W, C, seg) in enumerate([(3, 32, 32, 384, 12), (2, 16, 32, 256, 8), (5, 32, 32, 384, 12)]):
+        G = C // seg
+        rows = B_ * H * W
+        x = (rnd((rows, C), dtype, 2100 + ci) * 1.7 + 0.2).to(dtype).to(dev())
+        gamma = (rnd((C,), torch.float32, 2110 + ci) * 0.3 + 1.0).to(dev())
+        beta = (rnd((C,), torch.float32, 2120 + ci) * 0.2).to(dev())
+        mean = torch.empty((rows,), dtype=torch.float32, device=dev())
+        rstd = torch.empty_like(mean)
+        E.row_stats(x, rows, C, C, mean, rstd)
+        assert E.vip_branch_supported(dtype, H, W, C, seg)
+        for which, L, O in ((0, H, W), (1, W, H)):
+            K = L * seg
+            w = rnd((K, K), dtype, 2130 + 2 * ci + which, 1.0 / math.sqrt(K)).to(dev())
+            bias = (rnd((K,), torch.float32, 2140 + 2 * ci + which) * 0.3).to(dev())
+            ldp = E.round_up(K, 32)
+            assert ldp == K
+            perm = torch.full((B_ * O * G, ldp), float("nan"), dtype=dtype, device=dev())
+            s_old = torch.zeros((B_ * G, O * seg), dtype=torch.float32, device=dev())
+            kw = dict(out_ph=perm, sum_ph=s_old) if which == 0 else dict(out_pw=perm, sum_pw=s_old)
+            E.norm_apply(x, rows, C, C, mean=mean, rstd=rstd, gamma=gamma, beta=beta, H=H, W=W, seg=seg, ld_p=ldp, ld_sum=O * seg, **kw)
+            z_old = torch.full((B_ * O * G, K), float("nan"), dtype=dtype, device=dev())
+            E.gemm(perm, w, z_old, B_ * O * G, K, K, bias=bias)
+            z_new = torch.full((B_ * O * G, K), float("nan"), dtype=dtype, device=dev())
+            s_new = torch.full((B_ * G, O * seg), float("nan"), dtype=torch.float32, device=dev())
+            E.vip_branch(which, x, C, B_, H, W, C, seg, mean, rstd, gamma, beta, w, bias, z_new, K, sums=s_new, ld_sum=O * seg)
+            z_nosum = torch.full((B_ * O * G, K), float("nan"), dtype=dtype, device=dev())
+            E.vip_branch(which, x, C, B_, H, W, C, seg, mean, rstd, gamma, beta, w, bias, z_nosum, K)
+            torch.cuda.synchronize()
+            assert torch.isfinite(z_new.float()).all()
+            assert torch.equal(z_new.view(torch.int16), z_old.view(torch.int16)), (str(dtype), ci, which, (z_new.float() - z_old.float()).abs().max().item())
+            assert torch.equal(z_new, z_nosum)
+            assert torch.equal(s_new, s_old), (str(dtype), ci, which)
+    # shapes it does not take: refused by the query, and by the call
+    assert not E.vip_branch_supported(dtype, 4, 4, 32, 8) and not E.vip_branch_supported(dtype, 32, 32, 384, 16)
+    with pytest.raises(RuntimeError):
+        E.vip_branch(0, x, C, B_, 7, 32, C, seg, mean, rstd, gamma, beta, w, bias, z_new, K)
