@@ -98,6 +98,7 @@ constexpr int TM_LDS = TM_B2 + 16 * (TM_NB0 + TM_NB1) * 4;
 enum { TM_RAMP = 0, TM_STEADY = 1, TM_DRAIN = 2, TM_LAST = 3 };   // LAST = the DRAIN iteration that requests the residual tile
 template <int M> struct ModeC { static constexpr int value = M; };
 template <bool B> struct BoolC { static constexpr bool value = B; };
+template <int I> struct IntC { static constexpr int value = I; };
 
 // A wave issues at most one instruction per ~4 cycles, so the loop bodies below are written for instruction
 // count: the steady-state iterations are branch-free instantiations (STEADY), the two ramp-up and two drain
@@ -1095,6 +1096,316 @@ __global__ void __launch_bounds__(512, 1) token_gemm_kernel(const TokenGemmArgs 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no LDS-DMA may outlive the workgroup
 }
 
+// ====================================================================================================================
+// Round 5 -- mlpk_token_gemm_ln as a software pipeline across tiles (G >= 3 groups, even S: gMLP / ResMLP at 196 tokens).
+// The kernel above waits `vmcnt(0)` at the top of every iteration, builds a tile's operand in seven dependent load -> normalise ->
+// transpose steps, and spends one iteration per tile on draining the last group.  Here
+//   * the iterations of a workgroup's tiles form ONE sequence i = 0 .. n (n = tiles x G): iteration i sends group i - 1 out (possibly the
+//     previous tile's last one), requests the gate / residual values of group i (used one iteration later) and the weights of group
+//     i + 2 (three-stage ring), and multiplies group i -- no per-tile drain iteration;
+//   * the NEXT tile's x rows (+ their statistics) are requested at the first iteration of a tile, all 14 + 14 loads at once, and turned into
+//     MFMA operands at the first iteration of their own tile, G iterations later;
+//   * every load of the loop is issued by `asm volatile` and waited for by a COUNTED `s_waitcnt vmcnt(N)`, N = the loads issued AFTER the
+//     ones the iteration needs (vector-memory operations retire in order, so "at most N outstanding" = everything older has landed;
+//     the stores, which the compiler may skip for a wave without live items, are older than the loads of their iteration and never
+//     counted).  An asm load's destination is not touched until the wait that covers it (each use is behind a "+v" no-op asm after
+//     the wait); tools/isa_lint.py `inflight` (tests/test_host_cpu.py) scans the built ISA for a compiler instruction on such a
+//     register in between -- two R register sets selected by the iteration's parity failed exactly that check.
+// gamma / beta / rscale come from LDS tables (filled once per workgroup), so the loop has no compiler-visible load at all.
+// Measured (profiles/r05_token_gemm_pipe_ab.txt): ResMLP-24 5.40 -> 5.20 ms, gMLP-S 9.38 -> 9.32 ms same-box; gMLP's call moves 462 MB
+// (u, v: 308 MB in, 154 MB out at 256 images) in 119 us = 3.9 TB/s either way -- that one is bound by the bytes, not by the waits.
+// LDS: 48 (W ring) + 64 (staging) + 1 (bias) + 20 (transposes) + 24 (tables) = 157 KiB.
+constexpr int T5_TMAX = 2048;                          // channels per image / rscale period the tables hold
+constexpr int T5_R1 = 0;
+constexpr int T5_STG = 3 * TM_STAGE;
+constexpr int T5_B = T5_STG + 2 * 32768;
+constexpr int T5_XT = T5_B + 256 * 4;
+constexpr int T5_TAB = T5_XT + 8 * 32 * T3_XT_PITCH;
+constexpr int T5_LDS = T5_TAB + 3 * T5_TMAX * 4;
+static_assert(T5_LDS <= 160 * 1024, "LDS budget");
+
+__device__ __forceinline__ u32x4 tg_load16(const void* ptr) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+__device__ __forceinline__ f32x2 tg_load8(const void* ptr) {
+    f32x2 v;
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+// n = number of asm loads issued after the ones that must have landed (wave-uniform; one of the sums the loop can produce)
+__device__ __forceinline__ void tg_wait(const int n) {
+    switch (n) {
+        case 30: asm volatile("s_waitcnt vmcnt(30) lgkmcnt(0)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory"); break;
+        case 28: asm volatile("s_waitcnt vmcnt(28) lgkmcnt(0)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+    }
+}
+
+template <typename T, int RES, int LNL>
+__global__ void __launch_bounds__(512, 1) token_gemm_pipe_kernel(const TokenGemmArgs p) {
+    static_assert(LNL == 1 || LNL == 2, "operand-loader variants only");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const T* __restrict__ w = reinterpret_cast<const T*>(p.w);
+    const T* __restrict__ Rp = reinterpret_cast<const T*>(LNL == 2 ? p.x : p.R);
+    const int ldr = LNL == 2 ? p.ldx : p.ldr;
+    T* __restrict__ out = reinterpret_cast<T*>(p.out);
+    const int G = p.G;
+    const int ks1 = p.ks1;
+    const int ntiles = (p.M + T3_BM - 1) / T3_BM;
+    const int mine = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;       // (grid <= tiles: >= 1)
+    const int n = mine * G;
+    const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)smem;
+    float* const bs = reinterpret_cast<float*>(smem + T5_B);
+    float* const tgam = reinterpret_cast<float*>(smem + T5_TAB);
+    float* const tbet = tgam + T5_TMAX;
+    float* const trs = tbet + T5_TMAX;
+    for (int i = tid; i < 256; i += 512) bs[i] = (p.bias && i < G * 32) ? p.bias[i] : 0.f;
+    for (int i = tid; i < p.t_rows; i += 512) { tgam[i] = p.gamma[i]; tbet[i] = p.beta[i]; }
+    // (no rscale: rperiod = 1 and items index trs[0 .. 7])
+    for (int i = tid; i < (p.rscale ? p.rperiod : 8); i += 512) trs[i] = p.rscale ? p.rscale[i] : 1.f;
+    const bool has_ln = p.ln_mean != nullptr;
+    const int nx = has_ln ? 28 : 14;                       // asm loads of one x request
+
+    auto lane_now = [&]() {
+        unsigned l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return (int)l;
+    };
+    auto issue_w = [&](const int g, const unsigned stage, const int ln) {
+        const T* base = w + (size_t)__builtin_amdgcn_readfirstlane(g) * (32 * 256);      // (the asm's scalar operand)
+        const int lrow = ln >> 2;
+        const int lchunk = (ln & 3) ^ ((lrow & 8) >> 2);
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) {
+            int q = wave * 2 + pi;
+            q = q < 14 ? q : 13;
+            const unsigned off = (unsigned)(((q & 1) * 16 + lrow) * 256 + (q >> 1) * 32 + lchunk * 8) * (unsigned)sizeof(T);
+            tm_glds(off, base, __builtin_amdgcn_readfirstlane(lds_base + T5_R1 + stage * TM_STAGE + q * 1024));
+        }
+    };
+
+    // ---- the operand: this wave's 32 channels of one image, all tokens
+    u32x4 xa[2][TM_KMAX];
+    u32x4 raw[TM_KMAX][2];
+    f32x2 mu[TM_KMAX], rs[TM_KMAX];                        // (S is even: the statistics of a lane's token pair are one 8-byte load)
+    auto x_origin = [&](const int tile, int& b, int& c0) {
+        int m0w = tile * T3_BM + wave * 32;
+        m0w = m0w < p.M ? m0w : p.M - 32;
+        b = m0w / p.t_rows;
+        c0 = m0w - b * p.t_rows;
+    };
+    auto request_x = [&](const int tile, const int ln) {       // nx asm loads
+        int b, c0;
+        x_origin(tile, b, c0);
+        const int pr = ln >> 2, q = ln & 3;
+        const T* xr = reinterpret_cast<const T*>(p.x) + (size_t)b * p.S * p.ldx + c0 + q * 8;
+        const float* mr_ = p.ln_mean + (size_t)b * p.S;
+        const float* rr_ = p.ln_rstd + (size_t)b * p.S;
+#pragma unroll
+        for (int kk = 0; kk < TM_KMAX; ++kk) {
+            int s0 = (kk < ks1 ? kk : ks1 - 1) * 32 + pr * 2;
+            s0 = s0 < p.S ? s0 : p.S - 2;                       // (pairs past S: valid memory, zeroed in finish_x)
+            raw[kk][0] = tg_load16(xr + (size_t)s0 * p.ldx);
+            raw[kk][1] = tg_load16(xr + (size_t)(s0 + 1) * p.ldx);
+            if (has_ln) {
+                mu[kk] = tg_load8(mr_ + s0);
+                rs[kk] = tg_load8(rr_ + s0);
+            }
+        }
+    };
+    auto finish_x = [&](const int tile, const int ln) {         // (after the wait that covers the request)
+        int b, c0;
+        x_origin(tile, b, c0);
+        const int frow = ln & 15, fg = ln >> 4;
+        const int pr = ln >> 2, q = ln & 3;
+        float ga[8], be[8];
+        {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(tgam + c0 + q * 8), g1 = *reinterpret_cast<const f32x4*>(tgam + c0 + q * 8 + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(tbet + c0 + q * 8), b1 = *reinterpret_cast<const f32x4*>(tbet + c0 + q * 8 + 4);
+            ga[0] = g0.x; ga[1] = g0.y; ga[2] = g0.z; ga[3] = g0.w; ga[4] = g1.x; ga[5] = g1.y; ga[6] = g1.z; ga[7] = g1.w;
+            be[0] = b0.x; be[1] = b0.y; be[2] = b0.z; be[3] = b0.w; be[4] = b1.x; be[5] = b1.y; be[6] = b1.z; be[7] = b1.w;
+        }
+        char* const xt_w = smem + T5_XT + wave * (32 * T3_XT_PITCH);
+#pragma unroll
+        for (int kk = 0; kk < TM_KMAX; ++kk) {
+            float y[2][8];
+            asm volatile("" : "+v"(raw[kk][0]), "+v"(raw[kk][1]));
+            f32x2 m2 = {0.f, 0.f}, r2 = {1.f, 1.f};
+            if (has_ln) {
+                asm volatile("" : "+v"(mu[kk]), "+v"(rs[kk]));
+                m2 = mu[kk]; r2 = rs[kk];
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float m_ = h ? m2.y : m2.x, r_ = h ? r2.y : r2.x;
+                T e8[8];
+                __builtin_memcpy(e8, &raw[kk][h], 16);
+                const bool live = kk < ks1 && kk * 32 + pr * 2 + h < p.S;
+                const float nm = -m_ * r_;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = __builtin_fmaf(__builtin_fmaf(to_f32(e8[e]), r_, nm), ga[e], be[e]);
+                    y[h][e] = live ? v : 0.f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                T pk2[2] = {from_f32<T>(y[0][e]), from_f32<T>(y[1][e])};
+                unsigned wv;
+                __builtin_memcpy(&wv, pk2, 4);
+                *reinterpret_cast<unsigned*>(xt_w + (q * 8 + e) * T3_XT_PITCH + pr * 4) = wv;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 2; ++i) xa[i][kk] = *reinterpret_cast<const u32x4*>(xt_w + (i * 16 + frow) * T3_XT_PITCH + fg * 16);
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+
+    // ---- reader items: (token slot wave * 2 + (lane >> 5) (+16), channels (lane & 31) * 8 .. + 7 of the tile's 256)
+    struct RG { int rimg, rcc, rso; bool ok; };
+    auto rgeo = [&](const int tile, const int rc) {
+        RG r;
+        const int mr = tile * T3_BM + rc * 8;
+        r.ok = mr < p.M;
+        const int mc = r.ok ? mr : 0;
+        r.rimg = mc / p.t_rows;
+        r.rcc = mc - r.rimg * p.t_rows;
+        r.rso = p.rscale ? mc % p.rperiod : 0;
+        return r;
+    };
+    // R values of ONE group: requested right after the previous group's values were used, one iteration ahead of their own use (two
+    // register sets selected by the iteration's parity -- a branch, or a loop unrolled by two -- made hipcc copy the set in flight around
+    // the branch, resp. run out of scalar registers: tools/isa_lint.py inflight)
+    u32x4 rv[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
+    // R values of group g of a tile (2 asm loads; dead items read a valid address and are not used)
+    auto request_r = [&](const RG& r, const int g, const int rt, u32x4 (&dst)[2]) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            int t = g * 32 + rt + 16 * k;
+            t = t < p.S ? t : p.S - 1;
+            dst[k] = tg_load16(Rp + ((size_t)r.rimg * p.S + t) * ldr + r.rcc);
+        }
+    };
+    auto leave = [&](const RG& r, const int g, const int rt, const int rc, u32x4 (&src)[2], const char* sb) {
+        asm volatile("" : "+v"(src[0]), "+v"(src[1]));
+        float rsc[8];
+        {
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(trs + r.rso), s1 = *reinterpret_cast<const f32x4*>(trs + r.rso + 4);
+            rsc[0] = s0.x; rsc[1] = s0.y; rsc[2] = s0.z; rsc[3] = s0.w; rsc[4] = s1.x; rsc[5] = s1.y; rsc[6] = s1.z; rsc[7] = s1.w;
+        }
+        float rga[LNL == 2 ? 8 : 1], rbe[LNL == 2 ? 8 : 1];
+        if constexpr (LNL == 2) {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(tgam + r.rcc), g1 = *reinterpret_cast<const f32x4*>(tgam + r.rcc + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(tbet + r.rcc), b1 = *reinterpret_cast<const f32x4*>(tbet + r.rcc + 4);
+            rga[0] = g0.x; rga[1] = g0.y; rga[2] = g0.z; rga[3] = g0.w; rga[4] = g1.x; rga[5] = g1.y; rga[6] = g1.z; rga[7] = g1.w;
+            rbe[0] = b0.x; rbe[1] = b0.y; rbe[2] = b0.z; rbe[3] = b0.w; rbe[4] = b1.x; rbe[5] = b1.y; rbe[6] = b1.z; rbe[7] = b1.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int slot = rt + 16 * k;
+            const int t = g * 32 + slot;
+            if (t < p.S && r.ok) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(sb + slot * 1024 + (((2 * rc) ^ (slot & 15)) << 4));
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(sb + slot * 1024 + (((2 * rc + 1) ^ (slot & 15)) << 4));
+                const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                T r8[8], e[8];
+                __builtin_memcpy(r8, &src[k], 16);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    float y = v[q] * rsc[q];
+                    if constexpr (LNL == 2) y += to_f32(from_f32<T>(__builtin_fmaf(to_f32(r8[q]), rga[q], rbe[q])));
+                    else if constexpr (RES == MLPK_RES_ADD) y += to_f32(r8[q]);
+                    else if constexpr (RES == MLPK_RES_MUL) y *= to_f32(r8[q]);
+                    e[q] = from_f32<T>(y);
+                }
+                u32x4 o;
+                __builtin_memcpy(&o, e, 16);
+                *reinterpret_cast<u32x4*>(out + ((size_t)r.rimg * p.S + t) * p.ldo + r.rcc) = o;
+            }
+        }
+    };
+    constexpr bool NEEDS_R = LNL == 2 || RES != MLPK_RES_NONE;
+
+    __syncthreads();                                       // tables
+    int tile = blockIdx.x, g = 0;                          // of iteration i
+    RG gp, gc;                                             // reader geometry of the previous / current tile
+    {
+        const int ln = lane_now();
+        gc = rgeo(tile, ln & 31);
+        gp = gc;
+        issue_w(0, 0, ln);
+        issue_w(1, 1, ln);
+    }
+    int nprev = -1;                                        // asm loads issued after the previous iteration's R request (-1: wait for everything)
+    // Iteration -1 requests the first tile's x; iteration i >= 0 as described above.  (ONE copy of the request / operand code in the kernel:
+    // with a prologue copy and an unrolled pair of iterations the kernel ran out of scalar registers.)
+    for (int i = -1; i <= n; ++i) {
+        const unsigned par = (unsigned)i & 1u;
+        if (i >= 0) {
+            tg_wait(nprev);
+            TM_BARRIER();
+        }
+        const int ln = lane_now();
+        const int frow = ln & 15, fg = ln >> 4;
+        const int rt = wave * 2 + (ln >> 5), rc = ln & 31;
+        const bool more = i >= 0 && i < n;
+        const bool first = g == 0 && more;
+        // this tile's x (requested G iterations ago) -> operands; the last MFMA of the previous tile was issued before the barrier
+        if (first) finish_x(tile, ln);
+        // (1) group i - 1 leaves
+        if (i > 0) leave(g == 0 ? gp : gc, g == 0 ? G - 1 : g - 1, rt, rc, rv, smem + T5_STG + (par ^ 1u) * 32768);
+        // (2) requests: the R values of group i (the wait at the top of iteration i + 1 allows what follows them to stay in flight), the next
+        // tile's x, the weights of group i + 2
+        if (more && NEEDS_R) request_r(gc, g, rt, rv);
+        int after = 0;
+        const int xt_tile = i < 0 ? tile : tile + (int)gridDim.x;
+        if ((i < 0 || first) && xt_tile < ntiles) { request_x(xt_tile, ln); after += nx; }
+        if (i >= 0 && i + 2 < n) { issue_w(g + 2 >= G ? g + 2 - G : g + 2, (unsigned)((i + 2) % 3), ln); after += 2; }
+        nprev = i < 0 ? -1 : after;
+        // (3) the MFMAs of group i, (4) its accumulators (+ bias) staged
+        if (more) {
+            const char* r1 = smem + T5_R1 + (i % 3) * TM_STAGE;
+            const int f_rd = frow * 64 + ((fg ^ ((frow & 8) >> 2)) << 4);
+            f32x4 acc[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < TM_KMAX; ++kk) {
+                const u32x4 bw0 = *reinterpret_cast<const u32x4*>(r1 + kk * 2048 + f_rd);
+                const u32x4 bw1 = *reinterpret_cast<const u32x4*>(r1 + kk * 2048 + f_rd + 1024);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    acc[a][0] = Mma2<T>::run(xa[a][kk], bw0, acc[a][0]);
+                    acc[a][1] = Mma2<T>::run(xa[a][kk], bw1, acc[a][1]);
+                }
+            }
+            char* const sw = smem + T5_STG + par * 32768;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float bn = bs[g * 32 + j * 16 + frow];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const f32x4 v = {acc[a][j].x + bn, acc[a][j].y + bn, acc[a][j].z + bn, acc[a][j].w + bn};
+                    *reinterpret_cast<f32x4*>(sw + (j * 16 + frow) * 1024 + (((wave * 8 + a * 4 + fg) ^ frow) << 4)) = v;
+                }
+            }
+            if (++g == G) { g = 0; tile += gridDim.x; gp = gc; gc = rgeo(tile, rc); }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 static unsigned long long* g_tm_dbg = nullptr;
 
 static int tm_grid_cap() {
@@ -1246,6 +1557,29 @@ static int token_gemm_launch(int dtype, TokenGemmArgs& a, int res_mode, int lnl,
     }
 #define TG_RES(TT, LL)                                                                                                 \
     if (res_mode == MLPK_RES_ADD) TG_LAUNCH(TT, MLPK_RES_ADD, LL) else if (res_mode == MLPK_RES_MUL) TG_LAUNCH(TT, MLPK_RES_MUL, LL) else TG_LAUNCH(TT, MLPK_RES_NONE, LL)
+    // round 5: the operand-loader variants with >= 3 groups run as the two-iterations-deep pipeline (MLPK_TOKEN_GEMM_PIPE=0: the kernel above, A/B aid)
+    static const bool pipe_on = !(getenv("MLPK_TOKEN_GEMM_PIPE") && atoi(getenv("MLPK_TOKEN_GEMM_PIPE")) == 0);
+    if (lnl && pipe_on && a.G >= 3 && a.S % 2 == 0 && a.t_rows <= T5_TMAX && (!a.rscale || (a.rperiod % 8 == 0 && a.rperiod <= T5_TMAX)) &&
+        !(((uintptr_t)a.ln_mean | (uintptr_t)a.ln_rstd) & 7)) {      // (the statistics of a token pair are one 8-byte load)
+#define TP_LAUNCH(TT, RR, LL)                                                                                          \
+    {                                                                                                                   \
+        auto k = token_gemm_pipe_kernel<TT, RR, LL>;                                                                    \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, T5_LDS); \
+        if (e != hipSuccess) return (int)e;                                                                             \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(512), T5_LDS, s, a);                                                     \
+    }
+#define TP_RES(TT)                                                                                                     \
+    if (res_mode == MLPK_RES_ADD) TP_LAUNCH(TT, MLPK_RES_ADD, 1) else if (res_mode == MLPK_RES_MUL) TP_LAUNCH(TT, MLPK_RES_MUL, 1) else TP_LAUNCH(TT, MLPK_RES_NONE, 1)
+        if (dtype == MLPK_BF16) {
+            if (lnl == 2) TP_LAUNCH(bf16_t, MLPK_RES_ADD, 2) else { TP_RES(bf16_t) }
+        } else {
+            if (lnl == 2) TP_LAUNCH(f16_t, MLPK_RES_ADD, 2) else { TP_RES(f16_t) }
+        }
+#undef TP_RES
+#undef TP_LAUNCH
+        MLPK_LAUNCH_CHECK();
+        return 0;
+    }
     if (dtype == MLPK_BF16) {
         if (lnl == 2) TG_LAUNCH(bf16_t, MLPK_RES_ADD, 2) else if (lnl) { TG_RES(bf16_t, 1) } else { TG_RES(bf16_t, 0) }
     } else {

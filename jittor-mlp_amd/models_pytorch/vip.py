@@ -12,6 +12,7 @@ three NT GEMMs; the inverse rearranges; split attention as reduce -> two tiny fp
 softmax -> weighted apply; projection GEMM with the residual in its epilogue.
 """
 import contextlib
+import os
 import torch
 from torch import nn
 
@@ -229,7 +230,7 @@ class _PermutatorBase(E.EngineModule):
                              out_ph=ph, H=H, W=W, seg=seg, ld_p=ldh, sum_ph=asum[:, ldh:] if lin else None, ld_sum=ldh + ldw)
                 E.norm_apply(x, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "ln.g"], beta=pk[p + "ln.b"],
                              out_pw=pw, H=H, W=W, seg=seg, ld_p=ldw, sum_pw=asum, ld_sum=ldh + ldw)
-            bar, inline = None, False
+            bar, inline, side = None, False, False
             if lin:
                 # SplitAttention's weights from the by-product sums: two tiny fp32 GEMMs instead of a 600 MB pass over the three
                 # branch outputs, then mlp2 + softmax.  Four latency-bound kernels (~80 us in a row on a few CUs) that depend only
@@ -247,7 +248,8 @@ class _PermutatorBase(E.EngineModule):
                 # in line, 28.8 - 29.6 for the two-kernel branches (profiles/r05_vip_branch_ab.txt)
                 inline = branch and B * G <= 16384 and (ldh + ldw) % 16 == 0 and (G * 2 * seg) % 16 == 0 and C % 16 == 0     # what algo 16 takes
                 sk = dict(algo=16) if inline else {}
-                chain = contextlib.nullcontext() if inline else E.SideChain(ws, "sa", x.device)
+                side = not inline or os.environ.get("MLPK_VIP_CHAIN_SIDE") == "1"      # experiment: the skinny chain BESIDE the channel-branch GEMM
+                chain = E.SideChain(ws, "sa", x.device) if side else contextlib.nullcontext()
                 with chain:
                     E.gemm(asum, pk[p + "sa.w1"], o, B * G, 2 * seg, ldh + ldw, bias=pk[p + "sa.b1"], **sk)
                     E.gemm(o.view(B, G * 2 * seg), pk[p + "sa.m1w2"], t, B, C, G * 2 * seg, bias=pk[p + "sa.m1b"], act=N.ACT_GELU, **sk)
@@ -266,7 +268,7 @@ class _PermutatorBase(E.EngineModule):
                 # the inverse rearranges (vip.py:71,76) are load addresses of the split-attention kernels: xH / xW are never
                 # written back in (B,H,W,C) order (two full-tensor passes per block fewer)
                 if self.weighted:
-                    if not inline:
+                    if side:
                         chain.join()
                 else:
                     bar = ws.get("vip.ones", (B, 3 * C), torch.float32, fill=1.0)     # plain sum (vip.py:16-22)

@@ -199,6 +199,9 @@ def test_hand_scheduled_gemm_loops_have_no_compiler_vmem_waits():
     assert lint.lint(asm, "gemm_nt_p8_pair_kernel", every_loop=True) == 0          # both heights' loops of the two-height launch
     # the fused token-mixing kernels: same rule for their iteration loops (one hand-counted vmcnt wait, no scratch)
     assert lint.lint_token(os.path.join(builder.OBJ, "mlpk_tokenmlp-hip-amdgcn-amd-amdhsa-gfx950.s")) == 0
+    # round 5, the pipelined token product: its loads are `asm volatile` with hand-counted waits -- no compiler instruction may name the
+    # destination of such a load before the wait that covers it (a copy or a spill would read data that has not arrived), no scratch
+    assert lint.lint_inflight(os.path.join(builder.OBJ, "mlpk_tokenmlp-hip-amdgcn-amd-amdhsa-gfx950.s")) == 0
 
 
 def test_packed_f16_gelu_of_the_token_kernel():

@@ -78,7 +78,62 @@ def lint_token(path):
     return sum(lint(path, pat, wait, every_loop=True) for pat, wait in TOKEN_KERNELS)
 
 
+def _regs(tok):
+    """VGPR numbers named by one operand (v7, v[4:7])"""
+    m = re.fullmatch(r"v(\d+)", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    return set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else set()
+
+
+def lint_inflight(path, pattern="token_gemm_pipe_kernel"):
+    """Kernels that issue global loads from `asm volatile` and wait for them with hand-counted s_waitcnt: the compiler does not know
+    that the destination of such a load is in flight.  Walk every kernel in layout order: a register written by an asm global_load is
+    in flight until the next asm `s_waitcnt vmcnt` (a conservative reading: in the loop the covering wait is the one at the top of the
+    iteration after next, which in layout order comes first); any compiler instruction that names it before that -- a copy, a spill, a
+    use -- reads data that has not arrived.  Also: no scratch traffic, and no vmcnt wait the compiler added, anywhere in the loop."""
+    lines = open(path).read().split("\n")
+    bad = 0
+    for name, a, b in kernels(lines, pattern):
+        body = lines[a:b]
+        inflight, in_asm, hits, loads = set(), False, [], 0
+        for l in body:
+            t = l.strip()
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if t.startswith(";;#ASMEND"):
+                in_asm = False
+                continue
+            if not t or t.startswith((";", ".")):
+                continue
+            ops = [x.strip() for x in t.split(None, 1)[1].split(",")] if len(t.split(None, 1)) > 1 else []
+            if in_asm:
+                if t.startswith("global_load_dword"):
+                    inflight |= _regs(ops[0])
+                    loads += 1
+                elif t.startswith("s_waitcnt") and "vmcnt" in t:
+                    inflight = set()
+                continue
+            named = set()
+            for o in ops:
+                named |= _regs(o.split()[0] if o else o)
+            if named & inflight:
+                hits.append(t)
+        loop = [x.strip() for x in body]
+        spills = [x for x in loop if x.startswith("scratch_")]
+        print("%-70s %3d asm loads, %d compiler instructions on in-flight registers, %d scratch ops -> %s"
+              % (name[9:], loads, len(hits), len(spills), "ok" if not hits and not spills and loads else "BAD"))
+        for h in hits[:5]:
+            print("    ", h)
+        bad += bool(hits or spills or not loads)
+    return bad
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "inflight":
+        sys.exit(1 if lint_inflight(sys.argv[1]) else 0)
     if len(sys.argv) > 2 and sys.argv[2] == "token":
         sys.exit(1 if lint_token(sys.argv[1]) else 0)
     sys.exit(1 if lint(sys.argv[1], *(sys.argv[2:3])) else 0)
