@@ -729,7 +729,7 @@ class EngineModule(torch.nn.Module):
         if x.dim() != 4:
             raise ValueError("expected a (B, C, H, W) tensor")
         self.__dict__["_in_shape"] = tuple(x.shape[1:])
-        if self.training and not self._warned_train:
+        if self.training and not self._warned_train and not getattr(self, "_train_forward", False):
             import warnings
             warnings.warn("%s is inference-only: forward() ignores train mode (Dropout / DropPath are identity, BatchNorm uses "
                           "its running statistics) and the outputs carry no grad_fn; call .eval()" % type(self).__name__,

@@ -199,7 +199,15 @@ def _gn_params(norm, device):
 
 
 class AS_MLP(E.EngineModule):
-    """Same signature and defaults as the reference (as_mlp.py:368-373)."""
+    """Same signature and defaults as the reference (as_mlp.py:368-373).
+
+    train() (round 5): the forward applies the blocks' stochastic depth (as_mlp.py:144,159-160: DropPath in front of both residual
+    additions) -- per sample, branch * floor(keep + u) / keep with u uniform in [0, 1), the algorithm of timm's drop_path as the reference
+    repository itself restates it (conv_mlp.py:17-34; timm is not vendored) -- as a per-row scale in the epilogue of the GEMM that adds the
+    residual (mlpk.h: v * rscale[m] in front of + R).  The draws come from `drop_path_uniform(B, dtype, device)` (default torch.rand on the
+    input's device, one call per DropPath in the reference's order); GroupNorm has no batch statistics, Dropout has p = 0.  Forward only:
+    the outputs carry no grad_fn."""
+    _train_forward = True
 
     def __init__(self, img_size=224, patch_size=4, in_chans=3, num_classes=1000, embed_dim=96, depths=[2, 2, 6, 2],
                  shift_size=5, mlp_ratio=4., as_bias=True, drop_rate=0., drop_path_rate=0.1, norm_layer=MyNorm,
@@ -230,6 +238,7 @@ class AS_MLP(E.EngineModule):
         self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
         self.apply(self._init_weights)
         self._shift = shift_size
+        self.__dict__["drop_path_uniform"] = lambda B, dtype, device: torch.rand((B,), dtype=dtype, device=device)
         for li, layer in enumerate(self.layers):
             for bi, blk in enumerate(layer.blocks):
                 blk.__dict__["_owner"] = (self, (li, bi))          # lets `model.layers[l].blocks[b](x)` run (common.Block)
@@ -303,6 +312,16 @@ class AS_MLP(E.EngineModule):
         E.norm_apply(x, B * HW, C, C, mean=mean, rstd=rstd, gamma=g, beta=b, act=act, stat_group=HW, out_rm=out, ld_rm=C)
         return out
 
+    def _drop_scale(self, blk, B, HW, dtype, device):
+        """Per-row scale of one DropPath call in train mode (None: identity): conv_mlp.py:27-34 per sample, repeated over the sample's rows."""
+        rate = float(blk.drop_path_rate)
+        if not self.training or rate == 0.0:
+            return None
+        keep = 1.0 - rate
+        u = self.drop_path_uniform(B, dtype, device)
+        mask = torch.floor(keep + u.reshape(B).float())
+        return (mask / keep).repeat_interleave(HW).contiguous()
+
     def _run_layers(self, ws, pk, cur, B, H, W, C, cd, only=None):
         """The stages on channel-last rows `cur` (B*H*W, C).  only = (layer, block): that one block alone, on a `cur` that already has
         the layer's resolution and width (AxialShiftedBlock called on its own).  Returns (cur, H, W, C, have, mean, rstd)."""
@@ -361,10 +380,18 @@ class AS_MLP(E.EngineModule):
                         got = E.gemm(t2, pk[p + "c22.w"], t1, rows, C, C, bias=pk[p + "c22.b"], act=N.ACT_GELU, R=t1, res=N.RES_ADD,
                                      tag="as_conv", part=part)                                       # gelu(.) + x_lr (H shift)
                     stats(t1, C, got)
+                    dp1 = self._drop_scale(layer.blocks[bi], B, HW, cd, cur.device)                 # train mode: x + drop_path(.) (as_mlp.py:159)
                     got = E.gemm(t1, pk[p + "c3f.w"], cur, rows, C, C, bias=pk[p + "c3f.b"], ln=(mean, rstd, pk[p + "c3f.csum"]), ln_group=HW,
-                                 R=cur, res=N.RES_ADD, tag="as_conv", part=part)                     # x + conv3(norm2(.))
+                                 R=cur, res=N.RES_ADD, tag="as_conv", part=part if dp1 is None else None,
+                                 rscale=dp1, rperiod=rows if dp1 is not None else 0)                 # x + conv3(norm2(.))
                     stats(cur, C, got)
-                    if (p + "mlpf") in pk and E.channel_mlp_fused_supported(cd, C, hid):
+                    dp2 = self._drop_scale(layer.blocks[bi], B, HW, cd, cur.device)                 # ... x + drop_path(mlp(norm2(x))) (:160)
+                    if dp2 is not None:
+                        E.gemm(cur, pk[p + "fc1f.w"], hbuf, rows, hid, C, bias=pk[p + "fc1f.b"], act=N.ACT_GELU,
+                               ln=(mean, rstd, pk[p + "fc1f.csum"]), ln_group=HW, tag="as_fc1")
+                        got = E.gemm(hbuf, pk[p + "fc2.w"], cur, rows, C, hid, bias=pk[p + "fc2.b"], R=cur, res=N.RES_ADD, tag="as_fc2",
+                                     rscale=dp2, rperiod=rows)
+                    elif (p + "mlpf") in pk and E.channel_mlp_fused_supported(cd, C, hid):
                         # (its by-product statistics are one plane, summed inside a wave: always taken -- unlike the s3 tile's, whose
                         # statistics epilogue costs more than the pass it saves, profiles/r04_epilogue_stats_ab.txt)
                         got = E.channel_mlp_fused(cur, rows, C, pk[p + "mlpf"], cur, R=cur, ln=(mean, rstd), ln_group=HW,
@@ -387,10 +414,14 @@ class AS_MLP(E.EngineModule):
                 E.gemm(t0, pk[p + "c22.w"], t2, rows, C, C, bias=pk[p + "c22.b"], act=N.ACT_GELU, R=t2, res=N.RES_ADD,
                        tag="as_conv")                                                                # gelu(.) + x_lr
                 self._gn(ws, tag, t2, B, HW, C, pk[p + "an2.g"], pk[p + "an2.b"], t2)
-                E.gemm(t2, pk[p + "c3.w"], cur, rows, C, C, bias=pk[p + "c3.b"], R=cur, res=N.RES_ADD, tag="as_conv")
+                dp1 = self._drop_scale(layer.blocks[bi], B, HW, cd, cur.device)
+                E.gemm(t2, pk[p + "c3.w"], cur, rows, C, C, bias=pk[p + "c3.b"], R=cur, res=N.RES_ADD, tag="as_conv",
+                       rscale=dp1, rperiod=rows if dp1 is not None else 0)
                 self._gn(ws, tag, cur, B, HW, C, pk[p + "n2.g"], pk[p + "n2.b"], t0)                 # norm2(x)
                 E.gemm(t0, pk[p + "fc1.w"], hbuf, rows, hid, C, bias=pk[p + "fc1.b"], act=N.ACT_GELU, tag="as_fc1")
-                E.gemm(hbuf, pk[p + "fc2.w"], cur, rows, C, hid, bias=pk[p + "fc2.b"], R=cur, res=N.RES_ADD, tag="as_fc2")
+                dp2 = self._drop_scale(layer.blocks[bi], B, HW, cd, cur.device)
+                E.gemm(hbuf, pk[p + "fc2.w"], cur, rows, C, hid, bias=pk[p + "fc2.b"], R=cur, res=N.RES_ADD, tag="as_fc2",
+                       rscale=dp2, rperiod=rows if dp2 is not None else 0)
             if layer.downsample is not None and (only is None or only[1] in ("layer", "down")):
                 assert H % 2 == 0 and W % 2 == 0, f"x size ({H}*{W}) are not even."                   # as_mlp.py:203
                 p = "l%d.down." % li

@@ -54,6 +54,7 @@ def _bn_affine(bn, device):
 
 class ConvMixer(E.EngineModule):
     """Same signature and defaults as the reference (conv_mixer.py:14)."""
+    _train_forward = True          # train(): BatchNorm on batch statistics + running-statistics update (_forward_train)
 
     def __init__(self, dim, depth, kernel_size=9, patch_size=7, n_classes=1000):
         super().__init__()

@@ -135,6 +135,7 @@ class MLPMixer(E.EngineModule):
 
     def __init__(self, num_patches, d_model, depth, expansion_factor=4, dropout=0.):
         super().__init__()
+        self.__dict__["_train_forward"] = dropout == 0.          # train(): autograd through the HIP path (_forward_train); Dropout is not implemented
         chan_first, chan_last = partial(nn.Conv1d, kernel_size=1), nn.Linear
         self.model = nn.Sequential(*[
             nn.Sequential(

@@ -464,13 +464,23 @@ def _opt(sd, key, like):
     return _p(sd, key, like) if key in sd else None
 
 
-def asmlp_block(sd, x, pre, shift_size):
-    """AxialShiftedBlock.forward in eval mode: DropPath is the identity (as_mlp.py:149-162)."""
+def drop_path(x, rate, u):
+    """Stochastic depth per sample, train mode (as_mlp.py:144 DropPath = timm's drop_path, restated by the reference repository in
+    conv_mlp.py:17-34): x / keep * floor(keep + u), u = one uniform draw in [0, 1) per sample."""
+    keep = 1.0 - rate
+    return x.div(keep) * torch.floor(keep + u.reshape((-1,) + (1,) * (x.dim() - 1)).to(x.dtype))
+
+
+def asmlp_block(sd, x, pre, shift_size, drop=None):
+    """AxialShiftedBlock.forward (as_mlp.py:149-162).  Eval mode (drop None): DropPath is the identity; train mode: drop = (rate, u1, u2),
+    the block's rate and the uniform draws of its two DropPath calls."""
     t = group_norm1(x, _p(sd, pre + "norm1.weight", x), _p(sd, pre + "norm1.bias", x))
-    x = x + asmlp_axial_shift(sd, t, pre + "axial_shift.", shift_size)
+    t = asmlp_axial_shift(sd, t, pre + "axial_shift.", shift_size)
+    x = x + (t if drop is None else drop_path(t, drop[0], drop[1]))
     t = group_norm1(x, _p(sd, pre + "norm2.weight", x), _p(sd, pre + "norm2.bias", x))
     h = gelu(conv1x1(t, _p(sd, pre + "mlp.fc1.weight", x), _p(sd, pre + "mlp.fc1.bias", x)))
-    return x + conv1x1(h, _p(sd, pre + "mlp.fc2.weight", x), _p(sd, pre + "mlp.fc2.bias", x))
+    t = conv1x1(h, _p(sd, pre + "mlp.fc2.weight", x), _p(sd, pre + "mlp.fc2.bias", x))
+    return x + (t if drop is None else drop_path(t, drop[0], drop[2]))
 
 
 def asmlp_patch_merging(sd, x, pre):
@@ -484,17 +494,31 @@ def asmlp_patch_merging(sd, x, pre):
     return conv1x1(t, _p(sd, pre + "reduction.weight", x), None)
 
 
-def asmlp_forward(sd, x, shift_size=5, hooks=None):
-    """AS_MLP.forward (as_mlp.py:428-443), eval mode, NCHW throughout."""
+def asmlp_forward(sd, x, shift_size=5, hooks=None, drop_path_rate=None, draws=None):
+    """AS_MLP.forward (as_mlp.py:428-443), NCHW throughout.  Eval mode by default; train mode: drop_path_rate = the constructor's rate (the
+    blocks get torch.linspace(0, rate, total depth), as_mlp.py:394; a block with rate 0 holds an Identity and draws nothing) and draws =
+    the uniform draws of the DropPath calls in forward order, each (B,)."""
     x = x.detach().cpu()
     t = patch_embed(x, _p(sd, "patch_embed.proj.weight", x), _p(sd, "patch_embed.proj.bias", x))
     t = t.permute(0, 3, 1, 2)
     if "patch_embed.norm.weight" in sd:
         t = group_norm1(t, _p(sd, "patch_embed.norm.weight", x), _p(sd, "patch_embed.norm.bias", x))
     layer = 0
+    rates, nb, nd = None, 0, 0
+    if drop_path_rate is not None:
+        total = 0
+        while ("layers.%d.blocks.0.norm1.weight" % total) in sd:
+            total += 1
+        total = sum(_depth(sd, "layers.%d" % l + ".blocks.%d.norm1.weight") for l in range(total))
+        rates = [float(v) for v in torch.linspace(0, drop_path_rate, total)]
     while ("layers.%d.blocks.0.norm1.weight" % layer) in sd:
         for i in range(_depth(sd, "layers.%d" % layer + ".blocks.%d.norm1.weight")):
-            t = asmlp_block(sd, t, "layers.%d.blocks.%d." % (layer, i), shift_size)
+            drop = None
+            if rates is not None and rates[nb] > 0.0:
+                drop = (rates[nb], torch.as_tensor(draws[nd]), torch.as_tensor(draws[nd + 1]))
+                nd += 2
+            nb += 1
+            t = asmlp_block(sd, t, "layers.%d.blocks.%d." % (layer, i), shift_size, drop)
             if hooks is not None:
                 hooks("layers.%d.blocks.%d" % (layer, i), t)
         if ("layers.%d.downsample.reduction.weight" % layer) in sd:

@@ -78,13 +78,21 @@ def load_reference():
     tl = types.ModuleType("timm.models.layers")
 
     class DropPath(torch.nn.Module):
+        """timm is not vendored by the reference: its drop_path as the reference repository itself restates it (conv_mlp.py:17-34).  Identity in
+        eval mode (every forward-parity fixture); in train mode the uniform draws are recorded for make_train's AS-MLP case."""
+        draws = []
+
         def __init__(self, p=0.0):
             super().__init__()
             self.p = p
 
         def forward(self, x):
-            assert not self.training
-            return x
+            if self.p == 0.0 or not self.training:
+                return x
+            keep = 1 - self.p
+            u = torch.rand((x.shape[0],) + (1,) * (x.ndim - 1), dtype=x.dtype, device=x.device)
+            DropPath.draws.append(u.reshape(-1).numpy().copy())
+            return x.div(keep) * (keep + u).floor_()
 
     tl.DropPath = DropPath
     tl.to_2tuple = lambda v: v if isinstance(v, (tuple, list)) else (v, v)
@@ -610,6 +618,28 @@ def make_train(ref):
         if "running_" in k or "num_batches" in k:
             out["convmixer/after/" + k] = v.numpy().copy()
     print("train convmixer logits", tuple(logits.shape), "max |logit| %.3f" % float(logits.abs().max()))
+    # AS-MLP in train(): stochastic depth in front of both residual additions of every block (as_mlp.py:144,159-160); the tiny fixture's
+    # weights, drop_path_rate 0.5 (DropPath has no parameters), batch 4; the uniform draws of the 2 x 5 DropPath calls are part of the fixture
+    z = np.load(os.path.join(HERE, "tiny_asmlp.npz"))
+    kw = dict(json.loads(str(z["kwargs"])), drop_path_rate=0.5)
+    model = ref["as_mlp"].AS_MLP(**kw)
+    model.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}, strict=True)
+    model.train()
+    x = torch.from_numpy(portable_input((4, 3, kw["img_size"], kw["img_size"]), seed=14))
+    dp = sys.modules["timm.models.layers"].DropPath
+    dp.draws.clear()
+    torch.manual_seed(15)
+    with torch.no_grad():
+        logits = model(x)
+        model.eval()
+        plain = model(x)
+    out["asmlp/kwargs"] = np.array(_jsonable(kw))
+    out["asmlp/input"] = x.numpy().copy()
+    out["asmlp/logits"] = logits.numpy().copy()
+    out["asmlp/draws"] = np.stack(dp.draws)
+    print("train asmlp logits %s, %d DropPath calls with a rate > 0, kept %s, max |train - eval| %.3f" % (
+        tuple(logits.shape), len(dp.draws), [int(np.floor(1 - r + d).sum()) for r, d in zip(np.linspace(0, 0.5, 5).repeat(2)[2:], dp.draws)],
+        float((logits - plain).abs().max())))
     np.savez_compressed(os.path.join(HERE, "train_tiny.npz"), **out)
 
 
