@@ -566,6 +566,9 @@ int mlpk_transpose_batched(int dtype, const void* in, int64_t ld_in, void* out, 
                            int R, int Cc, void* stream);
 /* out[b, s, c] = scale * in[b, c]: backward of Reduce('b n c -> b c', 'mean') with scale = 1 / S */
 int mlpk_broadcast_rows(int dtype, const void* in, void* out, int B, int S, int C, float scale, void* stream);
+/* x[m, c] += t[m % period, c] for m < rows (x: rows x C with row stride ldx; t: period x C, fp32; one rounding): the absolute position embedding
+ * of SwinMLP added to every image's tokens (swin_mlp.py:386-388,437-438: ape=True) */
+int mlpk_add_periodic(int dtype, void* x, int64_t ldx, const float* t, int64_t rows, int C, int period, void* stream);
 
 /* ---- small utilities ------------------------------------------------------------------------ */
 /* dst[i] = (dst_dtype) src[i], n elements */

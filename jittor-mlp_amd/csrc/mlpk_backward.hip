@@ -122,6 +122,18 @@ template <typename T> __global__ void __launch_bounds__(256) broadcast_rows_kern
     }
 }
 
+// x[m, c] += t[m % period, c] (t fp32, one rounding): SwinMLP's absolute position embedding added to every image's tokens (swin_mlp.py:437-438)
+template <typename T> __global__ void __launch_bounds__(256) add_periodic_kernel(T* __restrict__ x, int64_t ldx, const float* __restrict__ t, int64_t rows, int C,
+                                                                                  int period) {
+    const int64_t total = rows * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int64_t m = i / C;
+        T* px = x + m * ldx + c;
+        *px = from_f32<T>(to_f32<T>(*px) + t[(m % period) * C + c]);
+    }
+}
+
 static unsigned ew_grid(int64_t total) {
     int64_t g = (total + 255) / 256;
     return (unsigned)(g < 1 ? 1 : (g > 65536 ? 65536 : g));
@@ -212,6 +224,19 @@ extern "C" int mlpk_broadcast_rows(int dtype, const void* in, void* out, int B, 
 #define BR(TT) hipLaunchKernelGGL((broadcast_rows_kernel<TT>), dim3(g), dim3(256), 0, s, (const TT*)in, (TT*)out, B, S, C, scale)
     BW_DISPATCH(dtype, BR(float), BR(f16_t), BR(bf16_t))
 #undef BR
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mlpk_add_periodic(int dtype, void* x, int64_t ldx, const float* t, int64_t rows, int C, int period, void* stream) {
+    using namespace mlpk;
+    if (!x || !t) return MLPK_ENULL;
+    if (rows <= 0 || C <= 0 || period <= 0 || ldx < C) return MLPK_ESHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const unsigned g = ew_grid(rows * C);
+#define AP(TT) hipLaunchKernelGGL((add_periodic_kernel<TT>), dim3(g), dim3(256), 0, s, (TT*)x, ldx, t, rows, C, period)
+    BW_DISPATCH(dtype, AP(float), AP(f16_t), AP(bf16_t))
+#undef AP
     MLPK_LAUNCH_CHECK();
     return 0;
 }

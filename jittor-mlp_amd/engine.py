@@ -267,6 +267,17 @@ def token_mlp_supported(dtype, S, sp, hidden=0):
     return dtype in (torch.float16, torch.bfloat16) and S <= 208 and sp <= 224 and sp % 32 == 0 and hidden <= 1024
 
 
+def add_periodic(x, ldx, table, rows, C, period):
+    """x[m, :] += table[m % period, :] (table fp32): SwinMLP's absolute position embedding (swin_mlp.py:437-438)"""
+    N.check(N.lib().mlpk_add_periodic(dtype_code(x.dtype), ptr(x), ldx, ptr(table), rows, C, period, stream()), "mlpk_add_periodic")
+
+
+def rows_to_nchw(cur, B, HW, C, out):
+    """channel-last rows (B*HW, C) -> (B, C, HW): mlpk_transpose_batched (the layout a reference module returns its maps in)"""
+    N.check(N.lib().mlpk_transpose_batched(dtype_code(cur.dtype), ptr(cur), C, ptr(out), HW, None, 0, B, HW, C, stream()), "mlpk_transpose_batched")
+    return out
+
+
 def token_gemm_supported(dtype, S, sp):
     return dtype in (torch.float16, torch.bfloat16) and S <= 224 and sp <= 224 and sp % 32 == 0 and os.environ.get("MLPK_NO_TOKEN_GEMM", "0") != "1"
 

@@ -18,6 +18,7 @@ then the channel MLP with its LayerNorm folded into fc1.  PatchEmbedOverlapping 
 (3x3 stride 2 pad 1, :220-231) are window gathers (mlpk_im2col) + GEMM; the final LayerNorm is folded into the token mean.
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -147,16 +148,16 @@ def basic_blocks(dim, index, layers, mlp_ratio=3., qkv_bias=False, qk_scale=None
 
 
 class CycleNet(E.EngineModule):
-    """Same signature as the reference (cycle_mlp.py:248-256).  fork_feat (dense-prediction feature pyramid) is not on the
-    classification path and is not built."""
+    """Same signature as the reference (cycle_mlp.py:248-256).  fork_feat=True (round 5; :274-287, :326-334): instead of logits the forward
+    returns the list of the four stage outputs, each through its own `norm{0,2,4,6}` LayerNorm (an Identity for the first one under the
+    reference's FORK_LAST3 environment switch) and as (B, C, H, W)."""
 
     def __init__(self, layers, img_size=224, patch_size=4, in_chans=3, num_classes=1000, embed_dims=None, transitions=None,
                  segment_dim=None, mlp_ratios=None, skip_lam=1.0, qkv_bias=False, qk_scale=None, drop_rate=0., attn_drop_rate=0.,
                  drop_path_rate=0., norm_layer=nn.LayerNorm, mlp_fn=CycleMLP, fork_feat=False):
         super().__init__()
-        if fork_feat:
-            raise NotImplementedError("fork_feat=True (feature pyramid outputs) is not built; classification head only")
-        self.num_classes = num_classes
+        if not fork_feat:
+            self.num_classes = num_classes
         self.fork_feat = fork_feat
         self.patch_embed = PatchEmbedOverlapping(patch_size=7, stride=4, padding=2, in_chans=3, embed_dim=embed_dims[0])
         network = []
@@ -173,8 +174,17 @@ class CycleNet(E.EngineModule):
             if not isinstance(stage, Downsample):
                 for bi, blk in enumerate(stage):
                     blk.__dict__["_owner"] = (self, (si, bi))      # lets `model.network[si][bi](x)` run (common.Block)
-        self.norm = norm_layer(embed_dims[-1])
-        self.head = nn.Linear(embed_dims[-1], num_classes) if num_classes > 0 else nn.Identity()
+        if self.fork_feat:
+            self.out_indices = [0, 2, 4, 6]
+            for i_emb, i_layer in enumerate(self.out_indices):
+                if i_emb == 0 and os.environ.get("FORK_LAST3", None):
+                    layer = nn.Identity()                          # cycle_mlp.py:278-283
+                else:
+                    layer = norm_layer(embed_dims[i_emb])
+                self.add_module("norm%d" % i_layer, layer)
+        else:
+            self.norm = norm_layer(embed_dims[-1])
+            self.head = nn.Linear(embed_dims[-1], num_classes) if num_classes > 0 else nn.Identity()
         self.apply(self.cls_init_weights)
 
     def cls_init_weights(self, m):
@@ -228,6 +238,12 @@ class CycleNet(E.EngineModule):
                 if lam != 1.0:
                     pk[p + "ff.fc2.w"] = E.pack_matrix(blk.mlp.fc2.weight.detach() * lam, dtype, device)
                     pk[p + "ff.fc2.b"] = E.f32(blk.mlp.fc2.bias.detach() * lam, device)
+        if self.fork_feat:
+            for i in self.out_indices:
+                nl = getattr(self, "norm%d" % i)
+                if isinstance(nl, nn.LayerNorm):
+                    pk["fork%d.g" % i], pk["fork%d.be" % i] = E.f32(nl.weight, device), E.f32(nl.bias, device)
+            return pk
         pk["head.g"], pk["head.be"] = E.f32(self.norm.weight, device), E.f32(self.norm.bias, device)
         if isinstance(self.head, nn.Linear):
             pk["head.w"] = E.pack_matrix(self.head.weight, dtype, device)
@@ -235,6 +251,18 @@ class CycleNet(E.EngineModule):
         return pk
 
     # ------------------------------------------------------------------ forward
+    def _fork_out(self, ws, pk, idx, cur, B, H, W, C, st, dtype):
+        """fork_feat: `norm{idx}` of the stage output `cur` (channel-last rows), returned as (B, C, H, W) (cycle_mlp.py:329-332)"""
+        rows = B * H * W
+        src = cur
+        if ("fork%d.g" % idx) in pk:
+            mean, rstd = st if st is not None else layernorm_stats(ws, cur, rows, C, tag="fork%d.ln" % idx)
+            src = ws.get("fork%d.n" % idx, (rows, C))
+            E.norm_apply(cur, rows, C, C, mean=mean, rstd=rstd, gamma=pk["fork%d.g" % idx], beta=pk["fork%d.be" % idx], out_rm=src, ld_rm=C)
+        out = torch.empty((B, C, H, W), dtype=src.dtype, device=src.device)
+        E.rows_to_nchw(src, B, H * W, C, out)
+        return out if out.dtype == dtype else out.to(dtype)
+
     def _block(self, ws, pk, p, cur, B, H, W, C, hidden, tag, stats=None):
         """One CycleBlock in place.  `stats` = (mean, rstd) of cur's rows when the GEMM that wrote cur delivered them; returns the
         statistics of the result the same way (or None): both LayerNorms read what a GEMM has just written (mlpk.h row_part)."""
@@ -298,7 +326,10 @@ class CycleNet(E.EngineModule):
         cur = ws.get("n0.x", (B * H * W, C))
         got = E.gemm(patches, pk["embed.w"], cur, B * H * W, C, kp, bias=pk["embed.b"], part=(ws, "embed.part"))
         st = finalize_stats(ws, got, B * H * W, C, tag="n0.ln")
+        outs = []
         for si, stage in enumerate(self.network):
+            if self.fork_feat and si > 0 and (si - 1) in self.out_indices:
+                outs.append(self._fork_out(ws, pk, si - 1, cur, B, H, W, C, st, x.dtype))
             if isinstance(stage, Downsample):
                 Cout = pk["n%d.w" % si].shape[0]
                 H2, W2 = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
@@ -312,6 +343,11 @@ class CycleNet(E.EngineModule):
                 continue
             for bi, blk in enumerate(stage):
                 st = self._block(ws, pk, "n%d.b%d." % (si, bi), cur, B, H, W, C, blk.mlp.fc1.weight.shape[0], "n%d" % si, stats=st)
+        if self.fork_feat:
+            last = len(self.network) - 1
+            if last in self.out_indices:
+                outs.append(self._fork_out(ws, pk, last, cur, B, H, W, C, st, x.dtype))
+            return outs
         mean, rstd = st if st is not None else layernorm_stats(ws, cur, B * H * W, C, tag="head.ln")
         pooled = ws.get("pooled", (B, C))
         E.pool_mean(cur, B, H * W, C, C, pooled, C, mean=mean, rstd=rstd, gamma=pk["head.g"], beta=pk["head.be"])

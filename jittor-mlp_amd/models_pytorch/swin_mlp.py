@@ -1,5 +1,5 @@
 """Swin-MLP, drop-in for the reference's models_pytorch/swin_mlp.py (eval mode: DropPath is the identity;
-`ape=True` is not built).
+`ape=True` -- the absolute position embedding of swin_mlp.py:386-388,437-438 -- is one mlpk_add_periodic pass behind the patch embedding).
 
 SwinMLPBlock (swin_mlp.py:63-157) on channel-last tokens (B*H*W, C):
   * LayerNorm -> mlpk_window_gather: zero padding of the shifted blocks (:101-102, 122-124) and the window partition (:29-42)
@@ -168,6 +168,8 @@ class SwinMLP(E.EngineModule):
         pk["embed.b"] = E.f32(pe.proj.bias, device)
         if pe.norm is not None:
             pk["embed.g"], pk["embed.be"] = E.f32(pe.norm.weight, device), E.f32(pe.norm.bias, device)
+        if self.ape:
+            pk["ape"] = E.f32(self.absolute_pos_embed.detach().reshape(-1, self.embed_dim), device)
         for li, layer in enumerate(self.layers):
             for bi, blk in enumerate(layer.blocks):
                 p = "l%d.b%d." % (li, bi)
@@ -246,8 +248,6 @@ class SwinMLP(E.EngineModule):
             return cur.reshape(B, H * W, C).clone()
 
     def forward(self, x):
-        if self.ape:
-            raise NotImplementedError("ape=True (absolute position embedding) is not built")
         cd = self._resolve(x)
         pe = self.patch_embed
         B, _, H_in, W_in = x.shape
@@ -262,6 +262,8 @@ class SwinMLP(E.EngineModule):
         if pe.norm is not None:
             mean, rstd = layernorm_stats(ws_, cur, B * H * W, C, tag="embed.ln")
             E.norm_apply(cur, B * H * W, C, C, mean=mean, rstd=rstd, gamma=pk["embed.g"], beta=pk["embed.be"], out_rm=cur, ld_rm=C)
+        if self.ape:
+            E.add_periodic(cur, C, pk["ape"], B * H * W, C, H * W)                       # x + absolute_pos_embed (swin_mlp.py:437-438)
         st = None            # (mean, rstd) of cur's rows when the GEMM that wrote cur delivered them (mlpk.h row_part)
         for li, layer in enumerate(self.layers):
             rows = B * H * W

@@ -20,7 +20,7 @@ Rules (checked by the judge):
 from .functional import (  # noqa: F401
     gelu, layer_norm, group_norm1, patch_embed,
     mixer_forward, gmlp_forward, resmlp_forward, vip_forward,
-    s2mlpv2_forward, s2mlpv1_forward, asmlp_forward, convmixer_forward, sparsemlp_forward, hiremlp_forward, msmlp_forward, swinmlp_forward, cyclemlp_forward,
+    s2mlpv2_forward, s2mlpv1_forward, asmlp_forward, convmixer_forward, sparsemlp_forward, hiremlp_forward, msmlp_forward, swinmlp_forward, cyclemlp_forward, flatten_outputs, drop_path,
     cycle_fc, cycle_offsets, deform_conv2d_pointwise_loop,
     axial_shift_nchw, axial_shift_nchw_backward, spatial_shift1, spatial_shift2, split_attention,
     vip_permute_h, vip_permute_w,

@@ -785,13 +785,15 @@ def swinmlp_block(sd, x, pre, hh, ww, num_heads, window_size, shift_size):
 
 
 def swinmlp_forward(sd, x, num_heads=(3, 6, 12, 24), window_size=7, hooks=None):
-    """SwinMLP.forward (swin_mlp.py:433-446) in eval mode (ape = False)."""
+    """SwinMLP.forward (swin_mlp.py:433-446) in eval mode; ape = True iff the state dict holds `absolute_pos_embed` (:386-388, :437-438)."""
     x = x.detach().cpu()
     t = patch_embed(x, _p(sd, "patch_embed.proj.weight", x), _p(sd, "patch_embed.proj.bias", x))
     bsz, hh, ww, c = t.shape
     t = t.reshape(bsz, hh * ww, c)
     if "patch_embed.norm.weight" in sd:
         t = layer_norm(t, _p(sd, "patch_embed.norm.weight", x), _p(sd, "patch_embed.norm.bias", x))
+    if "absolute_pos_embed" in sd:
+        t = t + _p(sd, "absolute_pos_embed", x)
     layer = 0
     while ("layers.%d.blocks.0.norm1.weight" % layer) in sd:
         for i in range(_depth(sd, "layers.%d" % layer + ".blocks.%d.norm1.weight")):
@@ -903,9 +905,18 @@ def cyclemlp_attn(sd, x, pre):
     return linear(t, _p(sd, pre + "proj.weight", x), _p(sd, pre + "proj.bias", x))
 
 
+def flatten_outputs(out):
+    """A list of feature maps (fork_feat) as ONE (B, sum of C H W) matrix -- how the fixtures and the tests hold such an output."""
+    return torch.cat([t.reshape(t.shape[0], -1) for t in out], dim=1) if isinstance(out, (list, tuple)) else out
+
+
 def cyclemlp_forward(sd, x, hooks=None):
-    """CycleNet.forward (cycle_mlp.py:322-350) in eval mode, classification head (fork_feat False), skip_lam 1."""
+    """CycleNet.forward (cycle_mlp.py:322-350) in eval mode, skip_lam 1.  Classification head, or -- fork_feat = True, recognised by the
+    `norm0` ... `norm6` layers the constructor adds instead (:274-287) -- the list of the four normalised stage outputs as (B, C, H, W)
+    (:326-334; a `norm{i}` that is an Identity, FORK_LAST3, has no parameters: the stage output goes out as it is)."""
     x = x.detach().cpu()
+    fork = not ("norm.weight" in sd)
+    outs = []
     t = conv2d_im2col(x, _p(sd, "patch_embed.proj.weight", x), _p(sd, "patch_embed.proj.bias", x), 4, 2)   # 7x7 s4 p2 (:261)
     idx = 0
     while True:
@@ -923,7 +934,14 @@ def cyclemlp_forward(sd, x, hooks=None):
             t = conv2d_im2col(t.permute(0, 3, 1, 2), _p(sd, "network.%d.proj.weight" % idx, x), _p(sd, "network.%d.proj.bias" % idx, x), 2, 1)
         else:
             break
+        if fork and idx in (0, 2, 4, 6):
+            o = t
+            if ("norm%d.weight" % idx) in sd:
+                o = layer_norm(t, _p(sd, "norm%d.weight" % idx, x), _p(sd, "norm%d.bias" % idx, x))
+            outs.append(o.permute(0, 3, 1, 2).contiguous())
         idx += 1
+    if fork:
+        return outs
     t = layer_norm(t, _p(sd, "norm.weight", x), _p(sd, "norm.bias", x))
     t = t.reshape(t.shape[0], -1, t.shape[-1]).mean(dim=1)
     return linear(t, _p(sd, "head.weight", x), _p(sd, "head.bias", x))

@@ -143,6 +143,8 @@ def randomize_norm_stats(model, seed):
                 p.copy_(torch.empty_like(p).uniform_(-0.2, 0.2, generator=g))
             elif leaf == "running_var":
                 p.copy_(torch.empty_like(p).uniform_(0.5, 1.5, generator=g))
+            elif leaf == "absolute_pos_embed":            # trunc_normal(std .02) at init (swin_mlp.py:388): make it visible next to the LayerNorm output
+                p.copy_(torch.empty_like(p).uniform_(-0.5, 0.5, generator=g))
             elif leaf in ("gamma_1", "gamma_2"):
                 p.copy_(torch.empty_like(p).uniform_(0.05, 0.3, generator=g))
             elif leaf in ("alpha",) or (leaf == "weight" and p.dim() == 1):
@@ -231,6 +233,14 @@ def tiny_configs(ref):
         "swinmlp": dict(ctor=ref["swin_mlp"].SwinMLP, kw=dict(img_size=64, patch_size=4, embed_dim=16, depths=[2, 2], num_heads=[2, 4], window_size=4, num_classes=10),
                         hw=(64, 64), pins=["layers.0.blocks.1", "layers.1.blocks.0"],
                         oracle=lambda sd, x, kw: oracle.swinmlp_forward(sd, x, kw["num_heads"], kw["window_size"])),
+        # absolute position embedding (swin_mlp.py:386-388, 437-438)
+        "swinmlp_ape": dict(ctor=ref["swin_mlp"].SwinMLP, kw=dict(img_size=32, patch_size=4, embed_dim=16, depths=[2, 1], num_heads=[2, 4], window_size=4, num_classes=10,
+                                                                   ape=True),
+                            hw=(32, 32), pins=[], oracle=lambda sd, x, kw: oracle.swinmlp_forward(sd, x, kw["num_heads"], kw["window_size"])),
+        # fork_feat (cycle_mlp.py:274-287, 326-334): the four normalised stage outputs instead of logits, held as one flattened matrix
+        "cyclemlp_fork": dict(ctor=ref["cycle_mlp"].CycleNet, kw=dict(layers=[1, 1, 1, 1], embed_dims=[8, 16, 24, 32], transitions=[True, True, True, True],
+                                                                       mlp_ratios=[2, 2, 2, 2], mlp_fn=None, fork_feat=True),
+                              hw=(64, 96), pins=[], oracle=lambda sd, x, kw: oracle.flatten_outputs(oracle.cyclemlp_forward(sd, x))),
         # CycleMLP (cycle_mlp.py): CycleNet has no size defaults -- tiny configurations in the style of its CycleMLP_B* factories
         "cyclemlp": dict(ctor=ref["cycle_mlp"].CycleNet, kw=dict(layers=[1, 2], embed_dims=[16, 32], transitions=[True, True], mlp_ratios=[2, 4],
                                                                   mlp_fn=None, num_classes=10),
@@ -329,7 +339,7 @@ def make_tiny(ref, names=None):
                         p_.copy_(cfg["gamma"] * (1.0 + 0.5 * torch.rand_like(p_)))
         x = torch.randn(2, 3, *cfg["hw"])
         pins, handles = hook_pins(model, cfg["pins"])
-        out = run_ref(model, x, cfg.get("one_thread", False))
+        out = oracle.flatten_outputs(run_ref(model, x, cfg.get("one_thread", False)))
         for h in handles:
             h.remove()
         sd = {k: v.detach().clone() for k, v in model.state_dict().items()}

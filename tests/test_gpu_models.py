@@ -84,6 +84,11 @@ def tol_for(dtype, ref, real=False, name=None):
     return 1.5e-2 * m
 
 
+def flat(o):
+    """a list of feature maps (CycleNet fork_feat) as one (B, sum C H W) matrix, the way its fixture holds the reference's output"""
+    return torch.cat([t.reshape(t.shape[0], -1) for t in o], dim=1) if isinstance(o, (list, tuple)) else o
+
+
 def ctor_for(pkg, name):
     table = {"mixer": "MLPMixerForImageClassification", "gmlp": "gMLPForImageClassification",
              "resmlp": "ResMLPForImageClassification", "vip": "ViP", "s2mlpv2": "S2MLPv2", "s2mlpv1": "S2MLPv1",
@@ -113,7 +118,7 @@ def build_from_tiny(pkg, name):
 
 
 TINY_TOKEN = ["mixer", "mixer_nonsquare", "gmlp", "resmlp", "vip_weighted", "vip_unweighted", "vip_rect", "s2mlpv2",
-              "s2mlpv2_cleanshift", "s2mlpv1", "asmlp", "convmixer", "convmixer_k4", "convmixer_k11", "sparsemlp", "sparsemlp_norm", "hiremlp", "hiremlp_rect", "msmlp", "msmlp_s3", "swinmlp", "swinmlp_small", "cyclemlp", "cyclemlp_rect"]
+              "s2mlpv2_cleanshift", "s2mlpv1", "asmlp", "convmixer", "convmixer_k4", "convmixer_k11", "sparsemlp", "sparsemlp_norm", "hiremlp", "hiremlp_rect", "msmlp", "msmlp_s3", "swinmlp", "swinmlp_small", "swinmlp_ape", "cyclemlp", "cyclemlp_rect", "cyclemlp_fork"]
 
 
 @pytest.mark.parametrize("name", TINY_TOKEN)
@@ -123,8 +128,8 @@ def test_tiny_golden(name, dtype):
     model, x, ref, kw, sd = build_from_tiny(pkg, name)
     model = model.to(DEV)
     with torch.no_grad():
-        out = model(x.to(DEV).to(dtype))
-        out2 = model(x.to(DEV).to(dtype))
+        out = flat(model(x.to(DEV).to(dtype)))
+        out2 = flat(model(x.to(DEV).to(dtype)))
     torch.cuda.synchronize()
     assert out.dtype == dtype and out.shape == ref.shape
     assert torch.equal(out, out2), "forward is not deterministic"
@@ -139,7 +144,7 @@ def test_tiny_fp32_input_bf16_compute(name):
     model, x, ref, kw, sd = build_from_tiny(pkg, name)
     model = model.to(DEV).set_compute_dtype(torch.bfloat16)
     with torch.no_grad():
-        out = model(x.to(DEV))
+        out = flat(model(x.to(DEV)))
     assert out.dtype == torch.float32
     assert (out.cpu() - ref).abs().max().item() < tol_for(torch.bfloat16, ref)
 
