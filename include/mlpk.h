@@ -566,6 +566,14 @@ int mlpk_transpose_batched(int dtype, const void* in, int64_t ld_in, void* out, 
                            int R, int Cc, void* stream);
 /* out[b, s, c] = scale * in[b, c]: backward of Reduce('b n c -> b c', 'mean') with scale = 1 / S */
 int mlpk_broadcast_rows(int dtype, const void* in, void* out, int B, int S, int C, float scale, void* stream);
+/* Sparse-MLP's sMLP block up to the concatenation, behind the block's eval-mode BatchNorm (sparse_mlp.py:61-72,92), one launch:
+ *   x^ = bn_scale[c] * x + bn_shift[c];   out[(b,h,w), :] = [ proj_h(x^) | proj_w(x^) | x^ ]   (3 C columns: the operand of the 3C -> C fuse)
+ *   proj_h: x_h[b,h',w,c] = sum_h wh[h',h] x^[b,h,w,c] + bh[h'];  proj_w: x_w[b,h,w',c] = sum_w ww[w',w] x^[b,h,w,c] + bw[w']
+ * x: (B*H*W, ldx) channel-last rows; wh / ww: (32, 32) in the storage type, zero-padded; bh / bw: (32) fp32, zero-padded; H, W <= 32, C % 32 == 0,
+ * 16-bit storage (mlpk_smlp_mix_supported).  x^ and the two mixes are rounded once each. */
+int mlpk_smlp_mix_supported(int dtype, int H, int W, int C);
+int mlpk_smlp_mix(int dtype, const void* x, int ldx, int B, int H, int W, int C, const float* bn_scale, const float* bn_shift, const void* wh,
+                  const float* bh, const void* ww, const float* bw, void* out, int ldo, void* stream);
 /* x[m, c] += t[m % period, c] for m < rows (x: rows x C with row stride ldx; t: period x C, fp32; one rounding): the absolute position embedding
  * of SwinMLP added to every image's tokens (swin_mlp.py:386-388,437-438: ape=True) */
 int mlpk_add_periodic(int dtype, void* x, int64_t ldx, const float* t, int64_t rows, int C, int period, void* stream);

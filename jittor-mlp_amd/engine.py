@@ -278,6 +278,30 @@ def rows_to_nchw(cur, B, HW, C, out):
     return out
 
 
+def smlp_mix_supported(dtype, H, W, C):
+    """mlpk_smlp_mix (round 5): Sparse-MLP's BatchNorm + both axial mixes + the concatenation in one kernel (maps up to 32 x 32, 16 bit);
+    MLPK_SMLP_MIX=0 keeps the four-launch path (A/B aid)"""
+    if os.environ.get("MLPK_SMLP_MIX") == "0" or dtype not in (torch.float16, torch.bfloat16):
+        return False
+    return bool(N.lib().mlpk_smlp_mix_supported(dtype_code(dtype), H, W, C))
+
+
+def pack_smlp_mix(w, b, dtype, device):
+    """(S, S) axial mixing weight of nn.Linear(S, S) (sparse_mlp.py:64-65) -> (32, 32) zero-padded in the storage type, bias -> (32,) fp32"""
+    S = w.shape[0]
+    wp = torch.zeros((32, 32), dtype=dtype, device=device)
+    wp[:S, :S] = w.detach().to(device=device, dtype=dtype)
+    bp = torch.zeros((32,), dtype=torch.float32, device=device)
+    bp[:S] = b.detach().to(device=device, dtype=torch.float32)
+    return wp, bp
+
+
+def smlp_mix(x, ldx, B, H, W, C, bn_s, bn_h, wh, bh, ww, bw, out, ldo):
+    """out (B*H*W, 3C) = [proj_h(x^) | proj_w(x^) | x^], x^ = bn_s * x + bn_h (sparse_mlp.py:66-71 behind the block's BatchNorm)"""
+    N.check(N.lib().mlpk_smlp_mix(dtype_code(x.dtype), ptr(x), ldx, B, H, W, C, ptr(bn_s), ptr(bn_h), ptr(wh), ptr(bh), ptr(ww), ptr(bw), ptr(out), ldo,
+                                  stream()), "mlpk_smlp_mix")
+
+
 def token_gemm_supported(dtype, S, sp):
     return dtype in (torch.float16, torch.bfloat16) and S <= 224 and sp <= 224 and sp % 32 == 0 and os.environ.get("MLPK_NO_TOKEN_GEMM", "0") != "1"
 

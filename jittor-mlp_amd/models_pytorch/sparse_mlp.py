@@ -128,6 +128,11 @@ class SparseMLP(E.EngineModule):
                     # the persistent single-product token kernel (gMLP / ResMLP) serves the two axial mixes as well
                     pk[p + "ph.tg"] = E.pack_token_gemm(sm.proj_h.weight, sm.proj_h.bias, dtype, device)
                     pk[p + "pw.tg"] = E.pack_token_gemm(sm.proj_w.weight, sm.proj_w.bias, dtype, device)
+                if E.smlp_mix_supported(dtype, H, W, C):
+                    # round 5: BatchNorm + both mixes + the concatenation in one kernel, the 3C -> C fuse as ONE GEMM on [x_h | x_w | x^]
+                    pk[p + "mix.wh"], pk[p + "mix.bh"] = E.pack_smlp_mix(sm.proj_h.weight, sm.proj_h.bias, dtype, device)
+                    pk[p + "mix.ww"], pk[p + "mix.bw"] = E.pack_smlp_mix(sm.proj_w.weight, sm.proj_w.bias, dtype, device)
+                    pk[p + "fu.w3"] = E.pack_matrix(sm.fuse.weight.detach().reshape(C, 3 * C), dtype, device)
                 wf = sm.fuse.weight.detach().reshape(C, 3 * C)
                 pk[p + "fu.wh"] = E.pack_matrix(wf[:, :C], dtype, device)
                 pk[p + "fu.wr"] = E.pack_matrix(wf[:, C:], dtype, device)                                # [x_w | x^] columns
@@ -149,6 +154,19 @@ class SparseMLP(E.EngineModule):
         cannot run in place); returns (result buffer, the other one)."""
         H, W, C, depth, ef = stage.geom
         rows = B * H * W
+        p = "l%d.b%d." % (li, bi)
+        if (p + "mix.wh") in pk:
+            # round 5 (maps up to 32 x 32): x + dwconv, then ONE kernel for BN + proj_h + proj_w + cat (mlpk_smlp_mix: the tile of an image's 32
+            # channels is transposed inside LDS instead of through two transposed tensors in HBM), then the fuse as one K = 3C GEMM
+            cat3 = ws.get("l%d.cat3" % li, (rows, 3 * C))
+            E.dwconv_affine_nhwc(cur, tmp, B, H, W, C, 3, pk[p + "dw.w"], pk[p + "dw.b"], pk[p + "dw.s"], pk[p + "dw.h"])
+            cur, tmp = tmp, cur
+            E.smlp_mix(cur, C, B, H, W, C, pk[p + "bn.s"], pk[p + "bn.h"], pk[p + "mix.wh"], pk[p + "mix.bh"], pk[p + "mix.ww"], pk[p + "mix.bw"],
+                       cat3, 3 * C)
+            got = E.gemm(cat3, pk[p + "fu.w3"], cur, rows, C, 3 * C, bias=pk[p + "fu.b"], R=cur, res=N.RES_ADD, tag="smlp_fuse",
+                         part=(ws, "l%d.fu.part" % li))
+            channel_mlp(ws, cur, rows, C, pk, p + "ff.", C * ef, tag="l%d.cm" % li, stats=finalize_stats(ws, got, rows, C, tag="l%d.cm.ln" % li))
+            return cur, tmp
         tgk = ("l%d.b0.pw.tg" % li) in pk                            # token kernel: K padded to whole 64-byte slabs
         hp, wp = E.round_up(H, 32 if tgk else 8), E.round_up(W, 32 if tgk else 8)
         xh = ws.get("l%d.xh" % li, (rows, C))

@@ -1779,3 +1779,40 @@ def test_vip_branch_in_one_kernel_is_bit_equal_to_rearrange_plus_gemm(dtype):
     assert not E.vip_branch_supported(dtype, 4, 4, 32, 8) and not E.vip_branch_supported(dtype, 32, 32, 384, 16)
     with pytest.raises(RuntimeError):
         E.vip_branch(0, x, C, B_, 7, 32, C, seg, mean, rstd, gamma, beta, w, bias, z_new, K)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_smlp_mix_in_one_kernel(dtype):
+    """mlpk_smlp_mix (round 5): Sparse-MLP's sMLP block up to the concatenation behind its eval-mode BatchNorm (sparse_mlp.py:61-72,92) -- x^ =
+    s x + h, proj_h along H, proj_w along W, out = [x_h | x_w | x^] -- against fp64 on the same rounded x^, incl. rectangular maps, maps that
+    need two 16-position blocks, more units than the chip holds at once (workgroups walk several), the smallest map."""
+    pkg = load_pkg()
+    E, N = pkg.engine, pkg._native
+    for ci, (B_, H, W, C) in enumerate([(2, 14, 14, 64), (3, 28, 28, 32), (2, 7, 7, 96), (2, 9, 20, 64), (70, 14, 14, 384), (1, 32, 32, 32), (2, 1, 5, 32)]):
+        assert E.smlp_mix_supported(dtype, H, W, C)
+        rows = B_ * H * W
+        x = (rnd((rows, C), dtype, 2300 + ci) * 1.5).to(dev())
+        s = (rnd((C,), torch.float32, 2310 + ci) * 0.3 + 1.0).to(dev())
+        h = (rnd((C,), torch.float32, 2320 + ci) * 0.5).to(dev())
+        wh = rnd((H, H), torch.float32, 2330 + ci, 1.0 / math.sqrt(H))
+        ww = rnd((W, W), torch.float32, 2340 + ci, 1.0 / math.sqrt(W))
+        bh, bw = rnd((H,), torch.float32, 2350 + ci), rnd((W,), torch.float32, 2360 + ci)
+        whp, bhp = E.pack_smlp_mix(wh, bh, dtype, dev())
+        wwp, bwp = E.pack_smlp_mix(ww, bw, dtype, dev())
+        out = torch.full((rows, 3 * C), float("nan"), dtype=dtype, device=dev())
+        E.smlp_mix(x, C, B_, H, W, C, s, h, whp, bhp, wwp, bwp, out, 3 * C)
+        torch.cuda.synchronize()
+        got = out.cpu().double().reshape(B_, H, W, 3 * C)
+        assert torch.isfinite(got).all(), (str(dtype), ci)
+        xh = out[:, 2 * C:].cpu()                                                       # the kernel's x^: one rounding of the fp32 fma ...
+        want = x.cpu().double() * s.cpu().double() + h.cpu().double()
+        assert (xh.double() - want).abs().max().item() < EPS[dtype] * max(1.0, want.abs().max().item()), (str(dtype), ci)
+        xd = xh.double().reshape(B_, H, W, C)                                           # ... and the operand of both mixes
+        ref_h = torch.einsum("gh,bhwc->bgwc", wh.to(dtype).double(), xd) + bh.double().view(1, H, 1, 1)
+        ref_w = torch.einsum("vw,bhwc->bhvc", ww.to(dtype).double(), xd) + bw.double().view(1, 1, W, 1)
+        for name, ref, sl in (("h", ref_h, slice(0, C)), ("w", ref_w, slice(C, 2 * C))):
+            err = (got[..., sl] - ref).abs().max().item()
+            assert err < EPS[dtype] * 2 * max(1.0, ref.abs().max().item()), (str(dtype), ci, name, err)
+    assert not E.smlp_mix_supported(dtype, 56, 56, 96) and not E.smlp_mix_supported(dtype, 14, 14, 48) and not E.smlp_mix_supported(torch.float32, 14, 14, 64)
+    with pytest.raises(RuntimeError):
+        E.smlp_mix(x, C, B_, 56, 56, C, s, h, whp, bhp, wwp, bwp, out, 3 * C)
