@@ -1052,9 +1052,11 @@ def test_token_gemm_with_the_layernorm_as_its_operand_loader(dtype):
     pkg = load_pkg()
     E, N = pkg.engine, pkg._native
     for ci, (B_, C, S, mode) in enumerate([(2, 256, 196, "sgu"), (3, 384, 196, "aff"), (5, 64, 49, "sgu"), (2, 1536, 50, "sgu"), (4, 96, 224, "aff"),
-                                           (90, 768, 196, "sgu"), (150, 384, 100, "aff"), (3, 64, 97, "sgu"), (40, 1536, 196, "sgu")]):
+                                           (90, 768, 196, "sgu"), (150, 384, 100, "aff"), (3, 64, 97, "sgu"), (40, 1536, 196, "sgu"),
+                                           (4, 32, 66, "aff"), (2, 2048, 128, "sgu"), (2, 2080, 96, "aff"), (300, 32, 224, "sgu")]):
         # (round 5: >= 3 groups of 32 tokens and an even token count run as token_gemm_pipe_kernel -- cases 0, 1, 4, 5, 6, 8; two groups or
-        #  an odd count -- cases 2, 3, 7 -- stay on the round-4 kernel)
+        #  an odd count -- cases 2, 3, 7 -- stay on the round-4 kernel; 9 - 12: three groups exactly, the widest image the LDS tables hold
+        #  (2048 channels), one more than that (round-4 kernel), seven groups with 32-channel images)
         rows = B_ * S
         w = rnd((S, S), torch.float32, 2110 + ci, 1.0 / math.sqrt(S))
         bias = rnd((S,), torch.float32, 2120 + ci)
