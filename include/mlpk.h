@@ -574,6 +574,13 @@ int mlpk_broadcast_rows(int dtype, const void* in, void* out, int B, int S, int 
 int mlpk_smlp_mix_supported(int dtype, int H, int W, int C);
 int mlpk_smlp_mix(int dtype, const void* x, int ldx, int B, int H, int W, int C, const float* bn_scale, const float* bn_shift, const void* wh,
                   const float* bh, const void* ww, const float* bw, void* out, int ldo, void* stream);
+/* The same with the block's first sublayer in front (sparse_mlp.py:88-91), for maps up to 15 x 15 (mlpk_smlp_mix_dw_supported: the tiles of two workgroups share a CU's LDS):
+ *   xres = x + dwconv3x3(dw_scale[c] * x + dw_shift[c]) + dw_bias[c]   (zero padding on the affine's OUTPUT; dw_w: (9, C) fp32, tap 3 dy + dx --
+ *   the operation and the bits of mlpk_dwconv_affine_nhwc with k = 3), stored to xres (B*H*W, ldxr; not x itself), then mlpk_smlp_mix of xres. */
+int mlpk_smlp_mix_dw_supported(int dtype, int H, int W, int C);
+int mlpk_smlp_mix_dw(int dtype, const void* x, int ldx, int B, int H, int W, int C, const float* dw_w, const float* dw_bias, const float* dw_scale,
+                     const float* dw_shift, void* xres, int ldxr, const float* bn_scale, const float* bn_shift, const void* wh, const float* bh,
+                     const void* ww, const float* bw, void* out, int ldo, void* stream);
 /* x[m, c] += t[m % period, c] for m < rows (x: rows x C with row stride ldx; t: period x C, fp32; one rounding): the absolute position embedding
  * of SwinMLP added to every image's tokens (swin_mlp.py:386-388,437-438: ape=True) */
 int mlpk_add_periodic(int dtype, void* x, int64_t ldx, const float* t, int64_t rows, int C, int period, void* stream);

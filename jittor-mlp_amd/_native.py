@@ -85,6 +85,8 @@ PROTOTYPES = {
     "mlpk_add_periodic": (c_int, [c_int, c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_void_p]),
     "mlpk_smlp_mix_supported": (c_int, [c_int] * 4),
     "mlpk_smlp_mix": (c_int, [c_int, c_void_p] + [c_int] * 5 + [c_void_p] * 7 + [c_int, c_void_p]),
+    "mlpk_smlp_mix_dw_supported": (c_int, [c_int] * 4),
+    "mlpk_smlp_mix_dw": (c_int, [c_int, c_void_p] + [c_int] * 5 + [c_void_p] * 5 + [c_int] + [c_void_p] * 7 + [c_int, c_void_p]),
     "mlpk_shift_nhwc": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "mlpk_norm_shift_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p] * 4 + [c_int, c_void_p]),
     "mlpk_cycle_shift": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),

@@ -29,6 +29,14 @@ struct SmlpArgs {
     const float* bh;        // (32) zero-padded
     const float* bw;
     int B, H, W, C, ldx, ldo;
+    // DW: the block's first sublayer in front (sparse_mlp.py:88-91: x + dwconv3x3(BatchNorm(x)) + bias, zero padding on the BatchNorm output):
+    // x is that sublayer's INPUT; its output x' is written to xres and is what the BatchNorm above applies to
+    void* xres;             // (B*H*W, ldxr)
+    const float* dw_w;      // (9, C): tap t = 3 dy + dx, per channel
+    const float* dw_b;      // (C)
+    const float* dw_s;      // (C) scale / shift of the BatchNorm in front of the convolution
+    const float* dw_h;
+    int ldxr;
 };
 
 template <typename T> struct SmMma;
@@ -44,7 +52,7 @@ template <> struct SmMma<f16_t> {
 };
 
 constexpr int SM_NT = 512;                                 // threads per workgroup
-constexpr int SM_NL = 8;                                   // 16-byte pieces per thread: 32 x 32 pixels x 4 pieces / 512 threads
+// (16-byte pieces per thread = template parameter SM_NL: 8 covers 32 x 32 pixels x 4 pieces / 512 threads, 2 covers maps up to 16 x 16)
 
 // element (line, channel c, position k) of a transposed copy: 64-byte rows, the four 16-byte chunks of a row XORed with the channel's octet
 // (the writers of one instruction differ in the octet: without it they would all hit the same banks)
@@ -52,7 +60,12 @@ __device__ __forceinline__ unsigned sm_addr(int line, int c, int k) {
     return (unsigned)(((line * 32 + c) * 64) + ((((k >> 3) ^ (c >> 3)) & 3) << 4) + (k & 7) * 2);
 }
 
-template <typename T>
+// DW (maps whose raw tile fits beside the two transposed copies: 14 x 14, 7 x 7): the depthwise 3 x 3 sublayer of the block runs on the same tile
+// first -- the loaded pieces go to a plain copy [pixel][32 channels] in LDS, every thread then reads the 9 neighbours of its pieces (clamped
+// address + mask: what lies outside the map contributes zero, as the padding of the BatchNorm's OUTPUT does), applies the BatchNorm per tap in
+// fp32 exactly like mlpk_dwconv_affine_nhwc, and adds the centre value: the result x' is stored (the residual of the fuse GEMM) and replaces
+// the piece.  One pass over the activation fewer per block; the same bits as the two kernels.
+template <typename T, bool DW, int SM_NL>
 __global__ void __launch_bounds__(SM_NT, 4) smlp_mix_kernel(const SmlpArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -62,6 +75,8 @@ __global__ void __launch_bounds__(SM_NT, 4) smlp_mix_kernel(const SmlpArgs p) {
     const int npx = H * W;
     char* const LA = smem;                                 // [h][c][w]
     char* const LB = smem + H * 32 * 64;                   // [w][c][h]
+    char* const LP = smem + (H + W) * 32 * 64;             // DW: [pixel][32 channels] raw, then 12 x 32 floats: 9 taps, bias, scale, shift
+    float* const LW = reinterpret_cast<float*>(LP + npx * 64);
     const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
     T* __restrict__ out = reinterpret_cast<T*>(p.out);
     // zero both copies once: the positions >= W (>= H) of every row are never written again
@@ -82,12 +97,22 @@ __global__ void __launch_bounds__(SM_NT, 4) smlp_mix_kernel(const SmlpArgs p) {
     // per-piece geometry, the same for every unit: 32-bit byte offsets of the piece in x / of its x^ in out (relative to the unit's origin) and
     // the LDS addresses of its first channel in the two copies (channel e of the octet: + 64 e)
     unsigned xoff[SM_NL], ooff[SM_NL], la[SM_NL], lb[SM_NL];
+    unsigned nbm[DW ? SM_NL : 1];                            // DW: which of the 9 neighbours of the piece's pixel lie inside the map
 #pragma unroll
     for (int i = 0; i < SM_NL; ++i) {
         int idx = tid + i * SM_NT;
         idx = idx < npx * 4 ? idx : npx * 4 - 1;             // (clamped, not branched: a load behind a branch is a serialised load)
         const int px = idx >> 2, o = idx & 3;
         const int hh = px / W, ww_ = px - hh * W;
+        if constexpr (DW) {
+            unsigned m = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = hh + t / 3 - 1, xx = ww_ + t % 3 - 1;
+                m |= ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W ? 1u : 0u) << t;
+            }
+            nbm[i] = m;
+        }
         xoff[i] = (unsigned)(px * p.ldx + o * 8) * (unsigned)sizeof(T);
         ooff[i] = (unsigned)(px * p.ldo + o * 8) * (unsigned)sizeof(T);
         la[i] = sm_addr(hh, o * 8, ww_);
@@ -105,6 +130,58 @@ __global__ void __launch_bounds__(SM_NT, 4) smlp_mix_kernel(const SmlpArgs p) {
     __syncthreads();
     for (; u < units; u += gridDim.x) {
         const int b = u / cgroups, c0 = (u - b * cgroups) * 32;
+        if constexpr (DW) {
+            // ---- x' = x + dwconv3x3(BN(x)) + b on the tile
+            for (int i = tid; i < 12 * 32; i += SM_NT) {
+                const int r = i >> 5, c = i & 31;
+                LW[i] = r < 9 ? p.dw_w[(size_t)r * C + c0 + c] : (r == 9 ? p.dw_b : r == 10 ? p.dw_s : p.dw_h)[c0 + c];
+            }
+#pragma unroll
+            for (int i = 0; i < SM_NL; ++i)
+                if (tid + i * SM_NT < npx * 4) *reinterpret_cast<u32x4*>(LP + (size_t)(tid + i * SM_NT) * 16) = raw[i];
+            __syncthreads();
+            const int o = tid & 3;
+            float bs_[8], a_[8], h_[8];
+            {
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(LW + 9 * 32 + o * 8), b1 = *reinterpret_cast<const f32x4*>(LW + 9 * 32 + o * 8 + 4);
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(LW + 10 * 32 + o * 8), s1 = *reinterpret_cast<const f32x4*>(LW + 10 * 32 + o * 8 + 4);
+                const f32x4 h0 = *reinterpret_cast<const f32x4*>(LW + 11 * 32 + o * 8), h1 = *reinterpret_cast<const f32x4*>(LW + 11 * 32 + o * 8 + 4);
+                bs_[0] = b0.x; bs_[1] = b0.y; bs_[2] = b0.z; bs_[3] = b0.w; bs_[4] = b1.x; bs_[5] = b1.y; bs_[6] = b1.z; bs_[7] = b1.w;
+                a_[0] = s0.x; a_[1] = s0.y; a_[2] = s0.z; a_[3] = s0.w; a_[4] = s1.x; a_[5] = s1.y; a_[6] = s1.z; a_[7] = s1.w;
+                h_[0] = h0.x; h_[1] = h0.y; h_[2] = h0.z; h_[3] = h0.w; h_[4] = h1.x; h_[5] = h1.y; h_[6] = h1.z; h_[7] = h1.w;
+            }
+            char* const rb = reinterpret_cast<char*>(reinterpret_cast<T*>(p.xres) + (size_t)b * npx * p.ldxr + c0);
+#pragma unroll
+            for (int i = 0; i < SM_NL; ++i) {
+                const int idx = tid + i * SM_NT;
+                if (idx < npx * 4) {
+                    float acc[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] = bs_[e];
+#pragma unroll 1
+                    for (int t = 0; t < 9; ++t) {                    // (rolled: unrolled, the 27 LDS reads of a piece went out at once and spilled)
+                        const bool ok = (nbm[i] >> t) & 1u;
+                        const int nidx = ok ? idx + ((t / 3 - 1) * W + (t % 3 - 1)) * 4 : idx;
+                        const u32x4 nv = *reinterpret_cast<const u32x4*>(LP + (size_t)nidx * 16);
+                        T e8[8];
+                        __builtin_memcpy(e8, &nv, 16);
+                        const f32x4 w0 = *reinterpret_cast<const f32x4*>(LW + t * 32 + o * 8), w1 = *reinterpret_cast<const f32x4*>(LW + t * 32 + o * 8 + 4);
+                        const float wt[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float tap = ok ? __builtin_fmaf(a_[e], to_f32(e8[e]), h_[e]) : 0.f;
+                            acc[e] = __builtin_fmaf(wt[e], tap, acc[e]);
+                        }
+                    }
+                    T c8[8];
+                    __builtin_memcpy(c8, &raw[i], 16);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) c8[e] = from_f32<T>(to_f32(c8[e]) + acc[e]);
+                    __builtin_memcpy(&raw[i], c8, 16);
+                    *reinterpret_cast<u32x4*>(rb + (size_t)(idx >> 2) * p.ldxr * sizeof(T) + (idx & 3) * 16) = raw[i];
+                }
+            }
+        }
         // ---- x^ = s x + h: out[:, 2C + c] from the registers, the two transposed copies into LDS
         {
             const int o = tid & 3;
@@ -182,6 +259,17 @@ extern "C" int mlpk_smlp_mix_supported(int dtype, int H, int W, int C) {
     return (dtype == MLPK_F16 || dtype == MLPK_BF16) && H >= 1 && W >= 1 && H <= 32 && W <= 32 && C >= 32 && C % 32 == 0 && (H + W) * 2048 <= 160 * 1024;
 }
 
+static int smlp_dw_lds(int H, int W) { return (H + W) * 32 * 64 + H * W * 64 + 12 * 32 * 4; }
+constexpr int SM_NL_SMALL = 2;
+
+// the variant with the block's depthwise 3 x 3 sublayer in front (mlpk_smlp_mix_dw): the raw tile must fit beside the transposed copies,
+// two workgroups per CU
+extern "C" int mlpk_smlp_mix_dw_supported(int dtype, int H, int W, int C) {
+    return mlpk_smlp_mix_supported(dtype, H, W, C) && smlp_dw_lds(H, W) <= 78 * 1024 && H * W * 4 <= SM_NL_SMALL * SM_NT;
+}
+
+static int smlp_launch(int dtype, SmlpArgs& a, bool dw, hipStream_t s);
+
 extern "C" int mlpk_smlp_mix(int dtype, const void* x, int ldx, int B, int H, int W, int C, const float* bn_scale, const float* bn_shift,
                              const void* wh, const float* bh, const void* ww, const float* bw, void* out, int ldo, void* stream) {
     if (!x || !out || !bn_scale || !bn_shift || !wh || !ww || !bh || !bw) return MLPK_ENULL;
@@ -192,25 +280,51 @@ extern "C" int mlpk_smlp_mix(int dtype, const void* x, int ldx, int B, int H, in
     SmlpArgs a;
     a.x = x; a.out = out; a.bn_s = bn_scale; a.bn_h = bn_shift; a.wh = wh; a.ww = ww; a.bh = bh; a.bw = bw;
     a.B = B; a.H = H; a.W = W; a.C = C; a.ldx = ldx; a.ldo = ldo;
-    const int lds = (H + W) * 32 * 64;
+    a.xres = nullptr; a.dw_w = a.dw_b = a.dw_s = a.dw_h = nullptr; a.ldxr = 0;
+    return smlp_launch(dtype, a, false, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int mlpk_smlp_mix_dw(int dtype, const void* x, int ldx, int B, int H, int W, int C, const float* dw_w, const float* dw_bias,
+                                const float* dw_scale, const float* dw_shift, void* xres, int ldxr, const float* bn_scale, const float* bn_shift,
+                                const void* wh, const float* bh, const void* ww, const float* bw, void* out, int ldo, void* stream) {
+    if (!x || !out || !xres || !dw_w || !dw_bias || !dw_scale || !dw_shift || !bn_scale || !bn_shift || !wh || !ww || !bh || !bw) return MLPK_ENULL;
+    if (B <= 0 || !mlpk_smlp_mix_dw_supported(dtype, H, W, C)) return MLPK_ESHAPE;
+    if (ldx < C || ldx % 8 || ldxr < C || ldxr % 8 || ldo < 3 * C || ldo % 8 || x == xres) return MLPK_ESHAPE;   // (a stencil: not in place)
+    if (((uintptr_t)x & 15) || ((uintptr_t)xres & 15) || ((uintptr_t)out & 15) || ((uintptr_t)wh & 15) || ((uintptr_t)ww & 15) || ((uintptr_t)bn_scale & 15) ||
+        ((uintptr_t)bn_shift & 15))
+        return MLPK_EALIGN;
+    SmlpArgs a;
+    a.x = x; a.out = out; a.bn_s = bn_scale; a.bn_h = bn_shift; a.wh = wh; a.ww = ww; a.bh = bh; a.bw = bw;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.ldx = ldx; a.ldo = ldo;
+    a.xres = xres; a.dw_w = dw_w; a.dw_b = dw_bias; a.dw_s = dw_scale; a.dw_h = dw_shift; a.ldxr = ldxr;
+    return smlp_launch(dtype, a, true, reinterpret_cast<hipStream_t>(stream));
+}
+
+static int smlp_launch(int dtype, SmlpArgs& a, bool dw, hipStream_t s) {
+    const int H = a.H, W = a.W, C = a.C, B = a.B;
+    const int lds = dw ? smlp_dw_lds(H, W) : (H + W) * 32 * 64;
     const int units = B * (C / 32);
     int dev = 0, cu = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu < 1) cu = 256;
     const int per_cu = lds <= 78 * 1024 ? 2 : 1;
     const int grid = units < cu * per_cu ? units : cu * per_cu;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipError_t e;
-    if (dtype == MLPK_BF16) {
-        auto k = smlp_mix_kernel<bf16_t>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(SM_NT), lds, s, a);
-    } else {
-        auto k = smlp_mix_kernel<f16_t>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(SM_NT), lds, s, a);
+    const bool small = H * W * 4 <= SM_NL_SMALL * SM_NT;     // few pieces per thread: the short unrolling (no spills)
+#define SM_LAUNCH(TT, DD)                                                                                               \
+    if (small) SM_LAUNCH2(TT, DD, SM_NL_SMALL) else SM_LAUNCH2(TT, false, 8)
+#define SM_LAUNCH2(TT, DD, NN)                                                                                          \
+    {                                                                                                                   \
+        auto k = smlp_mix_kernel<TT, DD, NN>;                                                                           \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        if (e != hipSuccess) return (int)e;                                                                             \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(SM_NT), lds, s, a);                                                      \
     }
+    if (dtype == MLPK_BF16) {
+        if (dw) SM_LAUNCH(bf16_t, true) else SM_LAUNCH(bf16_t, false)
+    } else {
+        if (dw) SM_LAUNCH(f16_t, true) else SM_LAUNCH(f16_t, false)
+    }
+#undef SM_LAUNCH
+#undef SM_LAUNCH2
     MLPK_LAUNCH_CHECK();
     return 0;
 }

@@ -286,6 +286,20 @@ def smlp_mix_supported(dtype, H, W, C):
     return bool(N.lib().mlpk_smlp_mix_supported(dtype_code(dtype), H, W, C))
 
 
+def smlp_mix_dw_supported(dtype, H, W, C):
+    """mlpk_smlp_mix_dw: the same with the block's depthwise 3 x 3 sublayer in front, for maps whose raw tile fits beside the transposed
+    copies (14 x 14, 7 x 7); MLPK_SMLP_MIX_DW=0: two kernels (A/B aid)"""
+    if os.environ.get("MLPK_SMLP_MIX_DW") == "0" or not smlp_mix_supported(dtype, H, W, C):
+        return False
+    return bool(N.lib().mlpk_smlp_mix_dw_supported(dtype_code(dtype), H, W, C))
+
+
+def smlp_mix_dw(x, ldx, B, H, W, C, dw_w, dw_b, dw_s, dw_h, xres, ldxr, bn_s, bn_h, wh, bh, ww, bw, out, ldo):
+    """xres = x + dwconv3x3(dw_s * x + dw_h) + dw_b (sparse_mlp.py:88-91), then smlp_mix of xres"""
+    N.check(N.lib().mlpk_smlp_mix_dw(dtype_code(x.dtype), ptr(x), ldx, B, H, W, C, ptr(dw_w), ptr(dw_b), ptr(dw_s), ptr(dw_h), ptr(xres), ldxr,
+                                     ptr(bn_s), ptr(bn_h), ptr(wh), ptr(bh), ptr(ww), ptr(bw), ptr(out), ldo, stream()), "mlpk_smlp_mix_dw")
+
+
 def pack_smlp_mix(w, b, dtype, device):
     """(S, S) axial mixing weight of nn.Linear(S, S) (sparse_mlp.py:64-65) -> (32, 32) zero-padded in the storage type, bias -> (32,) fp32"""
     S = w.shape[0]

@@ -159,10 +159,16 @@ class SparseMLP(E.EngineModule):
             # round 5 (maps up to 32 x 32): x + dwconv, then ONE kernel for BN + proj_h + proj_w + cat (mlpk_smlp_mix: the tile of an image's 32
             # channels is transposed inside LDS instead of through two transposed tensors in HBM), then the fuse as one K = 3C GEMM
             cat3 = ws.get("l%d.cat3" % li, (rows, 3 * C))
-            E.dwconv_affine_nhwc(cur, tmp, B, H, W, C, 3, pk[p + "dw.w"], pk[p + "dw.b"], pk[p + "dw.s"], pk[p + "dw.h"])
-            cur, tmp = tmp, cur
-            E.smlp_mix(cur, C, B, H, W, C, pk[p + "bn.s"], pk[p + "bn.h"], pk[p + "mix.wh"], pk[p + "mix.bh"], pk[p + "mix.ww"], pk[p + "mix.bw"],
-                       cat3, 3 * C)
+            if E.smlp_mix_dw_supported(cur.dtype, H, W, C):
+                # ... and on maps up to 15 x 15 the depthwise sublayer in the same kernel: its output goes to `tmp` (the fuse GEMM's residual)
+                E.smlp_mix_dw(cur, C, B, H, W, C, pk[p + "dw.w"], pk[p + "dw.b"], pk[p + "dw.s"], pk[p + "dw.h"], tmp, C,
+                              pk[p + "bn.s"], pk[p + "bn.h"], pk[p + "mix.wh"], pk[p + "mix.bh"], pk[p + "mix.ww"], pk[p + "mix.bw"], cat3, 3 * C)
+                cur, tmp = tmp, cur
+            else:
+                E.dwconv_affine_nhwc(cur, tmp, B, H, W, C, 3, pk[p + "dw.w"], pk[p + "dw.b"], pk[p + "dw.s"], pk[p + "dw.h"])
+                cur, tmp = tmp, cur
+                E.smlp_mix(cur, C, B, H, W, C, pk[p + "bn.s"], pk[p + "bn.h"], pk[p + "mix.wh"], pk[p + "mix.bh"], pk[p + "mix.ww"], pk[p + "mix.bw"],
+                           cat3, 3 * C)
             got = E.gemm(cat3, pk[p + "fu.w3"], cur, rows, C, 3 * C, bias=pk[p + "fu.b"], R=cur, res=N.RES_ADD, tag="smlp_fuse",
                          part=(ws, "l%d.fu.part" % li))
             channel_mlp(ws, cur, rows, C, pk, p + "ff.", C * ef, tag="l%d.cm" % li, stats=finalize_stats(ws, got, rows, C, tag="l%d.cm.ln" % li))

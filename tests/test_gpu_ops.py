@@ -1818,3 +1818,37 @@ def test_smlp_mix_in_one_kernel(dtype):
     assert not E.smlp_mix_supported(dtype, 56, 56, 96) and not E.smlp_mix_supported(dtype, 14, 14, 48) and not E.smlp_mix_supported(torch.float32, 14, 14, 64)
     with pytest.raises(RuntimeError):
         E.smlp_mix(x, C, B_, 56, 56, C, s, h, whp, bhp, wwp, bwp, out, 3 * C)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_smlp_mix_with_the_depthwise_sublayer_in_front(dtype):
+    """mlpk_smlp_mix_dw (round 5): x' = x + dwconv3x3(BN(x)) + b (sparse_mlp.py:88-91) and the sMLP mixing of x' in one kernel, for maps up to
+    15 x 15 -- bit-equal to mlpk_dwconv_affine_nhwc followed by mlpk_smlp_mix, for x' and for all 3 C output columns."""
+    pkg = load_pkg()
+    E, N = pkg.engine, pkg._native
+    for ci, (B_, H, W, C) in enumerate([(2, 14, 14, 64), (3, 7, 7, 96), (70, 14, 14, 384), (2, 15, 13, 32), (2, 9, 12, 64), (1, 1, 1, 32)]):
+        assert E.smlp_mix_dw_supported(dtype, H, W, C)
+        rows = B_ * H * W
+        x = (rnd((rows, C), dtype, 2400 + ci) * 1.5).to(dev())
+        dw_w = (rnd((9, C), torch.float32, 2410 + ci) * 0.3).to(dev())
+        dw_b = (rnd((C,), torch.float32, 2420 + ci) * 0.2).to(dev())
+        dw_s = (rnd((C,), torch.float32, 2430 + ci) * 0.3 + 1.0).to(dev())
+        dw_h = (rnd((C,), torch.float32, 2440 + ci) * 0.5).to(dev())
+        s = (rnd((C,), torch.float32, 2450 + ci) * 0.3 + 1.0).to(dev())
+        h = (rnd((C,), torch.float32, 2460 + ci) * 0.5).to(dev())
+        whp, bhp = E.pack_smlp_mix(rnd((H, H), torch.float32, 2470 + ci, 1.0 / math.sqrt(H)), rnd((H,), torch.float32, 2480 + ci), dtype, dev())
+        wwp, bwp = E.pack_smlp_mix(rnd((W, W), torch.float32, 2490 + ci, 1.0 / math.sqrt(W)), rnd((W,), torch.float32, 2500 + ci), dtype, dev())
+        x1 = torch.full((rows, C), float("nan"), dtype=dtype, device=dev())
+        E.dwconv_affine_nhwc(x, x1, B_, H, W, C, 3, dw_w, dw_b, dw_s, dw_h)
+        two = torch.full((rows, 3 * C), float("nan"), dtype=dtype, device=dev())
+        E.smlp_mix(x1, C, B_, H, W, C, s, h, whp, bhp, wwp, bwp, two, 3 * C)
+        x2 = torch.full((rows, C), float("nan"), dtype=dtype, device=dev())
+        one = torch.full((rows, 3 * C), float("nan"), dtype=dtype, device=dev())
+        E.smlp_mix_dw(x, C, B_, H, W, C, dw_w, dw_b, dw_s, dw_h, x2, C, s, h, whp, bhp, wwp, bwp, one, 3 * C)
+        torch.cuda.synchronize()
+        assert torch.isfinite(one.float()).all() and torch.isfinite(x2.float()).all()
+        assert torch.equal(x2.view(torch.int16), x1.view(torch.int16)), (str(dtype), ci, (x2.float() - x1.float()).abs().max().item())
+        assert torch.equal(one.view(torch.int16), two.view(torch.int16)), (str(dtype), ci, (one.float() - two.float()).abs().max().item())
+    assert not E.smlp_mix_dw_supported(dtype, 28, 28, 192)
+    with pytest.raises(RuntimeError):
+        E.smlp_mix_dw(x, C, B_, H, W, C, dw_w, dw_b, dw_s, dw_h, x, C, s, h, whp, bhp, wwp, bwp, one, 3 * C)      # not in place
