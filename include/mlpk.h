@@ -507,6 +507,14 @@ int mlpk_hire_gather(int dtype, const void* xn, void* a_h, void* a_w, int B, int
                      int step, int ld_h, int ld_w, void* stream);
 int mlpk_hire_combine(int dtype, void* x, const void* y_h, const void* y_w, int B, int H, int W, int C, int h, int w,
                       int step, int ld_h, int ld_w, void* stream);
+/* round 5 -- the block without a stored LayerNorm output: gather_ln takes the UN-normalised x and applies the block's LayerNorm (hire_mlp.py:176;
+ * mean / rstd per pixel, gamma / beta per channel, (x - mean) rstd gamma + beta with one rounding: mlpk_norm_apply's expression) to every vector it
+ * moves; combine_from reads the tensor the branch results are added to from `src` and writes x = src + y_h + y_w (src = x + proj_c(LN(x)), produced by a
+ * GEMM with the LayerNorm folded in, which cannot write in place). */
+int mlpk_hire_gather_ln(int dtype, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, void* a_h, void* a_w,
+                        int B, int H, int W, int C, int h, int w, int step, int ld_h, int ld_w, void* stream);
+int mlpk_hire_combine_from(int dtype, void* x, const void* src, const void* y_h, const void* y_w, int B, int H, int W, int C, int h, int w,
+                           int step, int ld_h, int ld_w, void* stream);
 
 /* ---- MS-MLP mix-shift (ms_mlp.py:48-66) -------------------------------------------
  * x, out: (B,H,W,C) channel-last.  The C channels form `groups` <= 8 chunks of ceil(C/groups) channels (torch.chunk); chunk g is

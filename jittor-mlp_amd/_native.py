@@ -110,6 +110,8 @@ PROTOTYPES = {
     "mlpk_dwconv_affine_nhwc": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p] * 4 + [c_void_p]),
     "mlpk_im2col": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p]),
     "mlpk_hire_gather": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
+    "mlpk_hire_gather_ln": (c_int, [c_int] + [c_void_p] * 7 + [c_int] * 9 + [c_void_p]),
+    "mlpk_hire_combine_from": (c_int, [c_int] + [c_void_p] * 4 + [c_int] * 9 + [c_void_p]),
     "mlpk_hire_combine": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     "mlpk_mixshift_nhwc": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 5 + [ctypes.POINTER(c_int), ctypes.POINTER(c_int)] + [c_void_p] * 4 + [c_void_p]),
     "mlpk_window_gather": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),

@@ -13,7 +13,27 @@ struct HireArgs {
     void* a_h;           // (B * gh * W, ld_h): row (b, g, x), columns hh * C + c  <-  xn[b, src_h((hh * gh + g - step) mod Hp), x, c]
     void* a_w;           // (B * H * gw, ld_w): row (b, y, g), columns ww * C + c  <-  xn[b, y, src_w((ww * gw + g - step) mod Wp), c]
     int B, H, W, C, h, w, step, Hp, Wp, gh, gw, ld_h, ld_w;
+    // round 5 (mlpk_hire_gather_ln): xn is the UN-normalised x and the block's LayerNorm (hire_mlp.py:176, per pixel over C) is applied to every
+    // vector on the way -- (x - mean) rstd gamma + beta, one rounding, the expression of mlpk_norm_apply: no normalised tensor is stored
+    const float* mean;   // per pixel (B*H*W), or NULL: xn is used as it is
+    const float* rstd;
+    const float* gamma;  // per channel
+    const float* beta;
 };
+
+template <typename T>
+__device__ __forceinline__ u32x4 hire_ln(const HireArgs& p, u32x4 v, int64_t pix, int c0) {
+    constexpr int EPV = 16 / (int)sizeof(T);
+    if (!p.mean) return v;
+    const float rs = p.rstd[pix], mu = p.mean[pix];
+    T e[EPV];
+    __builtin_memcpy(e, &v, 16);
+#pragma unroll
+    for (int k = 0; k < EPV; ++k) e[k] = from_f32<T>(__builtin_fmaf((to_f32(e[k]) - mu) * rs, p.gamma[c0 + k], p.beta[c0 + k]));   // (norm_apply_tile_kernel's form)
+    u32x4 o;
+    __builtin_memcpy(&o, e, 16);
+    return o;
+}
 
 template <typename T>
 __global__ void __launch_bounds__(256) hire_gather_kernel(const HireArgs p) {
@@ -33,7 +53,7 @@ __global__ void __launch_bounds__(256) hire_gather_kernel(const HireArgs p) {
             int q = (hh * p.gh + g - p.step) % p.Hp;
             if (q < 0) q += p.Hp;
             const int y = q < p.H ? q : q - p.H;                       // circular padding: appended rows repeat the first ones
-            const u32x4 v = *reinterpret_cast<const u32x4*>(xn + ((b * p.H + y) * p.W + x) * p.C + c0);
+            const u32x4 v = hire_ln<T>(p, *reinterpret_cast<const u32x4*>(xn + ((b * p.H + y) * p.W + x) * p.C + c0), (b * p.H + y) * p.W + x, c0);
             T* o = reinterpret_cast<T*>(p.a_h) + ((b * p.gh + g) * p.W + x) * p.ld_h + hh * p.C + c0;
             *reinterpret_cast<u32x4*>(o) = v;
         } else {
@@ -47,7 +67,7 @@ __global__ void __launch_bounds__(256) hire_gather_kernel(const HireArgs p) {
             int q = (ww * p.gw + g - p.step) % p.Wp;
             if (q < 0) q += p.Wp;
             const int x = q < p.W ? q : q - p.W;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(xn + ((b * p.H + y) * p.W + x) * p.C + c0);
+            const u32x4 v = hire_ln<T>(p, *reinterpret_cast<const u32x4*>(xn + ((b * p.H + y) * p.W + x) * p.C + c0), (b * p.H + y) * p.W + x, c0);
             T* o = reinterpret_cast<T*>(p.a_w) + ((b * p.H + y) * p.gw + g) * p.ld_w + ww * p.C + c0;
             *reinterpret_cast<u32x4*>(o) = v;
         }
@@ -55,7 +75,8 @@ __global__ void __launch_bounds__(256) hire_gather_kernel(const HireArgs p) {
 }
 
 struct HireCombineArgs {
-    void* x;             // (B, H, W, C): x += y_h(restored) + y_w(restored)
+    void* x;             // (B, H, W, C): x = src + y_h(restored) + y_w(restored)
+    const void* src;     // (B, H, W, C); == x: in place (mlpk_hire_combine)
     const void* y_h;     // (B * gh * W, ld_h), columns hh * C + c
     const void* y_w;     // (B * H * gw, ld_w), columns ww * C + c
     int B, H, W, C, h, w, step, Hp, Wp, gh, gw, ld_h, ld_w;
@@ -64,7 +85,8 @@ struct HireCombineArgs {
 template <typename T>
 __global__ void __launch_bounds__(256) hire_combine_kernel(const HireCombineArgs p) {
     constexpr int EPV = 16 / (int)sizeof(T);
-    T* __restrict__ xo = reinterpret_cast<T*>(p.x);
+    T* xo = reinterpret_cast<T*>(p.x);
+    const T* xs = reinterpret_cast<const T*>(p.src);
     const T* __restrict__ yh = reinterpret_cast<const T*>(p.y_h);
     const T* __restrict__ yw = reinterpret_cast<const T*>(p.y_w);
     const int cv = p.C / EPV;
@@ -84,7 +106,7 @@ __global__ void __launch_bounds__(256) hire_combine_kernel(const HireCombineArgs
         const T* pw = yw + ((b * p.H + y) * p.gw + qw % p.gw) * p.ld_w + (qw / p.gw) * p.C + c0;
         T* po = xo + ((b * p.H + y) * p.W + x) * p.C + c0;
         T a[EPV], u[EPV], v[EPV];
-        *reinterpret_cast<u32x4*>(a) = *reinterpret_cast<const u32x4*>(po);
+        *reinterpret_cast<u32x4*>(a) = *reinterpret_cast<const u32x4*>(xs + ((b * p.H + y) * p.W + x) * p.C + c0);
         *reinterpret_cast<u32x4*>(u) = *reinterpret_cast<const u32x4*>(ph);
         *reinterpret_cast<u32x4*>(v) = *reinterpret_cast<const u32x4*>(pw);
 #pragma unroll
@@ -108,10 +130,20 @@ static int hire_geometry(int B, int H, int W, int C, int h, int w, int dtype, in
 
 using namespace mlpk;
 
+extern "C" int mlpk_hire_gather_ln(int dtype, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, void* a_h,
+                                   void* a_w, int B, int H, int W, int C, int h, int w, int step, int ld_h, int ld_w, void* stream);
+
 extern "C" int mlpk_hire_gather(int dtype, const void* xn, void* a_h, void* a_w, int B, int H, int W, int C, int h, int w,
                                 int step, int ld_h, int ld_w, void* stream) {
+    return mlpk_hire_gather_ln(dtype, xn, nullptr, nullptr, nullptr, nullptr, a_h, a_w, B, H, W, C, h, w, step, ld_h, ld_w, stream);
+}
+
+extern "C" int mlpk_hire_gather_ln(int dtype, const void* xn, const float* mean, const float* rstd, const float* gamma, const float* beta, void* a_h,
+                                   void* a_w, int B, int H, int W, int C, int h, int w, int step, int ld_h, int ld_w, void* stream) {
     if (!xn || !a_h || !a_w) return MLPK_ENULL;
+    if ((mean != nullptr) != (rstd != nullptr) || (mean != nullptr) != (gamma != nullptr) || (mean != nullptr) != (beta != nullptr)) return MLPK_ENULL;
     HireArgs a;
+    a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta;
     int rc = hire_geometry(B, H, W, C, h, w, dtype, ld_h, ld_w, &a.Hp, &a.Wp);
     if (rc) return rc;
     if (((uintptr_t)xn & 15) || ((uintptr_t)a_h & 15) || ((uintptr_t)a_w & 15)) return MLPK_EALIGN;
@@ -130,10 +162,20 @@ extern "C" int mlpk_hire_gather(int dtype, const void* xn, void* a_h, void* a_w,
     return 0;
 }
 
+extern "C" int mlpk_hire_combine_from(int dtype, void* x, const void* src, const void* y_h, const void* y_w, int B, int H, int W, int C, int h, int w,
+                                      int step, int ld_h, int ld_w, void* stream);
+
 extern "C" int mlpk_hire_combine(int dtype, void* x, const void* y_h, const void* y_w, int B, int H, int W, int C, int h, int w,
                                  int step, int ld_h, int ld_w, void* stream) {
-    if (!x || !y_h || !y_w) return MLPK_ENULL;
+    return mlpk_hire_combine_from(dtype, x, x, y_h, y_w, B, H, W, C, h, w, step, ld_h, ld_w, stream);
+}
+
+extern "C" int mlpk_hire_combine_from(int dtype, void* x, const void* src, const void* y_h, const void* y_w, int B, int H, int W, int C, int h, int w,
+                                      int step, int ld_h, int ld_w, void* stream) {
+    if (!x || !src || !y_h || !y_w) return MLPK_ENULL;
+    if ((uintptr_t)src & 15) return MLPK_EALIGN;
     HireCombineArgs a;
+    a.src = src;
     int rc = hire_geometry(B, H, W, C, h, w, dtype, ld_h, ld_w, &a.Hp, &a.Wp);
     if (rc) return rc;
     if (((uintptr_t)x & 15) || ((uintptr_t)y_h & 15) || ((uintptr_t)y_w & 15)) return MLPK_EALIGN;

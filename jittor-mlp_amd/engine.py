@@ -660,6 +660,16 @@ def hire_gather(xn, a_h, a_w, B, H, W, C, h, w, step, ld_h, ld_w):
                                      stream()), "mlpk_hire_gather")
 
 
+def hire_gather_ln(x, mean, rstd, gamma, beta, a_h, a_w, B, H, W, C, h, w, step, ld_h, ld_w):
+    N.check(N.lib().mlpk_hire_gather_ln(dtype_code(x.dtype), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(a_h), ptr(a_w), B, H, W, C, h, w,
+                                        step, ld_h, ld_w, stream()), "mlpk_hire_gather_ln")
+
+
+def hire_combine_from(x, src, y_h, y_w, B, H, W, C, h, w, step, ld_h, ld_w):
+    N.check(N.lib().mlpk_hire_combine_from(dtype_code(x.dtype), ptr(x), ptr(src), ptr(y_h), ptr(y_w), B, H, W, C, h, w, step, ld_h, ld_w,
+                                           stream()), "mlpk_hire_combine_from")
+
+
 def hire_combine(x, y_h, y_w, B, H, W, C, h, w, step, ld_h, ld_w):
     N.check(N.lib().mlpk_hire_combine(dtype_code(x.dtype), ptr(x), ptr(y_h), ptr(y_w), B, H, W, C, h, w, step, ld_h, ld_w,
                                       stream()), "mlpk_hire_combine")

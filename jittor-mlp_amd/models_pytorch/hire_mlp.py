@@ -13,6 +13,9 @@ HireMLPBlock (hire_mlp.py:96-152) on the channel-last LayerNorm output xn (B*H*W
 The patcher (7x7 stride-4 pad-3 conv, :203) and the stage transitions (3x3 stride-2 pad-1 conv, :161) are window gathers
 (mlpk_im2col) + GEMM; the channel MLP folds its LayerNorm into fc1; the head folds its LayerNorm into the token mean.
 """
+import os
+
+import torch
 from torch import nn
 
 from .. import _native as N
@@ -144,6 +147,9 @@ class HireMLP(E.EngineModule):
                     pk[p + tag + "2.b"] = E.f32(b2, device)
                 pk[p + "c.w"] = E.pack_matrix(hb.proj_c.weight, dtype, device)
                 pk[p + "c.b"] = E.f32(hb.proj_c.bias, device)
+                # round 5: proj_c with the block's LayerNorm folded in (reads x itself; the gather applies the LayerNorm to what it moves)
+                pk[p + "cf.w"], pk[p + "cf.b"], pk[p + "cf.csum"] = E.pack_ln_folded(hb.proj_c.weight, hb.proj_c.bias, blk[0].norm.weight, blk[0].norm.bias,
+                                                                                   dtype, device)
                 ff = blk[1]
                 pack_channel_mlp(pk, p + "ff.", ff.norm, ff.fn[0], ff.fn[3], dtype, device)
             if stage.pooling:
@@ -175,8 +181,13 @@ class HireMLP(E.EngineModule):
         p = "l%d.b%d." % (li, bi)
         step = blk[0].fn[0].step
         mean, rstd = st if st is not None else layernorm_stats(ws, cur, rows, C, tag="l%d.ln" % li)
-        E.norm_apply(cur, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "ln.g"], beta=pk[p + "ln.b"], out_rm=xn, ld_rm=C)
-        E.hire_gather(xn, a_h, a_w, B, H, W, C, h, w, step, h * C, w * C)
+        fold = cur.dtype != torch.float32 and os.environ.get("MLPK_HIRE_LN_FOLD") != "0"
+        if fold:
+            # round 5: no stored LayerNorm output -- the gather normalises the vectors it moves, proj_c reads x with the LayerNorm folded in
+            E.hire_gather_ln(cur, mean, rstd, pk[p + "ln.g"], pk[p + "ln.b"], a_h, a_w, B, H, W, C, h, w, step, h * C, w * C)
+        else:
+            E.norm_apply(cur, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "ln.g"], beta=pk[p + "ln.b"], out_rm=xn, ld_rm=C)
+            E.hire_gather(xn, a_h, a_w, B, H, W, C, h, w, step, h * C, w * C)
         # the w-branch pair of GEMMs touches only a_w / t_w: it runs on a side stream beside the h-branch pair and proj_c
         # (short GEMMs of 20-50 us each: two kernels in flight fill the tail of each other's last wave of tiles)
         chain = E.SideChain(ws, "hire.w", cur.device)
@@ -185,9 +196,14 @@ class HireMLP(E.EngineModule):
             E.gemm(t_w, pk[p + "w2.w"], a_w, rows_w, w * C, hidp, bias=pk[p + "w2.b"], tag="hire_fc2")
         E.gemm(a_h, pk[p + "h1.w"], t_h, rows_h, hid, h * C, bias=pk[p + "h1.b"], act=N.ACT_GELU, tag="hire_fc1")
         E.gemm(t_h, pk[p + "h2.w"], a_h, rows_h, h * C, hidp, bias=pk[p + "h2.b"], tag="hire_fc2")    # y_h overwrites a_h
-        E.gemm(xn, pk[p + "c.w"], cur, rows, C, C, bias=pk[p + "c.b"], R=cur, res=N.RES_ADD, tag="hire_c")   # x + proj_c(xn)
-        chain.join()
-        E.hire_combine(cur, a_h, a_w, B, H, W, C, h, w, step, h * C, w * C)
+        if fold:
+            E.gemm(cur, pk[p + "cf.w"], xn, rows, C, C, bias=pk[p + "cf.b"], ln=(mean, rstd, pk[p + "cf.csum"]), R=cur, res=N.RES_ADD, tag="hire_c")
+            chain.join()
+            E.hire_combine_from(cur, xn, a_h, a_w, B, H, W, C, h, w, step, h * C, w * C)      # x = (x + proj_c(LN x)) + y_h + y_w
+        else:
+            E.gemm(xn, pk[p + "c.w"], cur, rows, C, C, bias=pk[p + "c.b"], R=cur, res=N.RES_ADD, tag="hire_c")   # x + proj_c(xn)
+            chain.join()
+            E.hire_combine(cur, a_h, a_w, B, H, W, C, h, w, step, h * C, w * C)
         got = channel_mlp(ws, cur, rows, C, pk, p + "ff.", C * ef, tag="l%d.cm" % li, part=(ws, "l%d.fc2.part" % li))
         st = finalize_stats(ws, got, rows, C, tag="l%d.ln" % li)
         return st

@@ -1203,6 +1203,27 @@ def test_hire_gather_combine(dtype):
         torch.cuda.synchronize()
         err = (xg.float().cpu() - want.float()).abs().max().item()
         assert err <= (1e-6 if dtype == torch.float32 else 2e-2), (str(dtype), ci, err)
+        # round 5: the same two kernels without a stored LayerNorm output -- gather_ln normalises what it moves (bit-equal to mlpk_norm_apply
+        # followed by the gather), combine_from adds the branch results onto another tensor (bit-equal to the in-place form on a copy)
+        rows = B * H * W
+        xr = (rnd((rows, C), dtype, 1140 + ci) * 1.5 + 0.2).to(dev())
+        gamma, beta = (rnd((C,), torch.float32, 1150 + ci) * 0.3 + 1.0).to(dev()), (rnd((C,), torch.float32, 1160 + ci) * 0.2).to(dev())
+        mean, rstd = torch.empty((rows,), dtype=torch.float32, device=dev()), torch.empty((rows,), dtype=torch.float32, device=dev())
+        E.row_stats(xr, rows, C, C, mean, rstd)
+        xnn = torch.empty_like(xr)
+        E.norm_apply(xr, rows, C, C, mean=mean, rstd=rstd, gamma=gamma, beta=beta, out_rm=xnn, ld_rm=C)
+        b_h, b_w = torch.full_like(a_h, float("nan")), torch.full_like(a_w, float("nan"))
+        E.hire_gather(xnn, b_h, b_w, B, H, W, C, h, w, step, h * C, w * C)
+        c_h, c_w = torch.full_like(a_h, float("nan")), torch.full_like(a_w, float("nan"))
+        E.hire_gather_ln(xr, mean, rstd, gamma, beta, c_h, c_w, B, H, W, C, h, w, step, h * C, w * C)
+        src = rnd((B, H, W, C), dtype, 1170 + ci).to(dev())
+        inplace = src.clone()
+        E.hire_combine(inplace, y_h.to(dev()), y_w.to(dev()), B, H, W, C, h, w, step, h * C, w * C)
+        other = torch.full_like(src, float("nan"))
+        E.hire_combine_from(other, src, y_h.to(dev()), y_w.to(dev()), B, H, W, C, h, w, step, h * C, w * C)
+        torch.cuda.synchronize()
+        assert torch.equal(c_h, b_h) and torch.equal(c_w, b_w), (str(dtype), ci)
+        assert torch.equal(other, inplace), (str(dtype), ci)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
