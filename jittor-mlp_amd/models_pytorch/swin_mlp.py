@@ -65,8 +65,8 @@ class SwinMLPBlock(Block):
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
 
 
-class PatchMerging(Holder):
-    """swin_mlp.py:178-191."""
+class PatchMerging(Block):
+    """swin_mlp.py:178-191.  Inside a SwinMLP it runs on its own like the reference's (:193-212): (B, H*W, C) -> (B, H/2*W/2, 2C); round 5."""
 
     def __init__(self, input_resolution, dim, norm_layer=nn.LayerNorm):
         super().__init__()
@@ -76,8 +76,8 @@ class PatchMerging(Holder):
         self.norm = norm_layer(4 * dim)
 
 
-class BasicLayer(Holder):
-    """swin_mlp.py:231-256."""
+class BasicLayer(Block):
+    """swin_mlp.py:231-256.  Inside a SwinMLP a stage runs on its own like the reference's (:258-266): its blocks, then its PatchMerging; round 5."""
 
     def __init__(self, dim, input_resolution, depth, num_heads, window_size, mlp_ratio=4., drop=0., drop_path=0., norm_layer=nn.LayerNorm,
                  downsample=None, use_checkpoint=False):
@@ -93,8 +93,8 @@ class BasicLayer(Holder):
         self.downsample = downsample(input_resolution, dim=dim, norm_layer=norm_layer) if downsample is not None else None
 
 
-class PatchEmbed(Holder):
-    """swin_mlp.py:296-322."""
+class PatchEmbed(Block):
+    """swin_mlp.py:296-322.  Inside a SwinMLP it runs on its own like the reference's (:324-333): (B, 3, H, W) -> (B, H/4*W/4, embed_dim); round 5."""
 
     def __init__(self, img_size=224, patch_size=4, in_chans=3, embed_dim=96, norm_layer=None):
         super().__init__()
@@ -149,6 +149,10 @@ class SwinMLP(E.EngineModule):
         for li, layer in enumerate(self.layers):
             for bi, blk in enumerate(layer.blocks):
                 blk.__dict__["_owner"] = (self, (li, bi))          # lets `model.layers[l].blocks[b](x)` run (common.Block)
+            layer.__dict__["_owner"] = (self, (li, "layer"))       # ... `model.layers[l](x)`: the blocks, then the PatchMerging
+            if layer.downsample is not None:
+                layer.downsample.__dict__["_owner"] = (self, (li, "down"))
+        self.patch_embed.__dict__["_owner"] = (self, ("embed", None))
         self.apply(self._init_weights)
 
     def _init_weights(self, m):
@@ -228,23 +232,67 @@ class SwinMLP(E.EngineModule):
         st = finalize_stats(ws_, got, rows, C, tag="l%d.ln" % li)
         return st
 
+    def _embed(self, ws_, pk, x, B, cd):
+        """PatchEmbed (swin_mlp.py:324-333): Conv2d(k = stride = patch) + flatten + transpose (+ LayerNorm) -> channel-last tokens"""
+        pe = self.patch_embed
+        C = self.embed_dim
+        cur, H, W = embed_patches(ws_, "embed", x, pk["embed.w"], pk["embed.b"], cd, tuple(pe.patch_size),
+                                  out=ws_.get("l0.x", (B * pe.patches_resolution[0] * pe.patches_resolution[1], C)))
+        if pe.norm is not None:
+            mean, rstd = layernorm_stats(ws_, cur, B * H * W, C, tag="embed.ln")
+            E.norm_apply(cur, B * H * W, C, C, mean=mean, rstd=rstd, gamma=pk["embed.g"], beta=pk["embed.be"], out_rm=cur, ld_rm=C)
+        return cur, H, W
+
+    def _merge(self, ws_, pk, li, cur, B, H, W, C):
+        """PatchMerging (swin_mlp.py:193-212): 2 x 2 gather + LayerNorm folded into the bias-free reduction GEMM; returns (next, statistics)"""
+        assert H % 2 == 0 and W % 2 == 0, f"x size ({H}*{W}) are not even."                                 # swin_mlp.py:201
+        p = "l%d.merge." % li
+        H2, W2 = H // 2, W // 2
+        merged = ws_.get("l%d.merged" % li, (B * H2 * W2, 4 * C))
+        E.patchify(cur, merged, B, C, H, W, 2, 2, 0, 4 * C, layout=N.LAYOUT_NHWC, px_stride=C, order=1)
+        mean, rstd = layernorm_stats(ws_, merged, B * H2 * W2, 4 * C, tag="l%d.merge.ln" % li)
+        nxt = ws_.get("l%d.x" % (li + 1), (B * H2 * W2, 2 * C))
+        got = E.gemm(merged, pk[p + "w"], nxt, B * H2 * W2, 2 * C, 4 * C, bias=pk[p + "b"], ln=(mean, rstd, pk[p + "csum"]), tag="swin_merge",
+                     part=(ws_, "l%d.merge.part" % li))
+        return nxt, finalize_stats(ws_, got, B * H2 * W2, 2 * C, tag="l%d.ln" % (li + 1))
+
     def _run_single(self, key, x):
-        """SwinMLPBlock (layer, block) alone on (B, H*W, C), as `model.layers[l].blocks[b](x)` in the reference (swin_mlp.py:113-157)"""
+        """An inner module alone, as calling it does in the reference: `model.layers[l].blocks[b](x)` (swin_mlp.py:113-157), `model.layers[l](x)`
+        (a stage: :258-266), `model.layers[l].downsample(x)` (:193-212) on (B, H*W, C); `model.patch_embed(x)` (:324-333) on (B, 3, H, W)"""
         li, bi = key
-        E.require_gpu(x, "SwinMLPBlock.forward")
+        E.require_gpu(x, "SwinMLP inner module")
         E.dtype_code(x.dtype)
-        blk = self.layers[li].blocks[bi]
-        H, W = blk.input_resolution
-        C = blk.dim
+        if li == "embed":
+            pe = self.patch_embed
+            if x.dim() != 4 or x.shape[1] != pe.in_chans:
+                raise ValueError("expected a (B, %d, H, W) tensor" % pe.in_chans)
+            B, _, H_in, W_in = x.shape
+            assert H_in == pe.img_size[0] and W_in == pe.img_size[1], \
+                f"Input image size ({H_in}*{W_in}) doesn't match model ({pe.img_size[0]}*{pe.img_size[1]})."      # swin_mlp.py:327-328
+            with E.on_device(x):
+                pk = self._get_pack(x.dtype, x.device)
+                ws_ = self._get_space(("embed", B, H_in, W_in), x.dtype, x.device)
+                cur, H, W = self._embed(ws_, pk, x.contiguous(), B, x.dtype)
+                return cur.reshape(B, H * W, self.embed_dim).clone()
+        layer = self.layers[li]
+        H, W = layer.input_resolution
+        C = layer.dim
         if x.dim() != 3 or x.shape[1] != H * W or x.shape[2] != C:
             raise ValueError("expected a (B, %d, %d) tensor" % (H * W, C))
         B = x.shape[0]
         with E.on_device(x):
             pk = self._get_pack(x.dtype, x.device)
             ws_ = self._get_space(("block", B, H, W, C), x.dtype, x.device)     # (C: blocks of different stages can meet at one map size)
-            cur = ws_.get("blk.x", (B * H * W, C))
+            cur = ws_.get("l%d.x" % li, (B * H * W, C))
             cur.copy_(x.reshape(B * H * W, C))
-            self._block(ws_, pk, li, bi, blk, cur, B, H, W, C, None)
+            st = None
+            if bi != "down":
+                for b_i, blk in enumerate(layer.blocks):
+                    if bi == "layer" or b_i == bi:
+                        st = self._block(ws_, pk, li, b_i, blk, cur, B, H, W, C, st)
+            if bi == "down" or (bi == "layer" and layer.downsample is not None):
+                cur, _ = self._merge(ws_, pk, li, cur, B, H, W, C)
+                H, W, C = H // 2, W // 2, 2 * C
             return cur.reshape(B, H * W, C).clone()
 
     def forward(self, x):
@@ -255,13 +303,8 @@ class SwinMLP(E.EngineModule):
             f"Input image size ({H_in}*{W_in}) doesn't match model ({pe.img_size[0]}*{pe.img_size[1]})."          # swin_mlp.py:327-328
         pk = self._get_pack(cd, x.device)
         ws_ = self._get_space(B, cd, x.device)
-        x = x.contiguous()
         C = self.embed_dim
-        cur, H, W = embed_patches(ws_, "embed", x, pk["embed.w"], pk["embed.b"], cd, tuple(pe.patch_size),
-                                  out=ws_.get("l0.x", (B * pe.patches_resolution[0] * pe.patches_resolution[1], C)))
-        if pe.norm is not None:
-            mean, rstd = layernorm_stats(ws_, cur, B * H * W, C, tag="embed.ln")
-            E.norm_apply(cur, B * H * W, C, C, mean=mean, rstd=rstd, gamma=pk["embed.g"], beta=pk["embed.be"], out_rm=cur, ld_rm=C)
+        cur, H, W = self._embed(ws_, pk, x.contiguous(), B, cd)
         if self.ape:
             E.add_periodic(cur, C, pk["ape"], B * H * W, C, H * W)                       # x + absolute_pos_embed (swin_mlp.py:437-438)
         st = None            # (mean, rstd) of cur's rows when the GEMM that wrote cur delivered them (mlpk.h row_part)
@@ -271,17 +314,8 @@ class SwinMLP(E.EngineModule):
             for bi, blk in enumerate(layer.blocks):
                 st = self._block(ws_, pk, li, bi, blk, cur, B, H, W, C, st)
             if layer.downsample is not None:
-                assert H % 2 == 0 and W % 2 == 0, f"x size ({H}*{W}) are not even."                                 # swin_mlp.py:201
-                p = "l%d.merge." % li
-                H2, W2 = H // 2, W // 2
-                merged = ws_.get("l%d.merged" % li, (B * H2 * W2, 4 * C))
-                E.patchify(cur, merged, B, C, H, W, 2, 2, 0, 4 * C, layout=N.LAYOUT_NHWC, px_stride=C, order=1)
-                mean, rstd = layernorm_stats(ws_, merged, B * H2 * W2, 4 * C, tag="l%d.merge.ln" % li)
-                nxt = ws_.get("l%d.x" % (li + 1), (B * H2 * W2, 2 * C))
-                got = E.gemm(merged, pk[p + "w"], nxt, B * H2 * W2, 2 * C, 4 * C, bias=pk[p + "b"], ln=(mean, rstd, pk[p + "csum"]), tag="swin_merge",
-                             part=(ws_, "l%d.merge.part" % li))
-                st = finalize_stats(ws_, got, B * H2 * W2, 2 * C, tag="l%d.ln" % (li + 1))
-                cur, H, W, C = nxt, H2, W2, 2 * C
+                cur, st = self._merge(ws_, pk, li, cur, B, H, W, C)
+                H, W, C = H // 2, W // 2, 2 * C
         mean, rstd = st if st is not None else layernorm_stats(ws_, cur, B * H * W, C, tag="head.ln")
         pooled = ws_.get("pooled", (B, C))
         E.pool_mean(cur, B, H * W, C, C, pooled, C, mean=mean, rstd=rstd, gamma=pk["norm.g"], beta=pk["norm.b"])

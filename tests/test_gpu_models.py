@@ -509,6 +509,36 @@ def test_swin_and_msmlp_blocks_callable_like_the_reference():
         ref = Fo.swinmlp_block(sd, t, "layers.%d.blocks.%d." % (li, bi), hw, hw, nh, 4, blk.shift_size if hw > 4 else 0)
         got = blk(t.to(DEV))
         assert (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), ("swin", li, bi)
+    # round 5: PatchEmbed (swin_mlp.py:324-333), PatchMerging (:193-212) and a whole stage (BasicLayer, :258-266) run on their own too
+    img = torch.randn(2, 3, 32, 32)
+    ref = Fo.patch_embed(img, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"]).reshape(2, 64, 32)
+    ref = Fo.layer_norm(ref, sd["patch_embed.norm.weight"], sd["patch_embed.norm.bias"])
+    got = swin.patch_embed(img.to(DEV))
+    assert got.shape == ref.shape and (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+    def merging(t, pre, hw):
+        g = t.reshape(2, hw, hw, t.shape[-1])
+        g = torch.cat([g[:, 0::2, 0::2, :], g[:, 1::2, 0::2, :], g[:, 0::2, 1::2, :], g[:, 1::2, 1::2, :]], dim=-1).reshape(2, hw * hw // 4, -1)
+        return Fo.linear(Fo.layer_norm(g, sd[pre + "norm.weight"], sd[pre + "norm.bias"]), sd[pre + "reduction.weight"], None)
+
+    t = torch.randn(2, 64, 32)
+    ref = merging(t, "layers.0.downsample.", 8)
+    got = swin.layers[0].downsample(t.to(DEV))
+    assert got.shape == ref.shape == (2, 16, 64) and (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    ref = t
+    for bi in range(2):
+        ref = Fo.swinmlp_block(sd, ref, "layers.0.blocks.%d." % bi, 8, 8, 2, 4, swin.layers[0].blocks[bi].shift_size)
+    ref = merging(ref, "layers.0.downsample.", 8)
+    got = swin.layers[0](t.to(DEV))                                            # stage 0: two blocks, then the merging
+    assert got.shape == ref.shape and (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    t = torch.randn(2, 16, 64)
+    ref = t
+    for bi in range(2):
+        ref = Fo.swinmlp_block(sd, ref, "layers.1.blocks.%d." % bi, 4, 4, 4, 4, 0)
+    got = swin.layers[1](t.to(DEV))                                            # the last stage has no downsample
+    assert got.shape == ref.shape and (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    with pytest.raises(NotImplementedError):
+        mp.swin_mlp.PatchMerging((8, 8), 32)(t.to(DEV))                        # outside a model: a parameter container
     sd = {k: v.detach().clone() for k, v in ms.state_dict().items()}
     ms = ms.to(DEV)
     for (li, bi, C, hw) in ((0, 1, 40, 8), (1, 0, 80, 4)):
