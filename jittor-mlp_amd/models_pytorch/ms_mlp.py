@@ -62,8 +62,9 @@ class MixShiftBlock(Block):
         self.drop_path = nn.Identity()
 
 
-class PatchEmbed(Holder):
-    """ms_mlp.py:229-253 (also the stage transition, with patch_size 2)."""
+class PatchEmbed(Block):
+    """ms_mlp.py:229-253 (also the stage transition, with patch_size 2).  Inside an MS_MLP it runs on its own like the reference's (:255-262):
+    (B, C_in, H, W) -> (B, embed_dim, H / p, W / p); round 5."""
 
     def __init__(self, img_size=224, patch_size=4, in_chans=3, embed_dim=96, norm_layer=None):
         super().__init__()
@@ -80,8 +81,8 @@ class PatchEmbed(Holder):
         self.norm = norm_layer(embed_dim) if norm_layer is not None else None
 
 
-class BasicLayer(Holder):
-    """ms_mlp.py:151-181."""
+class BasicLayer(Block):
+    """ms_mlp.py:151-181.  Inside an MS_MLP a stage runs on its own like the reference's (:177-185): its blocks, then its PatchEmbed; round 5."""
 
     def __init__(self, dim, input_resolution, depth, shift_size, shift_dist, mix_size, mlp_ratio=4., drop=0., drop_path=0.,
                  norm_layer=nn.LayerNorm, downsample=None, use_checkpoint=False):
@@ -133,6 +134,10 @@ class MS_MLP(E.EngineModule):
         for li, layer in enumerate(self.layers):
             for bi, blk in enumerate(layer.blocks):
                 blk.__dict__["_owner"] = (self, (li, bi))          # lets `model.layers[l].blocks[b](x)` run (common.Block)
+            layer.__dict__["_owner"] = (self, (li, "layer"))       # ... `model.layers[l](x)`: the blocks, then the downsampling PatchEmbed
+            if layer.downsample is not None:
+                layer.downsample.__dict__["_owner"] = (self, (li, "down"))
+        self.patch_embed.__dict__["_owner"] = (self, ("embed", None))
         self.apply(self._init_weights)
 
     def _init_weights(self, m):
@@ -191,13 +196,54 @@ class MS_MLP(E.EngineModule):
             pk["head.b"] = E.f32(self.head.bias, device)
         return pk
 
+    def _embed(self, ws, pk, x, B, cd):
+        """the model's PatchEmbed (ms_mlp.py:255-262) on the NCHW image -> channel-last rows"""
+        pe = self.patch_embed
+        C = self.embed_dim
+        cur, H, W = embed_patches(ws, "embed", x, pk["embed.w"], pk["embed.b"], cd, tuple(pe.patch_size),
+                                  out=ws.get("l0.x", (B * pe.patches_resolution[0] * pe.patches_resolution[1], C)))
+        if pe.norm is not None:
+            mean, rstd = layernorm_stats(ws, cur, B * H * W, C, tag="embed.ln", eps=MS_EPS)
+            E.norm_apply(cur, B * H * W, C, C, mean=mean, rstd=rstd, gamma=pk["embed.g"], beta=pk["embed.be"], out_rm=cur, ld_rm=C)
+        return cur, H, W
+
+    def _down(self, ws, pk, li, cur, B, H, W, C):
+        """a stage's downsampling PatchEmbed (patch 2) on channel-last rows: 2 x 2 gather + GEMM (+ LayerNorm)"""
+        d = self.layers[li].downsample
+        p = "l%d.down." % li
+        assert H == d.img_size[0] and W == d.img_size[1], \
+            f"Input image size ({H}*{W}) doesn't match model ({d.img_size[0]}*{d.img_size[1]})."
+        H2, W2, C2 = H // 2, W // 2, d.embed_dim
+        kp = pk[p + "w"].shape[1]
+        cols = ws.get("l%d.cols" % li, (B * H2 * W2, kp))
+        E.patchify(cur, cols, B, C, H, W, 2, 2, 0, kp, layout=N.LAYOUT_NHWC, px_stride=C)
+        nxt = ws.get("l%d.x" % (li + 1), (B * H2 * W2, C2))
+        E.gemm(cols, pk[p + "w"], nxt, B * H2 * W2, C2, kp, bias=pk[p + "b"], tag="ms_down")
+        if d.norm is not None:
+            mean, rstd = layernorm_stats(ws, nxt, B * H2 * W2, C2, tag="l%d.down.ln" % li, eps=MS_EPS)
+            E.norm_apply(nxt, B * H2 * W2, C2, C2, mean=mean, rstd=rstd, gamma=pk[p + "g"], beta=pk[p + "be"], out_rm=nxt, ld_rm=C2)
+        return nxt, H2, W2, C2
+
     def _run_single(self, key, x):
-        """MixShiftBlock (layer, block) alone on (B, C, H, W), as `model.layers[l].blocks[b](x)` in the reference (ms_mlp.py:48-78)"""
+        """An inner module alone on (B, C, H, W), as calling it does in the reference: `model.layers[l].blocks[b](x)` (ms_mlp.py:48-78),
+        `model.layers[l](x)` (a stage: :177-185), `model.layers[l].downsample(x)` and `model.patch_embed(x)` (PatchEmbed: :255-262)"""
         li, bi = key
-        E.require_gpu(x, "MixShiftBlock.forward")
+        E.require_gpu(x, "MS_MLP inner module")
         E.dtype_code(x.dtype)
-        blk = self.layers[li].blocks[bi]
-        C = blk.dim
+        if li == "embed":
+            pe = self.patch_embed
+            if x.dim() != 4 or x.shape[1] != pe.in_chans:
+                raise ValueError("expected a (B, %d, H, W) tensor" % pe.in_chans)
+            B, _, H_in, W_in = x.shape
+            assert H_in == pe.img_size[0] and W_in == pe.img_size[1], \
+                f"Input image size ({H_in}*{W_in}) doesn't match model ({pe.img_size[0]}*{pe.img_size[1]})."          # ms_mlp.py:256-257
+            with E.on_device(x):
+                pk = self._get_pack(x.dtype, x.device)
+                ws = self._get_space(("embed", B, H_in, W_in), x.dtype, x.device)
+                cur, H, W = self._embed(ws, pk, x.contiguous(), B, x.dtype)
+                return cur.reshape(B, H, W, self.embed_dim).permute(0, 3, 1, 2).contiguous()
+        layer = self.layers[li]
+        C = layer.dim
         if x.dim() != 4 or x.shape[1] != C:
             raise ValueError("expected a (B, %d, H, W) tensor" % C)
         B, _, H, W = x.shape
@@ -208,11 +254,18 @@ class MS_MLP(E.EngineModule):
             cur = ws.get("blk.x", (rows, C))
             cur.copy_(x.permute(0, 2, 3, 1).reshape(rows, C))                          # channel-last rows, as the stages keep them
             mix = ws.get("blk.mix", (rows, C))
-            p = "l%d.b%d." % (li, bi)
-            E.mixshift_nhwc(cur, mix, B, H, W, C, list(blk.shift_dist), [k for k, _ in blk.kernel_size], pk[p + "lr.w"], pk[p + "lr.b"],
-                            pk[p + "td.w"], pk[p + "td.b"])
-            channel_mlp(ws, mix, rows, C, pk, p + "ff.", int(self.mlp_ratio * C), cscale2=pk[p + "gamma"], res_src=cur, tag="blk.cm", eps=MS_EPS)
-            return mix.reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
+            if bi != "down":
+                for b_i, blk in enumerate(layer.blocks):
+                    if bi != "layer" and b_i != bi:
+                        continue
+                    p = "l%d.b%d." % (li, b_i)
+                    E.mixshift_nhwc(cur, mix, B, H, W, C, list(blk.shift_dist), [k for k, _ in blk.kernel_size], pk[p + "lr.w"], pk[p + "lr.b"],
+                                    pk[p + "td.w"], pk[p + "td.b"])
+                    channel_mlp(ws, mix, rows, C, pk, p + "ff.", int(self.mlp_ratio * C), cscale2=pk[p + "gamma"], res_src=cur, tag="blk.cm", eps=MS_EPS)
+                    cur, mix = mix, cur
+            if bi == "down" or (bi == "layer" and layer.downsample is not None):
+                cur, H, W, C = self._down(ws, pk, li, cur, B, H, W, C)
+            return cur.reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
 
     def forward(self, x):
         cd = self._resolve(x)
@@ -222,13 +275,8 @@ class MS_MLP(E.EngineModule):
             f"Input image size ({H_in}*{W_in}) doesn't match model ({pe.img_size[0]}*{pe.img_size[1]})."          # ms_mlp.py:256-257
         pk = self._get_pack(cd, x.device)
         ws = self._get_space(B, cd, x.device)
-        x = x.contiguous()
         C = self.embed_dim
-        cur, H, W = embed_patches(ws, "embed", x, pk["embed.w"], pk["embed.b"], cd, tuple(pe.patch_size),
-                                  out=ws.get("l0.x", (B * pe.patches_resolution[0] * pe.patches_resolution[1], C)))
-        if pe.norm is not None:
-            mean, rstd = layernorm_stats(ws, cur, B * H * W, C, tag="embed.ln", eps=MS_EPS)
-            E.norm_apply(cur, B * H * W, C, C, mean=mean, rstd=rstd, gamma=pk["embed.g"], beta=pk["embed.be"], out_rm=cur, ld_rm=C)
+        cur, H, W = self._embed(ws, pk, x.contiguous(), B, cd)
         for li, layer in enumerate(self.layers):
             rows = B * H * W
             hid = int(self.mlp_ratio * C)
@@ -241,20 +289,7 @@ class MS_MLP(E.EngineModule):
                 channel_mlp(ws, mix, rows, C, pk, p + "ff.", hid, cscale2=pk[p + "gamma"], res_src=cur, tag="l%d.cm" % li, eps=MS_EPS)
                 cur, mix = mix, cur
             if layer.downsample is not None:
-                d = layer.downsample
-                p = "l%d.down." % li
-                assert H == d.img_size[0] and W == d.img_size[1], \
-                    f"Input image size ({H}*{W}) doesn't match model ({d.img_size[0]}*{d.img_size[1]})."
-                H2, W2, C2 = H // 2, W // 2, d.embed_dim
-                kp = pk[p + "w"].shape[1]
-                cols = ws.get("l%d.cols" % li, (B * H2 * W2, kp))
-                E.patchify(cur, cols, B, C, H, W, 2, 2, 0, kp, layout=N.LAYOUT_NHWC, px_stride=C)
-                nxt = ws.get("l%d.x" % (li + 1), (B * H2 * W2, C2))
-                E.gemm(cols, pk[p + "w"], nxt, B * H2 * W2, C2, kp, bias=pk[p + "b"], tag="ms_down")
-                if d.norm is not None:
-                    mean, rstd = layernorm_stats(ws, nxt, B * H2 * W2, C2, tag="l%d.down.ln" % li, eps=MS_EPS)
-                    E.norm_apply(nxt, B * H2 * W2, C2, C2, mean=mean, rstd=rstd, gamma=pk[p + "g"], beta=pk[p + "be"], out_rm=nxt, ld_rm=C2)
-                cur, H, W, C = nxt, H2, W2, C2
+                cur, H, W, C = self._down(ws, pk, li, cur, B, H, W, C)
         pooled = ws.get("pooled", (B, C))
         E.pool_mean(cur, B, H * W, C, C, pooled, C)
         mean, rstd = layernorm_stats(ws, pooled, B, C, tag="head.ln", eps=MS_EPS)                                   # LayerNorm after the pool

@@ -547,6 +547,30 @@ def test_swin_and_msmlp_blocks_callable_like_the_reference():
         ref = Fo.msmlp_block(sd, t, "layers.%d.blocks.%d." % (li, bi), tuple(blk.shift_dist), tuple(k for k, _ in blk.kernel_size))
         got = blk(t.to(DEV))
         assert (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), ("msmlp", li, bi)
+    # round 5: PatchEmbed -- the model's and a stage's downsampling one (ms_mlp.py:255-262) -- and a whole stage (BasicLayer, :177-185)
+
+    def embed(t, pre):
+        e = Fo.layer_norm(Fo.patch_embed(t, sd[pre + "proj.weight"], sd[pre + "proj.bias"]), sd[pre + "norm.weight"], sd[pre + "norm.bias"], eps=1e-6)
+        return e.permute(0, 3, 1, 2)
+
+    img = torch.randn(2, 3, 32, 32)
+    ref, got = embed(img, "patch_embed."), ms.patch_embed(img.to(DEV))
+    assert got.shape == ref.shape == (2, 40, 8, 8) and (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    t = torch.randn(2, 40, 8, 8)
+    ref, got = embed(t, "layers.0.downsample."), ms.layers[0].downsample(t.to(DEV))
+    assert got.shape == ref.shape == (2, 80, 4, 4) and (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    ref = t
+    for bi in range(2):
+        blk = ms.layers[0].blocks[bi]
+        ref = Fo.msmlp_block(sd, ref, "layers.0.blocks.%d." % bi, tuple(blk.shift_dist), tuple(k for k, _ in blk.kernel_size))
+    ref = embed(ref, "layers.0.downsample.")
+    got = ms.layers[0](t.to(DEV))                                              # stage 0: two blocks, then the downsampling
+    assert got.shape == ref.shape and (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    t = torch.randn(2, 80, 4, 4)
+    blk = ms.layers[1].blocks[0]
+    ref = Fo.msmlp_block(sd, t, "layers.1.blocks.0.", tuple(blk.shift_dist), tuple(k for k, _ in blk.kernel_size))
+    got = ms.layers[1](t.to(DEV))                                              # the last stage has no downsampling
+    assert got.shape == ref.shape and (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
