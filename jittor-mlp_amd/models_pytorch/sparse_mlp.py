@@ -22,7 +22,7 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import BlockSequential, Holder, channel_mlp, finalize_stats, embed_patches, head_linear, layernorm_stats, pack_channel_mlp
+from .common import Block, BlockSequential, Holder, channel_mlp, finalize_stats, embed_patches, head_linear, layernorm_stats, pack_channel_mlp
 from .conv_mixer import _bn_affine
 from .utils import pair
 
@@ -36,8 +36,9 @@ class PreNormResidual(Holder):
         self.norm = norm(dim)
 
 
-class PatchMerging(Holder):
-    """sparse_mlp.py:17-31."""
+class PatchMerging(Block):
+    """sparse_mlp.py:17-31.  Inside a SparseMLP it runs on its own like the reference's (:33-50): channel-last (B, H, W, C) -> (B, H/2, W/2, 2C);
+    round 5."""
 
     def __init__(self, input_resolution, dim, norm_layer=nn.LayerNorm):
         super().__init__()
@@ -57,9 +58,10 @@ class sMLPBlock(Holder):
         self.fuse = nn.Conv2d(3 * d_model, d_model, kernel_size=1)
 
 
-class sMLPStage(Holder):
+class sMLPStage(Block):
     """sparse_mlp.py:76-104.  `patch_merge` exists in every stage (also where pooling is False), like the reference's,
-    so that the state_dict keys match."""
+    so that the state_dict keys match.  Inside a SparseMLP a stage runs on its own like the reference's (:106-110): (B, C, H, W) through its
+    blocks and, where pooling, its PatchMerging -> (B, 2C, H/2, W/2); round 5."""
 
     def __init__(self, height, width, d_model, depth, expansion_factor=2, dropout=0., pooling=False):
         super().__init__()
@@ -103,6 +105,8 @@ class SparseMLP(E.EngineModule):
         for li, stage in enumerate(self.layers):
             for bi, blk in enumerate(stage.model):
                 blk.__dict__["_owner"] = (self, (li, bi))          # lets `model.layers[l].model[b](x)` run (common.BlockSequential)
+            stage.__dict__["_owner"] = (self, (li, "layer"))       # ... `model.layers[l](x)`: the blocks, then the PatchMerging where pooling
+            stage.patch_merge[1].__dict__["_owner"] = (self, (li, "merge"))
 
     def _pack(self, dtype, device):
         pk = {}
@@ -202,13 +206,55 @@ class SparseMLP(E.EngineModule):
         channel_mlp(ws, cur, rows, C, pk, p + "ff.", C * ef, tag="l%d.cm" % li, stats=finalize_stats(ws, got, rows, C, tag="l%d.cm.ln" % li))
         return cur, tmp
 
+    def _merge(self, ws, pk, li, cur, B, H, W, C):
+        """PatchMerging (sparse_mlp.py:33-50): 2 x 2 gather + LayerNorm folded into the bias-free reduction GEMM"""
+        assert H % 2 == 0 and W % 2 == 0, f"x size ({H}*{W}) are not even."                      # sparse_mlp.py:38
+        p = "l%d.merge." % li
+        H2, W2 = H // 2, W // 2
+        merged = ws.get("l%d.merged" % li, (B * H2 * W2, 4 * C))
+        E.patchify(cur, merged, B, C, H, W, 2, 2, 0, 4 * C, layout=N.LAYOUT_NHWC, px_stride=C, order=1)
+        mean, rstd = layernorm_stats(ws, merged, B * H2 * W2, 4 * C, tag="l%d.merge.ln" % li)
+        nxt = ws.get("l%d.x" % (li + 1), (B * H2 * W2, 2 * C))
+        E.gemm(merged, pk[p + "w"], nxt, B * H2 * W2, 2 * C, 4 * C, bias=pk[p + "b"], ln=(mean, rstd, pk[p + "csum"]), tag="smlp_merge")
+        return nxt
+
     def _run_single(self, key, x):
-        """block `layers[l].model[b]` alone on (B, C, H, W) with the stage's H x W, as calling it does in the reference (sparse_mlp.py:84-104)"""
+        """An inner module alone, as calling it does in the reference: block `layers[l].model[b]` and stage `layers[l]` on (B, C, H, W) with the
+        stage's H x W (sparse_mlp.py:84-110), `layers[l].patch_merge[1]` (PatchMerging, :33-50) on channel-last (B, H, W, C)"""
         li, bi = key
-        E.require_gpu(x, "SparseMLP block")
+        E.require_gpu(x, "SparseMLP inner module")
         E.dtype_code(x.dtype)
         stage = self.layers[li]
         H, W, C = stage.geom[:3]
+        if bi == "merge":
+            if (("l%d.merge.w" % li) not in self._get_pack(x.dtype, x.device)):
+                raise NotImplementedError("this stage does not pool: its PatchMerging only holds parameters, like the reference's unused one")
+            if x.dim() != 4 or tuple(x.shape[1:]) != (H, W, C):
+                raise ValueError("expected a channel-last (B, %d, %d, %d) tensor" % (H, W, C))
+            B = x.shape[0]
+            with E.on_device(x):
+                pk = self._get_pack(x.dtype, x.device)
+                ws = self._get_space(("block", B, H, W, C), x.dtype, x.device)
+                cur = ws.get("blk.x", (B * H * W, C))
+                cur.copy_(x.reshape(B * H * W, C))
+                return self._merge(ws, pk, li, cur, B, H, W, C).reshape(B, H // 2, W // 2, 2 * C).clone()
+        if bi == "layer":
+            if x.dim() != 4 or tuple(x.shape[1:]) != (C, H, W):
+                raise ValueError("expected a (B, %d, %d, %d) tensor" % (C, H, W))
+            B = x.shape[0]
+            rows = B * H * W
+            with E.on_device(x):
+                pk = self._get_pack(x.dtype, x.device)
+                ws = self._get_space(("block", B, H, W, C), x.dtype, x.device)
+                cur = ws.get("blk.x", (rows, C))
+                cur.copy_(x.permute(0, 2, 3, 1).reshape(rows, C))
+                tmp = ws.get("blk.tmp", (rows, C))
+                for b_i in range(stage.geom[3]):
+                    cur, tmp = self._block(ws, pk, li, b_i, stage, cur, tmp, B)
+                if stage.pooling:
+                    cur = self._merge(ws, pk, li, cur, B, H, W, C)
+                    H, W, C = H // 2, W // 2, 2 * C
+                return cur.reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
         if x.dim() != 4 or tuple(x.shape[1:]) != (C, H, W):
             raise ValueError("expected a (B, %d, %d, %d) tensor" % (C, H, W))
         B = x.shape[0]
@@ -242,16 +288,7 @@ class SparseMLP(E.EngineModule):
             for bi in range(depth):
                 cur, tmp = self._block(ws, pk, li, bi, stage, cur, tmp, B)
             if stage.pooling:
-                assert H % 2 == 0 and W % 2 == 0, f"x size ({H}*{W}) are not even."                      # sparse_mlp.py:38
-                p = "l%d.merge." % li
-                H2, W2 = H // 2, W // 2
-                merged = ws.get("l%d.merged" % li, (B * H2 * W2, 4 * C))
-                E.patchify(cur, merged, B, C, H, W, 2, 2, 0, 4 * C, layout=N.LAYOUT_NHWC, px_stride=C, order=1)
-                mean, rstd = layernorm_stats(ws, merged, B * H2 * W2, 4 * C, tag="l%d.merge.ln" % li)
-                nxt = ws.get("l%d.x" % (li + 1), (B * H2 * W2, 2 * C))
-                E.gemm(merged, pk[p + "w"], nxt, B * H2 * W2, 2 * C, 4 * C, bias=pk[p + "b"], ln=(mean, rstd, pk[p + "csum"]),
-                       tag="smlp_merge")
-                cur = nxt
+                cur = self._merge(ws, pk, li, cur, B, H, W, C)
         H, W, C = self.layers[-1].geom[:3]
         mean, rstd = layernorm_stats(ws, cur, B * H * W, C, tag="head.ln")
         pooled = ws.get("pooled", (B, C))

@@ -732,6 +732,22 @@ def test_sparsemlp_block_callable_like_the_reference():
         got = stage.model[bi](t.to(DEV))
         assert got.shape == ref.shape
         assert (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), (li, bi)
+        # round 5: the whole stage (sparse_mlp.py:106-110) and its PatchMerging (:33-50, channel-last) on their own
+        Fo = oracle.functional
+        ref = t
+        for b_i in range(len(stage.model)):
+            ref = Fo.sparsemlp_block(sd, ref, "layers.%d.model.%d." % (li, b_i))
+        if stage.pooling:
+            ref = Fo.sparsemlp_patch_merging(sd, ref.permute(0, 2, 3, 1), "layers.%d.patch_merge.1." % li).permute(0, 3, 1, 2)
+            tl = torch.randn(2, H, W, C)
+            rm = Fo.sparsemlp_patch_merging(sd, tl, "layers.%d.patch_merge.1." % li)
+            gm = stage.patch_merge[1](tl.to(DEV))
+            assert gm.shape == rm.shape and (gm.cpu() - rm).abs().max().item() < 2e-5 * max(1.0, rm.abs().max().item()), li
+        else:
+            with pytest.raises(NotImplementedError):
+                stage.patch_merge[1](torch.randn(2, H, W, C).to(DEV))           # built but unused by the reference too (:80-84, :108-109)
+        got = stage(t.to(DEV))
+        assert got.shape == ref.shape and (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), li
 
 
 def test_cpu_input_raises():
