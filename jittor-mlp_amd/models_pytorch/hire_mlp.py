@@ -20,7 +20,7 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import BlockSequential, Holder, channel_mlp, finalize_stats, head_linear, layernorm_stats, pack_channel_mlp
+from .common import Block, BlockSequential, Holder, channel_mlp, finalize_stats, head_linear, layernorm_stats, pack_channel_mlp
 from .utils import pair
 
 
@@ -33,8 +33,9 @@ class PreNormResidual(Holder):
         self.norm = norm(dim)
 
 
-class PatchEmbedding(Holder):
-    """hire_mlp.py:17-31."""
+class PatchEmbedding(Block):
+    """hire_mlp.py:17-31.  Inside a HireMLP -- as `model.patcher` (7 x 7, stride = patch, padding 3) and as a pooling stage's `patch_merge[1]`
+    (3 x 3, stride 2, padding 1) -- it runs on its own like the reference's: NCHW in, NCHW out; round 5."""
 
     def __init__(self, dim_in, dim_out, kernel_size, stride, padding, norm_layer=False):
         super().__init__()
@@ -69,8 +70,9 @@ class HireMLPBlock(Holder):
         self.proj_c = nn.Conv2d(d_model, d_model, kernel_size=1)
 
 
-class HireMLPStage(Holder):
-    """hire_mlp.py:154-187; `patch_merge` exists in every stage, like the reference's."""
+class HireMLPStage(Block):
+    """hire_mlp.py:154-187; `patch_merge` exists in every stage, like the reference's.  Inside a HireMLP a stage runs on its own like the
+    reference's (:182-186): channel-last (B, H, W, C) through its blocks and, where pooling, its PatchEmbedding; round 5."""
 
     def __init__(self, h, w, d_model_in, d_model_out, depth, cross_region_step, cross_region_interval, expansion_factor=2,
                  dropout=0., pooling=False, padding_type='circular'):
@@ -123,6 +125,9 @@ class HireMLP(E.EngineModule):
         for li, stage in enumerate(self.layers):
             for bi, blk in enumerate(stage.model):
                 blk.__dict__["_owner"] = (self, (li, bi))          # lets `model.layers[l].model[b](x)` run (common.BlockSequential)
+            stage.__dict__["_owner"] = (self, (li, "layer"))       # ... `model.layers[l](x)`: the blocks, then the PatchEmbedding where pooling
+            stage.patch_merge[1].__dict__["_owner"] = (self, (li, "merge"))
+        self.patcher.__dict__["_owner"] = (self, ("embed", None))
 
     def _pack(self, dtype, device):
         pk = {}
@@ -208,31 +213,9 @@ class HireMLP(E.EngineModule):
         st = finalize_stats(ws, got, rows, C, tag="l%d.ln" % li)
         return st
 
-    def _run_single(self, key, x):
-        """block `layers[l].model[b]` alone on channel-last (B, H, W, C), as calling it does in the reference (hire_mlp.py:176-187)"""
-        li, bi = key
-        E.require_gpu(x, "HireMLP block")
-        E.dtype_code(x.dtype)
-        stage = self.layers[li]
-        C = stage.geom[2]
-        if x.dim() != 4 or x.shape[-1] != C:
-            raise ValueError("expected a channel-last (B, H, W, %d) tensor" % C)
-        B, H, W, _ = x.shape
-        with E.on_device(x):
-            pk = self._get_pack(x.dtype, x.device)
-            ws = self._get_space(("block", B, H, W, C), x.dtype, x.device)     # (C: blocks of different stages can meet at one map size)
-            cur = ws.get("blk.x", (B * H * W, C))
-            cur.copy_(x.reshape(B * H * W, C))
-            self._block(ws, pk, li, bi, stage, cur, B, H, W, None)
-            return cur.reshape(B, H, W, C).clone()
-
-    def forward(self, x):
-        cd = self._resolve(x)
+    def _embed(self, ws, pk, x, B, H_in, W_in):
+        """`patcher` (hire_mlp.py:203): 7 x 7 stride-patch pad-3 conv (+ LayerNorm) on the NCHW image -> channel-last rows"""
         patch, cin, num_classes, patcher_norm = self._cfg
-        B, _, H_in, W_in = x.shape
-        pk = self._get_pack(cd, x.device)
-        ws = self._get_space(B, cd, x.device)
-        x = x.contiguous()
         C = self.layers[0].geom[2]
         H, W = (H_in + 6 - 7) // patch[0] + 1, (W_in + 6 - 7) // patch[1] + 1
         kp = pk["embed.w"].shape[1]
@@ -243,21 +226,81 @@ class HireMLP(E.EngineModule):
         if patcher_norm:
             mean, rstd = layernorm_stats(ws, cur, B * H * W, C, tag="embed.ln")
             E.norm_apply(cur, B * H * W, C, C, mean=mean, rstd=rstd, gamma=pk["embed.g"], beta=pk["embed.be"], out_rm=cur, ld_rm=C)
+        return cur, H, W, C
+
+    def _merge(self, ws, pk, li, cur, B, H, W, C):
+        """a pooling stage's `patch_merge` (hire_mlp.py:158-162): 3 x 3 stride-2 pad-1 conv on channel-last rows; returns (next, H2, W2, Cout, statistics)"""
+        Cout = self.layers[li].geom[3]
+        H2, W2 = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        kp = pk["l%d.merge.w" % li].shape[1]
+        cols = ws.get("l%d.cols" % li, (B * H2 * W2, kp))
+        E.im2col(cur, cols, B, C, H, W, 3, 3, 2, 2, 1, kp, layout=N.LAYOUT_NHWC, px_stride=C)
+        nxt = ws.get("l%d.x" % (li + 1), (B * H2 * W2, Cout))
+        got = E.gemm(cols, pk["l%d.merge.w" % li], nxt, B * H2 * W2, Cout, kp, bias=pk["l%d.merge.b" % li], tag="hire_merge",
+                     part=(ws, "l%d.merge.part" % li))
+        return nxt, H2, W2, Cout, finalize_stats(ws, got, B * H2 * W2, Cout, tag="l%d.ln" % (li + 1))
+
+    def _run_single(self, key, x):
+        """An inner module alone, as calling it does in the reference: block `layers[l].model[b]` and stage `layers[l]` on channel-last
+        (B, H, W, C) (hire_mlp.py:176-187); `patcher` and `layers[l].patch_merge[1]` (PatchEmbedding, :17-31) on NCHW"""
+        li, bi = key
+        E.require_gpu(x, "HireMLP inner module")
+        E.dtype_code(x.dtype)
+        if li == "embed":
+            cin = self._cfg[1]
+            if x.dim() != 4 or x.shape[1] != cin:
+                raise ValueError("expected a (B, %d, H, W) tensor" % cin)
+            B, _, H_in, W_in = x.shape
+            with E.on_device(x):
+                pk = self._get_pack(x.dtype, x.device)
+                ws = self._get_space(("embed", B, H_in, W_in), x.dtype, x.device)
+                cur, H, W, C = self._embed(ws, pk, x.contiguous(), B, H_in, W_in)
+                return cur.reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
+        stage = self.layers[li]
+        C = stage.geom[2]
+        if bi == "merge":
+            if not stage.pooling:
+                raise NotImplementedError("this stage does not pool: its PatchEmbedding only holds parameters, like the reference's unused one")
+            if x.dim() != 4 or x.shape[1] != C:
+                raise ValueError("expected a (B, %d, H, W) tensor" % C)
+            B, _, H, W = x.shape
+            with E.on_device(x):
+                pk = self._get_pack(x.dtype, x.device)
+                ws = self._get_space(("block", B, H, W, C), x.dtype, x.device)
+                cur = ws.get("blk.x", (B * H * W, C))
+                cur.copy_(x.permute(0, 2, 3, 1).reshape(B * H * W, C))
+                nxt, H2, W2, Cout, _ = self._merge(ws, pk, li, cur, B, H, W, C)
+                return nxt.reshape(B, H2, W2, Cout).permute(0, 3, 1, 2).contiguous()
+        if x.dim() != 4 or x.shape[-1] != C:
+            raise ValueError("expected a channel-last (B, H, W, %d) tensor" % C)
+        B, H, W, _ = x.shape
+        with E.on_device(x):
+            pk = self._get_pack(x.dtype, x.device)
+            ws = self._get_space(("block", B, H, W, C), x.dtype, x.device)     # (C: blocks of different stages can meet at one map size)
+            cur = ws.get("blk.x", (B * H * W, C))
+            cur.copy_(x.reshape(B * H * W, C))
+            st = None
+            for b_i in range(len(stage.model)):
+                if bi == "layer" or b_i == bi:
+                    st = self._block(ws, pk, li, b_i, stage, cur, B, H, W, st)
+            if bi == "layer" and stage.pooling:
+                cur, H, W, C, _ = self._merge(ws, pk, li, cur, B, H, W, C)
+            return cur.reshape(B, H, W, C).clone()
+
+    def forward(self, x):
+        cd = self._resolve(x)
+        patch, cin, num_classes, patcher_norm = self._cfg
+        B, _, H_in, W_in = x.shape
+        pk = self._get_pack(cd, x.device)
+        ws = self._get_space(B, cd, x.device)
+        cur, H, W, C = self._embed(ws, pk, x.contiguous(), B, H_in, W_in)
         st = None            # (mean, rstd) of cur's rows when the GEMM that wrote cur delivered them (mlpk.h row_part)
         for li, stage in enumerate(self.layers):
             h, w, C, Cout, depth, ef = stage.geom
             for bi in range(len(stage.model)):
                 st = self._block(ws, pk, li, bi, stage, cur, B, H, W, st)
             if stage.pooling:
-                H2, W2 = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
-                kp = pk["l%d.merge.w" % li].shape[1]
-                cols = ws.get("l%d.cols" % li, (B * H2 * W2, kp))
-                E.im2col(cur, cols, B, C, H, W, 3, 3, 2, 2, 1, kp, layout=N.LAYOUT_NHWC, px_stride=C)
-                nxt = ws.get("l%d.x" % (li + 1), (B * H2 * W2, Cout))
-                got = E.gemm(cols, pk["l%d.merge.w" % li], nxt, B * H2 * W2, Cout, kp, bias=pk["l%d.merge.b" % li], tag="hire_merge",
-                             part=(ws, "l%d.merge.part" % li))
-                st = finalize_stats(ws, got, B * H2 * W2, Cout, tag="l%d.ln" % (li + 1))
-                cur, H, W = nxt, H2, W2
+                cur, H, W, _, st = self._merge(ws, pk, li, cur, B, H, W, C)
         C = self.layers[-1].geom[2]
         mean, rstd = st if st is not None else layernorm_stats(ws, cur, B * H * W, C, tag="head.ln")
         pooled = ws.get("pooled", (B, C))

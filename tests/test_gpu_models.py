@@ -706,6 +706,34 @@ def test_hire_block_callable_like_the_reference():
                                   sd[pre + "1.fn.3.bias"])
             got = stage.model[bi](t.to(DEV))
             assert (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), (li, bi)
+        # round 5: the whole stage (hire_mlp.py:182-186) and its PatchEmbedding (:17-31, NCHW) on their own
+        t = torch.randn(2, 7, 9, C)
+        ref = t
+        for bi in range(len(stage.model)):
+            pre = "layers.%d.model.%d." % (li, bi)
+            n = Fo.layer_norm(ref, sd[pre + "0.norm.weight"], sd[pre + "0.norm.bias"])
+            ref = ref + Fo.hiremlp_block(sd, n, pre + "0.fn.0.", h, w, stage.model[bi][0].fn[0].step or 1, (bi + 1) % interval == 0)
+            n = Fo.layer_norm(ref, sd[pre + "1.norm.weight"], sd[pre + "1.norm.bias"])
+            ref = ref + Fo.linear(Fo.gelu(Fo.linear(n, sd[pre + "1.fn.0.weight"], sd[pre + "1.fn.0.bias"])), sd[pre + "1.fn.3.weight"],
+                                  sd[pre + "1.fn.3.bias"])
+        pm = "layers.%d.patch_merge.1.reduction.0." % li
+        if stage.pooling:
+            ref = Fo.conv2d_im2col(ref.permute(0, 3, 1, 2), sd[pm + "weight"], sd[pm + "bias"], 2, 1)
+            tn = torch.randn(2, C, 7, 9)
+            rm = Fo.conv2d_im2col(tn, sd[pm + "weight"], sd[pm + "bias"], 2, 1).permute(0, 3, 1, 2)
+            gm = stage.patch_merge[1](tn.to(DEV))
+            assert gm.shape == rm.shape and (gm.cpu() - rm).abs().max().item() < 2e-5 * max(1.0, rm.abs().max().item()), li
+        else:
+            with pytest.raises(NotImplementedError):
+                stage.patch_merge[1](torch.randn(2, C, 7, 9).to(DEV))
+        got = stage(t.to(DEV))
+        assert got.shape == ref.shape and (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), li
+    img = torch.randn(2, 3, 36, 28)
+    ref = Fo.conv2d_im2col(img, sd["patcher.reduction.0.weight"], sd["patcher.reduction.0.bias"], kw.get("patch_size", 4), 3)
+    if "patcher.reduction.1.1.weight" in sd:
+        ref = Fo.layer_norm(ref, sd["patcher.reduction.1.1.weight"], sd["patcher.reduction.1.1.bias"])
+    got = model.patcher(img.to(DEV))
+    assert got.shape == ref.permute(0, 3, 1, 2).shape and (got.cpu() - ref.permute(0, 3, 1, 2)).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
 def test_sparsemlp_block_callable_like_the_reference():
