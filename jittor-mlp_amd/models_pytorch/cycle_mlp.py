@@ -116,8 +116,9 @@ class CycleBlock(Block):
         self.skip_lam = skip_lam
 
 
-class PatchEmbedOverlapping(Holder):
-    """cycle_mlp.py:200-217."""
+class PatchEmbedOverlapping(Block):
+    """cycle_mlp.py:200-217.  Inside a CycleNet (`model.patch_embed`) it runs on its own like the reference's (:213-215): (B, 3, H, W) -> (B, C, H', W');
+    round 5."""
 
     def __init__(self, patch_size=16, stride=16, padding=0, in_chans=3, embed_dim=768, norm_layer=None, groups=1):
         super().__init__()
@@ -127,8 +128,9 @@ class PatchEmbedOverlapping(Holder):
         self.norm = norm_layer(embed_dim) if norm_layer else nn.Identity()
 
 
-class Downsample(Holder):
-    """cycle_mlp.py:220-231."""
+class Downsample(Block):
+    """cycle_mlp.py:220-231.  Inside a CycleNet (`model.network[i]`) it runs on its own like the reference's (:227-231): channel-last
+    (B, H, W, C) -> (B, H', W', C'); round 5."""
 
     def __init__(self, in_embed_dim, out_embed_dim, patch_size):
         super().__init__()
@@ -174,6 +176,9 @@ class CycleNet(E.EngineModule):
             if not isinstance(stage, Downsample):
                 for bi, blk in enumerate(stage):
                     blk.__dict__["_owner"] = (self, (si, bi))      # lets `model.network[si][bi](x)` run (common.Block)
+            else:
+                stage.__dict__["_owner"] = (self, (si, "down"))    # ... `model.network[si](x)` for a Downsample
+        self.patch_embed.__dict__["_owner"] = (self, ("embed", None))
         if self.fork_feat:
             self.out_indices = [0, 2, 4, 6]
             for i_emb, i_layer in enumerate(self.out_indices):
@@ -297,8 +302,41 @@ class CycleNet(E.EngineModule):
     def _run_single(self, key, x):
         """CycleBlock (si, bi) alone on channel-last (B, H, W, C), as `model.network[si][bi](x)` in the reference (cycle_mlp.py:194-197)"""
         si, bi = key
-        E.require_gpu(x, "CycleBlock.forward")
+        E.require_gpu(x, "CycleNet inner module")
         E.dtype_code(x.dtype)
+        if si == "embed":                                          # PatchEmbedOverlapping (cycle_mlp.py:213-215): 7 x 7 stride-4 pad-2 conv, NCHW out
+            if x.dim() != 4 or x.shape[1] != self.patch_embed.proj.in_channels:
+                raise ValueError("expected a (B, %d, H, W) tensor" % self.patch_embed.proj.in_channels)
+            B, cin, H_in, W_in = x.shape
+            with E.on_device(x):
+                pk = self._get_pack(x.dtype, x.device)
+                ws = self._get_space(("embed", B, H_in, W_in), x.dtype, x.device)
+                C = pk["embed.w"].shape[0]
+                H, W = (H_in + 4 - 7) // 4 + 1, (W_in + 4 - 7) // 4 + 1
+                kp = pk["embed.w"].shape[1]
+                patches = ws.get("embed.patches", (B * H * W, kp))
+                E.im2col(x.contiguous(), patches, B, cin, H_in, W_in, 7, 7, 4, 4, 2, kp)
+                cur = ws.get("n0.x", (B * H * W, C))
+                E.gemm(patches, pk["embed.w"], cur, B * H * W, C, kp, bias=pk["embed.b"])
+                return cur.reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
+        if bi == "down":                                           # Downsample (:227-231): 3 x 3 stride-2 pad-1 conv on channel-last
+            C = self.network[si].proj.in_channels
+            if x.dim() != 4 or x.shape[-1] != C:
+                raise ValueError("expected a channel-last (B, H, W, %d) tensor" % C)
+            B, H, W, _ = x.shape
+            with E.on_device(x):
+                pk = self._get_pack(x.dtype, x.device)
+                ws = self._get_space(("block", B, H, W, C), x.dtype, x.device)
+                cur = ws.get("blk.x", (B * H * W, C))
+                cur.copy_(x.reshape(B * H * W, C))
+                Cout = pk["n%d.w" % si].shape[0]
+                H2, W2 = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+                kp = pk["n%d.w" % si].shape[1]
+                cols = ws.get("n%d.cols" % si, (B * H2 * W2, kp))
+                E.im2col(cur, cols, B, C, H, W, 3, 3, 2, 2, 1, kp, layout=N.LAYOUT_NHWC, px_stride=C)
+                nxt = ws.get("n%d.x" % (si + 1), (B * H2 * W2, Cout))
+                E.gemm(cols, pk["n%d.w" % si], nxt, B * H2 * W2, Cout, kp, bias=pk["n%d.b" % si], tag="cycle_down")
+                return nxt.reshape(B, H2, W2, Cout).clone()
         blk = self.network[si][bi]
         C = blk.norm1.normalized_shape[0]
         if x.dim() != 4 or x.shape[-1] != C:

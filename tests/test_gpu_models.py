@@ -444,6 +444,16 @@ def test_cycle_block_callable_like_the_reference():
         got = model.network[si][0](t.to(DEV))
         assert got.shape == ref.shape
         assert (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), si
+        assert torch.equal(model.network[si](t.to(DEV)), got)                  # a stage is an nn.Sequential of such blocks
+    # round 5: PatchEmbedOverlapping (cycle_mlp.py:213-215, NCHW out) and Downsample (:227-231, channel-last) on their own
+    img = torch.randn(2, 3, 30, 26)
+    ref = Fo.conv2d_im2col(img, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], 4, 2).permute(0, 3, 1, 2)
+    got = model.patch_embed(img.to(DEV))
+    assert got.shape == ref.shape and (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    t = torch.randn(2, 7, 6, 16)
+    ref = Fo.conv2d_im2col(t.permute(0, 3, 1, 2), sd["network.1.proj.weight"], sd["network.1.proj.bias"], 2, 1)
+    got = model.network[1](t.to(DEV))
+    assert got.shape == ref.shape == (2, 4, 3, 32) and (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
