@@ -86,6 +86,36 @@ def two_layer_mlp(ws, pk, xb, rows, dim, hidden, out_dim):
     return y
 
 
+class LinearMlp(SubModule):
+    """Linear -> act -> Dropout -> Linear -> Dropout on the last dimension with the members `fc1`, `act`, `fc2`, `drop` (the `Mlp` of
+    swin_mlp.py:12-26 and cycle_mlp.py:35-51): callable on its own like the reference's, through two NT GEMMs (GELU in the first epilogue)."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+
+    def _pack(self, dtype, device):
+        return {"fc1.w": E.pack_matrix(self.fc1.weight, dtype, device), "fc1.b": E.f32(self.fc1.bias, device),
+                "fc2.w": E.pack_matrix(self.fc2.weight, dtype, device), "fc2.b": E.f32(self.fc2.bias, device)}
+
+    def forward(self, x):
+        if not isinstance(self.act, nn.GELU):
+            raise NotImplementedError("Mlp runs on its own with the reference's default activation (GELU) only")
+        dim, hidden, out = self.fc1.in_features, self.fc1.out_features, self.fc2.out_features
+        pk = self._begin(x, dim)
+        rows = x.numel() // dim
+        with E.on_device(x):
+            ws = self._get_space(rows, x.dtype, x.device)
+            xb = ws.get("mlp.x", (rows, pk["fc1.w"].shape[1]))          # K zero-padded to whole 16-byte chunks
+            xb[:, :dim].copy_(x.reshape(rows, dim))
+            return two_layer_mlp(ws, pk, xb, rows, dim, hidden, out).reshape(tuple(x.shape[:-1]) + (out,)).clone()
+
+
 def standalone_space(x):
     """A workspace for ONE call of an inner module on its own (the sub-block boundary of the reference: g_mlp.py:17-22,
     vip.py:24-57, s2_mlp_v2.py:15-69, as_mlp.py:55-95).  Not a hot path: weights are packed per call."""

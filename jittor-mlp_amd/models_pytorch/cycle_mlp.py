@@ -26,21 +26,13 @@ from torch.nn import init
 
 from .. import _native as N
 from .. import engine as E
-from .common import Block, Holder, channel_mlp, finalize_stats, head_linear, layernorm_stats, pack_channel_mlp
+from .common import Block, Holder, LinearMlp, channel_mlp, finalize_stats, head_linear, layernorm_stats, pack_channel_mlp
 from .utils import pair
 
 
-class Mlp(Holder):
-    """cycle_mlp.py:35-51."""
-
-    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
-        super().__init__()
-        out_features = out_features or in_features
-        hidden_features = hidden_features or in_features
-        self.fc1 = nn.Linear(in_features, hidden_features)
-        self.act = act_layer()
-        self.fc2 = nn.Linear(hidden_features, out_features)
-        self.drop = nn.Dropout(drop)
+class Mlp(LinearMlp):
+    """cycle_mlp.py:35-51; callable on its own like the reference's (common.LinearMlp); inside a model a parameter container whose weights the
+    block packs into its fused channel MLP."""
 
 
 class CycleFC(Holder):

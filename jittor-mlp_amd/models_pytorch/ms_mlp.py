@@ -14,7 +14,7 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Block, Holder, channel_mlp, embed_patches, head_linear, layernorm_stats
+from .common import Block, Holder, SubModule, channel_mlp, embed_patches, head_linear, layernorm_stats
 
 MS_EPS = 1e-6
 
@@ -23,8 +23,10 @@ def to_2tuple(v):
     return v if isinstance(v, (tuple, list)) else (v, v)
 
 
-class LayerNorm(Holder):
-    """The reference's own LayerNorm class (ms_mlp.py:273-298): eps 1e-6, parameters `weight`, `bias`."""
+class LayerNorm(SubModule):
+    """The reference's own LayerNorm class (ms_mlp.py:273-298): eps 1e-6, parameters `weight`, `bias`.  Callable on its own like the reference's --
+    over the last dimension (channels_last) or over dimension 1 of (B, C, H, W) (channels_first) -- through mlpk_row_stats + mlpk_norm_apply;
+    inside a model its parameters are folded into the GEMM that follows."""
 
     def __init__(self, normalized_shape, eps=1e-6, data_format="channels_last"):
         super().__init__()
@@ -35,6 +37,25 @@ class LayerNorm(Holder):
         if self.data_format not in ["channels_last", "channels_first"]:
             raise NotImplementedError
         self.normalized_shape = (normalized_shape, )
+
+    def _pack(self, dtype, device):
+        return {"g": E.f32(self.weight, device), "b": E.f32(self.bias, device)}
+
+    def forward(self, x):
+        C = self.normalized_shape[0]
+        first = self.data_format == "channels_first"
+        pk = self._begin(x, C, axis=1 if first else -1)
+        if first and x.dim() != 4:
+            raise ValueError("channels_first expects a (B, C, H, W) tensor")
+        with E.on_device(x):
+            src = (x.permute(0, 2, 3, 1) if first else x).contiguous()
+            rows = src.numel() // C
+            ws = self._get_space(rows, x.dtype, x.device)
+            mean, rstd = layernorm_stats(ws, src.view(rows, C), rows, C, tag="ln", eps=self.eps)
+            out = torch.empty((rows, C), dtype=x.dtype, device=x.device)
+            E.norm_apply(src.view(rows, C), rows, C, C, mean=mean, rstd=rstd, gamma=pk["g"], beta=pk["b"], out_rm=out, ld_rm=C)
+            out = out.view(src.shape)
+            return out.permute(0, 3, 1, 2).contiguous() if first else out
 
 
 class MixShiftBlock(Block):

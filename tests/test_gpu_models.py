@@ -581,6 +581,24 @@ def test_swin_and_msmlp_blocks_callable_like_the_reference():
     ref = Fo.msmlp_block(sd, t, "layers.1.blocks.0.", tuple(blk.shift_dist), tuple(k for k, _ in blk.kernel_size))
     got = ms.layers[1](t.to(DEV))                                              # the last stage has no downsampling
     assert got.shape == ref.shape and (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    # the leaf modules: MS-MLP's own LayerNorm class in both data formats (ms_mlp.py:287-298), Swin-MLP's Mlp (swin_mlp.py:20-26)
+    ln = ms.norm
+    t = torch.randn(3, 5, 80)
+    ref = Fo.layer_norm(t, sd["norm.weight"], sd["norm.bias"], eps=1e-6)
+    assert (ln(t.to(DEV)).cpu() - ref).abs().max().item() < 2e-5
+    lf = mp.ms_mlp.LayerNorm(24, data_format="channels_first").to(DEV)
+    with torch.no_grad():
+        lf.weight.uniform_(0.5, 1.5); lf.bias.normal_(0, 0.2)
+    t = torch.randn(2, 24, 3, 5)
+    ref = Fo.layer_norm(t.permute(0, 2, 3, 1), lf.weight.cpu(), lf.bias.cpu(), eps=1e-6).permute(0, 3, 1, 2)
+    assert (lf(t.to(DEV)).cpu() - ref).abs().max().item() < 2e-5
+    sd = {k: v.detach().clone().cpu() for k, v in swin.state_dict().items()}
+    mlp = swin.layers[0].blocks[0].mlp
+    t = torch.randn(2, 7, 32)
+    ref = Fo.linear(Fo.gelu(Fo.linear(t, sd["layers.0.blocks.0.mlp.fc1.weight"], sd["layers.0.blocks.0.mlp.fc1.bias"])),
+                    sd["layers.0.blocks.0.mlp.fc2.weight"], sd["layers.0.blocks.0.mlp.fc2.bias"])
+    got = mlp(t.to(DEV))
+    assert got.shape == ref.shape and (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
