@@ -249,6 +249,12 @@ int mlpk_token_gemm_ln(int dtype, const void* x, int ldx, int M, int S, const fl
  * rows [r*group, (r+1)*group) of all `nplanes` planes, pair (q, m) at part[(q*plane_stride + m)*2]; count = elements per
  * statistic (group * row length).  group = 1: LayerNorm of the producer's rows; group = H*W: GroupNorm(1,C) per sample on
  * channel-last rows (as_mlp.py:343-344).  rstd = 1 / sqrt(max(0, S2/count - mean^2) + eps). */
+/* mlpk_token_gemm_ln with a per-channel affine applied to what is stored (round 5): out = post_scale[c] * round(result) + post_shift[c], rounded
+ * again -- ResMLP's post_affine (res_mlp.py:56), which overwrites the cross-patch sublayer's output.  Only on the pipelined kernel (>= 3 groups of 32
+ * tokens, an even token count, t_rows <= 1024): MLPK_ESHAPE otherwise, and the caller applies the affine with mlpk_norm_apply.  NULL, NULL = mlpk_token_gemm_ln. */
+int mlpk_token_gemm_ln_post(int dtype, const void* x, int ldx, int M, int S, const float* ln_mean, const float* ln_rstd, const float* gamma,
+                            const float* beta, const void* w, int ldw, const float* bias, int ngroups, const float* rscale, int rperiod, const void* R,
+                            int ldr, int res_mode, const float* post_scale, const float* post_shift, void* out, int ldo, int t_rows, void* stream);
 int mlpk_stats_finalize_planar(const float* part, int64_t rows, int nplanes, int64_t plane_stride, int group, int64_t count, float eps,
                                float* mean, float* rstd, void* stream);
 /* Tuning hook (tools/tokenmlp_timeline.py), not part of the forward path: when `buf` is non-NULL, later mlpk_token_mlp

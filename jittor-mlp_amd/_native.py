@@ -61,6 +61,9 @@ PROTOTYPES = {
     # (dtype, x, ldx, M, S, ln_mean, ln_rstd, gamma, beta, w, ldw, bias, ngroups, rscale, rperiod, R, ldr, res_mode, out, ldo, t_rows, stream)
     "mlpk_token_gemm_ln": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                    c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    # (... res_mode, post_scale, post_shift, out, ldo, t_rows, stream)
+    "mlpk_token_gemm_ln_post": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                        c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "mlpk_layernorm_transpose": (c_int, [c_int, c_void_p, c_i64, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p]),
     "mlpk_stats_finalize_planar": (c_int, [c_void_p, c_i64, c_int, c_i64, c_int, c_i64, c_float, c_void_p, c_void_p, c_void_p]),
     "mlpk_token_mlp_debug": (None, [c_void_p]),

@@ -862,6 +862,10 @@ struct TokenGemmArgs {
     const float* gamma;     // per channel (t_rows)
     const float* beta;
     int ldx;
+    // round 5 (mlpk_token_gemm_ln_post, pipelined kernel only): out = post_scale[c] * round(result) + post_shift[c], rounded again -- the Aff that
+    // FOLLOWS the cross-patch sublayer of ResMLP (res_mlp.py:56: x = self.post_affine(x)) applied where the sublayer's result is stored
+    const float* post_scale;   // per channel (t_rows), or NULL
+    const float* post_shift;
 };
 
 template <typename T, int RES, int LNL = 0>
@@ -1167,8 +1171,14 @@ __global__ void __launch_bounds__(512, 1) token_gemm_pipe_kernel(const TokenGemm
     float* const tgam = reinterpret_cast<float*>(smem + T5_TAB);
     float* const tbet = tgam + T5_TMAX;
     float* const trs = tbet + T5_TMAX;
+    // (the post-affine tables share the second half of the gamma / beta tables: the launcher admits t_rows <= T5_TMAX / 2 with them)
+    float* const tpa = tgam + T5_TMAX / 2;
+    float* const tpb = tbet + T5_TMAX / 2;
+    const bool post = p.post_scale != nullptr;
     for (int i = tid; i < 256; i += 512) bs[i] = (p.bias && i < G * 32) ? p.bias[i] : 0.f;
     for (int i = tid; i < p.t_rows; i += 512) { tgam[i] = p.gamma[i]; tbet[i] = p.beta[i]; }
+    if (post)
+        for (int i = tid; i < p.t_rows; i += 512) { tpa[i] = p.post_scale[i]; tpb[i] = p.post_shift[i]; }
     // (no rscale: rperiod = 1 and items index trs[0 .. 7])
     for (int i = tid; i < (p.rscale ? p.rperiod : 8); i += 512) trs[i] = p.rscale ? p.rscale[i] : 1.f;
     const bool has_ln = p.ln_mean != nullptr;
@@ -1326,6 +1336,13 @@ __global__ void __launch_bounds__(512, 1) token_gemm_pipe_kernel(const TokenGemm
                     else if constexpr (RES == MLPK_RES_ADD) y += to_f32(r8[q]);
                     else if constexpr (RES == MLPK_RES_MUL) y *= to_f32(r8[q]);
                     e[q] = from_f32<T>(y);
+                }
+                if (post) {                                    // (workgroup-uniform)
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(tpa + r.rcc), a1 = *reinterpret_cast<const f32x4*>(tpa + r.rcc + 4);
+                    const f32x4 c0_ = *reinterpret_cast<const f32x4*>(tpb + r.rcc), c1_ = *reinterpret_cast<const f32x4*>(tpb + r.rcc + 4);
+                    const float pa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, pb[8] = {c0_.x, c0_.y, c0_.z, c0_.w, c1_.x, c1_.y, c1_.z, c1_.w};
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) e[q] = from_f32<T>(__builtin_fmaf(to_f32(e[q]), pa[q], pb[q]));   // (mlpk_norm_apply's form without statistics)
                 }
                 u32x4 o;
                 __builtin_memcpy(&o, e, 16);
@@ -1559,8 +1576,10 @@ static int token_gemm_launch(int dtype, TokenGemmArgs& a, int res_mode, int lnl,
     if (res_mode == MLPK_RES_ADD) TG_LAUNCH(TT, MLPK_RES_ADD, LL) else if (res_mode == MLPK_RES_MUL) TG_LAUNCH(TT, MLPK_RES_MUL, LL) else TG_LAUNCH(TT, MLPK_RES_NONE, LL)
     // round 5: the operand-loader variants with >= 3 groups run as the two-iterations-deep pipeline (MLPK_TOKEN_GEMM_PIPE=0: the kernel above, A/B aid)
     static const bool pipe_on = !(getenv("MLPK_TOKEN_GEMM_PIPE") && atoi(getenv("MLPK_TOKEN_GEMM_PIPE")) == 0);
-    if (lnl && pipe_on && a.G >= 3 && a.S % 2 == 0 && a.t_rows <= T5_TMAX && (!a.rscale || (a.rperiod % 8 == 0 && a.rperiod <= T5_TMAX)) &&
-        !(((uintptr_t)a.ln_mean | (uintptr_t)a.ln_rstd) & 7)) {      // (the statistics of a token pair are one 8-byte load)
+    const bool pipe_ok = lnl && pipe_on && a.G >= 3 && a.S % 2 == 0 && a.t_rows <= T5_TMAX && (!a.rscale || (a.rperiod % 8 == 0 && a.rperiod <= T5_TMAX)) &&
+                         !(((uintptr_t)a.ln_mean | (uintptr_t)a.ln_rstd) & 7);
+    if (a.post_scale && !(pipe_ok && a.t_rows <= T5_TMAX / 2)) return MLPK_ESHAPE;   // (the caller applies the Aff itself)
+    if (pipe_ok) {      // (the statistics of a token pair are one 8-byte load)
 #define TP_LAUNCH(TT, RR, LL)                                                                                          \
     {                                                                                                                   \
         auto k = token_gemm_pipe_kernel<TT, RR, LL>;                                                                    \
@@ -1610,14 +1629,31 @@ extern "C" int mlpk_token_gemm(int dtype, const void* xt, int ldxt, int M, int S
     a.M = M; a.S = S; a.ks1 = ldxt / 32; a.G = ngroups;
     a.ldxt = ldxt; a.ldr = ldr; a.ldo = ldo; a.t_rows = t_rows; a.rperiod = rperiod > 0 ? rperiod : 1; a.res_mode = res_mode;
     a.x = nullptr; a.ln_mean = a.ln_rstd = a.gamma = a.beta = nullptr; a.ldx = 0;
+    a.post_scale = a.post_shift = nullptr;
     return token_gemm_launch(dtype, a, res_mode, 0, reinterpret_cast<hipStream_t>(stream));
 }
 
 // mlpk_token_gemm with the LayerNorm / affine of its operand inside (mlpk.h): x token-major, no xt tensor
+extern "C" int mlpk_token_gemm_ln_post(int dtype, const void* x, int ldx, int M, int S, const float* ln_mean, const float* ln_rstd, const float* gamma,
+                                       const float* beta, const void* w, int ldw, const float* bias, int ngroups, const float* rscale, int rperiod,
+                                       const void* R, int ldr, int res_mode, const float* post_scale, const float* post_shift, void* out, int ldo,
+                                       int t_rows, void* stream);
+
 extern "C" int mlpk_token_gemm_ln(int dtype, const void* x, int ldx, int M, int S, const float* ln_mean, const float* ln_rstd, const float* gamma,
                                   const float* beta, const void* w, int ldw, const float* bias, int ngroups, const float* rscale, int rperiod,
                                   const void* R, int ldr, int res_mode, void* out, int ldo, int t_rows, void* stream) {
+    return mlpk_token_gemm_ln_post(dtype, x, ldx, M, S, ln_mean, ln_rstd, gamma, beta, w, ldw, bias, ngroups, rscale, rperiod, R, ldr, res_mode, nullptr, nullptr,
+                                   out, ldo, t_rows, stream);
+}
+
+// ... with the per-channel affine that FOLLOWS the sublayer applied to what is stored (ResMLP's post_affine, res_mlp.py:56); MLPK_ESHAPE when the shape
+// does not run on the pipelined kernel (the caller then applies the affine with mlpk_norm_apply, as before)
+extern "C" int mlpk_token_gemm_ln_post(int dtype, const void* x, int ldx, int M, int S, const float* ln_mean, const float* ln_rstd, const float* gamma,
+                                       const float* beta, const void* w, int ldw, const float* bias, int ngroups, const float* rscale, int rperiod,
+                                       const void* R, int ldr, int res_mode, const float* post_scale, const float* post_shift, void* out, int ldo,
+                                       int t_rows, void* stream) {
     if (!x || !w || !out || !gamma || !beta) return MLPK_ENULL;
+    if ((post_scale != nullptr) != (post_shift != nullptr)) return MLPK_ENULL;
     if ((ln_mean != nullptr) != (ln_rstd != nullptr)) return MLPK_ENULL;
     if (dtype != MLPK_F16 && dtype != MLPK_BF16) return MLPK_EDTYPE;
     if (M <= 0 || S <= 0 || ngroups <= 0 || t_rows <= 0) return MLPK_ESHAPE;
@@ -1643,5 +1679,6 @@ extern "C" int mlpk_token_gemm_ln(int dtype, const void* x, int ldx, int M, int 
     a.M = M; a.S = S; a.ks1 = (S + 31) / 32; a.G = ngroups;
     a.ldxt = 0; a.ldr = ldr; a.ldo = ldo; a.t_rows = t_rows; a.rperiod = rperiod > 0 ? rperiod : 1; a.res_mode = res_mode;
     a.x = x; a.ln_mean = ln_mean; a.ln_rstd = ln_rstd; a.gamma = gamma; a.beta = beta; a.ldx = ldx;
+    a.post_scale = post_scale; a.post_shift = post_shift;
     return token_gemm_launch(dtype, a, res_mode, raff ? 2 : 1, reinterpret_cast<hipStream_t>(stream));
 }

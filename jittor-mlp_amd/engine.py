@@ -345,8 +345,22 @@ def token_gemm_ln_supported(dtype, S, t_rows, ldx):
             and os.environ.get("MLPK_TOKEN_GEMM_LN", "1") != "0")
 
 
-def token_gemm_ln(x, ldx, M, S, mean, rstd, gamma, beta, wp, bp, ng, out, ldo, t_rows, *, R=None, ldr=0, res=N.RES_NONE, rscale=None, rperiod=0):
-    """x: token-major (B*S, >= t_rows) view (a column slice is fine: pass its stride as ldx); mean / rstd per token row or None."""
+def token_gemm_ln_post_supported(dtype, S, t_rows, ldx):
+    """mlpk_token_gemm_ln_post: the per-channel affine that FOLLOWS the sublayer applied where its result is stored -- the pipelined kernel only
+    (>= 3 groups of 32 tokens, an even token count, <= 1024 channels per image); MLPK_TOKEN_GEMM_POST=0: a separate mlpk_norm_apply (A/B aid)"""
+    return (token_gemm_ln_supported(dtype, S, t_rows, ldx) and S > 64 and S % 2 == 0 and t_rows <= 1024
+            and os.environ.get("MLPK_TOKEN_GEMM_POST", "1") != "0" and os.environ.get("MLPK_TOKEN_GEMM_PIPE", "1") != "0")
+
+
+def token_gemm_ln(x, ldx, M, S, mean, rstd, gamma, beta, wp, bp, ng, out, ldo, t_rows, *, R=None, ldr=0, res=N.RES_NONE, rscale=None, rperiod=0,
+                  post=None):
+    """x: token-major (B*S, >= t_rows) view (a column slice is fine: pass its stride as ldx); mean / rstd per token row or None.
+    post = (scale, shift) per channel: out = scale * round(result) + shift (token_gemm_ln_post_supported)."""
+    if post is not None:
+        N.check(N.lib().mlpk_token_gemm_ln_post(dtype_code(x.dtype), ptr(x), ldx, M, S, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(wp), wp.stride(0),
+                                                ptr(bp), ng, ptr(rscale), rperiod, ptr(R), ldr, res, ptr(post[0]), ptr(post[1]), ptr(out), ldo, t_rows,
+                                                stream()), "mlpk_token_gemm_ln_post")
+        return
     N.check(N.lib().mlpk_token_gemm_ln(dtype_code(x.dtype), ptr(x), ldx, M, S, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(wp), wp.stride(0),
                                        ptr(bp), ng, ptr(rscale), rperiod, ptr(R), ldr, res, ptr(out), ldo, t_rows, stream()), "mlpk_token_gemm_ln")
 

@@ -134,9 +134,14 @@ class ResMLP(E.EngineModule):
                 # round 4: Aff (res_mlp.py:17-19,53) is the cross-patch product's operand loader AND its residual -- the kernel reads x,
                 # builds x1 = alpha x + beta for its operand (transposed through LDS) and for the residual items, and writes
                 # x2 = x1 + gamma_1 (Wt x1 + bt) over x: no Aff pass, no x1 tensor, no token-transposed copy
+                # round 5: ... and the Aff that FOLLOWS (post_affine, res_mlp.py:56) is applied where x2 is stored: x3 = alpha' x2 + beta' leaves
+                # the kernel instead of x2 (the same two roundings as the separate pass)
+                post = E.token_gemm_ln_post_supported(x.dtype, S, C, C)
                 E.token_gemm_ln(x, C, B * C, S, None, None, pk[p + "pre.a"], pk[p + "pre.b"], tg[0], tg[1], tg[2], x, C, C,
-                                R=x, ldr=C, res=N.RES_ADD_AFFINE, rscale=pk[p + "g1"], rperiod=C)
-                E.norm_apply(x, rows, C, C, gamma=pk[p + "post.a"], beta=pk[p + "post.b"], out_rm=x, ld_rm=C)
+                                R=x, ldr=C, res=N.RES_ADD_AFFINE, rscale=pk[p + "g1"], rperiod=C,
+                                post=(pk[p + "post.a"], pk[p + "post.b"]) if post else None)
+                if not post:
+                    E.norm_apply(x, rows, C, C, gamma=pk[p + "post.a"], beta=pk[p + "post.b"], out_rm=x, ld_rm=C)
                 h = ws.get("h", (rows, hidden))
                 E.gemm(x, pk[p + "fc1.w"], h, rows, hidden, C, bias=pk[p + "fc1.b"], act=N.ACT_GELU)
                 self._fc2(pk, p, h, x, rows, C, hidden)

@@ -1104,6 +1104,20 @@ def test_token_gemm_with_the_layernorm_as_its_operand_loader(dtype):
                 E.token_gemm_ln(xin, C, B_ * C, S, None, None, gamma, beta, wp, bp, ng, xin, C, C, R=xin, ldr=C, res=N.RES_ADD, rscale=g1, rperiod=C)
             torch.cuda.synchronize()
             assert torch.equal(xin.view(torch.int16), out.view(torch.int16)), (str(dtype), ci, "in place, residual rebuilt")
+            # round 5: the affine that FOLLOWS the sublayer (ResMLP's post_affine, res_mlp.py:56) applied where the result is stored -- bit-equal
+            # to mlpk_norm_apply on the stored result; shapes outside the pipelined kernel are refused
+            pa, pb = (rnd((C,), torch.float32, 2170 + ci) * 0.3 + 1.0).to(dev()), (rnd((C,), torch.float32, 2180 + ci) * 0.2).to(dev())
+            if E.token_gemm_ln_post_supported(dtype, S, C, C):
+                xp = x.clone()
+                E.token_gemm_ln(xp, C, B_ * C, S, None, None, gamma, beta, wp, bp, ng, xp, C, C, R=xp, ldr=C, res=N.RES_ADD_AFFINE, rscale=g1, rperiod=C,
+                                post=(pa, pb))
+                E.norm_apply(xin, rows, C, C, gamma=pa, beta=pb, out_rm=xin, ld_rm=C)
+                torch.cuda.synchronize()
+                assert torch.equal(xp.view(torch.int16), xin.view(torch.int16)), (str(dtype), ci, "post affine")
+            else:
+                with pytest.raises(RuntimeError):
+                    E.token_gemm_ln(x.clone(), C, B_ * C, S, None, None, gamma, beta, wp, bp, ng, torch.empty_like(x), C, C, R=x1, ldr=C, res=N.RES_ADD,
+                                    rscale=g1, rperiod=C, post=(pa, pb))
         torch.cuda.synchronize()
         got = out.cpu().double().reshape(B_, S, C)
         assert torch.isfinite(got).all(), (str(dtype), ci)
