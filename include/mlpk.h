@@ -553,6 +553,11 @@ int mlpk_window_scatter_add(int dtype, void* x, const void* windows, int B, int 
  * The normalised window is rounded to the storage type once (MFMA operand), the product once, the sum with x once -- the roundings of the
  * five-pass form it replaces (mlpk_norm_apply, mlpk_window_gather, transpose, mlpk_gemm_nt, mlpk_window_scatter_add). */
 int mlpk_swin_spatial_supported(int dtype, int C, int heads, int ws);
+/* ... mlpk_swin_spatial that also delivers the LayerNorm statistics (mean, 1 / sqrt(var + eps); fp32, per row) of the rows it writes: what the
+ * block's norm2 (swin_mlp.py:154) needs, without a statistics pass (round 5).  out_mean / out_rstd NULL = mlpk_swin_spatial. */
+int mlpk_swin_spatial_stats(int dtype, void* x, int B, int H, int W, int C, int ws, int pad_t, int pad_l, int Hp, int Wp, int heads,
+                            const float* mean, const float* rstd, const float* gamma, const float* beta, const void* w, const float* bias,
+                            float* out_mean, float* out_rstd, float eps, void* stream);
 int mlpk_swin_spatial(int dtype, void* x, int B, int H, int W, int C, int ws, int pad_t, int pad_l, int Hp, int Wp, int heads,
                       const float* mean, const float* rstd, const float* gamma, const float* beta, const void* w, const float* bias,
                       void* stream);

@@ -85,6 +85,7 @@ PROTOTYPES = {
     "mlpk_col_sum": (c_int, [c_int, c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_void_p, c_void_p]),
     "mlpk_transpose_batched": (c_int, [c_int, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_int, c_void_p]),
     "mlpk_broadcast_rows": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "mlpk_swin_spatial_stats": (c_int, [c_int, c_void_p] + [c_int] * 10 + [c_void_p] * 8 + [c_float, c_void_p]),
     "mlpk_add_periodic": (c_int, [c_int, c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_void_p]),
     "mlpk_smlp_mix_supported": (c_int, [c_int] * 4),
     "mlpk_smlp_mix": (c_int, [c_int, c_void_p] + [c_int] * 5 + [c_void_p] * 7 + [c_int, c_void_p]),

@@ -591,6 +591,11 @@ struct SwinArgs {
     const void* w;           // (heads, 64, 64) zero-padded [t_out][t_in]
     const float* bias;       // (heads, 64)
     int B, H, W, C, ws, pad_t, pad_l, nWy, nWx, heads;
+    // round 5 (mlpk_swin_spatial_stats): the LayerNorm statistics of the rows the kernel WRITES -- what norm2 of the block needs (swin_mlp.py:154) --
+    // so that no statistics pass follows: a workgroup holds whole rows (every channel of its window's tokens)
+    float* out_mean;         // per row of x, or NULL
+    float* out_rstd;
+    float eps;
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -736,7 +741,37 @@ __global__ void __launch_bounds__(SW_NT) swin_spatial_kernel(const SwinArgs p) {
                 u32x4 ov;
                 __builtin_memcpy(&ov, o, 16);
                 *reinterpret_cast<u32x4*>(x + (((size_t)b * p.H + yy) * p.W + xx) * C + cq * 8) = ov;
+                if (p.out_mean) *reinterpret_cast<u32x4*>(smem_sw + t * opitch + cq * 16) = ov;      // (the item's own bytes: read above by this thread only)
             }
+        }
+    }
+    if (!p.out_mean) return;                                 // (workgroup-uniform)
+    // ---- statistics of the stored rows: four threads per token, a quarter of the channels each, in a fixed order (deterministic) ----
+    __syncthreads();
+    {
+        const int t = tid >> 2, part = tid & 3;
+        float s = 0.f, ss = 0.f;
+        const int ty = t / ws, tx = t - ty * ws;
+        const int yy = wy * ws + ty - p.pad_t, xx = wx * ws + tx - p.pad_l;
+        const bool live = t < T2 && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+        if (live) {
+            const int nq = C / 32;                           // 16-byte chunks per quarter row
+            for (int i = 0; i < nq; ++i) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(smem_sw + t * opitch + (part * nq + i) * 16);
+                T e[8];
+                __builtin_memcpy(e, &v, 16);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const float f = to_f32(e[q]); s += f; ss = __builtin_fmaf(f, f, ss); }
+            }
+        }
+        s += __shfl_xor(s, 1); ss += __shfl_xor(ss, 1);       // (p0 + p1) + (p2 + p3): the same order in every lane of the quad
+        s += __shfl_xor(s, 2); ss += __shfl_xor(ss, 2);
+        if (live && part == 0) {
+            const float mean = s / (float)C;
+            const float var = ss / (float)C - mean * mean;
+            const size_t row = ((size_t)b * p.H + yy) * p.W + xx;
+            p.out_mean[row] = mean;
+            p.out_rstd[row] = 1.0f / __builtin_sqrtf((var > 0.f ? var : 0.f) + p.eps);
         }
     }
 }
@@ -748,16 +783,28 @@ extern "C" int mlpk_swin_spatial_supported(int dtype, int C, int heads, int ws) 
            (ws * ws * (C / 8) + SW_NT - 1) / SW_NT <= SW_MAXI;
 }
 
+extern "C" int mlpk_swin_spatial_stats(int dtype, void* x, int B, int H, int W, int C, int ws, int pad_t, int pad_l, int Hp, int Wp, int heads,
+                                       const float* mean, const float* rstd, const float* gamma, const float* beta, const void* w, const float* bias,
+                                       float* out_mean, float* out_rstd, float eps, void* stream);
+
 extern "C" int mlpk_swin_spatial(int dtype, void* x, int B, int H, int W, int C, int ws, int pad_t, int pad_l, int Hp, int Wp, int heads,
                                  const float* mean, const float* rstd, const float* gamma, const float* beta, const void* w, const float* bias,
                                  void* stream) {
+    return mlpk_swin_spatial_stats(dtype, x, B, H, W, C, ws, pad_t, pad_l, Hp, Wp, heads, mean, rstd, gamma, beta, w, bias, nullptr, nullptr, 0.f, stream);
+}
+
+extern "C" int mlpk_swin_spatial_stats(int dtype, void* x, int B, int H, int W, int C, int ws, int pad_t, int pad_l, int Hp, int Wp, int heads,
+                                       const float* mean, const float* rstd, const float* gamma, const float* beta, const void* w, const float* bias,
+                                       float* out_mean, float* out_rstd, float eps, void* stream) {
     if (!x || !mean || !rstd || !gamma || !beta || !w || !bias) return MLPK_ENULL;
+    if ((out_mean != nullptr) != (out_rstd != nullptr)) return MLPK_ENULL;
     if (B <= 0 || H <= 0 || W <= 0 || ws <= 0 || Hp % ws || Wp % ws || Hp < H + pad_t || Wp < W + pad_l || pad_t < 0 || pad_l < 0) return MLPK_ESHAPE;
     if (!mlpk_swin_spatial_supported(dtype, C, heads, ws)) return MLPK_ESHAPE;
     if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)bias) & 15) return MLPK_EALIGN;
     SwinArgs a;
     a.x = x; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.w = w; a.bias = bias;
     a.B = B; a.H = H; a.W = W; a.C = C; a.ws = ws; a.pad_t = pad_t; a.pad_l = pad_l; a.nWy = Hp / ws; a.nWx = Wp / ws; a.heads = heads;
+    a.out_mean = out_mean; a.out_rstd = out_rstd; a.eps = eps;
     const long long nwin = (long long)B * a.nWy * a.nWx;
     if (nwin > 0x7fffffffLL) return MLPK_ESHAPE;
     const int t2 = ws * ws;

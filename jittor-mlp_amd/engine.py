@@ -486,7 +486,12 @@ def pack_swin_spatial(weight, bias, heads, ws, dtype, device):
     return wp.contiguous(), bp.contiguous()
 
 
-def swin_spatial(x, B, H, W, C, ws, pad_t, pad_l, Hp, Wp, heads, mean, rstd, gamma, beta, wp, bp):
+def swin_spatial(x, B, H, W, C, ws, pad_t, pad_l, Hp, Wp, heads, mean, rstd, gamma, beta, wp, bp, out_stats=None, eps=1e-5):
+    """out_stats = (mean, rstd) fp32 per row: the kernel also delivers the LayerNorm statistics of the rows it writes"""
+    if out_stats is not None:
+        N.check(N.lib().mlpk_swin_spatial_stats(dtype_code(x.dtype), ptr(x), B, H, W, C, ws, pad_t, pad_l, Hp, Wp, heads, ptr(mean), ptr(rstd), ptr(gamma),
+                                                ptr(beta), ptr(wp), ptr(bp), ptr(out_stats[0]), ptr(out_stats[1]), eps, stream()), "mlpk_swin_spatial_stats")
+        return
     N.check(N.lib().mlpk_swin_spatial(dtype_code(x.dtype), ptr(x), B, H, W, C, ws, pad_t, pad_l, Hp, Wp, heads, ptr(mean), ptr(rstd), ptr(gamma),
                                       ptr(beta), ptr(wp), ptr(bp), stream()), "mlpk_swin_spatial")
 

@@ -14,6 +14,8 @@ SwinMLPBlock (swin_mlp.py:63-157) on channel-last tokens (B*H*W, C):
 PatchMerging (:178-212) = 2x2 gather + LayerNorm(4C) folded into the bias-free reduction; head = LayerNorm folded into the
 token mean, then the classifier GEMM.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -207,8 +209,14 @@ class SwinMLP(E.EngineModule):
         tag = "l%d.s%d." % (li, 1 if blk.shift_size > 0 else 0)
         mean, rstd = st if st is not None else layernorm_stats(ws_, cur, rows, C, tag="l%d.ln" % li)
         if (p + "sp.fw") in pk and E.swin_spatial_supported(cur.dtype, C, nh, ws):
-            E.swin_spatial(cur, B, H, W, C, ws, pad_t, pad_l, Hp, Wp, nh, mean, rstd, pk[p + "n1.g"], pk[p + "n1.b"], pk[p + "sp.fw"], pk[p + "sp.fb"])
-            got = channel_mlp(ws_, cur, rows, C, pk, p + "ff.", int(C * self.mlp_ratio), tag="l%d.cm" % li, part=(ws_, "l%d.fc2.part" % li))
+            # round 5: the kernel holds whole rows, so it also delivers norm2's statistics of what it writes (no statistics pass;
+            # MLPK_SWIN_SPATIAL_STATS=0: the pass, A/B aid)
+            st2 = None
+            if os.environ.get("MLPK_SWIN_SPATIAL_STATS") != "0":
+                st2 = (ws_.get("l%d.cm.mean" % li, (rows,), torch.float32), ws_.get("l%d.cm.rstd" % li, (rows,), torch.float32))
+            E.swin_spatial(cur, B, H, W, C, ws, pad_t, pad_l, Hp, Wp, nh, mean, rstd, pk[p + "n1.g"], pk[p + "n1.b"], pk[p + "sp.fw"], pk[p + "sp.fb"],
+                           out_stats=st2)
+            got = channel_mlp(ws_, cur, rows, C, pk, p + "ff.", int(C * self.mlp_ratio), tag="l%d.cm" % li, part=(ws_, "l%d.fc2.part" % li), stats=st2)
             return finalize_stats(ws_, got, rows, C, tag="l%d.ln" % li)
         xn = ws_.get("l%d.xn" % li, (rows, C))
         xw = ws_.get(tag + "xw", (nwin * ws * ws, C))

@@ -1697,6 +1697,17 @@ def test_swin_spatial_mlp_half_of_a_block_in_one_kernel(dtype):
         scale = max(1.0, ref.abs().max().item())
         err = (g - ref).abs().max().item()
         assert err < EPS[dtype] * 4 * scale, (str(dtype), ci, (B, H, W, heads, ws, shift), err)
+        # round 5: the same call delivering the LayerNorm statistics of the rows it wrote -- the same output bits, statistics of exactly them
+        got2 = x.clone()
+        m2 = torch.full((B * H * W,), float("nan"), dtype=torch.float32, device=dev())
+        r2 = torch.full((B * H * W,), float("nan"), dtype=torch.float32, device=dev())
+        E.swin_spatial(got2, B, H, W, C, ws, pad_t, pad_l, Hp, Wp, heads, mean, rstd, gamma.to(dev()), beta.to(dev()), wp, bp, out_stats=(m2, r2), eps=1e-5)
+        torch.cuda.synchronize()
+        assert torch.equal(got2, got), (str(dtype), ci)
+        gd = got.cpu().double().reshape(B * H * W, C)
+        assert (m2.cpu().double() - gd.mean(1)).abs().max().item() < 1e-5 * scale, (str(dtype), ci)
+        want_r = 1.0 / torch.sqrt(gd.var(1, unbiased=False) + 1e-5)
+        assert ((r2.cpu().double() - want_r).abs() / want_r).max().item() < 1e-4, (str(dtype), ci)
     assert not E.swin_spatial_supported(dtype, 96, 4, 7) and not E.swin_spatial_supported(dtype, 96, 3, 9) and not E.swin_spatial_supported(torch.float32, 96, 3, 7)
 
 
