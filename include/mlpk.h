@@ -424,6 +424,11 @@ int mlpk_channel_mlp(int dtype, const void* x, int ldx, int M, int C, const floa
  *   out_w[b,y,x,c] = in[b, y + d(c), x, c]     the operand of `sfc_w` = CycleFC(kernel (k,1))
  * zero where the source pixel lies outside the map; either output may be NULL; pixel stride ldo; k odd.
  */
+/* (round 5) mlpk_cycle_shift_ln: the same on LayerNorm(in) without storing it -- `in` un-normalised, mean / rstd per pixel, gamma / beta per channel,
+ * applied to every element with the statistics of the pixel it comes from ((x - mean) rstd gamma + beta, one rounding: mlpk_norm_apply's expression);
+ * 16-bit storage, C % 8 == 0, k = 3 / 5 / 7 (MLPK_ESHAPE otherwise). */
+int mlpk_cycle_shift_ln(int dtype, const void* in, const float* mean, const float* rstd, const float* gamma, const float* beta, void* out_h, void* out_w,
+                        int B, int H, int W, int C, int k, int ldi, int ldo, void* stream);
 int mlpk_cycle_shift(int dtype, const void* in, void* out_h, void* out_w, int B, int H, int W, int C, int k,
                      int ldi, int ldo, void* stream);
 

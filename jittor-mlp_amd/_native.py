@@ -94,6 +94,7 @@ PROTOTYPES = {
     "mlpk_shift_nhwc": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "mlpk_norm_shift_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p] * 4 + [c_int, c_void_p]),
     "mlpk_cycle_shift": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    "mlpk_cycle_shift_ln": (c_int, [c_int] + [c_void_p] * 7 + [c_int] * 7 + [c_void_p]),
     "mlpk_as_conv2_supported": (c_int, [c_int] * 5),
     "mlpk_channel_mlp_supported": (c_int, [c_int] * 3),
     "mlpk_linear_gelu_supported": (c_int, [c_int] * 4),

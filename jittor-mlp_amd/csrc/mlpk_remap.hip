@@ -114,9 +114,13 @@ __global__ void __launch_bounds__(256) cycle_shift_kernel(const T* __restrict__ 
 
 // 16-bit types, C % 8 == 0: one thread produces 8 channels (16 bytes) of both outputs from the <= k neighbouring pixels'
 // vectors at the same channel offset (all but the centre one are L1 / L2 hits: the neighbours' threads read them too).
+// (round 5, mlpk_cycle_shift_ln: `in` is the UN-normalised tensor and the LayerNorm in front of the three branches -- cycle_mlp.py:195, per pixel
+//  over C -- is applied to every element on the way, with the statistics of the pixel it comes FROM; what lies outside the map stays zero)
 template <typename T, int K>
 __global__ void __launch_bounds__(256) cycle_shift_vec_kernel(const T* __restrict__ in, T* __restrict__ out_h, T* __restrict__ out_w, int B,
-                                                              int H, int W, int C, int ldi, int ldo) {
+                                                              int H, int W, int C, int ldi, int ldo, const float* __restrict__ mean = nullptr,
+                                                              const float* __restrict__ rstd = nullptr, const float* __restrict__ gamma = nullptr,
+                                                              const float* __restrict__ beta = nullptr) {
     const int CV = C / 8;
     const unsigned total = (unsigned)B * H * W * CV;
     for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
@@ -128,6 +132,11 @@ __global__ void __launch_bounds__(256) cycle_shift_vec_kernel(const T* __restric
         T oh[8], ow[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) oh[e] = ow[e] = from_f32<T>(0.f);
+        float gg[8], bb[8];
+        if (mean) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { gg[e] = gamma[c + e]; bb[e] = beta[c + e]; }
+        }
 #pragma unroll
         for (int d = -(K / 2); d <= K / 2; ++d) {
             // elements of this vector whose cycle step is d: (c + e + K/2) % K == d + K/2
@@ -137,6 +146,11 @@ __global__ void __launch_bounds__(256) cycle_shift_vec_kernel(const T* __restric
                     const u32x4 v = *reinterpret_cast<const u32x4*>(src + (ptrdiff_t)d * ldi);
                     T a[8];
                     __builtin_memcpy(a, &v, 16);
+                    if (mean) {
+                        const float mu = mean[px + d], rs = rstd[px + d];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) a[e] = from_f32<T>(__builtin_fmaf((to_f32(a[e]) - mu) * rs, gg[e], bb[e]));   // (norm_apply's form)
+                    }
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
                         if (e >= first && (e - first) % K == 0) oh[e] = a[e];
@@ -145,6 +159,11 @@ __global__ void __launch_bounds__(256) cycle_shift_vec_kernel(const T* __restric
                     const u32x4 v = *reinterpret_cast<const u32x4*>(src + (ptrdiff_t)d * W * ldi);
                     T a[8];
                     __builtin_memcpy(a, &v, 16);
+                    if (mean) {
+                        const float mu = mean[(ptrdiff_t)px + d * W], rs = rstd[(ptrdiff_t)px + d * W];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) a[e] = from_f32<T>(__builtin_fmaf((to_f32(a[e]) - mu) * rs, gg[e], bb[e]));
+                    }
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
                         if (e >= first && (e - first) % K == 0) ow[e] = a[e];
@@ -805,9 +824,18 @@ extern "C" int mlpk_norm_shift_nhwc(int dtype, const void* in, void* out_w, void
     return 0;
 }
 
+extern "C" int mlpk_cycle_shift_ln(int dtype, const void* in, const float* mean, const float* rstd, const float* gamma, const float* beta, void* out_h,
+                                   void* out_w, int B, int H, int W, int C, int k, int ldi, int ldo, void* stream);
+
 extern "C" int mlpk_cycle_shift(int dtype, const void* in, void* out_h, void* out_w, int B, int H, int W, int C, int k, int ldi,
                                 int ldo, void* stream) {
+    return mlpk_cycle_shift_ln(dtype, in, nullptr, nullptr, nullptr, nullptr, out_h, out_w, B, H, W, C, k, ldi, ldo, stream);
+}
+
+extern "C" int mlpk_cycle_shift_ln(int dtype, const void* in, const float* mean, const float* rstd, const float* gamma, const float* beta, void* out_h,
+                                   void* out_w, int B, int H, int W, int C, int k, int ldi, int ldo, void* stream) {
     if (!in || (!out_h && !out_w)) return MLPK_ENULL;
+    if ((mean != nullptr) != (rstd != nullptr) || (mean != nullptr) != (gamma != nullptr) || (mean != nullptr) != (beta != nullptr)) return MLPK_ENULL;
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || ldi < C || ldo < C) return MLPK_ESHAPE;
     if (k < 1 || !(k & 1)) return MLPK_ESHAPE;
     if (in == out_h || in == out_w) return MLPK_ESHAPE;         // a gather cannot run in place
@@ -818,13 +846,14 @@ extern "C" int mlpk_cycle_shift(int dtype, const void* in, void* out_h, void* ou
     if (vec) {
         const dim3 grid(grid_for(total / 8));
         if (k == 3) {
-            DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((cycle_shift_vec_kernel<T, 3>), grid, dim3(256), 0, s, (const T*)in, (T*)out_h, (T*)out_w, B, H, W, C, ldi, ldo));
+            DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((cycle_shift_vec_kernel<T, 3>), grid, dim3(256), 0, s, (const T*)in, (T*)out_h, (T*)out_w, B, H, W, C, ldi, ldo, mean, rstd, gamma, beta));
         } else if (k == 5) {
-            DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((cycle_shift_vec_kernel<T, 5>), grid, dim3(256), 0, s, (const T*)in, (T*)out_h, (T*)out_w, B, H, W, C, ldi, ldo));
+            DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((cycle_shift_vec_kernel<T, 5>), grid, dim3(256), 0, s, (const T*)in, (T*)out_h, (T*)out_w, B, H, W, C, ldi, ldo, mean, rstd, gamma, beta));
         } else {
-            DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((cycle_shift_vec_kernel<T, 7>), grid, dim3(256), 0, s, (const T*)in, (T*)out_h, (T*)out_w, B, H, W, C, ldi, ldo));
+            DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((cycle_shift_vec_kernel<T, 7>), grid, dim3(256), 0, s, (const T*)in, (T*)out_h, (T*)out_w, B, H, W, C, ldi, ldo, mean, rstd, gamma, beta));
         }
     } else {
+        if (mean) return MLPK_ESHAPE;                            // (the LayerNorm form runs on the 16-byte-vector kernel only: 16 bit, C % 8 == 0, k = 3 / 5 / 7)
         DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((cycle_shift_kernel<T>), dim3(grid_for(total)), dim3(256), 0, s, (const T*)in, (T*)out_h,
                                                  (T*)out_w, B, H, W, C, k, k, ldi, ldo));
     }

@@ -630,6 +630,12 @@ def as_conv2(t, y, B, H, W, C, kernel_size, mean, rstd, gamma, beta, w1, b1, w2,
                                   ptr(w1), ptr(b1), ptr(w2), ptr(b2), w1.stride(0), stream()), "mlpk_as_conv2")
 
 
+def cycle_shift_ln(x, mean, rstd, gamma, beta, out_h, out_w, B, H, W, C, k, ldi, ldo):
+    """mlpk_cycle_shift on LayerNorm(x) without storing it: x un-normalised, (mean, rstd) per pixel, gamma / beta per channel"""
+    N.check(N.lib().mlpk_cycle_shift_ln(dtype_code(x.dtype), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(out_h), ptr(out_w), B, H, W, C, k,
+                                        ldi, ldo, stream()), "mlpk_cycle_shift_ln")
+
+
 def cycle_shift(x, out_h, out_w, B, H, W, C, k, ldi, ldo):
     N.check(N.lib().mlpk_cycle_shift(dtype_code(x.dtype), ptr(x), ptr(out_h), ptr(out_w), B, H, W, C, k, ldi, ldo, stream()),
             "mlpk_cycle_shift")

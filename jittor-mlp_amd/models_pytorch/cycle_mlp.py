@@ -224,6 +224,10 @@ class CycleNet(E.EngineModule):
                 pk[p + "w.b"] = E.f32(att.sfc_w.bias, device)
                 pk[p + "c.w"] = E.pack_matrix(att.mlp_c.weight, dtype, device)
                 pk[p + "c.b"] = E.f32(att.mlp_c.bias, device)
+                if dtype != torch.float32 and C % 8 == 0:
+                    # round 5: mlp_c with norm1 folded in (reads x itself; the shift kernel normalises what it moves): no stored LayerNorm output
+                    pk[p + "cf.w"], pk[p + "cf.b"], pk[p + "cf.csum"] = E.pack_ln_folded(att.mlp_c.weight, att.mlp_c.bias, blk.norm1.weight, blk.norm1.bias,
+                                                                                       dtype, device)
                 pk[p + "r1.w"] = E.pack_matrix(att.reweight.fc1.weight, torch.float32, device)
                 pk[p + "r1.b"] = E.f32(att.reweight.fc1.bias, device)
                 w2 = att.reweight.fc2.weight.detach()                                               # rows c*3 + k -> k*C + c
@@ -265,14 +269,21 @@ class CycleNet(E.EngineModule):
         statistics of the result the same way (or None): both LayerNorms read what a GEMM has just written (mlpk.h row_part)."""
         rows = B * H * W
         mean, rstd = stats if stats is not None else layernorm_stats(ws, cur, rows, C, tag=tag + ".ln")
-        xn = ws.get(tag + ".xn", (rows, C))
-        E.norm_apply(cur, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "ln.g"], beta=pk[p + "ln.b"], out_rm=xn, ld_rm=C)
         sh, sw = ws.get(tag + ".sh", (rows, C)), ws.get(tag + ".sw", (rows, C))
-        E.cycle_shift(xn, sh, sw, B, H, W, C, 3, C, C)
         th, tw, tc = ws.get(tag + ".th", (rows, C)), ws.get(tag + ".tw", (rows, C)), ws.get(tag + ".tc", (rows, C))
+        fold = (p + "cf.w") in pk and os.environ.get("MLPK_CYCLE_LN_FOLD") != "0"
+        if fold:
+            E.cycle_shift_ln(cur, mean, rstd, pk[p + "ln.g"], pk[p + "ln.b"], sh, sw, B, H, W, C, 3, C, C)
+        else:
+            xn = ws.get(tag + ".xn", (rows, C))
+            E.norm_apply(cur, rows, C, C, mean=mean, rstd=rstd, gamma=pk[p + "ln.g"], beta=pk[p + "ln.b"], out_rm=xn, ld_rm=C)
+            E.cycle_shift(xn, sh, sw, B, H, W, C, 3, C, C)
         E.gemm(sh, pk[p + "h.w"], th, rows, C, C, bias=pk[p + "h.b"], tag="cycle_fc")
         E.gemm(sw, pk[p + "w.w"], tw, rows, C, C, bias=pk[p + "w.b"], tag="cycle_fc")
-        E.gemm(xn, pk[p + "c.w"], tc, rows, C, C, bias=pk[p + "c.b"], tag="cycle_c")
+        if fold:
+            E.gemm(cur, pk[p + "cf.w"], tc, rows, C, C, bias=pk[p + "cf.b"], ln=(mean, rstd, pk[p + "cf.csum"]), tag="cycle_c")
+        else:
+            E.gemm(xn, pk[p + "c.w"], tc, rows, C, C, bias=pk[p + "c.b"], tag="cycle_c")
         # reweight: mean over pixels -> Mlp -> softmax over the three branches (fp32, B rows)
         a = ws.get(tag + ".a", (B, C), torch.float32)
         E.split_sum(th, tw, tc, C, C, C, B, H, W, C, N.SHIFT_NONE, a, scale=1.0 / (H * W))

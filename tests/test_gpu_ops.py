@@ -1342,6 +1342,20 @@ def test_cycle_shift_bit_exact(dtype):
         only = torch.full((B, H, W, C), float("nan"), dtype=dtype, device=dev())
         E.cycle_shift(xg, None, only, B, H, W, C, k, C, C)                      # one output only
         assert torch.equal(only.float().cpu(), ref_w)
+        if dtype != torch.float32 and C % 8 == 0:
+            # round 5: the same on LayerNorm(x) without storing it -- bit-equal to mlpk_norm_apply followed by the plain shift
+            rows = B * H * W
+            gamma, beta = (rnd((C,), torch.float32, 1510 + ci) * 0.3 + 1.0).to(dev()), (rnd((C,), torch.float32, 1520 + ci) * 0.2).to(dev())
+            mean, rstd = torch.empty((rows,), dtype=torch.float32, device=dev()), torch.empty((rows,), dtype=torch.float32, device=dev())
+            E.row_stats(xg.view(rows, C), rows, C, C, mean, rstd)
+            xn = torch.empty_like(xg)
+            E.norm_apply(xg.view(rows, C), rows, C, C, mean=mean, rstd=rstd, gamma=gamma, beta=beta, out_rm=xn.view(rows, C), ld_rm=C)
+            ah, aw = torch.full_like(oh, float("nan")), torch.full_like(ow, float("nan"))
+            E.cycle_shift(xn, ah, aw, B, H, W, C, k, C, C)
+            bh, bw = torch.full_like(oh, float("nan")), torch.full_like(ow, float("nan"))
+            E.cycle_shift_ln(xg, mean, rstd, gamma, beta, bh, bw, B, H, W, C, k, C, C)
+            torch.cuda.synchronize()
+            assert torch.equal(bh, ah) and torch.equal(bw, aw), (str(dtype), ci)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
