@@ -25,9 +25,7 @@ from .utils.shift import Shift
 # SLOWER than the separate statistics pass on AS-MLP-T (the C = 96 / 192 GEMMs are short-K and epilogue-bound, and the statistics
 # pass over a whole sample runs at HBM speed); MLPK_ASMLP_EPILOGUE_STATS=1 switches it on (A/B runs, tests).
 EPILOGUE_STATS = os.environ.get("MLPK_ASMLP_EPILOGUE_STATS", "0") == "1"
-# round 5 experiment: by-product statistics only where the 1x1-conv GEMMs run on the generated tile (C >= 384: stages 3 and 4), whose statistics
-# epilogue is cheap; MLPK_ASMLP_EPILOGUE_STATS_WIDE=1 switches it on
-EPILOGUE_STATS_WIDE = os.environ.get("MLPK_ASMLP_EPILOGUE_STATS_WIDE", "0") == "1"
+# (round 5: only on the stages whose GEMMs run on the generated tile, C >= 384 -- also slower: 6.52 vs 6.43 ms, profiles/r05_as_conv2_384_ab.txt)
 
 
 def to_2tuple(v):
@@ -358,7 +356,7 @@ class AS_MLP(E.EngineModule):
                 if finalize_stats(ws, got, rows, width, tag=tag, group=HW) is None:
                     E.row_stats(t, B, HW * width, HW * width, mean, rstd)
 
-            part = (ws, "l%d.part" % li) if (EPILOGUE_STATS or (EPILOGUE_STATS_WIDE and C >= 384)) else None
+            part = (ws, "l%d.part" % li) if EPILOGUE_STATS else None
             for bi in range(len(layer.blocks)):
                 if only is not None and only[1] != "layer" and bi != only[1]:
                     continue
