@@ -1325,6 +1325,7 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, char* const smem) {
     unsigned long long tw = 0, tl = 0, te = 0, ts = 0;
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int ntiles = 0;
+    const unsigned long long wall0 = wall_clock64(), cyc0 = __builtin_readcyclecounter();   // 100 MHz constant clock: start / end skew between CUs
 #define P8_STAMP(acc_)                                                       \
     {                                                                        \
         const unsigned long long n__ = __builtin_readcyclecounter();          \
@@ -1492,10 +1493,12 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, char* const smem) {
     }
 #ifdef MLPK_P8_PROF
     if ((p.dbg & 8) && tid == 0) {
-        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.prof_buf) + (size_t)blockIdx.x * 64;
+        // (a pair launch runs two bodies: the second one, m_base != 0, reports 16 slots further on)
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.prof_buf) + (size_t)blockIdx.x * 64 + (p.m_base ? 16 : 0);
         o[0] = tw; o[1] = tl; o[2] = te; o[3] = (unsigned long long)ntiles;
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[4 + k] = prof[k];
+        o[12] = wall0; o[13] = wall_clock64(); o[14] = __builtin_readcyclecounter() - cyc0;
     }
 #endif
 #undef P8_STAMP

@@ -799,7 +799,9 @@ class EngineModule(torch.nn.Module):
 
     def _get_space(self, batch, dtype, device):
         # keyed by the input's spatial shape too: ConvMixer / Hire-MLP / ... take any resolution, like the reference
-        key = (batch, self._in_shape, dtype, str(device))
+        # ... and by the stream the call is issued on: two streams running the same module at once (batch shards of one
+        # device, tools/two_stream_probe.py) must not share scratch buffers
+        key = (batch, self._in_shape, dtype, str(device), stream())
         ws = self._spaces.get(key)
         if ws is None:
             if len(self._spaces) >= 4:          # bound resident workspaces (288 GB is big, not infinite)
