@@ -49,6 +49,22 @@ def col_sum(x, rows, cols, square=False, sub=None):
     return out
 
 
+_PACKS = {}
+
+
+def _packed(w, w2, cd, dev):
+    """the packed (compute-dtype, K-padded) copy of parameter w, cached per parameter version like EngineModule._get_pack (a training
+    step used to re-pack every weight in every forward)"""
+    key = (w.data_ptr(), cd, str(dev))
+    hit = _PACKS.get(key)
+    if hit is None or hit[0] != w._version or hit[1].shape[0] != w2.shape[0]:
+        if len(_PACKS) > 512:
+            _PACKS.clear()
+        hit = (w._version, E.pack_matrix(w2, cd, dev, kpad=_epc(cd)))
+        _PACKS[key] = hit
+    return hit[1]
+
+
 class Linear(torch.autograd.Function):
     """y = x W^T + b (+ r).  x: (M, K) or (M, K_pad) with zero padding columns; w: parameter (N, K, ...) in fp32; r: (M, N) or None."""
 
@@ -61,7 +77,7 @@ class Linear(torch.autograd.Function):
         assert x.dim() == 2 and x.shape[1] in (k, kp), (tuple(x.shape), k)
         with E.on_device(x):
             xp = _pad_cols(x, kp)
-            wp = E.pack_matrix(w2, cd, dev, kpad=_epc(cd))
+            wp = _packed(w, w2, cd, dev)
             y = torch.empty((x.shape[0], n), dtype=cd, device=dev)
             E.gemm(xp, wp, y, x.shape[0], n, kp, bias=E.f32(b, dev), R=r, res=N.RES_ADD if r is not None else N.RES_NONE)
         ctx.save_for_backward(xp, wp)
@@ -87,9 +103,14 @@ class Linear(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 dyt = transpose(dy, 1, m, n, ld_out=mp)                             # (N, M_pad)
                 xt = transpose(xp, 1, m, k, ld_out=mp)                              # (K, M_pad)
-                dwc = torch.empty((n, k), dtype=cd, device=dev)
+                # the weight gradient is produced in fp32 like the reference's autograd / AMP master gradients: a 16-bit store of the
+                # product would underflow (fp16, loss scaling) or keep 8 bits (bf16).  16-bit runs multiply the fp32 copies of the two
+                # transposed operands on the exact-f32 MFMA tile (advisor, round 5)
+                if cd != torch.float32:
+                    dyt, xt = dyt.float(), xt.float()
+                dwc = torch.empty((n, k), dtype=torch.float32, device=dev)
                 E.gemm(dyt, xt, dwc, n, k, mp)
-                dw = dwc.float().reshape(wshape)
+                dw = dwc.reshape(wshape)
             if has_b and ctx.needs_input_grad[2]:
                 db = col_sum(dy, m, n)
         return dx, dw, db, (dy if has_r else None)

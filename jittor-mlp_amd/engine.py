@@ -387,6 +387,12 @@ def pack_token_mlp(w1, b1, w2, b2, dtype, device, sp, layout=None, t_rows=None):
     w2p[:, :T] = w2.to(device=device, dtype=dtype)
     if layout is None:
         layout = N.lib().mlpk_token_mlp_layout_for(dtype_code(dtype), S, nch, t_rows) if t_rows else N.lib().mlpk_token_mlp_layout(S, nch)
+    if layout == 3:
+        # layout 3 stores W2 as f16 (the hidden stays f16 on chip): weights outside f16's range would overflow / flush where the
+        # reference's bf16 keeps them -- such a model takes layout 2 (bf16 W2, fp32 GELU), same kernel family (advisor, round 5)
+        amax = float(w2.abs().max()) if w2.numel() else 0.0
+        if not amax <= 6.0e4:
+            layout = 2
     if layout in (2, 3):
         # include/mlpk.h: W2 group-major -- (nch + 1) groups x 224 token rows x 32 k slots, slot 16 kk + 8 h + e of a group <- hidden
         # 16 kk + 8 (e >> 2) + 4 h + (e & 3); group nch and the token rows behind S are zeros; b1 / b2 as padded tables
@@ -820,6 +826,11 @@ class EngineModule(torch.nn.Module):
             warnings.warn("%s is inference-only: forward() ignores train mode (Dropout / DropPath are identity, BatchNorm uses "
                           "its running statistics) and the outputs carry no grad_fn; call .eval()" % type(self).__name__,
                           stacklevel=3)
+            self.__dict__["_warned_train"] = True
+        elif self.training and not self._warned_train and getattr(self, "_train_forward", False) == "forward-only":
+            import warnings
+            warnings.warn("%s.train(): the train-mode FORWARD is implemented (batch statistics / stochastic depth), the backward is not -- "
+                          "the outputs carry no grad_fn and a frozen sub-module contributes no gradients" % type(self).__name__, stacklevel=3)
             self.__dict__["_warned_train"] = True
         cd = self._compute_dtype or x.dtype
         dtype_code(cd)

@@ -208,7 +208,7 @@ class AS_MLP(E.EngineModule):
     residual (mlpk.h: v * rscale[m] in front of + R).  The draws come from `drop_path_uniform(B, dtype, device)` (default torch.rand on the
     input's device, one call per DropPath in the reference's order); GroupNorm has no batch statistics, Dropout has p = 0.  Forward only:
     the outputs carry no grad_fn."""
-    _train_forward = True
+    _train_forward = "forward-only"
 
     def __init__(self, img_size=224, patch_size=4, in_chans=3, num_classes=1000, embed_dim=96, depths=[2, 2, 6, 2],
                  shift_size=5, mlp_ratio=4., as_bias=True, drop_rate=0., drop_path_rate=0.1, norm_layer=MyNorm,
@@ -239,7 +239,6 @@ class AS_MLP(E.EngineModule):
         self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
         self.apply(self._init_weights)
         self._shift = shift_size
-        self.__dict__["drop_path_uniform"] = lambda B, dtype, device: torch.rand((B,), dtype=dtype, device=device)
         for li, layer in enumerate(self.layers):
             for bi, blk in enumerate(layer.blocks):
                 blk.__dict__["_owner"] = (self, (li, bi))          # lets `model.layers[l].blocks[b](x)` run (common.Block)
@@ -247,6 +246,11 @@ class AS_MLP(E.EngineModule):
             if layer.downsample is not None:
                 layer.downsample.__dict__["_owner"] = (self, (li, "down"))
         self.patch_embed.__dict__["_owner"] = (self, ("embed", None))
+
+    def drop_path_uniform(self, B, dtype, device):
+        """the uniform draws of one DropPath call in train mode (a method, so that the module pickles; tests replace it per instance
+        with the reference run's recorded draws)"""
+        return torch.rand((B,), dtype=dtype, device=device)
 
     def _init_weights(self, m):
         # as_mlp.py:419-426: only nn.Linear (= the head) gets the truncated normal

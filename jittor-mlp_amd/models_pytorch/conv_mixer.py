@@ -25,7 +25,7 @@ class Residual(Holder):
 
 
 def _check_k(k):
-    if not 1 <= k <= 13 and not (k % 2 == 0 and k <= 12):
+    if not 1 <= k <= 13:
         raise NotImplementedError("depthwise kernel sizes 1 .. 13 are built; got %d" % k)
 
 
@@ -54,7 +54,7 @@ def _bn_affine(bn, device):
 
 class ConvMixer(E.EngineModule):
     """Same signature and defaults as the reference (conv_mixer.py:14)."""
-    _train_forward = True          # train(): BatchNorm on batch statistics + running-statistics update (_forward_train)
+    _train_forward = "forward-only"          # train(): BatchNorm on batch statistics + running-statistics update (_forward_train)
 
     def __init__(self, dim, depth, kernel_size=9, patch_size=7, n_classes=1000):
         super().__init__()

@@ -135,7 +135,9 @@ class MLPMixer(E.EngineModule):
 
     def __init__(self, num_patches, d_model, depth, expansion_factor=4, dropout=0.):
         super().__init__()
-        self.__dict__["_train_forward"] = dropout == 0.          # train(): autograd through the HIP path (_forward_train); Dropout is not implemented
+        # train(): autograd through the HIP path (MLPMixerForImageClassification._forward_train); Dropout is not implemented, and the bare
+        # backbone has no train path: it warns like every inference-only module
+        self.__dict__["_train_forward"] = dropout == 0. and hasattr(self, "_forward_train")
         chan_first, chan_last = partial(nn.Conv1d, kernel_size=1), nn.Linear
         self.model = nn.Sequential(*[
             nn.Sequential(
@@ -267,6 +269,11 @@ class MLPMixerForImageClassification(MLPMixer):
         E.require_gpu(x, "MLPMixerForImageClassification.forward")
         if x.dim() != 4:
             raise ValueError("expected a (B, C, H, W) tensor")
+        if x.requires_grad and not self.__dict__.get("_warned_input_grad"):
+            import warnings
+            warnings.warn("MLPMixerForImageClassification.train(): the gradient with respect to the input image is not produced "
+                          "(parameter gradients only)", stacklevel=3)
+            self.__dict__["_warned_input_grad"] = True
         cd = self._compute_dtype or x.dtype
         E.dtype_code(cd)
         S, C, depth, _ = self._dims

@@ -522,9 +522,9 @@ def make_s2_lowp(ref):
                                max|d| against its fp32 logits.  The 18-block network amplifies round-off ~100x (the
                                in-place "smear" shift + SplitAttention sums over all pixels), so a 16-bit run of the
                                reference itself is 0.4 / 0.7 away from its fp32 logits: that, not 1e-3, is the floor.
-      real_s2mlpv2_blocks.npz  teacher forcing: full input and output (fp32, reference layout (B,H,W,C)) of blocks
-                               0, 3 of stage 1 and 0, 7, 13 of stage 2 at bs=1, plus the reference's own 16-bit error
-                               on each of those blocks fed the SAME input -- per-block parity has no conditioning excuse.
+      real_s2mlpv2_blocks.npz  teacher forcing: input and output (fp32, reference layout (B,H,W,C)) of EVERY block of both
+                               stages (4 + 14) at bs=1, plus the reference's own 16-bit error on each block fed the SAME
+                               input -- per-block parity has no conditioning excuse.
     s2_mlp_v2.py:15-92."""
     s2 = ref["s2_mlp_v2"]
     nt = torch.get_num_threads()
@@ -549,9 +549,10 @@ def make_s2_lowp(ref):
             print("  s2mlpv2 reference %s vs its fp32: max|d| %.4f (max|ref| %.3f)" % (tag, blob["err_" + tag], o32.abs().max().item()), flush=True)
         np.savez_compressed(os.path.join(HERE, "real_s2mlpv2_lowp.npz"), **blob)
 
-        # ---- teacher-forced blocks, bs = 1
+        # ---- teacher-forced blocks, bs = 1: EVERY block of both stages (round 6: 4 + 14 = 18; round 4 kept five).  A stage's blocks are an
+        # nn.Sequential, so block i + 1's input IS block i's output: the fixture stores each stage's first input and every block's output
         model = fresh()
-        picks = [(0, 0), (0, 3), (1, 0), (1, 7), (1, 13)]
+        picks = [(s, i) for s in range(len(model.stages)) for i in range(len(model.stages[s][1].model))]
         cap, handles = {}, []
         for s, i in picks:
             mod = model.stages[s][1].model[i]
@@ -561,11 +562,15 @@ def make_s2_lowp(ref):
             model(x[:1].clone())
         for h in handles:
             h.remove()
-        blob = {}
+        blob = {"nblocks": np.array([len(model.stages[s][1].model) for s in range(len(model.stages))])}
         for s, i in picks:
-            key = "s%d.b%d" % (s, i)
-            xin, yout = cap[key]
-            blob[key + "/in"], blob[key + "/out"] = xin.numpy(), yout.numpy()
+            key = "s%d.b%02d" % (s, i)
+            xin, yout = cap["s%d.b%d" % (s, i)]
+            if i == 0:
+                blob["s%d/in" % s] = xin.numpy()
+            else:
+                assert torch.equal(xin, cap["s%d.b%d" % (s, i - 1)][1]), "a block's input is not its predecessor's output"
+            blob[key + "/out"] = yout.numpy()
             for tag, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
                 blk = fresh().stages[s][1].model[i].to(dt)
                 with torch.no_grad():

@@ -213,8 +213,9 @@ def s2_real_gate(dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
 def test_s2mlpv2_teacher_forced_blocks(dtype):
-    """Per-block parity at the real shapes (C = 192 @ 32x32, C = 384 @ 16x16) with no error amplification: feed the
-    reference's own block INPUT (fp32 golden, bs = 1) to the HIP block and compare with the reference's block OUTPUT.
+    """Per-block parity at the real shapes (C = 192 @ 32x32, C = 384 @ 16x16) with no error amplification, for every one of the 18
+    blocks of the BASELINE configuration: feed the reference's own block INPUT (fp32 golden, bs = 1) to the HIP block and compare
+    with the reference's block OUTPUT.
     Gates, relative to max|out|: fp32 1e-5; fp16 2^-10; bf16 2^-7 -- rounding level, and at or below what the reference
     itself achieves on the same block in that dtype (stored next to the tensors: fp16 7e-4..1.1e-3, bf16 5.7e-3..1.1e-2).
     s2_mlp_v2.py:53-92."""
@@ -227,24 +228,33 @@ def test_s2mlpv2_teacher_forced_blocks(dtype):
     model.load_state_dict({k: torch.from_numpy(v) for k, v in portable_state_dict(shapes, seed=0).items()}, strict=True)
     model = model.to(DEV)
     gate = {torch.float32: 1e-5, torch.float16: 2.0 ** -10, torch.bfloat16: 2.0 ** -7}[dtype]
-    keys = sorted({k.split("/")[0] for k in z.files})
-    assert len(keys) == 5
-    for key in keys:
-        s, i = int(key[1]), int(key.split(".b")[1])
-        xin, yout = torch.from_numpy(z[key + "/in"]), torch.from_numpy(z[key + "/out"])
-        with torch.no_grad():
-            y = model.forward_block(s, i, xin.to(DEV).to(dtype))
-        torch.cuda.synchronize()
-        assert y.shape == yout.shape and y.dtype == dtype
-        rel = ((y.float().cpu() - yout).abs().max() / yout.abs().max()).item()
-        ref_rel = float(z[key + "/ref_relerr_" + ("bf16" if dtype == torch.bfloat16 else "fp16")]) if dtype != torch.float32 else 0.0
-        print("block %-7s %-8s rel err %.3e (2^%.1f)   reference's own: %.3e" % (key, str(dtype)[6:], rel, np.log2(max(rel, 1e-30)), ref_rel))
-        if dtype == torch.float32:
-            assert rel < gate, (key, str(dtype), rel)
-        else:
-            # 16 bit: the bar is the reference's OWN error on this block in this dtype (the absolute 2^-7 / 2^-10 figures above
-            # are what is typically seen; block s0.b0 sits within 5 % of them and moves with the box's rounding)
-            assert rel < 1.25 * ref_rel, (key, str(dtype), rel, ref_rel)
+    # round 6: ALL 18 blocks (4 at C = 192, 14 at C = 384).  A stage is an nn.Sequential, so the fixture stores the stage's first input and
+    # every block's output: block i is fed the REFERENCE's output of block i - 1 (teacher forcing), never this library's
+    nblocks = [int(n) for n in z["nblocks"]]
+    assert nblocks == [4, 14]
+    worst = 0.0
+    for s, nb in enumerate(nblocks):
+        xin = torch.from_numpy(z["s%d/in" % s])
+        for i in range(nb):
+            key = "s%d.b%02d" % (s, i)
+            yout = torch.from_numpy(z[key + "/out"])
+            with torch.no_grad():
+                y = model.forward_block(s, i, xin.to(DEV).to(dtype))
+            torch.cuda.synchronize()
+            assert y.shape == yout.shape and y.dtype == dtype
+            rel = ((y.float().cpu() - yout).abs().max() / yout.abs().max()).item()
+            ref_rel = float(z[key + "/ref_relerr_" + ("bf16" if dtype == torch.bfloat16 else "fp16")]) if dtype != torch.float32 else 0.0
+            print("block %-7s %-8s rel err %.3e (2^%.1f)   reference's own: %.3e" % (key, str(dtype)[6:], rel, np.log2(max(rel, 1e-30)), ref_rel))
+            if dtype == torch.float32:
+                assert rel < gate, (key, str(dtype), rel)
+            else:
+                # 16 bit: the bar is the reference's OWN error on this block in this dtype (the absolute 2^-7 / 2^-10 figures above
+                # are what is typically seen; block s0.b00 sits within 5 % of them and moves with the box's rounding)
+                assert rel < 1.25 * ref_rel, (key, str(dtype), rel, ref_rel)
+                worst = max(worst, rel / ref_rel)
+            xin = yout
+    if dtype != torch.float32:
+        print("worst block error relative to the reference's own on that block: %.2f" % worst)
 
 
 BS256 = [
