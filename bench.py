@@ -245,6 +245,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=sorted(DT))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the fp32-input variant line (profiling runs count forwards)")
     ap.add_argument("--algo", default="", help="tag=algo[,tag=algo] GEMM tile overrides (tuning)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm; gloo only for "
                     "exercising the multi-process path on a single-GPU box together with --share-device)")
@@ -345,7 +346,7 @@ def main():
         # set_compute_dtype: the image is converted while the patches are gathered and the logits come back in fp32.  The headline above
         # keeps the batch resident in the compute dtype; this variant line times the contract itself on the same model (N = 1 only).
         fp32_variant = None
-        if world == 1 and cd != torch.float32 and hasattr(model, "set_compute_dtype"):
+        if world == 1 and cd != torch.float32 and hasattr(model, "set_compute_dtype") and not args.no_variants:
             x32 = x.float()
             model.set_compute_dtype(cd)
             for _ in range(3):

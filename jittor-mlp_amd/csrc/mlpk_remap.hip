@@ -595,10 +595,10 @@ __global__ void __launch_bounds__(256) norm_shift_vec_kernel(const T* __restrict
 // workgroup per image.  t = act(norm(u)) is evaluated ONCE per element into an LDS copy of the image (the gather form above evaluates
 // it for each of its two outputs, and spends as many instructions on dividing its flat index into (n, h, w, c)); both outputs are then
 // 16-byte reads of that copy at the shifted pixel -- zero outside the map, two reads where a vector straddles two shift groups.
-template <typename T>
+template <typename T, bool GELU>
 __global__ void __launch_bounds__(512) norm_shift_img_kernel(const T* __restrict__ in, T* __restrict__ out_w, T* __restrict__ out_h, int H, int W, int C,
                                                              int ksz, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                             const float* __restrict__ gamma, const float* __restrict__ beta, int act) {
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta) {
     extern __shared__ __attribute__((aligned(16))) char smem_img[];
     u32x4* const img = reinterpret_cast<u32x4*>(smem_img);
     const int n = blockIdx.x, tid = threadIdx.x;
@@ -607,33 +607,51 @@ __global__ void __launch_bounds__(512) norm_shift_img_kernel(const T* __restrict
     const float mu = mean[n], rs = rstd[n];
     const float inv_cv = 1.0f / (float)CV, inv_w = 1.0f / (float)W;
     const T* src = in + (size_t)n * HW * C;
+    // per-channel scale and shift ONCE per workgroup, behind the image in LDS.  (Until round 6 every vector re-read its eight gamma / beta
+    // values through sixteen scalar-branch-guarded dword loads in the same loop iteration as its own 16-byte load: one memory latency after
+    // the other, 18 iterations per thread -- 72 us for 115 MB moved, profiles/r05_asmlp_t_kernel_stats_v4.csv.)  The expressions stay those
+    // of norm_shift_vec_kernel, term for term: the two forms -- and mlpk_as_conv2, which is bit-equal to that one -- must round alike
+    float* const scs = reinterpret_cast<float*>(smem_img + (size_t)HW * C * sizeof(T));
+    for (int c = tid; c < C; c += 512) {
+        const float g = gamma ? gamma[c] : 1.f;
+        scs[c] = rs * g;
+        scs[C + c] = (beta ? beta[c] : 0.f) - mu * rs * g;
+    }
+    __syncthreads();
     // (index arithmetic by float reciprocals: exact for these ranges -- NV < 2^17, the quotients are at least 0.5 / CV away from an integer)
-    for (int v = tid; v < NV; v += 512) {
-        const int px = (int)(((float)v + 0.5f) * inv_cv);
-        const int c = (v - px * CV) * 8;
-        float x[8], o[8];
-        ld8<T>(src + (size_t)v * 8, x);
-        // (the expressions of norm_shift_vec_kernel, term for term: the two forms -- and mlpk_as_conv2, which is bit-equal to that one --
-        // must round alike)
-        float sc[8], sh[8];
+    constexpr int U = 6;                                    // vectors of a round: all their loads are in flight before the first is used
+    for (int base = 0; base < NV; base += 512 * U) {
+        u32x4 raw[U];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float g = gamma ? gamma[c + e] : 1.f;
-            sc[e] = rs * g;
-            sh[e] = (beta ? beta[c + e] : 0.f) - mu * rs * g;
+        for (int u = 0; u < U; ++u) {
+            const int v = base + u * 512 + tid;
+            raw[u] = *reinterpret_cast<const u32x4*>(src + (size_t)(v < NV ? v : NV - 1) * 8);      // (clamped, not predicated: no branch between the loads)
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float t = x[e] * sc[e] + sh[e];
-            if (act == MLPK_ACT_GELU) t = gelu_t<T>(t);
-            o[e] = t;
-        }
-        T r[8];
+        for (int u = 0; u < U; ++u) {
+            const int v = base + u * 512 + tid;
+            if (v >= NV) continue;
+            const int px = (int)(((float)v + 0.5f) * inv_cv);
+            const int c = (v - px * CV) * 8;
+            T xe[8];
+            __builtin_memcpy(xe, &raw[u], 16);
+            const f32x4 sc0 = *reinterpret_cast<const f32x4*>(scs + c), sc1 = *reinterpret_cast<const f32x4*>(scs + c + 4);
+            const f32x4 sh0 = *reinterpret_cast<const f32x4*>(scs + C + c), sh1 = *reinterpret_cast<const f32x4*>(scs + C + c + 4);
+            const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
+            const float sh[8] = {sh0.x, sh0.y, sh0.z, sh0.w, sh1.x, sh1.y, sh1.z, sh1.w};
+            T r[8];
+            f32x2 g2[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) r[e] = from_f32<T>(o[e]);
-        u32x4 pk;
-        __builtin_memcpy(&pk, r, 16);
-        img[v] = pk;
+            for (int e = 0; e < 4; ++e) g2[e] = f32x2{__builtin_fmaf(to_f32(xe[2 * e]), sc[2 * e], sh[2 * e]), __builtin_fmaf(to_f32(xe[2 * e + 1]), sc[2 * e + 1], sh[2 * e + 1])};
+            // (GELU is a template parameter: as a run-time flag hipcc branched around every element's evaluation; four pairs abreast give
+            //  the same bits as gelu16_f per element -- mlpk_as_conv2 stages its band the same way)
+            if (GELU) gelu_pk_n<T, 4>(g2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { r[2 * e] = from_f32<T>(g2[e].x); r[2 * e + 1] = from_f32<T>(g2[e].y); }
+            u32x4 pk;
+            __builtin_memcpy(&pk, r, 16);
+            img[v] = pk;
+        }
     }
     __syncthreads();
     T* const dw = out_w + (size_t)n * HW * C;
@@ -797,19 +815,23 @@ extern "C" int mlpk_norm_shift_nhwc(int dtype, const void* in, void* out_w, void
     // maps that fit the LDS: one workgroup per image, the activation evaluated once per element (MLPK_NORM_SHIFT_IMG=0: the gather form, A/B aid)
     const size_t img_bytes = (size_t)H * W * C * 2;
     static const bool img_off = getenv("MLPK_NORM_SHIFT_IMG") && atoi(getenv("MLPK_NORM_SHIFT_IMG")) == 0;
-    if (!img_off && img_bytes <= 160 * 1024 && (size_t)H * W * (C / 8) < (1u << 17)) {
-        hipError_t e;
+    const size_t img_lds = img_bytes + (size_t)C * 8;                // + the per-channel scale / shift tables
+    if (!img_off && img_lds <= 160 * 1024 && (size_t)H * W * (C / 8) < (1u << 17)) {
+        hipError_t e = hipSuccess;
+#define NSI_LAUNCH(TT, GG)                                                                                                              \
+    {                                                                                                                                   \
+        auto k = norm_shift_img_kernel<TT, GG>;                                                                                         \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)img_lds);           \
+        if (e != hipSuccess) return (int)e;                                                                                             \
+        hipLaunchKernelGGL(k, dim3(N), dim3(512), img_lds, s, (const TT*)in, (TT*)out_w, (TT*)out_h, H, W, C, kernel_size, mean, rstd, gamma, beta); \
+    }
+        const bool gelu = act == MLPK_ACT_GELU;
         if (dtype == MLPK_BF16) {
-            auto k = norm_shift_img_kernel<bf16_t>;
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)img_bytes);
-            if (e != hipSuccess) return (int)e;
-            hipLaunchKernelGGL(k, dim3(N), dim3(512), img_bytes, s, (const bf16_t*)in, (bf16_t*)out_w, (bf16_t*)out_h, H, W, C, kernel_size, mean, rstd, gamma, beta, act);
+            if (gelu) NSI_LAUNCH(bf16_t, true) else NSI_LAUNCH(bf16_t, false)
         } else {
-            auto k = norm_shift_img_kernel<f16_t>;
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)img_bytes);
-            if (e != hipSuccess) return (int)e;
-            hipLaunchKernelGGL(k, dim3(N), dim3(512), img_bytes, s, (const f16_t*)in, (f16_t*)out_w, (f16_t*)out_h, H, W, C, kernel_size, mean, rstd, gamma, beta, act);
+            if (gelu) NSI_LAUNCH(f16_t, true) else NSI_LAUNCH(f16_t, false)
         }
+#undef NSI_LAUNCH
         MLPK_LAUNCH_CHECK();
         return 0;
     }

@@ -32,7 +32,7 @@ PY
 fi
 if has prof; then
   rm -rf $OUT/prof
-  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o mixer_b16 -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err" )
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o mixer_b16 -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-variants > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err" )
   echo "prof rc=$?"
   find $OUT/prof -name "*kernel_stats*" | head -3
   f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
