@@ -12,6 +12,8 @@ Only the instructions the generator uses are implemented; an unknown mnemonic ra
 """
 import struct
 
+import os
+
 import numpy as np
 
 POISON = 0x7FC0DEAD
@@ -339,10 +341,16 @@ class Emu:
         return np.asarray(x, np.float32).view(np.uint32)
 
     # ---- asynchronous completion
+    # Stores are modelled as the operations that complete FIRST (out of issue order): adversarial for any wait that would count them.
+    # The family's documented behaviour is in-order completion for loads and stores alike (LLVM AMDGPUUsage, memory model GFX6-GFX9 /
+    # GFX90A / GFX942: "completion is reported to a wavefront in execution order"); STORES_IN_ORDER = True models that -- needed only by
+    # kernels generated with MLPK_Q4_COUNT_STORES=1 (a round-6 experiment that measured no gain).
+    STORES_IN_ORDER = os.environ.get("MLPK_Q4_COUNT_STORES", "0") == "1"
+
     def wait_vm(self, w, n):
-        """adversarial: stores are the ones that complete first; loads / LDS-DMA complete in order, as late as allowed"""
+        """in issue order, as late as allowed (STORES_IN_ORDER = False: adversarial for counted stores -- stores complete first)"""
         while len(w.vm) > n:
-            k = next((i for i, (kind, _) in enumerate(w.vm) if kind == "store"), None)
+            k = None if self.STORES_IN_ORDER else next((i for i, (kind, _) in enumerate(w.vm) if kind == "store"), None)
             if k is None:
                 k = 0
             _, fn = w.vm.pop(k)

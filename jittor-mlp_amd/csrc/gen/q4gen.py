@@ -712,12 +712,22 @@ class Q4:
                 rest.pop(0)()
         # vmcnt in front of the barrier: the pieces of the PREVIOUS iteration must have landed (<= 12 loads of this one may be
         # in flight: loads return in order, stores may not be counted on), and so must every VGPR load issued in this one
-        kinds = [("load" if x.op.startswith("global_load_dword") else "dma") for x in a.ins[i_start:]
-                 if x.op.startswith("global_load")]
+        # Round 6 experiment, kept as an option (MLPK_Q4_COUNT_STORES=1 at generation time; the emulator then needs STORES_IN_ORDER): counting
+        # this iteration's STORES in the wait as well.  A wave's vector-memory operations report completion in issue order on this family
+        # (LLVM AMDGPUUsage, memory model GFX6-GFX9 / GFX90A / GFX942), so vmcnt(operations issued in this iteration) would be enough
+        # for "everything older has completed"; counting the loads only also covers this iteration's first pieces, one per store behind
+        # them.  Hypothesis: that is what makes gMLP's proj1 (K = 256: 16 stores per 4 slabs) run 144 us in the model against 83 alone.
+        # Measured same-box, three alternations (profiles/r06_q4_count_stores_ab.txt): gMLP-S 9.932 / 9.946 / 9.928 against 9.939 / 9.940 /
+        # 9.912 ms, Mixer-B/16 7.39 vs 7.40, ViP-S7 27.81 vs 27.62 (-0.6 %), ResMLP-24 5.07 vs 5.07: nothing -- the slab waits are not
+        # what the stores hold up.  Default off.
+        count_stores = os.environ.get("MLPK_Q4_COUNT_STORES", "0") == "1"
+        kinds = [("load" if x.op.startswith("global_load_dword") else ("store" if x.op.startswith("global_store") else "dma"))
+                 for x in a.ins[i_start:] if x.op.startswith("global_load") or (count_stores and x.op.startswith("global_store"))]
         allow = len(kinds)
         if "load" in kinds:
             allow = len(kinds) - 1 - max(k for k, x in enumerate(kinds) if x == "load")
-        a("s_waitcnt", vmcnt=min(allow, 12 if self.dma_on else 0), lgkmcnt=0)
+        cap = 63 if count_stores else 12
+        a("s_waitcnt", vmcnt=min(allow, cap if self.dma_on else 0), lgkmcnt=0)
         a("s_barrier")
 
     # ------------------------------------------------------------------ the kernel

@@ -955,7 +955,10 @@ def test_axial_shift_core_in_one_kernel(dtype):
     wrap rows), both widths the kernel is built for, several bands per image."""
     pkg = load_pkg()
     E, N = pkg.engine, pkg._native
-    for ci, (B, H, W, C) in enumerate([(2, 56, 56, 96), (3, 28, 28, 192), (2, 7, 9, 96), (1, 33, 5, 192), (5, 14, 14, 96), (2, 1, 1, 192)]):
+    # (round 6: the kernel is persistent over (image, row segment) units and walks a ring of staged rows -- one image split into several
+    #  segments, more units than CUs, a single step per unit, steps with a short tail)
+    for ci, (B, H, W, C) in enumerate([(2, 56, 56, 96), (3, 28, 28, 192), (2, 7, 9, 96), (1, 33, 5, 192), (5, 14, 14, 96), (2, 1, 1, 192),
+                                       (1, 56, 56, 96), (7, 28, 28, 192), (300, 7, 9, 96), (1, 61, 12, 192)]):
         rows = B * H * W
         t = (rnd((rows, C), dtype, 4000 + ci) * 1.5 + 0.3).to(dev())
         mean = (rnd((B,), torch.float32, 4010 + ci) * 0.2).to(dev())
