@@ -382,6 +382,17 @@ int mlpk_as_conv2_supported(int dtype, int H, int W, int C, int kernel_size);
 int mlpk_as_conv2(int dtype, const void* t, void* y, int B, int H, int W, int C, int kernel_size, const float* mean, const float* rstd,
                   const float* gamma, const float* beta, const void* w1, const float* b1, const void* w2, const float* b2, int ldw,
                   void* stream);
+/* ABI 10 (round 6).  mlpk_as_conv2 that also delivers the GroupNorm(1, C) statistics of y -- AxialShift's norm2 (as_mlp.py:52,94) -- so that
+ * no statistics pass reads y back: every step of image rows leaves (sum, sum of squares) of the values it STORED (the rounded ones) at
+ * part[2 (b * steps + s)], steps = mlpk_as_conv2_steps(...) (a function of dtype, C and the map only, so an image's statistics do not
+ * depend on the batch it is in), and the image's pairs are added in step order in fp64 by one thread inside the kernel:
+ * mean_out[b], rstd_out[b] = 1 / sqrt(var + eps), var = E[y^2] - mean^2 clamped at 0, over H*W*C values.  Small batches cut an image into
+ * row segments for several workgroups: the one that finishes an image last (counter[b], B zeroed ints, left zeroed) adds the pairs.
+ * mean_out / rstd_out must not be mean / rstd (other workgroups still read those).  part: B * steps * 2 floats, 8-byte aligned. */
+int mlpk_as_conv2_steps(int dtype, int H, int W, int C, int kernel_size);
+int mlpk_as_conv2_stats(int dtype, const void* t, void* y, int B, int H, int W, int C, int kernel_size, const float* mean, const float* rstd,
+                        const float* gamma, const float* beta, const void* w1, const float* b1, const void* w2, const float* b2, int ldw,
+                        float* part, float* mean_out, float* rstd_out, int* counter, float eps, void* stream);
 
 /* ---- fused channel MLP for narrow channel-last tensors (ABI 8, round 4) -------------------------------------------------------
  * out[m, :] = R[m, :] + W2 . gelu( W1 . norm(x[m, :]) + b1 ) + b2      (as_mlp.py:36-52 with :343-344; the Mlp / FeedForward of every

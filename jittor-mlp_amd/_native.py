@@ -106,6 +106,9 @@ PROTOTYPES = {
                                  c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     # (dtype, t, y, B, H, W, C, kernel_size, mean, rstd, gamma, beta, w1, b1, w2, b2, ldw, stream)
     "mlpk_as_conv2": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p] * 8 + [c_int, c_void_p]),
+    "mlpk_as_conv2_steps": (c_int, [c_int] * 5),
+    # (... ldw, part, mean_out, rstd_out, counter, eps, stream)
+    "mlpk_as_conv2_stats": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p] * 8 + [c_int] + [c_void_p] * 4 + [c_float, c_void_p]),
     "mlpk_split_sum": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_float, c_void_p, c_void_p]),
     "mlpk_split_softmax": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "mlpk_split_apply": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p, c_void_p, c_int, c_void_p]),

@@ -34,6 +34,12 @@ struct AsConvArgs {
     const float* b1;
     const float* b2;
     int B, H, W, ldw, TH, bands, seg_rows;
+    float* part;          // optional by-product: (sum, sum of squares) of the values stored by step s of image b at [2 (b * steps + s)], or NULL
+    int steps;            // steps of TH rows per image
+    float* mean_out;      // with part: GroupNorm(1, C) statistics of y per image, finished inside the kernel
+    float* rstd_out;
+    int* counter;         // with part and bands > 1: one zeroed counter per image (left zeroed)
+    float eps;
 };
 
 template <typename T> struct Mfma32;
@@ -87,6 +93,8 @@ __global__ void __launch_bounds__(512, 1) as_conv2_kernel(const AsConvArgs p) {
     // ---- staging geometry: thread = (octet of channels, pixel lane); a stage set is `nrows` whole rows of W pixels, swept PL pixels at a time
     const int oct = tid % NOCT, pl = tid / NOCT;
     const bool stager = pl < PL;
+    const int pl_r = pl / W, pl_x = pl - pl_r * W;               // pixel pl of a stage set, and the step of a sweep
+    const int pl_dr = PL / W, pl_dx = PL - pl_dr * W;
     // per-channel scale / shift of the image being staged, as tables in LDS behind the staging tiles (registers are what this kernel is short of)
     float* const scs = reinterpret_cast<float*>(smem + (size_t)R * rowb + 8 * ASC_STG_BYTES);
     int tab_img = -1;
@@ -109,14 +117,17 @@ __global__ void __launch_bounds__(512, 1) as_conv2_kernel(const AsConvArgs p) {
         if (!stager) return;
         const T* __restrict__ tin = reinterpret_cast<const T*>(p.t) + (size_t)st.img * H * W * C;
         const int npix = st.nrows * W;
+        int r = pl_r, gx = pl_x;                     // (row, column) of pixel pl + k PL, advanced by (PL / W, PL % W) per sweep: no division
 #pragma unroll
         for (int k = 0; k < NPRE; ++k) {
             const int pp = pl + k * PL;
-            const int r = pp / W, gx = pp - r * W, gy = st.gy0 + r;
+            const int gy = st.gy0 + r;
             const bool in = pp < npix && gy >= 0 && gy < H;
             // (clamped address, not a predicated load: nothing between the loads that could make hipcc wait for one before the next)
             const size_t off = in ? ((size_t)gy * W + gx) * C + oct * 8 : (size_t)oct * 8;
             raw[k] = *reinterpret_cast<const u32x4*>(tin + off);
+            gx += pl_dx; r += pl_dr;
+            if (gx >= W) { gx -= W; ++r; }
         }
     };
     // write a set into the ring: u = round(gelu(t * sc + sh)); sweeps beyond NPRE (a unit's first set is TH + 4 rows) are loaded here
@@ -134,8 +145,8 @@ __global__ void __launch_bounds__(512, 1) as_conv2_kernel(const AsConvArgs p) {
         if (!stager) return;
         const T* __restrict__ tin = reinterpret_cast<const T*>(p.t) + (size_t)st.img * H * W * C;
         const int npix = st.nrows * W;
-        auto put = [&](const int pp, const u32x4 rawv) {
-            const int r = pp / W, gx = pp - r * W, gy = st.gy0 + r;
+        auto put = [&](const int r, const int gx, const u32x4 rawv) {
+            const int gy = st.gy0 + r;
             int slot = st.slot0 + r;
             slot = slot >= R ? slot - R : slot;
             u32x4 o = {0u, 0u, 0u, 0u};
@@ -156,24 +167,31 @@ __global__ void __launch_bounds__(512, 1) as_conv2_kernel(const AsConvArgs p) {
             }
             *reinterpret_cast<u32x4*>(smem + (size_t)slot * rowb + (size_t)(gx + P2) * PITCH + oct * 16) = o;
         };
+        int r = pl_r, gx = pl_x;
 #pragma unroll
         for (int k = 0; k < NPRE; ++k) {
             const int pp = pl + k * PL;
-            if (pp < npix) put(pp, raw[k]);
+            if (pp < npix) put(r, gx, raw[k]);
+            gx += pl_dx; r += pl_dr;
+            if (gx >= W) { gx -= W; ++r; }
         }
         // the rest of a long set, four sweeps at a time with their loads abreast
         for (int pp0 = pl + NPRE * PL; pp0 < npix; pp0 += 4 * PL) {
             u32x4 rr[4];
+            int rk[4], xk[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int pp = pp0 + k * PL;
-                const int r = pp / W, gx = pp - r * W, gy = st.gy0 + r;
+                rk[k] = r; xk[k] = gx;
+                const int gy = st.gy0 + r;
                 const bool in = pp < npix && gy >= 0 && gy < H;
                 rr[k] = *reinterpret_cast<const u32x4*>(tin + (in ? ((size_t)gy * W + gx) * C + oct * 8 : (size_t)oct * 8));
+                gx += pl_dx; r += pl_dr;
+                if (gx >= W) { gx -= W; ++r; }
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (pp0 + k * PL < npix) put(pp0 + k * PL, rr[k]);
+                if (pp0 + k * PL < npix) put(rk[k], xk[k], rr[k]);
         }
     };
 
@@ -193,6 +211,7 @@ __global__ void __launch_bounds__(512, 1) as_conv2_kernel(const AsConvArgs p) {
     stage(cur);
     int r0 = ra;                                     // first output row of the step
     int base = 0;                                    // ring slot of row r0 - 2
+    double ds1 = 0.0, ds2 = 0.0;                     // (thread 0) the image's step pairs so far
     for (;;) {
         __syncthreads();                             // the rows of this step are staged
         // ---- what comes next: the TH new rows of the following step, or the first set of the next unit
@@ -215,6 +234,7 @@ __global__ void __launch_bounds__(512, 1) as_conv2_kernel(const AsConvArgs p) {
         if (more) request(nxt);
 
         // ---- the matrix phase of rows r0 .. r0 + th - 1
+        float st1 = 0.f, st2 = 0.f;
         {
             const int th = rb - r0 < TH ? rb - r0 : TH;
             const int M = th * W;
@@ -284,17 +304,35 @@ __global__ void __launch_bounds__(512, 1) as_conv2_kernel(const AsConvArgs p) {
                     // (the epilogue's LDS reads stay behind this convolution's MFMAs: hoisted to the top of the task they cost C = 192 its registers)
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 bz = *reinterpret_cast<const f32x4*>(bias + nc * 32 + 8 * g + 4 * hh);
-                        const float bb[4] = {bz.x, bz.y, bz.z, bz.w};
-                        f32x2 g2[2] = {f32x2{acc[4 * g] + bb[0], acc[4 * g + 1] + bb[1]}, f32x2{acc[4 * g + 2] + bb[2], acc[4 * g + 3] + bb[3]}};
-                        gelu_pk_n<T, 2>(g2);
-                        const float gv[4] = {g2[0].x, g2[0].y, g2[1].x, g2[1].y};
+                    for (int g2i = 0; g2i < 2; ++g2i) {
+                        // two channel groups = four float pairs abreast through the GELU (the packed-f16 steps of two pairs alone left a
+                        // wait state after every instruction: 90 s_nop per task); per element the same operation sequence, the same bits
+                        f32x2 g2[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float v = to_f32(from_f32<T>(gv[r]));
-                            yv[4 * g + r] = conv == 0 ? v : to_f32(from_f32<T>(v + yv[4 * g + r]));
+                        for (int q = 0; q < 2; ++q) {
+                            const int g = 2 * g2i + q;
+                            const f32x4 bz = *reinterpret_cast<const f32x4*>(bias + nc * 32 + 8 * g + 4 * hh);
+                            g2[2 * q] = f32x2{acc[4 * g] + bz.x, acc[4 * g + 1] + bz.y};
+                            g2[2 * q + 1] = f32x2{acc[4 * g + 2] + bz.z, acc[4 * g + 3] + bz.w};
                         }
+                        gelu_pk_n<T, 4>(g2);
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int g = 2 * g2i + q;
+                            const float gv[4] = {g2[2 * q].x, g2[2 * q].y, g2[2 * q + 1].x, g2[2 * q + 1].y};
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float v = to_f32(from_f32<T>(gv[r]));
+                                yv[4 * g + r] = conv == 0 ? v : to_f32(from_f32<T>(v + yv[4 * g + r]));
+                            }
+                        }
+                    }
+                }
+                if (p.part && pb * 32 + l31 < M) {              // by-product statistics of what is stored (the rounded values), this lane's pixel
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        st1 += yv[r];
+                        st2 = __builtin_fmaf(yv[r], yv[r], st2);
                     }
                 }
                 // ---- store: [32 pixels][32 channels] through the wave's staging tile, then 16-byte pieces (pixel lane >> 2, + 16; piece lane & 3)
@@ -316,6 +354,57 @@ __global__ void __launch_bounds__(512, 1) as_conv2_kernel(const AsConvArgs p) {
                 __builtin_amdgcn_wave_barrier();
             }
         }
+        if (p.part) {
+            // GroupNorm(1, C) statistics of the sample as a by-product: one (sum, sum of squares) pair per STEP -- the step grid depends on the
+            // map only, not on the batch or on how images are cut into units, so a sample's statistics do not depend on the batch it is in --
+            // lanes by xor-shuffles, the eight waves in order by one thread; mlpk_stats_finalize_planar(group = steps) adds the steps up
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                st1 += __shfl_xor(st1, o);
+                st2 += __shfl_xor(st2, o);
+            }
+            float* const red = btab + 2 * C;
+            if (lane == 0) { red[2 * wave] = st1; red[2 * wave + 1] = st2; }
+            __syncthreads();
+            if (tid == 0) {
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int w8 = 0; w8 < 8; ++w8) { a1 += red[2 * w8]; a2 += red[2 * w8 + 1]; }
+                float* const dst = p.part + 2 * ((size_t)img * p.steps + r0 / TH);
+                dst[0] = a1;
+                dst[1] = a2;
+                // ... and the statistics themselves, without a launch of their own: the step pairs of an image added in step order in
+                // fp64 by ONE thread -- the workgroup that owns the whole image as it goes, else (small batches: an image cut into
+                // segments) whichever workgroup finishes the image last, reading the others' pairs behind a device-scope fence
+                if (p.mean_out) {
+                    bool fin = false;
+                    if (p.bands == 1) {
+                        ds1 += (double)a1;
+                        ds2 += (double)a2;
+                        fin = !same_unit;
+                    } else if (!same_unit) {
+                        __threadfence();
+                        fin = atomicAdd(p.counter + img, 1) == p.bands - 1;
+                        if (fin) {
+                            __threadfence();
+                            ds1 = ds2 = 0.0;
+                            const volatile float* pp = p.part + 2 * (size_t)img * p.steps;
+                            for (int q = 0; q < p.steps; ++q) { ds1 += (double)pp[2 * q]; ds2 += (double)pp[2 * q + 1]; }
+                            p.counter[img] = 0;
+                        }
+                    }
+                    if (fin) {
+                        const double inv = 1.0 / ((double)H * W * C);
+                        const double mu = ds1 * inv;
+                        double var = ds2 * inv - mu * mu;
+                        var = var > 0.0 ? var : 0.0;
+                        p.mean_out[img] = (float)mu;
+                        p.rstd_out[img] = 1.0f / __builtin_sqrtf((float)var + p.eps);
+                        ds1 = ds2 = 0.0;
+                    }
+                }
+            }
+        }
         if (!more) break;
         __syncthreads();                             // every wave is done reading the rows the next set overwrites
         stage(nxt);
@@ -332,27 +421,45 @@ __global__ void __launch_bounds__(512, 1) as_conv2_kernel(const AsConvArgs p) {
     }
 }
 
+// sweeps of a stage set held in registers across the matrix phase: what the register file leaves beside the weight fragments of both
+// convolutions (2 x C / 16 x 4 registers; the f16 GELU polynomial needs a few more temporaries than the bf16 form) without a spill
+template <typename T, int C> struct AsPre {
+    static constexpr int value = C == 96 ? (dtype_of<T>::value == MLPK_F16 ? 6 : 10) : 0;       // (C = 192: the weight fragments leave no room -- hipcc parks the prefetch in scratch, i.e. waits for it)
+};
+
+// the step grid of a map: rows per step and steps per image -- a function of (dtype, C, H, W) alone, never of the batch (the by-product
+// statistics are one pair per step)
+template <typename T, int C>
+static int as_conv2_steps(const int H, const int W, int& th_out) {
+    constexpr int PITCH = 2 * C + 16;
+    constexpr int NPRE = AsPre<T, C>::value;
+    constexpr int PL = 512 / (C / 8);
+    const int Wp = W + 4;
+    const int budget = 160 * 1024 - 8 * ASC_STG_BYTES - C * 16 - 64;     // ring + 8 staging tiles + the scale / shift and bias tables + the waves' statistics
+    int th = budget / (Wp * PITCH) - 4;              // ring = th + 4 rows
+    if (th < 1) return 0;
+    if (th > H) th = H;
+    // a step's new rows should fit the prefetch registers where that leaves a step tall enough to feed eight waves (longer sets still
+    // work: the sweeps beyond NPRE are loaded at staging time, four abreast)
+    const int th_pre = (NPRE * PL) / W;
+    if (th_pre >= 5 && th > th_pre) th = th_pre;
+    // steps of equal height where possible
+    const int steps = (H + th - 1) / th;
+    th_out = (H + steps - 1) / steps;
+    return steps;
+}
+
 template <typename T, int C>
 static int as_conv2_launch(const AsConvArgs& a0, hipStream_t s) {
     AsConvArgs a = a0;
     constexpr int PITCH = 2 * C + 16;
-    // sweeps of a stage set held in registers across the matrix phase: what the register file leaves beside the weight fragments of both
-    // convolutions (2 x C / 16 x 4 registers; the f16 GELU polynomial needs a few more temporaries than the bf16 form) without a spill
-    constexpr int NPRE = C == 96 ? (dtype_of<T>::value == MLPK_F16 ? 6 : 10) : 0;       // (C = 192: the weight fragments leave no room -- hipcc parks the prefetch in scratch, i.e. waits for it)
-    constexpr int PL = 512 / (C / 8);
+    constexpr int NPRE = AsPre<T, C>::value;
     const int Wp = a.W + 4;
-    const int budget = 160 * 1024 - 8 * ASC_STG_BYTES - C * 16;          // ring + 8 staging tiles + the scale / shift and bias tables
-    int th = budget / (Wp * PITCH) - 4;              // ring = th + 4 rows
-    if (th < 1) return MLPK_ESHAPE;
-    if (th > a.H) th = a.H;
-    // a step's new rows should fit the prefetch registers where that leaves a step tall enough to feed eight waves (longer sets still
-    // work: the sweeps beyond NPRE are loaded at staging time, four abreast)
-    const int th_pre = (NPRE * PL) / a.W;
-    if (th_pre >= 5 && th > th_pre) th = th_pre;
-    // steps of equal height where possible
-    const int steps = (a.H + th - 1) / th;
-    th = (a.H + steps - 1) / steps;
+    int th = 0;
+    const int steps = as_conv2_steps<T, C>(a.H, a.W, th);
+    if (steps < 1) return MLPK_ESHAPE;
     a.TH = th;
+    a.steps = steps;
     // row segments per image: one unit per CU and launch when the batch allows, more (each with its own halo) when it is small
     int cus = 256;
     {
@@ -366,10 +473,10 @@ static int as_conv2_launch(const AsConvArgs& a0, hipStream_t s) {
     a.bands = segs;
     a.seg_rows = steps_per_seg * th;
     const int units = a.B * segs;
-    const int lds = (th + 4) * Wp * PITCH + 8 * ASC_STG_BYTES + C * 16;
+    const int lds = (th + 4) * Wp * PITCH + 8 * ASC_STG_BYTES + C * 16 + 64;
     auto k = as_conv2_kernel<T, C, 5, NPRE>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
+    if (e != hipSuccess) return MLPK_ESHAPE;
     hipLaunchKernelGGL(k, dim3((unsigned)(units < cus ? units : cus)), dim3(512), lds, s, a);
     MLPK_LAUNCH_CHECK();
     return 0;
@@ -382,13 +489,39 @@ using namespace mlpk;
 extern "C" int mlpk_as_conv2_supported(int dtype, int H, int W, int C, int kernel_size) {
     if (dtype != MLPK_F16 && dtype != MLPK_BF16) return 0;
     if (kernel_size != 5 || (C != 96 && C != 192)) return 0;
-    const int budget = 160 * 1024 - 8 * ASC_STG_BYTES - C * 16;
+    const int budget = 160 * 1024 - 8 * ASC_STG_BYTES - C * 16 - 64;
     return H >= 1 && W >= 1 && budget / ((W + 4) * (2 * C + 16)) - 4 >= 1;
 }
+
+extern "C" int mlpk_as_conv2_steps(int dtype, int H, int W, int C, int kernel_size) {
+    if (!mlpk_as_conv2_supported(dtype, H, W, C, kernel_size)) return 0;
+    int th = 0;
+    if (dtype == MLPK_BF16) return C == 96 ? as_conv2_steps<bf16_t, 96>(H, W, th) : as_conv2_steps<bf16_t, 192>(H, W, th);
+    return C == 96 ? as_conv2_steps<f16_t, 96>(H, W, th) : as_conv2_steps<f16_t, 192>(H, W, th);
+}
+
+static int as_conv2_run(int dtype, const void* t, void* y, int B, int H, int W, int C, int kernel_size, const float* mean, const float* rstd,
+                        const float* gamma, const float* beta, const void* w1, const float* b1, const void* w2, const float* b2, int ldw,
+                        float* part, float* mean_out, float* rstd_out, int* counter, float eps, void* stream);
 
 extern "C" int mlpk_as_conv2(int dtype, const void* t, void* y, int B, int H, int W, int C, int kernel_size, const float* mean, const float* rstd,
                              const float* gamma, const float* beta, const void* w1, const float* b1, const void* w2, const float* b2, int ldw,
                              void* stream) {
+    return as_conv2_run(dtype, t, y, B, H, W, C, kernel_size, mean, rstd, gamma, beta, w1, b1, w2, b2, ldw, nullptr, nullptr, nullptr, nullptr, 0.f, stream);
+}
+
+extern "C" int mlpk_as_conv2_stats(int dtype, const void* t, void* y, int B, int H, int W, int C, int kernel_size, const float* mean, const float* rstd,
+                                   const float* gamma, const float* beta, const void* w1, const float* b1, const void* w2, const float* b2, int ldw,
+                                   float* part, float* mean_out, float* rstd_out, int* counter, float eps, void* stream) {
+    if (!part || !mean_out || !rstd_out || !counter) return MLPK_ENULL;
+    if (mean_out == mean || rstd_out == rstd) return MLPK_ESHAPE;            // other workgroups still read the input's statistics
+    if (((uintptr_t)part & 7) || ((uintptr_t)counter & 3)) return MLPK_EALIGN;
+    return as_conv2_run(dtype, t, y, B, H, W, C, kernel_size, mean, rstd, gamma, beta, w1, b1, w2, b2, ldw, part, mean_out, rstd_out, counter, eps, stream);
+}
+
+static int as_conv2_run(int dtype, const void* t, void* y, int B, int H, int W, int C, int kernel_size, const float* mean, const float* rstd,
+                        const float* gamma, const float* beta, const void* w1, const float* b1, const void* w2, const float* b2, int ldw,
+                        float* part, float* mean_out, float* rstd_out, int* counter, float eps, void* stream) {
     if (!t || !y || !mean || !rstd || !gamma || !beta || !w1 || !w2 || !b1 || !b2) return MLPK_ENULL;
     if (B <= 0 || H <= 0 || W <= 0 || ldw < C || ldw % 8) return MLPK_ESHAPE;
     if (!mlpk_as_conv2_supported(dtype, H, W, C, kernel_size)) return MLPK_ESHAPE;
@@ -397,6 +530,7 @@ extern "C" int mlpk_as_conv2(int dtype, const void* t, void* y, int B, int H, in
     AsConvArgs a;
     a.t = t; a.y = y; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.w1 = w1; a.w2 = w2; a.b1 = b1; a.b2 = b2;
     a.B = B; a.H = H; a.W = W; a.ldw = ldw; a.TH = 0; a.bands = 0; a.seg_rows = 0;
+    a.part = part; a.steps = 0; a.mean_out = mean_out; a.rstd_out = rstd_out; a.counter = counter; a.eps = eps;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MLPK_BF16) return C == 96 ? as_conv2_launch<bf16_t, 96>(a, s) : as_conv2_launch<bf16_t, 192>(a, s);
     return C == 96 ? as_conv2_launch<f16_t, 96>(a, s) : as_conv2_launch<f16_t, 192>(a, s);

@@ -88,8 +88,19 @@ template <int KS1, int NB, int D, bool FC2 = true> struct CmGeo {
 // waves per SIMD alternate between MFMAs and GELU, and a lane's 8 rounded values -- with W1's ROWS stored as [hidden 8 f + 4 j + r at row
 // 16 j + 4 f + r] of every 32 -- are 8 consecutive output columns: one 16-byte store per (row, group), no epilogue at all.  STATS: the
 // by-product planes of 32 columns in the canonical order (a lane's chunk by chunk_sums, then (c0 + c1) + (c2 + c3) across the 4 lanes).
-template <typename T, int KS1, int NB, int D, bool FC2 = true, bool STATS = false>
-__global__ void __launch_bounds__(512, 1) chan_mlp_kernel(const ChanMlpArgs p) {
+#ifndef CM_WGS2
+#define CM_WGS2 0
+#endif
+#ifndef CM_PREFETCH
+#define CM_PREFETCH 0
+#endif
+// workgroups per CU: two where their rings and registers fit twice (C <= 96, both products) -- one's tile hand-over (epilogue stores, the
+// next tile's rows) and barrier waits are then filled by the other's iterations
+template <int KS1, int D, bool FC2> struct CmWgs { static constexpr int value = (CM_WGS2 && FC2 && KS1 <= 3 && D == 2) ? 2 : 1; };
+
+// SAME: the residual rows ARE the operand rows (R == x, the pre-norm residual block of every family): read once
+template <typename T, int KS1, int NB, int D, bool FC2 = true, bool STATS = false, bool SAME = false>
+__global__ void __launch_bounds__(512, (2 * CmWgs<KS1, D, FC2>::value)) chan_mlp_kernel(const ChanMlpArgs p) {
     using Geo = CmGeo<KS1, NB, D, FC2>;
     constexpr int PPW = Geo::PPW, N1 = Geo::N1, P = Geo::P;
     constexpr int C = 16 * NB;
@@ -175,8 +186,8 @@ __global__ void __launch_bounds__(512, 1) chan_mlp_kernel(const ChanMlpArgs p) {
     if (FC2 && tid < C) b2s[tid] = p.b2[tid];
     __syncthreads();
 
-    u32x4 xa[2][KS1], rr[2][FC2 ? KS1 : 1];
-    float lmu[2], lrs[2];
+    u32x4 xa[2][KS1], rr[2][FC2 && !SAME ? KS1 : 1];
+    float lmu[2], lrs[2], nmu[2], nrs[2];
     auto load_tile = [&](const int tile, const int ln) {     // operand rows, residual rows, row statistics of a tile
         const int frow = ln & 15, fg = ln >> 4;
 #pragma unroll
@@ -185,13 +196,13 @@ __global__ void __launch_bounds__(512, 1) chan_mlp_kernel(const ChanMlpArgs p) {
             gm = gm < p.M ? gm : p.M - 1;
 #pragma unroll
             for (int kk = 0; kk < KS1; ++kk) xa[i][kk] = *reinterpret_cast<const u32x4*>(x + (size_t)gm * p.ldx + kk * 32 + fg * 8);
-            if constexpr (FC2) {
+            if constexpr (FC2 && !SAME) {
 #pragma unroll
                 for (int kk = 0; kk < KS1; ++kk)
                     rr[i][kk] = R ? *reinterpret_cast<const u32x4*>(R + (size_t)gm * p.ldr + kk * 32 + fg * 8) : u32x4{0u, 0u, 0u, 0u};
             }
-            lmu[i] = fold ? p.ln_mean[gm / p.ln_group] : 0.f;
-            lrs[i] = fold ? p.ln_rstd[gm / p.ln_group] : 1.f;
+            nmu[i] = fold ? p.ln_mean[gm / p.ln_group] : 0.f;
+            nrs[i] = fold ? p.ln_rstd[gm / p.ln_group] : 1.f;
         }
     };
 
@@ -294,6 +305,8 @@ __global__ void __launch_bounds__(512, 1) chan_mlp_kernel(const ChanMlpArgs p) {
         load_tile(blockIdx.x, lane_now());
         for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
             __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the tile's rows have landed, and the compiler knows it
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { lmu[i] = nmu[i]; lrs[i] = nrs[i]; }
             if constexpr (FC2) {
                 // accumulators start from R + b2: lane (row, fg) holds channels 32 q + 8 fg + {0..3} in block 2q, + {4..7} in block 2q + 1
                 const int fg = lane_now() >> 4;
@@ -304,13 +317,15 @@ __global__ void __launch_bounds__(512, 1) chan_mlp_kernel(const ChanMlpArgs p) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         T r8[8];
-                        __builtin_memcpy(r8, &rr[i][q], 16);
+                        __builtin_memcpy(r8, SAME ? &xa[i][q] : &rr[i][q], 16);
                         acc2[i][2 * q] = f32x4{to_f32(r8[0]) + c0.x, to_f32(r8[1]) + c0.y, to_f32(r8[2]) + c0.z, to_f32(r8[3]) + c0.w};
                         acc2[i][2 * q + 1] = f32x4{to_f32(r8[4]) + c1.x, to_f32(r8[5]) + c1.y, to_f32(r8[6]) + c1.z, to_f32(r8[7]) + c1.w};
                     }
                 }
             }
-            auto iter = [&](auto first_c, auto second_c, const int t) {
+            bool requested = false;                           // the next tile's rows are on their way (CM_PREFETCH)
+            auto iter = [&](auto first_c, auto second_c, const int t, auto last_c) {
+                constexpr bool LAST = decltype(last_c)::value;
                 constexpr bool FIRST = decltype(first_c)::value;
                 // what may still be in flight at this point: the pieces requested last iteration -- and, first product alone, the stores
                 // of last iteration (none in a tile's iteration 0 for the late half: the sync of iteration 1 does not count them)
@@ -333,6 +348,9 @@ __global__ void __launch_bounds__(512, 1) chan_mlp_kernel(const ChanMlpArgs p) {
                     fc1(s3, ln);
 #pragma unroll
                     for (int pi = PH; pi < PPW; ++pi) issue(pi, ln);
+                    // the tile's last fc1 is done: its operand registers take the next tile's rows, which travel under the GELU, fc2 and
+                    // the epilogue instead of after them
+                    if constexpr (LAST) { load_tile(tile + gridDim.x, ln); requested = true; }
                     gelu(t, ln);
                     if constexpr (FC2) fc2(s4, ln); else store_h(t, tile, ln);
                 } else {
@@ -344,14 +362,17 @@ __global__ void __launch_bounds__(512, 1) chan_mlp_kernel(const ChanMlpArgs p) {
 #pragma unroll
                     for (int pi = PH; pi < PPW; ++pi) issue(pi, ln);
                     fc1(s3, ln);
+                    if constexpr (LAST) { load_tile(tile + gridDim.x, ln); requested = true; }
                 }
                 s3 = s3 == D ? 0 : s3 + 1;
                 s4 = s4 == D + 1 ? 0 : s4 + 1;
             };
-            iter(CmBool<true>{}, CmBool<false>{}, 0);
-            if (G > 1) iter(CmBool<false>{}, CmBool<true>{}, 1);
+            iter(CmBool<true>{}, CmBool<false>{}, 0, CmBool<false>{});
+            if (G > 1) iter(CmBool<false>{}, CmBool<true>{}, 1, CmBool<false>{});
+            constexpr bool PRE = CM_PREFETCH && FC2;
 #pragma unroll 1
-            for (int t = 2; t < G; ++t) iter(CmBool<false>{}, CmBool<false>{}, t);
+            for (int t = 2; t < (PRE ? G - 1 : G); ++t) iter(CmBool<false>{}, CmBool<false>{}, t, CmBool<false>{});
+            if (PRE && G > 2) iter(CmBool<false>{}, CmBool<false>{}, G - 1, CmBool<true>{});
             if constexpr (LAG) {
                 const int ln = lane_now();
                 gelu(G - 1, ln);
@@ -384,7 +405,7 @@ __global__ void __launch_bounds__(512, 1) chan_mlp_kernel(const ChanMlpArgs p) {
                     if (fg == 0 && gm < p.M) *reinterpret_cast<f32x2*>(p.row_part + (size_t)gm * 2) = f32x2{ssum, ssq};
                 }
             }
-            load_tile(tile + gridDim.x, le);                  // (unconditionally: rows past M clamp to the last row)
+            if (!requested) load_tile(tile + gridDim.x, le);  // (unconditionally: rows past M clamp to the last row)
         }
     };
     if (!lag) run(CmBool<false>{}); else run(CmBool<true>{});
@@ -404,11 +425,13 @@ static int cm_grid_cap() {
 template <typename T, int KS1, int D>
 static int cm_launch_d(const ChanMlpArgs& a, hipStream_t s) {
     using Geo = CmGeo<KS1, 2 * KS1, D>;
-    auto k = chan_mlp_kernel<T, KS1, 2 * KS1, D>;
+    const bool same = a.R == a.x && a.ldr == a.ldx;
+    auto k = same ? chan_mlp_kernel<T, KS1, 2 * KS1, D, true, false, true> : chan_mlp_kernel<T, KS1, 2 * KS1, D, true, false, false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, Geo::LDS);
-    if (e != hipSuccess) return (int)e;
+    if (e != hipSuccess) return MLPK_ESHAPE;
     const int tiles = (a.M + CM_BM - 1) / CM_BM;
-    const unsigned grid = (unsigned)(tiles < cm_grid_cap() ? tiles : cm_grid_cap());
+    const int cap = cm_grid_cap() * CmWgs<KS1, D, true>::value;
+    const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), Geo::LDS, s, a);
     MLPK_LAUNCH_CHECK();
     return 0;

@@ -630,10 +630,23 @@ def as_conv2_supported(dtype, H, W, C, kernel_size):
             and bool(N.lib().mlpk_as_conv2_supported(dtype_code(dtype), H, W, C, kernel_size)))
 
 
-def as_conv2(t, y, B, H, W, C, kernel_size, mean, rstd, gamma, beta, w1, b1, w2, b2):
-    """y = gelu(conv2_1(shift_W(u)) + b1) + gelu(conv2_2(shift_H(u)) + b2), u = gelu(GroupNorm affine of t): AxialShift's core in one kernel"""
-    N.check(N.lib().mlpk_as_conv2(dtype_code(t.dtype), ptr(t), ptr(y), B, H, W, C, kernel_size, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
-                                  ptr(w1), ptr(b1), ptr(w2), ptr(b2), w1.stride(0), stream()), "mlpk_as_conv2")
+def as_conv2(t, y, B, H, W, C, kernel_size, mean, rstd, gamma, beta, w1, b1, w2, b2, stats=None, eps=1e-5):
+    """y = gelu(conv2_1(shift_W(u)) + b1) + gelu(conv2_2(shift_H(u)) + b2), u = gelu(GroupNorm affine of t): AxialShift's core in one kernel.
+    stats = (workspace, name): the kernel also finishes the GroupNorm(1, C) statistics of y (mlpk_as_conv2_stats: one pair per step of
+    rows, added in step order inside the kernel -- no statistics pass, no finalize launch); returns (mean, rstd) of y, else None."""
+    if stats is None or os.environ.get("MLPK_ASCONV_STATS", "1") == "0":
+        N.check(N.lib().mlpk_as_conv2(dtype_code(t.dtype), ptr(t), ptr(y), B, H, W, C, kernel_size, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
+                                      ptr(w1), ptr(b1), ptr(w2), ptr(b2), w1.stride(0), stream()), "mlpk_as_conv2")
+        return None
+    ws, name = stats
+    steps = N.lib().mlpk_as_conv2_steps(dtype_code(t.dtype), H, W, C, kernel_size)
+    part = ws.get(name + ".part", (B, steps, 2), torch.float32)
+    counter = ws.get(name + ".count", (B,), torch.int32, fill=0)
+    mo, ro = ws.get(name + ".mean", (B,), torch.float32), ws.get(name + ".rstd", (B,), torch.float32)
+    N.check(N.lib().mlpk_as_conv2_stats(dtype_code(t.dtype), ptr(t), ptr(y), B, H, W, C, kernel_size, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
+                                        ptr(w1), ptr(b1), ptr(w2), ptr(b2), w1.stride(0), ptr(part), ptr(mo), ptr(ro), ptr(counter), eps, stream()),
+            "mlpk_as_conv2_stats")
+    return mo, ro
 
 
 def cycle_shift_ln(x, mean, rstd, gamma, beta, out_h, out_w, B, H, W, C, k, ldi, ldo):

@@ -375,18 +375,22 @@ class AS_MLP(E.EngineModule):
                         # round 4 (stages with C = 96 / 192): GroupNorm + GELU, both axial shifts, conv2_1, conv2_2, their GELUs and the sum
                         # in ONE kernel -- the shifts are LDS read addresses of the matrix-core operands (mlpk_as_conv2); bit-equal to the
                         # three kernels below, 2 tensor passes over HBM instead of 9
-                        E.as_conv2(t1, t0, B, H, W, C, self._shift, mean, rstd, pk[p + "an1.g"], pk[p + "an1.b"],
-                                   pk[p + "c21.w"], pk[p + "c21.b"], pk[p + "c22.w"], pk[p + "c22.b"])
+                        # (round 6: ... and the statistics of the sum for norm2, finished inside the kernel: no pass over it)
+                        st2 = E.as_conv2(t1, t0, B, H, W, C, self._shift, mean, rstd, pk[p + "an1.g"], pk[p + "an1.b"],
+                                         pk[p + "c21.w"], pk[p + "c21.b"], pk[p + "c22.w"], pk[p + "c22.b"], stats=(ws, tag + ".asc"))
                         t0, t1 = t1, t0                                                              # the sum now lives in what was t0
                         got = None
                     else:
+                        st2 = None
                         E.norm_shift_nhwc(t1, t0, t2, B, H, W, C, self._shift, mean, rstd, pk[p + "an1.g"], pk[p + "an1.b"], N.ACT_GELU)
                         E.gemm(t0, pk[p + "c21.w"], t1, rows, C, C, bias=pk[p + "c21.b"], act=N.ACT_GELU, tag="as_conv")      # x_lr (W shift)
                         got = E.gemm(t2, pk[p + "c22.w"], t1, rows, C, C, bias=pk[p + "c22.b"], act=N.ACT_GELU, R=t1, res=N.RES_ADD,
                                      tag="as_conv", part=part)                                       # gelu(.) + x_lr (H shift)
-                    stats(t1, C, got)
+                    if st2 is None:
+                        stats(t1, C, got)
+                        st2 = (mean, rstd)
                     dp1 = self._drop_scale(layer.blocks[bi], B, HW, cd, cur.device)                 # train mode: x + drop_path(.) (as_mlp.py:159)
-                    got = E.gemm(t1, pk[p + "c3f.w"], cur, rows, C, C, bias=pk[p + "c3f.b"], ln=(mean, rstd, pk[p + "c3f.csum"]), ln_group=HW,
+                    got = E.gemm(t1, pk[p + "c3f.w"], cur, rows, C, C, bias=pk[p + "c3f.b"], ln=(st2[0], st2[1], pk[p + "c3f.csum"]), ln_group=HW,
                                  R=cur, res=N.RES_ADD, tag="as_conv", part=part if dp1 is None else None,
                                  rscale=dp1, rperiod=rows if dp1 is not None else 0)                 # x + conv3(norm2(.))
                     stats(cur, C, got)

@@ -992,6 +992,28 @@ def test_axial_shift_core_in_one_kernel(dtype):
         want = torch.nn.functional.gelu(sw @ w1.double().cpu().t() + b1.double().cpu()) + torch.nn.functional.gelu(sh @ w2.double().cpu().t() + b2.double().cpu())
         err = (y.double().cpu() - want).abs().max().item()
         assert err < EPS[dtype] * 4 * max(1.0, want.abs().max().item()), (str(dtype), ci, err)
+        # round 6: the same kernel finishing the GroupNorm(1, C) statistics of what it stored (as_mlp.py:52,94) -- same y, the statistics
+        # of the ROUNDED values, and an image's statistics independent of the batch it is in (two calls on the workspace: the
+        # counters of the segmented small-batch path are left zeroed)
+        ws = E.Workspace(dev(), dtype)
+        for _ in range(2):
+            y2 = torch.full((rows, C), float("nan"), dtype=dtype, device=dev())
+            mo, ro = E.as_conv2(t, y2, B, H, W, C, 5, mean, rstd, gamma, beta, w1, b1, w2, b2, stats=(ws, "asc"))
+            torch.cuda.synchronize()
+            assert int((y2.view(torch.int16) != y.view(torch.int16)).sum()) == 0, (str(dtype), ci)
+            yd = y.double().cpu().reshape(B, -1)
+            mu = yd.mean(dim=1)
+            rs = 1.0 / torch.sqrt(yd.var(dim=1, unbiased=False) + 1e-5)
+            assert (mo.double().cpu() - mu).abs().max().item() < 5e-6 * max(1.0, mu.abs().max().item()), (str(dtype), ci)
+            assert ((ro.double().cpu() - rs).abs() / rs).max().item() < 5e-5, (str(dtype), ci)
+        if B > 1:
+            last = slice((B - 1) * H * W, rows)
+            y1 = torch.empty((H * W, C), dtype=dtype, device=dev())
+            m1, r1 = E.as_conv2(t[last].contiguous(), y1, 1, H, W, C, 5, mean[B - 1:].contiguous(), rstd[B - 1:].contiguous(), gamma, beta,
+                                w1, b1, w2, b2, stats=(E.Workspace(dev(), dtype), "one"))
+            torch.cuda.synchronize()
+            assert m1.view(torch.int32)[0].item() == mo.view(torch.int32)[B - 1].item(), (str(dtype), ci)
+            assert r1.view(torch.int32)[0].item() == ro.view(torch.int32)[B - 1].item(), (str(dtype), ci)
     assert not E.as_conv2_supported(dtype, 14, 14, 384, 5) and not E.as_conv2_supported(torch.float32, 56, 56, 96, 5)
     with pytest.raises(RuntimeError):
         E.as_conv2(t, t, B, H, W, C, 5, mean, rstd, gamma, beta, w1, b1, w2, b2)       # in place: a band reads its neighbours' rows
