@@ -63,6 +63,31 @@ template <> struct CmMma<f16_t> {
 };
 template <bool B> struct CmBool { static constexpr bool value = B; };
 
+// A tile's rows are loaded by asm the compiler does not track: requested before the previous tile's epilogue, they are waited for by
+// COUNT (everything but the stores behind them); a load the compiler tracks gets its own wait in front of the first use -- and with
+// stores in conditional blocks behind it that wait is vmcnt(0): the epilogue's stores and the weight pieces just requested.
+static __device__ __forceinline__ u32x4 cm_load16(const void* ptr) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+// v + (the same lane of the neighbouring lane row, lane ^ 16), then + (the other half of the wave, lane ^ 32): the (fg 0 + fg 1) +
+// (fg 2 + fg 3) of a row's four lanes by the gfx950 lane-row swaps -- __shfl_xor needs the lane id, a register the kernel kept for the
+// whole launch (spilled under the 128-register cap, and every reload of it waited for all memory operations in flight)
+static __device__ __forceinline__ float cm_rows4_sum(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float h = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    const unsigned uh = __builtin_bit_cast(unsigned, h);
+    const auto q = __builtin_amdgcn_permlane32_swap(uh, uh, false, false);
+    return __builtin_bit_cast(float, (unsigned)q[0]) + __builtin_bit_cast(float, (unsigned)q[1]);
+}
+static __device__ __forceinline__ float cm_load4(const void* ptr) {
+    float v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+
 constexpr int CM_BM = 256;
 constexpr int CM_HID_MAX = 1024;                          // both products
 constexpr int CM_N_MAX = 4096;                             // the first product alone
@@ -88,23 +113,33 @@ template <int KS1, int NB, int D, bool FC2 = true> struct CmGeo {
 // waves per SIMD alternate between MFMAs and GELU, and a lane's 8 rounded values -- with W1's ROWS stored as [hidden 8 f + 4 j + r at row
 // 16 j + 4 f + r] of every 32 -- are 8 consecutive output columns: one 16-byte store per (row, group), no epilogue at all.  STATS: the
 // by-product planes of 32 columns in the canonical order (a lane's chunk by chunk_sums, then (c0 + c1) + (c2 + c3) across the 4 lanes).
+// Round 6 (profiles/r06_chanmlp_variants.txt; -DCM_WGS2=0 / -DCM_PREFETCH=0 rebuild the round-5 kernel for A/B):
+//   * the residual rows ARE the operand rows in every pre-norm residual block (R == x): read once (template SAME);
+//   * the next tile's rows are requested straight after the tile's last fc1 -- their registers are free from there on -- and travel
+//     under the last GELU, fc2 and the epilogue instead of after them;
+//   * two workgroups per CU where their rings and registers fit twice (C <= 96): one's tile hand-over and barrier waits are filled
+//     by the other's iterations.  802816 x 96: 253 -> 224 us, x 64: 151 -> 127, 200704 x 128: 114 -> 101, x 192: 197 -> 191.
 #ifndef CM_WGS2
-#define CM_WGS2 0
+#define CM_WGS2 1
 #endif
 #ifndef CM_PREFETCH
-#define CM_PREFETCH 0
+#define CM_PREFETCH 1
 #endif
-// workgroups per CU: two where their rings and registers fit twice (C <= 96, both products) -- one's tile hand-over (epilogue stores, the
-// next tile's rows) and barrier waits are then filled by the other's iterations
-template <int KS1, int D, bool FC2> struct CmWgs { static constexpr int value = (CM_WGS2 && FC2 && KS1 <= 3 && D == 2) ? 2 : 1; };
+// (f16 at C = 96: its longer GELU polynomial does not fit 128 registers without spilling -- one workgroup per CU there)
+template <typename T, int KS1, int D, bool FC2, bool SAME> struct CmWgs {
+    static constexpr int value = (CM_WGS2 && FC2 && SAME && D == 2 && (KS1 <= 2 || (KS1 == 3 && dtype_of<T>::value == MLPK_BF16))) ? 2 : 1;
+};
 
 // SAME: the residual rows ARE the operand rows (R == x, the pre-norm residual block of every family): read once
 template <typename T, int KS1, int NB, int D, bool FC2 = true, bool STATS = false, bool SAME = false>
-__global__ void __launch_bounds__(512, (2 * CmWgs<KS1, D, FC2>::value)) chan_mlp_kernel(const ChanMlpArgs p) {
+__global__ void __launch_bounds__(512, (2 * CmWgs<T, KS1, D, FC2, SAME>::value)) chan_mlp_kernel(const ChanMlpArgs p) {
     using Geo = CmGeo<KS1, NB, D, FC2>;
     constexpr int PPW = Geo::PPW, N1 = Geo::N1, P = Geo::P;
     constexpr int C = 16 * NB;
     constexpr int NSTORE = FC2 ? 0 : (STATS ? 4 : 2);       // vector-memory stores a wave issues per iteration (first product alone)
+    // the next tile's rows requested straight after the tile's last fc1 (a residual that is not the operand doubles the registers
+    // requested ahead: the wide widths would spill)
+    constexpr bool PRE = CM_PREFETCH && FC2 && (SAME || KS1 <= 4);
     static_assert(!FC2 || NB == 2 * KS1, "C = 32 KS1 = 16 NB");
     static_assert(FC2 || D == 2, "the store-counting waits below are written for two iterations of look-ahead");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -188,6 +223,10 @@ __global__ void __launch_bounds__(512, (2 * CmWgs<KS1, D, FC2>::value)) chan_mlp
 
     u32x4 xa[2][KS1], rr[2][FC2 && !SAME ? KS1 : 1];
     float lmu[2], lrs[2], nmu[2], nrs[2];
+    // RULE for the asm loads: the compiler believes their results are there when they are issued.  So no value they produce may meet
+    // another definition of the same variable (a branch merge, a loop back edge: the register copies of such a merge would read the
+    // registers early -- and free them for reuse while the data is still on its way) before `settle` has waited for them: the addresses are
+    // selected, the loads are unconditional, and every path from a load_tile to the loop's back edge runs through settle.
     auto load_tile = [&](const int tile, const int ln) {     // operand rows, residual rows, row statistics of a tile
         const int frow = ln & 15, fg = ln >> 4;
 #pragma unroll
@@ -195,14 +234,59 @@ __global__ void __launch_bounds__(512, (2 * CmWgs<KS1, D, FC2>::value)) chan_mlp
             int gm = tile * CM_BM + wave * 32 + i * 16 + frow;
             gm = gm < p.M ? gm : p.M - 1;
 #pragma unroll
-            for (int kk = 0; kk < KS1; ++kk) xa[i][kk] = *reinterpret_cast<const u32x4*>(x + (size_t)gm * p.ldx + kk * 32 + fg * 8);
+            for (int kk = 0; kk < KS1; ++kk) xa[i][kk] = cm_load16(x + (size_t)gm * p.ldx + kk * 32 + fg * 8);
+            if constexpr (FC2 && !SAME) {
+                // (no residual: the operand rows once more, zeroed in settle)
+                const T* rsrc = R ? R + (size_t)gm * p.ldr : x + (size_t)gm * p.ldx;
+#pragma unroll
+                for (int kk = 0; kk < KS1; ++kk) rr[i][kk] = cm_load16(rsrc + kk * 32 + fg * 8);
+            }
+            // the statistic of a row: m / ln_group.  LayerNorm: the row itself; a group that is a multiple of 16 rows (GroupNorm(1, C) over
+            // a 56 x 56 or 28 x 28 map): the 16 rows of this half share it -- a scalar division, where the per-lane division kept its
+            // reciprocal in a vector register across the whole kernel (spilled, and every reload of it waited for all memory operations
+            // in flight); anything else: per lane, the divisor hidden from loop-invariant hoisting for the same reason.  No
+            // normalisation: any readable address (the values are replaced in settle).
+            int si = 0;
+            if (fold) {
+                if (p.ln_group == 1) {
+                    si = gm;
+                } else if ((p.ln_group & 15) == 0) {
+                    int base = __builtin_amdgcn_readfirstlane(tile * CM_BM + wave * 32 + i * 16);
+                    base = base < p.M ? base : p.M - 1;
+                    si = base / p.ln_group;
+                } else {
+                    int g = p.ln_group;
+                    asm volatile("" : "+s"(g));
+                    si = gm / g;
+                }
+            }
+            const float* const pm = fold ? p.ln_mean + si : p.b1;
+            const float* const pr = fold ? p.ln_rstd + si : p.b1;
+            nmu[i] = cm_load4(pm);
+            nrs[i] = cm_load4(pr);
+        }
+    };
+    // wait for a load_tile: `behind` = the loads were requested BEFORE an epilogue's stores (the 2 KS1 row stores of a wave; with the
+    // by-product statistics two more, of which the first two stores are then waited for as well; a tile with fewer stores -- rows past M
+    // -- is a workgroup's last): everything but those stores.  Then the loaded registers are handed to the compiler.
+    auto settle = [&](const bool behind) {
+        constexpr int NS = FC2 ? 2 * KS1 : 0;
+        static_assert(NS <= 15, "vmcnt immediate");
+        if (!behind) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS) : "memory");
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int kk = 0; kk < KS1; ++kk) asm volatile("" : "+v"(xa[i][kk]));
             if constexpr (FC2 && !SAME) {
 #pragma unroll
-                for (int kk = 0; kk < KS1; ++kk)
-                    rr[i][kk] = R ? *reinterpret_cast<const u32x4*>(R + (size_t)gm * p.ldr + kk * 32 + fg * 8) : u32x4{0u, 0u, 0u, 0u};
+                for (int kk = 0; kk < KS1; ++kk) {
+                    asm volatile("" : "+v"(rr[i][kk]));
+                    if (!R) rr[i][kk] = u32x4{0u, 0u, 0u, 0u};
+                }
             }
-            nmu[i] = fold ? p.ln_mean[gm / p.ln_group] : 0.f;
-            nrs[i] = fold ? p.ln_rstd[gm / p.ln_group] : 1.f;
+            asm volatile("" : "+v"(nmu[i]), "+v"(nrs[i]));
+            if (!fold) { nmu[i] = 0.f; nrs[i] = 1.f; }
         }
     };
 
@@ -219,7 +303,9 @@ __global__ void __launch_bounds__(512, (2 * CmWgs<KS1, D, FC2>::value)) chan_mlp
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) a1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        constexpr int BWD = KS1 < 3 ? KS1 : 3;              // fragment pairs read ahead of their MFMAs, pinned there
+        // fragment pairs read ahead of their MFMAs, pinned there (two workgroups per CU: 128 registers per wave, and twice the waves
+        // to hide a fragment read behind)
+        constexpr int BWD = CmWgs<T, KS1, D, FC2, SAME>::value > 1 ? 2 : (KS1 < 3 ? KS1 : 3);
         u32x4 bw[BWD + 1][2];
 #pragma unroll
         for (int kk = 0; kk < BWD; ++kk) {
@@ -264,7 +350,7 @@ __global__ void __launch_bounds__(512, (2 * CmWgs<KS1, D, FC2>::value)) chan_mlp
       if constexpr (FC2) {
         const int f_rd = frag_off(ln);
         const char* r2 = smem + Geo::R2 + st4 * Geo::ST2;
-        constexpr int BFD = NB < 4 ? NB : 4;                // W2 fragments read ahead of their MFMAs
+        constexpr int BFD = CmWgs<T, KS1, D, FC2, SAME>::value > 1 ? 3 : (NB < 4 ? NB : 4);                // W2 fragments read ahead of their MFMAs
         u32x4 bf[BFD + 1];
 #pragma unroll
         for (int j = 0; j < BFD; ++j) bf[j] = *reinterpret_cast<const u32x4*>(r2 + j * 1024 + f_rd);
@@ -289,10 +375,8 @@ __global__ void __launch_bounds__(512, (2 * CmWgs<KS1, D, FC2>::value)) chan_mlp
             if constexpr (STATS) {
                 float ssum = 0.f, ssq = 0.f;
                 chunk_sums<T>(hf[i], ssum, ssq);
-                ssum += __shfl_xor(ssum, 16);
-                ssq += __shfl_xor(ssq, 16);
-                ssum += __shfl_xor(ssum, 32);
-                ssq += __shfl_xor(ssq, 32);
+                ssum = cm_rows4_sum(ssum);
+                ssq = cm_rows4_sum(ssq);
                 // (every lane stores: lanes fg != 0 to their own row's pair as well -- the same value four times, one store instruction
                 // with a fixed count for the vmcnt arithmetic)
                 *reinterpret_cast<f32x2*>(p.row_part + ((size_t)g * p.M + gm) * 2) = f32x2{ssum, ssq};
@@ -303,8 +387,8 @@ __global__ void __launch_bounds__(512, (2 * CmWgs<KS1, D, FC2>::value)) chan_mlp
     auto run = [&](auto lag_c) {
         constexpr bool LAG = decltype(lag_c)::value;
         load_tile(blockIdx.x, lane_now());
+        settle(false);
         for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-            __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the tile's rows have landed, and the compiler knows it
 #pragma unroll
             for (int i = 0; i < 2; ++i) { lmu[i] = nmu[i]; lrs[i] = nrs[i]; }
             if constexpr (FC2) {
@@ -323,14 +407,16 @@ __global__ void __launch_bounds__(512, (2 * CmWgs<KS1, D, FC2>::value)) chan_mlp
                     }
                 }
             }
-            bool requested = false;                           // the next tile's rows are on their way (CM_PREFETCH)
             auto iter = [&](auto first_c, auto second_c, const int t, auto last_c) {
                 constexpr bool LAST = decltype(last_c)::value;
                 constexpr bool FIRST = decltype(first_c)::value;
                 // what may still be in flight at this point: the pieces requested last iteration -- and, first product alone, the stores
                 // of last iteration (none in a tile's iteration 0 for the late half: the sync of iteration 1 does not count them)
                 constexpr int INFLIGHT = (D - 1) * PPW + (decltype(second_c)::value ? 0 : NSTORE);
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(INFLIGHT) : "memory");
+                // (both products: the pieces of a tile's first two groups were requested during the previous tile and are covered by the
+                // wait at the top of the tile -- counting here would wait for the previous epilogue's stores, which are younger)
+                if constexpr (FC2 && (FIRST || decltype(second_c)::value)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(INFLIGHT) : "memory");
                 asm volatile("s_barrier" ::: "memory");
                 int g2 = t + D;                                // pieces of iteration t + D (the next tile's first groups at the end of this one)
                 g2 = g2 < G ? g2 : g2 - G;
@@ -350,7 +436,7 @@ __global__ void __launch_bounds__(512, (2 * CmWgs<KS1, D, FC2>::value)) chan_mlp
                     for (int pi = PH; pi < PPW; ++pi) issue(pi, ln);
                     // the tile's last fc1 is done: its operand registers take the next tile's rows, which travel under the GELU, fc2 and
                     // the epilogue instead of after them
-                    if constexpr (LAST) { load_tile(tile + gridDim.x, ln); requested = true; }
+                    if constexpr (LAST) load_tile(tile + gridDim.x, ln);
                     gelu(t, ln);
                     if constexpr (FC2) fc2(s4, ln); else store_h(t, tile, ln);
                 } else {
@@ -362,17 +448,17 @@ __global__ void __launch_bounds__(512, (2 * CmWgs<KS1, D, FC2>::value)) chan_mlp
 #pragma unroll
                     for (int pi = PH; pi < PPW; ++pi) issue(pi, ln);
                     fc1(s3, ln);
-                    if constexpr (LAST) { load_tile(tile + gridDim.x, ln); requested = true; }
+                    if constexpr (LAST) load_tile(tile + gridDim.x, ln);
                 }
                 s3 = s3 == D ? 0 : s3 + 1;
                 s4 = s4 == D + 1 ? 0 : s4 + 1;
             };
             iter(CmBool<true>{}, CmBool<false>{}, 0, CmBool<false>{});
             if (G > 1) iter(CmBool<false>{}, CmBool<true>{}, 1, CmBool<false>{});
-            constexpr bool PRE = CM_PREFETCH && FC2;
+            // (PRE: the host guarantees G >= 3, mlpk_channel_mlp_supported -- the tile's last iteration is then always the peeled one)
 #pragma unroll 1
             for (int t = 2; t < (PRE ? G - 1 : G); ++t) iter(CmBool<false>{}, CmBool<false>{}, t, CmBool<false>{});
-            if (PRE && G > 2) iter(CmBool<false>{}, CmBool<false>{}, G - 1, CmBool<true>{});
+            if constexpr (PRE) iter(CmBool<false>{}, CmBool<false>{}, G - 1, CmBool<true>{});
             if constexpr (LAG) {
                 const int ln = lane_now();
                 gelu(G - 1, ln);
@@ -398,14 +484,19 @@ __global__ void __launch_bounds__(512, (2 * CmWgs<KS1, D, FC2>::value)) chan_mlp
                 if (p.row_part) {
                     // a row's C channels sit in the 4 lanes (row, fg = 0..3) of this wave: chunks q ascending inside a lane, then
                     // (fg 0 + fg 1) + (fg 2 + fg 3) -- one fixed order whatever the batch or the grid
-                    ssum += __shfl_xor(ssum, 16);
-                    ssq += __shfl_xor(ssq, 16);
-                    ssum += __shfl_xor(ssum, 32);
-                    ssq += __shfl_xor(ssq, 32);
+                    ssum = cm_rows4_sum(ssum);
+                    ssq = cm_rows4_sum(ssq);
                     if (fg == 0 && gm < p.M) *reinterpret_cast<f32x2*>(p.row_part + (size_t)gm * 2) = f32x2{ssum, ssq};
                 }
             }
-            if (!requested) load_tile(tile + gridDim.x, le);  // (unconditionally: rows past M clamp to the last row)
+            // the next tile's rows (and every weight piece requested so far) have landed, and the compiler knows it -- settled on either
+            // path BEFORE the two meet
+            if constexpr (!PRE) {
+                load_tile(tile + gridDim.x, le);              // (unconditionally: rows past M clamp to the last row)
+                settle(false);
+            } else {
+                settle(true);
+            }
         }
     };
     if (!lag) run(CmBool<false>{}); else run(CmBool<true>{});
@@ -430,7 +521,7 @@ static int cm_launch_d(const ChanMlpArgs& a, hipStream_t s) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, Geo::LDS);
     if (e != hipSuccess) return MLPK_ESHAPE;
     const int tiles = (a.M + CM_BM - 1) / CM_BM;
-    const int cap = cm_grid_cap() * CmWgs<KS1, D, true>::value;
+    const int cap = cm_grid_cap() * (same ? CmWgs<T, KS1, D, true, true>::value : 1);
     const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), Geo::LDS, s, a);
     MLPK_LAUNCH_CHECK();
@@ -505,7 +596,8 @@ extern "C" int mlpk_linear_gelu(int dtype, const void* x, int ldx, int M, int K,
 }
 
 extern "C" int mlpk_channel_mlp_supported(int dtype, int C, int hidden) {
-    return (dtype == MLPK_F16 || dtype == MLPK_BF16) && C % 32 == 0 && C >= 64 && C <= 192 && hidden > 0 && hidden <= CM_HID_MAX;
+    // (hidden >= 96: the kernel peels a tile's last group of 32 hidden units off its steady loop)
+    return (dtype == MLPK_F16 || dtype == MLPK_BF16) && C % 32 == 0 && C >= 64 && C <= 192 && hidden > 64 && hidden <= CM_HID_MAX;
 }
 
 extern "C" int mlpk_channel_mlp(int dtype, const void* x, int ldx, int M, int C, const float* ln_mean, const float* ln_rstd, int ln_group,

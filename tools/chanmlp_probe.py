@@ -19,7 +19,7 @@ def timeit(fn, n=30):
     return a.elapsed_time(b) / n * 1e3
 
 
-print("lib:", os.environ.get("MLPK_LIB_PATH", "default"))
+print("lib:", os.environ.get("MLPK_LIB_PATH", "default"), flush=True)
 for (name, M, C, hid, group) in [("asmlp l0", 802816, 96, 384, 3136), ("asmlp l0 2x hidden", 802816, 96, 768, 3136), ("asmlp l1", 200704, 192, 768, 784),
                                  ("hire/cycle l0", 802816, 64, 256, 1), ("cycle l1", 200704, 128, 512, 1), ("l2 160", 50176, 160, 640, 1)]:
     g = torch.Generator().manual_seed(1)
@@ -36,7 +36,11 @@ for (name, M, C, hid, group) in [("asmlp l0", 802816, 96, 384, 3136), ("asmlp l0
     def inplace(): E.channel_mlp_fused(x, M, C, pack, x, R=x, ln=(mean, rstd), ln_group=group, part=(ws, "p"))
     def apart(): E.channel_mlp_fused(x0, M, C, pack, out, R=x0, ln=(mean, rstd), ln_group=group, part=(ws, "p"))
     def other_res(): E.channel_mlp_fused(x0, M, C, pack, out, R=out, ln=(mean, rstd), ln_group=group, part=(ws, "p"))
+    if os.environ.get("CM_DEBUG"):
+        for nm, fn in (("inplace", inplace), ("apart", apart), ("other_res", other_res)):
+            print("  running", name, nm, flush=True)
+            fn(); torch.cuda.synchronize()
     ti, ta, to = timeit(inplace), timeit(apart), timeit(other_res)
     fl = 4.0 * M * C * hid
     print("%-20s M=%7d C=%3d hid=%4d  in place %7.1f us (%6.1f TFLOP/s, %5.2f TB/s x+out)  out!=x %7.1f us  R!=x %7.1f us" %
-          (name, M, C, hid, ti, fl / ti / 1e6, 4.0 * M * C / ti / 1e6, ta, to))
+          (name, M, C, hid, ti, fl / ti / 1e6, 4.0 * M * C / ti / 1e6, ta, to), flush=True)
