@@ -14,6 +14,8 @@ derivative below is a call through the C ABI:
 Used by the train-mode forward of MLPMixerForImageClassification (mlp_mixer.py:30-75); inference keeps its fused kernels.  Parameter
 gradients come back in fp32 whatever the compute dtype (the GEMMs accumulate in fp32 and round dW once to the compute dtype).
 """
+import weakref
+
 import torch
 
 from . import _native as N
@@ -54,15 +56,16 @@ _PACKS = {}
 
 def _packed(w, w2, cd, dev):
     """the packed (compute-dtype, K-padded) copy of parameter w, cached per parameter version like EngineModule._get_pack (a training
-    step used to re-pack every weight in every forward)"""
-    key = (w.data_ptr(), cd, str(dev))
+    step used to re-pack every weight in every forward).  An entry belongs to ONE live tensor object (weak reference): the allocator
+    hands a freed parameter's address -- with version 0 again -- to the next model's parameter, so the address alone is not an identity."""
+    key = (id(w), cd, str(dev))
     hit = _PACKS.get(key)
-    if hit is None or hit[0] != w._version or hit[1].shape[0] != w2.shape[0]:
+    if hit is None or hit[0]() is not w or hit[1] != (w.data_ptr(), w._version) or hit[2].shape[0] != w2.shape[0]:
         if len(_PACKS) > 512:
             _PACKS.clear()
-        hit = (w._version, E.pack_matrix(w2, cd, dev, kpad=_epc(cd)))
+        hit = (weakref.ref(w), (w.data_ptr(), w._version), E.pack_matrix(w2, cd, dev, kpad=_epc(cd)))
         _PACKS[key] = hit
-    return hit[1]
+    return hit[2]
 
 
 class Linear(torch.autograd.Function):
