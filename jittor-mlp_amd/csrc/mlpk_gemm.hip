@@ -1054,6 +1054,14 @@ __device__ __forceinline__ void p8_store_tile(const GemmArgs& p, f32x4 (&acc)[8]
 // CUs' store bursts: the folded LayerNorm cost fc1 22 us = 8 %, almost all of it waiting); issued in the second-to-last K
 // slab the same wait merely moved into the last slab's vmcnt(0).  (Registers instead of LDS do not fit: 192 live + 48.)
 // LDS image: [0, 1 KiB) ln_mean of logical tile rows 0..255, [1, 2) ln_rstd, [2, 3) bias of tile columns 0..255, [3, 4) ln_csum.
+// 0: the statistics epilogue loads its residual chunks by untracked asm and waits for each by count (round 6 experiment: the
+// compiler's own waits cannot count the stores issued since, so from the fifth chunk on every step waits for the stores of four steps
+// earlier to be acknowledged).  Measured NEUTRAL on one box in alternation (profiles/r06_p8_counted_epilogue_ab.txt: Mixer-B/16 7.331 /
+// 7.298 / 7.335 ms against 7.333 / 7.311 / 7.327; ResMLP-24, gMLP-S within 0.2 %): the 20 k cycles of a tile's epilogue are its ~1800
+// VALU instructions per wave, not the write latency.  The tracked form stays the default (nothing to keep in step with the compiler).
+#ifndef P8_RES_TRACKED
+#define P8_RES_TRACKED 1
+#endif
 #define P8_PAR_OFF (2 * 4 * 128 * 128)
 #define P8_LDS_BYTES (P8_PAR_OFF + 2 * 4096)
 
@@ -1076,13 +1084,75 @@ __device__ __forceinline__ void p8_par_prefetch(const GemmArgs& p, const int m0,
     if (wave < 4) {
         int r = seg * 64 + lane;
         r = r < BM ? r : BM - 1;                               // short tiles: stay inside this tile's rows
-        const unsigned vo = (unsigned)((m0 + r) / p.ln_group) * 4u;          // (ln_group = 1 when there is no LayerNorm)
-        glds_dword_s(p.ln_mean ? vo : (unsigned)r * 4u, p.ln_mean ? reinterpret_cast<const char*>(p.ln_mean) : dummy, dst);
-        glds_dword_s(p.ln_mean ? vo : (unsigned)r * 4u, p.ln_mean ? reinterpret_cast<const char*>(p.ln_rstd) : dummy, dst + 1024);
+        // (the divisor is hidden from the compiler: it hoisted the reciprocal of a loop-invariant divisor out of the persistent loop into
+        // vector registers that the 256-row kernel then spilled -- and the reload, a scratch load, waited for every memory operation in
+        // flight, i.e. for the two pieces just issued, once per tile; no LayerNorm: no division)
+        unsigned vo = (unsigned)r * 4u;
+        if (p.ln_mean) {
+            int g = p.ln_group;
+            asm volatile("" : "+s"(g));
+            vo = g == 1 ? (unsigned)(m0 + r) * 4u : (unsigned)((m0 + r) / g) * 4u;
+        }
+        glds_dword_s(vo, p.ln_mean ? reinterpret_cast<const char*>(p.ln_mean) : dummy, dst);
+        glds_dword_s(vo, p.ln_mean ? reinterpret_cast<const char*>(p.ln_rstd) : dummy, dst + 1024);
     } else {
         const unsigned vo = (unsigned)(seg * 64 + lane) * 4u;
         glds_dword_s(vo, p.bias ? reinterpret_cast<const char*>(p.bias + n0) : dummy, dst);
         glds_dword_s(vo, p.ln_mean ? reinterpret_cast<const char*>(p.ln_csum + n0) : dummy, dst + 1024);
+    }
+}
+
+// s_waitcnt vmcnt(n) for an n that is a constant once the epilogue's loops are unrolled
+__device__ __forceinline__ void p8_wait_vm(const int n) {
+    switch (n) {
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+        case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
+        case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+        case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
+        case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        case 25: asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); break;
+        case 26: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
+        case 27: asm volatile("s_waitcnt vmcnt(27)" ::: "memory"); break;
+        case 28: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+        case 29: asm volatile("s_waitcnt vmcnt(29)" ::: "memory"); break;
+        case 30: asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); break;
+        case 31: asm volatile("s_waitcnt vmcnt(31)" ::: "memory"); break;
+        case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+        case 33: asm volatile("s_waitcnt vmcnt(33)" ::: "memory"); break;
+        case 34: asm volatile("s_waitcnt vmcnt(34)" ::: "memory"); break;
+        case 35: asm volatile("s_waitcnt vmcnt(35)" ::: "memory"); break;
+        case 36: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
+        case 37: asm volatile("s_waitcnt vmcnt(37)" ::: "memory"); break;
+        case 38: asm volatile("s_waitcnt vmcnt(38)" ::: "memory"); break;
+        case 39: asm volatile("s_waitcnt vmcnt(39)" ::: "memory"); break;
+        case 40: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+        case 41: asm volatile("s_waitcnt vmcnt(41)" ::: "memory"); break;
+        case 42: asm volatile("s_waitcnt vmcnt(42)" ::: "memory"); break;
+        case 43: asm volatile("s_waitcnt vmcnt(43)" ::: "memory"); break;
+        case 44: asm volatile("s_waitcnt vmcnt(44)" ::: "memory"); break;
+        case 45: asm volatile("s_waitcnt vmcnt(45)" ::: "memory"); break;
+        case 46: asm volatile("s_waitcnt vmcnt(46)" ::: "memory"); break;
+        case 47: asm volatile("s_waitcnt vmcnt(47)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 }
 
@@ -1114,15 +1184,25 @@ __device__ __forceinline__ void p8_store_direct(const GemmArgs& p, f32x4 (&acc)[
     // residual chunks of BOTH halves in flight before any math: the load latency (and the burst of every CU reading its
     // residual tile at once) is paid once per tile, the second half arrives under the first half's math
     u32x4 rr[RES ? 2 : 1][RES ? NI : 1][2];
+    // COUNTED (round 6, the statistics epilogue = the residual-stream GEMMs): the residual chunks are loaded by asm the compiler does not
+    // track and each is waited for by count.  Tracked, the compiler's wait in front of chunk s counted the 15 - s chunks behind it but
+    // not the stores issued since (it cannot tell how many of them ran: they sit in conditional blocks) -- so from the fifth chunk on
+    // every step waited for the STORES of four steps earlier to be acknowledged, and the last one for all of them: an epilogue paced by
+    // the write latency (11 us per 256-row tile where its instructions take 5).  P8_RES_TRACKED=1 rebuilds the old form for A/B.
+    constexpr bool COUNTED = RES && STATS && !P8_RES_TRACKED;
     if constexpr (has_res) {
 #pragma unroll
         for (int hm = 0; hm < 2; ++hm)
 #pragma unroll
             for (int i4 = 0; i4 < NI; ++i4)
 #pragma unroll
-                for (int hn = 0; hn < 2; ++hn)
-                    rr[hm][i4][hn] = *reinterpret_cast<const u32x4*>(R + (size_t)(m0 + hm * (NI * 32) + grp * (NI * 16) + i4 * 16 + frow) * p.ldr +
-                                                                     n0 + hn * 128 + wn * 32 + ccol);
+                for (int hn = 0; hn < 2; ++hn) {
+                    const T* src = R + (size_t)(m0 + hm * (NI * 32) + grp * (NI * 16) + i4 * 16 + frow) * p.ldr + n0 + hn * 128 + wn * 32 + ccol;
+                    if constexpr (COUNTED) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rr[hm][i4][hn]) : "v"(src) : "memory");
+                    else rr[hm][i4][hn] = *reinterpret_cast<const u32x4*>(src);
+                }
+        // (tuning mode "no stores": the counts below assume the stores of the steps before)
+        if (COUNTED && (p.dbg & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     float lmu[2][NI], lrs[2][NI];
     if (LN) {
@@ -1177,6 +1257,14 @@ __device__ __forceinline__ void p8_store_direct(const GemmArgs& p, f32x4 (&acc)[
                 const auto s0 = __builtin_amdgcn_permlane16_swap(w[0], w[2], false, false);
                 const auto s1 = __builtin_amdgcn_permlane16_swap(w[1], w[3], false, false);
                 u32x4 outv = {s0[0], s1[0], s0[1], s1[1]};
+                if constexpr (COUNTED) {
+                    // chunk `step` has landed when at most the chunks behind it and the two stores (row, statistics pair) of every step
+                    // before are still in flight; the empty statement hands the registers to the compiler only here
+                    constexpr int NCH = 4 * NI;
+                    const int step = (hm * NI + i4) * 2 + hn;
+                    p8_wait_vm(NCH - 1 - step + 2 * step);
+                    asm volatile("" : "+v"(rr[hm][i4][hn]));
+                }
                 if constexpr (has_res) {
                     T a8[8], r8[8];
                     __builtin_memcpy(a8, &outv, 16);
@@ -1483,7 +1571,9 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, char* const smem) {
         // protects the first fragment reads of every slab with s_waitcnt vmcnt(0..4) -- which drains the LDS-DMA prefetch
         // queue it knows nothing about (tools/isa_lint.py).  Here it costs nothing extra: the loop-top vmcnt(6) waits
         // for the same stores anyway, and only slab 1's pieces are issued behind it.
-        __builtin_amdgcn_s_waitcnt(0x0F70);
+        // (round 6: the statistics epilogue loads its residual by untracked asm and waits by count -- nothing for the compiler to carry,
+        // and slab 1's pieces leave straight behind the last store instead of after its acknowledgement)
+        if constexpr (!(EPI == 2 && !P8_RES_TRACKED)) __builtin_amdgcn_s_waitcnt(0x0F70);
         if (more) { stage(1, 2); stage(1, 0); stage(1, 3); }
 #ifdef MLPK_P8_PROF
         P8_STAMP(te);
