@@ -455,7 +455,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
                             float t = v[r] + bn;
                             if (gelu) t = gelu_t<T>(t);
                             t = t * cs + ch;
-                            if (p.rscale) t *= p.rscale[(c0 + ml + r) % p.rperiod];
+                            if (p.rscale) t *= p.rscale[(m0 + ml + r) % p.rperiod];        // (the GEMM row, as in the row-major epilogue: a period of t_rows gives the channel)
                             e[r] = from_f32<T>(t);
                         }
                         u32x2 pk;
@@ -510,7 +510,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
                     float t = v[r] + bn;
                     if (gelu) t = gelu_t<T>(t);
                     t = t * cs + ch;
-                    if (p.rscale) t *= p.rscale[(c + r) % p.rperiod];
+                    if (p.rscale) t *= p.rscale[(mb + r) % p.rperiod];
                     v[r] = t;
                 }
                 const size_t row = (size_t)img * p.t_tokens + n;

@@ -222,13 +222,36 @@ def finalize_stats(ws, got, rows, count, tag="ln", eps=1e-5, group=1):
     return mean, rstd
 
 
-def channel_mlp(ws, x, rows, C, pk, prefix, hidden, *, norm=True, cscale2=None, res_src=None, tag="cm", eps=1e-5, stats=None, part=None):
+class StochasticDepth:
+    """Train-mode stochastic depth (DropPath) of the hierarchical families, forward only: per sample,
+    branch * floor(keep + u) / keep with u uniform in [0, 1) -- timm's drop_path as the reference repository itself restates it
+    (conv_mlp.py:17-34; timm is not vendored) -- applied as a per-row scale in the epilogue of the GEMM that adds the residual
+    (mlpk.h: v * rscale[m] in front of + R).  The draws come from `drop_path_uniform(B, dtype, device)` (default torch.rand on the
+    input's device, one call per DropPath with a rate > 0, in the reference's order; tests replace it with a reference run's draws)."""
+
+    def drop_path_uniform(self, B, dtype, device):
+        return torch.rand((B,), dtype=dtype, device=device)
+
+    def _drop_scale(self, rate, B, rows_per_sample, dtype, device):
+        """per-row scale of one DropPath call (None: identity -- eval mode or rate 0)"""
+        rate = float(rate)
+        if not self.training or rate == 0.0:
+            return None
+        keep = 1.0 - rate
+        u = self.drop_path_uniform(B, dtype, device)
+        mask = torch.floor(keep + u.reshape(B).float())
+        return (mask / keep).repeat_interleave(rows_per_sample).contiguous()
+
+
+def channel_mlp(ws, x, rows, C, pk, prefix, hidden, *, norm=True, cscale2=None, res_src=None, tag="cm", eps=1e-5, stats=None, part=None, rscale=None):
     """x <- x + fc2(gelu(fc1(LN(x))))   (mlp_mixer.py:38; vip.py:82-88; s2_mlp_v2.py:78-84).
     LN -> row-major normalised copy; fc1 epilogue = bias + exact GELU; fc2 epilogue = bias + residual.
     `stats` = (mean, rstd) of x's rows when the producer of x already delivered them (token_mlp's epilogue, a GEMM's row_part).
     `part` = (workspace, name): fc2's epilogue delivers the row statistics of the new x for the LayerNorm that follows; the
-    return value is then what finalize_stats takes (None when they could not be delivered) instead of x."""
-    if norm and (cscale2 is None or pk.get(prefix + "fused.scaled")) and (prefix + "fused") in pk and E.channel_mlp_fused_supported(x.dtype, C, hidden):
+    return value is then what finalize_stats takes (None when they could not be delivered) instead of x.
+    `rscale` (rows,) fp32: a per-row scale of the branch in front of the residual addition (train-mode stochastic depth): the two
+    GEMMs, the scale in fc2's epilogue."""
+    if rscale is None and norm and (cscale2 is None or pk.get(prefix + "fused.scaled")) and (prefix + "fused") in pk and E.channel_mlp_fused_supported(x.dtype, C, hidden):
         mean, rstd = stats if stats is not None else layernorm_stats(ws, x, rows, C, tag=tag + ".ln", eps=eps)
         got = E.channel_mlp_fused(x, rows, C, pk[prefix + "fused"], x, R=res_src if res_src is not None else x, ln=(mean, rstd), part=part)
         return got if part is not None else x
@@ -261,7 +284,8 @@ def channel_mlp(ws, x, rows, C, pk, prefix, hidden, *, norm=True, cscale2=None, 
         else:
             E.gemm(xn[sl], pk[prefix + "fc1.w"], h[sl], step, hidden, C, bias=pk[prefix + "fc1.b"], act=N.ACT_GELU, ln=lnc, tag="channel_fc1")
         got = E.gemm(h[sl], pk[prefix + "fc2.w"], x[sl], step, C, hidden, bias=pk[prefix + "fc2.b"], cscale=cscale2,
-                     R=res[sl], res=N.RES_ADD, tag="channel_fc2", part=part if nchunk == 1 else None)
+                     R=res[sl], res=N.RES_ADD, tag="channel_fc2", part=part if nchunk == 1 and rscale is None else None,
+                     rscale=rscale[sl] if rscale is not None else None, rperiod=step if rscale is not None else 0)
     return got if part is not None else x
 
 

@@ -26,7 +26,7 @@ from torch.nn import init
 
 from .. import _native as N
 from .. import engine as E
-from .common import Block, Holder, LinearMlp, channel_mlp, finalize_stats, head_linear, layernorm_stats, pack_channel_mlp
+from .common import Block, Holder, LinearMlp, StochasticDepth, channel_mlp, finalize_stats, head_linear, layernorm_stats, pack_channel_mlp
 from .utils import pair
 
 
@@ -101,7 +101,8 @@ class CycleBlock(Block):
         super().__init__()
         self.norm1 = norm_layer(dim)
         self.attn = mlp_fn(dim, qkv_bias=qkv_bias, qk_scale=None, attn_drop=attn_drop)
-        self.drop_path = nn.Identity()
+        self.drop_path = nn.Identity()                 # DropPath(p): identity in eval mode; train mode: CycleNet._block (round 6)
+        self.drop_path_rate = drop_path
         self.norm2 = norm_layer(dim)
         mlp_hidden_dim = int(dim * mlp_ratio)
         self.mlp = Mlp(in_features=dim, hidden_features=mlp_hidden_dim, act_layer=act_layer)
@@ -141,10 +142,15 @@ def basic_blocks(dim, index, layers, mlp_ratio=3., qkv_bias=False, qk_scale=None
     return nn.Sequential(*blocks)
 
 
-class CycleNet(E.EngineModule):
-    """Same signature as the reference (cycle_mlp.py:248-256).  fork_feat=True (round 5; :274-287, :326-334): instead of logits the forward
+class CycleNet(StochasticDepth, E.EngineModule):
+    """train() (round 6): the forward applies the blocks' stochastic depth (cycle_mlp.py:186,194-195: the same DropPath in front
+    of both residual additions, then / skip_lam) -- see common.StochasticDepth; forward only, the outputs carry no grad_fn.
+
+    Same signature as the reference (cycle_mlp.py:248-256).  fork_feat=True (round 5; :274-287, :326-334): instead of logits the forward
     returns the list of the four stage outputs, each through its own `norm{0,2,4,6}` LayerNorm (an Identity for the first one under the
     reference's FORK_LAST3 environment switch) and as (B, C, H, W)."""
+
+    _train_forward = "forward-only"
 
     def __init__(self, layers, img_size=224, patch_size=4, in_chans=3, num_classes=1000, embed_dims=None, transitions=None,
                  segment_dim=None, mlp_ratios=None, skip_lam=1.0, qkv_bias=False, qk_scale=None, drop_rate=0., attn_drop_rate=0.,
@@ -264,7 +270,7 @@ class CycleNet(E.EngineModule):
         E.rows_to_nchw(src, B, H * W, C, out)
         return out if out.dtype == dtype else out.to(dtype)
 
-    def _block(self, ws, pk, p, cur, B, H, W, C, hidden, tag, stats=None):
+    def _block(self, ws, pk, p, cur, B, H, W, C, hidden, tag, stats=None, rate=0.0):
         """One CycleBlock in place.  `stats` = (mean, rstd) of cur's rows when the GEMM that wrote cur delivered them; returns the
         statistics of the result the same way (or None): both LayerNorms read what a GEMM has just written (mlpk.h row_part)."""
         rows = B * H * W
@@ -297,9 +303,14 @@ class CycleNet(E.EngineModule):
         E.split_softmax(hat, bar, B, C)
         m = ws.get(tag + ".m", (rows, C))
         E.split_apply(th, tw, tc, C, C, C, B, H, W, C, N.SHIFT_NONE, bar, m, C)
-        got = E.gemm(m, pk[p + "p.w"], cur, rows, C, C, bias=pk[p + "p.b"], R=cur, res=N.RES_ADD, tag="cycle_proj", part=(ws, tag + ".p.part"))
+        # train mode: x + drop_path(attn(.)) / skip_lam, x + drop_path(mlp(.)) / skip_lam (cycle_mlp.py:194-195; 1 / skip_lam sits in the packed
+        # weights): a per-row scale in the epilogues that add the residuals, two draws per block
+        dp1 = self._drop_scale(rate, B, H * W, cur.dtype, cur.device)
+        dp2 = self._drop_scale(rate, B, H * W, cur.dtype, cur.device)
+        got = E.gemm(m, pk[p + "p.w"], cur, rows, C, C, bias=pk[p + "p.b"], R=cur, res=N.RES_ADD, tag="cycle_proj",
+                     part=(ws, tag + ".p.part") if dp1 is None else None, rscale=dp1, rperiod=rows if dp1 is not None else 0)
         got = channel_mlp(ws, cur, rows, C, pk, p + "ff.", hidden, tag=tag + ".cm", stats=finalize_stats(ws, got, rows, C, tag=tag + ".cm.ln"),
-                          part=(ws, tag + ".fc2.part"))
+                          part=(ws, tag + ".fc2.part"), rscale=dp2)
         return finalize_stats(ws, got, rows, C, tag=tag + ".ln")
 
     def _run_single(self, key, x):
@@ -350,7 +361,7 @@ class CycleNet(E.EngineModule):
             ws = self._get_space(("block", B, H, W, C), x.dtype, x.device)     # (C: blocks of different stages can meet at one map size)
             cur = ws.get("blk.x", (B * H * W, C))
             cur.copy_(x.reshape(B * H * W, C))
-            self._block(ws, pk, "n%d.b%d." % (si, bi), cur, B, H, W, C, blk.mlp.fc1.weight.shape[0], "n%d" % si)
+            self._block(ws, pk, "n%d.b%d." % (si, bi), cur, B, H, W, C, blk.mlp.fc1.weight.shape[0], "n%d" % si, rate=blk.drop_path_rate)
             return cur.reshape(B, H, W, C).clone()
 
     def forward(self, x):
@@ -383,7 +394,8 @@ class CycleNet(E.EngineModule):
                 cur, H, W, C = nxt, H2, W2, Cout
                 continue
             for bi, blk in enumerate(stage):
-                st = self._block(ws, pk, "n%d.b%d." % (si, bi), cur, B, H, W, C, blk.mlp.fc1.weight.shape[0], "n%d" % si, stats=st)
+                st = self._block(ws, pk, "n%d.b%d." % (si, bi), cur, B, H, W, C, blk.mlp.fc1.weight.shape[0], "n%d" % si, stats=st,
+                                 rate=blk.drop_path_rate)
         if self.fork_feat:
             last = len(self.network) - 1
             if last in self.out_indices:

@@ -14,7 +14,7 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Block, Holder, SubModule, channel_mlp, embed_patches, head_linear, layernorm_stats
+from .common import Block, Holder, StochasticDepth, SubModule, channel_mlp, embed_patches, head_linear, layernorm_stats
 
 MS_EPS = 1e-6
 
@@ -80,7 +80,8 @@ class MixShiftBlock(Block):
         self.act = nn.GELU()
         self.pwconv2 = nn.Linear(int(mlp_ratio * dim), dim)
         self.gamma = nn.Parameter(layer_scale_init_value * torch.ones((dim)), requires_grad=True) if layer_scale_init_value > 0 else None
-        self.drop_path = nn.Identity()
+        self.drop_path = nn.Identity()                 # DropPath(p): identity in eval mode; train mode: MS_MLP.forward (round 6)
+        self.drop_path_rate = drop_path
 
 
 class PatchEmbed(Block):
@@ -122,8 +123,12 @@ class BasicLayer(Block):
             self.downsample = None
 
 
-class MS_MLP(E.EngineModule):
-    """Same signature and defaults as the reference (ms_mlp.py:300-306)."""
+class MS_MLP(StochasticDepth, E.EngineModule):
+    """Same signature and defaults as the reference (ms_mlp.py:300-306).
+
+    train() (round 6): the forward applies the blocks' stochastic depth (ms_mlp.py:46,77: x = input + drop_path(gamma * branch)) --
+    see common.StochasticDepth; the LayerNorms have no batch statistics, Dropout has p = 0.  Forward only: the outputs carry no grad_fn."""
+    _train_forward = "forward-only"
 
     def __init__(self, img_size=224, patch_size=4, in_chans=3, num_classes=1000, embed_dim=96, depths=[2, 2, 6, 2], shift_size=5,
                  shift_dist=[-2, -1, 0, 1, 2], mix_size=[[1, 1, 3, 5, 7], [1, 1, 3, 5, 5], [1, 1, 3, 3, 3], [1, 1, 1, 1, 3]], mlp_ratio=4.,
@@ -282,7 +287,8 @@ class MS_MLP(E.EngineModule):
                     p = "l%d.b%d." % (li, b_i)
                     E.mixshift_nhwc(cur, mix, B, H, W, C, list(blk.shift_dist), [k for k, _ in blk.kernel_size], pk[p + "lr.w"], pk[p + "lr.b"],
                                     pk[p + "td.w"], pk[p + "td.b"])
-                    channel_mlp(ws, mix, rows, C, pk, p + "ff.", int(self.mlp_ratio * C), cscale2=pk[p + "gamma"], res_src=cur, tag="blk.cm", eps=MS_EPS)
+                    channel_mlp(ws, mix, rows, C, pk, p + "ff.", int(self.mlp_ratio * C), cscale2=pk[p + "gamma"], res_src=cur, tag="blk.cm", eps=MS_EPS,
+                                rscale=self._drop_scale(blk.drop_path_rate, B, H * W, x.dtype, x.device))
                     cur, mix = mix, cur
             if bi == "down" or (bi == "layer" and layer.downsample is not None):
                 cur, H, W, C = self._down(ws, pk, li, cur, B, H, W, C)
@@ -307,7 +313,9 @@ class MS_MLP(E.EngineModule):
                 E.mixshift_nhwc(cur, mix, B, H, W, C, list(blk.shift_dist), [k for k, _ in blk.kernel_size], pk[p + "lr.w"], pk[p + "lr.b"],
                                 pk[p + "td.w"], pk[p + "td.b"])
                 # mix <- cur + gamma * pwconv2(gelu(pwconv1(LN(mix))));  then the roles of the two buffers swap
-                channel_mlp(ws, mix, rows, C, pk, p + "ff.", hid, cscale2=pk[p + "gamma"], res_src=cur, tag="l%d.cm" % li, eps=MS_EPS)
+                # (train mode: ... + drop_path(gamma * .), ms_mlp.py:77 -- a per-row scale in pwconv2's epilogue)
+                channel_mlp(ws, mix, rows, C, pk, p + "ff.", hid, cscale2=pk[p + "gamma"], res_src=cur, tag="l%d.cm" % li, eps=MS_EPS,
+                            rscale=self._drop_scale(blk.drop_path_rate, B, H * W, cd, x.device))
                 cur, mix = mix, cur
             if layer.downsample is not None:
                 cur, H, W, C = self._down(ws, pk, li, cur, B, H, W, C)

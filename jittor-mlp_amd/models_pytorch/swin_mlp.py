@@ -21,7 +21,7 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Block, Holder, LinearMlp, channel_mlp, finalize_stats, embed_patches, head_linear, layernorm_stats, pack_channel_mlp
+from .common import Block, Holder, LinearMlp, StochasticDepth, channel_mlp, finalize_stats, embed_patches, head_linear, layernorm_stats, pack_channel_mlp
 
 
 def to_2tuple(v):
@@ -54,7 +54,8 @@ class SwinMLPBlock(Block):
         self.norm1 = norm_layer(dim)
         self.spatial_mlp = nn.Conv1d(self.num_heads * self.window_size ** 2, self.num_heads * self.window_size ** 2, kernel_size=1,
                                      groups=self.num_heads)
-        self.drop_path = nn.Identity()
+        self.drop_path = nn.Identity()                 # DropPath(p): identity in eval mode; train mode: SwinMLP._block (round 6)
+        self.drop_path_rate = drop_path
         self.norm2 = norm_layer(dim)
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
 
@@ -105,8 +106,13 @@ class PatchEmbed(Block):
         self.norm = norm_layer(embed_dim) if norm_layer is not None else None
 
 
-class SwinMLP(E.EngineModule):
-    """Same signature and defaults as the reference (swin_mlp.py:374-379)."""
+class SwinMLP(StochasticDepth, E.EngineModule):
+    """Same signature and defaults as the reference (swin_mlp.py:374-379).
+
+    train() (round 6): the forward applies the blocks' stochastic depth (swin_mlp.py:105,154-155: the same DropPath in front of
+    both residual additions of a block) -- see common.StochasticDepth; LayerNorm has no batch statistics, Dropout has p = 0.  Forward only:
+    the outputs carry no grad_fn."""
+    _train_forward = "forward-only"
 
     def __init__(self, img_size=224, patch_size=4, in_chans=3, num_classes=1000, embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24],
                  window_size=7, mlp_ratio=4., drop_rate=0., drop_path_rate=0.1, norm_layer=nn.LayerNorm, ape=False, patch_norm=True,
@@ -208,7 +214,10 @@ class SwinMLP(E.EngineModule):
         kp = E.round_up(tk, 8)
         tag = "l%d.s%d." % (li, 1 if blk.shift_size > 0 else 0)
         mean, rstd = st if st is not None else layernorm_stats(ws_, cur, rows, C, tag="l%d.ln" % li)
-        if (p + "sp.fw") in pk and E.swin_spatial_supported(cur.dtype, C, nh, ws):
+        # train mode: x = shortcut + drop_path(spatial branch), x = x + drop_path(mlp(norm2(x))) (swin_mlp.py:154-155) -- two draws per block
+        dp1 = self._drop_scale(blk.drop_path_rate, B, (Hp // ws) * (Wp // ws) * d, cur.dtype, cur.device)
+        dp2 = self._drop_scale(blk.drop_path_rate, B, H * W, cur.dtype, cur.device)
+        if dp1 is None and dp2 is None and (p + "sp.fw") in pk and E.swin_spatial_supported(cur.dtype, C, nh, ws):
             # round 5: the kernel holds whole rows, so it also delivers norm2's statistics of what it writes (no statistics pass;
             # MLPK_SWIN_SPATIAL_STATS=0: the pass, A/B aid)
             st2 = None
@@ -225,10 +234,12 @@ class SwinMLP(E.EngineModule):
         E.window_gather(xn, xw, B, H, W, C, ws, pad_t, pad_l, Hp, Wp)
         # rows (window, token, head) x d channels  ->  per window transposed: ((window, channel), (token, head))
         E.norm_apply(xw, nwin * tk, d, d, out_tt=xt, S=tk, ld_tt=kp)
+        # (stochastic depth: the branch scaled per sample where the product stores it -- GEMM row = (window, channel), the windows of an
+        # image are consecutive -- before the windows are added back)
         E.gemm(xt, pk[p + "sp.w"], xw, nwin * d, tk, kp, ldc=d, bias=pk[p + "sp.b"], out_mode=N.OUT_TOKEN_T, t_rows=d, t_tokens=tk,
-               tag="swin_spatial")
+               tag="swin_spatial", rscale=dp1, rperiod=nwin * d if dp1 is not None else 0)
         E.window_scatter_add(cur, xw, B, H, W, C, ws, pad_t, pad_l, Hp, Wp)
-        got = channel_mlp(ws_, cur, rows, C, pk, p + "ff.", int(C * self.mlp_ratio), tag="l%d.cm" % li, part=(ws_, "l%d.fc2.part" % li))
+        got = channel_mlp(ws_, cur, rows, C, pk, p + "ff.", int(C * self.mlp_ratio), tag="l%d.cm" % li, part=(ws_, "l%d.fc2.part" % li), rscale=dp2)
         st = finalize_stats(ws_, got, rows, C, tag="l%d.ln" % li)
         return st
 

@@ -655,6 +655,31 @@ def make_train(ref):
     print("train asmlp logits %s, %d DropPath calls with a rate > 0, kept %s, max |train - eval| %.3f" % (
         tuple(logits.shape), len(dp.draws), [int(np.floor(1 - r + d).sum()) for r, d in zip(np.linspace(0, 0.5, 5).repeat(2)[2:], dp.draws)],
         float((logits - plain).abs().max())))
+    # round 6: the other three families whose only train-mode ingredient is stochastic depth (LayerNorm has no batch statistics, Dropout p = 0):
+    # Swin-MLP (swin_mlp.py:105,154-155), MS-MLP (ms_mlp.py:46,77), CycleMLP (cycle_mlp.py:186,194-195).  The tiny fixtures' weights,
+    # drop_path_rate 0.5, batch 4; the recorded uniform draws are part of the fixture, like AS-MLP's.
+    for tag, fixture, ctor, extra in (("swinmlp", "tiny_swinmlp.npz", ref["swin_mlp"].SwinMLP, {}),
+                                      ("msmlp", "tiny_msmlp.npz", ref["ms_mlp"].MS_MLP, {}),
+                                      ("cyclemlp", "tiny_cyclemlp.npz", ref["cycle_mlp"].CycleNet, {"mlp_fn": None})):
+        z = np.load(os.path.join(HERE, fixture))
+        kw = dict(json.loads(str(z["kwargs"])), drop_path_rate=0.5)
+        model = ctor(**ctor_kw(ref, dict(kw, **extra)))
+        model.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}, strict=True)
+        model.train()
+        hw = tuple(z["input"].shape[2:])
+        x = torch.from_numpy(portable_input((4, 3) + hw, seed=21))
+        dp.draws.clear()
+        torch.manual_seed(22)
+        with torch.no_grad():
+            logits = model(x)
+            model.eval()
+            plain = model(x)
+        out[tag + "/kwargs"] = np.array(_jsonable(kw))
+        out[tag + "/input"] = x.numpy().copy()
+        out[tag + "/logits"] = logits.numpy().copy()
+        out[tag + "/draws"] = np.stack(dp.draws)
+        print("train %-8s logits %s, %d DropPath calls with a rate > 0, max |train - eval| %.3f" % (
+            tag, tuple(logits.shape), len(dp.draws), float((logits - plain).abs().max())))
     np.savez_compressed(os.path.join(HERE, "train_tiny.npz"), **out)
 
 

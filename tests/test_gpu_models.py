@@ -61,14 +61,14 @@ BF16_RECORDED = {"mixer_s16": 2.34e-3, "mixer_b16": 2.51e-3, "gmlp_s": 4.27e-3, 
 REGRESSION_HEADROOM = 1.3
 
 
-FP16_REAL_EXCEPTIONS = {
-    # measured 1.03e-3 on logits of magnitude 0.44 after 18 blocks x 6 GEMMs with fp16 storage.  Same-box switches (round 2):
-    # SplitAttention's `a` from fp32 sums of the branch inputs (2.5e-4 from an fp64 evaluation of the same operands,
-    # tools/vip_a_check.py) 1.03e-3 | `a` summed from the fp16-ROUNDED branch outputs (4.5e-2 from fp64) 8.3e-4 | without the
-    # channel-branch LayerNorm fold 1.15e-3; bf16 moves the other way (5.9e-3 | 6.9e-3 | 6.4e-3): the max over 8000 logits
-    # fluctuates by +-20 % between equally valid roundings, and the more exact evaluation is kept.
-    "vip_s7": 1.2e-3,
-}
+# fp16 at real depth: north_star's 1e-3 (x max(1, |ref|)), or -- where the REFERENCE ITSELF, run in fp16 on the same input, is further than
+# that from its own fp32 output (tests/golden/real_lowp.json, err_fp16; ViP-S7: 1.6e-3 on logits of magnitude 0.44 after 18 blocks x 6
+# GEMMs with fp16 storage) -- 0.8 x the reference's own fp16 error: never less accurate than the reference in the same dtype, with
+# margin.  (Round 6: this rule replaces a hand-set 1.2e-3 for ViP-S7, which measures 1.03e-3.  Same-box switches, round 2:
+# SplitAttention's `a` from fp32 sums of the branch inputs -- 2.5e-4 from an fp64 evaluation of the same operands, tools/vip_a_check.py --
+# 1.03e-3 | `a` summed from the fp16-ROUNDED branch outputs (4.5e-2 from fp64) 8.3e-4 | without the channel-branch LayerNorm fold
+# 1.15e-3: the max over 8000 logits moves by +-20 % between equally valid roundings, and the more exact evaluation is kept.)
+FP16_REF_FRACTION = 0.8
 
 
 def tol_for(dtype, ref, real=False, name=None):
@@ -76,7 +76,9 @@ def tol_for(dtype, ref, real=False, name=None):
     if dtype == torch.float32:
         return 1e-5
     if dtype == torch.float16:
-        return (FP16_REAL_EXCEPTIONS.get(name, 1e-3) if real else 1e-3) * m
+        if real and name in REF_LOWP:
+            return max(1e-3 * m, FP16_REF_FRACTION * REF_LOWP[name]["err_fp16"])
+        return 1e-3 * m
     if real:
         if name in REF_LOWP:
             return max(5e-3 * m, 1.25 * REF_LOWP[name]["err_bf16"])
