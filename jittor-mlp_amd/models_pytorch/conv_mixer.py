@@ -13,11 +13,12 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import BlockSequential, adopt_blocks, Holder, head_linear
+from .common import Block, BlockSequential, adopt_blocks, Holder, head_linear
 
 
-class Residual(Holder):
-    """fn(x) + x (conv_mixer.py:5-11)."""
+class Residual(Block):
+    """fn(x) + x (conv_mixer.py:5-11).  Inside a ConvMixer (`model.blocks[i][0]`: depthwise convolution -> GELU -> BatchNorm, plus x) it runs
+    on its own like the reference's, on (B, dim, H, W) -- the depthwise kernel has the residual built in; round 6."""
 
     def __init__(self, fn):
         super().__init__()
@@ -66,6 +67,8 @@ class ConvMixer(E.EngineModule):
         self.classifier = nn.Sequential(nn.AdaptiveAvgPool2d((1, 1)), nn.Flatten(), nn.Linear(dim, n_classes))
         self._cfg = (dim, depth, kernel_size, patch_size, n_classes)
         adopt_blocks(self, self.blocks)                            # lets `model.blocks[i](x)` run (common.BlockSequential)
+        for i, blk in enumerate(self.blocks):
+            blk[0].__dict__["_owner"] = (self, (i, "res"))         # ... and `model.blocks[i][0](x)`, the Residual (round 6)
 
     def _pack(self, dtype, device):
         dim, depth, k, patch, _ = self._cfg
@@ -91,6 +94,9 @@ class ConvMixer(E.EngineModule):
         """block i alone on (B, dim, H, W), as `model.blocks[i](x)` in the reference (conv_mixer.py:23-32)"""
         E.require_gpu(x, "ConvMixer block")
         E.dtype_code(x.dtype)
+        residual_only = isinstance(i, tuple)                           # (i, "res"): blocks[i][0] alone (round 6)
+        if residual_only:
+            i = i[0]
         dim, _, k, _, _ = self._cfg
         if x.dim() != 4 or x.shape[1] != dim:
             raise ValueError("expected a (B, %d, H, W) tensor" % dim)
@@ -104,6 +110,8 @@ class ConvMixer(E.EngineModule):
             tmp = ws.get("blk.y", (rows, dim))
             p = "b%d." % i
             E.dwconv_nhwc(cur, tmp, B, H, W, dim, _keff(k), pk[p + "dw.w"], pk[p + "dw.b"], pk[p + "dw.s"], pk[p + "dw.h"])
+            if residual_only:
+                return tmp.reshape(B, H, W, dim).permute(0, 3, 1, 2).contiguous()
             E.gemm(tmp, pk[p + "pw.w"], cur, rows, dim, dim, bias=pk[p + "pw.b"], act=N.ACT_GELU, cscale=pk[p + "pw.s"], cshift=pk[p + "pw.h"])
             return cur.reshape(B, H, W, dim).permute(0, 3, 1, 2).contiguous()
 

@@ -20,12 +20,13 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Block, BlockSequential, Holder, channel_mlp, finalize_stats, head_linear, layernorm_stats, pack_channel_mlp
+from .common import Block, BlockSequential, Holder, SubModule, channel_mlp, finalize_stats, head_linear, layernorm_stats, pack_channel_mlp
 from .utils import pair
 
 
-class PreNormResidual(Holder):
-    """fn(norm(x)) + x (hire_mlp.py:8-15)."""
+class PreNormResidual(Block):
+    """fn(norm(x)) + x (hire_mlp.py:8-15).  Inside a HireMLP both halves of a block -- `layers[l].model[b][0]` (around the HireMLPBlock) and
+    `[b][1]` (around the channel MLP) -- run on their own like the reference's, on channel-last (B, H, W, C); round 6."""
 
     def __init__(self, dim, fn, norm=nn.LayerNorm):
         super().__init__()
@@ -44,16 +45,42 @@ class PatchEmbedding(Block):
             nn.Identity() if (not norm_layer) else nn.Sequential(nn.Identity(), nn.LayerNorm(dim_out), nn.Identity()))
 
 
-class FeedForward(Holder):
-    """hire_mlp.py:33-42."""
+class FeedForward(SubModule):
+    """hire_mlp.py:33-42: Conv2d(1 x 1) -> GELU -> Conv2d(1 x 1) on (B, C, H, W).  Inside a model a parameter container (the block packs
+    `proj_h` / `proj_w` in its gathered order); on its own callable like the reference's (round 6): channel-last inside, the two 1 x 1
+    convolutions are NT GEMMs with the GELU in the first epilogue."""
 
     def __init__(self, dim_in, hidden_dim, dim_out):
         super().__init__()
         self.net = nn.Sequential(nn.Conv2d(dim_in, hidden_dim, kernel_size=1), nn.GELU(), nn.Conv2d(hidden_dim, dim_out, kernel_size=1))
 
+    def _pack(self, dtype, device):
+        c1, c2 = self.net[0], self.net[2]
+        return {"w1": E.pack_matrix(c1.weight, dtype, device), "b1": E.f32(c1.bias, device),
+                "w2": E.pack_matrix(c2.weight, dtype, device), "b2": E.f32(c2.bias, device)}
 
-class HireMLPBlock(Holder):
-    """hire_mlp.py:96-125 (the rearrange / roll sub-modules hold no parameters and are index arithmetic here)."""
+    def forward(self, x):
+        c1, c2 = self.net[0], self.net[2]
+        cin, hid, cout = c1.in_channels, c1.out_channels, c2.out_channels
+        if x.dim() != 4:
+            raise ValueError("expected a (B, C, H, W) tensor")
+        pk = self._begin(x, cin, axis=1)
+        B, _, H, W = x.shape
+        rows = B * H * W
+        with E.on_device(x):
+            ws = self._get_space((rows, cin), x.dtype, x.device)
+            xb = ws.get("ff.x", (rows, pk["w1"].shape[1]))              # K zero-padded to whole 16-byte chunks
+            xb[:, :cin].copy_(x.permute(0, 2, 3, 1).reshape(rows, cin))
+            t = ws.get("ff.t", (rows, pk["w2"].shape[1]))
+            E.gemm(xb, pk["w1"], t, rows, hid, pk["w1"].shape[1], bias=pk["b1"], act=N.ACT_GELU)
+            y = torch.empty((rows, cout), dtype=x.dtype, device=x.device)
+            E.gemm(t, pk["w2"], y, rows, cout, pk["w2"].shape[1], bias=pk["b2"])
+            return y.reshape(B, H, W, cout).permute(0, 3, 1, 2).contiguous()
+
+
+class HireMLPBlock(Block):
+    """hire_mlp.py:96-152 (the rearrange / roll sub-modules hold no parameters and are index arithmetic here).  Inside a HireMLP it runs on its
+    own like the reference's (:128-152): channel-last (B, H, W, C) in and out, no LayerNorm, no residual; round 6."""
 
     def __init__(self, h, w, d_model, cross_region_step=1, cross_region_id=0, cross_region_interval=2, padding_type='circular'):
         super().__init__()
@@ -125,6 +152,9 @@ class HireMLP(E.EngineModule):
         for li, stage in enumerate(self.layers):
             for bi, blk in enumerate(stage.model):
                 blk.__dict__["_owner"] = (self, (li, bi))          # lets `model.layers[l].model[b](x)` run (common.BlockSequential)
+                blk[0].__dict__["_owner"] = (self, (li, (bi, "pre0")))    # ... its two PreNormResidual halves and the HireMLPBlock (round 6)
+                blk[1].__dict__["_owner"] = (self, (li, (bi, "pre1")))
+                blk[0].fn[0].__dict__["_owner"] = (self, (li, (bi, "hire")))
             stage.__dict__["_owner"] = (self, (li, "layer"))       # ... `model.layers[l](x)`: the blocks, then the PatchEmbedding where pooling
             stage.patch_merge[1].__dict__["_owner"] = (self, (li, "merge"))
         self.patcher.__dict__["_owner"] = (self, ("embed", None))
@@ -167,9 +197,11 @@ class HireMLP(E.EngineModule):
         pk["head.b"] = E.f32(self.mlp_head[2].bias, device)
         return pk
 
-    def _block(self, ws, pk, li, bi, stage, cur, B, H, W, st):
+    def _block(self, ws, pk, li, bi, stage, cur, B, H, W, st, part="both"):
         """Block `layers[li].model[bi]` in place on channel-last rows `cur` (B*H*W, C); st = (mean, rstd) of cur's rows when the GEMM that
-        wrote them delivered the statistics (else None); returns the statistics of the result the same way."""
+        wrote them delivered the statistics (else None); returns the statistics of the result the same way.
+        part (round 6, the block's inner modules on their own): "pre0" = x + HireMLPBlock(LN x) only, "pre1" = x + MLP(LN x) only,
+        "hire" = HireMLPBlock(x) alone (no LayerNorm, no residual)."""
         h, w, C, Cout, depth, ef = stage.geom
         rows = B * H * W
         Hp, Wp = H + (h - H % h), W + (w - W % w)                                         # hire_mlp.py:131-133
@@ -185,6 +217,20 @@ class HireMLP(E.EngineModule):
         blk = stage.model[bi]
         p = "l%d.b%d." % (li, bi)
         step = blk[0].fn[0].step
+        if part == "pre1":
+            channel_mlp(ws, cur, rows, C, pk, p + "ff.", C * ef, tag="l%d.cm" % li)
+            return None
+        if part == "hire":
+            # x is what the block's LayerNorm would have delivered: gather it as it is, out = proj_c(x) + y_h + y_w
+            xn.copy_(cur)
+            E.hire_gather(xn, a_h, a_w, B, H, W, C, h, w, step, h * C, w * C)
+            E.gemm(a_w, pk[p + "w1.w"], t_w, rows_w, hid, w * C, bias=pk[p + "w1.b"], act=N.ACT_GELU, tag="hire_fc1")
+            E.gemm(t_w, pk[p + "w2.w"], a_w, rows_w, w * C, hidp, bias=pk[p + "w2.b"], tag="hire_fc2")
+            E.gemm(a_h, pk[p + "h1.w"], t_h, rows_h, hid, h * C, bias=pk[p + "h1.b"], act=N.ACT_GELU, tag="hire_fc1")
+            E.gemm(t_h, pk[p + "h2.w"], a_h, rows_h, h * C, hidp, bias=pk[p + "h2.b"], tag="hire_fc2")
+            E.gemm(xn, pk[p + "c.w"], cur, rows, C, C, bias=pk[p + "c.b"], tag="hire_c")
+            E.hire_combine(cur, a_h, a_w, B, H, W, C, h, w, step, h * C, w * C)
+            return None
         mean, rstd = st if st is not None else layernorm_stats(ws, cur, rows, C, tag="l%d.ln" % li)
         fold = cur.dtype != torch.float32 and os.environ.get("MLPK_HIRE_LN_FOLD") != "0"
         if fold:
@@ -209,6 +255,8 @@ class HireMLP(E.EngineModule):
             E.gemm(xn, pk[p + "c.w"], cur, rows, C, C, bias=pk[p + "c.b"], R=cur, res=N.RES_ADD, tag="hire_c")   # x + proj_c(xn)
             chain.join()
             E.hire_combine(cur, a_h, a_w, B, H, W, C, h, w, step, h * C, w * C)
+        if part == "pre0":
+            return None
         got = channel_mlp(ws, cur, rows, C, pk, p + "ff.", C * ef, tag="l%d.cm" % li, part=(ws, "l%d.fc2.part" % li))
         st = finalize_stats(ws, got, rows, C, tag="l%d.ln" % li)
         return st
@@ -280,6 +328,9 @@ class HireMLP(E.EngineModule):
             cur = ws.get("blk.x", (B * H * W, C))
             cur.copy_(x.reshape(B * H * W, C))
             st = None
+            if isinstance(bi, tuple):                                  # an inner module of block bi[0] (round 6)
+                self._block(ws, pk, li, bi[0], stage, cur, B, H, W, None, part=bi[1])
+                return cur.reshape(B, H, W, C).clone()
             for b_i in range(len(stage.model)):
                 if bi == "layer" or b_i == bi:
                     st = self._block(ws, pk, li, b_i, stage, cur, B, H, W, st)

@@ -27,8 +27,10 @@ from .conv_mixer import _bn_affine
 from .utils import pair
 
 
-class PreNormResidual(Holder):
-    """fn(norm(x)) + x (sparse_mlp.py:8-15)."""
+class PreNormResidual(Block):
+    """fn(norm(x)) + x (sparse_mlp.py:8-15).  Inside a SparseMLP the three of a block run on their own like the reference's (round 6):
+    `layers[l].model[b][0]` (BatchNorm + depthwise 3 x 3) and `[b][1]` (BatchNorm + sMLPBlock) on (B, C, H, W), `[b][3]` (LayerNorm + MLP) on
+    channel-last (B, H, W, C)."""
 
     def __init__(self, dim, fn, norm=nn.LayerNorm):
         super().__init__()
@@ -48,8 +50,9 @@ class PatchMerging(Block):
         self.norm = norm_layer(4 * dim)
 
 
-class sMLPBlock(Holder):
-    """sparse_mlp.py:61-66."""
+class sMLPBlock(Block):
+    """sparse_mlp.py:61-74.  Inside a SparseMLP it runs on its own like the reference's (:68-74): (B, C, H, W) -> fuse([proj_h x | proj_w x | x]),
+    no normalisation, no residual; round 6."""
 
     def __init__(self, h=224, w=224, d_model=3):
         super().__init__()
@@ -105,6 +108,10 @@ class SparseMLP(E.EngineModule):
         for li, stage in enumerate(self.layers):
             for bi, blk in enumerate(stage.model):
                 blk.__dict__["_owner"] = (self, (li, bi))          # lets `model.layers[l].model[b](x)` run (common.BlockSequential)
+                blk[0].__dict__["_owner"] = (self, (li, (bi, "pre0")))    # ... its PreNormResidual thirds and the sMLPBlock (round 6)
+                blk[1].__dict__["_owner"] = (self, (li, (bi, "pre1")))
+                blk[3].__dict__["_owner"] = (self, (li, (bi, "pre3")))
+                blk[1].fn[0].__dict__["_owner"] = (self, (li, (bi, "smlp")))
             stage.__dict__["_owner"] = (self, (li, "layer"))       # ... `model.layers[l](x)`: the blocks, then the PatchMerging where pooling
             stage.patch_merge[1].__dict__["_owner"] = (self, (li, "merge"))
 
@@ -152,6 +159,50 @@ class SparseMLP(E.EngineModule):
         pk["head.w"] = E.pack_matrix(self.mlp_head[3].weight, dtype, device)
         pk["head.b"] = E.f32(self.mlp_head[3].bias, device)
         return pk
+
+    def _part(self, ws, pk, li, bi, stage, cur, tmp, B, part):
+        """One inner module of block `layers[li].model[bi]` on its own (round 6): "pre0" = x + dwconv(BN x), "pre1" = x + sMLPBlock(BN x),
+        "smlp" = sMLPBlock(x) (identity in place of the BatchNorm affine, no residual), "pre3" = x + MLP(LN x).  The unfused kernels of the
+        block, one sublayer at a time; returns the result buffer."""
+        H, W, C, depth, ef = stage.geom
+        rows = B * H * W
+        p = "l%d.b%d." % (li, bi)
+        if part == "pre0":
+            E.dwconv_affine_nhwc(cur, tmp, B, H, W, C, 3, pk[p + "dw.w"], pk[p + "dw.b"], pk[p + "dw.s"], pk[p + "dw.h"])
+            return tmp
+        if part == "pre3":
+            channel_mlp(ws, cur, rows, C, pk, p + "ff.", C * ef, tag="l%d.cm" % li)
+            return cur
+        plain = part == "smlp"
+        one = ws.get("part.one", (max(C, W * C),), torch.float32, fill=1.0)
+        zero = ws.get("part.zero", (max(C, W * C),), torch.float32)
+        bs, bh = (one[:C], zero[:C]) if plain else (pk[p + "bn.s"], pk[p + "bn.h"])
+        if (p + "mix.wh") in pk:
+            cat3 = ws.get("l%d.cat3" % li, (rows, 3 * C))
+            E.smlp_mix(cur, C, B, H, W, C, bs, bh, pk[p + "mix.wh"], pk[p + "mix.bh"], pk[p + "mix.ww"], pk[p + "mix.bw"], cat3, 3 * C)
+            E.gemm(cat3, pk[p + "fu.w3"], tmp, rows, C, 3 * C, bias=pk[p + "fu.b"], R=None if plain else cur, res=N.RES_NONE if plain else N.RES_ADD,
+                   tag="smlp_fuse")
+            return tmp
+        tgk = ("l%d.b0.pw.tg" % li) in pk
+        hp, wp = E.round_up(H, 32 if tgk else 8), E.round_up(W, 32 if tgk else 8)
+        xh = ws.get("l%d.xh" % li, (rows, C))
+        cat = ws.get("l%d.cat" % li, (rows, 2 * C))
+        xt_w = ws.get("l%d.xtw" % li, (B * H * C, wp))
+        xt_h = ws.get("l%d.xth" % li, (B * W * C, hp))
+        E.norm_apply(cur, rows, C, C, gamma=bs, beta=bh, out_rm=cat[:, C:], ld_rm=2 * C, out_tt=xt_w, S=W, ld_tt=wp)
+        E.norm_apply(cur, B * H, W * C, W * C, gamma=one[:W * C] if plain else pk[p + "bn.sw"], beta=zero[:W * C] if plain else pk[p + "bn.hw"],
+                     out_tt=xt_h, S=H, ld_tt=hp)
+        if tgk:
+            tw, th = pk[p + "pw.tg"], pk[p + "ph.tg"]
+            E.token_gemm(xt_w, wp, B * H * C, W, tw[0], tw[1], tw[2], cat, 2 * C, C)
+            E.token_gemm(xt_h, hp, B * W * C, H, th[0], th[1], th[2], xh, W * C, W * C)
+        else:
+            E.gemm(xt_w, pk[p + "pw.w"], cat, B * H * C, W, wp, ldc=2 * C, bias=pk[p + "pw.b"], out_mode=N.OUT_TOKEN_T, t_rows=C, t_tokens=W, tag="smlp_w")
+            E.gemm(xt_h, pk[p + "ph.w"], xh, B * W * C, H, hp, ldc=W * C, bias=pk[p + "ph.b"], out_mode=N.OUT_TOKEN_T, t_rows=W * C, t_tokens=H,
+                   tag="smlp_h")
+        E.gemm(xh, pk[p + "fu.wh"], tmp, rows, C, C, bias=pk[p + "fu.b"], R=None if plain else cur, res=N.RES_NONE if plain else N.RES_ADD, tag="smlp_fuse")
+        E.gemm(cat, pk[p + "fu.wr"], tmp, rows, C, 2 * C, R=tmp, res=N.RES_ADD, tag="smlp_fuse")
+        return tmp
 
     def _block(self, ws, pk, li, bi, stage, cur, tmp, B):
         """Block `layers[li].model[bi]` on channel-last rows `cur` (B*H*W, C) with `tmp` as the other half of the ping-pong pair (a stencil
@@ -255,6 +306,16 @@ class SparseMLP(E.EngineModule):
                     cur = self._merge(ws, pk, li, cur, B, H, W, C)
                     H, W, C = H // 2, W // 2, 2 * C
                 return cur.reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
+        if isinstance(bi, tuple) and bi[1] == "pre3":             # the channel MLP third: channel-last in and out (sparse_mlp.py:93-101)
+            if x.dim() != 4 or tuple(x.shape[1:]) != (H, W, C):
+                raise ValueError("expected a channel-last (B, %d, %d, %d) tensor" % (H, W, C))
+            B = x.shape[0]
+            with E.on_device(x):
+                pk = self._get_pack(x.dtype, x.device)
+                ws = self._get_space(("block", B, H, W, C), x.dtype, x.device)
+                cur = ws.get("blk.x", (B * H * W, C))
+                cur.copy_(x.reshape(B * H * W, C))
+                return self._part(ws, pk, li, bi[0], stage, cur, None, B, "pre3").reshape(B, H, W, C).clone()
         if x.dim() != 4 or tuple(x.shape[1:]) != (C, H, W):
             raise ValueError("expected a (B, %d, %d, %d) tensor" % (C, H, W))
         B = x.shape[0]
@@ -264,6 +325,9 @@ class SparseMLP(E.EngineModule):
             ws = self._get_space(("block", B, H, W, C), x.dtype, x.device)     # (C: blocks of different stages can meet at one map size)
             cur = ws.get("blk.x", (rows, C))
             cur.copy_(x.permute(0, 2, 3, 1).reshape(rows, C))                          # channel-last rows, as the stages keep them
+            if isinstance(bi, tuple):                                  # an inner module of block bi[0] (round 6)
+                out = self._part(ws, pk, li, bi[0], stage, cur, ws.get("blk.tmp", (rows, C)), B, bi[1])
+                return out.reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
             cur, _ = self._block(ws, pk, li, bi, stage, cur, ws.get("blk.tmp", (rows, C)), B)
             return cur.reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
 

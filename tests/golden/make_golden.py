@@ -11,7 +11,7 @@ The reference is imported read-only through the shim of SURVEY.md section 8c:
 Nothing from the reference's source text is written to the repo: fixtures hold inputs,
 weights (tiny configs only) and the reference's outputs.
 
-Usage:  python tests/golden/make_golden.py [--only tiny|real|ops|manifest|s2lowp|lowp|train] [--check]
+Usage:  python tests/golden/make_golden.py [--only tiny|real|ops|manifest|s2lowp|lowp|train|leaf] [--check]
 """
 import argparse
 import importlib
@@ -584,6 +584,42 @@ def make_s2_lowp(ref):
         torch.set_num_threads(nt)
 
 
+def make_leaf(ref):
+    """leaf_modules.npz (round 6): the inner modules of a block that the reference lets a caller run on their own -- what each of them is
+    fed and what it returns inside the tiny fixtures' forward, captured with forward hooks on the REFERENCE model:
+      hiremlp:   layers[0].model[b][0] / [b][1] (the two PreNormResidual), [b][0].fn[0] (HireMLPBlock), its proj_h (FeedForward), b = 0, 1
+                 (block 1 crosses regions); sparsemlp: layers[1].model[0][0] / [1] / [3] (PreNormResidual) and [1].fn[0] (sMLPBlock);
+      convmixer: blocks[0][0] (Residual)."""
+    out = {}
+    plan = {
+        "hiremlp": (ref["hire_mlp"].HireMLP, "tiny_hiremlp.npz",
+                    ["layers.0.model.0.0", "layers.0.model.0.1", "layers.0.model.0.0.fn.0", "layers.0.model.0.0.fn.0.proj_h",
+                     "layers.0.model.1.0", "layers.0.model.1.0.fn.0", "layers.1.model.0.0.fn.0"]),
+        "sparsemlp": (ref["sparse_mlp"].SparseMLP, "tiny_sparsemlp.npz",
+                      ["layers.1.model.0.0", "layers.1.model.0.1", "layers.1.model.0.3", "layers.1.model.0.1.fn.0", "layers.0.model.0.1.fn.0"]),
+        "convmixer": (ref["conv_mixer"].ConvMixer, "tiny_convmixer.npz", ["blocks.0.0", "blocks.1.0"]),
+    }
+    for tag, (ctor, fixture, paths) in plan.items():
+        z = np.load(os.path.join(HERE, fixture))
+        kw = json.loads(str(z["kwargs"]))
+        model = ctor(**kw).eval()
+        model.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}, strict=True)
+        mods = dict(model.named_modules())
+        hooks = []
+        for pth in paths:
+            def hook(m, inp, outp, pth=pth):
+                out["%s/%s/in" % (tag, pth)] = inp[0].detach().numpy().copy()
+                out["%s/%s/out" % (tag, pth)] = outp.detach().numpy().copy()
+            hooks.append(mods[pth].register_forward_hook(hook))
+        with torch.no_grad():
+            model(torch.from_numpy(z["input"]))
+        for h in hooks:
+            h.remove()
+        out[tag + "/paths"] = np.array(json.dumps(paths))
+        print("leaf %-10s %d modules:" % (tag, len(paths)), ", ".join("%s %s->%s" % (p_, out["%s/%s/in" % (tag, p_)].shape, out["%s/%s/out" % (tag, p_)].shape) for p_ in paths))
+    np.savez_compressed(os.path.join(HERE, "leaf_modules.npz"), **out)
+
+
 def make_train(ref):
     """train_tiny.npz (round 5): what the REFERENCE's own autograd and train-mode BatchNorm produce.
       mixer/...      MLPMixerForImageClassification (the tiny fixture's weights and input) in train(): logits, and the gradient of
@@ -733,6 +769,8 @@ def main():
         make_s2_lowp(ref)
     if args.only in (None, "lowp"):
         make_real_lowp(ref)
+    if args.only in (None, "leaf"):
+        make_leaf(ref)
     if args.only in (None, "train"):
         make_train(ref)
 
