@@ -147,8 +147,68 @@ class MLPMixer(E.EngineModule):
         self._dims = (num_patches, d_model, depth, expansion_factor)
         self.__dict__["fused_token_mlp"] = os.environ.get("MLPK_NO_FUSED_TOKEN", "0") != "1"
 
+    # ---- widths that are not whole 16-byte chunks (round 6; the reference takes any d_model, mlp_mixer.py:46-54) ----
+    # The activations carry round_up(C, 8) channels; the extra ones are EXACTLY zero everywhere: zero rows in every weight that produces
+    # channels (patch embedding, channel fc2) with zero bias, zero LayerNorm gamma / beta, zero weight columns wherever channels are
+    # contracted -- and a 0 / 1 channel mask as the per-row scale of the token-mixing product's epilogue (mlpk.h rscale: a padded channel
+    # would otherwise pick up W2 gelu(b1) + b2, the same constant for every image).  LayerNorm statistics are taken over the C real
+    # channels (mlpk_row_stats with length C on rows of pitch Cp).  Every product is the unfused GEMM path: a drop-in hole closed, not
+    # a fast path.
+    def _cpad(self):
+        C = self._dims[1]
+        return E.round_up(C, 8) if C % 8 else None
+
+    def _pack_blocks_padded(self, pk, dtype, device, Cp):
+        S, C, depth, ef = self._dims
+        hid = C * ef
+        hidp = E.round_up(hid, 8)
+
+        def padv(v, n):
+            out = torch.zeros((n,), dtype=torch.float32, device=device)
+            out[:v.numel()] = v.detach().to(device=device, dtype=torch.float32).reshape(-1)
+            return out
+        pk["mask"] = padv(torch.ones(C), Cp)
+        for i, blk in enumerate(self.model):
+            tok, ch = blk[0], blk[1]
+            p = "b%d." % i
+            pk[p + "tok.ln.g"], pk[p + "tok.ln.b"] = padv(tok.norm.weight, Cp), padv(tok.norm.bias, Cp)
+            pk[p + "tok.fc1.w"] = E.pack_matrix(tok.fn.net[0].weight, dtype, device, kpad=32)
+            pk[p + "tok.fc1.b"] = E.f32(tok.fn.net[0].bias, device)
+            pk[p + "tok.fc2.w"] = E.pack_matrix(tok.fn.net[3].weight, dtype, device, kpad=32)
+            pk[p + "tok.fc2.b"] = E.f32(tok.fn.net[3].bias, device)
+            w1 = torch.zeros((hidp, C), dtype=torch.float32, device=device)
+            w1[:hid] = ch.fn.net[0].weight.detach().to(device=device, dtype=torch.float32)
+            w2 = torch.zeros((Cp, hid), dtype=torch.float32, device=device)
+            w2[:C] = ch.fn.net[3].weight.detach().to(device=device, dtype=torch.float32)
+            pk[p + "ch.fc1.w"], pk[p + "ch.fc1.b"], pk[p + "ch.fc1.csum"] = E.pack_ln_folded(w1, padv(ch.fn.net[0].bias, hidp), ch.norm.weight, ch.norm.bias,
+                                                                                          dtype, device)
+            pk[p + "ch.fc2.w"] = E.pack_matrix(w2, dtype, device)
+            pk[p + "ch.fc2.b"] = padv(ch.fn.net[3].bias, Cp)
+
+    def _run_blocks_padded(self, ws, pk, x, B, Cp):
+        """x: (B*S, Cp) channel-last tokens with zero padding channels, updated in place."""
+        S, C, depth, ef = self._dims
+        rows = B * S
+        sp = E.round_up(S, 32)
+        th = S * ef
+        thp = E.round_up(th, 32)
+        hidp = E.round_up(C * ef, 8)
+        xt = ws.get("tok.xt", (B * Cp, sp))
+        ht = ws.get("tok.h", (B * Cp, thp))
+        for i in range(depth):
+            p = "b%d." % i
+            mean, rstd = layernorm_stats(ws, x, rows, C)
+            E.norm_apply(x, rows, Cp, Cp, mean=mean, rstd=rstd, gamma=pk[p + "tok.ln.g"], beta=pk[p + "tok.ln.b"], out_tt=xt, S=S, ld_tt=sp)
+            E.gemm(xt, pk[p + "tok.fc1.w"], ht, B * Cp, th, sp, bias=pk[p + "tok.fc1.b"], act=N.ACT_GELU, tag="token_fc1")
+            E.gemm(ht, pk[p + "tok.fc2.w"], x, B * Cp, S, thp, ldc=Cp, bias=pk[p + "tok.fc2.b"], R=x, ldr=Cp, res=N.RES_ADD,
+                   out_mode=N.OUT_TOKEN_T, t_rows=Cp, t_tokens=S, rscale=pk["mask"], rperiod=Cp, tag="token_fc2")
+            channel_mlp(ws, x, rows, Cp, pk, p + "ch.", hidp, stats=layernorm_stats(ws, x, rows, C, tag="cm.ln"))
+        return x
+
     # ---- weight packing: compute-dtype matrices (K zero-padded to 16 B), fp32 vectors ----
     def _pack_blocks(self, pk, dtype, device):
+        if self._cpad():
+            return self._pack_blocks_padded(pk, dtype, device, self._cpad())
         for i, blk in enumerate(self.model):
             tok, ch = blk[0], blk[1]
             p = "b%d." % i
@@ -231,6 +291,12 @@ class MLPMixer(E.EngineModule):
         B = x.shape[0]
         pk = self._get_pack(x.dtype, x.device)
         ws = self._get_space(B, x.dtype, x.device)
+        Cp = self._cpad()
+        if Cp:
+            buf = ws.get("x", (B * S, Cp))
+            buf[:, :C].copy_(x.reshape(B * S, C))
+            self._run_blocks_padded(ws, pk, buf, B, Cp)
+            return buf[:, :C].reshape(B, S, C).clone()
         buf = ws.get("x", (B * S, C))
         buf.copy_(x.reshape(B * S, C))
         self._run_blocks(ws, pk, buf, B)
@@ -253,6 +319,19 @@ class MLPMixerForImageClassification(MLPMixer):
     def _pack(self, dtype, device):
         pk = {}
         self._pack_blocks(pk, dtype, device)
+        Cp = self._cpad()
+        if Cp:
+            C = self._dims[1]
+            conv = self.patcher[0]
+            wz = torch.zeros((Cp, conv.weight[0].numel()), dtype=torch.float32, device=device)
+            wz[:C] = conv.weight.detach().to(device=device, dtype=torch.float32).reshape(C, -1)
+            pk["embed.w"] = E.pack_matrix(wz, dtype, device)
+            for key, v in (("embed.b", conv.bias), ("active.g", self.active.weight), ("active.b", self.active.bias)):
+                pk[key] = torch.zeros((Cp,), dtype=torch.float32, device=device)
+                pk[key][:C] = v.detach().to(device=device, dtype=torch.float32)
+            pk["head.w"] = E.pack_matrix(self.mlp_head[0].weight, dtype, device)            # (classes, C -> Cp zero columns)
+            pk["head.b"] = E.f32(self.mlp_head[0].bias, device)
+            return pk
         pk["embed.w"] = E.pack_matrix(self.patcher[0].weight, dtype, device)
         pk["embed.b"] = E.f32(self.patcher[0].bias, device)
         pk["active.g"], pk["active.b"] = E.f32(self.active.weight, device), E.f32(self.active.bias, device)
@@ -309,6 +388,17 @@ class MLPMixerForImageClassification(MLPMixer):
         pk = self._get_pack(cd, x.device)
         ws = self._get_space(B, cd, x.device)
         x = x.contiguous()
+        Cp = self._cpad()
+        if Cp:
+            # any d_model (mlp_mixer.py:46-54): zero padding channels up to whole 16-byte chunks, see _cpad
+            tokens, hp, wp = embed_patches(ws, "embed", x, pk["embed.w"], pk["embed.b"], cd, self._patch, out=ws.get("x", (B * S, Cp)))
+            if hp * wp != S:
+                raise ValueError("input size gives %d patches, the model was built for %d" % (hp * wp, S))
+            self._run_blocks_padded(ws, pk, tokens, B, Cp)
+            mean, rstd = layernorm_stats(ws, tokens, B * S, C)
+            pooled = ws.get("pooled", (B, Cp))
+            E.pool_mean(tokens, B, S, Cp, Cp, pooled, Cp, mean=mean, rstd=rstd, gamma=pk["active.g"], beta=pk["active.b"])
+            return head_linear(ws, pooled, B, Cp, pk["head.w"], pk["head.b"], self._num_classes, x.dtype)
         tokens, hp, wp = embed_patches(ws, "embed", x, pk["embed.w"], pk["embed.b"], cd, self._patch,
                                        out=ws.get("x", (B * S, C)))
         if hp * wp != S:
