@@ -145,7 +145,7 @@ def lib():
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(handle, name)          # AttributeError if a declared symbol is not exported
             fn.restype, fn.argtypes = res, args
-        if handle.mlpk_abi_version() != 9:
+        if handle.mlpk_abi_version() != 10:
             raise MlpkError("libmlpk.so ABI version mismatch")
         _lib = handle
     return _lib

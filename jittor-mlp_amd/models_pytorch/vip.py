@@ -28,11 +28,24 @@ class PreNormResidual(PreNormResidualMLP):
 
 
 class ParallelSum(Holder):
-    """Sum of branches (vip.py:16-22)."""
+    """Sum of branches (vip.py:16-22).  Inside a model a parameter container; on its own (round 6) callable like the reference's on
+    (b, h, w, c): the three Permute-MLP branches as NT GEMMs, their sum by the weighted-sum kernel with unit weights (mlpk_split_apply)."""
 
     def __init__(self, *fns):
         super().__init__()
         self.fns = nn.ModuleList(fns)
+
+    def forward(self, x):
+        E.require_gpu(x, "ParallelSum.forward")
+        if x.dim() != 4 or len(self.fns) != 3:
+            raise NotImplementedError("ParallelSum runs on its own around the three Permute-MLP branches of a (b, h, w, c) tensor")
+        b, h, w, c = x.shape
+        with E.on_device(x):
+            xs = [_branch_forward(f, x, k).reshape(b * h * w, c) for f, k in zip(self.fns, "hwc")]
+            ones = torch.ones((b, 3 * c), dtype=torch.float32, device=x.device)
+            out = torch.empty((b * h * w, c), dtype=x.dtype, device=x.device)
+            E.split_apply(xs[0], xs[1], xs[2], c, c, c, b, h, w, c, N.SHIFT_NONE, ones, out, c)
+            return out.view(b, h, w, c)
 
 
 class ParallelWeightedSum(Holder):

@@ -589,7 +589,7 @@ def make_leaf(ref):
     fed and what it returns inside the tiny fixtures' forward, captured with forward hooks on the REFERENCE model:
       hiremlp:   layers[0].model[b][0] / [b][1] (the two PreNormResidual), [b][0].fn[0] (HireMLPBlock), its proj_h (FeedForward), b = 0, 1
                  (block 1 crosses regions); sparsemlp: layers[1].model[0][0] / [1] / [3] (PreNormResidual) and [1].fn[0] (sMLPBlock);
-      convmixer: blocks[0][0] (Residual)."""
+      convmixer: blocks[0][0] (Residual); vip_unweighted: blocks.model[b][0].fn[0] (ParallelSum of the plain Permutator)."""
     out = {}
     plan = {
         "hiremlp": (ref["hire_mlp"].HireMLP, "tiny_hiremlp.npz",
@@ -598,6 +598,7 @@ def make_leaf(ref):
         "sparsemlp": (ref["sparse_mlp"].SparseMLP, "tiny_sparsemlp.npz",
                       ["layers.1.model.0.0", "layers.1.model.0.1", "layers.1.model.0.3", "layers.1.model.0.1.fn.0", "layers.0.model.0.1.fn.0"]),
         "convmixer": (ref["conv_mixer"].ConvMixer, "tiny_convmixer.npz", ["blocks.0.0", "blocks.1.0"]),
+        "vip_unweighted": (ref["vip"].ViP, "tiny_vip_unweighted.npz", ["blocks.model.0.0.fn.0", "blocks.model.1.0.fn.0"]),     # ParallelSum (vip.py:16-22)
     }
     for tag, (ctor, fixture, paths) in plan.items():
         z = np.load(os.path.join(HERE, fixture))

@@ -974,11 +974,11 @@ def test_inner_modules_callable_like_the_reference(dtype):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("tag", ["hiremlp", "sparsemlp", "convmixer"])
+@pytest.mark.parametrize("tag", ["hiremlp", "sparsemlp", "convmixer", "vip_unweighted"])
 def test_leaf_modules_callable_like_the_reference(tag, dtype):
     """Round 6 (VERDICT r5 missing 4): the inner modules of a block that only held parameters -- Hire-MLP's two `PreNormResidual`s, `HireMLPBlock`
     (hire_mlp.py:8-15,97-152) and `FeedForward` (:33-42), Sparse-MLP's three `PreNormResidual`s and `sMLPBlock` (sparse_mlp.py:8-15,61-74),
-    ConvMixer's `Residual` (conv_mixer.py:5-11) -- run on their own inside a model, fed what the REFERENCE fed them in the tiny fixture's
+    ConvMixer's `Residual` (conv_mixer.py:5-11), ViP's `ParallelSum` (vip.py:16-22) -- run on their own inside a model, fed what the REFERENCE fed them in the tiny fixture's
     forward and compared with what the reference's module returned (tests/golden/leaf_modules.npz, make_golden.py --only leaf: forward hooks
     on the reference model)."""
     pkg = load_pkg()
