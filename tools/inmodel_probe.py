@@ -11,7 +11,10 @@ ctor, kw, _ = bench.MODELS[name]
 torch.manual_seed(0)
 model = getattr(pkg.models_pytorch, ctor)(**kw).eval().cuda()
 x = torch.rand(256, 3, 224, 224, device="cuda").bfloat16()
-NAMES = ["gemm", "linear_gelu", "token_gemm_ln", "token_gemm", "stats_finalize_planar", "row_stats", "norm_apply", "channel_mlp_fused", "token_mlp_ln"]
+NAMES = ["gemm", "linear_gelu", "token_gemm_ln", "token_gemm", "token_mlp", "token_mlp_ln", "stats_finalize_planar", "row_stats", "norm_apply", "channel_mlp_fused",
+         "vip_branch", "vip_split_apply", "vip_unpermute", "split_sum", "split_softmax", "split_apply", "s2_shift", "dwconv_nhwc", "dwconv_affine_nhwc", "im2col",
+         "patchify", "pool_mean", "as_conv2", "norm_shift_nhwc", "smlp_mix", "smlp_mix_dw", "swin_spatial", "hire_gather_ln", "hire_combine_from", "mixshift_nhwc",
+         "cycle_shift_ln", "layernorm_transpose", "add_periodic", "convert"]
 NAMES = [n for n in NAMES if hasattr(E, n)]
 orig = {n: getattr(E, n) for n in NAMES}
 log = []          # (name, args, kwargs, ev0, ev1)
