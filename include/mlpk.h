@@ -620,6 +620,36 @@ int mlpk_smlp_mix_dw(int dtype, const void* x, int ldx, int B, int H, int W, int
  * of SwinMLP added to every image's tokens (swin_mlp.py:386-388,437-438: ape=True) */
 int mlpk_add_periodic(int dtype, void* x, int64_t ldx, const float* t, int64_t rows, int C, int period, void* stream);
 
+/* ---- backward of the other families (ABI 11, round 6) ----------------------------------------------------------
+ * The element-wise, normalisation and remap derivatives that the train mode of gMLP (g_mlp.py:10-39), ResMLP (res_mlp.py:11-57), AS-MLP
+ * (as_mlp.py:55-162,182-216) and ConvMixer (conv_mixer.py:5-39) needs beside the ABI-9 set; products stay mlpk_gemm_nt calls.  fp32 math,
+ * one rounding per stored value, fixed summation orders. */
+/* per-column / per-row-group combinations of row-major tensors (rows x cols; strides lda / ldb / ldo; g, h, k fp32 vectors):
+ *   mode 0: out = a * g[c] + h[c]  (g NULL = 1, h NULL = 0)   Aff (res_mlp.py:17-19); the affine half of GroupNorm / BatchNorm; dx of a scale
+ *   mode 1: out = a * b                                       the SGU gate u * v (g_mlp.py:21) and both its derivatives
+ *   mode 2: out = a + g[c] * b     (g NULL: a + b)            x + gamma * f(x) (res_mlp.py:53,55); sums of gradient paths
+ *   mode 3: out = a * g[m / period]                           stochastic depth's per-sample scale (as_mlp.py:159-160) and its derivative
+ *   mode 4: out = a * g[c] + b * h[c] + k[c]                  BatchNorm backward on batch statistics (conv_mixer.py:20,28,31) */
+int mlpk_ew_cols(int dtype, int mode, const void* a, int64_t lda, const void* b, int64_t ldb, const float* g, const float* h, const float* k,
+                 void* out, int64_t ldo, int64_t rows, int cols, int period, void* stream);
+/* out[c] = sum over rows of x[r, c] * y[r, c], fp32: the gradient of a per-channel scale (Aff alpha, gamma_1 / gamma_2, GroupNorm / BatchNorm weight) */
+int mlpk_col_dot(int dtype, const void* x, int64_t ldx, const void* y, int64_t ldy, int64_t rows, int cols, float* out, void* stream);
+/* GroupNorm(1, C) backward on channel-last samples of glen = H W C contiguous values (as_mlp.py:343-344): xh = the normalised values,
+ * g = dy * gamma[c];  dx = rstd[b] * (g - mean_b(g) - xh * mean_b(g xh)) */
+int mlpk_group_norm_backward(int dtype, const void* xh, const void* g, const float* rstd, void* dx, int groups, int64_t glen, void* stream);
+/* adjoint of mlpk_shift_nhwc: grad_in[n,h,w,c] = grad_out[n,h-s,w,c] (dim 2) | grad_out[n,h,w-s,c] (dim 3), zero outside
+ * (shift_backward_grad_input_kernel, utils/shift_cuda.py:75-103, on the channel-last layout) */
+int mlpk_shift_nhwc_backward(int dtype, const void* grad_out, void* grad_in, int N, int H, int W, int C, int kernel_size, int dim, void* stream);
+/* PatchMerging's gather on channel-last tensors (as_mlp.py:207-211; the order of mlpk_patchify order 1) and its adjoint:
+ * dir 0: src (B,H,W,C) -> dst (B,H/2,W/2,4C);  dir 1: src (B,H/2,W/2,4C) -> dst (B,H,W,C).  H, W even. */
+int mlpk_merge2x2_nhwc(int dtype, int dir, const void* src, void* dst, int B, int H, int W, int C, void* stream);
+/* depthwise Conv2d(k, groups = C, padding = "same") on (B,H,W,C) WITHOUT an epilogue (train mode keeps the pre-activation: conv_mixer.py:25),
+ * w fp32 [k*k][C] tap-major like mlpk_dwconv_nhwc, bias fp32 [C] or NULL;  adjoint = 1: the gradient w.r.t. the input (bias ignored) */
+int mlpk_dwconv_plain_nhwc(int dtype, int adjoint, const void* in, void* out, int B, int H, int W, int C, int k, const float* w, const float* bias,
+                           void* stream);
+/* dw[i*k + j][c] = sum over (b, y, x) of dy[b,y,x,c] * x[b, y+i-p, x+j-p, c], p = (k-1)/2: the gradient of the depthwise taps, fp32 */
+int mlpk_dwconv_wgrad_nhwc(int dtype, const void* x, const void* dy, float* dw, int B, int H, int W, int C, int k, void* stream);
+
 /* ---- small utilities ------------------------------------------------------------------------ */
 /* dst[i] = (dst_dtype) src[i], n elements */
 int mlpk_convert(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);

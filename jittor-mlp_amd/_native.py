@@ -124,6 +124,13 @@ PROTOTYPES = {
     "mlpk_mixshift_nhwc": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 5 + [ctypes.POINTER(c_int), ctypes.POINTER(c_int)] + [c_void_p] * 4 + [c_void_p]),
     "mlpk_window_gather": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     "mlpk_window_scatter_add": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
+    "mlpk_ew_cols": (c_int, [c_int, c_int, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_int, c_int, c_void_p]),
+    "mlpk_col_dot": (c_int, [c_int, c_void_p, c_i64, c_void_p, c_i64, c_i64, c_int, c_void_p, c_void_p]),
+    "mlpk_group_norm_backward": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_void_p]),
+    "mlpk_shift_nhwc_backward": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "mlpk_merge2x2_nhwc": (c_int, [c_int, c_int, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
+    "mlpk_dwconv_plain_nhwc": (c_int, [c_int, c_int, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p]),
+    "mlpk_dwconv_wgrad_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     "mlpk_convert": (c_int, [c_int, c_int, c_void_p, c_void_p, c_i64, c_void_p]),
 }
 
@@ -145,7 +152,7 @@ def lib():
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(handle, name)          # AttributeError if a declared symbol is not exported
             fn.restype, fn.argtypes = res, args
-        if handle.mlpk_abi_version() != 10:
+        if handle.mlpk_abi_version() != 11:
             raise MlpkError("libmlpk.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -254,3 +254,291 @@ def batchnorm_train_affine(bn, mean, var, rows):
             bn.running_var.mul_(1 - mom).add_(mom * (var * (rows / max(rows - 1, 1))).to(bn.running_var.dtype))
             bn.num_batches_tracked += 1
     return scale.float().contiguous(), shift.float().contiguous()
+
+
+# ---- round 6: the pieces the train mode of gMLP, ResMLP, AS-MLP and ConvMixer adds (ABI 11) ----------------------------------------------
+def _ew(mode, a, b=None, g=None, h=None, k=None, period=1, out=None):
+    """mlpk_ew_cols on (rows, cols) tensors (any row stride); g / h / k fp32 vectors"""
+    rows, cols = a.shape
+    out = torch.empty((rows, cols), dtype=a.dtype, device=a.device) if out is None else out
+    assert a.stride(1) == 1 and (b is None or (b.stride(1) == 1 and b.shape == a.shape and b.dtype == a.dtype))
+    N.check(N.lib().mlpk_ew_cols(E.dtype_code(a.dtype), mode, E.ptr(a), a.stride(0), E.ptr(b), b.stride(0) if b is not None else 0, E.ptr(g), E.ptr(h),
+                                 E.ptr(k), E.ptr(out), out.stride(0), rows, cols, period, E.stream()), "mlpk_ew_cols")
+    return out
+
+
+def col_dot(x, y):
+    rows, cols = x.shape
+    assert x.stride(1) == 1 and y.stride(1) == 1 and x.shape == y.shape and x.dtype == y.dtype
+    out = torch.empty((cols,), dtype=torch.float32, device=x.device)
+    N.check(N.lib().mlpk_col_dot(E.dtype_code(x.dtype), E.ptr(x), x.stride(0), E.ptr(y), y.stride(0), rows, cols, E.ptr(out), E.stream()), "mlpk_col_dot")
+    return out
+
+
+def _rows(t):
+    """a gradient as the kernels take it: unit column stride (a chunk of a wider tensor keeps its row stride)"""
+    return t if t.stride(1) == 1 else t.contiguous()
+
+
+class Affine(torch.autograd.Function):
+    """y = x * alpha[c] + beta[c] on (M, C) rows: Aff (res_mlp.py:11-19), the affine half of GroupNorm / BatchNorm.  beta may be None."""
+
+    @staticmethod
+    def forward(ctx, x, alpha, beta):
+        with E.on_device(x):
+            a32 = E.f32(alpha.reshape(-1), x.device)
+            y = _ew(0, x, g=a32, h=E.f32(beta.reshape(-1), x.device) if beta is not None else None)
+        ctx.save_for_backward(x, a32)
+        ctx.pshape = (tuple(alpha.shape), tuple(beta.shape) if beta is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, a32 = ctx.saved_tensors
+        dy = _rows(dy)
+        dx = da = db = None
+        with E.on_device(x):
+            if ctx.needs_input_grad[0]:
+                dx = _ew(0, dy, g=a32)
+            if ctx.needs_input_grad[1]:
+                da = col_dot(dy, x).reshape(ctx.pshape[0])
+            if ctx.pshape[1] is not None and ctx.needs_input_grad[2]:
+                db = col_sum(dy, dy.shape[0], dy.shape[1]).reshape(ctx.pshape[1])
+        return dx, da, db
+
+
+class ScaleAdd(torch.autograd.Function):
+    """out = x + gamma[c] * z (res_mlp.py:53,55: x + gamma_1 * token_mix(x));  gamma None: x + z"""
+
+    @staticmethod
+    def forward(ctx, x, z, gamma):
+        with E.on_device(x):
+            g32 = E.f32(gamma.reshape(-1), x.device) if gamma is not None else None
+            out = _ew(2, x, b=_rows(z), g=g32)
+        ctx.save_for_backward(z, g32)
+        ctx.gshape = tuple(gamma.shape) if gamma is not None else None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, g32 = ctx.saved_tensors
+        dy = _rows(dy)
+        dz = dg = None
+        with E.on_device(dy):
+            if ctx.needs_input_grad[1]:
+                dz = _ew(0, dy, g=g32) if g32 is not None else dy
+            if g32 is not None and ctx.needs_input_grad[2]:
+                dg = col_dot(dy, _rows(z)).reshape(ctx.gshape)
+        return dy, dz, dg
+
+
+class Mul(torch.autograd.Function):
+    """out = u * v (the SGU gate, g_mlp.py:21); u, v: (M, C) rows, possibly the two halves of one wider tensor"""
+
+    @staticmethod
+    def forward(ctx, u, v):
+        with E.on_device(u):
+            out = _ew(1, u, b=v)
+        ctx.save_for_backward(u, v)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        u, v = ctx.saved_tensors
+        dy = _rows(dy)
+        with E.on_device(dy):
+            return _ew(1, dy, b=v), _ew(1, dy, b=u)
+
+
+class RowScale(torch.autograd.Function):
+    """out[m] = x[m] * s[m // period]: stochastic depth's keep / (1 - p) per sample (as_mlp.py:159-160); s fp32, no gradient"""
+
+    @staticmethod
+    def forward(ctx, x, s, period):
+        ctx.save_for_backward(s)
+        ctx.period = period
+        with E.on_device(x):
+            return _ew(3, x, g=s, period=period)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (s,) = ctx.saved_tensors
+        with E.on_device(dy):
+            return _ew(3, _rows(dy), g=s, period=ctx.period), None, None
+
+
+class RowsToTokens(torch.autograd.Function):
+    """(B*C, S) rows back to token-major (B*S, C) -- RowsToTokensAdd without the residual (res_mlp.py:53: the product is scaled first)"""
+
+    @staticmethod
+    def forward(ctx, y, B, S, C):
+        ctx.dims = (B, S, C)
+        with E.on_device(y):
+            return transpose(y, B, C, S, ld_out=C)
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, S, C = ctx.dims
+        with E.on_device(dout):
+            return transpose(dout.contiguous(), B, S, C, ld_out=S), None, None, None
+
+
+class GroupNorm1(torch.autograd.Function):
+    """nn.GroupNorm(1, C) (as_mlp.py:343-344 MyNorm) on channel-last samples: x (B * HW, C) contiguous, one statistic per sample"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, B, eps):
+        rows, C = x.shape
+        HW = rows // B
+        dev = x.device
+        x = x.contiguous()
+        with E.on_device(x):
+            mean = torch.empty((B,), dtype=torch.float32, device=dev)
+            rstd = torch.empty_like(mean)
+            E.row_stats(x, B, HW * C, HW * C, mean, rstd, eps=eps)
+            xh = torch.empty_like(x)
+            E.norm_apply(x, rows, C, C, mean=mean, rstd=rstd, stat_group=HW, out_rm=xh, ld_rm=C)
+            g32 = E.f32(gamma, dev)
+            y = _ew(0, xh, g=g32, h=E.f32(beta, dev))
+        ctx.save_for_backward(xh, rstd, g32)
+        ctx.meta = (B, HW * C, tuple(gamma.shape), tuple(beta.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xh, rstd, g32 = ctx.saved_tensors
+        B, glen, gs, bs = ctx.meta
+        dy = dy.contiguous()
+        dx = dg = db = None
+        with E.on_device(dy):
+            if ctx.needs_input_grad[0]:
+                g = _ew(0, dy, g=g32)
+                dx = torch.empty_like(xh)
+                N.check(N.lib().mlpk_group_norm_backward(E.dtype_code(xh.dtype), E.ptr(xh), E.ptr(g), E.ptr(rstd), E.ptr(dx), B, glen, E.stream()),
+                        "mlpk_group_norm_backward")
+            if ctx.needs_input_grad[1]:
+                dg = col_dot(dy, xh).reshape(gs)
+            if ctx.needs_input_grad[2]:
+                db = col_sum(dy, dy.shape[0], dy.shape[1]).reshape(bs)
+        return dx, dg, db, None, None
+
+
+class ShiftNHWC(torch.autograd.Function):
+    """Shift (utils/shift_cuda.py:165-192; torch_shift :177-189) on channel-last rows (B*H*W, C): the reference's one native op and its backward kernel"""
+
+    @staticmethod
+    def forward(ctx, x, B, H, W, ksz, dim):
+        ctx.meta = (B, H, W, x.shape[1], ksz, dim)
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        with E.on_device(x):
+            E.shift_nhwc(x, out, B, H, W, x.shape[1], ksz, dim)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, C, ksz, dim = ctx.meta
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        with E.on_device(dy):
+            N.check(N.lib().mlpk_shift_nhwc_backward(E.dtype_code(dy.dtype), E.ptr(dy), E.ptr(dx), B, H, W, C, ksz, dim, E.stream()), "mlpk_shift_nhwc_backward")
+        return dx, None, None, None, None, None
+
+
+class Merge2x2(torch.autograd.Function):
+    """PatchMerging's strided gather + concatenation (as_mlp.py:207-211) on channel-last rows: (B*H*W, C) -> (B*H/2*W/2, 4C)"""
+
+    @staticmethod
+    def forward(ctx, x, B, H, W):
+        C = x.shape[1]
+        ctx.meta = (B, H, W, C)
+        x = x.contiguous()
+        out = torch.empty((B * (H // 2) * (W // 2), 4 * C), dtype=x.dtype, device=x.device)
+        with E.on_device(x):
+            N.check(N.lib().mlpk_merge2x2_nhwc(E.dtype_code(x.dtype), 0, E.ptr(x), E.ptr(out), B, H, W, C, E.stream()), "mlpk_merge2x2_nhwc")
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, C = ctx.meta
+        dy = dy.contiguous()
+        dx = torch.empty((B * H * W, C), dtype=dy.dtype, device=dy.device)
+        with E.on_device(dy):
+            N.check(N.lib().mlpk_merge2x2_nhwc(E.dtype_code(dy.dtype), 1, E.ptr(dy), E.ptr(dx), B, H, W, C, E.stream()), "mlpk_merge2x2_nhwc")
+        return dx, None, None, None
+
+
+def _taps(w, dev):
+    """depthwise Conv2d weight (C, 1, k, k) -> fp32 [k*k][C] tap-major, the layout of mlpk_dwconv_nhwc"""
+    C, k = w.shape[0], w.shape[-1]
+    return w.detach().to(device=dev, dtype=torch.float32).reshape(C, k * k).t().contiguous()
+
+
+class DepthwiseConv(torch.autograd.Function):
+    """Conv2d(C, C, k, groups=C, padding="same") on channel-last rows (B*H*W, C), no epilogue (conv_mixer.py:25): the pre-activation is kept"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, B, H, W):
+        C, k = x.shape[1], w.shape[-1]
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        with E.on_device(x):
+            wt = _taps(w, x.device)
+            N.check(N.lib().mlpk_dwconv_plain_nhwc(E.dtype_code(x.dtype), 0, E.ptr(x), E.ptr(out), B, H, W, C, k, E.ptr(wt), E.ptr(E.f32(b, x.device)), E.stream()),
+                    "mlpk_dwconv_plain_nhwc")
+        ctx.save_for_backward(x, wt)
+        ctx.meta = (B, H, W, C, k, tuple(w.shape), b is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wt = ctx.saved_tensors
+        B, H, W, C, k, wshape, has_b = ctx.meta
+        dy = dy.contiguous()
+        dx = dw = db = None
+        with E.on_device(dy):
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                N.check(N.lib().mlpk_dwconv_plain_nhwc(E.dtype_code(x.dtype), 1, E.ptr(dy), E.ptr(dx), B, H, W, C, k, E.ptr(wt), None, E.stream()),
+                        "mlpk_dwconv_plain_nhwc")
+            if ctx.needs_input_grad[1]:
+                dwt = torch.empty((k * k, C), dtype=torch.float32, device=x.device)
+                N.check(N.lib().mlpk_dwconv_wgrad_nhwc(E.dtype_code(x.dtype), E.ptr(x), E.ptr(dy), E.ptr(dwt), B, H, W, C, k, E.stream()), "mlpk_dwconv_wgrad_nhwc")
+                dw = dwt.t().reshape(wshape)
+            if has_b and ctx.needs_input_grad[2]:
+                db = col_sum(dy, dy.shape[0], C)
+        return dx, dw, db, None, None, None
+
+
+class BatchNormTrain(torch.autograd.Function):
+    """nn.BatchNorm2d in train mode on channel-last rows (M, C): batch statistics (biased variance) in the forward, the running statistics
+    updated by the caller (batchnorm_train_affine), the full backward through the statistics (conv_mixer.py:20,28,31)"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mean, var, eps):
+        dev = x.device
+        with E.on_device(x):
+            rs = (1.0 / torch.sqrt(var + eps)).float().contiguous()
+            xh = _ew(0, x, g=rs, h=(-mean * rs.double()).float().contiguous())
+            g32 = E.f32(gamma, dev)
+            y = _ew(0, xh, g=g32, h=E.f32(beta, dev))
+        ctx.save_for_backward(xh, rs, g32)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xh, rs, g32 = ctx.saved_tensors
+        dy = _rows(dy)
+        m, c = dy.shape
+        dx = dg = db = None
+        with E.on_device(dy):
+            s1 = col_sum(dy, m, c)
+            s2 = col_dot(dy, xh)
+            if ctx.needs_input_grad[0]:
+                a = (g32 * rs).contiguous()
+                dx = _ew(4, dy, b=xh, g=a, h=(-a * s2 / m).contiguous(), k=(-a * s1 / m).contiguous())
+            if ctx.needs_input_grad[1]:
+                dg = s2
+            if ctx.needs_input_grad[2]:
+                db = s1
+        return dx, dg, db, None, None, None

@@ -134,6 +134,170 @@ template <typename T> __global__ void __launch_bounds__(256) add_periodic_kernel
     }
 }
 
+// ---- round 6: the element-wise / normalisation / remap derivatives the other families' train mode needs ----
+// per-column / per-row-group combinations of one or two row-major tensors, fp32 math, one rounding:
+//   0: out = a * g[c] + h[c]           Aff (res_mlp.py:17-19), GroupNorm / BatchNorm affine; dx of a per-channel scale (h NULL)
+//   1: out = a * b                     the SGU gate u * v and its two derivatives (g_mlp.py:21)
+//   2: out = a + g[c] * b              x + gamma * f(x) (res_mlp.py:53,55); g NULL: a + b (sum of two gradient paths, x_lr + x_td as_mlp.py:91)
+//   3: out = a * g[m / period]         stochastic depth's per-sample scale and its derivative (as_mlp.py:159-160)
+//   4: out = a * g[c] + b * h[c] + k[c]   BatchNorm (batch statistics) backward: dx = (gamma / sigma) (dy - mean(dy) - x^ mean(dy x^)) (conv_mixer.py:20,28,31)
+template <typename T, int MODE> __global__ void __launch_bounds__(256) ew_cols_kernel(const T* __restrict__ a, int64_t lda, const T* __restrict__ b, int64_t ldb,
+                                                                                     const float* __restrict__ g, const float* __restrict__ h,
+                                                                                     const float* __restrict__ k, T* __restrict__ out, int64_t ldo,
+                                                                                     int64_t rows, int cols, int period) {
+    const int64_t total = rows * (int64_t)cols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cols;
+        const int c = (int)(i - r * cols);
+        const float av = to_f32<T>(a[r * lda + c]);
+        float v;
+        if (MODE == 0) v = __builtin_fmaf(av, g ? g[c] : 1.f, h ? h[c] : 0.f);
+        else if (MODE == 1) v = av * to_f32<T>(b[r * ldb + c]);
+        else if (MODE == 2) v = __builtin_fmaf(g ? g[c] : 1.f, to_f32<T>(b[r * ldb + c]), av);
+        else if (MODE == 3) v = av * g[r / period];
+        else v = __builtin_fmaf(av, g[c], __builtin_fmaf(to_f32<T>(b[r * ldb + c]), h[c], k[c]));
+        out[r * ldo + c] = from_f32<T>(v);
+    }
+}
+
+// out[c] = sum over rows of x[r, c] * y[r, c], fp32 (Kahan, fixed order): the gradient of a per-channel scale (Aff alpha, layer scale gamma,
+// GroupNorm / BatchNorm weight: sum of dy * x^)
+template <typename T> __global__ void __launch_bounds__(256) col_dot_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ y, int64_t ldy, int64_t rows,
+                                                                            int cols, float* __restrict__ out) {
+    __shared__ float sm[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    float s = 0.f, comp = 0.f;
+    if (c < cols)
+        for (int64_t r = rl; r < rows; r += 4) {
+            const float v = to_f32<T>(x[r * ldx + c]) * to_f32<T>(y[r * ldy + c]);
+            const float yk = v - comp;
+            const float t = s + yk;
+            comp = (t - s) - yk;
+            s = t;
+        }
+    sm[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < cols) out[c] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+
+// GroupNorm(1, C) backward on channel-last samples (as_mlp.py:343-344: MyNorm = GroupNorm(1, dim)): a sample is glen = H W C contiguous
+// values; xh = the normalised values (before the affine), g = dy * gamma[c] (the caller's mode-0 pass):
+//   dx = rstd[b] * (g - mean_b(g) - xh * mean_b(g xh))
+// one workgroup per sample, two passes over it (the second hits the L2), fp32 sums in a fixed order
+template <typename T> __global__ void __launch_bounds__(1024) group_norm_bwd_kernel(const T* __restrict__ xh, const T* __restrict__ g, const float* __restrict__ rstd,
+                                                                                    T* __restrict__ dx, int64_t glen) {
+    __shared__ float sm[2][16];
+    const int64_t base = (int64_t)blockIdx.x * glen;
+    float s1 = 0.f, s2 = 0.f;
+    for (int64_t i = threadIdx.x; i < glen; i += 1024) {
+        const float gv = to_f32<T>(g[base + i]);
+        s1 += gv;
+        s2 = __builtin_fmaf(gv, to_f32<T>(xh[base + i]), s2);
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = s1; sm[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    float t1 = 0.f, t2 = 0.f;
+    for (int w = 0; w < 16; ++w) { t1 += sm[0][w]; t2 += sm[1][w]; }
+    const float m1 = t1 / (float)glen, m2 = t2 / (float)glen, rs = rstd[blockIdx.x];
+    for (int64_t i = threadIdx.x; i < glen; i += 1024)
+        dx[base + i] = from_f32<T>(rs * (to_f32<T>(g[base + i]) - m1 - to_f32<T>(xh[base + i]) * m2));
+}
+
+// adjoint of mlpk_shift_nhwc (as_mlp.py:84-89 through the channel-last layout): grad_in[n,h,w,c] = grad_out[n,h-s,w,c] (dim 2) |
+// grad_out[n,h,w-s,c] (dim 3), s = ksz / 2 - c / group, zero outside -- shift_backward_grad_input_kernel (utils/shift_cuda.py:75-103) on (N,H,W,C)
+template <typename T> __global__ void __launch_bounds__(256) shift_nhwc_bwd_kernel(const T* __restrict__ go, T* __restrict__ gi, int N, int H, int W, int C, int ksz,
+                                                                                   int dim) {
+    const int64_t total = (int64_t)N * H * W * C;
+    const int group = (C + ksz - 1) / ksz;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        const int w = (int)((idx / C) % W);
+        const int h = (int)((idx / ((int64_t)C * W)) % H);
+        const int s = ksz / 2 - c / group;
+        T v = from_f32<T>(0.f);
+        if (dim == 2) {
+            if (h - s >= 0 && h - s < H) v = go[idx - (int64_t)s * W * C];
+        } else {
+            if (w - s >= 0 && w - s < W) v = go[idx - (int64_t)s * C];
+        }
+        gi[idx] = v;
+    }
+}
+
+// PatchMerging's gather (as_mlp.py:207-211: cat of x[0::2,0::2], x[1::2,0::2], x[0::2,1::2], x[1::2,1::2] over the channels) on channel-last
+// tensors and its adjoint (a permutation: every element moves once).  dir 0: (B,H,W,C) -> (B,H/2,W/2,4C);  dir 1: back
+template <typename T> __global__ void __launch_bounds__(256) merge2x2_kernel(const T* __restrict__ src, T* __restrict__ dst, int B, int H, int W, int C, int dir) {
+    const int64_t total = (int64_t)B * H * W * C;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        const int x = (int)((idx / C) % W);
+        const int y = (int)((idx / ((int64_t)C * W)) % H);
+        const int64_t b = idx / ((int64_t)C * W * H);
+        const int q = (x & 1) * 2 + (y & 1);
+        const int64_t m = ((b * (H / 2) + (y >> 1)) * (W / 2) + (x >> 1)) * (4 * (int64_t)C) + (int64_t)q * C + c;
+        if (dir == 0) dst[m] = src[idx];
+        else dst[idx] = src[m];
+    }
+}
+
+// depthwise Conv2d(k, groups = C, padding = "same") on channel-last tensors without an epilogue (train mode keeps the pre-activation), and its
+// adjoint (the gradient w.r.t. the input): w fp32 [k*k][C] tap-major; "same" pads (k-1)/2 before and k/2 after (conv_mixer.py:25)
+//   fwd:     out[b,y,x,c] = bias[c] + sum_{i,j} w[i,j,c] in[b, y+i-p, x+j-p, c]
+//   adjoint: out[b,y,x,c] =           sum_{i,j} w[i,j,c] in[b, y-i+p, x-j+p, c]
+template <typename T> __global__ void __launch_bounds__(256) dwconv_plain_kernel(const T* __restrict__ in, T* __restrict__ out, const float* __restrict__ w,
+                                                                                 const float* __restrict__ bias, int B, int H, int W, int C, int k, int adj) {
+    const int64_t total = (int64_t)B * H * W * C;
+    const int p = (k - 1) / 2;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        const int x = (int)((idx / C) % W);
+        const int y = (int)((idx / ((int64_t)C * W)) % H);
+        const int64_t b = idx / ((int64_t)C * W * H);
+        float acc = (bias && !adj) ? bias[c] : 0.f;
+        for (int i = 0; i < k; ++i) {
+            const int yy = adj ? y - i + p : y + i - p;
+            if (yy < 0 || yy >= H) continue;
+            for (int j = 0; j < k; ++j) {
+                const int xx = adj ? x - j + p : x + j - p;
+                if (xx < 0 || xx >= W) continue;
+                acc = __builtin_fmaf(w[(size_t)(i * k + j) * C + c], to_f32<T>(in[((b * H + yy) * W + xx) * (int64_t)C + c]), acc);
+            }
+        }
+        out[idx] = from_f32<T>(acc);
+    }
+}
+
+// gradient of the depthwise taps: dw[i,j,c] = sum_{b,y,x} dy[b,y,x,c] x[b, y+i-p, x+j-p, c].  One workgroup per (64 channels, tap): 4 pixel
+// lanes, Kahan sums, fixed order (no atomics)
+template <typename T> __global__ void __launch_bounds__(256) dwconv_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw, int B, int H,
+                                                                                 int W, int C, int k) {
+    __shared__ float sm[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int pl = threadIdx.x >> 6;
+    const int tap = blockIdx.y, i = tap / k, j = tap - i * k, p = (k - 1) / 2;
+    float s = 0.f, comp = 0.f;
+    if (c < C) {
+        const int64_t npx = (int64_t)B * H * W;
+        for (int64_t px = pl; px < npx; px += 4) {
+            const int xo = (int)(px % W), yo = (int)((px / W) % H);
+            const int yy = yo + i - p, xx = xo + j - p;
+            if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+            const int64_t src = px + (int64_t)(yy - yo) * W + (xx - xo);
+            const float v = to_f32<T>(dy[px * C + c]) * to_f32<T>(x[src * C + c]);
+            const float yk = v - comp;
+            const float t = s + yk;
+            comp = (t - s) - yk;
+            s = t;
+        }
+    }
+    sm[pl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (pl == 0 && c < C) dw[(size_t)tap * C + c] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+
 static unsigned ew_grid(int64_t total) {
     int64_t g = (total + 255) / 256;
     return (unsigned)(g < 1 ? 1 : (g > 65536 ? 65536 : g));
@@ -237,6 +401,114 @@ extern "C" int mlpk_add_periodic(int dtype, void* x, int64_t ldx, const float* t
 #define AP(TT) hipLaunchKernelGGL((add_periodic_kernel<TT>), dim3(g), dim3(256), 0, s, (TT*)x, ldx, t, rows, C, period)
     BW_DISPATCH(dtype, AP(float), AP(f16_t), AP(bf16_t))
 #undef AP
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mlpk_ew_cols(int dtype, int mode, const void* a, int64_t lda, const void* b, int64_t ldb, const float* g, const float* h, const float* k,
+                            void* out, int64_t ldo, int64_t rows, int cols, int period, void* stream) {
+    using namespace mlpk;
+    if (!a || !out) return MLPK_ENULL;
+    if (mode < 0 || mode > 4) return MLPK_EMODE;
+    if (((mode == 1 || mode == 2 || mode == 4) && !b) || (mode == 3 && !g) || (mode == 4 && (!g || !h || !k))) return MLPK_ENULL;
+    if (rows <= 0 || cols <= 0 || lda < cols || ldo < cols || (b && ldb < cols) || (mode == 3 && period <= 0)) return MLPK_ESHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const unsigned gr = ew_grid(rows * (int64_t)cols);
+#define EW(TT, MM) hipLaunchKernelGGL((ew_cols_kernel<TT, MM>), dim3(gr), dim3(256), 0, s, (const TT*)a, lda, (const TT*)b, ldb, g, h, k, (TT*)out, ldo, rows, cols, period)
+#define EWM(TT)                  \
+    switch (mode) {              \
+        case 0: EW(TT, 0); break; \
+        case 1: EW(TT, 1); break; \
+        case 2: EW(TT, 2); break; \
+        case 3: EW(TT, 3); break; \
+        default: EW(TT, 4); break; \
+    }
+    BW_DISPATCH(dtype, EWM(float), EWM(f16_t), EWM(bf16_t))
+#undef EWM
+#undef EW
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mlpk_col_dot(int dtype, const void* x, int64_t ldx, const void* y, int64_t ldy, int64_t rows, int cols, float* out, void* stream) {
+    using namespace mlpk;
+    if (!x || !y || !out) return MLPK_ENULL;
+    if (rows <= 0 || cols <= 0 || ldx < cols || ldy < cols) return MLPK_ESHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const unsigned g = (unsigned)((cols + 63) / 64);
+#define CD(TT) hipLaunchKernelGGL((col_dot_kernel<TT>), dim3(g), dim3(256), 0, s, (const TT*)x, ldx, (const TT*)y, ldy, rows, cols, out)
+    BW_DISPATCH(dtype, CD(float), CD(f16_t), CD(bf16_t))
+#undef CD
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mlpk_group_norm_backward(int dtype, const void* xh, const void* g, const float* rstd, void* dx, int groups, int64_t glen, void* stream) {
+    using namespace mlpk;
+    if (!xh || !g || !rstd || !dx) return MLPK_ENULL;
+    if (groups <= 0 || glen <= 0) return MLPK_ESHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define GB(TT) hipLaunchKernelGGL((group_norm_bwd_kernel<TT>), dim3((unsigned)groups), dim3(1024), 0, s, (const TT*)xh, (const TT*)g, rstd, (TT*)dx, glen)
+    BW_DISPATCH(dtype, GB(float), GB(f16_t), GB(bf16_t))
+#undef GB
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mlpk_shift_nhwc_backward(int dtype, const void* grad_out, void* grad_in, int N, int H, int W, int C, int kernel_size, int dim, void* stream) {
+    using namespace mlpk;
+    if (!grad_out || !grad_in) return MLPK_ENULL;
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return MLPK_ESHAPE;
+    if (kernel_size < 3 || !(kernel_size & 1)) return MLPK_ESHAPE;
+    if (dim != 2 && dim != 3) return MLPK_EMODE;
+    if (grad_out == grad_in) return MLPK_ESHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const unsigned g = ew_grid((int64_t)N * H * W * C);
+#define SB(TT) hipLaunchKernelGGL((shift_nhwc_bwd_kernel<TT>), dim3(g), dim3(256), 0, s, (const TT*)grad_out, (TT*)grad_in, N, H, W, C, kernel_size, dim)
+    BW_DISPATCH(dtype, SB(float), SB(f16_t), SB(bf16_t))
+#undef SB
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mlpk_merge2x2_nhwc(int dtype, int dir, const void* src, void* dst, int B, int H, int W, int C, void* stream) {
+    using namespace mlpk;
+    if (!src || !dst) return MLPK_ENULL;
+    if (dir != 0 && dir != 1) return MLPK_EMODE;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || src == dst) return MLPK_ESHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const unsigned g = ew_grid((int64_t)B * H * W * C);
+#define MG(TT) hipLaunchKernelGGL((merge2x2_kernel<TT>), dim3(g), dim3(256), 0, s, (const TT*)src, (TT*)dst, B, H, W, C, dir)
+    BW_DISPATCH(dtype, MG(float), MG(f16_t), MG(bf16_t))
+#undef MG
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mlpk_dwconv_plain_nhwc(int dtype, int adjoint, const void* in, void* out, int B, int H, int W, int C, int k, const float* w, const float* bias,
+                                      void* stream) {
+    using namespace mlpk;
+    if (!in || !out || !w) return MLPK_ENULL;
+    if (adjoint != 0 && adjoint != 1) return MLPK_EMODE;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || k < 1 || k > 13 || in == out) return MLPK_ESHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const unsigned g = ew_grid((int64_t)B * H * W * C);
+#define DP(TT) hipLaunchKernelGGL((dwconv_plain_kernel<TT>), dim3(g), dim3(256), 0, s, (const TT*)in, (TT*)out, w, bias, B, H, W, C, k, adjoint)
+    BW_DISPATCH(dtype, DP(float), DP(f16_t), DP(bf16_t))
+#undef DP
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mlpk_dwconv_wgrad_nhwc(int dtype, const void* x, const void* dy, float* dw, int B, int H, int W, int C, int k, void* stream) {
+    using namespace mlpk;
+    if (!x || !dy || !dw) return MLPK_ENULL;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || k < 1 || k > 13) return MLPK_ESHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 g((unsigned)((C + 63) / 64), (unsigned)(k * k));
+#define DW(TT) hipLaunchKernelGGL((dwconv_wgrad_kernel<TT>), g, dim3(256), 0, s, (const TT*)x, (const TT*)dy, dw, B, H, W, C, k)
+    BW_DISPATCH(dtype, DW(float), DW(f16_t), DW(bf16_t))
+#undef DW
     MLPK_LAUNCH_CHECK();
     return 0;
 }

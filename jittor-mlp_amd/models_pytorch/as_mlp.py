@@ -207,8 +207,9 @@ class AS_MLP(E.EngineModule):
     repository itself restates it (conv_mlp.py:17-34; timm is not vendored) -- as a per-row scale in the epilogue of the GEMM that adds the
     residual (mlpk.h: v * rscale[m] in front of + R).  The draws come from `drop_path_uniform(B, dtype, device)` (default torch.rand on the
     input's device, one call per DropPath in the reference's order); GroupNorm has no batch statistics, Dropout has p = 0.  Forward only:
-    the outputs carry no grad_fn."""
-    _train_forward = "forward-only"
+    the outputs carry no grad_fn under torch.no_grad().  Round 6: with gradients enabled, train() runs `_forward_train` -- every step an
+    autograd.Function whose forward and backward are C-ABI calls -- and loss.backward() fills every parameter's .grad."""
+    _train_forward = True
 
     def __init__(self, img_size=224, patch_size=4, in_chans=3, num_classes=1000, embed_dim=96, depths=[2, 2, 6, 2],
                  shift_size=5, mlp_ratio=4., as_bias=True, drop_rate=0., drop_path_rate=0.1, norm_layer=MyNorm,
@@ -497,7 +498,74 @@ class AS_MLP(E.EngineModule):
             cur, H, W, C = self._run_layers(ws, pk, cur, B, H, W, C, x.dtype, only=(li, bi))[:4]
             return cur.reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
 
+    def _forward_train(self, x):
+        """Train mode WITH autograd (round 6, SURVEY 8f-4: the review's "AS-MLP block backward built on the Shift op's backward kernel"): the same
+        mathematics as forward() with every step an autograd.Function of `..autograd` whose forward and backward are C-ABI calls -- 1x1
+        convolutions = mlpk_gemm_nt (dX, dW as GEMMs on transposed operands), GroupNorm(1, C) = mlpk_row_stats + mlpk_norm_apply /
+        mlpk_group_norm_backward, GELU = mlpk_gelu_elementwise, the two axial shifts = mlpk_shift_nhwc / mlpk_shift_nhwc_backward (the
+        reference's shift_backward_grad_input_kernel, utils/shift_cuda.py:75-103, on the channel-last layout), PatchMerging's gather =
+        mlpk_merge2x2_nhwc and its adjoint, stochastic depth = a per-sample row scale (as_mlp.py:55-95,118-162,197-216,428-443).
+        Unfused on purpose: the pre-activations and normalised tensors are what the backward needs.  No gradient w.r.t. the input image."""
+        from .. import autograd as AG
+        E.require_gpu(x, "AS_MLP.forward")
+        if x.dim() != 4:
+            raise ValueError("expected a (B, C, H, W) tensor")
+        cd = self._compute_dtype or x.dtype
+        E.dtype_code(cd)
+        pe = self.patch_embed
+        B, cin, H_in, W_in = x.shape
+        assert H_in == pe.img_size[0] and W_in == pe.img_size[1], \
+            f"Input image size ({H_in}*{W_in}) doesn't match model ({pe.img_size[0]}*{pe.img_size[1]})."
+        ph, pw = pe.patch_size
+        H, W = H_in // ph, W_in // pw
+        dev = x.device
+        kp = E.round_up(cin * ph * pw, 4 if cd == torch.float32 else 8)
+        with E.on_device(x):
+            patches = torch.zeros((B * H * W, kp), dtype=cd, device=dev)
+            E.patchify(x.contiguous(), patches, B, cin, H_in, W_in, ph, pw, 0, kp)
+
+        def gn(t, norm):
+            return AG.GroupNorm1.apply(t, norm.weight, norm.bias, B, norm.eps)
+
+        def conv(t, c, res=None):
+            return AG.Linear.apply(t, c.weight, c.bias, res)
+
+        def add_dropped(t, z, blk, HW):
+            # x + drop_path(z) (as_mlp.py:159-160); rate 0 / eval: handled by the callers through the GEMM's residual epilogue
+            keep = 1.0 - float(blk.drop_path_rate)
+            u = self.drop_path_uniform(B, cd, dev)
+            scale = (torch.floor(keep + u.reshape(B).float()) / keep).contiguous()
+            return AG.ScaleAdd.apply(t, AG.RowScale.apply(z, scale, HW), None)
+
+        t = conv(patches, pe.proj)
+        if pe.norm is not None:
+            t = gn(t, pe.norm)
+        for layer in self.layers:
+            HW = H * W
+            for blk in layer.blocks:
+                a = blk.axial_shift
+                dropped = float(blk.drop_path_rate) > 0.0
+                u = AG.Gelu.apply(gn(conv(gn(t, blk.norm1), a.conv1), a.norm1))
+                x_lr = AG.Gelu.apply(conv(AG.ShiftNHWC.apply(u, B, H, W, self._shift, 3), a.conv2_1))
+                x_td = AG.Gelu.apply(conv(AG.ShiftNHWC.apply(u, B, H, W, self._shift, 2), a.conv2_2))
+                s = gn(AG.ScaleAdd.apply(x_lr, x_td, None), a.norm2)
+                t = add_dropped(t, conv(s, a.conv3), blk, HW) if dropped else conv(s, a.conv3, t)
+                h = AG.Gelu.apply(conv(gn(t, blk.norm2), blk.mlp.fc1))
+                t = add_dropped(t, conv(h, blk.mlp.fc2), blk, HW) if dropped else conv(h, blk.mlp.fc2, t)
+            if layer.downsample is not None:
+                assert H % 2 == 0 and W % 2 == 0, f"x size ({H}*{W}) are not even."
+                ds = layer.downsample
+                t = conv(gn(AG.Merge2x2.apply(t, B, H, W), ds.norm), ds.reduction)
+                H, W = H // 2, W // 2
+        pooled = AG.TokenMean.apply(gn(t, self.norm), B, H * W)
+        if not isinstance(self.head, nn.Linear):
+            return pooled if pooled.dtype == x.dtype else pooled.to(x.dtype)
+        logits = AG.Linear.apply(pooled, self.head.weight, self.head.bias, None)
+        return logits if logits.dtype == x.dtype else logits.to(x.dtype)
+
     def forward(self, x):
+        if self.training and torch.is_grad_enabled():
+            return self._forward_train(x)
         cd = self._resolve(x)
         pe = self.patch_embed
         B, _, H_in, W_in = x.shape

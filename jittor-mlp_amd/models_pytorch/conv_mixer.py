@@ -55,7 +55,7 @@ def _bn_affine(bn, device):
 
 class ConvMixer(E.EngineModule):
     """Same signature and defaults as the reference (conv_mixer.py:14)."""
-    _train_forward = "forward-only"          # train(): BatchNorm on batch statistics + running-statistics update (_forward_train)
+    _train_forward = True                    # train(): BatchNorm on batch statistics + running-statistics update; with gradients enabled, autograd (_forward_autograd)
 
     def __init__(self, dim, depth, kernel_size=9, patch_size=7, n_classes=1000):
         super().__init__()
@@ -160,9 +160,49 @@ class ConvMixer(E.EngineModule):
             E.pool_mean(cur, B, H * W, dim, dim, pooled, dim)
             return head_linear(ws, pooled, B, dim, E.pack_matrix(self.classifier[2].weight, cd, dev), E.f32(self.classifier[2].bias, dev), n_classes, x.dtype)
 
+    def _forward_autograd(self, x):
+        """Train mode WITH autograd (round 6): conv_mixer.py:17-39 as autograd.Functions of `..autograd` whose forward and backward
+        are C-ABI calls -- the patch / pointwise convolutions = mlpk_gemm_nt (+ the two GEMMs of their backward), the depthwise convolution =
+        mlpk_dwconv_plain_nhwc (its adjoint for dX, mlpk_dwconv_wgrad_nhwc for the taps), GELU = mlpk_gelu_elementwise, BatchNorm2d on BATCH
+        statistics with the full backward through them (mlpk_col_sum / mlpk_col_dot + one mlpk_ew_cols pass) and the running-statistics update,
+        the Residual = mlpk_ew_cols.  No gradient w.r.t. the input image."""
+        from .. import autograd as AG
+        E.require_gpu(x, "ConvMixer.forward")
+        if x.dim() != 4:
+            raise ValueError("expected a (B, C, H, W) tensor")
+        cd = self._compute_dtype or x.dtype
+        E.dtype_code(cd)
+        dim, depth, k, patch, n_classes = self._cfg
+        _check_k(k)
+        B, cin, H_in, W_in = x.shape
+        pad = patch // 2
+        H, W = (H_in + 2 * pad - patch) // patch + 1, (W_in + 2 * pad - patch) // patch + 1
+        rows = B * H * W
+        kp = E.round_up(cin * patch * patch, 4 if cd == torch.float32 else 8)
+        with E.on_device(x):
+            patches = torch.zeros((rows, kp), dtype=cd, device=x.device)
+            E.patchify(x.contiguous(), patches, B, cin, H_in, W_in, patch, patch, pad, kp)
+
+        def bn(a, mod):
+            mean, var = AG.batch_stats(a.detach(), rows, dim)
+            AG.batchnorm_train_affine(mod, mean, var, rows)                     # (the running statistics: momentum, unbiased variance)
+            return AG.BatchNormTrain.apply(a, mod.weight, mod.bias, mean, var, mod.eps)
+
+        e = self.embedding
+        t = bn(AG.Gelu.apply(AG.Linear.apply(patches, e[0].weight, e[0].bias, None)), e[2])
+        for blk in self.blocks:
+            dw, bn_a = blk[0].fn[0], blk[0].fn[2]
+            y = bn(AG.Gelu.apply(AG.DepthwiseConv.apply(t, dw.weight, dw.bias, B, H, W)), bn_a)
+            t = AG.ScaleAdd.apply(y, t, None)                                   # Residual: fn(x) + x (conv_mixer.py:10)
+            t = bn(AG.Gelu.apply(AG.Linear.apply(t, blk[1].weight, blk[1].bias, None)), blk[3])
+        pooled = AG.TokenMean.apply(t, B, H * W)
+        head = self.classifier[2]
+        logits = AG.Linear.apply(pooled, head.weight, head.bias, None)
+        return logits if logits.dtype == x.dtype else logits.to(x.dtype)
+
     def forward(self, x):
         if self.training:
-            return self._forward_train(x)
+            return self._forward_autograd(x) if torch.is_grad_enabled() else self._forward_train(x)
         cd = self._resolve(x)
         dim, depth, k, patch, n_classes = self._cfg
         B, cin, H_in, W_in = x.shape

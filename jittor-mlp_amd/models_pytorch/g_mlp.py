@@ -212,7 +212,45 @@ class gMLPForImageClassification(gMLP):
         pk["head.b"] = E.f32(self.mlp_head[0].bias, device)
         return pk
 
+    _train_forward = True
+
+    def _forward_train(self, x):
+        """Train mode with autograd (round 6): g_mlp.py:10-39,64-82 as autograd.Functions of `..autograd`, forward and backward
+        through the C ABI -- the projections and the spatial Conv1d(k=1) = mlpk_gemm_nt (+ the two GEMMs of their backward), both LayerNorms
+        = mlpk_row_stats + mlpk_norm_apply / mlpk_layernorm_backward (the SGU's on the v half of h IN PLACE: a row stride of 2 d_ffn), the
+        gate u * v and its two derivatives = mlpk_ew_cols, the token <-> channel rearranges = mlpk_transpose_batched.  Unfused on purpose."""
+        from .. import autograd as AG
+        E.require_gpu(x, "gMLPForImageClassification.forward")
+        if x.dim() != 4:
+            raise ValueError("expected a (B, C, H, W) tensor")
+        cd = self._compute_dtype or x.dtype
+        E.dtype_code(cd)
+        S, C, F, _ = self._dims
+        B, cin, H, W = x.shape
+        ph, pw = self._patch
+        if (H // ph) * (W // pw) != S:
+            raise ValueError("input size gives %d patches, the model was built for %d" % ((H // ph) * (W // pw), S))
+        conv = self.patcher[0]
+        kp = E.round_up(cin * ph * pw, 4 if cd == torch.float32 else 8)
+        with E.on_device(x):
+            patches = torch.zeros((B * S, kp), dtype=cd, device=x.device)
+            E.patchify(x.contiguous(), patches, B, cin, H, W, ph, pw, 0, kp)
+        t = AG.Linear.apply(patches, conv.weight, conv.bias, None)
+        for blk in self.model:
+            n = AG.LayerNorm.apply(t, blk.norm.weight, blk.norm.bias, blk.norm.eps)
+            h = AG.Gelu.apply(AG.Linear.apply(n, blk.channel_proj1.weight, blk.channel_proj1.bias, None))            # (B*S, 2F)
+            u, v = h[:, :F], h[:, F:]                                                                                  # chunk(2, dim=-1): views
+            vn = AG.LayerNorm.apply(v, blk.sgu.norm.weight, blk.sgu.norm.bias, blk.sgu.norm.eps)
+            sp = blk.sgu.spatial_proj
+            vs = AG.RowsToTokens.apply(AG.Linear.apply(AG.TokensToRows.apply(vn, B, S), sp.weight, sp.bias, None), B, S, F)
+            t = AG.Linear.apply(AG.Mul.apply(u, vs), blk.channel_proj2.weight, blk.channel_proj2.bias, t)
+        head = self.mlp_head[0]
+        logits = AG.Linear.apply(AG.TokenMean.apply(t, B, S), head.weight, head.bias, None)
+        return logits if logits.dtype == x.dtype else logits.to(x.dtype)
+
     def forward(self, x):
+        if self.training and torch.is_grad_enabled():
+            return self._forward_train(x)
         cd = self._resolve(x)
         S, C, _, _ = self._dims
         B = x.shape[0]

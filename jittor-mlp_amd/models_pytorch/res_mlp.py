@@ -214,7 +214,45 @@ class ResMLPForImageClassification(ResMLP):
         pk["head.b"] = E.f32(self.mlp_head[0].bias, device)
         return pk
 
+    _train_forward = True
+
+    def _forward_train(self, x):
+        """Train mode with autograd (round 6): res_mlp.py:11-57,88-99 as autograd.Functions of `..autograd`, forward and backward
+        through the C ABI -- Aff and the layer scales gamma_1 / gamma_2 = mlpk_ew_cols (parameter gradients: mlpk_col_dot / mlpk_col_sum), the
+        cross-patch Conv1d(k=1) and the FeedForward = mlpk_gemm_nt (+ the two GEMMs of their backward) between mlpk_transpose_batched rearranges.
+        The model-level `affine` takes no part in forward (res_mlp.py:86,91-99): its parameters get no gradient, as in the reference."""
+        from .. import autograd as AG
+        E.require_gpu(x, "ResMLPForImageClassification.forward")
+        if x.dim() != 4:
+            raise ValueError("expected a (B, C, H, W) tensor")
+        cd = self._compute_dtype or x.dtype
+        E.dtype_code(cd)
+        S, C, _, _ = self._dims
+        B, cin, H, W = x.shape
+        ph, pw = self._patch
+        if (H // ph) * (W // pw) != S:
+            raise ValueError("input size gives %d patches, the model was built for %d" % ((H // ph) * (W // pw), S))
+        conv = self.patcher[0]
+        kp = E.round_up(cin * ph * pw, 4 if cd == torch.float32 else 8)
+        with E.on_device(x):
+            patches = torch.zeros((B * S, kp), dtype=cd, device=x.device)
+            E.patchify(x.contiguous(), patches, B, cin, H, W, ph, pw, 0, kp)
+        t = AG.Linear.apply(patches, conv.weight, conv.bias, None)
+        for blk in self.model:
+            x1 = AG.Affine.apply(t, blk.pre_affine.alpha, blk.pre_affine.beta)
+            tm = blk.token_mix
+            z = AG.RowsToTokens.apply(AG.Linear.apply(AG.TokensToRows.apply(x1, B, S), tm.weight, tm.bias, None), B, S, C)
+            x3 = AG.Affine.apply(AG.ScaleAdd.apply(x1, z, blk.gamma_1), blk.post_affine.alpha, blk.post_affine.beta)
+            fc1, fc2 = blk.ff.net[0], blk.ff.net[3]
+            f = AG.Linear.apply(AG.Gelu.apply(AG.Linear.apply(x3, fc1.weight, fc1.bias, None)), fc2.weight, fc2.bias, None)
+            t = AG.ScaleAdd.apply(x3, f, blk.gamma_2)
+        head = self.mlp_head[0]
+        logits = AG.Linear.apply(AG.TokenMean.apply(t, B, S), head.weight, head.bias, None)
+        return logits if logits.dtype == x.dtype else logits.to(x.dtype)
+
     def forward(self, x):
+        if self.training and torch.is_grad_enabled():
+            return self._forward_train(x)
         cd = self._resolve(x)
         S, C, _, _ = self._dims
         B = x.shape[0]

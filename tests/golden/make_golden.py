@@ -11,7 +11,7 @@ The reference is imported read-only through the shim of SURVEY.md section 8c:
 Nothing from the reference's source text is written to the repo: fixtures hold inputs,
 weights (tiny configs only) and the reference's outputs.
 
-Usage:  python tests/golden/make_golden.py [--only tiny|real|ops|manifest|s2lowp|lowp|train|leaf] [--check]
+Usage:  python tests/golden/make_golden.py [--only tiny|real|ops|manifest|s2lowp|lowp|train|traingrad|leaf] [--check]
 """
 import argparse
 import importlib
@@ -720,6 +720,55 @@ def make_train(ref):
     np.savez_compressed(os.path.join(HERE, "train_tiny.npz"), **out)
 
 
+def make_train_grad(ref):
+    """train_grad_tiny.npz (round 6): the REFERENCE's own autograd on the families whose backward round 6 built -- gMLP
+    (g_mlp.py:10-82), ResMLP (res_mlp.py:11-99), AS-MLP (as_mlp.py:55-162,197-216,428-443; Shift through the reference's torch_shift), ConvMixer
+    (conv_mixer.py:5-39, BatchNorm on batch statistics).  Per case: the tiny fixture's weights, a portable batch of 4, train(), logits, the
+    gradient of sum(logits * G) w.r.t. every parameter (parameters the forward never touches -- ResMLP's model-level `affine` -- have none),
+    ConvMixer's running statistics after the step, and for `asmlp_dp` (drop_path_rate 0.5) the recorded uniform draws."""
+    out = {}
+    dp = sys.modules["timm.models.layers"].DropPath
+    cases = (("gmlp", "tiny_gmlp.npz", ref["g_mlp"].gMLPForImageClassification, {}, 31),
+             ("resmlp", "tiny_resmlp.npz", ref["res_mlp"].ResMLPForImageClassification, {}, 32),
+             ("asmlp", "tiny_asmlp.npz", ref["as_mlp"].AS_MLP, {"drop_path_rate": 0.0}, 33),
+             ("asmlp_dp", "tiny_asmlp.npz", ref["as_mlp"].AS_MLP, {"drop_path_rate": 0.5}, 34),
+             ("convmixer", "tiny_convmixer.npz", ref["conv_mixer"].ConvMixer, {}, 35),
+             ("convmixer_k4", "tiny_convmixer_k4.npz", ref["conv_mixer"].ConvMixer, {}, 36))
+    for tag, fixture, ctor, extra, seed in cases:
+        z = np.load(os.path.join(HERE, fixture))
+        kw = dict(json.loads(str(z["kwargs"])), **extra)
+        model = ctor(**kw)
+        model.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}, strict=True)
+        model.train()
+        x = torch.from_numpy(portable_input((4,) + tuple(z["input"].shape[1:]), seed=seed))
+        dp.draws.clear()
+        torch.manual_seed(seed + 100)
+        logits = model(x)
+        G = torch.from_numpy(portable_input(tuple(logits.shape), seed=seed + 200))
+        (logits * G).sum().backward()
+        out[tag + "/fixture"] = np.array(fixture)
+        out[tag + "/kwargs"] = np.array(_jsonable(kw))
+        out[tag + "/input"] = x.numpy().copy()
+        out[tag + "/logits"] = logits.detach().numpy().copy()
+        out[tag + "/G"] = G.numpy().copy()
+        if dp.draws:
+            out[tag + "/draws"] = np.stack(dp.draws)
+        nograd = []
+        for k, p_ in model.named_parameters():
+            if p_.grad is None:
+                nograd.append(k)
+            else:
+                out["%s/grad/%s" % (tag, k)] = p_.grad.numpy().copy()
+        out[tag + "/nograd"] = np.array(json.dumps(nograd))
+        for k, v in model.state_dict().items():
+            if "running_" in k or "num_batches" in k:
+                out["%s/after/%s" % (tag, k)] = v.numpy().copy()
+        gs = [float(p_.grad.abs().max()) for p_ in model.parameters() if p_.grad is not None]
+        print("train-grad %-13s logits %s, %d gradients (max %.3e, min-of-max %.3e), %d parameters without, %d DropPath draws" % (
+            tag, tuple(logits.shape), len(gs), max(gs), min(gs), len(nograd), len(dp.draws)))
+    np.savez_compressed(os.path.join(HERE, "train_grad_tiny.npz"), **out)
+
+
 def make_manifest(ref):
     """Drop-in manifests: constructor signatures + state_dict key->shape for every hot-path model."""
     man = {"signatures": {}, "state_dicts": {}}
@@ -774,6 +823,8 @@ def main():
         make_leaf(ref)
     if args.only in (None, "train"):
         make_train(ref)
+    if args.only in (None, "traingrad"):
+        make_train_grad(ref)
 
 
 if __name__ == "__main__":
