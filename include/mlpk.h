@@ -629,7 +629,9 @@ int mlpk_add_periodic(int dtype, void* x, int64_t ldx, const float* t, int64_t r
  *   mode 1: out = a * b                                       the SGU gate u * v (g_mlp.py:21) and both its derivatives
  *   mode 2: out = a + g[c] * b     (g NULL: a + b)            x + gamma * f(x) (res_mlp.py:53,55); sums of gradient paths
  *   mode 3: out = a * g[m / period]                           stochastic depth's per-sample scale (as_mlp.py:159-160) and its derivative
- *   mode 4: out = a * g[c] + b * h[c] + k[c]                  BatchNorm backward on batch statistics (conv_mixer.py:20,28,31) */
+ *   mode 4: out = a * g[c] + b * h[c] + k[c]                  BatchNorm backward on batch statistics (conv_mixer.py:20,28,31)
+ *   mode 5: out = a * g[i, c] + h[i, c] + b,  i = m / period  (g: (rows / period) x cols; h, b optional)  one branch's term of SplitAttention's weighted
+ *                                                             sum (vip.py:54-56; s2_mlp_v2.py:48-50) and its derivative w.r.t. the branch */
 int mlpk_ew_cols(int dtype, int mode, const void* a, int64_t lda, const void* b, int64_t ldb, const float* g, const float* h, const float* k,
                  void* out, int64_t ldo, int64_t rows, int cols, int period, void* stream);
 /* out[c] = sum over rows of x[r, c] * y[r, c], fp32: the gradient of a per-channel scale (Aff alpha, gamma_1 / gamma_2, GroupNorm / BatchNorm weight) */
@@ -643,12 +645,26 @@ int mlpk_shift_nhwc_backward(int dtype, const void* grad_out, void* grad_in, int
 /* PatchMerging's gather on channel-last tensors (as_mlp.py:207-211; the order of mlpk_patchify order 1) and its adjoint:
  * dir 0: src (B,H,W,C) -> dst (B,H/2,W/2,4C);  dir 1: src (B,H/2,W/2,4C) -> dst (B,H,W,C).  H, W even. */
 int mlpk_merge2x2_nhwc(int dtype, int dir, const void* src, void* dst, int B, int H, int W, int C, void* stream);
+/* the general form: the im2col half of any kernel == stride convolution read from channel-last rows, (B,H,W,C) -> (B,H/ph,W/pw, ph*pw*C) with
+ * column ((i*pw + j) [order 0, = mlpk_patchify NHWC] | (j*ph + i) [order 1, PatchMerging]) * C + c, and back (dir 1): the stage convolutions of
+ * S2-MLPv2 on the previous stage's output (s2_mlp_v2.py:118-119) and the gradient that flows back through them.  H % ph == 0, W % pw == 0. */
+int mlpk_patch_rows_nhwc(int dtype, int dir, int order, const void* src, void* dst, int B, int H, int W, int C, int ph, int pw, void* stream);
 /* depthwise Conv2d(k, groups = C, padding = "same") on (B,H,W,C) WITHOUT an epilogue (train mode keeps the pre-activation: conv_mixer.py:25),
  * w fp32 [k*k][C] tap-major like mlpk_dwconv_nhwc, bias fp32 [C] or NULL;  adjoint = 1: the gradient w.r.t. the input (bias ignored) */
 int mlpk_dwconv_plain_nhwc(int dtype, int adjoint, const void* in, void* out, int B, int H, int W, int C, int k, const float* w, const float* bias,
                            void* stream);
 /* dw[i*k + j][c] = sum over (b, y, x) of dy[b,y,x,c] * x[b, y+i-p, x+j-p, c], p = (k-1)/2: the gradient of the depthwise taps, fp32 */
 int mlpk_dwconv_wgrad_nhwc(int dtype, const void* x, const void* dy, float* dw, int B, int H, int W, int C, int k, void* stream);
+
+/* mlpk_col_dot per segment of seg_rows consecutive rows: out[i, c] = sum over the rows of segment i of x * y (the gradient of SplitAttention's
+ * per-image branch weights: sum over an image's pixels of dy * x_k) */
+int mlpk_col_dot_seg(int dtype, const void* x, int64_t ldx, const void* y, int64_t ldy, int segments, int64_t seg_rows, int cols, float* out, void* stream);
+/* backward of mlpk_split_softmax (nn.Softmax(1) over the k = 3 branches, vip.py:52-53): fp32 [B][3][C]; dhat[k] = bar[k] (dbar[k] - sum_j bar[j] dbar[j]) */
+int mlpk_split_softmax_backward(const float* bar, const float* dbar, float* dhat, int B, int C, void* stream);
+/* spatial_shift1 / spatial_shift2 of S2-MLPv2 (s2_mlp_v2.py:15-29; which = 1 / 2) on (B, D1, D2, C) rows with strides ldi / ldo, out of place.
+ * adjoint 0: the forward -- mode 0 the intended one-pixel shift, mode 1 the reference's in-place result (the +1 groups smear: y[i] = x[0]);
+ * adjoint 1: what the reference's autograd returns for the in-place slice assignments -- the adjoint of the INTENDED shift, whatever the forward did. */
+int mlpk_s2_shift2(int dtype, int which, int mode, int adjoint, const void* in, int64_t ldi, void* out, int64_t ldo, int B, int D1, int D2, int C, void* stream);
 
 /* ---- small utilities ------------------------------------------------------------------------ */
 /* dst[i] = (dst_dtype) src[i], n elements */

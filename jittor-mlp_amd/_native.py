@@ -129,8 +129,12 @@ PROTOTYPES = {
     "mlpk_group_norm_backward": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_void_p]),
     "mlpk_shift_nhwc_backward": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "mlpk_merge2x2_nhwc": (c_int, [c_int, c_int, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
+    "mlpk_patch_rows_nhwc": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "mlpk_dwconv_plain_nhwc": (c_int, [c_int, c_int, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p]),
     "mlpk_dwconv_wgrad_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
+    "mlpk_col_dot_seg": (c_int, [c_int, c_void_p, c_i64, c_void_p, c_i64, c_int, c_i64, c_int, c_void_p, c_void_p]),
+    "mlpk_split_softmax_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "mlpk_s2_shift2": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_void_p]),
     "mlpk_convert": (c_int, [c_int, c_int, c_void_p, c_void_p, c_i64, c_void_p]),
 }
 

@@ -542,3 +542,204 @@ class BatchNormTrain(torch.autograd.Function):
             if ctx.needs_input_grad[2]:
                 db = s1
         return dx, dg, db, None, None, None
+
+
+# ---- ViP / S2-MLP: rearranges, SplitAttention, the spatial shifts (round 6) ----------------------------------------------------------------
+class VipPermute(torch.autograd.Function):
+    """einops Rearrange 'b h w (c s) -> b w c (h s)' (which 0, vip.py:69) / '-> b h c (w s)' (which 1, vip.py:74) on channel-last rows:
+    (B*H*W, C) -> (B*L*G, K_pad), K = H*seg or W*seg, zero padding columns up to the GEMM's K.  Backward: the inverse rearrange."""
+
+    @staticmethod
+    def forward(ctx, x, B, H, W, seg, which):
+        C = x.shape[1]
+        G = C // seg
+        K = (H if which == 0 else W) * seg
+        kp = E.round_up(K, _epc(x.dtype))
+        ctx.meta = (B, H, W, C, seg, which, kp)
+        x = x.contiguous()
+        z = torch.zeros((B * (W if which == 0 else H) * G, kp), dtype=x.dtype, device=x.device)
+        with E.on_device(x):
+            if which == 0:
+                E.norm_apply(x, B * H * W, C, C, out_ph=z, H=H, W=W, seg=seg, ld_p=kp)
+            else:
+                E.norm_apply(x, B * H * W, C, C, out_pw=z, H=H, W=W, seg=seg, ld_p=kp)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        B, H, W, C, seg, which, kp = ctx.meta
+        dz = dz.contiguous()
+        dx = torch.empty((B * H * W, C), dtype=dz.dtype, device=dz.device)
+        with E.on_device(dz):
+            E.vip_unpermute(which, dz, dx, B, H, W, C, seg, dz.stride(0))
+        return dx, None, None, None, None, None
+
+
+class VipUnpermute(torch.autograd.Function):
+    """the Rearrange back, 'b w c (h s) -> b h w (c s)' (which 0, vip.py:71) / 'b h c (w s) -> b h w (c s)' (which 1, vip.py:76)"""
+
+    @staticmethod
+    def forward(ctx, z, B, H, W, C, seg, which):
+        ctx.meta = (B, H, W, C, seg, which, z.shape[1])
+        z = z.contiguous()
+        out = torch.empty((B * H * W, C), dtype=z.dtype, device=z.device)
+        with E.on_device(z):
+            E.vip_unpermute(which, z, out, B, H, W, C, seg, z.stride(0))
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, C, seg, which, K = ctx.meta
+        dy = dy.contiguous()
+        dz = torch.empty((B * (W if which == 0 else H) * (C // seg), K), dtype=dy.dtype, device=dy.device)
+        with E.on_device(dy):
+            if which == 0:
+                E.norm_apply(dy, B * H * W, C, C, out_ph=dz, H=H, W=W, seg=seg, ld_p=K)
+            else:
+                E.norm_apply(dy, B * H * W, C, C, out_pw=dz, H=H, W=W, seg=seg, ld_p=K)
+        return dz, None, None, None, None, None, None
+
+
+class ImageSum(torch.autograd.Function):
+    """(B*S, C) -> (B, C): the sum over an image's pixels (SplitAttention's reduction, vip.py:49-50; s2_mlp_v2.py:43-44)"""
+
+    @staticmethod
+    def forward(ctx, x, B, S):
+        C = x.shape[1]
+        ctx.dims = (B, S, C)
+        x = _rows(x)
+        out = torch.empty((B, C), dtype=x.dtype, device=x.device)
+        with E.on_device(x):
+            E.pool_mean(x, B, S, C, x.stride(0), out, C)
+            return _ew(0, out, g=torch.full((C,), float(S), dtype=torch.float32, device=x.device))
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, S, C = ctx.dims
+        dy = dy.contiguous()
+        dx = torch.empty((B * S, C), dtype=dy.dtype, device=dy.device)
+        with E.on_device(dy):
+            N.check(N.lib().mlpk_broadcast_rows(E.dtype_code(dy.dtype), E.ptr(dy), E.ptr(dx), B, S, C, 1.0, E.stream()), "mlpk_broadcast_rows")
+        return dx, None, None
+
+
+class SoftmaxBranches(torch.autograd.Function):
+    """nn.Softmax(1) over the k = 3 branches of hat_a viewed (B, 3, C) (vip.py:51-53), fp32 in and out"""
+
+    @staticmethod
+    def forward(ctx, hat, B, C):
+        hat = hat.contiguous()
+        bar = torch.empty_like(hat)
+        with E.on_device(hat):
+            E.split_softmax(hat, bar, B, C)
+        ctx.save_for_backward(bar)
+        ctx.dims = (B, C)
+        return bar
+
+    @staticmethod
+    def backward(ctx, dbar):
+        (bar,) = ctx.saved_tensors
+        B, C = ctx.dims
+        dbar = dbar.contiguous()
+        dhat = torch.empty_like(bar)
+        with E.on_device(bar):
+            N.check(N.lib().mlpk_split_softmax_backward(E.ptr(bar), E.ptr(dbar), E.ptr(dhat), B, C, E.stream()), "mlpk_split_softmax_backward")
+        return dhat, None, None
+
+
+class WeightedSum3(torch.autograd.Function):
+    """out[b, n, :] = sum_k bar[b, k, :] * x_k[b, n, :] (vip.py:54-56; s2_mlp_v2.py:48-50); bar fp32 (B, 3C); the branches may be column
+    slices of one wider tensor (S2-MLPv2: the thirds of mlp1's output)"""
+
+    @staticmethod
+    def forward(ctx, x0, x1, x2, bar, B, S):
+        C = x0.shape[1]
+        bar3 = bar.reshape(B, 3, C)
+        parts = [bar3[:, k].contiguous() for k in range(3)]
+        with E.on_device(x0):
+            out = _ew(5, _rows(x0), g=parts[0], period=S)
+            out = _ew(5, _rows(x1), b=out, g=parts[1], period=S)
+            out = _ew(5, _rows(x2), b=out, g=parts[2], period=S)
+        ctx.save_for_backward(x0, x1, x2, *parts)
+        ctx.dims = (B, S, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x0, x1, x2, p0, p1, p2 = ctx.saved_tensors
+        B, S, C = ctx.dims
+        dy = _rows(dy)
+        grads = []
+        dbar = torch.empty((B, 3, C), dtype=torch.float32, device=dy.device)
+        with E.on_device(dy):
+            for k, (xk, pk_) in enumerate(((x0, p0), (x1, p1), (x2, p2))):
+                grads.append(_ew(5, dy, g=pk_, period=S) if ctx.needs_input_grad[k] else None)
+                xk = _rows(xk)
+                seg = torch.empty((B, C), dtype=torch.float32, device=dy.device)
+                N.check(N.lib().mlpk_col_dot_seg(E.dtype_code(dy.dtype), E.ptr(dy), dy.stride(0), E.ptr(xk), xk.stride(0), B, S, C, E.ptr(seg), E.stream()),
+                        "mlpk_col_dot_seg")
+                dbar[:, k] = seg
+        return grads[0], grads[1], grads[2], dbar.reshape(B, 3 * C), None, None
+
+
+def split_attention(x0, x1, x2, sa, B, S):
+    """SplitAttention.forward (vip.py:46-57 = s2_mlp_v2.py:40-51) on three (B*S, C) branches as autograd.Functions"""
+    cd = x0.dtype
+    C = x0.shape[1]
+    a = ScaleAdd.apply(ScaleAdd.apply(ImageSum.apply(x0, B, S), ImageSum.apply(x1, B, S), None), ImageSum.apply(x2, B, S), None)
+    hat = Linear.apply(Gelu.apply(Linear.apply(a, sa.mlp1.weight, None, None)), sa.mlp2.weight, None, None)          # (B, 3C)
+    bar = SoftmaxBranches.apply(hat.float(), B, C)
+    return WeightedSum3.apply(x0, x1, x2, bar, B, S).to(cd)
+
+
+class S2Shift(torch.autograd.Function):
+    """spatial_shift1 / spatial_shift2 (s2_mlp_v2.py:15-29; which 1 / 2) on (B*D1*D2, C) rows -- possibly a column slice of a wider tensor.
+    Forward: the reference's in-place result (mode "reference_inplace": the +1 groups smear) or the intended shift; backward: what the
+    reference's autograd returns for the slice assignments -- the adjoint of the INTENDED shift in both modes (mlpk.h mlpk_s2_shift2)."""
+
+    @staticmethod
+    def forward(ctx, x, B, D1, D2, which, smear):
+        C = x.shape[1]
+        ctx.meta = (B, D1, D2, C, which)
+        x = _rows(x)
+        out = torch.empty((x.shape[0], C), dtype=x.dtype, device=x.device)
+        with E.on_device(x):
+            N.check(N.lib().mlpk_s2_shift2(E.dtype_code(x.dtype), which, 1 if smear else 0, 0, E.ptr(x), x.stride(0), E.ptr(out), C, B, D1, D2, C, E.stream()),
+                    "mlpk_s2_shift2")
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, D1, D2, C, which = ctx.meta
+        dy = _rows(dy)
+        dx = torch.empty((dy.shape[0], C), dtype=dy.dtype, device=dy.device)
+        with E.on_device(dy):
+            N.check(N.lib().mlpk_s2_shift2(E.dtype_code(dy.dtype), which, 0, 1, E.ptr(dy), dy.stride(0), E.ptr(dx), C, B, D1, D2, C, E.stream()), "mlpk_s2_shift2")
+        return dx, None, None, None, None, None
+
+
+class PatchRowsNHWC(torch.autograd.Function):
+    """the im2col half of Conv2d(kernel = stride = (ph, pw)) read from channel-last rows (B*H*W, C) -> (B*H/ph*W/pw, K_pad), K = ph*pw*C in
+    mlpk_patchify's NHWC order 0, zero padding columns up to the GEMM's K; backward: the inverse permutation (s2_mlp_v2.py:118-119)"""
+
+    @staticmethod
+    def forward(ctx, x, B, H, W, ph, pw):
+        C = x.shape[1]
+        K = ph * pw * C
+        kp = E.round_up(K, _epc(x.dtype))
+        ctx.meta = (B, H, W, C, ph, pw, K, kp)
+        x = x.contiguous()
+        rows = B * (H // ph) * (W // pw)
+        out = torch.empty((rows, K), dtype=x.dtype, device=x.device)
+        with E.on_device(x):
+            N.check(N.lib().mlpk_patch_rows_nhwc(E.dtype_code(x.dtype), 0, 0, E.ptr(x), E.ptr(out), B, H, W, C, ph, pw, E.stream()), "mlpk_patch_rows_nhwc")
+        return _pad_cols(out, kp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, C, ph, pw, K, kp = ctx.meta
+        dy = dy[:, :K].contiguous()
+        dx = torch.empty((B * H * W, C), dtype=dy.dtype, device=dy.device)
+        with E.on_device(dy):
+            N.check(N.lib().mlpk_patch_rows_nhwc(E.dtype_code(dy.dtype), 1, 0, E.ptr(dy), E.ptr(dx), B, H, W, C, ph, pw, E.stream()), "mlpk_patch_rows_nhwc")
+        return dx, None, None, None, None, None

@@ -141,6 +141,8 @@ template <typename T> __global__ void __launch_bounds__(256) add_periodic_kernel
 //   2: out = a + g[c] * b              x + gamma * f(x) (res_mlp.py:53,55); g NULL: a + b (sum of two gradient paths, x_lr + x_td as_mlp.py:91)
 //   3: out = a * g[m / period]         stochastic depth's per-sample scale and its derivative (as_mlp.py:159-160)
 //   4: out = a * g[c] + b * h[c] + k[c]   BatchNorm (batch statistics) backward: dx = (gamma / sigma) (dy - mean(dy) - x^ mean(dy x^)) (conv_mixer.py:20,28,31)
+//   5: out = a * g[i, c] + h[i, c] + b,  i = m / period   SplitAttention's weighted sum over the branches, one term per call (vip.py:54-56,
+//      s2_mlp_v2.py:48-50), and its derivative w.r.t. a branch: dy * bar_a[k] + the broadcast gradient of the pixel sum (h, b optional)
 template <typename T, int MODE> __global__ void __launch_bounds__(256) ew_cols_kernel(const T* __restrict__ a, int64_t lda, const T* __restrict__ b, int64_t ldb,
                                                                                      const float* __restrict__ g, const float* __restrict__ h,
                                                                                      const float* __restrict__ k, T* __restrict__ out, int64_t ldo,
@@ -155,19 +157,27 @@ template <typename T, int MODE> __global__ void __launch_bounds__(256) ew_cols_k
         else if (MODE == 1) v = av * to_f32<T>(b[r * ldb + c]);
         else if (MODE == 2) v = __builtin_fmaf(g ? g[c] : 1.f, to_f32<T>(b[r * ldb + c]), av);
         else if (MODE == 3) v = av * g[r / period];
-        else v = __builtin_fmaf(av, g[c], __builtin_fmaf(to_f32<T>(b[r * ldb + c]), h[c], k[c]));
+        else if (MODE == 4) v = __builtin_fmaf(av, g[c], __builtin_fmaf(to_f32<T>(b[r * ldb + c]), h[c], k[c]));
+        else {
+            const int64_t pi = (r / period) * cols + c;
+            v = __builtin_fmaf(av, g[pi], (h ? h[pi] : 0.f) + (b ? to_f32<T>(b[r * ldb + c]) : 0.f));
+        }
         out[r * ldo + c] = from_f32<T>(v);
     }
 }
 
 // out[c] = sum over rows of x[r, c] * y[r, c], fp32 (Kahan, fixed order): the gradient of a per-channel scale (Aff alpha, layer scale gamma,
 // GroupNorm / BatchNorm weight: sum of dy * x^)
+// (blockIdx.y = segment of `rows` consecutive rows: mlpk_col_dot_seg -- per-image sums, the gradient of SplitAttention's weights)
 template <typename T> __global__ void __launch_bounds__(256) col_dot_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ y, int64_t ldy, int64_t rows,
                                                                             int cols, float* __restrict__ out) {
     __shared__ float sm[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int rl = threadIdx.x >> 6;
     float s = 0.f, comp = 0.f;
+    x += (int64_t)blockIdx.y * rows * ldx;
+    y += (int64_t)blockIdx.y * rows * ldy;
+    out += (int64_t)blockIdx.y * cols;
     if (c < cols)
         for (int64_t r = rl; r < rows; r += 4) {
             const float v = to_f32<T>(x[r * ldx + c]) * to_f32<T>(y[r * ldy + c]);
@@ -227,17 +237,21 @@ template <typename T> __global__ void __launch_bounds__(256) shift_nhwc_bwd_kern
     }
 }
 
-// PatchMerging's gather (as_mlp.py:207-211: cat of x[0::2,0::2], x[1::2,0::2], x[0::2,1::2], x[1::2,1::2] over the channels) on channel-last
-// tensors and its adjoint (a permutation: every element moves once).  dir 0: (B,H,W,C) -> (B,H/2,W/2,4C);  dir 1: back
-template <typename T> __global__ void __launch_bounds__(256) merge2x2_kernel(const T* __restrict__ src, T* __restrict__ dst, int B, int H, int W, int C, int dir) {
+// the im2col half of a kernel == stride convolution on channel-last tensors, and its adjoint (a permutation: every element moves once):
+// PatchMerging's gather (as_mlp.py:207-211: cat of x[0::2,0::2], x[1::2,0::2], x[0::2,1::2], x[1::2,1::2] over the channels = order 1) and the
+// stage convolutions of S2-MLPv2 read from the previous stage's channel-last rows (s2_mlp_v2.py:118-119 = mlpk_patchify NHWC order 0).
+//   dir 0: (B,H,W,C) -> (B,H/ph,W/pw, ph*pw*C), column ((i*pw + j) [order 0] | (j*ph + i) [order 1]) * C + c;   dir 1: back
+template <typename T> __global__ void __launch_bounds__(256) patch_rows_kernel(const T* __restrict__ src, T* __restrict__ dst, int B, int H, int W, int C, int ph, int pw,
+                                                                               int order, int dir) {
     const int64_t total = (int64_t)B * H * W * C;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         const int c = (int)(idx % C);
         const int x = (int)((idx / C) % W);
         const int y = (int)((idx / ((int64_t)C * W)) % H);
         const int64_t b = idx / ((int64_t)C * W * H);
-        const int q = (x & 1) * 2 + (y & 1);
-        const int64_t m = ((b * (H / 2) + (y >> 1)) * (W / 2) + (x >> 1)) * (4 * (int64_t)C) + (int64_t)q * C + c;
+        const int i = y % ph, j = x % pw;
+        const int q = order == 0 ? i * pw + j : j * ph + i;
+        const int64_t m = ((b * (H / ph) + y / ph) * (W / pw) + x / pw) * ((int64_t)ph * pw * C) + (int64_t)q * C + c;
         if (dir == 0) dst[m] = src[idx];
         else dst[idx] = src[m];
     }
@@ -296,6 +310,55 @@ template <typename T> __global__ void __launch_bounds__(256) dwconv_wgrad_kernel
     sm[pl][threadIdx.x & 63] = s;
     __syncthreads();
     if (pl == 0 && c < C) dw[(size_t)tap * C + c] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+
+// softmax over the k = 3 branches, backward (vip.py:52-53, s2_mlp_v2.py:46-47): bar, dbar, dhat fp32 [B][3][C]
+//   dhat[k] = bar[k] * (dbar[k] - sum_j bar[j] dbar[j])
+__global__ void __launch_bounds__(256) split_softmax_bwd_kernel(const float* __restrict__ bar, const float* __restrict__ dbar, float* __restrict__ dhat, int B, int C) {
+    const int64_t total = (int64_t)B * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / C;
+        const int c = (int)(i - b * C);
+        const int64_t o = b * 3 * C + c;
+        const float a0 = bar[o], a1 = bar[o + C], a2 = bar[o + 2 * C];
+        const float d0 = dbar[o], d1 = dbar[o + C], d2 = dbar[o + 2 * C];
+        const float sdot = __builtin_fmaf(a0, d0, __builtin_fmaf(a1, d1, a2 * d2));
+        dhat[o] = a0 * (d0 - sdot);
+        dhat[o + C] = a1 * (d1 - sdot);
+        dhat[o + 2 * C] = a2 * (d2 - sdot);
+    }
+}
+
+// S2-MLPv2's spatial_shift1 / spatial_shift2 (s2_mlp_v2.py:15-29) on (B, D1, D2, C) rows with strides ldi / ldo, out of place, and the
+// backward the REFERENCE's autograd performs.  The reference assigns in place on overlapping views: its forward smears the +1 groups
+// (mode 1: y[i] = x[0]; mode 0 = the intended shift y[i] = x[i-1]), while its autograd (CopySlices on the pre-assignment values) returns
+// the adjoint of the INTENDED shift whatever the forward did -- checked on the reference itself (tests/golden/make_golden.py --only traingrad).
+//   which 1: groups (dim1,+1), (dim1,-1), (dim2,+1), (dim2,-1);  which 2: (dim2,+1), (dim2,-1), (dim1,+1), (dim1,-1)
+//   adjoint: dx[j] = dy[j+1] (j+1 < n) + (j == 0 ? dy[0] : 0) for +1;   dx[j] = dy[j-1] (j >= 1) + (j == n-1 ? dy[n-1] : 0) for -1
+template <typename T> __global__ void __launch_bounds__(256) s2_shift2_kernel(const T* __restrict__ in, int64_t ldi, T* __restrict__ out, int64_t ldo, int B, int D1,
+                                                                              int D2, int C, int which, int mode, int adjoint) {
+    const int64_t total = (int64_t)B * D1 * D2 * C;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        const int64_t px = idx / C;
+        const int j = (int)(px % D2);
+        const int i = (int)((px / D2) % D1);
+        const int grp = c < C / 4 ? 0 : (c < C / 2 ? 1 : (c < C * 3 / 4 ? 2 : 3));
+        const bool ax1 = which == 1 ? grp < 2 : grp >= 2;          // the axis this group moves along
+        const int dir = (grp & 1) ? -1 : +1;
+        const int n = ax1 ? D1 : D2, pos = ax1 ? i : j;
+        const int64_t step = ax1 ? (int64_t)D2 : 1;                // rows between neighbours along the axis
+        float v;
+        if (!adjoint) {
+            int src = dir < 0 ? (pos + 1 < n ? pos + 1 : n - 1) : (mode == 1 ? 0 : (pos > 0 ? pos - 1 : 0));
+            v = to_f32<T>(in[(px + (int64_t)(src - pos) * step) * ldi + c]);
+        } else if (dir > 0) {
+            v = (pos + 1 < n ? to_f32<T>(in[(px + step) * ldi + c]) : 0.f) + (pos == 0 ? to_f32<T>(in[px * ldi + c]) : 0.f);
+        } else {
+            v = (pos >= 1 ? to_f32<T>(in[(px - step) * ldi + c]) : 0.f) + (pos == n - 1 ? to_f32<T>(in[px * ldi + c]) : 0.f);
+        }
+        out[px * ldo + c] = from_f32<T>(v);
+    }
 }
 
 static unsigned ew_grid(int64_t total) {
@@ -409,9 +472,9 @@ extern "C" int mlpk_ew_cols(int dtype, int mode, const void* a, int64_t lda, con
                             void* out, int64_t ldo, int64_t rows, int cols, int period, void* stream) {
     using namespace mlpk;
     if (!a || !out) return MLPK_ENULL;
-    if (mode < 0 || mode > 4) return MLPK_EMODE;
-    if (((mode == 1 || mode == 2 || mode == 4) && !b) || (mode == 3 && !g) || (mode == 4 && (!g || !h || !k))) return MLPK_ENULL;
-    if (rows <= 0 || cols <= 0 || lda < cols || ldo < cols || (b && ldb < cols) || (mode == 3 && period <= 0)) return MLPK_ESHAPE;
+    if (mode < 0 || mode > 5) return MLPK_EMODE;
+    if (((mode == 1 || mode == 2 || mode == 4) && !b) || ((mode == 3 || mode == 5) && !g) || (mode == 4 && (!g || !h || !k))) return MLPK_ENULL;
+    if (rows <= 0 || cols <= 0 || lda < cols || ldo < cols || (b && ldb < cols) || ((mode == 3 || mode == 5) && period <= 0)) return MLPK_ESHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const unsigned gr = ew_grid(rows * (int64_t)cols);
 #define EW(TT, MM) hipLaunchKernelGGL((ew_cols_kernel<TT, MM>), dim3(gr), dim3(256), 0, s, (const TT*)a, lda, (const TT*)b, ldb, g, h, k, (TT*)out, ldo, rows, cols, period)
@@ -421,7 +484,8 @@ extern "C" int mlpk_ew_cols(int dtype, int mode, const void* a, int64_t lda, con
         case 1: EW(TT, 1); break; \
         case 2: EW(TT, 2); break; \
         case 3: EW(TT, 3); break; \
-        default: EW(TT, 4); break; \
+        case 4: EW(TT, 4); break; \
+        default: EW(TT, 5); break; \
     }
     BW_DISPATCH(dtype, EWM(float), EWM(f16_t), EWM(bf16_t))
 #undef EWM
@@ -471,18 +535,22 @@ extern "C" int mlpk_shift_nhwc_backward(int dtype, const void* grad_out, void* g
     return 0;
 }
 
-extern "C" int mlpk_merge2x2_nhwc(int dtype, int dir, const void* src, void* dst, int B, int H, int W, int C, void* stream) {
+extern "C" int mlpk_patch_rows_nhwc(int dtype, int dir, int order, const void* src, void* dst, int B, int H, int W, int C, int ph, int pw, void* stream) {
     using namespace mlpk;
     if (!src || !dst) return MLPK_ENULL;
-    if (dir != 0 && dir != 1) return MLPK_EMODE;
-    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || src == dst) return MLPK_ESHAPE;
+    if ((dir != 0 && dir != 1) || (order != 0 && order != 1)) return MLPK_EMODE;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || ph <= 0 || pw <= 0 || H % ph || W % pw || src == dst) return MLPK_ESHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const unsigned g = ew_grid((int64_t)B * H * W * C);
-#define MG(TT) hipLaunchKernelGGL((merge2x2_kernel<TT>), dim3(g), dim3(256), 0, s, (const TT*)src, (TT*)dst, B, H, W, C, dir)
-    BW_DISPATCH(dtype, MG(float), MG(f16_t), MG(bf16_t))
-#undef MG
+#define PR(TT) hipLaunchKernelGGL((patch_rows_kernel<TT>), dim3(g), dim3(256), 0, s, (const TT*)src, (TT*)dst, B, H, W, C, ph, pw, order, dir)
+    BW_DISPATCH(dtype, PR(float), PR(f16_t), PR(bf16_t))
+#undef PR
     MLPK_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int mlpk_merge2x2_nhwc(int dtype, int dir, const void* src, void* dst, int B, int H, int W, int C, void* stream) {
+    return mlpk_patch_rows_nhwc(dtype, dir, 1, src, dst, B, H, W, C, 2, 2, stream);
 }
 
 extern "C" int mlpk_dwconv_plain_nhwc(int dtype, int adjoint, const void* in, void* out, int B, int H, int W, int C, int k, const float* w, const float* bias,
@@ -509,6 +577,45 @@ extern "C" int mlpk_dwconv_wgrad_nhwc(int dtype, const void* x, const void* dy, 
 #define DW(TT) hipLaunchKernelGGL((dwconv_wgrad_kernel<TT>), g, dim3(256), 0, s, (const TT*)x, (const TT*)dy, dw, B, H, W, C, k)
     BW_DISPATCH(dtype, DW(float), DW(f16_t), DW(bf16_t))
 #undef DW
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mlpk_col_dot_seg(int dtype, const void* x, int64_t ldx, const void* y, int64_t ldy, int segments, int64_t seg_rows, int cols, float* out,
+                                void* stream) {
+    using namespace mlpk;
+    if (!x || !y || !out) return MLPK_ENULL;
+    if (segments <= 0 || segments > 65535 || seg_rows <= 0 || cols <= 0 || ldx < cols || ldy < cols) return MLPK_ESHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 g((unsigned)((cols + 63) / 64), (unsigned)segments);
+#define CDS(TT) hipLaunchKernelGGL((col_dot_kernel<TT>), g, dim3(256), 0, s, (const TT*)x, ldx, (const TT*)y, ldy, seg_rows, cols, out)
+    BW_DISPATCH(dtype, CDS(float), CDS(f16_t), CDS(bf16_t))
+#undef CDS
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mlpk_split_softmax_backward(const float* bar, const float* dbar, float* dhat, int B, int C, void* stream) {
+    using namespace mlpk;
+    if (!bar || !dbar || !dhat) return MLPK_ENULL;
+    if (B <= 0 || C <= 0) return MLPK_ESHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(split_softmax_bwd_kernel, dim3(ew_grid((int64_t)B * C)), dim3(256), 0, s, bar, dbar, dhat, B, C);
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mlpk_s2_shift2(int dtype, int which, int mode, int adjoint, const void* in, int64_t ldi, void* out, int64_t ldo, int B, int D1, int D2, int C,
+                              void* stream) {
+    using namespace mlpk;
+    if (!in || !out) return MLPK_ENULL;
+    if ((which != 1 && which != 2) || (mode != 0 && mode != 1) || (adjoint != 0 && adjoint != 1)) return MLPK_EMODE;
+    if (B <= 0 || D1 <= 0 || D2 <= 0 || C <= 0 || ldi < C || ldo < C || in == out) return MLPK_ESHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const unsigned g = ew_grid((int64_t)B * D1 * D2 * C);
+#define S2(TT) hipLaunchKernelGGL((s2_shift2_kernel<TT>), dim3(g), dim3(256), 0, s, (const TT*)in, ldi, (TT*)out, ldo, B, D1, D2, C, which, mode, adjoint)
+    BW_DISPATCH(dtype, S2(float), S2(f16_t), S2(bf16_t))
+#undef S2
     MLPK_LAUNCH_CHECK();
     return 0;
 }

@@ -251,7 +251,56 @@ class S2MLPv2(E.EngineModule):
             self._block_runner(stage)(ws, pk, buf, B, H, W, "s%d." % stage, SHIFT_MODES[self.shift_mode], only=[index])
             return buf.reshape(B, H, W, C).to(x.dtype).clone()
 
+    _train_forward = True
+
+    def _forward_train(self, x):
+        """Train mode with autograd (round 6): s2_mlp_v2.py:6-132 as autograd.Functions of `..autograd`, forward and backward through
+        the C ABI.  The spatial shifts run on the thirds of mlp1's output IN PLACE of the reference's slice assignments: the forward in the model's
+        shift_mode (default: the reference's in-place result), the backward what the reference's autograd returns for those assignments -- the
+        adjoint of the INTENDED shift (mlpk_s2_shift2, checked against the reference's own gradients).  Stage convolutions after the first read
+        the previous stage's channel-last rows (mlpk_patch_rows_nhwc and its inverse for the gradient that flows back)."""
+        from .. import autograd as AG
+        E.require_gpu(x, "S2MLPv2.forward")
+        if x.dim() != 4:
+            raise ValueError("expected a (B, C, H, W) tensor")
+        cd = self._compute_dtype or x.dtype
+        E.dtype_code(cd)
+        B, cin, H, W = x.shape
+        smear = self.shift_mode == "reference_inplace"
+        t = None
+        for s in range(self.stage):
+            conv, blk = self.stages[s][0], self.stages[s][1]
+            ph, pw = self._patches[s]
+            if s == 0:
+                kp = E.round_up(cin * ph * pw, 4 if cd == torch.float32 else 8)
+                with E.on_device(x):
+                    patches = torch.zeros((B * (H // ph) * (W // pw), kp), dtype=cd, device=x.device)
+                    E.patchify(x.contiguous(), patches, B, cin, H, W, ph, pw, 0, kp)
+                t = AG.Linear.apply(patches, conv.weight, conv.bias, None)
+            else:
+                # channel-last source: columns (i, j, ci) -- the weight viewed in that order (a permute autograd maps back)
+                t = AG.Linear.apply(AG.PatchRowsNHWC.apply(t, B, H, W, ph, pw), conv.weight.permute(0, 2, 3, 1), conv.bias, None)
+            H, W = H // ph, W // pw
+            C = self._d_model[s]
+            for b2 in blk.model:
+                pre, mlp = b2[0], b2[1]
+                att = pre.fn
+                n = AG.LayerNorm.apply(t, pre.norm.weight, pre.norm.bias, pre.norm.eps)
+                y = AG.Linear.apply(n, att.mlp1.weight, att.mlp1.bias, None)                                 # (rows, 3C)
+                x1 = AG.S2Shift.apply(y[:, :C], B, H, W, 1, smear)
+                x2 = AG.S2Shift.apply(y[:, C:2 * C], B, H, W, 2, smear)
+                a = AG.split_attention(x1, x2, y[:, 2 * C:], att.split_attention, B, H * W)
+                t = AG.Linear.apply(a, att.mlp2.weight, att.mlp2.bias, t)
+                n2 = AG.LayerNorm.apply(t, mlp.norm.weight, mlp.norm.bias, mlp.norm.eps)
+                fc1, fc2 = mlp.fn[0], mlp.fn[3]
+                t = AG.Linear.apply(AG.Gelu.apply(AG.Linear.apply(n2, fc1.weight, fc1.bias, None)), fc2.weight, fc2.bias, t)
+        head = self.mlp_head[1]
+        logits = AG.Linear.apply(AG.TokenMean.apply(t, B, H * W), head.weight, head.bias, None)
+        return logits if logits.dtype == x.dtype else logits.to(x.dtype)
+
     def forward(self, x):
+        if self.training and torch.is_grad_enabled():
+            return self._forward_train(x)
         cd = self._resolve(x)
         B = x.shape[0]
         pk = self._get_pack(cd, x.device)

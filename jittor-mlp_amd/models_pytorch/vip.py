@@ -364,7 +364,58 @@ class ViP(E.EngineModule):
         pk["head.b"] = E.f32(self.mlp_head[2].bias, device)
         return pk
 
+    _train_forward = True
+
+    def _forward_train(self, x):
+        """Train mode with autograd (round 6): vip.py:7-57,59-128,150-175 as autograd.Functions of `..autograd`, forward and backward
+        through the C ABI -- the three branch Linears, the projection and the channel MLP = mlpk_gemm_nt (+ the two GEMMs of their backward),
+        the einops rearranges = mlpk_norm_apply(out_ph / out_pw) and mlpk_vip_unpermute (each the other's backward), SplitAttention = per-image
+        sums (mlpk_pool_mean / mlpk_broadcast_rows), two small Linears, mlpk_split_softmax (+ _backward) and the weighted sum by mlpk_ew_cols
+        (weights' gradient: mlpk_col_dot_seg); ParallelSum (weighted=False) = two mlpk_ew_cols additions."""
+        from .. import autograd as AG
+        E.require_gpu(x, "ViP.forward")
+        if x.dim() != 4:
+            raise ValueError("expected a (B, C, H, W) tensor")
+        cd = self._compute_dtype or x.dtype
+        E.dtype_code(cd)
+        H, W = self._hw
+        C = self._C
+        seg = self.blocks._dims[4]
+        B, cin, H_in, W_in = x.shape
+        ph, pw = self._patch
+        if (H_in // ph, W_in // pw) != (H, W):
+            raise ValueError("input size gives a %dx%d grid, the model was built for %dx%d" % (H_in // ph, W_in // pw, H, W))
+        conv = self.patcher[0]
+        kp = E.round_up(cin * ph * pw, 4 if cd == torch.float32 else 8)
+        S = H * W
+        with E.on_device(x):
+            patches = torch.zeros((B * S, kp), dtype=cd, device=x.device)
+            E.patchify(x.contiguous(), patches, B, cin, H_in, W_in, ph, pw, 0, kp)
+        t = AG.Linear.apply(patches, conv.weight, conv.bias, None)
+        for blk in self.blocks.model:
+            pre, mlp = blk[0], blk[1]
+            mix, proj = pre.fn[0], pre.fn[1]
+            n = AG.LayerNorm.apply(t, pre.norm.weight, pre.norm.bias, pre.norm.eps)
+            lh, lw, lc = mix.fns[0][1], mix.fns[1][1], mix.fns[2]
+            xh = AG.VipUnpermute.apply(AG.Linear.apply(AG.VipPermute.apply(n, B, H, W, seg, 0), lh.weight, lh.bias, None), B, H, W, C, seg, 0)
+            xw = AG.VipUnpermute.apply(AG.Linear.apply(AG.VipPermute.apply(n, B, H, W, seg, 1), lw.weight, lw.bias, None), B, H, W, C, seg, 1)
+            xc = AG.Linear.apply(n, lc.weight, lc.bias, None)
+            if self.blocks.weighted:
+                m = AG.split_attention(xh, xw, xc, mix.split_attention, B, S)
+            else:
+                m = AG.ScaleAdd.apply(AG.ScaleAdd.apply(xh, xw, None), xc, None)
+            t = AG.Linear.apply(m, proj.weight, proj.bias, t)
+            n2 = AG.LayerNorm.apply(t, mlp.norm.weight, mlp.norm.bias, mlp.norm.eps)
+            fc1, fc2 = mlp.fn[0], mlp.fn[3]
+            t = AG.Linear.apply(AG.Gelu.apply(AG.Linear.apply(n2, fc1.weight, fc1.bias, None)), fc2.weight, fc2.bias, t)
+        ln, head = self.mlp_head[0], self.mlp_head[2]
+        nf = AG.LayerNorm.apply(t, ln.weight, ln.bias, ln.eps)
+        logits = AG.Linear.apply(AG.TokenMean.apply(nf, B, S), head.weight, head.bias, None)
+        return logits if logits.dtype == x.dtype else logits.to(x.dtype)
+
     def forward(self, x):
+        if self.training and torch.is_grad_enabled():
+            return self._forward_train(x)
         cd = self._resolve(x)
         H, W = self._hw
         C = self._C

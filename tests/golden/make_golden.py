@@ -733,11 +733,16 @@ def make_train_grad(ref):
              ("asmlp", "tiny_asmlp.npz", ref["as_mlp"].AS_MLP, {"drop_path_rate": 0.0}, 33),
              ("asmlp_dp", "tiny_asmlp.npz", ref["as_mlp"].AS_MLP, {"drop_path_rate": 0.5}, 34),
              ("convmixer", "tiny_convmixer.npz", ref["conv_mixer"].ConvMixer, {}, 35),
-             ("convmixer_k4", "tiny_convmixer_k4.npz", ref["conv_mixer"].ConvMixer, {}, 36))
+             ("convmixer_k4", "tiny_convmixer_k4.npz", ref["conv_mixer"].ConvMixer, {}, 36),
+             ("vip", "tiny_vip_weighted.npz", ref["vip"].ViP, {}, 37),
+             ("vip_unweighted", "tiny_vip_unweighted.npz", ref["vip"].ViP, {}, 38),
+             ("vip_rect", "tiny_vip_rect.npz", ref["vip"].ViP, {}, 39),
+             ("s2mlpv2", "tiny_s2mlpv2.npz", ref["s2_mlp_v2"].S2MLPv2, {}, 40))
     for tag, fixture, ctor, extra, seed in cases:
+        torch.set_num_threads(1 if tag.startswith("s2") else 8)          # (S2-MLP's in-place shift is only deterministic on one thread)
         z = np.load(os.path.join(HERE, fixture))
         kw = dict(json.loads(str(z["kwargs"])), **extra)
-        model = ctor(**kw)
+        model = ctor(**{k: (tuple(v) if k in ("image_size",) and isinstance(v, list) else v) for k, v in kw.items()})
         model.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}, strict=True)
         model.train()
         x = torch.from_numpy(portable_input((4,) + tuple(z["input"].shape[1:]), seed=seed))
@@ -766,6 +771,7 @@ def make_train_grad(ref):
         gs = [float(p_.grad.abs().max()) for p_ in model.parameters() if p_.grad is not None]
         print("train-grad %-13s logits %s, %d gradients (max %.3e, min-of-max %.3e), %d parameters without, %d DropPath draws" % (
             tag, tuple(logits.shape), len(gs), max(gs), min(gs), len(nograd), len(dp.draws)))
+    torch.set_num_threads(8)
     np.savez_compressed(os.path.join(HERE, "train_grad_tiny.npz"), **out)
 
 
