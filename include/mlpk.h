@@ -666,6 +666,12 @@ int mlpk_split_softmax_backward(const float* bar, const float* dbar, float* dhat
  * adjoint 1: what the reference's autograd returns for the in-place slice assignments -- the adjoint of the INTENDED shift, whatever the forward did. */
 int mlpk_s2_shift2(int dtype, int which, int mode, int adjoint, const void* in, int64_t ldi, void* out, int64_t ldo, int B, int D1, int D2, int C, void* stream);
 
+/* A remap as an index table shared by all images of a batch: dst[(b, i), :] = sum over q < kmax of src[(b, idx[i * kmax + q]), :], rows of `width`
+ * contiguous elements, idx int32 (negative: no source).  kmax = 1: a gather -- the pads, rolls, window partitions, region rearranges and overlapping
+ * convolution windows of Swin-MLP (swin_mlp.py:33-60,129-151), MS-MLP (ms_mlp.py:52-54), Hire-MLP (hire_mlp.py:38-152) and CycleMLP (cycle_mlp.py:
+ * 104-131: CycleFC's fixed integer offsets, width = 1); the table of the inverse relation (kmax = largest multiplicity) is the adjoint -- the gradient. */
+int mlpk_index_gather(int dtype, const void* src, void* dst, const int* idx, int batch, int64_t n_out, int64_t n_in, int width, int kmax, void* stream);
+
 /* ---- small utilities ------------------------------------------------------------------------ */
 /* dst[i] = (dst_dtype) src[i], n elements */
 int mlpk_convert(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);

@@ -54,16 +54,19 @@ def col_sum(x, rows, cols, square=False, sub=None):
 _PACKS = {}
 
 
-def _packed(w, w2, cd, dev):
+def _packed(w, w2, cd, dev, kp=None):
     """the packed (compute-dtype, K-padded) copy of parameter w, cached per parameter version like EngineModule._get_pack (a training
     step used to re-pack every weight in every forward).  An entry belongs to ONE live tensor object (weak reference): the allocator
     hands a freed parameter's address -- with version 0 again -- to the next model's parameter, so the address alone is not an identity."""
-    key = (id(w), cd, str(dev))
+    key = (id(w), cd, str(dev), kp)
     hit = _PACKS.get(key)
     if hit is None or hit[0]() is not w or hit[1] != (w.data_ptr(), w._version) or hit[2].shape[0] != w2.shape[0]:
         if len(_PACKS) > 512:
             _PACKS.clear()
-        hit = (weakref.ref(w), (w.data_ptr(), w._version), E.pack_matrix(w2, cd, dev, kpad=_epc(cd)))
+        packed = E.pack_matrix(w2, cd, dev, kpad=_epc(cd))
+        if kp is not None and kp > packed.shape[1]:                      # an operand with more zero padding columns than the dtype needs (im2col: 16-byte rows)
+            packed = _pad_cols(packed, kp)
+        hit = (weakref.ref(w), (w.data_ptr(), w._version), packed)
         _PACKS[key] = hit
     return hit[2]
 
@@ -77,10 +80,12 @@ class Linear(torch.autograd.Function):
         w2 = w.reshape(w.shape[0], -1)
         n, k = w2.shape
         kp = E.round_up(k, _epc(cd))
+        if x.shape[1] > kp and x.shape[1] % _epc(cd) == 0:
+            kp = x.shape[1]                                                 # wider zero padding (mlpk_im2col pads rows to 16 bytes whatever the dtype)
         assert x.dim() == 2 and x.shape[1] in (k, kp), (tuple(x.shape), k)
         with E.on_device(x):
             xp = _pad_cols(x, kp)
-            wp = _packed(w, w2, cd, dev)
+            wp = _packed(w, w2, cd, dev, kp)
             y = torch.empty((x.shape[0], n), dtype=cd, device=dev)
             E.gemm(xp, wp, y, x.shape[0], n, kp, bias=E.f32(b, dev), R=r, res=N.RES_ADD if r is not None else N.RES_NONE)
         ctx.save_for_backward(xp, wp)
@@ -743,3 +748,139 @@ class PatchRowsNHWC(torch.autograd.Function):
         with E.on_device(dy):
             N.check(N.lib().mlpk_patch_rows_nhwc(E.dtype_code(dy.dtype), 1, 0, E.ptr(dy), E.ptr(dx), B, H, W, C, ph, pw, E.stream()), "mlpk_patch_rows_nhwc")
         return dx, None, None, None, None, None
+
+
+# ---- remaps as index tables (round 6: Swin-MLP, MS-MLP, Hire-MLP, CycleMLP) ----------------------------------------------------------------
+class IndexTable:
+    """A batch-independent remap `dst[i] = src[idx[i]]` (idx < 0: zero) over rows of `width` elements, with the table of its adjoint.
+    Built from a LongTensor of source positions per destination position -- produced by running the reference's own index arithmetic
+    (torch.roll, F.pad, view / permute) on a tensor of positions, so the table IS the reference's remap."""
+
+    def __init__(self, idx, n_in, width, device):
+        idx = idx.reshape(-1).to(torch.int64).cpu()
+        self.n_out, self.n_in, self.width = idx.numel(), int(n_in), int(width)
+        self.fwd = idx.to(torch.int32).to(device).contiguous()
+        # the inverse relation: for every source position the destinations that read it, padded with -1 to the largest multiplicity
+        valid = idx >= 0
+        dst_pos = torch.nonzero(valid).reshape(-1)
+        src_pos = idx[valid]
+        order = torch.argsort(src_pos, stable=True)
+        src_sorted, dst_sorted = src_pos[order], dst_pos[order]
+        counts = torch.bincount(src_sorted, minlength=self.n_in)
+        self.kmax = max(int(counts.max()) if counts.numel() else 1, 1)
+        starts = torch.cumsum(counts, 0) - counts
+        rank = torch.arange(src_sorted.numel()) - starts[src_sorted]
+        inv = torch.full((self.n_in, self.kmax), -1, dtype=torch.int64)
+        inv[src_sorted, rank] = dst_sorted
+        self.inv = inv.to(torch.int32).to(device).contiguous()
+
+
+def _index_gather(src, table, kmax, batch, n_out, n_in, width):
+    out = torch.empty((batch * n_out * width,), dtype=src.dtype, device=src.device)
+    N.check(N.lib().mlpk_index_gather(E.dtype_code(src.dtype), E.ptr(src), E.ptr(out), E.ptr(table), batch, n_out, n_in, width, kmax, E.stream()), "mlpk_index_gather")
+    return out
+
+
+class IndexMap(torch.autograd.Function):
+    """x: (B * n_in * width / cols, cols) contiguous -> (B * n_out * width / out_cols, out_cols): the remap of an IndexTable; backward: its adjoint"""
+
+    @staticmethod
+    def forward(ctx, x, tab, B, out_cols):
+        x = x.contiguous()
+        assert x.numel() == B * tab.n_in * tab.width, (tuple(x.shape), B, tab.n_in, tab.width)
+        ctx.tab, ctx.B, ctx.in_cols = tab, B, x.shape[1]
+        with E.on_device(x):
+            return _index_gather(x, tab.fwd, 1, B, tab.n_out, tab.n_in, tab.width).view(-1, out_cols)
+
+    @staticmethod
+    def backward(ctx, dy):
+        tab = ctx.tab
+        dy = dy.contiguous()
+        with E.on_device(dy):
+            return _index_gather(dy, tab.inv, tab.kmax, ctx.B, tab.n_in, tab.n_out, tab.width).view(-1, ctx.in_cols), None, None, None
+
+
+class ConcatCols(torch.autograd.Function):
+    """torch.cat over the channel axis of channel-last rows (sparse_mlp.py:71, ms_mlp.py:58-59): the parts copied into column slices of one buffer"""
+
+    @staticmethod
+    def forward(ctx, *parts):
+        widths = [p_.shape[1] for p_ in parts]
+        ctx.widths = widths
+        out = torch.empty((parts[0].shape[0], sum(widths)), dtype=parts[0].dtype, device=parts[0].device)
+        c0 = 0
+        with E.on_device(out):
+            for p_, wd in zip(parts, widths):
+                _ew(0, _rows(p_), out=out[:, c0:c0 + wd])
+                c0 += wd
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        outs, c0 = [], 0
+        for wd in ctx.widths:
+            outs.append(dy[:, c0:c0 + wd])
+            c0 += wd
+        return tuple(outs)
+
+
+class AddPeriodic(torch.autograd.Function):
+    """x[b, l, :] + t[l, :] (SwinMLP's absolute position embedding, swin_mlp.py:437-438); t: parameter (1, L, C)"""
+
+    @staticmethod
+    def forward(ctx, x, t, L):
+        out = x.clone()
+        ctx.meta = (tuple(t.shape), L)
+        with E.on_device(x):
+            E.add_periodic(out, out.stride(0), E.f32(t, x.device), out.shape[0], out.shape[1], L)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        tshape, L = ctx.meta
+        dy = dy.contiguous()
+        Bn = dy.shape[0] // L
+        with E.on_device(dy):
+            dt = col_sum(dy.view(Bn, L * dy.shape[1]), Bn, L * dy.shape[1])
+        return dy, dt.reshape(tshape), None
+
+
+def drop_add(owner, t, z, rate, B, period):
+    """t + drop_path(z) in train mode (the per-sample keep / (1 - p) scale of conv_mlp.py:27-34 on the draws of owner.drop_path_uniform);
+    rate 0: the plain sum"""
+    rate = float(rate)
+    if rate == 0.0:
+        return ScaleAdd.apply(t, z, None)
+    keep = 1.0 - rate
+    u = owner.drop_path_uniform(B, t.dtype, t.device)
+    scale = (torch.floor(keep + u.reshape(B).float()) / keep).contiguous()
+    return ScaleAdd.apply(t, RowScale.apply(z, scale, period), None)
+
+
+def position_table(fn, n_in, width, device, cache, key):
+    """IndexTable of a remap given as torch index arithmetic: fn(pos) is applied to a float64 tensor of source positions + 1 (0 = padding)
+    and returns the destination layout; cached per key"""
+    tab = cache.get(key)
+    if tab is None:
+        pos = torch.arange(1, n_in + 1, dtype=torch.float64)
+        idx = fn(pos).reshape(-1).round().to(torch.int64) - 1
+        tab = IndexTable(idx, n_in, width, device)
+        cache[key] = tab
+    return tab
+
+
+def conv_window_table(H, W, C, k, stride, pad, device, cache):
+    """IndexTable of the im2col of Conv2d(kernel k, stride, padding pad) on channel-last rows: destination rows (ho, wo), columns (kh, kw, c) --
+    pixel granularity (width C), -1 where the window hangs over the border; its inverse table sums the overlapping windows (col2im)"""
+    key = ("convwin", H, W, C, k, stride, pad)
+    tab = cache.get(key)
+    if tab is None:
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        yy = (torch.arange(Ho) * stride - pad).view(Ho, 1, 1, 1) + torch.arange(k).view(1, 1, k, 1)
+        xx = (torch.arange(Wo) * stride - pad).view(1, Wo, 1, 1) + torch.arange(k).view(1, 1, 1, k)
+        ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W)
+        idx = torch.where(ok, yy * W + xx, torch.full_like(yy * W + xx, -1))
+        tab = IndexTable(idx, H * W, C, device)
+        tab.out_hw = (Ho, Wo)
+        cache[key] = tab
+    return tab

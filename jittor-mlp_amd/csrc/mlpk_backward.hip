@@ -361,6 +361,27 @@ template <typename T> __global__ void __launch_bounds__(256) s2_shift2_kernel(co
     }
 }
 
+// A remap given as an index table, the same for every image of the batch: dst[(b, i), :] = sum over q < kmax of src[(b, idx[i * kmax + q]), :]
+// (rows of `width` contiguous elements; idx < 0: nothing).  kmax = 1 is a gather -- zero padding, circular padding, rolls, window partitions,
+// region rearranges, overlapping-window im2col, per-channel shifts (width = 1) -- and the table of the INVERSE relation (every source's list of
+// readers, kmax = the largest multiplicity) is its adjoint, again as a gather: no atomics, a fixed summation order.  The tables are built once
+// per shape by running the reference's own index arithmetic (torch.roll / F.pad / view / permute) on a tensor of positions.
+template <typename T> __global__ void __launch_bounds__(256) index_gather_kernel(const T* __restrict__ src, T* __restrict__ dst, const int* __restrict__ idx, int batch,
+                                                                                 int64_t n_out, int64_t n_in, int width, int kmax) {
+    const int64_t total = (int64_t)batch * n_out * width;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int e = (int)(t % width);
+        const int64_t r = t / width;
+        const int64_t i = r % n_out, b = r / n_out;
+        float acc = 0.f;
+        for (int q = 0; q < kmax; ++q) {
+            const int j = idx[i * kmax + q];
+            if (j >= 0) acc += to_f32<T>(src[(b * n_in + j) * width + e]);
+        }
+        dst[t] = from_f32<T>(acc);
+    }
+}
+
 static unsigned ew_grid(int64_t total) {
     int64_t g = (total + 255) / 256;
     return (unsigned)(g < 1 ? 1 : (g > 65536 ? 65536 : g));
@@ -616,6 +637,19 @@ extern "C" int mlpk_s2_shift2(int dtype, int which, int mode, int adjoint, const
 #define S2(TT) hipLaunchKernelGGL((s2_shift2_kernel<TT>), dim3(g), dim3(256), 0, s, (const TT*)in, ldi, (TT*)out, ldo, B, D1, D2, C, which, mode, adjoint)
     BW_DISPATCH(dtype, S2(float), S2(f16_t), S2(bf16_t))
 #undef S2
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mlpk_index_gather(int dtype, const void* src, void* dst, const int* idx, int batch, int64_t n_out, int64_t n_in, int width, int kmax, void* stream) {
+    using namespace mlpk;
+    if (!src || !dst || !idx) return MLPK_ENULL;
+    if (batch <= 0 || n_out <= 0 || n_in <= 0 || width <= 0 || kmax <= 0 || n_in > 0x7fffffffLL || src == dst) return MLPK_ESHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const unsigned g = ew_grid((int64_t)batch * n_out * width);
+#define IG(TT) hipLaunchKernelGGL((index_gather_kernel<TT>), dim3(g), dim3(256), 0, s, (const TT*)src, (TT*)dst, idx, batch, n_out, n_in, width, kmax)
+    BW_DISPATCH(dtype, IG(float), IG(f16_t), IG(bf16_t))
+#undef IG
     MLPK_LAUNCH_CHECK();
     return 0;
 }

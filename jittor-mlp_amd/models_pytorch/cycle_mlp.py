@@ -150,7 +150,7 @@ class CycleNet(StochasticDepth, E.EngineModule):
     returns the list of the four stage outputs, each through its own `norm{0,2,4,6}` LayerNorm (an Identity for the first one under the
     reference's FORK_LAST3 environment switch) and as (B, C, H, W)."""
 
-    _train_forward = "forward-only"
+    _train_forward = True
 
     def __init__(self, layers, img_size=224, patch_size=4, in_chans=3, num_classes=1000, embed_dims=None, transitions=None,
                  segment_dim=None, mlp_ratios=None, skip_lam=1.0, qkv_bias=False, qk_scale=None, drop_rate=0., attn_drop_rate=0.,
@@ -364,7 +364,85 @@ class CycleNet(StochasticDepth, E.EngineModule):
             self._block(ws, pk, "n%d.b%d." % (si, bi), cur, B, H, W, C, blk.mlp.fc1.weight.shape[0], "n%d" % si, rate=blk.drop_path_rate)
             return cur.reshape(B, H, W, C).clone()
 
+    def _forward_train(self, x):
+        """Train mode with autograd (round 6): cycle_mlp.py:54-131,163-199,213-226,297-345 as autograd.Functions of `..autograd`, forward
+        and backward through the C ABI.  CycleFC = deform_conv2d with a 1 x 1 kernel and fixed integer offsets = a per-channel pixel shift with
+        zero fill (an index table at element granularity from CycleFC.offset itself; its inverse is the gradient) followed by mlpk_gemm_nt;
+        the reweighting = per-image means, two small Linears, the softmax over the three branches (mlpk_split_softmax + backward) and the weighted
+        sum (mlpk_ew_cols); stochastic depth and 1 / skip_lam as per-sample / per-channel scales; Downsample (3 x 3 stride 2) = an
+        overlapping-window table + mlpk_gemm_nt.  (deform_conv2d itself: the stand-in caveat of SURVEY 8f-3 applies to the fixture, not to this code.)"""
+        from .. import autograd as AG
+        E.require_gpu(x, "CycleNet.forward")
+        if x.dim() != 4:
+            raise ValueError("expected a (B, C, H, W) tensor")
+        if self.fork_feat:
+            raise NotImplementedError("fork_feat=True is a dense-prediction backbone: train() with autograd is built for the classifier")
+        cd = self._compute_dtype or x.dtype
+        E.dtype_code(cd)
+        B, cin, H_in, W_in = x.shape
+        dev = x.device
+        H, W = (H_in + 4 - 7) // 4 + 1, (W_in + 4 - 7) // 4 + 1
+        kp = E.round_up(cin * 49, 8)                                                     # (mlpk_im2col: rows of whole 16-byte chunks)
+        with E.on_device(x):
+            patches = torch.zeros((B * H * W, kp), dtype=cd, device=dev)
+            E.im2col(x.contiguous(), patches, B, cin, H_in, W_in, 7, 7, 4, 4, 2, kp)
+        tables = self.__dict__.setdefault("_tables", {})
+
+        def ln(t, norm):
+            return AG.LayerNorm.apply(t, norm.weight, norm.bias, norm.eps)
+
+        def shifted(fc, t, H, W, C):
+            off = fc.offset.reshape(C, 2).round().to(torch.int64).cpu()                           # (dy, dx) per input channel (cycle_mlp.py:104-120)
+
+            def fn(pos, H=H, W=W, C=C, off=off):
+                g = pos.view(H, W, C)
+                yy = torch.arange(H).view(H, 1, 1) + off[:, 0].view(1, 1, C)
+                xx = torch.arange(W).view(1, W, 1) + off[:, 1].view(1, 1, C)
+                ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W)
+                src = g[yy.clamp(0, H - 1), xx.clamp(0, W - 1), torch.arange(C).view(1, 1, C).expand(H, W, C)]
+                return torch.where(ok, src, torch.zeros_like(src))
+            tab = AG.position_table(fn, H * W * C, 1, dev, tables, ("cyc", H, W, C, tuple(off.reshape(-1).tolist())))
+            return AG.Linear.apply(AG.IndexMap.apply(t, tab, B, C), fc.weight, fc.bias, None)
+
+        pe = self.patch_embed
+        t = AG.Linear.apply(patches, pe.proj.weight, pe.proj.bias, None)
+        C = pe.proj.weight.shape[0]
+        for stage in self.network:
+            if isinstance(stage, Downsample):
+                tab = AG.conv_window_table(H, W, C, 3, 2, 1, dev, tables)
+                t = AG.Linear.apply(AG.IndexMap.apply(t, tab, B, 9 * C), stage.proj.weight.permute(0, 2, 3, 1), stage.proj.bias, None)
+                H, W = tab.out_hw
+                C = stage.proj.weight.shape[0]
+                continue
+            for blk in stage:
+                at = blk.attn
+                lam = None if float(blk.skip_lam) == 1.0 else torch.full((C,), 1.0 / float(blk.skip_lam), dtype=torch.float32, device=dev)
+                n = ln(t, blk.norm1)
+                xh, xw = shifted(at.sfc_h, n, H, W, C), shifted(at.sfc_w, n, H, W, C)
+                xc = AG.Linear.apply(n, at.mlp_c.weight, at.mlp_c.bias, None)
+                a = AG.TokenMean.apply(AG.ScaleAdd.apply(AG.ScaleAdd.apply(xh, xw, None), xc, None), B, H * W)            # (h + w + c).mean over pixels
+                r = AG.Linear.apply(AG.Gelu.apply(AG.Linear.apply(a, at.reweight.fc1.weight, at.reweight.fc1.bias, None)),
+                                    at.reweight.fc2.weight, at.reweight.fc2.bias, None)                                    # (B, 3C), column c * 3 + k
+                hat = r.float().reshape(B, C, 3).permute(0, 2, 1).reshape(B, 3 * C)                                     # -> [B][k][C] (tiny; autograd-native)
+                bar = AG.SoftmaxBranches.apply(hat, B, C)
+                z = AG.Linear.apply(AG.WeightedSum3.apply(xh, xw, xc, bar, B, H * W).to(cd), at.proj.weight, at.proj.bias, None)
+                if lam is not None:
+                    z = AG.Affine.apply(z, lam, None)
+                t = AG.drop_add(self, t, z, blk.drop_path_rate, B, H * W)
+                z = AG.Linear.apply(AG.Gelu.apply(AG.Linear.apply(ln(t, blk.norm2), blk.mlp.fc1.weight, blk.mlp.fc1.bias, None)),
+                                    blk.mlp.fc2.weight, blk.mlp.fc2.bias, None)
+                if lam is not None:
+                    z = AG.Affine.apply(z, lam, None)
+                t = AG.drop_add(self, t, z, blk.drop_path_rate, B, H * W)
+        pooled = AG.TokenMean.apply(ln(t, self.norm), B, H * W)
+        if not isinstance(self.head, nn.Linear):
+            return pooled if pooled.dtype == x.dtype else pooled.to(x.dtype)
+        logits = AG.Linear.apply(pooled, self.head.weight, self.head.bias, None)
+        return logits if logits.dtype == x.dtype else logits.to(x.dtype)
+
     def forward(self, x):
+        if self.training and torch.is_grad_enabled():
+            return self._forward_train(x)
         cd = self._resolve(x)
         B, cin, H_in, W_in = x.shape
         pk = self._get_pack(cd, x.device)

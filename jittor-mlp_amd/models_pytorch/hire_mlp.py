@@ -338,7 +338,104 @@ class HireMLP(E.EngineModule):
                 cur, H, W, C, _ = self._merge(ws, pk, li, cur, B, H, W, C)
             return cur.reshape(B, H, W, C).clone()
 
+    _train_forward = True
+
+    def _forward_train(self, x):
+        """Train mode with autograd (round 6): hire_mlp.py:6-215 as autograd.Functions of `..autograd`, forward and backward through the
+        C ABI.  A block's circular padding + cross-region roll + inner-region rearrange, and the restore + roll back + crop, are ONE index
+        table each per axis (mlpk_index_gather at element granularity; built by running the reference's own F.pad / torch.roll / einops
+        patterns on a tensor of positions; the inverse table -- which sums the duplicates the circular padding makes -- is the gradient);
+        the region FeedForwards and proj_c are mlpk_gemm_nt (proj_c is pointwise: it commutes with the padding and the crop); the 3 x 3
+        stride-2 stage transitions are an overlapping-window table + mlpk_gemm_nt (col2im = the inverse table)."""
+        import torch.nn.functional as F
+        from .. import autograd as AG
+        E.require_gpu(x, "HireMLP.forward")
+        if x.dim() != 4:
+            raise ValueError("expected a (B, C, H, W) tensor")
+        cd = self._compute_dtype or x.dtype
+        E.dtype_code(cd)
+        patch, cin, num_classes, patcher_norm = self._cfg
+        B, _, H_in, W_in = x.shape
+        dev = x.device
+        H, W = (H_in + 6 - 7) // patch[0] + 1, (W_in + 6 - 7) // patch[1] + 1
+        kp = E.round_up(cin * 49, 8)                                                     # (mlpk_im2col: rows of whole 16-byte chunks)
+        with E.on_device(x):
+            patches = torch.zeros((B * H * W, kp), dtype=cd, device=dev)
+            E.im2col(x.contiguous(), patches, B, cin, H_in, W_in, 7, 7, patch[0], patch[1], 3, kp)
+        tables = self.__dict__.setdefault("_tables", {})
+
+        def ln(t, norm):
+            return AG.LayerNorm.apply(t, norm.weight, norm.bias, norm.eps)
+
+        def ff(rows, m):                                                                          # FeedForward (hire_mlp.py:33-42): two 1x1 convs
+            return AG.Linear.apply(AG.Gelu.apply(AG.Linear.apply(rows, m.net[0].weight, m.net[0].bias, None)), m.net[2].weight, m.net[2].bias, None)
+
+        red = self.patcher.reduction
+        t = AG.Linear.apply(patches, red[0].weight, red[0].bias, None)
+        if patcher_norm:
+            t = ln(t, red[1][1])
+        for stage in self.layers:
+            h, w, C, Cout, depth, ef = stage.geom
+            for blk in stage.model:
+                pre, mlp = blk[0], blk[1]
+                hb = pre.fn[0]
+                step = hb.step
+                Hp, Wp = H + (h - H % h), W + (w - W % w)                                          # hire_mlp.py:134-136 (a whole region more when divisible)
+
+                def padded(pos, H=H, W=W, C=C, Hp=Hp, Wp=Wp, mode=hb.padding_type):
+                    g = pos.view(1, H, W, C).permute(0, 3, 1, 2)                                   # NCHW view of the channel-last positions
+                    return F.pad(g, (0, Wp - W, 0, Hp - H), mode) if mode != "constant" else F.pad(g, (0, Wp - W, 0, Hp - H), "constant", 0)
+
+                def region_h(pos, h=h, C=C, Hp=Hp, Wp=Wp, step=step):
+                    g = padded(pos)
+                    g = torch.roll(g, step, 2) if step else g                                      # cross_regionH
+                    g = g.reshape(1, C * h, Hp // h, Wp)                                           # 'b c (h group) w -> b (c h) group w'
+                    return g.permute(0, 2, 3, 1).contiguous()                                      # rows (group, w), columns (c h)
+
+                def region_w(pos, w=w, C=C, Hp=Hp, Wp=Wp, step=step):
+                    g = padded(pos)
+                    g = torch.roll(g, step, 3) if step else g                                      # cross_regionW
+                    g = g.view(1, C, Hp, w, Wp // w).permute(0, 1, 3, 2, 4).reshape(1, C * w, Hp, Wp // w)      # 'b c h (w group) -> b (c w) h group'
+                    return g.permute(0, 2, 3, 1).contiguous()
+
+                def restore_h(pos, h=h, C=C, H=H, W=W, Hp=Hp, Wp=Wp, step=step):
+                    g = pos.view(1, Hp // h, Wp, C * h).permute(0, 3, 1, 2)                        # (b, (c h), group, w)
+                    g = g.reshape(1, C, Hp, Wp)                                                    # 'b (c h) group w -> b c (h group) w'
+                    g = torch.roll(g, -step, 2) if step else g
+                    return g[:, :, :H, :W].permute(0, 2, 3, 1).contiguous()
+
+                def restore_w(pos, w=w, C=C, H=H, W=W, Hp=Hp, Wp=Wp, step=step):
+                    g = pos.view(1, Hp, Wp // w, C * w).permute(0, 3, 1, 2)                        # (b, (c w), h, group)
+                    g = g.view(1, C, w, Hp, Wp // w).permute(0, 1, 3, 2, 4).reshape(1, C, Hp, Wp)  # 'b (c w) h group -> b c h (w group)'
+                    g = torch.roll(g, -step, 3) if step else g
+                    return g[:, :, :H, :W].permute(0, 2, 3, 1).contiguous()
+
+                key = (H, W, C, h, w, step, hb.padding_type)
+                if hb.padding_type in ("reflect", "replicate", "circular"):
+                    pass
+                th = AG.position_table(region_h, H * W * C, 1, dev, tables, ("rh",) + key)
+                tw = AG.position_table(region_w, H * W * C, 1, dev, tables, ("rw",) + key)
+                bh = AG.position_table(restore_h, Hp * Wp * C, 1, dev, tables, ("bh",) + key)
+                bw = AG.position_table(restore_w, Hp * Wp * C, 1, dev, tables, ("bw",) + key)
+                n = ln(t, pre.norm)
+                x_h = AG.IndexMap.apply(ff(AG.IndexMap.apply(n, th, B, C * h), hb.proj_h), bh, B, C)
+                x_w = AG.IndexMap.apply(ff(AG.IndexMap.apply(n, tw, B, C * w), hb.proj_w), bw, B, C)
+                x_c = AG.Linear.apply(n, hb.proj_c.weight, hb.proj_c.bias, None)
+                t = AG.ScaleAdd.apply(AG.ScaleAdd.apply(AG.ScaleAdd.apply(x_c, x_h, None), x_w, None), t, None)
+                fc1, fc2 = mlp.fn[0], mlp.fn[3]
+                t = AG.Linear.apply(AG.Gelu.apply(AG.Linear.apply(ln(t, mlp.norm), fc1.weight, fc1.bias, None)), fc2.weight, fc2.bias, t)
+            if stage.pooling:
+                conv = stage.patch_merge[1].reduction[0]
+                tab = AG.conv_window_table(H, W, C, 3, 2, 1, dev, tables)
+                t = AG.Linear.apply(AG.IndexMap.apply(t, tab, B, 9 * C), conv.weight.permute(0, 2, 3, 1), conv.bias, None)
+                H, W = tab.out_hw
+        head_ln, head = self.mlp_head[0], self.mlp_head[2]
+        logits = AG.Linear.apply(AG.TokenMean.apply(ln(t, head_ln), B, H * W), head.weight, head.bias, None)
+        return logits if logits.dtype == x.dtype else logits.to(x.dtype)
+
     def forward(self, x):
+        if self.training and torch.is_grad_enabled():
+            return self._forward_train(x)
         cd = self._resolve(x)
         patch, cin, num_classes, patcher_norm = self._cfg
         B, _, H_in, W_in = x.shape

@@ -128,7 +128,7 @@ class MS_MLP(StochasticDepth, E.EngineModule):
 
     train() (round 6): the forward applies the blocks' stochastic depth (ms_mlp.py:46,77: x = input + drop_path(gamma * branch)) --
     see common.StochasticDepth; the LayerNorms have no batch statistics, Dropout has p = 0.  Forward only: the outputs carry no grad_fn."""
-    _train_forward = "forward-only"
+    _train_forward = True
 
     def __init__(self, img_size=224, patch_size=4, in_chans=3, num_classes=1000, embed_dim=96, depths=[2, 2, 6, 2], shift_size=5,
                  shift_dist=[-2, -1, 0, 1, 2], mix_size=[[1, 1, 3, 5, 7], [1, 1, 3, 5, 5], [1, 1, 3, 3, 3], [1, 1, 1, 1, 3]], mlp_ratio=4.,
@@ -294,7 +294,86 @@ class MS_MLP(StochasticDepth, E.EngineModule):
                 cur, H, W, C = self._down(ws, pk, li, cur, B, H, W, C)
             return cur.reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
 
+    def _forward_train(self, x):
+        """Train mode with autograd (round 6): ms_mlp.py:12-84,145-290,352-367 as autograd.Functions of `..autograd`, forward and backward
+        through the C ABI.  The per-chunk torch.roll along W resp. H is one index table per direction (mlpk_index_gather at element
+        granularity, built by running torch.roll on a tensor of positions; the inverse table is the gradient); the per-chunk depthwise
+        convolutions of different sizes run as ONE depthwise convolution whose taps are the chunks' kernels zero-padded to the largest size
+        (mlpk_dwconv_plain_nhwc; the padding and concatenation of the small weight tensors are torch views autograd maps back); layer scale =
+        mlpk_ew_cols; stochastic depth on drop_path_uniform's draws; the stage transitions (Conv2d 2 x 2 stride 2 + LayerNorm) =
+        mlpk_patch_rows_nhwc + mlpk_gemm_nt."""
+        import torch.nn.functional as F
+        from .. import autograd as AG
+        E.require_gpu(x, "MS_MLP.forward")
+        if x.dim() != 4:
+            raise ValueError("expected a (B, C, H, W) tensor")
+        cd = self._compute_dtype or x.dtype
+        E.dtype_code(cd)
+        pe = self.patch_embed
+        B, cin, H_in, W_in = x.shape
+        assert H_in == pe.img_size[0] and W_in == pe.img_size[1], \
+            f"Input image size ({H_in}*{W_in}) doesn't match model ({pe.img_size[0]}*{pe.img_size[1]})."
+        ph, pw = pe.patch_size
+        H, W = H_in // ph, W_in // pw
+        dev = x.device
+        kp = E.round_up(cin * ph * pw, 4 if cd == torch.float32 else 8)
+        with E.on_device(x):
+            patches = torch.zeros((B * H * W, kp), dtype=cd, device=dev)
+            E.patchify(x.contiguous(), patches, B, cin, H_in, W_in, ph, pw, 0, kp)
+        tables = self.__dict__.setdefault("_tables", {})
+
+        def ln(t, norm):
+            return AG.LayerNorm.apply(t, norm.weight, norm.bias, norm.eps)
+
+        t = AG.Linear.apply(patches, pe.proj.weight, pe.proj.bias, None)
+        if pe.norm is not None:
+            t = ln(t, pe.norm)
+        C = self.embed_dim
+        for layer in self.layers:
+            for blk in layer.blocks:
+                sizes, dist = blk.chunk_size, blk.shift_dist
+
+                def rolled(pos, axis, H=H, W=W, C=C, sizes=sizes, dist=dist):
+                    g = pos.view(1, H, W, C).permute(0, 3, 1, 2)                                  # NCHW view of the channel-last positions
+                    parts = [torch.roll(xc, sh, axis) for xc, sh in zip(torch.split(g, sizes, 1), dist)]       # ms_mlp.py:52-54
+                    return torch.cat(parts, 1).permute(0, 2, 3, 1).contiguous()
+
+                t_lr = AG.position_table(lambda p_: rolled(p_, 3), H * W * C, 1, dev, tables, ("roll", 3, H, W, C, tuple(sizes), tuple(dist)))
+                t_td = AG.position_table(lambda p_: rolled(p_, 2), H * W * C, 1, dev, tables, ("roll", 2, H, W, C, tuple(sizes), tuple(dist)))
+                kmax = max(ks[0] for ks in blk.kernel_size)
+
+                def taps(convs):
+                    ws_, bs_ = [], []
+                    for cv in convs:
+                        pd = (kmax - cv.weight.shape[-1]) // 2
+                        ws_.append(F.pad(cv.weight, [pd, pd, pd, pd]))
+                        bs_.append(cv.bias if cv.bias is not None else torch.zeros(cv.weight.shape[0], dtype=cv.weight.dtype, device=cv.weight.device))
+                    return torch.cat(ws_, 0), torch.cat(bs_, 0)
+
+                w_lr, b_lr = taps(blk.dwconv_lr)
+                w_td, b_td = taps(blk.dwconv_td)
+                x_lr = AG.DepthwiseConv.apply(AG.IndexMap.apply(t, t_lr, B, C), w_lr, b_lr, B, H, W)
+                x_td = AG.DepthwiseConv.apply(AG.IndexMap.apply(t, t_td, B, C), w_td, b_td, B, H, W)
+                n = ln(AG.ScaleAdd.apply(x_lr, x_td, None), blk.norm)
+                z = AG.Linear.apply(AG.Gelu.apply(AG.Linear.apply(n, blk.pwconv1.weight, blk.pwconv1.bias, None)), blk.pwconv2.weight, blk.pwconv2.bias, None)
+                if blk.gamma is not None:
+                    z = AG.Affine.apply(z, blk.gamma, None)
+                t = AG.drop_add(self, t, z, blk.drop_path_rate, B, H * W)
+            if layer.downsample is not None:
+                ds = layer.downsample
+                t = AG.Linear.apply(AG.PatchRowsNHWC.apply(t, B, H, W, 2, 2), ds.proj.weight.permute(0, 2, 3, 1), ds.proj.bias, None)
+                if ds.norm is not None:
+                    t = ln(t, ds.norm)
+                H, W, C = H // 2, W // 2, 2 * C
+        pooled = ln(AG.TokenMean.apply(t, B, H * W), self.norm)                               # avgpool, THEN the norm (ms_mlp.py:359-361)
+        if not isinstance(self.head, nn.Linear):
+            return pooled if pooled.dtype == x.dtype else pooled.to(x.dtype)
+        logits = AG.Linear.apply(pooled, self.head.weight, self.head.bias, None)
+        return logits if logits.dtype == x.dtype else logits.to(x.dtype)
+
     def forward(self, x):
+        if self.training and torch.is_grad_enabled():
+            return self._forward_train(x)
         cd = self._resolve(x)
         pe = self.patch_embed
         B, _, H_in, W_in = x.shape

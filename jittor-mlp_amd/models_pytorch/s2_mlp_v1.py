@@ -163,7 +163,49 @@ class S2MLPv1(E.EngineModule):
         pk["head.b"] = E.f32(self.mlp_head[1].bias, device)
         return pk
 
+    _train_forward = True
+
+    def _forward_train(self, x):
+        """Train mode with autograd (round 6): s2_mlp_v1.py:6-93 as autograd.Functions of `..autograd` (see S2MLPv2._forward_train): the
+        Spatial_Shift between the two Linears of the token-mixing sublayer runs in the model's shift_mode forward and returns the gradient the
+        reference's autograd returns for the in-place slice assignments (the adjoint of the intended shift)."""
+        from .. import autograd as AG
+        E.require_gpu(x, "S2MLPv1.forward")
+        if x.dim() != 4:
+            raise ValueError("expected a (B, C, H, W) tensor")
+        cd = self._compute_dtype or x.dtype
+        E.dtype_code(cd)
+        B, cin, H, W = x.shape
+        smear = self.shift_mode == "reference_inplace"
+        t = None
+        for s in range(self.stage):
+            conv, blk = self.stages[s][0], self.stages[s][1]
+            ph, pw = self._patches[s]
+            if s == 0:
+                kp = E.round_up(cin * ph * pw, 4 if cd == torch.float32 else 8)
+                with E.on_device(x):
+                    patches = torch.zeros((B * (H // ph) * (W // pw), kp), dtype=cd, device=x.device)
+                    E.patchify(x.contiguous(), patches, B, cin, H, W, ph, pw, 0, kp)
+                t = AG.Linear.apply(patches, conv.weight, conv.bias, None)
+            else:
+                t = AG.Linear.apply(AG.PatchRowsNHWC.apply(t, B, H, W, ph, pw), conv.weight.permute(0, 2, 3, 1), conv.bias, None)
+            H, W = H // ph, W // pw
+            for b2 in blk.model:
+                pre, mlp = b2[0], b2[1]
+                l1, l2 = pre.fn[0], pre.fn[3]
+                n = AG.LayerNorm.apply(t, pre.norm.weight, pre.norm.bias, pre.norm.eps)
+                y = AG.S2Shift.apply(AG.Gelu.apply(AG.Linear.apply(n, l1.weight, l1.bias, None)), B, H, W, 1, smear)
+                t = AG.Linear.apply(y, l2.weight, l2.bias, t)
+                n2 = AG.LayerNorm.apply(t, mlp.norm.weight, mlp.norm.bias, mlp.norm.eps)
+                fc1, fc2 = mlp.fn[0], mlp.fn[3]
+                t = AG.Linear.apply(AG.Gelu.apply(AG.Linear.apply(n2, fc1.weight, fc1.bias, None)), fc2.weight, fc2.bias, t)
+        head = self.mlp_head[1]
+        logits = AG.Linear.apply(AG.TokenMean.apply(t, B, H * W), head.weight, head.bias, None)
+        return logits if logits.dtype == x.dtype else logits.to(x.dtype)
+
     def forward(self, x):
+        if self.training and torch.is_grad_enabled():
+            return self._forward_train(x)
         cd = self._resolve(x)
         B = x.shape[0]
         pk = self._get_pack(cd, x.device)

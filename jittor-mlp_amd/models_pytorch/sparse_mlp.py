@@ -331,7 +331,68 @@ class SparseMLP(E.EngineModule):
             cur, _ = self._block(ws, pk, li, bi, stage, cur, ws.get("blk.tmp", (rows, C)), B)
             return cur.reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
 
+    _train_forward = True
+
+    def _forward_train(self, x):
+        """Train mode with autograd (round 6): sparse_mlp.py:6-175 as autograd.Functions of `..autograd`, forward and backward through the
+        C ABI.  BatchNorm2d runs on BATCH statistics with the full backward through them and updates its running statistics (the two
+        PreNormResidual(norm = BatchNorm2d) sublayers); proj_h / proj_w contract over H resp. W: the ViP rearranges with one-channel segments
+        (mlpk_norm_apply out_ph / out_pw, mlpk_vip_unpermute) around mlpk_gemm_nt; the concatenation in front of `fuse` = column slices of one
+        buffer; the depthwise 3 x 3 = mlpk_dwconv_plain_nhwc (+ adjoint, + mlpk_dwconv_wgrad_nhwc); PatchMerging = mlpk_merge2x2_nhwc."""
+        from .. import autograd as AG
+        E.require_gpu(x, "SparseMLP.forward")
+        if x.dim() != 4:
+            raise ValueError("expected a (B, C, H, W) tensor")
+        cd = self._compute_dtype or x.dtype
+        E.dtype_code(cd)
+        image_size, patch, cin, num_classes, patcher_norm = self._cfg
+        B, _, H_in, W_in = x.shape
+        ph, pw = patch
+        H, W = H_in // ph, W_in // pw
+        if (H, W) != self.layers[0].geom[:2]:
+            raise ValueError("input size gives a %dx%d grid, the model was built for %dx%d" % ((H, W) + self.layers[0].geom[:2]))
+        kp = E.round_up(cin * ph * pw, 4 if cd == torch.float32 else 8)
+        with E.on_device(x):
+            patches = torch.zeros((B * H * W, kp), dtype=cd, device=x.device)
+            E.patchify(x.contiguous(), patches, B, cin, H_in, W_in, ph, pw, 0, kp)
+
+        def ln(t, norm):
+            return AG.LayerNorm.apply(t, norm.weight, norm.bias, norm.eps)
+
+        def bn(t, mod):
+            rows, dim = t.shape
+            mean, var = AG.batch_stats(t.detach(), rows, dim)
+            AG.batchnorm_train_affine(mod, mean, var, rows)
+            return AG.BatchNormTrain.apply(t, mod.weight, mod.bias, mean, var, mod.eps)
+
+        conv = self.patcher[0]
+        t = AG.Linear.apply(patches, conv.weight, conv.bias, None)
+        if patcher_norm:
+            t = ln(t, self.patcher[1][1])
+        for stage in self.layers:
+            C = stage.geom[2]
+            for blk in stage.model:
+                dw_pre, mix_pre, mlp = blk[0], blk[1], blk[3]
+                dw = dw_pre.fn[0]
+                t = AG.ScaleAdd.apply(AG.DepthwiseConv.apply(bn(t, dw_pre.norm), dw.weight, dw.bias, B, H, W), t, None)
+                sm = mix_pre.fn[0]
+                n = bn(t, mix_pre.norm)
+                x_h = AG.VipUnpermute.apply(AG.Linear.apply(AG.VipPermute.apply(n, B, H, W, 1, 0), sm.proj_h.weight, sm.proj_h.bias, None), B, H, W, C, 1, 0)
+                x_w = AG.VipUnpermute.apply(AG.Linear.apply(AG.VipPermute.apply(n, B, H, W, 1, 1), sm.proj_w.weight, sm.proj_w.bias, None), B, H, W, C, 1, 1)
+                t = AG.Linear.apply(AG.ConcatCols.apply(x_h, x_w, n), sm.fuse.weight, sm.fuse.bias, t)
+                fc1, fc2 = mlp.fn[0], mlp.fn[3]
+                t = AG.Linear.apply(AG.Gelu.apply(AG.Linear.apply(ln(t, mlp.norm), fc1.weight, fc1.bias, None)), fc2.weight, fc2.bias, t)
+            if stage.pooling:
+                pm = stage.patch_merge[1]
+                t = AG.Linear.apply(ln(AG.Merge2x2.apply(t, B, H, W), pm.norm), pm.reduction.weight, None, None)
+                H, W = H // 2, W // 2
+        head_ln, head = self.mlp_head[1], self.mlp_head[3]
+        logits = AG.Linear.apply(AG.TokenMean.apply(ln(t, head_ln), B, H * W), head.weight, head.bias, None)
+        return logits if logits.dtype == x.dtype else logits.to(x.dtype)
+
     def forward(self, x):
+        if self.training and torch.is_grad_enabled():
+            return self._forward_train(x)
         cd = self._resolve(x)
         image_size, patch, cin, num_classes, patcher_norm = self._cfg
         B = x.shape[0]

@@ -112,7 +112,7 @@ class SwinMLP(StochasticDepth, E.EngineModule):
     train() (round 6): the forward applies the blocks' stochastic depth (swin_mlp.py:105,154-155: the same DropPath in front of
     both residual additions of a block) -- see common.StochasticDepth; LayerNorm has no batch statistics, Dropout has p = 0.  Forward only:
     the outputs carry no grad_fn."""
-    _train_forward = "forward-only"
+    _train_forward = True
 
     def __init__(self, img_size=224, patch_size=4, in_chans=3, num_classes=1000, embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24],
                  window_size=7, mlp_ratio=4., drop_rate=0., drop_path_rate=0.1, norm_layer=nn.LayerNorm, ape=False, patch_norm=True,
@@ -306,7 +306,88 @@ class SwinMLP(StochasticDepth, E.EngineModule):
                 H, W, C = H // 2, W // 2, 2 * C
             return cur.reshape(B, H * W, C).clone()
 
+    def _forward_train(self, x):
+        """Train mode with autograd (round 6): swin_mlp.py:33-157,175-215,295-335,428-456 as autograd.Functions of `..autograd`,
+        forward and backward through the C ABI.  The zero padding of the shifted blocks, the window partition and their inverses are index
+        tables (mlpk_index_gather; the inverse table is the gradient), built by running the reference's own F.pad / view / permute on a tensor
+        of positions; the multi-head spatial MLP (a grouped Conv1d over a window's tokens) is one mlpk_gemm_nt per head between per-window
+        transposes (mlpk_transpose_batched); stochastic depth on drop_path_uniform's draws; PatchMerging = mlpk_merge2x2_nhwc."""
+        import torch.nn.functional as F
+        from .. import autograd as AG
+        E.require_gpu(x, "SwinMLP.forward")
+        if x.dim() != 4:
+            raise ValueError("expected a (B, C, H, W) tensor")
+        cd = self._compute_dtype or x.dtype
+        E.dtype_code(cd)
+        pe = self.patch_embed
+        B, cin, H_in, W_in = x.shape
+        assert H_in == pe.img_size[0] and W_in == pe.img_size[1], \
+            f"Input image size ({H_in}*{W_in}) doesn't match model ({pe.img_size[0]}*{pe.img_size[1]})."
+        ph, pw = pe.patch_size
+        H, W = H_in // ph, W_in // pw
+        dev = x.device
+        kp = E.round_up(cin * ph * pw, 4 if cd == torch.float32 else 8)
+        with E.on_device(x):
+            patches = torch.zeros((B * H * W, kp), dtype=cd, device=dev)
+            E.patchify(x.contiguous(), patches, B, cin, H_in, W_in, ph, pw, 0, kp)
+        tables = self.__dict__.setdefault("_tables", {})
+
+        def ln(t, norm):
+            return AG.LayerNorm.apply(t, norm.weight, norm.bias, norm.eps)
+
+        t = AG.Linear.apply(patches, pe.proj.weight, pe.proj.bias, None)
+        if pe.norm is not None:
+            t = ln(t, pe.norm)
+        if self.ape:
+            t = AG.AddPeriodic.apply(t, self.absolute_pos_embed, H * W)
+        C = self.embed_dim
+        for layer in self.layers:
+            for blk in layer.blocks:
+                ws, nH = blk.window_size, blk.num_heads
+                P_l, P_r, P_t, P_b = blk.padding if blk.shift_size > 0 else (0, 0, 0, 0)
+                Hp, Wp = H + P_t + P_b, W + P_l + P_r
+
+                def part(pos, H=H, W=W, Hp=Hp, Wp=Wp, ws=ws, pads=(P_l, P_r, P_t, P_b)):
+                    g = F.pad(pos.view(1, H, W, 1), [0, 0, pads[0], pads[1], pads[2], pads[3]], "constant", 0)      # swin_mlp.py:129-132
+                    g = g.view(1, Hp // ws, ws, Wp // ws, ws, 1).permute(0, 1, 3, 2, 4, 5).contiguous()            # window_partition (:33-45)
+                    return g
+
+                def rev(pos, H=H, W=W, Hp=Hp, Wp=Wp, ws=ws, pads=(P_l, P_r, P_t, P_b)):
+                    g = pos.view(1, Hp // ws, Wp // ws, ws, ws, 1).permute(0, 1, 3, 2, 4, 5).contiguous().view(1, Hp, Wp, 1)   # window_reverse (:48-60)
+                    return g[:, pads[2]:Hp - pads[3], pads[0]:Wp - pads[1], :].contiguous()                        # reverse shift (:146-149)
+
+                t_part = AG.position_table(part, H * W, C, dev, tables, ("part", H, W, ws, P_l, P_t, C))
+                t_rev = AG.position_table(rev, Hp * Wp, C, dev, tables, ("rev", H, W, ws, P_l, P_t, C))
+                nwb = B * (Hp // ws) * (Wp // ws)
+                xw = AG.IndexMap.apply(ln(t, blk.norm1), t_part, B, C)                       # (nW*B * ws*ws, C): windows, tokens row-major
+                ch = C // nH
+                heads = []
+                for h in range(nH):
+                    # head h: the window's tokens mixed by rows [h ws^2, (h+1) ws^2) of the grouped Conv1d (swin_mlp.py:101-104,137-143)
+                    wgt = blk.spatial_mlp.weight[h * ws * ws:(h + 1) * ws * ws]
+                    bias = blk.spatial_mlp.bias[h * ws * ws:(h + 1) * ws * ws] if blk.spatial_mlp.bias is not None else None
+                    rows_h = AG.TokensToRows.apply(xw[:, h * ch:(h + 1) * ch], nwb, ws * ws)
+                    heads.append(AG.RowsToTokens.apply(AG.Linear.apply(rows_h, wgt, bias, None), nwb, ws * ws, ch))
+                y = AG.IndexMap.apply(AG.ConcatCols.apply(*heads) if nH > 1 else heads[0], t_rev, B, C)
+                t = AG.drop_add(self, t, y, blk.drop_path_rate if self.training else 0.0, B, H * W)
+                hdn = AG.Gelu.apply(AG.Linear.apply(ln(t, blk.norm2), blk.mlp.fc1.weight, blk.mlp.fc1.bias, None))
+                if float(blk.drop_path_rate) > 0.0:
+                    t = AG.drop_add(self, t, AG.Linear.apply(hdn, blk.mlp.fc2.weight, blk.mlp.fc2.bias, None), blk.drop_path_rate, B, H * W)
+                else:
+                    t = AG.Linear.apply(hdn, blk.mlp.fc2.weight, blk.mlp.fc2.bias, t)
+            if layer.downsample is not None:
+                ds = layer.downsample
+                t = AG.Linear.apply(ln(AG.Merge2x2.apply(t, B, H, W), ds.norm), ds.reduction.weight, None, None)
+                H, W, C = H // 2, W // 2, 2 * C
+        pooled = AG.TokenMean.apply(ln(t, self.norm), B, H * W)
+        if not isinstance(self.head, nn.Linear):
+            return pooled if pooled.dtype == x.dtype else pooled.to(x.dtype)
+        logits = AG.Linear.apply(pooled, self.head.weight, self.head.bias, None)
+        return logits if logits.dtype == x.dtype else logits.to(x.dtype)
+
     def forward(self, x):
+        if self.training and torch.is_grad_enabled():
+            return self._forward_train(x)
         cd = self._resolve(x)
         pe = self.patch_embed
         B, _, H_in, W_in = x.shape

@@ -737,12 +737,21 @@ def make_train_grad(ref):
              ("vip", "tiny_vip_weighted.npz", ref["vip"].ViP, {}, 37),
              ("vip_unweighted", "tiny_vip_unweighted.npz", ref["vip"].ViP, {}, 38),
              ("vip_rect", "tiny_vip_rect.npz", ref["vip"].ViP, {}, 39),
-             ("s2mlpv2", "tiny_s2mlpv2.npz", ref["s2_mlp_v2"].S2MLPv2, {}, 40))
+             ("s2mlpv2", "tiny_s2mlpv2.npz", ref["s2_mlp_v2"].S2MLPv2, {}, 40),
+             ("s2mlpv1", "tiny_s2mlpv1.npz", ref["s2_mlp_v1"].S2MLPv1, {}, 41),
+             ("sparsemlp", "tiny_sparsemlp.npz", ref["sparse_mlp"].SparseMLP, {}, 42),
+             ("sparsemlp_norm", "tiny_sparsemlp_norm.npz", ref["sparse_mlp"].SparseMLP, {}, 43),
+             ("swinmlp", "tiny_swinmlp.npz", ref["swin_mlp"].SwinMLP, {"drop_path_rate": 0.5}, 44),
+             ("swinmlp_ape", "tiny_swinmlp_ape.npz", ref["swin_mlp"].SwinMLP, {"drop_path_rate": 0.0}, 45),
+             ("msmlp", "tiny_msmlp.npz", ref["ms_mlp"].MS_MLP, {"drop_path_rate": 0.5}, 46),
+             ("hiremlp", "tiny_hiremlp.npz", ref["hire_mlp"].HireMLP, {}, 47),
+             ("hiremlp_rect", "tiny_hiremlp_rect.npz", ref["hire_mlp"].HireMLP, {}, 48),
+             ("cyclemlp", "tiny_cyclemlp.npz", ref["cycle_mlp"].CycleNet, {"drop_path_rate": 0.5, "mlp_fn": None}, 49))
     for tag, fixture, ctor, extra, seed in cases:
         torch.set_num_threads(1 if tag.startswith("s2") else 8)          # (S2-MLP's in-place shift is only deterministic on one thread)
         z = np.load(os.path.join(HERE, fixture))
         kw = dict(json.loads(str(z["kwargs"])), **extra)
-        model = ctor(**{k: (tuple(v) if k in ("image_size",) and isinstance(v, list) else v) for k, v in kw.items()})
+        model = ctor(**ctor_kw(ref, {k: (tuple(v) if k in ("image_size",) and isinstance(v, list) else v) for k, v in kw.items()}))
         model.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}, strict=True)
         model.train()
         x = torch.from_numpy(portable_input((4,) + tuple(z["input"].shape[1:]), seed=seed))

@@ -62,12 +62,18 @@ def test_forward_on_a_device_that_is_not_current():
 
 
 def test_train_mode_warns_once():
-    """a family whose train mode is not built (gMLP) says so once; the ones that implement it (round 5: MLP-Mixer without Dropout, ConvMixer,
-    AS-MLP) do not"""
+    """a module whose train mode is not built says so once (the mechanism: EngineModule._resolve); round 6: every model family implements train()
+    -- forward and backward -- so none of them warns any more"""
     pkg = load_pkg()
     x = torch.randn(1, 3, 32, 32, device=DEV)
     model = pkg.models_pytorch.gMLPForImageClassification(image_size=32, patch_size=8, d_model=32, d_ffn=64, depth=1, num_classes=10).to(DEV)
     model.train()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        with torch.no_grad():
+            model(x)
+    assert not any("inference-only" in str(m.message) for m in w)
+    model.__dict__["_train_forward"] = False                # what a family without a train path looks like to the engine
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         with torch.no_grad():
