@@ -480,57 +480,68 @@ __global__ void __launch_bounds__(256) vip_split_apply_kernel(const VipSplitArgs
 // bytes at seg = 12) -- and of the w branch the mirror image.  Both sets of runs are staged in LDS as they lie (16-byte copies),
 // the (pixel, 8 channels) items then pick their 8-byte pieces out of LDS; xc, the weights and the output are contiguous anyway.
 template <typename T>
-__global__ void __launch_bounds__(512) vip_split_apply_tile_kernel(const VipSplitArgs p, const float* __restrict__ bar, T* __restrict__ out, int ldo) {
+__global__ void __launch_bounds__(512) vip_split_apply_tile_kernel(const VipSplitArgs p, const float* __restrict__ bar, T* __restrict__ out, int ldo, int parts) {
+    // round 6: `parts` workgroups share a pixel tile, each taking G / parts channel groups -- the staged tiles of one workgroup then fill a
+    // third of the LDS instead of two thirds, so that three workgroups (not one) live on a CU and one's load phase runs under another's
+    // weighted-sum phase (the kernel has no pipeline of its own); the runs read from zh / zw stay 8 x seg elements long.  Same arithmetic.
     static_assert(sizeof(T) == 2, "16-bit storage types");
     extern __shared__ __attribute__((aligned(16))) char vsmem[];
     const int tid = threadIdx.x;
     const int G = p.C / p.seg;
+    const int Gs = G / parts;                                // channel groups of this workgroup
+    const int Cs = Gs * p.seg;
     const int run = 8 * p.seg;                              // elements per run (one (w, g) row x 8 h, or one (h, g) row x 8 w)
-    T* const zh_t = reinterpret_cast<T*>(vsmem);            // [8 w][G][8 h * seg]
-    T* const zw_t = zh_t + 8 * G * run;                     // [8 h][G][8 w * seg]
-    float* const wt = reinterpret_cast<float*>(zw_t + 8 * G * run);   // bar[b]: 3 x C
+    T* const zh_t = reinterpret_cast<T*>(vsmem);            // [8 w][Gs][8 h * seg]
+    T* const zw_t = zh_t + 8 * Gs * run;                    // [8 h][Gs][8 w * seg]
+    float* const wt = reinterpret_cast<float*>(zw_t + 8 * Gs * run);   // bar[b] of this workgroup's channels: 3 x Cs
     const int tw = p.W >> 3, th = p.H >> 3;
-    const int b = blockIdx.x / (th * tw);
-    const int t = blockIdx.x - b * (th * tw);
+    const int part = blockIdx.x % parts;
+    const int bt = blockIdx.x / parts;
+    const int b = bt / (th * tw);
+    const int t = bt - b * (th * tw);
     const int h0 = (t / tw) * 8, w0 = (t % tw) * 8;
+    const int g0 = part * Gs, c0 = part * Cs;
     const T* zh = reinterpret_cast<const T*>(p.zh);
     const T* zw = reinterpret_cast<const T*>(p.zw);
     const T* xc = reinterpret_cast<const T*>(p.xc);
     const int ppr = p.seg;                                  // 16-byte pieces per run: 8 * seg * 2 / 16
-    for (int idx = tid; idx < 8 * G * ppr; idx += 512) {
-        const int r = idx / ppr, pc = idx - r * ppr;        // r = l * G + g
-        const int l = r / G, g = r - l * G;
+    for (int idx = tid; idx < 8 * Gs * ppr; idx += 512) {
+        const int r = idx / ppr, pc = idx - r * ppr;        // r = l * Gs + g
+        const int l = r / Gs, g = r - l * Gs;
         *reinterpret_cast<u32x4*>(zh_t + (size_t)r * run + pc * 8) =
-            *reinterpret_cast<const u32x4*>(zh + (((int64_t)b * p.W + w0 + l) * G + g) * p.ldh + h0 * p.seg + pc * 8);
+            *reinterpret_cast<const u32x4*>(zh + (((int64_t)b * p.W + w0 + l) * G + g0 + g) * p.ldh + h0 * p.seg + pc * 8);
         *reinterpret_cast<u32x4*>(zw_t + (size_t)r * run + pc * 8) =
-            *reinterpret_cast<const u32x4*>(zw + (((int64_t)b * p.H + h0 + l) * G + g) * p.ldw + w0 * p.seg + pc * 8);
+            *reinterpret_cast<const u32x4*>(zw + (((int64_t)b * p.H + h0 + l) * G + g0 + g) * p.ldw + w0 * p.seg + pc * 8);
     }
-    for (int i = tid; i < 3 * p.C; i += 512) wt[i] = bar[(int64_t)b * 3 * p.C + i];
+    for (int i = tid; i < 3 * Cs; i += 512) {
+        const int k = i / Cs;
+        wt[i] = bar[(int64_t)b * 3 * p.C + k * p.C + c0 + (i - k * Cs)];
+    }
     __syncthreads();
-    const int cv = p.C / 8;
+    const int cv = Cs / 8;
     for (int idx = tid; idx < 64 * cv; idx += 512) {
         const int pl = idx / cv;
-        const int c = (idx - pl * cv) * 8;
+        const int c = (idx - pl * cv) * 8;                  // channel inside this workgroup's range
         const int hl = pl >> 3, wl = pl & 7;
         const int64_t px = ((int64_t)b * p.H + h0 + hl) * p.W + w0 + wl;
         float v0[8], v1[8], v2[8], o[8];
 #pragma unroll
-        for (int part = 0; part < 2; ++part) {
-            const int cc = c + 4 * part;
+        for (int half = 0; half < 2; ++half) {
+            const int cc = c + 4 * half;
             const int g = cc / p.seg;
             const int q = cc - g * p.seg;                   // multiple of 4: the 4 channels stay inside group g
-            const u32x2 a0 = *reinterpret_cast<const u32x2*>(zh_t + (size_t)(wl * G + g) * run + hl * p.seg + q);
-            const u32x2 a1 = *reinterpret_cast<const u32x2*>(zw_t + (size_t)(hl * G + g) * run + wl * p.seg + q);
+            const u32x2 a0 = *reinterpret_cast<const u32x2*>(zh_t + (size_t)(wl * Gs + g) * run + hl * p.seg + q);
+            const u32x2 a1 = *reinterpret_cast<const u32x2*>(zw_t + (size_t)(hl * Gs + g) * run + wl * p.seg + q);
             T e0[4], e1[4];
             __builtin_memcpy(e0, &a0, 8);
             __builtin_memcpy(e1, &a1, 8);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { v0[4 * part + i] = to_f32(e0[i]); v1[4 * part + i] = to_f32(e1[i]); }
+            for (int i = 0; i < 4; ++i) { v0[4 * half + i] = to_f32(e0[i]); v1[4 * half + i] = to_f32(e1[i]); }
         }
-        ld8<T>(xc + px * p.ldc + c, v2);
+        ld8<T>(xc + px * p.ldc + c0 + c, v2);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = wt[c + e] * v0[e] + wt[p.C + c + e] * v1[e] + wt[2 * p.C + c + e] * v2[e];
-        st8<T>(out + px * ldo + c, o);
+        for (int e = 0; e < 8; ++e) o[e] = wt[c + e] * v0[e] + wt[Cs + c + e] * v1[e] + wt[2 * Cs + c + e] * v2[e];
+        st8<T>(out + px * ldo + c0 + c, o);
     }
 }
 
@@ -967,22 +978,33 @@ extern "C" int mlpk_vip_split_apply(int dtype, const void* zh, const void* zw, c
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int64_t total = (int64_t)B * H * W * C;
     // 8 x 8 pixel tiles when the map is made of whole tiles, the runs are 16-byte aligned and the two staged tiles fit in LDS
-    const size_t lds_tile = (size_t)2 * 8 * (C / seg) * 8 * seg * 2 + (size_t)3 * C * 4;
+    // channel split (round 6): as many workgroups per pixel tile as it takes for three of them to fit a CU's LDS (each takes whole groups,
+    // a multiple of 8 channels); MLPK_VIP_APPLY_PARTS overrides (A/B aid)
+    const int G = C / seg;
+    static const int parts_env = getenv("MLPK_VIP_APPLY_PARTS") ? atoi(getenv("MLPK_VIP_APPLY_PARTS")) : 0;
+    int parts = 1;
+    auto lds_of = [&](int pp) { return (size_t)2 * 8 * (G / pp) * 8 * seg * 2 + (size_t)3 * (C / pp) * 4; };
+    auto parts_ok = [&](int pp) { return pp >= 1 && G % pp == 0 && ((G / pp) * seg) % 8 == 0; };
+    if (parts_env > 0 && parts_ok(parts_env)) parts = parts_env;
+    else
+        for (int pp = 1; pp <= 4; ++pp)
+            if (parts_ok(pp)) { parts = pp; if (lds_of(pp) <= 52 * 1024) break; }
+    const size_t lds_tile = lds_of(parts);
     static const bool no_tile = getenv("MLPK_VIP_APPLY_NO_TILE") != nullptr;       // A/B aid
-    if (!no_tile && H % 8 == 0 && W % 8 == 0 && ldh % 8 == 0 && ldw % 8 == 0 && lds_tile <= 150 * 1024 && (int64_t)B * (H / 8) * (W / 8) < 0x7fffffff &&
+    if (!no_tile && H % 8 == 0 && W % 8 == 0 && ldh % 8 == 0 && ldw % 8 == 0 && lds_tile <= 150 * 1024 && (int64_t)B * (H / 8) * (W / 8) * parts < 0x7fffffff &&
         (((uintptr_t)zh | (uintptr_t)zw) & 15) == 0) {
-        const unsigned grid = (unsigned)((int64_t)B * (H / 8) * (W / 8));
+        const unsigned grid = (unsigned)((int64_t)B * (H / 8) * (W / 8) * parts);
         hipError_t e = hipSuccess;
         if (dtype == MLPK_BF16) {
             auto k = vip_split_apply_tile_kernel<bf16_t>;
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile);
             if (e != hipSuccess) return (int)e;
-            hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds_tile, s, p, bar, (bf16_t*)out, ldo);
+            hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds_tile, s, p, bar, (bf16_t*)out, ldo, parts);
         } else {
             auto k = vip_split_apply_tile_kernel<f16_t>;
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile);
             if (e != hipSuccess) return (int)e;
-            hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds_tile, s, p, bar, (f16_t*)out, ldo);
+            hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds_tile, s, p, bar, (f16_t*)out, ldo, parts);
         }
         MLPK_LAUNCH_CHECK();
         return 0;
