@@ -715,35 +715,42 @@ __global__ void __launch_bounds__(NW * 64) dwconv_mfma_kernel(const T* __restric
     }
 }
 
-template <typename T>
-static int dwconv_mfma_launch(int k, const void* x, void* out, int B, int H, int W, int C, const float* w, const float* bias,
-                              const float* bns, const float* bnh, hipStream_t s) {
+template <typename T, int cpw, int NWV = 8>
+static int dwconv_mfma_launch_cpw(int k, const void* x, void* out, int B, int H, int W, int C, const float* w, const float* bias,
+                                  const float* bns, const float* bnh, hipStream_t s) {
     // 8 waves x 4 channels = 32 channels per workgroup (64 aligned bytes of every pixel); fragments of 2 (k = 9) or 3 (k = 7) of a
     // wave's channels in registers, the others' in the LDS.  History on ConvMixer-1536/20 (k = 9, per layer): 8 x 3 channels, all
     // fragments in registers (48-byte pieces): 0.88 ms; 4 waves x 8 channels with the whole 512-register file per wave: 1.33 ms;
     // 8 waves x 1 channel (16-byte pieces): 1.41 ms; the VALU stencil it replaces: 1.66 ms.
-    constexpr int cpw = 4, cg = 8 * cpw;
-    const int creg = k <= 5 ? 4 : (k == 7 ? DWM_CREG7 : DWM_CREG9);
+    // Round 6 experiment (MLPK_DWM_CPW=2): 8 waves x 2 channels -- 16 channels per workgroup, every fragment in registers, planes of
+    // 55 KB: two workgroups per CU, one's image hand-over (store, load, two barriers) under the other's matrix phase.
+    constexpr int cg = NWV * cpw;
+    constexpr int creg_cap = cpw;
+    const int creg_want = k <= 5 ? 4 : (k == 7 ? DWM_CREG7 : DWM_CREG9);
+    const int creg = creg_want < creg_cap ? creg_want : creg_cap;
     const int groups = (C + cg - 1) / cg;
-    // images per workgroup: rounds of 256 workgroups x (images + about 2 images' worth of set-up: taps, fragments, zeroing) -- the
-    // fewest image-times wins (1536 channels, 256 images: 48 groups x 16 ranges of 16 = 3 whole rounds)
+    const int lds = dwm_plane_off(cg) + DWM_PLANE + NWV * (cpw - creg) * k * DWM_NPAT * 16;
+    const int per_cu = (160 * 1024) / (lds + 1024) >= 2 ? 2 : 1;
+    // images per workgroup: rounds of 256 (x workgroups per CU) workgroups x (images + about 2 images' worth of set-up: taps, fragments,
+    // zeroing) -- the fewest image-times wins (1536 channels, 256 images: 48 groups x 16 ranges of 16 = 3 whole rounds)
     int per = 4;
     long long best = -1;
+    const long long slots = 256LL * per_cu;
     for (int cand = 32; cand >= 4; cand /= 2) {
         const long long wgs = (long long)groups * ((B + cand - 1) / cand);
-        const long long cost = ((wgs + 255) / 256) * (cand + 2);
+        const long long cost = ((wgs + slots - 1) / slots) * (cand + 2);
         if (best < 0 || cost < best) best = cost, per = cand;
     }
     const dim3 grid((unsigned)groups, (unsigned)((B + per - 1) / per));
-    const int lds = dwm_plane_off(cg) + DWM_PLANE + 8 * (cpw - creg) * k * DWM_NPAT * 16;
     const bool full = H == 32 && W == 32 && C % cg == 0;
     hipError_t e = hipSuccess;
 #define DWM_CASE(KS, CREG)                                                                                              \
     case KS: {                                                                                                         \
-        auto kern = full ? dwconv_mfma_kernel<T, KS, cpw, CREG, 8, true> : dwconv_mfma_kernel<T, KS, cpw, CREG, 8, false>; \
+        constexpr int CR = (CREG) < cpw ? (CREG) : cpw;                                                                \
+        auto kern = full ? dwconv_mfma_kernel<T, KS, cpw, CR, NWV, true> : dwconv_mfma_kernel<T, KS, cpw, CR, NWV, false>; \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
         if (e != hipSuccess) return (int)e;                                                                            \
-        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, (const T*)x, (T*)out, B, H, W, C, w, bias, bns, bnh, per);   \
+        hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), lds, s, (const T*)x, (T*)out, B, H, W, C, w, bias, bns, bnh, per); \
         break;                                                                                                         \
     }
     switch (k) {
@@ -753,6 +760,16 @@ static int dwconv_mfma_launch(int k, const void* x, void* out, int B, int H, int
 #undef DWM_CASE
     MLPK_LAUNCH_CHECK();
     return 0;
+}
+
+template <typename T>
+static int dwconv_mfma_launch(int k, const void* x, void* out, int B, int H, int W, int C, const float* w, const float* bias,
+                              const float* bns, const float* bnh, hipStream_t s) {
+    static const int cpw_env = getenv("MLPK_DWM_CPW") ? atoi(getenv("MLPK_DWM_CPW")) : 0;
+    if (cpw_env == 2 && k >= 7 && C % 16 == 0) return dwconv_mfma_launch_cpw<T, 2>(k, x, out, B, H, W, C, w, bias, bns, bnh, s);
+    // MLPK_DWM_CPW=44: 4 waves x 4 channels -- two half-size workgroups per CU with the SAME registers per wave as the default
+    if (cpw_env == 44 && k >= 7 && C % 16 == 0) return dwconv_mfma_launch_cpw<T, 4, 4>(k, x, out, B, H, W, C, w, bias, bns, bnh, s);
+    return dwconv_mfma_launch_cpw<T, 4>(k, x, out, B, H, W, C, w, bias, bns, bnh, s);
 }
 
 extern "C" int mlpk_dwconv_nhwc(int dtype, const void* x, void* out, int B, int H, int W, int C, int k, const float* w,
