@@ -620,18 +620,6 @@ int mlpk_smlp_mix_dw(int dtype, const void* x, int ldx, int B, int H, int W, int
  * of SwinMLP added to every image's tokens (swin_mlp.py:386-388,437-438: ape=True) */
 int mlpk_add_periodic(int dtype, void* x, int64_t ldx, const float* t, int64_t rows, int C, int period, void* stream);
 
-/* AS-MLP: the whole axial-shift half of a block for one SAMPLE per workgroup (round 6; as_mlp.py:55-95,149-159), for a stage whose sample fits a
- * CU's LDS (C = 384, maps of 193 .. 208 pixels: AS-MLP's 14 x 14 stage):
- *   x <- x + conv3(norm2(gelu(conv2_1(sh_W u)) + gelu(conv2_2(sh_H u)))),  u = gelu(norm1a(conv1(norm1(x))))     (all norms GroupNorm(1, C), eps)
- * x: (B*H*W, C) channel-last, updated in place; u, v: scratch tensors of the same size; w1 / w3: (C, ldw) with the GroupNorm gamma folded in
- * (b1 / b3 = bias + W beta, cs1 / cs3 = column sums of the folded weights, as for mlpk_gemm_nt's ln_*); ag / ab: AxialShift.norm1's gamma / beta;
- * mean_out / rstd_out (optional): GroupNorm statistics of the new x per sample (the block's norm2).  Replaces 4 statistics passes, 4 GEMMs and the
- * normalise-and-shift pass; every reduction is a fixed-order workgroup reduction (a sample's result does not depend on its batch). */
-int mlpk_as_block_supported(int dtype, int H, int W, int C, int kernel_size);
-int mlpk_as_block(int dtype, void* x, void* u, void* v, int B, int H, int W, int C, int kernel_size, const void* w1, const float* b1, const float* cs1,
-                  const float* ag, const float* ab, const void* w21, const float* b21, const void* w22, const float* b22, const void* w3, const float* b3,
-                  const float* cs3, int ldw, float eps, float* mean_out, float* rstd_out, void* stream);
-
 /* ---- backward of the other families (ABI 11, round 6) ----------------------------------------------------------
  * The element-wise, normalisation and remap derivatives that the train mode of gMLP (g_mlp.py:10-39), ResMLP (res_mlp.py:11-57), AS-MLP
  * (as_mlp.py:55-162,182-216) and ConvMixer (conv_mixer.py:5-39) needs beside the ABI-9 set; products stay mlpk_gemm_nt calls.  fp32 math,

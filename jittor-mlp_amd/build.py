@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmlpk.so")
-SOURCES = ["mlpk_gemm.hip", "mlpk_gemm_q4.hip", "mlpk_gemm_skinny.hip", "mlpk_norm.hip", "mlpk_embed.hip", "mlpk_remap.hip", "mlpk_tokenmlp.hip", "mlpk_tokenmlp_t4.hip", "mlpk_dwconv.hip", "mlpk_hire.hip", "mlpk_asconv.hip", "mlpk_asblock.hip", "mlpk_chanmlp.hip", "mlpk_backward.hip", "mlpk_vipbranch.hip", "mlpk_smlp.hip"]
+SOURCES = ["mlpk_gemm.hip", "mlpk_gemm_q4.hip", "mlpk_gemm_skinny.hip", "mlpk_norm.hip", "mlpk_embed.hip", "mlpk_remap.hip", "mlpk_tokenmlp.hip", "mlpk_tokenmlp_t4.hip", "mlpk_dwconv.hip", "mlpk_hire.hip", "mlpk_asconv.hip", "mlpk_chanmlp.hip", "mlpk_backward.hip", "mlpk_vipbranch.hip", "mlpk_smlp.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
 FLAGS += os.environ.get("MLPK_EXTRA_FLAGS", "").split()      # tuning aid: A/B builds of a kernel variant (-DTM_...)
 

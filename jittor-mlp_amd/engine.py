@@ -624,18 +624,6 @@ def norm_shift_nhwc(x, out_w, out_h, n, h, w, c, kernel_size, mean, rstd, gamma,
                                          ptr(gamma), ptr(beta), act, stream()), "mlpk_norm_shift_nhwc")
 
 
-def as_block_supported(dtype, H, W, C, kernel_size):
-    """mlpk_as_block: the whole axial-shift half of an AS-MLP block, one sample per workgroup (MLPK_AS_BLOCK=0: the separate kernels, A/B aid)"""
-    return (dtype in (torch.float16, torch.bfloat16) and os.environ.get("MLPK_AS_BLOCK", "1") != "0"
-            and bool(N.lib().mlpk_as_block_supported(dtype_code(dtype), H, W, C, kernel_size)))
-
-
-def as_block(x, u, v, B, H, W, C, kernel_size, w1, b1, cs1, ag, ab, w21, b21, w22, b22, w3, b3, cs3, eps, mean_out, rstd_out):
-    N.check(N.lib().mlpk_as_block(dtype_code(x.dtype), ptr(x), ptr(u), ptr(v), B, H, W, C, kernel_size, ptr(w1), ptr(b1), ptr(cs1), ptr(ag), ptr(ab),
-                                  ptr(w21), ptr(b21), ptr(w22), ptr(b22), ptr(w3), ptr(b3), ptr(cs3), w1.stride(0), eps, ptr(mean_out), ptr(rstd_out),
-                                  stream()), "mlpk_as_block")
-
-
 def as_conv2_supported(dtype, H, W, C, kernel_size):
     """mlpk_as_conv2 takes the shape (MLPK_ASMLP_FUSED_CONV2=0: the three-kernel sequence, A/B aid)"""
     return (dtype in (torch.float16, torch.bfloat16) and os.environ.get("MLPK_ASMLP_FUSED_CONV2", "1") != "0"

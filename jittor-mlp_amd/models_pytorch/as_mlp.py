@@ -366,23 +366,6 @@ class AS_MLP(E.EngineModule):
                 if only is not None and only[1] != "layer" and bi != only[1]:
                     continue
                 p = "l%d.b%d." % (li, bi)
-                if (fused and pk.get(p + "c21.b") is not None and pk.get(p + "c22.b") is not None and (not self.training or float(layer.blocks[bi].drop_path_rate) == 0.0)
-                        and pk[p + "c1f.w"].stride(0) == pk[p + "c3f.w"].stride(0) == pk[p + "c21.w"].stride(0) == pk[p + "c22.w"].stride(0)
-                        and E.as_block_supported(cd, H, W, C, self._shift)):
-                    # round 6 (the stage whose sample fits a CU's LDS: 14 x 14 x 384): the whole axial-shift half of the block -- four GroupNorm
-                    # statistics, conv1, the normalise-GELU-shift, conv2_1, conv2_2, conv3 and the residual -- in ONE kernel, one sample per
-                    # workgroup (mlpk_as_block); it also delivers the statistics of the new x for norm2
-                    E.as_block(cur, t0, t1, B, H, W, C, self._shift, pk[p + "c1f.w"], pk[p + "c1f.b"], pk[p + "c1f.csum"], pk[p + "an1.g"], pk[p + "an1.b"],
-                               pk[p + "c21.w"], pk[p + "c21.b"], pk[p + "c22.w"], pk[p + "c22.b"], pk[p + "c3f.w"], pk[p + "c3f.b"], pk[p + "c3f.csum"],
-                               float(layer.blocks[bi].norm1.eps), mean, rstd)
-                    if (p + "mlpf") in pk and E.channel_mlp_fused_supported(cd, C, hid):
-                        got = E.channel_mlp_fused(cur, rows, C, pk[p + "mlpf"], cur, R=cur, ln=(mean, rstd), ln_group=HW, part=(ws, "l%d.mlppart" % li))
-                    else:
-                        E.gemm(cur, pk[p + "fc1f.w"], hbuf, rows, hid, C, bias=pk[p + "fc1f.b"], act=N.ACT_GELU,
-                               ln=(mean, rstd, pk[p + "fc1f.csum"]), ln_group=HW, tag="as_fc1")
-                        got = E.gemm(hbuf, pk[p + "fc2.w"], cur, rows, C, hid, bias=pk[p + "fc2.b"], R=cur, res=N.RES_ADD, tag="as_fc2", part=part)
-                    have = finalize_stats(ws, got, rows, C, tag=tag, group=HW) is not None
-                    continue
                 if fused:
                     if not have:
                         stats(cur, C)
