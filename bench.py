@@ -243,6 +243,10 @@ def main():
     ap.add_argument("--model", default="mixer_b16", choices=sorted(MODELS))
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--dtype", default="bf16", choices=sorted(DT))
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the consecutive steps alternate over (round 6): every step is a whole forward of the whole batch; with 2, "
+                         "step i + 1 is enqueued on the other stream while step i runs, so the partly empty last rounds of one step's persistent "
+                         "kernels are filled by the next step's (two batches in flight, like a server with two request slots).  1 = strictly one step after the other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the fp32-input variant line (profiling runs count forwards)")
@@ -312,9 +316,63 @@ def main():
     parallel = importlib.import_module("jittor-mlp_amd.parallel")
     runner = parallel.DataParallelForward(model, world)
 
+    # Consecutive steps are independent forwards of the same resident batch: they alternate over `--streams` HIP streams (each stream has its
+    # own workspace inside the model), so that step i + 1 starts filling the CUs that the tail of step i's kernels leaves idle.  Same kernels,
+    # same K whole steps inside the timed region, same bits; `single_stream` below is the strictly serial figure from the same process.
+    nstreams = max(1, args.streams)
+    side = [torch.cuda.Stream(device=dev) for _ in range(nstreams)] if nstreams > 1 else None
+    if side is not None:
+        for s_ in side:
+            s_.wait_stream(torch.cuda.current_stream())
+
+    def step(i):
+        if side is None:
+            return runner(x)
+        with torch.cuda.stream(side[i % nstreams]):
+            return runner(x)
+
+    def kernel_timing_pass():
+        """Per-kernel durations for `roofline`: HIP events around the channel-MLP GEMM launches (on the stream they are launched on) in a
+        SEPARATE short pass of whole steps, one step at a time on one stream -- same process, same resident batch -- so that the headline
+        loop carries no event records at all (round-4 review: 24 pairs per step sat inside it)"""
+        if args.no_kernel_timing:
+            return None, 0
+        timer = E.KernelTimer()
+        n = max(2, min(args.steps, 6))
+        E.TIMER = timer
+        for _ in range(n):
+            runner(x)
+        E.TIMER = None
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        return timer, n
+
     with torch.no_grad():
-        for _ in range(args.warmup):
-            out = runner(x)
+        # (1) two steps in flight only: the strictly serial figure first (one step after the other on ONE stream, = --streams 1), and the
+        # kernel-timing pass in THAT regime -- a kernel's own duration at the clock the serial steady state runs at (with two steps in
+        # flight the chip sits 4 % lower at the power cap and a kernel shares the CUs with the other step: not a statement about the kernel)
+        serial = None
+        timer, timing_steps, timing_where = None, 0, ""
+        if side is not None:
+            ns = max(5, min(args.steps, 30))
+            for _ in range(3):
+                out1 = runner(x)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            ts0 = time.perf_counter()
+            for _ in range(ns):
+                out1 = runner(x)
+            torch.cuda.synchronize()
+            tser = (time.perf_counter() - ts0) / ns
+            serial = {"value": round(args.batch * world / tser, 1), "unit": "images/s", "ms_per_step": round(tser * 1e3, 4), "steps": ns,
+                      "what": "the same steps one after the other on ONE stream (--streams 1), measured in front of the timed region"}
+            timer, timing_steps = kernel_timing_pass()
+            timing_where = "%d serial steps straight after the %d steps of `single_stream`, in front of the timed region" % (timing_steps, ns)
+        # (2) the contract: W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize pairs
+        for it in range(args.warmup):
+            out = step(it)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -322,26 +380,20 @@ def main():
         sampler = PowerSampler().start() if rank == 0 else None
         t0 = time.perf_counter()
         for it in range(args.steps):
-            out = runner(x)
+            out = step(it)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         t1 = time.perf_counter()
         sensors = sampler.stop() if sampler is not None else None
-        # Per-kernel durations for `roofline`: HIP events around the channel-MLP GEMM launches (on the stream they are launched on) in a
-        # SEPARATE short pass straight after the timed region -- same process, same resident batch, the chip at the same temperature --
-        # so that the headline loop carries no event records at all (round-4 review: 24 pairs per step sat inside it)
-        timer = None if args.no_kernel_timing else E.KernelTimer()
-        timing_steps = 0
-        if timer is not None:
-            timing_steps = max(2, min(args.steps, 6))
-            E.TIMER = timer
-            for it in range(timing_steps):
-                out = runner(x)
-            E.TIMER = None
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
+        timer_after = None
+        if side is None:
+            timer, timing_steps = kernel_timing_pass()
+            timing_where = "%d extra steps straight after the %d timed ones" % (timing_steps, args.steps)
+        else:
+            serial["bits_equal_to_timed_steps"] = bool(torch.equal(out1, out))
+            del out1
+            timer_after, _ = kernel_timing_pass()               # the same pass behind the two-in-flight region (hotter chip): reported beside
         # The drop-in contract hands over fp32 images (the reference's models take float tensors) and runs the 16-bit path through
         # set_compute_dtype: the image is converted while the patches are gathered and the logits come back in fp32.  The headline above
         # keeps the batch resident in the compute dtype; this variant line times the contract itself on the same model (N = 1 only).
@@ -381,11 +433,14 @@ def main():
             "config": {"workload": "%s forward, 224x224, %d images/GPU x %d GPU, random-init weights, uniform[0,1) input resident in HBM"
                                    % (args.model, args.batch, world),
                        "global_batch": global_batch, "parallelism": "dp%d" % world,
+                       "streams": nstreams, "steps_in_flight": nstreams,
                        "collective": ("all_gather(logits) over %s%s" % (args.backend, ", all ranks on cuda:0" if args.share_device else "")) if world > 1 else "none"},
             "model_tflops": round(gflop_img * global_batch * args.steps / elapsed / 1e3, 1),
             # sysfs sensors of the GPU sampled every 20 ms DURING the timed loop (null if the box does not expose them)
             "sensors_timed_loop": sensors,
         }
+        if serial is not None:
+            line["single_stream"] = serial
         if fp32_variant is not None:
             line["fp32_input_variant"] = fp32_variant
         if timer is not None and timer.events:
@@ -402,7 +457,7 @@ def main():
                 line["roofline"] = {"bound": "mfma", "kernel": names, "achieved": round(ach, 1),
                                     "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                                     "flops_per_launch": flops / n_launch, "avg_launch_ms": round(secs / n_launch * 1e3, 4),
-                                    "launches_timed": n_launch, "timed_in": "%d extra steps straight after the %d timed ones (no event records inside the headline loop)" % (timing_steps, args.steps),
+                                    "launches_timed": n_launch, "timed_in": timing_where + "; one step at a time on one stream: a kernel's own duration (no event records inside the headline loop)",
                                     "traffic_source": traffic_src,
                                     # "traffic" is NOT measured in this run: it is the PMC result of tools/pmc_bench.sh on this command,
                                     # read from profiles/ and dropped (null) when the GEMM sources changed since it was taken
@@ -413,6 +468,14 @@ def main():
                                     "launch_means": "one mlpk_gemm_nt call; kernel names as answered by the dispatch for the timed calls"}
             line["kernels"] = {t: {"avg_ms": round(v["avg_ms"], 4), "tflops": round(v["flops_per_launch"] / v["avg_ms"] / 1e9, 1),
                                    "launches": v["launches"]} for t, v in summ.items()}
+            if timer_after is not None and timer_after.events and "roofline" in line:
+                sa = timer_after.summary()
+                da = [t for t in ("channel_fc1", "channel_fc2") if t in sa]
+                if da:
+                    fa = sum(sa[t]["flops_per_launch"] * sa[t]["launches"] for t in da) / (sum(sa[t]["avg_ms"] * sa[t]["launches"] for t in da) * 1e-3) / 1e12
+                    line["roofline"]["frac_behind_timed_region"] = round(fa / line["roofline"]["peak"], 4)
+                    line["roofline"]["frac_behind_timed_region_note"] = ("the same serial pass repeated straight after the timed region: with two steps in flight "
+                                                                         "the chip sits lower at its power cap and the pass inherits that state")
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = run_cpu_baseline(args.model, kwargs, ctor_name, pkg)

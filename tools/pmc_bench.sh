@@ -7,7 +7,7 @@ OUT=$PWD/gpurun_out/pmc
 rm -rf $OUT; mkdir -p $OUT
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS"; do
   tag=$(echo $grp | cut -d' ' -f1)
-  ( cd /tmp && timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/$tag -o run -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-variants > $OUT/$tag.json 2> $OUT/$tag.err )
+  ( cd /tmp && timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/$tag -o run -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-variants --streams 1 > $OUT/$tag.json 2> $OUT/$tag.err )
   echo "$tag rc=$?"
 done
 python - <<'PY'

@@ -8,7 +8,7 @@ OUT=$PWD/gpurun_out/pmc_$m
 rm -rf $OUT; mkdir -p $OUT
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE" "SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
   tag=$(echo $grp | cut -d' ' -f1)
-  ( cd /tmp && timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/$tag -o run -- python $OLDPWD/bench.py --model $m --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-variants > $OUT/$tag.json 2> $OUT/$tag.err )
+  ( cd /tmp && timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/$tag -o run -- python $OLDPWD/bench.py --model $m --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-variants --streams 1 > $OUT/$tag.json 2> $OUT/$tag.err )
   echo "$tag rc=$?"
 done
 python - "$OUT" "$pat" <<'PY'

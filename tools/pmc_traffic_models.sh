@@ -6,7 +6,7 @@ export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 OUT=$PWD/gpurun_out/pmc_traffic; rm -rf $OUT; mkdir -p $OUT
 for m in "$@"; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    ( cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$m/$c -o run -- python $OLDPWD/bench.py --model $m --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-variants > $OUT/$m.$c.json 2> $OUT/$m.$c.err )
+    ( cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$m/$c -o run -- python $OLDPWD/bench.py --model $m --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-variants --streams 1 > $OUT/$m.$c.json 2> $OUT/$m.$c.err )
   done
   python - "$OUT/$m" "$m" <<'PY' | tee $OUT/$m.txt
 import csv, glob, collections, sys

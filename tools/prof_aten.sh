@@ -7,7 +7,7 @@ export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 m=${1:-mixer_b16}
 for n in 2 12; do
   OUT=$PWD/gpurun_out/prof_aten_${m}_$n; rm -rf $OUT; mkdir -p $OUT
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o $m -- python $OLDPWD/bench.py --model $m --steps $n --warmup 1 --no-cpu-baseline --no-kernel-timing --no-variants > $OUT/bench.json 2> $OUT/err.txt )
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o $m -- python $OLDPWD/bench.py --model $m --steps $n --warmup 1 --no-cpu-baseline --no-kernel-timing --no-variants --streams 1 > $OUT/bench.json 2> $OUT/err.txt )
   find $OUT -name "*kernel_trace.csv" -delete
 done
 python - $m <<'PY' | tee gpurun_out/prof_aten_$1.txt

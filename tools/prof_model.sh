@@ -5,7 +5,7 @@ export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 m=$1
 OUT=$PWD/gpurun_out/prof_$m
 rm -rf $OUT; mkdir -p $OUT
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o $m -- python $OLDPWD/bench.py --model $m --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-variants > $OUT/bench.json 2> $OUT/err.txt )
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o $m -- python $OLDPWD/bench.py --model $m --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-variants --streams 1 > $OUT/bench.json 2> $OUT/err.txt )
 f=$(find $OUT -name "*kernel_stats.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys, re

@@ -81,3 +81,30 @@ for rep in range(3):
     for nm, f in variants:
         ms = timeit(f, steps)
         print("%-28s %8.3f ms per %d images  %9.1f images/s" % (nm, ms, B, B / ms * 1e3), flush=True)
+
+# ---- round 6, second question: WHOLE batches on alternating streams (step i on stream i % n): consecutive steps are independent, so the
+# tail of one step's kernels can be filled by the next step's -- throughput of back-to-back steps, not latency of one
+if os.environ.get("ALTERNATE", "1") == "1":
+    def make_alternate(nstreams):
+        streams = [torch.cuda.Stream() for _ in range(nstreams)]
+        state = {"i": 0}
+
+        def f():
+            s = streams[state["i"] % nstreams]
+            state["i"] += 1
+            with torch.cuda.stream(s), torch.no_grad():
+                return model(x)
+        return f, streams
+
+    for n in (2, 3):
+        f, streams = make_alternate(n)
+        for _ in range(6):
+            f()
+        torch.cuda.synchronize()
+        for rep in range(3):
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                f()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps * 1e3
+            print("whole batches alternating over %d streams   %.3f ms per %d images   %.1f images/s" % (n, dt, B, B / dt * 1e3), flush=True)
