@@ -320,16 +320,10 @@ def main():
     # own workspace inside the model), so that step i + 1 starts filling the CUs that the tail of step i's kernels leaves idle.  Same kernels,
     # same K whole steps inside the timed region, same bits; `single_stream` below is the strictly serial figure from the same process.
     nstreams = max(1, args.streams)
-    side = [torch.cuda.Stream(device=dev) for _ in range(nstreams)] if nstreams > 1 else None
-    if side is not None:
-        for s_ in side:
-            s_.wait_stream(torch.cuda.current_stream())
+    side = parallel.InFlight(runner, nstreams, device=dev) if nstreams > 1 else None     # (jittor-mlp_amd/parallel.py)
 
     def step(i):
-        if side is None:
-            return runner(x)
-        with torch.cuda.stream(side[i % nstreams]):
-            return runner(x)
+        return runner(x) if side is None else side(x)[0]
 
     def kernel_timing_pass():
         """Per-kernel durations for `roofline`: HIP events around the channel-MLP GEMM launches (on the stream they are launched on) in a

@@ -61,3 +61,34 @@ class DataParallelForward:
             # gloo (CPU tests, or two ranks sharing one GPU): the list form, gathering into the row blocks of `out`
             dist.all_gather(list(out.chunk(self.world, dim=0)), logits, group=self.group)
         return out
+
+
+class InFlight:
+    """Keep `n` forwards in flight on one GPU (round 6): successive calls alternate over `n` HIP streams, so the next request's workgroups
+    fill the CUs that the tail of the current request's persistent kernels leaves idle (every big kernel of the path is a persistent grid
+    with a static tile list: a launch ends with a partly empty last round).  Each stream has its own workspace inside the model
+    (EngineModule._get_space is keyed by the stream), the kernels and hence the results are the same bits as one call after the other.
+    Same-box: Mixer-B/16 at 256 images 34.65 -> 36.55 k images/s with n = 2; n = 3 adds nothing (profiles/r06_two_steps_in_flight_probe.txt).
+
+        slots = InFlight(model, 2)
+        out, stream = slots(x)          # enqueued, not waited for; x must stay alive and unmodified until the call has run
+        ...
+        torch.cuda.current_stream().wait_stream(stream)   # (or stream.synchronize()) before `out` is consumed elsewhere
+    """
+
+    def __init__(self, forward_fn, n=2, device=None):
+        self.forward_fn = forward_fn
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(max(1, int(n)))]
+        self._i = 0
+
+    def __call__(self, x):
+        s = self.streams[self._i % len(self.streams)]
+        self._i += 1
+        s.wait_stream(torch.cuda.current_stream(x.device))         # x may have been produced on the caller's stream
+        with torch.cuda.stream(s):
+            out = self.forward_fn(x)
+        return out, s
+
+    def synchronize(self):
+        for s in self.streams:
+            s.synchronize()

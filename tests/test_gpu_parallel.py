@@ -109,3 +109,23 @@ def test_rccl_all_gather_is_ordered_on_the_compute_stream():
     ok = q.get(timeout=600)
     p.join(timeout=120)
     assert p.exitcode == 0 and ok
+
+
+def test_two_forwards_in_flight_give_the_serial_bits():
+    """parallel.InFlight (round 6): successive forwards alternate over two HIP streams -- each stream its own workspace inside the model -- and
+    return exactly what one call after the other returns; a call on inputs that differ per request keeps the requests apart"""
+    sys.path.insert(0, ROOT)
+    DEV = "cuda:0"
+    pkg = importlib.import_module("jittor-mlp_amd")
+    parallel = importlib.import_module("jittor-mlp_amd.parallel")
+    torch.manual_seed(0)
+    model = pkg.models_pytorch.MLPMixerForImageClassification(d_model=128, depth=2, patch_size=16, image_size=64, num_classes=10).to(DEV).eval()
+    xs = [torch.rand(8, 3, 64, 64, device=DEV).bfloat16() for _ in range(5)]
+    with torch.no_grad():
+        serial = [model(x).clone() for x in xs]
+        slots = parallel.InFlight(model, 2, device=DEV)
+        pending = [slots(x) for x in xs]                         # all five enqueued before any is waited for
+        slots.synchronize()
+    for (out, _), want in zip(pending, serial):
+        assert torch.equal(out, want)
+    assert len({id(s) for _, s in pending}) == 2
