@@ -247,6 +247,9 @@ def main():
                     help="HIP streams the consecutive steps alternate over (round 6): every step is a whole forward of the whole batch; with 2, "
                          "step i + 1 is enqueued on the other stream while step i runs, so the partly empty last rounds of one step's persistent "
                          "kernels are filled by the next step's (two batches in flight, like a server with two request slots).  1 = strictly one step after the other")
+    ap.add_argument("--gemm-plan", default="auto", choices=["auto", "mixed", "whole"],
+                    help="tile heights of the persistent GEMM: mixed = shortest single launch, whole = least total CU time (engine.set_gemm_plan); "
+                         "auto = whole when several steps are in flight, mixed otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the fp32-input variant line (profiling runs count forwards)")
@@ -320,7 +323,9 @@ def main():
     # own workspace inside the model), so that step i + 1 starts filling the CUs that the tail of step i's kernels leaves idle.  Same kernels,
     # same K whole steps inside the timed region, same bits; `single_stream` below is the strictly serial figure from the same process.
     nstreams = max(1, args.streams)
-    side = parallel.InFlight(runner, nstreams, device=dev) if nstreams > 1 else None     # (jittor-mlp_amd/parallel.py)
+    side = parallel.InFlight(runner, nstreams, device=dev, throughput_plan=args.gemm_plan != "mixed") if nstreams > 1 else None     # (jittor-mlp_amd/parallel.py)
+    if args.gemm_plan == "whole":
+        E.set_gemm_plan(True)
 
     def step(i):
         return runner(x) if side is None else side(x)[0]
@@ -349,6 +354,9 @@ def main():
         serial = None
         timer, timing_steps, timing_where = None, 0, ""
         if side is not None:
+            plan_in_flight = E.GEMM_PLAN_WHOLE                  # the serial passes run the serial regime's own GEMM plan (engine.set_gemm_plan)
+            if args.gemm_plan == "auto":
+                E.set_gemm_plan(False)
             ns = max(5, min(args.steps, 30))
             for _ in range(3):
                 out1 = runner(x)
@@ -364,6 +372,7 @@ def main():
                       "what": "the same steps one after the other on ONE stream (--streams 1), measured in front of the timed region"}
             timer, timing_steps = kernel_timing_pass()
             timing_where = "%d serial steps straight after the %d steps of `single_stream`, in front of the timed region" % (timing_steps, ns)
+            E.set_gemm_plan(plan_in_flight)
         # (2) the contract: W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize pairs
         for it in range(args.warmup):
             out = step(it)
@@ -387,7 +396,10 @@ def main():
         else:
             serial["bits_equal_to_timed_steps"] = bool(torch.equal(out1, out))
             del out1
+            if args.gemm_plan == "auto":
+                E.set_gemm_plan(False)
             timer_after, _ = kernel_timing_pass()               # the same pass behind the two-in-flight region (hotter chip): reported beside
+            E.set_gemm_plan(plan_in_flight)
         # The drop-in contract hands over fp32 images (the reference's models take float tensors) and runs the 16-bit path through
         # set_compute_dtype: the image is converted while the patches are gathered and the logits come back in fp32.  The headline above
         # keeps the batch resident in the compute dtype; this variant line times the contract itself on the same model (N = 1 only).
@@ -428,6 +440,7 @@ def main():
                                    % (args.model, args.batch, world),
                        "global_batch": global_batch, "parallelism": "dp%d" % world,
                        "streams": nstreams, "steps_in_flight": nstreams,
+                       "gemm_plan": "whole 256-row tiles where they fill a round (least total CU time: engine.set_gemm_plan)" if E.GEMM_PLAN_WHOLE else "mixed tile heights (shortest single launch)",
                        "collective": ("all_gather(logits) over %s%s" % (args.backend, ", all ranks on cuda:0" if args.share_device else "")) if world > 1 else "none"},
             "model_tflops": round(gflop_img * global_batch * args.steps / elapsed / 1e3, 1),
             # sysfs sensors of the GPU sampled every 20 ms DURING the timed loop (null if the box does not expose them)

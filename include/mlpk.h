@@ -672,6 +672,12 @@ int mlpk_s2_shift2(int dtype, int which, int mode, int adjoint, const void* in, 
  * 104-131: CycleFC's fixed integer offsets, width = 1); the table of the inverse relation (kmax = largest multiplicity) is the adjoint -- the gradient. */
 int mlpk_index_gather(int dtype, const void* src, void* dst, const int* idx, int batch, int64_t n_out, int64_t n_in, int width, int kmax, void* stream);
 
+/* Tile-height plan of the persistent GEMM tile, process-wide (round 6): 0 (default) = mixed tile heights, the shortest SINGLE launch (Mixer-B fc2: 588 tiles on
+ * 256 CUs run as 2.58 instead of 3 round-times); 1 = whole 256-row tiles only wherever they still fill a round of CUs and K >= 1024, the least TOTAL CU time (3 % less for that
+ * product) -- the better plan when several forwards share the chip (parallel.InFlight) and the other request fills the last round anyway.  Same K order per output
+ * element: results are bit-identical under either plan. */
+int mlpk_gemm_set_plan(int mode);
+
 /* ---- small utilities ------------------------------------------------------------------------ */
 /* dst[i] = (dst_dtype) src[i], n elements */
 int mlpk_convert(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);

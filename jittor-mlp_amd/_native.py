@@ -130,6 +130,7 @@ PROTOTYPES = {
     "mlpk_shift_nhwc_backward": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "mlpk_merge2x2_nhwc": (c_int, [c_int, c_int, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "mlpk_patch_rows_nhwc": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "mlpk_gemm_set_plan": (c_int, [c_int]),
     "mlpk_index_gather": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_i64, c_int, c_int, c_void_p]),
     "mlpk_dwconv_plain_nhwc": (c_int, [c_int, c_int, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p]),
     "mlpk_dwconv_wgrad_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),

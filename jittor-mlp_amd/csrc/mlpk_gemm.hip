@@ -1704,8 +1704,14 @@ static const double* p8_weights() {
     return w;
 }
 
+// 0 = mixed tile heights (the shortest single launch), 1 = whole 256-row tiles only (the least total CU time): mlpk_gemm_set_plan
+static int g_p8_plan_mode = 0;
+
 static P8Plan p8_plan(int M, int tiles_n, int nk, int G, bool mixed, double* cost_out = nullptr) {
     const double* w = p8_weights();
+    // whole tiles where that still fills a round of CUs (a launch with fewer tiles than CUs keeps its mixed heights: gMLP's N = 256 product) and the
+    // tiles are long (K >= 1024: a short tile is mostly fixed cost, and more, lower tiles then pack better -- ResMLP's K = 384 fc1 loses 7 %)
+    if (g_p8_plan_mode == 1 && (long long)(M / 256) * tiles_n >= G && nk >= 16) mixed = false;
     const int m = M / 64;
     const double launch_pen = 6000.0 / (nk * 2413.0 + 8000.0);
     auto rounds = [&](long long panels) { return (int)((panels * tiles_n + G - 1) / G); };
@@ -2161,4 +2167,10 @@ extern "C" int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream) {
         case MLPK_F16: return launch_algo<f16_t>(algo, a, trans, s, d->workspace, d->workspace_bytes);
         default: return launch_algo<bf16_t>(algo, a, trans, s, d->workspace, d->workspace_bytes);
     }
+}
+
+extern "C" int mlpk_gemm_set_plan(int mode) {
+    if (mode != 0 && mode != 1) return MLPK_EMODE;
+    g_p8_plan_mode = mode;
+    return 0;
 }

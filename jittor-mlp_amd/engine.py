@@ -152,6 +152,19 @@ TIMER = None
 GEMM_ALGO = {}                    # tag -> forced tile config (tuning/bench hook); default auto
 
 
+def set_gemm_plan(whole_tiles):
+    """mlpk_gemm_set_plan: tile-height plan of the persistent GEMM tile, process-wide.  False (default): mixed tile heights -- the shortest single
+    launch (Mixer-B fc2: 2.58 instead of 3 round-times); True: whole 256-row tiles wherever they still fill a round of CUs and K >= 1024 -- 3 % less CU time in
+    total, the better plan when several forwards share the chip (parallel.InFlight: Mixer-B/16, two in flight, 36.55 -> 37.3 k images/s; one at a
+    time 34.8 -> 34.1 k).  Same K order per output element: same bits."""
+    N.check(N.lib().mlpk_gemm_set_plan(1 if whole_tiles else 0), "mlpk_gemm_set_plan")
+    global GEMM_PLAN_WHOLE
+    GEMM_PLAN_WHOLE = bool(whole_tiles)
+
+
+GEMM_PLAN_WHOLE = False
+
+
 def gemm(A, B, C, M, Nn, K, *, lda=None, ldb=None, ldc=None, bias=None, act=N.ACT_NONE, cscale=None, cshift=None,
          rscale=None, rperiod=0, R=None, ldr=None, res=N.RES_NONE, out_mode=N.OUT_ROWMAJOR, t_rows=0, t_tokens=0,
          algo=0, tag=None, dbg=0, ln=None, ln_group=1, part=None, prof=None):

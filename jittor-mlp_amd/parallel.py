@@ -76,10 +76,22 @@ class InFlight:
         torch.cuda.current_stream().wait_stream(stream)   # (or stream.synchronize()) before `out` is consumed elsewhere
     """
 
-    def __init__(self, forward_fn, n=2, device=None):
+    def __init__(self, forward_fn, n=2, device=None, throughput_plan=True):
         self.forward_fn = forward_fn
         self.streams = [torch.cuda.Stream(device=device) for _ in range(max(1, int(n)))]
         self._i = 0
+        if throughput_plan and len(self.streams) > 1:
+            # with several forwards sharing the chip the persistent GEMM's plan with the least TOTAL work wins over the one with the shortest
+            # single launch (engine.set_gemm_plan): whole 256-row tiles.  Process-wide, same bits; InFlight.restore_plan() undoes it.
+            from . import engine as E
+            self._old_plan = E.GEMM_PLAN_WHOLE
+            E.set_gemm_plan(True)
+
+    def restore_plan(self):
+        if hasattr(self, "_old_plan"):
+            from . import engine as E
+            E.set_gemm_plan(self._old_plan)
+            del self._old_plan
 
     def __call__(self, x):
         s = self.streams[self._i % len(self.streams)]
