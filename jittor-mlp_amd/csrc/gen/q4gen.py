@@ -118,6 +118,9 @@ def sig_gelu_ops(E, x, q, v_k2, s_k1, s_k0):
 SQRT2 = 1.41421356237
 
 STAGE_B = 49152          # one LDS stage: A 256 x 128 B, then B 128 x 128 B
+# round 6: a workgroup's last block drains its last tile WITHOUT multiplying a dummy tile (Q4.build drain_only); MLPK_Q4_DRAIN_ONLY=0 at
+# generation time rebuilds the round-5 kernels (A/B)
+DRAIN_ONLY = os.environ.get("MLPK_Q4_DRAIN_ONLY", "1") != "0"
 B_OFF = 32768
 OUT_OFF = 3 * STAGE_B     # 4 x 4 KiB: one staging tile per wave for the stores
 LDS_BYTES = OUT_OFF + 16384
@@ -920,6 +923,7 @@ class Q4:
         L_roll = [a.newlabel("ROLL0"), a.newlabel("ROLL1")]
         L_block = [a.newlabel("BLK0"), a.newlabel("BLK1")]
         L_rtest = [a.newlabel("RT0"), a.newlabel("RT1")]
+        L_drain = [a.newlabel("DRN0"), a.newlabel("DRN1")]
         if self.static:
             for slab in range(2):
                 for kind, npc in (("A", 8), ("B", 4)):
@@ -937,6 +941,9 @@ class Q4:
             a("s_cmp_eq_u32", self.s_left, 0)
             a("s_cbranch_scc1", L_end)
             a("s_sub_u32", self.s_left, self.s_left, 1)
+            if DRAIN_ONLY:
+                a("s_cmp_eq_u32", self.s_left, 0)
+                a("s_cbranch_scc1", L_drain[1])
             a("s_branch", L_block[1])
         else:
             a("s_mov_b32", self.s_wr, 0)
@@ -1007,12 +1014,45 @@ class Q4:
             a("s_cmp_eq_u32", self.s_left, 0)
             a("s_cbranch_scc1", L_end)
             a("s_sub_u32", self.s_left, self.s_left, 1)
+            if DRAIN_ONLY:
+                # no tile left to multiply: the draining block WITHOUT its dummy tile (round 6)
+                a("s_cmp_eq_u32", self.s_left, 0)
+                a("s_cbranch_scc1", L_drain[1 - P])
             # fall through / jump to the other parity
+
+        def drain_only(Q):
+            """Round 6: the LAST block of a workgroup.  Until round 5 it was an ordinary block (its tile: the clamped last tile once more, the
+            result never stored) whose MFMAs only carried the fillers that drain the real last tile -- one tile's worth of matrix work and operand
+            traffic per workgroup for nothing: +5.4 % at Mixer-B's fc1 (18.4 tiles per workgroup), +30 - 40 % at the K = N = 384 products of 50176
+            rows (2.3 tiles per workgroup).  Here: the one k-step the K loop's skew leaves for the next block's step 0 (the finished tile's LAST
+            k-step, into set 1 - Q, its fragments already in registers), the head (tile coordinates, epilogue bases, parameter loads), and the
+            drain itself, straight through -- no operand stream, no barrier (the staging tile is the wave's own)."""
+            a.label(L_drain[Q])
+            head = self.block_start_ops()
+            ops = self.epilogue_ops(1 - Q) if self.fillers_on else []
+            for qm in range(8):
+                i, j = qm >> 1, qm & 1
+                d = self.acc(1 - Q, 2 * i + j)
+                a(self.mfma, d, self.FB[1][j], self.FA[1][i], d)
+                for _ in range(4):
+                    if head:
+                        head.pop(0)()
+            while head:
+                head.pop(0)()
+            # (an ordinary block's first iteration ends with the wait that covers the head's parameter loads; here nothing else is in flight
+            # that matters -- the operand pieces requested ahead belong to no tile)
+            a("s_waitcnt", vmcnt=0, lgkmcnt=0)
+            for op in ops:
+                op()
+            a("s_branch", L_end)
         L_rdone = [a.newlabel("RD0"), a.newlabel("RD1")]
         block(0)
         a("s_branch", L_block[1])          # (block 1 follows in the listing; kept explicit)
         block(1)
         a("s_branch", L_block[0])
+        if DRAIN_ONLY:
+            drain_only(0)
+            drain_only(1)
         a.label(L_end)
         a("s_waitcnt", vmcnt=0, lgkmcnt=0)
         # tuning: prof != 0 -> wave 0 of every workgroup stores (cycles of the whole kernel body, tiles)
