@@ -129,3 +129,7 @@ def test_two_forwards_in_flight_give_the_serial_bits():
     for (out, _), want in zip(pending, serial):
         assert torch.equal(out, want)
     assert len({id(s) for _, s in pending}) == 2
+    # the in-flight regime switched the persistent GEMM to its whole-tile plan (engine.set_gemm_plan): same bits, and it can be undone
+    assert pkg.engine.GEMM_PLAN_WHOLE
+    slots.restore_plan()
+    assert not pkg.engine.GEMM_PLAN_WHOLE
