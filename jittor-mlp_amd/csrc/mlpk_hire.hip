@@ -570,6 +570,268 @@ static int mixshift_band_launch(const MixShiftArgs& a, hipStream_t s) {
     return 0;
 }
 
+// ---- round 6: the whole mix-shift as ONE launch over aligned channel blocks (mixshift_tile_kernel) ----------------------------------
+// The band kernel above runs once per chunk, and MS-MLP's chunks are 20 / 39 / 77 / 154 channels (torch.chunk of 96 / 192 / 384 / 768
+// into 5): no chunk starts or ends on a 16-byte vector, so its staging fell back to 2-byte loads, its results left as 2-byte stores of
+// 40-byte pieces (partial 64-byte sectors), up to 12 of a wave's 32 channel lanes idled, and a call was five launches: 780 us for the
+// 154 MB + 154 MB of the 56 x 56 x 96 stage (0.4 TB/s).  Here a workgroup owns one image x a band of R rows x 32 ALIGNED channels
+// (64 contiguous bytes of every pixel) and walks the chunks that meet its block: per chunk and branch the band (+ halo) of the chunk's
+// channels is staged as in the band kernel -- but from aligned 16-byte loads, the elements of other chunks masked out, four loads in
+// flight per thread -- a thread is one channel of the chunk and one of 256 / nch task slots (every lane works whatever the chunk
+// width), the stencil arithmetic is the band kernel's (same fused multiply-adds in the same order: bit-equal results), and the
+// results go through an LDS image of the block's output rows, which leaves as whole 64-byte pixel pieces.
+constexpr int MT_CB = 32, MT_NT = 256, MT_TMAX = 7;
+
+struct MtDiv {                                   // x / n for x < 2^32 / n by one multiply (n fixed per chunk)
+    unsigned inv, n;
+    __device__ explicit MtDiv(unsigned n_) : inv(n_ > 1 ? (unsigned)(((1ull << 32) + n_ - 1) / n_) : 0u), n(n_) {}
+    __device__ __forceinline__ unsigned operator()(unsigned x) const { return n > 1 ? __umulhi(x, inv) : x; }
+};
+
+template <typename T, int KS>
+__device__ __forceinline__ void mixtile_chunk(const MixShiftArgs& p, T* __restrict__ tile, T* __restrict__ otile, const T* __restrict__ img,
+                                              const int g, const int c_lo, const int nch, const int cb0, const int y0, const int R,
+                                              const int pitch, const int plane, const int tid) {
+    constexpr int P = KS / 2;
+    constexpr int STRIP = 8;
+    constexpr int EPV = 8;
+    constexpr int WIN = STRIP + KS - 1;
+    constexpr int NV = (WIN + EPV - 1) / EPV;
+    int sh = p.shift[g] % p.H, sw = p.shift[g] % p.W;
+    if (sh < 0) sh += p.H;
+    if (sw < 0) sw += p.W;
+    const int slots = MT_NT / nch;                          // nch <= 32: at least 8 task slots
+    const int cl = tid % nch, slot = tid / nch;
+    const bool live = slot < slots;
+    const int c = c_lo + cl;
+    if constexpr (KS == 1) {
+        // no stencil: two rolled reads and two multiply-adds per element (the k = 1 kernel's arithmetic), straight from global
+        if (!live) return;
+        const int rows_here = min(R, p.H - y0);
+        const int npx = rows_here * p.W;
+        const float wl = p.w_lr[c], wt = p.w_td[c], bs = p.b_lr[c] + p.b_td[c];
+        const MtDiv by_w((unsigned)p.W);
+        T* oc = otile + (c - cb0);
+        const T* ic = img + c;
+#pragma unroll 4
+        for (int px = slot; px < npx; px += slots) {
+            const int ly = (int)by_w((unsigned)px), xx = px - ly * p.W, y = y0 + ly;
+            int xs = xx - sw; if (xs < 0) xs += p.W;
+            int ys = y - sh; if (ys < 0) ys += p.H;
+            const float a_lr = to_f32(ic[((size_t)y * p.W + xs) * p.C]);
+            const float a_td = to_f32(ic[((size_t)ys * p.W + xx) * p.C]);
+            float acc = bs;
+            acc = fmaf(a_lr, wl, acc);
+            acc = fmaf(a_td, wt, acc);
+            oc[px * MT_CB] = from_f32<T>(acc);
+        }
+        return;
+    }
+    const int rows_t = R + 2 * P;
+    const int strips = (p.W + STRIP - 1) / STRIP;
+    const int ntask = R * strips;                           // <= 56 = MT_TMAX * 8
+    const T* cplane = tile + cl * plane;
+    const int rel0 = c_lo - cb0;                            // the chunk's first channel inside the block
+    const int v_lo = rel0 / EPV, nvec = (rel0 + nch - 1) / EPV - v_lo + 1;
+    const int quads = pitch / 4;                            // four tile columns per staging item: one 8-byte LDS write per channel
+    const int row_items = quads * nvec, total = rows_t * row_items;
+    const MtDiv by_items((unsigned)row_items), by_nvec((unsigned)nvec), by_strips((unsigned)strips);
+    f32x2 acc2[MT_TMAX][STRIP / 2];
+    {
+        const float bs = live ? p.b_lr[c] + p.b_td[c] : 0.f;
+#pragma unroll
+        for (int k = 0; k < MT_TMAX; ++k)
+#pragma unroll
+            for (int o = 0; o < STRIP / 2; ++o) acc2[k][o] = f32x2{bs, bs};
+    }
+#pragma unroll 1
+    for (int branch = 0; branch < 2; ++branch) {
+        __syncthreads();                                    // the reads of the tile (previous branch / previous chunk) are done
+        // ---- stage: (tile row r, four tile columns 4 qq .., vector v) <- the rolled source pixels' 8 channels, zeros outside the map and in
+        // the slack columns up to the pitch (the window reads run past a strip's end).  The loads are unconditional (a position outside reads
+        // pixel 0), eight are in flight per thread before the first LDS write; the transposition is one 8-byte write per channel ----
+#pragma unroll 1
+        for (int base = tid; base < total; base += 2 * MT_NT) {
+            u32x4 raw[2][4];
+            int dst[2], vv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int idx = base + u * MT_NT;
+                const int id = idx < total ? idx : total - 1;
+                const int r = (int)by_items((unsigned)id);
+                const int rem = id - r * row_items;
+                const int qq = (int)by_nvec((unsigned)rem);
+                const int v = v_lo + rem - qq * nvec;
+                const int yy = y0 + r - P;
+                const bool row_in = yy >= 0 && yy < p.H;
+                int ys = row_in ? yy : 0;
+                if (branch == 1) { ys -= sh; if (ys < 0) ys += p.H; }
+                const T* srow = img + (size_t)ys * p.W * p.C + cb0 + v * EPV;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int xx = 4 * qq + j - P;
+                    const bool inside = row_in && xx >= 0 && xx < p.W;
+                    int xs = inside ? xx : 0;
+                    if (branch == 0) { xs -= sw; if (xs < 0) xs += p.W; }
+                    const u32x4 t = *reinterpret_cast<const u32x4*>(srow + (size_t)xs * p.C);
+                    raw[u][j] = inside ? t : u32x4{0u, 0u, 0u, 0u};
+                }
+                dst[u] = idx < total ? r * pitch + 4 * qq : -1;
+                vv[u] = v * EPV - rel0;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (dst[u] < 0) continue;
+#pragma unroll
+                for (int k = 0; k < EPV; ++k) {
+                    const int rel = vv[u] + k;              // channel inside the chunk
+                    if (rel < 0 || rel >= nch) continue;
+                    const int w = k >> 1;
+                    u32x2 pk;
+                    if (k & 1) {
+                        pk.x = (raw[u][0][w] >> 16) | (raw[u][1][w] & 0xffff0000u);
+                        pk.y = (raw[u][2][w] >> 16) | (raw[u][3][w] & 0xffff0000u);
+                    } else {
+                        pk.x = (raw[u][0][w] & 0xffffu) | (raw[u][1][w] << 16);
+                        pk.y = (raw[u][2][w] & 0xffffu) | (raw[u][3][w] << 16);
+                    }
+                    *reinterpret_cast<u32x2*>(tile + rel * plane + dst[u]) = pk;
+                }
+            }
+        }
+        __syncthreads();
+        if (live) {
+            const float* wsrc = branch == 0 ? p.w_lr : p.w_td;
+            constexpr int NT2 = (KS * KS + 1) / 2;
+            f32x2 wt2[NT2];
+#pragma unroll
+            for (int q = 0; q < NT2; ++q) {
+                wt2[q].x = wsrc[(size_t)(2 * q) * p.C + c];
+                wt2[q].y = 2 * q + 1 < KS * KS ? wsrc[(size_t)(2 * q + 1) * p.C + c] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < MT_TMAX; ++k) {
+                const int task = slot + k * slots;
+                if (task >= ntask) break;
+                const int ly = (int)by_strips((unsigned)task), st = task - ly * strips;
+                const int x0 = st * STRIP;
+#pragma unroll
+                for (int dy = 0; dy < KS; ++dy) {
+                    const T* row = cplane + (ly + dy) * pitch + x0;
+                    float win[NV * EPV + 1];
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        const u32x4 rw = *reinterpret_cast<const u32x4*>(row + v * EPV);
+                        T e[EPV];
+                        __builtin_memcpy(e, &rw, 16);
+#pragma unroll
+                        for (int kk = 0; kk < EPV; ++kk) win[v * EPV + kk] = to_f32(e[kk]);
+                    }
+                    win[NV * EPV] = 0.f;
+#pragma unroll
+                    for (int dx = 0; dx < KS; ++dx) {
+                        const int tap = dy * KS + dx;
+#pragma unroll
+                        for (int o = 0; o < STRIP / 2; ++o) {
+                            const f32x2 xin = {win[2 * o + dx], win[2 * o + dx + 1]};
+                            if (tap & 1) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc2[k][o]) : "v"(xin), "v"(wt2[tap >> 1]));
+                            else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc2[k][o]) : "v"(xin), "v"(wt2[tap >> 1]));
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (!live) return;
+    // results -> the block's output image in LDS, [row][column][channel of the block]
+    T* oc = otile + (c - cb0);
+#pragma unroll
+    for (int k = 0; k < MT_TMAX; ++k) {
+        const int task = slot + k * slots;
+        if (task >= ntask) break;
+        const int ly = (int)by_strips((unsigned)task), st = task - ly * strips;
+#pragma unroll
+        for (int o = 0; o < STRIP; ++o) {
+            const int xx = st * STRIP + o;
+            if (xx < p.W) oc[(ly * p.W + xx) * MT_CB] = from_f32<T>((o & 1) ? acc2[k][o >> 1].y : acc2[k][o >> 1].x);
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(MT_NT) mixshift_tile_kernel(const MixShiftArgs p, const int R, const int pitch, const int plane, const int nbands) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* tile = reinterpret_cast<T*>(smem_raw);               // [<= MT_CB channels of one chunk][R + 2P rows][pitch]
+    T* otile = tile + MT_CB * plane;                        // [R][W][MT_CB]
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / nbands;
+    const int y0 = (blockIdx.x - b * nbands) * R;
+    const int cb0 = blockIdx.y * MT_CB;
+    const int cbn = min(MT_CB, p.C - cb0);
+    const T* img = reinterpret_cast<const T*>(p.x) + (size_t)b * p.H * p.W * p.C;
+    for (int g = cb0 / p.chunk0; g < p.groups; ++g) {
+        const int glo = g * p.chunk0;
+        if (glo >= cb0 + cbn) break;
+        const int c_lo = max(glo, cb0);
+        const int c_hi = min(min(glo + p.chunk0, p.C), cb0 + cbn);
+        const int nch = c_hi - c_lo;
+        switch (p.ksize[g]) {
+            case 1: mixtile_chunk<T, 1>(p, tile, otile, img, g, c_lo, nch, cb0, y0, R, pitch, plane, tid); break;
+            case 3: mixtile_chunk<T, 3>(p, tile, otile, img, g, c_lo, nch, cb0, y0, R, pitch, plane, tid); break;
+            case 5: mixtile_chunk<T, 5>(p, tile, otile, img, g, c_lo, nch, cb0, y0, R, pitch, plane, tid); break;
+            default: mixtile_chunk<T, 7>(p, tile, otile, img, g, c_lo, nch, cb0, y0, R, pitch, plane, tid); break;
+        }
+    }
+    __syncthreads();
+    // the block's rows leave as whole 16-byte vectors: cbn * 2 contiguous bytes per pixel
+    const int vpp = cbn / 8;
+    const int rows_here = min(R, p.H - y0);
+    const int total = rows_here * p.W * vpp;
+    T* o = reinterpret_cast<T*>(p.out) + (((size_t)b * p.H + y0) * p.W) * p.C + cb0;
+    for (int i = tid; i < total; i += MT_NT) {
+        const int px = i / vpp, v = i - px * vpp;
+        *reinterpret_cast<u32x4*>(o + (size_t)px * p.C + v * 8) = *reinterpret_cast<const u32x4*>(otile + px * MT_CB + v * 8);
+    }
+}
+
+// 0 = launched, 1 = shape outside this kernel (the per-chunk band kernel / the gather kernels take it), else a HIP error
+template <typename T>
+static int mixshift_tile_launch(const MixShiftArgs& a, hipStream_t s) {
+    if (sizeof(T) != 2 || (a.C & 7) || (((uintptr_t)a.x | (uintptr_t)a.out) & 15)) return 1;
+    const int strips = (a.W + 7) / 8;
+    if (strips > 7) return 1;
+    int kmax = 1;
+    for (int g = 0; g < a.groups; ++g) {
+        if (a.ksize[g] != 1 && a.ksize[g] != 3 && a.ksize[g] != 5 && a.ksize[g] != 7) return 1;
+        kmax = a.ksize[g] > kmax ? a.ksize[g] : kmax;
+    }
+    const int P = kmax / 2;
+    int pitch = (strips - 1) * 8 + ((8 + kmax - 1 + 7) / 8) * 8;
+    if (pitch < a.W + 2 * P) pitch = a.W + 2 * P;
+    pitch = (pitch + 7) / 8 * 8;
+    static const int r_env = getenv("MLPK_MIXSHIFT_R") ? atoi(getenv("MLPK_MIXSHIFT_R")) : 0;       // tuning hook
+    int R = r_env >= 1 && r_env <= 8 ? r_env : (a.H % 7 == 0 ? 7 : 8);
+    if (R > a.H) R = a.H;
+    int plane;
+    size_t lds;
+    for (;;) {
+        plane = (R + 2 * P) * pitch;                           // pitch is a multiple of 8: whole 16-byte slots
+        if (((plane / 8) & 1) == 0) plane += 8;                // odd number of 16-byte slots per channel plane: conflict-free across channels
+        lds = ((size_t)MT_CB * plane + (size_t)R * a.W * MT_CB) * sizeof(T);
+        if (lds <= 79 * 1024 || R == 1 || r_env) break;        // two workgroups per CU
+        R = (R + 1) / 2;
+    }
+    if (lds > 150 * 1024) return 1;
+    const int nbands = (a.H + R - 1) / R;
+    if ((long long)a.B * nbands > 0x7fffffffll) return 1;
+    auto kern = mixshift_tile_kernel<T>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    const dim3 grid((unsigned)(a.B * nbands), (unsigned)((a.C + MT_CB - 1) / MT_CB));
+    hipLaunchKernelGGL(kern, grid, dim3(MT_NT), lds, s, a, R, pitch, plane, nbands);
+    return 0;
+}
+
 // ================================ Swin-MLP: the whole spatial-MLP half of a block in one kernel ================================
 // swin_mlp.py:97-151: x <- x + merge(crop(spatial_mlp(partition(pad(LayerNorm(x)))))) where spatial_mlp is a grouped Conv1d over the ws^2
 // positions of a window, one (ws^2 x ws^2) matrix per head, a head = C / heads consecutive channels.  As separate passes this was
@@ -854,6 +1116,15 @@ extern "C" int mlpk_mixshift_nhwc(int dtype, const void* x, void* out, int B, in
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     static const bool no_band = getenv("MLPK_MIXSHIFT_NO_BAND") != nullptr;      // tuning hook
+    const char* tile_env = getenv("MLPK_MIXSHIFT_TILE");                         // "0": the per-chunk band kernel (A/B runs, the bit-equality test)
+    if (!no_band && !(tile_env && tile_env[0] == '0') && dtype != MLPK_F32) {
+        const int rc = dtype == MLPK_F16 ? mlpk::mixshift_tile_launch<mlpk::f16_t>(a, s) : mlpk::mixshift_tile_launch<mlpk::bf16_t>(a, s);
+        if (rc != 1) {
+            if (rc) return rc;
+            MLPK_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (!no_band && B <= 0x7fffff) {
         int rc;
         switch (dtype) {

@@ -1299,6 +1299,47 @@ def test_mixshift_nhwc(dtype):
         assert err < tol * max(1.0, ref.abs().max().item()), (str(dtype), ci, err)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_mixshift_tile_kernel_is_bit_equal_to_the_per_chunk_kernels(dtype):
+    """mixshift_tile_kernel (round 6): the whole mix-shift of ms_mlp.py:52-67 as one launch over aligned 32-channel blocks -- the same fused
+    multiply-adds in the same order as the per-chunk band / k = 1 kernels it replaces (MLPK_MIXSHIFT_TILE=0), so BIT-EQUAL to them, which
+    test_mixshift_nhwc and the model goldens hold to the reference.  MS-MLP-T's four stages (chunks of 20 / 39 / 77 / 154 channels: no chunk
+    boundary on a 16-byte vector), bands that do not divide the map, a last block of fewer than 32 channels, one-channel chunks."""
+    pkg = load_pkg()
+    E = pkg.engine
+    cases = ((2, 56, 56, 96, [-2, -1, 0, 1, 2], [1, 1, 3, 5, 7]), (2, 28, 28, 192, [-2, -1, 0, 1, 2], [1, 1, 3, 5, 5]),
+             (3, 14, 14, 384, [-2, -1, 0, 1, 2], [1, 1, 3, 3, 3]), (2, 7, 7, 768, [-2, -1, 0, 1, 2], [1, 1, 1, 1, 3]),
+             (2, 13, 11, 40, [5, -7, 1], [7, 3, 5]), (1, 9, 50, 8, [1, 2, 3, 4, 5, 6, 7, 8], [1, 3, 5, 7, 7, 5, 3, 1]),
+             (2, 10, 6, 72, [0, 30], [5, 7]))
+    for ci, (B, H, W, C, shift, ks) in enumerate(cases):
+        kmax = max(ks)
+        x = rnd((B, H, W, C), dtype, 1500 + ci).to(dev())
+        w_lr, w_td = rnd((kmax * kmax, C), torch.float32, 1510 + ci, 0.5).to(dev()), rnd((kmax * kmax, C), torch.float32, 1520 + ci, 0.5).to(dev())
+        b_lr, b_td = rnd((C,), torch.float32, 1530 + ci).to(dev()), rnd((C,), torch.float32, 1540 + ci).to(dev())
+        outs = []
+        for mode in ("1", "0"):
+            os.environ["MLPK_MIXSHIFT_TILE"] = mode
+            try:
+                out = torch.full((B, H, W, C), float("nan"), dtype=dtype, device=dev())
+                E.mixshift_nhwc(x, out, B, H, W, C, shift, ks, w_lr, b_lr, w_td, b_td)
+                torch.cuda.synchronize()
+            finally:
+                os.environ.pop("MLPK_MIXSHIFT_TILE", None)
+            outs.append(out)
+        assert not torch.isnan(outs[0].float()).any(), (str(dtype), ci)
+        if dtype == torch.float16:
+            # the k = 1 kernel's last multiply-add and the conversion are ONE instruction for f16 (v_fma_mixlo_f16: one rounding), here the sum is
+            # rounded to fp32 first: a handful of results per million differ by one f16 ulp on the k = 1 chunks -- and only there
+            chunk0 = (C + len(ks) - 1) // len(ks)
+            k_of = torch.tensor([ks[c // chunk0] for c in range(C)], device=dev())
+            a, b_ = outs[0].float(), outs[1].float()
+            assert torch.equal(a[..., k_of > 1], b_[..., k_of > 1]), (str(dtype), ci)
+            d = (a - b_).abs()
+            assert (d <= b_.abs() * 2.0 ** -10 + 1e-7).all() and (d > 0).float().mean().item() < 1e-4, (str(dtype), ci, d.max().item())
+            continue
+        assert torch.equal(outs[0], outs[1]), (str(dtype), ci, (outs[0].float() - outs[1].float()).abs().max().item())
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_window_gather_scatter(dtype):
     """Swin-MLP window partition with the shifted blocks' zero padding and the inverse merge + crop + residual
