@@ -810,17 +810,29 @@ static int mixshift_tile_launch(const MixShiftArgs& a, hipStream_t s) {
     if (pitch < a.W + 2 * P) pitch = a.W + 2 * P;
     pitch = (pitch + 7) / 8 * 8;
     static const int r_env = getenv("MLPK_MIXSHIFT_R") ? atoi(getenv("MLPK_MIXSHIFT_R")) : 0;       // tuning hook
-    int R = r_env >= 1 && r_env <= 8 ? r_env : (a.H % 7 == 0 ? 7 : 8);
-    if (R > a.H) R = a.H;
-    int plane;
-    size_t lds;
-    for (;;) {
-        plane = (R + 2 * P) * pitch;                           // pitch is a multiple of 8: whole 16-byte slots
-        if (((plane / 8) & 1) == 0) plane += 8;                // odd number of 16-byte slots per channel plane: conflict-free across channels
-        lds = ((size_t)MT_CB * plane + (size_t)R * a.W * MT_CB) * sizeof(T);
-        if (lds <= 79 * 1024 || R == 1 || r_env) break;        // two workgroups per CU
-        R = (R + 1) / 2;
+    // rows per band: a thread holds at most MT_TMAX tasks of its >= 8 slots; among the heights whose tile leaves room for two workgroups
+    // per CU, the one that stages the fewest rows (bands x (R + halo)) -- measured: 14 rows against 7 on the 28 x 28 and 14 x 14 maps
+    // 188 -> 155 and 104 -> 79 us, 8 rows on the 56 x 56 map (one workgroup per CU) 362 -> 530
+    const int r_cap = 8 * MT_TMAX / strips < a.H ? 8 * MT_TMAX / strips : a.H;
+    auto geometry = [&](int R_, int* plane_) {
+        int pl = (R_ + 2 * P) * pitch;                         // pitch is a multiple of 8: whole 16-byte slots
+        if (((pl / 8) & 1) == 0) pl += 8;                      // odd number of 16-byte slots per channel plane: conflict-free across channels
+        *plane_ = pl;
+        return ((size_t)MT_CB * pl + (size_t)R_ * a.W * MT_CB) * sizeof(T);
+    };
+    int R = 1, plane = 0;
+    if (r_env >= 1) {
+        R = r_env < r_cap ? r_env : r_cap;
+    } else {
+        long best = -1;
+        for (int r = r_cap; r >= 1; --r) {
+            int pl;
+            if (geometry(r, &pl) > 79 * 1024 && r > 1) continue;
+            const long cost = (long)((a.H + r - 1) / r) * (r + 2 * P);
+            if (best < 0 || cost < best) { best = cost; R = r; }
+        }
     }
+    const size_t lds = geometry(R, &plane);
     if (lds > 150 * 1024) return 1;
     const int nbands = (a.H + R - 1) / R;
     if ((long long)a.B * nbands > 0x7fffffffll) return 1;
