@@ -1050,6 +1050,192 @@ __global__ void __launch_bounds__(SW_NT) swin_spatial_kernel(const SwinArgs p) {
     }
 }
 
+// Round 6: the same kernel with the LDS traffic rearranged (swin_spatial_q_kernel; MLPK_SWIN_SPATIAL_Q=0 runs the one above).  Measured on the
+// one above: 124 us per call on the 14 x 14 x 384 maps = 0.6 TB/s, 65 k cycles per window of 49 x 384 values.  Its loader wrote the transposed
+// image with one 2-byte LDS write per value, consecutive lanes = consecutive 8-channel chunks = rows 8 x SW_TPITCH = 288 dwords apart: TWO banks for a
+// whole wave (any 16-byte-aligned row pitch gives 0 or 32 mod 64), and the results went back as 16 2-byte writes per lane and product.  Here
+//   * an item is (four consecutive tokens, 8-channel chunk), lanes ordered (chunk & 3, token quad, chunk / 4): four 16-byte loads per item (the four
+//     chunks of a 64-byte sector side by side), the normalised values leave as ONE 8-byte write per channel, lanes of a quad of chunks 32 banks apart
+//     and token quads 2 banks apart (2-way instead of 32-way);
+//   * the product is computed transposed -- A = the image (channel x token), B = W_h^T -- so a lane's accumulators are 4 consecutive CHANNELS of one
+//     token: an 8-byte write into the [token][channel] result image instead of four 2-byte ones; the same products summed in the same order;
+//   * residual / store / statistics as above, on the new item shape.  Bit-equal to the kernel above.
+template <typename T, int MAXQ, int NHW>
+__global__ void __launch_bounds__(SW_NT) swin_spatial_q_kernel(const SwinArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_sw[];
+    T* __restrict__ x = reinterpret_cast<T*>(p.x);
+    const T* __restrict__ wgt = reinterpret_cast<const T*>(p.w);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = p.C, CV = C / 8, ws = p.ws, T2 = ws * ws, NQ = (T2 + 3) >> 2;
+    const int win = blockIdx.x;
+    const int wx = win % p.nWx, wy = (win / p.nWx) % p.nWy, b = win / (p.nWx * p.nWy);
+    const int nitem = CV * NQ;
+    const int opitch = 2 * C + 16;                           // LDS row of the result image [token][channel]
+    // zero the k-padding columns the loader does not write (token quads NQ .. 15) of every channel row
+    {
+        const int zq = 16 - NQ;
+        for (int i = tid; i < C * zq; i += SW_NT) {
+            const int ch = i / zq, q = NQ + i - ch * zq;
+            *reinterpret_cast<u32x2*>(smem_sw + ch * SW_TPITCH + q * 8) = u32x2{0u, 0u};
+        }
+    }
+    u32x4 raw[MAXQ][4];
+    const float inv_nq = 1.0f / (float)NQ, inv_ws = 1.0f / (float)ws;
+#pragma unroll
+    for (int k = 0; k < MAXQ; ++k) {
+        const int it = tid + k * SW_NT;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) raw[k][j] = u32x4{0u, 0u, 0u, 0u};
+        if (it < nitem) {
+            const int r_ = it >> 2;
+            const int cg = (int)(((float)r_ + 0.5f) * inv_nq), tq = r_ - cg * NQ;
+            const int cq = cg * 4 + (it & 3);
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gamma + cq * 8), g1 = *reinterpret_cast<const f32x4*>(p.gamma + cq * 8 + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.beta + cq * 8), b1 = *reinterpret_cast<const f32x4*>(p.beta + cq * 8 + 4);
+            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            size_t rows[4];
+            bool ins[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int t = 4 * tq + j;
+                const int ty = (int)(((float)t + 0.5f) * inv_ws), tx = t - ty * ws;
+                const int yy = wy * ws + ty - p.pad_t, xx = wx * ws + tx - p.pad_l;
+                ins[j] = t < T2 && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+                rows[j] = ((size_t)b * p.H + (ins[j] ? yy : 0)) * p.W + (ins[j] ? xx : 0);
+                raw[k][j] = *reinterpret_cast<const u32x4*>(x + rows[j] * C + cq * 8);
+            }
+            T xn[4][8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float mu = p.mean[rows[j]], rs = p.rstd[rows[j]];
+                T e[8];
+                __builtin_memcpy(e, &raw[k][j], 16);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float v = (to_f32(e[q]) - mu) * rs * gg[q] + bb[q];
+                    xn[j][q] = ins[j] ? from_f32<T>(v) : from_f32<T>(0.f);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const T four[4] = {xn[0][q], xn[1][q], xn[2][q], xn[3][q]};
+                u32x2 pk;
+                __builtin_memcpy(&pk, four, 8);
+                *reinterpret_cast<u32x2*>(smem_sw + (cq * 8 + q) * SW_TPITCH + tq * 8) = pk;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- head by head, transposed: out^T (32 channels x 64 tokens) = xn_h^T (32 x 64 tokens) . W_h^T ----
+    const int n = lane & 31, kh = lane >> 5;
+    f32x16 acc[2];
+    const int nh_w = (p.heads - wave + SW_NT / 64 - 1) / (SW_NT / 64);      // heads of this wave: wave, wave + 4, ...
+    u32x4 res[NHW][2][2];
+#pragma unroll
+    for (int hi = 0; hi < NHW; ++hi) {
+        if (hi < nh_w) {
+            const int h = wave + hi * (SW_NT / 64);
+            const T* wh = wgt + (size_t)h * 64 * 64;
+            acc[0] = acc[1] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const u32x4 xfrag = *reinterpret_cast<const u32x4*>(smem_sw + (h * 32 + n) * SW_TPITCH + (16 * ks + 8 * kh) * 2);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const u32x4 wfrag = *reinterpret_cast<const u32x4*>(wh + (size_t)(32 * nb + n) * 64 + 16 * ks + 8 * kh);
+                    acc[nb] = SwinMma<T>::run(xfrag, wfrag, acc[nb]);
+                }
+            }
+            // lane (token 32 nb + n, kh): acc[nb][r] = out[token][channel 32 h + 8 (r / 4) + 4 kh + (r % 4)]; + bias of the token, round, pack
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const float bv = p.bias[h * 64 + 32 * nb + n];
+                T e[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) e[r] = from_f32<T>(acc[nb][r] + bv);
+                __builtin_memcpy(&res[hi][nb][0], e, 16);
+                __builtin_memcpy(&res[hi][nb][1], e + 8, 16);
+            }
+        }
+    }
+    __syncthreads();                                         // every wave is done reading the transposed image: its bytes become the result image
+#pragma unroll
+    for (int hi = 0; hi < NHW; ++hi) {
+        if (hi < nh_w) {
+            const int h = wave + hi * (SW_NT / 64);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const int t = 32 * nb + n;
+                if (t < T2) {
+                    char* o = smem_sw + t * opitch + (h * 32 + 4 * kh) * 2;
+                    *reinterpret_cast<u32x2*>(o) = u32x2{res[hi][nb][0].x, res[hi][nb][0].y};
+                    *reinterpret_cast<u32x2*>(o + 16) = u32x2{res[hi][nb][0].z, res[hi][nb][0].w};
+                    *reinterpret_cast<u32x2*>(o + 32) = u32x2{res[hi][nb][1].x, res[hi][nb][1].y};
+                    *reinterpret_cast<u32x2*>(o + 48) = u32x2{res[hi][nb][1].z, res[hi][nb][1].w};
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- residual and store (the positions inside the map only: the crop of swin_mlp.py:148-149) ----
+#pragma unroll
+    for (int k = 0; k < MAXQ; ++k) {
+        const int it = tid + k * SW_NT;
+        if (it < nitem) {
+            const int r_ = it >> 2;
+            const int cg = (int)(((float)r_ + 0.5f) * inv_nq), tq = r_ - cg * NQ;
+            const int cq = cg * 4 + (it & 3);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int t = 4 * tq + j;
+                const int ty = (int)(((float)t + 0.5f) * inv_ws), tx = t - ty * ws;
+                const int yy = wy * ws + ty - p.pad_t, xx = wx * ws + tx - p.pad_l;
+                if (t < T2 && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) {
+                    const u32x4 yv = *reinterpret_cast<const u32x4*>(smem_sw + t * opitch + cq * 16);
+                    T a[8], y8[8], o[8];
+                    __builtin_memcpy(a, &raw[k][j], 16);
+                    __builtin_memcpy(y8, &yv, 16);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) o[q] = from_f32<T>(to_f32(a[q]) + to_f32(y8[q]));
+                    u32x4 ov;
+                    __builtin_memcpy(&ov, o, 16);
+                    *reinterpret_cast<u32x4*>(x + (((size_t)b * p.H + yy) * p.W + xx) * C + cq * 8) = ov;
+                    if (p.out_mean) *reinterpret_cast<u32x4*>(smem_sw + t * opitch + cq * 16) = ov;      // (the item's own bytes: read above by this thread only)
+                }
+            }
+        }
+    }
+    if (!p.out_mean) return;                                 // (workgroup-uniform)
+    // ---- statistics of the stored rows: four threads per token, a quarter of the channels each, in a fixed order (deterministic) ----
+    __syncthreads();
+    {
+        const int t = tid >> 2, part = tid & 3;
+        float s = 0.f, ss = 0.f;
+        const int ty = t / ws, tx = t - ty * ws;
+        const int yy = wy * ws + ty - p.pad_t, xx = wx * ws + tx - p.pad_l;
+        const bool live = t < T2 && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+        if (live) {
+            const int nq = C / 32;                           // 16-byte chunks per quarter row
+            for (int i = 0; i < nq; ++i) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(smem_sw + t * opitch + (part * nq + i) * 16);
+                T e[8];
+                __builtin_memcpy(e, &v, 16);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const float f = to_f32(e[q]); s += f; ss = __builtin_fmaf(f, f, ss); }
+            }
+        }
+        s += __shfl_xor(s, 1); ss += __shfl_xor(ss, 1);       // (p0 + p1) + (p2 + p3): the same order in every lane of the quad
+        s += __shfl_xor(s, 2); ss += __shfl_xor(ss, 2);
+        if (live && part == 0) {
+            const float mean = s / (float)C;
+            const float var = ss / (float)C - mean * mean;
+            const size_t row = ((size_t)b * p.H + yy) * p.W + xx;
+            p.out_mean[row] = mean;
+            p.out_rstd[row] = 1.0f / __builtin_sqrtf((var > 0.f ? var : 0.f) + p.eps);
+        }
+    }
+}
+
 }  // namespace mlpk
 
 extern "C" int mlpk_swin_spatial_supported(int dtype, int C, int heads, int ws) {
@@ -1088,6 +1274,29 @@ extern "C" int mlpk_swin_spatial_stats(int dtype, void* x, int B, int H, int W, 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipError_t e = hipSuccess;
     const int items = (t2 * (C / 8) + SW_NT - 1) / SW_NT, hpw = (heads + 3) / 4;
+    const char* q_env = getenv("MLPK_SWIN_SPATIAL_Q");                 // "0": the round-4 kernel (A/B runs, the bit-equality test)
+    if (!(q_env && q_env[0] == '0')) {
+        const int qitems = (((t2 + 3) / 4) * (C / 8) + SW_NT - 1) / SW_NT;
+#define SWQ_LAUNCH(TT, MAXQ, NHW)                                                                                          \
+    do {                                                                                                                   \
+        auto k = swin_spatial_q_kernel<TT, MAXQ, NHW>;                                                                     \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);        \
+        if (e != hipSuccess) return (int)e;                                                                                \
+        hipLaunchKernelGGL(k, dim3((unsigned)nwin), dim3(SW_NT), lds, s, a);                                               \
+    } while (0)
+#define SWQ_PICK(TT)                                                                                                       \
+    do {                                                                                                                   \
+        if (qitems <= 1 && hpw <= 1) SWQ_LAUNCH(TT, 1, 1);                                                                 \
+        else if (qitems <= 2 && hpw <= 2) SWQ_LAUNCH(TT, 2, 2);                                                            \
+        else if (qitems <= 3 && hpw <= 3) SWQ_LAUNCH(TT, 3, 3);                                                            \
+        else SWQ_LAUNCH(TT, 6, 6);                                                                                         \
+    } while (0)
+        if (dtype == MLPK_BF16) SWQ_PICK(bf16_t); else SWQ_PICK(f16_t);
+#undef SWQ_PICK
+#undef SWQ_LAUNCH
+        MLPK_LAUNCH_CHECK();
+        return 0;
+    }
 #define SW_LAUNCH(TT, MAXI, NHW)                                                                                           \
     do {                                                                                                                   \
         auto k = swin_spatial_kernel<TT, MAXI, NHW, (MAXI > 3) && SW_RELOAD>;                                                                       \

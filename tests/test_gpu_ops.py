@@ -1743,7 +1743,7 @@ def test_swin_spatial_mlp_half_of_a_block_in_one_kernel(dtype):
     pkg = load_pkg()
     E = pkg.engine
     for ci, (B, H, W, heads, ws, shift) in enumerate([(2, 14, 14, 3, 7, 0), (3, 14, 14, 3, 7, 3), (2, 7, 7, 24, 7, 0), (1, 28, 21, 6, 7, 3), (2, 8, 8, 1, 4, 2),
-                                                      (5, 56, 56, 3, 7, 3), (2, 14, 14, 12, 7, 3)]):
+                                                      (5, 56, 56, 3, 7, 3), (2, 14, 14, 12, 7, 3), (2, 28, 28, 6, 7, 3), (2, 12, 10, 2, 5, 2)]):
         C, t = heads * 32, ws * ws
         assert E.swin_spatial_supported(dtype, C, heads, ws)
         x = (rnd((B * H * W, C), dtype, 4100 + ci) * 1.3 + 0.2).to(dev())
@@ -1784,6 +1784,15 @@ def test_swin_spatial_mlp_half_of_a_block_in_one_kernel(dtype):
         E.swin_spatial(got2, B, H, W, C, ws, pad_t, pad_l, Hp, Wp, heads, mean, rstd, gamma.to(dev()), beta.to(dev()), wp, bp, out_stats=(m2, r2), eps=1e-5)
         torch.cuda.synchronize()
         assert torch.equal(got2, got), (str(dtype), ci)
+        # round 6: the kernel above is the quad-token form (8-byte LDS writes, transposed product); the round-4 form gives the same bits
+        got3 = x.clone()
+        os.environ["MLPK_SWIN_SPATIAL_Q"] = "0"
+        try:
+            E.swin_spatial(got3, B, H, W, C, ws, pad_t, pad_l, Hp, Wp, heads, mean, rstd, gamma.to(dev()), beta.to(dev()), wp, bp)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("MLPK_SWIN_SPATIAL_Q", None)
+        assert torch.equal(got3, got), (str(dtype), ci, (got3.float() - got.float()).abs().max().item())
         gd = got.cpu().double().reshape(B * H * W, C)
         assert (m2.cpu().double() - gd.mean(1)).abs().max().item() < 1e-5 * scale, (str(dtype), ci)
         want_r = 1.0 / torch.sqrt(gd.var(1, unbiased=False) + 1e-5)
