@@ -20,12 +20,24 @@ __global__ void __launch_bounds__(256) patchify_kernel(const PatchArgs p) {
     TD* __restrict__ out = reinterpret_cast<TD*>(p.out);
     const int chunks = p.ldo / 8;
     const int64_t total = p.rows * chunks;
+    const bool small = total <= 0x7fffffffll;             // 32-bit index arithmetic where it fits (64-bit divisions cost ~100 instructions each)
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        const int64_t row = idx / chunks;
-        const int k0 = (int)(idx - row * chunks) * 8;
-        const int wp = (int)(row % p.Wp);
-        const int hp = (int)((row / p.Wp) % p.Hp);
-        const int b = (int)(row / ((int64_t)p.Wp * p.Hp));
+        int64_t row;
+        int k0, wp, hp, b;
+        if (small) {
+            const unsigned i32 = (unsigned)idx, r32 = i32 / (unsigned)chunks, hw = r32 / (unsigned)p.Wp;
+            row = r32;
+            k0 = (int)(i32 - r32 * (unsigned)chunks) * 8;
+            wp = (int)(r32 - hw * (unsigned)p.Wp);
+            b = (int)(hw / (unsigned)p.Hp);
+            hp = (int)(hw - (unsigned)b * (unsigned)p.Hp);
+        } else {
+            row = idx / chunks;
+            k0 = (int)(idx - row * chunks) * 8;
+            wp = (int)(row % p.Wp);
+            hp = (int)((row / p.Wp) % p.Hp);
+            b = (int)(row / ((int64_t)p.Wp * p.Hp));
+        }
         TD e[8];
         if (p.layout == MLPK_LAYOUT_NHWC && (p.Cin & 7) == 0 && k0 < p.K) {
             // 8 consecutive k share the patch offset (i,j): one contiguous 8-channel run
@@ -61,31 +73,35 @@ __global__ void __launch_bounds__(256) patchify_kernel(const PatchArgs p) {
 #pragma unroll
                 for (int t = 0; t < 8; ++t) e[t] = from_f32<TD>(to_f32(t8[t]));
             }
+        } else if (p.layout == MLPK_LAYOUT_NCHW) {
+            // overlapping / padded windows on NCHW (the 7 x 7 stride-4 stems of Hire-MLP and CycleMLP): k -> (ci, i, j) decoded ONCE per
+            // chunk and advanced with carries (round 6: two divisions per element made this path ALU-bound, 230 us for 77 MB in / 244 MB out)
+            int ci = k0 / (p.ph * p.pw);
+            const int rem = k0 - ci * (p.ph * p.pw);
+            int i = rem / p.pw;
+            int j = rem - i * p.pw;
+            const int y0 = hp * p.sh - p.pad, x0 = wp * p.sw - p.pad;
+            const TS* img = src + (int64_t)b * p.Cin * p.H * p.W;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int y = y0 + i, x = x0 + j;
+                const bool ok = k0 + t < p.K && y >= 0 && y < p.H && x >= 0 && x < p.W;
+                const TS raw = img[ok ? ((int64_t)ci * p.H + y) * p.W + x : 0];          // unconditional load: the eight are in flight together
+                e[t] = ok ? from_f32<TD>(to_f32(raw)) : from_f32<TD>(0.f);
+                if (++j == p.pw) { j = 0; if (++i == p.ph) { i = 0; ++ci; } }
+            }
         } else {
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const int k = k0 + t;
                 float v = 0.f;
                 if (k < p.K) {
-                    int ci, i, j;
-                    if (p.layout == MLPK_LAYOUT_NCHW) {
-                        ci = k / (p.ph * p.pw);
-                        const int rem = k - ci * (p.ph * p.pw);
-                        i = rem / p.pw;
-                        j = rem - i * p.pw;
-                    } else {
-                        const int q = k / p.Cin;
-                        ci = k - q * p.Cin;
-                        i = p.order == 1 ? (q & 1) : q / p.pw;
-                        j = p.order == 1 ? (q >> 1) : q - (q / p.pw) * p.pw;
-                    }
+                    const int q = k / p.Cin;
+                    const int ci = k - q * p.Cin;
+                    const int i = p.order == 1 ? (q & 1) : q / p.pw;
+                    const int j = p.order == 1 ? (q >> 1) : q - (q / p.pw) * p.pw;
                     const int y = hp * p.sh + i - p.pad, x = wp * p.sw + j - p.pad;
-                    if (y >= 0 && y < p.H && x >= 0 && x < p.W) {
-                        const int64_t si = p.layout == MLPK_LAYOUT_NCHW
-                                               ? (((int64_t)b * p.Cin + ci) * p.H + y) * p.W + x
-                                               : (((int64_t)b * p.H + y) * p.W + x) * p.px_stride + ci;
-                        v = to_f32(src[si]);
-                    }
+                    if (y >= 0 && y < p.H && x >= 0 && x < p.W) v = to_f32(src[(((int64_t)b * p.H + y) * p.W + x) * p.px_stride + ci]);
                 }
                 e[t] = from_f32<TD>(v);
             }
