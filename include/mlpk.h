@@ -537,6 +537,10 @@ int mlpk_hire_gather_ln(int dtype, const void* x, const float* mean, const float
                         int B, int H, int W, int C, int h, int w, int step, int ld_h, int ld_w, void* stream);
 int mlpk_hire_combine_from(int dtype, void* x, const void* src, const void* y_h, const void* y_w, int B, int H, int W, int C, int h, int w,
                            int step, int ld_h, int ld_w, void* stream);
+/* round 6 (ABI 12) -- combine_from that also delivers the LayerNorm statistics (mean, 1 / sqrt(var + eps), biased variance, per pixel, fp32) of the
+ * rows it writes: what the block's second PreNormResidual needs (hire_mlp.py:181) without another pass over x.  Sums of the ROUNDED results. */
+int mlpk_hire_combine_stats(int dtype, void* x, const void* src, const void* y_h, const void* y_w, int B, int H, int W, int C, int h, int w,
+                            int step, int ld_h, int ld_w, float* out_mean, float* out_rstd, float eps, void* stream);
 
 /* ---- MS-MLP mix-shift (ms_mlp.py:48-66) -------------------------------------------
  * x, out: (B,H,W,C) channel-last.  The C channels form `groups` <= 8 chunks of ceil(C/groups) channels (torch.chunk); chunk g is

@@ -121,6 +121,7 @@ PROTOTYPES = {
     "mlpk_hire_gather_ln": (c_int, [c_int] + [c_void_p] * 7 + [c_int] * 9 + [c_void_p]),
     "mlpk_hire_combine_from": (c_int, [c_int] + [c_void_p] * 4 + [c_int] * 9 + [c_void_p]),
     "mlpk_hire_combine": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
+    "mlpk_hire_combine_stats": (c_int, [c_int] + [c_void_p] * 4 + [c_int] * 9 + [c_void_p, c_void_p, c_float, c_void_p]),
     "mlpk_mixshift_nhwc": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 5 + [ctypes.POINTER(c_int), ctypes.POINTER(c_int)] + [c_void_p] * 4 + [c_void_p]),
     "mlpk_window_gather": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     "mlpk_window_scatter_add": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
@@ -158,7 +159,7 @@ def lib():
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(handle, name)          # AttributeError if a declared symbol is not exported
             fn.restype, fn.argtypes = res, args
-        if handle.mlpk_abi_version() != 11:
+        if handle.mlpk_abi_version() != 12:
             raise MlpkError("libmlpk.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -115,6 +115,60 @@ __global__ void __launch_bounds__(256) hire_combine_kernel(const HireCombineArgs
     }
 }
 
+// The same combine with the LayerNorm statistics of the rows it writes (round 6, mlpk_hire_combine_stats): what the block's second PreNormResidual
+// needs next (hire_mlp.py:181), so that no statistics pass reads x again.  Eight lanes own one pixel (C / 8 16-byte vectors in strides of 8: 128
+// contiguous bytes per step), the pixel's index arithmetic is done once; sums and sums of squares of the ROUNDED results in fp32, reduced over the eight
+// lanes in a fixed order (deterministic, independent of the batch).
+template <typename T>
+__global__ void __launch_bounds__(256) hire_combine_stats_kernel(const HireCombineArgs p, float* __restrict__ out_mean, float* __restrict__ out_rstd, const float eps) {
+    constexpr int EPV = 16 / (int)sizeof(T);
+    T* xo = reinterpret_cast<T*>(p.x);
+    const T* xs = reinterpret_cast<const T*>(p.src);
+    const T* __restrict__ yh = reinterpret_cast<const T*>(p.y_h);
+    const T* __restrict__ yw = reinterpret_cast<const T*>(p.y_w);
+    const int cv = p.C / EPV;
+    const int64_t npix = (int64_t)p.B * p.H * p.W;
+    const int sub = threadIdx.x & 7;
+    for (int64_t px = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3); px < npix; px += (int64_t)gridDim.x * 32) {
+        int64_t r = px;
+        const int x = (int)(r % p.W); r /= p.W;
+        const int y = (int)(r % p.H);
+        const int64_t b = r / p.H;
+        int qh = (y + p.step) % p.Hp;
+        if (qh < 0) qh += p.Hp;
+        int qw = (x + p.step) % p.Wp;
+        if (qw < 0) qw += p.Wp;
+        const T* ph = yh + ((b * p.gh + qh % p.gh) * p.W + x) * p.ld_h + (qh / p.gh) * p.C;
+        const T* pw = yw + ((b * p.H + y) * p.gw + qw % p.gw) * p.ld_w + (qw / p.gw) * p.C;
+        const T* ps = xs + px * p.C;
+        T* po = xo + px * p.C;
+        float s = 0.f, ss = 0.f;
+        for (int v = sub; v < cv; v += 8) {
+            T a[EPV], u[EPV], w[EPV];
+            *reinterpret_cast<u32x4*>(a) = *reinterpret_cast<const u32x4*>(ps + v * EPV);
+            *reinterpret_cast<u32x4*>(u) = *reinterpret_cast<const u32x4*>(ph + v * EPV);
+            *reinterpret_cast<u32x4*>(w) = *reinterpret_cast<const u32x4*>(pw + v * EPV);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                a[e] = from_f32<T>(to_f32(a[e]) + (to_f32(u[e]) + to_f32(w[e])));
+                const float f = to_f32(a[e]);
+                s += f;
+                ss = __builtin_fmaf(f, f, ss);
+            }
+            *reinterpret_cast<u32x4*>(po + v * EPV) = *reinterpret_cast<const u32x4*>(a);
+        }
+        s += __shfl_xor(s, 1); ss += __shfl_xor(ss, 1);
+        s += __shfl_xor(s, 2); ss += __shfl_xor(ss, 2);
+        s += __shfl_xor(s, 4); ss += __shfl_xor(ss, 4);
+        if (sub == 0) {
+            const float mean = s / (float)p.C;
+            const float var = ss / (float)p.C - mean * mean;
+            out_mean[px] = mean;
+            out_rstd[px] = 1.0f / __builtin_sqrtf((var > 0.f ? var : 0.f) + eps);
+        }
+    }
+}
+
 static int hire_geometry(int B, int H, int W, int C, int h, int w, int dtype, int ld_h, int ld_w, int* Hp, int* Wp) {
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || h <= 0 || w <= 0) return MLPK_ESHAPE;
     if (dtype != MLPK_F32 && dtype != MLPK_F16 && dtype != MLPK_BF16) return MLPK_EDTYPE;
@@ -189,6 +243,33 @@ extern "C" int mlpk_hire_combine_from(int dtype, void* x, const void* src, const
         case MLPK_F32: hipLaunchKernelGGL(hire_combine_kernel<float>, dim3(grid), dim3(256), 0, s, a); break;
         case MLPK_F16: hipLaunchKernelGGL(hire_combine_kernel<f16_t>, dim3(grid), dim3(256), 0, s, a); break;
         default: hipLaunchKernelGGL(hire_combine_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a); break;
+    }
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mlpk_hire_combine_stats(int dtype, void* x, const void* src, const void* y_h, const void* y_w, int B, int H, int W, int C, int h, int w,
+                                       int step, int ld_h, int ld_w, float* out_mean, float* out_rstd, float eps, void* stream);
+
+extern "C" int mlpk_hire_combine_stats(int dtype, void* x, const void* src, const void* y_h, const void* y_w, int B, int H, int W, int C, int h, int w,
+                                       int step, int ld_h, int ld_w, float* out_mean, float* out_rstd, float eps, void* stream) {
+    if (!x || !src || !y_h || !y_w || !out_mean || !out_rstd) return MLPK_ENULL;
+    if ((uintptr_t)src & 15) return MLPK_EALIGN;
+    HireCombineArgs a;
+    a.src = src;
+    int rc = hire_geometry(B, H, W, C, h, w, dtype, ld_h, ld_w, &a.Hp, &a.Wp);
+    if (rc) return rc;
+    if (((uintptr_t)x | (uintptr_t)y_h | (uintptr_t)y_w) & 15) return MLPK_EALIGN;
+    if (!(eps > 0.f)) return MLPK_ESHAPE;
+    a.x = x; a.y_h = y_h; a.y_w = y_w; a.B = B; a.H = H; a.W = W; a.C = C; a.h = h; a.w = w; a.step = step;
+    a.gh = a.Hp / h; a.gw = a.Wp / w; a.ld_h = ld_h; a.ld_w = ld_w;
+    const long long npix = (long long)B * H * W;
+    const unsigned grid = (unsigned)((npix + 31) / 32 < 65536 ? (npix + 31) / 32 : 65536);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case MLPK_F32: hipLaunchKernelGGL(hire_combine_stats_kernel<float>, dim3(grid), dim3(256), 0, s, a, out_mean, out_rstd, eps); break;
+        case MLPK_F16: hipLaunchKernelGGL(hire_combine_stats_kernel<f16_t>, dim3(grid), dim3(256), 0, s, a, out_mean, out_rstd, eps); break;
+        default: hipLaunchKernelGGL(hire_combine_stats_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a, out_mean, out_rstd, eps); break;
     }
     MLPK_LAUNCH_CHECK();
     return 0;

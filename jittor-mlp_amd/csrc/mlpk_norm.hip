@@ -1071,7 +1071,7 @@ extern "C" int mlpk_convert(int src_dtype, int dst_dtype, const void* src, void*
     }
 }
 
-extern "C" int mlpk_abi_version(void) { return 11; }
+extern "C" int mlpk_abi_version(void) { return 12; }
 
 extern "C" const char* mlpk_strerror(int code) {
     switch (code) {

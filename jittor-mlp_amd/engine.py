@@ -47,6 +47,15 @@ def stream():
 
 
 _SIDE = {}
+SIDE_STREAMS = True
+
+
+def set_side_streams(on):
+    """Process-wide switch of the side streams (SideChain then issues in line).  With several forwards in flight (parallel.InFlight) the other
+    forward already fills what a small chain leaves idle, and the fork / join events only tie the streams together: Hire-MLP 9.47 -> 8.84 ms per
+    step in flight without its side chain, 9.52 -> 10.10 ms one step at a time (profiles/r06_hire_combine_stats_ab.txt).  Same bits either way."""
+    global SIDE_STREAMS
+    SIDE_STREAMS = bool(on)
 
 
 def side_stream(device):
@@ -54,7 +63,7 @@ def side_stream(device):
     (ViP's SplitAttention MLP beside the branch GEMMs); None when MLPK_NO_SIDE_STREAM=1.  Fork / join are events on both sides:
         ev = torch.cuda.Event(); ev.record(); with torch.cuda.stream(side): side.wait_event(ev); ...; done.record(side)
         ...; torch.cuda.current_stream().wait_event(done)"""
-    if os.environ.get("MLPK_NO_SIDE_STREAM", "0") == "1":
+    if not SIDE_STREAMS or os.environ.get("MLPK_NO_SIDE_STREAM", "0") == "1":
         return None
     key = (device.type, device.index)
     st = _SIDE.get(key)
@@ -739,6 +748,12 @@ def hire_gather_ln(x, mean, rstd, gamma, beta, a_h, a_w, B, H, W, C, h, w, step,
 def hire_combine_from(x, src, y_h, y_w, B, H, W, C, h, w, step, ld_h, ld_w):
     N.check(N.lib().mlpk_hire_combine_from(dtype_code(x.dtype), ptr(x), ptr(src), ptr(y_h), ptr(y_w), B, H, W, C, h, w, step, ld_h, ld_w,
                                            stream()), "mlpk_hire_combine_from")
+
+
+def hire_combine_stats(x, src, y_h, y_w, B, H, W, C, h, w, step, ld_h, ld_w, mean, rstd, eps=1e-5):
+    """hire_combine_from that also delivers (mean, rstd) of the rows it writes (round 6): the next LayerNorm needs no statistics pass"""
+    N.check(N.lib().mlpk_hire_combine_stats(dtype_code(x.dtype), ptr(x), ptr(src), ptr(y_h), ptr(y_w), B, H, W, C, h, w, step, ld_h, ld_w,
+                                            ptr(mean), ptr(rstd), eps, stream()), "mlpk_hire_combine_stats")
 
 
 def hire_combine(x, y_h, y_w, B, H, W, C, h, w, step, ld_h, ld_w):

@@ -232,6 +232,7 @@ class HireMLP(E.EngineModule):
             E.hire_combine(cur, a_h, a_w, B, H, W, C, h, w, step, h * C, w * C)
             return None
         mean, rstd = st if st is not None else layernorm_stats(ws, cur, rows, C, tag="l%d.ln" % li)
+        st2 = None                                                                        # statistics of the block's first half, when the combine delivers them
         fold = cur.dtype != torch.float32 and os.environ.get("MLPK_HIRE_LN_FOLD") != "0"
         if fold:
             # round 5: no stored LayerNorm output -- the gather normalises the vectors it moves, proj_c reads x with the LayerNorm folded in
@@ -250,14 +251,19 @@ class HireMLP(E.EngineModule):
         if fold:
             E.gemm(cur, pk[p + "cf.w"], xn, rows, C, C, bias=pk[p + "cf.b"], ln=(mean, rstd, pk[p + "cf.csum"]), R=cur, res=N.RES_ADD, tag="hire_c")
             chain.join()
-            E.hire_combine_from(cur, xn, a_h, a_w, B, H, W, C, h, w, step, h * C, w * C)      # x = (x + proj_c(LN x)) + y_h + y_w
+            if part != "pre0" and os.environ.get("MLPK_HIRE_COMBINE_STATS") != "0":
+                # round 6: the combine delivers the statistics of the rows it writes -- the MLP half's LayerNorm needs no pass over x
+                st2 = (ws.get("l%d.cm.mean" % li, (rows,), torch.float32), ws.get("l%d.cm.rstd" % li, (rows,), torch.float32))
+                E.hire_combine_stats(cur, xn, a_h, a_w, B, H, W, C, h, w, step, h * C, w * C, st2[0], st2[1], eps=blk[1].norm.eps)
+            else:
+                E.hire_combine_from(cur, xn, a_h, a_w, B, H, W, C, h, w, step, h * C, w * C)  # x = (x + proj_c(LN x)) + y_h + y_w
         else:
             E.gemm(xn, pk[p + "c.w"], cur, rows, C, C, bias=pk[p + "c.b"], R=cur, res=N.RES_ADD, tag="hire_c")   # x + proj_c(xn)
             chain.join()
             E.hire_combine(cur, a_h, a_w, B, H, W, C, h, w, step, h * C, w * C)
         if part == "pre0":
             return None
-        got = channel_mlp(ws, cur, rows, C, pk, p + "ff.", C * ef, tag="l%d.cm" % li, part=(ws, "l%d.fc2.part" % li))
+        got = channel_mlp(ws, cur, rows, C, pk, p + "ff.", C * ef, tag="l%d.cm" % li, part=(ws, "l%d.fc2.part" % li), stats=st2, eps=blk[1].norm.eps)
         st = finalize_stats(ws, got, rows, C, tag="l%d.ln" % li)
         return st
 

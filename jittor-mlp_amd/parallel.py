@@ -86,11 +86,15 @@ class InFlight:
             from . import engine as E
             self._old_plan = E.GEMM_PLAN_WHOLE
             E.set_gemm_plan(True)
+            # ... and a model's own side stream (Hire-MLP's second branch chain) only couples the in-flight streams: issue in line
+            self._old_side = E.SIDE_STREAMS
+            E.set_side_streams(False)
 
     def restore_plan(self):
         if hasattr(self, "_old_plan"):
             from . import engine as E
             E.set_gemm_plan(self._old_plan)
+            E.set_side_streams(self._old_side)
             del self._old_plan
 
     def __call__(self, x):

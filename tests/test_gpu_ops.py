@@ -1263,6 +1263,17 @@ def test_hire_gather_combine(dtype):
         torch.cuda.synchronize()
         assert torch.equal(c_h, b_h) and torch.equal(c_w, b_w), (str(dtype), ci)
         assert torch.equal(other, inplace), (str(dtype), ci)
+        # round 6 (ABI 12): the combine that also delivers the LayerNorm statistics of the rows it writes -- the same bits, statistics of exactly them
+        third = torch.full_like(src, float("nan"))
+        m3 = torch.full((B * H * W,), float("nan"), dtype=torch.float32, device=dev())
+        r3 = torch.full((B * H * W,), float("nan"), dtype=torch.float32, device=dev())
+        E.hire_combine_stats(third, src, y_h.to(dev()), y_w.to(dev()), B, H, W, C, h, w, step, h * C, w * C, m3, r3, eps=1e-5)
+        torch.cuda.synchronize()
+        assert torch.equal(third, inplace), (str(dtype), ci)
+        od = third.double().reshape(B * H * W, C).cpu()
+        assert (m3.cpu().double() - od.mean(1)).abs().max().item() < 1e-5 * max(1.0, od.abs().max().item()), (str(dtype), ci)
+        want_r = 1.0 / torch.sqrt(od.var(1, unbiased=False) + 1e-5)
+        assert ((r3.cpu().double() - want_r).abs() / want_r).max().item() < 1e-4, (str(dtype), ci)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

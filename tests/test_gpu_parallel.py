@@ -123,13 +123,21 @@ def test_two_forwards_in_flight_give_the_serial_bits():
     xs = [torch.rand(8, 3, 64, 64, device=DEV).bfloat16() for _ in range(5)]
     with torch.no_grad():
         serial = [model(x).clone() for x in xs]
-        slots = parallel.InFlight(model, 2, device=DEV)
+        slots = parallel.InFlight(lambda t: (hire if t.shape[0] == 4 else model)(t), 2, device=DEV)
         pending = [slots(x) for x in xs]                         # all five enqueued before any is waited for
         slots.synchronize()
     for (out, _), want in zip(pending, serial):
         assert torch.equal(out, want)
     assert len({id(s) for _, s in pending}) == 2
     # the in-flight regime switched the persistent GEMM to its whole-tile plan (engine.set_gemm_plan): same bits, and it can be undone
-    assert pkg.engine.GEMM_PLAN_WHOLE
-    slots.restore_plan()
-    assert not pkg.engine.GEMM_PLAN_WHOLE
+    assert pkg.engine.GEMM_PLAN_WHOLE and not pkg.engine.SIDE_STREAMS
+    # ... and a model with a side chain of its own (Hire-MLP's second branch) issues it in line while forwards are in flight: same bits
+    hire = pkg.models_pytorch.HireMLP(d_model=[32, 64], h=[4, 3], w=[4, 3], cross_region_step=[2, 1], depth=[2, 2], num_classes=10).to(DEV).eval()
+    hx = [torch.rand(4, 3, 64, 64, device=DEV).bfloat16() for _ in range(3)]
+    with torch.no_grad():
+        got = [slots(x) for x in hx]
+        slots.synchronize()
+        slots.restore_plan()
+        assert not pkg.engine.GEMM_PLAN_WHOLE and pkg.engine.SIDE_STREAMS
+        for (out, _), x in zip(got, hx):
+            assert torch.equal(out, hire(x))                     # (one call after the other, on its side stream again)

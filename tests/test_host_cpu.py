@@ -31,7 +31,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libmlpk.so does not export %s" % name
         assert name in pkg._native.PROTOTYPES, "no ctypes prototype for %s" % name
-    assert lib.mlpk_abi_version() == 11
+    assert lib.mlpk_abi_version() == 12
     assert lib.mlpk_gemm_algo_count() >= 4
     bm, bn, th, lds = (ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int())
     assert lib.mlpk_gemm_algo_info(1, bm, bn, th, lds) == 0
