@@ -552,6 +552,14 @@ int mlpk_hire_combine_stats(int dtype, void* x, const void* src, const void* y_h
 int mlpk_mixshift_nhwc(int dtype, const void* x, void* out, int B, int H, int W, int C, int groups, const int* shift,
                        const int* ksize, const float* w_lr, const float* b_lr, const float* w_td, const float* b_td,
                        void* stream);
+/* round 6 (ABI 12) -- the same with by-product statistics for the LayerNorm that follows (ms_mlp.py:72): planar (sum, sum of squares) pairs of the
+ * STORED values, one plane per 32 channels, pair (q, row) at row_part[(q * row_part_ld + row) * 2] -- what mlpk_stats_finalize_planar takes.
+ * 16-bit dtypes, C % 32 == 0, kernel sizes 1 / 3 / 5 / 7, maps up to 56 columns: mlpk_mixshift_stats_planes returns the number of planes (C / 32) for a
+ * shape the call takes, 0 otherwise (then: mlpk_mixshift_nhwc + mlpk_row_stats). */
+int mlpk_mixshift_stats_planes(int dtype, int B, int H, int W, int C, int groups, const int* ksize);
+int mlpk_mixshift_nhwc_stats(int dtype, const void* x, void* out, int B, int H, int W, int C, int groups, const int* shift,
+                             const int* ksize, const float* w_lr, const float* b_lr, const float* w_td, const float* b_td,
+                             float* row_part, long long row_part_ld, void* stream);
 
 /* ---- Swin-MLP window partition / merge (swin_mlp.py:29-60, 122-151) ---------------
  * The (B,H,W,C) map is zero-padded to Hp x Wp (pad_t rows on top, pad_l columns on the left, the rest at the bottom / right;

@@ -123,6 +123,9 @@ PROTOTYPES = {
     "mlpk_hire_combine": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     "mlpk_hire_combine_stats": (c_int, [c_int] + [c_void_p] * 4 + [c_int] * 9 + [c_void_p, c_void_p, c_float, c_void_p]),
     "mlpk_mixshift_nhwc": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 5 + [ctypes.POINTER(c_int), ctypes.POINTER(c_int)] + [c_void_p] * 4 + [c_void_p]),
+    "mlpk_mixshift_nhwc_stats": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 5 + [ctypes.POINTER(c_int), ctypes.POINTER(c_int)] + [c_void_p] * 4
+                                 + [c_void_p, c_i64, c_void_p]),
+    "mlpk_mixshift_stats_planes": (c_int, [c_int] * 6 + [ctypes.POINTER(c_int)]),
     "mlpk_window_gather": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     "mlpk_window_scatter_add": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     "mlpk_ew_cols": (c_int, [c_int, c_int, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_int, c_int, c_void_p]),

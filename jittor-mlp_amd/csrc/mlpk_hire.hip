@@ -840,7 +840,8 @@ __device__ __forceinline__ void mixtile_chunk(const MixShiftArgs& p, T* __restri
 }
 
 template <typename T>
-__global__ void __launch_bounds__(MT_NT) mixshift_tile_kernel(const MixShiftArgs p, const int R, const int pitch, const int plane, const int nbands) {
+__global__ void __launch_bounds__(MT_NT) mixshift_tile_kernel(const MixShiftArgs p, const int R, const int pitch, const int plane, const int nbands,
+                                                               float* __restrict__ row_part, const long long row_part_ld) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* tile = reinterpret_cast<T*>(smem_raw);               // [<= MT_CB channels of one chunk][R + 2P rows][pitch]
     T* otile = tile + MT_CB * plane;                        // [R][W][MT_CB]
@@ -871,14 +872,31 @@ __global__ void __launch_bounds__(MT_NT) mixshift_tile_kernel(const MixShiftArgs
     T* o = reinterpret_cast<T*>(p.out) + (((size_t)b * p.H + y0) * p.W) * p.C + cb0;
     for (int i = tid; i < total; i += MT_NT) {
         const int px = i / vpp, v = i - px * vpp;
-        *reinterpret_cast<u32x4*>(o + (size_t)px * p.C + v * 8) = *reinterpret_cast<const u32x4*>(otile + px * MT_CB + v * 8);
+        const u32x4 ov = *reinterpret_cast<const u32x4*>(otile + px * MT_CB + v * 8);
+        *reinterpret_cast<u32x4*>(o + (size_t)px * p.C + v * 8) = ov;
+        if (row_part) {
+            // by-product statistics (mlpk_mixshift_nhwc_stats): (sum, sum of squares) of the block's 32 stored channels of this pixel -- plane
+            // blockIdx.y of the planar pairs mlpk_stats_finalize_planar reads; the pixel's four lanes (vpp == 4) add in a fixed order
+            T e[8];
+            __builtin_memcpy(e, &ov, 16);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const float f = to_f32(e[q]); s1 += f; s2 = __builtin_fmaf(f, f, s2); }
+            s1 += __shfl_xor(s1, 1); s2 += __shfl_xor(s2, 1);
+            s1 += __shfl_xor(s1, 2); s2 += __shfl_xor(s2, 2);
+            if (v == 0) {
+                const long long row = ((long long)b * p.H + y0) * p.W + px;
+                *reinterpret_cast<f32x2*>(row_part + ((long long)blockIdx.y * row_part_ld + row) * 2) = f32x2{s1, s2};
+            }
+        }
     }
 }
 
 // 0 = launched, 1 = shape outside this kernel (the per-chunk band kernel / the gather kernels take it), else a HIP error
 template <typename T>
-static int mixshift_tile_launch(const MixShiftArgs& a, hipStream_t s) {
-    if (sizeof(T) != 2 || (a.C & 7) || (((uintptr_t)a.x | (uintptr_t)a.out) & 15)) return 1;
+static int mixshift_tile_launch(const MixShiftArgs& a, hipStream_t s, float* row_part = nullptr, long long row_part_ld = 0, bool query = false) {
+    if (sizeof(T) != 2 || (a.C & 7) || (!query && (((uintptr_t)a.x | (uintptr_t)a.out) & 15))) return 1;
+    if ((row_part || query) && (a.C % MT_CB)) return 1;        // the statistics planes are whole 32-channel blocks
     const int strips = (a.W + 7) / 8;
     if (strips > 7) return 1;
     int kmax = 1;
@@ -917,11 +935,12 @@ static int mixshift_tile_launch(const MixShiftArgs& a, hipStream_t s) {
     if (lds > 150 * 1024) return 1;
     const int nbands = (a.H + R - 1) / R;
     if ((long long)a.B * nbands > 0x7fffffffll) return 1;
+    if (query) return 0;
     auto kern = mixshift_tile_kernel<T>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     const dim3 grid((unsigned)(a.B * nbands), (unsigned)((a.C + MT_CB - 1) / MT_CB));
-    hipLaunchKernelGGL(kern, grid, dim3(MT_NT), lds, s, a, R, pitch, plane, nbands);
+    hipLaunchKernelGGL(kern, grid, dim3(MT_NT), lds, s, a, R, pitch, plane, nbands, row_part, row_part_ld);
     return 0;
 }
 
@@ -1399,22 +1418,65 @@ extern "C" int mlpk_swin_spatial_stats(int dtype, void* x, int B, int H, int W, 
     return 0;
 }
 
-extern "C" int mlpk_mixshift_nhwc(int dtype, const void* x, void* out, int B, int H, int W, int C, int groups, const int* shift,
-                                  const int* ksize, const float* w_lr, const float* b_lr, const float* w_td, const float* b_td,
-                                  void* stream) {
-    if (!x || !out || !shift || !ksize || !w_lr || !b_lr || !w_td || !b_td) return MLPK_ENULL;
+static int mixshift_args(mlpk::MixShiftArgs& a, int dtype, const void* x, void* out, int B, int H, int W, int C, int groups, const int* shift, const int* ksize,
+                         const float* w_lr, const float* b_lr, const float* w_td, const float* b_td) {
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || groups <= 0 || groups > 8 || groups > C) return MLPK_ESHAPE;
-    if (x == out) return MLPK_ESHAPE;
     if (dtype != MLPK_F32 && dtype != MLPK_F16 && dtype != MLPK_BF16) return MLPK_EDTYPE;
-    MixShiftArgs a;
     a.x = x; a.out = out; a.w_lr = w_lr; a.w_td = w_td; a.b_lr = b_lr; a.b_td = b_td;
     a.B = B; a.H = H; a.W = W; a.C = C; a.groups = groups;
     a.chunk0 = (C + groups - 1) / groups;                       // torch.chunk
     if ((C + a.chunk0 - 1) / a.chunk0 != groups) return MLPK_ESHAPE;     // torch.chunk would return fewer chunks
     for (int g = 0; g < 8; ++g) {
-        a.shift[g] = g < groups ? shift[g] : 0;
+        a.shift[g] = g < groups && shift ? shift[g] : 0;
         a.ksize[g] = g < groups ? ksize[g] : 1;
         if (a.ksize[g] < 1 || !(a.ksize[g] & 1) || a.ksize[g] > 15) return MLPK_ESHAPE;
+    }
+    return 0;
+}
+
+extern "C" int mlpk_mixshift_stats_planes(int dtype, int B, int H, int W, int C, int groups, const int* ksize);
+extern "C" int mlpk_mixshift_nhwc_stats(int dtype, const void* x, void* out, int B, int H, int W, int C, int groups, const int* shift,
+                                        const int* ksize, const float* w_lr, const float* b_lr, const float* w_td, const float* b_td,
+                                        float* row_part, long long row_part_ld, void* stream);
+
+// planes of by-product statistics mlpk_mixshift_nhwc_stats writes for this shape (C / 32), 0 when it does not take the shape
+extern "C" int mlpk_mixshift_stats_planes(int dtype, int B, int H, int W, int C, int groups, const int* ksize) {
+    if (!ksize || (dtype != MLPK_F16 && dtype != MLPK_BF16)) return 0;
+    mlpk::MixShiftArgs a;
+    if (mixshift_args(a, dtype, nullptr, nullptr, B, H, W, C, groups, nullptr, ksize, nullptr, nullptr, nullptr, nullptr)) return 0;
+    const int rc = dtype == MLPK_F16 ? mlpk::mixshift_tile_launch<mlpk::f16_t>(a, nullptr, nullptr, 0, true)
+                                     : mlpk::mixshift_tile_launch<mlpk::bf16_t>(a, nullptr, nullptr, 0, true);
+    return rc == 0 ? C / mlpk::MT_CB : 0;
+}
+
+extern "C" int mlpk_mixshift_nhwc_stats(int dtype, const void* x, void* out, int B, int H, int W, int C, int groups, const int* shift,
+                                        const int* ksize, const float* w_lr, const float* b_lr, const float* w_td, const float* b_td,
+                                        float* row_part, long long row_part_ld, void* stream) {
+    if (!x || !out || !shift || !ksize || !w_lr || !b_lr || !w_td || !b_td || !row_part) return MLPK_ENULL;
+    if (x == out) return MLPK_ESHAPE;
+    if (dtype != MLPK_F16 && dtype != MLPK_BF16) return MLPK_EDTYPE;
+    if (row_part_ld < (long long)B * H * W) return MLPK_ESHAPE;
+    if ((uintptr_t)row_part & 7) return MLPK_EALIGN;
+    mlpk::MixShiftArgs a;
+    int rc = mixshift_args(a, dtype, x, out, B, H, W, C, groups, shift, ksize, w_lr, b_lr, w_td, b_td);
+    if (rc) return rc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    rc = dtype == MLPK_F16 ? mlpk::mixshift_tile_launch<mlpk::f16_t>(a, s, row_part, row_part_ld) : mlpk::mixshift_tile_launch<mlpk::bf16_t>(a, s, row_part, row_part_ld);
+    if (rc == 1) return MLPK_ESHAPE;                         // ask mlpk_mixshift_stats_planes first
+    if (rc) return rc;
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mlpk_mixshift_nhwc(int dtype, const void* x, void* out, int B, int H, int W, int C, int groups, const int* shift,
+                                  const int* ksize, const float* w_lr, const float* b_lr, const float* w_td, const float* b_td,
+                                  void* stream) {
+    if (!x || !out || !shift || !ksize || !w_lr || !b_lr || !w_td || !b_td) return MLPK_ENULL;
+    if (x == out) return MLPK_ESHAPE;
+    MixShiftArgs a;
+    {
+        const int rc0 = mixshift_args(a, dtype, x, out, B, H, W, C, groups, shift, ksize, w_lr, b_lr, w_td, b_td);
+        if (rc0) return rc0;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     static const bool no_band = getenv("MLPK_MIXSHIFT_NO_BAND") != nullptr;      // tuning hook

@@ -761,11 +761,22 @@ def hire_combine(x, y_h, y_w, B, H, W, C, h, w, step, ld_h, ld_w):
                                       stream()), "mlpk_hire_combine")
 
 
-def mixshift_nhwc(x, out, B, H, W, C, shift, ksize, w_lr, b_lr, w_td, b_td):
+def mixshift_nhwc(x, out, B, H, W, C, shift, ksize, w_lr, b_lr, w_td, b_td, part=None):
+    """part = (workspace, name): also deliver the by-product statistics planes of `out` (32 channels each) when the kernel takes the shape --
+    returns (buffer (C / 32, rows, 2), C / 32) as engine.gemm(part=...) does, for finalize_stats; None otherwise (the caller runs row_stats)."""
     g = len(shift)
     arr = ctypes.c_int * g
+    if part is not None and epilogue_stats() and x.dtype != torch.float32:
+        nq = N.lib().mlpk_mixshift_stats_planes(dtype_code(x.dtype), B, H, W, C, g, arr(*ksize))
+        if nq > 0:
+            rows = B * H * W
+            buf = part[0].get("%s.%d" % (part[1], nq), (nq, rows, 2), torch.float32)
+            N.check(N.lib().mlpk_mixshift_nhwc_stats(dtype_code(x.dtype), ptr(x), ptr(out), B, H, W, C, g, arr(*shift), arr(*ksize), ptr(w_lr), ptr(b_lr),
+                                                     ptr(w_td), ptr(b_td), ptr(buf), rows, stream()), "mlpk_mixshift_nhwc_stats")
+            return buf, nq
     N.check(N.lib().mlpk_mixshift_nhwc(dtype_code(x.dtype), ptr(x), ptr(out), B, H, W, C, g, arr(*shift), arr(*ksize), ptr(w_lr), ptr(b_lr),
                                        ptr(w_td), ptr(b_td), stream()), "mlpk_mixshift_nhwc")
+    return None
 
 
 def window_gather(x, windows, B, H, W, C, ws, pad_t, pad_l, Hp, Wp):

@@ -14,7 +14,7 @@ from torch import nn
 
 from .. import _native as N
 from .. import engine as E
-from .common import Block, Holder, StochasticDepth, SubModule, channel_mlp, embed_patches, head_linear, layernorm_stats
+from .common import Block, Holder, StochasticDepth, SubModule, channel_mlp, embed_patches, finalize_stats, head_linear, layernorm_stats
 
 MS_EPS = 1e-6
 
@@ -389,12 +389,14 @@ class MS_MLP(StochasticDepth, E.EngineModule):
             mix = ws.get("l%d.mix" % li, (rows, C))
             for bi, blk in enumerate(layer.blocks):
                 p = "l%d.b%d." % (li, bi)
-                E.mixshift_nhwc(cur, mix, B, H, W, C, list(blk.shift_dist), [k for k, _ in blk.kernel_size], pk[p + "lr.w"], pk[p + "lr.b"],
-                                pk[p + "td.w"], pk[p + "td.b"])
+                # round 6: the mix-shift kernel delivers the statistics planes of what it stores -- the block's LayerNorm needs no pass over mix
+                got = E.mixshift_nhwc(cur, mix, B, H, W, C, list(blk.shift_dist), [k for k, _ in blk.kernel_size], pk[p + "lr.w"], pk[p + "lr.b"],
+                                      pk[p + "td.w"], pk[p + "td.b"], part=(ws, "l%d.mix.part" % li))
                 # mix <- cur + gamma * pwconv2(gelu(pwconv1(LN(mix))));  then the roles of the two buffers swap
                 # (train mode: ... + drop_path(gamma * .), ms_mlp.py:77 -- a per-row scale in pwconv2's epilogue)
                 channel_mlp(ws, mix, rows, C, pk, p + "ff.", hid, cscale2=pk[p + "gamma"], res_src=cur, tag="l%d.cm" % li, eps=MS_EPS,
-                            rscale=self._drop_scale(blk.drop_path_rate, B, H * W, cd, x.device))
+                            rscale=self._drop_scale(blk.drop_path_rate, B, H * W, cd, x.device),
+                            stats=finalize_stats(ws, got, rows, C, tag="l%d.cm.ln" % li, eps=MS_EPS))
                 cur, mix = mix, cur
             if layer.downsample is not None:
                 cur, H, W, C = self._down(ws, pk, li, cur, B, H, W, C)

@@ -1349,6 +1349,36 @@ def test_mixshift_tile_kernel_is_bit_equal_to_the_per_chunk_kernels(dtype):
             assert (d <= b_.abs() * 2.0 ** -10 + 1e-7).all() and (d > 0).float().mean().item() < 1e-4, (str(dtype), ci, d.max().item())
             continue
         assert torch.equal(outs[0], outs[1]), (str(dtype), ci, (outs[0].float() - outs[1].float()).abs().max().item())
+    # ABI 12: the same kernel delivering the statistics planes of what it stores (one (sum, sum of squares) pair per pixel and 32 channels)
+    class WS:
+        def get(self, name, shape, dt):
+            return torch.full(shape, float("nan"), dtype=dt, device=dev())
+    for ci, (B, H, W, C, shift, ks) in enumerate(cases):
+        kmax = max(ks)
+        x = rnd((B, H, W, C), dtype, 1500 + ci).to(dev())
+        w_lr, w_td = rnd((kmax * kmax, C), torch.float32, 1510 + ci, 0.5).to(dev()), rnd((kmax * kmax, C), torch.float32, 1520 + ci, 0.5).to(dev())
+        b_lr, b_td = rnd((C,), torch.float32, 1530 + ci).to(dev()), rnd((C,), torch.float32, 1540 + ci).to(dev())
+        plain = torch.full((B, H, W, C), float("nan"), dtype=dtype, device=dev())
+        assert E.mixshift_nhwc(x, plain, B, H, W, C, shift, ks, w_lr, b_lr, w_td, b_td) is None
+        out = torch.full((B, H, W, C), float("nan"), dtype=dtype, device=dev())
+        got = E.mixshift_nhwc(x, out, B, H, W, C, shift, ks, w_lr, b_lr, w_td, b_td, part=(WS(), "p"))
+        torch.cuda.synchronize()
+        assert (got is not None) == (C % 32 == 0), (str(dtype), ci)
+        assert torch.equal(out, plain), (str(dtype), ci)
+        if got is not None:
+            buf, nq = got
+            assert nq == C // 32 and tuple(buf.shape) == (nq, B * H * W, 2)
+            od = out.double().reshape(B * H * W, nq, 32)
+            s1, s2 = od.sum(2).t(), (od * od).sum(2).t()
+            assert (buf[..., 0].double() - s1).abs().max().item() < 1e-4 * max(1.0, s1.abs().max().item()), (str(dtype), ci)
+            assert ((buf[..., 1].double() - s2).abs() / s2.clamp_min(1.0)).max().item() < 1e-5, (str(dtype), ci)
+            mean = torch.empty((B * H * W,), dtype=torch.float32, device=dev()); rstd = torch.empty_like(mean)
+            E.stats_finalize_planar(buf, B * H * W, C, mean, rstd, eps=1e-6)
+            torch.cuda.synchronize()
+            o2 = out.double().reshape(B * H * W, C)
+            assert (mean.double() - o2.mean(1)).abs().max().item() < 1e-5 * max(1.0, o2.abs().max().item())
+            want_r = 1.0 / torch.sqrt(o2.var(1, unbiased=False) + 1e-6)
+            assert ((rstd.double() - want_r).abs() / want_r).max().item() < 1e-4
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
