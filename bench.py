@@ -243,8 +243,9 @@ def main():
     ap.add_argument("--model", default="mixer_b16", choices=sorted(MODELS))
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--dtype", default="bf16", choices=sorted(DT))
-    ap.add_argument("--streams", type=int, default=2,
-                    help="HIP streams the consecutive steps alternate over (round 6): every step is a whole forward of the whole batch; with 2, "
+    ap.add_argument("--streams", type=int, default=None,
+                    help="(default 2; 1 with --share-device, where two processes already time-slice the one GPU and their all_gather runs over gloo "
+                         "through the host: 262 ms per step with two in flight against 15.9 ms one at a time) HIP streams the consecutive steps alternate over (round 6): every step is a whole forward of the whole batch; with 2, "
                          "step i + 1 is enqueued on the other stream while step i runs, so the partly empty last rounds of one step's persistent "
                          "kernels are filled by the next step's (two batches in flight, like a server with two request slots).  1 = strictly one step after the other")
     ap.add_argument("--gemm-plan", default="auto", choices=["auto", "mixed", "whole"],
@@ -277,6 +278,8 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if args.cpu_stub:
         return cpu_stub(args, world, rank)
+    if args.streams is None:
+        args.streams = 1 if args.share_device else 2
     if args.share_device:
         local_rank = 0
         if args.backend == "nccl" and world > 1:
