@@ -56,8 +56,12 @@ constexpr int SM_NT = 512;                                 // threads per workgr
 
 // element (line, channel c, position k) of a transposed copy: 64-byte rows, the four 16-byte chunks of a row XORed with the channel's octet
 // (the writers of one instruction differ in the octet: without it they would all hit the same banks)
+// Round 6: a line (32 rows of 64 bytes) is SM_LINE = 2048 + 16 bytes long.  With 2048 the writers of the SECOND copy -- 16 pixels of one image row per wave,
+// i.e. 16 different lines at the same position inside the line -- met on 4 banks (16-way: SQ_LDS_BANK_CONFLICT 74 % of the LDS cycles of the 28 x 28 stage);
+// 4 dwords of skew per line spread them over 16 (2-byte writes reach a quarter of the banks at best).
+constexpr int SM_LINE = 32 * 64 + 16;
 __device__ __forceinline__ unsigned sm_addr(int line, int c, int k) {
-    return (unsigned)(((line * 32 + c) * 64) + ((((k >> 3) ^ (c >> 3)) & 3) << 4) + (k & 7) * 2);
+    return (unsigned)((line * SM_LINE + c * 64) + ((((k >> 3) ^ (c >> 3)) & 3) << 4) + (k & 7) * 2);
 }
 
 // DW (maps whose raw tile fits beside the two transposed copies: 14 x 14, 7 x 7): the depthwise 3 x 3 sublayer of the block runs on the same tile
@@ -74,13 +78,13 @@ __global__ void __launch_bounds__(SM_NT, 4) smlp_mix_kernel(const SmlpArgs p) {
     const int H = p.H, W = p.W, C = p.C;
     const int npx = H * W;
     char* const LA = smem;                                 // [h][c][w]
-    char* const LB = smem + H * 32 * 64;                   // [w][c][h]
-    char* const LP = smem + (H + W) * 32 * 64;             // DW: [pixel][32 channels] raw, then 12 x 32 floats: 9 taps, bias, scale, shift
+    char* const LB = smem + H * SM_LINE;                   // [w][c][h]
+    char* const LP = smem + (H + W) * SM_LINE;             // DW: [pixel][32 channels] raw, then 12 x 32 floats: 9 taps, bias, scale, shift
     float* const LW = reinterpret_cast<float*>(LP + npx * 64);
     const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
     T* __restrict__ out = reinterpret_cast<T*>(p.out);
     // zero both copies once: the positions >= W (>= H) of every row are never written again
-    for (int i = tid; i < (H + W) * 32 * 4; i += SM_NT) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
+    for (int i = tid; i < (H + W) * (SM_LINE / 16); i += SM_NT) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
     // weight fragments: B'[k][n] = Ww[w' = nb * 16 + n][w = k], lane n = lane & 15, k = 8 (lane >> 4) ..
     const int fn = lane & 15, fq = lane >> 4;
     u32x4 fw[2], fh[2];
@@ -116,7 +120,7 @@ __global__ void __launch_bounds__(SM_NT, 4) smlp_mix_kernel(const SmlpArgs p) {
         xoff[i] = (unsigned)(px * p.ldx + o * 8) * (unsigned)sizeof(T);
         ooff[i] = (unsigned)(px * p.ldo + o * 8) * (unsigned)sizeof(T);
         la[i] = sm_addr(hh, o * 8, ww_);
-        lb[i] = (unsigned)(H * 32 * 64) + sm_addr(ww_, o * 8, hh);
+        lb[i] = (unsigned)(H * SM_LINE) + sm_addr(ww_, o * 8, hh);
     }
     u32x4 raw[SM_NL];
     auto request = [&](const int u) {
@@ -256,10 +260,10 @@ __global__ void __launch_bounds__(SM_NT, 4) smlp_mix_kernel(const SmlpArgs p) {
 using namespace mlpk;
 
 extern "C" int mlpk_smlp_mix_supported(int dtype, int H, int W, int C) {
-    return (dtype == MLPK_F16 || dtype == MLPK_BF16) && H >= 1 && W >= 1 && H <= 32 && W <= 32 && C >= 32 && C % 32 == 0 && (H + W) * 2048 <= 160 * 1024;
+    return (dtype == MLPK_F16 || dtype == MLPK_BF16) && H >= 1 && W >= 1 && H <= 32 && W <= 32 && C >= 32 && C % 32 == 0 && (H + W) * mlpk::SM_LINE <= 160 * 1024;
 }
 
-static int smlp_dw_lds(int H, int W) { return (H + W) * 32 * 64 + H * W * 64 + 12 * 32 * 4; }
+static int smlp_dw_lds(int H, int W) { return (H + W) * mlpk::SM_LINE + H * W * 64 + 12 * 32 * 4; }
 constexpr int SM_NL_SMALL = 2;
 
 // the variant with the block's depthwise 3 x 3 sublayer in front (mlpk_smlp_mix_dw): the raw tile must fit beside the transposed copies,
@@ -302,7 +306,7 @@ extern "C" int mlpk_smlp_mix_dw(int dtype, const void* x, int ldx, int B, int H,
 
 static int smlp_launch(int dtype, SmlpArgs& a, bool dw, hipStream_t s) {
     const int H = a.H, W = a.W, C = a.C, B = a.B;
-    const int lds = dw ? smlp_dw_lds(H, W) : (H + W) * 32 * 64;
+    const int lds = dw ? smlp_dw_lds(H, W) : (H + W) * mlpk::SM_LINE;
     const int units = B * (C / 32);
     int dev = 0, cu = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu < 1) cu = 256;
