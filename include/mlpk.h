@@ -165,6 +165,11 @@ typedef struct mlpk_gemm_desc {
 } mlpk_gemm_desc;
 
 int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream);
+/* round 6 (ABI 12): two INDEPENDENT products in one launch where the dispatch gives both the same 16-bit "s3" tile family (algo 11..13) -- workgroups
+ * [0, tiles of d0) compute d0, the rest d1; every tile exactly as mlpk_gemm_nt computes it (same bits).  Otherwise the two calls one after the other.
+ * For the short, latency-bound products of sibling branches (Hire-MLP's proj_h / proj_w pairs, hire_mlp.py:139-143): half the launches, no side stream.
+ * The two outputs must not overlap each other or the other call's operands. */
+int mlpk_gemm_nt_pair(const mlpk_gemm_desc* d0, const mlpk_gemm_desc* d1, void* stream);
 /* planes (pairs per row) that mlpk_gemm_nt would write for this descriptor (row_part may still be NULL); an error code when the
    descriptor cannot deliver statistics (fp32, token-transposed output, unaligned rows, an explicit algo with 64-column tiles) */
 int mlpk_gemm_row_parts(const mlpk_gemm_desc* d, int* nparts);

@@ -707,7 +707,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_nt_kernel(const GemmArgs p) 
 // 8-wave / 1-workgroup-per-CU kernel above cannot hide (measured: 46 % MFMA busy in its main loop).
 // 64-byte rows: chunk c of row r is stored at chunk c ^ ((r & 8) >> 2), conflict-free for ds_read_b128.
 template <typename T, int BM, int BN, int WM, int WN, bool TRANS>
-__global__ void __launch_bounds__(WM* WN * 64, 2) gemm_nt_s3_kernel(const GemmArgs p) {
+__device__ __forceinline__ void gemm_nt_s3_body(const GemmArgs& p, const int bid, const int nblocks) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 16, FN = TN / 16;
@@ -725,7 +725,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) gemm_nt_s3_kernel(const GemmAr
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int wg = xcd_remap(bid, nblocks);
     const int m0 = (wg / tiles_n) * BM;
     const int n0 = (wg % tiles_n) * BN;
     const T* __restrict__ A = reinterpret_cast<const T*>(p.A);
@@ -782,7 +782,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) gemm_nt_s3_kernel(const GemmAr
     // Both start together and would run main loop / epilogue in lockstep, leaving the matrix pipe idle
     // during both epilogues.  The second arriver on a CU (per-CU ticket, first launch round only) sleeps
     // for about one epilogue, so that from then on one workgroup's VALU/store phase overlaps the other's MFMAs.
-    if ((p.dbg & 16) && blockIdx.x < 512) {
+    if ((p.dbg & 16) && bid < 512) {
         if (tid == 0) {
             const unsigned hw = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);     // HW_REG_HW_ID[15:0]
             const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);    // HW_REG_XCC_ID[3:0]
@@ -837,6 +837,20 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) gemm_nt_s3_kernel(const GemmAr
     MLPK_STAMP(61);
     if (p.dbg & 8) return;
     gemm_epilogue<T, BM, BN, WM, WN, TRANS>(p, acc, smem, m0, n0, threadIdx.x);
+}
+
+template <typename T, int BM, int BN, int WM, int WN, bool TRANS>
+__global__ void __launch_bounds__(WM* WN * 64, 2) gemm_nt_s3_kernel(const GemmArgs p) {
+    gemm_nt_s3_body<T, BM, BN, WM, WN, TRANS>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Two independent products of the same tile family in ONE launch (round 6, mlpk_gemm_nt_pair): workgroups [0, tiles0) compute p0's tiles,
+// the rest p1's -- Hire-MLP's h- and w-branch Linears (hire_mlp.py:139-143: 20-30 us each, launch- and latency-bound) as two launches per
+// block instead of four and without a side stream.  Every tile is computed exactly as by the single launch: the same bits.
+template <typename T, int BM, int BN, int WM, int WN, bool TRANS>
+__global__ void __launch_bounds__(WM* WN * 64, 2) gemm_nt_s3_pair_kernel(const GemmArgs p0, const GemmArgs p1, const int tiles0) {
+    if ((int)blockIdx.x < tiles0) gemm_nt_s3_body<T, BM, BN, WM, WN, TRANS>(p0, (int)blockIdx.x, tiles0);
+    else gemm_nt_s3_body<T, BM, BN, WM, WN, TRANS>(p1, (int)blockIdx.x - tiles0, (int)gridDim.x - tiles0);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1673,6 +1687,18 @@ static int launch_s3(const GemmArgs& a, bool trans, hipStream_t stream) {
     return 0;
 }
 
+template <typename T, int BM, int BN, int WM, int WN>
+static int launch_s3_pair(const GemmArgs& a0, const GemmArgs& a1, hipStream_t stream) {
+    const int lds = 3 * (BM + BN) * 64;
+    const int tiles0 = ((a0.M + BM - 1) / BM) * ((a0.N + BN - 1) / BN), tiles1 = ((a1.M + BM - 1) / BM) * ((a1.N + BN - 1) / BN);
+    auto k = gemm_nt_s3_pair_kernel<T, BM, BN, WM, WN, false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k, dim3(tiles0 + tiles1), dim3(WM * WN * 64), lds, stream, a0, a1, tiles0);
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
 // one persistent workgroup per compute unit (a multiple of 8: whole XCDs)
 static int p8_grid_cap() {
     static int cap = 0;
@@ -2167,6 +2193,35 @@ extern "C" int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream) {
         case MLPK_F16: return launch_algo<f16_t>(algo, a, trans, s, d->workspace, d->workspace_bytes);
         default: return launch_algo<bf16_t>(algo, a, trans, s, d->workspace, d->workspace_bytes);
     }
+}
+
+extern "C" int mlpk_gemm_nt_pair(const mlpk_gemm_desc* d0, const mlpk_gemm_desc* d1, void* stream);
+
+// two products in one launch where the dispatch gives both the same "s3" tile (row-major outputs, 16-bit); anything else: one after the other
+extern "C" int mlpk_gemm_nt_pair(const mlpk_gemm_desc* d0, const mlpk_gemm_desc* d1, void* stream) {
+    GemmArgs a0, a1;
+    int algo0 = 0, algo1 = 0;
+    bool t0 = false, t1 = false;
+    int rc = gemm_prepare(d0, a0, algo0, t0);
+    if (rc) return rc;
+    rc = gemm_prepare(d1, a1, algo1, t1);
+    if (rc) return rc;
+    static const bool off = getenv("MLPK_GEMM_PAIR") && atoi(getenv("MLPK_GEMM_PAIR")) == 0;      // A/B aid: two launches
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (!off && algo0 == algo1 && algo0 >= 11 && algo0 <= 13 && !t0 && !t1 && d0->dtype == d1->dtype && d0->dtype != MLPK_F32 &&
+        !(a0.dbg | a1.dbg)) {
+#define MLPK_PAIR(TT)                                                                  \
+    switch (algo0) {                                                                   \
+        case 11: return launch_s3_pair<TT, 256, 128, 2, 2>(a0, a1, s);                 \
+        case 12: return launch_s3_pair<TT, 128, 128, 2, 2>(a0, a1, s);                 \
+        default: return launch_s3_pair<TT, 128, 256, 2, 2>(a0, a1, s);                 \
+    }
+        if (d0->dtype == MLPK_F16) { MLPK_PAIR(f16_t) } else { MLPK_PAIR(bf16_t) }
+#undef MLPK_PAIR
+    }
+    rc = mlpk_gemm_nt(d0, stream);
+    if (rc) return rc;
+    return mlpk_gemm_nt(d1, stream);
 }
 
 extern "C" int mlpk_gemm_set_plan(int mode) {

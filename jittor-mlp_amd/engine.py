@@ -190,7 +190,7 @@ GEMM_PLAN_WHOLE = False
 
 def gemm(A, B, C, M, Nn, K, *, lda=None, ldb=None, ldc=None, bias=None, act=N.ACT_NONE, cscale=None, cshift=None,
          rscale=None, rperiod=0, R=None, ldr=None, res=N.RES_NONE, out_mode=N.OUT_ROWMAJOR, t_rows=0, t_tokens=0,
-         algo=0, tag=None, dbg=0, ln=None, ln_group=1, part=None, prof=None):
+         algo=0, tag=None, dbg=0, ln=None, ln_group=1, part=None, prof=None, _defer=False):
     """C = epilogue(A . B^T).  `part` = (workspace, name): the epilogue also delivers the row statistics of what it stores
     (mlpk.h: row_part) into a float32 buffer (nparts, M, 2) taken from the workspace; returns (buffer, nparts) for
     stats_finalize_planar, or None when the descriptor cannot deliver them (fp32, unaligned rows) and the caller runs row_stats."""
@@ -199,7 +199,7 @@ def gemm(A, B, C, M, Nn, K, *, lda=None, ldb=None, ldc=None, bias=None, act=N.AC
     if GEMM_LOG is not None:                             # tuning: the distinct GEMM calls of a forward (tools/gemm_shapes.py)
         GEMM_LOG.add((str(A.dtype), M, Nn, K, int(act), int(res), ln is not None, part is not None, cscale is not None or cshift is not None,
                       rscale is not None, int(out_mode), bias is not None))
-    timed = TIMER is not None and tag is not None
+    timed = TIMER is not None and tag is not None and not _defer
     if timed:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
@@ -228,6 +228,8 @@ def gemm(A, B, C, M, Nn, K, *, lda=None, ldb=None, ldc=None, bias=None, act=N.AC
             buf = part[0].get("%s.%d" % (part[1], n.value), (n.value, M, 2), torch.float32)     # (one buffer per plane count: no re-allocation)
             d.row_part, d.row_part_ld = ptr(buf), M
             out = (buf, n.value)
+    if _defer:                                           # gemm_pair: the filled descriptor (it keeps the tensors alive through the caller's references)
+        return d, out
     N.check(N.lib().mlpk_gemm_nt(ctypes.byref(d), stream()), "mlpk_gemm_nt")
     if timed:
         ev1.record()
@@ -237,6 +239,18 @@ def gemm(A, B, C, M, Nn, K, *, lda=None, ldb=None, ldc=None, bias=None, act=N.AC
             if N.lib().mlpk_gemm_kernel_name(ctypes.byref(d), nm, 96) == 0:
                 TIMER.kernels[tag].add(nm.value.decode())
     return out
+
+
+def gemm_pair(first, second):
+    """Two independent products in ONE launch where the dispatch gives both the same 16-bit "s3" tile (mlpk_gemm_nt_pair; otherwise one after the
+    other): `first` / `second` = (args, kwargs) of engine.gemm.  Returns the two calls' `part` results.  Same bits as two calls."""
+    (a0, k0), (a1, k1) = first, second
+    if TIMER is not None:                                # per-call timing wants separate launches
+        return gemm(*a0, **k0), gemm(*a1, **k1)
+    d0, o0 = gemm(*a0, _defer=True, **k0)
+    d1, o1 = gemm(*a1, _defer=True, **k1)
+    N.check(N.lib().mlpk_gemm_nt_pair(ctypes.byref(d0), ctypes.byref(d1), stream()), "mlpk_gemm_nt_pair")
+    return o0, o1
 
 
 GEMM_LOG = None

@@ -13,6 +13,7 @@ HireMLPBlock (hire_mlp.py:96-152) on the channel-last LayerNorm output xn (B*H*W
 The patcher (7x7 stride-4 pad-3 conv, :203) and the stage transitions (3x3 stride-2 pad-1 conv, :161) are window gathers
 (mlpk_im2col) + GEMM; the channel MLP folds its LayerNorm into fc1; the head folds its LayerNorm into the token mean.
 """
+import contextlib
 import os
 
 import torch
@@ -242,15 +243,29 @@ class HireMLP(E.EngineModule):
             E.hire_gather(xn, a_h, a_w, B, H, W, C, h, w, step, h * C, w * C)
         # the w-branch pair of GEMMs touches only a_w / t_w: it runs on a side stream beside the h-branch pair and proj_c
         # (short GEMMs of 20-50 us each: two kernels in flight fill the tail of each other's last wave of tiles)
-        chain = E.SideChain(ws, "hire.w", cur.device)
-        with chain:
-            E.gemm(a_w, pk[p + "w1.w"], t_w, rows_w, hid, w * C, bias=pk[p + "w1.b"], act=N.ACT_GELU, tag="hire_fc1")
-            E.gemm(t_w, pk[p + "w2.w"], a_w, rows_w, w * C, hidp, bias=pk[p + "w2.b"], tag="hire_fc2")
-        E.gemm(a_h, pk[p + "h1.w"], t_h, rows_h, hid, h * C, bias=pk[p + "h1.b"], act=N.ACT_GELU, tag="hire_fc1")
-        E.gemm(t_h, pk[p + "h2.w"], a_h, rows_h, h * C, hidp, bias=pk[p + "h2.b"], tag="hire_fc2")    # y_h overwrites a_h
+        # one step at a time the w-branch pair runs on a side stream beside the h-branch pair and proj_c; with forwards in flight (no side streams:
+        # engine.set_side_streams) the branches' Linears go pairwise into one launch each.  Same box: 9.31 -> 9.14 ms per step in flight with the pairs,
+        # 10.08 -> 10.20 ms one at a time (there the side chain also overlaps proj_c) -- profiles/r06_hire_combine_stats_ab.txt.  MLPK_HIRE_PAIR=0/1 forces.
+        pe = os.environ.get("MLPK_HIRE_PAIR")
+        paired = (pe != "0") if pe is not None else E.side_stream(cur.device) is None
+        chain = E.SideChain(ws, "hire.w", cur.device) if not paired else contextlib.nullcontext()
+        if paired:
+            # round 6: the two branches' Linears pairwise in ONE launch each (mlpk_gemm_nt_pair: the same tiles, the same bits) -- 20-30 us products,
+            # launch- and latency-bound: two launches per block instead of four, and no side stream with its fork / join events
+            E.gemm_pair(((a_w, pk[p + "w1.w"], t_w, rows_w, hid, w * C), dict(bias=pk[p + "w1.b"], act=N.ACT_GELU, tag="hire_fc1")),
+                        ((a_h, pk[p + "h1.w"], t_h, rows_h, hid, h * C), dict(bias=pk[p + "h1.b"], act=N.ACT_GELU, tag="hire_fc1")))
+            E.gemm_pair(((t_w, pk[p + "w2.w"], a_w, rows_w, w * C, hidp), dict(bias=pk[p + "w2.b"], tag="hire_fc2")),
+                        ((t_h, pk[p + "h2.w"], a_h, rows_h, h * C, hidp), dict(bias=pk[p + "h2.b"], tag="hire_fc2")))     # y_w / y_h overwrite a_w / a_h
+        else:
+            with chain:
+                E.gemm(a_w, pk[p + "w1.w"], t_w, rows_w, hid, w * C, bias=pk[p + "w1.b"], act=N.ACT_GELU, tag="hire_fc1")
+                E.gemm(t_w, pk[p + "w2.w"], a_w, rows_w, w * C, hidp, bias=pk[p + "w2.b"], tag="hire_fc2")
+            E.gemm(a_h, pk[p + "h1.w"], t_h, rows_h, hid, h * C, bias=pk[p + "h1.b"], act=N.ACT_GELU, tag="hire_fc1")
+            E.gemm(t_h, pk[p + "h2.w"], a_h, rows_h, h * C, hidp, bias=pk[p + "h2.b"], tag="hire_fc2")    # y_h overwrites a_h
         if fold:
             E.gemm(cur, pk[p + "cf.w"], xn, rows, C, C, bias=pk[p + "cf.b"], ln=(mean, rstd, pk[p + "cf.csum"]), R=cur, res=N.RES_ADD, tag="hire_c")
-            chain.join()
+            if not paired:
+                chain.join()
             if part != "pre0" and os.environ.get("MLPK_HIRE_COMBINE_STATS") != "0":
                 # round 6: the combine delivers the statistics of the rows it writes -- the MLP half's LayerNorm needs no pass over x
                 st2 = (ws.get("l%d.cm.mean" % li, (rows,), torch.float32), ws.get("l%d.cm.rstd" % li, (rows,), torch.float32))
@@ -259,7 +274,8 @@ class HireMLP(E.EngineModule):
                 E.hire_combine_from(cur, xn, a_h, a_w, B, H, W, C, h, w, step, h * C, w * C)  # x = (x + proj_c(LN x)) + y_h + y_w
         else:
             E.gemm(xn, pk[p + "c.w"], cur, rows, C, C, bias=pk[p + "c.b"], R=cur, res=N.RES_ADD, tag="hire_c")   # x + proj_c(xn)
-            chain.join()
+            if not paired:
+                chain.join()
             E.hire_combine(cur, a_h, a_w, B, H, W, C, h, w, step, h * C, w * C)
         if part == "pre0":
             return None

@@ -1311,6 +1311,35 @@ def test_mixshift_nhwc(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_gemm_pair_gives_the_bits_of_two_calls(dtype):
+    """mlpk_gemm_nt_pair (ABI 12): two independent products in one launch where the dispatch gives both the same "s3" tile -- Hire-MLP's proj_h / proj_w
+    pairs (hire_mlp.py:139-143) at their stage-3 and stage-1 sizes, with GELU and without -- and the fall-back (different tile families, fp32): in every case
+    exactly the bits of two mlpk_gemm_nt calls."""
+    pkg = load_pkg()
+    E, N = pkg.engine, pkg._native
+    cases = [((17920, 160, 960), (17920, 160, 960), N.ACT_GELU), ((17920, 960, 160), (12544, 960, 160), N.ACT_NONE), ((3000, 32, 256), (2816, 32, 256), N.ACT_GELU),
+             ((1024, 256, 512), (50176, 3072, 768), N.ACT_NONE), ((300, 96, 64), (333, 72, 40), N.ACT_NONE)]
+    for ci, (s0, s1, act) in enumerate(cases):
+        ops = []
+        for si, (M, Nn, K) in enumerate((s0, s1)):
+            A = rnd((M, K), dtype, 1600 + 10 * ci + si).to(dev())
+            B = (rnd((Nn, K), dtype, 1605 + 10 * ci + si) / math.sqrt(K)).to(dtype).to(dev())
+            bias = rnd((Nn,), torch.float32, 1608 + 10 * ci + si).to(dev())
+            ops.append((A, B, bias, M, Nn, K))
+        want, got = [], []
+        for A, B, bias, M, Nn, K in ops:
+            C = torch.full((M, Nn), float("nan"), dtype=dtype, device=dev())
+            E.gemm(A, B, C, M, Nn, K, bias=bias, act=act)
+            want.append(C)
+            got.append(torch.full((M, Nn), float("nan"), dtype=dtype, device=dev()))
+        E.gemm_pair(((ops[0][0], ops[0][1], got[0]) + ops[0][3:], dict(bias=ops[0][2], act=act)),
+                    ((ops[1][0], ops[1][1], got[1]) + ops[1][3:], dict(bias=ops[1][2], act=act)))
+        torch.cuda.synchronize()
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), (str(dtype), ci)
+        assert not torch.isnan(got[0].float()).any() and not torch.isnan(got[1].float()).any()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_mixshift_tile_kernel_is_bit_equal_to_the_per_chunk_kernels(dtype):
     """mixshift_tile_kernel (round 6): the whole mix-shift of ms_mlp.py:52-67 as one launch over aligned 32-channel blocks -- the same fused
     multiply-adds in the same order as the per-chunk band / k = 1 kernels it replaces (MLPK_MIXSHIFT_TILE=0), so BIT-EQUAL to them, which
