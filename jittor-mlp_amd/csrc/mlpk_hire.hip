@@ -892,16 +892,18 @@ __global__ void __launch_bounds__(MT_NT) mixshift_tile_kernel(const MixShiftArgs
     }
 }
 
-// 0 = launched, 1 = shape outside this kernel (the per-chunk band kernel / the gather kernels take it), else a HIP error
+// 0 = launched, MT_NOT_TAKEN = shape outside this kernel (the per-chunk band kernel / the gather kernels take it; distinct from every hipError_t >= 0
+// and MLPK_E* value), else a HIP error
+constexpr int MT_NOT_TAKEN = -1000;
 template <typename T>
 static int mixshift_tile_launch(const MixShiftArgs& a, hipStream_t s, float* row_part = nullptr, long long row_part_ld = 0, bool query = false) {
-    if (sizeof(T) != 2 || (a.C & 7) || (!query && (((uintptr_t)a.x | (uintptr_t)a.out) & 15))) return 1;
-    if ((row_part || query) && (a.C % MT_CB)) return 1;        // the statistics planes are whole 32-channel blocks
+    if (sizeof(T) != 2 || (a.C & 7) || (!query && (((uintptr_t)a.x | (uintptr_t)a.out) & 15))) return MT_NOT_TAKEN;
+    if ((row_part || query) && (a.C % MT_CB)) return MT_NOT_TAKEN;        // the statistics planes are whole 32-channel blocks
     const int strips = (a.W + 7) / 8;
-    if (strips > 7) return 1;
+    if (strips > 7) return MT_NOT_TAKEN;
     int kmax = 1;
     for (int g = 0; g < a.groups; ++g) {
-        if (a.ksize[g] != 1 && a.ksize[g] != 3 && a.ksize[g] != 5 && a.ksize[g] != 7) return 1;
+        if (a.ksize[g] != 1 && a.ksize[g] != 3 && a.ksize[g] != 5 && a.ksize[g] != 7) return MT_NOT_TAKEN;
         kmax = a.ksize[g] > kmax ? a.ksize[g] : kmax;
     }
     const int P = kmax / 2;
@@ -932,9 +934,9 @@ static int mixshift_tile_launch(const MixShiftArgs& a, hipStream_t s, float* row
         }
     }
     const size_t lds = geometry(R, &plane);
-    if (lds > 150 * 1024) return 1;
+    if (lds > 150 * 1024) return MT_NOT_TAKEN;
     const int nbands = (a.H + R - 1) / R;
-    if ((long long)a.B * nbands > 0x7fffffffll) return 1;
+    if ((long long)a.B * nbands > 0x7fffffffll) return MT_NOT_TAKEN;
     if (query) return 0;
     auto kern = mixshift_tile_kernel<T>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1462,7 +1464,7 @@ extern "C" int mlpk_mixshift_nhwc_stats(int dtype, const void* x, void* out, int
     if (rc) return rc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     rc = dtype == MLPK_F16 ? mlpk::mixshift_tile_launch<mlpk::f16_t>(a, s, row_part, row_part_ld) : mlpk::mixshift_tile_launch<mlpk::bf16_t>(a, s, row_part, row_part_ld);
-    if (rc == 1) return MLPK_ESHAPE;                         // ask mlpk_mixshift_stats_planes first
+    if (rc == mlpk::MT_NOT_TAKEN) return MLPK_ESHAPE;        // ask mlpk_mixshift_stats_planes first
     if (rc) return rc;
     MLPK_LAUNCH_CHECK();
     return 0;
@@ -1483,7 +1485,7 @@ extern "C" int mlpk_mixshift_nhwc(int dtype, const void* x, void* out, int B, in
     const char* tile_env = getenv("MLPK_MIXSHIFT_TILE");                         // "0": the per-chunk band kernel (A/B runs, the bit-equality test)
     if (!no_band && !(tile_env && tile_env[0] == '0') && dtype != MLPK_F32) {
         const int rc = dtype == MLPK_F16 ? mlpk::mixshift_tile_launch<mlpk::f16_t>(a, s) : mlpk::mixshift_tile_launch<mlpk::bf16_t>(a, s);
-        if (rc != 1) {
+        if (rc != mlpk::MT_NOT_TAKEN) {
             if (rc) return rc;
             MLPK_LAUNCH_CHECK();
             return 0;
