@@ -282,6 +282,16 @@ int mlpk_patchify(int src_dtype, int dst_dtype, int src_layout, const void* src,
                   int B, int Cin, int H, int W, int ph, int pw, int pad, int src_px_stride,
                   int ldo, int order, void* stream);
 
+/* round 6 (ABI 12) -- the 4 x 4 patch embedding of the hierarchical families in one kernel: out[(b, py, px), :] = [LayerNorm](W patch + bias), patch = the
+ * 3 x 4 x 4 window of the NCHW image in Conv2d's (channel, row, column) order (swin_mlp.py:324-333, ms_mlp.py:255-262, as_mlp.py:319,330, sparse_mlp.py).
+ * x: (B, 3, H, W), src_dtype = dst_dtype or fp32 (converted on load, as mlpk_patchify does); w: (C, ldw >= 48) 16-bit; C = 32 / 64 / 96 / 128; gamma = beta =
+ * NULL: no LayerNorm.  With it: the product is rounded to the storage type, two-pass statistics of the rounded values, (v - mean) rstd gamma + beta, one
+ * more rounding -- the arithmetic of mlpk_gemm_nt + mlpk_row_stats + mlpk_norm_apply, which it replaces (not their bits: the product's summation order
+ * is the 32 x 32 x 16 MFMA's).  mlpk_patch_embed4_supported says whether the call takes a shape. */
+int mlpk_patch_embed4_supported(int src_dtype, int dst_dtype, int Cin, int H, int W, int C);
+int mlpk_patch_embed4(int src_dtype, int dst_dtype, const void* x, int B, int Cin, int H, int W, const void* w, int ldw, const float* bias,
+                      const float* gamma, const float* beta, float eps, void* out, int ldo, int C, void* stream);
+
 /* ---- row statistics ---------------------------------------------------------------------
  * For each of `rows` rows of `len` contiguous elements (row r starts at x + r*ldx):
  * mean[r], rstd[r] = 1/sqrt(biased_var + eps).  Two-pass (mean, then centred squares), fp32.

@@ -129,6 +129,155 @@ template <typename TS> static int patchify_from(int dst, const PatchArgs& a, uns
     return 0;
 }
 
+// ---- round 6: the 4 x 4 patch embedding of the hierarchical families in ONE kernel (mlpk_patch_embed4) --------------------------------------
+// swin_mlp.py:324-333 / ms_mlp.py:255-262 / as_mlp.py:319,330 / sparse_mlp.py: Conv2d(3 -> C, k = stride = 4) on the NCHW image, flatten, transpose,
+// (LayerNorm).  As separate launches this was the patch gather (77 MB in, 77 MB out), the GEMM (K = 48: 88 us for 0.07 GFLOP per image), a statistics
+// pass and the normalise pass: 275 us per forward and five trips over the tokens.  Here a wave owns 32 consecutive patches and multiplies them where
+// they are loaded: with the weight as the FIRST operand of v_mfma_f32_32x32x16 (M = 32 channels) a lane is ONE patch n = lane & 31 and the k-half
+// kh = lane >> 5, and its second-operand fragment of k-step ks -- k = 16 ks + 8 kh .. + 7 in the Conv2d's (channel, row, column) order -- is rows 2 kh,
+// 2 kh + 1 of input channel ks of its own patch: two 8-byte loads straight from the image (32 lanes = 256 contiguous bytes), no gather buffer, no LDS.
+// The weight fragments (C / 32 x 3 x 16 bytes per lane) stay in registers.  A lane ends up with 16 channels per block of ONE token, so the LayerNorm
+// is the token's own registers and one exchange with the other k-half: bias, rounding to the storage type (what the GEMM stored), two-pass
+// statistics of the rounded values (what mlpk_row_stats computed), (v - mean) rstd gamma + beta, one more rounding.  The tokens leave through a
+// per-wave LDS image as whole rows: 32 tokens x C x 2 contiguous bytes.
+template <typename T> struct PeMma;
+template <> struct PeMma<bf16_t> {
+    typedef __attribute__((ext_vector_type(16))) float f32x16;
+    static __device__ __forceinline__ f32x16 run(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct PeMma<f16_t> {
+    typedef __attribute__((ext_vector_type(16))) float f32x16;
+    static __device__ __forceinline__ f32x16 run(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+
+struct PatchEmbedArgs {
+    const void* x;          // (B, 3, H, W) NCHW
+    const void* w;          // (C, ldw) 16-bit, k = ci * 16 + i * 4 + j
+    const float* bias;      // (C) or NULL
+    const float* gamma;     // (C) LayerNorm affine, or NULL: no LayerNorm
+    const float* beta;
+    void* out;              // (B * Hp * Wp, ldo)
+    int B, H, W, Hp, Wp, ldw, ldo;
+    float eps;
+    long long npatch;
+};
+
+template <typename TS, typename T, int NMB>
+__global__ void __launch_bounds__(256) patch_embed4_kernel(const PatchEmbedArgs p) {
+    typedef typename PeMma<T>::f32x16 f32x16;
+    constexpr int C = NMB * 32;
+    constexpr int ROWB = C * 2 + 16;                          // LDS row of a token (+ 16 bytes: the 8-byte writers of a phase on different banks)
+    extern __shared__ __attribute__((aligned(16))) char pe_smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 31, kh = lane >> 5;
+    char* const img = pe_smem + wave * (32 * ROWB);
+    const T* __restrict__ wgt = reinterpret_cast<const T*>(p.w);
+    const TS* __restrict__ x = reinterpret_cast<const TS*>(p.x);
+    u32x4 wf[NMB][3];
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) wf[mb][ks] = *reinterpret_cast<const u32x4*>(wgt + (size_t)(mb * 32 + n) * p.ldw + 16 * ks + 8 * kh);
+    const long long first = ((long long)blockIdx.x * 4 + wave) * 32;
+    if (first >= p.npatch) return;                            // (wave-uniform; no workgroup barrier below)
+    long long pi = first + n;
+    const bool live = pi < p.npatch;
+    pi = live ? pi : p.npatch - 1;
+    const int px = (int)(pi % p.Wp);
+    const long long t = pi / p.Wp;
+    const int py = (int)(t % p.Hp);
+    const long long b = t / p.Hp;
+    // ---- the token's 48 values: channel ks, rows 2 kh and 2 kh + 1 of the patch, 4 pixels each
+    u32x4 bf[3];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+        const TS* r0 = x + ((b * 3 + ks) * p.H + 4 * py + 2 * kh) * p.W + 4 * px;
+        T e[8];
+        if constexpr (sizeof(TS) == 4) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(r0), a1 = *reinterpret_cast<const f32x4*>(r0 + p.W);
+            e[0] = from_f32<T>(a0.x); e[1] = from_f32<T>(a0.y); e[2] = from_f32<T>(a0.z); e[3] = from_f32<T>(a0.w);
+            e[4] = from_f32<T>(a1.x); e[5] = from_f32<T>(a1.y); e[6] = from_f32<T>(a1.z); e[7] = from_f32<T>(a1.w);
+        } else {
+            TS s8[8];
+            *reinterpret_cast<u32x2*>(s8) = *reinterpret_cast<const u32x2*>(r0);
+            *reinterpret_cast<u32x2*>(s8 + 4) = *reinterpret_cast<const u32x2*>(r0 + p.W);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) e[q] = from_f32<T>(to_f32(s8[q]));
+        }
+        __builtin_memcpy(&bf[ks], e, 16);
+    }
+    f32x16 acc[NMB];
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) acc[mb] = PeMma<T>::run(wf[mb][ks], bf[ks], acc[mb]);
+    }
+    // lane (token n, kh): acc[mb][r] = channel 32 mb + 8 (r >> 2) + 4 kh + (r & 3)
+    float v[NMB][16];
+    float s = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c0 = 32 * mb + 8 * q + 4 * kh;
+            const f32x4 bz = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const float b4[4] = {bz.x, bz.y, bz.z, bz.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[mb][4 * q + i] = to_f32(from_f32<T>(acc[mb][4 * q + i] + b4[i]));          // what the GEMM stored
+                s += v[mb][4 * q + i];
+            }
+        }
+    if (p.gamma) {
+        s += __shfl_xor(s, 32);
+        const float mean = s / (float)C;
+        float ss = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float d = v[mb][r] - mean; ss = __builtin_fmaf(d, d, ss); }
+        ss += __shfl_xor(ss, 32);
+        const float rstd = 1.0f / __builtin_sqrtf(ss / (float)C + p.eps);
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c0 = 32 * mb + 8 * q + 4 * kh;
+                const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + c0), be = *reinterpret_cast<const f32x4*>(p.beta + c0);
+                const float g4[4] = {g.x, g.y, g.z, g.w}, b4[4] = {be.x, be.y, be.z, be.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[mb][4 * q + i] = (v[mb][4 * q + i] - mean) * rstd * g4[i] + b4[i];      // (mlpk_norm_apply's expression)
+            }
+    }
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            T e[4] = {from_f32<T>(v[mb][4 * q]), from_f32<T>(v[mb][4 * q + 1]), from_f32<T>(v[mb][4 * q + 2]), from_f32<T>(v[mb][4 * q + 3])};
+            u32x2 pk;
+            __builtin_memcpy(&pk, e, 8);
+            *reinterpret_cast<u32x2*>(img + n * ROWB + (32 * mb + 8 * q + 4 * kh) * 2) = pk;
+        }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // ---- 32 tokens x C x 2 bytes, rows contiguous in memory where ldo == C
+    constexpr int VPR = C / 8;                                // 16-byte vectors per token
+    T* const orow = reinterpret_cast<T*>(p.out) + first * p.ldo;
+    const long long left = p.npatch - first;
+#pragma unroll
+    for (int i = 0; i < (32 * VPR + 63) / 64; ++i) {
+        const int idx = lane + 64 * i;
+        const int tk = idx / VPR, vq = idx - tk * VPR;
+        if (idx < 32 * VPR && tk < left) *reinterpret_cast<u32x4*>(orow + (size_t)tk * p.ldo + vq * 8) = *reinterpret_cast<const u32x4*>(img + tk * ROWB + vq * 16);
+    }
+}
+
 }  // namespace mlpk
 
 using namespace mlpk;
@@ -174,4 +323,48 @@ extern "C" int mlpk_im2col(int src_dtype, int dst_dtype, int src_layout, const v
                            int H, int W, int kh, int kw, int stride_h, int stride_w, int pad, int src_px_stride, int ldo,
                            void* stream) {
     return im2col_impl(src_dtype, dst_dtype, src_layout, src, out, B, Cin, H, W, kh, kw, stride_h, stride_w, pad, src_px_stride, ldo, 0, stream);
+}
+
+extern "C" int mlpk_patch_embed4_supported(int src_dtype, int dst_dtype, int Cin, int H, int W, int C);
+extern "C" int mlpk_patch_embed4(int src_dtype, int dst_dtype, const void* x, int B, int Cin, int H, int W, const void* w, int ldw, const float* bias,
+                                 const float* gamma, const float* beta, float eps, void* out, int ldo, int C, void* stream);
+
+extern "C" int mlpk_patch_embed4_supported(int src_dtype, int dst_dtype, int Cin, int H, int W, int C) {
+    return (dst_dtype == MLPK_F16 || dst_dtype == MLPK_BF16) && (src_dtype == dst_dtype || src_dtype == MLPK_F32) && Cin == 3 && H >= 4 && W >= 4 &&
+           H % 4 == 0 && W % 4 == 0 && C >= 32 && C <= 128 && C % 32 == 0;
+}
+
+extern "C" int mlpk_patch_embed4(int src_dtype, int dst_dtype, const void* x, int B, int Cin, int H, int W, const void* w, int ldw, const float* bias,
+                                 const float* gamma, const float* beta, float eps, void* out, int ldo, int C, void* stream) {
+    if (!x || !w || !out) return MLPK_ENULL;
+    if ((gamma != nullptr) != (beta != nullptr)) return MLPK_ENULL;
+    if (B <= 0 || !mlpk_patch_embed4_supported(src_dtype, dst_dtype, Cin, H, W, C)) return MLPK_ESHAPE;
+    if (ldw < 48 || ldw % 8 || ldo < C || ldo % 8 || (gamma && !(eps > 0.f))) return MLPK_ESHAPE;
+    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)out | (uintptr_t)bias | (uintptr_t)gamma | (uintptr_t)beta) & 15) return MLPK_EALIGN;
+    PatchEmbedArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.gamma = gamma; a.beta = beta; a.out = out;
+    a.B = B; a.H = H; a.W = W; a.Hp = H / 4; a.Wp = W / 4; a.ldw = ldw; a.ldo = ldo; a.eps = eps;
+    a.npatch = (long long)B * a.Hp * a.Wp;
+    const long long wgs = (a.npatch + 127) / 128;
+    if (wgs > 0x7fffffffll) return MLPK_ESHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int nmb = C / 32;
+    const int lds = 4 * 32 * (C * 2 + 16);
+#define PE_GO(TS, TD, NMB) hipLaunchKernelGGL((patch_embed4_kernel<TS, TD, NMB>), dim3((unsigned)wgs), dim3(256), lds, s, a)
+#define PE_NMB(TS, TD)                                                                 \
+    switch (nmb) {                                                                     \
+        case 1: PE_GO(TS, TD, 1); break;                                               \
+        case 2: PE_GO(TS, TD, 2); break;                                               \
+        case 3: PE_GO(TS, TD, 3); break;                                               \
+        default: PE_GO(TS, TD, 4); break;                                              \
+    }
+    if (dst_dtype == MLPK_BF16) {
+        if (src_dtype == MLPK_F32) { PE_NMB(float, bf16_t) } else { PE_NMB(bf16_t, bf16_t) }
+    } else {
+        if (src_dtype == MLPK_F32) { PE_NMB(float, f16_t) } else { PE_NMB(f16_t, f16_t) }
+    }
+#undef PE_NMB
+#undef PE_GO
+    MLPK_LAUNCH_CHECK();
+    return 0;
 }

@@ -612,6 +612,17 @@ def patchify(src, out, B, Cin, H, W, ph, pw, pad, ldo, layout=N.LAYOUT_NCHW, px_
                                   ph, pw, pad, px_stride, ldo, order, stream()), "mlpk_patchify")
 
 
+def patch_embed4_supported(src_dtype, dst_dtype, cin, H, W, C):
+    """mlpk_patch_embed4: Conv2d(3 -> C, k = stride = 4) (+ LayerNorm) in one kernel (MLPK_PATCH_EMBED4=0: gather + GEMM + passes, A/B aid)"""
+    return (dst_dtype in (torch.float16, torch.bfloat16) and os.environ.get("MLPK_PATCH_EMBED4", "1") != "0"
+            and bool(N.lib().mlpk_patch_embed4_supported(dtype_code(src_dtype), dtype_code(dst_dtype), cin, H, W, C)))
+
+
+def patch_embed4(x, w, bias, out, B, H, W, C, gamma=None, beta=None, eps=1e-5):
+    N.check(N.lib().mlpk_patch_embed4(dtype_code(x.dtype), dtype_code(out.dtype), ptr(x), B, 3, H, W, ptr(w), w.stride(0), ptr(bias), ptr(gamma), ptr(beta), eps,
+                                      ptr(out), out.stride(0), C, stream()), "mlpk_patch_embed4")
+
+
 def row_stats(x, rows, length, ldx, mean, rstd, eps=1e-5):
     N.check(N.lib().mlpk_row_stats(dtype_code(x.dtype), ptr(x), rows, length, ldx, eps, ptr(mean), ptr(rstd), stream()),
             "mlpk_row_stats")

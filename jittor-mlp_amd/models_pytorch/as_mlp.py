@@ -462,10 +462,13 @@ class AS_MLP(E.EngineModule):
         H, W = H_in // ph, W_in // pw
         C = self.embed_dim
         kp = pk["embed.w"].shape[1]
-        patches = ws.get("embed.patches", (B * H * W, kp))
-        E.patchify(x, patches, B, pe.in_chans, H_in, W_in, ph, pw, 0, kp)
         cur = ws.get("l0.x", (B * H * W, C))
-        E.gemm(patches, pk["embed.w"], cur, B * H * W, C, kp, bias=pk["embed.b"])
+        if (ph, pw) == (4, 4) and E.patch_embed4_supported(x.dtype, cur.dtype, pe.in_chans, H_in, W_in, C):
+            E.patch_embed4(x, pk["embed.w"], pk["embed.b"], cur, B, H_in, W_in, C)            # round 6: gather + product in one kernel
+        else:
+            patches = ws.get("embed.patches", (B * H * W, kp))
+            E.patchify(x, patches, B, pe.in_chans, H_in, W_in, ph, pw, 0, kp)
+            E.gemm(patches, pk["embed.w"], cur, B * H * W, C, kp, bias=pk["embed.b"])
         if pe.norm is not None:
             self._gn(ws, "gn0", cur, B, H * W, C, pk["embed.g"], pk["embed.be"], cur)
         return cur, H, W, C

@@ -170,20 +170,29 @@ def adopt_blocks(backbone, blocks):
         b.__dict__["_owner"] = (backbone, i)
 
 
-def embed_patches(ws, name, x, w_packed, bias, cdtype, patch, pad=0, out=None):
+def embed_patches(ws, name, x, w_packed, bias, cdtype, patch, pad=0, out=None, ln=None):
     """Conv2d(k = stride = patch) on an NCHW input -> channel-last tokens (B*Hp*Wp, Cout).
-    mlp_mixer.py:58-60,68-71; conv_mixer.py:18."""
+    mlp_mixer.py:58-60,68-71; conv_mixer.py:18.
+    ln = (gamma, beta, eps): the LayerNorm that follows the embedding (swin_mlp.py:332-333, ms_mlp.py:261-262) is applied too -- in the same kernel
+    for the 4 x 4 embeddings of three input channels (mlpk_patch_embed4, round 6), by a statistics and a normalise pass otherwise."""
     B, cin, H, W = x.shape
     ph, pw = patch
     hp, wp = (H + 2 * pad - ph) // ph + 1, (W + 2 * pad - pw) // pw + 1
     kp = w_packed.shape[1]
     cout = w_packed.shape[0]
     rows = B * hp * wp
-    patches = ws.get(name + ".patches", (rows, kp))
-    E.patchify(x, patches, B, cin, H, W, ph, pw, pad, kp)
     if out is None:
         out = ws.get(name + ".tokens", (rows, cout))
+    if (ph, pw) == (4, 4) and pad == 0 and out.stride(0) == cout and E.patch_embed4_supported(x.dtype, out.dtype, cin, H, W, cout):
+        g, b_, eps = ln if ln is not None else (None, None, 1e-5)
+        E.patch_embed4(x, w_packed, bias, out, B, H, W, cout, gamma=g, beta=b_, eps=eps)
+        return out, hp, wp
+    patches = ws.get(name + ".patches", (rows, kp))
+    E.patchify(x, patches, B, cin, H, W, ph, pw, pad, kp)
     E.gemm(patches, w_packed, out, rows, cout, kp, bias=bias)
+    if ln is not None:
+        mean, rstd = layernorm_stats(ws, out, rows, cout, tag=name + ".ln", eps=ln[2])
+        E.norm_apply(out, rows, cout, cout, mean=mean, rstd=rstd, gamma=ln[0], beta=ln[1], out_rm=out, ld_rm=cout)
     return out, hp, wp
 
 

@@ -227,10 +227,8 @@ class MS_MLP(StochasticDepth, E.EngineModule):
         pe = self.patch_embed
         C = self.embed_dim
         cur, H, W = embed_patches(ws, "embed", x, pk["embed.w"], pk["embed.b"], cd, tuple(pe.patch_size),
-                                  out=ws.get("l0.x", (B * pe.patches_resolution[0] * pe.patches_resolution[1], C)))
-        if pe.norm is not None:
-            mean, rstd = layernorm_stats(ws, cur, B * H * W, C, tag="embed.ln", eps=MS_EPS)
-            E.norm_apply(cur, B * H * W, C, C, mean=mean, rstd=rstd, gamma=pk["embed.g"], beta=pk["embed.be"], out_rm=cur, ld_rm=C)
+                                  out=ws.get("l0.x", (B * pe.patches_resolution[0] * pe.patches_resolution[1], C)),
+                                  ln=(pk["embed.g"], pk["embed.be"], MS_EPS) if pe.norm is not None else None)
         return cur, H, W
 
     def _down(self, ws, pk, li, cur, B, H, W, C):

@@ -248,10 +248,8 @@ class SwinMLP(StochasticDepth, E.EngineModule):
         pe = self.patch_embed
         C = self.embed_dim
         cur, H, W = embed_patches(ws_, "embed", x, pk["embed.w"], pk["embed.b"], cd, tuple(pe.patch_size),
-                                  out=ws_.get("l0.x", (B * pe.patches_resolution[0] * pe.patches_resolution[1], C)))
-        if pe.norm is not None:
-            mean, rstd = layernorm_stats(ws_, cur, B * H * W, C, tag="embed.ln")
-            E.norm_apply(cur, B * H * W, C, C, mean=mean, rstd=rstd, gamma=pk["embed.g"], beta=pk["embed.be"], out_rm=cur, ld_rm=C)
+                                  out=ws_.get("l0.x", (B * pe.patches_resolution[0] * pe.patches_resolution[1], C)),
+                                  ln=(pk["embed.g"], pk["embed.be"], pe.norm.eps) if pe.norm is not None else None)
         return cur, H, W
 
     def _merge(self, ws_, pk, li, cur, B, H, W, C):

@@ -1311,6 +1311,37 @@ def test_mixshift_nhwc(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_patch_embed4_conv_and_layernorm_in_one_kernel(dtype):
+    """mlpk_patch_embed4 (ABI 12): Conv2d(3 -> C, k = stride = 4) on the NCHW image, flatten, transpose (+ LayerNorm) of swin_mlp.py:324-333 /
+    ms_mlp.py:255-262 / as_mlp.py:319,330 -- against F.conv2d + F.layer_norm in fp64 on the rounded operands (the product rounded to the storage type in
+    between, as the GEMM it replaces stored it); 16-bit and fp32 images, C = 32 .. 128, maps that are not square, a token count that is not a multiple of a
+    workgroup's 128."""
+    pkg = load_pkg()
+    E = pkg.engine
+    F = torch.nn.functional
+    for ci, (B, H, W, C, with_ln, src) in enumerate([(2, 32, 32, 96, True, dtype), (3, 20, 12, 32, True, torch.float32), (1, 64, 36, 128, False, dtype),
+                                                      (5, 8, 8, 64, True, dtype), (2, 224, 224, 96, True, dtype), (1, 12, 4, 96, False, torch.float32)]):
+        assert E.patch_embed4_supported(src, dtype, 3, H, W, C)
+        x = rnd((B, 3, H, W), src, 1700 + ci)
+        wconv = rnd((C, 3, 4, 4), torch.float32, 1710 + ci, 1.0 / math.sqrt(48))
+        bias = rnd((C,), torch.float32, 1720 + ci, 0.3)
+        gamma, beta = rnd((C,), torch.float32, 1730 + ci) * 0.3 + 1.0, rnd((C,), torch.float32, 1740 + ci) * 0.2
+        wp = E.pack_matrix(wconv, dtype, dev())
+        out = torch.full((B * (H // 4) * (W // 4), C), float("nan"), dtype=dtype, device=dev())
+        E.patch_embed4(x.to(dev()), wp, bias.to(dev()), out, B, H, W, C, gamma=gamma.to(dev()) if with_ln else None, beta=beta.to(dev()) if with_ln else None, eps=1e-5)
+        torch.cuda.synchronize()
+        xd = x.to(dtype).double()
+        y = F.conv2d(xd, wconv.to(dtype).double(), bias.double(), stride=4).flatten(2).transpose(1, 2).reshape(-1, C)
+        y = y.to(dtype).double()
+        if with_ln:
+            y = F.layer_norm(y, (C,), gamma.double(), beta.double(), 1e-5)
+        err = (out.double().cpu() - y).abs().max().item()
+        assert torch.isfinite(out.float()).all() and err < EPS[dtype] * 4 * max(1.0, y.abs().max().item()), (str(dtype), ci, err)
+    assert not E.patch_embed4_supported(dtype, dtype, 4, 32, 32, 96) and not E.patch_embed4_supported(dtype, dtype, 3, 30, 32, 96)
+    assert not E.patch_embed4_supported(dtype, dtype, 3, 32, 32, 160) and not E.patch_embed4_supported(dtype, torch.float32, 3, 32, 32, 96)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_gemm_pair_gives_the_bits_of_two_calls(dtype):
     """mlpk_gemm_nt_pair (ABI 12): two independent products in one launch where the dispatch gives both the same "s3" tile -- Hire-MLP's proj_h / proj_w
     pairs (hire_mlp.py:139-143) at their stage-3 and stage-1 sizes, with GELU and without -- and the fall-back (different tile families, fp32): in every case
