@@ -292,6 +292,13 @@ int mlpk_patch_embed4_supported(int src_dtype, int dst_dtype, int Cin, int H, in
 int mlpk_patch_embed4(int src_dtype, int dst_dtype, const void* x, int B, int Cin, int H, int W, const void* w, int ldw, const float* bias,
                       const float* gamma, const float* beta, float eps, void* out, int ldo, int C, void* stream);
 
+/* round 6 (ABI 12) -- the 7 x 7 stride-4 stems (hire_mlp.py:21 pad 3, cycle_mlp.py:261 pad 2) as a direct convolution: out[(b, oy, ox), :] = W window + bias,
+ * x: (B, 3, H, W) NCHW (dst dtype or fp32), W % 8 == 0, at most 64 output columns; w: (C, 176) 16-bit with k = (ci * 7 + i) * 8 + j (zero for j = 7 and
+ * k >= 168: engine.pack_stem7); C = 32 .. 128 in steps of 32.  Replaces mlpk_im2col + mlpk_gemm_nt (same arithmetic, the 32 x 32 x 16 MFMA's summation order). */
+int mlpk_stem7_supported(int src_dtype, int dst_dtype, int Cin, int H, int W, int pad, int C);
+int mlpk_stem7(int src_dtype, int dst_dtype, const void* x, int B, int Cin, int H, int W, int pad, const void* w, const float* bias, void* out,
+               int ldo, int C, float* out_mean, float* out_rstd, float eps, void* stream);   /* out_mean / out_rstd (or NULL, NULL): LayerNorm statistics of the rows written */
+
 /* ---- row statistics ---------------------------------------------------------------------
  * For each of `rows` rows of `len` contiguous elements (row r starts at x + r*ldx):
  * mean[r], rstd[r] = 1/sqrt(biased_var + eps).  Two-pass (mean, then centred squares), fp32.

@@ -119,6 +119,8 @@ PROTOTYPES = {
     "mlpk_dwconv_affine_nhwc": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p] * 4 + [c_void_p]),
     "mlpk_im2col": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p]),
     "mlpk_patch_embed4_supported": (c_int, [c_int] * 6),
+    "mlpk_stem7_supported": (c_int, [c_int] * 7),
+    "mlpk_stem7": (c_int, [c_int, c_int, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p]),
     "mlpk_patch_embed4": (c_int, [c_int, c_int, c_void_p] + [c_int] * 4 + [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p]),
     "mlpk_hire_gather": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     "mlpk_hire_gather_ln": (c_int, [c_int] + [c_void_p] * 7 + [c_int] * 9 + [c_void_p]),

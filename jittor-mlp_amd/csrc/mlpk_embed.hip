@@ -278,6 +278,142 @@ __global__ void __launch_bounds__(256) patch_embed4_kernel(const PatchEmbedArgs 
     }
 }
 
+// ---- round 6: the 7 x 7 stride-4 stems of Hire-MLP and CycleMLP as a direct convolution (mlpk_stem7) -----------------------------------------------
+// hire_mlp.py:21 (pad 3), cycle_mlp.py:261 (pad 2): Conv2d(3 -> C, k = 7, stride = 4) on the NCHW image -> channel-last rows.  As window gather + GEMM
+// this wrote and re-read a 244 MB operand (K = 147 padded to 152) for a 77 MB image: 177 + 130 us per forward.  Here a workgroup takes one image and TWO
+// output rows: the 11 input rows x 3 channels it needs are staged in LDS once (zeros outside the image; tile column = x + pad, so the window of output
+// column ox starts at column 4 ox: 8-byte aligned), and the product runs on v_mfma_f32_32x32x16 with the weight as the first operand -- a lane is one
+// output pixel n = lane & 31 and the k-half kh; K is ordered (channel, window row, 8 columns): k-step ks, half kh is window row rr = 2 ks + kh (of 21),
+// its 8 columns one 16-byte piece of the tile (two ds_read_b64); the eighth column and row 21 meet zero weights.  The weight (C x 176, packed by
+// engine.pack_stem7) stays in registers; bias, one rounding, the pixels leave through a per-wave LDS image as whole rows.
+struct Stem7Args {
+    const void* x;          // (B, 3, H, W)
+    const void* w;          // (C, 176): k = (ci * 7 + i) * 8 + j, zero for j = 7 and k >= 168
+    const float* bias;
+    void* out;              // (B * Ho * Wo, ldo)
+    int B, H, W, Ho, Wo, pad, ldo, pitch;       // pitch: tile row in elements
+    float* out_mean;        // or NULL: LayerNorm statistics (two-pass, of the rounded values) of the rows written, per pixel
+    float* out_rstd;
+    float eps;
+};
+
+template <typename TS, typename T, int NMB>
+__global__ void __launch_bounds__(256) stem7_kernel(const Stem7Args p) {
+    typedef typename PeMma<T>::f32x16 f32x16;
+    constexpr int C = NMB * 32;
+    constexpr int ROWB = C * 2 + 16;
+    constexpr int NKS = 11;
+    extern __shared__ __attribute__((aligned(16))) char st_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, kh = lane >> 5;
+    const int pitch = p.pitch;
+    T* const tile = reinterpret_cast<T*>(st_smem);                        // [3][11][pitch]
+    char* const img = st_smem + 33 * pitch * 2 + wave * (32 * ROWB);
+    const T* __restrict__ wgt = reinterpret_cast<const T*>(p.w);
+    const int opairs = (p.Ho + 1) >> 1;
+    const int b = blockIdx.x / opairs, oy0 = (blockIdx.x - b * opairs) * 2;
+    u32x4 wf[NMB][NKS];
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) wf[mb][ks] = *reinterpret_cast<const u32x4*>(wgt + (size_t)(mb * 32 + n) * 176 + 16 * ks + 8 * kh);
+    // ---- stage: zero the tile, then the image rows 4 oy0 - pad .. + 10 of the three channels at tile column x + pad
+    for (int i = tid; i < 33 * pitch / 8; i += 256) reinterpret_cast<u32x4*>(tile)[i] = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    {
+        const TS* __restrict__ x = reinterpret_cast<const TS*>(p.x) + (size_t)b * 3 * p.H * p.W;
+        const int vpr = p.W / 8;                                          // 8-pixel pieces per image row
+        const int y0 = 4 * oy0 - p.pad;
+        for (int i = tid; i < 33 * vpr; i += 256) {
+            const int row = i / vpr, v = i - row * vpr;                   // row = ci * 11 + r
+            const int ci = row / 11, r = row - ci * 11;
+            const int y = y0 + r;
+            if (y < 0 || y >= p.H) continue;
+            const TS* src = x + ((size_t)ci * p.H + y) * p.W + v * 8;
+            T e[8];
+            if constexpr (sizeof(TS) == 4) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 4);
+                e[0] = from_f32<T>(a0.x); e[1] = from_f32<T>(a0.y); e[2] = from_f32<T>(a0.z); e[3] = from_f32<T>(a0.w);
+                e[4] = from_f32<T>(a1.x); e[5] = from_f32<T>(a1.y); e[6] = from_f32<T>(a1.z); e[7] = from_f32<T>(a1.w);
+            } else {
+                const u32x4 raw = *reinterpret_cast<const u32x4*>(src);
+                __builtin_memcpy(e, &raw, 16);
+            }
+            T* dst = tile + row * pitch + v * 8 + p.pad;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dst[q] = e[q];
+        }
+    }
+    __syncthreads();
+    // ---- this wave's 32 of the workgroup's 2 Wo pixels
+    const int npx = (p.Ho - oy0 >= 2 ? 2 : 1) * p.Wo;
+    const int first = wave * 32;
+    if (first >= npx) return;                                             // (wave-uniform; no workgroup barrier below)
+    int pi = first + n;
+    pi = pi < npx ? pi : npx - 1;
+    const int prow = pi >= p.Wo ? 1 : 0, ox = pi - prow * p.Wo;
+    const T* const base = tile + (prow * 4) * pitch + 4 * ox;
+    f32x16 acc[NMB];
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int rr0 = 2 * ks, rr1 = 2 * ks + 1;                         // window rows of the two k-halves (compile-time)
+        const int off0 = ((rr0 / 7) * 11 + rr0 % 7) * pitch;
+        const int off1 = rr1 < 21 ? ((rr1 / 7) * 11 + rr1 % 7) * pitch : off0;
+        const T* src = base + (kh ? off1 : off0);
+        u32x2 lo = *reinterpret_cast<const u32x2*>(src), hi = *reinterpret_cast<const u32x2*>(src + 4);
+        if (rr1 >= 21 && kh) { lo = u32x2{0u, 0u}; hi = u32x2{0u, 0u}; }
+        hi.y &= 0xffffu;                                                  // the eighth column is not part of the window (0 x inf must not be NaN)
+        const u32x4 bfrag = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb) acc[mb] = PeMma<T>::run(wf[mb][ks], bfrag, acc[mb]);
+    }
+    float ssum = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c0 = 32 * mb + 8 * q + 4 * kh;
+            const f32x4 bz = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+            T e[4] = {from_f32<T>(acc[mb][4 * q] + bz.x), from_f32<T>(acc[mb][4 * q + 1] + bz.y), from_f32<T>(acc[mb][4 * q + 2] + bz.z),
+                      from_f32<T>(acc[mb][4 * q + 3] + bz.w)};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { acc[mb][4 * q + i] = to_f32(e[i]); ssum += acc[mb][4 * q + i]; }       // (the rounded values: what is stored)
+            u32x2 pk;
+            __builtin_memcpy(&pk, e, 8);
+            *reinterpret_cast<u32x2*>(img + n * ROWB + c0 * 2) = pk;
+        }
+    const int left = npx - first;
+    if (p.out_mean) {
+        ssum += __shfl_xor(ssum, 32);
+        const float mean = ssum / (float)C;
+        float ss = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float d = acc[mb][r] - mean; ss = __builtin_fmaf(d, d, ss); }
+        ss += __shfl_xor(ss, 32);
+        if (kh == 0 && n < left) {
+            const size_t row = ((size_t)b * p.Ho + oy0) * p.Wo + first + n;
+            p.out_mean[row] = mean;
+            p.out_rstd[row] = 1.0f / __builtin_sqrtf(ss / (float)C + p.eps);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    constexpr int VPR = C / 8;
+    T* const orow = reinterpret_cast<T*>(p.out) + (((size_t)b * p.Ho + oy0) * p.Wo + first) * p.ldo;
+#pragma unroll
+    for (int i = 0; i < (32 * VPR + 63) / 64; ++i) {
+        const int idx = lane + 64 * i;
+        const int tk = idx / VPR, vq = idx - tk * VPR;
+        if (idx < 32 * VPR && tk < left) *reinterpret_cast<u32x4*>(orow + (size_t)tk * p.ldo + vq * 8) = *reinterpret_cast<const u32x4*>(img + tk * ROWB + vq * 16);
+    }
+}
+
 }  // namespace mlpk
 
 using namespace mlpk;
@@ -365,6 +501,57 @@ extern "C" int mlpk_patch_embed4(int src_dtype, int dst_dtype, const void* x, in
     }
 #undef PE_NMB
 #undef PE_GO
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mlpk_stem7_supported(int src_dtype, int dst_dtype, int Cin, int H, int W, int pad, int C);
+extern "C" int mlpk_stem7(int src_dtype, int dst_dtype, const void* x, int B, int Cin, int H, int W, int pad, const void* w, const float* bias, void* out,
+                          int ldo, int C, float* out_mean, float* out_rstd, float eps, void* stream);
+
+extern "C" int mlpk_stem7_supported(int src_dtype, int dst_dtype, int Cin, int H, int W, int pad, int C) {
+    if (!((dst_dtype == MLPK_F16 || dst_dtype == MLPK_BF16) && (src_dtype == dst_dtype || src_dtype == MLPK_F32) && Cin == 3)) return 0;
+    if (pad < 0 || pad > 3 || H + 2 * pad < 7 || W + 2 * pad < 7 || W % 8 || C < 32 || C > 128 || C % 32) return 0;
+    const int Wo = (W + 2 * pad - 7) / 4 + 1;
+    return 2 * Wo <= 128;
+}
+
+extern "C" int mlpk_stem7(int src_dtype, int dst_dtype, const void* x, int B, int Cin, int H, int W, int pad, const void* w, const float* bias, void* out,
+                          int ldo, int C, float* out_mean, float* out_rstd, float eps, void* stream) {
+    if (!x || !w || !out) return MLPK_ENULL;
+    if ((out_mean != nullptr) != (out_rstd != nullptr)) return MLPK_ENULL;
+    if (out_mean && !(eps > 0.f)) return MLPK_ESHAPE;
+    if (B <= 0 || !mlpk_stem7_supported(src_dtype, dst_dtype, Cin, H, W, pad, C)) return MLPK_ESHAPE;
+    if (ldo < C || ldo % 8) return MLPK_ESHAPE;
+    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)out | (uintptr_t)bias) & 15) return MLPK_EALIGN;
+    Stem7Args a;
+    a.x = x; a.w = w; a.bias = bias; a.out = out; a.B = B; a.H = H; a.W = W; a.pad = pad; a.ldo = ldo;
+    a.out_mean = out_mean; a.out_rstd = out_rstd; a.eps = eps;
+    a.Ho = (H + 2 * pad - 7) / 4 + 1;
+    a.Wo = (W + 2 * pad - 7) / 4 + 1;
+    int pitch = 4 * a.Wo + 8;                                  // the last window: columns 4 (Wo - 1) .. + 7
+    if (pitch < W + pad) pitch = W + pad;
+    a.pitch = (pitch + 7) / 8 * 8;
+    const long long wgs = (long long)B * ((a.Ho + 1) / 2);
+    if (wgs > 0x7fffffffll) return MLPK_ESHAPE;
+    const int lds = 33 * a.pitch * 2 + 4 * 32 * (C * 2 + 16);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int nmb = C / 32;
+#define S7_GO(TS, TD, NMB) hipLaunchKernelGGL((stem7_kernel<TS, TD, NMB>), dim3((unsigned)wgs), dim3(256), lds, s, a)
+#define S7_NMB(TS, TD)                                                                 \
+    switch (nmb) {                                                                     \
+        case 1: S7_GO(TS, TD, 1); break;                                               \
+        case 2: S7_GO(TS, TD, 2); break;                                               \
+        case 3: S7_GO(TS, TD, 3); break;                                               \
+        default: S7_GO(TS, TD, 4); break;                                              \
+    }
+    if (dst_dtype == MLPK_BF16) {
+        if (src_dtype == MLPK_F32) { S7_NMB(float, bf16_t) } else { S7_NMB(bf16_t, bf16_t) }
+    } else {
+        if (src_dtype == MLPK_F32) { S7_NMB(float, f16_t) } else { S7_NMB(f16_t, f16_t) }
+    }
+#undef S7_NMB
+#undef S7_GO
     MLPK_LAUNCH_CHECK();
     return 0;
 }

@@ -623,6 +623,27 @@ def patch_embed4(x, w, bias, out, B, H, W, C, gamma=None, beta=None, eps=1e-5):
                                       ptr(out), out.stride(0), C, stream()), "mlpk_patch_embed4")
 
 
+def stem7_supported(src_dtype, dst_dtype, cin, H, W, pad, C):
+    """mlpk_stem7: Conv2d(3 -> C, k = 7, stride = 4) as a direct convolution (MLPK_STEM7=0: window gather + GEMM, A/B aid)"""
+    return (dst_dtype in (torch.float16, torch.bfloat16) and os.environ.get("MLPK_STEM7", "1") != "0"
+            and bool(N.lib().mlpk_stem7_supported(dtype_code(src_dtype), dtype_code(dst_dtype), cin, H, W, pad, C)))
+
+
+def pack_stem7(weight, dtype, device):
+    """Conv2d weight (C, 3, 7, 7) -> (C, 176): k = (ci * 7 + i) * 8 + j, zero for j = 7 and k >= 168 (mlpk_stem7's operand order)"""
+    w = weight.detach().to(device=device, dtype=torch.float32)
+    C = w.shape[0]
+    wp = torch.zeros((C, 176), dtype=dtype, device=device)
+    wp[:, :168] = torch.nn.functional.pad(w, (0, 1)).reshape(C, 168).to(dtype)
+    return wp.contiguous()
+
+
+def stem7(x, w7, bias, out, B, H, W, pad, C, out_stats=None, eps=1e-5):
+    """out_stats = (mean, rstd) fp32 per output pixel: the LayerNorm statistics of the rows written, for the block that follows"""
+    N.check(N.lib().mlpk_stem7(dtype_code(x.dtype), dtype_code(out.dtype), ptr(x), B, 3, H, W, pad, ptr(w7), ptr(bias), ptr(out), out.stride(0), C,
+                               ptr(out_stats[0]) if out_stats else None, ptr(out_stats[1]) if out_stats else None, eps, stream()), "mlpk_stem7")
+
+
 def row_stats(x, rows, length, ldx, mean, rstd, eps=1e-5):
     N.check(N.lib().mlpk_row_stats(dtype_code(x.dtype), ptr(x), rows, length, ldx, eps, ptr(mean), ptr(rstd), stream()),
             "mlpk_row_stats")

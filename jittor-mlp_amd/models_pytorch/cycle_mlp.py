@@ -211,6 +211,8 @@ class CycleNet(StochasticDepth, E.EngineModule):
         pk = {}
         conv = self.patch_embed.proj
         pk["embed.w"] = E.pack_matrix(conv.weight, dtype, device)
+        if dtype != torch.float32 and tuple(conv.kernel_size) == (7, 7) and tuple(conv.stride) == (4, 4) and conv.in_channels == 3:
+            pk["embed.w7"] = E.pack_stem7(conv.weight, dtype, device)                      # round 6: the stem as a direct convolution (mlpk_stem7)
         pk["embed.b"] = E.f32(conv.bias, device)
         for si, stage in enumerate(self.network):
             if isinstance(stage, Downsample):
@@ -328,10 +330,13 @@ class CycleNet(StochasticDepth, E.EngineModule):
                 C = pk["embed.w"].shape[0]
                 H, W = (H_in + 4 - 7) // 4 + 1, (W_in + 4 - 7) // 4 + 1
                 kp = pk["embed.w"].shape[1]
-                patches = ws.get("embed.patches", (B * H * W, kp))
-                E.im2col(x.contiguous(), patches, B, cin, H_in, W_in, 7, 7, 4, 4, 2, kp)
                 cur = ws.get("n0.x", (B * H * W, C))
-                E.gemm(patches, pk["embed.w"], cur, B * H * W, C, kp, bias=pk["embed.b"])
+                if "embed.w7" in pk and E.stem7_supported(x.dtype, cur.dtype, cin, H_in, W_in, 2, C):
+                    E.stem7(x.contiguous(), pk["embed.w7"], pk["embed.b"], cur, B, H_in, W_in, 2, C)
+                else:
+                    patches = ws.get("embed.patches", (B * H * W, kp))
+                    E.im2col(x.contiguous(), patches, B, cin, H_in, W_in, 7, 7, 4, 4, 2, kp)
+                    E.gemm(patches, pk["embed.w"], cur, B * H * W, C, kp, bias=pk["embed.b"])
                 return cur.reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
         if bi == "down":                                           # Downsample (:227-231): 3 x 3 stride-2 pad-1 conv on channel-last
             C = self.network[si].proj.in_channels
@@ -451,11 +456,16 @@ class CycleNet(StochasticDepth, E.EngineModule):
         C = pk["embed.w"].shape[0]
         H, W = (H_in + 4 - 7) // 4 + 1, (W_in + 4 - 7) // 4 + 1
         kp = pk["embed.w"].shape[1]
-        patches = ws.get("embed.patches", (B * H * W, kp))
-        E.im2col(x, patches, B, cin, H_in, W_in, 7, 7, 4, 4, 2, kp)
         cur = ws.get("n0.x", (B * H * W, C))
-        got = E.gemm(patches, pk["embed.w"], cur, B * H * W, C, kp, bias=pk["embed.b"], part=(ws, "embed.part"))
-        st = finalize_stats(ws, got, B * H * W, C, tag="n0.ln")
+        if "embed.w7" in pk and E.stem7_supported(x.dtype, cur.dtype, cin, H_in, W_in, 2, C):
+            # round 6: the stem as a direct convolution, delivering the first block's LayerNorm statistics too
+            st = (ws.get("n0.ln.mean", (B * H * W,), torch.float32), ws.get("n0.ln.rstd", (B * H * W,), torch.float32))
+            E.stem7(x, pk["embed.w7"], pk["embed.b"], cur, B, H_in, W_in, 2, C, out_stats=st, eps=self.network[0][0].norm1.eps)
+        else:
+            patches = ws.get("embed.patches", (B * H * W, kp))
+            E.im2col(x, patches, B, cin, H_in, W_in, 7, 7, 4, 4, 2, kp)
+            got = E.gemm(patches, pk["embed.w"], cur, B * H * W, C, kp, bias=pk["embed.b"], part=(ws, "embed.part"))
+            st = finalize_stats(ws, got, B * H * W, C, tag="n0.ln")
         outs = []
         for si, stage in enumerate(self.network):
             if self.fork_feat and si > 0 and (si - 1) in self.out_indices:

@@ -164,6 +164,8 @@ class HireMLP(E.EngineModule):
         pk = {}
         conv = self.patcher.reduction[0]
         pk["embed.w"] = E.pack_matrix(conv.weight, dtype, device)                           # (ci, i, j) order == the NCHW window gather
+        if dtype != torch.float32 and self._cfg[0] == (4, 4) and self._cfg[1] == 3:
+            pk["embed.w7"] = E.pack_stem7(conv.weight, dtype, device)                      # round 6: the stem as a direct convolution (mlpk_stem7)
         pk["embed.b"] = E.f32(conv.bias, device)
         if self._cfg[3]:
             ln = self.patcher.reduction[1][1]
@@ -289,10 +291,13 @@ class HireMLP(E.EngineModule):
         C = self.layers[0].geom[2]
         H, W = (H_in + 6 - 7) // patch[0] + 1, (W_in + 6 - 7) // patch[1] + 1
         kp = pk["embed.w"].shape[1]
-        patches = ws.get("embed.patches", (B * H * W, kp))
-        E.im2col(x, patches, B, cin, H_in, W_in, 7, 7, patch[0], patch[1], 3, kp)
         cur = ws.get("l0.x", (B * H * W, C))
-        E.gemm(patches, pk["embed.w"], cur, B * H * W, C, kp, bias=pk["embed.b"])
+        if "embed.w7" in pk and E.stem7_supported(x.dtype, cur.dtype, cin, H_in, W_in, 3, C):
+            E.stem7(x, pk["embed.w7"], pk["embed.b"], cur, B, H_in, W_in, 3, C)
+        else:
+            patches = ws.get("embed.patches", (B * H * W, kp))
+            E.im2col(x, patches, B, cin, H_in, W_in, 7, 7, patch[0], patch[1], 3, kp)
+            E.gemm(patches, pk["embed.w"], cur, B * H * W, C, kp, bias=pk["embed.b"])
         if patcher_norm:
             mean, rstd = layernorm_stats(ws, cur, B * H * W, C, tag="embed.ln")
             E.norm_apply(cur, B * H * W, C, C, mean=mean, rstd=rstd, gamma=pk["embed.g"], beta=pk["embed.be"], out_rm=cur, ld_rm=C)

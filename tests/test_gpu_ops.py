@@ -1342,6 +1342,40 @@ def test_patch_embed4_conv_and_layernorm_in_one_kernel(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_stem7_direct_convolution(dtype):
+    """mlpk_stem7 (ABI 12): Conv2d(3 -> C, k = 7, stride = 4, pad 3 / 2) of hire_mlp.py:21 / cycle_mlp.py:261 as a direct convolution -- against F.conv2d in
+    fp64 on the rounded operands; 16-bit and fp32 images, an odd number of output rows, heights that are not a multiple of the stride, and the
+    LayerNorm statistics of the written rows."""
+    pkg = load_pkg()
+    E = pkg.engine
+    F = torch.nn.functional
+    for ci, (B, H, W, C, pad, src) in enumerate([(2, 32, 32, 64, 3, dtype), (3, 30, 40, 64, 2, dtype), (1, 224, 224, 64, 3, dtype), (2, 21, 16, 32, 2, torch.float32),
+                                                  (2, 36, 24, 128, 3, torch.float32), (1, 9, 8, 96, 0, dtype)]):
+        assert E.stem7_supported(src, dtype, 3, H, W, pad, C)
+        x = rnd((B, 3, H, W), src, 1800 + ci)
+        wconv = rnd((C, 3, 7, 7), torch.float32, 1810 + ci, 1.0 / math.sqrt(147))
+        bias = rnd((C,), torch.float32, 1820 + ci, 0.3)
+        w7 = E.pack_stem7(wconv, dtype, dev())
+        Ho, Wo = (H + 2 * pad - 7) // 4 + 1, (W + 2 * pad - 7) // 4 + 1
+        out = torch.full((B * Ho * Wo, C), float("nan"), dtype=dtype, device=dev())
+        mean = torch.full((B * Ho * Wo,), float("nan"), dtype=torch.float32, device=dev())
+        rstd = torch.full_like(mean, float("nan"))
+        E.stem7(x.to(dev()), w7, bias.to(dev()), out, B, H, W, pad, C, out_stats=(mean, rstd), eps=1e-5)
+        plain = torch.full_like(out, float("nan"))
+        E.stem7(x.to(dev()), w7, bias.to(dev()), plain, B, H, W, pad, C)
+        torch.cuda.synchronize()
+        y = F.conv2d(x.to(dtype).double(), wconv.to(dtype).double(), bias.double(), stride=4, padding=pad).permute(0, 2, 3, 1).reshape(-1, C)
+        err = (out.double().cpu() - y).abs().max().item()
+        assert torch.isfinite(out.float()).all() and err < EPS[dtype] * 4 * max(1.0, y.abs().max().item()), (str(dtype), ci, err)
+        assert torch.equal(plain, out), (str(dtype), ci)
+        od = out.double().cpu()
+        assert (mean.cpu().double() - od.mean(1)).abs().max().item() < 1e-5 * max(1.0, od.abs().max().item()), (str(dtype), ci)
+        want_r = 1.0 / torch.sqrt(od.var(1, unbiased=False) + 1e-5)
+        assert ((rstd.cpu().double() - want_r).abs() / want_r).max().item() < 1e-4, (str(dtype), ci)
+    assert not E.stem7_supported(dtype, dtype, 4, 32, 32, 3, 64) and not E.stem7_supported(dtype, dtype, 3, 32, 30, 3, 64) and not E.stem7_supported(dtype, dtype, 3, 32, 512, 3, 64)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_gemm_pair_gives_the_bits_of_two_calls(dtype):
     """mlpk_gemm_nt_pair (ABI 12): two independent products in one launch where the dispatch gives both the same "s3" tile -- Hire-MLP's proj_h / proj_w
     pairs (hire_mlp.py:139-143) at their stage-3 and stage-1 sizes, with GELU and without -- and the fall-back (different tile families, fp32): in every case
