@@ -23,7 +23,7 @@ for l in open("gpurun_out/final/bench_models.jsonl"):
     d = json.loads(l)
     print("%-40s %10.1f img/s %8.2f ms  %7.1f model-TF/s" % (d["metric"], d["value"], d["ms_per_step"], d["model_tflops"]))
 PY
-for m in vip_s7 gmlp_s resmlp_24 asmlp_t convmixer_1536_20 msmlp_t swinmlp_t; do timeout 200 bash tools/prof_model.sh $m < /dev/null 2>&1 | tail -9; done
+for m in vip_s7 gmlp_s resmlp_24 asmlp_t convmixer_1536_20 msmlp_t swinmlp_t hiremlp_s cyclemlp_b1; do timeout 200 bash tools/prof_model.sh $m < /dev/null 2>&1 | tail -9; done
 if [ -n "$FINAL_FULL" ]; then
 echo "== torch / runtime kernels per forward (one-time packing separated)"; timeout 400 bash tools/prof_aten.sh mixer_b16 < /dev/null 2>&1 | tail -12
 echo "== epilogue statistics A/B"; timeout 400 bash tools/gpu_stats.sh < /dev/null > $OUT/epilogue_stats_ab.txt 2>&1; cat $OUT/epilogue_stats_ab.txt
