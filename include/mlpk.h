@@ -165,6 +165,14 @@ typedef struct mlpk_gemm_desc {
 } mlpk_gemm_desc;
 
 int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream);
+/* round 6 (ABI 12): a strided k x k convolution on a channel-last tensor as ONE product whose A operand is read through the window -- no gathered operand
+ * (mlpk_im2col wrote B Ho Wo x kh kw Cin values for mlpk_gemm_nt to read back): the 3 x 3 stride-2 pad-1 transitions of Hire-MLP (hire_mlp.py:161) and
+ * CycleMLP (cycle_mlp.py:220-231).  d: the product's descriptor with A = the dense (B, H, W, Cin) input, M = B Ho Wo, K = kh kw Cin in mlpk_im2col's NHWC
+ * order (tap-major, then channel), lda = K (unused), a row-major output; every epilogue option of mlpk_gemm_nt (bias, residual, by-product statistics).
+ * 16-bit, Cin % 32 == 0 (a 64-byte slab of K is 32 channels of one tap; taps outside the map read a zero slab).  The 128 x 128 "s3" tile in the K order of
+ * mlpk_gemm_nt: the bits of mlpk_im2col + mlpk_gemm_nt on that tile. */
+int mlpk_conv_gemm_nhwc_supported(int dtype, int Cin, int kh, int kw, int stride, int pad);
+int mlpk_conv_gemm_nhwc(const mlpk_gemm_desc* d, int B, int H, int W, int Cin, int kh, int kw, int stride, int pad, void* stream);
 /* round 6 (ABI 12): two INDEPENDENT products in one launch where the dispatch gives both the same 16-bit "s3" tile family (algo 11..13) -- workgroups
  * [0, tiles of d0) compute d0, the rest d1; every tile exactly as mlpk_gemm_nt computes it (same bits).  Otherwise the two calls one after the other.
  * For the short, latency-bound products of sibling branches (Hire-MLP's proj_h / proj_w pairs, hire_mlp.py:139-143): half the launches, no side stream.

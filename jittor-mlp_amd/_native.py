@@ -45,6 +45,8 @@ PROTOTYPES = {
     "mlpk_strerror": (ctypes.c_char_p, [c_int]),
     "mlpk_gemm_nt": (c_int, [ctypes.POINTER(GemmDesc), c_void_p]),
     "mlpk_gemm_nt_pair": (c_int, [ctypes.POINTER(GemmDesc), ctypes.POINTER(GemmDesc), c_void_p]),
+    "mlpk_conv_gemm_nhwc_supported": (c_int, [c_int] * 6),
+    "mlpk_conv_gemm_nhwc": (c_int, [ctypes.POINTER(GemmDesc)] + [c_int] * 8 + [c_void_p]),
     "mlpk_gemm_row_parts": (c_int, [ctypes.POINTER(GemmDesc), ctypes.POINTER(c_int)]),
     "mlpk_gemm_workspace_bytes": (ctypes.c_longlong, []),
     "mlpk_gemm_algo_count": (c_int, []),

@@ -57,7 +57,12 @@ struct GemmArgs {
     // 130 us GEMM)
     float* row_part;
     int row_part_ld;    // plane stride in pairs (>= M)
+    // implicit-convolution A operand (gemm_nt_s3_conv_kernel, round 6): A = a channel-last (B, cv_H, cv_W, cv_Cin) tensor, row m = output pixel (b, oy, ox),
+    // column k = (tap dy * cv_kw + dx) * cv_Cin + channel; a 64-byte slab of K = 32 channels of ONE tap (cv_Cin % 32 == 0), zeros outside the map
+    int cv_H, cv_W, cv_Cin, cv_kw, cv_cpk, cv_inv_cpk, cv_inv_kw, cv_stride, cv_pad, cv_Ho, cv_Wo;
 };
+
+__device__ __attribute__((aligned(64))) unsigned g_zero_slab[16];      // 64 zero bytes: the slab of a tap outside the map
 
 // tuning aid (dbg & 8): wave 0 / lane 0 of each workgroup logs s_memtime stamps into the buffer passed in R
 #define MLPK_STAMP(slot)                                                                          \
@@ -706,7 +711,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_nt_kernel(const GemmArgs p) 
 // epilogue (VALU GELU + stores) overlaps the other's main loop -- the two costs the lockstep
 // 8-wave / 1-workgroup-per-CU kernel above cannot hide (measured: 46 % MFMA busy in its main loop).
 // 64-byte rows: chunk c of row r is stored at chunk c ^ ((r & 8) >> 2), conflict-free for ds_read_b128.
-template <typename T, int BM, int BN, int WM, int WN, bool TRANS>
+template <typename T, int BM, int BN, int WM, int WN, bool TRANS, bool CONV = false>
 __device__ __forceinline__ void gemm_nt_s3_body(const GemmArgs& p, const int bid, const int nblocks) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN;
@@ -736,11 +741,21 @@ __device__ __forceinline__ void gemm_nt_s3_body(const GemmArgs& p, const int bid
     const int lchunk = (lane & 3) ^ ((lrow & 8) >> 2);
     const T* srcA[A_G];
     const T* srcB[B_G];
+    int cvy[CONV ? A_G : 1], cvx[CONV ? A_G : 1];          // CONV: the window's first input row / column of the piece's output pixel
 #pragma unroll
     for (int g = 0; g < A_G; ++g) {
         int gm = m0 + (wave * A_G + g) * 16 + lrow;
         gm = gm < p.M ? gm : p.M - 1;
-        srcA[g] = A + (size_t)gm * p.lda + lchunk * EPC;
+        if constexpr (CONV) {
+            const int img = gm / (p.cv_Ho * p.cv_Wo), rem = gm - img * (p.cv_Ho * p.cv_Wo);
+            const int oy = rem / p.cv_Wo, ox = rem - oy * p.cv_Wo;
+            cvy[g] = oy * p.cv_stride - p.cv_pad;
+            cvx[g] = ox * p.cv_stride - p.cv_pad;
+            // (may point in front of the tensor for a halo window: only dereferenced for taps inside the map)
+            srcA[g] = A + (((ptrdiff_t)img * p.cv_H + cvy[g]) * p.cv_W + cvx[g]) * p.cv_Cin + lchunk * EPC;
+        } else {
+            srcA[g] = A + (size_t)gm * p.lda + lchunk * EPC;
+        }
     }
 #pragma unroll
     for (int g = 0; g < B_G; ++g) {
@@ -748,6 +763,14 @@ __device__ __forceinline__ void gemm_nt_s3_body(const GemmArgs& p, const int bid
         gn = gn < p.N ? gn : p.N - 1;
         srcB[g] = B + (size_t)gn * p.ldb + lchunk * EPC;
     }
+    const T* const zslab = reinterpret_cast<const T*>(g_zero_slab) + lchunk * EPC;
+    // CONV: the A piece q of slab kt = 32 channels of tap (dy, dx) of the piece's window, or the zero slab outside the map (kt is wave-uniform)
+    auto conv_src = [&](const int q, const int kt) -> const T* {
+        const int tap = (kt * p.cv_inv_cpk) >> 16, c32 = kt - tap * p.cv_cpk;
+        const int dy = (tap * p.cv_inv_kw) >> 16, dx = tap - dy * p.cv_kw;
+        const bool ok = (unsigned)(cvy[CONV ? q : 0] + dy) < (unsigned)p.cv_H && (unsigned)(cvx[CONV ? q : 0] + dx) < (unsigned)p.cv_W;
+        return ok ? srcA[q] + ((ptrdiff_t)dy * p.cv_W + dx) * p.cv_Cin + c32 * BK : zslab;
+    };
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef const __attribute__((address_space(1))) void* glb_ptr_t;
     const int nk = (p.dbg & 1) ? 0 : p.K / BK;
@@ -758,7 +781,7 @@ __device__ __forceinline__ void gemm_nt_s3_body(const GemmArgs& p, const int bid
 #define S3_PIECE(kt, q)                                                                                \
     {                                                                                                  \
         const unsigned st__ = ((kt) % 3) * STAGE_B;                                                     \
-        if ((q) < A_G) glds_piece(srcA[(q) < A_G ? (q) : 0] + (size_t)(kt)*BK, dst_a + st__ + (q)*1024); \
+        if ((q) < A_G) glds_piece(CONV ? conv_src((q) < A_G ? (q) : 0, (kt)) : srcA[(q) < A_G ? (q) : 0] + (size_t)(kt)*BK, dst_a + st__ + (q)*1024); \
         else glds_piece(srcB[(q) >= A_G ? (q)-A_G : 0] + (size_t)(kt)*BK, dst_b + st__ + ((q)-A_G) * 1024); \
     }
 #define S3_STAGE(kt)                                                                                   \
@@ -842,6 +865,14 @@ __device__ __forceinline__ void gemm_nt_s3_body(const GemmArgs& p, const int bid
 template <typename T, int BM, int BN, int WM, int WN, bool TRANS>
 __global__ void __launch_bounds__(WM* WN * 64, 2) gemm_nt_s3_kernel(const GemmArgs p) {
     gemm_nt_s3_body<T, BM, BN, WM, WN, TRANS>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// The A operand as an implicit convolution window (round 6, mlpk_conv_gemm_nhwc): the strided 3 x 3 transitions of Hire-MLP / CycleMLP (hire_mlp.py:161,
+// cycle_mlp.py:220-231) without the gathered operand -- mlpk_im2col wrote B Ho Wo x 9 Cin values for the GEMM to read back.  Same tile, same K order, same
+// epilogue: the bits of mlpk_im2col + mlpk_gemm_nt on this tile.
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(WM* WN * 64, 2) gemm_nt_s3_conv_kernel(const GemmArgs p) {
+    gemm_nt_s3_body<T, BM, BN, WM, WN, false, true>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Two independent products of the same tile family in ONE launch (round 6, mlpk_gemm_nt_pair): workgroups [0, tiles0) compute p0's tiles,
@@ -2193,6 +2224,45 @@ extern "C" int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream) {
         case MLPK_F16: return launch_algo<f16_t>(algo, a, trans, s, d->workspace, d->workspace_bytes);
         default: return launch_algo<bf16_t>(algo, a, trans, s, d->workspace, d->workspace_bytes);
     }
+}
+
+extern "C" int mlpk_conv_gemm_nhwc_supported(int dtype, int Cin, int kh, int kw, int stride, int pad);
+extern "C" int mlpk_conv_gemm_nhwc(const mlpk_gemm_desc* d, int B, int H, int W, int Cin, int kh, int kw, int stride, int pad, void* stream);
+
+extern "C" int mlpk_conv_gemm_nhwc_supported(int dtype, int Cin, int kh, int kw, int stride, int pad) {
+    return (dtype == MLPK_F16 || dtype == MLPK_BF16) && Cin >= 32 && Cin % 32 == 0 && kh >= 1 && kw >= 1 && kh * kw <= 49 && stride >= 1 && pad >= 0 && pad < kh &&
+           pad < kw && (long long)kh * kw * (Cin / 32) < 65536;
+}
+
+template <typename T>
+static int launch_s3_conv(const GemmArgs& a, hipStream_t stream) {
+    constexpr int BM = 128, BN = 128;
+    const int lds = 3 * (BM + BN) * 64;
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    auto k = gemm_nt_s3_conv_kernel<T, BM, BN, 2, 2>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(256), lds, stream, a);
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+// d: the product's descriptor with A = the channel-last (B, H, W, Cin) input (dense pixels), M = B Ho Wo, K = kh kw Cin, lda = K (unused), row-major output
+extern "C" int mlpk_conv_gemm_nhwc(const mlpk_gemm_desc* d, int B, int H, int W, int Cin, int kh, int kw, int stride, int pad, void* stream) {
+    GemmArgs a;
+    int algo = 0;
+    bool trans = false;
+    const int rc = gemm_prepare(d, a, algo, trans);
+    if (rc) return rc;
+    if (B <= 0 || H <= 0 || W <= 0 || !mlpk_conv_gemm_nhwc_supported(d->dtype, Cin, kh, kw, stride, pad) || trans) return MLPK_ESHAPE;
+    if (H + 2 * pad < kh || W + 2 * pad < kw) return MLPK_ESHAPE;
+    const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+    if ((long long)B * Ho * Wo != d->M || (long long)kh * kw * Cin != d->K || d->N % 8) return MLPK_ESHAPE;
+    a.cv_H = H; a.cv_W = W; a.cv_Cin = Cin; a.cv_kw = kw; a.cv_cpk = Cin / 32; a.cv_stride = stride; a.cv_pad = pad; a.cv_Ho = Ho; a.cv_Wo = Wo;
+    a.cv_inv_cpk = (65536 + a.cv_cpk - 1) / a.cv_cpk;      // kt / cpk for kt < 65536 / cpk by one multiply
+    a.cv_inv_kw = (65536 + kw - 1) / kw;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return d->dtype == MLPK_F16 ? launch_s3_conv<f16_t>(a, s) : launch_s3_conv<bf16_t>(a, s);
 }
 
 extern "C" int mlpk_gemm_nt_pair(const mlpk_gemm_desc* d0, const mlpk_gemm_desc* d1, void* stream);

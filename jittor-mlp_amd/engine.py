@@ -253,6 +253,23 @@ def gemm_pair(first, second):
     return o0, o1
 
 
+def conv_gemm_nhwc_supported(dtype, Cin, kh, kw, stride, pad):
+    """mlpk_conv_gemm_nhwc: a strided convolution on channel-last rows as one product reading its operand through the window (MLPK_CONV_GEMM=0: window
+    gather + GEMM, A/B aid)"""
+    return (dtype in (torch.float16, torch.bfloat16) and os.environ.get("MLPK_CONV_GEMM", "1") != "0"
+            and bool(N.lib().mlpk_conv_gemm_nhwc_supported(dtype_code(dtype), Cin, kh, kw, stride, pad)))
+
+
+def conv_gemm_nhwc(x, w, out, B, H, W, Cin, kh, kw, stride, pad, **kw_gemm):
+    """out (B Ho Wo, N) = epilogue(window(x) . w^T): x = dense channel-last (B, H, W, Cin) rows, w (N, >= kh kw Cin) in mlpk_im2col's NHWC column order;
+    the keyword arguments of engine.gemm (bias, R / res, part, tag).  Returns what engine.gemm returns."""
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    K = kh * kw * Cin
+    d, o = gemm(x, w, out, B * Ho * Wo, w.shape[0], K, lda=K, _defer=True, **kw_gemm)
+    N.check(N.lib().mlpk_conv_gemm_nhwc(ctypes.byref(d), B, H, W, Cin, kh, kw, stride, pad, stream()), "mlpk_conv_gemm_nhwc")
+    return o
+
+
 GEMM_LOG = None
 CHANNEL_CHUNKS = int(os.environ.get("MLPK_CHANNEL_CHUNKS", "0"))      # 0 = by size (below); tuning override
 

@@ -474,10 +474,15 @@ class CycleNet(StochasticDepth, E.EngineModule):
                 Cout = pk["n%d.w" % si].shape[0]
                 H2, W2 = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
                 kp = pk["n%d.w" % si].shape[1]
-                cols = ws.get("n%d.cols" % si, (B * H2 * W2, kp))
-                E.im2col(cur, cols, B, C, H, W, 3, 3, 2, 2, 1, kp, layout=N.LAYOUT_NHWC, px_stride=C)
                 nxt = ws.get("n%d.x" % (si + 1), (B * H2 * W2, Cout))
-                got = E.gemm(cols, pk["n%d.w" % si], nxt, B * H2 * W2, Cout, kp, bias=pk["n%d.b" % si], tag="cycle_down", part=(ws, "n%d.down.part" % si))
+                if kp == 9 * C and E.conv_gemm_nhwc_supported(cur.dtype, C, 3, 3, 2, 1):
+                    # round 6: the window is the product's operand loader -- no gathered copy of the map (mlpk_conv_gemm_nhwc)
+                    got = E.conv_gemm_nhwc(cur, pk["n%d.w" % si], nxt, B, H, W, C, 3, 3, 2, 1, bias=pk["n%d.b" % si], tag="cycle_down",
+                                           part=(ws, "n%d.down.part" % si))
+                else:
+                    cols = ws.get("n%d.cols" % si, (B * H2 * W2, kp))
+                    E.im2col(cur, cols, B, C, H, W, 3, 3, 2, 2, 1, kp, layout=N.LAYOUT_NHWC, px_stride=C)
+                    got = E.gemm(cols, pk["n%d.w" % si], nxt, B * H2 * W2, Cout, kp, bias=pk["n%d.b" % si], tag="cycle_down", part=(ws, "n%d.down.part" % si))
                 st = finalize_stats(ws, got, B * H2 * W2, Cout, tag="n%d.ln" % (si + 1))
                 cur, H, W, C = nxt, H2, W2, Cout
                 continue

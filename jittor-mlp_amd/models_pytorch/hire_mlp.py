@@ -308,11 +308,16 @@ class HireMLP(E.EngineModule):
         Cout = self.layers[li].geom[3]
         H2, W2 = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
         kp = pk["l%d.merge.w" % li].shape[1]
-        cols = ws.get("l%d.cols" % li, (B * H2 * W2, kp))
-        E.im2col(cur, cols, B, C, H, W, 3, 3, 2, 2, 1, kp, layout=N.LAYOUT_NHWC, px_stride=C)
         nxt = ws.get("l%d.x" % (li + 1), (B * H2 * W2, Cout))
-        got = E.gemm(cols, pk["l%d.merge.w" % li], nxt, B * H2 * W2, Cout, kp, bias=pk["l%d.merge.b" % li], tag="hire_merge",
-                     part=(ws, "l%d.merge.part" % li))
+        if kp == 9 * C and E.conv_gemm_nhwc_supported(cur.dtype, C, 3, 3, 2, 1):
+            # round 6: the window is the product's operand loader -- no gathered copy of the map (mlpk_conv_gemm_nhwc)
+            got = E.conv_gemm_nhwc(cur, pk["l%d.merge.w" % li], nxt, B, H, W, C, 3, 3, 2, 1, bias=pk["l%d.merge.b" % li], tag="hire_merge",
+                                   part=(ws, "l%d.merge.part" % li))
+        else:
+            cols = ws.get("l%d.cols" % li, (B * H2 * W2, kp))
+            E.im2col(cur, cols, B, C, H, W, 3, 3, 2, 2, 1, kp, layout=N.LAYOUT_NHWC, px_stride=C)
+            got = E.gemm(cols, pk["l%d.merge.w" % li], nxt, B * H2 * W2, Cout, kp, bias=pk["l%d.merge.b" % li], tag="hire_merge",
+                         part=(ws, "l%d.merge.part" % li))
         return nxt, H2, W2, Cout, finalize_stats(ws, got, B * H2 * W2, Cout, tag="l%d.ln" % (li + 1))
 
     def _run_single(self, key, x):

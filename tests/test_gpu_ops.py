@@ -1376,6 +1376,39 @@ def test_stem7_direct_convolution(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_conv_gemm_nhwc_is_im2col_plus_gemm(dtype):
+    """mlpk_conv_gemm_nhwc (ABI 12): the strided 3 x 3 transitions of hire_mlp.py:161 / cycle_mlp.py:220-231 as one product whose operand loader is the
+    window (zero slabs outside the map) -- BIT-EQUAL to mlpk_im2col + mlpk_gemm_nt on the same tile (algo 12), which the model goldens hold to the
+    reference; Hire-MLP's / CycleMLP's three transitions at small batch, odd maps, a 2 x 2 stride-2 window without padding, by-product statistics."""
+    pkg = load_pkg()
+    E, N = pkg.engine, pkg._native
+
+    class WS:
+        def get(self, name, shape, dt):
+            return torch.full(shape, float("nan"), dtype=dt, device=dev())
+    for ci, (B, H, W, Cin, Cout, k, st, pad) in enumerate([(3, 56, 56, 64, 128, 3, 2, 1), (2, 28, 28, 128, 320, 3, 2, 1), (2, 14, 14, 320, 512, 3, 2, 1), (2, 9, 7, 32, 72, 3, 2, 1),
+                                                            (2, 8, 12, 96, 192, 2, 2, 0), (1, 5, 5, 64, 64, 3, 1, 1)]):
+        assert E.conv_gemm_nhwc_supported(dtype, Cin, k, k, st, pad)
+        Ho, Wo = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1
+        K = k * k * Cin
+        x = rnd((B * H * W, Cin), dtype, 1900 + ci).to(dev())
+        w = (rnd((Cout, K), dtype, 1910 + ci) / math.sqrt(K)).to(dtype).to(dev())
+        bias = rnd((Cout,), torch.float32, 1920 + ci).to(dev())
+        cols = torch.full((B * Ho * Wo, K), float("nan"), dtype=dtype, device=dev())
+        E.im2col(x, cols, B, Cin, H, W, k, k, st, st, pad, K, layout=N.LAYOUT_NHWC, px_stride=Cin)
+        want = torch.full((B * Ho * Wo, Cout), float("nan"), dtype=dtype, device=dev())
+        part_w = E.gemm(cols, w, want, B * Ho * Wo, Cout, K, bias=bias, algo=12, part=(WS(), "a"))
+        got = torch.full_like(want, float("nan"))
+        part_g = E.conv_gemm_nhwc(x, w, got, B, H, W, Cin, k, k, st, pad, bias=bias, part=(WS(), "b"))
+        torch.cuda.synchronize()
+        assert not torch.isnan(got.float()).any() and torch.equal(got, want), (str(dtype), ci, (got.float() - want.float()).abs().max().item())
+        assert (part_w is None) == (part_g is None)
+        if part_g is not None:
+            assert part_g[1] == part_w[1] and torch.equal(part_g[0], part_w[0]), (str(dtype), ci)
+    assert not E.conv_gemm_nhwc_supported(dtype, 48, 3, 3, 2, 1) and not E.conv_gemm_nhwc_supported(torch.float32, 64, 3, 3, 2, 1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_gemm_pair_gives_the_bits_of_two_calls(dtype):
     """mlpk_gemm_nt_pair (ABI 12): two independent products in one launch where the dispatch gives both the same "s3" tile -- Hire-MLP's proj_h / proj_w
     pairs (hire_mlp.py:139-143) at their stage-3 and stage-1 sizes, with GELU and without -- and the fall-back (different tile families, fp32): in every case
