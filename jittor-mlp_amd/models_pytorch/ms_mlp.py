@@ -239,12 +239,20 @@ class MS_MLP(StochasticDepth, E.EngineModule):
             f"Input image size ({H}*{W}) doesn't match model ({d.img_size[0]}*{d.img_size[1]})."
         H2, W2, C2 = H // 2, W // 2, d.embed_dim
         kp = pk[p + "w"].shape[1]
-        cols = ws.get("l%d.cols" % li, (B * H2 * W2, kp))
-        E.patchify(cur, cols, B, C, H, W, 2, 2, 0, kp, layout=N.LAYOUT_NHWC, px_stride=C)
         nxt = ws.get("l%d.x" % (li + 1), (B * H2 * W2, C2))
-        E.gemm(cols, pk[p + "w"], nxt, B * H2 * W2, C2, kp, bias=pk[p + "b"], tag="ms_down")
+        st = None
+        if kp == 4 * C and H % 2 == 0 and W % 2 == 0 and E.conv_gemm_nhwc_supported(cur.dtype, C, 2, 2, 2, 0):
+            # round 6: the 2 x 2 window is the product's operand loader (mlpk_conv_gemm_nhwc) -- no gathered copy -- and its epilogue delivers the
+            # statistics of the LayerNorm that follows
+            got = E.conv_gemm_nhwc(cur, pk[p + "w"], nxt, B, H, W, C, 2, 2, 2, 0, bias=pk[p + "b"], tag="ms_down",
+                                   part=(ws, "l%d.down.part" % li) if d.norm is not None else None)
+            st = finalize_stats(ws, got, B * H2 * W2, C2, tag="l%d.down.ln" % li, eps=MS_EPS) if d.norm is not None else None
+        else:
+            cols = ws.get("l%d.cols" % li, (B * H2 * W2, kp))
+            E.patchify(cur, cols, B, C, H, W, 2, 2, 0, kp, layout=N.LAYOUT_NHWC, px_stride=C)
+            E.gemm(cols, pk[p + "w"], nxt, B * H2 * W2, C2, kp, bias=pk[p + "b"], tag="ms_down")
         if d.norm is not None:
-            mean, rstd = layernorm_stats(ws, nxt, B * H2 * W2, C2, tag="l%d.down.ln" % li, eps=MS_EPS)
+            mean, rstd = st if st is not None else layernorm_stats(ws, nxt, B * H2 * W2, C2, tag="l%d.down.ln" % li, eps=MS_EPS)
             E.norm_apply(nxt, B * H2 * W2, C2, C2, mean=mean, rstd=rstd, gamma=pk[p + "g"], beta=pk[p + "be"], out_rm=nxt, ld_rm=C2)
         return nxt, H2, W2, C2
 
