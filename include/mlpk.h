@@ -173,6 +173,11 @@ int mlpk_gemm_nt(const mlpk_gemm_desc* d, void* stream);
  * mlpk_gemm_nt: the bits of mlpk_im2col + mlpk_gemm_nt on that tile. */
 int mlpk_conv_gemm_nhwc_supported(int dtype, int Cin, int kh, int kw, int stride, int pad);
 int mlpk_conv_gemm_nhwc(const mlpk_gemm_desc* d, int B, int H, int W, int Cin, int kh, int kw, int stride, int pad, void* stream);
+/* round 6 (ABI 12): LayerNorm statistics (two-pass, biased variance, fp32) of the rows PatchMerging normalises -- the concatenation of a 2 x 2 window's four
+ * pixels of a channel-last (B, H, W, C) tensor (swin_mlp.py:203-210, sparse_mlp.py:40-48; the order of the four does not matter to the statistics) -- without
+ * the concatenated tensor: row (b, oy, ox) of B (H/2) (W/2).  16-bit, even H and W, C % 8 == 0, C <= 1536.  With mlpk_conv_gemm_nhwc (k = stride = 2) and
+ * the LayerNorm folded into the reduction weight the merged tensor is never stored. */
+int mlpk_merge2x2_row_stats(int dtype, const void* x, int B, int H, int W, int C, float eps, float* mean, float* rstd, void* stream);
 /* round 6 (ABI 12): two INDEPENDENT products in one launch where the dispatch gives both the same 16-bit "s3" tile family (algo 11..13) -- workgroups
  * [0, tiles of d0) compute d0, the rest d1; every tile exactly as mlpk_gemm_nt computes it (same bits).  Otherwise the two calls one after the other.
  * For the short, latency-bound products of sibling branches (Hire-MLP's proj_h / proj_w pairs, hire_mlp.py:139-143): half the launches, no side stream.

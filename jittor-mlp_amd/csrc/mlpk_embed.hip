@@ -414,6 +414,58 @@ __global__ void __launch_bounds__(256) stem7_kernel(const Stem7Args p) {
     }
 }
 
+// ---- round 6: LayerNorm statistics of 2 x 2 merged rows without the merged tensor (mlpk_merge2x2_row_stats) -----------------------------------------
+// PatchMerging (swin_mlp.py:203-210, sparse_mlp.py:40-48) normalises the concatenation of a 2 x 2 window's four pixels (4 C values) in front of its
+// reduction Linear.  With the reduction running as an implicit-convolution product (mlpk_conv_gemm_nhwc) the concatenated tensor is never stored; its row
+// statistics come from here: one wave per window, the four pixels' 16-byte pieces spread over the lanes, two passes in registers (mean, then centred
+// squares: mlpk_row_stats' definition), biased variance.
+template <typename T>
+__global__ void __launch_bounds__(256) merge2x2_row_stats_kernel(const T* __restrict__ x, int B, int H, int W, int C, float eps, float* __restrict__ mean,
+                                                                 float* __restrict__ rstd) {
+    constexpr int EPV = 16 / (int)sizeof(T);
+    constexpr int MAXV = 12;                                   // pieces per lane: 4 C / EPV / 64 <= 12 (C <= 1536 for 16-bit)
+    const int lane = threadIdx.x & 63;
+    const int H2 = H >> 1, W2 = W >> 1;
+    const long long rows = (long long)B * H2 * W2;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int ox = (int)(row % W2);
+    const long long t = row / W2;
+    const int oy = (int)(t % H2);
+    const long long b = t / H2;
+    const int cv = C / EPV, nv = 4 * cv;
+    float v[MAXV][EPV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            const int q = idx / cv, c = (idx - q * cv) * EPV;
+            const T* src = x + (((b * H + 2 * oy + (q >> 1)) * W + 2 * ox + (q & 1)) * (long long)C + c);
+            T e[EPV];
+            *reinterpret_cast<u32x4*>(e) = *reinterpret_cast<const u32x4*>(src);
+#pragma unroll
+            for (int k = 0; k < EPV; ++k) { v[i][k] = to_f32(e[k]); s += v[i][k]; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    const float mu = s / (float)(4 * C);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (lane + 64 * i < nv) {
+#pragma unroll
+            for (int k = 0; k < EPV; ++k) { const float d = v[i][k] - mu; ss = __builtin_fmaf(d, d, ss); }
+        }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+    if (lane == 0) {
+        mean[row] = mu;
+        rstd[row] = 1.0f / __builtin_sqrtf(ss / (float)(4 * C) + eps);
+    }
+}
+
 }  // namespace mlpk
 
 using namespace mlpk;
@@ -552,6 +604,23 @@ extern "C" int mlpk_stem7(int src_dtype, int dst_dtype, const void* x, int B, in
     }
 #undef S7_NMB
 #undef S7_GO
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mlpk_merge2x2_row_stats(int dtype, const void* x, int B, int H, int W, int C, float eps, float* mean, float* rstd, void* stream);
+
+extern "C" int mlpk_merge2x2_row_stats(int dtype, const void* x, int B, int H, int W, int C, float eps, float* mean, float* rstd, void* stream) {
+    if (!x || !mean || !rstd) return MLPK_ENULL;
+    if (dtype != MLPK_F16 && dtype != MLPK_BF16) return MLPK_EDTYPE;
+    if (B <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1) || C < 8 || C % 8 || 4 * (C / 8) > 12 * 64 || !(eps > 0.f)) return MLPK_ESHAPE;
+    if ((uintptr_t)x & 15) return MLPK_EALIGN;
+    const long long rows = (long long)B * (H / 2) * (W / 2);
+    const long long wgs = (rows + 3) / 4;
+    if (wgs > 0x7fffffffll) return MLPK_ESHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MLPK_F16) hipLaunchKernelGGL(merge2x2_row_stats_kernel<f16_t>, dim3((unsigned)wgs), dim3(256), 0, s, (const f16_t*)x, B, H, W, C, eps, mean, rstd);
+    else hipLaunchKernelGGL(merge2x2_row_stats_kernel<bf16_t>, dim3((unsigned)wgs), dim3(256), 0, s, (const bf16_t*)x, B, H, W, C, eps, mean, rstd);
     MLPK_LAUNCH_CHECK();
     return 0;
 }

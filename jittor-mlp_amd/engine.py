@@ -270,6 +270,18 @@ def conv_gemm_nhwc(x, w, out, B, H, W, Cin, kh, kw, stride, pad, **kw_gemm):
     return o
 
 
+def merge2x2_row_stats(x, B, H, W, C, mean, rstd, eps=1e-5):
+    """LayerNorm statistics of the 2 x 2 merged rows (4 C values per window) of a channel-last tensor, without the merged tensor"""
+    N.check(N.lib().mlpk_merge2x2_row_stats(dtype_code(x.dtype), ptr(x), B, H, W, C, eps, ptr(mean), ptr(rstd), stream()), "mlpk_merge2x2_row_stats")
+
+
+def merge_taps(w, C):
+    """PatchMerging's weight columns (x0 | x1 | x2 | x3 = window positions (0,0), (1,0), (0,1), (1,1): swin_mlp.py:203-207) in mlpk_conv_gemm_nhwc's tap order
+    (row-major: (0,0), (0,1), (1,0), (1,1)): the middle two blocks of C columns swapped"""
+    n = w.shape[0]
+    return w[:, :4 * C].reshape(n, 4, C)[:, [0, 2, 1, 3]].reshape(n, 4 * C).contiguous()
+
+
 GEMM_LOG = None
 CHANNEL_CHUNKS = int(os.environ.get("MLPK_CHANNEL_CHUNKS", "0"))      # 0 = by size (below); tuning override
 

@@ -303,6 +303,8 @@ class AS_MLP(E.EngineModule):
                 pk[p + "g"], pk[p + "b"] = _gn_params(layer.downsample.norm, device)
                 pk[p + "w"] = E.pack_matrix(layer.downsample.reduction.weight, dtype, device)
                 conv(p + "f", layer.downsample.reduction, layer.downsample.norm)
+                if dtype != torch.float32 and (p + "f.w") in pk:
+                    pk[p + "f.wc"] = E.merge_taps(pk[p + "f.w"], pk[p + "f.w"].shape[1] // 4)     # round 6: the reduction as an implicit-convolution product
         pk["norm.g"], pk["norm.b"] = _gn_params(self.norm, device)
         if isinstance(self.head, nn.Linear):
             pk["head.w"] = E.pack_matrix(self.head.weight, dtype, device)
@@ -436,9 +438,23 @@ class AS_MLP(E.EngineModule):
                 assert H % 2 == 0 and W % 2 == 0, f"x size ({H}*{W}) are not even."                   # as_mlp.py:203
                 p = "l%d.down." % li
                 H2, W2 = H // 2, W // 2
+                nxt = ws.get("l%d.x" % (li + 1), (B * H2 * W2, 2 * C))
+                implicit = cd != torch.float32 and (p + "f.wc") in pk and pk[p + "f.w"].shape[1] == 4 * C and E.conv_gemm_nhwc_supported(cd, C, 2, 2, 2, 0)
+                if implicit:
+                    # round 6: no merged tensor -- GroupNorm(1, 4C) of it normalises over the same elements per sample as one over `cur`, and the
+                    # reduction reads `cur` through the 2 x 2 window (mlpk_conv_gemm_nhwc, the weight's column blocks in its tap order)
+                    if have:
+                        mm, mr = mean, rstd
+                    else:
+                        mm = ws.get("l%d.gnm.mean" % li, (B,), torch.float32)
+                        mr = ws.get("l%d.gnm.rstd" % li, (B,), torch.float32)
+                        E.row_stats(cur, B, H * W * C, H * W * C, mm, mr)
+                    pending = E.conv_gemm_nhwc(cur, pk[p + "f.wc"], nxt, B, H, W, C, 2, 2, 2, 0, bias=pk[p + "f.b"], ln=(mm, mr, pk[p + "f.csum"]),
+                                               ln_group=H2 * W2, tag="as_merge", part=(ws, "l%d.mpart" % li) if EPILOGUE_STATS else None)
+                    cur, H, W, C = nxt, H2, W2, 2 * C
+                    continue
                 merged = ws.get("l%d.merged" % li, (B * H2 * W2, 4 * C))
                 E.patchify(cur, merged, B, C, H, W, 2, 2, 0, 4 * C, layout=N.LAYOUT_NHWC, px_stride=C, order=1)
-                nxt = ws.get("l%d.x" % (li + 1), (B * H2 * W2, 2 * C))
                 if cd != torch.float32:
                     if have:
                         # GroupNorm(1, 4C) of the merged tensor (as_mlp.py:212) normalises over the same elements per sample as

@@ -17,6 +17,8 @@ One entry of sMLPStage.model (sparse_mlp.py:84-104), on channel-last activations
 PatchMerging (:17-52) = 2x2 space-to-depth gather + LayerNorm(4C) folded into the bias-free reduction GEMM.
 Head (:151-157) = LayerNorm folded into the token mean, then one small GEMM.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -155,6 +157,8 @@ class SparseMLP(E.EngineModule):
                 p = "l%d.merge." % li
                 pk[p + "w"], pk[p + "b"], pk[p + "csum"] = E.pack_ln_folded(pm.reduction.weight, None, pm.norm.weight, pm.norm.bias,
                                                                              dtype, device)
+                if dtype != torch.float32:
+                    pk[p + "wc"] = E.merge_taps(pk[p + "w"], pm.norm.weight.shape[0] // 4)       # round 6: the reduction as an implicit-convolution product
         pk["head.g"], pk["head.be"] = E.f32(self.mlp_head[1].weight, device), E.f32(self.mlp_head[1].bias, device)
         pk["head.w"] = E.pack_matrix(self.mlp_head[3].weight, dtype, device)
         pk["head.b"] = E.f32(self.mlp_head[3].bias, device)
@@ -262,10 +266,20 @@ class SparseMLP(E.EngineModule):
         assert H % 2 == 0 and W % 2 == 0, f"x size ({H}*{W}) are not even."                      # sparse_mlp.py:38
         p = "l%d.merge." % li
         H2, W2 = H // 2, W // 2
+        nxt = ws.get("l%d.x" % (li + 1), (B * H2 * W2, 2 * C))
+        # (opt-in, MLPK_MERGE_IMPLICIT=1: measured neutral to -0.9 % here -- the statistics pass over the windows costs what the gather saved;
+        #  AS-MLP, whose GroupNorm statistics are already there, uses the same product by default: profiles/r06_conv_gemm_ab.txt)
+        if (os.environ.get("MLPK_MERGE_IMPLICIT") == "1" and (p + "wc") in pk and pk[p + "w"].shape[1] == 4 * C
+                and E.conv_gemm_nhwc_supported(cur.dtype, C, 2, 2, 2, 0)):
+            # round 6: no merged tensor (mlpk_merge2x2_row_stats + mlpk_conv_gemm_nhwc, the weight's column blocks in its tap order)
+            mean = ws.get("l%d.merge.ln.mean" % li, (B * H2 * W2,), torch.float32)
+            rstd = ws.get("l%d.merge.ln.rstd" % li, (B * H2 * W2,), torch.float32)
+            E.merge2x2_row_stats(cur, B, H, W, C, mean, rstd, eps=self.layers[li].patch_merge[1].norm.eps)
+            E.conv_gemm_nhwc(cur, pk[p + "wc"], nxt, B, H, W, C, 2, 2, 2, 0, bias=pk[p + "b"], ln=(mean, rstd, pk[p + "csum"]), tag="smlp_merge")
+            return nxt
         merged = ws.get("l%d.merged" % li, (B * H2 * W2, 4 * C))
         E.patchify(cur, merged, B, C, H, W, 2, 2, 0, 4 * C, layout=N.LAYOUT_NHWC, px_stride=C, order=1)
         mean, rstd = layernorm_stats(ws, merged, B * H2 * W2, 4 * C, tag="l%d.merge.ln" % li)
-        nxt = ws.get("l%d.x" % (li + 1), (B * H2 * W2, 2 * C))
         E.gemm(merged, pk[p + "w"], nxt, B * H2 * W2, 2 * C, 4 * C, bias=pk[p + "b"], ln=(mean, rstd, pk[p + "csum"]), tag="smlp_merge")
         return nxt
 

@@ -194,6 +194,8 @@ class SwinMLP(StochasticDepth, E.EngineModule):
                 pm = layer.downsample
                 p = "l%d.merge." % li
                 pk[p + "w"], pk[p + "b"], pk[p + "csum"] = E.pack_ln_folded(pm.reduction.weight, None, pm.norm.weight, pm.norm.bias, dtype, device)
+                if dtype != torch.float32:
+                    pk[p + "wc"] = E.merge_taps(pk[p + "w"], pm.norm.weight.shape[0] // 4)       # round 6: the reduction as an implicit-convolution product
         pk["norm.g"], pk["norm.b"] = E.f32(self.norm.weight, device), E.f32(self.norm.bias, device)
         if isinstance(self.head, nn.Linear):
             pk["head.w"] = E.pack_matrix(self.head.weight, dtype, device)
@@ -257,12 +259,24 @@ class SwinMLP(StochasticDepth, E.EngineModule):
         assert H % 2 == 0 and W % 2 == 0, f"x size ({H}*{W}) are not even."                                 # swin_mlp.py:201
         p = "l%d.merge." % li
         H2, W2 = H // 2, W // 2
-        merged = ws_.get("l%d.merged" % li, (B * H2 * W2, 4 * C))
-        E.patchify(cur, merged, B, C, H, W, 2, 2, 0, 4 * C, layout=N.LAYOUT_NHWC, px_stride=C, order=1)
-        mean, rstd = layernorm_stats(ws_, merged, B * H2 * W2, 4 * C, tag="l%d.merge.ln" % li)
         nxt = ws_.get("l%d.x" % (li + 1), (B * H2 * W2, 2 * C))
-        got = E.gemm(merged, pk[p + "w"], nxt, B * H2 * W2, 2 * C, 4 * C, bias=pk[p + "b"], ln=(mean, rstd, pk[p + "csum"]), tag="swin_merge",
-                     part=(ws_, "l%d.merge.part" % li))
+        # (opt-in, MLPK_MERGE_IMPLICIT=1: measured neutral to -0.9 % here -- the statistics pass over the windows costs what the gather saved;
+        #  AS-MLP, whose GroupNorm statistics are already there, uses the same product by default: profiles/r06_conv_gemm_ab.txt)
+        if (os.environ.get("MLPK_MERGE_IMPLICIT") == "1" and (p + "wc") in pk and pk[p + "w"].shape[1] == 4 * C
+                and E.conv_gemm_nhwc_supported(cur.dtype, C, 2, 2, 2, 0)):
+            # round 6: no merged tensor -- its LayerNorm statistics from the four pixels of every window (mlpk_merge2x2_row_stats), the reduction as a product
+            # whose operand loader is the window (mlpk_conv_gemm_nhwc; the weight's column blocks in its tap order)
+            mean = ws_.get("l%d.merge.ln.mean" % li, (B * H2 * W2,), torch.float32)
+            rstd = ws_.get("l%d.merge.ln.rstd" % li, (B * H2 * W2,), torch.float32)
+            E.merge2x2_row_stats(cur, B, H, W, C, mean, rstd, eps=self.layers[li].downsample.norm.eps)
+            got = E.conv_gemm_nhwc(cur, pk[p + "wc"], nxt, B, H, W, C, 2, 2, 2, 0, bias=pk[p + "b"], ln=(mean, rstd, pk[p + "csum"]), tag="swin_merge",
+                                   part=(ws_, "l%d.merge.part" % li))
+        else:
+            merged = ws_.get("l%d.merged" % li, (B * H2 * W2, 4 * C))
+            E.patchify(cur, merged, B, C, H, W, 2, 2, 0, 4 * C, layout=N.LAYOUT_NHWC, px_stride=C, order=1)
+            mean, rstd = layernorm_stats(ws_, merged, B * H2 * W2, 4 * C, tag="l%d.merge.ln" % li)
+            got = E.gemm(merged, pk[p + "w"], nxt, B * H2 * W2, 2 * C, 4 * C, bias=pk[p + "b"], ln=(mean, rstd, pk[p + "csum"]), tag="swin_merge",
+                         part=(ws_, "l%d.merge.part" % li))
         return nxt, finalize_stats(ws_, got, B * H2 * W2, 2 * C, tag="l%d.ln" % (li + 1))
 
     def _run_single(self, key, x):

@@ -1409,6 +1409,37 @@ def test_conv_gemm_nhwc_is_im2col_plus_gemm(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_patch_merging_without_the_merged_tensor(dtype):
+    """PatchMerging (swin_mlp.py:193-212; sparse_mlp.py:33-50) without the concatenated tensor: mlpk_merge2x2_row_stats gives the LayerNorm statistics of the
+    4 C-wide rows, mlpk_conv_gemm_nhwc multiplies through the 2 x 2 window with the weight's column blocks in tap order (engine.merge_taps) and the LayerNorm
+    folded in -- against the reference's own lines (strided slices, cat, LayerNorm, Linear) in fp64 on the rounded operands."""
+    pkg = load_pkg()
+    E = pkg.engine
+    F = torch.nn.functional
+    for ci, (B, H, W, C) in enumerate([(2, 8, 8, 96), (3, 14, 6, 32), (1, 28, 28, 192), (2, 4, 6, 384)]):
+        x = (rnd((B, H, W, C), dtype, 2000 + ci) * 1.3 + 0.2).to(dtype)
+        wlin = rnd((2 * C, 4 * C), torch.float32, 2010 + ci, 1.0 / math.sqrt(4 * C))
+        gamma, beta = rnd((4 * C,), torch.float32, 2020 + ci) * 0.3 + 1.0, rnd((4 * C,), torch.float32, 2030 + ci) * 0.2
+        rows = B * (H // 2) * (W // 2)
+        mean = torch.full((rows,), float("nan"), dtype=torch.float32, device=dev()); rstd = torch.full_like(mean, float("nan"))
+        xg = x.reshape(B * H * W, C).to(dev())
+        E.merge2x2_row_stats(xg, B, H, W, C, mean, rstd, eps=1e-5)
+        xd = x.double()
+        cat = torch.cat([xd[:, 0::2, 0::2], xd[:, 1::2, 0::2], xd[:, 0::2, 1::2], xd[:, 1::2, 1::2]], -1).reshape(rows, 4 * C)      # swin_mlp.py:203-208
+        torch.cuda.synchronize()
+        assert (mean.cpu().double() - cat.mean(1)).abs().max().item() < 1e-5 * max(1.0, cat.abs().max().item()), (str(dtype), ci)
+        want_r = 1.0 / torch.sqrt(cat.var(1, unbiased=False) + 1e-5)
+        assert ((rstd.cpu().double() - want_r).abs() / want_r).max().item() < 1e-4, (str(dtype), ci)
+        wp, bp, csum = E.pack_ln_folded(wlin, None, gamma, beta, dtype, dev())
+        out = torch.full((rows, 2 * C), float("nan"), dtype=dtype, device=dev())
+        E.conv_gemm_nhwc(xg, E.merge_taps(wp, C), out, B, H, W, C, 2, 2, 2, 0, bias=bp, ln=(mean, rstd, csum))
+        torch.cuda.synchronize()
+        ref = F.linear(F.layer_norm(cat, (4 * C,), gamma.double(), beta.double(), 1e-5), wlin.double())
+        err = (out.double().cpu() - ref).abs().max().item()
+        assert torch.isfinite(out.float()).all() and err < EPS[dtype] * 12 * max(1.0, ref.abs().max().item()), (str(dtype), ci, err)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_gemm_pair_gives_the_bits_of_two_calls(dtype):
     """mlpk_gemm_nt_pair (ABI 12): two independent products in one launch where the dispatch gives both the same "s3" tile -- Hire-MLP's proj_h / proj_w
     pairs (hire_mlp.py:139-143) at their stage-3 and stage-1 sizes, with GELU and without -- and the fall-back (different tile families, fp32): in every case
