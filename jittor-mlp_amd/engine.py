@@ -132,6 +132,14 @@ def pack_matrix(w, dtype, device, kpad=8):
     return out
 
 
+def embed_kpad(dtype):
+    """K padding of a patch-embedding weight whose K is ragged (7 x 7 x 3 = 147): whole 64-byte slabs for the 16-bit dtypes, so that the product runs on the
+    LDS-DMA tiles instead of the register-staged fallback (ConvMixer-1536/20's embedding: 565 us at K = 152); MLPK_EMBED_KPAD overrides (A/B aid)"""
+    if os.environ.get("MLPK_EMBED_KPAD"):
+        return int(os.environ["MLPK_EMBED_KPAD"])
+    return 8 if dtype == torch.float32 else 32
+
+
 def pack_ln_folded(w, b, gamma, beta, dtype, device, kpad=8):
     """Fold LayerNorm(gamma, beta) into the Linear(w, b) that consumes it:
     LN(x) W^T + b = rstd * (x W'^T - mu * csum) + b',  W' = W diag(gamma), csum[n] = sum_k W'[n,k]

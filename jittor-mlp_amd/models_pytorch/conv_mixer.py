@@ -74,7 +74,7 @@ class ConvMixer(E.EngineModule):
         dim, depth, k, patch, _ = self._cfg
         _check_k(k)
         pk = {}
-        pk["embed.w"] = E.pack_matrix(self.embedding[0].weight, dtype, device)
+        pk["embed.w"] = E.pack_matrix(self.embedding[0].weight, dtype, device, kpad=E.embed_kpad(dtype))
         pk["embed.b"] = E.f32(self.embedding[0].bias, device)
         pk["embed.s"], pk["embed.h"] = _bn_affine(self.embedding[2], device)
         for i, blk in enumerate(self.blocks):

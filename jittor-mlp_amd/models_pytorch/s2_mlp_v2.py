@@ -221,7 +221,7 @@ class S2MLPv2(E.EngineModule):
             w = conv.weight
             if s > 0:                                              # channel-last source: k = (i*pw + j)*Cin + ci
                 w = w.permute(0, 2, 3, 1)
-            pk["s%d.embed.w" % s] = E.pack_matrix(w.reshape(w.shape[0], -1), dtype, device)
+            pk["s%d.embed.w" % s] = E.pack_matrix(w.reshape(w.shape[0], -1), dtype, device, kpad=E.embed_kpad(dtype))
             pk["s%d.embed.b" % s] = E.f32(conv.bias, device)
             blk._pack_blocks(pk, dtype, device, "s%d." % s)
         pk["head.w"] = E.pack_matrix(self.mlp_head[1].weight, dtype, device)

@@ -357,7 +357,7 @@ class ViP(E.EngineModule):
     def _pack(self, dtype, device):
         pk = {}
         self.blocks._pack_blocks(pk, dtype, device)
-        pk["embed.w"] = E.pack_matrix(self.patcher[0].weight, dtype, device)
+        pk["embed.w"] = E.pack_matrix(self.patcher[0].weight, dtype, device, kpad=E.embed_kpad(dtype))
         pk["embed.b"] = E.f32(self.patcher[0].bias, device)
         pk["head.ln.g"], pk["head.ln.b"] = E.f32(self.mlp_head[0].weight, device), E.f32(self.mlp_head[0].bias, device)
         pk["head.w"] = E.pack_matrix(self.mlp_head[2].weight, dtype, device)
