@@ -479,7 +479,7 @@ class AS_MLP(E.EngineModule):
         C = self.embed_dim
         kp = pk["embed.w"].shape[1]
         cur = ws.get("l0.x", (B * H * W, C))
-        if (ph, pw) == (4, 4) and E.patch_embed4_supported(x.dtype, cur.dtype, pe.in_chans, H_in, W_in, C):
+        if (ph, pw) == (4, 4) and x.data_ptr() % 16 == 0 and E.patch_embed4_supported(x.dtype, cur.dtype, pe.in_chans, H_in, W_in, C):
             E.patch_embed4(x, pk["embed.w"], pk["embed.b"], cur, B, H_in, W_in, C)            # round 6: gather + product in one kernel
         else:
             patches = ws.get("embed.patches", (B * H * W, kp))

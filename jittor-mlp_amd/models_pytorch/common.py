@@ -183,7 +183,8 @@ def embed_patches(ws, name, x, w_packed, bias, cdtype, patch, pad=0, out=None, l
     rows = B * hp * wp
     if out is None:
         out = ws.get(name + ".tokens", (rows, cout))
-    if (ph, pw) == (4, 4) and pad == 0 and out.stride(0) == cout and E.patch_embed4_supported(x.dtype, out.dtype, cin, H, W, cout):
+    if ((ph, pw) == (4, 4) and pad == 0 and out.stride(0) == cout and x.data_ptr() % 16 == 0
+            and E.patch_embed4_supported(x.dtype, out.dtype, cin, H, W, cout)):
         g, b_, eps = ln if ln is not None else (None, None, 1e-5)
         E.patch_embed4(x, w_packed, bias, out, B, H, W, cout, gamma=g, beta=b_, eps=eps)
         return out, hp, wp

@@ -331,7 +331,7 @@ class CycleNet(StochasticDepth, E.EngineModule):
                 H, W = (H_in + 4 - 7) // 4 + 1, (W_in + 4 - 7) // 4 + 1
                 kp = pk["embed.w"].shape[1]
                 cur = ws.get("n0.x", (B * H * W, C))
-                if "embed.w7" in pk and E.stem7_supported(x.dtype, cur.dtype, cin, H_in, W_in, 2, C):
+                if "embed.w7" in pk and x.data_ptr() % 16 == 0 and E.stem7_supported(x.dtype, cur.dtype, cin, H_in, W_in, 2, C):
                     E.stem7(x.contiguous(), pk["embed.w7"], pk["embed.b"], cur, B, H_in, W_in, 2, C)
                 else:
                     patches = ws.get("embed.patches", (B * H * W, kp))
@@ -457,7 +457,7 @@ class CycleNet(StochasticDepth, E.EngineModule):
         H, W = (H_in + 4 - 7) // 4 + 1, (W_in + 4 - 7) // 4 + 1
         kp = pk["embed.w"].shape[1]
         cur = ws.get("n0.x", (B * H * W, C))
-        if "embed.w7" in pk and E.stem7_supported(x.dtype, cur.dtype, cin, H_in, W_in, 2, C):
+        if "embed.w7" in pk and x.data_ptr() % 16 == 0 and E.stem7_supported(x.dtype, cur.dtype, cin, H_in, W_in, 2, C):
             # round 6: the stem as a direct convolution, delivering the first block's LayerNorm statistics too
             st = (ws.get("n0.ln.mean", (B * H * W,), torch.float32), ws.get("n0.ln.rstd", (B * H * W,), torch.float32))
             E.stem7(x, pk["embed.w7"], pk["embed.b"], cur, B, H_in, W_in, 2, C, out_stats=st, eps=self.network[0][0].norm1.eps)

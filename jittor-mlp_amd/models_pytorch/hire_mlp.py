@@ -292,7 +292,7 @@ class HireMLP(E.EngineModule):
         H, W = (H_in + 6 - 7) // patch[0] + 1, (W_in + 6 - 7) // patch[1] + 1
         kp = pk["embed.w"].shape[1]
         cur = ws.get("l0.x", (B * H * W, C))
-        if "embed.w7" in pk and E.stem7_supported(x.dtype, cur.dtype, cin, H_in, W_in, 3, C):
+        if "embed.w7" in pk and x.data_ptr() % 16 == 0 and E.stem7_supported(x.dtype, cur.dtype, cin, H_in, W_in, 3, C):
             E.stem7(x, pk["embed.w7"], pk["embed.b"], cur, B, H_in, W_in, 3, C)
         else:
             patches = ws.get("embed.patches", (B * H * W, kp))
