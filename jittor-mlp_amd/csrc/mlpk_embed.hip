@@ -324,24 +324,37 @@ __global__ void __launch_bounds__(256) stem7_kernel(const Stem7Args p) {
         const TS* __restrict__ x = reinterpret_cast<const TS*>(p.x) + (size_t)b * 3 * p.H * p.W;
         const int vpr = p.W / 8;                                          // 8-pixel pieces per image row
         const int y0 = 4 * oy0 - p.pad;
-        for (int i = tid; i < 33 * vpr; i += 256) {
-            const int row = i / vpr, v = i - row * vpr;                   // row = ci * 11 + r
-            const int ci = row / 11, r = row - ci * 11;
-            const int y = y0 + r;
-            if (y < 0 || y >= p.H) continue;
-            const TS* src = x + ((size_t)ci * p.H + y) * p.W + v * 8;
-            T e[8];
-            if constexpr (sizeof(TS) == 4) {
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 4);
-                e[0] = from_f32<T>(a0.x); e[1] = from_f32<T>(a0.y); e[2] = from_f32<T>(a0.z); e[3] = from_f32<T>(a0.w);
-                e[4] = from_f32<T>(a1.x); e[5] = from_f32<T>(a1.y); e[6] = from_f32<T>(a1.z); e[7] = from_f32<T>(a1.w);
-            } else {
-                const u32x4 raw = *reinterpret_cast<const u32x4*>(src);
-                __builtin_memcpy(e, &raw, 16);
-            }
-            T* dst = tile + row * pitch + v * 8 + p.pad;
+        const int total = 33 * vpr;
+        // four pieces per thread and pass, their loads UNCONDITIONAL (a row outside the image reads row 0 and is not written) and in flight together:
+        // behind `continue` every load waited for the one before it
+        for (int base = tid; base < total; base += 4 * 256) {
+            T e[4][8];
+            int dsto[4];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) dst[q] = e[q];
+            for (int u = 0; u < 4; ++u) {
+                const int i = base + u * 256;
+                const int ic = i < total ? i : total - 1;
+                const int row = ic / vpr, v = ic - row * vpr;             // row = ci * 11 + r
+                const int ci = row / 11, r = row - ci * 11;
+                const int y = y0 + r;
+                const bool ok = i < total && y >= 0 && y < p.H;
+                const TS* src = x + ((size_t)ci * p.H + (ok ? y : 0)) * p.W + v * 8;
+                if constexpr (sizeof(TS) == 4) {
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 4);
+                    e[u][0] = from_f32<T>(a0.x); e[u][1] = from_f32<T>(a0.y); e[u][2] = from_f32<T>(a0.z); e[u][3] = from_f32<T>(a0.w);
+                    e[u][4] = from_f32<T>(a1.x); e[u][5] = from_f32<T>(a1.y); e[u][6] = from_f32<T>(a1.z); e[u][7] = from_f32<T>(a1.w);
+                } else {
+                    const u32x4 raw = *reinterpret_cast<const u32x4*>(src);
+                    __builtin_memcpy(e[u], &raw, 16);
+                }
+                dsto[u] = ok ? row * pitch + v * 8 + p.pad : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (dsto[u] < 0) continue;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) tile[dsto[u] + q] = e[u][q];
+            }
         }
     }
     __syncthreads();

@@ -14,7 +14,8 @@ x = torch.rand(256, 3, 224, 224, device="cuda").bfloat16()
 NAMES = ["gemm", "linear_gelu", "token_gemm_ln", "token_gemm", "token_mlp", "token_mlp_ln", "stats_finalize_planar", "row_stats", "norm_apply", "channel_mlp_fused",
          "vip_branch", "vip_split_apply", "vip_unpermute", "split_sum", "split_softmax", "split_apply", "s2_shift", "dwconv_nhwc", "dwconv_affine_nhwc", "im2col",
          "patchify", "pool_mean", "as_conv2", "norm_shift_nhwc", "smlp_mix", "smlp_mix_dw", "swin_spatial", "hire_gather_ln", "hire_combine_from", "mixshift_nhwc",
-         "cycle_shift_ln", "layernorm_transpose", "add_periodic", "convert"]
+         "cycle_shift_ln", "layernorm_transpose", "add_periodic", "convert", "stem7", "patch_embed4", "conv_gemm_nhwc", "merge2x2_row_stats", "hire_combine_stats",
+         "im2col", "hire_gather_ln"]
 NAMES = [n for n in NAMES if hasattr(E, n)]
 orig = {n: getattr(E, n) for n in NAMES}
 log = []          # (name, args, kwargs, ev0, ev1)
