@@ -178,6 +178,10 @@ int mlpk_conv_gemm_nhwc(const mlpk_gemm_desc* d, int B, int H, int W, int Cin, i
  * the concatenated tensor: row (b, oy, ox) of B (H/2) (W/2).  16-bit, even H and W, C % 8 == 0, C <= 1536.  With mlpk_conv_gemm_nhwc (k = stride = 2) and
  * the LayerNorm folded into the reduction weight the merged tensor is never stored. */
 int mlpk_merge2x2_row_stats(int dtype, const void* x, int B, int H, int W, int C, float eps, float* mean, float* rstd, void* stream);
+/* ... or from the per-pixel LayerNorm statistics (mean, 1 / sqrt(var + eps_in) over the SAME C channels per pixel) a producer already delivered: the
+ * merged row's mean = the average of the four pixels' means, its variance = avg(var_q + mean_q^2) - mean^2; combined in fp64. */
+int mlpk_merge2x2_stats_combine(const float* mean, const float* rstd, int B, int H, int W, float eps_in, float eps_out, float* out_mean, float* out_rstd,
+                                void* stream);
 /* round 6 (ABI 12): two INDEPENDENT products in one launch where the dispatch gives both the same 16-bit "s3" tile family (algo 11..13) -- workgroups
  * [0, tiles of d0) compute d0, the rest d1; every tile exactly as mlpk_gemm_nt computes it (same bits).  Otherwise the two calls one after the other.
  * For the short, latency-bound products of sibling branches (Hire-MLP's proj_h / proj_w pairs, hire_mlp.py:139-143): half the launches, no side stream.

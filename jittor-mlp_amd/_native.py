@@ -47,6 +47,7 @@ PROTOTYPES = {
     "mlpk_gemm_nt_pair": (c_int, [ctypes.POINTER(GemmDesc), ctypes.POINTER(GemmDesc), c_void_p]),
     "mlpk_conv_gemm_nhwc_supported": (c_int, [c_int] * 6),
     "mlpk_merge2x2_row_stats": (c_int, [c_int, c_void_p] + [c_int] * 4 + [c_float, c_void_p, c_void_p, c_void_p]),
+    "mlpk_merge2x2_stats_combine": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "mlpk_conv_gemm_nhwc": (c_int, [ctypes.POINTER(GemmDesc)] + [c_int] * 8 + [c_void_p]),
     "mlpk_gemm_row_parts": (c_int, [ctypes.POINTER(GemmDesc), ctypes.POINTER(c_int)]),
     "mlpk_gemm_workspace_bytes": (ctypes.c_longlong, []),

@@ -479,6 +479,36 @@ __global__ void __launch_bounds__(256) merge2x2_row_stats_kernel(const T* __rest
     }
 }
 
+// The same statistics from the PER-PIXEL LayerNorm statistics the producing GEMM's epilogue already delivered (mlpk_merge2x2_stats_combine): with
+// var_q = 1 / rstd_q^2 - eps_in of the window's four pixels, mean = avg(mean_q), var = avg(var_q + mean_q^2) - mean^2 -- combined in fp64 (a residual
+// stream's mean can be large against its spread) -- so the merged rows' statistics cost 1.6 MB of traffic instead of a pass over the activations.
+__global__ void __launch_bounds__(256) merge2x2_stats_combine_kernel(const float* __restrict__ mean, const float* __restrict__ rstd, int B, int H, int W, float eps_in,
+                                                                     float eps_out, float* __restrict__ out_mean, float* __restrict__ out_rstd) {
+    const int H2 = H >> 1, W2 = W >> 1;
+    const long long rows = (long long)B * H2 * W2;
+    const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    const int ox = (int)(row % W2);
+    const long long t = row / W2;
+    const int oy = (int)(t % H2);
+    const long long b = t / H2;
+    double sm = 0.0, sv = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long long px = (b * H + 2 * oy + (q >> 1)) * W + 2 * ox + (q & 1);
+        const double m = (double)mean[px], r = (double)rstd[px];
+        double v = 1.0 / (r * r) - (double)eps_in;
+        v = v > 0.0 ? v : 0.0;
+        sm += m;
+        sv += v + m * m;
+    }
+    const double mu = sm * 0.25;
+    double var = sv * 0.25 - mu * mu;
+    var = var > 0.0 ? var : 0.0;
+    out_mean[row] = (float)mu;
+    out_rstd[row] = (float)(1.0 / __builtin_sqrt(var + (double)eps_out));
+}
+
 }  // namespace mlpk
 
 using namespace mlpk;
@@ -634,6 +664,22 @@ extern "C" int mlpk_merge2x2_row_stats(int dtype, const void* x, int B, int H, i
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MLPK_F16) hipLaunchKernelGGL(merge2x2_row_stats_kernel<f16_t>, dim3((unsigned)wgs), dim3(256), 0, s, (const f16_t*)x, B, H, W, C, eps, mean, rstd);
     else hipLaunchKernelGGL(merge2x2_row_stats_kernel<bf16_t>, dim3((unsigned)wgs), dim3(256), 0, s, (const bf16_t*)x, B, H, W, C, eps, mean, rstd);
+    MLPK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mlpk_merge2x2_stats_combine(const float* mean, const float* rstd, int B, int H, int W, float eps_in, float eps_out, float* out_mean, float* out_rstd,
+                                           void* stream);
+
+extern "C" int mlpk_merge2x2_stats_combine(const float* mean, const float* rstd, int B, int H, int W, float eps_in, float eps_out, float* out_mean, float* out_rstd,
+                                           void* stream) {
+    if (!mean || !rstd || !out_mean || !out_rstd) return MLPK_ENULL;
+    if (B <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1) || !(eps_in >= 0.f) || !(eps_out > 0.f)) return MLPK_ESHAPE;
+    const long long rows = (long long)B * (H / 2) * (W / 2);
+    const long long wgs = (rows + 255) / 256;
+    if (wgs > 0x7fffffffll) return MLPK_ESHAPE;
+    hipLaunchKernelGGL(merge2x2_stats_combine_kernel, dim3((unsigned)wgs), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), mean, rstd, B, H, W, eps_in, eps_out,
+                       out_mean, out_rstd);
     MLPK_LAUNCH_CHECK();
     return 0;
 }

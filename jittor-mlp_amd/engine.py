@@ -283,6 +283,11 @@ def merge2x2_row_stats(x, B, H, W, C, mean, rstd, eps=1e-5):
     N.check(N.lib().mlpk_merge2x2_row_stats(dtype_code(x.dtype), ptr(x), B, H, W, C, eps, ptr(mean), ptr(rstd), stream()), "mlpk_merge2x2_row_stats")
 
 
+def merge2x2_stats_combine(mean, rstd, B, H, W, out_mean, out_rstd, eps_in=1e-5, eps_out=1e-5):
+    """the merged rows' LayerNorm statistics from the per-pixel statistics a producer delivered (no pass over the activations)"""
+    N.check(N.lib().mlpk_merge2x2_stats_combine(ptr(mean), ptr(rstd), B, H, W, eps_in, eps_out, ptr(out_mean), ptr(out_rstd), stream()), "mlpk_merge2x2_stats_combine")
+
+
 def merge_taps(w, C):
     """PatchMerging's weight columns (x0 | x1 | x2 | x3 = window positions (0,0), (1,0), (0,1), (1,1): swin_mlp.py:203-207) in mlpk_conv_gemm_nhwc's tap order
     (row-major: (0,0), (0,1), (1,0), (1,1)): the middle two blocks of C columns swapped"""

@@ -254,21 +254,26 @@ class SwinMLP(StochasticDepth, E.EngineModule):
                                   ln=(pk["embed.g"], pk["embed.be"], pe.norm.eps) if pe.norm is not None else None)
         return cur, H, W
 
-    def _merge(self, ws_, pk, li, cur, B, H, W, C):
+    def _merge(self, ws_, pk, li, cur, B, H, W, C, st=None):
         """PatchMerging (swin_mlp.py:193-212): 2 x 2 gather + LayerNorm folded into the bias-free reduction GEMM; returns (next, statistics)"""
         assert H % 2 == 0 and W % 2 == 0, f"x size ({H}*{W}) are not even."                                 # swin_mlp.py:201
         p = "l%d.merge." % li
         H2, W2 = H // 2, W // 2
         nxt = ws_.get("l%d.x" % (li + 1), (B * H2 * W2, 2 * C))
-        # (opt-in, MLPK_MERGE_IMPLICIT=1: measured neutral to -0.9 % here -- the statistics pass over the windows costs what the gather saved;
-        #  AS-MLP, whose GroupNorm statistics are already there, uses the same product by default: profiles/r06_conv_gemm_ab.txt)
-        if (os.environ.get("MLPK_MERGE_IMPLICIT") == "1" and (p + "wc") in pk and pk[p + "w"].shape[1] == 4 * C
-                and E.conv_gemm_nhwc_supported(cur.dtype, C, 2, 2, 2, 0)):
-            # round 6: no merged tensor -- its LayerNorm statistics from the four pixels of every window (mlpk_merge2x2_row_stats), the reduction as a product
-            # whose operand loader is the window (mlpk_conv_gemm_nhwc; the weight's column blocks in its tap order)
+        # round 6: no merged tensor where the last block's GEMM delivered the per-pixel statistics of `cur` (st): the merged rows' LayerNorm statistics are
+        # combined from them (mlpk_merge2x2_stats_combine: 1.6 MB instead of a pass over the activations) and the reduction reads `cur` through the 2 x 2
+        # window (mlpk_conv_gemm_nhwc, the weight's column blocks in its tap order).  Without st: MLPK_MERGE_IMPLICIT=1 takes the statistics from a pass
+        # over the windows (mlpk_merge2x2_row_stats: measured neutral), the default is the gather.
+        implicit = (p + "wc") in pk and pk[p + "w"].shape[1] == 4 * C and E.conv_gemm_nhwc_supported(cur.dtype, C, 2, 2, 2, 0) and \
+            os.environ.get("MLPK_CONV_GEMM", "1") != "0" and (st is not None or os.environ.get("MLPK_MERGE_IMPLICIT") == "1")
+        if implicit:
             mean = ws_.get("l%d.merge.ln.mean" % li, (B * H2 * W2,), torch.float32)
             rstd = ws_.get("l%d.merge.ln.rstd" % li, (B * H2 * W2,), torch.float32)
-            E.merge2x2_row_stats(cur, B, H, W, C, mean, rstd, eps=self.layers[li].downsample.norm.eps)
+            eps_m = self.layers[li].downsample.norm.eps
+            if st is not None:
+                E.merge2x2_stats_combine(st[0], st[1], B, H, W, mean, rstd, eps_in=1e-5, eps_out=eps_m)
+            else:
+                E.merge2x2_row_stats(cur, B, H, W, C, mean, rstd, eps=eps_m)
             got = E.conv_gemm_nhwc(cur, pk[p + "wc"], nxt, B, H, W, C, 2, 2, 2, 0, bias=pk[p + "b"], ln=(mean, rstd, pk[p + "csum"]), tag="swin_merge",
                                    part=(ws_, "l%d.merge.part" % li))
         else:
@@ -418,7 +423,7 @@ class SwinMLP(StochasticDepth, E.EngineModule):
             for bi, blk in enumerate(layer.blocks):
                 st = self._block(ws_, pk, li, bi, blk, cur, B, H, W, C, st)
             if layer.downsample is not None:
-                cur, st = self._merge(ws_, pk, li, cur, B, H, W, C)
+                cur, st = self._merge(ws_, pk, li, cur, B, H, W, C, st)
                 H, W, C = H // 2, W // 2, 2 * C
         mean, rstd = st if st is not None else layernorm_stats(ws_, cur, B * H * W, C, tag="head.ln")
         pooled = ws_.get("pooled", (B, C))

@@ -1430,6 +1430,14 @@ def test_patch_merging_without_the_merged_tensor(dtype):
         assert (mean.cpu().double() - cat.mean(1)).abs().max().item() < 1e-5 * max(1.0, cat.abs().max().item()), (str(dtype), ci)
         want_r = 1.0 / torch.sqrt(cat.var(1, unbiased=False) + 1e-5)
         assert ((rstd.cpu().double() - want_r).abs() / want_r).max().item() < 1e-4, (str(dtype), ci)
+        # ... and the same statistics combined from the per-pixel LayerNorm statistics a producer delivered (mlpk_merge2x2_stats_combine)
+        pm = torch.empty((B * H * W,), dtype=torch.float32, device=dev()); pr = torch.empty_like(pm)
+        E.row_stats(xg, B * H * W, C, C, pm, pr, eps=1e-5)
+        m2 = torch.full((rows,), float("nan"), dtype=torch.float32, device=dev()); r2 = torch.full_like(m2, float("nan"))
+        E.merge2x2_stats_combine(pm, pr, B, H, W, m2, r2, eps_in=1e-5, eps_out=1e-5)
+        torch.cuda.synchronize()
+        assert (m2 - mean).abs().max().item() < 1e-5 * max(1.0, cat.abs().max().item()), (str(dtype), ci)
+        assert ((r2 - rstd).abs() / rstd).max().item() < 1e-4, (str(dtype), ci)
         wp, bp, csum = E.pack_ln_folded(wlin, None, gamma, beta, dtype, dev())
         out = torch.full((rows, 2 * C), float("nan"), dtype=dtype, device=dev())
         E.conv_gemm_nhwc(xg, E.merge_taps(wp, C), out, B, H, W, C, 2, 2, 2, 0, bias=bp, ln=(mean, rstd, csum))
